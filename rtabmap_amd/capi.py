@@ -1,0 +1,259 @@
+"""ctypes binding of include/lcd.h (rtabmap_amd/liblcd_hip.so).
+
+This is plumbing: the product is the shared library.  There is no Python/CPU fallback -- if the library is missing it
+is built with hipcc, and if that is impossible the import fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+LCD_OK = 0
+LCD_F32, LCD_U8 = 0, 1
+LCD_Q_INCREMENTAL, LCD_Q_NEW_WORDS_COMPARED = 1, 2
+STATUS = {0: "LCD_OK", 1: "LCD_ERR_INVALID", 2: "LCD_ERR_HIP", 3: "LCD_ERR_NOMEM", 4: "LCD_ERR_STATE", 5: "LCD_ERR_UNSUPPORTED"}
+
+# every symbol include/lcd.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "lcd_abi_version", "lcd_create", "lcd_destroy", "lcd_last_error", "lcd_synchronize",
+    "lcd_vocab_clear", "lcd_vocab_append", "lcd_vocab_remove", "lcd_vocab_rebuild", "lcd_vocab_count", "lcd_vocab_read",
+    "lcd_knn2", "lcd_selfdist", "lcd_quantize", "lcd_find_nn",
+    "lcd_sig_add", "lcd_sig_remove", "lcd_sig_add_bulk", "lcd_sig_count", "lcd_word_nrefs",
+    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_frame_dev", "lcd_knn2_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats",
+]
+
+
+class LcdConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("dtype", C.c_int32), ("dim", C.c_int32),
+                ("vocab_capacity", C.c_int64), ("sig_capacity", C.c_int64), ("max_queries", C.c_int32),
+                ("reserved0", C.c_int32), ("stream", C.c_void_p)]
+
+
+class LcdStats(C.Structure):
+    _fields_ = [("vocab_rows", C.c_int64), ("vocab_live", C.c_int64), ("signatures", C.c_int64), ("postings", C.c_int64),
+                ("knn_launches", C.c_int64), ("likelihood_launches", C.c_int64), ("rebuilds", C.c_int64),
+                ("bytes_device", C.c_int64)]
+
+
+class LcdError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("%s: %s" % (STATUS.get(status, status), msg))
+        self.status = status
+
+
+_lib = None
+
+
+def library_path():
+    return _build.OUT
+
+
+def load():
+    """Load (building if needed) liblcd_hip.so.  Raises if it cannot be produced: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build()
+    L = C.CDLL(path)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    L.lcd_abi_version.restype = C.c_int
+    L.lcd_create.argtypes = [C.POINTER(LcdConfig), C.POINTER(vp)]
+    L.lcd_destroy.argtypes = [vp]
+    L.lcd_destroy.restype = None
+    L.lcd_last_error.argtypes = [vp]
+    L.lcd_last_error.restype = C.c_char_p
+    L.lcd_synchronize.argtypes = [vp]
+    L.lcd_vocab_clear.argtypes = [vp]
+    L.lcd_vocab_append.argtypes = [vp, vp, C.c_int, vp]
+    L.lcd_vocab_remove.argtypes = [vp, vp, C.c_int]
+    L.lcd_vocab_rebuild.argtypes = [vp]
+    L.lcd_vocab_count.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.lcd_vocab_read.argtypes = [vp, i64, C.c_int, vp, vp]
+    L.lcd_knn2.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.lcd_selfdist.argtypes = [vp, vp, C.c_int, vp]
+    L.lcd_quantize.argtypes = [vp, vp, C.c_int, C.c_int, f32, vp, C.POINTER(i32)]
+    L.lcd_find_nn.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, f32, vp]
+    L.lcd_sig_add.argtypes = [vp, i32, vp, C.c_int, i32]
+    L.lcd_sig_remove.argtypes = [vp, i32]
+    L.lcd_sig_add_bulk.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.lcd_sig_count.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.lcd_word_nrefs.argtypes = [vp, i32, C.POINTER(i32)]
+    L.lcd_likelihood.argtypes = [vp, vp, C.c_int, vp, C.c_int, f32, vp]
+    L.lcd_adjust_likelihood.argtypes = [vp, vp, C.c_int, f32]
+    L.lcd_frame_dev.argtypes = [vp, vp, C.c_int, C.c_int, f32, i32, f32, vp, vp, i64]
+    L.lcd_knn2_dev.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.lcd_slots_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    L.lcd_stream.argtypes = [vp]
+    L.lcd_stream.restype = vp
+    L.lcd_get_stats.argtypes = [vp, C.POINTER(LcdStats)]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One lcd_engine handle.  numpy in / numpy out through the C-ABI; *_dev methods take raw device pointers."""
+
+    def __init__(self, dtype, dim, device=0, vocab_capacity=0, sig_capacity=0, stream=None):
+        self.L = load()
+        self.dtype = LCD_F32 if dtype in (LCD_F32, np.float32, "f32") else LCD_U8
+        self.np_dtype = np.float32 if self.dtype == LCD_F32 else np.uint8
+        self.dim = int(dim)
+        cfg = LcdConfig(C.sizeof(LcdConfig), device, self.dtype, self.dim, vocab_capacity, sig_capacity, 0, 0, stream)
+        h = C.c_void_p()
+        rc = self.L.lcd_create(C.byref(cfg), C.byref(h))
+        if rc != LCD_OK:
+            raise LcdError(rc, "lcd_create failed (no gfx950 device / HIP runtime?)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lcd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != LCD_OK:
+            raise LcdError(rc, self.L.lcd_last_error(self.h).decode())
+
+    def _rows(self, a):
+        a = np.ascontiguousarray(a, dtype=self.np_dtype)
+        if a.ndim != 2 or a.shape[1] != self.dim:
+            raise ValueError("expected [n, %d] %s" % (self.dim, self.np_dtype.__name__))
+        return a
+
+    def synchronize(self):
+        self._ck(self.L.lcd_synchronize(self.h))
+
+    # ---- vocabulary
+    def vocab_clear(self):
+        self._ck(self.L.lcd_vocab_clear(self.h))
+
+    def vocab_append(self, rows, word_ids):
+        rows = self._rows(rows)
+        ids = np.ascontiguousarray(word_ids, dtype=np.int32)
+        assert ids.shape[0] == rows.shape[0]
+        self._ck(self.L.lcd_vocab_append(self.h, _p(rows), rows.shape[0], _p(ids)))
+
+    def vocab_remove(self, word_ids):
+        ids = np.ascontiguousarray(word_ids, dtype=np.int32)
+        self._ck(self.L.lcd_vocab_remove(self.h, _p(ids), ids.shape[0]))
+
+    def vocab_rebuild(self):
+        self._ck(self.L.lcd_vocab_rebuild(self.h))
+
+    def vocab_count(self):
+        r, l = C.c_int64(), C.c_int64()
+        self._ck(self.L.lcd_vocab_count(self.h, C.byref(r), C.byref(l)))
+        return r.value, l.value
+
+    def vocab_read(self, first, n):
+        rows = np.empty((n, self.dim), self.np_dtype)
+        ids = np.empty(n, np.int32)
+        self._ck(self.L.lcd_vocab_read(self.h, first, n, _p(rows), _p(ids)))
+        return rows, ids
+
+    # ---- search
+    def knn2(self, queries):
+        q = self._rows(queries)
+        ids = np.zeros((q.shape[0], 2), np.int32)
+        dist = np.zeros((q.shape[0], 2), np.float32)
+        self._ck(self.L.lcd_knn2(self.h, _p(q), q.shape[0], _p(ids), _p(dist)))
+        return ids, dist
+
+    def selfdist(self, queries):
+        q = self._rows(queries)
+        out = np.zeros((q.shape[0], q.shape[0]), np.float32)
+        self._ck(self.L.lcd_selfdist(self.h, _p(q), q.shape[0], _p(out)))
+        return out
+
+    def quantize(self, descriptors, incremental=True, new_words_compared=True, nndr=0.8):
+        q = self._rows(descriptors)
+        out = np.zeros(q.shape[0], np.int32)
+        nn = C.c_int32()
+        flags = (LCD_Q_INCREMENTAL if incremental else 0) | (LCD_Q_NEW_WORDS_COMPARED if new_words_compared else 0)
+        self._ck(self.L.lcd_quantize(self.h, _p(q), q.shape[0], flags, nndr, _p(out), C.byref(nn)))
+        return out, nn.value
+
+    def find_nn(self, queries, extra_rows=None, extra_word_ids=None, incremental=True, nndr=0.8):
+        q = self._rows(queries)
+        out = np.zeros(q.shape[0], np.int32)
+        ne = 0
+        er = ei = None
+        if extra_rows is not None and len(extra_rows):
+            er = self._rows(extra_rows)
+            ei = np.ascontiguousarray(extra_word_ids, dtype=np.int32)
+            ne = er.shape[0]
+        flags = LCD_Q_INCREMENTAL if incremental else 0
+        self._ck(self.L.lcd_find_nn(self.h, _p(q), q.shape[0], _p(er), _p(ei), ne, flags, nndr, _p(out)))
+        return out
+
+    # ---- inverted index
+    def sig_add(self, sig_id, word_ids, ni=None):
+        w = np.ascontiguousarray(word_ids, dtype=np.int32)
+        self._ck(self.L.lcd_sig_add(self.h, sig_id, _p(w), w.shape[0], w.shape[0] if ni is None else ni))
+
+    def sig_add_bulk(self, sig_ids, offsets, word_ids, ni=None):
+        s = np.ascontiguousarray(sig_ids, dtype=np.int32)
+        o = np.ascontiguousarray(offsets, dtype=np.int64)
+        w = np.ascontiguousarray(word_ids, dtype=np.int32)
+        n = None if ni is None else np.ascontiguousarray(ni, dtype=np.int32)
+        self._ck(self.L.lcd_sig_add_bulk(self.h, s.shape[0], _p(s), _p(o), _p(w), _p(n)))
+
+    def sig_remove(self, sig_id):
+        self._ck(self.L.lcd_sig_remove(self.h, sig_id))
+
+    def sig_count(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._ck(self.L.lcd_sig_count(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def word_nrefs(self, word_id):
+        v = C.c_int32()
+        self._ck(self.L.lcd_word_nrefs(self.h, word_id, C.byref(v)))
+        return v.value
+
+    def likelihood(self, query_word_ids, sig_ids, N):
+        w = np.ascontiguousarray(query_word_ids, dtype=np.int32)
+        s = np.ascontiguousarray(sig_ids, dtype=np.int32)
+        out = np.zeros(s.shape[0], np.float32)
+        self._ck(self.L.lcd_likelihood(self.h, _p(w), w.shape[0], _p(s), s.shape[0], float(N), _p(out)))
+        return out
+
+    def adjust_likelihood(self, L, ratio=0.0):
+        a = np.ascontiguousarray(L, dtype=np.float32).copy()
+        self._ck(self.L.lcd_adjust_likelihood(self.h, _p(a), a.shape[0], ratio))
+        return a
+
+    # ---- device-resident frame path
+    def frame_dev(self, d_desc_ptr, q, sig_id, N, d_word_ids_ptr, d_like_ptr, like_capacity, incremental=True,
+                  new_words_compared=True, nndr=0.8):
+        flags = (LCD_Q_INCREMENTAL if incremental else 0) | (LCD_Q_NEW_WORDS_COMPARED if new_words_compared else 0)
+        self._ck(self.L.lcd_frame_dev(self.h, d_desc_ptr, q, flags, nndr, sig_id, float(N), d_word_ids_ptr, d_like_ptr,
+                                      like_capacity))
+
+    def knn2_dev(self, d_queries_ptr, q, d_word_ids_ptr, d_dist_ptr):
+        self._ck(self.L.lcd_knn2_dev(self.h, d_queries_ptr, q, d_word_ids_ptr, d_dist_ptr))
+
+    def slots_dev(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._ck(self.L.lcd_slots_dev(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def stream(self):
+        return self.L.lcd_stream(self.h)
+
+    def stats(self):
+        s = LcdStats()
+        self._ck(self.L.lcd_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in LcdStats._fields_}

@@ -1,0 +1,49 @@
+// engine.h -- internal state of an lcd_engine handle (liblcd_hip.so).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/lcd.h"
+#include "devbuf.h"
+#include "lcd_kernels.h"
+#include "tfidf.h"
+
+
+struct lcd_engine {
+    int device = 0;
+    int dtype = 0;
+    int dim = 0;            // columns as given by the caller
+    int row_bytes = 0;      // bytes per stored row (u8 rows are zero-padded to a multiple of 4)
+    int kdim = 0;           // `dim` as the kernels see it (floats, or padded bytes)
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int64_t bytes_device = 0;
+
+    // ---- vocabulary: rows [n_rows x row_bytes], row_id[r] = word id (0 = tombstone), row_wslot[r] = postings key
+    lcd::DevBuf vocab, row_id, row_wslot;
+    lcd::DevBuf vocab_alt, row_id_alt, row_wslot_alt;   // rebuild target (swapped in)
+    int64_t n_rows = 0, n_live = 0;
+    std::vector<int32_t> h_row_id;                      // host mirror of row_id (row order is the tie-break contract)
+    std::unordered_map<int32_t, int32_t> word_row;      // live word id -> row
+
+    // ---- per-call scratch
+    lcd::DevBuf d_queries, d_partial, d_knn_row, d_knn_word, d_knn_wslot, d_knn_dist, d_selfdist, d_out_word, d_out_wslot,
+        d_n_new, d_tmp_i32, d_extra_rows, d_extra_id, d_extra_word, d_extra_dist, d_extra_row, d_like, d_slots;
+    lcd::PinBuf h_in, h_out, h_out2;
+
+    // ---- inverted index / TF-IDF
+    lcd::Tfidf tfidf;
+
+    // ---- statistics
+    int64_t knn_launches = 0, likelihood_launches = 0, rebuilds = 0;
+
+    int fail(int code, const std::string& msg) { err = msg; return code; }
+    int hip_fail(hipError_t e, const char* what) {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return LCD_ERR_HIP;
+    }
+};

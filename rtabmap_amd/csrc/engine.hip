@@ -1,0 +1,564 @@
+// engine.hip -- implementation of the C-ABI declared in include/lcd.h (liblcd_hip.so).
+//
+// Host-side orchestration only: device memory, staging, stream ordering and the bookkeeping that keeps the
+// vocabulary row order (the distance tie-break of the reference) and the signature/word slot maps.  All arithmetic
+// of the hot path runs in the gfx950 kernels (knn2_kernels.hip, resolve_kernels.hip, tfidf.hip).  There is no CPU
+// fallback: every entry point either runs on the device or returns an error status.
+#include "engine.h"
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <numeric>
+
+using namespace lcd;
+
+#define LCD_CHECK_HANDLE(h) do { if (!(h)) return LCD_ERR_INVALID; } while (0)
+#define LCD_HIP(h, x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return (h)->hip_fail(e__, #x); } while (0)
+#define LCD_DEV(h) LCD_HIP(h, hipSetDevice((h)->device))
+
+namespace {
+
+struct HandleGuard {   // every entry: select the device, clear the previous error
+    lcd_engine* h;
+};
+
+inline hipError_t dreserve(lcd_engine* h, DevBuf& b, size_t bytes, size_t keep = 0) {
+    return b.reserve(bytes, keep, h->stream, &h->bytes_device);
+}
+
+// copy `rows` host rows (h->dim columns) into a device buffer laid out with h->row_bytes per row (u8 rows zero-padded)
+int upload_rows(lcd_engine* h, const void* rows, int n, DevBuf& dst) {
+    const size_t bytes = (size_t)n * h->row_bytes;
+    LCD_HIP(h, dreserve(h, dst, std::max<size_t>(bytes, 4)));
+    if (n == 0) return LCD_OK;
+    LCD_HIP(h, h->h_in.reserve(bytes));
+    const size_t src_row = (size_t)h->dim * (h->dtype == LCD_F32 ? 4 : 1);
+    if (src_row == (size_t)h->row_bytes) {
+        std::memcpy(h->h_in.p, rows, bytes);
+    } else {
+        std::memset(h->h_in.p, 0, bytes);
+        for (int i = 0; i < n; ++i) std::memcpy((char*)h->h_in.p + (size_t)i * h->row_bytes, (const char*)rows + (size_t)i * src_row, src_row);
+    }
+    LCD_HIP(h, hipMemcpyAsync(dst.p, h->h_in.p, bytes, hipMemcpyHostToDevice, h->stream));
+    // the staging buffer is reused by the next call: the copy must have left it
+    LCD_HIP(h, hipStreamSynchronize(h->stream));
+    return LCD_OK;
+}
+
+// 2-NN of q device-resident queries against the vocabulary -> d_knn_{row,word,wslot,dist}[q*2]
+int run_knn2(lcd_engine* h, const void* d_queries, int q, const void* vocab, const int32_t* row_id, const int32_t* row_wslot,
+             int64_t n_rows, DevBuf& o_row, DevBuf& o_word, DevBuf& o_dist) {
+    (void)row_wslot;
+    const KnnPlan p = knn_plan(q, (int)n_rows, h->row_bytes);
+    LCD_HIP(h, dreserve(h, h->d_partial, knn_partial_bytes(p)));
+    LCD_HIP(h, dreserve(h, o_row, (size_t)std::max(q, 1) * 2 * 4));
+    LCD_HIP(h, dreserve(h, o_word, (size_t)std::max(q, 1) * 2 * 4));
+    LCD_HIP(h, dreserve(h, o_dist, (size_t)std::max(q, 1) * 2 * 4));
+    if (q == 0) return LCD_OK;
+    LCD_HIP(h, launch_knn2_partial(h->dtype, h->kdim, vocab, row_id, d_queries, p, h->d_partial.as<uint64_t>(), h->stream));
+    LCD_HIP(h, launch_knn2_merge(h->dtype, p, h->d_partial.as<uint64_t>(), row_id, o_row.as<int32_t>(), o_word.as<int32_t>(),
+                                 o_dist.as<float>(), h->stream));
+    h->knn_launches += 1;
+    return LCD_OK;
+}
+
+int download(lcd_engine* h, void* dst, const void* d_src, size_t bytes, PinBuf& pin) {
+    if (!bytes) return LCD_OK;
+    LCD_HIP(h, pin.reserve(bytes));
+    LCD_HIP(h, hipMemcpyAsync(pin.p, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+    LCD_HIP(h, hipStreamSynchronize(h->stream));
+    std::memcpy(dst, pin.p, bytes);
+    return LCD_OK;
+}
+
+__global__ void rows_to_wslot_kernel(const int32_t* __restrict__ word, const int32_t* __restrict__ knn_row,
+                                     const int32_t* __restrict__ knn_word, const int32_t* __restrict__ row_wslot, int q,
+                                     int32_t* __restrict__ out_wslot) {
+    // word slot of each descriptor's chosen EXISTING word: it is one of its two indexed neighbours
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q) return;
+    const int32_t w = word[i];
+    int32_t ws = -1;
+    if (w > 0) {
+        if (knn_word[2 * i] == w) ws = row_wslot[knn_row[2 * i]];
+        else if (knn_word[2 * i + 1] == w) ws = row_wslot[knn_row[2 * i + 1]];
+    }
+    out_wslot[i] = ws;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lcd_abi_version(void) { return LCD_ABI_VERSION; }
+
+int lcd_create(const lcd_config* cfg, lcd_engine** out) {
+    if (!cfg || !out) return LCD_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(lcd_config)) return LCD_ERR_INVALID;
+    if (cfg->dim <= 0 || cfg->dim > 4096 || (cfg->dtype != LCD_F32 && cfg->dtype != LCD_U8)) return LCD_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return LCD_ERR_HIP;
+    if (hipSetDevice(cfg->device) != hipSuccess) return LCD_ERR_HIP;
+    lcd_engine* h = new (std::nothrow) lcd_engine();
+    if (!h) return LCD_ERR_NOMEM;
+    h->device = cfg->device;
+    h->dtype = cfg->dtype;
+    h->dim = cfg->dim;
+    if (cfg->dtype == LCD_F32) { h->row_bytes = cfg->dim * 4; h->kdim = cfg->dim; }
+    else { h->row_bytes = (cfg->dim + 3) / 4 * 4; h->kdim = h->row_bytes; }
+    if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; h->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return LCD_ERR_HIP; }
+        h->own_stream = true;
+    }
+    const int64_t vcap = cfg->vocab_capacity > 0 ? cfg->vocab_capacity : 4096;
+    hipError_t e = h->vocab.reserve((size_t)vcap * h->row_bytes, 0, h->stream, &h->bytes_device);
+    if (e == hipSuccess) e = h->row_id.reserve((size_t)vcap * 4, 0, h->stream, &h->bytes_device);
+    if (e == hipSuccess) e = h->row_wslot.reserve((size_t)vcap * 4, 0, h->stream, &h->bytes_device);
+    if (e == hipSuccess) e = h->d_n_new.reserve(64, 0, h->stream, &h->bytes_device);
+    if (e == hipSuccess) e = h->tfidf.init(h->stream, &h->bytes_device, cfg->sig_capacity);
+    if (e != hipSuccess) { lcd_destroy(h); return LCD_ERR_HIP; }
+    *out = h;
+    return LCD_OK;
+}
+
+void lcd_destroy(lcd_engine* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->tfidf.destroy();
+    DevBuf* all[] = {&h->vocab, &h->row_id, &h->row_wslot, &h->vocab_alt, &h->row_id_alt, &h->row_wslot_alt, &h->d_queries,
+                     &h->d_partial, &h->d_knn_row, &h->d_knn_word, &h->d_knn_wslot, &h->d_knn_dist, &h->d_selfdist, &h->d_out_word,
+                     &h->d_out_wslot, &h->d_n_new, &h->d_tmp_i32, &h->d_extra_rows, &h->d_extra_id, &h->d_extra_word,
+                     &h->d_extra_dist, &h->d_extra_row, &h->d_like, &h->d_slots};
+    for (DevBuf* d : all) d->release(&h->bytes_device);
+    h->h_in.release(); h->h_out.release(); h->h_out2.release();
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* lcd_last_error(const lcd_engine* h) { return h ? h->err.c_str() : "null handle"; }
+
+int lcd_synchronize(lcd_engine* h) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    LCD_HIP(h, hipStreamSynchronize(h->stream));
+    return LCD_OK;
+}
+
+void* lcd_stream(lcd_engine* h) { return h ? (void*)h->stream : nullptr; }
+
+// ------------------------------------------------------------------------------------------------ vocabulary
+int lcd_vocab_clear(lcd_engine* h) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    LCD_HIP(h, hipStreamSynchronize(h->stream));
+    h->n_rows = 0; h->n_live = 0;
+    h->h_row_id.clear();
+    h->word_row.clear();
+    return LCD_OK;
+}
+
+int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word_ids) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (n < 0 || (n > 0 && (!rows || !word_ids))) return h->fail(LCD_ERR_INVALID, "lcd_vocab_append: null input");
+    if (n == 0) return LCD_OK;
+    for (int i = 0; i < n; ++i) {
+        if (word_ids[i] <= 0) return h->fail(LCD_ERR_INVALID, "lcd_vocab_append: word ids must be > 0");
+        if (h->word_row.count(word_ids[i])) return h->fail(LCD_ERR_STATE, "lcd_vocab_append: word already in the vocabulary");
+    }
+    const int64_t total = h->n_rows + n;
+    if (total > 0x7FFFFFF0ll) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_vocab_append: more than 2^31 rows");
+    LCD_HIP(h, dreserve(h, h->vocab, (size_t)total * h->row_bytes, (size_t)h->n_rows * h->row_bytes));
+    LCD_HIP(h, dreserve(h, h->row_id, (size_t)total * 4, (size_t)h->n_rows * 4));
+    LCD_HIP(h, dreserve(h, h->row_wslot, (size_t)total * 4, (size_t)h->n_rows * 4));
+    // stage rows | ids | wslots in one pinned block
+    const size_t rb = (size_t)n * h->row_bytes;
+    LCD_HIP(h, h->h_in.reserve(rb + (size_t)n * 8));
+    char* st = (char*)h->h_in.p;
+    const size_t src_row = (size_t)h->dim * (h->dtype == LCD_F32 ? 4 : 1);
+    if (src_row == (size_t)h->row_bytes) std::memcpy(st, rows, rb);
+    else {
+        std::memset(st, 0, rb);
+        for (int i = 0; i < n; ++i) std::memcpy(st + (size_t)i * h->row_bytes, (const char*)rows + (size_t)i * src_row, src_row);
+    }
+    int32_t* ids = (int32_t*)(st + rb);
+    int32_t* ws = ids + n;
+    for (int i = 0; i < n; ++i) {
+        ids[i] = word_ids[i];
+        LCD_HIP(h, h->tfidf.wslot_of(word_ids[i], &ws[i]));
+    }
+    LCD_HIP(h, hipMemcpyAsync((char*)h->vocab.p + (size_t)h->n_rows * h->row_bytes, st, rb, hipMemcpyHostToDevice, h->stream));
+    LCD_HIP(h, hipMemcpyAsync(h->row_id.as<int32_t>() + h->n_rows, ids, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    LCD_HIP(h, hipMemcpyAsync(h->row_wslot.as<int32_t>() + h->n_rows, ws, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    LCD_HIP(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; ++i) { h->word_row[word_ids[i]] = (int32_t)(h->n_rows + i); h->h_row_id.push_back(word_ids[i]); }
+    h->n_rows = total;
+    h->n_live += n;
+    return LCD_OK;
+}
+
+int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (n < 0 || (n > 0 && !word_ids)) return h->fail(LCD_ERR_INVALID, "lcd_vocab_remove: null input");
+    if (n == 0) return LCD_OK;
+    std::vector<int32_t> rows;
+    rows.reserve(n);
+    for (int i = 0; i < n; ++i) {
+        auto it = h->word_row.find(word_ids[i]);
+        if (it == h->word_row.end()) return h->fail(LCD_ERR_STATE, "lcd_vocab_remove: word not in the vocabulary");
+        rows.push_back(it->second);
+    }
+    LCD_HIP(h, dreserve(h, h->d_tmp_i32, (size_t)n * 4));
+    LCD_HIP(h, h->h_in.reserve((size_t)n * 4));
+    std::memcpy(h->h_in.p, rows.data(), (size_t)n * 4);
+    LCD_HIP(h, hipMemcpyAsync(h->d_tmp_i32.p, h->h_in.p, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    LCD_HIP(h, launch_tombstone(h->row_id.as<int32_t>(), h->d_tmp_i32.as<int32_t>(), n, h->stream));
+    LCD_HIP(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; ++i) { h->h_row_id[rows[i]] = 0; h->word_row.erase(word_ids[i]); }
+    h->n_live -= n;
+    return LCD_OK;
+}
+
+int lcd_vocab_rebuild(lcd_engine* h) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    // permutation: live rows ordered by ascending word id (VWDictionary.cpp:636-660 walks std::map<int,VisualWord*>)
+    std::vector<int32_t> perm;
+    perm.reserve((size_t)h->n_live);
+    for (int64_t r = 0; r < h->n_rows; ++r) if (h->h_row_id[r] != 0) perm.push_back((int32_t)r);
+    std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return h->h_row_id[a] < h->h_row_id[b]; });
+    const int n = (int)perm.size();
+    LCD_HIP(h, dreserve(h, h->vocab_alt, std::max<size_t>(h->vocab.cap, 4)));
+    LCD_HIP(h, dreserve(h, h->row_id_alt, std::max<size_t>(h->row_id.cap, 4)));
+    LCD_HIP(h, dreserve(h, h->row_wslot_alt, std::max<size_t>(h->row_wslot.cap, 4)));
+    if (n) {
+        LCD_HIP(h, dreserve(h, h->d_tmp_i32, (size_t)n * 4));
+        LCD_HIP(h, h->h_in.reserve((size_t)n * 4));
+        std::memcpy(h->h_in.p, perm.data(), (size_t)n * 4);
+        LCD_HIP(h, hipMemcpyAsync(h->d_tmp_i32.p, h->h_in.p, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+        LCD_HIP(h, launch_gather_rows(h->vocab.p, h->row_id.as<int32_t>(), h->d_tmp_i32.as<int32_t>(), n, h->row_bytes,
+                                      h->vocab_alt.p, h->row_id_alt.as<int32_t>(), h->stream));
+        LCD_HIP(h, launch_gather_rows(h->row_wslot.p, h->row_id.as<int32_t>(), h->d_tmp_i32.as<int32_t>(), n, 4,
+                                      h->row_wslot_alt.p, h->row_id_alt.as<int32_t>(), h->stream));
+        LCD_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    std::swap(h->vocab, h->vocab_alt);
+    std::swap(h->row_id, h->row_id_alt);
+    std::swap(h->row_wslot, h->row_wslot_alt);
+    std::vector<int32_t> ids(n);
+    h->word_row.clear();
+    for (int i = 0; i < n; ++i) { ids[i] = h->h_row_id[perm[i]]; h->word_row[ids[i]] = i; }
+    h->h_row_id.swap(ids);
+    h->n_rows = n;
+    h->n_live = n;
+    h->rebuilds += 1;
+    return LCD_OK;
+}
+
+int lcd_vocab_count(const lcd_engine* h, int64_t* rows, int64_t* live) {
+    LCD_CHECK_HANDLE(h);
+    if (rows) *rows = h->n_rows;
+    if (live) *live = h->n_live;
+    return LCD_OK;
+}
+
+int lcd_vocab_read(lcd_engine* h, int64_t first, int n, void* out_rows, int32_t* out_word_ids) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (first < 0 || n < 0 || first + n > h->n_rows) return h->fail(LCD_ERR_INVALID, "lcd_vocab_read: range");
+    if (n == 0) return LCD_OK;
+    if (out_rows) {
+        const size_t bytes = (size_t)n * h->row_bytes;
+        LCD_HIP(h, h->h_out.reserve(bytes));
+        LCD_HIP(h, hipMemcpyAsync(h->h_out.p, (const char*)h->vocab.p + (size_t)first * h->row_bytes, bytes, hipMemcpyDeviceToHost, h->stream));
+        LCD_HIP(h, hipStreamSynchronize(h->stream));
+        const size_t dst_row = (size_t)h->dim * (h->dtype == LCD_F32 ? 4 : 1);
+        for (int i = 0; i < n; ++i) std::memcpy((char*)out_rows + (size_t)i * dst_row, (const char*)h->h_out.p + (size_t)i * h->row_bytes, dst_row);
+    }
+    if (out_word_ids) { int rc = download(h, out_word_ids, h->row_id.as<int32_t>() + first, (size_t)n * 4, h->h_out2); if (rc) return rc; }
+    return LCD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ 2-NN
+int lcd_knn2(lcd_engine* h, const void* queries, int q, int32_t* out_word_ids, float* out_dist) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (q < 0 || (q > 0 && (!queries || !out_word_ids || !out_dist))) return h->fail(LCD_ERR_INVALID, "lcd_knn2: null input");
+    if (q == 0) return LCD_OK;
+    int rc = upload_rows(h, queries, q, h->d_queries);
+    if (rc) return rc;
+    rc = run_knn2(h, h->d_queries.p, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), h->n_rows, h->d_knn_row,
+                  h->d_knn_word, h->d_knn_dist);
+    if (rc) return rc;
+    rc = download(h, out_word_ids, h->d_knn_word.p, (size_t)q * 8, h->h_out);
+    if (rc) return rc;
+    return download(h, out_dist, h->d_knn_dist.p, (size_t)q * 8, h->h_out);
+}
+
+int lcd_selfdist(lcd_engine* h, const void* queries, int q, float* out_qxq) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (q < 0 || (q > 0 && (!queries || !out_qxq))) return h->fail(LCD_ERR_INVALID, "lcd_selfdist: null input");
+    if (q == 0) return LCD_OK;
+    int rc = upload_rows(h, queries, q, h->d_queries);
+    if (rc) return rc;
+    LCD_HIP(h, dreserve(h, h->d_selfdist, (size_t)q * q * 4));
+    LCD_HIP(h, launch_selfdist(h->dtype, h->kdim, h->d_queries.p, q, h->d_selfdist.as<float>(), q, h->stream));
+    return download(h, out_qxq, h->d_selfdist.p, (size_t)q * q * 4, h->h_out);
+}
+
+// device part of addNewWords: d_queries already holds q descriptors.  Leaves d_out_word[q], d_n_new[1].
+static int quantize_dev(lcd_engine* h, const void* d_desc, int q, int flags, float nndr, int32_t* d_out_word) {
+    const int have_index = h->n_live >= 2 ? 1 : 0;                  // VWDictionary.cpp:1015
+    int rc = run_knn2(h, d_desc, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), have_index ? h->n_rows : 0,
+                      h->d_knn_row, h->d_knn_word, h->d_knn_dist);
+    if (rc) return rc;
+    const bool incremental = (flags & LCD_Q_INCREMENTAL) != 0;
+    const bool together = incremental && (flags & LCD_Q_NEW_WORDS_COMPARED);
+    int ld = (q + 63) / 64 * 64;
+    if (together) {
+        LCD_HIP(h, dreserve(h, h->d_selfdist, (size_t)q * ld * 4));
+        LCD_HIP(h, launch_selfdist(h->dtype, h->kdim, d_desc, q, h->d_selfdist.as<float>(), ld, h->stream));
+    }
+    const int rflags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0);
+    LCD_HIP(h, launch_resolve(q, rflags, nndr, have_index, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
+                              together ? h->d_selfdist.as<float>() : nullptr, ld, d_out_word, h->d_n_new.as<int32_t>(), h->stream));
+    return LCD_OK;
+}
+
+int lcd_quantize(lcd_engine* h, const void* descriptors, int q, int flags, float nndr_ratio, int32_t* out_word_ids, int32_t* out_n_new) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (q < 0 || (q > 0 && (!descriptors || !out_word_ids))) return h->fail(LCD_ERR_INVALID, "lcd_quantize: null input");
+    if (out_n_new) *out_n_new = 0;
+    if (q == 0) return LCD_OK;
+    if (q > 8192) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_quantize: more than 8192 descriptors per call");
+    int rc = upload_rows(h, descriptors, q, h->d_queries);
+    if (rc) return rc;
+    LCD_HIP(h, dreserve(h, h->d_out_word, (size_t)q * 4));
+    rc = quantize_dev(h, h->d_queries.p, q, flags, nndr_ratio, h->d_out_word.as<int32_t>());
+    if (rc) return rc;
+    rc = download(h, out_word_ids, h->d_out_word.p, (size_t)q * 4, h->h_out);
+    if (rc) return rc;
+    if (out_n_new) return download(h, out_n_new, h->d_n_new.p, 4, h->h_out2);
+    return LCD_OK;
+}
+
+int lcd_find_nn(lcd_engine* h, const void* queries, int q, const void* extra_rows, const int32_t* extra_word_ids, int n_extra, int flags,
+                float nndr_ratio, int32_t* out_word_ids) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (q < 0 || n_extra < 0 || (q > 0 && (!queries || !out_word_ids)) || (n_extra > 0 && (!extra_rows || !extra_word_ids)))
+        return h->fail(LCD_ERR_INVALID, "lcd_find_nn: null input");
+    if (q == 0) return LCD_OK;
+    int rc = upload_rows(h, queries, q, h->d_queries);
+    if (rc) return rc;
+    const int have_index = h->n_live >= 2 ? 1 : 0;                  // VWDictionary.cpp:1347
+    rc = run_knn2(h, h->d_queries.p, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), have_index ? h->n_rows : 0,
+                  h->d_knn_row, h->d_knn_word, h->d_knn_dist);
+    if (rc) return rc;
+    if (n_extra > 0) {   // the not-yet-indexed words: a second, temporary vocabulary (VWDictionary.cpp:1416-1451)
+        // upload_rows stages through h_in: upload extra rows after the queries are on the device
+        rc = upload_rows(h, extra_rows, n_extra, h->d_extra_rows);
+        if (rc) return rc;
+        LCD_HIP(h, dreserve(h, h->d_extra_id, (size_t)n_extra * 4));
+        LCD_HIP(h, h->h_in.reserve((size_t)n_extra * 4));
+        std::memcpy(h->h_in.p, extra_word_ids, (size_t)n_extra * 4);
+        LCD_HIP(h, hipMemcpyAsync(h->d_extra_id.p, h->h_in.p, (size_t)n_extra * 4, hipMemcpyHostToDevice, h->stream));
+        LCD_HIP(h, hipStreamSynchronize(h->stream));
+        // the merge kernel of the indexed search has consumed d_partial (stream order), so it can be reused
+        rc = run_knn2(h, h->d_queries.p, q, h->d_extra_rows.p, h->d_extra_id.as<int32_t>(), nullptr, n_extra, h->d_extra_row,
+                      h->d_extra_word, h->d_extra_dist);
+        if (rc) return rc;
+    }
+    LCD_HIP(h, dreserve(h, h->d_out_word, (size_t)q * 4));
+    LCD_HIP(h, launch_findnn_resolve(q, flags, nndr_ratio, have_index, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
+                                     n_extra > 0 ? 1 : 0, h->d_extra_word.as<int32_t>(), h->d_extra_dist.as<float>(),
+                                     h->d_out_word.as<int32_t>(), h->stream));
+    return download(h, out_word_ids, h->d_out_word.p, (size_t)q * 4, h->h_out);
+}
+
+// ------------------------------------------------------------------------------------------------ inverted index
+static int stage_wslots(lcd_engine* h, const int32_t* word_ids, int n, bool create) {
+    Tfidf& t = h->tfidf;
+    LCD_HIP(h, t.h_stage.reserve((size_t)std::max(n, 1) * 4));
+    LCD_HIP(h, dreserve(h, t.d_stage, (size_t)std::max(n, 1) * 4));
+    int32_t* st = t.h_stage.as<int32_t>();
+    for (int i = 0; i < n; ++i) {
+        int32_t ws = -1;
+        if (word_ids[i] > 0) {
+            if (create) LCD_HIP(h, t.wslot_of(word_ids[i], &ws));
+            else { auto it = t.word_wslot.find(word_ids[i]); ws = it == t.word_wslot.end() ? -1 : it->second; }
+        }
+        st[i] = ws;
+    }
+    if (n) LCD_HIP(h, hipMemcpyAsync(t.d_stage.p, st, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    return LCD_OK;
+}
+
+int lcd_sig_add(lcd_engine* h, int32_t sig_id, const int32_t* word_ids, int n, int32_t ni) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (sig_id == 0 || n < 0 || (n > 0 && !word_ids) || ni < 0) return h->fail(LCD_ERR_INVALID, "lcd_sig_add: bad argument");
+    if (n > TF_MAX_WORDS) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_sig_add: more than 8192 words in one signature");
+    if (h->tfidf.sig_slot.count(sig_id)) return h->fail(LCD_ERR_STATE, "lcd_sig_add: signature already registered");
+    int rc = stage_wslots(h, word_ids, n, true);
+    if (rc) return rc;
+    LCD_HIP(h, h->tfidf.register_dev(sig_id, h->tfidf.d_stage.as<int32_t>(), n, ni, 0.0f));
+    LCD_HIP(h, hipStreamSynchronize(h->stream));   // staging buffer reuse
+    return LCD_OK;
+}
+
+int lcd_sig_add_bulk(lcd_engine* h, int n_sigs, const int32_t* sig_ids, const int64_t* sig_offsets, const int32_t* word_ids, const int32_t* ni) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (n_sigs < 0 || (n_sigs > 0 && (!sig_ids || !sig_offsets || !word_ids))) return h->fail(LCD_ERR_INVALID, "lcd_sig_add_bulk: null input");
+    if (n_sigs == 0) return LCD_OK;
+    Tfidf& t = h->tfidf;
+    const int64_t total = sig_offsets[n_sigs] - sig_offsets[0];
+    // all word slots staged at once, one registration kernel per signature, one synchronisation at the end
+    LCD_HIP(h, t.h_stage.reserve((size_t)std::max<int64_t>(total, 1) * 4));
+    LCD_HIP(h, dreserve(h, t.d_stage, (size_t)std::max<int64_t>(total, 1) * 4));
+    int32_t* st = t.h_stage.as<int32_t>();
+    for (int s = 0; s < n_sigs; ++s) {
+        if (sig_ids[s] == 0 || t.sig_slot.count(sig_ids[s])) return h->fail(LCD_ERR_STATE, "lcd_sig_add_bulk: bad or duplicate signature id");
+        const int64_t a = sig_offsets[s], b = sig_offsets[s + 1];
+        if (b < a || b - a > TF_MAX_WORDS) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_sig_add_bulk: bad offsets / more than 8192 words");
+        for (int64_t k = a; k < b; ++k) {
+            int32_t ws = -1;
+            if (word_ids[k] > 0) LCD_HIP(h, t.wslot_of(word_ids[k], &ws));
+            st[k - sig_offsets[0]] = ws;
+        }
+    }
+    if (total) LCD_HIP(h, hipMemcpyAsync(t.d_stage.p, st, (size_t)total * 4, hipMemcpyHostToDevice, h->stream));
+    for (int s = 0; s < n_sigs; ++s) {
+        const int64_t a = sig_offsets[s] - sig_offsets[0];
+        const int n = (int)(sig_offsets[s + 1] - sig_offsets[s]);
+        LCD_HIP(h, t.register_dev(sig_ids[s], t.d_stage.as<int32_t>() + a, n, ni ? ni[s] : n, 0.0f));
+    }
+    LCD_HIP(h, hipStreamSynchronize(h->stream));
+    return LCD_OK;
+}
+
+int lcd_sig_remove(lcd_engine* h, int32_t sig_id) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (!h->tfidf.sig_slot.count(sig_id)) return h->fail(LCD_ERR_STATE, "lcd_sig_remove: unknown signature");
+    LCD_HIP(h, h->tfidf.retire(sig_id));
+    return LCD_OK;
+}
+
+int lcd_sig_count(const lcd_engine* h, int64_t* live_signatures, int64_t* postings) {
+    LCD_CHECK_HANDLE(h);
+    if (live_signatures) *live_signatures = h->tfidf.live_sigs;
+    if (postings) *postings = h->tfidf.postings_ub;
+    return LCD_OK;
+}
+
+int lcd_word_nrefs(lcd_engine* h, int32_t word_id, int32_t* out_nw) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (!out_nw) return h->fail(LCD_ERR_INVALID, "lcd_word_nrefs: null output");
+    auto it = h->tfidf.word_wslot.find(word_id);
+    if (it == h->tfidf.word_wslot.end()) { *out_nw = 0; return LCD_OK; }
+    return download(h, out_nw, h->tfidf.nw.as<uint32_t>() + it->second, 4, h->h_out2);
+}
+
+int lcd_likelihood(lcd_engine* h, const int32_t* query_word_ids, int nq, const int32_t* sig_ids, int n_ids, float N, float* out) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (nq < 0 || n_ids < 0 || (nq > 0 && !query_word_ids) || (n_ids > 0 && (!sig_ids || !out)))
+        return h->fail(LCD_ERR_INVALID, "lcd_likelihood: null input");
+    if (n_ids == 0) return LCD_OK;                                   // reference: empty ids -> empty map (Memory.cpp:2227)
+    if (nq > TF_MAX_WORDS) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_likelihood: more than 8192 query words");
+    Tfidf& t = h->tfidf;
+    if (t.n_slots == 0 || !(N > 0.0f)) { std::memset(out, 0, (size_t)n_ids * 4); return LCD_OK; }
+    int rc = stage_wslots(h, query_word_ids, nq, false);
+    if (rc) return rc;
+    LCD_HIP(h, t.query_dev(t.d_stage.as<int32_t>(), nq, N));
+    LCD_HIP(h, dreserve(h, h->d_like, (size_t)(t.n_slots + n_ids) * 4));
+    LCD_HIP(h, t.score(h->d_like.as<float>()));
+    h->likelihood_launches += 1;
+    // gather the requested signatures
+    LCD_HIP(h, h->h_in.reserve((size_t)n_ids * 8));
+    int64_t* slots = h->h_in.as<int64_t>();
+    for (int i = 0; i < n_ids; ++i) { auto it = t.sig_slot.find(sig_ids[i]); slots[i] = it == t.sig_slot.end() ? -1 : it->second; }
+    LCD_HIP(h, dreserve(h, h->d_slots, (size_t)n_ids * 8));
+    LCD_HIP(h, hipMemcpyAsync(h->d_slots.p, slots, (size_t)n_ids * 8, hipMemcpyHostToDevice, h->stream));
+    float* d_out = h->d_like.as<float>() + t.n_slots;
+    LCD_HIP(h, launch_gather_f32(h->d_like.as<float>(), h->d_slots.as<int64_t>(), n_ids, d_out, h->stream));
+    return download(h, out, d_out, (size_t)n_ids * 4, h->h_out);
+}
+
+int lcd_adjust_likelihood(lcd_engine* h, float* likelihood, int n, float virtual_place_ratio) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (n < 0 || (n > 0 && !likelihood)) return h->fail(LCD_ERR_INVALID, "lcd_adjust_likelihood: null input");
+    if (n == 0) return LCD_OK;
+    LCD_HIP(h, dreserve(h, h->d_like, (size_t)n * 4));
+    LCD_HIP(h, h->h_in.reserve((size_t)n * 4));
+    std::memcpy(h->h_in.p, likelihood, (size_t)n * 4);
+    LCD_HIP(h, hipMemcpyAsync(h->d_like.p, h->h_in.p, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    LCD_HIP(h, launch_adjust_likelihood(h->d_like.as<float>(), n, virtual_place_ratio, h->stream));
+    return download(h, likelihood, h->d_like.p, (size_t)n * 4, h->h_out);
+}
+
+// ------------------------------------------------------------------------------------------------ device-resident frame
+int lcd_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, float nndr_ratio, int32_t sig_id, float N,
+                  int32_t* d_word_ids, float* d_likelihood, int64_t likelihood_capacity) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (q <= 0 || q > 8192 || !d_descriptors || !d_word_ids) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: bad argument");
+    Tfidf& t = h->tfidf;
+    if (sig_id != 0 && t.sig_slot.count(sig_id)) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
+    const int64_t slots_after = t.n_slots + (sig_id != 0 ? 1 : 0);
+    if (d_likelihood && likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
+    int rc = quantize_dev(h, d_descriptors, q, flags, nndr_ratio, d_word_ids);
+    if (rc) return rc;
+    LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
+    rows_to_wslot_kernel<<<(q + 255) / 256, 256, 0, h->stream>>>(d_word_ids, h->d_knn_row.as<int32_t>(), h->d_knn_word.as<int32_t>(),
+                                                                h->row_wslot.as<int32_t>(), q, h->d_out_wslot.as<int32_t>());
+    LCD_HIP(h, hipGetLastError());
+    if (sig_id != 0) LCD_HIP(h, t.register_dev(sig_id, h->d_out_wslot.as<int32_t>(), q, q, N));
+    else LCD_HIP(h, t.query_dev(h->d_out_wslot.as<int32_t>(), q, N));
+    if (d_likelihood) { LCD_HIP(h, t.score(d_likelihood)); h->likelihood_launches += 1; }
+    return LCD_OK;
+}
+
+int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_ids, float* d_dist) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (q <= 0 || !d_queries || !d_word_ids || !d_dist) return h->fail(LCD_ERR_INVALID, "lcd_knn2_dev: bad argument");
+    const KnnPlan p = knn_plan(q, (int)h->n_rows, h->row_bytes);
+    LCD_HIP(h, dreserve(h, h->d_partial, knn_partial_bytes(p)));
+    LCD_HIP(h, dreserve(h, h->d_knn_row, (size_t)q * 2 * 4));
+    LCD_HIP(h, launch_knn2_partial(h->dtype, h->kdim, h->vocab.p, h->row_id.as<int32_t>(), d_queries, p, h->d_partial.as<uint64_t>(), h->stream));
+    LCD_HIP(h, launch_knn2_merge(h->dtype, p, h->d_partial.as<uint64_t>(), h->row_id.as<int32_t>(), h->d_knn_row.as<int32_t>(),
+                                 d_word_ids, d_dist, h->stream));
+    h->knn_launches += 1;
+    return LCD_OK;
+}
+
+int lcd_slots_dev(lcd_engine* h, const int32_t** d_slot_sig, int64_t* n_slots) {
+    LCD_CHECK_HANDLE(h);
+    if (d_slot_sig) *d_slot_sig = h->tfidf.slot_sig.as<int32_t>();
+    if (n_slots) *n_slots = h->tfidf.n_slots;
+    return LCD_OK;
+}
+
+int lcd_get_stats(const lcd_engine* h, lcd_stats* out) {
+    LCD_CHECK_HANDLE(h);
+    if (!out) return LCD_ERR_INVALID;
+    out->vocab_rows = h->n_rows; out->vocab_live = h->n_live;
+    out->signatures = h->tfidf.live_sigs; out->postings = h->tfidf.postings_ub;
+    out->knn_launches = h->knn_launches; out->likelihood_launches = h->likelihood_launches; out->rebuilds = h->rebuilds;
+    out->bytes_device = h->bytes_device;
+    return LCD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,396 @@
+// knn2_kernels.hip -- exact brute-force 2-NN (squared L2 / Hamming) over the device-resident vocabulary, gfx950.
+//
+// Replaces, for the quantisation hot loop of VWDictionary::addNewWords / findNN (reference VWDictionary.cpp:1015-1086,
+// 1347-1404): rtflann LinearIndex::findNeighbors (linear_index.h:129-144) with KNNSimpleResultSet (result_set.h:151-171)
+// and the cv::BFMatcher / cv::cuda brute-force matchers (VWDictionary.cpp:1027-1028, 1053-1066).
+//
+// Mapping (wave64, no LDS staging needed):
+//   * one LANE owns one query descriptor and keeps it in VGPRs for the whole kernel (64 floats / 8 dwords);
+//   * a WAVE walks a contiguous strip of vocabulary rows; the row address is wave-uniform, so the row is fetched
+//     with scalar loads (s_load_dwordx8/x16 through the scalar cache) and fed to the VALU as SGPR operands --
+//     the descriptor matrix is read from HBM/L2 exactly once per 64 queries, perfectly coalesced, zero VGPR cost;
+//   * each lane keeps a running (best, second) pair of packed keys (distance << 32 | row): "lower row wins ties"
+//     is part of the integer comparison, no cross-lane traffic in the loop;
+//   * the 4 waves of a workgroup cover 4 strips for the same 64 queries and merge through LDS once; the per-workgroup
+//     partials [n_blocks][2][qpad] are merged by knn2_merge_kernel (one wave per query, __shfl_xor butterfly).
+//   * grid.x = row blocks (a multiple of 8 so that the blocks sharing a row range land on one XCD/L2), grid.y = 64-query
+//     groups.
+//
+// Arithmetic is the reference's own, bit for bit:
+//   L2: ((d0*d0 + d1*d1) + d2*d2) + d3*d3 per group of four, added to one running float (dist.h:158-166), every product
+//       and sum individually rounded (__fmul_rn/__fadd_rn: no FMA contraction);
+//   Hamming: popcount(a ^ b) (dist.h:555-579).
+// Bound: VALU issue (3 VALU ops per float element, 2+ per dword for Hamming), not HBM: see DESIGN.md.
+#include "lcd_kernels.h"
+
+namespace lcd {
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = 4;
+constexpr int HSHIFT = 21;                       // Hamming packed key: (dist << 21) | row-in-block
+constexpr uint32_t HROWMASK = (1u << HSHIFT) - 1;
+
+__device__ __forceinline__ void top2_push(uint64_t& best, uint64_t& second, uint64_t k) {
+    const uint64_t hi = best > k ? best : k;
+    best = best < k ? best : k;
+    second = second < hi ? second : hi;
+}
+__device__ __forceinline__ void top2_push32(uint32_t& best, uint32_t& second, uint32_t k) {
+    const uint32_t hi = max(best, k);
+    best = min(best, k);
+    second = min(second, hi);
+}
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, m, 64);
+    hi = __shfl_xor(hi, m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// rtflann::L2<float>::operator() (dist.h:150-177), a = vocabulary row (wave-uniform), b = the lane's query
+template <int DIM>
+__device__ __forceinline__ float l2_ref(const float* __restrict__ row, const float (&q)[DIM]) {
+    float res = 0.0f;
+#pragma unroll
+    for (int g = 0; g + 3 < DIM; g += 4) {
+        const float d0 = __fsub_rn(row[g + 0], q[g + 0]);
+        const float d1 = __fsub_rn(row[g + 1], q[g + 1]);
+        const float d2 = __fsub_rn(row[g + 2], q[g + 2]);
+        const float d3 = __fsub_rn(row[g + 3], q[g + 3]);
+        float t = __fmul_rn(d0, d0);
+        t = __fadd_rn(t, __fmul_rn(d1, d1));
+        t = __fadd_rn(t, __fmul_rn(d2, d2));
+        t = __fadd_rn(t, __fmul_rn(d3, d3));
+        res = __fadd_rn(res, t);
+    }
+#pragma unroll
+    for (int g = DIM & ~3; g < DIM; ++g) {
+        const float d0 = __fsub_rn(row[g], q[g]);
+        res = __fadd_rn(res, __fmul_rn(d0, d0));
+    }
+    return res;
+}
+// any dimension: the query is re-read from memory (L1-resident) -- correctness path for unusual descriptor sizes
+__device__ __forceinline__ float l2_ref_dyn(const float* __restrict__ row, const float* __restrict__ q, int dim) {
+    float res = 0.0f;
+    int g = 0;
+    for (; g + 3 < dim; g += 4) {
+        const float d0 = __fsub_rn(row[g + 0], q[g + 0]);
+        const float d1 = __fsub_rn(row[g + 1], q[g + 1]);
+        const float d2 = __fsub_rn(row[g + 2], q[g + 2]);
+        const float d3 = __fsub_rn(row[g + 3], q[g + 3]);
+        float t = __fmul_rn(d0, d0);
+        t = __fadd_rn(t, __fmul_rn(d1, d1));
+        t = __fadd_rn(t, __fmul_rn(d2, d2));
+        t = __fadd_rn(t, __fmul_rn(d3, d3));
+        res = __fadd_rn(res, t);
+    }
+    for (; g < dim; ++g) {
+        const float d0 = __fsub_rn(row[g], q[g]);
+        res = __fadd_rn(res, __fmul_rn(d0, d0));
+    }
+    return res;
+}
+
+template <int W>
+__device__ __forceinline__ uint32_t hamming_ref(const uint32_t* __restrict__ row, const uint32_t (&q)[W]) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) d += __popc(row[w] ^ q[w]);
+    return d;
+}
+__device__ __forceinline__ uint32_t hamming_dyn(const uint32_t* __restrict__ row, const uint32_t* __restrict__ q, int w32) {
+    uint32_t d = 0;
+    for (int w = 0; w < w32; ++w) d += __popc(row[w] ^ q[w]);
+    return d;
+}
+
+struct Strip { int begin, end; };
+// rows [row0, row1) of the workgroup split into WAVES contiguous strips
+__device__ __forceinline__ Strip wave_strip(int row0, int row1, int wave) {
+    const int per = (row1 - row0 + WAVES - 1) / WAVES;
+    Strip s;
+    s.begin = min(row0 + wave * per, row1);
+    s.end = min(s.begin + per, row1);
+    return s;
+}
+
+// cross-wave merge + partial store.  partial layout: [block][slot][qpad]
+__device__ __forceinline__ void block_merge_store(uint64_t best, uint64_t second, int wave, int lane, int qi, int qpad,
+                                                  uint64_t* __restrict__ partial) {
+    __shared__ uint64_t s_key[WAVES][2][64];
+    s_key[wave][0][lane] = best;
+    s_key[wave][1][lane] = second;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {
+            top2_push(best, second, s_key[w][0][lane]);
+            top2_push(best, second, s_key[w][1][lane]);
+        }
+        partial[((size_t)blockIdx.x * 2 + 0) * qpad + qi] = best;
+        partial[((size_t)blockIdx.x * 2 + 1) * qpad + qi] = second;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ L2, fixed DIM
+template <int DIM>
+__global__ __launch_bounds__(BLOCK) void knn2_l2_kernel(const float* __restrict__ vocab, const int32_t* __restrict__ row_id,
+                                                        int n_rows, const float* __restrict__ queries, int nq, int qpad,
+                                                        int rows_per_block, uint64_t* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qi = blockIdx.y * 64 + lane;
+    const int qsrc = qi < nq ? qi : nq - 1;        // tail lanes repeat the last query; their results are never read
+    float q[DIM];
+    {
+        const float4* src = reinterpret_cast<const float4*>(queries + (size_t)qsrc * DIM);
+#pragma unroll
+        for (int g = 0; g < DIM / 4; ++g) {
+            const float4 v = src[g];
+            q[4 * g + 0] = v.x; q[4 * g + 1] = v.y; q[4 * g + 2] = v.z; q[4 * g + 3] = v.w;
+        }
+    }
+    const int row0 = blockIdx.x * rows_per_block;
+    const int row1 = min(row0 + rows_per_block, n_rows);
+    const Strip s = wave_strip(row0, row1, wave);
+    uint64_t best = KEY_NONE, second = KEY_NONE;
+    for (int r = s.begin; r < s.end; ++r) {
+        if (row_id[r] == 0) continue;               // tombstone (wave-uniform branch)
+        const float d = l2_ref<DIM>(vocab + (size_t)r * DIM, q);
+        top2_push(best, second, ((uint64_t)__float_as_uint(d) << 32) | (uint32_t)r);
+    }
+    block_merge_store(best, second, wave, lane, qi, qpad, partial);
+}
+
+__global__ __launch_bounds__(BLOCK) void knn2_l2_dyn_kernel(const float* __restrict__ vocab, const int32_t* __restrict__ row_id,
+                                                            int n_rows, int dim, const float* __restrict__ queries, int nq,
+                                                            int qpad, int rows_per_block, uint64_t* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qi = blockIdx.y * 64 + lane;
+    const float* q = queries + (size_t)(qi < nq ? qi : nq - 1) * dim;
+    const int row0 = blockIdx.x * rows_per_block;
+    const int row1 = min(row0 + rows_per_block, n_rows);
+    const Strip s = wave_strip(row0, row1, wave);
+    uint64_t best = KEY_NONE, second = KEY_NONE;
+    for (int r = s.begin; r < s.end; ++r) {
+        if (row_id[r] == 0) continue;
+        const float d = l2_ref_dyn(vocab + (size_t)r * dim, q, dim);
+        top2_push(best, second, ((uint64_t)__float_as_uint(d) << 32) | (uint32_t)r);
+    }
+    block_merge_store(best, second, wave, lane, qi, qpad, partial);
+}
+
+// ------------------------------------------------------------------------------------------------ Hamming, W dwords
+template <int W>
+__global__ __launch_bounds__(BLOCK) void knn2_hamming_kernel(const uint32_t* __restrict__ vocab, const int32_t* __restrict__ row_id,
+                                                             int n_rows, const uint32_t* __restrict__ queries, int nq, int qpad,
+                                                             int rows_per_block, uint64_t* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qi = blockIdx.y * 64 + lane;
+    const int qsrc = qi < nq ? qi : nq - 1;
+    uint32_t q[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) q[w] = queries[(size_t)qsrc * W + w];
+    const int row0 = blockIdx.x * rows_per_block;
+    const int row1 = min(row0 + rows_per_block, n_rows);
+    const Strip s = wave_strip(row0, row1, wave);
+    uint32_t best = ~0u, second = ~0u;              // (dist << 21) | (row - row0): one v_min/v_max each per candidate
+    int r = s.begin;
+    // 4 rows per trip: the 4 scalar row loads (and the 4 tombstone flags) are issued back to back, so one wave has
+    // 128 B of vocabulary in flight while it works; tombstones are masked by a wave-uniform select, not a branch.
+    for (; r + 4 <= s.end; r += 4) {
+        uint32_t key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t d = hamming_ref<W>(vocab + (size_t)(r + u) * W, q);
+            key[u] = row_id[r + u] != 0 ? ((d << HSHIFT) | (uint32_t)(r + u - row0)) : ~0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) top2_push32(best, second, key[u]);
+    }
+    for (; r < s.end; ++r) {
+        if (row_id[r] == 0) continue;
+        const uint32_t d = hamming_ref<W>(vocab + (size_t)r * W, q);
+        top2_push32(best, second, (d << HSHIFT) | (uint32_t)(r - row0));
+    }
+    const uint64_t b64 = best == ~0u ? KEY_NONE : (((uint64_t)(best >> HSHIFT) << 32) | (uint32_t)(row0 + (best & HROWMASK)));
+    const uint64_t s64 = second == ~0u ? KEY_NONE : (((uint64_t)(second >> HSHIFT) << 32) | (uint32_t)(row0 + (second & HROWMASK)));
+    block_merge_store(b64, s64, wave, lane, qi, qpad, partial);
+}
+
+__global__ __launch_bounds__(BLOCK) void knn2_hamming_dyn_kernel(const uint32_t* __restrict__ vocab, const int32_t* __restrict__ row_id,
+                                                                 int n_rows, int w32, const uint32_t* __restrict__ queries, int nq,
+                                                                 int qpad, int rows_per_block, uint64_t* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qi = blockIdx.y * 64 + lane;
+    const uint32_t* q = queries + (size_t)(qi < nq ? qi : nq - 1) * w32;
+    const int row0 = blockIdx.x * rows_per_block;
+    const int row1 = min(row0 + rows_per_block, n_rows);
+    const Strip s = wave_strip(row0, row1, wave);
+    uint64_t best = KEY_NONE, second = KEY_NONE;
+    for (int r = s.begin; r < s.end; ++r) {
+        if (row_id[r] == 0) continue;
+        const uint32_t d = hamming_dyn(vocab + (size_t)r * w32, q, w32);
+        top2_push(best, second, ((uint64_t)d << 32) | (uint32_t)r);
+    }
+    block_merge_store(best, second, wave, lane, qi, qpad, partial);
+}
+
+// ------------------------------------------------------------------------------------------------ merge
+// one wave per query: lanes stride over the [n_blocks*2] partial keys, then a 6-step butterfly
+__global__ __launch_bounds__(BLOCK) void knn2_merge_kernel(int dtype, const uint64_t* __restrict__ partial, int n_keys, int qpad,
+                                                           int nq, const int32_t* __restrict__ row_id,
+                                                           int32_t* __restrict__ out_row, int32_t* __restrict__ out_word,
+                                                           float* __restrict__ out_dist) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    uint64_t best = KEY_NONE, second = KEY_NONE;
+    for (int c = lane; c < n_keys; c += 64) top2_push(best, second, partial[(size_t)c * qpad + qi]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint64_t ob = shfl_xor_u64(best, m), os = shfl_xor_u64(second, m);
+        top2_push(best, second, ob);
+        top2_push(best, second, os);
+    }
+    if (lane == 0) {
+        const uint64_t k[2] = {best, second};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (k[j] == KEY_NONE) {
+                out_row[2 * qi + j] = -1; out_word[2 * qi + j] = 0; out_dist[2 * qi + j] = -1.0f;
+            } else {
+                const uint32_t row = (uint32_t)k[j], hi = (uint32_t)(k[j] >> 32);
+                out_row[2 * qi + j] = (int32_t)row;
+                out_word[2 * qi + j] = row_id[row];
+                out_dist[2 * qi + j] = dtype == 0 ? __uint_as_float(hi) : (float)hi;   // VWDictionary.cpp:1078-1083
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ self distances
+// out[r*ld + qi] = dist(query r, query qi): lane = qi (coalesced stores), wave walks rows r of the same matrix
+template <int DIM>
+__global__ __launch_bounds__(BLOCK) void selfdist_l2_kernel(const float* __restrict__ queries, int nq, int rows_per_block,
+                                                            float* __restrict__ out, int ld) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qi = blockIdx.y * 64 + lane;
+    const int qsrc = qi < nq ? qi : nq - 1;
+    float q[DIM];
+    const float4* src = reinterpret_cast<const float4*>(queries + (size_t)qsrc * DIM);
+#pragma unroll
+    for (int g = 0; g < DIM / 4; ++g) {
+        const float4 v = src[g];
+        q[4 * g + 0] = v.x; q[4 * g + 1] = v.y; q[4 * g + 2] = v.z; q[4 * g + 3] = v.w;
+    }
+    const int row0 = blockIdx.x * rows_per_block;
+    const Strip s = wave_strip(row0, min(row0 + rows_per_block, nq), wave);
+    for (int r = s.begin; r < s.end; ++r) {
+        const float d = l2_ref<DIM>(queries + (size_t)r * DIM, q);
+        if (qi < nq) out[(size_t)r * ld + qi] = d;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void selfdist_l2_dyn_kernel(const float* __restrict__ queries, int nq, int dim, int rows_per_block,
+                                                                float* __restrict__ out, int ld) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qi = blockIdx.y * 64 + lane;
+    const float* q = queries + (size_t)(qi < nq ? qi : nq - 1) * dim;
+    const int row0 = blockIdx.x * rows_per_block;
+    const Strip s = wave_strip(row0, min(row0 + rows_per_block, nq), wave);
+    for (int r = s.begin; r < s.end; ++r) {
+        const float d = l2_ref_dyn(queries + (size_t)r * dim, q, dim);
+        if (qi < nq) out[(size_t)r * ld + qi] = d;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void selfdist_hamming_dyn_kernel(const uint32_t* __restrict__ queries, int nq, int w32,
+                                                                     int rows_per_block, float* __restrict__ out, int ld) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qi = blockIdx.y * 64 + lane;
+    const uint32_t* q = queries + (size_t)(qi < nq ? qi : nq - 1) * w32;
+    const int row0 = blockIdx.x * rows_per_block;
+    const Strip s = wave_strip(row0, min(row0 + rows_per_block, nq), wave);
+    for (int r = s.begin; r < s.end; ++r) {
+        const uint32_t d = hamming_dyn(queries + (size_t)r * w32, q, w32);
+        if (qi < nq) out[(size_t)r * ld + qi] = (float)d;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================ host side
+KnnPlan knn_plan(int q, int n_rows, int dim_bytes) {
+    (void)dim_bytes;
+    KnnPlan p;
+    p.q = q;
+    p.qpad = (q + 63) / 64 * 64;
+    p.n_rows = n_rows;
+    const int qgroups = p.qpad / 64;
+    // aim at ~6 waves per SIMD over the chip (256 CUs x 4 SIMDs) so that scalar-load latency is covered by other waves
+    const int target_blocks = (256 * 4 * 6 + WAVES * qgroups - 1) / (WAVES * qgroups);
+    int nb = target_blocks;
+    const int min_rows_per_block = 4 * WAVES;              // do not shred the vocabulary below 4 rows per wave
+    if ((long long)nb * min_rows_per_block > n_rows) nb = (n_rows + min_rows_per_block - 1) / min_rows_per_block;
+    if (nb < 1) nb = 1;
+    nb = (nb + 7) / 8 * 8;                                 // blocks that share a row range stay on one XCD (b % 8)
+    int rpb = (n_rows + nb - 1) / nb;
+    if (rpb < 1) rpb = 1;
+    if (rpb > (int)HROWMASK) rpb = (int)HROWMASK;          // Hamming packed key holds 21 bits of row-in-block
+    p.rows_per_block = rpb;
+    p.n_blocks = n_rows > 0 ? (n_rows + rpb - 1) / rpb : 0;
+    return p;
+}
+size_t knn_partial_bytes(const KnnPlan& p) { return (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * 2 * p.qpad * sizeof(uint64_t); }
+
+hipError_t launch_knn2_partial(int dtype, int dim, const void* vocab, const int32_t* row_id, const void* queries,
+                               const KnnPlan& p, uint64_t* partial, hipStream_t s) {
+    if (p.n_blocks == 0 || p.q == 0) return hipSuccess;
+    dim3 grid(p.n_blocks, p.qpad / 64), block(BLOCK);
+    if (dtype == 0) {
+        const float* v = (const float*)vocab; const float* qq = (const float*)queries;
+        if (dim == 64) knn2_l2_kernel<64><<<grid, block, 0, s>>>(v, row_id, p.n_rows, qq, p.q, p.qpad, p.rows_per_block, partial);
+        else if (dim == 128) knn2_l2_kernel<128><<<grid, block, 0, s>>>(v, row_id, p.n_rows, qq, p.q, p.qpad, p.rows_per_block, partial);
+        else knn2_l2_dyn_kernel<<<grid, block, 0, s>>>(v, row_id, p.n_rows, dim, qq, p.q, p.qpad, p.rows_per_block, partial);
+    } else {
+        const uint32_t* v = (const uint32_t*)vocab; const uint32_t* qq = (const uint32_t*)queries;
+        const int w32 = dim / 4;
+        if (w32 == 8) knn2_hamming_kernel<8><<<grid, block, 0, s>>>(v, row_id, p.n_rows, qq, p.q, p.qpad, p.rows_per_block, partial);
+        else if (w32 == 16) knn2_hamming_kernel<16><<<grid, block, 0, s>>>(v, row_id, p.n_rows, qq, p.q, p.qpad, p.rows_per_block, partial);
+        else if (w32 == 4) knn2_hamming_kernel<4><<<grid, block, 0, s>>>(v, row_id, p.n_rows, qq, p.q, p.qpad, p.rows_per_block, partial);
+        else knn2_hamming_dyn_kernel<<<grid, block, 0, s>>>(v, row_id, p.n_rows, w32, qq, p.q, p.qpad, p.rows_per_block, partial);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_knn2_merge(int dtype, const KnnPlan& p, const uint64_t* partial, const int32_t* row_id,
+                             int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s) {
+    if (p.q == 0) return hipSuccess;
+    knn2_merge_kernel<<<(p.q + WAVES - 1) / WAVES, BLOCK, 0, s>>>(dtype, partial, p.n_blocks * 2, p.qpad, p.q, row_id,
+                                                                   out_row, out_word, out_dist);
+    return hipGetLastError();
+}
+
+hipError_t launch_selfdist(int dtype, int dim, const void* queries, int q, float* out, int ld, hipStream_t s) {
+    if (q == 0) return hipSuccess;
+    const int rpb = 16;
+    dim3 grid((q + rpb - 1) / rpb, (q + 63) / 64), block(BLOCK);
+    if (dtype == 0) {
+        const float* qq = (const float*)queries;
+        if (dim == 64) selfdist_l2_kernel<64><<<grid, block, 0, s>>>(qq, q, rpb, out, ld);
+        else if (dim == 128) selfdist_l2_kernel<128><<<grid, block, 0, s>>>(qq, q, rpb, out, ld);
+        else selfdist_l2_dyn_kernel<<<grid, block, 0, s>>>(qq, q, dim, rpb, out, ld);
+    } else {
+        selfdist_hamming_dyn_kernel<<<grid, block, 0, s>>>((const uint32_t*)queries, q, dim / 4, rpb, out, ld);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace lcd

@@ -1,0 +1,51 @@
+// lcd_kernels.h -- host-callable launchers of the hand-written gfx950 kernels (internal to liblcd_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lcd {
+
+// A candidate is one 64-bit key: (distance << 32) | row.  For LCD_F32 the distance half is the IEEE bit pattern of
+// the (non-negative) squared L2 distance, for LCD_U8 it is the integer Hamming distance; both order like unsigned
+// integers, and the row in the low half makes "lower row wins ties" (result_set.h:151-171) part of the comparison.
+static const uint64_t KEY_NONE = ~0ull;
+
+struct KnnPlan {
+    int q;             // queries
+    int qpad;          // q rounded up to 64
+    int n_rows;        // vocabulary rows (incl. tombstones)
+    int rows_per_block;
+    int n_blocks;      // row blocks (grid.x)
+};
+KnnPlan knn_plan(int q, int n_rows, int dim_bytes);
+size_t knn_partial_bytes(const KnnPlan& p);   // [n_blocks][2][qpad] keys
+
+// 2-NN of `queries` [q x dim] against `vocab` [n_rows x dim] (row_id[r] == 0 -> tombstone, skipped).
+// dtype: 0 = f32 (dim floats), 1 = u8 (dim bytes, dim % 4 == 0).  Writes per-block partial top-2 keys.
+hipError_t launch_knn2_partial(int dtype, int dim, const void* vocab, const int32_t* row_id, const void* queries,
+                               const KnnPlan& p, uint64_t* partial, hipStream_t s);
+// Merge the partial keys: out_row[q*2] (row or -1), out_word[q*2] (row_id[row] or 0), out_dist[q*2] (float, -1 = none)
+hipError_t launch_knn2_merge(int dtype, const KnnPlan& p, const uint64_t* partial, const int32_t* row_id,
+                             int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s);
+// q x q distances of a block against itself; out[i*ld + j], ld >= q.
+hipError_t launch_selfdist(int dtype, int dim, const void* queries, int q, float* out, int ld, hipStream_t s);
+
+// The addNewWords decision loop (VWDictionary.cpp:1089-1219) for a whole frame, on the device.
+//   knn_word/knn_dist [q*2] indexed candidates (word 0 / dist < 0 = none); have_index = vocabulary had >= 2 live rows
+//   selfdist [q x ld] (may be NULL when !(flags & NEW_WORDS_COMPARED))
+//   out_word[q]: > 0 existing word, < 0: -(k+1) for the k-th new word, 0: no entry (fixed dictionary, no candidate)
+//   out_n_new[1]
+hipError_t launch_resolve(int q, int flags, float nndr, int have_index, const int32_t* knn_word, const float* knn_dist,
+                          const float* selfdist, int ld, int32_t* out_word, int32_t* out_n_new, hipStream_t s);
+// findNN merge (VWDictionary.cpp:1457-1542): indexed candidates + candidates among the not-indexed words + NNDR.
+hipError_t launch_findnn_resolve(int q, int flags, float nndr, int have_index, const int32_t* knn_word,
+                                 const float* knn_dist, int have_extra, const int32_t* extra_word,
+                                 const float* extra_dist, int32_t* out_word, hipStream_t s);
+
+// Row gather used by lcd_vocab_rebuild: dst[i] = src[perm[i]] (rows of row_bytes bytes, multiple of 4), ids likewise.
+hipError_t launch_gather_rows(const void* src, const int32_t* src_id, const int32_t* perm, int n, int row_bytes,
+                              void* dst, int32_t* dst_id, hipStream_t s);
+// row_id[rows[i]] = 0
+hipError_t launch_tombstone(int32_t* row_id, const int32_t* rows, int n, hipStream_t s);
+
+}  // namespace lcd

@@ -1,0 +1,573 @@
+// tfidf.hip -- kernels and host-side management of the blocked inverted index (see tfidf.h for the layout).
+//
+// Reference behaviour reproduced (Memory.cpp:2215-2291): for every UNIQUE word id w > 0 of the query,
+//   nw = refs(w).size(); logNnw = log10(N / nw) (float); skipped when nw == 0 or logNnw == 0;
+//   for every (signature s, count nwi) in refs(w): ni = getNi(s); if ni != 0: L[s] += (nwi * logNnw) / ni   (all fp32).
+// Every term is evaluated with exactly these fp32 operations; only the accumulation differs: the reference adds the
+// terms of one signature in ascending word order in fp32, here they are added as Q15.48 integers (order-free,
+// truncation error < 2^-48 per term), so results agree to ~1e-6 relative (bound 1e-4, tests/test_gpu_likelihood.py).
+#include "tfidf.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace lcd {
+namespace {
+
+constexpr int FW_BLOCK = 1024;   // frame_words_kernel
+constexpr int SC_BLOCK = 256;    // scoring kernels
+
+// exclusive scan, in place, of data[0..n) (LDS) by a whole workgroup; returns the total.  scratch[blockDim.x + 1] in LDS.
+__device__ uint32_t block_exclusive_scan(uint32_t* data, int n, uint32_t* scratch) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int per = (n + nt - 1) / nt;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += data[i];
+    scratch[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {
+        const uint32_t t = tid >= off ? scratch[tid - off] : 0;
+        __syncthreads();
+        scratch[tid] += t;
+        __syncthreads();
+    }
+    uint32_t run = scratch[tid] - sum;     // exclusive prefix of this thread's chunk
+    const uint32_t total = scratch[nt - 1];
+    for (int i = lo; i < hi; ++i) { const uint32_t v = data[i]; data[i] = run; run += v; }
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ unsigned long long to_fixed(float t) {
+    // t >= 0, t < 2^15.  floor(t * 2^48) from the bit pattern (no f32->i64 instruction on the VALU)
+    const uint32_t bits = __float_as_uint(t);
+    const uint32_t mant = (bits & 0x7FFFFFu) | 0x800000u;
+    const int shift = (int)(bits >> 23) - (127 + 23 - TF_FIX_SHIFT);
+    if ((bits >> 23) == 0) return 0ull;                      // zero / subnormal
+    if (shift >= 0) return (unsigned long long)mant << min(shift, 39);
+    return shift > -24 ? (unsigned long long)(mant >> (-shift)) : 0ull;
+}
+
+// ---------------------------------------------------------------------------------------------- frame words
+// One workgroup: sort the frame's word slots, reduce to (unique word, count), optionally append them to the open
+// bucket as the postings of signature `slot` (nw += 1 each), and leave word/count/idf lists for the scoring kernels.
+__global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(const int32_t* __restrict__ wslots, int n, int P, int do_register,
+                                                               int32_t sig_id, long long slot, uint32_t slot_local, uint32_t ni, float N,
+                                                               uint32_t* __restrict__ nw, uint32_t* __restrict__ coo_w,
+                                                               uint32_t* __restrict__ coo_pc, uint32_t* __restrict__ ne_counter,
+                                                               int32_t* __restrict__ slot_sig, uint32_t* __restrict__ slot_ni,
+                                                               uint32_t* __restrict__ slot_begin, uint32_t* __restrict__ slot_cnt,
+                                                               uint32_t* __restrict__ q_w, uint32_t* __restrict__ q_cnt,
+                                                               float* __restrict__ q_idf, uint32_t* __restrict__ q_meta) {
+    extern __shared__ uint32_t fw_smem[];
+    uint32_t* keys = fw_smem;            // [P]
+    uint32_t* pos = fw_smem + P;         // [P] head flags -> head positions
+    uint32_t* scratch = pos + P;         // [FW_BLOCK + 1]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < P; i += FW_BLOCK) {
+        const int32_t w = i < n ? wslots[i] : -1;
+        keys[i] = w >= 0 ? (uint32_t)w : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    // bitonic sort, ascending
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += FW_BLOCK) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // heads of runs of equal valid keys
+    for (int i = tid; i < P; i += FW_BLOCK) {
+        const uint32_t k = keys[i];
+        pos[i] = (k != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+    }
+    __syncthreads();
+    // count of valid keys (they sort first)
+    __shared__ uint32_t s_valid;
+    if (tid == 0) s_valid = 0;
+    __syncthreads();
+    for (int i = tid; i < P; i += FW_BLOCK)
+        if (keys[i] != 0xFFFFFFFFu && (i + 1 == P || keys[i + 1] == 0xFFFFFFFFu)) s_valid = (uint32_t)i + 1;
+    __syncthreads();
+    const uint32_t V = s_valid;
+    // exclusive scan of the head flags: a head at i gets unique index pos[i]; heads[u] = position of the u-th unique word
+    const uint32_t U = block_exclusive_scan(pos, P, scratch);
+    uint32_t* heads = scratch + FW_BLOCK + 1;   // [P]
+    for (int i = tid; i < P; i += FW_BLOCK) {
+        const uint32_t k = keys[i];
+        if (k != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != k)) heads[pos[i]] = (uint32_t)i;
+    }
+    __syncthreads();
+    const uint32_t base = do_register ? ne_counter[0] : 0u;
+    __syncthreads();
+    for (uint32_t u = tid; u < U; u += FW_BLOCK) {
+        const uint32_t i = heads[u];
+        const uint32_t end = (u + 1 < U) ? heads[u + 1] : V;
+        const uint32_t w = keys[i];
+        uint32_t cnt = end - i;
+        if (cnt > TF_CNT_MASK) cnt = TF_CNT_MASK;
+        uint32_t nwv;
+        if (do_register) {
+            nwv = atomicAdd(&nw[w], 1u) + 1u;
+            coo_w[base + u] = w;
+            coo_pc[base + u] = (slot_local << TF_CNT_BITS) | cnt;
+        } else {
+            nwv = nw[w];
+        }
+        q_w[u] = w;
+        q_cnt[u] = cnt;
+        float idf = 0.0f;
+        if (N > 0.0f && nwv > 0u) idf = log10f(__fdiv_rn(N, (float)nwv));   // Memory.cpp:2264-2266
+        q_idf[u] = idf;
+    }
+    if (tid == 0) {
+        q_meta[0] = U;
+        if (do_register) {
+            ne_counter[0] = base + U;
+            slot_sig[slot] = sig_id;
+            slot_ni[slot] = ni;
+            slot_begin[slot] = base;
+            slot_cnt[slot] = U;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- sealed buckets
+// grid = (sealed live buckets, G word groups).  LDS: acc[R] i64 | ni[R] | start[Wg] | scan[Wg + 1] | idf[Wg] | scratch
+__global__ __launch_bounds__(SC_BLOCK) void score_sealed_kernel(const BucketDev* __restrict__ tab, const int32_t* __restrict__ list, int G,
+                                                                int wg_cap, const uint32_t* __restrict__ q_w,
+                                                                const float* __restrict__ q_idf, const uint32_t* __restrict__ q_meta,
+                                                                const uint32_t* __restrict__ slot_ni,
+                                                                unsigned long long* __restrict__ lfix) {
+    extern __shared__ unsigned long long sc_smem[];
+    unsigned long long* acc = sc_smem;                              // [R]
+    uint32_t* s_ni = (uint32_t*)(acc + TF_R);                       // [R]
+    uint32_t* s_start = s_ni + TF_R;                                // [wg_cap]
+    uint32_t* s_scan = s_start + wg_cap;                            // [wg_cap + 1]
+    float* s_idf = (float*)(s_scan + wg_cap + 1);                   // [wg_cap]
+    uint32_t* scratch = (uint32_t*)(s_idf + wg_cap);                // [SC_BLOCK + 1]
+    const int tid = threadIdx.x;
+    const int b = list[blockIdx.x];
+    const int g = blockIdx.y;
+    const uint32_t* __restrict__ dir = tab[b].dir;
+    const uint32_t* __restrict__ ent = tab[b].ent;
+    const uint32_t W = tab[b].W;
+    const long long first_slot = (long long)b * TF_R;
+    const int U = (int)q_meta[0];
+    int Ug = U > g ? (U - g + G - 1) / G : 0;
+    if (Ug > wg_cap) Ug = wg_cap;                                   // cannot happen: wg_cap is sized from the word count
+    for (int i = tid; i < TF_R; i += SC_BLOCK) { acc[i] = 0ull; s_ni[i] = slot_ni[first_slot + i]; }
+    for (int k = tid; k < Ug; k += SC_BLOCK) {
+        const int u = g + k * G;
+        const uint32_t w = q_w[u];
+        const float idf = q_idf[u];
+        uint32_t s = 0, e = 0;
+        if (w < W && idf != 0.0f) { s = dir[w]; e = dir[w + 1]; }    // "if(logNnw)" (Memory.cpp:2267)
+        s_start[k] = s;
+        s_scan[k] = e - s;
+        s_idf[k] = idf;
+    }
+    if (tid == 0) s_scan[Ug] = 0;
+    __syncthreads();
+    const uint32_t T = block_exclusive_scan(s_scan, Ug + 1, scratch);   // s_scan[Ug] == T afterwards
+    // flattened, load-balanced walk over all postings of this bucket that belong to the group's words
+    int k = 0;
+    for (uint32_t t = tid; t < T; t += SC_BLOCK) {
+        while (s_scan[k + 1] <= t) ++k;
+        const uint32_t e = ent[s_start[k] + (t - s_scan[k])];
+        const uint32_t sl = e >> TF_CNT_BITS;
+        const uint32_t ni = s_ni[sl];
+        if (ni != 0u) {                                              // "if(ni != 0)" (Memory.cpp:2275), 0 = retired slot
+            const float term = __fdiv_rn(__fmul_rn((float)(e & TF_CNT_MASK), s_idf[k]), (float)ni);
+            atomicAdd(&acc[sl], to_fixed(term));                     // ds_add_u64
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < TF_R; i += SC_BLOCK) {
+        const unsigned long long v = acc[i];
+        if (v != 0ull) {
+            if (G == 1) lfix[first_slot + i] = v;
+            else atomicAdd(&lfix[first_slot + i], v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- open bucket
+// arrival-order log scanned against the frame's sorted unique words (binary search in LDS)
+__global__ __launch_bounds__(SC_BLOCK) void score_open_kernel(const uint32_t* __restrict__ coo_w, const uint32_t* __restrict__ coo_pc,
+                                                              const uint32_t* __restrict__ ne_counter, long long first_slot,
+                                                              int w_cap, const uint32_t* __restrict__ q_w,
+                                                              const float* __restrict__ q_idf, const uint32_t* __restrict__ q_meta,
+                                                              const uint32_t* __restrict__ slot_ni,
+                                                              unsigned long long* __restrict__ lfix) {
+    extern __shared__ uint32_t so_smem[];
+    uint32_t* s_w = so_smem;                    // [w_cap]
+    float* s_idf = (float*)(so_smem + w_cap);   // [w_cap]
+    int U = (int)q_meta[0];
+    if (U > w_cap) U = w_cap;
+    for (int i = threadIdx.x; i < U; i += SC_BLOCK) { s_w[i] = q_w[i]; s_idf[i] = q_idf[i]; }
+    __syncthreads();
+    const uint32_t ne = ne_counter[0];
+    for (uint32_t e = blockIdx.x * SC_BLOCK + threadIdx.x; e < ne; e += gridDim.x * SC_BLOCK) {
+        const uint32_t w = coo_w[e];
+        int lo = 0, hi = U;                     // first index with s_w[idx] >= w
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_w[mid] < w) lo = mid + 1; else hi = mid; }
+        if (lo < U && s_w[lo] == w) {
+            const float idf = s_idf[lo];
+            if (idf != 0.0f) {
+                const uint32_t pc = coo_pc[e];
+                const long long slot = first_slot + (pc >> TF_CNT_BITS);
+                const uint32_t ni = slot_ni[slot];
+                if (ni != 0u) {
+                    const float term = __fdiv_rn(__fmul_rn((float)(pc & TF_CNT_MASK), idf), (float)ni);
+                    atomicAdd(&lfix[slot], to_fixed(term));
+                }
+            }
+        }
+    }
+}
+
+__global__ void finalize_kernel(const long long* __restrict__ lfix, long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)((double)lfix[i] * (1.0 / 281474976710656.0));   // 2^-48
+}
+__global__ void gather_f32_kernel(const float* __restrict__ dense, const long long* __restrict__ slots, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const long long s = slots[i]; out[i] = s >= 0 ? dense[s] : 0.0f; }
+}
+
+// ---------------------------------------------------------------------------------------------- sealing
+__global__ void seal_count_kernel(const uint32_t* __restrict__ coo_w, uint32_t ne, uint32_t* __restrict__ dir) {
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) atomicAdd(&dir[coo_w[e] + 1], 1u);
+}
+// inclusive scan of dir[0..n) in global memory by one workgroup (n up to a few million, sealing is rare)
+__global__ __launch_bounds__(1024) void seal_scan_kernel(uint32_t* __restrict__ dir, uint32_t n) {
+    __shared__ uint32_t scratch[1025];
+    const int tid = threadIdx.x;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = min((uint32_t)tid * per, n), hi = min(lo + per, n);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += dir[i];
+    scratch[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t t = tid >= off ? scratch[tid - off] : 0;
+        __syncthreads();
+        scratch[tid] += t;
+        __syncthreads();
+    }
+    uint32_t run = scratch[tid] - sum;
+    for (uint32_t i = lo; i < hi; ++i) { run += dir[i]; dir[i] = run; }
+}
+__global__ void seal_scatter_kernel(const uint32_t* __restrict__ coo_w, const uint32_t* __restrict__ coo_pc, uint32_t ne,
+                                    const uint32_t* __restrict__ dir, uint32_t* __restrict__ cursor, uint32_t* __restrict__ ent) {
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
+        const uint32_t w = coo_w[e];
+        ent[dir[w] + atomicAdd(&cursor[w], 1u)] = coo_pc[e];
+    }
+}
+__global__ void retire_kernel(long long slot, const uint32_t* __restrict__ coo_w, const uint32_t* __restrict__ slot_begin,
+                              const uint32_t* __restrict__ slot_cnt, uint32_t* __restrict__ nw, uint32_t* __restrict__ slot_ni,
+                              int32_t* __restrict__ slot_sig) {
+    const uint32_t begin = slot_begin[slot], cnt = slot_cnt[slot];
+    for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) atomicSub(&nw[coo_w[begin + k]], 1u);
+    if (threadIdx.x == 0) { slot_ni[slot] = 0u; slot_sig[slot] = 0; }
+}
+
+
+// ---------------------------------------------------------------------------------------------- adjustLikelihood
+// Rtabmap::adjustLikelihood (Rtabmap.cpp:5691-5760): mean / sample standard deviation over the entries > 0 after the
+// virtual place (entry 0), rescale the entries above mean + stddev, then set the virtual place.  One workgroup, three
+// passes over L[1..n) (0.4 MB at 100k signatures, L2-resident).  Sums are accumulated in double (the reference adds
+// floats sequentially, uMean/uVariance UMath.h:419-432, 512-526): results agree to ~1e-6 relative.
+__global__ __launch_bounds__(1024) void adjust_likelihood_kernel(float* __restrict__ L, int n, float ratio) {
+    __shared__ double s_sum[1024];
+    __shared__ unsigned int s_cnt[1024];
+    __shared__ float s_max[1024];
+    const int tid = threadIdx.x;
+    double sum = 0.0; unsigned int cnt = 0; float mx = 0.0f;
+    for (int i = 1 + tid; i < n; i += 1024) {
+        const float v = L[i];
+        if (v > 0.0f) { sum += (double)v; ++cnt; }
+        if (v > mx) mx = v;
+    }
+    s_sum[tid] = sum; s_cnt[tid] = cnt; s_max[tid] = mx;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) { s_sum[tid] += s_sum[tid + off]; s_cnt[tid] += s_cnt[tid + off]; s_max[tid] = fmaxf(s_max[tid], s_max[tid + off]); }
+        __syncthreads();
+    }
+    const unsigned int count = s_cnt[0];
+    const float mean = count ? (float)(s_sum[0] / (double)count) : 0.0f;
+    const float maxv = s_max[0];
+    __syncthreads();
+    double sq = 0.0;
+    for (int i = 1 + tid; i < n; i += 1024) {
+        const float v = L[i];
+        if (v > 0.0f) { const float d = v - mean; sq += (double)(d * d); }
+    }
+    s_sum[tid] = sq;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) s_sum[tid] += s_sum[tid + off];
+        __syncthreads();
+    }
+    const float var = count > 1 ? (float)(s_sum[0] / (double)(count - 1)) : 0.0f;
+    const float stdDev = sqrtf(var);
+    const float epsilon = 0.0001f;
+    for (int i = 1 + tid; i < n; i += 1024) {
+        const float value = L[i];
+        float o = 1.0f;
+        if (value > mean + stdDev) {
+            if (ratio == 0.0f && mean != 0.0f) o = (value - (stdDev - epsilon)) / mean;
+            else if (ratio != 0.0f && stdDev != 0.0f) o = (value - mean) / stdDev;
+        }
+        L[i] = o;
+    }
+    if (tid == 0 && n > 0) {
+        float vp;
+        if (ratio == 0.0f && stdDev > epsilon && maxv != 0.0f) vp = mean / stdDev + 1.0f;
+        else if (ratio != 0.0f && maxv > mean) vp = stdDev / (maxv - mean) + 1.0f;
+        else vp = 2.0f;
+        L[0] = vp;
+    }
+}
+
+inline int next_pow2(int v) { int p = 2; while (p < v) p <<= 1; return p; }
+
+}  // namespace
+
+hipError_t launch_adjust_likelihood(float* d_L, int n, float ratio, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    adjust_likelihood_kernel<<<1, 1024, 0, s>>>(d_L, n, ratio);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_f32(const float* dense, const int64_t* slots, int n, float* out, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    gather_f32_kernel<<<(n + 255) / 256, 256, 0, s>>>(dense, (const long long*)slots, n, out);
+    return hipGetLastError();
+}
+
+// ================================================================================================ host side
+#define TF_TRY(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return e__; } while (0)
+
+hipError_t Tfidf::init(hipStream_t s, int64_t* bytes, int64_t sig_capacity) {
+    stream = s;
+    bytes_device = bytes;
+    TF_TRY(ensure_slots(sig_capacity > 0 ? sig_capacity : TF_R));
+    TF_TRY(q_w.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
+    TF_TRY(q_cnt.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
+    TF_TRY(q_idf.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
+    TF_TRY(q_meta.reserve(64, 0, stream, bytes_device));
+    TF_TRY(hipMemsetAsync(q_meta.p, 0, 64, stream));
+    return hipSuccess;
+}
+
+void Tfidf::destroy() {
+    for (Bucket& b : buckets) { b.coo_w.release(bytes_device); b.coo_pc.release(bytes_device); b.dir.release(bytes_device); b.ent.release(bytes_device); }
+    buckets.clear();
+    DevBuf* all[] = {&slot_sig, &slot_ni, &slot_begin, &slot_cnt, &nw, &bkt_tab, &bkt_ne, &bkt_list, &lfix, &q_w, &q_cnt, &q_idf,
+                     &q_meta, &tmp_cursor, &d_stage};
+    for (DevBuf* d : all) d->release(bytes_device);
+    h_stage.release();
+}
+
+// grow a zero-initialised table
+static hipError_t grow_zeroed(DevBuf& buf, size_t bytes, hipStream_t s, int64_t* total) {
+    const size_t old = buf.cap;
+    if (bytes <= old) return hipSuccess;
+    hipError_t e = buf.reserve(bytes, old, s, total);
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync((char*)buf.p + old, 0, buf.cap - old, s);
+}
+
+hipError_t Tfidf::ensure_slots(int64_t n) {
+    TF_TRY(grow_zeroed(slot_sig, (size_t)n * 4, stream, bytes_device));
+    TF_TRY(grow_zeroed(slot_ni, (size_t)n * 4, stream, bytes_device));
+    TF_TRY(grow_zeroed(slot_begin, (size_t)n * 4, stream, bytes_device));
+    TF_TRY(grow_zeroed(slot_cnt, (size_t)n * 4, stream, bytes_device));
+    TF_TRY(grow_zeroed(lfix, (size_t)n * 8, stream, bytes_device));
+    return hipSuccess;
+}
+
+hipError_t Tfidf::wslot_of(int32_t word_id, int32_t* out) {
+    auto it = word_wslot.find(word_id);
+    if (it != word_wslot.end()) { *out = it->second; return hipSuccess; }
+    const int32_t w = n_wslots++;
+    word_wslot.emplace(word_id, w);
+    TF_TRY(grow_zeroed(nw, (size_t)n_wslots * 4, stream, bytes_device));
+    *out = w;
+    return hipSuccess;
+}
+
+hipError_t Tfidf::upload_buckets() {
+    if (!bkt_dirty) return hipSuccess;
+    h_bkt.resize(buckets.size());
+    std::vector<int32_t> list;
+    for (size_t i = 0; i < buckets.size(); ++i) {
+        Bucket& b = buckets[i];
+        BucketDev d;
+        d.coo_w = b.coo_w.as<uint32_t>(); d.coo_pc = b.coo_pc.as<uint32_t>();
+        d.dir = b.dir.as<uint32_t>(); d.ent = b.ent.as<uint32_t>();
+        d.W = b.W; d.sealed = b.sealed ? 1u : 0u; d.n_e_sealed = b.n_e_sealed; d.pad = 0;
+        h_bkt[i] = d;
+        if (b.sealed && b.live > 0) list.push_back((int32_t)i);
+    }
+    n_list = (int)list.size();
+    if (!buckets.empty()) {
+        TF_TRY(bkt_tab.reserve(buckets.size() * sizeof(BucketDev), 0, stream, bytes_device));
+        TF_TRY(hipStreamSynchronize(stream));   // pageable source: keep it simple and ordered
+        TF_TRY(hipMemcpy(bkt_tab.p, h_bkt.data(), buckets.size() * sizeof(BucketDev), hipMemcpyHostToDevice));
+    }
+    if (n_list) {
+        TF_TRY(bkt_list.reserve(list.size() * 4, 0, stream, bytes_device));
+        TF_TRY(hipMemcpy(bkt_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice));
+    }
+    bkt_dirty = false;
+    return hipSuccess;
+}
+
+hipError_t Tfidf::seal(int bi) {
+    Bucket& b = buckets[bi];
+    if (b.sealed) return hipSuccess;
+    uint32_t ne = 0;
+    TF_TRY(hipMemcpyAsync(&ne, bkt_ne.as<uint32_t>() + bi, 4, hipMemcpyDeviceToHost, stream));
+    TF_TRY(hipStreamSynchronize(stream));
+    const uint32_t W = (uint32_t)n_wslots;
+    TF_TRY(b.dir.reserve(((size_t)W + 1) * 4, 0, stream, bytes_device));
+    TF_TRY(b.ent.reserve(std::max<size_t>(ne, 1) * 4, 0, stream, bytes_device));
+    TF_TRY(tmp_cursor.reserve(((size_t)W + 1) * 4, 0, stream, bytes_device));
+    TF_TRY(hipMemsetAsync(b.dir.p, 0, ((size_t)W + 1) * 4, stream));
+    TF_TRY(hipMemsetAsync(tmp_cursor.p, 0, ((size_t)W + 1) * 4, stream));
+    if (ne) {
+        int blocks = (int)std::min<uint32_t>((ne + 255) / 256, 1024);
+        seal_count_kernel<<<blocks, 256, 0, stream>>>(b.coo_w.as<uint32_t>(), ne, b.dir.as<uint32_t>());
+        seal_scan_kernel<<<1, 1024, 0, stream>>>(b.dir.as<uint32_t>(), W + 1);
+        seal_scatter_kernel<<<blocks, 256, 0, stream>>>(b.coo_w.as<uint32_t>(), b.coo_pc.as<uint32_t>(), ne, b.dir.as<uint32_t>(),
+                                                       tmp_cursor.as<uint32_t>(), b.ent.as<uint32_t>());
+        TF_TRY(hipGetLastError());
+    }
+    b.W = W;
+    b.n_e_sealed = ne;
+    b.sealed = true;
+    bkt_dirty = true;
+    return hipSuccess;
+}
+
+static hipError_t run_frame_words(Tfidf& t, const int32_t* d_wslots, int n, bool reg, int32_t sig_id, int64_t slot, int32_t ni, float N) {
+    const int P = next_pow2(std::max(n, 2));
+    const size_t shmem = ((size_t)P * 3 + FW_BLOCK + 1 + 8) * 4;
+    uint32_t* coo_w = nullptr; uint32_t* coo_pc = nullptr; uint32_t* ne = nullptr;
+    if (reg) {
+        const int bi = (int)(slot / TF_R);
+        coo_w = t.buckets[bi].coo_w.as<uint32_t>();
+        coo_pc = t.buckets[bi].coo_pc.as<uint32_t>();
+        ne = t.bkt_ne.as<uint32_t>() + bi;
+    }
+    frame_words_kernel<<<1, FW_BLOCK, shmem, t.stream>>>(d_wslots, n, P, reg ? 1 : 0, sig_id, (long long)slot, (uint32_t)(slot % TF_R),
+                                                        (uint32_t)ni, N, t.nw.as<uint32_t>(), coo_w, coo_pc, ne,
+                                                        t.slot_sig.as<int32_t>(), t.slot_ni.as<uint32_t>(),
+                                                        t.slot_begin.as<uint32_t>(), t.slot_cnt.as<uint32_t>(),
+                                                        t.q_w.as<uint32_t>(), t.q_cnt.as<uint32_t>(), t.q_idf.as<float>(),
+                                                        t.q_meta.as<uint32_t>());
+    t.q_n_ub = n;
+    return hipGetLastError();
+}
+
+hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N) {
+    if (n > TF_MAX_WORDS) return hipErrorInvalidValue;
+    const int64_t slot = n_slots;
+    TF_TRY(ensure_slots(slot + 1));
+    const int bi = (int)(slot / TF_R);
+    if (bi >= (int)buckets.size()) {
+        if (bi > 0) TF_TRY(seal(bi - 1));
+        buckets.emplace_back();
+        TF_TRY(grow_zeroed(bkt_ne, (size_t)(bi + 1) * 4, stream, bytes_device));
+        bkt_dirty = true;
+    }
+    Bucket& b = buckets[bi];
+    const size_t need = (size_t)(b.ub_entries + n) * 4;
+    if (need > b.coo_w.cap) {
+        const size_t want = std::max(need, (size_t)TF_R * 512 * 4);
+        TF_TRY(b.coo_w.reserve(want, (size_t)b.ub_entries * 4, stream, bytes_device));
+        TF_TRY(b.coo_pc.reserve(want, (size_t)b.ub_entries * 4, stream, bytes_device));
+        bkt_dirty = true;
+    }
+    TF_TRY(run_frame_words(*this, d_wslots, n, true, sig_id, slot, ni, N));
+    b.ub_entries += n;
+    b.n_slots += 1;
+    b.live += 1;
+    postings_ub += n;
+    n_slots += 1;
+    live_sigs += 1;
+    sig_slot[sig_id] = slot;
+    return hipSuccess;
+}
+
+hipError_t Tfidf::query_dev(const int32_t* d_wslots, int n, float N) {
+    if (n > TF_MAX_WORDS) return hipErrorInvalidValue;
+    return run_frame_words(*this, d_wslots, n, false, 0, 0, 0, N);
+}
+
+hipError_t Tfidf::score(float* d_likelihood) {
+    if (n_slots == 0) return hipSuccess;
+    TF_TRY(upload_buckets());
+    TF_TRY(hipMemsetAsync(lfix.p, 0, (size_t)n_slots * 8, stream));
+    const int wcap_all = std::max(q_n_ub, 1);
+    if (n_list > 0) {
+        int G = (768 + n_list - 1) / n_list;
+        G = std::max(1, std::min(G, 8));
+        const int wg_cap = (wcap_all + G - 1) / G;
+        const size_t shmem = (size_t)TF_R * 8 + (size_t)TF_R * 4 + ((size_t)wg_cap * 3 + 1 + SC_BLOCK + 1 + 4) * 4;
+        score_sealed_kernel<<<dim3(n_list, G), SC_BLOCK, shmem, stream>>>(bkt_tab.as<BucketDev>(), bkt_list.as<int32_t>(), G, wg_cap,
+                                                                         q_w.as<uint32_t>(), q_idf.as<float>(), q_meta.as<uint32_t>(),
+                                                                         slot_ni.as<uint32_t>(), lfix.as<unsigned long long>());
+        TF_TRY(hipGetLastError());
+    }
+    if (!buckets.empty() && !buckets.back().sealed && buckets.back().ub_entries > 0) {
+        const int bi = (int)buckets.size() - 1;
+        const Bucket& b = buckets[bi];
+        int blocks = (int)std::min<int64_t>((b.ub_entries + SC_BLOCK - 1) / SC_BLOCK, 128);
+        score_open_kernel<<<blocks, SC_BLOCK, (size_t)wcap_all * 8, stream>>>(b.coo_w.as<uint32_t>(), b.coo_pc.as<uint32_t>(),
+                                                                             bkt_ne.as<uint32_t>() + bi, (long long)bi * TF_R, wcap_all,
+                                                                             q_w.as<uint32_t>(), q_idf.as<float>(), q_meta.as<uint32_t>(),
+                                                                             slot_ni.as<uint32_t>(), lfix.as<unsigned long long>());
+        TF_TRY(hipGetLastError());
+    }
+    finalize_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, stream>>>(lfix.as<long long>(), (long long)n_slots, d_likelihood);
+    return hipGetLastError();
+}
+
+hipError_t Tfidf::retire(int32_t sig_id) {
+    auto it = sig_slot.find(sig_id);
+    if (it == sig_slot.end()) return hipErrorInvalidValue;
+    const int64_t slot = it->second;
+    const int bi = (int)(slot / TF_R);
+    Bucket& b = buckets[bi];
+    retire_kernel<<<1, 256, 0, stream>>>((long long)slot, b.coo_w.as<uint32_t>(), slot_begin.as<uint32_t>(), slot_cnt.as<uint32_t>(),
+                                         nw.as<uint32_t>(), slot_ni.as<uint32_t>(), slot_sig.as<int32_t>());
+    TF_TRY(hipGetLastError());
+    sig_slot.erase(it);
+    live_sigs -= 1;
+    b.live -= 1;
+    if (b.live == 0 && b.sealed) {
+        // every signature of the bucket is gone: drop its postings (the retire kernel above must finish first)
+        TF_TRY(hipStreamSynchronize(stream));
+        postings_ub -= b.ub_entries;
+        b.coo_w.release(bytes_device); b.coo_pc.release(bytes_device); b.dir.release(bytes_device); b.ent.release(bytes_device);
+        b.W = 0; b.n_e_sealed = 0; b.ub_entries = 0;
+        bkt_dirty = true;
+    }
+    return hipSuccess;
+}
+
+}  // namespace lcd

@@ -73,6 +73,24 @@ def query_from_signature(sig_words, n_words, seed, resample=0.3):
     return out
 
 
+def frame_from_signature(vocab, sig_words, seed, resample=0.3, sigma=0.05):
+    """Descriptors of a revisit of an earlier place: descriptor i is a noisy copy of the vocabulary row of the i-th word
+    of that signature (quantisation maps it back to the word), except `resample` of them which are fresh descriptors
+    (NNDR rejects them: would-be new words).  vocab row r holds word id r + 1.  Works for float and binary vocabularies."""
+    rng = np.random.default_rng(seed)
+    q = sig_words.shape[0]
+    fresh = rng.random(q) < resample
+    rows = vocab[np.clip(sig_words, 1, vocab.shape[0]) - 1]
+    if vocab.dtype == np.uint8:
+        out = rows ^ np.packbits(rng.random((q, vocab.shape[1] * 8)) < sigma, axis=1)
+        out[fresh] = rng.integers(0, 256, (int(fresh.sum()), vocab.shape[1]), dtype=np.uint8)
+        return np.ascontiguousarray(out)
+    out = rows + rng.standard_normal(rows.shape, dtype=np.float32) * np.float32(sigma)
+    out[fresh] = vocab_surf(int(fresh.sum()), seed=seed + 104729, dim=vocab.shape[1]) if fresh.any() else out[fresh]
+    out /= np.linalg.norm(out, axis=1, keepdims=True)
+    return np.ascontiguousarray(out, dtype=np.float32)
+
+
 def write_dictionary_text(path, vocab, first_id=1):
     """The reference's dictionary text format (VWDictionary.cpp:1655,1680-1688): '%d ' then '%f ' per value."""
     with open(path, "w") as f:

@@ -1,0 +1,142 @@
+"""GPU parity: exact 2-NN / self distances of the HIP engine (through the C-ABI) vs the CPU oracle.
+Bit-exact for Hamming (ids and distances) AND for squared L2 (the kernel reproduces rtflann's summation order)."""
+import numpy as np
+import pytest
+
+from rtabmap_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(dtype, dim, **kw):
+    import rtabmap_amd
+    return rtabmap_amd.Engine(dtype, dim, **kw)
+
+
+def _check(eng, oracle, vocab, ids, queries, removed=None):
+    got_ids, got_d = eng.knn2(queries)
+    idx, d = oracle.knn2_linear(vocab, queries, removed=removed)
+    exp_ids = np.where(idx >= 0, ids[np.maximum(idx, 0)], 0).astype(np.int32)
+    np.testing.assert_array_equal(got_ids, exp_ids)
+    np.testing.assert_array_equal(got_d, d)          # bit-exact, also for float32 L2
+
+
+@pytest.mark.parametrize("n,q", [(49000, 500), (5000, 77), (257, 64), (3, 5)])
+def test_knn2_surf_bit_exact(oracle, n, q):
+    v = synth.vocab_surf(n)
+    qs = synth.queries_surf(v, q)
+    ids = np.arange(1, n + 1, dtype=np.int32)
+    eng = _engine("f32", 64)
+    eng.vocab_append(v, ids)
+    _check(eng, oracle, v, ids, qs)
+    eng.close()
+
+
+@pytest.mark.parametrize("n,q", [(200000, 500), (4097, 130)])
+def test_knn2_orb_bit_exact(oracle, n, q):
+    v = synth.vocab_orb(n)
+    qs = synth.queries_orb(v, q)
+    ids = np.arange(1, n + 1, dtype=np.int32)
+    eng = _engine("u8", 32)
+    eng.vocab_append(v, ids)
+    _check(eng, oracle, v, ids, qs)
+    eng.close()
+
+
+def test_knn2_ties_lowest_row_wins(oracle):
+    rng = np.random.default_rng(5)
+    v = rng.integers(0, 4, (6000, 32), dtype=np.uint8)
+    v[3000:] = v[:3000]                                  # every row has an exact duplicate later on
+    q = rng.integers(0, 4, (200, 32), dtype=np.uint8)
+    ids = np.arange(1, 6001, dtype=np.int32)
+    eng = _engine("u8", 32)
+    eng.vocab_append(v, ids)
+    got_ids, got_d = eng.knn2(q)
+    _check(eng, oracle, v, ids, q)
+    assert (got_d[:, 0] == got_d[:, 1]).any() and (got_ids[:, 0] <= 3000).all()
+    # float duplicates as well
+    vf = synth.vocab_surf(2000)
+    vf[1000:] = vf[:1000]
+    qf = synth.queries_surf(vf, 100)
+    e2 = _engine("f32", 64)
+    e2.vocab_append(vf, np.arange(1, 2001, dtype=np.int32))
+    _check(e2, oracle, vf, np.arange(1, 2001, dtype=np.int32), qf)
+    eng.close(); e2.close()
+
+
+def test_knn2_tombstones_append_rebuild(oracle):
+    v = synth.vocab_orb(3000, seed=3)
+    q = synth.queries_orb(v, 150, seed=4)
+    ids = np.arange(10, 3010, dtype=np.int32)
+    eng = _engine("u8", 32)
+    eng.vocab_append(v[:2000], ids[:2000])
+    eng.vocab_append(v[2000:], ids[2000:])               # second append keeps the order
+    rng = np.random.default_rng(9)
+    dead = np.sort(rng.choice(3000, 700, replace=False))
+    eng.vocab_remove(ids[dead])
+    removed = np.zeros(3000, np.uint8); removed[dead] = 1
+    _check(eng, oracle, v, ids, q, removed=removed)      # tombstoned rows are never returned
+    assert eng.vocab_count() == (3000, 2300)
+    # rows re-added with LOWER ids than existing ones go to the end (append branch) ...
+    extra = synth.vocab_orb(50, seed=12)
+    extra_ids = np.arange(1, 51, dtype=np.int32) * 0 + np.arange(3100, 3150, dtype=np.int32)
+    low_ids = np.array([3, 5, 7], np.int32)
+    eng.vocab_append(extra, extra_ids)
+    eng.vocab_append(v[dead[:3]], low_ids)
+    allv = np.vstack([v, extra, v[dead[:3]]])
+    allids = np.concatenate([ids, extra_ids, low_ids])
+    rem = np.concatenate([removed, np.zeros(53, np.uint8)])
+    _check(eng, oracle, allv, allids, q, removed=rem)
+    # ... and a rebuild compacts and orders by ascending word id (VWDictionary.cpp:636-660)
+    eng.vocab_rebuild()
+    keep = rem == 0
+    order = np.argsort(allids[keep], kind="stable")
+    rv, rids = allv[keep][order], allids[keep][order]
+    rows, got_ids = eng.vocab_read(0, rv.shape[0])
+    np.testing.assert_array_equal(got_ids, rids)
+    np.testing.assert_array_equal(rows, rv)
+    _check(eng, oracle, rv, rids, q)
+    eng.close()
+
+
+def test_knn2_tiny_and_empty_vocabulary(oracle):
+    eng = _engine("f32", 64)
+    q = synth.queries_surf(synth.vocab_surf(10), 7)
+    ids, d = eng.knn2(q)
+    assert (ids == 0).all() and (d == -1).all()
+    v = synth.vocab_surf(1, seed=1)
+    eng.vocab_append(v, np.array([42], np.int32))
+    ids, d = eng.knn2(q)
+    assert (ids[:, 0] == 42).all() and (ids[:, 1] == 0).all() and (d[:, 1] == -1).all()
+    np.testing.assert_array_equal(d[:, 0], oracle.dist_matrix(q, v)[:, 0])
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype,dim", [("f32", 128), ("f32", 61), ("f32", 3), ("u8", 64), ("u8", 16), ("u8", 8), ("u8", 24)])
+def test_knn2_other_descriptor_sizes(oracle, dtype, dim):
+    rng = np.random.default_rng(dim)
+    if dtype == "f32":
+        v = rng.standard_normal((1500, dim)).astype(np.float32)
+        q = rng.standard_normal((70, dim)).astype(np.float32)
+    else:
+        v = rng.integers(0, 256, (1500, dim), dtype=np.uint8)
+        q = rng.integers(0, 256, (70, dim), dtype=np.uint8)
+    ids = np.arange(1, 1501, dtype=np.int32)
+    eng = _engine(dtype, dim)
+    eng.vocab_append(v, ids)
+    _check(eng, oracle, v, ids, q)
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", ["surf", "orb"])
+def test_selfdist_bit_exact_and_symmetric(oracle, kind):
+    if kind == "surf":
+        q = synth.queries_surf(synth.vocab_surf(1000), 300)
+        eng = _engine("f32", 64)
+    else:
+        q = synth.queries_orb(synth.vocab_orb(1000), 300)
+        eng = _engine("u8", 32)
+    D = eng.selfdist(q)
+    np.testing.assert_array_equal(D, oracle.dist_matrix(q, q))
+    np.testing.assert_array_equal(D, D.T)
+    eng.close()
