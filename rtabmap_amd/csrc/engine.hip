@@ -72,21 +72,6 @@ int download(lcd_engine* h, void* dst, const void* d_src, size_t bytes, PinBuf& 
     return LCD_OK;
 }
 
-__global__ void rows_to_wslot_kernel(const int32_t* __restrict__ word, const int32_t* __restrict__ knn_row,
-                                     const int32_t* __restrict__ knn_word, const int32_t* __restrict__ row_wslot, int q,
-                                     int32_t* __restrict__ out_wslot) {
-    // word slot of each descriptor's chosen EXISTING word: it is one of its two indexed neighbours
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= q) return;
-    const int32_t w = word[i];
-    int32_t ws = -1;
-    if (w > 0) {
-        if (knn_word[2 * i] == w) ws = row_wslot[knn_row[2 * i]];
-        else if (knn_word[2 * i + 1] == w) ws = row_wslot[knn_row[2 * i + 1]];
-    }
-    out_wslot[i] = ws;
-}
-
 }  // namespace
 
 extern "C" {
@@ -132,7 +117,7 @@ void lcd_destroy(lcd_engine* h) {
     DevBuf* all[] = {&h->vocab, &h->row_id, &h->row_wslot, &h->vocab_alt, &h->row_id_alt, &h->row_wslot_alt, &h->d_queries,
                      &h->d_partial, &h->d_knn_row, &h->d_knn_word, &h->d_knn_wslot, &h->d_knn_dist, &h->d_selfdist, &h->d_out_word,
                      &h->d_out_wslot, &h->d_n_new, &h->d_tmp_i32, &h->d_extra_rows, &h->d_extra_id, &h->d_extra_word,
-                     &h->d_extra_dist, &h->d_extra_row, &h->d_like, &h->d_slots};
+                     &h->d_extra_dist, &h->d_extra_row, &h->d_like, &h->d_slots, &h->d_bits};
     for (DevBuf* d : all) d->release(&h->bytes_device);
     h->h_in.release(); h->h_out.release(); h->h_out2.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -313,7 +298,7 @@ int lcd_selfdist(lcd_engine* h, const void* queries, int q, float* out_qxq) {
 }
 
 // device part of addNewWords: d_queries already holds q descriptors.  Leaves d_out_word[q], d_n_new[1].
-static int quantize_dev(lcd_engine* h, const void* d_desc, int q, int flags, float nndr, int32_t* d_out_word) {
+static int quantize_dev(lcd_engine* h, const void* d_desc, int q, int flags, float nndr, int32_t* d_out_word, int32_t* d_out_wslot = nullptr) {
     const int have_index = h->n_live >= 2 ? 1 : 0;                  // VWDictionary.cpp:1015
     int rc = run_knn2(h, d_desc, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), have_index ? h->n_rows : 0,
                       h->d_knn_row, h->d_knn_word, h->d_knn_dist);
@@ -321,13 +306,18 @@ static int quantize_dev(lcd_engine* h, const void* d_desc, int q, int flags, flo
     const bool incremental = (flags & LCD_Q_INCREMENTAL) != 0;
     const bool together = incremental && (flags & LCD_Q_NEW_WORDS_COMPARED);
     int ld = (q + 63) / 64 * 64;
+    const int bw = ld / 32;
     if (together) {
         LCD_HIP(h, dreserve(h, h->d_selfdist, (size_t)q * ld * 4));
-        LCD_HIP(h, launch_selfdist(h->dtype, h->kdim, d_desc, q, h->d_selfdist.as<float>(), ld, h->stream));
+        LCD_HIP(h, dreserve(h, h->d_bits, (size_t)q * bw * 4));
+        LCD_HIP(h, launch_selfdist(h->dtype, h->kdim, d_desc, q, h->d_selfdist.as<float>(), ld, h->stream, have_index,
+                                   h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), h->d_bits.as<uint32_t>(), bw));
     }
     const int rflags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0);
     LCD_HIP(h, launch_resolve(q, rflags, nndr, have_index, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
-                              together ? h->d_selfdist.as<float>() : nullptr, ld, d_out_word, h->d_n_new.as<int32_t>(), h->stream));
+                              together ? h->d_selfdist.as<float>() : nullptr, ld, together ? h->d_bits.as<uint32_t>() : nullptr, bw,
+                              d_out_word, h->d_n_new.as<int32_t>(), h->stream, h->d_knn_row.as<int32_t>(), h->row_wslot.as<int32_t>(),
+                              d_out_wslot));
     return LCD_OK;
 }
 
@@ -518,12 +508,9 @@ int lcd_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, fl
     if (sig_id != 0 && t.sig_slot.count(sig_id)) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
     const int64_t slots_after = t.n_slots + (sig_id != 0 ? 1 : 0);
     if (d_likelihood && likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
-    int rc = quantize_dev(h, d_descriptors, q, flags, nndr_ratio, d_word_ids);
-    if (rc) return rc;
     LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
-    rows_to_wslot_kernel<<<(q + 255) / 256, 256, 0, h->stream>>>(d_word_ids, h->d_knn_row.as<int32_t>(), h->d_knn_word.as<int32_t>(),
-                                                                h->row_wslot.as<int32_t>(), q, h->d_out_wslot.as<int32_t>());
-    LCD_HIP(h, hipGetLastError());
+    int rc = quantize_dev(h, d_descriptors, q, flags, nndr_ratio, d_word_ids, h->d_out_wslot.as<int32_t>());
+    if (rc) return rc;
     if (sig_id != 0) LCD_HIP(h, t.register_dev(sig_id, h->d_out_wslot.as<int32_t>(), q, q, N));
     else LCD_HIP(h, t.query_dev(h->d_out_wslot.as<int32_t>(), q, N));
     if (d_likelihood) { LCD_HIP(h, t.score(d_likelihood)); h->likelihood_launches += 1; }

@@ -275,10 +275,26 @@ __global__ __launch_bounds__(BLOCK) void knn2_merge_kernel(int dtype, const uint
 }
 
 // ------------------------------------------------------------------------------------------------ self distances
-// out[r*ld + qi] = dist(query r, query qi): lane = qi (coalesced stores), wave walks rows r of the same matrix
+// out[r*ld + qi] = dist(query r, query qi): lane = qi (coalesced stores), each wave walks exactly 32 rows r of the
+// same matrix.  Optionally also emits, for the addNewWords resolution (resolve_kernels.hip), the candidate bit matrix
+//     bits[qi][r / 32] bit (r & 31)  =  dist(r, qi) < thr(qi)
+// where thr(qi) is the distance of qi's second indexed neighbour (+inf when it has fewer than two): a same-frame new
+// word r can only enter the two best candidates of descriptor qi if it is strictly closer than that neighbour
+// (std::multimap keeps the indexed entries first on equal keys, VWDictionary.cpp:1091-1160).
+constexpr int SD_ROWS = 32 * WAVES;
+
+__device__ __forceinline__ float cand_threshold(int have_index, const int32_t* __restrict__ knn_word,
+                                                const float* __restrict__ knn_dist, int qi) {
+    if (!have_index) return __int_as_float(0x7f800000);
+    const bool v0 = knn_dist[2 * qi] >= 0.0f && knn_word[2 * qi] != 0;
+    const bool v1 = knn_dist[2 * qi + 1] >= 0.0f && knn_word[2 * qi + 1] != 0;
+    return (v0 && v1) ? knn_dist[2 * qi + 1] : __int_as_float(0x7f800000);
+}
+
 template <int DIM>
-__global__ __launch_bounds__(BLOCK) void selfdist_l2_kernel(const float* __restrict__ queries, int nq, int rows_per_block,
-                                                            float* __restrict__ out, int ld) {
+__global__ __launch_bounds__(BLOCK) void selfdist_l2_kernel(const float* __restrict__ queries, int nq, float* __restrict__ out, int ld,
+                                                            int have_index, const int32_t* __restrict__ knn_word,
+                                                            const float* __restrict__ knn_dist, uint32_t* __restrict__ bits, int bw) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qi = blockIdx.y * 64 + lane;
@@ -290,38 +306,55 @@ __global__ __launch_bounds__(BLOCK) void selfdist_l2_kernel(const float* __restr
         const float4 v = src[g];
         q[4 * g + 0] = v.x; q[4 * g + 1] = v.y; q[4 * g + 2] = v.z; q[4 * g + 3] = v.w;
     }
-    const int row0 = blockIdx.x * rows_per_block;
-    const Strip s = wave_strip(row0, min(row0 + rows_per_block, nq), wave);
-    for (int r = s.begin; r < s.end; ++r) {
+    const float thr = bits ? cand_threshold(have_index, knn_word, knn_dist, qsrc) : 0.0f;
+    const int r0 = blockIdx.x * SD_ROWS + wave * 32;
+    const int r1 = min(r0 + 32, nq);
+    uint32_t word = 0;
+    for (int r = r0; r < r1; ++r) {
         const float d = l2_ref<DIM>(queries + (size_t)r * DIM, q);
         if (qi < nq) out[(size_t)r * ld + qi] = d;
+        word |= (d < thr ? 1u : 0u) << (r - r0);
     }
+    if (bits && qi < nq && r0 < nq) bits[(size_t)qi * bw + (r0 >> 5)] = word;
 }
-__global__ __launch_bounds__(BLOCK) void selfdist_l2_dyn_kernel(const float* __restrict__ queries, int nq, int dim, int rows_per_block,
-                                                                float* __restrict__ out, int ld) {
+__global__ __launch_bounds__(BLOCK) void selfdist_l2_dyn_kernel(const float* __restrict__ queries, int nq, int dim, float* __restrict__ out,
+                                                                int ld, int have_index, const int32_t* __restrict__ knn_word,
+                                                                const float* __restrict__ knn_dist, uint32_t* __restrict__ bits, int bw) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qi = blockIdx.y * 64 + lane;
-    const float* q = queries + (size_t)(qi < nq ? qi : nq - 1) * dim;
-    const int row0 = blockIdx.x * rows_per_block;
-    const Strip s = wave_strip(row0, min(row0 + rows_per_block, nq), wave);
-    for (int r = s.begin; r < s.end; ++r) {
+    const int qsrc = qi < nq ? qi : nq - 1;
+    const float* q = queries + (size_t)qsrc * dim;
+    const float thr = bits ? cand_threshold(have_index, knn_word, knn_dist, qsrc) : 0.0f;
+    const int r0 = blockIdx.x * SD_ROWS + wave * 32;
+    const int r1 = min(r0 + 32, nq);
+    uint32_t word = 0;
+    for (int r = r0; r < r1; ++r) {
         const float d = l2_ref_dyn(queries + (size_t)r * dim, q, dim);
         if (qi < nq) out[(size_t)r * ld + qi] = d;
+        word |= (d < thr ? 1u : 0u) << (r - r0);
     }
+    if (bits && qi < nq && r0 < nq) bits[(size_t)qi * bw + (r0 >> 5)] = word;
 }
 __global__ __launch_bounds__(BLOCK) void selfdist_hamming_dyn_kernel(const uint32_t* __restrict__ queries, int nq, int w32,
-                                                                     int rows_per_block, float* __restrict__ out, int ld) {
+                                                                     float* __restrict__ out, int ld, int have_index,
+                                                                     const int32_t* __restrict__ knn_word,
+                                                                     const float* __restrict__ knn_dist, uint32_t* __restrict__ bits, int bw) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qi = blockIdx.y * 64 + lane;
-    const uint32_t* q = queries + (size_t)(qi < nq ? qi : nq - 1) * w32;
-    const int row0 = blockIdx.x * rows_per_block;
-    const Strip s = wave_strip(row0, min(row0 + rows_per_block, nq), wave);
-    for (int r = s.begin; r < s.end; ++r) {
-        const uint32_t d = hamming_dyn(queries + (size_t)r * w32, q, w32);
-        if (qi < nq) out[(size_t)r * ld + qi] = (float)d;
+    const int qsrc = qi < nq ? qi : nq - 1;
+    const uint32_t* q = queries + (size_t)qsrc * w32;
+    const float thr = bits ? cand_threshold(have_index, knn_word, knn_dist, qsrc) : 0.0f;
+    const int r0 = blockIdx.x * SD_ROWS + wave * 32;
+    const int r1 = min(r0 + 32, nq);
+    uint32_t word = 0;
+    for (int r = r0; r < r1; ++r) {
+        const float d = (float)hamming_dyn(queries + (size_t)r * w32, q, w32);
+        if (qi < nq) out[(size_t)r * ld + qi] = d;
+        word |= (d < thr ? 1u : 0u) << (r - r0);
     }
+    if (bits && qi < nq && r0 < nq) bits[(size_t)qi * bw + (r0 >> 5)] = word;
 }
 
 }  // namespace
@@ -378,17 +411,18 @@ hipError_t launch_knn2_merge(int dtype, const KnnPlan& p, const uint64_t* partia
     return hipGetLastError();
 }
 
-hipError_t launch_selfdist(int dtype, int dim, const void* queries, int q, float* out, int ld, hipStream_t s) {
+hipError_t launch_selfdist(int dtype, int dim, const void* queries, int q, float* out, int ld, hipStream_t s, int have_index,
+                           const int32_t* knn_word, const float* knn_dist, uint32_t* bits, int bw) {
     if (q == 0) return hipSuccess;
-    const int rpb = 16;
-    dim3 grid((q + rpb - 1) / rpb, (q + 63) / 64), block(BLOCK);
+    dim3 grid((q + SD_ROWS - 1) / SD_ROWS, (q + 63) / 64), block(BLOCK);
     if (dtype == 0) {
         const float* qq = (const float*)queries;
-        if (dim == 64) selfdist_l2_kernel<64><<<grid, block, 0, s>>>(qq, q, rpb, out, ld);
-        else if (dim == 128) selfdist_l2_kernel<128><<<grid, block, 0, s>>>(qq, q, rpb, out, ld);
-        else selfdist_l2_dyn_kernel<<<grid, block, 0, s>>>(qq, q, dim, rpb, out, ld);
+        if (dim == 64) selfdist_l2_kernel<64><<<grid, block, 0, s>>>(qq, q, out, ld, have_index, knn_word, knn_dist, bits, bw);
+        else if (dim == 128) selfdist_l2_kernel<128><<<grid, block, 0, s>>>(qq, q, out, ld, have_index, knn_word, knn_dist, bits, bw);
+        else selfdist_l2_dyn_kernel<<<grid, block, 0, s>>>(qq, q, dim, out, ld, have_index, knn_word, knn_dist, bits, bw);
     } else {
-        selfdist_hamming_dyn_kernel<<<grid, block, 0, s>>>((const uint32_t*)queries, q, dim / 4, rpb, out, ld);
+        selfdist_hamming_dyn_kernel<<<grid, block, 0, s>>>((const uint32_t*)queries, q, dim / 4, out, ld, have_index, knn_word, knn_dist,
+                                                           bits, bw);
     }
     return hipGetLastError();
 }

@@ -27,16 +27,21 @@ hipError_t launch_knn2_partial(int dtype, int dim, const void* vocab, const int3
 // Merge the partial keys: out_row[q*2] (row or -1), out_word[q*2] (row_id[row] or 0), out_dist[q*2] (float, -1 = none)
 hipError_t launch_knn2_merge(int dtype, const KnnPlan& p, const uint64_t* partial, const int32_t* row_id,
                              int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s);
-// q x q distances of a block against itself; out[i*ld + j], ld >= q.
-hipError_t launch_selfdist(int dtype, int dim, const void* queries, int q, float* out, int ld, hipStream_t s);
+// q x q distances of a block against itself; out[i*ld + j], ld >= q.  When `bits` is given ([q][bw] words, bw >= ceil(q/32))
+// also the candidate bit matrix of the addNewWords resolution: bit j of row i = dist(j, i) < (distance of i's second
+// indexed neighbour, +inf if it has none) -- see knn2_kernels.hip.
+hipError_t launch_selfdist(int dtype, int dim, const void* queries, int q, float* out, int ld, hipStream_t s, int have_index = 0,
+                           const int32_t* knn_word = nullptr, const float* knn_dist = nullptr, uint32_t* bits = nullptr, int bw = 0);
 
 // The addNewWords decision loop (VWDictionary.cpp:1089-1219) for a whole frame, on the device.
 //   knn_word/knn_dist [q*2] indexed candidates (word 0 / dist < 0 = none); have_index = vocabulary had >= 2 live rows
-//   selfdist [q x ld] (may be NULL when !(flags & NEW_WORDS_COMPARED))
+//   selfdist [q x ld] and cand_bits [q x bw] from launch_selfdist (may be NULL when !(flags & NEW_WORDS_COMPARED))
 //   out_word[q]: > 0 existing word, < 0: -(k+1) for the k-th new word, 0: no entry (fixed dictionary, no candidate)
 //   out_n_new[1]
 hipError_t launch_resolve(int q, int flags, float nndr, int have_index, const int32_t* knn_word, const float* knn_dist,
-                          const float* selfdist, int ld, int32_t* out_word, int32_t* out_n_new, hipStream_t s);
+                          const float* selfdist, int ld, const uint32_t* cand_bits, int bw, int32_t* out_word, int32_t* out_n_new,
+                          hipStream_t s, const int32_t* knn_row = nullptr, const int32_t* row_wslot = nullptr,
+                          int32_t* out_wslot = nullptr);   // out_wslot[q]: postings key of the chosen existing word (-1: none/new)
 // findNN merge (VWDictionary.cpp:1457-1542): indexed candidates + candidates among the not-indexed words + NNDR.
 hipError_t launch_findnn_resolve(int q, int flags, float nndr, int have_index, const int32_t* knn_word,
                                  const float* knn_dist, int have_extra, const int32_t* extra_word,

@@ -7,10 +7,15 @@
 //     isNew[i] = f_i(isNew[0..i-1]),
 // solved here by Jacobi sweeps over all descriptors in parallel until a sweep changes nothing.  Entry i is final
 // once entries < i are, so after t sweeps the first t entries are exact and a sweep without change is the unique
-// solution -- i.e. exactly the reference's sequential result (worst case q sweeps, in practice 2-4).
+// solution -- i.e. exactly the reference's sequential result (worst case q sweeps, in practice 1-3).
 //
-// One workgroup (1024 threads) handles the frame: the data is tiny (q x q distances from L2) and the work is
-// latency-, not throughput-bound; the frame's heavy part is knn2_kernels.hip.
+// A sweep is cheap because a same-frame new word j can only matter for descriptor i when it is strictly closer than
+// i's second indexed neighbour: the self-distance kernel already reduced that test to one bit per (i, j)
+// (cand_bits, knn2_kernels.hip).  A sweep is then "AND my bit row with the current new-word mask (LDS)" and a distance
+// is fetched only for the surviving bits -- none at all for most descriptors of a mature vocabulary.
+//
+// One workgroup (1024 threads) handles the frame: the data is tiny and the work is latency-, not throughput-bound;
+// the frame's heavy part is knn2_kernels.hip.
 #include "lcd_kernels.h"
 
 namespace lcd {
@@ -31,11 +36,11 @@ __device__ __forceinline__ void cand_push(Cand& c0, Cand& c1, int& n, float d, i
     ++n;
 }
 
-// candidates of descriptor i given the current guess of which earlier descriptors are new words
-__device__ __forceinline__ void gather_candidates(int i, int flags, int have_index, const int32_t* __restrict__ knn_word,
+// candidates of descriptor i given the current guess (bit mask in LDS) of which earlier descriptors are new words
+__device__ __forceinline__ void gather_candidates(int i, bool together, int have_index, const int32_t* __restrict__ knn_word,
                                                   const float* __restrict__ knn_dist, const float* __restrict__ selfdist,
-                                                  int ld, const unsigned char* __restrict__ is_new, int jmax,
-                                                  Cand& c0, Cand& c1, int& n) {
+                                                  int ld, const uint32_t* __restrict__ cand_bits, int bw,
+                                                  const uint32_t* new_mask, Cand& c0, Cand& c1, int& n) {
     n = 0;
     c0.d = 0.f; c0.id = 0; c1.d = 0.f; c1.id = 0;
     if (have_index) {
@@ -46,12 +51,17 @@ __device__ __forceinline__ void gather_candidates(int i, int flags, int have_ind
             if (d >= 0.0f && id != 0) cand_push(c0, c1, n, d, id); else break;
         }
     }
-    if (flags & LCD_Q_NEW_WORDS_COMPARED) {
-        // exact 2-NN (1-NN when only one exists) among the new words created before i, lowest j on ties (:1140-1160)
+    if (together) {
+        // exact 2-NN (1-NN when only one exists) among the new words created before i, lowest j on ties (:1140-1160),
+        // restricted to the ones that can reach the two best candidates (cand_bits)
         uint64_t b = KEY_NONE, s = KEY_NONE;
-        for (int j = 0; j < jmax; ++j) {             // jmax is wave-uniform (>= i for every lane), is_new[j] uniform
-            if (!is_new[j]) continue;
-            if (j < i) {
+        const int wlast = i >> 5;
+        for (int w = 0; w <= wlast; ++w) {
+            uint32_t m = cand_bits[(size_t)i * bw + w] & new_mask[w];
+            if (w == wlast) m &= (1u << (i & 31)) - 1u;           // only j < i
+            while (m) {
+                const int j = (w << 5) + __builtin_ctz(m);
+                m &= m - 1;
                 const uint64_t k = ((uint64_t)__float_as_uint(selfdist[(size_t)j * ld + i]) << 32) | (uint32_t)j;
                 const uint64_t hi = b > k ? b : k;
                 b = b < k ? b : k;
@@ -63,77 +73,94 @@ __device__ __forceinline__ void gather_candidates(int i, int flags, int have_ind
     }
 }
 
+// rank of descriptor j among the new words = number of mask bits below j (word prefix sums in LDS)
+__device__ __forceinline__ int new_rank(const uint32_t* mask, const uint32_t* prefix, int j) {
+    return (int)(prefix[j >> 5] + __popc(mask[j >> 5] & ((1u << (j & 31)) - 1u)));
+}
+
 __global__ __launch_bounds__(RBLOCK) void resolve_kernel(int q, int flags, float nndr, int have_index,
                                                          const int32_t* __restrict__ knn_word, const float* __restrict__ knn_dist,
                                                          const float* __restrict__ selfdist, int ld,
-                                                         int32_t* __restrict__ out_word, int32_t* __restrict__ out_n_new) {
-    extern __shared__ unsigned char smem[];          // is_new[qpad] (current guess) | is_new[qpad] (next guess)
-    const int qpad = (q + 15) / 16 * 16;
-    unsigned char* is_new = smem;
-    unsigned char* is_next = smem + qpad;
+                                                         const uint32_t* __restrict__ cand_bits, int bw,
+                                                         int32_t* __restrict__ out_word, int32_t* __restrict__ out_n_new,
+                                                         const int32_t* __restrict__ knn_row, const int32_t* __restrict__ row_wslot,
+                                                         int32_t* __restrict__ out_wslot) {
+    extern __shared__ uint32_t rs_smem[];             // mask_a[mw] | mask_b[mw] | prefix[mw + 1]
+    const int mw = (q + 63) / 64 * 2;                 // mask words (a whole number of waves)
+    uint32_t* mask_cur = rs_smem;
+    uint32_t* mask_next = rs_smem + mw;
+    uint32_t* prefix = rs_smem + 2 * mw;
     __shared__ int s_changed;
-    __shared__ int s_scan[RBLOCK];
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const bool incremental = (flags & LCD_Q_INCREMENTAL) != 0;
+    const bool together = incremental && (flags & LCD_Q_NEW_WORDS_COMPARED) && cand_bits != nullptr;
+    const int qpad = mw * 32;
 
-    // sweep 0: decide from the indexed candidates only
-    for (int i = tid; i < q; i += RBLOCK) {
-        Cand c0, c1; int n;
-        gather_candidates(i, flags & ~LCD_Q_NEW_WORDS_COMPARED, have_index, knn_word, knn_dist, selfdist, ld, is_new, 0, c0, c1, n);
-        const bool reject = incremental && (n < 2 || c0.d > nndr * c1.d);
-        is_new[i] = reject ? 1 : 0;
+    // sweep 0: decide from the indexed candidates only; out_word holds the current winner of every descriptor
+    for (int i = tid; i < qpad; i += RBLOCK) {
+        bool reject = false;
+        if (i < q) {
+            Cand c0, c1; int n;
+            gather_candidates(i, false, have_index, knn_word, knn_dist, selfdist, ld, cand_bits, bw, mask_cur, c0, c1, n);
+            reject = incremental && (n < 2 || c0.d > nndr * c1.d);
+            out_word[i] = n > 0 ? c0.id : 0;
+        }
+        const unsigned long long bal = __ballot(reject);
+        if (lane == 0) { mask_cur[(i >> 5)] = (uint32_t)bal; mask_cur[(i >> 5) + 1] = (uint32_t)(bal >> 32); }
     }
     __syncthreads();
-    if (incremental && (flags & LCD_Q_NEW_WORDS_COMPARED)) {
+    if (together) {
         for (int sweep = 0; sweep <= q; ++sweep) {
             if (tid == 0) s_changed = 0;
             __syncthreads();
-            for (int i = tid; i < q; i += RBLOCK) {
-                const int jmax = min(q, ((i | 63) + 1));   // same bound for the whole wave
-                Cand c0, c1; int n;
-                gather_candidates(i, flags, have_index, knn_word, knn_dist, selfdist, ld, is_new, jmax, c0, c1, n);
-                const unsigned char v = (n < 2 || c0.d > nndr * c1.d) ? 1 : 0;
-                is_next[i] = v;
-                if (v != is_new[i]) s_changed = 1;
+            for (int i = tid; i < qpad; i += RBLOCK) {
+                bool reject = false;
+                if (i < q) {
+                    Cand c0, c1; int n;
+                    gather_candidates(i, true, have_index, knn_word, knn_dist, selfdist, ld, cand_bits, bw, mask_cur, c0, c1, n);
+                    reject = n < 2 || c0.d > nndr * c1.d;
+                    out_word[i] = n > 0 ? c0.id : 0;
+                }
+                const unsigned long long bal = __ballot(reject);
+                if (lane == 0) {
+                    const uint32_t lo = (uint32_t)bal, hi = (uint32_t)(bal >> 32);
+                    mask_next[i >> 5] = lo; mask_next[(i >> 5) + 1] = hi;
+                    if (lo != mask_cur[i >> 5] || hi != mask_cur[(i >> 5) + 1]) s_changed = 1;
+                }
             }
             __syncthreads();
-            unsigned char* t = is_new; is_new = is_next; is_next = t;
+            uint32_t* t = mask_cur; mask_cur = mask_next; mask_next = t;
             if (!s_changed) break;
             __syncthreads();
         }
     }
-    // ranks of the new words in descriptor order (getNextId() is called in that order, :1185)
-    int base = 0;
-    for (int i0 = 0; i0 < q; i0 += RBLOCK) {
-        const int i = i0 + tid;
-        const int v = (i < q && is_new[i]) ? 1 : 0;
-        s_scan[tid] = v;
-        __syncthreads();
-        for (int off = 1; off < RBLOCK; off <<= 1) {
-            const int t = tid >= off ? s_scan[tid - off] : 0;
-            __syncthreads();
-            s_scan[tid] += t;
-            __syncthreads();
-        }
-        if (i < q && v) out_word[i] = -(base + s_scan[tid] - 1 + 1);
-        const int total = s_scan[RBLOCK - 1];
-        __syncthreads();
-        base += total;
+    // word prefix sums of the final mask -> ranks of the new words in descriptor order (getNextId() order, :1185)
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int w = 0; w < mw; ++w) { prefix[w] = run; run += __popc(mask_cur[w]); }
+        prefix[mw] = run;
+        out_n_new[0] = (int32_t)run;
     }
-    if (tid == 0) out_n_new[0] = base;
     __syncthreads();
-    // accepted descriptors: nearest candidate; a candidate that is itself a new word (-(j+1)) maps to that word's rank
     for (int i = tid; i < q; i += RBLOCK) {
-        if (is_new[i]) continue;
-        const int jmax = min(q, ((i | 63) + 1));
-        Cand c0, c1; int n;
-        gather_candidates(i, flags, have_index, knn_word, knn_dist, selfdist, ld, is_new, jmax, c0, c1, n);
-        int w = 0;
-        if (n > 0) {
-            w = c0.id;
-            if (w < 0) w = out_word[-w - 1];          // already final: written above
+        const bool is_new = (mask_cur[i >> 5] >> (i & 31)) & 1u;
+        int w;
+        if (is_new) w = -(new_rank(mask_cur, prefix, i) + 1);
+        else {
+            w = out_word[i];                           // winner of the last sweep (own entry: no cross-thread read)
+            if (w < 0) w = -(new_rank(mask_cur, prefix, -w - 1) + 1);   // matched a same-frame new word
         }
-        out_word[i] = w;                              // fixed dictionary without candidate: 0 ("no entry", :1211-1218)
+        out_word[i] = w;                               // fixed dictionary without candidate: 0 ("no entry", :1211-1218)
+        if (out_wslot) {
+            // postings key of the chosen EXISTING word: it is one of the descriptor's two indexed neighbours
+            int32_t ws = -1;
+            if (w > 0) {
+                if (knn_word[2 * i] == w) ws = row_wslot[knn_row[2 * i]];
+                else if (knn_word[2 * i + 1] == w) ws = row_wslot[knn_row[2 * i + 1]];
+            }
+            out_wslot[i] = ws;
+        }
     }
 }
 
@@ -187,11 +214,13 @@ __global__ void tombstone_kernel(int32_t* __restrict__ row_id, const int32_t* __
 }  // namespace
 
 hipError_t launch_resolve(int q, int flags, float nndr, int have_index, const int32_t* knn_word, const float* knn_dist,
-                          const float* selfdist, int ld, int32_t* out_word, int32_t* out_n_new, hipStream_t s) {
+                          const float* selfdist, int ld, const uint32_t* cand_bits, int bw, int32_t* out_word, int32_t* out_n_new,
+                          hipStream_t s, const int32_t* knn_row, const int32_t* row_wslot, int32_t* out_wslot) {
     if (q <= 0) return hipSuccess;
     if (q > 8 * RBLOCK) return hipErrorInvalidValue;
-    resolve_kernel<<<1, RBLOCK, (size_t)((q + 15) / 16 * 16) * 2, s>>>(q, flags, nndr, have_index, knn_word, knn_dist, selfdist, ld,
-                                                                  out_word, out_n_new);
+    const int mw = (q + 63) / 64 * 2;
+    resolve_kernel<<<1, RBLOCK, (size_t)(3 * mw + 2) * 4, s>>>(q, flags, nndr, have_index, knn_word, knn_dist, selfdist, ld, cand_bits, bw,
+                                                            out_word, out_n_new, knn_row, row_wslot, out_wslot);
     return hipGetLastError();
 }
 

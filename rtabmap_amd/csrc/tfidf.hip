@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace lcd {
 namespace {
@@ -70,40 +71,67 @@ __global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(const int32_t* __
         keys[i] = w >= 0 ? (uint32_t)w : 0xFFFFFFFFu;
     }
     __syncthreads();
-    // bitonic sort, ascending
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P; i += FW_BLOCK) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const uint32_t a = keys[i], b = keys[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
-                }
+    if (P <= FW_BLOCK) {
+        // rank sort: every thread counts the keys that sort before its own (LDS broadcast reads, no barriers in the loop)
+        const uint32_t mine = tid < P ? keys[tid] : 0xFFFFFFFFu;
+        uint32_t rank = 0;
+        if (tid < P) {
+            for (int j = 0; j < P; ++j) {
+                const uint32_t k = keys[j];
+                rank += (k < mine || (k == mine && j < tid)) ? 1u : 0u;
             }
-            __syncthreads();
+        }
+        __syncthreads();
+        if (tid < P) keys[rank] = mine;
+        __syncthreads();
+    } else {
+        // bitonic sort, ascending
+        for (int k = 2; k <= P; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < P; i += FW_BLOCK) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const uint32_t a = keys[i], b = keys[ixj];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
-    // heads of runs of equal valid keys
-    for (int i = tid; i < P; i += FW_BLOCK) {
-        const uint32_t k = keys[i];
-        pos[i] = (k != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
-    }
-    __syncthreads();
-    // count of valid keys (they sort first)
+    // heads of runs of equal valid keys -> compact list heads[u] = position of the u-th unique word.
+    // Per 64-key group: ballot of the head flags, group popcounts scanned by one thread, ranks by popcount below the lane.
+    uint32_t* heads = scratch + FW_BLOCK + 1;   // [P]
+    uint32_t* grp = scratch;                    // [P / 64 + 1] exclusive prefix of heads per group
     __shared__ uint32_t s_valid;
     if (tid == 0) s_valid = 0;
     __syncthreads();
-    for (int i = tid; i < P; i += FW_BLOCK)
-        if (keys[i] != 0xFFFFFFFFu && (i + 1 == P || keys[i + 1] == 0xFFFFFFFFu)) s_valid = (uint32_t)i + 1;
+    for (int i0 = 0; i0 < P; i0 += FW_BLOCK) {
+        const int i = i0 + tid;
+        bool head = false;
+        if (i < P) {
+            const uint32_t k = keys[i];
+            head = k != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != k);
+            if (k != 0xFFFFFFFFu && (i + 1 == P || keys[i + 1] == 0xFFFFFFFFu)) s_valid = (uint32_t)i + 1;   // valid keys sort first
+        }
+        const unsigned long long bal = __ballot(head);
+        if ((tid & 63) == 0 && i < P) grp[i >> 6] = (uint32_t)__popcll(bal);
+        if (i < P) pos[i] = (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        const int ng = (P + 63) / 64;
+        for (int g = 0; g < ng; ++g) { const uint32_t c = grp[g]; grp[g] = run; run += c; }
+        grp[ng] = run;
+    }
     __syncthreads();
     const uint32_t V = s_valid;
-    // exclusive scan of the head flags: a head at i gets unique index pos[i]; heads[u] = position of the u-th unique word
-    const uint32_t U = block_exclusive_scan(pos, P, scratch);
-    uint32_t* heads = scratch + FW_BLOCK + 1;   // [P]
+    const uint32_t U = grp[(P + 63) / 64];
     for (int i = tid; i < P; i += FW_BLOCK) {
         const uint32_t k = keys[i];
-        if (k != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != k)) heads[pos[i]] = (uint32_t)i;
+        if (k != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != k)) heads[grp[i >> 6] + pos[i]] = (uint32_t)i;
     }
     __syncthreads();
     const uint32_t base = do_register ? ne_counter[0] : 0u;
@@ -142,7 +170,8 @@ __global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(const int32_t* __
 
 // ---------------------------------------------------------------------------------------------- sealed buckets
 // grid = (sealed live buckets, G word groups).  LDS: acc[R] i64 | ni[R] | start[Wg] | scan[Wg + 1] | idf[Wg] | scratch
-__global__ __launch_bounds__(SC_BLOCK) void score_sealed_kernel(const BucketDev* __restrict__ tab, const int32_t* __restrict__ list, int G,
+template <int SCB>
+__global__ __launch_bounds__(SCB) void score_sealed_kernel(const BucketDev* __restrict__ tab, const int32_t* __restrict__ list, int G,
                                                                 int wg_cap, const uint32_t* __restrict__ q_w,
                                                                 const float* __restrict__ q_idf, const uint32_t* __restrict__ q_meta,
                                                                 const uint32_t* __restrict__ slot_ni,
@@ -153,7 +182,7 @@ __global__ __launch_bounds__(SC_BLOCK) void score_sealed_kernel(const BucketDev*
     uint32_t* s_start = s_ni + TF_R;                                // [wg_cap]
     uint32_t* s_scan = s_start + wg_cap;                            // [wg_cap + 1]
     float* s_idf = (float*)(s_scan + wg_cap + 1);                   // [wg_cap]
-    uint32_t* scratch = (uint32_t*)(s_idf + wg_cap);                // [SC_BLOCK + 1]
+    uint32_t* scratch = (uint32_t*)(s_idf + wg_cap);                // [SCB + 1]
     const int tid = threadIdx.x;
     const int b = list[blockIdx.x];
     const int g = blockIdx.y;
@@ -164,8 +193,8 @@ __global__ __launch_bounds__(SC_BLOCK) void score_sealed_kernel(const BucketDev*
     const int U = (int)q_meta[0];
     int Ug = U > g ? (U - g + G - 1) / G : 0;
     if (Ug > wg_cap) Ug = wg_cap;                                   // cannot happen: wg_cap is sized from the word count
-    for (int i = tid; i < TF_R; i += SC_BLOCK) { acc[i] = 0ull; s_ni[i] = slot_ni[first_slot + i]; }
-    for (int k = tid; k < Ug; k += SC_BLOCK) {
+    for (int i = tid; i < TF_R; i += SCB) { acc[i] = 0ull; s_ni[i] = slot_ni[first_slot + i]; }
+    for (int k = tid; k < Ug; k += SCB) {
         const int u = g + k * G;
         const uint32_t w = q_w[u];
         const float idf = q_idf[u];
@@ -180,7 +209,7 @@ __global__ __launch_bounds__(SC_BLOCK) void score_sealed_kernel(const BucketDev*
     const uint32_t T = block_exclusive_scan(s_scan, Ug + 1, scratch);   // s_scan[Ug] == T afterwards
     // flattened, load-balanced walk over all postings of this bucket that belong to the group's words
     int k = 0;
-    for (uint32_t t = tid; t < T; t += SC_BLOCK) {
+    for (uint32_t t = tid; t < T; t += SCB) {
         while (s_scan[k + 1] <= t) ++k;
         const uint32_t e = ent[s_start[k] + (t - s_scan[k])];
         const uint32_t sl = e >> TF_CNT_BITS;
@@ -191,7 +220,7 @@ __global__ __launch_bounds__(SC_BLOCK) void score_sealed_kernel(const BucketDev*
         }
     }
     __syncthreads();
-    for (int i = tid; i < TF_R; i += SC_BLOCK) {
+    for (int i = tid; i < TF_R; i += SCB) {
         const unsigned long long v = acc[i];
         if (v != 0ull) {
             if (G == 1) lfix[first_slot + i] = v;
@@ -204,20 +233,28 @@ __global__ __launch_bounds__(SC_BLOCK) void score_sealed_kernel(const BucketDev*
 // arrival-order log scanned against the frame's sorted unique words (binary search in LDS)
 __global__ __launch_bounds__(SC_BLOCK) void score_open_kernel(const uint32_t* __restrict__ coo_w, const uint32_t* __restrict__ coo_pc,
                                                               const uint32_t* __restrict__ ne_counter, long long first_slot,
-                                                              int w_cap, const uint32_t* __restrict__ q_w,
+                                                              int w_cap, int bitmap_words, const uint32_t* __restrict__ q_w,
                                                               const float* __restrict__ q_idf, const uint32_t* __restrict__ q_meta,
                                                               const uint32_t* __restrict__ slot_ni,
                                                               unsigned long long* __restrict__ lfix) {
     extern __shared__ uint32_t so_smem[];
-    uint32_t* s_w = so_smem;                    // [w_cap]
+    uint32_t* s_w = so_smem;                    // [w_cap] sorted unique words of the frame
     float* s_idf = (float*)(so_smem + w_cap);   // [w_cap]
+    uint32_t* s_bits = so_smem + 2 * w_cap;     // [bitmap_words] membership bitmap over word slots (0 words = not used)
     int U = (int)q_meta[0];
     if (U > w_cap) U = w_cap;
-    for (int i = threadIdx.x; i < U; i += SC_BLOCK) { s_w[i] = q_w[i]; s_idf[i] = q_idf[i]; }
+    for (int i = threadIdx.x; i < bitmap_words; i += SC_BLOCK) s_bits[i] = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < U; i += SC_BLOCK) {
+        const uint32_t w = q_w[i];
+        s_w[i] = w; s_idf[i] = q_idf[i];
+        if ((w >> 5) < (uint32_t)bitmap_words) atomicOr(&s_bits[w >> 5], 1u << (w & 31));
+    }
     __syncthreads();
     const uint32_t ne = ne_counter[0];
     for (uint32_t e = blockIdx.x * SC_BLOCK + threadIdx.x; e < ne; e += gridDim.x * SC_BLOCK) {
         const uint32_t w = coo_w[e];
+        if ((w >> 5) < (uint32_t)bitmap_words && !((s_bits[w >> 5] >> (w & 31)) & 1u)) continue;   // not a word of the frame
         int lo = 0, hi = U;                     // first index with s_w[idx] >= w
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_w[mid] < w) lo = mid + 1; else hi = mid; }
         if (lo < U && s_w[lo] == w) {
@@ -235,9 +272,14 @@ __global__ __launch_bounds__(SC_BLOCK) void score_open_kernel(const uint32_t* __
     }
 }
 
-__global__ void finalize_kernel(const long long* __restrict__ lfix, long long n, float* __restrict__ out) {
+// fixed point -> float, and the accumulator is left zeroed for the next frame (no separate memset launch)
+__global__ void finalize_kernel(long long* __restrict__ lfix, long long n, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (float)((double)lfix[i] * (1.0 / 281474976710656.0));   // 2^-48
+    if (i < n) {
+        const long long v = lfix[i];
+        out[i] = (float)((double)v * (1.0 / 281474976710656.0));   // 2^-48
+        if (v != 0) lfix[i] = 0;
+    }
 }
 __global__ void gather_f32_kernel(const float* __restrict__ dense, const long long* __restrict__ slots, int n, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -518,29 +560,39 @@ hipError_t Tfidf::query_dev(const int32_t* d_wslots, int n, float N) {
     return run_frame_words(*this, d_wslots, n, false, 0, 0, 0, N);
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
 hipError_t Tfidf::score(float* d_likelihood) {
     if (n_slots == 0) return hipSuccess;
     TF_TRY(upload_buckets());
-    TF_TRY(hipMemsetAsync(lfix.p, 0, (size_t)n_slots * 8, stream));
+    // lfix is all zero here: zero-initialised on growth and re-zeroed by the previous frame's finalize_kernel
     const int wcap_all = std::max(q_n_ub, 1);
     if (n_list > 0) {
-        int G = (768 + n_list - 1) / n_list;
+        static const int scb = env_int("LCD_SC_BLOCK", 1024);
+        static const int gforce = env_int("LCD_SC_G", 0);
+        int G = gforce > 0 ? gforce : (256 + n_list - 1) / n_list;     // aim at >= one workgroup per CU
         G = std::max(1, std::min(G, 8));
         const int wg_cap = (wcap_all + G - 1) / G;
-        const size_t shmem = (size_t)TF_R * 8 + (size_t)TF_R * 4 + ((size_t)wg_cap * 3 + 1 + SC_BLOCK + 1 + 4) * 4;
-        score_sealed_kernel<<<dim3(n_list, G), SC_BLOCK, shmem, stream>>>(bkt_tab.as<BucketDev>(), bkt_list.as<int32_t>(), G, wg_cap,
-                                                                         q_w.as<uint32_t>(), q_idf.as<float>(), q_meta.as<uint32_t>(),
-                                                                         slot_ni.as<uint32_t>(), lfix.as<unsigned long long>());
+        const size_t shmem = (size_t)TF_R * 8 + (size_t)TF_R * 4 + ((size_t)wg_cap * 3 + 1 + scb + 1 + 4) * 4;
+        const dim3 grid(n_list, G);
+#define LCD_SCORE_SEALED(B) score_sealed_kernel<B><<<grid, B, shmem, stream>>>(bkt_tab.as<BucketDev>(), bkt_list.as<int32_t>(), G, wg_cap, \
+            q_w.as<uint32_t>(), q_idf.as<float>(), q_meta.as<uint32_t>(), slot_ni.as<uint32_t>(), lfix.as<unsigned long long>())
+        if (scb == 256) LCD_SCORE_SEALED(256); else if (scb == 512) LCD_SCORE_SEALED(512); else LCD_SCORE_SEALED(1024);
+#undef LCD_SCORE_SEALED
         TF_TRY(hipGetLastError());
     }
     if (!buckets.empty() && !buckets.back().sealed && buckets.back().ub_entries > 0) {
         const int bi = (int)buckets.size() - 1;
         const Bucket& b = buckets[bi];
-        int blocks = (int)std::min<int64_t>((b.ub_entries + SC_BLOCK - 1) / SC_BLOCK, 128);
-        score_open_kernel<<<blocks, SC_BLOCK, (size_t)wcap_all * 8, stream>>>(b.coo_w.as<uint32_t>(), b.coo_pc.as<uint32_t>(),
-                                                                             bkt_ne.as<uint32_t>() + bi, (long long)bi * TF_R, wcap_all,
-                                                                             q_w.as<uint32_t>(), q_idf.as<float>(), q_meta.as<uint32_t>(),
-                                                                             slot_ni.as<uint32_t>(), lfix.as<unsigned long long>());
+        int blocks = (int)std::min<int64_t>((b.ub_entries + SC_BLOCK - 1) / SC_BLOCK, 256);
+        int bitmap_words = (n_wslots + 31) / 32;
+        if ((size_t)bitmap_words * 4 + (size_t)wcap_all * 8 > 96 * 1024) bitmap_words = 0;   // huge vocabularies: binary search only
+        score_open_kernel<<<blocks, SC_BLOCK, (size_t)wcap_all * 8 + (size_t)bitmap_words * 4, stream>>>(
+            b.coo_w.as<uint32_t>(), b.coo_pc.as<uint32_t>(), bkt_ne.as<uint32_t>() + bi, (long long)bi * TF_R, wcap_all, bitmap_words,
+            q_w.as<uint32_t>(), q_idf.as<float>(), q_meta.as<uint32_t>(), slot_ni.as<uint32_t>(), lfix.as<unsigned long long>());
         TF_TRY(hipGetLastError());
     }
     finalize_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, stream>>>(lfix.as<long long>(), (long long)n_slots, d_likelihood);

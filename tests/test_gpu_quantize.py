@@ -45,7 +45,7 @@ def test_quantize_stream_matches_oracle(oracle, kind, together):
         exp = m.vwd.add_new_words(desc, t + 1)
         mapped = np.where(got < 0, last_id - got, got)          # -(k+1) -> last_id + k + 1
         assert mapped.tolist() == exp, "frame %d" % t
-        assert n_new == sum(1 for e in exp if e > last_id)
+        assert n_new == len({e for e in exp if e > last_id})
         total_new += n_new
         for i, w in enumerate(exp):
             if w > last_id and w not in words:
