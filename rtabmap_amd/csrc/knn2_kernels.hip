@@ -275,13 +275,14 @@ __global__ __launch_bounds__(BLOCK) void knn2_merge_kernel(int dtype, const uint
 }
 
 // ------------------------------------------------------------------------------------------------ self distances
-// out[r*ld + qi] = dist(query r, query qi): lane = qi (coalesced stores), each wave walks exactly 32 rows r of the
-// same matrix.  Optionally also emits, for the addNewWords resolution (resolve_kernels.hip), the candidate bit matrix
+// out[r*ld + qi] = dist(query r, query qi): lane = qi (coalesced stores), each wave walks exactly 8 rows r of the
+// same matrix (one byte of the bit row below).  Optionally also emits, for the addNewWords resolution (resolve_kernels.hip), the candidate bit matrix
 //     bits[qi][r / 32] bit (r & 31)  =  dist(r, qi) < thr(qi)
 // where thr(qi) is the distance of qi's second indexed neighbour (+inf when it has fewer than two): a same-frame new
 // word r can only enter the two best candidates of descriptor qi if it is strictly closer than that neighbour
 // (std::multimap keeps the indexed entries first on equal keys, VWDictionary.cpp:1091-1160).
-constexpr int SD_ROWS = 32 * WAVES;
+constexpr int SD_WROWS = 8;                  // rows per wave = bits per stored byte
+constexpr int SD_ROWS = SD_WROWS * WAVES;
 
 __device__ __forceinline__ float cand_threshold(int have_index, const int32_t* __restrict__ knn_word,
                                                 const float* __restrict__ knn_dist, int qi) {
@@ -307,15 +308,15 @@ __global__ __launch_bounds__(BLOCK) void selfdist_l2_kernel(const float* __restr
         q[4 * g + 0] = v.x; q[4 * g + 1] = v.y; q[4 * g + 2] = v.z; q[4 * g + 3] = v.w;
     }
     const float thr = bits ? cand_threshold(have_index, knn_word, knn_dist, qsrc) : 0.0f;
-    const int r0 = blockIdx.x * SD_ROWS + wave * 32;
-    const int r1 = min(r0 + 32, nq);
+    const int r0 = blockIdx.x * SD_ROWS + wave * SD_WROWS;
+    const int r1 = min(r0 + SD_WROWS, nq);
     uint32_t word = 0;
     for (int r = r0; r < r1; ++r) {
         const float d = l2_ref<DIM>(queries + (size_t)r * DIM, q);
         if (qi < nq) out[(size_t)r * ld + qi] = d;
         word |= (d < thr ? 1u : 0u) << (r - r0);
     }
-    if (bits && qi < nq && r0 < nq) bits[(size_t)qi * bw + (r0 >> 5)] = word;
+    if (bits && qi < nq && r0 < nq) reinterpret_cast<unsigned char*>(bits)[(size_t)qi * bw * 4 + (r0 >> 3)] = (unsigned char)word;
 }
 __global__ __launch_bounds__(BLOCK) void selfdist_l2_dyn_kernel(const float* __restrict__ queries, int nq, int dim, float* __restrict__ out,
                                                                 int ld, int have_index, const int32_t* __restrict__ knn_word,
@@ -326,15 +327,15 @@ __global__ __launch_bounds__(BLOCK) void selfdist_l2_dyn_kernel(const float* __r
     const int qsrc = qi < nq ? qi : nq - 1;
     const float* q = queries + (size_t)qsrc * dim;
     const float thr = bits ? cand_threshold(have_index, knn_word, knn_dist, qsrc) : 0.0f;
-    const int r0 = blockIdx.x * SD_ROWS + wave * 32;
-    const int r1 = min(r0 + 32, nq);
+    const int r0 = blockIdx.x * SD_ROWS + wave * SD_WROWS;
+    const int r1 = min(r0 + SD_WROWS, nq);
     uint32_t word = 0;
     for (int r = r0; r < r1; ++r) {
         const float d = l2_ref_dyn(queries + (size_t)r * dim, q, dim);
         if (qi < nq) out[(size_t)r * ld + qi] = d;
         word |= (d < thr ? 1u : 0u) << (r - r0);
     }
-    if (bits && qi < nq && r0 < nq) bits[(size_t)qi * bw + (r0 >> 5)] = word;
+    if (bits && qi < nq && r0 < nq) reinterpret_cast<unsigned char*>(bits)[(size_t)qi * bw * 4 + (r0 >> 3)] = (unsigned char)word;
 }
 __global__ __launch_bounds__(BLOCK) void selfdist_hamming_dyn_kernel(const uint32_t* __restrict__ queries, int nq, int w32,
                                                                      float* __restrict__ out, int ld, int have_index,
@@ -346,15 +347,15 @@ __global__ __launch_bounds__(BLOCK) void selfdist_hamming_dyn_kernel(const uint3
     const int qsrc = qi < nq ? qi : nq - 1;
     const uint32_t* q = queries + (size_t)qsrc * w32;
     const float thr = bits ? cand_threshold(have_index, knn_word, knn_dist, qsrc) : 0.0f;
-    const int r0 = blockIdx.x * SD_ROWS + wave * 32;
-    const int r1 = min(r0 + 32, nq);
+    const int r0 = blockIdx.x * SD_ROWS + wave * SD_WROWS;
+    const int r1 = min(r0 + SD_WROWS, nq);
     uint32_t word = 0;
     for (int r = r0; r < r1; ++r) {
         const float d = (float)hamming_dyn(queries + (size_t)r * w32, q, w32);
         if (qi < nq) out[(size_t)r * ld + qi] = d;
         word |= (d < thr ? 1u : 0u) << (r - r0);
     }
-    if (bits && qi < nq && r0 < nq) bits[(size_t)qi * bw + (r0 >> 5)] = word;
+    if (bits && qi < nq && r0 < nq) reinterpret_cast<unsigned char*>(bits)[(size_t)qi * bw * 4 + (r0 >> 3)] = (unsigned char)word;
 }
 
 }  // namespace

@@ -4,7 +4,7 @@
 // (Memory.cpp:4955) and the scoring loop of Memory::computeLikelihood (Memory.cpp:2215-2291).
 //
 // Data layout in HBM ("blocked inverted index"):
-//   * a signature gets a SLOT (dense, arrival order); slots are grouped in BUCKETS of TF_R = 1024 consecutive slots;
+//   * a signature gets a SLOT (dense, arrival order); slots are grouped in BUCKETS of TF_R = 256 consecutive slots;
 //   * a word gets a WSLOT (dense); nw[wslot] = number of live signatures referencing the word;
 //   * every bucket keeps the arrival-order log of its postings (coo_w[e] = wslot, coo_pc[e] = slot_local << 22 | count),
 //     which is also the forward index used to retire a signature;
@@ -14,7 +14,7 @@
 //   * ni[slot] (0 = retired) is read once per workgroup into LDS.
 // Scoring a frame = for every sealed bucket, one workgroup (x G word groups) walks the segments of the frame's words
 // flattened into one load-balanced index space (heavy-tailed posting lists cannot starve a wave), accumulates into an
-// LDS array of 1024 fixed-point (Q15.48, int64) sums with ds_add_u64 and flushes each slot once.  The open bucket is
+// LDS array of TF_R fixed-point (Q15.48, int64) sums with ds_add_u64 and flushes each slot once.  The open bucket is
 // scanned in arrival order against the frame's sorted word list.  Integer accumulation makes the result independent
 // of the order of the adds (bit-reproducible run to run and across any sharding of the words over GPUs); each term
 // is computed in fp32 exactly as the reference does, (nwi * log10(N/nw)) / ni.
@@ -29,7 +29,7 @@
 
 namespace lcd {
 
-constexpr int TF_R = 1024;                 // slots per bucket
+constexpr int TF_R = 256;                  // slots per bucket
 constexpr int TF_CNT_BITS = 22;            // posting = slot_local << 22 | count
 constexpr uint32_t TF_CNT_MASK = (1u << TF_CNT_BITS) - 1;
 constexpr int TF_MAX_WORDS = 8192;         // words of one signature / one query frame handled by the 1-workgroup kernels
@@ -64,6 +64,8 @@ struct Tfidf {
     DevBuf slot_sig, slot_ni, slot_begin, slot_cnt;
     // per wslot
     DevBuf nw;
+    DevBuf idf_tab;                      // {stamp, idf bits} of the words of the current frame (valid iff stamp matches)
+    uint32_t stamp = 0;
     // per bucket
     DevBuf bkt_tab, bkt_ne, bkt_list;
     std::vector<Bucket> buckets;

@@ -51,96 +51,64 @@ __device__ __forceinline__ unsigned long long to_fixed(float t) {
 }
 
 // ---------------------------------------------------------------------------------------------- frame words
-// One workgroup: sort the frame's word slots, reduce to (unique word, count), optionally append them to the open
-// bucket as the postings of signature `slot` (nw += 1 each), and leave word/count/idf lists for the scoring kernels.
-__global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(const int32_t* __restrict__ wslots, int n, int P, int do_register,
+// One workgroup: reduce the frame's word slots to (unique word, count) with an LDS hash table (linear probing, atomicCAS),
+// optionally append them to the open bucket as the postings of signature `slot` (nw += 1 each), and leave the
+// word / count / idf lists plus the per-word idf table (idf_tab[w] = {stamp, idf}) for the scoring kernels.
+// The list order is whatever the table yields: nothing downstream depends on it (integer accumulation).
+__global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(const int32_t* __restrict__ wslots, int n, int H, int do_register,
                                                                int32_t sig_id, long long slot, uint32_t slot_local, uint32_t ni, float N,
-                                                               uint32_t* __restrict__ nw, uint32_t* __restrict__ coo_w,
+                                                               uint32_t stamp, uint32_t* __restrict__ nw, uint32_t* __restrict__ coo_w,
                                                                uint32_t* __restrict__ coo_pc, uint32_t* __restrict__ ne_counter,
                                                                int32_t* __restrict__ slot_sig, uint32_t* __restrict__ slot_ni,
                                                                uint32_t* __restrict__ slot_begin, uint32_t* __restrict__ slot_cnt,
                                                                uint32_t* __restrict__ q_w, uint32_t* __restrict__ q_cnt,
-                                                               float* __restrict__ q_idf, uint32_t* __restrict__ q_meta) {
+                                                               float* __restrict__ q_idf, uint32_t* __restrict__ q_meta,
+                                                               uint2* __restrict__ idf_tab) {
     extern __shared__ uint32_t fw_smem[];
-    uint32_t* keys = fw_smem;            // [P]
-    uint32_t* pos = fw_smem + P;         // [P] head flags -> head positions
-    uint32_t* scratch = pos + P;         // [FW_BLOCK + 1]
+    uint32_t* tkey = fw_smem;            // [H] 0xFFFFFFFF = empty
+    uint32_t* tcnt = fw_smem + H;        // [H]
+    uint32_t* grp = tcnt + H;            // [H / 64 + 1]
     const int tid = threadIdx.x;
-    for (int i = tid; i < P; i += FW_BLOCK) {
-        const int32_t w = i < n ? wslots[i] : -1;
-        keys[i] = w >= 0 ? (uint32_t)w : 0xFFFFFFFFu;
-    }
+    for (int i = tid; i < H; i += FW_BLOCK) { tkey[i] = 0xFFFFFFFFu; tcnt[i] = 0u; }
     __syncthreads();
-    if (P <= FW_BLOCK) {
-        // rank sort: every thread counts the keys that sort before its own (LDS broadcast reads, no barriers in the loop)
-        const uint32_t mine = tid < P ? keys[tid] : 0xFFFFFFFFu;
-        uint32_t rank = 0;
-        if (tid < P) {
-            for (int j = 0; j < P; ++j) {
-                const uint32_t k = keys[j];
-                rank += (k < mine || (k == mine && j < tid)) ? 1u : 0u;
-            }
-        }
-        __syncthreads();
-        if (tid < P) keys[rank] = mine;
-        __syncthreads();
-    } else {
-        // bitonic sort, ascending
-        for (int k = 2; k <= P; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < P; i += FW_BLOCK) {
-                    const int ixj = i ^ j;
-                    if (ixj > i) {
-                        const uint32_t a = keys[i], b = keys[ixj];
-                        const bool up = (i & k) == 0;
-                        if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
-                    }
-                }
-                __syncthreads();
-            }
+    for (int i = tid; i < n; i += FW_BLOCK) {
+        const int32_t ws = wslots[i];
+        if (ws < 0) continue;
+        const uint32_t w = (uint32_t)ws;
+        uint32_t h = (w * 2654435761u) & (uint32_t)(H - 1);
+        for (;;) {
+            const uint32_t old = atomicCAS(&tkey[h], 0xFFFFFFFFu, w);
+            if (old == 0xFFFFFFFFu || old == w) { atomicAdd(&tcnt[h], 1u); break; }
+            h = (h + 1) & (uint32_t)(H - 1);
         }
     }
-    // heads of runs of equal valid keys -> compact list heads[u] = position of the u-th unique word.
-    // Per 64-key group: ballot of the head flags, group popcounts scanned by one thread, ranks by popcount below the lane.
-    uint32_t* heads = scratch + FW_BLOCK + 1;   // [P]
-    uint32_t* grp = scratch;                    // [P / 64 + 1] exclusive prefix of heads per group
-    __shared__ uint32_t s_valid;
-    if (tid == 0) s_valid = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < P; i0 += FW_BLOCK) {
+    // compact the occupied table entries: ballot per 64-entry group, group offsets scanned by one thread
+    const int ng = H / 64;
+    for (int i0 = 0; i0 < H; i0 += FW_BLOCK) {
         const int i = i0 + tid;
-        bool head = false;
-        if (i < P) {
-            const uint32_t k = keys[i];
-            head = k != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != k);
-            if (k != 0xFFFFFFFFu && (i + 1 == P || keys[i + 1] == 0xFFFFFFFFu)) s_valid = (uint32_t)i + 1;   // valid keys sort first
-        }
-        const unsigned long long bal = __ballot(head);
-        if ((tid & 63) == 0 && i < P) grp[i >> 6] = (uint32_t)__popcll(bal);
-        if (i < P) pos[i] = (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
+        const bool occ = i < H && tkey[i] != 0xFFFFFFFFu;
+        const unsigned long long bal = __ballot(occ);
+        if ((tid & 63) == 0 && i < H) grp[i >> 6] = (uint32_t)__popcll(bal);
     }
     __syncthreads();
     if (tid == 0) {
         uint32_t run = 0;
-        const int ng = (P + 63) / 64;
         for (int g = 0; g < ng; ++g) { const uint32_t c = grp[g]; grp[g] = run; run += c; }
         grp[ng] = run;
     }
     __syncthreads();
-    const uint32_t V = s_valid;
-    const uint32_t U = grp[(P + 63) / 64];
-    for (int i = tid; i < P; i += FW_BLOCK) {
-        const uint32_t k = keys[i];
-        if (k != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != k)) heads[grp[i >> 6] + pos[i]] = (uint32_t)i;
-    }
-    __syncthreads();
+    const uint32_t U = grp[ng];
     const uint32_t base = do_register ? ne_counter[0] : 0u;
     __syncthreads();
-    for (uint32_t u = tid; u < U; u += FW_BLOCK) {
-        const uint32_t i = heads[u];
-        const uint32_t end = (u + 1 < U) ? heads[u + 1] : V;
-        const uint32_t w = keys[i];
-        uint32_t cnt = end - i;
+    for (int i0 = 0; i0 < H; i0 += FW_BLOCK) {
+        const int i = i0 + tid;
+        const bool occ = i < H && tkey[i] != 0xFFFFFFFFu;
+        const unsigned long long bal = __ballot(occ);
+        if (!occ) continue;
+        const uint32_t u = grp[i >> 6] + (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
+        const uint32_t w = tkey[i];
+        uint32_t cnt = tcnt[i];
         if (cnt > TF_CNT_MASK) cnt = TF_CNT_MASK;
         uint32_t nwv;
         if (do_register) {
@@ -150,11 +118,12 @@ __global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(const int32_t* __
         } else {
             nwv = nw[w];
         }
-        q_w[u] = w;
-        q_cnt[u] = cnt;
         float idf = 0.0f;
         if (N > 0.0f && nwv > 0u) idf = log10f(__fdiv_rn(N, (float)nwv));   // Memory.cpp:2264-2266
+        q_w[u] = w;
+        q_cnt[u] = cnt;
         q_idf[u] = idf;
+        idf_tab[w] = make_uint2(stamp, __float_as_uint(idf));
     }
     if (tid == 0) {
         q_meta[0] = U;
@@ -230,45 +199,55 @@ __global__ __launch_bounds__(SCB) void score_sealed_kernel(const BucketDev* __re
 }
 
 // ---------------------------------------------------------------------------------------------- open bucket
-// arrival-order log scanned against the frame's sorted unique words (binary search in LDS)
+// The arrival-order log of the bucket that is still filling (<= TF_R signatures) is scanned once: a word-slot bitmap in
+// LDS rejects the postings of words the frame does not contain, the survivors fetch idf from idf_tab.  The log is
+// slot-major, so the postings a workgroup sees belong to a handful of consecutive signatures: they are summed in a
+// small LDS window first and only the window is flushed with global atomics.
+constexpr int OPEN_WIN = 64;
 __global__ __launch_bounds__(SC_BLOCK) void score_open_kernel(const uint32_t* __restrict__ coo_w, const uint32_t* __restrict__ coo_pc,
                                                               const uint32_t* __restrict__ ne_counter, long long first_slot,
-                                                              int w_cap, int bitmap_words, const uint32_t* __restrict__ q_w,
-                                                              const float* __restrict__ q_idf, const uint32_t* __restrict__ q_meta,
+                                                              int bitmap_words, uint32_t stamp, const uint32_t* __restrict__ q_w,
+                                                              const uint32_t* __restrict__ q_meta, const uint2* __restrict__ idf_tab,
                                                               const uint32_t* __restrict__ slot_ni,
                                                               unsigned long long* __restrict__ lfix) {
     extern __shared__ uint32_t so_smem[];
-    uint32_t* s_w = so_smem;                    // [w_cap] sorted unique words of the frame
-    float* s_idf = (float*)(so_smem + w_cap);   // [w_cap]
-    uint32_t* s_bits = so_smem + 2 * w_cap;     // [bitmap_words] membership bitmap over word slots (0 words = not used)
-    int U = (int)q_meta[0];
-    if (U > w_cap) U = w_cap;
+    uint32_t* s_bits = so_smem;                 // [bitmap_words] membership bitmap over word slots (0 words = not used)
+    __shared__ unsigned long long s_win[OPEN_WIN];
+    __shared__ uint32_t s_win0;
+    const uint32_t ne = ne_counter[0];
+    const uint32_t per = (ne + gridDim.x - 1) / gridDim.x;          // contiguous chunk of the log per workgroup
+    const uint32_t e0 = min(blockIdx.x * per, ne), e1 = min(e0 + per, ne);
+    if (e0 >= e1) return;
+    const int U = (int)q_meta[0];
     for (int i = threadIdx.x; i < bitmap_words; i += SC_BLOCK) s_bits[i] = 0u;
+    if (threadIdx.x < OPEN_WIN) s_win[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) s_win0 = coo_pc[e0] >> TF_CNT_BITS;      // slot_local of the chunk's first posting
     __syncthreads();
     for (int i = threadIdx.x; i < U; i += SC_BLOCK) {
         const uint32_t w = q_w[i];
-        s_w[i] = w; s_idf[i] = q_idf[i];
         if ((w >> 5) < (uint32_t)bitmap_words) atomicOr(&s_bits[w >> 5], 1u << (w & 31));
     }
     __syncthreads();
-    const uint32_t ne = ne_counter[0];
-    for (uint32_t e = blockIdx.x * SC_BLOCK + threadIdx.x; e < ne; e += gridDim.x * SC_BLOCK) {
+    const uint32_t win0 = s_win0;
+    for (uint32_t e = e0 + threadIdx.x; e < e1; e += SC_BLOCK) {
         const uint32_t w = coo_w[e];
         if ((w >> 5) < (uint32_t)bitmap_words && !((s_bits[w >> 5] >> (w & 31)) & 1u)) continue;   // not a word of the frame
-        int lo = 0, hi = U;                     // first index with s_w[idx] >= w
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_w[mid] < w) lo = mid + 1; else hi = mid; }
-        if (lo < U && s_w[lo] == w) {
-            const float idf = s_idf[lo];
-            if (idf != 0.0f) {
-                const uint32_t pc = coo_pc[e];
-                const long long slot = first_slot + (pc >> TF_CNT_BITS);
-                const uint32_t ni = slot_ni[slot];
-                if (ni != 0u) {
-                    const float term = __fdiv_rn(__fmul_rn((float)(pc & TF_CNT_MASK), idf), (float)ni);
-                    atomicAdd(&lfix[slot], to_fixed(term));
-                }
-            }
-        }
+        const uint2 t = idf_tab[w];
+        if (t.x != stamp) continue;
+        const float idf = __uint_as_float(t.y);
+        if (idf == 0.0f) continue;                                   // "if(logNnw)" (Memory.cpp:2267)
+        const uint32_t pc = coo_pc[e];
+        const uint32_t sl = pc >> TF_CNT_BITS;
+        const uint32_t ni = slot_ni[first_slot + sl];
+        if (ni == 0u) continue;
+        const unsigned long long v = to_fixed(__fdiv_rn(__fmul_rn((float)(pc & TF_CNT_MASK), idf), (float)ni));
+        if (sl - win0 < (uint32_t)OPEN_WIN) atomicAdd(&s_win[sl - win0], v);
+        else atomicAdd(&lfix[first_slot + sl], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < OPEN_WIN) {
+        const unsigned long long v = s_win[threadIdx.x];
+        if (v != 0ull) atomicAdd(&lfix[first_slot + win0 + threadIdx.x], v);
     }
 }
 
@@ -418,7 +397,7 @@ void Tfidf::destroy() {
     for (Bucket& b : buckets) { b.coo_w.release(bytes_device); b.coo_pc.release(bytes_device); b.dir.release(bytes_device); b.ent.release(bytes_device); }
     buckets.clear();
     DevBuf* all[] = {&slot_sig, &slot_ni, &slot_begin, &slot_cnt, &nw, &bkt_tab, &bkt_ne, &bkt_list, &lfix, &q_w, &q_cnt, &q_idf,
-                     &q_meta, &tmp_cursor, &d_stage};
+                     &q_meta, &tmp_cursor, &d_stage, &idf_tab};
     for (DevBuf* d : all) d->release(bytes_device);
     h_stage.release();
 }
@@ -447,6 +426,7 @@ hipError_t Tfidf::wslot_of(int32_t word_id, int32_t* out) {
     const int32_t w = n_wslots++;
     word_wslot.emplace(word_id, w);
     TF_TRY(grow_zeroed(nw, (size_t)n_wslots * 4, stream, bytes_device));
+    TF_TRY(grow_zeroed(idf_tab, (size_t)n_wslots * 8, stream, bytes_device));
     *out = w;
     return hipSuccess;
 }
@@ -506,8 +486,8 @@ hipError_t Tfidf::seal(int bi) {
 }
 
 static hipError_t run_frame_words(Tfidf& t, const int32_t* d_wslots, int n, bool reg, int32_t sig_id, int64_t slot, int32_t ni, float N) {
-    const int P = next_pow2(std::max(n, 2));
-    const size_t shmem = ((size_t)P * 3 + FW_BLOCK + 1 + 8) * 4;
+    const int H = next_pow2(std::max(2 * n, 128));
+    const size_t shmem = ((size_t)H * 2 + H / 64 + 2) * 4;
     uint32_t* coo_w = nullptr; uint32_t* coo_pc = nullptr; uint32_t* ne = nullptr;
     if (reg) {
         const int bi = (int)(slot / TF_R);
@@ -515,12 +495,14 @@ static hipError_t run_frame_words(Tfidf& t, const int32_t* d_wslots, int n, bool
         coo_pc = t.buckets[bi].coo_pc.as<uint32_t>();
         ne = t.bkt_ne.as<uint32_t>() + bi;
     }
-    frame_words_kernel<<<1, FW_BLOCK, shmem, t.stream>>>(d_wslots, n, P, reg ? 1 : 0, sig_id, (long long)slot, (uint32_t)(slot % TF_R),
-                                                        (uint32_t)ni, N, t.nw.as<uint32_t>(), coo_w, coo_pc, ne,
+    t.stamp += 1;
+    if (t.stamp == 0) t.stamp = 1;
+    frame_words_kernel<<<1, FW_BLOCK, shmem, t.stream>>>(d_wslots, n, H, reg ? 1 : 0, sig_id, (long long)slot, (uint32_t)(slot % TF_R),
+                                                        (uint32_t)ni, N, t.stamp, t.nw.as<uint32_t>(), coo_w, coo_pc, ne,
                                                         t.slot_sig.as<int32_t>(), t.slot_ni.as<uint32_t>(),
                                                         t.slot_begin.as<uint32_t>(), t.slot_cnt.as<uint32_t>(),
                                                         t.q_w.as<uint32_t>(), t.q_cnt.as<uint32_t>(), t.q_idf.as<float>(),
-                                                        t.q_meta.as<uint32_t>());
+                                                        t.q_meta.as<uint32_t>(), t.idf_tab.as<uint2>());
     t.q_n_ub = n;
     return hipGetLastError();
 }
@@ -571,7 +553,7 @@ hipError_t Tfidf::score(float* d_likelihood) {
     // lfix is all zero here: zero-initialised on growth and re-zeroed by the previous frame's finalize_kernel
     const int wcap_all = std::max(q_n_ub, 1);
     if (n_list > 0) {
-        static const int scb = env_int("LCD_SC_BLOCK", 1024);
+        static const int scb = env_int("LCD_SC_BLOCK", 512);
         static const int gforce = env_int("LCD_SC_G", 0);
         int G = gforce > 0 ? gforce : (256 + n_list - 1) / n_list;     // aim at >= one workgroup per CU
         G = std::max(1, std::min(G, 8));
@@ -587,12 +569,12 @@ hipError_t Tfidf::score(float* d_likelihood) {
     if (!buckets.empty() && !buckets.back().sealed && buckets.back().ub_entries > 0) {
         const int bi = (int)buckets.size() - 1;
         const Bucket& b = buckets[bi];
-        int blocks = (int)std::min<int64_t>((b.ub_entries + SC_BLOCK - 1) / SC_BLOCK, 256);
+        int blocks = (int)std::min<int64_t>((b.ub_entries + 4 * SC_BLOCK - 1) / (4 * SC_BLOCK), 512);
         int bitmap_words = (n_wslots + 31) / 32;
-        if ((size_t)bitmap_words * 4 + (size_t)wcap_all * 8 > 96 * 1024) bitmap_words = 0;   // huge vocabularies: binary search only
-        score_open_kernel<<<blocks, SC_BLOCK, (size_t)wcap_all * 8 + (size_t)bitmap_words * 4, stream>>>(
-            b.coo_w.as<uint32_t>(), b.coo_pc.as<uint32_t>(), bkt_ne.as<uint32_t>() + bi, (long long)bi * TF_R, wcap_all, bitmap_words,
-            q_w.as<uint32_t>(), q_idf.as<float>(), q_meta.as<uint32_t>(), slot_ni.as<uint32_t>(), lfix.as<unsigned long long>());
+        if ((size_t)bitmap_words * 4 > 128 * 1024) bitmap_words = 0;   // > 1M word slots: idf_tab stamps alone decide
+        score_open_kernel<<<blocks, SC_BLOCK, (size_t)std::max(bitmap_words, 1) * 4, stream>>>(
+            b.coo_w.as<uint32_t>(), b.coo_pc.as<uint32_t>(), bkt_ne.as<uint32_t>() + bi, (long long)bi * TF_R, bitmap_words, stamp,
+            q_w.as<uint32_t>(), q_meta.as<uint32_t>(), idf_tab.as<uint2>(), slot_ni.as<uint32_t>(), lfix.as<unsigned long long>());
         TF_TRY(hipGetLastError());
     }
     finalize_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, stream>>>(lfix.as<long long>(), (long long)n_slots, d_likelihood);
