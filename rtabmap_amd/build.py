@@ -59,5 +59,30 @@ def build(force=False, verbose=False):
     return OUT
 
 
+HOST_OUT = os.path.join(HERE, "liblcd_host.so")
+HOST_SOURCES = ["VWDictionaryHip.cpp", "MemoryHip.cpp", "c_shim.cpp"]
+
+
+def build_host(force=False, verbose=False):
+    """The C++ host mirror of the reference's VWDictionary / Memory interface (rtabmap_amd/host), linked against the C-ABI."""
+    lib = build(force=force, verbose=verbose)
+    hdir = os.path.join(HERE, "host")
+    if not force and os.path.exists(HOST_OUT):
+        t = os.path.getmtime(HOST_OUT)
+        deps = [os.path.join(hdir, f) for f in os.listdir(hdir)] + [lib]
+        if all(os.path.getmtime(d) <= t for d in deps):
+            return HOST_OUT
+    cxx = shutil.which("g++") or "g++"
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_OUT] + [os.path.join(hdir, s) for s in HOST_SOURCES] + \
+          ["-L" + HERE, "-llcd_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("host library build failed:\n" + r.stdout)
+    return HOST_OUT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

@@ -176,16 +176,31 @@ __global__ __launch_bounds__(SCB) void score_sealed_kernel(const BucketDev* __re
     if (tid == 0) s_scan[Ug] = 0;
     __syncthreads();
     const uint32_t T = block_exclusive_scan(s_scan, Ug + 1, scratch);   // s_scan[Ug] == T afterwards
-    // flattened, load-balanced walk over all postings of this bucket that belong to the group's words
+    // flattened, load-balanced walk over all postings of this bucket that belong to the group's words.  Four postings per
+    // thread and trip: the four segment lookups (LDS) come first, then four independent global loads are in flight at once.
     int k = 0;
-    for (uint32_t t = tid; t < T; t += SCB) {
-        while (s_scan[k + 1] <= t) ++k;
-        const uint32_t e = ent[s_start[k] + (t - s_scan[k])];
-        const uint32_t sl = e >> TF_CNT_BITS;
-        const uint32_t ni = s_ni[sl];
-        if (ni != 0u) {                                              // "if(ni != 0)" (Memory.cpp:2275), 0 = retired slot
-            const float term = __fdiv_rn(__fmul_rn((float)(e & TF_CNT_MASK), s_idf[k]), (float)ni);
-            atomicAdd(&acc[sl], to_fixed(term));                     // ds_add_u64
+    for (uint32_t t0 = tid; t0 < T; t0 += 4 * SCB) {
+        uint32_t addr[4]; int kk[4]; uint32_t e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t t = t0 + u * SCB;
+            if (t < T) {
+                while (s_scan[k + 1] <= t) ++k;
+                addr[u] = s_start[k] + (t - s_scan[k]);
+            } else addr[u] = 0xFFFFFFFFu;
+            kk[u] = k;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = addr[u] != 0xFFFFFFFFu ? ent[addr[u]] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (addr[u] == 0xFFFFFFFFu) continue;
+            const uint32_t sl = e[u] >> TF_CNT_BITS;
+            const uint32_t ni = s_ni[sl];
+            if (ni != 0u) {                                          // "if(ni != 0)" (Memory.cpp:2275), 0 = retired slot
+                const float term = __fdiv_rn(__fmul_rn((float)(e[u] & TF_CNT_MASK), s_idf[kk[u]]), (float)ni);
+                atomicAdd(&acc[sl], to_fixed(term));                 // ds_add_u64
+            }
         }
     }
     __syncthreads();

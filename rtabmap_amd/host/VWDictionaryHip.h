@@ -1,0 +1,145 @@
+// VWDictionaryHip.h -- host-side mirror of rtabmap::VWDictionary / VisualWord over the C-ABI of include/lcd.h.
+//
+// The reference is compiled C++ (corelib/include/rtabmap/core/VWDictionary.h:46-156, VisualWord.h:38-64) and its
+// toolchain dependencies (OpenCV) are absent from this image, so this is a stand-alone C++ class with the SAME method
+// names, argument meaning and error behaviour as the reference class, on a minimal matrix type instead of cv::Mat.
+// It is what a maintainer's `Kp/NNStrategy = 5 (kNNBruteForceHIP)` branch inside the real VWDictionary.cpp would do
+// (see INTEGRATION.md): the host keeps the authoritative word / reference bookkeeping exactly like the reference, the
+// three hot spots call the device:
+//     update()        -> lcd_vocab_append | lcd_vocab_remove + lcd_vocab_rebuild      (VWDictionary.cpp:475-701)
+//     addNewWords()   -> lcd_quantize (2-NN + same-frame words + NNDR on the device)  (VWDictionary.cpp:913-1229)
+//     findNN()        -> lcd_find_nn                                                  (VWDictionary.cpp:1273-1552)
+// and Memory::computeLikelihood's TF-IDF branch (Memory.cpp:2215-2291) -> lcd_likelihood through computeLikelihood().
+// No search or scoring arithmetic is done on the host: if the engine cannot be created every call fails loudly.
+#pragma once
+#include <functional>
+#include <list>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/lcd.h"
+
+namespace rtabmap_amd {
+
+// cv::Mat stand-in: row-major, CV_32F (type 5) or CV_8U (type 0) single channel
+enum { MAT_8U = 0, MAT_32F = 5 };
+struct Mat {
+    int rows = 0, cols = 0, type_ = -1;
+    std::vector<unsigned char> data;
+    Mat() {}
+    Mat(int r, int c, int t, const void* src = nullptr);
+    int type() const { return type_; }
+    bool empty() const { return rows == 0 || cols == 0; }
+    size_t elemSize() const { return type_ == MAT_32F ? 4 : 1; }
+    size_t rowBytes() const { return (size_t)cols * elemSize(); }
+    const unsigned char* ptr(int r) const { return data.data() + (size_t)r * rowBytes(); }
+    Mat row(int r) const { return Mat(1, cols, type_, ptr(r)); }
+};
+
+typedef std::map<std::string, std::string> ParametersMap;
+
+class VisualWord {   // reference VisualWord.h:38-64, VisualWord.cpp:36-70
+public:
+    VisualWord(int id, const Mat& descriptor, int signatureId = 0);
+    void addRef(int signatureId);
+    int removeAllRef(int signatureId);
+    int getTotalReferences() const { return _totalReferences; }
+    int id() const { return _id; }
+    const Mat& getDescriptor() const { return _descriptor; }
+    const std::map<int, int>& getReferences() const { return _references; }
+    bool isSaved() const { return _saved; }
+    void setSaved(bool saved) { _saved = saved; }
+private:
+    int _id;
+    Mat _descriptor;
+    bool _saved;
+    int _totalReferences;
+    std::map<int, int> _references;   // (signature id , occurrence in the signature)
+};
+
+class VWDictionaryHip {
+public:
+    enum NNStrategy { kNNFlannNaive, kNNFlannKdTree, kNNFlannLSH, kNNBruteForce, kNNBruteForceGPU, kNNBruteForceHIP, kNNUndef };
+    static const int ID_START;     // 1
+    static const int ID_INVALID;   // 0
+
+    explicit VWDictionaryHip(const ParametersMap& parameters = ParametersMap(), int device = 0);
+    virtual ~VWDictionaryHip();
+
+    virtual void parseParameters(const ParametersMap& parameters);   // Kp/* keys of Parameters.h:243-266
+    virtual void update();
+    virtual std::list<int> addNewWords(const Mat& descriptors, int signatureId);
+    virtual void addWord(VisualWord* vw);   // takes ownership
+
+    std::vector<int> findNN(const std::list<VisualWord*>& vws) const;
+    std::vector<int> findNN(const Mat& descriptors) const;
+
+    bool addWordRef(int wordId, int signatureId);
+    void removeAllWordRef(int wordId, int signatureId);
+    const VisualWord* getWord(int id) const;
+    VisualWord* getUnusedWord(int id) const;
+    void setLastWordId(int id) { _lastWordId = id; }
+    const std::map<int, VisualWord*>& getVisualWords() const { return _visualWords; }
+    float getNndrRatio() const { return _nndrRatio; }
+    unsigned int getNotIndexedWordsCount() const { return (unsigned int)_notIndexedWords.size(); }
+    int getLastIndexedWordId() const;
+    int getTotalActiveReferences() const { return _totalActiveReferences; }
+    unsigned int getIndexedWordsCount() const { return (unsigned int)_mapIndexId.size(); }
+    bool isIncremental() const { return _incrementalDictionary; }
+    void setIncrementalDictionary();
+    void setFixedDictionary(const std::string& dictionaryPath);   // text format only (VWDictionary.cpp:181-257)
+    void exportDictionary(const char* fileNameReferences, const char* fileNameDescriptors) const;
+
+    void clear(bool printWarningsIfNotEmpty = true);
+    std::vector<VisualWord*> getUnusedWords() const;
+    std::vector<int> getUnusedWordIds() const;
+    unsigned int getUnusedWordsSize() const { return (unsigned int)_unusedWords.size(); }
+    void removeWords(const std::vector<VisualWord*>& words);   // caller must delete the words
+    void deleteUnusedWords();
+
+    // ---- Memory::computeLikelihood(signature, ids), TF-IDF branch (Memory.cpp:2215-2291).
+    // wordIds: the keys of signature->getWords(); N = Memory::getSignatures().size(); getNi = Memory::getNi.
+    std::map<int, float> computeLikelihood(const std::list<int>& wordIds, const std::list<int>& ids, float N,
+                                           const std::function<int(int)>& getNi);
+
+    // ids of the indexed rows in device row order (the tie-break order); for tests
+    std::vector<int> getIndexedWordIds() const;
+    bool isAvailable() const { return _engine != nullptr; }
+    const std::string& lastError() const { return _lastError; }
+    lcd_engine* engine() const { return _engine; }
+
+protected:
+    int getNextId() { return ++_lastWordId; }
+    bool ensureEngine(int type, int cols) const;
+    void markDirty(int signatureId);
+    bool flushReferences(const std::function<int(int)>& getNi);
+
+protected:
+    std::map<int, VisualWord*> _visualWords;
+    int _totalActiveReferences;
+
+private:
+    bool _incrementalDictionary;
+    float _nndrRatio;
+    std::string _dictionaryPath, _newDictionaryPath;
+    bool _newWordsComparedTogether;
+    int _lastWordId;
+    NNStrategy _strategy;
+    std::map<int, int> _mapIndexId, _mapIdIndex;
+    std::map<int, VisualWord*> _unusedWords;
+    std::set<int> _notIndexedWords;
+    std::set<int> _removedIndexedWords;
+    // device side
+    int _device;
+    mutable lcd_engine* _engine;
+    mutable int _engineType, _engineCols;
+    mutable std::string _lastError;
+    // signature-granular mirror of the references for the device inverted index
+    std::map<int, std::vector<int> > _sigWords;   // signature -> word ids referenced (one entry per addWordRef)
+    std::set<int> _dirtySigs;
+    std::set<int> _deviceSigs;
+};
+
+}  // namespace rtabmap_amd

@@ -1,0 +1,104 @@
+// c_shim.cpp -- flat C entry points over VWDictionaryHip / MemoryHip so that the Python parity tests can drive the C++
+// host mirror exactly as they drive the oracle (same call sequence, same argument meaning).  Not part of lcd.h.
+#include <cstring>
+
+#include "MemoryHip.h"
+
+using namespace rtabmap_amd;
+
+static ParametersMap make_params(int strategy, int incremental, float nndr, int together, const char* dictPath) {
+    ParametersMap p;
+    p["Kp/NNStrategy"] = std::to_string(strategy);
+    p["Kp/IncrementalDictionary"] = incremental ? "true" : "false";
+    p["Kp/NndrRatio"] = std::to_string(nndr);
+    p["Kp/NewWordsComparedTogether"] = together ? "true" : "false";
+    if (dictPath && dictPath[0]) p["Kp/DictionaryPath"] = dictPath;
+    return p;
+}
+static Mat make_mat(const void* data, int rows, int cols, int type) { return Mat(rows, cols, type == 0 ? MAT_32F : MAT_8U, data); }
+
+extern "C" {
+
+void* hvwd_create(int strategy, int incremental, float nndr, int together, const char* dictPath, int device) {
+    return new VWDictionaryHip(make_params(strategy, incremental, nndr, together, dictPath), device);
+}
+void hvwd_destroy(void* h) { delete (VWDictionaryHip*)h; }
+int hvwd_available(void* h) { return ((VWDictionaryHip*)h)->isAvailable() ? 1 : 0; }
+const char* hvwd_last_error(void* h) { return ((VWDictionaryHip*)h)->lastError().c_str(); }
+int hvwd_add_new_words(void* h, const void* desc, int rows, int cols, int type, int sigId, int* out, int cap) {
+    std::list<int> ids = ((VWDictionaryHip*)h)->addNewWords(make_mat(desc, rows, cols, type), sigId);
+    int n = 0;
+    for (std::list<int>::iterator i = ids.begin(); i != ids.end() && n < cap; ++i) out[n++] = *i;
+    return (int)ids.size();
+}
+int hvwd_find_nn(void* h, const void* desc, int rows, int cols, int type, int* out) {
+    std::vector<int> r = ((VWDictionaryHip*)h)->findNN(make_mat(desc, rows, cols, type));
+    for (int i = 0; i < rows; ++i) out[i] = r[i];
+    return rows;
+}
+void hvwd_update(void* h) { ((VWDictionaryHip*)h)->update(); }
+void hvwd_add_word(void* h, int id, const void* desc, int cols, int type) {
+    ((VWDictionaryHip*)h)->addWord(new VisualWord(id, make_mat(desc, 1, cols, type)));
+}
+int hvwd_add_word_ref(void* h, int wordId, int sigId) { return ((VWDictionaryHip*)h)->addWordRef(wordId, sigId) ? 1 : 0; }
+void hvwd_remove_all_word_ref(void* h, int wordId, int sigId) { ((VWDictionaryHip*)h)->removeAllWordRef(wordId, sigId); }
+int hvwd_get_unused_word_ids(void* h, int* out, int cap) {
+    std::vector<int> v = ((VWDictionaryHip*)h)->getUnusedWordIds();
+    for (size_t i = 0; i < v.size() && (int)i < cap; ++i) out[i] = v[i];
+    return (int)v.size();
+}
+void hvwd_delete_unused_words(void* h) { ((VWDictionaryHip*)h)->deleteUnusedWords(); }
+void hvwd_clear(void* h) { ((VWDictionaryHip*)h)->clear(false); }
+// which: 0 visualWords, 1 notIndexed, 2 indexed, 3 totalActiveReferences, 4 lastIndexedWordId, 5 unused
+long hvwd_stat(void* h, int which) {
+    VWDictionaryHip* d = (VWDictionaryHip*)h;
+    switch (which) {
+        case 0: return (long)d->getVisualWords().size();
+        case 1: return (long)d->getNotIndexedWordsCount();
+        case 2: return (long)d->getIndexedWordsCount();
+        case 3: return d->getTotalActiveReferences();
+        case 4: return d->getLastIndexedWordId();
+        case 5: return (long)d->getUnusedWordsSize();
+    }
+    return -1;
+}
+int hvwd_get_word_refs(void* h, int wordId, int* sigs, int* counts, int cap) {
+    const VisualWord* vw = ((VWDictionaryHip*)h)->getWord(wordId);
+    if (!vw) return -1;
+    int n = 0;
+    for (std::map<int, int>::const_iterator j = vw->getReferences().begin(); j != vw->getReferences().end(); ++j, ++n)
+        if (n < cap) { sigs[n] = j->first; counts[n] = j->second; }
+    return n;
+}
+int hvwd_index_ids(void* h, int* out, int cap) {
+    std::vector<int> v = ((VWDictionaryHip*)h)->getIndexedWordIds();
+    for (size_t i = 0; i < v.size() && (int)i < cap; ++i) out[i] = v[i];
+    return (int)v.size();
+}
+int hvwd_export_text(void* h, const char* refs, const char* desc) { ((VWDictionaryHip*)h)->exportDictionary(refs, desc); return 0; }
+
+void* hmem_create(int strategy, int incremental, float nndr, int together, const char* dictPath, int device) {
+    return new MemoryHip(make_params(strategy, incremental, nndr, together, dictPath), device);
+}
+void hmem_destroy(void* h) { delete (MemoryHip*)h; }
+void* hmem_vwd(void* h) { return ((MemoryHip*)h)->getVWDictionary(); }
+int hmem_update(void* h, const void* desc, int rows, int cols, int type, int nq, int* outIds) {
+    std::vector<int> ids;
+    const int id = ((MemoryHip*)h)->update(make_mat(desc, rows, cols, type), nq, ids);
+    for (size_t i = 0; i < ids.size(); ++i) outIds[i] = ids[i];
+    return id;
+}
+int hmem_add_signature(void* h, int id, const int* wordIds, int n) {
+    return ((MemoryHip*)h)->addSignature(std::vector<int>(wordIds, wordIds + n), id);
+}
+void hmem_forget(void* h, int sigId) { ((MemoryHip*)h)->forget(sigId); }
+int hmem_get_ni(void* h, int sigId) { return ((MemoryHip*)h)->getNi(sigId); }
+long hmem_num_signatures(void* h) { return (long)((MemoryHip*)h)->signaturesSize(); }
+int hmem_compute_likelihood(void* h, const int* words, int nwords, const int* ids, int nids, int* outIds, float* out) {
+    std::map<int, float> L = ((MemoryHip*)h)->computeLikelihood(std::list<int>(words, words + nwords), std::list<int>(ids, ids + nids));
+    int n = 0;
+    for (std::map<int, float>::iterator i = L.begin(); i != L.end(); ++i, ++n) { outIds[n] = i->first; out[n] = i->second; }
+    return n;
+}
+
+}  // extern "C"

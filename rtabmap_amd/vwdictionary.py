@@ -1,0 +1,200 @@
+"""ctypes view of the C++ host mirror (rtabmap_amd/host: VWDictionaryHip / MemoryHip over the C-ABI).
+
+Same method names as the reference classes (snake_case): update / add_new_words / find_nn / add_word_ref /
+remove_all_word_ref / compute_likelihood ...  All search and scoring runs on the device through liblcd_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import build as _build
+
+kNNFlannNaive, kNNFlannKdTree, kNNFlannLSH, kNNBruteForce, kNNBruteForceGPU, kNNBruteForceHIP = 0, 1, 2, 3, 4, 5
+_lib = None
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _type_of(a):
+    if a.dtype == np.float32:
+        return 0
+    if a.dtype == np.uint8:
+        return 1
+    raise TypeError("descriptors must be float32 or uint8")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(_build.build_host())
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        L.hvwd_create.restype = vp
+        L.hvwd_create.argtypes = [ci, ci, cf, ci, C.c_char_p, ci]
+        L.hvwd_destroy.argtypes = [vp]
+        L.hvwd_available.argtypes = [vp]
+        L.hvwd_last_error.argtypes = [vp]
+        L.hvwd_last_error.restype = C.c_char_p
+        L.hvwd_add_new_words.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci]
+        L.hvwd_find_nn.argtypes = [vp, vp, ci, ci, ci, vp]
+        L.hvwd_update.argtypes = [vp]
+        L.hvwd_add_word.argtypes = [vp, ci, vp, ci, ci]
+        L.hvwd_add_word_ref.argtypes = [vp, ci, ci]
+        L.hvwd_remove_all_word_ref.argtypes = [vp, ci, ci]
+        L.hvwd_get_unused_word_ids.argtypes = [vp, vp, ci]
+        L.hvwd_delete_unused_words.argtypes = [vp]
+        L.hvwd_clear.argtypes = [vp]
+        L.hvwd_stat.argtypes = [vp, ci]
+        L.hvwd_stat.restype = C.c_long
+        L.hvwd_get_word_refs.argtypes = [vp, ci, vp, vp, ci]
+        L.hvwd_index_ids.argtypes = [vp, vp, ci]
+        L.hvwd_export_text.argtypes = [vp, C.c_char_p, C.c_char_p]
+        L.hmem_create.restype = vp
+        L.hmem_create.argtypes = [ci, ci, cf, ci, C.c_char_p, ci]
+        L.hmem_destroy.argtypes = [vp]
+        L.hmem_vwd.restype = vp
+        L.hmem_vwd.argtypes = [vp]
+        L.hmem_update.argtypes = [vp, vp, ci, ci, ci, ci, vp]
+        L.hmem_add_signature.argtypes = [vp, ci, vp, ci]
+        L.hmem_forget.argtypes = [vp, ci]
+        L.hmem_get_ni.argtypes = [vp, ci]
+        L.hmem_num_signatures.argtypes = [vp]
+        L.hmem_num_signatures.restype = C.c_long
+        L.hmem_compute_likelihood.argtypes = [vp, vp, ci, vp, ci, vp, vp]
+        _lib = L
+    return _lib
+
+
+class VWDictionaryHip:
+    def __init__(self, strategy=kNNBruteForceHIP, incremental=True, nndr=0.8, new_words_compared_together=True,
+                 dictionary_path="", device=0, _handle=None, _owner=None):
+        self._owner = _owner
+        self.h = _handle if _handle is not None else lib().hvwd_create(
+            strategy, int(incremental), float(nndr), int(new_words_compared_together), dictionary_path.encode(), device)
+
+    def close(self):
+        if self.h and self._owner is None:
+            lib().hvwd_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self):
+        return lib().hvwd_last_error(self.h).decode()
+
+    def add_new_words(self, desc, sig_id):
+        desc = np.ascontiguousarray(desc)
+        out = np.zeros(max(desc.shape[0], 1), np.int32)
+        n = lib().hvwd_add_new_words(self.h, _p(desc), desc.shape[0], desc.shape[1] if desc.ndim == 2 else 0, _type_of(desc),
+                                     sig_id, _p(out), out.shape[0])
+        return out[:n].tolist()
+
+    def find_nn(self, desc):
+        desc = np.ascontiguousarray(desc)
+        out = np.zeros(desc.shape[0], np.int32)
+        lib().hvwd_find_nn(self.h, _p(desc), desc.shape[0], desc.shape[1], _type_of(desc), _p(out))
+        return out.tolist()
+
+    def update(self):
+        lib().hvwd_update(self.h)
+
+    def add_word(self, word_id, desc):
+        desc = np.ascontiguousarray(desc).reshape(-1)
+        lib().hvwd_add_word(self.h, word_id, _p(desc), desc.shape[0], _type_of(desc))
+
+    def add_word_ref(self, word_id, sig_id):
+        return bool(lib().hvwd_add_word_ref(self.h, word_id, sig_id))
+
+    def remove_all_word_ref(self, word_id, sig_id):
+        lib().hvwd_remove_all_word_ref(self.h, word_id, sig_id)
+
+    def get_unused_word_ids(self):
+        n = lib().hvwd_get_unused_word_ids(self.h, None, 0)
+        out = np.zeros(max(n, 1), np.int32)
+        lib().hvwd_get_unused_word_ids(self.h, _p(out), n)
+        return out[:n].tolist()
+
+    def delete_unused_words(self):
+        lib().hvwd_delete_unused_words(self.h)
+
+    def clear(self):
+        lib().hvwd_clear(self.h)
+
+    def stat(self, which):
+        return int(lib().hvwd_stat(self.h, which))
+
+    visual_words = property(lambda s: s.stat(0))
+    not_indexed_words = property(lambda s: s.stat(1))
+    indexed_words = property(lambda s: s.stat(2))
+    total_active_references = property(lambda s: s.stat(3))
+    unused_words = property(lambda s: s.stat(5))
+
+    def word_refs(self, word_id):
+        n = lib().hvwd_get_word_refs(self.h, word_id, None, None, 0)
+        if n < 0:
+            return None
+        s = np.zeros(max(n, 1), np.int32)
+        c = np.zeros(max(n, 1), np.int32)
+        lib().hvwd_get_word_refs(self.h, word_id, _p(s), _p(c), n)
+        return dict(zip(s[:n].tolist(), c[:n].tolist()))
+
+    def index_ids(self):
+        n = lib().hvwd_index_ids(self.h, None, 0)
+        out = np.zeros(max(n, 1), np.int32)
+        lib().hvwd_index_ids(self.h, _p(out), n)
+        return out[:n].tolist()
+
+    def export_text(self, refs_path, desc_path):
+        return lib().hvwd_export_text(self.h, (refs_path or "").encode(), (desc_path or "").encode())
+
+
+class MemoryHip:
+    def __init__(self, strategy=kNNBruteForceHIP, incremental=True, nndr=0.8, new_words_compared_together=True,
+                 dictionary_path="", device=0):
+        self.h = lib().hmem_create(strategy, int(incremental), float(nndr), int(new_words_compared_together),
+                                   dictionary_path.encode(), device)
+        self.vwd = VWDictionaryHip(_handle=lib().hmem_vwd(self.h), _owner=self)
+
+    def close(self):
+        if self.h:
+            lib().hmem_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update(self, desc, nq=None):
+        desc = np.ascontiguousarray(desc)
+        rows = desc.shape[0]
+        out = np.zeros(max(rows, 1), np.int32)
+        sid = lib().hmem_update(self.h, _p(desc), rows, desc.shape[1], _type_of(desc), -1 if nq is None else nq, _p(out))
+        return sid, out[:rows].tolist()
+
+    def add_signature(self, word_ids, sig_id=0):
+        a = np.ascontiguousarray(word_ids, dtype=np.int32)
+        return lib().hmem_add_signature(self.h, sig_id, _p(a), a.shape[0])
+
+    def forget(self, sig_id):
+        lib().hmem_forget(self.h, sig_id)
+
+    def get_ni(self, sig_id):
+        return lib().hmem_get_ni(self.h, sig_id)
+
+    def num_signatures(self):
+        return int(lib().hmem_num_signatures(self.h))
+
+    def compute_likelihood(self, words, ids):
+        w = np.ascontiguousarray(words, dtype=np.int32)
+        i = np.ascontiguousarray(ids, dtype=np.int32)
+        oid = np.zeros(max(i.shape[0], 1), np.int32)
+        out = np.zeros(max(i.shape[0], 1), np.float32)
+        n = lib().hmem_compute_likelihood(self.h, _p(w), w.shape[0], _p(i), i.shape[0], _p(oid), _p(out))
+        return oid[:n], out[:n]
