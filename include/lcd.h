@@ -173,8 +173,10 @@ typedef struct lcd_stats {
     int64_t signatures, postings;
     int64_t knn_launches, likelihood_launches, rebuilds;
     int64_t bytes_device;                  /* HBM held by the handle */
+    int64_t knn_last_fallback_queries;     /* queries of the LAST 2-NN call that the MFMA certificate sent to the exact scan */
 } lcd_stats;
-int lcd_get_stats(const lcd_engine* h, lcd_stats* out);
+/* synchronises the engine stream (the fallback counter lives on the device) */
+int lcd_get_stats(lcd_engine* h, lcd_stats* out);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,7 @@ class LcdConfig(C.Structure):
 class LcdStats(C.Structure):
     _fields_ = [("vocab_rows", C.c_int64), ("vocab_live", C.c_int64), ("signatures", C.c_int64), ("postings", C.c_int64),
                 ("knn_launches", C.c_int64), ("likelihood_launches", C.c_int64), ("rebuilds", C.c_int64),
-                ("bytes_device", C.c_int64)]
+                ("bytes_device", C.c_int64), ("knn_last_fallback_queries", C.c_int64)]
 
 
 class LcdError(RuntimeError):

@@ -7,6 +7,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -46,21 +47,43 @@ int upload_rows(lcd_engine* h, const void* rows, int n, DevBuf& dst) {
     return LCD_OK;
 }
 
-// 2-NN of q device-resident queries against the vocabulary -> d_knn_{row,word,wslot,dist}[q*2]
+// 2-NN of q device-resident queries against a row matrix -> o_{row,word,dist}[q*2].  `main_vocab` selects the resident
+// vocabulary (which has row norms and may use the MFMA filter); other matrices (findNN's not-indexed words) use the exact scan.
+int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab, const int32_t* row_id, int64_t n_rows, bool main_vocab,
+                 int32_t* o_row, int32_t* o_word, float* o_dist) {
+    if (q == 0) return LCD_OK;
+    const bool mfma = main_vocab && h->knn_mode == 1 && knn_mfma_supported(h->dtype, h->kdim) && n_rows >= 256;
+    const KnnPlan p = knn_plan(q, (int)n_rows, h->row_bytes);
+    if (mfma) {
+        const MfmaPlan mp = knn_mfma_plan(q, (int)n_rows);
+        LCD_HIP(h, dreserve(h, h->d_partial2, knn_mfma_partial_bytes(mp)));
+        LCD_HIP(h, dreserve(h, h->d_fail_list, (size_t)q * 4));
+        LCD_HIP(h, dreserve(h, h->d_fail_count, 64));
+        LCD_HIP(h, launch_knn_mfma(h->kdim, vocab, h->row_norm.as<float>(), h->norm_max.as<uint32_t>(), row_id, d_queries, mp, h->d_partial2.p,
+                                   o_row, o_word, o_dist, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(), h->stream));
+        // exact scan of the queries the certificate rejected (usually none: the workgroups leave at once)
+        LCD_HIP(h, dreserve(h, h->d_partial, knn_partial_bytes(p)));
+        LCD_HIP(h, launch_knn2_partial(h->dtype, h->kdim, vocab, row_id, d_queries, p, h->d_partial.as<uint64_t>(), h->stream,
+                                       h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>()));
+        LCD_HIP(h, launch_knn2_merge(h->dtype, p, h->d_partial.as<uint64_t>(), row_id, o_row, o_word, o_dist, h->stream,
+                                     h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>()));
+    } else {
+        LCD_HIP(h, dreserve(h, h->d_partial, knn_partial_bytes(p)));
+        LCD_HIP(h, launch_knn2_partial(h->dtype, h->kdim, vocab, row_id, d_queries, p, h->d_partial.as<uint64_t>(), h->stream));
+        LCD_HIP(h, launch_knn2_merge(h->dtype, p, h->d_partial.as<uint64_t>(), row_id, o_row, o_word, o_dist, h->stream));
+    }
+    h->knn_launches += 1;
+    return LCD_OK;
+}
+
 int run_knn2(lcd_engine* h, const void* d_queries, int q, const void* vocab, const int32_t* row_id, const int32_t* row_wslot,
              int64_t n_rows, DevBuf& o_row, DevBuf& o_word, DevBuf& o_dist) {
     (void)row_wslot;
-    const KnnPlan p = knn_plan(q, (int)n_rows, h->row_bytes);
-    LCD_HIP(h, dreserve(h, h->d_partial, knn_partial_bytes(p)));
     LCD_HIP(h, dreserve(h, o_row, (size_t)std::max(q, 1) * 2 * 4));
     LCD_HIP(h, dreserve(h, o_word, (size_t)std::max(q, 1) * 2 * 4));
     LCD_HIP(h, dreserve(h, o_dist, (size_t)std::max(q, 1) * 2 * 4));
-    if (q == 0) return LCD_OK;
-    LCD_HIP(h, launch_knn2_partial(h->dtype, h->kdim, vocab, row_id, d_queries, p, h->d_partial.as<uint64_t>(), h->stream));
-    LCD_HIP(h, launch_knn2_merge(h->dtype, p, h->d_partial.as<uint64_t>(), row_id, o_row.as<int32_t>(), o_word.as<int32_t>(),
-                                 o_dist.as<float>(), h->stream));
-    h->knn_launches += 1;
-    return LCD_OK;
+    return run_knn2_raw(h, d_queries, q, vocab, row_id, n_rows, vocab == h->vocab.p, o_row.as<int32_t>(), o_word.as<int32_t>(),
+                        o_dist.as<float>());
 }
 
 int download(lcd_engine* h, void* dst, const void* d_src, size_t bytes, PinBuf& pin) {
@@ -103,6 +126,10 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
     if (e == hipSuccess) e = h->row_id.reserve((size_t)vcap * 4, 0, h->stream, &h->bytes_device);
     if (e == hipSuccess) e = h->row_wslot.reserve((size_t)vcap * 4, 0, h->stream, &h->bytes_device);
     if (e == hipSuccess) e = h->d_n_new.reserve(64, 0, h->stream, &h->bytes_device);
+    if (e == hipSuccess) e = h->norm_max.reserve(64, 0, h->stream, &h->bytes_device);
+    if (e == hipSuccess) e = hipMemsetAsync(h->norm_max.p, 0, 64, h->stream);
+    if (e == hipSuccess) e = h->row_norm.reserve((size_t)vcap * 4, 0, h->stream, &h->bytes_device);
+    { const char* m = getenv("LCD_KNN_MODE"); if (m && *m) h->knn_mode = (m[0] == 'v' || m[0] == '0') ? 0 : 1; }
     if (e == hipSuccess) e = h->tfidf.init(h->stream, &h->bytes_device, cfg->sig_capacity);
     if (e != hipSuccess) { lcd_destroy(h); return LCD_ERR_HIP; }
     *out = h;
@@ -117,7 +144,8 @@ void lcd_destroy(lcd_engine* h) {
     DevBuf* all[] = {&h->vocab, &h->row_id, &h->row_wslot, &h->vocab_alt, &h->row_id_alt, &h->row_wslot_alt, &h->d_queries,
                      &h->d_partial, &h->d_knn_row, &h->d_knn_word, &h->d_knn_wslot, &h->d_knn_dist, &h->d_selfdist, &h->d_out_word,
                      &h->d_out_wslot, &h->d_n_new, &h->d_tmp_i32, &h->d_extra_rows, &h->d_extra_id, &h->d_extra_word,
-                     &h->d_extra_dist, &h->d_extra_row, &h->d_like, &h->d_slots, &h->d_bits};
+                     &h->d_extra_dist, &h->d_extra_row, &h->d_like, &h->d_slots, &h->d_bits, &h->row_norm, &h->norm_max, &h->d_partial2,
+                     &h->d_fail_list, &h->d_fail_count};
     for (DevBuf* d : all) d->release(&h->bytes_device);
     h->h_in.release(); h->h_out.release(); h->h_out2.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -179,6 +207,11 @@ int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word
     LCD_HIP(h, hipMemcpyAsync((char*)h->vocab.p + (size_t)h->n_rows * h->row_bytes, st, rb, hipMemcpyHostToDevice, h->stream));
     LCD_HIP(h, hipMemcpyAsync(h->row_id.as<int32_t>() + h->n_rows, ids, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     LCD_HIP(h, hipMemcpyAsync(h->row_wslot.as<int32_t>() + h->n_rows, ws, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    if (h->dtype == LCD_F32) {   // |row|^2 for the MFMA filter
+        LCD_HIP(h, dreserve(h, h->row_norm, (size_t)total * 4, (size_t)h->n_rows * 4));
+        LCD_HIP(h, launch_row_norms(h->vocab.p, h->row_id.as<int32_t>(), (int)h->n_rows, n, h->kdim, h->row_norm.as<float>(),
+                                    h->norm_max.as<uint32_t>(), h->stream));
+    }
     LCD_HIP(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < n; ++i) { h->word_row[word_ids[i]] = (int32_t)(h->n_rows + i); h->h_row_id.push_back(word_ids[i]); }
     h->n_rows = total;
@@ -203,6 +236,7 @@ int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n) {
     std::memcpy(h->h_in.p, rows.data(), (size_t)n * 4);
     LCD_HIP(h, hipMemcpyAsync(h->d_tmp_i32.p, h->h_in.p, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     LCD_HIP(h, launch_tombstone(h->row_id.as<int32_t>(), h->d_tmp_i32.as<int32_t>(), n, h->stream));
+    if (h->dtype == LCD_F32) LCD_HIP(h, launch_norm_tombstone(h->row_norm.as<float>(), h->d_tmp_i32.as<int32_t>(), n, h->stream));
     LCD_HIP(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < n; ++i) { h->h_row_id[rows[i]] = 0; h->word_row.erase(word_ids[i]); }
     h->n_live -= n;
@@ -235,6 +269,12 @@ int lcd_vocab_rebuild(lcd_engine* h) {
     std::swap(h->vocab, h->vocab_alt);
     std::swap(h->row_id, h->row_id_alt);
     std::swap(h->row_wslot, h->row_wslot_alt);
+    if (h->dtype == LCD_F32 && n) {
+        LCD_HIP(h, dreserve(h, h->row_norm, (size_t)n * 4));
+        LCD_HIP(h, launch_row_norms(h->vocab.p, h->row_id.as<int32_t>(), 0, n, h->kdim, h->row_norm.as<float>(), h->norm_max.as<uint32_t>(),
+                                    h->stream));
+        LCD_HIP(h, hipStreamSynchronize(h->stream));
+    }
     std::vector<int32_t> ids(n);
     h->word_row.clear();
     for (int i = 0; i < n; ++i) { ids[i] = h->h_row_id[perm[i]]; h->word_row[ids[i]] = i; }
@@ -521,14 +561,8 @@ int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_id
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (q <= 0 || !d_queries || !d_word_ids || !d_dist) return h->fail(LCD_ERR_INVALID, "lcd_knn2_dev: bad argument");
-    const KnnPlan p = knn_plan(q, (int)h->n_rows, h->row_bytes);
-    LCD_HIP(h, dreserve(h, h->d_partial, knn_partial_bytes(p)));
     LCD_HIP(h, dreserve(h, h->d_knn_row, (size_t)q * 2 * 4));
-    LCD_HIP(h, launch_knn2_partial(h->dtype, h->kdim, h->vocab.p, h->row_id.as<int32_t>(), d_queries, p, h->d_partial.as<uint64_t>(), h->stream));
-    LCD_HIP(h, launch_knn2_merge(h->dtype, p, h->d_partial.as<uint64_t>(), h->row_id.as<int32_t>(), h->d_knn_row.as<int32_t>(),
-                                 d_word_ids, d_dist, h->stream));
-    h->knn_launches += 1;
-    return LCD_OK;
+    return run_knn2_raw(h, d_queries, q, h->vocab.p, h->row_id.as<int32_t>(), h->n_rows, true, h->d_knn_row.as<int32_t>(), d_word_ids, d_dist);
 }
 
 int lcd_slots_dev(lcd_engine* h, const int32_t** d_slot_sig, int64_t* n_slots) {
@@ -538,9 +572,17 @@ int lcd_slots_dev(lcd_engine* h, const int32_t** d_slot_sig, int64_t* n_slots) {
     return LCD_OK;
 }
 
-int lcd_get_stats(const lcd_engine* h, lcd_stats* out) {
+int lcd_get_stats(lcd_engine* h, lcd_stats* out) {
     LCD_CHECK_HANDLE(h);
     if (!out) return LCD_ERR_INVALID;
+    LCD_DEV(h);
+    out->knn_last_fallback_queries = 0;
+    if (h->d_fail_count.p) {
+        int32_t n = 0;
+        int rc = download(h, &n, h->d_fail_count.p, 4, h->h_out2);
+        if (rc) return rc;
+        out->knn_last_fallback_queries = n;
+    }
     out->vocab_rows = h->n_rows; out->vocab_live = h->n_live;
     out->signatures = h->tfidf.live_sigs; out->postings = h->tfidf.postings_ub;
     out->knn_launches = h->knn_launches; out->likelihood_launches = h->likelihood_launches; out->rebuilds = h->rebuilds;

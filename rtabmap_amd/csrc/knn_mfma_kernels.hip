@@ -1,0 +1,355 @@
+// knn_mfma_kernels.hip -- squared-L2 2-NN as a dense contraction on the matrix cores, with an exactness certificate.
+//
+// The reference's arithmetic, sum_k (v_k - q_k)^2 in rtflann's order (dist.h:150-177), costs 3 VALU ops per element and
+// cannot use FMA.  Here the scan is split in two:
+//
+//   1. FILTER (this file, MFMA): s(i, j) = |v_i|^2 + |q_j|^2 - 2 v_i . q_j for every (vocabulary row i, query j) with
+//      v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate: an exact fp32 FMA chain at the matrix-core rate (157 TFLOP/s,
+//      MI355X_MICROARCH.md).  |v|^2 and |q|^2 ride along as one extra k-step (A = (|v_i|^2, 1), B = (1, |q_j|^2)) and
+//      the queries are pre-scaled by -2, so the accumulator IS the approximate squared distance.  Every lane keeps a
+//      running top-2 of packed (distance << 32 | row) keys for the queries it sees -- no cross-lane traffic in the loop.
+//   2. RE-RANK (knn_mfma_rerank_kernel): per query the 8 best filter candidates are re-evaluated with the reference's
+//      own arithmetic (bit-exact distances, lower row wins ties) and the two best are returned.  The result is PROVEN
+//      equal to the exact scan when every row the filter dropped is certainly farther than the exact second neighbour:
+//            bound - eps > d2_exact,
+//      bound = the smallest filter score any dropped row can have (tracked through every merge level), eps = a bound on
+//      |filter score - reference distance| (fp32 summation error of both orders, see eps_for()).  Queries that fail the
+//      certificate (near-duplicate clusters) are re-done by the exact VALU scan (knn2_kernels.hip, list mode), so the
+//      output is always the reference's bit-exact answer.
+//
+// Tiling (wave64, CDNA4): one wave = 64 queries (two 32-query MFMA column groups, their k-halves resident in VGPRs for
+// the whole kernel) x a strip of 32-row vocabulary tiles.  A operand = 32 rows x 64 floats straight from global memory
+// (L2-resident: grid.x is a multiple of 8, row ranges stay on one XCD); lane (row l&31, half l>>5) holds the 32 contiguous
+// floats [32h, 32h+32) of its row, i.e. k-step t multiplies element 32h + t -- A and B use the same k permutation, which
+// a dot product does not see.  D layout: lane holds query (l&31), 16 rows (reg&3) + 8*(reg>>2) + 4*(l>>5).
+#include "lcd_kernels.h"
+
+namespace lcd {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MF_BLOCK = 256;
+constexpr int MF_WAVES = 4;
+constexpr int MF_KEEP = 4;     // keys kept per (row block, query)
+constexpr int MF_CAND = 8;     // candidates re-ranked exactly per query
+
+__device__ __forceinline__ void top2_push(uint64_t& best, uint64_t& second, uint64_t k) {
+    const uint64_t hi = best > k ? best : k;
+    best = best < k ? best : k;
+    second = second < hi ? second : hi;
+}
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, m, 64);
+    hi = __shfl_xor(hi, m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// |row|^2 of the vocabulary (any summation order: the filter only needs it to ~1 ulp x dim); tombstones get +inf
+__global__ void row_norm_kernel(const float* __restrict__ vocab, const int32_t* __restrict__ row_id, int first, int n, int dim,
+                                float* __restrict__ norm, uint32_t* __restrict__ norm_max_bits) {
+    const int r = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= first + n) return;
+    float s = __int_as_float(0x7f800000);
+    if (row_id[r] != 0) {
+        s = 0.0f;
+        const float* v = vocab + (size_t)r * dim;
+        for (int k = 0; k < dim; ++k) s = fmaf(v[k], v[k], s);
+        atomicMax(norm_max_bits, __float_as_uint(s));
+    }
+    norm[r] = s;
+}
+__global__ void norm_tombstone_kernel(float* __restrict__ norm, const int32_t* __restrict__ rows, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) norm[rows[i]] = __int_as_float(0x7f800000);
+}
+
+// ------------------------------------------------------------------------------------------------ filter
+// partial_keys [n_blocks][MF_KEEP][qpad] u64, partial_lmin [n_blocks][qpad] f32 bits
+template <int DIM>
+__global__ __launch_bounds__(MF_BLOCK, 2) void knn_mfma_filter_kernel(const float* __restrict__ vocab, const float* __restrict__ row_norm,
+                                                                      int n_rows, const float* __restrict__ queries, int nq, int qpad,
+                                                                      int tiles_per_block, uint64_t* __restrict__ partial_keys,
+                                                                      uint32_t* __restrict__ partial_lmin) {
+    constexpr int KH = DIM / 2;                    // floats of a row held by one lane
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int q0 = blockIdx.y * 64;
+
+    // B operand: both 32-query groups, pre-scaled by -2 (exact), + |q|^2 for the extra k-step
+    float b[2][KH];
+    float b_aug[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int qi = min(q0 + g * 32 + col, nq - 1);
+        const float4* src = reinterpret_cast<const float4*>(queries + (size_t)qi * DIM + half * KH);
+        float part = 0.0f;
+#pragma unroll
+        for (int v = 0; v < KH / 4; ++v) {
+            const float4 x = src[v];
+            b[g][4 * v + 0] = -2.0f * x.x; b[g][4 * v + 1] = -2.0f * x.y; b[g][4 * v + 2] = -2.0f * x.z; b[g][4 * v + 3] = -2.0f * x.w;
+            part = fmaf(x.x, x.x, part); part = fmaf(x.y, x.y, part); part = fmaf(x.z, x.z, part); part = fmaf(x.w, x.w, part);
+        }
+        const float qn = part + __shfl_xor(part, 32, 64);          // both halves of the row
+        b_aug[g] = half == 0 ? 1.0f : qn;                          // B[k0][j] = 1, B[k1][j] = |q_j|^2
+    }
+
+    const int tile0 = blockIdx.x * tiles_per_block;
+    const int n_tiles = (n_rows + 31) / 32;
+    const int tile1 = min(tile0 + tiles_per_block, n_tiles);
+    const int per_wave = (tile1 - tile0 + MF_WAVES - 1) / MF_WAVES;
+    const int t_begin = min(tile0 + wave * per_wave, tile1);
+    const int t_end = min(t_begin + per_wave, tile1);
+
+    uint64_t best[2] = {KEY_NONE, KEY_NONE}, second[2] = {KEY_NONE, KEY_NONE};
+    for (int t = t_begin; t < t_end; ++t) {
+        const int row = t * 32 + col;
+        const int rsrc = min(row, n_rows - 1);
+        // A operand: this lane's half of its vocabulary row
+        float a[KH];
+        const float4* src = reinterpret_cast<const float4*>(vocab + (size_t)rsrc * DIM + half * KH);
+#pragma unroll
+        for (int v = 0; v < KH / 4; ++v) {
+            const float4 x = src[v];
+            a[4 * v + 0] = x.x; a[4 * v + 1] = x.y; a[4 * v + 2] = x.z; a[4 * v + 3] = x.w;
+        }
+        const float vn = row < n_rows ? row_norm[row] : __int_as_float(0x7f800000);
+        const float a_aug = half == 0 ? vn : 1.0f;                  // A[i][k0] = |v_i|^2, A[i][k1] = 1
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug[g], acc, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < KH; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[g][k], acc, 0, 0, 0);
+            // acc[r] = approximate squared distance between query (g, col) and row t*32 + (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t vrow = (uint32_t)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+                const float s = fmaxf(acc[r], 0.0f);
+                top2_push(best[g], second[g], ((uint64_t)__float_as_uint(s) << 32) | vrow);
+            }
+        }
+    }
+
+    // workgroup merge: 8 partitions (4 waves x 2 halves) x top-2 per query -> top-MF_KEEP + the smallest partition second
+    __shared__ uint64_t s_key[64][MF_WAVES * 2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        s_key[g * 32 + col][wave * 2 + half][0] = best[g];
+        s_key[g * 32 + col][wave * 2 + half][1] = second[g];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int ql = threadIdx.x;
+        uint64_t keep[MF_KEEP];
+#pragma unroll
+        for (int i = 0; i < MF_KEEP; ++i) keep[i] = KEY_NONE;
+        uint32_t lmin = 0x7f800000u;                                 // +inf
+        for (int p = 0; p < MF_WAVES * 2; ++p) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                uint64_t k = s_key[ql][p][e];
+                if (e == 1) lmin = min(lmin, (uint32_t)min(k >> 32, (uint64_t)0x7f800000u));   // rows hidden behind a partition's top-2
+#pragma unroll
+                for (int i = 0; i < MF_KEEP; ++i) {                  // sorted insertion
+                    const uint64_t lo = keep[i] < k ? keep[i] : k;
+                    k = keep[i] < k ? k : keep[i];
+                    keep[i] = lo;
+                }
+            }
+        }
+        const int qi = q0 + ql;
+#pragma unroll
+        for (int i = 0; i < MF_KEEP; ++i) partial_keys[((size_t)blockIdx.x * MF_KEEP + i) * qpad + qi] = keep[i];
+        partial_lmin[(size_t)blockIdx.x * qpad + qi] = lmin;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ re-rank + certificate
+// rtflann::L2 (dist.h:150-177), a = vocabulary row, b = query -- the same code as knn2_kernels.hip::l2_ref_dyn
+__device__ __forceinline__ float l2_ref_row(const float* __restrict__ row, const float* __restrict__ q, int dim) {
+    float res = 0.0f;
+    int g = 0;
+    for (; g + 3 < dim; g += 4) {
+        const float d0 = __fsub_rn(row[g + 0], q[g + 0]);
+        const float d1 = __fsub_rn(row[g + 1], q[g + 1]);
+        const float d2 = __fsub_rn(row[g + 2], q[g + 2]);
+        const float d3 = __fsub_rn(row[g + 3], q[g + 3]);
+        float t = __fmul_rn(d0, d0);
+        t = __fadd_rn(t, __fmul_rn(d1, d1));
+        t = __fadd_rn(t, __fmul_rn(d2, d2));
+        t = __fadd_rn(t, __fmul_rn(d3, d3));
+        res = __fadd_rn(res, t);
+    }
+    for (; g < dim; ++g) {
+        const float d0 = __fsub_rn(row[g], q[g]);
+        res = __fadd_rn(res, __fmul_rn(d0, d0));
+    }
+    return res;
+}
+
+// |filter score - reference distance| <= eps.  Both are fp32 evaluations of the same real number:
+//   filter:    dim + 2 FMA steps over terms bounded by 2|q||v| + |v|^2 + |q|^2 <= 2 (|v|^2 + |q|^2), norms carry dim ulps each;
+//   reference: dim products + dim sums over a quantity <= 2 (|v|^2 + |q|^2).
+// gamma_n ~ n * 2^-24; with n <= 2 dim + 8 on each side: eps = (4 dim + 16) * 2^-24 * 2 (|v|max^2 + |q|^2), doubled for slack.
+__device__ __forceinline__ float eps_for(int dim, float qn, float vn_max) {
+    return (float)(4 * dim + 16) * 5.9604645e-8f * 4.0f * (qn + vn_max);
+}
+
+// one wave per query
+__global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_t* __restrict__ partial_keys,
+                                                                   const uint32_t* __restrict__ partial_lmin, int n_blocks, int qpad,
+                                                                   int nq, int dim, const float* __restrict__ vocab,
+                                                                   const float* __restrict__ queries, const int32_t* __restrict__ row_id,
+                                                                   const uint32_t* __restrict__ norm_max_bits,
+                                                                   int32_t* __restrict__ out_row, int32_t* __restrict__ out_word,
+                                                                   float* __restrict__ out_dist, int32_t* __restrict__ fail_list,
+                                                                   int32_t* __restrict__ fail_count) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * MF_WAVES + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    // every lane keeps up to 4 sorted keys of its share of the partial lists
+    uint64_t mine[4] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
+    uint32_t bound = 0x7f800000u;                                    // smallest score a dropped row can have (float bits)
+    const int n_keys = n_blocks * MF_KEEP;
+    for (int c = lane; c < n_keys; c += 64) {
+        uint64_t k = partial_keys[(size_t)c * qpad + qi];
+        if ((c % MF_KEEP) == MF_KEEP - 1) bound = min(bound, (uint32_t)min(k >> 32, (uint64_t)0x7f800000u));   // dropped at the block merge
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint64_t lo = mine[i] < k ? mine[i] : k;
+            k = mine[i] < k ? k : mine[i];
+            mine[i] = lo;
+        }
+        if (k != KEY_NONE) bound = min(bound, (uint32_t)min(k >> 32, (uint64_t)0x7f800000u));                 // dropped by this lane
+    }
+    for (int c = lane; c < n_blocks; c += 64) bound = min(bound, partial_lmin[(size_t)c * qpad + qi]);
+    // MF_CAND rounds of "pop the global minimum"
+    uint64_t cand = KEY_NONE;                                        // lane r (< MF_CAND) ends up owning candidate r
+#pragma unroll
+    for (int r = 0; r < MF_CAND; ++r) {
+        uint64_t m = mine[0];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) { const uint64_t o = shfl_xor_u64(m, s); m = m < o ? m : o; }
+        if (lane == r) cand = m;
+        if (mine[0] == m && m != KEY_NONE) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = KEY_NONE; }   // keys are unique (row in the low half)
+    }
+    // whatever is left in any lane was dropped here
+    bound = min(bound, (uint32_t)min(mine[0] >> 32, (uint64_t)0x7f800000u));
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) bound = min(bound, (uint32_t)__shfl_xor((int)bound, s, 64));
+
+    // exact distances of the candidates, reference arithmetic; a filter score of +inf is a tombstone / padding row
+    const float* q = queries + (size_t)qi * dim;
+    uint64_t exact = KEY_NONE;
+    if (lane < MF_CAND && cand != KEY_NONE && (uint32_t)(cand >> 32) < 0x7f800000u) {
+        const uint32_t row = (uint32_t)cand;
+        exact = ((uint64_t)__float_as_uint(l2_ref_row(vocab + (size_t)row * dim, q, dim)) << 32) | row;
+    }
+    uint64_t best = exact, second = KEY_NONE;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const uint64_t ob = shfl_xor_u64(best, s), os = shfl_xor_u64(second, s);
+        top2_push(best, second, ob);
+        top2_push(best, second, os);
+    }
+    // |q|^2 for eps (lane-parallel partial sums)
+    float qn = 0.0f;
+    for (int k = lane; k < dim; k += 64) qn = fmaf(q[k], q[k], qn);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) qn += __shfl_xor(qn, s, 64);
+    if (lane == 0) {
+        const uint64_t k[2] = {best, second};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (k[j] == KEY_NONE) { out_row[2 * qi + j] = -1; out_word[2 * qi + j] = 0; out_dist[2 * qi + j] = -1.0f; }
+            else {
+                const uint32_t row = (uint32_t)k[j];
+                out_row[2 * qi + j] = (int32_t)row;
+                out_word[2 * qi + j] = row_id[row];
+                out_dist[2 * qi + j] = __uint_as_float((uint32_t)(k[j] >> 32));
+            }
+        }
+        // certificate: every dropped row is strictly farther than the exact second neighbour
+        bool ok = true;
+        if (bound < 0x7f800000u) {                                    // something finite was dropped
+            if (second == KEY_NONE) ok = false;                       // fewer than two exact candidates but rows were dropped
+            else {
+                const float eps = eps_for(dim, qn, __uint_as_float(norm_max_bits[0]));
+                ok = __uint_as_float(bound) - eps > __uint_as_float((uint32_t)(second >> 32));
+            }
+        }
+        if (!ok) fail_list[atomicAdd(fail_count, 1)] = qi;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================ host side
+bool knn_mfma_supported(int dtype, int dim) { return dtype == 0 && dim == 64; }
+
+MfmaPlan knn_mfma_plan(int q, int n_rows) {
+    MfmaPlan p;
+    p.q = q;
+    p.qpad = (q + 63) / 64 * 64;
+    p.n_rows = n_rows;
+    const int n_tiles = (n_rows + 31) / 32;
+    const int qgroups = p.qpad / 64;
+    // 2 waves per SIMD over the chip: 256 CUs x 4 SIMDs x 2 = 2048 waves = 512 workgroups
+    int nb = (512 + qgroups - 1) / qgroups;
+    if (nb > (n_tiles + MF_WAVES - 1) / MF_WAVES) nb = (n_tiles + MF_WAVES - 1) / MF_WAVES;   // at least one tile per wave
+    if (nb < 1) nb = 1;
+    nb = (nb + 7) / 8 * 8;
+    int tpb = (n_tiles + nb - 1) / nb;
+    tpb = (tpb + MF_WAVES - 1) / MF_WAVES * MF_WAVES;               // equal strips for the 4 waves
+    if (tpb < MF_WAVES) tpb = MF_WAVES;
+    p.tiles_per_block = tpb;
+    p.n_blocks = n_tiles > 0 ? (n_tiles + tpb - 1) / tpb : 0;
+    return p;
+}
+size_t knn_mfma_partial_bytes(const MfmaPlan& p) {
+    const size_t nb = (size_t)(p.n_blocks > 0 ? p.n_blocks : 1);
+    return nb * MF_KEEP * p.qpad * sizeof(uint64_t) + nb * p.qpad * sizeof(uint32_t);
+}
+
+hipError_t launch_row_norms(const void* vocab, const int32_t* row_id, int first, int n, int dim, float* norm, uint32_t* norm_max_bits,
+                            hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    row_norm_kernel<<<(n + 255) / 256, 256, 0, s>>>((const float*)vocab, row_id, first, n, dim, norm, norm_max_bits);
+    return hipGetLastError();
+}
+hipError_t launch_norm_tombstone(float* norm, const int32_t* rows, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    norm_tombstone_kernel<<<(n + 255) / 256, 256, 0, s>>>(norm, rows, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, const uint32_t* norm_max_bits, const int32_t* row_id,
+                           const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist,
+                           int32_t* fail_list, int32_t* fail_count, hipStream_t s) {
+    if (p.q == 0) return hipSuccess;
+    uint64_t* pk = (uint64_t*)partial;
+    uint32_t* pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * MF_KEEP * p.qpad);
+    hipError_t e = hipMemsetAsync(fail_count, 0, 4, s);
+    if (e != hipSuccess) return e;
+    if (p.n_blocks > 0) {
+        dim3 grid(p.n_blocks, p.qpad / 64);
+        knn_mfma_filter_kernel<64><<<grid, MF_BLOCK, 0, s>>>((const float*)vocab, row_norm, p.n_rows, (const float*)queries, p.q, p.qpad,
+                                                              p.tiles_per_block, pk, pl);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    knn_mfma_rerank_kernel<<<(p.q + MF_WAVES - 1) / MF_WAVES, MF_BLOCK, 0, s>>>(pk, pl, p.n_blocks, p.qpad, p.q, dim, (const float*)vocab,
+                                                                               (const float*)queries, row_id, norm_max_bits, out_row,
+                                                                               out_word, out_dist, fail_list, fail_count);
+    return hipGetLastError();
+}
+
+}  // namespace lcd

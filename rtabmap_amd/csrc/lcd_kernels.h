@@ -22,11 +22,28 @@ size_t knn_partial_bytes(const KnnPlan& p);   // [n_blocks][2][qpad] keys
 
 // 2-NN of `queries` [q x dim] against `vocab` [n_rows x dim] (row_id[r] == 0 -> tombstone, skipped).
 // dtype: 0 = f32 (dim floats), 1 = u8 (dim bytes, dim % 4 == 0).  Writes per-block partial top-2 keys.
+// List mode (qlist/qcount device pointers, f32 dim 64/128 only): only the queries qlist[0 .. *qcount) are searched.
 hipError_t launch_knn2_partial(int dtype, int dim, const void* vocab, const int32_t* row_id, const void* queries,
-                               const KnnPlan& p, uint64_t* partial, hipStream_t s);
+                               const KnnPlan& p, uint64_t* partial, hipStream_t s, const int32_t* qlist = nullptr,
+                               const int32_t* qcount = nullptr);
 // Merge the partial keys: out_row[q*2] (row or -1), out_word[q*2] (row_id[row] or 0), out_dist[q*2] (float, -1 = none)
 hipError_t launch_knn2_merge(int dtype, const KnnPlan& p, const uint64_t* partial, const int32_t* row_id,
-                             int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s);
+                             int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s, const int32_t* qlist = nullptr,
+                             const int32_t* qcount = nullptr);
+
+// ---- squared-L2 2-NN on the matrix cores (knn_mfma_kernels.hip): MFMA filter + exact re-rank + certificate.
+// Queries whose result cannot be certified are appended to fail_list / fail_count for the exact scan (list mode above).
+struct MfmaPlan { int q, qpad, n_rows, tiles_per_block, n_blocks; };
+bool knn_mfma_supported(int dtype, int dim);
+MfmaPlan knn_mfma_plan(int q, int n_rows);
+size_t knn_mfma_partial_bytes(const MfmaPlan& p);
+// |row|^2 for rows [first, first + n) (+inf for tombstones), running maximum in norm_max_bits
+hipError_t launch_row_norms(const void* vocab, const int32_t* row_id, int first, int n, int dim, float* norm, uint32_t* norm_max_bits,
+                            hipStream_t s);
+hipError_t launch_norm_tombstone(float* norm, const int32_t* rows, int n, hipStream_t s);
+hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, const uint32_t* norm_max_bits, const int32_t* row_id,
+                           const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist,
+                           int32_t* fail_list, int32_t* fail_count, hipStream_t s);
 // q x q distances of a block against itself; out[i*ld + j], ld >= q.  When `bits` is given ([q][bw] words, bw >= ceil(q/32))
 // also the candidate bit matrix of the addNewWords resolution: bit j of row i = dist(j, i) < (distance of i's second
 // indexed neighbour, +inf if it has none) -- see knn2_kernels.hip.

@@ -140,3 +140,39 @@ def test_selfdist_bit_exact_and_symmetric(oracle, kind):
     np.testing.assert_array_equal(D, oracle.dist_matrix(q, q))
     np.testing.assert_array_equal(D, D.T)
     eng.close()
+
+
+def test_knn2_mfma_filter_matches_exact_scan_and_falls_back_on_clusters(oracle, monkeypatch):
+    """f32 dim-64 vocabularies >= 256 rows go through the MFMA filter + exact re-rank.  Results must be the exact scan's,
+    bit for bit; a cluster of identical rows around a query cannot be certified and must take the exact-scan fallback."""
+    import rtabmap_amd
+    v = synth.vocab_surf(20000, seed=5)
+    q = synth.queries_surf(v, 300, seed=6)
+    # 40 copies of one row scattered over the vocabulary: more equal candidates than the re-rank keeps
+    v[::500] = v[123]
+    q[7] = v[123]
+    q[8] = v[123] + np.float32(1e-4)
+    ids = np.arange(1, 20001, dtype=np.int32)
+    res = {}
+    for mode in ("mfma", "valu"):
+        monkeypatch.setenv("LCD_KNN_MODE", mode)
+        eng = rtabmap_amd.Engine("f32", 64)
+        eng.vocab_append(v, ids)
+        res[mode] = eng.knn2(q)
+        fb = eng.stats()["knn_last_fallback_queries"]
+        if mode == "mfma":
+            assert 1 <= fb < 50, fb          # the cluster queries, not everything
+        else:
+            assert fb == 0
+        _check(eng, oracle, v, ids, q)
+        # tombstones in MFMA mode: remove the current nearest rows of every query, search again
+        dead = np.unique(res[mode][0][:, 0])
+        eng.vocab_remove(dead)
+        removed = np.zeros(20000, np.uint8); removed[dead - 1] = 1
+        _check(eng, oracle, v, ids, q, removed=removed)
+        eng.vocab_rebuild()
+        keep = removed == 0
+        _check(eng, oracle, v[keep], ids[keep], q)
+        eng.close()
+    np.testing.assert_array_equal(res["mfma"][0], res["valu"][0])
+    np.testing.assert_array_equal(res["mfma"][1], res["valu"][1])
