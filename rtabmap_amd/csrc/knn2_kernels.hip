@@ -142,10 +142,10 @@ template <int DIM>
 __global__ __launch_bounds__(BLOCK) void knn2_l2_kernel(const float* __restrict__ vocab, const int32_t* __restrict__ row_id,
                                                         int n_rows, const float* __restrict__ queries, int nq, int qpad,
                                                         int rows_per_block, uint64_t* __restrict__ partial,
-                                                        const int32_t* __restrict__ qlist, const int32_t* __restrict__ qcount) {
+                                                        const int32_t* __restrict__ qlist, const int32_t* __restrict__ qcount, int list_min) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (qlist) nq = min(qcount[0], nq);
+    if (qlist) { nq = min(qcount[0], nq); if (nq <= list_min) return; }   // short lists are served by the row-parallel kernel
     // normal mode: one 64-query group per blockIdx.y; list mode: the (few) listed queries are looped over
     for (int gy = blockIdx.y; gy * 64 < nq; gy += gridDim.y) {
         const int qi = gy * 64 + lane;
@@ -257,10 +257,10 @@ __global__ __launch_bounds__(BLOCK) void knn2_merge_kernel(int dtype, const uint
                                                            int nq, const int32_t* __restrict__ row_id,
                                                            int32_t* __restrict__ out_row, int32_t* __restrict__ out_word,
                                                            float* __restrict__ out_dist, const int32_t* __restrict__ qlist,
-                                                           const int32_t* __restrict__ qcount) {
+                                                           const int32_t* __restrict__ qcount, int list_min) {
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * WAVES + (threadIdx.x >> 6);
-    if (qlist) nq = min(qcount[0], nq);
+    if (qlist) { nq = min(qcount[0], nq); if (nq <= list_min) return; }
     if (qi >= nq) return;
     uint64_t best = KEY_NONE, second = KEY_NONE;
     for (int c = lane; c < n_keys; c += 64) top2_push(best, second, partial[(size_t)c * qpad + qi]);
@@ -398,13 +398,13 @@ KnnPlan knn_plan(int q, int n_rows, int dim_bytes) {
 size_t knn_partial_bytes(const KnnPlan& p) { return (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * 2 * p.qpad * sizeof(uint64_t); }
 
 hipError_t launch_knn2_partial(int dtype, int dim, const void* vocab, const int32_t* row_id, const void* queries,
-                               const KnnPlan& p, uint64_t* partial, hipStream_t s, const int32_t* qlist, const int32_t* qcount) {
+                               const KnnPlan& p, uint64_t* partial, hipStream_t s, const int32_t* qlist, const int32_t* qcount, int list_min) {
     if (p.n_blocks == 0 || p.q == 0) return hipSuccess;
     dim3 grid(p.n_blocks, qlist ? 1 : p.qpad / 64), block(BLOCK);
     if (dtype == 0) {
         const float* v = (const float*)vocab; const float* qq = (const float*)queries;
-        if (dim == 64) knn2_l2_kernel<64><<<grid, block, 0, s>>>(v, row_id, p.n_rows, qq, p.q, p.qpad, p.rows_per_block, partial, qlist, qcount);
-        else if (dim == 128) knn2_l2_kernel<128><<<grid, block, 0, s>>>(v, row_id, p.n_rows, qq, p.q, p.qpad, p.rows_per_block, partial, qlist, qcount);
+        if (dim == 64) knn2_l2_kernel<64><<<grid, block, 0, s>>>(v, row_id, p.n_rows, qq, p.q, p.qpad, p.rows_per_block, partial, qlist, qcount, list_min);
+        else if (dim == 128) knn2_l2_kernel<128><<<grid, block, 0, s>>>(v, row_id, p.n_rows, qq, p.q, p.qpad, p.rows_per_block, partial, qlist, qcount, list_min);
         else if (qlist) return hipErrorInvalidValue;
         else knn2_l2_dyn_kernel<<<grid, block, 0, s>>>(v, row_id, p.n_rows, dim, qq, p.q, p.qpad, p.rows_per_block, partial);
     } else {
@@ -420,10 +420,10 @@ hipError_t launch_knn2_partial(int dtype, int dim, const void* vocab, const int3
 
 hipError_t launch_knn2_merge(int dtype, const KnnPlan& p, const uint64_t* partial, const int32_t* row_id,
                              int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s, const int32_t* qlist,
-                             const int32_t* qcount) {
+                             const int32_t* qcount, int list_min) {
     if (p.q == 0) return hipSuccess;
     knn2_merge_kernel<<<(p.q + WAVES - 1) / WAVES, BLOCK, 0, s>>>(dtype, partial, p.n_blocks * 2, p.qpad, p.q, row_id,
-                                                                   out_row, out_word, out_dist, qlist, qcount);
+                                                                   out_row, out_word, out_dist, qlist, qcount, list_min);
     return hipGetLastError();
 }
 

@@ -8,14 +8,14 @@
 //      MI355X_MICROARCH.md).  |v|^2 and |q|^2 ride along as one extra k-step (A = (|v_i|^2, 1), B = (1, |q_j|^2)) and
 //      the queries are pre-scaled by -2, so the accumulator IS the approximate squared distance.  Every lane keeps a
 //      running top-2 of packed (distance << 32 | row) keys for the queries it sees -- no cross-lane traffic in the loop.
-//   2. RE-RANK (knn_mfma_rerank_kernel): per query the 8 best filter candidates are re-evaluated with the reference's
+//   2. RE-RANK (knn_mfma_rerank_kernel): per query the 16 best filter candidates are re-evaluated with the reference's
 //      own arithmetic (bit-exact distances, lower row wins ties) and the two best are returned.  The result is PROVEN
 //      equal to the exact scan when every row the filter dropped is certainly farther than the exact second neighbour:
 //            bound - eps > d2_exact,
 //      bound = the smallest filter score any dropped row can have (tracked through every merge level), eps = a bound on
 //      |filter score - reference distance| (fp32 summation error of both orders, see eps_for()).  Queries that fail the
-//      certificate (near-duplicate clusters) are re-done by the exact VALU scan (knn2_kernels.hip, list mode), so the
-//      output is always the reference's bit-exact answer.
+//      certificate (near-duplicate clusters) are re-done exactly -- a few by knn_rowpar_kernel (one lane per vocabulary
+//      row), many by the VALU scan in list mode (knn2_kernels.hip) -- so the output is always the reference's bit-exact answer.
 //
 // Tiling (wave64, CDNA4): one wave = 64 queries (two 32-query MFMA column groups, their k-halves resident in VGPRs for
 // the whole kernel) x a strip of 32-row vocabulary tiles.  A operand = 32 rows x 64 floats straight from global memory
@@ -31,7 +31,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MF_BLOCK = 256;
 constexpr int MF_WAVES = 4;
 constexpr int MF_KEEP = 4;     // keys kept per (row block, query)
-constexpr int MF_CAND = 8;     // candidates re-ranked exactly per query
+constexpr int MF_CAND = 16;    // candidates re-ranked exactly per query
+constexpr int MF_ROWPAR_MAX = 32;   // up to this many uncertified queries are redone by the row-parallel exact kernel
 
 __device__ __forceinline__ void top2_push(uint64_t& best, uint64_t& second, uint64_t k) {
     const uint64_t hi = best > k ? best : k;
@@ -195,12 +196,15 @@ __device__ __forceinline__ float l2_ref_row(const float* __restrict__ row, const
     return res;
 }
 
-// |filter score - reference distance| <= eps.  Both are fp32 evaluations of the same real number:
-//   filter:    dim + 2 FMA steps over terms bounded by 2|q||v| + |v|^2 + |q|^2 <= 2 (|v|^2 + |q|^2), norms carry dim ulps each;
-//   reference: dim products + dim sums over a quantity <= 2 (|v|^2 + |q|^2).
-// gamma_n ~ n * 2^-24; with n <= 2 dim + 8 on each side: eps = (4 dim + 16) * 2^-24 * 2 (|v|max^2 + |q|^2), doubled for slack.
+// |filter score - reference distance| <= eps: both are fp32 evaluations of the same real number d = |v - q|^2 <= 2 (|v|^2 + |q|^2).
+// With u = 2^-24 and gamma_n ~ n u:
+//   filter: a chain of dim + 2 FMAs over terms whose magnitudes sum to <= 2 (|v|^2 + |q|^2)        -> 2 (dim + 2) u (|v|^2 + |q|^2)
+//           the two norms are themselves dim-term FMA chains                                          ->       dim u (|v|^2 + |q|^2)
+//   reference (dist.h:150-177): every term (v_k - q_k)^2 carries 3 roundings, then dim/4 + 3 additions
+//           of non-negative numbers                                                                   -> 2 (dim/4 + 6) u (|v|^2 + |q|^2)
+// total (3.5 dim + 16) u (|v|^2 + |q|^2); a quarter more is added for slack.  |v|^2 is replaced by the vocabulary maximum.
 __device__ __forceinline__ float eps_for(int dim, float qn, float vn_max) {
-    return (float)(4 * dim + 16) * 5.9604645e-8f * 4.0f * (qn + vn_max);
+    return (3.5f * (float)dim + 16.0f) * 5.9604645e-8f * 1.25f * (qn + vn_max);
 }
 
 // one wave per query
@@ -290,6 +294,93 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ row-parallel exact scan
+// The handful of queries the certificate rejects are redone exactly with the WHOLE chip on each of them: one lane per
+// vocabulary row (the row stays in VGPRs), the listed queries are looped over (query broadcast from LDS), the
+// workgroup reduces to its two best keys per query.  n_fail > MF_ROWPAR_MAX is left to the query-parallel list-mode scan.
+template <int DIM>
+__global__ __launch_bounds__(MF_BLOCK) void knn_rowpar_kernel(const float* __restrict__ vocab, const int32_t* __restrict__ row_id, int n_rows,
+                                                              const float* __restrict__ queries, const int32_t* __restrict__ fail_list,
+                                                              const int32_t* __restrict__ fail_count, uint64_t* __restrict__ partial) {
+    const int nf = fail_count[0];
+    if (nf <= 0 || nf > MF_ROWPAR_MAX) return;
+    __shared__ float s_q[DIM];
+    __shared__ uint64_t s_k[MF_WAVES][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * MF_BLOCK + threadIdx.x;
+    const bool live = row < n_rows && row_id[row] != 0;
+    float v[DIM];
+    {
+        const float4* src = reinterpret_cast<const float4*>(vocab + (size_t)min(row, n_rows - 1) * DIM);
+#pragma unroll
+        for (int g = 0; g < DIM / 4; ++g) { const float4 x = src[g]; v[4 * g] = x.x; v[4 * g + 1] = x.y; v[4 * g + 2] = x.z; v[4 * g + 3] = x.w; }
+    }
+    for (int f = 0; f < nf; ++f) {
+        __syncthreads();
+        if (threadIdx.x < DIM) s_q[threadIdx.x] = queries[(size_t)fail_list[f] * DIM + threadIdx.x];
+        __syncthreads();
+        float res = 0.0f;                              // rtflann::L2 (dist.h:150-177), a = row, b = query
+#pragma unroll
+        for (int g = 0; g + 3 < DIM; g += 4) {
+            const float d0 = __fsub_rn(v[g + 0], s_q[g + 0]);
+            const float d1 = __fsub_rn(v[g + 1], s_q[g + 1]);
+            const float d2 = __fsub_rn(v[g + 2], s_q[g + 2]);
+            const float d3 = __fsub_rn(v[g + 3], s_q[g + 3]);
+            float t = __fmul_rn(d0, d0);
+            t = __fadd_rn(t, __fmul_rn(d1, d1));
+            t = __fadd_rn(t, __fmul_rn(d2, d2));
+            t = __fadd_rn(t, __fmul_rn(d3, d3));
+            res = __fadd_rn(res, t);
+        }
+        uint64_t best = live ? (((uint64_t)__float_as_uint(res) << 32) | (uint32_t)row) : KEY_NONE, second = KEY_NONE;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint64_t ob = shfl_xor_u64(best, m), os = shfl_xor_u64(second, m);
+            top2_push(best, second, ob);
+            top2_push(best, second, os);
+        }
+        if (lane == 0) { s_k[wave][0] = best; s_k[wave][1] = second; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int w = 1; w < MF_WAVES; ++w) { top2_push(best, second, s_k[w][0]); top2_push(best, second, s_k[w][1]); }
+            partial[((size_t)f * gridDim.x + blockIdx.x) * 2 + 0] = best;
+            partial[((size_t)f * gridDim.x + blockIdx.x) * 2 + 1] = second;
+        }
+    }
+}
+// one wave per listed query: merge the per-workgroup keys, write the result into the query's own slot
+__global__ __launch_bounds__(64) void knn_rowpar_merge_kernel(const uint64_t* __restrict__ partial, int n_blocks, const int32_t* __restrict__ fail_list,
+                                                              const int32_t* __restrict__ fail_count, const int32_t* __restrict__ row_id,
+                                                              int32_t* __restrict__ out_row, int32_t* __restrict__ out_word,
+                                                              float* __restrict__ out_dist) {
+    const int nf = fail_count[0];
+    if (nf <= 0 || nf > MF_ROWPAR_MAX || (int)blockIdx.x >= nf) return;
+    const int f = blockIdx.x, lane = threadIdx.x;
+    uint64_t best = KEY_NONE, second = KEY_NONE;
+    for (int c = lane; c < n_blocks * 2; c += 64) top2_push(best, second, partial[(size_t)f * n_blocks * 2 + c]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint64_t ob = shfl_xor_u64(best, m), os = shfl_xor_u64(second, m);
+        top2_push(best, second, ob);
+        top2_push(best, second, os);
+    }
+    if (lane == 0) {
+        const int qo = fail_list[f];
+        const uint64_t k[2] = {best, second};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (k[j] == KEY_NONE) { out_row[2 * qo + j] = -1; out_word[2 * qo + j] = 0; out_dist[2 * qo + j] = -1.0f; }
+            else {
+                const uint32_t row = (uint32_t)k[j];
+                out_row[2 * qo + j] = (int32_t)row;
+                out_word[2 * qo + j] = row_id[row];
+                out_dist[2 * qo + j] = __uint_as_float((uint32_t)(k[j] >> 32));
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // ================================================================================================ host side
@@ -349,6 +440,19 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
     knn_mfma_rerank_kernel<<<(p.q + MF_WAVES - 1) / MF_WAVES, MF_BLOCK, 0, s>>>(pk, pl, p.n_blocks, p.qpad, p.q, dim, (const float*)vocab,
                                                                                (const float*)queries, row_id, norm_max_bits, out_row,
                                                                                out_word, out_dist, fail_list, fail_count);
+    return hipGetLastError();
+}
+
+size_t knn_rowpar_partial_bytes(int n_rows) { return (size_t)MF_ROWPAR_MAX * ((n_rows + MF_BLOCK - 1) / MF_BLOCK + 1) * 2 * sizeof(uint64_t); }
+int knn_rowpar_max() { return MF_ROWPAR_MAX; }
+
+hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, int n_rows, const void* queries, const int32_t* fail_list,
+                             const int32_t* fail_count, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s) {
+    if (dim != 64 || n_rows <= 0) return hipErrorInvalidValue;
+    const int nb = (n_rows + MF_BLOCK - 1) / MF_BLOCK;
+    knn_rowpar_kernel<64><<<nb, MF_BLOCK, 0, s>>>((const float*)vocab, row_id, n_rows, (const float*)queries, fail_list, fail_count,
+                                                  (uint64_t*)partial);
+    knn_rowpar_merge_kernel<<<MF_ROWPAR_MAX, 64, 0, s>>>((const uint64_t*)partial, nb, fail_list, fail_count, row_id, out_row, out_word, out_dist);
     return hipGetLastError();
 }
 

@@ -25,11 +25,11 @@ size_t knn_partial_bytes(const KnnPlan& p);   // [n_blocks][2][qpad] keys
 // List mode (qlist/qcount device pointers, f32 dim 64/128 only): only the queries qlist[0 .. *qcount) are searched.
 hipError_t launch_knn2_partial(int dtype, int dim, const void* vocab, const int32_t* row_id, const void* queries,
                                const KnnPlan& p, uint64_t* partial, hipStream_t s, const int32_t* qlist = nullptr,
-                               const int32_t* qcount = nullptr);
+                               const int32_t* qcount = nullptr, int list_min = 0);   // list mode only runs when *qcount > list_min
 // Merge the partial keys: out_row[q*2] (row or -1), out_word[q*2] (row_id[row] or 0), out_dist[q*2] (float, -1 = none)
 hipError_t launch_knn2_merge(int dtype, const KnnPlan& p, const uint64_t* partial, const int32_t* row_id,
                              int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s, const int32_t* qlist = nullptr,
-                             const int32_t* qcount = nullptr);
+                             const int32_t* qcount = nullptr, int list_min = 0);
 
 // ---- squared-L2 2-NN on the matrix cores (knn_mfma_kernels.hip): MFMA filter + exact re-rank + certificate.
 // Queries whose result cannot be certified are appended to fail_list / fail_count for the exact scan (list mode above).
@@ -41,6 +41,11 @@ size_t knn_mfma_partial_bytes(const MfmaPlan& p);
 hipError_t launch_row_norms(const void* vocab, const int32_t* row_id, int first, int n, int dim, float* norm, uint32_t* norm_max_bits,
                             hipStream_t s);
 hipError_t launch_norm_tombstone(float* norm, const int32_t* rows, int n, hipStream_t s);
+// exact redo of the (<= knn_rowpar_max()) queries in fail_list with one lane per vocabulary row; more than that is left alone
+size_t knn_rowpar_partial_bytes(int n_rows);
+int knn_rowpar_max();
+hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, int n_rows, const void* queries, const int32_t* fail_list,
+                             const int32_t* fail_count, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s);
 hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, const uint32_t* norm_max_bits, const int32_t* row_id,
                            const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist,
                            int32_t* fail_list, int32_t* fail_count, hipStream_t s);

@@ -142,7 +142,8 @@ def test_selfdist_bit_exact_and_symmetric(oracle, kind):
     eng.close()
 
 
-def test_knn2_mfma_filter_matches_exact_scan_and_falls_back_on_clusters(oracle, monkeypatch):
+@pytest.mark.parametrize("many_clusters", [False, True])
+def test_knn2_mfma_filter_matches_exact_scan_and_falls_back_on_clusters(oracle, monkeypatch, many_clusters):
     """f32 dim-64 vocabularies >= 256 rows go through the MFMA filter + exact re-rank.  Results must be the exact scan's,
     bit for bit; a cluster of identical rows around a query cannot be certified and must take the exact-scan fallback."""
     import rtabmap_amd
@@ -152,6 +153,8 @@ def test_knn2_mfma_filter_matches_exact_scan_and_falls_back_on_clusters(oracle, 
     v[::500] = v[123]
     q[7] = v[123]
     q[8] = v[123] + np.float32(1e-4)
+    if many_clusters:                    # > 32 uncertifiable queries: served by the list-mode scan instead of the row-parallel kernel
+        q[100:160] = v[123] + (np.arange(60, dtype=np.float32)[:, None] * np.float32(1e-5))
     ids = np.arange(1, 20001, dtype=np.int32)
     res = {}
     for mode in ("mfma", "valu"):
@@ -161,7 +164,7 @@ def test_knn2_mfma_filter_matches_exact_scan_and_falls_back_on_clusters(oracle, 
         res[mode] = eng.knn2(q)
         fb = eng.stats()["knn_last_fallback_queries"]
         if mode == "mfma":
-            assert 1 <= fb < 50, fb          # the cluster queries, not everything
+            assert (33 <= fb < 120) if many_clusters else (1 <= fb <= 32), fb          # the cluster queries, not everything
         else:
             assert fb == 0
         _check(eng, oracle, v, ids, q)
