@@ -61,16 +61,10 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
         LCD_HIP(h, dreserve(h, h->d_fail_count, 64));
         LCD_HIP(h, launch_knn_mfma(h->kdim, vocab, h->row_norm.as<float>(), h->norm_max.as<uint32_t>(), row_id, d_queries, mp, h->d_partial2.p,
                                    o_row, o_word, o_dist, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(), h->stream));
-        // the queries the certificate rejected are redone exactly: a few -> row-parallel kernel (whole chip per query),
-        // many -> the query-parallel scan in list mode.  Usually none: both launches leave at once.
-        LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows)));
+        // the queries the certificate rejected are redone exactly by the row-parallel kernel (usually none: it leaves at once)
+        LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
         LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(),
                                      h->d_partial3.p, o_row, o_word, o_dist, h->stream));
-        LCD_HIP(h, dreserve(h, h->d_partial, knn_partial_bytes(p)));
-        LCD_HIP(h, launch_knn2_partial(h->dtype, h->kdim, vocab, row_id, d_queries, p, h->d_partial.as<uint64_t>(), h->stream,
-                                       h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(), knn_rowpar_max()));
-        LCD_HIP(h, launch_knn2_merge(h->dtype, p, h->d_partial.as<uint64_t>(), row_id, o_row, o_word, o_dist, h->stream,
-                                     h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(), knn_rowpar_max()));
     } else {
         LCD_HIP(h, dreserve(h, h->d_partial, knn_partial_bytes(p)));
         LCD_HIP(h, launch_knn2_partial(h->dtype, h->kdim, vocab, row_id, d_queries, p, h->d_partial.as<uint64_t>(), h->stream));

@@ -7,15 +7,15 @@
 //      v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate: an exact fp32 FMA chain at the matrix-core rate (157 TFLOP/s,
 //      MI355X_MICROARCH.md).  |v|^2 and |q|^2 ride along as one extra k-step (A = (|v_i|^2, 1), B = (1, |q_j|^2)) and
 //      the queries are pre-scaled by -2, so the accumulator IS the approximate squared distance.  Every lane keeps a
-//      running top-2 of packed (distance << 32 | row) keys for the queries it sees -- no cross-lane traffic in the loop.
+//      running top-3 of packed (distance << 32 | row) keys for the queries it sees -- no cross-lane traffic in the loop.
 //   2. RE-RANK (knn_mfma_rerank_kernel): per query the 16 best filter candidates are re-evaluated with the reference's
 //      own arithmetic (bit-exact distances, lower row wins ties) and the two best are returned.  The result is PROVEN
 //      equal to the exact scan when every row the filter dropped is certainly farther than the exact second neighbour:
 //            bound - eps > d2_exact,
 //      bound = the smallest filter score any dropped row can have (tracked through every merge level), eps = a bound on
 //      |filter score - reference distance| (fp32 summation error of both orders, see eps_for()).  Queries that fail the
-//      certificate (near-duplicate clusters) are re-done exactly -- a few by knn_rowpar_kernel (one lane per vocabulary
-//      row), many by the VALU scan in list mode (knn2_kernels.hip) -- so the output is always the reference's bit-exact answer.
+//      certificate (near-duplicate clusters) are re-done exactly by knn_rowpar_kernel (one lane per vocabulary row, the
+//      whole chip on each rejected query), so the output is always the reference's bit-exact answer.
 //
 // Tiling (wave64, CDNA4): one wave = 64 queries (two 32-query MFMA column groups, their k-halves resident in VGPRs for
 // the whole kernel) x a strip of 32-row vocabulary tiles.  A operand = 32 rows x 64 floats straight from global memory
@@ -32,7 +32,6 @@ constexpr int MF_BLOCK = 256;
 constexpr int MF_WAVES = 4;
 constexpr int MF_KEEP = 4;     // keys kept per (row block, query)
 constexpr int MF_CAND = 16;    // candidates re-ranked exactly per query
-constexpr int MF_ROWPAR_MAX = 32;   // up to this many uncertified queries are redone by the row-parallel exact kernel
 
 __device__ __forceinline__ void top2_push(uint64_t& best, uint64_t& second, uint64_t k) {
     const uint64_t hi = best > k ? best : k;
@@ -72,6 +71,63 @@ __global__ void norm_tombstone_kernel(float* __restrict__ norm, const int32_t* _
 }
 
 // ------------------------------------------------------------------------------------------------ filter
+// In-loop candidate key: 32 bits = the score's float bits with the low MF_IDX_BITS mantissa bits replaced by the
+// candidate's position inside the wave's strip (tile-in-strip << 4 | accumulator register).  Scores are >= 0, so the keys
+// order like unsigned integers and a top-3 update is five v_min_u32 / v_max_u32.  Truncation only LOWERS a key
+// (by < 2^-16 relative): a dropped row's true score is >= its key >= the bound derived from kept keys, so the
+// certificate stays valid; at most MF_STRIP_TILES tiles per wave strip keep the index in 7 bits.
+constexpr int MF_IDX_BITS = 7;
+constexpr int MF_STRIP_TILES = 1 << (MF_IDX_BITS - 4);
+constexpr uint32_t MF_IDX_MASK = (1u << MF_IDX_BITS) - 1;
+
+__device__ __forceinline__ void top3_push32(uint32_t& k0, uint32_t& k1, uint32_t& k2, uint32_t k) {
+    const uint32_t h1 = max(k0, k);
+    k0 = min(k0, k);
+    const uint32_t h2 = max(k1, h1);
+    k1 = min(k1, h1);
+    k2 = min(k2, h2);
+}
+// strip key -> merge key (score bits << 32 | vocabulary row)
+__device__ __forceinline__ uint64_t widen_key(uint32_t k, int t_begin, int half) {
+    if (k == 0xFFFFFFFFu) return KEY_NONE;
+    const uint32_t idx = k & MF_IDX_MASK, r = idx & 15u;
+    const uint32_t row = (uint32_t)(t_begin + (int)(idx >> 4)) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)half;
+    return ((uint64_t)(k & ~MF_IDX_MASK) << 32) | row;
+}
+
+template <int KH>
+__device__ __forceinline__ void load_a_tile(const float* __restrict__ vocab, const float* __restrict__ row_norm, int n_rows, int t, int col,
+                                            int half, float (&a)[KH], float& a_aug) {
+    const int row = t * 32 + col;
+    const int rsrc = min(row, n_rows - 1);
+    const float4* src = reinterpret_cast<const float4*>(vocab + (size_t)rsrc * (2 * KH) + half * KH);
+#pragma unroll
+    for (int v = 0; v < KH / 4; ++v) {
+        const float4 x = src[v];
+        a[4 * v + 0] = x.x; a[4 * v + 1] = x.y; a[4 * v + 2] = x.z; a[4 * v + 3] = x.w;
+    }
+    const float vn = row < n_rows ? row_norm[row] : __int_as_float(0x7f800000);
+    a_aug = half == 0 ? vn : 1.0f;                  // A[i][k0] = |v_i|^2, A[i][k1] = 1
+}
+
+// one 32-row tile against one 32-query group: 33 MFMAs
+template <int KH>
+__device__ __forceinline__ f32x16 mfma_group(const float (&a)[KH], float a_aug, const float (&b)[KH], float b_aug) {
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug, acc, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < KH; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], acc, 0, 0, 0);
+    return acc;
+}
+// acc[r] = approximate squared distance between the lane's query and row t*32 + (r&3) + 8*(r>>2) + 4*half
+__device__ __forceinline__ void push_group(const f32x16& acc, uint32_t tl, uint32_t& k0, uint32_t& k1, uint32_t& k2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t sbits = (uint32_t)max(__float_as_int(acc[r]), 0);   // clamp tiny negative scores (sign bit set) to +0
+        top3_push32(k0, k1, k2, (sbits & ~MF_IDX_MASK) | (tl << 4) | (uint32_t)r);
+    }
+}
+
 // partial_keys [n_blocks][MF_KEEP][qpad] u64, partial_lmin [n_blocks][qpad] f32 bits
 template <int DIM>
 __global__ __launch_bounds__(MF_BLOCK, 2) void knn_mfma_filter_kernel(const float* __restrict__ vocab, const float* __restrict__ row_norm,
@@ -109,42 +165,41 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void knn_mfma_filter_kernel(const floa
     const int t_begin = min(tile0 + wave * per_wave, tile1);
     const int t_end = min(t_begin + per_wave, tile1);
 
-    uint64_t best[2] = {KEY_NONE, KEY_NONE}, second[2] = {KEY_NONE, KEY_NONE};
-    for (int t = t_begin; t < t_end; ++t) {
-        const int row = t * 32 + col;
-        const int rsrc = min(row, n_rows - 1);
-        // A operand: this lane's half of its vocabulary row
-        float a[KH];
-        const float4* src = reinterpret_cast<const float4*>(vocab + (size_t)rsrc * DIM + half * KH);
-#pragma unroll
-        for (int v = 0; v < KH / 4; ++v) {
-            const float4 x = src[v];
-            a[4 * v + 0] = x.x; a[4 * v + 1] = x.y; a[4 * v + 2] = x.z; a[4 * v + 3] = x.w;
-        }
-        const float vn = row < n_rows ? row_norm[row] : __int_as_float(0x7f800000);
-        const float a_aug = half == 0 ? vn : 1.0f;                  // A[i][k0] = |v_i|^2, A[i][k1] = 1
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug[g], acc, 0, 0, 0);
-#pragma unroll
-            for (int k = 0; k < KH; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[g][k], acc, 0, 0, 0);
-            // acc[r] = approximate squared distance between query (g, col) and row t*32 + (r&3) + 8*(r>>2) + 4*half
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t vrow = (uint32_t)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
-                const float s = fmaxf(acc[r], 0.0f);
-                top2_push(best[g], second[g], ((uint64_t)__float_as_uint(s) << 32) | vrow);
-            }
+    // every lane keeps its three best keys per query group: a row the lane drops is no better than its third key
+    uint32_t k0[2] = {~0u, ~0u}, k1[2] = {~0u, ~0u}, k2[2] = {~0u, ~0u};
+    // Software pipeline: the A tile of step t+1 is loaded while tile t occupies the matrix pipe, and the VALU top-3
+    // update of one accumulator is issued under the 33 MFMAs of the next one (acc_prev / acc_cur).
+    float a0[KH], a1[KH];
+    float aug0 = 0.0f, aug1 = 0.0f;
+    if (t_begin < t_end) {
+        load_a_tile<KH>(vocab, row_norm, n_rows, t_begin, col, half, a0, aug0);
+        f32x16 pend = mfma_group<KH>(a0, aug0, b[0], b_aug[0]);      // (tile t_begin, group 0) in flight
+        int pend_tl = 0;
+        for (int t = t_begin; t < t_end; t += 2) {
+            const bool has1 = t + 1 < t_end, has2 = t + 2 < t_end;
+            if (has1) load_a_tile<KH>(vocab, row_norm, n_rows, t + 1, col, half, a1, aug1);
+            f32x16 cur = mfma_group<KH>(a0, aug0, b[1], b_aug[1]);   // (t, group 1)
+            push_group(pend, (uint32_t)pend_tl, k0[0], k1[0], k2[0]);    // (t, group 0) under those MFMAs
+            if (!has1) { push_group(cur, (uint32_t)(t - t_begin), k0[1], k1[1], k2[1]); break; }
+            pend = mfma_group<KH>(a1, aug1, b[0], b_aug[0]);         // (t+1, group 0)
+            push_group(cur, (uint32_t)(t - t_begin), k0[1], k1[1], k2[1]);
+            if (has2) load_a_tile<KH>(vocab, row_norm, n_rows, t + 2, col, half, a0, aug0);
+            cur = mfma_group<KH>(a1, aug1, b[1], b_aug[1]);          // (t+1, group 1)
+            push_group(pend, (uint32_t)(t + 1 - t_begin), k0[0], k1[0], k2[0]);
+            if (!has2) { push_group(cur, (uint32_t)(t + 1 - t_begin), k0[1], k1[1], k2[1]); break; }
+            pend = mfma_group<KH>(a0, aug0, b[0], b_aug[0]);         // (t+2, group 0)
+            pend_tl = t + 2 - t_begin;
+            push_group(cur, (uint32_t)(t + 1 - t_begin), k0[1], k1[1], k2[1]);
         }
     }
 
-    // workgroup merge: 8 partitions (4 waves x 2 halves) x top-2 per query -> top-MF_KEEP + the smallest partition second
-    __shared__ uint64_t s_key[64][MF_WAVES * 2][2];
+    // workgroup merge: 8 partitions (4 waves x 2 halves) x top-3 per query -> top-MF_KEEP + the smallest partition third
+    __shared__ uint64_t s_key[64][MF_WAVES * 2][3];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        s_key[g * 32 + col][wave * 2 + half][0] = best[g];
-        s_key[g * 32 + col][wave * 2 + half][1] = second[g];
+        s_key[g * 32 + col][wave * 2 + half][0] = widen_key(k0[g], t_begin, half);
+        s_key[g * 32 + col][wave * 2 + half][1] = widen_key(k1[g], t_begin, half);
+        s_key[g * 32 + col][wave * 2 + half][2] = widen_key(k2[g], t_begin, half);
     }
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -155,9 +210,9 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void knn_mfma_filter_kernel(const floa
         uint32_t lmin = 0x7f800000u;                                 // +inf
         for (int p = 0; p < MF_WAVES * 2; ++p) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < 3; ++e) {
                 uint64_t k = s_key[ql][p][e];
-                if (e == 1) lmin = min(lmin, (uint32_t)min(k >> 32, (uint64_t)0x7f800000u));   // rows hidden behind a partition's top-2
+                if (e == 2) lmin = min(lmin, (uint32_t)min(k >> 32, (uint64_t)0x7f800000u));   // rows hidden behind a partition's top-3
 #pragma unroll
                 for (int i = 0; i < MF_KEEP; ++i) {                  // sorted insertion
                     const uint64_t lo = keep[i] < k ? keep[i] : k;
@@ -295,17 +350,22 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
 }
 
 // ------------------------------------------------------------------------------------------------ row-parallel exact scan
-// The handful of queries the certificate rejects are redone exactly with the WHOLE chip on each of them: one lane per
-// vocabulary row (the row stays in VGPRs), the listed queries are looped over (query broadcast from LDS), the
-// workgroup reduces to its two best keys per query.  n_fail > MF_ROWPAR_MAX is left to the query-parallel list-mode scan.
+// The queries the certificate rejects (usually none, sometimes a handful) are redone exactly with the WHOLE chip on
+// each of them: one lane per vocabulary row (the row stays in VGPRs), the listed queries are looped over (query
+// broadcast from LDS), every workgroup reduces to its two best keys per query and the LAST workgroup to arrive
+// (agent-scope release / acquire around a counter, cdna_hip_programming.md guideline 16) merges them and writes the
+// result into the query's own slot -- one launch, which leaves at once when the list is empty.
 template <int DIM>
 __global__ __launch_bounds__(MF_BLOCK) void knn_rowpar_kernel(const float* __restrict__ vocab, const int32_t* __restrict__ row_id, int n_rows,
                                                               const float* __restrict__ queries, const int32_t* __restrict__ fail_list,
-                                                              const int32_t* __restrict__ fail_count, uint64_t* __restrict__ partial) {
+                                                              int32_t* __restrict__ fail_count /* [0] count, [1] arrivals */,
+                                                              uint64_t* __restrict__ partial, int32_t* __restrict__ out_row,
+                                                              int32_t* __restrict__ out_word, float* __restrict__ out_dist) {
     const int nf = fail_count[0];
-    if (nf <= 0 || nf > MF_ROWPAR_MAX) return;
+    if (nf <= 0) return;
     __shared__ float s_q[DIM];
     __shared__ uint64_t s_k[MF_WAVES][2];
+    __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * MF_BLOCK + threadIdx.x;
     const bool live = row < n_rows && row_id[row] != 0;
@@ -348,34 +408,41 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_rowpar_kernel(const float* __res
             partial[((size_t)f * gridDim.x + blockIdx.x) * 2 + 1] = second;
         }
     }
-}
-// one wave per listed query: merge the per-workgroup keys, write the result into the query's own slot
-__global__ __launch_bounds__(64) void knn_rowpar_merge_kernel(const uint64_t* __restrict__ partial, int n_blocks, const int32_t* __restrict__ fail_list,
-                                                              const int32_t* __restrict__ fail_count, const int32_t* __restrict__ row_id,
-                                                              int32_t* __restrict__ out_row, int32_t* __restrict__ out_word,
-                                                              float* __restrict__ out_dist) {
-    const int nf = fail_count[0];
-    if (nf <= 0 || nf > MF_ROWPAR_MAX || (int)blockIdx.x >= nf) return;
-    const int f = blockIdx.x, lane = threadIdx.x;
-    uint64_t best = KEY_NONE, second = KEY_NONE;
-    for (int c = lane; c < n_blocks * 2; c += 64) top2_push(best, second, partial[(size_t)f * n_blocks * 2 + c]);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const uint64_t ob = shfl_xor_u64(best, m), os = shfl_xor_u64(second, m);
-        top2_push(best, second, ob);
-        top2_push(best, second, os);
+    // publish this workgroup's keys, find out whether it is the last one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(&fail_count[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == (int)gridDim.x - 1;
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    if (lane == 0) {
-        const int qo = fail_list[f];
-        const uint64_t k[2] = {best, second};
+    __syncthreads();
+    if (!s_last) return;
+    // last workgroup: one wave per listed query merges the gridDim.x * 2 keys
+    const int n_keys = (int)gridDim.x * 2;
+    for (int f = wave; f < nf; f += MF_WAVES) {
+        uint64_t best = KEY_NONE, second = KEY_NONE;
+        for (int c = lane; c < n_keys; c += 64) top2_push(best, second, partial[(size_t)f * n_keys + c]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (k[j] == KEY_NONE) { out_row[2 * qo + j] = -1; out_word[2 * qo + j] = 0; out_dist[2 * qo + j] = -1.0f; }
-            else {
-                const uint32_t row = (uint32_t)k[j];
-                out_row[2 * qo + j] = (int32_t)row;
-                out_word[2 * qo + j] = row_id[row];
-                out_dist[2 * qo + j] = __uint_as_float((uint32_t)(k[j] >> 32));
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint64_t ob = shfl_xor_u64(best, m), os = shfl_xor_u64(second, m);
+            top2_push(best, second, ob);
+            top2_push(best, second, os);
+        }
+        if (lane == 0) {
+            const int qo = fail_list[f];
+            const uint64_t k[2] = {best, second};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (k[j] == KEY_NONE) { out_row[2 * qo + j] = -1; out_word[2 * qo + j] = 0; out_dist[2 * qo + j] = -1.0f; }
+                else {
+                    const uint32_t r = (uint32_t)k[j];
+                    out_row[2 * qo + j] = (int32_t)r;
+                    out_word[2 * qo + j] = row_id[r];
+                    out_dist[2 * qo + j] = __uint_as_float((uint32_t)(k[j] >> 32));
+                }
             }
         }
     }
@@ -401,6 +468,7 @@ MfmaPlan knn_mfma_plan(int q, int n_rows) {
     int tpb = (n_tiles + nb - 1) / nb;
     tpb = (tpb + MF_WAVES - 1) / MF_WAVES * MF_WAVES;               // equal strips for the 4 waves
     if (tpb < MF_WAVES) tpb = MF_WAVES;
+    if (tpb > MF_STRIP_TILES * MF_WAVES) tpb = MF_STRIP_TILES * MF_WAVES;   // the in-loop keys index at most 8 tiles per wave
     p.tiles_per_block = tpb;
     p.n_blocks = n_tiles > 0 ? (n_tiles + tpb - 1) / tpb : 0;
     return p;
@@ -428,7 +496,7 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
     if (p.q == 0) return hipSuccess;
     uint64_t* pk = (uint64_t*)partial;
     uint32_t* pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * MF_KEEP * p.qpad);
-    hipError_t e = hipMemsetAsync(fail_count, 0, 4, s);
+    hipError_t e = hipMemsetAsync(fail_count, 0, 8, s);   // [0] rejected queries, [1] arrival counter of the row-parallel redo
     if (e != hipSuccess) return e;
     if (p.n_blocks > 0) {
         dim3 grid(p.n_blocks, p.qpad / 64);
@@ -443,16 +511,14 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
     return hipGetLastError();
 }
 
-size_t knn_rowpar_partial_bytes(int n_rows) { return (size_t)MF_ROWPAR_MAX * ((n_rows + MF_BLOCK - 1) / MF_BLOCK + 1) * 2 * sizeof(uint64_t); }
-int knn_rowpar_max() { return MF_ROWPAR_MAX; }
+size_t knn_rowpar_partial_bytes(int n_rows, int q) { return (size_t)(q > 0 ? q : 1) * ((n_rows + MF_BLOCK - 1) / MF_BLOCK + 1) * 2 * sizeof(uint64_t); }
 
 hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, int n_rows, const void* queries, const int32_t* fail_list,
-                             const int32_t* fail_count, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s) {
+                             int32_t* fail_count, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s) {
     if (dim != 64 || n_rows <= 0) return hipErrorInvalidValue;
     const int nb = (n_rows + MF_BLOCK - 1) / MF_BLOCK;
     knn_rowpar_kernel<64><<<nb, MF_BLOCK, 0, s>>>((const float*)vocab, row_id, n_rows, (const float*)queries, fail_list, fail_count,
-                                                  (uint64_t*)partial);
-    knn_rowpar_merge_kernel<<<MF_ROWPAR_MAX, 64, 0, s>>>((const uint64_t*)partial, nb, fail_list, fail_count, row_id, out_row, out_word, out_dist);
+                                                  (uint64_t*)partial, out_row, out_word, out_dist);
     return hipGetLastError();
 }
 

@@ -41,11 +41,10 @@ size_t knn_mfma_partial_bytes(const MfmaPlan& p);
 hipError_t launch_row_norms(const void* vocab, const int32_t* row_id, int first, int n, int dim, float* norm, uint32_t* norm_max_bits,
                             hipStream_t s);
 hipError_t launch_norm_tombstone(float* norm, const int32_t* rows, int n, hipStream_t s);
-// exact redo of the (<= knn_rowpar_max()) queries in fail_list with one lane per vocabulary row; more than that is left alone
-size_t knn_rowpar_partial_bytes(int n_rows);
-int knn_rowpar_max();
+// exact redo of the queries in fail_list (fail_count[0] of them; fail_count[1] is scratch) with one lane per vocabulary row
+size_t knn_rowpar_partial_bytes(int n_rows, int q);
 hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, int n_rows, const void* queries, const int32_t* fail_list,
-                             const int32_t* fail_count, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s);
+                             int32_t* fail_count, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s);
 hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, const uint32_t* norm_max_bits, const int32_t* row_id,
                            const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist,
                            int32_t* fail_list, int32_t* fail_count, hipStream_t s);

@@ -153,7 +153,7 @@ def test_knn2_mfma_filter_matches_exact_scan_and_falls_back_on_clusters(oracle, 
     v[::500] = v[123]
     q[7] = v[123]
     q[8] = v[123] + np.float32(1e-4)
-    if many_clusters:                    # > 32 uncertifiable queries: served by the list-mode scan instead of the row-parallel kernel
+    if many_clusters:                    # many uncertifiable queries at once
         q[100:160] = v[123] + (np.arange(60, dtype=np.float32)[:, None] * np.float32(1e-5))
     ids = np.arange(1, 20001, dtype=np.int32)
     res = {}
