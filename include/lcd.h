@@ -161,6 +161,18 @@ int lcd_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, fl
                   float N, int32_t* d_word_ids, float* d_likelihood, int64_t likelihood_capacity);
 /* lcd_knn2 with device-resident queries and outputs (d_word_ids[q*2], d_dist[q*2]); enqueued, not synchronised */
 int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_ids, float* d_dist);
+/* ---- vocabulary sharded by word-ID range over several engines/GPUs (one handle per rank).
+ * Every rank holds a consecutive id range of the vocabulary and the references of those words; every rank registers
+ * every signature (same order => same slots).  Per frame: (1) lcd_shard_knn2_dev on each rank, (2) all-gather of the
+ * 16-byte candidate records, (3) lcd_shard_frame_dev on each rank (merge + same-frame resolution, replicated; registers the
+ * frame with the words THIS rank owns; integer partial likelihood into d_lfix), (4) all-reduce(sum, int64) of d_lfix --
+ * order-free, so the result equals the single-GPU one bit for bit -- (5) lcd_finalize_dev. */
+typedef struct lcd_shard_cand { uint64_t key; int32_t word; int32_t wslot; } lcd_shard_cand;
+int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shard_cand* d_cand /* [q*2] */);
+int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, float nndr_ratio, int32_t sig_id, float N,
+                        int rank, int world, const lcd_shard_cand* d_all_cand /* [world*q*2], rank-major */,
+                        int64_t total_live_rows, int32_t* d_word_ids, int64_t* d_lfix, int64_t lfix_capacity);
+int lcd_finalize_dev(lcd_engine* h, int64_t* d_lfix, int64_t n, float* d_likelihood);
 /* slot table: d_slot_sig[slot] = signature id (0 = retired slot), n_slots = number of slots in use */
 int lcd_slots_dev(lcd_engine* h, const int32_t** d_slot_sig, int64_t* n_slots);
 /* the engine's hipStream_t (so a caller can record events around enqueued work) */

@@ -21,7 +21,7 @@ SYMBOLS = [
     "lcd_vocab_clear", "lcd_vocab_append", "lcd_vocab_remove", "lcd_vocab_rebuild", "lcd_vocab_count", "lcd_vocab_read",
     "lcd_knn2", "lcd_selfdist", "lcd_quantize", "lcd_find_nn",
     "lcd_sig_add", "lcd_sig_remove", "lcd_sig_add_bulk", "lcd_sig_count", "lcd_word_nrefs",
-    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_frame_dev", "lcd_knn2_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats",
+    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats",
 ]
 
 
@@ -84,6 +84,9 @@ def load():
     L.lcd_adjust_likelihood.argtypes = [vp, vp, C.c_int, f32]
     L.lcd_frame_dev.argtypes = [vp, vp, C.c_int, C.c_int, f32, i32, f32, vp, vp, i64]
     L.lcd_knn2_dev.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.lcd_shard_knn2_dev.argtypes = [vp, vp, C.c_int, vp]
+    L.lcd_shard_frame_dev.argtypes = [vp, vp, C.c_int, C.c_int, f32, i32, f32, C.c_int, C.c_int, vp, i64, vp, vp, i64]
+    L.lcd_finalize_dev.argtypes = [vp, vp, i64, vp]
     L.lcd_slots_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.lcd_stream.argtypes = [vp]
     L.lcd_stream.restype = vp
@@ -244,6 +247,18 @@ class Engine:
 
     def knn2_dev(self, d_queries_ptr, q, d_word_ids_ptr, d_dist_ptr):
         self._ck(self.L.lcd_knn2_dev(self.h, d_queries_ptr, q, d_word_ids_ptr, d_dist_ptr))
+
+    def shard_knn2_dev(self, d_desc_ptr, q, d_cand_ptr):
+        self._ck(self.L.lcd_shard_knn2_dev(self.h, d_desc_ptr, q, d_cand_ptr))
+
+    def shard_frame_dev(self, d_desc_ptr, q, sig_id, N, rank, world, d_all_cand_ptr, total_live_rows, d_word_ids_ptr, d_lfix_ptr,
+                        lfix_capacity, incremental=True, new_words_compared=True, nndr=0.8):
+        flags = (LCD_Q_INCREMENTAL if incremental else 0) | (LCD_Q_NEW_WORDS_COMPARED if new_words_compared else 0)
+        self._ck(self.L.lcd_shard_frame_dev(self.h, d_desc_ptr, q, flags, nndr, sig_id, float(N), rank, world, d_all_cand_ptr,
+                                            total_live_rows, d_word_ids_ptr, d_lfix_ptr, lfix_capacity))
+
+    def finalize_dev(self, d_lfix_ptr, n, d_like_ptr):
+        self._ck(self.L.lcd_finalize_dev(self.h, d_lfix_ptr, n, d_like_ptr))
 
     def slots_dev(self):
         p, n = C.c_void_p(), C.c_int64()

@@ -563,6 +563,69 @@ int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_id
     return run_knn2_raw(h, d_queries, q, h->vocab.p, h->row_id.as<int32_t>(), h->n_rows, true, h->d_knn_row.as<int32_t>(), d_word_ids, d_dist);
 }
 
+int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shard_cand* d_cand) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (q <= 0 || !d_descriptors || !d_cand) return h->fail(LCD_ERR_INVALID, "lcd_shard_knn2_dev: bad argument");
+    int rc = run_knn2(h, d_descriptors, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), h->n_rows, h->d_knn_row,
+                      h->d_knn_word, h->d_knn_dist);
+    if (rc) return rc;
+    LCD_HIP(h, launch_shard_pack(h->d_knn_row.as<int32_t>(), h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
+                                 h->row_wslot.as<int32_t>(), q, d_cand, h->stream));
+    return LCD_OK;
+}
+
+int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, float nndr_ratio, int32_t sig_id, float N, int rank,
+                        int world, const lcd_shard_cand* d_all_cand, int64_t total_live_rows, int32_t* d_word_ids, int64_t* d_lfix,
+                        int64_t lfix_capacity) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (q <= 0 || q > 8192 || !d_descriptors || !d_all_cand || !d_word_ids || world < 1 || world > 64 || rank < 0 || rank >= world)
+        return h->fail(LCD_ERR_INVALID, "lcd_shard_frame_dev: bad argument");
+    Tfidf& t = h->tfidf;
+    if (sig_id != 0 && t.sig_slot.count(sig_id)) return h->fail(LCD_ERR_STATE, "lcd_shard_frame_dev: signature already registered");
+    const int64_t slots_after = t.n_slots + (sig_id != 0 ? 1 : 0);
+    if (d_lfix && lfix_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_shard_frame_dev: lfix buffer too small");
+    LCD_HIP(h, dreserve(h, h->d_knn_row, (size_t)q * 2 * 4));
+    LCD_HIP(h, dreserve(h, h->d_knn_word, (size_t)q * 2 * 4));
+    LCD_HIP(h, dreserve(h, h->d_knn_dist, (size_t)q * 2 * 4));
+    // global 2-NN from the gathered per-rank candidates; d_knn_row holds the postings keys of the neighbours this rank owns
+    LCD_HIP(h, launch_shard_merge(d_all_cand, world, rank, q, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
+                                  h->d_knn_row.as<int32_t>(), h->stream));
+    const int have_index = total_live_rows >= 2 ? 1 : 0;
+    const bool incremental = (flags & LCD_Q_INCREMENTAL) != 0;
+    const bool together = incremental && (flags & LCD_Q_NEW_WORDS_COMPARED);
+    const int ld = (q + 63) / 64 * 64, bw = ld / 32;
+    if (together) {
+        LCD_HIP(h, dreserve(h, h->d_selfdist, (size_t)q * ld * 4));
+        LCD_HIP(h, dreserve(h, h->d_bits, (size_t)q * bw * 4));
+        LCD_HIP(h, launch_selfdist(h->dtype, h->kdim, d_descriptors, q, h->d_selfdist.as<float>(), ld, h->stream, have_index,
+                                   h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), h->d_bits.as<uint32_t>(), bw));
+    }
+    LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
+    const int rflags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0);
+    LCD_HIP(h, launch_resolve(q, rflags, nndr_ratio, have_index, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
+                              together ? h->d_selfdist.as<float>() : nullptr, ld, together ? h->d_bits.as<uint32_t>() : nullptr, bw,
+                              d_word_ids, h->d_n_new.as<int32_t>(), h->stream, h->d_knn_row.as<int32_t>(), nullptr,
+                              h->d_out_wslot.as<int32_t>()));
+    if (sig_id != 0) LCD_HIP(h, t.register_dev(sig_id, h->d_out_wslot.as<int32_t>(), q, q, N));
+    else LCD_HIP(h, t.query_dev(h->d_out_wslot.as<int32_t>(), q, N));
+    if (d_lfix) {
+        LCD_HIP(h, hipMemsetAsync(d_lfix, 0, (size_t)t.n_slots * 8, h->stream));
+        LCD_HIP(h, t.score_partial((unsigned long long*)d_lfix));
+        h->likelihood_launches += 1;
+    }
+    return LCD_OK;
+}
+
+int lcd_finalize_dev(lcd_engine* h, int64_t* d_lfix, int64_t n, float* d_likelihood) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (n < 0 || (n > 0 && (!d_lfix || !d_likelihood))) return h->fail(LCD_ERR_INVALID, "lcd_finalize_dev: bad argument");
+    LCD_HIP(h, h->tfidf.finalize((long long*)d_lfix, (long long)n, d_likelihood));
+    return LCD_OK;
+}
+
 int lcd_slots_dev(lcd_engine* h, const int32_t** d_slot_sig, int64_t* n_slots) {
     LCD_CHECK_HANDLE(h);
     if (d_slot_sig) *d_slot_sig = h->tfidf.slot_sig.as<int32_t>();

@@ -68,6 +68,13 @@ hipError_t launch_findnn_resolve(int q, int flags, float nndr, int have_index, c
                                  const float* knn_dist, int have_extra, const int32_t* extra_word,
                                  const float* extra_dist, int32_t* out_word, hipStream_t s);
 
+// Sharded vocabulary (one rank per word-id range): local candidates -> 16-byte records {u64 key, i32 word, i32 wslot}, and the
+// merge of the all-gathered records [world][q][2] (ties: lower rank, then lower local row); out_wslot is -1 for foreign words.
+hipError_t launch_shard_pack(const int32_t* knn_row, const int32_t* knn_word, const float* knn_dist, const int32_t* row_wslot, int q,
+                             void* out_cand, hipStream_t s);
+hipError_t launch_shard_merge(const void* all_cand, int world, int rank, int q, int32_t* out_word, float* out_dist, int32_t* out_wslot,
+                              hipStream_t s);
+
 // Row gather used by lcd_vocab_rebuild: dst[i] = src[perm[i]] (rows of row_bytes bytes, multiple of 4), ids likewise.
 hipError_t launch_gather_rows(const void* src, const int32_t* src_id, const int32_t* perm, int n, int row_bytes,
                               void* dst, int32_t* dst_id, hipStream_t s);

@@ -154,10 +154,11 @@ __global__ __launch_bounds__(RBLOCK) void resolve_kernel(int q, int flags, float
         out_word[i] = w;                               // fixed dictionary without candidate: 0 ("no entry", :1211-1218)
         if (out_wslot) {
             // postings key of the chosen EXISTING word: it is one of the descriptor's two indexed neighbours
+            // (row_wslot == NULL: knn_row already holds the postings key of each neighbour -- sharded mode)
             int32_t ws = -1;
             if (w > 0) {
-                if (knn_word[2 * i] == w) ws = row_wslot[knn_row[2 * i]];
-                else if (knn_word[2 * i + 1] == w) ws = row_wslot[knn_row[2 * i + 1]];
+                if (knn_word[2 * i] == w) ws = row_wslot ? row_wslot[knn_row[2 * i]] : knn_row[2 * i];
+                else if (knn_word[2 * i + 1] == w) ws = row_wslot ? row_wslot[knn_row[2 * i + 1]] : knn_row[2 * i + 1];
             }
             out_wslot[i] = ws;
         }
@@ -191,6 +192,50 @@ __global__ void findnn_resolve_kernel(int q, int flags, float nndr, int have_ind
         w = c0.id;
     }
     out_word[i] = w;
+}
+
+// ------------------------------------------------------------------------------------------------ sharded vocabulary
+// Word-ID-range sharding: every rank searched its own rows; the all-gathered per-rank candidates
+// cand[rank][q][2] = {key = distance bits << 32 | local row, word id, postings key on the owning rank} are merged here.
+// Global row order = (rank, local row): the lower rank, then the lower row, wins ties -- the single-GPU order when the
+// shards are consecutive id ranges.  out_wslot[q*2] is the postings key if THIS rank owns the neighbour, else -1.
+struct ShardCand { unsigned long long key; int32_t word; int32_t wslot; };
+__global__ void shard_merge_kernel(const ShardCand* __restrict__ cand, int world, int rank, int q, int32_t* __restrict__ out_word,
+                                   float* __restrict__ out_dist, int32_t* __restrict__ out_wslot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q) return;
+    // composite (distance, rank, local row, slot index) compared lexicographically
+    unsigned long long bk = KEY_NONE, sk = KEY_NONE;
+    int bsrc = -1, ssrc = -1;
+    for (int r = 0; r < world; ++r) {
+        for (int j = 0; j < 2; ++j) {
+            const ShardCand c = cand[((size_t)r * q + i) * 2 + j];
+            if (c.key == KEY_NONE || c.word == 0) continue;
+            const unsigned long long k = (c.key & 0xFFFFFFFF00000000ull) | ((unsigned long long)r << 26) | (c.key & 0x3FFFFFFull);
+            const int src = (r * q + i) * 2 + j;
+            if (k < bk) { sk = bk; ssrc = bsrc; bk = k; bsrc = src; }
+            else if (k < sk) { sk = k; ssrc = src; }
+        }
+    }
+    const int srcs[2] = {bsrc, ssrc};
+    for (int j = 0; j < 2; ++j) {
+        if (srcs[j] < 0) { out_word[2 * i + j] = 0; out_dist[2 * i + j] = -1.0f; out_wslot[2 * i + j] = -1; continue; }
+        const ShardCand c = cand[srcs[j]];
+        out_word[2 * i + j] = c.word;
+        out_dist[2 * i + j] = __uint_as_float((uint32_t)(c.key >> 32));
+        out_wslot[2 * i + j] = (srcs[j] / (2 * q)) == rank ? c.wslot : -1;
+    }
+}
+// local candidates of one rank in ShardCand form (dist as float already converted for Hamming by the merge kernel)
+__global__ void shard_pack_kernel(const int32_t* __restrict__ knn_row, const int32_t* __restrict__ knn_word, const float* __restrict__ knn_dist,
+                                  const int32_t* __restrict__ row_wslot, int q2, ShardCand* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q2) return;
+    ShardCand c;
+    const int row = knn_row[i];
+    if (row < 0) { c.key = KEY_NONE; c.word = 0; c.wslot = -1; }
+    else { c.key = ((unsigned long long)__float_as_uint(knn_dist[i]) << 32) | (uint32_t)row; c.word = knn_word[i]; c.wslot = row_wslot[row]; }
+    out[i] = c;
 }
 
 // ------------------------------------------------------------------------------------------------ vocabulary upkeep
@@ -230,6 +275,19 @@ hipError_t launch_findnn_resolve(int q, int flags, float nndr, int have_index, c
     if (q <= 0) return hipSuccess;
     findnn_resolve_kernel<<<(q + 255) / 256, 256, 0, s>>>(q, flags, nndr, have_index, knn_word, knn_dist, have_extra,
                                                           extra_word, extra_dist, out_word);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_pack(const int32_t* knn_row, const int32_t* knn_word, const float* knn_dist, const int32_t* row_wslot, int q,
+                             void* out_cand, hipStream_t s) {
+    if (q <= 0) return hipSuccess;
+    shard_pack_kernel<<<(2 * q + 255) / 256, 256, 0, s>>>(knn_row, knn_word, knn_dist, row_wslot, 2 * q, (ShardCand*)out_cand);
+    return hipGetLastError();
+}
+hipError_t launch_shard_merge(const void* all_cand, int world, int rank, int q, int32_t* out_word, float* out_dist, int32_t* out_wslot,
+                              hipStream_t s) {
+    if (q <= 0) return hipSuccess;
+    shard_merge_kernel<<<(q + 255) / 256, 256, 0, s>>>((const ShardCand*)all_cand, world, rank, q, out_word, out_dist, out_wslot);
     return hipGetLastError();
 }
 

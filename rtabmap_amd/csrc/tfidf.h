@@ -98,6 +98,9 @@ struct Tfidf {
     hipError_t query_dev(const int32_t* d_wslots, int n, float N);
     // score q_* against every live signature: dense float likelihood over slots [0, n_slots)
     hipError_t score(float* d_likelihood);
+    // the two halves of score(): integer partial sums into a ZEROED caller buffer, and fixed point -> float (re-zeroes the source)
+    hipError_t score_partial(unsigned long long* lfix_target);
+    hipError_t finalize(long long* lfix_src, long long n, float* d_likelihood);
     hipError_t retire(int32_t sig_id);
     hipError_t seal(int b);
     hipError_t ensure_slots(int64_t n);

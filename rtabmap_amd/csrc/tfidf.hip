@@ -564,8 +564,17 @@ static int env_int(const char* name, int dflt) {
 
 hipError_t Tfidf::score(float* d_likelihood) {
     if (n_slots == 0) return hipSuccess;
-    TF_TRY(upload_buckets());
     // lfix is all zero here: zero-initialised on growth and re-zeroed by the previous frame's finalize_kernel
+    TF_TRY(score_partial(lfix.as<unsigned long long>()));
+    finalize_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, stream>>>(lfix.as<long long>(), (long long)n_slots, d_likelihood);
+    return hipGetLastError();
+}
+
+// fixed-point sums of q_* against every live signature, ADDED into lfix_target[0 .. n_slots) (caller provides zeros
+// or a running sum); the multi-GPU path all-reduces these integers before finalize()
+hipError_t Tfidf::score_partial(unsigned long long* lfix_target) {
+    if (n_slots == 0) return hipSuccess;
+    TF_TRY(upload_buckets());
     const int wcap_all = std::max(q_n_ub, 1);
     if (n_list > 0) {
         static const int scb = env_int("LCD_SC_BLOCK", 512);
@@ -576,7 +585,7 @@ hipError_t Tfidf::score(float* d_likelihood) {
         const size_t shmem = (size_t)TF_R * 8 + (size_t)TF_R * 4 + ((size_t)wg_cap * 3 + 1 + scb + 1 + 4) * 4;
         const dim3 grid(n_list, G);
 #define LCD_SCORE_SEALED(B) score_sealed_kernel<B><<<grid, B, shmem, stream>>>(bkt_tab.as<BucketDev>(), bkt_list.as<int32_t>(), G, wg_cap, \
-            q_w.as<uint32_t>(), q_idf.as<float>(), q_meta.as<uint32_t>(), slot_ni.as<uint32_t>(), lfix.as<unsigned long long>())
+            q_w.as<uint32_t>(), q_idf.as<float>(), q_meta.as<uint32_t>(), slot_ni.as<uint32_t>(), lfix_target)
         if (scb == 256) LCD_SCORE_SEALED(256); else if (scb == 512) LCD_SCORE_SEALED(512); else LCD_SCORE_SEALED(1024);
 #undef LCD_SCORE_SEALED
         TF_TRY(hipGetLastError());
@@ -589,10 +598,15 @@ hipError_t Tfidf::score(float* d_likelihood) {
         if ((size_t)bitmap_words * 4 > 128 * 1024) bitmap_words = 0;   // > 1M word slots: idf_tab stamps alone decide
         score_open_kernel<<<blocks, SC_BLOCK, (size_t)std::max(bitmap_words, 1) * 4, stream>>>(
             b.coo_w.as<uint32_t>(), b.coo_pc.as<uint32_t>(), bkt_ne.as<uint32_t>() + bi, (long long)bi * TF_R, bitmap_words, stamp,
-            q_w.as<uint32_t>(), q_meta.as<uint32_t>(), idf_tab.as<uint2>(), slot_ni.as<uint32_t>(), lfix.as<unsigned long long>());
+            q_w.as<uint32_t>(), q_meta.as<uint32_t>(), idf_tab.as<uint2>(), slot_ni.as<uint32_t>(), lfix_target);
         TF_TRY(hipGetLastError());
     }
-    finalize_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, stream>>>(lfix.as<long long>(), (long long)n_slots, d_likelihood);
+    return hipSuccess;
+}
+
+hipError_t Tfidf::finalize(long long* lfix_src, long long n, float* d_likelihood) {
+    if (n <= 0) return hipSuccess;
+    finalize_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(lfix_src, n, d_likelihood);
     return hipGetLastError();
 }
 

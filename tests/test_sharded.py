@@ -1,0 +1,131 @@
+"""Multi-process coverage of the sharded (word-ID range) path.
+
+CPU (gloo, world_size 2): the partition arithmetic and the collective wrappers of rtabmap_amd/sharded.py.
+GPU (-m gpu; 2 ranks sharing the one GPU of the test box, gloo staging): the full sharded frame path must give the same
+word ids as the single-GPU engine and a BIT-IDENTICAL likelihood (integer partial sums are order-free)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _cpu_worker(rank, world, port, out):
+    _init(rank, world, port)
+    from rtabmap_amd.sharded import shard_bounds
+    b = shard_bounds(49000, world)
+    # all-gather of per-rank candidate records and all-reduce of int64 partial sums, as the frame path issues them
+    cand = torch.full((8,), rank + 1, dtype=torch.int64)
+    parts = [torch.empty_like(cand) for _ in range(world)]
+    dist.all_gather(parts, cand)
+    lfix = torch.arange(5, dtype=torch.int64) * (rank + 1)
+    dist.all_reduce(lfix, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        out.put((b, torch.cat(parts).tolist(), lfix.tolist()))
+    dist.destroy_process_group()
+
+
+def test_partition_and_collectives_gloo_world2():
+    from rtabmap_amd.sharded import shard_bounds
+    assert shard_bounds(10, 3) == [0, 4, 7, 10]
+    assert shard_bounds(49000, 8)[-1] == 49000 and all(b2 - b1 == 6125 for b1, b2 in zip(shard_bounds(49000, 8), shard_bounds(49000, 8)[1:]))
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cpu_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    b, gathered, summed = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert b == [0, 24500, 49000]
+    assert gathered == [1] * 8 + [2] * 8
+    assert summed == [0, 3, 6, 9, 12]
+
+
+def _gpu_worker(rank, world, port, out):
+    _init(rank, world, port)
+    torch.cuda.set_device(0)
+    import rtabmap_amd
+    from rtabmap_amd import synth
+    from rtabmap_amd.sharded import ShardedLoopClosure
+    n_words, n_sig, q = 6000, 700, 160
+    vocab = synth.vocab_surf(n_words)
+    ids = np.arange(1, n_words + 1, dtype=np.int32)
+    words = synth.zipf_words(n_sig, q, n_words, seed=3)
+    sig_ids = np.arange(1, n_sig + 1, dtype=np.int32)
+    offsets = np.arange(0, (n_sig + 1) * q, q, dtype=np.int64)
+    sh = ShardedLoopClosure("f32", 64, rank=rank, world=world, device=0, stream=torch.cuda.Stream())
+    sh.load_vocabulary(vocab, ids)
+    sh.add_signatures_bulk(sig_ids, offsets, words.reshape(-1))
+    res = []
+    for t in range(4):
+        desc = synth.frame_from_signature(vocab, words[37 * t + 5], seed=t)
+        w, like = sh.frame(torch.from_numpy(desc).cuda(), n_sig + 1 + t, float(n_sig + 1 + t))
+        torch.cuda.synchronize()
+        res.append((w.cpu().numpy().copy(), like.cpu().numpy().copy()))
+        if t == 2:
+            sh.retire(3)
+    sh.close()
+    if rank == 0:
+        # single-GPU engine on the same inputs
+        eng = rtabmap_amd.Engine("f32", 64)
+        eng.vocab_append(vocab, ids)
+        eng.sig_add_bulk(sig_ids, offsets, words.reshape(-1))
+        d_words = torch.zeros(q, dtype=torch.int32, device="cuda")
+        ok = True
+        msgs = []
+        for t in range(4):
+            desc = synth.frame_from_signature(vocab, words[37 * t + 5], seed=t)
+            d = torch.from_numpy(desc).cuda()
+            cap = n_sig + 16
+            d_like = torch.zeros(cap, dtype=torch.float32, device="cuda")
+            eng.frame_dev(d.data_ptr(), q, n_sig + 1 + t, float(n_sig + 1 + t), d_words.data_ptr(), d_like.data_ptr(), cap)
+            eng.synchronize()
+            n = n_sig + 1 + t
+            w1, l1 = d_words.cpu().numpy(), d_like[:n].cpu().numpy()
+            if not np.array_equal(w1, res[t][0]):
+                ok = False; msgs.append("word ids differ in frame %d" % t)
+            if not np.array_equal(l1.view(np.uint32), res[t][1].view(np.uint32)):
+                ok = False; msgs.append("likelihood not bit-identical in frame %d (max abs diff %g)" % (t, np.abs(l1 - res[t][1]).max()))
+            if int(np.argmax(l1[:n_sig])) != 37 * t + 5:
+                ok = False; msgs.append("arg-max is not the revisited place in frame %d" % t)
+            if t == 2:
+                eng.sig_remove(3)
+        eng.close()
+        out.put((ok, msgs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_two_ranks_match_single_gpu_bit_for_bit():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, msgs = out.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ok, msgs
