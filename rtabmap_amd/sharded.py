@@ -119,7 +119,7 @@ class ShardedLoopClosure:
             if want_likelihood:
                 self._all_reduce_sum(lfix[:n_slots])
                 self.eng.finalize_dev(lfix.data_ptr(), n_slots, like.data_ptr())
-        return words, like[:n_slots]
+        return words[:q], like[:n_slots]
 
     def close(self):
         self.eng.close()
