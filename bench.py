@@ -108,10 +108,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        backend = os.environ.get("LCD_BENCH_BACKEND", "nccl")      # "gloo" only for single-GPU sanity runs of the N > 1 code path
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import rtabmap_amd
     from rtabmap_amd import synth
@@ -175,6 +180,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    eng.profile_begin(args.steps)        # HIP events around the dominant kernel of every timed step, on the engine's stream
     t0 = time.perf_counter()
     e0.record(stream)
     for i in range(args.steps):
@@ -186,34 +192,24 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)
-    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    kern_ms, kern_n, kern_name = eng.profile_read()
     if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall = float(t.item())
+        wall = float(t.item())
 
     # sanity of the last frame: the revisited place must be the arg-max (excluding the frame itself)
     like = (last_like[0] if shard else d_like[: n_sig + args.steps + args.warmup]).cpu().numpy()
     last = (args.warmup + args.steps - 1) % n_frames
 
-    # ---- dominant kernel (L2 2-NN scan) timed alone with events on the engine's stream
-    reps = max(20, min(args.steps, 200))
-    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    d_kw = torch.zeros(Q * 2, dtype=torch.int32, device="cuda")
-    d_kd = torch.zeros(Q * 2, dtype=torch.float32, device="cuda")
-    for _ in range(5):
-        eng.knn2_dev(d_frames[0].data_ptr(), Q, d_kw.data_ptr(), d_kd.data_ptr())
-    torch.cuda.synchronize()
-    k0.record(stream)
-    for r in range(reps):
-        eng.knn2_dev(d_frames[r % n_frames].data_ptr(), Q, d_kw.data_ptr(), d_kd.data_ptr())
-    k1.record(stream)
-    torch.cuda.synchronize()
-    knn_ms = k0.elapsed_time(k1) / reps
-    flops = 2.0 * Q * N_WORDS * DIM                      # GEMM-equivalent 2*Q*N*D = 3.136 GFLOP per frame
-    achieved = flops / (knn_ms * 1e-3) / 1e12
+    # ---- roofline of the dominant kernel (the 2-NN distance scan), from the events recorded inside the timed region.
+    # ALGORITHMIC work per launch: 2*Q*N*D = 3.136 GFLOP GEMM-equivalent over this rank's vocabulary rows.
+    n_rows_rank = (sh.hi - sh.lo) if shard else N_WORDS
+    flops = 2.0 * Q * n_rows_rank * DIM
+    achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
     roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS,
-                "traffic": None, "kernel": "knn2_l2_kernel<64> + knn2_merge_kernel", "ms": knn_ms,
-                "algorithmic_gbps": (N_WORDS * DIM * 4 + Q * DIM * 4 + Q * 16) / (knn_ms * 1e-3) / 1e9}
+                "traffic": None, "kernel": kern_name, "ms": kern_ms, "samples": kern_n,
+                "algorithmic_gbps": (n_rows_rank * DIM * 4 + Q * DIM * 4 + Q * 16) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0}
 
     out = {
         "metric": "loop-closure candidates/sec (49k vocab, 100k signatures, 500 desc/frame)",

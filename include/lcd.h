@@ -179,6 +179,13 @@ int lcd_slots_dev(lcd_engine* h, const int32_t** d_slot_sig, int64_t* n_slots);
 void* lcd_stream(lcd_engine* h);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * kernel timing: while enabled, every launch of the dominant kernel of a frame (the 2-NN scan: MFMA filter, or the VALU
+ * scan when the filter does not apply) is bracketed by a pair of HIP events on the engine stream.  lcd_profile_read
+ * synchronises, returns the average duration in milliseconds and the number of samples, and disables profiling. */
+int lcd_profile_begin(lcd_engine* h, int max_samples);
+int lcd_profile_read(lcd_engine* h, float* avg_ms, int* n_samples, const char** kernel_name);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * statistics (names follow Statistics.h:178,202,209-212 where one exists) */
 typedef struct lcd_stats {
     int64_t vocab_rows, vocab_live;        /* Keypoint/Dictionary_size */

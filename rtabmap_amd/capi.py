@@ -21,7 +21,7 @@ SYMBOLS = [
     "lcd_vocab_clear", "lcd_vocab_append", "lcd_vocab_remove", "lcd_vocab_rebuild", "lcd_vocab_count", "lcd_vocab_read",
     "lcd_knn2", "lcd_selfdist", "lcd_quantize", "lcd_find_nn",
     "lcd_sig_add", "lcd_sig_remove", "lcd_sig_add_bulk", "lcd_sig_count", "lcd_word_nrefs",
-    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats",
+    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read",
 ]
 
 
@@ -90,6 +90,8 @@ def load():
     L.lcd_slots_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.lcd_stream.argtypes = [vp]
     L.lcd_stream.restype = vp
+    L.lcd_profile_begin.argtypes = [vp, C.c_int]
+    L.lcd_profile_read.argtypes = [vp, C.POINTER(f32), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
     L.lcd_get_stats.argtypes = [vp, C.POINTER(LcdStats)]
     _lib = L
     return L
@@ -267,6 +269,14 @@ class Engine:
 
     def stream(self):
         return self.L.lcd_stream(self.h)
+
+    def profile_begin(self, max_samples):
+        self._ck(self.L.lcd_profile_begin(self.h, max_samples))
+
+    def profile_read(self):
+        ms, n, name = C.c_float(), C.c_int(), C.c_char_p()
+        self._ck(self.L.lcd_profile_read(self.h, C.byref(ms), C.byref(n), C.byref(name)))
+        return ms.value, n.value, (name.value or b"").decode()
 
     def stats(self):
         s = LcdStats()

@@ -39,6 +39,11 @@ struct lcd_engine {
     // ---- inverted index / TF-IDF
     lcd::Tfidf tfidf;
 
+    // ---- event bracketing of the dominant kernel (lcd_profile_*)
+    std::vector<hipEvent_t> prof_ev;
+    int prof_n = 0, prof_cap = 0;
+    const char* prof_kernel = "";
+
     // ---- statistics
     int64_t knn_launches = 0, likelihood_launches = 0, rebuilds = 0;
 

@@ -59,15 +59,21 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
         LCD_HIP(h, dreserve(h, h->d_partial2, knn_mfma_partial_bytes(mp)));
         LCD_HIP(h, dreserve(h, h->d_fail_list, (size_t)q * 4));
         LCD_HIP(h, dreserve(h, h->d_fail_count, 64));
+        const bool prof = h->prof_cap > 0 && h->prof_n < h->prof_cap;
         LCD_HIP(h, launch_knn_mfma(h->kdim, vocab, h->row_norm.as<float>(), h->norm_max.as<uint32_t>(), row_id, d_queries, mp, h->d_partial2.p,
-                                   o_row, o_word, o_dist, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(), h->stream));
+                                   o_row, o_word, o_dist, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(), h->stream,
+                                   prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr));
+        if (prof) { h->prof_n += 1; h->prof_kernel = "knn_mfma_filter_kernel<64>"; }
         // the queries the certificate rejected are redone exactly by the row-parallel kernel (usually none: it leaves at once)
         LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
         LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(),
                                      h->d_partial3.p, o_row, o_word, o_dist, h->stream));
     } else {
         LCD_HIP(h, dreserve(h, h->d_partial, knn_partial_bytes(p)));
+        const bool prof = main_vocab && h->prof_cap > 0 && h->prof_n < h->prof_cap;
+        if (prof) LCD_HIP(h, hipEventRecord(h->prof_ev[2 * h->prof_n], h->stream));
         LCD_HIP(h, launch_knn2_partial(h->dtype, h->kdim, vocab, row_id, d_queries, p, h->d_partial.as<uint64_t>(), h->stream));
+        if (prof) { LCD_HIP(h, hipEventRecord(h->prof_ev[2 * h->prof_n + 1], h->stream)); h->prof_n += 1; h->prof_kernel = h->dtype == LCD_F32 ? "knn2_l2_kernel" : "knn2_hamming_kernel"; }
         LCD_HIP(h, launch_knn2_merge(h->dtype, p, h->d_partial.as<uint64_t>(), row_id, o_row, o_word, o_dist, h->stream));
     }
     h->knn_launches += 1;
@@ -139,6 +145,7 @@ void lcd_destroy(lcd_engine* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->tfidf.destroy();
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     DevBuf* all[] = {&h->vocab, &h->row_id, &h->row_wslot, &h->vocab_alt, &h->row_id_alt, &h->row_wslot_alt, &h->d_queries,
                      &h->d_partial, &h->d_knn_row, &h->d_knn_word, &h->d_knn_wslot, &h->d_knn_dist, &h->d_selfdist, &h->d_out_word,
                      &h->d_out_wslot, &h->d_n_new, &h->d_tmp_i32, &h->d_extra_rows, &h->d_extra_id, &h->d_extra_word,
@@ -630,6 +637,37 @@ int lcd_slots_dev(lcd_engine* h, const int32_t** d_slot_sig, int64_t* n_slots) {
     LCD_CHECK_HANDLE(h);
     if (d_slot_sig) *d_slot_sig = h->tfidf.slot_sig.as<int32_t>();
     if (n_slots) *n_slots = h->tfidf.n_slots;
+    return LCD_OK;
+}
+
+int lcd_profile_begin(lcd_engine* h, int max_samples) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (max_samples <= 0 || max_samples > (1 << 20)) return h->fail(LCD_ERR_INVALID, "lcd_profile_begin: bad sample count");
+    while ((int)h->prof_ev.size() < 2 * max_samples) {
+        hipEvent_t e;
+        LCD_HIP(h, hipEventCreate(&e));
+        h->prof_ev.push_back(e);
+    }
+    h->prof_n = 0;
+    h->prof_cap = max_samples;
+    return LCD_OK;
+}
+
+int lcd_profile_read(lcd_engine* h, float* avg_ms, int* n_samples, const char** kernel_name) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    LCD_HIP(h, hipStreamSynchronize(h->stream));
+    double sum = 0.0;
+    for (int i = 0; i < h->prof_n; ++i) {
+        float ms = 0.0f;
+        LCD_HIP(h, hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
+        sum += ms;
+    }
+    if (avg_ms) *avg_ms = h->prof_n ? (float)(sum / h->prof_n) : 0.0f;
+    if (n_samples) *n_samples = h->prof_n;
+    if (kernel_name) *kernel_name = h->prof_kernel;
+    h->prof_cap = 0;
     return LCD_OK;
 }
 

@@ -492,7 +492,7 @@ hipError_t launch_norm_tombstone(float* norm, const int32_t* rows, int n, hipStr
 
 hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, const uint32_t* norm_max_bits, const int32_t* row_id,
                            const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist,
-                           int32_t* fail_list, int32_t* fail_count, hipStream_t s) {
+                           int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
     if (p.q == 0) return hipSuccess;
     uint64_t* pk = (uint64_t*)partial;
     uint32_t* pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * MF_KEEP * p.qpad);
@@ -500,10 +500,12 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
     if (e != hipSuccess) return e;
     if (p.n_blocks > 0) {
         dim3 grid(p.n_blocks, p.qpad / 64);
+        if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
         knn_mfma_filter_kernel<64><<<grid, MF_BLOCK, 0, s>>>((const float*)vocab, row_norm, p.n_rows, (const float*)queries, p.q, p.qpad,
                                                               p.tiles_per_block, pk, pl);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
+        if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }
     }
     knn_mfma_rerank_kernel<<<(p.q + MF_WAVES - 1) / MF_WAVES, MF_BLOCK, 0, s>>>(pk, pl, p.n_blocks, p.qpad, p.q, dim, (const float*)vocab,
                                                                                (const float*)queries, row_id, norm_max_bits, out_row,
