@@ -8,7 +8,8 @@
 //      MI355X_MICROARCH.md).  |v|^2 and |q|^2 ride along as one extra k-step (A = (|v_i|^2, 1), B = (1, |q_j|^2)) and
 //      the queries are pre-scaled by -2, so the accumulator IS the approximate squared distance.  Every lane keeps a
 //      running top-3 of packed (distance << 32 | row) keys for the queries it sees -- no cross-lane traffic in the loop.
-//   2. RE-RANK (knn_mfma_rerank_kernel): per query the 16 best filter candidates are re-evaluated with the reference's
+//   2. RE-RANK (knn_mfma_rerank_kernel): per query 128 filter candidates (the two best of every lane's share of the
+//      per-workgroup lists) are re-evaluated with the reference's
 //      own arithmetic (bit-exact distances, lower row wins ties) and the two best are returned.  The result is PROVEN
 //      equal to the exact scan when every row the filter dropped is certainly farther than the exact second neighbour:
 //            bound - eps > d2_exact,
@@ -31,7 +32,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MF_BLOCK = 256;
 constexpr int MF_WAVES = 4;
 constexpr int MF_KEEP = 4;     // keys kept per (row block, query)
-constexpr int MF_CAND = 16;    // candidates re-ranked exactly per query
 
 __device__ __forceinline__ void top2_push(uint64_t& best, uint64_t& second, uint64_t k) {
     const uint64_t hi = best > k ? best : k;
@@ -290,29 +290,24 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
         if (k != KEY_NONE) bound = min(bound, (uint32_t)min(k >> 32, (uint64_t)0x7f800000u));                 // dropped by this lane
     }
     for (int c = lane; c < n_blocks; c += 64) bound = min(bound, partial_lmin[(size_t)c * qpad + qi]);
-    // MF_CAND rounds of "pop the global minimum"
-    uint64_t cand = KEY_NONE;                                        // lane r (< MF_CAND) ends up owning candidate r
-#pragma unroll
-    for (int r = 0; r < MF_CAND; ++r) {
-        uint64_t m = mine[0];
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) { const uint64_t o = shfl_xor_u64(m, s); m = m < o ? m : o; }
-        if (lane == r) cand = m;
-        if (mine[0] == m && m != KEY_NONE) { mine[0] = mine[1]; mine[1] = mine[2]; mine[2] = mine[3]; mine[3] = KEY_NONE; }   // keys are unique (row in the low half)
-    }
-    // whatever is left in any lane was dropped here
-    bound = min(bound, (uint32_t)min(mine[0] >> 32, (uint64_t)0x7f800000u));
+    // Candidates: the two best keys of every lane (128 per query) -- no cross-lane selection rounds.  A key a lane drops is
+    // no better than the lane's third key, so the true second neighbour can only be dropped together with two better rows
+    // of the same lane, which the bound then reports.
+    bound = min(bound, (uint32_t)min(mine[2] >> 32, (uint64_t)0x7f800000u));
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) bound = min(bound, (uint32_t)__shfl_xor((int)bound, s, 64));
 
     // exact distances of the candidates, reference arithmetic; a filter score of +inf is a tombstone / padding row
     const float* q = queries + (size_t)qi * dim;
-    uint64_t exact = KEY_NONE;
-    if (lane < MF_CAND && cand != KEY_NONE && (uint32_t)(cand >> 32) < 0x7f800000u) {
-        const uint32_t row = (uint32_t)cand;
-        exact = ((uint64_t)__float_as_uint(l2_ref_row(vocab + (size_t)row * dim, q, dim)) << 32) | row;
+    uint64_t best = KEY_NONE, second = KEY_NONE;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const uint64_t cand = mine[c];
+        if (cand != KEY_NONE && (uint32_t)(cand >> 32) < 0x7f800000u) {
+            const uint32_t row = (uint32_t)cand;
+            top2_push(best, second, ((uint64_t)__float_as_uint(l2_ref_row(vocab + (size_t)row * dim, q, dim)) << 32) | row);
+        }
     }
-    uint64_t best = exact, second = KEY_NONE;
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
         const uint64_t ob = shfl_xor_u64(best, s), os = shfl_xor_u64(second, s);

@@ -177,18 +177,17 @@ __global__ __launch_bounds__(SCB) void score_sealed_kernel(const BucketDev* __re
     __syncthreads();
     const uint32_t T = block_exclusive_scan(s_scan, Ug + 1, scratch);   // s_scan[Ug] == T afterwards
     // flattened, load-balanced walk over all postings of this bucket that belong to the group's words.  Four postings per
-    // thread and trip: the four segment lookups (LDS) come first, then four independent global loads are in flight at once.
-    int k = 0;
+    // thread and trip: their segments are found by binary search in the scanned offsets (LDS; the four searches are
+    // independent chains), then four independent global loads are in flight at once.
     for (uint32_t t0 = tid; t0 < T; t0 += 4 * SCB) {
         uint32_t addr[4]; int kk[4]; uint32_t e[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t t = t0 + u * SCB;
-            if (t < T) {
-                while (s_scan[k + 1] <= t) ++k;
-                addr[u] = s_start[k] + (t - s_scan[k]);
-            } else addr[u] = 0xFFFFFFFFu;
-            kk[u] = k;
+            int lo = 0, hi = Ug;                         // largest k with s_scan[k] <= t  (s_scan[Ug] == T > t)
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_scan[mid] <= t) lo = mid; else hi = mid; }
+            kk[u] = lo;
+            addr[u] = t < T ? s_start[lo] + (t - s_scan[lo]) : 0xFFFFFFFFu;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) e[u] = addr[u] != 0xFFFFFFFFu ? ent[addr[u]] : 0u;
