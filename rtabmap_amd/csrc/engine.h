@@ -33,6 +33,7 @@ struct lcd_engine {
     // ---- per-call scratch
     lcd::DevBuf d_queries, d_partial, d_knn_row, d_knn_word, d_knn_wslot, d_knn_dist, d_selfdist, d_out_word, d_out_wslot,
         d_n_new, d_tmp_i32, d_extra_rows, d_extra_id, d_extra_word, d_extra_dist, d_extra_row, d_like, d_slots, d_bits, row_norm, norm_max, d_partial2, d_partial3, d_fail_list, d_fail_count;
+    bool fail_count_clean = false;                      // d_fail_count[0..1] known to be zero (the fused frame tail resets them)
     int knn_mode = 1;                                   // 1 = MFMA filter + exact re-rank (f32, dim 64), 0 = exact VALU scan only
     lcd::PinBuf h_in, h_out, h_out2;
 

@@ -62,7 +62,9 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
         const bool prof = h->prof_cap > 0 && h->prof_n < h->prof_cap;
         LCD_HIP(h, launch_knn_mfma(h->kdim, vocab, h->row_norm.as<float>(), h->norm_max.as<uint32_t>(), row_id, d_queries, mp, h->d_partial2.p,
                                    o_row, o_word, o_dist, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(), h->stream,
-                                   prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr));
+                                   prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr,
+                                   !h->fail_count_clean));
+        h->fail_count_clean = false;
         if (prof) { h->prof_n += 1; h->prof_kernel = "knn_mfma_filter_kernel<64>"; }
         // the queries the certificate rejected are redone exactly by the row-parallel kernel (usually none: it leaves at once)
         LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
@@ -342,8 +344,10 @@ int lcd_selfdist(lcd_engine* h, const void* queries, int q, float* out_qxq) {
     return download(h, out_qxq, h->d_selfdist.p, (size_t)q * q * 4, h->h_out);
 }
 
-// device part of addNewWords: d_queries already holds q descriptors.  Leaves d_out_word[q], d_n_new[1].
-static int quantize_dev(lcd_engine* h, const void* d_desc, int q, int flags, float nndr, int32_t* d_out_word, int32_t* d_out_wslot = nullptr) {
+// device part of addNewWords up to (not including) the decision loop: 2-NN, same-frame distances + candidate bits.
+// Fills the decision loop's arguments.
+static int prepare_resolve(lcd_engine* h, const void* d_desc, int q, int flags, float nndr, int32_t* d_out_word, int32_t* d_out_wslot,
+                           ResolveArgs* r) {
     const int have_index = h->n_live >= 2 ? 1 : 0;                  // VWDictionary.cpp:1015
     int rc = run_knn2(h, d_desc, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), have_index ? h->n_rows : 0,
                       h->d_knn_row, h->d_knn_word, h->d_knn_dist);
@@ -358,11 +362,32 @@ static int quantize_dev(lcd_engine* h, const void* d_desc, int q, int flags, flo
         LCD_HIP(h, launch_selfdist(h->dtype, h->kdim, d_desc, q, h->d_selfdist.as<float>(), ld, h->stream, have_index,
                                    h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), h->d_bits.as<uint32_t>(), bw));
     }
-    const int rflags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0);
-    LCD_HIP(h, launch_resolve(q, rflags, nndr, have_index, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
-                              together ? h->d_selfdist.as<float>() : nullptr, ld, together ? h->d_bits.as<uint32_t>() : nullptr, bw,
-                              d_out_word, h->d_n_new.as<int32_t>(), h->stream, h->d_knn_row.as<int32_t>(), h->row_wslot.as<int32_t>(),
-                              d_out_wslot));
+    r->q = q;
+    r->flags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0);
+    r->nndr = nndr;
+    r->have_index = have_index;
+    r->knn_word = h->d_knn_word.as<int32_t>();
+    r->knn_dist = h->d_knn_dist.as<float>();
+    r->selfdist = together ? h->d_selfdist.as<float>() : nullptr;
+    r->ld = ld;
+    r->cand_bits = together ? h->d_bits.as<uint32_t>() : nullptr;
+    r->bw = bw;
+    r->out_word = d_out_word;
+    r->out_n_new = h->d_n_new.as<int32_t>();
+    r->knn_row = h->d_knn_row.as<int32_t>();
+    r->row_wslot = h->row_wslot.as<int32_t>();
+    r->out_wslot = d_out_wslot;
+    r->fail_count = nullptr;
+    return LCD_OK;
+}
+
+// device part of addNewWords: d_queries already holds q descriptors.  Leaves d_out_word[q], d_n_new[1].
+static int quantize_dev(lcd_engine* h, const void* d_desc, int q, int flags, float nndr, int32_t* d_out_word, int32_t* d_out_wslot = nullptr) {
+    ResolveArgs r;
+    int rc = prepare_resolve(h, d_desc, q, flags, nndr, d_out_word, d_out_wslot, &r);
+    if (rc) return rc;
+    LCD_HIP(h, launch_resolve(r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
+                              r.out_n_new, h->stream, r.knn_row, r.row_wslot, r.out_wslot));
     return LCD_OK;
 }
 
@@ -554,10 +579,13 @@ int lcd_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, fl
     const int64_t slots_after = t.n_slots + (sig_id != 0 ? 1 : 0);
     if (d_likelihood && likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
     LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
-    int rc = quantize_dev(h, d_descriptors, q, flags, nndr_ratio, d_word_ids, h->d_out_wslot.as<int32_t>());
+    // 2-NN + same-frame distances, then ONE single-workgroup launch: decision loop -> pending retirements -> registration / idf
+    ResolveArgs r;
+    int rc = prepare_resolve(h, d_descriptors, q, flags, nndr_ratio, d_word_ids, h->d_out_wslot.as<int32_t>(), &r);
     if (rc) return rc;
-    if (sig_id != 0) LCD_HIP(h, t.register_dev(sig_id, h->d_out_wslot.as<int32_t>(), q, q, N));
-    else LCD_HIP(h, t.query_dev(h->d_out_wslot.as<int32_t>(), q, N));
+    if (h->d_fail_count.p) { r.fail_count = h->d_fail_count.as<int32_t>(); h->fail_count_clean = true; }
+    if (sig_id != 0) LCD_HIP(h, t.register_dev(sig_id, h->d_out_wslot.as<int32_t>(), q, q, N, &r));
+    else LCD_HIP(h, t.query_dev(h->d_out_wslot.as<int32_t>(), q, N, &r));
     if (d_likelihood) { LCD_HIP(h, t.score(d_likelihood)); h->likelihood_launches += 1; }
     return LCD_OK;
 }

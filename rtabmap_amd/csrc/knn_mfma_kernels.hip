@@ -487,12 +487,15 @@ hipError_t launch_norm_tombstone(float* norm, const int32_t* rows, int n, hipStr
 
 hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, const uint32_t* norm_max_bits, const int32_t* row_id,
                            const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist,
-                           int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
+                           int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, bool reset_count) {
     if (p.q == 0) return hipSuccess;
     uint64_t* pk = (uint64_t*)partial;
     uint32_t* pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * MF_KEEP * p.qpad);
-    hipError_t e = hipMemsetAsync(fail_count, 0, 8, s);   // [0] rejected queries, [1] arrival counter of the row-parallel redo
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    if (reset_count) {   // [0] rejected queries, [1] arrival counter of the row-parallel redo (the fused frame tail leaves them zeroed)
+        e = hipMemsetAsync(fail_count, 0, 8, s);
+        if (e != hipSuccess) return e;
+    }
     if (p.n_blocks > 0) {
         dim3 grid(p.n_blocks, p.qpad / 64);
         if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }

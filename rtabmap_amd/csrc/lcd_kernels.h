@@ -48,7 +48,8 @@ hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, 
 hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, const uint32_t* norm_max_bits, const int32_t* row_id,
                            const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist,
                            int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin = nullptr,
-                           hipEvent_t ev_end = nullptr);   // optional events bracketing the filter kernel alone
+                           hipEvent_t ev_end = nullptr,    // optional events bracketing the filter kernel alone
+                           bool reset_count = true);       // false: fail_count[0..1] are already zero
 // q x q distances of a block against itself; out[i*ld + j], ld >= q.  When `bits` is given ([q][bw] words, bw >= ceil(q/32))
 // also the candidate bit matrix of the addNewWords resolution: bit j of row i = dist(j, i) < (distance of i's second
 // indexed neighbour, +inf if it has none) -- see knn2_kernels.hip.

@@ -17,66 +17,10 @@
 // One workgroup (1024 threads) handles the frame: the data is tiny and the work is latency-, not throughput-bound;
 // the frame's heavy part is knn2_kernels.hip.
 #include "lcd_kernels.h"
+#include "resolve_body.cuh"
 
 namespace lcd {
 namespace {
-
-constexpr int RBLOCK = 1024;
-constexpr int LCD_Q_INCREMENTAL = 1;
-constexpr int LCD_Q_NEW_WORDS_COMPARED = 2;
-
-struct Cand { float d; int id; };   // id > 0: word id, id < 0: -(j+1) = the new word created by descriptor j
-
-// std::multimap<float,int> insertion (equal keys keep insertion order, VWDictionary.cpp:1091) restricted to what is
-// read afterwards: the two smallest entries.
-__device__ __forceinline__ void cand_push(Cand& c0, Cand& c1, int& n, float d, int id) {
-    if (n == 0) { c0.d = d; c0.id = id; }
-    else if (d < c0.d) { c1 = c0; c0.d = d; c0.id = id; }
-    else if (n == 1 || d < c1.d) { c1.d = d; c1.id = id; }
-    ++n;
-}
-
-// candidates of descriptor i given the current guess (bit mask in LDS) of which earlier descriptors are new words
-__device__ __forceinline__ void gather_candidates(int i, bool together, int have_index, const int32_t* __restrict__ knn_word,
-                                                  const float* __restrict__ knn_dist, const float* __restrict__ selfdist,
-                                                  int ld, const uint32_t* __restrict__ cand_bits, int bw,
-                                                  const uint32_t* new_mask, Cand& c0, Cand& c1, int& n) {
-    n = 0;
-    c0.d = 0.f; c0.id = 0; c1.d = 0.f; c1.id = 0;
-    if (have_index) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {                // :1092-1137, stop at the first invalid neighbour
-            const float d = knn_dist[2 * i + j];
-            const int id = knn_word[2 * i + j];
-            if (d >= 0.0f && id != 0) cand_push(c0, c1, n, d, id); else break;
-        }
-    }
-    if (together) {
-        // exact 2-NN (1-NN when only one exists) among the new words created before i, lowest j on ties (:1140-1160),
-        // restricted to the ones that can reach the two best candidates (cand_bits)
-        uint64_t b = KEY_NONE, s = KEY_NONE;
-        const int wlast = i >> 5;
-        for (int w = 0; w <= wlast; ++w) {
-            uint32_t m = cand_bits[(size_t)i * bw + w] & new_mask[w];
-            if (w == wlast) m &= (1u << (i & 31)) - 1u;           // only j < i
-            while (m) {
-                const int j = (w << 5) + __builtin_ctz(m);
-                m &= m - 1;
-                const uint64_t k = ((uint64_t)__float_as_uint(selfdist[(size_t)j * ld + i]) << 32) | (uint32_t)j;
-                const uint64_t hi = b > k ? b : k;
-                b = b < k ? b : k;
-                s = s < hi ? s : hi;
-            }
-        }
-        if (b != KEY_NONE) cand_push(c0, c1, n, __uint_as_float((uint32_t)(b >> 32)), -((int)(uint32_t)b + 1));
-        if (s != KEY_NONE) cand_push(c0, c1, n, __uint_as_float((uint32_t)(s >> 32)), -((int)(uint32_t)s + 1));
-    }
-}
-
-// rank of descriptor j among the new words = number of mask bits below j (word prefix sums in LDS)
-__device__ __forceinline__ int new_rank(const uint32_t* mask, const uint32_t* prefix, int j) {
-    return (int)(prefix[j >> 5] + __popc(mask[j >> 5] & ((1u << (j & 31)) - 1u)));
-}
 
 __global__ __launch_bounds__(RBLOCK) void resolve_kernel(int q, int flags, float nndr, int have_index,
                                                          const int32_t* __restrict__ knn_word, const float* __restrict__ knn_dist,
@@ -85,84 +29,9 @@ __global__ __launch_bounds__(RBLOCK) void resolve_kernel(int q, int flags, float
                                                          int32_t* __restrict__ out_word, int32_t* __restrict__ out_n_new,
                                                          const int32_t* __restrict__ knn_row, const int32_t* __restrict__ row_wslot,
                                                          int32_t* __restrict__ out_wslot) {
-    extern __shared__ uint32_t rs_smem[];             // mask_a[mw] | mask_b[mw] | prefix[mw + 1]
-    const int mw = (q + 63) / 64 * 2;                 // mask words (a whole number of waves)
-    uint32_t* mask_cur = rs_smem;
-    uint32_t* mask_next = rs_smem + mw;
-    uint32_t* prefix = rs_smem + 2 * mw;
-    __shared__ int s_changed;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const bool incremental = (flags & LCD_Q_INCREMENTAL) != 0;
-    const bool together = incremental && (flags & LCD_Q_NEW_WORDS_COMPARED) && cand_bits != nullptr;
-    const int qpad = mw * 32;
-
-    // sweep 0: decide from the indexed candidates only; out_word holds the current winner of every descriptor
-    for (int i = tid; i < qpad; i += RBLOCK) {
-        bool reject = false;
-        if (i < q) {
-            Cand c0, c1; int n;
-            gather_candidates(i, false, have_index, knn_word, knn_dist, selfdist, ld, cand_bits, bw, mask_cur, c0, c1, n);
-            reject = incremental && (n < 2 || c0.d > nndr * c1.d);
-            out_word[i] = n > 0 ? c0.id : 0;
-        }
-        const unsigned long long bal = __ballot(reject);
-        if (lane == 0) { mask_cur[(i >> 5)] = (uint32_t)bal; mask_cur[(i >> 5) + 1] = (uint32_t)(bal >> 32); }
-    }
-    __syncthreads();
-    if (together) {
-        for (int sweep = 0; sweep <= q; ++sweep) {
-            if (tid == 0) s_changed = 0;
-            __syncthreads();
-            for (int i = tid; i < qpad; i += RBLOCK) {
-                bool reject = false;
-                if (i < q) {
-                    Cand c0, c1; int n;
-                    gather_candidates(i, true, have_index, knn_word, knn_dist, selfdist, ld, cand_bits, bw, mask_cur, c0, c1, n);
-                    reject = n < 2 || c0.d > nndr * c1.d;
-                    out_word[i] = n > 0 ? c0.id : 0;
-                }
-                const unsigned long long bal = __ballot(reject);
-                if (lane == 0) {
-                    const uint32_t lo = (uint32_t)bal, hi = (uint32_t)(bal >> 32);
-                    mask_next[i >> 5] = lo; mask_next[(i >> 5) + 1] = hi;
-                    if (lo != mask_cur[i >> 5] || hi != mask_cur[(i >> 5) + 1]) s_changed = 1;
-                }
-            }
-            __syncthreads();
-            uint32_t* t = mask_cur; mask_cur = mask_next; mask_next = t;
-            if (!s_changed) break;
-            __syncthreads();
-        }
-    }
-    // word prefix sums of the final mask -> ranks of the new words in descriptor order (getNextId() order, :1185)
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int w = 0; w < mw; ++w) { prefix[w] = run; run += __popc(mask_cur[w]); }
-        prefix[mw] = run;
-        out_n_new[0] = (int32_t)run;
-    }
-    __syncthreads();
-    for (int i = tid; i < q; i += RBLOCK) {
-        const bool is_new = (mask_cur[i >> 5] >> (i & 31)) & 1u;
-        int w;
-        if (is_new) w = -(new_rank(mask_cur, prefix, i) + 1);
-        else {
-            w = out_word[i];                           // winner of the last sweep (own entry: no cross-thread read)
-            if (w < 0) w = -(new_rank(mask_cur, prefix, -w - 1) + 1);   // matched a same-frame new word
-        }
-        out_word[i] = w;                               // fixed dictionary without candidate: 0 ("no entry", :1211-1218)
-        if (out_wslot) {
-            // postings key of the chosen EXISTING word: it is one of the descriptor's two indexed neighbours
-            // (row_wslot == NULL: knn_row already holds the postings key of each neighbour -- sharded mode)
-            int32_t ws = -1;
-            if (w > 0) {
-                if (knn_word[2 * i] == w) ws = row_wslot ? row_wslot[knn_row[2 * i]] : knn_row[2 * i];
-                else if (knn_word[2 * i + 1] == w) ws = row_wslot ? row_wslot[knn_row[2 * i + 1]] : knn_row[2 * i + 1];
-            }
-            out_wslot[i] = ws;
-        }
-    }
+    extern __shared__ uint32_t rs_dyn_smem[];
+    resolve_body(rs_dyn_smem, q, flags, nndr, have_index, knn_word, knn_dist, selfdist, ld, cand_bits, bw, out_word, out_n_new, knn_row,
+                 row_wslot, out_wslot);
 }
 
 // findNN (:1457-1542): indexed candidates are NOT cut at the first invalid one; not-indexed candidates are

@@ -57,6 +57,14 @@ struct Bucket {
     uint32_t n_e_sealed = 0;
 };
 
+// arguments of the addNewWords decision loop (resolve_body.cuh) when it is fused into the frame-words launch
+struct ResolveArgs {
+    int q, flags; float nndr; int have_index;
+    const int32_t* knn_word; const float* knn_dist; const float* selfdist; int ld; const uint32_t* cand_bits; int bw;
+    int32_t* out_word; int32_t* out_n_new; const int32_t* knn_row; const int32_t* row_wslot; int32_t* out_wslot;
+    int32_t* fail_count;   // reset for the next frame's certificate (saves a memset launch); may be NULL
+};
+
 struct Tfidf {
     hipStream_t stream = nullptr;
     int64_t* bytes_device = nullptr;
@@ -67,11 +75,12 @@ struct Tfidf {
     DevBuf idf_tab;                      // {stamp, idf bits} of the words of the current frame (valid iff stamp matches)
     uint32_t stamp = 0;
     // per bucket
-    DevBuf bkt_tab, bkt_ne, bkt_list;
+    DevBuf bkt_tab, bkt_ne, bkt_list, bkt_list_all, open_done;
     std::vector<Bucket> buckets;
     std::vector<BucketDev> h_bkt;
     bool bkt_dirty = true;
     int n_list = 0;                      // sealed buckets with live signatures (entries of bkt_list)
+    int n_list_all = 0;                  // all sealed buckets, retired ones included (entries of bkt_list_all)
     int q_n_ub = 0;                      // word count of the last frame handed to frame_words (upper bound of its unique words)
     // per frame
     DevBuf lfix;                         // int64 accumulator per slot
@@ -93,9 +102,11 @@ struct Tfidf {
     hipError_t wslot_of(int32_t word_id, int32_t* out);
     // register one signature whose word slots are already on the device (d_wslots[n]; < 0 = no word); if N > 0 the
     // frame's unique words / idf are left in q_* for a following score()
-    hipError_t register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N);
+    hipError_t register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N, const ResolveArgs* resolve = nullptr);
     // prepare q_* from word slots on the device without registering anything
-    hipError_t query_dev(const int32_t* d_wslots, int n, float N);
+    hipError_t query_dev(const int32_t* d_wslots, int n, float N, const ResolveArgs* resolve = nullptr);
+    hipError_t flush_retire();
+    std::vector<int64_t> pending_retire;   // slots whose device-side retirement rides along with the next frame-words launch
     // score q_* against every live signature: dense float likelihood over slots [0, n_slots)
     hipError_t score(float* d_likelihood);
     // the two halves of score(): integer partial sums into a ZEROED caller buffer, and fixed point -> float (re-zeroes the source)

@@ -7,6 +7,7 @@
 // terms of one signature in ascending word order in fp32, here they are added as Q15.48 integers (order-free,
 // truncation error < 2^-48 per term), so results agree to ~1e-6 relative (bound 1e-4, tests/test_gpu_likelihood.py).
 #include "tfidf.h"
+#include "resolve_body.cuh"
 
 #include <algorithm>
 #include <cmath>
@@ -55,7 +56,7 @@ __device__ __forceinline__ unsigned long long to_fixed(float t) {
 // optionally append them to the open bucket as the postings of signature `slot` (nw += 1 each), and leave the
 // word / count / idf lists plus the per-word idf table (idf_tab[w] = {stamp, idf}) for the scoring kernels.
 // The list order is whatever the table yields: nothing downstream depends on it (integer accumulation).
-__global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(const int32_t* __restrict__ wslots, int n, int H, int do_register,
+__device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const int32_t* __restrict__ wslots, int n, int H, int do_register,
                                                                int32_t sig_id, long long slot, uint32_t slot_local, uint32_t ni, float N,
                                                                uint32_t stamp, uint32_t* __restrict__ nw, uint32_t* __restrict__ coo_w,
                                                                uint32_t* __restrict__ coo_pc, uint32_t* __restrict__ ne_counter,
@@ -64,7 +65,6 @@ __global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(const int32_t* __
                                                                uint32_t* __restrict__ q_w, uint32_t* __restrict__ q_cnt,
                                                                float* __restrict__ q_idf, uint32_t* __restrict__ q_meta,
                                                                uint2* __restrict__ idf_tab) {
-    extern __shared__ uint32_t fw_smem[];
     uint32_t* tkey = fw_smem;            // [H] 0xFFFFFFFF = empty
     uint32_t* tcnt = fw_smem + H;        // [H]
     uint32_t* grp = tcnt + H;            // [H / 64 + 1]
@@ -137,15 +137,69 @@ __global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(const int32_t* __
     }
 }
 
+
+// signatures whose retirement was requested since the last frame (Memory::disableWordsRef -> removeAllWordRef): their
+// words lose one reference each and the slot is marked dead (ni = 0).  Up to 4 ride along with the next frame-words launch.
+struct RetireArgs { long long slot[4]; const uint32_t* coo_w[4]; int n; };
+__device__ __forceinline__ void retire_body(const RetireArgs& r, const uint32_t* __restrict__ slot_begin, const uint32_t* __restrict__ slot_cnt,
+                                            uint32_t* __restrict__ nw, uint32_t* __restrict__ slot_ni, int32_t* __restrict__ slot_sig) {
+    for (int p = 0; p < r.n; ++p) {
+        const long long slot = r.slot[p];
+        const uint32_t begin = slot_begin[slot], cnt = slot_cnt[slot];
+        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) atomicSub(&nw[r.coo_w[p][begin + k]], 1u);
+        if (threadIdx.x == 0) { slot_ni[slot] = 0u; slot_sig[slot] = 0; }
+    }
+}
+
+__global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(const int32_t* __restrict__ wslots, int n, int H, int do_register,
+                                                               int32_t sig_id, long long slot, uint32_t slot_local, uint32_t ni, float N,
+                                                               uint32_t stamp, uint32_t* __restrict__ nw, uint32_t* __restrict__ coo_w,
+                                                               uint32_t* __restrict__ coo_pc, uint32_t* __restrict__ ne_counter,
+                                                               int32_t* __restrict__ slot_sig, uint32_t* __restrict__ slot_ni,
+                                                               uint32_t* __restrict__ slot_begin, uint32_t* __restrict__ slot_cnt,
+                                                               uint32_t* __restrict__ q_w, uint32_t* __restrict__ q_cnt,
+                                                               float* __restrict__ q_idf, uint32_t* __restrict__ q_meta,
+                                                               uint2* __restrict__ idf_tab, RetireArgs retire) {
+    extern __shared__ uint32_t fw_dyn_smem[];
+    retire_body(retire, slot_begin, slot_cnt, nw, slot_ni, slot_sig);
+    __syncthreads();
+    frame_words_body(fw_dyn_smem, wslots, n, H, do_register, sig_id, slot, slot_local, ni, N, stamp, nw, coo_w, coo_pc, ne_counter, slot_sig,
+                     slot_ni, slot_begin, slot_cnt, q_w, q_cnt, q_idf, q_meta, idf_tab);
+}
+
+// The single-workgroup tail of a frame in ONE launch: addNewWords decision loop (resolve_body.cuh) -> pending retirements
+// -> unique words / registration / idf (frame_words_body).  Saves two dependent kernel boundaries per frame.
+__global__ __launch_bounds__(FW_BLOCK) void frame_tail_kernel(ResolveArgs r, int H, int do_register, int32_t sig_id, long long slot,
+                                                              uint32_t slot_local, uint32_t ni, float N, uint32_t stamp,
+                                                              uint32_t* __restrict__ nw, uint32_t* __restrict__ coo_w,
+                                                              uint32_t* __restrict__ coo_pc, uint32_t* __restrict__ ne_counter,
+                                                              int32_t* __restrict__ slot_sig, uint32_t* __restrict__ slot_ni,
+                                                              uint32_t* __restrict__ slot_begin, uint32_t* __restrict__ slot_cnt,
+                                                              uint32_t* __restrict__ q_w, uint32_t* __restrict__ q_cnt,
+                                                              float* __restrict__ q_idf, uint32_t* __restrict__ q_meta,
+                                                              uint2* __restrict__ idf_tab, RetireArgs retire) {
+    extern __shared__ uint32_t ft_dyn_smem[];
+    resolve_body(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
+                 r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot);
+    if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; }
+    retire_body(retire, slot_begin, slot_cnt, nw, slot_ni, slot_sig);
+    __syncthreads();      // out_wslot (global, written by this workgroup) and the LDS region are handed over
+    frame_words_body(ft_dyn_smem, r.out_wslot, r.q, H, do_register, sig_id, slot, slot_local, ni, N, stamp, nw, coo_w, coo_pc, ne_counter,
+                     slot_sig, slot_ni, slot_begin, slot_cnt, q_w, q_cnt, q_idf, q_meta, idf_tab);
+}
+
 // ---------------------------------------------------------------------------------------------- sealed buckets
-// grid = (sealed live buckets, G word groups).  LDS: acc[R] i64 | ni[R] | start[Wg] | scan[Wg + 1] | idf[Wg] | scratch
+__device__ __forceinline__ float fixed_to_float(unsigned long long v) { return (float)((double)(long long)v * (1.0 / 281474976710656.0)); }   // 2^-48
+
+// One workgroup scores one sealed bucket for the word group g of G.  LDS (dynamic): acc[R] i64 | ni[R] | start[wg_cap] |
+// scan[wg_cap + 1] | idf[wg_cap] | scratch[SCB + 1].  With out_like != NULL (only valid for G == 1) the bucket's TF_R
+// likelihood values are written straight from the LDS accumulators (no round trip through lfix, no finalize launch);
+// otherwise the sums are added into lfix.
 template <int SCB>
-__global__ __launch_bounds__(SCB) void score_sealed_kernel(const BucketDev* __restrict__ tab, const int32_t* __restrict__ list, int G,
-                                                                int wg_cap, const uint32_t* __restrict__ q_w,
-                                                                const float* __restrict__ q_idf, const uint32_t* __restrict__ q_meta,
-                                                                const uint32_t* __restrict__ slot_ni,
-                                                                unsigned long long* __restrict__ lfix) {
-    extern __shared__ unsigned long long sc_smem[];
+__device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, const BucketDev* __restrict__ tab, int b, int g, int G, int wg_cap,
+                                                  const uint32_t* __restrict__ q_w, const float* __restrict__ q_idf,
+                                                  const uint32_t* __restrict__ q_meta, const uint32_t* __restrict__ slot_ni,
+                                                  unsigned long long* __restrict__ lfix, float* __restrict__ out_like) {
     unsigned long long* acc = sc_smem;                              // [R]
     uint32_t* s_ni = (uint32_t*)(acc + TF_R);                       // [R]
     uint32_t* s_start = s_ni + TF_R;                                // [wg_cap]
@@ -153,12 +207,14 @@ __global__ __launch_bounds__(SCB) void score_sealed_kernel(const BucketDev* __re
     float* s_idf = (float*)(s_scan + wg_cap + 1);                   // [wg_cap]
     uint32_t* scratch = (uint32_t*)(s_idf + wg_cap);                // [SCB + 1]
     const int tid = threadIdx.x;
-    const int b = list[blockIdx.x];
-    const int g = blockIdx.y;
     const uint32_t* __restrict__ dir = tab[b].dir;
     const uint32_t* __restrict__ ent = tab[b].ent;
     const uint32_t W = tab[b].W;
     const long long first_slot = (long long)b * TF_R;
+    if (dir == nullptr) {                                           // every signature of the bucket is retired
+        if (out_like) for (int i = tid; i < TF_R; i += SCB) out_like[first_slot + i] = 0.0f;
+        return;
+    }
     const int U = (int)q_meta[0];
     int Ug = U > g ? (U - g + G - 1) / G : 0;
     if (Ug > wg_cap) Ug = wg_cap;                                   // cannot happen: wg_cap is sized from the word count
@@ -205,11 +261,23 @@ __global__ __launch_bounds__(SCB) void score_sealed_kernel(const BucketDev* __re
     __syncthreads();
     for (int i = tid; i < TF_R; i += SCB) {
         const unsigned long long v = acc[i];
-        if (v != 0ull) {
+        if (out_like) out_like[first_slot + i] = fixed_to_float(v);
+        else if (v != 0ull) {
             if (G == 1) lfix[first_slot + i] = v;
             else atomicAdd(&lfix[first_slot + i], v);
         }
     }
+}
+
+// grid = (sealed live buckets, G word groups)
+template <int SCB>
+__global__ __launch_bounds__(SCB) void score_sealed_kernel(const BucketDev* __restrict__ tab, const int32_t* __restrict__ list, int G,
+                                                           int wg_cap, const uint32_t* __restrict__ q_w,
+                                                           const float* __restrict__ q_idf, const uint32_t* __restrict__ q_meta,
+                                                           const uint32_t* __restrict__ slot_ni,
+                                                           unsigned long long* __restrict__ lfix) {
+    extern __shared__ unsigned long long sc_smem[];
+    score_sealed_body<SCB>(sc_smem, tab, list[blockIdx.x], blockIdx.y, G, wg_cap, q_w, q_idf, q_meta, slot_ni, lfix, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------- open bucket
@@ -218,6 +286,75 @@ __global__ __launch_bounds__(SCB) void score_sealed_kernel(const BucketDev* __re
 // slot-major, so the postings a workgroup sees belong to a handful of consecutive signatures: they are summed in a
 // small LDS window first and only the window is flushed with global atomics.
 constexpr int OPEN_WIN = 64;
+// ob / n_ob: this workgroup's index among the open-bucket workgroups.  With out_like != NULL the LAST of them to finish
+// (agent-scope release / acquire around done_counter) converts the bucket's slots to float and re-zeroes lfix.
+__device__ __forceinline__ void score_open_body(uint32_t* so_smem, int ob, int n_ob, const uint32_t* __restrict__ coo_w,
+                                                const uint32_t* __restrict__ coo_pc, const uint32_t* __restrict__ ne_counter,
+                                                long long first_slot, int n_open_slots, int bitmap_words, uint32_t stamp,
+                                                const uint32_t* __restrict__ q_w, const uint32_t* __restrict__ q_meta,
+                                                const uint2* __restrict__ idf_tab, const uint32_t* __restrict__ slot_ni,
+                                                unsigned long long* __restrict__ lfix, float* __restrict__ out_like,
+                                                int* __restrict__ done_counter) {
+    uint32_t* s_bits = so_smem;                 // [bitmap_words] membership bitmap over word slots (0 words = not used)
+    __shared__ unsigned long long s_win[OPEN_WIN];
+    __shared__ uint32_t s_win0;
+    __shared__ int s_last;
+    const int nt = blockDim.x;
+    const uint32_t ne = ne_counter[0];
+    const uint32_t per = (ne + n_ob - 1) / n_ob;                    // contiguous chunk of the log per workgroup
+    const uint32_t e0 = min((uint32_t)ob * per, ne), e1 = min(e0 + per, ne);
+    if (e0 < e1) {
+        const int U = (int)q_meta[0];
+        for (int i = threadIdx.x; i < bitmap_words; i += nt) s_bits[i] = 0u;
+        if (threadIdx.x < OPEN_WIN) s_win[threadIdx.x] = 0ull;
+        if (threadIdx.x == 0) s_win0 = coo_pc[e0] >> TF_CNT_BITS;  // slot_local of the chunk's first posting
+        __syncthreads();
+        for (int i = threadIdx.x; i < U; i += nt) {
+            const uint32_t w = q_w[i];
+            if ((w >> 5) < (uint32_t)bitmap_words) atomicOr(&s_bits[w >> 5], 1u << (w & 31));
+        }
+        __syncthreads();
+        const uint32_t win0 = s_win0;
+        for (uint32_t e = e0 + threadIdx.x; e < e1; e += nt) {
+            const uint32_t w = coo_w[e];
+            if ((w >> 5) < (uint32_t)bitmap_words && !((s_bits[w >> 5] >> (w & 31)) & 1u)) continue;   // not a word of the frame
+            const uint2 t = idf_tab[w];
+            if (t.x != stamp) continue;
+            const float idf = __uint_as_float(t.y);
+            if (idf == 0.0f) continue;                                   // "if(logNnw)" (Memory.cpp:2267)
+            const uint32_t pc = coo_pc[e];
+            const uint32_t sl = pc >> TF_CNT_BITS;
+            const uint32_t ni = slot_ni[first_slot + sl];
+            if (ni == 0u) continue;
+            const unsigned long long v = to_fixed(__fdiv_rn(__fmul_rn((float)(pc & TF_CNT_MASK), idf), (float)ni));
+            if (sl - win0 < (uint32_t)OPEN_WIN) atomicAdd(&s_win[sl - win0], v);
+            else atomicAdd(&lfix[first_slot + sl], v);
+        }
+        __syncthreads();
+        if (threadIdx.x < OPEN_WIN) {
+            const unsigned long long v = s_win[threadIdx.x];
+            if (v != 0ull) atomicAdd(&lfix[first_slot + win0 + threadIdx.x], v);
+        }
+    }
+    if (!out_like) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == n_ob - 1;
+        if (s_last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); done_counter[0] = 0; }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int i = threadIdx.x; i < n_open_slots; i += nt) {
+        const unsigned long long v = __hip_atomic_load(&lfix[first_slot + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out_like[first_slot + i] = fixed_to_float(v);
+        if (v != 0ull) lfix[first_slot + i] = 0ull;
+    }
+}
+
 __global__ __launch_bounds__(SC_BLOCK) void score_open_kernel(const uint32_t* __restrict__ coo_w, const uint32_t* __restrict__ coo_pc,
                                                               const uint32_t* __restrict__ ne_counter, long long first_slot,
                                                               int bitmap_words, uint32_t stamp, const uint32_t* __restrict__ q_w,
@@ -225,44 +362,27 @@ __global__ __launch_bounds__(SC_BLOCK) void score_open_kernel(const uint32_t* __
                                                               const uint32_t* __restrict__ slot_ni,
                                                               unsigned long long* __restrict__ lfix) {
     extern __shared__ uint32_t so_smem[];
-    uint32_t* s_bits = so_smem;                 // [bitmap_words] membership bitmap over word slots (0 words = not used)
-    __shared__ unsigned long long s_win[OPEN_WIN];
-    __shared__ uint32_t s_win0;
-    const uint32_t ne = ne_counter[0];
-    const uint32_t per = (ne + gridDim.x - 1) / gridDim.x;          // contiguous chunk of the log per workgroup
-    const uint32_t e0 = min(blockIdx.x * per, ne), e1 = min(e0 + per, ne);
-    if (e0 >= e1) return;
-    const int U = (int)q_meta[0];
-    for (int i = threadIdx.x; i < bitmap_words; i += SC_BLOCK) s_bits[i] = 0u;
-    if (threadIdx.x < OPEN_WIN) s_win[threadIdx.x] = 0ull;
-    if (threadIdx.x == 0) s_win0 = coo_pc[e0] >> TF_CNT_BITS;      // slot_local of the chunk's first posting
-    __syncthreads();
-    for (int i = threadIdx.x; i < U; i += SC_BLOCK) {
-        const uint32_t w = q_w[i];
-        if ((w >> 5) < (uint32_t)bitmap_words) atomicOr(&s_bits[w >> 5], 1u << (w & 31));
-    }
-    __syncthreads();
-    const uint32_t win0 = s_win0;
-    for (uint32_t e = e0 + threadIdx.x; e < e1; e += SC_BLOCK) {
-        const uint32_t w = coo_w[e];
-        if ((w >> 5) < (uint32_t)bitmap_words && !((s_bits[w >> 5] >> (w & 31)) & 1u)) continue;   // not a word of the frame
-        const uint2 t = idf_tab[w];
-        if (t.x != stamp) continue;
-        const float idf = __uint_as_float(t.y);
-        if (idf == 0.0f) continue;                                   // "if(logNnw)" (Memory.cpp:2267)
-        const uint32_t pc = coo_pc[e];
-        const uint32_t sl = pc >> TF_CNT_BITS;
-        const uint32_t ni = slot_ni[first_slot + sl];
-        if (ni == 0u) continue;
-        const unsigned long long v = to_fixed(__fdiv_rn(__fmul_rn((float)(pc & TF_CNT_MASK), idf), (float)ni));
-        if (sl - win0 < (uint32_t)OPEN_WIN) atomicAdd(&s_win[sl - win0], v);
-        else atomicAdd(&lfix[first_slot + sl], v);
-    }
-    __syncthreads();
-    if (threadIdx.x < OPEN_WIN) {
-        const unsigned long long v = s_win[threadIdx.x];
-        if (v != 0ull) atomicAdd(&lfix[first_slot + win0 + threadIdx.x], v);
-    }
+    score_open_body(so_smem, blockIdx.x, gridDim.x, coo_w, coo_pc, ne_counter, first_slot, 0, bitmap_words, stamp, q_w, q_meta, idf_tab,
+                    slot_ni, lfix, nullptr, nullptr);
+}
+
+// single-GPU fast path: every sealed bucket (retired ones included: they write zeros) and the open bucket in ONE launch,
+// likelihood written directly -- no lfix round trip, no finalize launch.  blockIdx.x < n_sealed: sealed bucket list_all[x].
+template <int SCB>
+__global__ __launch_bounds__(SCB) void score_fused_kernel(const BucketDev* __restrict__ tab, const int32_t* __restrict__ list_all, int n_sealed,
+                                                          int wg_cap, const uint32_t* __restrict__ q_w, const float* __restrict__ q_idf,
+                                                          const uint32_t* __restrict__ q_meta, const uint32_t* __restrict__ slot_ni,
+                                                          unsigned long long* __restrict__ lfix, float* __restrict__ out_like,
+                                                          const uint32_t* __restrict__ coo_w, const uint32_t* __restrict__ coo_pc,
+                                                          const uint32_t* __restrict__ ne_counter, long long open_first_slot,
+                                                          int n_open_slots, int bitmap_words, uint32_t stamp,
+                                                          const uint2* __restrict__ idf_tab, int* __restrict__ done_counter) {
+    extern __shared__ unsigned long long sf_smem[];
+    if ((int)blockIdx.x < n_sealed)
+        score_sealed_body<SCB>(sf_smem, tab, list_all[blockIdx.x], 0, 1, wg_cap, q_w, q_idf, q_meta, slot_ni, lfix, out_like);
+    else
+        score_open_body((uint32_t*)sf_smem, (int)blockIdx.x - n_sealed, (int)gridDim.x - n_sealed, coo_w, coo_pc, ne_counter, open_first_slot,
+                        n_open_slots, bitmap_words, stamp, q_w, q_meta, idf_tab, slot_ni, lfix, out_like, done_counter);
 }
 
 // fixed point -> float, and the accumulator is left zeroed for the next frame (no separate memset launch)
@@ -411,7 +531,7 @@ void Tfidf::destroy() {
     for (Bucket& b : buckets) { b.coo_w.release(bytes_device); b.coo_pc.release(bytes_device); b.dir.release(bytes_device); b.ent.release(bytes_device); }
     buckets.clear();
     DevBuf* all[] = {&slot_sig, &slot_ni, &slot_begin, &slot_cnt, &nw, &bkt_tab, &bkt_ne, &bkt_list, &lfix, &q_w, &q_cnt, &q_idf,
-                     &q_meta, &tmp_cursor, &d_stage, &idf_tab};
+                     &q_meta, &tmp_cursor, &d_stage, &idf_tab, &bkt_list_all, &open_done};
     for (DevBuf* d : all) d->release(bytes_device);
     h_stage.release();
 }
@@ -448,7 +568,7 @@ hipError_t Tfidf::wslot_of(int32_t word_id, int32_t* out) {
 hipError_t Tfidf::upload_buckets() {
     if (!bkt_dirty) return hipSuccess;
     h_bkt.resize(buckets.size());
-    std::vector<int32_t> list;
+    std::vector<int32_t> list, list_all;
     for (size_t i = 0; i < buckets.size(); ++i) {
         Bucket& b = buckets[i];
         BucketDev d;
@@ -457,8 +577,15 @@ hipError_t Tfidf::upload_buckets() {
         d.W = b.W; d.sealed = b.sealed ? 1u : 0u; d.n_e_sealed = b.n_e_sealed; d.pad = 0;
         h_bkt[i] = d;
         if (b.sealed && b.live > 0) list.push_back((int32_t)i);
+        if (b.sealed) list_all.push_back((int32_t)i);
     }
     n_list = (int)list.size();
+    n_list_all = (int)list_all.size();
+    if (n_list_all) {
+        TF_TRY(bkt_list_all.reserve(list_all.size() * 4, 0, stream, bytes_device));
+        TF_TRY(hipStreamSynchronize(stream));
+        TF_TRY(hipMemcpy(bkt_list_all.p, list_all.data(), list_all.size() * 4, hipMemcpyHostToDevice));
+    }
     if (!buckets.empty()) {
         TF_TRY(bkt_tab.reserve(buckets.size() * sizeof(BucketDev), 0, stream, bytes_device));
         TF_TRY(hipStreamSynchronize(stream));   // pageable source: keep it simple and ordered
@@ -499,9 +626,36 @@ hipError_t Tfidf::seal(int bi) {
     return hipSuccess;
 }
 
-static hipError_t run_frame_words(Tfidf& t, const int32_t* d_wslots, int n, bool reg, int32_t sig_id, int64_t slot, int32_t ni, float N) {
+static RetireArgs take_pending(Tfidf& t) {
+    RetireArgs r;
+    r.n = 0;
+    for (int i = 0; i < 4; ++i) { r.slot[i] = 0; r.coo_w[i] = nullptr; }
+    while (r.n < 4 && !t.pending_retire.empty()) {
+        const int64_t slot = t.pending_retire.back();
+        t.pending_retire.pop_back();
+        r.slot[r.n] = slot;
+        r.coo_w[r.n] = t.buckets[(size_t)(slot / TF_R)].coo_w.as<uint32_t>();
+        r.n += 1;
+    }
+    return r;
+}
+
+// apply every pending retirement now (stand-alone launch): needed before a bucket's memory is released
+hipError_t Tfidf::flush_retire() {
+    while (!pending_retire.empty()) {
+        const int64_t slot = pending_retire.back();
+        pending_retire.pop_back();
+        retire_kernel<<<1, 256, 0, stream>>>((long long)slot, buckets[(size_t)(slot / TF_R)].coo_w.as<uint32_t>(), slot_begin.as<uint32_t>(),
+                                             slot_cnt.as<uint32_t>(), nw.as<uint32_t>(), slot_ni.as<uint32_t>(), slot_sig.as<int32_t>());
+        TF_TRY(hipGetLastError());
+    }
+    return hipSuccess;
+}
+
+static hipError_t run_frame_words(Tfidf& t, const int32_t* d_wslots, int n, bool reg, int32_t sig_id, int64_t slot, int32_t ni, float N,
+                                  const ResolveArgs* resolve = nullptr) {
     const int H = next_pow2(std::max(2 * n, 128));
-    const size_t shmem = ((size_t)H * 2 + H / 64 + 2) * 4;
+    size_t shmem = ((size_t)H * 2 + H / 64 + 2) * 4;
     uint32_t* coo_w = nullptr; uint32_t* coo_pc = nullptr; uint32_t* ne = nullptr;
     if (reg) {
         const int bi = (int)(slot / TF_R);
@@ -509,19 +663,31 @@ static hipError_t run_frame_words(Tfidf& t, const int32_t* d_wslots, int n, bool
         coo_pc = t.buckets[bi].coo_pc.as<uint32_t>();
         ne = t.bkt_ne.as<uint32_t>() + bi;
     }
+    if (t.pending_retire.size() > 4) TF_TRY(t.flush_retire());
+    const RetireArgs ret = take_pending(t);
     t.stamp += 1;
     if (t.stamp == 0) t.stamp = 1;
-    frame_words_kernel<<<1, FW_BLOCK, shmem, t.stream>>>(d_wslots, n, H, reg ? 1 : 0, sig_id, (long long)slot, (uint32_t)(slot % TF_R),
-                                                        (uint32_t)ni, N, t.stamp, t.nw.as<uint32_t>(), coo_w, coo_pc, ne,
-                                                        t.slot_sig.as<int32_t>(), t.slot_ni.as<uint32_t>(),
-                                                        t.slot_begin.as<uint32_t>(), t.slot_cnt.as<uint32_t>(),
-                                                        t.q_w.as<uint32_t>(), t.q_cnt.as<uint32_t>(), t.q_idf.as<float>(),
-                                                        t.q_meta.as<uint32_t>(), t.idf_tab.as<uint2>());
+    if (resolve) {
+        const int mw = (resolve->q + 63) / 64 * 2;
+        shmem = std::max(shmem, (size_t)(3 * mw + 2) * 4);
+        frame_tail_kernel<<<1, FW_BLOCK, shmem, t.stream>>>(*resolve, H, reg ? 1 : 0, sig_id, (long long)slot, (uint32_t)(slot % TF_R),
+                                                           (uint32_t)ni, N, t.stamp, t.nw.as<uint32_t>(), coo_w, coo_pc, ne,
+                                                           t.slot_sig.as<int32_t>(), t.slot_ni.as<uint32_t>(), t.slot_begin.as<uint32_t>(),
+                                                           t.slot_cnt.as<uint32_t>(), t.q_w.as<uint32_t>(), t.q_cnt.as<uint32_t>(),
+                                                           t.q_idf.as<float>(), t.q_meta.as<uint32_t>(), t.idf_tab.as<uint2>(), ret);
+    } else {
+        frame_words_kernel<<<1, FW_BLOCK, shmem, t.stream>>>(d_wslots, n, H, reg ? 1 : 0, sig_id, (long long)slot, (uint32_t)(slot % TF_R),
+                                                            (uint32_t)ni, N, t.stamp, t.nw.as<uint32_t>(), coo_w, coo_pc, ne,
+                                                            t.slot_sig.as<int32_t>(), t.slot_ni.as<uint32_t>(),
+                                                            t.slot_begin.as<uint32_t>(), t.slot_cnt.as<uint32_t>(),
+                                                            t.q_w.as<uint32_t>(), t.q_cnt.as<uint32_t>(), t.q_idf.as<float>(),
+                                                            t.q_meta.as<uint32_t>(), t.idf_tab.as<uint2>(), ret);
+    }
     t.q_n_ub = n;
     return hipGetLastError();
 }
 
-hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N) {
+hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N, const ResolveArgs* resolve) {
     if (n > TF_MAX_WORDS) return hipErrorInvalidValue;
     const int64_t slot = n_slots;
     TF_TRY(ensure_slots(slot + 1));
@@ -540,7 +706,7 @@ hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, i
         TF_TRY(b.coo_pc.reserve(want, (size_t)b.ub_entries * 4, stream, bytes_device));
         bkt_dirty = true;
     }
-    TF_TRY(run_frame_words(*this, d_wslots, n, true, sig_id, slot, ni, N));
+    TF_TRY(run_frame_words(*this, d_wslots, n, true, sig_id, slot, ni, N, resolve));
     b.ub_entries += n;
     b.n_slots += 1;
     b.live += 1;
@@ -551,9 +717,9 @@ hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, i
     return hipSuccess;
 }
 
-hipError_t Tfidf::query_dev(const int32_t* d_wslots, int n, float N) {
+hipError_t Tfidf::query_dev(const int32_t* d_wslots, int n, float N, const ResolveArgs* resolve) {
     if (n > TF_MAX_WORDS) return hipErrorInvalidValue;
-    return run_frame_words(*this, d_wslots, n, false, 0, 0, 0, N);
+    return run_frame_words(*this, d_wslots, n, false, 0, 0, 0, N, resolve);
 }
 
 static int env_int(const char* name, int dflt) {
@@ -563,7 +729,38 @@ static int env_int(const char* name, int dflt) {
 
 hipError_t Tfidf::score(float* d_likelihood) {
     if (n_slots == 0) return hipSuccess;
-    // lfix is all zero here: zero-initialised on growth and re-zeroed by the previous frame's finalize_kernel
+    TF_TRY(flush_retire());
+    TF_TRY(upload_buckets());
+    // lfix is all zero here: zero-initialised on growth and re-zeroed by whoever consumed it last
+    static const int scb = env_int("LCD_SC_BLOCK", 512);
+    static const int gforce = env_int("LCD_SC_G", 0);
+    static const int fuse = env_int("LCD_SC_FUSED", 1);
+    const int wcap_all = std::max(q_n_ub, 1);
+    const bool has_open = !buckets.empty() && !buckets.back().sealed;
+    const int bitmap_words = (n_wslots + 31) / 32;
+    if (fuse && gforce <= 1 && (size_t)bitmap_words * 4 <= 32 * 1024 && (scb == 256 || scb == 512 || scb == 1024)) {
+        // one launch: every sealed bucket writes its 256 likelihood values straight from LDS, the open bucket's workgroups
+        // accumulate through lfix and the last of them converts its slots
+        const size_t sealed_bytes = (size_t)TF_R * 8 + (size_t)TF_R * 4 + ((size_t)wcap_all * 3 + 1 + scb + 1 + 4) * 4;
+        const size_t shmem = std::max(sealed_bytes, (size_t)std::max(bitmap_words, 1) * 4);
+        int open_blocks = 0, bi = 0, n_open_slots = 0;
+        const Bucket* ob = nullptr;
+        if (has_open) {
+            bi = (int)buckets.size() - 1;
+            ob = &buckets[bi];
+            n_open_slots = ob->n_slots;
+            open_blocks = (int)std::min<int64_t>(std::max<int64_t>((ob->ub_entries + 4 * scb - 1) / (4 * scb), 1), 256);
+        }
+        if (n_list_all + open_blocks == 0) return hipSuccess;
+        TF_TRY(grow_zeroed(open_done, 64, stream, bytes_device));
+#define LCD_SCORE_FUSED(B) score_fused_kernel<B><<<n_list_all + open_blocks, B, shmem, stream>>>(bkt_tab.as<BucketDev>(), bkt_list_all.as<int32_t>(), \
+            n_list_all, wcap_all, q_w.as<uint32_t>(), q_idf.as<float>(), q_meta.as<uint32_t>(), slot_ni.as<uint32_t>(), lfix.as<unsigned long long>(), \
+            d_likelihood, ob ? ob->coo_w.as<uint32_t>() : nullptr, ob ? ob->coo_pc.as<uint32_t>() : nullptr, bkt_ne.as<uint32_t>() + bi, \
+            (long long)bi * TF_R, n_open_slots, bitmap_words, stamp, idf_tab.as<uint2>(), open_done.as<int>())
+        if (scb == 256) LCD_SCORE_FUSED(256); else if (scb == 512) LCD_SCORE_FUSED(512); else LCD_SCORE_FUSED(1024);
+#undef LCD_SCORE_FUSED
+        return hipGetLastError();
+    }
     TF_TRY(score_partial(lfix.as<unsigned long long>()));
     finalize_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, stream>>>(lfix.as<long long>(), (long long)n_slots, d_likelihood);
     return hipGetLastError();
@@ -573,6 +770,7 @@ hipError_t Tfidf::score(float* d_likelihood) {
 // or a running sum); the multi-GPU path all-reduces these integers before finalize()
 hipError_t Tfidf::score_partial(unsigned long long* lfix_target) {
     if (n_slots == 0) return hipSuccess;
+    TF_TRY(flush_retire());
     TF_TRY(upload_buckets());
     const int wcap_all = std::max(q_n_ub, 1);
     if (n_list > 0) {
@@ -615,14 +813,14 @@ hipError_t Tfidf::retire(int32_t sig_id) {
     const int64_t slot = it->second;
     const int bi = (int)(slot / TF_R);
     Bucket& b = buckets[bi];
-    retire_kernel<<<1, 256, 0, stream>>>((long long)slot, b.coo_w.as<uint32_t>(), slot_begin.as<uint32_t>(), slot_cnt.as<uint32_t>(),
-                                         nw.as<uint32_t>(), slot_ni.as<uint32_t>(), slot_sig.as<int32_t>());
-    TF_TRY(hipGetLastError());
+    // the device side (nw -= 1 for the signature's words, ni = 0) rides along with the next frame-words launch
+    pending_retire.push_back(slot);
     sig_slot.erase(it);
     live_sigs -= 1;
     b.live -= 1;
     if (b.live == 0 && b.sealed) {
-        // every signature of the bucket is gone: drop its postings (the retire kernel above must finish first)
+        // every signature of the bucket is gone: drop its postings (pending retirements read its log: apply them first)
+        TF_TRY(flush_retire());
         TF_TRY(hipStreamSynchronize(stream));
         postings_ub -= b.ub_entries;
         b.coo_w.release(bytes_device); b.coo_pc.release(bytes_device); b.dir.release(bytes_device); b.ent.release(bytes_device);
