@@ -25,6 +25,8 @@
 // a dot product does not see.  D layout: lane holds query (l&31), 16 rows (reg&3) + 8*(reg>>2) + 4*(l>>5).
 #include "lcd_kernels.h"
 
+#include <cstdlib>
+
 namespace lcd {
 namespace {
 
@@ -128,23 +130,28 @@ __device__ __forceinline__ void push_group(const f32x16& acc, uint32_t tl, uint3
     }
 }
 
-// partial_keys [n_blocks][MF_KEEP][qpad] u64, partial_lmin [n_blocks][qpad] f32 bits
-template <int DIM>
-__global__ __launch_bounds__(MF_BLOCK, 2) void knn_mfma_filter_kernel(const float* __restrict__ vocab, const float* __restrict__ row_norm,
-                                                                      int n_rows, const float* __restrict__ queries, int nq, int qpad,
-                                                                      int tiles_per_block, uint64_t* __restrict__ partial_keys,
-                                                                      uint32_t* __restrict__ partial_lmin) {
+// partial_keys [n_blocks][MF_KEEP][qpad] u64, partial_lmin [n_blocks][qpad] f32 bits.
+// NG = 32-query column groups per wave (wave tile = NG*32 queries x 32 rows).  NG = 4 runs ONE wave per SIMD with four
+// independent accumulator chains (A tiles reused 4x, the VALU top-3 update of one accumulator issues under the MFMAs of
+// the next); NG = 2 runs two waves per SIMD.
+template <int DIM, int NG>
+__global__ __launch_bounds__(MF_BLOCK, (NG == 2 ? 2 : 1)) void knn_mfma_filter_kernel(const float* __restrict__ vocab,
+                                                                                     const float* __restrict__ row_norm, int n_rows,
+                                                                                     const float* __restrict__ queries, int nq, int qpad,
+                                                                                     int tiles_per_block, uint64_t* __restrict__ partial_keys,
+                                                                                     uint32_t* __restrict__ partial_lmin) {
     constexpr int KH = DIM / 2;                    // floats of a row held by one lane
+    constexpr int QW = NG * 32;                    // queries per wave / workgroup
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 31, half = lane >> 5;
-    const int q0 = blockIdx.y * 64;
+    const int q0 = blockIdx.y * QW;
 
-    // B operand: both 32-query groups, pre-scaled by -2 (exact), + |q|^2 for the extra k-step
-    float b[2][KH];
-    float b_aug[2];
+    // B operand: the NG 32-query groups, pre-scaled by -2 (exact), + |q|^2 for the extra k-step
+    float b[NG][KH];
+    float b_aug[NG];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NG; ++g) {
         const int qi = min(q0 + g * 32 + col, nq - 1);
         const float4* src = reinterpret_cast<const float4*>(queries + (size_t)qi * DIM + half * KH);
         float part = 0.0f;
@@ -166,43 +173,58 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void knn_mfma_filter_kernel(const floa
     const int t_end = min(t_begin + per_wave, tile1);
 
     // every lane keeps its three best keys per query group: a row the lane drops is no better than its third key
-    uint32_t k0[2] = {~0u, ~0u}, k1[2] = {~0u, ~0u}, k2[2] = {~0u, ~0u};
-    // Software pipeline: the A tile of step t+1 is loaded while tile t occupies the matrix pipe, and the VALU top-3
-    // update of one accumulator is issued under the 33 MFMAs of the next one (acc_prev / acc_cur).
+    uint32_t k0[NG], k1[NG], k2[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { k0[g] = ~0u; k1[g] = ~0u; k2[g] = ~0u; }
+    // Software pipeline over the flattened (tile, group) sequence: the A tile of the next step is loaded while the current
+    // one occupies the matrix pipe, and the VALU top-3 update of accumulator i is issued under the 33 MFMAs of accumulator i+1.
     float a0[KH], a1[KH];
     float aug0 = 0.0f, aug1 = 0.0f;
     if (t_begin < t_end) {
         load_a_tile<KH>(vocab, row_norm, n_rows, t_begin, col, half, a0, aug0);
-        f32x16 pend = mfma_group<KH>(a0, aug0, b[0], b_aug[0]);      // (tile t_begin, group 0) in flight
-        int pend_tl = 0;
+        f32x16 pend = mfma_group<KH>(a0, aug0, b[0], b_aug[0]);      // (t_begin, group 0) in flight
         for (int t = t_begin; t < t_end; t += 2) {
             const bool has1 = t + 1 < t_end, has2 = t + 2 < t_end;
             if (has1) load_a_tile<KH>(vocab, row_norm, n_rows, t + 1, col, half, a1, aug1);
-            f32x16 cur = mfma_group<KH>(a0, aug0, b[1], b_aug[1]);   // (t, group 1)
-            push_group(pend, (uint32_t)pend_tl, k0[0], k1[0], k2[0]);    // (t, group 0) under those MFMAs
-            if (!has1) { push_group(cur, (uint32_t)(t - t_begin), k0[1], k1[1], k2[1]); break; }
-            pend = mfma_group<KH>(a1, aug1, b[0], b_aug[0]);         // (t+1, group 0)
-            push_group(cur, (uint32_t)(t - t_begin), k0[1], k1[1], k2[1]);
+            // tile t (registers a0): groups 1 .. NG-1, each overlapping the update of its predecessor
+#pragma unroll
+            for (int g = 1; g < NG; ++g) {
+                f32x16 cur = mfma_group<KH>(a0, aug0, b[g], b_aug[g]);
+                push_group(pend, (uint32_t)(t - t_begin), k0[g - 1], k1[g - 1], k2[g - 1]);
+                pend = cur;
+            }
+            if (!has1) { push_group(pend, (uint32_t)(t - t_begin), k0[NG - 1], k1[NG - 1], k2[NG - 1]); break; }
+            {
+                f32x16 cur = mfma_group<KH>(a1, aug1, b[0], b_aug[0]);   // (t+1, group 0)
+                push_group(pend, (uint32_t)(t - t_begin), k0[NG - 1], k1[NG - 1], k2[NG - 1]);
+                pend = cur;
+            }
             if (has2) load_a_tile<KH>(vocab, row_norm, n_rows, t + 2, col, half, a0, aug0);
-            cur = mfma_group<KH>(a1, aug1, b[1], b_aug[1]);          // (t+1, group 1)
-            push_group(pend, (uint32_t)(t + 1 - t_begin), k0[0], k1[0], k2[0]);
-            if (!has2) { push_group(cur, (uint32_t)(t + 1 - t_begin), k0[1], k1[1], k2[1]); break; }
-            pend = mfma_group<KH>(a0, aug0, b[0], b_aug[0]);         // (t+2, group 0)
-            pend_tl = t + 2 - t_begin;
-            push_group(cur, (uint32_t)(t + 1 - t_begin), k0[1], k1[1], k2[1]);
+#pragma unroll
+            for (int g = 1; g < NG; ++g) {
+                f32x16 cur = mfma_group<KH>(a1, aug1, b[g], b_aug[g]);
+                push_group(pend, (uint32_t)(t + 1 - t_begin), k0[g - 1], k1[g - 1], k2[g - 1]);
+                pend = cur;
+            }
+            if (!has2) { push_group(pend, (uint32_t)(t + 1 - t_begin), k0[NG - 1], k1[NG - 1], k2[NG - 1]); break; }
+            {
+                f32x16 cur = mfma_group<KH>(a0, aug0, b[0], b_aug[0]);   // (t+2, group 0)
+                push_group(pend, (uint32_t)(t + 1 - t_begin), k0[NG - 1], k1[NG - 1], k2[NG - 1]);
+                pend = cur;
+            }
         }
     }
 
     // workgroup merge: 8 partitions (4 waves x 2 halves) x top-3 per query -> top-MF_KEEP + the smallest partition third
-    __shared__ uint64_t s_key[64][MF_WAVES * 2][3];
+    __shared__ uint64_t s_key[QW][MF_WAVES * 2][3];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NG; ++g) {
         s_key[g * 32 + col][wave * 2 + half][0] = widen_key(k0[g], t_begin, half);
         s_key[g * 32 + col][wave * 2 + half][1] = widen_key(k1[g], t_begin, half);
         s_key[g * 32 + col][wave * 2 + half][2] = widen_key(k2[g], t_begin, half);
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < QW) {
         const int ql = threadIdx.x;
         uint64_t keep[MF_KEEP];
 #pragma unroll
@@ -222,9 +244,11 @@ __global__ __launch_bounds__(MF_BLOCK, 2) void knn_mfma_filter_kernel(const floa
             }
         }
         const int qi = q0 + ql;
+        if (qi < qpad) {
 #pragma unroll
-        for (int i = 0; i < MF_KEEP; ++i) partial_keys[((size_t)blockIdx.x * MF_KEEP + i) * qpad + qi] = keep[i];
-        partial_lmin[(size_t)blockIdx.x * qpad + qi] = lmin;
+            for (int i = 0; i < MF_KEEP; ++i) partial_keys[((size_t)blockIdx.x * MF_KEEP + i) * qpad + qi] = keep[i];
+            partial_lmin[(size_t)blockIdx.x * qpad + qi] = lmin;
+        }
     }
 }
 
@@ -448,15 +472,21 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_rowpar_kernel(const float* __res
 // ================================================================================================ host side
 bool knn_mfma_supported(int dtype, int dim) { return dtype == 0 && dim == 64; }
 
+static int mfma_ng() {   // 32-query groups per wave: 4 (one wave per SIMD, default) or 2 (two waves per SIMD)
+    static const int ng = [] { const char* e = getenv("LCD_MFMA_NG"); return (e && atoi(e) == 2) ? 2 : 4; }();
+    return ng;
+}
+
 MfmaPlan knn_mfma_plan(int q, int n_rows) {
     MfmaPlan p;
     p.q = q;
     p.qpad = (q + 63) / 64 * 64;
     p.n_rows = n_rows;
     const int n_tiles = (n_rows + 31) / 32;
-    const int qgroups = p.qpad / 64;
-    // 2 waves per SIMD over the chip: 256 CUs x 4 SIMDs x 2 = 2048 waves = 512 workgroups
-    int nb = (512 + qgroups - 1) / qgroups;
+    const int qw = mfma_ng() * 32;
+    const int qgroups = (q + qw - 1) / qw;
+    // waves to fill the chip: 256 CUs x 4 SIMDs x (2 waves for NG = 2, 1 wave for NG = 4) -> workgroups of 4 waves
+    int nb = ((mfma_ng() == 2 ? 512 : 256) + qgroups - 1) / qgroups;
     if (nb > (n_tiles + MF_WAVES - 1) / MF_WAVES) nb = (n_tiles + MF_WAVES - 1) / MF_WAVES;   // at least one tile per wave
     if (nb < 1) nb = 1;
     nb = (nb + 7) / 8 * 8;
@@ -497,10 +527,15 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
         if (e != hipSuccess) return e;
     }
     if (p.n_blocks > 0) {
-        dim3 grid(p.n_blocks, p.qpad / 64);
+        const int ng = mfma_ng();
+        dim3 grid(p.n_blocks, (p.q + ng * 32 - 1) / (ng * 32));
         if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
-        knn_mfma_filter_kernel<64><<<grid, MF_BLOCK, 0, s>>>((const float*)vocab, row_norm, p.n_rows, (const float*)queries, p.q, p.qpad,
-                                                              p.tiles_per_block, pk, pl);
+        if (ng == 2)
+            knn_mfma_filter_kernel<64, 2><<<grid, MF_BLOCK, 0, s>>>((const float*)vocab, row_norm, p.n_rows, (const float*)queries, p.q, p.qpad,
+                                                                     p.tiles_per_block, pk, pl);
+        else
+            knn_mfma_filter_kernel<64, 4><<<grid, MF_BLOCK, 0, s>>>((const float*)vocab, row_norm, p.n_rows, (const float*)queries, p.q, p.qpad,
+                                                                     p.tiles_per_block, pk, pl);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }
