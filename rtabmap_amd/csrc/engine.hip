@@ -134,7 +134,7 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
     if (e == hipSuccess) e = h->d_n_new.reserve(64, 0, h->stream, &h->bytes_device);
     if (e == hipSuccess) e = h->norm_max.reserve(64, 0, h->stream, &h->bytes_device);
     if (e == hipSuccess) e = hipMemsetAsync(h->norm_max.p, 0, 64, h->stream);
-    if (e == hipSuccess) e = h->row_norm.reserve((size_t)vcap * 4, 0, h->stream, &h->bytes_device);
+    if (e == hipSuccess) e = h->row_norm.reserve(((size_t)vcap + 1) * 8, 0, h->stream, &h->bytes_device);
     { const char* m = getenv("LCD_KNN_MODE"); if (m && *m) h->knn_mode = (m[0] == 'v' || m[0] == '0') ? 0 : 1; }
     if (e == hipSuccess) e = h->tfidf.init(h->stream, &h->bytes_device, cfg->sig_capacity);
     if (e != hipSuccess) { lcd_destroy(h); return LCD_ERR_HIP; }
@@ -215,7 +215,7 @@ int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word
     LCD_HIP(h, hipMemcpyAsync(h->row_id.as<int32_t>() + h->n_rows, ids, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     LCD_HIP(h, hipMemcpyAsync(h->row_wslot.as<int32_t>() + h->n_rows, ws, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     if (h->dtype == LCD_F32) {   // |row|^2 for the MFMA filter
-        LCD_HIP(h, dreserve(h, h->row_norm, (size_t)total * 4, (size_t)h->n_rows * 4));
+        LCD_HIP(h, dreserve(h, h->row_norm, ((size_t)total + 1) * 8, (size_t)h->n_rows * 8));
         LCD_HIP(h, launch_row_norms(h->vocab.p, h->row_id.as<int32_t>(), (int)h->n_rows, n, h->kdim, h->row_norm.as<float>(),
                                     h->norm_max.as<uint32_t>(), h->stream));
     }
@@ -277,7 +277,7 @@ int lcd_vocab_rebuild(lcd_engine* h) {
     std::swap(h->row_id, h->row_id_alt);
     std::swap(h->row_wslot, h->row_wslot_alt);
     if (h->dtype == LCD_F32 && n) {
-        LCD_HIP(h, dreserve(h, h->row_norm, (size_t)n * 4));
+        LCD_HIP(h, dreserve(h, h->row_norm, ((size_t)n + 1) * 8));
         LCD_HIP(h, launch_row_norms(h->vocab.p, h->row_id.as<int32_t>(), 0, n, h->kdim, h->row_norm.as<float>(), h->norm_max.as<uint32_t>(),
                                     h->stream));
         LCD_HIP(h, hipStreamSynchronize(h->stream));

@@ -53,9 +53,11 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-// |row|^2 of the vocabulary (any summation order: the filter only needs it to ~1 ulp x dim); tombstones get +inf
+// Augmentation table of the vocabulary: aug[2r] = |row r|^2 (any summation order: the filter only needs it to ~dim ulps;
+// +inf for tombstones), aug[2r + 1] = 1, plus a sentinel entry {+inf, 1} at r = n_rows for the padding rows of the last
+// tile.  The MFMA filter reads aug[2 * min(row, n_rows) + half] with ONE unconditional load per lane.
 __global__ void row_norm_kernel(const float* __restrict__ vocab, const int32_t* __restrict__ row_id, int first, int n, int dim,
-                                float* __restrict__ norm, uint32_t* __restrict__ norm_max_bits) {
+                                float* __restrict__ aug, uint32_t* __restrict__ norm_max_bits) {
     const int r = first + blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= first + n) return;
     float s = __int_as_float(0x7f800000);
@@ -65,11 +67,13 @@ __global__ void row_norm_kernel(const float* __restrict__ vocab, const int32_t* 
         for (int k = 0; k < dim; ++k) s = fmaf(v[k], v[k], s);
         atomicMax(norm_max_bits, __float_as_uint(s));
     }
-    norm[r] = s;
+    aug[2 * (size_t)r] = s;
+    aug[2 * (size_t)r + 1] = 1.0f;
+    if (r == first + n - 1) { aug[2 * (size_t)(r + 1)] = __int_as_float(0x7f800000); aug[2 * (size_t)(r + 1) + 1] = 1.0f; }
 }
-__global__ void norm_tombstone_kernel(float* __restrict__ norm, const int32_t* __restrict__ rows, int n) {
+__global__ void norm_tombstone_kernel(float* __restrict__ aug, const int32_t* __restrict__ rows, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) norm[rows[i]] = __int_as_float(0x7f800000);
+    if (i < n) aug[2 * (size_t)rows[i]] = __int_as_float(0x7f800000);
 }
 
 // ------------------------------------------------------------------------------------------------ filter
@@ -108,8 +112,9 @@ __device__ __forceinline__ void load_a_tile(const float* __restrict__ vocab, con
         const float4 x = src[v];
         a[4 * v + 0] = x.x; a[4 * v + 1] = x.y; a[4 * v + 2] = x.z; a[4 * v + 3] = x.w;
     }
-    const float vn = row < n_rows ? row_norm[row] : __int_as_float(0x7f800000);
-    a_aug = half == 0 ? vn : 1.0f;                  // A[i][k0] = |v_i|^2, A[i][k1] = 1
+    // A[i][k0] = |v_i|^2 (half 0), A[i][k1] = 1 (half 1): one unconditional load from the augmentation table (a load under a
+    // branch would be waited for at the join, i.e. before the MFMAs it is supposed to hide behind)
+    a_aug = row_norm[2 * (size_t)min(row, n_rows) + half];
 }
 
 // one 32-row tile against one 32-query group: 33 MFMAs
@@ -185,7 +190,8 @@ __global__ __launch_bounds__(MF_BLOCK, (NG == 2 ? 2 : 1)) void knn_mfma_filter_k
         f32x16 pend = mfma_group<KH>(a0, aug0, b[0], b_aug[0]);      // (t_begin, group 0) in flight
         for (int t = t_begin; t < t_end; t += 2) {
             const bool has1 = t + 1 < t_end, has2 = t + 2 < t_end;
-            if (has1) load_a_tile<KH>(vocab, row_norm, n_rows, t + 1, col, half, a1, aug1);
+            // unconditional prefetch (clamped tile index): a load under a branch would be waited for at the join, before the MFMAs
+            load_a_tile<KH>(vocab, row_norm, n_rows, min(t + 1, t_end - 1), col, half, a1, aug1);
             // tile t (registers a0): groups 1 .. NG-1, each overlapping the update of its predecessor
 #pragma unroll
             for (int g = 1; g < NG; ++g) {
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(MF_BLOCK, (NG == 2 ? 2 : 1)) void knn_mfma_filter_k
                 push_group(pend, (uint32_t)(t - t_begin), k0[NG - 1], k1[NG - 1], k2[NG - 1]);
                 pend = cur;
             }
-            if (has2) load_a_tile<KH>(vocab, row_norm, n_rows, t + 2, col, half, a0, aug0);
+            load_a_tile<KH>(vocab, row_norm, n_rows, min(t + 2, t_end - 1), col, half, a0, aug0);
 #pragma unroll
             for (int g = 1; g < NG; ++g) {
                 f32x16 cur = mfma_group<KH>(a1, aug1, b[g], b_aug[g]);
