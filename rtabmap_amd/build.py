@@ -35,6 +35,7 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return OUT
     hipcc = _hipcc()
+    extra = os.environ.get("LCD_EXTRA_HIPCC_FLAGS", "").split()     # timing experiments only (e.g. -DLCD_MFMA_ABLATE=1)
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     procs = []
@@ -42,7 +43,7 @@ def build(force=False, verbose=False):
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

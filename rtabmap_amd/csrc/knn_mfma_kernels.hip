@@ -101,37 +101,112 @@ __device__ __forceinline__ uint64_t widen_key(uint32_t k, int t_begin, int half)
     return ((uint64_t)(k & ~MF_IDX_MASK) << 32) | row;
 }
 
+// A tile = 32 vocabulary rows x DIM floats (8 KB for DIM = 64).  It goes global -> LDS with the asynchronous LDS-DMA
+// (global_load_lds, 16 B per lane, no staging VGPRs, fully coalesced: every instruction moves 1 KiB = 8 whole 128-B lines),
+// then LDS -> VGPRs in MFMA operand order (lane (row l&31, half l>>5) gets the contiguous floats [KH*half, KH*half + KH) of
+// its row).  The DMA writes LDS linearly (wave-uniform base + 16 * lane), so the bank-conflict fix is an XOR swizzle applied
+// to the SOURCE address and to the read address alike (cdna_hip_programming.md rule 21): 16-B chunk c of row r lives at
+// chunk position c ^ (r & 15).  A per-lane gather straight from global memory (row stride 256 B across lanes) touches 64
+// lines per load and thrashes the 32 KiB L1: it made the kernel load-bound.
 template <int KH>
-__device__ __forceinline__ void load_a_tile(const float* __restrict__ vocab, const float* __restrict__ row_norm, int n_rows, int t, int col,
-                                            int half, float (&a)[KH], float& a_aug) {
-    const int row = t * 32 + col;
-    const int rsrc = min(row, n_rows - 1);
-    const float4* src = reinterpret_cast<const float4*>(vocab + (size_t)rsrc * (2 * KH) + half * KH);
+__device__ __forceinline__ void dma_a_tile(const float* __restrict__ vocab, int n_rows, int t, int lane, float* __restrict__ lds_slot) {
+    constexpr int DIM = 2 * KH;
+    constexpr int CPR = DIM / 4;                          // 16-B chunks per row
+    static_assert(CPR == 16 || CPR == 32, "swizzle written for 64- or 128-float rows");
+#pragma unroll
+    for (int i = 0; i < (32 * CPR) / 64; ++i) {           // 8 instructions for DIM = 64
+        const int p = i * 64 + lane;                      // linear chunk position in the LDS slot
+        const int r = p / CPR, cpos = p % CPR;
+        const int c = cpos ^ (r & 15);                    // the global chunk that belongs at this position
+        const int row = min(t * 32 + r, n_rows - 1);      // padding rows repeat the last row (their score is forced to +inf)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vocab + (size_t)row * DIM + c * 4),
+                                         (__attribute__((address_space(3))) void*)(lds_slot + i * 256), 16, 0, 0);
+    }
+}
+template <int KH>
+__device__ __forceinline__ void read_a_tile(const float* __restrict__ lds_slot, int col, int half, float (&a)[KH]) {
+    constexpr int DIM = 2 * KH;
+    const float* rowp = lds_slot + col * DIM;
 #pragma unroll
     for (int v = 0; v < KH / 4; ++v) {
-        const float4 x = src[v];
+        const int c = half * (KH / 4) + v;                // chunk of the row this lane needs
+        const float4 x = *reinterpret_cast<const float4*>(rowp + ((c ^ (col & 15)) << 2));
         a[4 * v + 0] = x.x; a[4 * v + 1] = x.y; a[4 * v + 2] = x.z; a[4 * v + 3] = x.w;
     }
-    // A[i][k0] = |v_i|^2 (half 0), A[i][k1] = 1 (half 1): one unconditional load from the augmentation table (a load under a
-    // branch would be waited for at the join, i.e. before the MFMAs it is supposed to hide behind)
-    a_aug = row_norm[2 * (size_t)min(row, n_rows) + half];
 }
 
 // one 32-row tile against one 32-query group: 33 MFMAs
 template <int KH>
 __device__ __forceinline__ f32x16 mfma_group(const float (&a)[KH], float a_aug, const float (&b)[KH], float b_aug) {
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#if LCD_MFMA_ABLATE == 2
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = a[r] * b[r] + a_aug * b_aug;
+    return acc;
+#endif
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug, acc, 0, 0, 0);
 #pragma unroll
     for (int k = 0; k < KH; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], acc, 0, 0, 0);
     return acc;
 }
+// one 32-row tile against TWO 32-query groups with the two accumulator chains interleaved k-step by k-step: consecutive
+// MFMAs are independent, so the matrix pipe never waits for a dependent accumulator
+template <int KH>
+__device__ __forceinline__ void mfma_pair(const float (&a)[KH], float a_aug, const float (&b0)[KH], float b0_aug, const float (&b1)[KH],
+                                          float b1_aug, f32x16& acc0, f32x16& acc1) {
+    const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b0_aug, z, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b1_aug, z, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b0[k], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b1[k], acc1, 0, 0, 0);
+    }
+}
+
 // acc[r] = approximate squared distance between the lane's query and row t*32 + (r&3) + 8*(r>>2) + 4*half
+#ifndef LCD_MFMA_ABLATE
+#define LCD_MFMA_ABLATE 0      // 1: skip the top-3 update (timing experiment only), 2: skip the MFMAs
+#endif
 __device__ __forceinline__ void push_group(const f32x16& acc, uint32_t tl, uint32_t& k0, uint32_t& k1, uint32_t& k2) {
+#if LCD_MFMA_ABLATE == 1
+    asm volatile("" :: "v"(acc[0]), "v"(acc[5]), "v"(acc[10]), "v"(acc[15]));
+    k0 = min(k0, __float_as_uint(acc[3])); (void)tl; (void)k1; (void)k2;
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const uint32_t sbits = (uint32_t)max(__float_as_int(acc[r]), 0);   // clamp tiny negative scores (sign bit set) to +0
         top3_push32(k0, k1, k2, (sbits & ~MF_IDX_MASK) | (tl << 4) | (uint32_t)r);
+    }
+}
+
+// One software-pipeline step in explicit program order: the 66 MFMAs of a group pair (two interleaved accumulator chains)
+// with the top-3 update of the PREVIOUS pair's 32 scores spread between them -- 4 MFMAs, then the update of one score of
+// each pending accumulator (~14 VALU), sixteen times.  A wave issues in order and the compiler otherwise emits the MFMAs
+// back to back and the VALU afterwards (measured: MFMA-busy 57 % of the wave cycles, VALU time additive), so the order is
+// pinned with sched_barrier(0): the VALU then issues in the shadow of the 64-cycle MFMAs.
+template <int KH>
+__device__ __forceinline__ void mfma_pair_push(const float (&a)[KH], float a_aug, const float (&b0)[KH], float b0_aug, const float (&b1)[KH],
+                                               float b1_aug, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1, uint32_t tl,
+                                               uint32_t& k00, uint32_t& k01, uint32_t& k02, uint32_t& k10, uint32_t& k11, uint32_t& k12) {
+    static_assert(KH == 32, "interleave pattern written for 64-float rows");
+    const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b0_aug, z, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b1_aug, z, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * r], b0[2 * r], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * r], b1[2 * r], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * r + 1], b0[2 * r + 1], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * r + 1], b1[2 * r + 1], c1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const uint32_t s0 = (uint32_t)max(__float_as_int(p0[r]), 0), s1 = (uint32_t)max(__float_as_int(p1[r]), 0);
+            top3_push32(k00, k01, k02, (s0 & ~MF_IDX_MASK) | (tl << 4) | (uint32_t)r);
+            top3_push32(k10, k11, k12, (s1 & ~MF_IDX_MASK) | (tl << 4) | (uint32_t)r);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -181,44 +256,52 @@ __global__ __launch_bounds__(MF_BLOCK, (NG == 2 ? 2 : 1)) void knn_mfma_filter_k
     uint32_t k0[NG], k1[NG], k2[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) { k0[g] = ~0u; k1[g] = ~0u; k2[g] = ~0u; }
-    // Software pipeline over the flattened (tile, group) sequence: the A tile of the next step is loaded while the current
-    // one occupies the matrix pipe, and the VALU top-3 update of accumulator i is issued under the 33 MFMAs of accumulator i+1.
-    float a0[KH], a1[KH];
-    float aug0 = 0.0f, aug1 = 0.0f;
+    // Software pipeline per wave: while tile t occupies the matrix pipe, the LDS-DMA of tile t+1 is in flight into the wave's
+    // other LDS slot; it is waited for (vmcnt) and read back in operand order right before it is needed.  The two accumulator
+    // chains of a group pair are interleaved (independent consecutive MFMAs); the VALU top-3 update of a pair is issued under
+    // the MFMAs of the next pair.  Each wave owns its two slots: no workgroup barrier in the loop.
+    __shared__ __attribute__((aligned(16))) float s_tile[MF_WAVES][2][32 * DIM];
+    float a[KH];
+    float aug = 0.0f;
     if (t_begin < t_end) {
-        load_a_tile<KH>(vocab, row_norm, n_rows, t_begin, col, half, a0, aug0);
-        f32x16 pend = mfma_group<KH>(a0, aug0, b[0], b_aug[0]);      // (t_begin, group 0) in flight
-        for (int t = t_begin; t < t_end; t += 2) {
-            const bool has1 = t + 1 < t_end, has2 = t + 2 < t_end;
-            // unconditional prefetch (clamped tile index): a load under a branch would be waited for at the join, before the MFMAs
-            load_a_tile<KH>(vocab, row_norm, n_rows, min(t + 1, t_end - 1), col, half, a1, aug1);
-            // tile t (registers a0): groups 1 .. NG-1, each overlapping the update of its predecessor
+        dma_a_tile<KH>(vocab, n_rows, t_begin, lane, s_tile[wave][0]);
+        aug = row_norm[2 * (size_t)min(t_begin * 32 + col, n_rows) + half];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        read_a_tile<KH>(s_tile[wave][0], col, half, a);
+        dma_a_tile<KH>(vocab, n_rows, min(t_begin + 1, t_end - 1), lane, s_tile[wave][1]);        // prefetch tile t_begin + 1
+        float aug_next = row_norm[2 * (size_t)min(min(t_begin + 1, t_end - 1) * 32 + col, n_rows) + half];
+        f32x16 p0, p1;                                               // pending accumulators (previous pair)
+        int pend_t = t_begin;
+        mfma_pair<KH>(a, aug, b[0], b_aug[0], b[1], b_aug[1], p0, p1);
+        for (int t = t_begin; t < t_end; ++t) {
 #pragma unroll
-            for (int g = 1; g < NG; ++g) {
-                f32x16 cur = mfma_group<KH>(a0, aug0, b[g], b_aug[g]);
-                push_group(pend, (uint32_t)(t - t_begin), k0[g - 1], k1[g - 1], k2[g - 1]);
-                pend = cur;
+            for (int gp = 1; gp < NG / 2; ++gp) {                    // remaining pairs of tile t
+                f32x16 c0, c1;
+                mfma_pair_push<KH>(a, aug, b[2 * gp], b_aug[2 * gp], b[2 * gp + 1], b_aug[2 * gp + 1], c0, c1, p0, p1,
+                                   (uint32_t)(pend_t - t_begin), k0[2 * gp - 2], k1[2 * gp - 2], k2[2 * gp - 2], k0[2 * gp - 1],
+                                   k1[2 * gp - 1], k2[2 * gp - 1]);
+                p0 = c0; p1 = c1;
             }
-            if (!has1) { push_group(pend, (uint32_t)(t - t_begin), k0[NG - 1], k1[NG - 1], k2[NG - 1]); break; }
+            if (t + 1 >= t_end) break;
+            // tile t+1 has landed in the other slot: operand order -> registers (the MFMAs that read `a` are already issued),
+            // then start the DMA of tile t+2 into the slot just vacated
+            const int cur = (t + 1 - t_begin) & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_a_tile<KH>(s_tile[wave][cur], col, half, a);
+            aug = aug_next;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot reads above precede the DMA that overwrites the other slot's twin
+            dma_a_tile<KH>(vocab, n_rows, min(t + 2, t_end - 1), lane, s_tile[wave][cur ^ 1]);
+            aug_next = row_norm[2 * (size_t)min(min(t + 2, t_end - 1) * 32 + col, n_rows) + half];
             {
-                f32x16 cur = mfma_group<KH>(a1, aug1, b[0], b_aug[0]);   // (t+1, group 0)
-                push_group(pend, (uint32_t)(t - t_begin), k0[NG - 1], k1[NG - 1], k2[NG - 1]);
-                pend = cur;
-            }
-            load_a_tile<KH>(vocab, row_norm, n_rows, min(t + 2, t_end - 1), col, half, a0, aug0);
-#pragma unroll
-            for (int g = 1; g < NG; ++g) {
-                f32x16 cur = mfma_group<KH>(a1, aug1, b[g], b_aug[g]);
-                push_group(pend, (uint32_t)(t + 1 - t_begin), k0[g - 1], k1[g - 1], k2[g - 1]);
-                pend = cur;
-            }
-            if (!has2) { push_group(pend, (uint32_t)(t + 1 - t_begin), k0[NG - 1], k1[NG - 1], k2[NG - 1]); break; }
-            {
-                f32x16 cur = mfma_group<KH>(a0, aug0, b[0], b_aug[0]);   // (t+2, group 0)
-                push_group(pend, (uint32_t)(t + 1 - t_begin), k0[NG - 1], k1[NG - 1], k2[NG - 1]);
-                pend = cur;
+                f32x16 c0, c1;                                       // (t+1, pair 0) with the update of (t, last pair)
+                mfma_pair_push<KH>(a, aug, b[0], b_aug[0], b[1], b_aug[1], c0, c1, p0, p1, (uint32_t)(t - t_begin), k0[NG - 2], k1[NG - 2],
+                                   k2[NG - 2], k0[NG - 1], k1[NG - 1], k2[NG - 1]);
+                p0 = c0; p1 = c1; pend_t = t + 1;
             }
         }
+        // the last pending pair: the last pair of groups of the last tile
+        push_group(p0, (uint32_t)(pend_t - t_begin), k0[NG - 2], k1[NG - 2], k2[NG - 2]);
+        push_group(p1, (uint32_t)(pend_t - t_begin), k0[NG - 1], k1[NG - 1], k2[NG - 1]);
     }
 
     // workgroup merge: 8 partitions (4 waves x 2 halves) x top-3 per query -> top-MF_KEEP + the smallest partition third
