@@ -207,8 +207,18 @@ def main():
     n_rows_rank = (sh.hi - sh.lo) if shard else N_WORDS
     flops = 2.0 * Q * n_rows_rank * DIM
     achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    # HBM traffic per launch of that kernel: from the committed rocprofv3 --pmc summary (FETCH_SIZE / WRITE_SIZE cannot be read
+    # from inside the process); null when the profile is not there or was taken for another vocabulary split
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+        if not shard and kern_name in pmc:
+            traffic = pmc[kern_name]["hbm_bytes_per_launch"] / 1e9
+    except Exception:
+        traffic = None
     roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS,
-                "traffic": None, "kernel": kern_name, "ms": kern_ms, "samples": kern_n,
+                "traffic": traffic, "traffic_unit": "GB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)", "kernel": kern_name, "ms": kern_ms,
+                "samples": kern_n,
                 "algorithmic_gbps": (n_rows_rank * DIM * 4 + Q * DIM * 4 + Q * 16) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0}
 
     out = {

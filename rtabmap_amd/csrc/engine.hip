@@ -65,7 +65,7 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
                                    prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr,
                                    !h->fail_count_clean));
         h->fail_count_clean = false;
-        if (prof) { h->prof_n += 1; h->prof_kernel = "knn_mfma_filter_kernel<64>"; }
+        if (prof) { h->prof_n += 1; h->prof_kernel = "knn_mfma_filter_kernel"; }
         // the queries the certificate rejected are redone exactly by the row-parallel kernel (usually none: it leaves at once)
         LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
         LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(),
