@@ -27,8 +27,16 @@ struct lcd_engine {
     lcd::DevBuf vocab, row_id, row_wslot;
     lcd::DevBuf vocab_alt, row_id_alt, row_wslot_alt;   // rebuild target (swapped in)
     int64_t n_rows = 0, n_live = 0;
-    std::vector<int32_t> h_row_id;                      // host mirror of row_id (row order is the tie-break contract)
-    std::unordered_map<int32_t, int32_t> word_row;      // live word id -> row
+    // host mirror of the row order (the tie-break contract): key = word id the row was appended with, live = not tombstoned.
+    // While the keys are ascending (the usual case: word ids only grow) a word's row is found by binary search; only a
+    // vocabulary with out-of-order appends (re-activated old words) needs the id -> row map, built lazily.
+    std::vector<int32_t> h_row_key;
+    std::vector<char> h_row_live;
+    bool rows_sorted = true;
+    std::unordered_map<int32_t, int32_t> word_row;      // only valid when !rows_sorted && word_row_valid
+    bool word_row_valid = false;
+    lcd::DevBuf row_norm_alt;
+    int find_row(int32_t word_id);
 
     // ---- per-call scratch
     lcd::DevBuf d_queries, d_partial, d_knn_row, d_knn_word, d_knn_wslot, d_knn_dist, d_selfdist, d_out_word, d_out_wslot,

@@ -14,6 +14,24 @@
 
 using namespace lcd;
 
+// row of a live word, -1 if absent
+int lcd_engine::find_row(int32_t word_id) {
+    if (rows_sorted) {
+        auto it = std::lower_bound(h_row_key.begin(), h_row_key.begin() + n_rows, word_id);
+        if (it == h_row_key.begin() + n_rows || *it != word_id) return -1;
+        const int r = (int)(it - h_row_key.begin());
+        return h_row_live[r] ? r : -1;
+    }
+    if (!word_row_valid) {
+        word_row.clear();
+        word_row.reserve((size_t)n_rows * 2);
+        for (int64_t r = 0; r < n_rows; ++r) if (h_row_live[r]) word_row[h_row_key[r]] = (int32_t)r;
+        word_row_valid = true;
+    }
+    auto it = word_row.find(word_id);
+    return it == word_row.end() ? -1 : it->second;
+}
+
 #define LCD_CHECK_HANDLE(h) do { if (!(h)) return LCD_ERR_INVALID; } while (0)
 #define LCD_HIP(h, x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return (h)->hip_fail(e__, #x); } while (0)
 #define LCD_DEV(h) LCD_HIP(h, hipSetDevice((h)->device))
@@ -152,7 +170,7 @@ void lcd_destroy(lcd_engine* h) {
                      &h->d_partial, &h->d_knn_row, &h->d_knn_word, &h->d_knn_wslot, &h->d_knn_dist, &h->d_selfdist, &h->d_out_word,
                      &h->d_out_wslot, &h->d_n_new, &h->d_tmp_i32, &h->d_extra_rows, &h->d_extra_id, &h->d_extra_word,
                      &h->d_extra_dist, &h->d_extra_row, &h->d_like, &h->d_slots, &h->d_bits, &h->row_norm, &h->norm_max, &h->d_partial2,
-                     &h->d_fail_list, &h->d_fail_count, &h->d_partial3};
+                     &h->d_fail_list, &h->d_fail_count, &h->d_partial3, &h->row_norm_alt};
     for (DevBuf* d : all) d->release(&h->bytes_device);
     h->h_in.release(); h->h_out.release(); h->h_out2.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -176,8 +194,11 @@ int lcd_vocab_clear(lcd_engine* h) {
     LCD_DEV(h);
     LCD_HIP(h, hipStreamSynchronize(h->stream));
     h->n_rows = 0; h->n_live = 0;
-    h->h_row_id.clear();
+    h->h_row_key.clear();
+    h->h_row_live.clear();
+    h->rows_sorted = true;
     h->word_row.clear();
+    h->word_row_valid = false;
     return LCD_OK;
 }
 
@@ -188,7 +209,7 @@ int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word
     if (n == 0) return LCD_OK;
     for (int i = 0; i < n; ++i) {
         if (word_ids[i] <= 0) return h->fail(LCD_ERR_INVALID, "lcd_vocab_append: word ids must be > 0");
-        if (h->word_row.count(word_ids[i])) return h->fail(LCD_ERR_STATE, "lcd_vocab_append: word already in the vocabulary");
+        if (h->find_row(word_ids[i]) >= 0) return h->fail(LCD_ERR_STATE, "lcd_vocab_append: word already in the vocabulary");
     }
     const int64_t total = h->n_rows + n;
     if (total > 0x7FFFFFF0ll) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_vocab_append: more than 2^31 rows");
@@ -220,7 +241,12 @@ int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word
                                     h->norm_max.as<uint32_t>(), h->stream));
     }
     LCD_HIP(h, hipStreamSynchronize(h->stream));
-    for (int i = 0; i < n; ++i) { h->word_row[word_ids[i]] = (int32_t)(h->n_rows + i); h->h_row_id.push_back(word_ids[i]); }
+    for (int i = 0; i < n; ++i) {
+        if (h->rows_sorted && !h->h_row_key.empty() && word_ids[i] <= h->h_row_key.back()) h->rows_sorted = false;   // out-of-order id
+        if (h->word_row_valid) h->word_row[word_ids[i]] = (int32_t)(h->n_rows + i);
+        h->h_row_key.push_back(word_ids[i]);
+        h->h_row_live.push_back(1);
+    }
     h->n_rows = total;
     h->n_live += n;
     return LCD_OK;
@@ -234,9 +260,9 @@ int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n) {
     std::vector<int32_t> rows;
     rows.reserve(n);
     for (int i = 0; i < n; ++i) {
-        auto it = h->word_row.find(word_ids[i]);
-        if (it == h->word_row.end()) return h->fail(LCD_ERR_STATE, "lcd_vocab_remove: word not in the vocabulary");
-        rows.push_back(it->second);
+        const int r = h->find_row(word_ids[i]);
+        if (r < 0) return h->fail(LCD_ERR_STATE, "lcd_vocab_remove: word not in the vocabulary");
+        rows.push_back(r);
     }
     LCD_HIP(h, dreserve(h, h->d_tmp_i32, (size_t)n * 4));
     LCD_HIP(h, h->h_in.reserve((size_t)n * 4));
@@ -245,7 +271,7 @@ int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n) {
     LCD_HIP(h, launch_tombstone(h->row_id.as<int32_t>(), h->d_tmp_i32.as<int32_t>(), n, h->stream));
     if (h->dtype == LCD_F32) LCD_HIP(h, launch_norm_tombstone(h->row_norm.as<float>(), h->d_tmp_i32.as<int32_t>(), n, h->stream));
     LCD_HIP(h, hipStreamSynchronize(h->stream));
-    for (int i = 0; i < n; ++i) { h->h_row_id[rows[i]] = 0; h->word_row.erase(word_ids[i]); }
+    for (int i = 0; i < n; ++i) { h->h_row_live[rows[i]] = 0; if (h->word_row_valid) h->word_row.erase(word_ids[i]); }
     h->n_live -= n;
     return LCD_OK;
 }
@@ -253,39 +279,52 @@ int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n) {
 int lcd_vocab_rebuild(lcd_engine* h) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
-    // permutation: live rows ordered by ascending word id (VWDictionary.cpp:636-660 walks std::map<int,VisualWord*>)
+    // permutation: live rows ordered by ascending word id (VWDictionary.cpp:636-660 walks std::map<int,VisualWord*>).
+    // Word ids only grow in normal operation, so the live rows are already ascending and this is a stable compaction;
+    // the sort is only needed after out-of-order appends (re-activated old words).
     std::vector<int32_t> perm;
     perm.reserve((size_t)h->n_live);
-    for (int64_t r = 0; r < h->n_rows; ++r) if (h->h_row_id[r] != 0) perm.push_back((int32_t)r);
-    std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return h->h_row_id[a] < h->h_row_id[b]; });
+    for (int64_t r = 0; r < h->n_rows; ++r) if (h->h_row_live[r]) perm.push_back((int32_t)r);
+    if (!h->rows_sorted)
+        std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return h->h_row_key[a] < h->h_row_key[b]; });
     const int n = (int)perm.size();
+    if (n == (int)h->n_rows && h->rows_sorted) return LCD_OK;       // nothing to drop, nothing to reorder
     LCD_HIP(h, dreserve(h, h->vocab_alt, std::max<size_t>(h->vocab.cap, 4)));
     LCD_HIP(h, dreserve(h, h->row_id_alt, std::max<size_t>(h->row_id.cap, 4)));
     LCD_HIP(h, dreserve(h, h->row_wslot_alt, std::max<size_t>(h->row_wslot.cap, 4)));
+    if (h->dtype == LCD_F32) LCD_HIP(h, dreserve(h, h->row_norm_alt, std::max<size_t>(h->row_norm.cap, 16)));
     if (n) {
         LCD_HIP(h, dreserve(h, h->d_tmp_i32, (size_t)n * 4));
-        LCD_HIP(h, h->h_in.reserve((size_t)n * 4));
+        LCD_HIP(h, h->h_in.reserve((size_t)n * 4 + 16));
         std::memcpy(h->h_in.p, perm.data(), (size_t)n * 4);
         LCD_HIP(h, hipMemcpyAsync(h->d_tmp_i32.p, h->h_in.p, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
         LCD_HIP(h, launch_gather_rows(h->vocab.p, h->row_id.as<int32_t>(), h->d_tmp_i32.as<int32_t>(), n, h->row_bytes,
                                       h->vocab_alt.p, h->row_id_alt.as<int32_t>(), h->stream));
         LCD_HIP(h, launch_gather_rows(h->row_wslot.p, h->row_id.as<int32_t>(), h->d_tmp_i32.as<int32_t>(), n, 4,
                                       h->row_wslot_alt.p, h->row_id_alt.as<int32_t>(), h->stream));
-        LCD_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->dtype == LCD_F32) {
+            // the augmentation table ({|row|^2, 1} per row) moves with the rows; the sentinel entry follows the last row
+            LCD_HIP(h, launch_gather_rows(h->row_norm.p, h->row_id.as<int32_t>(), h->d_tmp_i32.as<int32_t>(), n, 8,
+                                          h->row_norm_alt.p, h->row_id_alt.as<int32_t>(), h->stream));
+            float* sentinel = (float*)((char*)h->h_in.p + (size_t)n * 4);
+            const uint32_t inf_bits = 0x7f800000u;
+            std::memcpy(&sentinel[0], &inf_bits, 4);
+            sentinel[1] = 1.0f;
+            LCD_HIP(h, hipMemcpyAsync(h->row_norm_alt.as<float>() + 2 * (size_t)n, sentinel, 8, hipMemcpyHostToDevice, h->stream));
+        }
+        LCD_HIP(h, hipStreamSynchronize(h->stream));                 // staging buffer reuse
     }
     std::swap(h->vocab, h->vocab_alt);
     std::swap(h->row_id, h->row_id_alt);
     std::swap(h->row_wslot, h->row_wslot_alt);
-    if (h->dtype == LCD_F32 && n) {
-        LCD_HIP(h, dreserve(h, h->row_norm, ((size_t)n + 1) * 8));
-        LCD_HIP(h, launch_row_norms(h->vocab.p, h->row_id.as<int32_t>(), 0, n, h->kdim, h->row_norm.as<float>(), h->norm_max.as<uint32_t>(),
-                                    h->stream));
-        LCD_HIP(h, hipStreamSynchronize(h->stream));
-    }
-    std::vector<int32_t> ids(n);
+    if (h->dtype == LCD_F32) std::swap(h->row_norm, h->row_norm_alt);
+    std::vector<int32_t> keys(n);
+    for (int i = 0; i < n; ++i) keys[i] = h->h_row_key[perm[i]];
+    h->h_row_key.swap(keys);
+    h->h_row_live.assign((size_t)n, 1);
+    h->rows_sorted = true;
     h->word_row.clear();
-    for (int i = 0; i < n; ++i) { ids[i] = h->h_row_id[perm[i]]; h->word_row[ids[i]] = i; }
-    h->h_row_id.swap(ids);
+    h->word_row_valid = false;
     h->n_rows = n;
     h->n_live = n;
     h->rebuilds += 1;

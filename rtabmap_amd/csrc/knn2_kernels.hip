@@ -135,22 +135,15 @@ __device__ __forceinline__ void block_merge_store(uint64_t best, uint64_t second
 }
 
 // ------------------------------------------------------------------------------------------------ L2, fixed DIM
-// List mode (qlist != NULL): the kernel serves only the queries qlist[0 .. *qcount) -- the ones whose MFMA-filter result
-// could not be certified (knn_mfma_kernels.hip); logical query i reads descriptor qlist[i].  The grid is sized for the
-// worst case and workgroups beyond *qcount leave at once.
 template <int DIM>
 __global__ __launch_bounds__(BLOCK) void knn2_l2_kernel(const float* __restrict__ vocab, const int32_t* __restrict__ row_id,
                                                         int n_rows, const float* __restrict__ queries, int nq, int qpad,
-                                                        int rows_per_block, uint64_t* __restrict__ partial,
-                                                        const int32_t* __restrict__ qlist, const int32_t* __restrict__ qcount, int list_min) {
+                                                        int rows_per_block, uint64_t* __restrict__ partial) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (qlist) { nq = min(qcount[0], nq); if (nq <= list_min) return; }   // short lists are served by the row-parallel kernel
-    // normal mode: one 64-query group per blockIdx.y; list mode: the (few) listed queries are looped over
-    for (int gy = blockIdx.y; gy * 64 < nq; gy += gridDim.y) {
-        const int qi = gy * 64 + lane;
-        int qsrc = qi < nq ? qi : nq - 1;        // tail lanes repeat the last query; their results are never read
-        if (qlist) qsrc = qlist[qsrc];
+    {
+        const int qi = blockIdx.y * 64 + lane;
+        const int qsrc = qi < nq ? qi : nq - 1;        // tail lanes repeat the last query; their results are never read
         float q[DIM];
         {
             const float4* src = reinterpret_cast<const float4*>(queries + (size_t)qsrc * DIM);
@@ -170,7 +163,6 @@ __global__ __launch_bounds__(BLOCK) void knn2_l2_kernel(const float* __restrict_
             top2_push(best, second, ((uint64_t)__float_as_uint(d) << 32) | (uint32_t)r);
         }
         block_merge_store(best, second, wave, lane, qi, qpad, partial);
-        __syncthreads();                                // the LDS merge buffer is reused by the next group
     }
 }
 
@@ -256,11 +248,9 @@ __global__ __launch_bounds__(BLOCK) void knn2_hamming_dyn_kernel(const uint32_t*
 __global__ __launch_bounds__(BLOCK) void knn2_merge_kernel(int dtype, const uint64_t* __restrict__ partial, int n_keys, int qpad,
                                                            int nq, const int32_t* __restrict__ row_id,
                                                            int32_t* __restrict__ out_row, int32_t* __restrict__ out_word,
-                                                           float* __restrict__ out_dist, const int32_t* __restrict__ qlist,
-                                                           const int32_t* __restrict__ qcount, int list_min) {
+                                                           float* __restrict__ out_dist) {
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * WAVES + (threadIdx.x >> 6);
-    if (qlist) { nq = min(qcount[0], nq); if (nq <= list_min) return; }
     if (qi >= nq) return;
     uint64_t best = KEY_NONE, second = KEY_NONE;
     for (int c = lane; c < n_keys; c += 64) top2_push(best, second, partial[(size_t)c * qpad + qi]);
@@ -271,7 +261,7 @@ __global__ __launch_bounds__(BLOCK) void knn2_merge_kernel(int dtype, const uint
         top2_push(best, second, os);
     }
     if (lane == 0) {
-        const int qo = qlist ? qlist[qi] : qi;      // list mode: results go to the query's own slot
+        const int qo = qi;
         const uint64_t k[2] = {best, second};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -398,14 +388,13 @@ KnnPlan knn_plan(int q, int n_rows, int dim_bytes) {
 size_t knn_partial_bytes(const KnnPlan& p) { return (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * 2 * p.qpad * sizeof(uint64_t); }
 
 hipError_t launch_knn2_partial(int dtype, int dim, const void* vocab, const int32_t* row_id, const void* queries,
-                               const KnnPlan& p, uint64_t* partial, hipStream_t s, const int32_t* qlist, const int32_t* qcount, int list_min) {
+                               const KnnPlan& p, uint64_t* partial, hipStream_t s) {
     if (p.n_blocks == 0 || p.q == 0) return hipSuccess;
-    dim3 grid(p.n_blocks, qlist ? 1 : p.qpad / 64), block(BLOCK);
+    dim3 grid(p.n_blocks, p.qpad / 64), block(BLOCK);
     if (dtype == 0) {
         const float* v = (const float*)vocab; const float* qq = (const float*)queries;
-        if (dim == 64) knn2_l2_kernel<64><<<grid, block, 0, s>>>(v, row_id, p.n_rows, qq, p.q, p.qpad, p.rows_per_block, partial, qlist, qcount, list_min);
-        else if (dim == 128) knn2_l2_kernel<128><<<grid, block, 0, s>>>(v, row_id, p.n_rows, qq, p.q, p.qpad, p.rows_per_block, partial, qlist, qcount, list_min);
-        else if (qlist) return hipErrorInvalidValue;
+        if (dim == 64) knn2_l2_kernel<64><<<grid, block, 0, s>>>(v, row_id, p.n_rows, qq, p.q, p.qpad, p.rows_per_block, partial);
+        else if (dim == 128) knn2_l2_kernel<128><<<grid, block, 0, s>>>(v, row_id, p.n_rows, qq, p.q, p.qpad, p.rows_per_block, partial);
         else knn2_l2_dyn_kernel<<<grid, block, 0, s>>>(v, row_id, p.n_rows, dim, qq, p.q, p.qpad, p.rows_per_block, partial);
     } else {
         const uint32_t* v = (const uint32_t*)vocab; const uint32_t* qq = (const uint32_t*)queries;
@@ -419,11 +408,10 @@ hipError_t launch_knn2_partial(int dtype, int dim, const void* vocab, const int3
 }
 
 hipError_t launch_knn2_merge(int dtype, const KnnPlan& p, const uint64_t* partial, const int32_t* row_id,
-                             int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s, const int32_t* qlist,
-                             const int32_t* qcount, int list_min) {
+                             int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s) {
     if (p.q == 0) return hipSuccess;
     knn2_merge_kernel<<<(p.q + WAVES - 1) / WAVES, BLOCK, 0, s>>>(dtype, partial, p.n_blocks * 2, p.qpad, p.q, row_id,
-                                                                   out_row, out_word, out_dist, qlist, qcount, list_min);
+                                                                   out_row, out_word, out_dist);
     return hipGetLastError();
 }
 

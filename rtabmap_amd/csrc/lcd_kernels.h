@@ -22,17 +22,14 @@ size_t knn_partial_bytes(const KnnPlan& p);   // [n_blocks][2][qpad] keys
 
 // 2-NN of `queries` [q x dim] against `vocab` [n_rows x dim] (row_id[r] == 0 -> tombstone, skipped).
 // dtype: 0 = f32 (dim floats), 1 = u8 (dim bytes, dim % 4 == 0).  Writes per-block partial top-2 keys.
-// List mode (qlist/qcount device pointers, f32 dim 64/128 only): only the queries qlist[0 .. *qcount) are searched.
 hipError_t launch_knn2_partial(int dtype, int dim, const void* vocab, const int32_t* row_id, const void* queries,
-                               const KnnPlan& p, uint64_t* partial, hipStream_t s, const int32_t* qlist = nullptr,
-                               const int32_t* qcount = nullptr, int list_min = 0);   // list mode only runs when *qcount > list_min
+                               const KnnPlan& p, uint64_t* partial, hipStream_t s);
 // Merge the partial keys: out_row[q*2] (row or -1), out_word[q*2] (row_id[row] or 0), out_dist[q*2] (float, -1 = none)
 hipError_t launch_knn2_merge(int dtype, const KnnPlan& p, const uint64_t* partial, const int32_t* row_id,
-                             int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s, const int32_t* qlist = nullptr,
-                             const int32_t* qcount = nullptr, int list_min = 0);
+                             int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s);
 
 // ---- squared-L2 2-NN on the matrix cores (knn_mfma_kernels.hip): MFMA filter + exact re-rank + certificate.
-// Queries whose result cannot be certified are appended to fail_list / fail_count for the exact scan (list mode above).
+// Queries whose result cannot be certified are appended to fail_list / fail_count and redone by launch_knn_rowpar.
 struct MfmaPlan { int q, qpad, n_rows, tiles_per_block, n_blocks; };
 bool knn_mfma_supported(int dtype, int dim);
 MfmaPlan knn_mfma_plan(int q, int n_rows);

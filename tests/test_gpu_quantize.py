@@ -117,3 +117,23 @@ def test_find_nn_matches_oracle(oracle, kind, n_extra):
     got = eng.find_nn(q, extra, extra_ids, incremental=True, nndr=0.8)
     assert got.tolist() == m.find_nn(q)
     eng.close()
+
+
+def test_quantize_large_frame_more_than_1024_descriptors(oracle):
+    """Kp/MaxFeatures above the decision kernel's workgroup size: every thread resolves several descriptors."""
+    import rtabmap_amd
+    v = synth.vocab_surf(3000, seed=11)
+    q = synth.queries_surf(v, 1500, seed=12, frac_known=0.6, sigma=0.03)
+    q[700:760] = q[100:160]                                   # same-frame duplicates far apart in the frame
+    ids = np.arange(1, 3001, dtype=np.int32)
+    eng = rtabmap_amd.Engine("f32", 64)
+    eng.vocab_append(v, ids)
+    m = oracle.OracleVWDictionary(strategy=oracle.kNNBruteForce, nndr=0.8)
+    for i, r in zip(ids, v):
+        m.add_word(int(i), r)
+    m.update()
+    got, n_new = eng.quantize(q, incremental=True, new_words_compared=True, nndr=0.8)
+    exp = m.add_new_words(q, 1)
+    assert np.where(got < 0, 3000 - got, got).tolist() == exp
+    assert n_new == len({e for e in exp if e > 3000}) > 100
+    eng.close()
