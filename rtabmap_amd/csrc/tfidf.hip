@@ -231,10 +231,35 @@ __device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, c
     }
     if (tid == 0) s_scan[Ug] = 0;
     __syncthreads();
+    // LONG segments (>= 64 postings of this bucket, i.e. words present in a quarter or more of its signatures: with a
+    // heavy-tailed vocabulary they hold most of the postings) are walked wave by wave in 64-posting chunks -- the word,
+    // hence idf, is wave-uniform and no per-posting lookup is needed.  Their length is then zeroed so that the flattened
+    // pass below only sees the short segments.
+    {
+        const int wv = tid >> 6, ln = tid & 63, nwv = SCB / 64;
+        for (int k = wv; k < Ug; k += nwv) {                         // s_scan[k] still holds the segment LENGTH here
+            const uint32_t len = s_scan[k];
+            if (len < 64u) continue;                                 // wave-uniform
+            const uint32_t start = s_start[k];
+            const float idf = s_idf[k];
+            for (uint32_t o = ln; o < len; o += 64) {
+                const uint32_t e = ent[start + o];
+                const uint32_t sl = e >> TF_CNT_BITS;
+                const uint32_t ni = s_ni[sl];
+                if (ni != 0u) {
+                    const float term = __fdiv_rn(__fmul_rn((float)(e & TF_CNT_MASK), idf), (float)ni);
+                    atomicAdd(&acc[sl], to_fixed(term));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < Ug; k += SCB) if (s_scan[k] >= 64u) s_scan[k] = 0u;
+    __syncthreads();
     const uint32_t T = block_exclusive_scan(s_scan, Ug + 1, scratch);   // s_scan[Ug] == T afterwards
-    // flattened, load-balanced walk over all postings of this bucket that belong to the group's words.  Four postings per
-    // thread and trip: their segments are found by binary search in the scanned offsets (LDS; the four searches are
-    // independent chains), then four independent global loads are in flight at once.
+    // SHORT segments: flattened, load-balanced walk.  Four postings per thread and trip: their segments are found by binary
+    // search in the scanned offsets (LDS; the four searches are independent chains), then four independent global loads are
+    // in flight at once.
     for (uint32_t t0 = tid; t0 < T; t0 += 4 * SCB) {
         uint32_t addr[4]; int kk[4]; uint32_t e[4];
 #pragma unroll
