@@ -757,7 +757,7 @@ hipError_t Tfidf::score(float* d_likelihood) {
     TF_TRY(flush_retire());
     TF_TRY(upload_buckets());
     // lfix is all zero here: zero-initialised on growth and re-zeroed by whoever consumed it last
-    static const int scb = env_int("LCD_SC_BLOCK", 512);
+    static const int scb = env_int("LCD_SC_BLOCK", 1024);
     static const int gforce = env_int("LCD_SC_G", 0);
     static const int fuse = env_int("LCD_SC_FUSED", 1);
     const int wcap_all = std::max(q_n_ub, 1);
@@ -799,7 +799,7 @@ hipError_t Tfidf::score_partial(unsigned long long* lfix_target) {
     TF_TRY(upload_buckets());
     const int wcap_all = std::max(q_n_ub, 1);
     if (n_list > 0) {
-        static const int scb = env_int("LCD_SC_BLOCK", 512);
+        static const int scb = env_int("LCD_SC_BLOCK", 1024);
         static const int gforce = env_int("LCD_SC_G", 0);
         int G = gforce > 0 ? gforce : (256 + n_list - 1) / n_list;     // aim at >= one workgroup per CU
         G = std::max(1, std::min(G, 8));
