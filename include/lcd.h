@@ -193,6 +193,7 @@ typedef struct lcd_stats {
     int64_t knn_launches, likelihood_launches, rebuilds;
     int64_t bytes_device;                  /* HBM held by the handle */
     int64_t knn_last_fallback_queries;     /* queries of the LAST 2-NN call that the MFMA certificate sent to the exact scan */
+    double knn_max_err_ratio;              /* largest |filter score - exact distance| / eps seen by the re-rank so far (must stay < 1) */
 } lcd_stats;
 /* synchronises the engine stream (the fallback counter lives on the device) */
 int lcd_get_stats(lcd_engine* h, lcd_stats* out);

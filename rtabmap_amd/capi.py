@@ -34,7 +34,7 @@ class LcdConfig(C.Structure):
 class LcdStats(C.Structure):
     _fields_ = [("vocab_rows", C.c_int64), ("vocab_live", C.c_int64), ("signatures", C.c_int64), ("postings", C.c_int64),
                 ("knn_launches", C.c_int64), ("likelihood_launches", C.c_int64), ("rebuilds", C.c_int64),
-                ("bytes_device", C.c_int64), ("knn_last_fallback_queries", C.c_int64)]
+                ("bytes_device", C.c_int64), ("knn_last_fallback_queries", C.c_int64), ("knn_max_err_ratio", C.c_double)]
 
 
 class LcdError(RuntimeError):
@@ -55,7 +55,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.build()
+    path = os.environ.get("LCD_LIB_PATH") or _build.build()      # LCD_LIB_PATH: timing experiments with variant builds
     L = C.CDLL(path)
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     L.lcd_abi_version.restype = C.c_int

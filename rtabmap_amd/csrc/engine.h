@@ -36,13 +36,15 @@ struct lcd_engine {
     std::unordered_map<int32_t, int32_t> word_row;      // only valid when !rows_sorted && word_row_valid
     bool word_row_valid = false;
     lcd::DevBuf row_norm_alt;
+    lcd::DevBuf vocab_bf;                               // hi/lo bf16 split of the rows (256 B per row) for the bf16x3 filter
     int find_row(int32_t word_id);
 
     // ---- per-call scratch
     lcd::DevBuf d_queries, d_partial, d_knn_row, d_knn_word, d_knn_wslot, d_knn_dist, d_selfdist, d_out_word, d_out_wslot,
         d_n_new, d_tmp_i32, d_extra_rows, d_extra_id, d_extra_word, d_extra_dist, d_extra_row, d_like, d_slots, d_bits, row_norm, norm_max, d_partial2, d_partial3, d_fail_list, d_fail_count;
     bool fail_count_clean = false;                      // d_fail_count[0..1] known to be zero (the fused frame tail resets them)
-    int knn_mode = 1;                                   // 1 = MFMA filter + exact re-rank (f32, dim 64), 0 = exact VALU scan only
+    int knn_mode = 2;                                   // f32 dim 64: 2 = bf16x3 MFMA filter + exact re-rank (default), 1 = f32 MFMA filter
+                                                        // + exact re-rank, 0 = exact VALU scan only (LCD_KNN_MODE = bf16 | mfma32 | valu)
     lcd::PinBuf h_in, h_out, h_out2;
 
     // ---- inverted index / TF-IDF

@@ -70,13 +70,26 @@ int upload_rows(lcd_engine* h, const void* rows, int n, DevBuf& dst) {
 int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab, const int32_t* row_id, int64_t n_rows, bool main_vocab,
                  int32_t* o_row, int32_t* o_word, float* o_dist) {
     if (q == 0) return LCD_OK;
-    const bool mfma = main_vocab && h->knn_mode == 1 && knn_mfma_supported(h->dtype, h->kdim) && n_rows >= 256;
+    const bool mfma = main_vocab && h->knn_mode != 0 && knn_mfma_supported(h->dtype, h->kdim) && n_rows >= 256;
     const KnnPlan p = knn_plan(q, (int)n_rows, h->row_bytes);
-    if (mfma) {
+    if (mfma && h->knn_mode == 2) {
+        const MfmaPlan mp = knn_bf16_plan(q, (int)n_rows);
+        LCD_HIP(h, dreserve(h, h->d_partial2, knn_bf16_partial_bytes(mp)));
+        LCD_HIP(h, dreserve(h, h->d_fail_list, (size_t)q * 4));
+        const bool prof = h->prof_cap > 0 && h->prof_n < h->prof_cap;
+        LCD_HIP(h, launch_knn_bf16(h->kdim, vocab, h->vocab_bf.p, h->row_norm.as<float>(), h->norm_max.as<uint32_t>(), row_id, d_queries, mp,
+                                   h->d_partial2.p, o_row, o_word, o_dist, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(),
+                                   h->stream, prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr,
+                                   !h->fail_count_clean));
+        h->fail_count_clean = false;
+        if (prof) { h->prof_n += 1; h->prof_kernel = "knn_bf16_filter_kernel"; }
+        LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
+        LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(),
+                                     h->d_partial3.p, o_row, o_word, o_dist, h->stream));
+    } else if (mfma) {
         const MfmaPlan mp = knn_mfma_plan(q, (int)n_rows);
         LCD_HIP(h, dreserve(h, h->d_partial2, knn_mfma_partial_bytes(mp)));
         LCD_HIP(h, dreserve(h, h->d_fail_list, (size_t)q * 4));
-        LCD_HIP(h, dreserve(h, h->d_fail_count, 64));
         const bool prof = h->prof_cap > 0 && h->prof_n < h->prof_cap;
         LCD_HIP(h, launch_knn_mfma(h->kdim, vocab, h->row_norm.as<float>(), h->norm_max.as<uint32_t>(), row_id, d_queries, mp, h->d_partial2.p,
                                    o_row, o_word, o_dist, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(), h->stream,
@@ -153,7 +166,12 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
     if (e == hipSuccess) e = h->norm_max.reserve(64, 0, h->stream, &h->bytes_device);
     if (e == hipSuccess) e = hipMemsetAsync(h->norm_max.p, 0, 64, h->stream);
     if (e == hipSuccess) e = h->row_norm.reserve(((size_t)vcap + 1) * 8, 0, h->stream, &h->bytes_device);
-    { const char* m = getenv("LCD_KNN_MODE"); if (m && *m) h->knn_mode = (m[0] == 'v' || m[0] == '0') ? 0 : 1; }
+    if (e == hipSuccess) e = h->d_fail_count.reserve(64, 0, h->stream, &h->bytes_device);   // [0] rejected, [1] arrivals, [2] max err / eps
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_fail_count.p, 0, 64, h->stream);
+    {
+        const char* m = getenv("LCD_KNN_MODE");
+        if (m && *m) h->knn_mode = (m[0] == 'v' || m[0] == '0') ? 0 : (m[0] == 'm' || m[0] == 'f' || m[0] == '1') ? 1 : 2;
+    }
     if (e == hipSuccess) e = h->tfidf.init(h->stream, &h->bytes_device, cfg->sig_capacity);
     if (e != hipSuccess) { lcd_destroy(h); return LCD_ERR_HIP; }
     *out = h;
@@ -170,7 +188,7 @@ void lcd_destroy(lcd_engine* h) {
                      &h->d_partial, &h->d_knn_row, &h->d_knn_word, &h->d_knn_wslot, &h->d_knn_dist, &h->d_selfdist, &h->d_out_word,
                      &h->d_out_wslot, &h->d_n_new, &h->d_tmp_i32, &h->d_extra_rows, &h->d_extra_id, &h->d_extra_word,
                      &h->d_extra_dist, &h->d_extra_row, &h->d_like, &h->d_slots, &h->d_bits, &h->row_norm, &h->norm_max, &h->d_partial2,
-                     &h->d_fail_list, &h->d_fail_count, &h->d_partial3, &h->row_norm_alt};
+                     &h->d_fail_list, &h->d_fail_count, &h->d_partial3, &h->row_norm_alt, &h->vocab_bf};
     for (DevBuf* d : all) d->release(&h->bytes_device);
     h->h_in.release(); h->h_out.release(); h->h_out2.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -239,6 +257,10 @@ int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word
         LCD_HIP(h, dreserve(h, h->row_norm, ((size_t)total + 1) * 8, (size_t)h->n_rows * 8));
         LCD_HIP(h, launch_row_norms(h->vocab.p, h->row_id.as<int32_t>(), (int)h->n_rows, n, h->kdim, h->row_norm.as<float>(),
                                     h->norm_max.as<uint32_t>(), h->stream));
+        if (knn_mfma_supported(h->dtype, h->kdim)) {   // hi/lo bf16 split of the new rows
+            LCD_HIP(h, dreserve(h, h->vocab_bf, (size_t)total * 256, (size_t)h->n_rows * 256));
+            LCD_HIP(h, launch_vocab_bf16(h->vocab.p, (int)h->n_rows, n, h->kdim, h->vocab_bf.p, h->stream));
+        }
     }
     LCD_HIP(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < n; ++i) {
@@ -318,6 +340,10 @@ int lcd_vocab_rebuild(lcd_engine* h) {
     std::swap(h->row_id, h->row_id_alt);
     std::swap(h->row_wslot, h->row_wslot_alt);
     if (h->dtype == LCD_F32) std::swap(h->row_norm, h->row_norm_alt);
+    if (n && knn_mfma_supported(h->dtype, h->kdim)) {   // the split is recomputed from the compacted rows
+        LCD_HIP(h, dreserve(h, h->vocab_bf, (size_t)n * 256));
+        LCD_HIP(h, launch_vocab_bf16(h->vocab.p, 0, n, h->kdim, h->vocab_bf.p, h->stream));
+    }
     std::vector<int32_t> keys(n);
     for (int i = 0; i < n; ++i) keys[i] = h->h_row_key[perm[i]];
     h->h_row_key.swap(keys);
@@ -743,11 +769,15 @@ int lcd_get_stats(lcd_engine* h, lcd_stats* out) {
     if (!out) return LCD_ERR_INVALID;
     LCD_DEV(h);
     out->knn_last_fallback_queries = 0;
+    out->knn_max_err_ratio = 0.0;
     if (h->d_fail_count.p) {
-        int32_t n = 0;
-        int rc = download(h, &n, h->d_fail_count.p, 4, h->h_out2);
+        int32_t n[3] = {0, 0, 0};
+        int rc = download(h, n, h->d_fail_count.p, 12, h->h_out2);
         if (rc) return rc;
-        out->knn_last_fallback_queries = n;
+        out->knn_last_fallback_queries = n[0];
+        float r;
+        std::memcpy(&r, &n[2], 4);
+        out->knn_max_err_ratio = r;
     }
     out->vocab_rows = h->n_rows; out->vocab_live = h->n_live;
     out->signatures = h->tfidf.live_sigs; out->postings = h->tfidf.postings_ub;

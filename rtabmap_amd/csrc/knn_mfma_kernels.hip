@@ -76,29 +76,74 @@ __global__ void norm_tombstone_kernel(float* __restrict__ aug, const int32_t* __
     if (i < n) aug[2 * (size_t)rows[i]] = __int_as_float(0x7f800000);
 }
 
+// bf16 split of the vocabulary for the bf16x3 filter: row r -> 256 bytes = 64 bf16 "hi" (the float rounded to bf16, RNE) then
+// 64 bf16 "lo" (the exact remainder float - hi, rounded to bf16).  hi + lo carries ~17 significant bits of the float.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bf16_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));      // v_cvt_pk_bf16_f32
+    const float ra = __fsub_rn(a, __uint_as_float(hi << 16)), rb = __fsub_rn(b, __uint_as_float(hi & 0xFFFF0000u));   // exact
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){ra, rb}, bf16x2_t));
+}
+__global__ void vocab_bf16_kernel(const float* __restrict__ vocab, int first, int n, uint32_t* __restrict__ bf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 4 floats of a 64-float row
+    if (i >= n * 16) return;
+    const int r = first + (i >> 4), c = i & 15;
+    const float4 x = reinterpret_cast<const float4*>(vocab + (size_t)r * 64)[c];
+    uint2 hi, lo;
+    bf16_split2(x.x, x.y, hi.x, lo.x);
+    bf16_split2(x.z, x.w, hi.y, lo.y);
+    reinterpret_cast<uint2*>(bf + (size_t)r * 64)[c] = hi;
+    reinterpret_cast<uint2*>(bf + (size_t)r * 64 + 32)[c] = lo;
+}
+
 // ------------------------------------------------------------------------------------------------ filter
 // In-loop candidate key: 32 bits = the score's float bits with the low MF_IDX_BITS mantissa bits replaced by the
 // candidate's position inside the wave's strip (tile-in-strip << 4 | accumulator register).  Scores are >= 0, so the keys
-// order like unsigned integers and a top-3 update is five v_min_u32 / v_max_u32.  Truncation only LOWERS a key
+// strip (tile-in-strip << 4 | accumulator register).  Keys are compared as SIGNED integers: non-negative floats order like
+// their bit patterns, and a score that rounding pushed slightly below zero (an exact duplicate of the query) sorts first,
+// which is where it belongs; a top-3 update is one v_min_i32 and two v_med3_i32.  Truncation only LOWERS a key
 // (by < 2^-16 relative): a dropped row's true score is >= its key >= the bound derived from kept keys, so the
 // certificate stays valid; at most MF_STRIP_TILES tiles per wave strip keep the index in 7 bits.
 constexpr int MF_IDX_BITS = 7;
 constexpr int MF_STRIP_TILES = 1 << (MF_IDX_BITS - 4);
 constexpr uint32_t MF_IDX_MASK = (1u << MF_IDX_BITS) - 1;
+constexpr int32_t MF_KEY_NONE = 0x7FFFFFFF;
 
-__device__ __forceinline__ void top3_push32(uint32_t& k0, uint32_t& k1, uint32_t& k2, uint32_t k) {
-    const uint32_t h1 = max(k0, k);
-    k0 = min(k0, k);
-    const uint32_t h2 = max(k1, h1);
-    k1 = min(k1, h1);
-    k2 = min(k2, h2);
+// sorted insertion into k0 <= k1 <= k2 from the OLD values only (three independent VALU, no dependent chain):
+//   k0' = min(k0, k), k1' = med3(k0, k1, k), k2' = med3(k1, k2, k)
+__device__ __forceinline__ int32_t med3_i32(int32_t a, int32_t b, int32_t c) {
+    int32_t r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
-// strip key -> merge key (score bits << 32 | vocabulary row)
-__device__ __forceinline__ uint64_t widen_key(uint32_t k, int t_begin, int half) {
-    if (k == 0xFFFFFFFFu) return KEY_NONE;
-    const uint32_t idx = k & MF_IDX_MASK, r = idx & 15u;
+__device__ __forceinline__ void top3_push32(int32_t& k0, int32_t& k1, int32_t& k2, int32_t k) {
+    const int32_t n2 = med3_i32(k1, k2, k);
+    const int32_t n1 = med3_i32(k0, k1, k);
+    k0 = min(k0, k);
+    k1 = n1;
+    k2 = n2;
+}
+// strip key of accumulator register r of strip tile tl: the score bits with the index in the low mantissa bits -- one v_and_or_b32
+// (the index is wave-uniform)
+// (the index is wave-uniform; the mask is kept in a VGPR the compiler cannot see through, or it would pick v_and + v_or with
+// a literal)
+__device__ __forceinline__ uint32_t strip_mask() {
+    uint32_t m;
+    asm("v_mov_b32 %0, 0xffffff80" : "=v"(m));
+    static_assert(MF_IDX_BITS == 7, "literal above");
+    return m;
+}
+__device__ __forceinline__ int32_t strip_key(float score, uint32_t mask, uint32_t idx) {
+    return (int32_t)((__float_as_uint(score) & mask) | idx);
+}
+// strip key -> merge key (score bits << 32 | vocabulary row); a slightly negative score (rounding of a distance ~ 0) becomes +0
+__device__ __forceinline__ uint64_t widen_key(int32_t k, int t_begin, int half) {
+    if (k == MF_KEY_NONE) return KEY_NONE;
+    const uint32_t idx = (uint32_t)k & MF_IDX_MASK, r = idx & 15u;
     const uint32_t row = (uint32_t)(t_begin + (int)(idx >> 4)) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)half;
-    return ((uint64_t)(k & ~MF_IDX_MASK) << 32) | row;
+    const uint32_t bits = k < 0 ? 0u : ((uint32_t)k & ~MF_IDX_MASK);
+    return ((uint64_t)bits << 32) | row;
 }
 
 // A tile = 32 vocabulary rows x DIM floats (8 KB for DIM = 64).  It goes global -> LDS with the asynchronous LDS-DMA
@@ -168,17 +213,16 @@ __device__ __forceinline__ void mfma_pair(const float (&a)[KH], float a_aug, con
 #ifndef LCD_MFMA_ABLATE
 #define LCD_MFMA_ABLATE 0      // 1: skip the top-3 update (timing experiment only), 2: skip the MFMAs
 #endif
-__device__ __forceinline__ void push_group(const f32x16& acc, uint32_t tl, uint32_t& k0, uint32_t& k1, uint32_t& k2) {
+__device__ __forceinline__ void push_group(const f32x16& acc, uint32_t tl, int32_t& k0, int32_t& k1, int32_t& k2) {
 #if LCD_MFMA_ABLATE == 1
     asm volatile("" :: "v"(acc[0]), "v"(acc[5]), "v"(acc[10]), "v"(acc[15]));
-    k0 = min(k0, __float_as_uint(acc[3])); (void)tl; (void)k1; (void)k2;
+    k0 = min(k0, __float_as_int(acc[3])); (void)tl; (void)k1; (void)k2;
     return;
 #endif
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tl << 4));
+    const uint32_t mask = strip_mask();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const uint32_t sbits = (uint32_t)max(__float_as_int(acc[r]), 0);   // clamp tiny negative scores (sign bit set) to +0
-        top3_push32(k0, k1, k2, (sbits & ~MF_IDX_MASK) | (tl << 4) | (uint32_t)r);
-    }
+    for (int r = 0; r < 16; ++r) top3_push32(k0, k1, k2, strip_key(acc[r], mask, base | (uint32_t)r));
 }
 
 // One software-pipeline step in explicit program order: the 66 MFMAs of a group pair (two interleaved accumulator chains)
@@ -189,9 +233,11 @@ __device__ __forceinline__ void push_group(const f32x16& acc, uint32_t tl, uint3
 template <int KH>
 __device__ __forceinline__ void mfma_pair_push(const float (&a)[KH], float a_aug, const float (&b0)[KH], float b0_aug, const float (&b1)[KH],
                                                float b1_aug, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1, uint32_t tl,
-                                               uint32_t& k00, uint32_t& k01, uint32_t& k02, uint32_t& k10, uint32_t& k11, uint32_t& k12) {
+                                               int32_t& k00, int32_t& k01, int32_t& k02, int32_t& k10, int32_t& k11, int32_t& k12) {
     static_assert(KH == 32, "interleave pattern written for 64-float rows");
     const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tl << 4));
+    const uint32_t mask = strip_mask();
     c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b0_aug, z, 0, 0, 0);
     c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b1_aug, z, 0, 0, 0);
 #pragma unroll
@@ -201,19 +247,27 @@ __device__ __forceinline__ void mfma_pair_push(const float (&a)[KH], float a_aug
         c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * r + 1], b0[2 * r + 1], c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * r + 1], b1[2 * r + 1], c1, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        {
-            const uint32_t s0 = (uint32_t)max(__float_as_int(p0[r]), 0), s1 = (uint32_t)max(__float_as_int(p1[r]), 0);
-            top3_push32(k00, k01, k02, (s0 & ~MF_IDX_MASK) | (tl << 4) | (uint32_t)r);
-            top3_push32(k10, k11, k12, (s1 & ~MF_IDX_MASK) | (tl << 4) | (uint32_t)r);
-        }
+        top3_push32(k00, k01, k02, strip_key(p0[r], mask, base | (uint32_t)r));
+        top3_push32(k10, k11, k12, strip_key(p1[r], mask, base | (uint32_t)r));
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// partial_keys [n_blocks][MF_KEEP][qpad] u64, partial_lmin [n_blocks][qpad] f32 bits.
+// partial_keys [qpad][n_blocks][MF_KEEP] u64, partial_lmin [qpad][n_blocks] f32 bits (query-major: the re-rank wave of a query
+// reads one contiguous run).
 // NG = 32-query column groups per wave (wave tile = NG*32 queries x 32 rows).  NG = 4 runs ONE wave per SIMD with four
 // independent accumulator chains (A tiles reused 4x, the VALU top-3 update of one accumulator issues under the MFMAs of
 // the next); NG = 2 runs two waves per SIMD.
+#ifdef LCD_MFMA_TIMING   // timing experiment only: per-wave timestamps (100 MHz) at kernel entry, loop entry, loop exit, kernel exit
+__device__ unsigned long long g_mf_timing[4 * 4096];
+#define MF_STAMP(i) do { if (lane == 0) g_mf_timing[4 * ((blockIdx.y * gridDim.x + blockIdx.x) * MF_WAVES + wave) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_mf_timing2[8 * 4096];   // finer stamps inside one loop trip of the bf16 filter
+#define MF_STAMP2(i) do { if (lane == 0 && (i) < 8) { g_mf_timing2[8 * ((blockIdx.y * gridDim.x + blockIdx.x) * MF_WAVES + wave) + (i)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define MF_STAMP(i) do { } while (0)
+#define MF_STAMP2(i) do { } while (0)
+#endif
+
 template <int DIM, int NG>
 __global__ __launch_bounds__(MF_BLOCK, (NG == 2 ? 2 : 1)) void knn_mfma_filter_kernel(const float* __restrict__ vocab,
                                                                                      const float* __restrict__ row_norm, int n_rows,
@@ -226,6 +280,7 @@ __global__ __launch_bounds__(MF_BLOCK, (NG == 2 ? 2 : 1)) void knn_mfma_filter_k
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 31, half = lane >> 5;
     const int q0 = blockIdx.y * QW;
+    MF_STAMP(0);
 
     // B operand: the NG 32-query groups, pre-scaled by -2 (exact), + |q|^2 for the extra k-step
     float b[NG][KH];
@@ -253,9 +308,9 @@ __global__ __launch_bounds__(MF_BLOCK, (NG == 2 ? 2 : 1)) void knn_mfma_filter_k
     const int t_end = min(t_begin + per_wave, tile1);
 
     // every lane keeps its three best keys per query group: a row the lane drops is no better than its third key
-    uint32_t k0[NG], k1[NG], k2[NG];
+    int32_t k0[NG], k1[NG], k2[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) { k0[g] = ~0u; k1[g] = ~0u; k2[g] = ~0u; }
+    for (int g = 0; g < NG; ++g) { k0[g] = MF_KEY_NONE; k1[g] = MF_KEY_NONE; k2[g] = MF_KEY_NONE; }
     // Software pipeline per wave: while tile t occupies the matrix pipe, the LDS-DMA of tile t+1 is in flight into the wave's
     // other LDS slot; it is waited for (vmcnt) and read back in operand order right before it is needed.  The two accumulator
     // chains of a group pair are interleaved (independent consecutive MFMAs); the VALU top-3 update of a pair is issued under
@@ -272,6 +327,7 @@ __global__ __launch_bounds__(MF_BLOCK, (NG == 2 ? 2 : 1)) void knn_mfma_filter_k
         float aug_next = row_norm[2 * (size_t)min(min(t_begin + 1, t_end - 1) * 32 + col, n_rows) + half];
         f32x16 p0, p1;                                               // pending accumulators (previous pair)
         int pend_t = t_begin;
+        MF_STAMP(1);
         mfma_pair<KH>(a, aug, b[0], b_aug[0], b[1], b_aug[1], p0, p1);
         for (int t = t_begin; t < t_end; ++t) {
 #pragma unroll
@@ -304,6 +360,7 @@ __global__ __launch_bounds__(MF_BLOCK, (NG == 2 ? 2 : 1)) void knn_mfma_filter_k
         push_group(p1, (uint32_t)(pend_t - t_begin), k0[NG - 1], k1[NG - 1], k2[NG - 1]);
     }
 
+    MF_STAMP(2);
     // workgroup merge: 8 partitions (4 waves x 2 halves) x top-3 per query -> top-MF_KEEP + the smallest partition third
     __shared__ uint64_t s_key[QW][MF_WAVES * 2][3];
 #pragma unroll
@@ -335,35 +392,226 @@ __global__ __launch_bounds__(MF_BLOCK, (NG == 2 ? 2 : 1)) void knn_mfma_filter_k
         const int qi = q0 + ql;
         if (qi < qpad) {
 #pragma unroll
-            for (int i = 0; i < MF_KEEP; ++i) partial_keys[((size_t)blockIdx.x * MF_KEEP + i) * qpad + qi] = keep[i];
-            partial_lmin[(size_t)blockIdx.x * qpad + qi] = lmin;
+            for (int i = 0; i < MF_KEEP; ++i) partial_keys[((size_t)qi * gridDim.x + blockIdx.x) * MF_KEEP + i] = keep[i];
+            partial_lmin[(size_t)qi * gridDim.x + blockIdx.x] = lmin;
+        }
+    }
+    MF_STAMP(3);
+}
+
+
+// ------------------------------------------------------------------------------------------------ bf16x3 filter
+// The same filter with the contraction on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate): every float
+// is split hi + lo (two bf16), and q . v ~ qh.vh + qh.vl + ql.vh -- three bf16 MFMA chains accumulated in fp32 into the SAME
+// accumulator that the f32 augmentation step (|v|^2 + |q|^2, exact) initialised.  The neglected ql.vl and the bf16 rounding of
+// the lo parts cost < 2^-16 relative to |q||v|, which eps_bf16() adds to the certificate -- the result stays the exact scan's.
+//
+// Workgroup = 4 waves x 128 queries (512 queries) against ONE shared strip of vocabulary tiles: a tile (32 rows x {hi, lo} =
+// 8 KiB) is brought in once by LDS-DMA (each wave issues a quarter), double-buffered, one barrier per tile, and read by all four
+// waves -- the vocabulary crosses L2 -> LDS once per 512 queries.  The queries are staged the same way (coalesced DMA, then
+// operand order), split on the fly, and stay in registers for the whole kernel.
+constexpr int BF_KEEP = 2;                       // keys kept per (row block, query); the third best is the block's bound
+constexpr int BF_QW = 128;                       // queries per wave
+constexpr int BF_QB = BF_QW * MF_WAVES;          // queries per workgroup
+constexpr int BF_TILE_F = 32 * 64;               // floats (dwords) per staged tile
+constexpr size_t BF_LDS_BYTES = (size_t)(MF_WAVES * 4 + 2) * BF_TILE_F * 4;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// DMA instructions [i0, i1) of the 8 that move one 32-row x 256-byte tile (same swizzle as dma_a_tile)
+__device__ __forceinline__ void dma_tile_part(const float* __restrict__ base, int n_rows, int t, int lane, float* __restrict__ lds_slot,
+                                              int i0, int i1) {
+    for (int i = i0; i < i1; ++i) {
+        const int p = i * 64 + lane;
+        const int r = p >> 4, cpos = p & 15;
+        const int c = cpos ^ (r & 15);
+        const int row = min(t * 32 + r, n_rows - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)row * 64 + c * 4),
+                                         (__attribute__((address_space(3))) void*)(lds_slot + i * 256), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ f32x16 bf_mfma(const uint4& a, const uint4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// One 32-row tile against two 32-query groups: 2 x (1 f32 augmentation step + 12 bf16 steps), the two accumulator chains
+// interleaved; with PUSH the top-3 update of the previous pair's 32 scores is spread between the steps.
+template <bool PUSH>
+__device__ __forceinline__ void bf_pair(const uint4 (&ah)[4], const uint4 (&al)[4], float a_aug, const uint4 (&bh0)[4], const uint4 (&bl0)[4],
+                                        float b0_aug, const uint4 (&bh1)[4], const uint4 (&bl1)[4], float b1_aug, f32x16& c0, f32x16& c1,
+                                        const f32x16& p0, const f32x16& p1, uint32_t tl, int32_t& k00, int32_t& k01, int32_t& k02,
+                                        int32_t& k10, int32_t& k11, int32_t& k12) {
+    const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tl << 4));
+    const uint32_t mask = strip_mask();
+    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b0_aug, z, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b1_aug, z, 0, 0, 0);
+#pragma unroll
+    for (int st = 0; st < 12; ++st) {
+        const int s = st / 3, term = st % 3;                        // (hi, hi), (hi, lo), (lo, hi)
+        const uint4& a = term == 2 ? al[s] : ah[s];
+#if LCD_MFMA_ABLATE != 3
+        c0 = bf_mfma(a, term == 1 ? bl0[s] : bh0[s], c0);
+#endif
+        if (PUSH && LCD_MFMA_ABLATE == 1) asm volatile("" :: "v"(p0[st]), "v"(p1[st]));   // keep the ablated chains alive
+        if (PUSH && LCD_MFMA_ABLATE != 1) {                         // one MFMA, then the VALU that fits in its 32-cycle shadow
+            __builtin_amdgcn_sched_barrier(0);
+            top3_push32(k00, k01, k02, strip_key(p0[st], mask, base | (uint32_t)st));
+            if (st < 4) top3_push32(k00, k01, k02, strip_key(p0[12 + st], mask, base | (uint32_t)(12 + st)));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#if LCD_MFMA_ABLATE != 3
+        c1 = bf_mfma(a, term == 1 ? bl1[s] : bh1[s], c1);
+#endif
+        if (PUSH && LCD_MFMA_ABLATE != 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            top3_push32(k10, k11, k12, strip_key(p1[st], mask, base | (uint32_t)st));
+            if (st < 4) top3_push32(k10, k11, k12, strip_key(p1[12 + st], mask, base | (uint32_t)(12 + st)));
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------------ re-rank + certificate
-// rtflann::L2 (dist.h:150-177), a = vocabulary row, b = query -- the same code as knn2_kernels.hip::l2_ref_dyn
-__device__ __forceinline__ float l2_ref_row(const float* __restrict__ row, const float* __restrict__ q, int dim) {
-    float res = 0.0f;
-    int g = 0;
-    for (; g + 3 < dim; g += 4) {
-        const float d0 = __fsub_rn(row[g + 0], q[g + 0]);
-        const float d1 = __fsub_rn(row[g + 1], q[g + 1]);
-        const float d2 = __fsub_rn(row[g + 2], q[g + 2]);
-        const float d3 = __fsub_rn(row[g + 3], q[g + 3]);
-        float t = __fmul_rn(d0, d0);
-        t = __fadd_rn(t, __fmul_rn(d1, d1));
-        t = __fadd_rn(t, __fmul_rn(d2, d2));
-        t = __fadd_rn(t, __fmul_rn(d3, d3));
-        res = __fadd_rn(res, t);
-    }
-    for (; g < dim; ++g) {
-        const float d0 = __fsub_rn(row[g], q[g]);
-        res = __fadd_rn(res, __fmul_rn(d0, d0));
-    }
-    return res;
+// third smallest of two sorted triples
+__device__ __forceinline__ uint64_t third_of_two_triples(uint64_t a0, uint64_t a1, uint64_t a2, uint64_t b0, uint64_t b1, uint64_t b2) {
+    const uint64_t x = a1 > b0 ? a1 : b0, y = a0 > b1 ? a0 : b1;
+    uint64_t m = a2 < b2 ? a2 : b2;
+    m = m < x ? m : x;
+    return m < y ? m : y;
 }
 
+// partial_keys [qpad][n_blocks][BF_KEEP] u64, partial_bound [qpad][n_blocks] f32 bits
+template <int NG>
+__global__ __launch_bounds__(MF_BLOCK, 1) void knn_bf16_filter_kernel(const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
+                                                                      int n_rows, const float* __restrict__ queries, int nq, int qpad,
+                                                                      int tiles_per_block, uint64_t* __restrict__ partial_keys,
+                                                                      uint32_t* __restrict__ partial_bound) {
+    static_assert(NG * 32 == BF_QW, "wave tile");
+    constexpr int KH = 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int q0 = blockIdx.y * BF_QB + wave * BF_QW;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    float* s_q = s_dyn + (size_t)wave * NG * BF_TILE_F;             // this wave's query staging (prologue only)
+    float* s_tile = s_dyn + (size_t)MF_WAVES * NG * BF_TILE_F;      // [2] vocabulary tiles shared by the workgroup
+    MF_STAMP(0);
+
+    const int tile0 = blockIdx.x * tiles_per_block;
+    const int n_tiles = (n_rows + 31) / 32;
+    const int tile1 = min(tile0 + tiles_per_block, n_tiles);
+
+    // everything the prologue needs is put in flight at once: the wave's four query groups and its quarter of the first tile
+#pragma unroll
+    for (int g = 0; g < NG; ++g) dma_a_tile<KH>(queries, nq, q0 / 32 + g, lane, s_q + g * BF_TILE_F);
+    float aug_next = 0.0f;
+    if (tile0 < tile1) {
+        dma_tile_part(vocab_bf, n_rows, tile0, lane, s_tile, 2 * wave, 2 * wave + 2);
+        aug_next = row_norm[2 * (size_t)min(tile0 * 32 + col, n_rows) + half];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // B operands: -2 q split hi/lo in operand order (lane (query l&31, half l>>5) holds floats [32h, 32h + 32) of its query: k-step s
+    // multiplies elements 32h + 8s .. + 8 -- A uses the same k permutation), + |q|^2 for the augmentation step
+    uint4 bh[NG][4], bl[NG][4];
+    float b_aug[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        float x[KH];
+        read_a_tile<KH>(s_q + g * BF_TILE_F, col, half, x);
+        float part = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KH; ++k) part = fmaf(x[k], x[k], part);
+        const float qn = part + __shfl_xor(part, 32, 64);
+        b_aug[g] = half == 0 ? 1.0f : qn;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16_split2(-2.0f * x[8 * s + 0], -2.0f * x[8 * s + 1], bh[g][s].x, bl[g][s].x);
+            bf16_split2(-2.0f * x[8 * s + 2], -2.0f * x[8 * s + 3], bh[g][s].y, bl[g][s].y);
+            bf16_split2(-2.0f * x[8 * s + 4], -2.0f * x[8 * s + 5], bh[g][s].z, bl[g][s].z);
+            bf16_split2(-2.0f * x[8 * s + 6], -2.0f * x[8 * s + 7], bh[g][s].w, bl[g][s].w);
+        }
+    }
+
+    int32_t k0[NG], k1[NG], k2[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { k0[g] = MF_KEY_NONE; k1[g] = MF_KEY_NONE; k2[g] = MF_KEY_NONE; }
+    f32x16 p0, p1;                                                   // pending accumulators (groups NG-2, NG-1 of the previous tile)
+    MF_STAMP(1);
+    for (int t = tile0; t < tile1; ++t) {
+        const int cur = (t - tile0) & 1;
+        // my quarter of tile t has landed; after the barrier so has everybody's, and every wave is done reading tile t-1,
+        // whose slot the DMA of tile t+1 overwrites.  The LDS reads of tile t come FIRST and are waited for before that DMA is
+        // issued: the compiler orders any later LDS read behind an outstanding LDS-DMA with a full vmcnt(0).
+        MF_STAMP2(t - tile0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float aug = aug_next;
+        // A operands: hi chunks 4h .. 4h+3 and lo chunks 8+4h .. 8+4h+3 of row `col` (16-byte chunks, XOR-swizzled)
+        uint4 ah[4], al[4];
+        {
+            const float* rowp = s_tile + cur * BF_TILE_F + col * 64;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                ah[v] = *reinterpret_cast<const uint4*>(rowp + (((4 * half + v) ^ (col & 15)) << 2));
+                al[v] = *reinterpret_cast<const uint4*>(rowp + (((8 + 4 * half + v) ^ (col & 15)) << 2));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {
+            const int tn = min(t + 1, tile1 - 1);                    // unconditional: the last trip re-fetches its own tile into the idle slot
+            dma_tile_part(vocab_bf, n_rows, tn, lane, s_tile + (cur ^ 1) * BF_TILE_F, 2 * wave, 2 * wave + 2);
+            aug_next = row_norm[2 * (size_t)min(tn * 32 + col, n_rows) + half];
+        }
+        const uint32_t tl = (uint32_t)(t - tile0);
+        // two accumulator pairs take turns (no copies): groups 0,1 are computed into (x0, x1) while the pending scores of groups
+        // 2,3 of the previous tile (p0, p1) are pushed, then groups 2,3 into (p0, p1) while (x0, x1) are pushed
+        static_assert(NG == 4, "two pairs per tile");
+        f32x16 x0, x1;
+        if (t == tile0) bf_pair<false>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, 0u, k0[2], k1[2], k2[2], k0[3],
+                                       k1[3], k2[3]);
+        else bf_pair<true>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, tl - 1u, k0[2], k1[2], k2[2], k0[3], k1[3],
+                           k2[3]);
+        bf_pair<true>(ah, al, aug, bh[2], bl[2], b_aug[2], bh[3], bl[3], b_aug[3], p0, p1, x0, x1, tl, k0[0], k1[0], k2[0], k0[1], k1[1], k2[1]);
+    }
+    if (tile0 < tile1) {
+        push_group(p0, (uint32_t)(tile1 - 1 - tile0), k0[NG - 2], k1[NG - 2], k2[NG - 2]);
+        push_group(p1, (uint32_t)(tile1 - 1 - tile0), k0[NG - 1], k1[NG - 1], k2[NG - 1]);
+    }
+    MF_STAMP(2);
+
+    // the two halves of a query's rows meet in registers: best two of the six keys, and the third as the bound on everything
+    // this workgroup dropped for the query
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const uint64_t a0 = widen_key(k0[g], tile0, half), a1 = widen_key(k1[g], tile0, half), a2 = widen_key(k2[g], tile0, half);
+        const uint64_t b0 = shfl_xor_u64(a0, 32), b1 = shfl_xor_u64(a1, 32), b2 = shfl_xor_u64(a2, 32);
+        const uint64_t m0 = a0 < b0 ? a0 : b0;
+        const uint64_t hx = a0 < b0 ? b0 : a0, lx = a1 < b1 ? a1 : b1;
+        const uint64_t m1 = hx < lx ? hx : lx;
+        const uint64_t third = third_of_two_triples(a0, a1, a2, b0, b1, b2);
+        const int qi = q0 + g * 32 + col;
+        if (half == 0 && qi < qpad) {
+            uint64_t* dst = partial_keys + ((size_t)qi * gridDim.x + blockIdx.x) * BF_KEEP;
+            dst[0] = m0;
+            dst[1] = m1;
+            partial_bound[(size_t)qi * gridDim.x + blockIdx.x] = (uint32_t)min(third >> 32, (uint64_t)0x7f800000u);
+        }
+    }
+    MF_STAMP(3);
+}
+
+// |bf16x3 filter score - reference distance| <= eps, u = 2^-24:
+//   split: x = hi + lo + d with |lo| <= 2^-9 |x|, |d| <= 2^-18 |x|; the neglected ql.vl and the d terms cost
+//          <= 3 * 2^-18 |q||v| (1 + 2^-8) on q.v, twice that on the score                            -> 3.1 * 2^-18 (|v|^2 + |q|^2)
+//   accumulation: 2 + 3 dim products summed in fp32 by the matrix pipe; each addition is charged 2u (round-to-nearest or
+//          truncation) of the running magnitude <= |v|^2 + |q|^2 + 2 * 3 |q||v| <= 4 (|v|^2 + |q|^2)  -> (3 dim + 4) * 2u * 4 (..)
+//   norms (dim-term FMA chains) and the reference's own rounding, as in eps_for()                     -> (dim + 2 (dim/4 + 6)) u (..)
+// a quarter more is added for slack; the measured worst case is reported by the tests (knn_max_err_ratio).
+__device__ __forceinline__ float eps_bf16(int dim, float qn, float vn_max) {
+    const float u = 5.9604645e-8f;
+    return (3.1f * 3.8146973e-6f + ((3.0f * (float)dim + 4.0f) * 8.0f + 1.5f * (float)dim + 12.0f) * u) * 1.25f * (qn + vn_max);
+}
+
+// ------------------------------------------------------------------------------------------------ re-rank + certificate
 // |filter score - reference distance| <= eps: both are fp32 evaluations of the same real number d = |v - q|^2 <= 2 (|v|^2 + |q|^2).
 // With u = 2^-24 and gamma_n ~ n u:
 //   filter: a chain of dim + 2 FMAs over terms whose magnitudes sum to <= 2 (|v|^2 + |q|^2)        -> 2 (dim + 2) u (|v|^2 + |q|^2)
@@ -375,64 +623,106 @@ __device__ __forceinline__ float eps_for(int dim, float qn, float vn_max) {
     return (3.5f * (float)dim + 16.0f) * 5.9604645e-8f * 1.25f * (qn + vn_max);
 }
 
-// one wave per query
+// One wave per query.  Pass 1 finds tau = the second smallest filter score among the kept keys; a kept row whose score
+// exceeds tau (1 + 2^-15) + 2 eps is strictly farther than the two rows that define tau (|score - distance| <= eps, keys are
+// truncated by < 2^-16 relative), so only the few keys below that threshold are re-computed exactly in pass 2 -- each by 16
+// lanes: lane i of the group holds the term of floats [4i, 4i + 4) (one coalesced 256-byte row read) and the sixteen terms are
+// added in the reference's order.  Nothing is dropped at this stage: the bound on dropped rows comes from the filter alone.
+// KEEP keys per (row block, query); LAST_KEY_BOUNDS: the block's last kept key also bounds what its merge dropped (f32 filter);
+// BF16: the keys come from the bf16x3 filter (eps_bf16).  fail_count[2] collects max |score - distance| / eps (diagnostics).
+template <int DIM, int KEEP, bool LAST_KEY_BOUNDS, bool BF16>
 __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_t* __restrict__ partial_keys,
-                                                                   const uint32_t* __restrict__ partial_lmin, int n_blocks, int qpad,
-                                                                   int nq, int dim, const float* __restrict__ vocab,
-                                                                   const float* __restrict__ queries, const int32_t* __restrict__ row_id,
+                                                                   const uint32_t* __restrict__ partial_lmin, int n_blocks, int nq,
+                                                                   const float* __restrict__ vocab, const float* __restrict__ queries,
+                                                                   const int32_t* __restrict__ row_id,
                                                                    const uint32_t* __restrict__ norm_max_bits,
                                                                    int32_t* __restrict__ out_row, int32_t* __restrict__ out_word,
                                                                    float* __restrict__ out_dist, int32_t* __restrict__ fail_list,
                                                                    int32_t* __restrict__ fail_count) {
+    static_assert(DIM == 64, "16 lanes x 4 floats per candidate row");
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * MF_WAVES + (threadIdx.x >> 6);
     if (qi >= nq) return;
-    // every lane keeps up to 4 sorted keys of its share of the partial lists
-    uint64_t mine[4] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
-    uint32_t bound = 0x7f800000u;                                    // smallest score a dropped row can have (float bits)
-    const int n_keys = n_blocks * MF_KEEP;
-    for (int c = lane; c < n_keys; c += 64) {
-        uint64_t k = partial_keys[(size_t)c * qpad + qi];
-        if ((c % MF_KEEP) == MF_KEEP - 1) bound = min(bound, (uint32_t)min(k >> 32, (uint64_t)0x7f800000u));   // dropped at the block merge
+    const int n_keys = n_blocks * KEEP;
+    const uint64_t* __restrict__ keys = partial_keys + (size_t)qi * n_keys;
+    constexpr uint32_t INF = 0x7f800000u;
+    // the query slice of this lane's position in a 16-lane group, |q|^2
+    const float4 q4 = reinterpret_cast<const float4*>(queries + (size_t)qi * DIM)[lane & 15];
+    float qn = fmaf(q4.w, q4.w, fmaf(q4.z, q4.z, fmaf(q4.y, q4.y, q4.x * q4.x)));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint64_t lo = mine[i] < k ? mine[i] : k;
-            k = mine[i] < k ? k : mine[i];
-            mine[i] = lo;
-        }
-        if (k != KEY_NONE) bound = min(bound, (uint32_t)min(k >> 32, (uint64_t)0x7f800000u));                 // dropped by this lane
-    }
-    for (int c = lane; c < n_blocks; c += 64) bound = min(bound, partial_lmin[(size_t)c * qpad + qi]);
-    // Candidates: the two best keys of every lane (128 per query) -- no cross-lane selection rounds.  A key a lane drops is
-    // no better than the lane's third key, so the true second neighbour can only be dropped together with two better rows
-    // of the same lane, which the bound then reports.
-    bound = min(bound, (uint32_t)min(mine[2] >> 32, (uint64_t)0x7f800000u));
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) bound = min(bound, (uint32_t)__shfl_xor((int)bound, s, 64));
+    for (int m = 8; m >= 1; m >>= 1) qn += __shfl_xor(qn, m, 64);
 
-    // exact distances of the candidates, reference arithmetic; a filter score of +inf is a tombstone / padding row
-    const float* q = queries + (size_t)qi * dim;
-    uint64_t best = KEY_NONE, second = KEY_NONE;
+    // ---- pass 1: tau and the bound on dropped rows
+    uint32_t a0 = INF, a1 = INF, bound = INF;
+    for (int c = lane; c < n_keys; c += 64) {
+        const uint32_t sc = min((uint32_t)(keys[c] >> 32), INF);             // KEY_NONE -> +inf
+        if (LAST_KEY_BOUNDS && (c % KEEP) == KEEP - 1) bound = min(bound, sc);   // rows the block merge dropped are no better than its last key
+        const uint32_t h = max(a0, sc);
+        a0 = min(a0, sc);
+        a1 = min(a1, h);
+    }
+    for (int c = lane; c < n_blocks; c += 64) bound = min(bound, partial_lmin[(size_t)qi * n_blocks + c]);
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const uint64_t cand = mine[c];
-        if (cand != KEY_NONE && (uint32_t)(cand >> 32) < 0x7f800000u) {
-            const uint32_t row = (uint32_t)cand;
-            top2_push(best, second, ((uint64_t)__float_as_uint(l2_ref_row(vocab + (size_t)row * dim, q, dim)) << 32) | row);
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint32_t o0 = (uint32_t)__shfl_xor((int)a0, m, 64), o1 = (uint32_t)__shfl_xor((int)a1, m, 64);
+        a1 = min(max(a0, o0), min(a1, o1));
+        a0 = min(a0, o0);
+        bound = min(bound, (uint32_t)__shfl_xor((int)bound, m, 64));
+    }
+    const float eps = BF16 ? eps_bf16(DIM, qn, __uint_as_float(norm_max_bits[0])) : eps_for(DIM, qn, __uint_as_float(norm_max_bits[0]));
+    const float tau = __uint_as_float(a1);
+    const float thr = tau + (2.0f * eps + tau * 3.0517578e-5f);               // +inf when fewer than two finite keys exist
+
+    // ---- pass 2: exact distances (reference arithmetic, dist.h:150-177) of the keys at or below the threshold
+    uint64_t best = KEY_NONE, second = KEY_NONE;
+    float err_ratio = 0.0f;
+    const int grp = lane >> 4;
+    for (int base = 0; base < n_keys; base += 64) {
+        const int c = base + lane;
+        const uint64_t k = c < n_keys ? keys[c] : KEY_NONE;
+        const uint32_t sc = (uint32_t)(k >> 32);
+        const bool hit = k != KEY_NONE && sc < INF && __uint_as_float(sc) <= thr;   // +inf: tombstone / padding row
+        unsigned long long mask = __ballot(hit);
+        while (mask) {                                                        // four candidates per trip, one per 16-lane group
+            int src = -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (mask) {
+                    const int bpos = __ffsll((long long)mask) - 1;
+                    if (j == grp) src = bpos;
+                    mask &= mask - 1;
+                }
+            }
+            const uint32_t row = (uint32_t)__shfl((int)(uint32_t)k, max(src, 0), 64);
+            const float approx = __uint_as_float((uint32_t)__shfl((int)sc, max(src, 0), 64));
+            float t = 0.0f;
+            if (src >= 0) {
+                const float4 v4 = reinterpret_cast<const float4*>(vocab + (size_t)row * DIM)[lane & 15];
+                const float d0 = __fsub_rn(v4.x, q4.x), d1 = __fsub_rn(v4.y, q4.y), d2 = __fsub_rn(v4.z, q4.z), d3 = __fsub_rn(v4.w, q4.w);
+                t = __fmul_rn(d0, d0);
+                t = __fadd_rn(t, __fmul_rn(d1, d1));
+                t = __fadd_rn(t, __fmul_rn(d2, d2));
+                t = __fadd_rn(t, __fmul_rn(d3, d3));
+            }
+            float res = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) res = __fadd_rn(res, __shfl(t, (lane & 48) + i, 64));
+            if (src >= 0 && (lane & 15) == 0) {
+                top2_push(best, second, ((uint64_t)__float_as_uint(res) << 32) | row);
+                err_ratio = fmaxf(err_ratio, fabsf(approx - res) / eps);
+            }
         }
     }
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        const uint64_t ob = shfl_xor_u64(best, s), os = shfl_xor_u64(second, s);
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint64_t ob = shfl_xor_u64(best, m), os = shfl_xor_u64(second, m);
         top2_push(best, second, ob);
         top2_push(best, second, os);
     }
-    // |q|^2 for eps (lane-parallel partial sums)
-    float qn = 0.0f;
-    for (int k = lane; k < dim; k += 64) qn = fmaf(q[k], q[k], qn);
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) qn += __shfl_xor(qn, s, 64);
+    for (int m = 32; m >= 1; m >>= 1) err_ratio = fmaxf(err_ratio, __shfl_xor(err_ratio, m, 64));
     if (lane == 0) {
+        if (err_ratio > 0.0f && eps > 0.0f) atomicMax(reinterpret_cast<uint32_t*>(fail_count) + 2, __float_as_uint(err_ratio));
         const uint64_t k[2] = {best, second};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -444,14 +734,11 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
                 out_dist[2 * qi + j] = __uint_as_float((uint32_t)(k[j] >> 32));
             }
         }
-        // certificate: every dropped row is strictly farther than the exact second neighbour
+        // certificate: every row the filter dropped is strictly farther than the exact second neighbour
         bool ok = true;
-        if (bound < 0x7f800000u) {                                    // something finite was dropped
+        if (bound < INF) {                                            // something finite was dropped
             if (second == KEY_NONE) ok = false;                       // fewer than two exact candidates but rows were dropped
-            else {
-                const float eps = eps_for(dim, qn, __uint_as_float(norm_max_bits[0]));
-                ok = __uint_as_float(bound) - eps > __uint_as_float((uint32_t)(second >> 32));
-            }
+            else ok = __uint_as_float(bound) - eps > __uint_as_float((uint32_t)(second >> 32));
         }
         if (!ok) fail_list[atomicAdd(fail_count, 1)] = qi;
     }
@@ -557,6 +844,18 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_rowpar_kernel(const float* __res
 }
 
 }  // namespace
+}  // namespace lcd
+#ifdef LCD_MFMA_TIMING
+extern "C" int lcd_debug_mfma_timing(unsigned long long* out, int n_words) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcd::g_mf_timing), (size_t)n_words * 8);
+}
+extern "C" int lcd_debug_mfma_timing2(unsigned long long* out, int n_words) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcd::g_mf_timing2), (size_t)n_words * 8);
+}
+#endif
+namespace lcd {
 
 // ================================================================================================ host side
 bool knn_mfma_supported(int dtype, int dim) { return dtype == 0 && dim == 64; }
@@ -629,9 +928,69 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
         if (e != hipSuccess) return e;
         if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }
     }
-    knn_mfma_rerank_kernel<<<(p.q + MF_WAVES - 1) / MF_WAVES, MF_BLOCK, 0, s>>>(pk, pl, p.n_blocks, p.qpad, p.q, dim, (const float*)vocab,
-                                                                               (const float*)queries, row_id, norm_max_bits, out_row,
-                                                                               out_word, out_dist, fail_list, fail_count);
+    if (dim != 64) return hipErrorInvalidValue;
+    knn_mfma_rerank_kernel<64, MF_KEEP, true, false><<<(p.q + MF_WAVES - 1) / MF_WAVES, MF_BLOCK, 0, s>>>(pk, pl, p.n_blocks, p.q, (const float*)vocab,
+                                                                                   (const float*)queries, row_id, norm_max_bits, out_row,
+                                                                                   out_word, out_dist, fail_list, fail_count);
+    return hipGetLastError();
+}
+
+// ---- bf16x3 filter
+MfmaPlan knn_bf16_plan(int q, int n_rows) {
+    MfmaPlan p;
+    p.q = q;
+    p.qpad = (q + 63) / 64 * 64;
+    p.n_rows = n_rows;
+    const int n_tiles = (n_rows + 31) / 32;
+    const int qchunks = (q + BF_QB - 1) / BF_QB;
+    int nb = (256 + qchunks - 1) / qchunks;                            // one workgroup (4 waves, one per SIMD) per CU
+    if (nb > n_tiles) nb = n_tiles;
+    if (nb < 1) nb = 1;
+    int tpb = (n_tiles + nb - 1) / nb;
+    if (tpb < 1) tpb = 1;
+    if (tpb > MF_STRIP_TILES) tpb = MF_STRIP_TILES;                    // the in-loop keys index at most 8 tiles per strip
+    p.tiles_per_block = tpb;
+    p.n_blocks = n_tiles > 0 ? (n_tiles + tpb - 1) / tpb : 0;
+    return p;
+}
+size_t knn_bf16_partial_bytes(const MfmaPlan& p) {
+    const size_t nb = (size_t)(p.n_blocks > 0 ? p.n_blocks : 1);
+    return nb * BF_KEEP * p.qpad * sizeof(uint64_t) + nb * p.qpad * sizeof(uint32_t);
+}
+hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void* bf, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (dim != 64) return hipErrorInvalidValue;
+    vocab_bf16_kernel<<<(n * 16 + 255) / 256, 256, 0, s>>>((const float*)vocab, first, n, (uint32_t*)bf);
+    return hipGetLastError();
+}
+hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, const float* row_norm, const uint32_t* norm_max_bits,
+                           const int32_t* row_id, const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word,
+                           float* out_dist, int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
+                           bool reset_count) {
+    if (p.q == 0) return hipSuccess;
+    if (dim != 64) return hipErrorInvalidValue;
+    uint64_t* pk = (uint64_t*)partial;
+    uint32_t* pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * BF_KEEP * p.qpad);
+    hipError_t e = hipSuccess;
+    if (reset_count) {
+        e = hipMemsetAsync(fail_count, 0, 8, s);
+        if (e != hipSuccess) return e;
+    }
+    if (p.n_blocks > 0) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_bf16_filter_kernel<4>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES);
+        (void)attr;
+        dim3 grid(p.n_blocks, (p.q + BF_QB - 1) / BF_QB);
+        if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
+        knn_bf16_filter_kernel<4><<<grid, MF_BLOCK, BF_LDS_BYTES, s>>>((const float*)vocab_bf, row_norm, p.n_rows, (const float*)queries, p.q,
+                                                                        p.qpad, p.tiles_per_block, pk, pl);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }
+    }
+    knn_mfma_rerank_kernel<64, BF_KEEP, false, true><<<(p.q + MF_WAVES - 1) / MF_WAVES, MF_BLOCK, 0, s>>>(
+        pk, pl, p.n_blocks, p.q, (const float*)vocab, (const float*)queries, row_id, norm_max_bits, out_row, out_word, out_dist, fail_list,
+        fail_count);
     return hipGetLastError();
 }
 

@@ -74,6 +74,16 @@ hipError_t launch_shard_pack(const int32_t* knn_row, const int32_t* knn_word, co
 hipError_t launch_shard_merge(const void* all_cand, int world, int rank, int q, int32_t* out_word, float* out_dist, int32_t* out_wslot,
                               hipStream_t s);
 
+// ---- the same filter on the bf16 matrix pipe (three bf16 products per f32 product, fp32 accumulate): needs the hi/lo bf16
+// split of the vocabulary (256 bytes per row) kept by launch_vocab_bf16 next to the rows.
+MfmaPlan knn_bf16_plan(int q, int n_rows);
+size_t knn_bf16_partial_bytes(const MfmaPlan& p);
+hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void* bf, hipStream_t s);
+hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, const float* row_norm, const uint32_t* norm_max_bits,
+                           const int32_t* row_id, const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word,
+                           float* out_dist, int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin = nullptr,
+                           hipEvent_t ev_end = nullptr, bool reset_count = true);
+
 // Row gather used by lcd_vocab_rebuild: dst[i] = src[perm[i]] (rows of row_bytes bytes, multiple of 4), ids likewise.
 hipError_t launch_gather_rows(const void* src, const int32_t* src_id, const int32_t* perm, int n, int row_bytes,
                               void* dst, int32_t* dst_id, hipStream_t s);

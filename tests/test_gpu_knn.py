@@ -144,27 +144,29 @@ def test_selfdist_bit_exact_and_symmetric(oracle, kind):
 
 @pytest.mark.parametrize("many_clusters", [False, True])
 def test_knn2_mfma_filter_matches_exact_scan_and_falls_back_on_clusters(oracle, monkeypatch, many_clusters):
-    """f32 dim-64 vocabularies >= 256 rows go through the MFMA filter + exact re-rank.  Results must be the exact scan's,
-    bit for bit; a cluster of identical rows around a query cannot be certified and must take the exact-scan fallback."""
+    """f32 dim-64 vocabularies >= 256 rows go through an MFMA filter (bf16x3 by default, f32 MFMA on request) + exact re-rank.
+    Results must be the exact scan's, bit for bit; a run of identical rows next to each other (more equal candidates than a
+    row block keeps) cannot be certified and must take the exact-scan fallback, scattered copies are certified."""
     import rtabmap_amd
     v = synth.vocab_surf(20000, seed=5)
     q = synth.queries_surf(v, 300, seed=6)
-    # 40 copies of one row scattered over the vocabulary: more equal candidates than the re-rank keeps
-    v[::500] = v[123]
+    v[::500] = v[123]                    # 40 copies of one row scattered over the vocabulary ...
+    v[7000:7040] = v[123]                # ... and 40 more in one run
     q[7] = v[123]
     q[8] = v[123] + np.float32(1e-4)
     if many_clusters:                    # many uncertifiable queries at once
         q[100:160] = v[123] + (np.arange(60, dtype=np.float32)[:, None] * np.float32(1e-5))
     ids = np.arange(1, 20001, dtype=np.int32)
     res = {}
-    for mode in ("mfma", "valu"):
+    for mode in ("bf16", "mfma32", "valu"):
         monkeypatch.setenv("LCD_KNN_MODE", mode)
         eng = rtabmap_amd.Engine("f32", 64)
         eng.vocab_append(v, ids)
         res[mode] = eng.knn2(q)
-        fb = eng.stats()["knn_last_fallback_queries"]
-        if mode == "mfma":
-            assert (33 <= fb < 120) if many_clusters else (1 <= fb <= 32), fb          # the cluster queries, not everything
+        st = eng.stats()
+        fb = st["knn_last_fallback_queries"]
+        if mode != "valu":
+            assert (33 <= fb < 120) if many_clusters else (1 <= fb <= 32), (mode, fb)   # the cluster queries, not everything
         else:
             assert fb == 0
         _check(eng, oracle, v, ids, q)
@@ -176,6 +178,35 @@ def test_knn2_mfma_filter_matches_exact_scan_and_falls_back_on_clusters(oracle, 
         eng.vocab_rebuild()
         keep = removed == 0
         _check(eng, oracle, v[keep], ids[keep], q)
+        if mode != "valu":               # the filter's error bound must hold with room to spare
+            assert 0.0 < eng.stats()["knn_max_err_ratio"] < 0.5, eng.stats()["knn_max_err_ratio"]
         eng.close()
-    np.testing.assert_array_equal(res["mfma"][0], res["valu"][0])
-    np.testing.assert_array_equal(res["mfma"][1], res["valu"][1])
+    np.testing.assert_array_equal(res["bf16"][0], res["valu"][0])
+    np.testing.assert_array_equal(res["bf16"][1], res["valu"][1])
+    np.testing.assert_array_equal(res["mfma32"][0], res["valu"][0])
+    np.testing.assert_array_equal(res["mfma32"][1], res["valu"][1])
+
+
+@pytest.mark.parametrize("mode", ["bf16", "mfma32"])
+def test_knn2_filter_error_bound_on_wide_range_descriptors(oracle, monkeypatch, mode):
+    """The filter certificate rests on |filter score - exact distance| <= eps.  Descriptors with a wide dynamic range (large
+    and tiny components, mixed signs, non-unit norms, queries far from and equal to rows) must stay inside it, and the answers
+    must still be the exact scan's."""
+    import rtabmap_amd
+    rng = np.random.default_rng(11)
+    n, qn = 4096, 257
+    v = (rng.standard_normal((n, 64)) * np.exp(rng.uniform(-6, 6, (n, 64)))).astype(np.float32)
+    v[::7] *= np.float32(1e3)
+    v[1::7] *= np.float32(1e-3)
+    q = v[rng.integers(0, n, qn)] * (1 + rng.standard_normal((qn, 64)).astype(np.float32) * np.float32(1e-3))
+    q = q.astype(np.float32)
+    q[:16] = v[:16]
+    q[16:32] = (rng.standard_normal((16, 64)) * 50).astype(np.float32)
+    ids = np.arange(1, n + 1, dtype=np.int32)
+    monkeypatch.setenv("LCD_KNN_MODE", mode)
+    eng = rtabmap_amd.Engine("f32", 64)
+    eng.vocab_append(v, ids)
+    _check(eng, oracle, v, ids, q)
+    r = eng.stats()["knn_max_err_ratio"]
+    assert 0.0 < r < 0.5, r
+    eng.close()
