@@ -68,7 +68,7 @@ int upload_rows(lcd_engine* h, const void* rows, int n, DevBuf& dst) {
 // 2-NN of q device-resident queries against a row matrix -> o_{row,word,dist}[q*2].  `main_vocab` selects the resident
 // vocabulary (which has row norms and may use the MFMA filter); other matrices (findNN's not-indexed words) use the exact scan.
 int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab, const int32_t* row_id, int64_t n_rows, bool main_vocab,
-                 int32_t* o_row, int32_t* o_word, float* o_dist) {
+                 int32_t* o_row, int32_t* o_word, float* o_dist, const CandBits* cb = nullptr) {
     if (q == 0) return LCD_OK;
     const bool mfma = main_vocab && h->knn_mode != 0 && knn_mfma_supported(h->dtype, h->kdim) && n_rows >= 256;
     const KnnPlan p = knn_plan(q, (int)n_rows, h->row_bytes);
@@ -80,27 +80,28 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
         LCD_HIP(h, launch_knn_bf16(h->kdim, vocab, h->vocab_bf.p, h->row_norm.as<float>(), h->norm_max.as<uint32_t>(), row_id, d_queries, mp,
                                    h->d_partial2.p, o_row, o_word, o_dist, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(),
                                    h->stream, prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr,
-                                   !h->fail_count_clean));
+                                   !h->fail_count_clean, cb, cb != nullptr));
         h->fail_count_clean = false;
         if (prof) { h->prof_n += 1; h->prof_kernel = "knn_bf16_filter_kernel"; }
         LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
         LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(),
-                                     h->d_partial3.p, o_row, o_word, o_dist, h->stream));
+                                     h->d_partial3.p, o_row, o_word, o_dist, h->stream, cb));
     } else if (mfma) {
         const MfmaPlan mp = knn_mfma_plan(q, (int)n_rows);
         LCD_HIP(h, dreserve(h, h->d_partial2, knn_mfma_partial_bytes(mp)));
         LCD_HIP(h, dreserve(h, h->d_fail_list, (size_t)q * 4));
         const bool prof = h->prof_cap > 0 && h->prof_n < h->prof_cap;
+        if (cb) LCD_HIP(h, launch_selfdist(h->dtype, h->kdim, d_queries, q, const_cast<float*>(cb->selfdist), cb->ld, h->stream));
         LCD_HIP(h, launch_knn_mfma(h->kdim, vocab, h->row_norm.as<float>(), h->norm_max.as<uint32_t>(), row_id, d_queries, mp, h->d_partial2.p,
                                    o_row, o_word, o_dist, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(), h->stream,
                                    prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr,
-                                   !h->fail_count_clean));
+                                   !h->fail_count_clean, cb));
         h->fail_count_clean = false;
         if (prof) { h->prof_n += 1; h->prof_kernel = "knn_mfma_filter_kernel"; }
         // the queries the certificate rejected are redone exactly by the row-parallel kernel (usually none: it leaves at once)
         LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
         LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(),
-                                     h->d_partial3.p, o_row, o_word, o_dist, h->stream));
+                                     h->d_partial3.p, o_row, o_word, o_dist, h->stream, cb));
     } else {
         LCD_HIP(h, dreserve(h, h->d_partial, knn_partial_bytes(p)));
         const bool prof = main_vocab && h->prof_cap > 0 && h->prof_n < h->prof_cap;
@@ -414,9 +415,6 @@ int lcd_selfdist(lcd_engine* h, const void* queries, int q, float* out_qxq) {
 static int prepare_resolve(lcd_engine* h, const void* d_desc, int q, int flags, float nndr, int32_t* d_out_word, int32_t* d_out_wslot,
                            ResolveArgs* r) {
     const int have_index = h->n_live >= 2 ? 1 : 0;                  // VWDictionary.cpp:1015
-    int rc = run_knn2(h, d_desc, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), have_index ? h->n_rows : 0,
-                      h->d_knn_row, h->d_knn_word, h->d_knn_dist);
-    if (rc) return rc;
     const bool incremental = (flags & LCD_Q_INCREMENTAL) != 0;
     const bool together = incremental && (flags & LCD_Q_NEW_WORDS_COMPARED);
     int ld = (q + 63) / 64 * 64;
@@ -424,8 +422,29 @@ static int prepare_resolve(lcd_engine* h, const void* d_desc, int q, int flags, 
     if (together) {
         LCD_HIP(h, dreserve(h, h->d_selfdist, (size_t)q * ld * 4));
         LCD_HIP(h, dreserve(h, h->d_bits, (size_t)q * bw * 4));
-        LCD_HIP(h, launch_selfdist(h->dtype, h->kdim, d_desc, q, h->d_selfdist.as<float>(), ld, h->stream, have_index,
-                                   h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), h->d_bits.as<uint32_t>(), bw));
+    }
+    // With the MFMA filter the same-frame distance matrix does not wait for the 2-NN: extra workgroups of the filter launch
+    // compute it, and the re-rank workgroup of a query -- the first to know the query's second neighbour -- derives the query's
+    // candidate bits from its (symmetric) row: two launches fewer per frame.
+    const int64_t knn_rows = have_index ? h->n_rows : 0;
+    const bool side = together && h->knn_mode != 0 && knn_mfma_supported(h->dtype, h->kdim) && knn_rows >= 256 && q > 0;
+    int rc;
+    if (side) {
+        CandBits cb;
+        cb.selfdist = h->d_selfdist.as<float>(); cb.ld = ld; cb.nq = q; cb.bits = h->d_bits.as<uint32_t>(); cb.bw = bw; cb.have_index = have_index;
+        LCD_HIP(h, dreserve(h, h->d_knn_row, (size_t)q * 2 * 4));
+        LCD_HIP(h, dreserve(h, h->d_knn_word, (size_t)q * 2 * 4));
+        LCD_HIP(h, dreserve(h, h->d_knn_dist, (size_t)q * 2 * 4));
+        rc = run_knn2_raw(h, d_desc, q, h->vocab.p, h->row_id.as<int32_t>(), knn_rows, true, h->d_knn_row.as<int32_t>(),
+                          h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), &cb);
+        if (rc) return rc;
+    } else {
+        rc = run_knn2(h, d_desc, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), knn_rows, h->d_knn_row, h->d_knn_word,
+                      h->d_knn_dist);
+        if (rc) return rc;
+        if (together)
+            LCD_HIP(h, launch_selfdist(h->dtype, h->kdim, d_desc, q, h->d_selfdist.as<float>(), ld, h->stream, have_index,
+                                       h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), h->d_bits.as<uint32_t>(), bw));
     }
     r->q = q;
     r->flags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0);

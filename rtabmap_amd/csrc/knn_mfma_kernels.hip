@@ -260,9 +260,9 @@ __device__ __forceinline__ void mfma_pair_push(const float (&a)[KH], float a_aug
 // the next); NG = 2 runs two waves per SIMD.
 #ifdef LCD_MFMA_TIMING   // timing experiment only: per-wave timestamps (100 MHz) at kernel entry, loop entry, loop exit, kernel exit
 __device__ unsigned long long g_mf_timing[4 * 4096];
-#define MF_STAMP(i) do { if (lane == 0) g_mf_timing[4 * ((blockIdx.y * gridDim.x + blockIdx.x) * MF_WAVES + wave) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MF_STAMP(i) do { if (lane == 0) g_mf_timing[4 * (((blockIdx.y * gridDim.x + blockIdx.x) & 1023) * MF_WAVES + wave) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 __device__ unsigned long long g_mf_timing2[8 * 4096];   // finer stamps inside one loop trip of the bf16 filter
-#define MF_STAMP2(i) do { if (lane == 0 && (i) < 8) { g_mf_timing2[8 * ((blockIdx.y * gridDim.x + blockIdx.x) * MF_WAVES + wave) + (i)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define MF_STAMP2(i) do { if (lane == 0 && (i) < 8) { g_mf_timing2[8 * (((blockIdx.y * gridDim.x + blockIdx.x) & 1023) * MF_WAVES + wave) + (i)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define MF_STAMP(i) do { } while (0)
 #define MF_STAMP2(i) do { } while (0)
@@ -478,24 +478,93 @@ __device__ __forceinline__ uint64_t third_of_two_triples(uint64_t a0, uint64_t a
     return m < y ? m : y;
 }
 
-// partial_keys [qpad][n_blocks][BF_KEEP] u64, partial_bound [qpad][n_blocks] f32 bits
+// ---- same-frame distance matrix, computed by extra workgroups of the filter launch (independent of the 2-NN; a launch of its own
+// costs more than the work).  One workgroup = one 32 x 32 tile of the upper triangle of D[r][c] = |q_r - q_c|^2 in the reference's
+// arithmetic (dist.h:150-177; (a - b)^2 == (b - a)^2 bit for bit, so the mirrored tile is a copy).  Both 32-query tiles are staged
+// in LDS (16-byte chunks XOR-swizzled by the row so that the 32 lanes of a half-wave, one query each, read conflict-free).
+struct SelfdistJob {
+    const float* queries = nullptr;    // [nq x 64]
+    int nq = 0;
+    float* out = nullptr;              // [nq x ld]
+    int ld = 0;
+    int n_tiles = 0;                   // workgroups: T (T + 1) / 2, T = ceil(nq / 32); 0 = no job
+};
+__device__ __forceinline__ void selfdist_tile(const SelfdistJob& sd, int k, float* __restrict__ lds) {
+    const int T = (sd.nq + 31) / 32;
+    int ti = 0, rem = k;
+    while (rem >= T - ti) { rem -= T - ti; ++ti; }
+    const int tj = ti + rem;
+    const int tid = threadIdx.x;
+    float* sA = lds;                   // rows of tile ti   [32][64] swizzled
+    float* sB = lds + 2048;            // rows of tile tj
+    float* sT = lds + 4096;            // [32][33] transposed result
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + u * 256;                   // float4 index within a tile: row e / 16, chunk e % 16
+        const int r = e >> 4, c = e & 15;
+        const int ra = min(ti * 32 + r, sd.nq - 1), rb = min(tj * 32 + r, sd.nq - 1);
+        const float4 a = reinterpret_cast<const float4*>(sd.queries + (size_t)ra * 64)[c];
+        const float4 b = reinterpret_cast<const float4*>(sd.queries + (size_t)rb * 64)[c];
+        *reinterpret_cast<float4*>(sA + r * 64 + ((c ^ (r & 15)) << 2)) = a;
+        *reinterpret_cast<float4*>(sB + r * 64 + ((c ^ (r & 15)) << 2)) = b;
+    }
+    __syncthreads();
+    const int i = tid & 31, jj = tid >> 5;             // column query i of tile tj; rows jj, jj + 8, jj + 16, jj + 24 of tile ti
+    float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+    for (int g = 0; g < 16; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(sB + i * 64 + ((g ^ (i & 15)) << 2));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int r = jj + 8 * m;
+            const float4 a = *reinterpret_cast<const float4*>(sA + r * 64 + ((g ^ (r & 15)) << 2));
+            const float d0 = __fsub_rn(a.x, b.x), d1 = __fsub_rn(a.y, b.y), d2 = __fsub_rn(a.z, b.z), d3 = __fsub_rn(a.w, b.w);
+            float t = __fmul_rn(d0, d0);
+            t = __fadd_rn(t, __fmul_rn(d1, d1));
+            t = __fadd_rn(t, __fmul_rn(d2, d2));
+            t = __fadd_rn(t, __fmul_rn(d3, d3));
+            res[m] = __fadd_rn(res[m], t);
+        }
+    }
+    const int c = tj * 32 + i;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int r = ti * 32 + jj + 8 * m;
+        if (r < sd.nq && c < sd.nq) sd.out[(size_t)r * sd.ld + c] = res[m];
+        sT[(jj + 8 * m) * 33 + i] = res[m];
+    }
+    if (ti == tj) return;                              // uniform
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {                      // mirrored tile: D[tj*32 + x][ti*32 + i] = D[ti*32 + i][tj*32 + x]
+        const int x = jj + 8 * m;
+        const int r = tj * 32 + x, cc = ti * 32 + i;
+        if (r < sd.nq && cc < sd.nq) sd.out[(size_t)r * sd.ld + cc] = sT[i * 33 + x];
+    }
+}
+
+// partial_keys [qpad][n_blocks][BF_KEEP] u64, partial_bound [qpad][n_blocks] f32 bits.  Grid (1-D): sd.n_tiles distance-matrix
+// workgroups first, then n_blocks x ceil(nq / 512) filter workgroups.
 template <int NG>
 __global__ __launch_bounds__(MF_BLOCK, 1) void knn_bf16_filter_kernel(const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
                                                                       int n_rows, const float* __restrict__ queries, int nq, int qpad,
-                                                                      int tiles_per_block, uint64_t* __restrict__ partial_keys,
-                                                                      uint32_t* __restrict__ partial_bound) {
+                                                                      int tiles_per_block, int n_blocks, uint64_t* __restrict__ partial_keys,
+                                                                      uint32_t* __restrict__ partial_bound, SelfdistJob sd) {
     static_assert(NG * 32 == BF_QW, "wave tile");
     constexpr int KH = 32;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    if ((int)blockIdx.x < sd.n_tiles) { selfdist_tile(sd, (int)blockIdx.x, s_dyn); return; }
+    const int fb = (int)blockIdx.x - sd.n_tiles;
+    const int bx = fb % n_blocks, by = fb / n_blocks;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 31, half = lane >> 5;
-    const int q0 = blockIdx.y * BF_QB + wave * BF_QW;
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    const int q0 = by * BF_QB + wave * BF_QW;
     float* s_q = s_dyn + (size_t)wave * NG * BF_TILE_F;             // this wave's query staging (prologue only)
     float* s_tile = s_dyn + (size_t)MF_WAVES * NG * BF_TILE_F;      // [2] vocabulary tiles shared by the workgroup
     MF_STAMP(0);
 
-    const int tile0 = blockIdx.x * tiles_per_block;
+    const int tile0 = bx * tiles_per_block;
     const int n_tiles = (n_rows + 31) / 32;
     const int tile1 = min(tile0 + tiles_per_block, n_tiles);
 
@@ -590,10 +659,10 @@ __global__ __launch_bounds__(MF_BLOCK, 1) void knn_bf16_filter_kernel(const floa
         const uint64_t third = third_of_two_triples(a0, a1, a2, b0, b1, b2);
         const int qi = q0 + g * 32 + col;
         if (half == 0 && qi < qpad) {
-            uint64_t* dst = partial_keys + ((size_t)qi * gridDim.x + blockIdx.x) * BF_KEEP;
+            uint64_t* dst = partial_keys + ((size_t)qi * n_blocks + bx) * BF_KEEP;
             dst[0] = m0;
             dst[1] = m1;
-            partial_bound[(size_t)qi * gridDim.x + blockIdx.x] = (uint32_t)min(third >> 32, (uint64_t)0x7f800000u);
+            partial_bound[(size_t)qi * n_blocks + bx] = (uint32_t)min(third >> 32, (uint64_t)0x7f800000u);
         }
     }
     MF_STAMP(3);
@@ -623,13 +692,28 @@ __device__ __forceinline__ float eps_for(int dim, float qn, float vn_max) {
     return (3.5f * (float)dim + 16.0f) * 5.9604645e-8f * 1.25f * (qn + vn_max);
 }
 
-// One wave per query.  Pass 1 finds tau = the second smallest filter score among the kept keys; a kept row whose score
-// exceeds tau (1 + 2^-15) + 2 eps is strictly farther than the two rows that define tau (|score - distance| <= eps, keys are
-// truncated by < 2^-16 relative), so only the few keys below that threshold are re-computed exactly in pass 2 -- each by 16
-// lanes: lane i of the group holds the term of floats [4i, 4i + 4) (one coalesced 256-byte row read) and the sixteen terms are
-// added in the reference's order.  Nothing is dropped at this stage: the bound on dropped rows comes from the filter alone.
+// Row `qi` of the candidate bit matrix of the addNewWords resolution (knn2_kernels.hip: bit r = dist(r, qi) < distance of qi's
+// second indexed neighbour) from the already computed same-frame distance matrix, which is symmetric bit for bit.  Called by
+// whole waves (n_threads a multiple of 64); writes all bw words of the row.
+__device__ __forceinline__ void cand_bits_row(const CandBits& cb, int qi, float thr, int tid, int n_threads) {
+    for (int base = (tid >> 6) * 64; base < cb.ld; base += n_threads) {
+        const int r = base + (tid & 63);
+        const float d = r < cb.nq ? cb.selfdist[(size_t)qi * cb.ld + r] : __int_as_float(0x7f800000);
+        const unsigned long long m = __ballot(d < thr);
+        if ((tid & 63) == 0) *reinterpret_cast<unsigned long long*>(cb.bits + (size_t)qi * cb.bw + (base >> 5)) = m;
+    }
+}
+
+// One workgroup per query (the kernel is a chain of dependent memory round trips: the more lanes share them, the shorter).
+// Pass 1 finds tau = the second smallest filter score among the kept keys; a kept row whose score exceeds
+// tau (1 + 2^-15) + 2 eps is strictly farther than the two rows that define tau (|score - distance| <= eps, keys are truncated by
+// < 2^-16 relative), so only the few keys at or below that threshold are re-computed exactly in pass 2 -- each by 16 lanes:
+// lane i of the group holds the term of floats [4i, 4i + 4) (one coalesced 256-byte row read) and the sixteen terms are added in
+// the reference's order.  Nothing is dropped at this stage (more than RR_MAX_CAND keys under the threshold -- a cluster of
+// near-identical rows -- sends the query to the exact scan): the bound on dropped rows comes from the filter alone.
 // KEEP keys per (row block, query); LAST_KEY_BOUNDS: the block's last kept key also bounds what its merge dropped (f32 filter);
 // BF16: the keys come from the bf16x3 filter (eps_bf16).  fail_count[2] collects max |score - distance| / eps (diagnostics).
+constexpr int RR_MAX_CAND = 128;
 template <int DIM, int KEEP, bool LAST_KEY_BOUNDS, bool BF16>
 __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_t* __restrict__ partial_keys,
                                                                    const uint32_t* __restrict__ partial_lmin, int n_blocks, int nq,
@@ -638,14 +722,18 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
                                                                    const uint32_t* __restrict__ norm_max_bits,
                                                                    int32_t* __restrict__ out_row, int32_t* __restrict__ out_word,
                                                                    float* __restrict__ out_dist, int32_t* __restrict__ fail_list,
-                                                                   int32_t* __restrict__ fail_count) {
+                                                                   int32_t* __restrict__ fail_count, CandBits cb) {
     static_assert(DIM == 64, "16 lanes x 4 floats per candidate row");
-    const int lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * MF_WAVES + (threadIdx.x >> 6);
-    if (qi >= nq) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = blockIdx.x;
+    __shared__ float s_thr;
     const int n_keys = n_blocks * KEEP;
     const uint64_t* __restrict__ keys = partial_keys + (size_t)qi * n_keys;
     constexpr uint32_t INF = 0x7f800000u;
+    __shared__ uint32_t s_a0[MF_WAVES], s_a1[MF_WAVES], s_bound[MF_WAVES];
+    __shared__ int s_ncand;
+    __shared__ uint64_t s_cand[RR_MAX_CAND], s_exact[RR_MAX_CAND];
+    __shared__ float s_err[MF_WAVES];
     // the query slice of this lane's position in a 16-lane group, |q|^2
     const float4 q4 = reinterpret_cast<const float4*>(queries + (size_t)qi * DIM)[lane & 15];
     float qn = fmaf(q4.w, q4.w, fmaf(q4.z, q4.z, fmaf(q4.y, q4.y, q4.x * q4.x)));
@@ -654,14 +742,14 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
 
     // ---- pass 1: tau and the bound on dropped rows
     uint32_t a0 = INF, a1 = INF, bound = INF;
-    for (int c = lane; c < n_keys; c += 64) {
+    for (int c = tid; c < n_keys; c += MF_BLOCK) {
         const uint32_t sc = min((uint32_t)(keys[c] >> 32), INF);             // KEY_NONE -> +inf
         if (LAST_KEY_BOUNDS && (c % KEEP) == KEEP - 1) bound = min(bound, sc);   // rows the block merge dropped are no better than its last key
         const uint32_t h = max(a0, sc);
         a0 = min(a0, sc);
         a1 = min(a1, h);
     }
-    for (int c = lane; c < n_blocks; c += 64) bound = min(bound, partial_lmin[(size_t)qi * n_blocks + c]);
+    for (int c = tid; c < n_blocks; c += MF_BLOCK) bound = min(bound, partial_lmin[(size_t)qi * n_blocks + c]);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const uint32_t o0 = (uint32_t)__shfl_xor((int)a0, m, 64), o1 = (uint32_t)__shfl_xor((int)a1, m, 64);
@@ -669,59 +757,72 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
         a0 = min(a0, o0);
         bound = min(bound, (uint32_t)__shfl_xor((int)bound, m, 64));
     }
+    if (lane == 0) { s_a0[wave] = a0; s_a1[wave] = a1; s_bound[wave] = bound; }
+    if (tid == 0) s_ncand = 0;
+    __syncthreads();
+    a0 = s_a0[0]; a1 = s_a1[0]; bound = s_bound[0];
+#pragma unroll
+    for (int w = 1; w < MF_WAVES; ++w) {
+        const uint32_t o0 = s_a0[w], o1 = s_a1[w];
+        a1 = min(max(a0, o0), min(a1, o1));
+        a0 = min(a0, o0);
+        bound = min(bound, s_bound[w]);
+    }
     const float eps = BF16 ? eps_bf16(DIM, qn, __uint_as_float(norm_max_bits[0])) : eps_for(DIM, qn, __uint_as_float(norm_max_bits[0]));
     const float tau = __uint_as_float(a1);
     const float thr = tau + (2.0f * eps + tau * 3.0517578e-5f);               // +inf when fewer than two finite keys exist
 
-    // ---- pass 2: exact distances (reference arithmetic, dist.h:150-177) of the keys at or below the threshold
-    uint64_t best = KEY_NONE, second = KEY_NONE;
-    float err_ratio = 0.0f;
-    const int grp = lane >> 4;
-    for (int base = 0; base < n_keys; base += 64) {
-        const int c = base + lane;
-        const uint64_t k = c < n_keys ? keys[c] : KEY_NONE;
+    // ---- pass 2: the keys at or below the threshold (+inf: tombstone / padding row) ...
+    for (int c = tid; c < n_keys; c += MF_BLOCK) {
+        const uint64_t k = keys[c];
         const uint32_t sc = (uint32_t)(k >> 32);
-        const bool hit = k != KEY_NONE && sc < INF && __uint_as_float(sc) <= thr;   // +inf: tombstone / padding row
-        unsigned long long mask = __ballot(hit);
-        while (mask) {                                                        // four candidates per trip, one per 16-lane group
-            int src = -1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (mask) {
-                    const int bpos = __ffsll((long long)mask) - 1;
-                    if (j == grp) src = bpos;
-                    mask &= mask - 1;
-                }
-            }
-            const uint32_t row = (uint32_t)__shfl((int)(uint32_t)k, max(src, 0), 64);
-            const float approx = __uint_as_float((uint32_t)__shfl((int)sc, max(src, 0), 64));
-            float t = 0.0f;
-            if (src >= 0) {
-                const float4 v4 = reinterpret_cast<const float4*>(vocab + (size_t)row * DIM)[lane & 15];
-                const float d0 = __fsub_rn(v4.x, q4.x), d1 = __fsub_rn(v4.y, q4.y), d2 = __fsub_rn(v4.z, q4.z), d3 = __fsub_rn(v4.w, q4.w);
-                t = __fmul_rn(d0, d0);
-                t = __fadd_rn(t, __fmul_rn(d1, d1));
-                t = __fadd_rn(t, __fmul_rn(d2, d2));
-                t = __fadd_rn(t, __fmul_rn(d3, d3));
-            }
+        if (k != KEY_NONE && sc < INF && __uint_as_float(sc) <= thr) {
+            const int slot = atomicAdd(&s_ncand, 1);
+            if (slot < RR_MAX_CAND) s_cand[slot] = k;
+        }
+    }
+    __syncthreads();
+    const int n_cand = s_ncand;
+    const bool overflow = n_cand > RR_MAX_CAND;
+    // ... get their exact distances (reference arithmetic, dist.h:150-177), one candidate per 16-lane group and trip
+    float err_ratio = 0.0f;
+    if (!overflow) {
+        for (int i = tid >> 4; i < n_cand; i += MF_BLOCK / 16) {
+            const uint64_t k = s_cand[i];
+            const uint32_t row = (uint32_t)k;
+            const float4 v4 = reinterpret_cast<const float4*>(vocab + (size_t)row * DIM)[lane & 15];
+            const float d0 = __fsub_rn(v4.x, q4.x), d1 = __fsub_rn(v4.y, q4.y), d2 = __fsub_rn(v4.z, q4.z), d3 = __fsub_rn(v4.w, q4.w);
+            float t = __fmul_rn(d0, d0);
+            t = __fadd_rn(t, __fmul_rn(d1, d1));
+            t = __fadd_rn(t, __fmul_rn(d2, d2));
+            t = __fadd_rn(t, __fmul_rn(d3, d3));
             float res = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) res = __fadd_rn(res, __shfl(t, (lane & 48) + i, 64));
-            if (src >= 0 && (lane & 15) == 0) {
-                top2_push(best, second, ((uint64_t)__float_as_uint(res) << 32) | row);
-                err_ratio = fmaxf(err_ratio, fabsf(approx - res) / eps);
+            for (int j = 0; j < 16; ++j) res = __fadd_rn(res, __shfl(t, (lane & 48) + j, 64));
+            if ((lane & 15) == 0) {
+                s_exact[i] = ((uint64_t)__float_as_uint(res) << 32) | row;
+                err_ratio = fmaxf(err_ratio, fabsf(__uint_as_float((uint32_t)(k >> 32)) - res) / eps);
             }
         }
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const uint64_t ob = shfl_xor_u64(best, m), os = shfl_xor_u64(second, m);
-        top2_push(best, second, ob);
-        top2_push(best, second, os);
-    }
-#pragma unroll
     for (int m = 32; m >= 1; m >>= 1) err_ratio = fmaxf(err_ratio, __shfl_xor(err_ratio, m, 64));
-    if (lane == 0) {
+    if (lane == 0) s_err[wave] = err_ratio;
+    __syncthreads();
+    uint64_t best = KEY_NONE, second = KEY_NONE;
+    if (wave == 0) {
+        if (!overflow)
+            for (int i = lane; i < n_cand; i += 64) top2_push(best, second, s_exact[i]);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint64_t ob = shfl_xor_u64(best, m), os = shfl_xor_u64(second, m);
+            top2_push(best, second, ob);
+            top2_push(best, second, os);
+        }
+    }
+    if (tid == 0) {
+        s_thr = (cb.have_index && second != KEY_NONE) ? __uint_as_float((uint32_t)(second >> 32)) : __int_as_float(0x7f800000);
+        err_ratio = fmaxf(fmaxf(s_err[0], s_err[1]), fmaxf(s_err[2], s_err[3]));
         if (err_ratio > 0.0f && eps > 0.0f) atomicMax(reinterpret_cast<uint32_t*>(fail_count) + 2, __float_as_uint(err_ratio));
         const uint64_t k[2] = {best, second};
 #pragma unroll
@@ -735,12 +836,16 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
             }
         }
         // certificate: every row the filter dropped is strictly farther than the exact second neighbour
-        bool ok = true;
-        if (bound < INF) {                                            // something finite was dropped
+        bool ok = !overflow;
+        if (ok && bound < INF) {                                      // something finite was dropped
             if (second == KEY_NONE) ok = false;                       // fewer than two exact candidates but rows were dropped
             else ok = __uint_as_float(bound) - eps > __uint_as_float((uint32_t)(second >> 32));
         }
         if (!ok) fail_list[atomicAdd(fail_count, 1)] = qi;
+    }
+    if (cb.bits) {                                                    // the query's row of the candidate bit matrix (uniform branch)
+        __syncthreads();
+        cand_bits_row(cb, qi, s_thr, tid, MF_BLOCK);
     }
 }
 
@@ -755,7 +860,7 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_rowpar_kernel(const float* __res
                                                               const float* __restrict__ queries, const int32_t* __restrict__ fail_list,
                                                               int32_t* __restrict__ fail_count /* [0] count, [1] arrivals */,
                                                               uint64_t* __restrict__ partial, int32_t* __restrict__ out_row,
-                                                              int32_t* __restrict__ out_word, float* __restrict__ out_dist) {
+                                                              int32_t* __restrict__ out_word, float* __restrict__ out_dist, CandBits cb) {
     const int nf = fail_count[0];
     if (nf <= 0) return;
     __shared__ float s_q[DIM];
@@ -840,6 +945,10 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_rowpar_kernel(const float* __res
                 }
             }
         }
+        if (cb.bits) {                                                // the redone query's candidate bits
+            const float thr = (cb.have_index && second != KEY_NONE) ? __uint_as_float((uint32_t)(second >> 32)) : __int_as_float(0x7f800000);
+            cand_bits_row(cb, fail_list[f], thr, lane, 64);
+        }
     }
 }
 
@@ -905,7 +1014,8 @@ hipError_t launch_norm_tombstone(float* norm, const int32_t* rows, int n, hipStr
 
 hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, const uint32_t* norm_max_bits, const int32_t* row_id,
                            const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist,
-                           int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, bool reset_count) {
+                           int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, bool reset_count,
+                           const CandBits* cb) {
     if (p.q == 0) return hipSuccess;
     uint64_t* pk = (uint64_t*)partial;
     uint32_t* pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * MF_KEEP * p.qpad);
@@ -929,9 +1039,10 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
         if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }
     }
     if (dim != 64) return hipErrorInvalidValue;
-    knn_mfma_rerank_kernel<64, MF_KEEP, true, false><<<(p.q + MF_WAVES - 1) / MF_WAVES, MF_BLOCK, 0, s>>>(pk, pl, p.n_blocks, p.q, (const float*)vocab,
+    knn_mfma_rerank_kernel<64, MF_KEEP, true, false><<<p.q, MF_BLOCK, 0, s>>>(pk, pl, p.n_blocks, p.q, (const float*)vocab,
                                                                                    (const float*)queries, row_id, norm_max_bits, out_row,
-                                                                                   out_word, out_dist, fail_list, fail_count);
+                                                                                   out_word, out_dist, fail_list, fail_count,
+                                                                                   cb ? *cb : CandBits{});
     return hipGetLastError();
 }
 
@@ -966,7 +1077,7 @@ hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void*
 hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, const float* row_norm, const uint32_t* norm_max_bits,
                            const int32_t* row_id, const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word,
                            float* out_dist, int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
-                           bool reset_count) {
+                           bool reset_count, const CandBits* cb, bool with_selfdist) {
     if (p.q == 0) return hipSuccess;
     if (dim != 64) return hipErrorInvalidValue;
     uint64_t* pk = (uint64_t*)partial;
@@ -980,28 +1091,36 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_bf16_filter_kernel<4>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES);
         (void)attr;
-        dim3 grid(p.n_blocks, (p.q + BF_QB - 1) / BF_QB);
+        SelfdistJob sd;
+        if (with_selfdist && cb) {                                    // the same-frame distance matrix rides along
+            const int T = (p.q + 31) / 32;
+            sd.queries = (const float*)queries; sd.nq = p.q; sd.out = const_cast<float*>(cb->selfdist); sd.ld = cb->ld; sd.n_tiles = T * (T + 1) / 2;
+        }
+        const int grid = sd.n_tiles + p.n_blocks * ((p.q + BF_QB - 1) / BF_QB);
         if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
         knn_bf16_filter_kernel<4><<<grid, MF_BLOCK, BF_LDS_BYTES, s>>>((const float*)vocab_bf, row_norm, p.n_rows, (const float*)queries, p.q,
-                                                                        p.qpad, p.tiles_per_block, pk, pl);
+                                                                        p.qpad, p.tiles_per_block, p.n_blocks, pk, pl, sd);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }
     }
-    knn_mfma_rerank_kernel<64, BF_KEEP, false, true><<<(p.q + MF_WAVES - 1) / MF_WAVES, MF_BLOCK, 0, s>>>(
+    knn_mfma_rerank_kernel<64, BF_KEEP, false, true><<<p.q, MF_BLOCK, 0, s>>>(
         pk, pl, p.n_blocks, p.q, (const float*)vocab, (const float*)queries, row_id, norm_max_bits, out_row, out_word, out_dist, fail_list,
-        fail_count);
+        fail_count, cb ? *cb : CandBits{});
     return hipGetLastError();
 }
 
 size_t knn_rowpar_partial_bytes(int n_rows, int q) { return (size_t)(q > 0 ? q : 1) * ((n_rows + MF_BLOCK - 1) / MF_BLOCK + 1) * 2 * sizeof(uint64_t); }
 
 hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, int n_rows, const void* queries, const int32_t* fail_list,
-                             int32_t* fail_count, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s) {
+                             int32_t* fail_count, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s,
+                             const CandBits* cb) {
     if (dim != 64 || n_rows <= 0) return hipErrorInvalidValue;
+    static const bool skip = getenv("LCD_EXPERIMENT_SKIP_ROWPAR") != nullptr;   // timing experiment only: results are wrong when a query fails
+    if (skip) return hipSuccess;
     const int nb = (n_rows + MF_BLOCK - 1) / MF_BLOCK;
     knn_rowpar_kernel<64><<<nb, MF_BLOCK, 0, s>>>((const float*)vocab, row_id, n_rows, (const float*)queries, fail_list, fail_count,
-                                                  (uint64_t*)partial, out_row, out_word, out_dist);
+                                                  (uint64_t*)partial, out_row, out_word, out_dist, cb ? *cb : CandBits{});
     return hipGetLastError();
 }
 

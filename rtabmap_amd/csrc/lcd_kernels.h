@@ -28,6 +28,16 @@ hipError_t launch_knn2_partial(int dtype, int dim, const void* vocab, const int3
 hipError_t launch_knn2_merge(int dtype, const KnnPlan& p, const uint64_t* partial, const int32_t* row_id,
                              int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s);
 
+// Optional by-product of the MFMA 2-NN: the candidate bit matrix of the addNewWords resolution (see launch_selfdist) from an
+// already computed same-frame distance matrix.  bits == nullptr: not wanted.
+struct CandBits {
+    const float* selfdist = nullptr;   // [nq x ld], symmetric
+    int ld = 0, nq = 0;
+    uint32_t* bits = nullptr;          // [nq x bw], bw = ld / 32 (even)
+    int bw = 0;
+    int have_index = 0;
+};
+
 // ---- squared-L2 2-NN on the matrix cores (knn_mfma_kernels.hip): MFMA filter + exact re-rank + certificate.
 // Queries whose result cannot be certified are appended to fail_list / fail_count and redone by launch_knn_rowpar.
 struct MfmaPlan { int q, qpad, n_rows, tiles_per_block, n_blocks; };
@@ -41,12 +51,14 @@ hipError_t launch_norm_tombstone(float* norm, const int32_t* rows, int n, hipStr
 // exact redo of the queries in fail_list (fail_count[0] of them; fail_count[1] is scratch) with one lane per vocabulary row
 size_t knn_rowpar_partial_bytes(int n_rows, int q);
 hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, int n_rows, const void* queries, const int32_t* fail_list,
-                             int32_t* fail_count, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s);
+                             int32_t* fail_count, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s,
+                             const CandBits* cb = nullptr);
 hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, const uint32_t* norm_max_bits, const int32_t* row_id,
                            const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist,
                            int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin = nullptr,
                            hipEvent_t ev_end = nullptr,    // optional events bracketing the filter kernel alone
-                           bool reset_count = true);       // false: fail_count[0..1] are already zero
+                           bool reset_count = true,        // false: fail_count[0..1] are already zero
+                           const CandBits* cb = nullptr);  // also emit the candidate bits (cb->selfdist must be complete on `s`)
 // q x q distances of a block against itself; out[i*ld + j], ld >= q.  When `bits` is given ([q][bw] words, bw >= ceil(q/32))
 // also the candidate bit matrix of the addNewWords resolution: bit j of row i = dist(j, i) < (distance of i's second
 // indexed neighbour, +inf if it has none) -- see knn2_kernels.hip.
@@ -82,7 +94,8 @@ hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void*
 hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, const float* row_norm, const uint32_t* norm_max_bits,
                            const int32_t* row_id, const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word,
                            float* out_dist, int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin = nullptr,
-                           hipEvent_t ev_end = nullptr, bool reset_count = true);
+                           hipEvent_t ev_end = nullptr, bool reset_count = true, const CandBits* cb = nullptr,
+                           bool with_selfdist = false);    // true: extra workgroups of the filter launch fill cb->selfdist (queries x queries)
 
 // Row gather used by lcd_vocab_rebuild: dst[i] = src[perm[i]] (rows of row_bytes bytes, multiple of 4), ids likewise.
 hipError_t launch_gather_rows(const void* src, const int32_t* src_id, const int32_t* perm, int n, int row_bytes,
