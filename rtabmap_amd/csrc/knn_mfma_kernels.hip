@@ -733,23 +733,38 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
     __shared__ uint32_t s_a0[MF_WAVES], s_a1[MF_WAVES], s_bound[MF_WAVES];
     __shared__ int s_ncand;
     __shared__ uint64_t s_cand[RR_MAX_CAND], s_exact[RR_MAX_CAND];
+    __shared__ int32_t s_word[RR_MAX_CAND];
     __shared__ float s_err[MF_WAVES];
-    // the query slice of this lane's position in a 16-lane group, |q|^2
+    // Everything that does not depend on other loads is requested up front (the kernel is a chain of round trips): the first two
+    // keys and the first bound of every thread, the query slice, the vocabulary norm bound and -- for the candidate bits -- the
+    // thread's two entries of the query's row of the same-frame distance matrix.
+    const uint64_t kreg0 = tid < n_keys ? keys[tid] : KEY_NONE;
+    const uint64_t kreg1 = tid + MF_BLOCK < n_keys ? keys[tid + MF_BLOCK] : KEY_NONE;
+    const uint32_t breg0 = tid < n_blocks ? partial_lmin[(size_t)qi * n_blocks + tid] : INF;
     const float4 q4 = reinterpret_cast<const float4*>(queries + (size_t)qi * DIM)[lane & 15];
+    const float vn_max = __uint_as_float(norm_max_bits[0]);
+    float dreg0 = __int_as_float(0x7f800000), dreg1 = __int_as_float(0x7f800000);
+    if (cb.bits) {
+        if (tid < cb.nq) dreg0 = cb.selfdist[(size_t)qi * cb.ld + tid];
+        if (tid + MF_BLOCK < cb.nq) dreg1 = cb.selfdist[(size_t)qi * cb.ld + tid + MF_BLOCK];
+    }
     float qn = fmaf(q4.w, q4.w, fmaf(q4.z, q4.z, fmaf(q4.y, q4.y, q4.x * q4.x)));
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) qn += __shfl_xor(qn, m, 64);
 
     // ---- pass 1: tau and the bound on dropped rows
-    uint32_t a0 = INF, a1 = INF, bound = INF;
-    for (int c = tid; c < n_keys; c += MF_BLOCK) {
-        const uint32_t sc = min((uint32_t)(keys[c] >> 32), INF);             // KEY_NONE -> +inf
+    uint32_t a0 = INF, a1 = INF, bound = breg0;
+    auto see = [&](uint64_t k, int c) {
+        const uint32_t sc = min((uint32_t)(k >> 32), INF);                  // KEY_NONE -> +inf
         if (LAST_KEY_BOUNDS && (c % KEEP) == KEEP - 1) bound = min(bound, sc);   // rows the block merge dropped are no better than its last key
         const uint32_t h = max(a0, sc);
         a0 = min(a0, sc);
         a1 = min(a1, h);
-    }
-    for (int c = tid; c < n_blocks; c += MF_BLOCK) bound = min(bound, partial_lmin[(size_t)qi * n_blocks + c]);
+    };
+    see(kreg0, tid);
+    see(kreg1, tid + MF_BLOCK);
+    for (int c = tid + 2 * MF_BLOCK; c < n_keys; c += MF_BLOCK) see(keys[c], c);
+    for (int c = tid + MF_BLOCK; c < n_blocks; c += MF_BLOCK) bound = min(bound, partial_lmin[(size_t)qi * n_blocks + c]);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const uint32_t o0 = (uint32_t)__shfl_xor((int)a0, m, 64), o1 = (uint32_t)__shfl_xor((int)a1, m, 64);
@@ -768,29 +783,33 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
         a0 = min(a0, o0);
         bound = min(bound, s_bound[w]);
     }
-    const float eps = BF16 ? eps_bf16(DIM, qn, __uint_as_float(norm_max_bits[0])) : eps_for(DIM, qn, __uint_as_float(norm_max_bits[0]));
+    const float eps = BF16 ? eps_bf16(DIM, qn, vn_max) : eps_for(DIM, qn, vn_max);
     const float tau = __uint_as_float(a1);
     const float thr = tau + (2.0f * eps + tau * 3.0517578e-5f);               // +inf when fewer than two finite keys exist
 
     // ---- pass 2: the keys at or below the threshold (+inf: tombstone / padding row) ...
-    for (int c = tid; c < n_keys; c += MF_BLOCK) {
-        const uint64_t k = keys[c];
+    auto take = [&](uint64_t k) {
         const uint32_t sc = (uint32_t)(k >> 32);
         if (k != KEY_NONE && sc < INF && __uint_as_float(sc) <= thr) {
             const int slot = atomicAdd(&s_ncand, 1);
             if (slot < RR_MAX_CAND) s_cand[slot] = k;
         }
-    }
+    };
+    take(kreg0);
+    take(kreg1);
+    for (int c = tid + 2 * MF_BLOCK; c < n_keys; c += MF_BLOCK) take(keys[c]);
     __syncthreads();
     const int n_cand = s_ncand;
     const bool overflow = n_cand > RR_MAX_CAND;
-    // ... get their exact distances (reference arithmetic, dist.h:150-177), one candidate per 16-lane group and trip
+    // ... get their exact distances (reference arithmetic, dist.h:150-177), one candidate per 16-lane group and trip; the word
+    // id of the row is fetched in the same round trip
     float err_ratio = 0.0f;
     if (!overflow) {
         for (int i = tid >> 4; i < n_cand; i += MF_BLOCK / 16) {
             const uint64_t k = s_cand[i];
             const uint32_t row = (uint32_t)k;
             const float4 v4 = reinterpret_cast<const float4*>(vocab + (size_t)row * DIM)[lane & 15];
+            const int32_t wid = (lane & 15) == 0 ? row_id[row] : 0;
             const float d0 = __fsub_rn(v4.x, q4.x), d1 = __fsub_rn(v4.y, q4.y), d2 = __fsub_rn(v4.z, q4.z), d3 = __fsub_rn(v4.w, q4.w);
             float t = __fmul_rn(d0, d0);
             t = __fadd_rn(t, __fmul_rn(d1, d1));
@@ -800,7 +819,8 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
 #pragma unroll
             for (int j = 0; j < 16; ++j) res = __fadd_rn(res, __shfl(t, (lane & 48) + j, 64));
             if ((lane & 15) == 0) {
-                s_exact[i] = ((uint64_t)__float_as_uint(res) << 32) | row;
+                s_exact[i] = ((uint64_t)__float_as_uint(res) << 32) | (uint32_t)i;   // the slot stands in for the row: see below
+                s_word[i] = wid;
                 err_ratio = fmaxf(err_ratio, fabsf(__uint_as_float((uint32_t)(k >> 32)) - res) / eps);
             }
         }
@@ -809,15 +829,32 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
     for (int m = 32; m >= 1; m >>= 1) err_ratio = fmaxf(err_ratio, __shfl_xor(err_ratio, m, 64));
     if (lane == 0) s_err[wave] = err_ratio;
     __syncthreads();
+    // the two best (distance, row) keys: ties go to the lower ROW (result_set.h:151-171), so the comparison key carries the row
     uint64_t best = KEY_NONE, second = KEY_NONE;
+    int sbest = -1, ssecond = -1;
     if (wave == 0) {
         if (!overflow)
-            for (int i = lane; i < n_cand; i += 64) top2_push(best, second, s_exact[i]);
+            for (int i = lane; i < n_cand; i += 64) {
+                const uint64_t e = s_exact[i];
+                top2_push(best, second, (e & 0xFFFFFFFF00000000ull) | (uint32_t)s_cand[(uint32_t)e]);
+            }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
             const uint64_t ob = shfl_xor_u64(best, m), os = shfl_xor_u64(second, m);
             top2_push(best, second, ob);
             top2_push(best, second, os);
+        }
+        // which candidate slots won (for their word ids)
+        if (!overflow)
+            for (int i = lane; i < n_cand; i += 64) {
+                const uint64_t key = (s_exact[i] & 0xFFFFFFFF00000000ull) | (uint32_t)s_cand[i];
+                if (key == best) sbest = i;
+                if (key == second) ssecond = i;
+            }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            sbest = max(sbest, __shfl_xor(sbest, m, 64));
+            ssecond = max(ssecond, __shfl_xor(ssecond, m, 64));
         }
     }
     if (tid == 0) {
@@ -825,13 +862,13 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
         err_ratio = fmaxf(fmaxf(s_err[0], s_err[1]), fmaxf(s_err[2], s_err[3]));
         if (err_ratio > 0.0f && eps > 0.0f) atomicMax(reinterpret_cast<uint32_t*>(fail_count) + 2, __float_as_uint(err_ratio));
         const uint64_t k[2] = {best, second};
+        const int sl[2] = {sbest, ssecond};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (k[j] == KEY_NONE) { out_row[2 * qi + j] = -1; out_word[2 * qi + j] = 0; out_dist[2 * qi + j] = -1.0f; }
             else {
-                const uint32_t row = (uint32_t)k[j];
-                out_row[2 * qi + j] = (int32_t)row;
-                out_word[2 * qi + j] = row_id[row];
+                out_row[2 * qi + j] = (int32_t)(uint32_t)k[j];
+                out_word[2 * qi + j] = s_word[sl[j]];
                 out_dist[2 * qi + j] = __uint_as_float((uint32_t)(k[j] >> 32));
             }
         }
@@ -845,7 +882,14 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
     }
     if (cb.bits) {                                                    // the query's row of the candidate bit matrix (uniform branch)
         __syncthreads();
-        cand_bits_row(cb, qi, s_thr, tid, MF_BLOCK);
+        const float thr2 = s_thr;
+        for (int base = wave * 64; base < cb.ld; base += MF_BLOCK) {
+            const int r = base + lane;
+            float d = r == tid ? dreg0 : (r == tid + MF_BLOCK ? dreg1 : __int_as_float(0x7f800000));
+            if (r >= 2 * MF_BLOCK && r < cb.nq) d = cb.selfdist[(size_t)qi * cb.ld + r];
+            const unsigned long long m = __ballot(d < thr2);
+            if (lane == 0) *reinterpret_cast<unsigned long long*>(cb.bits + (size_t)qi * cb.bw + (base >> 5)) = m;
+        }
     }
 }
 
