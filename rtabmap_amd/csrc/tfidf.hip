@@ -167,6 +167,13 @@ __global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(const int32_t* __
                      slot_ni, slot_begin, slot_cnt, q_w, q_cnt, q_idf, q_meta, idf_tab);
 }
 
+#ifdef LCD_TAIL_TIMING   // timing experiment only: 100 MHz stamps between the phases of the frame tail
+__device__ unsigned long long g_tail_timing[8];
+#define FT_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_tail_timing[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FT_STAMP(i) do { } while (0)
+#endif
+
 // The single-workgroup tail of a frame in ONE launch: addNewWords decision loop (resolve_body.cuh) -> pending retirements
 // -> unique words / registration / idf (frame_words_body).  Saves two dependent kernel boundaries per frame.
 __global__ __launch_bounds__(FW_BLOCK) void frame_tail_kernel(ResolveArgs r, int H, int do_register, int32_t sig_id, long long slot,
@@ -179,13 +186,17 @@ __global__ __launch_bounds__(FW_BLOCK) void frame_tail_kernel(ResolveArgs r, int
                                                               float* __restrict__ q_idf, uint32_t* __restrict__ q_meta,
                                                               uint2* __restrict__ idf_tab, RetireArgs retire) {
     extern __shared__ uint32_t ft_dyn_smem[];
+    FT_STAMP(0);
     resolve_body(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
                  r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot);
     if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; }
+    FT_STAMP(1);
     retire_body(retire, slot_begin, slot_cnt, nw, slot_ni, slot_sig);
     __syncthreads();      // out_wslot (global, written by this workgroup) and the LDS region are handed over
+    FT_STAMP(2);
     frame_words_body(ft_dyn_smem, r.out_wslot, r.q, H, do_register, sig_id, slot, slot_local, ni, N, stamp, nw, coo_w, coo_pc, ne_counter,
                      slot_sig, slot_ni, slot_begin, slot_cnt, q_w, q_cnt, q_idf, q_meta, idf_tab);
+    FT_STAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------------- sealed buckets
@@ -856,3 +867,10 @@ hipError_t Tfidf::retire(int32_t sig_id) {
 }
 
 }  // namespace lcd
+
+#ifdef LCD_TAIL_TIMING
+extern "C" int lcd_debug_tail_timing(unsigned long long* out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcd::g_tail_timing), 64);
+}
+#endif
