@@ -42,13 +42,13 @@ __device__ uint32_t block_exclusive_scan(uint32_t* data, int n, uint32_t* scratc
 }
 
 __device__ __forceinline__ unsigned long long to_fixed(float t) {
-    // t >= 0, t < 2^15.  floor(t * 2^48) from the bit pattern (no f32->i64 instruction on the VALU)
-    const uint32_t bits = __float_as_uint(t);
-    const uint32_t mant = (bits & 0x7FFFFFu) | 0x800000u;
-    const int shift = (int)(bits >> 23) - (127 + 23 - TF_FIX_SHIFT);
-    if ((bits >> 23) == 0) return 0ull;                      // zero / subnormal
-    if (shift >= 0) return (unsigned long long)mant << min(shift, 39);
-    return shift > -24 ? (unsigned long long)(mant >> (-shift)) : 0ull;
+    // t >= 0, t < 2^15.  floor(t * 2^48) in two exact halves (there is no f32 -> i64 conversion on the VALU): s = t * 2^16 is
+    // exact, floor(s) < 2^31 is the high word, the fraction s - floor(s) is exact (it needs no more bits than t has) and its
+    // product with 2^32 truncates to the low word.
+    const float s = t * 65536.0f;
+    const float fl = floorf(s);
+    const float rem = s - fl;
+    return ((unsigned long long)(uint32_t)fl << 32) | (uint32_t)(rem * 4294967296.0f);
 }
 
 // ---------------------------------------------------------------------------------------------- frame words
