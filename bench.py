@@ -186,6 +186,7 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     e1.record(stream)
+    host_enqueue = time.perf_counter() - t0          # host time to enqueue the timed steps (diagnostic: launch-bound if ~ wall)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -230,6 +231,7 @@ def main():
         "config": {"workload": "SURF-64 fp32 brute-force 2-NN (49k words) + NNDR + TF-IDF likelihood (%d signatures x 500 words, "
                                "Zipf), 500 desc/frame, 1 frame/step" % n_sig,
                    "frames_per_s": (1 if shard else world) * args.steps / wall, "device_ms_per_step": dev_ms / args.steps,
+                   "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
                    "parallelism": ("vocabulary sharded by word-id range over %d GPUs (all-gather top-2 + int64 all-reduce)" % world) if shard
                    else ("%d independent replicas (one frame stream per GPU, no data-path collective)" % world if world > 1 else "1 GPU")},
         "roofline": roofline,

@@ -5,6 +5,7 @@ is built with hipcc, and if that is impossible the import fails loudly.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -56,6 +57,13 @@ def load():
     if _lib is not None:
         return _lib
     path = os.environ.get("LCD_LIB_PATH") or _build.build()      # LCD_LIB_PATH: timing experiments with variant builds
+    # PyTorch-ROCm ships its own libamdhip64: a process that loads the system runtime first (through this library) and torch
+    # later ends up with two HIP runtimes, and the second one finds no GPU.  When torch is installed, let it load first.
+    if "torch" not in sys.modules and not os.environ.get("LCD_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(path)
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     L.lcd_abi_version.restype = C.c_int

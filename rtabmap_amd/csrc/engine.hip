@@ -65,10 +65,19 @@ int upload_rows(lcd_engine* h, const void* rows, int n, DevBuf& dst) {
     return LCD_OK;
 }
 
+// the exact redo of rejected queries is left to the caller's next launch (the fused frame tail): describe it
+static void fill_redo(lcd_engine* h, RowparArgs* a, const void* vocab, const int32_t* row_id, int n_rows, const void* d_queries, int32_t* o_row,
+                      int32_t* o_word, float* o_dist, const CandBits* cb) {
+    a->enabled = 1; a->vocab = (const float*)vocab; a->row_id = row_id; a->n_rows = n_rows; a->queries = (const float*)d_queries;
+    a->fail_list = h->d_fail_list.as<int32_t>(); a->partial = (unsigned long long*)h->d_partial3.p;
+    a->out_row = o_row; a->out_word = o_word; a->out_dist = o_dist;
+    if (cb) a->cb = *cb;
+}
+
 // 2-NN of q device-resident queries against a row matrix -> o_{row,word,dist}[q*2].  `main_vocab` selects the resident
 // vocabulary (which has row norms and may use the MFMA filter); other matrices (findNN's not-indexed words) use the exact scan.
 int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab, const int32_t* row_id, int64_t n_rows, bool main_vocab,
-                 int32_t* o_row, int32_t* o_word, float* o_dist, const CandBits* cb = nullptr) {
+                 int32_t* o_row, int32_t* o_word, float* o_dist, const CandBits* cb = nullptr, RowparArgs* defer_redo = nullptr) {
     if (q == 0) return LCD_OK;
     const bool mfma = main_vocab && h->knn_mode != 0 && knn_mfma_supported(h->dtype, h->kdim) && n_rows >= 256;
     const KnnPlan p = knn_plan(q, (int)n_rows, h->row_bytes);
@@ -84,8 +93,9 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
         h->fail_count_clean = false;
         if (prof) { h->prof_n += 1; h->prof_kernel = "knn_bf16_filter_kernel"; }
         LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
-        LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(),
-                                     h->d_partial3.p, o_row, o_word, o_dist, h->stream, cb));
+        if (defer_redo) fill_redo(h, defer_redo, vocab, row_id, (int)n_rows, d_queries, o_row, o_word, o_dist, cb);
+        else LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(),
+                                          h->d_fail_count.as<int32_t>(), h->d_partial3.p, o_row, o_word, o_dist, h->stream, cb));
     } else if (mfma) {
         const MfmaPlan mp = knn_mfma_plan(q, (int)n_rows);
         LCD_HIP(h, dreserve(h, h->d_partial2, knn_mfma_partial_bytes(mp)));
@@ -100,8 +110,9 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
         if (prof) { h->prof_n += 1; h->prof_kernel = "knn_mfma_filter_kernel"; }
         // the queries the certificate rejected are redone exactly by the row-parallel kernel (usually none: it leaves at once)
         LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
-        LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(),
-                                     h->d_partial3.p, o_row, o_word, o_dist, h->stream, cb));
+        if (defer_redo) fill_redo(h, defer_redo, vocab, row_id, (int)n_rows, d_queries, o_row, o_word, o_dist, cb);
+        else LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(),
+                                          h->d_fail_count.as<int32_t>(), h->d_partial3.p, o_row, o_word, o_dist, h->stream, cb));
     } else {
         LCD_HIP(h, dreserve(h, h->d_partial, knn_partial_bytes(p)));
         const bool prof = main_vocab && h->prof_cap > 0 && h->prof_n < h->prof_cap;
@@ -413,7 +424,8 @@ int lcd_selfdist(lcd_engine* h, const void* queries, int q, float* out_qxq) {
 // device part of addNewWords up to (not including) the decision loop: 2-NN, same-frame distances + candidate bits.
 // Fills the decision loop's arguments.
 static int prepare_resolve(lcd_engine* h, const void* d_desc, int q, int flags, float nndr, int32_t* d_out_word, int32_t* d_out_wslot,
-                           ResolveArgs* r) {
+                           ResolveArgs* r, bool defer_redo = false /* the caller's next launch is the fused frame tail */) {
+    r->rp = RowparArgs{};
     const int have_index = h->n_live >= 2 ? 1 : 0;                  // VWDictionary.cpp:1015
     const bool incremental = (flags & LCD_Q_INCREMENTAL) != 0;
     const bool together = incremental && (flags & LCD_Q_NEW_WORDS_COMPARED);
@@ -436,7 +448,7 @@ static int prepare_resolve(lcd_engine* h, const void* d_desc, int q, int flags, 
         LCD_HIP(h, dreserve(h, h->d_knn_word, (size_t)q * 2 * 4));
         LCD_HIP(h, dreserve(h, h->d_knn_dist, (size_t)q * 2 * 4));
         rc = run_knn2_raw(h, d_desc, q, h->vocab.p, h->row_id.as<int32_t>(), knn_rows, true, h->d_knn_row.as<int32_t>(),
-                          h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), &cb);
+                          h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), &cb, defer_redo ? &r->rp : nullptr);
         if (rc) return rc;
     } else {
         rc = run_knn2(h, d_desc, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), knn_rows, h->d_knn_row, h->d_knn_word,
@@ -665,7 +677,7 @@ int lcd_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, fl
     LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
     // 2-NN + same-frame distances, then ONE single-workgroup launch: decision loop -> pending retirements -> registration / idf
     ResolveArgs r;
-    int rc = prepare_resolve(h, d_descriptors, q, flags, nndr_ratio, d_word_ids, h->d_out_wslot.as<int32_t>(), &r);
+    int rc = prepare_resolve(h, d_descriptors, q, flags, nndr_ratio, d_word_ids, h->d_out_wslot.as<int32_t>(), &r, true);
     if (rc) return rc;
     if (h->d_fail_count.p) { r.fail_count = h->d_fail_count.as<int32_t>(); h->fail_count_clean = true; }
     if (sig_id != 0) LCD_HIP(h, t.register_dev(sig_id, h->d_out_wslot.as<int32_t>(), q, q, N, &r));

@@ -24,6 +24,7 @@
 // floats [32h, 32h+32) of its row, i.e. k-step t multiplies element 32h + t -- A and B use the same k permutation, which
 // a dot product does not see.  D layout: lane holds query (l&31), 16 rows (reg&3) + 8*(reg>>2) + 4*(l>>5).
 #include "lcd_kernels.h"
+#include "rowpar_body.cuh"
 
 #include <cstdlib>
 
@@ -34,24 +35,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MF_BLOCK = 256;
 constexpr int MF_WAVES = 4;
 constexpr int MF_KEEP = 4;     // keys kept per (row block, query)
-
-__device__ __forceinline__ void top2_push(uint64_t& best, uint64_t& second, uint64_t k) {
-    const uint64_t hi = best > k ? best : k;
-    best = best < k ? best : k;
-    second = second < hi ? second : hi;
-}
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = __shfl_xor(lo, m, 64);
-    hi = __shfl_xor(hi, m, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = __shfl(lo, src, 64);
-    hi = __shfl(hi, src, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
 
 // Augmentation table of the vocabulary: aug[2r] = |row r|^2 (any summation order: the filter only needs it to ~dim ulps;
 // +inf for tombstones), aug[2r + 1] = 1, plus a sentinel entry {+inf, 1} at r = n_rows for the padding rows of the last
@@ -692,18 +675,6 @@ __device__ __forceinline__ float eps_for(int dim, float qn, float vn_max) {
     return (3.5f * (float)dim + 16.0f) * 5.9604645e-8f * 1.25f * (qn + vn_max);
 }
 
-// Row `qi` of the candidate bit matrix of the addNewWords resolution (knn2_kernels.hip: bit r = dist(r, qi) < distance of qi's
-// second indexed neighbour) from the already computed same-frame distance matrix, which is symmetric bit for bit.  Called by
-// whole waves (n_threads a multiple of 64); writes all bw words of the row.
-__device__ __forceinline__ void cand_bits_row(const CandBits& cb, int qi, float thr, int tid, int n_threads) {
-    for (int base = (tid >> 6) * 64; base < cb.ld; base += n_threads) {
-        const int r = base + (tid & 63);
-        const float d = r < cb.nq ? cb.selfdist[(size_t)qi * cb.ld + r] : __int_as_float(0x7f800000);
-        const unsigned long long m = __ballot(d < thr);
-        if ((tid & 63) == 0) *reinterpret_cast<unsigned long long*>(cb.bits + (size_t)qi * cb.bw + (base >> 5)) = m;
-    }
-}
-
 // One workgroup per query (the kernel is a chain of dependent memory round trips: the more lanes share them, the shorter).
 // Pass 1 finds tau = the second smallest filter score among the kept keys; a kept row whose score exceeds
 // tau (1 + 2^-15) + 2 eps is strictly farther than the two rows that define tau (|score - distance| <= eps, keys are truncated by
@@ -894,106 +865,9 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
 }
 
 // ------------------------------------------------------------------------------------------------ row-parallel exact scan
-// The queries the certificate rejects (usually none, sometimes a handful) are redone exactly with the WHOLE chip on
-// each of them: one lane per vocabulary row (the row stays in VGPRs), the listed queries are looped over (query
-// broadcast from LDS), every workgroup reduces to its two best keys per query and the LAST workgroup to arrive
-// (agent-scope release / acquire around a counter, cdna_hip_programming.md guideline 16) merges them and writes the
-// result into the query's own slot -- one launch, which leaves at once when the list is empty.
-template <int DIM>
-__global__ __launch_bounds__(MF_BLOCK) void knn_rowpar_kernel(const float* __restrict__ vocab, const int32_t* __restrict__ row_id, int n_rows,
-                                                              const float* __restrict__ queries, const int32_t* __restrict__ fail_list,
-                                                              int32_t* __restrict__ fail_count /* [0] count, [1] arrivals */,
-                                                              uint64_t* __restrict__ partial, int32_t* __restrict__ out_row,
-                                                              int32_t* __restrict__ out_word, float* __restrict__ out_dist, CandBits cb) {
-    const int nf = fail_count[0];
-    if (nf <= 0) return;
-    __shared__ float s_q[DIM];
-    __shared__ uint64_t s_k[MF_WAVES][2];
-    __shared__ int s_last;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * MF_BLOCK + threadIdx.x;
-    const bool live = row < n_rows && row_id[row] != 0;
-    float v[DIM];
-    {
-        const float4* src = reinterpret_cast<const float4*>(vocab + (size_t)min(row, n_rows - 1) * DIM);
-#pragma unroll
-        for (int g = 0; g < DIM / 4; ++g) { const float4 x = src[g]; v[4 * g] = x.x; v[4 * g + 1] = x.y; v[4 * g + 2] = x.z; v[4 * g + 3] = x.w; }
-    }
-    for (int f = 0; f < nf; ++f) {
-        __syncthreads();
-        if (threadIdx.x < DIM) s_q[threadIdx.x] = queries[(size_t)fail_list[f] * DIM + threadIdx.x];
-        __syncthreads();
-        float res = 0.0f;                              // rtflann::L2 (dist.h:150-177), a = row, b = query
-#pragma unroll
-        for (int g = 0; g + 3 < DIM; g += 4) {
-            const float d0 = __fsub_rn(v[g + 0], s_q[g + 0]);
-            const float d1 = __fsub_rn(v[g + 1], s_q[g + 1]);
-            const float d2 = __fsub_rn(v[g + 2], s_q[g + 2]);
-            const float d3 = __fsub_rn(v[g + 3], s_q[g + 3]);
-            float t = __fmul_rn(d0, d0);
-            t = __fadd_rn(t, __fmul_rn(d1, d1));
-            t = __fadd_rn(t, __fmul_rn(d2, d2));
-            t = __fadd_rn(t, __fmul_rn(d3, d3));
-            res = __fadd_rn(res, t);
-        }
-        uint64_t best = live ? (((uint64_t)__float_as_uint(res) << 32) | (uint32_t)row) : KEY_NONE, second = KEY_NONE;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const uint64_t ob = shfl_xor_u64(best, m), os = shfl_xor_u64(second, m);
-            top2_push(best, second, ob);
-            top2_push(best, second, os);
-        }
-        if (lane == 0) { s_k[wave][0] = best; s_k[wave][1] = second; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int w = 1; w < MF_WAVES; ++w) { top2_push(best, second, s_k[w][0]); top2_push(best, second, s_k[w][1]); }
-            partial[((size_t)f * gridDim.x + blockIdx.x) * 2 + 0] = best;
-            partial[((size_t)f * gridDim.x + blockIdx.x) * 2 + 1] = second;
-        }
-    }
-    // publish this workgroup's keys, find out whether it is the last one
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int ticket = __hip_atomic_fetch_add(&fail_count[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = ticket == (int)gridDim.x - 1;
-        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // last workgroup: one wave per listed query merges the gridDim.x * 2 keys
-    const int n_keys = (int)gridDim.x * 2;
-    for (int f = wave; f < nf; f += MF_WAVES) {
-        uint64_t best = KEY_NONE, second = KEY_NONE;
-        for (int c = lane; c < n_keys; c += 64) top2_push(best, second, partial[(size_t)f * n_keys + c]);
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const uint64_t ob = shfl_xor_u64(best, m), os = shfl_xor_u64(second, m);
-            top2_push(best, second, ob);
-            top2_push(best, second, os);
-        }
-        if (lane == 0) {
-            const int qo = fail_list[f];
-            const uint64_t k[2] = {best, second};
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (k[j] == KEY_NONE) { out_row[2 * qo + j] = -1; out_word[2 * qo + j] = 0; out_dist[2 * qo + j] = -1.0f; }
-                else {
-                    const uint32_t r = (uint32_t)k[j];
-                    out_row[2 * qo + j] = (int32_t)r;
-                    out_word[2 * qo + j] = row_id[r];
-                    out_dist[2 * qo + j] = __uint_as_float((uint32_t)(k[j] >> 32));
-                }
-            }
-        }
-        if (cb.bits) {                                                // the redone query's candidate bits
-            const float thr = (cb.have_index && second != KEY_NONE) ? __uint_as_float((uint32_t)(second >> 32)) : __int_as_float(0x7f800000);
-            cand_bits_row(cb, fail_list[f], thr, lane, 64);
-        }
-    }
+// rowpar_body.cuh; stand-alone launch for the paths without a fused frame tail
+__global__ __launch_bounds__(MF_BLOCK) void knn_rowpar_kernel(RowparArgs a, int32_t* __restrict__ fail_count) {
+    rowpar_body<64, MF_BLOCK>(a, (int)blockIdx.x, (int)gridDim.x, fail_count);
 }
 
 }  // namespace
@@ -1160,11 +1034,12 @@ hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, 
                              int32_t* fail_count, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s,
                              const CandBits* cb) {
     if (dim != 64 || n_rows <= 0) return hipErrorInvalidValue;
-    static const bool skip = getenv("LCD_EXPERIMENT_SKIP_ROWPAR") != nullptr;   // timing experiment only: results are wrong when a query fails
-    if (skip) return hipSuccess;
+    RowparArgs a;
+    a.enabled = 1; a.vocab = (const float*)vocab; a.row_id = row_id; a.n_rows = n_rows; a.queries = (const float*)queries;
+    a.fail_list = fail_list; a.partial = (unsigned long long*)partial; a.out_row = out_row; a.out_word = out_word; a.out_dist = out_dist;
+    if (cb) a.cb = *cb;
     const int nb = (n_rows + MF_BLOCK - 1) / MF_BLOCK;
-    knn_rowpar_kernel<64><<<nb, MF_BLOCK, 0, s>>>((const float*)vocab, row_id, n_rows, (const float*)queries, fail_list, fail_count,
-                                                  (uint64_t*)partial, out_row, out_word, out_dist, cb ? *cb : CandBits{});
+    knn_rowpar_kernel<<<nb, MF_BLOCK, 0, s>>>(a, fail_count);
     return hipGetLastError();
 }
 

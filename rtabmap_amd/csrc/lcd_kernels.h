@@ -38,6 +38,16 @@ struct CandBits {
     int have_index = 0;
 };
 
+// Arguments of the exact redo of rejected queries (rowpar_body.cuh).  enabled == 0: no redo wanted.
+struct RowparArgs {
+    int enabled = 0;
+    const float* vocab = nullptr; const int32_t* row_id = nullptr; int n_rows = 0;
+    const float* queries = nullptr; const int32_t* fail_list = nullptr;
+    unsigned long long* partial = nullptr;             // knn_rowpar_partial_bytes()
+    int32_t* out_row = nullptr; int32_t* out_word = nullptr; float* out_dist = nullptr;
+    CandBits cb;
+};
+
 // ---- squared-L2 2-NN on the matrix cores (knn_mfma_kernels.hip): MFMA filter + exact re-rank + certificate.
 // Queries whose result cannot be certified are appended to fail_list / fail_count and redone by launch_knn_rowpar.
 struct MfmaPlan { int q, qpad, n_rows, tiles_per_block, n_blocks; };

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "devbuf.h"
+#include "lcd_kernels.h"
 
 namespace lcd {
 
@@ -63,6 +64,7 @@ struct ResolveArgs {
     const int32_t* knn_word; const float* knn_dist; const float* selfdist; int ld; const uint32_t* cand_bits; int bw;
     int32_t* out_word; int32_t* out_n_new; const int32_t* knn_row; const int32_t* row_wslot; int32_t* out_wslot;
     int32_t* fail_count;   // reset for the next frame's certificate (saves a memset launch); may be NULL
+    RowparArgs rp;         // rp.enabled: the exact redo of rejected queries runs as extra workgroups of the tail launch
 };
 
 struct Tfidf {

@@ -8,6 +8,7 @@
 // truncation error < 2^-48 per term), so results agree to ~1e-6 relative (bound 1e-4, tests/test_gpu_likelihood.py).
 #include "tfidf.h"
 #include "resolve_body.cuh"
+#include "rowpar_body.cuh"
 
 #include <algorithm>
 #include <cmath>
@@ -186,10 +187,20 @@ __global__ __launch_bounds__(FW_BLOCK) void frame_tail_kernel(ResolveArgs r, int
                                                               float* __restrict__ q_idf, uint32_t* __restrict__ q_meta,
                                                               uint2* __restrict__ idf_tab, RetireArgs retire) {
     extern __shared__ uint32_t ft_dyn_smem[];
+    // workgroups 1.. : the exact redo of the queries the 2-NN certificate rejected (they leave at once when there are none, which
+    // is the usual case: no launch of its own for that check).  Workgroup 0 waits for them only when something was rejected.
+    if (blockIdx.x > 0) { rowpar_body<64, FW_BLOCK>(r.rp, (int)blockIdx.x - 1, (int)gridDim.x - 1, r.fail_count); return; }
+    if (r.rp.enabled && gridDim.x > 1) {
+        if (threadIdx.x == 0 && r.fail_count[0] > 0) {
+            while (__hip_atomic_load(&r.fail_count[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
     FT_STAMP(0);
     resolve_body(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
                  r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot);
-    if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; }
+    if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; r.fail_count[3] = 0; }
     FT_STAMP(1);
     retire_body(retire, slot_begin, slot_cnt, nw, slot_ni, slot_sig);
     __syncthreads();      // out_wslot (global, written by this workgroup) and the LDS region are handed over
@@ -706,7 +717,8 @@ static hipError_t run_frame_words(Tfidf& t, const int32_t* d_wslots, int n, bool
     if (resolve) {
         const int mw = (resolve->q + 63) / 64 * 2;
         shmem = std::max(shmem, (size_t)(3 * mw + 2) * 4);
-        frame_tail_kernel<<<1, FW_BLOCK, shmem, t.stream>>>(*resolve, H, reg ? 1 : 0, sig_id, (long long)slot, (uint32_t)(slot % TF_R),
+        const int n_redo = (resolve->rp.enabled && resolve->fail_count) ? (resolve->rp.n_rows + FW_BLOCK - 1) / FW_BLOCK : 0;
+        frame_tail_kernel<<<1 + n_redo, FW_BLOCK, shmem, t.stream>>>(*resolve, H, reg ? 1 : 0, sig_id, (long long)slot, (uint32_t)(slot % TF_R),
                                                            (uint32_t)ni, N, t.stamp, t.nw.as<uint32_t>(), coo_w, coo_pc, ne,
                                                            t.slot_sig.as<int32_t>(), t.slot_ni.as<uint32_t>(), t.slot_begin.as<uint32_t>(),
                                                            t.slot_cnt.as<uint32_t>(), t.q_w.as<uint32_t>(), t.q_cnt.as<uint32_t>(),

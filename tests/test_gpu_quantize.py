@@ -2,6 +2,7 @@
 restated VWDictionary on identical descriptor streams.  Word assignments must be identical (ORB and SURF)."""
 import numpy as np
 import pytest
+import torch  # before liblcd_hip.so is loaded: one HIP runtime per process (rtabmap_amd/capi.py)
 
 from rtabmap_amd import synth
 
@@ -136,4 +137,43 @@ def test_quantize_large_frame_more_than_1024_descriptors(oracle):
     exp = m.add_new_words(q, 1)
     assert np.where(got < 0, 3000 - got, got).tolist() == exp
     assert n_new == len({e for e in exp if e > 3000}) > 100
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", ["bf16", "mfma32"])
+def test_frame_dev_redoes_uncertifiable_queries_inside_the_tail_launch(oracle, monkeypatch, mode):
+    """lcd_frame_dev has no launch of its own for the exact redo of queries the filter certificate rejects: extra workgroups
+    of the frame-tail launch do it and the decision workgroup waits for them.  A vocabulary with a run of identical rows makes
+    some queries of every frame uncertifiable; the word assignment must still be the reference's, frame after frame (the
+    counters the tail resets must be clean for the next frame), and identical to lcd_quantize's (stand-alone redo kernel)."""
+    import rtabmap_amd
+    monkeypatch.setenv("LCD_KNN_MODE", mode)
+    n = 6000
+    v = synth.vocab_surf(n, seed=21)
+    v[3000:3040] = v[77]                                      # 41 identical rows: more equal candidates than a row block keeps
+    ids = np.arange(1, n + 1, dtype=np.int32)
+    eng = rtabmap_amd.Engine("f32", 64, sig_capacity=64)
+    eng.vocab_append(v, ids)
+    d_words = torch.zeros(400, dtype=torch.int32, device="cuda")
+    for t in range(3):
+        m = oracle.OracleVWDictionary(strategy=oracle.kNNBruteForce, nndr=0.8)     # a fresh reference dictionary per frame
+        for i, r in zip(ids, v):
+            m.add_word(int(i), r)
+        m.update()
+        q = synth.queries_surf(v, 400, seed=300 + t, frac_known=0.7, sigma=0.03)
+        q[5] = v[77]
+        q[6] = v[77] + np.float32(1e-4)
+        q[200:230] = v[77] + (np.arange(30, dtype=np.float32)[:, None] * np.float32(2e-5))
+        q[390] = q[5]                                         # same-frame duplicate of an uncertifiable query
+        assert eng.knn2(q)[0].shape == (400, 2) and eng.stats()["knn_last_fallback_queries"] >= 1   # the premise of the test
+        d = torch.from_numpy(q).cuda()
+        eng.frame_dev(d.data_ptr(), 400, 0, 10.0, d_words.data_ptr(), 0, 0, incremental=True, new_words_compared=True,
+                      nndr=0.8)                               # sig_id 0, no likelihood: the dictionary and the index stay as they are
+        torch.cuda.synchronize()
+        got = d_words.cpu().numpy()
+        exp = m.add_new_words(q, 1000 + t)
+        assert np.where(got < 0, n - got, got).tolist() == exp, "frame %d" % t
+        got_q, _ = eng.quantize(q, incremental=True, new_words_compared=True, nndr=0.8)
+        assert got_q.tolist() == got.tolist()
+        assert eng.stats()["knn_last_fallback_queries"] >= 1
     eng.close()
