@@ -8,7 +8,9 @@ One STEP = one query frame through the hot path, inputs already resident in HBM:
     against every signature (Memory::computeLikelihood).
     candidates/sec = frames/sec x N_signatures.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the L2 2-NN scan); `cpu_baseline` times the
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the step -- the longer of the 2-NN filter and the fused
+TF-IDF scoring kernel, both bracketed by HIP events inside the timed region (the other one is reported next to it as
+`roofline_other`); `cpu_baseline` times the
 reference-style CPU path (the reference's own rtflann kd-tree when oracle/_ref is present + the restated std::map
 computeLikelihood) on a bounded sample on this box's host cores.
 """
@@ -25,8 +27,10 @@ sys.path.insert(0, ROOT)
 
 N_WORDS, N_SIG, Q, DIM = 49000, 100000, 500, 64
 NNDR = 0.8
-# MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md): fp32 matrix/vector 157.3 TFLOP/s, HBM3E 8 TB/s
+# MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md): fp32 matrix/vector 157.3 TFLOP/s, bf16 MFMA 2.5 PFLOP/s dense, HBM3E 8 TB/s
 PEAK_F32_TFLOPS = 157.3
+PEAK_BF16_TFLOPS = 2500.0
+PEAK_HBM_GBPS = 8000.0
 
 
 def log(*a):
@@ -193,6 +197,7 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)
+    sc_ms, sc_n, sc_name = eng.profile_read_likelihood()
     kern_ms, kern_n, kern_name = eng.profile_read()
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -203,24 +208,53 @@ def main():
     like = (last_like[0] if shard else d_like[: n_sig + args.steps + args.warmup]).cpu().numpy()
     last = (args.warmup + args.steps - 1) % n_frames
 
-    # ---- roofline of the dominant kernel (the 2-NN distance scan), from the events recorded inside the timed region.
-    # ALGORITHMIC work per launch: 2*Q*N*D = 3.136 GFLOP GEMM-equivalent over this rank's vocabulary rows.
+    # ---- rooflines, from the events recorded inside the timed region (first 20 % of the steps).
+    # (1) 2-NN filter.  ALGORITHMIC work per launch: 2*Q*N*D = 3.136 GFLOP GEMM-equivalent over this rank's rows.
+    #     The bf16x3 filter executes three bf16 products per algorithmic product (+ the f32 augmentation step): `executed` counts
+    #     those, `achieved` only the algorithmic ones, both against the dense MFMA peak of the type the kernel multiplies in.
     n_rows_rank = (sh.hi - sh.lo) if shard else N_WORDS
     flops = 2.0 * Q * n_rows_rank * DIM
     achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-    # HBM traffic per launch of that kernel: from the committed rocprofv3 --pmc summary (FETCH_SIZE / WRITE_SIZE cannot be read
-    # from inside the process); null when the profile is not there or was taken for another vocabulary split
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-        if not shard and kern_name in pmc:
-            traffic = pmc[kern_name]["hbm_bytes_per_launch"] / 1e9
-    except Exception:
-        traffic = None
-    roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS,
-                "traffic": traffic, "traffic_unit": "GB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)", "kernel": kern_name, "ms": kern_ms,
-                "samples": kern_n,
+    bf16 = "bf16" in kern_name
+    peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+
+    def pmc_traffic(name):
+        # HBM traffic per launch: from the committed rocprofv3 --pmc summary (FETCH_SIZE / WRITE_SIZE cannot be read from inside
+        # the process); null when the profile is not there or was taken for another vocabulary split
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+            return pmc[name]["hbm_bytes_per_launch"] / 1e9 if (not shard and name in pmc) else None
+        except Exception:
+            return None
+
+    roof_knn = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": pmc_traffic(kern_name), "traffic_unit": "GB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)", "kernel": kern_name,
+                "ms": kern_ms, "samples": kern_n, "mfma_dtype": "bf16 (3 products per fp32 product, fp32 accumulate)" if bf16 else "f32",
+                "executed_tflops": (3.0 if bf16 else 1.0) * achieved,
+                "frac_of_f32_mfma_peak": achieved / PEAK_F32_TFLOPS,
                 "algorithmic_gbps": (n_rows_rank * DIM * 4 + Q * DIM * 4 + Q * 16) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0}
+    # (2) fused TF-IDF scoring kernel (single-GPU path).  ALGORITHMIC bytes per launch: 4 B per posting of the frame's words (this
+    #     engine packs a posting in 4 B; SURVEY.md 8d budgets 8) + ni read + likelihood write (4 B per signature each).
+    roof_score = None
+    if not shard and sc_ms > 0:
+        t0h = time.time()
+        srt = np.sort(words, axis=1)
+        first = np.ones_like(srt, dtype=bool)
+        first[:, 1:] = srt[:, 1:] != srt[:, :-1]
+        npost = np.bincount(srt[first], minlength=N_WORDS + 1)              # signatures that contain each word (initial memory)
+        fw = np.unique(d_words.cpu().numpy())
+        fw = fw[(fw > 0) & (fw <= N_WORDS)]
+        p_frame = int(npost[fw].sum())
+        sc_bytes = 4.0 * p_frame + 8.0 * n_sig
+        gbps = sc_bytes / (sc_ms * 1e-3) / 1e9
+        roof_score = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                      "traffic": pmc_traffic(sc_name), "traffic_unit": "GB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)", "kernel": sc_name,
+                      "ms": sc_ms, "samples": sc_n, "postings_per_launch": p_frame, "algorithmic_bytes_per_launch": sc_bytes}
+        log("[bench] postings of the last frame's words: %d (%.1fs)" % (p_frame, time.time() - t0h))
+    if roof_score is not None and roof_score["ms"] > roof_knn["ms"]:
+        roofline, roofline_other = roof_score, roof_knn
+    else:
+        roofline, roofline_other = roof_knn, roof_score
 
     out = {
         "metric": "loop-closure candidates/sec (49k vocab, 100k signatures, 500 desc/frame)",
@@ -235,6 +269,7 @@ def main():
                    "parallelism": ("vocabulary sharded by word-id range over %d GPUs (all-gather top-2 + int64 all-reduce)" % world) if shard
                    else ("%d independent replicas (one frame stream per GPU, no data-path collective)" % world if world > 1 else "1 GPU")},
         "roofline": roofline,
+        "roofline_other": roofline_other,
     }
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(vocab, words, frames, sample_sigs=min(10000, n_sig), n_frames=3)

@@ -184,6 +184,8 @@ void* lcd_stream(lcd_engine* h);
  * synchronises, returns the average duration in milliseconds and the number of samples, and disables profiling. */
 int lcd_profile_begin(lcd_engine* h, int max_samples);
 int lcd_profile_read(lcd_engine* h, float* avg_ms, int* n_samples, const char** kernel_name);
+/* the same for the fused likelihood kernel of lcd_frame_dev (both series are recorded while profiling is enabled) */
+int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, const char** kernel_name);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * statistics (names follow Statistics.h:178,202,209-212 where one exists) */

@@ -22,7 +22,7 @@ SYMBOLS = [
     "lcd_vocab_clear", "lcd_vocab_append", "lcd_vocab_remove", "lcd_vocab_rebuild", "lcd_vocab_count", "lcd_vocab_read",
     "lcd_knn2", "lcd_selfdist", "lcd_quantize", "lcd_find_nn",
     "lcd_sig_add", "lcd_sig_remove", "lcd_sig_add_bulk", "lcd_sig_count", "lcd_word_nrefs",
-    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read",
+    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood",
 ]
 
 
@@ -100,6 +100,7 @@ def load():
     L.lcd_stream.restype = vp
     L.lcd_profile_begin.argtypes = [vp, C.c_int]
     L.lcd_profile_read.argtypes = [vp, C.POINTER(f32), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
+    L.lcd_profile_read_likelihood.argtypes = [vp, C.POINTER(f32), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
     L.lcd_get_stats.argtypes = [vp, C.POINTER(LcdStats)]
     _lib = L
     return L
@@ -284,6 +285,11 @@ class Engine:
     def profile_read(self):
         ms, n, name = C.c_float(), C.c_int(), C.c_char_p()
         self._ck(self.L.lcd_profile_read(self.h, C.byref(ms), C.byref(n), C.byref(name)))
+        return ms.value, n.value, (name.value or b"").decode()
+
+    def profile_read_likelihood(self):
+        ms, n, name = C.c_float(), C.c_int(), C.c_char_p()
+        self._ck(self.L.lcd_profile_read_likelihood(self.h, C.byref(ms), C.byref(n), C.byref(name)))
         return ms.value, n.value, (name.value or b"").decode()
 
     def stats(self):

@@ -51,8 +51,8 @@ struct lcd_engine {
     lcd::Tfidf tfidf;
 
     // ---- event bracketing of the dominant kernel (lcd_profile_*)
-    std::vector<hipEvent_t> prof_ev;
-    int prof_n = 0, prof_cap = 0;
+    std::vector<hipEvent_t> prof_ev, prof2_ev;          // 2-NN scan kernel / fused likelihood kernel
+    int prof_n = 0, prof_cap = 0, prof2_n = 0;
     const char* prof_kernel = "";
 
     // ---- statistics

@@ -110,6 +110,7 @@ struct Tfidf {
     hipError_t flush_retire();
     std::vector<int64_t> pending_retire;   // slots whose device-side retirement rides along with the next frame-words launch
     // score q_* against every live signature: dense float likelihood over slots [0, n_slots)
+    hipEvent_t prof_b = nullptr, prof_e = nullptr;   // one-shot: bracket the next fused scoring launch (lcd_profile_*)
     hipError_t score(float* d_likelihood);
     // the two halves of score(): integer partial sums into a ZEROED caller buffer, and fixed point -> float (re-zeroes the source)
     hipError_t score_partial(unsigned long long* lfix_target);

@@ -805,9 +805,13 @@ hipError_t Tfidf::score(float* d_likelihood) {
             n_list_all, wcap_all, q_w.as<uint32_t>(), q_idf.as<float>(), q_meta.as<uint32_t>(), slot_ni.as<uint32_t>(), lfix.as<unsigned long long>(), \
             d_likelihood, ob ? ob->coo_w.as<uint32_t>() : nullptr, ob ? ob->coo_pc.as<uint32_t>() : nullptr, bkt_ne.as<uint32_t>() + bi, \
             (long long)bi * TF_R, n_open_slots, bitmap_words, stamp, idf_tab.as<uint2>(), open_done.as<int>())
+        if (prof_b) TF_TRY(hipEventRecord(prof_b, stream));
         if (scb == 256) LCD_SCORE_FUSED(256); else if (scb == 512) LCD_SCORE_FUSED(512); else LCD_SCORE_FUSED(1024);
 #undef LCD_SCORE_FUSED
-        return hipGetLastError();
+        TF_TRY(hipGetLastError());
+        if (prof_e) TF_TRY(hipEventRecord(prof_e, stream));
+        prof_b = prof_e = nullptr;
+        return hipSuccess;
     }
     TF_TRY(score_partial(lfix.as<unsigned long long>()));
     finalize_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, stream>>>(lfix.as<long long>(), (long long)n_slots, d_likelihood);
