@@ -3,26 +3,27 @@
 // The reference's arithmetic, sum_k (v_k - q_k)^2 in rtflann's order (dist.h:150-177), costs 3 VALU ops per element and
 // cannot use FMA.  Here the scan is split in two:
 //
-//   1. FILTER (this file, MFMA): s(i, j) = |v_i|^2 + |q_j|^2 - 2 v_i . q_j for every (vocabulary row i, query j) with
-//      v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate: an exact fp32 FMA chain at the matrix-core rate (157 TFLOP/s,
-//      MI355X_MICROARCH.md).  |v|^2 and |q|^2 ride along as one extra k-step (A = (|v_i|^2, 1), B = (1, |q_j|^2)) and
-//      the queries are pre-scaled by -2, so the accumulator IS the approximate squared distance.  Every lane keeps a
-//      running top-3 of packed (distance << 32 | row) keys for the queries it sees -- no cross-lane traffic in the loop.
-//   2. RE-RANK (knn_mfma_rerank_kernel): per query 128 filter candidates (the two best of every lane's share of the
-//      per-workgroup lists) are re-evaluated with the reference's
-//      own arithmetic (bit-exact distances, lower row wins ties) and the two best are returned.  The result is PROVEN
-//      equal to the exact scan when every row the filter dropped is certainly farther than the exact second neighbour:
+//   1. FILTER (MFMA): s(i, j) = |v_i|^2 + |q_j|^2 - 2 v_i . q_j for every (vocabulary row i, query j).  |v|^2 and |q|^2 ride
+//      along as one extra f32 k-step (A = (|v_i|^2, 1), B = (1, |q_j|^2)) and the queries are pre-scaled by -2, so the
+//      accumulator IS the approximate squared distance.  Every lane keeps a running top-3 of 32-bit keys (score bits | in-strip
+//      row index) for the queries it sees -- no cross-lane traffic in the loop.  Two variants:
+//        knn_bf16_filter_kernel  (default)  three bf16 MFMA chains per product on a hi/lo split of the operands
+//                                           (v_mfma_f32_32x32x16_bf16, 16x the f32 rate), one vocabulary tile shared by the
+//                                           four waves of a workgroup; the same launch also computes the same-frame distance matrix
+//        knn_mfma_filter_kernel             v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate: an exact fp32 FMA chain
+//   2. RE-RANK (knn_mfma_rerank_kernel): per query the few kept keys that can still be a neighbour (filter score within
+//      2 eps of the second best) are re-evaluated with the reference's own arithmetic (bit-exact distances, lower row wins
+//      ties) and the two best are returned.  The result is PROVEN equal to the exact scan when every row the filter dropped
+//      is certainly farther than the exact second neighbour:
 //            bound - eps > d2_exact,
 //      bound = the smallest filter score any dropped row can have (tracked through every merge level), eps = a bound on
-//      |filter score - reference distance| (fp32 summation error of both orders, see eps_for()).  Queries that fail the
-//      certificate (near-duplicate clusters) are re-done exactly by knn_rowpar_kernel (one lane per vocabulary row, the
-//      whole chip on each rejected query), so the output is always the reference's bit-exact answer.
+//      |filter score - reference distance| (eps_for() / eps_bf16()).  Queries that fail the certificate (near-duplicate
+//      clusters) are re-done exactly by rowpar_body.cuh (one lane per vocabulary row, the whole chip on each rejected
+//      query), so the output is always the reference's bit-exact answer.
 //
-// Tiling (wave64, CDNA4): one wave = 64 queries (two 32-query MFMA column groups, their k-halves resident in VGPRs for
-// the whole kernel) x a strip of 32-row vocabulary tiles.  A operand = 32 rows x 64 floats straight from global memory
-// (L2-resident: grid.x is a multiple of 8, row ranges stay on one XCD); lane (row l&31, half l>>5) holds the 32 contiguous
-// floats [32h, 32h+32) of its row, i.e. k-step t multiplies element 32h + t -- A and B use the same k permutation, which
-// a dot product does not see.  D layout: lane holds query (l&31), 16 rows (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// MFMA operand layout (both variants): lane (row or query l&31, half l>>5) holds the contiguous elements [32h, 32h+32) of its
+// row, i.e. a k-step multiplies the same element subset on both sides -- A and B use the same k permutation, which a dot
+// product does not see.  D layout: lane holds query (l&31), 16 rows (reg&3) + 8*(reg>>2) + 4*(l>>5).
 #include "lcd_kernels.h"
 #include "rowpar_body.cuh"
 
