@@ -258,19 +258,39 @@ __device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, c
     // hence idf, is wave-uniform and no per-posting lookup is needed.  Their length is then zeroed so that the flattened
     // pass below only sees the short segments.
     {
+        // A segment has at most TF_R = 256 postings (one per signature of the bucket), i.e. four 64-posting chunks.  A wave
+        // takes four words per trip and puts all (up to 16) chunk loads in flight before it touches any of them: the walk is a
+        // chain of memory round trips otherwise (one per chunk).
         const int wv = tid >> 6, ln = tid & 63, nwv = SCB / 64;
-        for (int k = wv; k < Ug; k += nwv) {                         // s_scan[k] still holds the segment LENGTH here
-            const uint32_t len = s_scan[k];
-            if (len < 64u) continue;                                 // wave-uniform
-            const uint32_t start = s_start[k];
-            const float idf = s_idf[k];
-            for (uint32_t o = ln; o < len; o += 64) {
-                const uint32_t e = ent[start + o];
-                const uint32_t sl = e >> TF_CNT_BITS;
-                const uint32_t ni = s_ni[sl];
-                if (ni != 0u) {
-                    const float term = __fdiv_rn(__fmul_rn((float)(e & TF_CNT_MASK), idf), (float)ni);
-                    atomicAdd(&acc[sl], to_fixed(term));
+        static_assert(TF_R == 256, "four chunks per segment");
+        for (int k0 = wv; k0 < Ug; k0 += 4 * nwv) {                  // s_scan[k] still holds the segment LENGTH here
+            uint32_t len[4], e[4][4];
+            float idf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j * nwv;
+                const uint32_t l = k < Ug ? s_scan[k] : 0u;
+                len[j] = l >= 64u ? l : 0u;                          // wave-uniform
+                idf[j] = k < Ug ? s_idf[k] : 0.0f;
+                const uint32_t start = k < Ug ? s_start[k] : 0u;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t o = (uint32_t)(c * 64 + ln);
+                    e[j][c] = o < len[j] ? ent[start + o] : 0xFFFFFFFFu;      // a posting is < 2^30: the sentinel cannot occur
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t p = e[j][c];
+                    if (p == 0xFFFFFFFFu) continue;
+                    const uint32_t sl = p >> TF_CNT_BITS;
+                    const uint32_t ni = s_ni[sl];
+                    if (ni != 0u) {
+                        const float term = __fdiv_rn(__fmul_rn((float)(p & TF_CNT_MASK), idf[j]), (float)ni);
+                        atomicAdd(&acc[sl], to_fixed(term));
+                    }
                 }
             }
         }
