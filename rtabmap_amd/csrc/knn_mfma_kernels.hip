@@ -398,7 +398,7 @@ constexpr int BF_KEEP = 2;                       // keys kept per (row block, qu
 constexpr int BF_QW = 128;                       // queries per wave
 constexpr int BF_QB = BF_QW * MF_WAVES;          // queries per workgroup
 constexpr int BF_TILE_F = 32 * 64;               // floats (dwords) per staged tile
-constexpr size_t BF_LDS_BYTES = (size_t)(MF_WAVES * 4 + 2) * BF_TILE_F * 4;
+constexpr size_t BF_LDS_BYTES = (size_t)(MF_WAVES * 4 + 2) * BF_TILE_F * 4 + (size_t)MF_STRIP_TILES * 64 * 4;   // + the strip's augmentation entries
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 // DMA instructions [i0, i1) of the 8 that move one 32-row x 256-byte tile (same swizzle as dma_a_tile)
@@ -454,6 +454,23 @@ __device__ __forceinline__ void bf_pair(const uint4 (&ah)[4], const uint4 (&al)[
     }
 }
 
+// Eight 16-byte LDS reads + the wait for them, as ONE inline-assembly statement the compiler does not see as LDS traffic (see the
+// filter loop).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_read8_b128(const uint32_t (&addr)[8], uint4 (&out)[8], uint32_t addr32, float& out32) {
+    u32x4_t v0, v1, v2, v3, v4, v5, v6, v7;
+    asm volatile(
+        "ds_read_b128 %0, %9\n\tds_read_b128 %1, %10\n\tds_read_b128 %2, %11\n\tds_read_b128 %3, %12\n\t"
+        "ds_read_b128 %4, %13\n\tds_read_b128 %5, %14\n\tds_read_b128 %6, %15\n\tds_read_b128 %7, %16\n\t"
+        "ds_read_b32 %8, %17\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7), "=&v"(out32)
+        : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7]), "v"(addr32)
+        : "memory");
+    out[0] = __builtin_bit_cast(uint4, v0); out[1] = __builtin_bit_cast(uint4, v1); out[2] = __builtin_bit_cast(uint4, v2);
+    out[3] = __builtin_bit_cast(uint4, v3); out[4] = __builtin_bit_cast(uint4, v4); out[5] = __builtin_bit_cast(uint4, v5);
+    out[6] = __builtin_bit_cast(uint4, v6); out[7] = __builtin_bit_cast(uint4, v7);
+}
 // third smallest of two sorted triples
 __device__ __forceinline__ uint64_t third_of_two_triples(uint64_t a0, uint64_t a1, uint64_t a2, uint64_t b0, uint64_t b1, uint64_t b2) {
     const uint64_t x = a1 > b0 ? a1 : b0, y = a0 > b1 ? a0 : b1;
@@ -479,63 +496,75 @@ __device__ __forceinline__ void selfdist_tile(const SelfdistJob& sd, int k, floa
     while (rem >= T - ti) { rem -= T - ti; ++ti; }
     const int tj = ti + rem;
     const int tid = threadIdx.x;
+    const bool act = tid < 256;                        // the tile is the work of 256 threads; a larger workgroup's other threads idle
     float* sA = lds;                   // rows of tile ti   [32][64] swizzled
     float* sB = lds + 2048;            // rows of tile tj
     float* sT = lds + 4096;            // [32][33] transposed result
+    if (act) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int e = tid + u * 256;                   // float4 index within a tile: row e / 16, chunk e % 16
-        const int r = e >> 4, c = e & 15;
-        const int ra = min(ti * 32 + r, sd.nq - 1), rb = min(tj * 32 + r, sd.nq - 1);
-        const float4 a = reinterpret_cast<const float4*>(sd.queries + (size_t)ra * 64)[c];
-        const float4 b = reinterpret_cast<const float4*>(sd.queries + (size_t)rb * 64)[c];
-        *reinterpret_cast<float4*>(sA + r * 64 + ((c ^ (r & 15)) << 2)) = a;
-        *reinterpret_cast<float4*>(sB + r * 64 + ((c ^ (r & 15)) << 2)) = b;
-    }
-    __syncthreads();
-    const int i = tid & 31, jj = tid >> 5;             // column query i of tile tj; rows jj, jj + 8, jj + 16, jj + 24 of tile ti
-    float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
-    for (int g = 0; g < 16; ++g) {
-        const float4 b = *reinterpret_cast<const float4*>(sB + i * 64 + ((g ^ (i & 15)) << 2));
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int r = jj + 8 * m;
-            const float4 a = *reinterpret_cast<const float4*>(sA + r * 64 + ((g ^ (r & 15)) << 2));
-            const float d0 = __fsub_rn(a.x, b.x), d1 = __fsub_rn(a.y, b.y), d2 = __fsub_rn(a.z, b.z), d3 = __fsub_rn(a.w, b.w);
-            float t = __fmul_rn(d0, d0);
-            t = __fadd_rn(t, __fmul_rn(d1, d1));
-            t = __fadd_rn(t, __fmul_rn(d2, d2));
-            t = __fadd_rn(t, __fmul_rn(d3, d3));
-            res[m] = __fadd_rn(res[m], t);
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * 256;                   // float4 index within a tile: row e / 16, chunk e % 16
+            const int r = e >> 4, c = e & 15;
+            const int ra = min(ti * 32 + r, sd.nq - 1), rb = min(tj * 32 + r, sd.nq - 1);
+            const float4 a = reinterpret_cast<const float4*>(sd.queries + (size_t)ra * 64)[c];
+            const float4 b = reinterpret_cast<const float4*>(sd.queries + (size_t)rb * 64)[c];
+            *reinterpret_cast<float4*>(sA + r * 64 + ((c ^ (r & 15)) << 2)) = a;
+            *reinterpret_cast<float4*>(sB + r * 64 + ((c ^ (r & 15)) << 2)) = b;
         }
     }
-    const int c = tj * 32 + i;
+    __syncthreads();
+    const int i = tid & 31, jj = (tid >> 5) & 7;       // column query i of tile tj; rows jj, jj + 8, jj + 16, jj + 24 of tile ti
+    if (act) {
+        float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+        for (int g = 0; g < 16; ++g) {
+            const float4 b = *reinterpret_cast<const float4*>(sB + i * 64 + ((g ^ (i & 15)) << 2));
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int r = ti * 32 + jj + 8 * m;
-        if (r < sd.nq && c < sd.nq) sd.out[(size_t)r * sd.ld + c] = res[m];
-        sT[(jj + 8 * m) * 33 + i] = res[m];
+            for (int m = 0; m < 4; ++m) {
+                const int r = jj + 8 * m;
+                const float4 a = *reinterpret_cast<const float4*>(sA + r * 64 + ((g ^ (r & 15)) << 2));
+                const float d0 = __fsub_rn(a.x, b.x), d1 = __fsub_rn(a.y, b.y), d2 = __fsub_rn(a.z, b.z), d3 = __fsub_rn(a.w, b.w);
+                float t = __fmul_rn(d0, d0);
+                t = __fadd_rn(t, __fmul_rn(d1, d1));
+                t = __fadd_rn(t, __fmul_rn(d2, d2));
+                t = __fadd_rn(t, __fmul_rn(d3, d3));
+                res[m] = __fadd_rn(res[m], t);
+            }
+        }
+        const int c = tj * 32 + i;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int r = ti * 32 + jj + 8 * m;
+            if (r < sd.nq && c < sd.nq) sd.out[(size_t)r * sd.ld + c] = res[m];
+            sT[(jj + 8 * m) * 33 + i] = res[m];
+        }
     }
     if (ti == tj) return;                              // uniform
     __syncthreads();
+    if (act) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {                      // mirrored tile: D[tj*32 + x][ti*32 + i] = D[ti*32 + i][tj*32 + x]
-        const int x = jj + 8 * m;
-        const int r = tj * 32 + x, cc = ti * 32 + i;
-        if (r < sd.nq && cc < sd.nq) sd.out[(size_t)r * sd.ld + cc] = sT[i * 33 + x];
+        for (int m = 0; m < 4; ++m) {                  // mirrored tile: D[tj*32 + x][ti*32 + i] = D[ti*32 + i][tj*32 + x]
+            const int x = jj + 8 * m;
+            const int r = tj * 32 + x, cc = ti * 32 + i;
+            if (r < sd.nq && cc < sd.nq) sd.out[(size_t)r * sd.ld + cc] = sT[i * 33 + x];
+        }
     }
 }
 
 // partial_keys [qpad][n_blocks][BF_KEEP] u64, partial_bound [qpad][n_blocks] f32 bits.  Grid (1-D): sd.n_tiles distance-matrix
 // workgroups first, then n_blocks x ceil(nq / 512) filter workgroups.
 template <int NG>
-__global__ __launch_bounds__(MF_BLOCK, 1) void knn_bf16_filter_kernel(const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
+__global__ __launch_bounds__((BF_QB / (NG * 32)) * 64) void knn_bf16_filter_kernel(const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
                                                                       int n_rows, const float* __restrict__ queries, int nq, int qpad,
                                                                       int tiles_per_block, int n_blocks, uint64_t* __restrict__ partial_keys,
                                                                       uint32_t* __restrict__ partial_bound, SelfdistJob sd) {
-    static_assert(NG * 32 == BF_QW, "wave tile");
+    // NG = 32-query groups per wave: 4 -> four waves, one per SIMD; 2 -> eight waves, two per SIMD (one wave's tile
+    // synchronisation, LDS reads and top-3 update hide behind the other's MFMAs).  The workgroup covers BF_QB queries either way.
+    static_assert(NG == 4 || NG == 2, "wave tile");
     constexpr int KH = 32;
+    constexpr int NW = BF_QB / (NG * 32);          // waves per workgroup
+    constexpr int QW = NG * 32;                    // queries per wave
+    constexpr int DPW = 8 / NW;                    // DMA instructions of a tile issued by one wave
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     if ((int)blockIdx.x < sd.n_tiles) { selfdist_tile(sd, (int)blockIdx.x, s_dyn); return; }
     const int fb = (int)blockIdx.x - sd.n_tiles;
@@ -543,24 +572,37 @@ __global__ __launch_bounds__(MF_BLOCK, 1) void knn_bf16_filter_kernel(const floa
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 31, half = lane >> 5;
-    const int q0 = by * BF_QB + wave * BF_QW;
+    const int q0 = by * BF_QB + wave * QW;
     float* s_q = s_dyn + (size_t)wave * NG * BF_TILE_F;             // this wave's query staging (prologue only)
-    float* s_tile = s_dyn + (size_t)MF_WAVES * NG * BF_TILE_F;      // [2] vocabulary tiles shared by the workgroup
+    float* s_tile = s_dyn + (size_t)NW * NG * BF_TILE_F;      // [2] vocabulary tiles shared by the workgroup
+    float* s_aug = s_tile + 2 * BF_TILE_F;                    // [MF_STRIP_TILES][64] augmentation entries of the strip, per lane
     MF_STAMP(0);
 
     const int tile0 = bx * tiles_per_block;
     const int n_tiles = (n_rows + 31) / 32;
     const int tile1 = min(tile0 + tiles_per_block, n_tiles);
 
-    // everything the prologue needs is put in flight at once: the wave's four query groups and its quarter of the first tile
+    // Everything the prologue needs is put in flight at once: the wave's query groups, its share of the first TWO vocabulary tiles
+    // and the augmentation entries of every tile of the strip.  The strip's other tiles follow as soon as the query staging area
+    // is free (below): the whole strip is requested long before it is needed -- with one tile of look-ahead the loop ran at the
+    // memory LATENCY (a tile trip is shorter than a round trip to HBM), not at the matrix rate.
 #pragma unroll
     for (int g = 0; g < NG; ++g) dma_a_tile<KH>(queries, nq, q0 / 32 + g, lane, s_q + g * BF_TILE_F);
-    float aug_next = 0.0f;
+    float augs[MF_STRIP_TILES];
+#pragma unroll
+    for (int i = 0; i < MF_STRIP_TILES; ++i) {
+        const int t = min(tile0 + i, max(tile1 - 1, tile0));
+        augs[i] = row_norm[2 * (size_t)min(t * 32 + col, n_rows) + half];
+    }
     if (tile0 < tile1) {
-        dma_tile_part(vocab_bf, n_rows, tile0, lane, s_tile, 2 * wave, 2 * wave + 2);
-        aug_next = row_norm[2 * (size_t)min(tile0 * 32 + col, n_rows) + half];
+        dma_tile_part(vocab_bf, n_rows, tile0, lane, s_tile, DPW * wave, DPW * wave + DPW);
+        dma_tile_part(vocab_bf, n_rows, min(tile0 + 1, tile1 - 1), lane, s_tile + BF_TILE_F, DPW * wave, DPW * wave + DPW);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave == 0) {                                                 // the loop takes them from LDS: a VMEM load there would wait behind the whole prefetch
+#pragma unroll
+        for (int i = 0; i < MF_STRIP_TILES; ++i) s_aug[i * 64 + lane] = augs[i];
+    }
 
     // B operands: -2 q split hi/lo in operand order (lane (query l&31, half l>>5) holds floats [32h, 32h + 32) of its query: k-step s
     // multiplies elements 32h + 8s .. + 8 -- A uses the same k permutation), + |q|^2 for the augmentation step
@@ -588,46 +630,68 @@ __global__ __launch_bounds__(MF_BLOCK, 1) void knn_bf16_filter_kernel(const floa
 #pragma unroll
     for (int g = 0; g < NG; ++g) { k0[g] = MF_KEY_NONE; k1[g] = MF_KEY_NONE; k2[g] = MF_KEY_NONE; }
     f32x16 p0, p1;                                                   // pending accumulators (groups NG-2, NG-1 of the previous tile)
+    f32x16 r0, r1;                                                   // NG == 2: the other pair (odd tiles)
+    // every wave has its queries in registers (and the first two tiles have landed for everybody): the staging area now takes
+    // tiles 2.. of the strip, all requested at once
+    __syncthreads();
+    for (int t = tile0 + 2; t < tile1; ++t)
+        dma_tile_part(vocab_bf, n_rows, t, lane, s_dyn + (size_t)(t - tile0 - 2) * BF_TILE_F, DPW * wave, DPW * wave + DPW);
     MF_STAMP(1);
     for (int t = tile0; t < tile1; ++t) {
-        const int cur = (t - tile0) & 1;
-        // my quarter of tile t has landed; after the barrier so has everybody's, and every wave is done reading tile t-1,
-        // whose slot the DMA of tile t+1 overwrites.  The LDS reads of tile t come FIRST and are waited for before that DMA is
-        // issued: the compiler orders any later LDS read behind an outstanding LDS-DMA with a full vmcnt(0).
-        MF_STAMP2(t - tile0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const float aug = aug_next;
-        // A operands: hi chunks 4h .. 4h+3 and lo chunks 8+4h .. 8+4h+3 of row `col` (16-byte chunks, XOR-swizzled)
+        const int ti = t - tile0;
+        MF_STAMP2(ti);
+        if (ti == 2) {                                               // tiles 2.. : one wait and one barrier for all of them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        // A operands: hi chunks 4h .. 4h+3 and lo chunks 8+4h .. 8+4h+3 of row `col` (16-byte chunks, XOR-swizzled).  The reads
+        // are issued as inline assembly: the compiler orders every LDS read it knows of behind ALL outstanding LDS-DMA
+        // (s_waitcnt vmcnt(0)), which would serialise the loop behind the strip's prefetch.
         uint4 ah[4], al[4];
+        float aug;
         {
-            const float* rowp = s_tile + cur * BF_TILE_F + col * 64;
+            const float* slot = ti < 2 ? s_tile + ti * BF_TILE_F : s_dyn + (size_t)(ti - 2) * BF_TILE_F;
+            const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(slot + col * 64);
+            uint32_t addr[8];
+            uint4 av[8];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                ah[v] = *reinterpret_cast<const uint4*>(rowp + (((4 * half + v) ^ (col & 15)) << 2));
-                al[v] = *reinterpret_cast<const uint4*>(rowp + (((8 + 4 * half + v) ^ (col & 15)) << 2));
+                addr[v] = base + ((((uint32_t)(4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
+                addr[4 + v] = base + ((((uint32_t)(8 + 4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
             }
+            lds_read8_b128(addr, av, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(s_aug + ti * 64 + lane), aug);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { ah[v] = av[v]; al[v] = av[4 + v]; }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        {
-            const int tn = min(t + 1, tile1 - 1);                    // unconditional: the last trip re-fetches its own tile into the idle slot
-            dma_tile_part(vocab_bf, n_rows, tn, lane, s_tile + (cur ^ 1) * BF_TILE_F, 2 * wave, 2 * wave + 2);
-            aug_next = row_norm[2 * (size_t)min(tn * 32 + col, n_rows) + half];
+        const uint32_t tl = (uint32_t)ti;
+        if constexpr (NG == 4) {
+            // two accumulator pairs take turns (no copies): groups 0,1 are computed into (x0, x1) while the pending scores of
+            // groups 2,3 of the previous tile (p0, p1) are pushed, then groups 2,3 into (p0, p1) while (x0, x1) are pushed
+            f32x16 x0, x1;
+            if (t == tile0) bf_pair<false>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, 0u, k0[2], k1[2], k2[2],
+                                           k0[3], k1[3], k2[3]);
+            else bf_pair<true>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, tl - 1u, k0[2], k1[2], k2[2], k0[3],
+                               k1[3], k2[3]);
+            bf_pair<true>(ah, al, aug, bh[2], bl[2], b_aug[2], bh[3], bl[3], b_aug[3], p0, p1, x0, x1, tl, k0[0], k1[0], k2[0], k0[1], k1[1], k2[1]);
+        } else {
+            // one pair per tile: the two accumulator pairs take turns from tile to tile (even tiles -> (p0, p1), odd -> (r0, r1))
+            if (t == tile0) bf_pair<false>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], p0, p1, r0, r1, 0u, k0[0], k1[0], k2[0],
+                                           k0[1], k1[1], k2[1]);
+            else if (tl & 1u) bf_pair<true>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], r0, r1, p0, p1, tl - 1u, k0[0], k1[0],
+                                            k2[0], k0[1], k1[1], k2[1]);
+            else bf_pair<true>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], p0, p1, r0, r1, tl - 1u, k0[0], k1[0], k2[0], k0[1],
+                               k1[1], k2[1]);
         }
-        const uint32_t tl = (uint32_t)(t - tile0);
-        // two accumulator pairs take turns (no copies): groups 0,1 are computed into (x0, x1) while the pending scores of groups
-        // 2,3 of the previous tile (p0, p1) are pushed, then groups 2,3 into (p0, p1) while (x0, x1) are pushed
-        static_assert(NG == 4, "two pairs per tile");
-        f32x16 x0, x1;
-        if (t == tile0) bf_pair<false>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, 0u, k0[2], k1[2], k2[2], k0[3],
-                                       k1[3], k2[3]);
-        else bf_pair<true>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, tl - 1u, k0[2], k1[2], k2[2], k0[3], k1[3],
-                           k2[3]);
-        bf_pair<true>(ah, al, aug, bh[2], bl[2], b_aug[2], bh[3], bl[3], b_aug[3], p0, p1, x0, x1, tl, k0[0], k1[0], k2[0], k0[1], k1[1], k2[1]);
     }
     if (tile0 < tile1) {
-        push_group(p0, (uint32_t)(tile1 - 1 - tile0), k0[NG - 2], k1[NG - 2], k2[NG - 2]);
-        push_group(p1, (uint32_t)(tile1 - 1 - tile0), k0[NG - 1], k1[NG - 1], k2[NG - 1]);
+        const uint32_t tlast = (uint32_t)(tile1 - 1 - tile0);
+        if (NG == 2 && (tlast & 1u)) {
+            push_group(r0, tlast, k0[0], k1[0], k2[0]);
+            push_group(r1, tlast, k0[1], k1[1], k2[1]);
+        } else {
+            push_group(p0, tlast, k0[NG - 2], k1[NG - 2], k2[NG - 2]);
+            push_group(p1, tlast, k0[NG - 1], k1[NG - 1], k2[NG - 1]);
+        }
     }
     MF_STAMP(2);
 
@@ -1007,9 +1071,12 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
         if (e != hipSuccess) return e;
     }
     if (p.n_blocks > 0) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_bf16_filter_kernel<4>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES);
-        (void)attr;
+        static const int ng = [] { const char* e = getenv("LCD_BF16_NG"); return (e && atoi(e) == 2) ? 2 : 4; }();   // waves per SIMD = 4 / ng (measured equal; 4 by default)
+        static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_bf16_filter_kernel<4>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES);
+        static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_bf16_filter_kernel<2>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES);
+        (void)attr4; (void)attr2;
         SelfdistJob sd;
         if (with_selfdist && cb) {                                    // the same-frame distance matrix rides along
             const int T = (p.q + 31) / 32;
@@ -1017,8 +1084,12 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
         }
         const int grid = sd.n_tiles + p.n_blocks * ((p.q + BF_QB - 1) / BF_QB);
         if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
-        knn_bf16_filter_kernel<4><<<grid, MF_BLOCK, BF_LDS_BYTES, s>>>((const float*)vocab_bf, row_norm, p.n_rows, (const float*)queries, p.q,
-                                                                        p.qpad, p.tiles_per_block, p.n_blocks, pk, pl, sd);
+        if (ng == 4)
+            knn_bf16_filter_kernel<4><<<grid, 256, BF_LDS_BYTES, s>>>((const float*)vocab_bf, row_norm, p.n_rows, (const float*)queries, p.q,
+                                                                       p.qpad, p.tiles_per_block, p.n_blocks, pk, pl, sd);
+        else
+            knn_bf16_filter_kernel<2><<<grid, 512, BF_LDS_BYTES, s>>>((const float*)vocab_bf, row_norm, p.n_rows, (const float*)queries, p.q,
+                                                                       p.qpad, p.tiles_per_block, p.n_blocks, pk, pl, sd);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }
