@@ -213,8 +213,15 @@ __global__ __launch_bounds__(FW_BLOCK) void frame_tail_kernel(ResolveArgs r, int
 // ---------------------------------------------------------------------------------------------- sealed buckets
 __device__ __forceinline__ float fixed_to_float(unsigned long long v) { return (float)((double)(long long)v * (1.0 / 281474976710656.0)); }   // 2^-48
 
+#ifdef LCD_SCORE_TIMING   // timing experiment only: 100 MHz stamps between the phases of score_sealed_body, per workgroup
+__device__ unsigned long long g_score_timing[1024 * 8];
+#define SC_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 1024) g_score_timing[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SC_STAMP(i) do { } while (0)
+#endif
+
 // One workgroup scores one sealed bucket for the word group g of G.  LDS (dynamic): acc[R] i64 | ni[R] | start[wg_cap] |
-// scan[wg_cap + 1] | idf[wg_cap] | scratch[SCB + 1].  With out_like != NULL (only valid for G == 1) the bucket's TF_R
+// scan[wg_cap + 1] | idf[wg_cap] | len[wg_cap] | scratch[SCB + 1].  With out_like != NULL (only valid for G == 1) the bucket's TF_R
 // likelihood values are written straight from the LDS accumulators (no round trip through lfix, no finalize launch);
 // otherwise the sums are added into lfix.
 template <int SCB>
@@ -227,7 +234,8 @@ __device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, c
     uint32_t* s_start = s_ni + TF_R;                                // [wg_cap]
     uint32_t* s_scan = s_start + wg_cap;                            // [wg_cap + 1]
     float* s_idf = (float*)(s_scan + wg_cap + 1);                   // [wg_cap]
-    uint32_t* scratch = (uint32_t*)(s_idf + wg_cap);                // [SCB + 1]
+    uint32_t* s_len = (uint32_t*)(s_idf + wg_cap);                  // [wg_cap]
+    uint32_t* scratch = s_len + wg_cap;                             // [SCB + 1]
     const int tid = threadIdx.x;
     const uint32_t* __restrict__ dir = tab[b].dir;
     const uint32_t* __restrict__ ent = tab[b].ent;
@@ -237,10 +245,15 @@ __device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, c
         if (out_like) for (int i = tid; i < TF_R; i += SCB) out_like[first_slot + i] = 0.0f;
         return;
     }
+    SC_STAMP(0);
     const int U = (int)q_meta[0];
     int Ug = U > g ? (U - g + G - 1) / G : 0;
     if (Ug > wg_cap) Ug = wg_cap;                                   // cannot happen: wg_cap is sized from the word count
     for (int i = tid; i < TF_R; i += SCB) { acc[i] = 0ull; s_ni[i] = slot_ni[first_slot + i]; }
+    // A word's postings inside this bucket are one segment.  LONG segments (>= 64 postings, i.e. words present in a quarter or
+    // more of the bucket's signatures: with a heavy-tailed vocabulary they hold most of the postings) are walked wave by wave in
+    // 64-posting chunks -- the word, hence idf, is wave-uniform and no per-posting lookup is needed; the SHORT ones are walked as
+    // one flattened, load-balanced list (s_scan = exclusive scan of their lengths).
     for (int k = tid; k < Ug; k += SCB) {
         const int u = g + k * G;
         const uint32_t w = q_w[u];
@@ -248,28 +261,40 @@ __device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, c
         uint32_t s = 0, e = 0;
         if (w < W && idf != 0.0f) { s = dir[w]; e = dir[w + 1]; }    // "if(logNnw)" (Memory.cpp:2267)
         s_start[k] = s;
-        s_scan[k] = e - s;
+        s_len[k] = e - s;
+        s_scan[k] = (e - s) < 64u ? (e - s) : 0u;
         s_idf[k] = idf;
     }
     if (tid == 0) s_scan[Ug] = 0;
     __syncthreads();
-    // LONG segments (>= 64 postings of this bucket, i.e. words present in a quarter or more of its signatures: with a
-    // heavy-tailed vocabulary they hold most of the postings) are walked wave by wave in 64-posting chunks -- the word,
-    // hence idf, is wave-uniform and no per-posting lookup is needed.  Their length is then zeroed so that the flattened
-    // pass below only sees the short segments.
+    SC_STAMP(1);
+    const uint32_t T = block_exclusive_scan(s_scan, Ug + 1, scratch);   // s_scan[Ug] == T afterwards
+    // The first four short postings of every thread are located (binary search in the scanned offsets, LDS; four independent
+    // chains) and REQUESTED now; they are consumed after the long segments, whose walk hides that round trip.
+    uint32_t sh_addr[4], sh_e[4]; int sh_k[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t t = (uint32_t)tid + (uint32_t)(u * SCB);
+        int lo = 0, hi = Ug;                             // largest k with s_scan[k] <= t  (s_scan[Ug] == T > t)
+        if (t < T) { while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_scan[mid] <= t) lo = mid; else hi = mid; } }
+        sh_k[u] = lo;
+        sh_addr[u] = t < T ? s_start[lo] + (t - s_scan[lo]) : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sh_e[u] = sh_addr[u] != 0xFFFFFFFFu ? ent[sh_addr[u]] : 0u;
     {
         // A segment has at most TF_R = 256 postings (one per signature of the bucket), i.e. four 64-posting chunks.  A wave
         // takes four words per trip and puts all (up to 16) chunk loads in flight before it touches any of them: the walk is a
         // chain of memory round trips otherwise (one per chunk).
         const int wv = tid >> 6, ln = tid & 63, nwv = SCB / 64;
         static_assert(TF_R == 256, "four chunks per segment");
-        for (int k0 = wv; k0 < Ug; k0 += 4 * nwv) {                  // s_scan[k] still holds the segment LENGTH here
+        for (int k0 = wv; k0 < Ug; k0 += 4 * nwv) {
             uint32_t len[4], e[4][4];
             float idf[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = k0 + j * nwv;
-                const uint32_t l = k < Ug ? s_scan[k] : 0u;
+                const uint32_t l = k < Ug ? s_len[k] : 0u;
                 len[j] = l >= 64u ? l : 0u;                          // wave-uniform
                 idf[j] = k < Ug ? s_idf[k] : 0.0f;
                 const uint32_t start = k < Ug ? s_start[k] : 0u;
@@ -295,19 +320,25 @@ __device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, c
             }
         }
     }
-    __syncthreads();
-    for (int k = tid; k < Ug; k += SCB) if (s_scan[k] >= 64u) s_scan[k] = 0u;
-    __syncthreads();
-    const uint32_t T = block_exclusive_scan(s_scan, Ug + 1, scratch);   // s_scan[Ug] == T afterwards
-    // SHORT segments: flattened, load-balanced walk.  Four postings per thread and trip: their segments are found by binary
-    // search in the scanned offsets (LDS; the four searches are independent chains), then four independent global loads are
-    // in flight at once.
-    for (uint32_t t0 = tid; t0 < T; t0 += 4 * SCB) {
+    SC_STAMP(2);
+    // the short postings requested above ...
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (sh_addr[u] == 0xFFFFFFFFu) continue;
+        const uint32_t sl = sh_e[u] >> TF_CNT_BITS;
+        const uint32_t ni = s_ni[sl];
+        if (ni != 0u) {                                              // "if(ni != 0)" (Memory.cpp:2275), 0 = retired slot
+            const float term = __fdiv_rn(__fmul_rn((float)(sh_e[u] & TF_CNT_MASK), s_idf[sh_k[u]]), (float)ni);
+            atomicAdd(&acc[sl], to_fixed(term));                     // ds_add_u64
+        }
+    }
+    // ... and, for a bucket with more than 4 * SCB of them, the rest: four per thread and trip
+    for (uint32_t t0 = (uint32_t)tid + 4u * SCB; t0 < T; t0 += 4 * SCB) {
         uint32_t addr[4]; int kk[4]; uint32_t e[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t t = t0 + u * SCB;
-            int lo = 0, hi = Ug;                         // largest k with s_scan[k] <= t  (s_scan[Ug] == T > t)
+            int lo = 0, hi = Ug;
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_scan[mid] <= t) lo = mid; else hi = mid; }
             kk[u] = lo;
             addr[u] = t < T ? s_start[lo] + (t - s_scan[lo]) : 0xFFFFFFFFu;
@@ -319,13 +350,14 @@ __device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, c
             if (addr[u] == 0xFFFFFFFFu) continue;
             const uint32_t sl = e[u] >> TF_CNT_BITS;
             const uint32_t ni = s_ni[sl];
-            if (ni != 0u) {                                          // "if(ni != 0)" (Memory.cpp:2275), 0 = retired slot
+            if (ni != 0u) {
                 const float term = __fdiv_rn(__fmul_rn((float)(e[u] & TF_CNT_MASK), s_idf[kk[u]]), (float)ni);
-                atomicAdd(&acc[sl], to_fixed(term));                 // ds_add_u64
+                atomicAdd(&acc[sl], to_fixed(term));
             }
         }
     }
     __syncthreads();
+    SC_STAMP(3);
     for (int i = tid; i < TF_R; i += SCB) {
         const unsigned long long v = acc[i];
         if (out_like) out_like[first_slot + i] = fixed_to_float(v);
@@ -809,7 +841,7 @@ hipError_t Tfidf::score(float* d_likelihood) {
     if (fuse && gforce <= 1 && (size_t)bitmap_words * 4 <= 32 * 1024 && (scb == 256 || scb == 512 || scb == 1024)) {
         // one launch: every sealed bucket writes its 256 likelihood values straight from LDS, the open bucket's workgroups
         // accumulate through lfix and the last of them converts its slots
-        const size_t sealed_bytes = (size_t)TF_R * 8 + (size_t)TF_R * 4 + ((size_t)wcap_all * 3 + 1 + scb + 1 + 4) * 4;
+        const size_t sealed_bytes = (size_t)TF_R * 8 + (size_t)TF_R * 4 + ((size_t)wcap_all * 4 + 1 + scb + 1 + 4) * 4;
         const size_t shmem = std::max(sealed_bytes, (size_t)std::max(bitmap_words, 1) * 4);
         int open_blocks = 0, bi = 0, n_open_slots = 0;
         const Bucket* ob = nullptr;
@@ -851,7 +883,7 @@ hipError_t Tfidf::score_partial(unsigned long long* lfix_target) {
         int G = gforce > 0 ? gforce : (256 + n_list - 1) / n_list;     // aim at >= one workgroup per CU
         G = std::max(1, std::min(G, 8));
         const int wg_cap = (wcap_all + G - 1) / G;
-        const size_t shmem = (size_t)TF_R * 8 + (size_t)TF_R * 4 + ((size_t)wg_cap * 3 + 1 + scb + 1 + 4) * 4;
+        const size_t shmem = (size_t)TF_R * 8 + (size_t)TF_R * 4 + ((size_t)wg_cap * 4 + 1 + scb + 1 + 4) * 4;
         const dim3 grid(n_list, G);
 #define LCD_SCORE_SEALED(B) score_sealed_kernel<B><<<grid, B, shmem, stream>>>(bkt_tab.as<BucketDev>(), bkt_list.as<int32_t>(), G, wg_cap, \
             q_w.as<uint32_t>(), q_idf.as<float>(), q_meta.as<uint32_t>(), slot_ni.as<uint32_t>(), lfix_target)
@@ -904,6 +936,12 @@ hipError_t Tfidf::retire(int32_t sig_id) {
 
 }  // namespace lcd
 
+#ifdef LCD_SCORE_TIMING
+extern "C" int lcd_debug_score_timing(unsigned long long* out, int n_words) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcd::g_score_timing), (size_t)n_words * 8);
+}
+#endif
 #ifdef LCD_TAIL_TIMING
 extern "C" int lcd_debug_tail_timing(unsigned long long* out) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;

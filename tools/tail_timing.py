@@ -12,8 +12,28 @@ import rtabmap_amd  # noqa: E402
 from rtabmap_amd import capi, synth  # noqa: E402
 
 
+def score_timing(lib, eng, vocab, words, n_sig, q, d_words, d_like, cap):
+    """phases of score_sealed_body per workgroup (LCD_SCORE_TIMING build)"""
+    lib.lcd_debug_score_timing.restype = ctypes.c_int
+    for i in range(6):
+        f = torch.from_numpy(synth.frame_from_signature(vocab, words[i * 11], seed=i)).cuda()
+        eng.frame_dev(f.data_ptr(), q, n_sig + 1 + i, float(n_sig + 1), d_words.data_ptr(), d_like.data_ptr(), cap, incremental=True,
+                      new_words_compared=True, nndr=0.8)
+    buf = (ctypes.c_ulonglong * (1024 * 8))()
+    assert lib.lcd_debug_score_timing(buf, 1024 * 8) == 0
+    t = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8)[:, :4].astype(np.float64) / 100.0
+    t = t[t[:, 0] > 0]
+    t0 = t[:, 0].min()
+    print("%d sealed-bucket workgroups; start spread %.2f us" % (len(t), t[:, 0].max() - t0))
+    d = np.diff(t, axis=1)
+    for i, nme in enumerate(["lookups (tab, words, dir)", "long segments", "short segments"]):
+        print("  %-28s median %5.2f  p90 %5.2f us" % (nme, np.median(d[:, i]), np.percentile(d[:, i], 90)))
+    print("  last workgroup leaves %.2f us after the first started" % (t[:, 3].max() - t0))
+    eng.close()
+
+
 def main():
-    n_words, q, n_sig = 49000, 500, 3000
+    n_words, q, n_sig = 49000, 500, int(os.environ.get("N_SIG", "3000"))
     vocab = synth.vocab_surf(n_words)
     words = synth.zipf_words(n_sig, q, n_words, seed=100000)
     eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 1024, sig_capacity=n_sig + 4096)
@@ -24,6 +44,8 @@ def main():
     cap = n_sig + 4096
     d_like = torch.zeros(cap, dtype=torch.float32, device="cuda")
     lib = capi.load()
+    if hasattr(lib, "lcd_debug_score_timing"):
+        return score_timing(lib, eng, vocab, words, n_sig, q, d_words, d_like, cap)
     lib.lcd_debug_tail_timing.restype = ctypes.c_int
     buf = (ctypes.c_ulonglong * 8)()
     rows = []
