@@ -21,7 +21,7 @@ def _check(eng, oracle, vocab, ids, queries, removed=None):
     np.testing.assert_array_equal(got_d, d)          # bit-exact, also for float32 L2
 
 
-@pytest.mark.parametrize("n,q", [(49000, 500), (5000, 77), (257, 64), (3, 5)])
+@pytest.mark.parametrize("n,q", [(49000, 500), (49000, 1000), (5000, 77), (257, 64), (3, 5)])
 def test_knn2_surf_bit_exact(oracle, n, q):
     v = synth.vocab_surf(n)
     qs = synth.queries_surf(v, q)
@@ -210,3 +210,38 @@ def test_knn2_filter_error_bound_on_wide_range_descriptors(oracle, monkeypatch, 
     r = eng.stats()["knn_max_err_ratio"]
     assert 0.0 < r < 0.5, r
     eng.close()
+
+
+def test_knn2_one_million_words_properties(monkeypatch):
+    """BASELINE.json config 4 scale (1M SURF words; one GPU's HBM holds them easily).  The CPU oracle would need minutes per
+    frame, so the checks are size-independent properties: a query that IS a vocabulary row comes back as that row at distance
+    exactly 0 (lowest row among duplicates); a slightly perturbed row comes back as that row; and the MFMA-filter path (thousands
+    of row blocks: the re-rank's general loops) agrees bit for bit with the exact VALU scan on every query."""
+    import rtabmap_amd
+    n, q = 1_000_000, 500
+    rng = np.random.default_rng(4)
+    v = rng.standard_normal((n, 64)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    pick = rng.integers(0, n, q)
+    qs = v[pick].copy()
+    qs[250:] += rng.standard_normal((q - 250, 64)).astype(np.float32) * np.float32(0.01)
+    v[999_999] = v[pick[0]]                                   # a duplicate far away: the lower row must win the tie
+    ids = np.arange(1, n + 1, dtype=np.int32)
+    res = {}
+    for mode in ("bf16", "valu"):
+        monkeypatch.setenv("LCD_KNN_MODE", mode)
+        eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n)
+        for a in range(0, n, 250_000):
+            eng.vocab_append(v[a:a + 250_000], ids[a:a + 250_000])
+        res[mode] = eng.knn2(qs)
+        eng.close()
+    w, d = res["bf16"]
+    np.testing.assert_array_equal(w, res["valu"][0])
+    np.testing.assert_array_equal(d, res["valu"][1])
+    first_row = {}
+    for r in pick[:250]:
+        first_row.setdefault(int(r), int(r))
+    exp = np.array([min(int(r), 999_999) if i == 0 else int(r) for i, r in enumerate(pick)], dtype=np.int64)
+    np.testing.assert_array_equal(w[:, 0], exp + 1)
+    assert (d[:250, 0] == 0.0).all() and (d[:, 1] > d[:, 0]).sum() >= q - 1
+    assert w[0, 1] == 1_000_000 and d[0, 1] == 0.0            # the duplicate is the second neighbour, also at distance 0
