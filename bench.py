@@ -271,7 +271,7 @@ def main():
         "roofline": roofline,
         "roofline_other": roofline_other,
     }
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU leg runs at N = 1 only
         out["cpu_baseline"] = cpu_baseline(vocab, words, frames, sample_sigs=min(10000, n_sig), n_frames=3)
     if rank == 0:
         exp_top = int(src[last]) + 1
