@@ -145,6 +145,9 @@ int lcd_likelihood(lcd_engine* h, const int32_t* query_word_ids, int nq, const i
 /* Rtabmap::adjustLikelihood (Rtabmap.cpp:5691-5760) on a likelihood vector whose entry 0 is the virtual place;
  * in/out on the host, reduction on the device.  ("next" row f1 of the scope table) */
 int lcd_adjust_likelihood(lcd_engine* h, float* likelihood, int n, float virtual_place_ratio);
+/* the same in place on a DEVICE vector, enqueued on the engine stream and not synchronised: with the likelihood of lcd_frame_dev
+ * written at d_likelihood + 1 and the virtual place's value at d_likelihood[0], the adjusted vector never leaves the device */
+int lcd_adjust_likelihood_dev(lcd_engine* h, float* d_likelihood, int n, float virtual_place_ratio);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * device-resident frame path (no host round trip; what bench.py times).  All pointers are DEVICE pointers valid on

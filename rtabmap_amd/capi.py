@@ -22,7 +22,7 @@ SYMBOLS = [
     "lcd_vocab_clear", "lcd_vocab_append", "lcd_vocab_remove", "lcd_vocab_rebuild", "lcd_vocab_count", "lcd_vocab_read",
     "lcd_knn2", "lcd_selfdist", "lcd_quantize", "lcd_find_nn",
     "lcd_sig_add", "lcd_sig_remove", "lcd_sig_add_bulk", "lcd_sig_count", "lcd_word_nrefs",
-    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood",
+    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_adjust_likelihood_dev", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood",
 ]
 
 
@@ -90,6 +90,7 @@ def load():
     L.lcd_word_nrefs.argtypes = [vp, i32, C.POINTER(i32)]
     L.lcd_likelihood.argtypes = [vp, vp, C.c_int, vp, C.c_int, f32, vp]
     L.lcd_adjust_likelihood.argtypes = [vp, vp, C.c_int, f32]
+    L.lcd_adjust_likelihood_dev.argtypes = [vp, vp, C.c_int, f32]
     L.lcd_frame_dev.argtypes = [vp, vp, C.c_int, C.c_int, f32, i32, f32, vp, vp, i64]
     L.lcd_knn2_dev.argtypes = [vp, vp, C.c_int, vp, vp]
     L.lcd_shard_knn2_dev.argtypes = [vp, vp, C.c_int, vp]
@@ -243,6 +244,9 @@ class Engine:
         out = np.zeros(s.shape[0], np.float32)
         self._ck(self.L.lcd_likelihood(self.h, _p(w), w.shape[0], _p(s), s.shape[0], float(N), _p(out)))
         return out
+
+    def adjust_likelihood_dev(self, d_ptr, n, ratio=0.0):
+        self._ck(self.L.lcd_adjust_likelihood_dev(self.h, d_ptr, n, ratio))
 
     def adjust_likelihood(self, L, ratio=0.0):
         a = np.ascontiguousarray(L, dtype=np.float32).copy()

@@ -665,6 +665,15 @@ int lcd_adjust_likelihood(lcd_engine* h, float* likelihood, int n, float virtual
     return download(h, likelihood, h->d_like.p, (size_t)n * 4, h->h_out);
 }
 
+int lcd_adjust_likelihood_dev(lcd_engine* h, float* d_likelihood, int n, float virtual_place_ratio) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (n < 0 || (n > 0 && !d_likelihood)) return h->fail(LCD_ERR_INVALID, "lcd_adjust_likelihood_dev: null input");
+    if (n == 0) return LCD_OK;
+    LCD_HIP(h, launch_adjust_likelihood(d_likelihood, n, virtual_place_ratio, h->stream));
+    return LCD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ device-resident frame
 int lcd_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, float nndr_ratio, int32_t sig_id, float N,
                   int32_t* d_word_ids, float* d_likelihood, int64_t likelihood_capacity) {

@@ -5,6 +5,7 @@ Tolerance (BASELINE.json north_star): <= 1e-4 relative on likelihood scores (abs
 must be identical.  In practice the fixed-point accumulation agrees to ~1e-6."""
 import numpy as np
 import pytest
+import torch  # before liblcd_hip.so is loaded: one HIP runtime per process (rtabmap_amd/capi.py)
 
 from helpers import update_common_signature
 from rtabmap_amd import synth
@@ -134,6 +135,10 @@ def test_adjust_likelihood_matches_oracle(oracle):
             exp = oracle.adjust_likelihood(L, ratio)
             got = eng.adjust_likelihood(L, ratio)
             np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1e-6)
+            d = torch.from_numpy(L.copy()).cuda()                       # device-resident variant: same kernel, no host round trip
+            eng.adjust_likelihood_dev(d.data_ptr(), L.shape[0], ratio)
+            eng.synchronize()
+            np.testing.assert_array_equal(d.cpu().numpy(), got)
     z = eng.adjust_likelihood(np.zeros(5, np.float32))
     assert z.tolist() == [2.0, 1.0, 1.0, 1.0, 1.0]
     eng.close()
