@@ -44,7 +44,8 @@ namespace orc {
 enum { T_F32 = 0, T_U8 = 1 };
 // Kp/NNStrategy values (VWDictionary.h:49-55)
 enum { kNNFlannNaive = 0, kNNFlannKdTree = 1, kNNFlannLSH = 2, kNNBruteForce = 3, kNNBruteForceGPU = 4 };
-enum { METRIC_L2 = 0, METRIC_HAMMING = 1, METRIC_L1 = 2 };
+enum { METRIC_L2 = 0, METRIC_HAMMING = 1, METRIC_L1 = 2, METRIC_HAMMING_CV = 3 };
+static inline bool metric_is_u8(int metric) { return metric == METRIC_HAMMING || metric == METRIC_HAMMING_CV; }
 
 // ---------------------------------------------------------------------------------------------- distances
 // rtflann::L2<float>::operator()  dist.h:150-177 (worst_dist = -1: no early exit)
@@ -90,8 +91,18 @@ static inline unsigned dist_hamming(const unsigned char* a, const unsigned char*
     }
     return result;
 }
+// cv::NORM_HAMMING as cv::BFMatcher / cv::cuda::DescriptorMatcher compute it (VWDictionary.cpp:1027-1075, :1143): the bits of
+// EVERY byte.  It differs from rtflann::Hamming above only for descriptor sizes that are not a multiple of 8 bytes (AKAZE's
+// 61): the reference's FLANN strategies then ignore the tail, its brute-force strategies and the same-frame comparison do not.
+// OpenCV's source is not in the reference tree: this is the documented definition of NORM_HAMMING.
+static inline unsigned dist_hamming_cv(const unsigned char* a, const unsigned char* b, size_t size) {
+    unsigned result = dist_hamming(a, b, size);
+    for (size_t i = size / 8 * 8; i < size; ++i) result += popcnt64((uint64_t)(a[i] ^ b[i]));
+    return result;
+}
 static inline float dist_any(int metric, const void* a, const void* b, size_t cols) {
     if (metric == METRIC_HAMMING) return (float)dist_hamming((const unsigned char*)a, (const unsigned char*)b, cols);
+    if (metric == METRIC_HAMMING_CV) return (float)dist_hamming_cv((const unsigned char*)a, (const unsigned char*)b, cols);
     if (metric == METRIC_L1) return dist_l1((const float*)a, (const float*)b, cols);
     return dist_l2((const float*)a, (const float*)b, cols);
 }
@@ -203,7 +214,7 @@ struct VWDictionary {
 
     bool isFlann() const { return strategy < kNNBruteForce; }
     int metricFor(int type) const {   // VWDictionary.cpp:1027, 1143: HAMMING for CV_8U else (L1 if useDistanceL1_) L2SQR
-        if (type == T_U8) return METRIC_HAMMING;
+        if (type == T_U8) return METRIC_HAMMING_CV;               // cv::BFMatcher(NORM_HAMMING)
         return useDistanceL1 ? METRIC_L1 : METRIC_L2;
     }
 
@@ -328,7 +339,7 @@ struct VWDictionary {
     void indexed2nn(const unsigned char* q, int type, long idx[2], float d[2]) const {
         int metric;
         if (isFlann()) metric = (type == T_U8) ? METRIC_HAMMING : (useDistanceL1 ? METRIC_L1 : METRIC_L2);  // FlannIndex.cpp:727-744
-        else metric = (type == T_U8) ? METRIC_HAMMING : METRIC_L2;                                           // :1027
+        else metric = (type == T_U8) ? METRIC_HAMMING_CV : METRIC_L2;                                        // :1027 (cv::BFMatcher)
         Top2 t;
         scan_top2(metric, dataTree, q, 2, t, isFlann() ? &rowRemoved : 0);
         for (int j = 0; j < 2; ++j) {
@@ -686,7 +697,7 @@ unsigned orc_dist_hamming(const unsigned char* a, const unsigned char* b, size_t
 // threads > 1 parallelises over queries (the "generous" CPU baseline; results are per-query so unchanged).
 void orc_knn2_linear(int metric, const void* train, long n, int cols, const unsigned char* removed,
                      const void* queries, long nq, long* idx, float* dist, int threads) {
-    const size_t rb = (size_t)cols * (metric == METRIC_HAMMING ? 1 : 4);
+    const size_t rb = (size_t)cols * (metric_is_u8(metric) ? 1 : 4);
 #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
     for (long q = 0; q < nq; ++q) {
         const unsigned char* qp = (const unsigned char*)queries + (size_t)q * rb;
@@ -703,7 +714,7 @@ void orc_knn2_linear(int metric, const void* train, long n, int cols, const unsi
 }
 // full nq x n distance matrix (row-major), for the self-distance checks
 void orc_dist_matrix(int metric, const void* a, long na, const void* b, long nb, int cols, float* out) {
-    const size_t rb = (size_t)cols * (metric == METRIC_HAMMING ? 1 : 4);
+    const size_t rb = (size_t)cols * (metric_is_u8(metric) ? 1 : 4);
     for (long i = 0; i < na; ++i)
         for (long j = 0; j < nb; ++j)
             out[i * nb + j] = dist_any(metric, (const unsigned char*)a + (size_t)i * rb, (const unsigned char*)b + (size_t)j * rb, cols);

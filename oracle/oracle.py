@@ -8,7 +8,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 T_F32, T_U8 = 0, 1
-METRIC_L2, METRIC_HAMMING, METRIC_L1 = 0, 1, 2
+METRIC_L2, METRIC_HAMMING, METRIC_L1, METRIC_HAMMING_CV = 0, 1, 2, 3
+# METRIC_HAMMING = rtflann::Hamming (ignores the bytes beyond a multiple of 8, like the reference's FLANN strategies);
+# METRIC_HAMMING_CV = cv::NORM_HAMMING (every byte: the reference's brute-force strategies and same-frame comparison)
 ALGO_LINEAR, ALGO_KDTREE = 0, 1
 # Kp/NNStrategy (reference VWDictionary.h:49-55)
 kNNFlannNaive, kNNFlannKdTree, kNNFlannLSH, kNNBruteForce, kNNBruteForceGPU = 0, 1, 2, 3, 4
