@@ -11,7 +11,9 @@
  *
  * Numeric contract (identical to the reference): distances are SQUARED L2 for float descriptors (rtflann L2 functor,
  * dist.h:150-177, and cv::NORM_L2SQR) accumulated in the reference's own order -> bit-exact; Hamming distances as
- * float (VWDictionary.cpp:1078-1083); on equal distance the lower vocabulary row wins (result_set.h:151-171); word
+ * float (VWDictionary.cpp:1078-1083) over EVERY byte of the descriptor (cv::NORM_HAMMING, the metric of the brute-force
+ * strategies this engine stands in for; rtflann::Hamming, used by the FLANN strategies, ignores the size % 8 trailing
+ * bytes, dist.h:555-579 -- the two only differ for sizes that are not a multiple of 8); on equal distance the lower vocabulary row wins (result_set.h:151-171); word
  * ids >= 1, 0 == none (ID_INVALID, VWDictionary.cpp:59-60); signature ids are any non-zero int (virtual place -1).
  *
  * There is NO CPU fallback inside this library: without a gfx950 device lcd_create() fails with LCD_ERR_HIP.

@@ -36,6 +36,22 @@ def test_distance_functors_bitwise(oracle, ref):
             d = oracle.lib().orc_dist_hamming(pa, pb, nb)
             assert d == ref.ref_dist_hamming(pa, pb, nb)
             assert d == int(np.unpackbits(a[i] ^ b[i]).sum())
+    # sizes that are not a multiple of 8 bytes (AKAZE: 61): the real rtflann functor ignores the trailing size % 8 bytes
+    # (dist.h:555-579) and so does its restatement; cv::NORM_HAMMING (brute-force strategies, same-frame comparison) counts every
+    # byte -- the oracle's METRIC_HAMMING_CV, which is what the engine is checked against
+    for nb in (61, 33, 7, 12):
+        a = rng.integers(0, 256, (100, nb), dtype=np.uint8)
+        b = rng.integers(0, 256, (100, nb), dtype=np.uint8)
+        for i in range(100):
+            pa, pb = a[i].ctypes.data_as(C.c_void_p), b[i].ctypes.data_as(C.c_void_p)
+            d = oracle.lib().orc_dist_hamming(pa, pb, nb)
+            assert d == ref.ref_dist_hamming(pa, pb, nb)
+            assert d == int(np.unpackbits(a[i, :nb // 8 * 8] ^ b[i, :nb // 8 * 8]).sum())
+        full = oracle.dist_matrix(a, b, metric=oracle.METRIC_HAMMING_CV)
+        trunc = oracle.dist_matrix(a, b, metric=oracle.METRIC_HAMMING)
+        bits = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(axis=2)
+        np.testing.assert_array_equal(full, bits.astype(np.float32))
+        assert (trunc <= full).all() and (trunc < full).any()
 
 
 @pytest.mark.parametrize("kind", ["surf", "orb", "orb_ties"])
