@@ -34,9 +34,23 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP translation unit and link the shared library.  Returns the path."""
+    """Compile every HIP translation unit and link the shared library.  Returns the path.
+    Several processes may get here at once (one rank per GPU): the build is serialised by a file lock and the library is
+    moved into place atomically, so a concurrent loader never sees a half-written file."""
     if not force and not _stale():
         return OUT
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():       # another process built it while this one waited
+                return OUT
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     hipcc = _hipcc()
     extra = os.environ.get("LCD_EXTRA_HIPCC_FLAGS", "").split()     # timing experiments only (e.g. -DLCD_MFMA_ABLATE=1)
     objdir = os.path.join(HERE, "build")
@@ -56,10 +70,12 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
         if verbose and out.strip():
             print(out, file=sys.stderr)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    tmp = OUT + ".tmp.%d" % os.getpid()
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)
+    os.replace(tmp, OUT)
     return OUT
 
 
