@@ -717,15 +717,17 @@ __global__ __launch_bounds__((BF_QB / (NG * 32)) * 64) void knn_bf16_filter_kern
 }
 
 // |bf16x3 filter score - reference distance| <= eps, u = 2^-24:
-//   split: x = hi + lo + d with |lo| <= 2^-9 |x|, |d| <= 2^-18 |x|; the neglected ql.vl and the d terms cost
-//          <= 3 * 2^-18 |q||v| (1 + 2^-8) on q.v, twice that on the score                            -> 3.1 * 2^-18 (|v|^2 + |q|^2)
+//   split: bf16 keeps 8 significant bits (unit roundoff 2^-8): x = hi + lo + d with |lo| <= 2^-8 |x|, |d| <= 2^-8 |lo| <= 2^-16 |x|;
+//          the neglected ql.vl and the two d terms cost <= 3 * 2^-16 |q||v| (1 + 2^-7) on q.v, twice that on the score
+//          -> 3.1 * 2^-16 (|v|^2 + |q|^2)   (tests/test_bf16_split_bound.py emulates the split on the CPU: adversarial inputs reach
+//          a third of it)
 //   accumulation: 2 + 3 dim products summed in fp32 by the matrix pipe; each addition is charged 2u (round-to-nearest or
 //          truncation) of the running magnitude <= |v|^2 + |q|^2 + 2 * 3 |q||v| <= 4 (|v|^2 + |q|^2)  -> (3 dim + 4) * 2u * 4 (..)
 //   norms (dim-term FMA chains) and the reference's own rounding, as in eps_for()                     -> (dim + 2 (dim/4 + 6)) u (..)
 // a quarter more is added for slack; the measured worst case is reported by the tests (knn_max_err_ratio).
 __device__ __forceinline__ float eps_bf16(int dim, float qn, float vn_max) {
     const float u = 5.9604645e-8f;
-    return (3.1f * 3.8146973e-6f + ((3.0f * (float)dim + 4.0f) * 8.0f + 1.5f * (float)dim + 12.0f) * u) * 1.25f * (qn + vn_max);
+    return (3.1f * 1.5258789e-5f + ((3.0f * (float)dim + 4.0f) * 8.0f + 1.5f * (float)dim + 12.0f) * u) * 1.25f * (qn + vn_max);
 }
 
 // ------------------------------------------------------------------------------------------------ re-rank + certificate
