@@ -3,20 +3,26 @@
 
 One STEP = one query frame through the hot path, inputs already resident in HBM:
     500 SURF-64 descriptors -> exact 2-NN against the 49k-word vocabulary + NNDR + same-frame resolution
-    (VWDictionary::addNewWords) -> the frame's references registered in the inverted index and the oldest signature
-    retired (memory stays at 100k signatures, as Rtabmap's WM->LTM transfer keeps it) -> TF-IDF likelihood of the frame
-    against every signature (Memory::computeLikelihood).
+    (VWDictionary::addNewWords) -> the frame's references registered in the inverted index (existing and new words) and the
+    oldest signature retired (memory stays at 100k signatures, as Rtabmap's WM->LTM transfer keeps it) -> TF-IDF likelihood of
+    the frame against every signature (Memory::computeLikelihood).
     candidates/sec = frames/sec x N_signatures.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the step -- the longer of the 2-NN filter and the fused
-TF-IDF scoring kernel, both bracketed by HIP events inside the timed region (the other one is reported next to it as
-`roofline_other`); `cpu_baseline` times the
-reference-style CPU path (the reference's own rtflann kd-tree when oracle/_ref is present + the restated std::map
-computeLikelihood) on a bounded sample on this box's host cores.
+`python bench.py --gpus N`: N == 1 runs in this process; N > 1 starts N ranks itself (one per GPU) unless a launcher
+(torch.distributed.run) already did -- RANK / WORLD_SIZE in the environment.  N > 1 defaults to the north-star split: ONE frame
+stream, the vocabulary and its postings sharded by word-id range, an all-gather of the per-rank 2-NN candidates and an int64
+all-reduce of the partial likelihood per frame (RCCL); the independent-replica throughput is measured in the same run and
+reported next to it (`config.replicas_value`).
+
+Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel of the step, `roofline_score` / `roofline_knn` are the two big
+kernels under fixed keys (HIP events around each launch inside the timed region, on the stream it is launched on);
+`cpu_baseline` times the reference-style CPU path on this box's host cores in the same run (three variants); `parity` re-runs
+frames of this configuration through a fresh engine and the oracle side by side.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,95 +37,382 @@ NNDR = 0.8
 PEAK_F32_TFLOPS = 157.3
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBPS = 8000.0
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_state(eng, rank, world, n_sig, seed=100000):
+# ----------------------------------------------------------------------------------------------------------------- launch
+def spawn_ranks(n, argv):
+    """N > 1 without a launcher: start N copies of this script, one rank per GPU (ranks share GPUs round-robin when the box has
+    fewer -- then the collectives go over gloo, a functional check only)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, p.wait())
+    sys.exit(rc)
+
+
+# ----------------------------------------------------------------------------------------------------------------- pieces
+def make_state(n_sig):
     from rtabmap_amd import synth
-    t0 = time.time()
     vocab = synth.vocab_surf(N_WORDS)
-    words = synth.zipf_words(n_sig, Q, N_WORDS, seed=seed)
-    eng.vocab_append(vocab, np.arange(1, N_WORDS + 1, dtype=np.int32))
-    offsets = np.arange(0, (n_sig + 1) * Q, Q, dtype=np.int64)
-    chunk = 10000
-    for a in range(0, n_sig, chunk):
-        b = min(a + chunk, n_sig)
-        eng.sig_add_bulk(np.arange(a + 1, b + 1, dtype=np.int32), offsets[a:b + 1] - offsets[a], words[a:b].reshape(-1))
-    log("[bench] state built in %.1fs: %d words, %d signatures" % (time.time() - t0, N_WORDS, n_sig))
+    words = synth.zipf_words(n_sig, Q, N_WORDS, seed=100000)
     return vocab, words
 
 
-def cpu_baseline(vocab, words, frames, sample_sigs, n_frames):
-    """Reference-style CPU path on a bounded sample: kd-tree 2-NN (the reference default, Kp/NNStrategy=1: 4 trees,
-    32 checks, 1 thread -- the REAL rtflann when oracle/_ref is there, else the exact linear port) + NNDR, then the
-    restated std::map Memory::computeLikelihood over `sample_sigs` signatures.  candidates/s = frames/s x sample_sigs."""
+def load_engine(eng, vocab, words, owned=None):
+    """Bulk-load the vocabulary and the signature memory (Memory::loadDataFromDb).  Returns the load time of the signatures."""
+    n_sig = words.shape[0]
+    eng.vocab_append(vocab, np.arange(1, N_WORDS + 1, dtype=np.int32))
+    offsets = np.arange(0, (n_sig + 1) * Q, Q, dtype=np.int64)
+    t0 = time.perf_counter()
+    eng.sig_add_bulk(np.arange(1, n_sig + 1, dtype=np.int32), offsets, words.reshape(-1))
+    return time.perf_counter() - t0
+
+
+class Stepper:
+    """The bench step on one engine: frame t registered as signature n_sig + 1 + t, the oldest signature retired."""
+
+    def __init__(self, eng, torch, d_frames, n_sig, cap, want_like=True):
+        self.eng, self.d_frames, self.n_sig, self.cap = eng, d_frames, n_sig, cap
+        self.d_words = torch.zeros(Q, dtype=torch.int32, device="cuda")
+        self.d_like = torch.zeros(cap, dtype=torch.float32, device="cuda") if want_like else None
+        self.next_sig, self.oldest, self.first_new = n_sig + 1, 1, N_WORDS + 1
+
+    def __call__(self, i):
+        self.eng.frame_dev(self.d_frames[i % len(self.d_frames)].data_ptr(), Q, self.next_sig, float(self.n_sig + 1),
+                           self.d_words.data_ptr(), self.d_like.data_ptr(), self.cap, incremental=True, new_words_compared=True,
+                           nndr=NNDR, first_new_word_id=self.first_new)
+        self.eng.sig_remove(self.oldest)
+        self.next_sig += 1
+        self.oldest += 1
+        self.first_new += Q          # ids are only reserved here (the words are never appended): any consecutive numbering will do
+
+
+def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None):
+    """warmup untimed steps, then exactly `steps` steps bracketed by barrier + synchronize; an event per step for the distribution."""
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    if profile_eng is not None:
+        profile_eng.profile_begin(max(10, steps // 5))   # HIP events around the two big kernels of the first 20 % of the timed steps
+    t0 = time.perf_counter()
+    evs[0].record(stream)
+    for i in range(steps):
+        step(warmup + i)
+        evs[i + 1].record(stream)
+    host_enqueue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    return {"wall": wall, "dev_ms": evs[0].elapsed_time(evs[steps]), "host_enqueue": host_enqueue, "per_step_ms": per_step}
+
+
+def pmc_traffic(name):
+    """HBM traffic per launch of a kernel: from the committed rocprofv3 --pmc summary of this command (FETCH_SIZE / WRITE_SIZE cannot
+    be read from inside the process); null when the profile is not there."""
+    try:
+        pmc = json.load(open(PMC_PROFILE))
+        return pmc[name]["hbm_bytes_per_launch"] / 1e9 if name in pmc else None
+    except Exception:
+        return None
+
+
+def rooflines(eng, n_rows_rank, n_sig, shard):
+    """Both big kernels, from the HIP events the engine recorded around their launches inside the timed region."""
+    sc_ms, sc_n, sc_name = eng.profile_read_likelihood()
+    kern_ms, kern_n, kern_name = eng.profile_read()
+    flops = 2.0 * Q * n_rows_rank * DIM           # ALGORITHMIC work per launch (SURVEY.md 8d): GEMM-equivalent 2*Q*N*D
+    achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    bf16 = "bf16" in kern_name
+    peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+    roof_knn = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": pmc_traffic(kern_name), "traffic_unit": "GB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)", "kernel": kern_name,
+                "ms": kern_ms, "samples": kern_n, "mfma_dtype": "bf16 (3 products per fp32 product, fp32 accumulate)" if bf16 else "f32",
+                "executed_tflops": (3.0 if bf16 else 1.0) * achieved, "frac_of_f32_mfma_peak": achieved / PEAK_F32_TFLOPS,
+                "algorithmic_gbps": (n_rows_rank * DIM * 4 + Q * DIM * 4 + Q * 16) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0}
+    roof_score = None
+    if sc_ms > 0:
+        # ALGORITHMIC bytes of the scoring launch, counted by the engine for the last frame's words (lcd_profile_score_work):
+        # dense count rows read (256 B per dense word and bucket) + 4 B per sparse posting + 8 B per entry of the open bucket's log
+        # + ni read and likelihood write (8 B per signature).  `postings` = what SURVEY.md 8d counts (P of the frame's words).
+        work = eng.profile_score_work()
+        sc_bytes = work["dense_row_bytes"] + 4.0 * work["sparse_postings"] + 8.0 * work["open_log_entries"] + 8.0 * n_sig
+        gbps = sc_bytes / (sc_ms * 1e-3) / 1e9
+        roof_score = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                      "traffic": pmc_traffic(sc_name), "traffic_unit": "GB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)", "kernel": sc_name,
+                      "ms": sc_ms, "samples": sc_n, "algorithmic_bytes_per_launch": sc_bytes, "work": work,
+                      "frac_if_4B_per_posting": (4.0 * work["postings"] + 8.0 * n_sig) / (sc_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS}
+    return roof_knn, roof_score
+
+
+# ----------------------------------------------------------------------------------------------------------------- CPU side
+def build_oracle(vocab, words):
     import oracle as O
     t0 = time.time()
-    m = O.OracleMemory(strategy=O.kNNBruteForce)
+    m = O.OracleMemory(strategy=O.kNNBruteForce, nndr=NNDR)
     for w in range(1, N_WORDS + 1):
-        m.vwd.add_word(w, np.zeros(1, np.float32))
-    for s in range(sample_sigs):
-        m.add_signature(words[s])
-    ids = np.arange(1, sample_sigs + 1, dtype=np.int32)
-    kind = "port"
-    index = None
-    if O.have_ref():
-        index = O.RefIndex(vocab, algo=O.ALGO_KDTREE, trees=4)
-        kind = "reference"
-    log("[bench] cpu baseline state (%d signatures) built in %.1fs" % (sample_sigs, time.time() - t0))
+        m.vwd.add_word(w, vocab[w - 1])
+    m.vwd.update()
+    m.add_signatures_bulk(words)
+    log("[bench] oracle memory (%d signatures) built in %.1fs" % (words.shape[0], time.time() - t0))
+    return m
+
+
+def parity_block(torch, vocab, words, frames_np, m, n_frames=3):
+    """SURVEY.md 8d 'parity checks run with every bench': frames of THIS configuration through a fresh engine (the timed entry
+    point, lcd_frame_dev with registration + retirement) and through the oracle's Memory::update -> computeLikelihood."""
+    import rtabmap_amd
+    n_sig = words.shape[0]
+    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=N_WORDS + 1024, sig_capacity=n_sig + 64, pipeline=True)
+    load_engine(eng, vocab, words)
+    cap = n_sig + 16
+    d_words = torch.zeros(Q, dtype=torch.int32, device="cuda")
+    d_like = torch.zeros(cap, dtype=torch.float32, device="cuda")
+    ids_equal, argmax_equal, max_rel, n_cmp = True, True, 0.0, 0
     t_knn = t_lik = 0.0
-    for f in range(n_frames):
-        desc = frames[f]
+    for t in range(n_frames):
+        desc = frames_np[t]
+        first_new = m.vwd.last_word_id + 1
         t1 = time.perf_counter()
-        if index is not None:
-            idx, dist = index.knn(desc, k=2, checks=32, cores=1)
-        else:
-            idx, dist = O.knn2_linear(vocab, desc)
-        accept = ~(dist[:, 0] > np.float32(NNDR) * dist[:, 1])
-        qwords = (idx[accept, 0] + 1).astype(np.int32)
+        sid, exp = m.update(desc)                              # exact linear 2-NN + addNewWords, 1 thread
         t2 = time.perf_counter()
-        m.compute_likelihood(qwords, ids)
+        eng.frame_dev(torch.from_numpy(desc).cuda().data_ptr(), Q, sid, float(m.num_signatures()), d_words.data_ptr(), d_like.data_ptr(), cap,
+                      first_new_word_id=first_new)
+        eng.synchronize()
+        got = d_words.cpu().numpy()
+        ids_equal &= bool(np.where(got < 0, first_new - got - 1, got).tolist() == exp)
+        live = np.array(m.signature_ids(), np.int32)
         t3 = time.perf_counter()
+        oi, Lo = m.compute_likelihood(np.array(exp, np.int32), live)
+        t4 = time.perf_counter()
         t_knn += t2 - t1
+        t_lik += t4 - t3
+        Lh = d_like[: n_sig + t + 1].cpu().numpy()[oi - 1]    # signature id s sits in slot s - 1
+        err = np.abs(Lh - Lo) / np.maximum(np.abs(Lo), 1e-7 / 1e-4)      # relative, with the 1e-7 absolute floor of the 1e-4 bound
+        max_rel = max(max_rel, float(err.max()))
+        n_cmp += int(Lo.size)
+        argmax_equal &= bool(int(np.argmax(Lh[:-1])) == int(np.argmax(Lo[:-1])))
+        m.forget(t + 1)
+        eng.sig_remove(t + 1)
+    eng.close()
+    return ({"frames": n_frames, "word_ids_equal": ids_equal, "likelihood_max_rel": max_rel, "likelihood_values_compared": n_cmp,
+             "argmax_equal": argmax_equal, "bound": "1e-4 relative (abs floor 1e-7)", "signatures": n_sig,
+             "path": "lcd_frame_dev (registration + retirement + TF-IDF, pipelined handle) vs oracle Memory::update + computeLikelihood"},
+            t_knn / n_frames, t_lik / n_frames)
+
+
+def cpu_baselines(vocab, frames_np, t_linear_port, t_lik_full, n_sig):
+    """(i) the reference default -- rtflann kd-tree (4 trees, 32 checks), 1 thread; (ii) the exact configuration --
+    rtflann LINEAR, 1 thread; (iii) generous -- the same rtflann code with OpenMP over the queries on every host core.  The TF-IDF
+    leg is the restated std::map Memory::computeLikelihood over the FULL signature memory (it is single-threaded in the reference)."""
+    import oracle as O
+    cores = os.cpu_count() or 1
+    out = {}
+
+    def rate(t_knn):
+        return n_sig / (t_knn + t_lik_full)
+    if O.have_ref():
+        kd = O.RefIndex(vocab, algo=O.ALGO_KDTREE, trees=4)
+        lin = O.RefIndex(vocab, algo=O.ALGO_LINEAR)
+        def timeit(f, n):
+            t0 = time.perf_counter()
+            for i in range(n):
+                f(frames_np[i % len(frames_np)])
+            return (time.perf_counter() - t0) / n
+        t_kd1 = timeit(lambda d: kd.knn(d, k=2, checks=32, cores=1), 20)
+        t_lin1 = timeit(lambda d: lin.knn(d, k=2, checks=32, cores=1), 2)
+        t_linN = timeit(lambda d: lin.knn(d, k=2, checks=32, cores=cores), 6)
+        t_kdN = timeit(lambda d: kd.knn(d, k=2, checks=32, cores=cores), 20)
+        kind = "reference"
+    else:
+        t_kd1 = t_kdN = None
+        t_lin1 = t_linear_port
+        t0 = time.perf_counter()
+        O.knn2_linear(vocab, frames_np[0], threads=cores)
+        t_linN = time.perf_counter() - t0
+        kind = "port"
+    variants = {}
+    if t_kd1 is not None:
+        variants["i_kdtree_1core"] = {"value": rate(t_kd1), "knn_ms": 1e3 * t_kd1, "cores": 1}
+        variants["iii_kdtree_all_cores"] = {"value": rate(t_kdN), "knn_ms": 1e3 * t_kdN, "cores": cores}
+    variants["ii_linear_1core"] = {"value": rate(t_lin1), "knn_ms": 1e3 * t_lin1, "cores": 1}
+    variants["iii_linear_all_cores"] = {"value": rate(t_linN), "knn_ms": 1e3 * t_linN, "cores": cores}
+    head = variants.get("i_kdtree_1core", variants["ii_linear_1core"])
+    out = {"value": head["value"], "unit": "candidates/s", "cores": 1, "kind": kind,
+           "sample": "2-NN of %d-descriptor frames over the full 49k vocabulary with the reference's own rtflann (%s) + restated std::map "
+                     "Memory::computeLikelihood over the full %d-signature memory (%.0f ms/frame, 3 frames); every variant below uses the "
+                     "same TF-IDF time" % (Q, "kd-tree 4 trees / 32 checks" if t_kd1 is not None else "exact linear port", n_sig, 1e3 * t_lik_full),
+           "tfidf_ms": 1e3 * t_lik_full, "variants": variants,
+           "best_cpu_value": max(v["value"] for v in variants.values())}
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------- extras (N = 1)
+def host_path_ms(torch, eng, frames_np, n_sig, steps=20):
+    """What a cv::Mat caller of VWDictionary::addNewWords / Memory::computeLikelihood gets: host pointers in, host pointers out
+    (lcd_quantize + lcd_sig_add + lcd_likelihood + lcd_sig_remove), PCIe and synchronisation included."""
+    sig_ids = np.arange(2000, 2000 + n_sig, dtype=np.int32)         # live ids do not matter for the cost: score whatever is live
+    next_sig, oldest = 5_000_000, 4000
+    t0 = None
+    for i in range(steps + 3):
+        if i == 3:
+            t0 = time.perf_counter()
+        w, _ = eng.quantize(frames_np[i % len(frames_np)], incremental=True, new_words_compared=True, nndr=NNDR)
+        eng.sig_add(next_sig, np.where(w > 0, w, 0).astype(np.int32))
+        eng.likelihood(w, sig_ids, float(n_sig + 1))
+        eng.sig_remove(oldest)
+        next_sig += 1
+        oldest += 1
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def with_update_ms(torch, eng, vocab, stepper, d_frames, frames_np, steps=32):
+    """The step + VWDictionary::update() (VWDictionary.cpp:475-701): the frame's word ids come back to the host (2 KB), its new
+    words are appended to the device vocabulary (lcd_vocab_append) before the next frame, and every 8th frame the words appended 8
+    frames earlier are removed again and the vocabulary is rebuilt (removeWords + the full-rebuild branch)."""
+    appended = []
+    next_id = stepper.first_new
+    t0 = None
+    for i in range(steps + 4):
+        if i == 4:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        k = i % len(d_frames)
+        stepper.first_new = next_id
+        stepper(k)
+        got = stepper.d_words.cpu().numpy()                          # synchronises: update() needs the decisions
+        new_rows, seen = [], set()
+        for j in np.flatnonzero(got < 0).tolist():
+            if got[j] not in seen:
+                seen.add(int(got[j]))
+                new_rows.append(j)
+        if new_rows:
+            ids = np.arange(next_id, next_id + len(new_rows), dtype=np.int32)
+            eng.vocab_append(frames_np[k][new_rows], ids)
+            appended.append(ids)
+            next_id += len(new_rows)
+        if i % 8 == 7 and len(appended) > 8:
+            eng.vocab_remove(appended.pop(0))
+            eng.vocab_rebuild()
+    torch.cuda.synchronize()
+    stepper.first_new = next_id
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+# ----------------------------------------------------------------------------------------------------------------- ORB stream
+def run_orb_stream(args):
+    """BASELINE.json config 3 as SURVEY.md 8d specifies it: 2 000 frames of 500 ORB descriptors against an initially EMPTY
+    incremental dictionary (NNDR 0.8), every frame also forgetting frame t - 1000, VWDictionary::update() inside the step
+    (append of the previous frame's new words, removal of unreferenced words + rebuild), TF-IDF against the working memory.
+    Runs through the C++ host mirror of the reference interface (MemoryHip over the C-ABI, host pointers); the first frames are
+    checked id for id against the oracle."""
+    import torch
+    from rtabmap_amd import synth
+    from rtabmap_amd.vwdictionary import MemoryHip
+    import oracle as O
+    n_frames, q, W, n_check = args.steps if args.steps != 200 else 2000, 500, 1000, 60
+    base = synth.vocab_orb(200000)
+    frames = [synth.queries_orb(base, q, seed=501 + t, frac_known=0.55, flip=0.04) for t in range(64)]
+    h = MemoryHip(nndr=NNDR, new_words_compared_together=True)
+    o = O.OracleMemory(strategy=O.kNNBruteForce, nndr=NNDR, new_words_compared_together=True)
+    ids_equal = True
+    t_upd = t_lik = 0.0
+    t0 = time.perf_counter()
+    for t in range(n_frames):
+        rng = np.random.default_rng(t)
+        desc = frames[t % 64] ^ np.packbits(rng.random((q, 256)) < 0.01, axis=1)        # every frame differs a little
+        t1 = time.perf_counter()
+        sid, ids = h.update(desc)
+        t2 = time.perf_counter()
+        live = np.arange(max(1, sid - W + 1), sid + 1, dtype=np.int32)
+        h.compute_likelihood(np.array(ids, np.int32), live)
+        t3 = time.perf_counter()
+        t_upd += t2 - t1
         t_lik += t3 - t2
-    per_frame = (t_knn + t_lik) / n_frames
-    return {"value": sample_sigs / per_frame, "unit": "candidates/s", "cores": 1, "kind": kind,
-            "sample": "%d frames x %d descriptors; 2-NN = %s over the full 49k vocabulary (%.1f ms/frame), TF-IDF = restated "
-                      "std::map computeLikelihood over a %d-signature memory (%.1f ms/frame); rate scaled by the sample's "
-                      "signature count" % (n_frames, Q, "reference rtflann kd-tree (4 trees, 32 checks)" if index is not None
-                                           else "exact linear port", 1e3 * t_knn / n_frames, sample_sigs, 1e3 * t_lik / n_frames)}
+        if t < n_check:
+            so, ido = o.update(desc)
+            ids_equal &= (so == sid and ido == ids)
+            if so > W:
+                o.forget(so - W)
+        if sid > W:
+            h.forget(sid - W)
+    wall = time.perf_counter() - t0
+    out = {"metric": "loop-closure candidates/sec (ORB 256-bit, incremental dictionary from empty, W=1000)", "unit": "candidates/s",
+           "value": n_frames * min(W, n_frames) / wall, "n_gpus": 1, "steps": n_frames, "warmup": 0, "ms_per_step": 1e3 * wall / n_frames,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "config 3: %d ORB frames x %d descriptors, incremental dictionary grown to %d words, update() in the step, "
+                                  "W=%d retirement, host-pointer path through the C++ mirror of VWDictionary/Memory" % (n_frames, q, h.vwd.visual_words, W),
+                      "update_ms_per_frame": 1e3 * t_upd / n_frames, "likelihood_ms_per_frame": 1e3 * t_lik / n_frames,
+                      "dictionary_words": h.vwd.visual_words},
+           "parity": {"frames_checked": n_check, "word_ids_equal": bool(ids_equal)}}
+    print(json.dumps(out), flush=True)
+    h.close()
 
 
+# ----------------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--signatures", type=int, default=N_SIG)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parallelism", choices=["replicas", "shard"], default="replicas",
-                    help="N > 1: independent frame streams per GPU (weak scaling, no data-path collective) or ONE stream with the "
-                         "vocabulary sharded by word-id range + all-gather / all-reduce per frame (strong scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (oracle build, parity block, CPU baselines)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (unpipelined, host path, with update)")
+    ap.add_argument("--pipeline", type=int, default=1, help="1: the 2-NN stage of frame t+1 overlaps the scoring of frame t (two streams)")
+    ap.add_argument("--parallelism", choices=["shard", "replicas"], default="shard",
+                    help="N > 1: ONE frame stream with the vocabulary sharded by word-id range + all-gather / all-reduce per frame (the "
+                         "north star; strong scaling), or independent frame streams per GPU (weak scaling, no data-path collective)")
+    ap.add_argument("--config", choices=["headline", "orb_stream"], default="headline")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])
+        return
 
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    local = local % torch.cuda.device_count()
+    if args.config == "orb_stream":
+        return run_orb_stream(args)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
     torch.cuda.set_device(local)
+    backend = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("LCD_BENCH_BACKEND", "nccl")      # "gloo" only for single-GPU sanity runs of the N > 1 code path
+        backend = os.environ.get("LCD_BENCH_BACKEND", "nccl" if torch.cuda.device_count() >= world else "gloo")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
+            log("[bench] rank %d: %d ranks on %d GPU(s): collectives over %s (functional run, not a measurement of xGMI)"
+                % (rank, world, torch.cuda.device_count(), backend))
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import rtabmap_amd
@@ -127,158 +420,140 @@ def main():
     stream = torch.cuda.Stream()
     n_sig = args.signatures
     shard = world > 1 and args.parallelism == "shard"
-    if shard:
-        from rtabmap_amd.sharded import ShardedLoopClosure
-        sh = ShardedLoopClosure("f32", DIM, rank=rank, world=world, device=local, stream=stream, vocab_capacity=N_WORDS + 1024,
-                                sig_capacity=n_sig + 8192)
-        eng = sh.eng
-        t0 = time.time()
-        vocab = synth.vocab_surf(N_WORDS)
-        words = synth.zipf_words(n_sig, Q, N_WORDS, seed=100000)
-        sh.load_vocabulary(vocab, np.arange(1, N_WORDS + 1, dtype=np.int32))
-        offsets = np.arange(0, (n_sig + 1) * Q, Q, dtype=np.int64)
-        for a in range(0, n_sig, 10000):
-            b = min(a + 10000, n_sig)
-            w = words[a:b].reshape(-1)
-            sh.add_signatures_bulk(np.arange(a + 1, b + 1, dtype=np.int32), offsets[a:b + 1] - offsets[a], w,
-                                   owned_mask=(w > sh.lo) & (w <= sh.hi))
-        log("[bench] rank %d: sharded state built in %.1fs (rows %d..%d)" % (rank, time.time() - t0, sh.lo, sh.hi))
-    else:
-        eng = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 1024, sig_capacity=n_sig + 8192,
-                                 stream=stream.cuda_stream)
-        vocab, words = build_state(eng, rank, world, n_sig)
+    vocab, words = make_state(n_sig)
+    cap = n_sig + args.steps + args.warmup + 4096
 
     # frames resident in HBM: revisits of earlier places (70 % of the descriptors quantise back to that place's words).
-    # replicas: every rank has its own stream of frames; shard: all ranks see the same frames.
     n_frames = min(64, max(8, args.steps))
-    rng = np.random.default_rng(7 + (0 if shard else rank))
-    src = rng.integers(0, n_sig, n_frames)
-    frames = [synth.frame_from_signature(vocab, words[s], seed=1000 * (0 if shard else rank) + i) for i, s in enumerate(src)]
-    d_frames = [torch.from_numpy(f).cuda() for f in frames]
-    d_words = torch.zeros(Q, dtype=torch.int32, device="cuda")
-    cap = n_sig + args.steps + args.warmup + 4096
-    d_like = torch.zeros(cap, dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
 
-    next_sig = n_sig + 1
-    oldest = 1
-    last_like = [None]
+    def make_frames(stream_id):
+        rng = np.random.default_rng(7 + stream_id)
+        src = rng.integers(0, n_sig, n_frames)
+        fr = [synth.frame_from_signature(vocab, words[s], seed=1000 * stream_id + i) for i, s in enumerate(src)]
+        return src, fr
 
-    def step(i):
-        nonlocal next_sig, oldest
-        if shard:
-            _, last_like[0] = sh.frame(d_frames[i % n_frames], next_sig, float(n_sig + 1), incremental=True, new_words_compared=True,
-                                       nndr=NNDR)
-            sh.retire(oldest)
-        else:
-            eng.frame_dev(d_frames[i % n_frames].data_ptr(), Q, next_sig, float(n_sig + 1), d_words.data_ptr(), d_like.data_ptr(), cap,
-                          incremental=True, new_words_compared=True, nndr=NNDR)
-            eng.sig_remove(oldest)
-        next_sig += 1
-        oldest += 1
+    results = {}
+    # ---- primary measurement
+    if shard:
+        from rtabmap_amd.sharded import ShardedLoopClosure
+        src, frames_np = make_frames(0)                    # all ranks see the same frames
+        d_frames = [torch.from_numpy(f).cuda() for f in frames_np]
+        sh = ShardedLoopClosure("f32", DIM, rank=rank, world=world, device=local, stream=stream, vocab_capacity=N_WORDS + 1024,
+                                sig_capacity=n_sig + 8192)
+        t0 = time.perf_counter()
+        sh.load_vocabulary(vocab, np.arange(1, N_WORDS + 1, dtype=np.int32))
+        w = words.reshape(-1)
+        sh.add_signatures_bulk(np.arange(1, n_sig + 1, dtype=np.int32), np.arange(0, (n_sig + 1) * Q, Q, dtype=np.int64), w,
+                               owned_mask=(w > sh.lo) & (w <= sh.hi))
+        build_s = time.perf_counter() - t0
+        state = {"next": n_sig + 1, "old": 1, "like": None, "first_new": N_WORDS + 1}
 
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    eng.profile_begin(max(10, args.steps // 5))   # HIP events around the dominant kernel of the first 20 % of the timed steps (engine stream)
-    t0 = time.perf_counter()
-    e0.record(stream)
-    for i in range(args.steps):
-        step(args.warmup + i)
-    e1.record(stream)
-    host_enqueue = time.perf_counter() - t0          # host time to enqueue the timed steps (diagnostic: launch-bound if ~ wall)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)
-    sc_ms, sc_n, sc_name = eng.profile_read_likelihood()
-    kern_ms, kern_n, kern_name = eng.profile_read()
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-
-    # sanity of the last frame: the revisited place must be the arg-max (excluding the frame itself)
-    like = (last_like[0] if shard else d_like[: n_sig + args.steps + args.warmup]).cpu().numpy()
+        def step(i):
+            _, state["like"] = sh.frame(d_frames[i % n_frames], state["next"], float(n_sig + 1), incremental=True, new_words_compared=True,
+                                        nndr=NNDR, first_new_word_id=state["first_new"])
+            sh.retire(state["old"])
+            state["next"] += 1
+            state["old"] += 1
+            state["first_new"] += Q
+        res = timed_loop(torch, dist, world, stream, step, args.steps, args.warmup, profile_eng=sh.eng)
+        roof_knn, roof_score = rooflines(sh.eng, sh.hi - sh.lo, n_sig, True)
+        like = state["like"].cpu().numpy()
+        sh.close()
+        frames_total = args.steps
+    else:
+        src, frames_np = make_frames(rank)                 # replicas: every rank has its own stream of frames
+        d_frames = [torch.from_numpy(f).cuda() for f in frames_np]
+        eng = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 1024, sig_capacity=n_sig + 8192,
+                                 stream=stream.cuda_stream, pipeline=bool(args.pipeline))
+        build_s = load_engine(eng, vocab, words)
+        log("[bench] rank %d: %d signatures bulk-loaded in %.2fs" % (rank, n_sig, build_s))
+        step = Stepper(eng, torch, d_frames, n_sig, cap)
+        res = timed_loop(torch, dist, world, stream, step, args.steps, args.warmup, profile_eng=eng)
+        roof_knn, roof_score = rooflines(eng, N_WORDS, n_sig, False)
+        like = step.d_like[: n_sig + args.steps + args.warmup].cpu().numpy()
+        frames_total = world * args.steps
+    wall = res["wall"]
+    value = frames_total * n_sig / wall
     last = (args.warmup + args.steps - 1) % n_frames
 
-    # ---- rooflines, from the events recorded inside the timed region (first 20 % of the steps).
-    # (1) 2-NN filter.  ALGORITHMIC work per launch: 2*Q*N*D = 3.136 GFLOP GEMM-equivalent over this rank's rows.
-    #     The bf16x3 filter executes three bf16 products per algorithmic product (+ the f32 augmentation step): `executed` counts
-    #     those, `achieved` only the algorithmic ones, both against the dense MFMA peak of the type the kernel multiplies in.
-    n_rows_rank = (sh.hi - sh.lo) if shard else N_WORDS
-    flops = 2.0 * Q * n_rows_rank * DIM
-    achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-    bf16 = "bf16" in kern_name
-    peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+    config = {"workload": "SURF-64 fp32 brute-force 2-NN (49k words) + NNDR + TF-IDF likelihood (%d signatures x 500 words, Zipf), "
+                          "500 desc/frame, 1 frame/step" % n_sig,
+              "frames_per_s": frames_total / wall, "device_ms_per_step": res["dev_ms"] / args.steps,
+              "host_enqueue_ms_per_step": 1e3 * res["host_enqueue"] / args.steps,
+              "step_ms_median": float(np.median(res["per_step_ms"])), "step_ms_p95": float(np.percentile(res["per_step_ms"], 95)),
+              "world_size_observed": world, "collective_backend": backend, "signatures_bulk_load_s": build_s,
+              "pipeline": "2-NN stage of frame t+1 on a second stream while frame t is registered and scored" if (args.pipeline and not shard)
+              else "one stream",
+              "parallelism": ("vocabulary sharded by word-id range over %d GPUs (all-gather top-2 + int64 all-reduce per frame)" % world) if shard
+              else ("%d independent replicas (one frame stream per GPU, no data-path collective)" % world if world > 1 else "1 GPU")}
 
-    def pmc_traffic(name):
-        # HBM traffic per launch: from the committed rocprofv3 --pmc summary (FETCH_SIZE / WRITE_SIZE cannot be read from inside
-        # the process); null when the profile is not there or was taken for another vocabulary split
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-            return pmc[name]["hbm_bytes_per_launch"] / 1e9 if (not shard and name in pmc) else None
-        except Exception:
-            return None
+    # ---- the distribution needs >= 50 frames: extra, untimed-for-`value` steps when the driver asked for fewer
+    if not shard and args.steps < 50:
+        extra = timed_loop(torch, dist, world, stream, step, 64, 0)
+        config["step_ms_median"] = float(np.median(extra["per_step_ms"]))
+        config["step_ms_p95"] = float(np.percentile(extra["per_step_ms"], 95))
+        config["distribution_from"] = "64 extra steps after the timed region"
 
-    roof_knn = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": pmc_traffic(kern_name), "traffic_unit": "GB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)", "kernel": kern_name,
-                "ms": kern_ms, "samples": kern_n, "mfma_dtype": "bf16 (3 products per fp32 product, fp32 accumulate)" if bf16 else "f32",
-                "executed_tflops": (3.0 if bf16 else 1.0) * achieved,
-                "frac_of_f32_mfma_peak": achieved / PEAK_F32_TFLOPS,
-                "algorithmic_gbps": (n_rows_rank * DIM * 4 + Q * DIM * 4 + Q * 16) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0}
-    # (2) fused TF-IDF scoring kernel (single-GPU path).  ALGORITHMIC bytes per launch: 4 B per posting of the frame's words (this
-    #     engine packs a posting in 4 B; SURVEY.md 8d budgets 8) + ni read + likelihood write (4 B per signature each).
-    roof_score = None
-    if not shard and sc_ms > 0:
-        t0h = time.time()
-        srt = np.sort(words, axis=1)
-        first = np.ones_like(srt, dtype=bool)
-        first[:, 1:] = srt[:, 1:] != srt[:, :-1]
-        npost = np.bincount(srt[first], minlength=N_WORDS + 1)              # signatures that contain each word (initial memory)
-        fw = np.unique(d_words.cpu().numpy())
-        fw = fw[(fw > 0) & (fw <= N_WORDS)]
-        p_frame = int(npost[fw].sum())
-        sc_bytes = 4.0 * p_frame + 8.0 * n_sig
-        gbps = sc_bytes / (sc_ms * 1e-3) / 1e9
-        roof_score = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-                      "traffic": pmc_traffic(sc_name), "traffic_unit": "GB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)", "kernel": sc_name,
-                      "ms": sc_ms, "samples": sc_n, "postings_per_launch": p_frame, "algorithmic_bytes_per_launch": sc_bytes}
-        log("[bench] postings of the last frame's words: %d (%.1fs)" % (p_frame, time.time() - t0h))
-    if roof_score is not None and roof_score["ms"] > roof_knn["ms"]:
-        roofline, roofline_other = roof_score, roof_knn
-    else:
-        roofline, roofline_other = roof_knn, roof_score
+    # ---- N > 1: the other parallelism, same run, secondary key
+    if world > 1 and not args.no_extras:
+        if shard:
+            src2, fr2 = make_frames(rank)
+            d_fr2 = [torch.from_numpy(f).cuda() for f in fr2]
+            eng2 = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 1024, sig_capacity=n_sig + 8192,
+                                      stream=stream.cuda_stream, pipeline=bool(args.pipeline))
+            load_engine(eng2, vocab, words)
+            st2 = Stepper(eng2, torch, d_fr2, n_sig, cap)
+            r2 = timed_loop(torch, dist, world, stream, st2, args.steps, args.warmup)
+            config["replicas_value"] = world * args.steps * n_sig / r2["wall"]
+            config["replicas_ms_per_step"] = 1e3 * r2["wall"] / args.steps
+            eng2.close()
 
     out = {
         "metric": "loop-closure candidates/sec (49k vocab, 100k signatures, 500 desc/frame)",
-        "value": (1 if shard else world) * args.steps * n_sig / wall,
-        "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "SURF-64 fp32 brute-force 2-NN (49k words) + NNDR + TF-IDF likelihood (%d signatures x 500 words, "
-                               "Zipf), 500 desc/frame, 1 frame/step" % n_sig,
-                   "frames_per_s": (1 if shard else world) * args.steps / wall, "device_ms_per_step": dev_ms / args.steps,
-                   "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
-                   "parallelism": ("vocabulary sharded by word-id range over %d GPUs (all-gather top-2 + int64 all-reduce)" % world) if shard
-                   else ("%d independent replicas (one frame stream per GPU, no data-path collective)" % world if world > 1 else "1 GPU")},
-        "roofline": roofline,
-        "roofline_other": roofline_other,
+        "dtype": "f32", "data": "synthetic", "config": config,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU leg runs at N = 1 only
-        out["cpu_baseline"] = cpu_baseline(vocab, words, frames, sample_sigs=min(10000, n_sig), n_frames=3)
+    if roof_score is not None and roof_score["ms"] > roof_knn["ms"]:
+        out["roofline"] = roof_score
+    else:
+        out["roofline"] = roof_knn
+    out["roofline_score"] = roof_score
+    out["roofline_knn"] = roof_knn
+
     if rank == 0:
         exp_top = int(src[last]) + 1
         got_top = int(np.argmax(like[:n_sig])) + 1
-        out["config"]["last_frame_top_candidate_ok"] = bool(got_top == exp_top or exp_top < oldest)
+        config["last_frame_top_candidate_ok"] = bool(got_top == exp_top or exp_top < (1 + args.warmup + args.steps))
+
+    # ---- N = 1: secondary measurements, parity, CPU baselines
+    if world == 1 and rank == 0:
+        if not args.no_extras:
+            engu = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 8192,
+                                      stream=stream.cuda_stream, pipeline=not bool(args.pipeline))
+            load_engine(engu, vocab, words)
+            stu = Stepper(engu, torch, d_frames, n_sig, cap)
+            ru = timed_loop(torch, dist, 1, stream, stu, max(50, min(args.steps, 200)), 10, profile_eng=engu)
+            ku, su = rooflines(engu, N_WORDS, n_sig, False)
+            key = "unpipelined" if args.pipeline else "pipelined"
+            config[key + "_ms_per_step"] = 1e3 * ru["wall"] / max(50, min(args.steps, 200))
+            config[key + "_kernel_ms"] = {"knn": ku["ms"], "score": su["ms"] if su else None}
+            config["with_update_ms_per_step"] = with_update_ms(torch, engu, vocab, stu, d_frames, frames_np)
+            config["host_path_ms_per_step"] = host_path_ms(torch, engu, frames_np, n_sig)
+            config["with_update_note"] = "step + D2H of the word ids + lcd_vocab_append of the frame's new words; every 8th frame " \
+                                         "lcd_vocab_remove of an older frame's words + lcd_vocab_rebuild"
+            config["host_path_note"] = "lcd_quantize + lcd_sig_add + lcd_likelihood + lcd_sig_remove from host pointers (PCIe + syncs included)"
+            engu.close()
+        if not args.no_cpu_baseline:
+            m = build_oracle(vocab, words)
+            par, t_lin_port, t_lik = parity_block(torch, vocab, words, frames_np, m)
+            out["parity"] = par
+            out["cpu_baseline"] = cpu_baselines(vocab, frames_np, t_lin_port, t_lik, n_sig)
+            out["cpu_baseline"]["gpu_over_best_cpu"] = value / out["cpu_baseline"]["best_cpu_value"]
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    eng.close()
+    if not shard:
+        eng.close()
     if world > 1:
         dist.destroy_process_group()
 

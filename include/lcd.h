@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LCD_ABI_VERSION 1
+#define LCD_ABI_VERSION 2
 
 typedef struct lcd_engine lcd_engine;
 
@@ -52,6 +52,16 @@ enum lcd_quantize_flags {
     LCD_Q_NEW_WORDS_COMPARED = 2        /* Kp/NewWordsComparedTogether: also match words created earlier in the same call */
 };
 
+/* how the squared-L2 2-NN of 64-float descriptors is computed.  Every mode returns the SAME bits (the reference's distances and
+ * tie-break): the matrix-core modes only rank candidates, an exact re-rank in the reference's arithmetic plus a completeness
+ * certificate (exact redo when it fails) produces the result.  Other descriptor types always use the exact scan. */
+enum lcd_knn_mode {
+    LCD_KNN_DEFAULT = 0,       /* = LCD_KNN_BF16X3 where it applies */
+    LCD_KNN_EXACT_VALU = 1,    /* exact vector-ALU scan only */
+    LCD_KNN_F32_MFMA = 2,      /* fp32 matrix-core filter (v_mfma_f32_32x32x2_f32) + exact re-rank */
+    LCD_KNN_BF16X3 = 3         /* bf16 matrix-core filter, three bf16 products per fp32 product + exact re-rank */
+};
+
 typedef struct lcd_config {
     int32_t struct_size;       /* sizeof(lcd_config), for ABI evolution */
     int32_t device;            /* HIP device ordinal */
@@ -60,8 +70,11 @@ typedef struct lcd_config {
     int64_t vocab_capacity;    /* initial row capacity (grows on demand) */
     int64_t sig_capacity;      /* initial signature-slot capacity (grows on demand) */
     int32_t max_queries;       /* initial per-call query capacity (Kp/MaxFeatures; grows on demand) */
-    int32_t reserved0;
+    int32_t knn_mode;          /* lcd_knn_mode, per handle */
     void*   stream;            /* optional hipStream_t to enqueue on; NULL = engine-owned stream */
+    int32_t pipeline;          /* 1: lcd_frame_dev runs the 2-NN stage of frame t+1 on an internal second stream while frame t's
+                                  registration / scoring still runs on the engine stream (see lcd_frame_args) */
+    int32_t reserved1;
 } lcd_config;
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -82,7 +95,9 @@ int  lcd_synchronize(lcd_engine* h);
 int lcd_vocab_clear(lcd_engine* h);
 /* brute-force append branch :571-609: rows appended in the given order; word_ids[i] > 0, not already present */
 int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word_ids);
-/* _removedIndexedWords (removeWords :1595-1607): rows are tombstoned at once (never returned by a search) */
+/* VWDictionary::removeWords (:1595-1607, _removedIndexedWords): rows are tombstoned at once (never returned by a search) and
+ * the words cease to exist.  As in the reference, only words without references are removed (its callers pass getUnusedWords(),
+ * Memory.cpp:2867,6906); the postings key of a removed word is recycled once the device has confirmed that. */
 int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n);
 /* full-rebuild branch :610-690: drop tombstones and reorder the live rows by ascending word id, on the device */
 int lcd_vocab_rebuild(lcd_engine* h);
@@ -129,7 +144,8 @@ int lcd_find_nn(lcd_engine* h, const void* queries, int q, const void* extra_row
 int lcd_sig_add(lcd_engine* h, int32_t sig_id, const int32_t* word_ids, int n, int32_t ni);
 /* Memory::disableWordsRef (:6877-6897) == removeAllWordRef(word, sig) for every word of the signature */
 int lcd_sig_remove(lcd_engine* h, int32_t sig_id);
-/* bulk registration (Memory::loadDataFromDb replay, Memory.cpp:447-480): sig_offsets[n_sigs+1] index word_ids */
+/* bulk registration (Memory::loadDataFromDb replay, Memory.cpp:447-480): sig_offsets[n_sigs+1] index word_ids.  One
+ * registration launch for the whole call and a fixed number of launches per 64 full buckets (16 384 signatures) sealed. */
 int lcd_sig_add_bulk(lcd_engine* h, int n_sigs, const int32_t* sig_ids, const int64_t* sig_offsets,
                      const int32_t* word_ids, const int32_t* ni);
 int lcd_sig_count(const lcd_engine* h, int64_t* live_signatures, int64_t* postings);
@@ -153,17 +169,51 @@ int lcd_adjust_likelihood_dev(lcd_engine* h, float* d_likelihood, int n, float v
 
 /* ---------------------------------------------------------------------------------------------------------------
  * device-resident frame path (no host round trip; what bench.py times).  All pointers are DEVICE pointers valid on
- * the engine's device; work is enqueued on the engine stream and NOT synchronised.
+ * the engine's device; work is enqueued and NOT synchronised (lcd_synchronize, or synchronise the engine stream).
  *
- * lcd_frame_dev == Memory::update's quantisation (addNewWords :913) -> register the frame's references ->
- * Memory::computeLikelihood against every live signature:
- *   d_descriptors [q x dim]; out d_word_ids[q] as lcd_quantize; new words are NOT added to the vocabulary here
- *   (that is VWDictionary::update() of the next frame); if sig_id != 0 the frame is registered as signature sig_id
- *   (new words excluded: they reference only this signature and cannot score any other);
- *   d_likelihood[n_slots] receives the dense likelihood over signature slots (see lcd_slots_dev), the frame's own
- *   slot included.  N is the caller's signature count. */
-int lcd_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, float nndr_ratio, int32_t sig_id,
-                  float N, int32_t* d_word_ids, float* d_likelihood, int64_t likelihood_capacity);
+ * lcd_frame_dev == Memory::update's quantisation (addNewWords :913) -> the frame's references (addWordRef :880 for
+ * existing words, the VisualWord constructor's addRef :1185 for new ones) -> Memory::computeLikelihood (Memory.cpp:2177)
+ * against every live signature -> optionally Rtabmap::adjustLikelihood (Rtabmap.cpp:5691) and the best candidate.
+ * New words are NOT added to the vocabulary here (that is VWDictionary::update() of the next frame: lcd_vocab_append). */
+typedef struct lcd_hypothesis {
+    int32_t sig_id;            /* signature with the highest likelihood among the considered ones (0: none is positive) */
+    int32_t slot;              /* its slot (-1: none) */
+    float likelihood;          /* its raw likelihood */
+    float adjusted;            /* its value after adjustLikelihood (1.0 when it is not above mean + stddev) */
+    float virtual_place;       /* adjustLikelihood's value for the virtual place (entry -1 of the reference's map) */
+    float mean, stddev;        /* over the positive likelihoods considered (uMean / sqrt(uVariance), UMath.h:419,512) */
+    int32_t n_positive;
+} lcd_hypothesis;
+
+typedef struct lcd_frame_args {
+    int32_t struct_size;               /* sizeof(lcd_frame_args) */
+    int32_t q;                         /* descriptors in the frame (1..8192) */
+    const void* d_descriptors;         /* [q x dim] */
+    int32_t flags;                     /* lcd_quantize_flags */
+    float nndr_ratio;
+    int32_t sig_id;                    /* != 0: register the frame as this signature (it must not exist yet) */
+    int32_t first_new_word_id;         /* the id the caller gives the frame's first new word (VWDictionary::_lastWordId + 1); the
+                                          k-th new word (descriptor order, the -(k+1) codes of d_word_ids) is first_new_word_id + k,
+                                          and consecutive frames must number their new words consecutively, as ++_lastWordId does
+                                          (:1185).  The frame's signature then references its new words as well, so that a later
+                                          frame matching one of them -- after lcd_vocab_append -- scores this signature.
+                                          0: new words get no references (fixed dictionary / caller never indexes them). */
+    float N;                           /* Memory::getSignatures().size() as the caller counts it (Memory.cpp:2248) */
+    int32_t exclude_recent;            /* hypothesis only: the newest `exclude_recent` slots (short-term memory + this frame,
+                                          Rtabmap.cpp:2050-2117 compares against the working memory only) are not considered */
+    int32_t* d_word_ids;               /* out [q], as lcd_quantize */
+    float* d_likelihood;               /* out, may be NULL: dense likelihood over signature slots [n_slots] (lcd_slots_dev), the
+                                          frame's own slot included */
+    int64_t likelihood_capacity;       /* floats available at d_likelihood */
+    lcd_hypothesis* d_hypothesis;      /* out, may be NULL (needs d_likelihood): 32 bytes instead of the whole vector to the host */
+    float* d_adjusted;                 /* out, may be NULL: [n_slots + 1], entry 0 = virtual place, entry 1 + slot = adjusted value
+                                          (0 for slots that are retired or not considered) */
+    float virtual_place_ratio;         /* Rtabmap/VirtualPlaceLikelihoodRatio (0 = default branch) */
+    int32_t reserved0;
+    void* ready_event;                 /* pipelined handles only: hipEvent_t after which d_descriptors is complete; NULL = it is
+                                          complete when the call is made (the 2-NN stage does not run on the engine stream) */
+} lcd_frame_args;
+int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* args);
 /* lcd_knn2 with device-resident queries and outputs (d_word_ids[q*2], d_dist[q*2]); enqueued, not synchronised */
 int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_ids, float* d_dist);
 /* ---- vocabulary sharded by word-ID range over several engines/GPUs (one handle per rank).
@@ -174,7 +224,8 @@ int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_id
  * order-free, so the result equals the single-GPU one bit for bit -- (5) lcd_finalize_dev. */
 typedef struct lcd_shard_cand { uint64_t key; int32_t word; int32_t wslot; } lcd_shard_cand;
 int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shard_cand* d_cand /* [q*2] */);
-int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, float nndr_ratio, int32_t sig_id, float N,
+int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, float nndr_ratio, int32_t sig_id,
+                        int32_t first_new_word_id /* as lcd_frame_args; new words belong to the LAST rank */, float N,
                         int rank, int world, const lcd_shard_cand* d_all_cand /* [world*q*2], rank-major */,
                         int64_t total_live_rows, int32_t* d_word_ids, int64_t* d_lfix, int64_t lfix_capacity);
 int lcd_finalize_dev(lcd_engine* h, int64_t* d_lfix, int64_t n, float* d_likelihood);
@@ -192,12 +243,21 @@ int lcd_profile_read(lcd_engine* h, float* avg_ms, int* n_samples, const char** 
 /* the same for the fused likelihood kernel of lcd_frame_dev (both series are recorded while profiling is enabled) */
 int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, const char** kernel_name);
 
+/* the work of ONE scoring launch for the words of the last frame (diagnostic, synchronises): out8[0] bytes of dense count rows
+ * read, [1] sparse postings read (4 B each), [2] directory lookups, [3] lookups that found the word, [4] entries of the open
+ * bucket's log (8 B each), [5] postings of the frame's words over all live signatures (the P of SURVEY.md 8d), [6] unique
+ * words of the frame, [7] of them with dense rows */
+int lcd_profile_score_work(lcd_engine* h, int64_t* out8);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * statistics (names follow Statistics.h:178,202,209-212 where one exists) */
 typedef struct lcd_stats {
     int64_t vocab_rows, vocab_live;        /* Keypoint/Dictionary_size */
     int64_t signatures, postings;
     int64_t knn_launches, likelihood_launches, rebuilds;
+    int64_t buckets_sealed;                /* 256-signature blocks of the inverted index regrouped on the device */
+    int64_t word_slots;                    /* postings keys in use (recycled when words are removed) */
+    int64_t dense_words;                   /* words whose postings are kept as dense count rows (last value the device reported) */
     int64_t bytes_device;                  /* HBM held by the handle */
     int64_t knn_last_fallback_queries;     /* queries of the LAST 2-NN call that the MFMA certificate sent to the exact scan */
     double knn_max_err_ratio;              /* largest |filter score - exact distance| / eps seen by the re-rank so far (must stay < 1) */

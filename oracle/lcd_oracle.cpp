@@ -816,6 +816,47 @@ int orc_mem_add_signature(void* h, const int* wordIds, int n) {
     m->signatures.insert(m->signatures.end(), std::make_pair(id, s));
     return id;
 }
+// The same state as n_sigs calls of orc_mem_add_signature (rows of `q` word ids), built fast: the new signature ids are larger
+// than every id already referenced, so each std::map insertion happens at the end (O(1) with a hint) and the words are found
+// through a direct index instead of the id map.  Test glue for the 100k-signature memories of bench.py / the headline-size test
+// (the reference fills its maps the slow way, through addWordRef, Memory.cpp:447-480); tests/test_oracle_bulk.py pins it
+// against the call-by-call construction.  Returns the first new signature id.
+int orc_mem_add_signatures_bulk(void* h, const int* wordIds, int n_sigs, int q) {
+    Memory* m = (Memory*)h;
+    int maxId = 0;
+    for (std::map<int, VisualWord*>::iterator i = m->vwd.visualWords.begin(); i != m->vwd.visualWords.end(); ++i) if (i->first > maxId) maxId = i->first;
+    std::vector<VisualWord*> byId((size_t)maxId + 1, (VisualWord*)0);
+    for (std::map<int, VisualWord*>::iterator i = m->vwd.visualWords.begin(); i != m->vwd.visualWords.end(); ++i) byId[i->first] = i->second;
+    const int first = m->idCount + 1;
+    std::vector<std::pair<int, int> > sorted((size_t)q);
+    for (int s = 0; s < n_sigs; ++s) {
+        const int id = ++m->idCount;
+        const int* w = wordIds + (size_t)s * q;
+        Signature* sg = new Signature(); sg->id = id; sg->enabled = true;
+        for (int k = 0; k < q; ++k) sorted[k] = std::make_pair(w[k], k);
+        std::stable_sort(sorted.begin(), sorted.end());          // multimap order: by word id, equal ids in insertion order
+        for (int k = 0; k < q; ++k) sg->words.insert(sg->words.end(), sorted[k]);
+        for (int k = 0; k < q;) {
+            int e = k;
+            while (e < q && sorted[e].first == sorted[k].first) ++e;
+            const int word = sorted[k].first;
+            if (word > 0 && word <= maxId && byId[word]) {
+                VisualWord* vw = byId[word];
+                if (!vw->references.empty() && vw->references.rbegin()->first >= id) {       // not the fast case: fall back
+                    for (int r = k; r < e; ++r) m->vwd.addWordRef(word, id);
+                } else {
+                    vw->references.insert(vw->references.end(), std::make_pair(id, e - k));
+                    vw->totalReferences += e - k;
+                    m->vwd.totalActiveReferences += e - k;
+                    if (vw->references.size() == 1) m->vwd.unusedWords.erase(word);
+                }
+            }
+            k = e;
+        }
+        m->signatures.insert(m->signatures.end(), std::make_pair(id, sg));
+    }
+    return first;
+}
 // same, with an explicit signature id (fixtures: the virtual place is id -1, Memory.cpp:71)
 int orc_mem_add_signature_with_id(void* h, int id, const int* wordIds, int n) {
     Memory* m = (Memory*)h;

@@ -77,6 +77,7 @@ def lib():
         L.orc_mem_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_mem_add_signature.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_mem_add_signature_with_id.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_mem_add_signatures_bulk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_mem_forget.argtypes = [C.c_void_p, C.c_int]
         L.orc_mem_get_ni.argtypes = [C.c_void_p, C.c_int]
         L.orc_mem_num_signatures.argtypes = [C.c_void_p]
@@ -329,6 +330,11 @@ class OracleMemory:
     def add_signature(self, word_ids):
         a = np.ascontiguousarray(word_ids, dtype=np.int32)
         return lib().orc_mem_add_signature(self.h, _ptr(a), a.shape[0])
+
+    def add_signatures_bulk(self, words):
+        """words: [n_sigs, q] int32.  Same state as add_signature row by row (see lcd_oracle.cpp); returns the first new id."""
+        a = np.ascontiguousarray(words, dtype=np.int32)
+        return lib().orc_mem_add_signatures_bulk(self.h, _ptr(a), a.shape[0], a.shape[1])
 
     def add_signature_with_id(self, sig_id, word_ids):
         a = np.ascontiguousarray(word_ids, dtype=np.int32)

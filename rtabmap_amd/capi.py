@@ -22,19 +22,37 @@ SYMBOLS = [
     "lcd_vocab_clear", "lcd_vocab_append", "lcd_vocab_remove", "lcd_vocab_rebuild", "lcd_vocab_count", "lcd_vocab_read",
     "lcd_knn2", "lcd_selfdist", "lcd_quantize", "lcd_find_nn",
     "lcd_sig_add", "lcd_sig_remove", "lcd_sig_add_bulk", "lcd_sig_count", "lcd_word_nrefs",
-    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_adjust_likelihood_dev", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood",
+    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_adjust_likelihood_dev", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood", "lcd_profile_score_work",
 ]
+
+
+LCD_KNN_DEFAULT, LCD_KNN_EXACT_VALU, LCD_KNN_F32_MFMA, LCD_KNN_BF16X3 = 0, 1, 2, 3
+KNN_MODES = {None: 0, "default": 0, "valu": 1, "exact": 1, "mfma32": 2, "f32": 2, "bf16": 3, "bf16x3": 3}
 
 
 class LcdConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("dtype", C.c_int32), ("dim", C.c_int32),
                 ("vocab_capacity", C.c_int64), ("sig_capacity", C.c_int64), ("max_queries", C.c_int32),
-                ("reserved0", C.c_int32), ("stream", C.c_void_p)]
+                ("knn_mode", C.c_int32), ("stream", C.c_void_p), ("pipeline", C.c_int32), ("reserved1", C.c_int32)]
+
+
+class LcdHypothesis(C.Structure):
+    _fields_ = [("sig_id", C.c_int32), ("slot", C.c_int32), ("likelihood", C.c_float), ("adjusted", C.c_float),
+                ("virtual_place", C.c_float), ("mean", C.c_float), ("stddev", C.c_float), ("n_positive", C.c_int32)]
+
+
+class LcdFrameArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("q", C.c_int32), ("d_descriptors", C.c_void_p), ("flags", C.c_int32),
+                ("nndr_ratio", C.c_float), ("sig_id", C.c_int32), ("first_new_word_id", C.c_int32), ("N", C.c_float),
+                ("exclude_recent", C.c_int32), ("d_word_ids", C.c_void_p), ("d_likelihood", C.c_void_p),
+                ("likelihood_capacity", C.c_int64), ("d_hypothesis", C.c_void_p), ("d_adjusted", C.c_void_p),
+                ("virtual_place_ratio", C.c_float), ("reserved0", C.c_int32), ("ready_event", C.c_void_p)]
 
 
 class LcdStats(C.Structure):
     _fields_ = [("vocab_rows", C.c_int64), ("vocab_live", C.c_int64), ("signatures", C.c_int64), ("postings", C.c_int64),
                 ("knn_launches", C.c_int64), ("likelihood_launches", C.c_int64), ("rebuilds", C.c_int64),
+                ("buckets_sealed", C.c_int64), ("word_slots", C.c_int64), ("dense_words", C.c_int64),
                 ("bytes_device", C.c_int64), ("knn_last_fallback_queries", C.c_int64), ("knn_max_err_ratio", C.c_double)]
 
 
@@ -91,10 +109,10 @@ def load():
     L.lcd_likelihood.argtypes = [vp, vp, C.c_int, vp, C.c_int, f32, vp]
     L.lcd_adjust_likelihood.argtypes = [vp, vp, C.c_int, f32]
     L.lcd_adjust_likelihood_dev.argtypes = [vp, vp, C.c_int, f32]
-    L.lcd_frame_dev.argtypes = [vp, vp, C.c_int, C.c_int, f32, i32, f32, vp, vp, i64]
+    L.lcd_frame_dev.argtypes = [vp, C.POINTER(LcdFrameArgs)]
     L.lcd_knn2_dev.argtypes = [vp, vp, C.c_int, vp, vp]
     L.lcd_shard_knn2_dev.argtypes = [vp, vp, C.c_int, vp]
-    L.lcd_shard_frame_dev.argtypes = [vp, vp, C.c_int, C.c_int, f32, i32, f32, C.c_int, C.c_int, vp, i64, vp, vp, i64]
+    L.lcd_shard_frame_dev.argtypes = [vp, vp, C.c_int, C.c_int, f32, i32, i32, f32, C.c_int, C.c_int, vp, i64, vp, vp, i64]
     L.lcd_finalize_dev.argtypes = [vp, vp, i64, vp]
     L.lcd_slots_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.lcd_stream.argtypes = [vp]
@@ -103,6 +121,7 @@ def load():
     L.lcd_profile_read.argtypes = [vp, C.POINTER(f32), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
     L.lcd_profile_read_likelihood.argtypes = [vp, C.POINTER(f32), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
     L.lcd_get_stats.argtypes = [vp, C.POINTER(LcdStats)]
+    L.lcd_profile_score_work.argtypes = [vp, C.POINTER(i64)]
     _lib = L
     return L
 
@@ -114,12 +133,14 @@ def _p(a):
 class Engine:
     """One lcd_engine handle.  numpy in / numpy out through the C-ABI; *_dev methods take raw device pointers."""
 
-    def __init__(self, dtype, dim, device=0, vocab_capacity=0, sig_capacity=0, stream=None):
+    def __init__(self, dtype, dim, device=0, vocab_capacity=0, sig_capacity=0, stream=None, knn_mode=None, pipeline=False):
         self.L = load()
         self.dtype = LCD_F32 if dtype in (LCD_F32, np.float32, "f32") else LCD_U8
         self.np_dtype = np.float32 if self.dtype == LCD_F32 else np.uint8
         self.dim = int(dim)
-        cfg = LcdConfig(C.sizeof(LcdConfig), device, self.dtype, self.dim, vocab_capacity, sig_capacity, 0, 0, stream)
+        mode = KNN_MODES[knn_mode] if (knn_mode is None or isinstance(knn_mode, str)) else int(knn_mode)
+        cfg = LcdConfig(C.sizeof(LcdConfig), device, self.dtype, self.dim, vocab_capacity, sig_capacity, 0, mode, stream,
+                        1 if pipeline else 0, 0)
         h = C.c_void_p()
         rc = self.L.lcd_create(C.byref(cfg), C.byref(h))
         if rc != LCD_OK:
@@ -255,10 +276,13 @@ class Engine:
 
     # ---- device-resident frame path
     def frame_dev(self, d_desc_ptr, q, sig_id, N, d_word_ids_ptr, d_like_ptr, like_capacity, incremental=True,
-                  new_words_compared=True, nndr=0.8):
+                  new_words_compared=True, nndr=0.8, first_new_word_id=0, d_hypothesis_ptr=None, d_adjusted_ptr=None,
+                  exclude_recent=0, virtual_place_ratio=0.0, ready_event=None):
         flags = (LCD_Q_INCREMENTAL if incremental else 0) | (LCD_Q_NEW_WORDS_COMPARED if new_words_compared else 0)
-        self._ck(self.L.lcd_frame_dev(self.h, d_desc_ptr, q, flags, nndr, sig_id, float(N), d_word_ids_ptr, d_like_ptr,
-                                      like_capacity))
+        a = LcdFrameArgs(C.sizeof(LcdFrameArgs), q, d_desc_ptr, flags, nndr, sig_id, first_new_word_id, float(N), exclude_recent,
+                         d_word_ids_ptr, d_like_ptr, like_capacity, d_hypothesis_ptr, d_adjusted_ptr, virtual_place_ratio, 0,
+                         ready_event)
+        self._ck(self.L.lcd_frame_dev(self.h, C.byref(a)))
 
     def knn2_dev(self, d_queries_ptr, q, d_word_ids_ptr, d_dist_ptr):
         self._ck(self.L.lcd_knn2_dev(self.h, d_queries_ptr, q, d_word_ids_ptr, d_dist_ptr))
@@ -267,10 +291,10 @@ class Engine:
         self._ck(self.L.lcd_shard_knn2_dev(self.h, d_desc_ptr, q, d_cand_ptr))
 
     def shard_frame_dev(self, d_desc_ptr, q, sig_id, N, rank, world, d_all_cand_ptr, total_live_rows, d_word_ids_ptr, d_lfix_ptr,
-                        lfix_capacity, incremental=True, new_words_compared=True, nndr=0.8):
+                        lfix_capacity, incremental=True, new_words_compared=True, nndr=0.8, first_new_word_id=0):
         flags = (LCD_Q_INCREMENTAL if incremental else 0) | (LCD_Q_NEW_WORDS_COMPARED if new_words_compared else 0)
-        self._ck(self.L.lcd_shard_frame_dev(self.h, d_desc_ptr, q, flags, nndr, sig_id, float(N), rank, world, d_all_cand_ptr,
-                                            total_live_rows, d_word_ids_ptr, d_lfix_ptr, lfix_capacity))
+        self._ck(self.L.lcd_shard_frame_dev(self.h, d_desc_ptr, q, flags, nndr, sig_id, first_new_word_id, float(N), rank, world,
+                                            d_all_cand_ptr, total_live_rows, d_word_ids_ptr, d_lfix_ptr, lfix_capacity))
 
     def finalize_dev(self, d_lfix_ptr, n, d_like_ptr):
         self._ck(self.L.lcd_finalize_dev(self.h, d_lfix_ptr, n, d_like_ptr))
@@ -295,6 +319,13 @@ class Engine:
         ms, n, name = C.c_float(), C.c_int(), C.c_char_p()
         self._ck(self.L.lcd_profile_read_likelihood(self.h, C.byref(ms), C.byref(n), C.byref(name)))
         return ms.value, n.value, (name.value or b"").decode()
+
+    def profile_score_work(self):
+        out = (C.c_int64 * 8)()
+        self._ck(self.L.lcd_profile_score_work(self.h, out))
+        keys = ["dense_row_bytes", "sparse_postings", "directory_lookups", "directory_hits", "open_log_entries", "postings",
+                "unique_words", "dense_words"]
+        return {k: int(v) for k, v in zip(keys, out)}
 
     def stats(self):
         s = LcdStats()

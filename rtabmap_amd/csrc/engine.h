@@ -44,7 +44,21 @@ struct lcd_engine {
         d_n_new, d_tmp_i32, d_extra_rows, d_extra_id, d_extra_word, d_extra_dist, d_extra_row, d_like, d_slots, d_bits, row_norm, norm_max, d_partial2, d_partial3, d_fail_list, d_fail_count;
     bool fail_count_clean = false;                      // d_fail_count[0..1] known to be zero (the fused frame tail resets them)
     int knn_mode = 2;                                   // f32 dim 64: 2 = bf16x3 MFMA filter + exact re-rank (default), 1 = f32 MFMA filter
-                                                        // + exact re-rank, 0 = exact VALU scan only (LCD_KNN_MODE = bf16 | mfma32 | valu)
+                                                        // + exact re-rank, 0 = exact VALU scan only (lcd_config.knn_mode)
+    // ---- pipelined frames (lcd_config.pipeline): the 2-NN stage of a frame runs on `kstream`, its registration / scoring on
+    // `stream`; the scratch the two stages share exists twice (the set in use above and `alt`), swapped every frame
+    hipStream_t kstream = nullptr;                      // NULL: not pipelined
+    hipStream_t kst = nullptr;                          // the stream the 2-NN stage is being enqueued on right now
+    struct AltScratch {
+        lcd::DevBuf d_knn_row, d_knn_word, d_knn_dist, d_selfdist, d_bits, d_partial2, d_partial3, d_fail_list, d_fail_count, d_out_wslot;
+        bool fail_count_clean = false;
+    } alt;
+    int ks_idx = 0;                                     // which of the two sets is the current one
+    int ks_q[2] = {0, 0};                               // queries each set has been sized for
+    hipEvent_t ev_knn[2] = {nullptr, nullptr};          // 2-NN stage of the frame that uses set i finished (recorded on kstream)
+    hipEvent_t ev_tail[2] = {nullptr, nullptr};         // the frame tail that read set i finished (recorded on stream)
+    bool k_busy = false;                                // work may be in flight on kstream
+    int sync_all();                                     // both streams drained
     lcd::PinBuf h_in, h_out, h_out2;
 
     // ---- inverted index / TF-IDF

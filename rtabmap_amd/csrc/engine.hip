@@ -14,6 +14,8 @@
 
 using namespace lcd;
 
+static_assert(sizeof(lcd::HypothesisOut) == sizeof(lcd_hypothesis), "lcd_hypothesis is the kernel's output record");
+
 // row of a live word, -1 if absent
 int lcd_engine::find_row(int32_t word_id) {
     if (rows_sorted) {
@@ -36,11 +38,20 @@ int lcd_engine::find_row(int32_t word_id) {
 #define LCD_HIP(h, x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return (h)->hip_fail(e__, #x); } while (0)
 #define LCD_DEV(h) LCD_HIP(h, hipSetDevice((h)->device))
 
-namespace {
+int lcd_engine::sync_all() {
+    if (kstream && k_busy) {
+        hipError_t e = hipStreamSynchronize(kstream);
+        if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(kstream)");
+        k_busy = false;
+    }
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(stream)");
+    return LCD_OK;
+}
+// entries that use the 2-NN scratch or change what the 2-NN stage reads: the second stream of a pipelined handle must be idle
+#define LCD_JOIN_K(h) do { if ((h)->kstream && (h)->k_busy) { LCD_HIP(h, hipStreamSynchronize((h)->kstream)); (h)->k_busy = false; } } while (0)
 
-struct HandleGuard {   // every entry: select the device, clear the previous error
-    lcd_engine* h;
-};
+namespace {
 
 inline hipError_t dreserve(lcd_engine* h, DevBuf& b, size_t bytes, size_t keep = 0) {
     return b.reserve(bytes, keep, h->stream, &h->bytes_device);
@@ -88,22 +99,22 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
         const bool prof = h->prof_cap > 0 && h->prof_n < h->prof_cap;
         LCD_HIP(h, launch_knn_bf16(h->kdim, vocab, h->vocab_bf.p, h->row_norm.as<float>(), h->norm_max.as<uint32_t>(), row_id, d_queries, mp,
                                    h->d_partial2.p, o_row, o_word, o_dist, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(),
-                                   h->stream, prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr,
+                                   h->kst, prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr,
                                    !h->fail_count_clean, cb, cb != nullptr));
         h->fail_count_clean = false;
         if (prof) { h->prof_n += 1; h->prof_kernel = "knn_bf16_filter_kernel"; }
         LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
         if (defer_redo) fill_redo(h, defer_redo, vocab, row_id, (int)n_rows, d_queries, o_row, o_word, o_dist, cb);
         else LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(),
-                                          h->d_fail_count.as<int32_t>(), h->d_partial3.p, o_row, o_word, o_dist, h->stream, cb));
+                                          h->d_fail_count.as<int32_t>(), h->d_partial3.p, o_row, o_word, o_dist, h->kst, cb));
     } else if (mfma) {
         const MfmaPlan mp = knn_mfma_plan(q, (int)n_rows);
         LCD_HIP(h, dreserve(h, h->d_partial2, knn_mfma_partial_bytes(mp)));
         LCD_HIP(h, dreserve(h, h->d_fail_list, (size_t)q * 4));
         const bool prof = h->prof_cap > 0 && h->prof_n < h->prof_cap;
-        if (cb) LCD_HIP(h, launch_selfdist(h->dtype, h->kdim, d_queries, q, const_cast<float*>(cb->selfdist), cb->ld, h->stream));
+        if (cb) LCD_HIP(h, launch_selfdist(h->dtype, h->kdim, d_queries, q, const_cast<float*>(cb->selfdist), cb->ld, h->kst));
         LCD_HIP(h, launch_knn_mfma(h->kdim, vocab, h->row_norm.as<float>(), h->norm_max.as<uint32_t>(), row_id, d_queries, mp, h->d_partial2.p,
-                                   o_row, o_word, o_dist, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(), h->stream,
+                                   o_row, o_word, o_dist, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(), h->kst,
                                    prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr,
                                    !h->fail_count_clean, cb));
         h->fail_count_clean = false;
@@ -112,14 +123,14 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
         LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
         if (defer_redo) fill_redo(h, defer_redo, vocab, row_id, (int)n_rows, d_queries, o_row, o_word, o_dist, cb);
         else LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(),
-                                          h->d_fail_count.as<int32_t>(), h->d_partial3.p, o_row, o_word, o_dist, h->stream, cb));
+                                          h->d_fail_count.as<int32_t>(), h->d_partial3.p, o_row, o_word, o_dist, h->kst, cb));
     } else {
         LCD_HIP(h, dreserve(h, h->d_partial, knn_partial_bytes(p)));
         const bool prof = main_vocab && h->prof_cap > 0 && h->prof_n < h->prof_cap;
-        if (prof) LCD_HIP(h, hipEventRecord(h->prof_ev[2 * h->prof_n], h->stream));
-        LCD_HIP(h, launch_knn2_partial(h->dtype, h->kdim, vocab, row_id, d_queries, p, h->d_partial.as<uint64_t>(), h->stream));
-        if (prof) { LCD_HIP(h, hipEventRecord(h->prof_ev[2 * h->prof_n + 1], h->stream)); h->prof_n += 1; h->prof_kernel = h->dtype == LCD_F32 ? "knn2_l2_kernel" : "knn2_hamming_kernel"; }
-        LCD_HIP(h, launch_knn2_merge(h->dtype, p, h->d_partial.as<uint64_t>(), row_id, o_row, o_word, o_dist, h->stream));
+        if (prof) LCD_HIP(h, hipEventRecord(h->prof_ev[2 * h->prof_n], h->kst));
+        LCD_HIP(h, launch_knn2_partial(h->dtype, h->kdim, vocab, row_id, d_queries, p, h->d_partial.as<uint64_t>(), h->kst));
+        if (prof) { LCD_HIP(h, hipEventRecord(h->prof_ev[2 * h->prof_n + 1], h->kst)); h->prof_n += 1; h->prof_kernel = h->dtype == LCD_F32 ? "knn2_l2_kernel" : "knn2_hamming_kernel"; }
+        LCD_HIP(h, launch_knn2_merge(h->dtype, p, h->d_partial.as<uint64_t>(), row_id, o_row, o_word, o_dist, h->kst));
     }
     h->knn_launches += 1;
     return LCD_OK;
@@ -155,6 +166,7 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
     *out = nullptr;
     if (cfg->struct_size != (int32_t)sizeof(lcd_config)) return LCD_ERR_INVALID;
     if (cfg->dim <= 0 || cfg->dim > 4096 || (cfg->dtype != LCD_F32 && cfg->dtype != LCD_U8)) return LCD_ERR_INVALID;
+    if (cfg->knn_mode < LCD_KNN_DEFAULT || cfg->knn_mode > LCD_KNN_BF16X3) return LCD_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return LCD_ERR_HIP;
     if (hipSetDevice(cfg->device) != hipSuccess) return LCD_ERR_HIP;
@@ -180,9 +192,16 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
     if (e == hipSuccess) e = h->row_norm.reserve(((size_t)vcap + 1) * 8, 0, h->stream, &h->bytes_device);
     if (e == hipSuccess) e = h->d_fail_count.reserve(64, 0, h->stream, &h->bytes_device);   // [0] rejected, [1] arrivals, [2] max err / eps
     if (e == hipSuccess) e = hipMemsetAsync(h->d_fail_count.p, 0, 64, h->stream);
-    {
-        const char* m = getenv("LCD_KNN_MODE");
-        if (m && *m) h->knn_mode = (m[0] == 'v' || m[0] == '0') ? 0 : (m[0] == 'm' || m[0] == 'f' || m[0] == '1') ? 1 : 2;
+    h->knn_mode = cfg->knn_mode == LCD_KNN_EXACT_VALU ? 0 : cfg->knn_mode == LCD_KNN_F32_MFMA ? 1 : 2;
+    h->kst = h->stream;
+    if (cfg->pipeline) {
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->kstream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = h->alt.d_fail_count.reserve(64, 0, h->stream, &h->bytes_device);
+        if (e == hipSuccess) e = hipMemsetAsync(h->alt.d_fail_count.p, 0, 64, h->stream);
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+            e = hipEventCreateWithFlags(&h->ev_knn[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_tail[i], hipEventDisableTiming);
+        }
     }
     if (e == hipSuccess) e = h->tfidf.init(h->stream, &h->bytes_device, cfg->sig_capacity);
     if (e != hipSuccess) { lcd_destroy(h); return LCD_ERR_HIP; }
@@ -193,8 +212,16 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
 void lcd_destroy(lcd_engine* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->kstream) (void)hipStreamSynchronize(h->kstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->tfidf.destroy();
+    for (int i = 0; i < 2; ++i) { if (h->ev_knn[i]) (void)hipEventDestroy(h->ev_knn[i]); if (h->ev_tail[i]) (void)hipEventDestroy(h->ev_tail[i]); }
+    {
+        DevBuf* alts[] = {&h->alt.d_knn_row, &h->alt.d_knn_word, &h->alt.d_knn_dist, &h->alt.d_selfdist, &h->alt.d_bits, &h->alt.d_partial2,
+                          &h->alt.d_partial3, &h->alt.d_fail_list, &h->alt.d_fail_count, &h->alt.d_out_wslot};
+        for (DevBuf* d : alts) d->release(&h->bytes_device);
+    }
+    if (h->kstream) (void)hipStreamDestroy(h->kstream);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->prof2_ev) (void)hipEventDestroy(e);
     DevBuf* all[] = {&h->vocab, &h->row_id, &h->row_wslot, &h->vocab_alt, &h->row_id_alt, &h->row_wslot_alt, &h->d_queries,
@@ -213,8 +240,7 @@ const char* lcd_last_error(const lcd_engine* h) { return h ? h->err.c_str() : "n
 int lcd_synchronize(lcd_engine* h) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
-    LCD_HIP(h, hipStreamSynchronize(h->stream));
-    return LCD_OK;
+    return h->sync_all();
 }
 
 void* lcd_stream(lcd_engine* h) { return h ? (void*)h->stream : nullptr; }
@@ -223,7 +249,7 @@ void* lcd_stream(lcd_engine* h) { return h ? (void*)h->stream : nullptr; }
 int lcd_vocab_clear(lcd_engine* h) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
-    LCD_HIP(h, hipStreamSynchronize(h->stream));
+    { int rc = h->sync_all(); if (rc) return rc; }
     h->n_rows = 0; h->n_live = 0;
     h->h_row_key.clear();
     h->h_row_live.clear();
@@ -238,9 +264,16 @@ int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word
     LCD_DEV(h);
     if (n < 0 || (n > 0 && (!rows || !word_ids))) return h->fail(LCD_ERR_INVALID, "lcd_vocab_append: null input");
     if (n == 0) return LCD_OK;
+    { int rc = h->sync_all(); if (rc) return rc; }                   // the 2-NN stage of a pipelined frame may still read the vocabulary
     for (int i = 0; i < n; ++i) {
         if (word_ids[i] <= 0) return h->fail(LCD_ERR_INVALID, "lcd_vocab_append: word ids must be > 0");
         if (h->find_row(word_ids[i]) >= 0) return h->fail(LCD_ERR_STATE, "lcd_vocab_append: word already in the vocabulary");
+    }
+    {   // the same id twice in one call would create two live rows for one word
+        std::vector<int32_t> sorted(word_ids, word_ids + n);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+            return h->fail(LCD_ERR_INVALID, "lcd_vocab_append: duplicate word id in the call");
     }
     const int64_t total = h->n_rows + n;
     if (total > 0x7FFFFFF0ll) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_vocab_append: more than 2^31 rows");
@@ -261,7 +294,7 @@ int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word
     int32_t* ws = ids + n;
     for (int i = 0; i < n; ++i) {
         ids[i] = word_ids[i];
-        LCD_HIP(h, h->tfidf.wslot_of(word_ids[i], &ws[i]));
+        LCD_HIP(h, h->tfidf.wslot_of(word_ids[i], true, &ws[i]));
     }
     LCD_HIP(h, hipMemcpyAsync((char*)h->vocab.p + (size_t)h->n_rows * h->row_bytes, st, rb, hipMemcpyHostToDevice, h->stream));
     LCD_HIP(h, hipMemcpyAsync(h->row_id.as<int32_t>() + h->n_rows, ids, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
@@ -292,12 +325,19 @@ int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n) {
     LCD_DEV(h);
     if (n < 0 || (n > 0 && !word_ids)) return h->fail(LCD_ERR_INVALID, "lcd_vocab_remove: null input");
     if (n == 0) return LCD_OK;
+    { int rc = h->sync_all(); if (rc) return rc; }
     std::vector<int32_t> rows;
     rows.reserve(n);
     for (int i = 0; i < n; ++i) {
         const int r = h->find_row(word_ids[i]);
         if (r < 0) return h->fail(LCD_ERR_STATE, "lcd_vocab_remove: word not in the vocabulary");
         rows.push_back(r);
+    }
+    {   // the same word twice would be counted out of n_live twice
+        std::vector<int32_t> sorted(rows);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+            return h->fail(LCD_ERR_INVALID, "lcd_vocab_remove: duplicate word id in the call");
     }
     LCD_HIP(h, dreserve(h, h->d_tmp_i32, (size_t)n * 4));
     LCD_HIP(h, h->h_in.reserve((size_t)n * 4));
@@ -308,12 +348,15 @@ int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n) {
     LCD_HIP(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < n; ++i) { h->h_row_live[rows[i]] = 0; if (h->word_row_valid) h->word_row.erase(word_ids[i]); }
     h->n_live -= n;
+    // removeWords: the words are gone; their postings keys come back once the device has found them unreferenced
+    LCD_HIP(h, h->tfidf.release_words(word_ids, n));
     return LCD_OK;
 }
 
 int lcd_vocab_rebuild(lcd_engine* h) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
+    { int rc = h->sync_all(); if (rc) return rc; }
     // permutation: live rows ordered by ascending word id (VWDictionary.cpp:636-660 walks std::map<int,VisualWord*>).
     // Word ids only grow in normal operation, so the live rows are already ascending and this is a stable compaction;
     // the sort is only needed after out-of-order appends (re-activated old words).
@@ -398,6 +441,7 @@ int lcd_vocab_read(lcd_engine* h, int64_t first, int n, void* out_rows, int32_t*
 int lcd_knn2(lcd_engine* h, const void* queries, int q, int32_t* out_word_ids, float* out_dist) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
+    LCD_JOIN_K(h);
     if (q < 0 || (q > 0 && (!queries || !out_word_ids || !out_dist))) return h->fail(LCD_ERR_INVALID, "lcd_knn2: null input");
     if (q == 0) return LCD_OK;
     int rc = upload_rows(h, queries, q, h->d_queries);
@@ -413,6 +457,7 @@ int lcd_knn2(lcd_engine* h, const void* queries, int q, int32_t* out_word_ids, f
 int lcd_selfdist(lcd_engine* h, const void* queries, int q, float* out_qxq) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
+    LCD_JOIN_K(h);
     if (q < 0 || (q > 0 && (!queries || !out_qxq))) return h->fail(LCD_ERR_INVALID, "lcd_selfdist: null input");
     if (q == 0) return LCD_OK;
     int rc = upload_rows(h, queries, q, h->d_queries);
@@ -456,7 +501,7 @@ static int prepare_resolve(lcd_engine* h, const void* d_desc, int q, int flags, 
                       h->d_knn_dist);
         if (rc) return rc;
         if (together)
-            LCD_HIP(h, launch_selfdist(h->dtype, h->kdim, d_desc, q, h->d_selfdist.as<float>(), ld, h->stream, have_index,
+            LCD_HIP(h, launch_selfdist(h->dtype, h->kdim, d_desc, q, h->d_selfdist.as<float>(), ld, h->kst, have_index,
                                        h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), h->d_bits.as<uint32_t>(), bw));
     }
     r->q = q;
@@ -474,6 +519,7 @@ static int prepare_resolve(lcd_engine* h, const void* d_desc, int q, int flags, 
     r->knn_row = h->d_knn_row.as<int32_t>();
     r->row_wslot = h->row_wslot.as<int32_t>();
     r->out_wslot = d_out_wslot;
+    r->new_ws_base = -1;
     r->fail_count = nullptr;
     return LCD_OK;
 }
@@ -491,6 +537,7 @@ static int quantize_dev(lcd_engine* h, const void* d_desc, int q, int flags, flo
 int lcd_quantize(lcd_engine* h, const void* descriptors, int q, int flags, float nndr_ratio, int32_t* out_word_ids, int32_t* out_n_new) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
+    LCD_JOIN_K(h);
     if (q < 0 || (q > 0 && (!descriptors || !out_word_ids))) return h->fail(LCD_ERR_INVALID, "lcd_quantize: null input");
     if (out_n_new) *out_n_new = 0;
     if (q == 0) return LCD_OK;
@@ -510,6 +557,7 @@ int lcd_find_nn(lcd_engine* h, const void* queries, int q, const void* extra_row
                 float nndr_ratio, int32_t* out_word_ids) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
+    LCD_JOIN_K(h);
     if (q < 0 || n_extra < 0 || (q > 0 && (!queries || !out_word_ids)) || (n_extra > 0 && (!extra_rows || !extra_word_ids)))
         return h->fail(LCD_ERR_INVALID, "lcd_find_nn: null input");
     if (q == 0) return LCD_OK;
@@ -541,21 +589,22 @@ int lcd_find_nn(lcd_engine* h, const void* queries, int q, const void* extra_row
 }
 
 // ------------------------------------------------------------------------------------------------ inverted index
-static int stage_wslots(lcd_engine* h, const int32_t* word_ids, int n, bool create) {
+// word ids of a host-side call -> device (t.d_stage); the id -> postings-key translation happens in the kernels through the
+// device copy of the table.  create: unknown ids get a postings key now (addWordRef on a word the index has not seen yet).
+static int stage_word_ids(lcd_engine* h, const int32_t* word_ids, int64_t n, bool create) {
     Tfidf& t = h->tfidf;
-    LCD_HIP(h, t.h_stage.reserve((size_t)std::max(n, 1) * 4));
-    LCD_HIP(h, dreserve(h, t.d_stage, (size_t)std::max(n, 1) * 4));
-    int32_t* st = t.h_stage.as<int32_t>();
-    for (int i = 0; i < n; ++i) {
-        int32_t ws = -1;
-        if (word_ids[i] > 0) {
-            if (create) LCD_HIP(h, t.wslot_of(word_ids[i], &ws));
-            else { auto it = t.word_wslot.find(word_ids[i]); ws = it == t.word_wslot.end() ? -1 : it->second; }
-        }
-        st[i] = ws;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t id = word_ids[i];
+        if (id <= 0) continue;
+        if ((size_t)id < t.id2ws.size() && t.id2ws[id] >= 0) continue;          // the common case: one vector read
+        int32_t ws;
+        hipError_t e = t.wslot_of(id, create, &ws);
+        if (e == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "word ids must be below 2^28");
+        if (e != hipSuccess) return h->hip_fail(e, "wslot_of");
     }
-    if (n) LCD_HIP(h, hipMemcpyAsync(t.d_stage.p, st, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    return LCD_OK;
+    LCD_HIP(h, dreserve(h, t.d_stage, (size_t)std::max<int64_t>(n, 1) * 4));
+    if (n) LCD_HIP(h, hipMemcpyAsync(t.d_stage.p, word_ids, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));   // caller-owned source:
+    return LCD_OK;                                                                                               // every caller synchronises
 }
 
 int lcd_sig_add(lcd_engine* h, int32_t sig_id, const int32_t* word_ids, int n, int32_t ni) {
@@ -564,10 +613,10 @@ int lcd_sig_add(lcd_engine* h, int32_t sig_id, const int32_t* word_ids, int n, i
     if (sig_id == 0 || n < 0 || (n > 0 && !word_ids) || ni < 0) return h->fail(LCD_ERR_INVALID, "lcd_sig_add: bad argument");
     if (n > TF_MAX_WORDS) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_sig_add: more than 8192 words in one signature");
     if (h->tfidf.sig_slot.count(sig_id)) return h->fail(LCD_ERR_STATE, "lcd_sig_add: signature already registered");
-    int rc = stage_wslots(h, word_ids, n, true);
+    int rc = stage_word_ids(h, word_ids, n, true);
     if (rc) return rc;
-    LCD_HIP(h, h->tfidf.register_dev(sig_id, h->tfidf.d_stage.as<int32_t>(), n, ni, 0.0f));
-    LCD_HIP(h, hipStreamSynchronize(h->stream));   // staging buffer reuse
+    LCD_HIP(h, h->tfidf.register_dev(sig_id, h->tfidf.d_stage.as<int32_t>(), n, ni, 0.0f, nullptr, true));
+    LCD_HIP(h, hipStreamSynchronize(h->stream));   // the caller's buffer was the copy source
     return LCD_OK;
 }
 
@@ -578,27 +627,23 @@ int lcd_sig_add_bulk(lcd_engine* h, int n_sigs, const int32_t* sig_ids, const in
     if (n_sigs == 0) return LCD_OK;
     Tfidf& t = h->tfidf;
     const int64_t total = sig_offsets[n_sigs] - sig_offsets[0];
-    // all word slots staged at once, one registration kernel per signature, one synchronisation at the end
-    LCD_HIP(h, t.h_stage.reserve((size_t)std::max<int64_t>(total, 1) * 4));
-    LCD_HIP(h, dreserve(h, t.d_stage, (size_t)std::max<int64_t>(total, 1) * 4));
-    int32_t* st = t.h_stage.as<int32_t>();
+    int max_n = 0;
+    {
+        std::vector<int32_t> sorted(sig_ids, sig_ids + n_sigs);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return h->fail(LCD_ERR_STATE, "lcd_sig_add_bulk: duplicate signature id");
+    }
     for (int s = 0; s < n_sigs; ++s) {
         if (sig_ids[s] == 0 || t.sig_slot.count(sig_ids[s])) return h->fail(LCD_ERR_STATE, "lcd_sig_add_bulk: bad or duplicate signature id");
         const int64_t a = sig_offsets[s], b = sig_offsets[s + 1];
         if (b < a || b - a > TF_MAX_WORDS) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_sig_add_bulk: bad offsets / more than 8192 words");
-        for (int64_t k = a; k < b; ++k) {
-            int32_t ws = -1;
-            if (word_ids[k] > 0) LCD_HIP(h, t.wslot_of(word_ids[k], &ws));
-            st[k - sig_offsets[0]] = ws;
-        }
+        if (ni && ni[s] < 0) return h->fail(LCD_ERR_INVALID, "lcd_sig_add_bulk: negative ni");
+        max_n = std::max(max_n, (int)(b - a));
     }
-    if (total) LCD_HIP(h, hipMemcpyAsync(t.d_stage.p, st, (size_t)total * 4, hipMemcpyHostToDevice, h->stream));
-    for (int s = 0; s < n_sigs; ++s) {
-        const int64_t a = sig_offsets[s] - sig_offsets[0];
-        const int n = (int)(sig_offsets[s + 1] - sig_offsets[s]);
-        LCD_HIP(h, t.register_dev(sig_ids[s], t.d_stage.as<int32_t>() + a, n, ni ? ni[s] : n, 0.0f));
-    }
-    LCD_HIP(h, hipStreamSynchronize(h->stream));
+    // all word ids in one copy, one registration launch for every signature, a fixed number of launches per batch of sealed buckets
+    int rc = stage_word_ids(h, word_ids + sig_offsets[0], total, true);
+    if (rc) return rc;
+    LCD_HIP(h, t.register_bulk(n_sigs, sig_ids, sig_offsets, ni, t.d_stage.as<int32_t>(), total, max_n));   // synchronises
     return LCD_OK;
 }
 
@@ -621,9 +666,11 @@ int lcd_word_nrefs(lcd_engine* h, int32_t word_id, int32_t* out_nw) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (!out_nw) return h->fail(LCD_ERR_INVALID, "lcd_word_nrefs: null output");
-    auto it = h->tfidf.word_wslot.find(word_id);
-    if (it == h->tfidf.word_wslot.end()) { *out_nw = 0; return LCD_OK; }
-    return download(h, out_nw, h->tfidf.nw.as<uint32_t>() + it->second, 4, h->h_out2);
+    int32_t ws = -1;
+    LCD_HIP(h, h->tfidf.wslot_of(word_id, false, &ws));
+    if (ws < 0) { *out_nw = 0; return LCD_OK; }
+    LCD_HIP(h, h->tfidf.flush_retire());             // retirements ride with the next frame otherwise: nw would be stale
+    return download(h, out_nw, h->tfidf.nw.as<uint32_t>() + ws, 4, h->h_out2);
 }
 
 int lcd_likelihood(lcd_engine* h, const int32_t* query_word_ids, int nq, const int32_t* sig_ids, int n_ids, float N, float* out) {
@@ -635,9 +682,9 @@ int lcd_likelihood(lcd_engine* h, const int32_t* query_word_ids, int nq, const i
     if (nq > TF_MAX_WORDS) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_likelihood: more than 8192 query words");
     Tfidf& t = h->tfidf;
     if (t.n_slots == 0 || !(N > 0.0f)) { std::memset(out, 0, (size_t)n_ids * 4); return LCD_OK; }
-    int rc = stage_wslots(h, query_word_ids, nq, false);
+    int rc = stage_word_ids(h, query_word_ids, nq, false);
     if (rc) return rc;
-    LCD_HIP(h, t.query_dev(t.d_stage.as<int32_t>(), nq, N));
+    LCD_HIP(h, t.query_dev(t.d_stage.as<int32_t>(), nq, N, nullptr, true));
     LCD_HIP(h, dreserve(h, h->d_like, (size_t)(t.n_slots + n_ids) * 4));
     LCD_HIP(h, t.score(h->d_like.as<float>()));
     h->likelihood_launches += 1;
@@ -675,31 +722,82 @@ int lcd_adjust_likelihood_dev(lcd_engine* h, float* d_likelihood, int n, float v
 }
 
 // ------------------------------------------------------------------------------------------------ device-resident frame
-int lcd_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, float nndr_ratio, int32_t sig_id, float N,
-                  int32_t* d_word_ids, float* d_likelihood, int64_t likelihood_capacity) {
+// pipelined handles keep two sets of the scratch that the 2-NN stage writes and the frame tail reads
+static void swap_scratch(lcd_engine* h) {
+    std::swap(h->d_knn_row, h->alt.d_knn_row); std::swap(h->d_knn_word, h->alt.d_knn_word); std::swap(h->d_knn_dist, h->alt.d_knn_dist);
+    std::swap(h->d_selfdist, h->alt.d_selfdist); std::swap(h->d_bits, h->alt.d_bits); std::swap(h->d_partial2, h->alt.d_partial2);
+    std::swap(h->d_partial3, h->alt.d_partial3); std::swap(h->d_fail_list, h->alt.d_fail_list); std::swap(h->d_fail_count, h->alt.d_fail_count);
+    std::swap(h->d_out_wslot, h->alt.d_out_wslot); std::swap(h->fail_count_clean, h->alt.fail_count_clean);
+    h->ks_idx ^= 1;
+}
+
+int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
-    if (q <= 0 || q > 8192 || !d_descriptors || !d_word_ids) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: bad argument");
+    if (!a || a->struct_size != (int32_t)sizeof(lcd_frame_args)) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: bad argument block");
+    const int q = a->q;
+    if (q <= 0 || q > 8192 || !a->d_descriptors || !a->d_word_ids) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: bad argument");
+    if ((a->d_hypothesis || a->d_adjusted) && !a->d_likelihood) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: the hypothesis needs d_likelihood");
     Tfidf& t = h->tfidf;
-    if (sig_id != 0 && t.sig_slot.count(sig_id)) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
-    const int64_t slots_after = t.n_slots + (sig_id != 0 ? 1 : 0);
-    if (d_likelihood && likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
+    if (a->sig_id != 0 && t.sig_slot.count(a->sig_id)) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
+    const int64_t slots_after = t.n_slots + (a->sig_id != 0 ? 1 : 0);
+    if (a->d_likelihood && a->likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
+    // postings keys for the words this frame may create (VisualWord(id, descriptor, signatureId) references the signature)
+    int32_t new_ws_base = -1;
+    if (a->sig_id != 0 && a->first_new_word_id > 0 && (a->flags & LCD_Q_INCREMENTAL)) {
+        hipError_t e = t.reserve_new_words(a->first_new_word_id, q, &new_ws_base);
+        if (e == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: word ids must be below 2^28");
+        if (e != hipSuccess) return h->hip_fail(e, "reserve_new_words");
+    }
+    const bool pipe = h->kstream != nullptr;
+    int p = 0;
+    if (pipe) {
+        swap_scratch(h);
+        p = h->ks_idx;
+        if (q > h->ks_q[p]) {                       // this set's buffers are about to grow: nothing may still be using them
+            int rc = h->sync_all();
+            if (rc) return rc;
+            h->ks_q[p] = q;
+        }
+        // the tail of the frame before last read this set; the 2-NN stage of this frame overwrites it
+        LCD_HIP(h, hipStreamWaitEvent(h->kstream, h->ev_tail[p], 0));
+        if (a->ready_event) LCD_HIP(h, hipStreamWaitEvent(h->kstream, (hipEvent_t)a->ready_event, 0));
+        h->kst = h->kstream;
+        h->k_busy = true;
+    }
     LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
     // 2-NN + same-frame distances, then ONE single-workgroup launch: decision loop -> pending retirements -> registration / idf
     ResolveArgs r;
-    int rc = prepare_resolve(h, d_descriptors, q, flags, nndr_ratio, d_word_ids, h->d_out_wslot.as<int32_t>(), &r, true);
+    int rc = prepare_resolve(h, a->d_descriptors, q, a->flags, a->nndr_ratio, a->d_word_ids, h->d_out_wslot.as<int32_t>(), &r, true);
+    h->kst = h->stream;
     if (rc) return rc;
+    if (pipe) {
+        LCD_HIP(h, hipEventRecord(h->ev_knn[p], h->kstream));
+        LCD_HIP(h, hipStreamWaitEvent(h->stream, h->ev_knn[p], 0));
+    }
+    r.new_ws_base = new_ws_base;
     if (h->d_fail_count.p) { r.fail_count = h->d_fail_count.as<int32_t>(); h->fail_count_clean = true; }
-    if (sig_id != 0) LCD_HIP(h, t.register_dev(sig_id, h->d_out_wslot.as<int32_t>(), q, q, N, &r));
-    else LCD_HIP(h, t.query_dev(h->d_out_wslot.as<int32_t>(), q, N, &r));
-    if (d_likelihood) {
+    if (a->sig_id != 0) LCD_HIP(h, t.register_dev(a->sig_id, h->d_out_wslot.as<int32_t>(), q, q, a->N, &r));
+    else LCD_HIP(h, t.query_dev(h->d_out_wslot.as<int32_t>(), q, a->N, &r));
+    if (pipe) LCD_HIP(h, hipEventRecord(h->ev_tail[p], h->stream));
+    if (a->d_likelihood) {
         if (h->prof_cap > 0 && h->prof2_n < h->prof_cap) {
             t.prof_b = h->prof2_ev[2 * h->prof2_n]; t.prof_e = h->prof2_ev[2 * h->prof2_n + 1];
             h->prof2_n += 1;
         }
-        LCD_HIP(h, t.score(d_likelihood));
+        LCD_HIP(h, t.score(a->d_likelihood));
         if (t.prof_b) { t.prof_b = t.prof_e = nullptr; h->prof2_n -= 1; }     // the launch that would have been bracketed did not happen
         h->likelihood_launches += 1;
+        if (a->d_hypothesis || a->d_adjusted) {
+            // Rtabmap::adjustLikelihood + the best candidate, without the vector leaving the device (Rtabmap.cpp:2121-2158)
+            if (!a->d_hypothesis) {
+                LCD_HIP(h, dreserve(h, h->d_tmp_i32, 64));
+            }
+            HypothesisOut* out = a->d_hypothesis ? (HypothesisOut*)a->d_hypothesis : (HypothesisOut*)h->d_tmp_i32.p;
+            const long long n_cons = (long long)t.n_slots - std::max(a->exclude_recent, 0);
+            LCD_HIP(h, launch_hypothesis(a->d_likelihood, t.slot_sig.as<int32_t>(), (long long)t.n_slots, n_cons, a->virtual_place_ratio,
+                                         a->d_adjusted, out, h->stream));
+        }
     }
     return LCD_OK;
 }
@@ -707,6 +805,7 @@ int lcd_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, fl
 int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_ids, float* d_dist) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
+    LCD_JOIN_K(h);
     if (q <= 0 || !d_queries || !d_word_ids || !d_dist) return h->fail(LCD_ERR_INVALID, "lcd_knn2_dev: bad argument");
     LCD_HIP(h, dreserve(h, h->d_knn_row, (size_t)q * 2 * 4));
     return run_knn2_raw(h, d_queries, q, h->vocab.p, h->row_id.as<int32_t>(), h->n_rows, true, h->d_knn_row.as<int32_t>(), d_word_ids, d_dist);
@@ -715,6 +814,7 @@ int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_id
 int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shard_cand* d_cand) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
+    LCD_JOIN_K(h);
     if (q <= 0 || !d_descriptors || !d_cand) return h->fail(LCD_ERR_INVALID, "lcd_shard_knn2_dev: bad argument");
     int rc = run_knn2(h, d_descriptors, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), h->n_rows, h->d_knn_row,
                       h->d_knn_word, h->d_knn_dist);
@@ -724,11 +824,12 @@ int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shar
     return LCD_OK;
 }
 
-int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, float nndr_ratio, int32_t sig_id, float N, int rank,
-                        int world, const lcd_shard_cand* d_all_cand, int64_t total_live_rows, int32_t* d_word_ids, int64_t* d_lfix,
-                        int64_t lfix_capacity) {
+int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, float nndr_ratio, int32_t sig_id,
+                        int32_t first_new_word_id, float N, int rank, int world, const lcd_shard_cand* d_all_cand, int64_t total_live_rows,
+                        int32_t* d_word_ids, int64_t* d_lfix, int64_t lfix_capacity) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
+    LCD_JOIN_K(h);
     if (q <= 0 || q > 8192 || !d_descriptors || !d_all_cand || !d_word_ids || world < 1 || world > 64 || rank < 0 || rank >= world)
         return h->fail(LCD_ERR_INVALID, "lcd_shard_frame_dev: bad argument");
     Tfidf& t = h->tfidf;
@@ -752,16 +853,24 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
                                    h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), h->d_bits.as<uint32_t>(), bw));
     }
     LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
+    // new words: every rank reserves the same keys (identical call sequence => identical numbering); only the LAST rank, which
+    // will hold their rows, references them
+    int32_t new_ws_base = -1;
+    if (sig_id != 0 && first_new_word_id > 0 && incremental) {
+        hipError_t e = t.reserve_new_words(first_new_word_id, q, &new_ws_base);
+        if (e == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_shard_frame_dev: word ids must be below 2^28");
+        if (e != hipSuccess) return h->hip_fail(e, "reserve_new_words");
+        if (rank != world - 1) new_ws_base = -1;
+    }
     const int rflags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0);
     LCD_HIP(h, launch_resolve(q, rflags, nndr_ratio, have_index, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
                               together ? h->d_selfdist.as<float>() : nullptr, ld, together ? h->d_bits.as<uint32_t>() : nullptr, bw,
                               d_word_ids, h->d_n_new.as<int32_t>(), h->stream, h->d_knn_row.as<int32_t>(), nullptr,
-                              h->d_out_wslot.as<int32_t>()));
+                              h->d_out_wslot.as<int32_t>(), new_ws_base));
     if (sig_id != 0) LCD_HIP(h, t.register_dev(sig_id, h->d_out_wslot.as<int32_t>(), q, q, N));
     else LCD_HIP(h, t.query_dev(h->d_out_wslot.as<int32_t>(), q, N));
     if (d_lfix) {
-        LCD_HIP(h, hipMemsetAsync(d_lfix, 0, (size_t)t.n_slots * 8, h->stream));
-        LCD_HIP(h, t.score_partial((unsigned long long*)d_lfix));
+        LCD_HIP(h, t.score_fix((long long*)d_lfix));       // every slot written: no zero-fill needed
         h->likelihood_launches += 1;
     }
     return LCD_OK;
@@ -771,7 +880,8 @@ int lcd_finalize_dev(lcd_engine* h, int64_t* d_lfix, int64_t n, float* d_likelih
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (n < 0 || (n > 0 && (!d_lfix || !d_likelihood))) return h->fail(LCD_ERR_INVALID, "lcd_finalize_dev: bad argument");
-    LCD_HIP(h, h->tfidf.finalize((long long*)d_lfix, (long long)n, d_likelihood));
+    if (n > h->tfidf.n_slots) return h->fail(LCD_ERR_INVALID, "lcd_finalize_dev: more entries than signature slots");
+    LCD_HIP(h, h->tfidf.finalize((const long long*)d_lfix, (long long)n, d_likelihood));
     return LCD_OK;
 }
 
@@ -806,7 +916,7 @@ int lcd_profile_begin(lcd_engine* h, int max_samples) {
 int lcd_profile_read(lcd_engine* h, float* avg_ms, int* n_samples, const char** kernel_name) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
-    LCD_HIP(h, hipStreamSynchronize(h->stream));
+    { int rc = h->sync_all(); if (rc) return rc; }
     double sum = 0.0;
     for (int i = 0; i < h->prof_n; ++i) {
         float ms = 0.0f;
@@ -823,7 +933,7 @@ int lcd_profile_read(lcd_engine* h, float* avg_ms, int* n_samples, const char** 
 int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, const char** kernel_name) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
-    LCD_HIP(h, hipStreamSynchronize(h->stream));
+    { int rc = h->sync_all(); if (rc) return rc; }
     double sum = 0.0;
     for (int i = 0; i < h->prof2_n; ++i) {
         float ms = 0.0f;
@@ -837,10 +947,20 @@ int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, co
     return LCD_OK;
 }
 
+int lcd_profile_score_work(lcd_engine* h, int64_t* out8) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (!out8) return h->fail(LCD_ERR_INVALID, "lcd_profile_score_work: null output");
+    { int rc = h->sync_all(); if (rc) return rc; }
+    LCD_HIP(h, h->tfidf.score_work(out8));
+    return LCD_OK;
+}
+
 int lcd_get_stats(lcd_engine* h, lcd_stats* out) {
     LCD_CHECK_HANDLE(h);
     if (!out) return LCD_ERR_INVALID;
     LCD_DEV(h);
+    { int rc = h->sync_all(); if (rc) return rc; }
     out->knn_last_fallback_queries = 0;
     out->knn_max_err_ratio = 0.0;
     if (h->d_fail_count.p) {
@@ -855,6 +975,10 @@ int lcd_get_stats(lcd_engine* h, lcd_stats* out) {
     out->vocab_rows = h->n_rows; out->vocab_live = h->n_live;
     out->signatures = h->tfidf.live_sigs; out->postings = h->tfidf.postings_ub;
     out->knn_launches = h->knn_launches; out->likelihood_launches = h->likelihood_launches; out->rebuilds = h->rebuilds;
+    h->tfidf.harvest_released(false);
+    out->buckets_sealed = h->tfidf.seals;
+    out->word_slots = (int64_t)h->tfidf.n_wslots - (int64_t)h->tfidf.ws_free.size();
+    out->dense_words = h->tfidf.h_n_dense ? (int64_t)*(volatile uint32_t*)h->tfidf.h_n_dense : 0;
     out->bytes_device = h->bytes_device;
     return LCD_OK;
 }

@@ -955,8 +955,7 @@ namespace lcd {
 bool knn_mfma_supported(int dtype, int dim) { return dtype == 0 && dim == 64; }
 
 static int mfma_ng() {   // 32-query groups per wave: 4 (one wave per SIMD, default) or 2 (two waves per SIMD)
-    static const int ng = [] { const char* e = getenv("LCD_MFMA_NG"); return (e && atoi(e) == 2) ? 2 : 4; }();
-    return ng;
+    return 4;            // (the two-waves-per-SIMD variant, 2, measured the same)
 }
 
 MfmaPlan knn_mfma_plan(int q, int n_rows) {
@@ -1073,7 +1072,7 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
         if (e != hipSuccess) return e;
     }
     if (p.n_blocks > 0) {
-        static const int ng = [] { const char* e = getenv("LCD_BF16_NG"); return (e && atoi(e) == 2) ? 2 : 4; }();   // waves per SIMD = 4 / ng (measured equal; 4 by default)
+        constexpr int ng = 4;                                         // waves per SIMD = 4 / ng (2 measured equal)
         static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_bf16_filter_kernel<4>),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES);
         static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_bf16_filter_kernel<2>),

@@ -83,7 +83,8 @@ hipError_t launch_selfdist(int dtype, int dim, const void* queries, int q, float
 hipError_t launch_resolve(int q, int flags, float nndr, int have_index, const int32_t* knn_word, const float* knn_dist,
                           const float* selfdist, int ld, const uint32_t* cand_bits, int bw, int32_t* out_word, int32_t* out_n_new,
                           hipStream_t s, const int32_t* knn_row = nullptr, const int32_t* row_wslot = nullptr,
-                          int32_t* out_wslot = nullptr);   // out_wslot[q]: postings key of the chosen existing word (-1: none/new)
+                          int32_t* out_wslot = nullptr,    // out_wslot[q]: postings key of the chosen word (-1: none)
+                          int32_t new_ws_base = -1);       // postings key of the frame's k-th new word = new_ws_base + k (< 0: none)
 // findNN merge (VWDictionary.cpp:1457-1542): indexed candidates + candidates among the not-indexed words + NNDR.
 hipError_t launch_findnn_resolve(int q, int flags, float nndr, int have_index, const int32_t* knn_word,
                                  const float* knn_dist, int have_extra, const int32_t* extra_word,

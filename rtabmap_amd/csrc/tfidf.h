@@ -3,21 +3,29 @@
 // Replaces VisualWord::_references (reference VisualWord.h:62, std::map<sigId,count> per word), Memory::getNi
 // (Memory.cpp:4955) and the scoring loop of Memory::computeLikelihood (Memory.cpp:2215-2291).
 //
-// Data layout in HBM ("blocked inverted index"):
+// Data layout in HBM ("blocked inverted index", second version):
 //   * a signature gets a SLOT (dense, arrival order); slots are grouped in BUCKETS of TF_R = 256 consecutive slots;
-//   * a word gets a WSLOT (dense); nw[wslot] = number of live signatures referencing the word;
-//   * every bucket keeps the arrival-order log of its postings (coo_w[e] = wslot, coo_pc[e] = slot_local << 22 | count),
-//     which is also the forward index used to retire a signature;
-//   * when a bucket is full it is SEALED: its postings are regrouped by word (counting sort on the device) into
-//     ent[] (4 B per posting: slot_local << 22 | count) with a directory dir[wslot] -> first posting, so that
-//     "the postings of word w that fall in bucket b" is one contiguous segment found with two loads;
-//   * ni[slot] (0 = retired) is read once per workgroup into LDS.
-// Scoring a frame = for every sealed bucket, one workgroup (x G word groups) walks the segments of the frame's words
-// flattened into one load-balanced index space (heavy-tailed posting lists cannot starve a wave), accumulates into an
-// LDS array of TF_R fixed-point (Q15.48, int64) sums with ds_add_u64 and flushes each slot once.  The open bucket is
-// scanned in arrival order against the frame's sorted word list.  Integer accumulation makes the result independent
-// of the order of the adds (bit-reproducible run to run and across any sharding of the words over GPUs); each term
-// is computed in fp32 exactly as the reference does, (nwi * log10(N/nw)) / ni.
+//   * a word gets a WSLOT (dense, recycled once the word is removed and the device has confirmed that nothing references
+//     it any more); nw[wslot] = number of live signatures referencing the word;
+//   * every bucket keeps the arrival-order log of its postings (coo_w[e] = wslot, coo_pc[e] = slot_local << 22 | count;
+//     the entries of one signature are contiguous: slot_begin / slot_cnt), which is also the forward index used to retire a
+//     signature.  The bucket that is still filling is scored from this log, one wavefront per signature;
+//   * when a bucket is full it is SEALED on the device (no host round trip) into two parts:
+//       DENSE ROWS  -- words that occur in many signatures (>= TF_DENSE_T of the 256 of some bucket) get a global dense id;
+//                      a sealed bucket holds one 256-byte row per dense id known when it was sealed: row[d][slot] = count
+//                      (saturating at 255, the excess goes to the sparse part).  1 byte per signature instead of 4 bytes per
+//                      posting, no directory lookup, no decode, no atomics: a wavefront reads a row with one coalesced load
+//                      and every lane owns four signatures.  With a heavy-tailed (Zipf) vocabulary these rows carry > 90 %
+//                      of the postings a frame touches;
+//       SPARSE PART -- every other posting, 4 bytes each, grouped by word, found through a compact directory whose size
+//                      is bounded by the postings, not by buckets x words: one {presence bits, rank} pair per 32 wslots
+//                      and one offset per word PRESENT in the bucket.
+// Arithmetic: idf(w) = log10f(N / nw) as the reference computes it, then rounded ONCE to Q5.26 fixed point; a signature's
+// score is the exact 64-bit integer sum of count x idf over the frame's words, converted to float and divided by ni once.
+// Integer accumulation is order-free: the result does not depend on workgroup scheduling, on how a count is split between the
+// dense and the sparse part, or on how the words are sharded over GPUs (an int64 all-reduce of the partial sums gives the
+// single-GPU bits).  It differs from the reference's float accumulation (sum of (count * idf) / ni in ascending word order) by
+// rounding only: ~1e-7 relative (bound 1e-4 in tests/test_gpu_likelihood.py, abs floor 1e-7).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,28 +42,44 @@ constexpr int TF_R = 256;                  // slots per bucket
 constexpr int TF_CNT_BITS = 22;            // posting = slot_local << 22 | count
 constexpr uint32_t TF_CNT_MASK = (1u << TF_CNT_BITS) - 1;
 constexpr int TF_MAX_WORDS = 8192;         // words of one signature / one query frame handled by the 1-workgroup kernels
-constexpr int TF_FIX_SHIFT = 48;           // Q15.48 fixed point
+constexpr int TF_IDF_SHIFT = 26;           // idf in Q5.26 (|idf| < 32: N up to 1e32)
+constexpr int TF_DENSE_T = 32;             // a word present in >= 32 of a bucket's 256 signatures becomes dense
+constexpr int TF_DENSE_MAX = 4096;         // dense ids (1 MB of rows per bucket at most)
 
 // one bucket as the kernels see it
 struct BucketDev {
-    uint32_t* coo_w;       // [cap] arrival-order log: wslot
-    uint32_t* coo_pc;      // [cap] arrival-order log: slot_local << 22 | count
-    const uint32_t* dir;   // sealed: [W + 1] first posting of each wslot
-    const uint32_t* ent;   // sealed: [n_e] postings grouped by wslot
-    uint32_t W;            // wslots covered by dir
-    uint32_t sealed;
-    uint32_t n_e_sealed;   // postings in ent
+    const uint32_t* coo_w;     // [cap] arrival-order log: wslot (kept after sealing: forward index for retirement)
+    const uint32_t* coo_pc;    // [cap] arrival-order log: slot_local << 22 | count (released after sealing)
+    const uint8_t* dense;      // sealed: [D_alloc][256] counts
+    const uint2* dirb;         // sealed: [(W + 31) / 32] {presence bits, number of present words before the block}
+    const uint32_t* sp_off;    // sealed: [present + 1] first sparse posting of each present word
+    const uint32_t* sp_ent;    // sealed: sparse postings grouped by word
+    uint32_t W;                // wslots covered by dirb
+    uint32_t D_alloc;          // dense rows allocated
+    uint32_t state;            // 0 = open, 1 = sealed, 2 = dead (every signature retired, memory released)
     uint32_t pad;
 };
 
+// one sealing job (kernel argument, by value: no staging buffer to keep alive)
+struct SealJob {
+    int bucket;
+    const uint32_t* coo_w; const uint32_t* coo_pc; const uint32_t* ne;   // log and its length (device counter)
+    uint8_t* dense; uint32_t D_alloc;
+    uint2* dirb; uint32_t* sp_off; uint32_t* sp_ent;
+    uint32_t* cntw;            // [W] scratch, zeroed
+    uint32_t* tile_sums;       // [2 * tiles] scratch
+    uint32_t W;
+    uint32_t ent_cap;          // capacity of sp_ent (host upper bound of the log length)
+};
+
 struct Bucket {
-    bool sealed = false;
+    int state = 0;            // 0 open, 1 sealed, 2 dead
     int n_slots = 0;          // slots handed out in this bucket
     int live = 0;             // live signatures among them
     int64_t ub_entries = 0;   // host upper bound of log entries (device appends without telling the host)
-    DevBuf coo_w, coo_pc, dir, ent;
-    uint32_t W = 0;
-    uint32_t n_e_sealed = 0;
+    DevBuf coo_w, coo_pc, sealed;
+    size_t off_dirb = 0, off_spoff = 0, off_spent = 0;   // byte offsets inside `sealed` (dense rows at 0)
+    uint32_t W = 0, D_alloc = 0;
 };
 
 // arguments of the addNewWords decision loop (resolve_body.cuh) when it is fused into the frame-words launch
@@ -63,8 +87,18 @@ struct ResolveArgs {
     int q, flags; float nndr; int have_index;
     const int32_t* knn_word; const float* knn_dist; const float* selfdist; int ld; const uint32_t* cand_bits; int bw;
     int32_t* out_word; int32_t* out_n_new; const int32_t* knn_row; const int32_t* row_wslot; int32_t* out_wslot;
+    int32_t new_ws_base;   // postings key of the frame's k-th new word = new_ws_base + k (< 0: new words get no postings)
     int32_t* fail_count;   // reset for the next frame's certificate (saves a memset launch); may be NULL
     RowparArgs rp;         // rp.enabled: the exact redo of rejected queries runs as extra workgroups of the tail launch
+};
+
+// recycled allocations of bucket-sized device buffers (a bucket is born and dies every 256 frames in steady state:
+// hipMalloc / hipFree there would synchronise the device)
+struct BufPool {
+    std::vector<DevBuf> free_list;
+    hipError_t get(size_t bytes, DevBuf* out, int64_t* total);
+    void put(DevBuf* b);
+    void destroy(int64_t* total);
 };
 
 struct Tfidf {
@@ -73,52 +107,77 @@ struct Tfidf {
     // per slot
     DevBuf slot_sig, slot_ni, slot_begin, slot_cnt;
     // per wslot
-    DevBuf nw;
-    DevBuf idf_tab;                      // {stamp, idf bits} of the words of the current frame (valid iff stamp matches)
+    DevBuf nw, did;                      // references, dense id (-1: none)
+    DevBuf idf_tab;                      // {stamp, idf Q5.26} of the words of the current frame (valid iff stamp matches)
     uint32_t stamp = 0;
+    // word id -> wslot: host vector (ids are small consecutive integers in the reference, ++_lastWordId) mirrored on the device
+    std::vector<int32_t> id2ws;          // -1 = none
+    DevBuf d_id2ws;
+    int64_t d_id2ws_n = 0;               // entries valid on the device
+    std::vector<int32_t> id2ws_dirty;    // ids whose device entry is out of date
+    std::vector<int32_t> ws_free;        // recycled wslots (confirmed unreferenced by the device)
+    struct ReleaseBatch { hipEvent_t ev = nullptr; std::vector<int32_t> ws; void* pinned = nullptr; const uint8_t* ok = nullptr; };
+    std::vector<ReleaseBatch> releasing; // wslots whose release kernel is in flight
+    struct Reservation { int32_t first_id = 0, ws_base = 0, n = 0; } resv;   // wslots reserved for the new words of the last frame
     // per bucket
-    DevBuf bkt_tab, bkt_ne, bkt_list, bkt_list_all, open_done;
+    DevBuf bkt_tab, bkt_ne, bkt_D, bkt_flags;
     std::vector<Bucket> buckets;
-    std::vector<BucketDev> h_bkt;
-    bool bkt_dirty = true;
-    int n_list = 0;                      // sealed buckets with live signatures (entries of bkt_list)
-    int n_list_all = 0;                  // all sealed buckets, retired ones included (entries of bkt_list_all)
     int q_n_ub = 0;                      // word count of the last frame handed to frame_words (upper bound of its unique words)
+    BufPool pool;
+    DevBuf n_dense;                      // [0] number of dense ids handed out (device counter)
+    uint32_t* h_n_dense = nullptr;       // pinned host mirror written by the sealing kernels (read without synchronising: stale is fine)
+    DevBuf seal_cntw, seal_tiles;        // sealing scratch
     // per frame
-    DevBuf lfix;                         // int64 accumulator per slot
-    DevBuf q_w, q_cnt, q_idf, q_meta;    // the frame's unique words (sorted wslots), counts, idf, [0] = unique count
-    DevBuf tmp_cursor;                   // sealing scratch
-    DevBuf d_stage;                      // staged word slots of host-side calls
+    DevBuf q_w, q_idf, q_did, qd_did, qd_idf, q_meta;   // the frame's unique words: wslot, idf, dense id; its dense words; [0] = unique, [1] = dense
+    DevBuf d_stage;                      // staged word ids of host-side calls
+    DevBuf d_pairs;                      // (id, wslot) pairs on their way into d_id2ws
     PinBuf h_stage;
     // host maps
     std::unordered_map<int32_t, int64_t> sig_slot;    // live signature id -> slot
-    std::unordered_map<int32_t, int32_t> word_wslot;  // word id -> wslot (never recycled in this version)
     int32_t n_wslots = 0;
     int64_t n_slots = 0, live_sigs = 0;
     int64_t postings_ub = 0;
+    int64_t seals = 0;
     std::string err;
 
     hipError_t init(hipStream_t s, int64_t* bytes, int64_t sig_capacity);
     void destroy();
-    // wslot of a word id (assigned on first sight); grows nw[]
-    hipError_t wslot_of(int32_t word_id, int32_t* out);
+    // wslot of a word id (assigned on first sight when `create`); -1 if unknown and !create
+    hipError_t wslot_of(int32_t word_id, bool create, int32_t* out);
+    // bring the device copy of id2ws up to date
+    hipError_t sync_id2ws();
+    // the word left the dictionary (VWDictionary::removeWords): its wslot is recycled once the device confirms nw == 0
+    hipError_t release_words(const int32_t* word_ids, int n);
+    hipError_t release_wslots(const std::vector<int32_t>& ws);
+    void harvest_released(bool wait);
+    // reserve n consecutive wslots for the new words first_id, first_id + 1, ... of the coming frame; returns the base
+    hipError_t reserve_new_words(int32_t first_id, int n, int32_t* ws_base);
     // register one signature whose word slots are already on the device (d_wslots[n]; < 0 = no word); if N > 0 the
     // frame's unique words / idf are left in q_* for a following score()
-    hipError_t register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N, const ResolveArgs* resolve = nullptr);
+    hipError_t register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N, const ResolveArgs* resolve = nullptr,
+                            bool ids_given = false /* d_wslots holds word ids, translated on the device */);
     // prepare q_* from word slots on the device without registering anything
-    hipError_t query_dev(const int32_t* d_wslots, int n, float N, const ResolveArgs* resolve = nullptr);
+    hipError_t query_dev(const int32_t* d_wslots, int n, float N, const ResolveArgs* resolve = nullptr, bool ids_given = false);
+    // Memory::loadDataFromDb replay: many signatures in O(1) launches; d_ids = word ids on the device, offsets[n_sigs + 1]
+    hipError_t register_bulk(int n_sigs, const int32_t* sig_ids, const int64_t* offsets, const int32_t* ni, const int32_t* d_ids,
+                             int64_t total_ids, int max_n);
     hipError_t flush_retire();
     std::vector<int64_t> pending_retire;   // slots whose device-side retirement rides along with the next frame-words launch
     // score q_* against every live signature: dense float likelihood over slots [0, n_slots)
-    hipEvent_t prof_b = nullptr, prof_e = nullptr;   // one-shot: bracket the next fused scoring launch (lcd_profile_*)
+    hipEvent_t prof_b = nullptr, prof_e = nullptr;   // one-shot: bracket the next scoring launch (lcd_profile_*)
     hipError_t score(float* d_likelihood);
-    // the two halves of score(): integer partial sums into a ZEROED caller buffer, and fixed point -> float (re-zeroes the source)
-    hipError_t score_partial(unsigned long long* lfix_target);
-    hipError_t finalize(long long* lfix_src, long long n, float* d_likelihood);
+    hipError_t score_work(int64_t out[8]);   // diagnostic, synchronises: what one scoring launch reads for the frame in q_*
+    // sharded path: exact integer partial sums per slot (every slot written), and fixed point -> float after the all-reduce
+    hipError_t score_fix(long long* lfix);
+    hipError_t finalize(const long long* lfix_src, long long n, float* d_likelihood);
     hipError_t retire(int32_t sig_id);
-    hipError_t seal(int b);
+    hipError_t seal_batch(const std::vector<int>& bucket_ids, bool bulk);
     hipError_t ensure_slots(int64_t n);
-    hipError_t upload_buckets();
+    hipError_t ensure_wslots(int32_t n);
+    hipError_t ensure_buckets(int n);
+    hipError_t set_bucket(int b);          // upload one bucket descriptor (tiny kernel: the data travels as kernel arguments)
+    hipError_t new_bucket();
+    hipError_t launch_score(float* d_likelihood, long long* lfix);
 };
 
 // gather of the dense likelihood: out[k] = slots[k] >= 0 ? dense[slots[k]] : 0
@@ -126,5 +185,12 @@ hipError_t launch_gather_f32(const float* dense, const int64_t* slots, int n, fl
 
 // Rtabmap::adjustLikelihood on a device vector (entry 0 = virtual place), in place
 hipError_t launch_adjust_likelihood(float* d_L, int n, float ratio, hipStream_t s);
+
+// Rtabmap::adjustLikelihood + selection of the best candidate over the dense slot likelihood (lcd_frame_dev's hypothesis output)
+struct HypothesisOut {          // == lcd_hypothesis (include/lcd.h)
+    int32_t sig_id; int32_t slot; float likelihood; float adjusted; float virtual_place; float mean; float stddev; int32_t n_positive;
+};
+hipError_t launch_hypothesis(const float* d_like, const int32_t* slot_sig, long long n_slots, long long n_considered, float ratio,
+                             float* d_adjusted /* may be NULL; [n_slots + 1], entry 0 = virtual place */, HypothesisOut* d_out, hipStream_t s);
 
 }  // namespace lcd

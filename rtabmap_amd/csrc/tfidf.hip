@@ -3,9 +3,9 @@
 // Reference behaviour reproduced (Memory.cpp:2215-2291): for every UNIQUE word id w > 0 of the query,
 //   nw = refs(w).size(); logNnw = log10(N / nw) (float); skipped when nw == 0 or logNnw == 0;
 //   for every (signature s, count nwi) in refs(w): ni = getNi(s); if ni != 0: L[s] += (nwi * logNnw) / ni   (all fp32).
-// Every term is evaluated with exactly these fp32 operations; only the accumulation differs: the reference adds the
-// terms of one signature in ascending word order in fp32, here they are added as Q15.48 integers (order-free,
-// truncation error < 2^-48 per term), so results agree to ~1e-6 relative (bound 1e-4, tests/test_gpu_likelihood.py).
+// Here logNnw is computed with the same fp32 operations, rounded once to Q5.26, and L[s] = (sum of nwi * logNnw as exact 64-bit
+// integers) / ni: one float rounding and one float division per signature instead of one of each per posting.  The two agree to
+// rounding (~1e-7 relative; the tests bound 1e-4 with an absolute floor of 1e-7).
 #include "tfidf.h"
 #include "resolve_body.cuh"
 #include "rowpar_body.cuh"
@@ -13,67 +13,91 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 namespace lcd {
 namespace {
 
-constexpr int FW_BLOCK = 1024;   // frame_words_kernel
-constexpr int SC_BLOCK = 256;    // scoring kernels
+constexpr int FW_BLOCK = 1024;   // frame_words_kernel / frame_tail_kernel
+constexpr int BR_BLOCK = 256;    // bulk_register_kernel (one workgroup per signature)
+constexpr int SC_BLOCK = 1024;   // score_kernel
+constexpr int SEAL_BLOCK = 256;
+constexpr int SEAL_TILE = SEAL_BLOCK * 32;   // wslots per workgroup of the sealing scan (one 32-wslot directory block per thread)
 
-// exclusive scan, in place, of data[0..n) (LDS) by a whole workgroup; returns the total.  scratch[blockDim.x + 1] in LDS.
-__device__ uint32_t block_exclusive_scan(uint32_t* data, int n, uint32_t* scratch) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int per = (n + nt - 1) / nt;
+// exclusive scan, in place, of data[0..n) (LDS) by a whole workgroup of NT threads; returns the total.  scratch[NT / 64 + 1] in
+// LDS.  data[] must be complete (barrier) before the call; three barriers inside.
+template <int NT>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t* data, int n, uint32_t* scratch) {
+    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (n + NT - 1) / NT;
     const int lo = min(tid * per, n), hi = min(lo + per, n);
     uint32_t sum = 0;
     for (int i = lo; i < hi; ++i) sum += data[i];
-    scratch[tid] = sum;
+    uint32_t x = sum;                                   // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+    if (lane == 63) scratch[wv] = x;
     __syncthreads();
-    for (int off = 1; off < nt; off <<= 1) {
-        const uint32_t t = tid >= off ? scratch[tid - off] : 0;
-        __syncthreads();
-        scratch[tid] += t;
-        __syncthreads();
+    if (wv == 0) {
+        const uint32_t t = lane < NW ? scratch[lane] : 0u;
+        uint32_t s = t;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(s, off, 64); if (lane >= off) s += y; }
+        if (lane < NW) scratch[lane] = s - t;
+        if (lane == NW - 1) scratch[NW] = s;
     }
-    uint32_t run = scratch[tid] - sum;     // exclusive prefix of this thread's chunk
-    const uint32_t total = scratch[nt - 1];
+    __syncthreads();
+    uint32_t run = scratch[wv] + x - sum;               // exclusive prefix of this thread's chunk
+    const uint32_t total = scratch[NW];
     for (int i = lo; i < hi; ++i) { const uint32_t v = data[i]; data[i] = run; run += v; }
     __syncthreads();
     return total;
 }
 
-__device__ __forceinline__ unsigned long long to_fixed(float t) {
-    // t >= 0, t < 2^15.  floor(t * 2^48) in two exact halves (there is no f32 -> i64 conversion on the VALU): s = t * 2^16 is
-    // exact, floor(s) < 2^31 is the high word, the fraction s - floor(s) is exact (it needs no more bits than t has) and its
-    // product with 2^32 truncates to the low word.
-    const float s = t * 65536.0f;
-    const float fl = floorf(s);
-    const float rem = s - fl;
-    return ((unsigned long long)(uint32_t)fl << 32) | (uint32_t)(rem * 4294967296.0f);
+// idf -> Q5.26, round to nearest, saturating
+__device__ __forceinline__ int32_t idf_to_fixed(float idf) {
+    float s = idf * 67108864.0f;                        // 2^26, exact scaling
+    s = fminf(fmaxf(s, -2147483520.0f), 2147483520.0f);
+    return (int32_t)rintf(s);
+}
+// exact integer sum -> likelihood: one rounding to float, exact scaling by 2^-26, one division by ni
+__device__ __forceinline__ float fixed_to_like(long long acc, uint32_t ni) {
+    if (ni == 0u) return 0.0f;                          // "if(ni != 0)" (Memory.cpp:2275); 0 also marks a retired slot
+    return __fdiv_rn(__ll2float_rn(acc) * 1.4901161193847656e-08f, (float)ni);
 }
 
 // ---------------------------------------------------------------------------------------------- frame words
+struct FwArgs {
+    const int32_t* src; int n;                    // word slots of the frame (or word ids when xlate != NULL); < 0 / <= 0 = no word
+    const int32_t* xlate; long long xlate_n;      // word id -> wslot table (device copy of Tfidf::id2ws)
+    int H; int do_register; int want_q;
+    int32_t sig_id; long long slot; uint32_t slot_local; uint32_t ni; float N; uint32_t stamp;
+    uint32_t* nw; const int32_t* did;
+    uint32_t* coo_w; uint32_t* coo_pc; uint32_t* ne_counter;
+    int32_t* slot_sig; uint32_t* slot_ni; uint32_t* slot_begin; uint32_t* slot_cnt;
+    uint32_t* q_w; int32_t* q_idf; int32_t* q_did; int32_t* qd_did; int32_t* qd_idf; uint32_t* q_meta; uint2* idf_tab;
+};
+
 // One workgroup: reduce the frame's word slots to (unique word, count) with an LDS hash table (linear probing, atomicCAS),
-// optionally append them to the open bucket as the postings of signature `slot` (nw += 1 each), and leave the
-// word / count / idf lists plus the per-word idf table (idf_tab[w] = {stamp, idf}) for the scoring kernels.
+// optionally append them to the bucket log as the postings of signature `slot` (nw += 1 each), and leave the word / idf /
+// dense-id lists plus the per-word idf table (idf_tab[w] = {stamp, idf}) for the scoring kernel.
 // The list order is whatever the table yields: nothing downstream depends on it (integer accumulation).
-__device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const int32_t* __restrict__ wslots, int n, int H, int do_register,
-                                                               int32_t sig_id, long long slot, uint32_t slot_local, uint32_t ni, float N,
-                                                               uint32_t stamp, uint32_t* __restrict__ nw, uint32_t* __restrict__ coo_w,
-                                                               uint32_t* __restrict__ coo_pc, uint32_t* __restrict__ ne_counter,
-                                                               int32_t* __restrict__ slot_sig, uint32_t* __restrict__ slot_ni,
-                                                               uint32_t* __restrict__ slot_begin, uint32_t* __restrict__ slot_cnt,
-                                                               uint32_t* __restrict__ q_w, uint32_t* __restrict__ q_cnt,
-                                                               float* __restrict__ q_idf, uint32_t* __restrict__ q_meta,
-                                                               uint2* __restrict__ idf_tab) {
+// LDS: 2 * H + H / 64 + 4 words.
+template <int NT>
+__device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs& a) {
+    const int H = a.H;
     uint32_t* tkey = fw_smem;            // [H] 0xFFFFFFFF = empty
     uint32_t* tcnt = fw_smem + H;        // [H]
     uint32_t* grp = tcnt + H;            // [H / 64 + 1]
+    uint32_t* s_misc = grp + H / 64 + 1; // [0] log base, [1] dense list length
     const int tid = threadIdx.x;
-    for (int i = tid; i < H; i += FW_BLOCK) { tkey[i] = 0xFFFFFFFFu; tcnt[i] = 0u; }
+    for (int i = tid; i < H; i += NT) { tkey[i] = 0xFFFFFFFFu; tcnt[i] = 0u; }
+    if (tid == 0) { s_misc[0] = 0u; s_misc[1] = 0u; }
     __syncthreads();
-    for (int i = tid; i < n; i += FW_BLOCK) {
-        const int32_t ws = wslots[i];
+    for (int i = tid; i < a.n; i += NT) {
+        int32_t ws = a.src[i];
+        if (a.xlate) ws = (ws > 0 && (long long)ws < a.xlate_n) ? a.xlate[ws] : -1;
         if (ws < 0) continue;
         const uint32_t w = (uint32_t)ws;
         uint32_t h = (w * 2654435761u) & (uint32_t)(H - 1);
@@ -86,7 +110,7 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const int32_
     __syncthreads();
     // compact the occupied table entries: ballot per 64-entry group, group offsets scanned by one thread
     const int ng = H / 64;
-    for (int i0 = 0; i0 < H; i0 += FW_BLOCK) {
+    for (int i0 = 0; i0 < H; i0 += NT) {
         const int i = i0 + tid;
         const bool occ = i < H && tkey[i] != 0xFFFFFFFFu;
         const unsigned long long bal = __ballot(occ);
@@ -97,12 +121,12 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const int32_
         uint32_t run = 0;
         for (int g = 0; g < ng; ++g) { const uint32_t c = grp[g]; grp[g] = run; run += c; }
         grp[ng] = run;
+        if (a.do_register) s_misc[0] = atomicAdd(a.ne_counter, run);     // reserve the signature's stretch of the log
     }
     __syncthreads();
     const uint32_t U = grp[ng];
-    const uint32_t base = do_register ? ne_counter[0] : 0u;
-    __syncthreads();
-    for (int i0 = 0; i0 < H; i0 += FW_BLOCK) {
+    const uint32_t base = s_misc[0];
+    for (int i0 = 0; i0 < H; i0 += NT) {
         const int i = i0 + tid;
         const bool occ = i < H && tkey[i] != 0xFFFFFFFFu;
         const unsigned long long bal = __ballot(occ);
@@ -112,32 +136,40 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const int32_
         uint32_t cnt = tcnt[i];
         if (cnt > TF_CNT_MASK) cnt = TF_CNT_MASK;
         uint32_t nwv;
-        if (do_register) {
-            nwv = atomicAdd(&nw[w], 1u) + 1u;
-            coo_w[base + u] = w;
-            coo_pc[base + u] = (slot_local << TF_CNT_BITS) | cnt;
+        if (a.do_register) {
+            nwv = atomicAdd(&a.nw[w], 1u) + 1u;
+            a.coo_w[base + u] = w;
+            a.coo_pc[base + u] = (a.slot_local << TF_CNT_BITS) | cnt;
         } else {
-            nwv = nw[w];
+            nwv = a.nw[w];
         }
-        float idf = 0.0f;
-        if (N > 0.0f && nwv > 0u) idf = log10f(__fdiv_rn(N, (float)nwv));   // Memory.cpp:2264-2266
-        q_w[u] = w;
-        q_cnt[u] = cnt;
-        q_idf[u] = idf;
-        idf_tab[w] = make_uint2(stamp, __float_as_uint(idf));
+        if (a.want_q) {
+            float idf = 0.0f;
+            if (a.N > 0.0f && nwv > 0u) idf = log10f(__fdiv_rn(a.N, (float)nwv));   // Memory.cpp:2264-2266
+            const int32_t idfq = idf_to_fixed(idf);
+            const int32_t d = a.did[w];
+            a.q_w[u] = w;
+            a.q_idf[u] = idfq;
+            a.q_did[u] = d;
+            a.idf_tab[w] = make_uint2(a.stamp, (uint32_t)idfq);
+            if (d >= 0 && idfq != 0) {                                   // "if(logNnw)" (Memory.cpp:2267)
+                const uint32_t j = atomicAdd(&s_misc[1], 1u);
+                a.qd_did[j] = d;
+                a.qd_idf[j] = idfq;
+            }
+        }
     }
+    __syncthreads();
     if (tid == 0) {
-        q_meta[0] = U;
-        if (do_register) {
-            ne_counter[0] = base + U;
-            slot_sig[slot] = sig_id;
-            slot_ni[slot] = ni;
-            slot_begin[slot] = base;
-            slot_cnt[slot] = U;
+        if (a.want_q) { a.q_meta[0] = U; a.q_meta[1] = s_misc[1]; }
+        if (a.do_register) {
+            a.slot_sig[a.slot] = a.sig_id;
+            a.slot_ni[a.slot] = a.ni;
+            a.slot_begin[a.slot] = base;
+            a.slot_cnt[a.slot] = U;
         }
     }
 }
-
 
 // signatures whose retirement was requested since the last frame (Memory::disableWordsRef -> removeAllWordRef): their
 // words lose one reference each and the slot is marked dead (ni = 0).  Up to 4 ride along with the next frame-words launch.
@@ -152,20 +184,11 @@ __device__ __forceinline__ void retire_body(const RetireArgs& r, const uint32_t*
     }
 }
 
-__global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(const int32_t* __restrict__ wslots, int n, int H, int do_register,
-                                                               int32_t sig_id, long long slot, uint32_t slot_local, uint32_t ni, float N,
-                                                               uint32_t stamp, uint32_t* __restrict__ nw, uint32_t* __restrict__ coo_w,
-                                                               uint32_t* __restrict__ coo_pc, uint32_t* __restrict__ ne_counter,
-                                                               int32_t* __restrict__ slot_sig, uint32_t* __restrict__ slot_ni,
-                                                               uint32_t* __restrict__ slot_begin, uint32_t* __restrict__ slot_cnt,
-                                                               uint32_t* __restrict__ q_w, uint32_t* __restrict__ q_cnt,
-                                                               float* __restrict__ q_idf, uint32_t* __restrict__ q_meta,
-                                                               uint2* __restrict__ idf_tab, RetireArgs retire) {
+__global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(FwArgs a, RetireArgs retire) {
     extern __shared__ uint32_t fw_dyn_smem[];
-    retire_body(retire, slot_begin, slot_cnt, nw, slot_ni, slot_sig);
+    retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
     __syncthreads();
-    frame_words_body(fw_dyn_smem, wslots, n, H, do_register, sig_id, slot, slot_local, ni, N, stamp, nw, coo_w, coo_pc, ne_counter, slot_sig,
-                     slot_ni, slot_begin, slot_cnt, q_w, q_cnt, q_idf, q_meta, idf_tab);
+    frame_words_body<FW_BLOCK>(fw_dyn_smem, a);
 }
 
 #ifdef LCD_TAIL_TIMING   // timing experiment only: 100 MHz stamps between the phases of the frame tail
@@ -177,15 +200,7 @@ __device__ unsigned long long g_tail_timing[8];
 
 // The single-workgroup tail of a frame in ONE launch: addNewWords decision loop (resolve_body.cuh) -> pending retirements
 // -> unique words / registration / idf (frame_words_body).  Saves two dependent kernel boundaries per frame.
-__global__ __launch_bounds__(FW_BLOCK) void frame_tail_kernel(ResolveArgs r, int H, int do_register, int32_t sig_id, long long slot,
-                                                              uint32_t slot_local, uint32_t ni, float N, uint32_t stamp,
-                                                              uint32_t* __restrict__ nw, uint32_t* __restrict__ coo_w,
-                                                              uint32_t* __restrict__ coo_pc, uint32_t* __restrict__ ne_counter,
-                                                              int32_t* __restrict__ slot_sig, uint32_t* __restrict__ slot_ni,
-                                                              uint32_t* __restrict__ slot_begin, uint32_t* __restrict__ slot_cnt,
-                                                              uint32_t* __restrict__ q_w, uint32_t* __restrict__ q_cnt,
-                                                              float* __restrict__ q_idf, uint32_t* __restrict__ q_meta,
-                                                              uint2* __restrict__ idf_tab, RetireArgs retire) {
+__global__ __launch_bounds__(FW_BLOCK) void frame_tail_kernel(ResolveArgs r, FwArgs a, RetireArgs retire) {
     extern __shared__ uint32_t ft_dyn_smem[];
     // workgroups 1.. : the exact redo of the queries the 2-NN certificate rejected (they leave at once when there are none, which
     // is the usual case: no launch of its own for that check).  Workgroup 0 waits for them only when something was rejected.
@@ -199,20 +214,46 @@ __global__ __launch_bounds__(FW_BLOCK) void frame_tail_kernel(ResolveArgs r, int
     }
     FT_STAMP(0);
     resolve_body(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
-                 r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot);
+                 r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws_base);
     if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; r.fail_count[3] = 0; }
     FT_STAMP(1);
-    retire_body(retire, slot_begin, slot_cnt, nw, slot_ni, slot_sig);
+    retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
     __syncthreads();      // out_wslot (global, written by this workgroup) and the LDS region are handed over
     FT_STAMP(2);
-    frame_words_body(ft_dyn_smem, r.out_wslot, r.q, H, do_register, sig_id, slot, slot_local, ni, N, stamp, nw, coo_w, coo_pc, ne_counter,
-                     slot_sig, slot_ni, slot_begin, slot_cnt, q_w, q_cnt, q_idf, q_meta, idf_tab);
+    frame_words_body<FW_BLOCK>(ft_dyn_smem, a);
     FT_STAMP(3);
 }
 
-// ---------------------------------------------------------------------------------------------- sealed buckets
-__device__ __forceinline__ float fixed_to_float(unsigned long long v) { return (float)((double)(long long)v * (1.0 / 281474976710656.0)); }   // 2^-48
+// ---------------------------------------------------------------------------------------------- bulk registration
+// Memory::loadDataFromDb replay (Memory.cpp:447-480): one workgroup per signature, all signatures of the call in ONE launch.
+// Signature s gets slot slot0 + s; its (unique word, count) pairs are appended to its bucket's log at a position reserved with
+// one atomic on the bucket's entry counter (the order of the signatures inside a bucket's log is irrelevant).
+__global__ __launch_bounds__(BR_BLOCK) void bulk_register_kernel(const int32_t* __restrict__ ids, const long long* __restrict__ offsets,
+                                                                 const int32_t* __restrict__ sig_ids, const int32_t* __restrict__ ni,
+                                                                 long long slot0, const int32_t* __restrict__ xlate, long long xlate_n,
+                                                                 const BucketDev* __restrict__ tab, uint32_t* __restrict__ bkt_ne,
+                                                                 uint32_t* __restrict__ nw, int32_t* __restrict__ slot_sig,
+                                                                 uint32_t* __restrict__ slot_ni, uint32_t* __restrict__ slot_begin,
+                                                                 uint32_t* __restrict__ slot_cnt) {
+    extern __shared__ uint32_t br_dyn_smem[];
+    const long long s = blockIdx.x;
+    const long long o0 = offsets[s] - offsets[0], o1 = offsets[s + 1] - offsets[0];
+    const int n = (int)(o1 - o0);
+    int H = 64;
+    while (H < 2 * n) H <<= 1;
+    const long long slot = slot0 + s;
+    const int b = (int)(slot / TF_R);
+    FwArgs a;
+    a.src = ids + o0; a.n = n; a.xlate = xlate; a.xlate_n = xlate_n; a.H = H; a.do_register = 1; a.want_q = 0;
+    a.sig_id = sig_ids[s]; a.slot = slot; a.slot_local = (uint32_t)(slot % TF_R); a.ni = ni ? (uint32_t)ni[s] : (uint32_t)n;
+    a.N = 0.0f; a.stamp = 0u; a.nw = nw; a.did = nullptr;
+    a.coo_w = const_cast<uint32_t*>(tab[b].coo_w); a.coo_pc = const_cast<uint32_t*>(tab[b].coo_pc); a.ne_counter = bkt_ne + b;
+    a.slot_sig = slot_sig; a.slot_ni = slot_ni; a.slot_begin = slot_begin; a.slot_cnt = slot_cnt;
+    a.q_w = nullptr; a.q_idf = nullptr; a.q_did = nullptr; a.qd_did = nullptr; a.qd_idf = nullptr; a.q_meta = nullptr; a.idf_tab = nullptr;
+    frame_words_body<BR_BLOCK>(br_dyn_smem, a);
+}
 
+// ---------------------------------------------------------------------------------------------- scoring
 #ifdef LCD_SCORE_TIMING   // timing experiment only: 100 MHz stamps between the phases of score_sealed_body, per workgroup
 __device__ unsigned long long g_score_timing[1024 * 8];
 #define SC_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 1024) g_score_timing[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -220,278 +261,231 @@ __device__ unsigned long long g_score_timing[1024 * 8];
 #define SC_STAMP(i) do { } while (0)
 #endif
 
-// One workgroup scores one sealed bucket for the word group g of G.  LDS (dynamic): acc[R] i64 | ni[R] | start[wg_cap] |
-// scan[wg_cap + 1] | idf[wg_cap] | len[wg_cap] | scratch[SCB + 1].  With out_like != NULL (only valid for G == 1) the bucket's TF_R
-// likelihood values are written straight from the LDS accumulators (no round trip through lfix, no finalize launch);
-// otherwise the sums are added into lfix.
+struct ScoreArgs {
+    const BucketDev* tab; const uint32_t* bkt_D; const uint32_t* bkt_flags;
+    int n_closed;                           // buckets [0, n_closed) are sealed or dead; bucket n_closed (if any) is the open one
+    int n_open_slots; int wcap;
+    const uint32_t* q_w; const int32_t* q_idf; const int32_t* q_did; const int32_t* qd_did; const int32_t* qd_idf; const uint32_t* q_meta;
+    const uint32_t* slot_ni; const uint32_t* slot_begin; const uint32_t* slot_cnt;
+    const uint2* idf_tab; uint32_t stamp;
+    float* out_like; long long* out_fix;    // exactly one is non-NULL
+};
+
+// One workgroup scores one sealed bucket (256 signatures).
+//   dense rows : wavefront v takes the frame's dense words v, v + 16, ...; a lane reads the four counts of its four signatures
+//                with one 4-byte load (the wavefront reads the 256-byte row in one coalesced request) and keeps four 64-bit
+//                sums in registers; all loads of a trip are issued before any is consumed;
+//   sparse part: one thread per frame word looks the word up in the bucket's directory (one 8-byte read; a second one for the
+//                offsets when the word is present), the segments are flattened into one load-balanced index space (exclusive
+//                scan of their lengths, binary search per posting) and accumulated with LDS 64-bit atomics;
+//   output     : acc / ni, written straight from LDS.
+// LDS: acc[256] i64 | ni[256] | start[wcap] | scan[wcap + 1] | idf[wcap] | scratch[SCB / 64 + 1].
 template <int SCB>
-__device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, const BucketDev* __restrict__ tab, int b, int g, int G, int wg_cap,
-                                                  const uint32_t* __restrict__ q_w, const float* __restrict__ q_idf,
-                                                  const uint32_t* __restrict__ q_meta, const uint32_t* __restrict__ slot_ni,
-                                                  unsigned long long* __restrict__ lfix, float* __restrict__ out_like) {
+__device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, const ScoreArgs& A, int b) {
     unsigned long long* acc = sc_smem;                              // [R]
     uint32_t* s_ni = (uint32_t*)(acc + TF_R);                       // [R]
-    uint32_t* s_start = s_ni + TF_R;                                // [wg_cap]
-    uint32_t* s_scan = s_start + wg_cap;                            // [wg_cap + 1]
-    float* s_idf = (float*)(s_scan + wg_cap + 1);                   // [wg_cap]
-    uint32_t* s_len = (uint32_t*)(s_idf + wg_cap);                  // [wg_cap]
-    uint32_t* scratch = s_len + wg_cap;                             // [SCB + 1]
+    uint32_t* s_start = s_ni + TF_R;                                // [wcap]
+    uint32_t* s_scan = s_start + A.wcap;                            // [wcap + 1]
+    int32_t* s_idf = (int32_t*)(s_scan + A.wcap + 1);               // [wcap]
+    uint32_t* scratch = (uint32_t*)(s_idf + A.wcap);                // [SCB / 64 + 1]
     const int tid = threadIdx.x;
-    const uint32_t* __restrict__ dir = tab[b].dir;
-    const uint32_t* __restrict__ ent = tab[b].ent;
-    const uint32_t W = tab[b].W;
+    const BucketDev B = A.tab[b];
     const long long first_slot = (long long)b * TF_R;
-    if (dir == nullptr) {                                           // every signature of the bucket is retired
-        if (out_like) for (int i = tid; i < TF_R; i += SCB) out_like[first_slot + i] = 0.0f;
+    if (B.state != 1u) {                                            // every signature of the bucket is retired
+        for (int i = tid; i < TF_R; i += SCB) {
+            if (A.out_like) A.out_like[first_slot + i] = 0.0f; else A.out_fix[first_slot + i] = 0;
+        }
         return;
     }
     SC_STAMP(0);
-    const int U = (int)q_meta[0];
-    int Ug = U > g ? (U - g + G - 1) / G : 0;
-    if (Ug > wg_cap) Ug = wg_cap;                                   // cannot happen: wg_cap is sized from the word count
-    for (int i = tid; i < TF_R; i += SCB) { acc[i] = 0ull; s_ni[i] = slot_ni[first_slot + i]; }
-    // A word's postings inside this bucket are one segment.  LONG segments (>= 64 postings, i.e. words present in a quarter or
-    // more of the bucket's signatures: with a heavy-tailed vocabulary they hold most of the postings) are walked wave by wave in
-    // 64-posting chunks -- the word, hence idf, is wave-uniform and no per-posting lookup is needed; the SHORT ones are walked as
-    // one flattened, load-balanced list (s_scan = exclusive scan of their lengths).
-    for (int k = tid; k < Ug; k += SCB) {
-        const int u = g + k * G;
-        const uint32_t w = q_w[u];
-        const float idf = q_idf[u];
-        uint32_t s = 0, e = 0;
-        if (w < W && idf != 0.0f) { s = dir[w]; e = dir[w + 1]; }    // "if(logNnw)" (Memory.cpp:2267)
-        s_start[k] = s;
-        s_len[k] = e - s;
-        s_scan[k] = (e - s) < 64u ? (e - s) : 0u;
+    const uint32_t D = A.bkt_D[b];
+    const uint32_t flags = A.bkt_flags[b];
+    int U = (int)A.q_meta[0];
+    const int Ud = (int)A.q_meta[1];
+    if (U > A.wcap) U = A.wcap;                                     // cannot happen: wcap is sized from the word count
+    for (int i = tid; i < TF_R; i += SCB) { acc[i] = 0ull; s_ni[i] = A.slot_ni[first_slot + i]; }
+    // ---- sparse directory lookups (requested first: their round trips overlap the dense rows)
+    for (int k = tid; k < U; k += SCB) {
+        const uint32_t w = A.q_w[k];
+        const int32_t idf = A.q_idf[k];
+        const int32_t d = A.q_did[k];
+        const bool dense_here = d >= 0 && (uint32_t)d < D;
+        uint32_t start = 0, len = 0;
+        if (idf != 0 && w < B.W && (!dense_here || (flags & 1u))) {  // a dense word has sparse postings only for counts > 255
+            const uint2 blk = B.dirb[w >> 5];
+            const uint32_t bit = 1u << (w & 31);
+            if (blk.x & bit) {
+                const uint32_t r = blk.y + (uint32_t)__popc(blk.x & (bit - 1u));
+                start = B.sp_off[r];
+                len = B.sp_off[r + 1] - start;
+            }
+        }
+        s_start[k] = start;
+        s_scan[k] = len;
         s_idf[k] = idf;
     }
-    if (tid == 0) s_scan[Ug] = 0;
-    __syncthreads();
-    SC_STAMP(1);
-    const uint32_t T = block_exclusive_scan(s_scan, Ug + 1, scratch);   // s_scan[Ug] == T afterwards
-    // The first four short postings of every thread are located (binary search in the scanned offsets, LDS; four independent
-    // chains) and REQUESTED now; they are consumed after the long segments, whose walk hides that round trip.
-    uint32_t sh_addr[4], sh_e[4]; int sh_k[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const uint32_t t = (uint32_t)tid + (uint32_t)(u * SCB);
-        int lo = 0, hi = Ug;                             // largest k with s_scan[k] <= t  (s_scan[Ug] == T > t)
-        if (t < T) { while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_scan[mid] <= t) lo = mid; else hi = mid; } }
-        sh_k[u] = lo;
-        sh_addr[u] = t < T ? s_start[lo] + (t - s_scan[lo]) : 0xFFFFFFFFu;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) sh_e[u] = sh_addr[u] != 0xFFFFFFFFu ? ent[sh_addr[u]] : 0u;
+    if (tid == 0) s_scan[U] = 0u;
+    // ---- dense rows
+    long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     {
-        // A segment has at most TF_R = 256 postings (one per signature of the bucket), i.e. four 64-posting chunks.  A wave
-        // takes four words per trip and puts all (up to 16) chunk loads in flight before it touches any of them: the walk is a
-        // chain of memory round trips otherwise (one per chunk).
-        const int wv = tid >> 6, ln = tid & 63, nwv = SCB / 64;
-        static_assert(TF_R == 256, "four chunks per segment");
-        for (int k0 = wv; k0 < Ug; k0 += 4 * nwv) {
-            uint32_t len[4], e[4][4];
-            float idf[4];
+        const int wv = tid >> 6, ln = tid & 63;
+        constexpr int NWV = SCB / 64;
+        for (int j0 = wv; j0 < Ud; j0 += 4 * NWV) {
+            uint32_t c[4]; int32_t f[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = k0 + j * nwv;
-                const uint32_t l = k < Ug ? s_len[k] : 0u;
-                len[j] = l >= 64u ? l : 0u;                          // wave-uniform
-                idf[j] = k < Ug ? s_idf[k] : 0.0f;
-                const uint32_t start = k < Ug ? s_start[k] : 0u;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint32_t o = (uint32_t)(c * 64 + ln);
-                    e[j][c] = o < len[j] ? ent[start + o] : 0xFFFFFFFFu;      // a posting is < 2^30: the sentinel cannot occur
-                }
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * NWV;
+                int32_t d = -1; f[u] = 0;
+                if (j < Ud) { d = A.qd_did[j]; f[u] = A.qd_idf[j]; }
+                c[u] = (d >= 0 && (uint32_t)d < D) ? *(const uint32_t*)(B.dense + (size_t)d * TF_R + 4 * ln) : 0u;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint32_t p = e[j][c];
-                    if (p == 0xFFFFFFFFu) continue;
-                    const uint32_t sl = p >> TF_CNT_BITS;
-                    const uint32_t ni = s_ni[sl];
-                    if (ni != 0u) {
-                        const float term = __fdiv_rn(__fmul_rn((float)(p & TF_CNT_MASK), idf[j]), (float)ni);
-                        atomicAdd(&acc[sl], to_fixed(term));
-                    }
-                }
+            for (int u = 0; u < 4; ++u) {
+                const long long f64 = (long long)f[u];
+                a0 += (long long)(int)(c[u] & 255u) * f64;
+                a1 += (long long)(int)((c[u] >> 8) & 255u) * f64;
+                a2 += (long long)(int)((c[u] >> 16) & 255u) * f64;
+                a3 += (long long)(int)(c[u] >> 24) * f64;
             }
         }
     }
+    __syncthreads();                                                 // acc zeroed, s_* complete
+    SC_STAMP(1);
+    {
+        const int ln4 = (tid & 63) * 4;
+        if (a0) atomicAdd(&acc[ln4 + 0], (unsigned long long)a0);
+        if (a1) atomicAdd(&acc[ln4 + 1], (unsigned long long)a1);
+        if (a2) atomicAdd(&acc[ln4 + 2], (unsigned long long)a2);
+        if (a3) atomicAdd(&acc[ln4 + 3], (unsigned long long)a3);
+    }
+    const uint32_t T = block_exclusive_scan<SCB>(s_scan, U + 1, scratch);   // s_scan[U] == T afterwards
     SC_STAMP(2);
-    // the short postings requested above ...
+    for (uint32_t t0 = (uint32_t)tid; t0 < T; t0 += 2 * SCB) {
+        uint32_t addr[2], e[2]; int kk[2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        if (sh_addr[u] == 0xFFFFFFFFu) continue;
-        const uint32_t sl = sh_e[u] >> TF_CNT_BITS;
-        const uint32_t ni = s_ni[sl];
-        if (ni != 0u) {                                              // "if(ni != 0)" (Memory.cpp:2275), 0 = retired slot
-            const float term = __fdiv_rn(__fmul_rn((float)(sh_e[u] & TF_CNT_MASK), s_idf[sh_k[u]]), (float)ni);
-            atomicAdd(&acc[sl], to_fixed(term));                     // ds_add_u64
-        }
-    }
-    // ... and, for a bucket with more than 4 * SCB of them, the rest: four per thread and trip
-    for (uint32_t t0 = (uint32_t)tid + 4u * SCB; t0 < T; t0 += 4 * SCB) {
-        uint32_t addr[4]; int kk[4]; uint32_t e[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const uint32_t t = t0 + u * SCB;
-            int lo = 0, hi = Ug;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_scan[mid] <= t) lo = mid; else hi = mid; }
+            int lo = 0, hi = U;                             // largest k with s_scan[k] <= t  (s_scan[U] == T > t)
+            if (t < T) { while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_scan[mid] <= t) lo = mid; else hi = mid; } }
             kk[u] = lo;
             addr[u] = t < T ? s_start[lo] + (t - s_scan[lo]) : 0xFFFFFFFFu;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = addr[u] != 0xFFFFFFFFu ? ent[addr[u]] : 0u;
+        for (int u = 0; u < 2; ++u) e[u] = addr[u] != 0xFFFFFFFFu ? B.sp_ent[addr[u]] : 0u;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 2; ++u) {
             if (addr[u] == 0xFFFFFFFFu) continue;
-            const uint32_t sl = e[u] >> TF_CNT_BITS;
-            const uint32_t ni = s_ni[sl];
-            if (ni != 0u) {
-                const float term = __fdiv_rn(__fmul_rn((float)(e[u] & TF_CNT_MASK), s_idf[kk[u]]), (float)ni);
-                atomicAdd(&acc[sl], to_fixed(term));
-            }
+            const long long term = (long long)(int)(e[u] & TF_CNT_MASK) * (long long)s_idf[kk[u]];
+            atomicAdd(&acc[e[u] >> TF_CNT_BITS], (unsigned long long)term);      // ds_add_u64
         }
     }
     __syncthreads();
     SC_STAMP(3);
     for (int i = tid; i < TF_R; i += SCB) {
-        const unsigned long long v = acc[i];
-        if (out_like) out_like[first_slot + i] = fixed_to_float(v);
-        else if (v != 0ull) {
-            if (G == 1) lfix[first_slot + i] = v;
-            else atomicAdd(&lfix[first_slot + i], v);
-        }
+        const long long v = (long long)acc[i];
+        const uint32_t ni = s_ni[i];
+        if (A.out_like) A.out_like[first_slot + i] = fixed_to_like(v, ni);
+        else A.out_fix[first_slot + i] = ni ? v : 0;
     }
 }
 
-// grid = (sealed live buckets, G word groups)
+// The bucket that is still filling (<= 256 signatures): one wavefront per signature walks the signature's own stretch of the
+// arrival-order log, keeps the postings whose word belongs to the frame (idf_tab stamp) and reduces them inside the wave --
+// no atomics, no second pass, every slot written exactly once.
 template <int SCB>
-__global__ __launch_bounds__(SCB) void score_sealed_kernel(const BucketDev* __restrict__ tab, const int32_t* __restrict__ list, int G,
-                                                           int wg_cap, const uint32_t* __restrict__ q_w,
-                                                           const float* __restrict__ q_idf, const uint32_t* __restrict__ q_meta,
-                                                           const uint32_t* __restrict__ slot_ni,
-                                                           unsigned long long* __restrict__ lfix) {
-    extern __shared__ unsigned long long sc_smem[];
-    score_sealed_body<SCB>(sc_smem, tab, list[blockIdx.x], blockIdx.y, G, wg_cap, q_w, q_idf, q_meta, slot_ni, lfix, nullptr);
-}
-
-// ---------------------------------------------------------------------------------------------- open bucket
-// The arrival-order log of the bucket that is still filling (<= TF_R signatures) is scanned once: a word-slot bitmap in
-// LDS rejects the postings of words the frame does not contain, the survivors fetch idf from idf_tab.  The log is
-// slot-major, so the postings a workgroup sees belong to a handful of consecutive signatures: they are summed in a
-// small LDS window first and only the window is flushed with global atomics.
-constexpr int OPEN_WIN = 64;
-// ob / n_ob: this workgroup's index among the open-bucket workgroups.  With out_like != NULL the LAST of them to finish
-// (agent-scope release / acquire around done_counter) converts the bucket's slots to float and re-zeroes lfix.
-__device__ __forceinline__ void score_open_body(uint32_t* so_smem, int ob, int n_ob, const uint32_t* __restrict__ coo_w,
-                                                const uint32_t* __restrict__ coo_pc, const uint32_t* __restrict__ ne_counter,
-                                                long long first_slot, int n_open_slots, int bitmap_words, uint32_t stamp,
-                                                const uint32_t* __restrict__ q_w, const uint32_t* __restrict__ q_meta,
-                                                const uint2* __restrict__ idf_tab, const uint32_t* __restrict__ slot_ni,
-                                                unsigned long long* __restrict__ lfix, float* __restrict__ out_like,
-                                                int* __restrict__ done_counter) {
-    uint32_t* s_bits = so_smem;                 // [bitmap_words] membership bitmap over word slots (0 words = not used)
-    __shared__ unsigned long long s_win[OPEN_WIN];
-    __shared__ uint32_t s_win0;
-    __shared__ int s_last;
-    const int nt = blockDim.x;
-    const uint32_t ne = ne_counter[0];
-    const uint32_t per = (ne + n_ob - 1) / n_ob;                    // contiguous chunk of the log per workgroup
-    const uint32_t e0 = min((uint32_t)ob * per, ne), e1 = min(e0 + per, ne);
-    if (e0 < e1) {
-        const int U = (int)q_meta[0];
-        for (int i = threadIdx.x; i < bitmap_words; i += nt) s_bits[i] = 0u;
-        if (threadIdx.x < OPEN_WIN) s_win[threadIdx.x] = 0ull;
-        if (threadIdx.x == 0) s_win0 = coo_pc[e0] >> TF_CNT_BITS;  // slot_local of the chunk's first posting
-        __syncthreads();
-        for (int i = threadIdx.x; i < U; i += nt) {
-            const uint32_t w = q_w[i];
-            if ((w >> 5) < (uint32_t)bitmap_words) atomicOr(&s_bits[w >> 5], 1u << (w & 31));
-        }
-        __syncthreads();
-        const uint32_t win0 = s_win0;
-        for (uint32_t e = e0 + threadIdx.x; e < e1; e += nt) {
-            const uint32_t w = coo_w[e];
-            if ((w >> 5) < (uint32_t)bitmap_words && !((s_bits[w >> 5] >> (w & 31)) & 1u)) continue;   // not a word of the frame
-            const uint2 t = idf_tab[w];
-            if (t.x != stamp) continue;
-            const float idf = __uint_as_float(t.y);
-            if (idf == 0.0f) continue;                                   // "if(logNnw)" (Memory.cpp:2267)
-            const uint32_t pc = coo_pc[e];
-            const uint32_t sl = pc >> TF_CNT_BITS;
-            const uint32_t ni = slot_ni[first_slot + sl];
-            if (ni == 0u) continue;
-            const unsigned long long v = to_fixed(__fdiv_rn(__fmul_rn((float)(pc & TF_CNT_MASK), idf), (float)ni));
-            if (sl - win0 < (uint32_t)OPEN_WIN) atomicAdd(&s_win[sl - win0], v);
-            else atomicAdd(&lfix[first_slot + sl], v);
-        }
-        __syncthreads();
-        if (threadIdx.x < OPEN_WIN) {
-            const unsigned long long v = s_win[threadIdx.x];
-            if (v != 0ull) atomicAdd(&lfix[first_slot + win0 + threadIdx.x], v);
+__device__ __forceinline__ void score_open_body(const ScoreArgs& A, int ob) {
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int sl = ob * (SCB / 64) + wv;
+    if (sl >= A.n_open_slots) return;
+    const BucketDev B = A.tab[A.n_closed];
+    const long long slot = (long long)A.n_closed * TF_R + sl;
+    const uint32_t begin = A.slot_begin[slot], cnt = A.slot_cnt[slot], ni = A.slot_ni[slot];
+    long long acc = 0;
+    if (ni != 0u) {
+        for (uint32_t e0 = 0; e0 < cnt; e0 += 4 * 64) {
+            uint32_t w[4], pc[4]; uint2 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t e = e0 + u * 64 + ln;
+                w[u] = e < cnt ? B.coo_w[begin + e] : 0xFFFFFFFFu;
+                pc[u] = e < cnt ? B.coo_pc[begin + e] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = w[u] != 0xFFFFFFFFu ? A.idf_tab[w[u]] : make_uint2(0u, 0u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (w[u] != 0xFFFFFFFFu && t[u].x == A.stamp) acc += (long long)(int)(pc[u] & TF_CNT_MASK) * (long long)(int32_t)t[u].y;
         }
     }
-    if (!out_like) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int ticket = __hip_atomic_fetch_add(done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = ticket == n_ob - 1;
-        if (s_last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); done_counter[0] = 0; }
+    int lo = (int)(uint32_t)acc, hi = (int)(acc >> 32);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int olo = __shfl_xor(lo, off, 64), ohi = __shfl_xor(hi, off, 64);
+        const long long s = (((long long)hi << 32) | (uint32_t)lo) + (((long long)ohi << 32) | (uint32_t)olo);
+        lo = (int)(uint32_t)s; hi = (int)(s >> 32);
     }
-    __syncthreads();
-    if (!s_last) return;
-    for (int i = threadIdx.x; i < n_open_slots; i += nt) {
-        const unsigned long long v = __hip_atomic_load(&lfix[first_slot + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        out_like[first_slot + i] = fixed_to_float(v);
-        if (v != 0ull) lfix[first_slot + i] = 0ull;
+    if (ln == 0) {
+        const long long v = ((long long)hi << 32) | (uint32_t)lo;
+        if (A.out_like) A.out_like[slot] = fixed_to_like(v, ni);
+        else A.out_fix[slot] = ni ? v : 0;
     }
 }
 
-__global__ __launch_bounds__(SC_BLOCK) void score_open_kernel(const uint32_t* __restrict__ coo_w, const uint32_t* __restrict__ coo_pc,
-                                                              const uint32_t* __restrict__ ne_counter, long long first_slot,
-                                                              int bitmap_words, uint32_t stamp, const uint32_t* __restrict__ q_w,
-                                                              const uint32_t* __restrict__ q_meta, const uint2* __restrict__ idf_tab,
-                                                              const uint32_t* __restrict__ slot_ni,
-                                                              unsigned long long* __restrict__ lfix) {
-    extern __shared__ uint32_t so_smem[];
-    score_open_body(so_smem, blockIdx.x, gridDim.x, coo_w, coo_pc, ne_counter, first_slot, 0, bitmap_words, stamp, q_w, q_meta, idf_tab,
-                    slot_ni, lfix, nullptr, nullptr);
-}
-
-// single-GPU fast path: every sealed bucket (retired ones included: they write zeros) and the open bucket in ONE launch,
-// likelihood written directly -- no lfix round trip, no finalize launch.  blockIdx.x < n_sealed: sealed bucket list_all[x].
+// every closed bucket (dead ones write zeros) and the open bucket in ONE launch, likelihood (or the integer sums) written directly
 template <int SCB>
-__global__ __launch_bounds__(SCB) void score_fused_kernel(const BucketDev* __restrict__ tab, const int32_t* __restrict__ list_all, int n_sealed,
-                                                          int wg_cap, const uint32_t* __restrict__ q_w, const float* __restrict__ q_idf,
-                                                          const uint32_t* __restrict__ q_meta, const uint32_t* __restrict__ slot_ni,
-                                                          unsigned long long* __restrict__ lfix, float* __restrict__ out_like,
-                                                          const uint32_t* __restrict__ coo_w, const uint32_t* __restrict__ coo_pc,
-                                                          const uint32_t* __restrict__ ne_counter, long long open_first_slot,
-                                                          int n_open_slots, int bitmap_words, uint32_t stamp,
-                                                          const uint2* __restrict__ idf_tab, int* __restrict__ done_counter) {
+__global__ __launch_bounds__(SCB) void score_kernel(ScoreArgs A) {
     extern __shared__ unsigned long long sf_smem[];
-    if ((int)blockIdx.x < n_sealed)
-        score_sealed_body<SCB>(sf_smem, tab, list_all[blockIdx.x], 0, 1, wg_cap, q_w, q_idf, q_meta, slot_ni, lfix, out_like);
-    else
-        score_open_body((uint32_t*)sf_smem, (int)blockIdx.x - n_sealed, (int)gridDim.x - n_sealed, coo_w, coo_pc, ne_counter, open_first_slot,
-                        n_open_slots, bitmap_words, stamp, q_w, q_meta, idf_tab, slot_ni, lfix, out_like, done_counter);
+    if ((int)blockIdx.x < A.n_closed) score_sealed_body<SCB>(sf_smem, A, (int)blockIdx.x);
+    else score_open_body<SCB>(A, (int)blockIdx.x - A.n_closed);
 }
 
-// fixed point -> float, and the accumulator is left zeroed for the next frame (no separate memset launch)
-__global__ void finalize_kernel(long long* __restrict__ lfix, long long n, float* __restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const long long v = lfix[i];
-        out[i] = (float)((double)v * (1.0 / 281474976710656.0));   // 2^-48
-        if (v != 0) lfix[i] = 0;
+// what one scoring launch has to read for the frame in q_* (bench.py's algorithmic bytes): cnt[0] dense row bytes, [1] sparse postings,
+// [2] directory lookups, [3] lookups that found the word, [4] entries of the open bucket's log, [5] postings of the frame's words
+// over all live signatures (sum of nw), [6] unique words, [7] dense words of the frame
+__global__ __launch_bounds__(256) void score_work_kernel(ScoreArgs A, const uint32_t* __restrict__ nw, unsigned long long* __restrict__ cnt) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int U = (int)A.q_meta[0], Ud = (int)A.q_meta[1];
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+    if (b < A.n_closed) {
+        const BucketDev B = A.tab[b];
+        if (B.state != 1u) return;
+        const uint32_t D = A.bkt_D[b], flags = A.bkt_flags[b];
+        for (int j = tid; j < Ud; j += 256) if ((uint32_t)A.qd_did[j] < D) c0 += TF_R;
+        for (int k = tid; k < U; k += 256) {
+            const uint32_t w = A.q_w[k];
+            const int32_t d = A.q_did[k];
+            const bool dense_here = d >= 0 && (uint32_t)d < D;
+            if (A.q_idf[k] != 0 && w < B.W && (!dense_here || (flags & 1u))) {
+                c2 += 1;
+                const uint2 blk = B.dirb[w >> 5];
+                const uint32_t bit = 1u << (w & 31);
+                if (blk.x & bit) {
+                    const uint32_t r = blk.y + (uint32_t)__popc(blk.x & (bit - 1u));
+                    c1 += B.sp_off[r + 1] - B.sp_off[r];
+                    c3 += 1;
+                }
+            }
+        }
+    } else {
+        for (int sl = tid; sl < A.n_open_slots; sl += 256) {
+            const long long slot = (long long)A.n_closed * TF_R + sl;
+            if (A.slot_ni[slot] != 0u) c4 += A.slot_cnt[slot];
+        }
+        for (int k = tid; k < U; k += 256) if (A.q_idf[k] != 0) c5 += nw[A.q_w[k]];
+        if (tid == 0) { atomicAdd(&cnt[6], (unsigned long long)U); atomicAdd(&cnt[7], (unsigned long long)Ud); }
     }
+    if (c0) atomicAdd(&cnt[0], c0);
+    if (c1) atomicAdd(&cnt[1], c1);
+    if (c2) atomicAdd(&cnt[2], c2);
+    if (c3) atomicAdd(&cnt[3], c3);
+    if (c4) atomicAdd(&cnt[4], c4);
+    if (c5) atomicAdd(&cnt[5], c5);
+}
+
+// fixed point -> float after the cross-GPU sum
+__global__ void finalize_kernel(const long long* __restrict__ lfix, long long n, const uint32_t* __restrict__ slot_ni, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fixed_to_like(lfix[i], slot_ni[i]);
 }
 __global__ void gather_f32_kernel(const float* __restrict__ dense, const long long* __restrict__ slots, int n, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -499,35 +493,113 @@ __global__ void gather_f32_kernel(const float* __restrict__ dense, const long lo
 }
 
 // ---------------------------------------------------------------------------------------------- sealing
-__global__ void seal_count_kernel(const uint32_t* __restrict__ coo_w, uint32_t ne, uint32_t* __restrict__ dir) {
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) atomicAdd(&dir[coo_w[e] + 1], 1u);
+// All sealing kernels take a batch of jobs (blockIdx.y); a single job travels by value in the kernel arguments.
+#define SEAL_JOB() const SealJob J = jobs ? jobs[blockIdx.y] : job1
+
+// (1) postings per word in this bucket
+__global__ __launch_bounds__(SEAL_BLOCK) void seal_count_kernel(const SealJob* __restrict__ jobs, SealJob job1) {
+    SEAL_JOB();
+    const uint32_t ne = min(J.ne[0], J.ent_cap);
+    for (uint32_t e = blockIdx.x * SEAL_BLOCK + threadIdx.x; e < ne; e += gridDim.x * SEAL_BLOCK) atomicAdd(&J.cntw[J.coo_w[e]], 1u);
 }
-// inclusive scan of dir[0..n) in global memory by one workgroup (n up to a few million, sealing is rare)
-__global__ __launch_bounds__(1024) void seal_scan_kernel(uint32_t* __restrict__ dir, uint32_t n) {
-    __shared__ uint32_t scratch[1025];
-    const int tid = threadIdx.x;
-    const uint32_t per = (n + 1023) / 1024;
-    const uint32_t lo = min((uint32_t)tid * per, n), hi = min(lo + per, n);
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += dir[i];
-    scratch[tid] = sum;
+// (2) words that reach TF_DENSE_T postings in one bucket get a dense id (once; several buckets of a batch may race for a word)
+__global__ __launch_bounds__(SEAL_BLOCK) void seal_densify_kernel(const SealJob* __restrict__ jobs, SealJob job1, int32_t* __restrict__ did,
+                                                                  uint32_t* __restrict__ n_dense) {
+    SEAL_JOB();
+    for (uint32_t w = blockIdx.x * SEAL_BLOCK + threadIdx.x; w < J.W; w += gridDim.x * SEAL_BLOCK) {
+        if (J.cntw[w] < (uint32_t)TF_DENSE_T || did[w] != -1) continue;
+        if (__hip_atomic_load(n_dense, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)TF_DENSE_MAX) continue;
+        if (atomicCAS(&did[w], -1, -2) != -1) continue;                    // another bucket of the batch claimed it
+        const uint32_t id = atomicAdd(n_dense, 1u);
+        did[w] = id < (uint32_t)TF_DENSE_MAX ? (int32_t)id : -1;
+    }
+}
+// (3) dense cells are written, the others stay counted in cntw (= sparse postings per word from here on)
+__global__ __launch_bounds__(SEAL_BLOCK) void seal_classify_kernel(const SealJob* __restrict__ jobs, SealJob job1, const int32_t* __restrict__ did,
+                                                                   const uint32_t* __restrict__ n_dense, uint32_t* __restrict__ bkt_D,
+                                                                   uint32_t* __restrict__ bkt_flags, uint32_t* __restrict__ h_n_dense) {
+    SEAL_JOB();
+    const uint32_t nd = min(n_dense[0], (uint32_t)TF_DENSE_MAX);
+    const uint32_t D = min(nd, J.D_alloc);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { bkt_D[J.bucket] = D; if (h_n_dense && blockIdx.y == 0) h_n_dense[0] = nd; }
+    const uint32_t ne = min(J.ne[0], J.ent_cap);
+    for (uint32_t e = blockIdx.x * SEAL_BLOCK + threadIdx.x; e < ne; e += gridDim.x * SEAL_BLOCK) {
+        const uint32_t w = J.coo_w[e], pc = J.coo_pc[e];
+        const int32_t d = did[w];
+        if (d < 0 || (uint32_t)d >= D) continue;
+        const uint32_t cnt = pc & TF_CNT_MASK, sl = pc >> TF_CNT_BITS;
+        J.dense[(size_t)d * TF_R + sl] = (uint8_t)min(cnt, 255u);
+        if (cnt <= 255u) atomicSub(&J.cntw[w], 1u);
+        else atomicOr(&bkt_flags[J.bucket], 1u);                         // the excess stays a sparse posting
+    }
+}
+// (4) per tile of SEAL_TILE wslots: number of present words and of sparse postings
+__global__ __launch_bounds__(SEAL_BLOCK) void seal_tile_kernel(const SealJob* __restrict__ jobs, SealJob job1) {
+    SEAL_JOB();
+    __shared__ uint32_t s_p[SEAL_BLOCK / 64], s_a[SEAL_BLOCK / 64];
+    const uint32_t w0 = (blockIdx.x * SEAL_BLOCK + threadIdx.x) * 32u;
+    uint32_t p = 0, a = 0;
+    for (uint32_t i = 0; i < 32u && w0 + i < J.W; ++i) { const uint32_t c = J.cntw[w0 + i]; p += c ? 1u : 0u; a += c; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { p += __shfl_xor(p, off, 64); a += __shfl_xor(a, off, 64); }
+    if ((threadIdx.x & 63) == 0) { s_p[threadIdx.x >> 6] = p; s_a[threadIdx.x >> 6] = a; }
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const uint32_t t = tid >= off ? scratch[tid - off] : 0;
-        __syncthreads();
-        scratch[tid] += t;
-        __syncthreads();
-    }
-    uint32_t run = scratch[tid] - sum;
-    for (uint32_t i = lo; i < hi; ++i) { run += dir[i]; dir[i] = run; }
-}
-__global__ void seal_scatter_kernel(const uint32_t* __restrict__ coo_w, const uint32_t* __restrict__ coo_pc, uint32_t ne,
-                                    const uint32_t* __restrict__ dir, uint32_t* __restrict__ cursor, uint32_t* __restrict__ ent) {
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
-        const uint32_t w = coo_w[e];
-        ent[dir[w] + atomicAdd(&cursor[w], 1u)] = coo_pc[e];
+    if (threadIdx.x == 0) {
+        uint32_t tp = 0, ta = 0;
+        for (int i = 0; i < SEAL_BLOCK / 64; ++i) { tp += s_p[i]; ta += s_a[i]; }
+        J.tile_sums[2 * blockIdx.x] = tp; J.tile_sums[2 * blockIdx.x + 1] = ta;
     }
 }
+// (5) directory blocks {presence bits, rank of the block's first word} and the offsets of the present words
+__global__ __launch_bounds__(SEAL_BLOCK) void seal_scan_kernel(const SealJob* __restrict__ jobs, SealJob job1) {
+    SEAL_JOB();
+    __shared__ uint32_t s_p[SEAL_BLOCK], s_a[SEAL_BLOCK], scratch[SEAL_BLOCK / 64 + 1];
+    uint32_t base_p = 0, base_a = 0;
+    for (uint32_t t = 0; t < blockIdx.x; ++t) { base_p += J.tile_sums[2 * t]; base_a += J.tile_sums[2 * t + 1]; }
+    const uint32_t blk = blockIdx.x * SEAL_BLOCK + threadIdx.x;
+    const uint32_t w0 = blk * 32u;
+    uint32_t bits = 0, p = 0, a = 0;
+    uint32_t c[32];
+#pragma unroll
+    for (uint32_t i = 0; i < 32u; ++i) {
+        c[i] = (w0 + i < J.W) ? J.cntw[w0 + i] : 0u;
+        if (c[i]) { bits |= 1u << i; p += 1u; }
+        a += c[i];
+    }
+    s_p[threadIdx.x] = p; s_a[threadIdx.x] = a;
+    __syncthreads();
+    const uint32_t tot_p = block_exclusive_scan<SEAL_BLOCK>(s_p, SEAL_BLOCK, scratch);
+    const uint32_t tot_a = block_exclusive_scan<SEAL_BLOCK>(s_a, SEAL_BLOCK, scratch);
+    uint32_t rp = base_p + s_p[threadIdx.x], ra = base_a + s_a[threadIdx.x];
+    if (w0 < J.W) J.dirb[blk] = make_uint2(bits, rp);
+#pragma unroll
+    for (uint32_t i = 0; i < 32u; ++i) if (c[i]) { J.sp_off[rp++] = ra; ra += c[i]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) J.sp_off[base_p + tot_p] = base_a + tot_a;   // end of the last segment
+}
+// (6) sparse postings into their segments (cntw counts down: no second cursor array)
+__global__ __launch_bounds__(SEAL_BLOCK) void seal_scatter_kernel(const SealJob* __restrict__ jobs, SealJob job1, const int32_t* __restrict__ did,
+                                                                  const uint32_t* __restrict__ bkt_D) {
+    SEAL_JOB();
+    const uint32_t D = bkt_D[J.bucket];
+    const uint32_t ne = min(J.ne[0], J.ent_cap);
+    for (uint32_t e = blockIdx.x * SEAL_BLOCK + threadIdx.x; e < ne; e += gridDim.x * SEAL_BLOCK) {
+        const uint32_t w = J.coo_w[e];
+        uint32_t pc = J.coo_pc[e];
+        const int32_t d = did[w];
+        if (d >= 0 && (uint32_t)d < D) {
+            const uint32_t cnt = pc & TF_CNT_MASK;
+            if (cnt <= 255u) continue;
+            pc = (pc & ~TF_CNT_MASK) | (cnt - 255u);
+        }
+        const uint2 blk = J.dirb[w >> 5];
+        const uint32_t r = blk.y + (uint32_t)__popc(blk.x & ((1u << (w & 31)) - 1u));
+        const uint32_t pos = J.sp_off[r] + atomicSub(&J.cntw[w], 1u) - 1u;
+        J.sp_ent[pos] = pc;
+    }
+}
+
+__global__ void set_bucket_kernel(BucketDev* tab, int b, BucketDev v) { tab[b] = v; }
+
 __global__ void retire_kernel(long long slot, const uint32_t* __restrict__ coo_w, const uint32_t* __restrict__ slot_begin,
                               const uint32_t* __restrict__ slot_cnt, uint32_t* __restrict__ nw, uint32_t* __restrict__ slot_ni,
                               int32_t* __restrict__ slot_sig) {
@@ -536,6 +608,25 @@ __global__ void retire_kernel(long long slot, const uint32_t* __restrict__ coo_w
     if (threadIdx.x == 0) { slot_ni[slot] = 0u; slot_sig[slot] = 0; }
 }
 
+// the words left the dictionary: a wslot may be handed out again only if nothing references it (ok[i] tells the host)
+__global__ void wslot_release_kernel(const int32_t* __restrict__ ws, int n, const uint32_t* __restrict__ nw, int32_t* __restrict__ did,
+                                     uint2* __restrict__ idf_tab, uint8_t* __restrict__ ok) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t w = ws[i];
+    const bool free_now = nw[w] == 0u;
+    if (free_now) { did[w] = -1; idf_tab[w] = make_uint2(0u, 0u); }
+    ok[i] = free_now ? 1 : 0;
+}
+// table[pairs[2i]] = pairs[2i + 1]
+__global__ void scatter_pairs_kernel(const int32_t* __restrict__ pairs, int n, int32_t* __restrict__ table) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) table[pairs[2 * i]] = pairs[2 * i + 1];
+}
+__global__ void iota_i32_kernel(int32_t* dst, int n, int32_t first) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = first + i;
+}
 
 // ---------------------------------------------------------------------------------------------- adjustLikelihood
 // Rtabmap::adjustLikelihood (Rtabmap.cpp:5691-5760): mean / sample standard deviation over the entries > 0 after the
@@ -595,6 +686,89 @@ __global__ __launch_bounds__(1024) void adjust_likelihood_kernel(float* __restri
     }
 }
 
+// adjustLikelihood + the best candidate, straight from the dense slot likelihood of a frame: the signatures considered are the
+// live slots among the first n_considered (the caller leaves out the most recent ones: Rtabmap compares against the working
+// memory, not the short-term memory, Rtabmap.cpp:2050-2117).  Two reduction passes; a third one only if the adjusted vector is
+// wanted (entry 0 = virtual place, entry 1 + slot = adjusted value, 0 for slots that are not considered).  On equal likelihood
+// the higher slot wins (the reference walks its map from the highest id down with a strict comparison, Rtabmap.cpp:2150-2156).
+__global__ __launch_bounds__(1024) void hypothesis_kernel(const float* __restrict__ like, const int32_t* __restrict__ slot_sig, long long n_slots,
+                                                          long long n_cons, float ratio, float* __restrict__ adjusted, HypothesisOut* __restrict__ out) {
+    __shared__ double s_sum[1024];
+    __shared__ unsigned int s_cnt[1024];
+    __shared__ unsigned long long s_key[1024];
+    const int tid = threadIdx.x;
+    double sum = 0.0; unsigned int cnt = 0; unsigned long long key = 0ull;   // key = value bits << 32 | slot + 1 (values >= 0 order like their bits)
+    for (long long i = tid; i < n_cons; i += 1024) {
+        if (slot_sig[i] == 0) continue;
+        const float v = like[i];
+        if (v > 0.0f) {
+            sum += (double)v; ++cnt;
+            const unsigned long long k = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(uint32_t)(i + 1);
+            key = k > key ? k : key;
+        }
+    }
+    s_sum[tid] = sum; s_cnt[tid] = cnt; s_key[tid] = key;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) { s_sum[tid] += s_sum[tid + off]; s_cnt[tid] += s_cnt[tid + off]; s_key[tid] = s_key[tid] > s_key[tid + off] ? s_key[tid] : s_key[tid + off]; }
+        __syncthreads();
+    }
+    const unsigned int count = s_cnt[0];
+    const float mean = count ? (float)(s_sum[0] / (double)count) : 0.0f;
+    const unsigned long long best = s_key[0];
+    const float maxv = __uint_as_float((uint32_t)(best >> 32));
+    __syncthreads();
+    double sq = 0.0;
+    for (long long i = tid; i < n_cons; i += 1024) {
+        if (slot_sig[i] == 0) continue;
+        const float v = like[i];
+        if (v > 0.0f) { const float d = v - mean; sq += (double)(d * d); }
+    }
+    s_sum[tid] = sq;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) s_sum[tid] += s_sum[tid + off];
+        __syncthreads();
+    }
+    const float var = count > 1 ? (float)(s_sum[0] / (double)(count - 1)) : 0.0f;
+    const float stdDev = sqrtf(var);
+    const float epsilon = 0.0001f;
+    float vp;
+    if (ratio == 0.0f && stdDev > epsilon && maxv != 0.0f) vp = mean / stdDev + 1.0f;
+    else if (ratio != 0.0f && maxv > mean) vp = stdDev / (maxv - mean) + 1.0f;
+    else vp = 2.0f;
+    if (adjusted) {
+        for (long long i = tid; i < n_slots; i += 1024) {
+            float o = 0.0f;
+            if (i < n_cons && slot_sig[i] != 0) {
+                const float value = like[i];
+                o = 1.0f;
+                if (value > mean + stdDev) {
+                    if (ratio == 0.0f && mean != 0.0f) o = (value - (stdDev - epsilon)) / mean;
+                    else if (ratio != 0.0f && stdDev != 0.0f) o = (value - mean) / stdDev;
+                }
+            }
+            adjusted[1 + i] = o;
+        }
+        if (tid == 0) adjusted[0] = vp;
+    }
+    if (tid == 0) {
+        HypothesisOut h;
+        const long long slot = (long long)(uint32_t)best - 1;
+        h.slot = (int32_t)slot;
+        h.sig_id = slot >= 0 ? slot_sig[slot] : 0;
+        h.likelihood = slot >= 0 ? maxv : 0.0f;
+        float o = 1.0f;
+        if (slot >= 0 && maxv > mean + stdDev) {
+            if (ratio == 0.0f && mean != 0.0f) o = (maxv - (stdDev - epsilon)) / mean;
+            else if (ratio != 0.0f && stdDev != 0.0f) o = (maxv - mean) / stdDev;
+        }
+        h.adjusted = slot >= 0 ? o : 0.0f;
+        h.virtual_place = vp; h.mean = mean; h.stddev = stdDev; h.n_positive = (int32_t)count;
+        *out = h;
+    }
+}
+
 inline int next_pow2(int v) { int p = 2; while (p < v) p <<= 1; return p; }
 
 }  // namespace
@@ -602,6 +776,14 @@ inline int next_pow2(int v) { int p = 2; while (p < v) p <<= 1; return p; }
 hipError_t launch_adjust_likelihood(float* d_L, int n, float ratio, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     adjust_likelihood_kernel<<<1, 1024, 0, s>>>(d_L, n, ratio);
+    return hipGetLastError();
+}
+
+hipError_t launch_hypothesis(const float* d_like, const int32_t* slot_sig, long long n_slots, long long n_considered, float ratio,
+                             float* d_adjusted, HypothesisOut* d_out, hipStream_t s) {
+    if (n_considered < 0) n_considered = 0;
+    if (n_considered > n_slots) n_considered = n_slots;
+    hypothesis_kernel<<<1, 1024, 0, s>>>(d_like, slot_sig, n_slots, n_considered, ratio, d_adjusted, d_out);
     return hipGetLastError();
 }
 
@@ -614,34 +796,79 @@ hipError_t launch_gather_f32(const float* dense, const int64_t* slots, int n, fl
 // ================================================================================================ host side
 #define TF_TRY(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return e__; } while (0)
 
-hipError_t Tfidf::init(hipStream_t s, int64_t* bytes, int64_t sig_capacity) {
-    stream = s;
-    bytes_device = bytes;
-    TF_TRY(ensure_slots(sig_capacity > 0 ? sig_capacity : TF_R));
-    TF_TRY(q_w.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
-    TF_TRY(q_cnt.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
-    TF_TRY(q_idf.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
-    TF_TRY(q_meta.reserve(64, 0, stream, bytes_device));
-    TF_TRY(hipMemsetAsync(q_meta.p, 0, 64, stream));
+hipError_t BufPool::get(size_t bytes, DevBuf* out, int64_t* total) {
+    // smallest free buffer that fits and is not more than 4x too large
+    int best = -1;
+    for (size_t i = 0; i < free_list.size(); ++i) {
+        if (free_list[i].cap >= bytes && free_list[i].cap <= 4 * std::max<size_t>(bytes, 4096) && (best < 0 || free_list[i].cap < free_list[best].cap)) best = (int)i;
+    }
+    if (best >= 0) { *out = free_list[best]; free_list.erase(free_list.begin() + best); return hipSuccess; }
+    size_t cap = 4096;
+    while (cap < bytes) cap *= 2;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, cap);
+    if (e != hipSuccess) return e;
+    out->p = p; out->cap = cap;
+    if (total) *total += (int64_t)cap;
     return hipSuccess;
 }
-
-void Tfidf::destroy() {
-    for (Bucket& b : buckets) { b.coo_w.release(bytes_device); b.coo_pc.release(bytes_device); b.dir.release(bytes_device); b.ent.release(bytes_device); }
-    buckets.clear();
-    DevBuf* all[] = {&slot_sig, &slot_ni, &slot_begin, &slot_cnt, &nw, &bkt_tab, &bkt_ne, &bkt_list, &lfix, &q_w, &q_cnt, &q_idf,
-                     &q_meta, &tmp_cursor, &d_stage, &idf_tab, &bkt_list_all, &open_done};
-    for (DevBuf* d : all) d->release(bytes_device);
-    h_stage.release();
+void BufPool::put(DevBuf* b) {
+    if (b->p) free_list.push_back(*b);
+    b->p = nullptr; b->cap = 0;
+}
+void BufPool::destroy(int64_t* total) {
+    for (DevBuf& b : free_list) b.release(total);
+    free_list.clear();
 }
 
-// grow a zero-initialised table
-static hipError_t grow_zeroed(DevBuf& buf, size_t bytes, hipStream_t s, int64_t* total) {
+// grow a table, new part filled with `byte`
+static hipError_t grow_filled(DevBuf& buf, size_t bytes, int byte, hipStream_t s, int64_t* total) {
     const size_t old = buf.cap;
     if (bytes <= old) return hipSuccess;
     hipError_t e = buf.reserve(bytes, old, s, total);
     if (e != hipSuccess) return e;
-    return hipMemsetAsync((char*)buf.p + old, 0, buf.cap - old, s);
+    return hipMemsetAsync((char*)buf.p + old, byte, buf.cap - old, s);
+}
+static hipError_t grow_zeroed(DevBuf& buf, size_t bytes, hipStream_t s, int64_t* total) { return grow_filled(buf, bytes, 0, s, total); }
+
+static hipError_t set_max_lds(const void* fn) {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t Tfidf::init(hipStream_t s, int64_t* bytes, int64_t sig_capacity) {
+    stream = s;
+    bytes_device = bytes;
+    TF_TRY(ensure_slots(sig_capacity > 0 ? sig_capacity : TF_R));
+    TF_TRY(ensure_buckets((int)((sig_capacity > 0 ? sig_capacity : TF_R) / TF_R) + 64));
+    TF_TRY(ensure_wslots(65536));
+    TF_TRY(q_w.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
+    TF_TRY(q_idf.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
+    TF_TRY(q_did.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
+    TF_TRY(qd_did.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
+    TF_TRY(qd_idf.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
+    TF_TRY(q_meta.reserve(64, 0, stream, bytes_device));
+    TF_TRY(hipMemsetAsync(q_meta.p, 0, 64, stream));
+    TF_TRY(n_dense.reserve(64, 0, stream, bytes_device));
+    TF_TRY(hipMemsetAsync(n_dense.p, 0, 64, stream));
+    TF_TRY(hipHostMalloc((void**)&h_n_dense, 64, hipHostMallocDefault));
+    h_n_dense[0] = 0;
+    TF_TRY(set_max_lds(reinterpret_cast<const void*>(&frame_words_kernel)));
+    TF_TRY(set_max_lds(reinterpret_cast<const void*>(&frame_tail_kernel)));
+    TF_TRY(set_max_lds(reinterpret_cast<const void*>(&bulk_register_kernel)));
+    TF_TRY(set_max_lds(reinterpret_cast<const void*>(&score_kernel<SC_BLOCK>)));
+    return hipSuccess;
+}
+
+void Tfidf::destroy() {
+    harvest_released(true);
+    for (Bucket& b : buckets) { b.coo_w.release(bytes_device); b.coo_pc.release(bytes_device); b.sealed.release(bytes_device); }
+    buckets.clear();
+    pool.destroy(bytes_device);
+    DevBuf* all[] = {&slot_sig, &slot_ni, &slot_begin, &slot_cnt, &nw, &did, &idf_tab, &d_id2ws, &bkt_tab, &bkt_ne, &bkt_D, &bkt_flags,
+                     &n_dense, &seal_cntw, &seal_tiles, &q_w, &q_idf, &q_did, &qd_did, &qd_idf, &q_meta, &d_stage, &d_pairs};
+    for (DevBuf* d : all) d->release(bytes_device);
+    h_stage.release();
+    if (h_n_dense) { (void)hipHostFree(h_n_dense); h_n_dense = nullptr; }
 }
 
 hipError_t Tfidf::ensure_slots(int64_t n) {
@@ -649,79 +876,261 @@ hipError_t Tfidf::ensure_slots(int64_t n) {
     TF_TRY(grow_zeroed(slot_ni, (size_t)n * 4, stream, bytes_device));
     TF_TRY(grow_zeroed(slot_begin, (size_t)n * 4, stream, bytes_device));
     TF_TRY(grow_zeroed(slot_cnt, (size_t)n * 4, stream, bytes_device));
-    TF_TRY(grow_zeroed(lfix, (size_t)n * 8, stream, bytes_device));
     return hipSuccess;
 }
 
-hipError_t Tfidf::wslot_of(int32_t word_id, int32_t* out) {
-    auto it = word_wslot.find(word_id);
-    if (it != word_wslot.end()) { *out = it->second; return hipSuccess; }
-    const int32_t w = n_wslots++;
-    word_wslot.emplace(word_id, w);
-    TF_TRY(grow_zeroed(nw, (size_t)n_wslots * 4, stream, bytes_device));
-    TF_TRY(grow_zeroed(idf_tab, (size_t)n_wslots * 8, stream, bytes_device));
+hipError_t Tfidf::ensure_wslots(int32_t n) {
+    TF_TRY(grow_zeroed(nw, (size_t)n * 4, stream, bytes_device));
+    TF_TRY(grow_filled(did, (size_t)n * 4, 0xFF, stream, bytes_device));
+    TF_TRY(grow_zeroed(idf_tab, (size_t)n * 8, stream, bytes_device));
+    return hipSuccess;
+}
+
+hipError_t Tfidf::ensure_buckets(int n) {
+    TF_TRY(grow_zeroed(bkt_tab, (size_t)n * sizeof(BucketDev), stream, bytes_device));
+    TF_TRY(grow_zeroed(bkt_ne, (size_t)n * 4, stream, bytes_device));
+    TF_TRY(grow_zeroed(bkt_D, (size_t)n * 4, stream, bytes_device));
+    TF_TRY(grow_zeroed(bkt_flags, (size_t)n * 4, stream, bytes_device));
+    return hipSuccess;
+}
+
+hipError_t Tfidf::wslot_of(int32_t word_id, bool create, int32_t* out) {
+    *out = -1;
+    if (word_id <= 0) return hipSuccess;
+    if ((size_t)word_id < id2ws.size() && id2ws[word_id] >= 0) { *out = id2ws[word_id]; return hipSuccess; }
+    int32_t w = -1;
+    if (resv.n > 0 && word_id >= resv.first_id && word_id < resv.first_id + resv.n) {
+        // a new word of the last device-quantised frame: its wslot was reserved when the frame was enqueued
+        w = resv.ws_base + (word_id - resv.first_id);
+    } else {
+        if (!create) return hipSuccess;
+        if (word_id >= (1 << 28)) return hipErrorInvalidValue;        // the id -> wslot table is direct-indexed
+        harvest_released(false);
+        if (!ws_free.empty()) { w = ws_free.back(); ws_free.pop_back(); }
+        else { w = n_wslots++; TF_TRY(ensure_wslots(n_wslots)); }
+    }
+    if ((size_t)word_id >= id2ws.size()) id2ws.resize((size_t)word_id + 1 + id2ws.size() / 2, -1);
+    id2ws[word_id] = w;
+    id2ws_dirty.push_back(word_id);
     *out = w;
     return hipSuccess;
 }
 
-hipError_t Tfidf::upload_buckets() {
-    if (!bkt_dirty) return hipSuccess;
-    h_bkt.resize(buckets.size());
-    std::vector<int32_t> list, list_all;
-    for (size_t i = 0; i < buckets.size(); ++i) {
-        Bucket& b = buckets[i];
-        BucketDev d;
-        d.coo_w = b.coo_w.as<uint32_t>(); d.coo_pc = b.coo_pc.as<uint32_t>();
-        d.dir = b.dir.as<uint32_t>(); d.ent = b.ent.as<uint32_t>();
-        d.W = b.W; d.sealed = b.sealed ? 1u : 0u; d.n_e_sealed = b.n_e_sealed; d.pad = 0;
-        h_bkt[i] = d;
-        if (b.sealed && b.live > 0) list.push_back((int32_t)i);
-        if (b.sealed) list_all.push_back((int32_t)i);
-    }
-    n_list = (int)list.size();
-    n_list_all = (int)list_all.size();
-    if (n_list_all) {
-        TF_TRY(bkt_list_all.reserve(list_all.size() * 4, 0, stream, bytes_device));
-        TF_TRY(hipStreamSynchronize(stream));
-        TF_TRY(hipMemcpy(bkt_list_all.p, list_all.data(), list_all.size() * 4, hipMemcpyHostToDevice));
-    }
-    if (!buckets.empty()) {
-        TF_TRY(bkt_tab.reserve(buckets.size() * sizeof(BucketDev), 0, stream, bytes_device));
-        TF_TRY(hipStreamSynchronize(stream));   // pageable source: keep it simple and ordered
-        TF_TRY(hipMemcpy(bkt_tab.p, h_bkt.data(), buckets.size() * sizeof(BucketDev), hipMemcpyHostToDevice));
-    }
-    if (n_list) {
-        TF_TRY(bkt_list.reserve(list.size() * 4, 0, stream, bytes_device));
-        TF_TRY(hipMemcpy(bkt_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice));
-    }
-    bkt_dirty = false;
+// bring the device copy of id2ws up to date: the entries changed since the last call travel as (id, wslot) pairs
+hipError_t Tfidf::sync_id2ws() {
+    TF_TRY(grow_filled(d_id2ws, std::max<size_t>(id2ws.size(), 1) * 4, 0xFF, stream, bytes_device));
+    d_id2ws_n = (int64_t)(d_id2ws.cap / 4);
+    if (id2ws_dirty.empty()) return hipSuccess;
+    const size_t m = id2ws_dirty.size();
+    TF_TRY(h_stage.reserve(m * 8));
+    int32_t* st = h_stage.as<int32_t>();
+    for (size_t i = 0; i < m; ++i) { st[2 * i] = id2ws_dirty[i]; st[2 * i + 1] = id2ws[id2ws_dirty[i]]; }
+    TF_TRY(d_pairs.reserve(m * 8, 0, stream, bytes_device));
+    TF_TRY(hipMemcpyAsync(d_pairs.p, st, m * 8, hipMemcpyHostToDevice, stream));
+    scatter_pairs_kernel<<<(unsigned)((m + 255) / 256), 256, 0, stream>>>(d_pairs.as<int32_t>(), (int)m, d_id2ws.as<int32_t>());
+    TF_TRY(hipGetLastError());
+    TF_TRY(hipStreamSynchronize(stream));                             // staging buffers are reused
+    id2ws_dirty.clear();
     return hipSuccess;
 }
 
-hipError_t Tfidf::seal(int bi) {
-    Bucket& b = buckets[bi];
-    if (b.sealed) return hipSuccess;
-    uint32_t ne = 0;
-    TF_TRY(hipMemcpyAsync(&ne, bkt_ne.as<uint32_t>() + bi, 4, hipMemcpyDeviceToHost, stream));
-    TF_TRY(hipStreamSynchronize(stream));
-    const uint32_t W = (uint32_t)n_wslots;
-    TF_TRY(b.dir.reserve(((size_t)W + 1) * 4, 0, stream, bytes_device));
-    TF_TRY(b.ent.reserve(std::max<size_t>(ne, 1) * 4, 0, stream, bytes_device));
-    TF_TRY(tmp_cursor.reserve(((size_t)W + 1) * 4, 0, stream, bytes_device));
-    TF_TRY(hipMemsetAsync(b.dir.p, 0, ((size_t)W + 1) * 4, stream));
-    TF_TRY(hipMemsetAsync(tmp_cursor.p, 0, ((size_t)W + 1) * 4, stream));
-    if (ne) {
-        int blocks = (int)std::min<uint32_t>((ne + 255) / 256, 1024);
-        seal_count_kernel<<<blocks, 256, 0, stream>>>(b.coo_w.as<uint32_t>(), ne, b.dir.as<uint32_t>());
-        seal_scan_kernel<<<1, 1024, 0, stream>>>(b.dir.as<uint32_t>(), W + 1);
-        seal_scatter_kernel<<<blocks, 256, 0, stream>>>(b.coo_w.as<uint32_t>(), b.coo_pc.as<uint32_t>(), ne, b.dir.as<uint32_t>(),
-                                                       tmp_cursor.as<uint32_t>(), b.ent.as<uint32_t>());
-        TF_TRY(hipGetLastError());
+void Tfidf::harvest_released(bool wait) {
+    for (size_t i = 0; i < releasing.size();) {
+        ReleaseBatch& r = releasing[i];
+        const hipError_t q = wait ? hipEventSynchronize(r.ev) : hipEventQuery(r.ev);
+        if (q != hipSuccess) { ++i; continue; }
+        for (size_t k = 0; k < r.ws.size(); ++k) if (r.ok[k]) ws_free.push_back(r.ws[k]);
+        (void)hipEventDestroy(r.ev);
+        (void)hipHostFree(r.pinned);
+        releasing.erase(releasing.begin() + i);
     }
-    b.W = W;
-    b.n_e_sealed = ne;
-    b.sealed = true;
-    bkt_dirty = true;
+}
+
+// hand wslots back: a kernel checks each one (nw == 0) and reports through pinned memory; the host collects the verdicts of
+// finished batches later (harvest_released), so nothing is synchronised here and a wslot that is still referenced is never reused
+hipError_t Tfidf::release_wslots(const std::vector<int32_t>& ws) {
+    if (ws.empty()) return hipSuccess;
+    const size_t m = ws.size();
+    ReleaseBatch r;
+    r.ws = ws;
+    TF_TRY(hipHostMalloc(&r.pinned, m * 5 + 16, hipHostMallocDefault));      // [m wslots][m verdicts]
+    int32_t* p_ws = (int32_t*)r.pinned;
+    uint8_t* p_ok = (uint8_t*)(p_ws + m);
+    std::memcpy(p_ws, ws.data(), m * 4);
+    std::memset(p_ok, 0, m);
+    r.ok = p_ok;
+    wslot_release_kernel<<<(unsigned)((m + 255) / 256), 256, 0, stream>>>(p_ws, (int)m, nw.as<uint32_t>(), did.as<int32_t>(),
+                                                                           idf_tab.as<uint2>(), p_ok);
+    TF_TRY(hipGetLastError());
+    TF_TRY(hipEventCreateWithFlags(&r.ev, hipEventDisableTiming));
+    TF_TRY(hipEventRecord(r.ev, stream));
+    releasing.push_back(r);
+    return hipSuccess;
+}
+
+hipError_t Tfidf::release_words(const int32_t* word_ids, int n) {
+    std::vector<int32_t> ws;
+    for (int i = 0; i < n; ++i) {
+        int32_t w = -1;
+        TF_TRY(wslot_of(word_ids[i], false, &w));
+        if (w < 0) continue;
+        id2ws[word_ids[i]] = -1;
+        id2ws_dirty.push_back(word_ids[i]);
+        ws.push_back(w);
+    }
+    return release_wslots(ws);
+}
+
+hipError_t Tfidf::reserve_new_words(int32_t first_id, int n, int32_t* ws_base) {
+    *ws_base = -1;
+    if (first_id <= 0 || n <= 0) return hipSuccess;
+    if ((int64_t)first_id + n >= (1 << 28)) return hipErrorInvalidValue;
+    // the previous reservation: ids below first_id were handed to new words (their mapping becomes permanent), the rest of its
+    // wslots go back through the verified release path (a wslot is recycled only if the device finds it unreferenced)
+    if (resv.n > 0) {
+        const int32_t used = std::max(0, std::min(resv.n, first_id - resv.first_id));
+        if ((size_t)(resv.first_id + used) > id2ws.size()) id2ws.resize((size_t)(resv.first_id + used) + id2ws.size() / 2, -1);
+        for (int32_t k = 0; k < used; ++k)
+            if (id2ws[resv.first_id + k] < 0) { id2ws[resv.first_id + k] = resv.ws_base + k; id2ws_dirty.push_back(resv.first_id + k); }
+        std::vector<int32_t> rest_ws;
+        for (int32_t k = used; k < resv.n; ++k) rest_ws.push_back(resv.ws_base + k);
+        resv.n = 0;
+        TF_TRY(release_wslots(rest_ws));
+    }
+    harvest_released(false);
+    const int32_t base = n_wslots;                                    // consecutive: taken from the top, not from the free list
+    n_wslots += n;
+    TF_TRY(ensure_wslots(n_wslots));
+    resv.first_id = first_id; resv.ws_base = base; resv.n = n;
+    *ws_base = base;
+    return hipSuccess;
+}
+
+hipError_t Tfidf::set_bucket(int b) {
+    const Bucket& k = buckets[b];
+    BucketDev d;
+    d.coo_w = k.coo_w.as<uint32_t>(); d.coo_pc = k.coo_pc.as<uint32_t>();
+    d.dense = k.sealed.as<uint8_t>();
+    d.dirb = k.sealed.p ? (const uint2*)((const char*)k.sealed.p + k.off_dirb) : nullptr;
+    d.sp_off = k.sealed.p ? (const uint32_t*)((const char*)k.sealed.p + k.off_spoff) : nullptr;
+    d.sp_ent = k.sealed.p ? (const uint32_t*)((const char*)k.sealed.p + k.off_spent) : nullptr;
+    d.W = k.W; d.D_alloc = k.D_alloc; d.state = (uint32_t)k.state; d.pad = 0;
+    set_bucket_kernel<<<1, 1, 0, stream>>>(bkt_tab.as<BucketDev>(), b, d);
+    return hipGetLastError();
+}
+
+hipError_t Tfidf::new_bucket() {
+    const int b = (int)buckets.size();
+    buckets.emplace_back();
+    TF_TRY(ensure_buckets(b + 1));
+    return hipSuccess;
+}
+
+// log capacity of bucket b for `entries` postings (grows; the first allocation comes from the pool)
+static hipError_t ensure_log(Tfidf& t, int b, int64_t entries) {
+    Bucket& k = t.buckets[b];
+    const size_t need = (size_t)std::max<int64_t>(entries, 1) * 4;
+    if (need <= k.coo_w.cap) return hipSuccess;
+    if (!k.coo_w.p) {
+        TF_TRY(t.pool.get(std::max(need, (size_t)TF_R * 512 * 4), &k.coo_w, t.bytes_device));
+        TF_TRY(t.pool.get(std::max(need, (size_t)TF_R * 512 * 4), &k.coo_pc, t.bytes_device));
+    } else {
+        TF_TRY(k.coo_w.reserve(need, (size_t)k.ub_entries * 4, t.stream, t.bytes_device));
+        TF_TRY(k.coo_pc.reserve(need, (size_t)k.ub_entries * 4, t.stream, t.bytes_device));
+    }
+    return t.set_bucket(b);
+}
+
+// Seal full buckets on the device.  bulk: the caller is a synchronous bulk load -- the dense ids discovered in the first batch are
+// read back once so that every bucket of the load gets exactly the rows it needs; otherwise nothing is read back and the number
+// of rows is an upper estimate from the (possibly stale) pinned mirror of the dense-id counter.
+hipError_t Tfidf::seal_batch(const std::vector<int>& ids, bool bulk) {
+    if (ids.empty()) return hipSuccess;
+    const uint32_t W = (uint32_t)n_wslots;
+    const int tiles = std::max(1, (int)((W + SEAL_TILE - 1) / SEAL_TILE));
+    const size_t BATCH = 64;
+    TF_TRY(seal_cntw.reserve(std::min(BATCH, ids.size()) * std::max<size_t>(W, 1) * 4, 0, stream, bytes_device));
+    TF_TRY(seal_tiles.reserve(std::min(BATCH, ids.size()) * (size_t)tiles * 8, 0, stream, bytes_device));
+    DevBuf d_jobs;                                                     // batch > 1: job table on the device
+    bool have_dense_count = false;
+    for (size_t i0 = 0; i0 < ids.size(); i0 += BATCH) {
+        const size_t nb = std::min(BATCH, ids.size() - i0);
+        std::vector<SealJob> jobs(nb);
+        uint32_t max_e = 1;
+        TF_TRY(hipMemsetAsync(seal_cntw.p, 0, nb * std::max<size_t>(W, 1) * 4, stream));
+        for (size_t j = 0; j < nb; ++j) {
+            Bucket& k = buckets[ids[i0 + j]];
+            SealJob& J = jobs[j];
+            J.bucket = ids[i0 + j];
+            J.coo_w = k.coo_w.as<uint32_t>(); J.coo_pc = k.coo_pc.as<uint32_t>(); J.ne = bkt_ne.as<uint32_t>() + J.bucket;
+            J.cntw = seal_cntw.as<uint32_t>() + j * (size_t)W; J.tile_sums = seal_tiles.as<uint32_t>() + j * (size_t)tiles * 2;
+            J.W = W; J.ent_cap = (uint32_t)std::max<int64_t>(k.ub_entries, 1);
+            J.dense = nullptr; J.D_alloc = 0; J.dirb = nullptr; J.sp_off = nullptr; J.sp_ent = nullptr;
+            max_e = std::max(max_e, J.ent_cap);
+        }
+        const SealJob* dj = nullptr;
+        auto upload_jobs = [&]() -> hipError_t {
+            if (nb == 1) return hipSuccess;
+            TF_TRY(d_jobs.reserve(nb * sizeof(SealJob), 0, stream, bytes_device));
+            TF_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), nb * sizeof(SealJob), hipMemcpyHostToDevice, stream));
+            TF_TRY(hipStreamSynchronize(stream));                      // pageable source; only bulk loads come here
+            dj = (const SealJob*)d_jobs.p;
+            return hipSuccess;
+        };
+        TF_TRY(upload_jobs());
+        const dim3 ge((unsigned)std::min<uint32_t>((max_e + SEAL_BLOCK - 1) / SEAL_BLOCK, 512), (unsigned)nb);
+        const dim3 gw((unsigned)std::min<uint32_t>((W + SEAL_BLOCK - 1) / SEAL_BLOCK + 1, 512), (unsigned)nb);
+        seal_count_kernel<<<ge, SEAL_BLOCK, 0, stream>>>(dj, jobs[0]);
+        seal_densify_kernel<<<gw, SEAL_BLOCK, 0, stream>>>(dj, jobs[0], did.as<int32_t>(), n_dense.as<uint32_t>());
+        TF_TRY(hipGetLastError());
+        uint32_t D_alloc;
+        if (bulk) {
+            if (!have_dense_count) {
+                uint32_t nd = 0;
+                TF_TRY(hipMemcpyAsync(&nd, n_dense.p, 4, hipMemcpyDeviceToHost, stream));
+                TF_TRY(hipStreamSynchronize(stream));
+                h_n_dense[0] = std::min<uint32_t>(nd, TF_DENSE_MAX);
+                have_dense_count = true;
+            }
+            D_alloc = std::min<uint32_t>(TF_DENSE_MAX, h_n_dense[0] + 32);
+        } else {
+            const uint32_t hv = *(volatile uint32_t*)h_n_dense;
+            D_alloc = std::min<uint32_t>(TF_DENSE_MAX, hv + (hv ? 128u : 1024u));
+        }
+        for (size_t j = 0; j < nb; ++j) {
+            Bucket& k = buckets[ids[i0 + j]];
+            SealJob& J = jobs[j];
+            const size_t a256 = 255;
+            const size_t sz_dense = ((size_t)D_alloc * TF_R + a256) & ~a256;
+            const size_t sz_dirb = ((((size_t)W + 31) / 32) * 8 + a256) & ~a256;
+            const size_t sz_off = ((std::min<size_t>(J.ent_cap, W) + 1) * 4 + a256) & ~a256;
+            const size_t sz_ent = ((size_t)J.ent_cap * 4 + a256) & ~a256;
+            TF_TRY(pool.get(sz_dense + sz_dirb + sz_off + sz_ent, &k.sealed, bytes_device));
+            k.off_dirb = sz_dense; k.off_spoff = sz_dense + sz_dirb; k.off_spent = sz_dense + sz_dirb + sz_off;
+            k.W = W; k.D_alloc = D_alloc;
+            J.dense = k.sealed.as<uint8_t>(); J.D_alloc = D_alloc;
+            J.dirb = (uint2*)((char*)k.sealed.p + k.off_dirb);
+            J.sp_off = (uint32_t*)((char*)k.sealed.p + k.off_spoff);
+            J.sp_ent = (uint32_t*)((char*)k.sealed.p + k.off_spent);
+            if (sz_dense) TF_TRY(hipMemsetAsync(J.dense, 0, sz_dense, stream));
+        }
+        TF_TRY(upload_jobs());
+        const dim3 gt((unsigned)tiles, (unsigned)nb);
+        seal_classify_kernel<<<ge, SEAL_BLOCK, 0, stream>>>(dj, jobs[0], did.as<int32_t>(), n_dense.as<uint32_t>(), bkt_D.as<uint32_t>(),
+                                                           bkt_flags.as<uint32_t>(), h_n_dense);
+        seal_tile_kernel<<<gt, SEAL_BLOCK, 0, stream>>>(dj, jobs[0]);
+        seal_scan_kernel<<<gt, SEAL_BLOCK, 0, stream>>>(dj, jobs[0]);
+        seal_scatter_kernel<<<ge, SEAL_BLOCK, 0, stream>>>(dj, jobs[0], did.as<int32_t>(), bkt_D.as<uint32_t>());
+        TF_TRY(hipGetLastError());
+        for (size_t j = 0; j < nb; ++j) {
+            Bucket& k = buckets[ids[i0 + j]];
+            k.state = 1;
+            pool.put(&k.coo_pc);                                       // stream order: later users are enqueued after the scatter
+            TF_TRY(set_bucket(ids[i0 + j]));
+            seals += 1;
+        }
+    }
+    if (d_jobs.p) { TF_TRY(hipStreamSynchronize(stream)); d_jobs.release(bytes_device); }
     return hipSuccess;
 }
 
@@ -751,62 +1160,57 @@ hipError_t Tfidf::flush_retire() {
     return hipSuccess;
 }
 
-static hipError_t run_frame_words(Tfidf& t, const int32_t* d_wslots, int n, bool reg, int32_t sig_id, int64_t slot, int32_t ni, float N,
-                                  const ResolveArgs* resolve = nullptr) {
+static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool ids_given, bool reg, int32_t sig_id, int64_t slot, int32_t ni,
+                                  float N, const ResolveArgs* resolve) {
     const int H = next_pow2(std::max(2 * n, 128));
-    size_t shmem = ((size_t)H * 2 + H / 64 + 2) * 4;
-    uint32_t* coo_w = nullptr; uint32_t* coo_pc = nullptr; uint32_t* ne = nullptr;
+    size_t shmem = ((size_t)H * 2 + H / 64 + 8) * 4;
+    if (ids_given) TF_TRY(t.sync_id2ws());
+    FwArgs a;
+    a.src = d_src; a.n = n; a.xlate = ids_given ? t.d_id2ws.as<int32_t>() : nullptr; a.xlate_n = ids_given ? t.d_id2ws_n : 0;
+    a.H = H; a.do_register = reg ? 1 : 0; a.want_q = 1;
+    a.sig_id = sig_id; a.slot = (long long)slot; a.slot_local = (uint32_t)(slot % TF_R); a.ni = (uint32_t)ni; a.N = N;
+    a.coo_w = nullptr; a.coo_pc = nullptr; a.ne_counter = nullptr;
     if (reg) {
         const int bi = (int)(slot / TF_R);
-        coo_w = t.buckets[bi].coo_w.as<uint32_t>();
-        coo_pc = t.buckets[bi].coo_pc.as<uint32_t>();
-        ne = t.bkt_ne.as<uint32_t>() + bi;
+        a.coo_w = t.buckets[bi].coo_w.as<uint32_t>();
+        a.coo_pc = t.buckets[bi].coo_pc.as<uint32_t>();
+        a.ne_counter = t.bkt_ne.as<uint32_t>() + bi;
     }
     if (t.pending_retire.size() > 4) TF_TRY(t.flush_retire());
     const RetireArgs ret = take_pending(t);
     t.stamp += 1;
     if (t.stamp == 0) t.stamp = 1;
+    a.stamp = t.stamp;
+    a.nw = t.nw.as<uint32_t>(); a.did = t.did.as<int32_t>();
+    a.slot_sig = t.slot_sig.as<int32_t>(); a.slot_ni = t.slot_ni.as<uint32_t>(); a.slot_begin = t.slot_begin.as<uint32_t>();
+    a.slot_cnt = t.slot_cnt.as<uint32_t>();
+    a.q_w = t.q_w.as<uint32_t>(); a.q_idf = t.q_idf.as<int32_t>(); a.q_did = t.q_did.as<int32_t>(); a.qd_did = t.qd_did.as<int32_t>();
+    a.qd_idf = t.qd_idf.as<int32_t>(); a.q_meta = t.q_meta.as<uint32_t>(); a.idf_tab = t.idf_tab.as<uint2>();
     if (resolve) {
+        a.src = resolve->out_wslot;
         const int mw = (resolve->q + 63) / 64 * 2;
         shmem = std::max(shmem, (size_t)(3 * mw + 2) * 4);
         const int n_redo = (resolve->rp.enabled && resolve->fail_count) ? (resolve->rp.n_rows + FW_BLOCK - 1) / FW_BLOCK : 0;
-        frame_tail_kernel<<<1 + n_redo, FW_BLOCK, shmem, t.stream>>>(*resolve, H, reg ? 1 : 0, sig_id, (long long)slot, (uint32_t)(slot % TF_R),
-                                                           (uint32_t)ni, N, t.stamp, t.nw.as<uint32_t>(), coo_w, coo_pc, ne,
-                                                           t.slot_sig.as<int32_t>(), t.slot_ni.as<uint32_t>(), t.slot_begin.as<uint32_t>(),
-                                                           t.slot_cnt.as<uint32_t>(), t.q_w.as<uint32_t>(), t.q_cnt.as<uint32_t>(),
-                                                           t.q_idf.as<float>(), t.q_meta.as<uint32_t>(), t.idf_tab.as<uint2>(), ret);
+        frame_tail_kernel<<<1 + n_redo, FW_BLOCK, shmem, t.stream>>>(*resolve, a, ret);
     } else {
-        frame_words_kernel<<<1, FW_BLOCK, shmem, t.stream>>>(d_wslots, n, H, reg ? 1 : 0, sig_id, (long long)slot, (uint32_t)(slot % TF_R),
-                                                            (uint32_t)ni, N, t.stamp, t.nw.as<uint32_t>(), coo_w, coo_pc, ne,
-                                                            t.slot_sig.as<int32_t>(), t.slot_ni.as<uint32_t>(),
-                                                            t.slot_begin.as<uint32_t>(), t.slot_cnt.as<uint32_t>(),
-                                                            t.q_w.as<uint32_t>(), t.q_cnt.as<uint32_t>(), t.q_idf.as<float>(),
-                                                            t.q_meta.as<uint32_t>(), t.idf_tab.as<uint2>(), ret);
+        frame_words_kernel<<<1, FW_BLOCK, shmem, t.stream>>>(a, ret);
     }
     t.q_n_ub = n;
     return hipGetLastError();
 }
 
-hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N, const ResolveArgs* resolve) {
+hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N, const ResolveArgs* resolve, bool ids_given) {
     if (n > TF_MAX_WORDS) return hipErrorInvalidValue;
     const int64_t slot = n_slots;
     TF_TRY(ensure_slots(slot + 1));
     const int bi = (int)(slot / TF_R);
     if (bi >= (int)buckets.size()) {
-        if (bi > 0) TF_TRY(seal(bi - 1));
-        buckets.emplace_back();
-        TF_TRY(grow_zeroed(bkt_ne, (size_t)(bi + 1) * 4, stream, bytes_device));
-        bkt_dirty = true;
+        if (bi > 0 && buckets[bi - 1].state == 0) TF_TRY(seal_batch(std::vector<int>(1, bi - 1), false));
+        TF_TRY(new_bucket());
     }
     Bucket& b = buckets[bi];
-    const size_t need = (size_t)(b.ub_entries + n) * 4;
-    if (need > b.coo_w.cap) {
-        const size_t want = std::max(need, (size_t)TF_R * 512 * 4);
-        TF_TRY(b.coo_w.reserve(want, (size_t)b.ub_entries * 4, stream, bytes_device));
-        TF_TRY(b.coo_pc.reserve(want, (size_t)b.ub_entries * 4, stream, bytes_device));
-        bkt_dirty = true;
-    }
-    TF_TRY(run_frame_words(*this, d_wslots, n, true, sig_id, slot, ni, N, resolve));
+    TF_TRY(ensure_log(*this, bi, b.ub_entries + n));
+    TF_TRY(run_frame_words(*this, d_wslots, n, ids_given, true, sig_id, slot, ni, N, resolve));
     b.ub_entries += n;
     b.n_slots += 1;
     b.live += 1;
@@ -817,97 +1221,122 @@ hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, i
     return hipSuccess;
 }
 
-hipError_t Tfidf::query_dev(const int32_t* d_wslots, int n, float N, const ResolveArgs* resolve) {
+hipError_t Tfidf::query_dev(const int32_t* d_wslots, int n, float N, const ResolveArgs* resolve, bool ids_given) {
     if (n > TF_MAX_WORDS) return hipErrorInvalidValue;
-    return run_frame_words(*this, d_wslots, n, false, 0, 0, 0, N, resolve);
+    return run_frame_words(*this, d_wslots, n, ids_given, false, 0, 0, 0, N, resolve);
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
-hipError_t Tfidf::score(float* d_likelihood) {
-    if (n_slots == 0) return hipSuccess;
-    TF_TRY(flush_retire());
-    TF_TRY(upload_buckets());
-    // lfix is all zero here: zero-initialised on growth and re-zeroed by whoever consumed it last
-    static const int scb = env_int("LCD_SC_BLOCK", 1024);
-    static const int gforce = env_int("LCD_SC_G", 0);
-    static const int fuse = env_int("LCD_SC_FUSED", 1);
-    const int wcap_all = std::max(q_n_ub, 1);
-    const bool has_open = !buckets.empty() && !buckets.back().sealed;
-    const int bitmap_words = (n_wslots + 31) / 32;
-    if (fuse && gforce <= 1 && (size_t)bitmap_words * 4 <= 32 * 1024 && (scb == 256 || scb == 512 || scb == 1024)) {
-        // one launch: every sealed bucket writes its 256 likelihood values straight from LDS, the open bucket's workgroups
-        // accumulate through lfix and the last of them converts its slots
-        const size_t sealed_bytes = (size_t)TF_R * 8 + (size_t)TF_R * 4 + ((size_t)wcap_all * 4 + 1 + scb + 1 + 4) * 4;
-        const size_t shmem = std::max(sealed_bytes, (size_t)std::max(bitmap_words, 1) * 4);
-        int open_blocks = 0, bi = 0, n_open_slots = 0;
-        const Bucket* ob = nullptr;
-        if (has_open) {
-            bi = (int)buckets.size() - 1;
-            ob = &buckets[bi];
-            n_open_slots = ob->n_slots;
-            open_blocks = (int)std::min<int64_t>(std::max<int64_t>((ob->ub_entries + 4 * scb - 1) / (4 * scb), 1), 256);
-        }
-        if (n_list_all + open_blocks == 0) return hipSuccess;
-        TF_TRY(grow_zeroed(open_done, 64, stream, bytes_device));
-#define LCD_SCORE_FUSED(B) score_fused_kernel<B><<<n_list_all + open_blocks, B, shmem, stream>>>(bkt_tab.as<BucketDev>(), bkt_list_all.as<int32_t>(), \
-            n_list_all, wcap_all, q_w.as<uint32_t>(), q_idf.as<float>(), q_meta.as<uint32_t>(), slot_ni.as<uint32_t>(), lfix.as<unsigned long long>(), \
-            d_likelihood, ob ? ob->coo_w.as<uint32_t>() : nullptr, ob ? ob->coo_pc.as<uint32_t>() : nullptr, bkt_ne.as<uint32_t>() + bi, \
-            (long long)bi * TF_R, n_open_slots, bitmap_words, stamp, idf_tab.as<uint2>(), open_done.as<int>())
-        if (prof_b) TF_TRY(hipEventRecord(prof_b, stream));
-        if (scb == 256) LCD_SCORE_FUSED(256); else if (scb == 512) LCD_SCORE_FUSED(512); else LCD_SCORE_FUSED(1024);
-#undef LCD_SCORE_FUSED
-        TF_TRY(hipGetLastError());
-        if (prof_e) TF_TRY(hipEventRecord(prof_e, stream));
-        prof_b = prof_e = nullptr;
-        return hipSuccess;
+hipError_t Tfidf::register_bulk(int n_sigs, const int32_t* sig_ids, const int64_t* offsets, const int32_t* ni, const int32_t* d_ids,
+                                int64_t total_ids, int max_n) {
+    if (n_sigs <= 0) return hipSuccess;
+    (void)total_ids;
+    TF_TRY(sync_id2ws());
+    const int64_t slot0 = n_slots;
+    TF_TRY(ensure_slots(slot0 + n_sigs));
+    // buckets touched by the call: the open one is topped up, the others are new; every one that ends up full is sealed
+    const int b_first = (int)(slot0 / TF_R), b_last = (int)((slot0 + n_sigs - 1) / TF_R);
+    if (b_first > 0 && b_first >= (int)buckets.size() && buckets[b_first - 1].state == 0)
+        TF_TRY(seal_batch(std::vector<int>(1, b_first - 1), false));
+    while ((int)buckets.size() <= b_last) TF_TRY(new_bucket());
+    std::vector<int64_t> add(b_last - b_first + 1, 0);
+    for (int s = 0; s < n_sigs; ++s) add[(size_t)((slot0 + s) / TF_R - b_first)] += offsets[s + 1] - offsets[s];
+    for (int b = b_first; b <= b_last; ++b) TF_TRY(ensure_log(*this, b, buckets[b].ub_entries + add[b - b_first]));
+    // per-signature tables on the device (synchronous call: plain staging)
+    DevBuf d_off, d_sig, d_ni;
+    TF_TRY(d_off.reserve((size_t)(n_sigs + 1) * 8, 0, stream, bytes_device));
+    TF_TRY(d_sig.reserve((size_t)n_sigs * 4, 0, stream, bytes_device));
+    TF_TRY(hipMemcpyAsync(d_off.p, offsets, (size_t)(n_sigs + 1) * 8, hipMemcpyHostToDevice, stream));
+    TF_TRY(hipMemcpyAsync(d_sig.p, sig_ids, (size_t)n_sigs * 4, hipMemcpyHostToDevice, stream));
+    if (ni) {
+        TF_TRY(d_ni.reserve((size_t)n_sigs * 4, 0, stream, bytes_device));
+        TF_TRY(hipMemcpyAsync(d_ni.p, ni, (size_t)n_sigs * 4, hipMemcpyHostToDevice, stream));
     }
-    TF_TRY(score_partial(lfix.as<unsigned long long>()));
-    finalize_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, stream>>>(lfix.as<long long>(), (long long)n_slots, d_likelihood);
-    return hipGetLastError();
-}
-
-// fixed-point sums of q_* against every live signature, ADDED into lfix_target[0 .. n_slots) (caller provides zeros
-// or a running sum); the multi-GPU path all-reduces these integers before finalize()
-hipError_t Tfidf::score_partial(unsigned long long* lfix_target) {
-    if (n_slots == 0) return hipSuccess;
-    TF_TRY(flush_retire());
-    TF_TRY(upload_buckets());
-    const int wcap_all = std::max(q_n_ub, 1);
-    if (n_list > 0) {
-        static const int scb = env_int("LCD_SC_BLOCK", 1024);
-        static const int gforce = env_int("LCD_SC_G", 0);
-        int G = gforce > 0 ? gforce : (256 + n_list - 1) / n_list;     // aim at >= one workgroup per CU
-        G = std::max(1, std::min(G, 8));
-        const int wg_cap = (wcap_all + G - 1) / G;
-        const size_t shmem = (size_t)TF_R * 8 + (size_t)TF_R * 4 + ((size_t)wg_cap * 4 + 1 + scb + 1 + 4) * 4;
-        const dim3 grid(n_list, G);
-#define LCD_SCORE_SEALED(B) score_sealed_kernel<B><<<grid, B, shmem, stream>>>(bkt_tab.as<BucketDev>(), bkt_list.as<int32_t>(), G, wg_cap, \
-            q_w.as<uint32_t>(), q_idf.as<float>(), q_meta.as<uint32_t>(), slot_ni.as<uint32_t>(), lfix_target)
-        if (scb == 256) LCD_SCORE_SEALED(256); else if (scb == 512) LCD_SCORE_SEALED(512); else LCD_SCORE_SEALED(1024);
-#undef LCD_SCORE_SEALED
-        TF_TRY(hipGetLastError());
+    const int H = next_pow2(std::max(2 * max_n, 64));
+    const size_t shmem = ((size_t)H * 2 + H / 64 + 8) * 4;
+    bulk_register_kernel<<<(unsigned)n_sigs, BR_BLOCK, shmem, stream>>>(d_ids, (const long long*)d_off.p, d_sig.as<int32_t>(),
+                                                                         ni ? d_ni.as<int32_t>() : nullptr, (long long)slot0,
+                                                                         d_id2ws.as<int32_t>(), d_id2ws_n, bkt_tab.as<BucketDev>(),
+                                                                         bkt_ne.as<uint32_t>(), nw.as<uint32_t>(), slot_sig.as<int32_t>(),
+                                                                         slot_ni.as<uint32_t>(), slot_begin.as<uint32_t>(), slot_cnt.as<uint32_t>());
+    TF_TRY(hipGetLastError());
+    std::vector<int> full;
+    for (int s = 0; s < n_sigs; ++s) {
+        const int64_t slot = slot0 + s;
+        Bucket& b = buckets[(size_t)(slot / TF_R)];
+        b.n_slots += 1; b.live += 1;
+        sig_slot[sig_ids[s]] = slot;
     }
-    if (!buckets.empty() && !buckets.back().sealed && buckets.back().ub_entries > 0) {
-        const int bi = (int)buckets.size() - 1;
-        const Bucket& b = buckets[bi];
-        int blocks = (int)std::min<int64_t>((b.ub_entries + 4 * SC_BLOCK - 1) / (4 * SC_BLOCK), 512);
-        int bitmap_words = (n_wslots + 31) / 32;
-        if ((size_t)bitmap_words * 4 > 128 * 1024) bitmap_words = 0;   // > 1M word slots: idf_tab stamps alone decide
-        score_open_kernel<<<blocks, SC_BLOCK, (size_t)std::max(bitmap_words, 1) * 4, stream>>>(
-            b.coo_w.as<uint32_t>(), b.coo_pc.as<uint32_t>(), bkt_ne.as<uint32_t>() + bi, (long long)bi * TF_R, bitmap_words, stamp,
-            q_w.as<uint32_t>(), q_meta.as<uint32_t>(), idf_tab.as<uint2>(), slot_ni.as<uint32_t>(), lfix_target);
-        TF_TRY(hipGetLastError());
+    for (int b = b_first; b <= b_last; ++b) {
+        buckets[b].ub_entries += add[b - b_first];
+        if (buckets[b].n_slots == TF_R && b < b_last) full.push_back(b);   // the last bucket stays open until the next one is started
     }
+    postings_ub += offsets[n_sigs] - offsets[0];
+    n_slots += n_sigs;
+    live_sigs += n_sigs;
+    TF_TRY(seal_batch(full, true));
+    TF_TRY(hipStreamSynchronize(stream));
+    d_off.release(bytes_device); d_sig.release(bytes_device); d_ni.release(bytes_device);
     return hipSuccess;
 }
 
-hipError_t Tfidf::finalize(long long* lfix_src, long long n, float* d_likelihood) {
+hipError_t Tfidf::launch_score(float* d_likelihood, long long* lfix) {
+    if (n_slots == 0) return hipSuccess;
+    TF_TRY(flush_retire());
+    const bool has_open = !buckets.empty() && buckets.back().state == 0;
+    ScoreArgs A;
+    A.tab = bkt_tab.as<BucketDev>(); A.bkt_D = bkt_D.as<uint32_t>(); A.bkt_flags = bkt_flags.as<uint32_t>();
+    A.n_closed = (int)buckets.size() - (has_open ? 1 : 0);
+    A.n_open_slots = has_open ? buckets.back().n_slots : 0;
+    A.wcap = std::max(q_n_ub, 1);
+    A.q_w = q_w.as<uint32_t>(); A.q_idf = q_idf.as<int32_t>(); A.q_did = q_did.as<int32_t>(); A.qd_did = qd_did.as<int32_t>();
+    A.qd_idf = qd_idf.as<int32_t>(); A.q_meta = q_meta.as<uint32_t>();
+    A.slot_ni = slot_ni.as<uint32_t>(); A.slot_begin = slot_begin.as<uint32_t>(); A.slot_cnt = slot_cnt.as<uint32_t>();
+    A.idf_tab = idf_tab.as<uint2>(); A.stamp = stamp;
+    A.out_like = d_likelihood; A.out_fix = lfix;
+    const int open_blocks = (A.n_open_slots + SC_BLOCK / 64 - 1) / (SC_BLOCK / 64);
+    const int grid = A.n_closed + open_blocks;
+    if (grid == 0) return hipSuccess;
+    const size_t shmem = (size_t)TF_R * 8 + (size_t)TF_R * 4 + ((size_t)A.wcap * 3 + 1 + SC_BLOCK / 64 + 1 + 4) * 4;
+    if (prof_b) TF_TRY(hipEventRecord(prof_b, stream));
+    score_kernel<SC_BLOCK><<<grid, SC_BLOCK, shmem, stream>>>(A);
+    TF_TRY(hipGetLastError());
+    if (prof_e) TF_TRY(hipEventRecord(prof_e, stream));
+    prof_b = prof_e = nullptr;
+    return hipSuccess;
+}
+
+// diagnostic (synchronises): the work of one scoring launch for the frame currently in q_*
+hipError_t Tfidf::score_work(int64_t out[8]) {
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (n_slots == 0) return hipSuccess;
+    TF_TRY(flush_retire());
+    const bool has_open = !buckets.empty() && buckets.back().state == 0;
+    ScoreArgs A;
+    A.tab = bkt_tab.as<BucketDev>(); A.bkt_D = bkt_D.as<uint32_t>(); A.bkt_flags = bkt_flags.as<uint32_t>();
+    A.n_closed = (int)buckets.size() - (has_open ? 1 : 0);
+    A.n_open_slots = has_open ? buckets.back().n_slots : 0;
+    A.wcap = std::max(q_n_ub, 1);
+    A.q_w = q_w.as<uint32_t>(); A.q_idf = q_idf.as<int32_t>(); A.q_did = q_did.as<int32_t>(); A.qd_did = qd_did.as<int32_t>();
+    A.qd_idf = qd_idf.as<int32_t>(); A.q_meta = q_meta.as<uint32_t>();
+    A.slot_ni = slot_ni.as<uint32_t>(); A.slot_begin = slot_begin.as<uint32_t>(); A.slot_cnt = slot_cnt.as<uint32_t>();
+    A.idf_tab = idf_tab.as<uint2>(); A.stamp = stamp; A.out_like = nullptr; A.out_fix = nullptr;
+    DevBuf cnt;
+    TF_TRY(cnt.reserve(64, 0, stream, bytes_device));
+    TF_TRY(hipMemsetAsync(cnt.p, 0, 64, stream));
+    score_work_kernel<<<A.n_closed + 1, 256, 0, stream>>>(A, nw.as<uint32_t>(), (unsigned long long*)cnt.p);
+    TF_TRY(hipGetLastError());
+    TF_TRY(hipMemcpyAsync(out, cnt.p, 64, hipMemcpyDeviceToHost, stream));
+    TF_TRY(hipStreamSynchronize(stream));
+    cnt.release(bytes_device);
+    return hipSuccess;
+}
+
+hipError_t Tfidf::score(float* d_likelihood) { return launch_score(d_likelihood, nullptr); }
+hipError_t Tfidf::score_fix(long long* lfix) { return launch_score(nullptr, lfix); }
+
+hipError_t Tfidf::finalize(const long long* lfix_src, long long n, float* d_likelihood) {
     if (n <= 0) return hipSuccess;
-    finalize_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(lfix_src, n, d_likelihood);
+    finalize_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(lfix_src, n, slot_ni.as<uint32_t>(), d_likelihood);
     return hipGetLastError();
 }
 
@@ -922,14 +1351,14 @@ hipError_t Tfidf::retire(int32_t sig_id) {
     sig_slot.erase(it);
     live_sigs -= 1;
     b.live -= 1;
-    if (b.live == 0 && b.sealed) {
-        // every signature of the bucket is gone: drop its postings (pending retirements read its log: apply them first)
+    if (b.live == 0 && b.state == 1) {
+        // every signature of the bucket is gone: its memory goes back to the pool (pending retirements read its log: apply them
+        // first; everything already enqueued on the stream still sees the old contents, later users are ordered behind it)
         TF_TRY(flush_retire());
-        TF_TRY(hipStreamSynchronize(stream));
         postings_ub -= b.ub_entries;
-        b.coo_w.release(bytes_device); b.coo_pc.release(bytes_device); b.dir.release(bytes_device); b.ent.release(bytes_device);
-        b.W = 0; b.n_e_sealed = 0; b.ub_entries = 0;
-        bkt_dirty = true;
+        pool.put(&b.coo_w); pool.put(&b.coo_pc); pool.put(&b.sealed);
+        b.W = 0; b.D_alloc = 0; b.ub_entries = 0; b.state = 2;
+        TF_TRY(set_bucket(bi));
     }
     return hipSuccess;
 }

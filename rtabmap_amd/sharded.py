@@ -98,9 +98,20 @@ class ShardedLoopClosure:
         return t
 
     # ---- one frame
-    def frame(self, d_desc, sig_id, N, incremental=True, new_words_compared=True, nndr=0.8, want_likelihood=True):
+    def frame(self, d_desc, sig_id, N, incremental=True, new_words_compared=True, nndr=0.8, want_likelihood=True, first_new_word_id=0):
         """d_desc: [q, dim] device tensor.  Returns (word ids int32 [q], likelihood float32 [n_slots]) device tensors."""
         q = d_desc.shape[0]
+        if self.world == 1:
+            # one rank owns everything: the sharded frame IS the single-GPU frame (fused launches, no exchange)
+            with torch.cuda.stream(self.stream):
+                words = self._buf("words", (q,), torch.int32)
+                _, n_slots = self.eng.slots_dev()
+                like = self._buf("like", (n_slots + 2,), torch.float32)
+                self.eng.frame_dev(d_desc.data_ptr(), q, sig_id, N, words.data_ptr(), like.data_ptr() if want_likelihood else None,
+                                   like.shape[0], incremental=incremental, new_words_compared=new_words_compared, nndr=nndr,
+                                   first_new_word_id=first_new_word_id)
+                _, n_slots = self.eng.slots_dev()
+            return words[:q], like[:n_slots]
         with torch.cuda.stream(self.stream):
             cand = self._buf("cand", (q * 2 * 2,), torch.int64)                  # 16-byte records as 2 x int64
             allc = self._buf("allc", (self.world * q * 2 * 2,), torch.int64)
@@ -114,7 +125,8 @@ class ShardedLoopClosure:
             like = self._buf("like", (max(cap, 1),), torch.float32)
             self.eng.shard_frame_dev(d_desc.data_ptr(), q, sig_id, N, self.rank, self.world, allc.data_ptr(), self.total_rows,
                                      words.data_ptr(), lfix.data_ptr() if want_likelihood else None, lfix.shape[0],
-                                     incremental=incremental, new_words_compared=new_words_compared, nndr=nndr)
+                                     incremental=incremental, new_words_compared=new_words_compared, nndr=nndr,
+                                     first_new_word_id=first_new_word_id)
             _, n_slots = self.eng.slots_dev()
             if want_likelihood:
                 self._all_reduce_sum(lfix[:n_slots])

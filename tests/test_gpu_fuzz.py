@@ -22,7 +22,6 @@ def _pick(rng, edges, lo, hi):
 @pytest.mark.parametrize("mode", ["bf16", "mfma32", "valu"])
 def test_fuzz_knn2_f32(oracle, monkeypatch, mode):
     import rtabmap_amd
-    monkeypatch.setenv("LCD_KNN_MODE", mode)
     rng = np.random.default_rng({"bf16": 1, "mfma32": 2, "valu": 3}[mode])
     for it in range(ITERS):
         n, q = _pick(rng, EDGE_N, 1, 9000), _pick(rng, EDGE_Q, 1, 700)
@@ -32,7 +31,7 @@ def test_fuzz_knn2_f32(oracle, monkeypatch, mode):
             v[rng.integers(0, n, 4)] = v[rng.integers(0, n)]
             qs[rng.integers(0, q)] = v[rng.integers(0, n)]
         ids = rng.permutation(np.arange(1, n + 1)).astype(np.int32) if rng.random() < 0.3 else np.arange(1, n + 1, dtype=np.int32)
-        eng = rtabmap_amd.Engine("f32", 64)
+        eng = rtabmap_amd.Engine("f32", 64, knn_mode=mode)
         eng.vocab_append(v, ids)
         removed = None
         if n > 4 and rng.random() < 0.5:                       # tombstones
@@ -75,7 +74,6 @@ def test_fuzz_knn2_hamming(oracle):
 def test_fuzz_quantize_and_frame(oracle, monkeypatch, mode):
     """lcd_quantize and the fused lcd_frame_dev tail against the restated addNewWords on random frames."""
     import rtabmap_amd
-    monkeypatch.setenv("LCD_KNN_MODE", mode)
     rng = np.random.default_rng(7 if mode == "bf16" else 8)
     for it in range(max(4, ITERS // 2)):
         n, q = _pick(rng, [2, 3, 255, 256, 257, 600, 2500], 2, 3000), _pick(rng, [1, 2, 63, 64, 65, 300, 512, 513], 1, 600)
@@ -86,7 +84,7 @@ def test_fuzz_quantize_and_frame(oracle, monkeypatch, mode):
         together = bool(rng.random() < 0.7)
         nndr = float(rng.choice([0.6, 0.8, 0.95]))
         ids = np.arange(1, n + 1, dtype=np.int32)
-        eng = rtabmap_amd.Engine("f32", 64, sig_capacity=64)
+        eng = rtabmap_amd.Engine("f32", 64, sig_capacity=64, knn_mode=mode)
         eng.vocab_append(v, ids)
         m = oracle.OracleVWDictionary(strategy=oracle.kNNBruteForce, nndr=nndr, new_words_compared_together=together)
         for i, r in zip(ids, v):

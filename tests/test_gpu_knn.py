@@ -162,8 +162,7 @@ def test_knn2_mfma_filter_matches_exact_scan_and_falls_back_on_clusters(oracle, 
     ids = np.arange(1, 20001, dtype=np.int32)
     res = {}
     for mode in ("bf16", "mfma32", "valu"):
-        monkeypatch.setenv("LCD_KNN_MODE", mode)
-        eng = rtabmap_amd.Engine("f32", 64)
+        eng = rtabmap_amd.Engine("f32", 64, knn_mode=mode)
         eng.vocab_append(v, ids)
         res[mode] = eng.knn2(q)
         st = eng.stats()
@@ -206,8 +205,7 @@ def test_knn2_filter_error_bound_on_wide_range_descriptors(oracle, monkeypatch, 
     q[:16] = v[:16]
     q[16:32] = (rng.standard_normal((16, 64)) * 50).astype(np.float32)
     ids = np.arange(1, n + 1, dtype=np.int32)
-    monkeypatch.setenv("LCD_KNN_MODE", mode)
-    eng = rtabmap_amd.Engine("f32", 64)
+    eng = rtabmap_amd.Engine("f32", 64, knn_mode=mode)
     eng.vocab_append(v, ids)
     _check(eng, oracle, v, ids, q)
     r = eng.stats()["knn_max_err_ratio"]
@@ -232,8 +230,7 @@ def test_knn2_one_million_words_properties(monkeypatch):
     ids = np.arange(1, n + 1, dtype=np.int32)
     res = {}
     for mode in ("bf16", "valu"):
-        monkeypatch.setenv("LCD_KNN_MODE", mode)
-        eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n)
+        eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n, knn_mode=mode)
         for a in range(0, n, 250_000):
             eng.vocab_append(v[a:a + 250_000], ids[a:a + 250_000])
         res[mode] = eng.knn2(qs)

@@ -147,12 +147,11 @@ def test_frame_dev_redoes_uncertifiable_queries_inside_the_tail_launch(oracle, m
     some queries of every frame uncertifiable; the word assignment must still be the reference's, frame after frame (the
     counters the tail resets must be clean for the next frame), and identical to lcd_quantize's (stand-alone redo kernel)."""
     import rtabmap_amd
-    monkeypatch.setenv("LCD_KNN_MODE", mode)
     n = 6000
     v = synth.vocab_surf(n, seed=21)
     v[3000:3040] = v[77]                                      # 41 identical rows: more equal candidates than a row block keeps
     ids = np.arange(1, n + 1, dtype=np.int32)
-    eng = rtabmap_amd.Engine("f32", 64, sig_capacity=64)
+    eng = rtabmap_amd.Engine("f32", 64, sig_capacity=64, knn_mode=mode)
     eng.vocab_append(v, ids)
     d_words = torch.zeros(400, dtype=torch.int32, device="cuda")
     for t in range(3):
