@@ -203,7 +203,7 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
             if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_tail[i], hipEventDisableTiming);
         }
     }
-    if (e == hipSuccess) e = h->tfidf.init(h->stream, &h->bytes_device, cfg->sig_capacity);
+    if (e == hipSuccess) e = h->tfidf.init(h->stream, &h->bytes_device, cfg->sig_capacity, cfg->vocab_capacity);
     if (e != hipSuccess) { lcd_destroy(h); return LCD_ERR_HIP; }
     *out = h;
     return LCD_OK;
@@ -519,7 +519,7 @@ static int prepare_resolve(lcd_engine* h, const void* d_desc, int q, int flags, 
     r->knn_row = h->d_knn_row.as<int32_t>();
     r->row_wslot = h->row_wslot.as<int32_t>();
     r->out_wslot = d_out_wslot;
-    r->new_ws_base = -1;
+    r->new_ws = WsRuns();
     r->fail_count = nullptr;
     return LCD_OK;
 }
@@ -743,9 +743,9 @@ int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     const int64_t slots_after = t.n_slots + (a->sig_id != 0 ? 1 : 0);
     if (a->d_likelihood && a->likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
     // postings keys for the words this frame may create (VisualWord(id, descriptor, signatureId) references the signature)
-    int32_t new_ws_base = -1;
+    WsRuns new_ws;
     if (a->sig_id != 0 && a->first_new_word_id > 0 && (a->flags & LCD_Q_INCREMENTAL)) {
-        hipError_t e = t.reserve_new_words(a->first_new_word_id, q, &new_ws_base);
+        hipError_t e = t.reserve_new_words(a->first_new_word_id, q, &new_ws);
         if (e == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: word ids must be below 2^28");
         if (e != hipSuccess) return h->hip_fail(e, "reserve_new_words");
     }
@@ -775,7 +775,7 @@ int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
         LCD_HIP(h, hipEventRecord(h->ev_knn[p], h->kstream));
         LCD_HIP(h, hipStreamWaitEvent(h->stream, h->ev_knn[p], 0));
     }
-    r.new_ws_base = new_ws_base;
+    r.new_ws = new_ws;
     if (h->d_fail_count.p) { r.fail_count = h->d_fail_count.as<int32_t>(); h->fail_count_clean = true; }
     if (a->sig_id != 0) LCD_HIP(h, t.register_dev(a->sig_id, h->d_out_wslot.as<int32_t>(), q, q, a->N, &r));
     else LCD_HIP(h, t.query_dev(h->d_out_wslot.as<int32_t>(), q, a->N, &r));
@@ -855,18 +855,18 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
     LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
     // new words: every rank reserves the same keys (identical call sequence => identical numbering); only the LAST rank, which
     // will hold their rows, references them
-    int32_t new_ws_base = -1;
+    WsRuns new_ws;
     if (sig_id != 0 && first_new_word_id > 0 && incremental) {
-        hipError_t e = t.reserve_new_words(first_new_word_id, q, &new_ws_base);
+        hipError_t e = t.reserve_new_words(first_new_word_id, q, &new_ws);
         if (e == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_shard_frame_dev: word ids must be below 2^28");
         if (e != hipSuccess) return h->hip_fail(e, "reserve_new_words");
-        if (rank != world - 1) new_ws_base = -1;
+        if (rank != world - 1) new_ws.n = 0;
     }
     const int rflags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0);
     LCD_HIP(h, launch_resolve(q, rflags, nndr_ratio, have_index, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
                               together ? h->d_selfdist.as<float>() : nullptr, ld, together ? h->d_bits.as<uint32_t>() : nullptr, bw,
                               d_word_ids, h->d_n_new.as<int32_t>(), h->stream, h->d_knn_row.as<int32_t>(), nullptr,
-                              h->d_out_wslot.as<int32_t>(), new_ws_base));
+                              h->d_out_wslot.as<int32_t>(), &new_ws));
     if (sig_id != 0) LCD_HIP(h, t.register_dev(sig_id, h->d_out_wslot.as<int32_t>(), q, q, N));
     else LCD_HIP(h, t.query_dev(h->d_out_wslot.as<int32_t>(), q, N));
     if (d_lfix) {
@@ -977,7 +977,7 @@ int lcd_get_stats(lcd_engine* h, lcd_stats* out) {
     out->knn_launches = h->knn_launches; out->likelihood_launches = h->likelihood_launches; out->rebuilds = h->rebuilds;
     h->tfidf.harvest_released(false);
     out->buckets_sealed = h->tfidf.seals;
-    out->word_slots = (int64_t)h->tfidf.n_wslots - (int64_t)h->tfidf.ws_free.size();
+    out->word_slots = (int64_t)h->tfidf.n_wslots - h->tfidf.ws_free_count;
     out->dense_words = h->tfidf.h_n_dense ? (int64_t)*(volatile uint32_t*)h->tfidf.h_n_dense : 0;
     out->bytes_device = h->bytes_device;
     return LCD_OK;

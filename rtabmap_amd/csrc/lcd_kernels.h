@@ -38,6 +38,18 @@ struct CandBits {
     int have_index = 0;
 };
 
+// Postings keys reserved for the words a frame may create: the k-th new word of the frame gets the k-th key of the
+// concatenated runs (recycled keys come back as a handful of intervals; the rest is one fresh interval).  n == 0: none.
+struct WsRuns {
+    int32_t start[16];
+    int32_t len[16];
+    int32_t n = 0;
+};
+__host__ __device__ inline int32_t ws_runs_at(const WsRuns& r, int k) {
+    for (int i = 0; i < r.n; ++i) { if (k < r.len[i]) return r.start[i] + k; k -= r.len[i]; }
+    return -1;
+}
+
 // Arguments of the exact redo of rejected queries (rowpar_body.cuh).  enabled == 0: no redo wanted.
 struct RowparArgs {
     int enabled = 0;
@@ -84,7 +96,7 @@ hipError_t launch_resolve(int q, int flags, float nndr, int have_index, const in
                           const float* selfdist, int ld, const uint32_t* cand_bits, int bw, int32_t* out_word, int32_t* out_n_new,
                           hipStream_t s, const int32_t* knn_row = nullptr, const int32_t* row_wslot = nullptr,
                           int32_t* out_wslot = nullptr,    // out_wslot[q]: postings key of the chosen word (-1: none)
-                          int32_t new_ws_base = -1);       // postings key of the frame's k-th new word = new_ws_base + k (< 0: none)
+                          const WsRuns* new_ws = nullptr); // postings keys of the frame's new words (NULL: they get none)
 // findNN merge (VWDictionary.cpp:1457-1542): indexed candidates + candidates among the not-indexed words + NNDR.
 hipError_t launch_findnn_resolve(int q, int flags, float nndr, int have_index, const int32_t* knn_word,
                                  const float* knn_dist, int have_extra, const int32_t* extra_word,

@@ -71,7 +71,7 @@ __device__ __forceinline__ void resolve_body(uint32_t* rs_smem, int q, int flags
                                                          const uint32_t* __restrict__ cand_bits, int bw,
                                                          int32_t* __restrict__ out_word, int32_t* __restrict__ out_n_new,
                                                          const int32_t* __restrict__ knn_row, const int32_t* __restrict__ row_wslot,
-                                                         int32_t* __restrict__ out_wslot, int32_t new_ws_base = -1) {
+                                                         int32_t* __restrict__ out_wslot, const WsRuns& new_ws) {
     // rs_smem: mask_a[mw] | mask_b[mw] | prefix[mw + 1]
     const int mw = (q + 63) / 64 * 2;                 // mask words (a whole number of waves)
     uint32_t* mask_cur = rs_smem;
@@ -143,10 +143,10 @@ __device__ __forceinline__ void resolve_body(uint32_t* rs_smem, int q, int flags
             // postings key of the chosen EXISTING word: it is one of the descriptor's two indexed neighbours
             // (row_wslot == NULL: knn_row already holds the postings key of each neighbour -- sharded mode)
             // A NEW word (created by this descriptor or by an earlier one of the frame it matched) references the frame's signature
-            // too -- the VisualWord constructor does addRef(signatureId), VWDictionary.cpp:1185 -- under the key the caller reserved
-            // for the frame's k-th new word (new_ws_base + k); without a reservation new words get no posting.
+            // too -- the VisualWord constructor does addRef(signatureId), VWDictionary.cpp:1185 -- under the k-th key the caller reserved
+            // for the frame's new words; without a reservation new words get no posting.
             int32_t ws = -1;
-            if (w < 0 && new_ws_base >= 0) ws = new_ws_base + (-w - 1);
+            if (w < 0 && new_ws.n > 0) ws = ws_runs_at(new_ws, -w - 1);
             if (w > 0) {
                 if (knn_word[2 * i] == w) ws = row_wslot ? row_wslot[knn_row[2 * i]] : knn_row[2 * i];
                 else if (knn_word[2 * i + 1] == w) ws = row_wslot ? row_wslot[knn_row[2 * i + 1]] : knn_row[2 * i + 1];

@@ -29,6 +29,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -87,7 +88,7 @@ struct ResolveArgs {
     int q, flags; float nndr; int have_index;
     const int32_t* knn_word; const float* knn_dist; const float* selfdist; int ld; const uint32_t* cand_bits; int bw;
     int32_t* out_word; int32_t* out_n_new; const int32_t* knn_row; const int32_t* row_wslot; int32_t* out_wslot;
-    int32_t new_ws_base;   // postings key of the frame's k-th new word = new_ws_base + k (< 0: new words get no postings)
+    WsRuns new_ws;         // postings keys of the frame's new words (n == 0: new words get no postings)
     int32_t* fail_count;   // reset for the next frame's certificate (saves a memset launch); may be NULL
     RowparArgs rp;         // rp.enabled: the exact redo of rejected queries runs as extra workgroups of the tail launch
 };
@@ -115,10 +116,15 @@ struct Tfidf {
     DevBuf d_id2ws;
     int64_t d_id2ws_n = 0;               // entries valid on the device
     std::vector<int32_t> id2ws_dirty;    // ids whose device entry is out of date
-    std::vector<int32_t> ws_free;        // recycled wslots (confirmed unreferenced by the device)
-    struct ReleaseBatch { hipEvent_t ev = nullptr; std::vector<int32_t> ws; void* pinned = nullptr; const uint8_t* ok = nullptr; };
-    std::vector<ReleaseBatch> releasing; // wslots whose release kernel is in flight
-    struct Reservation { int32_t first_id = 0, ws_base = 0, n = 0; } resv;   // wslots reserved for the new words of the last frame
+    std::map<int32_t, int32_t> ws_free;  // recycled wslots (confirmed unreferenced by the device) as intervals: start -> length
+    int64_t ws_free_count = 0;
+    // wslots on their way back: a kernel checks nw == 0 for each and reports through pinned memory.  ids[i] != 0: the wslot was
+    // reserved for new word ids[i] of a frame; if it turns out to be referenced, that word exists and keeps the wslot.
+    struct PinBlock { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; };   // pinned memory + event, recycled (one batch per frame)
+    std::vector<PinBlock> pin_free;
+    struct ReleaseBatch { std::vector<int32_t> ws, ids; PinBlock blk; const uint8_t* ok = nullptr; };
+    std::vector<ReleaseBatch> releasing;
+    struct Reservation { int32_t first_id = 0, n = 0; WsRuns runs; } resv;   // wslots reserved for the new words of the last frame
     // per bucket
     DevBuf bkt_tab, bkt_ne, bkt_D, bkt_flags;
     std::vector<Bucket> buckets;
@@ -140,7 +146,7 @@ struct Tfidf {
     int64_t seals = 0;
     std::string err;
 
-    hipError_t init(hipStream_t s, int64_t* bytes, int64_t sig_capacity);
+    hipError_t init(hipStream_t s, int64_t* bytes, int64_t sig_capacity, int64_t vocab_capacity);
     void destroy();
     // wslot of a word id (assigned on first sight when `create`); -1 if unknown and !create
     hipError_t wslot_of(int32_t word_id, bool create, int32_t* out);
@@ -148,10 +154,12 @@ struct Tfidf {
     hipError_t sync_id2ws();
     // the word left the dictionary (VWDictionary::removeWords): its wslot is recycled once the device confirms nw == 0
     hipError_t release_words(const int32_t* word_ids, int n);
-    hipError_t release_wslots(const std::vector<int32_t>& ws);
+    hipError_t release_wslots(const std::vector<int32_t>& ws, const std::vector<int32_t>* ids = nullptr);
+    void free_wslot(int32_t w);          // into the interval set
+    int32_t take_wslot();                // one recycled wslot, or -1
     void harvest_released(bool wait);
-    // reserve n consecutive wslots for the new words first_id, first_id + 1, ... of the coming frame; returns the base
-    hipError_t reserve_new_words(int32_t first_id, int n, int32_t* ws_base);
+    // reserve n wslots for the new words first_id, first_id + 1, ... of the coming frame (recycled intervals first)
+    hipError_t reserve_new_words(int32_t first_id, int n, WsRuns* runs);
     // register one signature whose word slots are already on the device (d_wslots[n]; < 0 = no word); if N > 0 the
     // frame's unique words / idf are left in q_* for a following score()
     hipError_t register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N, const ResolveArgs* resolve = nullptr,

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 
 namespace lcd {
 namespace {
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(FW_BLOCK) void frame_tail_kernel(ResolveArgs r, FwA
     }
     FT_STAMP(0);
     resolve_body(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
-                 r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws_base);
+                 r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
     if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; r.fail_count[3] = 0; }
     FT_STAMP(1);
     retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
@@ -835,12 +836,12 @@ static hipError_t set_max_lds(const void* fn) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-hipError_t Tfidf::init(hipStream_t s, int64_t* bytes, int64_t sig_capacity) {
+hipError_t Tfidf::init(hipStream_t s, int64_t* bytes, int64_t sig_capacity, int64_t vocab_capacity) {
     stream = s;
     bytes_device = bytes;
     TF_TRY(ensure_slots(sig_capacity > 0 ? sig_capacity : TF_R));
     TF_TRY(ensure_buckets((int)((sig_capacity > 0 ? sig_capacity : TF_R) / TF_R) + 64));
-    TF_TRY(ensure_wslots(65536));
+    TF_TRY(ensure_wslots((int32_t)std::min<int64_t>(std::max<int64_t>(65536, 4 * vocab_capacity), 1 << 27)));   // growing later means a stream sync
     TF_TRY(q_w.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
     TF_TRY(q_idf.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
     TF_TRY(q_did.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
@@ -861,6 +862,8 @@ hipError_t Tfidf::init(hipStream_t s, int64_t* bytes, int64_t sig_capacity) {
 
 void Tfidf::destroy() {
     harvest_released(true);
+    for (PinBlock& b : pin_free) { (void)hipEventDestroy(b.ev); (void)hipHostFree(b.p); }
+    pin_free.clear();
     for (Bucket& b : buckets) { b.coo_w.release(bytes_device); b.coo_pc.release(bytes_device); b.sealed.release(bytes_device); }
     buckets.clear();
     pool.destroy(bytes_device);
@@ -894,6 +897,29 @@ hipError_t Tfidf::ensure_buckets(int n) {
     return hipSuccess;
 }
 
+void Tfidf::free_wslot(int32_t w) {
+    // insert w into the interval set, merging with its neighbours
+    int32_t start = w, len = 1;
+    auto next = ws_free.lower_bound(w);
+    if (next != ws_free.begin()) {
+        auto prev = std::prev(next);
+        if (prev->first + prev->second > w) return;                   // already free (cannot happen)
+        if (prev->first + prev->second == w) { start = prev->first; len += prev->second; ws_free.erase(prev); }
+    }
+    if (next != ws_free.end() && next->first == w + 1) { len += next->second; ws_free.erase(next); }
+    ws_free[start] = len;
+    ws_free_count += 1;
+}
+
+int32_t Tfidf::take_wslot() {
+    if (ws_free.empty()) return -1;
+    auto it = std::prev(ws_free.end());
+    const int32_t w = it->first + it->second - 1;
+    if (--it->second == 0) ws_free.erase(it);
+    ws_free_count -= 1;
+    return w;
+}
+
 hipError_t Tfidf::wslot_of(int32_t word_id, bool create, int32_t* out) {
     *out = -1;
     if (word_id <= 0) return hipSuccess;
@@ -901,13 +927,19 @@ hipError_t Tfidf::wslot_of(int32_t word_id, bool create, int32_t* out) {
     int32_t w = -1;
     if (resv.n > 0 && word_id >= resv.first_id && word_id < resv.first_id + resv.n) {
         // a new word of the last device-quantised frame: its wslot was reserved when the frame was enqueued
-        w = resv.ws_base + (word_id - resv.first_id);
+        w = ws_runs_at(resv.runs, word_id - resv.first_id);
     } else {
+        // a new word of an earlier frame whose reservation is being checked by the device: the verdict decides whether it exists
+        for (size_t i = 0; i < releasing.size(); ++i) {
+            const ReleaseBatch& r = releasing[i];
+            if (std::find(r.ids.begin(), r.ids.end(), word_id) != r.ids.end()) { harvest_released(true); break; }
+        }
+        if ((size_t)word_id < id2ws.size() && id2ws[word_id] >= 0) { *out = id2ws[word_id]; return hipSuccess; }
         if (!create) return hipSuccess;
         if (word_id >= (1 << 28)) return hipErrorInvalidValue;        // the id -> wslot table is direct-indexed
         harvest_released(false);
-        if (!ws_free.empty()) { w = ws_free.back(); ws_free.pop_back(); }
-        else { w = n_wslots++; TF_TRY(ensure_wslots(n_wslots)); }
+        w = take_wslot();
+        if (w < 0) { w = n_wslots++; TF_TRY(ensure_wslots(n_wslots)); }
     }
     if ((size_t)word_id >= id2ws.size()) id2ws.resize((size_t)word_id + 1 + id2ws.size() / 2, -1);
     id2ws[word_id] = w;
@@ -937,24 +969,40 @@ hipError_t Tfidf::sync_id2ws() {
 void Tfidf::harvest_released(bool wait) {
     for (size_t i = 0; i < releasing.size();) {
         ReleaseBatch& r = releasing[i];
-        const hipError_t q = wait ? hipEventSynchronize(r.ev) : hipEventQuery(r.ev);
+        const hipError_t q = wait ? hipEventSynchronize(r.blk.ev) : hipEventQuery(r.blk.ev);
         if (q != hipSuccess) { ++i; continue; }
-        for (size_t k = 0; k < r.ws.size(); ++k) if (r.ok[k]) ws_free.push_back(r.ws[k]);
-        (void)hipEventDestroy(r.ev);
-        (void)hipHostFree(r.pinned);
+        for (size_t k = 0; k < r.ws.size(); ++k) {
+            if (r.ok[k]) { free_wslot(r.ws[k]); continue; }
+            // still referenced.  A wslot reserved for a frame's new word: the word exists (the frame created it) and keeps it.
+            const int32_t id = k < r.ids.size() ? r.ids[k] : 0;
+            if (id > 0) {
+                if ((size_t)id >= id2ws.size()) id2ws.resize((size_t)id + 1 + id2ws.size() / 2, -1);
+                if (id2ws[id] < 0) { id2ws[id] = r.ws[k]; id2ws_dirty.push_back(id); }
+            }
+        }
+        pin_free.push_back(r.blk);
         releasing.erase(releasing.begin() + i);
     }
 }
 
 // hand wslots back: a kernel checks each one (nw == 0) and reports through pinned memory; the host collects the verdicts of
 // finished batches later (harvest_released), so nothing is synchronised here and a wslot that is still referenced is never reused
-hipError_t Tfidf::release_wslots(const std::vector<int32_t>& ws) {
+hipError_t Tfidf::release_wslots(const std::vector<int32_t>& ws, const std::vector<int32_t>* ids) {
     if (ws.empty()) return hipSuccess;
     const size_t m = ws.size();
     ReleaseBatch r;
     r.ws = ws;
-    TF_TRY(hipHostMalloc(&r.pinned, m * 5 + 16, hipHostMallocDefault));      // [m wslots][m verdicts]
-    int32_t* p_ws = (int32_t*)r.pinned;
+    if (ids) r.ids = *ids;
+    const size_t need = m * 5 + 16;                                          // [m wslots][m verdicts]
+    for (size_t i = 0; i < pin_free.size(); ++i)
+        if (pin_free[i].cap >= need) { r.blk = pin_free[i]; pin_free.erase(pin_free.begin() + i); break; }
+    if (!r.blk.p) {
+        r.blk.cap = 8192;
+        while (r.blk.cap < need) r.blk.cap *= 2;
+        TF_TRY(hipHostMalloc(&r.blk.p, r.blk.cap, hipHostMallocDefault));
+        TF_TRY(hipEventCreateWithFlags(&r.blk.ev, hipEventDisableTiming));
+    }
+    int32_t* p_ws = (int32_t*)r.blk.p;
     uint8_t* p_ok = (uint8_t*)(p_ws + m);
     std::memcpy(p_ws, ws.data(), m * 4);
     std::memset(p_ok, 0, m);
@@ -962,8 +1010,7 @@ hipError_t Tfidf::release_wslots(const std::vector<int32_t>& ws) {
     wslot_release_kernel<<<(unsigned)((m + 255) / 256), 256, 0, stream>>>(p_ws, (int)m, nw.as<uint32_t>(), did.as<int32_t>(),
                                                                            idf_tab.as<uint2>(), p_ok);
     TF_TRY(hipGetLastError());
-    TF_TRY(hipEventCreateWithFlags(&r.ev, hipEventDisableTiming));
-    TF_TRY(hipEventRecord(r.ev, stream));
+    TF_TRY(hipEventRecord(r.blk.ev, stream));
     releasing.push_back(r);
     return hipSuccess;
 }
@@ -981,28 +1028,40 @@ hipError_t Tfidf::release_words(const int32_t* word_ids, int n) {
     return release_wslots(ws);
 }
 
-hipError_t Tfidf::reserve_new_words(int32_t first_id, int n, int32_t* ws_base) {
-    *ws_base = -1;
+// Postings keys for the words the coming frame may create (at most n).  The previous frame's reservation is handed to the device
+// for checking: keys it did not use (nw == 0) are recycled, used ones become the permanent keys of those words.
+hipError_t Tfidf::reserve_new_words(int32_t first_id, int n, WsRuns* runs) {
+    runs->n = 0;
     if (first_id <= 0 || n <= 0) return hipSuccess;
     if ((int64_t)first_id + n >= (1 << 28)) return hipErrorInvalidValue;
-    // the previous reservation: ids below first_id were handed to new words (their mapping becomes permanent), the rest of its
-    // wslots go back through the verified release path (a wslot is recycled only if the device finds it unreferenced)
     if (resv.n > 0) {
-        const int32_t used = std::max(0, std::min(resv.n, first_id - resv.first_id));
-        if ((size_t)(resv.first_id + used) > id2ws.size()) id2ws.resize((size_t)(resv.first_id + used) + id2ws.size() / 2, -1);
-        for (int32_t k = 0; k < used; ++k)
-            if (id2ws[resv.first_id + k] < 0) { id2ws[resv.first_id + k] = resv.ws_base + k; id2ws_dirty.push_back(resv.first_id + k); }
-        std::vector<int32_t> rest_ws;
-        for (int32_t k = used; k < resv.n; ++k) rest_ws.push_back(resv.ws_base + k);
+        std::vector<int32_t> ws, ids;
+        for (int32_t k = 0; k < resv.n; ++k) {
+            const int32_t id = resv.first_id + k;
+            if ((size_t)id < id2ws.size() && id2ws[id] >= 0) continue;        // already the word's permanent key
+            ws.push_back(ws_runs_at(resv.runs, k));
+            ids.push_back(id < first_id ? id : 0);                            // ids the caller is re-using now name other words
+        }
         resv.n = 0;
-        TF_TRY(release_wslots(rest_ws));
+        TF_TRY(release_wslots(ws, &ids));
     }
     harvest_released(false);
-    const int32_t base = n_wslots;                                    // consecutive: taken from the top, not from the free list
-    n_wslots += n;
-    TF_TRY(ensure_wslots(n_wslots));
-    resv.first_id = first_id; resv.ws_base = base; resv.n = n;
-    *ws_base = base;
+    int left = n;
+    while (left > 0 && runs->n < 15 && !ws_free.empty()) {                    // recycled intervals first ...
+        auto it = std::prev(ws_free.end());
+        const int32_t take = std::min(it->second, left);
+        const int32_t start = it->first + it->second - take;
+        runs->start[runs->n] = start; runs->len[runs->n] = take; runs->n += 1;
+        if ((it->second -= take) == 0) ws_free.erase(it);
+        ws_free_count -= take;
+        left -= take;
+    }
+    if (left > 0) {                                                           // ... the rest fresh
+        runs->start[runs->n] = n_wslots; runs->len[runs->n] = left; runs->n += 1;
+        n_wslots += left;
+        TF_TRY(ensure_wslots(n_wslots));
+    }
+    resv.first_id = first_id; resv.n = n; resv.runs = *runs;
     return hipSuccess;
 }
 
