@@ -91,11 +91,16 @@ class Stepper:
         self.d_words = torch.zeros(Q, dtype=torch.int32, device="cuda")
         self.d_like = torch.zeros(cap, dtype=torch.float32, device="cuda") if want_like else None
         self.next_sig, self.oldest, self.first_new = n_sig + 1, 1, N_WORDS + 1
+        self.ptrs = [f.data_ptr() for f in d_frames]
+        self.args = eng.frame_args(q=Q, flags=3, nndr_ratio=NNDR, N=float(n_sig + 1), d_word_ids=self.d_words.data_ptr(),
+                                   d_likelihood=self.d_like.data_ptr(), likelihood_capacity=cap)
 
     def __call__(self, i):
-        self.eng.frame_dev(self.d_frames[i % len(self.d_frames)].data_ptr(), Q, self.next_sig, float(self.n_sig + 1),
-                           self.d_words.data_ptr(), self.d_like.data_ptr(), self.cap, incremental=True, new_words_compared=True,
-                           nndr=NNDR, first_new_word_id=self.first_new)
+        a = self.args
+        a.d_descriptors = self.ptrs[i % len(self.ptrs)]
+        a.sig_id = self.next_sig
+        a.first_new_word_id = self.first_new
+        self.eng.frame_dev_args(a)
         self.eng.sig_remove(self.oldest)
         self.next_sig += 1
         self.oldest += 1
@@ -472,6 +477,8 @@ def main():
         roof_knn, roof_score = rooflines(eng, N_WORDS, n_sig, False)
         like = step.d_like[: n_sig + args.steps + args.warmup].cpu().numpy()
         frames_total = world * args.steps
+        st = eng.stats()
+        host_in_c = 1e-6 * st["frame_host_ns"] / max(st["frame_calls"], 1)
     wall = res["wall"]
     value = frames_total * n_sig / wall
     last = (args.warmup + args.steps - 1) % n_frames
@@ -480,6 +487,7 @@ def main():
                           "500 desc/frame, 1 frame/step" % n_sig,
               "frames_per_s": frames_total / wall, "device_ms_per_step": res["dev_ms"] / args.steps,
               "host_enqueue_ms_per_step": 1e3 * res["host_enqueue"] / args.steps,
+              "host_ms_inside_lcd_frame_dev": None,
               "step_ms_median": float(np.median(res["per_step_ms"])), "step_ms_p95": float(np.percentile(res["per_step_ms"], 95)),
               "world_size_observed": world, "collective_backend": backend, "signatures_bulk_load_s": build_s,
               "pipeline": "2-NN stage of frame t+1 on a second stream while frame t is registered and scored" if (args.pipeline and not shard)
@@ -487,6 +495,8 @@ def main():
               "parallelism": ("vocabulary sharded by word-id range over %d GPUs (all-gather top-2 + int64 all-reduce per frame)" % world) if shard
               else ("%d independent replicas (one frame stream per GPU, no data-path collective)" % world if world > 1 else "1 GPU")}
 
+    if not shard:
+        config["host_ms_inside_lcd_frame_dev"] = host_in_c
     # ---- the distribution needs >= 50 frames: extra, untimed-for-`value` steps when the driver asked for fewer
     if not shard and args.steps < 50:
         extra = timed_loop(torch, dist, world, stream, step, 64, 0)

@@ -258,6 +258,7 @@ typedef struct lcd_stats {
     int64_t buckets_sealed;                /* 256-signature blocks of the inverted index regrouped on the device */
     int64_t word_slots;                    /* postings keys in use (recycled when words are removed) */
     int64_t dense_words;                   /* words whose postings are kept as dense count rows (last value the device reported) */
+    int64_t frame_calls, frame_host_ns;    /* lcd_frame_dev calls and the host time spent inside them (enqueue cost) */
     int64_t bytes_device;                  /* HBM held by the handle */
     int64_t knn_last_fallback_queries;     /* queries of the LAST 2-NN call that the MFMA certificate sent to the exact scan */
     double knn_max_err_ratio;              /* largest |filter score - exact distance| / eps seen by the re-rank so far (must stay < 1) */

@@ -53,6 +53,7 @@ class LcdStats(C.Structure):
     _fields_ = [("vocab_rows", C.c_int64), ("vocab_live", C.c_int64), ("signatures", C.c_int64), ("postings", C.c_int64),
                 ("knn_launches", C.c_int64), ("likelihood_launches", C.c_int64), ("rebuilds", C.c_int64),
                 ("buckets_sealed", C.c_int64), ("word_slots", C.c_int64), ("dense_words", C.c_int64),
+                ("frame_calls", C.c_int64), ("frame_host_ns", C.c_int64),
                 ("bytes_device", C.c_int64), ("knn_last_fallback_queries", C.c_int64), ("knn_max_err_ratio", C.c_double)]
 
 
@@ -283,6 +284,19 @@ class Engine:
                          d_word_ids_ptr, d_like_ptr, like_capacity, d_hypothesis_ptr, d_adjusted_ptr, virtual_place_ratio, 0,
                          ready_event)
         self._ck(self.L.lcd_frame_dev(self.h, C.byref(a)))
+
+    def frame_args(self, **kw):
+        """A reusable argument block for frame_dev_args (callers in a tight loop change a few fields per frame)."""
+        a = LcdFrameArgs()
+        a.struct_size = C.sizeof(LcdFrameArgs)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+
+    def frame_dev_args(self, a):
+        rc = self.L.lcd_frame_dev(self.h, C.byref(a))
+        if rc != LCD_OK:
+            self._ck(rc)
 
     def knn2_dev(self, d_queries_ptr, q, d_word_ids_ptr, d_dist_ptr):
         self._ck(self.L.lcd_knn2_dev(self.h, d_queries_ptr, q, d_word_ids_ptr, d_dist_ptr))

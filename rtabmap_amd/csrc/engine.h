@@ -70,7 +70,7 @@ struct lcd_engine {
     const char* prof_kernel = "";
 
     // ---- statistics
-    int64_t knn_launches = 0, likelihood_launches = 0, rebuilds = 0;
+    int64_t knn_launches = 0, likelihood_launches = 0, rebuilds = 0, frame_calls = 0, frame_host_ns = 0;
 
     int fail(int code, const std::string& msg) { err = msg; return code; }
     int hip_fail(hipError_t e, const char* what) {

@@ -7,6 +7,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -330,8 +331,12 @@ int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n) {
     rows.reserve(n);
     for (int i = 0; i < n; ++i) {
         const int r = h->find_row(word_ids[i]);
-        if (r < 0) return h->fail(LCD_ERR_STATE, "lcd_vocab_remove: word not in the vocabulary");
-        rows.push_back(r);
+        if (r >= 0) { rows.push_back(r); continue; }
+        // not a row: a word that was created by a frame (_notIndexedWords) and dies before update() indexed it only gives its
+        // postings key back (removeWords erases it from _notIndexedWords, :1602); anything else is an error
+        int32_t ws = -1;
+        LCD_HIP(h, h->tfidf.wslot_of(word_ids[i], false, &ws));
+        if (ws < 0) return h->fail(LCD_ERR_STATE, "lcd_vocab_remove: unknown word");
     }
     {   // the same word twice would be counted out of n_live twice
         std::vector<int32_t> sorted(rows);
@@ -339,15 +344,19 @@ int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n) {
         if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
             return h->fail(LCD_ERR_INVALID, "lcd_vocab_remove: duplicate word id in the call");
     }
-    LCD_HIP(h, dreserve(h, h->d_tmp_i32, (size_t)n * 4));
-    LCD_HIP(h, h->h_in.reserve((size_t)n * 4));
-    std::memcpy(h->h_in.p, rows.data(), (size_t)n * 4);
-    LCD_HIP(h, hipMemcpyAsync(h->d_tmp_i32.p, h->h_in.p, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    LCD_HIP(h, launch_tombstone(h->row_id.as<int32_t>(), h->d_tmp_i32.as<int32_t>(), n, h->stream));
-    if (h->dtype == LCD_F32) LCD_HIP(h, launch_norm_tombstone(h->row_norm.as<float>(), h->d_tmp_i32.as<int32_t>(), n, h->stream));
-    LCD_HIP(h, hipStreamSynchronize(h->stream));
-    for (int i = 0; i < n; ++i) { h->h_row_live[rows[i]] = 0; if (h->word_row_valid) h->word_row.erase(word_ids[i]); }
-    h->n_live -= n;
+    const int nr = (int)rows.size();
+    if (nr) {
+        LCD_HIP(h, dreserve(h, h->d_tmp_i32, (size_t)nr * 4));
+        LCD_HIP(h, h->h_in.reserve((size_t)nr * 4));
+        std::memcpy(h->h_in.p, rows.data(), (size_t)nr * 4);
+        LCD_HIP(h, hipMemcpyAsync(h->d_tmp_i32.p, h->h_in.p, (size_t)nr * 4, hipMemcpyHostToDevice, h->stream));
+        LCD_HIP(h, launch_tombstone(h->row_id.as<int32_t>(), h->d_tmp_i32.as<int32_t>(), nr, h->stream));
+        if (h->dtype == LCD_F32) LCD_HIP(h, launch_norm_tombstone(h->row_norm.as<float>(), h->d_tmp_i32.as<int32_t>(), nr, h->stream));
+        LCD_HIP(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < nr; ++i) h->h_row_live[rows[i]] = 0;
+        if (h->word_row_valid) for (int i = 0; i < n; ++i) h->word_row.erase(word_ids[i]);
+        h->n_live -= nr;
+    }
     // removeWords: the words are gone; their postings keys come back once the device has found them unreferenced
     LCD_HIP(h, h->tfidf.release_words(word_ids, n));
     return LCD_OK;
@@ -731,8 +740,17 @@ static void swap_scratch(lcd_engine* h) {
     h->ks_idx ^= 1;
 }
 
+namespace {
+struct FrameHostTimer {   // host time spent inside lcd_frame_dev (lcd_stats.frame_host_ns)
+    lcd_engine* h; std::chrono::steady_clock::time_point t0;
+    explicit FrameHostTimer(lcd_engine* e) : h(e), t0(std::chrono::steady_clock::now()) {}
+    ~FrameHostTimer() { h->frame_host_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); h->frame_calls += 1; }
+};
+}  // namespace
+
 int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     LCD_CHECK_HANDLE(h);
+    FrameHostTimer timer__(h);
     LCD_DEV(h);
     if (!a || a->struct_size != (int32_t)sizeof(lcd_frame_args)) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: bad argument block");
     const int q = a->q;
@@ -942,7 +960,7 @@ int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, co
     }
     if (avg_ms) *avg_ms = h->prof2_n ? (float)(sum / h->prof2_n) : 0.0f;
     if (n_samples) *n_samples = h->prof2_n;
-    if (kernel_name) *kernel_name = "score_fused_kernel";
+    if (kernel_name) *kernel_name = "score_kernel";
     h->prof_cap = 0;
     return LCD_OK;
 }
@@ -976,6 +994,7 @@ int lcd_get_stats(lcd_engine* h, lcd_stats* out) {
     out->signatures = h->tfidf.live_sigs; out->postings = h->tfidf.postings_ub;
     out->knn_launches = h->knn_launches; out->likelihood_launches = h->likelihood_launches; out->rebuilds = h->rebuilds;
     h->tfidf.harvest_released(false);
+    out->frame_calls = h->frame_calls; out->frame_host_ns = h->frame_host_ns;
     out->buckets_sealed = h->tfidf.seals;
     out->word_slots = (int64_t)h->tfidf.n_wslots - h->tfidf.ws_free_count;
     out->dense_words = h->tfidf.h_n_dense ? (int64_t)*(volatile uint32_t*)h->tfidf.h_n_dense : 0;

@@ -124,6 +124,8 @@ struct Tfidf {
     std::vector<PinBlock> pin_free;
     struct ReleaseBatch { std::vector<int32_t> ws, ids; PinBlock blk; const uint8_t* ok = nullptr; };
     std::vector<ReleaseBatch> releasing;
+    std::vector<int32_t> held_ws, held_ids;   // keys of superseded reservations waiting for a batched check
+    hipError_t flush_held();
     struct Reservation { int32_t first_id = 0, n = 0; WsRuns runs; } resv;   // wslots reserved for the new words of the last frame
     // per bucket
     DevBuf bkt_tab, bkt_ne, bkt_D, bkt_flags;

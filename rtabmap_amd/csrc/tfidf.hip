@@ -56,6 +56,14 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t* data, int n, 
     return total;
 }
 
+// A pointer that was itself read from memory (the bucket table) has no known address space, and the compiler falls back to FLAT
+// loads -- which also count on lgkmcnt, so every LDS wait would wait for them too.  These are global pointers: say so.
+template <typename T> __device__ __forceinline__ T gload(const T* p) { return *(const __attribute__((address_space(1))) T*)p; }
+__device__ __forceinline__ uint2 gload2(const uint2* p) {
+    const unsigned long long v = *(const __attribute__((address_space(1))) unsigned long long*)p;
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+
 // idf -> Q5.26, round to nearest, saturating
 __device__ __forceinline__ int32_t idf_to_fixed(float idf) {
     float s = idf * 67108864.0f;                        // 2^26, exact scaling
@@ -299,61 +307,100 @@ __device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, c
         return;
     }
     SC_STAMP(0);
+    constexpr int NWV = SCB / 64;
+    constexpr int DR = 8;                                           // dense rows per wavefront and trip
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
     const uint32_t D = A.bkt_D[b];
     const uint32_t flags = A.bkt_flags[b];
     int U = (int)A.q_meta[0];
     const int Ud = (int)A.q_meta[1];
     if (U > A.wcap) U = A.wcap;                                     // cannot happen: wcap is sized from the word count
-    for (int i = tid; i < TF_R; i += SCB) { acc[i] = 0ull; s_ni[i] = A.slot_ni[first_slot + i]; }
-    // ---- sparse directory lookups (requested first: their round trips overlap the dense rows)
-    for (int k = tid; k < U; k += SCB) {
-        const uint32_t w = A.q_w[k];
-        const int32_t idf = A.q_idf[k];
-        const int32_t d = A.q_did[k];
-        const bool dense_here = d >= 0 && (uint32_t)d < D;
-        uint32_t start = 0, len = 0;
-        if (idf != 0 && w < B.W && (!dense_here || (flags & 1u))) {  // a dense word has sparse postings only for counts > 255
-            const uint2 blk = B.dirb[w >> 5];
-            const uint32_t bit = 1u << (w & 31);
-            if (blk.x & bit) {
-                const uint32_t r = blk.y + (uint32_t)__popc(blk.x & (bit - 1u));
-                start = B.sp_off[r];
-                len = B.sp_off[r + 1] - start;
+    // The phase is a chain of dependent global reads (word list -> directory block -> segment offsets; dense list -> rows).  Every
+    // wavefront issues ALL independent loads of a stage before it consumes any of them (loads return in order, so waiting for an
+    // older one leaves the younger ones in flight): three round trips for the whole phase instead of one per step and row.
+    // ---- stage A: the frame's lists (L2-resident: every workgroup reads the same few KB), ni
+    const bool has_k = tid < U;
+    uint32_t w = 0; int32_t idf = 0, did = -1;
+    if (has_k) { w = A.q_w[tid]; idf = A.q_idf[tid]; did = A.q_did[tid]; }
+    int32_t dj[DR], fj[DR];
+#pragma unroll
+    for (int u = 0; u < DR; ++u) {
+        const int j = wv + u * NWV;                                  // wave-uniform: scalar loads
+        dj[u] = j < Ud ? A.qd_did[j] : -1;
+        fj[u] = j < Ud ? A.qd_idf[j] : 0;
+    }
+    uint32_t ni_v = 0;
+    if (tid < TF_R) ni_v = A.slot_ni[first_slot + tid];
+    // ---- stage B: directory blocks of the sparse words, dense rows
+    const bool dense_here = did >= 0 && (uint32_t)did < D;
+    const bool look = has_k && idf != 0 && w < B.W && (!dense_here || (flags & 1u));   // a dense word has sparse postings only for counts > 255
+    uint2 blk = make_uint2(0u, 0u);
+    if (look) blk = gload2(B.dirb + (w >> 5));
+    uint32_t c[DR];
+#pragma unroll
+    for (int u = 0; u < DR; ++u) c[u] = (dj[u] >= 0 && (uint32_t)dj[u] < D) ? gload((const uint32_t*)(B.dense + (size_t)dj[u] * TF_R + 4 * ln)) : 0u;
+    // ---- stage C: segment offsets of the words that are present
+    uint32_t start = 0, len = 0;
+    {
+        const uint32_t bit = 1u << (w & 31);
+        if (look && (blk.x & bit)) {
+            const uint32_t r = blk.y + (uint32_t)__popc(blk.x & (bit - 1u));
+            const uint32_t s0 = gload(B.sp_off + r), s1 = gload(B.sp_off + r + 1);
+            start = s0; len = s1 - s0;
+        }
+    }
+    // the dense rows: a lane owns four signatures
+    long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int u = 0; u < DR; ++u) {
+        const long long f64 = (long long)fj[u];
+        a0 += (long long)(int)(c[u] & 255u) * f64;
+        a1 += (long long)(int)((c[u] >> 8) & 255u) * f64;
+        a2 += (long long)(int)((c[u] >> 16) & 255u) * f64;
+        a3 += (long long)(int)(c[u] >> 24) * f64;
+    }
+    for (int j0 = wv + DR * NWV; j0 < Ud; j0 += DR * NWV) {           // frames with more than 128 dense words
+#pragma unroll
+        for (int u = 0; u < DR; ++u) {
+            const int j = j0 + u * NWV;
+            dj[u] = j < Ud ? A.qd_did[j] : -1;
+            fj[u] = j < Ud ? A.qd_idf[j] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < DR; ++u) c[u] = (dj[u] >= 0 && (uint32_t)dj[u] < D) ? gload((const uint32_t*)(B.dense + (size_t)dj[u] * TF_R + 4 * ln)) : 0u;
+#pragma unroll
+        for (int u = 0; u < DR; ++u) {
+            const long long f64 = (long long)fj[u];
+            a0 += (long long)(int)(c[u] & 255u) * f64;
+            a1 += (long long)(int)((c[u] >> 8) & 255u) * f64;
+            a2 += (long long)(int)((c[u] >> 16) & 255u) * f64;
+            a3 += (long long)(int)(c[u] >> 24) * f64;
+        }
+    }
+    if (tid < TF_R) { acc[tid] = 0ull; s_ni[tid] = ni_v; }
+    if (has_k) { s_start[tid] = start; s_scan[tid] = len; s_idf[tid] = idf; }
+    for (int k = tid + SCB; k < U; k += SCB) {                       // frames with more than 1024 unique words
+        const uint32_t w2 = A.q_w[k];
+        const int32_t idf2 = A.q_idf[k];
+        const int32_t d2 = A.q_did[k];
+        const bool dh = d2 >= 0 && (uint32_t)d2 < D;
+        uint32_t st2 = 0, ln2 = 0;
+        if (idf2 != 0 && w2 < B.W && (!dh || (flags & 1u))) {
+            const uint2 bk = gload2(B.dirb + (w2 >> 5));
+            const uint32_t bit = 1u << (w2 & 31);
+            if (bk.x & bit) {
+                const uint32_t r = bk.y + (uint32_t)__popc(bk.x & (bit - 1u));
+                st2 = gload(B.sp_off + r);
+                ln2 = gload(B.sp_off + r + 1) - st2;
             }
         }
-        s_start[k] = start;
-        s_scan[k] = len;
-        s_idf[k] = idf;
+        s_start[k] = st2; s_scan[k] = ln2; s_idf[k] = idf2;
     }
     if (tid == 0) s_scan[U] = 0u;
-    // ---- dense rows
-    long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    {
-        const int wv = tid >> 6, ln = tid & 63;
-        constexpr int NWV = SCB / 64;
-        for (int j0 = wv; j0 < Ud; j0 += 4 * NWV) {
-            uint32_t c[4]; int32_t f[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u * NWV;
-                int32_t d = -1; f[u] = 0;
-                if (j < Ud) { d = A.qd_did[j]; f[u] = A.qd_idf[j]; }
-                c[u] = (d >= 0 && (uint32_t)d < D) ? *(const uint32_t*)(B.dense + (size_t)d * TF_R + 4 * ln) : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long long f64 = (long long)f[u];
-                a0 += (long long)(int)(c[u] & 255u) * f64;
-                a1 += (long long)(int)((c[u] >> 8) & 255u) * f64;
-                a2 += (long long)(int)((c[u] >> 16) & 255u) * f64;
-                a3 += (long long)(int)(c[u] >> 24) * f64;
-            }
-        }
-    }
     __syncthreads();                                                 // acc zeroed, s_* complete
     SC_STAMP(1);
     {
-        const int ln4 = (tid & 63) * 4;
+        const int ln4 = ln * 4;
         if (a0) atomicAdd(&acc[ln4 + 0], (unsigned long long)a0);
         if (a1) atomicAdd(&acc[ln4 + 1], (unsigned long long)a1);
         if (a2) atomicAdd(&acc[ln4 + 2], (unsigned long long)a2);
@@ -372,7 +419,7 @@ __device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, c
             addr[u] = t < T ? s_start[lo] + (t - s_scan[lo]) : 0xFFFFFFFFu;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) e[u] = addr[u] != 0xFFFFFFFFu ? B.sp_ent[addr[u]] : 0u;
+        for (int u = 0; u < 2; ++u) e[u] = addr[u] != 0xFFFFFFFFu ? gload(B.sp_ent + addr[u]) : 0u;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (addr[u] == 0xFFFFFFFFu) continue;
@@ -382,11 +429,10 @@ __device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, c
     }
     __syncthreads();
     SC_STAMP(3);
-    for (int i = tid; i < TF_R; i += SCB) {
-        const long long v = (long long)acc[i];
-        const uint32_t ni = s_ni[i];
-        if (A.out_like) A.out_like[first_slot + i] = fixed_to_like(v, ni);
-        else A.out_fix[first_slot + i] = ni ? v : 0;
+    if (tid < TF_R) {
+        const long long v = (long long)acc[tid];
+        if (A.out_like) A.out_like[first_slot + tid] = fixed_to_like(v, ni_v);
+        else A.out_fix[first_slot + tid] = ni_v ? v : 0;
     }
 }
 
@@ -408,11 +454,11 @@ __device__ __forceinline__ void score_open_body(const ScoreArgs& A, int ob) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t e = e0 + u * 64 + ln;
-                w[u] = e < cnt ? B.coo_w[begin + e] : 0xFFFFFFFFu;
-                pc[u] = e < cnt ? B.coo_pc[begin + e] : 0u;
+                w[u] = e < cnt ? gload(B.coo_w + begin + e) : 0xFFFFFFFFu;
+                pc[u] = e < cnt ? gload(B.coo_pc + begin + e) : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) t[u] = w[u] != 0xFFFFFFFFu ? A.idf_tab[w[u]] : make_uint2(0u, 0u);
+            for (int u = 0; u < 4; ++u) t[u] = A.idf_tab[w[u] != 0xFFFFFFFFu ? w[u] : 0u];      // unconditional: four loads in flight
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (w[u] != 0xFFFFFFFFu && t[u].x == A.stamp) acc += (long long)(int)(pc[u] & TF_CNT_MASK) * (long long)(int32_t)t[u].y;
@@ -832,8 +878,14 @@ static hipError_t grow_filled(DevBuf& buf, size_t bytes, int byte, hipStream_t s
 }
 static hipError_t grow_zeroed(DevBuf& buf, size_t bytes, hipStream_t s, int64_t* total) { return grow_filled(buf, bytes, 0, s, total); }
 
+// frames / signatures of thousands of words need more than the default 64 KB of dynamic LDS: allow everything the CU has left
+// after the kernel's static LDS.  A failure here is not fatal: only launches that actually ask for more than 64 KB would fail.
 static hipError_t set_max_lds(const void* fn) {
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncAttributes attr;
+    size_t fixed = 1024;
+    if (hipFuncGetAttributes(&attr, fn) == hipSuccess) fixed = (attr.sharedSizeBytes + 255) & ~(size_t)255;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - fixed)) != hipSuccess) (void)hipGetLastError();
+    return hipSuccess;
 }
 
 hipError_t Tfidf::init(hipStream_t s, int64_t* bytes, int64_t sig_capacity, int64_t vocab_capacity) {
@@ -930,6 +982,7 @@ hipError_t Tfidf::wslot_of(int32_t word_id, bool create, int32_t* out) {
         w = ws_runs_at(resv.runs, word_id - resv.first_id);
     } else {
         // a new word of an earlier frame whose reservation is being checked by the device: the verdict decides whether it exists
+        if (std::find(held_ids.begin(), held_ids.end(), word_id) != held_ids.end()) { TF_TRY(flush_held()); harvest_released(true); }
         for (size_t i = 0; i < releasing.size(); ++i) {
             const ReleaseBatch& r = releasing[i];
             if (std::find(r.ids.begin(), r.ids.end(), word_id) != r.ids.end()) { harvest_released(true); break; }
@@ -1015,7 +1068,15 @@ hipError_t Tfidf::release_wslots(const std::vector<int32_t>& ws, const std::vect
     return hipSuccess;
 }
 
+hipError_t Tfidf::flush_held() {
+    if (held_ws.empty()) return hipSuccess;
+    hipError_t e = release_wslots(held_ws, &held_ids);
+    held_ws.clear(); held_ids.clear();
+    return e;
+}
+
 hipError_t Tfidf::release_words(const int32_t* word_ids, int n) {
+    TF_TRY(flush_retire());               // retirements ride with the next frame otherwise: the check below would still see their references
     std::vector<int32_t> ws;
     for (int i = 0; i < n; ++i) {
         int32_t w = -1;
@@ -1035,15 +1096,18 @@ hipError_t Tfidf::reserve_new_words(int32_t first_id, int n, WsRuns* runs) {
     if (first_id <= 0 || n <= 0) return hipSuccess;
     if ((int64_t)first_id + n >= (1 << 28)) return hipErrorInvalidValue;
     if (resv.n > 0) {
-        std::vector<int32_t> ws, ids;
-        for (int32_t k = 0; k < resv.n; ++k) {
-            const int32_t id = resv.first_id + k;
-            if ((size_t)id < id2ws.size() && id2ws[id] >= 0) continue;        // already the word's permanent key
-            ws.push_back(ws_runs_at(resv.runs, k));
-            ids.push_back(id < first_id ? id : 0);                            // ids the caller is re-using now name other words
+        int32_t k = 0;
+        for (int i = 0; i < resv.runs.n; ++i) {
+            for (int32_t j = 0; j < resv.runs.len[i]; ++j, ++k) {
+                const int32_t id = resv.first_id + k;
+                if ((size_t)id < id2ws.size() && id2ws[id] >= 0) continue;    // already the word's permanent key
+                held_ws.push_back(resv.runs.start[i] + j);
+                held_ids.push_back(id < first_id ? id : 0);                   // ids the caller is re-using now name other words
+            }
         }
         resv.n = 0;
-        TF_TRY(release_wslots(ws, &ids));
+        // one check launch per ~8 frames, not per frame (the frame tail that may have used these keys is already enqueued)
+        if (held_ws.size() >= 4096) TF_TRY(flush_held());
     }
     harvest_released(false);
     int left = n;

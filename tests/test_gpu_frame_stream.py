@@ -54,9 +54,10 @@ class _Mirror:
         """What Memory::preUpdate does before addNewWords: cleanUnusedWords + VWDictionary::update()."""
         unused = set(self.m.vwd.get_unused_word_ids())
         gone = sorted(w for w in unused if w in self.rows)
+        never_indexed = sorted(w for (w, _) in self.pending if w in unused)     # created by the last frame, unreferenced already
         self.pending = [(w, r) for (w, r) in self.pending if w not in unused]
-        if gone:
-            self.eng.vocab_remove(np.array(gone, np.int32))
+        if gone or never_indexed:
+            self.eng.vocab_remove(np.array(gone + never_indexed, np.int32))    # removeWords: rows are tombstoned, keys come back
             self.rows.difference_update(gone)
         if self.pending:
             ids = np.array([w for w, _ in self.pending], np.int32)
@@ -161,7 +162,7 @@ def test_frame_dev_register_and_score_stream(oracle, kind):
     st = _run_stream(oracle, kind, n_frames=540, q=96, wm=270)
     assert st["buckets_sealed"] >= 3
     # postings keys are recycled: far fewer in use than words ever created
-    assert st["word_slots"] < st["vocab_live"] + 4000
+    assert st["word_slots"] < st["vocab_live"] + 6000, st            # (up to 4096 keys wait for the next batched check)
 
 
 def test_frame_dev_stream_pipelined_handle(oracle):
@@ -189,7 +190,7 @@ def test_pipelined_frames_enqueued_back_to_back(oracle):
         torch.cuda.synchronize()
         for t in range(T):
             eng.frame_dev(frames[t].data_ptr(), q, n_sig + 1 + t, float(n_sig + 1 + t), d_w[t].data_ptr(), d_l[t].data_ptr(), cap,
-                          first_new_word_id=0)
+                          first_new_word_id=n_words + 1 + t * q)    # new words are never read back here: an upper bound per frame
             if t % 3 == 2:
                 eng.sig_remove(1 + t // 3)
         eng.synchronize()

@@ -26,14 +26,14 @@ def score_timing(lib, eng, vocab, words, n_sig, q, d_words, d_like, cap):
     t0 = t[:, 0].min()
     print("%d sealed-bucket workgroups; start spread %.2f us" % (len(t), t[:, 0].max() - t0))
     d = np.diff(t, axis=1)
-    for i, nme in enumerate(["lookups (tab, words, dir)", "long segments", "short segments"]):
+    for i, nme in enumerate(["lists + directory + dense rows", "LDS flush + scan", "sparse postings"]):
         print("  %-28s median %5.2f  p90 %5.2f us" % (nme, np.median(d[:, i]), np.percentile(d[:, i], 90)))
     print("  last workgroup leaves %.2f us after the first started" % (t[:, 3].max() - t0))
     eng.close()
 
 
 def main():
-    n_words, q, n_sig = 49000, 500, int(os.environ.get("N_SIG", "3000"))
+    n_words, q, n_sig = 49000, 500, int(os.environ.get("N_SIG", "100000"))
     vocab = synth.vocab_surf(n_words)
     words = synth.zipf_words(n_sig, q, n_words, seed=100000)
     eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 1024, sig_capacity=n_sig + 4096)
