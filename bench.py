@@ -346,8 +346,7 @@ def run_orb_stream(args):
     h = MemoryHip(nndr=NNDR, new_words_compared_together=True)
     o = O.OracleMemory(strategy=O.kNNBruteForce, nndr=NNDR, new_words_compared_together=True)
     ids_equal = True
-    t_upd = t_lik = 0.0
-    t0 = time.perf_counter()
+    t_upd = t_lik = t_fgt = 0.0
     for t in range(n_frames):
         rng = np.random.default_rng(t)
         desc = frames[t % 64] ^ np.packbits(rng.random((q, 256)) < 0.01, axis=1)        # every frame differs a little
@@ -365,8 +364,10 @@ def run_orb_stream(args):
             if so > W:
                 o.forget(so - W)
         if sid > W:
+            t4 = time.perf_counter()
             h.forget(sid - W)
-    wall = time.perf_counter() - t0
+            t_fgt += time.perf_counter() - t4
+    wall = t_upd + t_lik + t_fgt                          # the engine-side step: update() + addNewWords, computeLikelihood, forget
     out = {"metric": "loop-closure candidates/sec (ORB 256-bit, incremental dictionary from empty, W=1000)", "unit": "candidates/s",
            "value": n_frames * min(W, n_frames) / wall, "n_gpus": 1, "steps": n_frames, "warmup": 0, "ms_per_step": 1e3 * wall / n_frames,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -393,6 +394,7 @@ def main():
                     help="N > 1: ONE frame stream with the vocabulary sharded by word-id range + all-gather / all-reduce per frame (the "
                          "north star; strong scaling), or independent frame streams per GPU (weak scaling, no data-path collective)")
     ap.add_argument("--config", choices=["headline", "orb_stream"], default="headline")
+    ap.add_argument("--score-block", type=int, default=0, help="experiment: threads per workgroup of the scoring kernel (256/512/1024)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -470,6 +472,8 @@ def main():
         d_frames = [torch.from_numpy(f).cuda() for f in frames_np]
         eng = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 1024, sig_capacity=n_sig + 8192,
                                  stream=stream.cuda_stream, pipeline=bool(args.pipeline))
+        if args.score_block:
+            eng.set_option("score_block", args.score_block)
         build_s = load_engine(eng, vocab, words)
         log("[bench] rank %d: %d signatures bulk-loaded in %.2fs" % (rank, n_sig, build_s))
         step = Stepper(eng, torch, d_frames, n_sig, cap)
@@ -541,6 +545,8 @@ def main():
         if not args.no_extras:
             engu = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 8192,
                                       stream=stream.cuda_stream, pipeline=not bool(args.pipeline))
+            if args.score_block:
+                engu.set_option("score_block", args.score_block)
             load_engine(engu, vocab, words)
             stu = Stepper(engu, torch, d_frames, n_sig, cap)
             ru = timed_loop(torch, dist, 1, stream, stu, max(50, min(args.steps, 200)), 10, profile_eng=engu)

@@ -243,6 +243,10 @@ int lcd_profile_read(lcd_engine* h, float* avg_ms, int* n_samples, const char** 
 /* the same for the fused likelihood kernel of lcd_frame_dev (both series are recorded while profiling is enabled) */
 int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, const char** kernel_name);
 
+/* tuning knobs for experiments (results never depend on them).  "score_block": threads per workgroup of the scoring kernel
+ * (256 / 512 / 1024).  Unknown keys / values -> LCD_ERR_INVALID. */
+int lcd_set_option(lcd_engine* h, const char* key, int64_t value);
+
 /* the work of ONE scoring launch for the words of the last frame (diagnostic, synchronises): out8[0] bytes of dense count rows
  * read, [1] sparse postings read (4 B each), [2] directory lookups, [3] lookups that found the word, [4] entries of the open
  * bucket's log (8 B each), [5] postings of the frame's words over all live signatures (the P of SURVEY.md 8d), [6] unique

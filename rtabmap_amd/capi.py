@@ -22,7 +22,7 @@ SYMBOLS = [
     "lcd_vocab_clear", "lcd_vocab_append", "lcd_vocab_remove", "lcd_vocab_rebuild", "lcd_vocab_count", "lcd_vocab_read",
     "lcd_knn2", "lcd_selfdist", "lcd_quantize", "lcd_find_nn",
     "lcd_sig_add", "lcd_sig_remove", "lcd_sig_add_bulk", "lcd_sig_count", "lcd_word_nrefs",
-    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_adjust_likelihood_dev", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood", "lcd_profile_score_work",
+    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_adjust_likelihood_dev", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood", "lcd_profile_score_work", "lcd_set_option",
 ]
 
 
@@ -123,6 +123,7 @@ def load():
     L.lcd_profile_read_likelihood.argtypes = [vp, C.POINTER(f32), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
     L.lcd_get_stats.argtypes = [vp, C.POINTER(LcdStats)]
     L.lcd_profile_score_work.argtypes = [vp, C.POINTER(i64)]
+    L.lcd_set_option.argtypes = [vp, C.c_char_p, i64]
     _lib = L
     return L
 
@@ -333,6 +334,9 @@ class Engine:
         ms, n, name = C.c_float(), C.c_int(), C.c_char_p()
         self._ck(self.L.lcd_profile_read_likelihood(self.h, C.byref(ms), C.byref(n), C.byref(name)))
         return ms.value, n.value, (name.value or b"").decode()
+
+    def set_option(self, key, value):
+        self._ck(self.L.lcd_set_option(self.h, key.encode(), int(value)))
 
     def profile_score_work(self):
         out = (C.c_int64 * 8)()

@@ -49,6 +49,9 @@ struct lcd_engine {
     // `stream`; the scratch the two stages share exists twice (the set in use above and `alt`), swapped every frame
     hipStream_t kstream = nullptr;                      // NULL: not pipelined
     hipStream_t kst = nullptr;                          // the stream the 2-NN stage is being enqueued on right now
+    hipStream_t rstream = nullptr;                      // pipelined: the re-rank of frame t runs here, next to the filter of frame t + 1
+    hipStream_t rst = nullptr;                          // the stream the re-rank is being enqueued on right now (NULL: same as kst)
+    hipEvent_t ev_filter[2] = {nullptr, nullptr};       // filter of the frame that uses set i finished (recorded on kstream)
     struct AltScratch {
         lcd::DevBuf d_knn_row, d_knn_word, d_knn_dist, d_selfdist, d_bits, d_partial2, d_partial3, d_fail_list, d_fail_count, d_out_wslot;
         bool fail_count_clean = false;

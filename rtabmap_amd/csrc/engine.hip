@@ -42,6 +42,7 @@ int lcd_engine::find_row(int32_t word_id) {
 int lcd_engine::sync_all() {
     if (kstream && k_busy) {
         hipError_t e = hipStreamSynchronize(kstream);
+        if (e == hipSuccess && rstream) e = hipStreamSynchronize(rstream);
         if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(kstream)");
         k_busy = false;
     }
@@ -50,7 +51,8 @@ int lcd_engine::sync_all() {
     return LCD_OK;
 }
 // entries that use the 2-NN scratch or change what the 2-NN stage reads: the second stream of a pipelined handle must be idle
-#define LCD_JOIN_K(h) do { if ((h)->kstream && (h)->k_busy) { LCD_HIP(h, hipStreamSynchronize((h)->kstream)); (h)->k_busy = false; } } while (0)
+#define LCD_JOIN_K(h) do { if ((h)->kstream && (h)->k_busy) { LCD_HIP(h, hipStreamSynchronize((h)->kstream)); \
+                                 if ((h)->rstream) LCD_HIP(h, hipStreamSynchronize((h)->rstream)); (h)->k_busy = false; } } while (0)
 
 namespace {
 
@@ -101,7 +103,7 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
         LCD_HIP(h, launch_knn_bf16(h->kdim, vocab, h->vocab_bf.p, h->row_norm.as<float>(), h->norm_max.as<uint32_t>(), row_id, d_queries, mp,
                                    h->d_partial2.p, o_row, o_word, o_dist, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(),
                                    h->kst, prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr,
-                                   !h->fail_count_clean, cb, cb != nullptr));
+                                   !h->fail_count_clean, cb, cb != nullptr, h->rst, h->rst ? h->ev_filter[h->ks_idx] : nullptr));
         h->fail_count_clean = false;
         if (prof) { h->prof_n += 1; h->prof_kernel = "knn_bf16_filter_kernel"; }
         LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
@@ -197,11 +199,13 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
     h->kst = h->stream;
     if (cfg->pipeline) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->kstream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->rstream, hipStreamNonBlocking);
         if (e == hipSuccess) e = h->alt.d_fail_count.reserve(64, 0, h->stream, &h->bytes_device);
         if (e == hipSuccess) e = hipMemsetAsync(h->alt.d_fail_count.p, 0, 64, h->stream);
         for (int i = 0; i < 2 && e == hipSuccess; ++i) {
             e = hipEventCreateWithFlags(&h->ev_knn[i], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_tail[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_filter[i], hipEventDisableTiming);
         }
     }
     if (e == hipSuccess) e = h->tfidf.init(h->stream, &h->bytes_device, cfg->sig_capacity, cfg->vocab_capacity);
@@ -214,15 +218,21 @@ void lcd_destroy(lcd_engine* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->kstream) (void)hipStreamSynchronize(h->kstream);
+    if (h->rstream) (void)hipStreamSynchronize(h->rstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->tfidf.destroy();
-    for (int i = 0; i < 2; ++i) { if (h->ev_knn[i]) (void)hipEventDestroy(h->ev_knn[i]); if (h->ev_tail[i]) (void)hipEventDestroy(h->ev_tail[i]); }
+    for (int i = 0; i < 2; ++i) {
+        if (h->ev_knn[i]) (void)hipEventDestroy(h->ev_knn[i]);
+        if (h->ev_tail[i]) (void)hipEventDestroy(h->ev_tail[i]);
+        if (h->ev_filter[i]) (void)hipEventDestroy(h->ev_filter[i]);
+    }
     {
         DevBuf* alts[] = {&h->alt.d_knn_row, &h->alt.d_knn_word, &h->alt.d_knn_dist, &h->alt.d_selfdist, &h->alt.d_bits, &h->alt.d_partial2,
                           &h->alt.d_partial3, &h->alt.d_fail_list, &h->alt.d_fail_count, &h->alt.d_out_wslot};
         for (DevBuf* d : alts) d->release(&h->bytes_device);
     }
     if (h->kstream) (void)hipStreamDestroy(h->kstream);
+    if (h->rstream) (void)hipStreamDestroy(h->rstream);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->prof2_ev) (void)hipEventDestroy(e);
     DevBuf* all[] = {&h->vocab, &h->row_id, &h->row_wslot, &h->vocab_alt, &h->row_id_alt, &h->row_wslot_alt, &h->d_queries,
@@ -781,6 +791,7 @@ int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
         LCD_HIP(h, hipStreamWaitEvent(h->kstream, h->ev_tail[p], 0));
         if (a->ready_event) LCD_HIP(h, hipStreamWaitEvent(h->kstream, (hipEvent_t)a->ready_event, 0));
         h->kst = h->kstream;
+        h->rst = h->rstream;
         h->k_busy = true;
     }
     LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
@@ -788,9 +799,13 @@ int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     ResolveArgs r;
     int rc = prepare_resolve(h, a->d_descriptors, q, a->flags, a->nndr_ratio, a->d_word_ids, h->d_out_wslot.as<int32_t>(), &r, true);
     h->kst = h->stream;
+    hipStream_t knn_end = h->rst ? h->rst : h->kstream;              // the stream the last kernel of the 2-NN stage went to
+    const bool split = h->rst != nullptr && h->knn_mode == 2 && knn_mfma_supported(h->dtype, h->kdim) && h->n_live >= 2 && h->n_rows >= 256;
+    if (!split) knn_end = h->kstream;
+    h->rst = nullptr;
     if (rc) return rc;
     if (pipe) {
-        LCD_HIP(h, hipEventRecord(h->ev_knn[p], h->kstream));
+        LCD_HIP(h, hipEventRecord(h->ev_knn[p], knn_end));
         LCD_HIP(h, hipStreamWaitEvent(h->stream, h->ev_knn[p], 0));
     }
     r.new_ws = new_ws;
@@ -963,6 +978,13 @@ int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, co
     if (kernel_name) *kernel_name = "score_kernel";
     h->prof_cap = 0;
     return LCD_OK;
+}
+
+int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
+    LCD_CHECK_HANDLE(h);
+    if (!key) return h->fail(LCD_ERR_INVALID, "lcd_set_option: null key");
+    if (!std::strcmp(key, "score_block") && (value == 256 || value == 512 || value == 1024)) { h->tfidf.score_block = (int)value; return LCD_OK; }
+    return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");
 }
 
 int lcd_profile_score_work(lcd_engine* h, int64_t* out8) {

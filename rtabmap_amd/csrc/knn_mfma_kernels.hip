@@ -1061,9 +1061,10 @@ hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void*
 hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, const float* row_norm, const uint32_t* norm_max_bits,
                            const int32_t* row_id, const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word,
                            float* out_dist, int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
-                           bool reset_count, const CandBits* cb, bool with_selfdist) {
+                           bool reset_count, const CandBits* cb, bool with_selfdist, hipStream_t s_rerank, hipEvent_t ev_bridge) {
     if (p.q == 0) return hipSuccess;
     if (dim != 64) return hipErrorInvalidValue;
+    if (!s_rerank || !ev_bridge) s_rerank = s;
     uint64_t* pk = (uint64_t*)partial;
     uint32_t* pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * BF_KEEP * p.qpad);
     hipError_t e = hipSuccess;
@@ -1095,7 +1096,13 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
         if (e != hipSuccess) return e;
         if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }
     }
-    knn_mfma_rerank_kernel<64, BF_KEEP, false, true><<<p.q, MF_BLOCK, 0, s>>>(
+    if (s_rerank != s) {                                             // the re-rank of this frame on its own stream: the next frame's
+        e = hipEventRecord(ev_bridge, s);                             // filter does not have to wait for it
+        if (e != hipSuccess) return e;
+        e = hipStreamWaitEvent(s_rerank, ev_bridge, 0);
+        if (e != hipSuccess) return e;
+    }
+    knn_mfma_rerank_kernel<64, BF_KEEP, false, true><<<p.q, MF_BLOCK, 0, s_rerank>>>(
         pk, pl, p.n_blocks, p.q, (const float*)vocab, (const float*)queries, row_id, norm_max_bits, out_row, out_word, out_dist, fail_list,
         fail_count, cb ? *cb : CandBits{});
     return hipGetLastError();

@@ -118,7 +118,8 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
                            const int32_t* row_id, const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word,
                            float* out_dist, int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin = nullptr,
                            hipEvent_t ev_end = nullptr, bool reset_count = true, const CandBits* cb = nullptr,
-                           bool with_selfdist = false);    // true: extra workgroups of the filter launch fill cb->selfdist (queries x queries)
+                           bool with_selfdist = false,     // true: extra workgroups of the filter launch fill cb->selfdist (queries x queries)
+                           hipStream_t s_rerank = nullptr, hipEvent_t ev_bridge = nullptr);   // re-rank on its own stream behind ev_bridge
 
 // Row gather used by lcd_vocab_rebuild: dst[i] = src[perm[i]] (rows of row_bytes bytes, multiple of 4), ids likewise.
 hipError_t launch_gather_rows(const void* src, const int32_t* src_id, const int32_t* perm, int n, int row_bytes,

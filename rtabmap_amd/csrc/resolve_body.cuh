@@ -63,6 +63,163 @@ __device__ __forceinline__ int new_rank(const uint32_t* mask, const uint32_t* pr
     return (int)(prefix[j >> 5] + __popc(mask[j >> 5] & ((1u << (j & 31)) - 1u)));
 }
 
+// The same decision loop for frames of at most RBLOCK descriptors (one descriptor per thread), latency-trimmed: the kernel this
+// runs in is ONE workgroup on the critical path of every frame, so what counts is the number of dependent global round trips.
+//   * the indexed neighbours, their vocabulary rows and the descriptor's candidate-bit row are read ONCE, all loads in flight
+//     together; the postings keys of both neighbours are requested before the sweeps and consumed after them;
+//   * the bit row is kept as at most four non-zero (word, bits) pairs in registers (rows with more fall back to memory): a
+//     descriptor whose row is empty -- nearly all of them in a mature vocabulary -- has its sweep-0 decision for good and a sweep
+//     costs it nothing; the winner of a sweep lives in a register, not in out_word;
+//   * the result is also left in LDS (lds_wslot, may be NULL) for the registration that follows in the same kernel.
+// Same results as resolve_body (tests drive both).  rs_smem as below.
+__device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* lds_wslot, int q, int flags, float nndr, int have_index,
+                                                  const int32_t* __restrict__ knn_word, const float* __restrict__ knn_dist,
+                                                  const float* __restrict__ selfdist, int ld,
+                                                  const uint32_t* __restrict__ cand_bits, int bw,
+                                                  int32_t* __restrict__ out_word, int32_t* __restrict__ out_n_new,
+                                                  const int32_t* __restrict__ knn_row, const int32_t* __restrict__ row_wslot,
+                                                  int32_t* __restrict__ out_wslot, const WsRuns& new_ws) {
+    const int mw = (q + 63) / 64 * 2;
+    uint32_t* mask_cur = rs_smem;
+    uint32_t* mask_next = rs_smem + mw;
+    uint32_t* prefix = rs_smem + 2 * mw;
+    __shared__ int s_changed_f;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const bool incremental = (flags & LCD_Q_INCREMENTAL) != 0;
+    const bool together = incremental && (flags & LCD_Q_NEW_WORDS_COMPARED) && cand_bits != nullptr;
+    const int qpad = mw * 32;
+    const int i = tid;
+    const bool valid = i < q;
+    // ---- round trip 1: indexed neighbours + their rows, the bit row
+    float d0 = -1.0f, d1 = -1.0f; int w0 = 0, w1 = 0, r0 = -1, r1 = -1;
+    if (valid && have_index) {
+        const float2 dd = *reinterpret_cast<const float2*>(knn_dist + 2 * i);
+        const int2 ww = *reinterpret_cast<const int2*>(knn_word + 2 * i);
+        d0 = dd.x; d1 = dd.y; w0 = ww.x; w1 = ww.y;
+        if (out_wslot || lds_wslot) { const int2 rr = *reinterpret_cast<const int2*>(knn_row + 2 * i); r0 = rr.x; r1 = rr.y; }
+    }
+    int nzw[4]; uint32_t nzb[4]; int nz = 0; bool overflow = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { nzw[e] = 0; nzb[e] = 0u; }
+    if (together && valid) {
+        const int wlast = i >> 5;
+        for (int wb = 0; wb <= wlast; wb += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (wb + u <= wlast) ? cand_bits[(size_t)i * bw + wb + u] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                uint32_t m = v[u];
+                if (wb + u == wlast) m &= (1u << (i & 31)) - 1u;       // only j < i
+                if (m) {
+                    if (nz < 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (e == nz) { nzw[e] = wb + u; nzb[e] = m; }
+                        ++nz;
+                    } else overflow = true;
+                }
+            }
+        }
+    }
+    // ---- the indexed candidates (they do not change from sweep to sweep), :1092-1137: stop at the first invalid neighbour
+    Cand b0, b1; int nb = 0;
+    b0.d = 0.f; b0.id = 0; b1.d = 0.f; b1.id = 0;
+    if (valid && have_index) {
+        if (d0 >= 0.0f && w0 != 0) { cand_push(b0, b1, nb, d0, w0); if (d1 >= 0.0f && w1 != 0) cand_push(b0, b1, nb, d1, w1); }
+    }
+    // ---- round trip 2 (requested now, consumed after the sweeps): postings keys of both neighbours
+    int32_t ws_a = -1, ws_b = -1;
+    if (valid && (out_wslot || lds_wslot)) {
+        if (r0 >= 0) ws_a = row_wslot ? row_wslot[r0] : r0;
+        if (r1 >= 0) ws_b = row_wslot ? row_wslot[r1] : r1;
+    }
+    bool reject = valid && incremental && (nb < 2 || b0.d > nndr * b1.d);
+    int win = nb > 0 ? b0.id : 0;
+    if (i < qpad) {
+        const unsigned long long bal = __ballot(reject);
+        if (lane == 0) { mask_cur[i >> 5] = (uint32_t)bal; mask_cur[(i >> 5) + 1] = (uint32_t)(bal >> 32); }
+    }
+    __syncthreads();
+    if (together) {
+        const bool dyn = valid && (nz > 0 || overflow);                // only these descriptors can change their mind
+        for (int sweep = 0; sweep <= q; ++sweep) {
+            if (tid == 0) s_changed_f = 0;
+            __syncthreads();
+            if (dyn) {
+                Cand c0 = b0, c1 = b1; int n = nb;
+                uint64_t b = KEY_NONE, sk = KEY_NONE;
+                if (!overflow) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        uint32_t m = e < nz ? (nzb[e] & mask_cur[nzw[e]]) : 0u;
+                        while (m) {
+                            const int j = (nzw[e] << 5) + __builtin_ctz(m);
+                            m &= m - 1;
+                            const uint64_t k = ((uint64_t)__float_as_uint(selfdist[(size_t)j * ld + i]) << 32) | (uint32_t)j;
+                            const uint64_t hi = b > k ? b : k;
+                            b = b < k ? b : k;
+                            sk = sk < hi ? sk : hi;
+                        }
+                    }
+                } else {
+                    const int wlast = i >> 5;
+                    for (int w = 0; w <= wlast; ++w) {
+                        uint32_t m = cand_bits[(size_t)i * bw + w] & mask_cur[w];
+                        if (w == wlast) m &= (1u << (i & 31)) - 1u;
+                        while (m) {
+                            const int j = (w << 5) + __builtin_ctz(m);
+                            m &= m - 1;
+                            const uint64_t k = ((uint64_t)__float_as_uint(selfdist[(size_t)j * ld + i]) << 32) | (uint32_t)j;
+                            const uint64_t hi = b > k ? b : k;
+                            b = b < k ? b : k;
+                            sk = sk < hi ? sk : hi;
+                        }
+                    }
+                }
+                if (b != KEY_NONE) cand_push(c0, c1, n, __uint_as_float((uint32_t)(b >> 32)), -((int)(uint32_t)b + 1));
+                if (sk != KEY_NONE) cand_push(c0, c1, n, __uint_as_float((uint32_t)(sk >> 32)), -((int)(uint32_t)sk + 1));
+                reject = n < 2 || c0.d > nndr * c1.d;
+                win = n > 0 ? c0.id : 0;
+            }
+            if (i < qpad) {
+                const unsigned long long bal = __ballot(reject);
+                if (lane == 0) {
+                    const uint32_t lo = (uint32_t)bal, hi = (uint32_t)(bal >> 32);
+                    mask_next[i >> 5] = lo; mask_next[(i >> 5) + 1] = hi;
+                    if (lo != mask_cur[i >> 5] || hi != mask_cur[(i >> 5) + 1]) s_changed_f = 1;
+                }
+            }
+            __syncthreads();
+            uint32_t* t = mask_cur; mask_cur = mask_next; mask_next = t;
+            if (!s_changed_f) break;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int w = 0; w < mw; ++w) { prefix[w] = run; run += __popc(mask_cur[w]); }
+        prefix[mw] = run;
+        out_n_new[0] = (int32_t)run;
+    }
+    __syncthreads();
+    if (valid) {
+        const bool is_new = (mask_cur[i >> 5] >> (i & 31)) & 1u;
+        int w;
+        if (is_new) w = -(new_rank(mask_cur, prefix, i) + 1);
+        else {
+            w = win;
+            if (w < 0) w = -(new_rank(mask_cur, prefix, -w - 1) + 1);   // matched a same-frame new word
+        }
+        out_word[i] = w;
+        int32_t ws = -1;
+        if (w < 0 && new_ws.n > 0) ws = ws_runs_at(new_ws, -w - 1);
+        if (w > 0) { if (w0 == w) ws = ws_a; else if (w1 == w) ws = ws_b; }
+        if (lds_wslot) lds_wslot[i] = ws;
+        else if (out_wslot) out_wslot[i] = ws;
+    }
+}
+
 // The whole decision loop for one frame, executed by ONE workgroup of RBLOCK threads.  rs_smem: 3 * mw + 2 words of LDS,
 // mw = ceil(q / 64) * 2.
 __device__ __forceinline__ void resolve_body(uint32_t* rs_smem, int q, int flags, float nndr, int have_index,

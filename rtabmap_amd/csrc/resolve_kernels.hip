@@ -30,8 +30,12 @@ __global__ __launch_bounds__(RBLOCK) void resolve_kernel(int q, int flags, float
                                                          const int32_t* __restrict__ knn_row, const int32_t* __restrict__ row_wslot,
                                                          int32_t* __restrict__ out_wslot, WsRuns new_ws) {
     extern __shared__ uint32_t rs_dyn_smem[];
-    resolve_body(rs_dyn_smem, q, flags, nndr, have_index, knn_word, knn_dist, selfdist, ld, cand_bits, bw, out_word, out_n_new, knn_row,
-                 row_wslot, out_wslot, new_ws);
+    if (q <= RBLOCK)
+        resolve_body_fast(rs_dyn_smem, nullptr, q, flags, nndr, have_index, knn_word, knn_dist, selfdist, ld, cand_bits, bw, out_word, out_n_new,
+                          knn_row, row_wslot, out_wslot, new_ws);
+    else
+        resolve_body(rs_dyn_smem, q, flags, nndr, have_index, knn_word, knn_dist, selfdist, ld, cand_bits, bw, out_word, out_n_new, knn_row,
+                     row_wslot, out_wslot, new_ws);
 }
 
 // findNN (:1457-1542): indexed candidates are NOT cut at the first invalid one; not-indexed candidates are

@@ -130,6 +130,7 @@ struct Tfidf {
     // per bucket
     DevBuf bkt_tab, bkt_ne, bkt_D, bkt_flags;
     std::vector<Bucket> buckets;
+    int score_block = 512;               // threads per scoring workgroup (256 / 512 / 1024; lcd_set_option "score_block")
     int q_n_ub = 0;                      // word count of the last frame handed to frame_words (upper bound of its unique words)
     BufPool pool;
     DevBuf n_dense;                      // [0] number of dense ids handed out (device counter)

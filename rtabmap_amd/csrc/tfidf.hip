@@ -21,7 +21,6 @@ namespace {
 
 constexpr int FW_BLOCK = 1024;   // frame_words_kernel / frame_tail_kernel
 constexpr int BR_BLOCK = 256;    // bulk_register_kernel (one workgroup per signature)
-constexpr int SC_BLOCK = 1024;   // score_kernel
 constexpr int SEAL_BLOCK = 256;
 constexpr int SEAL_TILE = SEAL_BLOCK * 32;   // wslots per workgroup of the sealing scan (one 32-wslot directory block per thread)
 
@@ -93,8 +92,11 @@ struct FwArgs {
 // dense-id lists plus the per-word idf table (idf_tab[w] = {stamp, idf}) for the scoring kernel.
 // The list order is whatever the table yields: nothing downstream depends on it (integer accumulation).
 // LDS: 2 * H + H / 64 + 4 words.
-template <int NT>
-__device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs& a) {
+// SOLE: this workgroup is the only writer of the bucket's log right now (the frame path: one frame at a time on one stream), so the
+// log position is read at the start and written back at the end instead of being reserved with a returning atomic in the middle.
+// src_lds: the word slots in LDS (left there by the decision loop of the same kernel) instead of a.src.
+template <int NT, bool SOLE>
+__device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs& a, const int32_t* src_lds = nullptr) {
     const int H = a.H;
     uint32_t* tkey = fw_smem;            // [H] 0xFFFFFFFF = empty
     uint32_t* tcnt = fw_smem + H;        // [H]
@@ -102,10 +104,10 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
     uint32_t* s_misc = grp + H / 64 + 1; // [0] log base, [1] dense list length
     const int tid = threadIdx.x;
     for (int i = tid; i < H; i += NT) { tkey[i] = 0xFFFFFFFFu; tcnt[i] = 0u; }
-    if (tid == 0) { s_misc[0] = 0u; s_misc[1] = 0u; }
+    if (tid == 0) { s_misc[0] = (SOLE && a.do_register) ? a.ne_counter[0] : 0u; s_misc[1] = 0u; }
     __syncthreads();
     for (int i = tid; i < a.n; i += NT) {
-        int32_t ws = a.src[i];
+        int32_t ws = src_lds ? src_lds[i] : a.src[i];
         if (a.xlate) ws = (ws > 0 && (long long)ws < a.xlate_n) ? a.xlate[ws] : -1;
         if (ws < 0) continue;
         const uint32_t w = (uint32_t)ws;
@@ -130,7 +132,7 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
         uint32_t run = 0;
         for (int g = 0; g < ng; ++g) { const uint32_t c = grp[g]; grp[g] = run; run += c; }
         grp[ng] = run;
-        if (a.do_register) s_misc[0] = atomicAdd(a.ne_counter, run);     // reserve the signature's stretch of the log
+        if (a.do_register && !SOLE) s_misc[0] = atomicAdd(a.ne_counter, run);   // reserve the signature's stretch of the log
     }
     __syncthreads();
     const uint32_t U = grp[ng];
@@ -172,6 +174,7 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
     if (tid == 0) {
         if (a.want_q) { a.q_meta[0] = U; a.q_meta[1] = s_misc[1]; }
         if (a.do_register) {
+            if (SOLE) a.ne_counter[0] = base + U;
             a.slot_sig[a.slot] = a.sig_id;
             a.slot_ni[a.slot] = a.ni;
             a.slot_begin[a.slot] = base;
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(FwArgs a, RetireA
     extern __shared__ uint32_t fw_dyn_smem[];
     retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
     __syncthreads();
-    frame_words_body<FW_BLOCK>(fw_dyn_smem, a);
+    frame_words_body<FW_BLOCK, true>(fw_dyn_smem, a);
 }
 
 #ifdef LCD_TAIL_TIMING   // timing experiment only: 100 MHz stamps between the phases of the frame tail
@@ -222,14 +225,18 @@ __global__ __launch_bounds__(FW_BLOCK) void frame_tail_kernel(ResolveArgs r, FwA
         __syncthreads();
     }
     FT_STAMP(0);
-    resolve_body(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
-                 r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
+    // frames of up to 1024 descriptors: the register-resident decision loop, its result handed to the registration through LDS
+    int32_t* lds_ws = r.q <= RBLOCK ? (int32_t*)(ft_dyn_smem + 2 * a.H + a.H / 64 + 8) : nullptr;
+    if (lds_ws) resolve_body_fast(ft_dyn_smem, lds_ws, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits,
+                                  r.bw, r.out_word, r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
+    else resolve_body(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
+                      r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
     if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; r.fail_count[3] = 0; }
     FT_STAMP(1);
     retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
-    __syncthreads();      // out_wslot (global, written by this workgroup) and the LDS region are handed over
+    __syncthreads();      // out_wslot (global or LDS, written by this workgroup) and the LDS region are handed over
     FT_STAMP(2);
-    frame_words_body<FW_BLOCK>(ft_dyn_smem, a);
+    frame_words_body<FW_BLOCK, true>(ft_dyn_smem, a, lds_ws);
     FT_STAMP(3);
 }
 
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(BR_BLOCK) void bulk_register_kernel(const int32_t* 
     a.coo_w = const_cast<uint32_t*>(tab[b].coo_w); a.coo_pc = const_cast<uint32_t*>(tab[b].coo_pc); a.ne_counter = bkt_ne + b;
     a.slot_sig = slot_sig; a.slot_ni = slot_ni; a.slot_begin = slot_begin; a.slot_cnt = slot_cnt;
     a.q_w = nullptr; a.q_idf = nullptr; a.q_did = nullptr; a.qd_did = nullptr; a.qd_idf = nullptr; a.q_meta = nullptr; a.idf_tab = nullptr;
-    frame_words_body<BR_BLOCK>(br_dyn_smem, a);
+    frame_words_body<BR_BLOCK, false>(br_dyn_smem, a);
 }
 
 // ---------------------------------------------------------------------------------------------- scoring
@@ -281,22 +288,51 @@ struct ScoreArgs {
 };
 
 // One workgroup scores one sealed bucket (256 signatures).
-//   dense rows : wavefront v takes the frame's dense words v, v + 16, ...; a lane reads the four counts of its four signatures
+//   dense rows : wavefront v takes the frame's dense words v, v + NWV, ...; a lane reads the four counts of its four signatures
 //                with one 4-byte load (the wavefront reads the 256-byte row in one coalesced request) and keeps four 64-bit
 //                sums in registers; all loads of a trip are issued before any is consumed;
 //   sparse part: one thread per frame word looks the word up in the bucket's directory (one 8-byte read; a second one for the
-//                offsets when the word is present), the segments are flattened into one load-balanced index space (exclusive
-//                scan of their lengths, binary search per posting) and accumulated with LDS 64-bit atomics;
+//                offsets when the word is present).  The segments of the 64 words of a wavefront are then walked by that
+//                wavefront alone: lane-wise inclusive scan of the lengths, every lane finds the segment of "its" posting with six
+//                cross-lane reads (no LDS arrays, no workgroup barrier, no per-workgroup scan) and adds count x idf with an LDS
+//                64-bit atomic;
 //   output     : acc / ni, written straight from LDS.
-// LDS: acc[256] i64 | ni[256] | start[wcap] | scan[wcap + 1] | idf[wcap] | scratch[SCB / 64 + 1].
+// The whole body is a chain of dependent global reads (word list -> directory block -> segment offsets -> postings; dense list
+// -> rows): every wavefront issues ALL independent loads of a stage before it consumes any of them (loads return in order, so
+// waiting for an older one leaves the younger ones in flight).  LDS: acc[256] i64 | ni[256] (3 KB, static).
 template <int SCB>
-__device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, const ScoreArgs& A, int b) {
-    unsigned long long* acc = sc_smem;                              // [R]
-    uint32_t* s_ni = (uint32_t*)(acc + TF_R);                       // [R]
-    uint32_t* s_start = s_ni + TF_R;                                // [wcap]
-    uint32_t* s_scan = s_start + A.wcap;                            // [wcap + 1]
-    int32_t* s_idf = (int32_t*)(s_scan + A.wcap + 1);               // [wcap]
-    uint32_t* scratch = (uint32_t*)(s_idf + A.wcap);                // [SCB / 64 + 1]
+__device__ __forceinline__ void score_segments(const uint32_t* __restrict__ sp_ent, unsigned long long* acc, uint32_t start, uint32_t len, int32_t idf) {
+    const int ln = threadIdx.x & 63;
+    uint32_t incl = len;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(incl, off, 64); if (ln >= off) incl += y; }
+    const uint32_t Tw = __shfl(incl, 63, 64);                       // wave-uniform
+    for (uint32_t t0 = 0; t0 < Tw; t0 += 128) {
+        uint32_t e[2]; int32_t f[2]; bool ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t t = t0 + (uint32_t)(u * 64 + ln);
+            int pos = 0;                                            // number of lanes whose inclusive sum is <= t = the owner of posting t
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) { const uint32_t v = __shfl(incl, pos + step - 1, 64); if (v <= t) pos += step; }
+            if (pos > 63) pos = 63;
+            const uint32_t i_o = __shfl(incl, pos, 64), l_o = __shfl(len, pos, 64), s_o = __shfl(start, pos, 64);
+            f[u] = __shfl(idf, pos, 64);
+            ok[u] = t < Tw;
+            e[u] = ok[u] ? gload(sp_ent + s_o + (t - (i_o - l_o))) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!ok[u]) continue;
+            const long long term = (long long)(int)(e[u] & TF_CNT_MASK) * (long long)f[u];
+            atomicAdd(&acc[e[u] >> TF_CNT_BITS], (unsigned long long)term);      // ds_add_u64
+        }
+    }
+}
+
+template <int SCB>
+__device__ __forceinline__ void score_sealed_body(const ScoreArgs& A, int b) {
+    __shared__ unsigned long long acc[TF_R];
     const int tid = threadIdx.x;
     const BucketDev B = A.tab[b];
     const long long first_slot = (long long)b * TF_R;
@@ -308,20 +344,22 @@ __device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, c
     }
     SC_STAMP(0);
     constexpr int NWV = SCB / 64;
-    constexpr int DR = 8;                                           // dense rows per wavefront and trip
+    constexpr int DR = 128 / NWV > 16 ? 16 : 128 / NWV;            // dense rows per wavefront and trip
+    constexpr int KW = SCB >= 512 ? 1 : 512 / SCB;                  // frame words per thread in the fused first pass
+    constexpr int NI = TF_R / SCB > 0 ? TF_R / SCB : 1;             // signatures whose ni a thread carries
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
     const uint32_t D = A.bkt_D[b];
     const uint32_t flags = A.bkt_flags[b];
-    int U = (int)A.q_meta[0];
+    const int U = (int)A.q_meta[0];
     const int Ud = (int)A.q_meta[1];
-    if (U > A.wcap) U = A.wcap;                                     // cannot happen: wcap is sized from the word count
-    // The phase is a chain of dependent global reads (word list -> directory block -> segment offsets; dense list -> rows).  Every
-    // wavefront issues ALL independent loads of a stage before it consumes any of them (loads return in order, so waiting for an
-    // older one leaves the younger ones in flight): three round trips for the whole phase instead of one per step and row.
     // ---- stage A: the frame's lists (L2-resident: every workgroup reads the same few KB), ni
-    const bool has_k = tid < U;
-    uint32_t w = 0; int32_t idf = 0, did = -1;
-    if (has_k) { w = A.q_w[tid]; idf = A.q_idf[tid]; did = A.q_did[tid]; }
+    uint32_t w[KW]; int32_t idf[KW], did[KW]; bool look[KW];
+#pragma unroll
+    for (int u = 0; u < KW; ++u) {
+        const int k = tid + u * SCB;
+        w[u] = 0; idf[u] = 0; did[u] = -1;
+        if (k < U) { w[u] = A.q_w[k]; idf[u] = A.q_idf[k]; did[u] = A.q_did[k]; }
+    }
     int32_t dj[DR], fj[DR];
 #pragma unroll
     for (int u = 0; u < DR; ++u) {
@@ -329,24 +367,31 @@ __device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, c
         dj[u] = j < Ud ? A.qd_did[j] : -1;
         fj[u] = j < Ud ? A.qd_idf[j] : 0;
     }
-    uint32_t ni_v = 0;
-    if (tid < TF_R) ni_v = A.slot_ni[first_slot + tid];
+    uint32_t ni_v[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) { const int i = tid + u * SCB; ni_v[u] = i < TF_R ? A.slot_ni[first_slot + i] : 0u; }
     // ---- stage B: directory blocks of the sparse words, dense rows
-    const bool dense_here = did >= 0 && (uint32_t)did < D;
-    const bool look = has_k && idf != 0 && w < B.W && (!dense_here || (flags & 1u));   // a dense word has sparse postings only for counts > 255
-    uint2 blk = make_uint2(0u, 0u);
-    if (look) blk = gload2(B.dirb + (w >> 5));
+    uint2 blk[KW];
+#pragma unroll
+    for (int u = 0; u < KW; ++u) {
+        const bool dense_here = did[u] >= 0 && (uint32_t)did[u] < D;
+        look[u] = idf[u] != 0 && w[u] < B.W && (!dense_here || (flags & 1u));   // a dense word has sparse postings only for counts > 255
+        blk[u] = make_uint2(0u, 0u);
+        if (look[u]) blk[u] = gload2(B.dirb + (w[u] >> 5));
+    }
     uint32_t c[DR];
 #pragma unroll
     for (int u = 0; u < DR; ++u) c[u] = (dj[u] >= 0 && (uint32_t)dj[u] < D) ? gload((const uint32_t*)(B.dense + (size_t)dj[u] * TF_R + 4 * ln)) : 0u;
     // ---- stage C: segment offsets of the words that are present
-    uint32_t start = 0, len = 0;
-    {
-        const uint32_t bit = 1u << (w & 31);
-        if (look && (blk.x & bit)) {
-            const uint32_t r = blk.y + (uint32_t)__popc(blk.x & (bit - 1u));
+    uint32_t start[KW], len[KW];
+#pragma unroll
+    for (int u = 0; u < KW; ++u) {
+        start[u] = 0; len[u] = 0;
+        const uint32_t bit = 1u << (w[u] & 31);
+        if (look[u] && (blk[u].x & bit)) {
+            const uint32_t r = blk[u].y + (uint32_t)__popc(blk[u].x & (bit - 1u));
             const uint32_t s0 = gload(B.sp_off + r), s1 = gload(B.sp_off + r + 1);
-            start = s0; len = s1 - s0;
+            start[u] = s0; len[u] = s1 - s0;
         }
     }
     // the dense rows: a lane owns four signatures
@@ -377,27 +422,8 @@ __device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, c
             a3 += (long long)(int)(c[u] >> 24) * f64;
         }
     }
-    if (tid < TF_R) { acc[tid] = 0ull; s_ni[tid] = ni_v; }
-    if (has_k) { s_start[tid] = start; s_scan[tid] = len; s_idf[tid] = idf; }
-    for (int k = tid + SCB; k < U; k += SCB) {                       // frames with more than 1024 unique words
-        const uint32_t w2 = A.q_w[k];
-        const int32_t idf2 = A.q_idf[k];
-        const int32_t d2 = A.q_did[k];
-        const bool dh = d2 >= 0 && (uint32_t)d2 < D;
-        uint32_t st2 = 0, ln2 = 0;
-        if (idf2 != 0 && w2 < B.W && (!dh || (flags & 1u))) {
-            const uint2 bk = gload2(B.dirb + (w2 >> 5));
-            const uint32_t bit = 1u << (w2 & 31);
-            if (bk.x & bit) {
-                const uint32_t r = bk.y + (uint32_t)__popc(bk.x & (bit - 1u));
-                st2 = gload(B.sp_off + r);
-                ln2 = gload(B.sp_off + r + 1) - st2;
-            }
-        }
-        s_start[k] = st2; s_scan[k] = ln2; s_idf[k] = idf2;
-    }
-    if (tid == 0) s_scan[U] = 0u;
-    __syncthreads();                                                 // acc zeroed, s_* complete
+    for (int i = tid; i < TF_R; i += SCB) acc[i] = 0ull;
+    __syncthreads();                                                 // accumulators zeroed
     SC_STAMP(1);
     {
         const int ln4 = ln * 4;
@@ -406,33 +432,39 @@ __device__ __forceinline__ void score_sealed_body(unsigned long long* sc_smem, c
         if (a2) atomicAdd(&acc[ln4 + 2], (unsigned long long)a2);
         if (a3) atomicAdd(&acc[ln4 + 3], (unsigned long long)a3);
     }
-    const uint32_t T = block_exclusive_scan<SCB>(s_scan, U + 1, scratch);   // s_scan[U] == T afterwards
     SC_STAMP(2);
-    for (uint32_t t0 = (uint32_t)tid; t0 < T; t0 += 2 * SCB) {
-        uint32_t addr[2], e[2]; int kk[2];
+    // ---- sparse postings, wavefront by wavefront
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t t = t0 + u * SCB;
-            int lo = 0, hi = U;                             // largest k with s_scan[k] <= t  (s_scan[U] == T > t)
-            if (t < T) { while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_scan[mid] <= t) lo = mid; else hi = mid; } }
-            kk[u] = lo;
-            addr[u] = t < T ? s_start[lo] + (t - s_scan[lo]) : 0xFFFFFFFFu;
+    for (int u = 0; u < KW; ++u) score_segments<SCB>(B.sp_ent, acc, start[u], len[u], idf[u]);
+    for (int k0 = KW * SCB; k0 < U; k0 += SCB) {                     // frames with more than 512 unique words
+        const int k = k0 + tid;
+        uint32_t st2 = 0, ln2 = 0; int32_t idf2 = 0;
+        if (k < U) {
+            const uint32_t w2 = A.q_w[k];
+            idf2 = A.q_idf[k];
+            const int32_t d2 = A.q_did[k];
+            const bool dh = d2 >= 0 && (uint32_t)d2 < D;
+            if (idf2 != 0 && w2 < B.W && (!dh || (flags & 1u))) {
+                const uint2 bk = gload2(B.dirb + (w2 >> 5));
+                const uint32_t bit = 1u << (w2 & 31);
+                if (bk.x & bit) {
+                    const uint32_t r = bk.y + (uint32_t)__popc(bk.x & (bit - 1u));
+                    st2 = gload(B.sp_off + r);
+                    ln2 = gload(B.sp_off + r + 1) - st2;
+                }
+            }
         }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) e[u] = addr[u] != 0xFFFFFFFFu ? gload(B.sp_ent + addr[u]) : 0u;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (addr[u] == 0xFFFFFFFFu) continue;
-            const long long term = (long long)(int)(e[u] & TF_CNT_MASK) * (long long)s_idf[kk[u]];
-            atomicAdd(&acc[e[u] >> TF_CNT_BITS], (unsigned long long)term);      // ds_add_u64
-        }
+        score_segments<SCB>(B.sp_ent, acc, st2, ln2, idf2);
     }
     __syncthreads();
     SC_STAMP(3);
-    if (tid < TF_R) {
-        const long long v = (long long)acc[tid];
-        if (A.out_like) A.out_like[first_slot + tid] = fixed_to_like(v, ni_v);
-        else A.out_fix[first_slot + tid] = ni_v ? v : 0;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = tid + u * SCB;
+        if (i >= TF_R) continue;
+        const long long v = (long long)acc[i];
+        if (A.out_like) A.out_like[first_slot + i] = fixed_to_like(v, ni_v[u]);
+        else A.out_fix[first_slot + i] = ni_v[u] ? v : 0;
     }
 }
 
@@ -481,8 +513,7 @@ __device__ __forceinline__ void score_open_body(const ScoreArgs& A, int ob) {
 // every closed bucket (dead ones write zeros) and the open bucket in ONE launch, likelihood (or the integer sums) written directly
 template <int SCB>
 __global__ __launch_bounds__(SCB) void score_kernel(ScoreArgs A) {
-    extern __shared__ unsigned long long sf_smem[];
-    if ((int)blockIdx.x < A.n_closed) score_sealed_body<SCB>(sf_smem, A, (int)blockIdx.x);
+    if ((int)blockIdx.x < A.n_closed) score_sealed_body<SCB>(A, (int)blockIdx.x);
     else score_open_body<SCB>(A, (int)blockIdx.x - A.n_closed);
 }
 
@@ -908,7 +939,6 @@ hipError_t Tfidf::init(hipStream_t s, int64_t* bytes, int64_t sig_capacity, int6
     TF_TRY(set_max_lds(reinterpret_cast<const void*>(&frame_words_kernel)));
     TF_TRY(set_max_lds(reinterpret_cast<const void*>(&frame_tail_kernel)));
     TF_TRY(set_max_lds(reinterpret_cast<const void*>(&bulk_register_kernel)));
-    TF_TRY(set_max_lds(reinterpret_cast<const void*>(&score_kernel<SC_BLOCK>)));
     return hipSuccess;
 }
 
@@ -1312,7 +1342,7 @@ static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool id
     if (resolve) {
         a.src = resolve->out_wslot;
         const int mw = (resolve->q + 63) / 64 * 2;
-        shmem = std::max(shmem, (size_t)(3 * mw + 2) * 4);
+        shmem = std::max(shmem, (size_t)(3 * mw + 2) * 4) + (size_t)n * 4;    // + the word slots handed over in LDS
         const int n_redo = (resolve->rp.enabled && resolve->fail_count) ? (resolve->rp.n_rows + FW_BLOCK - 1) / FW_BLOCK : 0;
         frame_tail_kernel<<<1 + n_redo, FW_BLOCK, shmem, t.stream>>>(*resolve, a, ret);
     } else {
@@ -1416,12 +1446,14 @@ hipError_t Tfidf::launch_score(float* d_likelihood, long long* lfix) {
     A.slot_ni = slot_ni.as<uint32_t>(); A.slot_begin = slot_begin.as<uint32_t>(); A.slot_cnt = slot_cnt.as<uint32_t>();
     A.idf_tab = idf_tab.as<uint2>(); A.stamp = stamp;
     A.out_like = d_likelihood; A.out_fix = lfix;
-    const int open_blocks = (A.n_open_slots + SC_BLOCK / 64 - 1) / (SC_BLOCK / 64);
+    const int scb = score_block == 256 || score_block == 1024 ? score_block : 512;
+    const int open_blocks = (A.n_open_slots + scb / 64 - 1) / (scb / 64);
     const int grid = A.n_closed + open_blocks;
     if (grid == 0) return hipSuccess;
-    const size_t shmem = (size_t)TF_R * 8 + (size_t)TF_R * 4 + ((size_t)A.wcap * 3 + 1 + SC_BLOCK / 64 + 1 + 4) * 4;
     if (prof_b) TF_TRY(hipEventRecord(prof_b, stream));
-    score_kernel<SC_BLOCK><<<grid, SC_BLOCK, shmem, stream>>>(A);
+    if (scb == 256) score_kernel<256><<<grid, 256, 0, stream>>>(A);
+    else if (scb == 512) score_kernel<512><<<grid, 512, 0, stream>>>(A);
+    else score_kernel<1024><<<grid, 1024, 0, stream>>>(A);
     TF_TRY(hipGetLastError());
     if (prof_e) TF_TRY(hipEventRecord(prof_e, stream));
     prof_b = prof_e = nullptr;

@@ -26,7 +26,7 @@ def score_timing(lib, eng, vocab, words, n_sig, q, d_words, d_like, cap):
     t0 = t[:, 0].min()
     print("%d sealed-bucket workgroups; start spread %.2f us" % (len(t), t[:, 0].max() - t0))
     d = np.diff(t, axis=1)
-    for i, nme in enumerate(["lists + directory + dense rows", "LDS flush + scan", "sparse postings"]):
+    for i, nme in enumerate(["lists + directory + dense rows", "dense flush (LDS)", "sparse postings"]):
         print("  %-28s median %5.2f  p90 %5.2f us" % (nme, np.median(d[:, i]), np.percentile(d[:, i], 90)))
     print("  last workgroup leaves %.2f us after the first started" % (t[:, 3].max() - t0))
     eng.close()
@@ -37,6 +37,8 @@ def main():
     vocab = synth.vocab_surf(n_words)
     words = synth.zipf_words(n_sig, q, n_words, seed=100000)
     eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 1024, sig_capacity=n_sig + 4096)
+    if os.environ.get("SCORE_BLOCK"):
+        eng.set_option("score_block", int(os.environ["SCORE_BLOCK"]))
     eng.vocab_append(vocab, np.arange(1, n_words + 1, dtype=np.int32))
     offsets = np.arange(0, (n_sig + 1) * q, q, dtype=np.int64)
     eng.sig_add_bulk(np.arange(1, n_sig + 1, dtype=np.int32), offsets, words.reshape(-1))
