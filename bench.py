@@ -107,23 +107,33 @@ class Stepper:
         self.first_new += Q          # ids are only reserved here (the words are never appended): any consecutive numbering will do
 
 
-def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None):
-    """warmup untimed steps, then exactly `steps` steps bracketed by barrier + synchronize; an event per step for the distribution."""
+def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None, eng=None):
+    """warmup untimed steps, then exactly `steps` steps bracketed by barrier + synchronize; an event per step for the distribution.
+    eng: the engine the steps run on -- its events are recorded in call order (lcd_record_event: a threaded handle enqueues the index
+    stage of a frame after lcd_frame_dev returned) and it is drained (lcd_synchronize) before the clock stops."""
     for i in range(warmup):
         step(i)
+    if eng is not None:
+        eng.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    for e in evs:
+        e.record(stream)                                # creates the underlying hipEvent_t
+    torch.cuda.synchronize()
+    rec = (lambda e: eng.record_event(e.cuda_event)) if eng is not None else (lambda e: e.record(stream))
     if profile_eng is not None:
         profile_eng.profile_begin(max(10, steps // 5))   # HIP events around the two big kernels of the first 20 % of the timed steps
     t0 = time.perf_counter()
-    evs[0].record(stream)
+    rec(evs[0])
     for i in range(steps):
         step(warmup + i)
-        evs[i + 1].record(stream)
+        rec(evs[i + 1])
     host_enqueue = time.perf_counter() - t0
+    if eng is not None:
+        eng.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -193,7 +203,7 @@ def parity_block(torch, vocab, words, frames_np, m, n_frames=3):
     point, lcd_frame_dev with registration + retirement) and through the oracle's Memory::update -> computeLikelihood."""
     import rtabmap_amd
     n_sig = words.shape[0]
-    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=N_WORDS + 1024, sig_capacity=n_sig + 64, pipeline=True)
+    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=N_WORDS + 1024, sig_capacity=n_sig + 64, pipeline=2)
     load_engine(eng, vocab, words)
     cap = n_sig + 16
     d_words = torch.zeros(Q, dtype=torch.int32, device="cuda")
@@ -227,7 +237,7 @@ def parity_block(torch, vocab, words, frames_np, m, n_frames=3):
     eng.close()
     return ({"frames": n_frames, "word_ids_equal": ids_equal, "likelihood_max_rel": max_rel, "likelihood_values_compared": n_cmp,
              "argmax_equal": argmax_equal, "bound": "1e-4 relative (abs floor 1e-7)", "signatures": n_sig,
-             "path": "lcd_frame_dev (registration + retirement + TF-IDF, pipelined handle) vs oracle Memory::update + computeLikelihood"},
+             "path": "lcd_frame_dev (registration + retirement + TF-IDF, threaded pipelined handle) vs oracle Memory::update + computeLikelihood"},
             t_knn / n_frames, t_lik / n_frames)
 
 
@@ -389,7 +399,8 @@ def main():
     ap.add_argument("--signatures", type=int, default=N_SIG)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (oracle build, parity block, CPU baselines)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (unpipelined, host path, with update)")
-    ap.add_argument("--pipeline", type=int, default=1, help="1: the 2-NN stage of frame t+1 overlaps the scoring of frame t (two streams)")
+    ap.add_argument("--pipeline", type=int, default=2, help="0: one stream; 1: the 2-NN stage of frame t+1 overlaps the registration / "
+                    "scoring of frame t (three streams); 2: + the index stage is enqueued by the engine's own thread")
     ap.add_argument("--parallelism", choices=["shard", "replicas"], default="shard",
                     help="N > 1: ONE frame stream with the vocabulary sharded by word-id range + all-gather / all-reduce per frame (the "
                          "north star; strong scaling), or independent frame streams per GPU (weak scaling, no data-path collective)")
@@ -471,17 +482,17 @@ def main():
         src, frames_np = make_frames(rank)                 # replicas: every rank has its own stream of frames
         d_frames = [torch.from_numpy(f).cuda() for f in frames_np]
         eng = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 1024, sig_capacity=n_sig + 8192,
-                                 stream=stream.cuda_stream, pipeline=bool(args.pipeline))
+                                 stream=stream.cuda_stream, pipeline=args.pipeline)
         if args.score_block:
             eng.set_option("score_block", args.score_block)
         build_s = load_engine(eng, vocab, words)
         log("[bench] rank %d: %d signatures bulk-loaded in %.2fs" % (rank, n_sig, build_s))
         step = Stepper(eng, torch, d_frames, n_sig, cap)
-        res = timed_loop(torch, dist, world, stream, step, args.steps, args.warmup, profile_eng=eng)
+        res = timed_loop(torch, dist, world, stream, step, args.steps, args.warmup, profile_eng=eng, eng=eng)
         roof_knn, roof_score = rooflines(eng, N_WORDS, n_sig, False)
+        st = eng.stats()                                  # (drains the engine's thread)
         like = step.d_like[: n_sig + args.steps + args.warmup].cpu().numpy()
         frames_total = world * args.steps
-        st = eng.stats()
         host_in_c = 1e-6 * st["frame_host_ns"] / max(st["frame_calls"], 1)
     wall = res["wall"]
     value = frames_total * n_sig / wall
@@ -494,8 +505,9 @@ def main():
               "host_ms_inside_lcd_frame_dev": None,
               "step_ms_median": float(np.median(res["per_step_ms"])), "step_ms_p95": float(np.percentile(res["per_step_ms"], 95)),
               "world_size_observed": world, "collective_backend": backend, "signatures_bulk_load_s": build_s,
-              "pipeline": "2-NN stage of frame t+1 on a second stream while frame t is registered and scored" if (args.pipeline and not shard)
-              else "one stream",
+              "pipeline": ("lcd_config.pipeline = %d: 2-NN stage of frame t+1 on its own streams while frame t is registered and scored%s"
+                           % (args.pipeline, "; index stage enqueued by the engine's thread" if args.pipeline == 2 else ""))
+              if (args.pipeline and not shard) else "one stream",
               "parallelism": ("vocabulary sharded by word-id range over %d GPUs (all-gather top-2 + int64 all-reduce per frame)" % world) if shard
               else ("%d independent replicas (one frame stream per GPU, no data-path collective)" % world if world > 1 else "1 GPU")}
 
@@ -503,7 +515,7 @@ def main():
         config["host_ms_inside_lcd_frame_dev"] = host_in_c
     # ---- the distribution needs >= 50 frames: extra, untimed-for-`value` steps when the driver asked for fewer
     if not shard and args.steps < 50:
-        extra = timed_loop(torch, dist, world, stream, step, 64, 0)
+        extra = timed_loop(torch, dist, world, stream, step, 64, 0, eng=eng)
         config["step_ms_median"] = float(np.median(extra["per_step_ms"]))
         config["step_ms_p95"] = float(np.percentile(extra["per_step_ms"], 95))
         config["distribution_from"] = "64 extra steps after the timed region"
@@ -514,10 +526,10 @@ def main():
             src2, fr2 = make_frames(rank)
             d_fr2 = [torch.from_numpy(f).cuda() for f in fr2]
             eng2 = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 1024, sig_capacity=n_sig + 8192,
-                                      stream=stream.cuda_stream, pipeline=bool(args.pipeline))
+                                      stream=stream.cuda_stream, pipeline=args.pipeline)
             load_engine(eng2, vocab, words)
             st2 = Stepper(eng2, torch, d_fr2, n_sig, cap)
-            r2 = timed_loop(torch, dist, world, stream, st2, args.steps, args.warmup)
+            r2 = timed_loop(torch, dist, world, stream, st2, args.steps, args.warmup, eng=eng2)
             config["replicas_value"] = world * args.steps * n_sig / r2["wall"]
             config["replicas_ms_per_step"] = 1e3 * r2["wall"] / args.steps
             eng2.close()
@@ -544,12 +556,12 @@ def main():
     if world == 1 and rank == 0:
         if not args.no_extras:
             engu = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 8192,
-                                      stream=stream.cuda_stream, pipeline=not bool(args.pipeline))
+                                      stream=stream.cuda_stream, pipeline=0 if args.pipeline else 1)
             if args.score_block:
                 engu.set_option("score_block", args.score_block)
             load_engine(engu, vocab, words)
             stu = Stepper(engu, torch, d_frames, n_sig, cap)
-            ru = timed_loop(torch, dist, 1, stream, stu, max(50, min(args.steps, 200)), 10, profile_eng=engu)
+            ru = timed_loop(torch, dist, 1, stream, stu, max(50, min(args.steps, 200)), 10, profile_eng=engu, eng=engu)
             ku, su = rooflines(engu, N_WORDS, n_sig, False)
             key = "unpipelined" if args.pipeline else "pipelined"
             config[key + "_ms_per_step"] = 1e3 * ru["wall"] / max(50, min(args.steps, 200))

@@ -72,8 +72,13 @@ typedef struct lcd_config {
     int32_t max_queries;       /* initial per-call query capacity (Kp/MaxFeatures; grows on demand) */
     int32_t knn_mode;          /* lcd_knn_mode, per handle */
     void*   stream;            /* optional hipStream_t to enqueue on; NULL = engine-owned stream */
-    int32_t pipeline;          /* 1: lcd_frame_dev runs the 2-NN stage of frame t+1 on an internal second stream while frame t's
-                                  registration / scoring still runs on the engine stream (see lcd_frame_args) */
+    int32_t pipeline;          /* 1: lcd_frame_dev runs the 2-NN stage of frame t+1 on internal streams while frame t's registration /
+                                  scoring still runs on the engine stream (see lcd_frame_args).
+                                  2: additionally the registration / scoring launches of a frame (and lcd_sig_remove) are issued by an
+                                  engine thread, in call order, while the caller already enqueues the next frame: lcd_frame_dev and
+                                  lcd_sig_remove return before that work is enqueued, a failure of theirs (unknown / duplicate
+                                  signature, buffer too small) is returned by the next other call on the handle, and every other
+                                  call first waits for the thread to catch up.  Results are identical in all three modes. */
     int32_t reserved1;
 } lcd_config;
 
@@ -231,6 +236,10 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
 int lcd_finalize_dev(lcd_engine* h, int64_t* d_lfix, int64_t n, float* d_likelihood);
 /* slot table: d_slot_sig[slot] = signature id (0 = retired slot), n_slots = number of slots in use */
 int lcd_slots_dev(lcd_engine* h, const int32_t** d_slot_sig, int64_t* n_slots);
+/* record a caller-owned hipEvent_t on the engine stream BEHIND everything the calls made so far will enqueue there (on a
+ * threaded handle, lcd_config.pipeline == 2, the work of the latest lcd_frame_dev calls may not be enqueued yet when they
+ * return: recording on lcd_stream() directly would land in front of it) */
+int lcd_record_event(lcd_engine* h, void* event);
 /* the engine's hipStream_t (so a caller can record events around enqueued work) */
 void* lcd_stream(lcd_engine* h);
 

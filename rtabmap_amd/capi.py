@@ -22,7 +22,7 @@ SYMBOLS = [
     "lcd_vocab_clear", "lcd_vocab_append", "lcd_vocab_remove", "lcd_vocab_rebuild", "lcd_vocab_count", "lcd_vocab_read",
     "lcd_knn2", "lcd_selfdist", "lcd_quantize", "lcd_find_nn",
     "lcd_sig_add", "lcd_sig_remove", "lcd_sig_add_bulk", "lcd_sig_count", "lcd_word_nrefs",
-    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_adjust_likelihood_dev", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood", "lcd_profile_score_work", "lcd_set_option",
+    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_adjust_likelihood_dev", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood", "lcd_profile_score_work", "lcd_set_option", "lcd_record_event",
 ]
 
 
@@ -124,6 +124,7 @@ def load():
     L.lcd_get_stats.argtypes = [vp, C.POINTER(LcdStats)]
     L.lcd_profile_score_work.argtypes = [vp, C.POINTER(i64)]
     L.lcd_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.lcd_record_event.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -142,7 +143,7 @@ class Engine:
         self.dim = int(dim)
         mode = KNN_MODES[knn_mode] if (knn_mode is None or isinstance(knn_mode, str)) else int(knn_mode)
         cfg = LcdConfig(C.sizeof(LcdConfig), device, self.dtype, self.dim, vocab_capacity, sig_capacity, 0, mode, stream,
-                        1 if pipeline else 0, 0)
+                        int(pipeline), 0)     # 0: one stream; 1: 2-NN stage on its own streams; 2: + index stage enqueued by a thread
         h = C.c_void_p()
         rc = self.L.lcd_create(C.byref(cfg), C.byref(h))
         if rc != LCD_OK:
@@ -334,6 +335,9 @@ class Engine:
         ms, n, name = C.c_float(), C.c_int(), C.c_char_p()
         self._ck(self.L.lcd_profile_read_likelihood(self.h, C.byref(ms), C.byref(n), C.byref(name)))
         return ms.value, n.value, (name.value or b"").decode()
+
+    def record_event(self, event_handle):
+        self._ck(self.L.lcd_record_event(self.h, event_handle))
 
     def set_option(self, key, value):
         self._ck(self.L.lcd_set_option(self.h, key.encode(), int(value)))

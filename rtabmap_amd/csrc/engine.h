@@ -2,7 +2,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -11,6 +16,27 @@
 #include "lcd_kernels.h"
 #include "tfidf.h"
 
+
+// lcd_config.pipeline == 2: the index stage of a frame (registration + scoring launches and all the host bookkeeping of the
+// inverted index) is enqueued by this thread while the caller's thread already enqueues the 2-NN stage of the next frame -- the
+// HIP launch cost of a frame (~45 us on one thread) is what bounds a fully device-resident loop.  Jobs run in posting order, so
+// the index sees exactly the call sequence; every API entry other than lcd_frame_dev / lcd_sig_remove drains the queue first.
+struct IndexWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::deque<std::function<int(std::string*)>> jobs;
+    bool stop = false;
+    uint64_t posted = 0, done = 0;
+    int err_code = 0;               // first failure of an asynchronous job since it was last reported
+    std::string err_msg;
+    int device = 0;
+    void start(int dev);
+    uint64_t post(std::function<int(std::string*)> f);
+    void wait(uint64_t n);          // until job number n (1-based posting order) has run
+    void drain() { wait(posted); }
+    void shutdown();
+};
 
 struct lcd_engine {
     int device = 0;
@@ -62,7 +88,11 @@ struct lcd_engine {
     hipEvent_t ev_tail[2] = {nullptr, nullptr};         // the frame tail that read set i finished (recorded on stream)
     bool k_busy = false;                                // work may be in flight on kstream
     int sync_all();                                     // both streams drained
+    IndexWorker* worker = nullptr;                      // pipeline == 2
+    uint64_t set_job[2] = {0, 0};                       // the index job that last used scratch set i
+    int drain();                                        // run every queued index job; reports a failure one of them had
     lcd::PinBuf h_in, h_out, h_out2;
+    lcd::DevBuf d_hyp_scratch;                          // hypothesis record when the caller only wants the adjusted vector
 
     // ---- inverted index / TF-IDF
     lcd::Tfidf tfidf;

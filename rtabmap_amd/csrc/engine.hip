@@ -37,9 +37,67 @@ int lcd_engine::find_row(int32_t word_id) {
 
 #define LCD_CHECK_HANDLE(h) do { if (!(h)) return LCD_ERR_INVALID; } while (0)
 #define LCD_HIP(h, x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return (h)->hip_fail(e__, #x); } while (0)
-#define LCD_DEV(h) LCD_HIP(h, hipSetDevice((h)->device))
+#define LCD_DEV_NODRAIN(h) LCD_HIP(h, hipSetDevice((h)->device))
+#define LCD_DEV(h) do { LCD_DEV_NODRAIN(h); int rc__ = (h)->drain(); if (rc__) return rc__; } while (0)
+
+void IndexWorker::start(int dev) {
+    device = dev;
+    th = std::thread([this] {
+        (void)hipSetDevice(device);
+        for (;;) {
+            std::function<int(std::string*)> f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [this] { return stop || !jobs.empty(); });
+                if (jobs.empty()) return;                            // stop requested and nothing left
+                f = std::move(jobs.front());
+                jobs.pop_front();
+            }
+            std::string msg;
+            const int rc = f(&msg);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc != 0 && err_code == 0) { err_code = rc; err_msg = msg; }
+                done += 1;
+            }
+            cv_done.notify_all();
+        }
+    });
+}
+uint64_t IndexWorker::post(std::function<int(std::string*)> f) {
+    uint64_t n;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        jobs.push_back(std::move(f));
+        n = ++posted;
+    }
+    cv_job.notify_one();
+    return n;
+}
+void IndexWorker::wait(uint64_t n) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [this, n] { return done >= n; });
+}
+void IndexWorker::shutdown() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv_job.notify_all();
+    if (th.joinable()) th.join();
+}
+
+int lcd_engine::drain() {
+    if (!worker) return LCD_OK;
+    worker->drain();
+    std::lock_guard<std::mutex> lk(worker->mu);
+    if (worker->err_code == 0) return LCD_OK;
+    const int rc = worker->err_code;
+    err = "asynchronous index job failed: " + worker->err_msg;
+    worker->err_code = 0;
+    worker->err_msg.clear();
+    return rc;
+}
 
 int lcd_engine::sync_all() {
+    { int rc = drain(); if (rc) return rc; }
     if (kstream && k_busy) {
         hipError_t e = hipStreamSynchronize(kstream);
         if (e == hipSuccess && rstream) e = hipStreamSynchronize(rstream);
@@ -194,9 +252,11 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
     if (e == hipSuccess) e = hipMemsetAsync(h->norm_max.p, 0, 64, h->stream);
     if (e == hipSuccess) e = h->row_norm.reserve(((size_t)vcap + 1) * 8, 0, h->stream, &h->bytes_device);
     if (e == hipSuccess) e = h->d_fail_count.reserve(64, 0, h->stream, &h->bytes_device);   // [0] rejected, [1] arrivals, [2] max err / eps
+    if (e == hipSuccess) e = h->d_hyp_scratch.reserve(64, 0, h->stream, &h->bytes_device);
     if (e == hipSuccess) e = hipMemsetAsync(h->d_fail_count.p, 0, 64, h->stream);
     h->knn_mode = cfg->knn_mode == LCD_KNN_EXACT_VALU ? 0 : cfg->knn_mode == LCD_KNN_F32_MFMA ? 1 : 2;
     h->kst = h->stream;
+    if (cfg->pipeline < 0 || cfg->pipeline > 2) { delete h; return LCD_ERR_INVALID; }
     if (cfg->pipeline) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->kstream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->rstream, hipStreamNonBlocking);
@@ -210,6 +270,11 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
     }
     if (e == hipSuccess) e = h->tfidf.init(h->stream, &h->bytes_device, cfg->sig_capacity, cfg->vocab_capacity);
     if (e != hipSuccess) { lcd_destroy(h); return LCD_ERR_HIP; }
+    if (cfg->pipeline == 2) {
+        h->worker = new (std::nothrow) IndexWorker();
+        if (!h->worker) { lcd_destroy(h); return LCD_ERR_NOMEM; }
+        h->worker->start(h->device);
+    }
     *out = h;
     return LCD_OK;
 }
@@ -217,6 +282,7 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
 void lcd_destroy(lcd_engine* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->worker) { h->worker->drain(); h->worker->shutdown(); delete h->worker; h->worker = nullptr; }
     if (h->kstream) (void)hipStreamSynchronize(h->kstream);
     if (h->rstream) (void)hipStreamSynchronize(h->rstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -239,7 +305,7 @@ void lcd_destroy(lcd_engine* h) {
                      &h->d_partial, &h->d_knn_row, &h->d_knn_word, &h->d_knn_wslot, &h->d_knn_dist, &h->d_selfdist, &h->d_out_word,
                      &h->d_out_wslot, &h->d_n_new, &h->d_tmp_i32, &h->d_extra_rows, &h->d_extra_id, &h->d_extra_word,
                      &h->d_extra_dist, &h->d_extra_row, &h->d_like, &h->d_slots, &h->d_bits, &h->row_norm, &h->norm_max, &h->d_partial2,
-                     &h->d_fail_list, &h->d_fail_count, &h->d_partial3, &h->row_norm_alt, &h->vocab_bf};
+                     &h->d_fail_list, &h->d_fail_count, &h->d_partial3, &h->row_norm_alt, &h->vocab_bf, &h->d_hyp_scratch};
     for (DevBuf* d : all) d->release(&h->bytes_device);
     h->h_in.release(); h->h_out.release(); h->h_out2.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -255,6 +321,22 @@ int lcd_synchronize(lcd_engine* h) {
 }
 
 void* lcd_stream(lcd_engine* h) { return h ? (void*)h->stream : nullptr; }
+
+int lcd_record_event(lcd_engine* h, void* event) {
+    LCD_CHECK_HANDLE(h);
+    if (!event) return h->fail(LCD_ERR_INVALID, "lcd_record_event: null event");
+    if (h->worker) {
+        h->worker->post([h, event](std::string* msg) -> int {
+            const hipError_t e = hipEventRecord((hipEvent_t)event, h->stream);
+            if (e != hipSuccess) { *msg = std::string("lcd_record_event: ") + hipGetErrorString(e); return LCD_ERR_HIP; }
+            return LCD_OK;
+        });
+        return LCD_OK;
+    }
+    LCD_DEV_NODRAIN(h);
+    LCD_HIP(h, hipEventRecord((hipEvent_t)event, h->stream));
+    return LCD_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ vocabulary
 int lcd_vocab_clear(lcd_engine* h) {
@@ -668,6 +750,15 @@ int lcd_sig_add_bulk(lcd_engine* h, int n_sigs, const int32_t* sig_ids, const in
 
 int lcd_sig_remove(lcd_engine* h, int32_t sig_id) {
     LCD_CHECK_HANDLE(h);
+    if (h->worker) {     // threaded handle: in order behind the frames already posted (an unknown id is reported by the next draining call)
+        h->worker->post([h, sig_id](std::string* msg) -> int {
+            if (!h->tfidf.sig_slot.count(sig_id)) { *msg = "lcd_sig_remove: unknown signature"; return LCD_ERR_STATE; }
+            const hipError_t e = h->tfidf.retire(sig_id);
+            if (e != hipSuccess) { *msg = std::string("lcd_sig_remove: ") + hipGetErrorString(e); return LCD_ERR_HIP; }
+            return LCD_OK;
+        });
+        return LCD_OK;
+    }
     LCD_DEV(h);
     if (!h->tfidf.sig_slot.count(sig_id)) return h->fail(LCD_ERR_STATE, "lcd_sig_remove: unknown signature");
     LCD_HIP(h, h->tfidf.retire(sig_id));
@@ -676,6 +767,7 @@ int lcd_sig_remove(lcd_engine* h, int32_t sig_id) {
 
 int lcd_sig_count(const lcd_engine* h, int64_t* live_signatures, int64_t* postings) {
     LCD_CHECK_HANDLE(h);
+    { int rc = const_cast<lcd_engine*>(h)->drain(); if (rc) return rc; }
     if (live_signatures) *live_signatures = h->tfidf.live_sigs;
     if (postings) *postings = h->tfidf.postings_ub;
     return LCD_OK;
@@ -758,30 +850,61 @@ struct FrameHostTimer {   // host time spent inside lcd_frame_dev (lcd_stats.fra
 };
 }  // namespace
 
+// the index stage of a frame: registration (or query preparation), scoring, hypothesis.  Runs on the caller's thread, or on
+// the index thread of a threaded handle (then failures are reported through *msg).
+static int frame_stage_s(lcd_engine* h, const lcd_frame_args& a, ResolveArgs r, int p, bool pipe, std::string* msg) {
+#define S_FAIL(code, text) do { *msg = (text); return (code); } while (0)
+#define S_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { *msg = std::string(#x) + ": " + hipGetErrorString(e__); return LCD_ERR_HIP; } } while (0)
+    Tfidf& t = h->tfidf;
+    const int q = a.q;
+    if (a.sig_id != 0 && t.sig_slot.count(a.sig_id)) S_FAIL(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
+    const int64_t slots_after = t.n_slots + (a.sig_id != 0 ? 1 : 0);
+    if (a.d_likelihood && a.likelihood_capacity < slots_after) S_FAIL(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
+    // postings keys for the words this frame may create (VisualWord(id, descriptor, signatureId) references the signature)
+    if (a.sig_id != 0 && a.first_new_word_id > 0 && (a.flags & LCD_Q_INCREMENTAL)) {
+        hipError_t e = t.reserve_new_words(a.first_new_word_id, q, &r.new_ws);
+        if (e == hipErrorInvalidValue) S_FAIL(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: word ids must be below 2^28");
+        S_HIP(e);
+    }
+    if (pipe) S_HIP(hipStreamWaitEvent(h->stream, h->ev_knn[p], 0));
+    if (a.sig_id != 0) S_HIP(t.register_dev(a.sig_id, r.out_wslot, q, q, a.N, &r));
+    else S_HIP(t.query_dev(r.out_wslot, q, a.N, &r));
+    if (pipe) S_HIP(hipEventRecord(h->ev_tail[p], h->stream));
+    if (a.d_likelihood) {
+        if (h->prof_cap > 0 && h->prof2_n < h->prof_cap) {
+            t.prof_b = h->prof2_ev[2 * h->prof2_n]; t.prof_e = h->prof2_ev[2 * h->prof2_n + 1];
+            h->prof2_n += 1;
+        }
+        S_HIP(t.score(a.d_likelihood));
+        if (t.prof_b) { t.prof_b = t.prof_e = nullptr; h->prof2_n -= 1; }     // the launch that would have been bracketed did not happen
+        h->likelihood_launches += 1;
+        if (a.d_hypothesis || a.d_adjusted) {
+            // Rtabmap::adjustLikelihood + the best candidate, without the vector leaving the device (Rtabmap.cpp:2121-2158)
+            HypothesisOut* out = a.d_hypothesis ? (HypothesisOut*)a.d_hypothesis : (HypothesisOut*)h->d_hyp_scratch.p;
+            const long long n_cons = (long long)t.n_slots - std::max(a.exclude_recent, 0);
+            S_HIP(launch_hypothesis(a.d_likelihood, t.slot_sig.as<int32_t>(), (long long)t.n_slots, n_cons, a.virtual_place_ratio,
+                                    a.d_adjusted, out, h->stream));
+        }
+    }
+    return LCD_OK;
+#undef S_FAIL
+#undef S_HIP
+}
+
 int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     LCD_CHECK_HANDLE(h);
     FrameHostTimer timer__(h);
-    LCD_DEV(h);
+    if (h->worker) LCD_DEV_NODRAIN(h); else LCD_DEV(h);
     if (!a || a->struct_size != (int32_t)sizeof(lcd_frame_args)) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: bad argument block");
     const int q = a->q;
     if (q <= 0 || q > 8192 || !a->d_descriptors || !a->d_word_ids) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: bad argument");
     if ((a->d_hypothesis || a->d_adjusted) && !a->d_likelihood) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: the hypothesis needs d_likelihood");
-    Tfidf& t = h->tfidf;
-    if (a->sig_id != 0 && t.sig_slot.count(a->sig_id)) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
-    const int64_t slots_after = t.n_slots + (a->sig_id != 0 ? 1 : 0);
-    if (a->d_likelihood && a->likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
-    // postings keys for the words this frame may create (VisualWord(id, descriptor, signatureId) references the signature)
-    WsRuns new_ws;
-    if (a->sig_id != 0 && a->first_new_word_id > 0 && (a->flags & LCD_Q_INCREMENTAL)) {
-        hipError_t e = t.reserve_new_words(a->first_new_word_id, q, &new_ws);
-        if (e == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: word ids must be below 2^28");
-        if (e != hipSuccess) return h->hip_fail(e, "reserve_new_words");
-    }
     const bool pipe = h->kstream != nullptr;
     int p = 0;
     if (pipe) {
         swap_scratch(h);
         p = h->ks_idx;
+        if (h->worker) h->worker->wait(h->set_job[p]);   // the index job that read this set is enqueued (its ev_tail is recorded)
         if (q > h->ks_q[p]) {                       // this set's buffers are about to grow: nothing may still be using them
             int rc = h->sync_all();
             if (rc) return rc;
@@ -804,34 +927,16 @@ int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     if (!split) knn_end = h->kstream;
     h->rst = nullptr;
     if (rc) return rc;
-    if (pipe) {
-        LCD_HIP(h, hipEventRecord(h->ev_knn[p], knn_end));
-        LCD_HIP(h, hipStreamWaitEvent(h->stream, h->ev_knn[p], 0));
+    if (pipe) LCD_HIP(h, hipEventRecord(h->ev_knn[p], knn_end));
+    if (h->d_fail_count.p) { r.fail_count = h->d_fail_count.as<int32_t>(); h->fail_count_clean = true; }   // the tail resets the counters
+    if (h->worker) {
+        const lcd_frame_args copy = *a;
+        h->set_job[p] = h->worker->post([h, copy, r, p](std::string* msg) -> int { return frame_stage_s(h, copy, r, p, true, msg); });
+        return LCD_OK;
     }
-    r.new_ws = new_ws;
-    if (h->d_fail_count.p) { r.fail_count = h->d_fail_count.as<int32_t>(); h->fail_count_clean = true; }
-    if (a->sig_id != 0) LCD_HIP(h, t.register_dev(a->sig_id, h->d_out_wslot.as<int32_t>(), q, q, a->N, &r));
-    else LCD_HIP(h, t.query_dev(h->d_out_wslot.as<int32_t>(), q, a->N, &r));
-    if (pipe) LCD_HIP(h, hipEventRecord(h->ev_tail[p], h->stream));
-    if (a->d_likelihood) {
-        if (h->prof_cap > 0 && h->prof2_n < h->prof_cap) {
-            t.prof_b = h->prof2_ev[2 * h->prof2_n]; t.prof_e = h->prof2_ev[2 * h->prof2_n + 1];
-            h->prof2_n += 1;
-        }
-        LCD_HIP(h, t.score(a->d_likelihood));
-        if (t.prof_b) { t.prof_b = t.prof_e = nullptr; h->prof2_n -= 1; }     // the launch that would have been bracketed did not happen
-        h->likelihood_launches += 1;
-        if (a->d_hypothesis || a->d_adjusted) {
-            // Rtabmap::adjustLikelihood + the best candidate, without the vector leaving the device (Rtabmap.cpp:2121-2158)
-            if (!a->d_hypothesis) {
-                LCD_HIP(h, dreserve(h, h->d_tmp_i32, 64));
-            }
-            HypothesisOut* out = a->d_hypothesis ? (HypothesisOut*)a->d_hypothesis : (HypothesisOut*)h->d_tmp_i32.p;
-            const long long n_cons = (long long)t.n_slots - std::max(a->exclude_recent, 0);
-            LCD_HIP(h, launch_hypothesis(a->d_likelihood, t.slot_sig.as<int32_t>(), (long long)t.n_slots, n_cons, a->virtual_place_ratio,
-                                         a->d_adjusted, out, h->stream));
-        }
-    }
+    std::string msg;
+    rc = frame_stage_s(h, *a, r, p, pipe, &msg);
+    if (rc) return h->fail(rc, msg);
     return LCD_OK;
 }
 
@@ -920,6 +1025,7 @@ int lcd_finalize_dev(lcd_engine* h, int64_t* d_lfix, int64_t n, float* d_likelih
 
 int lcd_slots_dev(lcd_engine* h, const int32_t** d_slot_sig, int64_t* n_slots) {
     LCD_CHECK_HANDLE(h);
+    { int rc = h->drain(); if (rc) return rc; }
     if (d_slot_sig) *d_slot_sig = h->tfidf.slot_sig.as<int32_t>();
     if (n_slots) *n_slots = h->tfidf.n_slots;
     return LCD_OK;
@@ -982,6 +1088,7 @@ int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, co
 
 int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     LCD_CHECK_HANDLE(h);
+    { int rc = h->drain(); if (rc) return rc; }
     if (!key) return h->fail(LCD_ERR_INVALID, "lcd_set_option: null key");
     if (!std::strcmp(key, "score_block") && (value == 256 || value == 512 || value == 1024)) { h->tfidf.score_block = (int)value; return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");

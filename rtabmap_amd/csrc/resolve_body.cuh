@@ -10,6 +10,13 @@ constexpr int RBLOCK = 1024;
 constexpr int LCD_Q_INCREMENTAL = 1;
 constexpr int LCD_Q_NEW_WORDS_COMPARED = 2;
 
+#ifdef LCD_TAIL_TIMING   // timing experiment only: 100 MHz stamps inside the fast decision loop
+__device__ unsigned long long g_resolve_timing[8];
+#define RB_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_resolve_timing[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RB_STAMP(i) do { } while (0)
+#endif
+
 struct Cand { float d; int id; };   // id > 0: word id, id < 0: -(j+1) = the new word created by descriptor j
 
 // std::multimap<float,int> insertion (equal keys keep insertion order, VWDictionary.cpp:1091) restricted to what is
@@ -91,6 +98,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
     const int qpad = mw * 32;
     const int i = tid;
     const bool valid = i < q;
+    RB_STAMP(0);
     // ---- round trip 1: indexed neighbours + their rows, the bit row
     float d0 = -1.0f, d1 = -1.0f; int w0 = 0, w1 = 0, r0 = -1, r1 = -1;
     if (valid && have_index) {
@@ -134,6 +142,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
         if (r0 >= 0) ws_a = row_wslot ? row_wslot[r0] : r0;
         if (r1 >= 0) ws_b = row_wslot ? row_wslot[r1] : r1;
     }
+    RB_STAMP(1);
     bool reject = valid && incremental && (nb < 2 || b0.d > nndr * b1.d);
     int win = nb > 0 ? b0.id : 0;
     if (i < qpad) {
@@ -141,6 +150,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
         if (lane == 0) { mask_cur[i >> 5] = (uint32_t)bal; mask_cur[(i >> 5) + 1] = (uint32_t)(bal >> 32); }
     }
     __syncthreads();
+    RB_STAMP(2);
     if (together) {
         const bool dyn = valid && (nz > 0 || overflow);                // only these descriptors can change their mind
         for (int sweep = 0; sweep <= q; ++sweep) {
@@ -196,6 +206,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
             __syncthreads();
         }
     }
+    RB_STAMP(3);
     if (tid == 0) {
         uint32_t run = 0;
         for (int w = 0; w < mw; ++w) { prefix[w] = run; run += __popc(mask_cur[w]); }
@@ -203,6 +214,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
         out_n_new[0] = (int32_t)run;
     }
     __syncthreads();
+    RB_STAMP(4);
     if (valid) {
         const bool is_new = (mask_cur[i >> 5] >> (i & 31)) & 1u;
         int w;
@@ -218,6 +230,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
         if (lds_wslot) lds_wslot[i] = ws;
         else if (out_wslot) out_wslot[i] = ws;
     }
+    RB_STAMP(5);
 }
 
 // The whole decision loop for one frame, executed by ONE workgroup of RBLOCK threads.  rs_smem: 3 * mw + 2 words of LDS,

@@ -1529,6 +1529,7 @@ extern "C" int lcd_debug_score_timing(unsigned long long* out, int n_words) {
 #ifdef LCD_TAIL_TIMING
 extern "C" int lcd_debug_tail_timing(unsigned long long* out) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcd::g_tail_timing), 64);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lcd::g_tail_timing), 64) != hipSuccess) return -2;
+    return (int)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(lcd::g_resolve_timing), 64);
 }
 #endif

@@ -165,9 +165,11 @@ def test_frame_dev_register_and_score_stream(oracle, kind):
     assert st["word_slots"] < st["vocab_live"] + 6000, st            # (up to 4096 keys wait for the next batched check)
 
 
-def test_frame_dev_stream_pipelined_handle(oracle):
-    """The same stream on a handle whose 2-NN stage runs on its own stream (lcd_config.pipeline): identical results."""
-    _run_stream(oracle, "surf", n_frames=70, q=128, wm=330, pipeline=True, seed=9)
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_frame_dev_stream_pipelined_handle(oracle, pipeline):
+    """The same stream on a handle whose 2-NN stage runs on its own streams (lcd_config.pipeline = 1) and whose index stage is
+    enqueued by the engine's thread (= 2): identical results."""
+    _run_stream(oracle, "surf", n_frames=70, q=128, wm=330, pipeline=pipeline, seed=9)
 
 
 def test_pipelined_frames_enqueued_back_to_back(oracle):
@@ -180,7 +182,7 @@ def test_pipelined_frames_enqueued_back_to_back(oracle):
     ids = np.arange(1, n_words + 1, dtype=np.int32)
     frames = [torch.from_numpy(synth.frame_from_signature(vocab, words[(37 * t) % n_sig], seed=50 + t)).cuda() for t in range(T)]
     out = {}
-    for pipe in (False, True):
+    for pipe in (0, 1, 2):
         eng = rtabmap_amd.Engine("f32", 64, sig_capacity=n_sig + T, pipeline=pipe)
         eng.vocab_append(vocab, ids)
         eng.sig_add_bulk(np.arange(1, n_sig + 1, dtype=np.int32), np.arange(0, (n_sig + 1) * q, q, dtype=np.int64), words.reshape(-1))
@@ -196,8 +198,9 @@ def test_pipelined_frames_enqueued_back_to_back(oracle):
         eng.synchronize()
         out[pipe] = (d_w.cpu().numpy(), d_l.cpu().numpy())
         eng.close()
-    np.testing.assert_array_equal(out[True][0], out[False][0])
-    np.testing.assert_array_equal(out[True][1], out[False][1])
+    for pipe in (1, 2):
+        np.testing.assert_array_equal(out[pipe][0], out[0][0])
+        np.testing.assert_array_equal(out[pipe][1], out[0][1])
     # and the first frame agrees with the oracle (later frames meet words the oracle has indexed meanwhile and this test never appends)
     m = oracle.OracleMemory(strategy=oracle.kNNBruteForce, nndr=0.8)
     for i, r in zip(ids, vocab):
@@ -206,11 +209,11 @@ def test_pipelined_frames_enqueued_back_to_back(oracle):
     for s in range(n_sig):
         m.add_signature(words[s])
     sid, exp = m.update(frames[0].cpu().numpy())
-    got = out[False][0][0]
+    got = out[0][0][0]
     assert [w if w > 0 else 0 for w in got.tolist()] == [w if w <= n_words else 0 for w in exp]
     live = np.array(m.signature_ids(), np.int32)
     oi, Lo = m.compute_likelihood(np.array(exp, np.int32), live)
-    np.testing.assert_allclose(out[False][1][0][: n_sig + 1], Lo, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out[0][1][0][: n_sig + 1], Lo, rtol=RTOL, atol=ATOL)
 
 
 def test_frame_dev_at_headline_sizes(oracle):

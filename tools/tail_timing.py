@@ -49,8 +49,8 @@ def main():
     if hasattr(lib, "lcd_debug_score_timing"):
         return score_timing(lib, eng, vocab, words, n_sig, q, d_words, d_like, cap)
     lib.lcd_debug_tail_timing.restype = ctypes.c_int
-    buf = (ctypes.c_ulonglong * 8)()
-    rows = []
+    buf = (ctypes.c_ulonglong * 16)()
+    rows, rrows = [], []
     for i in range(12):
         f = torch.from_numpy(synth.frame_from_signature(vocab, words[i * 11], seed=i)).cuda()
         eng.frame_dev(f.data_ptr(), q, n_sig + 1 + i, float(n_sig + 1), d_words.data_ptr(), d_like.data_ptr(), cap, incremental=True,
@@ -58,8 +58,11 @@ def main():
         assert lib.lcd_debug_tail_timing(buf) == 0
         t = np.array(buf[:4], dtype=np.float64) / 100.0
         rows.append(np.diff(t))
+        rrows.append(np.diff(np.array(buf[8:14], dtype=np.float64) / 100.0))
     rows = np.array(rows[2:])
     print("frame tail phases (us, median over %d frames): resolve %.2f  retire %.2f  frame_words %.2f" % (len(rows), *np.median(rows, axis=0)))
+    rr = np.median(np.array(rrows[2:]), axis=0)
+    print("  inside the decision loop (us): loads + bit rows %.2f  sweep 0 %.2f  sweeps %.2f  prefix %.2f  output %.2f" % tuple(rr))
     eng.close()
 
 
