@@ -199,45 +199,58 @@ def build_oracle(vocab, words):
 
 
 def parity_block(torch, vocab, words, frames_np, m, n_frames=3):
-    """SURVEY.md 8d 'parity checks run with every bench': frames of THIS configuration through a fresh engine (the timed entry
-    point, lcd_frame_dev with registration + retirement) and through the oracle's Memory::update -> computeLikelihood."""
+    """SURVEY.md 8d 'parity checks run with every bench': frames of THIS configuration through a fresh engine -- the timed entry
+    point: lcd_frame_dev with registration + retirement on a pipelined handle, the frames enqueued back to back exactly as the timed
+    loop does, so the fused launches are what is checked -- and through the oracle's Memory::update -> computeLikelihood."""
     import rtabmap_amd
     n_sig = words.shape[0]
-    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=N_WORDS + 1024, sig_capacity=n_sig + 64, pipeline=2)
+    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=N_WORDS + 1024, sig_capacity=n_sig + 64, pipeline=1)
     load_engine(eng, vocab, words)
     cap = n_sig + 16
-    d_words = torch.zeros(Q, dtype=torch.int32, device="cuda")
-    d_like = torch.zeros(cap, dtype=torch.float32, device="cuda")
+    d_desc = [torch.from_numpy(frames_np[t]).cuda() for t in range(n_frames)]
+    d_words = torch.zeros((n_frames, Q), dtype=torch.int32, device="cuda")
+    d_like = torch.zeros((n_frames, cap), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for t in range(n_frames):      # new words are numbered with an upper bound per frame: nothing is read back in between
+        eng.frame_dev(d_desc[t].data_ptr(), Q, n_sig + 1 + t, float(n_sig + 1), d_words[t].data_ptr(), d_like[t].data_ptr(), cap,
+                      first_new_word_id=N_WORDS + 1 + t * Q)
+        eng.sig_remove(t + 1)
+    eng.synchronize()
+    got_all, like_all = d_words.cpu().numpy(), d_like.cpu().numpy()
     ids_equal, argmax_equal, max_rel, n_cmp = True, True, 0.0, 0
     t_knn = t_lik = 0.0
     for t in range(n_frames):
-        desc = frames_np[t]
         first_new = m.vwd.last_word_id + 1
         t1 = time.perf_counter()
-        sid, exp = m.update(desc)                              # exact linear 2-NN + addNewWords, 1 thread
+        sid, exp = m.update(frames_np[t])                      # exact linear 2-NN + addNewWords, 1 thread
         t2 = time.perf_counter()
-        eng.frame_dev(torch.from_numpy(desc).cuda().data_ptr(), Q, sid, float(m.num_signatures()), d_words.data_ptr(), d_like.data_ptr(), cap,
-                      first_new_word_id=first_new)
-        eng.synchronize()
-        got = d_words.cpu().numpy()
-        ids_equal &= bool(np.where(got < 0, first_new - got - 1, got).tolist() == exp)
+        got = got_all[t]
+        # word ids; a frame's new words compare by their rank (the k-th word the frame created)
+        ids_equal &= bool(np.where(got < 0, -got - 1 + (1 << 30), got).tolist() == [w if w < first_new else w - first_new + (1 << 30) for w in exp])
         live = np.array(m.signature_ids(), np.int32)
         t3 = time.perf_counter()
         oi, Lo = m.compute_likelihood(np.array(exp, np.int32), live)
         t4 = time.perf_counter()
         t_knn += t2 - t1
         t_lik += t4 - t3
-        Lh = d_like[: n_sig + t + 1].cpu().numpy()[oi - 1]    # signature id s sits in slot s - 1
+        Lh = like_all[t][: n_sig + t + 1][oi - 1]             # signature id s sits in slot s - 1
         err = np.abs(Lh - Lo) / np.maximum(np.abs(Lo), 1e-7 / 1e-4)      # relative, with the 1e-7 absolute floor of the 1e-4 bound
         max_rel = max(max_rel, float(err.max()))
         n_cmp += int(Lo.size)
         argmax_equal &= bool(int(np.argmax(Lh[:-1])) == int(np.argmax(Lo[:-1])))
         m.forget(t + 1)
-        eng.sig_remove(t + 1)
+        # the oracle indexes the frame's new words before the next frame (VWDictionary::update); the engine's vocabulary is not
+        # appended to in this loop (nor in the timed one): keep the two in step by dropping them again
+        new_ids = sorted(set(w for w in exp if w >= first_new))
+        if new_ids:
+            for w in new_ids:
+                m.vwd.remove_all_word_ref(int(w), sid)
+            m.vwd.remove_words(new_ids)
     eng.close()
     return ({"frames": n_frames, "word_ids_equal": ids_equal, "likelihood_max_rel": max_rel, "likelihood_values_compared": n_cmp,
              "argmax_equal": argmax_equal, "bound": "1e-4 relative (abs floor 1e-7)", "signatures": n_sig,
-             "path": "lcd_frame_dev (registration + retirement + TF-IDF, threaded pipelined handle) vs oracle Memory::update + computeLikelihood"},
+             "path": "lcd_frame_dev (registration + retirement + TF-IDF, pipelined handle, frames enqueued back to back) vs oracle "
+                     "Memory::update + computeLikelihood"},
             t_knn / n_frames, t_lik / n_frames)
 
 
@@ -399,8 +412,8 @@ def main():
     ap.add_argument("--signatures", type=int, default=N_SIG)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (oracle build, parity block, CPU baselines)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (unpipelined, host path, with update)")
-    ap.add_argument("--pipeline", type=int, default=2, help="0: one stream; 1: the 2-NN stage of frame t+1 overlaps the registration / "
-                    "scoring of frame t (three streams); 2: + the index stage is enqueued by the engine's own thread")
+    ap.add_argument("--pipeline", type=int, default=1, help="1: software-pipelined frames (the launches of frame t carry the registration "
+                    "and scoring of frame t-1); 0: four launches per frame, nothing overlapped")
     ap.add_argument("--parallelism", choices=["shard", "replicas"], default="shard",
                     help="N > 1: ONE frame stream with the vocabulary sharded by word-id range + all-gather / all-reduce per frame (the "
                          "north star; strong scaling), or independent frame streams per GPU (weak scaling, no data-path collective)")
@@ -505,9 +518,8 @@ def main():
               "host_ms_inside_lcd_frame_dev": None,
               "step_ms_median": float(np.median(res["per_step_ms"])), "step_ms_p95": float(np.percentile(res["per_step_ms"], 95)),
               "world_size_observed": world, "collective_backend": backend, "signatures_bulk_load_s": build_s,
-              "pipeline": ("lcd_config.pipeline = %d: 2-NN stage of frame t+1 on its own streams while frame t is registered and scored%s"
-                           % (args.pipeline, "; index stage enqueued by the engine's thread" if args.pipeline == 2 else ""))
-              if (args.pipeline and not shard) else "one stream",
+              "pipeline": "software-pipelined frames: 2 launches per frame (filter of frame t + tail of frame t-1; re-rank of frame t + "
+                          "scoring of frame t-1), one stream" if (args.pipeline and not shard) else "4 launches per frame, one stream",
               "parallelism": ("vocabulary sharded by word-id range over %d GPUs (all-gather top-2 + int64 all-reduce per frame)" % world) if shard
               else ("%d independent replicas (one frame stream per GPU, no data-path collective)" % world if world > 1 else "1 GPU")}
 

@@ -72,13 +72,13 @@ typedef struct lcd_config {
     int32_t max_queries;       /* initial per-call query capacity (Kp/MaxFeatures; grows on demand) */
     int32_t knn_mode;          /* lcd_knn_mode, per handle */
     void*   stream;            /* optional hipStream_t to enqueue on; NULL = engine-owned stream */
-    int32_t pipeline;          /* 1: lcd_frame_dev runs the 2-NN stage of frame t+1 on internal streams while frame t's registration /
-                                  scoring still runs on the engine stream (see lcd_frame_args).
-                                  2: additionally the registration / scoring launches of a frame (and lcd_sig_remove) are issued by an
-                                  engine thread, in call order, while the caller already enqueues the next frame: lcd_frame_dev and
-                                  lcd_sig_remove return before that work is enqueued, a failure of theirs (unknown / duplicate
-                                  signature, buffer too small) is returned by the next other call on the handle, and every other
-                                  call first waits for the thread to catch up.  Results are identical in all three modes. */
+    int32_t pipeline;          /* 1: consecutive lcd_frame_dev calls are software-pipelined (matrix-core 2-NN handles): the launches of
+                                  frame t also carry the registration and the scoring of frame t - 1, whose single-workgroup
+                                  decision loop then hides behind the distance filter of frame t.  Consequence for the caller: the
+                                  outputs of a frame (d_word_ids, d_likelihood, ...) and its descriptors must stay valid until the
+                                  NEXT lcd_frame_dev or any other call on the handle, which completes the owed stage first
+                                  (lcd_synchronize to wait for it).  lcd_sig_remove and lcd_record_event keep their place in the
+                                  call order.  Results are identical with and without. */
     int32_t reserved1;
 } lcd_config;
 
@@ -215,8 +215,7 @@ typedef struct lcd_frame_args {
                                           (0 for slots that are retired or not considered) */
     float virtual_place_ratio;         /* Rtabmap/VirtualPlaceLikelihoodRatio (0 = default branch) */
     int32_t reserved0;
-    void* ready_event;                 /* pipelined handles only: hipEvent_t after which d_descriptors is complete; NULL = it is
-                                          complete when the call is made (the 2-NN stage does not run on the engine stream) */
+    void* ready_event;                 /* reserved (NULL) */
 } lcd_frame_args;
 int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* args);
 /* lcd_knn2 with device-resident queries and outputs (d_word_ids[q*2], d_dist[q*2]); enqueued, not synchronised */
@@ -236,9 +235,9 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
 int lcd_finalize_dev(lcd_engine* h, int64_t* d_lfix, int64_t n, float* d_likelihood);
 /* slot table: d_slot_sig[slot] = signature id (0 = retired slot), n_slots = number of slots in use */
 int lcd_slots_dev(lcd_engine* h, const int32_t** d_slot_sig, int64_t* n_slots);
-/* record a caller-owned hipEvent_t on the engine stream BEHIND everything the calls made so far will enqueue there (on a
- * threaded handle, lcd_config.pipeline == 2, the work of the latest lcd_frame_dev calls may not be enqueued yet when they
- * return: recording on lcd_stream() directly would land in front of it) */
+/* record a caller-owned hipEvent_t on the engine stream BEHIND everything the calls made so far will enqueue there (a pipelined
+ * handle enqueues the registration / scoring of its latest frame with the next call: recording on lcd_stream() directly would
+ * land in front of it) */
 int lcd_record_event(lcd_engine* h, void* event);
 /* the engine's hipStream_t (so a caller can record events around enqueued work) */
 void* lcd_stream(lcd_engine* h);

@@ -143,7 +143,7 @@ class Engine:
         self.dim = int(dim)
         mode = KNN_MODES[knn_mode] if (knn_mode is None or isinstance(knn_mode, str)) else int(knn_mode)
         cfg = LcdConfig(C.sizeof(LcdConfig), device, self.dtype, self.dim, vocab_capacity, sig_capacity, 0, mode, stream,
-                        int(pipeline), 0)     # 0: one stream; 1: 2-NN stage on its own streams; 2: + index stage enqueued by a thread
+                        1 if pipeline else 0, 0)
         h = C.c_void_p()
         rc = self.L.lcd_create(C.byref(cfg), C.byref(h))
         if rc != LCD_OK:

@@ -2,12 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <condition_variable>
-#include <deque>
-#include <functional>
-#include <mutex>
 #include <string>
-#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -16,27 +11,6 @@
 #include "lcd_kernels.h"
 #include "tfidf.h"
 
-
-// lcd_config.pipeline == 2: the index stage of a frame (registration + scoring launches and all the host bookkeeping of the
-// inverted index) is enqueued by this thread while the caller's thread already enqueues the 2-NN stage of the next frame -- the
-// HIP launch cost of a frame (~45 us on one thread) is what bounds a fully device-resident loop.  Jobs run in posting order, so
-// the index sees exactly the call sequence; every API entry other than lcd_frame_dev / lcd_sig_remove drains the queue first.
-struct IndexWorker {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv_job, cv_done;
-    std::deque<std::function<int(std::string*)>> jobs;
-    bool stop = false;
-    uint64_t posted = 0, done = 0;
-    int err_code = 0;               // first failure of an asynchronous job since it was last reported
-    std::string err_msg;
-    int device = 0;
-    void start(int dev);
-    uint64_t post(std::function<int(std::string*)> f);
-    void wait(uint64_t n);          // until job number n (1-based posting order) has run
-    void drain() { wait(posted); }
-    void shutdown();
-};
 
 struct lcd_engine {
     int device = 0;
@@ -71,26 +45,22 @@ struct lcd_engine {
     bool fail_count_clean = false;                      // d_fail_count[0..1] known to be zero (the fused frame tail resets them)
     int knn_mode = 2;                                   // f32 dim 64: 2 = bf16x3 MFMA filter + exact re-rank (default), 1 = f32 MFMA filter
                                                         // + exact re-rank, 0 = exact VALU scan only (lcd_config.knn_mode)
-    // ---- pipelined frames (lcd_config.pipeline): the 2-NN stage of a frame runs on `kstream`, its registration / scoring on
-    // `stream`; the scratch the two stages share exists twice (the set in use above and `alt`), swapped every frame
-    hipStream_t kstream = nullptr;                      // NULL: not pipelined
-    hipStream_t kst = nullptr;                          // the stream the 2-NN stage is being enqueued on right now
-    hipStream_t rstream = nullptr;                      // pipelined: the re-rank of frame t runs here, next to the filter of frame t + 1
-    hipStream_t rst = nullptr;                          // the stream the re-rank is being enqueued on right now (NULL: same as kst)
-    hipEvent_t ev_filter[2] = {nullptr, nullptr};       // filter of the frame that uses set i finished (recorded on kstream)
+    // ---- pipelined frames (lcd_config.pipeline): frame t's filter launch carries the tail of frame t - 1 and its re-rank launch the
+    // scoring of frame t - 1; the scratch the two frames in flight use exists twice (the set in use above and `alt`), swapped every
+    // frame.  The index stage of the latest frame stays owed (`deferred`) until the next frame or any other call on the handle.
+    int pipeline = 0;
+    hipStream_t kst = nullptr;                          // the stream the 2-NN stage is enqueued on (== stream)
     struct AltScratch {
         lcd::DevBuf d_knn_row, d_knn_word, d_knn_dist, d_selfdist, d_bits, d_partial2, d_partial3, d_fail_list, d_fail_count, d_out_wslot;
         bool fail_count_clean = false;
     } alt;
     int ks_idx = 0;                                     // which of the two sets is the current one
-    int ks_q[2] = {0, 0};                               // queries each set has been sized for
-    hipEvent_t ev_knn[2] = {nullptr, nullptr};          // 2-NN stage of the frame that uses set i finished (recorded on kstream)
-    hipEvent_t ev_tail[2] = {nullptr, nullptr};         // the frame tail that read set i finished (recorded on stream)
-    bool k_busy = false;                                // work may be in flight on kstream
-    int sync_all();                                     // both streams drained
-    IndexWorker* worker = nullptr;                      // pipeline == 2
-    uint64_t set_job[2] = {0, 0};                       // the index job that last used scratch set i
-    int drain();                                        // run every queued index job; reports a failure one of them had
+    struct Deferred { bool valid = false; lcd_frame_args a; lcd::ResolveArgs r; } deferred;
+    std::vector<int32_t> deferred_retire;               // lcd_sig_remove calls made while a frame's index stage is owed
+    std::vector<void*> deferred_events;                 // lcd_record_event calls made while a frame's index stage is owed
+    int sync_all();                                     // stream drained
+    int drain();                                        // complete the owed index stage (stand-alone launches)
+    const char* prof2_kernel = "score_kernel";
     lcd::PinBuf h_in, h_out, h_out2;
     lcd::DevBuf d_hyp_scratch;                          // hypothesis record when the caller only wants the adjusted vector
 

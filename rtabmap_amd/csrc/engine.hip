@@ -37,80 +37,17 @@ int lcd_engine::find_row(int32_t word_id) {
 
 #define LCD_CHECK_HANDLE(h) do { if (!(h)) return LCD_ERR_INVALID; } while (0)
 #define LCD_HIP(h, x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return (h)->hip_fail(e__, #x); } while (0)
+// every entry selects the device; every entry except lcd_frame_dev / lcd_sig_remove / lcd_record_event first completes the index
+// stage a pipelined handle still owes for its last frame
 #define LCD_DEV_NODRAIN(h) LCD_HIP(h, hipSetDevice((h)->device))
 #define LCD_DEV(h) do { LCD_DEV_NODRAIN(h); int rc__ = (h)->drain(); if (rc__) return rc__; } while (0)
 
-void IndexWorker::start(int dev) {
-    device = dev;
-    th = std::thread([this] {
-        (void)hipSetDevice(device);
-        for (;;) {
-            std::function<int(std::string*)> f;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_job.wait(lk, [this] { return stop || !jobs.empty(); });
-                if (jobs.empty()) return;                            // stop requested and nothing left
-                f = std::move(jobs.front());
-                jobs.pop_front();
-            }
-            std::string msg;
-            const int rc = f(&msg);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (rc != 0 && err_code == 0) { err_code = rc; err_msg = msg; }
-                done += 1;
-            }
-            cv_done.notify_all();
-        }
-    });
-}
-uint64_t IndexWorker::post(std::function<int(std::string*)> f) {
-    uint64_t n;
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        jobs.push_back(std::move(f));
-        n = ++posted;
-    }
-    cv_job.notify_one();
-    return n;
-}
-void IndexWorker::wait(uint64_t n) {
-    std::unique_lock<std::mutex> lk(mu);
-    cv_done.wait(lk, [this, n] { return done >= n; });
-}
-void IndexWorker::shutdown() {
-    { std::lock_guard<std::mutex> lk(mu); stop = true; }
-    cv_job.notify_all();
-    if (th.joinable()) th.join();
-}
-
-int lcd_engine::drain() {
-    if (!worker) return LCD_OK;
-    worker->drain();
-    std::lock_guard<std::mutex> lk(worker->mu);
-    if (worker->err_code == 0) return LCD_OK;
-    const int rc = worker->err_code;
-    err = "asynchronous index job failed: " + worker->err_msg;
-    worker->err_code = 0;
-    worker->err_msg.clear();
-    return rc;
-}
-
 int lcd_engine::sync_all() {
-    { int rc = drain(); if (rc) return rc; }
-    if (kstream && k_busy) {
-        hipError_t e = hipStreamSynchronize(kstream);
-        if (e == hipSuccess && rstream) e = hipStreamSynchronize(rstream);
-        if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(kstream)");
-        k_busy = false;
-    }
     hipError_t e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(stream)");
     return LCD_OK;
 }
-// entries that use the 2-NN scratch or change what the 2-NN stage reads: the second stream of a pipelined handle must be idle
-#define LCD_JOIN_K(h) do { if ((h)->kstream && (h)->k_busy) { LCD_HIP(h, hipStreamSynchronize((h)->kstream)); \
-                                 if ((h)->rstream) LCD_HIP(h, hipStreamSynchronize((h)->rstream)); (h)->k_busy = false; } } while (0)
+#define LCD_JOIN_K(h) do { } while (0)
 
 namespace {
 
@@ -161,7 +98,7 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
         LCD_HIP(h, launch_knn_bf16(h->kdim, vocab, h->vocab_bf.p, h->row_norm.as<float>(), h->norm_max.as<uint32_t>(), row_id, d_queries, mp,
                                    h->d_partial2.p, o_row, o_word, o_dist, h->d_fail_list.as<int32_t>(), h->d_fail_count.as<int32_t>(),
                                    h->kst, prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr,
-                                   !h->fail_count_clean, cb, cb != nullptr, h->rst, h->rst ? h->ev_filter[h->ks_idx] : nullptr));
+                                   !h->fail_count_clean, cb, cb != nullptr));
         h->fail_count_clean = false;
         if (prof) { h->prof_n += 1; h->prof_kernel = "knn_bf16_filter_kernel"; }
         LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
@@ -256,25 +193,14 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
     if (e == hipSuccess) e = hipMemsetAsync(h->d_fail_count.p, 0, 64, h->stream);
     h->knn_mode = cfg->knn_mode == LCD_KNN_EXACT_VALU ? 0 : cfg->knn_mode == LCD_KNN_F32_MFMA ? 1 : 2;
     h->kst = h->stream;
-    if (cfg->pipeline < 0 || cfg->pipeline > 2) { delete h; return LCD_ERR_INVALID; }
+    if (cfg->pipeline < 0 || cfg->pipeline > 1) { delete h; return LCD_ERR_INVALID; }
+    h->pipeline = cfg->pipeline;
     if (cfg->pipeline) {
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->kstream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->rstream, hipStreamNonBlocking);
         if (e == hipSuccess) e = h->alt.d_fail_count.reserve(64, 0, h->stream, &h->bytes_device);
         if (e == hipSuccess) e = hipMemsetAsync(h->alt.d_fail_count.p, 0, 64, h->stream);
-        for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-            e = hipEventCreateWithFlags(&h->ev_knn[i], hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_tail[i], hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_filter[i], hipEventDisableTiming);
-        }
     }
     if (e == hipSuccess) e = h->tfidf.init(h->stream, &h->bytes_device, cfg->sig_capacity, cfg->vocab_capacity);
     if (e != hipSuccess) { lcd_destroy(h); return LCD_ERR_HIP; }
-    if (cfg->pipeline == 2) {
-        h->worker = new (std::nothrow) IndexWorker();
-        if (!h->worker) { lcd_destroy(h); return LCD_ERR_NOMEM; }
-        h->worker->start(h->device);
-    }
     *out = h;
     return LCD_OK;
 }
@@ -282,23 +208,14 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
 void lcd_destroy(lcd_engine* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->worker) { h->worker->drain(); h->worker->shutdown(); delete h->worker; h->worker = nullptr; }
-    if (h->kstream) (void)hipStreamSynchronize(h->kstream);
-    if (h->rstream) (void)hipStreamSynchronize(h->rstream);
+    (void)h->drain();
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->tfidf.destroy();
-    for (int i = 0; i < 2; ++i) {
-        if (h->ev_knn[i]) (void)hipEventDestroy(h->ev_knn[i]);
-        if (h->ev_tail[i]) (void)hipEventDestroy(h->ev_tail[i]);
-        if (h->ev_filter[i]) (void)hipEventDestroy(h->ev_filter[i]);
-    }
     {
         DevBuf* alts[] = {&h->alt.d_knn_row, &h->alt.d_knn_word, &h->alt.d_knn_dist, &h->alt.d_selfdist, &h->alt.d_bits, &h->alt.d_partial2,
                           &h->alt.d_partial3, &h->alt.d_fail_list, &h->alt.d_fail_count, &h->alt.d_out_wslot};
         for (DevBuf* d : alts) d->release(&h->bytes_device);
     }
-    if (h->kstream) (void)hipStreamDestroy(h->kstream);
-    if (h->rstream) (void)hipStreamDestroy(h->rstream);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->prof2_ev) (void)hipEventDestroy(e);
     DevBuf* all[] = {&h->vocab, &h->row_id, &h->row_wslot, &h->vocab_alt, &h->row_id_alt, &h->row_wslot_alt, &h->d_queries,
@@ -325,15 +242,8 @@ void* lcd_stream(lcd_engine* h) { return h ? (void*)h->stream : nullptr; }
 int lcd_record_event(lcd_engine* h, void* event) {
     LCD_CHECK_HANDLE(h);
     if (!event) return h->fail(LCD_ERR_INVALID, "lcd_record_event: null event");
-    if (h->worker) {
-        h->worker->post([h, event](std::string* msg) -> int {
-            const hipError_t e = hipEventRecord((hipEvent_t)event, h->stream);
-            if (e != hipSuccess) { *msg = std::string("lcd_record_event: ") + hipGetErrorString(e); return LCD_ERR_HIP; }
-            return LCD_OK;
-        });
-        return LCD_OK;
-    }
     LCD_DEV_NODRAIN(h);
+    if (h->deferred.valid) { h->deferred_events.push_back(event); return LCD_OK; }   // recorded behind the index stage still owed
     LCD_HIP(h, hipEventRecord((hipEvent_t)event, h->stream));
     return LCD_OK;
 }
@@ -750,16 +660,15 @@ int lcd_sig_add_bulk(lcd_engine* h, int n_sigs, const int32_t* sig_ids, const in
 
 int lcd_sig_remove(lcd_engine* h, int32_t sig_id) {
     LCD_CHECK_HANDLE(h);
-    if (h->worker) {     // threaded handle: in order behind the frames already posted (an unknown id is reported by the next draining call)
-        h->worker->post([h, sig_id](std::string* msg) -> int {
-            if (!h->tfidf.sig_slot.count(sig_id)) { *msg = "lcd_sig_remove: unknown signature"; return LCD_ERR_STATE; }
-            const hipError_t e = h->tfidf.retire(sig_id);
-            if (e != hipSuccess) { *msg = std::string("lcd_sig_remove: ") + hipGetErrorString(e); return LCD_ERR_HIP; }
-            return LCD_OK;
-        });
+    LCD_DEV_NODRAIN(h);
+    if (h->deferred.valid) {
+        // a pipelined handle still owes the index stage of its last frame: the retirement takes its place behind it
+        const bool known = h->tfidf.sig_slot.count(sig_id) || (h->deferred.a.sig_id != 0 && sig_id == h->deferred.a.sig_id);
+        if (!known || std::find(h->deferred_retire.begin(), h->deferred_retire.end(), sig_id) != h->deferred_retire.end())
+            return h->fail(LCD_ERR_STATE, "lcd_sig_remove: unknown signature");
+        h->deferred_retire.push_back(sig_id);
         return LCD_OK;
     }
-    LCD_DEV(h);
     if (!h->tfidf.sig_slot.count(sig_id)) return h->fail(LCD_ERR_STATE, "lcd_sig_remove: unknown signature");
     LCD_HIP(h, h->tfidf.retire(sig_id));
     return LCD_OK;
@@ -850,94 +759,168 @@ struct FrameHostTimer {   // host time spent inside lcd_frame_dev (lcd_stats.fra
 };
 }  // namespace
 
-// the index stage of a frame: registration (or query preparation), scoring, hypothesis.  Runs on the caller's thread, or on
-// the index thread of a threaded handle (then failures are reported through *msg).
-static int frame_stage_s(lcd_engine* h, const lcd_frame_args& a, ResolveArgs r, int p, bool pipe, std::string* msg) {
-#define S_FAIL(code, text) do { *msg = (text); return (code); } while (0)
-#define S_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { *msg = std::string(#x) + ": " + hipGetErrorString(e__); return LCD_ERR_HIP; } } while (0)
+// the index stage of a frame, launched on its own: registration (or query preparation), scoring, hypothesis
+static int frame_stage_s(lcd_engine* h, const lcd_frame_args& a, ResolveArgs r) {
     Tfidf& t = h->tfidf;
     const int q = a.q;
-    if (a.sig_id != 0 && t.sig_slot.count(a.sig_id)) S_FAIL(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
+    if (a.sig_id != 0 && t.sig_slot.count(a.sig_id)) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
     const int64_t slots_after = t.n_slots + (a.sig_id != 0 ? 1 : 0);
-    if (a.d_likelihood && a.likelihood_capacity < slots_after) S_FAIL(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
+    if (a.d_likelihood && a.likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
     // postings keys for the words this frame may create (VisualWord(id, descriptor, signatureId) references the signature)
     if (a.sig_id != 0 && a.first_new_word_id > 0 && (a.flags & LCD_Q_INCREMENTAL)) {
         hipError_t e = t.reserve_new_words(a.first_new_word_id, q, &r.new_ws);
-        if (e == hipErrorInvalidValue) S_FAIL(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: word ids must be below 2^28");
-        S_HIP(e);
+        if (e == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: word ids must be below 2^28");
+        LCD_HIP(h, e);
     }
-    if (pipe) S_HIP(hipStreamWaitEvent(h->stream, h->ev_knn[p], 0));
-    if (a.sig_id != 0) S_HIP(t.register_dev(a.sig_id, r.out_wslot, q, q, a.N, &r));
-    else S_HIP(t.query_dev(r.out_wslot, q, a.N, &r));
-    if (pipe) S_HIP(hipEventRecord(h->ev_tail[p], h->stream));
+    if (a.sig_id != 0) LCD_HIP(h, t.register_dev(a.sig_id, r.out_wslot, q, q, a.N, &r));
+    else LCD_HIP(h, t.query_dev(r.out_wslot, q, a.N, &r));
     if (a.d_likelihood) {
         if (h->prof_cap > 0 && h->prof2_n < h->prof_cap) {
             t.prof_b = h->prof2_ev[2 * h->prof2_n]; t.prof_e = h->prof2_ev[2 * h->prof2_n + 1];
             h->prof2_n += 1;
+            h->prof2_kernel = "score_kernel";
         }
-        S_HIP(t.score(a.d_likelihood));
+        LCD_HIP(h, t.score(a.d_likelihood));
         if (t.prof_b) { t.prof_b = t.prof_e = nullptr; h->prof2_n -= 1; }     // the launch that would have been bracketed did not happen
         h->likelihood_launches += 1;
         if (a.d_hypothesis || a.d_adjusted) {
             // Rtabmap::adjustLikelihood + the best candidate, without the vector leaving the device (Rtabmap.cpp:2121-2158)
             HypothesisOut* out = a.d_hypothesis ? (HypothesisOut*)a.d_hypothesis : (HypothesisOut*)h->d_hyp_scratch.p;
             const long long n_cons = (long long)t.n_slots - std::max(a.exclude_recent, 0);
-            S_HIP(launch_hypothesis(a.d_likelihood, t.slot_sig.as<int32_t>(), (long long)t.n_slots, n_cons, a.virtual_place_ratio,
-                                    a.d_adjusted, out, h->stream));
+            LCD_HIP(h, launch_hypothesis(a.d_likelihood, t.slot_sig.as<int32_t>(), (long long)t.n_slots, n_cons, a.virtual_place_ratio,
+                                         a.d_adjusted, out, h->stream));
         }
     }
     return LCD_OK;
-#undef S_FAIL
-#undef S_HIP
+}
+
+// what a pipelined handle still owes after its last lcd_frame_dev: the frame's index stage, then the retirements and event
+// records the caller asked for since, in call order
+static int finish_deferred_tail(lcd_engine* h) {
+    for (int32_t sig : h->deferred_retire) LCD_HIP(h, h->tfidf.retire(sig));
+    h->deferred_retire.clear();
+    for (void* ev : h->deferred_events) LCD_HIP(h, hipEventRecord((hipEvent_t)ev, h->stream));
+    h->deferred_events.clear();
+    return LCD_OK;
+}
+
+int lcd_engine::drain() {
+    if (!deferred.valid) return LCD_OK;
+    deferred.valid = false;
+    const int rc = frame_stage_s(this, deferred.a, deferred.r);      // stand-alone launches
+    const int rc2 = finish_deferred_tail(this);
+    return rc ? rc : rc2;
+}
+
+// Pipelined handle, matrix-core 2-NN: frame t's filter launch carries the tail of frame t - 1, its re-rank launch the scoring of
+// frame t - 1 (knn_mfma_kernels.hip, frame_a_kernel / frame_b_kernel).  The index stage of frame t itself stays owed until the
+// next lcd_frame_dev or any other call on the handle.
+static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
+    Tfidf& t = h->tfidf;
+    const int q = a->q;
+    // validate against the index as it will be once the owed stage has run
+    const bool prev = h->deferred.valid;
+    const int32_t prev_sig = prev ? h->deferred.a.sig_id : 0;
+    if (a->sig_id != 0 && (t.sig_slot.count(a->sig_id) || a->sig_id == prev_sig)) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
+    const int64_t slots_after = t.n_slots + (prev_sig != 0 ? 1 : 0) + (a->sig_id != 0 ? 1 : 0);
+    if (a->d_likelihood && a->likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
+    swap_scratch(h);
+    const bool incremental = (a->flags & LCD_Q_INCREMENTAL) != 0;
+    const bool together = incremental && (a->flags & LCD_Q_NEW_WORDS_COMPARED);
+    const int ld = (q + 63) / 64 * 64, bw = ld / 32;
+    // ---- this frame's 2-NN stage: buffers of the current scratch set
+    PipeKnn k;
+    k.plan = knn_bf16_plan(q, (int)h->n_rows);
+    LCD_HIP(h, dreserve(h, h->d_partial2, knn_bf16_partial_bytes(k.plan)));
+    LCD_HIP(h, dreserve(h, h->d_fail_list, (size_t)q * 4));
+    LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)h->n_rows, q)));
+    LCD_HIP(h, dreserve(h, h->d_knn_row, (size_t)q * 2 * 4));
+    LCD_HIP(h, dreserve(h, h->d_knn_word, (size_t)q * 2 * 4));
+    LCD_HIP(h, dreserve(h, h->d_knn_dist, (size_t)q * 2 * 4));
+    LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
+    if (together) {
+        LCD_HIP(h, dreserve(h, h->d_selfdist, (size_t)q * ld * 4));
+        LCD_HIP(h, dreserve(h, h->d_bits, (size_t)q * bw * 4));
+    }
+    k.vocab = h->vocab.p; k.vocab_bf = h->vocab_bf.p; k.row_norm = h->row_norm.as<float>(); k.norm_max_bits = h->norm_max.as<uint32_t>();
+    k.row_id = h->row_id.as<int32_t>(); k.queries = a->d_descriptors; k.partial = h->d_partial2.p;
+    k.out_row = h->d_knn_row.as<int32_t>(); k.out_word = h->d_knn_word.as<int32_t>(); k.out_dist = h->d_knn_dist.as<float>();
+    k.fail_list = h->d_fail_list.as<int32_t>(); k.fail_count = h->d_fail_count.as<int32_t>();
+    k.cb = CandBits();
+    if (together) { k.cb.selfdist = h->d_selfdist.as<float>(); k.cb.ld = ld; k.cb.nq = q; k.cb.bits = h->d_bits.as<uint32_t>(); k.cb.bw = bw; k.cb.have_index = 1; }
+    if (!h->fail_count_clean) LCD_HIP(h, hipMemsetAsync(h->d_fail_count.p, 0, 8, h->stream));
+    // ---- the owed index stage of the previous frame: host part now, its launches ride with this frame's
+    TailLaunch tl; ScoreArgs sa; int score_wgs = 0;
+    bool prev_like = false;
+    if (prev) {
+        h->deferred.valid = false;
+        const lcd_frame_args& pa = h->deferred.a;
+        ResolveArgs pr = h->deferred.r;
+        if (pa.sig_id != 0 && pa.first_new_word_id > 0 && (pa.flags & LCD_Q_INCREMENTAL)) {
+            hipError_t e = t.reserve_new_words(pa.first_new_word_id, pa.q, &pr.new_ws);
+            if (e == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: word ids must be below 2^28");
+            LCD_HIP(h, e);
+        }
+        if (pa.sig_id != 0) LCD_HIP(h, t.register_dev(pa.sig_id, pr.out_wslot, pa.q, pa.q, pa.N, &pr, false, &tl));
+        else LCD_HIP(h, t.query_dev(pr.out_wslot, pa.q, pa.N, &pr, false, &tl));
+        if (pa.d_likelihood) {
+            LCD_HIP(h, t.score_args(pa.d_likelihood, nullptr, pipe_block_size(), &sa, &score_wgs));
+            prev_like = true;
+            h->likelihood_launches += 1;
+        }
+    }
+    // ---- launch A: filter (this frame) + tail (previous frame); launch B: re-rank (this frame) + scoring (previous frame)
+    const bool prof = h->prof_cap > 0 && h->prof_n < h->prof_cap;
+    LCD_HIP(h, launch_frame_a(k, prev ? &tl : nullptr, h->stream, prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr));
+    if (prof) { h->prof_n += 1; h->prof_kernel = "frame_a_kernel (bf16 filter of frame t + tail of frame t-1)"; }
+    const bool prof2 = prev_like && h->prof_cap > 0 && h->prof2_n < h->prof_cap;
+    LCD_HIP(h, launch_frame_b(&k, prev_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
+                              prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr));
+    if (prof2) { h->prof2_n += 1; h->prof2_kernel = "frame_b_kernel (re-rank of frame t + scoring of frame t-1)"; }
+    h->knn_launches += 1;
+    h->fail_count_clean = true;                                      // this frame's tail (next launch A) resets the counters
+    if (prev) {
+        const lcd_frame_args& pa = h->deferred.a;
+        if (pa.d_likelihood && (pa.d_hypothesis || pa.d_adjusted)) {
+            HypothesisOut* out = pa.d_hypothesis ? (HypothesisOut*)pa.d_hypothesis : (HypothesisOut*)h->d_hyp_scratch.p;
+            const long long n_cons = (long long)t.n_slots - std::max(pa.exclude_recent, 0);
+            LCD_HIP(h, launch_hypothesis(pa.d_likelihood, t.slot_sig.as<int32_t>(), (long long)t.n_slots, n_cons, pa.virtual_place_ratio,
+                                         pa.d_adjusted, out, h->stream));
+        }
+        int rc = finish_deferred_tail(h);                            // retirements / events requested after the previous frame
+        if (rc) return rc;
+    }
+    // ---- this frame's index stage is owed from here on
+    ResolveArgs r;
+    r.rp = RowparArgs{};
+    r.q = q; r.flags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0); r.nndr = a->nndr_ratio; r.have_index = 1;
+    r.knn_word = k.out_word; r.knn_dist = k.out_dist; r.selfdist = together ? h->d_selfdist.as<float>() : nullptr; r.ld = ld;
+    r.cand_bits = together ? h->d_bits.as<uint32_t>() : nullptr; r.bw = bw; r.out_word = a->d_word_ids; r.out_n_new = h->d_n_new.as<int32_t>();
+    r.knn_row = k.out_row; r.row_wslot = h->row_wslot.as<int32_t>(); r.out_wslot = h->d_out_wslot.as<int32_t>(); r.new_ws = WsRuns();
+    r.fail_count = h->d_fail_count.as<int32_t>();
+    fill_redo(h, &r.rp, h->vocab.p, h->row_id.as<int32_t>(), (int)h->n_rows, a->d_descriptors, k.out_row, k.out_word, k.out_dist, together ? &k.cb : nullptr);
+    h->deferred.valid = true; h->deferred.a = *a; h->deferred.r = r;
+    return LCD_OK;
 }
 
 int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     LCD_CHECK_HANDLE(h);
     FrameHostTimer timer__(h);
-    if (h->worker) LCD_DEV_NODRAIN(h); else LCD_DEV(h);
+    LCD_DEV_NODRAIN(h);
     if (!a || a->struct_size != (int32_t)sizeof(lcd_frame_args)) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: bad argument block");
     const int q = a->q;
     if (q <= 0 || q > 8192 || !a->d_descriptors || !a->d_word_ids) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: bad argument");
     if ((a->d_hypothesis || a->d_adjusted) && !a->d_likelihood) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: the hypothesis needs d_likelihood");
-    const bool pipe = h->kstream != nullptr;
-    int p = 0;
-    if (pipe) {
-        swap_scratch(h);
-        p = h->ks_idx;
-        if (h->worker) h->worker->wait(h->set_job[p]);   // the index job that read this set is enqueued (its ev_tail is recorded)
-        if (q > h->ks_q[p]) {                       // this set's buffers are about to grow: nothing may still be using them
-            int rc = h->sync_all();
-            if (rc) return rc;
-            h->ks_q[p] = q;
-        }
-        // the tail of the frame before last read this set; the 2-NN stage of this frame overwrites it
-        LCD_HIP(h, hipStreamWaitEvent(h->kstream, h->ev_tail[p], 0));
-        if (a->ready_event) LCD_HIP(h, hipStreamWaitEvent(h->kstream, (hipEvent_t)a->ready_event, 0));
-        h->kst = h->kstream;
-        h->rst = h->rstream;
-        h->k_busy = true;
-    }
+    if (h->pipeline && q <= 4096 && h->knn_mode == 2 && knn_mfma_supported(h->dtype, h->kdim) && h->n_live >= 2 && h->n_rows >= 256)
+        return frame_pipelined(h, a);
+    { int rc = h->drain(); if (rc) return rc; }
     LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
     // 2-NN + same-frame distances, then ONE single-workgroup launch: decision loop -> pending retirements -> registration / idf
     ResolveArgs r;
     int rc = prepare_resolve(h, a->d_descriptors, q, a->flags, a->nndr_ratio, a->d_word_ids, h->d_out_wslot.as<int32_t>(), &r, true);
-    h->kst = h->stream;
-    hipStream_t knn_end = h->rst ? h->rst : h->kstream;              // the stream the last kernel of the 2-NN stage went to
-    const bool split = h->rst != nullptr && h->knn_mode == 2 && knn_mfma_supported(h->dtype, h->kdim) && h->n_live >= 2 && h->n_rows >= 256;
-    if (!split) knn_end = h->kstream;
-    h->rst = nullptr;
     if (rc) return rc;
-    if (pipe) LCD_HIP(h, hipEventRecord(h->ev_knn[p], knn_end));
     if (h->d_fail_count.p) { r.fail_count = h->d_fail_count.as<int32_t>(); h->fail_count_clean = true; }   // the tail resets the counters
-    if (h->worker) {
-        const lcd_frame_args copy = *a;
-        h->set_job[p] = h->worker->post([h, copy, r, p](std::string* msg) -> int { return frame_stage_s(h, copy, r, p, true, msg); });
-        return LCD_OK;
-    }
-    std::string msg;
-    rc = frame_stage_s(h, *a, r, p, pipe, &msg);
-    if (rc) return h->fail(rc, msg);
-    return LCD_OK;
+    return frame_stage_s(h, *a, r);
 }
 
 int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_ids, float* d_dist) {
@@ -1081,7 +1064,7 @@ int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, co
     }
     if (avg_ms) *avg_ms = h->prof2_n ? (float)(sum / h->prof2_n) : 0.0f;
     if (n_samples) *n_samples = h->prof2_n;
-    if (kernel_name) *kernel_name = "score_kernel";
+    if (kernel_name) *kernel_name = h->prof2_kernel;
     h->prof_cap = 0;
     return LCD_OK;
 }

@@ -1,0 +1,184 @@
+// frame_tail_body.cuh -- device code of the per-frame registration: unique words of the frame (LDS hash), postings appended to the
+// open bucket's log, nw / idf, retirements, and the whole frame tail (decision loop -> retirements -> registration) as ONE workgroup.
+// Shared by the stand-alone kernels of tfidf.hip and by the fused pipeline launches of knn_mfma_kernels.hip (where the tail of frame
+// t - 1 rides in the filter launch of frame t).
+#pragma once
+#include "tfidf.h"
+#include "resolve_body.cuh"
+#include "rowpar_body.cuh"
+
+namespace lcd {
+namespace {
+
+// A pointer that was itself read from memory (the bucket table) has no known address space, and the compiler falls back to FLAT
+// loads -- which also count on lgkmcnt, so every LDS wait would wait for them too.  These are global pointers: say so.
+template <typename T> __device__ __forceinline__ T gload(const T* p) { return *(const __attribute__((address_space(1))) T*)p; }
+__device__ __forceinline__ uint2 gload2(const uint2* p) {
+    const unsigned long long v = *(const __attribute__((address_space(1))) unsigned long long*)p;
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+
+// idf -> Q5.26, round to nearest, saturating
+__device__ __forceinline__ int32_t idf_to_fixed(float idf) {
+    float s = idf * 67108864.0f;                        // 2^26, exact scaling
+    s = fminf(fmaxf(s, -2147483520.0f), 2147483520.0f);
+    return (int32_t)rintf(s);
+}
+// exact integer sum -> likelihood: one rounding to float, exact scaling by 2^-26, one division by ni
+__device__ __forceinline__ float fixed_to_like(long long acc, uint32_t ni) {
+    if (ni == 0u) return 0.0f;                          // "if(ni != 0)" (Memory.cpp:2275); 0 also marks a retired slot
+    return __fdiv_rn(__ll2float_rn(acc) * 1.4901161193847656e-08f, (float)ni);
+}
+
+// ---------------------------------------------------------------------------------------------- frame words
+
+
+// One workgroup: reduce the frame's word slots to (unique word, count) with an LDS hash table (linear probing, atomicCAS),
+// optionally append them to the bucket log as the postings of signature `slot` (nw += 1 each), and leave the word / idf /
+// dense-id lists plus the per-word idf table (idf_tab[w] = {stamp, idf}) for the scoring kernel.
+// The list order is whatever the table yields: nothing downstream depends on it (integer accumulation).
+// LDS: 2 * H + H / 64 + 4 words.
+// SOLE: this workgroup is the only writer of the bucket's log right now (the frame path: one frame at a time on one stream), so the
+// log position is read at the start and written back at the end instead of being reserved with a returning atomic in the middle.
+// src_lds: the word slots in LDS (left there by the decision loop of the same kernel) instead of a.src.
+template <int NT, bool SOLE>
+__device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs& a, const int32_t* src_lds = nullptr) {
+    const int H = a.H;
+    uint32_t* tkey = fw_smem;            // [H] 0xFFFFFFFF = empty
+    uint32_t* tcnt = fw_smem + H;        // [H]
+    uint32_t* grp = tcnt + H;            // [H / 64 + 1]
+    uint32_t* s_misc = grp + H / 64 + 1; // [0] log base, [1] dense list length
+    const int tid = threadIdx.x;
+    for (int i = tid; i < H; i += NT) { tkey[i] = 0xFFFFFFFFu; tcnt[i] = 0u; }
+    if (tid == 0) { s_misc[0] = (SOLE && a.do_register) ? a.ne_counter[0] : 0u; s_misc[1] = 0u; }
+    __syncthreads();
+    for (int i = tid; i < a.n; i += NT) {
+        int32_t ws = src_lds ? src_lds[i] : a.src[i];
+        if (a.xlate) ws = (ws > 0 && (long long)ws < a.xlate_n) ? a.xlate[ws] : -1;
+        if (ws < 0) continue;
+        const uint32_t w = (uint32_t)ws;
+        uint32_t h = (w * 2654435761u) & (uint32_t)(H - 1);
+        for (;;) {
+            const uint32_t old = atomicCAS(&tkey[h], 0xFFFFFFFFu, w);
+            if (old == 0xFFFFFFFFu || old == w) { atomicAdd(&tcnt[h], 1u); break; }
+            h = (h + 1) & (uint32_t)(H - 1);
+        }
+    }
+    __syncthreads();
+    // compact the occupied table entries: ballot per 64-entry group, group offsets scanned by one thread
+    const int ng = H / 64;
+    for (int i0 = 0; i0 < H; i0 += NT) {
+        const int i = i0 + tid;
+        const bool occ = i < H && tkey[i] != 0xFFFFFFFFu;
+        const unsigned long long bal = __ballot(occ);
+        if ((tid & 63) == 0 && i < H) grp[i >> 6] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int g = 0; g < ng; ++g) { const uint32_t c = grp[g]; grp[g] = run; run += c; }
+        grp[ng] = run;
+        if (a.do_register && !SOLE) s_misc[0] = atomicAdd(a.ne_counter, run);   // reserve the signature's stretch of the log
+    }
+    __syncthreads();
+    const uint32_t U = grp[ng];
+    const uint32_t base = s_misc[0];
+    for (int i0 = 0; i0 < H; i0 += NT) {
+        const int i = i0 + tid;
+        const bool occ = i < H && tkey[i] != 0xFFFFFFFFu;
+        const unsigned long long bal = __ballot(occ);
+        if (!occ) continue;
+        const uint32_t u = grp[i >> 6] + (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
+        const uint32_t w = tkey[i];
+        uint32_t cnt = tcnt[i];
+        if (cnt > TF_CNT_MASK) cnt = TF_CNT_MASK;
+        uint32_t nwv;
+        if (a.do_register) {
+            nwv = atomicAdd(&a.nw[w], 1u) + 1u;
+            a.coo_w[base + u] = w;
+            a.coo_pc[base + u] = (a.slot_local << TF_CNT_BITS) | cnt;
+        } else {
+            nwv = a.nw[w];
+        }
+        if (a.want_q) {
+            float idf = 0.0f;
+            if (a.N > 0.0f && nwv > 0u) idf = log10f(__fdiv_rn(a.N, (float)nwv));   // Memory.cpp:2264-2266
+            const int32_t idfq = idf_to_fixed(idf);
+            const int32_t d = a.did[w];
+            a.q_w[u] = w;
+            a.q_idf[u] = idfq;
+            a.q_did[u] = d;
+            a.idf_tab[w] = make_uint2(a.stamp, (uint32_t)idfq);
+            if (d >= 0 && idfq != 0) {                                   // "if(logNnw)" (Memory.cpp:2267)
+                const uint32_t j = atomicAdd(&s_misc[1], 1u);
+                a.qd_did[j] = d;
+                a.qd_idf[j] = idfq;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (a.want_q) { a.q_meta[0] = U; a.q_meta[1] = s_misc[1]; }
+        if (a.do_register) {
+            if (SOLE) a.ne_counter[0] = base + U;
+            a.slot_sig[a.slot] = a.sig_id;
+            a.slot_ni[a.slot] = a.ni;
+            a.slot_begin[a.slot] = base;
+            a.slot_cnt[a.slot] = U;
+        }
+    }
+}
+
+// signatures whose retirement was requested since the last frame (Memory::disableWordsRef -> removeAllWordRef): their
+// words lose one reference each and the slot is marked dead (ni = 0).  Up to 4 ride along with the next frame-words launch.
+
+__device__ __forceinline__ void retire_body(const RetireArgs& r, const uint32_t* __restrict__ slot_begin, const uint32_t* __restrict__ slot_cnt,
+                                            uint32_t* __restrict__ nw, uint32_t* __restrict__ slot_ni, int32_t* __restrict__ slot_sig) {
+    for (int p = 0; p < r.n; ++p) {
+        const long long slot = r.slot[p];
+        const uint32_t begin = slot_begin[slot], cnt = slot_cnt[slot];
+        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) atomicSub(&nw[r.coo_w[p][begin + k]], 1u);
+        if (threadIdx.x == 0) { slot_ni[slot] = 0u; slot_sig[slot] = 0; }
+    }
+}
+
+#ifdef LCD_TAIL_TIMING   // timing experiment only: 100 MHz stamps between the phases of the frame tail
+__device__ unsigned long long g_tail_timing[8];
+#define FT_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_tail_timing[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FT_STAMP(i) do { } while (0)
+#endif
+
+// The single-workgroup tail of a frame in ONE launch: addNewWords decision loop (resolve_body.cuh) -> pending retirements
+// -> unique words / registration / idf (frame_words_body).  Saves two dependent kernel boundaries per frame.
+template <int NT>
+__device__ __forceinline__ void frame_tail_body(uint32_t* ft_dyn_smem, const ResolveArgs& r, const FwArgs& a, const RetireArgs& retire, int wb, int n_wb) {
+    // workgroups 1.. : the exact redo of the queries the 2-NN certificate rejected (they leave at once when there are none, which
+    // is the usual case: no launch of its own for that check).  Workgroup 0 waits for them only when something was rejected.
+    if (wb > 0) { rowpar_body<64, NT>(r.rp, wb - 1, n_wb - 1, r.fail_count); return; }
+    if (r.rp.enabled && n_wb > 1) {
+        if (threadIdx.x == 0 && r.fail_count[0] > 0) {
+            while (__hip_atomic_load(&r.fail_count[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+    FT_STAMP(0);
+    // frames of up to 1024 descriptors: the register-resident decision loop, its result handed to the registration through LDS
+    int32_t* lds_ws = r.q <= NT ? (int32_t*)(ft_dyn_smem + 2 * a.H + a.H / 64 + 8) : nullptr;
+    if (lds_ws) resolve_body_fast<NT>(ft_dyn_smem, lds_ws, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits,
+                                  r.bw, r.out_word, r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
+    else resolve_body<NT>(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
+                      r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
+    if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; r.fail_count[3] = 0; }
+    FT_STAMP(1);
+    retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
+    __syncthreads();      // out_wslot (global or LDS, written by this workgroup) and the LDS region are handed over
+    FT_STAMP(2);
+    frame_words_body<NT, true>(ft_dyn_smem, a, lds_ws);
+    FT_STAMP(3);
+}
+
+
+}  // namespace
+}  // namespace lcd

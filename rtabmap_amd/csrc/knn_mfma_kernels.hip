@@ -26,6 +26,8 @@
 // product does not see.  D layout: lane holds query (l&31), 16 rows (reg&3) + 8*(reg>>2) + 4*(l>>5).
 #include "lcd_kernels.h"
 #include "rowpar_body.cuh"
+#include "frame_tail_body.cuh"
+#include "score_body.cuh"
 
 #include <cstdlib>
 
@@ -554,10 +556,10 @@ __device__ __forceinline__ void selfdist_tile(const SelfdistJob& sd, int k, floa
 // partial_keys [qpad][n_blocks][BF_KEEP] u64, partial_bound [qpad][n_blocks] f32 bits.  Grid (1-D): sd.n_tiles distance-matrix
 // workgroups first, then n_blocks x ceil(nq / 512) filter workgroups.
 template <int NG>
-__global__ __launch_bounds__((BF_QB / (NG * 32)) * 64) void knn_bf16_filter_kernel(const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
-                                                                      int n_rows, const float* __restrict__ queries, int nq, int qpad,
-                                                                      int tiles_per_block, int n_blocks, uint64_t* __restrict__ partial_keys,
-                                                                      uint32_t* __restrict__ partial_bound, SelfdistJob sd) {
+__device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
+                                                     int n_rows, const float* __restrict__ queries, int nq, int qpad,
+                                                     int tiles_per_block, int n_blocks, uint64_t* __restrict__ partial_keys,
+                                                     uint32_t* __restrict__ partial_bound, const SelfdistJob& sd) {
     // NG = 32-query groups per wave: 4 -> four waves, one per SIMD; 2 -> eight waves, two per SIMD (one wave's tile
     // synchronisation, LDS reads and top-3 update hide behind the other's MFMAs).  The workgroup covers BF_QB queries either way.
     static_assert(NG == 4 || NG == 2, "wave tile");
@@ -565,9 +567,8 @@ __global__ __launch_bounds__((BF_QB / (NG * 32)) * 64) void knn_bf16_filter_kern
     constexpr int NW = BF_QB / (NG * 32);          // waves per workgroup
     constexpr int QW = NG * 32;                    // queries per wave
     constexpr int DPW = 8 / NW;                    // DMA instructions of a tile issued by one wave
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    if ((int)blockIdx.x < sd.n_tiles) { selfdist_tile(sd, (int)blockIdx.x, s_dyn); return; }
-    const int fb = (int)blockIdx.x - sd.n_tiles;
+    if (bid < sd.n_tiles) { selfdist_tile(sd, bid, s_dyn); return; }
+    const int fb = bid - sd.n_tiles;
     const int bx = fb % n_blocks, by = fb / n_blocks;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -742,6 +743,17 @@ __device__ __forceinline__ float eps_for(int dim, float qn, float vn_max) {
     return (3.5f * (float)dim + 16.0f) * 5.9604645e-8f * 1.25f * (qn + vn_max);
 }
 
+template <int NG>
+__global__ __launch_bounds__((BF_QB / (NG * 32)) * 64) void knn_bf16_filter_kernel(const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
+                                                                      int n_rows, const float* __restrict__ queries, int nq, int qpad,
+                                                                      int tiles_per_block, int n_blocks, uint64_t* __restrict__ partial_keys,
+                                                                      uint32_t* __restrict__ partial_bound, SelfdistJob sd) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn_f[];
+    knn_bf16_filter_body<NG>(s_dyn_f, (int)blockIdx.x, vocab_bf, row_norm, n_rows, queries, nq, qpad, tiles_per_block, n_blocks, partial_keys,
+                             partial_bound, sd);
+}
+
+
 // One workgroup per query (the kernel is a chain of dependent memory round trips: the more lanes share them, the shorter).
 // Pass 1 finds tau = the second smallest filter score among the kept keys; a kept row whose score exceeds
 // tau (1 + 2^-15) + 2 eps is strictly farther than the two rows that define tau (|score - distance| <= eps, keys are truncated by
@@ -753,17 +765,16 @@ __device__ __forceinline__ float eps_for(int dim, float qn, float vn_max) {
 // BF16: the keys come from the bf16x3 filter (eps_bf16).  fail_count[2] collects max |score - distance| / eps (diagnostics).
 constexpr int RR_MAX_CAND = 128;
 template <int DIM, int KEEP, bool LAST_KEY_BOUNDS, bool BF16>
-__global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_t* __restrict__ partial_keys,
-                                                                   const uint32_t* __restrict__ partial_lmin, int n_blocks, int nq,
-                                                                   const float* __restrict__ vocab, const float* __restrict__ queries,
-                                                                   const int32_t* __restrict__ row_id,
-                                                                   const uint32_t* __restrict__ norm_max_bits,
-                                                                   int32_t* __restrict__ out_row, int32_t* __restrict__ out_word,
-                                                                   float* __restrict__ out_dist, int32_t* __restrict__ fail_list,
-                                                                   int32_t* __restrict__ fail_count, CandBits cb) {
+__device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __restrict__ partial_keys,
+                                                     const uint32_t* __restrict__ partial_lmin, int n_blocks, int nq,
+                                                     const float* __restrict__ vocab, const float* __restrict__ queries,
+                                                     const int32_t* __restrict__ row_id,
+                                                     const uint32_t* __restrict__ norm_max_bits,
+                                                     int32_t* __restrict__ out_row, int32_t* __restrict__ out_word,
+                                                     float* __restrict__ out_dist, int32_t* __restrict__ fail_list,
+                                                     int32_t* __restrict__ fail_count, const CandBits& cb) {
     static_assert(DIM == 64, "16 lanes x 4 floats per candidate row");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qi = blockIdx.x;
     __shared__ float s_thr;
     const int n_keys = n_blocks * KEEP;
     const uint64_t* __restrict__ keys = partial_keys + (size_t)qi * n_keys;
@@ -929,6 +940,57 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
             if (lane == 0) *reinterpret_cast<unsigned long long*>(cb.bits + (size_t)qi * cb.bw + (base >> 5)) = m;
         }
     }
+}
+
+template <int DIM, int KEEP, bool LAST_KEY_BOUNDS, bool BF16>
+__global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_t* __restrict__ partial_keys,
+                                                                   const uint32_t* __restrict__ partial_lmin, int n_blocks, int nq,
+                                                                   const float* __restrict__ vocab, const float* __restrict__ queries,
+                                                                   const int32_t* __restrict__ row_id,
+                                                                   const uint32_t* __restrict__ norm_max_bits,
+                                                                   int32_t* __restrict__ out_row, int32_t* __restrict__ out_word,
+                                                                   float* __restrict__ out_dist, int32_t* __restrict__ fail_list,
+                                                                   int32_t* __restrict__ fail_count, CandBits cb) {
+    knn_mfma_rerank_body<DIM, KEEP, LAST_KEY_BOUNDS, BF16>((int)blockIdx.x, partial_keys, partial_lmin, n_blocks, nq, vocab, queries, row_id,
+                                                          norm_max_bits, out_row, out_word, out_dist, fail_list, fail_count, cb);
+}
+
+// ------------------------------------------------------------------------------------------------ software-pipelined frames
+// Consecutive frames of a device-resident stream overlap INSIDE two launches instead of across streams: the 2-NN stage of frame t
+// does not depend on the index stage of frame t - 1 (lcd_frame_dev never changes the vocabulary), so
+//   launch A(t) = matrix-core filter of frame t  +  ONE workgroup running the whole tail of frame t - 1 (decision loop, retirements,
+//                 registration, idf) + the redo workgroups of frame t - 1: the tail is a single-workgroup latency chain that used
+//                 to sit alone on the critical path of every frame; here it hides behind the filter;
+//   launch B(t) = exact re-rank of frame t  +  TF-IDF scoring of frame t - 1: two groups of small latency-bound workgroups that fill
+//                 each other's stalls.
+// Two dependent launches per frame on ONE stream, no events, no second host thread; the data each part reads was written by the
+// previous launch (A -> B -> A ...).  The per-frame scratch exists twice (see engine.h).
+struct FilterArgs {
+    const float* vocab_bf; const float* row_norm; int n_rows; const float* queries; int nq, qpad, tiles_per_block, n_blocks;
+    uint64_t* pk; uint32_t* pl; SelfdistJob sd;
+};
+struct RerankArgs {
+    const uint64_t* pk; const uint32_t* pl; int n_blocks, nq; const float* vocab; const float* queries; const int32_t* row_id;
+    const uint32_t* norm_max_bits; int32_t* out_row; int32_t* out_word; float* out_dist; int32_t* fail_list; int32_t* fail_count; CandBits cb;
+};
+constexpr int PIPE_BLOCK = 256;     // workgroup size of both fused launches (the filter's and the re-rank's)
+
+__global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel(FilterArgs f, int n_filter_wgs, ResolveArgs r, FwArgs a, RetireArgs ret) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn_a[];
+    const int bid = (int)blockIdx.x;
+    if (bid >= n_filter_wgs) { frame_tail_body<PIPE_BLOCK>((uint32_t*)s_dyn_a, r, a, ret, bid - n_filter_wgs, (int)gridDim.x - n_filter_wgs); return; }
+    knn_bf16_filter_body<4>(s_dyn_a, bid, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, f.pk, f.pl, f.sd);
+}
+__global__ __launch_bounds__(PIPE_BLOCK) void frame_b_kernel(RerankArgs k, int n_rerank_wgs, ScoreArgs A) {
+    const int bid = (int)blockIdx.x;
+    if (bid < n_rerank_wgs) {
+        knn_mfma_rerank_body<64, BF_KEEP, false, true>(bid, k.pk, k.pl, k.n_blocks, k.nq, k.vocab, k.queries, k.row_id, k.norm_max_bits, k.out_row,
+                                                       k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb);
+        return;
+    }
+    const int b = bid - n_rerank_wgs;
+    if (b < A.n_closed) score_sealed_body<PIPE_BLOCK>(A, b);
+    else score_open_body<PIPE_BLOCK>(A, b - A.n_closed);
 }
 
 // ------------------------------------------------------------------------------------------------ row-parallel exact scan
@@ -1121,6 +1183,63 @@ hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, 
     const int nb = (n_rows + MF_BLOCK - 1) / MF_BLOCK;
     knn_rowpar_kernel<<<nb, MF_BLOCK, 0, s>>>(a, fail_count);
     return hipGetLastError();
+}
+
+// ---- software-pipelined frames (see frame_a_kernel / frame_b_kernel)
+int pipe_block_size() { return PIPE_BLOCK; }
+
+hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* tail, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
+    const MfmaPlan& p = k.plan;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)BF_LDS_BYTES);
+    (void)attr;
+    uint64_t* pk = (uint64_t*)k.partial;
+    uint32_t* pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * BF_KEEP * p.qpad);
+    FilterArgs f;
+    f.vocab_bf = (const float*)k.vocab_bf; f.row_norm = k.row_norm; f.n_rows = p.n_rows; f.queries = (const float*)k.queries; f.nq = p.q; f.qpad = p.qpad;
+    f.tiles_per_block = p.tiles_per_block; f.n_blocks = p.n_blocks; f.pk = pk; f.pl = pl;
+    f.sd = SelfdistJob();
+    if (k.cb.selfdist) {                                              // the same-frame distance matrix rides along
+        const int T = (p.q + 31) / 32;
+        f.sd.queries = (const float*)k.queries; f.sd.nq = p.q; f.sd.out = const_cast<float*>(k.cb.selfdist); f.sd.ld = k.cb.ld; f.sd.n_tiles = T * (T + 1) / 2;
+    }
+    const int n_filter = p.q > 0 ? f.sd.n_tiles + p.n_blocks * ((p.q + BF_QB - 1) / BF_QB) : 0;
+    const int n_tail = tail ? 1 + tail->n_redo : 0;
+    if (n_filter + n_tail == 0) return hipSuccess;
+    if (tail && tail->shmem > BF_LDS_BYTES) return hipErrorInvalidValue;
+    ResolveArgs r{}; FwArgs a{}; RetireArgs ret{};
+    if (tail) { r = tail->r; a = tail->a; ret = tail->ret; }
+    hipError_t e;
+    if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
+    frame_a_kernel<<<n_filter + n_tail, PIPE_BLOCK, BF_LDS_BYTES, s>>>(f, n_filter, r, a, ret);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }
+    return hipSuccess;
+}
+
+hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wgs, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
+    RerankArgs rk{};
+    int n_rerank = 0;
+    if (k) {
+        const MfmaPlan& p = k->plan;
+        uint64_t* pk = (uint64_t*)k->partial;
+        rk.pk = pk; rk.pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * BF_KEEP * p.qpad);
+        rk.n_blocks = p.n_blocks; rk.nq = p.q; rk.vocab = (const float*)k->vocab; rk.queries = (const float*)k->queries; rk.row_id = k->row_id;
+        rk.norm_max_bits = k->norm_max_bits; rk.out_row = k->out_row; rk.out_word = k->out_word; rk.out_dist = k->out_dist;
+        rk.fail_list = k->fail_list; rk.fail_count = k->fail_count; rk.cb = k->cb;
+        n_rerank = p.q;
+    }
+    ScoreArgs A{};
+    if (score) A = *score; else score_wgs = 0;
+    if (n_rerank + score_wgs == 0) return hipSuccess;
+    hipError_t e;
+    if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
+    frame_b_kernel<<<n_rerank + score_wgs, PIPE_BLOCK, 0, s>>>(rk, n_rerank, A);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }
+    return hipSuccess;
 }
 
 }  // namespace lcd

@@ -70,7 +70,7 @@ __device__ __forceinline__ int new_rank(const uint32_t* mask, const uint32_t* pr
     return (int)(prefix[j >> 5] + __popc(mask[j >> 5] & ((1u << (j & 31)) - 1u)));
 }
 
-// The same decision loop for frames of at most RBLOCK descriptors (one descriptor per thread), latency-trimmed: the kernel this
+// The same decision loop for frames of at most NT (= workgroup size) descriptors (one descriptor per thread), latency-trimmed: the kernel this
 // runs in is ONE workgroup on the critical path of every frame, so what counts is the number of dependent global round trips.
 //   * the indexed neighbours, their vocabulary rows and the descriptor's candidate-bit row are read ONCE, all loads in flight
 //     together; the postings keys of both neighbours are requested before the sweeps and consumed after them;
@@ -79,6 +79,7 @@ __device__ __forceinline__ int new_rank(const uint32_t* mask, const uint32_t* pr
 //     costs it nothing; the winner of a sweep lives in a register, not in out_word;
 //   * the result is also left in LDS (lds_wslot, may be NULL) for the registration that follows in the same kernel.
 // Same results as resolve_body (tests drive both).  rs_smem as below.
+template <int NT>
 __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* lds_wslot, int q, int flags, float nndr, int have_index,
                                                   const int32_t* __restrict__ knn_word, const float* __restrict__ knn_dist,
                                                   const float* __restrict__ selfdist, int ld,
@@ -233,8 +234,9 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
     RB_STAMP(5);
 }
 
-// The whole decision loop for one frame, executed by ONE workgroup of RBLOCK threads.  rs_smem: 3 * mw + 2 words of LDS,
+// The whole decision loop for one frame, executed by ONE workgroup of NT threads.  rs_smem: 3 * mw + 2 words of LDS,
 // mw = ceil(q / 64) * 2.
+template <int NT>
 __device__ __forceinline__ void resolve_body(uint32_t* rs_smem, int q, int flags, float nndr, int have_index,
                                                          const int32_t* __restrict__ knn_word, const float* __restrict__ knn_dist,
                                                          const float* __restrict__ selfdist, int ld,
@@ -255,7 +257,7 @@ __device__ __forceinline__ void resolve_body(uint32_t* rs_smem, int q, int flags
     const int qpad = mw * 32;
 
     // sweep 0: decide from the indexed candidates only; out_word holds the current winner of every descriptor
-    for (int i = tid; i < qpad; i += RBLOCK) {
+    for (int i = tid; i < qpad; i += NT) {
         bool reject = false;
         if (i < q) {
             Cand c0, c1; int n;
@@ -271,7 +273,7 @@ __device__ __forceinline__ void resolve_body(uint32_t* rs_smem, int q, int flags
         for (int sweep = 0; sweep <= q; ++sweep) {
             if (tid == 0) s_changed = 0;
             __syncthreads();
-            for (int i = tid; i < qpad; i += RBLOCK) {
+            for (int i = tid; i < qpad; i += NT) {
                 bool reject = false;
                 if (i < q) {
                     Cand c0, c1; int n;
@@ -300,7 +302,7 @@ __device__ __forceinline__ void resolve_body(uint32_t* rs_smem, int q, int flags
         out_n_new[0] = (int32_t)run;
     }
     __syncthreads();
-    for (int i = tid; i < q; i += RBLOCK) {
+    for (int i = tid; i < q; i += NT) {
         const bool is_new = (mask_cur[i >> 5] >> (i & 31)) & 1u;
         int w;
         if (is_new) w = -(new_rank(mask_cur, prefix, i) + 1);

@@ -93,6 +93,47 @@ struct ResolveArgs {
     RowparArgs rp;         // rp.enabled: the exact redo of rejected queries runs as extra workgroups of the tail launch
 };
 
+// kernel argument blocks of the registration / scoring launches (frame_tail_body.cuh, score_body.cuh)
+struct FwArgs {
+    const int32_t* src; int n;                    // word slots of the frame (or word ids when xlate != NULL); < 0 / <= 0 = no word
+    const int32_t* xlate; long long xlate_n;      // word id -> wslot table (device copy of Tfidf::id2ws)
+    int H; int do_register; int want_q;
+    int32_t sig_id; long long slot; uint32_t slot_local; uint32_t ni; float N; uint32_t stamp;
+    uint32_t* nw; const int32_t* did;
+    uint32_t* coo_w; uint32_t* coo_pc; uint32_t* ne_counter;
+    int32_t* slot_sig; uint32_t* slot_ni; uint32_t* slot_begin; uint32_t* slot_cnt;
+    uint32_t* q_w; int32_t* q_idf; int32_t* q_did; int32_t* qd_did; int32_t* qd_idf; uint32_t* q_meta; uint2* idf_tab;
+};
+// signatures whose retirement was requested since the last frame (Memory::disableWordsRef -> removeAllWordRef): their
+// words lose one reference each and the slot is marked dead (ni = 0).  Up to 4 ride along with the next frame-words launch.
+struct RetireArgs { long long slot[4]; const uint32_t* coo_w[4]; int n; };
+struct ScoreArgs {
+    const BucketDev* tab; const uint32_t* bkt_D; const uint32_t* bkt_flags;
+    int n_closed;                           // buckets [0, n_closed) are sealed or dead; bucket n_closed (if any) is the open one
+    int n_open_slots; int wcap;
+    const uint32_t* q_w; const int32_t* q_idf; const int32_t* q_did; const int32_t* qd_did; const int32_t* qd_idf; const uint32_t* q_meta;
+    const uint32_t* slot_ni; const uint32_t* slot_begin; const uint32_t* slot_cnt;
+    const uint2* idf_tab; uint32_t stamp;
+    float* out_like; long long* out_fix;    // exactly one is non-NULL
+};
+// a frame tail ready to be launched (stand-alone, or inside the filter launch of the next frame)
+struct TailLaunch {
+    ResolveArgs r; FwArgs a; RetireArgs ret;
+    int n_redo = 0;            // extra workgroups for the exact redo of rejected queries
+    size_t shmem = 0;          // dynamic LDS of the tail workgroup
+};
+// the 2-NN stage of a pipelined frame: everything the fused launches need (pointers into one of the two scratch sets)
+struct PipeKnn {
+    MfmaPlan plan;
+    const void* vocab; const void* vocab_bf; const float* row_norm; const uint32_t* norm_max_bits; const int32_t* row_id; const void* queries;
+    void* partial; int32_t* out_row; int32_t* out_word; float* out_dist; int32_t* fail_list; int32_t* fail_count;
+    CandBits cb;               // cb.selfdist != NULL: the filter launch also fills the same-frame distance matrix
+};
+int pipe_block_size();
+hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* tail, hipStream_t s, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wgs, hipStream_t s, hipEvent_t ev_begin = nullptr,
+                          hipEvent_t ev_end = nullptr);
+
 // recycled allocations of bucket-sized device buffers (a bucket is born and dies every 256 frames in steady state:
 // hipMalloc / hipFree there would synchronise the device)
 struct BufPool {
@@ -165,10 +206,13 @@ struct Tfidf {
     hipError_t reserve_new_words(int32_t first_id, int n, WsRuns* runs);
     // register one signature whose word slots are already on the device (d_wslots[n]; < 0 = no word); if N > 0 the
     // frame's unique words / idf are left in q_* for a following score()
+    // defer != NULL (needs resolve): do not launch the frame tail, leave its launch arguments there -- sized for a workgroup of
+    // pipe_block_size() threads -- for the filter launch of the next frame to carry (knn_mfma_kernels.hip, frame_a_kernel)
     hipError_t register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N, const ResolveArgs* resolve = nullptr,
-                            bool ids_given = false /* d_wslots holds word ids, translated on the device */);
+                            bool ids_given = false /* d_wslots holds word ids, translated on the device */, TailLaunch* defer = nullptr);
     // prepare q_* from word slots on the device without registering anything
-    hipError_t query_dev(const int32_t* d_wslots, int n, float N, const ResolveArgs* resolve = nullptr, bool ids_given = false);
+    hipError_t query_dev(const int32_t* d_wslots, int n, float N, const ResolveArgs* resolve = nullptr, bool ids_given = false,
+                         TailLaunch* defer = nullptr);
     // Memory::loadDataFromDb replay: many signatures in O(1) launches; d_ids = word ids on the device, offsets[n_sigs + 1]
     hipError_t register_bulk(int n_sigs, const int32_t* sig_ids, const int64_t* offsets, const int32_t* ni, const int32_t* d_ids,
                              int64_t total_ids, int max_n);
@@ -189,6 +233,9 @@ struct Tfidf {
     hipError_t set_bucket(int b);          // upload one bucket descriptor (tiny kernel: the data travels as kernel arguments)
     hipError_t new_bucket();
     hipError_t launch_score(float* d_likelihood, long long* lfix);
+    // the arguments of a scoring launch with workgroups of `block` threads, and the number of workgroups (pending retirements are
+    // applied first); for the fused launch of a pipelined frame
+    hipError_t score_args(float* d_likelihood, long long* lfix, int block, ScoreArgs* out, int* n_wgs);
 };
 
 // gather of the dense likelihood: out[k] = slots[k] >= 0 ? dense[slots[k]] : 0

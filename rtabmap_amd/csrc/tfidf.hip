@@ -7,8 +7,8 @@
 // integers) / ni: one float rounding and one float division per signature instead of one of each per posting.  The two agree to
 // rounding (~1e-7 relative; the tests bound 1e-4 with an absolute floor of 1e-7).
 #include "tfidf.h"
-#include "resolve_body.cuh"
-#include "rowpar_body.cuh"
+#include "frame_tail_body.cuh"
+#include "score_body.cuh"
 
 #include <algorithm>
 #include <cmath>
@@ -55,147 +55,6 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t* data, int n, 
     return total;
 }
 
-// A pointer that was itself read from memory (the bucket table) has no known address space, and the compiler falls back to FLAT
-// loads -- which also count on lgkmcnt, so every LDS wait would wait for them too.  These are global pointers: say so.
-template <typename T> __device__ __forceinline__ T gload(const T* p) { return *(const __attribute__((address_space(1))) T*)p; }
-__device__ __forceinline__ uint2 gload2(const uint2* p) {
-    const unsigned long long v = *(const __attribute__((address_space(1))) unsigned long long*)p;
-    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
-}
-
-// idf -> Q5.26, round to nearest, saturating
-__device__ __forceinline__ int32_t idf_to_fixed(float idf) {
-    float s = idf * 67108864.0f;                        // 2^26, exact scaling
-    s = fminf(fmaxf(s, -2147483520.0f), 2147483520.0f);
-    return (int32_t)rintf(s);
-}
-// exact integer sum -> likelihood: one rounding to float, exact scaling by 2^-26, one division by ni
-__device__ __forceinline__ float fixed_to_like(long long acc, uint32_t ni) {
-    if (ni == 0u) return 0.0f;                          // "if(ni != 0)" (Memory.cpp:2275); 0 also marks a retired slot
-    return __fdiv_rn(__ll2float_rn(acc) * 1.4901161193847656e-08f, (float)ni);
-}
-
-// ---------------------------------------------------------------------------------------------- frame words
-struct FwArgs {
-    const int32_t* src; int n;                    // word slots of the frame (or word ids when xlate != NULL); < 0 / <= 0 = no word
-    const int32_t* xlate; long long xlate_n;      // word id -> wslot table (device copy of Tfidf::id2ws)
-    int H; int do_register; int want_q;
-    int32_t sig_id; long long slot; uint32_t slot_local; uint32_t ni; float N; uint32_t stamp;
-    uint32_t* nw; const int32_t* did;
-    uint32_t* coo_w; uint32_t* coo_pc; uint32_t* ne_counter;
-    int32_t* slot_sig; uint32_t* slot_ni; uint32_t* slot_begin; uint32_t* slot_cnt;
-    uint32_t* q_w; int32_t* q_idf; int32_t* q_did; int32_t* qd_did; int32_t* qd_idf; uint32_t* q_meta; uint2* idf_tab;
-};
-
-// One workgroup: reduce the frame's word slots to (unique word, count) with an LDS hash table (linear probing, atomicCAS),
-// optionally append them to the bucket log as the postings of signature `slot` (nw += 1 each), and leave the word / idf /
-// dense-id lists plus the per-word idf table (idf_tab[w] = {stamp, idf}) for the scoring kernel.
-// The list order is whatever the table yields: nothing downstream depends on it (integer accumulation).
-// LDS: 2 * H + H / 64 + 4 words.
-// SOLE: this workgroup is the only writer of the bucket's log right now (the frame path: one frame at a time on one stream), so the
-// log position is read at the start and written back at the end instead of being reserved with a returning atomic in the middle.
-// src_lds: the word slots in LDS (left there by the decision loop of the same kernel) instead of a.src.
-template <int NT, bool SOLE>
-__device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs& a, const int32_t* src_lds = nullptr) {
-    const int H = a.H;
-    uint32_t* tkey = fw_smem;            // [H] 0xFFFFFFFF = empty
-    uint32_t* tcnt = fw_smem + H;        // [H]
-    uint32_t* grp = tcnt + H;            // [H / 64 + 1]
-    uint32_t* s_misc = grp + H / 64 + 1; // [0] log base, [1] dense list length
-    const int tid = threadIdx.x;
-    for (int i = tid; i < H; i += NT) { tkey[i] = 0xFFFFFFFFu; tcnt[i] = 0u; }
-    if (tid == 0) { s_misc[0] = (SOLE && a.do_register) ? a.ne_counter[0] : 0u; s_misc[1] = 0u; }
-    __syncthreads();
-    for (int i = tid; i < a.n; i += NT) {
-        int32_t ws = src_lds ? src_lds[i] : a.src[i];
-        if (a.xlate) ws = (ws > 0 && (long long)ws < a.xlate_n) ? a.xlate[ws] : -1;
-        if (ws < 0) continue;
-        const uint32_t w = (uint32_t)ws;
-        uint32_t h = (w * 2654435761u) & (uint32_t)(H - 1);
-        for (;;) {
-            const uint32_t old = atomicCAS(&tkey[h], 0xFFFFFFFFu, w);
-            if (old == 0xFFFFFFFFu || old == w) { atomicAdd(&tcnt[h], 1u); break; }
-            h = (h + 1) & (uint32_t)(H - 1);
-        }
-    }
-    __syncthreads();
-    // compact the occupied table entries: ballot per 64-entry group, group offsets scanned by one thread
-    const int ng = H / 64;
-    for (int i0 = 0; i0 < H; i0 += NT) {
-        const int i = i0 + tid;
-        const bool occ = i < H && tkey[i] != 0xFFFFFFFFu;
-        const unsigned long long bal = __ballot(occ);
-        if ((tid & 63) == 0 && i < H) grp[i >> 6] = (uint32_t)__popcll(bal);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int g = 0; g < ng; ++g) { const uint32_t c = grp[g]; grp[g] = run; run += c; }
-        grp[ng] = run;
-        if (a.do_register && !SOLE) s_misc[0] = atomicAdd(a.ne_counter, run);   // reserve the signature's stretch of the log
-    }
-    __syncthreads();
-    const uint32_t U = grp[ng];
-    const uint32_t base = s_misc[0];
-    for (int i0 = 0; i0 < H; i0 += NT) {
-        const int i = i0 + tid;
-        const bool occ = i < H && tkey[i] != 0xFFFFFFFFu;
-        const unsigned long long bal = __ballot(occ);
-        if (!occ) continue;
-        const uint32_t u = grp[i >> 6] + (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
-        const uint32_t w = tkey[i];
-        uint32_t cnt = tcnt[i];
-        if (cnt > TF_CNT_MASK) cnt = TF_CNT_MASK;
-        uint32_t nwv;
-        if (a.do_register) {
-            nwv = atomicAdd(&a.nw[w], 1u) + 1u;
-            a.coo_w[base + u] = w;
-            a.coo_pc[base + u] = (a.slot_local << TF_CNT_BITS) | cnt;
-        } else {
-            nwv = a.nw[w];
-        }
-        if (a.want_q) {
-            float idf = 0.0f;
-            if (a.N > 0.0f && nwv > 0u) idf = log10f(__fdiv_rn(a.N, (float)nwv));   // Memory.cpp:2264-2266
-            const int32_t idfq = idf_to_fixed(idf);
-            const int32_t d = a.did[w];
-            a.q_w[u] = w;
-            a.q_idf[u] = idfq;
-            a.q_did[u] = d;
-            a.idf_tab[w] = make_uint2(a.stamp, (uint32_t)idfq);
-            if (d >= 0 && idfq != 0) {                                   // "if(logNnw)" (Memory.cpp:2267)
-                const uint32_t j = atomicAdd(&s_misc[1], 1u);
-                a.qd_did[j] = d;
-                a.qd_idf[j] = idfq;
-            }
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        if (a.want_q) { a.q_meta[0] = U; a.q_meta[1] = s_misc[1]; }
-        if (a.do_register) {
-            if (SOLE) a.ne_counter[0] = base + U;
-            a.slot_sig[a.slot] = a.sig_id;
-            a.slot_ni[a.slot] = a.ni;
-            a.slot_begin[a.slot] = base;
-            a.slot_cnt[a.slot] = U;
-        }
-    }
-}
-
-// signatures whose retirement was requested since the last frame (Memory::disableWordsRef -> removeAllWordRef): their
-// words lose one reference each and the slot is marked dead (ni = 0).  Up to 4 ride along with the next frame-words launch.
-struct RetireArgs { long long slot[4]; const uint32_t* coo_w[4]; int n; };
-__device__ __forceinline__ void retire_body(const RetireArgs& r, const uint32_t* __restrict__ slot_begin, const uint32_t* __restrict__ slot_cnt,
-                                            uint32_t* __restrict__ nw, uint32_t* __restrict__ slot_ni, int32_t* __restrict__ slot_sig) {
-    for (int p = 0; p < r.n; ++p) {
-        const long long slot = r.slot[p];
-        const uint32_t begin = slot_begin[slot], cnt = slot_cnt[slot];
-        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) atomicSub(&nw[r.coo_w[p][begin + k]], 1u);
-        if (threadIdx.x == 0) { slot_ni[slot] = 0u; slot_sig[slot] = 0; }
-    }
-}
-
 __global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(FwArgs a, RetireArgs retire) {
     extern __shared__ uint32_t fw_dyn_smem[];
     retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
@@ -203,41 +62,10 @@ __global__ __launch_bounds__(FW_BLOCK) void frame_words_kernel(FwArgs a, RetireA
     frame_words_body<FW_BLOCK, true>(fw_dyn_smem, a);
 }
 
-#ifdef LCD_TAIL_TIMING   // timing experiment only: 100 MHz stamps between the phases of the frame tail
-__device__ unsigned long long g_tail_timing[8];
-#define FT_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_tail_timing[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define FT_STAMP(i) do { } while (0)
-#endif
-
-// The single-workgroup tail of a frame in ONE launch: addNewWords decision loop (resolve_body.cuh) -> pending retirements
-// -> unique words / registration / idf (frame_words_body).  Saves two dependent kernel boundaries per frame.
+// The single-workgroup tail of a frame in ONE launch (frame_tail_body.cuh); workgroups 1.. are the exact redo of rejected queries
 __global__ __launch_bounds__(FW_BLOCK) void frame_tail_kernel(ResolveArgs r, FwArgs a, RetireArgs retire) {
     extern __shared__ uint32_t ft_dyn_smem[];
-    // workgroups 1.. : the exact redo of the queries the 2-NN certificate rejected (they leave at once when there are none, which
-    // is the usual case: no launch of its own for that check).  Workgroup 0 waits for them only when something was rejected.
-    if (blockIdx.x > 0) { rowpar_body<64, FW_BLOCK>(r.rp, (int)blockIdx.x - 1, (int)gridDim.x - 1, r.fail_count); return; }
-    if (r.rp.enabled && gridDim.x > 1) {
-        if (threadIdx.x == 0 && r.fail_count[0] > 0) {
-            while (__hip_atomic_load(&r.fail_count[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-    }
-    FT_STAMP(0);
-    // frames of up to 1024 descriptors: the register-resident decision loop, its result handed to the registration through LDS
-    int32_t* lds_ws = r.q <= RBLOCK ? (int32_t*)(ft_dyn_smem + 2 * a.H + a.H / 64 + 8) : nullptr;
-    if (lds_ws) resolve_body_fast(ft_dyn_smem, lds_ws, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits,
-                                  r.bw, r.out_word, r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
-    else resolve_body(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
-                      r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
-    if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; r.fail_count[3] = 0; }
-    FT_STAMP(1);
-    retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
-    __syncthreads();      // out_wslot (global or LDS, written by this workgroup) and the LDS region are handed over
-    FT_STAMP(2);
-    frame_words_body<FW_BLOCK, true>(ft_dyn_smem, a, lds_ws);
-    FT_STAMP(3);
+    frame_tail_body<FW_BLOCK>(ft_dyn_smem, r, a, retire, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------- bulk registration
@@ -267,247 +95,6 @@ __global__ __launch_bounds__(BR_BLOCK) void bulk_register_kernel(const int32_t* 
     a.slot_sig = slot_sig; a.slot_ni = slot_ni; a.slot_begin = slot_begin; a.slot_cnt = slot_cnt;
     a.q_w = nullptr; a.q_idf = nullptr; a.q_did = nullptr; a.qd_did = nullptr; a.qd_idf = nullptr; a.q_meta = nullptr; a.idf_tab = nullptr;
     frame_words_body<BR_BLOCK, false>(br_dyn_smem, a);
-}
-
-// ---------------------------------------------------------------------------------------------- scoring
-#ifdef LCD_SCORE_TIMING   // timing experiment only: 100 MHz stamps between the phases of score_sealed_body, per workgroup
-__device__ unsigned long long g_score_timing[1024 * 8];
-#define SC_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 1024) g_score_timing[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define SC_STAMP(i) do { } while (0)
-#endif
-
-struct ScoreArgs {
-    const BucketDev* tab; const uint32_t* bkt_D; const uint32_t* bkt_flags;
-    int n_closed;                           // buckets [0, n_closed) are sealed or dead; bucket n_closed (if any) is the open one
-    int n_open_slots; int wcap;
-    const uint32_t* q_w; const int32_t* q_idf; const int32_t* q_did; const int32_t* qd_did; const int32_t* qd_idf; const uint32_t* q_meta;
-    const uint32_t* slot_ni; const uint32_t* slot_begin; const uint32_t* slot_cnt;
-    const uint2* idf_tab; uint32_t stamp;
-    float* out_like; long long* out_fix;    // exactly one is non-NULL
-};
-
-// One workgroup scores one sealed bucket (256 signatures).
-//   dense rows : wavefront v takes the frame's dense words v, v + NWV, ...; a lane reads the four counts of its four signatures
-//                with one 4-byte load (the wavefront reads the 256-byte row in one coalesced request) and keeps four 64-bit
-//                sums in registers; all loads of a trip are issued before any is consumed;
-//   sparse part: one thread per frame word looks the word up in the bucket's directory (one 8-byte read; a second one for the
-//                offsets when the word is present).  The segments of the 64 words of a wavefront are then walked by that
-//                wavefront alone: lane-wise inclusive scan of the lengths, every lane finds the segment of "its" posting with six
-//                cross-lane reads (no LDS arrays, no workgroup barrier, no per-workgroup scan) and adds count x idf with an LDS
-//                64-bit atomic;
-//   output     : acc / ni, written straight from LDS.
-// The whole body is a chain of dependent global reads (word list -> directory block -> segment offsets -> postings; dense list
-// -> rows): every wavefront issues ALL independent loads of a stage before it consumes any of them (loads return in order, so
-// waiting for an older one leaves the younger ones in flight).  LDS: acc[256] i64 | ni[256] (3 KB, static).
-template <int SCB>
-__device__ __forceinline__ void score_segments(const uint32_t* __restrict__ sp_ent, unsigned long long* acc, uint32_t start, uint32_t len, int32_t idf) {
-    const int ln = threadIdx.x & 63;
-    uint32_t incl = len;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(incl, off, 64); if (ln >= off) incl += y; }
-    const uint32_t Tw = __shfl(incl, 63, 64);                       // wave-uniform
-    for (uint32_t t0 = 0; t0 < Tw; t0 += 128) {
-        uint32_t e[2]; int32_t f[2]; bool ok[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t t = t0 + (uint32_t)(u * 64 + ln);
-            int pos = 0;                                            // number of lanes whose inclusive sum is <= t = the owner of posting t
-#pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) { const uint32_t v = __shfl(incl, pos + step - 1, 64); if (v <= t) pos += step; }
-            if (pos > 63) pos = 63;
-            const uint32_t i_o = __shfl(incl, pos, 64), l_o = __shfl(len, pos, 64), s_o = __shfl(start, pos, 64);
-            f[u] = __shfl(idf, pos, 64);
-            ok[u] = t < Tw;
-            e[u] = ok[u] ? gload(sp_ent + s_o + (t - (i_o - l_o))) : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (!ok[u]) continue;
-            const long long term = (long long)(int)(e[u] & TF_CNT_MASK) * (long long)f[u];
-            atomicAdd(&acc[e[u] >> TF_CNT_BITS], (unsigned long long)term);      // ds_add_u64
-        }
-    }
-}
-
-template <int SCB>
-__device__ __forceinline__ void score_sealed_body(const ScoreArgs& A, int b) {
-    __shared__ unsigned long long acc[TF_R];
-    const int tid = threadIdx.x;
-    const BucketDev B = A.tab[b];
-    const long long first_slot = (long long)b * TF_R;
-    if (B.state != 1u) {                                            // every signature of the bucket is retired
-        for (int i = tid; i < TF_R; i += SCB) {
-            if (A.out_like) A.out_like[first_slot + i] = 0.0f; else A.out_fix[first_slot + i] = 0;
-        }
-        return;
-    }
-    SC_STAMP(0);
-    constexpr int NWV = SCB / 64;
-    constexpr int DR = 128 / NWV > 16 ? 16 : 128 / NWV;            // dense rows per wavefront and trip
-    constexpr int KW = SCB >= 512 ? 1 : 512 / SCB;                  // frame words per thread in the fused first pass
-    constexpr int NI = TF_R / SCB > 0 ? TF_R / SCB : 1;             // signatures whose ni a thread carries
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
-    const uint32_t D = A.bkt_D[b];
-    const uint32_t flags = A.bkt_flags[b];
-    const int U = (int)A.q_meta[0];
-    const int Ud = (int)A.q_meta[1];
-    // ---- stage A: the frame's lists (L2-resident: every workgroup reads the same few KB), ni
-    uint32_t w[KW]; int32_t idf[KW], did[KW]; bool look[KW];
-#pragma unroll
-    for (int u = 0; u < KW; ++u) {
-        const int k = tid + u * SCB;
-        w[u] = 0; idf[u] = 0; did[u] = -1;
-        if (k < U) { w[u] = A.q_w[k]; idf[u] = A.q_idf[k]; did[u] = A.q_did[k]; }
-    }
-    int32_t dj[DR], fj[DR];
-#pragma unroll
-    for (int u = 0; u < DR; ++u) {
-        const int j = wv + u * NWV;                                  // wave-uniform: scalar loads
-        dj[u] = j < Ud ? A.qd_did[j] : -1;
-        fj[u] = j < Ud ? A.qd_idf[j] : 0;
-    }
-    uint32_t ni_v[NI];
-#pragma unroll
-    for (int u = 0; u < NI; ++u) { const int i = tid + u * SCB; ni_v[u] = i < TF_R ? A.slot_ni[first_slot + i] : 0u; }
-    // ---- stage B: directory blocks of the sparse words, dense rows
-    uint2 blk[KW];
-#pragma unroll
-    for (int u = 0; u < KW; ++u) {
-        const bool dense_here = did[u] >= 0 && (uint32_t)did[u] < D;
-        look[u] = idf[u] != 0 && w[u] < B.W && (!dense_here || (flags & 1u));   // a dense word has sparse postings only for counts > 255
-        blk[u] = make_uint2(0u, 0u);
-        if (look[u]) blk[u] = gload2(B.dirb + (w[u] >> 5));
-    }
-    uint32_t c[DR];
-#pragma unroll
-    for (int u = 0; u < DR; ++u) c[u] = (dj[u] >= 0 && (uint32_t)dj[u] < D) ? gload((const uint32_t*)(B.dense + (size_t)dj[u] * TF_R + 4 * ln)) : 0u;
-    // ---- stage C: segment offsets of the words that are present
-    uint32_t start[KW], len[KW];
-#pragma unroll
-    for (int u = 0; u < KW; ++u) {
-        start[u] = 0; len[u] = 0;
-        const uint32_t bit = 1u << (w[u] & 31);
-        if (look[u] && (blk[u].x & bit)) {
-            const uint32_t r = blk[u].y + (uint32_t)__popc(blk[u].x & (bit - 1u));
-            const uint32_t s0 = gload(B.sp_off + r), s1 = gload(B.sp_off + r + 1);
-            start[u] = s0; len[u] = s1 - s0;
-        }
-    }
-    // the dense rows: a lane owns four signatures
-    long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll
-    for (int u = 0; u < DR; ++u) {
-        const long long f64 = (long long)fj[u];
-        a0 += (long long)(int)(c[u] & 255u) * f64;
-        a1 += (long long)(int)((c[u] >> 8) & 255u) * f64;
-        a2 += (long long)(int)((c[u] >> 16) & 255u) * f64;
-        a3 += (long long)(int)(c[u] >> 24) * f64;
-    }
-    for (int j0 = wv + DR * NWV; j0 < Ud; j0 += DR * NWV) {           // frames with more than 128 dense words
-#pragma unroll
-        for (int u = 0; u < DR; ++u) {
-            const int j = j0 + u * NWV;
-            dj[u] = j < Ud ? A.qd_did[j] : -1;
-            fj[u] = j < Ud ? A.qd_idf[j] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < DR; ++u) c[u] = (dj[u] >= 0 && (uint32_t)dj[u] < D) ? gload((const uint32_t*)(B.dense + (size_t)dj[u] * TF_R + 4 * ln)) : 0u;
-#pragma unroll
-        for (int u = 0; u < DR; ++u) {
-            const long long f64 = (long long)fj[u];
-            a0 += (long long)(int)(c[u] & 255u) * f64;
-            a1 += (long long)(int)((c[u] >> 8) & 255u) * f64;
-            a2 += (long long)(int)((c[u] >> 16) & 255u) * f64;
-            a3 += (long long)(int)(c[u] >> 24) * f64;
-        }
-    }
-    for (int i = tid; i < TF_R; i += SCB) acc[i] = 0ull;
-    __syncthreads();                                                 // accumulators zeroed
-    SC_STAMP(1);
-    {
-        const int ln4 = ln * 4;
-        if (a0) atomicAdd(&acc[ln4 + 0], (unsigned long long)a0);
-        if (a1) atomicAdd(&acc[ln4 + 1], (unsigned long long)a1);
-        if (a2) atomicAdd(&acc[ln4 + 2], (unsigned long long)a2);
-        if (a3) atomicAdd(&acc[ln4 + 3], (unsigned long long)a3);
-    }
-    SC_STAMP(2);
-    // ---- sparse postings, wavefront by wavefront
-#pragma unroll
-    for (int u = 0; u < KW; ++u) score_segments<SCB>(B.sp_ent, acc, start[u], len[u], idf[u]);
-    for (int k0 = KW * SCB; k0 < U; k0 += SCB) {                     // frames with more than 512 unique words
-        const int k = k0 + tid;
-        uint32_t st2 = 0, ln2 = 0; int32_t idf2 = 0;
-        if (k < U) {
-            const uint32_t w2 = A.q_w[k];
-            idf2 = A.q_idf[k];
-            const int32_t d2 = A.q_did[k];
-            const bool dh = d2 >= 0 && (uint32_t)d2 < D;
-            if (idf2 != 0 && w2 < B.W && (!dh || (flags & 1u))) {
-                const uint2 bk = gload2(B.dirb + (w2 >> 5));
-                const uint32_t bit = 1u << (w2 & 31);
-                if (bk.x & bit) {
-                    const uint32_t r = bk.y + (uint32_t)__popc(bk.x & (bit - 1u));
-                    st2 = gload(B.sp_off + r);
-                    ln2 = gload(B.sp_off + r + 1) - st2;
-                }
-            }
-        }
-        score_segments<SCB>(B.sp_ent, acc, st2, ln2, idf2);
-    }
-    __syncthreads();
-    SC_STAMP(3);
-#pragma unroll
-    for (int u = 0; u < NI; ++u) {
-        const int i = tid + u * SCB;
-        if (i >= TF_R) continue;
-        const long long v = (long long)acc[i];
-        if (A.out_like) A.out_like[first_slot + i] = fixed_to_like(v, ni_v[u]);
-        else A.out_fix[first_slot + i] = ni_v[u] ? v : 0;
-    }
-}
-
-// The bucket that is still filling (<= 256 signatures): one wavefront per signature walks the signature's own stretch of the
-// arrival-order log, keeps the postings whose word belongs to the frame (idf_tab stamp) and reduces them inside the wave --
-// no atomics, no second pass, every slot written exactly once.
-template <int SCB>
-__device__ __forceinline__ void score_open_body(const ScoreArgs& A, int ob) {
-    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    const int sl = ob * (SCB / 64) + wv;
-    if (sl >= A.n_open_slots) return;
-    const BucketDev B = A.tab[A.n_closed];
-    const long long slot = (long long)A.n_closed * TF_R + sl;
-    const uint32_t begin = A.slot_begin[slot], cnt = A.slot_cnt[slot], ni = A.slot_ni[slot];
-    long long acc = 0;
-    if (ni != 0u) {
-        for (uint32_t e0 = 0; e0 < cnt; e0 += 4 * 64) {
-            uint32_t w[4], pc[4]; uint2 t[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t e = e0 + u * 64 + ln;
-                w[u] = e < cnt ? gload(B.coo_w + begin + e) : 0xFFFFFFFFu;
-                pc[u] = e < cnt ? gload(B.coo_pc + begin + e) : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) t[u] = A.idf_tab[w[u] != 0xFFFFFFFFu ? w[u] : 0u];      // unconditional: four loads in flight
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (w[u] != 0xFFFFFFFFu && t[u].x == A.stamp) acc += (long long)(int)(pc[u] & TF_CNT_MASK) * (long long)(int32_t)t[u].y;
-        }
-    }
-    int lo = (int)(uint32_t)acc, hi = (int)(acc >> 32);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int olo = __shfl_xor(lo, off, 64), ohi = __shfl_xor(hi, off, 64);
-        const long long s = (((long long)hi << 32) | (uint32_t)lo) + (((long long)ohi << 32) | (uint32_t)olo);
-        lo = (int)(uint32_t)s; hi = (int)(s >> 32);
-    }
-    if (ln == 0) {
-        const long long v = ((long long)hi << 32) | (uint32_t)lo;
-        if (A.out_like) A.out_like[slot] = fixed_to_like(v, ni);
-        else A.out_fix[slot] = ni ? v : 0;
-    }
 }
 
 // every closed bucket (dead ones write zeros) and the open bucket in ONE launch, likelihood (or the integer sums) written directly
@@ -1314,7 +901,7 @@ hipError_t Tfidf::flush_retire() {
 }
 
 static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool ids_given, bool reg, int32_t sig_id, int64_t slot, int32_t ni,
-                                  float N, const ResolveArgs* resolve) {
+                                  float N, const ResolveArgs* resolve, TailLaunch* defer) {
     const int H = next_pow2(std::max(2 * n, 128));
     size_t shmem = ((size_t)H * 2 + H / 64 + 8) * 4;
     if (ids_given) TF_TRY(t.sync_id2ws());
@@ -1343,7 +930,13 @@ static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool id
         a.src = resolve->out_wslot;
         const int mw = (resolve->q + 63) / 64 * 2;
         shmem = std::max(shmem, (size_t)(3 * mw + 2) * 4) + (size_t)n * 4;    // + the word slots handed over in LDS
-        const int n_redo = (resolve->rp.enabled && resolve->fail_count) ? (resolve->rp.n_rows + FW_BLOCK - 1) / FW_BLOCK : 0;
+        const int block = defer ? pipe_block_size() : FW_BLOCK;
+        const int n_redo = (resolve->rp.enabled && resolve->fail_count) ? (resolve->rp.n_rows + block - 1) / block : 0;
+        if (defer) {                                                    // launched later, inside the next frame's filter launch
+            defer->r = *resolve; defer->a = a; defer->ret = ret; defer->n_redo = n_redo; defer->shmem = shmem;
+            t.q_n_ub = n;
+            return hipSuccess;
+        }
         frame_tail_kernel<<<1 + n_redo, FW_BLOCK, shmem, t.stream>>>(*resolve, a, ret);
     } else {
         frame_words_kernel<<<1, FW_BLOCK, shmem, t.stream>>>(a, ret);
@@ -1352,7 +945,9 @@ static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool id
     return hipGetLastError();
 }
 
-hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N, const ResolveArgs* resolve, bool ids_given) {
+hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N, const ResolveArgs* resolve, bool ids_given,
+                               TailLaunch* defer) {
+    if (defer && !resolve) return hipErrorInvalidValue;
     if (n > TF_MAX_WORDS) return hipErrorInvalidValue;
     const int64_t slot = n_slots;
     TF_TRY(ensure_slots(slot + 1));
@@ -1363,7 +958,7 @@ hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, i
     }
     Bucket& b = buckets[bi];
     TF_TRY(ensure_log(*this, bi, b.ub_entries + n));
-    TF_TRY(run_frame_words(*this, d_wslots, n, ids_given, true, sig_id, slot, ni, N, resolve));
+    TF_TRY(run_frame_words(*this, d_wslots, n, ids_given, true, sig_id, slot, ni, N, resolve, defer));
     b.ub_entries += n;
     b.n_slots += 1;
     b.live += 1;
@@ -1374,9 +969,9 @@ hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, i
     return hipSuccess;
 }
 
-hipError_t Tfidf::query_dev(const int32_t* d_wslots, int n, float N, const ResolveArgs* resolve, bool ids_given) {
-    if (n > TF_MAX_WORDS) return hipErrorInvalidValue;
-    return run_frame_words(*this, d_wslots, n, ids_given, false, 0, 0, 0, N, resolve);
+hipError_t Tfidf::query_dev(const int32_t* d_wslots, int n, float N, const ResolveArgs* resolve, bool ids_given, TailLaunch* defer) {
+    if (n > TF_MAX_WORDS || (defer && !resolve)) return hipErrorInvalidValue;
+    return run_frame_words(*this, d_wslots, n, ids_given, false, 0, 0, 0, N, resolve, defer);
 }
 
 hipError_t Tfidf::register_bulk(int n_sigs, const int32_t* sig_ids, const int64_t* offsets, const int32_t* ni, const int32_t* d_ids,
@@ -1432,11 +1027,12 @@ hipError_t Tfidf::register_bulk(int n_sigs, const int32_t* sig_ids, const int64_
     return hipSuccess;
 }
 
-hipError_t Tfidf::launch_score(float* d_likelihood, long long* lfix) {
+hipError_t Tfidf::score_args(float* d_likelihood, long long* lfix, int block, ScoreArgs* out, int* n_wgs) {
+    *n_wgs = 0;
     if (n_slots == 0) return hipSuccess;
     TF_TRY(flush_retire());
     const bool has_open = !buckets.empty() && buckets.back().state == 0;
-    ScoreArgs A;
+    ScoreArgs& A = *out;
     A.tab = bkt_tab.as<BucketDev>(); A.bkt_D = bkt_D.as<uint32_t>(); A.bkt_flags = bkt_flags.as<uint32_t>();
     A.n_closed = (int)buckets.size() - (has_open ? 1 : 0);
     A.n_open_slots = has_open ? buckets.back().n_slots : 0;
@@ -1446,9 +1042,15 @@ hipError_t Tfidf::launch_score(float* d_likelihood, long long* lfix) {
     A.slot_ni = slot_ni.as<uint32_t>(); A.slot_begin = slot_begin.as<uint32_t>(); A.slot_cnt = slot_cnt.as<uint32_t>();
     A.idf_tab = idf_tab.as<uint2>(); A.stamp = stamp;
     A.out_like = d_likelihood; A.out_fix = lfix;
+    *n_wgs = A.n_closed + (A.n_open_slots + block / 64 - 1) / (block / 64);
+    return hipSuccess;
+}
+
+hipError_t Tfidf::launch_score(float* d_likelihood, long long* lfix) {
     const int scb = score_block == 256 || score_block == 1024 ? score_block : 512;
-    const int open_blocks = (A.n_open_slots + scb / 64 - 1) / (scb / 64);
-    const int grid = A.n_closed + open_blocks;
+    ScoreArgs A;
+    int grid = 0;
+    TF_TRY(score_args(d_likelihood, lfix, scb, &A, &grid));
     if (grid == 0) return hipSuccess;
     if (prof_b) TF_TRY(hipEventRecord(prof_b, stream));
     if (scb == 256) score_kernel<256><<<grid, 256, 0, stream>>>(A);
