@@ -70,8 +70,8 @@ __device__ __forceinline__ int new_rank(const uint32_t* mask, const uint32_t* pr
     return (int)(prefix[j >> 5] + __popc(mask[j >> 5] & ((1u << (j & 31)) - 1u)));
 }
 
-// The same decision loop for frames of at most NT (= workgroup size) descriptors (one descriptor per thread), latency-trimmed: the kernel this
-// runs in is ONE workgroup on the critical path of every frame, so what counts is the number of dependent global round trips.
+// The same decision loop for frames of at most KPT * NT descriptors (KPT descriptors per thread, NT = workgroup size),
+// latency-trimmed: the kernel this runs in is ONE workgroup per frame, so what counts is the number of dependent global round trips.
 //   * the indexed neighbours, their vocabulary rows and the descriptor's candidate-bit row are read ONCE, all loads in flight
 //     together; the postings keys of both neighbours are requested before the sweeps and consumed after them;
 //   * the bit row is kept as at most four non-zero (word, bits) pairs in registers (rows with more fall back to memory): a
@@ -79,7 +79,7 @@ __device__ __forceinline__ int new_rank(const uint32_t* mask, const uint32_t* pr
 //     costs it nothing; the winner of a sweep lives in a register, not in out_word;
 //   * the result is also left in LDS (lds_wslot, may be NULL) for the registration that follows in the same kernel.
 // Same results as resolve_body (tests drive both).  rs_smem as below.
-template <int NT>
+template <int NT, int KPT>
 __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* lds_wslot, int q, int flags, float nndr, int have_index,
                                                   const int32_t* __restrict__ knn_word, const float* __restrict__ knn_dist,
                                                   const float* __restrict__ selfdist, int ld,
@@ -97,108 +97,136 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
     const bool incremental = (flags & LCD_Q_INCREMENTAL) != 0;
     const bool together = incremental && (flags & LCD_Q_NEW_WORDS_COMPARED) && cand_bits != nullptr;
     const int qpad = mw * 32;
-    const int i = tid;
-    const bool valid = i < q;
+    struct Dsc {
+        int w0, w1; int32_t ws_a, ws_b;
+        Cand b0, b1; int nb;
+        int nzw[4]; uint32_t nzb[4]; int nz; bool overflow;
+        bool reject; int win;
+    };
+    Dsc st[KPT];
     RB_STAMP(0);
-    // ---- round trip 1: indexed neighbours + their rows, the bit row
-    float d0 = -1.0f, d1 = -1.0f; int w0 = 0, w1 = 0, r0 = -1, r1 = -1;
-    if (valid && have_index) {
-        const float2 dd = *reinterpret_cast<const float2*>(knn_dist + 2 * i);
-        const int2 ww = *reinterpret_cast<const int2*>(knn_word + 2 * i);
-        d0 = dd.x; d1 = dd.y; w0 = ww.x; w1 = ww.y;
-        if (out_wslot || lds_wslot) { const int2 rr = *reinterpret_cast<const int2*>(knn_row + 2 * i); r0 = rr.x; r1 = rr.y; }
+    // ---- round trip 1: indexed neighbours + their rows (all descriptors of the thread in flight together)
+    float d0[KPT], d1[KPT]; int r0[KPT], r1[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int i = tid + k * NT;
+        d0[k] = -1.0f; d1[k] = -1.0f; st[k].w0 = 0; st[k].w1 = 0; r0[k] = -1; r1[k] = -1;
+        if (i < q && have_index) {
+            const float2 dd = *reinterpret_cast<const float2*>(knn_dist + 2 * i);
+            const int2 ww = *reinterpret_cast<const int2*>(knn_word + 2 * i);
+            d0[k] = dd.x; d1[k] = dd.y; st[k].w0 = ww.x; st[k].w1 = ww.y;
+            if (out_wslot || lds_wslot) { const int2 rr = *reinterpret_cast<const int2*>(knn_row + 2 * i); r0[k] = rr.x; r1[k] = rr.y; }
+        }
     }
-    int nzw[4]; uint32_t nzb[4]; int nz = 0; bool overflow = false;
+    // ---- the candidate-bit rows
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { nzw[e] = 0; nzb[e] = 0u; }
-    if (together && valid) {
-        const int wlast = i >> 5;
-        for (int wb = 0; wb <= wlast; wb += 8) {
-            uint32_t v[8];
+    for (int k = 0; k < KPT; ++k) {
+        const int i = tid + k * NT;
+        Dsc& S = st[k];
+        S.nz = 0; S.overflow = false;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (wb + u <= wlast) ? cand_bits[(size_t)i * bw + wb + u] : 0u;
+        for (int e = 0; e < 4; ++e) { S.nzw[e] = 0; S.nzb[e] = 0u; }
+        if (together && i < q) {
+            const int wlast = i >> 5;
+            for (int wb = 0; wb <= wlast; wb += 8) {
+                uint32_t v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                uint32_t m = v[u];
-                if (wb + u == wlast) m &= (1u << (i & 31)) - 1u;       // only j < i
-                if (m) {
-                    if (nz < 4) {
+                for (int u = 0; u < 8; ++u) v[u] = (wb + u <= wlast) ? cand_bits[(size_t)i * bw + wb + u] : 0u;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (e == nz) { nzw[e] = wb + u; nzb[e] = m; }
-                        ++nz;
-                    } else overflow = true;
+                for (int u = 0; u < 8; ++u) {
+                    uint32_t m = v[u];
+                    if (wb + u == wlast) m &= (1u << (i & 31)) - 1u;       // only j < i
+                    if (m) {
+                        if (S.nz < 4) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (e == S.nz) { S.nzw[e] = wb + u; S.nzb[e] = m; }
+                            ++S.nz;
+                        } else S.overflow = true;
+                    }
                 }
             }
         }
     }
-    // ---- the indexed candidates (they do not change from sweep to sweep), :1092-1137: stop at the first invalid neighbour
-    Cand b0, b1; int nb = 0;
-    b0.d = 0.f; b0.id = 0; b1.d = 0.f; b1.id = 0;
-    if (valid && have_index) {
-        if (d0 >= 0.0f && w0 != 0) { cand_push(b0, b1, nb, d0, w0); if (d1 >= 0.0f && w1 != 0) cand_push(b0, b1, nb, d1, w1); }
-    }
-    // ---- round trip 2 (requested now, consumed after the sweeps): postings keys of both neighbours
-    int32_t ws_a = -1, ws_b = -1;
-    if (valid && (out_wslot || lds_wslot)) {
-        if (r0 >= 0) ws_a = row_wslot ? row_wslot[r0] : r0;
-        if (r1 >= 0) ws_b = row_wslot ? row_wslot[r1] : r1;
+    // ---- the indexed candidates (they do not change from sweep to sweep), :1092-1137: stop at the first invalid neighbour;
+    //      round trip 2 (requested now, consumed after the sweeps): postings keys of both neighbours
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int i = tid + k * NT;
+        Dsc& S = st[k];
+        S.nb = 0; S.b0.d = 0.f; S.b0.id = 0; S.b1.d = 0.f; S.b1.id = 0;
+        if (i < q && have_index) {
+            if (d0[k] >= 0.0f && S.w0 != 0) { cand_push(S.b0, S.b1, S.nb, d0[k], S.w0); if (d1[k] >= 0.0f && S.w1 != 0) cand_push(S.b0, S.b1, S.nb, d1[k], S.w1); }
+        }
+        S.ws_a = -1; S.ws_b = -1;
+        if (i < q && (out_wslot || lds_wslot)) {
+            if (r0[k] >= 0) S.ws_a = row_wslot ? row_wslot[r0[k]] : r0[k];
+            if (r1[k] >= 0) S.ws_b = row_wslot ? row_wslot[r1[k]] : r1[k];
+        }
+        S.reject = i < q && incremental && (S.nb < 2 || S.b0.d > nndr * S.b1.d);
+        S.win = S.nb > 0 ? S.b0.id : 0;
     }
     RB_STAMP(1);
-    bool reject = valid && incremental && (nb < 2 || b0.d > nndr * b1.d);
-    int win = nb > 0 ? b0.id : 0;
-    if (i < qpad) {
-        const unsigned long long bal = __ballot(reject);
-        if (lane == 0) { mask_cur[i >> 5] = (uint32_t)bal; mask_cur[(i >> 5) + 1] = (uint32_t)(bal >> 32); }
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int i = tid + k * NT;
+        if (i < qpad) {
+            const unsigned long long bal = __ballot(st[k].reject);
+            if (lane == 0) { mask_cur[i >> 5] = (uint32_t)bal; mask_cur[(i >> 5) + 1] = (uint32_t)(bal >> 32); }
+        }
     }
     __syncthreads();
     RB_STAMP(2);
     if (together) {
-        const bool dyn = valid && (nz > 0 || overflow);                // only these descriptors can change their mind
         for (int sweep = 0; sweep <= q; ++sweep) {
             if (tid == 0) s_changed_f = 0;
             __syncthreads();
-            if (dyn) {
-                Cand c0 = b0, c1 = b1; int n = nb;
-                uint64_t b = KEY_NONE, sk = KEY_NONE;
-                if (!overflow) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        uint32_t m = e < nz ? (nzb[e] & mask_cur[nzw[e]]) : 0u;
-                        while (m) {
-                            const int j = (nzw[e] << 5) + __builtin_ctz(m);
-                            m &= m - 1;
-                            const uint64_t k = ((uint64_t)__float_as_uint(selfdist[(size_t)j * ld + i]) << 32) | (uint32_t)j;
-                            const uint64_t hi = b > k ? b : k;
-                            b = b < k ? b : k;
-                            sk = sk < hi ? sk : hi;
+            for (int k = 0; k < KPT; ++k) {
+                const int i = tid + k * NT;
+                Dsc& S = st[k];
+                if (i < q && (S.nz > 0 || S.overflow)) {                   // only these descriptors can change their mind
+                    Cand c0 = S.b0, c1 = S.b1; int n = S.nb;
+                    uint64_t b = KEY_NONE, sk = KEY_NONE;
+                    if (!S.overflow) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            uint32_t m = e < S.nz ? (S.nzb[e] & mask_cur[S.nzw[e]]) : 0u;
+                            while (m) {
+                                const int j = (S.nzw[e] << 5) + __builtin_ctz(m);
+                                m &= m - 1;
+                                const uint64_t key = ((uint64_t)__float_as_uint(selfdist[(size_t)j * ld + i]) << 32) | (uint32_t)j;
+                                const uint64_t hi = b > key ? b : key;
+                                b = b < key ? b : key;
+                                sk = sk < hi ? sk : hi;
+                            }
+                        }
+                    } else {
+                        const int wlast = i >> 5;
+                        for (int w = 0; w <= wlast; ++w) {
+                            uint32_t m = cand_bits[(size_t)i * bw + w] & mask_cur[w];
+                            if (w == wlast) m &= (1u << (i & 31)) - 1u;
+                            while (m) {
+                                const int j = (w << 5) + __builtin_ctz(m);
+                                m &= m - 1;
+                                const uint64_t key = ((uint64_t)__float_as_uint(selfdist[(size_t)j * ld + i]) << 32) | (uint32_t)j;
+                                const uint64_t hi = b > key ? b : key;
+                                b = b < key ? b : key;
+                                sk = sk < hi ? sk : hi;
+                            }
                         }
                     }
-                } else {
-                    const int wlast = i >> 5;
-                    for (int w = 0; w <= wlast; ++w) {
-                        uint32_t m = cand_bits[(size_t)i * bw + w] & mask_cur[w];
-                        if (w == wlast) m &= (1u << (i & 31)) - 1u;
-                        while (m) {
-                            const int j = (w << 5) + __builtin_ctz(m);
-                            m &= m - 1;
-                            const uint64_t k = ((uint64_t)__float_as_uint(selfdist[(size_t)j * ld + i]) << 32) | (uint32_t)j;
-                            const uint64_t hi = b > k ? b : k;
-                            b = b < k ? b : k;
-                            sk = sk < hi ? sk : hi;
-                        }
-                    }
+                    if (b != KEY_NONE) cand_push(c0, c1, n, __uint_as_float((uint32_t)(b >> 32)), -((int)(uint32_t)b + 1));
+                    if (sk != KEY_NONE) cand_push(c0, c1, n, __uint_as_float((uint32_t)(sk >> 32)), -((int)(uint32_t)sk + 1));
+                    S.reject = n < 2 || c0.d > nndr * c1.d;
+                    S.win = n > 0 ? c0.id : 0;
                 }
-                if (b != KEY_NONE) cand_push(c0, c1, n, __uint_as_float((uint32_t)(b >> 32)), -((int)(uint32_t)b + 1));
-                if (sk != KEY_NONE) cand_push(c0, c1, n, __uint_as_float((uint32_t)(sk >> 32)), -((int)(uint32_t)sk + 1));
-                reject = n < 2 || c0.d > nndr * c1.d;
-                win = n > 0 ? c0.id : 0;
-            }
-            if (i < qpad) {
-                const unsigned long long bal = __ballot(reject);
-                if (lane == 0) {
-                    const uint32_t lo = (uint32_t)bal, hi = (uint32_t)(bal >> 32);
-                    mask_next[i >> 5] = lo; mask_next[(i >> 5) + 1] = hi;
-                    if (lo != mask_cur[i >> 5] || hi != mask_cur[(i >> 5) + 1]) s_changed_f = 1;
+                if (i < qpad) {
+                    const unsigned long long bal = __ballot(S.reject);
+                    if (lane == 0) {
+                        const uint32_t lo = (uint32_t)bal, hi = (uint32_t)(bal >> 32);
+                        mask_next[i >> 5] = lo; mask_next[(i >> 5) + 1] = hi;
+                        if (lo != mask_cur[i >> 5] || hi != mask_cur[(i >> 5) + 1]) s_changed_f = 1;
+                    }
                 }
             }
             __syncthreads();
@@ -208,26 +236,38 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
         }
     }
     RB_STAMP(3);
-    if (tid == 0) {
+    // word prefix sums of the final mask -> ranks of the new words in descriptor order (getNextId() order, :1185): one wavefront
+    if (tid < 64) {
         uint32_t run = 0;
-        for (int w = 0; w < mw; ++w) { prefix[w] = run; run += __popc(mask_cur[w]); }
-        prefix[mw] = run;
-        out_n_new[0] = (int32_t)run;
+        for (int w0 = 0; w0 < mw; w0 += 64) {
+            const int w = w0 + tid;
+            const uint32_t c = w < mw ? (uint32_t)__popc(mask_cur[w]) : 0u;
+            uint32_t x = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+            if (w < mw) prefix[w] = run + x - c;
+            run += __shfl(x, 63, 64);
+        }
+        if (tid == 0) { prefix[mw] = run; out_n_new[0] = (int32_t)run; }
     }
     __syncthreads();
     RB_STAMP(4);
-    if (valid) {
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int i = tid + k * NT;
+        const Dsc& S = st[k];
+        if (i >= q) continue;
         const bool is_new = (mask_cur[i >> 5] >> (i & 31)) & 1u;
         int w;
         if (is_new) w = -(new_rank(mask_cur, prefix, i) + 1);
         else {
-            w = win;
+            w = S.win;
             if (w < 0) w = -(new_rank(mask_cur, prefix, -w - 1) + 1);   // matched a same-frame new word
         }
         out_word[i] = w;
         int32_t ws = -1;
         if (w < 0 && new_ws.n > 0) ws = ws_runs_at(new_ws, -w - 1);
-        if (w > 0) { if (w0 == w) ws = ws_a; else if (w1 == w) ws = ws_b; }
+        if (w > 0) { if (S.w0 == w) ws = S.ws_a; else if (S.w1 == w) ws = S.ws_b; }
         if (lds_wslot) lds_wslot[i] = ws;
         else if (out_wslot) out_wslot[i] = ws;
     }

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(RBLOCK) void resolve_kernel(int q, int flags, float
                                                          int32_t* __restrict__ out_wslot, WsRuns new_ws) {
     extern __shared__ uint32_t rs_dyn_smem[];
     if (q <= RBLOCK)
-        resolve_body_fast<RBLOCK>(rs_dyn_smem, nullptr, q, flags, nndr, have_index, knn_word, knn_dist, selfdist, ld, cand_bits, bw, out_word, out_n_new,
+        resolve_body_fast<RBLOCK, 1>(rs_dyn_smem, nullptr, q, flags, nndr, have_index, knn_word, knn_dist, selfdist, ld, cand_bits, bw, out_word, out_n_new,
                           knn_row, row_wslot, out_wslot, new_ws);
     else
         resolve_body<RBLOCK>(rs_dyn_smem, q, flags, nndr, have_index, knn_word, knn_dist, selfdist, ld, cand_bits, bw, out_word, out_n_new, knn_row,
