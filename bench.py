@@ -107,7 +107,7 @@ class Stepper:
         self.first_new += Q          # ids are only reserved here (the words are never appended): any consecutive numbering will do
 
 
-def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None, eng=None):
+def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None, eng=None, per_step_events=True):
     """warmup untimed steps, then exactly `steps` steps bracketed by barrier + synchronize; an event per step for the distribution.
     eng: the engine the steps run on -- its events are recorded in call order (lcd_record_event: a threaded handle enqueues the index
     stage of a frame after lcd_frame_dev returned) and it is drained (lcd_synchronize) before the clock stops."""
@@ -124,13 +124,14 @@ def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None
         e.record(stream)                                # creates the underlying hipEvent_t
     torch.cuda.synchronize()
     rec = (lambda e: eng.record_event(e.cuda_event)) if eng is not None else (lambda e: e.record(stream))
+    mid = rec if per_step_events else (lambda e: None)          # an event per step costs a few microseconds of stream time each
     if profile_eng is not None:
         profile_eng.profile_begin(max(10, steps // 5))   # HIP events around the two big kernels of the first 20 % of the timed steps
     t0 = time.perf_counter()
     rec(evs[0])
     for i in range(steps):
         step(warmup + i)
-        rec(evs[i + 1])
+        (rec if i == steps - 1 else mid)(evs[i + 1])
     host_enqueue = time.perf_counter() - t0
     if eng is not None:
         eng.synchronize()
@@ -139,7 +140,7 @@ def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
+    per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]) if per_step_events else np.zeros(0)
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -501,7 +502,7 @@ def main():
         build_s = load_engine(eng, vocab, words)
         log("[bench] rank %d: %d signatures bulk-loaded in %.2fs" % (rank, n_sig, build_s))
         step = Stepper(eng, torch, d_frames, n_sig, cap)
-        res = timed_loop(torch, dist, world, stream, step, args.steps, args.warmup, profile_eng=eng, eng=eng)
+        res = timed_loop(torch, dist, world, stream, step, args.steps, args.warmup, profile_eng=eng, eng=eng, per_step_events=False)
         roof_knn, roof_score = rooflines(eng, N_WORDS, n_sig, False)
         st = eng.stats()                                  # (drains the engine's thread)
         like = step.d_like[: n_sig + args.steps + args.warmup].cpu().numpy()
@@ -516,7 +517,8 @@ def main():
               "frames_per_s": frames_total / wall, "device_ms_per_step": res["dev_ms"] / args.steps,
               "host_enqueue_ms_per_step": 1e3 * res["host_enqueue"] / args.steps,
               "host_ms_inside_lcd_frame_dev": None,
-              "step_ms_median": float(np.median(res["per_step_ms"])), "step_ms_p95": float(np.percentile(res["per_step_ms"], 95)),
+              "step_ms_median": float(np.median(res["per_step_ms"])) if res["per_step_ms"].size else None,
+              "step_ms_p95": float(np.percentile(res["per_step_ms"], 95)) if res["per_step_ms"].size else None,
               "world_size_observed": world, "collective_backend": backend, "signatures_bulk_load_s": build_s,
               "pipeline": "software-pipelined frames: 2 launches per frame (filter of frame t + tail of frame t-1; re-rank of frame t + "
                           "scoring of frame t-1), one stream" if (args.pipeline and not shard) else "4 launches per frame, one stream",
@@ -526,11 +528,12 @@ def main():
     if not shard:
         config["host_ms_inside_lcd_frame_dev"] = host_in_c
     # ---- the distribution needs >= 50 frames: extra, untimed-for-`value` steps when the driver asked for fewer
-    if not shard and args.steps < 50:
-        extra = timed_loop(torch, dist, world, stream, step, 64, 0, eng=eng)
+    if not shard:
+        extra = timed_loop(torch, dist, world, stream, step, max(64, min(args.steps, 256)), 0, eng=eng)
         config["step_ms_median"] = float(np.median(extra["per_step_ms"]))
         config["step_ms_p95"] = float(np.percentile(extra["per_step_ms"], 95))
-        config["distribution_from"] = "64 extra steps after the timed region"
+        config["distribution_from"] = "%d extra steps after the timed region, one event per step (the timed region itself carries none: an " \
+                                      "event costs stream time); their mean %.4f ms" % (extra["per_step_ms"].size, float(extra["per_step_ms"].mean()))
 
     # ---- N > 1: the other parallelism, same run, secondary key
     if world > 1 and not args.no_extras:

@@ -490,7 +490,7 @@ static int prepare_resolve(lcd_engine* h, const void* d_desc, int q, int flags, 
     const int bw = ld / 32;
     if (together) {
         LCD_HIP(h, dreserve(h, h->d_selfdist, (size_t)q * ld * 4));
-        LCD_HIP(h, dreserve(h, h->d_bits, (size_t)q * bw * 4));
+        LCD_HIP(h, dreserve(h, h->d_bits, cand_bits_bytes(q, bw)));
     }
     // With the MFMA filter the same-frame distance matrix does not wait for the 2-NN: extra workgroups of the filter launch
     // compute it, and the re-rank workgroup of a query -- the first to know the query's second neighbour -- derives the query's
@@ -500,7 +500,8 @@ static int prepare_resolve(lcd_engine* h, const void* d_desc, int q, int flags, 
     int rc;
     if (side) {
         CandBits cb;
-        cb.selfdist = h->d_selfdist.as<float>(); cb.ld = ld; cb.nq = q; cb.bits = h->d_bits.as<uint32_t>(); cb.bw = bw; cb.have_index = have_index;
+        cb.selfdist = h->d_selfdist.as<float>(); cb.ld = ld; cb.nq = q; cb.have_index = have_index;
+        cand_bits_layout(cb, h->d_bits.as<uint32_t>(), q, bw);
         LCD_HIP(h, dreserve(h, h->d_knn_row, (size_t)q * 2 * 4));
         LCD_HIP(h, dreserve(h, h->d_knn_word, (size_t)q * 2 * 4));
         LCD_HIP(h, dreserve(h, h->d_knn_dist, (size_t)q * 2 * 4));
@@ -531,6 +532,12 @@ static int prepare_resolve(lcd_engine* h, const void* d_desc, int q, int flags, 
     r->row_wslot = h->row_wslot.as<int32_t>();
     r->out_wslot = d_out_wslot;
     r->new_ws = WsRuns();
+    r->cand_list = nullptr; r->cand_cnt = nullptr;
+    if (side) {                                                      // the re-rank also left the compact candidate lists
+        CandBits lay;
+        cand_bits_layout(lay, h->d_bits.as<uint32_t>(), q, bw);
+        r->cand_list = lay.list; r->cand_cnt = lay.cnt;
+    }
     r->fail_count = nullptr;
     return LCD_OK;
 }
@@ -541,7 +548,7 @@ static int quantize_dev(lcd_engine* h, const void* d_desc, int q, int flags, flo
     int rc = prepare_resolve(h, d_desc, q, flags, nndr, d_out_word, d_out_wslot, &r);
     if (rc) return rc;
     LCD_HIP(h, launch_resolve(r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
-                              r.out_n_new, h->stream, r.knn_row, r.row_wslot, r.out_wslot));
+                              r.out_n_new, h->stream, r.knn_row, r.row_wslot, r.out_wslot, nullptr, r.cand_list, r.cand_cnt));
     return LCD_OK;
 }
 
@@ -840,14 +847,14 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
     if (together) {
         LCD_HIP(h, dreserve(h, h->d_selfdist, (size_t)q * ld * 4));
-        LCD_HIP(h, dreserve(h, h->d_bits, (size_t)q * bw * 4));
+        LCD_HIP(h, dreserve(h, h->d_bits, cand_bits_bytes(q, bw)));
     }
     k.vocab = h->vocab.p; k.vocab_bf = h->vocab_bf.p; k.row_norm = h->row_norm.as<float>(); k.norm_max_bits = h->norm_max.as<uint32_t>();
     k.row_id = h->row_id.as<int32_t>(); k.queries = a->d_descriptors; k.partial = h->d_partial2.p;
     k.out_row = h->d_knn_row.as<int32_t>(); k.out_word = h->d_knn_word.as<int32_t>(); k.out_dist = h->d_knn_dist.as<float>();
     k.fail_list = h->d_fail_list.as<int32_t>(); k.fail_count = h->d_fail_count.as<int32_t>();
     k.cb = CandBits();
-    if (together) { k.cb.selfdist = h->d_selfdist.as<float>(); k.cb.ld = ld; k.cb.nq = q; k.cb.bits = h->d_bits.as<uint32_t>(); k.cb.bw = bw; k.cb.have_index = 1; }
+    if (together) { k.cb.selfdist = h->d_selfdist.as<float>(); k.cb.ld = ld; k.cb.nq = q; k.cb.have_index = 1; cand_bits_layout(k.cb, h->d_bits.as<uint32_t>(), q, bw); }
     if (!h->fail_count_clean) LCD_HIP(h, hipMemsetAsync(h->d_fail_count.p, 0, 8, h->stream));
     // ---- the owed index stage of the previous frame: host part now, its launches ride with this frame's
     TailLaunch tl; ScoreArgs sa; int score_wgs = 0;
@@ -896,6 +903,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     r.q = q; r.flags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0); r.nndr = a->nndr_ratio; r.have_index = 1;
     r.knn_word = k.out_word; r.knn_dist = k.out_dist; r.selfdist = together ? h->d_selfdist.as<float>() : nullptr; r.ld = ld;
     r.cand_bits = together ? h->d_bits.as<uint32_t>() : nullptr; r.bw = bw; r.out_word = a->d_word_ids; r.out_n_new = h->d_n_new.as<int32_t>();
+    r.cand_list = together ? k.cb.list : nullptr; r.cand_cnt = together ? k.cb.cnt : nullptr;
     r.knn_row = k.out_row; r.row_wslot = h->row_wslot.as<int32_t>(); r.out_wslot = h->d_out_wslot.as<int32_t>(); r.new_ws = WsRuns();
     r.fail_count = h->d_fail_count.as<int32_t>();
     fill_redo(h, &r.rp, h->vocab.p, h->row_id.as<int32_t>(), (int)h->n_rows, a->d_descriptors, k.out_row, k.out_word, k.out_dist, together ? &k.cb : nullptr);

@@ -930,6 +930,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
         if (!ok) fail_list[atomicAdd(fail_count, 1)] = qi;
     }
     if (cb.bits) {                                                    // the query's row of the candidate bit matrix (uniform branch)
+        __shared__ int s_below;                                       // + the compact list of the set bits below qi (CandBits::list)
+        if (tid == 0) s_below = 0;
         __syncthreads();
         const float thr2 = s_thr;
         for (int base = wave * 64; base < cb.ld; base += MF_BLOCK) {
@@ -938,6 +940,14 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
             if (r >= 2 * MF_BLOCK && r < cb.nq) d = cb.selfdist[(size_t)qi * cb.ld + r];
             const unsigned long long m = __ballot(d < thr2);
             if (lane == 0) *reinterpret_cast<unsigned long long*>(cb.bits + (size_t)qi * cb.bw + (base >> 5)) = m;
+            if (cb.cnt && d < thr2 && r < qi) {
+                const int pos = atomicAdd(&s_below, 1);               // any order: the decision loop takes the two smallest (distance, j)
+                if (pos < 4) cb.list[(size_t)qi * 4 + pos] = make_uint2((uint32_t)r, __float_as_uint(d));
+            }
+        }
+        if (cb.cnt) {
+            __syncthreads();
+            if (tid == 0) cb.cnt[qi] = s_below;
         }
     }
 }

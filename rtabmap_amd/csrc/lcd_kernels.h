@@ -36,7 +36,17 @@ struct CandBits {
     uint32_t* bits = nullptr;          // [nq x bw], bw = ld / 32 (even)
     int bw = 0;
     int have_index = 0;
+    // the same information in the form the decision loop wants: per descriptor i the number of set bits below i and, when there are
+    // at most four, the (j, distance bits) pairs themselves -- one coalesced read instead of a bit-row scan and distance gathers
+    uint2* list = nullptr;             // [nq x 4] {j, distance bits}
+    int32_t* cnt = nullptr;            // [nq] (> 4: the list is incomplete, use the bit row)
 };
+inline size_t cand_bits_bytes(int q, int bw) { return (size_t)q * (bw + 9) * 4; }   // bit rows | lists | counts in one buffer
+inline void cand_bits_layout(CandBits& cb, uint32_t* base, int q, int bw) {
+    cb.bits = base; cb.bw = bw;
+    cb.list = reinterpret_cast<uint2*>(base + (size_t)q * bw);
+    cb.cnt = reinterpret_cast<int32_t*>(base + (size_t)q * bw + (size_t)q * 8);
+}
 
 // Postings keys reserved for the words a frame may create: the k-th new word of the frame gets the k-th key of the
 // concatenated runs (recycled keys come back as a handful of intervals; the rest is one fresh interval).  n == 0: none.
@@ -96,7 +106,8 @@ hipError_t launch_resolve(int q, int flags, float nndr, int have_index, const in
                           const float* selfdist, int ld, const uint32_t* cand_bits, int bw, int32_t* out_word, int32_t* out_n_new,
                           hipStream_t s, const int32_t* knn_row = nullptr, const int32_t* row_wslot = nullptr,
                           int32_t* out_wslot = nullptr,    // out_wslot[q]: postings key of the chosen word (-1: none)
-                          const WsRuns* new_ws = nullptr); // postings keys of the frame's new words (NULL: they get none)
+                          const WsRuns* new_ws = nullptr,  // postings keys of the frame's new words (NULL: they get none)
+                          const uint2* cand_list = nullptr, const int32_t* cand_cnt = nullptr);   // CandBits::list / cnt when available
 // findNN merge (VWDictionary.cpp:1457-1542): indexed candidates + candidates among the not-indexed words + NNDR.
 hipError_t launch_findnn_resolve(int q, int flags, float nndr, int have_index, const int32_t* knn_word,
                                  const float* knn_dist, int have_extra, const int32_t* extra_word,

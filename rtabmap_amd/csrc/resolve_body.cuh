@@ -86,7 +86,8 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
                                                   const uint32_t* __restrict__ cand_bits, int bw,
                                                   int32_t* __restrict__ out_word, int32_t* __restrict__ out_n_new,
                                                   const int32_t* __restrict__ knn_row, const int32_t* __restrict__ row_wslot,
-                                                  int32_t* __restrict__ out_wslot, const WsRuns& new_ws) {
+                                                  int32_t* __restrict__ out_wslot, const WsRuns& new_ws,
+                                                  const uint2* __restrict__ cand_list = nullptr, const int32_t* __restrict__ cand_cnt = nullptr) {
     const int mw = (q + 63) / 64 * 2;
     uint32_t* mask_cur = rs_smem;
     uint32_t* mask_next = rs_smem + mw;
@@ -100,7 +101,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
     struct Dsc {
         int w0, w1; int32_t ws_a, ws_b;
         Cand b0, b1; int nb;
-        int nzw[4]; uint32_t nzb[4]; int nz; bool overflow;
+        int cj[4]; float cd[4]; int nc; bool overflow;     // the same-frame candidates below the descriptor (at most four kept)
         bool reject; int win;
     };
     Dsc st[KPT];
@@ -118,33 +119,28 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
             if (out_wslot || lds_wslot) { const int2 rr = *reinterpret_cast<const int2*>(knn_row + 2 * i); r0[k] = rr.x; r1[k] = rr.y; }
         }
     }
-    // ---- the candidate-bit rows
+    // ---- the same-frame candidates: count + compact list left by the re-rank (one read each); descriptors with more than four, and
+    //      paths without the lists, walk their bit row in every sweep instead
+    int cn[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int i = tid + k * NT;
+        cn[k] = 0;
+        if (together && i < q) cn[k] = cand_cnt ? cand_cnt[i] : 5;
+    }
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const int i = tid + k * NT;
         Dsc& S = st[k];
-        S.nz = 0; S.overflow = false;
+        S.nc = 0; S.overflow = cn[k] > 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { S.nzw[e] = 0; S.nzb[e] = 0u; }
-        if (together && i < q) {
-            const int wlast = i >> 5;
-            for (int wb = 0; wb <= wlast; wb += 8) {
-                uint32_t v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = (wb + u <= wlast) ? cand_bits[(size_t)i * bw + wb + u] : 0u;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    uint32_t m = v[u];
-                    if (wb + u == wlast) m &= (1u << (i & 31)) - 1u;       // only j < i
-                    if (m) {
-                        if (S.nz < 4) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) if (e == S.nz) { S.nzw[e] = wb + u; S.nzb[e] = m; }
-                            ++S.nz;
-                        } else S.overflow = true;
-                    }
-                }
-            }
+        for (int e = 0; e < 4; ++e) { S.cj[e] = 0; S.cd[e] = 0.0f; }
+        if (cn[k] > 0 && cn[k] <= 4) {
+            const uint4 lo = *reinterpret_cast<const uint4*>(cand_list + (size_t)i * 4);
+            const uint4 hi = cn[k] > 2 ? *reinterpret_cast<const uint4*>(cand_list + (size_t)i * 4 + 2) : make_uint4(0u, 0u, 0u, 0u);
+            S.cj[0] = (int)lo.x; S.cd[0] = __uint_as_float(lo.y); S.cj[1] = (int)lo.z; S.cd[1] = __uint_as_float(lo.w);
+            S.cj[2] = (int)hi.x; S.cd[2] = __uint_as_float(hi.y); S.cj[3] = (int)hi.z; S.cd[3] = __uint_as_float(hi.w);
+            S.nc = cn[k];
         }
     }
     // ---- the indexed candidates (they do not change from sweep to sweep), :1092-1137: stop at the first invalid neighbour;
@@ -184,17 +180,15 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
             for (int k = 0; k < KPT; ++k) {
                 const int i = tid + k * NT;
                 Dsc& S = st[k];
-                if (i < q && (S.nz > 0 || S.overflow)) {                   // only these descriptors can change their mind
+                if (i < q && (S.nc > 0 || S.overflow)) {                   // only these descriptors can change their mind
                     Cand c0 = S.b0, c1 = S.b1; int n = S.nb;
                     uint64_t b = KEY_NONE, sk = KEY_NONE;
                     if (!S.overflow) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            uint32_t m = e < S.nz ? (S.nzb[e] & mask_cur[S.nzw[e]]) : 0u;
-                            while (m) {
-                                const int j = (S.nzw[e] << 5) + __builtin_ctz(m);
-                                m &= m - 1;
-                                const uint64_t key = ((uint64_t)__float_as_uint(selfdist[(size_t)j * ld + i]) << 32) | (uint32_t)j;
+                            const int j = S.cj[e];
+                            if (e < S.nc && ((mask_cur[j >> 5] >> (j & 31)) & 1u)) {         // j became a new word
+                                const uint64_t key = ((uint64_t)__float_as_uint(S.cd[e]) << 32) | (uint32_t)j;
                                 const uint64_t hi = b > key ? b : key;
                                 b = b < key ? b : key;
                                 sk = sk < hi ? sk : hi;

@@ -28,11 +28,12 @@ __global__ __launch_bounds__(RBLOCK) void resolve_kernel(int q, int flags, float
                                                          const uint32_t* __restrict__ cand_bits, int bw,
                                                          int32_t* __restrict__ out_word, int32_t* __restrict__ out_n_new,
                                                          const int32_t* __restrict__ knn_row, const int32_t* __restrict__ row_wslot,
-                                                         int32_t* __restrict__ out_wslot, WsRuns new_ws) {
+                                                         int32_t* __restrict__ out_wslot, WsRuns new_ws,
+                                                         const uint2* __restrict__ cand_list, const int32_t* __restrict__ cand_cnt) {
     extern __shared__ uint32_t rs_dyn_smem[];
     if (q <= RBLOCK)
         resolve_body_fast<RBLOCK, 1>(rs_dyn_smem, nullptr, q, flags, nndr, have_index, knn_word, knn_dist, selfdist, ld, cand_bits, bw, out_word, out_n_new,
-                          knn_row, row_wslot, out_wslot, new_ws);
+                                     knn_row, row_wslot, out_wslot, new_ws, cand_list, cand_cnt);
     else
         resolve_body<RBLOCK>(rs_dyn_smem, q, flags, nndr, have_index, knn_word, knn_dist, selfdist, ld, cand_bits, bw, out_word, out_n_new, knn_row,
                      row_wslot, out_wslot, new_ws);
@@ -133,12 +134,14 @@ __global__ void tombstone_kernel(int32_t* __restrict__ row_id, const int32_t* __
 
 hipError_t launch_resolve(int q, int flags, float nndr, int have_index, const int32_t* knn_word, const float* knn_dist,
                           const float* selfdist, int ld, const uint32_t* cand_bits, int bw, int32_t* out_word, int32_t* out_n_new,
-                          hipStream_t s, const int32_t* knn_row, const int32_t* row_wslot, int32_t* out_wslot, const WsRuns* new_ws) {
+                          hipStream_t s, const int32_t* knn_row, const int32_t* row_wslot, int32_t* out_wslot, const WsRuns* new_ws,
+                          const uint2* cand_list, const int32_t* cand_cnt) {
     if (q <= 0) return hipSuccess;
     if (q > 8 * RBLOCK) return hipErrorInvalidValue;
     const int mw = (q + 63) / 64 * 2;
     resolve_kernel<<<1, RBLOCK, (size_t)(3 * mw + 2) * 4, s>>>(q, flags, nndr, have_index, knn_word, knn_dist, selfdist, ld, cand_bits, bw,
-                                                            out_word, out_n_new, knn_row, row_wslot, out_wslot, new_ws ? *new_ws : WsRuns());
+                                                            out_word, out_n_new, knn_row, row_wslot, out_wslot, new_ws ? *new_ws : WsRuns(), cand_list,
+                                                            cand_cnt);
     return hipGetLastError();
 }
 

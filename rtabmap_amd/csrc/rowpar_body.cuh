@@ -29,12 +29,20 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
 // second indexed neighbour) from the already computed same-frame distance matrix, which is symmetric bit for bit.  Called by
 // whole waves (n_threads a multiple of 64); writes all bw words of the row.
 __device__ __forceinline__ void cand_bits_row(const CandBits& cb, int qi, float thr, int tid, int n_threads) {
+    int below = 0;                                                  // set bits below qi so far (called by ONE wave: n_threads == 64)
     for (int base = (tid >> 6) * 64; base < cb.ld; base += n_threads) {
         const int r = base + (tid & 63);
         const float d = r < cb.nq ? cb.selfdist[(size_t)qi * cb.ld + r] : __int_as_float(0x7f800000);
         const unsigned long long m = __ballot(d < thr);
         if ((tid & 63) == 0) *reinterpret_cast<unsigned long long*>(cb.bits + (size_t)qi * cb.bw + (base >> 5)) = m;
+        if (cb.cnt && n_threads == 64) {
+            const unsigned long long m2 = __ballot(d < thr && r < qi);
+            const int pos = below + (int)__popcll(m2 & ((1ull << (tid & 63)) - 1ull));
+            if (d < thr && r < qi && pos < 4) cb.list[(size_t)qi * 4 + pos] = make_uint2((uint32_t)r, __float_as_uint(d));
+            below += (int)__popcll(m2);
+        }
     }
+    if (cb.cnt && n_threads == 64 && (tid & 63) == 0) cb.cnt[qi] = below;
 }
 
 
