@@ -83,36 +83,51 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
     __syncthreads();
     const uint32_t U = grp[ng];
     const uint32_t base = s_misc[0];
-    for (int i0 = 0; i0 < H; i0 += NT) {
-        const int i = i0 + tid;
-        const bool occ = i < H && tkey[i] != 0xFFFFFFFFu;
-        const unsigned long long bal = __ballot(occ);
-        if (!occ) continue;
-        const uint32_t u = grp[i >> 6] + (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
-        const uint32_t w = tkey[i];
-        uint32_t cnt = tcnt[i];
-        if (cnt > TF_CNT_MASK) cnt = TF_CNT_MASK;
-        uint32_t nwv;
-        if (a.do_register) {
-            nwv = atomicAdd(&a.nw[w], 1u) + 1u;
-            a.coo_w[base + u] = w;
-            a.coo_pc[base + u] = (a.slot_local << TF_CNT_BITS) | cnt;
-        } else {
-            nwv = a.nw[w];
+    // second pass, four table entries per thread and trip: the reference count of every word comes back from a returning atomic
+    // (one round trip) -- all four are in flight before the first is used
+    for (int i0 = 0; i0 < H; i0 += 4 * NT) {
+        uint32_t w4[4], c4[4], u4[4], n4[4]; int32_t d4[4]; bool o4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + r * NT + tid;
+            const bool occ = i < H && tkey[i] != 0xFFFFFFFFu;
+            const unsigned long long bal = __ballot(occ);
+            o4[r] = occ; w4[r] = 0; c4[r] = 0; u4[r] = 0;
+            if (occ) {
+                u4[r] = grp[i >> 6] + (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
+                w4[r] = tkey[i];
+                c4[r] = tcnt[i] > TF_CNT_MASK ? TF_CNT_MASK : tcnt[i];
+            }
         }
-        if (a.want_q) {
-            float idf = 0.0f;
-            if (a.N > 0.0f && nwv > 0u) idf = log10f(__fdiv_rn(a.N, (float)nwv));   // Memory.cpp:2264-2266
-            const int32_t idfq = idf_to_fixed(idf);
-            const int32_t d = a.did[w];
-            a.q_w[u] = w;
-            a.q_idf[u] = idfq;
-            a.q_did[u] = d;
-            a.idf_tab[w] = make_uint2(a.stamp, (uint32_t)idfq);
-            if (d >= 0 && idfq != 0) {                                   // "if(logNnw)" (Memory.cpp:2267)
-                const uint32_t j = atomicAdd(&s_misc[1], 1u);
-                a.qd_did[j] = d;
-                a.qd_idf[j] = idfq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            n4[r] = 0; d4[r] = -1;
+            if (!o4[r]) continue;
+            n4[r] = a.do_register ? atomicAdd(&a.nw[w4[r]], 1u) + 1u : a.nw[w4[r]];
+            if (a.want_q) d4[r] = a.did[w4[r]];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (!o4[r]) continue;
+            const uint32_t w = w4[r], u = u4[r], cnt = c4[r], nwv = n4[r];
+            if (a.do_register) {
+                a.coo_w[base + u] = w;
+                a.coo_pc[base + u] = (a.slot_local << TF_CNT_BITS) | cnt;
+            }
+            if (a.want_q) {
+                float idf = 0.0f;
+                if (a.N > 0.0f && nwv > 0u) idf = log10f(__fdiv_rn(a.N, (float)nwv));   // Memory.cpp:2264-2266
+                const int32_t idfq = idf_to_fixed(idf);
+                const int32_t d = d4[r];
+                a.q_w[u] = w;
+                a.q_idf[u] = idfq;
+                a.q_did[u] = d;
+                a.idf_tab[w] = make_uint2(a.stamp, (uint32_t)idfq);
+                if (d >= 0 && idfq != 0) {                                   // "if(logNnw)" (Memory.cpp:2267)
+                    const uint32_t j = atomicAdd(&s_misc[1], 1u);
+                    a.qd_did[j] = d;
+                    a.qd_idf[j] = idfq;
+                }
             }
         }
     }

@@ -17,6 +17,10 @@ __device__ unsigned long long g_resolve_timing[8];
 #define RB_STAMP(i) do { } while (0)
 #endif
 
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains the wave's outstanding GLOBAL loads
+// (s_waitcnt vmcnt(0)), which would end the overlap of a requested-early / consumed-late load with the work in between
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct Cand { float d; int id; };   // id > 0: word id, id < 0: -(j+1) = the new word created by descriptor j
 
 // std::multimap<float,int> insertion (equal keys keep insertion order, VWDictionary.cpp:1091) restricted to what is
@@ -170,12 +174,12 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
             if (lane == 0) { mask_cur[i >> 5] = (uint32_t)bal; mask_cur[(i >> 5) + 1] = (uint32_t)(bal >> 32); }
         }
     }
-    __syncthreads();
+    lds_barrier();
     RB_STAMP(2);
     if (together) {
         for (int sweep = 0; sweep <= q; ++sweep) {
             if (tid == 0) s_changed_f = 0;
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int k = 0; k < KPT; ++k) {
                 const int i = tid + k * NT;
@@ -223,10 +227,10 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             uint32_t* t = mask_cur; mask_cur = mask_next; mask_next = t;
             if (!s_changed_f) break;
-            __syncthreads();
+            lds_barrier();
         }
     }
     RB_STAMP(3);
@@ -244,7 +248,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
         }
         if (tid == 0) { prefix[mw] = run; out_n_new[0] = (int32_t)run; }
     }
-    __syncthreads();
+    lds_barrier();
     RB_STAMP(4);
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
