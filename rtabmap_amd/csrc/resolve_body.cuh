@@ -106,6 +106,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
         int w0, w1; int32_t ws_a, ws_b;
         Cand b0, b1; int nb;
         int cj[4]; float cd[4]; int nc; bool overflow;     // the same-frame candidates below the descriptor (at most four kept)
+        uint32_t rb[16];                                   // overflow: the descriptor's bit row (frames of up to 512 descriptors)
         bool reject; int win;
     };
     Dsc st[KPT];
@@ -145,6 +146,20 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
             S.cj[0] = (int)lo.x; S.cd[0] = __uint_as_float(lo.y); S.cj[1] = (int)lo.z; S.cd[1] = __uint_as_float(lo.w);
             S.cj[2] = (int)hi.x; S.cd[2] = __uint_as_float(hi.y); S.cj[3] = (int)hi.z; S.cd[3] = __uint_as_float(hi.w);
             S.nc = cn[k];
+        }
+        // more than four candidates (a word that occurs many times in the frame makes all its descriptors candidates of each other):
+        // keep the whole bit row in registers; a sweep then ANDs it with the new-word mask and touches memory only for the hits
+#pragma unroll
+        for (int u = 0; u < 16; ++u) S.rb[u] = 0u;
+        if (S.overflow && bw <= 16) {
+            const uint4* row = reinterpret_cast<const uint4*>(cand_bits + (size_t)i * bw);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (4 * u < bw) { const uint4 v = row[u]; S.rb[4 * u] = v.x; S.rb[4 * u + 1] = v.y; S.rb[4 * u + 2] = v.z; S.rb[4 * u + 3] = v.w; }
+            }
+            const int wlast = i >> 5;                            // only j < i
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { if (u == wlast) S.rb[u] &= (1u << (i & 31)) - 1u; else if (u > wlast) S.rb[u] = 0u; }
         }
     }
     // ---- the indexed candidates (they do not change from sweep to sweep), :1092-1137: stop at the first invalid neighbour;
@@ -193,6 +208,19 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
                             const int j = S.cj[e];
                             if (e < S.nc && ((mask_cur[j >> 5] >> (j & 31)) & 1u)) {         // j became a new word
                                 const uint64_t key = ((uint64_t)__float_as_uint(S.cd[e]) << 32) | (uint32_t)j;
+                                const uint64_t hi = b > key ? b : key;
+                                b = b < key ? b : key;
+                                sk = sk < hi ? sk : hi;
+                            }
+                        }
+                    } else if (bw <= 16) {
+#pragma unroll
+                        for (int w = 0; w < 16; ++w) {
+                            uint32_t m = w < mw ? (S.rb[w] & mask_cur[w]) : 0u;
+                            while (m) {
+                                const int j = (w << 5) + __builtin_ctz(m);
+                                m &= m - 1;
+                                const uint64_t key = ((uint64_t)__float_as_uint(selfdist[(size_t)j * ld + i]) << 32) | (uint32_t)j;
                                 const uint64_t hi = b > key ? b : key;
                                 b = b < key ? b : key;
                                 sk = sk < hi ? sk : hi;
