@@ -40,6 +40,9 @@ PEAK_HBM_GBPS = 8000.0
 PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
 
 
+DIAG = set()
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -99,9 +102,10 @@ class Stepper:
         a = self.args
         a.d_descriptors = self.ptrs[i % len(self.ptrs)]
         a.sig_id = self.next_sig
-        a.first_new_word_id = self.first_new
+        a.first_new_word_id = 0 if "no-new" in DIAG else self.first_new
         self.eng.frame_dev_args(a)
-        self.eng.sig_remove(self.oldest)
+        if "no-retire" not in DIAG:
+            self.eng.sig_remove(self.oldest)
         self.next_sig += 1
         self.oldest += 1
         self.first_new += Q          # ids are only reserved here (the words are never appended): any consecutive numbering will do
@@ -420,8 +424,11 @@ def main():
                          "north star; strong scaling), or independent frame streams per GPU (weak scaling, no data-path collective)")
     ap.add_argument("--config", choices=["headline", "orb_stream"], default="headline")
     ap.add_argument("--score-block", type=int, default=0, help="experiment: threads per workgroup of the scoring kernel (256/512/1024)")
+    ap.add_argument("--diag", default="", help="diagnostics only (not the benchmark): comma list of no-new (new words get no references), "
+                    "no-retire (the oldest signature is not retired)")
     args = ap.parse_args()
 
+    DIAG.update(x for x in args.diag.split(",") if x)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus, sys.argv[1:])
         return

@@ -985,12 +985,15 @@ struct RerankArgs {
 };
 constexpr int PIPE_BLOCK = 256;     // workgroup size of both fused launches (the filter's and the re-rank's)
 
-// workgroup 0 is the tail (dispatched first: it is the longest single workgroup of the launch), 1 .. n_tail_wgs - 1 its redo helpers
-__global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel(FilterArgs f, int n_tail_wgs, ResolveArgs r, FwArgs a, RetireArgs ret) {
+// workgroup 0 is the tail (dispatched first: it is the longest single workgroup of the launch); its redo helpers come LAST -- they
+// have nothing to do unless the certificate rejected a query, and in front they would each hold a compute unit's LDS while they find out
+__global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel(FilterArgs f, int n_tail_wgs, int n_filter_wgs, ResolveArgs r, FwArgs a, RetireArgs ret) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn_a[];
     const int bid = (int)blockIdx.x;
-    if (bid < n_tail_wgs) { frame_tail_body<PIPE_BLOCK>((uint32_t*)s_dyn_a, r, a, ret, bid, n_tail_wgs); return; }
-    knn_bf16_filter_body<4>(s_dyn_a, bid - n_tail_wgs, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, f.pk,
+    const int has_tail = n_tail_wgs > 0 ? 1 : 0;
+    if (bid < has_tail) { frame_tail_body<PIPE_BLOCK>((uint32_t*)s_dyn_a, r, a, ret, 0, n_tail_wgs); return; }
+    if (bid >= has_tail + n_filter_wgs) { frame_tail_body<PIPE_BLOCK>((uint32_t*)s_dyn_a, r, a, ret, bid - n_filter_wgs, n_tail_wgs); return; }
+    knn_bf16_filter_body<4>(s_dyn_a, bid - has_tail, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, f.pk,
                             f.pl, f.sd);
 }
 __global__ __launch_bounds__(PIPE_BLOCK) void frame_b_kernel(RerankArgs k, int n_rerank_wgs, ScoreArgs A) {
@@ -1223,7 +1226,7 @@ hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* tail, hipStream_t 
     if (tail) { r = tail->r; a = tail->a; ret = tail->ret; }
     hipError_t e;
     if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
-    frame_a_kernel<<<n_filter + n_tail, PIPE_BLOCK, BF_LDS_BYTES, s>>>(f, n_tail, r, a, ret);
+    frame_a_kernel<<<n_filter + n_tail, PIPE_BLOCK, BF_LDS_BYTES, s>>>(f, n_tail, n_filter, r, a, ret);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }

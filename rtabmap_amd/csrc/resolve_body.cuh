@@ -133,6 +133,16 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
         cn[k] = 0;
         if (together && i < q) cn[k] = cand_cnt ? cand_cnt[i] : 5;
     }
+    // ---- round trip 2: postings keys of both neighbours (consumed after the sweeps) together with the candidate lists below
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int i = tid + k * NT;
+        st[k].ws_a = -1; st[k].ws_b = -1;
+        if (i < q && (out_wslot || lds_wslot)) {
+            if (r0[k] >= 0) st[k].ws_a = row_wslot ? row_wslot[r0[k]] : r0[k];
+            if (r1[k] >= 0) st[k].ws_b = row_wslot ? row_wslot[r1[k]] : r1[k];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const int i = tid + k * NT;
@@ -163,7 +173,6 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
         }
     }
     // ---- the indexed candidates (they do not change from sweep to sweep), :1092-1137: stop at the first invalid neighbour;
-    //      round trip 2 (requested now, consumed after the sweeps): postings keys of both neighbours
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const int i = tid + k * NT;
@@ -171,11 +180,6 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
         S.nb = 0; S.b0.d = 0.f; S.b0.id = 0; S.b1.d = 0.f; S.b1.id = 0;
         if (i < q && have_index) {
             if (d0[k] >= 0.0f && S.w0 != 0) { cand_push(S.b0, S.b1, S.nb, d0[k], S.w0); if (d1[k] >= 0.0f && S.w1 != 0) cand_push(S.b0, S.b1, S.nb, d1[k], S.w1); }
-        }
-        S.ws_a = -1; S.ws_b = -1;
-        if (i < q && (out_wslot || lds_wslot)) {
-            if (r0[k] >= 0) S.ws_a = row_wslot ? row_wslot[r0[k]] : r0[k];
-            if (r1[k] >= 0) S.ws_b = row_wslot ? row_wslot[r1[k]] : r1[k];
         }
         S.reject = i < q && incremental && (S.nb < 2 || S.b0.d > nndr * S.b1.d);
         S.win = S.nb > 0 ? S.b0.id : 0;

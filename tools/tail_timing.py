@@ -36,7 +36,7 @@ def main():
     n_words, q, n_sig = 49000, 500, int(os.environ.get("N_SIG", "100000"))
     vocab = synth.vocab_surf(n_words)
     words = synth.zipf_words(n_sig, q, n_words, seed=100000)
-    eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 1024, sig_capacity=n_sig + 4096)
+    eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 1024, sig_capacity=n_sig + 4096, pipeline=bool(os.environ.get("PIPE")))
     if os.environ.get("SCORE_BLOCK"):
         eng.set_option("score_block", int(os.environ["SCORE_BLOCK"]))
     eng.vocab_append(vocab, np.arange(1, n_words + 1, dtype=np.int32))
@@ -55,6 +55,9 @@ def main():
         f = torch.from_numpy(synth.frame_from_signature(vocab, words[i * 11], seed=i)).cuda()
         eng.frame_dev(f.data_ptr(), q, n_sig + 1 + i, float(n_sig + 1), d_words.data_ptr(), d_like.data_ptr(), cap, incremental=True,
                       new_words_compared=True, nndr=0.8)
+        if os.environ.get("PIPE"):      # the tail of this frame runs inside the next frame's filter launch (256-thread workgroup)
+            eng.frame_dev(f.data_ptr(), q, 0, float(n_sig + 1), d_words.data_ptr(), 0, 0)
+            torch.cuda.synchronize()
         assert lib.lcd_debug_tail_timing(buf) == 0
         t = np.array(buf[:4], dtype=np.float64) / 100.0
         rows.append(np.diff(t))
