@@ -1258,3 +1258,11 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
 }
 
 }  // namespace lcd
+
+#ifdef LCD_TAIL_TIMING   // timing experiment only: the stamps of the tail that ran inside the fused filter launch (this translation unit's copy)
+extern "C" int lcd_debug_tail_timing_pipe(unsigned long long* out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lcd::g_tail_timing), 64) != hipSuccess) return -2;
+    return (int)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(lcd::g_resolve_timing), 64);
+}
+#endif

@@ -58,7 +58,7 @@ def main():
         if os.environ.get("PIPE"):      # the tail of this frame runs inside the next frame's filter launch (256-thread workgroup)
             eng.frame_dev(f.data_ptr(), q, 0, float(n_sig + 1), d_words.data_ptr(), 0, 0)
             torch.cuda.synchronize()
-        assert lib.lcd_debug_tail_timing(buf) == 0
+        assert (lib.lcd_debug_tail_timing_pipe if os.environ.get("PIPE") else lib.lcd_debug_tail_timing)(buf) == 0
         t = np.array(buf[:4], dtype=np.float64) / 100.0
         rows.append(np.diff(t))
         rrows.append(np.diff(np.array(buf[8:14], dtype=np.float64) / 100.0))
