@@ -74,11 +74,21 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
         if ((tid & 63) == 0 && i < H) grp[i >> 6] = (uint32_t)__popcll(bal);
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < 64) {                                     // exclusive scan of the group counts by one wavefront
         uint32_t run = 0;
-        for (int g = 0; g < ng; ++g) { const uint32_t c = grp[g]; grp[g] = run; run += c; }
-        grp[ng] = run;
-        if (a.do_register && !SOLE) s_misc[0] = atomicAdd(a.ne_counter, run);   // reserve the signature's stretch of the log
+        for (int g0 = 0; g0 < ng; g0 += 64) {
+            const int g = g0 + tid;
+            const uint32_t c = g < ng ? grp[g] : 0u;
+            uint32_t x = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if (tid >= off) x += y; }
+            if (g < ng) grp[g] = run + x - c;
+            run += __shfl(x, 63, 64);
+        }
+        if (tid == 0) {
+            grp[ng] = run;
+            if (a.do_register && !SOLE) s_misc[0] = atomicAdd(a.ne_counter, run);   // reserve the signature's stretch of the log
+        }
     }
     __syncthreads();
     const uint32_t U = grp[ng];
@@ -103,7 +113,12 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
         for (int r = 0; r < 4; ++r) {
             n4[r] = 0; d4[r] = -1;
             if (!o4[r]) continue;
-            n4[r] = a.do_register ? atomicAdd(&a.nw[w4[r]], 1u) + 1u : a.nw[w4[r]];
+            if (SOLE) {                                  // only writer of nw right now: read it, add without waiting for the answer
+                n4[r] = a.nw[w4[r]] + (a.do_register ? 1u : 0u);
+                if (a.do_register) atomicAdd(&a.nw[w4[r]], 1u);
+            } else {
+                n4[r] = a.do_register ? atomicAdd(&a.nw[w4[r]], 1u) + 1u : a.nw[w4[r]];
+            }
             if (a.want_q) d4[r] = a.did[w4[r]];
         }
 #pragma unroll

@@ -723,8 +723,8 @@ hipError_t Tfidf::reserve_new_words(int32_t first_id, int n, WsRuns* runs) {
             }
         }
         resv.n = 0;
-        // one check launch per ~8 frames, not per frame (the frame tail that may have used these keys is already enqueued)
-        if (held_ws.size() >= 4096) TF_TRY(flush_held());
+        // one check launch per ~32 frames, not per frame (the frame tail that may have used these keys is already enqueued)
+        if (held_ws.size() >= 16384) TF_TRY(flush_held());
     }
     harvest_released(false);
     int left = n;

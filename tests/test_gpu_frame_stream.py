@@ -162,7 +162,7 @@ def test_frame_dev_register_and_score_stream(oracle, kind):
     st = _run_stream(oracle, kind, n_frames=540, q=96, wm=270)
     assert st["buckets_sealed"] >= 3
     # postings keys are recycled: far fewer in use than words ever created
-    assert st["word_slots"] < st["vocab_live"] + 6000, st            # (up to 4096 keys wait for the next batched check)
+    assert st["word_slots"] < st["vocab_live"] + 20000, st           # (up to 16384 keys wait for the next batched check)
 
 
 def test_frame_dev_stream_pipelined_handle(oracle):
