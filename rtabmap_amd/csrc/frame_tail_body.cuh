@@ -113,12 +113,8 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
         for (int r = 0; r < 4; ++r) {
             n4[r] = 0; d4[r] = -1;
             if (!o4[r]) continue;
-            if (SOLE) {                                  // only writer of nw right now: read it, add without waiting for the answer
-                n4[r] = a.nw[w4[r]] + (a.do_register ? 1u : 0u);
-                if (a.do_register) atomicAdd(&a.nw[w4[r]], 1u);
-            } else {
-                n4[r] = a.do_register ? atomicAdd(&a.nw[w4[r]], 1u) + 1u : a.nw[w4[r]];
-            }
+            n4[r] = a.do_register ? atomicAdd(&a.nw[w4[r]], 1u) + 1u : a.nw[w4[r]];   // (a plain read + fire-and-forget add measured slower:
+                                                                                          // atomics drop the line from L2, the read then misses)
             if (a.want_q) d4[r] = a.did[w4[r]];
         }
 #pragma unroll
