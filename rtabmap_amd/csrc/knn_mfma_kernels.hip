@@ -983,9 +983,7 @@ struct RerankArgs {
     const uint64_t* pk; const uint32_t* pl; int n_blocks, nq; const float* vocab; const float* queries; const int32_t* row_id;
     const uint32_t* norm_max_bits; int32_t* out_row; int32_t* out_word; float* out_dist; int32_t* fail_list; int32_t* fail_count; CandBits cb;
 };
-constexpr int PIPE_BLOCK = 256;     // workgroup size of launch A (the filter's)
-constexpr int PIPE_B_BLOCK = 512;   // workgroup size of launch B: the scoring workgroups use all eight wavefronts (a bucket's latency chain is
-                                    // shorter with 512 threads), the re-rank workgroups four -- their other four leave at once
+constexpr int PIPE_BLOCK = 256;     // workgroup size of both fused launches (the filter's and the re-rank's)
 
 // workgroup 0 is the tail (dispatched first: it is the longest single workgroup of the launch); its redo helpers come LAST -- they
 // have nothing to do unless the certificate rejected a query, and in front they would each hold a compute unit's LDS while they find out
@@ -998,17 +996,16 @@ __global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel(FilterArgs f, int n
     knn_bf16_filter_body<4>(s_dyn_a, bid - has_tail, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, f.pk,
                             f.pl, f.sd);
 }
-__global__ __launch_bounds__(PIPE_B_BLOCK) void frame_b_kernel(RerankArgs k, int n_rerank_wgs, ScoreArgs A) {
+__global__ __launch_bounds__(PIPE_BLOCK) void frame_b_kernel(RerankArgs k, int n_rerank_wgs, ScoreArgs A) {
     const int bid = (int)blockIdx.x;
     if (bid < n_rerank_wgs) {
-        if (threadIdx.x >= MF_BLOCK) return;                          // (barriers count live wavefronts only)
         knn_mfma_rerank_body<64, BF_KEEP, false, true>(bid, k.pk, k.pl, k.n_blocks, k.nq, k.vocab, k.queries, k.row_id, k.norm_max_bits, k.out_row,
                                                        k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb);
         return;
     }
     const int b = bid - n_rerank_wgs;
-    if (b < A.n_closed) score_sealed_body<PIPE_B_BLOCK>(A, b);
-    else score_open_body<PIPE_B_BLOCK>(A, b - A.n_closed);
+    if (b < A.n_closed) score_sealed_body<PIPE_BLOCK>(A, b);
+    else score_open_body<PIPE_BLOCK>(A, b - A.n_closed);
 }
 
 // ------------------------------------------------------------------------------------------------ row-parallel exact scan
@@ -1204,8 +1201,7 @@ hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, 
 }
 
 // ---- software-pipelined frames (see frame_a_kernel / frame_b_kernel)
-int pipe_block_size() { return PIPE_B_BLOCK; }
-int pipe_tail_block_size() { return PIPE_BLOCK; }
+int pipe_block_size() { return PIPE_BLOCK; }
 
 hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* tail, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
     const MfmaPlan& p = k.plan;
@@ -1254,7 +1250,7 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
     if (n_rerank + score_wgs == 0) return hipSuccess;
     hipError_t e;
     if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
-    frame_b_kernel<<<n_rerank + score_wgs, PIPE_B_BLOCK, 0, s>>>(rk, n_rerank, A);
+    frame_b_kernel<<<n_rerank + score_wgs, PIPE_BLOCK, 0, s>>>(rk, n_rerank, A);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }

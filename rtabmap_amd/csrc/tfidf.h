@@ -130,8 +130,7 @@ struct PipeKnn {
     void* partial; int32_t* out_row; int32_t* out_word; float* out_dist; int32_t* fail_list; int32_t* fail_count;
     CandBits cb;               // cb.selfdist != NULL: the filter launch also fills the same-frame distance matrix
 };
-int pipe_block_size();        // workgroup size of the fused re-rank + scoring launch
-int pipe_tail_block_size();   // workgroup size of the fused filter + tail launch
+int pipe_block_size();
 hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* tail, hipStream_t s, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wgs, hipStream_t s, hipEvent_t ev_begin = nullptr,
                           hipEvent_t ev_end = nullptr);
@@ -209,7 +208,7 @@ struct Tfidf {
     // register one signature whose word slots are already on the device (d_wslots[n]; < 0 = no word); if N > 0 the
     // frame's unique words / idf are left in q_* for a following score()
     // defer != NULL (needs resolve): do not launch the frame tail, leave its launch arguments there -- sized for a workgroup of
-    // pipe_tail_block_size() threads -- for the filter launch of the next frame to carry (knn_mfma_kernels.hip, frame_a_kernel)
+    // pipe_block_size() threads -- for the filter launch of the next frame to carry (knn_mfma_kernels.hip, frame_a_kernel)
     hipError_t register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N, const ResolveArgs* resolve = nullptr,
                             bool ids_given = false /* d_wslots holds word ids, translated on the device */, TailLaunch* defer = nullptr);
     // prepare q_* from word slots on the device without registering anything

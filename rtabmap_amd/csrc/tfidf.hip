@@ -930,7 +930,7 @@ static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool id
         a.src = resolve->out_wslot;
         const int mw = (resolve->q + 63) / 64 * 2;
         shmem = std::max(shmem, (size_t)(3 * mw + 2) * 4) + (size_t)n * 4;    // + the word slots handed over in LDS
-        const int block = defer ? pipe_tail_block_size() : FW_BLOCK;
+        const int block = defer ? pipe_block_size() : FW_BLOCK;
         const int n_redo = (resolve->rp.enabled && resolve->fail_count) ? (resolve->rp.n_rows + block - 1) / block : 0;
         if (defer) {                                                    // launched later, inside the next frame's filter launch
             defer->r = *resolve; defer->a = a; defer->ret = ret; defer->n_redo = n_redo; defer->shmem = shmem;
