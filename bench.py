@@ -157,7 +157,8 @@ def pmc_traffic(name):
     be read from inside the process); null when the profile is not there."""
     try:
         pmc = json.load(open(PMC_PROFILE))
-        return pmc[name]["hbm_bytes_per_launch"] / 1e9 if name in pmc else None
+        key = name.split(" ")[0].split("<")[0]
+        return pmc[key]["hbm_bytes_per_launch"] / 1e9 if key in pmc else None
     except Exception:
         return None
 
@@ -588,6 +589,10 @@ def main():
             key = "unpipelined" if args.pipeline else "pipelined"
             config[key + "_ms_per_step"] = 1e3 * ru["wall"] / max(50, min(args.steps, 200))
             config[key + "_kernel_ms"] = {"knn": ku["ms"], "score": su["ms"] if su else None}
+            if args.pipeline:
+                # the same two kernels launched on their own (not fused with the other frame's stages): their own rooflines
+                out["roofline_knn_standalone"] = ku
+                out["roofline_score_standalone"] = su
             config["with_update_ms_per_step"] = with_update_ms(torch, engu, vocab, stu, d_frames, frames_np)
             config["host_path_ms_per_step"] = host_path_ms(torch, engu, frames_np, n_sig)
             config["with_update_note"] = "step + D2H of the word ids + lcd_vocab_append of the frame's new words; every 8th frame " \

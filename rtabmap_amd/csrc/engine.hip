@@ -945,6 +945,7 @@ int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shar
     LCD_DEV(h);
     LCD_JOIN_K(h);
     if (q <= 0 || !d_descriptors || !d_cand) return h->fail(LCD_ERR_INVALID, "lcd_shard_knn2_dev: bad argument");
+    if (h->n_rows >= (1 << 26)) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_shard_knn2_dev: a shard holds at most 2^26 - 1 rows (merge key: 26-bit row, 6-bit rank)");
     int rc = run_knn2(h, d_descriptors, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), h->n_rows, h->d_knn_row,
                       h->d_knn_word, h->d_knn_dist);
     if (rc) return rc;

@@ -927,6 +927,9 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
             if (second == KEY_NONE) ok = false;                       // fewer than two exact candidates but rows were dropped
             else ok = __uint_as_float(bound) - eps > __uint_as_float((uint32_t)(second >> 32));
         }
+        // the certificate's premise is |filter score - exact distance| <= eps for every row; on the re-ranked candidates that error was
+        // just measured: half the budget used up anywhere means the bound is no longer trusted for this query -> exact redo
+        if (err_ratio >= 0.5f) ok = false;
         if (!ok) fail_list[atomicAdd(fail_count, 1)] = qi;
     }
     if (cb.bits) {                                                    // the query's row of the candidate bit matrix (uniform branch)
