@@ -111,6 +111,47 @@ class Stepper:
         self.first_new += Q          # ids are only reserved here (the words are never appended): any consecutive numbering will do
 
 
+# Bayes/PredictionLC as BayesFilter::setPredictionLC parses the default string (reference Parameters.h:363; uStr2Float -> double)
+PREDICTION_LC = np.asarray([0.1, 0.36, 0.30, 0.16, 0.062, 0.0151, 0.00255, 0.000324, 2.5e-05, 1.3e-06, 4.8e-08, 1.2e-09, 1.9e-11, 2.2e-13,
+                            1.7e-15, 8.5e-18, 2.9e-20, 6.9e-23], dtype=np.float32).astype(np.float64)
+STM = 30          # Mem/STMSize default: the newest signatures are not loop-closure candidates
+
+
+def chain_neighbors(first, last, lo):
+    """Neighbour lists (Memory::getNeighborsId on an odometry chain) of the signatures first..last, naming ids >= lo and <= the signature
+    itself (a list is handed over when its signature appears; the engine completes the older signatures' lists)."""
+    depth = PREDICTION_LC.shape[0] - 1
+    ids = np.arange(first, last + 1, dtype=np.int64)
+    d = np.arange(depth - 1, -1, -1, dtype=np.int64)                       # margins depth-1 .. 0  <->  neighbours id-(depth-1) .. id
+    nbr = ids[:, None] - d[None, :]
+    keep = nbr >= lo
+    counts = keep.sum(axis=1)
+    off = np.zeros(ids.shape[0] + 1, np.int64)
+    np.cumsum(counts, out=off[1:])
+    return ids.astype(np.int32), off, nbr[keep].astype(np.int32), np.broadcast_to(d[None, :], nbr.shape)[keep].astype(np.int32)
+
+
+class BayesStepper(Stepper):
+    """The step followed by the rest of Rtabmap::process' loop-closure decision on the device: adjustLikelihood, the Bayes filter's
+    update over the working memory and the highest hypothesis (32 bytes out); the new signature's neighbour list goes in behind it."""
+
+    def __init__(self, eng, torch, d_frames, n_sig, cap):
+        super().__init__(eng, torch, d_frames, n_sig, cap)
+        eng.bayes_configure(PREDICTION_LC, 0.9)
+        t0 = time.perf_counter()
+        eng.bayes_set_neighbors(*chain_neighbors(1, n_sig, 1))
+        eng.synchronize()
+        self.lists_load_s = time.perf_counter() - t0
+        self.d_res = torch.zeros(8, dtype=torch.int32, device="cuda")
+        self.args.exclude_recent = STM
+        self.args.d_bayes = self.d_res.data_ptr()
+
+    def __call__(self, i):
+        sid = self.next_sig
+        super().__call__(i)
+        self.eng.bayes_set_neighbors(*chain_neighbors(sid, sid, self.oldest))
+
+
 def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None, eng=None, per_step_events=True):
     """warmup untimed steps, then exactly `steps` steps bracketed by barrier + synchronize; an event per step for the distribution.
     eng: the engine the steps run on -- its events are recorded in call order (lcd_record_event: a threaded handle enqueues the index
@@ -599,6 +640,18 @@ def main():
                                          "lcd_vocab_remove of an older frame's words + lcd_vocab_rebuild"
             config["host_path_note"] = "lcd_quantize + lcd_sig_add + lcd_likelihood + lcd_sig_remove from host pointers (PCIe + syncs included)"
             engu.close()
+            engb = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 8192,
+                                      stream=stream.cuda_stream, pipeline=args.pipeline)
+            load_engine(engb, vocab, words)
+            stb = BayesStepper(engb, torch, d_frames, n_sig, cap)
+            rb = timed_loop(torch, dist, 1, stream, stb, max(50, min(args.steps, 200)), 10, eng=engb, per_step_events=False)
+            config["with_bayes_ms_per_step"] = 1e3 * rb["wall"] / max(50, min(args.steps, 200))
+            config["with_bayes_note"] = "step + adjustLikelihood + Bayes filter update over the working memory (chain graph, default Bayes/PredictionLC, " \
+                                        "STM %d) + highest hypothesis on the device; the new signature's neighbour list handed over per frame; " \
+                                        "%d lists loaded in %.2f s" % (STM, n_sig, stb.lists_load_s)
+            res = np.frombuffer(stb.d_res.cpu().numpy().tobytes(), dtype=np.int32)
+            config["with_bayes_last_hypothesis"] = {"sig_id": int(res[0]), "n_considered": int(res[5])}
+            engb.close()
         if not args.no_cpu_baseline:
             m = build_oracle(vocab, words)
             par, t_lin_port, t_lik = parity_block(torch, vocab, words, frames_np, m)

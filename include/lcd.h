@@ -216,8 +216,48 @@ typedef struct lcd_frame_args {
     float virtual_place_ratio;         /* Rtabmap/VirtualPlaceLikelihoodRatio (0 = default branch) */
     int32_t reserved0;
     void* ready_event;                 /* reserved (NULL) */
+    float* d_posterior;                /* out, may be NULL (needs d_likelihood and lcd_bayes_configure): the Bayes filter's posterior
+                                          after this frame, [n_slots + 1], entry 0 = virtual place, 0 for slots that are retired or
+                                          not considered (BayesFilter::computePosterior, BayesFilter.cpp:145-235) */
+    struct lcd_bayes_result* d_bayes;  /* out, may be NULL: the highest loop-closure hypothesis (Rtabmap.cpp:2147-2158), 32 bytes */
 } lcd_frame_args;
 int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* args);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Bayes filter over the signatures of the working memory ("next" row f2 of the scope table).
+ * == BayesFilter (corelib/src/BayesFilter.cpp): the posterior lives on the device, one float per signature slot; the
+ * reference's dense m x m prediction matrix (:313) is never formed -- each column's non-zeros are evaluated from the
+ * signature's graph-neighbour list.  The considered signatures are the live slots below n_slots - exclude_recent, as for
+ * the hypothesis of lcd_frame_dev (the reference passes the working memory's likelihood, Rtabmap.cpp:2050-2133). */
+typedef struct lcd_bayes_result {
+    int32_t sig_id;            /* _highestHypothesis.first: the considered signature with the highest posterior (0: none > 0) */
+    int32_t slot;              /* its slot (-1: none) */
+    float posterior;           /* its posterior */
+    float value;               /* _highestHypothesis.second = 1 - posterior of the virtual place (Rtabmap.cpp:2157) */
+    float virtual_place;       /* posterior of the virtual place */
+    int32_t n_considered;      /* signatures that took part (the reference's likelihood.size() - 1) */
+    float sum;                 /* normalisation constant of this update (BayesFilter.cpp:221) */
+    int32_t reserved;
+} lcd_bayes_result;
+/* BayesFilter::setPredictionLC (:77-122) + Bayes/VirtualPlacePriorThr: prediction_lc = {virtual place, loop closure, neighbour
+ * level 1, level 2, ...} as getPredictionLC() returns them (2..32 values in [0, 1]).  Needed before any update. */
+int lcd_bayes_configure(lcd_engine* h, const double* prediction_lc, int n_values, float virtual_place_prior);
+/* BayesFilter::reset (:138-143): forget the posterior and the neighbour lists */
+int lcd_bayes_reset(lcd_engine* h);
+/* The graph neighbourhood of n_sigs registered signatures: for signature sig_ids[i] the entries [offsets[i], offsets[i+1]) of
+ * nbr_sig_ids / nbr_margins are what Memory::getNeighborsId(id, prediction_lc.size() - 1, 0, false, false, true, true) returned
+ * (BayesFilter.cpp:328, :581) -- the signature itself with margin 0 included, margins in [0, n_values - 2].  Like the reference's
+ * incremental update (:583-592) every entry is also entered into the neighbour's own list (an existing entry for the same pair is
+ * replaced), so a signature's list is passed once, when it enters the working memory.  Neighbours that are not registered are
+ * skipped (they are in the long-term memory and can not be in a likelihood).  Host pointers. */
+int lcd_bayes_set_neighbors(lcd_engine* h, int n_sigs, const int32_t* sig_ids, const int64_t* offsets, const int32_t* nbr_sig_ids,
+                            const int32_t* nbr_margins);
+/* One filter update from an adjusted likelihood that is already on the device: d_adjusted[n_slots + 1] laid out as lcd_frame_dev
+ * writes it (entry 0 = virtual place, entry 1 + slot).  Enqueued, not synchronised.  d_posterior (may be NULL) like d_adjusted. */
+int lcd_bayes_update_dev(lcd_engine* h, const float* d_adjusted, int exclude_recent, float* d_posterior, lcd_bayes_result* d_result);
+/* the filter's current posterior for some signatures (host arrays; unknown / never considered signatures -> 0); sig id -1 = the
+ * virtual place.  Synchronises. */
+int lcd_bayes_posterior(lcd_engine* h, const int32_t* sig_ids, int n, float* out);
 /* lcd_knn2 with device-resident queries and outputs (d_word_ids[q*2], d_dist[q*2]); enqueued, not synchronised */
 int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_ids, float* d_dist);
 /* ---- vocabulary sharded by word-ID range over several engines/GPUs (one handle per rank).

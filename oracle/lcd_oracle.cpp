@@ -16,6 +16,8 @@
 //                                 preUpdate :1004-1016, cleanUnusedWords :6899-6920, disableWordsRef :6877-6897,
 //                                 createSignature quantisation glue :5941-6059 (ids -1,-2,.. for unquantised features)
 //   * Rtabmap::adjustLikelihood   corelib/src/Rtabmap.cpp:5691-5760 with uMean/uVariance (utilite UMath.h:419-432, 512-526)
+//   * BayesFilter                 corelib/src/BayesFilter.cpp:77-122, 145-270, 273-420, 434-500, 709-736; hypothesis
+//                                 selection corelib/src/Rtabmap.cpp:2147-2158
 //
 // Pinning (see tests/test_oracle_*.py): the distance functors and the exact 2-NN are checked against the reference's
 // own vendored rtflann compiled in place (oracle/_ref/librtflann_ref.so); the TF-IDF restatement is checked against
@@ -683,6 +685,233 @@ static void adjustLikelihood(float* L, int n, float virtualPlaceLikelihoodRatio)
     else L[0] = 2.0f;
 }
 
+
+// ================================================================================================ BayesFilter
+// corelib/src/BayesFilter.cpp: setPredictionLC :77-122, computePosterior :145-235, addNeighborProb :237-270,
+// generatePrediction :273-420 (the full update; the incremental updatePrediction :502-706 rebuilds the same columns from
+// cached neighbour maps), normalize :434-500, updatePosterior :709-736.  Hypothesis selection: Rtabmap.cpp:2147-2158.
+// Memory is replaced by what the filter asks it: getNeighborsId(id, LC.size() - 1, 0, false, false, true, true) answers
+// (`graph`, set by the test harness) and isInSTM (`stm`).  The matrix product prior = prediction * posterior is cv::gemm on
+// CV_32F data -- OpenCV is not in the reference tree: restated as a row-by-column sum accumulated in double and rounded to
+// float once (OpenCV's generic GEMM kernel for float uses double accumulators); "parity unpinned" for that rounding.
+// Two evaluations of the same arithmetic: `dense` allocates the m x m matrix and follows the reference statement by statement
+// (small m only); the sparse one keeps the non-zero elements of each column and is valid when _totalPredictionLCValues >= 1
+// (no "all other places" fill, true for the default Bayes/PredictionLC), for the 100k-signature tests.
+struct BayesFilter {
+    std::vector<double> predictionLC;
+    float virtualPlacePrior = 0.9f;            // Parameters.h Bayes/VirtualPlacePriorThr
+    float totalPredictionLCValues = 0.0f;
+    float predictionEpsilon = 0.0f;
+    std::map<int, float> posterior;
+    std::map<int, std::map<int, int> > graph;  // id -> (neighbour id -> margin), the harness' Memory::getNeighborsId
+    std::set<int> stm;
+
+    void setPredictionLC(const double* v, int n) {                       // :77-122 (values already parsed)
+        predictionLC.assign(v, v + n);
+        totalPredictionLCValues = 0.0f;
+        for (unsigned int j = 0; j < predictionLC.size(); ++j) {
+            totalPredictionLCValues += predictionLC[j];
+            if (j == 0 || predictionLC[j] < predictionEpsilon) predictionEpsilon = predictionLC[j];
+        }
+    }
+    void reset() { posterior.clear(); }
+
+    // ---- dense, literal
+    float addNeighborProb(std::vector<float>& P, int cols, unsigned int col, const std::map<int, int>& neighbors,
+                          const std::map<int, int>& idToIndex) {        // :237-270
+        float sum = 0.0f;
+        for (std::map<int, int>::const_iterator iter = neighbors.begin(); iter != neighbors.end(); ++iter) {
+            if (iter->first >= 0) {
+                std::map<int, int>::const_iterator jter = idToIndex.find(iter->first);
+                if (jter != idToIndex.end()) sum += P[col + (size_t)jter->second * cols] = predictionLC[iter->second + 1];
+            }
+        }
+        return sum;
+    }
+    void normalize(std::vector<float>& P, int cols, unsigned int index, float addedProbabilitiesSum, bool virtualPlaceUsed) {   // :434-500
+        if (addedProbabilitiesSum < totalPredictionLCValues - predictionLC[0]) {
+            float delta = totalPredictionLCValues - predictionLC[0] - addedProbabilitiesSum;
+            P[index + (size_t)index * cols] += delta;
+            addedProbabilitiesSum += delta;
+        }
+        float allOtherPlacesValue = 0;
+        if (totalPredictionLCValues < 1) allOtherPlacesValue = 1.0f - totalPredictionLCValues;
+        if (allOtherPlacesValue > 0 && cols > 1) {
+            float value = allOtherPlacesValue / float(cols - 1);
+            for (int j = virtualPlaceUsed ? 1 : 0; j < cols; ++j) {
+                if (P[index + (size_t)j * cols] == 0) { P[index + (size_t)j * cols] = value; addedProbabilitiesSum += P[index + (size_t)j * cols]; }
+            }
+        }
+        float maxNorm = 1 - (virtualPlaceUsed ? predictionLC[0] : 0);
+        if (addedProbabilitiesSum < maxNorm - 0.0001 || addedProbabilitiesSum > maxNorm + 0.0001) {
+            for (int j = virtualPlaceUsed ? 1 : 0; j < cols; ++j) {
+                P[index + (size_t)j * cols] *= maxNorm / addedProbabilitiesSum;
+                if (P[index + (size_t)j * cols] < predictionEpsilon) P[index + (size_t)j * cols] = 0.0f;
+            }
+            addedProbabilitiesSum = maxNorm;
+        }
+        if (virtualPlaceUsed) { P[index] = predictionLC[0]; addedProbabilitiesSum += P[index]; }
+    }
+    std::map<int, int> neighborsNotInStm(int id) const {                // :330-352 (the filter part)
+        std::map<int, int> neighbors;
+        std::map<int, std::map<int, int> >::const_iterator g = graph.find(id);
+        if (g != graph.end()) neighbors = g->second;
+        for (std::map<int, int>::iterator iter = neighbors.begin(); iter != neighbors.end();) {
+            if (stm.count(iter->first)) neighbors.erase(iter++); else ++iter;
+        }
+        return neighbors;
+    }
+    bool generatePredictionDense(const std::vector<int>& ids, std::vector<float>& P) {   // :273-420
+        const int cols = (int)ids.size();
+        std::map<int, int> idToIndexMap;
+        for (unsigned int i = 0; i < ids.size(); ++i) if (ids[i] > 0) idToIndexMap[ids[i]] = i;
+        P.assign((size_t)cols * cols, 0.0f);
+        std::set<int> idsDone;
+        for (unsigned int i = 0; i < ids.size(); ++i) {
+            if (idsDone.find(ids[i]) != idsDone.end()) continue;
+            if (ids[i] > 0) {
+                std::map<int, int> neighbors = neighborsNotInStm(ids[i]);
+                std::list<int> idsLoopMargin;
+                for (std::map<int, int>::iterator iter = neighbors.begin(); iter != neighbors.end(); ++iter)
+                    if (iter->second == 0 && idToIndexMap.find(iter->first) != idToIndexMap.end()) idsLoopMargin.push_back(iter->first);
+                if (idsLoopMargin.size() == 0) return false;            // UFATAL :357
+                for (std::list<int>::iterator iter = idsLoopMargin.begin(); iter != idsLoopMargin.end(); ++iter) {
+                    float sum = 0.0f;
+                    int index = idToIndexMap.at(*iter);
+                    sum += addNeighborProb(P, cols, index, neighbors, idToIndexMap);
+                    idsDone.insert(*iter);
+                    normalize(P, cols, index, sum, ids[0] < 0);
+                }
+            } else {
+                if (virtualPlacePrior > 0) {
+                    if (cols > 1) {
+                        P[i] = virtualPlacePrior;
+                        float val = (1.0 - virtualPlacePrior) / (cols - 1);
+                        for (int j = 1; j < cols; j++) P[i + (size_t)j * cols] = val;
+                    } else if (cols > 0) P[i] = 1;
+                } else {
+                    if (cols > 1) { float val = 1.0 / cols; for (int j = 0; j < cols; j++) P[i + (size_t)j * cols] = val; }
+                    else if (cols > 0) P[i] = 1;
+                }
+            }
+        }
+        return true;
+    }
+    void updatePosterior(const std::vector<int>& likelihoodIds) {       // :709-736
+        std::map<int, float> newPosterior;
+        for (std::vector<int>::const_iterator i = likelihoodIds.begin(); i != likelihoodIds.end(); ++i) {
+            std::map<int, float>::iterator post = posterior.find(*i);
+            if (post == posterior.end()) newPosterior.insert(std::pair<int, float>(*i, posterior.size() == 0 ? 1.0f : 0.0f));
+            else newPosterior.insert(std::pair<int, float>(post->first, post->second));
+        }
+        posterior = newPosterior;
+    }
+    // ---- sparse evaluation of the same columns (totalPredictionLCValues >= 1 only)
+    struct Column { std::vector<std::pair<int, float> > rows; float row0; };   // rows: matrix row index >= 1 -> value; row0 = P[0][c]
+    bool columnSparse(int c_index, const std::map<int, int>& neighbors, const std::map<int, int>& idToIndex, bool virtualPlaceUsed, int cols, Column& out) {
+        std::map<int, float> col;                                          // row -> value, like the dense column's non-zeros
+        float sum = 0.0f;
+        for (std::map<int, int>::const_iterator iter = neighbors.begin(); iter != neighbors.end(); ++iter) {
+            if (iter->first >= 0) {
+                std::map<int, int>::const_iterator jter = idToIndex.find(iter->first);
+                if (jter != idToIndex.end()) sum += col[jter->second] = predictionLC[iter->second + 1];
+            }
+        }
+        if (sum < totalPredictionLCValues - predictionLC[0]) {
+            float delta = totalPredictionLCValues - predictionLC[0] - sum;
+            col[c_index] += delta;
+            sum += delta;
+        }
+        if (totalPredictionLCValues < 1 && cols > 1) return false;         // needs the dense fill
+        float maxNorm = 1 - (virtualPlaceUsed ? predictionLC[0] : 0);
+        if (sum < maxNorm - 0.0001 || sum > maxNorm + 0.0001) {
+            for (std::map<int, float>::iterator e = col.begin(); e != col.end(); ++e) {
+                if (virtualPlaceUsed && e->first == 0) continue;
+                e->second *= maxNorm / sum;
+                if (e->second < predictionEpsilon) e->second = 0.0f;
+            }
+        }
+        out.rows.assign(col.begin(), col.end());
+        out.row0 = virtualPlaceUsed ? (float)predictionLC[0] : 0.0f;
+        return true;
+    }
+
+    // computePosterior :145-235.  likelihood: ids ascending (std::map order), ids[0] may be the virtual place (-1).
+    // returns 0 ok, -1 invalid input, -2 a signature without a 0-margin neighbour (UFATAL), -3 sparse evaluation not valid
+    int computePosterior(const int* ids_in, const float* like, int m, int dense, float* out) {
+        if (m <= 0 || predictionLC.size() < 2) return -1;
+        std::vector<int> ids(ids_in, ids_in + m);
+        const int cols = m;
+        std::vector<float> prior(m, 0.0f);
+        std::vector<float> post(m);
+        if (dense) {
+            std::vector<float> P;
+            if (!generatePredictionDense(ids, P)) return -2;
+            updatePosterior(ids);
+            int j = 0;
+            for (std::map<int, float>::const_iterator i = posterior.begin(); i != posterior.end(); ++i) post[j++] = i->second;
+            for (int r = 0; r < m; ++r) {
+                double acc = 0.0;
+                for (int c = 0; c < m; ++c) acc += (double)P[c + (size_t)r * cols] * (double)post[c];
+                prior[r] = (float)acc;
+            }
+        } else {
+            std::map<int, int> idToIndexMap;
+            for (unsigned int i = 0; i < ids.size(); ++i) if (ids[i] > 0) idToIndexMap[ids[i]] = i;
+            const bool vp = ids[0] < 0;
+            std::vector<Column> columns(m);
+            std::vector<char> done(m, 0);
+            for (int i = 0; i < m; ++i) {
+                if (done[i] || ids[i] <= 0) continue;
+                std::map<int, int> neighbors = neighborsNotInStm(ids[i]);
+                std::list<int> idsLoopMargin;
+                for (std::map<int, int>::iterator iter = neighbors.begin(); iter != neighbors.end(); ++iter)
+                    if (iter->second == 0 && idToIndexMap.find(iter->first) != idToIndexMap.end()) idsLoopMargin.push_back(iter->first);
+                if (idsLoopMargin.size() == 0) return -2;
+                for (std::list<int>::iterator iter = idsLoopMargin.begin(); iter != idsLoopMargin.end(); ++iter) {
+                    int index = idToIndexMap.at(*iter);
+                    if (!columnSparse(index, neighbors, idToIndexMap, vp, cols, columns[index])) return -3;
+                    done[index] = 1;
+                }
+            }
+            updatePosterior(ids);
+            int j = 0;
+            for (std::map<int, float>::const_iterator i = posterior.begin(); i != posterior.end(); ++i) post[j++] = i->second;
+            std::vector<double> acc(m, 0.0);
+            for (int c = 0; c < m; ++c) {
+                if (ids[c] <= 0) {                                         // the virtual place's column :376-411
+                    if (virtualPlacePrior > 0) {
+                        if (cols > 1) {
+                            acc[c] += (double)virtualPlacePrior * (double)post[c];
+                            float val = (1.0 - virtualPlacePrior) / (cols - 1);
+                            for (int r = 1; r < cols; ++r) acc[r] += (double)val * (double)post[c];
+                        } else acc[c] += (double)post[c];
+                    } else {
+                        if (cols > 1) { float val = 1.0 / cols; for (int r = 0; r < cols; ++r) acc[r] += (double)val * (double)post[c]; }
+                        else acc[c] += (double)post[c];
+                    }
+                    continue;
+                }
+                const Column& col = columns[c];
+                if (vp) acc[0] += (double)col.row0 * (double)post[c];
+                for (size_t e = 0; e < col.rows.size(); ++e) acc[col.rows[e].first] += (double)col.rows[e].second * (double)post[c];
+            }
+            for (int r = 0; r < m; ++r) prior[r] = (float)acc[r];
+        }
+        // STEP 2 :205-233
+        float sum = 0;
+        int j = 0;
+        for (int i = 0; i < m; ++i) {
+            std::map<int, float>::iterator p = posterior.find(ids[i]);
+            if (p != posterior.end()) { p->second = like[i] * prior[j++]; sum += p->second; }
+        }
+        if (sum != 0) for (std::map<int, float>::iterator i = posterior.begin(); i != posterior.end(); ++i) i->second /= sum;
+        j = 0;
+        for (std::map<int, float>::const_iterator i = posterior.begin(); i != posterior.end(); ++i) out[j++] = i->second;
+        return 0;
+    }
+};
+
 }  // namespace orc
 
 // =============================================================================================== C entry points (ctypes)
@@ -884,5 +1113,32 @@ int orc_mem_compute_likelihood(void* h, const int* words, int nwords, const int*
     return n;
 }
 void orc_adjust_likelihood(float* L, int n, float ratio) { adjustLikelihood(L, n, ratio); }
+
+// ---- BayesFilter
+void* orc_bayes_create(const double* lc, int n, float virtualPlacePrior) {
+    BayesFilter* b = new BayesFilter();
+    b->setPredictionLC(lc, n);
+    b->virtualPlacePrior = virtualPlacePrior;
+    return b;
+}
+void orc_bayes_destroy(void* h) { delete (BayesFilter*)h; }
+void orc_bayes_reset(void* h) { ((BayesFilter*)h)->reset(); }
+// what Memory::getNeighborsId(id, LC.size() - 1, 0, false, false, true, true) returns from now on
+void orc_bayes_set_neighbors(void* h, int id, const int* nbr, const int* margin, int n) {
+    std::map<int, int>& g = ((BayesFilter*)h)->graph[id];
+    g.clear();
+    for (int i = 0; i < n; ++i) g[nbr[i]] = margin[i];
+}
+void orc_bayes_set_stm(void* h, const int* ids, int n) { BayesFilter* b = (BayesFilter*)h; b->stm.clear(); b->stm.insert(ids, ids + n); }
+int orc_bayes_compute_posterior(void* h, const int* ids, const float* like, int m, int dense, float* out) {
+    return ((BayesFilter*)h)->computePosterior(ids, like, m, dense, out);
+}
+// Rtabmap.cpp:2147-2158: walk from the highest id down, strict comparison, ids > 0 only; value = 1 - posterior of the first entry
+void orc_bayes_hypothesis(const int* ids, const float* post, int m, int* out_id, float* out_value) {
+    int best = 0; float v = 0.0f;
+    for (int i = m - 1; i >= 0; --i) if (ids[i] > 0 && post[i] > v) { best = ids[i]; v = post[i]; }
+    *out_id = best;
+    *out_value = m > 0 ? 1 - post[0] : 0.0f;
+}
 
 }  // extern "C"

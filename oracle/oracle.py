@@ -85,6 +85,14 @@ def lib():
         L.orc_mem_signature_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_mem_compute_likelihood.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_adjust_likelihood.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.orc_bayes_create.restype = C.c_void_p
+        L.orc_bayes_create.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.orc_bayes_destroy.argtypes = [C.c_void_p]
+        L.orc_bayes_reset.argtypes = [C.c_void_p]
+        L.orc_bayes_set_neighbors.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_bayes_set_stm.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_bayes_compute_posterior.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_bayes_hypothesis.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -365,3 +373,59 @@ class OracleMemory:
         if n < 0:
             return np.zeros(0, np.int32), np.zeros(0, np.float32)
         return oid[:n], out[:n]
+
+
+# Bayes/PredictionLC default (reference Parameters.h:363) and Bayes/VirtualPlacePriorThr (:361)
+DEFAULT_PREDICTION_LC = [0.1, 0.36, 0.30, 0.16, 0.062, 0.0151, 0.00255, 0.000324, 2.5e-05, 1.3e-06, 4.8e-08, 1.2e-09, 1.9e-11, 2.2e-13,
+                         1.7e-15, 8.5e-18, 2.9e-20, 6.9e-23]
+DEFAULT_VIRTUAL_PLACE_PRIOR = 0.9
+
+
+class OracleBayesFilter:
+    """BayesFilter (reference BayesFilter.cpp); Memory::getNeighborsId / isInSTM are answered from set_neighbors / set_stm."""
+
+    def __init__(self, prediction_lc=None, virtual_place_prior=DEFAULT_VIRTUAL_PLACE_PRIOR):
+        lc = np.ascontiguousarray(DEFAULT_PREDICTION_LC if prediction_lc is None else prediction_lc, dtype=np.float64)
+        self.h = lib().orc_bayes_create(_ptr(lc), lc.shape[0], virtual_place_prior)
+
+    def close(self):
+        if self.h:
+            lib().orc_bayes_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        lib().orc_bayes_reset(self.h)
+
+    def set_neighbors(self, sig_id, nbr_ids, margins):
+        a = np.ascontiguousarray(nbr_ids, dtype=np.int32)
+        b = np.ascontiguousarray(margins, dtype=np.int32)
+        lib().orc_bayes_set_neighbors(self.h, int(sig_id), _ptr(a), _ptr(b), a.shape[0])
+
+    def set_stm(self, ids):
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        lib().orc_bayes_set_stm(self.h, _ptr(a), a.shape[0])
+
+    def compute_posterior(self, ids, likelihood, dense=False):
+        """ids ascending (ids[0] may be -1, the virtual place); returns the posterior in the same order (float32)."""
+        i = np.ascontiguousarray(ids, dtype=np.int32)
+        l = np.ascontiguousarray(likelihood, dtype=np.float32)
+        out = np.zeros(i.shape[0], np.float32)
+        rc = lib().orc_bayes_compute_posterior(self.h, _ptr(i), _ptr(l), i.shape[0], 1 if dense else 0, _ptr(out))
+        if rc:
+            raise RuntimeError("orc_bayes_compute_posterior: %d" % rc)
+        return out
+
+    @staticmethod
+    def hypothesis(ids, posterior):
+        i = np.ascontiguousarray(ids, dtype=np.int32)
+        p = np.ascontiguousarray(posterior, dtype=np.float32)
+        oid = C.c_int(0)
+        val = C.c_float(0)
+        lib().orc_bayes_hypothesis(_ptr(i), _ptr(p), i.shape[0], C.byref(oid), C.byref(val))
+        return oid.value, val.value

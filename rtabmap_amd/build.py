@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblcd_hip.so")
-SOURCES = ["knn2_kernels.hip", "knn_mfma_kernels.hip", "resolve_kernels.hip", "tfidf.hip", "engine.hip"]
+SOURCES = ["knn2_kernels.hip", "knn_mfma_kernels.hip", "resolve_kernels.hip", "tfidf.hip", "bayes.hip", "engine.hip"]
 # -ffp-contract=off: the L2 distance must round every product and sum like the reference (no FMA contraction)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          # MFMA results straight into VGPRs: the top-3 epilogue of knn_mfma_filter_kernel reads them with VALU, and an

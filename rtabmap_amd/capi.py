@@ -23,6 +23,7 @@ SYMBOLS = [
     "lcd_knn2", "lcd_selfdist", "lcd_quantize", "lcd_find_nn",
     "lcd_sig_add", "lcd_sig_remove", "lcd_sig_add_bulk", "lcd_sig_count", "lcd_word_nrefs",
     "lcd_likelihood", "lcd_adjust_likelihood", "lcd_adjust_likelihood_dev", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood", "lcd_profile_score_work", "lcd_set_option", "lcd_record_event",
+    "lcd_bayes_configure", "lcd_bayes_reset", "lcd_bayes_set_neighbors", "lcd_bayes_update_dev", "lcd_bayes_posterior",
 ]
 
 
@@ -46,7 +47,13 @@ class LcdFrameArgs(C.Structure):
                 ("nndr_ratio", C.c_float), ("sig_id", C.c_int32), ("first_new_word_id", C.c_int32), ("N", C.c_float),
                 ("exclude_recent", C.c_int32), ("d_word_ids", C.c_void_p), ("d_likelihood", C.c_void_p),
                 ("likelihood_capacity", C.c_int64), ("d_hypothesis", C.c_void_p), ("d_adjusted", C.c_void_p),
-                ("virtual_place_ratio", C.c_float), ("reserved0", C.c_int32), ("ready_event", C.c_void_p)]
+                ("virtual_place_ratio", C.c_float), ("reserved0", C.c_int32), ("ready_event", C.c_void_p),
+                ("d_posterior", C.c_void_p), ("d_bayes", C.c_void_p)]
+
+
+class LcdBayesResult(C.Structure):
+    _fields_ = [("sig_id", C.c_int32), ("slot", C.c_int32), ("posterior", C.c_float), ("value", C.c_float),
+                ("virtual_place", C.c_float), ("n_considered", C.c_int32), ("sum", C.c_float), ("reserved", C.c_int32)]
 
 
 class LcdStats(C.Structure):
@@ -125,6 +132,11 @@ def load():
     L.lcd_profile_score_work.argtypes = [vp, C.POINTER(i64)]
     L.lcd_set_option.argtypes = [vp, C.c_char_p, i64]
     L.lcd_record_event.argtypes = [vp, vp]
+    L.lcd_bayes_configure.argtypes = [vp, vp, C.c_int, f32]
+    L.lcd_bayes_reset.argtypes = [vp]
+    L.lcd_bayes_set_neighbors.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.lcd_bayes_update_dev.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.lcd_bayes_posterior.argtypes = [vp, vp, C.c_int, vp]
     _lib = L
     return L
 
@@ -280,11 +292,11 @@ class Engine:
     # ---- device-resident frame path
     def frame_dev(self, d_desc_ptr, q, sig_id, N, d_word_ids_ptr, d_like_ptr, like_capacity, incremental=True,
                   new_words_compared=True, nndr=0.8, first_new_word_id=0, d_hypothesis_ptr=None, d_adjusted_ptr=None,
-                  exclude_recent=0, virtual_place_ratio=0.0, ready_event=None):
+                  exclude_recent=0, virtual_place_ratio=0.0, ready_event=None, d_posterior_ptr=None, d_bayes_ptr=None):
         flags = (LCD_Q_INCREMENTAL if incremental else 0) | (LCD_Q_NEW_WORDS_COMPARED if new_words_compared else 0)
         a = LcdFrameArgs(C.sizeof(LcdFrameArgs), q, d_desc_ptr, flags, nndr, sig_id, first_new_word_id, float(N), exclude_recent,
                          d_word_ids_ptr, d_like_ptr, like_capacity, d_hypothesis_ptr, d_adjusted_ptr, virtual_place_ratio, 0,
-                         ready_event)
+                         ready_event, d_posterior_ptr, d_bayes_ptr)
         self._ck(self.L.lcd_frame_dev(self.h, C.byref(a)))
 
     def frame_args(self, **kw):
@@ -299,6 +311,31 @@ class Engine:
         rc = self.L.lcd_frame_dev(self.h, C.byref(a))
         if rc != LCD_OK:
             self._ck(rc)
+
+    # ---- Bayes filter (BayesFilter.cpp)
+    def bayes_configure(self, prediction_lc, virtual_place_prior=0.9):
+        lc = np.ascontiguousarray(prediction_lc, dtype=np.float64)
+        self._ck(self.L.lcd_bayes_configure(self.h, _p(lc), lc.shape[0], virtual_place_prior))
+
+    def bayes_reset(self):
+        self._ck(self.L.lcd_bayes_reset(self.h))
+
+    def bayes_set_neighbors(self, sig_ids, offsets, nbr_sig_ids, nbr_margins):
+        s = np.ascontiguousarray(sig_ids, dtype=np.int32)
+        o = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = np.ascontiguousarray(nbr_sig_ids, dtype=np.int32)
+        m = np.ascontiguousarray(nbr_margins, dtype=np.int32)
+        assert o.shape[0] == s.shape[0] + 1 and n.shape[0] == m.shape[0]
+        self._ck(self.L.lcd_bayes_set_neighbors(self.h, s.shape[0], _p(s), _p(o), _p(n), _p(m)))
+
+    def bayes_update_dev(self, d_adjusted_ptr, exclude_recent=0, d_posterior_ptr=None, d_result_ptr=None):
+        self._ck(self.L.lcd_bayes_update_dev(self.h, d_adjusted_ptr, exclude_recent, d_posterior_ptr, d_result_ptr))
+
+    def bayes_posterior(self, sig_ids):
+        s = np.ascontiguousarray(sig_ids, dtype=np.int32)
+        out = np.zeros(s.shape[0], np.float32)
+        self._ck(self.L.lcd_bayes_posterior(self.h, _p(s), s.shape[0], _p(out)))
+        return out
 
     def knn2_dev(self, d_queries_ptr, q, d_word_ids_ptr, d_dist_ptr):
         self._ck(self.L.lcd_knn2_dev(self.h, d_queries_ptr, q, d_word_ids_ptr, d_dist_ptr))

@@ -9,6 +9,7 @@
 #include "../../include/lcd.h"
 #include "devbuf.h"
 #include "lcd_kernels.h"
+#include "bayes.h"
 #include "tfidf.h"
 
 
@@ -58,10 +59,13 @@ struct lcd_engine {
     struct Deferred { bool valid = false; lcd_frame_args a; lcd::ResolveArgs r; } deferred;
     std::vector<int32_t> deferred_retire;               // lcd_sig_remove calls made while a frame's index stage is owed
     std::vector<void*> deferred_events;                 // lcd_record_event calls made while a frame's index stage is owed
+    std::vector<std::vector<int32_t> > deferred_links;  // lcd_bayes_set_neighbors calls made while a frame's index stage is owed
     int sync_all();                                     // stream drained
     int drain();                                        // complete the owed index stage (stand-alone launches)
     const char* prof2_kernel = "score_kernel";
     lcd::PinBuf h_in, h_out, h_out2;
+    lcd::Bayes bayes;                                   // Bayes filter over the signature slots (bayes.h)
+    lcd::DevBuf d_adj_scratch;                          // adjusted likelihood when the caller wants the posterior but not that vector
     lcd::DevBuf d_hyp_scratch;                          // hypothesis record when the caller only wants the adjusted vector
 
     // ---- inverted index / TF-IDF

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <numeric>
+#include <unordered_map>
 
 using namespace lcd;
 
@@ -200,6 +201,7 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
         if (e == hipSuccess) e = hipMemsetAsync(h->alt.d_fail_count.p, 0, 64, h->stream);
     }
     if (e == hipSuccess) e = h->tfidf.init(h->stream, &h->bytes_device, cfg->sig_capacity, cfg->vocab_capacity);
+    h->bayes.init(h->stream, &h->bytes_device);
     if (e != hipSuccess) { lcd_destroy(h); return LCD_ERR_HIP; }
     *out = h;
     return LCD_OK;
@@ -211,6 +213,7 @@ void lcd_destroy(lcd_engine* h) {
     (void)h->drain();
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->tfidf.destroy();
+    h->bayes.destroy();
     {
         DevBuf* alts[] = {&h->alt.d_knn_row, &h->alt.d_knn_word, &h->alt.d_knn_dist, &h->alt.d_selfdist, &h->alt.d_bits, &h->alt.d_partial2,
                           &h->alt.d_partial3, &h->alt.d_fail_list, &h->alt.d_fail_count, &h->alt.d_out_wslot};
@@ -222,7 +225,7 @@ void lcd_destroy(lcd_engine* h) {
                      &h->d_partial, &h->d_knn_row, &h->d_knn_word, &h->d_knn_wslot, &h->d_knn_dist, &h->d_selfdist, &h->d_out_word,
                      &h->d_out_wslot, &h->d_n_new, &h->d_tmp_i32, &h->d_extra_rows, &h->d_extra_id, &h->d_extra_word,
                      &h->d_extra_dist, &h->d_extra_row, &h->d_like, &h->d_slots, &h->d_bits, &h->row_norm, &h->norm_max, &h->d_partial2,
-                     &h->d_fail_list, &h->d_fail_count, &h->d_partial3, &h->row_norm_alt, &h->vocab_bf, &h->d_hyp_scratch};
+                     &h->d_fail_list, &h->d_fail_count, &h->d_partial3, &h->row_norm_alt, &h->vocab_bf, &h->d_hyp_scratch, &h->d_adj_scratch};
     for (DevBuf* d : all) d->release(&h->bytes_device);
     h->h_in.release(); h->h_out.release(); h->h_out2.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -767,6 +770,24 @@ struct FrameHostTimer {   // host time spent inside lcd_frame_dev (lcd_stats.fra
 }  // namespace
 
 // the index stage of a frame, launched on its own: registration (or query preparation), scoring, hypothesis
+// Rtabmap::adjustLikelihood + the best candidate (Rtabmap.cpp:2121-2158), then the Bayes filter's update and its highest
+// hypothesis (Rtabmap.cpp:2133-2158), without any vector leaving the device.  The frame's likelihood is already enqueued.
+static int hypothesis_stage(lcd_engine* h, const lcd_frame_args& a) {
+    Tfidf& t = h->tfidf;
+    const bool bayes = a.d_posterior || a.d_bayes;
+    if (!(a.d_hypothesis || a.d_adjusted || bayes)) return LCD_OK;
+    float* adjusted = a.d_adjusted;
+    if (bayes && !adjusted) {
+        LCD_HIP(h, dreserve(h, h->d_adj_scratch, (size_t)(t.n_slots + 1) * 4));
+        adjusted = h->d_adj_scratch.as<float>();
+    }
+    HypothesisOut* out = a.d_hypothesis ? (HypothesisOut*)a.d_hypothesis : (HypothesisOut*)h->d_hyp_scratch.p;
+    const long long n_cons = (long long)t.n_slots - std::max(a.exclude_recent, 0);
+    LCD_HIP(h, launch_hypothesis(a.d_likelihood, t.slot_sig.as<int32_t>(), (long long)t.n_slots, n_cons, a.virtual_place_ratio, adjusted, out, h->stream));
+    if (bayes) LCD_HIP(h, h->bayes.update(adjusted, t.slot_sig.as<int32_t>(), t.n_slots, n_cons, a.d_posterior, (BayesOut*)a.d_bayes));
+    return LCD_OK;
+}
+
 static int frame_stage_s(lcd_engine* h, const lcd_frame_args& a, ResolveArgs r) {
     Tfidf& t = h->tfidf;
     const int q = a.q;
@@ -790,13 +811,7 @@ static int frame_stage_s(lcd_engine* h, const lcd_frame_args& a, ResolveArgs r) 
         LCD_HIP(h, t.score(a.d_likelihood));
         if (t.prof_b) { t.prof_b = t.prof_e = nullptr; h->prof2_n -= 1; }     // the launch that would have been bracketed did not happen
         h->likelihood_launches += 1;
-        if (a.d_hypothesis || a.d_adjusted) {
-            // Rtabmap::adjustLikelihood + the best candidate, without the vector leaving the device (Rtabmap.cpp:2121-2158)
-            HypothesisOut* out = a.d_hypothesis ? (HypothesisOut*)a.d_hypothesis : (HypothesisOut*)h->d_hyp_scratch.p;
-            const long long n_cons = (long long)t.n_slots - std::max(a.exclude_recent, 0);
-            LCD_HIP(h, launch_hypothesis(a.d_likelihood, t.slot_sig.as<int32_t>(), (long long)t.n_slots, n_cons, a.virtual_place_ratio,
-                                         a.d_adjusted, out, h->stream));
-        }
+        { int rc = hypothesis_stage(h, a); if (rc) return rc; }
     }
     return LCD_OK;
 }
@@ -806,6 +821,11 @@ static int frame_stage_s(lcd_engine* h, const lcd_frame_args& a, ResolveArgs r) 
 static int finish_deferred_tail(lcd_engine* h) {
     for (int32_t sig : h->deferred_retire) LCD_HIP(h, h->tfidf.retire(sig));
     h->deferred_retire.clear();
+    for (const std::vector<int32_t>& tr : h->deferred_links) {
+        LCD_HIP(h, h->bayes.ensure(std::max<int64_t>(h->tfidf.n_slots, 1)));
+        LCD_HIP(h, h->bayes.link(tr));
+    }
+    h->deferred_links.clear();
     for (void* ev : h->deferred_events) LCD_HIP(h, hipEventRecord((hipEvent_t)ev, h->stream));
     h->deferred_events.clear();
     return LCD_OK;
@@ -888,12 +908,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     h->fail_count_clean = true;                                      // this frame's tail (next launch A) resets the counters
     if (prev) {
         const lcd_frame_args& pa = h->deferred.a;
-        if (pa.d_likelihood && (pa.d_hypothesis || pa.d_adjusted)) {
-            HypothesisOut* out = pa.d_hypothesis ? (HypothesisOut*)pa.d_hypothesis : (HypothesisOut*)h->d_hyp_scratch.p;
-            const long long n_cons = (long long)t.n_slots - std::max(pa.exclude_recent, 0);
-            LCD_HIP(h, launch_hypothesis(pa.d_likelihood, t.slot_sig.as<int32_t>(), (long long)t.n_slots, n_cons, pa.virtual_place_ratio,
-                                         pa.d_adjusted, out, h->stream));
-        }
+        if (pa.d_likelihood) { int rc = hypothesis_stage(h, pa); if (rc) return rc; }
         int rc = finish_deferred_tail(h);                            // retirements / events requested after the previous frame
         if (rc) return rc;
     }
@@ -918,7 +933,9 @@ int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     if (!a || a->struct_size != (int32_t)sizeof(lcd_frame_args)) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: bad argument block");
     const int q = a->q;
     if (q <= 0 || q > 8192 || !a->d_descriptors || !a->d_word_ids) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: bad argument");
-    if ((a->d_hypothesis || a->d_adjusted) && !a->d_likelihood) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: the hypothesis needs d_likelihood");
+    if ((a->d_hypothesis || a->d_adjusted || a->d_posterior || a->d_bayes) && !a->d_likelihood)
+        return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: the hypothesis needs d_likelihood");
+    if ((a->d_posterior || a->d_bayes) && !h->bayes.configured) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: lcd_bayes_configure first");
     if (h->pipeline && q <= 4096 && h->knn_mode == 2 && knn_mfma_supported(h->dtype, h->kdim) && h->n_live >= 2 && h->n_rows >= 256)
         return frame_pipelined(h, a);
     { int rc = h->drain(); if (rc) return rc; }
@@ -938,6 +955,111 @@ int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_id
     if (q <= 0 || !d_queries || !d_word_ids || !d_dist) return h->fail(LCD_ERR_INVALID, "lcd_knn2_dev: bad argument");
     LCD_HIP(h, dreserve(h, h->d_knn_row, (size_t)q * 2 * 4));
     return run_knn2_raw(h, d_queries, q, h->vocab.p, h->row_id.as<int32_t>(), h->n_rows, true, h->d_knn_row.as<int32_t>(), d_word_ids, d_dist);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- Bayes filter
+int lcd_bayes_configure(lcd_engine* h, const double* prediction_lc, int n_values, float virtual_place_prior) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (!prediction_lc) return h->fail(LCD_ERR_INVALID, "lcd_bayes_configure: bad argument");
+    if (h->bayes.configure(prediction_lc, n_values, virtual_place_prior) != hipSuccess)
+        return h->fail(LCD_ERR_INVALID, "lcd_bayes_configure: 2..32 values in [0, 1] and a prior in [0, 1] expected");   // the reference logs UERROR (:83, :103)
+    return LCD_OK;
+}
+
+int lcd_bayes_reset(lcd_engine* h) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    LCD_HIP(h, h->bayes.reset());
+    return LCD_OK;
+}
+
+int lcd_bayes_set_neighbors(lcd_engine* h, int n_sigs, const int32_t* sig_ids, const int64_t* offsets, const int32_t* nbr_sig_ids,
+                            const int32_t* nbr_margins) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV_NODRAIN(h);                                       // a pipelined handle queues the lists behind the index stage it still owes
+    if (n_sigs < 0 || (n_sigs > 0 && (!sig_ids || !offsets))) return h->fail(LCD_ERR_INVALID, "lcd_bayes_set_neighbors: bad argument");
+    if (!h->bayes.configured) return h->fail(LCD_ERR_STATE, "lcd_bayes_set_neighbors: lcd_bayes_configure first");
+    if (n_sigs == 0) return LCD_OK;
+    if (offsets[n_sigs] > offsets[0] && (!nbr_sig_ids || !nbr_margins)) return h->fail(LCD_ERR_INVALID, "lcd_bayes_set_neighbors: bad argument");
+    Tfidf& t = h->tfidf;
+    if (t.n_slots >= (1ll << BAYES_SLOT_BITS)) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_bayes_set_neighbors: at most 2^27 signature slots");
+    const int max_margin = h->bayes.prm.n_lc - 2;
+    std::vector<uint64_t> keys;                               // (slot a << 32 | slot b), a <= b; the margin rides in a parallel map
+    std::vector<int32_t> triples;
+    std::unordered_map<uint64_t, int32_t> seen;
+    seen.reserve((size_t)(offsets[n_sigs] - offsets[0]) * 2 + 16);
+    // the signature of a frame whose index stage is still owed has no slot yet: it will get the next one
+    const int32_t owed_sig = h->deferred.valid ? h->deferred.a.sig_id : 0;
+    const bool owed_gone = owed_sig != 0 && std::find(h->deferred_retire.begin(), h->deferred_retire.end(), owed_sig) != h->deferred_retire.end();
+    auto slot_of = [&](int32_t id) -> int64_t {
+        if (owed_sig != 0 && id == owed_sig) return owed_gone ? -1 : t.n_slots;
+        auto it = t.sig_slot.find(id);
+        if (it == t.sig_slot.end()) return -1;
+        if (std::find(h->deferred_retire.begin(), h->deferred_retire.end(), id) != h->deferred_retire.end()) return -1;
+        return it->second;
+    };
+    for (int i = 0; i < n_sigs; ++i) {
+        const int64_t a = slot_of(sig_ids[i]);
+        if (a < 0) return h->fail(LCD_ERR_STATE, "lcd_bayes_set_neighbors: unknown signature");
+        if (offsets[i + 1] < offsets[i]) return h->fail(LCD_ERR_INVALID, "lcd_bayes_set_neighbors: offsets must not decrease");
+        for (int64_t e = offsets[i]; e < offsets[i + 1]; ++e) {
+            const int32_t m = nbr_margins[e];
+            if (m < 0 || m > max_margin) return h->fail(LCD_ERR_INVALID, "lcd_bayes_set_neighbors: margin outside the prediction's levels");   // UASSERT :263
+            if (nbr_sig_ids[e] < 0) continue;                 // "if(iter->first>=0)" (:254)
+            const int64_t b = slot_of(nbr_sig_ids[e]);
+            if (b < 0) continue;                              // not in memory: it can not be in a likelihood
+            const uint64_t key = ((uint64_t)std::min(a, b) << 32) | (uint64_t)std::max(a, b);
+            auto st = seen.find(key);
+            if (st != seen.end()) { triples[(size_t)st->second * 3 + 2] = m; continue; }   // listed from both ends: the later margin stays
+            seen.emplace(key, (int32_t)(triples.size() / 3));
+            triples.push_back((int32_t)std::min(a, b)); triples.push_back((int32_t)std::max(a, b)); triples.push_back(m);
+        }
+    }
+    if (h->deferred.valid) { h->deferred_links.push_back(std::move(triples)); return LCD_OK; }
+    LCD_HIP(h, h->bayes.ensure(std::max<int64_t>(t.n_slots, 1)));
+    LCD_HIP(h, h->bayes.link(triples));
+    return LCD_OK;
+}
+
+int lcd_bayes_update_dev(lcd_engine* h, const float* d_adjusted, int exclude_recent, float* d_posterior, lcd_bayes_result* d_result) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (!d_adjusted) return h->fail(LCD_ERR_INVALID, "lcd_bayes_update_dev: bad argument");
+    if (!h->bayes.configured) return h->fail(LCD_ERR_STATE, "lcd_bayes_update_dev: lcd_bayes_configure first");
+    Tfidf& t = h->tfidf;
+    LCD_HIP(h, t.flush_retire());                             // slot_sig must show the retirements asked for so far
+    const long long n_cons = (long long)t.n_slots - std::max(exclude_recent, 0);
+    LCD_HIP(h, h->bayes.update(d_adjusted, t.slot_sig.as<int32_t>(), t.n_slots, n_cons, d_posterior, (BayesOut*)d_result));
+    return LCD_OK;
+}
+
+int lcd_bayes_posterior(lcd_engine* h, const int32_t* sig_ids, int n, float* out) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (n < 0 || (n > 0 && (!sig_ids || !out))) return h->fail(LCD_ERR_INVALID, "lcd_bayes_posterior: bad argument");
+    if (n == 0) return LCD_OK;
+    Tfidf& t = h->tfidf;
+    std::vector<float> all;
+    const int64_t have = std::min<int64_t>(t.n_slots, h->bayes.cap);
+    all.assign((size_t)have + 1, 0.0f);
+    std::vector<uint8_t> in((size_t)have + 1, 0);
+    if (h->bayes.post.p && !h->bayes.empty) {
+        LCD_HIP(h, hipMemcpyAsync(all.data(), h->bayes.post.p, ((size_t)have + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+        if (have > 0) LCD_HIP(h, hipMemcpyAsync(in.data() + 1, h->bayes.was_in.p, (size_t)have, hipMemcpyDeviceToHost, h->stream));
+        LCD_HIP(h, hipStreamSynchronize(h->stream));
+        in[0] = 1;
+    }
+    for (int i = 0; i < n; ++i) {
+        float v = 0.0f;
+        if (sig_ids[i] == -1) v = in[0] ? all[0] : 0.0f;
+        else {
+            auto it = t.sig_slot.find(sig_ids[i]);
+            if (it != t.sig_slot.end() && it->second < have && in[(size_t)it->second + 1]) v = all[(size_t)it->second + 1];
+        }
+        out[i] = v;
+    }
+    return LCD_OK;
 }
 
 int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shard_cand* d_cand) {

@@ -1,0 +1,81 @@
+"""The oracle's BayesFilter restatement (oracle/lcd_oracle.cpp) against the reference's own known-answer table
+(archive/2010-LoopClosure/Tests/TestBayesFilter.m:32) and against itself (dense literal evaluation vs sparse evaluation)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from bayes_model import DEFAULT_LC, Graph, csr_lists, prediction_lc_as_parsed, random_adjusted, random_graph
+
+# TestBayesFilter.m:32: floor(posterior * 1000) after each of 10 updates with likelihood = 1, predictionNP = 0.9,
+# predictionLC = [0.1 0.24 0.18 0.18 0.1 0.1 0.04 0.04 0.01 0.01] (MATLAB format: one value per side and level)
+GOLDEN = np.array([
+    [1000, 0, 0, 0, 0, 0, 0, 0, 0, 0], [900, 99, 0, 0, 0, 0, 0, 0, 0, 0], [820, 117, 62, 0, 0, 0, 0, 0, 0, 0],
+    [756, 111, 82, 50, 0, 0, 0, 0, 0, 0], [704, 103, 84, 67, 40, 0, 0, 0, 0, 0], [663, 96, 82, 69, 54, 32, 0, 0, 0, 0],
+    [631, 90, 79, 69, 58, 44, 26, 0, 0, 0], [604, 84, 76, 68, 58, 48, 36, 21, 0, 0], [583, 79, 73, 66, 58, 49, 40, 30, 17, 0],
+    [567, 74, 69, 64, 58, 50, 41, 33, 25, 14]])
+
+
+@pytest.mark.parametrize("dense", [True, False])
+def test_matlab_known_answers(dense):
+    # the C++ prediction format has one value per level; a sixth value that no list ever reaches (the harness answers
+    # getNeighborsId to depth 4, as the MATLAB model does) brings the total to 1 like the MATLAB pattern's sum
+    lc = prediction_lc_as_parsed([0.1, 0.24, 0.18, 0.1, 0.04, 0.01, 0.33])
+    b = O.OracleBayesFilter(lc, 0.9)
+    for it in range(1, 11):
+        places = list(range(1, it))
+        g = Graph(max(it - 1, 1))
+        for s in places:
+            d = {k: v for k, v in g.neighbors(s, 5).items() if k < it}
+            b.set_neighbors(s, sorted(d), [d[k] for k in sorted(d)])
+        ids = [-1] + places
+        post = b.compute_posterior(ids, np.ones(len(ids), np.float32), dense=dense)
+        got = np.zeros(10)
+        got[:len(ids)] = np.floor(post.astype(np.float64) * 1000.0)
+        # the table was produced in double precision; the reference's C++ (and this restatement) computes in float:
+        # a value that sits on an integer boundary (0.1 * 1000) may fall on either side
+        assert np.all(np.abs(got - GOLDEN[it - 1]) <= 1), (it, got, GOLDEN[it - 1])
+        assert abs(float(post.sum()) - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_dense_and_sparse_evaluations_agree(seed):
+    rng = np.random.default_rng(seed)
+    n = 120
+    g = random_graph(n, 8, rng)
+    depth = DEFAULT_LC.shape[0] - 1
+    bd, bs = O.OracleBayesFilter(DEFAULT_LC), O.OracleBayesFilter(DEFAULT_LC)
+    for s in range(1, n + 1):
+        d = g.neighbors(s, depth)
+        for b in (bd, bs):
+            b.set_neighbors(s, sorted(d), [d[k] for k in sorted(d)])
+    stm = 5
+    for t in range(10, n + 1, 7):
+        wm = [s for s in range(1, t - stm + 1) if (s * 7 + seed) % 11 != 0]      # some signatures were transferred out
+        ids = [-1] + wm
+        for b in (bd, bs):
+            b.set_stm(list(range(t - stm + 1, t + 1)))
+        like = random_adjusted(len(ids), rng)
+        pd = bd.compute_posterior(ids, like, dense=True)
+        ps = bs.compute_posterior(ids, like, dense=False)
+        assert np.array_equal(pd, ps)
+        assert abs(float(pd.sum()) - 1.0) < 1e-4
+        hid, hval = O.OracleBayesFilter.hypothesis(ids, pd)
+        assert hid == ids[1 + int(np.argmax(pd[1:] + np.arange(len(wm)) * 1e-12))] or pd[1:].max() == 0
+        assert abs(hval - (1.0 - pd[0])) < 1e-6
+
+
+def test_fill_of_all_other_places_dense():
+    # a prediction whose values sum to less than 1 spreads the rest over every other place (normalize :448-465): dense evaluation only
+    lc = prediction_lc_as_parsed([0.1, 0.3, 0.2, 0.1])
+    b = O.OracleBayesFilter(lc, 0.9)
+    g = Graph(30)
+    for s in range(1, 31):
+        d = g.neighbors(s, 3)
+        b.set_neighbors(s, sorted(d), [d[k] for k in sorted(d)])
+    ids = [-1] + list(range(1, 31))
+    rng = np.random.default_rng(5)
+    for _ in range(3):
+        post = b.compute_posterior(ids, random_adjusted(len(ids), rng), dense=True)
+        assert abs(float(post.sum()) - 1.0) < 1e-5 and np.all(post > 0)
+    with pytest.raises(RuntimeError):
+        O.OracleBayesFilter(lc, 0.9).compute_posterior(ids, np.ones(len(ids), np.float32), dense=False)
