@@ -29,6 +29,7 @@ namespace lcd {
 constexpr int BAYES_MAX_LC = 32;          // Bayes/PredictionLC values (the default string has 18)
 constexpr int BAYES_SLOT_BITS = 27;       // neighbour slot in the low bits of an entry, margin above
 constexpr int BAYES_GRID = 256;           // workgroups of the column / row passes (grid-stride; = number of partial sums)
+constexpr int BAYES_MAX_K = 8192;         // longest neighbour list accepted
 
 struct BayesParams {                      // kernel argument: BayesFilter's members, in the types the reference computes with
     float lc[BAYES_MAX_LC];               // (float)_predictionLC[k]: what addNeighborProb stores into the float matrix
@@ -51,15 +52,16 @@ struct Bayes {
     BayesParams prm{};
     bool configured = false;
     bool empty = true;                    // BayesFilter::_posterior is empty: the entries of the next update start at 1 (:717-720)
-    int K = 64;                           // neighbour capacity per signature ("bayes_max_neighbors")
+    int K = 64;                           // neighbour capacity per signature: doubles whenever a list could outgrow it
     int64_t cap = 0;                      // slots allocated
+    std::vector<int32_t> cnt_ub;          // per slot: upper bound of its list length (every entry ever entered counts once)
     DevBuf nbr, cnt, post, was_in, col, tmp, partial, scal, pairs, overflow;
     std::string err;
 
     void init(hipStream_t s, int64_t* b) { stream = s; bytes = b; }
     void destroy();
     hipError_t configure(const double* lc, int n, float vp_prior);
-    hipError_t ensure(int64_t n_slots);
+    hipError_t ensure(int64_t n_slots, int k_needed = 0);
     hipError_t reset();
     // pairs: (slot a, slot b, margin) triples, canonical (a <= b) and unique; both directions are entered
     hipError_t link(const std::vector<int32_t>& triples);

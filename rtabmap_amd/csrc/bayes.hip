@@ -313,17 +313,22 @@ hipError_t Bayes::configure(const double* lc, int n, float vp_prior) {
     return hipSuccess;
 }
 
-hipError_t Bayes::ensure(int64_t n_slots) {
-    if (n_slots <= cap && cap > 0) return hipSuccess;
+hipError_t Bayes::ensure(int64_t n_slots, int k_needed) {
+    int nk = K;
+    while (nk < k_needed) nk *= 2;
+    if (nk > BAYES_MAX_K) return hipErrorInvalidValue;
+    if (n_slots <= cap && cap > 0 && nk == K) return hipSuccess;
     int64_t ncap = cap ? cap : 4096;
     while (ncap < n_slots) ncap *= 2;
-    // neighbour table: k-major, so growing the slot dimension is a pitched copy
+    // neighbour table: k-major, so growing the slot dimension is a pitched copy and growing K appends rows
     DevBuf nn;
-    BY_TRY(nn.reserve((size_t)K * ncap * 4, 0, stream, bytes));
-    BY_TRY(hipMemsetAsync(nn.p, 0xFF, (size_t)K * ncap * 4, stream));
+    BY_TRY(nn.reserve((size_t)nk * ncap * 4, 0, stream, bytes));
+    BY_TRY(hipMemsetAsync(nn.p, 0xFF, (size_t)nk * ncap * 4, stream));
     if (cap > 0) BY_TRY(hipMemcpy2DAsync(nn.p, (size_t)ncap * 4, nbr.p, (size_t)cap * 4, (size_t)cap * 4, (size_t)K, hipMemcpyDeviceToDevice, stream));
     if (nbr.p) { BY_TRY(hipStreamSynchronize(stream)); nbr.release(bytes); }
     nbr = nn;
+    K = nk;
+    if (ncap == cap) return hipSuccess;
     auto grow = [&](DevBuf& b, size_t old_bytes, size_t new_bytes) -> hipError_t {
         const size_t had = b.cap;
         BY_TRY(b.reserve(new_bytes, old_bytes, stream, bytes));
@@ -338,6 +343,7 @@ hipError_t Bayes::ensure(int64_t n_slots) {
     BY_TRY(grow(partial, 0, (size_t)BAYES_GRID * (sizeof(Part1) + sizeof(double) + 16)));
     BY_TRY(grow(overflow, 0, 256));
     cap = ncap;
+    cnt_ub.resize((size_t)cap, 0);
     return hipSuccess;
 }
 
@@ -348,12 +354,24 @@ hipError_t Bayes::reset() {
         BY_TRY(hipMemsetAsync(cnt.p, 0, (size_t)cap * 4, stream));
         BY_TRY(hipMemsetAsync(nbr.p, 0xFF, (size_t)K * cap * 4, stream));
     }
+    std::fill(cnt_ub.begin(), cnt_ub.end(), 0);
     return hipSuccess;
 }
 
 hipError_t Bayes::link(const std::vector<int32_t>& triples) {
     const int n = (int)(triples.size() / 3);
     if (n == 0) return hipSuccess;
+    // room for every entry this call may add (an entry that replaces an existing one is counted again: the bound only grows)
+    int64_t top = 0;
+    int k_needed = 0;
+    for (int i = 0; i < n; ++i) top = std::max<int64_t>(top, std::max(triples[3 * i], triples[3 * i + 1]));
+    BY_TRY(ensure(std::max<int64_t>(cap, top + 1)));
+    for (int i = 0; i < n; ++i) {
+        const int32_t a = triples[3 * i], b = triples[3 * i + 1];
+        k_needed = std::max(k_needed, ++cnt_ub[a]);
+        if (a != b) k_needed = std::max(k_needed, ++cnt_ub[b]);
+    }
+    if (k_needed > K) BY_TRY(ensure(cap, k_needed));
     if (n <= LINK_SMALL) {
         LinkArgs a;
         memcpy(a.t, triples.data(), triples.size() * 4);

@@ -823,7 +823,9 @@ static int finish_deferred_tail(lcd_engine* h) {
     h->deferred_retire.clear();
     for (const std::vector<int32_t>& tr : h->deferred_links) {
         LCD_HIP(h, h->bayes.ensure(std::max<int64_t>(h->tfidf.n_slots, 1)));
-        LCD_HIP(h, h->bayes.link(tr));
+        const hipError_t e = h->bayes.link(tr);
+        if (e == hipErrorInvalidValue) { h->deferred_links.clear(); return h->fail(LCD_ERR_UNSUPPORTED, "lcd_bayes_set_neighbors: a neighbour list longer than 8192 entries"); }
+        LCD_HIP(h, e);
     }
     h->deferred_links.clear();
     for (void* ev : h->deferred_events) LCD_HIP(h, hipEventRecord((hipEvent_t)ev, h->stream));
@@ -1018,7 +1020,9 @@ int lcd_bayes_set_neighbors(lcd_engine* h, int n_sigs, const int32_t* sig_ids, c
     }
     if (h->deferred.valid) { h->deferred_links.push_back(std::move(triples)); return LCD_OK; }
     LCD_HIP(h, h->bayes.ensure(std::max<int64_t>(t.n_slots, 1)));
-    LCD_HIP(h, h->bayes.link(triples));
+    const hipError_t le = h->bayes.link(triples);
+    if (le == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_bayes_set_neighbors: a neighbour list longer than 8192 entries");
+    LCD_HIP(h, le);
     return LCD_OK;
 }
 

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from bayes_model import DEFAULT_LC, Graph, csr_lists, prediction_lc_as_parsed, random_adjusted, random_graph
+from bayes_model import DEFAULT_LC, DeviceModel, Graph, csr_lists, prediction_lc_as_parsed, random_adjusted, random_graph
 
 # TestBayesFilter.m:32: floor(posterior * 1000) after each of 10 updates with likelihood = 1, predictionNP = 0.9,
 # predictionLC = [0.1 0.24 0.18 0.18 0.1 0.1 0.04 0.04 0.01 0.01] (MATLAB format: one value per side and level)
@@ -79,3 +79,33 @@ def test_fill_of_all_other_places_dense():
         assert abs(float(post.sum()) - 1.0) < 1e-5 and np.all(post > 0)
     with pytest.raises(RuntimeError):
         O.OracleBayesFilter(lc, 0.9).compute_posterior(ids, np.ones(len(ids), np.float32), dense=False)
+
+
+@pytest.mark.parametrize("lc,vp,dense,depth_cap", [(None, 0.9, False, 99), ([0.1, 0.3, 0.2, 0.1], 0.9, True, 99), ([0.2, 0.5, 0.2, 0.05, 0.05], 0.0, True, 99),
+                                                  ([0.1, 0.24, 0.18, 0.1, 0.04, 0.01, 0.33], 0.9, True, 5)])
+def test_device_algorithm_model_against_the_oracle(lc, vp, dense, depth_cap):
+    """bayes.hip's evaluation order (columns -> rows gathered from symmetric lists -> normalise), modelled in numpy, gives the
+    reference's posterior within float rounding for every prediction pattern -- including the ones that fill all other places."""
+    lcp = DEFAULT_LC if lc is None else prediction_lc_as_parsed(lc)
+    rng = np.random.default_rng(0)
+    n_sig = 300 if lc is None else 160
+    g = random_graph(n_sig, 6, rng)
+    depth = min(lcp.shape[0] - 1, depth_cap)
+    ob, dv = O.OracleBayesFilter(lcp, vp), DeviceModel(n_sig, lcp, vp)
+    for s in range(1, n_sig + 1):
+        d = g.neighbors(s, depth)
+        ob.set_neighbors(s, sorted(d), [d[k] for k in sorted(d)])
+        for k, m in d.items():
+            dv.link(s - 1, k - 1, m)
+    for exclude in [n_sig // 2, n_sig // 3, 20, 20, 0, 0]:
+        upto = n_sig - exclude
+        ids = [-1] + list(range(1, upto + 1))
+        like = random_adjusted(len(ids), rng)
+        adj = np.zeros(n_sig + 1, np.float32)
+        adj[: upto + 1] = like
+        inset = np.zeros(n_sig, bool)
+        inset[:upto] = True
+        ob.set_stm(list(range(upto + 1, n_sig + 1)))
+        po = ob.compute_posterior(ids, like, dense=dense)
+        pd = dv.update(adj, inset)[: upto + 1]
+        np.testing.assert_allclose(pd, po, rtol=2e-5, atol=1e-12)
