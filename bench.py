@@ -144,12 +144,21 @@ class BayesStepper(Stepper):
         self.lists_load_s = time.perf_counter() - t0
         self.d_res = torch.zeros(8, dtype=torch.int32, device="cuda")
         self.args.exclude_recent = STM
+        depth = PREDICTION_LC.shape[0] - 1
+        self.one_id = np.array([self.next_sig], np.int32)
+        self.one_off = np.array([0, depth], np.int64)
+        self.one_base = -np.arange(depth - 1, -1, -1, dtype=np.int32)
+        self.one_nbr = np.zeros(depth, np.int32)
+        self.one_mg = np.arange(depth - 1, -1, -1, dtype=np.int32)
         self.args.d_bayes = self.d_res.data_ptr()
 
     def __call__(self, i):
         sid = self.next_sig
         super().__call__(i)
-        self.eng.bayes_set_neighbors(*chain_neighbors(sid, sid, self.oldest))
+        # the new signature's list: itself and the depth - 1 signatures before it (chain_neighbors(sid, sid, oldest), without the numpy work)
+        self.one_nbr[:] = self.one_base + sid
+        self.eng.bayes_set_neighbors(self.one_id, self.one_off, self.one_nbr, self.one_mg)
+        self.one_id[0] = sid + 1
 
 
 def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None, eng=None, per_step_events=True):

@@ -3,9 +3,10 @@ BayesFilter::computePosterior (reference BayesFilter.cpp:145-235, generatePredic
 hypothesis selection (Rtabmap.cpp:2147-2158), on the same pose graph, the same adjusted likelihoods and the same changes of the
 working memory (signatures leaving the short-term memory, retirements).
 
-Tolerance: 1e-4 relative (+1e-12 absolute) on every posterior entry -- the reference sums the posterior into a float entry by entry
-before dividing (BayesFilter.cpp:205-230) and multiplies through cv::gemm; the device sums in double in a fixed order.  The selected
-hypothesis must be the oracle's unless the oracle's best two posteriors are closer than that tolerance."""
+Tolerance: every posterior entry within 2e-5 relative (+1e-12 absolute) of the oracle's after the normalisation constants are
+divided out, and the constants within m * 2^-24 of each other -- the reference adds the m unnormalised entries into a float one by
+one before dividing (BayesFilter.cpp:205-230) and multiplies through cv::gemm; the device sums in double in a fixed order.  The
+selected hypothesis must be the oracle's unless the oracle's best two posteriors are closer than that tolerance."""
 import ctypes as C
 
 import numpy as np
@@ -16,7 +17,7 @@ from bayes_model import DEFAULT_LC, Graph, csr_lists, prediction_lc_as_parsed, r
 from rtabmap_amd import synth
 
 pytestmark = pytest.mark.gpu
-RTOL, ATOL = 1e-4, 1e-12
+RTOL, ETOL, ATOL = 1e-4, 2e-5, 1e-12
 
 
 def _engine_with_signatures(n_sig, q=8, pipeline=False):
@@ -35,18 +36,26 @@ def _result(d_res):
 
 
 def _check(ids, post_o, post_d, res, ctx):
-    np.testing.assert_allclose(post_d, post_o, rtol=RTOL, atol=ATOL, err_msg=str(ctx))
+    """Entry by entry within ETOL once the two normalisation constants are divided out; the constants themselves within the error
+    the reference's own accumulation carries: it adds the m unnormalised entries into a float one by one (BayesFilter.cpp:205-218),
+    up to m * 2^-24 relative, while the device sums in double (measured: 6e-4 at m = 50 000, all of it in the reference's sum)."""
+    m = len(ids)
+    pos = post_o > 0
+    r = float(np.median(post_d[pos].astype(np.float64) / post_o[pos].astype(np.float64))) if pos.any() else 1.0
+    assert abs(r - 1.0) <= max(m * 2.0 ** -24, 2e-6), (ctx, r)
+    np.testing.assert_allclose(post_d, post_o.astype(np.float64) * r, rtol=ETOL, atol=ATOL, err_msg=str(ctx))
+    gtol = max(m * 2.0 ** -24, RTOL)
     hid, hval = __import__("oracle").OracleBayesFilter.hypothesis(ids, post_o)
-    assert res.n_considered == len(ids) - 1
-    np.testing.assert_allclose(res.value, hval, rtol=RTOL, atol=1e-6)
-    np.testing.assert_allclose(res.virtual_place, post_o[0], rtol=RTOL, atol=ATOL)
+    assert res.n_considered == m - 1
+    np.testing.assert_allclose(res.value, hval, rtol=gtol, atol=gtol)
+    np.testing.assert_allclose(res.virtual_place, post_o[0], rtol=gtol, atol=ATOL)
     if hid == 0:
         assert res.sig_id == 0 and res.slot == -1
         return
     po = np.asarray(post_o[1:], np.float64)
     top = np.sort(po)[::-1]
-    if len(top) > 1 and top[0] - top[1] <= RTOL * top[0]:
-        assert res.sig_id in [ids[1 + k] for k in np.flatnonzero(po >= top[0] * (1 - 2 * RTOL))]
+    if len(top) > 1 and top[0] - top[1] <= 4 * ETOL * top[0]:
+        assert res.sig_id in [ids[1 + k] for k in np.flatnonzero(po >= top[0] * (1 - 8 * ETOL))]
     else:
         assert res.sig_id == hid, ctx
         assert res.slot == hid - 1
@@ -206,7 +215,7 @@ def test_reset_and_argument_errors(oracle):
             d_adj.copy_(torch.from_numpy(like))
             eng.bayes_update_dev(d_adj.data_ptr(), 0, d_post.data_ptr(), None)
             eng.synchronize()
-            np.testing.assert_allclose(d_post.cpu().numpy(), ob.compute_posterior(lids, like), rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(d_post.cpu().numpy(), ob.compute_posterior(lids, like), rtol=RTOL, atol=ATOL)   # m = 301: 2e-5 of slack
         eng.bayes_reset()                                               # BayesFilter::reset: the next update starts from ones again
         ob.reset()
         eng.bayes_set_neighbors(ids, off, nbr, mg)
