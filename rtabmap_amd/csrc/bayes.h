@@ -9,12 +9,14 @@
 // the fly: O(m * neighbours) per frame.
 //
 // Layout in HBM (per signature slot s, the slots of the inverted index):
-//   nbr[k][s]   uint32  k-th neighbour of s: margin << 27 | neighbour slot   (k-major: lanes of a wave read consecutive slots)
+//   nbr         uint32  tiles of 8 slots x K entries, entry k of slot s at ((s / 8) * K + k) * 8 + s % 8: margin << 27 | neighbour slot
+//                       (8 lanes walk one slot's list, so a wave reads 8 entries of 8 slots = 256 contiguous bytes per step)
 //   cnt[s]      int32   entries in use
 //   post[1 + s] float   normalised posterior of the last update; post[0] = the virtual place
 //   was_in[s]   uint8   s took part in the last update (BayesFilter::updatePosterior :709-736: others restart at 0)
-// Three launches per update (columns -> rows -> normalise + arg-max); every reduction is in a fixed order (per-workgroup partials
-// summed in index order), so an update is bit-reproducible.
+// Three launches per update, shared with Rtabmap::adjustLikelihood (statistics + columns -> adjusted value + rows -> normalise +
+// arg-max); every reduction is in a fixed order (per-workgroup partials folded by the last workgroup), so an update is
+// bit-reproducible.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -42,8 +44,24 @@ struct BayesParams {                      // kernel argument: BayesFilter's memb
     float all_other;                      // _totalPredictionLCValues < 1 ? 1.0f - total : 0   (:448-452)
 };
 
+struct HypothesisOut {                    // == lcd_hypothesis (include/lcd.h)
+    int32_t sig_id; int32_t slot; float likelihood; float adjusted; float virtual_place; float mean; float stddev; int32_t n_positive;
+};
+
 struct BayesOut {                         // == lcd_bayes_result (include/lcd.h)
     int32_t sig_id; int32_t slot; float posterior; float value; float virtual_place; int32_t n_considered; float sum; int32_t reserved;
+};
+
+// one decision stage: what goes in and which outputs are wanted
+struct DecideArgs {
+    const float* like = nullptr;          // raw likelihood over the slots (adjusted on the fly), or NULL: adj_in is the adjusted vector
+    float ratio = 0.0f;                   // Rtabmap/VirtualPlaceLikelihoodRatio
+    const float* adj_in = nullptr;        // [1 + n_slots], entry 0 = virtual place (only when like == NULL)
+    float* adj_out = nullptr;             // out, may be NULL: the adjusted vector
+    HypothesisOut* hyp = nullptr;         // out, may be NULL: best raw likelihood + adjustLikelihood's statistics
+    bool bayes = false;                   // run the filter
+    float* d_posterior = nullptr;         // out, may be NULL
+    BayesOut* d_bayes = nullptr;          // out, may be NULL
 };
 
 struct Bayes {
@@ -55,7 +73,7 @@ struct Bayes {
     int K = 64;                           // neighbour capacity per signature: doubles whenever a list could outgrow it
     int64_t cap = 0;                      // slots allocated
     std::vector<int32_t> cnt_ub;          // per slot: upper bound of its list length (every entry ever entered counts once)
-    DevBuf nbr, cnt, post, was_in, col, tmp, partial, scal, pairs, overflow;
+    DevBuf nbr, cnt, post, was_in, col, partial, scal, pairs, overflow;
     std::string err;
 
     void init(hipStream_t s, int64_t* b) { stream = s; bytes = b; }
@@ -65,8 +83,9 @@ struct Bayes {
     hipError_t reset();
     // pairs: (slot a, slot b, margin) triples, canonical (a <= b) and unique; both directions are entered
     hipError_t link(const std::vector<int32_t>& triples);
-    // one update over the slots [0, n_cons) that are live (slot_sig != 0); d_adjusted[0] = virtual place, [1 + slot] = likelihood
-    hipError_t update(const float* d_adjusted, const int32_t* slot_sig, int64_t n_slots, int64_t n_cons, float* d_posterior, BayesOut* d_out);
+    hipError_t ensure_scratch();
+    // adjustLikelihood / filter update / hypotheses over the slots [0, n_cons) that are live (slot_sig != 0)
+    hipError_t decide(const DecideArgs& d, const int32_t* slot_sig, int64_t n_slots, int64_t n_cons);
     hipError_t read_overflow(int64_t* out);     // synchronises
 };
 

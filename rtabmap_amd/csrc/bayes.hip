@@ -1,10 +1,20 @@
-// bayes.hip -- BayesFilter::computePosterior on the device (see bayes.h for the layout).
+// bayes.hip -- the decision stage behind a frame's likelihood, on the device: Rtabmap::adjustLikelihood (Rtabmap.cpp:5691-5760),
+// BayesFilter::computePosterior (BayesFilter.cpp:145-235) and the selection of the highest hypothesis (Rtabmap.cpp:2147-2158).
+// See bayes.h for the layout.  Three launches, every one a grid-stride pass over the signature slots whose last workgroup (ticket)
+// folds the per-workgroup partials in a fixed order -- an update is bit-reproducible:
+//   pass 1  likelihood statistics (sum, sum of squares, count, best raw likelihood)            [adjustLikelihood's uMean / uVariance]
+//           + per column of the prediction matrix: what addNeighborProb / normalize derive from its neighbour list   [Bayes]
+//   pass 2  adjusted likelihood per slot; prior = prediction x posterior as a gather over the slot's own (symmetric) neighbour
+//           list; posterior = likelihood x prior, not yet normalised                                                    [Bayes]
+//   pass 3  normalise, remember who took part, best hypothesis                                                         [Bayes]
 //
 // The arithmetic follows the reference's statements in their types (float matrix elements, the double comparisons its mixed
-// float/double expressions promote to); two things are evaluated differently, both inside the float rounding the reference itself
-// leaves open:  (1) prior = prediction * posterior is cv::gemm in the reference (OpenCV, not in its tree); here every row is a
-// sum in double over the row's non-zeros, rounded to float once;  (2) the reference adds the posterior's entries into a float
-// one by one (:205-218) before dividing; here the sum is taken in double over per-workgroup partials in a fixed order.
+// float/double expressions promote to).  Evaluated differently, inside the float rounding the reference itself leaves open:
+//  (1) prior = prediction * posterior is cv::gemm in the reference (OpenCV, not in its tree); here every row is a sum in double
+//      over the row's non-zeros, rounded to float once;
+//  (2) the reference adds the posterior's entries into a float one by one (:205-218) before dividing; here the sum is taken in
+//      double;  (3) uMean / uVariance add floats one by one (UMath.h:419-432, 512-526); here sum and sum of squares are taken
+//      in double in one pass, the variance as (S2 - 2 m S1 + n m^2) / (n - 1) with m the float mean the reference subtracts.
 #include "bayes.h"
 
 #include <algorithm>
@@ -13,176 +23,364 @@
 namespace lcd {
 namespace {
 
-constexpr int BY_BLOCK = 256;
+constexpr int DC_BLOCK = 256;
+constexpr int DC_MAX_GRID = 1024;
 constexpr uint32_t SLOT_MASK = (1u << BAYES_SLOT_BITS) - 1u;
+constexpr int TILE = 8;                   // slots per tile of the neighbour table: nbr[(slot / 8) * K + k][slot % 8]
 
-struct ColS { float scale; float delta; float fill; uint32_t flags; };   // flags: 1 = renormalised, 2 = the list holds the column's own slot
-struct Part1 { double s_in; double fill; long long n_in; long long pad; };
+// per column: scale < 0 marks a renormalised column (|scale| = maxNorm / sum); scale == 0: the slot does not take part
+struct ColS { float scale; float delta; float fill; float pin; };
 
-__device__ __forceinline__ bool in_set(long long s, long long n_cons, const int32_t* __restrict__ slot_sig) {
-    return s < n_cons && slot_sig[s] != 0;
+struct Part1 { double s1, s2, s_in, s_fill; unsigned long long key; long long cnt, n_in; long long pad; };
+struct Part3 { unsigned long long key, slot; };
+struct Scal {
+    // pass 1
+    double s_in, s_fill;
+    long long n_in, cnt_pos;
+    float mean, stddev, vp_adj, maxv;
+    unsigned long long best_key;
+    // pass 2
+    float sum, p0, u0, pad0;
+    unsigned int ticket1, ticket2, ticket3, pad1;
+};
+
+__device__ __forceinline__ size_t tile_at(long long c, int k, int K) { return ((size_t)(c >> 3) * K + k) * TILE + (size_t)(c & 7); }
+__device__ __forceinline__ bool in_set(long long s, long long n_cons, const int32_t* __restrict__ slot_sig) { return s < n_cons && slot_sig[s] != 0; }
+
+__device__ __forceinline__ double shfl_xor_d(double v, int m) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __shfl_xor((unsigned)u, m, 64), hi = __shfl_xor((unsigned)(u >> 32), m, 64);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-
-// deterministic workgroup sum (fixed tree), result in every thread
-__device__ __forceinline__ double block_sum(double v, double* s_red) {
-    const int tid = threadIdx.x;
-    s_red[tid] = v;
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long u, int m) {
+    const unsigned lo = __shfl_xor((unsigned)u, m, 64), hi = __shfl_xor((unsigned)(u >> 32), m, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// workgroup reductions in a fixed order (wave butterfly, then the four waves in order); the result is valid in every thread
+__device__ __forceinline__ double block_sum_d(double v, double* s4) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
     __syncthreads();
-    for (int off = BY_BLOCK / 2; off > 0; off >>= 1) {
-        if (tid < off) s_red[tid] += s_red[tid + off];
-        __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s4[0] + s4[1] + s4[2] + s4[3];
+}
+__device__ __forceinline__ long long block_sum_ll(long long v, double* s4) {
+    long long* s = (long long*)s4;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += (long long)shfl_xor_u64((unsigned long long)v, m);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s[0] + s[1] + s[2] + s[3];
+}
+// the largest key of the workgroup and the payload that came with it (keys are unique unless 0)
+__device__ __forceinline__ void block_max_kv(unsigned long long& k, unsigned long long& p, unsigned long long* s8) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long ok = shfl_xor_u64(k, m), op = shfl_xor_u64(p, m);
+        if (ok > k) { k = ok; p = op; }
     }
-    const double r = s_red[0];
     __syncthreads();
-    return r;
+    if ((threadIdx.x & 63) == 0) { s8[(threadIdx.x >> 6) * 2] = k; s8[(threadIdx.x >> 6) * 2 + 1] = p; }
+    __syncthreads();
+    k = s8[0]; p = s8[1];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) if (s8[2 * w] > k) { k = s8[2 * w]; p = s8[2 * w + 1]; }
+}
+// publish this workgroup's partial (already stored by thread 0) and find out whether it is the last one to do so
+__device__ __forceinline__ bool last_block(unsigned int* ticket, bool* s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = t == gridDim.x - 1;
+        if (*s_flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    return *s_flag;
 }
 
-// number of signatures taking part (only needed ahead of the column pass when the prediction has an "all other places" fill)
-__global__ __launch_bounds__(BY_BLOCK) void bayes_count_kernel(long long n_cons, const int32_t* __restrict__ slot_sig, Part1* __restrict__ part) {
-    __shared__ double s_red[BY_BLOCK];
+__device__ __forceinline__ float adjusted_value(float value, float mean, float stdDev, float ratio) {   // Rtabmap.cpp:5722-5745
+    float o = 1.0f;
+    if (value > mean + stdDev) {
+        if (ratio == 0.0f && mean != 0.0f) o = (value - (stdDev - 0.0001f)) / mean;
+        else if (ratio != 0.0f && stdDev != 0.0f) o = (value - mean) / stdDev;
+    }
+    return o;
+}
+
+struct Pass1Args {
+    BayesParams prm;
+    long long n_slots, n_cons;
+    const int32_t* slot_sig;
+    const float* like;             // raw likelihood per slot, or NULL (the caller supplies the adjusted vector)
+    float ratio;
+    HypothesisOut* hyp;            // may be NULL
+    // Bayes
+    const uint32_t* nbr; const int32_t* cnt; int K;
+    const uint8_t* was_in; const float* post; int empty;
+    long long cols;                // < 0: counted ahead of the pass into scal->cnt_pos (the prediction fills "all other places")
+    ColS* col;
+    Part1* part; Scal* scal;
+};
+
+// number of signatures taking part, ahead of pass 1: only the fill variant needs it there
+__global__ __launch_bounds__(DC_BLOCK) void decide_count_kernel(long long n_cons, const int32_t* __restrict__ slot_sig, long long* __restrict__ out) {
+    __shared__ double s4[4];
     long long n = 0;
-    for (long long c = (long long)blockIdx.x * BY_BLOCK + threadIdx.x; c < n_cons; c += (long long)gridDim.x * BY_BLOCK) n += slot_sig[c] != 0;
-    const double t = block_sum((double)n, s_red);
-    if (threadIdx.x == 0) part[blockIdx.x].n_in = (long long)t;
+    for (long long c = (long long)blockIdx.x * DC_BLOCK + threadIdx.x; c < n_cons; c += (long long)gridDim.x * DC_BLOCK) n += slot_sig[c] != 0;
+    const long long t = block_sum_ll(n, s4);
+    if (threadIdx.x == 0) atomicAdd((unsigned long long*)out, (unsigned long long)t);     // integer: order-free
 }
 
-// pass 1, one thread per column c: the sum addNeighborProb returns (:237-270) and what normalize() derives from it (:434-500);
-// the posterior the column is multiplied with (updatePosterior :709-736) goes to pin[1 + c]
-__global__ __launch_bounds__(BY_BLOCK) void bayes_column_kernel(BayesParams prm, long long n_slots, long long n_cons, const int32_t* __restrict__ slot_sig,
-                                                                const uint32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, long long cap, int K,
-                                                                const uint8_t* __restrict__ was_in, const float* __restrict__ post, int empty,
-                                                                int cols_known, ColS* __restrict__ col, float* __restrict__ pin, Part1* __restrict__ part) {
-    __shared__ double s_red[BY_BLOCK];
-    long long cols = 0;
-    if (cols_known) {                                       // bayes_count_kernel ran: cols = 1 + signatures taking part
-        long long n = 0;
-        for (int b = 0; b < BAYES_GRID; ++b) n += part[b].n_in;
-        cols = n + 1;
+// BAYES: 8 lanes per slot walk its neighbour list (a wave covers a tile of 8 slots x 8 entries per step: 256 B coalesced);
+// otherwise one lane per slot for the likelihood statistics alone
+template <bool BAYES>
+__global__ __launch_bounds__(DC_BLOCK) void decide_pass1_kernel(Pass1Args a) {
+    constexpr int LPS = BAYES ? 8 : 1;
+    constexpr int SPB = DC_BLOCK / LPS;                     // slots per workgroup step
+    __shared__ double s4[4];
+    __shared__ unsigned long long s8[8];
+    __shared__ float s_lc[BAYES_MAX_LC];
+    __shared__ bool s_flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (BAYES) { if (tid < BAYES_MAX_LC) s_lc[tid] = a.prm.lc[tid]; __syncthreads(); }
+    const int slot_in_wave = BAYES ? (lane & 7) : lane, k_sub = BAYES ? (lane >> 3) : 0;
+    long long cols = a.cols;
+    if (BAYES && cols < 0) cols = a.scal->cnt_pos + 1;      // left there by decide_count_kernel
+    if (BAYES && blockIdx.x == 0 && tid == 0) {             // the virtual place's last posterior rides behind the last column
+        ColS v = {0.0f, 0.0f, 0.0f, a.empty ? 1.0f : a.post[0]};
+        a.col[a.n_slots] = v;
     }
-    double s_in = 0.0, s_fill = 0.0;
-    long long n_in = 0;
-    for (long long c = (long long)blockIdx.x * BY_BLOCK + threadIdx.x; c < n_slots; c += (long long)gridDim.x * BY_BLOCK) {
-        ColS cs = {1.0f, 0.0f, 0.0f, 0u};
-        float p = 0.0f;
-        if (in_set(c, n_cons, slot_sig)) {
-            p = empty ? 1.0f : (was_in[c] ? post[1 + c] : 0.0f);
+    double s1 = 0.0, s2 = 0.0, s_in = 0.0, s_fill = 0.0;
+    long long cnt_pos = 0, n_in = 0;
+    unsigned long long key = 0ull, keyp = 0ull;
+    for (long long base = (long long)blockIdx.x * SPB; base < a.n_slots; base += (long long)gridDim.x * SPB) {
+        const long long c = base + wave * (64 / LPS) + slot_in_wave;
+        const bool in = c < a.n_slots && in_set(c, a.n_cons, a.slot_sig);
+        if (a.like && in && k_sub == 0) {
+            const float v = a.like[c];
+            if (v > 0.0f) {
+                s1 += (double)v; s2 += (double)v * (double)v; ++cnt_pos;
+                const unsigned long long k = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(uint32_t)(c + 1);
+                if (k > key) key = k;
+            }
+        }
+        if (BAYES) {
             float sum = 0.0f, self_v = 0.0f;
             int nz = 0;
-            bool has_self = false;
-            const int n = min(cnt[c], K);
-            for (int k = 0; k < n; ++k) {
-                const uint32_t e = nbr[(size_t)k * cap + c];
-                const long long r = e & SLOT_MASK;
-                if (!in_set(r, n_cons, slot_sig)) continue;
-                const float v = prm.lc[(e >> BAYES_SLOT_BITS) + 1];
-                sum += v;
-                if (r == c) { has_self = true; self_v = v; }
-                else if (v != 0.0f) ++nz;
+            if (in) {
+                const int n = min(a.cnt[c], a.K);
+                for (int k = k_sub; k < n; k += 8) {
+                    const uint32_t e = a.nbr[tile_at(c, k, a.K)];
+                    const long long r = e & SLOT_MASK;
+                    if (!in_set(r, a.n_cons, a.slot_sig)) continue;
+                    const float v = s_lc[(e >> BAYES_SLOT_BITS) + 1];
+                    sum += v;
+                    if (r == c) self_v = v;
+                    else if (v != 0.0f) ++nz;
+                }
             }
-            if ((double)sum < (double)prm.total - prm.lc0) {                       // the neighbours that were not found go to the loop closure itself
-                cs.delta = (float)((double)prm.total - prm.lc0 - (double)sum);
-                sum += cs.delta;
+#pragma unroll
+            for (int m = 8; m <= 32; m <<= 1) {                        // the 8 lanes of a slot: fixed order
+                sum += __shfl_xor(sum, m, 64);
+                self_v = fmaxf(self_v, __shfl_xor(self_v, m, 64));
+                nz += __shfl_xor(nz, m, 64);
             }
-            if (self_v + cs.delta != 0.0f) ++nz;                                   // the diagonal element
-            if (prm.all_other > 0.0f && cols > 1) {                                // every element still 0 gets a small value (:455-465)
-                const float value = prm.all_other / (float)(cols - 1);
-                const long long n_zero = (cols - 1) - nz;
-                // the reference adds `value` n_zero times into the float; one rounded product here (non-default PredictionLC only)
-                sum = (float)((double)sum + (double)value * (double)n_zero);
-                cs.fill = value;
+            if (k_sub == 0 && c < a.n_slots) {
+                ColS cs = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (in) {
+                    const float p = a.empty ? 1.0f : (a.was_in[c] ? a.post[1 + c] : 0.0f);     // updatePosterior :709-736
+                    cs.scale = 1.0f;
+                    if ((double)sum < (double)a.prm.total - a.prm.lc0) {                       // neighbours not found go to the loop closure itself (:440-445)
+                        cs.delta = (float)((double)a.prm.total - a.prm.lc0 - (double)sum);
+                        sum += cs.delta;
+                    }
+                    if (self_v + cs.delta != 0.0f) ++nz;                                       // the diagonal element
+                    if (a.prm.all_other > 0.0f && cols > 1) {                                  // every element still 0 gets a small value (:455-465)
+                        const float value = a.prm.all_other / (float)(cols - 1);
+                        // the reference adds `value` once per zero element into the float; one rounded product here (non-default PredictionLC only)
+                        sum = (float)((double)sum + (double)value * (double)((cols - 1) - nz));
+                        cs.fill = value;
+                    }
+                    if ((double)sum < (double)a.prm.max_norm - 0.0001 || (double)sum > (double)a.prm.max_norm + 0.0001) {   // :467-477
+                        const float sc = a.prm.max_norm / sum;
+                        cs.scale = -sc;
+                        cs.fill = cs.fill * sc;
+                        if (cs.fill < a.prm.eps) cs.fill = 0.0f;
+                    }
+                    cs.pin = p;
+                    s_in += (double)p;
+                    s_fill += (double)cs.fill * (double)p;
+                    ++n_in;
+                }
+                a.col[c] = cs;
             }
-            if ((double)sum < (double)prm.max_norm - 0.0001 || (double)sum > (double)prm.max_norm + 0.0001) {
-                cs.scale = prm.max_norm / sum;
-                cs.flags |= 1u;
-                cs.fill = cs.fill * cs.scale;
-                if (cs.fill < prm.eps) cs.fill = 0.0f;
-            }
-            if (has_self) cs.flags |= 2u;
-            s_in += (double)p;
-            s_fill += (double)cs.fill * (double)p;
-            ++n_in;
         }
-        col[c] = cs;
-        pin[1 + c] = p;
     }
-    const double a = block_sum(s_in, s_red), b = block_sum(s_fill, s_red), n = block_sum((double)n_in, s_red);
-    if (threadIdx.x == 0) { part[blockIdx.x].s_in = a; part[blockIdx.x].fill = b; part[blockIdx.x].n_in = (long long)n; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) pin[0] = empty ? 1.0f : post[0];      // the virtual place is in every update
+    keyp = key;
+    const double t1 = block_sum_d(s1, s4), t2 = block_sum_d(s2, s4), t3 = block_sum_d(s_in, s4), t4 = block_sum_d(s_fill, s4);
+    const long long c1 = block_sum_ll(cnt_pos, s4), c2 = block_sum_ll(n_in, s4);
+    block_max_kv(key, keyp, s8);
+    if (tid == 0) { Part1 p = {t1, t2, t3, t4, key, c1, c2, 0}; a.part[blockIdx.x] = p; }
+    if (!last_block(&a.scal->ticket1, &s_flag)) return;
+    // ---- last workgroup: fold the partials (thread t takes partials t, t + 256, ... in order; then the fixed tree)
+    s1 = s2 = s_in = s_fill = 0.0; cnt_pos = n_in = 0; key = 0ull;
+    for (int b = tid; b < (int)gridDim.x; b += DC_BLOCK) {
+        const Part1 p = a.part[b];
+        s1 += p.s1; s2 += p.s2; s_in += p.s_in; s_fill += p.s_fill; cnt_pos += p.cnt; n_in += p.n_in;
+        if (p.key > key) key = p.key;
+    }
+    keyp = key;
+    const double S1 = block_sum_d(s1, s4), S2 = block_sum_d(s2, s4), SI = block_sum_d(s_in, s4), SF = block_sum_d(s_fill, s4);
+    const long long CP = block_sum_ll(cnt_pos, s4), NI = block_sum_ll(n_in, s4);
+    block_max_kv(key, keyp, s8);
+    if (tid == 0) {
+        Scal* sc = a.scal;
+        sc->s_in = SI; sc->s_fill = SF; sc->n_in = NI; sc->cnt_pos = CP; sc->best_key = key;
+        float mean = 0.0f, stdDev = 0.0f, vp = 2.0f;
+        const float maxv = __uint_as_float((uint32_t)(key >> 32));
+        if (a.like) {
+            mean = CP ? (float)(S1 / (double)CP) : 0.0f;                                       // uMean
+            double var = 0.0;
+            if (CP > 1) var = (S2 - 2.0 * (double)mean * S1 + (double)CP * (double)mean * (double)mean) / (double)(CP - 1);   // uVariance around the float mean
+            stdDev = sqrtf((float)fmax(var, 0.0));
+            if (a.ratio == 0.0f && stdDev > 0.0001f && maxv != 0.0f) vp = mean / stdDev + 1.0f;   // Rtabmap.cpp:5747-5758
+            else if (a.ratio != 0.0f && maxv > mean) vp = stdDev / (maxv - mean) + 1.0f;
+        }
+        sc->mean = mean; sc->stddev = stdDev; sc->vp_adj = vp; sc->maxv = maxv;
+        sc->ticket1 = 0u;
+        if (a.hyp && a.like) {
+            HypothesisOut h;
+            const long long slot = (long long)(uint32_t)key - 1;
+            h.slot = (int32_t)slot;
+            h.sig_id = slot >= 0 ? a.slot_sig[slot] : 0;
+            h.likelihood = slot >= 0 ? maxv : 0.0f;
+            h.adjusted = slot >= 0 ? adjusted_value(maxv, mean, stdDev, a.ratio) : 0.0f;
+            h.virtual_place = vp; h.mean = mean; h.stddev = stdDev; h.n_positive = (int32_t)CP;
+            *a.hyp = h;
+        }
+    }
 }
 
+struct Pass2Args {
+    BayesParams prm;
+    long long n_slots, n_cons;
+    const int32_t* slot_sig;
+    const float* like; float ratio;   // raw likelihood (adjusted here), or NULL: adj_in holds the adjusted vector
+    const float* adj_in;
+    float* adj_out;                   // may be NULL
+    const uint32_t* nbr; const int32_t* cnt; int K;
+    const ColS* col;
+    float* post;                      // [1 + slot]: unnormalised posterior out
+    double* part2; Scal* scal;
+};
+
 // one element of the prediction matrix as normalize() leaves it: v = the value addNeighborProb stored (+ delta on the diagonal)
-__device__ __forceinline__ float finish_element(float v, const ColS& cs, float eps) {
-    if (cs.flags & 1u) { v = v * cs.scale; if (v < eps) v = 0.0f; }
+__device__ __forceinline__ float finish_element(float v, float scale, float eps) {
+    if (scale < 0.0f) { v = v * -scale; if (v < eps) v = 0.0f; }
     return v;
 }
 
-// pass 2, one thread per row i: prior[i] = sum over the columns that hold i (its own neighbour list: the lists are symmetric),
-// then STEP 2 (:205-218): posterior = likelihood * prior, not yet normalised
-__global__ __launch_bounds__(BY_BLOCK) void bayes_row_kernel(BayesParams prm, long long n_slots, long long n_cons, const int32_t* __restrict__ slot_sig,
-                                                             const uint32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, long long cap, int K,
-                                                             const ColS* __restrict__ col, const float* __restrict__ pin, const Part1* __restrict__ part,
-                                                             const float* __restrict__ like, float* __restrict__ post, double* __restrict__ part2) {
-    __shared__ double s_red[BY_BLOCK];
-    double s_in = 0.0, s_fill = 0.0;
-    long long n_in = 0;
-    for (int b = 0; b < BAYES_GRID; ++b) { s_in += part[b].s_in; s_fill += part[b].fill; n_in += part[b].n_in; }
-    const long long cols = n_in + 1;
-    const float pin_vp = pin[0];
-    // the virtual place's column (:376-411): its value in every row >= 1
-    float vp_col = 0.0f, p00 = 1.0f;
-    if (prm.vp_prior > 0.0f) {
-        if (cols > 1) { vp_col = (float)((1.0 - prm.vp_prior) / (double)(cols - 1)); p00 = prm.vp_prior; }
+template <bool BAYES>
+__global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
+    constexpr int LPS = BAYES ? 8 : 1;
+    constexpr int SPB = DC_BLOCK / LPS;
+    __shared__ double s4[4];
+    __shared__ float s_lc[BAYES_MAX_LC];
+    __shared__ bool s_flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (BAYES) { if (tid < BAYES_MAX_LC) s_lc[tid] = a.prm.lc[tid]; __syncthreads(); }
+    const int slot_in_wave = BAYES ? (lane & 7) : lane, k_sub = BAYES ? (lane >> 3) : 0;
+    const Scal sc = *a.scal;
+    const long long cols = sc.n_in + 1;
+    const float pin_vp = BAYES ? a.col[a.n_slots].pin : 0.0f;          // the virtual place's last posterior rides behind the last column
+    float vp_col = 0.0f, p00 = 1.0f;                                   // the virtual place's column (:376-411)
+    if (a.prm.vp_prior > 0.0f) {
+        if (cols > 1) { vp_col = (float)((1.0 - a.prm.vp_prior) / (double)(cols - 1)); p00 = a.prm.vp_prior; }
     } else if (cols > 1) { vp_col = (float)(1.0 / (double)cols); p00 = vp_col; }
     const double from_vp = (double)vp_col * (double)pin_vp;
     double usum = 0.0;
-    for (long long i = (long long)blockIdx.x * BY_BLOCK + threadIdx.x; i < n_slots; i += (long long)gridDim.x * BY_BLOCK) {
-        float u = 0.0f;
-        if (in_set(i, n_cons, slot_sig)) {
-            double acc = 0.0;
-            bool has_self = false;
-            const int n = min(cnt[i], K);
-            for (int k = 0; k < n; ++k) {
-                const uint32_t e = nbr[(size_t)k * cap + i];
-                const long long c = e & SLOT_MASK;
-                if (!in_set(c, n_cons, slot_sig)) continue;
-                const ColS cs = col[c];
-                float v = prm.lc[(e >> BAYES_SLOT_BITS) + 1];
-                if (c == i) { v = v + cs.delta; has_self = true; }
-                if (v == 0.0f) continue;                                           // an element left at 0: it holds the column's fill value
-                v = finish_element(v, cs, prm.eps);
-                acc += ((double)v - (double)cs.fill) * (double)pin[1 + c];
-            }
-            if (!has_self) {                                                       // diagonal of a column whose list does not hold itself: 0 + delta
-                const ColS cs = col[i];
-                if (cs.delta != 0.0f) acc += ((double)finish_element(cs.delta, cs, prm.eps) - (double)cs.fill) * (double)pin[1 + i];
-            }
-            const float prior = (float)(acc + s_fill + from_vp);
-            u = like[1 + i] * prior;
-            usum += (double)u;
+    for (long long base = (long long)blockIdx.x * SPB; base < a.n_slots; base += (long long)gridDim.x * SPB) {
+        const long long i = base + wave * (64 / LPS) + slot_in_wave;
+        const bool valid = i < a.n_slots;
+        const bool in = valid && in_set(i, a.n_cons, a.slot_sig);
+        float o = 0.0f;
+        if (k_sub == 0 && valid) {
+            if (a.like) o = in ? adjusted_value(a.like[i], sc.mean, sc.stddev, a.ratio) : 0.0f;
+            else o = in ? a.adj_in[1 + i] : 0.0f;
+            if (a.adj_out) a.adj_out[1 + i] = o;
         }
-        post[1 + i] = u;
+        if (BAYES) {
+            double acc = 0.0;
+            int has_self = 0;
+            if (in) {
+                const int n = min(a.cnt[i], a.K);
+                for (int k = k_sub; k < n; k += 8) {
+                    const uint32_t e = a.nbr[tile_at(i, k, a.K)];
+                    const long long c = e & SLOT_MASK;
+                    const ColS cs = a.col[c];
+                    if (cs.scale == 0.0f) continue;                                    // the column's signature does not take part
+                    float v = s_lc[(e >> BAYES_SLOT_BITS) + 1];
+                    if (c == i) { v = v + cs.delta; has_self = 1; }
+                    if (v == 0.0f) continue;                                           // an element left at 0: it holds the column's fill value
+                    v = finish_element(v, cs.scale, a.prm.eps);
+                    acc += ((double)v - (double)cs.fill) * (double)cs.pin;
+                }
+            }
+#pragma unroll
+            for (int m = 8; m <= 32; m <<= 1) { acc += shfl_xor_d(acc, m); has_self |= __shfl_xor(has_self, m, 64); }
+            if (k_sub == 0 && valid) {
+                float u = 0.0f;
+                if (in) {
+                    if (!has_self) {                                                   // diagonal of a column whose list does not hold itself: 0 + delta
+                        const ColS cs = a.col[i];
+                        if (cs.delta != 0.0f) acc += ((double)finish_element(cs.delta, cs.scale, a.prm.eps) - (double)cs.fill) * (double)cs.pin;
+                    }
+                    const float prior = (float)(acc + sc.s_fill + from_vp);
+                    u = o * prior;                                                     // STEP 2 (:205-218)
+                    usum += (double)u;
+                }
+                a.post[1 + i] = u;
+            }
+        }
     }
-    const double t = block_sum(usum, s_red);
-    if (threadIdx.x == 0) part2[blockIdx.x] = t;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (!BAYES) {
+        if (blockIdx.x == 0 && tid == 0 && a.adj_out && a.like) a.adj_out[0] = sc.vp_adj;
+        return;
+    }
+    const double t = block_sum_d(usum, s4);
+    if (tid == 0) a.part2[blockIdx.x] = t;
+    if (!last_block(&a.scal->ticket2, &s_flag)) return;
+    double s = 0.0;
+    for (int b = tid; b < (int)gridDim.x; b += DC_BLOCK) s += a.part2[b];
+    const double T = block_sum_d(s, s4);
+    if (tid == 0) {
         // row 0: the virtual place's own value + Bayes/PredictionLC[0] from every other column (:486-490)
-        const float prior0 = (float)((double)p00 * (double)pin_vp + (double)(float)prm.lc0 * s_in);
-        post[0] = like[0] * prior0;
+        const float like0 = a.like ? sc.vp_adj : a.adj_in[0];
+        const float prior0 = (float)((double)p00 * (double)pin_vp + (double)(float)a.prm.lc0 * sc.s_in);
+        const float u0 = like0 * prior0;
+        const float sum = (float)(T + (double)u0);
+        a.scal->sum = sum; a.scal->u0 = u0;
+        a.scal->p0 = sum != 0.0f ? u0 / sum : u0;
+        a.scal->ticket2 = 0u;
+        if (a.adj_out && a.like) a.adj_out[0] = sc.vp_adj;
     }
 }
 
-// pass 3: normalise (:221-230), remember who took part, best hypothesis per workgroup (Rtabmap.cpp:2147-2158: ids > 0, highest
-// posterior, the higher id on equal values)
-__global__ __launch_bounds__(BY_BLOCK) void bayes_normalize_kernel(long long n_slots, long long n_cons, const int32_t* __restrict__ slot_sig,
-                                                                   const double* __restrict__ part2, float* __restrict__ post, uint8_t* __restrict__ was_in,
-                                                                   float* __restrict__ d_posterior, unsigned long long* __restrict__ part3) {
-    __shared__ unsigned long long s_key[BY_BLOCK], s_slot[BY_BLOCK];
-    double t = 0.0;
-    for (int b = 0; b < BAYES_GRID; ++b) t += part2[b];
-    const float u0 = post[0];
-    const float sum = (float)(t + (double)u0);
+// pass 3: normalise (:221-230), remember who took part, highest hypothesis (Rtabmap.cpp:2147-2158: ids > 0, highest posterior, the
+// higher id on equal values; its value is 1 - the virtual place's posterior)
+__global__ __launch_bounds__(DC_BLOCK) void decide_pass3_kernel(long long n_slots, long long n_cons, const int32_t* __restrict__ slot_sig, float* __restrict__ post,
+                                                                uint8_t* __restrict__ was_in, float* __restrict__ d_posterior, Part3* __restrict__ part3,
+                                                                Scal* __restrict__ scal, BayesOut* __restrict__ out) {
+    __shared__ unsigned long long s8[8];
+    __shared__ bool s_flag;
+    const int tid = threadIdx.x;
+    const float sum = scal->sum;
     unsigned long long key = 0ull, slot = ~0ull;
-    for (long long i = (long long)blockIdx.x * BY_BLOCK + threadIdx.x; i < n_slots; i += (long long)gridDim.x * BY_BLOCK) {
+    for (long long i = (long long)blockIdx.x * DC_BLOCK + tid; i < n_slots; i += (long long)gridDim.x * DC_BLOCK) {
         const bool in = in_set(i, n_cons, slot_sig);
         float p = 0.0f;
         if (in) {
@@ -197,88 +395,73 @@ __global__ __launch_bounds__(BY_BLOCK) void bayes_normalize_kernel(long long n_s
         was_in[i] = in ? 1 : 0;
         if (d_posterior) d_posterior[1 + i] = p;
     }
-    const int tid = threadIdx.x;
-    s_key[tid] = key; s_slot[tid] = slot;
-    __syncthreads();
-    for (int off = BY_BLOCK / 2; off > 0; off >>= 1) {
-        if (tid < off && s_key[tid + off] > s_key[tid]) { s_key[tid] = s_key[tid + off]; s_slot[tid] = s_slot[tid + off]; }
-        __syncthreads();
-    }
-    if (tid == 0) { part3[2 * blockIdx.x] = s_key[0]; part3[2 * blockIdx.x + 1] = s_slot[0]; }
-}
-
-// pass 4 (one workgroup): the virtual place's posterior and the best hypothesis
-__global__ __launch_bounds__(BY_BLOCK) void bayes_result_kernel(const double* __restrict__ part2, const Part1* __restrict__ part, const unsigned long long* __restrict__ part3,
-                                                                float* __restrict__ post, float* __restrict__ d_posterior, BayesOut* __restrict__ out) {
-    __shared__ unsigned long long s_key[BY_BLOCK], s_slot[BY_BLOCK];
-    const int tid = threadIdx.x;
-    s_key[tid] = tid < BAYES_GRID ? part3[2 * tid] : 0ull;
-    s_slot[tid] = tid < BAYES_GRID ? part3[2 * tid + 1] : ~0ull;
-    __syncthreads();
-    for (int off = BY_BLOCK / 2; off > 0; off >>= 1) {
-        if (tid < off && s_key[tid + off] > s_key[tid]) { s_key[tid] = s_key[tid + off]; s_slot[tid] = s_slot[tid + off]; }
-        __syncthreads();
-    }
+    block_max_kv(key, slot, s8);
+    if (tid == 0) { Part3 p = {key, slot}; part3[blockIdx.x] = p; }
+    if (!last_block(&scal->ticket3, &s_flag)) return;
+    key = 0ull; slot = ~0ull;
+    for (int b = tid; b < (int)gridDim.x; b += DC_BLOCK) { const Part3 p = part3[b]; if (p.key > key) { key = p.key; slot = p.slot; } }
+    block_max_kv(key, slot, s8);
     if (tid == 0) {
-        double t = 0.0;
-        long long n_in = 0;
-        for (int b = 0; b < BAYES_GRID; ++b) { t += part2[b]; n_in += part[b].n_in; }
-        const float u0 = post[0];
-        const float sum = (float)(t + (double)u0);
-        const float p0 = sum != 0.0f ? u0 / sum : u0;
+        const float p0 = scal->p0;
         post[0] = p0;
         if (d_posterior) d_posterior[0] = p0;
+        scal->ticket3 = 0u;
         if (out) {
             BayesOut o;
-            const unsigned long long k = s_key[0];
-            o.sig_id = k ? (int32_t)(uint32_t)k : 0;
-            o.slot = k ? (int32_t)s_slot[0] : -1;
-            o.posterior = __uint_as_float((uint32_t)(k >> 32));
+            o.sig_id = key ? (int32_t)(uint32_t)key : 0;
+            o.slot = key ? (int32_t)slot : -1;
+            o.posterior = __uint_as_float((uint32_t)(key >> 32));
             o.value = 1 - p0;
             o.virtual_place = p0;
-            o.n_considered = (int32_t)n_in;
+            o.n_considered = (int32_t)scal->n_in;
             o.sum = sum;
             o.reserved = 0;
             *out = o;
         }
     }
 }
-static_assert(BAYES_GRID <= BY_BLOCK, "the result pass reduces one partial per thread");
 
 // neighbour lists: enter (b, margin) into a's list and (a, margin) into b's; an entry for the same neighbour is replaced
-// (uInsert, BayesFilter.cpp:589).  The triples are unique, so no two threads enter the same neighbour into the same list.
-__device__ __forceinline__ void list_insert(uint32_t* __restrict__ nbr, int32_t* __restrict__ cnt, long long cap, int K, int32_t a, int32_t b, uint32_t margin,
-                                            unsigned long long* __restrict__ overflow) {
+// (uInsert, BayesFilter.cpp:589).  One wavefront per (triple, direction): the lanes search the list side by side.  The triples
+// of a call are unique, so no two wavefronts enter the same neighbour into the same list.
+__device__ __forceinline__ void list_insert(uint32_t* __restrict__ nbr, int32_t* __restrict__ cnt, int K, int32_t a, int32_t b, uint32_t margin,
+                                            unsigned long long* __restrict__ overflow, int lane) {
     const uint32_t e = (margin << BAYES_SLOT_BITS) | (uint32_t)b;
     const int n = min(__hip_atomic_load(&cnt[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), K);
-    for (int k = 0; k < n; ++k) {
-        if ((nbr[(size_t)k * cap + a] & SLOT_MASK) == (uint32_t)b) { nbr[(size_t)k * cap + a] = e; return; }
+    bool found = false;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        const bool hit = k < n && (nbr[tile_at(a, k, K)] & SLOT_MASK) == (uint32_t)b;
+        if (hit) nbr[tile_at(a, k, K)] = e;
+        if (__ballot(hit)) { found = true; break; }
     }
+    if (found || lane != 0) return;
     const int pos = atomicAdd(&cnt[a], 1);
-    if (pos < K) nbr[(size_t)pos * cap + a] = e;
+    if (pos < K) nbr[tile_at(a, pos, K)] = e;
     else { atomicSub(&cnt[a], 1); atomicAdd(overflow, 1ull); }
 }
-__global__ void bayes_link_kernel(const int32_t* __restrict__ triples, int n, uint32_t* __restrict__ nbr, int32_t* __restrict__ cnt, long long cap, int K,
-                                  unsigned long long* __restrict__ overflow) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(256) void bayes_link_kernel(const int32_t* __restrict__ triples, int n, uint32_t* __restrict__ nbr, int32_t* __restrict__ cnt, int K,
+                                                         unsigned long long* __restrict__ overflow) {
+    const int w = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (w >= 2 * n) return;
+    const int i = w >> 1;
     const int32_t a = triples[3 * i], b = triples[3 * i + 1];
     const uint32_t m = (uint32_t)triples[3 * i + 2];
-    list_insert(nbr, cnt, cap, K, a, b, m, overflow);
-    if (a != b) list_insert(nbr, cnt, cap, K, b, a, m, overflow);
+    if ((w & 1) == 0) list_insert(nbr, cnt, K, a, b, m, overflow, lane);
+    else if (a != b) list_insert(nbr, cnt, K, b, a, m, overflow, lane);
 }
-
 // a few lists (one signature entering the working memory): the triples travel as kernel arguments, no staging copy
 constexpr int LINK_SMALL = 256;
 struct LinkArgs { int32_t t[3 * LINK_SMALL]; };
-__global__ void bayes_link_small_kernel(LinkArgs a, int n, uint32_t* __restrict__ nbr, int32_t* __restrict__ cnt, long long cap, int K,
-                                        unsigned long long* __restrict__ overflow) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t x = a.t[3 * i], y = a.t[3 * i + 1];
-    const uint32_t m = (uint32_t)a.t[3 * i + 2];
-    list_insert(nbr, cnt, cap, K, x, y, m, overflow);
-    if (x != y) list_insert(nbr, cnt, cap, K, y, x, m, overflow);
+__global__ __launch_bounds__(256) void bayes_link_small_kernel(LinkArgs t, int n, uint32_t* __restrict__ nbr, int32_t* __restrict__ cnt, int K,
+                                                               unsigned long long* __restrict__ overflow) {
+    const int w = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (w >= 2 * n) return;
+    const int i = w >> 1;
+    const int32_t a = t.t[3 * i], b = t.t[3 * i + 1];
+    const uint32_t m = (uint32_t)t.t[3 * i + 2];
+    if ((w & 1) == 0) list_insert(nbr, cnt, K, a, b, m, overflow, lane);
+    else if (a != b) list_insert(nbr, cnt, K, b, a, m, overflow, lane);
 }
 
 }  // namespace
@@ -286,7 +469,7 @@ __global__ void bayes_link_small_kernel(LinkArgs a, int n, uint32_t* __restrict_
 #define BY_TRY(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return e__; } while (0)
 
 void Bayes::destroy() {
-    for (DevBuf* b : {&nbr, &cnt, &post, &was_in, &col, &tmp, &partial, &scal, &pairs, &overflow}) b->release(bytes);
+    for (DevBuf* b : {&nbr, &cnt, &post, &was_in, &col, &partial, &scal, &pairs, &overflow}) b->release(bytes);
     cap = 0;
 }
 
@@ -313,18 +496,30 @@ hipError_t Bayes::configure(const double* lc, int n, float vp_prior) {
     return hipSuccess;
 }
 
+hipError_t Bayes::ensure_scratch() {
+    if (partial.p) return hipSuccess;
+    const size_t need = (size_t)DC_MAX_GRID * (sizeof(Part1) + sizeof(double) + sizeof(Part3));
+    BY_TRY(partial.reserve(need, 0, stream, bytes));
+    BY_TRY(scal.reserve(256, 0, stream, bytes));
+    BY_TRY(hipMemsetAsync(scal.p, 0, 256, stream));
+    BY_TRY(overflow.reserve(256, 0, stream, bytes));
+    BY_TRY(hipMemsetAsync(overflow.p, 0, 256, stream));
+    return hipSuccess;
+}
+
 hipError_t Bayes::ensure(int64_t n_slots, int k_needed) {
+    BY_TRY(ensure_scratch());
     int nk = K;
     while (nk < k_needed) nk *= 2;
     if (nk > BAYES_MAX_K) return hipErrorInvalidValue;
     if (n_slots <= cap && cap > 0 && nk == K) return hipSuccess;
     int64_t ncap = cap ? cap : 4096;
     while (ncap < n_slots) ncap *= 2;
-    // neighbour table: k-major, so growing the slot dimension is a pitched copy and growing K appends rows
+    // neighbour table in tiles of 8 slots x K entries: more slots append tiles, a larger K widens every tile (pitched copy)
     DevBuf nn;
     BY_TRY(nn.reserve((size_t)nk * ncap * 4, 0, stream, bytes));
     BY_TRY(hipMemsetAsync(nn.p, 0xFF, (size_t)nk * ncap * 4, stream));
-    if (cap > 0) BY_TRY(hipMemcpy2DAsync(nn.p, (size_t)ncap * 4, nbr.p, (size_t)cap * 4, (size_t)cap * 4, (size_t)K, hipMemcpyDeviceToDevice, stream));
+    if (cap > 0) BY_TRY(hipMemcpy2DAsync(nn.p, (size_t)nk * TILE * 4, nbr.p, (size_t)K * TILE * 4, (size_t)K * TILE * 4, (size_t)(cap / TILE), hipMemcpyDeviceToDevice, stream));
     if (nbr.p) { BY_TRY(hipStreamSynchronize(stream)); nbr.release(bytes); }
     nbr = nn;
     K = nk;
@@ -338,10 +533,7 @@ hipError_t Bayes::ensure(int64_t n_slots, int k_needed) {
     BY_TRY(grow(cnt, (size_t)cap * 4, (size_t)ncap * 4));
     BY_TRY(grow(post, cap ? (size_t)(cap + 1) * 4 : 0, (size_t)(ncap + 1) * 4));
     BY_TRY(grow(was_in, (size_t)cap, (size_t)ncap));
-    BY_TRY(grow(col, 0, (size_t)ncap * sizeof(ColS)));
-    BY_TRY(grow(tmp, 0, (size_t)(ncap + 1) * 4));
-    BY_TRY(grow(partial, 0, (size_t)BAYES_GRID * (sizeof(Part1) + sizeof(double) + 16)));
-    BY_TRY(grow(overflow, 0, 256));
+    BY_TRY(grow(col, 0, (size_t)(ncap + 1) * sizeof(ColS)));
     cap = ncap;
     cnt_ub.resize((size_t)cap, 0);
     return hipSuccess;
@@ -372,42 +564,66 @@ hipError_t Bayes::link(const std::vector<int32_t>& triples) {
         if (a != b) k_needed = std::max(k_needed, ++cnt_ub[b]);
     }
     if (k_needed > K) BY_TRY(ensure(cap, k_needed));
+    const int blocks = (int)(((int64_t)2 * n * 64 + 255) / 256);
     if (n <= LINK_SMALL) {
         LinkArgs a;
         memcpy(a.t, triples.data(), triples.size() * 4);
-        bayes_link_small_kernel<<<(n + 63) / 64, 64, 0, stream>>>(a, n, nbr.as<uint32_t>(), cnt.as<int32_t>(), (long long)cap, K, overflow.as<unsigned long long>());
+        bayes_link_small_kernel<<<blocks, 256, 0, stream>>>(a, n, nbr.as<uint32_t>(), cnt.as<int32_t>(), K, overflow.as<unsigned long long>());
         return hipGetLastError();
     }
     BY_TRY(pairs.reserve(triples.size() * 4, 0, stream, bytes));
     // pageable source: the copy is staged by the runtime before the call returns
     BY_TRY(hipMemcpyAsync(pairs.p, triples.data(), triples.size() * 4, hipMemcpyHostToDevice, stream));
     BY_TRY(hipStreamSynchronize(stream));
-    bayes_link_kernel<<<(n + 255) / 256, 256, 0, stream>>>(pairs.as<int32_t>(), n, nbr.as<uint32_t>(), cnt.as<int32_t>(), (long long)cap, K,
-                                                          overflow.as<unsigned long long>());
+    bayes_link_kernel<<<blocks, 256, 0, stream>>>(pairs.as<int32_t>(), n, nbr.as<uint32_t>(), cnt.as<int32_t>(), K, overflow.as<unsigned long long>());
     return hipGetLastError();
 }
 
-hipError_t Bayes::update(const float* d_adjusted, const int32_t* slot_sig, int64_t n_slots, int64_t n_cons, float* d_posterior, BayesOut* d_out) {
-    if (!configured) return hipErrorNotReady;
+hipError_t Bayes::decide(const DecideArgs& d, const int32_t* slot_sig, int64_t n_slots, int64_t n_cons) {
+    if (d.bayes && !configured) return hipErrorNotReady;
     if (n_cons < 0) n_cons = 0;
     if (n_cons > n_slots) n_cons = n_slots;
-    BY_TRY(ensure(std::max<int64_t>(n_slots, 1)));
+    BY_TRY(ensure_scratch());
+    if (d.bayes) BY_TRY(ensure(std::max<int64_t>(n_slots, 1)));
     Part1* part = partial.as<Part1>();
-    double* part2 = (double*)(part + BAYES_GRID);
-    unsigned long long* part3 = (unsigned long long*)(part2 + BAYES_GRID);
-    const int cols_known = prm.all_other > 0.0f ? 1 : 0;
-    if (cols_known) bayes_count_kernel<<<BAYES_GRID, BY_BLOCK, 0, stream>>>((long long)n_cons, slot_sig, part);
-    bayes_column_kernel<<<BAYES_GRID, BY_BLOCK, 0, stream>>>(prm, (long long)n_slots, (long long)n_cons, slot_sig, nbr.as<uint32_t>(), cnt.as<int32_t>(),
-                                                           (long long)cap, K, was_in.as<uint8_t>(), post.as<float>(), empty ? 1 : 0, cols_known,
-                                                           col.as<ColS>(), tmp.as<float>(), part);
-    bayes_row_kernel<<<BAYES_GRID, BY_BLOCK, 0, stream>>>(prm, (long long)n_slots, (long long)n_cons, slot_sig, nbr.as<uint32_t>(), cnt.as<int32_t>(),
-                                                        (long long)cap, K, col.as<ColS>(), tmp.as<float>(), part, d_adjusted, post.as<float>(), part2);
-    bayes_normalize_kernel<<<BAYES_GRID, BY_BLOCK, 0, stream>>>((long long)n_slots, (long long)n_cons, slot_sig, part2, post.as<float>(), was_in.as<uint8_t>(),
-                                                              d_posterior, part3);
-    bayes_result_kernel<<<1, BY_BLOCK, 0, stream>>>(part2, part, part3, post.as<float>(), d_posterior, d_out);
-    BY_TRY(hipGetLastError());
-    empty = false;
-    return hipSuccess;
+    double* part2 = (double*)(part + DC_MAX_GRID);
+    Part3* part3 = (Part3*)(part2 + DC_MAX_GRID);
+    Scal* sc = scal.as<Scal>();
+    const int spb = d.bayes ? DC_BLOCK / 8 : DC_BLOCK;
+    const int grid = (int)std::min<int64_t>(DC_MAX_GRID, std::max<int64_t>(1, (n_slots + spb - 1) / spb));
+    Pass1Args a1{};
+    a1.prm = prm; a1.n_slots = n_slots; a1.n_cons = n_cons; a1.slot_sig = slot_sig; a1.like = d.like; a1.ratio = d.ratio; a1.hyp = d.hyp;
+    a1.part = part; a1.scal = sc; a1.cols = 0;
+    if (d.bayes) {
+        a1.nbr = nbr.as<uint32_t>(); a1.cnt = cnt.as<int32_t>(); a1.K = K; a1.was_in = was_in.as<uint8_t>(); a1.post = post.as<float>();
+        a1.empty = empty ? 1 : 0; a1.col = col.as<ColS>();
+        if (prm.all_other > 0.0f) {                              // the fill value needs the number of columns ahead of the pass
+            BY_TRY(hipMemsetAsync(&sc->cnt_pos, 0, 8, stream));
+            decide_count_kernel<<<std::min(grid, 256), DC_BLOCK, 0, stream>>>((long long)n_cons, slot_sig, (long long*)&sc->cnt_pos);
+            a1.cols = -1;
+        }
+        decide_pass1_kernel<true><<<grid, DC_BLOCK, 0, stream>>>(a1);
+    } else {
+        decide_pass1_kernel<false><<<grid, DC_BLOCK, 0, stream>>>(a1);
+    }
+    if (d.bayes || d.adj_out) {
+        Pass2Args a2{};
+        a2.prm = prm; a2.n_slots = n_slots; a2.n_cons = n_cons; a2.slot_sig = slot_sig; a2.like = d.like; a2.ratio = d.ratio;
+        a2.adj_in = d.adj_in; a2.adj_out = d.adj_out; a2.part2 = part2; a2.scal = sc;
+        if (d.bayes) {
+            a2.nbr = nbr.as<uint32_t>(); a2.cnt = cnt.as<int32_t>(); a2.K = K; a2.col = col.as<ColS>(); a2.post = post.as<float>();
+            decide_pass2_kernel<true><<<grid, DC_BLOCK, 0, stream>>>(a2);
+        } else {
+            decide_pass2_kernel<false><<<grid, DC_BLOCK, 0, stream>>>(a2);
+        }
+    }
+    if (d.bayes) {
+        const int g3 = (int)std::min<int64_t>(DC_MAX_GRID, std::max<int64_t>(1, (n_slots + DC_BLOCK - 1) / DC_BLOCK));
+        decide_pass3_kernel<<<g3, DC_BLOCK, 0, stream>>>((long long)n_slots, (long long)n_cons, slot_sig, post.as<float>(), was_in.as<uint8_t>(), d.d_posterior,
+                                                       part3, sc, d.d_bayes);
+        empty = false;
+    }
+    return hipGetLastError();
 }
 
 hipError_t Bayes::read_overflow(int64_t* out) {

@@ -776,15 +776,11 @@ static int hypothesis_stage(lcd_engine* h, const lcd_frame_args& a) {
     Tfidf& t = h->tfidf;
     const bool bayes = a.d_posterior || a.d_bayes;
     if (!(a.d_hypothesis || a.d_adjusted || bayes)) return LCD_OK;
-    float* adjusted = a.d_adjusted;
-    if (bayes && !adjusted) {
-        LCD_HIP(h, dreserve(h, h->d_adj_scratch, (size_t)(t.n_slots + 1) * 4));
-        adjusted = h->d_adj_scratch.as<float>();
-    }
-    HypothesisOut* out = a.d_hypothesis ? (HypothesisOut*)a.d_hypothesis : (HypothesisOut*)h->d_hyp_scratch.p;
     const long long n_cons = (long long)t.n_slots - std::max(a.exclude_recent, 0);
-    LCD_HIP(h, launch_hypothesis(a.d_likelihood, t.slot_sig.as<int32_t>(), (long long)t.n_slots, n_cons, a.virtual_place_ratio, adjusted, out, h->stream));
-    if (bayes) LCD_HIP(h, h->bayes.update(adjusted, t.slot_sig.as<int32_t>(), t.n_slots, n_cons, a.d_posterior, (BayesOut*)a.d_bayes));
+    DecideArgs d;
+    d.like = a.d_likelihood; d.ratio = a.virtual_place_ratio; d.adj_out = a.d_adjusted; d.hyp = (HypothesisOut*)a.d_hypothesis;
+    d.bayes = bayes; d.d_posterior = a.d_posterior; d.d_bayes = (BayesOut*)a.d_bayes;
+    LCD_HIP(h, h->bayes.decide(d, t.slot_sig.as<int32_t>(), t.n_slots, n_cons));
     return LCD_OK;
 }
 
@@ -1034,7 +1030,9 @@ int lcd_bayes_update_dev(lcd_engine* h, const float* d_adjusted, int exclude_rec
     Tfidf& t = h->tfidf;
     LCD_HIP(h, t.flush_retire());                             // slot_sig must show the retirements asked for so far
     const long long n_cons = (long long)t.n_slots - std::max(exclude_recent, 0);
-    LCD_HIP(h, h->bayes.update(d_adjusted, t.slot_sig.as<int32_t>(), t.n_slots, n_cons, d_posterior, (BayesOut*)d_result));
+    DecideArgs d;
+    d.adj_in = d_adjusted; d.bayes = true; d.d_posterior = d_posterior; d.d_bayes = (BayesOut*)d_result;
+    LCD_HIP(h, h->bayes.decide(d, t.slot_sig.as<int32_t>(), t.n_slots, n_cons));
     return LCD_OK;
 }
 

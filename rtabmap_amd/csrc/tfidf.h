@@ -34,6 +34,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "bayes.h"
 #include "devbuf.h"
 #include "lcd_kernels.h"
 
@@ -244,12 +245,5 @@ hipError_t launch_gather_f32(const float* dense, const int64_t* slots, int n, fl
 
 // Rtabmap::adjustLikelihood on a device vector (entry 0 = virtual place), in place
 hipError_t launch_adjust_likelihood(float* d_L, int n, float ratio, hipStream_t s);
-
-// Rtabmap::adjustLikelihood + selection of the best candidate over the dense slot likelihood (lcd_frame_dev's hypothesis output)
-struct HypothesisOut {          // == lcd_hypothesis (include/lcd.h)
-    int32_t sig_id; int32_t slot; float likelihood; float adjusted; float virtual_place; float mean; float stddev; int32_t n_positive;
-};
-hipError_t launch_hypothesis(const float* d_like, const int32_t* slot_sig, long long n_slots, long long n_considered, float ratio,
-                             float* d_adjusted /* may be NULL; [n_slots + 1], entry 0 = virtual place */, HypothesisOut* d_out, hipStream_t s);
 
 }  // namespace lcd

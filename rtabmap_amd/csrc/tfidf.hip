@@ -351,89 +351,6 @@ __global__ __launch_bounds__(1024) void adjust_likelihood_kernel(float* __restri
     }
 }
 
-// adjustLikelihood + the best candidate, straight from the dense slot likelihood of a frame: the signatures considered are the
-// live slots among the first n_considered (the caller leaves out the most recent ones: Rtabmap compares against the working
-// memory, not the short-term memory, Rtabmap.cpp:2050-2117).  Two reduction passes; a third one only if the adjusted vector is
-// wanted (entry 0 = virtual place, entry 1 + slot = adjusted value, 0 for slots that are not considered).  On equal likelihood
-// the higher slot wins (the reference walks its map from the highest id down with a strict comparison, Rtabmap.cpp:2150-2156).
-__global__ __launch_bounds__(1024) void hypothesis_kernel(const float* __restrict__ like, const int32_t* __restrict__ slot_sig, long long n_slots,
-                                                          long long n_cons, float ratio, float* __restrict__ adjusted, HypothesisOut* __restrict__ out) {
-    __shared__ double s_sum[1024];
-    __shared__ unsigned int s_cnt[1024];
-    __shared__ unsigned long long s_key[1024];
-    const int tid = threadIdx.x;
-    double sum = 0.0; unsigned int cnt = 0; unsigned long long key = 0ull;   // key = value bits << 32 | slot + 1 (values >= 0 order like their bits)
-    for (long long i = tid; i < n_cons; i += 1024) {
-        if (slot_sig[i] == 0) continue;
-        const float v = like[i];
-        if (v > 0.0f) {
-            sum += (double)v; ++cnt;
-            const unsigned long long k = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(uint32_t)(i + 1);
-            key = k > key ? k : key;
-        }
-    }
-    s_sum[tid] = sum; s_cnt[tid] = cnt; s_key[tid] = key;
-    __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if (tid < off) { s_sum[tid] += s_sum[tid + off]; s_cnt[tid] += s_cnt[tid + off]; s_key[tid] = s_key[tid] > s_key[tid + off] ? s_key[tid] : s_key[tid + off]; }
-        __syncthreads();
-    }
-    const unsigned int count = s_cnt[0];
-    const float mean = count ? (float)(s_sum[0] / (double)count) : 0.0f;
-    const unsigned long long best = s_key[0];
-    const float maxv = __uint_as_float((uint32_t)(best >> 32));
-    __syncthreads();
-    double sq = 0.0;
-    for (long long i = tid; i < n_cons; i += 1024) {
-        if (slot_sig[i] == 0) continue;
-        const float v = like[i];
-        if (v > 0.0f) { const float d = v - mean; sq += (double)(d * d); }
-    }
-    s_sum[tid] = sq;
-    __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if (tid < off) s_sum[tid] += s_sum[tid + off];
-        __syncthreads();
-    }
-    const float var = count > 1 ? (float)(s_sum[0] / (double)(count - 1)) : 0.0f;
-    const float stdDev = sqrtf(var);
-    const float epsilon = 0.0001f;
-    float vp;
-    if (ratio == 0.0f && stdDev > epsilon && maxv != 0.0f) vp = mean / stdDev + 1.0f;
-    else if (ratio != 0.0f && maxv > mean) vp = stdDev / (maxv - mean) + 1.0f;
-    else vp = 2.0f;
-    if (adjusted) {
-        for (long long i = tid; i < n_slots; i += 1024) {
-            float o = 0.0f;
-            if (i < n_cons && slot_sig[i] != 0) {
-                const float value = like[i];
-                o = 1.0f;
-                if (value > mean + stdDev) {
-                    if (ratio == 0.0f && mean != 0.0f) o = (value - (stdDev - epsilon)) / mean;
-                    else if (ratio != 0.0f && stdDev != 0.0f) o = (value - mean) / stdDev;
-                }
-            }
-            adjusted[1 + i] = o;
-        }
-        if (tid == 0) adjusted[0] = vp;
-    }
-    if (tid == 0) {
-        HypothesisOut h;
-        const long long slot = (long long)(uint32_t)best - 1;
-        h.slot = (int32_t)slot;
-        h.sig_id = slot >= 0 ? slot_sig[slot] : 0;
-        h.likelihood = slot >= 0 ? maxv : 0.0f;
-        float o = 1.0f;
-        if (slot >= 0 && maxv > mean + stdDev) {
-            if (ratio == 0.0f && mean != 0.0f) o = (maxv - (stdDev - epsilon)) / mean;
-            else if (ratio != 0.0f && stdDev != 0.0f) o = (maxv - mean) / stdDev;
-        }
-        h.adjusted = slot >= 0 ? o : 0.0f;
-        h.virtual_place = vp; h.mean = mean; h.stddev = stdDev; h.n_positive = (int32_t)count;
-        *out = h;
-    }
-}
-
 inline int next_pow2(int v) { int p = 2; while (p < v) p <<= 1; return p; }
 
 }  // namespace
@@ -441,14 +358,6 @@ inline int next_pow2(int v) { int p = 2; while (p < v) p <<= 1; return p; }
 hipError_t launch_adjust_likelihood(float* d_L, int n, float ratio, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     adjust_likelihood_kernel<<<1, 1024, 0, s>>>(d_L, n, ratio);
-    return hipGetLastError();
-}
-
-hipError_t launch_hypothesis(const float* d_like, const int32_t* slot_sig, long long n_slots, long long n_considered, float ratio,
-                             float* d_adjusted, HypothesisOut* d_out, hipStream_t s) {
-    if (n_considered < 0) n_considered = 0;
-    if (n_considered > n_slots) n_considered = n_slots;
-    hypothesis_kernel<<<1, 1024, 0, s>>>(d_like, slot_sig, n_slots, n_considered, ratio, d_adjusted, d_out);
     return hipGetLastError();
 }
 
