@@ -12,7 +12,7 @@
 //   nbr         uint32  tiles of 8 slots x K entries, entry k of slot s at ((s / 8) * K + k) * 8 + s % 8: margin << 27 | neighbour slot
 //                       (8 lanes walk one slot's list, so a wave reads 8 entries of 8 slots = 256 contiguous bytes per step)
 //   cnt[s]      int32   entries in use
-//   post[1 + s] float   normalised posterior of the last update; post[0] = the virtual place
+//   post[1 + s] float   posterior of the last update BEFORE the division by its sum (kept beside it: readers divide)
 //   was_in[s]   uint8   s took part in the last update (BayesFilter::updatePosterior :709-736: others restart at 0)
 // Three launches per update, shared with Rtabmap::adjustLikelihood (statistics + columns -> adjusted value + rows -> normalise +
 // arg-max); every reduction is in a fixed order (per-workgroup partials folded by the last workgroup), so an update is
@@ -87,6 +87,8 @@ struct Bayes {
     // adjustLikelihood / filter update / hypotheses over the slots [0, n_cons) that are live (slot_sig != 0)
     hipError_t decide(const DecideArgs& d, const int32_t* slot_sig, int64_t n_slots, int64_t n_cons);
     hipError_t read_overflow(int64_t* out);     // synchronises
+    // normalised posterior of the first n slots ([0] = virtual place) and who took part in the last update; synchronises
+    hipError_t read_posterior(int64_t n, std::vector<float>* p, std::vector<uint8_t>* in);
 };
 
 }  // namespace lcd

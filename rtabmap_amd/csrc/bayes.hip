@@ -1,12 +1,13 @@
 // bayes.hip -- the decision stage behind a frame's likelihood, on the device: Rtabmap::adjustLikelihood (Rtabmap.cpp:5691-5760),
 // BayesFilter::computePosterior (BayesFilter.cpp:145-235) and the selection of the highest hypothesis (Rtabmap.cpp:2147-2158).
-// See bayes.h for the layout.  Three launches, every one a grid-stride pass over the signature slots whose last workgroup (ticket)
+// See bayes.h for the layout.  Two launches, each a grid-stride pass over the signature slots whose last workgroup (ticket)
 // folds the per-workgroup partials in a fixed order -- an update is bit-reproducible:
 //   pass 1  likelihood statistics (sum, sum of squares, count, best raw likelihood)            [adjustLikelihood's uMean / uVariance]
 //           + per column of the prediction matrix: what addNeighborProb / normalize derive from its neighbour list   [Bayes]
 //   pass 2  adjusted likelihood per slot; prior = prediction x posterior as a gather over the slot's own (symmetric) neighbour
 //           list; posterior = likelihood x prior, not yet normalised                                                    [Bayes]
-//   pass 3  normalise, remember who took part, best hypothesis                                                         [Bayes]
+//           + its sum and the best hypothesis; the posterior stays unnormalised in HBM, readers divide by the sum        [Bayes]
+//   (pass 3, only when the caller wants the posterior as a vector: the division, written out)
 //
 // The arithmetic follows the reference's statements in their types (float matrix elements, the double comparisons its mixed
 // float/double expressions promote to).  Evaluated differently, inside the float rounding the reference itself leaves open:
@@ -24,7 +25,7 @@ namespace lcd {
 namespace {
 
 constexpr int DC_BLOCK = 256;
-constexpr int DC_MAX_GRID = 1024;
+constexpr int DC_MAX_GRID = 4096;
 constexpr uint32_t SLOT_MASK = (1u << BAYES_SLOT_BITS) - 1u;
 constexpr int TILE = 8;                   // slots per tile of the neighbour table: nbr[(slot / 8) * K + k][slot % 8]
 
@@ -32,14 +33,14 @@ constexpr int TILE = 8;                   // slots per tile of the neighbour tab
 struct ColS { float scale; float delta; float fill; float pin; };
 
 struct Part1 { double s1, s2, s_in, s_fill; unsigned long long key; long long cnt, n_in; long long pad; };
-struct Part3 { unsigned long long key, slot; };
+struct Part2 { double usum; unsigned long long key, slot; long long pad; };
 struct Scal {
     // pass 1
     double s_in, s_fill;
     long long n_in, cnt_pos;
     float mean, stddev, vp_adj, maxv;
     unsigned long long best_key;
-    // pass 2
+    // pass 2 (kept until the next update: the posterior stays unnormalised in post[], divided by `sum` when it is read)
     float sum, p0, u0, pad0;
     unsigned int ticket1, ticket2, ticket3, pad1;
 };
@@ -150,8 +151,9 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass1_kernel(Pass1Args a) {
     const int slot_in_wave = BAYES ? (lane & 7) : lane, k_sub = BAYES ? (lane >> 3) : 0;
     long long cols = a.cols;
     if (BAYES && cols < 0) cols = a.scal->cnt_pos + 1;      // left there by decide_count_kernel
+    const float sum_prev = BAYES ? a.scal->sum : 0.0f;      // normalisation constant of the last update
     if (BAYES && blockIdx.x == 0 && tid == 0) {             // the virtual place's last posterior rides behind the last column
-        ColS v = {0.0f, 0.0f, 0.0f, a.empty ? 1.0f : a.post[0]};
+        ColS v = {0.0f, 0.0f, 0.0f, a.empty ? 1.0f : a.scal->p0};
         a.col[a.n_slots] = v;
     }
     double s1 = 0.0, s2 = 0.0, s_in = 0.0, s_fill = 0.0;
@@ -173,14 +175,21 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass1_kernel(Pass1Args a) {
             int nz = 0;
             if (in) {
                 const int n = min(a.cnt[c], a.K);
-                for (int k = k_sub; k < n; k += 8) {
-                    const uint32_t e = a.nbr[tile_at(c, k, a.K)];
-                    const long long r = e & SLOT_MASK;
-                    if (!in_set(r, a.n_cons, a.slot_sig)) continue;
-                    const float v = s_lc[(e >> BAYES_SLOT_BITS) + 1];
-                    sum += v;
-                    if (r == c) self_v = v;
-                    else if (v != 0.0f) ++nz;
+                for (int k0 = 0; k0 < n; k0 += 64) {                   // 8 entries per lane and step, all loads of a step in flight together
+                    uint32_t e[8];
+                    int32_t sg[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const int k = k0 + k_sub + 8 * j; e[j] = k < n ? a.nbr[tile_at(c, k, a.K)] : 0xFFFFFFFFu; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const long long r = e[j] & SLOT_MASK; sg[j] = (e[j] != 0xFFFFFFFFu && r < a.n_cons) ? a.slot_sig[r] : 0; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (sg[j] == 0) continue;
+                        const float v = s_lc[(e[j] >> BAYES_SLOT_BITS) + 1];
+                        sum += v;
+                        if ((long long)(e[j] & SLOT_MASK) == c) self_v = v;
+                        else if (v != 0.0f) ++nz;
+                    }
                 }
             }
 #pragma unroll
@@ -192,7 +201,8 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass1_kernel(Pass1Args a) {
             if (k_sub == 0 && c < a.n_slots) {
                 ColS cs = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (in) {
-                    const float p = a.empty ? 1.0f : (a.was_in[c] ? a.post[1 + c] : 0.0f);     // updatePosterior :709-736
+                    float p = 1.0f;                                                            // updatePosterior :709-736
+                    if (!a.empty) { p = a.was_in[c] ? a.post[1 + c] : 0.0f; if (sum_prev != 0.0f) p = p / sum_prev; }   // the division of :221-230, made on reading
                     cs.scale = 1.0f;
                     if ((double)sum < (double)a.prm.total - a.prm.lc0) {                       // neighbours not found go to the loop closure itself (:440-445)
                         cs.delta = (float)((double)a.prm.total - a.prm.lc0 - (double)sum);
@@ -275,7 +285,9 @@ struct Pass2Args {
     const uint32_t* nbr; const int32_t* cnt; int K;
     const ColS* col;
     float* post;                      // [1 + slot]: unnormalised posterior out
-    double* part2; Scal* scal;
+    uint8_t* was_in;
+    Part2* part2; Scal* scal;
+    BayesOut* out;                    // may be NULL
 };
 
 // one element of the prediction matrix as normalize() leaves it: v = the value addNeighborProb stored (+ delta on the diagonal)
@@ -284,11 +296,16 @@ __device__ __forceinline__ float finish_element(float v, float scale, float eps)
     return v;
 }
 
+// pass 2: adjusted likelihood; prior row by row; STEP 2; the sum that normalises (:221-230) and the highest hypothesis
+// (Rtabmap.cpp:2147-2158: ids > 0, highest posterior, the higher id on equal values; its value is 1 - the virtual place's
+// posterior).  The posterior stays unnormalised in post[]: whoever reads it divides by scal->sum -- the same float division.
+// The hypothesis is picked on the unnormalised values (two that differ by an ulp could round to the same quotient).
 template <bool BAYES>
 __global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
     constexpr int LPS = BAYES ? 8 : 1;
     constexpr int SPB = DC_BLOCK / LPS;
     __shared__ double s4[4];
+    __shared__ unsigned long long s8[8];
     __shared__ float s_lc[BAYES_MAX_LC];
     __shared__ bool s_flag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -303,6 +320,7 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
     } else if (cols > 1) { vp_col = (float)(1.0 / (double)cols); p00 = vp_col; }
     const double from_vp = (double)vp_col * (double)pin_vp;
     double usum = 0.0;
+    unsigned long long key = 0ull, kslot = ~0ull;
     for (long long base = (long long)blockIdx.x * SPB; base < a.n_slots; base += (long long)gridDim.x * SPB) {
         const long long i = base + wave * (64 / LPS) + slot_in_wave;
         const bool valid = i < a.n_slots;
@@ -318,16 +336,25 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
             int has_self = 0;
             if (in) {
                 const int n = min(a.cnt[i], a.K);
-                for (int k = k_sub; k < n; k += 8) {
-                    const uint32_t e = a.nbr[tile_at(i, k, a.K)];
-                    const long long c = e & SLOT_MASK;
-                    const ColS cs = a.col[c];
-                    if (cs.scale == 0.0f) continue;                                    // the column's signature does not take part
-                    float v = s_lc[(e >> BAYES_SLOT_BITS) + 1];
-                    if (c == i) { v = v + cs.delta; has_self = 1; }
-                    if (v == 0.0f) continue;                                           // an element left at 0: it holds the column's fill value
-                    v = finish_element(v, cs.scale, a.prm.eps);
-                    acc += ((double)v - (double)cs.fill) * (double)cs.pin;
+                for (int k0 = 0; k0 < n; k0 += 64) {                   // 8 entries per lane and step, all loads of a step in flight together
+                    uint32_t e[8];
+                    ColS cs[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const int k = k0 + k_sub + 8 * j; e[j] = k < n ? a.nbr[tile_at(i, k, a.K)] : 0xFFFFFFFFu; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (e[j] != 0xFFFFFFFFu) cs[j] = a.col[e[j] & SLOT_MASK];
+                        else { cs[j].scale = 0.0f; cs[j].delta = 0.0f; cs[j].fill = 0.0f; cs[j].pin = 0.0f; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (cs[j].scale == 0.0f) continue;                             // the column's signature does not take part
+                        float v = s_lc[(e[j] >> BAYES_SLOT_BITS) + 1];
+                        if ((long long)(e[j] & SLOT_MASK) == i) { v = v + cs[j].delta; has_self = 1; }
+                        if (v == 0.0f) continue;                                       // an element left at 0: it holds the column's fill value
+                        v = finish_element(v, cs[j].scale, a.prm.eps);
+                        acc += ((double)v - (double)cs[j].fill) * (double)cs[j].pin;
+                    }
                 }
             }
 #pragma unroll
@@ -336,14 +363,19 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
                 float u = 0.0f;
                 if (in) {
                     if (!has_self) {                                                   // diagonal of a column whose list does not hold itself: 0 + delta
-                        const ColS cs = a.col[i];
-                        if (cs.delta != 0.0f) acc += ((double)finish_element(cs.delta, cs.scale, a.prm.eps) - (double)cs.fill) * (double)cs.pin;
+                        const ColS c0 = a.col[i];
+                        if (c0.delta != 0.0f) acc += ((double)finish_element(c0.delta, c0.scale, a.prm.eps) - (double)c0.fill) * (double)c0.pin;
                     }
                     const float prior = (float)(acc + sc.s_fill + from_vp);
                     u = o * prior;                                                     // STEP 2 (:205-218)
                     usum += (double)u;
+                    if (u > 0.0f) {
+                        const unsigned long long k = ((unsigned long long)__float_as_uint(u) << 32) | (unsigned long long)(uint32_t)a.slot_sig[i];
+                        if (k > key) { key = k; kslot = (unsigned long long)i; }
+                    }
                 }
                 a.post[1 + i] = u;
+                a.was_in[i] = in ? 1 : 0;
             }
         }
     }
@@ -352,73 +384,50 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
         return;
     }
     const double t = block_sum_d(usum, s4);
-    if (tid == 0) a.part2[blockIdx.x] = t;
+    block_max_kv(key, kslot, s8);
+    if (tid == 0) { Part2 p = {t, key, kslot, 0}; a.part2[blockIdx.x] = p; }
     if (!last_block(&a.scal->ticket2, &s_flag)) return;
     double s = 0.0;
-    for (int b = tid; b < (int)gridDim.x; b += DC_BLOCK) s += a.part2[b];
+    key = 0ull; kslot = ~0ull;
+    for (int b = tid; b < (int)gridDim.x; b += DC_BLOCK) { const Part2 p = a.part2[b]; s += p.usum; if (p.key > key) { key = p.key; kslot = p.slot; } }
     const double T = block_sum_d(s, s4);
+    block_max_kv(key, kslot, s8);
     if (tid == 0) {
         // row 0: the virtual place's own value + Bayes/PredictionLC[0] from every other column (:486-490)
         const float like0 = a.like ? sc.vp_adj : a.adj_in[0];
         const float prior0 = (float)((double)p00 * (double)pin_vp + (double)(float)a.prm.lc0 * sc.s_in);
         const float u0 = like0 * prior0;
         const float sum = (float)(T + (double)u0);
-        a.scal->sum = sum; a.scal->u0 = u0;
-        a.scal->p0 = sum != 0.0f ? u0 / sum : u0;
+        const float p0 = sum != 0.0f ? u0 / sum : u0;
+        a.scal->sum = sum; a.scal->u0 = u0; a.scal->p0 = p0;
         a.scal->ticket2 = 0u;
         if (a.adj_out && a.like) a.adj_out[0] = sc.vp_adj;
+        if (a.out) {
+            BayesOut o;
+            const float ub = __uint_as_float((uint32_t)(key >> 32));
+            o.sig_id = key ? (int32_t)(uint32_t)key : 0;
+            o.slot = key ? (int32_t)kslot : -1;
+            o.posterior = sum != 0.0f ? ub / sum : ub;
+            o.value = 1 - p0;
+            o.virtual_place = p0;
+            o.n_considered = (int32_t)sc.n_in;
+            o.sum = sum;
+            o.reserved = 0;
+            *a.out = o;
+        }
     }
 }
 
-// pass 3: normalise (:221-230), remember who took part, highest hypothesis (Rtabmap.cpp:2147-2158: ids > 0, highest posterior, the
-// higher id on equal values; its value is 1 - the virtual place's posterior)
-__global__ __launch_bounds__(DC_BLOCK) void decide_pass3_kernel(long long n_slots, long long n_cons, const int32_t* __restrict__ slot_sig, float* __restrict__ post,
-                                                                uint8_t* __restrict__ was_in, float* __restrict__ d_posterior, Part3* __restrict__ part3,
-                                                                Scal* __restrict__ scal, BayesOut* __restrict__ out) {
-    __shared__ unsigned long long s8[8];
-    __shared__ bool s_flag;
-    const int tid = threadIdx.x;
+// optional pass 3: the normalised posterior as a vector, for a caller that asked for it
+__global__ __launch_bounds__(DC_BLOCK) void decide_posterior_kernel(long long n_slots, const float* __restrict__ post, const uint8_t* __restrict__ was_in,
+                                                                    const Scal* __restrict__ scal, float* __restrict__ d_posterior) {
     const float sum = scal->sum;
-    unsigned long long key = 0ull, slot = ~0ull;
-    for (long long i = (long long)blockIdx.x * DC_BLOCK + tid; i < n_slots; i += (long long)gridDim.x * DC_BLOCK) {
-        const bool in = in_set(i, n_cons, slot_sig);
-        float p = 0.0f;
-        if (in) {
-            p = post[1 + i];
-            if (sum != 0.0f) p = p / sum;
-            post[1 + i] = p;
-            if (p > 0.0f) {
-                const unsigned long long k = ((unsigned long long)__float_as_uint(p) << 32) | (unsigned long long)(uint32_t)slot_sig[i];
-                if (k > key) { key = k; slot = (unsigned long long)i; }
-            }
-        }
-        was_in[i] = in ? 1 : 0;
-        if (d_posterior) d_posterior[1 + i] = p;
+    for (long long i = (long long)blockIdx.x * DC_BLOCK + threadIdx.x; i < n_slots; i += (long long)gridDim.x * DC_BLOCK) {
+        float p = was_in[i] ? post[1 + i] : 0.0f;
+        if (sum != 0.0f) p = p / sum;
+        d_posterior[1 + i] = p;
     }
-    block_max_kv(key, slot, s8);
-    if (tid == 0) { Part3 p = {key, slot}; part3[blockIdx.x] = p; }
-    if (!last_block(&scal->ticket3, &s_flag)) return;
-    key = 0ull; slot = ~0ull;
-    for (int b = tid; b < (int)gridDim.x; b += DC_BLOCK) { const Part3 p = part3[b]; if (p.key > key) { key = p.key; slot = p.slot; } }
-    block_max_kv(key, slot, s8);
-    if (tid == 0) {
-        const float p0 = scal->p0;
-        post[0] = p0;
-        if (d_posterior) d_posterior[0] = p0;
-        scal->ticket3 = 0u;
-        if (out) {
-            BayesOut o;
-            o.sig_id = key ? (int32_t)(uint32_t)key : 0;
-            o.slot = key ? (int32_t)slot : -1;
-            o.posterior = __uint_as_float((uint32_t)(key >> 32));
-            o.value = 1 - p0;
-            o.virtual_place = p0;
-            o.n_considered = (int32_t)scal->n_in;
-            o.sum = sum;
-            o.reserved = 0;
-            *out = o;
-        }
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) d_posterior[0] = scal->p0;
 }
 
 // neighbour lists: enter (b, margin) into a's list and (a, margin) into b's; an entry for the same neighbour is replaced
@@ -498,7 +507,7 @@ hipError_t Bayes::configure(const double* lc, int n, float vp_prior) {
 
 hipError_t Bayes::ensure_scratch() {
     if (partial.p) return hipSuccess;
-    const size_t need = (size_t)DC_MAX_GRID * (sizeof(Part1) + sizeof(double) + sizeof(Part3));
+    const size_t need = (size_t)DC_MAX_GRID * (sizeof(Part1) + sizeof(Part2));
     BY_TRY(partial.reserve(need, 0, stream, bytes));
     BY_TRY(scal.reserve(256, 0, stream, bytes));
     BY_TRY(hipMemsetAsync(scal.p, 0, 256, stream));
@@ -586,8 +595,7 @@ hipError_t Bayes::decide(const DecideArgs& d, const int32_t* slot_sig, int64_t n
     BY_TRY(ensure_scratch());
     if (d.bayes) BY_TRY(ensure(std::max<int64_t>(n_slots, 1)));
     Part1* part = partial.as<Part1>();
-    double* part2 = (double*)(part + DC_MAX_GRID);
-    Part3* part3 = (Part3*)(part2 + DC_MAX_GRID);
+    Part2* part2 = (Part2*)(part + DC_MAX_GRID);
     Scal* sc = scal.as<Scal>();
     const int spb = d.bayes ? DC_BLOCK / 8 : DC_BLOCK;
     const int grid = (int)std::min<int64_t>(DC_MAX_GRID, std::max<int64_t>(1, (n_slots + spb - 1) / spb));
@@ -612,18 +620,39 @@ hipError_t Bayes::decide(const DecideArgs& d, const int32_t* slot_sig, int64_t n
         a2.adj_in = d.adj_in; a2.adj_out = d.adj_out; a2.part2 = part2; a2.scal = sc;
         if (d.bayes) {
             a2.nbr = nbr.as<uint32_t>(); a2.cnt = cnt.as<int32_t>(); a2.K = K; a2.col = col.as<ColS>(); a2.post = post.as<float>();
+            a2.was_in = was_in.as<uint8_t>(); a2.out = d.d_bayes;
             decide_pass2_kernel<true><<<grid, DC_BLOCK, 0, stream>>>(a2);
         } else {
             decide_pass2_kernel<false><<<grid, DC_BLOCK, 0, stream>>>(a2);
         }
     }
     if (d.bayes) {
-        const int g3 = (int)std::min<int64_t>(DC_MAX_GRID, std::max<int64_t>(1, (n_slots + DC_BLOCK - 1) / DC_BLOCK));
-        decide_pass3_kernel<<<g3, DC_BLOCK, 0, stream>>>((long long)n_slots, (long long)n_cons, slot_sig, post.as<float>(), was_in.as<uint8_t>(), d.d_posterior,
-                                                       part3, sc, d.d_bayes);
+        if (d.d_posterior) {
+            const int g3 = (int)std::min<int64_t>(DC_MAX_GRID, std::max<int64_t>(1, (n_slots + DC_BLOCK - 1) / DC_BLOCK));
+            decide_posterior_kernel<<<g3, DC_BLOCK, 0, stream>>>((long long)n_slots, post.as<float>(), was_in.as<uint8_t>(), sc, d.d_posterior);
+        }
         empty = false;
     }
     return hipGetLastError();
+}
+
+hipError_t Bayes::read_posterior(int64_t n, std::vector<float>* p, std::vector<uint8_t>* in) {
+    p->assign((size_t)n + 1, 0.0f);
+    in->assign((size_t)n + 1, 0);
+    if (!post.p || empty || !scal.p) return hipSuccess;
+    Scal sc;
+    BY_TRY(hipMemcpyAsync(p->data(), post.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, stream));
+    if (n > 0) BY_TRY(hipMemcpyAsync(in->data() + 1, was_in.p, (size_t)n, hipMemcpyDeviceToHost, stream));
+    BY_TRY(hipMemcpyAsync(&sc, scal.p, sizeof(Scal), hipMemcpyDeviceToHost, stream));
+    BY_TRY(hipStreamSynchronize(stream));
+    (*in)[0] = 1;
+    (*p)[0] = sc.p0;
+    for (int64_t i = 1; i <= n; ++i) {
+        float v = (*in)[(size_t)i] ? (*p)[(size_t)i] : 0.0f;
+        if (sc.sum != 0.0f) v = v / sc.sum;                   // the division of BayesFilter.cpp:221-230
+        (*p)[(size_t)i] = v;
+    }
+    return hipSuccess;
 }
 
 hipError_t Bayes::read_overflow(int64_t* out) {

@@ -1043,15 +1043,9 @@ int lcd_bayes_posterior(lcd_engine* h, const int32_t* sig_ids, int n, float* out
     if (n == 0) return LCD_OK;
     Tfidf& t = h->tfidf;
     std::vector<float> all;
+    std::vector<uint8_t> in;
     const int64_t have = std::min<int64_t>(t.n_slots, h->bayes.cap);
-    all.assign((size_t)have + 1, 0.0f);
-    std::vector<uint8_t> in((size_t)have + 1, 0);
-    if (h->bayes.post.p && !h->bayes.empty) {
-        LCD_HIP(h, hipMemcpyAsync(all.data(), h->bayes.post.p, ((size_t)have + 1) * 4, hipMemcpyDeviceToHost, h->stream));
-        if (have > 0) LCD_HIP(h, hipMemcpyAsync(in.data() + 1, h->bayes.was_in.p, (size_t)have, hipMemcpyDeviceToHost, h->stream));
-        LCD_HIP(h, hipStreamSynchronize(h->stream));
-        in[0] = 1;
-    }
+    LCD_HIP(h, h->bayes.read_posterior(have, &all, &in));
     for (int i = 0; i < n; ++i) {
         float v = 0.0f;
         if (sig_ids[i] == -1) v = in[0] ? all[0] : 0.0f;
