@@ -1,7 +1,7 @@
 // bayes.hip -- the decision stage behind a frame's likelihood, on the device: Rtabmap::adjustLikelihood (Rtabmap.cpp:5691-5760),
 // BayesFilter::computePosterior (BayesFilter.cpp:145-235) and the selection of the highest hypothesis (Rtabmap.cpp:2147-2158).
-// See bayes.h for the layout.  Two launches, each a grid-stride pass over the signature slots whose last workgroup (ticket)
-// folds the per-workgroup partials in a fixed order -- an update is bit-reproducible:
+// See bayes.h for the layout.  Two passes over the signature slots, each followed by a one-workgroup fold of the per-workgroup
+// partials in a fixed order -- an update is bit-reproducible:
 //   pass 1  likelihood statistics (sum, sum of squares, count, best raw likelihood)            [adjustLikelihood's uMean / uVariance]
 //           + per column of the prediction matrix: what addNeighborProb / normalize derive from its neighbour list   [Bayes]
 //   pass 2  adjusted likelihood per slot; prior = prediction x posterior as a gather over the slot's own (symmetric) neighbour
@@ -57,52 +57,47 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long u,
     const unsigned lo = __shfl_xor((unsigned)u, m, 64), hi = __shfl_xor((unsigned)(u >> 32), m, 64);
     return ((unsigned long long)hi << 32) | lo;
 }
-// workgroup reductions in a fixed order (wave butterfly, then the four waves in order); the result is valid in every thread
-__device__ __forceinline__ double block_sum_d(double v, double* s4) {
+// workgroup reductions in a fixed order (wave butterfly, then the waves in order); the result is valid in every thread
+template <int NW>
+__device__ __forceinline__ double block_sum_d(double v, double* s_w) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
     __syncthreads();
-    return s4[0] + s4[1] + s4[2] + s4[3];
+    double r = s_w[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) r += s_w[w];
+    return r;
 }
-__device__ __forceinline__ long long block_sum_ll(long long v, double* s4) {
-    long long* s = (long long*)s4;
+template <int NW>
+__device__ __forceinline__ long long block_sum_ll(long long v, double* s_w) {
+    long long* s = (long long*)s_w;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += (long long)shfl_xor_u64((unsigned long long)v, m);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
     __syncthreads();
-    return s[0] + s[1] + s[2] + s[3];
+    long long r = s[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) r += s[w];
+    return r;
 }
 // the largest key of the workgroup and the payload that came with it (keys are unique unless 0)
-__device__ __forceinline__ void block_max_kv(unsigned long long& k, unsigned long long& p, unsigned long long* s8) {
+template <int NW>
+__device__ __forceinline__ void block_max_kv(unsigned long long& k, unsigned long long& p, unsigned long long* s_kv) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const unsigned long long ok = shfl_xor_u64(k, m), op = shfl_xor_u64(p, m);
         if (ok > k) { k = ok; p = op; }
     }
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) { s8[(threadIdx.x >> 6) * 2] = k; s8[(threadIdx.x >> 6) * 2 + 1] = p; }
+    if ((threadIdx.x & 63) == 0) { s_kv[(threadIdx.x >> 6) * 2] = k; s_kv[(threadIdx.x >> 6) * 2 + 1] = p; }
     __syncthreads();
-    k = s8[0]; p = s8[1];
+    k = s_kv[0]; p = s_kv[1];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) if (s8[2 * w] > k) { k = s8[2 * w]; p = s8[2 * w + 1]; }
+    for (int w = 1; w < NW; ++w) if (s_kv[2 * w] > k) { k = s_kv[2 * w]; p = s_kv[2 * w + 1]; }
 }
-// publish this workgroup's partial (already stored by thread 0) and find out whether it is the last one to do so
-__device__ __forceinline__ bool last_block(unsigned int* ticket, bool* s_flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_flag = t == gridDim.x - 1;
-        if (*s_flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    return *s_flag;
-}
-
 __device__ __forceinline__ float adjusted_value(float value, float mean, float stdDev, float ratio) {   // Rtabmap.cpp:5722-5745
     float o = 1.0f;
     if (value > mean + stdDev) {
@@ -132,7 +127,7 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_count_kernel(long long n_cons
     __shared__ double s4[4];
     long long n = 0;
     for (long long c = (long long)blockIdx.x * DC_BLOCK + threadIdx.x; c < n_cons; c += (long long)gridDim.x * DC_BLOCK) n += slot_sig[c] != 0;
-    const long long t = block_sum_ll(n, s4);
+    const long long t = block_sum_ll<4>(n, s4);
     if (threadIdx.x == 0) atomicAdd((unsigned long long*)out, (unsigned long long)t);     // integer: order-free
 }
 
@@ -145,7 +140,6 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass1_kernel(Pass1Args a) {
     __shared__ double s4[4];
     __shared__ unsigned long long s8[8];
     __shared__ float s_lc[BAYES_MAX_LC];
-    __shared__ bool s_flag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (BAYES) { if (tid < BAYES_MAX_LC) s_lc[tid] = a.prm.lc[tid]; __syncthreads(); }
     const int slot_in_wave = BAYES ? (lane & 7) : lane, k_sub = BAYES ? (lane >> 3) : 0;
@@ -231,22 +225,31 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass1_kernel(Pass1Args a) {
         }
     }
     keyp = key;
-    const double t1 = block_sum_d(s1, s4), t2 = block_sum_d(s2, s4), t3 = block_sum_d(s_in, s4), t4 = block_sum_d(s_fill, s4);
-    const long long c1 = block_sum_ll(cnt_pos, s4), c2 = block_sum_ll(n_in, s4);
-    block_max_kv(key, keyp, s8);
+    const double t1 = block_sum_d<4>(s1, s4), t2 = block_sum_d<4>(s2, s4), t3 = block_sum_d<4>(s_in, s4), t4 = block_sum_d<4>(s_fill, s4);
+    const long long c1 = block_sum_ll<4>(cnt_pos, s4), c2 = block_sum_ll<4>(n_in, s4);
+    block_max_kv<4>(key, keyp, s8);
     if (tid == 0) { Part1 p = {t1, t2, t3, t4, key, c1, c2, 0}; a.part[blockIdx.x] = p; }
-    if (!last_block(&a.scal->ticket1, &s_flag)) return;
-    // ---- last workgroup: fold the partials (thread t takes partials t, t + 256, ... in order; then the fixed tree)
-    s1 = s2 = s_in = s_fill = 0.0; cnt_pos = n_in = 0; key = 0ull;
-    for (int b = tid; b < (int)gridDim.x; b += DC_BLOCK) {
+}
+
+// fold of pass 1 (one workgroup, after the kernel boundary: a release/acquire hand-off inside pass 1 would cost every workgroup
+// an L2 write-back on this multi-die part): thread t takes partials t, t + 1024, ... in order, then the fixed tree
+constexpr int DC_FOLD = 1024;
+__global__ __launch_bounds__(DC_FOLD) void decide_fold1_kernel(Pass1Args a, int n_part) {
+    __shared__ double s_w[DC_FOLD / 64];
+    __shared__ unsigned long long s_kv[2 * DC_FOLD / 64];
+    const int tid = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0, s_in = 0.0, s_fill = 0.0;
+    long long cnt_pos = 0, n_in = 0;
+    unsigned long long key = 0ull, keyp = 0ull;
+    for (int b = tid; b < n_part; b += DC_FOLD) {
         const Part1 p = a.part[b];
         s1 += p.s1; s2 += p.s2; s_in += p.s_in; s_fill += p.s_fill; cnt_pos += p.cnt; n_in += p.n_in;
         if (p.key > key) key = p.key;
     }
     keyp = key;
-    const double S1 = block_sum_d(s1, s4), S2 = block_sum_d(s2, s4), SI = block_sum_d(s_in, s4), SF = block_sum_d(s_fill, s4);
-    const long long CP = block_sum_ll(cnt_pos, s4), NI = block_sum_ll(n_in, s4);
-    block_max_kv(key, keyp, s8);
+    const double S1 = block_sum_d<16>(s1, s_w), S2 = block_sum_d<16>(s2, s_w), SI = block_sum_d<16>(s_in, s_w), SF = block_sum_d<16>(s_fill, s_w);
+    const long long CP = block_sum_ll<16>(cnt_pos, s_w), NI = block_sum_ll<16>(n_in, s_w);
+    block_max_kv<16>(key, keyp, s_kv);
     if (tid == 0) {
         Scal* sc = a.scal;
         sc->s_in = SI; sc->s_fill = SF; sc->n_in = NI; sc->cnt_pos = CP; sc->best_key = key;
@@ -261,7 +264,6 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass1_kernel(Pass1Args a) {
             else if (a.ratio != 0.0f && maxv > mean) vp = stdDev / (maxv - mean) + 1.0f;
         }
         sc->mean = mean; sc->stddev = stdDev; sc->vp_adj = vp; sc->maxv = maxv;
-        sc->ticket1 = 0u;
         if (a.hyp && a.like) {
             HypothesisOut h;
             const long long slot = (long long)(uint32_t)key - 1;
@@ -307,7 +309,6 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
     __shared__ double s4[4];
     __shared__ unsigned long long s8[8];
     __shared__ float s_lc[BAYES_MAX_LC];
-    __shared__ bool s_flag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (BAYES) { if (tid < BAYES_MAX_LC) s_lc[tid] = a.prm.lc[tid]; __syncthreads(); }
     const int slot_in_wave = BAYES ? (lane & 7) : lane, k_sub = BAYES ? (lane >> 3) : 0;
@@ -379,20 +380,30 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
             }
         }
     }
-    if (!BAYES) {
-        if (blockIdx.x == 0 && tid == 0 && a.adj_out && a.like) a.adj_out[0] = sc.vp_adj;
-        return;
-    }
-    const double t = block_sum_d(usum, s4);
-    block_max_kv(key, kslot, s8);
+    if (blockIdx.x == 0 && tid == 0 && a.adj_out && a.like) a.adj_out[0] = sc.vp_adj;
+    if (!BAYES) return;
+    const double t = block_sum_d<4>(usum, s4);
+    block_max_kv<4>(key, kslot, s8);
     if (tid == 0) { Part2 p = {t, key, kslot, 0}; a.part2[blockIdx.x] = p; }
-    if (!last_block(&a.scal->ticket2, &s_flag)) return;
+}
+
+// fold of pass 2: the sum that normalises, the virtual place's posterior, the highest hypothesis
+__global__ __launch_bounds__(DC_FOLD) void decide_fold2_kernel(Pass2Args a, int n_part) {
+    __shared__ double s_w[DC_FOLD / 64];
+    __shared__ unsigned long long s_kv[2 * DC_FOLD / 64];
+    const int tid = threadIdx.x;
     double s = 0.0;
-    key = 0ull; kslot = ~0ull;
-    for (int b = tid; b < (int)gridDim.x; b += DC_BLOCK) { const Part2 p = a.part2[b]; s += p.usum; if (p.key > key) { key = p.key; kslot = p.slot; } }
-    const double T = block_sum_d(s, s4);
-    block_max_kv(key, kslot, s8);
+    unsigned long long key = 0ull, kslot = ~0ull;
+    for (int b = tid; b < n_part; b += DC_FOLD) { const Part2 p = a.part2[b]; s += p.usum; if (p.key > key) { key = p.key; kslot = p.slot; } }
+    const double T = block_sum_d<16>(s, s_w);
+    block_max_kv<16>(key, kslot, s_kv);
     if (tid == 0) {
+        const Scal sc = *a.scal;
+        const long long cols = sc.n_in + 1;
+        const float pin_vp = a.col[a.n_slots].pin;
+        float p00 = 1.0f;
+        if (a.prm.vp_prior > 0.0f) { if (cols > 1) p00 = a.prm.vp_prior; }
+        else if (cols > 1) p00 = (float)(1.0 / (double)cols);
         // row 0: the virtual place's own value + Bayes/PredictionLC[0] from every other column (:486-490)
         const float like0 = a.like ? sc.vp_adj : a.adj_in[0];
         const float prior0 = (float)((double)p00 * (double)pin_vp + (double)(float)a.prm.lc0 * sc.s_in);
@@ -400,8 +411,6 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
         const float sum = (float)(T + (double)u0);
         const float p0 = sum != 0.0f ? u0 / sum : u0;
         a.scal->sum = sum; a.scal->u0 = u0; a.scal->p0 = p0;
-        a.scal->ticket2 = 0u;
-        if (a.adj_out && a.like) a.adj_out[0] = sc.vp_adj;
         if (a.out) {
             BayesOut o;
             const float ub = __uint_as_float((uint32_t)(key >> 32));
@@ -614,6 +623,7 @@ hipError_t Bayes::decide(const DecideArgs& d, const int32_t* slot_sig, int64_t n
     } else {
         decide_pass1_kernel<false><<<grid, DC_BLOCK, 0, stream>>>(a1);
     }
+    decide_fold1_kernel<<<1, DC_FOLD, 0, stream>>>(a1, grid);
     if (d.bayes || d.adj_out) {
         Pass2Args a2{};
         a2.prm = prm; a2.n_slots = n_slots; a2.n_cons = n_cons; a2.slot_sig = slot_sig; a2.like = d.like; a2.ratio = d.ratio;
@@ -622,6 +632,7 @@ hipError_t Bayes::decide(const DecideArgs& d, const int32_t* slot_sig, int64_t n
             a2.nbr = nbr.as<uint32_t>(); a2.cnt = cnt.as<int32_t>(); a2.K = K; a2.col = col.as<ColS>(); a2.post = post.as<float>();
             a2.was_in = was_in.as<uint8_t>(); a2.out = d.d_bayes;
             decide_pass2_kernel<true><<<grid, DC_BLOCK, 0, stream>>>(a2);
+            decide_fold2_kernel<<<1, DC_FOLD, 0, stream>>>(a2, grid);
         } else {
             decide_pass2_kernel<false><<<grid, DC_BLOCK, 0, stream>>>(a2);
         }
