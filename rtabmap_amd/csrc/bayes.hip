@@ -27,6 +27,7 @@ namespace {
 constexpr int DC_BLOCK = 256;
 constexpr int DC_MAX_GRID = 4096;
 constexpr uint32_t SLOT_MASK = (1u << BAYES_SLOT_BITS) - 1u;
+constexpr int ROWS = 6;                   // list rows (8 entries each) requested up front by the passes: 48 entries cover a chain neighbourhood (33)
 constexpr int TILE = 8;                   // slots per tile of the neighbour table: nbr[(slot / 8) * K + k][slot % 8]
 
 // per column: scale < 0 marks a renormalised column (|scale| = maxNorm / sum); scale == 0: the slot does not take part
@@ -57,47 +58,32 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long u,
     const unsigned lo = __shfl_xor((unsigned)u, m, 64), hi = __shfl_xor((unsigned)(u >> 32), m, 64);
     return ((unsigned long long)hi << 32) | lo;
 }
-// workgroup reductions in a fixed order (wave butterfly, then the waves in order); the result is valid in every thread
+// One workgroup reduction for everything a pass accumulates: four double sums, two counts, one (key, payload) maximum.  Wave
+// butterfly, one LDS slot per wave, ONE barrier; thread 0 then adds the waves in order (fixed order: bit-reproducible).  The
+// result is valid in thread 0 only.
+struct Red { double d0, d1, d2, d3; long long c0, c1; unsigned long long key, pay; };
 template <int NW>
-__device__ __forceinline__ double block_sum_d(double v, double* s_w) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double r = s_w[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) r += s_w[w];
-    return r;
-}
-template <int NW>
-__device__ __forceinline__ long long block_sum_ll(long long v, double* s_w) {
-    long long* s = (long long*)s_w;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += (long long)shfl_xor_u64((unsigned long long)v, m);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
-    __syncthreads();
-    long long r = s[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) r += s[w];
-    return r;
-}
-// the largest key of the workgroup and the payload that came with it (keys are unique unless 0)
-template <int NW>
-__device__ __forceinline__ void block_max_kv(unsigned long long& k, unsigned long long& p, unsigned long long* s_kv) {
+__device__ __forceinline__ Red block_reduce(Red r, Red* s_r) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
-        const unsigned long long ok = shfl_xor_u64(k, m), op = shfl_xor_u64(p, m);
-        if (ok > k) { k = ok; p = op; }
+        r.d0 += shfl_xor_d(r.d0, m); r.d1 += shfl_xor_d(r.d1, m); r.d2 += shfl_xor_d(r.d2, m); r.d3 += shfl_xor_d(r.d3, m);
+        r.c0 += (long long)shfl_xor_u64((unsigned long long)r.c0, m); r.c1 += (long long)shfl_xor_u64((unsigned long long)r.c1, m);
+        const unsigned long long ok = shfl_xor_u64(r.key, m), op = shfl_xor_u64(r.pay, m);
+        if (ok > r.key) { r.key = ok; r.pay = op; }
     }
+    if ((threadIdx.x & 63) == 0) s_r[threadIdx.x >> 6] = r;
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) { s_kv[(threadIdx.x >> 6) * 2] = k; s_kv[(threadIdx.x >> 6) * 2 + 1] = p; }
-    __syncthreads();
-    k = s_kv[0]; p = s_kv[1];
+    if (threadIdx.x == 0) {
 #pragma unroll
-    for (int w = 1; w < NW; ++w) if (s_kv[2 * w] > k) { k = s_kv[2 * w]; p = s_kv[2 * w + 1]; }
+        for (int w = 1; w < NW; ++w) {
+            const Red o = s_r[w];
+            r.d0 += o.d0; r.d1 += o.d1; r.d2 += o.d2; r.d3 += o.d3; r.c0 += o.c0; r.c1 += o.c1;
+            if (o.key > r.key) { r.key = o.key; r.pay = o.pay; }
+        }
+    }
+    return r;
 }
+
 __device__ __forceinline__ float adjusted_value(float value, float mean, float stdDev, float ratio) {   // Rtabmap.cpp:5722-5745
     float o = 1.0f;
     if (value > mean + stdDev) {
@@ -124,11 +110,11 @@ struct Pass1Args {
 
 // number of signatures taking part, ahead of pass 1: only the fill variant needs it there
 __global__ __launch_bounds__(DC_BLOCK) void decide_count_kernel(long long n_cons, const int32_t* __restrict__ slot_sig, long long* __restrict__ out) {
-    __shared__ double s4[4];
-    long long n = 0;
-    for (long long c = (long long)blockIdx.x * DC_BLOCK + threadIdx.x; c < n_cons; c += (long long)gridDim.x * DC_BLOCK) n += slot_sig[c] != 0;
-    const long long t = block_sum_ll<4>(n, s4);
-    if (threadIdx.x == 0) atomicAdd((unsigned long long*)out, (unsigned long long)t);     // integer: order-free
+    __shared__ Red s_r[4];
+    Red r = {0.0, 0.0, 0.0, 0.0, 0, 0, 0ull, 0ull};
+    for (long long c = (long long)blockIdx.x * DC_BLOCK + threadIdx.x; c < n_cons; c += (long long)gridDim.x * DC_BLOCK) r.c0 += slot_sig[c] != 0;
+    r = block_reduce<4>(r, s_r);
+    if (threadIdx.x == 0) atomicAdd((unsigned long long*)out, (unsigned long long)r.c0);     // integer: order-free
 }
 
 // BAYES: 8 lanes per slot walk its neighbour list (a wave covers a tile of 8 slots x 8 entries per step: 256 B coalesced);
@@ -137,8 +123,7 @@ template <bool BAYES>
 __global__ __launch_bounds__(DC_BLOCK) void decide_pass1_kernel(Pass1Args a) {
     constexpr int LPS = BAYES ? 8 : 1;
     constexpr int SPB = DC_BLOCK / LPS;                     // slots per workgroup step
-    __shared__ double s4[4];
-    __shared__ unsigned long long s8[8];
+    __shared__ Red s_r[4];
     __shared__ float s_lc[BAYES_MAX_LC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (BAYES) { if (tid < BAYES_MAX_LC) s_lc[tid] = a.prm.lc[tid]; __syncthreads(); }
@@ -150,41 +135,50 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass1_kernel(Pass1Args a) {
         ColS v = {0.0f, 0.0f, 0.0f, a.empty ? 1.0f : a.scal->p0};
         a.col[a.n_slots] = v;
     }
-    double s1 = 0.0, s2 = 0.0, s_in = 0.0, s_fill = 0.0;
-    long long cnt_pos = 0, n_in = 0;
-    unsigned long long key = 0ull, keyp = 0ull;
+    Red acc = {0.0, 0.0, 0.0, 0.0, 0, 0, 0ull, 0ull};       // d0 = sum v, d1 = sum v^2, d2 = sum of the last posterior, d3 = its fill share; c0 = positives, c1 = taking part
     for (long long base = (long long)blockIdx.x * SPB; base < a.n_slots; base += (long long)gridDim.x * SPB) {
         const long long c = base + wave * (64 / LPS) + slot_in_wave;
-        const bool in = c < a.n_slots && in_set(c, a.n_cons, a.slot_sig);
-        if (a.like && in && k_sub == 0) {
-            const float v = a.like[c];
-            if (v > 0.0f) {
-                s1 += (double)v; s2 += (double)v * (double)v; ++cnt_pos;
-                const unsigned long long k = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(uint32_t)(c + 1);
-                if (k > key) key = k;
-            }
+        const bool valid = c < a.n_slots;
+        // everything that does not depend on another load is requested first
+        uint32_t e[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) e[j] = 0xFFFFFFFFu;
+        if (BAYES && valid) {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) e[j] = a.nbr[tile_at(c, k_sub + 8 * j, a.K)];      // an unused entry reads 0xFFFFFFFF: no count needed
+        }
+        const bool in = valid && in_set(c, a.n_cons, a.slot_sig);
+        float lv = 0.0f, pold = 0.0f;
+        uint8_t wi = 0;
+        if (k_sub == 0 && valid) {
+            if (a.like) lv = a.like[c];
+            if (BAYES && !a.empty) { wi = a.was_in[c]; pold = a.post[1 + c]; }
+        }
+        if (a.like && in && k_sub == 0 && lv > 0.0f) {
+            acc.d0 += (double)lv; acc.d1 += (double)lv * (double)lv; ++acc.c0;
+            const unsigned long long k = ((unsigned long long)__float_as_uint(lv) << 32) | (unsigned long long)(uint32_t)(c + 1);
+            if (k > acc.key) acc.key = k;
         }
         if (BAYES) {
             float sum = 0.0f, self_v = 0.0f;
             int nz = 0;
-            if (in) {
-                const int n = min(a.cnt[c], a.K);
-                for (int k0 = 0; k0 < n; k0 += 64) {                   // 8 entries per lane and step, all loads of a step in flight together
-                    uint32_t e[8];
-                    int32_t sg[8];
+            int k0 = 0;
+            while (true) {
+                int32_t sg[ROWS];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { const int k = k0 + k_sub + 8 * j; e[j] = k < n ? a.nbr[tile_at(c, k, a.K)] : 0xFFFFFFFFu; }
+                for (int j = 0; j < ROWS; ++j) { const long long r = e[j] & SLOT_MASK; sg[j] = (in && e[j] != 0xFFFFFFFFu && r < a.n_cons) ? a.slot_sig[r] : 0; }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { const long long r = e[j] & SLOT_MASK; sg[j] = (e[j] != 0xFFFFFFFFu && r < a.n_cons) ? a.slot_sig[r] : 0; }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (sg[j] == 0) continue;
-                        const float v = s_lc[(e[j] >> BAYES_SLOT_BITS) + 1];
-                        sum += v;
-                        if ((long long)(e[j] & SLOT_MASK) == c) self_v = v;
-                        else if (v != 0.0f) ++nz;
-                    }
+                for (int j = 0; j < ROWS; ++j) {
+                    if (sg[j] == 0) continue;
+                    const float v = s_lc[(e[j] >> BAYES_SLOT_BITS) + 1];
+                    sum += v;
+                    if ((long long)(e[j] & SLOT_MASK) == c) self_v = v;
+                    else if (v != 0.0f) ++nz;
                 }
+                k0 += 8 * ROWS;
+                if (k0 >= a.K || !__any(e[ROWS - 1] != 0xFFFFFFFFu)) break;                       // lists are filled front to back: an empty last row ends them
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j) { const int k = k0 + k_sub + 8 * j; e[j] = (valid && k < a.K) ? a.nbr[tile_at(c, k, a.K)] : 0xFFFFFFFFu; }
             }
 #pragma unroll
             for (int m = 8; m <= 32; m <<= 1) {                        // the 8 lanes of a slot: fixed order
@@ -192,11 +186,11 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass1_kernel(Pass1Args a) {
                 self_v = fmaxf(self_v, __shfl_xor(self_v, m, 64));
                 nz += __shfl_xor(nz, m, 64);
             }
-            if (k_sub == 0 && c < a.n_slots) {
+            if (k_sub == 0 && valid) {
                 ColS cs = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (in) {
                     float p = 1.0f;                                                            // updatePosterior :709-736
-                    if (!a.empty) { p = a.was_in[c] ? a.post[1 + c] : 0.0f; if (sum_prev != 0.0f) p = p / sum_prev; }   // the division of :221-230, made on reading
+                    if (!a.empty) { p = wi ? pold : 0.0f; if (sum_prev != 0.0f) p = p / sum_prev; }   // the division of :221-230, made on reading
                     cs.scale = 1.0f;
                     if ((double)sum < (double)a.prm.total - a.prm.lc0) {                       // neighbours not found go to the loop closure itself (:440-445)
                         cs.delta = (float)((double)a.prm.total - a.prm.lc0 - (double)sum);
@@ -216,40 +210,43 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass1_kernel(Pass1Args a) {
                         if (cs.fill < a.prm.eps) cs.fill = 0.0f;
                     }
                     cs.pin = p;
-                    s_in += (double)p;
-                    s_fill += (double)cs.fill * (double)p;
-                    ++n_in;
+                    acc.d2 += (double)p;
+                    acc.d3 += (double)cs.fill * (double)p;
+                    ++acc.c1;
                 }
                 a.col[c] = cs;
             }
         }
     }
-    keyp = key;
-    const double t1 = block_sum_d<4>(s1, s4), t2 = block_sum_d<4>(s2, s4), t3 = block_sum_d<4>(s_in, s4), t4 = block_sum_d<4>(s_fill, s4);
-    const long long c1 = block_sum_ll<4>(cnt_pos, s4), c2 = block_sum_ll<4>(n_in, s4);
-    block_max_kv<4>(key, keyp, s8);
-    if (tid == 0) { Part1 p = {t1, t2, t3, t4, key, c1, c2, 0}; a.part[blockIdx.x] = p; }
+    acc.pay = acc.key;
+    acc = block_reduce<4>(acc, s_r);
+    if (tid == 0) { Part1 p = {acc.d0, acc.d1, acc.d2, acc.d3, acc.key, acc.c0, acc.c1, 0}; a.part[blockIdx.x] = p; }
 }
 
 // fold of pass 1 (one workgroup, after the kernel boundary: a release/acquire hand-off inside pass 1 would cost every workgroup
 // an L2 write-back on this multi-die part): thread t takes partials t, t + 1024, ... in order, then the fixed tree
 constexpr int DC_FOLD = 1024;
 __global__ __launch_bounds__(DC_FOLD) void decide_fold1_kernel(Pass1Args a, int n_part) {
-    __shared__ double s_w[DC_FOLD / 64];
-    __shared__ unsigned long long s_kv[2 * DC_FOLD / 64];
+    __shared__ Red s_r[DC_FOLD / 64];
     const int tid = threadIdx.x;
-    double s1 = 0.0, s2 = 0.0, s_in = 0.0, s_fill = 0.0;
-    long long cnt_pos = 0, n_in = 0;
-    unsigned long long key = 0ull, keyp = 0ull;
-    for (int b = tid; b < n_part; b += DC_FOLD) {
-        const Part1 p = a.part[b];
-        s1 += p.s1; s2 += p.s2; s_in += p.s_in; s_fill += p.s_fill; cnt_pos += p.cnt; n_in += p.n_in;
-        if (p.key > key) key = p.key;
+    Part1 p[DC_MAX_GRID / DC_FOLD];
+#pragma unroll
+    for (int j = 0; j < DC_MAX_GRID / DC_FOLD; ++j) {          // all loads in flight together
+        const int b = tid + j * DC_FOLD;
+        if (b < n_part) p[j] = a.part[b];
+        else { p[j].s1 = p[j].s2 = p[j].s_in = p[j].s_fill = 0.0; p[j].key = 0ull; p[j].cnt = p[j].n_in = 0; }
     }
-    keyp = key;
-    const double S1 = block_sum_d<16>(s1, s_w), S2 = block_sum_d<16>(s2, s_w), SI = block_sum_d<16>(s_in, s_w), SF = block_sum_d<16>(s_fill, s_w);
-    const long long CP = block_sum_ll<16>(cnt_pos, s_w), NI = block_sum_ll<16>(n_in, s_w);
-    block_max_kv<16>(key, keyp, s_kv);
+    Red r = {0.0, 0.0, 0.0, 0.0, 0, 0, 0ull, 0ull};
+#pragma unroll
+    for (int j = 0; j < DC_MAX_GRID / DC_FOLD; ++j) {
+        r.d0 += p[j].s1; r.d1 += p[j].s2; r.d2 += p[j].s_in; r.d3 += p[j].s_fill; r.c0 += p[j].cnt; r.c1 += p[j].n_in;
+        if (p[j].key > r.key) r.key = p[j].key;
+    }
+    r.pay = r.key;
+    r = block_reduce<DC_FOLD / 64>(r, s_r);
+    const double S1 = r.d0, S2 = r.d1, SI = r.d2, SF = r.d3;
+    const long long CP = r.c0, NI = r.c1;
+    const unsigned long long key = r.key;
     if (tid == 0) {
         Scal* sc = a.scal;
         sc->s_in = SI; sc->s_fill = SF; sc->n_in = NI; sc->cnt_pos = CP; sc->best_key = key;
@@ -306,8 +303,7 @@ template <bool BAYES>
 __global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
     constexpr int LPS = BAYES ? 8 : 1;
     constexpr int SPB = DC_BLOCK / LPS;
-    __shared__ double s4[4];
-    __shared__ unsigned long long s8[8];
+    __shared__ Red s_r[4];
     __shared__ float s_lc[BAYES_MAX_LC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (BAYES) { if (tid < BAYES_MAX_LC) s_lc[tid] = a.prm.lc[tid]; __syncthreads(); }
@@ -325,6 +321,13 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
     for (long long base = (long long)blockIdx.x * SPB; base < a.n_slots; base += (long long)gridDim.x * SPB) {
         const long long i = base + wave * (64 / LPS) + slot_in_wave;
         const bool valid = i < a.n_slots;
+        uint32_t e[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) e[j] = 0xFFFFFFFFu;
+        if (BAYES && valid) {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) e[j] = a.nbr[tile_at(i, k_sub + 8 * j, a.K)];      // an unused entry reads 0xFFFFFFFF: no count needed
+        }
         const bool in = valid && in_set(i, a.n_cons, a.slot_sig);
         float o = 0.0f;
         if (k_sub == 0 && valid) {
@@ -335,28 +338,27 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
         if (BAYES) {
             double acc = 0.0;
             int has_self = 0;
-            if (in) {
-                const int n = min(a.cnt[i], a.K);
-                for (int k0 = 0; k0 < n; k0 += 64) {                   // 8 entries per lane and step, all loads of a step in flight together
-                    uint32_t e[8];
-                    ColS cs[8];
+            int k0 = 0;
+            while (true) {
+                ColS cs[ROWS];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { const int k = k0 + k_sub + 8 * j; e[j] = k < n ? a.nbr[tile_at(i, k, a.K)] : 0xFFFFFFFFu; }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (e[j] != 0xFFFFFFFFu) cs[j] = a.col[e[j] & SLOT_MASK];
-                        else { cs[j].scale = 0.0f; cs[j].delta = 0.0f; cs[j].fill = 0.0f; cs[j].pin = 0.0f; }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (cs[j].scale == 0.0f) continue;                             // the column's signature does not take part
-                        float v = s_lc[(e[j] >> BAYES_SLOT_BITS) + 1];
-                        if ((long long)(e[j] & SLOT_MASK) == i) { v = v + cs[j].delta; has_self = 1; }
-                        if (v == 0.0f) continue;                                       // an element left at 0: it holds the column's fill value
-                        v = finish_element(v, cs[j].scale, a.prm.eps);
-                        acc += ((double)v - (double)cs[j].fill) * (double)cs[j].pin;
-                    }
+                for (int j = 0; j < ROWS; ++j) {
+                    if (in && e[j] != 0xFFFFFFFFu) cs[j] = a.col[e[j] & SLOT_MASK];
+                    else { cs[j].scale = 0.0f; cs[j].delta = 0.0f; cs[j].fill = 0.0f; cs[j].pin = 0.0f; }
                 }
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j) {
+                    if (cs[j].scale == 0.0f) continue;                                 // the column's signature does not take part
+                    float v = s_lc[(e[j] >> BAYES_SLOT_BITS) + 1];
+                    if ((long long)(e[j] & SLOT_MASK) == i) { v = v + cs[j].delta; has_self = 1; }
+                    if (v == 0.0f) continue;                                           // an element left at 0: it holds the column's fill value
+                    v = finish_element(v, cs[j].scale, a.prm.eps);
+                    acc += ((double)v - (double)cs[j].fill) * (double)cs[j].pin;
+                }
+                k0 += 8 * ROWS;
+                if (k0 >= a.K || !__any(e[ROWS - 1] != 0xFFFFFFFFu)) break;                   // lists are filled front to back: an empty last row ends them
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j) { const int k = k0 + k_sub + 8 * j; e[j] = (valid && k < a.K) ? a.nbr[tile_at(i, k, a.K)] : 0xFFFFFFFFu; }
             }
 #pragma unroll
             for (int m = 8; m <= 32; m <<= 1) { acc += shfl_xor_d(acc, m); has_self |= __shfl_xor(has_self, m, 64); }
@@ -382,21 +384,28 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
     }
     if (blockIdx.x == 0 && tid == 0 && a.adj_out && a.like) a.adj_out[0] = sc.vp_adj;
     if (!BAYES) return;
-    const double t = block_sum_d<4>(usum, s4);
-    block_max_kv<4>(key, kslot, s8);
-    if (tid == 0) { Part2 p = {t, key, kslot, 0}; a.part2[blockIdx.x] = p; }
+    Red r = {usum, 0.0, 0.0, 0.0, 0, 0, key, kslot};
+    r = block_reduce<4>(r, s_r);
+    if (tid == 0) { Part2 p = {r.d0, r.key, r.pay, 0}; a.part2[blockIdx.x] = p; }
 }
 
 // fold of pass 2: the sum that normalises, the virtual place's posterior, the highest hypothesis
 __global__ __launch_bounds__(DC_FOLD) void decide_fold2_kernel(Pass2Args a, int n_part) {
-    __shared__ double s_w[DC_FOLD / 64];
-    __shared__ unsigned long long s_kv[2 * DC_FOLD / 64];
+    __shared__ Red s_r[DC_FOLD / 64];
     const int tid = threadIdx.x;
-    double s = 0.0;
-    unsigned long long key = 0ull, kslot = ~0ull;
-    for (int b = tid; b < n_part; b += DC_FOLD) { const Part2 p = a.part2[b]; s += p.usum; if (p.key > key) { key = p.key; kslot = p.slot; } }
-    const double T = block_sum_d<16>(s, s_w);
-    block_max_kv<16>(key, kslot, s_kv);
+    Part2 p[DC_MAX_GRID / DC_FOLD];
+#pragma unroll
+    for (int j = 0; j < DC_MAX_GRID / DC_FOLD; ++j) {
+        const int b = tid + j * DC_FOLD;
+        if (b < n_part) p[j] = a.part2[b];
+        else { p[j].usum = 0.0; p[j].key = 0ull; p[j].slot = ~0ull; }
+    }
+    Red r = {0.0, 0.0, 0.0, 0.0, 0, 0, 0ull, ~0ull};
+#pragma unroll
+    for (int j = 0; j < DC_MAX_GRID / DC_FOLD; ++j) { r.d0 += p[j].usum; if (p[j].key > r.key) { r.key = p[j].key; r.pay = p[j].slot; } }
+    r = block_reduce<DC_FOLD / 64>(r, s_r);
+    const double T = r.d0;
+    const unsigned long long key = r.key, kslot = r.pay;
     if (tid == 0) {
         const Scal sc = *a.scal;
         const long long cols = sc.n_in + 1;
