@@ -150,6 +150,7 @@ class BayesStepper(Stepper):
         self.one_base = -np.arange(depth - 1, -1, -1, dtype=np.int32)
         self.one_nbr = np.zeros(depth, np.int32)
         self.one_mg = np.arange(depth - 1, -1, -1, dtype=np.int32)
+        self.one_prep = eng.bayes_neighbors_prepared(self.one_id, self.one_off, self.one_nbr, self.one_mg)
         self.args.d_bayes = self.d_res.data_ptr()
 
     def __call__(self, i):
@@ -157,7 +158,7 @@ class BayesStepper(Stepper):
         super().__call__(i)
         # the new signature's list: itself and the depth - 1 signatures before it (chain_neighbors(sid, sid, oldest), without the numpy work)
         self.one_nbr[:] = self.one_base + sid
-        self.eng.bayes_set_neighbors(self.one_id, self.one_off, self.one_nbr, self.one_mg)
+        self.eng.bayes_set_neighbors_prepared(self.one_prep)
         self.one_id[0] = sid + 1
 
 

@@ -328,6 +328,18 @@ class Engine:
         assert o.shape[0] == s.shape[0] + 1 and n.shape[0] == m.shape[0]
         self._ck(self.L.lcd_bayes_set_neighbors(self.h, s.shape[0], _p(s), _p(o), _p(n), _p(m)))
 
+    def bayes_neighbors_prepared(self, sig_ids, offsets, nbr_sig_ids, nbr_margins):
+        """The argument pointers of bayes_set_neighbors for caller-owned arrays (int32 / int64 / int32 / int32, C-contiguous), built
+        once for a tight loop: the arrays' CONTENTS may change between calls, their shapes may not."""
+        assert sig_ids.dtype == np.int32 and offsets.dtype == np.int64 and nbr_sig_ids.dtype == np.int32 and nbr_margins.dtype == np.int32
+        assert offsets.shape[0] == sig_ids.shape[0] + 1 and nbr_sig_ids.shape[0] == nbr_margins.shape[0]
+        return (sig_ids.shape[0], _p(sig_ids), _p(offsets), _p(nbr_sig_ids), _p(nbr_margins), (sig_ids, offsets, nbr_sig_ids, nbr_margins))
+
+    def bayes_set_neighbors_prepared(self, prep):
+        rc = self.L.lcd_bayes_set_neighbors(self.h, prep[0], prep[1], prep[2], prep[3], prep[4])
+        if rc != LCD_OK:
+            self._ck(rc)
+
     def bayes_update_dev(self, d_adjusted_ptr, exclude_recent=0, d_posterior_ptr=None, d_result_ptr=None):
         self._ck(self.L.lcd_bayes_update_dev(self.h, d_adjusted_ptr, exclude_recent, d_posterior_ptr, d_result_ptr))
 

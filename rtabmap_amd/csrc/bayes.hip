@@ -25,7 +25,7 @@ namespace lcd {
 namespace {
 
 constexpr int DC_BLOCK = 256;
-constexpr int DC_MAX_GRID = 4096;
+constexpr int DC_MAX_GRID = 1024;
 constexpr uint32_t SLOT_MASK = (1u << BAYES_SLOT_BITS) - 1u;
 constexpr int ROWS = 6;                   // list rows (8 entries each) requested up front by the passes: 48 entries cover a chain neighbourhood (33)
 constexpr int TILE = 8;                   // slots per tile of the neighbour table: nbr[(slot / 8) * K + k][slot % 8]
@@ -136,16 +136,27 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass1_kernel(Pass1Args a) {
         a.col[a.n_slots] = v;
     }
     Red acc = {0.0, 0.0, 0.0, 0.0, 0, 0, 0ull, 0ull};       // d0 = sum v, d1 = sum v^2, d2 = sum of the last posterior, d3 = its fill share; c0 = positives, c1 = taking part
-    for (long long base = (long long)blockIdx.x * SPB; base < a.n_slots; base += (long long)gridDim.x * SPB) {
+    const long long stride = (long long)gridDim.x * SPB;
+    uint32_t en[ROWS];                                      // the next step's list rows, requested one step ahead
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) en[j] = 0xFFFFFFFFu;
+    if (BAYES) {
+        const long long c0 = (long long)blockIdx.x * SPB + wave * (64 / LPS) + slot_in_wave;
+        if (c0 < a.n_slots) {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) en[j] = a.nbr[tile_at(c0, k_sub + 8 * j, a.K)];    // an unused entry reads 0xFFFFFFFF: no count needed
+        }
+    }
+    for (long long base = (long long)blockIdx.x * SPB; base < a.n_slots; base += stride) {
         const long long c = base + wave * (64 / LPS) + slot_in_wave;
         const bool valid = c < a.n_slots;
         // everything that does not depend on another load is requested first
         uint32_t e[ROWS];
 #pragma unroll
-        for (int j = 0; j < ROWS; ++j) e[j] = 0xFFFFFFFFu;
-        if (BAYES && valid) {
+        for (int j = 0; j < ROWS; ++j) { e[j] = en[j]; en[j] = 0xFFFFFFFFu; }
+        if (BAYES && c + stride < a.n_slots) {
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j) e[j] = a.nbr[tile_at(c, k_sub + 8 * j, a.K)];      // an unused entry reads 0xFFFFFFFF: no count needed
+            for (int j = 0; j < ROWS; ++j) en[j] = a.nbr[tile_at(c + stride, k_sub + 8 * j, a.K)];
         }
         const bool in = valid && in_set(c, a.n_cons, a.slot_sig);
         float lv = 0.0f, pold = 0.0f;
@@ -223,55 +234,74 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass1_kernel(Pass1Args a) {
     if (tid == 0) { Part1 p = {acc.d0, acc.d1, acc.d2, acc.d3, acc.key, acc.c0, acc.c1, 0}; a.part[blockIdx.x] = p; }
 }
 
-// fold of pass 1 (one workgroup, after the kernel boundary: a release/acquire hand-off inside pass 1 would cost every workgroup
-// an L2 write-back on this multi-die part): thread t takes partials t, t + 1024, ... in order, then the fixed tree
-constexpr int DC_FOLD = 1024;
-__global__ __launch_bounds__(DC_FOLD) void decide_fold1_kernel(Pass1Args a, int n_part) {
-    __shared__ Red s_r[DC_FOLD / 64];
+// fold of pass 1: thread t takes partials t, t + NT, ... in order, then the fixed tree; thread 0 derives adjustLikelihood's
+// statistics.  Either its own one-workgroup launch or the prologue of EVERY pass-2 workgroup (same inputs, same order: same bits)
+// -- a release/acquire hand-off inside pass 1 would cost each workgroup an L2 write-back on this multi-die part.
+struct Fold1 { double s_in, s_fill; long long n_in, cnt_pos; float mean, stddev, vp_adj, maxv; unsigned long long best_key; };
+template <int NT>
+__device__ __forceinline__ void fold1(const Part1* __restrict__ part, int n_part, bool have_like, float ratio, Red* s_r, Fold1* s_out) {
+    constexpr int PER = DC_MAX_GRID / NT;
     const int tid = threadIdx.x;
-    Part1 p[DC_MAX_GRID / DC_FOLD];
-#pragma unroll
-    for (int j = 0; j < DC_MAX_GRID / DC_FOLD; ++j) {          // all loads in flight together
-        const int b = tid + j * DC_FOLD;
-        if (b < n_part) p[j] = a.part[b];
-        else { p[j].s1 = p[j].s2 = p[j].s_in = p[j].s_fill = 0.0; p[j].key = 0ull; p[j].cnt = p[j].n_in = 0; }
-    }
     Red r = {0.0, 0.0, 0.0, 0.0, 0, 0, 0ull, 0ull};
+    if (n_part <= NT) {                                          // the usual case: one partial per thread
+        if (tid < n_part) { const Part1 p = part[tid]; r.d0 = p.s1; r.d1 = p.s2; r.d2 = p.s_in; r.d3 = p.s_fill; r.c0 = p.cnt; r.c1 = p.n_in; r.key = p.key; }
+    } else {
+        Part1 p[PER];
 #pragma unroll
-    for (int j = 0; j < DC_MAX_GRID / DC_FOLD; ++j) {
-        r.d0 += p[j].s1; r.d1 += p[j].s2; r.d2 += p[j].s_in; r.d3 += p[j].s_fill; r.c0 += p[j].cnt; r.c1 += p[j].n_in;
-        if (p[j].key > r.key) r.key = p[j].key;
+        for (int j = 0; j < PER; ++j) {                          // all loads in flight together
+            const int b = tid + j * NT;
+            if (b < n_part) p[j] = part[b];
+            else { p[j].s1 = p[j].s2 = p[j].s_in = p[j].s_fill = 0.0; p[j].key = 0ull; p[j].cnt = p[j].n_in = 0; }
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            r.d0 += p[j].s1; r.d1 += p[j].s2; r.d2 += p[j].s_in; r.d3 += p[j].s_fill; r.c0 += p[j].cnt; r.c1 += p[j].n_in;
+            if (p[j].key > r.key) r.key = p[j].key;
+        }
     }
     r.pay = r.key;
-    r = block_reduce<DC_FOLD / 64>(r, s_r);
-    const double S1 = r.d0, S2 = r.d1, SI = r.d2, SF = r.d3;
-    const long long CP = r.c0, NI = r.c1;
-    const unsigned long long key = r.key;
+    r = block_reduce<NT / 64>(r, s_r);
     if (tid == 0) {
-        Scal* sc = a.scal;
-        sc->s_in = SI; sc->s_fill = SF; sc->n_in = NI; sc->cnt_pos = CP; sc->best_key = key;
+        Fold1 f;
+        f.s_in = r.d2; f.s_fill = r.d3; f.n_in = r.c1; f.cnt_pos = r.c0; f.best_key = r.key;
+        const double S1 = r.d0, S2 = r.d1;
+        const long long CP = r.c0;
         float mean = 0.0f, stdDev = 0.0f, vp = 2.0f;
-        const float maxv = __uint_as_float((uint32_t)(key >> 32));
-        if (a.like) {
+        const float maxv = __uint_as_float((uint32_t)(r.key >> 32));
+        if (have_like) {
             mean = CP ? (float)(S1 / (double)CP) : 0.0f;                                       // uMean
             double var = 0.0;
             if (CP > 1) var = (S2 - 2.0 * (double)mean * S1 + (double)CP * (double)mean * (double)mean) / (double)(CP - 1);   // uVariance around the float mean
             stdDev = sqrtf((float)fmax(var, 0.0));
-            if (a.ratio == 0.0f && stdDev > 0.0001f && maxv != 0.0f) vp = mean / stdDev + 1.0f;   // Rtabmap.cpp:5747-5758
-            else if (a.ratio != 0.0f && maxv > mean) vp = stdDev / (maxv - mean) + 1.0f;
+            if (ratio == 0.0f && stdDev > 0.0001f && maxv != 0.0f) vp = mean / stdDev + 1.0f;     // Rtabmap.cpp:5747-5758
+            else if (ratio != 0.0f && maxv > mean) vp = stdDev / (maxv - mean) + 1.0f;
         }
-        sc->mean = mean; sc->stddev = stdDev; sc->vp_adj = vp; sc->maxv = maxv;
-        if (a.hyp && a.like) {
-            HypothesisOut h;
-            const long long slot = (long long)(uint32_t)key - 1;
-            h.slot = (int32_t)slot;
-            h.sig_id = slot >= 0 ? a.slot_sig[slot] : 0;
-            h.likelihood = slot >= 0 ? maxv : 0.0f;
-            h.adjusted = slot >= 0 ? adjusted_value(maxv, mean, stdDev, a.ratio) : 0.0f;
-            h.virtual_place = vp; h.mean = mean; h.stddev = stdDev; h.n_positive = (int32_t)CP;
-            *a.hyp = h;
-        }
+        f.mean = mean; f.stddev = stdDev; f.vp_adj = vp; f.maxv = maxv;
+        *s_out = f;
     }
+    __syncthreads();
+}
+// what the fold leaves in HBM: the scalars (pass 2's fold and the next update read them) and the likelihood's best candidate
+__device__ __forceinline__ void publish_fold1(const Fold1& f, Scal* sc, HypothesisOut* hyp, bool have_like, float ratio, const int32_t* __restrict__ slot_sig) {
+    sc->s_in = f.s_in; sc->s_fill = f.s_fill; sc->n_in = f.n_in; sc->cnt_pos = f.cnt_pos; sc->best_key = f.best_key;
+    sc->mean = f.mean; sc->stddev = f.stddev; sc->vp_adj = f.vp_adj; sc->maxv = f.maxv;
+    if (hyp && have_like) {
+        HypothesisOut h;
+        const long long slot = (long long)(uint32_t)f.best_key - 1;
+        h.slot = (int32_t)slot;
+        h.sig_id = slot >= 0 ? slot_sig[slot] : 0;
+        h.likelihood = slot >= 0 ? f.maxv : 0.0f;
+        h.adjusted = slot >= 0 ? adjusted_value(f.maxv, f.mean, f.stddev, ratio) : 0.0f;
+        h.virtual_place = f.vp_adj; h.mean = f.mean; h.stddev = f.stddev; h.n_positive = (int32_t)f.cnt_pos;
+        *hyp = h;
+    }
+}
+constexpr int DC_FOLD = 1024;
+__global__ __launch_bounds__(DC_FOLD) void decide_fold1_kernel(Pass1Args a, int n_part) {
+    __shared__ Red s_r[DC_FOLD / 64];
+    __shared__ Fold1 s_f;
+    fold1<DC_FOLD>(a.part, n_part, a.like != nullptr, a.ratio, s_r, &s_f);
+    if (threadIdx.x == 0) publish_fold1(s_f, a.scal, a.hyp, a.like != nullptr, a.ratio, a.slot_sig);
 }
 
 struct Pass2Args {
@@ -287,6 +317,8 @@ struct Pass2Args {
     uint8_t* was_in;
     Part2* part2; Scal* scal;
     BayesOut* out;                    // may be NULL
+    const Part1* part1; int n_part1;  // pass 1's partials: every workgroup folds them itself
+    HypothesisOut* hyp;               // may be NULL
 };
 
 // one element of the prediction matrix as normalize() leaves it: v = the value addNeighborProb stored (+ delta on the diagonal)
@@ -308,9 +340,23 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (BAYES) { if (tid < BAYES_MAX_LC) s_lc[tid] = a.prm.lc[tid]; __syncthreads(); }
     const int slot_in_wave = BAYES ? (lane & 7) : lane, k_sub = BAYES ? (lane >> 3) : 0;
-    const Scal sc = *a.scal;
-    const long long cols = sc.n_in + 1;
+    const long long stride = (long long)gridDim.x * SPB;
+    uint32_t en[ROWS];                                                 // the first step's list rows: in flight while pass 1 is folded
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) en[j] = 0xFFFFFFFFu;
+    if (BAYES) {
+        const long long c0 = (long long)blockIdx.x * SPB + wave * (64 / LPS) + slot_in_wave;
+        if (c0 < a.n_slots) {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) en[j] = a.nbr[tile_at(c0, k_sub + 8 * j, a.K)];    // an unused entry reads 0xFFFFFFFF: no count needed
+        }
+    }
     const float pin_vp = BAYES ? a.col[a.n_slots].pin : 0.0f;          // the virtual place's last posterior rides behind the last column
+    __shared__ Fold1 s_f;
+    fold1<DC_BLOCK>(a.part1, a.n_part1, a.like != nullptr, a.ratio, s_r, &s_f);
+    const Fold1 sc = s_f;
+    if (blockIdx.x == 0 && tid == 0) publish_fold1(sc, a.scal, a.hyp, a.like != nullptr, a.ratio, a.slot_sig);
+    const long long cols = sc.n_in + 1;
     float vp_col = 0.0f, p00 = 1.0f;                                   // the virtual place's column (:376-411)
     if (a.prm.vp_prior > 0.0f) {
         if (cols > 1) { vp_col = (float)((1.0 - a.prm.vp_prior) / (double)(cols - 1)); p00 = a.prm.vp_prior; }
@@ -318,15 +364,15 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
     const double from_vp = (double)vp_col * (double)pin_vp;
     double usum = 0.0;
     unsigned long long key = 0ull, kslot = ~0ull;
-    for (long long base = (long long)blockIdx.x * SPB; base < a.n_slots; base += (long long)gridDim.x * SPB) {
+    for (long long base = (long long)blockIdx.x * SPB; base < a.n_slots; base += stride) {
         const long long i = base + wave * (64 / LPS) + slot_in_wave;
         const bool valid = i < a.n_slots;
         uint32_t e[ROWS];
 #pragma unroll
-        for (int j = 0; j < ROWS; ++j) e[j] = 0xFFFFFFFFu;
-        if (BAYES && valid) {
+        for (int j = 0; j < ROWS; ++j) { e[j] = en[j]; en[j] = 0xFFFFFFFFu; }
+        if (BAYES && i + stride < a.n_slots) {
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j) e[j] = a.nbr[tile_at(i, k_sub + 8 * j, a.K)];      // an unused entry reads 0xFFFFFFFF: no count needed
+            for (int j = 0; j < ROWS; ++j) en[j] = a.nbr[tile_at(i + stride, k_sub + 8 * j, a.K)];
         }
         const bool in = valid && in_set(i, a.n_cons, a.slot_sig);
         float o = 0.0f;
@@ -632,11 +678,11 @@ hipError_t Bayes::decide(const DecideArgs& d, const int32_t* slot_sig, int64_t n
     } else {
         decide_pass1_kernel<false><<<grid, DC_BLOCK, 0, stream>>>(a1);
     }
-    decide_fold1_kernel<<<1, DC_FOLD, 0, stream>>>(a1, grid);
+    if (!(d.bayes || d.adj_out)) decide_fold1_kernel<<<1, DC_FOLD, 0, stream>>>(a1, grid);      // otherwise pass 2 folds in its prologue
     if (d.bayes || d.adj_out) {
         Pass2Args a2{};
         a2.prm = prm; a2.n_slots = n_slots; a2.n_cons = n_cons; a2.slot_sig = slot_sig; a2.like = d.like; a2.ratio = d.ratio;
-        a2.adj_in = d.adj_in; a2.adj_out = d.adj_out; a2.part2 = part2; a2.scal = sc;
+        a2.adj_in = d.adj_in; a2.adj_out = d.adj_out; a2.part2 = part2; a2.scal = sc; a2.part1 = part; a2.n_part1 = grid; a2.hyp = d.hyp;
         if (d.bayes) {
             a2.nbr = nbr.as<uint32_t>(); a2.cnt = cnt.as<int32_t>(); a2.K = K; a2.col = col.as<ColS>(); a2.post = post.as<float>();
             a2.was_in = was_in.as<uint8_t>(); a2.out = d.d_bayes;

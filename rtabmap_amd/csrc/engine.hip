@@ -975,7 +975,17 @@ int lcd_bayes_reset(lcd_engine* h) {
 int lcd_bayes_set_neighbors(lcd_engine* h, int n_sigs, const int32_t* sig_ids, const int64_t* offsets, const int32_t* nbr_sig_ids,
                             const int32_t* nbr_margins) {
     LCD_CHECK_HANDLE(h);
+#ifdef LCD_DEBUG_TIMING
+    static double dbg[4]; static int dbg_n;
+    const auto d0 = std::chrono::steady_clock::now();
+#endif
     LCD_DEV_NODRAIN(h);                                       // a pipelined handle queues the lists behind the index stage it still owes
+#ifdef LCD_DEBUG_TIMING
+    const auto d1 = std::chrono::steady_clock::now();
+    struct Rep { std::chrono::steady_clock::time_point a, b; double* d; int* n; ~Rep() { auto c = std::chrono::steady_clock::now();
+        d[0] += std::chrono::duration<double, std::micro>(b - a).count(); d[1] += std::chrono::duration<double, std::micro>(c - b).count();
+        if (++*n % 100 == 0) { fprintf(stderr, "[set_neighbors] setdevice %.2f us, rest %.2f us (avg of 100)\n", d[0] / 100, d[1] / 100); d[0] = d[1] = 0; } } } rep__{d0, d1, dbg, &dbg_n};
+#endif
     if (n_sigs < 0 || (n_sigs > 0 && (!sig_ids || !offsets))) return h->fail(LCD_ERR_INVALID, "lcd_bayes_set_neighbors: bad argument");
     if (!h->bayes.configured) return h->fail(LCD_ERR_STATE, "lcd_bayes_set_neighbors: lcd_bayes_configure first");
     if (n_sigs == 0) return LCD_OK;
