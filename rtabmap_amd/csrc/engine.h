@@ -52,7 +52,7 @@ struct lcd_engine {
     int pipeline = 0;
     hipStream_t kst = nullptr;                          // the stream the 2-NN stage is enqueued on (== stream)
     struct AltScratch {
-        lcd::DevBuf d_knn_row, d_knn_word, d_knn_dist, d_selfdist, d_bits, d_partial2, d_partial3, d_fail_list, d_fail_count, d_out_wslot, d_knn_wslot;
+        lcd::DevBuf d_knn_row, d_knn_word, d_knn_dist, d_selfdist, d_bits, d_partial2, d_partial3, d_fail_list, d_fail_count, d_out_wslot;
         bool fail_count_clean = false;
     } alt;
     int ks_idx = 0;                                     // which of the two sets is the current one

@@ -216,7 +216,7 @@ void lcd_destroy(lcd_engine* h) {
     h->bayes.destroy();
     {
         DevBuf* alts[] = {&h->alt.d_knn_row, &h->alt.d_knn_word, &h->alt.d_knn_dist, &h->alt.d_selfdist, &h->alt.d_bits, &h->alt.d_partial2,
-                          &h->alt.d_partial3, &h->alt.d_fail_list, &h->alt.d_fail_count, &h->alt.d_out_wslot, &h->alt.d_knn_wslot};
+                          &h->alt.d_partial3, &h->alt.d_fail_list, &h->alt.d_fail_count, &h->alt.d_out_wslot};
         for (DevBuf* d : alts) d->release(&h->bytes_device);
     }
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -758,7 +758,6 @@ static void swap_scratch(lcd_engine* h) {
     std::swap(h->d_selfdist, h->alt.d_selfdist); std::swap(h->d_bits, h->alt.d_bits); std::swap(h->d_partial2, h->alt.d_partial2);
     std::swap(h->d_partial3, h->alt.d_partial3); std::swap(h->d_fail_list, h->alt.d_fail_list); std::swap(h->d_fail_count, h->alt.d_fail_count);
     std::swap(h->d_out_wslot, h->alt.d_out_wslot); std::swap(h->fail_count_clean, h->alt.fail_count_clean);
-    std::swap(h->d_knn_wslot, h->alt.d_knn_wslot);
     h->ks_idx ^= 1;
 }
 
@@ -874,8 +873,6 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     k.fail_list = h->d_fail_list.as<int32_t>(); k.fail_count = h->d_fail_count.as<int32_t>();
     k.cb = CandBits();
     if (together) { k.cb.selfdist = h->d_selfdist.as<float>(); k.cb.ld = ld; k.cb.nq = q; k.cb.have_index = 1; cand_bits_layout(k.cb, h->d_bits.as<uint32_t>(), q, bw); }
-    LCD_HIP(h, dreserve(h, h->d_knn_wslot, (size_t)q * 2 * 4));
-    k.cb.row_wslot = h->row_wslot.as<int32_t>(); k.cb.out_ws = h->d_knn_wslot.as<int32_t>();   // the neighbours' postings keys ride with their word ids
     if (!h->fail_count_clean) LCD_HIP(h, hipMemsetAsync(h->d_fail_count.p, 0, 8, h->stream));
     // ---- the owed index stage of the previous frame: host part now, its launches ride with this frame's
     TailLaunch tl; ScoreArgs sa; int score_wgs = 0;
@@ -919,10 +916,10 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     r.q = q; r.flags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0); r.nndr = a->nndr_ratio; r.have_index = 1;
     r.knn_word = k.out_word; r.knn_dist = k.out_dist; r.selfdist = together ? h->d_selfdist.as<float>() : nullptr; r.ld = ld;
     r.cand_bits = together ? h->d_bits.as<uint32_t>() : nullptr; r.bw = bw; r.out_word = a->d_word_ids; r.out_n_new = h->d_n_new.as<int32_t>();
-    r.cand_list = together ? k.cb.list : nullptr; r.cand_cnt = together ? k.cb.cnt : nullptr; r.knn_wslot = k.cb.out_ws;
+    r.cand_list = together ? k.cb.list : nullptr; r.cand_cnt = together ? k.cb.cnt : nullptr;
     r.knn_row = k.out_row; r.row_wslot = h->row_wslot.as<int32_t>(); r.out_wslot = h->d_out_wslot.as<int32_t>(); r.new_ws = WsRuns();
     r.fail_count = h->d_fail_count.as<int32_t>();
-    fill_redo(h, &r.rp, h->vocab.p, h->row_id.as<int32_t>(), (int)h->n_rows, a->d_descriptors, k.out_row, k.out_word, k.out_dist, &k.cb);
+    fill_redo(h, &r.rp, h->vocab.p, h->row_id.as<int32_t>(), (int)h->n_rows, a->d_descriptors, k.out_row, k.out_word, k.out_dist, together ? &k.cb : nullptr);
     h->deferred.valid = true; h->deferred.a = *a; h->deferred.r = r;
     return LCD_OK;
 }

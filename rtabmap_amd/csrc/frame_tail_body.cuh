@@ -195,7 +195,7 @@ __device__ __forceinline__ void frame_tail_body(uint32_t* ft_dyn_smem, const Res
     int32_t* lds_ws = r.q <= KPT * NT ? (int32_t*)(ft_dyn_smem + 2 * a.H + a.H / 64 + 8) : nullptr;
     if (lds_ws) resolve_body_fast<NT, KPT>(ft_dyn_smem, lds_ws, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld,
                                            r.cand_bits, r.bw, r.out_word, r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws, r.cand_list,
-                                           r.cand_cnt, r.knn_wslot);
+                                           r.cand_cnt);
     else resolve_body<NT>(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
                       r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
     if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; r.fail_count[3] = 0; }

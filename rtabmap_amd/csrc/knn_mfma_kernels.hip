@@ -783,7 +783,6 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
     __shared__ int s_ncand;
     __shared__ uint64_t s_cand[RR_MAX_CAND], s_exact[RR_MAX_CAND];
     __shared__ int32_t s_word[RR_MAX_CAND];
-    __shared__ int32_t s_ws[RR_MAX_CAND];
     __shared__ float s_err[MF_WAVES];
     // Everything that does not depend on other loads is requested up front (the kernel is a chain of round trips): the first two
     // keys and the first bound of every thread, the query slice, the vocabulary norm bound and -- for the candidate bits -- the
@@ -860,7 +859,6 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
             const uint32_t row = (uint32_t)k;
             const float4 v4 = reinterpret_cast<const float4*>(vocab + (size_t)row * DIM)[lane & 15];
             const int32_t wid = (lane & 15) == 0 ? row_id[row] : 0;
-            const int32_t wsl = ((lane & 15) == 0 && cb.out_ws) ? cb.row_wslot[row] : -1;
             const float d0 = __fsub_rn(v4.x, q4.x), d1 = __fsub_rn(v4.y, q4.y), d2 = __fsub_rn(v4.z, q4.z), d3 = __fsub_rn(v4.w, q4.w);
             float t = __fmul_rn(d0, d0);
             t = __fadd_rn(t, __fmul_rn(d1, d1));
@@ -872,7 +870,6 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
             if ((lane & 15) == 0) {
                 s_exact[i] = ((uint64_t)__float_as_uint(res) << 32) | (uint32_t)i;   // the slot stands in for the row: see below
                 s_word[i] = wid;
-                s_ws[i] = wsl;
                 err_ratio = fmaxf(err_ratio, fabsf(__uint_as_float((uint32_t)(k >> 32)) - res) / eps);
             }
         }
@@ -917,7 +914,6 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
         const int sl[2] = {sbest, ssecond};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if (cb.out_ws) cb.out_ws[2 * qi + j] = k[j] == KEY_NONE ? -1 : s_ws[sl[j]];
             if (k[j] == KEY_NONE) { out_row[2 * qi + j] = -1; out_word[2 * qi + j] = 0; out_dist[2 * qi + j] = -1.0f; }
             else {
                 out_row[2 * qi + j] = (int32_t)(uint32_t)k[j];

@@ -40,9 +40,6 @@ struct CandBits {
     // at most four, the (j, distance bits) pairs themselves -- one coalesced read instead of a bit-row scan and distance gathers
     uint2* list = nullptr;             // [nq x 4] {j, distance bits}
     int32_t* cnt = nullptr;            // [nq] (> 4: the list is incomplete, use the bit row)
-    // the postings keys of the two neighbours, fetched with the rows' word ids: the decision loop then has no dependent gather
-    const int32_t* row_wslot = nullptr;
-    int32_t* out_ws = nullptr;         // [nq x 2] (NULL: not wanted)
 };
 inline size_t cand_bits_bytes(int q, int bw) { return (size_t)q * (bw + 9) * 4; }   // bit rows | lists | counts in one buffer
 inline void cand_bits_layout(CandBits& cb, uint32_t* base, int q, int bw) {

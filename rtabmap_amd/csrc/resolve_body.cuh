@@ -91,8 +91,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
                                                   int32_t* __restrict__ out_word, int32_t* __restrict__ out_n_new,
                                                   const int32_t* __restrict__ knn_row, const int32_t* __restrict__ row_wslot,
                                                   int32_t* __restrict__ out_wslot, const WsRuns& new_ws,
-                                                  const uint2* __restrict__ cand_list = nullptr, const int32_t* __restrict__ cand_cnt = nullptr,
-                                                  const int32_t* __restrict__ knn_wslot = nullptr /* [q x 2] postings keys left by the re-rank */) {
+                                                  const uint2* __restrict__ cand_list = nullptr, const int32_t* __restrict__ cand_cnt = nullptr) {
     const int mw = (q + 63) / 64 * 2;
     uint32_t* mask_cur = rs_smem;
     uint32_t* mask_next = rs_smem + mw;
@@ -122,32 +121,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
             const float2 dd = *reinterpret_cast<const float2*>(knn_dist + 2 * i);
             const int2 ww = *reinterpret_cast<const int2*>(knn_word + 2 * i);
             d0[k] = dd.x; d1[k] = dd.y; st[k].w0 = ww.x; st[k].w1 = ww.y;
-            if ((out_wslot || lds_wslot) && !knn_wslot) { const int2 rr = *reinterpret_cast<const int2*>(knn_row + 2 * i); r0[k] = rr.x; r1[k] = rr.y; }
-        }
-    }
-    // with the re-rank's sidecar outputs everything below is part of the SAME round trip: postings keys, candidate lists and bit rows
-    // are read unconditionally (a list / row that is not needed costs 96 bytes, a dependent round trip costs microseconds)
-    int2 wsp[KPT];
-#pragma unroll
-    for (int k = 0; k < KPT; ++k) {
-        const int i = tid + k * NT;
-        wsp[k] = make_int2(-1, -1);
-        if (knn_wslot && i < q && have_index && (out_wslot || lds_wslot)) wsp[k] = *reinterpret_cast<const int2*>(knn_wslot + 2 * i);
-    }
-    const bool eager = knn_wslot != nullptr && together && cand_cnt != nullptr && bw <= 16;
-    uint4 e_lo[KPT], e_hi[KPT], e_rb[KPT][4];
-#pragma unroll
-    for (int k = 0; k < KPT; ++k) {
-        const int i = tid + k * NT;
-        e_lo[k] = make_uint4(0u, 0u, 0u, 0u); e_hi[k] = e_lo[k];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) e_rb[k][u] = make_uint4(0u, 0u, 0u, 0u);
-        if (eager && i < q) {
-            e_lo[k] = *reinterpret_cast<const uint4*>(cand_list + (size_t)i * 4);
-            e_hi[k] = *reinterpret_cast<const uint4*>(cand_list + (size_t)i * 4 + 2);
-            const uint4* row = reinterpret_cast<const uint4*>(cand_bits + (size_t)i * bw);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (4 * u < bw) e_rb[k][u] = row[u];
+            if (out_wslot || lds_wslot) { const int2 rr = *reinterpret_cast<const int2*>(knn_row + 2 * i); r0[k] = rr.x; r1[k] = rr.y; }
         }
     }
     // ---- the same-frame candidates: count + compact list left by the re-rank (one read each); descriptors with more than four, and
@@ -164,8 +138,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
     for (int k = 0; k < KPT; ++k) {
         const int i = tid + k * NT;
         st[k].ws_a = -1; st[k].ws_b = -1;
-        if (knn_wslot) { st[k].ws_a = wsp[k].x; st[k].ws_b = wsp[k].y; }
-        else if (i < q && (out_wslot || lds_wslot)) {
+        if (i < q && (out_wslot || lds_wslot)) {
             if (r0[k] >= 0) st[k].ws_a = row_wslot ? row_wslot[r0[k]] : r0[k];
             if (r1[k] >= 0) st[k].ws_b = row_wslot ? row_wslot[r1[k]] : r1[k];
         }
@@ -178,8 +151,8 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
 #pragma unroll
         for (int e = 0; e < 4; ++e) { S.cj[e] = 0; S.cd[e] = 0.0f; }
         if (cn[k] > 0 && cn[k] <= 4) {
-            const uint4 lo = eager ? e_lo[k] : *reinterpret_cast<const uint4*>(cand_list + (size_t)i * 4);
-            const uint4 hi = eager ? e_hi[k] : (cn[k] > 2 ? *reinterpret_cast<const uint4*>(cand_list + (size_t)i * 4 + 2) : make_uint4(0u, 0u, 0u, 0u));
+            const uint4 lo = *reinterpret_cast<const uint4*>(cand_list + (size_t)i * 4);
+            const uint4 hi = cn[k] > 2 ? *reinterpret_cast<const uint4*>(cand_list + (size_t)i * 4 + 2) : make_uint4(0u, 0u, 0u, 0u);
             S.cj[0] = (int)lo.x; S.cd[0] = __uint_as_float(lo.y); S.cj[1] = (int)lo.z; S.cd[1] = __uint_as_float(lo.w);
             S.cj[2] = (int)hi.x; S.cd[2] = __uint_as_float(hi.y); S.cj[3] = (int)hi.z; S.cd[3] = __uint_as_float(hi.w);
             S.nc = cn[k];
@@ -192,7 +165,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
             const uint4* row = reinterpret_cast<const uint4*>(cand_bits + (size_t)i * bw);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (4 * u < bw) { const uint4 v = eager ? e_rb[k][u] : row[u]; S.rb[4 * u] = v.x; S.rb[4 * u + 1] = v.y; S.rb[4 * u + 2] = v.z; S.rb[4 * u + 3] = v.w; }
+                if (4 * u < bw) { const uint4 v = row[u]; S.rb[4 * u] = v.x; S.rb[4 * u + 1] = v.y; S.rb[4 * u + 2] = v.z; S.rb[4 * u + 3] = v.w; }
             }
             const int wlast = i >> 5;                            // only j < i
 #pragma unroll
@@ -288,21 +261,10 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
             }
             lds_barrier();
             uint32_t* t = mask_cur; mask_cur = mask_next; mask_next = t;
-#ifdef LCD_TAIL_TIMING
-            if (tid == 0) g_resolve_timing[6] = (unsigned long long)(sweep + 1);
-#endif
             if (!s_changed_f) break;
             lds_barrier();
         }
     }
-#ifdef LCD_TAIL_TIMING
-    {
-        int na = 0, no = 0;
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) { const int i = tid + k * NT; if (i < q) { na += st[k].nc > 0 || st[k].overflow; no += st[k].overflow; } }
-        atomicAdd(&g_resolve_timing[7], ((unsigned long long)no << 32) | (unsigned long long)na);
-    }
-#endif
     RB_STAMP(3);
     // word prefix sums of the final mask -> ranks of the new words in descriptor order (getNextId() order, :1185): one wavefront
     if (tid < 64) {

@@ -130,7 +130,6 @@ __device__ __forceinline__ void rowpar_body(const RowparArgs& a, int wb, int n_w
             const uint64_t k[2] = {best, second};
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if (a.cb.out_ws) a.cb.out_ws[2 * qo + j] = k[j] == KEY_NONE ? -1 : a.cb.row_wslot[(uint32_t)k[j]];
                 if (k[j] == KEY_NONE) { a.out_row[2 * qo + j] = -1; a.out_word[2 * qo + j] = 0; a.out_dist[2 * qo + j] = -1.0f; }
                 else {
                     const uint32_t r = (uint32_t)k[j];

@@ -90,7 +90,6 @@ struct ResolveArgs {
     const int32_t* knn_word; const float* knn_dist; const float* selfdist; int ld; const uint32_t* cand_bits; int bw;
     int32_t* out_word; int32_t* out_n_new; const int32_t* knn_row; const int32_t* row_wslot; int32_t* out_wslot;
     const uint2* cand_list; const int32_t* cand_cnt;   // CandBits::list / cnt (NULL: only the bit rows exist)
-    const int32_t* knn_wslot = nullptr;                // CandBits::out_ws (NULL: the keys are gathered through knn_row / row_wslot)
     WsRuns new_ws;         // postings keys of the frame's new words (n == 0: new words get no postings)
     int32_t* fail_count;   // reset for the next frame's certificate (saves a memset launch); may be NULL
     RowparArgs rp;         // rp.enabled: the exact redo of rejected queries runs as extra workgroups of the tail launch

@@ -66,8 +66,6 @@ def main():
     print("frame tail phases (us, median over %d frames): resolve %.2f  retire %.2f  frame_words %.2f" % (len(rows), *np.median(rows, axis=0)))
     rr = np.median(np.array(rrows[2:]), axis=0)
     print("  inside the decision loop (us): loads + bit rows %.2f  sweep 0 %.2f  sweeps %.2f  prefix %.2f  output %.2f" % tuple(rr))
-    print("  last frame: %d sweeps; descriptors with same-frame candidates (cumulative over frames): %d, of them beyond four candidates: %d"
-          % (buf[14], buf[15] & 0xFFFFFFFF, buf[15] >> 32))
     eng.close()
 
 
