@@ -18,12 +18,6 @@ __device__ __forceinline__ uint2 gload2(const uint2* p) {
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 
-__device__ __forceinline__ uint4 gload4(const uint4* p) {
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = *(const __attribute__((address_space(1))) u32x4*)p;
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-
 // idf -> Q5.26, round to nearest, saturating
 __device__ __forceinline__ int32_t idf_to_fixed(float idf) {
     float s = idf * 67108864.0f;                        // 2^26, exact scaling
@@ -117,11 +111,11 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            n4[r] = 0; d4[r] = 0;
+            n4[r] = 0; d4[r] = -1;
             if (!o4[r]) continue;
             n4[r] = a.do_register ? atomicAdd(&a.nw[w4[r]], 1u) + 1u : a.nw[w4[r]];   // (a plain read + fire-and-forget add measured slower:
                                                                                           // atomics drop the line from L2, the read then misses)
-            if (a.want_q) d4[r] = a.did[w4[r]] & 0x3FFFFFFF;           // the word's tier word (dense id | mid id) without the sealing kernels' claim marks
+            if (a.want_q) d4[r] = a.did[w4[r]];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -135,10 +129,10 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
                 float idf = 0.0f;
                 if (a.N > 0.0f && nwv > 0u) idf = log10f(__fdiv_rn(a.N, (float)nwv));   // Memory.cpp:2264-2266
                 const int32_t idfq = idf_to_fixed(idf);
-                const int32_t d = tier_dense((uint32_t)d4[r]);
+                const int32_t d = d4[r];
                 a.q_w[u] = w;
                 a.q_idf[u] = idfq;
-                a.q_did[u] = d4[r];                                              // the tier word travels to the scoring kernel as it is
+                a.q_did[u] = d;
                 a.idf_tab[w] = make_uint2(a.stamp, (uint32_t)idfq);
                 if (d >= 0 && idfq != 0) {                                   // "if(logNnw)" (Memory.cpp:2267)
                     const uint32_t j = atomicAdd(&s_misc[1], 1u);

@@ -77,18 +77,17 @@ __device__ __forceinline__ void score_sealed_body(const ScoreArgs& A, int b) {
     constexpr int KW = SCB >= 512 ? 1 : 512 / SCB;                  // frame words per thread in the fused first pass
     constexpr int NI = TF_R / SCB > 0 ? TF_R / SCB : 1;             // signatures whose ni a thread carries
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
-    const uint32_t DM = A.bkt_D[b];
-    const uint32_t D = DM & TF_BKT_D_MASK, M = DM >> TF_BKT_M_SHIFT;
+    const uint32_t D = A.bkt_D[b];
     const uint32_t flags = A.bkt_flags[b];
     const int U = (int)A.q_meta[0];
     const int Ud = (int)A.q_meta[1];
     // ---- stage A: the frame's lists (L2-resident: every workgroup reads the same few KB), ni
-    uint32_t w[KW]; int32_t idf[KW], did[KW], mid[KW]; bool look[KW];
+    uint32_t w[KW]; int32_t idf[KW], did[KW]; bool look[KW];
 #pragma unroll
     for (int u = 0; u < KW; ++u) {
         const int k = tid + u * SCB;
-        w[u] = 0; idf[u] = 0; did[u] = -1; mid[u] = -1;
-        if (k < U) { w[u] = A.q_w[k]; idf[u] = A.q_idf[k]; const uint32_t tv = (uint32_t)A.q_did[k]; did[u] = tier_dense(tv); mid[u] = tier_mid(tv); }
+        w[u] = 0; idf[u] = 0; did[u] = -1;
+        if (k < U) { w[u] = A.q_w[k]; idf[u] = A.q_idf[k]; did[u] = A.q_did[k]; }
     }
     int32_t dj[DR], fj[DR];
 #pragma unroll
@@ -102,20 +101,12 @@ __device__ __forceinline__ void score_sealed_body(const ScoreArgs& A, int b) {
     for (int u = 0; u < NI; ++u) { const int i = tid + u * SCB; ni_v[u] = i < TF_R ? A.slot_ni[first_slot + i] : 0u; }
     // ---- stage B: directory blocks of the sparse words, dense rows
     uint2 blk[KW];
-    uint4 mr0[KW], mr1[KW];                                          // the word's mid row in this bucket (32 bytes), if it has one
 #pragma unroll
     for (int u = 0; u < KW; ++u) {
         const bool dense_here = did[u] >= 0 && (uint32_t)did[u] < D;
-        const bool mid_here = !dense_here && mid[u] >= 0 && (uint32_t)mid[u] < M && idf[u] != 0;
-        // a dense word has sparse postings only for counts > 255, a mid word only when a row of this bucket overflowed
-        look[u] = idf[u] != 0 && w[u] < B.W && (dense_here ? (flags & 1u) != 0u : (mid_here ? (flags & 2u) != 0u : true));
+        look[u] = idf[u] != 0 && w[u] < B.W && (!dense_here || (flags & 1u));   // a dense word has sparse postings only for counts > 255
         blk[u] = make_uint2(0u, 0u);
         if (look[u]) blk[u] = gload2(B.dirb + (w[u] >> 5));
-        mr0[u] = make_uint4(0u, 0u, 0u, 0u); mr1[u] = mr0[u];
-        if (mid_here) {
-            const uint4* row = reinterpret_cast<const uint4*>(B.mid + (size_t)mid[u] * (TF_MID_ROW / 4));
-            mr0[u] = gload4(row); mr1[u] = gload4(row + 1);
-        }
     }
     uint32_t c[DR];
 #pragma unroll
@@ -170,20 +161,6 @@ __device__ __forceinline__ void score_sealed_body(const ScoreArgs& A, int b) {
         if (a2) atomicAdd(&acc[ln4 + 2], (unsigned long long)a2);
         if (a3) atomicAdd(&acc[ln4 + 3], (unsigned long long)a3);
     }
-    // the mid rows: up to 15 {slot, count} entries per word, straight into the accumulators
-#pragma unroll
-    for (int u = 0; u < KW; ++u) {
-        const uint32_t rw[8] = {mr0[u].x, mr0[u].y, mr0[u].z, mr0[u].w, mr1[u].x, mr1[u].y, mr1[u].z, mr1[u].w};
-        const int n = min((int)(rw[0] & 0xFFFFu), TF_MID_CAP);
-        const long long f64 = (long long)idf[u];
-#pragma unroll
-        for (int e = 0; e < TF_MID_CAP; ++e) {
-            if (e < n) {
-                const uint32_t ent = (rw[(e + 1) >> 1] >> (((e + 1) & 1) * 16)) & 0xFFFFu;
-                atomicAdd(&acc[ent & 255u], (unsigned long long)((long long)(int)(ent >> 8) * f64));
-            }
-        }
-    }
     SC_STAMP(2);
     // ---- sparse postings, wavefront by wavefront
 #pragma unroll
@@ -194,21 +171,9 @@ __device__ __forceinline__ void score_sealed_body(const ScoreArgs& A, int b) {
         if (k < U) {
             const uint32_t w2 = A.q_w[k];
             idf2 = A.q_idf[k];
-            const uint32_t tv2 = (uint32_t)A.q_did[k];
-            const int32_t d2 = tier_dense(tv2), m2 = tier_mid(tv2);
+            const int32_t d2 = A.q_did[k];
             const bool dh = d2 >= 0 && (uint32_t)d2 < D;
-            const bool mh = !dh && m2 >= 0 && (uint32_t)m2 < M && idf2 != 0;
-            if (mh) {                                                   // (rare path: one row per thread, loaded and applied on the spot)
-                const uint4* row = reinterpret_cast<const uint4*>(B.mid + (size_t)m2 * (TF_MID_ROW / 4));
-                const uint4 a0 = gload4(row), a1 = gload4(row + 1);
-                const uint32_t rw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                const int n = min((int)(rw[0] & 0xFFFFu), TF_MID_CAP);
-                for (int e = 0; e < n; ++e) {
-                    const uint32_t ent = (rw[(e + 1) >> 1] >> (((e + 1) & 1) * 16)) & 0xFFFFu;
-                    atomicAdd(&acc[ent & 255u], (unsigned long long)((long long)(int)(ent >> 8) * (long long)idf2));
-                }
-            }
-            if (idf2 != 0 && w2 < B.W && (dh ? (flags & 1u) != 0u : (mh ? (flags & 2u) != 0u : true))) {
+            if (idf2 != 0 && w2 < B.W && (!dh || (flags & 1u))) {
                 const uint2 bk = gload2(B.dirb + (w2 >> 5));
                 const uint32_t bit = 1u << (w2 & 31);
                 if (bk.x & bit) {

@@ -45,28 +45,8 @@ constexpr int TF_CNT_BITS = 22;            // posting = slot_local << 22 | count
 constexpr uint32_t TF_CNT_MASK = (1u << TF_CNT_BITS) - 1;
 constexpr int TF_MAX_WORDS = 8192;         // words of one signature / one query frame handled by the 1-workgroup kernels
 constexpr int TF_IDF_SHIFT = 26;           // idf in Q5.26 (|idf| < 32: N up to 1e32)
-constexpr int TF_DENSE_T = 16;             // a word present in >= 16 of a bucket's 256 signatures becomes dense
+constexpr int TF_DENSE_T = 32;             // a word present in >= 32 of a bucket's 256 signatures becomes dense
 constexpr int TF_DENSE_MAX = 4096;         // dense ids (1 MB of rows per bucket at most)
-// MID ROWS: a word seen in >= TF_MID_T signatures of one bucket (and not dense) gets a global mid id; a sealed bucket holds one
-// 32-byte row per mid id known when it was sealed: u16 n (entries attempted) + up to 15 entries {slot_local u8, count u8}.
-// No directory probe, no offset lookup, no second round trip: the row is addressed by (mid id, bucket) like a dense row, at an
-// eighth of its size.  What does not fit (more than 15 signatures -- only once the dense ids ran out -- or a count above 255)
-// stays a sparse posting and sets bit 1 of the bucket's flags, which sends that bucket's mid words through the directory as well.
-constexpr int TF_MID_T = 2;
-constexpr int TF_MID_MAX = 32768;          // mid ids (1 MB of rows per bucket at most)
-constexpr int TF_MID_CAP = 15;             // entries per mid row
-constexpr int TF_MID_ROW = 32;             // bytes per mid row
-// tier word of a wslot (table `did`, copied verbatim into the frame's q_did list): bits 0..12 dense id + 1, bits 13..28 mid id + 1
-// (0 = none), bits 30 / 31 claim marks of the sealing kernels
-constexpr uint32_t TF_TIER_DENSE_MASK = 0x1FFFu;
-constexpr int TF_TIER_MID_SHIFT = 13;
-constexpr uint32_t TF_TIER_MID_MASK = 0xFFFFu;
-constexpr uint32_t TF_TIER_DCLAIM = 1u << 30, TF_TIER_MCLAIM = 1u << 31;
-__host__ __device__ inline int tier_dense(uint32_t v) { return (int)(v & TF_TIER_DENSE_MASK) - 1; }
-__host__ __device__ inline int tier_mid(uint32_t v) { return (int)((v >> TF_TIER_MID_SHIFT) & TF_TIER_MID_MASK) - 1; }
-// per bucket: rows valid when it was sealed, bkt_D[b] = D | M << 13
-constexpr uint32_t TF_BKT_D_MASK = 0x1FFFu;
-constexpr int TF_BKT_M_SHIFT = 13;
 
 // one bucket as the kernels see it
 struct BucketDev {
@@ -79,8 +59,7 @@ struct BucketDev {
     uint32_t W;                // wslots covered by dirb
     uint32_t D_alloc;          // dense rows allocated
     uint32_t state;            // 0 = open, 1 = sealed, 2 = dead (every signature retired, memory released)
-    uint32_t M_alloc;          // mid rows allocated
-    const uint32_t* mid;       // sealed: [M_alloc][8] mid rows
+    uint32_t pad;
 };
 
 // one sealing job (kernel argument, by value: no staging buffer to keep alive)
@@ -88,7 +67,6 @@ struct SealJob {
     int bucket;
     const uint32_t* coo_w; const uint32_t* coo_pc; const uint32_t* ne;   // log and its length (device counter)
     uint8_t* dense; uint32_t D_alloc;
-    uint32_t* mid; uint32_t M_alloc;
     uint2* dirb; uint32_t* sp_off; uint32_t* sp_ent;
     uint32_t* cntw;            // [W] scratch, zeroed
     uint32_t* tile_sums;       // [2 * tiles] scratch
@@ -102,8 +80,8 @@ struct Bucket {
     int live = 0;             // live signatures among them
     int64_t ub_entries = 0;   // host upper bound of log entries (device appends without telling the host)
     DevBuf coo_w, coo_pc, sealed;
-    size_t off_mid = 0, off_dirb = 0, off_spoff = 0, off_spent = 0;   // byte offsets inside `sealed` (dense rows at 0)
-    uint32_t W = 0, D_alloc = 0, M_alloc = 0;
+    size_t off_dirb = 0, off_spoff = 0, off_spent = 0;   // byte offsets inside `sealed` (dense rows at 0)
+    uint32_t W = 0, D_alloc = 0;
 };
 
 // arguments of the addNewWords decision loop (resolve_body.cuh) when it is fused into the frame-words launch
@@ -173,7 +151,7 @@ struct Tfidf {
     // per slot
     DevBuf slot_sig, slot_ni, slot_begin, slot_cnt;
     // per wslot
-    DevBuf nw, did;                      // references, tier word (dense / mid id, 0: none)
+    DevBuf nw, did;                      // references, dense id (-1: none)
     DevBuf idf_tab;                      // {stamp, idf Q5.26} of the words of the current frame (valid iff stamp matches)
     uint32_t stamp = 0;
     // word id -> wslot: host vector (ids are small consecutive integers in the reference, ++_lastWordId) mirrored on the device
@@ -198,7 +176,7 @@ struct Tfidf {
     int score_block = 512;               // threads per scoring workgroup (256 / 512 / 1024; lcd_set_option "score_block")
     int q_n_ub = 0;                      // word count of the last frame handed to frame_words (upper bound of its unique words)
     BufPool pool;
-    DevBuf n_dense;                      // [0] dense ids, [1] mid ids handed out (device counters)
+    DevBuf n_dense;                      // [0] number of dense ids handed out (device counter)
     uint32_t* h_n_dense = nullptr;       // pinned host mirror written by the sealing kernels (read without synchronising: stale is fine)
     DevBuf seal_cntw, seal_tiles;        // sealing scratch
     // per frame

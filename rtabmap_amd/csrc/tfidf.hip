@@ -114,16 +114,13 @@ __global__ __launch_bounds__(256) void score_work_kernel(ScoreArgs A, const uint
     if (b < A.n_closed) {
         const BucketDev B = A.tab[b];
         if (B.state != 1u) return;
-        const uint32_t DM = A.bkt_D[b], D = DM & TF_BKT_D_MASK, M = DM >> TF_BKT_M_SHIFT, flags = A.bkt_flags[b];
+        const uint32_t D = A.bkt_D[b], flags = A.bkt_flags[b];
         for (int j = tid; j < Ud; j += 256) if ((uint32_t)A.qd_did[j] < D) c0 += TF_R;
         for (int k = tid; k < U; k += 256) {
             const uint32_t w = A.q_w[k];
-            const uint32_t tv = (uint32_t)A.q_did[k];
-            const int32_t d = tier_dense(tv), m = tier_mid(tv);
+            const int32_t d = A.q_did[k];
             const bool dense_here = d >= 0 && (uint32_t)d < D;
-            const bool mid_here = !dense_here && m >= 0 && (uint32_t)m < M;
-            if (mid_here && A.q_idf[k] != 0) c0 += TF_MID_ROW;
-            if (A.q_idf[k] != 0 && w < B.W && (dense_here ? (flags & 1u) != 0u : (mid_here ? (flags & 2u) != 0u : true))) {
+            if (A.q_idf[k] != 0 && w < B.W && (!dense_here || (flags & 1u))) {
                 c2 += 1;
                 const uint2 blk = B.dirb[w >> 5];
                 const uint32_t bit = 1u << (w & 31);
@@ -170,67 +167,35 @@ __global__ __launch_bounds__(SEAL_BLOCK) void seal_count_kernel(const SealJob* _
     const uint32_t ne = min(J.ne[0], J.ent_cap);
     for (uint32_t e = blockIdx.x * SEAL_BLOCK + threadIdx.x; e < ne; e += gridDim.x * SEAL_BLOCK) atomicAdd(&J.cntw[J.coo_w[e]], 1u);
 }
-// (2) words that reach TF_DENSE_T postings in one bucket get a dense id, the others with at least TF_MID_T a mid id (once each;
-// several buckets of a batch may race for a word: the claim bit decides)
-__global__ __launch_bounds__(SEAL_BLOCK) void seal_densify_kernel(const SealJob* __restrict__ jobs, SealJob job1, uint32_t* __restrict__ tier,
-                                                                  uint32_t* __restrict__ n_ids) {
+// (2) words that reach TF_DENSE_T postings in one bucket get a dense id (once; several buckets of a batch may race for a word)
+__global__ __launch_bounds__(SEAL_BLOCK) void seal_densify_kernel(const SealJob* __restrict__ jobs, SealJob job1, int32_t* __restrict__ did,
+                                                                  uint32_t* __restrict__ n_dense) {
     SEAL_JOB();
     for (uint32_t w = blockIdx.x * SEAL_BLOCK + threadIdx.x; w < J.W; w += gridDim.x * SEAL_BLOCK) {
-        const uint32_t c = J.cntw[w];
-        if (c < (uint32_t)TF_MID_T) continue;
-        const uint32_t v = tier[w];
-        if (c >= (uint32_t)TF_DENSE_T) {
-            if (v & (TF_TIER_DENSE_MASK | TF_TIER_DCLAIM)) continue;
-            if (__hip_atomic_load(n_ids, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)TF_DENSE_MAX) continue;
-            if (atomicOr(&tier[w], TF_TIER_DCLAIM) & TF_TIER_DCLAIM) continue;            // another bucket of the batch claimed it
-            const uint32_t id = atomicAdd(n_ids, 1u);
-            if (id < (uint32_t)TF_DENSE_MAX) atomicOr(&tier[w], id + 1u);
-            continue;
-        }
-        if (v & ((TF_TIER_MID_MASK << TF_TIER_MID_SHIFT) | TF_TIER_MCLAIM | TF_TIER_DENSE_MASK)) continue;   // has a mid id, or is dense already
-        if (__hip_atomic_load(n_ids + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)TF_MID_MAX) continue;
-        if (atomicOr(&tier[w], TF_TIER_MCLAIM) & TF_TIER_MCLAIM) continue;
-        const uint32_t id = atomicAdd(n_ids + 1, 1u);
-        if (id < (uint32_t)TF_MID_MAX) atomicOr(&tier[w], (id + 1u) << TF_TIER_MID_SHIFT);
+        if (J.cntw[w] < (uint32_t)TF_DENSE_T || did[w] != -1) continue;
+        if (__hip_atomic_load(n_dense, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)TF_DENSE_MAX) continue;
+        if (atomicCAS(&did[w], -1, -2) != -1) continue;                    // another bucket of the batch claimed it
+        const uint32_t id = atomicAdd(n_dense, 1u);
+        did[w] = id < (uint32_t)TF_DENSE_MAX ? (int32_t)id : -1;
     }
 }
-// (3) dense cells and mid rows are written (a posting that went into a mid row is struck from the log: coo_pc is released after
-// sealing anyway), the others stay counted in cntw (= sparse postings per word from here on)
-constexpr uint32_t TF_PC_CONSUMED = 0xFFFFFFFFu;
-__global__ __launch_bounds__(SEAL_BLOCK) void seal_classify_kernel(const SealJob* __restrict__ jobs, SealJob job1, const uint32_t* __restrict__ tier,
-                                                                   const uint32_t* __restrict__ n_ids, uint32_t* __restrict__ bkt_D,
-                                                                   uint32_t* __restrict__ bkt_flags, uint32_t* __restrict__ h_n_ids) {
+// (3) dense cells are written, the others stay counted in cntw (= sparse postings per word from here on)
+__global__ __launch_bounds__(SEAL_BLOCK) void seal_classify_kernel(const SealJob* __restrict__ jobs, SealJob job1, const int32_t* __restrict__ did,
+                                                                   const uint32_t* __restrict__ n_dense, uint32_t* __restrict__ bkt_D,
+                                                                   uint32_t* __restrict__ bkt_flags, uint32_t* __restrict__ h_n_dense) {
     SEAL_JOB();
-    const uint32_t nd = min(n_ids[0], (uint32_t)TF_DENSE_MAX), nm = min(n_ids[1], (uint32_t)TF_MID_MAX);
-    const uint32_t D = min(nd, J.D_alloc), M = min(nm, J.M_alloc);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        bkt_D[J.bucket] = D | (M << TF_BKT_M_SHIFT);
-        if (h_n_ids && blockIdx.y == 0) { h_n_ids[0] = nd; h_n_ids[1] = nm; }
-    }
+    const uint32_t nd = min(n_dense[0], (uint32_t)TF_DENSE_MAX);
+    const uint32_t D = min(nd, J.D_alloc);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { bkt_D[J.bucket] = D; if (h_n_dense && blockIdx.y == 0) h_n_dense[0] = nd; }
     const uint32_t ne = min(J.ne[0], J.ent_cap);
-    uint32_t* pcw = const_cast<uint32_t*>(J.coo_pc);
     for (uint32_t e = blockIdx.x * SEAL_BLOCK + threadIdx.x; e < ne; e += gridDim.x * SEAL_BLOCK) {
         const uint32_t w = J.coo_w[e], pc = J.coo_pc[e];
-        const uint32_t tv = tier[w];
-        const int32_t d = tier_dense(tv), m = tier_mid(tv);
+        const int32_t d = did[w];
+        if (d < 0 || (uint32_t)d >= D) continue;
         const uint32_t cnt = pc & TF_CNT_MASK, sl = pc >> TF_CNT_BITS;
-        if (d >= 0 && (uint32_t)d < D) {
-            J.dense[(size_t)d * TF_R + sl] = (uint8_t)min(cnt, 255u);
-            if (cnt <= 255u) atomicSub(&J.cntw[w], 1u);
-            else atomicOr(&bkt_flags[J.bucket], 1u);                     // the excess stays a sparse posting
-        } else if (m >= 0 && (uint32_t)m < M) {
-            uint32_t* row = J.mid + (size_t)m * (TF_MID_ROW / 4);
-            bool placed = false;
-            if (cnt <= 255u) {
-                const uint32_t pos = atomicAdd(row, 1u) & 0xFFFFu;           // the low half of the first dword is the row's counter
-                if (pos < (uint32_t)TF_MID_CAP) {
-                    reinterpret_cast<uint16_t*>(row)[1 + pos] = (uint16_t)(sl | (cnt << 8));
-                    placed = true;
-                }
-            }
-            if (placed) { atomicSub(&J.cntw[w], 1u); pcw[e] = TF_PC_CONSUMED; }
-            else atomicOr(&bkt_flags[J.bucket], 2u);                     // stays a sparse posting: this bucket's mid words use the directory too
-        }
+        J.dense[(size_t)d * TF_R + sl] = (uint8_t)min(cnt, 255u);
+        if (cnt <= 255u) atomicSub(&J.cntw[w], 1u);
+        else atomicOr(&bkt_flags[J.bucket], 1u);                         // the excess stays a sparse posting
     }
 }
 // (4) per tile of SEAL_TILE wslots: number of present words and of sparse postings
@@ -277,16 +242,15 @@ __global__ __launch_bounds__(SEAL_BLOCK) void seal_scan_kernel(const SealJob* __
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) J.sp_off[base_p + tot_p] = base_a + tot_a;   // end of the last segment
 }
 // (6) sparse postings into their segments (cntw counts down: no second cursor array)
-__global__ __launch_bounds__(SEAL_BLOCK) void seal_scatter_kernel(const SealJob* __restrict__ jobs, SealJob job1, const uint32_t* __restrict__ tier,
+__global__ __launch_bounds__(SEAL_BLOCK) void seal_scatter_kernel(const SealJob* __restrict__ jobs, SealJob job1, const int32_t* __restrict__ did,
                                                                   const uint32_t* __restrict__ bkt_D) {
     SEAL_JOB();
-    const uint32_t D = bkt_D[J.bucket] & TF_BKT_D_MASK;
+    const uint32_t D = bkt_D[J.bucket];
     const uint32_t ne = min(J.ne[0], J.ent_cap);
     for (uint32_t e = blockIdx.x * SEAL_BLOCK + threadIdx.x; e < ne; e += gridDim.x * SEAL_BLOCK) {
         const uint32_t w = J.coo_w[e];
         uint32_t pc = J.coo_pc[e];
-        if (pc == TF_PC_CONSUMED) continue;                               // went into a mid row
-        const int32_t d = tier_dense(tier[w]);
+        const int32_t d = did[w];
         if (d >= 0 && (uint32_t)d < D) {
             const uint32_t cnt = pc & TF_CNT_MASK;
             if (cnt <= 255u) continue;
@@ -310,13 +274,13 @@ __global__ void retire_kernel(long long slot, const uint32_t* __restrict__ coo_w
 }
 
 // the words left the dictionary: a wslot may be handed out again only if nothing references it (ok[i] tells the host)
-__global__ void wslot_release_kernel(const int32_t* __restrict__ ws, int n, const uint32_t* __restrict__ nw, uint32_t* __restrict__ did,
+__global__ void wslot_release_kernel(const int32_t* __restrict__ ws, int n, const uint32_t* __restrict__ nw, int32_t* __restrict__ did,
                                      uint2* __restrict__ idf_tab, uint8_t* __restrict__ ok) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int32_t w = ws[i];
     const bool free_now = nw[w] == 0u;
-    if (free_now) { did[w] = 0u; idf_tab[w] = make_uint2(0u, 0u); }      // the key's next word starts without a dense / mid id
+    if (free_now) { did[w] = -1; idf_tab[w] = make_uint2(0u, 0u); }
     ok[i] = free_now ? 1 : 0;
 }
 // table[pairs[2i]] = pairs[2i + 1]
@@ -467,7 +431,7 @@ hipError_t Tfidf::init(hipStream_t s, int64_t* bytes, int64_t sig_capacity, int6
     TF_TRY(n_dense.reserve(64, 0, stream, bytes_device));
     TF_TRY(hipMemsetAsync(n_dense.p, 0, 64, stream));
     TF_TRY(hipHostMalloc((void**)&h_n_dense, 64, hipHostMallocDefault));
-    h_n_dense[0] = 0; h_n_dense[1] = 0;
+    h_n_dense[0] = 0;
     TF_TRY(set_max_lds(reinterpret_cast<const void*>(&frame_words_kernel)));
     TF_TRY(set_max_lds(reinterpret_cast<const void*>(&frame_tail_kernel)));
     TF_TRY(set_max_lds(reinterpret_cast<const void*>(&bulk_register_kernel)));
@@ -498,7 +462,7 @@ hipError_t Tfidf::ensure_slots(int64_t n) {
 
 hipError_t Tfidf::ensure_wslots(int32_t n) {
     TF_TRY(grow_zeroed(nw, (size_t)n * 4, stream, bytes_device));
-    TF_TRY(grow_zeroed(did, (size_t)n * 4, stream, bytes_device));
+    TF_TRY(grow_filled(did, (size_t)n * 4, 0xFF, stream, bytes_device));
     TF_TRY(grow_zeroed(idf_tab, (size_t)n * 8, stream, bytes_device));
     return hipSuccess;
 }
@@ -622,7 +586,7 @@ hipError_t Tfidf::release_wslots(const std::vector<int32_t>& ws, const std::vect
     std::memcpy(p_ws, ws.data(), m * 4);
     std::memset(p_ok, 0, m);
     r.ok = p_ok;
-    wslot_release_kernel<<<(unsigned)((m + 255) / 256), 256, 0, stream>>>(p_ws, (int)m, nw.as<uint32_t>(), did.as<uint32_t>(),
+    wslot_release_kernel<<<(unsigned)((m + 255) / 256), 256, 0, stream>>>(p_ws, (int)m, nw.as<uint32_t>(), did.as<int32_t>(),
                                                                            idf_tab.as<uint2>(), p_ok);
     TF_TRY(hipGetLastError());
     TF_TRY(hipEventRecord(r.blk.ev, stream));
@@ -699,8 +663,7 @@ hipError_t Tfidf::set_bucket(int b) {
     d.dirb = k.sealed.p ? (const uint2*)((const char*)k.sealed.p + k.off_dirb) : nullptr;
     d.sp_off = k.sealed.p ? (const uint32_t*)((const char*)k.sealed.p + k.off_spoff) : nullptr;
     d.sp_ent = k.sealed.p ? (const uint32_t*)((const char*)k.sealed.p + k.off_spent) : nullptr;
-    d.W = k.W; d.D_alloc = k.D_alloc; d.state = (uint32_t)k.state; d.M_alloc = k.M_alloc;
-    d.mid = k.sealed.p ? (const uint32_t*)((const char*)k.sealed.p + k.off_mid) : nullptr;
+    d.W = k.W; d.D_alloc = k.D_alloc; d.state = (uint32_t)k.state; d.pad = 0;
     set_bucket_kernel<<<1, 1, 0, stream>>>(bkt_tab.as<BucketDev>(), b, d);
     return hipGetLastError();
 }
@@ -751,7 +714,7 @@ hipError_t Tfidf::seal_batch(const std::vector<int>& ids, bool bulk) {
             J.coo_w = k.coo_w.as<uint32_t>(); J.coo_pc = k.coo_pc.as<uint32_t>(); J.ne = bkt_ne.as<uint32_t>() + J.bucket;
             J.cntw = seal_cntw.as<uint32_t>() + j * (size_t)W; J.tile_sums = seal_tiles.as<uint32_t>() + j * (size_t)tiles * 2;
             J.W = W; J.ent_cap = (uint32_t)std::max<int64_t>(k.ub_entries, 1);
-            J.dense = nullptr; J.D_alloc = 0; J.mid = nullptr; J.M_alloc = 0; J.dirb = nullptr; J.sp_off = nullptr; J.sp_ent = nullptr;
+            J.dense = nullptr; J.D_alloc = 0; J.dirb = nullptr; J.sp_off = nullptr; J.sp_ent = nullptr;
             max_e = std::max(max_e, J.ent_cap);
         }
         const SealJob* dj = nullptr;
@@ -767,51 +730,46 @@ hipError_t Tfidf::seal_batch(const std::vector<int>& ids, bool bulk) {
         const dim3 ge((unsigned)std::min<uint32_t>((max_e + SEAL_BLOCK - 1) / SEAL_BLOCK, 512), (unsigned)nb);
         const dim3 gw((unsigned)std::min<uint32_t>((W + SEAL_BLOCK - 1) / SEAL_BLOCK + 1, 512), (unsigned)nb);
         seal_count_kernel<<<ge, SEAL_BLOCK, 0, stream>>>(dj, jobs[0]);
-        seal_densify_kernel<<<gw, SEAL_BLOCK, 0, stream>>>(dj, jobs[0], did.as<uint32_t>(), n_dense.as<uint32_t>());
+        seal_densify_kernel<<<gw, SEAL_BLOCK, 0, stream>>>(dj, jobs[0], did.as<int32_t>(), n_dense.as<uint32_t>());
         TF_TRY(hipGetLastError());
-        uint32_t D_alloc, M_alloc;
+        uint32_t D_alloc;
         if (bulk) {
             if (!have_dense_count) {
-                uint32_t nd[2] = {0, 0};
-                TF_TRY(hipMemcpyAsync(nd, n_dense.p, 8, hipMemcpyDeviceToHost, stream));
+                uint32_t nd = 0;
+                TF_TRY(hipMemcpyAsync(&nd, n_dense.p, 4, hipMemcpyDeviceToHost, stream));
                 TF_TRY(hipStreamSynchronize(stream));
-                h_n_dense[0] = std::min<uint32_t>(nd[0], TF_DENSE_MAX);
-                h_n_dense[1] = std::min<uint32_t>(nd[1], TF_MID_MAX);
+                h_n_dense[0] = std::min<uint32_t>(nd, TF_DENSE_MAX);
                 have_dense_count = true;
             }
             D_alloc = std::min<uint32_t>(TF_DENSE_MAX, h_n_dense[0] + 32);
-            M_alloc = std::min<uint32_t>(TF_MID_MAX, h_n_dense[1] + 256);
         } else {
-            const uint32_t hv = *(volatile uint32_t*)h_n_dense, hm = *(volatile uint32_t*)(h_n_dense + 1);
+            const uint32_t hv = *(volatile uint32_t*)h_n_dense;
             D_alloc = std::min<uint32_t>(TF_DENSE_MAX, hv + (hv ? 128u : 1024u));
-            M_alloc = std::min<uint32_t>(TF_MID_MAX, hm + (hm ? 1024u : 8192u));
         }
         for (size_t j = 0; j < nb; ++j) {
             Bucket& k = buckets[ids[i0 + j]];
             SealJob& J = jobs[j];
             const size_t a256 = 255;
             const size_t sz_dense = ((size_t)D_alloc * TF_R + a256) & ~a256;
-            const size_t sz_mid = ((size_t)M_alloc * TF_MID_ROW + a256) & ~a256;
             const size_t sz_dirb = ((((size_t)W + 31) / 32) * 8 + a256) & ~a256;
             const size_t sz_off = ((std::min<size_t>(J.ent_cap, W) + 1) * 4 + a256) & ~a256;
             const size_t sz_ent = ((size_t)J.ent_cap * 4 + a256) & ~a256;
-            TF_TRY(pool.get(sz_dense + sz_mid + sz_dirb + sz_off + sz_ent, &k.sealed, bytes_device));
-            k.off_mid = sz_dense; k.off_dirb = sz_dense + sz_mid; k.off_spoff = k.off_dirb + sz_dirb; k.off_spent = k.off_spoff + sz_off;
-            k.W = W; k.D_alloc = D_alloc; k.M_alloc = M_alloc;
+            TF_TRY(pool.get(sz_dense + sz_dirb + sz_off + sz_ent, &k.sealed, bytes_device));
+            k.off_dirb = sz_dense; k.off_spoff = sz_dense + sz_dirb; k.off_spent = sz_dense + sz_dirb + sz_off;
+            k.W = W; k.D_alloc = D_alloc;
             J.dense = k.sealed.as<uint8_t>(); J.D_alloc = D_alloc;
-            J.mid = (uint32_t*)((char*)k.sealed.p + k.off_mid); J.M_alloc = M_alloc;
             J.dirb = (uint2*)((char*)k.sealed.p + k.off_dirb);
             J.sp_off = (uint32_t*)((char*)k.sealed.p + k.off_spoff);
             J.sp_ent = (uint32_t*)((char*)k.sealed.p + k.off_spent);
-            if (sz_dense + sz_mid) TF_TRY(hipMemsetAsync(J.dense, 0, sz_dense + sz_mid, stream));
+            if (sz_dense) TF_TRY(hipMemsetAsync(J.dense, 0, sz_dense, stream));
         }
         TF_TRY(upload_jobs());
         const dim3 gt((unsigned)tiles, (unsigned)nb);
-        seal_classify_kernel<<<ge, SEAL_BLOCK, 0, stream>>>(dj, jobs[0], did.as<uint32_t>(), n_dense.as<uint32_t>(), bkt_D.as<uint32_t>(),
+        seal_classify_kernel<<<ge, SEAL_BLOCK, 0, stream>>>(dj, jobs[0], did.as<int32_t>(), n_dense.as<uint32_t>(), bkt_D.as<uint32_t>(),
                                                            bkt_flags.as<uint32_t>(), h_n_dense);
         seal_tile_kernel<<<gt, SEAL_BLOCK, 0, stream>>>(dj, jobs[0]);
         seal_scan_kernel<<<gt, SEAL_BLOCK, 0, stream>>>(dj, jobs[0]);
-        seal_scatter_kernel<<<ge, SEAL_BLOCK, 0, stream>>>(dj, jobs[0], did.as<uint32_t>(), bkt_D.as<uint32_t>());
+        seal_scatter_kernel<<<ge, SEAL_BLOCK, 0, stream>>>(dj, jobs[0], did.as<int32_t>(), bkt_D.as<uint32_t>());
         TF_TRY(hipGetLastError());
         for (size_t j = 0; j < nb; ++j) {
             Bucket& k = buckets[ids[i0 + j]];
