@@ -1266,6 +1266,7 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
 extern "C" int lcd_debug_tail_timing_pipe(unsigned long long* out) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lcd::g_tail_timing), 64) != hipSuccess) return -2;
-    return (int)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(lcd::g_resolve_timing), 64);
+    if (hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(lcd::g_resolve_timing), 64) != hipSuccess) return -3;
+    return (int)hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(lcd::g_sweep_timing), 256);
 }
 #endif

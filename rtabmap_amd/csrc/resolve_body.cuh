@@ -13,8 +13,11 @@ constexpr int LCD_Q_NEW_WORDS_COMPARED = 2;
 #ifdef LCD_TAIL_TIMING   // timing experiment only: 100 MHz stamps inside the fast decision loop
 __device__ unsigned long long g_resolve_timing[8];
 #define RB_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_resolve_timing[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_sweep_timing[32];                    // [wave][point]: per-wave stamps inside the first sweep, no barrier added
+#define SW_STAMP(p) do { if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 4 && sweep == 0) g_sweep_timing[(threadIdx.x >> 6) * 8 + (p)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define RB_STAMP(i) do { } while (0)
+#define SW_STAMP(p) do { } while (0)
 #endif
 
 // workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains the wave's outstanding GLOBAL loads
@@ -197,8 +200,19 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
     RB_STAMP(2);
     if (together) {
         for (int sweep = 0; sweep <= q; ++sweep) {
+            SW_STAMP(0);
             if (tid == 0) s_changed_f = 0;
             lds_barrier();
+            SW_STAMP(1);
+            // the new-word mask of this sweep in registers (frames of up to 512 descriptors): the bit-row path below then ANDs registers
+            // -- sixteen dependent LDS round trips per descriptor with a long candidate list cost a wave ~2 us per sweep
+            uint32_t mreg[16];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                                     // mw is even: 8-byte reads are always aligned
+                uint2 v = make_uint2(0u, 0u);
+                if (bw <= 16 && 2 * u < mw) v = *reinterpret_cast<const uint2*>(mask_cur + 2 * u);
+                mreg[2 * u] = v.x; mreg[2 * u + 1] = v.y;
+            }
 #pragma unroll
             for (int k = 0; k < KPT; ++k) {
                 const int i = tid + k * NT;
@@ -220,7 +234,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
                     } else if (bw <= 16) {
 #pragma unroll
                         for (int w = 0; w < 16; ++w) {
-                            uint32_t m = w < mw ? (S.rb[w] & mask_cur[w]) : 0u;
+                            uint32_t m = S.rb[w] & mreg[w];
                             while (m) {
                                 const int j = (w << 5) + __builtin_ctz(m);
                                 m &= m - 1;
@@ -250,6 +264,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
                     S.reject = n < 2 || c0.d > nndr * c1.d;
                     S.win = n > 0 ? c0.id : 0;
                 }
+                SW_STAMP(2 + k);
                 if (i < qpad) {
                     const unsigned long long bal = __ballot(S.reject);
                     if (lane == 0) {
@@ -259,7 +274,9 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
                     }
                 }
             }
+            SW_STAMP(6);
             lds_barrier();
+            SW_STAMP(7);
             uint32_t* t = mask_cur; mask_cur = mask_next; mask_next = t;
             if (!s_changed_f) break;
             lds_barrier();

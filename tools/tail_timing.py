@@ -49,7 +49,7 @@ def main():
     if hasattr(lib, "lcd_debug_score_timing"):
         return score_timing(lib, eng, vocab, words, n_sig, q, d_words, d_like, cap)
     lib.lcd_debug_tail_timing.restype = ctypes.c_int
-    buf = (ctypes.c_ulonglong * 16)()
+    buf = (ctypes.c_ulonglong * 64)()
     rows, rrows = [], []
     for i in range(12):
         f = torch.from_numpy(synth.frame_from_signature(vocab, words[i * 11], seed=i)).cuda()
@@ -64,6 +64,11 @@ def main():
         rrows.append(np.diff(np.array(buf[8:14], dtype=np.float64) / 100.0))
     rows = np.array(rows[2:])
     print("frame tail phases (us, median over %d frames): resolve %.2f  retire %.2f  frame_words %.2f" % (len(rows), *np.median(rows, axis=0)))
+    if os.environ.get("PIPE"):
+        sw = np.array(buf[16:48], dtype=np.float64).reshape(4, 8) / 100.0
+        print("  first sweep, per wave (us from the wave's entry): after barrier | descriptor 0..3 done | before 2nd barrier | after")
+        for w in range(4):
+            print("    wave %d: %s" % (w, "  ".join("%.2f" % (x - sw[w, 0]) for x in sw[w, 1:])))
     rr = np.median(np.array(rrows[2:]), axis=0)
     print("  inside the decision loop (us): loads + bit rows %.2f  sweep 0 %.2f  sweeps %.2f  prefix %.2f  output %.2f" % tuple(rr))
     eng.close()
