@@ -42,7 +42,8 @@ __device__ __forceinline__ float fixed_to_like(long long acc, uint32_t ni) {
 // log position is read at the start and written back at the end instead of being reserved with a returning atomic in the middle.
 // src_lds: the word slots in LDS (left there by the decision loop of the same kernel) instead of a.src.
 template <int NT, bool SOLE>
-__device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs& a, const int32_t* src_lds = nullptr) {
+__device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs& a, const int32_t* src_lds = nullptr, bool have_ne0 = false,
+                                                 uint32_t ne0 = 0u /* thread 0: the log position, read by the caller well ahead of time */) {
     const int H = a.H;
     uint32_t* tkey = fw_smem;            // [H] 0xFFFFFFFF = empty
     uint32_t* tcnt = fw_smem + H;        // [H]
@@ -50,8 +51,8 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
     uint32_t* s_misc = grp + H / 64 + 1; // [0] log base, [1] dense list length
     const int tid = threadIdx.x;
     for (int i = tid; i < H; i += NT) { tkey[i] = 0xFFFFFFFFu; tcnt[i] = 0u; }
-    if (tid == 0) { s_misc[0] = (SOLE && a.do_register) ? a.ne_counter[0] : 0u; s_misc[1] = 0u; }
-    __syncthreads();
+    if (tid == 0) { s_misc[0] = (SOLE && a.do_register) ? (have_ne0 ? ne0 : a.ne_counter[0]) : 0u; s_misc[1] = 0u; }
+    if (have_ne0) lds_barrier(); else __syncthreads();
     for (int i = tid; i < a.n; i += NT) {
         int32_t ws = src_lds ? src_lds[i] : a.src[i];
         if (a.xlate) ws = (ws > 0 && (long long)ws < a.xlate_n) ? a.xlate[ws] : -1;
@@ -64,7 +65,7 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
             h = (h + 1) & (uint32_t)(H - 1);
         }
     }
-    __syncthreads();
+    lds_barrier();
     // compact the occupied table entries: ballot per 64-entry group, group offsets scanned by one thread
     const int ng = H / 64;
     for (int i0 = 0; i0 < H; i0 += NT) {
@@ -73,7 +74,7 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
         const unsigned long long bal = __ballot(occ);
         if ((tid & 63) == 0 && i < H) grp[i >> 6] = (uint32_t)__popcll(bal);
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < 64) {                                     // exclusive scan of the group counts by one wavefront
         uint32_t run = 0;
         for (int g0 = 0; g0 < ng; g0 += 64) {
@@ -142,7 +143,7 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
             }
         }
     }
-    __syncthreads();
+    lds_barrier();                                      // only s_misc[1] (LDS) is awaited: the stores above need no acknowledgement here
     if (tid == 0) {
         if (a.want_q) { a.q_meta[0] = U; a.q_meta[1] = s_misc[1]; }
         if (a.do_register) {
@@ -189,6 +190,10 @@ __device__ __forceinline__ void frame_tail_body(uint32_t* ft_dyn_smem, const Res
         }
         __syncthreads();
     }
+    // the log position of the open bucket is needed by the registration at the very end: requested now, a whole decision loop ahead
+    uint32_t ne0 = 0u;
+    const bool have_ne0 = a.do_register && a.ne_counter != nullptr;
+    if (threadIdx.x == 0 && have_ne0) ne0 = gload(a.ne_counter);
     FT_STAMP(0);
     // frames of up to 1024 descriptors: the register-resident decision loop, its result handed to the registration through LDS
     constexpr int KPT = 1024 / NT;                     // descriptors per thread of the register-resident loop: frames of up to 1024
@@ -203,7 +208,7 @@ __device__ __forceinline__ void frame_tail_body(uint32_t* ft_dyn_smem, const Res
     retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
     __syncthreads();      // out_wslot (global or LDS, written by this workgroup) and the LDS region are handed over
     FT_STAMP(2);
-    frame_words_body<NT, true>(ft_dyn_smem, a, lds_ws);
+    frame_words_body<NT, true>(ft_dyn_smem, a, lds_ws, have_ne0, ne0);
     FT_STAMP(3);
 }
 
