@@ -47,7 +47,8 @@ struct Scal {
 };
 
 __device__ __forceinline__ size_t tile_at(long long c, int k, int K) { return ((size_t)(c >> 3) * K + k) * TILE + (size_t)(c & 7); }
-__device__ __forceinline__ bool in_set(long long s, long long n_cons, const int32_t* __restrict__ slot_sig) { return s < n_cons && slot_sig[s] != 0; }
+// slot_sig == NULL: every slot below n_cons takes part (a plain likelihood vector, lcd_adjust_likelihood)
+__device__ __forceinline__ bool in_set(long long s, long long n_cons, const int32_t* __restrict__ slot_sig) { return s < n_cons && (slot_sig == nullptr || slot_sig[s] != 0); }
 
 __device__ __forceinline__ double shfl_xor_d(double v, int m) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(v);

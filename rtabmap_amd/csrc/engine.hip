@@ -729,6 +729,15 @@ int lcd_likelihood(lcd_engine* h, const int32_t* query_word_ids, int nq, const i
     return download(h, out, d_out, (size_t)n_ids * 4, h->h_out);
 }
 
+// Rtabmap::adjustLikelihood on a device vector whose entry 0 is the virtual place, in place: the decision stage's two passes
+// (bayes.hip) with every entry taking part
+static int adjust_vector(lcd_engine* h, float* d_L, int n, float ratio) {
+    DecideArgs d;
+    d.like = d_L + 1; d.ratio = ratio; d.adj_out = d_L;
+    LCD_HIP(h, h->bayes.decide(d, nullptr, (int64_t)n - 1, (int64_t)n - 1));
+    return LCD_OK;
+}
+
 int lcd_adjust_likelihood(lcd_engine* h, float* likelihood, int n, float virtual_place_ratio) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
@@ -738,7 +747,7 @@ int lcd_adjust_likelihood(lcd_engine* h, float* likelihood, int n, float virtual
     LCD_HIP(h, h->h_in.reserve((size_t)n * 4));
     std::memcpy(h->h_in.p, likelihood, (size_t)n * 4);
     LCD_HIP(h, hipMemcpyAsync(h->d_like.p, h->h_in.p, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    LCD_HIP(h, launch_adjust_likelihood(h->d_like.as<float>(), n, virtual_place_ratio, h->stream));
+    { int rc = adjust_vector(h, h->d_like.as<float>(), n, virtual_place_ratio); if (rc) return rc; }
     return download(h, likelihood, h->d_like.p, (size_t)n * 4, h->h_out);
 }
 
@@ -747,8 +756,7 @@ int lcd_adjust_likelihood_dev(lcd_engine* h, float* d_likelihood, int n, float v
     LCD_DEV(h);
     if (n < 0 || (n > 0 && !d_likelihood)) return h->fail(LCD_ERR_INVALID, "lcd_adjust_likelihood_dev: null input");
     if (n == 0) return LCD_OK;
-    LCD_HIP(h, launch_adjust_likelihood(d_likelihood, n, virtual_place_ratio, h->stream));
-    return LCD_OK;
+    return adjust_vector(h, d_likelihood, n, virtual_place_ratio);
 }
 
 // ------------------------------------------------------------------------------------------------ device-resident frame

@@ -243,7 +243,5 @@ struct Tfidf {
 // gather of the dense likelihood: out[k] = slots[k] >= 0 ? dense[slots[k]] : 0
 hipError_t launch_gather_f32(const float* dense, const int64_t* slots, int n, float* out, hipStream_t s);
 
-// Rtabmap::adjustLikelihood on a device vector (entry 0 = virtual place), in place
-hipError_t launch_adjust_likelihood(float* d_L, int n, float ratio, hipStream_t s);
 
 }  // namespace lcd

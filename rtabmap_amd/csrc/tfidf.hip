@@ -294,72 +294,9 @@ __global__ void iota_i32_kernel(int32_t* dst, int n, int32_t first) {
 }
 
 // ---------------------------------------------------------------------------------------------- adjustLikelihood
-// Rtabmap::adjustLikelihood (Rtabmap.cpp:5691-5760): mean / sample standard deviation over the entries > 0 after the
-// virtual place (entry 0), rescale the entries above mean + stddev, then set the virtual place.  One workgroup, three
-// passes over L[1..n) (0.4 MB at 100k signatures, L2-resident).  Sums are accumulated in double (the reference adds
-// floats sequentially, uMean/uVariance UMath.h:419-432, 512-526): results agree to ~1e-6 relative.
-__global__ __launch_bounds__(1024) void adjust_likelihood_kernel(float* __restrict__ L, int n, float ratio) {
-    __shared__ double s_sum[1024];
-    __shared__ unsigned int s_cnt[1024];
-    __shared__ float s_max[1024];
-    const int tid = threadIdx.x;
-    double sum = 0.0; unsigned int cnt = 0; float mx = 0.0f;
-    for (int i = 1 + tid; i < n; i += 1024) {
-        const float v = L[i];
-        if (v > 0.0f) { sum += (double)v; ++cnt; }
-        if (v > mx) mx = v;
-    }
-    s_sum[tid] = sum; s_cnt[tid] = cnt; s_max[tid] = mx;
-    __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if (tid < off) { s_sum[tid] += s_sum[tid + off]; s_cnt[tid] += s_cnt[tid + off]; s_max[tid] = fmaxf(s_max[tid], s_max[tid + off]); }
-        __syncthreads();
-    }
-    const unsigned int count = s_cnt[0];
-    const float mean = count ? (float)(s_sum[0] / (double)count) : 0.0f;
-    const float maxv = s_max[0];
-    __syncthreads();
-    double sq = 0.0;
-    for (int i = 1 + tid; i < n; i += 1024) {
-        const float v = L[i];
-        if (v > 0.0f) { const float d = v - mean; sq += (double)(d * d); }
-    }
-    s_sum[tid] = sq;
-    __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if (tid < off) s_sum[tid] += s_sum[tid + off];
-        __syncthreads();
-    }
-    const float var = count > 1 ? (float)(s_sum[0] / (double)(count - 1)) : 0.0f;
-    const float stdDev = sqrtf(var);
-    const float epsilon = 0.0001f;
-    for (int i = 1 + tid; i < n; i += 1024) {
-        const float value = L[i];
-        float o = 1.0f;
-        if (value > mean + stdDev) {
-            if (ratio == 0.0f && mean != 0.0f) o = (value - (stdDev - epsilon)) / mean;
-            else if (ratio != 0.0f && stdDev != 0.0f) o = (value - mean) / stdDev;
-        }
-        L[i] = o;
-    }
-    if (tid == 0 && n > 0) {
-        float vp;
-        if (ratio == 0.0f && stdDev > epsilon && maxv != 0.0f) vp = mean / stdDev + 1.0f;
-        else if (ratio != 0.0f && maxv > mean) vp = stdDev / (maxv - mean) + 1.0f;
-        else vp = 2.0f;
-        L[0] = vp;
-    }
-}
-
 inline int next_pow2(int v) { int p = 2; while (p < v) p <<= 1; return p; }
 
 }  // namespace
-
-hipError_t launch_adjust_likelihood(float* d_L, int n, float ratio, hipStream_t s) {
-    if (n <= 0) return hipSuccess;
-    adjust_likelihood_kernel<<<1, 1024, 0, s>>>(d_L, n, ratio);
-    return hipGetLastError();
-}
 
 hipError_t launch_gather_f32(const float* dense, const int64_t* slots, int n, float* out, hipStream_t s) {
     if (n <= 0) return hipSuccess;
