@@ -282,7 +282,6 @@ def test_frame_dev_carries_the_filter(oracle, pipeline):
         eng.bayes_set_neighbors([sid], off, nbr, mg)
         # oracle: likelihood over the working memory (everything but the newest `stm` signatures), adjusted, filtered
         wm = [s for s in range(1, sid - stm + 1) if s not in gone_before]
-        gone_before = set(gone)
         oi, Lo = m.compute_likelihood(np.array(exp_words, np.int32), np.array(wm, np.int32))
         vec = oracle.adjust_likelihood(np.concatenate([[0.0], Lo]).astype(np.float32), 0.0)
         ob.set_stm(list(range(sid - stm + 1, sid + 1)))
@@ -294,6 +293,7 @@ def test_frame_dev_carries_the_filter(oracle, pipeline):
             m.forget(old)
             eng.sig_remove(old)
             gone.add(old)
+        gone_before = set(gone)
         torch.cuda.synchronize()
         done = t - 1 if pipeline else t                                  # a pipelined frame's index stage runs inside the next call
         if done >= 0:
