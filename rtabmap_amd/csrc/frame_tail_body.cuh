@@ -18,6 +18,12 @@ __device__ __forceinline__ uint2 gload2(const uint2* p) {
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 
+__device__ __forceinline__ uint4 gload4(const uint4* p) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = *(const __attribute__((address_space(1))) u32x4*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // idf -> Q5.26, round to nearest, saturating
 __device__ __forceinline__ int32_t idf_to_fixed(float idf) {
     float s = idf * 67108864.0f;                        // 2^26, exact scaling

@@ -1006,9 +1006,11 @@ __global__ __launch_bounds__(PIPE_BLOCK) void frame_b_kernel(RerankArgs k, int n
                                                        k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb);
         return;
     }
-    const int b = bid - n_rerank_wgs;
-    if (b < A.n_closed) score_sealed_body<PIPE_BLOCK>(A, b);
-    else score_open_body<PIPE_BLOCK>(A, b - A.n_closed);
+    const int g = bid - n_rerank_wgs;
+    if (g < A.n_closed_pad) {                                            // consecutive buckets on one XCD: they share directory lines
+        const int b = (g & 7) * (A.n_closed_pad >> 3) + (g >> 3);
+        if (b < A.n_closed) score_sealed_body<PIPE_BLOCK>(A, b);
+    } else score_open_body<PIPE_BLOCK>(A, g - A.n_closed_pad);
 }
 
 // ------------------------------------------------------------------------------------------------ row-parallel exact scan

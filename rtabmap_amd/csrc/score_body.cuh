@@ -100,27 +100,49 @@ __device__ __forceinline__ void score_sealed_body(const ScoreArgs& A, int b) {
 #pragma unroll
     for (int u = 0; u < NI; ++u) { const int i = tid + u * SCB; ni_v[u] = i < TF_R ? A.slot_ni[first_slot + i] : 0u; }
     // ---- stage B: directory blocks of the sparse words, dense rows
-    uint2 blk[KW];
+    uint4 r0[KW], r1[KW];                                              // the word's record of the word-major directory (32 bytes)
 #pragma unroll
     for (int u = 0; u < KW; ++u) {
         const bool dense_here = did[u] >= 0 && (uint32_t)did[u] < D;
         look[u] = idf[u] != 0 && w[u] < B.W && (!dense_here || (flags & 1u));   // a dense word has sparse postings only for counts > 255
-        blk[u] = make_uint2(0u, 0u);
-        if (look[u]) blk[u] = gload2(B.dirb + (w[u] >> 5));
+        r0[u] = make_uint4(0u, 0u, 0u, 0u); r1[u] = r0[u];
+        if (look[u]) {
+            const uint4* rec = reinterpret_cast<const uint4*>(A.dir2 + ((size_t)(w[u] >> 5) * A.dir2_stride + (uint32_t)b) * TF_DIR2_DWORDS);
+            r0[u] = gload4(rec); r1[u] = gload4(rec + 1);
+        }
     }
     uint32_t c[DR];
 #pragma unroll
     for (int u = 0; u < DR; ++u) c[u] = (dj[u] >= 0 && (uint32_t)dj[u] < D) ? gload((const uint32_t*)(B.dense + (size_t)dj[u] * TF_R + 4 * ln)) : 0u;
-    // ---- stage C: segment offsets of the words that are present
+    // ---- stage C: start and length of the words' posting segments, from the record alone (a block with a count that does not
+    //      fit its 5-bit field goes through the per-bucket directory: a dependent lookup, rare)
     uint32_t start[KW], len[KW];
 #pragma unroll
     for (int u = 0; u < KW; ++u) {
         start[u] = 0; len[u] = 0;
-        const uint32_t bit = 1u << (w[u] & 31);
-        if (look[u] && (blk[u].x & bit)) {
-            const uint32_t r = blk[u].y + (uint32_t)__popc(blk[u].x & (bit - 1u));
-            const uint32_t s0 = gload(B.sp_off + r), s1 = gload(B.sp_off + r + 1);
-            start[u] = s0; len[u] = s1 - s0;
+        if (!look[u]) continue;
+        const uint32_t f[6] = {r0[u].z, r0[u].w, r1[u].x, r1[u].y, r1[u].z, r1[u].w};
+        const uint32_t p = w[u] & 31u, pd = p / 6u, ps = 5u * (p % 6u);
+        if (!(r0[u].y & TF_DIR2_SAT)) {
+            uint32_t before = 0;
+#pragma unroll
+            for (uint32_t d = 0; d < 6u; ++d) {
+                const uint32_t x = d < pd ? f[d] : (d == pd ? (f[d] & ((1u << ps) - 1u)) : 0u);
+                before += dir2_sum6(x);
+            }
+            uint32_t fd = f[0];
+#pragma unroll
+            for (uint32_t d = 1; d < 6u; ++d) fd = d == pd ? f[d] : fd;
+            len[u] = (fd >> ps) & 31u;
+            start[u] = r0[u].x + before;
+        } else {
+            const uint2 blk = gload2(B.dirb + (w[u] >> 5));
+            const uint32_t bit = 1u << p;
+            if (blk.x & bit) {
+                const uint32_t r = blk.y + (uint32_t)__popc(blk.x & (bit - 1u));
+                const uint32_t s0 = gload(B.sp_off + r), s1 = gload(B.sp_off + r + 1);
+                start[u] = s0; len[u] = s1 - s0;
+            }
         }
     }
     // the dense rows: a lane owns four signatures

@@ -47,6 +47,19 @@ constexpr int TF_MAX_WORDS = 8192;         // words of one signature / one query
 constexpr int TF_IDF_SHIFT = 26;           // idf in Q5.26 (|idf| < 32: N up to 1e32)
 constexpr int TF_DENSE_T = 32;             // a word present in >= 32 of a bucket's 256 signatures becomes dense
 constexpr int TF_DENSE_MAX = 4096;         // dense ids (1 MB of rows per bucket at most)
+// WORD-MAJOR DIRECTORY of the sparse part (dir2): one 32-byte record per (block of 32 wslots, bucket), laid out
+// dir2[block][bucket] -- the records of consecutive buckets share a 128-byte line, and consecutive buckets are scored by
+// workgroups of the same XCD, so a probe costs a quarter of a line instead of two whole ones:
+//   d[0] = offset of the block's first sparse posting in the bucket's sp_ent, d[1] = number of present words before the block
+//   (bit 31: some count of the block does not fit its field -> look the word up through dirb / sp_off instead),
+//   d[2..7] = the 32 words' posting counts, 5 bits each, six per dword.
+// start and length of a word's postings follow from ONE record: no second, dependent lookup of an offset.
+constexpr int TF_DIR2_DWORDS = 8;
+constexpr uint32_t TF_DIR2_SAT = 1u << 31;
+__host__ __device__ inline uint32_t dir2_sum6(uint32_t x) {           // sum of the six 5-bit fields of a dword
+    const uint32_t t = (x & 0x01F07C1Fu) + ((x >> 5) & 0x01F07C1Fu);
+    return (t & 0x3FFu) + ((t >> 10) & 0x3FFu) + (t >> 20);
+}
 
 // one bucket as the kernels see it
 struct BucketDev {
@@ -68,6 +81,7 @@ struct SealJob {
     const uint32_t* coo_w; const uint32_t* coo_pc; const uint32_t* ne;   // log and its length (device counter)
     uint8_t* dense; uint32_t D_alloc;
     uint2* dirb; uint32_t* sp_off; uint32_t* sp_ent;
+    uint32_t* dir2; uint32_t dir2_stride;   // the word-major directory (all buckets) and its buckets-per-block stride
     uint32_t* cntw;            // [W] scratch, zeroed
     uint32_t* tile_sums;       // [2 * tiles] scratch
     uint32_t W;
@@ -111,7 +125,9 @@ struct FwArgs {
 struct RetireArgs { long long slot[4]; const uint32_t* coo_w[4]; int n; };
 struct ScoreArgs {
     const BucketDev* tab; const uint32_t* bkt_D; const uint32_t* bkt_flags;
+    const uint32_t* dir2; uint32_t dir2_stride;
     int n_closed;                           // buckets [0, n_closed) are sealed or dead; bucket n_closed (if any) is the open one
+    int n_closed_pad;                       // workgroups launched for them: a multiple of 8, workgroup g scores bucket (g % 8) * pad / 8 + g / 8
     int n_open_slots; int wcap;
     const uint32_t* q_w; const int32_t* q_idf; const int32_t* q_did; const int32_t* qd_did; const int32_t* qd_idf; const uint32_t* q_meta;
     const uint32_t* slot_ni; const uint32_t* slot_begin; const uint32_t* slot_cnt;
@@ -176,6 +192,9 @@ struct Tfidf {
     int score_block = 512;               // threads per scoring workgroup (256 / 512 / 1024; lcd_set_option "score_block")
     int q_n_ub = 0;                      // word count of the last frame handed to frame_words (upper bound of its unique words)
     BufPool pool;
+    DevBuf dir2;                         // word-major directory of the sparse parts: [dir2_blocks][dir2_stride] records of 32 bytes
+    uint32_t dir2_blocks = 0, dir2_stride = 0, dir2_hint_blocks = 0, dir2_hint_stride = 0;
+    hipError_t ensure_dir2(uint32_t blocks, uint32_t buckets_needed);
     DevBuf n_dense;                      // [0] number of dense ids handed out (device counter)
     uint32_t* h_n_dense = nullptr;       // pinned host mirror written by the sealing kernels (read without synchronising: stale is fine)
     DevBuf seal_cntw, seal_tiles;        // sealing scratch

@@ -100,8 +100,11 @@ __global__ __launch_bounds__(BR_BLOCK) void bulk_register_kernel(const int32_t* 
 // every closed bucket (dead ones write zeros) and the open bucket in ONE launch, likelihood (or the integer sums) written directly
 template <int SCB>
 __global__ __launch_bounds__(SCB) void score_kernel(ScoreArgs A) {
-    if ((int)blockIdx.x < A.n_closed) score_sealed_body<SCB>(A, (int)blockIdx.x);
-    else score_open_body<SCB>(A, (int)blockIdx.x - A.n_closed);
+    const int g = (int)blockIdx.x;
+    if (g < A.n_closed_pad) {                                            // consecutive buckets on one XCD: they share directory lines
+        const int b = (g & 7) * (A.n_closed_pad >> 3) + (g >> 3);
+        if (b < A.n_closed) score_sealed_body<SCB>(A, b);
+    } else score_open_body<SCB>(A, g - A.n_closed_pad);
 }
 
 // what one scoring launch has to read for the frame in q_* (bench.py's algorithmic bytes): cnt[0] dense row bytes, [1] sparse postings,
@@ -236,7 +239,18 @@ __global__ __launch_bounds__(SEAL_BLOCK) void seal_scan_kernel(const SealJob* __
     const uint32_t tot_p = block_exclusive_scan<SEAL_BLOCK>(s_p, SEAL_BLOCK, scratch);
     const uint32_t tot_a = block_exclusive_scan<SEAL_BLOCK>(s_a, SEAL_BLOCK, scratch);
     uint32_t rp = base_p + s_p[threadIdx.x], ra = base_a + s_a[threadIdx.x];
-    if (w0 < J.W) J.dirb[blk] = make_uint2(bits, rp);
+    if (w0 < J.W) {
+        J.dirb[blk] = make_uint2(bits, rp);
+        if (J.dir2) {                                                    // the same block in the word-major directory
+            uint32_t f[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+            bool sat = false;
+#pragma unroll
+            for (uint32_t i = 0; i < 32u; ++i) { sat = sat || c[i] > 30u; f[i / 6] |= (c[i] > 30u ? 31u : c[i]) << (5u * (i % 6)); }
+            uint4* rec = reinterpret_cast<uint4*>(J.dir2 + ((size_t)blk * J.dir2_stride + (uint32_t)J.bucket) * TF_DIR2_DWORDS);
+            rec[0] = make_uint4(ra, rp | (sat ? TF_DIR2_SAT : 0u), f[0], f[1]);
+            rec[1] = make_uint4(f[2], f[3], f[4], f[5]);
+        }
+    }
 #pragma unroll
     for (uint32_t i = 0; i < 32u; ++i) if (c[i]) { J.sp_off[rp++] = ra; ra += c[i]; }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) J.sp_off[base_p + tot_p] = base_a + tot_a;   // end of the last segment
@@ -358,6 +372,10 @@ hipError_t Tfidf::init(hipStream_t s, int64_t* bytes, int64_t sig_capacity, int6
     TF_TRY(ensure_slots(sig_capacity > 0 ? sig_capacity : TF_R));
     TF_TRY(ensure_buckets((int)((sig_capacity > 0 ? sig_capacity : TF_R) / TF_R) + 64));
     TF_TRY(ensure_wslots((int32_t)std::min<int64_t>(std::max<int64_t>(65536, 4 * vocab_capacity), 1 << 27)));   // growing later means a stream sync
+    // the word-major directory is sized for the same horizon (its growth is a stream sync and a copy of the whole table): blocks for
+    // twice the vocabulary hint + the keys a stream of frames holds in reserve, buckets for the signature hint
+    dir2_hint_blocks = (uint32_t)std::min<int64_t>((2 * std::max<int64_t>(vocab_capacity, 8192) + 65536) / 32, 1 << 22);
+    dir2_hint_stride = (uint32_t)std::min<int64_t>((sig_capacity > 0 ? sig_capacity : TF_R) / TF_R + 64, 1 << 20);
     TF_TRY(q_w.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
     TF_TRY(q_idf.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
     TF_TRY(q_did.reserve(TF_MAX_WORDS * 4, 0, stream, bytes_device));
@@ -383,7 +401,7 @@ void Tfidf::destroy() {
     buckets.clear();
     pool.destroy(bytes_device);
     DevBuf* all[] = {&slot_sig, &slot_ni, &slot_begin, &slot_cnt, &nw, &did, &idf_tab, &d_id2ws, &bkt_tab, &bkt_ne, &bkt_D, &bkt_flags,
-                     &n_dense, &seal_cntw, &seal_tiles, &q_w, &q_idf, &q_did, &qd_did, &qd_idf, &q_meta, &d_stage, &d_pairs};
+                     &n_dense, &dir2, &seal_cntw, &seal_tiles, &q_w, &q_idf, &q_did, &qd_did, &qd_idf, &q_meta, &d_stage, &d_pairs};
     for (DevBuf* d : all) d->release(bytes_device);
     h_stage.release();
     if (h_n_dense) { (void)hipHostFree(h_n_dense); h_n_dense = nullptr; }
@@ -630,9 +648,28 @@ static hipError_t ensure_log(Tfidf& t, int b, int64_t entries) {
 // Seal full buckets on the device.  bulk: the caller is a synchronous bulk load -- the dense ids discovered in the first batch are
 // read back once so that every bucket of the load gets exactly the rows it needs; otherwise nothing is read back and the number
 // of rows is an upper estimate from the (possibly stale) pinned mirror of the dense-id counter.
+// the word-major directory grows in both directions: more blocks of 32 wslots (rows appended), more buckets (wider rows)
+hipError_t Tfidf::ensure_dir2(uint32_t blocks, uint32_t buckets_needed) {
+    if (blocks <= dir2_blocks && buckets_needed <= dir2_stride) return hipSuccess;
+    uint32_t nb = std::max<uint32_t>(dir2_blocks, 256), ns = std::max<uint32_t>(dir2_stride, 64);
+    if (!dir2.p) { while (nb < dir2_hint_blocks) nb *= 2; while (ns < dir2_hint_stride) ns *= 2; }
+    while (nb < blocks) nb *= 2;
+    while (ns < buckets_needed) ns *= 2;
+    DevBuf nd;
+    const size_t rec = (size_t)TF_DIR2_DWORDS * 4;
+    TF_TRY(nd.reserve((size_t)nb * ns * rec, 0, stream, bytes_device));
+    TF_TRY(hipMemsetAsync(nd.p, 0, (size_t)nb * ns * rec, stream));
+    if (dir2.p && dir2_blocks && dir2_stride)
+        TF_TRY(hipMemcpy2DAsync(nd.p, (size_t)ns * rec, dir2.p, (size_t)dir2_stride * rec, (size_t)dir2_stride * rec, dir2_blocks, hipMemcpyDeviceToDevice, stream));
+    if (dir2.p) { TF_TRY(hipStreamSynchronize(stream)); dir2.release(bytes_device); }
+    dir2 = nd; dir2_blocks = nb; dir2_stride = ns;
+    return hipSuccess;
+}
+
 hipError_t Tfidf::seal_batch(const std::vector<int>& ids, bool bulk) {
     if (ids.empty()) return hipSuccess;
     const uint32_t W = (uint32_t)n_wslots;
+    TF_TRY(ensure_dir2((W + 31) / 32, (uint32_t)buckets.size() + 1));
     const int tiles = std::max(1, (int)((W + SEAL_TILE - 1) / SEAL_TILE));
     const size_t BATCH = 64;
     TF_TRY(seal_cntw.reserve(std::min(BATCH, ids.size()) * std::max<size_t>(W, 1) * 4, 0, stream, bytes_device));
@@ -652,6 +689,7 @@ hipError_t Tfidf::seal_batch(const std::vector<int>& ids, bool bulk) {
             J.cntw = seal_cntw.as<uint32_t>() + j * (size_t)W; J.tile_sums = seal_tiles.as<uint32_t>() + j * (size_t)tiles * 2;
             J.W = W; J.ent_cap = (uint32_t)std::max<int64_t>(k.ub_entries, 1);
             J.dense = nullptr; J.D_alloc = 0; J.dirb = nullptr; J.sp_off = nullptr; J.sp_ent = nullptr;
+            J.dir2 = dir2.as<uint32_t>(); J.dir2_stride = dir2_stride;
             max_e = std::max(max_e, J.ent_cap);
         }
         const SealJob* dj = nullptr;
@@ -888,7 +926,9 @@ hipError_t Tfidf::score_args(float* d_likelihood, long long* lfix, int block, Sc
     A.slot_ni = slot_ni.as<uint32_t>(); A.slot_begin = slot_begin.as<uint32_t>(); A.slot_cnt = slot_cnt.as<uint32_t>();
     A.idf_tab = idf_tab.as<uint2>(); A.stamp = stamp;
     A.out_like = d_likelihood; A.out_fix = lfix;
-    *n_wgs = A.n_closed + (A.n_open_slots + block / 64 - 1) / (block / 64);
+    A.dir2 = dir2.as<uint32_t>(); A.dir2_stride = dir2_stride;
+    A.n_closed_pad = (A.n_closed + 7) / 8 * 8;
+    *n_wgs = A.n_closed_pad + (A.n_open_slots + block / 64 - 1) / (block / 64);
     return hipSuccess;
 }
 
