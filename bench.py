@@ -203,12 +203,59 @@ def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None
     return {"wall": wall, "dev_ms": evs[0].elapsed_time(evs[steps]), "host_enqueue": host_enqueue, "per_step_ms": per_step}
 
 
+PMC_LIVE = {}          # kernel -> {"fetch_kb", "write_kb", "hbm_bytes_per_launch"}: measured by THIS run (measure_pmc), else the committed profile
+
+
+def measure_pmc():
+    """HBM traffic per launch, measured by this run: two rocprofv3 passes (--pmc FETCH_SIZE, then --pmc WRITE_SIZE; kernel trace
+    only, as MI355X_MICROARCH.md prescribes) over a short invocation of this same script, reduced like tools/make_pmc_json.py
+    (rocprofv3 reports KB; gfx950 counts 64 B per 128-B read request: reads are doubled).  Fills PMC_LIVE; returns a note."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return "rocprofv3 not found: traffic from the committed profile"
+    base = tempfile.mkdtemp(prefix="lcd_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", LCD_BENCH_INNER="1")
+    inner = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "30", "--warmup", "5"]
+    sums = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(base, counter)
+            r = subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + inner,
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not files:
+                return "rocprofv3 --pmc %s failed (%d): traffic from the committed profile" % (counter, r.returncode)
+            agg = collections.defaultdict(lambda: [0, 0.0])
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != counter:
+                    continue
+                k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("lcd::", "").replace("void ", "").split("(")[0].split("<")[0]
+                agg[k][0] += 1
+                agg[k][1] += float(row["Counter_Value"])
+            sums[counter] = {k: v[1] / v[0] for k, v in agg.items()}
+        for k, fe in sums["FETCH_SIZE"].items():
+            w = sums["WRITE_SIZE"].get(k, 0.0)
+            PMC_LIVE[k] = {"fetch_kb": fe, "write_kb": w, "hbm_bytes_per_launch": (2.0 * fe + w) * 1024.0}
+        return "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over `bench.py --no-cpu-baseline --steps 30 --warmup 5`"
+    except Exception as e:  # noqa: BLE001
+        return "PMC measurement failed (%s): traffic from the committed profile" % type(e).__name__
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
 def pmc_traffic(name):
-    """HBM traffic per launch of a kernel: from the committed rocprofv3 --pmc summary of this command (FETCH_SIZE / WRITE_SIZE cannot
-    be read from inside the process); null when the profile is not there."""
+    """HBM traffic per launch of a kernel in GB: from this run's own rocprofv3 --pmc passes (measure_pmc) when they ran, else from the
+    committed summary of the same command (profiles/r02_pmc.json); null when neither has the kernel."""
+    key = name.split(" ")[0].split("<")[0]
+    if key in PMC_LIVE:
+        return PMC_LIVE[key]["hbm_bytes_per_launch"] / 1e9
     try:
         pmc = json.load(open(PMC_PROFILE))
-        key = name.split(" ")[0].split("<")[0]
         return pmc[key]["hbm_bytes_per_launch"] / 1e9 if key in pmc else None
     except Exception:
         return None
@@ -468,6 +515,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--signatures", type=int, default=N_SIG)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (oracle build, parity block, CPU baselines)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure HBM traffic with rocprofv3 (two extra short runs of this script)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (unpipelined, host path, with update)")
     ap.add_argument("--pipeline", type=int, default=1, help="1: software-pipelined frames (the launches of frame t carry the registration "
                     "and scoring of frame t-1); 0: four launches per frame, nothing overlapped")
@@ -662,6 +710,14 @@ def main():
             res = np.frombuffer(stb.d_res.cpu().numpy().tobytes(), dtype=np.int32)
             config["with_bayes_last_hypothesis"] = {"sig_id": int(res[0]), "n_considered": int(res[5])}
             engb.close()
+        if not args.no_cpu_baseline and not args.no_pmc and not os.environ.get("LCD_BENCH_INNER"):
+            # HBM traffic of the big kernels, measured by this run (two short rocprofv3 passes over this script) instead of read
+            # from the committed profile
+            note = measure_pmc()
+            for k in ("roofline", "roofline_score", "roofline_knn", "roofline_knn_standalone", "roofline_score_standalone"):
+                if out.get(k):
+                    out[k]["traffic"] = pmc_traffic(out[k]["kernel"])
+                    out[k]["traffic_source"] = note if PMC_LIVE else note + " (profiles/r02_pmc.json)"
         if not args.no_cpu_baseline:
             m = build_oracle(vocab, words)
             par, t_lin_port, t_lik = parity_block(torch, vocab, words, frames_np, m)
