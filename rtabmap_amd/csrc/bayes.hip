@@ -358,10 +358,10 @@ __global__ __launch_bounds__(DC_BLOCK) void decide_pass2_kernel(Pass2Args a) {
     const Fold1 sc = s_f;
     if (blockIdx.x == 0 && tid == 0) publish_fold1(sc, a.scal, a.hyp, a.like != nullptr, a.ratio, a.slot_sig);
     const long long cols = sc.n_in + 1;
-    float vp_col = 0.0f, p00 = 1.0f;                                   // the virtual place's column (:376-411)
+    float vp_col = 0.0f;                                               // the virtual place's column in the rows >= 1 (:376-411; row 0: fold 2)
     if (a.prm.vp_prior > 0.0f) {
-        if (cols > 1) { vp_col = (float)((1.0 - a.prm.vp_prior) / (double)(cols - 1)); p00 = a.prm.vp_prior; }
-    } else if (cols > 1) { vp_col = (float)(1.0 / (double)cols); p00 = vp_col; }
+        if (cols > 1) vp_col = (float)((1.0 - a.prm.vp_prior) / (double)(cols - 1));
+    } else if (cols > 1) vp_col = (float)(1.0 / (double)cols);
     const double from_vp = (double)vp_col * (double)pin_vp;
     double usum = 0.0;
     unsigned long long key = 0ull, kslot = ~0ull;
