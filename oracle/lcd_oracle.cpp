@@ -705,6 +705,10 @@ struct BayesFilter {
     std::map<int, float> posterior;
     std::map<int, std::map<int, int> > graph;  // id -> (neighbour id -> margin), the harness' Memory::getNeighborsId
     std::set<int> stm;
+    // Bayes/FullPredictionUpdate = false (the reference's default): the matrix of the last call and the neighbour cache it is patched from
+    bool fullPredictionUpdate = true;
+    std::vector<float> prediction; int predictionCols = 0;
+    std::map<int, std::map<int, int> > neighborsIndex;
 
     void setPredictionLC(const double* v, int n) {                       // :77-122 (values already parsed)
         predictionLC.assign(v, v + n);
@@ -714,7 +718,11 @@ struct BayesFilter {
             if (j == 0 || predictionLC[j] < predictionEpsilon) predictionEpsilon = predictionLC[j];
         }
     }
-    void reset() { posterior.clear(); }
+    void reset() { posterior.clear(); prediction.clear(); predictionCols = 0; neighborsIndex.clear(); }   // :138-143
+    std::map<int, int> getNeighborsId(int id) const {                   // Memory::getNeighborsId as the harness answers it
+        std::map<int, std::map<int, int> >::const_iterator g = graph.find(id);
+        return g == graph.end() ? std::map<int, int>() : g->second;
+    }
 
     // ---- dense, literal
     float addNeighborProb(std::vector<float>& P, int cols, unsigned int col, const std::map<int, int>& neighbors,
@@ -770,12 +778,14 @@ struct BayesFilter {
         for (unsigned int i = 0; i < ids.size(); ++i) {
             if (idsDone.find(ids[i]) != idsDone.end()) continue;
             if (ids[i] > 0) {
+                if (!fullPredictionUpdate) neighborsIndex[ids[i]] = getNeighborsId(ids[i]);     // uInsert :332-335 (before the STM filter)
                 std::map<int, int> neighbors = neighborsNotInStm(ids[i]);
                 std::list<int> idsLoopMargin;
                 for (std::map<int, int>::iterator iter = neighbors.begin(); iter != neighbors.end(); ++iter)
                     if (iter->second == 0 && idToIndexMap.find(iter->first) != idToIndexMap.end()) idsLoopMargin.push_back(iter->first);
                 if (idsLoopMargin.size() == 0) return false;            // UFATAL :357
                 for (std::list<int>::iterator iter = idsLoopMargin.begin(); iter != idsLoopMargin.end(); ++iter) {
+                    if (!fullPredictionUpdate) neighborsIndex[*iter] = neighbors;                  // uInsert :364-367 (the filtered map)
                     float sum = 0.0f;
                     int index = idToIndexMap.at(*iter);
                     sum += addNeighborProb(P, cols, index, neighbors, idToIndexMap);
@@ -796,6 +806,91 @@ struct BayesFilter {
             }
         }
         return true;
+    }
+    // updatePrediction :502-706: the old matrix patched for the ids that came and went, columns rebuilt from _neighborsIndex
+    bool updatePredictionDense(const std::vector<float>& oldPrediction, const std::vector<int>& oldIds, const std::vector<int>& newIds,
+                               std::vector<float>& P) {
+        const int oldCols = (int)oldIds.size(), cols = (int)newIds.size();
+        P.assign((size_t)cols * cols, 0.0f);
+        std::set<int> oldIdsSet(oldIds.begin(), oldIds.end());
+        std::map<int, int> newIdToIndexMap;
+        for (unsigned int i = 0; i < newIds.size(); ++i) if (newIds[i] > 0) newIdToIndexMap[newIds[i]] = i;
+        std::set<int> removedIds;                                        // :543-553
+        for (unsigned int i = 0; i < oldIds.size(); ++i) {
+            if (oldIds[i] > 0 && newIdToIndexMap.find(oldIds[i]) == newIdToIndexMap.end()) { removedIds.insert(removedIds.end(), oldIds[i]); neighborsIndex.erase(oldIds[i]); }
+        }
+        bool oldAllCopied = false;                                       // :556-564
+        if (removedIds.empty() && newIds.size() > oldIds.size() && std::equal(oldIds.begin(), oldIds.end(), newIds.begin())) {
+            for (int r = 0; r < oldCols; ++r) for (int c = 0; c < oldCols; ++c) P[c + (size_t)r * cols] = oldPrediction[c + (size_t)r * oldCols];
+            oldAllCopied = true;
+        }
+        std::set<int> idsToUpdate;                                       // :566-621
+        for (unsigned int i = 0; i < oldIds.size() || i < newIds.size(); ++i) {
+            if (i < oldIds.size()) {
+                if (removedIds.find(oldIds[i]) != removedIds.end()) {
+                    for (unsigned int j = 0; j < (unsigned int)oldCols; ++j)
+                        if (j != i && removedIds.find(oldIds[j]) == removedIds.end()) idsToUpdate.insert(oldIds[j]);
+                }
+            }
+            if (i < newIds.size() && oldIdsSet.find(newIds[i]) == oldIdsSet.end()) {
+                if (neighborsIndex.find(newIds[i]) == neighborsIndex.end()) {
+                    std::map<int, int> neighbors = getNeighborsId(newIds[i]);
+                    for (std::map<int, int>::iterator iter = neighbors.begin(); iter != neighbors.end(); ++iter) {
+                        std::map<int, std::map<int, int> >::iterator jter = neighborsIndex.find(iter->first);
+                        if (jter != neighborsIndex.end()) jter->second[newIds[i]] = iter->second;                     // uInsert :589
+                    }
+                    neighborsIndex.insert(std::make_pair(newIds[i], neighbors));
+                }
+                const std::map<int, int>& neighbors = neighborsIndex.at(newIds[i]);
+                float sum = addNeighborProb(P, cols, i, neighbors, newIdToIndexMap);
+                normalize(P, cols, i, sum, newIds[0] < 0);
+                for (std::map<int, int>::const_iterator iter = neighbors.begin(); iter != neighbors.end(); ++iter)
+                    if (oldIdsSet.find(iter->first) != oldIdsSet.end() && removedIds.find(iter->first) == removedIds.end()) idsToUpdate.insert(iter->first);
+            }
+        }
+        for (std::set<int>::iterator iter = idsToUpdate.begin(); iter != idsToUpdate.end(); ++iter) {              // :628-650
+            int id = *iter;
+            if (id > 0) {
+                int index = newIdToIndexMap.at(id);
+                std::map<int, std::map<int, int> >::iterator kter = neighborsIndex.find(id);
+                if (kter == neighborsIndex.end()) return false;          // UASSERT_MSG :636
+                float sum = addNeighborProb(P, cols, index, kter->second, newIdToIndexMap);
+                normalize(P, cols, index, sum, newIds[0] < 0);
+            }
+        }
+        if (!oldAllCopied) {                                             // :654-682: copy the columns that did not change
+            for (unsigned int i = 0; i < oldIds.size(); ++i) {
+                if (oldIds[i] > 0 && removedIds.find(oldIds[i]) == removedIds.end() && idsToUpdate.find(oldIds[i]) == idsToUpdate.end()) {
+                    for (int j = 0; j < oldCols; ++j) {
+                        if (oldIds[j] > 0 && removedIds.find(oldIds[j]) == removedIds.end()) {
+                            float v = oldPrediction[i + (size_t)j * oldCols];
+                            int ii = newIdToIndexMap.at(oldIds[i]);
+                            int jj = newIdToIndexMap.at(oldIds[j]);
+                            P[ii + (size_t)jj * cols] = v;
+                        }
+                    }
+                }
+            }
+        }
+        if (newIds[0] < 0) {                                             // :685-700: the virtual place
+            if (cols > 1) {
+                P[0] = virtualPlacePrior;
+                float val = (1.0 - virtualPlacePrior) / (cols - 1);
+                for (int j = 1; j < cols; j++) { P[(size_t)j * cols] = val; P[j] = predictionLC[0]; }
+            } else if (cols > 0) P[0] = 1;
+        }
+        return true;
+    }
+    // generatePrediction's dispatch :273-286 for Bayes/FullPredictionUpdate = false
+    bool generatePredictionIncremental(const std::vector<int>& ids, std::vector<float>& P) {
+        std::vector<int> oldIds;
+        for (std::map<int, float>::const_iterator i = posterior.begin(); i != posterior.end(); ++i) oldIds.push_back(i->first);
+        if (oldIds == ids && !prediction.empty()) { P = prediction; return true; }
+        bool ok;
+        if (!prediction.empty()) ok = updatePredictionDense(prediction, oldIds, ids, P);
+        else ok = generatePredictionDense(ids, P);
+        if (ok) { prediction = P; predictionCols = (int)ids.size(); }
+        return ok;
     }
     void updatePosterior(const std::vector<int>& likelihoodIds) {       // :709-736
         std::map<int, float> newPosterior;
@@ -846,7 +941,8 @@ struct BayesFilter {
         std::vector<float> post(m);
         if (dense) {
             std::vector<float> P;
-            if (!generatePredictionDense(ids, P)) return -2;
+            fullPredictionUpdate = dense != 2;                           // dense == 2: the reference's default incremental mode
+            if (!(dense == 2 ? generatePredictionIncremental(ids, P) : generatePredictionDense(ids, P))) return -2;
             updatePosterior(ids);
             int j = 0;
             for (std::map<int, float>::const_iterator i = posterior.begin(); i != posterior.end(); ++i) post[j++] = i->second;

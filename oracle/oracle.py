@@ -411,12 +411,15 @@ class OracleBayesFilter:
         a = np.ascontiguousarray(ids, dtype=np.int32)
         lib().orc_bayes_set_stm(self.h, _ptr(a), a.shape[0])
 
-    def compute_posterior(self, ids, likelihood, dense=False):
-        """ids ascending (ids[0] may be -1, the virtual place); returns the posterior in the same order (float32)."""
+    def compute_posterior(self, ids, likelihood, dense=False, incremental=False):
+        """ids ascending (ids[0] may be -1, the virtual place); returns the posterior in the same order (float32).
+        dense: the statement-by-statement m x m evaluation; incremental (implies dense): Bayes/FullPredictionUpdate = false, the
+        reference's default -- the matrix of the last call patched by updatePrediction (BayesFilter.cpp:502-706)."""
         i = np.ascontiguousarray(ids, dtype=np.int32)
         l = np.ascontiguousarray(likelihood, dtype=np.float32)
         out = np.zeros(i.shape[0], np.float32)
-        rc = lib().orc_bayes_compute_posterior(self.h, _ptr(i), _ptr(l), i.shape[0], 1 if dense else 0, _ptr(out))
+        mode = 2 if incremental else (1 if dense else 0)
+        rc = lib().orc_bayes_compute_posterior(self.h, _ptr(i), _ptr(l), i.shape[0], mode, _ptr(out))
         if rc:
             raise RuntimeError("orc_bayes_compute_posterior: %d" % rc)
         return out

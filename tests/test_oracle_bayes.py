@@ -109,3 +109,36 @@ def test_device_algorithm_model_against_the_oracle(lc, vp, dense, depth_cap):
         po = ob.compute_posterior(ids, like, dense=dense)
         pd = dv.update(adj, inset)[: upto + 1]
         np.testing.assert_allclose(pd, po, rtol=2e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_incremental_prediction_update_equals_full_regeneration(seed):
+    """Bayes/FullPredictionUpdate = false (the reference's default: updatePrediction patches last call's matrix from the cached
+    neighbour maps, BayesFilter.cpp:502-706) against a full regeneration on every call -- what the device does -- while signatures
+    enter the working memory, leave the short-term memory and are transferred out.  With the default pattern the posteriors are
+    equal bit for bit: evaluating the prediction from the neighbour lists every frame IS the reference's default behaviour."""
+    rng = np.random.default_rng(seed)
+    n = 150
+    g = random_graph(n, 7, rng)
+    depth = DEFAULT_LC.shape[0] - 1
+    full, inc = O.OracleBayesFilter(DEFAULT_LC), O.OracleBayesFilter(DEFAULT_LC)
+    for s in range(1, n + 1):
+        d = g.neighbors(s, depth)
+        for b in (full, inc):
+            b.set_neighbors(s, sorted(d), [d[k] for k in sorted(d)])
+    stm, gone = 6, set()
+    for t in range(12, n + 1, 3):
+        if t % 4 == 0:
+            gone.add(int(rng.integers(1, max(t - stm - 5, 2))))               # Memory::forget / transfer of an old signature
+        wm = [s for s in range(1, t - stm + 1) if s not in gone]
+        ids = [-1] + wm
+        for b in (full, inc):
+            b.set_stm(list(range(t - stm + 1, t + 1)))
+        like = random_adjusted(len(ids), rng)
+        pf = full.compute_posterior(ids, like, dense=True)
+        pi = inc.compute_posterior(ids, like, incremental=True)
+        assert np.array_equal(pf, pi), (t, float(np.max(np.abs(pf - pi))))
+    # the same id set twice: the cached matrix is reused (:276-281)
+    pf = full.compute_posterior(ids, like, dense=True)
+    pi = inc.compute_posterior(ids, like, incremental=True)
+    assert np.array_equal(pf, pi)
