@@ -19,7 +19,10 @@
 namespace lcd {
 namespace {
 
-constexpr int FW_BLOCK = 1024;   // frame_words_kernel / frame_tail_kernel
+#ifndef LCD_FW_BLOCK
+#define LCD_FW_BLOCK 1024
+#endif
+constexpr int FW_BLOCK = LCD_FW_BLOCK;   // frame_words_kernel / frame_tail_kernel (timing experiments build it with 256 to compare with the fused launch's tail)
 constexpr int BR_BLOCK = 256;    // bulk_register_kernel (one workgroup per signature)
 constexpr int SEAL_BLOCK = 256;
 constexpr int SEAL_TILE = SEAL_BLOCK * 32;   // wslots per workgroup of the sealing scan (one 32-wslot directory block per thread)
