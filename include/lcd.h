@@ -75,10 +75,11 @@ typedef struct lcd_config {
     int32_t pipeline;          /* 1: consecutive lcd_frame_dev calls are software-pipelined (matrix-core 2-NN handles): the launches of
                                   frame t also carry the registration and the scoring of frame t - 1, whose single-workgroup
                                   decision loop then hides behind the distance filter of frame t.  Consequence for the caller: the
-                                  outputs of a frame (d_word_ids, d_likelihood, ...) and its descriptors must stay valid until the
-                                  NEXT lcd_frame_dev or any other call on the handle, which completes the owed stage first
-                                  (lcd_synchronize to wait for it).  lcd_sig_remove and lcd_record_event keep their place in the
-                                  call order.  Results are identical with and without. */
+                                  outputs of a frame (d_word_ids, d_likelihood, d_bayes, ...) are written -- and its descriptors
+                                  read -- by the work the NEXT lcd_frame_dev enqueues (or by any other call on the handle, which
+                                  completes the owed stage first; lcd_synchronize to wait for it): keep two sets of buffers and
+                                  alternate.  lcd_sig_remove, lcd_record_event and lcd_bayes_set_neighbors are queued behind the
+                                  owed stage, so they keep their place in the call order.  Results are identical with and without. */
     int32_t reserved1;
 } lcd_config;
 
