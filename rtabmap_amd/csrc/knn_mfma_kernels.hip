@@ -717,6 +717,199 @@ __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, cons
     MF_STAMP(3);
 }
 
+// ------------------------------------------------------------------------------------------------ persistent variant
+// Vocabularies of more than BF_PX strips (> ~60k words): a workgroup keeps its queries in registers and walks several strips
+// (strip bx0, bx0 + px, ...) instead of staging and splitting the same 512 queries once per strip -- with one workgroup per compute
+// unit (146 KB of LDS each) the strips of the non-persistent launch ran in ceil(strips / 256) rounds of prologue + loop + epilogue.
+// LDS holds two strips: the one being multiplied and the next one, requested (LDS-DMA, augmentation entries included) as soon as
+// the strip before it has been read by every wave.  Strip 0 uses the slots of the one-strip kernel (tiles 0,1 behind the query
+// staging area, tiles 2.. in it), odd strips slots 8..15, even strips >= 2 slots 0..7.
+constexpr int BF_PX = 248;                       // compute units the persistent launch plans for (the tail workgroup and the distance-matrix tiles share the chip)
+constexpr size_t BF_LDS_BYTES_P = (size_t)(MF_WAVES * 4 + 2) * BF_TILE_F * 4 + (size_t)2 * MF_STRIP_TILES * 64 * 4;
+// every tile of strip `bx` + its augmentation entries (wave 0): a FIXED number of DMA instructions per wave, so that the wait in
+// front of the strip before it can name how many may stay in flight
+__device__ __forceinline__ void bf_request_strip(const float* __restrict__ vocab_bf, const float* __restrict__ row_norm, int n_rows, int bx,
+                                                 int tiles_per_block, int n_tiles, int lane, int wave, int col, int half, float* slots, float* aug_dst) {
+    constexpr int DPW = 8 / MF_WAVES;
+    const int tile0 = bx * tiles_per_block;
+    const int tile1 = min(tile0 + tiles_per_block, n_tiles);
+#pragma unroll
+    for (int i = 0; i < MF_STRIP_TILES; ++i) {
+        const int t = min(tile0 + i, max(tile1 - 1, tile0));
+        dma_tile_part(vocab_bf, n_rows, t, lane, slots + (size_t)i * BF_TILE_F, DPW * wave, DPW * wave + DPW);
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < MF_STRIP_TILES; ++i) {
+            const int t = min(tile0 + i, max(tile1 - 1, tile0));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row_norm + 2 * (size_t)min(t * 32 + col, n_rows) + half),
+                                             (__attribute__((address_space(3))) void*)(aug_dst + i * 64), 4, 0, 0);
+        }
+    }
+}
+// everything issued before the newest strip request has arrived (vector memory operations of gfx9 complete in issue order)
+__device__ __forceinline__ void bf_wait_all_but_request(int wave) {
+    constexpr int DPW = 8 / MF_WAVES;
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(MF_STRIP_TILES * DPW + MF_STRIP_TILES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(MF_STRIP_TILES * DPW) : "memory");
+}
+// a barrier that waits for this wave's LDS traffic only (__syncthreads() would also wait for the strip in flight)
+__device__ __forceinline__ void bf_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void knn_bf16_filter_body_p(float* s_dyn, int bid, const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
+                                                       int n_rows, const float* __restrict__ queries, int nq, int qpad,
+                                                       int tiles_per_block, int n_blocks, int px, uint64_t* __restrict__ partial_keys,
+                                                       uint32_t* __restrict__ partial_bound, const SelfdistJob& sd) {
+    constexpr int NG = 4;
+    constexpr int KH = 32;
+    constexpr int NW = BF_QB / (NG * 32);
+    constexpr int QW = NG * 32;
+    constexpr int DPW = 8 / NW;
+    if (bid < sd.n_tiles) { selfdist_tile(sd, bid, s_dyn); return; }
+    const int fb = bid - sd.n_tiles;
+    const int bx0 = fb % px, by = fb / px;
+    const int n_my = (n_blocks - bx0 + px - 1) / px;                 // strips of this workgroup: bx0, bx0 + px, ...
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int q0 = by * BF_QB + wave * QW;
+    float* s_q = s_dyn + (size_t)wave * NG * BF_TILE_F;
+    float* s_tile = s_dyn + (size_t)NW * NG * BF_TILE_F;
+    float* s_aug = s_tile + 2 * BF_TILE_F;                           // [2][MF_STRIP_TILES][64]
+    const int n_tiles = (n_rows + 31) / 32;
+    // ---- prologue: as the one-strip kernel, for strip bx0
+    {
+        const int tile0 = bx0 * tiles_per_block;
+        const int tile1 = min(tile0 + tiles_per_block, n_tiles);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) dma_a_tile<KH>(queries, nq, q0 / 32 + g, lane, s_q + g * BF_TILE_F);
+        float augs[MF_STRIP_TILES];
+#pragma unroll
+        for (int i = 0; i < MF_STRIP_TILES; ++i) {
+            const int t = min(tile0 + i, max(tile1 - 1, tile0));
+            augs[i] = row_norm[2 * (size_t)min(t * 32 + col, n_rows) + half];
+        }
+        if (tile0 < tile1) {
+            dma_tile_part(vocab_bf, n_rows, tile0, lane, s_tile, DPW * wave, DPW * wave + DPW);
+            dma_tile_part(vocab_bf, n_rows, min(tile0 + 1, tile1 - 1), lane, s_tile + BF_TILE_F, DPW * wave, DPW * wave + DPW);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < MF_STRIP_TILES; ++i) s_aug[i * 64 + lane] = augs[i];
+        }
+    }
+    uint4 bh[NG][4], bl[NG][4];
+    float b_aug[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        float x[KH];
+        read_a_tile<KH>(s_q + g * BF_TILE_F, col, half, x);
+        float part = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KH; ++k) part = fmaf(x[k], x[k], part);
+        const float qn = part + __shfl_xor(part, 32, 64);
+        b_aug[g] = half == 0 ? 1.0f : qn;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16_split2(-2.0f * x[8 * s + 0], -2.0f * x[8 * s + 1], bh[g][s].x, bl[g][s].x);
+            bf16_split2(-2.0f * x[8 * s + 2], -2.0f * x[8 * s + 3], bh[g][s].y, bl[g][s].y);
+            bf16_split2(-2.0f * x[8 * s + 4], -2.0f * x[8 * s + 5], bh[g][s].z, bl[g][s].z);
+            bf16_split2(-2.0f * x[8 * s + 6], -2.0f * x[8 * s + 7], bh[g][s].w, bl[g][s].w);
+        }
+    }
+    __syncthreads();                                                 // every wave has its queries in registers: the staging area is free
+    {
+        const int tile0 = bx0 * tiles_per_block;
+        const int tile1 = min(tile0 + tiles_per_block, n_tiles);
+        for (int t = tile0 + 2; t < tile1; ++t)
+            dma_tile_part(vocab_bf, n_rows, t, lane, s_dyn + (size_t)(t - tile0 - 2) * BF_TILE_F, DPW * wave, DPW * wave + DPW);
+    }
+    if (n_my > 1) bf_request_strip(vocab_bf, row_norm, n_rows, bx0 + px, tiles_per_block, n_tiles, lane, wave, col, half,
+                                   s_dyn + (size_t)8 * BF_TILE_F, s_aug + MF_STRIP_TILES * 64);
+    // ---- the strips
+    for (int s = 0; s < n_my; ++s) {
+        const int bx = bx0 + s * px;
+        const int tile0 = bx * tiles_per_block;
+        const int tile1 = min(tile0 + tiles_per_block, n_tiles);
+        if (s > 0) {
+            // strip s was requested one strip ago; behind it only the request of strip s + 1 (a fixed number of instructions) may
+            // still be in flight
+            if (s + 1 < n_my) bf_wait_all_but_request(wave); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bf_lds_barrier();
+        }
+        int32_t k0[NG], k1[NG], k2[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { k0[g] = MF_KEY_NONE; k1[g] = MF_KEY_NONE; k2[g] = MF_KEY_NONE; }
+        f32x16 p0, p1;
+        const float* aug_s = s_aug + (s & 1) * (MF_STRIP_TILES * 64);
+        for (int t = tile0; t < tile1; ++t) {
+            const int ti = t - tile0;
+            if (s == 0 && ti == 2) {                                 // strip 0, tiles 2.. : one wait and one barrier for all of them
+                if (n_my > 1) bf_wait_all_but_request(wave); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bf_lds_barrier();
+            }
+            uint4 ah[4], al[4];
+            float aug;
+            {
+                const float* slot = s == 0 ? (ti < 2 ? s_tile + ti * BF_TILE_F : s_dyn + (size_t)(ti - 2) * BF_TILE_F)
+                                           : s_dyn + (size_t)(((s & 1) ? 8 : 0) + ti) * BF_TILE_F;
+                const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(slot + col * 64);
+                uint32_t addr[8];
+                uint4 av[8];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    addr[v] = base + ((((uint32_t)(4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
+                    addr[4 + v] = base + ((((uint32_t)(8 + 4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
+                }
+                lds_read8_b128(addr, av, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(aug_s + ti * 64 + lane), aug);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { ah[v] = av[v]; al[v] = av[4 + v]; }
+            }
+            const uint32_t tl = (uint32_t)ti;
+            f32x16 x0, x1;
+            if (t == tile0) bf_pair<false>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, 0u, k0[2], k1[2], k2[2],
+                                           k0[3], k1[3], k2[3]);
+            else bf_pair<true>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, tl - 1u, k0[2], k1[2], k2[2], k0[3],
+                               k1[3], k2[3]);
+            bf_pair<true>(ah, al, aug, bh[2], bl[2], b_aug[2], bh[3], bl[3], b_aug[3], p0, p1, x0, x1, tl, k0[0], k1[0], k2[0], k0[1], k1[1], k2[1]);
+        }
+        if (tile0 < tile1) {
+            const uint32_t tlast = (uint32_t)(tile1 - 1 - tile0);
+            push_group(p0, tlast, k0[NG - 2], k1[NG - 2], k2[NG - 2]);
+            push_group(p1, tlast, k0[NG - 1], k1[NG - 1], k2[NG - 1]);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const uint64_t a0 = widen_key(k0[g], tile0, half), a1 = widen_key(k1[g], tile0, half), a2 = widen_key(k2[g], tile0, half);
+            const uint64_t b0 = shfl_xor_u64(a0, 32), b1 = shfl_xor_u64(a1, 32), b2 = shfl_xor_u64(a2, 32);
+            const uint64_t m0 = a0 < b0 ? a0 : b0;
+            const uint64_t hx = a0 < b0 ? b0 : a0, lx = a1 < b1 ? a1 : b1;
+            const uint64_t m1 = hx < lx ? hx : lx;
+            const uint64_t third = third_of_two_triples(a0, a1, a2, b0, b1, b2);
+            const int qi = q0 + g * 32 + col;
+            if (half == 0 && qi < qpad) {
+                uint64_t* dst = partial_keys + ((size_t)qi * n_blocks + bx) * BF_KEEP;
+                dst[0] = m0;
+                dst[1] = m1;
+                partial_bound[(size_t)qi * n_blocks + bx] = (uint32_t)min(third >> 32, (uint64_t)0x7f800000u);
+            }
+        }
+        if (s + 2 < n_my) {                                          // strip s is read by every wave: its slots take strip s + 2
+            bf_lds_barrier();
+            bf_request_strip(vocab_bf, row_norm, n_rows, bx0 + (s + 2) * px, tiles_per_block, n_tiles, lane, wave, col, half,
+                             s_dyn + (size_t)((s & 1) ? 8 : 0) * BF_TILE_F, s_aug + (s & 1) * (MF_STRIP_TILES * 64));
+        }
+    }
+}
+__global__ __launch_bounds__(256) void knn_bf16_filter_kernel_p(const float* __restrict__ vocab_bf, const float* __restrict__ row_norm, int n_rows,
+                                                                const float* __restrict__ queries, int nq, int qpad, int tiles_per_block, int n_blocks,
+                                                                int px, uint64_t* __restrict__ partial_keys, uint32_t* __restrict__ partial_bound,
+                                                                SelfdistJob sd) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn_p[];
+    knn_bf16_filter_body_p(s_dyn_p, (int)blockIdx.x, vocab_bf, row_norm, n_rows, queries, nq, qpad, tiles_per_block, n_blocks, px, partial_keys,
+                           partial_bound, sd);
+}
+
 // |bf16x3 filter score - reference distance| <= eps, u = 2^-24:
 //   split: bf16 keeps 8 significant bits (unit roundoff 2^-8): x = hi + lo + d with |lo| <= 2^-8 |x|, |d| <= 2^-8 |lo| <= 2^-16 |x|;
 //          the neglected ql.vl and the two d terms cost <= 3 * 2^-16 |q||v| (1 + 2^-7) on q.v, twice that on the score
@@ -999,6 +1192,17 @@ __global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel(FilterArgs f, int n
     knn_bf16_filter_body<4>(s_dyn_a, bid - has_tail, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, f.pk,
                             f.pl, f.sd);
 }
+// the same launch over a vocabulary of more strips than compute units: persistent filter workgroups (knn_bf16_filter_body_p)
+__global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel_p(FilterArgs f, int px, int n_tail_wgs, int n_filter_wgs, ResolveArgs r, FwArgs a,
+                                                               RetireArgs ret) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn_ap[];
+    const int bid = (int)blockIdx.x;
+    const int has_tail = n_tail_wgs > 0 ? 1 : 0;
+    if (bid < has_tail) { frame_tail_body<PIPE_BLOCK>((uint32_t*)s_dyn_ap, r, a, ret, 0, n_tail_wgs); return; }
+    if (bid >= has_tail + n_filter_wgs) { frame_tail_body<PIPE_BLOCK>((uint32_t*)s_dyn_ap, r, a, ret, bid - n_filter_wgs, n_tail_wgs); return; }
+    knn_bf16_filter_body_p(s_dyn_ap, bid - has_tail, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, px,
+                           f.pk, f.pl, f.sd);
+}
 __global__ __launch_bounds__(PIPE_BLOCK) void frame_b_kernel(RerankArgs k, int n_rerank_wgs, ScoreArgs A) {
     const int bid = (int)blockIdx.x;
     if (bid < n_rerank_wgs) {
@@ -1140,6 +1344,17 @@ hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void*
     vocab_bf16_kernel<<<(n * 16 + 255) / 256, 256, 0, s>>>((const float*)vocab, first, n, (uint32_t*)bf);
     return hipGetLastError();
 }
+// Persistent filter workgroups per block of 512 queries, or 0: the one-strip kernel (every strip gets its own workgroup; up to one
+// workgroup per compute unit that is the faster launch).  LCD_BF_PX overrides the number of compute units to plan for.
+static int bf16_persistent_px(const MfmaPlan& p) {
+    const char* env = getenv("LCD_BF_PX");                             // read per launch: tests shorten it to walk many strips
+    const int cus = env ? (atoi(env) < 0 ? 0 : atoi(env)) : BF_PX;
+    const int qchunks = (p.q + BF_QB - 1) / BF_QB;
+    if (cus == 0 || qchunks <= 0 || p.n_blocks * qchunks <= 256 || p.tiles_per_block != MF_STRIP_TILES) return 0;
+    const int px_max = cus / qchunks > 0 ? cus / qchunks : 1;
+    const int rounds = (p.n_blocks + px_max - 1) / px_max;
+    return (p.n_blocks + rounds - 1) / rounds;                          // equal shares: ceil(strips / rounds) workgroups of <= rounds strips
+}
 hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, const float* row_norm, const uint32_t* norm_max_bits,
                            const int32_t* row_id, const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word,
                            float* out_dist, int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
@@ -1167,8 +1382,15 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
             sd.queries = (const float*)queries; sd.nq = p.q; sd.out = const_cast<float*>(cb->selfdist); sd.ld = cb->ld; sd.n_tiles = T * (T + 1) / 2;
         }
         const int grid = sd.n_tiles + p.n_blocks * ((p.q + BF_QB - 1) / BF_QB);
+        const int px = bf16_persistent_px(p);
         if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
-        if (ng == 4)
+        if (px > 0) {
+            static const hipError_t attrp = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_bf16_filter_kernel_p),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES_P);
+            (void)attrp;
+            knn_bf16_filter_kernel_p<<<sd.n_tiles + px * ((p.q + BF_QB - 1) / BF_QB), 256, BF_LDS_BYTES_P, s>>>(
+                (const float*)vocab_bf, row_norm, p.n_rows, (const float*)queries, p.q, p.qpad, p.tiles_per_block, p.n_blocks, px, pk, pl, sd);
+        } else if (ng == 4)
             knn_bf16_filter_kernel<4><<<grid, 256, BF_LDS_BYTES, s>>>((const float*)vocab_bf, row_norm, p.n_rows, (const float*)queries, p.q,
                                                                        p.qpad, p.tiles_per_block, p.n_blocks, pk, pl, sd);
         else
@@ -1223,7 +1445,8 @@ hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* tail, hipStream_t 
         const int T = (p.q + 31) / 32;
         f.sd.queries = (const float*)k.queries; f.sd.nq = p.q; f.sd.out = const_cast<float*>(k.cb.selfdist); f.sd.ld = k.cb.ld; f.sd.n_tiles = T * (T + 1) / 2;
     }
-    const int n_filter = p.q > 0 ? f.sd.n_tiles + p.n_blocks * ((p.q + BF_QB - 1) / BF_QB) : 0;
+    const int px = p.q > 0 ? bf16_persistent_px(p) : 0;
+    const int n_filter = p.q > 0 ? f.sd.n_tiles + (px > 0 ? px : p.n_blocks) * ((p.q + BF_QB - 1) / BF_QB) : 0;
     const int n_tail = tail ? 1 + tail->n_redo : 0;
     if (n_filter + n_tail == 0) return hipSuccess;
     if (tail && tail->shmem > BF_LDS_BYTES) return hipErrorInvalidValue;
@@ -1231,7 +1454,13 @@ hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* tail, hipStream_t 
     if (tail) { r = tail->r; a = tail->a; ret = tail->ret; }
     hipError_t e;
     if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
-    frame_a_kernel<<<n_filter + n_tail, PIPE_BLOCK, BF_LDS_BYTES, s>>>(f, n_tail, n_filter, r, a, ret);
+    if (px > 0) {
+        static const hipError_t attrp = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel_p),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES_P);
+        (void)attrp;
+        frame_a_kernel_p<<<n_filter + n_tail, PIPE_BLOCK, BF_LDS_BYTES_P, s>>>(f, px, n_tail, n_filter, r, a, ret);
+    } else
+        frame_a_kernel<<<n_filter + n_tail, PIPE_BLOCK, BF_LDS_BYTES, s>>>(f, n_tail, n_filter, r, a, ret);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }

@@ -171,14 +171,19 @@ def test_frame_dev_stream_pipelined_handle(oracle):
     _run_stream(oracle, "surf", n_frames=70, q=128, wm=330, pipeline=1, seed=9)
 
 
-def test_pipelined_frames_enqueued_back_to_back(oracle):
+# (72 000 words, 700 descriptors: 282 strips x 2 blocks of 512 queries -- the launches with persistent filter workgroups,
+# knn_bf16_filter_kernel_p on the plain handle and frame_a_kernel_p on the pipelined one)
+@pytest.mark.parametrize("n_words,q", [(6000, 200), (72000, 700)])
+def test_pipelined_frames_enqueued_back_to_back(oracle, n_words, q):
     """Frames enqueued without waiting for each other (the bench's pattern) on a pipelined handle -- the tail of frame t - 1 rides in
     the filter launch of frame t, its scoring in the re-rank launch, retirements and the hypothesis keep their place: every frame's
     word ids, likelihood and hypothesis equal the unpipelined handle's, bit for bit."""
     import rtabmap_amd
-    n_words, n_sig, q, T = 6000, 900, 200, 12
+    n_sig, T = 900, 12
     vocab = synth.vocab_surf(n_words, seed=41)
     words = synth.zipf_words(n_sig, q, n_words, seed=42)
+    if n_words > 6000:      # every word referenced at least once: Memory::update would drop the others (cleanUnusedWords), this test never does
+        words.reshape(-1)[-n_words:] = np.arange(1, n_words + 1, dtype=np.int32)
     ids = np.arange(1, n_words + 1, dtype=np.int32)
     frames = [torch.from_numpy(synth.frame_from_signature(vocab, words[(37 * t) % n_sig], seed=50 + t)).cuda() for t in range(T)]
     out = {}

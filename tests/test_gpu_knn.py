@@ -24,7 +24,9 @@ def _check(eng, oracle, vocab, ids, queries, removed=None):
     np.testing.assert_array_equal(got_d, d)          # bit-exact, also for float32 L2
 
 
-@pytest.mark.parametrize("n,q", [(49000, 500), (49000, 1000), (5000, 77), (257, 64), (3, 5)])
+# the last two: more strips of 256 words than compute units -> the persistent filter workgroups (knn_bf16_filter_body_p), 2 and 1
+# blocks of 512 queries, a ragged last strip
+@pytest.mark.parametrize("n,q", [(49000, 500), (49000, 1000), (5000, 77), (257, 64), (3, 5), (70001, 1000), (150003, 300)])
 def test_knn2_surf_bit_exact(oracle, n, q):
     v = synth.vocab_surf(n)
     qs = synth.queries_surf(v, q)
@@ -210,6 +212,29 @@ def test_knn2_filter_error_bound_on_wide_range_descriptors(oracle, monkeypatch, 
     _check(eng, oracle, v, ids, q)
     r = eng.stats()["knn_max_err_ratio"]
     assert 0.0 < r < 0.5, r
+    eng.close()
+
+
+@pytest.mark.parametrize("px", ["24", "7", "0"])
+def test_knn2_persistent_filter_many_strips_per_workgroup(oracle, monkeypatch, px):
+    """LCD_BF_PX plans the persistent filter for fewer compute units than the chip has: every workgroup walks 23 (px = 24: 12
+    workgroups per block of 512 queries) or 92 (px = 7: 3 workgroups) strips through the two LDS strip buffers, the last of them
+    ragged, unequal strip counts between workgroups; 0 switches the persistent launch off.  Bit-exact against the oracle each time,
+    tombstoned rows included."""
+    monkeypatch.setenv("LCD_BF_PX", px)
+    n, q = 70001, 1000
+    v = synth.vocab_surf(n, seed=21)
+    qs = synth.queries_surf(v, q, seed=22)
+    ids = np.arange(1, n + 1, dtype=np.int32)
+    eng = _engine("f32", 64)
+    eng.vocab_append(v, ids)
+    _check(eng, oracle, v, ids, qs)
+    rng = np.random.default_rng(23)
+    gone = np.unique(rng.integers(0, n, 3000))
+    eng.vocab_remove(ids[gone])
+    removed = np.zeros(n, np.uint8)
+    removed[gone] = 1
+    _check(eng, oracle, v, ids, qs, removed=removed)
     eng.close()
 
 
