@@ -592,15 +592,16 @@ def main():
         state = {"next": n_sig + 1, "old": 1, "like": None, "first_new": N_WORDS + 1}
 
         def step(i):
-            _, state["like"] = sh.frame(d_frames[i % n_frames], state["next"], float(n_sig + 1), incremental=True, new_words_compared=True,
-                                        nndr=NNDR, first_new_word_id=state["first_new"])
+            # the all-reduce of frame i runs under the nearest-neighbour search of frame i + 1; its likelihood comes back one call later
+            sh.frame(d_frames[i % n_frames], state["next"], float(n_sig + 1), incremental=True, new_words_compared=True,
+                     nndr=NNDR, first_new_word_id=state["first_new"], defer=True)
             sh.retire(state["old"])
             state["next"] += 1
             state["old"] += 1
             state["first_new"] += Q
         res = timed_loop(torch, dist, world, stream, step, args.steps, args.warmup, profile_eng=sh.eng)
         roof_knn, roof_score = rooflines(sh.eng, sh.hi - sh.lo, n_sig, True)
-        like = state["like"].cpu().numpy()
+        like = sh.flush().cpu().numpy()                    # the last frame's (every timed step finalised its predecessor's)
         sh.close()
         frames_total = args.steps
     else:
@@ -633,7 +634,8 @@ def main():
               "world_size_observed": world, "collective_backend": backend, "signatures_bulk_load_s": build_s,
               "pipeline": "software-pipelined frames: 2 launches per frame (filter of frame t + tail of frame t-1; re-rank of frame t + "
                           "scoring of frame t-1), one stream" if (args.pipeline and not shard) else "4 launches per frame, one stream",
-              "parallelism": ("vocabulary sharded by word-id range over %d GPUs (all-gather top-2 + int64 all-reduce per frame)" % world) if shard
+              "parallelism": ("vocabulary sharded by word-id range over %d GPUs (all-gather top-2 + int64 all-reduce per frame, the all-reduce "
+                              "overlapped with the next frame's search)" % world) if shard
               else ("%d independent replicas (one frame stream per GPU, no data-path collective)" % world if world > 1 else "1 GPU")}
 
     if not shard:

@@ -9,6 +9,11 @@ the vocabulary rows and the references of those words; per frame there are exact
 Everything else (same-frame resolution, registration of the frame, scoring of the owned words) runs replicated / locally
 in the engine (lcd_shard_knn2_dev / lcd_shard_frame_dev / lcd_finalize_dev).  This module is plumbing: torch tensors hold
 the exchange buffers, torch.distributed moves them.
+
+frame(..., defer=True) overlaps the all-reduce of frame t with the nearest-neighbour search of frame t + 1 (SURVEY.md hard
+part 9): the reduction runs on a second stream, the likelihood of frame t is finalised -- and handed back -- inside the call
+for frame t + 1, before that frame touches the index (the same one-frame deferral as the single-GPU pipelined handle);
+retirements asked for in between wait in a queue until then, so every frame sees exactly the state the undeferred order gives.
 """
 import numpy as np
 import torch
@@ -39,6 +44,11 @@ class ShardedLoopClosure:
         self.total_rows = 0
         self.lo = self.hi = 0            # owned word-id range (ids lo+1 .. hi when ids are 1..n in row order)
         self._bufs = {}
+        self.comm = None                 # second stream: the deferred all-reduce (created on first use)
+        self._pending = None             # (lfix, like, n_slots, event: all-reduce done) of the frame whose likelihood is owed
+        self._retire_q = []              # retirements asked for while a likelihood is owed
+        self._n_frames = 0
+        self._owed_single = None
 
     # ---- state
     def load_vocabulary(self, rows, word_ids):
@@ -60,7 +70,29 @@ class ShardedLoopClosure:
         self.eng.sig_add_bulk(sig_ids, offsets, mine, ni)
 
     def retire(self, sig_id):
-        self.eng.sig_remove(sig_id)
+        if self._pending is not None:    # the owed likelihood is finalised against the signature table as its frame left it
+            self._retire_q.append(int(sig_id))
+        else:
+            self.eng.sig_remove(sig_id)
+
+    def _complete_pending(self):
+        """Finalise the owed likelihood (engine stream waits for its all-reduce), then apply the queued retirements."""
+        like, self._owed_single = self._owed_single, None       # (world 1: the fused frame has finalised it already)
+        if self._pending is not None:
+            lfix, like_buf, n_slots, done = self._pending
+            self._pending = None
+            self.stream.wait_event(done)
+            with torch.cuda.stream(self.stream):
+                self.eng.finalize_dev(lfix.data_ptr(), n_slots, like_buf.data_ptr())
+            like = like_buf[:n_slots]
+        for s in self._retire_q:
+            self.eng.sig_remove(s)
+        self._retire_q = []
+        return like
+
+    def flush(self):
+        """The likelihood still owed after the last frame(defer=True) (None if there is none); queued retirements are applied."""
+        return self._complete_pending()
 
     # ---- collectives (RCCL directly on device tensors; other backends are staged through the host: tests only)
     def _all_gather(self, out, inp):
@@ -74,13 +106,13 @@ class ShardedLoopClosure:
             dist.all_gather(parts, inp.cpu(), group=self.group)
             out.copy_(torch.cat(parts).reshape(out.shape).to(out.device))
 
-    def _all_reduce_sum(self, t):
+    def _all_reduce_sum(self, t, stream=None):
         if self.world == 1:
             return
         if self.backend == "nccl":
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         else:
-            self.stream.synchronize()
+            (stream or self.stream).synchronize()
             c = t.cpu()
             dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
             t.copy_(c.to(t.device))
@@ -98,40 +130,66 @@ class ShardedLoopClosure:
         return t
 
     # ---- one frame
-    def frame(self, d_desc, sig_id, N, incremental=True, new_words_compared=True, nndr=0.8, want_likelihood=True, first_new_word_id=0):
-        """d_desc: [q, dim] device tensor.  Returns (word ids int32 [q], likelihood float32 [n_slots]) device tensors."""
+    def frame(self, d_desc, sig_id, N, incremental=True, new_words_compared=True, nndr=0.8, want_likelihood=True, first_new_word_id=0,
+              defer=False):
+        """d_desc: [q, dim] device tensor.  Returns (word ids int32 [q], likelihood float32 [n_slots]) device tensors.
+        defer=True: the likelihood returned is the PREVIOUS deferred frame's (None if there is none; flush() hands out the last) --
+        this frame's all-reduce is left running on the second stream, under the next frame's nearest-neighbour search.  The
+        buffers alternate between two sets: a returned tensor stays valid until the second frame after it."""
         q = d_desc.shape[0]
+        par = self._n_frames & 1
+        self._n_frames += 1
         if self.world == 1:
             # one rank owns everything: the sharded frame IS the single-GPU frame (fused launches, no exchange)
+            prev = self._complete_pending()
             with torch.cuda.stream(self.stream):
-                words = self._buf("words", (q,), torch.int32)
+                words = self._buf("words%d" % par, (q,), torch.int32)
                 _, n_slots = self.eng.slots_dev()
-                like = self._buf("like", (n_slots + 2,), torch.float32)
+                like = self._buf("like%d" % par, (n_slots + 2,), torch.float32)
                 self.eng.frame_dev(d_desc.data_ptr(), q, sig_id, N, words.data_ptr(), like.data_ptr() if want_likelihood else None,
                                    like.shape[0], incremental=incremental, new_words_compared=new_words_compared, nndr=nndr,
                                    first_new_word_id=first_new_word_id)
                 _, n_slots = self.eng.slots_dev()
+            if defer and want_likelihood:                 # nothing to overlap; the same contract: one frame late
+                self._owed_single = like[:n_slots]
+                return words[:q], prev
             return words[:q], like[:n_slots]
         with torch.cuda.stream(self.stream):
             cand = self._buf("cand", (q * 2 * 2,), torch.int64)                  # 16-byte records as 2 x int64
             allc = self._buf("allc", (self.world * q * 2 * 2,), torch.int64)
-            words = self._buf("words", (q,), torch.int32)
+            words = self._buf("words%d" % par, (q,), torch.int32)
             cand, allc = cand[: q * 4], allc[: self.world * q * 4]
-            self.eng.shard_knn2_dev(d_desc.data_ptr(), q, cand.data_ptr())
+            self.eng.shard_knn2_dev(d_desc.data_ptr(), q, cand.data_ptr())      # (the owed all-reduce runs under this)
             self._all_gather(allc, cand)
+        prev = self._complete_pending()                   # before this frame's registration and scoring touch the index
+        with torch.cuda.stream(self.stream):
             _, n_slots = self.eng.slots_dev()
             cap = n_slots + 1
-            lfix = self._buf("lfix", (max(cap, 1),), torch.int64)
-            like = self._buf("like", (max(cap, 1),), torch.float32)
+            lfix = self._buf("lfix%d" % par, (max(cap, 1),), torch.int64)
+            like = self._buf("like%d" % par, (max(cap, 1),), torch.float32)
             self.eng.shard_frame_dev(d_desc.data_ptr(), q, sig_id, N, self.rank, self.world, allc.data_ptr(), self.total_rows,
                                      words.data_ptr(), lfix.data_ptr() if want_likelihood else None, lfix.shape[0],
                                      incremental=incremental, new_words_compared=new_words_compared, nndr=nndr,
                                      first_new_word_id=first_new_word_id)
             _, n_slots = self.eng.slots_dev()
-            if want_likelihood:
+            if want_likelihood and not defer:
                 self._all_reduce_sum(lfix[:n_slots])
                 self.eng.finalize_dev(lfix.data_ptr(), n_slots, like.data_ptr())
-        return words[:q], like[:n_slots]
+        if not want_likelihood:
+            return words[:q], (prev if defer else None)
+        if not defer:
+            return words[:q], like[:n_slots]
+        if self.comm is None:
+            self.comm = torch.cuda.Stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(self.stream)
+        self.comm.wait_event(ready)
+        with torch.cuda.stream(self.comm):                # RCCL orders its own stream behind the current one: behind `ready`
+            self._all_reduce_sum(lfix[:n_slots], stream=self.comm)
+        done = torch.cuda.Event()
+        done.record(self.comm)
+        self._pending = (lfix, like, n_slots, done)
+        return words[:q], prev
 
     def close(self):
         self.eng.close()

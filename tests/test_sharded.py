@@ -73,18 +73,38 @@ def _gpu_worker(rank, world, port, out):
     words = synth.zipf_words(n_sig, q, n_words, seed=3)
     sig_ids = np.arange(1, n_sig + 1, dtype=np.int32)
     offsets = np.arange(0, (n_sig + 1) * q, q, dtype=np.int64)
-    sh = ShardedLoopClosure("f32", 64, rank=rank, world=world, device=0, stream=torch.cuda.Stream())
-    sh.load_vocabulary(vocab, ids)
-    sh.add_signatures_bulk(sig_ids, offsets, words.reshape(-1))
-    res = []
-    for t in range(4):
-        desc = synth.frame_from_signature(vocab, words[37 * t + 5], seed=t)
-        w, like = sh.frame(torch.from_numpy(desc).cuda(), n_sig + 1 + t, float(n_sig + 1 + t))
-        torch.cuda.synchronize()
-        res.append((w.cpu().numpy().copy(), like.cpu().numpy().copy()))
-        if t == 2:
-            sh.retire(3)
-    sh.close()
+    runs = {}
+    for defer in (False, True):
+        sh = ShardedLoopClosure("f32", 64, rank=rank, world=world, device=0, stream=torch.cuda.Stream())
+        sh.load_vocabulary(vocab, ids)
+        sh.add_signatures_bulk(sig_ids, offsets, words.reshape(-1))
+        res = []
+        if not defer:
+            for t in range(4):
+                desc = synth.frame_from_signature(vocab, words[37 * t + 5], seed=t)
+                w, like = sh.frame(torch.from_numpy(desc).cuda(), n_sig + 1 + t, float(n_sig + 1 + t))
+                torch.cuda.synchronize()
+                res.append((w.cpu().numpy().copy(), like.cpu().numpy().copy()))
+                if t == 2:
+                    sh.retire(3)
+        else:
+            # frames enqueued back to back, the likelihood of frame t handed out by the call for frame t + 1 (its all-reduce runs
+            # under that frame's nearest-neighbour search); the retirement asked for after frame 2 must not reach frame 2's vector
+            ws, likes = [], []
+            for t in range(4):
+                desc = synth.frame_from_signature(vocab, words[37 * t + 5], seed=t)
+                w, prev = sh.frame(torch.from_numpy(desc).cuda(), n_sig + 1 + t, float(n_sig + 1 + t), defer=True)
+                ws.append(w.cpu().numpy().copy())
+                assert (prev is None) == (t == 0)
+                if prev is not None:
+                    likes.append(prev.cpu().numpy().copy())
+                if t == 2:
+                    sh.retire(3)
+            likes.append(sh.flush().cpu().numpy().copy())
+            assert sh.flush() is None
+            res = list(zip(ws, likes))
+        sh.close()
+        runs[defer] = res
     if rank == 0:
         # single-GPU engine on the same inputs
         eng = rtabmap_amd.Engine("f32", 64)
@@ -102,10 +122,12 @@ def _gpu_worker(rank, world, port, out):
             eng.synchronize()
             n = n_sig + 1 + t
             w1, l1 = d_words.cpu().numpy(), d_like[:n].cpu().numpy()
-            if not np.array_equal(w1, res[t][0]):
-                ok = False; msgs.append("word ids differ in frame %d" % t)
-            if not np.array_equal(l1.view(np.uint32), res[t][1].view(np.uint32)):
-                ok = False; msgs.append("likelihood not bit-identical in frame %d (max abs diff %g)" % (t, np.abs(l1 - res[t][1]).max()))
+            for defer, res in runs.items():
+                tag = " (deferred all-reduce)" if defer else ""
+                if not np.array_equal(w1, res[t][0]):
+                    ok = False; msgs.append("word ids differ in frame %d%s" % (t, tag))
+                if res[t][1].shape != l1.shape or not np.array_equal(l1.view(np.uint32), res[t][1].view(np.uint32)):
+                    ok = False; msgs.append("likelihood not bit-identical in frame %d%s" % (t, tag))
             if int(np.argmax(l1[:n_sig])) != 37 * t + 5:
                 ok = False; msgs.append("arg-max is not the revisited place in frame %d" % t)
             if t == 2:
