@@ -247,15 +247,24 @@ int lcd_bayes_configure(lcd_engine* h, const double* prediction_lc, int n_values
 int lcd_bayes_reset(lcd_engine* h);
 /* The graph neighbourhood of n_sigs registered signatures: for signature sig_ids[i] the entries [offsets[i], offsets[i+1]) of
  * nbr_sig_ids / nbr_margins are what Memory::getNeighborsId(id, prediction_lc.size() - 1, 0, false, false, true, true) returned
- * (BayesFilter.cpp:328, :581) -- the signature itself with margin 0 included, margins in [0, n_values - 2].  Like the reference's
- * incremental update (:583-592) every entry is also entered into the neighbour's own list (an existing entry for the same pair is
- * replaced), so a signature's list is passed once, when it enters the working memory.  Neighbours that are not registered are
- * skipped (they are in the long-term memory and can not be in a likelihood).  Host pointers. */
+ * (BayesFilter.cpp:328, :581) -- the signature itself with margin 0 included, margins in [0, n_values - 2].  The list REPLACES
+ * what the engine held for that signature (the reference's _neighborsIndex entry of a new id is exactly this answer), and like the
+ * reference's incremental update (:583-592) every entry is also entered into the neighbour's own list (an existing entry for the
+ * same pair is replaced) -- so a signature's list is passed once, when it enters the working memory, and keeps growing through the
+ * lists of the signatures that come after it; passing every list again (Bayes/FullPredictionUpdate = true, :328-352) rebuilds them
+ * all.  Neighbours that are not registered are skipped (they are in the long-term memory and can not be in a likelihood).  Host
+ * pointers. */
 int lcd_bayes_set_neighbors(lcd_engine* h, int n_sigs, const int32_t* sig_ids, const int64_t* offsets, const int32_t* nbr_sig_ids,
                             const int32_t* nbr_margins);
 /* One filter update from an adjusted likelihood that is already on the device: d_adjusted[n_slots + 1] laid out as lcd_frame_dev
  * writes it (entry 0 = virtual place, entry 1 + slot).  Enqueued, not synchronised.  d_posterior (may be NULL) like d_adjusted. */
 int lcd_bayes_update_dev(lcd_engine* h, const float* d_adjusted, int exclude_recent, float* d_posterior, lcd_bayes_result* d_result);
+/* BayesFilter::computePosterior(memory, likelihood) (:145-235) with the likelihood as the std::map hands it out: n parallel host
+ * entries in ascending id order, the virtual place (id -1) first (Rtabmap.cpp:2111-2115 always compares against it; a likelihood
+ * without it is LCD_ERR_UNSUPPORTED).  The other ids must be every registered signature up to the newest one named -- the working
+ * memory without the short-term memory, the list Rtabmap.cpp:2046-2115 builds.  Synchronises; *result (may be NULL) receives the
+ * highest hypothesis (Rtabmap.cpp:2147-2158); lcd_bayes_posterior reads the vector. */
+int lcd_bayes_update(lcd_engine* h, const int32_t* sig_ids, const float* adjusted, int n, lcd_bayes_result* result);
 /* the filter's current posterior for some signatures (host arrays; unknown / never considered signatures -> 0); sig id -1 = the
  * virtual place.  Synchronises. */
 int lcd_bayes_posterior(lcd_engine* h, const int32_t* sig_ids, int n, float* out);

@@ -23,7 +23,7 @@ SYMBOLS = [
     "lcd_knn2", "lcd_selfdist", "lcd_quantize", "lcd_find_nn",
     "lcd_sig_add", "lcd_sig_remove", "lcd_sig_add_bulk", "lcd_sig_count", "lcd_word_nrefs",
     "lcd_likelihood", "lcd_adjust_likelihood", "lcd_adjust_likelihood_dev", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood", "lcd_profile_score_work", "lcd_set_option", "lcd_record_event",
-    "lcd_bayes_configure", "lcd_bayes_reset", "lcd_bayes_set_neighbors", "lcd_bayes_update_dev", "lcd_bayes_posterior",
+    "lcd_bayes_configure", "lcd_bayes_reset", "lcd_bayes_set_neighbors", "lcd_bayes_update_dev", "lcd_bayes_update", "lcd_bayes_posterior",
 ]
 
 
@@ -136,6 +136,7 @@ def load():
     L.lcd_bayes_reset.argtypes = [vp]
     L.lcd_bayes_set_neighbors.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.lcd_bayes_update_dev.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.lcd_bayes_update.argtypes = [vp, vp, vp, C.c_int, vp]
     L.lcd_bayes_posterior.argtypes = [vp, vp, C.c_int, vp]
     _lib = L
     return L
@@ -342,6 +343,15 @@ class Engine:
 
     def bayes_update_dev(self, d_adjusted_ptr, exclude_recent=0, d_posterior_ptr=None, d_result_ptr=None):
         self._ck(self.L.lcd_bayes_update_dev(self.h, d_adjusted_ptr, exclude_recent, d_posterior_ptr, d_result_ptr))
+
+    def bayes_update(self, sig_ids, adjusted):
+        """lcd_bayes_update: the likelihood as parallel host arrays in std::map order (-1 first); returns the highest hypothesis."""
+        s = np.ascontiguousarray(sig_ids, dtype=np.int32)
+        a = np.ascontiguousarray(adjusted, dtype=np.float32)
+        assert s.shape[0] == a.shape[0]
+        r = LcdBayesResult()
+        self._ck(self.L.lcd_bayes_update(self.h, _p(s), _p(a), s.shape[0], C.byref(r)))
+        return r
 
     def bayes_posterior(self, sig_ids):
         s = np.ascontiguousarray(sig_ids, dtype=np.int32)

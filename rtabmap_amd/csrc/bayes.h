@@ -81,8 +81,9 @@ struct Bayes {
     hipError_t configure(const double* lc, int n, float vp_prior);
     hipError_t ensure(int64_t n_slots, int k_needed = 0);
     hipError_t reset();
-    // pairs: (slot a, slot b, margin) triples, canonical (a <= b) and unique; both directions are entered
-    hipError_t link(const std::vector<int32_t>& triples);
+    // pairs: (slot a, slot b, margin) triples, canonical (a <= b) and unique; both directions are entered.  restart: slots whose own
+    // list is emptied first (the signatures the call lists: their list becomes what the call says, plus what later calls enter)
+    hipError_t link(const std::vector<int32_t>& triples, const std::vector<int32_t>& restart = std::vector<int32_t>());
     hipError_t ensure_scratch();
     // adjustLikelihood / filter update / hypotheses over the slots [0, n_cons) that are live (slot_sig != 0)
     hipError_t decide(const DecideArgs& d, const int32_t* slot_sig, int64_t n_slots, int64_t n_cons);

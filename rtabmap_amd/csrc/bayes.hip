@@ -524,6 +524,23 @@ __global__ __launch_bounds__(256) void bayes_link_kernel(const int32_t* __restri
     if ((w & 1) == 0) list_insert(nbr, cnt, K, a, b, m, overflow, lane);
     else if (a != b) list_insert(nbr, cnt, K, b, a, m, overflow, lane);
 }
+// the lists of the signatures a call names start over (the reference's _neighborsIndex entry of a new id IS what getNeighborsId
+// returned, BayesFilter.cpp:581-592): every entry back to "unused", one wavefront per list
+__global__ __launch_bounds__(256) void bayes_clear_kernel(const int32_t* __restrict__ slots, int n, uint32_t* __restrict__ nbr, int32_t* __restrict__ cnt, int K) {
+    const int w = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (w >= n) return;
+    const int32_t s = slots[w];
+    for (int k = lane; k < K; k += 64) nbr[tile_at(s, k, K)] = 0xFFFFFFFFu;
+    if (lane == 0) cnt[s] = 0;
+}
+struct ClearArgs { int32_t s[64]; };
+__global__ __launch_bounds__(256) void bayes_clear_small_kernel(ClearArgs a, int n, uint32_t* __restrict__ nbr, int32_t* __restrict__ cnt, int K) {
+    const int w = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (w >= n) return;
+    const int32_t s = a.s[w];
+    for (int k = lane; k < K; k += 64) nbr[tile_at(s, k, K)] = 0xFFFFFFFFu;
+    if (lane == 0) cnt[s] = 0;
+}
 // a few lists (one signature entering the working memory): the triples travel as kernel arguments, no staging copy
 constexpr int LINK_SMALL = 256;
 struct LinkArgs { int32_t t[3 * LINK_SMALL]; };
@@ -624,7 +641,29 @@ hipError_t Bayes::reset() {
     return hipSuccess;
 }
 
-hipError_t Bayes::link(const std::vector<int32_t>& triples) {
+hipError_t Bayes::link(const std::vector<int32_t>& triples, const std::vector<int32_t>& restart) {
+    // lists that start over; one that has never held an entry needs no launch (the usual case: a signature's list is passed once)
+    std::vector<int32_t> dirty;
+    for (int32_t s : restart) {
+        if (s < 0 || s >= (int64_t)cnt_ub.size() || cnt_ub[s] == 0) continue;
+        cnt_ub[s] = 0;
+        dirty.push_back(s);
+    }
+    if (!dirty.empty()) {
+        const int nd = (int)dirty.size();
+        const int blocks = (int)(((int64_t)nd * 64 + 255) / 256);
+        if (nd <= 64) {
+            ClearArgs a;
+            memcpy(a.s, dirty.data(), dirty.size() * 4);
+            bayes_clear_small_kernel<<<blocks, 256, 0, stream>>>(a, nd, nbr.as<uint32_t>(), cnt.as<int32_t>(), K);
+        } else {
+            BY_TRY(pairs.reserve(dirty.size() * 4, 0, stream, bytes));
+            BY_TRY(hipMemcpyAsync(pairs.p, dirty.data(), dirty.size() * 4, hipMemcpyHostToDevice, stream));
+            BY_TRY(hipStreamSynchronize(stream));
+            bayes_clear_kernel<<<blocks, 256, 0, stream>>>(pairs.as<int32_t>(), nd, nbr.as<uint32_t>(), cnt.as<int32_t>(), K);
+        }
+        BY_TRY(hipGetLastError());
+    }
     const int n = (int)(triples.size() / 3);
     if (n == 0) return hipSuccess;
     // room for every entry this call may add (an entry that replaces an existing one is counted again: the bound only grows)

@@ -59,7 +59,8 @@ struct lcd_engine {
     struct Deferred { bool valid = false; lcd_frame_args a; lcd::ResolveArgs r; } deferred;
     std::vector<int32_t> deferred_retire;               // lcd_sig_remove calls made while a frame's index stage is owed
     std::vector<void*> deferred_events;                 // lcd_record_event calls made while a frame's index stage is owed
-    std::vector<std::vector<int32_t> > deferred_links;  // lcd_bayes_set_neighbors calls made while a frame's index stage is owed
+    struct DeferredLink { std::vector<int32_t> triples, restart; };
+    std::vector<DeferredLink> deferred_links;           // lcd_bayes_set_neighbors calls made while a frame's index stage is owed
     int sync_all();                                     // stream drained
     int drain();                                        // complete the owed index stage (stand-alone launches)
     const char* prof2_kernel = "score_kernel";

@@ -825,9 +825,9 @@ static int frame_stage_s(lcd_engine* h, const lcd_frame_args& a, ResolveArgs r) 
 static int finish_deferred_tail(lcd_engine* h) {
     for (int32_t sig : h->deferred_retire) LCD_HIP(h, h->tfidf.retire(sig));
     h->deferred_retire.clear();
-    for (const std::vector<int32_t>& tr : h->deferred_links) {
+    for (const lcd_engine::DeferredLink& dl : h->deferred_links) {
         LCD_HIP(h, h->bayes.ensure(std::max<int64_t>(h->tfidf.n_slots, 1)));
-        const hipError_t e = h->bayes.link(tr);
+        const hipError_t e = h->bayes.link(dl.triples, dl.restart);
         if (e == hipErrorInvalidValue) { h->deferred_links.clear(); return h->fail(LCD_ERR_UNSUPPORTED, "lcd_bayes_set_neighbors: a neighbour list longer than 8192 entries"); }
         LCD_HIP(h, e);
     }
@@ -1001,8 +1001,7 @@ int lcd_bayes_set_neighbors(lcd_engine* h, int n_sigs, const int32_t* sig_ids, c
     Tfidf& t = h->tfidf;
     if (t.n_slots >= (1ll << BAYES_SLOT_BITS)) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_bayes_set_neighbors: at most 2^27 signature slots");
     const int max_margin = h->bayes.prm.n_lc - 2;
-    std::vector<uint64_t> keys;                               // (slot a << 32 | slot b), a <= b; the margin rides in a parallel map
-    std::vector<int32_t> triples;
+    std::vector<int32_t> triples, restart;                    // restart: the slots of the listed signatures (their lists start over)
     std::unordered_map<uint64_t, int32_t> seen;
     seen.reserve((size_t)(offsets[n_sigs] - offsets[0]) * 2 + 16);
     // the signature of a frame whose index stage is still owed has no slot yet: it will get the next one
@@ -1018,6 +1017,7 @@ int lcd_bayes_set_neighbors(lcd_engine* h, int n_sigs, const int32_t* sig_ids, c
     for (int i = 0; i < n_sigs; ++i) {
         const int64_t a = slot_of(sig_ids[i]);
         if (a < 0) return h->fail(LCD_ERR_STATE, "lcd_bayes_set_neighbors: unknown signature");
+        restart.push_back((int32_t)a);
         if (offsets[i + 1] < offsets[i]) return h->fail(LCD_ERR_INVALID, "lcd_bayes_set_neighbors: offsets must not decrease");
         for (int64_t e = offsets[i]; e < offsets[i + 1]; ++e) {
             const int32_t m = nbr_margins[e];
@@ -1032,9 +1032,9 @@ int lcd_bayes_set_neighbors(lcd_engine* h, int n_sigs, const int32_t* sig_ids, c
             triples.push_back((int32_t)std::min(a, b)); triples.push_back((int32_t)std::max(a, b)); triples.push_back(m);
         }
     }
-    if (h->deferred.valid) { h->deferred_links.push_back(std::move(triples)); return LCD_OK; }
+    if (h->deferred.valid) { h->deferred_links.push_back(lcd_engine::DeferredLink{std::move(triples), std::move(restart)}); return LCD_OK; }
     LCD_HIP(h, h->bayes.ensure(std::max<int64_t>(t.n_slots, 1)));
-    const hipError_t le = h->bayes.link(triples);
+    const hipError_t le = h->bayes.link(triples, restart);
     if (le == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_bayes_set_neighbors: a neighbour list longer than 8192 entries");
     LCD_HIP(h, le);
     return LCD_OK;
@@ -1051,6 +1051,44 @@ int lcd_bayes_update_dev(lcd_engine* h, const float* d_adjusted, int exclude_rec
     DecideArgs d;
     d.adj_in = d_adjusted; d.bayes = true; d.d_posterior = d_posterior; d.d_bayes = (BayesOut*)d_result;
     LCD_HIP(h, h->bayes.decide(d, t.slot_sig.as<int32_t>(), t.n_slots, n_cons));
+    return LCD_OK;
+}
+
+int lcd_bayes_update(lcd_engine* h, const int32_t* sig_ids, const float* adjusted, int n, lcd_bayes_result* result) {
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (n < 1 || !sig_ids || !adjusted) return h->fail(LCD_ERR_INVALID, "lcd_bayes_update: bad argument");
+    if (!h->bayes.configured) return h->fail(LCD_ERR_STATE, "lcd_bayes_update: lcd_bayes_configure first");
+    if (sig_ids[0] != -1) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_bayes_update: the likelihood must start with the virtual place (id -1)");
+    Tfidf& t = h->tfidf;
+    LCD_HIP(h, t.flush_retire());
+    // scatter the map into slot order; its keys must be the registered signatures without the most recently registered ones
+    const size_t bytes = ((size_t)t.n_slots + 1) * 4;
+    LCD_HIP(h, h->h_in.reserve(bytes));
+    float* adj = (float*)h->h_in.p;
+    std::memset(adj, 0, bytes);
+    adj[0] = adjusted[0];
+    int64_t n_cons = 0;
+    for (int i = 1; i < n; ++i) {
+        if (sig_ids[i] <= sig_ids[i - 1]) return h->fail(LCD_ERR_INVALID, "lcd_bayes_update: ids must ascend (std::map order)");
+        auto it = t.sig_slot.find(sig_ids[i]);
+        if (it == t.sig_slot.end()) return h->fail(LCD_ERR_INVALID, "lcd_bayes_update: a signature of the likelihood is not registered");
+        adj[(size_t)it->second + 1] = adjusted[i];
+        n_cons = std::max<int64_t>(n_cons, it->second + 1);
+    }
+    int64_t live_below = 0;
+    for (const auto& kv : t.sig_slot) live_below += kv.second < n_cons ? 1 : 0;
+    if (live_below != (int64_t)n - 1)
+        return h->fail(LCD_ERR_UNSUPPORTED, "lcd_bayes_update: the likelihood must hold every registered signature up to its newest one "
+                                            "(the working memory without the short-term memory)");
+    LCD_HIP(h, dreserve(h, h->d_adj_scratch, bytes));
+    LCD_HIP(h, hipMemcpyAsync(h->d_adj_scratch.p, adj, bytes, hipMemcpyHostToDevice, h->stream));
+    DecideArgs d;
+    d.adj_in = h->d_adj_scratch.as<float>(); d.bayes = true; d.d_bayes = (BayesOut*)h->d_hyp_scratch.p;
+    LCD_HIP(h, h->bayes.decide(d, t.slot_sig.as<int32_t>(), t.n_slots, n_cons));
+    lcd_bayes_result r;
+    { int rc = download(h, &r, h->d_hyp_scratch.p, sizeof(r), h->h_out); if (rc) return rc; }   // (synchronises: h_in is free again)
+    if (result) *result = r;
     return LCD_OK;
 }
 

@@ -1,11 +1,20 @@
 // MemoryHip.cpp -- see MemoryHip.h.
 #include "MemoryHip.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <set>
 
 namespace rtabmap_amd {
 
-MemoryHip::MemoryHip(const ParametersMap& parameters, int device) : _vwd(new VWDictionaryHip(parameters, device)), _idCount(0) {}
+const int MemoryHip::kIdVirtual = -1;
+
+MemoryHip::MemoryHip(const ParametersMap& parameters, int device) : _vwd(new VWDictionaryHip(parameters, device)), _idCount(0), _maxStMemSize(10) {
+    ParametersMap::const_iterator it = parameters.find("Mem/STMSize");
+    if (it != parameters.end()) _maxStMemSize = atoi(it->second.c_str());
+    if (_maxStMemSize < 0) _maxStMemSize = 0;
+    _workingMem.insert(kIdVirtual);             // Memory.cpp:592
+}
 MemoryHip::~MemoryHip() { delete _vwd; }
 
 void MemoryHip::cleanUnusedWords() {   // Memory.cpp:6899-6920 (no database: the words are deleted)
@@ -46,7 +55,67 @@ int MemoryHip::update(const Mat& descriptors, int nQuantized, std::vector<int>& 
     }
     _signatures[id] = std::vector<int>(wordIds.begin(), wordIds.end());
     outIds.assign(wordIds.begin(), wordIds.end());
+    this->addSignatureToStm(id);
     return id;
+}
+
+// Memory::addSignatureToStm :1146-1230 (the neighbour link to the newest signature of the short-term memory; poses and covariances
+// are out of scope) followed by the transfer loop of Memory::update :1112-1135 (no intermediate nodes here: every signature counts)
+void MemoryHip::addSignatureToStm(int id) {
+    if (_stMem.size()) {
+        const int last = *_stMem.rbegin();
+        _links[id][last] = kNeighbor;
+        _links[last][id] = kNeighbor;
+    }
+    _stMem.insert(id);
+    while (_stMem.size() && _maxStMemSize > 0 && (int)_stMem.size() > _maxStMemSize) {
+        const int oldest = *_stMem.begin();     // moveSignatureToWMFromSTM :1442-1500 without graph reduction
+        _workingMem.insert(oldest);
+        _stMem.erase(oldest);
+    }
+}
+
+// Memory::addLink :3877-3935 for a loop closure between two signatures in memory: nothing to do (true) when they are linked
+// already, false + error when one of them is not in the working / short-term memory (weights are out of scope)
+bool MemoryHip::addLink(int from, int to, LinkType type) {
+    if (!_signatures.count(from) || !_signatures.count(to)) {
+        if (!_signatures.count(from)) fprintf(stderr, "[ERROR] from=%d, to=%d, Signature %d not found in working/st memories\n", from, to, from);
+        if (!_signatures.count(to)) fprintf(stderr, "[ERROR] from=%d, to=%d, Signature %d not found in working/st memories\n", from, to, to);
+        return false;
+    }
+    if (from == to) return false;
+    std::map<int, std::map<int, LinkType> >::const_iterator l = _links.find(to);
+    if (l != _links.end() && l->second.count(from)) return true;
+    _links[from][to] = type;
+    _links[to][from] = type;
+    return true;
+}
+
+// Memory::getNeighborsId(id, maxGraphDepth, 0, false, false, true, true) :1703-1893.  Level by level over the neighbour links; a
+// loop-closure link puts its far end on the SAME level as the node it leaves from (incrementMarginOnLoop = false) and a node is
+// taken that way only once per call; nodes that are not in memory are neither reported nor expanded (maxCheckedInDatabase = 0).
+// Intermediate nodes, landmarks and local-space closures do not exist in this subset.  maxGraphDepth = 0: no limit.
+std::map<int, int> MemoryHip::getNeighborsId(int signatureId, int maxGraphDepth) const {
+    std::map<int, int> found;
+    if (signatureId <= 0 || maxGraphDepth < 0) return found;
+    std::set<int> nextLevel, viaClosure;
+    nextLevel.insert(signatureId);
+    for (int margin = 0; (maxGraphDepth == 0 || margin < maxGraphDepth) && !nextLevel.empty(); ++margin) {
+        std::list<int> level(nextLevel.rbegin(), nextLevel.rend());       // most recent first, as the reference walks a level
+        nextLevel.clear();
+        for (std::list<int>::iterator n = level.begin(); n != level.end(); ++n) {
+            if (found.count(*n) || !_signatures.count(*n)) continue;
+            found[*n] = margin;
+            std::map<int, std::map<int, LinkType> >::const_iterator links = _links.find(*n);
+            if (links == _links.end()) continue;
+            for (std::map<int, LinkType>::const_iterator l = links->second.begin(); l != links->second.end(); ++l) {
+                if (found.count(l->first)) continue;
+                if (l->second == kNeighbor) nextLevel.insert(l->first);
+                else if (viaClosure.insert(l->first).second) level.push_back(l->first);
+            }
+        }
+    }
+    return found;
 }
 
 int MemoryHip::addSignature(const std::vector<int>& wordIds, int id) {
@@ -55,6 +124,7 @@ int MemoryHip::addSignature(const std::vector<int>& wordIds, int id) {
     for (size_t k = 0; k < wordIds.size(); ++k) if (wordIds[k] > 0) _vwd->addWordRef(wordIds[k], id);
     _signatures[id] = wordIds;
     if (id > _idCount) _idCount = id;
+    _workingMem.insert(id);                     // Memory::loadDataFromDb: loaded signatures enter the working memory (:447-480)
     return id;
 }
 
@@ -72,6 +142,8 @@ void MemoryHip::forget(int signatureId) {
     for (std::set<int>::iterator k = keys.begin(); k != keys.end(); ++k) _vwd->removeAllWordRef(*k, signatureId);
     _dbNi[signatureId] = (int)it->second.size();
     _signatures.erase(it);
+    _stMem.erase(signatureId);                  // the links stay (they are in the database): getNeighborsId stops at the missing node
+    _workingMem.erase(signatureId);
 }
 
 std::vector<int> MemoryHip::signatureIds() const {

@@ -3,10 +3,15 @@
 // Mirrors (reference corelib/src/Memory.cpp): preUpdate :1004-1016 + cleanUnusedWords :6899-6920, the quantisation glue
 // of createSignature :5941-6059 (features not sent to quantisation get ids -1,-2,.. and still count in ni),
 // getNi :4955-4968, disableWordsRef :6877-6897 (WM -> LTM transfer) and computeLikelihood :2177-2292 (TF-IDF branch).
-// Everything else of Memory (graph, database, sensors) is out of scope.
+// For the Bayes filter it also keeps what BayesFilter asks a Memory: the short-term / working memory
+// split (addSignatureToStm :1146-1230, the transfer loop of update() :1112-1135, moveSignatureToWMFromSTM :1442), neighbour and
+// loop-closure links between signatures, and getNeighborsId :1703-1893 restricted to the arguments BayesFilter passes
+// (BayesFilter.cpp:329: maxCheckedInDatabase = 0, loop closures stay on the margin of the node they leave from).
+// Everything else of Memory (poses, database, sensors, rehearsal) is out of scope.
 #pragma once
 #include <list>
 #include <map>
+#include <set>
 #include <vector>
 
 #include "VWDictionaryHip.h"
@@ -31,6 +36,22 @@ public:
     std::map<int, float> computeLikelihood(int signatureId, const std::list<int>& ids);
     std::map<int, float> computeLikelihood(const std::list<int>& wordIds, const std::list<int>& ids);
 
+    // ---- what BayesFilter::computePosterior asks
+    enum LinkType { kNeighbor = 0, kGlobalClosure = 1 };   // Link::Type (Link.h:42-56), the two kinds this subset creates
+    static const int kIdVirtual;                           // -1 (Memory.cpp:71)
+    // loop-closure link between two signatures in memory (Memory::addLink :3500-3590: refused when either is missing, when
+    // from == to or when the two are already linked)
+    bool addLink(int from, int to, LinkType type = kGlobalClosure);
+    std::map<int, int> getNeighborsId(int signatureId, int maxGraphDepth) const;
+    bool isInSTM(int signatureId) const { return _stMem.find(signatureId) != _stMem.end(); }
+    bool isInWM(int signatureId) const { return _workingMem.find(signatureId) != _workingMem.end(); }
+    const std::set<int>& getStMem() const { return _stMem; }
+    const std::set<int>& getWorkingMem() const { return _workingMem; }   // kIdVirtual included, as in the reference
+    int getMaxStMemSize() const { return _maxStMemSize; }
+    // every signature's references are on the device (the Bayes filter works on registered signatures)
+    bool flushReferences() { return _vwd->flushReferences([this](int s) { return this->getNi(s); }); }
+    const std::string& lastError() const { return _vwd->lastError(); }
+
 private:
     void preUpdate();
     void cleanUnusedWords();
@@ -38,6 +59,10 @@ private:
     std::map<int, std::vector<int> > _signatures;   // id -> words in keypoint order (Signature::getWords keys)
     std::map<int, int> _dbNi;                       // DBDriver::getInvertedIndexNi of transferred nodes
     int _idCount;
+    void addSignatureToStm(int id);
+    std::set<int> _stMem, _workingMem;
+    int _maxStMemSize;                              // Mem/STMSize (Parameters.h: 10)
+    std::map<int, std::map<int, LinkType> > _links; // Signature::getLinks(): id -> (other id -> type)
 };
 
 }  // namespace rtabmap_amd

@@ -104,6 +104,9 @@ public:
     std::map<int, float> computeLikelihood(const std::list<int>& wordIds, const std::list<int>& ids, float N,
                                            const std::function<int(int)>& getNi);
 
+    // send the references added / removed since the last call to the device's inverted index (computeLikelihood does it itself)
+    bool flushReferences(const std::function<int(int)>& getNi);
+
     // ids of the indexed rows in device row order (the tie-break order); for tests
     std::vector<int> getIndexedWordIds() const;
     bool isAvailable() const { return _engine != nullptr; }
@@ -114,7 +117,6 @@ protected:
     int getNextId() { return ++_lastWordId; }
     bool ensureEngine(int type, int cols) const;
     void markDirty(int signatureId);
-    bool flushReferences(const std::function<int(int)>& getNi);
 
 protected:
     std::map<int, VisualWord*> _visualWords;

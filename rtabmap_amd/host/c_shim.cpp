@@ -2,6 +2,7 @@
 // host mirror exactly as they drive the oracle (same call sequence, same argument meaning).  Not part of lcd.h.
 #include <cstring>
 
+#include "BayesFilterHip.h"
 #include "MemoryHip.h"
 
 using namespace rtabmap_amd;
@@ -80,6 +81,11 @@ int hvwd_export_text(void* h, const char* refs, const char* desc) { ((VWDictiona
 void* hmem_create(int strategy, int incremental, float nndr, int together, const char* dictPath, int device) {
     return new MemoryHip(make_params(strategy, incremental, nndr, together, dictPath), device);
 }
+void* hmem_create_stm(int strategy, int incremental, float nndr, int together, const char* dictPath, int device, int stmSize) {
+    ParametersMap p = make_params(strategy, incremental, nndr, together, dictPath);
+    p["Mem/STMSize"] = std::to_string(stmSize);
+    return new MemoryHip(p, device);
+}
 void hmem_destroy(void* h) { delete (MemoryHip*)h; }
 void* hmem_vwd(void* h) { return ((MemoryHip*)h)->getVWDictionary(); }
 int hmem_update(void* h, const void* desc, int rows, int cols, int type, int nq, int* outIds) {
@@ -100,5 +106,53 @@ int hmem_compute_likelihood(void* h, const int* words, int nwords, const int* id
     for (std::map<int, float>::iterator i = L.begin(); i != L.end(); ++i, ++n) { outIds[n] = i->first; out[n] = i->second; }
     return n;
 }
+
+// type 1: Memory::addLink of a global loop closure; type 0: a neighbour link as the database hands it to a replayed signature
+int hmem_add_link(void* h, int from, int to, int type) {
+    return ((MemoryHip*)h)->addLink(from, to, type == 0 ? MemoryHip::kNeighbor : MemoryHip::kGlobalClosure) ? 1 : 0;
+}
+int hmem_get_neighbors_id(void* h, int sigId, int maxGraphDepth, int* outIds, int* outMargins, int cap) {
+    std::map<int, int> n = ((MemoryHip*)h)->getNeighborsId(sigId, maxGraphDepth);
+    int k = 0;
+    for (std::map<int, int>::iterator i = n.begin(); i != n.end(); ++i, ++k) if (k < cap) { outIds[k] = i->first; outMargins[k] = i->second; }
+    return (int)n.size();
+}
+// which: 0 short-term memory, 1 working memory (the virtual place -1 included)
+int hmem_ids(void* h, int which, int* out, int cap) {
+    const std::set<int>& s = which == 0 ? ((MemoryHip*)h)->getStMem() : ((MemoryHip*)h)->getWorkingMem();
+    int k = 0;
+    for (std::set<int>::const_iterator i = s.begin(); i != s.end(); ++i, ++k) if (k < cap) out[k] = *i;
+    return (int)s.size();
+}
+
+void* hbayes_create(const char* predictionLC, float virtualPlacePrior, int fullPredictionUpdate) {
+    ParametersMap p;
+    if (predictionLC && predictionLC[0]) p["Bayes/PredictionLC"] = predictionLC;
+    p["Bayes/VirtualPlacePriorThr"] = std::to_string(virtualPlacePrior);
+    p["Bayes/FullPredictionUpdate"] = fullPredictionUpdate ? "true" : "false";
+    return new BayesFilterHip(p);
+}
+void hbayes_destroy(void* b) { delete (BayesFilterHip*)b; }
+void hbayes_reset(void* b) { ((BayesFilterHip*)b)->reset(); }
+void hbayes_set_prediction_lc(void* b, const char* s) { ((BayesFilterHip*)b)->setPredictionLC(s); }
+int hbayes_get_prediction_lc(void* b, double* out, int cap) {
+    const std::vector<double>& v = ((BayesFilterHip*)b)->getPredictionLC();
+    for (size_t i = 0; i < v.size() && (int)i < cap; ++i) out[i] = v[i];
+    return (int)v.size();
+}
+// BayesFilter::computePosterior(memory, likelihood); returns the size of the posterior map, written to outIds / out; hyp = the
+// highest hypothesis (id, value) as Rtabmap.cpp:2147-2158 reads it off
+int hbayes_compute_posterior(void* b, void* mem, const int* ids, const float* values, int n, int* outIds, float* out, int cap, int* hypId,
+                             float* hypValue) {
+    std::map<int, float> L;
+    for (int i = 0; i < n; ++i) L[ids[i]] = values[i];
+    const std::map<int, float>& P = ((BayesFilterHip*)b)->computePosterior((MemoryHip*)mem, L);
+    int k = 0;
+    for (std::map<int, float>::const_iterator i = P.begin(); i != P.end(); ++i, ++k) if (k < cap) { outIds[k] = i->first; out[k] = i->second; }
+    if (hypId) *hypId = ((BayesFilterHip*)b)->getHighestHypothesis().first;
+    if (hypValue) *hypValue = ((BayesFilterHip*)b)->getHighestHypothesis().second;
+    return (int)P.size();
+}
+const char* hbayes_last_error(void* b) { return ((BayesFilterHip*)b)->lastError().c_str(); }
 
 }  // extern "C"

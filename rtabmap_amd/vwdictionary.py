@@ -52,6 +52,20 @@ def lib():
         L.hvwd_export_text.argtypes = [vp, C.c_char_p, C.c_char_p]
         L.hmem_create.restype = vp
         L.hmem_create.argtypes = [ci, ci, cf, ci, C.c_char_p, ci]
+        L.hmem_create_stm.restype = vp
+        L.hmem_create_stm.argtypes = [ci, ci, cf, ci, C.c_char_p, ci, ci]
+        L.hmem_add_link.argtypes = [vp, ci, ci, ci]
+        L.hmem_get_neighbors_id.argtypes = [vp, ci, ci, vp, vp, ci]
+        L.hmem_ids.argtypes = [vp, ci, vp, ci]
+        L.hbayes_create.restype = vp
+        L.hbayes_create.argtypes = [C.c_char_p, cf, ci]
+        L.hbayes_destroy.argtypes = [vp]
+        L.hbayes_reset.argtypes = [vp]
+        L.hbayes_set_prediction_lc.argtypes = [vp, C.c_char_p]
+        L.hbayes_get_prediction_lc.argtypes = [vp, vp, ci]
+        L.hbayes_compute_posterior.argtypes = [vp, vp, vp, vp, ci, vp, vp, ci, vp, vp]
+        L.hbayes_last_error.argtypes = [vp]
+        L.hbayes_last_error.restype = C.c_char_p
         L.hmem_destroy.argtypes = [vp]
         L.hmem_vwd.restype = vp
         L.hmem_vwd.argtypes = [vp]
@@ -155,9 +169,9 @@ class VWDictionaryHip:
 
 class MemoryHip:
     def __init__(self, strategy=kNNBruteForceHIP, incremental=True, nndr=0.8, new_words_compared_together=True,
-                 dictionary_path="", device=0):
-        self.h = lib().hmem_create(strategy, int(incremental), float(nndr), int(new_words_compared_together),
-                                   dictionary_path.encode(), device)
+                 dictionary_path="", device=0, stm_size=10):
+        self.h = lib().hmem_create_stm(strategy, int(incremental), float(nndr), int(new_words_compared_together),
+                                       dictionary_path.encode(), device, int(stm_size))
         self.vwd = VWDictionaryHip(_handle=lib().hmem_vwd(self.h), _owner=self)
 
     def close(self):
@@ -191,6 +205,31 @@ class MemoryHip:
     def num_signatures(self):
         return int(lib().hmem_num_signatures(self.h))
 
+    def add_link(self, a, b, neighbor=False):
+        """Memory::addLink for a global loop closure between two signatures in memory (neighbor=True: an odometry link of a
+        signature replayed from the database)."""
+        return bool(lib().hmem_add_link(self.h, a, b, 0 if neighbor else 1))
+
+    def get_neighbors_id(self, sig_id, max_graph_depth):
+        cap = 4096
+        ids, mg = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        n = lib().hmem_get_neighbors_id(self.h, sig_id, max_graph_depth, _p(ids), _p(mg), cap)
+        assert n <= cap
+        return dict(zip(ids[:n].tolist(), mg[:n].tolist()))
+
+    def _ids(self, which):
+        n = lib().hmem_ids(self.h, which, None, 0)
+        out = np.zeros(max(n, 1), np.int32)
+        lib().hmem_ids(self.h, which, _p(out), n)
+        return out[:n].tolist()
+
+    def st_mem(self):
+        return self._ids(0)
+
+    def working_mem(self):
+        """Ids of the working memory, the virtual place (-1) first, as Memory::getWorkingMem()."""
+        return self._ids(1)
+
     def compute_likelihood(self, words, ids):
         w = np.ascontiguousarray(words, dtype=np.int32)
         i = np.ascontiguousarray(ids, dtype=np.int32)
@@ -198,3 +237,47 @@ class MemoryHip:
         out = np.zeros(max(i.shape[0], 1), np.float32)
         n = lib().hmem_compute_likelihood(self.h, _p(w), w.shape[0], _p(i), i.shape[0], _p(oid), _p(out))
         return oid[:n], out[:n]
+
+
+class BayesFilterHip:
+    """rtabmap::BayesFilter's interface over the device filter (rtabmap_amd/host/BayesFilterHip.h)."""
+
+    def __init__(self, prediction_lc="", virtual_place_prior=0.9, full_prediction_update=False):
+        self.h = lib().hbayes_create(prediction_lc.encode(), float(virtual_place_prior), int(full_prediction_update))
+        self.highest_hypothesis = (0, 0.0)
+
+    def close(self):
+        if self.h:
+            lib().hbayes_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        lib().hbayes_reset(self.h)
+
+    def set_prediction_lc(self, s):
+        lib().hbayes_set_prediction_lc(self.h, s.encode())
+
+    def get_prediction_lc(self):
+        out = np.zeros(64, np.float64)
+        n = lib().hbayes_get_prediction_lc(self.h, _p(out), 64)
+        return out[:n].copy()
+
+    def compute_posterior(self, memory, ids, values):
+        """likelihood = {ids[i]: values[i]}; returns (ids, posterior) in std::map order."""
+        i = np.ascontiguousarray(ids, dtype=np.int32)
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        cap = max(i.shape[0], 1) + 8
+        oid, out = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+        hid, hv = C.c_int(0), C.c_float(0.0)
+        n = lib().hbayes_compute_posterior(self.h, memory.h, _p(i), _p(v), i.shape[0], _p(oid), _p(out), cap, C.byref(hid), C.byref(hv))
+        self.highest_hypothesis = (hid.value, hv.value)
+        return oid[:n].copy(), out[:n].copy()
+
+    def last_error(self):
+        return lib().hbayes_last_error(self.h).decode()

@@ -118,3 +118,90 @@ def test_error_paths_return_empty_like_the_reference(oracle):
     f = VWDictionaryHip(incremental=False)
     assert f.add_new_words(synth.vocab_surf(4), 1) == []                      # fixed dictionary without words
     d.close(); f.close()
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_bayes_filter_hip_behind_the_reference_interface(oracle, full):
+    """BayesFilterHip::computePosterior(memory, likelihood) -- the reference's call (Rtabmap.cpp:2131) -- frame after frame against the
+    restated BayesFilter on the same adjusted likelihood: MemoryHip keeps the short-term / working memory split, the neighbour link
+    of addSignatureToStm and the loop closures of addLink, answers getNeighborsId; the filter hands each new id's neighbourhood to
+    the device (Bayes/FullPredictionUpdate = false, the reference's default) or every id's on every call (true).  Signatures are
+    transferred out of the memory along the way.  Posterior entry by entry, the same highest hypothesis."""
+    import collections
+    from rtabmap_amd.vwdictionary import BayesFilterHip, MemoryHip
+    from bayes_model import DEFAULT_LC
+    from test_host_memory_graph import _search
+    T, q, STM = 64, 80, 5
+    frames = _frames("surf", T, q, base_n=900)
+    o = oracle.OracleMemory(strategy=oracle.kNNBruteForce)
+    ob = oracle.OracleBayesFilter(DEFAULT_LC)
+    h = MemoryHip(stm_size=STM)
+    hb = BayesFilterHip(full_prediction_update=full)
+    odom, loop = collections.defaultdict(set), collections.defaultdict(set)
+    alive, stm = set(), []
+    depth = DEFAULT_LC.shape[0] - 1
+    n_updates = 0
+    for t in range(T):
+        so, wo = o.update(frames[t])
+        sh, wh = h.update(frames[t])
+        assert (sh, wh) == (so, wo)
+        if stm:
+            odom[stm[-1]].add(sh); odom[sh].add(stm[-1])
+        stm.append(sh); alive.add(sh)
+        while len(stm) > STM:
+            stm.pop(0)
+        assert h.st_mem() == stm
+        wm = h.working_mem()
+        assert wm == [-1] + sorted(alive - set(stm))
+        if len(wm) < 3:
+            continue
+        ids = np.array(wm, np.int32)
+        hi, Lh = h.compute_likelihood(np.array(wh, np.int32), ids)
+        assert hi.tolist() == wm
+        adj = oracle.adjust_likelihood(Lh)                       # Rtabmap::adjustLikelihood, restated: the same input for both filters
+        for s in wm[1:]:                                         # what Memory::getNeighborsId answers right now
+            d = _search(odom, loop, alive, s, depth)
+            k = sorted(d)
+            ob.set_neighbors(s, k, [d[x] for x in k])
+        ob.set_stm(stm)
+        exp = ob.compute_posterior(ids, adj, dense=True, incremental=not full)
+        pid, post = hb.compute_posterior(h, ids, adj)
+        assert pid.tolist() == wm, hb.last_error()
+        pos = exp > 0
+        r = float(np.median(post[pos].astype(np.float64) / exp[pos].astype(np.float64)))
+        assert abs(r - 1.0) <= 2e-6, (t, r)
+        np.testing.assert_allclose(post, exp.astype(np.float64) * r, rtol=2e-5, atol=1e-9, err_msg="frame %d" % t)
+        hid, hval = oracle.OracleBayesFilter.hypothesis(ids, exp)
+        gid, gval = hb.highest_hypothesis
+        np.testing.assert_allclose(gval, hval, rtol=1e-5, atol=1e-6)
+        top = np.sort(exp[1:].astype(np.float64))[::-1]
+        if len(top) < 2 or top[0] - top[1] > 1e-4 * top[0]:
+            assert gid == hid, t
+        n_updates += 1
+        # the graph changes: a loop closure between the newest signature of the working memory and an old one; the oldest leaves
+        if t % 9 == 5 and len(wm) > 12:
+            a, b = wm[-1], wm[1 + (t % 5)]
+            assert h.add_link(a, b)
+            loop[a].add(b); loop[b].add(a)
+        if t % 11 == 7 and len(wm) > 20:
+            x = wm[1]
+            o.forget(x); h.forget(x)
+            alive.discard(x)
+    assert n_updates > 40
+    # BayesFilter::reset: the next posterior starts from scratch
+    hb.reset(); ob.reset()
+    wm = h.working_mem()
+    ids = np.array(wm, np.int32)
+    adj = np.ones(len(wm), np.float32); adj[0] = 2.0; adj[len(wm) // 2] = 7.0
+    for s in wm[1:]:
+        d = _search(odom, loop, alive, s, depth)
+        k = sorted(d)
+        ob.set_neighbors(s, k, [d[x] for x in k])
+    exp = ob.compute_posterior(ids, adj, dense=True, incremental=not full)
+    pid, post = hb.compute_posterior(h, ids, adj)
+    np.testing.assert_allclose(post, exp, rtol=3e-5, atol=1e-9)
+    # a likelihood that leaves out a signature of the working memory is not what the device state describes: refused, loudly
+    before = hb.compute_posterior(h, ids, adj)[1]
+    pid2, post2 = hb.compute_posterior(h, np.delete(ids, 3), np.delete(adj, 3))
+    assert "working memory" in hb.last_error() and pid2.tolist() == wm
+    hb.close(); h.close()
