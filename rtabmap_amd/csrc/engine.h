@@ -59,6 +59,7 @@ struct lcd_engine {
     struct Deferred { bool valid = false; lcd_frame_args a; lcd::ResolveArgs r; } deferred;
     std::vector<int32_t> deferred_retire;               // lcd_sig_remove calls made while a frame's index stage is owed
     std::vector<void*> deferred_events;                 // lcd_record_event calls made while a frame's index stage is owed
+    int filter_units = -1;                              // lcd_set_option("filter_units")
     struct DeferredLink { std::vector<int32_t> triples, restart; };
     std::vector<DeferredLink> deferred_links;           // lcd_bayes_set_neighbors calls made while a frame's index stage is owed
     int sync_all();                                     // stream drained

@@ -92,7 +92,8 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
     const bool mfma = main_vocab && h->knn_mode != 0 && knn_mfma_supported(h->dtype, h->kdim) && n_rows >= 256;
     const KnnPlan p = knn_plan(q, (int)n_rows, h->row_bytes);
     if (mfma && h->knn_mode == 2) {
-        const MfmaPlan mp = knn_bf16_plan(q, (int)n_rows);
+        MfmaPlan mp = knn_bf16_plan(q, (int)n_rows);
+        mp.filter_units = h->filter_units;
         LCD_HIP(h, dreserve(h, h->d_partial2, knn_bf16_partial_bytes(mp)));
         LCD_HIP(h, dreserve(h, h->d_fail_list, (size_t)q * 4));
         const bool prof = h->prof_cap > 0 && h->prof_n < h->prof_cap;
@@ -864,6 +865,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     // ---- this frame's 2-NN stage: buffers of the current scratch set
     PipeKnn k;
     k.plan = knn_bf16_plan(q, (int)h->n_rows);
+    k.plan.filter_units = h->filter_units;
     LCD_HIP(h, dreserve(h, h->d_partial2, knn_bf16_partial_bytes(k.plan)));
     LCD_HIP(h, dreserve(h, h->d_fail_list, (size_t)q * 4));
     LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)h->n_rows, q)));
@@ -1257,6 +1259,8 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     { int rc = h->drain(); if (rc) return rc; }
     if (!key) return h->fail(LCD_ERR_INVALID, "lcd_set_option: null key");
     if (!std::strcmp(key, "score_block") && (value == 256 || value == 512 || value == 1024)) { h->tfidf.score_block = (int)value; return LCD_OK; }
+    // compute units the bf16 filter's persistent launch plans for (vocabularies of more 256-word strips than that): -1 built-in, 0 off
+    if (!std::strcmp(key, "filter_units") && value >= -1 && value <= 4096) { h->filter_units = (int)value; return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");
 }
 

@@ -1345,10 +1345,10 @@ hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void*
     return hipGetLastError();
 }
 // Persistent filter workgroups per block of 512 queries, or 0: the one-strip kernel (every strip gets its own workgroup; up to one
-// workgroup per compute unit that is the faster launch).  LCD_BF_PX overrides the number of compute units to plan for.
+// workgroup per compute unit that is the faster launch).  MfmaPlan::filter_units (lcd_set_option "filter_units") overrides the
+// number of compute units to plan for: tests shorten it to walk many strips per workgroup.
 static int bf16_persistent_px(const MfmaPlan& p) {
-    const char* env = getenv("LCD_BF_PX");                             // read per launch: tests shorten it to walk many strips
-    const int cus = env ? (atoi(env) < 0 ? 0 : atoi(env)) : BF_PX;
+    const int cus = p.filter_units >= 0 ? p.filter_units : BF_PX;
     const int qchunks = (p.q + BF_QB - 1) / BF_QB;
     if (cus == 0 || qchunks <= 0 || p.n_blocks * qchunks <= 256 || p.tiles_per_block != MF_STRIP_TILES) return 0;
     const int px_max = cus / qchunks > 0 ? cus / qchunks : 1;

@@ -72,7 +72,10 @@ struct RowparArgs {
 
 // ---- squared-L2 2-NN on the matrix cores (knn_mfma_kernels.hip): MFMA filter + exact re-rank + certificate.
 // Queries whose result cannot be certified are appended to fail_list / fail_count and redone by launch_knn_rowpar.
-struct MfmaPlan { int q, qpad, n_rows, tiles_per_block, n_blocks; };
+struct MfmaPlan {
+    int q, qpad, n_rows, tiles_per_block, n_blocks;
+    int filter_units = -1;   // compute units the persistent bf16 filter plans for (-1: built-in; 0: one workgroup per strip always)
+};
 bool knn_mfma_supported(int dtype, int dim);
 MfmaPlan knn_mfma_plan(int q, int n_rows);
 size_t knn_mfma_partial_bytes(const MfmaPlan& p);

@@ -215,18 +215,18 @@ def test_knn2_filter_error_bound_on_wide_range_descriptors(oracle, monkeypatch, 
     eng.close()
 
 
-@pytest.mark.parametrize("px", ["24", "7", "0"])
-def test_knn2_persistent_filter_many_strips_per_workgroup(oracle, monkeypatch, px):
-    """LCD_BF_PX plans the persistent filter for fewer compute units than the chip has: every workgroup walks 23 (px = 24: 12
-    workgroups per block of 512 queries) or 92 (px = 7: 3 workgroups) strips through the two LDS strip buffers, the last of them
-    ragged, unequal strip counts between workgroups; 0 switches the persistent launch off.  Bit-exact against the oracle each time,
-    tombstoned rows included."""
-    monkeypatch.setenv("LCD_BF_PX", px)
+@pytest.mark.parametrize("units", [24, 7, 0])
+def test_knn2_persistent_filter_many_strips_per_workgroup(oracle, units):
+    """lcd_set_option("filter_units") plans the persistent filter for fewer compute units than the chip has: every workgroup walks
+    23 (24 units: 12 workgroups per block of 512 queries) or 92 (7 units: 3 workgroups) strips through the two LDS strip buffers,
+    the last of them ragged, unequal strip counts between workgroups; 0 switches the persistent launch off.  Bit-exact against the
+    oracle each time, tombstoned rows included."""
     n, q = 70001, 1000
     v = synth.vocab_surf(n, seed=21)
     qs = synth.queries_surf(v, q, seed=22)
     ids = np.arange(1, n + 1, dtype=np.int32)
     eng = _engine("f32", 64)
+    eng.set_option("filter_units", units)
     eng.vocab_append(v, ids)
     _check(eng, oracle, v, ids, qs)
     rng = np.random.default_rng(23)
