@@ -601,7 +601,7 @@ def main():
             state["first_new"] += Q
         res = timed_loop(torch, dist, world, stream, step, args.steps, args.warmup, profile_eng=sh.eng)
         roof_knn, roof_score = rooflines(sh.eng, sh.hi - sh.lo, n_sig, True)
-        like = sh.flush().cpu().numpy()                    # the last frame's (every timed step finalised its predecessor's)
+        like = sh.flush().cpu().numpy()                    # the last frame's (every timed step finalised its predecessor's); flush waits for the engine stream
         sh.close()
         frames_total = args.steps
     else:

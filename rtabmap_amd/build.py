@@ -80,7 +80,7 @@ def _build_locked(verbose):
 
 
 HOST_OUT = os.path.join(HERE, "liblcd_host.so")
-HOST_SOURCES = ["VWDictionaryHip.cpp", "MemoryHip.cpp", "BayesFilterHip.cpp", "c_shim.cpp"]
+HOST_SOURCES = ["VWDictionaryHip.cpp", "MemoryHip.cpp", "BayesFilterHip.cpp", "RtabmapHip.cpp", "c_shim.cpp"]
 
 
 def build_host(force=False, verbose=False):

@@ -4,6 +4,7 @@
 
 #include "BayesFilterHip.h"
 #include "MemoryHip.h"
+#include "RtabmapHip.h"
 
 using namespace rtabmap_amd;
 
@@ -154,5 +155,40 @@ int hbayes_compute_posterior(void* b, void* mem, const int* ids, const float* va
     return (int)P.size();
 }
 const char* hbayes_last_error(void* b) { return ((BayesFilterHip*)b)->lastError().c_str(); }
+
+void* hrtab_create(float loopThr, float loopRatio, int virtualPlaceLikelihoodRatio, int stmSize, const char* predictionLC, float virtualPlacePrior,
+                   int device) {
+    ParametersMap p = make_params(5, 1, 0.8f, 1, "");
+    p["Rtabmap/LoopThr"] = std::to_string(loopThr);
+    p["Rtabmap/LoopRatio"] = std::to_string(loopRatio);
+    p["Rtabmap/VirtualPlaceLikelihoodRatio"] = std::to_string(virtualPlaceLikelihoodRatio);
+    p["Mem/STMSize"] = std::to_string(stmSize);
+    if (predictionLC && predictionLC[0]) p["Bayes/PredictionLC"] = predictionLC;
+    p["Bayes/VirtualPlacePriorThr"] = std::to_string(virtualPlacePrior);
+    return new RtabmapHip(p, device);
+}
+void hrtab_destroy(void* r) { delete (RtabmapHip*)r; }
+void* hrtab_memory(void* r) { return ((RtabmapHip*)r)->getMemory(); }
+// Rtabmap::process for one frame of descriptors; out4 = {last location id, highest hypothesis id, loop closure id, processed}
+int hrtab_process(void* r, const void* desc, int rows, int cols, int type, int* out4, float* outValues2) {
+    RtabmapHip* R = (RtabmapHip*)r;
+    const bool ok = R->process(make_mat(desc, rows, cols, type));
+    out4[0] = R->getLastLocationId(); out4[1] = R->getHighestHypothesisId(); out4[2] = R->getLoopClosureId(); out4[3] = ok ? 1 : 0;
+    outValues2[0] = R->getHighestHypothesisValue(); outValues2[1] = R->getLoopClosureValue();
+    return ok ? 1 : 0;
+}
+// which: 0 raw likelihood, 1 adjusted likelihood, 2 posterior of the last frame
+int hrtab_vector(void* r, int which, int* outIds, float* out, int cap) {
+    RtabmapHip* R = (RtabmapHip*)r;
+    const std::map<int, float>& m = which == 0 ? R->getRawLikelihood() : which == 1 ? R->getLikelihood() : R->getPosterior();
+    int k = 0;
+    for (std::map<int, float>::const_iterator i = m.begin(); i != m.end(); ++i, ++k) if (k < cap) { outIds[k] = i->first; out[k] = i->second; }
+    return (int)m.size();
+}
+int hrtab_last_word_ids(void* r, int* out, int cap) {
+    const std::vector<int>& v = ((RtabmapHip*)r)->getLastWordIds();
+    for (size_t i = 0; i < v.size() && (int)i < cap; ++i) out[i] = v[i];
+    return (int)v.size();
+}
 
 }  // extern "C"

@@ -90,9 +90,13 @@ class ShardedLoopClosure:
         self._retire_q = []
         return like
 
-    def flush(self):
-        """The likelihood still owed after the last frame(defer=True) (None if there is none); queued retirements are applied."""
-        return self._complete_pending()
+    def flush(self, synchronize=True):
+        """The likelihood still owed after the last frame(defer=True) (None if there is none); queued retirements are applied.
+        Like everything frame() returns, the tensor is written on the engine stream: synchronize=True waits for it."""
+        like = self._complete_pending()
+        if synchronize:
+            self.stream.synchronize()
+        return like
 
     # ---- collectives (RCCL directly on device tensors; other backends are staged through the host: tests only)
     def _all_gather(self, out, inp):
@@ -135,7 +139,8 @@ class ShardedLoopClosure:
         """d_desc: [q, dim] device tensor.  Returns (word ids int32 [q], likelihood float32 [n_slots]) device tensors.
         defer=True: the likelihood returned is the PREVIOUS deferred frame's (None if there is none; flush() hands out the last) --
         this frame's all-reduce is left running on the second stream, under the next frame's nearest-neighbour search.  The
-        buffers alternate between two sets: a returned tensor stays valid until the second frame after it."""
+        buffers alternate between two sets: a returned tensor stays valid until the second frame after it.  Returned tensors are
+        written on the engine stream (self.stream): read them there, or synchronise it first."""
         q = d_desc.shape[0]
         par = self._n_frames & 1
         self._n_frames += 1

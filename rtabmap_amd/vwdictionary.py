@@ -66,6 +66,14 @@ def lib():
         L.hbayes_compute_posterior.argtypes = [vp, vp, vp, vp, ci, vp, vp, ci, vp, vp]
         L.hbayes_last_error.argtypes = [vp]
         L.hbayes_last_error.restype = C.c_char_p
+        L.hrtab_create.restype = vp
+        L.hrtab_create.argtypes = [cf, cf, ci, ci, C.c_char_p, cf, ci]
+        L.hrtab_destroy.argtypes = [vp]
+        L.hrtab_memory.restype = vp
+        L.hrtab_memory.argtypes = [vp]
+        L.hrtab_process.argtypes = [vp, vp, ci, ci, ci, vp, vp]
+        L.hrtab_vector.argtypes = [vp, ci, vp, vp, ci]
+        L.hrtab_last_word_ids.argtypes = [vp, vp, ci]
         L.hmem_destroy.argtypes = [vp]
         L.hmem_vwd.restype = vp
         L.hmem_vwd.argtypes = [vp]
@@ -169,15 +177,16 @@ class VWDictionaryHip:
 
 class MemoryHip:
     def __init__(self, strategy=kNNBruteForceHIP, incremental=True, nndr=0.8, new_words_compared_together=True,
-                 dictionary_path="", device=0, stm_size=10):
-        self.h = lib().hmem_create_stm(strategy, int(incremental), float(nndr), int(new_words_compared_together),
-                                       dictionary_path.encode(), device, int(stm_size))
+                 dictionary_path="", device=0, stm_size=10, _handle=None, _owner=None):
+        self._owner = _owner                    # a RtabmapHip owns its memory
+        self.h = _handle if _handle is not None else lib().hmem_create_stm(
+            strategy, int(incremental), float(nndr), int(new_words_compared_together), dictionary_path.encode(), device, int(stm_size))
         self.vwd = VWDictionaryHip(_handle=lib().hmem_vwd(self.h), _owner=self)
 
     def close(self):
-        if self.h:
+        if self.h and self._owner is None:
             lib().hmem_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -281,3 +290,47 @@ class BayesFilterHip:
 
     def last_error(self):
         return lib().hbayes_last_error(self.h).decode()
+
+
+class RtabmapHip:
+    """The loop-closure detection block of Rtabmap::process (rtabmap_amd/host/RtabmapHip.h): one frame of descriptors in, the highest
+    hypothesis and the accepted loop closure out."""
+
+    def __init__(self, loop_thr=0.11, loop_ratio=0.0, virtual_place_likelihood_ratio=0, stm_size=10, prediction_lc="",
+                 virtual_place_prior=0.9, device=0):
+        self.h = lib().hrtab_create(float(loop_thr), float(loop_ratio), int(virtual_place_likelihood_ratio), int(stm_size),
+                                    prediction_lc.encode(), float(virtual_place_prior), device)
+        self.memory = MemoryHip(_handle=lib().hrtab_memory(self.h), _owner=self)
+
+    def close(self):
+        if self.h:
+            self.memory.h = None
+            lib().hrtab_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process(self, desc):
+        """-> dict(id, highest=(id, value), loop=(id, value))"""
+        desc = np.ascontiguousarray(desc)
+        out4 = np.zeros(4, np.int32)
+        val2 = np.zeros(2, np.float32)
+        lib().hrtab_process(self.h, _p(desc), desc.shape[0], desc.shape[1], _type_of(desc), _p(out4), _p(val2))
+        return {"id": int(out4[0]), "highest": (int(out4[1]), float(val2[0])), "loop": (int(out4[2]), float(val2[1])), "ok": bool(out4[3])}
+
+    def vector(self, which):
+        """which: "raw" | "likelihood" | "posterior" of the last frame -> (ids, values) in std::map order"""
+        w = {"raw": 0, "likelihood": 1, "posterior": 2}[which]
+        n = lib().hrtab_vector(self.h, w, None, None, 0)
+        ids, out = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float32)
+        lib().hrtab_vector(self.h, w, _p(ids), _p(out), n)
+        return ids[:n].copy(), out[:n].copy()
+
+    def last_word_ids(self):
+        out = np.zeros(16384, np.int32)
+        n = lib().hrtab_last_word_ids(self.h, _p(out), 16384)
+        return out[:n].tolist()

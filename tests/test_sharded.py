@@ -94,6 +94,7 @@ def _gpu_worker(rank, world, port, out):
             for t in range(4):
                 desc = synth.frame_from_signature(vocab, words[37 * t + 5], seed=t)
                 w, prev = sh.frame(torch.from_numpy(desc).cuda(), n_sig + 1 + t, float(n_sig + 1 + t), defer=True)
+                sh.stream.synchronize()                              # the tensors are written on the engine stream
                 ws.append(w.cpu().numpy().copy())
                 assert (prev is None) == (t == 0)
                 if prev is not None:
