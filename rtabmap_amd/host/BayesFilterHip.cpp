@@ -23,7 +23,7 @@ void logError(const std::string& m) { fprintf(stderr, "[ERROR] %s\n", m.c_str())
 }  // namespace
 
 BayesFilterHip::BayesFilterHip(const ParametersMap& parameters)
-    : _virtualPlacePrior(kDefaultVirtualPlacePrior), _fullPredictionUpdate(false), _configuredEngine(0), _highestHypothesis(0, 0.0f) {
+    : _virtualPlacePrior(kDefaultVirtualPlacePrior), _fullPredictionUpdate(false), _engine(0), _deviceConfigured(false), _highestHypothesis(0, 0.0f) {
     this->setPredictionLC(kDefaultPredictionLC);
     this->parseParameters(parameters);
 }
@@ -37,7 +37,7 @@ void BayesFilterHip::parseParameters(const ParametersMap& parameters) {   // Bay
         const float v = str2Float(iter->second);
         if (v >= 0.0f && v <= 1.0f) _virtualPlacePrior = v;               // the reference asserts the range (:68)
         else logError("Bayes/VirtualPlacePriorThr must be in [0, 1]: \"" + iter->second + "\" ignored");
-        _configuredEngine = 0;
+        _deviceConfigured = false;
     }
     if ((iter = parameters.find("Bayes/FullPredictionUpdate")) != parameters.end()) _fullPredictionUpdate = parseBool(iter->second);
 }
@@ -61,7 +61,7 @@ void BayesFilterHip::setPredictionLC(const std::string& prediction) {
         }
     }
     _predictionLC = tmpValues;
-    _configuredEngine = 0;               // _totalPredictionLCValues / _predictionEpsilon (:109-117) are derived on the device side
+    _deviceConfigured = false;           // _totalPredictionLCValues / _predictionEpsilon (:109-117) are derived on the device side
 }
 
 std::string BayesFilterHip::getPredictionLCStr() const {   // :130-142
@@ -79,18 +79,19 @@ void BayesFilterHip::reset() {   // :138-143
     _posterior.clear();
     _listedIds.clear();
     _highestHypothesis = std::pair<int, float>(0, 0.0f);
-    if (_configuredEngine && lcd_bayes_reset(_configuredEngine) != LCD_OK) logError(lcd_last_error(_configuredEngine));
+    if (_engine && lcd_bayes_reset(_engine) != LCD_OK) logError(lcd_last_error(_engine));
 }
 
 bool BayesFilterHip::configureDevice(lcd_engine* engine) {
-    if (_configuredEngine == engine) return true;
+    if (_engine == engine && _deviceConfigured) return true;
     if (_predictionLC.size() > 32) { _lastError = "Bayes/PredictionLC: at most 32 values"; return false; }
     if (lcd_bayes_configure(engine, _predictionLC.data(), (int)_predictionLC.size(), _virtualPlacePrior) != LCD_OK) {
         _lastError = lcd_last_error(engine);
         return false;
     }
-    if (_configuredEngine && _configuredEngine != engine) { _posterior.clear(); _listedIds.clear(); }   // another device state altogether
-    _configuredEngine = engine;
+    if (_engine && _engine != engine) { _posterior.clear(); _listedIds.clear(); }   // another device state altogether
+    _engine = engine;
+    _deviceConfigured = true;
     return true;
 }
 

@@ -48,7 +48,8 @@ private:
     std::vector<double> _predictionLC;   // {Vp, Lc, l1, l2, l3, l4...}
     bool _fullPredictionUpdate;
     // device side
-    lcd_engine* _configuredEngine;       // the engine that holds the current _predictionLC / prior (none: configure before the next update)
+    lcd_engine* _engine;                 // the engine the filter state lives on (the dictionary's, seen at the first update)
+    bool _deviceConfigured;              // it holds the current _predictionLC / prior (false: configure before the next update)
     std::set<int> _listedIds;            // ids whose neighbour list the device has (the keys of the reference's _neighborsIndex)
     std::pair<int, float> _highestHypothesis;
     std::string _lastError;

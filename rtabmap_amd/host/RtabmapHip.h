@@ -5,6 +5,10 @@
 // :2131, the highest hypothesis :2147-2158, its acceptance against Rtabmap/LoopThr and Rtabmap/LoopRatio :2162-2222, and the
 // global loop-closure link :3129-3186.  Same member and parameter names.  Everything else of Rtabmap::process (odometry, graph
 // optimisation, retrieval, memory management, statistics) is out of scope.
+// A signature without words never reaches the device's inverted index (VWDictionaryHip::flushReferences), so a working memory that
+// holds one makes computePosterior refuse (error logged, the last posterior stays).  The reference keeps such "bad signatures" in
+// the working memory with likelihood 0 unless Mem/BadSignaturesIgnored drops them (Memory.cpp:2448, :2800; default false): frames
+// without features are the caller's to skip here.
 // Each step is one device call behind the mirrors: MemoryHip::update (lcd_quantize), MemoryHip::computeLikelihood
 // (lcd_likelihood), adjustLikelihood (lcd_adjust_likelihood), BayesFilterHip::computePosterior (lcd_bayes_*).
 #pragma once
