@@ -2,7 +2,8 @@
 # One GPU-box pass that produces everything kept under profiles/ for a round:
 #   tools/profile_round.sh r02        (run from the repo root on the MI355X box; writes gpurun_out/<tag>/)
 # kernel trace + stats, the two HBM counter passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel trace only), one SQ counter
-# pass, the default bench line (CPU baselines + parity block), and the secondary configurations (1M signatures, ORB stream, 2 ranks).
+# pass, the default bench line (CPU baselines + parity block), and the secondary configurations (1M signatures, ORB stream, 2 ranks,
+# 125k / 1M words).
 set -u
 TAG=${1:-r02}
 ROOT=$(pwd)
@@ -38,4 +39,8 @@ rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ
 timeout 600 python bench.py --signatures 1000000 --steps 100 --warmup 10 --no-cpu-baseline --no-extras > $O/bench_1m.json 2> $O/bench_1m.err
 timeout 600 python bench.py --config orb_stream --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_orb.json 2> $O/bench_orb.err
 timeout 600 python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline --no-extras > $O/bench_gpus2.json 2> $O/bench_gpus2.err
+# larger vocabularies (config 4's per-GPU share and the whole of it): the persistent filter launch
+timeout 300 python bench.py --words 125000 --steps 200 --warmup 20 --no-cpu-baseline --no-extras > $O/bench_125k_words.json 2> $O/bench_125k_words.err
+timeout 300 python bench.py --words 1000000 --steps 100 --warmup 10 --no-cpu-baseline --no-extras > $O/bench_1m_words.json 2> $O/bench_1m_words.err
+timeout 200 python tools/bench_knn_sizes.py > $O/knn_sizes.json 2> $O/knn_sizes.err
 ls -la $O
