@@ -1,6 +1,7 @@
 """Multi-process coverage of the sharded (word-ID range) path.
 
-CPU (gloo, world_size 2): the partition arithmetic and the collective wrappers of rtabmap_amd/sharded.py.
+CPU (gloo, world_size 2): the partition arithmetic, and the host side of ShardedLoopClosure on CPU tensors with a recording engine
+(which rows and references a rank keeps, the all-gather / all-reduce wrappers, the retirement queue of the deferred likelihood).
 GPU (-m gpu; 2 ranks sharing the one GPU of the test box, gloo staging): the full sharded frame path must give the same
 word ids as the single-GPU engine and a BIT-IDENTICAL likelihood (integer partial sums are order-free)."""
 import os
@@ -59,6 +60,88 @@ def test_partition_and_collectives_gloo_world2():
     assert b == [0, 24500, 49000]
     assert gathered == [1] * 8 + [2] * 8
     assert summed == [0, 3, 6, 9, 12]
+
+
+class _FakeStream:
+    def synchronize(self):
+        pass
+
+
+class _FakeEngine:
+    """Records what ShardedLoopClosure hands to the engine (no device)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def vocab_append(self, rows, ids):
+        self.calls.append(("vocab_append", np.asarray(rows).copy(), np.asarray(ids).copy()))
+
+    def sig_add_bulk(self, sig_ids, offsets, words, ni):
+        self.calls.append(("sig_add_bulk", np.asarray(sig_ids).copy(), np.asarray(offsets).copy(), np.asarray(words).copy(), np.asarray(ni).copy()))
+
+    def sig_remove(self, sig_id):
+        self.calls.append(("sig_remove", int(sig_id)))
+
+
+def _host_logic_worker(rank, world, port, out):
+    """The host side of the sharded path on CPU tensors: which rows / references a rank keeps, the two exchange wrappers."""
+    _init(rank, world, port)
+    from rtabmap_amd.sharded import ShardedLoopClosure
+    sh = ShardedLoopClosure.__new__(ShardedLoopClosure)          # no engine, no device: only the plumbing under test
+    sh.group, sh.rank, sh.world, sh.backend = None, rank, world, "gloo"
+    sh.stream, sh.device, sh.eng = _FakeStream(), torch.device("cpu"), _FakeEngine()
+    sh._bufs, sh.comm, sh._pending, sh._retire_q, sh._n_frames, sh._owed_single = {}, None, None, [], 0, None
+    n_words = 11                                                  # 6 + 5 rows: rank 0 owns ids 1..6, rank 1 owns 7..11
+    rows = np.arange(n_words * 4, dtype=np.float32).reshape(n_words, 4)
+    ids = np.arange(1, n_words + 1, dtype=np.int32)
+    sh.load_vocabulary(rows, ids)
+    kept = sh.eng.calls[-1]
+    # three signatures; every rank registers all of them with the words it owns (others -1), ni = all features
+    words = np.array([1, 7, 7, 3, 11, 2, 6, 6, 9], np.int32)
+    offsets = np.array([0, 3, 5, 9], np.int64)
+    sh.add_signatures_bulk(np.array([1, 2, 3], np.int32), offsets, words)
+    reg = sh.eng.calls[-1]
+    # exchange 1: all-gather of the per-rank candidate records, rank-major
+    cand = torch.arange(8, dtype=torch.int64) + 100 * (rank + 1)
+    allc = torch.zeros(world * 8, dtype=torch.int64)
+    sh._all_gather(allc, cand)
+    # exchange 2: int64 all-reduce of the partial likelihood, in place
+    lfix = torch.tensor([1, -2, 3 * (rank + 1), 1 << 40], dtype=torch.int64)
+    sh._all_reduce_sum(lfix)
+    # a retirement asked for while a likelihood is owed waits in the queue; without one it goes straight to the engine
+    sh.retire(5)
+    direct = sh.eng.calls[-1]
+    sh._pending = "owed"
+    sh.retire(6)
+    queued = list(sh._retire_q)
+    out.put((rank, (sh.lo, sh.hi), kept[1].tolist(), kept[2].tolist(), reg[3].tolist(), reg[4].tolist(), allc.tolist(), lfix.tolist(), direct, queued))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_host_logic_gloo_world2():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_host_logic_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r[0], r[1:]) for r in (out.get(timeout=120), out.get(timeout=120)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows = np.arange(44, dtype=np.float32).reshape(11, 4)
+    assert got[0][0] == (0, 6) and got[1][0] == (6, 11)
+    assert got[0][1] == rows[:6].tolist() and got[1][1] == rows[6:].tolist()
+    assert got[0][2] == [1, 2, 3, 4, 5, 6] and got[1][2] == [7, 8, 9, 10, 11]
+    assert got[0][3] == [1, -1, -1, 3, -1, 2, 6, 6, -1]             # the words a rank does not own are -1 in its registration
+    assert got[1][3] == [-1, 7, 7, -1, 11, -1, -1, -1, 9]
+    assert got[0][4] == got[1][4] == [3, 2, 4]                      # ni counts every feature on every rank
+    exp_all = list(range(100, 108)) + list(range(200, 208))
+    assert got[0][5] == got[1][5] == exp_all                        # rank-major on both ranks
+    assert got[0][6] == got[1][6] == [2, -4, 9, 2 << 40]            # integer sum: order-free, identical everywhere
+    for r in (0, 1):
+        assert got[r][7] == ("sig_remove", 5) and got[r][8] == [6]
 
 
 def _gpu_worker(rank, world, port, out):
