@@ -102,7 +102,7 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
                                    h->kst, prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr,
                                    !h->fail_count_clean, cb, cb != nullptr));
         h->fail_count_clean = false;
-        if (prof) { h->prof_n += 1; h->prof_kernel = "knn_bf16_filter_kernel"; }
+        if (prof) { h->prof_n += 1; h->prof_kernel = knn_bf16_persistent(mp) ? "knn_bf16_filter_kernel_p" : "knn_bf16_filter_kernel"; }
         LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
         if (defer_redo) fill_redo(h, defer_redo, vocab, row_id, (int)n_rows, d_queries, o_row, o_word, o_dist, cb);
         else LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(),
@@ -907,7 +907,11 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     // ---- launch A: filter (this frame) + tail (previous frame); launch B: re-rank (this frame) + scoring (previous frame)
     const bool prof = h->prof_cap > 0 && h->prof_n < h->prof_cap;
     LCD_HIP(h, launch_frame_a(k, prev ? &tl : nullptr, h->stream, prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr));
-    if (prof) { h->prof_n += 1; h->prof_kernel = "frame_a_kernel (bf16 filter of frame t + tail of frame t-1)"; }
+    if (prof) {
+        h->prof_n += 1;
+        h->prof_kernel = knn_bf16_persistent(k.plan) ? "frame_a_kernel_p (persistent bf16 filter of frame t + tail of frame t-1)"
+                                                     : "frame_a_kernel (bf16 filter of frame t + tail of frame t-1)";
+    }
     const bool prof2 = prev_like && h->prof_cap > 0 && h->prof2_n < h->prof_cap;
     LCD_HIP(h, launch_frame_b(&k, prev_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
                               prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr));

@@ -1355,6 +1355,7 @@ static int bf16_persistent_px(const MfmaPlan& p) {
     const int rounds = (p.n_blocks + px_max - 1) / px_max;
     return (p.n_blocks + rounds - 1) / rounds;                          // equal shares: ceil(strips / rounds) workgroups of <= rounds strips
 }
+bool knn_bf16_persistent(const MfmaPlan& p) { return p.q > 0 && bf16_persistent_px(p) > 0; }   // which kernel the launch will be (profile labels)
 hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, const float* row_norm, const uint32_t* norm_max_bits,
                            const int32_t* row_id, const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word,
                            float* out_dist, int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,

@@ -77,6 +77,7 @@ struct MfmaPlan {
     int filter_units = -1;   // compute units the persistent bf16 filter plans for (-1: built-in; 0: one workgroup per strip always)
 };
 bool knn_mfma_supported(int dtype, int dim);
+bool knn_bf16_persistent(const MfmaPlan& p);   // the bf16 filter launch of this plan uses the persistent kernels (..._kernel_p)
 MfmaPlan knn_mfma_plan(int q, int n_rows);
 size_t knn_mfma_partial_bytes(const MfmaPlan& p);
 // |row|^2 for rows [first, first + n) (+inf for tombstones), running maximum in norm_max_bits
