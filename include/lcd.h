@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LCD_ABI_VERSION 2
+#define LCD_ABI_VERSION 3
 
 typedef struct lcd_engine lcd_engine;
 
@@ -72,14 +72,15 @@ typedef struct lcd_config {
     int32_t max_queries;       /* initial per-call query capacity (Kp/MaxFeatures; grows on demand) */
     int32_t knn_mode;          /* lcd_knn_mode, per handle */
     void*   stream;            /* optional hipStream_t to enqueue on; NULL = engine-owned stream */
-    int32_t pipeline;          /* 1: consecutive lcd_frame_dev calls are software-pipelined (matrix-core 2-NN handles): the launches of
-                                  frame t also carry the registration and the scoring of frame t - 1, whose single-workgroup
-                                  decision loop then hides behind the distance filter of frame t.  Consequence for the caller: the
-                                  outputs of a frame (d_word_ids, d_likelihood, d_bayes, ...) are written -- and its descriptors
-                                  read -- by the work the NEXT lcd_frame_dev enqueues (or by any other call on the handle, which
-                                  completes the owed stage first; lcd_synchronize to wait for it): keep two sets of buffers and
-                                  alternate.  lcd_sig_remove, lcd_record_event and lcd_bayes_set_neighbors are queued behind the
-                                  owed stage, so they keep their place in the call order.  Results are identical with and without. */
+    int32_t pipeline;          /* 1: consecutive lcd_frame_dev calls are software-pipelined (matrix-core 2-NN handles), lcd_pipeline_depth() = 2
+                                  frames deep: the launches of frame t also carry the decision loop of frame t - 1 and the registration +
+                                  scoring of frame t - 2, whose single-workgroup latency chains then hide behind the distance filter of
+                                  frame t.  Consequence for the caller: the outputs of a frame (d_word_ids, d_likelihood, d_bayes, ...) are
+                                  written -- and its descriptors read -- by work that the NEXT TWO lcd_frame_dev calls enqueue (or any
+                                  other call on the handle, which completes the owed stages first; lcd_synchronize to wait for them):
+                                  keep lcd_pipeline_depth() + 1 sets of buffers and rotate.  lcd_sig_remove, lcd_record_event and
+                                  lcd_bayes_set_neighbors are queued behind the owed stages of the frame they follow, so they keep their
+                                  place in the call order.  Results are identical with and without. */
     int32_t reserved1;
 } lcd_config;
 
@@ -92,6 +93,9 @@ void lcd_destroy(lcd_engine* h);
 const char* lcd_last_error(const lcd_engine* h);
 /* block until all work enqueued by this handle has finished */
 int  lcd_synchronize(lcd_engine* h);
+/* 0 for a plain handle; for a pipelined one (lcd_config.pipeline) the number of later lcd_frame_dev calls that still enqueue work of a
+ * frame: its outputs are complete (enqueued) once that many further frames have been submitted, or after any other call */
+int  lcd_pipeline_depth(const lcd_engine* h);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * vocabulary == VWDictionary::_dataTree + _mapIndexId (VWDictionary.h:146-149), maintained by update() :475-701.

@@ -18,7 +18,7 @@ STATUS = {0: "LCD_OK", 1: "LCD_ERR_INVALID", 2: "LCD_ERR_HIP", 3: "LCD_ERR_NOMEM
 
 # every symbol include/lcd.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "lcd_abi_version", "lcd_create", "lcd_destroy", "lcd_last_error", "lcd_synchronize",
+    "lcd_abi_version", "lcd_create", "lcd_destroy", "lcd_last_error", "lcd_synchronize", "lcd_pipeline_depth",
     "lcd_vocab_clear", "lcd_vocab_append", "lcd_vocab_remove", "lcd_vocab_rebuild", "lcd_vocab_count", "lcd_vocab_read",
     "lcd_knn2", "lcd_selfdist", "lcd_quantize", "lcd_find_nn",
     "lcd_sig_add", "lcd_sig_remove", "lcd_sig_add_bulk", "lcd_sig_count", "lcd_word_nrefs",
@@ -99,6 +99,8 @@ def load():
     L.lcd_last_error.argtypes = [vp]
     L.lcd_last_error.restype = C.c_char_p
     L.lcd_synchronize.argtypes = [vp]
+    L.lcd_pipeline_depth.argtypes = [vp]
+    L.lcd_pipeline_depth.restype = C.c_int
     L.lcd_vocab_clear.argtypes = [vp]
     L.lcd_vocab_append.argtypes = [vp, vp, C.c_int, vp]
     L.lcd_vocab_remove.argtypes = [vp, vp, C.c_int]
@@ -186,6 +188,10 @@ class Engine:
 
     def synchronize(self):
         self._ck(self.L.lcd_synchronize(self.h))
+
+    def pipeline_depth(self):
+        """later frame_dev calls that still enqueue work of a frame (0: plain handle): keep pipeline_depth() + 1 buffer sets"""
+        return int(self.L.lcd_pipeline_depth(self.h))
 
     # ---- vocabulary
     def vocab_clear(self):

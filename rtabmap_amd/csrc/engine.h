@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <deque>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -46,22 +47,33 @@ struct lcd_engine {
     bool fail_count_clean = false;                      // d_fail_count[0..1] known to be zero (the fused frame tail resets them)
     int knn_mode = 2;                                   // f32 dim 64: 2 = bf16x3 MFMA filter + exact re-rank (default), 1 = f32 MFMA filter
                                                         // + exact re-rank, 0 = exact VALU scan only (lcd_config.knn_mode)
-    // ---- pipelined frames (lcd_config.pipeline): frame t's filter launch carries the tail of frame t - 1 and its re-rank launch the
-    // scoring of frame t - 1; the scratch the two frames in flight use exists twice (the set in use above and `alt`), swapped every
-    // frame.  The index stage of the latest frame stays owed (`deferred`) until the next frame or any other call on the handle.
+    // ---- pipelined frames (lcd_config.pipeline): three frames are in flight.  The call for frame t launches
+    //        A = filter of frame t  +  decision loop of frame t - 1  +  retirement / registration of frame t - 2
+    //        B = re-rank of frame t  +  scoring of frame t - 2            (then the decision stage of frame t - 2, if asked for)
+    // so every single-workgroup latency chain hides behind the matrix-core filter.  The scratch a frame's stages hand to each other
+    // lives in a ring indexed by the frame's sequence number; what a frame still owes (`stage`) and the calls made behind it
+    // (retirements, neighbour lists, event records) wait in `inflight` until a later lcd_frame_dev carries them or any other call
+    // on the handle completes them stand-alone (drain()).
     int pipeline = 0;
     hipStream_t kst = nullptr;                          // the stream the 2-NN stage is enqueued on (== stream)
-    struct AltScratch {
+    struct FrameScratch {
         lcd::DevBuf d_knn_row, d_knn_word, d_knn_dist, d_selfdist, d_bits, d_partial2, d_partial3, d_fail_list, d_fail_count, d_out_wslot;
         bool fail_count_clean = false;
-    } alt;
-    int ks_idx = 0;                                     // which of the two sets is the current one
-    struct Deferred { bool valid = false; lcd_frame_args a; lcd::ResolveArgs r; } deferred;
-    std::vector<int32_t> deferred_retire;               // lcd_sig_remove calls made while a frame's index stage is owed
-    std::vector<void*> deferred_events;                 // lcd_record_event calls made while a frame's index stage is owed
-    int filter_units = -1;                              // lcd_set_option("filter_units")
+    };
+    static constexpr int PIPE_SETS = 4;
+    FrameScratch ring[PIPE_SETS];
+    uint64_t frame_seq = 0;
+    const void* last_fail_count = nullptr;              // certificate counters of the latest pipelined frame (lcd_get_stats)
     struct DeferredLink { std::vector<int32_t> triples, restart; };
-    std::vector<DeferredLink> deferred_links;           // lcd_bayes_set_neighbors calls made while a frame's index stage is owed
+    struct InFlight {
+        lcd_frame_args a; lcd::ResolveArgs r; int set = 0;
+        int stage = 1;                                  // 1: the decision loop is owed (and everything after it), 2: registration + scoring are
+        std::vector<int32_t> retire_after;              // lcd_sig_remove calls made while this was the newest frame
+        std::vector<void*> events_after;                // lcd_record_event calls ...
+        std::vector<DeferredLink> links_after;          // lcd_bayes_set_neighbors calls ...
+    };
+    std::deque<InFlight> inflight;                      // oldest first
+    int filter_units = -1;                              // lcd_set_option("filter_units")
     int sync_all();                                     // stream drained
     int drain();                                        // complete the owed index stage (stand-alone launches)
     const char* prof2_kernel = "score_kernel";

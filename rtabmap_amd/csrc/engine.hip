@@ -92,7 +92,7 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
     const bool mfma = main_vocab && h->knn_mode != 0 && knn_mfma_supported(h->dtype, h->kdim) && n_rows >= 256;
     const KnnPlan p = knn_plan(q, (int)n_rows, h->row_bytes);
     if (mfma && h->knn_mode == 2) {
-        MfmaPlan mp = knn_bf16_plan(q, (int)n_rows);
+        MfmaPlan mp = knn_bf16_plan(q, (int)n_rows, cb != nullptr ? knn_selfdist_wgs(q) : 0);
         mp.filter_units = h->filter_units;
         LCD_HIP(h, dreserve(h, h->d_partial2, knn_bf16_partial_bytes(mp)));
         LCD_HIP(h, dreserve(h, h->d_fail_list, (size_t)q * 4));
@@ -133,6 +133,7 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
         LCD_HIP(h, launch_knn2_merge(h->dtype, p, h->d_partial.as<uint64_t>(), row_id, o_row, o_word, o_dist, h->kst));
     }
     h->knn_launches += 1;
+    if (mfma) h->last_fail_count = h->d_fail_count.p;
     return LCD_OK;
 }
 
@@ -198,8 +199,11 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
     if (cfg->pipeline < 0 || cfg->pipeline > 1) { delete h; return LCD_ERR_INVALID; }
     h->pipeline = cfg->pipeline;
     if (cfg->pipeline) {
-        if (e == hipSuccess) e = h->alt.d_fail_count.reserve(64, 0, h->stream, &h->bytes_device);
-        if (e == hipSuccess) e = hipMemsetAsync(h->alt.d_fail_count.p, 0, 64, h->stream);
+        for (lcd_engine::FrameScratch& sc : h->ring) {
+            if (e == hipSuccess) e = sc.d_fail_count.reserve(64, 0, h->stream, &h->bytes_device);
+            if (e == hipSuccess) e = hipMemsetAsync(sc.d_fail_count.p, 0, 64, h->stream);
+            sc.fail_count_clean = true;
+        }
     }
     if (e == hipSuccess) e = h->tfidf.init(h->stream, &h->bytes_device, cfg->sig_capacity, cfg->vocab_capacity);
     h->bayes.init(h->stream, &h->bytes_device);
@@ -215,10 +219,10 @@ void lcd_destroy(lcd_engine* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->tfidf.destroy();
     h->bayes.destroy();
-    {
-        DevBuf* alts[] = {&h->alt.d_knn_row, &h->alt.d_knn_word, &h->alt.d_knn_dist, &h->alt.d_selfdist, &h->alt.d_bits, &h->alt.d_partial2,
-                          &h->alt.d_partial3, &h->alt.d_fail_list, &h->alt.d_fail_count, &h->alt.d_out_wslot};
-        for (DevBuf* d : alts) d->release(&h->bytes_device);
+    for (lcd_engine::FrameScratch& sc : h->ring) {
+        DevBuf* all[] = {&sc.d_knn_row, &sc.d_knn_word, &sc.d_knn_dist, &sc.d_selfdist, &sc.d_bits, &sc.d_partial2, &sc.d_partial3, &sc.d_fail_list,
+                         &sc.d_fail_count, &sc.d_out_wslot};
+        for (DevBuf* d : all) d->release(&h->bytes_device);
     }
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->prof2_ev) (void)hipEventDestroy(e);
@@ -243,11 +247,13 @@ int lcd_synchronize(lcd_engine* h) {
 
 void* lcd_stream(lcd_engine* h) { return h ? (void*)h->stream : nullptr; }
 
+int lcd_pipeline_depth(const lcd_engine* h) { return (h && h->pipeline) ? 2 : 0; }
+
 int lcd_record_event(lcd_engine* h, void* event) {
     LCD_CHECK_HANDLE(h);
     if (!event) return h->fail(LCD_ERR_INVALID, "lcd_record_event: null event");
     LCD_DEV_NODRAIN(h);
-    if (h->deferred.valid) { h->deferred_events.push_back(event); return LCD_OK; }   // recorded behind the index stage still owed
+    if (!h->inflight.empty()) { h->inflight.back().events_after.push_back(event); return LCD_OK; }   // recorded behind the stages still owed
     LCD_HIP(h, hipEventRecord((hipEvent_t)event, h->stream));
     return LCD_OK;
 }
@@ -672,12 +678,15 @@ int lcd_sig_add_bulk(lcd_engine* h, int n_sigs, const int32_t* sig_ids, const in
 int lcd_sig_remove(lcd_engine* h, int32_t sig_id) {
     LCD_CHECK_HANDLE(h);
     LCD_DEV_NODRAIN(h);
-    if (h->deferred.valid) {
-        // a pipelined handle still owes the index stage of its last frame: the retirement takes its place behind it
-        const bool known = h->tfidf.sig_slot.count(sig_id) || (h->deferred.a.sig_id != 0 && sig_id == h->deferred.a.sig_id);
-        if (!known || std::find(h->deferred_retire.begin(), h->deferred_retire.end(), sig_id) != h->deferred_retire.end())
-            return h->fail(LCD_ERR_STATE, "lcd_sig_remove: unknown signature");
-        h->deferred_retire.push_back(sig_id);
+    if (!h->inflight.empty()) {
+        // a pipelined handle still owes stages of its latest frames: the retirement takes its place behind the newest of them
+        bool known = h->tfidf.sig_slot.count(sig_id) != 0, queued = false;
+        for (const lcd_engine::InFlight& f : h->inflight) {
+            if (f.a.sig_id != 0 && f.a.sig_id == sig_id) known = true;
+            if (std::find(f.retire_after.begin(), f.retire_after.end(), sig_id) != f.retire_after.end()) queued = true;
+        }
+        if (!known || queued) return h->fail(LCD_ERR_STATE, "lcd_sig_remove: unknown signature");
+        h->inflight.back().retire_after.push_back(sig_id);
         return LCD_OK;
     }
     if (!h->tfidf.sig_slot.count(sig_id)) return h->fail(LCD_ERR_STATE, "lcd_sig_remove: unknown signature");
@@ -761,15 +770,6 @@ int lcd_adjust_likelihood_dev(lcd_engine* h, float* d_likelihood, int n, float v
 }
 
 // ------------------------------------------------------------------------------------------------ device-resident frame
-// pipelined handles keep two sets of the scratch that the 2-NN stage writes and the frame tail reads
-static void swap_scratch(lcd_engine* h) {
-    std::swap(h->d_knn_row, h->alt.d_knn_row); std::swap(h->d_knn_word, h->alt.d_knn_word); std::swap(h->d_knn_dist, h->alt.d_knn_dist);
-    std::swap(h->d_selfdist, h->alt.d_selfdist); std::swap(h->d_bits, h->alt.d_bits); std::swap(h->d_partial2, h->alt.d_partial2);
-    std::swap(h->d_partial3, h->alt.d_partial3); std::swap(h->d_fail_list, h->alt.d_fail_list); std::swap(h->d_fail_count, h->alt.d_fail_count);
-    std::swap(h->d_out_wslot, h->alt.d_out_wslot); std::swap(h->fail_count_clean, h->alt.fail_count_clean);
-    h->ks_idx ^= 1;
-}
-
 namespace {
 struct FrameHostTimer {   // host time spent inside lcd_frame_dev (lcd_stats.frame_host_ns)
     lcd_engine* h; std::chrono::steady_clock::time_point t0;
@@ -793,148 +793,198 @@ static int hypothesis_stage(lcd_engine* h, const lcd_frame_args& a) {
     return LCD_OK;
 }
 
+// likelihood + decision stage of a frame whose registration (or query preparation) has just been enqueued stand-alone
+static int frame_score_s(lcd_engine* h, const lcd_frame_args& a) {
+    Tfidf& t = h->tfidf;
+    if (!a.d_likelihood) return LCD_OK;
+    if (h->prof_cap > 0 && h->prof2_n < h->prof_cap) {
+        t.prof_b = h->prof2_ev[2 * h->prof2_n]; t.prof_e = h->prof2_ev[2 * h->prof2_n + 1];
+        h->prof2_n += 1;
+        h->prof2_kernel = "score_kernel";
+    }
+    LCD_HIP(h, t.score(a.d_likelihood));
+    if (t.prof_b) { t.prof_b = t.prof_e = nullptr; h->prof2_n -= 1; }     // the launch that would have been bracketed did not happen
+    h->likelihood_launches += 1;
+    return hypothesis_stage(h, a);
+}
+
+static int reserve_frame_words(lcd_engine* h, const lcd_frame_args& a, WsRuns* runs) {
+    *runs = WsRuns();
+    // postings keys for the words this frame may create (VisualWord(id, descriptor, signatureId) references the signature)
+    if (a.sig_id != 0 && a.first_new_word_id > 0 && (a.flags & LCD_Q_INCREMENTAL)) {
+        hipError_t e = h->tfidf.reserve_new_words(a.first_new_word_id, a.q, runs);
+        if (e == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: word ids must be below 2^28");
+        LCD_HIP(h, e);
+    }
+    return LCD_OK;
+}
+
+// the whole index stage of a frame, launched on its own: decision loop + registration (one workgroup), scoring, decision stage
 static int frame_stage_s(lcd_engine* h, const lcd_frame_args& a, ResolveArgs r) {
     Tfidf& t = h->tfidf;
     const int q = a.q;
     if (a.sig_id != 0 && t.sig_slot.count(a.sig_id)) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
     const int64_t slots_after = t.n_slots + (a.sig_id != 0 ? 1 : 0);
     if (a.d_likelihood && a.likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
-    // postings keys for the words this frame may create (VisualWord(id, descriptor, signatureId) references the signature)
-    if (a.sig_id != 0 && a.first_new_word_id > 0 && (a.flags & LCD_Q_INCREMENTAL)) {
-        hipError_t e = t.reserve_new_words(a.first_new_word_id, q, &r.new_ws);
-        if (e == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: word ids must be below 2^28");
-        LCD_HIP(h, e);
-    }
+    { int rc = reserve_frame_words(h, a, &r.new_ws); if (rc) return rc; }
     if (a.sig_id != 0) LCD_HIP(h, t.register_dev(a.sig_id, r.out_wslot, q, q, a.N, &r));
     else LCD_HIP(h, t.query_dev(r.out_wslot, q, a.N, &r));
-    if (a.d_likelihood) {
-        if (h->prof_cap > 0 && h->prof2_n < h->prof_cap) {
-            t.prof_b = h->prof2_ev[2 * h->prof2_n]; t.prof_e = h->prof2_ev[2 * h->prof2_n + 1];
-            h->prof2_n += 1;
-            h->prof2_kernel = "score_kernel";
-        }
-        LCD_HIP(h, t.score(a.d_likelihood));
-        if (t.prof_b) { t.prof_b = t.prof_e = nullptr; h->prof2_n -= 1; }     // the launch that would have been bracketed did not happen
-        h->likelihood_launches += 1;
-        { int rc = hypothesis_stage(h, a); if (rc) return rc; }
-    }
-    return LCD_OK;
+    return frame_score_s(h, a);
 }
 
-// what a pipelined handle still owes after its last lcd_frame_dev: the frame's index stage, then the retirements and event
-// records the caller asked for since, in call order
-static int finish_deferred_tail(lcd_engine* h) {
-    for (int32_t sig : h->deferred_retire) LCD_HIP(h, h->tfidf.retire(sig));
-    h->deferred_retire.clear();
-    for (const lcd_engine::DeferredLink& dl : h->deferred_links) {
+// the same for a frame whose decision loop has already run (it left the word slots in r.out_wslot, new words as codes)
+static int frame_stage_reg_s(lcd_engine* h, const lcd_frame_args& a, const ResolveArgs& r) {
+    Tfidf& t = h->tfidf;
+    if (a.sig_id != 0 && t.sig_slot.count(a.sig_id)) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
+    WsRuns runs;
+    { int rc = reserve_frame_words(h, a, &runs); if (rc) return rc; }
+    if (a.sig_id != 0) LCD_HIP(h, t.register_dev(a.sig_id, r.out_wslot, a.q, a.q, a.N, nullptr, false, nullptr, &runs));
+    else LCD_HIP(h, t.query_dev(r.out_wslot, a.q, a.N, nullptr, false, nullptr, &runs));
+    return frame_score_s(h, a);
+}
+
+// the calls made while `f` was the newest frame of a pipelined handle, in call order, once every stage of `f` is enqueued
+static int finish_frame_ops(lcd_engine* h, lcd_engine::InFlight& f) {
+    for (int32_t sig : f.retire_after) LCD_HIP(h, h->tfidf.retire(sig));
+    f.retire_after.clear();
+    for (const lcd_engine::DeferredLink& dl : f.links_after) {
         LCD_HIP(h, h->bayes.ensure(std::max<int64_t>(h->tfidf.n_slots, 1)));
         const hipError_t e = h->bayes.link(dl.triples, dl.restart);
-        if (e == hipErrorInvalidValue) { h->deferred_links.clear(); return h->fail(LCD_ERR_UNSUPPORTED, "lcd_bayes_set_neighbors: a neighbour list longer than 8192 entries"); }
+        if (e == hipErrorInvalidValue) { f.links_after.clear(); return h->fail(LCD_ERR_UNSUPPORTED, "lcd_bayes_set_neighbors: a neighbour list longer than 8192 entries"); }
         LCD_HIP(h, e);
     }
-    h->deferred_links.clear();
-    for (void* ev : h->deferred_events) LCD_HIP(h, hipEventRecord((hipEvent_t)ev, h->stream));
-    h->deferred_events.clear();
+    f.links_after.clear();
+    for (void* ev : f.events_after) LCD_HIP(h, hipEventRecord((hipEvent_t)ev, h->stream));
+    f.events_after.clear();
     return LCD_OK;
 }
 
 int lcd_engine::drain() {
-    if (!deferred.valid) return LCD_OK;
-    deferred.valid = false;
-    const int rc = frame_stage_s(this, deferred.a, deferred.r);      // stand-alone launches
-    const int rc2 = finish_deferred_tail(this);
-    return rc ? rc : rc2;
+    int rc_all = LCD_OK;
+    while (!inflight.empty()) {                                      // oldest first: every frame is completed before the next one touches the index
+        InFlight f = std::move(inflight.front());
+        inflight.pop_front();
+        ResolveArgs r = f.r;
+        r.new_ws = WsRuns();
+        const int rc = f.stage == 2 ? frame_stage_reg_s(this, f.a, r) : frame_stage_s(this, f.a, r);
+        const int rc2 = finish_frame_ops(this, f);
+        if (!rc_all) rc_all = rc ? rc : rc2;
+    }
+    return rc_all;
 }
 
-// Pipelined handle, matrix-core 2-NN: frame t's filter launch carries the tail of frame t - 1, its re-rank launch the scoring of
-// frame t - 1 (knn_mfma_kernels.hip, frame_a_kernel / frame_b_kernel).  The index stage of frame t itself stays owed until the
-// next lcd_frame_dev or any other call on the handle.
+// Pipelined handle, matrix-core 2-NN (knn_mfma_kernels.hip, frame_a_kernel / frame_b_kernel): the call for frame t launches
+//   A = filter of frame t + decision loop of frame t - 1 + retirement / registration of frame t - 2,  B = re-rank of frame t + scoring of
+//   frame t - 2 (+ the decision stage of frame t - 2).  What frames t - 1 and t still owe afterwards waits in h->inflight.
 static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     Tfidf& t = h->tfidf;
     const int q = a->q;
-    // validate against the index as it will be once the owed stage has run
-    const bool prev = h->deferred.valid;
-    const int32_t prev_sig = prev ? h->deferred.a.sig_id : 0;
-    if (a->sig_id != 0 && (t.sig_slot.count(a->sig_id) || a->sig_id == prev_sig)) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
-    const int64_t slots_after = t.n_slots + (prev_sig != 0 ? 1 : 0) + (a->sig_id != 0 ? 1 : 0);
+    // validate against the index as it will be once the owed stages have run
+    int64_t owed_slots = 0;
+    for (const lcd_engine::InFlight& f : h->inflight) {
+        if (f.a.sig_id == 0) continue;
+        if (f.a.sig_id == a->sig_id) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
+        owed_slots += 1;
+    }
+    if (a->sig_id != 0 && t.sig_slot.count(a->sig_id)) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
+    const int64_t slots_after = t.n_slots + owed_slots + (a->sig_id != 0 ? 1 : 0);
     if (a->d_likelihood && a->likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
-    swap_scratch(h);
+    const int set = (int)(h->frame_seq % lcd_engine::PIPE_SETS);
+    lcd_engine::FrameScratch& sc = h->ring[set];
     const bool incremental = (a->flags & LCD_Q_INCREMENTAL) != 0;
     const bool together = incremental && (a->flags & LCD_Q_NEW_WORDS_COMPARED);
     const int ld = (q + 63) / 64 * 64, bw = ld / 32;
-    // ---- this frame's 2-NN stage: buffers of the current scratch set
+    // ---- this frame's 2-NN stage: buffers of its scratch set
     PipeKnn k;
-    k.plan = knn_bf16_plan(q, (int)h->n_rows);
+    k.plan = knn_bf16_plan(q, (int)h->n_rows, 2 + (together ? knn_selfdist_wgs(q) : 0));
     k.plan.filter_units = h->filter_units;
-    LCD_HIP(h, dreserve(h, h->d_partial2, knn_bf16_partial_bytes(k.plan)));
-    LCD_HIP(h, dreserve(h, h->d_fail_list, (size_t)q * 4));
-    LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)h->n_rows, q)));
-    LCD_HIP(h, dreserve(h, h->d_knn_row, (size_t)q * 2 * 4));
-    LCD_HIP(h, dreserve(h, h->d_knn_word, (size_t)q * 2 * 4));
-    LCD_HIP(h, dreserve(h, h->d_knn_dist, (size_t)q * 2 * 4));
-    LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
+    LCD_HIP(h, dreserve(h, sc.d_partial2, knn_bf16_partial_bytes(k.plan)));
+    LCD_HIP(h, dreserve(h, sc.d_fail_list, (size_t)q * 4));
+    LCD_HIP(h, dreserve(h, sc.d_partial3, knn_rowpar_partial_bytes((int)h->n_rows, q)));
+    LCD_HIP(h, dreserve(h, sc.d_knn_row, (size_t)q * 2 * 4));
+    LCD_HIP(h, dreserve(h, sc.d_knn_word, (size_t)q * 2 * 4));
+    LCD_HIP(h, dreserve(h, sc.d_knn_dist, (size_t)q * 2 * 4));
+    LCD_HIP(h, dreserve(h, sc.d_out_wslot, (size_t)q * 4));
     if (together) {
-        LCD_HIP(h, dreserve(h, h->d_selfdist, (size_t)q * ld * 4));
-        LCD_HIP(h, dreserve(h, h->d_bits, cand_bits_bytes(q, bw)));
+        LCD_HIP(h, dreserve(h, sc.d_selfdist, (size_t)q * ld * 4));
+        LCD_HIP(h, dreserve(h, sc.d_bits, cand_bits_bytes(q, bw)));
     }
     k.vocab = h->vocab.p; k.vocab_bf = h->vocab_bf.p; k.row_norm = h->row_norm.as<float>(); k.norm_max_bits = h->norm_max.as<uint32_t>();
-    k.row_id = h->row_id.as<int32_t>(); k.queries = a->d_descriptors; k.partial = h->d_partial2.p;
-    k.out_row = h->d_knn_row.as<int32_t>(); k.out_word = h->d_knn_word.as<int32_t>(); k.out_dist = h->d_knn_dist.as<float>();
-    k.fail_list = h->d_fail_list.as<int32_t>(); k.fail_count = h->d_fail_count.as<int32_t>();
+    k.row_id = h->row_id.as<int32_t>(); k.queries = a->d_descriptors; k.partial = sc.d_partial2.p;
+    k.out_row = sc.d_knn_row.as<int32_t>(); k.out_word = sc.d_knn_word.as<int32_t>(); k.out_dist = sc.d_knn_dist.as<float>();
+    k.fail_list = sc.d_fail_list.as<int32_t>(); k.fail_count = sc.d_fail_count.as<int32_t>();
     k.cb = CandBits();
-    if (together) { k.cb.selfdist = h->d_selfdist.as<float>(); k.cb.ld = ld; k.cb.nq = q; k.cb.have_index = 1; cand_bits_layout(k.cb, h->d_bits.as<uint32_t>(), q, bw); }
-    if (!h->fail_count_clean) LCD_HIP(h, hipMemsetAsync(h->d_fail_count.p, 0, 8, h->stream));
-    // ---- the owed index stage of the previous frame: host part now, its launches ride with this frame's
-    TailLaunch tl; ScoreArgs sa; int score_wgs = 0;
-    bool prev_like = false;
-    if (prev) {
-        h->deferred.valid = false;
-        const lcd_frame_args& pa = h->deferred.a;
-        ResolveArgs pr = h->deferred.r;
-        if (pa.sig_id != 0 && pa.first_new_word_id > 0 && (pa.flags & LCD_Q_INCREMENTAL)) {
-            hipError_t e = t.reserve_new_words(pa.first_new_word_id, pa.q, &pr.new_ws);
-            if (e == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: word ids must be below 2^28");
-            LCD_HIP(h, e);
-        }
-        if (pa.sig_id != 0) LCD_HIP(h, t.register_dev(pa.sig_id, pr.out_wslot, pa.q, pa.q, pa.N, &pr, false, &tl));
-        else LCD_HIP(h, t.query_dev(pr.out_wslot, pa.q, pa.N, &pr, false, &tl));
+    if (together) { k.cb.selfdist = sc.d_selfdist.as<float>(); k.cb.ld = ld; k.cb.nq = q; k.cb.have_index = 1; cand_bits_layout(k.cb, sc.d_bits.as<uint32_t>(), q, bw); }
+    if (!sc.fail_count_clean) LCD_HIP(h, hipMemsetAsync(sc.d_fail_count.p, 0, 8, h->stream));
+    h->last_fail_count = sc.d_fail_count.p;
+    // ---- what the frames in flight owe: host part now, the launches ride with this frame's
+    lcd_engine::InFlight* f_reg = nullptr; lcd_engine::InFlight* f_res = nullptr;
+    for (lcd_engine::InFlight& f : h->inflight) {
+        if (f.stage == 2 && !f_reg) f_reg = &f;
+        else if (f.stage == 1 && !f_res) f_res = &f;
+    }
+    TailLaunch tl_reg, tl_res; ScoreArgs sa; int score_wgs = 0;
+    bool reg_like = false;
+    if (f_reg) {
+        const lcd_frame_args& pa = f_reg->a;
+        WsRuns runs;
+        { int rc = reserve_frame_words(h, pa, &runs); if (rc) return rc; }
+        if (pa.sig_id != 0) LCD_HIP(h, t.register_dev(pa.sig_id, f_reg->r.out_wslot, pa.q, pa.q, pa.N, nullptr, false, &tl_reg, &runs));
+        else LCD_HIP(h, t.query_dev(f_reg->r.out_wslot, pa.q, pa.N, nullptr, false, &tl_reg, &runs));
         if (pa.d_likelihood) {
             LCD_HIP(h, t.score_args(pa.d_likelihood, nullptr, pipe_block_size(), &sa, &score_wgs));
-            prev_like = true;
+            reg_like = true;
             h->likelihood_launches += 1;
         }
     }
-    // ---- launch A: filter (this frame) + tail (previous frame); launch B: re-rank (this frame) + scoring (previous frame)
+    if (f_res) {
+        tl_res.r = f_res->r;
+        tl_res.r.new_ws = WsRuns(); tl_res.r.new_ws.n = -1;          // new words as codes: their postings keys are reserved with the registration
+        resolve_launch_info(tl_res.r, pipe_block_size(), &tl_res.n_redo, &tl_res.shmem_resolve);
+    }
+    // ---- launch A: filter (t) + decision loop (t - 1) + registration (t - 2); launch B: re-rank (t) + scoring (t - 2)
     const bool prof = h->prof_cap > 0 && h->prof_n < h->prof_cap;
-    LCD_HIP(h, launch_frame_a(k, prev ? &tl : nullptr, h->stream, prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr));
+    LCD_HIP(h, launch_frame_a(k, f_res ? &tl_res : nullptr, f_reg ? &tl_reg : nullptr, h->stream, prof ? h->prof_ev[2 * h->prof_n] : nullptr,
+                              prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr));
     if (prof) {
         h->prof_n += 1;
-        h->prof_kernel = knn_bf16_persistent(k.plan) ? "frame_a_kernel_p (persistent bf16 filter of frame t + tail of frame t-1)"
-                                                     : "frame_a_kernel (bf16 filter of frame t + tail of frame t-1)";
+        h->prof_kernel = knn_bf16_persistent(k.plan) ? "frame_a_kernel_p (persistent bf16 filter of frame t + decision loop of t-1 + registration of t-2)"
+                                                     : "frame_a_kernel (bf16 filter of frame t + decision loop of t-1 + registration of t-2)";
     }
-    const bool prof2 = prev_like && h->prof_cap > 0 && h->prof2_n < h->prof_cap;
-    LCD_HIP(h, launch_frame_b(&k, prev_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
+    const bool prof2 = reg_like && h->prof_cap > 0 && h->prof2_n < h->prof_cap;
+    LCD_HIP(h, launch_frame_b(&k, reg_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
                               prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr));
-    if (prof2) { h->prof2_n += 1; h->prof2_kernel = "frame_b_kernel (re-rank of frame t + scoring of frame t-1)"; }
+    if (prof2) { h->prof2_n += 1; h->prof2_kernel = "frame_b_kernel (re-rank of frame t + scoring of frame t-2)"; }
     h->knn_launches += 1;
-    h->fail_count_clean = true;                                      // this frame's tail (next launch A) resets the counters
-    if (prev) {
-        const lcd_frame_args& pa = h->deferred.a;
-        if (pa.d_likelihood) { int rc = hypothesis_stage(h, pa); if (rc) return rc; }
-        int rc = finish_deferred_tail(h);                            // retirements / events requested after the previous frame
+    sc.fail_count_clean = true;                                      // this frame's decision loop (a later launch A, or drain()) resets the counters
+    if (f_res) f_res->stage = 2;
+    if (f_reg) {                                                     // frame t - 2 is complete: its decision stage and the calls queued behind it
+        lcd_engine::InFlight done = std::move(*f_reg);
+        h->inflight.pop_front();                                     // (f_reg is the oldest entry: stages advance in order)
+        if (done.a.d_likelihood) { int rc = hypothesis_stage(h, done.a); if (rc) return rc; }
+        int rc = finish_frame_ops(h, done);
         if (rc) return rc;
     }
-    // ---- this frame's index stage is owed from here on
-    ResolveArgs r;
+    // ---- this frame's decision loop, registration and scoring are owed from here on
+    lcd_engine::InFlight nf;
+    nf.a = *a; nf.set = set; nf.stage = 1;
+    ResolveArgs& r = nf.r;
     r.rp = RowparArgs{};
     r.q = q; r.flags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0); r.nndr = a->nndr_ratio; r.have_index = 1;
-    r.knn_word = k.out_word; r.knn_dist = k.out_dist; r.selfdist = together ? h->d_selfdist.as<float>() : nullptr; r.ld = ld;
-    r.cand_bits = together ? h->d_bits.as<uint32_t>() : nullptr; r.bw = bw; r.out_word = a->d_word_ids; r.out_n_new = h->d_n_new.as<int32_t>();
+    r.knn_word = k.out_word; r.knn_dist = k.out_dist; r.selfdist = together ? sc.d_selfdist.as<float>() : nullptr; r.ld = ld;
+    r.cand_bits = together ? sc.d_bits.as<uint32_t>() : nullptr; r.bw = bw; r.out_word = a->d_word_ids; r.out_n_new = h->d_n_new.as<int32_t>();
     r.cand_list = together ? k.cb.list : nullptr; r.cand_cnt = together ? k.cb.cnt : nullptr;
-    r.knn_row = k.out_row; r.row_wslot = h->row_wslot.as<int32_t>(); r.out_wslot = h->d_out_wslot.as<int32_t>(); r.new_ws = WsRuns();
-    r.fail_count = h->d_fail_count.as<int32_t>();
-    fill_redo(h, &r.rp, h->vocab.p, h->row_id.as<int32_t>(), (int)h->n_rows, a->d_descriptors, k.out_row, k.out_word, k.out_dist, together ? &k.cb : nullptr);
-    h->deferred.valid = true; h->deferred.a = *a; h->deferred.r = r;
+    r.knn_row = k.out_row; r.row_wslot = h->row_wslot.as<int32_t>(); r.out_wslot = sc.d_out_wslot.as<int32_t>(); r.new_ws = WsRuns();
+    r.fail_count = sc.d_fail_count.as<int32_t>();
+    {   // the exact redo of rejected queries rides with the decision loop (fill_redo, with this frame's scratch set)
+        RowparArgs& rp = r.rp;
+        rp.enabled = 1; rp.vocab = (const float*)h->vocab.p; rp.row_id = h->row_id.as<int32_t>(); rp.n_rows = (int)h->n_rows;
+        rp.queries = (const float*)a->d_descriptors; rp.fail_list = sc.d_fail_list.as<int32_t>(); rp.partial = (unsigned long long*)sc.d_partial3.p;
+        rp.out_row = k.out_row; rp.out_word = k.out_word; rp.out_dist = k.out_dist;
+        if (together) rp.cb = k.cb;
+    }
+    h->inflight.push_back(std::move(nf));
+    h->frame_seq += 1;
     return LCD_OK;
 }
 
@@ -1010,14 +1060,21 @@ int lcd_bayes_set_neighbors(lcd_engine* h, int n_sigs, const int32_t* sig_ids, c
     std::vector<int32_t> triples, restart;                    // restart: the slots of the listed signatures (their lists start over)
     std::unordered_map<uint64_t, int32_t> seen;
     seen.reserve((size_t)(offsets[n_sigs] - offsets[0]) * 2 + 16);
-    // the signature of a frame whose index stage is still owed has no slot yet: it will get the next one
-    const int32_t owed_sig = h->deferred.valid ? h->deferred.a.sig_id : 0;
-    const bool owed_gone = owed_sig != 0 && std::find(h->deferred_retire.begin(), h->deferred_retire.end(), owed_sig) != h->deferred_retire.end();
+    // the signatures of frames whose registration is still owed have no slots yet: they will get the next ones, in frame order
+    auto gone = [&](int32_t id) {
+        for (const lcd_engine::InFlight& f : h->inflight)
+            if (std::find(f.retire_after.begin(), f.retire_after.end(), id) != f.retire_after.end()) return true;
+        return false;
+    };
     auto slot_of = [&](int32_t id) -> int64_t {
-        if (owed_sig != 0 && id == owed_sig) return owed_gone ? -1 : t.n_slots;
+        int64_t k = 0;
+        for (const lcd_engine::InFlight& f : h->inflight) {
+            if (f.a.sig_id == 0) continue;
+            if (f.a.sig_id == id) return gone(id) ? -1 : t.n_slots + k;
+            k += 1;
+        }
         auto it = t.sig_slot.find(id);
-        if (it == t.sig_slot.end()) return -1;
-        if (std::find(h->deferred_retire.begin(), h->deferred_retire.end(), id) != h->deferred_retire.end()) return -1;
+        if (it == t.sig_slot.end() || gone(id)) return -1;
         return it->second;
     };
     for (int i = 0; i < n_sigs; ++i) {
@@ -1038,7 +1095,7 @@ int lcd_bayes_set_neighbors(lcd_engine* h, int n_sigs, const int32_t* sig_ids, c
             triples.push_back((int32_t)std::min(a, b)); triples.push_back((int32_t)std::max(a, b)); triples.push_back(m);
         }
     }
-    if (h->deferred.valid) { h->deferred_links.push_back(lcd_engine::DeferredLink{std::move(triples), std::move(restart)}); return LCD_OK; }
+    if (!h->inflight.empty()) { h->inflight.back().links_after.push_back(lcd_engine::DeferredLink{std::move(triples), std::move(restart)}); return LCD_OK; }
     LCD_HIP(h, h->bayes.ensure(std::max<int64_t>(t.n_slots, 1)));
     const hipError_t le = h->bayes.link(triples, restart);
     if (le == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_bayes_set_neighbors: a neighbour list longer than 8192 entries");
@@ -1284,9 +1341,10 @@ int lcd_get_stats(lcd_engine* h, lcd_stats* out) {
     { int rc = h->sync_all(); if (rc) return rc; }
     out->knn_last_fallback_queries = 0;
     out->knn_max_err_ratio = 0.0;
-    if (h->d_fail_count.p) {
+    const void* fc = h->last_fail_count ? h->last_fail_count : h->d_fail_count.p;
+    if (fc) {
         int32_t n[3] = {0, 0, 0};
-        int rc = download(h, n, h->d_fail_count.p, 12, h->h_out2);
+        int rc = download(h, n, fc, 12, h->h_out2);
         if (rc) return rc;
         out->knn_last_fallback_queries = n[0];
         float r;

@@ -62,6 +62,7 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
     for (int i = tid; i < a.n; i += NT) {
         int32_t ws = src_lds ? src_lds[i] : a.src[i];
         if (a.xlate) ws = (ws > 0 && (long long)ws < a.xlate_n) ? a.xlate[ws] : -1;
+        else if (ws <= -2) ws = a.new_ws.n > 0 ? ws_runs_at(a.new_ws, -ws - 2) : -1;   // the k-th new word of the frame (split tail)
         if (ws < 0) continue;
         const uint32_t w = (uint32_t)ws;
         uint32_t h = (w * 2654435761u) & (uint32_t)(H - 1);
@@ -216,6 +217,43 @@ __device__ __forceinline__ void frame_tail_body(uint32_t* ft_dyn_smem, const Res
     FT_STAMP(2);
     frame_words_body<NT, true>(ft_dyn_smem, a, lds_ws, have_ne0, ne0);
     FT_STAMP(3);
+}
+
+// The same tail split in two for the pipelined handle (frame_a_kernel): the decision loop of frame t - 1 and the retirement +
+// registration of frame t - 2 run as two workgroups of the SAME launch (12.9 us + 9.2 us at 256 threads used to be one 22 us chain,
+// longer than the 20 us filter it was meant to hide behind).  The word slots travel through global memory (out_wslot), new words as
+// the codes -(k + 2) (ResolveArgs::new_ws.n < 0) because their postings keys are reserved when the registration is prepared.
+template <int NT>
+__device__ __forceinline__ void frame_resolve_part(uint32_t* ft_dyn_smem, const ResolveArgs& r, int wb, int n_wb) {
+    if (wb > 0) { rowpar_body<64, NT>(r.rp, wb - 1, n_wb - 1, r.fail_count); return; }
+    if (r.rp.enabled && n_wb > 1) {
+        if (threadIdx.x == 0 && r.fail_count[0] > 0) {
+            while (__hip_atomic_load(&r.fail_count[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+    FT_STAMP(0);
+    constexpr int KPT = 1024 / NT;
+    if (r.q <= KPT * NT) resolve_body_fast<NT, KPT>(ft_dyn_smem, nullptr, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld,
+                                                    r.cand_bits, r.bw, r.out_word, r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws,
+                                                    r.cand_list, r.cand_cnt);
+    else resolve_body<NT>(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
+                          r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
+    if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; r.fail_count[3] = 0; }
+    FT_STAMP(1);
+}
+template <int NT>
+__device__ __forceinline__ void frame_register_part(uint32_t* ft_dyn_smem, const FwArgs& a, const RetireArgs& retire) {
+    uint32_t ne0 = 0u;
+    const bool have_ne0 = a.do_register && a.ne_counter != nullptr;
+    if (threadIdx.x == 0 && have_ne0) ne0 = gload(a.ne_counter);
+    FT_STAMP(4);
+    retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
+    __syncthreads();
+    FT_STAMP(5);
+    frame_words_body<NT, true>(ft_dyn_smem, a, nullptr, have_ne0, ne0);
+    FT_STAMP(6);
 }
 
 

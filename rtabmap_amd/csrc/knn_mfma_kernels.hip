@@ -482,32 +482,36 @@ __device__ __forceinline__ uint64_t third_of_two_triples(uint64_t a0, uint64_t a
 }
 
 // ---- same-frame distance matrix, computed by extra workgroups of the filter launch (independent of the 2-NN; a launch of its own
-// costs more than the work).  One workgroup = one 32 x 32 tile of the upper triangle of D[r][c] = |q_r - q_c|^2 in the reference's
-// arithmetic (dist.h:150-177; (a - b)^2 == (b - a)^2 bit for bit, so the mirrored tile is a copy).  Both 32-query tiles are staged
-// in LDS (16-byte chunks XOR-swizzled by the row so that the 32 lanes of a half-wave, one query each, read conflict-free).
+// costs more than the work).  One workgroup = one 64 x 64 tile of the upper triangle of D[r][c] = |q_r - q_c|^2 in the reference's
+// arithmetic (dist.h:150-177; (a - b)^2 == (b - a)^2 bit for bit, so the mirrored tile is a copy).  Both 64-query tiles are staged
+// in LDS (16-byte chunks XOR-swizzled by the row so that lanes with different queries read conflict-free); a thread owns a 4 x 4 block
+// of the tile (rows ty + 16 m, columns tx + 16 n), so a 16-byte LDS read feeds four outputs.  64 x 64 and not 32 x 32: every workgroup
+// of the launch holds a whole compute unit's LDS, and 500 descriptors are 36 tiles -- which fit on the compute units the 192 filter
+// workgroups leave free -- instead of 136, which did not (the launch then ran in two rounds: 23 us instead of 15).
 struct SelfdistJob {
     const float* queries = nullptr;    // [nq x 64]
     int nq = 0;
     float* out = nullptr;              // [nq x ld]
     int ld = 0;
-    int n_tiles = 0;                   // workgroups: T (T + 1) / 2, T = ceil(nq / 32); 0 = no job
+    int n_tiles = 0;                   // workgroups: T (T + 1) / 2, T = ceil(nq / 64); 0 = no job
 };
+inline int selfdist_tiles(int q) { const int T = (q + 63) / 64; return T * (T + 1) / 2; }
 __device__ __forceinline__ void selfdist_tile(const SelfdistJob& sd, int k, float* __restrict__ lds) {
-    const int T = (sd.nq + 31) / 32;
+    const int T = (sd.nq + 63) / 64;
     int ti = 0, rem = k;
     while (rem >= T - ti) { rem -= T - ti; ++ti; }
     const int tj = ti + rem;
     const int tid = threadIdx.x;
     const bool act = tid < 256;                        // the tile is the work of 256 threads; a larger workgroup's other threads idle
-    float* sA = lds;                   // rows of tile ti   [32][64] swizzled
-    float* sB = lds + 2048;            // rows of tile tj
-    float* sT = lds + 4096;            // [32][33] transposed result
+    float* sA = lds;                   // rows of tile ti   [64][64] swizzled
+    float* sB = lds + 4096;            // rows of tile tj
+    float* sT = lds + 8192;            // [64][65] transposed result
     if (act) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const int e = tid + u * 256;                   // float4 index within a tile: row e / 16, chunk e % 16
             const int r = e >> 4, c = e & 15;
-            const int ra = min(ti * 32 + r, sd.nq - 1), rb = min(tj * 32 + r, sd.nq - 1);
+            const int ra = min(ti * 64 + r, sd.nq - 1), rb = min(tj * 64 + r, sd.nq - 1);
             const float4 a = reinterpret_cast<const float4*>(sd.queries + (size_t)ra * 64)[c];
             const float4 b = reinterpret_cast<const float4*>(sd.queries + (size_t)rb * 64)[c];
             *reinterpret_cast<float4*>(sA + r * 64 + ((c ^ (r & 15)) << 2)) = a;
@@ -515,46 +519,57 @@ __device__ __forceinline__ void selfdist_tile(const SelfdistJob& sd, int k, floa
         }
     }
     __syncthreads();
-    const int i = tid & 31, jj = (tid >> 5) & 7;       // column query i of tile tj; rows jj, jj + 8, jj + 16, jj + 24 of tile ti
+    const int tx = tid & 15, ty = (tid >> 4) & 15;     // columns tx + 16 n of tile tj; rows ty + 16 m of tile ti
     if (act) {
-        float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
+        float res[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) res[m][n] = 0.0f;
+#pragma unroll 2
         for (int g = 0; g < 16; ++g) {
-            const float4 b = *reinterpret_cast<const float4*>(sB + i * 64 + ((g ^ (i & 15)) << 2));
+            float4 a[4], b[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int r = jj + 8 * m;
-                const float4 a = *reinterpret_cast<const float4*>(sA + r * 64 + ((g ^ (r & 15)) << 2));
-                const float d0 = __fsub_rn(a.x, b.x), d1 = __fsub_rn(a.y, b.y), d2 = __fsub_rn(a.z, b.z), d3 = __fsub_rn(a.w, b.w);
-                float t = __fmul_rn(d0, d0);
-                t = __fadd_rn(t, __fmul_rn(d1, d1));
-                t = __fadd_rn(t, __fmul_rn(d2, d2));
-                t = __fadd_rn(t, __fmul_rn(d3, d3));
-                res[m] = __fadd_rn(res[m], t);
+            for (int m = 0; m < 4; ++m) { const int r = ty + 16 * m; a[m] = *reinterpret_cast<const float4*>(sA + r * 64 + ((g ^ (r & 15)) << 2)); }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { const int c = tx + 16 * n; b[n] = *reinterpret_cast<const float4*>(sB + c * 64 + ((g ^ (c & 15)) << 2)); }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const float d0 = __fsub_rn(a[m].x, b[n].x), d1 = __fsub_rn(a[m].y, b[n].y), d2 = __fsub_rn(a[m].z, b[n].z), d3 = __fsub_rn(a[m].w, b[n].w);
+                    float t = __fmul_rn(d0, d0);
+                    t = __fadd_rn(t, __fmul_rn(d1, d1));
+                    t = __fadd_rn(t, __fmul_rn(d2, d2));
+                    t = __fadd_rn(t, __fmul_rn(d3, d3));
+                    res[m][n] = __fadd_rn(res[m][n], t);
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int r = ti * 64 + ty + 16 * m, c = tj * 64 + tx + 16 * n;
+                if (r < sd.nq && c < sd.nq) sd.out[(size_t)r * sd.ld + c] = res[m][n];
+                sT[(ty + 16 * m) * 65 + tx + 16 * n] = res[m][n];
             }
-        }
-        const int c = tj * 32 + i;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int r = ti * 32 + jj + 8 * m;
-            if (r < sd.nq && c < sd.nq) sd.out[(size_t)r * sd.ld + c] = res[m];
-            sT[(jj + 8 * m) * 33 + i] = res[m];
-        }
     }
     if (ti == tj) return;                              // uniform
     __syncthreads();
     if (act) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {                  // mirrored tile: D[tj*32 + x][ti*32 + i] = D[ti*32 + i][tj*32 + x]
-            const int x = jj + 8 * m;
-            const int r = tj * 32 + x, cc = ti * 32 + i;
-            if (r < sd.nq && cc < sd.nq) sd.out[(size_t)r * sd.ld + cc] = sT[i * 33 + x];
-        }
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {              // mirrored tile: D[tj*64 + x][ti*64 + y] = D[ti*64 + y][tj*64 + x]
+                const int x = ty + 16 * m, y = tx + 16 * n;
+                const int r = tj * 64 + x, cc = ti * 64 + y;
+                if (r < sd.nq && cc < sd.nq) sd.out[(size_t)r * sd.ld + cc] = sT[y * 65 + x];
+            }
     }
 }
 
-// partial_keys [qpad][n_blocks][BF_KEEP] u64, partial_bound [qpad][n_blocks] f32 bits.  Grid (1-D): sd.n_tiles distance-matrix
-// workgroups first, then n_blocks x ceil(nq / 512) filter workgroups.
+// partial_keys [qpad][n_blocks][BF_KEEP] u64, partial_bound [qpad][n_blocks] f32 bits.  Grid (1-D): n_blocks x ceil(nq / 512) filter
+// workgroups first, then sd.n_tiles distance-matrix workgroups.
 template <int NG>
 __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
                                                      int n_rows, const float* __restrict__ queries, int nq, int qpad,
@@ -567,8 +582,12 @@ __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, cons
     constexpr int NW = BF_QB / (NG * 32);          // waves per workgroup
     constexpr int QW = NG * 32;                    // queries per wave
     constexpr int DPW = 8 / NW;                    // DMA instructions of a tile issued by one wave
-    if (bid < sd.n_tiles) { selfdist_tile(sd, bid, s_dyn); return; }
-    const int fb = bid - sd.n_tiles;
+    // the filter workgroups come FIRST in the grid: a workgroup holds a whole compute unit's LDS, workgroups are dispatched in index order,
+    // and the (short) distance-matrix tiles in front used to take 136 of the 256 compute units at the start of the launch -- a third of the
+    // filter workgroups then began only when a tile, or another filter workgroup, had finished (entry spread 0 .. 12 us for a 12 us workgroup)
+    const int n_fwg = n_blocks * ((nq + BF_QB - 1) / BF_QB);
+    if (bid >= n_fwg) { selfdist_tile(sd, bid - n_fwg, s_dyn); return; }
+    const int fb = bid;
     const int bx = fb % n_blocks, by = fb / n_blocks;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -764,8 +783,9 @@ __device__ __forceinline__ void knn_bf16_filter_body_p(float* s_dyn, int bid, co
     constexpr int NW = BF_QB / (NG * 32);
     constexpr int QW = NG * 32;
     constexpr int DPW = 8 / NW;
-    if (bid < sd.n_tiles) { selfdist_tile(sd, bid, s_dyn); return; }
-    const int fb = bid - sd.n_tiles;
+    const int n_fwg = px * ((nq + BF_QB - 1) / BF_QB);                // filter workgroups first, distance-matrix tiles behind them (see above)
+    if (bid >= n_fwg) { selfdist_tile(sd, bid - n_fwg, s_dyn); return; }
+    const int fb = bid;
     const int bx0 = fb % px, by = fb / px;
     const int n_my = (n_blocks - bx0 + px - 1) / px;                 // strips of this workgroup: bx0, bx0 + px, ...
     const int lane = threadIdx.x & 63;
@@ -1181,33 +1201,55 @@ struct RerankArgs {
 };
 constexpr int PIPE_BLOCK = 256;     // workgroup size of both fused launches (the filter's and the re-rank's)
 
-// workgroup 0 is the tail (dispatched first: it is the longest single workgroup of the launch); its redo helpers come LAST -- they
-// have nothing to do unless the certificate rejected a query, and in front they would each hold a compute unit's LDS while they find out
-__global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel(FilterArgs f, int n_tail_wgs, int n_filter_wgs, ResolveArgs r, FwArgs a, RetireArgs ret) {
-    extern __shared__ __attribute__((aligned(16))) float s_dyn_a[];
+// workgroup 0 is the decision loop of the previous frame, workgroup 1 the retirement + registration of the frame before that (dispatched
+// first: they are the longest single workgroups of the launch); the redo helpers of the decision loop come LAST -- they have nothing
+// to do unless the certificate rejected a query, and in front they would each hold a compute unit's LDS while they find out
+struct TailRoles { int has_resolve, has_register, n_redo, n_filter_wgs; };
+#ifdef LCD_B_TIMING   // timing experiment only: start / end of every workgroup of launch A (100 MHz)
+__device__ unsigned long long g_a_timing[2 * 4096];
+#define A_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4096) g_a_timing[2 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define A_STAMP(i) do { } while (0)
+#endif
+template <bool PERSISTENT>
+__device__ __forceinline__ void frame_a_body(float* s_dyn, const FilterArgs& f, int px, const TailRoles& tr, const ResolveArgs& r, const FwArgs& a,
+                                             const RetireArgs& ret) {
     const int bid = (int)blockIdx.x;
-    const int has_tail = n_tail_wgs > 0 ? 1 : 0;
-    if (bid < has_tail) { frame_tail_body<PIPE_BLOCK>((uint32_t*)s_dyn_a, r, a, ret, 0, n_tail_wgs); return; }
-    if (bid >= has_tail + n_filter_wgs) { frame_tail_body<PIPE_BLOCK>((uint32_t*)s_dyn_a, r, a, ret, bid - n_filter_wgs, n_tail_wgs); return; }
-    knn_bf16_filter_body<4>(s_dyn_a, bid - has_tail, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, f.pk,
-                            f.pl, f.sd);
+    const int n_front = tr.has_resolve + tr.has_register;
+    A_STAMP(0);
+    if (bid < tr.has_resolve) { frame_resolve_part<PIPE_BLOCK>((uint32_t*)s_dyn, r, 0, 1 + tr.n_redo); A_STAMP(1); return; }
+    if (bid < n_front) { frame_register_part<PIPE_BLOCK>((uint32_t*)s_dyn, a, ret); A_STAMP(1); return; }
+    if (bid >= n_front + tr.n_filter_wgs) { frame_resolve_part<PIPE_BLOCK>((uint32_t*)s_dyn, r, bid - n_front - tr.n_filter_wgs + 1, 1 + tr.n_redo); A_STAMP(1); return; }
+    if constexpr (PERSISTENT)
+        knn_bf16_filter_body_p(s_dyn, bid - n_front, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, px, f.pk,
+                               f.pl, f.sd);
+    else
+        knn_bf16_filter_body<4>(s_dyn, bid - n_front, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, f.pk, f.pl,
+                                f.sd);
+    A_STAMP(1);
+}
+__global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel(FilterArgs f, TailRoles tr, ResolveArgs r, FwArgs a, RetireArgs ret) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn_a[];
+    frame_a_body<false>(s_dyn_a, f, 0, tr, r, a, ret);
 }
 // the same launch over a vocabulary of more strips than compute units: persistent filter workgroups (knn_bf16_filter_body_p)
-__global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel_p(FilterArgs f, int px, int n_tail_wgs, int n_filter_wgs, ResolveArgs r, FwArgs a,
-                                                               RetireArgs ret) {
+__global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel_p(FilterArgs f, int px, TailRoles tr, ResolveArgs r, FwArgs a, RetireArgs ret) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn_ap[];
-    const int bid = (int)blockIdx.x;
-    const int has_tail = n_tail_wgs > 0 ? 1 : 0;
-    if (bid < has_tail) { frame_tail_body<PIPE_BLOCK>((uint32_t*)s_dyn_ap, r, a, ret, 0, n_tail_wgs); return; }
-    if (bid >= has_tail + n_filter_wgs) { frame_tail_body<PIPE_BLOCK>((uint32_t*)s_dyn_ap, r, a, ret, bid - n_filter_wgs, n_tail_wgs); return; }
-    knn_bf16_filter_body_p(s_dyn_ap, bid - has_tail, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, px,
-                           f.pk, f.pl, f.sd);
+    frame_a_body<true>(s_dyn_ap, f, px, tr, r, a, ret);
 }
+#ifdef LCD_B_TIMING   // timing experiment only: start / end of every workgroup of launch B (100 MHz)
+__device__ unsigned long long g_b_timing[2 * 4096];
+#define B_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4096) g_b_timing[2 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define B_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(PIPE_BLOCK) void frame_b_kernel(RerankArgs k, int n_rerank_wgs, ScoreArgs A) {
     const int bid = (int)blockIdx.x;
+    B_STAMP(0);
     if (bid < n_rerank_wgs) {
         knn_mfma_rerank_body<64, BF_KEEP, false, true>(bid, k.pk, k.pl, k.n_blocks, k.nq, k.vocab, k.queries, k.row_id, k.norm_max_bits, k.out_row,
                                                        k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb);
+        B_STAMP(1);
         return;
     }
     const int g = bid - n_rerank_wgs;
@@ -1215,6 +1257,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void frame_b_kernel(RerankArgs k, int n
         const int b = (g & 7) * (A.n_closed_pad >> 3) + (g >> 3);
         if (b < A.n_closed) score_sealed_body<PIPE_BLOCK>(A, b);
     } else score_open_body<PIPE_BLOCK>(A, g - A.n_closed_pad);
+    B_STAMP(1);
 }
 
 // ------------------------------------------------------------------------------------------------ row-parallel exact scan
@@ -1225,6 +1268,16 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_rowpar_kernel(RowparArgs a, int3
 
 }  // namespace
 }  // namespace lcd
+#ifdef LCD_B_TIMING
+extern "C" int lcd_debug_a_timing(unsigned long long* out, int n_words) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcd::g_a_timing), (size_t)n_words * 8);
+}
+extern "C" int lcd_debug_b_timing(unsigned long long* out, int n_words) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcd::g_b_timing), (size_t)n_words * 8);
+}
+#endif
 #ifdef LCD_MFMA_TIMING
 extern "C" int lcd_debug_mfma_timing(unsigned long long* out, int n_words) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
@@ -1317,14 +1370,19 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
 }
 
 // ---- bf16x3 filter
-MfmaPlan knn_bf16_plan(int q, int n_rows) {
+int knn_selfdist_wgs(int q) { return selfdist_tiles(q); }
+// other_wgs: workgroups of the same launch that run for about as long as a filter workgroup (distance-matrix tiles, the frame tail's
+// two workgroups).  Every workgroup of the launch holds a whole compute unit's LDS: 256 strips + 2 tail workgroups used to leave two
+// strips for a second round -- a 12 us workgroup each, the launch took twice as long as its filter.
+MfmaPlan knn_bf16_plan(int q, int n_rows, int other_wgs) {
     MfmaPlan p;
     p.q = q;
     p.qpad = (q + 63) / 64 * 64;
     p.n_rows = n_rows;
     const int n_tiles = (n_rows + 31) / 32;
     const int qchunks = (q + BF_QB - 1) / BF_QB;
-    int nb = (256 + qchunks - 1) / qchunks;                            // one workgroup (4 waves, one per SIMD) per CU
+    const int cus = other_wgs > 0 && other_wgs < 128 ? 256 - other_wgs : 256;
+    int nb = cus / qchunks > 0 ? cus / qchunks : 1;                    // one workgroup (4 waves, one per SIMD) per CU
     if (nb > n_tiles) nb = n_tiles;
     if (nb < 1) nb = 1;
     int tpb = (n_tiles + nb - 1) / nb;
@@ -1379,8 +1437,7 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
         (void)attr4; (void)attr2;
         SelfdistJob sd;
         if (with_selfdist && cb) {                                    // the same-frame distance matrix rides along
-            const int T = (p.q + 31) / 32;
-            sd.queries = (const float*)queries; sd.nq = p.q; sd.out = const_cast<float*>(cb->selfdist); sd.ld = cb->ld; sd.n_tiles = T * (T + 1) / 2;
+            sd.queries = (const float*)queries; sd.nq = p.q; sd.out = const_cast<float*>(cb->selfdist); sd.ld = cb->ld; sd.n_tiles = selfdist_tiles(p.q);
         }
         const int grid = sd.n_tiles + p.n_blocks * ((p.q + BF_QB - 1) / BF_QB);
         const int px = bf16_persistent_px(p);
@@ -1431,7 +1488,7 @@ hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, 
 // ---- software-pipelined frames (see frame_a_kernel / frame_b_kernel)
 int pipe_block_size() { return PIPE_BLOCK; }
 
-hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* tail, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
+hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* resolve, const TailLaunch* reg, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
     const MfmaPlan& p = k.plan;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        (int)BF_LDS_BYTES);
@@ -1443,25 +1500,27 @@ hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* tail, hipStream_t 
     f.tiles_per_block = p.tiles_per_block; f.n_blocks = p.n_blocks; f.pk = pk; f.pl = pl;
     f.sd = SelfdistJob();
     if (k.cb.selfdist) {                                              // the same-frame distance matrix rides along
-        const int T = (p.q + 31) / 32;
-        f.sd.queries = (const float*)k.queries; f.sd.nq = p.q; f.sd.out = const_cast<float*>(k.cb.selfdist); f.sd.ld = k.cb.ld; f.sd.n_tiles = T * (T + 1) / 2;
+        f.sd.queries = (const float*)k.queries; f.sd.nq = p.q; f.sd.out = const_cast<float*>(k.cb.selfdist); f.sd.ld = k.cb.ld; f.sd.n_tiles = selfdist_tiles(p.q);
     }
     const int px = p.q > 0 ? bf16_persistent_px(p) : 0;
-    const int n_filter = p.q > 0 ? f.sd.n_tiles + (px > 0 ? px : p.n_blocks) * ((p.q + BF_QB - 1) / BF_QB) : 0;
-    const int n_tail = tail ? 1 + tail->n_redo : 0;
-    if (n_filter + n_tail == 0) return hipSuccess;
-    if (tail && tail->shmem > BF_LDS_BYTES) return hipErrorInvalidValue;
+    TailRoles tr;
+    tr.n_filter_wgs = p.q > 0 ? f.sd.n_tiles + (px > 0 ? px : p.n_blocks) * ((p.q + BF_QB - 1) / BF_QB) : 0;
+    tr.has_resolve = resolve ? 1 : 0; tr.has_register = reg ? 1 : 0; tr.n_redo = resolve ? resolve->n_redo : 0;
+    const int grid = tr.n_filter_wgs + tr.has_resolve + tr.has_register + tr.n_redo;
+    if (grid == 0) return hipSuccess;
+    if ((resolve && resolve->shmem_resolve > BF_LDS_BYTES) || (reg && reg->shmem > BF_LDS_BYTES)) return hipErrorInvalidValue;
     ResolveArgs r{}; FwArgs a{}; RetireArgs ret{};
-    if (tail) { r = tail->r; a = tail->a; ret = tail->ret; }
+    if (resolve) r = resolve->r;
+    if (reg) { a = reg->a; ret = reg->ret; }
     hipError_t e;
     if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
     if (px > 0) {
         static const hipError_t attrp = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel_p),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES_P);
         (void)attrp;
-        frame_a_kernel_p<<<n_filter + n_tail, PIPE_BLOCK, BF_LDS_BYTES_P, s>>>(f, px, n_tail, n_filter, r, a, ret);
+        frame_a_kernel_p<<<grid, PIPE_BLOCK, BF_LDS_BYTES_P, s>>>(f, px, tr, r, a, ret);
     } else
-        frame_a_kernel<<<n_filter + n_tail, PIPE_BLOCK, BF_LDS_BYTES, s>>>(f, n_tail, n_filter, r, a, ret);
+        frame_a_kernel<<<grid, PIPE_BLOCK, BF_LDS_BYTES, s>>>(f, tr, r, a, ret);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }

@@ -50,6 +50,8 @@ inline void cand_bits_layout(CandBits& cb, uint32_t* base, int q, int bw) {
 
 // Postings keys reserved for the words a frame may create: the k-th new word of the frame gets the k-th key of the
 // concatenated runs (recycled keys come back as a handful of intervals; the rest is one fresh interval).  n == 0: none.
+// n < 0 (decision loop only): the keys are not known yet -- the loop leaves the code -(k + 2) for the frame's k-th new word and the
+// registration, which runs one launch later on a pipelined handle, translates it with the runs it was given.
 struct WsRuns {
     int32_t start[16];
     int32_t len[16];
@@ -126,7 +128,8 @@ hipError_t launch_shard_merge(const void* all_cand, int world, int rank, int q, 
 
 // ---- the same filter on the bf16 matrix pipe (three bf16 products per f32 product, fp32 accumulate): needs the hi/lo bf16
 // split of the vocabulary (256 bytes per row) kept by launch_vocab_bf16 next to the rows.
-MfmaPlan knn_bf16_plan(int q, int n_rows);
+MfmaPlan knn_bf16_plan(int q, int n_rows, int other_wgs = 0 /* long-running workgroups sharing the launch */);
+int knn_selfdist_wgs(int q);   // distance-matrix workgroups of a q-descriptor frame
 size_t knn_bf16_partial_bytes(const MfmaPlan& p);
 hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void* bf, hipStream_t s);
 hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, const float* row_norm, const uint32_t* norm_max_bits,

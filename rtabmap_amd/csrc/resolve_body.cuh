@@ -314,6 +314,7 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
         out_word[i] = w;
         int32_t ws = -1;
         if (w < 0 && new_ws.n > 0) ws = ws_runs_at(new_ws, -w - 1);
+        if (w < 0 && new_ws.n < 0) ws = w - 1;                          // split tail: code -(k + 2), translated by the registration workgroup
         if (w > 0) { if (S.w0 == w) ws = S.ws_a; else if (S.w1 == w) ws = S.ws_b; }
         if (lds_wslot) lds_wslot[i] = ws;
         else if (out_wslot) out_wslot[i] = ws;
@@ -406,6 +407,7 @@ __device__ __forceinline__ void resolve_body(uint32_t* rs_smem, int q, int flags
             // for the frame's new words; without a reservation new words get no posting.
             int32_t ws = -1;
             if (w < 0 && new_ws.n > 0) ws = ws_runs_at(new_ws, -w - 1);
+            if (w < 0 && new_ws.n < 0) ws = w - 1;                      // split tail: code -(k + 2) (see resolve_body_fast)
             if (w > 0) {
                 if (knn_word[2 * i] == w) ws = row_wslot ? row_wslot[knn_row[2 * i]] : knn_row[2 * i];
                 else if (knn_word[2 * i + 1] == w) ws = row_wslot ? row_wslot[knn_row[2 * i + 1]] : knn_row[2 * i + 1];

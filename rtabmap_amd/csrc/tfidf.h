@@ -119,6 +119,7 @@ struct FwArgs {
     uint32_t* coo_w; uint32_t* coo_pc; uint32_t* ne_counter;
     int32_t* slot_sig; uint32_t* slot_ni; uint32_t* slot_begin; uint32_t* slot_cnt;
     uint32_t* q_w; int32_t* q_idf; int32_t* q_did; int32_t* qd_did; int32_t* qd_idf; uint32_t* q_meta; uint2* idf_tab;
+    WsRuns new_ws;                                // src entries <= -2 are codes -(k + 2) of the frame's k-th new word (WsRuns, n < 0)
 };
 // signatures whose retirement was requested since the last frame (Memory::disableWordsRef -> removeAllWordRef): their
 // words lose one reference each and the slot is marked dead (ni = 0).  Up to 4 ride along with the next frame-words launch.
@@ -134,11 +135,14 @@ struct ScoreArgs {
     const uint2* idf_tab; uint32_t stamp;
     float* out_like; long long* out_fix;    // exactly one is non-NULL
 };
-// a frame tail ready to be launched (stand-alone, or inside the filter launch of the next frame)
+// a frame tail ready to be launched (stand-alone, or inside the filter launches of the following frames).  On a pipelined handle
+// the tail is split over two workgroups of two consecutive launches: the decision loop (r, n_redo, shmem_resolve) and, one launch
+// later, retirement + registration (a, ret, shmem): each is a chain of dependent round trips, and together they outlasted the filter.
 struct TailLaunch {
     ResolveArgs r; FwArgs a; RetireArgs ret;
     int n_redo = 0;            // extra workgroups for the exact redo of rejected queries
-    size_t shmem = 0;          // dynamic LDS of the tail workgroup
+    size_t shmem = 0;          // dynamic LDS of the tail workgroup (whole tail, or the registration alone)
+    size_t shmem_resolve = 0;  // dynamic LDS of the decision loop alone
 };
 // the 2-NN stage of a pipelined frame: everything the fused launches need (pointers into one of the two scratch sets)
 struct PipeKnn {
@@ -148,7 +152,11 @@ struct PipeKnn {
     CandBits cb;               // cb.selfdist != NULL: the filter launch also fills the same-frame distance matrix
 };
 int pipe_block_size();
-hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* tail, hipStream_t s, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+void resolve_launch_info(const ResolveArgs& r, int block, int* n_redo, size_t* shmem);
+// filter of the newest frame + the decision loop of one earlier frame (resolve: r / n_redo / shmem_resolve of that TailLaunch) + the
+// registration of a still earlier one (reg: a / ret / shmem); either may be NULL
+hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* resolve, const TailLaunch* reg, hipStream_t s, hipEvent_t ev_begin = nullptr,
+                          hipEvent_t ev_end = nullptr);
 hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wgs, hipStream_t s, hipEvent_t ev_begin = nullptr,
                           hipEvent_t ev_end = nullptr);
 
@@ -229,11 +237,14 @@ struct Tfidf {
     // frame's unique words / idf are left in q_* for a following score()
     // defer != NULL (needs resolve): do not launch the frame tail, leave its launch arguments there -- sized for a workgroup of
     // pipe_block_size() threads -- for the filter launch of the next frame to carry (knn_mfma_kernels.hip, frame_a_kernel)
+    // defer without resolve: the registration alone is left there (its word slots were written by a decision loop launched earlier;
+    // new_ws translates that loop's new-word codes, see WsRuns)
     hipError_t register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N, const ResolveArgs* resolve = nullptr,
-                            bool ids_given = false /* d_wslots holds word ids, translated on the device */, TailLaunch* defer = nullptr);
+                            bool ids_given = false /* d_wslots holds word ids, translated on the device */, TailLaunch* defer = nullptr,
+                            const WsRuns* new_ws = nullptr);
     // prepare q_* from word slots on the device without registering anything
     hipError_t query_dev(const int32_t* d_wslots, int n, float N, const ResolveArgs* resolve = nullptr, bool ids_given = false,
-                         TailLaunch* defer = nullptr);
+                         TailLaunch* defer = nullptr, const WsRuns* new_ws = nullptr);
     // Memory::loadDataFromDb replay: many signatures in O(1) launches; d_ids = word ids on the device, offsets[n_sigs + 1]
     hipError_t register_bulk(int n_sigs, const int32_t* sig_ids, const int64_t* offsets, const int32_t* ni, const int32_t* d_ids,
                              int64_t total_ids, int max_n);

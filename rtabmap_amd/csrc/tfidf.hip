@@ -788,7 +788,7 @@ hipError_t Tfidf::flush_retire() {
 }
 
 static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool ids_given, bool reg, int32_t sig_id, int64_t slot, int32_t ni,
-                                  float N, const ResolveArgs* resolve, TailLaunch* defer) {
+                                  float N, const ResolveArgs* resolve, TailLaunch* defer, const WsRuns* new_ws = nullptr) {
     const int H = next_pow2(std::max(2 * n, 128));
     size_t shmem = ((size_t)H * 2 + H / 64 + 8) * 4;
     if (ids_given) TF_TRY(t.sync_id2ws());
@@ -813,6 +813,12 @@ static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool id
     a.slot_cnt = t.slot_cnt.as<uint32_t>();
     a.q_w = t.q_w.as<uint32_t>(); a.q_idf = t.q_idf.as<int32_t>(); a.q_did = t.q_did.as<int32_t>(); a.qd_did = t.qd_did.as<int32_t>();
     a.qd_idf = t.qd_idf.as<int32_t>(); a.q_meta = t.q_meta.as<uint32_t>(); a.idf_tab = t.idf_tab.as<uint2>();
+    a.new_ws = new_ws ? *new_ws : WsRuns();
+    if (defer && !resolve) {                                            // registration alone, launched inside a later filter launch
+        defer->a = a; defer->ret = ret; defer->shmem = shmem;
+        t.q_n_ub = n;
+        return hipSuccess;
+    }
     if (resolve) {
         a.src = resolve->out_wslot;
         const int mw = (resolve->q + 63) / 64 * 2;
@@ -833,8 +839,7 @@ static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool id
 }
 
 hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N, const ResolveArgs* resolve, bool ids_given,
-                               TailLaunch* defer) {
-    if (defer && !resolve) return hipErrorInvalidValue;
+                               TailLaunch* defer, const WsRuns* new_ws) {
     if (n > TF_MAX_WORDS) return hipErrorInvalidValue;
     const int64_t slot = n_slots;
     TF_TRY(ensure_slots(slot + 1));
@@ -845,7 +850,7 @@ hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, i
     }
     Bucket& b = buckets[bi];
     TF_TRY(ensure_log(*this, bi, b.ub_entries + n));
-    TF_TRY(run_frame_words(*this, d_wslots, n, ids_given, true, sig_id, slot, ni, N, resolve, defer));
+    TF_TRY(run_frame_words(*this, d_wslots, n, ids_given, true, sig_id, slot, ni, N, resolve, defer, new_ws));
     b.ub_entries += n;
     b.n_slots += 1;
     b.live += 1;
@@ -856,9 +861,17 @@ hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, i
     return hipSuccess;
 }
 
-hipError_t Tfidf::query_dev(const int32_t* d_wslots, int n, float N, const ResolveArgs* resolve, bool ids_given, TailLaunch* defer) {
-    if (n > TF_MAX_WORDS || (defer && !resolve)) return hipErrorInvalidValue;
-    return run_frame_words(*this, d_wslots, n, ids_given, false, 0, 0, 0, N, resolve, defer);
+hipError_t Tfidf::query_dev(const int32_t* d_wslots, int n, float N, const ResolveArgs* resolve, bool ids_given, TailLaunch* defer,
+                            const WsRuns* new_ws) {
+    if (n > TF_MAX_WORDS) return hipErrorInvalidValue;
+    return run_frame_words(*this, d_wslots, n, ids_given, false, 0, 0, 0, N, resolve, defer, new_ws);
+}
+
+// the decision loop of a frame as a workgroup of `block` threads inside a later filter launch: its redo helpers and its dynamic LDS
+void resolve_launch_info(const ResolveArgs& r, int block, int* n_redo, size_t* shmem) {
+    const int mw = (r.q + 63) / 64 * 2;
+    *shmem = (size_t)(3 * mw + 2) * 4;
+    *n_redo = (r.rp.enabled && r.fail_count) ? (r.rp.n_rows + block - 1) / block : 0;
 }
 
 hipError_t Tfidf::register_bulk(int n_sigs, const int32_t* sig_ids, const int64_t* offsets, const int32_t* ni, const int32_t* d_ids,

@@ -16,7 +16,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
     for s in declared:
         assert hasattr(L, s), s
-    assert L.lcd_abi_version() == 2
+    assert L.lcd_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -260,7 +260,8 @@ def test_frame_dev_carries_the_filter(oracle, pipeline):
         ob.set_neighbors(s, sorted(d), [d[k] for k in sorted(d)])
     cap = total + 8
     bufs = []
-    for _ in range(2):                                                   # a pipelined handle writes a frame's outputs during the next call
+    pdepth = eng.pipeline_depth()                                        # a pipelined handle writes a frame's outputs during the next `pdepth` calls
+    for _ in range(pdepth + 1):
         bufs.append(dict(words=torch.zeros(q, dtype=torch.int32, device="cuda"), like=torch.zeros(cap, dtype=torch.float32, device="cuda"),
                          post=torch.zeros(cap + 1, dtype=torch.float32, device="cuda"), res=torch.zeros(8, dtype=torch.int32, device="cuda"),
                          desc=torch.zeros((q, 64), dtype=torch.float32, device="cuda")))
@@ -270,7 +271,7 @@ def test_frame_dev_carries_the_filter(oracle, pipeline):
         sid = n_bulk + 1 + t
         src = int(rng.integers(60, n_bulk - 50))
         desc = synth.frame_from_signature(vocab, words[src], seed=100 + t)
-        b = bufs[t % 2]
+        b = bufs[t % len(bufs)]
         b["desc"].copy_(torch.from_numpy(desc))
         osid, exp_words = m.update(desc)
         assert osid == sid
@@ -295,14 +296,17 @@ def test_frame_dev_carries_the_filter(oracle, pipeline):
             gone.add(old)
         gone_before = set(gone)
         torch.cuda.synchronize()
-        done = t - 1 if pipeline else t                                  # a pipelined frame's index stage runs inside the next call
+        done = t - pdepth                                                # a pipelined frame's index stage runs inside the later calls
         if done >= 0:
             pids, ppost = expected[done]
-            pb = bufs[done % 2]
+            pb = bufs[done % len(bufs)]
             _check(pids, ppost, _pick(pb["post"], pids), _result(pb["res"]), ("frame", done))
     eng.synchronize()
+    for done in range(max(n_frames - pdepth, 0), n_frames - 1):           # the frames the last calls left owed
+        pids, ppost = expected[done]
+        _check(pids, ppost, _pick(bufs[done % len(bufs)]["post"], pids), _result(bufs[done % len(bufs)]["res"]), ("frame", done))
     pids, ppost = expected[-1]
-    pb = bufs[(n_frames - 1) % 2]
+    pb = bufs[(n_frames - 1) % len(bufs)]
     _check(pids, ppost, _pick(pb["post"], pids), _result(pb["res"]), ("last frame",))
     st = eng.stats()
     assert st["frame_calls"] == n_frames

@@ -1,0 +1,102 @@
+#!/usr/bin/env python
+"""Timing experiment: where launch A of a pipelined frame spends its time.  Build a variant with both stamp sets,
+    python tools/build_variant.py atiming -DLCD_MFMA_TIMING -DLCD_TAIL_TIMING
+and run with LCD_LIB_PATH=rtabmap_amd/liblcd_hip_atiming.so.  Prints (us after the first stamp of the launch) when the filter waves
+entered / left the kernel and when the decision-loop and registration workgroups started / finished, for the last fused launch."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rtabmap_amd  # noqa: E402
+from rtabmap_amd import capi, synth  # noqa: E402
+
+
+def main():
+    n_words, q, n_sig = int(os.environ.get("N_WORDS", "49000")), 500, int(os.environ.get("N_SIG", "100000"))
+    vocab = synth.vocab_surf(n_words)
+    words = synth.zipf_words(n_sig, q, n_words, seed=100000)
+    eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 1024, sig_capacity=n_sig + 4096, pipeline=True)
+    eng.vocab_append(vocab, np.arange(1, n_words + 1, dtype=np.int32))
+    eng.sig_add_bulk(np.arange(1, n_sig + 1, dtype=np.int32), np.arange(0, (n_sig + 1) * q, q, dtype=np.int64), words.reshape(-1))
+    d_words = torch.zeros(q, dtype=torch.int32, device="cuda")
+    cap = n_sig + 4096
+    d_like = torch.zeros(cap, dtype=torch.float32, device="cuda")
+    lib = capi.load()
+    frames = [torch.from_numpy(synth.frame_from_signature(vocab, words[i * 11], seed=i)).cuda() for i in range(8)]
+    res = []
+    for rep in range(6):
+        n = 10 + rep
+        for i in range(n):
+            eng.frame_dev(frames[i % 8].data_ptr(), q, n_sig + 1000 * rep + 1 + i, float(n_sig + 1), d_words.data_ptr(), d_like.data_ptr(), cap,
+                          incremental=True, new_words_compared=True, nndr=0.8, first_new_word_id=n_words + 1 + (100 * rep + i) * q)
+            eng.sig_remove(1 + 20 * rep + i)
+        torch.cuda.synchronize()                       # NOT eng.synchronize(): the stamps of the last fused launch must survive
+        tb = (ctypes.c_ulonglong * 64)()
+        assert lib.lcd_debug_tail_timing_pipe(tb) == 0
+        mb = (ctypes.c_ulonglong * (4 * 4096))()
+        lib.lcd_debug_mfma_timing.restype = ctypes.c_int
+        assert lib.lcd_debug_mfma_timing(mb, 4 * 4096) == 0
+        t = np.frombuffer(mb, dtype=np.uint64).reshape(-1, 4).astype(np.float64)
+        wg_of = np.arange(t.shape[0]) // 4
+        keep = (t[:, 0] > 0) & (t[:, 3] >= t[:, 0])
+        keep &= t[:, 3] > t[keep, 3].max() - 20000
+        late = keep & (t[:, 0] > t[keep, 0].min() + 500)
+        if rep == 5:
+            print("workgroups entering > 5 us after the first:", sorted(set(wg_of[late].tolist())))
+        t = t[keep]
+        # keep the waves of the last launch only (stamps within 200 us of the newest one)
+        newest = t[:, 3].max()
+        t = t[t[:, 3] > newest - 20000]
+        tail = np.array(tb[:8], dtype=np.float64)
+        t0 = min(t[:, 0].min(), tail[0] if tail[0] > newest - 20000 else 1e30, tail[4] if tail[4] > newest - 20000 else 1e30)
+        f = (t - t0) / 100.0
+        tl = (tail - t0) / 100.0
+        res.append((f, tl))
+        if hasattr(lib, "lcd_debug_a_timing") and rep == 5:
+            ab = (ctypes.c_ulonglong * (2 * 4096))()
+            assert lib.lcd_debug_a_timing(ab, 2 * 4096) == 0
+            b = np.frombuffer(ab, dtype=np.uint64).reshape(-1, 2).astype(np.float64)
+            idx = np.nonzero(b[:, 1] > b[:, 1].max() - 20000)[0]
+            b = (b[idx] - b[idx, 0].min()) / 100.0
+            n_f = 192 if n_words == 49000 else None
+            print("launch A: %d workgroups stamped" % len(idx))
+            groups = [("decision loop", idx == 0), ("registration", idx == 1)]
+            if n_f:
+                groups += [("filter", (idx >= 2) & (idx < 2 + n_f)), ("distance tiles", (idx >= 2 + n_f) & (idx < 2 + n_f + 36)), ("redo helpers", idx >= 2 + n_f + 36)]
+            for nme, m in groups:
+                if m.sum():
+                    st, en = b[m, 0], b[m, 1]
+                    print("  %-14s n %4d start min %5.2f median %5.2f max %5.2f | end median %5.2f p90 %5.2f max %5.2f | duration median %5.2f max %5.2f" %
+                          (nme, m.sum(), st.min(), np.median(st), st.max(), np.median(en), np.percentile(en, 90), en.max(), np.median(en - st), (en - st).max()))
+        if hasattr(lib, "lcd_debug_b_timing") and rep == 5:
+            bb = (ctypes.c_ulonglong * (2 * 4096))()
+            assert lib.lcd_debug_b_timing(bb, 2 * 4096) == 0
+            b = np.frombuffer(bb, dtype=np.uint64).reshape(-1, 2).astype(np.float64)
+            idx = np.nonzero(b[:, 1] > b[:, 1].max() - 20000)[0]
+            b = (b[idx] - b[idx, 0].min()) / 100.0
+            nr = q
+            print("launch B: %d workgroups stamped (%d re-rank, %d scoring)" % (len(idx), (idx < nr).sum(), (idx >= nr).sum()))
+            for nme, m in (("re-rank", idx < nr), ("scoring", idx >= nr)):
+                if m.sum():
+                    st, en = b[m, 0], b[m, 1]
+                    print("  %-8s start min %5.2f median %5.2f max %5.2f | end median %5.2f p90 %5.2f max %5.2f | duration median %5.2f p90 %5.2f max %5.2f" %
+                          (nme, st.min(), np.median(st), st.max(), np.median(en), np.percentile(en, 90), en.max(), np.median(en - st),
+                           np.percentile(en - st, 90), (en - st).max()))
+        eng.synchronize()
+    f, tl = res[-1]
+    print("%d filter waves in the last launch" % len(f))
+    for i, nme in enumerate(["kernel entry", "loop entry", "loop exit", "kernel exit"]):
+        c = f[:, i]
+        print("  %-13s min %6.2f  p10 %6.2f  median %6.2f  p90 %6.2f  max %6.2f us" % (nme, c.min(), np.percentile(c, 10), np.median(c), np.percentile(c, 90), c.max()))
+    for (f, tl) in res:
+        print("filter: first entry 0.00, last exit %6.2f | decision loop %6.2f -> %6.2f | registration %6.2f -> retire done %6.2f -> %6.2f" %
+              (f[:, 3].max(), tl[0], tl[1], tl[4], tl[5], tl[6]))
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
