@@ -423,37 +423,51 @@ def host_path_ms(torch, eng, frames_np, n_sig, steps=20):
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
-def with_update_ms(torch, eng, vocab, stepper, d_frames, frames_np, steps=32):
-    """The step + VWDictionary::update() (VWDictionary.cpp:475-701): the frame's word ids come back to the host (2 KB), its new
-    words are appended to the device vocabulary (lcd_vocab_append) before the next frame, and every 8th frame the words appended 8
-    frames earlier are removed again and the vocabulary is rebuilt (removeWords + the full-rebuild branch)."""
-    appended = []
-    next_id = stepper.first_new
-    t0 = None
-    for i in range(steps + 4):
-        if i == 4:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        k = i % len(d_frames)
-        stepper.first_new = next_id
-        stepper(k)
-        got = stepper.d_words.cpu().numpy()                          # synchronises: update() needs the decisions
-        new_rows, seen = [], set()
-        for j in np.flatnonzero(got < 0).tolist():
-            if got[j] not in seen:
-                seen.add(int(got[j]))
-                new_rows.append(j)
-        if new_rows:
-            ids = np.arange(next_id, next_id + len(new_rows), dtype=np.int32)
-            eng.vocab_append(frames_np[k][new_rows], ids)
-            appended.append(ids)
-            next_id += len(new_rows)
-        if i % 8 == 7 and len(appended) > 8:
-            eng.vocab_remove(appended.pop(0))
-            eng.vocab_rebuild()
-    torch.cuda.synchronize()
-    stepper.first_new = next_id
-    return 1e3 * (time.perf_counter() - t0) / steps
+def with_update_ms(torch, eng, stepper, steps=256, remove_every=8, rebuild_every=64):
+    """The step + VWDictionary::update() (VWDictionary.cpp:475-701) on the device: every frame's new words become vocabulary rows behind
+    its decision loop (lcd_frame_args.append_new_words: no read-back, no lcd_vocab_append, the pipeline keeps running; the next frame's
+    re-rank scans the rows its filter could not see yet), and every `remove_every`-th frame the words created `remove_every` .. 2 x
+    `remove_every` frames earlier are removed again (lcd_vocab_remove: the pipeline is completed, the rows are tombstoned) -- the
+    vocabulary is compacted (lcd_vocab_rebuild, the full-rebuild branch :610-690) every `rebuild_every`-th frame.  Returns
+    (ms per step with removals, ms per step appending only)."""
+    a = stepper.args
+    a.append_new_words = 1
+    ring_all = torch.zeros((2 * remove_every, Q), dtype=torch.int32, device="cuda")
+    ring = [ring_all[j] for j in range(2 * remove_every)]
+    firsts = [0] * (2 * remove_every)
+    out = []
+    for removals in (True, False):
+        t0 = None
+        for i in range(steps + 16):
+            if i == 16:
+                eng.synchronize()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            slot = i % len(ring)
+            if removals and i % remove_every == remove_every - 1 and i >= 2 * remove_every:
+                # Memory::cleanUnusedWords + removeWords for the words of the frames in the older half of the ring: their ids are
+                # first_new + k for the k-th new word (the -(k+1) codes of d_word_ids)
+                eng.synchronize()
+                codes_all = ring_all.cpu().numpy()                    # one 32 KB read-back per `remove_every` frames
+                gone = []
+                for j in range(remove_every):
+                    o = (slot + 1 + j) % len(ring)
+                    n_new = int(-codes_all[o].min()) if (codes_all[o] < 0).any() else 0
+                    gone.append(np.arange(firsts[o], firsts[o] + n_new, dtype=np.int32))
+                gone = np.concatenate(gone)
+                if gone.size:
+                    eng.vocab_remove(gone)
+                if i % rebuild_every == rebuild_every - 1:
+                    eng.vocab_rebuild()
+            a.d_word_ids = ring[slot].data_ptr()
+            firsts[slot] = stepper.first_new
+            stepper(i)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        out.append(1e3 * (time.perf_counter() - t0) / steps)
+    a.append_new_words = 0
+    a.d_word_ids = stepper.d_words.data_ptr()
+    return out[0], out[1]
 
 
 # ----------------------------------------------------------------------------------------------------------------- ORB stream
@@ -699,10 +713,19 @@ def main():
                 # the same two kernels launched on their own (not fused with the other frame's stages): their own rooflines
                 out["roofline_knn_standalone"] = ku
                 out["roofline_score_standalone"] = su
-            config["with_update_ms_per_step"] = with_update_ms(torch, engu, vocab, stu, d_frames, frames_np)
             config["host_path_ms_per_step"] = host_path_ms(torch, engu, frames_np, n_sig)
-            config["with_update_note"] = "step + D2H of the word ids + lcd_vocab_append of the frame's new words; every 8th frame " \
-                                         "lcd_vocab_remove of an older frame's words + lcd_vocab_rebuild"
+            engw = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 65536, sig_capacity=n_sig + 8192,
+                                      stream=stream.cuda_stream, pipeline=args.pipeline)
+            load_engine(engw, vocab, words)
+            stw = Stepper(engw, torch, d_frames, n_sig, cap)
+            wu, wa = with_update_ms(torch, engw, stw)
+            config["with_update_ms_per_step"] = wu
+            config["with_append_ms_per_step"] = wa
+            config["with_update_note"] = "step with lcd_frame_args.append_new_words (the frame's new words become vocabulary rows on the device, " \
+                                         "VWDictionary::update()'s append branch; the pipeline keeps running) + every 8th frame lcd_vocab_remove of " \
+                                         "the words created 8..16 frames earlier (completes the pipeline, tombstones) + every 64th frame " \
+                                         "lcd_vocab_rebuild; with_append = the same without the removals; vocabulary at the end: %d rows" % engw.vocab_count()[0]
+            engw.close()
             config["host_path_note"] = "lcd_quantize + lcd_sig_add + lcd_likelihood + lcd_sig_remove from host pointers (PCIe + syncs included)"
             engu.close()
             engb = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 8192,

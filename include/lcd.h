@@ -219,7 +219,13 @@ typedef struct lcd_frame_args {
     float* d_adjusted;                 /* out, may be NULL: [n_slots + 1], entry 0 = virtual place, entry 1 + slot = adjusted value
                                           (0 for slots that are retired or not considered) */
     float virtual_place_ratio;         /* Rtabmap/VirtualPlaceLikelihoodRatio (0 = default branch) */
-    int32_t reserved0;
+    int32_t append_new_words;          /* 1 (needs first_new_word_id > 0, LCD_Q_INCREMENTAL, 64-float rows): the words this frame creates become
+                                          vocabulary rows ON THE DEVICE, in descriptor order behind the rows that exist, before the next frame is
+                                          searched == VWDictionary::update()'s append branch (:571-609) run by Memory::preUpdate of the next
+                                          frame (Memory.cpp:1004-1016) -- no lcd_vocab_append, no host round trip.  On a pipelined handle the next
+                                          frame's filter has already taken its snapshot by then: its re-rank scans the appended rows exactly, so
+                                          the result is the 2-NN over the updated vocabulary.  Removals (lcd_vocab_remove / lcd_vocab_rebuild,
+                                          cleanUnusedWords) stay host calls that complete the owed stages first. */
     void* ready_event;                 /* reserved (NULL) */
     float* d_posterior;                /* out, may be NULL (needs d_likelihood and lcd_bayes_configure): the Bayes filter's posterior
                                           after this frame, [n_slots + 1], entry 0 = virtual place, 0 for slots that are retired or

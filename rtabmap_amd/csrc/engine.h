@@ -67,12 +67,29 @@ struct lcd_engine {
     struct DeferredLink { std::vector<int32_t> triples, restart; };
     struct InFlight {
         lcd_frame_args a; lcd::ResolveArgs r; int set = 0;
+        uint64_t vseq = 0; bool chained = false;        // the frame takes part in the device row-count chain (vcnt_active at its call)
+        lcd::WsRuns runs; bool reserved = false;        // postings keys of its new words (reserved when its decision loop is prepared)
         int stage = 1;                                  // 1: the decision loop is owed (and everything after it), 2: registration + scoring are
         std::vector<int32_t> retire_after;              // lcd_sig_remove calls made while this was the newest frame
         std::vector<void*> events_after;                // lcd_record_event calls ...
         std::vector<DeferredLink> links_after;          // lcd_bayes_set_neighbors calls ...
     };
     std::deque<InFlight> inflight;                      // oldest first
+    // ---- VWDictionary::update()'s append branch on the device (lcd_frame_args.append_new_words): the decision loop's workgroup turns the
+    // frame's new words into vocabulary rows, so the row count lives on the device (d_vcnt: two alternating counters + a log of rows
+    // appended per frame).  The host plans launches for an upper bound (the pinned mirror the appender writes, + q per younger frame)
+    // and catches up with the exact rows (h_row_key ...) the next time the handle is drained (reconcile()).
+    static constexpr int VLOG = 4096;
+    lcd::DevBuf d_vcnt;                                 // int32: [0], [1] row counters, [16 .. 16 + VLOG) rows appended by frame seq % VLOG
+    unsigned long long* h_vmirror = nullptr;            // pinned: (seq + 1) << 32 | rows after that frame's append
+    struct DevAppend { uint64_t seq; int32_t first_id; int32_t q; bool enabled; };
+    std::deque<DevAppend> unreconciled;                 // frames whose appends the host mirror has not caught up with
+    uint64_t vseq = 0;                                  // sequence number of the next frame in the chain: it reads counter vseq & 1, writes the other
+    bool vcnt_active = false;                           // the counters hold the row count (set when the first appending frame arrives)
+    bool tail_dirty = true;                             // the host wrote (or reallocated) behind the rows since the tail was last filled
+    int64_t tail_filled_rows = 0;                       // rows [n_rows, tail_filled_rows) carry +inf norms and a zero bf16 split
+    int reconcile();
+    int64_t rows_ub() const;
     int filter_units = -1;                              // lcd_set_option("filter_units")
     int sync_all();                                     // stream drained
     int drain();                                        // complete the owed index stage (stand-alone launches)

@@ -156,7 +156,110 @@ int download(lcd_engine* h, void* dst, const void* d_src, size_t bytes, PinBuf& 
     return LCD_OK;
 }
 
+// ---- VWDictionary::update()'s append branch on the device (see engine.h)
+int64_t vocab_cap_rows(const lcd_engine* h) {
+    int64_t c = (int64_t)(h->vocab.cap / (size_t)h->row_bytes);
+    c = std::min<int64_t>(c, (int64_t)(h->row_id.cap / 4));
+    c = std::min<int64_t>(c, (int64_t)(h->row_wslot.cap / 4));
+    if (h->dtype == LCD_F32) c = std::min<int64_t>(c, (int64_t)(h->row_norm.cap / 8) - 1);
+    if (knn_mfma_supported(h->dtype, h->kdim)) c = std::min<int64_t>(c, (int64_t)(h->vocab_bf.cap / 256));
+    return std::max<int64_t>(c, 0);
+}
+
+// the row buffers hold `rows` rows; what lies behind the rows in use carries +inf norms and a zero bf16 split
+int ensure_append_capacity(lcd_engine* h, int64_t rows) {
+    const int64_t keep = h->rows_ub();
+    if (rows > vocab_cap_rows(h)) {
+        LCD_HIP(h, dreserve(h, h->vocab, (size_t)rows * h->row_bytes, (size_t)keep * h->row_bytes));
+        LCD_HIP(h, dreserve(h, h->row_id, (size_t)rows * 4, (size_t)keep * 4));
+        LCD_HIP(h, dreserve(h, h->row_wslot, (size_t)rows * 4, (size_t)keep * 4));
+        LCD_HIP(h, dreserve(h, h->row_norm, ((size_t)rows + 1) * 8, ((size_t)keep + 1) * 8));
+        LCD_HIP(h, dreserve(h, h->vocab_bf, (size_t)rows * 256, (size_t)keep * 256));
+        h->tail_filled_rows = std::min(h->tail_filled_rows, keep);
+    }
+    const int64_t cap = vocab_cap_rows(h);
+    const int64_t first = std::max(h->tail_filled_rows, keep);
+    if (first < cap) {
+        LCD_HIP(h, launch_vocab_tail(h->row_norm.as<float>(), h->vocab_bf.p, first, cap - first, h->stream));
+        h->tail_filled_rows = cap;
+    }
+    return LCD_OK;
+}
+
+// the first appending frame since the host last changed the vocabulary: the device counters take over the row count
+int activate_dev_rows(lcd_engine* h) {
+    if (h->vcnt_active) return LCD_OK;
+    LCD_HIP(h, dreserve(h, h->d_vcnt, (size_t)(16 + lcd_engine::VLOG) * 4));
+    if (!h->h_vmirror) {
+        LCD_HIP(h, hipHostMalloc((void**)&h->h_vmirror, 64, hipHostMallocDefault));
+        *h->h_vmirror = 0ull;
+    }
+    LCD_HIP(h, hipMemsetD32Async((hipDeviceptr_t)h->d_vcnt.p, (int)h->n_rows, 2, h->stream));
+    if (h->tail_dirty) h->tail_filled_rows = 0;                      // host-side appends / rebuilds wrote behind the rows (or reallocated)
+    h->tail_dirty = false;
+    h->vcnt_active = true;
+    return LCD_OK;
+}
+
+// the vocabulary buffers may have been reallocated since a frame's arguments were stored (device-side appends grow them)
+void refresh_vocab_ptrs(lcd_engine* h, ResolveArgs* r) {
+    r->row_wslot = h->row_wslot.as<int32_t>();
+    if (r->rp.enabled) { r->rp.vocab = (const float*)h->vocab.p; r->rp.row_id = h->row_id.as<int32_t>(); }
+}
+
+// the append (or, for a frame that appends nothing, the hand-over of the row count) that rides with the decision loop of chain frame `vseq`
+void fill_append(lcd_engine* h, const lcd_frame_args& a, uint64_t vseq, bool enabled, ResolveArgs* r) {
+    AppendArgs& ap = r->ap;
+    ap = AppendArgs();
+    ap.enabled = enabled ? 1 : 0;
+    ap.descriptors = (const float*)a.d_descriptors; ap.row_dwords = h->row_bytes / 4; ap.is_f32_64 = knn_mfma_supported(h->dtype, h->kdim) ? 1 : 0;
+    ap.vocab = h->vocab.as<uint32_t>(); ap.row_id = h->row_id.as<int32_t>(); ap.row_wslot = h->row_wslot.as<int32_t>();
+    ap.row_norm = h->row_norm.as<float>(); ap.norm_max_bits = h->norm_max.as<uint32_t>(); ap.vocab_bf = h->vocab_bf.as<uint32_t>();
+    ap.cnt_in = h->d_vcnt.as<int32_t>() + (vseq & 1); ap.cnt_out = h->d_vcnt.as<int32_t>() + ((vseq + 1) & 1);
+    ap.log_slot = h->d_vcnt.as<int32_t>() + 16 + (vseq % lcd_engine::VLOG);
+    ap.first_id = a.first_new_word_id; ap.capacity = vocab_cap_rows(h);
+    ap.host_mirror = h->h_vmirror; ap.tag = (uint32_t)(vseq + 1);
+}
+
 }  // namespace
+
+// rows the vocabulary can have by now: exact when nothing was appended on the device since the last reconciliation, else the count the
+// newest finished appender reported (pinned memory, read without synchronising) + q per younger appending frame
+int64_t lcd_engine::rows_ub() const {
+    if (unreconciled.empty()) return n_rows;
+    uint32_t tag = 0; int64_t cnt = 0;
+    if (h_vmirror) { const unsigned long long v = *(volatile const unsigned long long*)h_vmirror; tag = (uint32_t)(v >> 32); cnt = (int64_t)(uint32_t)v; }
+    int64_t extra = 0;
+    for (auto it = unreconciled.rbegin(); it != unreconciled.rend(); ++it) {
+        if (tag != 0 && (uint32_t)(it->seq + 1) == tag) return cnt + extra;
+        if (it->enabled) extra += it->q;
+    }
+    return n_rows + extra;
+}
+
+// the host's row mirror catches up with the device (synchronises)
+int lcd_engine::reconcile() {
+    if (unreconciled.empty()) return LCD_OK;
+    { int rc = sync_all(); if (rc) return rc; }
+    std::vector<int32_t> log((size_t)VLOG);
+    hipError_t e = hipMemcpy(log.data(), d_vcnt.as<int32_t>() + 16, (size_t)VLOG * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpy(append log)");
+    for (const DevAppend& a : unreconciled) {
+        if (!a.enabled) continue;
+        const int n = log[(size_t)(a.seq % VLOG)];
+        for (int k = 0; k < n; ++k) {
+            const int32_t id = a.first_id + k;
+            if (rows_sorted && !h_row_key.empty() && id <= h_row_key.back()) rows_sorted = false;
+            if (word_row_valid) word_row[id] = (int32_t)(n_rows + k);
+            h_row_key.push_back(id);
+            h_row_live.push_back(1);
+        }
+        n_rows += n;
+        n_live += n;
+    }
+    unreconciled.clear();
+    return LCD_OK;
+}
 
 extern "C" {
 
@@ -232,6 +335,8 @@ void lcd_destroy(lcd_engine* h) {
                      &h->d_extra_dist, &h->d_extra_row, &h->d_like, &h->d_slots, &h->d_bits, &h->row_norm, &h->norm_max, &h->d_partial2,
                      &h->d_fail_list, &h->d_fail_count, &h->d_partial3, &h->row_norm_alt, &h->vocab_bf, &h->d_hyp_scratch, &h->d_adj_scratch};
     for (DevBuf* d : all) d->release(&h->bytes_device);
+    h->d_vcnt.release(&h->bytes_device);
+    if (h->h_vmirror) (void)hipHostFree(h->h_vmirror);
     h->h_in.release(); h->h_out.release(); h->h_out2.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -264,6 +369,7 @@ int lcd_vocab_clear(lcd_engine* h) {
     LCD_DEV(h);
     { int rc = h->sync_all(); if (rc) return rc; }
     h->n_rows = 0; h->n_live = 0;
+    h->vcnt_active = false; h->tail_dirty = true;
     h->h_row_key.clear();
     h->h_row_live.clear();
     h->rows_sorted = true;
@@ -330,6 +436,7 @@ int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word
     }
     h->n_rows = total;
     h->n_live += n;
+    h->vcnt_active = false; h->tail_dirty = true;                    // the device row counters (appends by frames) start over from this count
     return LCD_OK;
 }
 
@@ -366,6 +473,8 @@ int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n) {
         if (h->dtype == LCD_F32) LCD_HIP(h, launch_norm_tombstone(h->row_norm.as<float>(), h->d_tmp_i32.as<int32_t>(), nr, h->stream));
         LCD_HIP(h, hipStreamSynchronize(h->stream));
         for (int i = 0; i < nr; ++i) h->h_row_live[rows[i]] = 0;
+        h->vcnt_active = false;                                      // the counters restart: the next frame's filter sees every row (tombstones carry
+                                                                     // +inf norms), its re-rank has no pending rows -- one of them might be gone now
         if (h->word_row_valid) for (int i = 0; i < n; ++i) h->word_row.erase(word_ids[i]);
         h->n_live -= nr;
     }
@@ -430,12 +539,15 @@ int lcd_vocab_rebuild(lcd_engine* h) {
     h->word_row_valid = false;
     h->n_rows = n;
     h->n_live = n;
+    h->vcnt_active = false; h->tail_dirty = true;
     h->rebuilds += 1;
     return LCD_OK;
 }
 
 int lcd_vocab_count(const lcd_engine* h, int64_t* rows, int64_t* live) {
     LCD_CHECK_HANDLE(h);
+    if (hipSetDevice(h->device) != hipSuccess) return LCD_ERR_HIP;
+    { int rc = const_cast<lcd_engine*>(h)->drain(); if (rc) return rc; }   // rows appended on the device: the owed stages run, the mirror catches up
     if (rows) *rows = h->n_rows;
     if (live) *live = h->n_live;
     return LCD_OK;
@@ -808,11 +920,16 @@ static int frame_score_s(lcd_engine* h, const lcd_frame_args& a) {
     return hypothesis_stage(h, a);
 }
 
-static int reserve_frame_words(lcd_engine* h, const lcd_frame_args& a, WsRuns* runs) {
+static bool frame_appends(const lcd_engine* h, const lcd_frame_args& a) {
+    return a.append_new_words != 0 && a.first_new_word_id > 0 && (a.flags & LCD_Q_INCREMENTAL) != 0 && knn_mfma_supported(h->dtype, h->kdim);
+}
+
+static int reserve_frame_words(lcd_engine* h, const lcd_frame_args& a, WsRuns* runs, bool may_flush = true) {
     *runs = WsRuns();
-    // postings keys for the words this frame may create (VisualWord(id, descriptor, signatureId) references the signature)
-    if (a.sig_id != 0 && a.first_new_word_id > 0 && (a.flags & LCD_Q_INCREMENTAL)) {
-        hipError_t e = h->tfidf.reserve_new_words(a.first_new_word_id, a.q, runs);
+    // postings keys for the words this frame may create (VisualWord(id, descriptor, signatureId) references the signature; a word that
+    // becomes a vocabulary row on the device needs its key there as well)
+    if ((a.sig_id != 0 || frame_appends(h, a)) && a.first_new_word_id > 0 && (a.flags & LCD_Q_INCREMENTAL)) {
+        hipError_t e = h->tfidf.reserve_new_words(a.first_new_word_id, a.q, runs, may_flush);
         if (e == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: word ids must be below 2^28");
         LCD_HIP(h, e);
     }
@@ -820,13 +937,15 @@ static int reserve_frame_words(lcd_engine* h, const lcd_frame_args& a, WsRuns* r
 }
 
 // the whole index stage of a frame, launched on its own: decision loop + registration (one workgroup), scoring, decision stage
-static int frame_stage_s(lcd_engine* h, const lcd_frame_args& a, ResolveArgs r) {
+// chained / vseq: the frame's place in the device row-count chain (a frame that takes part appends its new words, or hands the count on)
+static int frame_stage_s(lcd_engine* h, const lcd_frame_args& a, ResolveArgs r, bool chained = false, uint64_t vseq = 0) {
     Tfidf& t = h->tfidf;
     const int q = a.q;
     if (a.sig_id != 0 && t.sig_slot.count(a.sig_id)) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
     const int64_t slots_after = t.n_slots + (a.sig_id != 0 ? 1 : 0);
     if (a.d_likelihood && a.likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
     { int rc = reserve_frame_words(h, a, &r.new_ws); if (rc) return rc; }
+    if (chained) fill_append(h, a, vseq, frame_appends(h, a), &r); else r.ap = AppendArgs();
     if (a.sig_id != 0) LCD_HIP(h, t.register_dev(a.sig_id, r.out_wslot, q, q, a.N, &r));
     else LCD_HIP(h, t.query_dev(r.out_wslot, q, a.N, &r));
     return frame_score_s(h, a);
@@ -836,10 +955,8 @@ static int frame_stage_s(lcd_engine* h, const lcd_frame_args& a, ResolveArgs r) 
 static int frame_stage_reg_s(lcd_engine* h, const lcd_frame_args& a, const ResolveArgs& r) {
     Tfidf& t = h->tfidf;
     if (a.sig_id != 0 && t.sig_slot.count(a.sig_id)) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
-    WsRuns runs;
-    { int rc = reserve_frame_words(h, a, &runs); if (rc) return rc; }
-    if (a.sig_id != 0) LCD_HIP(h, t.register_dev(a.sig_id, r.out_wslot, a.q, a.q, a.N, nullptr, false, nullptr, &runs));
-    else LCD_HIP(h, t.query_dev(r.out_wslot, a.q, a.N, nullptr, false, nullptr, &runs));
+    if (a.sig_id != 0) LCD_HIP(h, t.register_dev(a.sig_id, r.out_wslot, a.q, a.q, a.N));
+    else LCD_HIP(h, t.query_dev(r.out_wslot, a.q, a.N));
     return frame_score_s(h, a);
 }
 
@@ -866,11 +983,13 @@ int lcd_engine::drain() {
         inflight.pop_front();
         ResolveArgs r = f.r;
         r.new_ws = WsRuns();
-        const int rc = f.stage == 2 ? frame_stage_reg_s(this, f.a, r) : frame_stage_s(this, f.a, r);
+        refresh_vocab_ptrs(this, &r);
+        const int rc = f.stage == 2 ? frame_stage_reg_s(this, f.a, r) : frame_stage_s(this, f.a, r, f.chained, f.vseq);
         const int rc2 = finish_frame_ops(this, f);
         if (!rc_all) rc_all = rc ? rc : rc2;
     }
-    return rc_all;
+    const int rc3 = reconcile();                                     // rows appended on the device: the host mirror catches up
+    return rc_all ? rc_all : rc3;
 }
 
 // Pipelined handle, matrix-core 2-NN (knn_mfma_kernels.hip, frame_a_kernel / frame_b_kernel): the call for frame t launches
@@ -889,6 +1008,27 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     if (a->sig_id != 0 && t.sig_slot.count(a->sig_id)) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: signature already registered");
     const int64_t slots_after = t.n_slots + owed_slots + (a->sig_id != 0 ? 1 : 0);
     if (a->d_likelihood && a->likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
+    if (h->unreconciled.size() >= (size_t)lcd_engine::VLOG / 2) { int rc = h->drain(); if (rc) return rc; }   // the append log is a ring
+    // rows appended on the device: the counters take over the row count, the buffers keep room for this frame's and the next one's words
+    const bool app = frame_appends(h, *a);
+    if (app) { int rc = activate_dev_rows(h); if (rc) return rc; }
+    const bool chained = h->vcnt_active;
+    if (chained && h->h_vmirror && h->unreconciled.size() > 8) {
+        // The launches are planned for an upper bound of the row count: what the newest FINISHED appender reported + q per younger
+        // frame.  A caller that enqueues frames much faster than the device runs them would inflate that bound without limit (the
+        // filter would scan mostly empty rows): such a caller waits here until the device is at most 8 frames behind.
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spins = 0;; ++spins) {
+            const uint32_t tag = (uint32_t)(*(volatile const unsigned long long*)h->h_vmirror >> 32);
+            if ((uint32_t)h->vseq - tag <= 8u) break;
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5))
+                return h->fail(LCD_ERR_HIP, "lcd_frame_dev: the device made no progress for 5 s");
+        }
+    }
+    if (chained) { int rc = ensure_append_capacity(h, h->rows_ub() + 2 * (int64_t)q); if (rc) return rc; }
+    const int64_t plan_rows = chained ? h->rows_ub() : h->n_rows;
+    if (plan_rows > 0x7FFFFFF0ll) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: more than 2^31 rows");
+    const uint64_t vseq = h->vseq;
     const int set = (int)(h->frame_seq % lcd_engine::PIPE_SETS);
     lcd_engine::FrameScratch& sc = h->ring[set];
     const bool incremental = (a->flags & LCD_Q_INCREMENTAL) != 0;
@@ -896,11 +1036,12 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     const int ld = (q + 63) / 64 * 64, bw = ld / 32;
     // ---- this frame's 2-NN stage: buffers of its scratch set
     PipeKnn k;
-    k.plan = knn_bf16_plan(q, (int)h->n_rows, 2 + (together ? knn_selfdist_wgs(q) : 0));
+    k.plan = knn_bf16_plan(q, (int)plan_rows, 2 + (together ? knn_selfdist_wgs(q) : 0));
     k.plan.filter_units = h->filter_units;
+    if (chained) { k.n_lo = h->d_vcnt.as<int32_t>() + ((vseq + 1) & 1); k.n_hi = h->d_vcnt.as<int32_t>() + (vseq & 1); }
     LCD_HIP(h, dreserve(h, sc.d_partial2, knn_bf16_partial_bytes(k.plan)));
     LCD_HIP(h, dreserve(h, sc.d_fail_list, (size_t)q * 4));
-    LCD_HIP(h, dreserve(h, sc.d_partial3, knn_rowpar_partial_bytes((int)h->n_rows, q)));
+    LCD_HIP(h, dreserve(h, sc.d_partial3, knn_rowpar_partial_bytes((int)plan_rows, q)));
     LCD_HIP(h, dreserve(h, sc.d_knn_row, (size_t)q * 2 * 4));
     LCD_HIP(h, dreserve(h, sc.d_knn_word, (size_t)q * 2 * 4));
     LCD_HIP(h, dreserve(h, sc.d_knn_dist, (size_t)q * 2 * 4));
@@ -927,10 +1068,8 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     bool reg_like = false;
     if (f_reg) {
         const lcd_frame_args& pa = f_reg->a;
-        WsRuns runs;
-        { int rc = reserve_frame_words(h, pa, &runs); if (rc) return rc; }
-        if (pa.sig_id != 0) LCD_HIP(h, t.register_dev(pa.sig_id, f_reg->r.out_wslot, pa.q, pa.q, pa.N, nullptr, false, &tl_reg, &runs));
-        else LCD_HIP(h, t.query_dev(f_reg->r.out_wslot, pa.q, pa.N, nullptr, false, &tl_reg, &runs));
+        if (pa.sig_id != 0) LCD_HIP(h, t.register_dev(pa.sig_id, f_reg->r.out_wslot, pa.q, pa.q, pa.N, nullptr, false, &tl_reg));
+        else LCD_HIP(h, t.query_dev(f_reg->r.out_wslot, pa.q, pa.N, nullptr, false, &tl_reg));
         if (pa.d_likelihood) {
             LCD_HIP(h, t.score_args(pa.d_likelihood, nullptr, pipe_block_size(), &sa, &score_wgs));
             reg_like = true;
@@ -938,8 +1077,14 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
         }
     }
     if (f_res) {
+        // the postings keys of the words frame t - 1 may create are reserved now (the batched check of older reservations waits until
+        // launch A is enqueued: the registration of frame t - 2, which rides in it, may still use some of those keys)
+        { int rc = reserve_frame_words(h, f_res->a, &f_res->runs, false); if (rc) return rc; }
+        f_res->reserved = true;
         tl_res.r = f_res->r;
-        tl_res.r.new_ws = WsRuns(); tl_res.r.new_ws.n = -1;          // new words as codes: their postings keys are reserved with the registration
+        tl_res.r.new_ws = f_res->runs;
+        refresh_vocab_ptrs(h, &tl_res.r);
+        if (f_res->chained) fill_append(h, f_res->a, f_res->vseq, frame_appends(h, f_res->a), &tl_res.r);
         resolve_launch_info(tl_res.r, pipe_block_size(), &tl_res.n_redo, &tl_res.shmem_resolve);
     }
     // ---- launch A: filter (t) + decision loop (t - 1) + registration (t - 2); launch B: re-rank (t) + scoring (t - 2)
@@ -951,6 +1096,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
         h->prof_kernel = knn_bf16_persistent(k.plan) ? "frame_a_kernel_p (persistent bf16 filter of frame t + decision loop of t-1 + registration of t-2)"
                                                      : "frame_a_kernel (bf16 filter of frame t + decision loop of t-1 + registration of t-2)";
     }
+    LCD_HIP(h, t.flush_held_if_due());
     const bool prof2 = reg_like && h->prof_cap > 0 && h->prof2_n < h->prof_cap;
     LCD_HIP(h, launch_frame_b(&k, reg_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
                               prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr));
@@ -967,7 +1113,8 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     }
     // ---- this frame's decision loop, registration and scoring are owed from here on
     lcd_engine::InFlight nf;
-    nf.a = *a; nf.set = set; nf.stage = 1;
+    nf.a = *a; nf.set = set; nf.stage = 1; nf.vseq = vseq; nf.chained = chained;
+    if (chained) { h->unreconciled.push_back(lcd_engine::DevAppend{vseq, a->first_new_word_id, q, app}); h->vseq += 1; }
     ResolveArgs& r = nf.r;
     r.rp = RowparArgs{};
     r.q = q; r.flags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0); r.nndr = a->nndr_ratio; r.have_index = 1;
@@ -978,7 +1125,8 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     r.fail_count = sc.d_fail_count.as<int32_t>();
     {   // the exact redo of rejected queries rides with the decision loop (fill_redo, with this frame's scratch set)
         RowparArgs& rp = r.rp;
-        rp.enabled = 1; rp.vocab = (const float*)h->vocab.p; rp.row_id = h->row_id.as<int32_t>(); rp.n_rows = (int)h->n_rows;
+        rp.enabled = 1; rp.vocab = (const float*)h->vocab.p; rp.row_id = h->row_id.as<int32_t>(); rp.n_rows = (int)plan_rows;
+        rp.n_rows_dev = k.n_hi;                                      // the rows that exist when the redo runs: after the previous frame's append
         rp.queries = (const float*)a->d_descriptors; rp.fail_list = sc.d_fail_list.as<int32_t>(); rp.partial = (unsigned long long*)sc.d_partial3.p;
         rp.out_row = k.out_row; rp.out_word = k.out_word; rp.out_dist = k.out_dist;
         if (together) rp.cb = k.cb;
@@ -1000,14 +1148,21 @@ int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     if ((a->d_posterior || a->d_bayes) && !h->bayes.configured) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: lcd_bayes_configure first");
     if (h->pipeline && q <= 4096 && h->knn_mode == 2 && knn_mfma_supported(h->dtype, h->kdim) && h->n_live >= 2 && h->n_rows >= 256)
         return frame_pipelined(h, a);
-    { int rc = h->drain(); if (rc) return rc; }
+    { int rc = h->drain(); if (rc) return rc; }                    // (also brings the host's row mirror up to date)
     LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
+    const bool app = frame_appends(h, *a);
+    if (app) {
+        { int rc = activate_dev_rows(h); if (rc) return rc; }
+        { int rc = ensure_append_capacity(h, h->n_rows + 2 * (int64_t)q); if (rc) return rc; }
+    }
     // 2-NN + same-frame distances, then ONE single-workgroup launch: decision loop -> pending retirements -> registration / idf
     ResolveArgs r;
     int rc = prepare_resolve(h, a->d_descriptors, q, a->flags, a->nndr_ratio, a->d_word_ids, h->d_out_wslot.as<int32_t>(), &r, true);
     if (rc) return rc;
     if (h->d_fail_count.p) { r.fail_count = h->d_fail_count.as<int32_t>(); h->fail_count_clean = true; }   // the tail resets the counters
-    return frame_stage_s(h, *a, r);
+    const uint64_t vseq = h->vseq;
+    if (app) { h->unreconciled.push_back(lcd_engine::DevAppend{vseq, a->first_new_word_id, q, true}); h->vseq += 1; }
+    return frame_stage_s(h, *a, r, app, vseq);
 }
 
 int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_ids, float* d_dist) {

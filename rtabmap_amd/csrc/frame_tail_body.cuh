@@ -36,6 +36,15 @@ __device__ __forceinline__ float fixed_to_like(long long acc, uint32_t ni) {
     return __fdiv_rn(__ll2float_rn(acc) * 1.4901161193847656e-08f, (float)ni);
 }
 
+// float pair -> bf16 "hi" (RNE) and bf16 "lo" (the exact remainder, rounded): the split the bf16x3 filter multiplies
+__device__ __forceinline__ void bf16_split2_dev(float a, float b, uint32_t& hi, uint32_t& lo) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){a, b}, bf2));
+    const float ra = __fsub_rn(a, __uint_as_float(hi << 16)), rb = __fsub_rn(b, __uint_as_float(hi & 0xFFFF0000u));
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){ra, rb}, bf2));
+}
+
 // ---------------------------------------------------------------------------------------------- frame words
 
 
@@ -176,6 +185,83 @@ __device__ __forceinline__ void retire_body(const RetireArgs& r, const uint32_t*
     }
 }
 
+// ---------------------------------------------------------------------------------------------- new words -> vocabulary rows
+// VWDictionary::update()'s append branch for the words the decision loop has just created (AppendArgs, tfidf.h).  `mask` / `prefix`:
+// the loop's final new-word mask and its word prefix sums (LDS); descriptor i created the k-th new word iff its bit is set, k = its
+// rank.  Sixteen lanes per descriptor: lane c moves the 16-byte chunk c, c + 16, ... of the row; for 64-float rows the same lanes
+// produce |row|^2 (any order will do: the filter needs it to ~dim ulps) and the hi / lo bf16 split the matrix-core filter multiplies.
+template <int NT>
+__device__ __forceinline__ void append_new_rows(const AppendArgs& ap, int q, const uint32_t* mask, const uint32_t* prefix, const WsRuns& new_ws,
+                                                uint32_t* list /* LDS scratch, q words */) {
+    const int n_in = ap.cnt_in[0];
+    const int mw = (q + 63) / 64 * 2;
+    const int n_new = (int)prefix[mw];
+    const int tid = threadIdx.x, c = tid & 15;
+    const int n_take = (long long)n_in + n_new <= ap.capacity ? n_new : 0;
+    // the descriptors that created words, in word order (the loop below then has no idle trips: ~150 of 500 descriptors create a word)
+    for (int i = tid; i < q; i += NT)
+        if ((mask[i >> 5] >> (i & 31)) & 1u) list[new_rank(mask, prefix, i)] = (uint32_t)i;
+    __syncthreads();
+    constexpr int G = NT / 16, UN = 4;                                  // 16-lane groups; rows per group and trip (their loads are in flight together)
+    for (int k0 = tid >> 4; k0 < n_take; k0 += G * UN) {
+        uint4 x[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = k0 + u * G;
+            x[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (k < n_take && ap.is_f32_64) x[u] = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(ap.descriptors) + (size_t)list[k] * ap.row_dwords)[c];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = k0 + u * G;
+            if (k >= n_take) continue;                                  // uniform over the 16 lanes of the row
+            const size_t row = (size_t)n_in + (size_t)k;
+            uint32_t* dst = ap.vocab + row * ap.row_dwords;
+            if (ap.is_f32_64) {
+                reinterpret_cast<uint4*>(dst)[c] = x[u];
+                const float f0 = __uint_as_float(x[u].x), f1 = __uint_as_float(x[u].y), f2 = __uint_as_float(x[u].z), f3 = __uint_as_float(x[u].w);
+                float s2 = fmaf(f3, f3, fmaf(f2, f2, fmaf(f1, f1, f0 * f0)));
+#pragma unroll
+                for (int m = 8; m >= 1; m >>= 1) s2 += __shfl_xor(s2, m, 64);
+                uint2 hi, lo;                                           // as vocab_bf16_kernel: 64 bf16 "hi" then 64 bf16 "lo" per row
+                bf16_split2_dev(f0, f1, hi.x, lo.x);
+                bf16_split2_dev(f2, f3, hi.y, lo.y);
+                reinterpret_cast<uint2*>(ap.vocab_bf + row * 64)[c] = hi;
+                reinterpret_cast<uint2*>(ap.vocab_bf + row * 64 + 32)[c] = lo;
+                if (c == 0) {
+                    ap.row_norm[2 * row] = s2; ap.row_norm[2 * row + 1] = 1.0f;
+                    atomicMax(ap.norm_max_bits, __float_as_uint(s2));
+                }
+            } else {
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(ap.descriptors) + (size_t)list[k] * ap.row_dwords;
+                for (int d = c; d < ap.row_dwords; d += 16) dst[d] = src[d];
+            }
+            if (c == 0) {
+                ap.row_id[row] = ap.first_id + k;
+                ap.row_wslot[row] = new_ws.n > 0 ? ws_runs_at(new_ws, k) : -1;
+            }
+        }
+    }
+    if (tid == 0) {
+        const int n_out = n_in + n_take;
+        if (ap.is_f32_64) { ap.row_norm[2 * (size_t)n_out] = __int_as_float(0x7f800000); ap.row_norm[2 * (size_t)n_out + 1] = 1.0f; }   // sentinel
+        ap.cnt_out[0] = n_out;
+        if (ap.log_slot) ap.log_slot[0] = n_take;
+        if (ap.host_mirror) __hip_atomic_store(ap.host_mirror, ((unsigned long long)ap.tag << 32) | (unsigned long long)(uint32_t)n_out, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// a frame that appends nothing still hands the row count on (the two counters alternate from frame to frame)
+__device__ __forceinline__ void append_pass_on(const AppendArgs& ap) {
+    if (threadIdx.x == 0 && ap.cnt_in && ap.cnt_out) {
+        const int n = ap.cnt_in[0];
+        ap.cnt_out[0] = n;
+        if (ap.log_slot) ap.log_slot[0] = 0;
+        if (ap.host_mirror) __hip_atomic_store(ap.host_mirror, ((unsigned long long)ap.tag << 32) | (unsigned long long)(uint32_t)n, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 #ifdef LCD_TAIL_TIMING   // timing experiment only: 100 MHz stamps between the phases of the frame tail
 __device__ unsigned long long g_tail_timing[8];
 #define FT_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_tail_timing[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -205,12 +291,16 @@ __device__ __forceinline__ void frame_tail_body(uint32_t* ft_dyn_smem, const Res
     // frames of up to 1024 descriptors: the register-resident decision loop, its result handed to the registration through LDS
     constexpr int KPT = 1024 / NT;                     // descriptors per thread of the register-resident loop: frames of up to 1024
     int32_t* lds_ws = r.q <= KPT * NT ? (int32_t*)(ft_dyn_smem + 2 * a.H + a.H / 64 + 8) : nullptr;
-    if (lds_ws) resolve_body_fast<NT, KPT>(ft_dyn_smem, lds_ws, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld,
-                                           r.cand_bits, r.bw, r.out_word, r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws, r.cand_list,
-                                           r.cand_cnt);
-    else resolve_body<NT>(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
-                      r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
+    const uint32_t* fmask;
+    if (lds_ws) fmask = resolve_body_fast<NT, KPT>(ft_dyn_smem, lds_ws, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld,
+                                                   r.cand_bits, r.bw, r.out_word, r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws, r.cand_list,
+                                                   r.cand_cnt);
+    else fmask = resolve_body<NT>(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
+                                  r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
     if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; r.fail_count[3] = 0; }
+    // (before the registration reuses the LDS; the list scratch lies behind the word slots handed over in LDS)
+    if (r.ap.enabled) append_new_rows<NT>(r.ap, r.q, fmask, ft_dyn_smem + 2 * ((r.q + 63) / 64 * 2), r.new_ws, ft_dyn_smem + 2 * a.H + a.H / 64 + 8 + r.q);
+    else append_pass_on(r.ap);
     FT_STAMP(1);
     retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
     __syncthreads();      // out_wslot (global or LDS, written by this workgroup) and the LDS region are handed over
@@ -235,12 +325,15 @@ __device__ __forceinline__ void frame_resolve_part(uint32_t* ft_dyn_smem, const 
     }
     FT_STAMP(0);
     constexpr int KPT = 1024 / NT;
-    if (r.q <= KPT * NT) resolve_body_fast<NT, KPT>(ft_dyn_smem, nullptr, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld,
-                                                    r.cand_bits, r.bw, r.out_word, r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws,
-                                                    r.cand_list, r.cand_cnt);
-    else resolve_body<NT>(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
-                          r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
+    const uint32_t* fmask;
+    if (r.q <= KPT * NT) fmask = resolve_body_fast<NT, KPT>(ft_dyn_smem, nullptr, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist,
+                                                            r.ld, r.cand_bits, r.bw, r.out_word, r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws,
+                                                            r.cand_list, r.cand_cnt);
+    else fmask = resolve_body<NT>(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
+                                  r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
     if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; r.fail_count[3] = 0; }
+    if (r.ap.enabled) append_new_rows<NT>(r.ap, r.q, fmask, ft_dyn_smem + 2 * ((r.q + 63) / 64 * 2), r.new_ws, ft_dyn_smem + 3 * ((r.q + 63) / 64 * 2) + 4);
+    else append_pass_on(r.ap);
     FT_STAMP(1);
 }
 template <int NT>

@@ -83,6 +83,17 @@ __global__ void vocab_bf16_kernel(const float* __restrict__ vocab, int first, in
     reinterpret_cast<uint2*>(bf + (size_t)r * 64 + 32)[c] = lo;
 }
 
+// rows [first, first + n) that hold no word yet (capacity behind the vocabulary, filled by the device-side append): |row|^2 = +inf so
+// that no filter ever ranks them, a zero bf16 split so that the product with them is finite
+__global__ void vocab_tail_kernel(float* __restrict__ aug, uint32_t* __restrict__ bf, long long first, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 16 bytes of the 256-byte split row
+    if (i >= n * 16) return;
+    const long long r = first + (i >> 4);
+    const int c = (int)(i & 15);
+    reinterpret_cast<uint4*>(bf + r * 64)[c] = make_uint4(0u, 0u, 0u, 0u);
+    if (c == 0) { aug[2 * r] = __int_as_float(0x7f800000); aug[2 * r + 1] = 1.0f; }
+}
+
 // ------------------------------------------------------------------------------------------------ filter
 // In-loop candidate key: 32 bits = the score's float bits with the low MF_IDX_BITS mantissa bits replaced by the
 // candidate's position inside the wave's strip (tile-in-strip << 4 | accumulator register).  Scores are >= 0, so the keys
@@ -574,7 +585,11 @@ template <int NG>
 __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
                                                      int n_rows, const float* __restrict__ queries, int nq, int qpad,
                                                      int tiles_per_block, int n_blocks, uint64_t* __restrict__ partial_keys,
-                                                     uint32_t* __restrict__ partial_bound, const SelfdistJob& sd) {
+                                                     uint32_t* __restrict__ partial_bound, const SelfdistJob& sd,
+                                                     const int32_t* __restrict__ n_lo = nullptr) {
+    // n_lo: the number of rows this search may see, on the device (a pipelined handle appends the previous frames' new words while
+    // this launch runs: rows at or beyond n_lo[0] -- up to n_rows, the host's upper bound -- are masked with an infinite |row|^2)
+    const int lo_rows = n_lo ? n_lo[0] : 0x7fffffff;
     // NG = 32-query groups per wave: 4 -> four waves, one per SIMD; 2 -> eight waves, two per SIMD (one wave's tile
     // synchronisation, LDS reads and top-3 update hide behind the other's MFMAs).  The workgroup covers BF_QB queries either way.
     static_assert(NG == 4 || NG == 2, "wave tile");
@@ -621,7 +636,10 @@ __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wave == 0) {                                                 // the loop takes them from LDS: a VMEM load there would wait behind the whole prefetch
 #pragma unroll
-        for (int i = 0; i < MF_STRIP_TILES; ++i) s_aug[i * 64 + lane] = augs[i];
+        for (int i = 0; i < MF_STRIP_TILES; ++i) {
+            const int t = min(tile0 + i, max(tile1 - 1, tile0));
+            s_aug[i * 64 + lane] = (half == 0 && t * 32 + col >= lo_rows) ? __int_as_float(0x7f800000) : augs[i];
+        }
     }
 
     // B operands: -2 q split hi/lo in operand order (lane (query l&31, half l>>5) holds floats [32h, 32h + 32) of its query: k-step s
@@ -743,7 +761,6 @@ __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, cons
 // LDS holds two strips: the one being multiplied and the next one, requested (LDS-DMA, augmentation entries included) as soon as
 // the strip before it has been read by every wave.  Strip 0 uses the slots of the one-strip kernel (tiles 0,1 behind the query
 // staging area, tiles 2.. in it), odd strips slots 8..15, even strips >= 2 slots 0..7.
-constexpr int BF_PX = 248;                       // compute units the persistent launch plans for (the tail workgroup and the distance-matrix tiles share the chip)
 constexpr size_t BF_LDS_BYTES_P = (size_t)(MF_WAVES * 4 + 2) * BF_TILE_F * 4 + (size_t)2 * MF_STRIP_TILES * 64 * 4;
 // every tile of strip `bx` + its augmentation entries (wave 0): a FIXED number of DMA instructions per wave, so that the wait in
 // front of the strip before it can name how many may stay in flight
@@ -777,7 +794,9 @@ __device__ __forceinline__ void bf_lds_barrier() { asm volatile("s_waitcnt lgkmc
 __device__ __forceinline__ void knn_bf16_filter_body_p(float* s_dyn, int bid, const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
                                                        int n_rows, const float* __restrict__ queries, int nq, int qpad,
                                                        int tiles_per_block, int n_blocks, int px, uint64_t* __restrict__ partial_keys,
-                                                       uint32_t* __restrict__ partial_bound, const SelfdistJob& sd) {
+                                                       uint32_t* __restrict__ partial_bound, const SelfdistJob& sd,
+                                                       const int32_t* __restrict__ n_lo = nullptr) {
+    if (n_lo) n_rows = min(n_rows, max(n_lo[0], 1));                 // rows the search may see (see knn_bf16_filter_body); the sentinel entry follows them
     constexpr int NG = 4;
     constexpr int KH = 32;
     constexpr int NW = BF_QB / (NG * 32);
@@ -985,8 +1004,13 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
                                                      const uint32_t* __restrict__ norm_max_bits,
                                                      int32_t* __restrict__ out_row, int32_t* __restrict__ out_word,
                                                      float* __restrict__ out_dist, int32_t* __restrict__ fail_list,
-                                                     int32_t* __restrict__ fail_count, const CandBits& cb) {
+                                                     int32_t* __restrict__ fail_count, const CandBits& cb,
+                                                     const int32_t* __restrict__ pend_lo = nullptr, const int32_t* __restrict__ pend_hi = nullptr) {
     static_assert(DIM == 64, "16 lanes x 4 floats per candidate row");
+    // rows [pend_lo[0], pend_hi[0]): words the previous frame created, appended on the device after this frame's filter took its
+    // snapshot of the vocabulary (VWDictionary::update() of a pipelined handle).  They are scanned exactly here, so the result is
+    // the 2-NN over the vocabulary as update() leaves it before this frame.
+    const int p_lo = pend_lo ? pend_lo[0] : 0, p_hi = pend_hi ? pend_hi[0] : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ float s_thr;
     const int n_keys = n_blocks * KEEP;
@@ -997,6 +1021,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
     __shared__ uint64_t s_cand[RR_MAX_CAND], s_exact[RR_MAX_CAND];
     __shared__ int32_t s_word[RR_MAX_CAND];
     __shared__ float s_err[MF_WAVES];
+    __shared__ uint64_t s_pend[MF_WAVES][2];
     // Everything that does not depend on other loads is requested up front (the kernel is a chain of round trips): the first two
     // keys and the first bound of every thread, the query slice, the vocabulary norm bound and -- for the candidate bits -- the
     // thread's two entries of the query's row of the same-frame distance matrix.
@@ -1090,6 +1115,41 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) err_ratio = fmaxf(err_ratio, __shfl_xor(err_ratio, m, 64));
     if (lane == 0) s_err[wave] = err_ratio;
+    {   // the pending rows, sixteen lanes each, in the reference's arithmetic
+        uint64_t pb = KEY_NONE, ps = KEY_NONE;
+        constexpr int PU = 4;                                          // rows per 16-lane group and trip: their loads are in flight together (more
+                                                                       // would cost the whole launch -- the scoring workgroups too -- occupancy)
+        for (int base = p_lo; base < p_hi; base += PU * (MF_BLOCK / 16)) {
+            float4 v4[PU];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const int r0 = base + u * (MF_BLOCK / 16) + (tid >> 4);
+                v4[u] = reinterpret_cast<const float4*>(vocab + (size_t)min(r0, p_hi - 1) * DIM)[lane & 15];
+            }
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const int r0 = base + u * (MF_BLOCK / 16) + (tid >> 4);
+                const float d0 = __fsub_rn(v4[u].x, q4.x), d1 = __fsub_rn(v4[u].y, q4.y), d2 = __fsub_rn(v4[u].z, q4.z), d3 = __fsub_rn(v4[u].w, q4.w);
+                float t = __fmul_rn(d0, d0);
+                t = __fadd_rn(t, __fmul_rn(d1, d1));
+                t = __fadd_rn(t, __fmul_rn(d2, d2));
+                t = __fadd_rn(t, __fmul_rn(d3, d3));
+                float res = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) res = __fadd_rn(res, __shfl(t, (lane & 48) + j, 64));
+                if ((lane & 15) == 0 && r0 < p_hi) top2_push(pb, ps, ((uint64_t)__float_as_uint(res) << 32) | (uint32_t)r0);
+            }
+        }
+        if (p_hi > p_lo) {                                             // uniform
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const uint64_t ob = shfl_xor_u64(pb, m), os = shfl_xor_u64(ps, m);
+                top2_push(pb, ps, ob);
+                top2_push(pb, ps, os);
+            }
+            if (lane == 0) { s_pend[wave][0] = pb; s_pend[wave][1] = ps; }
+        }
+    }
     __syncthreads();
     // the two best (distance, row) keys: ties go to the lower ROW (result_set.h:151-171), so the comparison key carries the row
     uint64_t best = KEY_NONE, second = KEY_NONE;
@@ -1106,7 +1166,11 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
             top2_push(best, second, ob);
             top2_push(best, second, os);
         }
-        // which candidate slots won (for their word ids)
+        if (p_hi > p_lo) {                                             // the pending rows' two best join (their rows differ from every kept key's)
+#pragma unroll
+            for (int w = 0; w < MF_WAVES; ++w) { top2_push(best, second, s_pend[w][0]); top2_push(best, second, s_pend[w][1]); }
+        }
+        // which candidate slots won (for their word ids; a pending row that won has no slot: -1)
         if (!overflow)
             for (int i = lane; i < n_cand; i += 64) {
                 const uint64_t key = (s_exact[i] & 0xFFFFFFFF00000000ull) | (uint32_t)s_cand[i];
@@ -1130,7 +1194,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
             if (k[j] == KEY_NONE) { out_row[2 * qi + j] = -1; out_word[2 * qi + j] = 0; out_dist[2 * qi + j] = -1.0f; }
             else {
                 out_row[2 * qi + j] = (int32_t)(uint32_t)k[j];
-                out_word[2 * qi + j] = s_word[sl[j]];
+                out_word[2 * qi + j] = sl[j] >= 0 ? s_word[sl[j]] : row_id[(uint32_t)k[j]];
                 out_dist[2 * qi + j] = __uint_as_float((uint32_t)(k[j] >> 32));
             }
         }
@@ -1193,11 +1257,12 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
 // previous launch (A -> B -> A ...).  The per-frame scratch exists twice (see engine.h).
 struct FilterArgs {
     const float* vocab_bf; const float* row_norm; int n_rows; const float* queries; int nq, qpad, tiles_per_block, n_blocks;
-    uint64_t* pk; uint32_t* pl; SelfdistJob sd;
+    uint64_t* pk; uint32_t* pl; SelfdistJob sd; const int32_t* n_lo;
 };
 struct RerankArgs {
     const uint64_t* pk; const uint32_t* pl; int n_blocks, nq; const float* vocab; const float* queries; const int32_t* row_id;
     const uint32_t* norm_max_bits; int32_t* out_row; int32_t* out_word; float* out_dist; int32_t* fail_list; int32_t* fail_count; CandBits cb;
+    const int32_t* n_lo; const int32_t* n_hi;
 };
 constexpr int PIPE_BLOCK = 256;     // workgroup size of both fused launches (the filter's and the re-rank's)
 
@@ -1222,10 +1287,10 @@ __device__ __forceinline__ void frame_a_body(float* s_dyn, const FilterArgs& f, 
     if (bid >= n_front + tr.n_filter_wgs) { frame_resolve_part<PIPE_BLOCK>((uint32_t*)s_dyn, r, bid - n_front - tr.n_filter_wgs + 1, 1 + tr.n_redo); A_STAMP(1); return; }
     if constexpr (PERSISTENT)
         knn_bf16_filter_body_p(s_dyn, bid - n_front, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, px, f.pk,
-                               f.pl, f.sd);
+                               f.pl, f.sd, f.n_lo);
     else
         knn_bf16_filter_body<4>(s_dyn, bid - n_front, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, f.pk, f.pl,
-                                f.sd);
+                                f.sd, f.n_lo);
     A_STAMP(1);
 }
 __global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel(FilterArgs f, TailRoles tr, ResolveArgs r, FwArgs a, RetireArgs ret) {
@@ -1248,7 +1313,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void frame_b_kernel(RerankArgs k, int n
     B_STAMP(0);
     if (bid < n_rerank_wgs) {
         knn_mfma_rerank_body<64, BF_KEEP, false, true>(bid, k.pk, k.pl, k.n_blocks, k.nq, k.vocab, k.queries, k.row_id, k.norm_max_bits, k.out_row,
-                                                       k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb);
+                                                       k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb, k.n_lo, k.n_hi);
         B_STAMP(1);
         return;
     }
@@ -1329,6 +1394,11 @@ hipError_t launch_row_norms(const void* vocab, const int32_t* row_id, int first,
     row_norm_kernel<<<(n + 255) / 256, 256, 0, s>>>((const float*)vocab, row_id, first, n, dim, norm, norm_max_bits);
     return hipGetLastError();
 }
+hipError_t launch_vocab_tail(float* norm, void* bf, long long first, long long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    vocab_tail_kernel<<<(unsigned)((n * 16 + 255) / 256), 256, 0, s>>>(norm, (uint32_t*)bf, first, n);
+    return hipGetLastError();
+}
 hipError_t launch_norm_tombstone(float* norm, const int32_t* rows, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     norm_tombstone_kernel<<<(n + 255) / 256, 256, 0, s>>>(norm, rows, n);
@@ -1379,15 +1449,20 @@ MfmaPlan knn_bf16_plan(int q, int n_rows, int other_wgs) {
     p.q = q;
     p.qpad = (q + 63) / 64 * 64;
     p.n_rows = n_rows;
+    p.other_wgs = other_wgs > 0 && other_wgs < 128 ? other_wgs : 0;
     const int n_tiles = (n_rows + 31) / 32;
     const int qchunks = (q + BF_QB - 1) / BF_QB;
-    const int cus = other_wgs > 0 && other_wgs < 128 ? 256 - other_wgs : 256;
-    int nb = cus / qchunks > 0 ? cus / qchunks : 1;                    // one workgroup (4 waves, one per SIMD) per CU
-    if (nb > n_tiles) nb = n_tiles;
-    if (nb < 1) nb = 1;
-    int tpb = (n_tiles + nb - 1) / nb;
+    const int cus = 256 - p.other_wgs;
+    const int per_q = cus / qchunks > 0 ? cus / qchunks : 1;         // workgroups (4 waves, one per SIMD, a whole compute unit's LDS) per block of 512 queries
+    // tiles per workgroup when every compute unit gets one; more than a strip holds (the in-loop keys index 8 tiles): the workgroups
+    // are persistent and walk `rounds` equal strips each -- so that a vocabulary a little larger than 256 x 8 tiles does not run as
+    // one full round plus a nearly empty one
+    int w = (n_tiles + per_q - 1) / per_q;
+    if (w < 1) w = 1;
+    const int rounds = (w + MF_STRIP_TILES - 1) / MF_STRIP_TILES;
+    int tpb = (w + rounds - 1) / rounds;
     if (tpb < 1) tpb = 1;
-    if (tpb > MF_STRIP_TILES) tpb = MF_STRIP_TILES;                    // the in-loop keys index at most 8 tiles per strip
+    if (tpb > MF_STRIP_TILES) tpb = MF_STRIP_TILES;
     p.tiles_per_block = tpb;
     p.n_blocks = n_tiles > 0 ? (n_tiles + tpb - 1) / tpb : 0;
     return p;
@@ -1406,9 +1481,9 @@ hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void*
 // workgroup per compute unit that is the faster launch).  MfmaPlan::filter_units (lcd_set_option "filter_units") overrides the
 // number of compute units to plan for: tests shorten it to walk many strips per workgroup.
 static int bf16_persistent_px(const MfmaPlan& p) {
-    const int cus = p.filter_units >= 0 ? p.filter_units : BF_PX;
+    const int cus = p.filter_units >= 0 ? p.filter_units : 256 - p.other_wgs;
     const int qchunks = (p.q + BF_QB - 1) / BF_QB;
-    if (cus == 0 || qchunks <= 0 || p.n_blocks * qchunks <= 256 || p.tiles_per_block != MF_STRIP_TILES) return 0;
+    if (cus == 0 || qchunks <= 0 || p.n_blocks * qchunks <= (p.filter_units >= 0 ? 256 : cus)) return 0;
     const int px_max = cus / qchunks > 0 ? cus / qchunks : 1;
     const int rounds = (p.n_blocks + px_max - 1) / px_max;
     return (p.n_blocks + rounds - 1) / rounds;                          // equal shares: ceil(strips / rounds) workgroups of <= rounds strips
@@ -1497,7 +1572,7 @@ hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* resolve, const Tai
     uint32_t* pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * BF_KEEP * p.qpad);
     FilterArgs f;
     f.vocab_bf = (const float*)k.vocab_bf; f.row_norm = k.row_norm; f.n_rows = p.n_rows; f.queries = (const float*)k.queries; f.nq = p.q; f.qpad = p.qpad;
-    f.tiles_per_block = p.tiles_per_block; f.n_blocks = p.n_blocks; f.pk = pk; f.pl = pl;
+    f.tiles_per_block = p.tiles_per_block; f.n_blocks = p.n_blocks; f.pk = pk; f.pl = pl; f.n_lo = k.n_lo;
     f.sd = SelfdistJob();
     if (k.cb.selfdist) {                                              // the same-frame distance matrix rides along
         f.sd.queries = (const float*)k.queries; f.sd.nq = p.q; f.sd.out = const_cast<float*>(k.cb.selfdist); f.sd.ld = k.cb.ld; f.sd.n_tiles = selfdist_tiles(p.q);
@@ -1536,7 +1611,7 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
         rk.pk = pk; rk.pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * BF_KEEP * p.qpad);
         rk.n_blocks = p.n_blocks; rk.nq = p.q; rk.vocab = (const float*)k->vocab; rk.queries = (const float*)k->queries; rk.row_id = k->row_id;
         rk.norm_max_bits = k->norm_max_bits; rk.out_row = k->out_row; rk.out_word = k->out_word; rk.out_dist = k->out_dist;
-        rk.fail_list = k->fail_list; rk.fail_count = k->fail_count; rk.cb = k->cb;
+        rk.fail_list = k->fail_list; rk.fail_count = k->fail_count; rk.cb = k->cb; rk.n_lo = k->n_lo; rk.n_hi = k->n_hi;
         n_rerank = p.q;
     }
     ScoreArgs A{};

@@ -66,6 +66,7 @@ __host__ __device__ inline int32_t ws_runs_at(const WsRuns& r, int k) {
 struct RowparArgs {
     int enabled = 0;
     const float* vocab = nullptr; const int32_t* row_id = nullptr; int n_rows = 0;
+    const int32_t* n_rows_dev = nullptr;               // the row count on the device (<= n_rows, the host's upper bound) when rows are appended there
     const float* queries = nullptr; const int32_t* fail_list = nullptr;
     unsigned long long* partial = nullptr;             // knn_rowpar_partial_bytes()
     int32_t* out_row = nullptr; int32_t* out_word = nullptr; float* out_dist = nullptr;
@@ -77,6 +78,7 @@ struct RowparArgs {
 struct MfmaPlan {
     int q, qpad, n_rows, tiles_per_block, n_blocks;
     int filter_units = -1;   // compute units the persistent bf16 filter plans for (-1: built-in; 0: one workgroup per strip always)
+    int other_wgs = 0;       // long-running workgroups of other kinds in the same launch (each holds a compute unit like a filter workgroup)
 };
 bool knn_mfma_supported(int dtype, int dim);
 bool knn_bf16_persistent(const MfmaPlan& p);   // the bf16 filter launch of this plan uses the persistent kernels (..._kernel_p)
@@ -86,6 +88,8 @@ size_t knn_mfma_partial_bytes(const MfmaPlan& p);
 hipError_t launch_row_norms(const void* vocab, const int32_t* row_id, int first, int n, int dim, float* norm, uint32_t* norm_max_bits,
                             hipStream_t s);
 hipError_t launch_norm_tombstone(float* norm, const int32_t* rows, int n, hipStream_t s);
+// rows [first, first + n) beyond the vocabulary: +inf norm entries ({+inf, 1}; entry first + n is NOT written) and a zero bf16 split
+hipError_t launch_vocab_tail(float* norm, void* bf, long long first, long long n, hipStream_t s);
 // exact redo of the queries in fail_list (fail_count[0] of them; fail_count[1] is scratch) with one lane per vocabulary row
 size_t knn_rowpar_partial_bytes(int n_rows, int q);
 hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, int n_rows, const void* queries, const int32_t* fail_list,

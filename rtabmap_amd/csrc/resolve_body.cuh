@@ -87,7 +87,7 @@ __device__ __forceinline__ int new_rank(const uint32_t* mask, const uint32_t* pr
 //   * the result is also left in LDS (lds_wslot, may be NULL) for the registration that follows in the same kernel.
 // Same results as resolve_body (tests drive both).  rs_smem as below.
 template <int NT, int KPT>
-__device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* lds_wslot, int q, int flags, float nndr, int have_index,
+__device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, int32_t* lds_wslot, int q, int flags, float nndr, int have_index,
                                                   const int32_t* __restrict__ knn_word, const float* __restrict__ knn_dist,
                                                   const float* __restrict__ selfdist, int ld,
                                                   const uint32_t* __restrict__ cand_bits, int bw,
@@ -320,12 +320,13 @@ __device__ __forceinline__ void resolve_body_fast(uint32_t* rs_smem, int32_t* ld
         else if (out_wslot) out_wslot[i] = ws;
     }
     RB_STAMP(5);
+    return mask_cur;                                   // the final new-word mask (its word prefix sums are at rs_smem + 2 * mw)
 }
 
 // The whole decision loop for one frame, executed by ONE workgroup of NT threads.  rs_smem: 3 * mw + 2 words of LDS,
 // mw = ceil(q / 64) * 2.
 template <int NT>
-__device__ __forceinline__ void resolve_body(uint32_t* rs_smem, int q, int flags, float nndr, int have_index,
+__device__ __forceinline__ const uint32_t* resolve_body(uint32_t* rs_smem, int q, int flags, float nndr, int have_index,
                                                          const int32_t* __restrict__ knn_word, const float* __restrict__ knn_dist,
                                                          const float* __restrict__ selfdist, int ld,
                                                          const uint32_t* __restrict__ cand_bits, int bw,
@@ -415,6 +416,7 @@ __device__ __forceinline__ void resolve_body(uint32_t* rs_smem, int q, int flags
             out_wslot[i] = ws;
         }
     }
+    return mask_cur;
 }
 
 

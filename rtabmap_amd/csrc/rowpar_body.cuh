@@ -63,7 +63,8 @@ __device__ __forceinline__ void rowpar_body(const RowparArgs& a, int wb, int n_w
     __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = wb * NT + (int)threadIdx.x;
-    const bool live = row < a.n_rows && a.row_id[row] != 0;
+    const int n_rows_now = a.n_rows_dev ? min(a.n_rows_dev[0], a.n_rows) : a.n_rows;
+    const bool live = row < n_rows_now && a.row_id[min(row, a.n_rows - 1)] != 0;
     float v[DIM];
     {
         const float4* src = reinterpret_cast<const float4*>(a.vocab + (size_t)min(row, a.n_rows - 1) * DIM);

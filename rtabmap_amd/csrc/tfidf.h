@@ -98,6 +98,25 @@ struct Bucket {
     uint32_t W = 0, D_alloc = 0;
 };
 
+// VWDictionary::update()'s append branch (VWDictionary.cpp:571-609) on the device, run by the decision loop's workgroup right after the
+// loop: the descriptors that created words become vocabulary rows (row, word id = first_id + k, postings key, |row|^2, bf16 split) in
+// descriptor order behind the rows that exist.  The number of rows lives on the device: cnt_in is read, cnt_out = cnt_in + new words
+// written (two alternating counters: the filter of the next frame, which runs in the same launch, keeps reading cnt_in).
+struct AppendArgs {
+    int enabled = 0;
+    const float* descriptors = nullptr;        // [q x dim floats] of the frame (dim == 64) or [q x row_bytes] bytes
+    int row_dwords = 0;                        // dwords per stored row
+    int is_f32_64 = 0;                         // rows are 64 floats: also the augmentation entries and the bf16 split
+    uint32_t* vocab = nullptr; int32_t* row_id = nullptr; int32_t* row_wslot = nullptr;
+    float* row_norm = nullptr; uint32_t* norm_max_bits = nullptr; uint32_t* vocab_bf = nullptr;
+    const int32_t* cnt_in = nullptr; int32_t* cnt_out = nullptr;
+    int32_t* log_slot = nullptr;               // receives the number of rows appended (host reconciliation)
+    int32_t first_id = 0;
+    long long capacity = 0;                    // rows the buffers hold: appends beyond are dropped (cannot happen: the host reserves q per frame)
+    unsigned long long* host_mirror = nullptr; // pinned: (tag << 32 | rows) after this append, read by the host WITHOUT synchronising to
+    uint32_t tag = 0;                          // bound the row count it plans the next launches for
+};
+
 // arguments of the addNewWords decision loop (resolve_body.cuh) when it is fused into the frame-words launch
 struct ResolveArgs {
     int q, flags; float nndr; int have_index;
@@ -107,6 +126,7 @@ struct ResolveArgs {
     WsRuns new_ws;         // postings keys of the frame's new words (n == 0: new words get no postings)
     int32_t* fail_count;   // reset for the next frame's certificate (saves a memset launch); may be NULL
     RowparArgs rp;         // rp.enabled: the exact redo of rejected queries runs as extra workgroups of the tail launch
+    AppendArgs ap;         // ap.enabled: the frame's new words become vocabulary rows behind the decision loop
 };
 
 // kernel argument blocks of the registration / scoring launches (frame_tail_body.cuh, score_body.cuh)
@@ -150,6 +170,8 @@ struct PipeKnn {
     const void* vocab; const void* vocab_bf; const float* row_norm; const uint32_t* norm_max_bits; const int32_t* row_id; const void* queries;
     void* partial; int32_t* out_row; int32_t* out_word; float* out_dist; int32_t* fail_list; int32_t* fail_count;
     CandBits cb;               // cb.selfdist != NULL: the filter launch also fills the same-frame distance matrix
+    const int32_t* n_lo = nullptr;   // device row counts (NULL: the host's plan.n_rows is exact): the filter sees rows [0, n_lo[0]), the re-rank
+    const int32_t* n_hi = nullptr;   // also scans [n_lo[0], n_hi[0]) exactly -- the words the previous frame appended meanwhile (AppendArgs)
 };
 int pipe_block_size();
 void resolve_launch_info(const ResolveArgs& r, int block, int* n_redo, size_t* shmem);
@@ -232,7 +254,10 @@ struct Tfidf {
     int32_t take_wslot();                // one recycled wslot, or -1
     void harvest_released(bool wait);
     // reserve n wslots for the new words first_id, first_id + 1, ... of the coming frame (recycled intervals first)
-    hipError_t reserve_new_words(int32_t first_id, int n, WsRuns* runs);
+    // may_flush = false: the batched check of superseded reservations is not launched here (a pipelined handle launches it with
+    // flush_held_if_due() once the registration that may still use those keys is enqueued)
+    hipError_t reserve_new_words(int32_t first_id, int n, WsRuns* runs, bool may_flush = true);
+    hipError_t flush_held_if_due() { return held_ws.size() >= 16384 ? flush_held() : hipSuccess; }
     // register one signature whose word slots are already on the device (d_wslots[n]; < 0 = no word); if N > 0 the
     // frame's unique words / idf are left in q_* for a following score()
     // defer != NULL (needs resolve): do not launch the frame tail, leave its launch arguments there -- sized for a workgroup of

@@ -575,7 +575,7 @@ hipError_t Tfidf::release_words(const int32_t* word_ids, int n) {
 
 // Postings keys for the words the coming frame may create (at most n).  The previous frame's reservation is handed to the device
 // for checking: keys it did not use (nw == 0) are recycled, used ones become the permanent keys of those words.
-hipError_t Tfidf::reserve_new_words(int32_t first_id, int n, WsRuns* runs) {
+hipError_t Tfidf::reserve_new_words(int32_t first_id, int n, WsRuns* runs, bool may_flush) {
     runs->n = 0;
     if (first_id <= 0 || n <= 0) return hipSuccess;
     if ((int64_t)first_id + n >= (1 << 28)) return hipErrorInvalidValue;
@@ -591,7 +591,7 @@ hipError_t Tfidf::reserve_new_words(int32_t first_id, int n, WsRuns* runs) {
         }
         resv.n = 0;
         // one check launch per ~32 frames, not per frame (the frame tail that may have used these keys is already enqueued)
-        if (held_ws.size() >= 16384) TF_TRY(flush_held());
+        if (may_flush && held_ws.size() >= 16384) TF_TRY(flush_held());
     }
     harvest_released(false);
     int left = n;
@@ -822,7 +822,7 @@ static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool id
     if (resolve) {
         a.src = resolve->out_wslot;
         const int mw = (resolve->q + 63) / 64 * 2;
-        shmem = std::max(shmem, (size_t)(3 * mw + 2) * 4) + (size_t)n * 4;    // + the word slots handed over in LDS
+        shmem = std::max(shmem, (size_t)(3 * mw + 2) * 4) + (size_t)n * 8;    // + the word slots handed over in LDS + the appender's list
         const int block = defer ? pipe_block_size() : FW_BLOCK;
         const int n_redo = (resolve->rp.enabled && resolve->fail_count) ? (resolve->rp.n_rows + block - 1) / block : 0;
         if (defer) {                                                    // launched later, inside the next frame's filter launch
@@ -870,7 +870,7 @@ hipError_t Tfidf::query_dev(const int32_t* d_wslots, int n, float N, const Resol
 // the decision loop of a frame as a workgroup of `block` threads inside a later filter launch: its redo helpers and its dynamic LDS
 void resolve_launch_info(const ResolveArgs& r, int block, int* n_redo, size_t* shmem) {
     const int mw = (r.q + 63) / 64 * 2;
-    *shmem = (size_t)(3 * mw + 2) * 4;
+    *shmem = (size_t)(3 * mw + 4) * 4 + (size_t)r.q * 4;               // + the appender's list of word-creating descriptors
     *n_redo = (r.rp.enabled && r.fail_count) ? (r.rp.n_rows + block - 1) / block : 0;
 }
 

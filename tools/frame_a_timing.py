@@ -19,7 +19,7 @@ def main():
     n_words, q, n_sig = int(os.environ.get("N_WORDS", "49000")), 500, int(os.environ.get("N_SIG", "100000"))
     vocab = synth.vocab_surf(n_words)
     words = synth.zipf_words(n_sig, q, n_words, seed=100000)
-    eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 1024, sig_capacity=n_sig + 4096, pipeline=True)
+    eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 65536, sig_capacity=n_sig + 4096, pipeline=True)
     eng.vocab_append(vocab, np.arange(1, n_words + 1, dtype=np.int32))
     eng.sig_add_bulk(np.arange(1, n_sig + 1, dtype=np.int32), np.arange(0, (n_sig + 1) * q, q, dtype=np.int64), words.reshape(-1))
     d_words = torch.zeros(q, dtype=torch.int32, device="cuda")
@@ -32,7 +32,8 @@ def main():
         n = 10 + rep
         for i in range(n):
             eng.frame_dev(frames[i % 8].data_ptr(), q, n_sig + 1000 * rep + 1 + i, float(n_sig + 1), d_words.data_ptr(), d_like.data_ptr(), cap,
-                          incremental=True, new_words_compared=True, nndr=0.8, first_new_word_id=n_words + 1 + (100 * rep + i) * q)
+                          incremental=True, new_words_compared=True, nndr=0.8, first_new_word_id=n_words + 1 + (100 * rep + i) * q,
+                          append_new_words=bool(os.environ.get("APPEND")))
             eng.sig_remove(1 + 20 * rep + i)
         torch.cuda.synchronize()                       # NOT eng.synchronize(): the stamps of the last fused launch must survive
         tb = (ctypes.c_ulonglong * 64)()
