@@ -261,11 +261,22 @@ int lcd_engine::reconcile() {
     return LCD_OK;
 }
 
+// No exception crosses the C-ABI (lcd.h): the bookkeeping of every entry point uses std:: containers, whose allocations may throw
+static int lcd_catch(const lcd_engine* h, int code, const char* what) noexcept {
+    if (h) { try { const_cast<lcd_engine*>(h)->err = what; } catch (...) { } }
+    return code;
+}
+#define LCD_TRY try {
+#define LCD_CATCH(h) } catch (const std::bad_alloc&) { return lcd_catch(h, LCD_ERR_NOMEM, "out of host memory"); } \
+    catch (const std::exception& e__) { return lcd_catch(h, LCD_ERR_STATE, e__.what()); } \
+    catch (...) { return lcd_catch(h, LCD_ERR_STATE, "unexpected exception"); }
+
 extern "C" {
 
 int lcd_abi_version(void) { return LCD_ABI_VERSION; }
 
 int lcd_create(const lcd_config* cfg, lcd_engine** out) {
+    LCD_TRY
     if (!cfg || !out) return LCD_ERR_INVALID;
     *out = nullptr;
     if (cfg->struct_size != (int32_t)sizeof(lcd_config)) return LCD_ERR_INVALID;
@@ -313,9 +324,11 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
     if (e != hipSuccess) { lcd_destroy(h); return LCD_ERR_HIP; }
     *out = h;
     return LCD_OK;
+    LCD_CATCH((const lcd_engine*)nullptr)
 }
 
 void lcd_destroy(lcd_engine* h) {
+    try {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)h->drain();
@@ -340,14 +353,17 @@ void lcd_destroy(lcd_engine* h) {
     h->h_in.release(); h->h_out.release(); h->h_out2.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+    } catch (...) { }
 }
 
 const char* lcd_last_error(const lcd_engine* h) { return h ? h->err.c_str() : "null handle"; }
 
 int lcd_synchronize(lcd_engine* h) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     return h->sync_all();
+    LCD_CATCH(h)
 }
 
 void* lcd_stream(lcd_engine* h) { return h ? (void*)h->stream : nullptr; }
@@ -355,16 +371,19 @@ void* lcd_stream(lcd_engine* h) { return h ? (void*)h->stream : nullptr; }
 int lcd_pipeline_depth(const lcd_engine* h) { return (h && h->pipeline) ? 2 : 0; }
 
 int lcd_record_event(lcd_engine* h, void* event) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     if (!event) return h->fail(LCD_ERR_INVALID, "lcd_record_event: null event");
     LCD_DEV_NODRAIN(h);
     if (!h->inflight.empty()) { h->inflight.back().events_after.push_back(event); return LCD_OK; }   // recorded behind the stages still owed
     LCD_HIP(h, hipEventRecord((hipEvent_t)event, h->stream));
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 // ------------------------------------------------------------------------------------------------ vocabulary
 int lcd_vocab_clear(lcd_engine* h) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     { int rc = h->sync_all(); if (rc) return rc; }
@@ -376,9 +395,11 @@ int lcd_vocab_clear(lcd_engine* h) {
     h->word_row.clear();
     h->word_row_valid = false;
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word_ids) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (n < 0 || (n > 0 && (!rows || !word_ids))) return h->fail(LCD_ERR_INVALID, "lcd_vocab_append: null input");
@@ -438,9 +459,11 @@ int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word
     h->n_live += n;
     h->vcnt_active = false; h->tail_dirty = true;                    // the device row counters (appends by frames) start over from this count
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (n < 0 || (n > 0 && !word_ids)) return h->fail(LCD_ERR_INVALID, "lcd_vocab_remove: null input");
@@ -481,9 +504,11 @@ int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n) {
     // removeWords: the words are gone; their postings keys come back once the device has found them unreferenced
     LCD_HIP(h, h->tfidf.release_words(word_ids, n));
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_vocab_rebuild(lcd_engine* h) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     { int rc = h->sync_all(); if (rc) return rc; }
@@ -542,18 +567,22 @@ int lcd_vocab_rebuild(lcd_engine* h) {
     h->vcnt_active = false; h->tail_dirty = true;
     h->rebuilds += 1;
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_vocab_count(const lcd_engine* h, int64_t* rows, int64_t* live) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     if (hipSetDevice(h->device) != hipSuccess) return LCD_ERR_HIP;
     { int rc = const_cast<lcd_engine*>(h)->drain(); if (rc) return rc; }   // rows appended on the device: the owed stages run, the mirror catches up
     if (rows) *rows = h->n_rows;
     if (live) *live = h->n_live;
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_vocab_read(lcd_engine* h, int64_t first, int n, void* out_rows, int32_t* out_word_ids) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (first < 0 || n < 0 || first + n > h->n_rows) return h->fail(LCD_ERR_INVALID, "lcd_vocab_read: range");
@@ -568,10 +597,12 @@ int lcd_vocab_read(lcd_engine* h, int64_t first, int n, void* out_rows, int32_t*
     }
     if (out_word_ids) { int rc = download(h, out_word_ids, h->row_id.as<int32_t>() + first, (size_t)n * 4, h->h_out2); if (rc) return rc; }
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 // ------------------------------------------------------------------------------------------------ 2-NN
 int lcd_knn2(lcd_engine* h, const void* queries, int q, int32_t* out_word_ids, float* out_dist) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     LCD_JOIN_K(h);
@@ -585,9 +616,11 @@ int lcd_knn2(lcd_engine* h, const void* queries, int q, int32_t* out_word_ids, f
     rc = download(h, out_word_ids, h->d_knn_word.p, (size_t)q * 8, h->h_out);
     if (rc) return rc;
     return download(h, out_dist, h->d_knn_dist.p, (size_t)q * 8, h->h_out);
+    LCD_CATCH(h)
 }
 
 int lcd_selfdist(lcd_engine* h, const void* queries, int q, float* out_qxq) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     LCD_JOIN_K(h);
@@ -598,6 +631,7 @@ int lcd_selfdist(lcd_engine* h, const void* queries, int q, float* out_qxq) {
     LCD_HIP(h, dreserve(h, h->d_selfdist, (size_t)q * q * 4));
     LCD_HIP(h, launch_selfdist(h->dtype, h->kdim, h->d_queries.p, q, h->d_selfdist.as<float>(), q, h->stream));
     return download(h, out_qxq, h->d_selfdist.p, (size_t)q * q * 4, h->h_out);
+    LCD_CATCH(h)
 }
 
 // device part of addNewWords up to (not including) the decision loop: 2-NN, same-frame distances + candidate bits.
@@ -675,6 +709,7 @@ static int quantize_dev(lcd_engine* h, const void* d_desc, int q, int flags, flo
 }
 
 int lcd_quantize(lcd_engine* h, const void* descriptors, int q, int flags, float nndr_ratio, int32_t* out_word_ids, int32_t* out_n_new) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     LCD_JOIN_K(h);
@@ -691,10 +726,12 @@ int lcd_quantize(lcd_engine* h, const void* descriptors, int q, int flags, float
     if (rc) return rc;
     if (out_n_new) return download(h, out_n_new, h->d_n_new.p, 4, h->h_out2);
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_find_nn(lcd_engine* h, const void* queries, int q, const void* extra_rows, const int32_t* extra_word_ids, int n_extra, int flags,
                 float nndr_ratio, int32_t* out_word_ids) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     LCD_JOIN_K(h);
@@ -726,6 +763,7 @@ int lcd_find_nn(lcd_engine* h, const void* queries, int q, const void* extra_row
                                      n_extra > 0 ? 1 : 0, h->d_extra_word.as<int32_t>(), h->d_extra_dist.as<float>(),
                                      h->d_out_word.as<int32_t>(), h->stream));
     return download(h, out_word_ids, h->d_out_word.p, (size_t)q * 4, h->h_out);
+    LCD_CATCH(h)
 }
 
 // ------------------------------------------------------------------------------------------------ inverted index
@@ -748,6 +786,7 @@ static int stage_word_ids(lcd_engine* h, const int32_t* word_ids, int64_t n, boo
 }
 
 int lcd_sig_add(lcd_engine* h, int32_t sig_id, const int32_t* word_ids, int n, int32_t ni) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (sig_id == 0 || n < 0 || (n > 0 && !word_ids) || ni < 0) return h->fail(LCD_ERR_INVALID, "lcd_sig_add: bad argument");
@@ -758,9 +797,11 @@ int lcd_sig_add(lcd_engine* h, int32_t sig_id, const int32_t* word_ids, int n, i
     LCD_HIP(h, h->tfidf.register_dev(sig_id, h->tfidf.d_stage.as<int32_t>(), n, ni, 0.0f, nullptr, true));
     LCD_HIP(h, hipStreamSynchronize(h->stream));   // the caller's buffer was the copy source
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_sig_add_bulk(lcd_engine* h, int n_sigs, const int32_t* sig_ids, const int64_t* sig_offsets, const int32_t* word_ids, const int32_t* ni) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (n_sigs < 0 || (n_sigs > 0 && (!sig_ids || !sig_offsets || !word_ids))) return h->fail(LCD_ERR_INVALID, "lcd_sig_add_bulk: null input");
@@ -785,9 +826,11 @@ int lcd_sig_add_bulk(lcd_engine* h, int n_sigs, const int32_t* sig_ids, const in
     if (rc) return rc;
     LCD_HIP(h, t.register_bulk(n_sigs, sig_ids, sig_offsets, ni, t.d_stage.as<int32_t>(), total, max_n));   // synchronises
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_sig_remove(lcd_engine* h, int32_t sig_id) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV_NODRAIN(h);
     if (!h->inflight.empty()) {
@@ -804,17 +847,21 @@ int lcd_sig_remove(lcd_engine* h, int32_t sig_id) {
     if (!h->tfidf.sig_slot.count(sig_id)) return h->fail(LCD_ERR_STATE, "lcd_sig_remove: unknown signature");
     LCD_HIP(h, h->tfidf.retire(sig_id));
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_sig_count(const lcd_engine* h, int64_t* live_signatures, int64_t* postings) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     { int rc = const_cast<lcd_engine*>(h)->drain(); if (rc) return rc; }
     if (live_signatures) *live_signatures = h->tfidf.live_sigs;
     if (postings) *postings = h->tfidf.postings_ub;
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_word_nrefs(lcd_engine* h, int32_t word_id, int32_t* out_nw) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (!out_nw) return h->fail(LCD_ERR_INVALID, "lcd_word_nrefs: null output");
@@ -823,9 +870,11 @@ int lcd_word_nrefs(lcd_engine* h, int32_t word_id, int32_t* out_nw) {
     if (ws < 0) { *out_nw = 0; return LCD_OK; }
     LCD_HIP(h, h->tfidf.flush_retire());             // retirements ride with the next frame otherwise: nw would be stale
     return download(h, out_nw, h->tfidf.nw.as<uint32_t>() + ws, 4, h->h_out2);
+    LCD_CATCH(h)
 }
 
 int lcd_likelihood(lcd_engine* h, const int32_t* query_word_ids, int nq, const int32_t* sig_ids, int n_ids, float N, float* out) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (nq < 0 || n_ids < 0 || (nq > 0 && !query_word_ids) || (n_ids > 0 && (!sig_ids || !out)))
@@ -849,6 +898,7 @@ int lcd_likelihood(lcd_engine* h, const int32_t* query_word_ids, int nq, const i
     float* d_out = h->d_like.as<float>() + t.n_slots;
     LCD_HIP(h, launch_gather_f32(h->d_like.as<float>(), h->d_slots.as<int64_t>(), n_ids, d_out, h->stream));
     return download(h, out, d_out, (size_t)n_ids * 4, h->h_out);
+    LCD_CATCH(h)
 }
 
 // Rtabmap::adjustLikelihood on a device vector whose entry 0 is the virtual place, in place: the decision stage's two passes
@@ -861,6 +911,7 @@ static int adjust_vector(lcd_engine* h, float* d_L, int n, float ratio) {
 }
 
 int lcd_adjust_likelihood(lcd_engine* h, float* likelihood, int n, float virtual_place_ratio) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (n < 0 || (n > 0 && !likelihood)) return h->fail(LCD_ERR_INVALID, "lcd_adjust_likelihood: null input");
@@ -871,14 +922,17 @@ int lcd_adjust_likelihood(lcd_engine* h, float* likelihood, int n, float virtual
     LCD_HIP(h, hipMemcpyAsync(h->d_like.p, h->h_in.p, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     { int rc = adjust_vector(h, h->d_like.as<float>(), n, virtual_place_ratio); if (rc) return rc; }
     return download(h, likelihood, h->d_like.p, (size_t)n * 4, h->h_out);
+    LCD_CATCH(h)
 }
 
 int lcd_adjust_likelihood_dev(lcd_engine* h, float* d_likelihood, int n, float virtual_place_ratio) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (n < 0 || (n > 0 && !d_likelihood)) return h->fail(LCD_ERR_INVALID, "lcd_adjust_likelihood_dev: null input");
     if (n == 0) return LCD_OK;
     return adjust_vector(h, d_likelihood, n, virtual_place_ratio);
+    LCD_CATCH(h)
 }
 
 // ------------------------------------------------------------------------------------------------ device-resident frame
@@ -1137,6 +1191,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
 }
 
 int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     FrameHostTimer timer__(h);
     LCD_DEV_NODRAIN(h);
@@ -1163,36 +1218,44 @@ int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     const uint64_t vseq = h->vseq;
     if (app) { h->unreconciled.push_back(lcd_engine::DevAppend{vseq, a->first_new_word_id, q, true}); h->vseq += 1; }
     return frame_stage_s(h, *a, r, app, vseq);
+    LCD_CATCH(h)
 }
 
 int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_ids, float* d_dist) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     LCD_JOIN_K(h);
     if (q <= 0 || !d_queries || !d_word_ids || !d_dist) return h->fail(LCD_ERR_INVALID, "lcd_knn2_dev: bad argument");
     LCD_HIP(h, dreserve(h, h->d_knn_row, (size_t)q * 2 * 4));
     return run_knn2_raw(h, d_queries, q, h->vocab.p, h->row_id.as<int32_t>(), h->n_rows, true, h->d_knn_row.as<int32_t>(), d_word_ids, d_dist);
+    LCD_CATCH(h)
 }
 
 // ---------------------------------------------------------------------------------------------------------------- Bayes filter
 int lcd_bayes_configure(lcd_engine* h, const double* prediction_lc, int n_values, float virtual_place_prior) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (!prediction_lc) return h->fail(LCD_ERR_INVALID, "lcd_bayes_configure: bad argument");
     if (h->bayes.configure(prediction_lc, n_values, virtual_place_prior) != hipSuccess)
         return h->fail(LCD_ERR_INVALID, "lcd_bayes_configure: 2..32 values in [0, 1] and a prior in [0, 1] expected");   // the reference logs UERROR (:83, :103)
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_bayes_reset(lcd_engine* h) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     LCD_HIP(h, h->bayes.reset());
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_bayes_set_neighbors(lcd_engine* h, int n_sigs, const int32_t* sig_ids, const int64_t* offsets, const int32_t* nbr_sig_ids,
                             const int32_t* nbr_margins) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
 #ifdef LCD_DEBUG_TIMING
     static double dbg[4]; static int dbg_n;
@@ -1234,9 +1297,12 @@ int lcd_bayes_set_neighbors(lcd_engine* h, int n_sigs, const int32_t* sig_ids, c
     };
     for (int i = 0; i < n_sigs; ++i) {
         const int64_t a = slot_of(sig_ids[i]);
-        if (a < 0) return h->fail(LCD_ERR_STATE, "lcd_bayes_set_neighbors: unknown signature");
-        restart.push_back((int32_t)a);
         if (offsets[i + 1] < offsets[i]) return h->fail(LCD_ERR_INVALID, "lcd_bayes_set_neighbors: offsets must not decrease");
+        // a signature the engine does not hold -- one without a single word never got references, hence no slot (a featureless
+        // frame, Rtabmap.cpp:2234 "bad signature") -- has no likelihood and no posterior: its list is skipped, the reference's filter
+        // carries such signatures along with probability 0 as well
+        if (a < 0) continue;
+        restart.push_back((int32_t)a);
         for (int64_t e = offsets[i]; e < offsets[i + 1]; ++e) {
             const int32_t m = nbr_margins[e];
             if (m < 0 || m > max_margin) return h->fail(LCD_ERR_INVALID, "lcd_bayes_set_neighbors: margin outside the prediction's levels");   // UASSERT :263
@@ -1256,9 +1322,11 @@ int lcd_bayes_set_neighbors(lcd_engine* h, int n_sigs, const int32_t* sig_ids, c
     if (le == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_bayes_set_neighbors: a neighbour list longer than 8192 entries");
     LCD_HIP(h, le);
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_bayes_update_dev(lcd_engine* h, const float* d_adjusted, int exclude_recent, float* d_posterior, lcd_bayes_result* d_result) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (!d_adjusted) return h->fail(LCD_ERR_INVALID, "lcd_bayes_update_dev: bad argument");
@@ -1270,9 +1338,11 @@ int lcd_bayes_update_dev(lcd_engine* h, const float* d_adjusted, int exclude_rec
     d.adj_in = d_adjusted; d.bayes = true; d.d_posterior = d_posterior; d.d_bayes = (BayesOut*)d_result;
     LCD_HIP(h, h->bayes.decide(d, t.slot_sig.as<int32_t>(), t.n_slots, n_cons));
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_bayes_update(lcd_engine* h, const int32_t* sig_ids, const float* adjusted, int n, lcd_bayes_result* result) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (n < 1 || !sig_ids || !adjusted) return h->fail(LCD_ERR_INVALID, "lcd_bayes_update: bad argument");
@@ -1286,17 +1356,19 @@ int lcd_bayes_update(lcd_engine* h, const int32_t* sig_ids, const float* adjuste
     float* adj = (float*)h->h_in.p;
     std::memset(adj, 0, bytes);
     adj[0] = adjusted[0];
-    int64_t n_cons = 0;
+    int64_t n_cons = 0, n_reg = 0;
     for (int i = 1; i < n; ++i) {
         if (sig_ids[i] <= sig_ids[i - 1]) return h->fail(LCD_ERR_INVALID, "lcd_bayes_update: ids must ascend (std::map order)");
         auto it = t.sig_slot.find(sig_ids[i]);
-        if (it == t.sig_slot.end()) return h->fail(LCD_ERR_INVALID, "lcd_bayes_update: a signature of the likelihood is not registered");
+        if (it == t.sig_slot.end()) continue;                    // a signature without words holds no slot: no likelihood, posterior 0 (see set_neighbors)
         adj[(size_t)it->second + 1] = adjusted[i];
         n_cons = std::max<int64_t>(n_cons, it->second + 1);
+        n_reg += 1;
     }
     int64_t live_below = 0;
-    for (const auto& kv : t.sig_slot) live_below += kv.second < n_cons ? 1 : 0;
-    if (live_below != (int64_t)n - 1)
+    if (n_cons == t.n_slots) live_below = t.live_sigs;             // the usual case without a short-term memory: no walk over the table
+    else for (const auto& kv : t.sig_slot) live_below += kv.second < n_cons ? 1 : 0;
+    if (live_below != n_reg)
         return h->fail(LCD_ERR_UNSUPPORTED, "lcd_bayes_update: the likelihood must hold every registered signature up to its newest one "
                                             "(the working memory without the short-term memory)");
     LCD_HIP(h, dreserve(h, h->d_adj_scratch, bytes));
@@ -1308,9 +1380,11 @@ int lcd_bayes_update(lcd_engine* h, const int32_t* sig_ids, const float* adjuste
     { int rc = download(h, &r, h->d_hyp_scratch.p, sizeof(r), h->h_out); if (rc) return rc; }   // (synchronises: h_in is free again)
     if (result) *result = r;
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_bayes_posterior(lcd_engine* h, const int32_t* sig_ids, int n, float* out) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (n < 0 || (n > 0 && (!sig_ids || !out))) return h->fail(LCD_ERR_INVALID, "lcd_bayes_posterior: bad argument");
@@ -1330,9 +1404,11 @@ int lcd_bayes_posterior(lcd_engine* h, const int32_t* sig_ids, int n, float* out
         out[i] = v;
     }
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shard_cand* d_cand) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     LCD_JOIN_K(h);
@@ -1344,11 +1420,13 @@ int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shar
     LCD_HIP(h, launch_shard_pack(h->d_knn_row.as<int32_t>(), h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
                                  h->row_wslot.as<int32_t>(), q, d_cand, h->stream));
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, float nndr_ratio, int32_t sig_id,
                         int32_t first_new_word_id, float N, int rank, int world, const lcd_shard_cand* d_all_cand, int64_t total_live_rows,
                         int32_t* d_word_ids, int64_t* d_lfix, int64_t lfix_capacity) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     LCD_JOIN_K(h);
@@ -1396,26 +1474,32 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
         h->likelihood_launches += 1;
     }
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_finalize_dev(lcd_engine* h, int64_t* d_lfix, int64_t n, float* d_likelihood) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (n < 0 || (n > 0 && (!d_lfix || !d_likelihood))) return h->fail(LCD_ERR_INVALID, "lcd_finalize_dev: bad argument");
     if (n > h->tfidf.n_slots) return h->fail(LCD_ERR_INVALID, "lcd_finalize_dev: more entries than signature slots");
     LCD_HIP(h, h->tfidf.finalize((const long long*)d_lfix, (long long)n, d_likelihood));
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_slots_dev(lcd_engine* h, const int32_t** d_slot_sig, int64_t* n_slots) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     { int rc = h->drain(); if (rc) return rc; }
     if (d_slot_sig) *d_slot_sig = h->tfidf.slot_sig.as<int32_t>();
     if (n_slots) *n_slots = h->tfidf.n_slots;
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_profile_begin(lcd_engine* h, int max_samples) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (max_samples <= 0 || max_samples > (1 << 20)) return h->fail(LCD_ERR_INVALID, "lcd_profile_begin: bad sample count");
@@ -1434,9 +1518,11 @@ int lcd_profile_begin(lcd_engine* h, int max_samples) {
     h->prof2_n = 0;
     h->prof_cap = max_samples;
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_profile_read(lcd_engine* h, float* avg_ms, int* n_samples, const char** kernel_name) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     { int rc = h->sync_all(); if (rc) return rc; }
@@ -1451,9 +1537,11 @@ int lcd_profile_read(lcd_engine* h, float* avg_ms, int* n_samples, const char** 
     if (kernel_name) *kernel_name = h->prof_kernel;
     h->prof_cap = 0;
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, const char** kernel_name) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     { int rc = h->sync_all(); if (rc) return rc; }
@@ -1468,9 +1556,11 @@ int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, co
     if (kernel_name) *kernel_name = h->prof2_kernel;
     h->prof_cap = 0;
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     { int rc = h->drain(); if (rc) return rc; }
     if (!key) return h->fail(LCD_ERR_INVALID, "lcd_set_option: null key");
@@ -1478,18 +1568,22 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     // compute units the bf16 filter's persistent launch plans for (vocabularies of more 256-word strips than that): -1 built-in, 0 off
     if (!std::strcmp(key, "filter_units") && value >= -1 && value <= 4096) { h->filter_units = (int)value; return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");
+    LCD_CATCH(h)
 }
 
 int lcd_profile_score_work(lcd_engine* h, int64_t* out8) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (!out8) return h->fail(LCD_ERR_INVALID, "lcd_profile_score_work: null output");
     { int rc = h->sync_all(); if (rc) return rc; }
     LCD_HIP(h, h->tfidf.score_work(out8));
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 int lcd_get_stats(lcd_engine* h, lcd_stats* out) {
+    LCD_TRY
     LCD_CHECK_HANDLE(h);
     if (!out) return LCD_ERR_INVALID;
     LCD_DEV(h);
@@ -1516,6 +1610,7 @@ int lcd_get_stats(lcd_engine* h, lcd_stats* out) {
     out->dense_words = h->tfidf.h_n_dense ? (int64_t)*(volatile uint32_t*)h->tfidf.h_n_dense : 0;
     out->bytes_device = h->bytes_device;
     return LCD_OK;
+    LCD_CATCH(h)
 }
 
 }  // extern "C"

@@ -52,6 +52,10 @@ void BayesFilterHip::setPredictionLC(const std::string& prediction) {
         logError("The number of values < 2 (prediction=\"" + prediction + "\")");
         return;
     }
+    if (strValues.size() > 32) {          // the device keeps the pattern in a 32-entry table (the margin field of a list entry has 5 bits)
+        logError("Bayes/PredictionLC: more than 32 values are not supported by the device filter (prediction=\"" + prediction + "\")");
+        return;
+    }
     std::vector<double> tmpValues(strValues.size());
     for (size_t i = 0; i < strValues.size(); ++i) {
         tmpValues[i] = str2Float(strValues[i]);
@@ -97,14 +101,14 @@ bool BayesFilterHip::configureDevice(lcd_engine* engine) {
 
 const std::map<int, float>& BayesFilterHip::computePosterior(const MemoryHip* memory, const std::map<int, float>& likelihood) {
     // the reference's three refusals (:149-165): the last posterior is returned unchanged
-    if (!memory) { logError("Memory is Null!"); return _posterior; }
-    if (!likelihood.size()) { logError("likelihood is empty!"); return _posterior; }
-    if (_predictionLC.size() < 2) { logError("Prediction is not valid!"); return _posterior; }
+    if (!memory) { logError("Memory is Null!"); return failed(); }
+    if (!likelihood.size()) { logError("likelihood is empty!"); return failed(); }
+    if (_predictionLC.size() < 2) { logError("Prediction is not valid!"); return failed(); }
     lcd_engine* engine = const_cast<MemoryHip*>(memory)->getVWDictionary()->engine();
-    if (!engine) { _lastError = "no device engine (the dictionary has not seen a descriptor yet)"; logError(_lastError); return _posterior; }
-    if (!this->configureDevice(engine)) { logError(_lastError); return _posterior; }
+    if (!engine) { _lastError = "no device engine (the dictionary has not seen a descriptor yet)"; logError(_lastError); return failed(); }
+    if (!this->configureDevice(engine)) { logError(_lastError); return failed(); }
     // the device scores registered signatures: references added since the last likelihood are sent now
-    if (!const_cast<MemoryHip*>(memory)->flushReferences()) { _lastError = memory->lastError(); logError(_lastError); return _posterior; }
+    if (!const_cast<MemoryHip*>(memory)->flushReferences()) { _lastError = memory->lastError(); logError(_lastError); return failed(); }
 
     // STEP 1 of the reference -- the prediction -- is the neighbour lists.  updatePrediction :560-592: ids that are new in the
     // likelihood bring their neighbourhood; removed ids need nothing (a signature that left the memory is skipped on the device).
@@ -129,7 +133,7 @@ const std::map<int, float>& BayesFilterHip::computePosterior(const MemoryHip* me
         lcd_bayes_set_neighbors(engine, (int)listIds.size(), listIds.data(), offsets.data(), nbrIds.data(), nbrMargins.data()) != LCD_OK) {
         _lastError = lcd_last_error(engine);
         logError(_lastError);
-        return _posterior;
+        return failed();
     }
     _listedIds.swap(present);            // the keys of _neighborsIndex after updatePrediction: exactly the ids of this likelihood
 
@@ -143,17 +147,18 @@ const std::map<int, float>& BayesFilterHip::computePosterior(const MemoryHip* me
     if (lcd_bayes_update(engine, ids.data(), values.data(), (int)ids.size(), &r) != LCD_OK) {
         _lastError = lcd_last_error(engine);
         logError(_lastError);
-        return _posterior;
+        return failed();
     }
     std::vector<float> post(ids.size(), 0.0f);
     if (lcd_bayes_posterior(engine, ids.data(), (int)ids.size(), post.data()) != LCD_OK) {
         _lastError = lcd_last_error(engine);
         logError(_lastError);
-        return _posterior;
+        return failed();
     }
     _posterior.clear();                  // updatePosterior :709-736: the posterior holds exactly the ids of the likelihood
     for (size_t k = 0; k < ids.size(); ++k) _posterior.insert(_posterior.end(), std::pair<int, float>(ids[k], post[k]));
     _highestHypothesis = std::pair<int, float>(r.sig_id, r.value);
+    _lastUpdateOk = true;
     return _posterior;
 }
 

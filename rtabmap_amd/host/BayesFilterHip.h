@@ -37,10 +37,14 @@ public:
 
     // what Rtabmap.cpp:2147-2158 reads off the posterior, computed by the same device pass: (signature id, 1 - virtual place)
     std::pair<int, float> getHighestHypothesis() const { return _highestHypothesis; }
+    // false when the last computePosterior failed (the reference logs UERROR and returns the old posterior, BayesFilter.cpp:150-166; here
+    // the device can fail as well): the highest hypothesis is (0, 0) then, so that no caller accepts a stale one
+    bool lastUpdateOk() const { return _lastUpdateOk; }
     const std::string& lastError() const { return _lastError; }
 
 private:
     bool configureDevice(lcd_engine* engine);
+    const std::map<int, float>& failed() { _lastUpdateOk = false; _highestHypothesis = std::pair<int, float>(0, 0.0f); return _posterior; }
 
 private:
     std::map<int, float> _posterior;
@@ -52,6 +56,7 @@ private:
     bool _deviceConfigured;              // it holds the current _predictionLC / prior (false: configure before the next update)
     std::set<int> _listedIds;            // ids whose neighbour list the device has (the keys of the reference's _neighborsIndex)
     std::pair<int, float> _highestHypothesis;
+    bool _lastUpdateOk = true;
     std::string _lastError;
 };
 

@@ -20,8 +20,8 @@ RtabmapHip::~RtabmapHip() {
 
 void RtabmapHip::parseParameters(const ParametersMap& parameters) {
     ParametersMap::const_iterator it;
-    if ((it = parameters.find("Rtabmap/LoopThr")) != parameters.end()) _loopThr = (float)atof(it->second.c_str());
-    if ((it = parameters.find("Rtabmap/LoopRatio")) != parameters.end()) _loopRatio = (float)atof(it->second.c_str());
+    if ((it = parameters.find("Rtabmap/LoopThr")) != parameters.end()) _loopThr = uStr2Float(it->second);
+    if ((it = parameters.find("Rtabmap/LoopRatio")) != parameters.end()) _loopRatio = uStr2Float(it->second);
     if ((it = parameters.find("Rtabmap/VirtualPlaceLikelihoodRatio")) != parameters.end()) _virtualPlaceLikelihoodRatio = atoi(it->second.c_str());
 }
 
@@ -60,8 +60,8 @@ bool RtabmapHip::process(const Mat& descriptors) {
         _likelihood = _rawLikelihood;
         this->adjustLikelihood(_likelihood);                                // :2121
         _posterior = _bayesFilter->computePosterior(_memory, _likelihood);  // :2131
-        if (_posterior.size()) {                                            // :2147-2158 (the device selected it in the same pass)
-            _highestHypothesis = _bayesFilter->getHighestHypothesis();
+        if (_posterior.size() && _bayesFilter->lastUpdateOk()) {            // :2147-2158 (the device selected it in the same pass); a failed
+            _highestHypothesis = _bayesFilter->getHighestHypothesis();      // update leaves (0, 0): no acceptance on a stale posterior
         }
         if (_highestHypothesis.first > 0) {                                 // :2162-2222 without the RGB-D and epipolar branches
             const float loopThr = _loopThr;

@@ -55,7 +55,7 @@ VWDictionaryHip::~VWDictionaryHip() {
 
 void VWDictionaryHip::parseParameters(const ParametersMap& p) {   // VWDictionary.cpp:88-132
     ParametersMap::const_iterator it;
-    if ((it = p.find("Kp/NndrRatio")) != p.end()) _nndrRatio = (float)atof(it->second.c_str());
+    if ((it = p.find("Kp/NndrRatio")) != p.end()) _nndrRatio = uStr2Float(it->second);
     if ((it = p.find("Kp/NewWordsComparedTogether")) != p.end()) _newWordsComparedTogether = parseBool(it->second);
     bool incremental = _incrementalDictionary;
     if ((it = p.find("Kp/IncrementalDictionary")) != p.end()) incremental = parseBool(it->second);
@@ -158,6 +158,40 @@ std::vector<int> VWDictionaryHip::getIndexedWordIds() const {
     std::vector<int> v;
     for (std::map<int, int>::const_iterator i = _mapIndexId.begin(); i != _mapIndexId.end(); ++i) v.push_back(i->second);
     return v;
+}
+
+// ---------------------------------------------------------------------------------------------- recovery
+bool VWDictionaryHip::rebuildEngine() {
+    if (_engine) { lcd_destroy(_engine); _engine = nullptr; }
+    _deviceSigs.clear();
+    _dirtySigs.clear();
+    for (std::map<int, std::vector<int> >::const_iterator s = _sigWords.begin(); s != _sigWords.end(); ++s) _dirtySigs.insert(s->first);
+    if (_visualWords.empty()) return true;                           // nothing to replay: the engine is created by the next update()
+    const Mat& d0 = _visualWords.begin()->second->getDescriptor();
+    if (!ensureEngine(d0.type(), d0.cols)) return false;
+    // the indexed words in ROW order (the distance tie-break): _mapIndexId is index -> word id
+    std::vector<int32_t> ids;
+    std::vector<unsigned char> rows;
+    for (std::map<int, int>::const_iterator i = _mapIndexId.begin(); i != _mapIndexId.end(); ++i) {
+        std::map<int, VisualWord*>::const_iterator w = _visualWords.find(i->second);
+        if (w == _visualWords.end()) continue;
+        const Mat& d = w->second->getDescriptor();
+        rows.insert(rows.end(), d.data.begin(), d.data.end());
+        ids.push_back(i->second);
+    }
+    if (!ids.empty() && lcd_vocab_append(_engine, rows.data(), (int)ids.size(), ids.data()) != LCD_OK) {
+        _lastError = lcd_last_error(_engine);
+        logError("%s", _lastError.c_str());
+        return false;
+    }
+    // row indices are dense again (removed rows are gone); words waiting for update() stay in _notIndexedWords
+    std::map<int, int> idx;
+    _mapIdIndex.clear();
+    int r = 0;
+    for (size_t k = 0; k < ids.size(); ++k, ++r) { idx.insert(idx.end(), std::pair<int, int>(r, ids[k])); _mapIdIndex[ids[k]] = r; }
+    _mapIndexId.swap(idx);
+    _removedIndexedWords.clear();
+    return true;                                                     // the references follow with the next flushReferences / computeLikelihood
 }
 
 // ---------------------------------------------------------------------------------------------- update()  :475-701

@@ -12,6 +12,7 @@
 // and Memory::computeLikelihood's TF-IDF branch (Memory.cpp:2215-2291) -> lcd_likelihood through computeLikelihood().
 // No search or scoring arithmetic is done on the host: if the engine cannot be created every call fails loudly.
 #pragma once
+#include <cstdlib>
 #include <functional>
 #include <list>
 #include <map>
@@ -39,6 +40,12 @@ struct Mat {
 };
 
 typedef std::map<std::string, std::string> ParametersMap;
+// uStr2Float (UConversion.cpp:138): the decimal mark may be '.' or ','
+inline float uStr2Float(const std::string& s) {
+    std::string v = s;
+    for (size_t i = 0; i < v.size(); ++i) if (v[i] == ',') v[i] = '.';
+    return (float)strtod(v.c_str(), 0);
+}
 
 class VisualWord {   // reference VisualWord.h:38-64, VisualWord.cpp:36-70
 public:
@@ -106,6 +113,12 @@ public:
 
     // send the references added / removed since the last call to the device's inverted index (computeLikelihood does it itself)
     bool flushReferences(const std::function<int(int)>& getNi);
+
+    // The engine is a cache of this object's state (failure row; the reference repairs its dictionary on load,
+    // Memory.cpp:481-565, and rebuilds a bad FLANN index, VWDictionary.cpp:835-838): after a device fault -- or whenever the caller
+    // wants a fresh device state -- destroy the handle, create a new one and replay the indexed words in row order and every
+    // signature's references from the host maps.  Returns false (lastError) when no device can be opened.
+    bool rebuildEngine();
 
     // ids of the indexed rows in device row order (the tie-break order); for tests
     std::vector<int> getIndexedWordIds() const;

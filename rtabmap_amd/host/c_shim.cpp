@@ -51,6 +51,7 @@ int hvwd_get_unused_word_ids(void* h, int* out, int cap) {
 }
 void hvwd_delete_unused_words(void* h) { ((VWDictionaryHip*)h)->deleteUnusedWords(); }
 void hvwd_clear(void* h) { ((VWDictionaryHip*)h)->clear(false); }
+int hvwd_rebuild_engine(void* h) { return ((VWDictionaryHip*)h)->rebuildEngine() ? 1 : 0; }
 // which: 0 visualWords, 1 notIndexed, 2 indexed, 3 totalActiveReferences, 4 lastIndexedWordId, 5 unused
 long hvwd_stat(void* h, int which) {
     VWDictionaryHip* d = (VWDictionaryHip*)h;

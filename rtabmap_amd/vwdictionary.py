@@ -45,6 +45,8 @@ def lib():
         L.hvwd_get_unused_word_ids.argtypes = [vp, vp, ci]
         L.hvwd_delete_unused_words.argtypes = [vp]
         L.hvwd_clear.argtypes = [vp]
+        L.hvwd_rebuild_engine.argtypes = [vp]
+        L.hvwd_rebuild_engine.restype = ci
         L.hvwd_stat.argtypes = [vp, ci]
         L.hvwd_stat.restype = C.c_long
         L.hvwd_get_word_refs.argtypes = [vp, ci, vp, vp, ci]
@@ -146,6 +148,10 @@ class VWDictionaryHip:
 
     def clear(self):
         lib().hvwd_clear(self.h)
+
+    def rebuild_engine(self):
+        """VWDictionaryHip::rebuildEngine: a fresh device handle, replayed from the host maps (recovery after a device fault)"""
+        return bool(lib().hvwd_rebuild_engine(self.h))
 
     def stat(self, which):
         return int(lib().hvwd_stat(self.h, which))

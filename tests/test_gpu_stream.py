@@ -301,3 +301,92 @@ def test_rtabmap_hip_process_detects_loop_closures_like_the_restated_block(oracl
     right = [c for c in second_pass if abs(c[1] - c[2]) <= 2]
     assert len(right) >= 0.4 * len(second_pass), second_pass
     r.close()
+
+
+@pytest.mark.parametrize("kind,rows", [("surf", 300), ("orb", 400), ("surf", 40)])
+def test_temporary_dictionary_of_a_frame_pair(oracle, kind, rows):
+    """The SECOND caller of the boundary: RegistrationVis.cpp:1482-1503 builds a temporary VWDictionary per frame pair --
+    addNewWords(descriptorsFrom, 1) -> update() -> addNewWords(descriptorsTo, 2) -> clear() -- to match the two frames' features.
+    Through VWDictionaryHip against the restated VWDictionary, id for id; the create / two calls / destroy cost is reported (it is what
+    INTEGRATION.md's size threshold for strategy 5 rests on)."""
+    import time
+    from rtabmap_amd.vwdictionary import VWDictionaryHip
+    rng = np.random.default_rng(rows)
+    if kind == "orb":
+        a = rng.integers(0, 256, (rows, 32), dtype=np.uint8)
+        b = a[rng.permutation(rows)[: rows * 3 // 4]] ^ np.packbits(rng.random((rows * 3 // 4, 256)) < 0.02, axis=1)
+        b = np.ascontiguousarray(np.concatenate([b, rng.integers(0, 256, (rows // 4, 32), dtype=np.uint8)]))
+    else:
+        a = synth.vocab_surf(rows, seed=rows)
+        b = a[rng.permutation(rows)[: rows * 3 // 4]] + rng.standard_normal((rows * 3 // 4, 64)).astype(np.float32) * np.float32(0.02)
+        b /= np.linalg.norm(b, axis=1, keepdims=True)
+        b = np.ascontiguousarray(np.concatenate([b, synth.vocab_surf(rows // 4, seed=rows + 1)]).astype(np.float32))
+    costs = []
+    for rep in range(3):
+        o = oracle.OracleVWDictionary(strategy=oracle.kNNBruteForce, nndr=0.8, new_words_compared_together=True)
+        t0 = time.perf_counter()
+        h = VWDictionaryHip(nndr=0.8, new_words_compared_together=True)
+        from_h = h.add_new_words(a, 1)
+        h.update()
+        to_h = h.add_new_words(b, 2)
+        h.clear()
+        h.close()
+        costs.append(time.perf_counter() - t0)
+        from_o = o.add_new_words(a, 1)
+        o.update()
+        to_o = o.add_new_words(b, 2)
+        assert from_h == from_o and to_h == to_o, "pair %d" % rep
+        assert len(set(from_h) & set(to_h)) > rows // 2          # most of frame B's features match words frame A created
+        o.close()
+    print("temporary dictionary, %s %d + %d descriptors: %.2f ms per pair (first pair %.2f ms)" % (kind, rows, b.shape[0], 1e3 * min(costs), 1e3 * costs[0]))
+
+
+def test_rtabmap_hip_survives_a_featureless_frame(oracle):
+    """A frame without features gives a signature without words: it never gets references, hence no slot on the device.  Once it
+    leaves the short-term memory it is in the likelihood like any other place (Rtabmap.cpp:2046-2115); the reference's filter
+    carries it with probability 0.  The filter must keep working -- and must not accept a stale hypothesis."""
+    from rtabmap_amd.vwdictionary import RtabmapHip
+    STM, q = 3, 80
+    places = [synth.vocab_surf(q, seed=7000 + p) for p in range(10)]
+    r = RtabmapHip(loop_thr=0.11, stm_size=STM)
+    ids = []
+    for t in range(22):
+        desc = np.zeros((0, 64), np.float32) if t == 4 else places[t % 10]
+        res = r.process(desc)
+        assert res["ok"], "frame %d" % t
+        ids.append(res["id"])
+        if t > 4 + STM + 1:
+            pi, pv = r.vector("posterior")
+            assert pi.size > 1 and np.isfinite(pv).all() and abs(float(pv.sum()) - 1.0) < 1e-3, "frame %d: the filter stopped updating" % t
+            assert ids[4] in pi.tolist() and pv[pi.tolist().index(ids[4])] == 0.0        # the wordless signature: probability 0
+    # the second pass over the places closes loops although the bad signature sits in the working memory
+    assert res["highest"][0] > 0
+    r.close()
+
+
+@pytest.mark.parametrize("kind", ["orb", "surf"])
+def test_engine_rebuilt_from_the_host_mirror(oracle, kind):
+    """Recovery: the device engine is a cache of VWDictionaryHip's maps.  Mid-stream the handle is thrown away and
+    re-created from them -- indexed words in row order, every signature's references -- and the stream goes on as if nothing had
+    happened: word ids, dictionary state and likelihood equal the oracle's before and after."""
+    from rtabmap_amd.vwdictionary import MemoryHip
+    frames = _frames(kind, 16, 140)
+    o = oracle.OracleMemory(strategy=oracle.kNNBruteForce, nndr=0.8, new_words_compared_together=True)
+    h = MemoryHip(nndr=0.8, new_words_compared_together=True)
+    W = 7
+    for t, desc in enumerate(frames):
+        if t in (6, 11):
+            assert h.vwd.rebuild_engine(), h.vwd.last_error()
+        so, ido = o.update(desc)
+        sh, idh = h.update(desc)
+        assert so == sh and idh == ido, "frame %d" % t
+        _same_state(o, h)
+        ids = np.array(o.signature_ids(), np.int32)
+        oi, Lo = o.compute_likelihood(np.array(ido, np.int32), ids)
+        hi, Lh = h.compute_likelihood(np.array(idh, np.int32), ids)
+        assert oi.tolist() == hi.tolist()
+        np.testing.assert_allclose(Lh, Lo, rtol=RTOL, atol=ATOL, err_msg="frame %d" % t)
+        if so > W:
+            o.forget(so - W)
+            h.forget(so - W)
+    h.close()
