@@ -89,9 +89,13 @@ def load_engine(eng, vocab, words, owned=None):
 class Stepper:
     """The bench step on one engine: frame t registered as signature n_sig + 1 + t, the oldest signature retired."""
 
-    def __init__(self, eng, torch, d_frames, n_sig, cap, want_like=True):
+    def __init__(self, eng, torch, d_frames, n_sig, cap, want_like=True, log_frames=0):
         self.eng, self.d_frames, self.n_sig, self.cap = eng, d_frames, n_sig, cap
         self.d_words = torch.zeros(Q, dtype=torch.int32, device="cuda")
+        # log_frames > 0: every frame's word ids are kept (one row each) so that the oracle can replay what THIS engine registered
+        self.d_words_log = torch.zeros((log_frames, Q), dtype=torch.int32, device="cuda") if log_frames else None
+        self.log_base = self.d_words_log.data_ptr() if log_frames else 0
+        self.n_calls, self.first_new_log = 0, []
         self.d_like = torch.zeros(cap, dtype=torch.float32, device="cuda") if want_like else None
         self.next_sig, self.oldest, self.first_new = n_sig + 1, 1, N_WORDS + 1
         self.ptrs = [f.data_ptr() for f in d_frames]
@@ -103,6 +107,12 @@ class Stepper:
         a.d_descriptors = self.ptrs[i % len(self.ptrs)]
         a.sig_id = self.next_sig
         a.first_new_word_id = 0 if "no-new" in DIAG else self.first_new
+        if self.log_base and self.n_calls < self.d_words_log.shape[0]:
+            a.d_word_ids = self.log_base + self.n_calls * Q * 4
+            self.first_new_log.append(self.first_new)
+        elif self.log_base:
+            a.d_word_ids = self.d_words.data_ptr()
+        self.n_calls += 1
         self.eng.frame_dev_args(a)
         if "no-retire" not in DIAG:
             self.eng.sig_remove(self.oldest)
@@ -358,47 +368,124 @@ def parity_block(torch, vocab, words, frames_np, m, n_frames=3):
             t_knn / n_frames, t_lik / n_frames)
 
 
-def cpu_baselines(vocab, frames_np, t_linear_port, t_lik_full, n_sig):
+def timed_engine_parity(m, step, frames_np, like_last, n_sig):
+    """Parity ON THE ENGINE THAT WAS TIMED: the oracle replays what that engine registered -- every frame's word ids as the device
+    decided them (the words a frame created get their descriptor; none is ever indexed, as in the timed loop), the retirement of the
+    oldest signature after every frame -- and its restated Memory::computeLikelihood of the LAST frame is compared with the likelihood
+    the timed engine left for that frame: the inverted index after hundreds of registrations, retirements, reserved and recycled
+    postings keys, pipelined launches.  (Word assignment itself is checked by parity_block on a fresh engine: the oracle's exact
+    2-NN of hundreds of frames would take minutes.)"""
+    T = len(step.first_new_log)
+    got = step.d_words_log[:T].cpu().numpy()
+    nf = len(frames_np)
+    t0 = time.perf_counter()
+    for i in range(T):
+        codes = got[i]
+        ids = np.where(codes < 0, step.first_new_log[i] - codes - 1, codes).astype(np.int32)
+        seen = set()
+        for j in np.flatnonzero(codes < 0).tolist():
+            if codes[j] not in seen:                                   # the first descriptor with the code created the word
+                seen.add(int(codes[j]))
+                m.vwd.add_word(int(ids[j]), frames_np[i % nf][j])
+        sid = m.add_signature_with_id(n_sig + 1 + i, ids)
+        assert sid == n_sig + 1 + i
+        if i < T - 1:
+            m.forget(1 + i)
+    live = np.array(m.signature_ids(), np.int32)
+    oi, Lo = m.compute_likelihood(ids, live)
+    slots = np.where(oi <= n_sig, oi - 1, oi - 1)                      # signature id s sits in slot s - 1 (bulk ids 1..n_sig, then the frames)
+    Lh = like_last[slots]
+    err = np.abs(Lh - Lo) / np.maximum(np.abs(Lo), 1e-7 / 1e-4)
+    dead = np.ones(n_sig + T, bool)
+    dead[slots] = False
+    return {"frames_replayed": T, "likelihood_max_rel": float(err.max()), "likelihood_values_compared": int(Lo.size),
+            "argmax_equal": bool(int(np.argmax(Lh[:-1])) == int(np.argmax(Lo[:-1]))), "retired_slots_all_zero": bool(not like_last[: n_sig + T][dead].any()),
+            "replay_s": time.perf_counter() - t0,
+            "path": "the timed engine's own last frame (after %d pipelined frames with registration + retirement) vs the oracle's "
+                    "Memory::computeLikelihood on the replayed memory" % T}
+
+
+def flat_tfidf_ms(words, frame_words, n_sig, thread_counts):
+    """The TF-IDF leg a CPU implementation could reach if it gave up the reference's std::map containers: flat word-major postings of the
+    frame's words (built outside the timed region, as an index would hold them) scored with OpenMP over the words (oracle.flat_tfidf --
+    a baseline, never a parity reference).  Returns {threads: ms}."""
+    import oracle as O
+    flat = words.reshape(-1)
+    qw = np.unique(frame_words[frame_words > 0])
+    sel = np.nonzero(np.isin(flat, qw))[0]
+    key = flat[sel].astype(np.int64) * n_sig + (sel // words.shape[1])
+    uk, cnt = np.unique(key, return_counts=True)
+    pw, ps = uk // n_sig, (uk % n_sig).astype(np.int32)
+    off = np.append(np.searchsorted(pw, qw, side="left"), len(pw)).astype(np.int64)
+    ni = np.full(n_sig, words.shape[1], np.int32)
+    out = {}
+    for th in thread_counts:
+        O.flat_tfidf(off, ps, cnt.astype(np.int32), ni, float(n_sig), th)                # warm (thread pool start-up)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            O.flat_tfidf(off, ps, cnt.astype(np.int32), ni, float(n_sig), th)
+        out[th] = 1e3 * (time.perf_counter() - t0) / 3
+    return out
+
+
+def cpu_baselines(vocab, frames_np, t_linear_port, t_lik_full, n_sig, words=None, frame_words=None):
     """(i) the reference default -- rtflann kd-tree (4 trees, 32 checks), 1 thread; (ii) the exact configuration --
-    rtflann LINEAR, 1 thread; (iii) generous -- the same rtflann code with OpenMP over the queries on every host core.  The TF-IDF
-    leg is the restated std::map Memory::computeLikelihood over the FULL signature memory (it is single-threaded in the reference)."""
+    rtflann LINEAR, 1 thread; (iii) generous -- the same rtflann code with OpenMP over the queries, at the thread count that is
+    FASTEST on this box (500 queries do not feed every core: all cores is slower than one).  The TF-IDF leg of (i)-(iii) is the
+    restated std::map Memory::computeLikelihood over the FULL signature memory (single-threaded in the reference); (iv) replaces it
+    with flat postings + OpenMP (flat_tfidf_ms) next to the best 2-NN time: what `best_cpu_value` means."""
     import oracle as O
     cores = os.cpu_count() or 1
+    counts = sorted(set(c for c in (1, 2, 4, 8, 16, 32, 64, cores) if c <= cores))
     out = {}
 
-    def rate(t_knn):
-        return n_sig / (t_knn + t_lik_full)
+    def rate(t_knn, t_lik=t_lik_full):
+        return n_sig / (t_knn + t_lik)
+    t_kd = {}
+    t_lin = {}
     if O.have_ref():
         kd = O.RefIndex(vocab, algo=O.ALGO_KDTREE, trees=4)
         lin = O.RefIndex(vocab, algo=O.ALGO_LINEAR)
         def timeit(f, n):
+            f(frames_np[0])
             t0 = time.perf_counter()
             for i in range(n):
                 f(frames_np[i % len(frames_np)])
             return (time.perf_counter() - t0) / n
-        t_kd1 = timeit(lambda d: kd.knn(d, k=2, checks=32, cores=1), 20)
-        t_lin1 = timeit(lambda d: lin.knn(d, k=2, checks=32, cores=1), 2)
-        t_linN = timeit(lambda d: lin.knn(d, k=2, checks=32, cores=cores), 6)
-        t_kdN = timeit(lambda d: kd.knn(d, k=2, checks=32, cores=cores), 20)
+        for c in counts:
+            t_kd[c] = timeit(lambda d: kd.knn(d, k=2, checks=32, cores=c), 10 if c == 1 else 5)
+        for c in (1, 8, 32, cores):
+            if c <= cores:
+                t_lin[c] = timeit(lambda d: lin.knn(d, k=2, checks=32, cores=c), 1 if c == 1 else 3)
         kind = "reference"
     else:
-        t_kd1 = t_kdN = None
-        t_lin1 = t_linear_port
+        t_lin[1] = t_linear_port
         t0 = time.perf_counter()
         O.knn2_linear(vocab, frames_np[0], threads=cores)
-        t_linN = time.perf_counter() - t0
+        t_lin[cores] = time.perf_counter() - t0
         kind = "port"
     variants = {}
-    if t_kd1 is not None:
-        variants["i_kdtree_1core"] = {"value": rate(t_kd1), "knn_ms": 1e3 * t_kd1, "cores": 1}
-        variants["iii_kdtree_all_cores"] = {"value": rate(t_kdN), "knn_ms": 1e3 * t_kdN, "cores": cores}
-    variants["ii_linear_1core"] = {"value": rate(t_lin1), "knn_ms": 1e3 * t_lin1, "cores": 1}
-    variants["iii_linear_all_cores"] = {"value": rate(t_linN), "knn_ms": 1e3 * t_linN, "cores": cores}
+    if t_kd:
+        cb = min(t_kd, key=t_kd.get)
+        variants["i_kdtree_1core"] = {"value": rate(t_kd[1]), "knn_ms": 1e3 * t_kd[1], "cores": 1}
+        variants["iii_kdtree_best_threads"] = {"value": rate(t_kd[cb]), "knn_ms": 1e3 * t_kd[cb], "cores": cb,
+                                               "knn_ms_by_threads": {str(c): 1e3 * t for c, t in t_kd.items()}}
+    lb = min(t_lin, key=t_lin.get)
+    variants["ii_linear_1core"] = {"value": rate(t_lin[1]), "knn_ms": 1e3 * t_lin[1], "cores": 1}
+    variants["iii_linear_best_threads"] = {"value": rate(t_lin[lb]), "knn_ms": 1e3 * t_lin[lb], "cores": lb,
+                                           "knn_ms_by_threads": {str(c): 1e3 * t for c, t in t_lin.items()}}
+    if words is not None and frame_words is not None:
+        ft = flat_tfidf_ms(words, frame_words, n_sig, [c for c in (1, 8, 32, cores) if c <= cores])
+        fb = min(ft, key=ft.get)
+        t_knn_best = min(list(t_kd.values()) + list(t_lin.values()))
+        variants["iv_best_knn_flat_tfidf"] = {"value": rate(t_knn_best, 1e-3 * ft[fb]), "knn_ms": 1e3 * t_knn_best, "tfidf_ms": ft[fb], "tfidf_threads": fb,
+                                              "tfidf_ms_by_threads": {str(c): t for c, t in ft.items()},
+                                              "note": "not the reference's algorithm: flat word-major postings + OpenMP instead of std::map per word"}
     head = variants.get("i_kdtree_1core", variants["ii_linear_1core"])
     out = {"value": head["value"], "unit": "candidates/s", "cores": 1, "kind": kind,
            "sample": "2-NN of %d-descriptor frames over the full 49k vocabulary with the reference's own rtflann (%s) + restated std::map "
-                     "Memory::computeLikelihood over the full %d-signature memory (%.0f ms/frame, 3 frames); every variant below uses the "
-                     "same TF-IDF time" % (Q, "kd-tree 4 trees / 32 checks" if t_kd1 is not None else "exact linear port", n_sig, 1e3 * t_lik_full),
+                     "Memory::computeLikelihood over the full %d-signature memory (%.0f ms/frame, 3 frames); variants i-iii use the "
+                     "same TF-IDF time, iv a flat threaded one" % (Q, "kd-tree 4 trees / 32 checks" if t_kd else "exact linear port", n_sig, 1e3 * t_lik_full),
            "tfidf_ms": 1e3 * t_lik_full, "variants": variants,
            "best_cpu_value": max(v["value"] for v in variants.values())}
     return out
@@ -472,53 +559,113 @@ def with_update_ms(torch, eng, stepper, steps=256, remove_every=8, rebuild_every
 
 # ----------------------------------------------------------------------------------------------------------------- ORB stream
 def run_orb_stream(args):
-    """BASELINE.json config 3 as SURVEY.md 8d specifies it: 2 000 frames of 500 ORB descriptors against an initially EMPTY
-    incremental dictionary (NNDR 0.8), every frame also forgetting frame t - 1000, VWDictionary::update() inside the step
-    (append of the previous frame's new words, removal of unreferenced words + rebuild), TF-IDF against the working memory.
-    Runs through the C++ host mirror of the reference interface (MemoryHip over the C-ABI, host pointers); the first frames are
-    checked id for id against the oracle."""
+    """BASELINE.json config 3 as SURVEY.md 8d specifies it: 2 000 frames of 500 ORB descriptors against an initially EMPTY incremental
+    dictionary (NNDR 0.8) grown to ~200k words, every frame also removing the references of frame t - 1000, TF-IDF against the working
+    memory.  Device-pointer path: lcd_frame_dev on a plain handle (the exact Hamming scan has no matrix-core stage to pipeline behind),
+    VWDictionary::update()'s append on the device (append_new_words), descriptors resident in HBM.  The first frames are checked word
+    for word against the oracle; the Hamming scan's HIP-event time at the final vocabulary gives the roofline (integer VALU:
+    SURVEY.md 8d Q2 counts 8 xor + 8 bit-count-adds per descriptor pair); the CPU baseline is the reference's rtflann Hamming scan
+    (exact linear, the strategy the oracle pins) over the final vocabulary + the restated TF-IDF, on a bounded sample."""
     import torch
+    import rtabmap_amd
     from rtabmap_amd import synth
-    from rtabmap_amd.vwdictionary import MemoryHip
     import oracle as O
-    n_frames, q, W, n_check = args.steps if args.steps != 200 else 2000, 500, 1000, 60
+    n_frames, q, W, n_check = (args.steps if args.steps != 200 else 2000), 500, 1000, 60
     base = synth.vocab_orb(200000)
-    frames = [synth.queries_orb(base, q, seed=501 + t, frac_known=0.55, flip=0.04) for t in range(64)]
-    h = MemoryHip(nndr=NNDR, new_words_compared_together=True)
+    # Queries-ORB of SURVEY.md 8d, a fresh draw per frame: 90 % noisy copies (each bit flipped w.p. 0.1) of rows of the hidden 200k-row
+    # Vocab-ORB -- they come back in later frames and keep their words alive --, 10 % uniform random descriptors: words that die when their
+    # frame leaves the working memory (the churn cleanUnusedWords is there for).  The dictionary settles near 200k words.
+    frames = [synth.queries_orb(base, q, seed=501 + t, frac_known=0.9, flip=0.1) for t in range(n_frames)]
+    d_frames = torch.from_numpy(np.stack(frames)).cuda()                                        # 2 000 x 16 KB resident in HBM
+    stream = torch.cuda.Stream()
+    eng = rtabmap_amd.Engine("u8", 32, vocab_capacity=262144, sig_capacity=n_frames + 64, stream=stream.cuda_stream)
+    cap = n_frames + 64
+    d_words = torch.zeros((n_frames, q), dtype=torch.int32, device="cuda")
+    d_like = torch.zeros(cap, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    base_ptr, words_ptr = d_frames.data_ptr(), d_words.data_ptr()
+    a = eng.frame_args(q=q, flags=3, nndr_ratio=NNDR, d_likelihood=d_like.data_ptr(), likelihood_capacity=cap, append_new_words=1)
+    n_prof = 40
+
+    def run(t0, t1):
+        for t in range(t0, t1):
+            a.d_descriptors = base_ptr + t * q * 32
+            a.d_word_ids = words_ptr + t * q * 4
+            a.sig_id = t + 1
+            a.first_new_word_id = 1 + t * q                      # an upper bound per frame: nothing is read back (ids only have to ascend)
+            a.N = float(min(t + 1, W))
+            eng.frame_dev_args(a)
+            if t + 1 > W:
+                eng.sig_remove(t + 1 - W)
+            if t % clean_every == clean_every - 1 and t + 1 > W:
+                # Memory::cleanUnusedWords from the device's reference counts (the reference runs it before every frame; here every
+                # `clean_every` frames: it completes the owed work and reads the removed rows back); compaction when a quarter is dead
+                eng.vocab_remove_unused()
+                rows_now, live_now = eng.vocab_count()
+                if rows_now - live_now > rows_now // 4:
+                    eng.vocab_rebuild()
+    clean_every = 25
+    t_start = time.perf_counter()
+    run(0, n_frames - n_prof)
+    eng.synchronize()
+    eng.profile_begin(n_prof)                                    # HIP events around the scan kernel of the last frames (largest vocabulary)
+    run(n_frames - n_prof, n_frames)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t_start
+    scan_ms, scan_n, scan_name = eng.profile_read()
+    rows, live = eng.vocab_count()
+    got = d_words.cpu().numpy()
+    # ---- parity: the first frames against the oracle (it assigns consecutive ids: compare the canonical form -- every word replaced by
+    # the position of its first occurrence in the stream)
     o = O.OracleMemory(strategy=O.kNNBruteForce, nndr=NNDR, new_words_compared_together=True)
-    ids_equal = True
-    t_upd = t_lik = t_fgt = 0.0
-    for t in range(n_frames):
-        rng = np.random.default_rng(t)
-        desc = frames[t % 64] ^ np.packbits(rng.random((q, 256)) < 0.01, axis=1)        # every frame differs a little
-        t1 = time.perf_counter()
-        sid, ids = h.update(desc)
-        t2 = time.perf_counter()
-        live = np.arange(max(1, sid - W + 1), sid + 1, dtype=np.int32)
-        h.compute_likelihood(np.array(ids, np.int32), live)
-        t3 = time.perf_counter()
-        t_upd += t2 - t1
-        t_lik += t3 - t2
-        if t < n_check:
-            so, ido = o.update(desc)
-            ids_equal &= (so == sid and ido == ids)
-            if so > W:
-                o.forget(so - W)
-        if sid > W:
-            t4 = time.perf_counter()
-            h.forget(sid - W)
-            t_fgt += time.perf_counter() - t4
-    wall = t_upd + t_lik + t_fgt                          # the engine-side step: update() + addNewWords, computeLikelihood, forget
+    canon_o, canon_h, first_o, first_h, exp_lists = [], [], {}, {}, []
+    for t in range(min(n_check, n_frames)):
+        so, ido = o.update(frames[t])
+        exp_lists.append(ido)
+        ids_h = np.where(got[t] < 0, 1 + t * q - got[t] - 1, got[t]).tolist()
+        for k, (wo, wh) in enumerate(zip(ido, ids_h)):
+            canon_o.append(first_o.setdefault(wo, len(first_o)))
+            canon_h.append(first_h.setdefault(wh, len(first_h)))
+    ids_equal = canon_o == canon_h
+    # ---- CPU baseline on a bounded sample: the reference's rtflann Hamming scan over the FINAL vocabulary, 1 core, + the restated TF-IDF
+    vr, _ = eng.vocab_read(0, rows)
+    if O.have_ref():
+        lin = O.RefIndex(vr, algo=O.ALGO_LINEAR)
+        knn = lambda d: lin.knn(d, k=2, checks=32, cores=1)       # noqa: E731
+    else:
+        knn = lambda d: O.knn2_linear(vr, d)                       # noqa: E731
+    t1 = time.perf_counter()
+    for t in range(2):
+        knn(frames[n_frames - 1 - t])
+    t_knn = (time.perf_counter() - t1) / 2
+    live_o = np.array(o.signature_ids(), np.int32)
+    t2 = time.perf_counter()
+    for ido in exp_lists[-3:]:
+        o.compute_likelihood(np.array(ido, np.int32), live_o)
+    t_lik = (time.perf_counter() - t2) / 3 * (min(W, n_frames) / max(len(live_o), 1))   # scaled to the full working memory
+    cand = min(W, n_frames)
+    pairs = float(q) * rows
+    lane_ops = pairs * 16.0                                       # 8 x (32-bit xor + 32-bit bit-count-add) per pair (SURVEY.md 8d Q2)
+    achieved = lane_ops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+    PEAK_INT = 39.3                                               # T lane-ops/s: 256 CUs x 64 lanes x 2.4 GHz (SURVEY.md 8d)
     out = {"metric": "loop-closure candidates/sec (ORB 256-bit, incremental dictionary from empty, W=1000)", "unit": "candidates/s",
-           "value": n_frames * min(W, n_frames) / wall, "n_gpus": 1, "steps": n_frames, "warmup": 0, "ms_per_step": 1e3 * wall / n_frames,
+           "value": n_frames * cand / wall, "n_gpus": 1, "steps": n_frames, "warmup": 0, "ms_per_step": 1e3 * wall / n_frames,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": {"workload": "config 3: %d ORB frames x %d descriptors, incremental dictionary grown to %d words, update() in the step, "
-                                  "W=%d retirement, host-pointer path through the C++ mirror of VWDictionary/Memory" % (n_frames, q, h.vwd.visual_words, W),
-                      "update_ms_per_frame": 1e3 * t_upd / n_frames, "likelihood_ms_per_frame": 1e3 * t_lik / n_frames,
-                      "dictionary_words": h.vwd.visual_words},
-           "parity": {"frames_checked": n_check, "word_ids_equal": bool(ids_equal)}}
+           "config": {"workload": "config 3: %d ORB frames x %d descriptors, incremental dictionary grown from empty to %d words (%d rows), "
+                                  "update() appends on the device, W=%d retirement, device-pointer path (lcd_frame_dev, plain handle)" % (n_frames, q, live, rows, W),
+                      "dictionary_words": int(live), "frames_per_s": n_frames / wall},
+           "roofline": {"bound": "valu-int", "achieved": achieved, "peak": PEAK_INT, "unit": "T lane-ops/s", "frac": achieved / PEAK_INT, "traffic": None,
+                        "kernel": scan_name, "ms": scan_ms, "samples": scan_n, "rows_scanned": int(rows),
+                        "algorithmic": "%d x %d descriptor pairs x 16 lane-ops (8 x (xor + bit-count-add))" % (q, rows),
+                        "algorithmic_gbps": (rows * 32.0 + q * 32.0) / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0},
+           "cpu_baseline": {"value": cand / (t_knn + t_lik), "unit": "candidates/s", "cores": 1, "kind": "reference" if O.have_ref() else "port",
+                            "sample": "2 frames x exact Hamming 2-NN over the final %d-row vocabulary (%.0f ms/frame) + restated std::map TF-IDF "
+                                      "scaled to %d signatures (%.1f ms/frame)" % (rows, 1e3 * t_knn, cand, 1e3 * t_lik)},
+           "parity": {"frames_checked": min(n_check, n_frames), "word_ids_equal": bool(ids_equal),
+                      "path": "lcd_frame_dev(u8, append_new_words) vs oracle Memory::update, canonical word numbering"}}
     print(json.dumps(out), flush=True)
-    h.close()
+    eng.close()
 
 
 # ----------------------------------------------------------------------------------------------------------------- main
@@ -627,7 +774,8 @@ def main():
             eng.set_option("score_block", args.score_block)
         build_s = load_engine(eng, vocab, words)
         log("[bench] rank %d: %d signatures bulk-loaded in %.2fs" % (rank, n_sig, build_s))
-        step = Stepper(eng, torch, d_frames, n_sig, cap)
+        log_frames = (args.warmup + args.steps) if (world == 1 and not args.no_cpu_baseline and args.warmup + args.steps <= 4096) else 0
+        step = Stepper(eng, torch, d_frames, n_sig, cap, log_frames=log_frames)
         res = timed_loop(torch, dist, world, stream, step, args.steps, args.warmup, profile_eng=eng, eng=eng, per_step_events=False)
         roof_knn, roof_score = rooflines(eng, N_WORDS, n_sig, False)
         st = eng.stats()                                  # (drains the engine's thread)
@@ -752,7 +900,11 @@ def main():
             m = build_oracle(vocab, words)
             par, t_lin_port, t_lik = parity_block(torch, vocab, words, frames_np, m)
             out["parity"] = par
-            out["cpu_baseline"] = cpu_baselines(vocab, frames_np, t_lin_port, t_lik, n_sig)
+            if step.first_new_log:
+                m.close()
+                m = build_oracle(vocab, words)                       # a fresh memory: the replay starts where the timed engine started
+                out["parity"]["timed_engine"] = timed_engine_parity(m, step, frames_np, like, n_sig)
+            out["cpu_baseline"] = cpu_baselines(vocab, frames_np, t_lin_port, t_lik, n_sig, words=words, frame_words=words[17])
             out["cpu_baseline"]["gpu_over_best_cpu"] = value / out["cpu_baseline"]["best_cpu_value"]
     if rank == 0:
         print(json.dumps(out), flush=True)

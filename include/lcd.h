@@ -109,6 +109,11 @@ int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word
  * the words cease to exist.  As in the reference, only words without references are removed (its callers pass getUnusedWords(),
  * Memory.cpp:2867,6906); the postings key of a removed word is recycled once the device has confirmed that. */
 int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n);
+/* Memory::cleanUnusedWords (Memory.cpp:6899-6920: removeWords(getUnusedWords()), run by preUpdate before every frame of an incremental
+ * dictionary) from the DEVICE's reference counts: every vocabulary row whose word no signature references is removed as by
+ * lcd_vocab_remove.  For callers that keep no host copy of the references (device-resident frame streams).  out_word_ids (may be NULL
+ * with capacity 0) receives up to `capacity` of the removed ids in ascending row order, *out_n their number.  Synchronises. */
+int lcd_vocab_remove_unused(lcd_engine* h, int32_t* out_word_ids, int capacity, int32_t* out_n);
 /* full-rebuild branch :610-690: drop tombstones and reorder the live rows by ascending word id, on the device */
 int lcd_vocab_rebuild(lcd_engine* h);
 /* rows = rows in the matrix incl. tombstones, live = searchable rows */

@@ -40,6 +40,9 @@
 #include <set>
 #include <string>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 namespace orc {
 
@@ -554,6 +557,7 @@ struct Signature {
     std::multimap<int, int> words;   // <word id, keypoint index> (Signature.h)
 };
 
+static bool g_log10_double = false;          // see computeLikelihood
 struct Memory {
     VWDictionary vwd;
     std::map<int, Signature*> signatures;     // STM + WM, what Memory::getSignatures() returns
@@ -641,7 +645,12 @@ struct Memory {
                     const std::map<int, int>& refs = w->second->references;
                     nw = (float)refs.size();
                     if (nw) {
-                        logNnw = log10f(N / nw);   // log10 of a float ratio, stored in float (:2266)
+                        // Memory.cpp:2266 writes the unqualified `log10(N/nw)` on floats.  Memory.cpp includes <cmath> through its
+                        // headers; with libstdc++ >= 6 / libc++ the global namespace then holds the float overload (the <math.h>
+                        // wrapper does `using std::log10`) and the call is log10f; an older library only declares ::log10(double) and
+                        // the ratio is promoted, the result rounded back to float on assignment.  g_log10_double selects the second
+                        // reading for tests/test_oracle_golden.py, which checks that both stay within the parity bound of each other.
+                        logNnw = g_log10_double ? (float)log10((double)(N / nw)) : log10f(N / nw);
                         if (logNnw) {
                             for (std::map<int, int>::const_iterator j = refs.begin(); j != refs.end(); ++j) {
                                 std::map<int, float>::iterator it = likelihood.find(j->first);
@@ -1209,6 +1218,7 @@ int orc_mem_compute_likelihood(void* h, const int* words, int nwords, const int*
     return n;
 }
 void orc_adjust_likelihood(float* L, int n, float ratio) { adjustLikelihood(L, n, ratio); }
+void orc_set_log10_double(int on) { g_log10_double = on != 0; }
 
 // ---- BayesFilter
 void* orc_bayes_create(const double* lc, int n, float virtualPlacePrior) {
@@ -1235,6 +1245,41 @@ void orc_bayes_hypothesis(const int* ids, const float* post, int m, int* out_id,
     for (int i = m - 1; i >= 0; --i) if (ids[i] > 0 && post[i] > v) { best = ids[i]; v = post[i]; }
     *out_id = best;
     *out_value = m > 0 ? 1 - post[0] : 0.0f;
+}
+
+// ---- the "generous" CPU baseline of bench.py ONLY (never a parity reference): Memory::computeLikelihood's TF-IDF sum over FLAT
+// postings (word-major CSR: the postings of word k are [word_off[k], word_off[k + 1]) of post_sig / post_cnt) instead of the
+// reference's std::map per word, with OpenMP over the query's words and one partial vector per thread -- what a CPU implementation
+// that gave up the reference's containers could do.  Same arithmetic as Memory.cpp:2264-2277 per posting; the summation order
+// differs (partial sums per thread).
+void orc_flat_tfidf(const long long* word_off, const int* post_sig, const int* post_cnt, const int* ni, int n_sig, int n_words, float N, int threads,
+                    float* out) {
+    if (threads < 1) threads = 1;
+    std::vector<float> part((size_t)threads * (size_t)n_sig, 0.0f);
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4)
+    for (int k = 0; k < n_words; ++k) {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        float* acc = part.data() + (size_t)tid * (size_t)n_sig;
+        const long long b = word_off[k], e = word_off[k + 1];
+        const float nw = (float)(e - b);
+        if (!(nw > 0.0f)) continue;
+        const float logNnw = log10f(N / nw);
+        if (logNnw == 0.0f) continue;
+        for (long long p = b; p < e; ++p) {
+            const int s = post_sig[p];
+            const float nis = (float)ni[s];
+            if (nis != 0.0f) acc[s] += ((float)post_cnt[p] * logNnw) / nis;
+        }
+    }
+#pragma omp parallel for num_threads(threads)
+    for (int s = 0; s < n_sig; ++s) {
+        float v = 0.0f;
+        for (int t = 0; t < threads; ++t) v += part[(size_t)t * (size_t)n_sig + s];
+        out[s] = v;
+    }
 }
 
 }  // extern "C"

@@ -159,6 +159,25 @@ def dist_matrix(a, b, metric=None):
     return out
 
 
+def flat_tfidf(word_off, post_sig, post_cnt, ni, N, threads=1):
+    """bench.py's generous CPU baseline (NOT a parity reference): TF-IDF over flat word-major postings, OpenMP over the words"""
+    word_off = np.ascontiguousarray(word_off, np.int64)
+    post_sig = np.ascontiguousarray(post_sig, np.int32)
+    post_cnt = np.ascontiguousarray(post_cnt, np.int32)
+    ni = np.ascontiguousarray(ni, np.int32)
+    out = np.zeros(ni.shape[0], np.float32)
+    L = lib()
+    L.orc_flat_tfidf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    L.orc_flat_tfidf.restype = None
+    L.orc_flat_tfidf(_ptr(word_off), _ptr(post_sig), _ptr(post_cnt), _ptr(ni), ni.shape[0], word_off.shape[0] - 1, float(N), int(threads), _ptr(out))
+    return out
+
+
+def set_log10_double(on):
+    """Memory.cpp:2266 `log10(N/nw)` read as the double overload (older standard libraries) instead of log10f -- see lcd_oracle.cpp"""
+    lib().orc_set_log10_double(1 if on else 0)
+
+
 def adjust_likelihood(L, ratio=0.0):
     L = np.ascontiguousarray(L, dtype=np.float32).copy()
     lib().orc_adjust_likelihood(_ptr(L), L.shape[0], ratio)

@@ -173,13 +173,13 @@ int ensure_append_capacity(lcd_engine* h, int64_t rows) {
         LCD_HIP(h, dreserve(h, h->vocab, (size_t)rows * h->row_bytes, (size_t)keep * h->row_bytes));
         LCD_HIP(h, dreserve(h, h->row_id, (size_t)rows * 4, (size_t)keep * 4));
         LCD_HIP(h, dreserve(h, h->row_wslot, (size_t)rows * 4, (size_t)keep * 4));
-        LCD_HIP(h, dreserve(h, h->row_norm, ((size_t)rows + 1) * 8, ((size_t)keep + 1) * 8));
-        LCD_HIP(h, dreserve(h, h->vocab_bf, (size_t)rows * 256, (size_t)keep * 256));
+        if (h->dtype == LCD_F32) LCD_HIP(h, dreserve(h, h->row_norm, ((size_t)rows + 1) * 8, ((size_t)keep + 1) * 8));
+        if (knn_mfma_supported(h->dtype, h->kdim)) LCD_HIP(h, dreserve(h, h->vocab_bf, (size_t)rows * 256, (size_t)keep * 256));
         h->tail_filled_rows = std::min(h->tail_filled_rows, keep);
     }
     const int64_t cap = vocab_cap_rows(h);
     const int64_t first = std::max(h->tail_filled_rows, keep);
-    if (first < cap) {
+    if (first < cap && knn_mfma_supported(h->dtype, h->kdim)) {
         LCD_HIP(h, launch_vocab_tail(h->row_norm.as<float>(), h->vocab_bf.p, first, cap - first, h->stream));
         h->tail_filled_rows = cap;
     }
@@ -242,8 +242,13 @@ int lcd_engine::reconcile() {
     if (unreconciled.empty()) return LCD_OK;
     { int rc = sync_all(); if (rc) return rc; }
     std::vector<int32_t> log((size_t)VLOG);
-    hipError_t e = hipMemcpy(log.data(), d_vcnt.as<int32_t>() + 16, (size_t)VLOG * 4, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return hip_fail(e, "hipMemcpy(append log)");
+    {   // the log is a ring: the entries of the frames to catch up with form at most two stretches of it
+        const size_t first = (size_t)(unreconciled.front().seq % VLOG), n = unreconciled.size();
+        const size_t n1 = std::min(n, (size_t)VLOG - first);
+        hipError_t e = hipMemcpy(log.data() + first, d_vcnt.as<int32_t>() + 16 + first, n1 * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && n > n1) e = hipMemcpy(log.data(), d_vcnt.as<int32_t>() + 16, std::min(n - n1, (size_t)VLOG) * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpy(append log)");
+    }
     for (const DevAppend& a : unreconciled) {
         if (!a.enabled) continue;
         const int n = log[(size_t)(a.seq % VLOG)];
@@ -462,12 +467,47 @@ int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word
     LCD_CATCH(h)
 }
 
+static int vocab_remove_ids(lcd_engine* h, const int32_t* word_ids, int n);
+
 int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n) {
     LCD_TRY
     LCD_CHECK_HANDLE(h);
     LCD_DEV(h);
     if (n < 0 || (n > 0 && !word_ids)) return h->fail(LCD_ERR_INVALID, "lcd_vocab_remove: null input");
     if (n == 0) return LCD_OK;
+    return vocab_remove_ids(h, word_ids, n);
+    LCD_CATCH(h)
+}
+
+int lcd_vocab_remove_unused(lcd_engine* h, int32_t* out_word_ids, int capacity, int32_t* out_n) {
+    LCD_TRY
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);
+    if (capacity < 0 || (capacity > 0 && !out_word_ids)) return h->fail(LCD_ERR_INVALID, "lcd_vocab_remove_unused: bad output buffer");
+    if (out_n) *out_n = 0;
+    if (h->n_rows == 0) return LCD_OK;
+    LCD_HIP(h, h->tfidf.flush_retire());                             // retirements ride with the next frame otherwise: nw would be stale
+    LCD_HIP(h, dreserve(h, h->d_tmp_i32, ((size_t)h->n_rows + 16) * 4));
+    int32_t* d_cnt = h->d_tmp_i32.as<int32_t>();
+    LCD_HIP(h, hipMemsetAsync(d_cnt, 0, 4, h->stream));
+    LCD_HIP(h, launch_unused_rows(h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), h->tfidf.nw.as<uint32_t>(), (int)h->n_rows, d_cnt + 16, d_cnt,
+                                  (int)h->n_rows, h->stream));
+    int32_t n = 0;
+    { int rc = download(h, &n, d_cnt, 4, h->h_out2); if (rc) return rc; }
+    if (n <= 0) return LCD_OK;
+    std::vector<int32_t> rows((size_t)n);
+    { int rc = download(h, rows.data(), d_cnt + 16, (size_t)n * 4, h->h_out); if (rc) return rc; }
+    std::sort(rows.begin(), rows.end());
+    std::vector<int32_t> ids((size_t)n);
+    for (int i = 0; i < n; ++i) ids[(size_t)i] = h->h_row_key[(size_t)rows[(size_t)i]];
+    { int rc = vocab_remove_ids(h, ids.data(), n); if (rc) return rc; }
+    if (out_n) *out_n = n;
+    for (int i = 0; i < n && i < capacity; ++i) out_word_ids[i] = ids[(size_t)i];
+    return LCD_OK;
+    LCD_CATCH(h)
+}
+
+static int vocab_remove_ids(lcd_engine* h, const int32_t* word_ids, int n) {
     { int rc = h->sync_all(); if (rc) return rc; }
     std::vector<int32_t> rows;
     rows.reserve(n);
@@ -504,7 +544,6 @@ int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n) {
     // removeWords: the words are gone; their postings keys come back once the device has found them unreferenced
     LCD_HIP(h, h->tfidf.release_words(word_ids, n));
     return LCD_OK;
-    LCD_CATCH(h)
 }
 
 int lcd_vocab_rebuild(lcd_engine* h) {
@@ -974,8 +1013,10 @@ static int frame_score_s(lcd_engine* h, const lcd_frame_args& a) {
     return hypothesis_stage(h, a);
 }
 
+// (any descriptor type: rows that are not 64 floats are copied without the matrix-core filter's tables -- such handles are never pipelined)
 static bool frame_appends(const lcd_engine* h, const lcd_frame_args& a) {
-    return a.append_new_words != 0 && a.first_new_word_id > 0 && (a.flags & LCD_Q_INCREMENTAL) != 0 && knn_mfma_supported(h->dtype, h->kdim);
+    return a.append_new_words != 0 && a.first_new_word_id > 0 && (a.flags & LCD_Q_INCREMENTAL) != 0 &&
+           h->row_bytes == h->dim * (h->dtype == LCD_F32 ? 4 : 1);     // (rows are stored as they arrive: no padding to add on the device)
 }
 
 static int reserve_frame_words(lcd_engine* h, const lcd_frame_args& a, WsRuns* runs, bool may_flush = true) {

@@ -146,6 +146,9 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
 // Row gather used by lcd_vocab_rebuild: dst[i] = src[perm[i]] (rows of row_bytes bytes, multiple of 4), ids likewise.
 hipError_t launch_gather_rows(const void* src, const int32_t* src_id, const int32_t* perm, int n, int row_bytes,
                               void* dst, int32_t* dst_id, hipStream_t s);
+// the live rows whose word has no reference (nw[row_wslot[r]] == 0): out_rows[0 .. min(*out_count, cap)), any order
+hipError_t launch_unused_rows(const int32_t* row_id, const int32_t* row_wslot, const uint32_t* nw, int n_rows, int32_t* out_rows, int32_t* out_count,
+                              int cap, hipStream_t s);
 // row_id[rows[i]] = 0
 hipError_t launch_tombstone(int32_t* row_id, const int32_t* rows, int n, hipStream_t s);
 

@@ -125,6 +125,17 @@ __global__ void gather_rows_kernel(const uint32_t* __restrict__ src, const int32
         if (c == 0) dst_id[r] = src_id[sr];
     }
 }
+// Memory::cleanUnusedWords' selection (VWDictionary::getUnusedWords: words without a reference) over the device's own reference counts:
+// the live rows whose word nobody references are listed (any order; the host sorts)
+__global__ void unused_rows_kernel(const int32_t* __restrict__ row_id, const int32_t* __restrict__ row_wslot, const uint32_t* __restrict__ nw,
+                                   int n_rows, int32_t* __restrict__ out_rows, int32_t* __restrict__ out_count, int cap) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows || row_id[r] == 0) return;
+    const int32_t ws = row_wslot[r];
+    if (ws >= 0 && nw[ws] != 0u) return;
+    const int pos = atomicAdd(out_count, 1);
+    if (pos < cap) out_rows[pos] = r;
+}
 __global__ void tombstone_kernel(int32_t* __restrict__ row_id, const int32_t* __restrict__ rows, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) row_id[rows[i]] = 0;
@@ -178,6 +189,12 @@ hipError_t launch_gather_rows(const void* src, const int32_t* src_id, const int3
     return hipGetLastError();
 }
 
+hipError_t launch_unused_rows(const int32_t* row_id, const int32_t* row_wslot, const uint32_t* nw, int n_rows, int32_t* out_rows, int32_t* out_count,
+                              int cap, hipStream_t s) {
+    if (n_rows <= 0) return hipSuccess;
+    unused_rows_kernel<<<(n_rows + 255) / 256, 256, 0, s>>>(row_id, row_wslot, nw, n_rows, out_rows, out_count, cap);
+    return hipGetLastError();
+}
 hipError_t launch_tombstone(int32_t* row_id, const int32_t* rows, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     tombstone_kernel<<<(n + 255) / 256, 256, 0, s>>>(row_id, rows, n);

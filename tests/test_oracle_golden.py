@@ -98,3 +98,38 @@ def test_adjust_likelihood_formula(oracle):
     # all zeros -> every entry 1, virtual place 2 (TestAdjustLikelihood.m first case)
     z = oracle.adjust_likelihood(np.zeros(5, np.float32))
     assert z.tolist() == [2.0, 1.0, 1.0, 1.0, 1.0]
+
+
+def test_log10_overload_does_not_matter_at_the_parity_bound(oracle, golden2010):
+    """Memory.cpp:2266 calls the unqualified log10 on a float ratio: log10f with a current standard library (the float overload
+    is in the global namespace), log10(double) rounded to float with an old one.  Both readings of the restated computeLikelihood
+    reproduce the reference's golden vector, and on a 3 000-signature Zipf memory they differ by far less than the 1e-4 relative
+    bound the device is held to -- so the choice (log10f, also what the device computes) cannot decide a parity test."""
+    from rtabmap_amd import synth
+    mem2, _ = _updated(golden2010)
+    m = _build_memory(oracle, mem2)
+    sign = mem2[-1]
+    words = sign[1:][sign[1:] != 0].astype(np.int32)
+    ids = mem2[:, 0].astype(np.int32)
+    try:
+        _, Lf = m.compute_likelihood(words, ids)
+        oracle.set_log10_double(True)
+        _, Ld = m.compute_likelihood(words, ids)
+        assert np.floor(Ld * 1000).astype(int).tolist() == np.floor(Lf * 1000).astype(int).tolist()
+        np.testing.assert_allclose(Ld, Lf, rtol=2e-6, atol=1e-9)
+        oracle.set_log10_double(False)
+        big = oracle.OracleMemory(strategy=oracle.kNNBruteForce)
+        vocab = synth.vocab_surf(2000, seed=3)
+        for w in range(1, 2001):
+            big.vwd.add_word(w, vocab[w - 1])
+        big.vwd.update()
+        sw = synth.zipf_words(3000, 200, 2000, seed=4)
+        big.add_signatures_bulk(sw)
+        all_ids = np.arange(1, 3001, dtype=np.int32)
+        _, a = big.compute_likelihood(sw[5], all_ids)
+        oracle.set_log10_double(True)
+        _, b = big.compute_likelihood(sw[5], all_ids)
+        rel = np.abs(a - b) / np.maximum(np.abs(a), 1e-7)
+        assert rel.max() < 5e-6 and int(np.argmax(a)) == int(np.argmax(b))
+    finally:
+        oracle.set_log10_double(False)
