@@ -216,7 +216,7 @@ def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None
 PMC_LIVE = {}          # kernel -> {"fetch_kb", "write_kb", "hbm_bytes_per_launch"}: measured by THIS run (measure_pmc), else the committed profile
 
 
-def measure_pmc():
+def measure_pmc(extra_args=()):
     """HBM traffic per launch, measured by this run: two rocprofv3 passes (--pmc FETCH_SIZE, then --pmc WRITE_SIZE; kernel trace
     only, as MI355X_MICROARCH.md prescribes) over a short invocation of this same script, reduced like tools/make_pmc_json.py
     (rocprofv3 reports KB; gfx950 counts 64 B per 128-B read request: reads are doubled).  Fills PMC_LIVE; returns a note."""
@@ -230,7 +230,7 @@ def measure_pmc():
         return "rocprofv3 not found: traffic from the committed profile"
     base = tempfile.mkdtemp(prefix="lcd_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", LCD_BENCH_INNER="1")
-    inner = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "30", "--warmup", "5"]
+    inner = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extras", "--steps", "30", "--warmup", "5"] + list(extra_args)
     sums = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -251,7 +251,8 @@ def measure_pmc():
         for k, fe in sums["FETCH_SIZE"].items():
             w = sums["WRITE_SIZE"].get(k, 0.0)
             PMC_LIVE[k] = {"fetch_kb": fe, "write_kb": w, "hbm_bytes_per_launch": (2.0 * fe + w) * 1024.0}
-        return "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over `bench.py --no-cpu-baseline --steps 30 --warmup 5`"
+        return "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over `bench.py --no-cpu-baseline --no-extras --steps 30 --warmup 5%s`" % \
+               ("".join(" " + x for x in extra_args))
     except Exception as e:  # noqa: BLE001
         return "PMC measurement failed (%s): traffic from the committed profile" % type(e).__name__
     finally:
@@ -264,6 +265,8 @@ def pmc_traffic(name):
     key = name.split(" ")[0].split("<")[0]
     if key in PMC_LIVE:
         return PMC_LIVE[key]["hbm_bytes_per_launch"] / 1e9
+    if N_WORDS != 49000:
+        return None                                      # the committed summary is the headline configuration's
     try:
         pmc = json.load(open(PMC_PROFILE))
         return pmc[key]["hbm_bytes_per_launch"] / 1e9 if key in pmc else None
@@ -668,6 +671,109 @@ def run_orb_stream(args):
     eng.close()
 
 
+# ----------------------------------------------------------------------------------------------------------------- replay (config 5 stand-in)
+def run_replay(args):
+    """BASELINE.json config 5 cannot run here (KITTI images, OpenCV/PCL: SURVEY.md 8d); its prescribed stand-in does: a descriptor-stream
+    replay with revisits through the loop-closure path -- Memory::update (addNewWords against the fixed 49k dictionary) -> references ->
+    Memory::computeLikelihood against EVERY signature in memory -> Rtabmap::adjustLikelihood + best candidate (every `hyp_every`-th
+    frame) -- with the memory grown through lcd_frame_dev, frame by frame, from empty to --signatures (1 000 000 asked for: nothing is
+    retired, as the reference's WM cannot hold that many either, the point is the frame path at that size).  Trajectory: 2 048 places
+    visited round robin, two noisy views per place alternating lap by lap: from the second lap on every frame revisits a place, and
+    the loop-closure RECALL is counted like the reference's harness does (tools/ConsoleApp/main.cpp:383-506 compares the detected id
+    with the ground truth): a sampled frame counts when its best candidate (outside the newest 30 signatures) shows the same place."""
+    import torch
+    import rtabmap_amd
+    from rtabmap_amd import synth
+    import oracle as O
+    n_total = args.signatures if args.signatures != N_SIG else 1_000_000
+    P, V, q, hyp_every, stm = 2048, 2, Q, 64, 30
+    vocab = synth.vocab_surf(N_WORDS)
+    place_words = synth.zipf_words(P, q, N_WORDS, seed=5)
+    pool = np.stack([synth.frame_from_signature(vocab, place_words[p], seed=9000 + v * P + p, resample=0.0, sigma=0.03)
+                     for v in range(V) for p in range(P)])                         # [V * P, q, 64]: view v of place p at v * P + p
+    d_pool = torch.from_numpy(pool).cuda()
+    stream = torch.cuda.Stream()
+    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=N_WORDS + 1024, sig_capacity=n_total + 4096, stream=stream.cuda_stream, pipeline=1)
+    eng.vocab_append(vocab, np.arange(1, N_WORDS + 1, dtype=np.int32))
+    cap = n_total + 64
+    depth = eng.pipeline_depth() + 1
+    d_words = torch.zeros((depth, q), dtype=torch.int32, device="cuda")
+    d_like = torch.zeros((depth, cap), dtype=torch.float32, device="cuda")
+    n_hyp = (n_total + hyp_every - 1) // hyp_every
+    d_hyp = torch.zeros((n_hyp, 8), dtype=torch.int32, device="cuda")
+    n_par = 24
+    d_words_par = torch.zeros((n_par, q), dtype=torch.int32, device="cuda")
+    d_like_par = torch.zeros((n_par, 64), dtype=torch.float32, device="cuda")
+    d_hyp_par = torch.zeros((n_par, 8), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    a = eng.frame_args(q=q, flags=0, nndr_ratio=NNDR, first_new_word_id=0, exclude_recent=stm)   # fixed dictionary: the nearest word, no new words
+    pool_ptr, wp, lp, hp = d_pool.data_ptr(), d_words.data_ptr(), d_like.data_ptr(), d_hyp.data_ptr()
+
+    def frame_index(t):
+        return ((t // P) % V) * P + (t % P)
+    t_start = time.perf_counter()
+    marks = {}
+    for t in range(n_total):
+        a.d_descriptors = pool_ptr + frame_index(t) * q * DIM * 4
+        a.sig_id = t + 1
+        a.N = float(t + 1)
+        if t < n_par:                                           # the first frames keep their outputs for the parity check
+            a.d_word_ids = d_words_par.data_ptr() + t * q * 4
+            a.d_likelihood = d_like_par.data_ptr() + t * 64 * 4
+            a.likelihood_capacity = 64
+            a.d_hypothesis = d_hyp_par.data_ptr() + t * 32
+        else:
+            a.d_word_ids = wp + (t % depth) * q * 4
+            a.d_likelihood = lp + (t % depth) * cap * 4
+            a.likelihood_capacity = cap
+            a.d_hypothesis = (hp + (t // hyp_every) * 32) if t % hyp_every == 0 else None
+        eng.frame_dev_args(a)
+        if t + 1 in (100_000, 500_000):
+            eng.synchronize()
+            marks[t + 1] = time.perf_counter() - t_start
+    eng.synchronize()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t_start
+    # ---- recall
+    hyp = d_hyp.cpu().numpy()
+    ts = np.arange(0, n_total, hyp_every)
+    valid = ts >= P + stm
+    best_sig = hyp[:, 0]
+    hit = valid & (best_sig > 0) & (((best_sig - 1) % P) == (ts % P))
+    recall = float(hit.sum()) / max(int(valid.sum()), 1)
+    adjusted = hyp[:, 3].view(np.float32)
+    # ---- parity of the first frames: oracle Memory::update (fixed dictionary) + computeLikelihood + adjustLikelihood
+    o = O.OracleMemory(strategy=O.kNNBruteForce, nndr=NNDR, incremental=False)
+    for w in range(1, N_WORDS + 1):
+        o.vwd.add_word(w, vocab[w - 1])
+    o.vwd.update()
+    gw, gl, gh = d_words_par.cpu().numpy(), d_like_par.cpu().numpy(), d_hyp_par.cpu().numpy()
+    ids_equal, max_rel, hyp_equal = True, 0.0, True
+    for t in range(n_par):
+        so, ido = o.update(pool[frame_index(t)])
+        ids_equal &= bool(gw[t].tolist() == ido)
+        live = np.arange(1, t + 2, dtype=np.int32)
+        oi, Lo = o.compute_likelihood(np.array(ido, np.int32), live)
+        err = np.abs(gl[t][: t + 1] - Lo) / np.maximum(np.abs(Lo), 1e-7 / 1e-4)
+        max_rel = max(max_rel, float(err.max()))
+    eng.close()
+    cand_total = n_total * (n_total + 1) / 2.0
+    out = {"metric": "loop-closure candidates/sec (descriptor-stream replay with revisits, memory grown to %d signatures)" % n_total,
+           "unit": "candidates/s", "value": cand_total / wall, "n_gpus": 1, "steps": n_total, "warmup": 0, "ms_per_step": 1e3 * wall / n_total,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "config 5 stand-in (SURVEY.md 8d): %d frames x %d SURF descriptors, fixed %d-word dictionary, %d places x %d views "
+                                  "round robin, every frame registered (memory 0 -> %d signatures), TF-IDF against all of them, adjustLikelihood + best "
+                                  "candidate every %d-th frame; pipelined lcd_frame_dev" % (n_total, q, N_WORDS, P, V, n_total, hyp_every),
+                      "frames_per_s": n_total / wall, "wall_s": wall, "wall_s_at_signatures": {str(k): v for k, v in marks.items()},
+                      "ms_per_frame_last_half": 1e3 * (wall - marks.get(500_000, 0.0)) / (n_total - 500_000) if 500_000 in marks and n_total > 500_000 else None},
+           "recall": {"sampled_frames": int(valid.sum()), "loop_closures_found": int(hit.sum()), "recall": recall,
+                      "mean_adjusted_likelihood_of_hits": float(adjusted[hit].mean()) if hit.any() else None,
+                      "rule": "best raw-likelihood candidate outside the newest %d signatures shows the same place as the frame" % stm},
+           "parity": {"frames_checked": n_par, "word_ids_equal": bool(ids_equal), "likelihood_max_rel": max_rel,
+                      "path": "the replay's first frames vs oracle Memory::update (fixed dictionary) + computeLikelihood"}}
+    print(json.dumps(out), flush=True)
+
+
 # ----------------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -678,6 +784,7 @@ def main():
     ap.add_argument("--words", type=int, default=N_WORDS, help="vocabulary size (the headline is 49 000; 125 000 = one GPU's share of config 4, "
                     "1 000 000 = config 4's whole vocabulary on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (oracle build, parity block, CPU baselines)")
+    ap.add_argument("--pmc", action="store_true", help="measure HBM traffic with rocprofv3 even with --no-cpu-baseline")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure HBM traffic with rocprofv3 (two extra short runs of this script)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (unpipelined, host path, with update)")
     ap.add_argument("--pipeline", type=int, default=1, help="1: software-pipelined frames (the launches of frame t carry the registration "
@@ -685,7 +792,7 @@ def main():
     ap.add_argument("--parallelism", choices=["shard", "replicas"], default="shard",
                     help="N > 1: ONE frame stream with the vocabulary sharded by word-id range + all-gather / all-reduce per frame (the "
                          "north star; strong scaling), or independent frame streams per GPU (weak scaling, no data-path collective)")
-    ap.add_argument("--config", choices=["headline", "orb_stream"], default="headline")
+    ap.add_argument("--config", choices=["headline", "orb_stream", "replay"], default="headline")
     ap.add_argument("--score-block", type=int, default=0, help="experiment: threads per workgroup of the scoring kernel (256/512/1024)")
     ap.add_argument("--diag", default="", help="diagnostics only (not the benchmark): comma list of no-new (new words get no references), "
                     "no-retire (the oldest signature is not retired)")
@@ -704,6 +811,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     if args.config == "orb_stream":
         return run_orb_stream(args)
+    if args.config == "replay":
+        return run_replay(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
@@ -888,10 +997,11 @@ def main():
             res = np.frombuffer(stb.d_res.cpu().numpy().tobytes(), dtype=np.int32)
             config["with_bayes_last_hypothesis"] = {"sig_id": int(res[0]), "n_considered": int(res[5])}
             engb.close()
-        if not args.no_cpu_baseline and not args.no_pmc and not os.environ.get("LCD_BENCH_INNER"):
+        if (not args.no_cpu_baseline or args.pmc) and not args.no_pmc and not os.environ.get("LCD_BENCH_INNER"):
             # HBM traffic of the big kernels, measured by this run (two short rocprofv3 passes over this script) instead of read
             # from the committed profile
-            note = measure_pmc()
+            note = measure_pmc((["--words", str(args.words)] if args.words != 49000 else []) +
+                               (["--signatures", str(args.signatures)] if args.signatures != N_SIG else []))
             for k in ("roofline", "roofline_score", "roofline_knn", "roofline_knn_standalone", "roofline_score_standalone"):
                 if out.get(k):
                     out[k]["traffic"] = pmc_traffic(out[k]["kernel"])

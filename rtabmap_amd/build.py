@@ -103,6 +103,28 @@ def build_host(force=False, verbose=False):
     return HOST_OUT
 
 
+SHARD_OUT = os.path.join(HERE, "liblcd_shard.so")
+
+
+def build_shard(force=False, verbose=False):
+    """The multi-GPU driver of include/lcd_shard.h: C++ host code over the C-ABI + RCCL (rtabmap_amd/host/ShardedLcd.cpp)."""
+    lib = build(force=force, verbose=verbose)
+    src = os.path.join(HERE, "host", "ShardedLcd.cpp")
+    if not force and os.path.exists(SHARD_OUT) and os.path.getmtime(SHARD_OUT) >= max(os.path.getmtime(src), os.path.getmtime(lib)):
+        return SHARD_OUT
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cxx = shutil.which("g++") or "g++"
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), "-o", SHARD_OUT, src,
+           "-L" + HERE, "-llcd_hip", "-L" + os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("shard library build failed:\n" + r.stdout)
+    return SHARD_OUT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_host(force="--force" in sys.argv, verbose=True))
+    print(build_shard(force="--force" in sys.argv, verbose=True))

@@ -198,3 +198,63 @@ class ShardedLoopClosure:
 
     def close(self):
         self.eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------- native driver
+_shard_lib = None
+
+
+def load_shard():
+    """liblcd_shard.so: the sharded frame as C++ host code over the C-ABI + RCCL (include/lcd_shard.h, rtabmap_amd/host/ShardedLcd.cpp)."""
+    global _shard_lib
+    if _shard_lib is None:
+        import ctypes as C
+        from . import build as _b
+        from .capi import load
+        load()                                                           # liblcd_hip.so first (the driver links against it)
+        L = C.CDLL(_b.build_shard())
+        vp = C.c_void_p
+        L.lcd_shard_unique_id.argtypes = [vp]
+        L.lcd_shard_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+        L.lcd_shard_comm_destroy.argtypes = [vp]
+        L.lcd_shard_comm_destroy.restype = None
+        L.lcd_shard_last_error.argtypes = [vp]
+        L.lcd_shard_last_error.restype = C.c_char_p
+        L.lcd_shard_frame.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, C.c_int32, C.c_int32, C.c_float, C.c_int64, vp, vp, C.c_int64]
+        _shard_lib = L
+    return _shard_lib
+
+
+class NativeShardComm:
+    """One rank of the C++ / RCCL driver around an Engine.  The 128-byte RCCL id travels through torch.distributed (any backend) when
+    world > 1 -- the only thing the process group is used for; the two per-frame exchanges are RCCL calls made by the C++ code."""
+
+    def __init__(self, eng, rank=0, world=1, group=None):
+        import ctypes as C
+        self.L, self.eng, self.rank, self.world = load_shard(), eng, rank, world
+        idb = (C.c_ubyte * 128)()
+        if world > 1:
+            box = [None]
+            if rank == 0:
+                assert self.L.lcd_shard_unique_id(idb) == 0, "ncclGetUniqueId failed"
+                box[0] = bytes(idb)
+            dist.broadcast_object_list(box, src=0, group=group)
+            idb = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        rc = self.L.lcd_shard_comm_create(eng.h, rank, world, idb, C.byref(h))
+        if rc != 0:
+            raise RuntimeError("lcd_shard_comm_create failed (%d)" % rc)
+        self.h = h
+
+    def frame(self, d_desc_ptr, q, sig_id, N, total_live_rows, d_word_ids_ptr, d_like_ptr, like_capacity, incremental=True,
+              new_words_compared=True, nndr=0.8, first_new_word_id=0):
+        flags = (1 if incremental else 0) | (2 if new_words_compared else 0)
+        rc = self.L.lcd_shard_frame(self.h, d_desc_ptr, q, flags, nndr, sig_id, first_new_word_id, float(N), int(total_live_rows), d_word_ids_ptr,
+                                    d_like_ptr, like_capacity)
+        if rc != 0:
+            raise RuntimeError("lcd_shard_frame: %s" % self.L.lcd_shard_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lcd_shard_comm_destroy(self.h)
+            self.h = None

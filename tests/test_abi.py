@@ -19,6 +19,19 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert L.lcd_abi_version() == 3
 
 
+def test_shard_driver_builds_and_exports_every_declared_symbol():
+    import ctypes
+    from rtabmap_amd import build as b
+    import rtabmap_amd
+    rtabmap_amd.load()
+    L = ctypes.CDLL(b.build_shard())
+    header = open(os.path.join(os.path.dirname(__file__), "..", "include", "lcd_shard.h")).read()
+    declared = set(re.findall(r"\b(lcd_shard_[a-z0-9_]+)\s*\(", header)) - {"lcd_shard_knn2_dev", "lcd_shard_frame_dev"}
+    assert declared == {"lcd_shard_unique_id", "lcd_shard_comm_create", "lcd_shard_comm_destroy", "lcd_shard_last_error", "lcd_shard_frame"}
+    for s in declared:
+        assert hasattr(L, s), s
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():

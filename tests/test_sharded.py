@@ -235,3 +235,41 @@ def test_sharded_two_ranks_match_single_gpu_bit_for_bit():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert ok, msgs
+
+
+@pytest.mark.gpu
+def test_native_rccl_driver_one_rank_equals_the_single_gpu_frame(oracle):
+    """liblcd_shard.so (C++ host code over the C-ABI + RCCL, include/lcd_shard.h) with a world of one rank: the five steps of the sharded
+    frame -- local 2-NN records, gather, merge + registration + integer scoring, reduce, finalise -- give the word ids and the
+    likelihood of lcd_frame_dev bit for bit, frame after frame (new words, retirement).  (More ranks need more GPUs than the test box
+    has; the exchanges are then ncclAllGather / ncclAllReduce on the same buffers.)"""
+    import torch
+    import rtabmap_amd
+    from rtabmap_amd import synth
+    from rtabmap_amd.sharded import NativeShardComm
+    n_words, n_sig, q, T = 5000, 600, 150, 10
+    vocab = synth.vocab_surf(n_words, seed=61)
+    words = synth.zipf_words(n_sig, q, n_words, seed=62)
+    ids = np.arange(1, n_words + 1, dtype=np.int32)
+    engs = []
+    for _ in range(2):
+        e = rtabmap_amd.Engine("f32", 64, sig_capacity=n_sig + T + 8)
+        e.vocab_append(vocab, ids)
+        e.sig_add_bulk(np.arange(1, n_sig + 1, dtype=np.int32), np.arange(0, (n_sig + 1) * q, q, dtype=np.int64), words.reshape(-1))
+        engs.append(e)
+    comm = NativeShardComm(engs[1], 0, 1)
+    cap = n_sig + T + 8
+    for t in range(T):
+        d = torch.from_numpy(synth.frame_from_signature(vocab, words[(31 * t) % n_sig], seed=70 + t)).cuda()
+        w0 = torch.zeros(q, dtype=torch.int32, device="cuda"); l0 = torch.zeros(cap, dtype=torch.float32, device="cuda")
+        w1 = torch.zeros(q, dtype=torch.int32, device="cuda"); l1 = torch.zeros(cap, dtype=torch.float32, device="cuda")
+        engs[0].frame_dev(d.data_ptr(), q, n_sig + 1 + t, float(n_sig + 1 + t), w0.data_ptr(), l0.data_ptr(), cap, first_new_word_id=n_words + 1 + t * q)
+        comm.frame(d.data_ptr(), q, n_sig + 1 + t, float(n_sig + 1 + t), n_words, w1.data_ptr(), l1.data_ptr(), cap, first_new_word_id=n_words + 1 + t * q)
+        engs[0].synchronize(); engs[1].synchronize()
+        np.testing.assert_array_equal(w1.cpu().numpy(), w0.cpu().numpy())
+        np.testing.assert_array_equal(l1.cpu().numpy(), l0.cpu().numpy())
+        if t % 3 == 2:
+            engs[0].sig_remove(1 + t); engs[1].sig_remove(1 + t)
+    comm.close()
+    for e in engs:
+        e.close()
