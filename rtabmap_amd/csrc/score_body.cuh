@@ -73,7 +73,13 @@ __device__ __forceinline__ void score_sealed_body(const ScoreArgs& A, int b) {
     }
     SC_STAMP(0);
     constexpr int NWV = SCB / 64;
-    constexpr int DR = 128 / NWV > 16 ? 16 : 128 / NWV;            // dense rows per wavefront and trip
+    // dense rows per wavefront and trip.  (24 rows for the 4-wave workgroups of the fused launch -- one trip instead of two for the ~95
+    // dense words of a frame -- measured SLOWER on the same box: launch B 21.1 us against 18.7; more loads in flight per wave, fewer
+    // waves resident.  -DLCD_SCORE_DR4=24 rebuilds the experiment.)
+#ifndef LCD_SCORE_DR4
+#define LCD_SCORE_DR4 16
+#endif
+    constexpr int DR = NWV == 4 ? LCD_SCORE_DR4 : (128 / NWV > 16 ? 16 : 128 / NWV);
     constexpr int KW = SCB >= 512 ? 1 : 512 / SCB;                  // frame words per thread in the fused first pass
     constexpr int NI = TF_R / SCB > 0 ? TF_R / SCB : 1;             // signatures whose ni a thread carries
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
