@@ -1166,7 +1166,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
         if (pa.sig_id != 0) LCD_HIP(h, t.register_dev(pa.sig_id, f_reg->r.out_wslot, pa.q, pa.q, pa.N, nullptr, false, &tl_reg));
         else LCD_HIP(h, t.query_dev(f_reg->r.out_wslot, pa.q, pa.N, nullptr, false, &tl_reg));
         if (pa.d_likelihood) {
-            LCD_HIP(h, t.score_args(pa.d_likelihood, nullptr, pipe_block_size(), &sa, &score_wgs));
+            LCD_HIP(h, t.score_args(pa.d_likelihood, nullptr, pipe_b_block_size(), &sa, &score_wgs));
             reg_like = true;
             h->likelihood_launches += 1;
         }

@@ -996,8 +996,12 @@ __global__ __launch_bounds__((BF_QB / (NG * 32)) * 64) void knn_bf16_filter_kern
 // KEEP keys per (row block, query); LAST_KEY_BOUNDS: the block's last kept key also bounds what its merge dropped (f32 filter);
 // BF16: the keys come from the bf16x3 filter (eps_bf16).  fail_count[2] collects max |score - distance| / eps (diagnostics).
 constexpr int RR_MAX_CAND = 128;
-template <int DIM, int KEEP, bool LAST_KEY_BOUNDS, bool BF16>
-__device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __restrict__ partial_keys,
+// HALVES = 2: a workgroup of 2 x MF_BLOCK threads re-ranks TWO queries (qi_first, qi_first + 1), one per half -- launch B of a
+// pipelined frame runs with 512-thread workgroups because its scoring half needs eight waves per bucket (a 4-wave scoring workgroup
+// takes twice as long), and a re-rank workgroup that used only half of its threads idled the other.  The halves share nothing but the
+// barriers (every barrier of the body is reached by all threads: the conditions around them are launch-uniform).
+template <int DIM, int KEEP, bool LAST_KEY_BOUNDS, bool BF16, int HALVES = 1>
+__device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_t* __restrict__ partial_keys,
                                                      const uint32_t* __restrict__ partial_lmin, int n_blocks, int nq,
                                                      const float* __restrict__ vocab, const float* __restrict__ queries,
                                                      const int32_t* __restrict__ row_id,
@@ -1011,17 +1015,27 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
     // snapshot of the vocabulary (VWDictionary::update() of a pipelined handle).  They are scanned exactly here, so the result is
     // the 2-NN over the vocabulary as update() leaves it before this frame.
     const int p_lo = pend_lo ? pend_lo[0] : 0, p_hi = pend_hi ? pend_hi[0] : 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ float s_thr;
+    const int hf = HALVES == 2 ? (int)threadIdx.x / MF_BLOCK : 0;
+    const int tid = HALVES == 2 ? (int)threadIdx.x % MF_BLOCK : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool valid = qi_first + hf < nq;                             // the odd query out: its half walks the last query again, writes nothing
+    const int qi = valid ? qi_first + hf : nq - 1;
+    __shared__ float s_thr_all[HALVES];
+    float& s_thr = s_thr_all[hf];
     const int n_keys = n_blocks * KEEP;
     const uint64_t* __restrict__ keys = partial_keys + (size_t)qi * n_keys;
     constexpr uint32_t INF = 0x7f800000u;
-    __shared__ uint32_t s_a0[MF_WAVES], s_a1[MF_WAVES], s_bound[MF_WAVES];
-    __shared__ int s_ncand;
-    __shared__ uint64_t s_cand[RR_MAX_CAND], s_exact[RR_MAX_CAND];
-    __shared__ int32_t s_word[RR_MAX_CAND];
-    __shared__ float s_err[MF_WAVES];
-    __shared__ uint64_t s_pend[MF_WAVES][2];
+    __shared__ uint32_t s_a0_all[HALVES][MF_WAVES], s_a1_all[HALVES][MF_WAVES], s_bound_all[HALVES][MF_WAVES];
+    __shared__ int s_ncand_all[HALVES];
+    __shared__ uint64_t s_cand_all[HALVES][RR_MAX_CAND], s_exact_all[HALVES][RR_MAX_CAND];
+    __shared__ int32_t s_word_all[HALVES][RR_MAX_CAND];
+    __shared__ float s_err_all[HALVES][MF_WAVES];
+    __shared__ uint64_t s_pend_all[HALVES][MF_WAVES][2];
+    uint32_t (&s_a0)[MF_WAVES] = s_a0_all[hf]; uint32_t (&s_a1)[MF_WAVES] = s_a1_all[hf]; uint32_t (&s_bound)[MF_WAVES] = s_bound_all[hf];
+    int& s_ncand = s_ncand_all[hf];
+    uint64_t (&s_cand)[RR_MAX_CAND] = s_cand_all[hf]; uint64_t (&s_exact)[RR_MAX_CAND] = s_exact_all[hf];
+    int32_t (&s_word)[RR_MAX_CAND] = s_word_all[hf];
+    float (&s_err)[MF_WAVES] = s_err_all[hf];
+    uint64_t (&s_pend)[MF_WAVES][2] = s_pend_all[hf];
     // Everything that does not depend on other loads is requested up front (the kernel is a chain of round trips): the first two
     // keys and the first bound of every thread, the query slice, the vocabulary norm bound and -- for the candidate bits -- the
     // thread's two entries of the query's row of the same-frame distance matrix.
@@ -1183,8 +1197,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
             ssecond = max(ssecond, __shfl_xor(ssecond, m, 64));
         }
     }
-    if (tid == 0) {
-        s_thr = (cb.have_index && second != KEY_NONE) ? __uint_as_float((uint32_t)(second >> 32)) : __int_as_float(0x7f800000);
+    if (tid == 0) s_thr = (cb.have_index && second != KEY_NONE) ? __uint_as_float((uint32_t)(second >> 32)) : __int_as_float(0x7f800000);
+    if (tid == 0 && valid) {
         err_ratio = fmaxf(fmaxf(s_err[0], s_err[1]), fmaxf(s_err[2], s_err[3]));
         if (err_ratio > 0.0f && eps > 0.0f) atomicMax(reinterpret_cast<uint32_t*>(fail_count) + 2, __float_as_uint(err_ratio));
         const uint64_t k[2] = {best, second};
@@ -1210,7 +1224,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
         if (!ok) fail_list[atomicAdd(fail_count, 1)] = qi;
     }
     if (cb.bits) {                                                    // the query's row of the candidate bit matrix (uniform branch)
-        __shared__ int s_below;                                       // + the compact list of the set bits below qi (CandBits::list)
+        __shared__ int s_below_all[HALVES];                           // + the compact list of the set bits below qi (CandBits::list)
+        int& s_below = s_below_all[hf];
         if (tid == 0) s_below = 0;
         __syncthreads();
         const float thr2 = s_thr;
@@ -1219,15 +1234,15 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi, const uint64_t* __r
             float d = r == tid ? dreg0 : (r == tid + MF_BLOCK ? dreg1 : __int_as_float(0x7f800000));
             if (r >= 2 * MF_BLOCK && r < cb.nq) d = cb.selfdist[(size_t)qi * cb.ld + r];
             const unsigned long long m = __ballot(d < thr2);
-            if (lane == 0) *reinterpret_cast<unsigned long long*>(cb.bits + (size_t)qi * cb.bw + (base >> 5)) = m;
+            if (lane == 0 && valid) *reinterpret_cast<unsigned long long*>(cb.bits + (size_t)qi * cb.bw + (base >> 5)) = m;
             if (cb.cnt && d < thr2 && r < qi) {
                 const int pos = atomicAdd(&s_below, 1);               // any order: the decision loop takes the two smallest (distance, j)
-                if (pos < 4) cb.list[(size_t)qi * 4 + pos] = make_uint2((uint32_t)r, __float_as_uint(d));
+                if (pos < 4 && valid) cb.list[(size_t)qi * 4 + pos] = make_uint2((uint32_t)r, __float_as_uint(d));
             }
         }
         if (cb.cnt) {
             __syncthreads();
-            if (tid == 0) cb.cnt[qi] = s_below;
+            if (tid == 0 && valid) cb.cnt[qi] = s_below;
         }
     }
 }
@@ -1308,20 +1323,22 @@ __device__ unsigned long long g_b_timing[2 * 4096];
 #else
 #define B_STAMP(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(PIPE_BLOCK) void frame_b_kernel(RerankArgs k, int n_rerank_wgs, ScoreArgs A) {
+constexpr int PIPE_B_BLOCK = 512;   // workgroup size of launch B: eight waves per sealed bucket, two queries per re-rank workgroup
+static_assert(PIPE_B_BLOCK == 2 * MF_BLOCK, "the re-rank halves");
+__global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, int n_rerank_wgs, ScoreArgs A) {
     const int bid = (int)blockIdx.x;
     B_STAMP(0);
     if (bid < n_rerank_wgs) {
-        knn_mfma_rerank_body<64, BF_KEEP, false, true>(bid, k.pk, k.pl, k.n_blocks, k.nq, k.vocab, k.queries, k.row_id, k.norm_max_bits, k.out_row,
-                                                       k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb, k.n_lo, k.n_hi);
+        knn_mfma_rerank_body<64, BF_KEEP, false, true, 2>(2 * bid, k.pk, k.pl, k.n_blocks, k.nq, k.vocab, k.queries, k.row_id, k.norm_max_bits, k.out_row,
+                                                          k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb, k.n_lo, k.n_hi);
         B_STAMP(1);
         return;
     }
     const int g = bid - n_rerank_wgs;
     if (g < A.n_closed_pad) {                                            // consecutive buckets on one XCD: they share directory lines
         const int b = (g & 7) * (A.n_closed_pad >> 3) + (g >> 3);
-        if (b < A.n_closed) score_sealed_body<PIPE_BLOCK>(A, b);
-    } else score_open_body<PIPE_BLOCK>(A, g - A.n_closed_pad);
+        if (b < A.n_closed) score_sealed_body<PIPE_B_BLOCK>(A, b);
+    } else score_open_body<PIPE_B_BLOCK>(A, g - A.n_closed_pad);
     B_STAMP(1);
 }
 
@@ -1562,6 +1579,7 @@ hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, 
 
 // ---- software-pipelined frames (see frame_a_kernel / frame_b_kernel)
 int pipe_block_size() { return PIPE_BLOCK; }
+int pipe_b_block_size() { return PIPE_B_BLOCK; }
 
 hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* resolve, const TailLaunch* reg, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
     const MfmaPlan& p = k.plan;
@@ -1612,14 +1630,14 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
         rk.n_blocks = p.n_blocks; rk.nq = p.q; rk.vocab = (const float*)k->vocab; rk.queries = (const float*)k->queries; rk.row_id = k->row_id;
         rk.norm_max_bits = k->norm_max_bits; rk.out_row = k->out_row; rk.out_word = k->out_word; rk.out_dist = k->out_dist;
         rk.fail_list = k->fail_list; rk.fail_count = k->fail_count; rk.cb = k->cb; rk.n_lo = k->n_lo; rk.n_hi = k->n_hi;
-        n_rerank = p.q;
+        n_rerank = (p.q + 1) / 2;                                     // two queries per workgroup
     }
     ScoreArgs A{};
     if (score) A = *score; else score_wgs = 0;
     if (n_rerank + score_wgs == 0) return hipSuccess;
     hipError_t e;
     if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
-    frame_b_kernel<<<n_rerank + score_wgs, PIPE_BLOCK, 0, s>>>(rk, n_rerank, A);
+    frame_b_kernel<<<n_rerank + score_wgs, PIPE_B_BLOCK, 0, s>>>(rk, n_rerank, A);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }

@@ -173,7 +173,8 @@ struct PipeKnn {
     const int32_t* n_lo = nullptr;   // device row counts (NULL: the host's plan.n_rows is exact): the filter sees rows [0, n_lo[0]), the re-rank
     const int32_t* n_hi = nullptr;   // also scans [n_lo[0], n_hi[0]) exactly -- the words the previous frame appended meanwhile (AppendArgs)
 };
-int pipe_block_size();
+int pipe_block_size();      // workgroup size of launch A (the filter's)
+int pipe_b_block_size();    // workgroup size of launch B (re-rank + scoring)
 void resolve_launch_info(const ResolveArgs& r, int block, int* n_redo, size_t* shmem);
 // filter of the newest frame + the decision loop of one earlier frame (resolve: r / n_redo / shmem_resolve of that TailLaunch) + the
 // registration of a still earlier one (reg: a / ret / shmem); either may be NULL
