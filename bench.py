@@ -37,7 +37,7 @@ NNDR = 0.8
 PEAK_F32_TFLOPS = 157.3
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBPS = 8000.0
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
 
 
 DIAG = set()
@@ -261,7 +261,7 @@ def measure_pmc(extra_args=()):
 
 def pmc_traffic(name):
     """HBM traffic per launch of a kernel in GB: from this run's own rocprofv3 --pmc passes (measure_pmc) when they ran, else from the
-    committed summary of the same command (profiles/r02_pmc.json); null when neither has the kernel."""
+    committed summary of the same command (profiles/r03_pmc.json); null when neither has the kernel."""
     key = name.split(" ")[0].split("<")[0]
     if key in PMC_LIVE:
         return PMC_LIVE[key]["hbm_bytes_per_launch"] / 1e9
@@ -903,8 +903,8 @@ def main():
               "step_ms_median": float(np.median(res["per_step_ms"])) if res["per_step_ms"].size else None,
               "step_ms_p95": float(np.percentile(res["per_step_ms"], 95)) if res["per_step_ms"].size else None,
               "world_size_observed": world, "collective_backend": backend, "signatures_bulk_load_s": build_s,
-              "pipeline": "software-pipelined frames: 2 launches per frame (filter of frame t + tail of frame t-1; re-rank of frame t + "
-                          "scoring of frame t-1), one stream" if (args.pipeline and not shard) else "4 launches per frame, one stream",
+              "pipeline": "software-pipelined frames, three in flight: 2 launches per frame (A: filter of frame t + decision loop of t-1 + registration "
+                          "of t-2; B: re-rank of frame t + scoring of t-2), one stream" if (args.pipeline and not shard) else "4 launches per frame, one stream",
               "parallelism": ("vocabulary sharded by word-id range over %d GPUs (all-gather top-2 + int64 all-reduce per frame, the all-reduce "
                               "overlapped with the next frame's search)" % world) if shard
               else ("%d independent replicas (one frame stream per GPU, no data-path collective)" % world if world > 1 else "1 GPU")}
@@ -1005,7 +1005,7 @@ def main():
             for k in ("roofline", "roofline_score", "roofline_knn", "roofline_knn_standalone", "roofline_score_standalone"):
                 if out.get(k):
                     out[k]["traffic"] = pmc_traffic(out[k]["kernel"])
-                    out[k]["traffic_source"] = note if PMC_LIVE else note + " (profiles/r02_pmc.json)"
+                    out[k]["traffic_source"] = note if PMC_LIVE else note + " (profiles/r03_pmc.json)"
         if not args.no_cpu_baseline:
             m = build_oracle(vocab, words)
             par, t_lin_port, t_lik = parity_block(torch, vocab, words, frames_np, m)
