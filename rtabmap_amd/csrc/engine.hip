@@ -1192,7 +1192,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
                                                      : "frame_a_kernel (bf16 filter of frame t + decision loop of t-1 + registration of t-2)";
     }
     LCD_HIP(h, t.flush_held_if_due());
-    const bool prof2 = reg_like && h->prof_cap > 0 && h->prof2_n < h->prof_cap;
+    const bool prof2 = reg_like && h->prof_likelihood && h->prof_cap > 0 && h->prof2_n < h->prof_cap;
     LCD_HIP(h, launch_frame_b(&k, reg_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
                               prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr));
     if (prof2) { h->prof2_n += 1; h->prof2_kernel = "frame_b_kernel (re-rank of frame t + scoring of frame t-2)"; }
@@ -1608,6 +1608,8 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     if (!std::strcmp(key, "score_block") && (value == 256 || value == 512 || value == 1024)) { h->tfidf.score_block = (int)value; return LCD_OK; }
     // compute units the bf16 filter's persistent launch plans for (vocabularies of more 256-word strips than that): -1 built-in, 0 off
     if (!std::strcmp(key, "filter_units") && value >= -1 && value <= 4096) { h->filter_units = (int)value; return LCD_OK; }
+    // 0: lcd_profile_begin brackets only the 2-NN launch of a pipelined frame (an event pair costs the stream ~10 us)
+    if (!std::strcmp(key, "profile_likelihood") && (value == 0 || value == 1)) { h->prof_likelihood = value != 0; return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");
     LCD_CATCH(h)
 }
