@@ -191,9 +191,9 @@ def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None
     rec = (lambda e: eng.record_event(e.cuda_event)) if eng is not None else (lambda e: e.record(stream))
     mid = rec if per_step_events else (lambda e: None)          # an event per step costs a few microseconds of stream time each
     if profile_eng is not None:
-        # HIP events around the dominant launch of the first timed steps (a tenth of them, at least 4): an event pair costs the stream
+        # HIP events around the dominant launch of the first timed steps (a tenth of them, at least 3): an event pair costs the stream
         # ~10 us, so the timed region brackets ONE launch per sampled frame; the other big kernel is bracketed in an untimed leg
-        profile_eng.profile_begin(max(4, steps // 10))
+        profile_eng.profile_begin(max(3, steps // 10))
     t0 = time.perf_counter()
     rec(evs[0])
     for i in range(steps):

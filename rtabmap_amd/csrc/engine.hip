@@ -1071,20 +1071,87 @@ static int finish_frame_ops(lcd_engine* h, lcd_engine::InFlight& f) {
     return LCD_OK;
 }
 
+static int pipeline_launch(lcd_engine* h, const PipeKnn* k);
+
 int lcd_engine::drain() {
     int rc_all = LCD_OK;
-    while (!inflight.empty()) {                                      // oldest first: every frame is completed before the next one touches the index
-        InFlight f = std::move(inflight.front());
-        inflight.pop_front();
-        ResolveArgs r = f.r;
-        r.new_ws = WsRuns();
-        refresh_vocab_ptrs(this, &r);
-        const int rc = f.stage == 2 ? frame_stage_reg_s(this, f.a, r) : frame_stage_s(this, f.a, r, f.chained, f.vseq);
-        const int rc2 = finish_frame_ops(this, f);
-        if (!rc_all) rc_all = rc ? rc : rc2;
+    while (!inflight.empty()) {                                      // two fused launch pairs complete two owed frames, oldest first
+        const size_t before = inflight.size();
+        const int stage_front = inflight.front().stage;
+        const int rc = pipeline_launch(this, nullptr);
+        if (rc && !rc_all) rc_all = rc;
+        if (rc && inflight.size() == before && inflight.front().stage == stage_front) {   // no progress: drop the frame instead of spinning
+            InFlight f = std::move(inflight.front());
+            inflight.pop_front();
+            (void)finish_frame_ops(this, f);
+        }
     }
     const int rc3 = reconcile();                                     // rows appended on the device: the host mirror catches up
     return rc_all ? rc_all : rc3;
+}
+
+// One pair of fused launches of a pipelined handle: A = [filter of the new frame `k`] + decision loop of the frame whose loop is owed +
+// registration of the frame whose registration is owed; B = [re-rank of `k`] + scoring of the latter (then its decision stage and the
+// calls queued behind it).  k == NULL: nothing new -- drain() advances what is in flight with the same fused launches (the stand-alone
+// kernels it used before cost the driver's 20-step run ~35 us more).
+static int pipeline_launch(lcd_engine* h, const PipeKnn* k) {
+    Tfidf& t = h->tfidf;
+    lcd_engine::InFlight* f_reg = nullptr; lcd_engine::InFlight* f_res = nullptr;
+    for (lcd_engine::InFlight& f : h->inflight) {
+        if (f.stage == 2 && !f_reg) f_reg = &f;
+        else if (f.stage == 1 && !f_res) f_res = &f;
+    }
+    TailLaunch tl_reg, tl_res; ScoreArgs sa; int score_wgs = 0;
+    bool reg_like = false;
+    if (f_reg) {
+        const lcd_frame_args& pa = f_reg->a;
+        if (pa.sig_id != 0) LCD_HIP(h, t.register_dev(pa.sig_id, f_reg->r.out_wslot, pa.q, pa.q, pa.N, nullptr, false, &tl_reg));
+        else LCD_HIP(h, t.query_dev(f_reg->r.out_wslot, pa.q, pa.N, nullptr, false, &tl_reg));
+        if (pa.d_likelihood) {
+            LCD_HIP(h, t.score_args(pa.d_likelihood, nullptr, pipe_b_block_size(), &sa, &score_wgs));
+            reg_like = true;
+            h->likelihood_launches += 1;
+        }
+    }
+    if (f_res) {
+        // the postings keys of the words that frame may create are reserved now (the batched check of older reservations waits until
+        // launch A is enqueued: the registration that rides in it may still use some of those keys)
+        { int rc = reserve_frame_words(h, f_res->a, &f_res->runs, false); if (rc) return rc; }
+        f_res->reserved = true;
+        tl_res.r = f_res->r;
+        tl_res.r.new_ws = f_res->runs;
+        refresh_vocab_ptrs(h, &tl_res.r);
+        if (f_res->chained) fill_append(h, f_res->a, f_res->vseq, frame_appends(h, f_res->a), &tl_res.r);
+        resolve_launch_info(tl_res.r, pipe_block_size(), &tl_res.n_redo, &tl_res.shmem_resolve);
+    }
+    PipeKnn none;
+    none.plan = MfmaPlan(); none.plan.q = 0; none.plan.qpad = 0; none.plan.n_rows = 0; none.plan.tiles_per_block = 1; none.plan.n_blocks = 0;
+    none.vocab = nullptr; none.vocab_bf = nullptr; none.row_norm = nullptr; none.norm_max_bits = nullptr; none.row_id = nullptr; none.queries = nullptr;
+    none.partial = nullptr; none.out_row = nullptr; none.out_word = nullptr; none.out_dist = nullptr; none.fail_list = nullptr; none.fail_count = nullptr;
+    const PipeKnn& kk = k ? *k : none;
+    // ---- launch A: filter (t) + decision loop (t - 1) + registration (t - 2); launch B: re-rank (t) + scoring (t - 2)
+    const bool prof = k && h->prof_cap > 0 && h->prof_n < h->prof_cap;
+    LCD_HIP(h, launch_frame_a(kk, f_res ? &tl_res : nullptr, f_reg ? &tl_reg : nullptr, h->stream, prof ? h->prof_ev[2 * h->prof_n] : nullptr,
+                              prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr));
+    if (prof) {
+        h->prof_n += 1;
+        h->prof_kernel = knn_bf16_persistent(kk.plan) ? "frame_a_kernel_p (persistent bf16 filter of frame t + decision loop of t-1 + registration of t-2)"
+                                                      : "frame_a_kernel (bf16 filter of frame t + decision loop of t-1 + registration of t-2)";
+    }
+    LCD_HIP(h, t.flush_held_if_due());
+    const bool prof2 = k && reg_like && h->prof_likelihood && h->prof_cap > 0 && h->prof2_n < h->prof_cap;
+    LCD_HIP(h, launch_frame_b(k, reg_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
+                              prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr));
+    if (prof2) { h->prof2_n += 1; h->prof2_kernel = "frame_b_kernel (re-rank of frame t + scoring of frame t-2)"; }
+    if (f_res) f_res->stage = 2;
+    if (f_reg) {                                                     // that frame is complete: its decision stage and the calls queued behind it
+        lcd_engine::InFlight done = std::move(*f_reg);
+        h->inflight.pop_front();                                     // (f_reg is the oldest entry: stages advance in order)
+        if (done.a.d_likelihood) { int rc = hypothesis_stage(h, done.a); if (rc) return rc; }
+        int rc = finish_frame_ops(h, done);
+        if (rc) return rc;
+    }
+    return LCD_OK;
 }
 
 // Pipelined handle, matrix-core 2-NN (knn_mfma_kernels.hip, frame_a_kernel / frame_b_kernel): the call for frame t launches
@@ -1153,59 +1220,10 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     if (together) { k.cb.selfdist = sc.d_selfdist.as<float>(); k.cb.ld = ld; k.cb.nq = q; k.cb.have_index = 1; cand_bits_layout(k.cb, sc.d_bits.as<uint32_t>(), q, bw); }
     if (!sc.fail_count_clean) LCD_HIP(h, hipMemsetAsync(sc.d_fail_count.p, 0, 8, h->stream));
     h->last_fail_count = sc.d_fail_count.p;
-    // ---- what the frames in flight owe: host part now, the launches ride with this frame's
-    lcd_engine::InFlight* f_reg = nullptr; lcd_engine::InFlight* f_res = nullptr;
-    for (lcd_engine::InFlight& f : h->inflight) {
-        if (f.stage == 2 && !f_reg) f_reg = &f;
-        else if (f.stage == 1 && !f_res) f_res = &f;
-    }
-    TailLaunch tl_reg, tl_res; ScoreArgs sa; int score_wgs = 0;
-    bool reg_like = false;
-    if (f_reg) {
-        const lcd_frame_args& pa = f_reg->a;
-        if (pa.sig_id != 0) LCD_HIP(h, t.register_dev(pa.sig_id, f_reg->r.out_wslot, pa.q, pa.q, pa.N, nullptr, false, &tl_reg));
-        else LCD_HIP(h, t.query_dev(f_reg->r.out_wslot, pa.q, pa.N, nullptr, false, &tl_reg));
-        if (pa.d_likelihood) {
-            LCD_HIP(h, t.score_args(pa.d_likelihood, nullptr, pipe_b_block_size(), &sa, &score_wgs));
-            reg_like = true;
-            h->likelihood_launches += 1;
-        }
-    }
-    if (f_res) {
-        // the postings keys of the words frame t - 1 may create are reserved now (the batched check of older reservations waits until
-        // launch A is enqueued: the registration of frame t - 2, which rides in it, may still use some of those keys)
-        { int rc = reserve_frame_words(h, f_res->a, &f_res->runs, false); if (rc) return rc; }
-        f_res->reserved = true;
-        tl_res.r = f_res->r;
-        tl_res.r.new_ws = f_res->runs;
-        refresh_vocab_ptrs(h, &tl_res.r);
-        if (f_res->chained) fill_append(h, f_res->a, f_res->vseq, frame_appends(h, f_res->a), &tl_res.r);
-        resolve_launch_info(tl_res.r, pipe_block_size(), &tl_res.n_redo, &tl_res.shmem_resolve);
-    }
-    // ---- launch A: filter (t) + decision loop (t - 1) + registration (t - 2); launch B: re-rank (t) + scoring (t - 2)
-    const bool prof = h->prof_cap > 0 && h->prof_n < h->prof_cap;
-    LCD_HIP(h, launch_frame_a(k, f_res ? &tl_res : nullptr, f_reg ? &tl_reg : nullptr, h->stream, prof ? h->prof_ev[2 * h->prof_n] : nullptr,
-                              prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr));
-    if (prof) {
-        h->prof_n += 1;
-        h->prof_kernel = knn_bf16_persistent(k.plan) ? "frame_a_kernel_p (persistent bf16 filter of frame t + decision loop of t-1 + registration of t-2)"
-                                                     : "frame_a_kernel (bf16 filter of frame t + decision loop of t-1 + registration of t-2)";
-    }
-    LCD_HIP(h, t.flush_held_if_due());
-    const bool prof2 = reg_like && h->prof_likelihood && h->prof_cap > 0 && h->prof2_n < h->prof_cap;
-    LCD_HIP(h, launch_frame_b(&k, reg_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
-                              prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr));
-    if (prof2) { h->prof2_n += 1; h->prof2_kernel = "frame_b_kernel (re-rank of frame t + scoring of frame t-2)"; }
+    // ---- what the frames in flight owe rides with this frame's launches
+    { int rc = pipeline_launch(h, &k); if (rc) return rc; }
     h->knn_launches += 1;
     sc.fail_count_clean = true;                                      // this frame's decision loop (a later launch A, or drain()) resets the counters
-    if (f_res) f_res->stage = 2;
-    if (f_reg) {                                                     // frame t - 2 is complete: its decision stage and the calls queued behind it
-        lcd_engine::InFlight done = std::move(*f_reg);
-        h->inflight.pop_front();                                     // (f_reg is the oldest entry: stages advance in order)
-        if (done.a.d_likelihood) { int rc = hypothesis_stage(h, done.a); if (rc) return rc; }
-        int rc = finish_frame_ops(h, done);
-        if (rc) return rc;
-    }
     // ---- this frame's decision loop, registration and scoring are owed from here on
     lcd_engine::InFlight nf;
     nf.a = *a; nf.set = set; nf.stage = 1; nf.vseq = vseq; nf.chained = chained;
