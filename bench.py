@@ -883,6 +883,8 @@ def main():
                                  stream=stream.cuda_stream, pipeline=args.pipeline)
         if args.score_block:
             eng.set_option("score_block", args.score_block)
+        for kv in filter(None, os.environ.get("LCD_BENCH_OPTS", "").split(",")):      # timing experiments: key=value engine options
+            eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         build_s = load_engine(eng, vocab, words)
         log("[bench] rank %d: %d signatures bulk-loaded in %.2fs" % (rank, n_sig, build_s))
         log_frames = (args.warmup + args.steps) if (world == 1 and not args.no_cpu_baseline and args.warmup + args.steps <= 4096) else 0

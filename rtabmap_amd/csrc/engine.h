@@ -58,9 +58,10 @@ struct lcd_engine {
     hipStream_t kst = nullptr;                          // the stream the 2-NN stage is enqueued on (== stream)
     struct FrameScratch {
         lcd::DevBuf d_knn_row, d_knn_word, d_knn_dist, d_selfdist, d_bits, d_partial2, d_partial3, d_fail_list, d_fail_count, d_out_wslot;
+        lcd::DevBuf d_qsplit, d_qnorm;                  // the frame's queries pre-split into bf16 matrix-core operands, their norms
         bool fail_count_clean = false;
     };
-    static constexpr int PIPE_SETS = 4;
+    static constexpr int PIPE_SETS = 6;                 // a frame's set is in use for four calls (pre-split .. registration)
     FrameScratch ring[PIPE_SETS];
     uint64_t frame_seq = 0;
     const void* last_fail_count = nullptr;              // certificate counters of the latest pipelined frame (lcd_get_stats)
@@ -69,7 +70,7 @@ struct lcd_engine {
         lcd_frame_args a; lcd::ResolveArgs r; int set = 0;
         uint64_t vseq = 0; bool chained = false;        // the frame takes part in the device row-count chain (vcnt_active at its call)
         lcd::WsRuns runs; bool reserved = false;        // postings keys of its new words (reserved when its decision loop is prepared)
-        int stage = 1;                                  // 1: the decision loop is owed (and everything after it), 2: registration + scoring are
+        int stage = 0;                                  // what is owed next: 0 filter + re-rank, 1 the decision loop, 2 registration + scoring
         std::vector<int32_t> retire_after;              // lcd_sig_remove calls made while this was the newest frame
         std::vector<void*> events_after;                // lcd_record_event calls ...
         std::vector<DeferredLink> links_after;          // lcd_bayes_set_neighbors calls ...
@@ -91,6 +92,7 @@ struct lcd_engine {
     int reconcile();
     int64_t rows_ub() const;
     int filter_units = -1;                              // lcd_set_option("filter_units")
+    int strip_tiles = 0;                                // lcd_set_option("strip_tiles"): tiles per filter workgroup of a pipelined frame (0: planner)
     int sync_all();                                     // stream drained
     int drain();                                        // complete the owed index stage (stand-alone launches)
     const char* prof2_kernel = "score_kernel";

@@ -342,7 +342,7 @@ void lcd_destroy(lcd_engine* h) {
     h->bayes.destroy();
     for (lcd_engine::FrameScratch& sc : h->ring) {
         DevBuf* all[] = {&sc.d_knn_row, &sc.d_knn_word, &sc.d_knn_dist, &sc.d_selfdist, &sc.d_bits, &sc.d_partial2, &sc.d_partial3, &sc.d_fail_list,
-                         &sc.d_fail_count, &sc.d_out_wslot};
+                         &sc.d_fail_count, &sc.d_out_wslot, &sc.d_qsplit, &sc.d_qnorm};
         for (DevBuf* d : all) d->release(&h->bytes_device);
     }
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -373,7 +373,7 @@ int lcd_synchronize(lcd_engine* h) {
 
 void* lcd_stream(lcd_engine* h) { return h ? (void*)h->stream : nullptr; }
 
-int lcd_pipeline_depth(const lcd_engine* h) { return (h && h->pipeline) ? 2 : 0; }
+int lcd_pipeline_depth(const lcd_engine* h) { return (h && h->pipeline) ? 3 : 0; }
 
 int lcd_record_event(lcd_engine* h, void* event) {
     LCD_TRY
@@ -1071,11 +1071,11 @@ static int finish_frame_ops(lcd_engine* h, lcd_engine::InFlight& f) {
     return LCD_OK;
 }
 
-static int pipeline_launch(lcd_engine* h, const PipeKnn* k);
+static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs);
 
 int lcd_engine::drain() {
     int rc_all = LCD_OK;
-    while (!inflight.empty()) {                                      // two fused launch pairs complete two owed frames, oldest first
+    while (!inflight.empty()) {                                      // three fused launch pairs complete what is owed, oldest first
         const size_t before = inflight.size();
         const int stage_front = inflight.front().stage;
         const int rc = pipeline_launch(this, nullptr);
@@ -1090,16 +1090,78 @@ int lcd_engine::drain() {
     return rc_all ? rc_all : rc3;
 }
 
-// One pair of fused launches of a pipelined handle: A = [filter of the new frame `k`] + decision loop of the frame whose loop is owed +
-// registration of the frame whose registration is owed; B = [re-rank of `k`] + scoring of the latter (then its decision stage and the
-// calls queued behind it).  k == NULL: nothing new -- drain() advances what is in flight with the same fused launches (the stand-alone
-// kernels it used before cost the driver's 20-step run ~35 us more).
-static int pipeline_launch(lcd_engine* h, const PipeKnn* k) {
+// The 2-NN stage of an in-flight frame, planned when its filter is about to be launched (the row count may have grown since the frame was
+// submitted): scratch of the frame's ring set, launch plan, and the arguments its decision loop will need one launch later.
+static int build_knn(lcd_engine* h, lcd_engine::InFlight& f, PipeKnn* kp) {
+    PipeKnn& k = *kp;
+    const lcd_frame_args& a = f.a;
+    const int q = a.q;
+    lcd_engine::FrameScratch& sc = h->ring[f.set];
+    const bool incremental = (a.flags & LCD_Q_INCREMENTAL) != 0;
+    const bool together = incremental && (a.flags & LCD_Q_NEW_WORDS_COMPARED);
+    const int ld = (q + 63) / 64 * 64, bw = ld / 32;
+    const int64_t plan_rows = f.chained ? h->rows_ub() : h->n_rows;
+    if (plan_rows > 0x7FFFFFF0ll) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: more than 2^31 rows");
+    // The distance tiles get compute units of their own (a tile that shares one with a strip takes twice as long, and so does the
+    // strip); the two tail workgroups do not: a filter workgroup holds 66 KB of LDS, so two of the launch's workgroups can share a
+    // compute unit, and one strip less per workgroup is worth more than the two shared units (49 000 words x 500 descriptors:
+    // 219 seven-tile strips + 36 tiles + 2 = 257 workgroups, frame 31.6 us; 192 eight-tile strips 32.1; 256 six-tile strips 34.5).
+    // A vocabulary of more strips than compute units runs the persistent kernel, whose workgroups own their compute unit.
+    const int n_tile_wgs = together ? knn_selfdist_wgs(q) : 0;
+    k.plan = knn_bf16_plan(q, (int)plan_rows, n_tile_wgs);
+    k.plan.filter_units = h->filter_units;
+    if (knn_bf16_persistent(k.plan)) {
+        k.plan = knn_bf16_plan(q, (int)plan_rows, 2 + n_tile_wgs);
+        k.plan.filter_units = h->filter_units;
+    }
+    if (h->strip_tiles > 0 && plan_rows > 0) {                       // timing experiments: a fixed strip length, one workgroup per strip
+        const int n_tiles = (int)((plan_rows + 31) / 32);
+        k.plan.tiles_per_block = h->strip_tiles; k.plan.n_blocks = (n_tiles + h->strip_tiles - 1) / h->strip_tiles; k.plan.one_strip = 1;
+    }
+    LCD_HIP(h, dreserve(h, sc.d_partial2, knn_bf16_partial_bytes(k.plan)));
+    LCD_HIP(h, dreserve(h, sc.d_partial3, knn_rowpar_partial_bytes((int)plan_rows, q)));
+    k.vocab = h->vocab.p; k.vocab_bf = h->vocab_bf.p; k.row_norm = h->row_norm.as<float>(); k.norm_max_bits = h->norm_max.as<uint32_t>();
+    k.row_id = h->row_id.as<int32_t>(); k.queries = a.d_descriptors; k.partial = sc.d_partial2.p;
+    k.qsplit = sc.d_qsplit.p; k.qnorm = sc.d_qnorm.as<float>();
+    k.out_row = sc.d_knn_row.as<int32_t>(); k.out_word = sc.d_knn_word.as<int32_t>(); k.out_dist = sc.d_knn_dist.as<float>();
+    k.fail_list = sc.d_fail_list.as<int32_t>(); k.fail_count = sc.d_fail_count.as<int32_t>();
+    k.n_lo = nullptr; k.n_hi = nullptr;
+    if (f.chained) { k.n_lo = h->d_vcnt.as<int32_t>() + ((f.vseq + 1) & 1); k.n_hi = h->d_vcnt.as<int32_t>() + (f.vseq & 1); }
+    k.cb = CandBits();
+    if (together) { k.cb.selfdist = sc.d_selfdist.as<float>(); k.cb.ld = ld; k.cb.nq = q; k.cb.have_index = 1; cand_bits_layout(k.cb, sc.d_bits.as<uint32_t>(), q, bw); }
+    if (!sc.fail_count_clean) LCD_HIP(h, hipMemsetAsync(sc.d_fail_count.p, 0, 8, h->stream));
+    sc.fail_count_clean = true;                                      // the frame's decision loop (a later launch A) resets the counters
+    h->last_fail_count = sc.d_fail_count.p;
+    // ---- the decision loop's arguments (launched one call later), the redo of rejected queries riding with it
+    ResolveArgs& r = f.r;
+    r = ResolveArgs();
+    r.q = q; r.flags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0); r.nndr = a.nndr_ratio; r.have_index = 1;
+    r.knn_word = k.out_word; r.knn_dist = k.out_dist; r.selfdist = together ? sc.d_selfdist.as<float>() : nullptr; r.ld = ld;
+    r.cand_bits = together ? sc.d_bits.as<uint32_t>() : nullptr; r.bw = bw; r.out_word = a.d_word_ids; r.out_n_new = h->d_n_new.as<int32_t>();
+    r.cand_list = together ? k.cb.list : nullptr; r.cand_cnt = together ? k.cb.cnt : nullptr;
+    r.knn_row = k.out_row; r.row_wslot = h->row_wslot.as<int32_t>(); r.out_wslot = sc.d_out_wslot.as<int32_t>(); r.new_ws = WsRuns();
+    r.fail_count = sc.d_fail_count.as<int32_t>();
+    RowparArgs& rp = r.rp;
+    rp.enabled = 1; rp.vocab = (const float*)h->vocab.p; rp.row_id = h->row_id.as<int32_t>(); rp.n_rows = (int)plan_rows;
+    rp.n_rows_dev = k.n_hi;                                          // the rows that exist when the redo runs: after the previous frame's append
+    rp.queries = (const float*)a.d_descriptors; rp.fail_list = sc.d_fail_list.as<int32_t>(); rp.partial = (unsigned long long*)sc.d_partial3.p;
+    rp.out_row = k.out_row; rp.out_word = k.out_word; rp.out_dist = k.out_dist;
+    if (together) rp.cb = k.cb;
+    return LCD_OK;
+}
+
+// One pair of fused launches of a pipelined handle.  With frame t the newest:
+//   A = queries of frame t pre-split into matrix-core operands  +  filter (+ same-frame distance tiles) of frame t-1
+//       + decision loop of frame t-2 (+ its redo helpers, + the append of its new words)  +  retirement / registration of frame t-3
+//   B = re-rank of frame t-1  +  scoring of frame t-3   (then the decision stage of frame t-3 and the calls queued behind it)
+// qs == NULL: nothing new -- drain() advances what is in flight with the same fused launches.
+static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
     Tfidf& t = h->tfidf;
-    lcd_engine::InFlight* f_reg = nullptr; lcd_engine::InFlight* f_res = nullptr;
+    lcd_engine::InFlight* f_reg = nullptr; lcd_engine::InFlight* f_res = nullptr; lcd_engine::InFlight* f_knn = nullptr;
     for (lcd_engine::InFlight& f : h->inflight) {
         if (f.stage == 2 && !f_reg) f_reg = &f;
         else if (f.stage == 1 && !f_res) f_res = &f;
+        else if (f.stage == 0 && !f_knn) f_knn = &f;
     }
     TailLaunch tl_reg, tl_res; ScoreArgs sa; int score_wgs = 0;
     bool reg_like = false;
@@ -1124,26 +1186,23 @@ static int pipeline_launch(lcd_engine* h, const PipeKnn* k) {
         if (f_res->chained) fill_append(h, f_res->a, f_res->vseq, frame_appends(h, f_res->a), &tl_res.r);
         resolve_launch_info(tl_res.r, pipe_block_size(), &tl_res.n_redo, &tl_res.shmem_resolve);
     }
-    PipeKnn none;
-    none.plan = MfmaPlan(); none.plan.q = 0; none.plan.qpad = 0; none.plan.n_rows = 0; none.plan.tiles_per_block = 1; none.plan.n_blocks = 0;
-    none.vocab = nullptr; none.vocab_bf = nullptr; none.row_norm = nullptr; none.norm_max_bits = nullptr; none.row_id = nullptr; none.queries = nullptr;
-    none.partial = nullptr; none.out_row = nullptr; none.out_word = nullptr; none.out_dist = nullptr; none.fail_list = nullptr; none.fail_count = nullptr;
-    const PipeKnn& kk = k ? *k : none;
-    // ---- launch A: filter (t) + decision loop (t - 1) + registration (t - 2); launch B: re-rank (t) + scoring (t - 2)
-    const bool prof = k && h->prof_cap > 0 && h->prof_n < h->prof_cap;
-    LCD_HIP(h, launch_frame_a(kk, f_res ? &tl_res : nullptr, f_reg ? &tl_reg : nullptr, h->stream, prof ? h->prof_ev[2 * h->prof_n] : nullptr,
-                              prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr));
+    PipeKnn k;
+    if (f_knn) { int rc = build_knn(h, *f_knn, &k); if (rc) return rc; h->knn_launches += 1; }
+    const bool prof = f_knn && h->prof_cap > 0 && h->prof_n < h->prof_cap;
+    LCD_HIP(h, launch_frame_a(f_knn ? &k : nullptr, qs, f_res ? &tl_res : nullptr, f_reg ? &tl_reg : nullptr, h->stream,
+                              prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr));
     if (prof) {
         h->prof_n += 1;
-        h->prof_kernel = knn_bf16_persistent(kk.plan) ? "frame_a_kernel_p (persistent bf16 filter of frame t + decision loop of t-1 + registration of t-2)"
-                                                      : "frame_a_kernel (bf16 filter of frame t + decision loop of t-1 + registration of t-2)";
+        h->prof_kernel = knn_bf16_persistent(k.plan) ? "frame_a_kernel_p (persistent bf16 filter of frame t-1 + query pre-split of t + decision loop of t-2 + registration of t-3)"
+                                                     : "frame_a_kernel (bf16 filter of frame t-1 + query pre-split of t + decision loop of t-2 + registration of t-3)";
     }
     LCD_HIP(h, t.flush_held_if_due());
-    const bool prof2 = k && reg_like && h->prof_likelihood && h->prof_cap > 0 && h->prof2_n < h->prof_cap;
-    LCD_HIP(h, launch_frame_b(k, reg_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
+    const bool prof2 = f_knn && reg_like && h->prof_likelihood && h->prof_cap > 0 && h->prof2_n < h->prof_cap;
+    LCD_HIP(h, launch_frame_b(f_knn ? &k : nullptr, reg_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
                               prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr));
-    if (prof2) { h->prof2_n += 1; h->prof2_kernel = "frame_b_kernel (re-rank of frame t + scoring of frame t-2)"; }
+    if (prof2) { h->prof2_n += 1; h->prof2_kernel = "frame_b_kernel (re-rank of frame t-1 + scoring of frame t-3)"; }
     if (f_res) f_res->stage = 2;
+    if (f_knn) f_knn->stage = 1;
     if (f_reg) {                                                     // that frame is complete: its decision stage and the calls queued behind it
         lcd_engine::InFlight done = std::move(*f_reg);
         h->inflight.pop_front();                                     // (f_reg is the oldest entry: stages advance in order)
@@ -1154,9 +1213,9 @@ static int pipeline_launch(lcd_engine* h, const PipeKnn* k) {
     return LCD_OK;
 }
 
-// Pipelined handle, matrix-core 2-NN (knn_mfma_kernels.hip, frame_a_kernel / frame_b_kernel): the call for frame t launches
-//   A = filter of frame t + decision loop of frame t - 1 + retirement / registration of frame t - 2,  B = re-rank of frame t + scoring of
-//   frame t - 2 (+ the decision stage of frame t - 2).  What frames t - 1 and t still owe afterwards waits in h->inflight.
+// Pipelined handle, matrix-core 2-NN (knn_mfma_kernels.hip, frame_a_kernel / frame_b_kernel): four frames are in flight.  The call for
+// frame t pre-splits its queries and carries one stage of each of the three frames before it (pipeline_launch); what the frames still
+// owe afterwards waits in h->inflight.
 static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     Tfidf& t = h->tfidf;
     const int q = a->q;
@@ -1171,7 +1230,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     const int64_t slots_after = t.n_slots + owed_slots + (a->sig_id != 0 ? 1 : 0);
     if (a->d_likelihood && a->likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
     if (h->unreconciled.size() >= (size_t)lcd_engine::VLOG / 2) { int rc = h->drain(); if (rc) return rc; }   // the append log is a ring
-    // rows appended on the device: the counters take over the row count, the buffers keep room for this frame's and the next one's words
+    // rows appended on the device: the counters take over the row count, the buffers keep room for the words of the frames in flight
     const bool app = frame_appends(h, *a);
     if (app) { int rc = activate_dev_rows(h); if (rc) return rc; }
     const bool chained = h->vcnt_active;
@@ -1187,23 +1246,17 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
                 return h->fail(LCD_ERR_HIP, "lcd_frame_dev: the device made no progress for 5 s");
         }
     }
-    if (chained) { int rc = ensure_append_capacity(h, h->rows_ub() + 2 * (int64_t)q); if (rc) return rc; }
-    const int64_t plan_rows = chained ? h->rows_ub() : h->n_rows;
-    if (plan_rows > 0x7FFFFFF0ll) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: more than 2^31 rows");
+    if (chained) { int rc = ensure_append_capacity(h, h->rows_ub() + 3 * (int64_t)q); if (rc) return rc; }
     const uint64_t vseq = h->vseq;
     const int set = (int)(h->frame_seq % lcd_engine::PIPE_SETS);
     lcd_engine::FrameScratch& sc = h->ring[set];
     const bool incremental = (a->flags & LCD_Q_INCREMENTAL) != 0;
     const bool together = incremental && (a->flags & LCD_Q_NEW_WORDS_COMPARED);
     const int ld = (q + 63) / 64 * 64, bw = ld / 32;
-    // ---- this frame's 2-NN stage: buffers of its scratch set
-    PipeKnn k;
-    k.plan = knn_bf16_plan(q, (int)plan_rows, 2 + (together ? knn_selfdist_wgs(q) : 0));
-    k.plan.filter_units = h->filter_units;
-    if (chained) { k.n_lo = h->d_vcnt.as<int32_t>() + ((vseq + 1) & 1); k.n_hi = h->d_vcnt.as<int32_t>() + (vseq & 1); }
-    LCD_HIP(h, dreserve(h, sc.d_partial2, knn_bf16_partial_bytes(k.plan)));
+    // ---- the frame's scratch set (what does not depend on the launch plan; the partial keys are sized when the filter is planned)
+    LCD_HIP(h, dreserve(h, sc.d_qsplit, knn_qsplit_bytes(q)));
+    LCD_HIP(h, dreserve(h, sc.d_qnorm, (size_t)ld * 4));
     LCD_HIP(h, dreserve(h, sc.d_fail_list, (size_t)q * 4));
-    LCD_HIP(h, dreserve(h, sc.d_partial3, knn_rowpar_partial_bytes((int)plan_rows, q)));
     LCD_HIP(h, dreserve(h, sc.d_knn_row, (size_t)q * 2 * 4));
     LCD_HIP(h, dreserve(h, sc.d_knn_word, (size_t)q * 2 * 4));
     LCD_HIP(h, dreserve(h, sc.d_knn_dist, (size_t)q * 2 * 4));
@@ -1212,38 +1265,14 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
         LCD_HIP(h, dreserve(h, sc.d_selfdist, (size_t)q * ld * 4));
         LCD_HIP(h, dreserve(h, sc.d_bits, cand_bits_bytes(q, bw)));
     }
-    k.vocab = h->vocab.p; k.vocab_bf = h->vocab_bf.p; k.row_norm = h->row_norm.as<float>(); k.norm_max_bits = h->norm_max.as<uint32_t>();
-    k.row_id = h->row_id.as<int32_t>(); k.queries = a->d_descriptors; k.partial = sc.d_partial2.p;
-    k.out_row = sc.d_knn_row.as<int32_t>(); k.out_word = sc.d_knn_word.as<int32_t>(); k.out_dist = sc.d_knn_dist.as<float>();
-    k.fail_list = sc.d_fail_list.as<int32_t>(); k.fail_count = sc.d_fail_count.as<int32_t>();
-    k.cb = CandBits();
-    if (together) { k.cb.selfdist = sc.d_selfdist.as<float>(); k.cb.ld = ld; k.cb.nq = q; k.cb.have_index = 1; cand_bits_layout(k.cb, sc.d_bits.as<uint32_t>(), q, bw); }
-    if (!sc.fail_count_clean) LCD_HIP(h, hipMemsetAsync(sc.d_fail_count.p, 0, 8, h->stream));
-    h->last_fail_count = sc.d_fail_count.p;
+    QSplitArgs qs;
+    qs.queries = (const float*)a->d_descriptors; qs.nq = q; qs.qpad = ld; qs.qsplit = (uint4*)sc.d_qsplit.p; qs.qnorm = sc.d_qnorm.as<float>(); qs.n_wgs = 0;
     // ---- what the frames in flight owe rides with this frame's launches
-    { int rc = pipeline_launch(h, &k); if (rc) return rc; }
-    h->knn_launches += 1;
-    sc.fail_count_clean = true;                                      // this frame's decision loop (a later launch A, or drain()) resets the counters
-    // ---- this frame's decision loop, registration and scoring are owed from here on
+    { int rc = pipeline_launch(h, &qs); if (rc) return rc; }
+    // ---- this frame's filter, re-rank, decision loop, registration and scoring are owed from here on
     lcd_engine::InFlight nf;
-    nf.a = *a; nf.set = set; nf.stage = 1; nf.vseq = vseq; nf.chained = chained;
+    nf.a = *a; nf.set = set; nf.stage = 0; nf.vseq = vseq; nf.chained = chained;
     if (chained) { h->unreconciled.push_back(lcd_engine::DevAppend{vseq, a->first_new_word_id, q, app}); h->vseq += 1; }
-    ResolveArgs& r = nf.r;
-    r.rp = RowparArgs{};
-    r.q = q; r.flags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0); r.nndr = a->nndr_ratio; r.have_index = 1;
-    r.knn_word = k.out_word; r.knn_dist = k.out_dist; r.selfdist = together ? sc.d_selfdist.as<float>() : nullptr; r.ld = ld;
-    r.cand_bits = together ? sc.d_bits.as<uint32_t>() : nullptr; r.bw = bw; r.out_word = a->d_word_ids; r.out_n_new = h->d_n_new.as<int32_t>();
-    r.cand_list = together ? k.cb.list : nullptr; r.cand_cnt = together ? k.cb.cnt : nullptr;
-    r.knn_row = k.out_row; r.row_wslot = h->row_wslot.as<int32_t>(); r.out_wslot = sc.d_out_wslot.as<int32_t>(); r.new_ws = WsRuns();
-    r.fail_count = sc.d_fail_count.as<int32_t>();
-    {   // the exact redo of rejected queries rides with the decision loop (fill_redo, with this frame's scratch set)
-        RowparArgs& rp = r.rp;
-        rp.enabled = 1; rp.vocab = (const float*)h->vocab.p; rp.row_id = h->row_id.as<int32_t>(); rp.n_rows = (int)plan_rows;
-        rp.n_rows_dev = k.n_hi;                                      // the rows that exist when the redo runs: after the previous frame's append
-        rp.queries = (const float*)a->d_descriptors; rp.fail_list = sc.d_fail_list.as<int32_t>(); rp.partial = (unsigned long long*)sc.d_partial3.p;
-        rp.out_row = k.out_row; rp.out_word = k.out_word; rp.out_dist = k.out_dist;
-        if (together) rp.cb = k.cb;
-    }
     h->inflight.push_back(std::move(nf));
     h->frame_seq += 1;
     return LCD_OK;
@@ -1626,6 +1655,7 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     if (!std::strcmp(key, "score_block") && (value == 256 || value == 512 || value == 1024)) { h->tfidf.score_block = (int)value; return LCD_OK; }
     // compute units the bf16 filter's persistent launch plans for (vocabularies of more 256-word strips than that): -1 built-in, 0 off
     if (!std::strcmp(key, "filter_units") && value >= -1 && value <= 4096) { h->filter_units = (int)value; return LCD_OK; }
+    if (!std::strcmp(key, "strip_tiles") && value >= 0 && value <= 8) { h->strip_tiles = (int)value; return LCD_OK; }
     // 0: lcd_profile_begin brackets only the 2-NN launch of a pipelined frame (an event pair costs the stream ~10 us)
     if (!std::strcmp(key, "profile_likelihood") && (value == 0 || value == 1)) { h->prof_likelihood = value != 0; return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");

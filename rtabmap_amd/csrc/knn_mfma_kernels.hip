@@ -754,6 +754,174 @@ __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, cons
     MF_STAMP(3);
 }
 
+// ------------------------------------------------------------------------------------------------ pre-split queries (pipelined frames)
+// Every strip's workgroup of the body above stages the SAME 512 queries through 128 KB of LDS and splits them into bf16 operands --
+// 192 times per frame, and the staging area is what makes a filter workgroup own a whole compute unit's LDS.  A pipelined handle
+// knows a frame one launch before its filter runs: the launch that carries the previous frame's filter also converts the new
+// frame's queries ONCE (qsplit_body, a handful of small workgroups) into MFMA operand order in global memory:
+//     qsplit[(((query / 32) * 4 + s) * 2 + kind) * 64 + lane]   uint4 = eight bf16 of  -2 q[32 * (lane >> 5) + 8 s .. + 8)  (kind 0: hi, 1: lo)
+//     qnorm[query] = |q|^2
+// so that the filter's prologue is 32 coalesced 16-byte loads per lane straight into the registers the operands live in, its LDS holds
+// only the strip (8 tiles + augmentation entries = 66 KB) and TWO workgroups share a compute unit.
+constexpr size_t BF_LDS_BYTES_Q = (size_t)MF_STRIP_TILES * BF_TILE_F * 4 + (size_t)MF_STRIP_TILES * 64 * 4;
+
+__device__ __forceinline__ void qsplit_body(const QSplitArgs& qs, int wg) {
+    for (int t = wg * (int)blockDim.x + (int)threadIdx.x; t < qs.qpad * 8; t += qs.n_wgs * (int)blockDim.x) {   // (qpad * 8 is a multiple of 64)
+        const int qi = t >> 3, h = (t >> 2) & 1, sx = t & 3;
+        const float4* src = reinterpret_cast<const float4*>(qs.queries + (size_t)min(qi, qs.nq - 1) * 64 + 32 * h + 8 * sx);   // padding repeats the last query
+        const float4 a = src[0], b = src[1];
+        uint4 hi, lo;
+        bf16_split2(-2.0f * a.x, -2.0f * a.y, hi.x, lo.x);
+        bf16_split2(-2.0f * a.z, -2.0f * a.w, hi.y, lo.y);
+        bf16_split2(-2.0f * b.x, -2.0f * b.y, hi.z, lo.z);
+        bf16_split2(-2.0f * b.z, -2.0f * b.w, hi.w, lo.w);
+        const size_t base = ((size_t)(qi >> 5) * 4 + sx) * 2;
+        qs.qsplit[(base + 0) * 64 + h * 32 + (qi & 31)] = hi;
+        qs.qsplit[(base + 1) * 64 + h * 32 + (qi & 31)] = lo;
+        float part = fmaf(b.w, b.w, fmaf(b.z, b.z, fmaf(b.y, b.y, fmaf(b.x, b.x, fmaf(a.w, a.w, fmaf(a.z, a.z, fmaf(a.y, a.y, a.x * a.x)))))));
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        if ((t & 7) == 0) qs.qnorm[qi] = part;
+    }
+}
+
+// the filter body over pre-split queries: as knn_bf16_filter_body<4> (one strip per workgroup), without the query staging
+__device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
+                                                       int n_rows, const uint4* qsplit, const float* qnorm, int nq, int qpad,
+                                                       int tiles_per_block, int n_blocks, uint64_t* __restrict__ partial_keys,
+                                                       uint32_t* __restrict__ partial_bound, const SelfdistJob& sd, const int32_t* __restrict__ n_lo) {
+    constexpr int NG = 4;
+    constexpr int NW = MF_WAVES;
+    constexpr int QW = NG * 32;
+    constexpr int DPW = 8 / NW;
+    // the rows this search may see (see knn_bf16_filter_body), through the scalar cache: a vector load would sit in the same in-order
+    // queue as the strip's requests below, and its first use would wait for all of them
+    int lo_rows = 0x7fffffff;
+    if (n_lo) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lo_rows) : "s"(n_lo) : "memory");
+    const int n_fwg = n_blocks * ((nq + BF_QB - 1) / BF_QB);
+    if (bid >= n_fwg) { selfdist_tile(sd, bid - n_fwg, s_dyn); return; }
+    const int bx = bid % n_blocks, by = bid / n_blocks;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int q0 = by * BF_QB + wave * QW;
+    float* s_aug = s_dyn + (size_t)MF_STRIP_TILES * BF_TILE_F;          // [MF_STRIP_TILES][64]
+    MF_STAMP(0);
+    const int tile0 = bx * tiles_per_block;
+    const int n_tiles = (n_rows + 31) / 32;
+    const int tile1 = min(tile0 + tiles_per_block, n_tiles);
+    // First what the loop needs to start -- two tiles, the augmentation entries, the query operands -- and, once that has arrived, the
+    // rest of the strip, which lands while the first two tiles are multiplied.  (Requested all at once and awaited in front of the loop,
+    // the strip cost 3.6 us per workgroup: every workgroup of the launch asks at the same moment, so the last byte of anybody's strip
+    // arrives when the whole vocabulary has crossed the fabric.  Requested all at once and awaited tile by tile is not expressible:
+    // the compiler waits for EVERY outstanding request at the first use of an operand register while LDS-DMA is in flight.)
+    const int tile_last = max(tile1 - 1, tile0);
+    dma_tile_part(vocab_bf, n_rows, tile0, lane, s_dyn, DPW * wave, DPW * wave + DPW);
+    dma_tile_part(vocab_bf, n_rows, min(tile0 + 1, tile_last), lane, s_dyn + BF_TILE_F, DPW * wave, DPW * wave + DPW);
+    // the augmentation entries of the strip go straight to LDS as well, two tiles per wave (the mask of rows that do not exist yet
+    // is patched into them below)
+    static_assert(MF_STRIP_TILES == 2 * NW, "two augmentation rows per wave");
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = 2 * wave + j;
+        const int t = min(tile0 + i, tile_last);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row_norm + 2 * (size_t)min(t * 32 + col, n_rows) + half),
+                                         (__attribute__((address_space(3))) void*)(s_aug + i * 64), 4, 0, 0);
+    }
+    uint4 bh[NG][4], bl[NG][4];
+    float b_aug[NG];
+    const int grp0 = q0 >> 5;
+    const int n_grp = qpad >> 5;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int grp = min(grp0 + g, n_grp - 1);                       // (a wave beyond the padded queries repeats the last group: its keys are not written)
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) {
+            const size_t base = ((size_t)grp * 4 + sx) * 2;
+            bh[g][sx] = qsplit[(base + 0) * 64 + lane];
+            bl[g][sx] = qsplit[(base + 1) * 64 + lane];
+        }
+        const float qn = qnorm[min(grp * 32 + col, qpad - 1)];
+        b_aug[g] = half == 0 ? 1.0f : qn;
+    }
+    // (a use of the youngest request here: the compiler waits for it -- and with it for everything older -- at this point, and knows
+    // from then on that the operand registers are complete; left alone it would wait at their first use, behind the requests below)
+    asm volatile("" : "+v"(b_aug[NG - 1]) : : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int t = tile0 + 2; t < tile1; ++t)
+        dma_tile_part(vocab_bf, n_rows, t, lane, s_dyn + (size_t)(t - tile0) * BF_TILE_F, DPW * wave, DPW * wave + DPW);
+    if ((tile0 + MF_STRIP_TILES) * 32 > lo_rows) {                       // (rare: the strip reaches rows that are being appended while this launch runs)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = 2 * wave + j;
+            if (half == 0 && (tile0 + i) * 32 + col >= lo_rows)
+                asm volatile("ds_write_b32 %0, %1" ::"v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(s_aug + i * 64 + lane)),
+                             "v"(__int_as_float(0x7f800000)) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                                        // every wave's share of tiles 0, 1 and the augmentation entries are in LDS
+    MF_STAMP(1);
+    int32_t k0[NG], k1[NG], k2[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { k0[g] = MF_KEY_NONE; k1[g] = MF_KEY_NONE; k2[g] = MF_KEY_NONE; }
+    f32x16 p0, p1;
+    for (int t = tile0; t < tile1; ++t) {
+        const int ti = t - tile0;
+        if (ti == 2) {                                                   // tiles 2.. : one wait and one barrier for all of them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        uint4 ah[4], al[4];
+        float aug;
+        {
+            const float* slot = s_dyn + (size_t)ti * BF_TILE_F;
+            const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(slot + col * 64);
+            uint32_t addr[8];
+            uint4 av[8];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                addr[v] = base + ((((uint32_t)(4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
+                addr[4 + v] = base + ((((uint32_t)(8 + 4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
+            }
+            lds_read8_b128(addr, av, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(s_aug + ti * 64 + lane), aug);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { ah[v] = av[v]; al[v] = av[4 + v]; }
+        }
+        const uint32_t tl = (uint32_t)ti;
+        f32x16 x0, x1;
+        if (t == tile0) bf_pair<false>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, 0u, k0[2], k1[2], k2[2],
+                                       k0[3], k1[3], k2[3]);
+        else bf_pair<true>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, tl - 1u, k0[2], k1[2], k2[2], k0[3],
+                           k1[3], k2[3]);
+        bf_pair<true>(ah, al, aug, bh[2], bl[2], b_aug[2], bh[3], bl[3], b_aug[3], p0, p1, x0, x1, tl, k0[0], k1[0], k2[0], k0[1], k1[1], k2[1]);
+    }
+    if (tile0 < tile1) {
+        const uint32_t tlast = (uint32_t)(tile1 - 1 - tile0);
+        push_group(p0, tlast, k0[NG - 2], k1[NG - 2], k2[NG - 2]);
+        push_group(p1, tlast, k0[NG - 1], k1[NG - 1], k2[NG - 1]);
+    }
+    MF_STAMP(2);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const uint64_t a0 = widen_key(k0[g], tile0, half), a1 = widen_key(k1[g], tile0, half), a2 = widen_key(k2[g], tile0, half);
+        const uint64_t b0 = shfl_xor_u64(a0, 32), b1 = shfl_xor_u64(a1, 32), b2 = shfl_xor_u64(a2, 32);
+        const uint64_t m0 = a0 < b0 ? a0 : b0;
+        const uint64_t hx = a0 < b0 ? b0 : a0, lx = a1 < b1 ? a1 : b1;
+        const uint64_t m1 = hx < lx ? hx : lx;
+        const uint64_t third = third_of_two_triples(a0, a1, a2, b0, b1, b2);
+        const int qi = q0 + g * 32 + col;
+        if (half == 0 && qi < qpad) {
+            uint64_t* dst = partial_keys + ((size_t)qi * n_blocks + bx) * BF_KEEP;
+            dst[0] = m0;
+            dst[1] = m1;
+            partial_bound[(size_t)qi * n_blocks + bx] = (uint32_t)min(third >> 32, (uint64_t)0x7f800000u);
+        }
+    }
+    MF_STAMP(3);
+}
+
 // ------------------------------------------------------------------------------------------------ persistent variant
 // Vocabularies of more than BF_PX strips (> ~60k words): a workgroup keeps its queries in registers and walks several strips
 // (strip bx0, bx0 + px, ...) instead of staging and splitting the same 512 queries once per strip -- with one workgroup per compute
@@ -1273,6 +1441,7 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
 struct FilterArgs {
     const float* vocab_bf; const float* row_norm; int n_rows; const float* queries; int nq, qpad, tiles_per_block, n_blocks;
     uint64_t* pk; uint32_t* pl; SelfdistJob sd; const int32_t* n_lo;
+    const uint4* qsplit; const float* qnorm;                           // pre-split queries (non-persistent pipelined launch)
 };
 struct RerankArgs {
     const uint64_t* pk; const uint32_t* pl; int n_blocks, nq; const float* vocab; const float* queries; const int32_t* row_id;
@@ -1284,38 +1453,42 @@ constexpr int PIPE_BLOCK = 256;     // workgroup size of both fused launches (th
 // workgroup 0 is the decision loop of the previous frame, workgroup 1 the retirement + registration of the frame before that (dispatched
 // first: they are the longest single workgroups of the launch); the redo helpers of the decision loop come LAST -- they have nothing
 // to do unless the certificate rejected a query, and in front they would each hold a compute unit's LDS while they find out
-struct TailRoles { int has_resolve, has_register, n_redo, n_filter_wgs; };
+struct TailRoles { int has_resolve, has_register, n_redo, n_filter_wgs, n_q_wgs; };
 #ifdef LCD_B_TIMING   // timing experiment only: start / end of every workgroup of launch A (100 MHz)
 __device__ unsigned long long g_a_timing[2 * 4096];
 #define A_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4096) g_a_timing[2 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define A_STAMP(i) do { } while (0)
 #endif
+// grid order: decision loop, registration, filter workgroups (+ distance tiles), query pre-split workgroups, redo helpers
 template <bool PERSISTENT>
 __device__ __forceinline__ void frame_a_body(float* s_dyn, const FilterArgs& f, int px, const TailRoles& tr, const ResolveArgs& r, const FwArgs& a,
-                                             const RetireArgs& ret) {
+                                             const RetireArgs& ret, const QSplitArgs& qs) {
     const int bid = (int)blockIdx.x;
     const int n_front = tr.has_resolve + tr.has_register;
     A_STAMP(0);
     if (bid < tr.has_resolve) { frame_resolve_part<PIPE_BLOCK>((uint32_t*)s_dyn, r, 0, 1 + tr.n_redo); A_STAMP(1); return; }
     if (bid < n_front) { frame_register_part<PIPE_BLOCK>((uint32_t*)s_dyn, a, ret); A_STAMP(1); return; }
-    if (bid >= n_front + tr.n_filter_wgs) { frame_resolve_part<PIPE_BLOCK>((uint32_t*)s_dyn, r, bid - n_front - tr.n_filter_wgs + 1, 1 + tr.n_redo); A_STAMP(1); return; }
+    const int after_filter = n_front + tr.n_filter_wgs;
+    if (bid >= after_filter && bid < after_filter + tr.n_q_wgs) { qsplit_body(qs, bid - after_filter); A_STAMP(1); return; }
+    if (bid >= after_filter + tr.n_q_wgs) { frame_resolve_part<PIPE_BLOCK>((uint32_t*)s_dyn, r, bid - after_filter - tr.n_q_wgs + 1, 1 + tr.n_redo); A_STAMP(1); return; }
     if constexpr (PERSISTENT)
         knn_bf16_filter_body_p(s_dyn, bid - n_front, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, px, f.pk,
                                f.pl, f.sd, f.n_lo);
     else
-        knn_bf16_filter_body<4>(s_dyn, bid - n_front, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, f.pk, f.pl,
-                                f.sd, f.n_lo);
+        knn_bf16_filter_body_q(s_dyn, bid - n_front, f.vocab_bf, f.row_norm, f.n_rows, f.qsplit, f.qnorm, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, f.pk,
+                               f.pl, f.sd, f.n_lo);
     A_STAMP(1);
 }
-__global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel(FilterArgs f, TailRoles tr, ResolveArgs r, FwArgs a, RetireArgs ret) {
+// two workgroups per compute unit: 66 KB of LDS each, and a register budget of two waves per SIMD
+__global__ __launch_bounds__(PIPE_BLOCK, 2) void frame_a_kernel(FilterArgs f, TailRoles tr, ResolveArgs r, FwArgs a, RetireArgs ret, QSplitArgs qs) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn_a[];
-    frame_a_body<false>(s_dyn_a, f, 0, tr, r, a, ret);
+    frame_a_body<false>(s_dyn_a, f, 0, tr, r, a, ret, qs);
 }
 // the same launch over a vocabulary of more strips than compute units: persistent filter workgroups (knn_bf16_filter_body_p)
-__global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel_p(FilterArgs f, int px, TailRoles tr, ResolveArgs r, FwArgs a, RetireArgs ret) {
+__global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel_p(FilterArgs f, int px, TailRoles tr, ResolveArgs r, FwArgs a, RetireArgs ret, QSplitArgs qs) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn_ap[];
-    frame_a_body<true>(s_dyn_ap, f, px, tr, r, a, ret);
+    frame_a_body<true>(s_dyn_ap, f, px, tr, r, a, ret, qs);
 }
 #ifdef LCD_B_TIMING   // timing experiment only: start / end of every workgroup of launch B (100 MHz)
 __device__ unsigned long long g_b_timing[2 * 4096];
@@ -1500,7 +1673,7 @@ hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void*
 static int bf16_persistent_px(const MfmaPlan& p) {
     const int cus = p.filter_units >= 0 ? p.filter_units : 256 - p.other_wgs;
     const int qchunks = (p.q + BF_QB - 1) / BF_QB;
-    if (cus == 0 || qchunks <= 0 || p.n_blocks * qchunks <= (p.filter_units >= 0 ? 256 : cus)) return 0;
+    if (p.one_strip || cus == 0 || qchunks <= 0 || p.n_blocks * qchunks <= (p.filter_units >= 0 ? 256 : cus)) return 0;
     const int px_max = cus / qchunks > 0 ? cus / qchunks : 1;
     const int rounds = (p.n_blocks + px_max - 1) / px_max;
     return (p.n_blocks + rounds - 1) / rounds;                          // equal shares: ceil(strips / rounds) workgroups of <= rounds strips
@@ -1581,27 +1754,40 @@ hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, 
 int pipe_block_size() { return PIPE_BLOCK; }
 int pipe_b_block_size() { return PIPE_B_BLOCK; }
 
-hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* resolve, const TailLaunch* reg, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
-    const MfmaPlan& p = k.plan;
+size_t knn_qsplit_bytes(int q) { return (size_t)((q + 63) / 64 * 64) * 256; }
+
+hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLaunch* resolve, const TailLaunch* reg, hipStream_t s, hipEvent_t ev_begin,
+                          hipEvent_t ev_end) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       (int)BF_LDS_BYTES);
+                                                       (int)BF_LDS_BYTES_Q);
     (void)attr;
-    uint64_t* pk = (uint64_t*)k.partial;
-    uint32_t* pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * BF_KEEP * p.qpad);
-    FilterArgs f;
-    f.vocab_bf = (const float*)k.vocab_bf; f.row_norm = k.row_norm; f.n_rows = p.n_rows; f.queries = (const float*)k.queries; f.nq = p.q; f.qpad = p.qpad;
-    f.tiles_per_block = p.tiles_per_block; f.n_blocks = p.n_blocks; f.pk = pk; f.pl = pl; f.n_lo = k.n_lo;
-    f.sd = SelfdistJob();
-    if (k.cb.selfdist) {                                              // the same-frame distance matrix rides along
-        f.sd.queries = (const float*)k.queries; f.sd.nq = p.q; f.sd.out = const_cast<float*>(k.cb.selfdist); f.sd.ld = k.cb.ld; f.sd.n_tiles = selfdist_tiles(p.q);
+    FilterArgs f{};
+    MfmaPlan p;
+    p.q = 0; p.qpad = 0; p.n_rows = 0; p.tiles_per_block = 1; p.n_blocks = 0;
+    if (kp) {
+        const PipeKnn& k = *kp;
+        p = k.plan;
+        uint64_t* pk = (uint64_t*)k.partial;
+        uint32_t* pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * BF_KEEP * p.qpad);
+        f.vocab_bf = (const float*)k.vocab_bf; f.row_norm = k.row_norm; f.n_rows = p.n_rows; f.queries = (const float*)k.queries; f.nq = p.q; f.qpad = p.qpad;
+        f.tiles_per_block = p.tiles_per_block; f.n_blocks = p.n_blocks; f.pk = pk; f.pl = pl; f.n_lo = k.n_lo;
+        f.qsplit = (const uint4*)k.qsplit; f.qnorm = k.qnorm;
+        if (k.cb.selfdist) {                                          // the same-frame distance matrix rides along
+            f.sd.queries = (const float*)k.queries; f.sd.nq = p.q; f.sd.out = const_cast<float*>(k.cb.selfdist); f.sd.ld = k.cb.ld; f.sd.n_tiles = selfdist_tiles(p.q);
+        }
     }
     const int px = p.q > 0 ? bf16_persistent_px(p) : 0;
+    if (px == 0 && p.q > 0 && (!f.qsplit || !f.qnorm)) return hipErrorInvalidValue;      // the one-strip launch reads pre-split queries
     TailRoles tr;
     tr.n_filter_wgs = p.q > 0 ? f.sd.n_tiles + (px > 0 ? px : p.n_blocks) * ((p.q + BF_QB - 1) / BF_QB) : 0;
     tr.has_resolve = resolve ? 1 : 0; tr.has_register = reg ? 1 : 0; tr.n_redo = resolve ? resolve->n_redo : 0;
-    const int grid = tr.n_filter_wgs + tr.has_resolve + tr.has_register + tr.n_redo;
+    QSplitArgs qs{};
+    if (qsp) { qs = *qsp; qs.n_wgs = (qs.qpad * 8 + PIPE_BLOCK * 2 - 1) / (PIPE_BLOCK * 2); if (qs.n_wgs < 1) qs.n_wgs = 1; }
+    tr.n_q_wgs = qsp ? qs.n_wgs : 0;
+    const int grid = tr.n_filter_wgs + tr.has_resolve + tr.has_register + tr.n_redo + tr.n_q_wgs;
     if (grid == 0) return hipSuccess;
-    if ((resolve && resolve->shmem_resolve > BF_LDS_BYTES) || (reg && reg->shmem > BF_LDS_BYTES)) return hipErrorInvalidValue;
+    const size_t lds = px > 0 ? BF_LDS_BYTES_P : BF_LDS_BYTES_Q;
+    if ((resolve && resolve->shmem_resolve > lds) || (reg && reg->shmem > lds)) return hipErrorInvalidValue;
     ResolveArgs r{}; FwArgs a{}; RetireArgs ret{};
     if (resolve) r = resolve->r;
     if (reg) { a = reg->a; ret = reg->ret; }
@@ -1611,9 +1797,9 @@ hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* resolve, const Tai
         static const hipError_t attrp = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel_p),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES_P);
         (void)attrp;
-        frame_a_kernel_p<<<grid, PIPE_BLOCK, BF_LDS_BYTES_P, s>>>(f, px, tr, r, a, ret);
+        frame_a_kernel_p<<<grid, PIPE_BLOCK, BF_LDS_BYTES_P, s>>>(f, px, tr, r, a, ret, qs);
     } else
-        frame_a_kernel<<<grid, PIPE_BLOCK, BF_LDS_BYTES, s>>>(f, tr, r, a, ret);
+        frame_a_kernel<<<grid, PIPE_BLOCK, BF_LDS_BYTES_Q, s>>>(f, tr, r, a, ret, qs);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }
@@ -1645,6 +1831,13 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
 }
 
 }  // namespace lcd
+
+#ifdef LCD_SCORE_TIMING   // timing experiment only: the phase stamps of the scoring workgroups of launch B (this translation unit's copy)
+extern "C" int lcd_debug_score_timing_pipe(unsigned long long* out, int n_words) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcd::g_score_timing), (size_t)n_words * 8);
+}
+#endif
 
 #ifdef LCD_TAIL_TIMING   // timing experiment only: the stamps of the tail that ran inside the fused filter launch (this translation unit's copy)
 extern "C" int lcd_debug_tail_timing_pipe(unsigned long long* out) {

@@ -79,6 +79,7 @@ struct MfmaPlan {
     int q, qpad, n_rows, tiles_per_block, n_blocks;
     int filter_units = -1;   // compute units the persistent bf16 filter plans for (-1: built-in; 0: one workgroup per strip always)
     int other_wgs = 0;       // long-running workgroups of other kinds in the same launch (each holds a compute unit like a filter workgroup)
+    int one_strip = 0;       // 1: one workgroup per strip whatever the number of strips (lcd_set_option "strip_tiles")
 };
 bool knn_mfma_supported(int dtype, int dim);
 bool knn_bf16_persistent(const MfmaPlan& p);   // the bf16 filter launch of this plan uses the persistent kernels (..._kernel_p)

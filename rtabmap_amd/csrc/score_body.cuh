@@ -65,12 +65,10 @@ __device__ __forceinline__ void score_sealed_body(const ScoreArgs& A, int b) {
     const int tid = threadIdx.x;
     const BucketDev B = A.tab[b];
     const long long first_slot = (long long)b * TF_R;
-    if (B.state != 1u) {                                            // every signature of the bucket is retired
-        for (int i = tid; i < TF_R; i += SCB) {
-            if (A.out_like) A.out_like[first_slot + i] = 0.0f; else A.out_fix[first_slot + i] = 0;
-        }
-        return;
-    }
+    // A bucket whose signatures are all retired has no rows and no directory below (D = 0, W = 0: every sum stays 0, and ni = 0 writes
+    // 0 like the reference's "if(ni != 0)").  No early exit on B.state: the branch would put the bucket record's round trip in front
+    // of every other load of the workgroup.
+    const bool live = B.state == 1u;
     SC_STAMP(0);
     constexpr int NWV = SCB / 64;
     // dense rows per wavefront and trip.  (24 rows for the 4-wave workgroups of the fused launch -- one trip instead of two for the ~95
@@ -83,25 +81,32 @@ __device__ __forceinline__ void score_sealed_body(const ScoreArgs& A, int b) {
     constexpr int KW = SCB >= 512 ? 1 : 512 / SCB;                  // frame words per thread in the fused first pass
     constexpr int NI = TF_R / SCB > 0 ? TF_R / SCB : 1;             // signatures whose ni a thread carries
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
-    const uint32_t D = A.bkt_D[b];
+    const uint32_t D = live ? A.bkt_D[b] : 0u;
+    const uint32_t BW = live ? B.W : 0u;
     const uint32_t flags = A.bkt_flags[b];
     const int U = (int)A.q_meta[0];
     const int Ud = (int)A.q_meta[1];
-    // ---- stage A: the frame's lists (L2-resident: every workgroup reads the same few KB), ni
+    // ---- stage A: the frame's lists (every workgroup reads the same few KB), ni.  The lists are read WITHOUT looking at their lengths
+    //      first (the buffers hold TF_MAX_WORDS entries; what lies beyond U / Ud is masked afterwards): one round trip for the bucket
+    //      record, the lengths and the lists instead of two.
+    static_assert(KW * SCB <= TF_MAX_WORDS && DR * NWV <= TF_MAX_WORDS, "the unconditional list reads stay inside the buffers");
     uint32_t w[KW]; int32_t idf[KW], did[KW]; bool look[KW];
 #pragma unroll
     for (int u = 0; u < KW; ++u) {
         const int k = tid + u * SCB;
-        w[u] = 0; idf[u] = 0; did[u] = -1;
-        if (k < U) { w[u] = A.q_w[k]; idf[u] = A.q_idf[k]; did[u] = A.q_did[k]; }
+        w[u] = A.q_w[k]; idf[u] = A.q_idf[k]; did[u] = A.q_did[k];
     }
     int32_t dj[DR], fj[DR];
 #pragma unroll
     for (int u = 0; u < DR; ++u) {
         const int j = wv + u * NWV;                                  // wave-uniform: scalar loads
-        dj[u] = j < Ud ? A.qd_did[j] : -1;
-        fj[u] = j < Ud ? A.qd_idf[j] : 0;
+        dj[u] = A.qd_did[j];
+        fj[u] = A.qd_idf[j];
     }
+#pragma unroll
+    for (int u = 0; u < KW; ++u) { if (tid + u * SCB >= U) { w[u] = 0; idf[u] = 0; did[u] = -1; } }
+#pragma unroll
+    for (int u = 0; u < DR; ++u) { if (wv + u * NWV >= Ud) { dj[u] = -1; fj[u] = 0; } }
     uint32_t ni_v[NI];
 #pragma unroll
     for (int u = 0; u < NI; ++u) { const int i = tid + u * SCB; ni_v[u] = i < TF_R ? A.slot_ni[first_slot + i] : 0u; }
@@ -110,7 +115,7 @@ __device__ __forceinline__ void score_sealed_body(const ScoreArgs& A, int b) {
 #pragma unroll
     for (int u = 0; u < KW; ++u) {
         const bool dense_here = did[u] >= 0 && (uint32_t)did[u] < D;
-        look[u] = idf[u] != 0 && w[u] < B.W && (!dense_here || (flags & 1u));   // a dense word has sparse postings only for counts > 255
+        look[u] = idf[u] != 0 && w[u] < BW && (!dense_here || (flags & 1u));   // a dense word has sparse postings only for counts > 255
         r0[u] = make_uint4(0u, 0u, 0u, 0u); r1[u] = r0[u];
         if (look[u]) {
             const uint4* rec = reinterpret_cast<const uint4*>(A.dir2 + ((size_t)(w[u] >> 5) * A.dir2_stride + (uint32_t)b) * TF_DIR2_DWORDS);
@@ -201,7 +206,7 @@ __device__ __forceinline__ void score_sealed_body(const ScoreArgs& A, int b) {
             idf2 = A.q_idf[k];
             const int32_t d2 = A.q_did[k];
             const bool dh = d2 >= 0 && (uint32_t)d2 < D;
-            if (idf2 != 0 && w2 < B.W && (!dh || (flags & 1u))) {
+            if (idf2 != 0 && w2 < BW && (!dh || (flags & 1u))) {
                 const uint2 bk = gload2(B.dirb + (w2 >> 5));
                 const uint32_t bit = 1u << (w2 & 31);
                 if (bk.x & bit) {

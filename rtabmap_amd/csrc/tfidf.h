@@ -170,16 +170,22 @@ struct PipeKnn {
     const void* vocab; const void* vocab_bf; const float* row_norm; const uint32_t* norm_max_bits; const int32_t* row_id; const void* queries;
     void* partial; int32_t* out_row; int32_t* out_word; float* out_dist; int32_t* fail_list; int32_t* fail_count;
     CandBits cb;               // cb.selfdist != NULL: the filter launch also fills the same-frame distance matrix
+    const void* qsplit = nullptr;    // the frame's queries, pre-split into bf16 MFMA operands by the previous launch (QSplitArgs), and their
+    const float* qnorm = nullptr;    // norms: what the one-strip filter of a pipelined launch reads instead of the descriptors
     const int32_t* n_lo = nullptr;   // device row counts (NULL: the host's plan.n_rows is exact): the filter sees rows [0, n_lo[0]), the re-rank
     const int32_t* n_hi = nullptr;   // also scans [n_lo[0], n_hi[0]) exactly -- the words the previous frame appended meanwhile (AppendArgs)
 };
+// the new frame's queries -> MFMA operand order in global memory (knn_mfma_kernels.hip, qsplit_body): a few workgroups of launch A
+struct QSplitArgs { const float* queries; int nq, qpad; uint4* qsplit; float* qnorm; int n_wgs; };
+size_t knn_qsplit_bytes(int q);
 int pipe_block_size();      // workgroup size of launch A (the filter's)
 int pipe_b_block_size();    // workgroup size of launch B (re-rank + scoring)
 void resolve_launch_info(const ResolveArgs& r, int block, int* n_redo, size_t* shmem);
 // filter of the newest frame + the decision loop of one earlier frame (resolve: r / n_redo / shmem_resolve of that TailLaunch) + the
 // registration of a still earlier one (reg: a / ret / shmem); either may be NULL
-hipError_t launch_frame_a(const PipeKnn& k, const TailLaunch* resolve, const TailLaunch* reg, hipStream_t s, hipEvent_t ev_begin = nullptr,
-                          hipEvent_t ev_end = nullptr);
+// k: the frame whose filter runs (NULL: none); qs: the frame whose queries are pre-split for the NEXT launch's filter (NULL: none)
+hipError_t launch_frame_a(const PipeKnn* k, const QSplitArgs* qs, const TailLaunch* resolve, const TailLaunch* reg, hipStream_t s,
+                          hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wgs, hipStream_t s, hipEvent_t ev_begin = nullptr,
                           hipEvent_t ev_end = nullptr);
 

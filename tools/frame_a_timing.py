@@ -20,6 +20,9 @@ def main():
     vocab = synth.vocab_surf(n_words)
     words = synth.zipf_words(n_sig, q, n_words, seed=100000)
     eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 65536, sig_capacity=n_sig + 4096, pipeline=True)
+    for kv in filter(None, os.environ.get("LCD_BENCH_OPTS", "").split(",")):
+        eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    strip = int(os.environ.get("LCD_BENCH_OPTS", "strip_tiles=0").split("strip_tiles=")[-1].split(",")[0] or 0)
     eng.vocab_append(vocab, np.arange(1, n_words + 1, dtype=np.int32))
     eng.sig_add_bulk(np.arange(1, n_sig + 1, dtype=np.int32), np.arange(0, (n_sig + 1) * q, q, dtype=np.int64), words.reshape(-1))
     d_words = torch.zeros(q, dtype=torch.int32, device="cuda")
@@ -63,7 +66,7 @@ def main():
             b = np.frombuffer(ab, dtype=np.uint64).reshape(-1, 2).astype(np.float64)
             idx = np.nonzero(b[:, 1] > b[:, 1].max() - 20000)[0]
             b = (b[idx] - b[idx, 0].min()) / 100.0
-            n_f = 192 if n_words == 49000 else None
+            n_f = (-(-((n_words + 31) // 32) // strip) if strip else 256) if n_words == 49000 else None
             print("launch A: %d workgroups stamped" % len(idx))
             groups = [("decision loop", idx == 0), ("registration", idx == 1)]
             if n_f:
@@ -87,6 +90,23 @@ def main():
                     print("  %-8s start min %5.2f median %5.2f max %5.2f | end median %5.2f p90 %5.2f max %5.2f | duration median %5.2f p90 %5.2f max %5.2f" %
                           (nme, st.min(), np.median(st), st.max(), np.median(en), np.percentile(en, 90), en.max(), np.median(en - st),
                            np.percentile(en - st, 90), (en - st).max()))
+        if rep == 5:
+            rb = np.array(tb[8:16], dtype=np.float64); ft = np.array(tb[0:8], dtype=np.float64)
+            print("decision loop stamps (us after its first): " + " ".join("%.2f" % ((x - rb[0]) / 100.0) for x in rb[:6]) +
+                  "   [entry | neighbours + rows read | reject mask | sweeps done | prefix | word ids written]")
+            print("tail stamps (us after the first): " + " ".join("%.2f" % ((x - ft[0]) / 100.0) for x in ft))
+            sw = np.array(tb[16:48], dtype=np.float64).reshape(4, 8)
+            print("first sweep, wave 0 (us after the decision loop's entry): " + " ".join("%.2f" % ((x - rb[0]) / 100.0) for x in sw[0]))
+        if hasattr(lib, "lcd_debug_score_timing_pipe") and rep == 5:
+            sb = (ctypes.c_ulonglong * (1024 * 8))()
+            assert lib.lcd_debug_score_timing_pipe(sb, 1024 * 8) == 0
+            s = np.frombuffer(sb, dtype=np.uint64).reshape(-1, 8).astype(np.float64)[:, :4]
+            m = (s[:, 0] > s[:, 0].max() - 20000) & (s[:, 3] >= s[:, 0])
+            s = (s[m] - s[m, 0].min()) / 100.0
+            print("launch B scoring phases, %d sealed-bucket workgroups (us after the first one started):" % m.sum())
+            for i, nme in enumerate(["start", "lists + directory + dense rows read", "dense sums in LDS", "sparse postings done"]):
+                c = s[:, i]
+                print("  %-38s min %5.2f median %5.2f p90 %5.2f max %5.2f" % (nme, c.min(), np.median(c), np.percentile(c, 90), c.max()))
         eng.synchronize()
     f, tl = res[-1]
     print("%d filter waves in the last launch" % len(f))
