@@ -193,7 +193,7 @@ def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None
     if profile_eng is not None:
         # HIP events around the dominant launch of the first timed steps (a tenth of them, at least 3): an event pair costs the stream
         # ~10 us, so the timed region brackets ONE launch per sampled frame; the other big kernel is bracketed in an untimed leg
-        profile_eng.profile_begin(max(3, steps // 10))
+        profile_eng.profile_begin(int(os.environ.get("LCD_BENCH_PROF_N", max(3, steps // 10))))
     t0 = time.perf_counter()
     rec(evs[0])
     for i in range(steps):
@@ -789,8 +789,8 @@ def main():
     ap.add_argument("--pmc", action="store_true", help="measure HBM traffic with rocprofv3 even with --no-cpu-baseline")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure HBM traffic with rocprofv3 (two extra short runs of this script)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (unpipelined, host path, with update)")
-    ap.add_argument("--pipeline", type=int, default=1, help="1: software-pipelined frames (the launches of frame t carry the registration "
-                    "and scoring of frame t-1); 0: four launches per frame, nothing overlapped")
+    ap.add_argument("--pipeline", type=int, default=1, help="1: software-pipelined frames (the launches of frame t carry the filter, decision loop, "
+                    "registration and scoring of the three frames before it); 0: four launches per frame, nothing overlapped")
     ap.add_argument("--parallelism", choices=["shard", "replicas"], default="shard",
                     help="N > 1: ONE frame stream with the vocabulary sharded by word-id range + all-gather / all-reduce per frame (the "
                          "north star; strong scaling), or independent frame streams per GPU (weak scaling, no data-path collective)")
@@ -915,8 +915,8 @@ def main():
               "step_ms_median": float(np.median(res["per_step_ms"])) if res["per_step_ms"].size else None,
               "step_ms_p95": float(np.percentile(res["per_step_ms"], 95)) if res["per_step_ms"].size else None,
               "world_size_observed": world, "collective_backend": backend, "signatures_bulk_load_s": build_s,
-              "pipeline": "software-pipelined frames, three in flight: 2 launches per frame (A: filter of frame t + decision loop of t-1 + registration "
-                          "of t-2; B: re-rank of frame t + scoring of t-2), one stream" if (args.pipeline and not shard) else "4 launches per frame, one stream",
+              "pipeline": "software-pipelined frames, four in flight: 2 launches per frame (A: query pre-split of frame t + filter of t-1 + decision loop "
+                          "of t-2 + registration of t-3; B: re-rank of frame t-1 + scoring of t-3), one stream" if (args.pipeline and not shard) else "4 launches per frame, one stream",
               "parallelism": ("vocabulary sharded by word-id range over %d GPUs (all-gather top-2 + int64 all-reduce per frame, the all-reduce "
                               "overlapped with the next frame's search)" % world) if shard
               else ("%d independent replicas (one frame stream per GPU, no data-path collective)" % world if world > 1 else "1 GPU")}

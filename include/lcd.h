@@ -72,13 +72,14 @@ typedef struct lcd_config {
     int32_t max_queries;       /* initial per-call query capacity (Kp/MaxFeatures; grows on demand) */
     int32_t knn_mode;          /* lcd_knn_mode, per handle */
     void*   stream;            /* optional hipStream_t to enqueue on; NULL = engine-owned stream */
-    int32_t pipeline;          /* 1: consecutive lcd_frame_dev calls are software-pipelined (matrix-core 2-NN handles), lcd_pipeline_depth() = 2
-                                  frames deep: the launches of frame t also carry the decision loop of frame t - 1 and the registration +
-                                  scoring of frame t - 2, whose single-workgroup latency chains then hide behind the distance filter of
-                                  frame t.  Consequence for the caller: the outputs of a frame (d_word_ids, d_likelihood, d_bayes, ...) are
-                                  written -- and its descriptors read -- by work that the NEXT TWO lcd_frame_dev calls enqueue (or any
-                                  other call on the handle, which completes the owed stages first; lcd_synchronize to wait for them):
-                                  keep lcd_pipeline_depth() + 1 sets of buffers and rotate.  lcd_sig_remove, lcd_record_event and
+    int32_t pipeline;          /* 1: consecutive lcd_frame_dev calls are software-pipelined (matrix-core 2-NN handles), lcd_pipeline_depth() = 3
+                                  frames deep: the call for frame t only converts its descriptors into matrix-core operands; its launches
+                                  carry the distance filter + re-rank of frame t - 1, the decision loop of frame t - 2 and the registration +
+                                  scoring of frame t - 3, whose single-workgroup latency chains hide behind the filter.  Consequence for the
+                                  caller: the outputs of a frame (d_word_ids, d_likelihood, d_bayes, ...) are written -- and its
+                                  descriptors read -- by work that the NEXT THREE lcd_frame_dev calls enqueue (or any other call on the
+                                  handle, which completes the owed stages first; lcd_synchronize to wait for them): keep
+                                  lcd_pipeline_depth() + 1 sets of buffers and rotate.  lcd_sig_remove, lcd_record_event and
                                   lcd_bayes_set_neighbors are queued behind the owed stages of the frame they follow, so they keep their
                                   place in the call order.  Results are identical with and without. */
     int32_t reserved1;

@@ -61,7 +61,7 @@ struct lcd_engine {
         lcd::DevBuf d_qsplit, d_qnorm;                  // the frame's queries pre-split into bf16 matrix-core operands, their norms
         bool fail_count_clean = false;
     };
-    static constexpr int PIPE_SETS = 6;                 // a frame's set is in use for four calls (pre-split .. registration)
+    static constexpr int PIPE_SETS = 4;                 // a frame's set is in use for four calls (pre-split .. registration)
     FrameScratch ring[PIPE_SETS];
     uint64_t frame_seq = 0;
     const void* last_fail_count = nullptr;              // certificate counters of the latest pipelined frame (lcd_get_stats)

@@ -56,6 +56,16 @@ inline hipError_t dreserve(lcd_engine* h, DevBuf& b, size_t bytes, size_t keep =
     return b.reserve(bytes, keep, h->stream, &h->bytes_device);
 }
 
+// One scratch buffer of a pipelined frame, in EVERY set of the ring: the sets are used in turn, and a set that met its first frame
+// (or a larger one) only then would allocate in the middle of a steady stream of frames -- a hipMalloc is hundreds of microseconds
+inline hipError_t ring_reserve(lcd_engine* h, DevBuf lcd_engine::FrameScratch::*member, size_t bytes) {
+    for (lcd_engine::FrameScratch& sc : h->ring) {
+        const hipError_t e = dreserve(h, sc.*member, bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 // copy `rows` host rows (h->dim columns) into a device buffer laid out with h->row_bytes per row (u8 rows zero-padded)
 int upload_rows(lcd_engine* h, const void* rows, int n, DevBuf& dst) {
     const size_t bytes = (size_t)n * h->row_bytes;
@@ -1118,8 +1128,8 @@ static int build_knn(lcd_engine* h, lcd_engine::InFlight& f, PipeKnn* kp) {
         const int n_tiles = (int)((plan_rows + 31) / 32);
         k.plan.tiles_per_block = h->strip_tiles; k.plan.n_blocks = (n_tiles + h->strip_tiles - 1) / h->strip_tiles; k.plan.one_strip = 1;
     }
-    LCD_HIP(h, dreserve(h, sc.d_partial2, knn_bf16_partial_bytes(k.plan)));
-    LCD_HIP(h, dreserve(h, sc.d_partial3, knn_rowpar_partial_bytes((int)plan_rows, q)));
+    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_partial2, knn_bf16_partial_bytes(k.plan)));
+    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_partial3, knn_rowpar_partial_bytes((int)plan_rows, q)));
     k.vocab = h->vocab.p; k.vocab_bf = h->vocab_bf.p; k.row_norm = h->row_norm.as<float>(); k.norm_max_bits = h->norm_max.as<uint32_t>();
     k.row_id = h->row_id.as<int32_t>(); k.queries = a.d_descriptors; k.partial = sc.d_partial2.p;
     k.qsplit = sc.d_qsplit.p; k.qnorm = sc.d_qnorm.as<float>();
@@ -1254,16 +1264,16 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     const bool together = incremental && (a->flags & LCD_Q_NEW_WORDS_COMPARED);
     const int ld = (q + 63) / 64 * 64, bw = ld / 32;
     // ---- the frame's scratch set (what does not depend on the launch plan; the partial keys are sized when the filter is planned)
-    LCD_HIP(h, dreserve(h, sc.d_qsplit, knn_qsplit_bytes(q)));
-    LCD_HIP(h, dreserve(h, sc.d_qnorm, (size_t)ld * 4));
-    LCD_HIP(h, dreserve(h, sc.d_fail_list, (size_t)q * 4));
-    LCD_HIP(h, dreserve(h, sc.d_knn_row, (size_t)q * 2 * 4));
-    LCD_HIP(h, dreserve(h, sc.d_knn_word, (size_t)q * 2 * 4));
-    LCD_HIP(h, dreserve(h, sc.d_knn_dist, (size_t)q * 2 * 4));
-    LCD_HIP(h, dreserve(h, sc.d_out_wslot, (size_t)q * 4));
+    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_qsplit, knn_qsplit_bytes(q)));
+    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_qnorm, (size_t)ld * 4));
+    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_fail_list, (size_t)q * 4));
+    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_knn_row, (size_t)q * 2 * 4));
+    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_knn_word, (size_t)q * 2 * 4));
+    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_knn_dist, (size_t)q * 2 * 4));
+    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_out_wslot, (size_t)q * 4));
     if (together) {
-        LCD_HIP(h, dreserve(h, sc.d_selfdist, (size_t)q * ld * 4));
-        LCD_HIP(h, dreserve(h, sc.d_bits, cand_bits_bytes(q, bw)));
+        LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_selfdist, (size_t)q * ld * 4));
+        LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_bits, cand_bits_bytes(q, bw)));
     }
     QSplitArgs qs;
     qs.queries = (const float*)a->d_descriptors; qs.nq = q; qs.qpad = ld; qs.qsplit = (uint4*)sc.d_qsplit.p; qs.qnorm = sc.d_qnorm.as<float>(); qs.n_wgs = 0;

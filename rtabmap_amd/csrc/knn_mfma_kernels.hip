@@ -24,6 +24,7 @@
 // MFMA operand layout (both variants): lane (row or query l&31, half l>>5) holds the contiguous elements [32h, 32h+32) of its
 // row, i.e. a k-step multiplies the same element subset on both sides -- A and B use the same k permutation, which a dot
 // product does not see.  D layout: lane holds query (l&31), 16 rows (reg&3) + 8*(reg>>2) + 4*(l>>5).
+#include <hip/hip_ext.h>
 #include "lcd_kernels.h"
 #include "rowpar_body.cuh"
 #include "frame_tail_body.cuh"
@@ -579,7 +580,9 @@ __device__ __forceinline__ void selfdist_tile(const SelfdistJob& sd, int k, floa
     }
 }
 
-// partial_keys [qpad][n_blocks][BF_KEEP] u64, partial_bound [qpad][n_blocks] f32 bits.  Grid (1-D): n_blocks x ceil(nq / 512) filter
+// partial_keys [n_blocks][qpad][BF_KEEP] u64, partial_bound [n_blocks][qpad] f32 bits (block-major: the filter's lanes own consecutive
+// queries of ONE block, so its records leave as full lines; query-major they were 16-byte pieces of 112 000 different lines per frame, and
+// the write-back of those partial lines at the end of the launch was a third of launch A's wall time).  Grid (1-D): n_blocks x ceil(nq / 512) filter
 // workgroups first, then sd.n_tiles distance-matrix workgroups.
 template <int NG>
 __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
@@ -745,10 +748,10 @@ __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, cons
         const uint64_t third = third_of_two_triples(a0, a1, a2, b0, b1, b2);
         const int qi = q0 + g * 32 + col;
         if (half == 0 && qi < qpad) {
-            uint64_t* dst = partial_keys + ((size_t)qi * n_blocks + bx) * BF_KEEP;
+            uint64_t* dst = partial_keys + ((size_t)bx * qpad + qi) * BF_KEEP;        // block-major: a wave's 32 queries make one 512-byte write
             dst[0] = m0;
             dst[1] = m1;
-            partial_bound[(size_t)qi * n_blocks + bx] = (uint32_t)min(third >> 32, (uint64_t)0x7f800000u);
+            partial_bound[(size_t)bx * qpad + qi] = (uint32_t)min(third >> 32, (uint64_t)0x7f800000u);
         }
     }
     MF_STAMP(3);
@@ -912,11 +915,15 @@ __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, co
         const uint64_t m1 = hx < lx ? hx : lx;
         const uint64_t third = third_of_two_triples(a0, a1, a2, b0, b1, b2);
         const int qi = q0 + g * 32 + col;
+#ifdef LCD_ABLATE_PARTIAL_WRITE   // timing experiment only: no candidate records leave the filter (results are wrong)
+        if (half == 0 && qi < qpad && m0 == 0x1234567ull) {
+#else
         if (half == 0 && qi < qpad) {
-            uint64_t* dst = partial_keys + ((size_t)qi * n_blocks + bx) * BF_KEEP;
+#endif
+            uint64_t* dst = partial_keys + ((size_t)bx * qpad + qi) * BF_KEEP;        // block-major: a wave's 32 queries make one 512-byte write
             dst[0] = m0;
             dst[1] = m1;
-            partial_bound[(size_t)qi * n_blocks + bx] = (uint32_t)min(third >> 32, (uint64_t)0x7f800000u);
+            partial_bound[(size_t)bx * qpad + qi] = (uint32_t)min(third >> 32, (uint64_t)0x7f800000u);
         }
     }
     MF_STAMP(3);
@@ -1095,10 +1102,10 @@ __device__ __forceinline__ void knn_bf16_filter_body_p(float* s_dyn, int bid, co
             const uint64_t third = third_of_two_triples(a0, a1, a2, b0, b1, b2);
             const int qi = q0 + g * 32 + col;
             if (half == 0 && qi < qpad) {
-                uint64_t* dst = partial_keys + ((size_t)qi * n_blocks + bx) * BF_KEEP;
+                uint64_t* dst = partial_keys + ((size_t)bx * qpad + qi) * BF_KEEP;        // block-major: a wave's 32 queries make one 512-byte write
                 dst[0] = m0;
                 dst[1] = m1;
-                partial_bound[(size_t)qi * n_blocks + bx] = (uint32_t)min(third >> 32, (uint64_t)0x7f800000u);
+                partial_bound[(size_t)bx * qpad + qi] = (uint32_t)min(third >> 32, (uint64_t)0x7f800000u);
             }
         }
         if (s + 2 < n_my) {                                          // strip s is read by every wave: its slots take strip s + 2
@@ -1190,7 +1197,13 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     __shared__ float s_thr_all[HALVES];
     float& s_thr = s_thr_all[hf];
     const int n_keys = n_blocks * KEEP;
-    const uint64_t* __restrict__ keys = partial_keys + (size_t)qi * n_keys;
+    // key c of the query: block c / KEEP, entry c % KEEP.  The bf16 filter's records are block-major ([block][query][KEEP], see
+    // knn_bf16_filter_body), the f32 filter's query-major
+    const int qpad_t = (nq + 63) / 64 * 64;
+    auto key_at = [&](int c) -> uint64_t {
+        return BF16 ? partial_keys[((size_t)(c / KEEP) * qpad_t + qi) * KEEP + (c % KEEP)] : partial_keys[(size_t)qi * n_keys + c];
+    };
+    auto bound_at = [&](int b) -> uint32_t { return BF16 ? partial_lmin[(size_t)b * qpad_t + qi] : partial_lmin[(size_t)qi * n_blocks + b]; };
     constexpr uint32_t INF = 0x7f800000u;
     __shared__ uint32_t s_a0_all[HALVES][MF_WAVES], s_a1_all[HALVES][MF_WAVES], s_bound_all[HALVES][MF_WAVES];
     __shared__ int s_ncand_all[HALVES];
@@ -1207,9 +1220,9 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     // Everything that does not depend on other loads is requested up front (the kernel is a chain of round trips): the first two
     // keys and the first bound of every thread, the query slice, the vocabulary norm bound and -- for the candidate bits -- the
     // thread's two entries of the query's row of the same-frame distance matrix.
-    const uint64_t kreg0 = tid < n_keys ? keys[tid] : KEY_NONE;
-    const uint64_t kreg1 = tid + MF_BLOCK < n_keys ? keys[tid + MF_BLOCK] : KEY_NONE;
-    const uint32_t breg0 = tid < n_blocks ? partial_lmin[(size_t)qi * n_blocks + tid] : INF;
+    const uint64_t kreg0 = tid < n_keys ? key_at(tid) : KEY_NONE;
+    const uint64_t kreg1 = tid + MF_BLOCK < n_keys ? key_at(tid + MF_BLOCK) : KEY_NONE;
+    const uint32_t breg0 = tid < n_blocks ? bound_at(tid) : INF;
     const float4 q4 = reinterpret_cast<const float4*>(queries + (size_t)qi * DIM)[lane & 15];
     const float vn_max = __uint_as_float(norm_max_bits[0]);
     float dreg0 = __int_as_float(0x7f800000), dreg1 = __int_as_float(0x7f800000);
@@ -1232,8 +1245,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     };
     see(kreg0, tid);
     see(kreg1, tid + MF_BLOCK);
-    for (int c = tid + 2 * MF_BLOCK; c < n_keys; c += MF_BLOCK) see(keys[c], c);
-    for (int c = tid + MF_BLOCK; c < n_blocks; c += MF_BLOCK) bound = min(bound, partial_lmin[(size_t)qi * n_blocks + c]);
+    for (int c = tid + 2 * MF_BLOCK; c < n_keys; c += MF_BLOCK) see(key_at(c), c);
+    for (int c = tid + MF_BLOCK; c < n_blocks; c += MF_BLOCK) bound = min(bound, bound_at(c));
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const uint32_t o0 = (uint32_t)__shfl_xor((int)a0, m, 64), o1 = (uint32_t)__shfl_xor((int)a1, m, 64);
@@ -1266,7 +1279,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     };
     take(kreg0);
     take(kreg1);
-    for (int c = tid + 2 * MF_BLOCK; c < n_keys; c += MF_BLOCK) take(keys[c]);
+    for (int c = tid + 2 * MF_BLOCK; c < n_keys; c += MF_BLOCK) take(key_at(c));
     __syncthreads();
     const int n_cand = s_ncand;
     const bool overflow = n_cand > RR_MAX_CAND;
@@ -1501,8 +1514,11 @@ static_assert(PIPE_B_BLOCK == 2 * MF_BLOCK, "the re-rank halves");
 __global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, int n_rerank_wgs, ScoreArgs A) {
     const int bid = (int)blockIdx.x;
     B_STAMP(0);
-    if (bid < n_rerank_wgs) {
-        knn_mfma_rerank_body<64, BF_KEEP, false, true, 2>(2 * bid, k.pk, k.pl, k.n_blocks, k.nq, k.vocab, k.queries, k.row_id, k.norm_max_bits, k.out_row,
+    if (bid < n_rerank_wgs) {                                            // (a multiple of 8: see launch_frame_b)
+        // consecutive query pairs on one XCD: eight queries share a 128-byte line of the block-major candidate records
+        const int pair = (bid & 7) * (n_rerank_wgs >> 3) + (bid >> 3);
+        if (2 * pair >= k.nq) return;
+        knn_mfma_rerank_body<64, BF_KEEP, false, true, 2>(2 * pair, k.pk, k.pl, k.n_blocks, k.nq, k.vocab, k.queries, k.row_id, k.norm_max_bits, k.out_row,
                                                           k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb, k.n_lo, k.n_hi);
         B_STAMP(1);
         return;
@@ -1791,19 +1807,20 @@ hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLa
     ResolveArgs r{}; FwArgs a{}; RetireArgs ret{};
     if (resolve) r = resolve->r;
     if (reg) { a = reg->a; ret = reg->ret; }
-    hipError_t e;
-    if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
+    // ev_begin / ev_end: the launch's own start and end time stamps (hipExtLaunchKernel attaches the two events to the dispatch; a pair
+    // of hipEventRecord around it costs the stream ~10 us of barrier packets -- and measures the gap in front of the kernel with it)
+    const bool timed = ev_begin != nullptr && ev_end != nullptr;
     if (px > 0) {
         static const hipError_t attrp = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel_p),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES_P);
         (void)attrp;
-        frame_a_kernel_p<<<grid, PIPE_BLOCK, BF_LDS_BYTES_P, s>>>(f, px, tr, r, a, ret, qs);
-    } else
-        frame_a_kernel<<<grid, PIPE_BLOCK, BF_LDS_BYTES_Q, s>>>(f, tr, r, a, ret, qs);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }
-    return hipSuccess;
+        if (timed) hipExtLaunchKernelGGL(frame_a_kernel_p, dim3(grid), dim3(PIPE_BLOCK), (uint32_t)BF_LDS_BYTES_P, s, ev_begin, ev_end, 0u, f, px, tr, r, a, ret, qs);
+        else frame_a_kernel_p<<<grid, PIPE_BLOCK, BF_LDS_BYTES_P, s>>>(f, px, tr, r, a, ret, qs);
+    } else {
+        if (timed) hipExtLaunchKernelGGL(frame_a_kernel, dim3(grid), dim3(PIPE_BLOCK), (uint32_t)BF_LDS_BYTES_Q, s, ev_begin, ev_end, 0u, f, tr, r, a, ret, qs);
+        else frame_a_kernel<<<grid, PIPE_BLOCK, BF_LDS_BYTES_Q, s>>>(f, tr, r, a, ret, qs);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wgs, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
@@ -1816,18 +1833,15 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
         rk.n_blocks = p.n_blocks; rk.nq = p.q; rk.vocab = (const float*)k->vocab; rk.queries = (const float*)k->queries; rk.row_id = k->row_id;
         rk.norm_max_bits = k->norm_max_bits; rk.out_row = k->out_row; rk.out_word = k->out_word; rk.out_dist = k->out_dist;
         rk.fail_list = k->fail_list; rk.fail_count = k->fail_count; rk.cb = k->cb; rk.n_lo = k->n_lo; rk.n_hi = k->n_hi;
-        n_rerank = (p.q + 1) / 2;                                     // two queries per workgroup
+        n_rerank = ((p.q + 1) / 2 + 7) & ~7;                          // two queries per workgroup; padded to the XCD count (frame_b_kernel)
     }
     ScoreArgs A{};
     if (score) A = *score; else score_wgs = 0;
     if (n_rerank + score_wgs == 0) return hipSuccess;
-    hipError_t e;
-    if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
-    frame_b_kernel<<<n_rerank + score_wgs, PIPE_B_BLOCK, 0, s>>>(rk, n_rerank, A);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }
-    return hipSuccess;
+    if (ev_begin != nullptr && ev_end != nullptr)
+        hipExtLaunchKernelGGL(frame_b_kernel, dim3(n_rerank + score_wgs), dim3(PIPE_B_BLOCK), 0u, s, ev_begin, ev_end, 0u, rk, n_rerank, A);
+    else frame_b_kernel<<<n_rerank + score_wgs, PIPE_B_BLOCK, 0, s>>>(rk, n_rerank, A);
+    return hipGetLastError();
 }
 
 }  // namespace lcd

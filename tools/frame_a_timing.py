@@ -82,7 +82,7 @@ def main():
             b = np.frombuffer(bb, dtype=np.uint64).reshape(-1, 2).astype(np.float64)
             idx = np.nonzero(b[:, 1] > b[:, 1].max() - 20000)[0]
             b = (b[idx] - b[idx, 0].min()) / 100.0
-            nr = (q + 1) // 2
+            nr = ((q + 1) // 2 + 7) & ~7
             print("launch B: %d workgroups stamped (%d re-rank, %d scoring)" % (len(idx), (idx < nr).sum(), (idx >= nr).sum()))
             for nme, m in (("re-rank", idx < nr), ("scoring", idx >= nr)):
                 if m.sum():
