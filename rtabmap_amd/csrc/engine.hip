@@ -1116,14 +1116,7 @@ static int build_knn(lcd_engine* h, lcd_engine::InFlight& f, PipeKnn* kp) {
     // strip); the two tail workgroups do not: a filter workgroup holds 66 KB of LDS, so two of the launch's workgroups can share a
     // compute unit, and one strip less per workgroup is worth more than the two shared units (49 000 words x 500 descriptors:
     // 219 seven-tile strips + 36 tiles + 2 = 257 workgroups, frame 31.6 us; 192 eight-tile strips 32.1; 256 six-tile strips 34.5).
-    // A vocabulary of more strips than compute units runs the persistent kernel, whose workgroups own their compute unit.
-    const int n_tile_wgs = together ? knn_selfdist_wgs(q) : 0;
-    k.plan = knn_bf16_plan(q, (int)plan_rows, n_tile_wgs);
-    k.plan.filter_units = h->filter_units;
-    if (knn_bf16_persistent(k.plan)) {
-        k.plan = knn_bf16_plan(q, (int)plan_rows, 2 + n_tile_wgs);
-        k.plan.filter_units = h->filter_units;
-    }
+    k.plan = knn_bf16_plan_pipelined(q, (int)plan_rows, together ? knn_selfdist_wgs(q) : 0, h->filter_units);
     if (h->strip_tiles > 0 && plan_rows > 0) {                       // timing experiments: a fixed strip length, one workgroup per strip
         const int n_tiles = (int)((plan_rows + 31) / 32);
         k.plan.tiles_per_block = h->strip_tiles; k.plan.n_blocks = (n_tiles + h->strip_tiles - 1) / h->strip_tiles; k.plan.one_strip = 1;

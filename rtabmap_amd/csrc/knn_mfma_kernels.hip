@@ -1695,6 +1695,36 @@ static int bf16_persistent_px(const MfmaPlan& p) {
     return (p.n_blocks + rounds - 1) / rounds;                          // equal shares: ceil(strips / rounds) workgroups of <= rounds strips
 }
 bool knn_bf16_persistent(const MfmaPlan& p) { return p.q > 0 && bf16_persistent_px(p) > 0; }   // which kernel the launch will be (profile labels)
+// The plan of a pipelined frame's filter (launch A, pre-split queries: 66 KB of LDS per workgroup, so two share a compute unit).
+//   up to one strip per compute unit the distance tiles leave free: one workgroup per strip, alone on its compute unit;
+//   up to TWO strips per compute unit: still one workgroup per strip, in pairs -- a pair runs its tiles at 2.2 us each instead of
+//     1.24, but starts and ends once per strip instead of walking two strips one after the other (59 000 words: 34.1 us per
+//     frame against 38.0 with persistent workgroups, 80 000 words: 39.0 against 41.6);
+//   beyond: persistent workgroups (146 KB of LDS, one per compute unit; the two tail workgroups need units of their own then).
+MfmaPlan knn_bf16_plan_pipelined(int q, int n_rows, int n_tile_wgs, int filter_units) {
+    MfmaPlan p = knn_bf16_plan(q, n_rows, n_tile_wgs);
+    p.filter_units = filter_units;
+    if (bf16_persistent_px(p) == 0) return p;
+    if (filter_units >= 0) {                                            // (tests: a fixed number of persistent workgroups)
+        p = knn_bf16_plan(q, n_rows, 2 + n_tile_wgs);
+        p.filter_units = filter_units;
+        return p;
+    }
+    const int n_tiles = (n_rows + 31) / 32;
+    const int qchunks = (q + BF_QB - 1) / BF_QB;
+    const int slots = 2 * (256 - p.other_wgs) / qchunks;                // strips that can be resident at once
+    if (slots > 0 && n_tiles <= slots * MF_STRIP_TILES) {
+        int tpb = (n_tiles + slots - 1) / slots;
+        if (tpb < 1) tpb = 1;
+        p.tiles_per_block = tpb;
+        p.n_blocks = (n_tiles + tpb - 1) / tpb;
+        p.one_strip = 1;
+        return p;
+    }
+    p = knn_bf16_plan(q, n_rows, 2 + n_tile_wgs);
+    p.filter_units = filter_units;
+    return p;
+}
 hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, const float* row_norm, const uint32_t* norm_max_bits,
                            const int32_t* row_id, const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word,
                            float* out_dist, int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,

@@ -84,6 +84,7 @@ struct MfmaPlan {
 bool knn_mfma_supported(int dtype, int dim);
 bool knn_bf16_persistent(const MfmaPlan& p);   // the bf16 filter launch of this plan uses the persistent kernels (..._kernel_p)
 MfmaPlan knn_mfma_plan(int q, int n_rows);
+MfmaPlan knn_bf16_plan_pipelined(int q, int n_rows, int n_tile_wgs, int filter_units);   // launch A of a pipelined frame (knn_mfma_kernels.hip)
 size_t knn_mfma_partial_bytes(const MfmaPlan& p);
 // |row|^2 for rows [first, first + n) (+inf for tombstones), running maximum in norm_max_bits
 hipError_t launch_row_norms(const void* vocab, const int32_t* row_id, int first, int n, int dim, float* norm, uint32_t* norm_max_bits,

@@ -66,11 +66,15 @@ def main():
             b = np.frombuffer(ab, dtype=np.uint64).reshape(-1, 2).astype(np.float64)
             idx = np.nonzero(b[:, 1] > b[:, 1].max() - 20000)[0]
             b = (b[idx] - b[idx, 0].min()) / 100.0
-            n_f = (-(-((n_words + 31) // 32) // strip) if strip else 256) if n_words == 49000 else None
+            n_t = (n_words + 31) // 32                                     # the engine's plan (build_knn): the distance tiles keep their compute units
+            w = -(-n_t // (256 - 36)) if not strip else strip
+            n_f = -(-n_t // w) if w <= 8 else None
             print("launch A: %d workgroups stamped" % len(idx))
             groups = [("decision loop", idx == 0), ("registration", idx == 1)]
             if n_f:
-                groups += [("filter", (idx >= 2) & (idx < 2 + n_f)), ("distance tiles", (idx >= 2 + n_f) & (idx < 2 + n_f + 36)), ("redo helpers", idx >= 2 + n_f + 36)]
+                a0 = 2 + n_f
+                groups += [("filter", (idx >= 2) & (idx < a0)), ("distance tiles", (idx >= a0) & (idx < a0 + 36)),
+                           ("query pre-split", (idx >= a0 + 36) & (idx < a0 + 44)), ("redo helpers", idx >= a0 + 44)]
             for nme, m in groups:
                 if m.sum():
                     st, en = b[m, 0], b[m, 1]
