@@ -19,6 +19,7 @@
 #include "bayes.h"
 
 #include <algorithm>
+#include <unordered_map>
 #include <cstring>
 
 namespace lcd {
@@ -666,17 +667,29 @@ hipError_t Bayes::link(const std::vector<int32_t>& triples, const std::vector<in
     }
     const int n = (int)(triples.size() / 3);
     if (n == 0) return hipSuccess;
-    // room for every entry this call may add (an entry that replaces an existing one is counted again: the bound only grows)
+    // room for every entry this call may add.  cnt_ub counts an entry that only replaces an existing one again, so it can run ahead
+    // of the true lengths: before the table is widened -- or the call refused -- the true lengths are read back (rare, synchronises)
     int64_t top = 0;
-    int k_needed = 0;
     for (int i = 0; i < n; ++i) top = std::max<int64_t>(top, std::max(triples[3 * i], triples[3 * i + 1]));
     BY_TRY(ensure(std::max<int64_t>(cap, top + 1)));
+    std::unordered_map<int32_t, int> inc;
+    inc.reserve((size_t)n * 2);
     for (int i = 0; i < n; ++i) {
         const int32_t a = triples[3 * i], b = triples[3 * i + 1];
-        k_needed = std::max(k_needed, ++cnt_ub[a]);
-        if (a != b) k_needed = std::max(k_needed, ++cnt_ub[b]);
+        inc[a] += 1;
+        if (a != b) inc[b] += 1;
     }
-    if (k_needed > K) BY_TRY(ensure(cap, k_needed));
+    auto needed = [&]() { int k = 0; for (const auto& e : inc) k = std::max(k, cnt_ub[(size_t)e.first] + e.second); return k; };
+    int k_needed = needed();
+    if (k_needed > K) {
+        std::vector<int32_t> true_cnt((size_t)cap);
+        BY_TRY(hipMemcpyAsync(true_cnt.data(), cnt.p, (size_t)cap * 4, hipMemcpyDeviceToHost, stream));   // behind the clears above
+        BY_TRY(hipStreamSynchronize(stream));
+        for (const auto& e : inc) cnt_ub[(size_t)e.first] = std::min(cnt_ub[(size_t)e.first], true_cnt[(size_t)e.first]);
+        k_needed = needed();
+    }
+    if (k_needed > K) BY_TRY(ensure(cap, k_needed));               // (nothing has been committed if this fails)
+    for (const auto& e : inc) cnt_ub[(size_t)e.first] += e.second;
     const int blocks = (int)(((int64_t)2 * n * 64 + 255) / 256);
     if (n <= LINK_SMALL) {
         LinkArgs a;

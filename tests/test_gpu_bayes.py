@@ -311,3 +311,23 @@ def test_frame_dev_carries_the_filter(oracle, pipeline):
     st = eng.stats()
     assert st["frame_calls"] == n_frames
     eng.close()
+
+
+def test_relisting_the_same_neighbours_does_not_grow_the_table():
+    """A signature listed again and again (its own list starts over, its entry in each neighbour's list is REPLACED): the host's
+    upper bound of the list lengths counts every replacement, the true lengths stay what they are.  9 000 re-listings used to
+    double the table's width until lcd_bayes_set_neighbors failed for good ('longer than 8192 entries')."""
+    eng = _engine_with_signatures(64)
+    eng.bayes_configure(DEFAULT_LC, 0.9)
+    sig = np.array([10], np.int32)
+    off = np.array([0, 5], np.int64)
+    nbr = np.array([8, 9, 10, 11, 12], np.int32)
+    mg = np.array([2, 1, 0, 1, 2], np.int32)
+    prep = eng.bayes_neighbors_prepared(sig, off, nbr, mg)
+    eng.bayes_set_neighbors_prepared(prep)                            # (allocates the table)
+    before = eng.stats()["bytes_device"]
+    for _ in range(9000):
+        eng.bayes_set_neighbors_prepared(prep)
+    eng.synchronize()
+    assert eng.stats()["bytes_device"] == before                      # the neighbour table kept its width
+    eng.close()
