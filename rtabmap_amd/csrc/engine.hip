@@ -1168,6 +1168,19 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
     }
     TailLaunch tl_reg, tl_res; ScoreArgs sa; int score_wgs = 0;
     bool reg_like = false;
+    if (f_res) {
+        // FIRST, before any launch argument is built: the reservation may move the word-indexed tables (they double when the keys run
+        // out -- every ~3 000 frames at 150 new words per frame), and the registration / scoring arguments below hold pointers into
+        // them.  The postings keys of the words that frame may create are reserved now (the batched check of older reservations waits until
+        // launch A is enqueued: the registration that rides in it may still use some of those keys)
+        { int rc = reserve_frame_words(h, f_res->a, &f_res->runs, false); if (rc) return rc; }
+        f_res->reserved = true;
+        tl_res.r = f_res->r;
+        tl_res.r.new_ws = f_res->runs;
+        refresh_vocab_ptrs(h, &tl_res.r);
+        if (f_res->chained) fill_append(h, f_res->a, f_res->vseq, frame_appends(h, f_res->a), &tl_res.r);
+        resolve_launch_info(tl_res.r, pipe_block_size(), &tl_res.n_redo, &tl_res.shmem_resolve);
+    }
     if (f_reg) {
         const lcd_frame_args& pa = f_reg->a;
         if (pa.sig_id != 0) LCD_HIP(h, t.register_dev(pa.sig_id, f_reg->r.out_wslot, pa.q, pa.q, pa.N, nullptr, false, &tl_reg));
@@ -1177,17 +1190,6 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
             reg_like = true;
             h->likelihood_launches += 1;
         }
-    }
-    if (f_res) {
-        // the postings keys of the words that frame may create are reserved now (the batched check of older reservations waits until
-        // launch A is enqueued: the registration that rides in it may still use some of those keys)
-        { int rc = reserve_frame_words(h, f_res->a, &f_res->runs, false); if (rc) return rc; }
-        f_res->reserved = true;
-        tl_res.r = f_res->r;
-        tl_res.r.new_ws = f_res->runs;
-        refresh_vocab_ptrs(h, &tl_res.r);
-        if (f_res->chained) fill_append(h, f_res->a, f_res->vseq, frame_appends(h, f_res->a), &tl_res.r);
-        resolve_launch_info(tl_res.r, pipe_block_size(), &tl_res.n_redo, &tl_res.shmem_resolve);
     }
     PipeKnn k;
     if (f_knn) { int rc = build_knn(h, *f_knn, &k); if (rc) return rc; h->knn_launches += 1; }

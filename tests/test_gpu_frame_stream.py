@@ -223,6 +223,49 @@ def test_pipelined_frames_enqueued_back_to_back(oracle, n_words, q):
     np.testing.assert_allclose(out[0][1][0][: n_sig + 1], Lo, rtol=RTOL, atol=ATOL)
 
 
+def test_pipelined_frames_across_growing_word_tables():
+    """Frames whose descriptors are all new words (128 postings keys reserved per frame) on a small engine: the word-indexed tables
+    (nw, dense ids, idf stamps) double several times while frames are in flight.  The reservation that moves them belongs to the
+    frame whose decision loop is about to run; the registration and scoring arguments of the OLDER frames in the same launches must
+    be built after it (they used to hold the freed tables: a memory fault after ~3 000 frames of the bench's stream -- a freed table
+    is not always unmapped, so this test guards the results; `bench.py --steps 8000` is the run that faulted).  Word ids and
+    likelihood equal the unpipelined handle's, bit for bit."""
+    import rtabmap_amd
+    n_words, n_sig, q, T = 600, 300, 128, 90
+    vocab = synth.vocab_surf(n_words, seed=61)
+    words = synth.zipf_words(n_sig, q, n_words, seed=62)
+    ids = np.arange(1, n_words + 1, dtype=np.int32)
+    rng = np.random.default_rng(63)
+    frames = []
+    for t in range(T):
+        f = rng.standard_normal((q, 64)).astype(np.float32)
+        f /= np.linalg.norm(f, axis=1, keepdims=True)
+        if t % 3 == 0:                                                # every third frame revisits a signature: some existing words too
+            f[: q // 2] = synth.frame_from_signature(vocab, words[(17 * t) % n_sig], seed=70 + t)[: q // 2]
+        frames.append(torch.from_numpy(f).cuda())
+    out = {}
+    for pipe in (0, 1):
+        eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words, sig_capacity=n_sig + T, pipeline=pipe)
+        eng.vocab_append(vocab, ids)
+        eng.sig_add_bulk(np.arange(1, n_sig + 1, dtype=np.int32), np.arange(0, (n_sig + 1) * q, q, dtype=np.int64), words.reshape(-1))
+        cap = n_sig + T
+        d_w = torch.zeros((T, q), dtype=torch.int32, device="cuda")
+        d_l = torch.zeros((T, cap), dtype=torch.float32, device="cuda")
+        bytes0 = eng.stats()["bytes_device"]
+        for t in range(T):
+            eng.frame_dev(frames[t].data_ptr(), q, n_sig + 1 + t, float(n_sig + 1 + t), d_w[t].data_ptr(), d_l[t].data_ptr(), cap,
+                          first_new_word_id=n_words + 1 + t * q)
+            if t % 4 == 3:
+                eng.sig_remove(1 + t // 4)
+        eng.synchronize()
+        assert eng.stats()["bytes_device"] > bytes0                   # (the tables did grow)
+        out[pipe] = (d_w.cpu().numpy(), d_l.cpu().numpy())
+        eng.close()
+    np.testing.assert_array_equal(out[1][0], out[0][0])
+    np.testing.assert_array_equal(out[1][1], out[0][1])
+    assert (out[0][0] < 0).sum() > T * q // 2                         # most descriptors became new words
+
+
 def test_frame_dev_at_headline_sizes(oracle):
     """BASELINE.json's configuration: 49k SURF words, 500 descriptors per frame, a Zipf memory of 20 000 signatures x 500 words
     (the oracle builds it in seconds; bench.py repeats the check at 100k).  Three frames through lcd_frame_dev with retirement of
