@@ -56,11 +56,14 @@ inline hipError_t dreserve(lcd_engine* h, DevBuf& b, size_t bytes, size_t keep =
     return b.reserve(bytes, keep, h->stream, &h->bytes_device);
 }
 
-// One scratch buffer of a pipelined frame, in EVERY set of the ring: the sets are used in turn, and a set that met its first frame
-// (or a larger one) only then would allocate in the middle of a steady stream of frames -- a hipMalloc is hundreds of microseconds
-inline hipError_t ring_reserve(lcd_engine* h, DevBuf lcd_engine::FrameScratch::*member, size_t bytes) {
+// One scratch buffer of a pipelined frame: in the frame's own set of the ring -- and, while nothing is in flight, in every other set as
+// well, so that a steady stream of frames does not meet a hipMalloc (hundreds of microseconds) each time a set sees its first frame.
+// The other sets are NOT touched while frames are in flight: those frames' launch arguments hold pointers into them.
+inline hipError_t ring_reserve(lcd_engine* h, int own_set, DevBuf lcd_engine::FrameScratch::*member, size_t bytes) {
+    hipError_t e = dreserve(h, h->ring[own_set].*member, bytes);
+    if (e != hipSuccess || !h->inflight.empty()) return e;
     for (lcd_engine::FrameScratch& sc : h->ring) {
-        const hipError_t e = dreserve(h, sc.*member, bytes);
+        e = dreserve(h, sc.*member, bytes);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -1121,8 +1124,8 @@ static int build_knn(lcd_engine* h, lcd_engine::InFlight& f, PipeKnn* kp) {
         const int n_tiles = (int)((plan_rows + 31) / 32);
         k.plan.tiles_per_block = h->strip_tiles; k.plan.n_blocks = (n_tiles + h->strip_tiles - 1) / h->strip_tiles; k.plan.one_strip = 1;
     }
-    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_partial2, knn_bf16_partial_bytes(k.plan)));
-    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_partial3, knn_rowpar_partial_bytes((int)plan_rows, q)));
+    LCD_HIP(h, ring_reserve(h, f.set, &lcd_engine::FrameScratch::d_partial2, knn_bf16_partial_bytes(k.plan)));
+    LCD_HIP(h, ring_reserve(h, f.set, &lcd_engine::FrameScratch::d_partial3, knn_rowpar_partial_bytes((int)plan_rows, q)));
     k.vocab = h->vocab.p; k.vocab_bf = h->vocab_bf.p; k.row_norm = h->row_norm.as<float>(); k.norm_max_bits = h->norm_max.as<uint32_t>();
     k.row_id = h->row_id.as<int32_t>(); k.queries = a.d_descriptors; k.partial = sc.d_partial2.p;
     k.qsplit = sc.d_qsplit.p; k.qnorm = sc.d_qnorm.as<float>();
@@ -1259,16 +1262,16 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     const bool together = incremental && (a->flags & LCD_Q_NEW_WORDS_COMPARED);
     const int ld = (q + 63) / 64 * 64, bw = ld / 32;
     // ---- the frame's scratch set (what does not depend on the launch plan; the partial keys are sized when the filter is planned)
-    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_qsplit, knn_qsplit_bytes(q)));
-    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_qnorm, (size_t)ld * 4));
-    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_fail_list, (size_t)q * 4));
-    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_knn_row, (size_t)q * 2 * 4));
-    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_knn_word, (size_t)q * 2 * 4));
-    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_knn_dist, (size_t)q * 2 * 4));
-    LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_out_wslot, (size_t)q * 4));
+    LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_qsplit, knn_qsplit_bytes(q)));
+    LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_qnorm, (size_t)ld * 4));
+    LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_fail_list, (size_t)q * 4));
+    LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_knn_row, (size_t)q * 2 * 4));
+    LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_knn_word, (size_t)q * 2 * 4));
+    LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_knn_dist, (size_t)q * 2 * 4));
+    LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_out_wslot, (size_t)q * 4));
     if (together) {
-        LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_selfdist, (size_t)q * ld * 4));
-        LCD_HIP(h, ring_reserve(h, &lcd_engine::FrameScratch::d_bits, cand_bits_bytes(q, bw)));
+        LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_selfdist, (size_t)q * ld * 4));
+        LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_bits, cand_bits_bytes(q, bw)));
     }
     QSplitArgs qs;
     qs.queries = (const float*)a->d_descriptors; qs.nq = q; qs.qpad = ld; qs.qsplit = (uint4*)sc.d_qsplit.p; qs.qnorm = sc.d_qnorm.as<float>(); qs.n_wgs = 0;

@@ -223,6 +223,40 @@ def test_pipelined_frames_enqueued_back_to_back(oracle, n_words, q):
     np.testing.assert_allclose(out[0][1][0][: n_sig + 1], Lo, rtol=RTOL, atol=ATOL)
 
 
+def test_pipelined_frames_of_changing_size():
+    """Descriptor counts that change from frame to frame (1 .. 700, growing and shrinking, across the 512-query block boundary) on a
+    pipelined handle: every frame's scratch lives in its own set of the ring, and a larger frame must not move the buffers of the
+    frames still in flight.  Word ids and likelihood equal the unpipelined handle's, bit for bit."""
+    import rtabmap_amd
+    n_words, n_sig, qs = 9000, 400, [40, 300, 90, 700, 33, 512, 513, 1, 640, 64, 700, 5, 256, 257, 100, 700]
+    vocab = synth.vocab_surf(n_words, seed=81)
+    words = synth.zipf_words(n_sig, 120, n_words, seed=82)
+    ids = np.arange(1, n_words + 1, dtype=np.int32)
+    T, qmax = len(qs), max(qs)
+    frames = []
+    for t, q in enumerate(qs):
+        base = np.concatenate([synth.frame_from_signature(vocab, words[(29 * t + k) % n_sig], seed=90 + 7 * t + k) for k in range(-(-q // 120))])
+        frames.append(torch.from_numpy(np.ascontiguousarray(base[:q])).cuda())
+    out = {}
+    for pipe in (0, 1):
+        eng = rtabmap_amd.Engine("f32", 64, sig_capacity=n_sig + T, pipeline=pipe)
+        eng.vocab_append(vocab, ids)
+        eng.sig_add_bulk(np.arange(1, n_sig + 1, dtype=np.int32), np.arange(0, (n_sig + 1) * 120, 120, dtype=np.int64), words.reshape(-1))
+        cap = n_sig + T
+        d_w = torch.zeros((T, qmax), dtype=torch.int32, device="cuda")
+        d_l = torch.zeros((T, cap), dtype=torch.float32, device="cuda")
+        first = n_words + 1
+        for t, q in enumerate(qs):
+            eng.frame_dev(frames[t].data_ptr(), q, n_sig + 1 + t, float(n_sig + 1 + t), d_w[t].data_ptr(), d_l[t].data_ptr(), cap,
+                          first_new_word_id=first)
+            first += q
+        eng.synchronize()
+        out[pipe] = (d_w.cpu().numpy(), d_l.cpu().numpy())
+        eng.close()
+    np.testing.assert_array_equal(out[1][0], out[0][0])
+    np.testing.assert_array_equal(out[1][1], out[0][1])
+
+
 def test_pipelined_frames_across_growing_word_tables():
     """Frames whose descriptors are all new words (128 postings keys reserved per frame) on a small engine: the word-indexed tables
     (nw, dense ids, idf stamps) double several times while frames are in flight.  The reservation that moves them belongs to the
