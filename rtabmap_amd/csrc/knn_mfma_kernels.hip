@@ -915,11 +915,7 @@ __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, co
         const uint64_t m1 = hx < lx ? hx : lx;
         const uint64_t third = third_of_two_triples(a0, a1, a2, b0, b1, b2);
         const int qi = q0 + g * 32 + col;
-#ifdef LCD_ABLATE_PARTIAL_WRITE   // timing experiment only: no candidate records leave the filter (results are wrong)
-        if (half == 0 && qi < qpad && m0 == 0x1234567ull) {
-#else
         if (half == 0 && qi < qpad) {
-#endif
             uint64_t* dst = partial_keys + ((size_t)bx * qpad + qi) * BF_KEEP;        // block-major: a wave's 32 queries make one 512-byte write
             dst[0] = m0;
             dst[1] = m1;

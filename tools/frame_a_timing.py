@@ -107,6 +107,22 @@ def main():
             s = np.frombuffer(sb, dtype=np.uint64).reshape(-1, 8).astype(np.float64)[:, :4]
             m = (s[:, 0] > s[:, 0].max() - 20000) & (s[:, 3] >= s[:, 0])
             s = (s[m] - s[m, 0].min()) / 100.0
+            if hasattr(lib, "lcd_debug_b_timing"):
+                # per XCD (workgroup index modulo 8) and the slowest workgroups: where the tail of launch B comes from
+                bb2 = (ctypes.c_ulonglong * (2 * 4096))()
+                assert lib.lcd_debug_b_timing(bb2, 2 * 4096) == 0
+                b2 = np.frombuffer(bb2, dtype=np.uint64).reshape(-1, 2).astype(np.float64)
+                idx2 = np.nonzero(b2[:, 1] > b2[:, 1].max() - 20000)[0]
+                t0b = b2[idx2, 0].min()
+                nr2 = ((q + 1) // 2 + 7) & ~7
+                sidx = idx2[idx2 >= nr2]
+                dur = (b2[sidx, 1] - b2[sidx, 0]) / 100.0
+                print("scoring workgroups by XCD (index mod 8): " + " ".join("%d:%.1f/%.1f" % (x, np.median(dur[sidx % 8 == x]), dur[sidx % 8 == x].max()) for x in range(8)))
+                order = np.argsort(-dur)[:12]
+                print("slowest scoring workgroups (launch index, us): " + " ".join("%d:%.1f" % (sidx[o], dur[o]) for o in order))
+                ridx = idx2[idx2 < nr2]
+                rdur = (b2[ridx, 1] - b2[ridx, 0]) / 100.0
+                print("re-rank workgroups by XCD: " + " ".join("%d:%.1f/%.1f" % (x, np.median(rdur[ridx % 8 == x]), rdur[ridx % 8 == x].max()) for x in range(8)))
             print("launch B scoring phases, %d sealed-bucket workgroups (us after the first one started):" % m.sum())
             for i, nme in enumerate(["start", "lists + directory + dense rows read", "dense sums in LDS", "sparse postings done"]):
                 c = s[:, i]
