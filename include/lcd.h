@@ -320,7 +320,8 @@ int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, co
 /* tuning knobs for experiments (results never depend on them).  "score_block": threads per workgroup of the scoring kernel
  * (256 / 512 / 1024).  "filter_units": compute units the bf16 filter plans its persistent workgroups for when the vocabulary has
  * more 256-word strips than that (-1 built-in, 0 never persistent).  "profile_likelihood": 0 = lcd_profile_begin brackets only the
- * 2-NN launch of a pipelined frame (every event pair costs stream time).  Unknown keys / values -> LCD_ERR_INVALID. */
+ * 2-NN launch of a pipelined frame (every timed launch costs stream time).  "strip_tiles": 32-word tiles per filter workgroup of a
+ * pipelined frame (1 .. 8; 0 = the built-in plan).  Unknown keys / values -> LCD_ERR_INVALID. */
 int lcd_set_option(lcd_engine* h, const char* key, int64_t value);
 
 /* the work of ONE scoring launch for the words of the last frame (diagnostic, synchronises): out8[0] bytes of dense count rows
