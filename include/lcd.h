@@ -204,7 +204,7 @@ typedef struct lcd_hypothesis {
 typedef struct lcd_frame_args {
     int32_t struct_size;               /* sizeof(lcd_frame_args) */
     int32_t q;                         /* descriptors in the frame (1..8192) */
-    const void* d_descriptors;         /* [q x dim] */
+    const void* d_descriptors;         /* [q x dim], 16-byte aligned (rows are read as 16-byte vectors) */
     int32_t flags;                     /* lcd_quantize_flags */
     float nndr_ratio;
     int32_t sig_id;                    /* != 0: register the frame as this signature (it must not exist yet) */

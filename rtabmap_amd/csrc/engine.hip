@@ -1294,6 +1294,7 @@ int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     if (!a || a->struct_size != (int32_t)sizeof(lcd_frame_args)) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: bad argument block");
     const int q = a->q;
     if (q <= 0 || q > 8192 || !a->d_descriptors || !a->d_word_ids) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: bad argument");
+    if (((uintptr_t)a->d_descriptors & 15u) != 0) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: d_descriptors must be 16-byte aligned");
     if ((a->d_hypothesis || a->d_adjusted || a->d_posterior || a->d_bayes) && !a->d_likelihood)
         return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: the hypothesis needs d_likelihood");
     if ((a->d_posterior || a->d_bayes) && !h->bayes.configured) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: lcd_bayes_configure first");
@@ -1323,6 +1324,7 @@ int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_id
     LCD_DEV(h);
     LCD_JOIN_K(h);
     if (q <= 0 || !d_queries || !d_word_ids || !d_dist) return h->fail(LCD_ERR_INVALID, "lcd_knn2_dev: bad argument");
+    if (((uintptr_t)d_queries & 15u) != 0) return h->fail(LCD_ERR_INVALID, "lcd_knn2_dev: d_queries must be 16-byte aligned");
     LCD_HIP(h, dreserve(h, h->d_knn_row, (size_t)q * 2 * 4));
     return run_knn2_raw(h, d_queries, q, h->vocab.p, h->row_id.as<int32_t>(), h->n_rows, true, h->d_knn_row.as<int32_t>(), d_word_ids, d_dist);
     LCD_CATCH(h)
@@ -1509,6 +1511,7 @@ int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shar
     LCD_DEV(h);
     LCD_JOIN_K(h);
     if (q <= 0 || !d_descriptors || !d_cand) return h->fail(LCD_ERR_INVALID, "lcd_shard_knn2_dev: bad argument");
+    if (((uintptr_t)d_descriptors & 15u) != 0) return h->fail(LCD_ERR_INVALID, "lcd_shard_knn2_dev: d_descriptors must be 16-byte aligned");
     if (h->n_rows >= (1 << 26)) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_shard_knn2_dev: a shard holds at most 2^26 - 1 rows (merge key: 26-bit row, 6-bit rank)");
     int rc = run_knn2(h, d_descriptors, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), h->n_rows, h->d_knn_row,
                       h->d_knn_word, h->d_knn_dist);

@@ -49,6 +49,16 @@ def test_error_statuses():
         eng.sig_remove(6)                                         # unknown signature
     with pytest.raises(LcdError):
         eng.sig_add(0, np.array([1], np.int32))                   # id 0 is invalid
+    import torch
+    d_q = torch.zeros(4 * 64 + 4, dtype=torch.float32, device="cuda")
+    d_w = torch.zeros(8, dtype=torch.int32, device="cuda")
+    d_d = torch.zeros(8, dtype=torch.float32, device="cuda")
+    with pytest.raises(LcdError) as e:
+        eng.knn2_dev(d_q.data_ptr() + 4, 4, d_w.data_ptr(), d_d.data_ptr())   # device descriptors are read as 16-byte vectors
+    assert "aligned" in str(e.value)
+    with pytest.raises(LcdError) as e:
+        eng.frame_dev(d_q.data_ptr() + 8, 4, 9, 1.0, d_w.data_ptr(), None, 0)
+    assert "aligned" in str(e.value)
     # the handle is still usable after errors
     ids, d = eng.knn2(v[:2])
     assert ids[:, 0].tolist() == [1, 2] and (d[:, 0] == 0).all()
