@@ -1708,7 +1708,7 @@ MfmaPlan knn_bf16_plan_pipelined(int q, int n_rows, int n_tile_wgs, int filter_u
     }
     const int n_tiles = (n_rows + 31) / 32;
     const int qchunks = (q + BF_QB - 1) / BF_QB;
-    const int slots = 2 * (256 - p.other_wgs) / qchunks;                // strips that can be resident at once
+    const int slots = (2 * (256 - p.other_wgs) - 16) / qchunks;         // strips that can be resident at once (16: the two tails, the pre-split, redo helpers)
     if (slots > 0 && n_tiles <= slots * MF_STRIP_TILES) {
         int tpb = (n_tiles + slots - 1) / slots;
         if (tpb < 1) tpb = 1;
@@ -1871,6 +1871,17 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
 }
 
 }  // namespace lcd
+
+// The launch plan of a pipelined frame's filter for a vocabulary of n_rows and q descriptors, as the engine makes it (tests; no device
+// needed): out[0] tiles per workgroup, [1] strips, [2] persistent workgroups per block of 512 queries (0: one workgroup per strip),
+// [3] distance-tile workgroups riding in the launch, [4] query blocks
+extern "C" int lcd_debug_frame_plan(int q, int n_rows, int new_words_compared, int* out) {
+    if (q <= 0 || n_rows <= 0 || !out) return -1;
+    const int tiles = new_words_compared ? lcd::knn_selfdist_wgs(q) : 0;
+    const lcd::MfmaPlan p = lcd::knn_bf16_plan_pipelined(q, n_rows, tiles, -1);
+    out[0] = p.tiles_per_block; out[1] = p.n_blocks; out[2] = lcd::bf16_persistent_px(p); out[3] = tiles; out[4] = (q + lcd::BF_QB - 1) / lcd::BF_QB;
+    return 0;
+}
 
 #ifdef LCD_SCORE_TIMING   // timing experiment only: the phase stamps of the scoring workgroups of launch B (this translation unit's copy)
 extern "C" int lcd_debug_score_timing_pipe(unsigned long long* out, int n_words) {

@@ -48,3 +48,36 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in src and "from oracle" not in src and "liblcd_oracle" not in src, f
+
+
+def test_pipelined_filter_plan_covers_every_size():
+    """The launch plan of a pipelined frame's filter (knn_bf16_plan_pipelined, host code: no device needed), over vocabulary sizes
+    from 256 to 1.3M rows and frames of 1 .. 4096 descriptors: every row belongs to exactly one strip, a strip holds 1 .. 8 tiles
+    and is never empty; for frames of up to 512 descriptors one-strip launches are resident at once, two workgroups to a compute
+    unit with the distance tiles keeping theirs, and persistent launches leave the two tail workgroups and the tiles a unit each;
+    the plan is the measured one at the headline size."""
+    import ctypes as C
+    import rtabmap_amd
+    rtabmap_amd.load()
+    lib = C.CDLL(rtabmap_amd.library_path())
+    lib.lcd_debug_frame_plan.restype = C.c_int
+    lib.lcd_debug_frame_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    out = (C.c_int * 5)()
+    sizes = sorted(set(list(range(256, 4000, 97)) + list(range(4000, 130000, 1777)) + list(range(130000, 1300000, 41011)) +
+                       [49000, 56320, 56321, 59000, 112640, 112641, 125000, 1000000]))
+    for q in (1, 33, 64, 500, 512, 513, 1000, 1024, 4096):
+        for together in (0, 1):
+            for n in sizes:
+                assert lib.lcd_debug_frame_plan(q, n, together, out) == 0
+                tpb, nb, px, tiles, qchunks = list(out)
+                n_tiles = (n + 31) // 32
+                assert 1 <= tpb <= 8 and nb >= 1
+                assert nb * tpb >= n_tiles > (nb - 1) * tpb, (q, n, tpb, nb)
+                if px == 0 and q <= 512:                       # (larger frames bring more distance tiles than the chip has units anyway)
+                    assert nb + tiles + 2 + 8 <= 512, (q, n, together, tpb, nb)      # everything resident at once, two to a unit
+                    assert nb <= 2 * (256 - tiles), (q, n, together, tpb, nb)        # the tiles keep their units
+                if px > 0 and q <= 512:
+                    assert px + tiles + 2 <= 256, (q, n, together, px)               # a persistent workgroup owns its unit
+    assert lib.lcd_debug_frame_plan(500, 49000, 1, out) == 0 and list(out)[:3] == [7, 219, 0]
+    assert lib.lcd_debug_frame_plan(500, 59000, 1, out) == 0 and list(out)[:3] == [5, 369, 0]
+    assert lib.lcd_debug_frame_plan(500, 125000, 1, out) == 0 and out[2] > 0
