@@ -91,7 +91,7 @@ def load_engine(eng, vocab, words, owned=None):
 class Stepper:
     """The bench step on one engine: frame t registered as signature n_sig + 1 + t, the oldest signature retired."""
 
-    def __init__(self, eng, torch, d_frames, n_sig, cap, want_like=True, log_frames=0):
+    def __init__(self, eng, torch, d_frames, n_sig, cap, want_like=True, log_frames=0, append=True):
         self.eng, self.d_frames, self.n_sig, self.cap = eng, d_frames, n_sig, cap
         self.d_words = torch.zeros(Q, dtype=torch.int32, device="cuda")
         # log_frames > 0: every frame's word ids are kept (one row each) so that the oracle can replay what THIS engine registered
@@ -101,8 +101,11 @@ class Stepper:
         self.d_like = torch.zeros(cap, dtype=torch.float32, device="cuda") if want_like else None
         self.next_sig, self.oldest, self.first_new = n_sig + 1, 1, N_WORDS + 1
         self.ptrs = [f.data_ptr() for f in d_frames]
+        # append: VWDictionary::update()'s append branch inside the step (the words a frame creates are vocabulary rows before the next
+        # frame is searched, as Memory::preUpdate has it, Memory.cpp:1004-1016)
         self.args = eng.frame_args(q=Q, flags=3, nndr_ratio=NNDR, N=float(n_sig + 1), d_word_ids=self.d_words.data_ptr(),
-                                   d_likelihood=self.d_like.data_ptr(), likelihood_capacity=cap)
+                                   d_likelihood=self.d_like.data_ptr(), likelihood_capacity=cap,
+                                   append_new_words=1 if (append and "no-new" not in DIAG) else 0)
 
     def __call__(self, i):
         a = self.args
@@ -120,7 +123,7 @@ class Stepper:
             self.eng.sig_remove(self.oldest)
         self.next_sig += 1
         self.oldest += 1
-        self.first_new += Q          # ids are only reserved here (the words are never appended): any consecutive numbering will do
+        self.first_new += Q          # an upper bound per frame (nothing is read back): ids only have to ascend
 
 
 # Bayes/PredictionLC as BayesFilter::setPredictionLC parses the default string (reference Parameters.h:363; uStr2Float -> double)
@@ -321,11 +324,12 @@ def build_oracle(vocab, words):
 
 def parity_block(torch, vocab, words, frames_np, m, n_frames=3):
     """SURVEY.md 8d 'parity checks run with every bench': frames of THIS configuration through a fresh engine -- the timed entry
-    point: lcd_frame_dev with registration + retirement on a pipelined handle, the frames enqueued back to back exactly as the timed
-    loop does, so the fused launches are what is checked -- and through the oracle's Memory::update -> computeLikelihood."""
+    point: lcd_frame_dev with registration + retirement + update()'s append on the device, on a pipelined handle, the frames enqueued
+    back to back exactly as the timed loop does, so the fused launches are what is checked -- and through the oracle's Memory::update
+    (preUpdate: cleanUnusedWords + VWDictionary::update(), then addNewWords) -> computeLikelihood."""
     import rtabmap_amd
     n_sig = words.shape[0]
-    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=N_WORDS + 1024, sig_capacity=n_sig + 64, pipeline=1)
+    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 64, pipeline=1)
     load_engine(eng, vocab, words)
     cap = n_sig + 16
     d_desc = [torch.from_numpy(frames_np[t]).cuda() for t in range(n_frames)]
@@ -334,20 +338,22 @@ def parity_block(torch, vocab, words, frames_np, m, n_frames=3):
     torch.cuda.synchronize()
     for t in range(n_frames):      # new words are numbered with an upper bound per frame: nothing is read back in between
         eng.frame_dev(d_desc[t].data_ptr(), Q, n_sig + 1 + t, float(n_sig + 1), d_words[t].data_ptr(), d_like[t].data_ptr(), cap,
-                      first_new_word_id=N_WORDS + 1 + t * Q)
+                      first_new_word_id=N_WORDS + 1 + t * Q, append_new_words=True)
         eng.sig_remove(t + 1)
     eng.synchronize()
     got_all, like_all = d_words.cpu().numpy(), d_like.cpu().numpy()
     ids_equal, argmax_equal, max_rel, n_cmp = True, True, 0.0, 0
     t_knn = t_lik = 0.0
+    eng2orc = {}                                                   # the engine numbers a frame's new words from its own upper bound
     for t in range(n_frames):
-        first_new = m.vwd.last_word_id + 1
         t1 = time.perf_counter()
         sid, exp = m.update(frames_np[t])                      # exact linear 2-NN + addNewWords, 1 thread
         t2 = time.perf_counter()
         got = got_all[t]
-        # word ids; a frame's new words compare by their rank (the k-th word the frame created)
-        ids_equal &= bool(np.where(got < 0, -got - 1 + (1 << 30), got).tolist() == [w if w < first_new else w - first_new + (1 << 30) for w in exp])
+        ids_h = np.where(got < 0, N_WORDS + 1 + t * Q - got - 1, got).tolist()
+        for j in np.flatnonzero(got < 0).tolist():
+            eng2orc.setdefault(ids_h[j], exp[j])
+        ids_equal &= bool([eng2orc.get(w, w) for w in ids_h] == list(exp))
         live = np.array(m.signature_ids(), np.int32)
         t3 = time.perf_counter()
         oi, Lo = m.compute_likelihood(np.array(exp, np.int32), live)
@@ -360,18 +366,13 @@ def parity_block(torch, vocab, words, frames_np, m, n_frames=3):
         n_cmp += int(Lo.size)
         argmax_equal &= bool(int(np.argmax(Lh[:-1])) == int(np.argmax(Lo[:-1])))
         m.forget(t + 1)
-        # the oracle indexes the frame's new words before the next frame (VWDictionary::update); the engine's vocabulary is not
-        # appended to in this loop (nor in the timed one): keep the two in step by dropping them again
-        new_ids = sorted(set(w for w in exp if w >= first_new))
-        if new_ids:
-            for w in new_ids:
-                m.vwd.remove_all_word_ref(int(w), sid)
-            m.vwd.remove_words(new_ids)
+    rows, live_rows = eng.vocab_count()
     eng.close()
     return ({"frames": n_frames, "word_ids_equal": ids_equal, "likelihood_max_rel": max_rel, "likelihood_values_compared": n_cmp,
              "argmax_equal": argmax_equal, "bound": "1e-4 relative (abs floor 1e-7)", "signatures": n_sig,
-             "path": "lcd_frame_dev (registration + retirement + TF-IDF, pipelined handle, frames enqueued back to back) vs oracle "
-                     "Memory::update + computeLikelihood"},
+             "vocabulary_rows_after": int(rows), "oracle_words_after": len(m.vwd.word_ids()),
+             "path": "lcd_frame_dev (registration + retirement + update()'s append on the device + TF-IDF, pipelined handle, frames enqueued "
+                     "back to back) vs oracle Memory::update (cleanUnusedWords + update() + addNewWords) + computeLikelihood"},
             t_knn / n_frames, t_lik / n_frames)
 
 
@@ -517,67 +518,108 @@ def host_path_ms(torch, eng, frames_np, n_sig, steps=20):
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
-def with_update_ms(torch, eng, stepper, steps=256, remove_every=8, rebuild_every=64):
-    """The step + VWDictionary::update() (VWDictionary.cpp:475-701) on the device: every frame's new words become vocabulary rows behind
-    its decision loop (lcd_frame_args.append_new_words: no read-back, no lcd_vocab_append, the pipeline keeps running; the next frame's
-    re-rank scans the rows its filter could not see yet), and every `remove_every`-th frame the words created `remove_every` .. 2 x
-    `remove_every` frames earlier are removed again (lcd_vocab_remove: the pipeline is completed, the rows are tombstoned) -- the
-    vocabulary is compacted (lcd_vocab_rebuild, the full-rebuild branch :610-690) every `rebuild_every`-th frame.  Returns
-    (ms per step with removals, ms per step appending only)."""
-    a = stepper.args
-    a.append_new_words = 1
-    ring_all = torch.zeros((2 * remove_every, Q), dtype=torch.int32, device="cuda")
-    ring = [ring_all[j] for j in range(2 * remove_every)]
-    firsts = [0] * (2 * remove_every)
-    out = []
-    for removals in (True, False):
-        t0 = None
-        for i in range(steps + 16):
-            if i == 16:
-                eng.synchronize()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-            slot = i % len(ring)
-            if removals and i % remove_every == remove_every - 1 and i >= 2 * remove_every:
-                # Memory::cleanUnusedWords + removeWords for the words of the frames in the older half of the ring: their ids are
-                # first_new + k for the k-th new word (the -(k+1) codes of d_word_ids)
-                eng.synchronize()
-                codes_all = ring_all.cpu().numpy()                    # one 32 KB read-back per `remove_every` frames
-                gone = []
-                for j in range(remove_every):
-                    o = (slot + 1 + j) % len(ring)
-                    n_new = int(-codes_all[o].min()) if (codes_all[o] < 0).any() else 0
-                    gone.append(np.arange(firsts[o], firsts[o] + n_new, dtype=np.int32))
-                gone = np.concatenate(gone)
-                if gone.size:
-                    eng.vocab_remove(gone)
-                if i % rebuild_every == rebuild_every - 1:
-                    eng.vocab_rebuild()
-            a.d_word_ids = ring[slot].data_ptr()
-            firsts[slot] = stepper.first_new
-            stepper(i)
+def with_update_ms(torch, eng, stepper, steps=256, lag=8, rebuild_every=64):
+    """The step with the WHOLE of Memory::preUpdate in it, every frame, nothing completed in between (Memory.cpp:1004-1016 runs
+    cleanUnusedWords + VWDictionary::update() before every addNewWords of an incremental dictionary): the frame's new words become
+    vocabulary rows behind its decision loop (append_new_words, as in the headline step); the signature registered `lag` frames earlier is
+    retired as well (a short-lived node, like a WM -> LTM transfer: the words only it referenced become unused); cleanUnusedWords is ONE
+    kernel enqueued behind the frames in flight (lcd_vocab_remove_unused_async: tombstones, logged for the host); every
+    `rebuild_every`-th frame the vocabulary is compacted (lcd_vocab_rebuild, the full-rebuild branch VWDictionary.cpp:610-690 -- the only
+    call of the loop that completes the pipeline).  Returns (ms per step, rows, live rows at the end)."""
+    t0 = None
+    for i in range(steps + 16):
+        if i == 16:
+            eng.synchronize()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        sid = stepper.next_sig
+        stepper(i)
+        if i >= lag:
+            eng.sig_remove(sid - lag)
+        eng.vocab_remove_unused_async()
+        if i % rebuild_every == rebuild_every - 1:
+            eng.vocab_rebuild()
+    eng.synchronize()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    rows, live = eng.vocab_count()
+    return ms, rows, live
+
+
+def frame_latency_ms(torch, eng, stepper, stream, base_i, n=48):
+    """What a caller waits for: (a) in a running stream of frames -- lcd_frame_dev(t) called -> the event recorded behind frame t
+    (lcd_record_event: behind every stage the frame still owes, i.e. its likelihood is readable) has fired, the following frames
+    being submitted meanwhile; host and device clocks are aligned once (an event + a synchronisation: a few microseconds of error);
+    (b) a single frame followed by lcd_synchronize (the owed stages run as three stand-alone launch pairs)."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    for e in evs:
+        e.record(stream)
+    torch.cuda.synchronize()
+    for i in range(8):
+        stepper(base_i + i)
+    eng.record_event(evs[0].cuda_event)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    t_base = time.perf_counter()                         # ~ the moment evs[0] fired (the stream was idle behind it)
+    sub = []
+    eng.record_event(evs[0].cuda_event)
+    torch.cuda.synchronize()
+    t_base = time.perf_counter()
+    for i in range(n):
+        sub.append(time.perf_counter() - t_base)
+        stepper(base_i + 8 + i)
+        eng.record_event(evs[i + 1].cuda_event)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    lat = np.array([evs[0].elapsed_time(evs[i + 1]) - 1e3 * sub[i] for i in range(n)])
+    lat = lat[8:]                                         # the first frames meet an empty pipeline
+    single = []
+    for i in range(12):
+        t0 = time.perf_counter()
+        stepper(base_i + 8 + n + i)
         eng.synchronize()
-        torch.cuda.synchronize()
-        out.append(1e3 * (time.perf_counter() - t0) / steps)
-    a.append_new_words = 0
-    a.d_word_ids = stepper.d_words.data_ptr()
-    return out[0], out[1]
+        single.append(1e3 * (time.perf_counter() - t0))
+    return float(np.median(lat)), float(np.percentile(lat, 95)), float(np.median(single[2:]))
+
+
+def cpp_interface_ms(vocab, words, frames_np, n_sig_small=10000, steps=12):
+    """What a caller of the reference's own interface gets: C++ MemoryHip::update (-> VWDictionaryHip::addNewWords) +
+    MemoryHip::computeLikelihood against every signature + forget of the oldest, in a C++ loop inside liblcd_host.so (cv::Mat-like host
+    matrices in, std::list / std::map out, the host mirror's std::map bookkeeping included) -- on a memory of `n_sig_small` signatures
+    (loading 100 000 signatures into the mirror's std::map containers takes minutes, as it does in the reference)."""
+    from rtabmap_amd import vwdictionary as V
+    mem = V.MemoryHip(strategy=V.kNNBruteForceHIP, incremental=True, nndr=NNDR, new_words_compared_together=True)
+    vw = mem.vwd
+    for w in range(1, vocab.shape[0] + 1):
+        vw.add_word(w, vocab[w - 1])
+    vw.update()
+    t0 = time.perf_counter()
+    for s_ in range(n_sig_small):
+        mem.add_signature(words[s_])
+    load_s = time.perf_counter() - t0
+    ms = mem.time_loop(np.stack(frames_np[: min(len(frames_np), 16)]), steps)
+    mem.close()
+    return ms, n_sig_small, load_s
 
 
 # ----------------------------------------------------------------------------------------------------------------- ORB stream
 def run_orb_stream(args):
     """BASELINE.json config 3 as SURVEY.md 8d specifies it: 2 000 frames of 500 ORB descriptors against an initially EMPTY incremental
     dictionary (NNDR 0.8) grown to ~200k words, every frame also removing the references of frame t - 1000, TF-IDF against the working
-    memory.  Device-pointer path: lcd_frame_dev on a plain handle (the exact Hamming scan has no matrix-core stage to pipeline behind),
-    VWDictionary::update()'s append on the device (append_new_words), descriptors resident in HBM.  The first frames are checked word
-    for word against the oracle; the Hamming scan's HIP-event time at the final vocabulary gives the roofline (integer VALU:
-    SURVEY.md 8d Q2 counts 8 xor + 8 bit-count-adds per descriptor pair); the CPU baseline is the reference's rtflann Hamming scan
-    (exact linear, the strategy the oracle pins) over the final vocabulary + the restated TF-IDF, on a bounded sample."""
+    memory, and -- as Memory::preUpdate does -- cleanUnusedWords before EVERY frame (lcd_vocab_remove_unused_async: one enqueued kernel).
+    Device-pointer path: lcd_frame_dev on a plain handle (the exact Hamming scan has no matrix-core stage to pipeline behind),
+    VWDictionary::update()'s append on the device (append_new_words), descriptors resident in HBM.  Parity at BOTH ends of the stream: the
+    first frames against an oracle that starts empty, and the LAST frames -- the dictionary beyond 200k words, after a thousand
+    retirements and two thousand device-side cleans -- against an oracle memory rebuilt from the engine's own state (its live rows in row
+    order, the working memory's signatures from the device's word log), frame by frame: word ids and likelihood.  The Hamming scan's
+    HIP-event time at the final vocabulary gives the roofline (integer VALU: SURVEY.md 8d Q2 counts 8 xor + 8 bit-count-adds per
+    descriptor pair); the CPU baseline is the reference's rtflann Hamming scan (exact linear, the strategy the oracle pins) over the
+    final vocabulary + the restated TF-IDF, on a bounded sample."""
     import torch
     import rtabmap_amd
     from rtabmap_amd import synth
     import oracle as O
-    n_frames, q, W, n_check = (args.steps if args.steps != 200 else 2000), 500, 1000, 60
+    n_frames, q, W, n_check, n_tail = (args.steps if args.steps != 200 else 2000), 500, 1000, 60, 20
     base = synth.vocab_orb(200000)
     # Queries-ORB of SURVEY.md 8d, a fresh draw per frame: 90 % noisy copies (each bit flipped w.p. 0.1) of rows of the hidden 200k-row
     # Vocab-ORB -- they come back in later frames and keep their words alive --, 10 % uniform random descriptors: words that die when their
@@ -593,50 +635,92 @@ def run_orb_stream(args):
     base_ptr, words_ptr = d_frames.data_ptr(), d_words.data_ptr()
     a = eng.frame_args(q=q, flags=3, nndr_ratio=NNDR, d_likelihood=d_like.data_ptr(), likelihood_capacity=cap, append_new_words=1)
     n_prof = 40
+    T0 = max(n_frames - n_tail, 0)                                 # the frames from T0 on run one by one next to the oracle
+
+    def one(t):
+        a.d_descriptors = base_ptr + t * q * 32
+        a.d_word_ids = words_ptr + t * q * 4
+        a.sig_id = t + 1
+        a.first_new_word_id = 1 + t * q                      # an upper bound per frame: nothing is read back (ids only have to ascend)
+        a.N = float(min(t + 1, W + 1))                      # Memory::getSignatures().size() with the new signature in it (Memory.cpp:2248)
+        eng.frame_dev_args(a)
+        if t + 1 > W:
+            eng.sig_remove(t + 1 - W)
+        eng.vocab_remove_unused_async()                      # Memory::cleanUnusedWords, in front of the next frame's update()
 
     def run(t0, t1):
         for t in range(t0, t1):
-            a.d_descriptors = base_ptr + t * q * 32
-            a.d_word_ids = words_ptr + t * q * 4
-            a.sig_id = t + 1
-            a.first_new_word_id = 1 + t * q                      # an upper bound per frame: nothing is read back (ids only have to ascend)
-            a.N = float(min(t + 1, W))
-            eng.frame_dev_args(a)
-            if t + 1 > W:
-                eng.sig_remove(t + 1 - W)
-            if t % clean_every == clean_every - 1 and t + 1 > W:
-                # Memory::cleanUnusedWords from the device's reference counts (the reference runs it before every frame; here every
-                # `clean_every` frames: it completes the owed work and reads the removed rows back); compaction when a quarter is dead
-                eng.vocab_remove_unused()
-                rows_now, live_now = eng.vocab_count()
+            one(t)
+            if t % compact_every == compact_every - 1 and t + 1 > W:
+                rows_now, live_now = eng.vocab_count()       # (completes the owed work) compaction when a quarter of the rows is dead
                 if rows_now - live_now > rows_now // 4:
                     eng.vocab_rebuild()
-    clean_every = 25
+    compact_every = 100
     t_start = time.perf_counter()
-    run(0, n_frames - n_prof)
+    run(0, max(T0 - n_prof, 0))
     eng.synchronize()
-    eng.profile_begin(n_prof)                                    # HIP events around the scan kernel of the last frames (largest vocabulary)
-    run(n_frames - n_prof, n_frames)
+    eng.profile_begin(n_prof)                                    # HIP events around the scan kernel of the last timed frames (largest vocabulary)
+    run(max(T0 - n_prof, 0), T0)
     eng.synchronize()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t_start
+    n_timed = max(T0, 1)
     scan_ms, scan_n, scan_name = eng.profile_read()
     rows, live = eng.vocab_count()
     got = d_words.cpu().numpy()
-    # ---- parity: the first frames against the oracle (it assigns consecutive ids: compare the canonical form -- every word replaced by
-    # the position of its first occurrence in the stream)
+
+    def eng_ids(t, codes):
+        return np.where(codes < 0, 1 + t * q - codes - 1, codes)
+    # ---- parity, head of the stream: the first frames against an oracle that starts empty (it assigns consecutive ids: compare the
+    # canonical form -- every word replaced by the position of its first occurrence in the stream)
     o = O.OracleMemory(strategy=O.kNNBruteForce, nndr=NNDR, new_words_compared_together=True)
     canon_o, canon_h, first_o, first_h, exp_lists = [], [], {}, {}, []
-    for t in range(min(n_check, n_frames)):
+    for t in range(min(n_check, T0)):
         so, ido = o.update(frames[t])
         exp_lists.append(ido)
-        ids_h = np.where(got[t] < 0, 1 + t * q - got[t] - 1, got[t]).tolist()
+        ids_h = eng_ids(t, got[t]).tolist()
         for k, (wo, wh) in enumerate(zip(ido, ids_h)):
             canon_o.append(first_o.setdefault(wo, len(first_o)))
             canon_h.append(first_h.setdefault(wh, len(first_h)))
     ids_equal = canon_o == canon_h
+    # ---- parity, tail of the stream: an oracle memory with the engine's own state at frame T0, then frame by frame
+    vr, vi = eng.vocab_read(0, rows)
+    keep = vi != 0
+    o2 = O.OracleMemory(strategy=O.kNNBruteForce, nndr=NNDR, new_words_compared_together=True)
+    for wid, r in zip(vi[keep].tolist(), vr[keep]):
+        o2.vwd.add_word(int(wid), r)
+    o2.vwd.update()
+    live_sigs = list(range(max(T0 - W, 0) + 1, T0 + 1))
+    known = set(vi[keep].tolist())
+    tail_state_ok = True
+    for sid in live_sigs:
+        w = eng_ids(sid - 1, got[sid - 1]).astype(np.int32)
+        tail_state_ok &= bool(set(w.tolist()) <= known)           # a live signature's words are rows of the vocabulary
+        assert o2.add_signature_with_id(sid, w) == sid
+    tail_state_ok &= not o2.vwd.get_unused_word_ids()            # the device-side cleans left no live row without a reference
+    tail_ids_equal, tail_max_rel, tail_n, eng2orc, t_knn_tail = True, 0.0, 0, {}, 0.0
+    for t in range(T0, n_frames):
+        one(t)
+        eng.synchronize()
+        codes = d_words[t].cpu().numpy()
+        t1 = time.perf_counter()
+        so, ido = o2.update(frames[t])
+        t_knn_tail += time.perf_counter() - t1
+        ids_h = eng_ids(t, codes).tolist()
+        for j in np.flatnonzero(codes < 0).tolist():
+            eng2orc.setdefault(ids_h[j], ido[j])
+        tail_ids_equal &= bool(so == t + 1 and [eng2orc.get(w, w) for w in ids_h] == list(ido))
+        live_sigs.append(t + 1)
+        oi, Lo = o2.compute_likelihood(np.array(ido, np.int32), np.array(live_sigs, np.int32))
+        Lh = d_like[: t + 1].cpu().numpy()[oi - 1]
+        err = np.abs(Lh - Lo) / np.maximum(np.abs(Lo), 1e-7 / 1e-4)
+        tail_max_rel = max(tail_max_rel, float(err.max()))
+        tail_n += int(Lo.size)
+        if t + 1 > W:
+            o2.forget(t + 1 - W)
+            live_sigs.remove(t + 1 - W)
+    rows_end, live_end = eng.vocab_count()
     # ---- CPU baseline on a bounded sample: the reference's rtflann Hamming scan over the FINAL vocabulary, 1 core, + the restated TF-IDF
-    vr, _ = eng.vocab_read(0, rows)
     if O.have_ref():
         lin = O.RefIndex(vr, algo=O.ALGO_LINEAR)
         knn = lambda d: lin.knn(d, k=2, checks=32, cores=1)       # noqa: E731
@@ -646,10 +730,10 @@ def run_orb_stream(args):
     for t in range(2):
         knn(frames[n_frames - 1 - t])
     t_knn = (time.perf_counter() - t1) / 2
-    live_o = np.array(o.signature_ids(), np.int32)
+    live_o = np.array(o2.signature_ids(), np.int32)
     t2 = time.perf_counter()
-    for ido in exp_lists[-3:]:
-        o.compute_likelihood(np.array(ido, np.int32), live_o)
+    for t in range(3):
+        o2.compute_likelihood(eng_ids(n_frames - 1 - t, got[n_frames - 1 - t] if n_frames - 1 - t < T0 else d_words[n_frames - 1 - t].cpu().numpy()).astype(np.int32), live_o)
     t_lik = (time.perf_counter() - t2) / 3 * (min(W, n_frames) / max(len(live_o), 1))   # scaled to the full working memory
     cand = min(W, n_frames)
     pairs = float(q) * rows
@@ -657,11 +741,12 @@ def run_orb_stream(args):
     achieved = lane_ops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
     PEAK_INT = 39.3                                               # T lane-ops/s: 256 CUs x 64 lanes x 2.4 GHz
     out = {"metric": "loop-closure candidates/sec (ORB 256-bit, incremental dictionary from empty, W=1000)", "unit": "candidates/s",
-           "value": n_frames * cand / wall, "n_gpus": 1, "steps": n_frames, "warmup": 0, "ms_per_step": 1e3 * wall / n_frames,
+           "value": n_timed * cand / wall, "n_gpus": 1, "steps": n_timed, "warmup": 0, "ms_per_step": 1e3 * wall / n_timed,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
            "config": {"workload": "config 3: %d ORB frames x %d descriptors, incremental dictionary grown from empty to %d words (%d rows), "
-                                  "update() appends on the device, W=%d retirement, device-pointer path (lcd_frame_dev, plain handle)" % (n_frames, q, live, rows, W),
-                      "dictionary_words": int(live), "frames_per_s": n_frames / wall},
+                                  "update() appends on the device, cleanUnusedWords enqueued every frame, W=%d retirement, device-pointer path "
+                                  "(lcd_frame_dev, plain handle); %d timed frames, then %d frames one by one next to the oracle" % (n_frames, q, live, rows, W, n_timed, n_frames - T0),
+                      "dictionary_words": int(live), "dictionary_words_at_the_end": int(live_end), "frames_per_s": n_timed / wall},
            "roofline": {"bound": "valu-int", "achieved": achieved, "peak": PEAK_INT, "unit": "T lane-ops/s", "frac": achieved / PEAK_INT, "traffic": None,
                         "kernel": scan_name, "ms": scan_ms, "samples": scan_n, "rows_scanned": int(rows),
                         "algorithmic": "%d x %d descriptor pairs x 16 lane-ops (8 x (xor + bit-count-add))" % (q, rows),
@@ -669,8 +754,16 @@ def run_orb_stream(args):
            "cpu_baseline": {"value": cand / (t_knn + t_lik), "unit": "candidates/s", "cores": 1, "kind": "reference" if O.have_ref() else "port",
                             "sample": "2 frames x exact Hamming 2-NN over the final %d-row vocabulary (%.0f ms/frame) + restated std::map TF-IDF "
                                       "scaled to %d signatures (%.1f ms/frame)" % (rows, 1e3 * t_knn, cand, 1e3 * t_lik)},
-           "parity": {"frames_checked": min(n_check, n_frames), "word_ids_equal": bool(ids_equal),
-                      "path": "lcd_frame_dev(u8, append_new_words) vs oracle Memory::update, canonical word numbering"}}
+           "parity": {"frames_checked": list(range(min(n_check, T0))) [:3] + ["...", min(n_check, T0) - 1] + list(range(T0, n_frames)),
+                      "head": {"frames": [0, min(n_check, T0) - 1], "word_ids_equal": bool(ids_equal)},
+                      "tail": {"frames": [T0, n_frames - 1], "dictionary_words": int(live), "retirements_before": max(T0 - W, 0),
+                               "state_consistent": bool(tail_state_ok), "word_ids_equal": bool(tail_ids_equal),
+                               "likelihood_max_rel": tail_max_rel, "likelihood_values_compared": tail_n,
+                               "oracle_ms_per_frame": 1e3 * t_knn_tail / max(n_frames - T0, 1)},
+                      "word_ids_equal": bool(ids_equal and tail_ids_equal and tail_state_ok),
+                      "path": "lcd_frame_dev(u8, append_new_words) + lcd_vocab_remove_unused_async vs oracle Memory::update (cleanUnusedWords + "
+                              "update() + addNewWords) + computeLikelihood; head: canonical word numbering from an empty dictionary; tail: the "
+                              "oracle's memory rebuilt from the engine's rows and word log at frame %d" % T0}}
     print(json.dumps(out), flush=True)
     eng.close()
 
@@ -678,59 +771,71 @@ def run_orb_stream(args):
 # ----------------------------------------------------------------------------------------------------------------- replay (config 5 stand-in)
 def run_replay(args):
     """BASELINE.json config 5 cannot run here (KITTI images, OpenCV/PCL: SURVEY.md 8d); its prescribed stand-in does: a descriptor-stream
-    replay with revisits through the loop-closure path -- Memory::update (addNewWords against the fixed 49k dictionary) -> references ->
-    Memory::computeLikelihood against EVERY signature in memory -> Rtabmap::adjustLikelihood + best candidate (every `hyp_every`-th
-    frame) -- with the memory grown through lcd_frame_dev, frame by frame, from empty to --signatures (1 000 000 asked for: nothing is
-    retired, as the reference's WM cannot hold that many either, the point is the frame path at that size).  Trajectory: 2 048 places
-    visited round robin, two noisy views per place alternating lap by lap: from the second lap on every frame revisits a place, and
-    the loop-closure RECALL is counted like the reference's harness does (tools/ConsoleApp/main.cpp:383-506 compares the detected id
-    with the ground truth): a sampled frame counts when its best candidate (outside the newest 30 signatures) shows the same place."""
+    replay with revisits through the loop-closure path of Rtabmap::process, EVERY frame: Memory::update (cleanUnusedWords is a no-op here:
+    nothing is retired; VWDictionary::update() appends the previous frame's new words; addNewWords against the INCREMENTAL dictionary that
+    starts as the 49k-word one, Memory.cpp:5941-6059) -> references -> Memory::computeLikelihood against EVERY signature in memory ->
+    Rtabmap::adjustLikelihood + the best candidate (Rtabmap.cpp:2117-2131), with the memory grown through lcd_frame_dev, frame by frame,
+    from empty to --signatures (1 000 000 asked for: nothing is retired, as the reference's WM cannot hold that many either, the point is
+    the frame path at that size).  Trajectory: 2 048 places visited round robin, two noisy views per place alternating lap by lap: from
+    the second lap on every frame revisits a place, and the loop-closure RECALL is counted like the reference's harness does
+    (tools/ConsoleApp/main.cpp:383-506 compares the detected id with the ground truth): a frame counts when its best candidate (outside
+    the newest 30 signatures) shows the same place.
+    Parity on frames SAMPLED ACROSS THE WHOLE RUN (every frame's word ids stay on the device, the sampled frames' likelihood vectors too):
+    word ids against the C++ oracle's VWDictionary::addNewWords over the dictionary as the engine had it at that frame (base words + the
+    words the device's log says earlier frames created, exact linear 2-NN); likelihood and adjustLikelihood's record against the
+    restated Memory::computeLikelihood on the memory replayed from the device's word log -- the C++ std::map oracle while the memory
+    fits it (<= 120 000 signatures), its numpy restatement (oracle/tfidf_np.py, pinned to the C++ one) beyond."""
     import torch
     import rtabmap_amd
     from rtabmap_amd import synth
     import oracle as O
+    from oracle import tfidf_np
     n_total = args.signatures if args.signatures != N_SIG else 1_000_000
-    P, V, q, hyp_every, stm = 2048, 2, Q, 64, 30
+    P, V, q, stm, n_samples = 2048, 2, Q, 30, 20
     vocab = synth.vocab_surf(N_WORDS)
     place_words = synth.zipf_words(P, q, N_WORDS, seed=5)
     pool = np.stack([synth.frame_from_signature(vocab, place_words[p], seed=9000 + v * P + p, resample=0.0, sigma=0.03)
                      for v in range(V) for p in range(P)])                         # [V * P, q, 64]: view v of place p at v * P + p
     d_pool = torch.from_numpy(pool).cuda()
     stream = torch.cuda.Stream()
-    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=N_WORDS + 1024, sig_capacity=n_total + 4096, stream=stream.cuda_stream, pipeline=1)
+    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=N_WORDS + V * P * q // 2, sig_capacity=n_total + 4096, stream=stream.cuda_stream, pipeline=1)
     eng.vocab_append(vocab, np.arange(1, N_WORDS + 1, dtype=np.int32))
     cap = n_total + 64
     depth = eng.pipeline_depth() + 1
-    d_words = torch.zeros((depth, q), dtype=torch.int32, device="cuda")
+    # sampled frames: spread over the run (the first laps -- where the dictionary still grows -- included), the last frame among them
+    sample_t = sorted(set([3, P // 2, P + 7, 2 * P + 11, 3 * P + 5] + np.linspace(4 * P, n_total - 1, n_samples - 5).astype(np.int64).tolist()))
+    sample_t = [t for t in sample_t if 0 <= t < n_total]
+    sample_slot = {t: k for k, t in enumerate(sample_t)}
+    d_words = torch.zeros((n_total, q), dtype=torch.int32, device="cuda")           # the word log: 2 KB per frame stays in HBM
     d_like = torch.zeros((depth, cap), dtype=torch.float32, device="cuda")
-    n_hyp = (n_total + hyp_every - 1) // hyp_every
-    d_hyp = torch.zeros((n_hyp, 8), dtype=torch.int32, device="cuda")
-    n_par = 24
-    d_words_par = torch.zeros((n_par, q), dtype=torch.int32, device="cuda")
-    d_like_par = torch.zeros((n_par, 64), dtype=torch.float32, device="cuda")
-    d_hyp_par = torch.zeros((n_par, 8), dtype=torch.int32, device="cuda")
+    d_like_s = [torch.zeros(t + 2, dtype=torch.float32, device="cuda") for t in sample_t]
+    d_hyp = torch.zeros((n_total, 8), dtype=torch.int32, device="cuda")             # adjustLikelihood's record of EVERY frame (32 B)
     torch.cuda.synchronize()
-    a = eng.frame_args(q=q, flags=0, nndr_ratio=NNDR, first_new_word_id=0, exclude_recent=stm)   # fixed dictionary: the nearest word, no new words
+    a = eng.frame_args(q=q, flags=3, nndr_ratio=NNDR, exclude_recent=stm, append_new_words=1)
     pool_ptr, wp, lp, hp = d_pool.data_ptr(), d_words.data_ptr(), d_like.data_ptr(), d_hyp.data_ptr()
+    n_prof = 40
 
     def frame_index(t):
         return ((t // P) % V) * P + (t % P)
     t_start = time.perf_counter()
     marks = {}
     for t in range(n_total):
+        if t == n_total - n_prof:
+            eng.synchronize()
+            eng.profile_begin(n_prof)
         a.d_descriptors = pool_ptr + frame_index(t) * q * DIM * 4
         a.sig_id = t + 1
         a.N = float(t + 1)
-        if t < n_par:                                           # the first frames keep their outputs for the parity check
-            a.d_word_ids = d_words_par.data_ptr() + t * q * 4
-            a.d_likelihood = d_like_par.data_ptr() + t * 64 * 4
-            a.likelihood_capacity = 64
-            a.d_hypothesis = d_hyp_par.data_ptr() + t * 32
+        a.first_new_word_id = N_WORDS + 1 + t * q                # an upper bound per frame: nothing is read back
+        a.d_word_ids = wp + t * q * 4
+        k = sample_slot.get(t)
+        if k is not None:
+            a.d_likelihood = d_like_s[k].data_ptr()
+            a.likelihood_capacity = t + 2
         else:
-            a.d_word_ids = wp + (t % depth) * q * 4
             a.d_likelihood = lp + (t % depth) * cap * 4
             a.likelihood_capacity = cap
-            a.d_hypothesis = (hp + (t // hyp_every) * 32) if t % hyp_every == 0 else None
+        a.d_hypothesis = hp + t * 32
         eng.frame_dev_args(a)
         if t + 1 in (100_000, 500_000):
             eng.synchronize()
@@ -738,43 +843,145 @@ def run_replay(args):
     eng.synchronize()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t_start
-    # ---- recall
+    rows, live = eng.vocab_count()
+    roof_knn, roof_score = rooflines(eng, rows, n_total, False)
+    for r in (roof_knn, roof_score):
+        if r:
+            r["traffic"] = None                                    # (the committed PMC summary is the headline configuration's)
+            r["traffic_note"] = "not measured for this configuration"
+            r["measured_in"] = "HIP events attached to the launches of the last %d frames (memory at its final size)" % n_prof
+    # ---- recall, over EVERY frame that revisits a place
     hyp = d_hyp.cpu().numpy()
-    ts = np.arange(0, n_total, hyp_every)
+    ts = np.arange(n_total)
     valid = ts >= P + stm
     best_sig = hyp[:, 0]
     hit = valid & (best_sig > 0) & (((best_sig - 1) % P) == (ts % P))
     recall = float(hit.sum()) / max(int(valid.sum()), 1)
     adjusted = hyp[:, 3].view(np.float32)
-    # ---- parity of the first frames: oracle Memory::update (fixed dictionary) + computeLikelihood + adjustLikelihood
-    o = O.OracleMemory(strategy=O.kNNBruteForce, nndr=NNDR, incremental=False)
+    # ---- parity on the sampled frames
+    t_par = time.perf_counter()
+    log = d_words.cpu().numpy()                                                    # [n_total, q] codes: > 0 word id, < 0 the frame's -(k+1)-th new word
+    first_new = N_WORDS + 1 + np.arange(n_total, dtype=np.int64) * q
+    ids_log = np.where(log < 0, first_new[:, None] - log - 1, log).astype(np.int32)
+    created_by = np.flatnonzero((log < 0).any(axis=1))                             # frames that created words (the first laps)
+    o = O.OracleVWDictionary(strategy=O.kNNBruteForce, incremental=True, nndr=NNDR, new_words_compared_together=True)
     for w in range(1, N_WORDS + 1):
-        o.vwd.add_word(w, vocab[w - 1])
-    o.vwd.update()
-    gw, gl, gh = d_words_par.cpu().numpy(), d_like_par.cpu().numpy(), d_hyp_par.cpu().numpy()
-    ids_equal, max_rel, hyp_equal = True, 0.0, True
-    for t in range(n_par):
-        so, ido = o.update(pool[frame_index(t)])
-        ids_equal &= bool(gw[t].tolist() == ido)
-        live = np.arange(1, t + 2, dtype=np.int32)
-        oi, Lo = o.compute_likelihood(np.array(ido, np.int32), live)
-        err = np.abs(gl[t][: t + 1] - Lo) / np.maximum(np.abs(Lo), 1e-7 / 1e-4)
+        o.add_word(w, vocab[w - 1])
+    added_upto = 0                                                                  # frames whose created words the oracle dictionary holds
+    known = set()
+    mem = None                                                                      # the C++ oracle memory, while the replay fits it
+    mem_upto = 0
+    ids_equal, max_rel, n_cmp, hyp_ok, checked = True, 0.0, 0, True, []
+    knn_s = lik_s = 0.0
+    for t in sample_t:
+        # the dictionary as update() leaves it in front of frame t: every word a frame < t created, in id order
+        for f in created_by[(created_by >= added_upto) & (created_by < t)].tolist():
+            codes = log[f]
+            for j in np.flatnonzero(codes < 0).tolist():
+                wid = int(ids_log[f, j])
+                if wid not in known:                                                # the first descriptor with the code created the word
+                    known.add(wid)
+                    o.add_word(wid, pool[frame_index(f)][j])
+        added_upto = max(added_upto, t)
+        o.update()
+        last_before = o.last_word_id
+        t1 = time.perf_counter()
+        exp = o.add_new_words(pool[frame_index(t)], t + 1)
+        knn_s += time.perf_counter() - t1
+        # the oracle numbers the new words of frame t consecutively from ITS last id (++_lastWordId): compare by rank within the frame,
+        # the form the device reports (-(k + 1) for the frame's k-th new word)
+        canon_o = [-(w - last_before) if w > last_before else w for w in exp]
+        ids_equal &= bool(canon_o == log[t].tolist())
+        # the oracle's own new words of this frame were only needed for the comparison: drop them again (the replayed dictionary takes
+        # the device's ids for them when a later sample needs them)
+        new_o = sorted(set(w for w in exp if w > last_before))
+        for w in set(exp):
+            o.remove_all_word_ref(int(w), t + 1)
+        if new_o:
+            o.remove_words(new_o)
+        # likelihood: Memory::computeLikelihood of frame t's words against signatures 1 .. t + 1 (frame t itself included)
+        t2 = time.perf_counter()
+        if t + 1 <= 120_000:
+            if mem is None:
+                mem = O.OracleMemory(strategy=O.kNNBruteForce, nndr=NNDR)
+                for w in range(1, N_WORDS + 1):
+                    mem.vwd.add_word(w, vocab[w - 1])
+            for f in range(mem_upto, t + 1):
+                for wid in set(ids_log[f][log[f] < 0].tolist()):
+                    if mem.vwd.word_refs(int(wid)) is None:
+                        mem.vwd.add_word(int(wid), vocab[0])                      # (the descriptor plays no part in the likelihood)
+                assert mem.add_signature_with_id(f + 1, ids_log[f]) == f + 1
+            mem_upto = t + 1
+            oi, Lo = mem.compute_likelihood(ids_log[t], np.arange(1, t + 2, dtype=np.int32))
+            how = "C++ oracle"
+        else:
+            Lo = tfidf_np.compute_likelihood_dense(ids_log[: t + 1], ids_log[t])
+            how = "numpy restatement"
+        lik_s += time.perf_counter() - t2
+        Lh = d_like_s[sample_slot[t]][: t + 1].cpu().numpy()
+        err = np.abs(Lh - Lo) / np.maximum(np.abs(Lo), 1e-7 / 1e-4)
         max_rel = max(max_rel, float(err.max()))
+        n_cmp += int(Lo.size)
+        # adjustLikelihood + best candidate over the signatures outside the newest `stm` (Rtabmap.cpp:2046-2131)
+        n_cons = t + 1 - stm
+        if n_cons > 0:
+            adj = O.adjust_likelihood(np.concatenate([[0.0], Lo[:n_cons]]).astype(np.float32), 0.0)
+            best = int(np.argmax(Lo[:n_cons]))
+            hyp_ok &= bool(int(hyp[t, 0]) == best + 1 or Lo[int(hyp[t, 0]) - 1] == Lo[best])
+            hyp_ok &= bool(abs(float(hyp[t, 3:4].view(np.float32)[0]) - float(adj[1 + best])) <= 1e-4 * max(abs(float(adj[1 + best])), 1e-3))
+        checked.append({"frame": int(t), "signatures": int(t + 1), "likelihood_by": how})
+    par_s = time.perf_counter() - t_par
+    # ---- CPU baseline on a bounded sample: the reference's kd-tree / exact scan over the FINAL dictionary + the restated std::map TF-IDF
+    # on the largest memory the C++ oracle held, scaled linearly to n_total signatures (the reference's loop is linear in the postings)
+    vr, _ = eng.vocab_read(0, rows)
+    if O.have_ref():
+        kd = O.RefIndex(vr, algo=O.ALGO_KDTREE, trees=4)
+        t1 = time.perf_counter()
+        for i in range(5):
+            kd.knn(pool[i], k=2, checks=32, cores=1)
+        t_knn_cpu = (time.perf_counter() - t1) / 5
+        knn_what = "rtflann kd-tree (4 trees, 32 checks), 1 core, %d rows" % rows
+        kind = "reference"
+    else:
+        t1 = time.perf_counter()
+        O.knn2_linear(vr, pool[0])
+        t_knn_cpu = time.perf_counter() - t1
+        knn_what = "exact linear port, 1 core, %d rows" % rows
+        kind = "port"
+    t_lik_cpu, lik_what = None, "not measured"
+    if mem is not None and mem_upto >= 1000:
+        t1 = time.perf_counter()
+        for i in range(3):
+            mem.compute_likelihood(ids_log[mem_upto - 1 - i], np.arange(1, mem_upto + 1, dtype=np.int32))
+        t_lik_cpu = (time.perf_counter() - t1) / 3 * (n_total / float(mem_upto))
+        lik_what = "restated std::map Memory::computeLikelihood on %d signatures, scaled x%.1f to %d" % (mem_upto, n_total / float(mem_upto), n_total)
     eng.close()
     cand_total = n_total * (n_total + 1) / 2.0
     out = {"metric": "loop-closure candidates/sec (descriptor-stream replay with revisits, memory grown to %d signatures)" % n_total,
            "unit": "candidates/s", "value": cand_total / wall, "n_gpus": 1, "steps": n_total, "warmup": 0, "ms_per_step": 1e3 * wall / n_total,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "config 5 stand-in (SURVEY.md 8d): %d frames x %d SURF descriptors, fixed %d-word dictionary, %d places x %d views "
-                                  "round robin, every frame registered (memory 0 -> %d signatures), TF-IDF against all of them, adjustLikelihood + best "
-                                  "candidate every %d-th frame; pipelined lcd_frame_dev" % (n_total, q, N_WORDS, P, V, n_total, hyp_every),
+           "config": {"workload": "config 5 stand-in (SURVEY.md 8d): %d frames x %d SURF descriptors through Memory::update -> addNewWords (incremental "
+                                  "dictionary from %d words, update()'s append on the device) -> references -> computeLikelihood against every signature "
+                                  "-> adjustLikelihood + best candidate, EVERY frame; %d places x %d views round robin, memory 0 -> %d signatures; "
+                                  "pipelined lcd_frame_dev" % (n_total, q, N_WORDS, P, V, n_total),
+                      "dictionary_rows_at_the_end": int(rows), "frames_that_created_words": int(created_by.size),
                       "frames_per_s": n_total / wall, "wall_s": wall, "wall_s_at_signatures": {str(k): v for k, v in marks.items()},
-                      "ms_per_frame_last_half": 1e3 * (wall - marks.get(500_000, 0.0)) / (n_total - 500_000) if 500_000 in marks and n_total > 500_000 else None},
-           "recall": {"sampled_frames": int(valid.sum()), "loop_closures_found": int(hit.sum()), "recall": recall,
+                      "ms_per_frame_last_half": 1e3 * (wall - marks.get(500_000, 0.0)) / (n_total - 500_000) if 500_000 in marks and n_total > 500_000 else None,
+                      "parity_host_seconds": par_s},
+           "roofline": roof_score if roof_score is not None else roof_knn, "roofline_score": roof_score, "roofline_knn": roof_knn,
+           "recall": {"frames_counted": int(valid.sum()), "loop_closures_found": int(hit.sum()), "recall": recall,
                       "mean_adjusted_likelihood_of_hits": float(adjusted[hit].mean()) if hit.any() else None,
-                      "rule": "best raw-likelihood candidate outside the newest %d signatures shows the same place as the frame" % stm},
-           "parity": {"frames_checked": n_par, "word_ids_equal": bool(ids_equal), "likelihood_max_rel": max_rel,
-                      "path": "the replay's first frames vs oracle Memory::update (fixed dictionary) + computeLikelihood"}}
+                      "rule": "every frame from the second lap on: the best raw-likelihood candidate outside the newest %d signatures shows the frame's place" % stm},
+           "parity": {"frames_checked": checked, "word_ids_equal": bool(ids_equal), "likelihood_max_rel": max_rel, "likelihood_values_compared": n_cmp,
+                      "adjust_likelihood_and_best_candidate_equal": bool(hyp_ok), "bound": "1e-4 relative (abs floor 1e-7)",
+                      "oracle_seconds": {"addNewWords": knn_s, "computeLikelihood": lik_s},
+                      "path": "sampled frames of the replay: word ids vs the C++ oracle's addNewWords over the dictionary replayed from the device's word "
+                              "log; likelihood + adjustLikelihood vs Memory::computeLikelihood on the memory replayed from that log (C++ std::map oracle up "
+                              "to 120 000 signatures, its numpy restatement oracle/tfidf_np.py beyond)"}}
+    if t_lik_cpu is not None:
+        out["cpu_baseline"] = {"value": n_total / (t_knn_cpu + t_lik_cpu), "unit": "candidates/s (at the final memory size)", "cores": 1, "kind": kind,
+                               "sample": "5 frames x %s (%.1f ms/frame) + 3 frames x %s (%.0f ms/frame)" % (knn_what, 1e3 * t_knn_cpu, lik_what, 1e3 * t_lik_cpu),
+                               "gpu_at_the_final_size": n_total / (1e-3 * (out["config"]["ms_per_frame_last_half"] or out["ms_per_step"]))}
     print(json.dumps(out), flush=True)
 
 
@@ -890,7 +1097,7 @@ def main():
     else:
         src, frames_np = make_frames(rank)                 # replicas: every rank has its own stream of frames
         d_frames = [torch.from_numpy(f).cuda() for f in frames_np]
-        eng = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 1024, sig_capacity=n_sig + 8192,
+        eng = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 65536, sig_capacity=n_sig + 8192,
                                  stream=stream.cuda_stream, pipeline=args.pipeline)
         if args.score_block:
             eng.set_option("score_block", args.score_block)
@@ -927,7 +1134,8 @@ def main():
               "step_ms_p95": float(np.percentile(res["per_step_ms"], 95)) if res["per_step_ms"].size else None,
               "world_size_observed": world, "collective_backend": backend, "signatures_bulk_load_s": build_s,
               "pipeline": "software-pipelined frames, four in flight: 2 launches per frame (A: query pre-split of frame t + filter of t-1 + decision loop "
-                          "of t-2 + registration of t-3; B: re-rank of frame t-1 + scoring of t-3), one stream" if (args.pipeline and not shard) else "4 launches per frame, one stream",
+                          "of t-2 + registration of t-3; B: re-rank of frame t-1 + scoring of t-3), one stream; the step includes VWDictionary::update()'s append branch on the device (append_new_words): the vocabulary "
+                          "grows by the frame's new words before the next frame is searched" if (args.pipeline and not shard) else "4 launches per frame, one stream",
               "parallelism": ("vocabulary sharded by word-id range over %d GPUs (all-gather top-2 + int64 all-reduce per frame, the all-reduce "
                               "overlapped with the next frame's search)" % world) if shard
               else ("%d independent replicas (one frame stream per GPU, no data-path collective)" % world if world > 1 else "1 GPU")}
@@ -1007,14 +1215,33 @@ def main():
                                       stream=stream.cuda_stream, pipeline=args.pipeline)
             load_engine(engw, vocab, words)
             stw = Stepper(engw, torch, d_frames, n_sig, cap)
-            wu, wa = with_update_ms(torch, engw, stw)
+            wu, wrows, wlive = with_update_ms(torch, engw, stw)
             config["with_update_ms_per_step"] = wu
-            config["with_append_ms_per_step"] = wa
-            config["with_update_note"] = "step with lcd_frame_args.append_new_words (the frame's new words become vocabulary rows on the device, " \
-                                         "VWDictionary::update()'s append branch; the pipeline keeps running) + every 8th frame lcd_vocab_remove of " \
-                                         "the words created 8..16 frames earlier (completes the pipeline, tombstones) + every 64th frame " \
-                                         "lcd_vocab_rebuild; with_append = the same without the removals; vocabulary at the end: %d rows" % engw.vocab_count()[0]
+            config["with_update_note"] = "the headline step + the rest of Memory::preUpdate EVERY frame, nothing completed in between: the signature " \
+                                         "registered 8 frames earlier retired too, cleanUnusedWords as one enqueued kernel " \
+                                         "(lcd_vocab_remove_unused_async), lcd_vocab_rebuild every 64th frame (the only draining call); 256 steps; " \
+                                         "vocabulary at the end: %d rows, %d live" % (wrows, wlive)
             engw.close()
+            engn = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 8192,
+                                      stream=stream.cuda_stream, pipeline=args.pipeline)
+            load_engine(engn, vocab, words)
+            stn = Stepper(engn, torch, d_frames, n_sig, cap, append=False)
+            rn = timed_loop(torch, dist, 1, stream, stn, args.steps, args.warmup, eng=engn, per_step_events=False)
+            config["no_append_ms_per_step"] = 1e3 * rn["wall"] / args.steps
+            config["no_append_note"] = "the step as rounds 1-3 timed it: the frame's new words get postings but never become vocabulary rows (same command)"
+            engn.close()
+            lat_med, lat_p95, lat_single = frame_latency_ms(torch, eng, step, stream, args.warmup + args.steps + 400)
+            config["frame_latency_ms"] = {"in_a_stream_median": lat_med, "in_a_stream_p95": lat_p95, "single_frame_then_synchronize_median": lat_single,
+                                          "note": "lcd_frame_dev(t) called -> frame t's likelihood readable (event behind every stage it owes): in a "
+                                                  "running stream three further calls carry its stages; alone, lcd_synchronize runs them stand-alone"}
+            try:
+                cms, cn, cload = cpp_interface_ms(vocab, words, frames_np)
+                config["cpp_interface_ms_per_step"] = cms
+                config["cpp_interface_note"] = "C++ loop in liblcd_host.so through the reference's interface: MemoryHip::update (VWDictionaryHip::addNewWords) + " \
+                                               "computeLikelihood against all %d signatures of its memory + forget(oldest), host matrices in, std::map out " \
+                                               "(%d signatures loaded into the mirror's containers in %.1f s)" % (cn, cn, cload)
+            except Exception as e:                                # noqa: BLE001
+                config["cpp_interface_error"] = "%s: %s" % (type(e).__name__, e)
             config["host_path_note"] = "lcd_quantize + lcd_sig_add + lcd_likelihood + lcd_sig_remove from host pointers (PCIe + syncs included)"
             engu.close()
             engb = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 8192,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LCD_ABI_VERSION 3
+#define LCD_ABI_VERSION 4
 
 typedef struct lcd_engine lcd_engine;
 
@@ -115,6 +115,16 @@ int lcd_vocab_remove(lcd_engine* h, const int32_t* word_ids, int n);
  * lcd_vocab_remove.  For callers that keep no host copy of the references (device-resident frame streams).  out_word_ids (may be NULL
  * with capacity 0) receives up to `capacity` of the removed ids in ascending row order, *out_n their number.  Synchronises. */
 int lcd_vocab_remove_unused(lcd_engine* h, int32_t* out_word_ids, int capacity, int32_t* out_n);
+/* The same cleanUnusedWords WITHOUT completing or synchronising anything: one kernel, enqueued behind the work the handle has taken on so
+ * far, tombstones every row whose word no signature references (row id 0, |row|^2 = +inf: no search finds it any more) and logs it on the
+ * device; the host's mirror of the rows and the postings keys of the removed words catch up the next time the handle is drained (any call
+ * that completes the owed stages: lcd_vocab_count, lcd_vocab_rebuild, lcd_synchronize ...).  On a pipelined handle with frames in flight
+ * the clean takes its place behind the newest frame -- its registration and the lcd_sig_remove calls made since, like those calls
+ * themselves -- so it is what Memory::preUpdate (Memory.cpp:1004-1010) runs in front of the NEXT frame's update(); the frames already in
+ * flight behind it (up to lcd_pipeline_depth()) took their snapshot of the vocabulary earlier: a word they still matched keeps the
+ * references of their signatures (its key is recycled once those are gone) but is never matched again.  A caller that needs the
+ * reference's order exactly calls lcd_vocab_remove_unused (or drains) instead. */
+int lcd_vocab_remove_unused_async(lcd_engine* h);
 /* full-rebuild branch :610-690: drop tombstones and reorder the live rows by ascending word id, on the device */
 int lcd_vocab_rebuild(lcd_engine* h);
 /* rows = rows in the matrix incl. tombstones, live = searchable rows */

@@ -19,7 +19,7 @@ STATUS = {0: "LCD_OK", 1: "LCD_ERR_INVALID", 2: "LCD_ERR_HIP", 3: "LCD_ERR_NOMEM
 # every symbol include/lcd.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "lcd_abi_version", "lcd_create", "lcd_destroy", "lcd_last_error", "lcd_synchronize", "lcd_pipeline_depth",
-    "lcd_vocab_clear", "lcd_vocab_append", "lcd_vocab_remove", "lcd_vocab_remove_unused", "lcd_vocab_rebuild", "lcd_vocab_count", "lcd_vocab_read",
+    "lcd_vocab_clear", "lcd_vocab_append", "lcd_vocab_remove", "lcd_vocab_remove_unused", "lcd_vocab_remove_unused_async", "lcd_vocab_rebuild", "lcd_vocab_count", "lcd_vocab_read",
     "lcd_knn2", "lcd_selfdist", "lcd_quantize", "lcd_find_nn",
     "lcd_sig_add", "lcd_sig_remove", "lcd_sig_add_bulk", "lcd_sig_count", "lcd_word_nrefs",
     "lcd_likelihood", "lcd_adjust_likelihood", "lcd_adjust_likelihood_dev", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood", "lcd_profile_score_work", "lcd_set_option", "lcd_record_event",
@@ -105,6 +105,7 @@ def load():
     L.lcd_vocab_append.argtypes = [vp, vp, C.c_int, vp]
     L.lcd_vocab_remove.argtypes = [vp, vp, C.c_int]
     L.lcd_vocab_remove_unused.argtypes = [vp, vp, C.c_int, vp]
+    L.lcd_vocab_remove_unused_async.argtypes = [vp]
     L.lcd_vocab_rebuild.argtypes = [vp]
     L.lcd_vocab_count.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.lcd_vocab_read.argtypes = [vp, i64, C.c_int, vp, vp]
@@ -214,6 +215,10 @@ class Engine:
         n = C.c_int32()
         self._ck(self.L.lcd_vocab_remove_unused(self.h, _p(out) if capacity else None, capacity, C.byref(n)))
         return n.value, out[: min(n.value, capacity)]
+
+    def vocab_remove_unused_async(self):
+        """cleanUnusedWords enqueued behind the frames in flight: nothing is completed, nothing comes back"""
+        self._ck(self.L.lcd_vocab_remove_unused_async(self.h))
 
     def vocab_rebuild(self):
         self._ck(self.L.lcd_vocab_rebuild(self.h))

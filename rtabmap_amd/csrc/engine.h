@@ -74,6 +74,7 @@ struct lcd_engine {
         std::vector<int32_t> retire_after;              // lcd_sig_remove calls made while this was the newest frame
         std::vector<void*> events_after;                // lcd_record_event calls ...
         std::vector<DeferredLink> links_after;          // lcd_bayes_set_neighbors calls ...
+        int cleans_after = 0;                           // lcd_vocab_remove_unused_async calls ...
     };
     std::deque<InFlight> inflight;                      // oldest first
     // ---- VWDictionary::update()'s append branch on the device (lcd_frame_args.append_new_words): the decision loop's workgroup turns the
@@ -89,6 +90,14 @@ struct lcd_engine {
     bool vcnt_active = false;                           // the counters hold the row count (set when the first appending frame arrives)
     bool tail_dirty = true;                             // the host wrote (or reallocated) behind the rows since the tail was last filled
     int64_t tail_filled_rows = 0;                       // rows [n_rows, tail_filled_rows) carry +inf norms and a zero bf16 split
+    // ---- Memory::cleanUnusedWords on the device without completing the frames in flight (lcd_vocab_remove_unused_async): the rows a
+    // clean_unused_kernel tombstoned are logged on the device; the host's row mirror and the postings keys of the removed words catch up
+    // with the log the next time the handle is drained (reconcile()).
+    lcd::DevBuf d_rmlog;                                // int32: [0] rows logged, [16 ..] the rows
+    int64_t rm_seen = 0;                                // log entries the host mirror has caught up with
+    bool rm_pending = false;                            // a clean was enqueued since the last reconciliation
+    int frames_since_reconcile = 0;                     // pipelined frames submitted with rm_pending set
+    int enqueue_clean();                                // flush the pending retirements, launch the kernel (nothing is synchronised)
     int reconcile();
     int64_t rows_ub() const;
     int filter_units = -1;                              // lcd_set_option("filter_units")

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <numeric>
+#include <thread>
 #include <unordered_map>
 
 using namespace lcd;
@@ -228,6 +229,7 @@ void fill_append(lcd_engine* h, const lcd_frame_args& a, uint64_t vseq, bool ena
     ap.descriptors = (const float*)a.d_descriptors; ap.row_dwords = h->row_bytes / 4; ap.is_f32_64 = knn_mfma_supported(h->dtype, h->kdim) ? 1 : 0;
     ap.vocab = h->vocab.as<uint32_t>(); ap.row_id = h->row_id.as<int32_t>(); ap.row_wslot = h->row_wslot.as<int32_t>();
     ap.row_norm = h->row_norm.as<float>(); ap.norm_max_bits = h->norm_max.as<uint32_t>(); ap.vocab_bf = h->vocab_bf.as<uint32_t>();
+    ap.wrow = h->tfidf.wrow.as<uint32_t>();
     ap.cnt_in = h->d_vcnt.as<int32_t>() + (vseq & 1); ap.cnt_out = h->d_vcnt.as<int32_t>() + ((vseq + 1) & 1);
     ap.log_slot = h->d_vcnt.as<int32_t>() + 16 + (vseq % lcd_engine::VLOG);
     ap.first_id = a.first_new_word_id; ap.capacity = vocab_cap_rows(h);
@@ -252,10 +254,10 @@ int64_t lcd_engine::rows_ub() const {
 
 // the host's row mirror catches up with the device (synchronises)
 int lcd_engine::reconcile() {
-    if (unreconciled.empty()) return LCD_OK;
+    if (unreconciled.empty() && !rm_pending) return LCD_OK;
     { int rc = sync_all(); if (rc) return rc; }
     std::vector<int32_t> log((size_t)VLOG);
-    {   // the log is a ring: the entries of the frames to catch up with form at most two stretches of it
+    if (!unreconciled.empty()) {   // the log is a ring: the entries of the frames to catch up with form at most two stretches of it
         const size_t first = (size_t)(unreconciled.front().seq % VLOG), n = unreconciled.size();
         const size_t n1 = std::min(n, (size_t)VLOG - first);
         hipError_t e = hipMemcpy(log.data() + first, d_vcnt.as<int32_t>() + 16 + first, n1 * 4, hipMemcpyDeviceToHost);
@@ -276,6 +278,57 @@ int lcd_engine::reconcile() {
         n_live += n;
     }
     unreconciled.clear();
+    if (rm_pending) {
+        // rows tombstoned by the device-side cleanUnusedWords since the last reconciliation: the words are gone (removeWords,
+        // VWDictionary.cpp:1595-1607), their postings keys go to the batched check that recycles them once nothing references them
+        int32_t cnt = 0;
+        hipError_t e = hipMemcpy(&cnt, d_rmlog.p, 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpy(removal log)");
+        const int64_t cap = ((int64_t)(d_rmlog.cap / 4) - 16) / 2;
+        const int64_t n = std::min<int64_t>(cnt, cap);
+        if (n > rm_seen) {
+            std::vector<int32_t> ent((size_t)(n - rm_seen) * 2);
+            e = hipMemcpy(ent.data(), d_rmlog.as<int32_t>() + 16 + 2 * rm_seen, ent.size() * 4, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return hip_fail(e, "hipMemcpy(removal log)");
+            // every batched key check enqueued so far has finished (the stream is drained): with their verdicts in, a key is either the
+            // word's permanent one -- released here -- or still on its way through the reservation checks, which will find it free
+            tfidf.harvest_released(true);
+            e = tfidf.rows_unlog_keys(d_rmlog.as<int32_t>() + 16 + 2 * rm_seen, (int)(n - rm_seen));   // nothing is in flight: the keys may circulate again
+            if (e != hipSuccess) return hip_fail(e, "wrow_unlog_kernel");
+            for (size_t i = 0; i < ent.size(); i += 2) {
+                const int32_t r = ent[i];
+                if (r < 0 || r >= n_rows || !h_row_live[(size_t)r]) continue;
+                h_row_live[(size_t)r] = 0;
+                n_live -= 1;
+                const int32_t id = h_row_key[(size_t)r];
+                if (word_row_valid) word_row.erase(id);
+                tfidf.forget_word(id, ent[i + 1]);
+            }
+            rm_seen = n;
+        }
+        rm_pending = false;
+    }
+    frames_since_reconcile = 0;
+    return LCD_OK;
+}
+
+int lcd_engine::enqueue_clean() {
+    const int64_t rows = rows_ub();
+    if (rows <= 0) return LCD_OK;
+    hipError_t e = tfidf.flush_retire();                 // retirements ride with the next registration otherwise: the counts would be stale
+    if (e != hipSuccess) return hip_fail(e, "flush_retire");
+    const size_t need = ((size_t)std::max<int64_t>(rows, (int64_t)(vocab.cap / (size_t)row_bytes)) * 2 + 16) * 4;   // a row is logged at most once
+    if (need > d_rmlog.cap) {
+        const bool fresh = d_rmlog.p == nullptr;
+        e = d_rmlog.reserve(need, d_rmlog.cap, stream, &bytes_device);
+        if (e == hipSuccess && fresh) e = hipMemsetAsync(d_rmlog.p, 0, 64, stream);
+        if (e != hipSuccess) return hip_fail(e, "removal log");
+    }
+    e = launch_clean_unused(row_id.as<int32_t>(), row_wslot.as<int32_t>(), tfidf.nw.as<uint32_t>(), tfidf.wrow.as<uint32_t>(),
+                            dtype == LCD_F32 ? row_norm.as<float>() : nullptr, (int)rows, vcnt_active ? d_vcnt.as<int32_t>() : nullptr,
+                            d_rmlog.as<int32_t>(), (int)((d_rmlog.cap / 4 - 16) / 2), stream);
+    if (e != hipSuccess) return hip_fail(e, "clean_unused_kernel");
+    rm_pending = true;
     return LCD_OK;
 }
 
@@ -303,6 +356,10 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return LCD_ERR_HIP;
     if (hipSetDevice(cfg->device) != hipSuccess) return LCD_ERR_HIP;
+    {   // the filter's launch plans fill THIS device's compute units (256 on MI355X; fewer on a partitioned part)
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) knn_set_compute_units(cus);
+    }
     lcd_engine* h = new (std::nothrow) lcd_engine();
     if (!h) return LCD_ERR_NOMEM;
     h->device = cfg->device;
@@ -367,6 +424,7 @@ void lcd_destroy(lcd_engine* h) {
                      &h->d_fail_list, &h->d_fail_count, &h->d_partial3, &h->row_norm_alt, &h->vocab_bf, &h->d_hyp_scratch, &h->d_adj_scratch};
     for (DevBuf* d : all) d->release(&h->bytes_device);
     h->d_vcnt.release(&h->bytes_device);
+    h->d_rmlog.release(&h->bytes_device);
     if (h->h_vmirror) (void)hipHostFree(h->h_vmirror);
     h->h_in.release(); h->h_out.release(); h->h_out2.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -407,6 +465,9 @@ int lcd_vocab_clear(lcd_engine* h) {
     { int rc = h->sync_all(); if (rc) return rc; }
     h->n_rows = 0; h->n_live = 0;
     h->vcnt_active = false; h->tail_dirty = true;
+    LCD_HIP(h, h->tfidf.rows_clear());
+    if (h->d_rmlog.p) LCD_HIP(h, hipMemsetAsync(h->d_rmlog.p, 0, 4, h->stream));
+    h->rm_seen = 0;
     h->h_row_key.clear();
     h->h_row_live.clear();
     h->rows_sorted = true;
@@ -457,6 +518,7 @@ int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word
     LCD_HIP(h, hipMemcpyAsync((char*)h->vocab.p + (size_t)h->n_rows * h->row_bytes, st, rb, hipMemcpyHostToDevice, h->stream));
     LCD_HIP(h, hipMemcpyAsync(h->row_id.as<int32_t>() + h->n_rows, ids, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     LCD_HIP(h, hipMemcpyAsync(h->row_wslot.as<int32_t>() + h->n_rows, ws, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    LCD_HIP(h, h->tfidf.rows_take_keys(h->row_wslot.as<int32_t>() + h->n_rows, n, h->n_rows));
     if (h->dtype == LCD_F32) {   // |row|^2 for the MFMA filter
         LCD_HIP(h, dreserve(h, h->row_norm, ((size_t)total + 1) * 8, (size_t)h->n_rows * 8));
         LCD_HIP(h, launch_row_norms(h->vocab.p, h->row_id.as<int32_t>(), (int)h->n_rows, n, h->kdim, h->row_norm.as<float>(),
@@ -520,6 +582,17 @@ int lcd_vocab_remove_unused(lcd_engine* h, int32_t* out_word_ids, int capacity, 
     LCD_CATCH(h)
 }
 
+int lcd_vocab_remove_unused_async(lcd_engine* h) {
+    LCD_TRY
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV_NODRAIN(h);
+    // a pipelined handle still owes stages of its latest frames: the clean takes its place behind the newest of them (its registration
+    // and the retirements asked for since), like lcd_sig_remove -- nothing is completed, nothing is synchronised
+    if (!h->inflight.empty()) { h->inflight.back().cleans_after += 1; return LCD_OK; }
+    return h->enqueue_clean();
+    LCD_CATCH(h)
+}
+
 static int vocab_remove_ids(lcd_engine* h, const int32_t* word_ids, int n) {
     { int rc = h->sync_all(); if (rc) return rc; }
     std::vector<int32_t> rows;
@@ -545,6 +618,7 @@ static int vocab_remove_ids(lcd_engine* h, const int32_t* word_ids, int n) {
         LCD_HIP(h, h->h_in.reserve((size_t)nr * 4));
         std::memcpy(h->h_in.p, rows.data(), (size_t)nr * 4);
         LCD_HIP(h, hipMemcpyAsync(h->d_tmp_i32.p, h->h_in.p, (size_t)nr * 4, hipMemcpyHostToDevice, h->stream));
+        LCD_HIP(h, h->tfidf.rows_drop_keys(h->row_wslot.as<int32_t>(), h->d_tmp_i32.as<int32_t>(), nr));
         LCD_HIP(h, launch_tombstone(h->row_id.as<int32_t>(), h->d_tmp_i32.as<int32_t>(), nr, h->stream));
         if (h->dtype == LCD_F32) LCD_HIP(h, launch_norm_tombstone(h->row_norm.as<float>(), h->d_tmp_i32.as<int32_t>(), nr, h->stream));
         LCD_HIP(h, hipStreamSynchronize(h->stream));
@@ -603,6 +677,9 @@ int lcd_vocab_rebuild(lcd_engine* h) {
     std::swap(h->row_id, h->row_id_alt);
     std::swap(h->row_wslot, h->row_wslot_alt);
     if (h->dtype == LCD_F32) std::swap(h->row_norm, h->row_norm_alt);
+    LCD_HIP(h, h->tfidf.rows_take_keys(h->row_wslot.as<int32_t>(), n, 0));   // the rows moved (the keys of dropped rows were released with them)
+    if (h->d_rmlog.p) LCD_HIP(h, hipMemsetAsync(h->d_rmlog.p, 0, 4, h->stream));   // (reconciled by the drain above: the log starts over)
+    h->rm_seen = 0;
     if (n && knn_mfma_supported(h->dtype, h->kdim)) {   // the split is recomputed from the compacted rows
         LCD_HIP(h, dreserve(h, h->vocab_bf, (size_t)n * 256));
         LCD_HIP(h, launch_vocab_bf16(h->vocab.p, 0, n, h->kdim, h->vocab_bf.p, h->stream));
@@ -1079,6 +1156,7 @@ static int finish_frame_ops(lcd_engine* h, lcd_engine::InFlight& f) {
         LCD_HIP(h, e);
     }
     f.links_after.clear();
+    if (f.cleans_after > 0) { f.cleans_after = 0; int rc = h->enqueue_clean(); if (rc) return rc; }
     for (void* ev : f.events_after) LCD_HIP(h, hipEventRecord((hipEvent_t)ev, h->stream));
     f.events_after.clear();
     return LCD_OK;
@@ -1238,6 +1316,9 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     const int64_t slots_after = t.n_slots + owed_slots + (a->sig_id != 0 ? 1 : 0);
     if (a->d_likelihood && a->likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: likelihood buffer too small");
     if (h->unreconciled.size() >= (size_t)lcd_engine::VLOG / 2) { int rc = h->drain(); if (rc) return rc; }   // the append log is a ring
+    // rows tombstoned by enqueued cleans keep their postings keys out of circulation until the host has caught up with the log: a stream
+    // that never completes anything does so every 512 frames (three fused launch pairs, ~0.2 us per frame)
+    if (h->rm_pending && ++h->frames_since_reconcile >= 512) { int rc = h->drain(); if (rc) return rc; }
     // rows appended on the device: the counters take over the row count, the buffers keep room for the words of the frames in flight
     const bool app = frame_appends(h, *a);
     if (app) { int rc = activate_dev_rows(h); if (rc) return rc; }
@@ -1246,12 +1327,17 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
         // The launches are planned for an upper bound of the row count: what the newest FINISHED appender reported + q per younger
         // frame.  A caller that enqueues frames much faster than the device runs them would inflate that bound without limit (the
         // filter would scan mostly empty rows): such a caller waits here until the device is at most 8 frames behind.
+        // (the wait spins for the few microseconds a frame takes, then yields; a stream that makes no progress for a long time --
+        // a caller-provided one may legitimately sit behind an event -- is waited for with hipStreamSynchronize instead of failing)
         const auto t0 = std::chrono::steady_clock::now();
         for (int spins = 0;; ++spins) {
             const uint32_t tag = (uint32_t)(*(volatile const unsigned long long*)h->h_vmirror >> 32);
             if ((uint32_t)h->vseq - tag <= 8u) break;
-            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5))
-                return h->fail(LCD_ERR_HIP, "lcd_frame_dev: the device made no progress for 5 s");
+            if (spins > 4096) std::this_thread::yield();
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+                LCD_HIP(h, hipStreamSynchronize(h->stream));
+                break;
+            }
         }
     }
     if (chained) { int rc = ensure_append_capacity(h, h->rows_ub() + 3 * (int64_t)q); if (rc) return rc; }

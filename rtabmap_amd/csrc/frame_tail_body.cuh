@@ -237,9 +237,11 @@ __device__ __forceinline__ void append_new_rows(const AppendArgs& ap, int q, con
                 for (int d = c; d < ap.row_dwords; d += 16) dst[d] = src[d];
             }
             if (c == 0) {
+                const int32_t key = new_ws.n > 0 ? ws_runs_at(new_ws, k) : -1;
                 ap.row_id[row] = ap.first_id + k;
-                ap.row_wslot[row] = new_ws.n > 0 ? ws_runs_at(new_ws, k) : -1;
-            }
+                ap.row_wslot[row] = key;
+                if (key >= 0 && ap.wrow) ap.wrow[key] = (uint32_t)row + 1u;     // the key now belongs to a row: the batched check of
+            }                                                                   // superseded reservations must not hand it out again
         }
     }
     if (tid == 0) {

@@ -935,6 +935,8 @@ __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, co
 constexpr size_t BF_LDS_BYTES_P = (size_t)(MF_WAVES * 4 + 2) * BF_TILE_F * 4 + (size_t)2 * MF_STRIP_TILES * 64 * 4;
 // every tile of strip `bx` + its augmentation entries (wave 0): a FIXED number of DMA instructions per wave, so that the wait in
 // front of the strip before it can name how many may stay in flight
+// the augmentation entry of a column that is not a visible row
+__device__ const float g_aug_inf[2] = {__builtin_inff(), 1.0f};
 __device__ __forceinline__ void bf_request_strip(const float* __restrict__ vocab_bf, const float* __restrict__ row_norm, int n_rows, int bx,
                                                  int tiles_per_block, int n_tiles, int lane, int wave, int col, int half, float* slots, float* aug_dst) {
     constexpr int DPW = 8 / MF_WAVES;
@@ -949,7 +951,10 @@ __device__ __forceinline__ void bf_request_strip(const float* __restrict__ vocab
 #pragma unroll
         for (int i = 0; i < MF_STRIP_TILES; ++i) {
             const int t = min(tile0 + i, max(tile1 - 1, tile0));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row_norm + 2 * (size_t)min(t * 32 + col, n_rows) + half),
+            // (columns at or beyond n_rows read a constant {+inf, 1}: the table's own entry behind the last visible row is where the
+            // appender of the previous frame -- a workgroup of this same launch on a pipelined handle -- writes its first row's norm)
+            const float* src = t * 32 + col >= n_rows ? g_aug_inf + half : row_norm + 2 * (size_t)(t * 32 + col) + half;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(aug_dst + i * 64), 4, 0, 0);
         }
     }
@@ -996,7 +1001,7 @@ __device__ __forceinline__ void knn_bf16_filter_body_p(float* s_dyn, int bid, co
 #pragma unroll
         for (int i = 0; i < MF_STRIP_TILES; ++i) {
             const int t = min(tile0 + i, max(tile1 - 1, tile0));
-            augs[i] = row_norm[2 * (size_t)min(t * 32 + col, n_rows) + half];
+            augs[i] = t * 32 + col >= n_rows ? g_aug_inf[half] : row_norm[2 * (size_t)(t * 32 + col) + half];
         }
         if (tile0 < tile1) {
             dma_tile_part(vocab_bf, n_rows, tile0, lane, s_tile, DPW * wave, DPW * wave + DPW);
@@ -1642,6 +1647,10 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
 }
 
 // ---- bf16x3 filter
+// compute units the launch plans are made for: the device's own count (lcd_create asks hipDeviceProp_t; 256 on MI355X, also the value the
+// plans are tested with on a machine without a device)
+static int g_plan_cus = 256;
+void knn_set_compute_units(int cus) { if (cus >= 16 && cus <= 4096) g_plan_cus = cus; }
 int knn_selfdist_wgs(int q) { return selfdist_tiles(q); }
 // other_wgs: workgroups of the same launch that run for about as long as a filter workgroup (distance-matrix tiles, the frame tail's
 // two workgroups).  Every workgroup of the launch holds a whole compute unit's LDS: 256 strips + 2 tail workgroups used to leave two
@@ -1651,10 +1660,10 @@ MfmaPlan knn_bf16_plan(int q, int n_rows, int other_wgs) {
     p.q = q;
     p.qpad = (q + 63) / 64 * 64;
     p.n_rows = n_rows;
-    p.other_wgs = other_wgs > 0 && other_wgs < 128 ? other_wgs : 0;
+    p.other_wgs = other_wgs > 0 && other_wgs < g_plan_cus / 2 ? other_wgs : 0;
     const int n_tiles = (n_rows + 31) / 32;
     const int qchunks = (q + BF_QB - 1) / BF_QB;
-    const int cus = 256 - p.other_wgs;
+    const int cus = g_plan_cus - p.other_wgs;
     const int per_q = cus / qchunks > 0 ? cus / qchunks : 1;         // workgroups (4 waves, one per SIMD, a whole compute unit's LDS) per block of 512 queries
     // tiles per workgroup when every compute unit gets one; more than a strip holds (the in-loop keys index 8 tiles): the workgroups
     // are persistent and walk `rounds` equal strips each -- so that a vocabulary a little larger than 256 x 8 tiles does not run as
@@ -1683,9 +1692,9 @@ hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void*
 // workgroup per compute unit that is the faster launch).  MfmaPlan::filter_units (lcd_set_option "filter_units") overrides the
 // number of compute units to plan for: tests shorten it to walk many strips per workgroup.
 static int bf16_persistent_px(const MfmaPlan& p) {
-    const int cus = p.filter_units >= 0 ? p.filter_units : 256 - p.other_wgs;
+    const int cus = p.filter_units >= 0 ? p.filter_units : g_plan_cus - p.other_wgs;
     const int qchunks = (p.q + BF_QB - 1) / BF_QB;
-    if (p.one_strip || cus == 0 || qchunks <= 0 || p.n_blocks * qchunks <= (p.filter_units >= 0 ? 256 : cus)) return 0;
+    if (p.one_strip || cus <= 0 || qchunks <= 0 || p.n_blocks * qchunks <= (p.filter_units >= 0 ? g_plan_cus : cus)) return 0;
     const int px_max = cus / qchunks > 0 ? cus / qchunks : 1;
     const int rounds = (p.n_blocks + px_max - 1) / px_max;
     return (p.n_blocks + rounds - 1) / rounds;                          // equal shares: ceil(strips / rounds) workgroups of <= rounds strips
@@ -1708,7 +1717,7 @@ MfmaPlan knn_bf16_plan_pipelined(int q, int n_rows, int n_tile_wgs, int filter_u
     }
     const int n_tiles = (n_rows + 31) / 32;
     const int qchunks = (q + BF_QB - 1) / BF_QB;
-    const int slots = (2 * (256 - p.other_wgs) - 16) / qchunks;         // strips that can be resident at once (16: the two tails, the pre-split, redo helpers)
+    const int slots = (2 * (g_plan_cus - p.other_wgs) - 16) / qchunks;         // strips that can be resident at once (16: the two tails, the pre-split, redo helpers)
     if (slots > 0 && n_tiles <= slots * MF_STRIP_TILES) {
         int tpb = (n_tiles + slots - 1) / slots;
         if (tpb < 1) tpb = 1;

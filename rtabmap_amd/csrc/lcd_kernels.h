@@ -82,6 +82,7 @@ struct MfmaPlan {
     int one_strip = 0;       // 1: one workgroup per strip whatever the number of strips (lcd_set_option "strip_tiles")
 };
 bool knn_mfma_supported(int dtype, int dim);
+void knn_set_compute_units(int cus);           // the device's compute units: what the filter launch plans fill (256 unless told otherwise)
 bool knn_bf16_persistent(const MfmaPlan& p);   // the bf16 filter launch of this plan uses the persistent kernels (..._kernel_p)
 MfmaPlan knn_mfma_plan(int q, int n_rows);
 MfmaPlan knn_bf16_plan_pipelined(int q, int n_rows, int n_tile_wgs, int filter_units);   // launch A of a pipelined frame (knn_mfma_kernels.hip)
@@ -151,6 +152,9 @@ hipError_t launch_gather_rows(const void* src, const int32_t* src_id, const int3
 // the live rows whose word has no reference (nw[row_wslot[r]] == 0): out_rows[0 .. min(*out_count, cap)), any order
 hipError_t launch_unused_rows(const int32_t* row_id, const int32_t* row_wslot, const uint32_t* nw, int n_rows, int32_t* out_rows, int32_t* out_count,
                               int cap, hipStream_t s);
+// cleanUnusedWords on the device (resolve_kernels.hip, clean_unused_kernel): rmlog[0] counts, rmlog[16 ..] lists {row, postings key} of the rows tombstoned (cap pairs)
+hipError_t launch_clean_unused(int32_t* row_id, const int32_t* row_wslot, const uint32_t* nw, uint32_t* wrow, float* aug, int n_rows,
+                               const int32_t* dev_cnt, int32_t* rmlog, int cap, hipStream_t s);
 // row_id[rows[i]] = 0
 hipError_t launch_tombstone(int32_t* row_id, const int32_t* rows, int n, hipStream_t s);
 

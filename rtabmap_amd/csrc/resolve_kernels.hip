@@ -136,6 +136,29 @@ __global__ void unused_rows_kernel(const int32_t* __restrict__ row_id, const int
     const int pos = atomicAdd(out_count, 1);
     if (pos < cap) out_rows[pos] = r;
 }
+// Memory::cleanUnusedWords (Memory.cpp:6899-6920) entirely on the device, enqueued behind the frames in flight: every live row whose word
+// nobody references is tombstoned here (row_id = 0, |row|^2 = +inf so that no filter ranks it, its postings key released from the row)
+// and logged for the host, which catches up the next time the handle is drained.  dev_cnt: the two alternating row counters of a handle
+// whose frames append their words on the device (the larger one is the newest), NULL: n_rows is exact.
+__global__ void clean_unused_kernel(int32_t* __restrict__ row_id, const int32_t* __restrict__ row_wslot, const uint32_t* __restrict__ nw,
+                                    uint32_t* __restrict__ wrow, float* __restrict__ aug, int n_rows, const int32_t* __restrict__ dev_cnt,
+                                    int32_t* __restrict__ rmlog, int cap) {
+    int n = n_rows;
+    if (dev_cnt) n = min(n_rows, max(dev_cnt[0], dev_cnt[1]));
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        if (row_id[r] == 0) continue;
+        const int32_t ws = row_wslot[r];
+        if (ws >= 0 && nw[ws] != 0u) continue;
+        row_id[r] = 0;
+        if (aug) aug[2 * (size_t)r] = __int_as_float(0x7f800000);
+        // the key stays out of circulation (0xFFFFFFFF reads as "a row's key" to the batched key check) until the host has caught up with
+        // the log -- which it does with nothing in flight: a frame that matched this row before it was tombstoned may still register
+        // references under the key, and a key recycled in between would be shared by two words
+        if (ws >= 0) wrow[ws] = 0xFFFFFFFFu;
+        const int pos = atomicAdd(&rmlog[0], 1);
+        if (pos < cap) { rmlog[16 + 2 * pos] = r; rmlog[16 + 2 * pos + 1] = ws; }
+    }
+}
 __global__ void tombstone_kernel(int32_t* __restrict__ row_id, const int32_t* __restrict__ rows, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) row_id[rows[i]] = 0;
@@ -193,6 +216,13 @@ hipError_t launch_unused_rows(const int32_t* row_id, const int32_t* row_wslot, c
                               int cap, hipStream_t s) {
     if (n_rows <= 0) return hipSuccess;
     unused_rows_kernel<<<(n_rows + 255) / 256, 256, 0, s>>>(row_id, row_wslot, nw, n_rows, out_rows, out_count, cap);
+    return hipGetLastError();
+}
+hipError_t launch_clean_unused(int32_t* row_id, const int32_t* row_wslot, const uint32_t* nw, uint32_t* wrow, float* aug, int n_rows,
+                               const int32_t* dev_cnt, int32_t* rmlog, int cap, hipStream_t s) {
+    if (n_rows <= 0) return hipSuccess;
+    const int blocks = (n_rows + 255) / 256 < 1024 ? (n_rows + 255) / 256 : 1024;
+    clean_unused_kernel<<<blocks, 256, 0, s>>>(row_id, row_wslot, nw, wrow, aug, n_rows, dev_cnt, rmlog, cap);
     return hipGetLastError();
 }
 hipError_t launch_tombstone(int32_t* row_id, const int32_t* rows, int n, hipStream_t s) {

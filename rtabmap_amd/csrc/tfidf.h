@@ -108,6 +108,7 @@ struct AppendArgs {
     int row_dwords = 0;                        // dwords per stored row
     int is_f32_64 = 0;                         // rows are 64 floats: also the augmentation entries and the bf16 split
     uint32_t* vocab = nullptr; int32_t* row_id = nullptr; int32_t* row_wslot = nullptr;
+    uint32_t* wrow = nullptr;                  // Tfidf::wrow: the appended rows claim their postings keys
     float* row_norm = nullptr; uint32_t* norm_max_bits = nullptr; uint32_t* vocab_bf = nullptr;
     const int32_t* cnt_in = nullptr; int32_t* cnt_out = nullptr;
     int32_t* log_slot = nullptr;               // receives the number of rows appended (host reconciliation)
@@ -205,6 +206,8 @@ struct Tfidf {
     DevBuf slot_sig, slot_ni, slot_begin, slot_cnt;
     // per wslot
     DevBuf nw, did;                      // references, dense id (-1: none)
+    DevBuf wrow;                         // vocabulary row that carries the key + 1 (0: none): a key held by a live row is never recycled, whatever
+                                         // its reference count (rows appended on the device get their key there, the host learns of it later)
     DevBuf idf_tab;                      // {stamp, idf Q5.26} of the words of the current frame (valid iff stamp matches)
     uint32_t stamp = 0;
     // word id -> wslot: host vector (ids are small consecutive integers in the reference, ++_lastWordId) mirrored on the device
@@ -218,9 +221,11 @@ struct Tfidf {
     // reserved for new word ids[i] of a frame; if it turns out to be referenced, that word exists and keeps the wslot.
     struct PinBlock { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; };   // pinned memory + event, recycled (one batch per frame)
     std::vector<PinBlock> pin_free;
-    struct ReleaseBatch { std::vector<int32_t> ws, ids; PinBlock blk; const uint8_t* ok = nullptr; };
+    struct ReleaseBatch { std::vector<int32_t> ws, ids; PinBlock blk; const uint8_t* ok = nullptr; bool recheck = false; };
     std::vector<ReleaseBatch> releasing;
     std::vector<int32_t> held_ws, held_ids;   // keys of superseded reservations waiting for a batched check
+    std::vector<int32_t> ghost_ws;            // keys of removed words that a batch found still referenced: asked about again every 8th batch
+    uint32_t flushes = 0;
     hipError_t flush_held();
     struct Reservation { int32_t first_id = 0, n = 0; WsRuns runs; } resv;   // wslots reserved for the new words of the last frame
     // per bucket
@@ -256,7 +261,18 @@ struct Tfidf {
     hipError_t sync_id2ws();
     // the word left the dictionary (VWDictionary::removeWords): its wslot is recycled once the device confirms nw == 0
     hipError_t release_words(const int32_t* word_ids, int n);
-    hipError_t release_wslots(const std::vector<int32_t>& ws, const std::vector<int32_t>* ids = nullptr);
+    // recheck: keys without a word id that turn out to be still referenced are checked again with a later batch
+    hipError_t release_wslots(const std::vector<int32_t>& ws, const std::vector<int32_t>* ids = nullptr, bool recheck = false);
+    // the vocabulary rows' claim on their keys (wrow): rows [first_row, first_row + n) carry d_ws[0 .. n); rows d_rows[0 .. n) are gone;
+    // the vocabulary was cleared
+    hipError_t rows_take_keys(const int32_t* d_ws, int n, int64_t first_row);
+    hipError_t rows_drop_keys(const int32_t* d_row_wslot, const int32_t* d_rows, int n);
+    hipError_t rows_clear();
+    // the device-side cleanUnusedWords keeps the keys of the rows it tombstones out of circulation (wrow = 0xFFFFFFFF) until the host has
+    // caught up with its log of {row, key} pairs -- with nothing in flight: then they are released like any removed word's key
+    hipError_t rows_unlog_keys(const int32_t* d_pairs, int n);
+    // the device tombstoned the row of word `word_id` (key `ws`): if that is the word's permanent key it goes to the batched check
+    void forget_word(int32_t word_id, int32_t ws);
     void free_wslot(int32_t w);          // into the interval set
     int32_t take_wslot();                // one recycled wslot, or -1
     void harvest_released(bool wait);

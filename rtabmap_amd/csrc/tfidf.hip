@@ -291,14 +291,36 @@ __global__ void retire_kernel(long long slot, const uint32_t* __restrict__ coo_w
 }
 
 // the words left the dictionary: a wslot may be handed out again only if nothing references it (ok[i] tells the host)
-__global__ void wslot_release_kernel(const int32_t* __restrict__ ws, int n, const uint32_t* __restrict__ nw, int32_t* __restrict__ did,
-                                     uint2* __restrict__ idf_tab, uint8_t* __restrict__ ok) {
+// verdict: 1 = free (nothing references the key and no vocabulary row carries it), 2 = a live row's key (permanent, whatever its reference
+// count: a word a frame appended on the device whose signature is gone, or that never had one), 0 = still referenced
+__global__ void wslot_release_kernel(const int32_t* __restrict__ ws, int n, const uint32_t* __restrict__ nw, const uint32_t* __restrict__ wrow,
+                                     int32_t* __restrict__ did, uint2* __restrict__ idf_tab, uint8_t* __restrict__ ok) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int32_t w = ws[i];
-    const bool free_now = nw[w] == 0u;
+    const bool is_row = wrow[w] != 0u;
+    const bool free_now = !is_row && nw[w] == 0u;
     if (free_now) { did[w] = -1; idf_tab[w] = make_uint2(0u, 0u); }
-    ok[i] = free_now ? 1 : 0;
+    ok[i] = free_now ? 1 : (is_row ? 2 : 0);
+}
+// rows [first_row, first_row + n) carry the keys ws[0 .. n)
+__global__ void wrow_set_kernel(const int32_t* __restrict__ ws, int n, long long first_row, uint32_t* __restrict__ wrow) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && ws[i] >= 0) wrow[ws[i]] = (uint32_t)(first_row + i) + 1u;
+}
+// the keys of logged removals ({row, key} pairs) leave their quarantine
+__global__ void wrow_unlog_kernel(const int32_t* __restrict__ pairs, int n, uint32_t* __restrict__ wrow) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t w = pairs[2 * i + 1];
+    if (w >= 0 && wrow[w] == 0xFFFFFFFFu) wrow[w] = 0u;
+}
+// the rows rows[0 .. n) are gone: their keys belong to no row any more
+__global__ void wrow_clear_kernel(const int32_t* __restrict__ row_wslot, const int32_t* __restrict__ rows, int n, uint32_t* __restrict__ wrow) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t w = row_wslot[rows[i]];
+    if (w >= 0) wrow[w] = 0u;
 }
 // table[pairs[2i]] = pairs[2i + 1]
 __global__ void scatter_pairs_kernel(const int32_t* __restrict__ pairs, int n, int32_t* __restrict__ table) {
@@ -403,7 +425,7 @@ void Tfidf::destroy() {
     for (Bucket& b : buckets) { b.coo_w.release(bytes_device); b.coo_pc.release(bytes_device); b.sealed.release(bytes_device); }
     buckets.clear();
     pool.destroy(bytes_device);
-    DevBuf* all[] = {&slot_sig, &slot_ni, &slot_begin, &slot_cnt, &nw, &did, &idf_tab, &d_id2ws, &bkt_tab, &bkt_ne, &bkt_D, &bkt_flags,
+    DevBuf* all[] = {&slot_sig, &slot_ni, &slot_begin, &slot_cnt, &nw, &did, &wrow, &idf_tab, &d_id2ws, &bkt_tab, &bkt_ne, &bkt_D, &bkt_flags,
                      &n_dense, &dir2, &seal_cntw, &seal_tiles, &q_w, &q_idf, &q_did, &qd_did, &qd_idf, &q_meta, &d_stage, &d_pairs};
     for (DevBuf* d : all) d->release(bytes_device);
     h_stage.release();
@@ -421,6 +443,7 @@ hipError_t Tfidf::ensure_slots(int64_t n) {
 hipError_t Tfidf::ensure_wslots(int32_t n) {
     TF_TRY(grow_zeroed(nw, (size_t)n * 4, stream, bytes_device));
     TF_TRY(grow_filled(did, (size_t)n * 4, 0xFF, stream, bytes_device));
+    TF_TRY(grow_zeroed(wrow, (size_t)n * 4, stream, bytes_device));
     TF_TRY(grow_zeroed(idf_tab, (size_t)n * 8, stream, bytes_device));
     return hipSuccess;
 }
@@ -509,12 +532,17 @@ void Tfidf::harvest_released(bool wait) {
         const hipError_t q = wait ? hipEventSynchronize(r.blk.ev) : hipEventQuery(r.blk.ev);
         if (q != hipSuccess) { ++i; continue; }
         for (size_t k = 0; k < r.ws.size(); ++k) {
-            if (r.ok[k]) { free_wslot(r.ws[k]); continue; }
-            // still referenced.  A wslot reserved for a frame's new word: the word exists (the frame created it) and keeps it.
+            if (r.ok[k] == 1) { free_wslot(r.ws[k]); continue; }
+            // still referenced, or the key of a vocabulary row.  A wslot reserved for a frame's new word: the word exists (the frame
+            // created it) and keeps it.
             const int32_t id = k < r.ids.size() ? r.ids[k] : 0;
             if (id > 0) {
                 if ((size_t)id >= id2ws.size()) id2ws.resize((size_t)id + 1 + id2ws.size() / 2, -1);
                 if (id2ws[id] < 0) { id2ws[id] = r.ws[k]; id2ws_dirty.push_back(id); }
+            } else if (r.ok[k] == 0 && r.recheck) {
+                // a key without a word: the word was removed from the dictionary while a frame in flight still matched it (its row is
+                // tombstoned, the references of that frame's signature remain).  It comes back when those references are gone.
+                ghost_ws.push_back(r.ws[k]);
             }
         }
         pin_free.push_back(r.blk);
@@ -524,11 +552,12 @@ void Tfidf::harvest_released(bool wait) {
 
 // hand wslots back: a kernel checks each one (nw == 0) and reports through pinned memory; the host collects the verdicts of
 // finished batches later (harvest_released), so nothing is synchronised here and a wslot that is still referenced is never reused
-hipError_t Tfidf::release_wslots(const std::vector<int32_t>& ws, const std::vector<int32_t>* ids) {
+hipError_t Tfidf::release_wslots(const std::vector<int32_t>& ws, const std::vector<int32_t>* ids, bool recheck) {
     if (ws.empty()) return hipSuccess;
     const size_t m = ws.size();
     ReleaseBatch r;
     r.ws = ws;
+    r.recheck = recheck;
     if (ids) r.ids = *ids;
     const size_t need = m * 5 + 16;                                          // [m wslots][m verdicts]
     for (size_t i = 0; i < pin_free.size(); ++i)
@@ -544,7 +573,7 @@ hipError_t Tfidf::release_wslots(const std::vector<int32_t>& ws, const std::vect
     std::memcpy(p_ws, ws.data(), m * 4);
     std::memset(p_ok, 0, m);
     r.ok = p_ok;
-    wslot_release_kernel<<<(unsigned)((m + 255) / 256), 256, 0, stream>>>(p_ws, (int)m, nw.as<uint32_t>(), did.as<int32_t>(),
+    wslot_release_kernel<<<(unsigned)((m + 255) / 256), 256, 0, stream>>>(p_ws, (int)m, nw.as<uint32_t>(), wrow.as<uint32_t>(), did.as<int32_t>(),
                                                                            idf_tab.as<uint2>(), p_ok);
     TF_TRY(hipGetLastError());
     TF_TRY(hipEventRecord(r.blk.ev, stream));
@@ -554,9 +583,39 @@ hipError_t Tfidf::release_wslots(const std::vector<int32_t>& ws, const std::vect
 
 hipError_t Tfidf::flush_held() {
     if (held_ws.empty()) return hipSuccess;
-    hipError_t e = release_wslots(held_ws, &held_ids);
-    held_ws.clear(); held_ids.clear();
-    return e;
+    std::vector<int32_t> ws, ids;
+    ws.swap(held_ws); ids.swap(held_ids);
+    if (!ghost_ws.empty() && (++flushes & 7u) == 0u) {                       // every 8th batch also asks about the keys that were still referenced
+        ws.insert(ws.end(), ghost_ws.begin(), ghost_ws.end());
+        ids.resize(ws.size(), 0);
+        ghost_ws.clear();
+    }
+    return release_wslots(ws, &ids, true);
+}
+
+hipError_t Tfidf::rows_take_keys(const int32_t* d_ws, int n, int64_t first_row) {
+    if (n <= 0) return hipSuccess;
+    wrow_set_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_ws, n, (long long)first_row, wrow.as<uint32_t>());
+    return hipGetLastError();
+}
+hipError_t Tfidf::rows_drop_keys(const int32_t* d_row_wslot, const int32_t* d_rows, int n) {
+    if (n <= 0) return hipSuccess;
+    wrow_clear_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_row_wslot, d_rows, n, wrow.as<uint32_t>());
+    return hipGetLastError();
+}
+void Tfidf::forget_word(int32_t word_id, int32_t ws) {
+    if (word_id <= 0 || ws < 0 || (size_t)word_id >= id2ws.size() || id2ws[word_id] != ws) return;
+    id2ws[word_id] = -1;
+    id2ws_dirty.push_back(word_id);
+    held_ws.push_back(ws); held_ids.push_back(0);
+}
+hipError_t Tfidf::rows_unlog_keys(const int32_t* d_pairs, int n) {
+    if (n <= 0) return hipSuccess;
+    wrow_unlog_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_pairs, n, wrow.as<uint32_t>());
+    return hipGetLastError();
+}
+hipError_t Tfidf::rows_clear() {
+    return (wrow.p && n_wslots > 0) ? hipMemsetAsync(wrow.p, 0, (size_t)n_wslots * 4, stream) : hipSuccess;
 }
 
 hipError_t Tfidf::release_words(const int32_t* word_ids, int n) {

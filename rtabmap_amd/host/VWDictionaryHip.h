@@ -17,6 +17,8 @@
 #include <list>
 #include <map>
 #include <set>
+#include <locale>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -41,10 +43,15 @@ struct Mat {
 
 typedef std::map<std::string, std::string> ParametersMap;
 // uStr2Float (UConversion.cpp:138): the decimal mark may be '.' or ','
+// and the number is read in the classic ("C") locale whatever LC_NUMERIC the process runs under, as the reference's imbued stream does
 inline float uStr2Float(const std::string& s) {
     std::string v = s;
     for (size_t i = 0; i < v.size(); ++i) if (v[i] == ',') v[i] = '.';
-    return (float)strtod(v.c_str(), 0);
+    std::istringstream in(v);
+    in.imbue(std::locale::classic());
+    double value = 0.0;
+    in >> value;
+    return (float)value;
 }
 
 class VisualWord {   // reference VisualWord.h:38-64, VisualWord.cpp:36-70

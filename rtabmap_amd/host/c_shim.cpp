@@ -1,5 +1,6 @@
 // c_shim.cpp -- flat C entry points over VWDictionaryHip / MemoryHip so that the Python parity tests can drive the C++
 // host mirror exactly as they drive the oracle (same call sequence, same argument meaning).  Not part of lcd.h.
+#include <chrono>
 #include <cstring>
 
 #include "BayesFilterHip.h"
@@ -107,6 +108,28 @@ int hmem_compute_likelihood(void* h, const int* words, int nwords, const int* id
     int n = 0;
     for (std::map<int, float>::iterator i = L.begin(); i != L.end(); ++i, ++n) { outIds[n] = i->first; out[n] = i->second; }
     return n;
+}
+
+// The per-frame loop a caller of the reference's interface runs, timed inside C++ (bench.py's `cpp_interface_ms_per_step`): Memory::update
+// (-> VWDictionary::addNewWords) of frame i, Memory::computeLikelihood of the new signature against every signature in memory
+// (Rtabmap.cpp:2046-2117 builds that list), the oldest signature forgotten (WM -> LTM).  Returns the mean milliseconds per frame.
+double hmem_time_loop(void* h, const void* descs, int n_frames, int rows, int cols, int type, int steps) {
+    MemoryHip* m = (MemoryHip*)h;
+    const size_t frame_bytes = (size_t)rows * cols * (type == 0 ? 4 : 1);
+    std::vector<int> ids;
+    double total = 0.0;
+    for (int i = 0; i < steps + 2; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const Mat d = make_mat((const char*)descs + (size_t)(i % n_frames) * frame_bytes, rows, cols, type);
+        const int id = m->update(d, -1, ids);
+        const std::vector<int> all = m->signatureIds();
+        std::list<int> lst(all.begin(), all.end());
+        const std::map<int, float> L = m->computeLikelihood(id, lst);
+        if (!all.empty()) m->forget(all.front());
+        if (L.empty()) return -1.0;
+        if (i >= 2) total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return total / steps;
 }
 
 // type 1: Memory::addLink of a global loop closure; type 0: a neighbour link as the database hands it to a replayed signature

@@ -56,6 +56,8 @@ def lib():
         L.hmem_create.argtypes = [ci, ci, cf, ci, C.c_char_p, ci]
         L.hmem_create_stm.restype = vp
         L.hmem_create_stm.argtypes = [ci, ci, cf, ci, C.c_char_p, ci, ci]
+        L.hmem_time_loop.argtypes = [vp, vp, ci, ci, ci, ci, ci]
+        L.hmem_time_loop.restype = C.c_double
         L.hmem_add_link.argtypes = [vp, ci, ci, ci]
         L.hmem_get_neighbors_id.argtypes = [vp, ci, ci, vp, vp, ci]
         L.hmem_ids.argtypes = [vp, ci, vp, ci]
@@ -213,6 +215,11 @@ class MemoryHip:
 
     def forget(self, sig_id):
         lib().hmem_forget(self.h, sig_id)
+
+    def time_loop(self, frames, steps):
+        """update + computeLikelihood against every signature + forget(oldest) per frame, looped and timed in C++ -> ms per frame"""
+        f = np.ascontiguousarray(frames)
+        return float(lib().hmem_time_loop(self.h, _p(f), f.shape[0], f.shape[1], f.shape[2], _type_of(f), int(steps)))
 
     def get_ni(self, sig_id):
         return lib().hmem_get_ni(self.h, sig_id)

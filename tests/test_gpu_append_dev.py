@@ -157,3 +157,206 @@ def test_device_resident_stream_with_clean_unused_words(oracle, kind, pipeline):
     rows, n_live = eng.vocab_count()
     assert n_live == len(m.vwd.word_ids())                             # (the words the last retirement left unused go with the next preUpdate)
     eng.close()
+
+
+@pytest.mark.parametrize("kind,pipeline", [("surf", False), ("surf", True), ("orb", False)])
+def test_clean_unused_words_enqueued_without_a_drain(oracle, kind, pipeline):
+    """lcd_vocab_remove_unused_async: the same Memory::preUpdate stream as above, but cleanUnusedWords is ONE kernel enqueued behind the
+    frame (nothing comes back, nothing is synchronised by the call).  The frames are completed one by one here (lcd_synchronize after
+    each), so the clean sits exactly where the reference runs it and everything downstream -- word assignment over the cleaned
+    vocabulary, likelihood, the number of live words the host mirror reports once it has caught up -- must be the oracle's."""
+    import rtabmap_amd
+    rng = np.random.default_rng(177)
+    n_words, q, n_frames, wm = 2000, 96, 70, 12
+    base = synth.vocab_surf(n_words, seed=178) if kind == "surf" else synth.vocab_orb(n_words, seed=178)
+    m = oracle.OracleMemory(strategy=oracle.kNNBruteForce, nndr=0.8, new_words_compared_together=True)
+    ids = np.arange(1, n_words + 1, dtype=np.int32)
+    for i, r in zip(ids, base):
+        m.vwd.add_word(int(i), r)
+    m.vwd.update()
+    eng = rtabmap_amd.Engine("f32" if kind == "surf" else "u8", base.shape[1], sig_capacity=n_frames + 8, pipeline=pipeline)
+    eng.vocab_append(base, ids)
+    cap = n_frames + 8
+    d_w = torch.zeros(q, dtype=torch.int32, device="cuda")
+    d_l = torch.zeros(cap, dtype=torch.float32, device="cuda")
+    history = [base[rng.integers(0, n_words, q)] for _ in range(2)]
+    live, removed_total = [], 0
+    for t in range(n_frames):
+        desc = _revisit(rng, kind, history, base, q, fresh_frac=0.3)
+        history.append(desc)
+        if len(history) > 12:
+            history.pop(0)
+        removed_total += len(m.vwd.get_unused_word_ids())
+        eng.vocab_remove_unused_async()
+        if t % 9 == 8:
+            rows, n_live = eng.vocab_count()                           # completes what is owed: the host mirror catches up with the log
+            assert n_live == len(m.vwd.word_ids()) - len(m.vwd.get_unused_word_ids()), "frame %d" % t
+            eng.vocab_rebuild()
+        first_new = m.vwd.last_word_id + 1
+        sid, exp = m.update(desc)
+        d = torch.from_numpy(desc).cuda()
+        eng.frame_dev(d.data_ptr(), q, sid, float(m.num_signatures()), d_w.data_ptr(), d_l.data_ptr(), cap, first_new_word_id=first_new,
+                      append_new_words=True)
+        eng.synchronize()
+        got = d_w.cpu().numpy()
+        assert np.where(got < 0, first_new - got - 1, got).tolist() == exp, "frame %d" % t
+        live.append(sid)
+        oi, Lo = m.compute_likelihood(np.array(exp, np.int32), np.array(live, np.int32))
+        np.testing.assert_allclose(d_l[:sid].cpu().numpy()[oi - 1], Lo, rtol=RTOL, atol=ATOL, err_msg="frame %d" % t)
+        if len(live) > wm:
+            old = live.pop(0)
+            m.forget(old)
+            eng.sig_remove(old)
+    assert removed_total > 500
+    n, _ = eng.vocab_remove_unused(capacity=0)                         # what the last retirement left unused
+    assert n == len(m.vwd.get_unused_word_ids())
+    rows, n_live = eng.vocab_count()
+    assert n_live == len(m.vwd.word_ids()) - n
+    eng.close()
+
+
+def test_clean_unused_words_behind_frames_in_flight(oracle):
+    """The pipelined stream the bench times with `update()` in the step: frame (append on the device), retirement, cleanUnusedWords -- all
+    enqueued, four frames in flight, nothing completed for 150 frames.  The clean then runs behind frames that took their snapshot of the
+    vocabulary earlier (lcd.h: a word such a frame still matched keeps that signature's references), so the word assignment is the
+    DEVICE's; what must hold whatever the interleaving: the likelihood is Memory::computeLikelihood of a memory that registered exactly the
+    words the device reported (postings keys are recycled ~5 times over in this stream: a key handed out twice, or the key of a live row
+    handed out again, shows up here), no live row is left without a reference except the last frames' leftovers, and every tombstoned
+    row's word is gone from the host mirror."""
+    import rtabmap_amd
+    rng = np.random.default_rng(277)
+    n_words, q, n_frames, wm = 3000, 200, 150, 6
+    base = synth.vocab_surf(n_words, seed=278)
+    ids = np.arange(1, n_words + 1, dtype=np.int32)
+    eng = rtabmap_amd.Engine("f32", 64, sig_capacity=n_frames + 8, pipeline=True)
+    eng.vocab_append(base, ids)
+    cap = n_frames + 8
+    frames, history = [], [base[rng.integers(0, n_words, q)] for _ in range(2)]
+    for t in range(n_frames):
+        desc = _revisit(rng, "surf", history, base, q, fresh_frac=0.3)
+        history.append(desc)
+        if len(history) > 8:
+            history.pop(0)
+        frames.append(desc)
+    d_desc = [torch.from_numpy(f).cuda() for f in frames]
+    d_w = torch.zeros((n_frames, q), dtype=torch.int32, device="cuda")
+    d_l = torch.zeros((4, cap), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for t in range(n_frames):
+        eng.frame_dev(d_desc[t].data_ptr(), q, t + 1, float(min(t + 1, wm + 1)), d_w[t].data_ptr(), d_l[t % 4].data_ptr(), cap,
+                      first_new_word_id=n_words + 1 + t * q, append_new_words=True)
+        if t >= wm:
+            eng.sig_remove(t + 1 - wm)
+        eng.vocab_remove_unused_async()
+    eng.synchronize()
+    got = d_w.cpu().numpy()
+    like = d_l[(n_frames - 1) % 4].cpu().numpy()
+    # the oracle's memory registers what the device decided (ids of new words: first_new + k)
+    m = oracle.OracleMemory(strategy=oracle.kNNBruteForce, nndr=0.8, new_words_compared_together=True)
+    for i, r in zip(ids, base):
+        m.vwd.add_word(int(i), r)
+    known = set(ids.tolist())
+    for t in range(n_frames):
+        w = np.where(got[t] < 0, n_words + 1 + t * q - got[t] - 1, got[t]).astype(np.int32)
+        assert (w > 0).all()
+        for j in np.flatnonzero(got[t] < 0).tolist():
+            if int(w[j]) not in known:
+                known.add(int(w[j]))
+                m.vwd.add_word(int(w[j]), frames[t][j])
+        assert m.add_signature_with_id(t + 1, w) == t + 1
+        if t >= wm and t < n_frames - 1:
+            m.forget(t + 1 - wm)
+    live = np.array(m.signature_ids(), np.int32)
+    oi, Lo = m.compute_likelihood(w, live)
+    np.testing.assert_allclose(like[oi - 1], Lo, rtol=RTOL, atol=ATOL)
+    dead = np.ones(n_frames, bool)
+    dead[oi - 1] = False
+    assert not like[:n_frames][dead].any()
+    rows, n_live = eng.vocab_count()
+    st = eng.stats()
+    assert rows > n_words + 1000 and n_live < rows - 1000, "the stream must create and remove thousands of words"
+    assert st["word_slots"] < 3 * n_live + 4 * q * 40, "postings keys are recycled, not leaked: %d keys for %d live words" % (st["word_slots"], n_live)
+    # the live rows are referenced words (up to what the last retirements left behind): one more clean removes little
+    vr, vi = eng.vocab_read(0, rows)
+    live_ids = vi[vi != 0]
+    assert live_ids.shape[0] == n_live and len(set(live_ids.tolist())) == n_live
+    n_left, _ = eng.vocab_remove_unused(capacity=0)
+    assert n_left <= 4 * q
+    refs_alive = set()
+    for t in range(max(0, n_frames - wm - 1), n_frames):
+        refs_alive.update(np.where(got[t] < 0, n_words + 1 + t * q - got[t] - 1, got[t]).tolist())
+    rows2, n_live2 = eng.vocab_count()
+    vr2, vi2 = eng.vocab_read(0, rows2)
+    assert set(vi2[vi2 != 0].tolist()) <= refs_alive, "a live row whose word no live signature references"
+    eng.close()
+
+
+def test_rows_appended_on_the_device_keep_their_postings_keys(oracle):
+    """A word that a frame appends on the device holds its postings key in the row (row_wslot) whether or not anything references it: the
+    batched check of superseded reservations must not hand that key to another word.  Frames WITHOUT a signature (sig_id = 0: no
+    references at all) append ~70 words each for 90 frames -- more than 16 384 reserved keys, so several batched checks run -- then
+    signatures are registered by word id (the host path: its id -> key table must name the row's key, not a second one) and by later
+    frames that match the appended rows; the likelihood over all of them is the oracle's."""
+    import rtabmap_amd
+    rng = np.random.default_rng(377)
+    n_words, q, n_frames = 2500, 256, 90
+    base = synth.vocab_surf(n_words, seed=378)
+    ids = np.arange(1, n_words + 1, dtype=np.int32)
+    eng = rtabmap_amd.Engine("f32", 64, sig_capacity=64, pipeline=True)
+    eng.vocab_append(base, ids)
+    m = oracle.OracleMemory(strategy=oracle.kNNBruteForce, nndr=0.8, new_words_compared_together=True)
+    for i, r in zip(ids, base):
+        m.vwd.add_word(int(i), r)
+    m.vwd.update()
+    frames = [np.ascontiguousarray(np.where((rng.random((q, 1)) < 0.3), synth.vocab_surf(q, seed=900 + t), base[rng.integers(0, n_words, q)]))
+              for t in range(n_frames)]
+    d_desc = [torch.from_numpy(f).cuda() for f in frames]
+    d_w = torch.zeros((n_frames, q), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    firsts = []
+    for t in range(n_frames):
+        firsts.append(n_words + 1 + t * q)
+        eng.frame_dev(d_desc[t].data_ptr(), q, 0, 1.0, d_w[t].data_ptr(), 0, 0, first_new_word_id=firsts[t], append_new_words=True)
+    eng.synchronize()
+    got = d_w.cpu().numpy()
+    created = {}                                                     # word id -> descriptor
+    per_frame_words = []
+    for t in range(n_frames):
+        w = np.where(got[t] < 0, firsts[t] - got[t] - 1, got[t]).astype(np.int32)
+        per_frame_words.append(w)
+        for j in np.flatnonzero(got[t] < 0).tolist():
+            created.setdefault(int(w[j]), frames[t][j])
+    assert len(created) > 4000
+    rows, n_live = eng.vocab_count()
+    assert rows == n_live == n_words + len(created)
+    for wid in sorted(created):
+        m.vwd.add_word(wid, created[wid])
+    m.vwd.update()
+    # signatures registered through the host path, naming appended words by id
+    sigs = []
+    for s in range(12):
+        w = per_frame_words[(7 * s) % n_frames]
+        sid = m.add_signature(w)
+        eng.sig_add(sid, w)
+        sigs.append(sid)
+    # ... and through the device path: a revisit of an early frame matches the rows that frame appended
+    cap = 64
+    d_l = torch.zeros(cap, dtype=torch.float32, device="cuda")
+    d_w1 = torch.zeros(q, dtype=torch.int32, device="cuda")
+    # Memory::update starts with cleanUnusedWords: the words nobody references go, on both sides (rows appended on the device included)
+    unused_o = sorted(m.vwd.get_unused_word_ids())
+    n_gone, gone = eng.vocab_remove_unused(capacity=1 << 20)
+    assert n_gone == len(unused_o) and sorted(gone.tolist()) == unused_o
+    first_new = m.vwd.last_word_id + 1
+    sid, exp = m.update(frames[3])
+    eng.frame_dev(d_desc[3].data_ptr(), q, sid, float(m.num_signatures()), d_w1.data_ptr(), d_l.data_ptr(), cap, first_new_word_id=first_new,
+                  append_new_words=True)
+    eng.synchronize()
+    g = d_w1.cpu().numpy()
+    assert np.where(g < 0, first_new - g - 1, g).tolist() == exp
+    sigs.append(sid)
+    oi, Lo = m.compute_likelihood(np.array(exp, np.int32), np.array(sigs, np.int32))
+    np.testing.assert_allclose(d_l[: len(sigs)].cpu().numpy(), Lo, rtol=RTOL, atol=ATOL)
+    for wid in [w for w in list(created)[:: max(1, len(created) // 60)] if w not in set(unused_o)]:
+        assert eng.word_nrefs(wid) == len(m.vwd.word_refs(wid))
+    eng.close()

@@ -300,12 +300,13 @@ def test_pipelined_frames_across_growing_word_tables():
     assert (out[0][0] < 0).sum() > T * q // 2                         # most descriptors became new words
 
 
-def test_frame_dev_at_headline_sizes(oracle):
-    """BASELINE.json's configuration: 49k SURF words, 500 descriptors per frame, a Zipf memory of 20 000 signatures x 500 words
-    (the oracle builds it in seconds; bench.py repeats the check at 100k).  Three frames through lcd_frame_dev with retirement of
-    the oldest signature: ids identical, likelihood within 1e-4 over every slot, the same best candidate, sampled nw identical."""
+@pytest.mark.parametrize("n_sig,pipeline", [(20000, False), (100000, True)])
+def test_frame_dev_at_headline_sizes(oracle, n_sig, pipeline):
+    """BASELINE.json's configuration: 49k SURF words, 500 descriptors per frame, a Zipf memory of 100 000 signatures x 500 words (and a
+    20 000-signature one on a plain handle).  Three frames through lcd_frame_dev with retirement of the oldest signature: ids identical,
+    likelihood within 1e-4 over every slot, the same best candidate, sampled nw identical."""
     import rtabmap_amd
-    n_words, n_sig, q = 49000, 20000, 500
+    n_words, q = 49000, 500
     vocab = synth.vocab_surf(n_words)
     words = synth.zipf_words(n_sig, q, n_words, seed=100000)
     ids = np.arange(1, n_words + 1, dtype=np.int32)
@@ -313,9 +314,8 @@ def test_frame_dev_at_headline_sizes(oracle):
     for i, r in zip(ids, vocab):
         m.vwd.add_word(int(i), r)
     m.vwd.update()
-    for s in range(n_sig):
-        m.add_signature(words[s])
-    eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 1024, sig_capacity=n_sig + 64)
+    assert m.add_signatures_bulk(words) == 1                        # (the bulk constructor is pinned to the one-by-one path: tests/test_oracle_bulk.py)
+    eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 1024, sig_capacity=n_sig + 64, pipeline=pipeline)
     eng.vocab_append(vocab, ids)
     eng.sig_add_bulk(np.arange(1, n_sig + 1, dtype=np.int32), np.arange(0, (n_sig + 1) * q, q, dtype=np.int64), words.reshape(-1))
     cap = n_sig + 16
