@@ -518,7 +518,7 @@ def host_path_ms(torch, eng, frames_np, n_sig, steps=20):
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
-def with_update_ms(torch, eng, stepper, steps=256, lag=8, rebuild_every=64):
+def with_update_ms(torch, eng, stepper, steps=256, lag=8, rebuild_every=128):
     """The step with the WHOLE of Memory::preUpdate in it, every frame, nothing completed in between (Memory.cpp:1004-1016 runs
     cleanUnusedWords + VWDictionary::update() before every addNewWords of an incremental dictionary): the frame's new words become
     vocabulary rows behind its decision loop (append_new_words, as in the headline step); the signature registered `lag` frames earlier is
@@ -547,39 +547,45 @@ def with_update_ms(torch, eng, stepper, steps=256, lag=8, rebuild_every=64):
 
 
 def frame_latency_ms(torch, eng, stepper, stream, base_i, n=48):
-    """What a caller waits for: (a) in a running stream of frames -- lcd_frame_dev(t) called -> the event recorded behind frame t
-    (lcd_record_event: behind every stage the frame still owes, i.e. its likelihood is readable) has fired, the following frames
-    being submitted meanwhile; host and device clocks are aligned once (an event + a synchronisation: a few microseconds of error);
-    (b) a single frame followed by lcd_synchronize (the owed stages run as three stand-alone launch pairs)."""
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
-    for e in evs:
-        e.record(stream)
-    torch.cuda.synchronize()
-    for i in range(8):
-        stepper(base_i + i)
-    eng.record_event(evs[0].cuda_event)
-    eng.synchronize()
-    torch.cuda.synchronize()
-    t_base = time.perf_counter()                         # ~ the moment evs[0] fired (the stream was idle behind it)
-    sub = []
-    eng.record_event(evs[0].cuda_event)
-    torch.cuda.synchronize()
-    t_base = time.perf_counter()
-    for i in range(n):
-        sub.append(time.perf_counter() - t_base)
-        stepper(base_i + 8 + i)
-        eng.record_event(evs[i + 1].cuda_event)
-    eng.synchronize()
-    torch.cuda.synchronize()
-    lat = np.array([evs[0].elapsed_time(evs[i + 1]) - 1e3 * sub[i] for i in range(n)])
-    lat = lat[8:]                                         # the first frames meet an empty pipeline
+    """What a caller waits for: lcd_frame_dev(t) called -> the event recorded behind frame t (lcd_record_event: behind every stage the
+    frame still owes, i.e. its likelihood is readable) has fired.
+      (a) paced: the caller keeps lcd_pipeline_depth() + 1 frames in flight (it waits for frame t - 3 before it submits frame t + 1): the
+          latency of the pipeline itself, four frame periods;
+      (b) saturated: frames submitted as fast as the call returns -- the queue in front of the device adds to it (the call itself holds the
+          caller when the device is more than 8 frames behind);
+      (c) a single frame followed by lcd_synchronize (the owed stages run as three stand-alone launch pairs).
+    Host and device clocks are aligned once per series (an event + a synchronisation: a few microseconds of error)."""
+    def series(paced):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        for e in evs:
+            e.record(stream)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        eng.record_event(evs[0].cuda_event)
+        torch.cuda.synchronize()
+        t_base = time.perf_counter()                     # ~ the moment evs[0] fired (the stream was idle behind it)
+        sub = []
+        for i in range(n):
+            if paced and i >= 4:
+                evs[i - 3].synchronize()                  # frame i - 4 is complete: four in flight with this one
+            sub.append(time.perf_counter() - t_base)
+            stepper(base_i + i)
+            eng.record_event(evs[i + 1].cuda_event)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        lat = np.array([evs[0].elapsed_time(evs[i + 1]) - 1e3 * sub[i] for i in range(n)])
+        return lat[8:]                                    # the first frames meet an empty pipeline
+    paced = series(True)
+    sat = series(False)
     single = []
     for i in range(12):
         t0 = time.perf_counter()
-        stepper(base_i + 8 + n + i)
+        stepper(base_i + i)
         eng.synchronize()
         single.append(1e3 * (time.perf_counter() - t0))
-    return float(np.median(lat)), float(np.percentile(lat, 95)), float(np.median(single[2:]))
+    return {"paced_median": float(np.median(paced)), "paced_p95": float(np.percentile(paced, 95)),
+            "saturated_median": float(np.median(sat)), "saturated_p95": float(np.percentile(sat, 95)),
+            "single_frame_then_synchronize_median": float(np.median(single[2:]))}
 
 
 def cpp_interface_ms(vocab, words, frames_np, n_sig_small=10000, steps=12):
@@ -1219,7 +1225,7 @@ def main():
             config["with_update_ms_per_step"] = wu
             config["with_update_note"] = "the headline step + the rest of Memory::preUpdate EVERY frame, nothing completed in between: the signature " \
                                          "registered 8 frames earlier retired too, cleanUnusedWords as one enqueued kernel " \
-                                         "(lcd_vocab_remove_unused_async), lcd_vocab_rebuild every 64th frame (the only draining call); 256 steps; " \
+                                         "(lcd_vocab_remove_unused_async), lcd_vocab_rebuild every 128th frame (the only draining call; ~20 % of the rows are tombstones by then); 256 steps; " \
                                          "vocabulary at the end: %d rows, %d live" % (wrows, wlive)
             engw.close()
             engn = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 8192,
@@ -1230,10 +1236,11 @@ def main():
             config["no_append_ms_per_step"] = 1e3 * rn["wall"] / args.steps
             config["no_append_note"] = "the step as rounds 1-3 timed it: the frame's new words get postings but never become vocabulary rows (same command)"
             engn.close()
-            lat_med, lat_p95, lat_single = frame_latency_ms(torch, eng, step, stream, args.warmup + args.steps + 400)
-            config["frame_latency_ms"] = {"in_a_stream_median": lat_med, "in_a_stream_p95": lat_p95, "single_frame_then_synchronize_median": lat_single,
-                                          "note": "lcd_frame_dev(t) called -> frame t's likelihood readable (event behind every stage it owes): in a "
-                                                  "running stream three further calls carry its stages; alone, lcd_synchronize runs them stand-alone"}
+            lat = frame_latency_ms(torch, eng, step, stream, args.warmup + args.steps + 400)
+            lat["note"] = "ms from the lcd_frame_dev call of a frame until its likelihood is readable (event behind every stage it owes): paced = the " \
+                          "caller keeps four frames in flight (three further calls carry a frame's stages); saturated = calls back to back, the queue " \
+                          "in front of the device included; single = one frame then lcd_synchronize (its stages run stand-alone)"
+            config["frame_latency_ms"] = lat
             try:
                 cms, cn, cload = cpp_interface_ms(vocab, words, frames_np)
                 config["cpp_interface_ms_per_step"] = cms

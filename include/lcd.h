@@ -305,7 +305,8 @@ int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_id
 typedef struct lcd_shard_cand { uint64_t key; int32_t word; int32_t wslot; } lcd_shard_cand;
 int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shard_cand* d_cand /* [q*2] */);
 int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, float nndr_ratio, int32_t sig_id,
-                        int32_t first_new_word_id /* as lcd_frame_args; new words belong to the LAST rank */, float N,
+                        int32_t first_new_word_id /* as lcd_frame_args; new words belong to the LAST rank, or block-cyclically to all of
+                                                     them: lcd_set_option "shard_growth_first" / "shard_growth_block" */, float N,
                         int rank, int world, const lcd_shard_cand* d_all_cand /* [world*q*2], rank-major */,
                         int64_t total_live_rows, int32_t* d_word_ids, int64_t* d_lfix, int64_t lfix_capacity);
 int lcd_finalize_dev(lcd_engine* h, int64_t* d_lfix, int64_t n, float* d_likelihood);
@@ -331,7 +332,11 @@ int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, co
  * (256 / 512 / 1024).  "filter_units": compute units the bf16 filter plans its persistent workgroups for when the vocabulary has
  * more 256-word strips than that (-1 built-in, 0 never persistent).  "profile_likelihood": 0 = lcd_profile_begin brackets only the
  * 2-NN launch of a pipelined frame (every timed launch costs stream time).  "strip_tiles": 32-word tiles per filter workgroup of a
- * pipelined frame (1 .. 8; 0 = the built-in plan).  Unknown keys / values -> LCD_ERR_INVALID. */
+ * pipelined frame (1 .. 8; 0 = the built-in plan).  Unknown keys / values -> LCD_ERR_INVALID.
+ * The two keys that DO change what a call means (sharded handles only, identical on every rank): "shard_growth_first" = F and
+ * "shard_growth_block" = B > 0 make lcd_shard_frame_dev give the words frames create (ids >= F) to rank ((id - F) / B) % world instead of
+ * the last rank, and merge the gathered candidates with ties going to the lower WORD ID -- the single-GPU row order as long as every rank
+ * appends its words in ascending id ("block-cyclic so growth stays balanced"). */
 int lcd_set_option(lcd_engine* h, const char* key, int64_t value);
 
 /* the work of ONE scoring launch for the words of the last frame (diagnostic, synchronises): out8[0] bytes of dense count rows

@@ -100,6 +100,15 @@ struct lcd_engine {
     int enqueue_clean();                                // flush the pending retirements, launch the kernel (nothing is synchronised)
     int reconcile();
     int64_t rows_ub() const;
+    // The rows the FILTER of chain frame `fseq` will most likely see (the count its launch reads is the one written a launch earlier: the
+    // words of the frames up to fseq - 2): what the newest finished appender reported + an estimate per appending frame between that one
+    // and fseq - 2, from the growth the reports have shown.  Only the launch PLAN is made for it -- correctness does not rest on it: the
+    // filter masks rows beyond the device's count, and the re-rank scans exactly everything from min(plan, device count) on.
+    int64_t rows_plan(uint64_t fseq);
+    uint32_t est_tag = 0; int64_t est_cnt = 0; double est_new = 0.0;   // last report seen, decaying maximum of new rows per appending frame
+    // sharded vocabulary, balanced growth (lcd_set_option "shard_growth_first" / "shard_growth_block"): the words frames create (ids >=
+    // shard_first) belong to rank ((id - shard_first) / shard_block) % world; 0 = they belong to the last rank
+    int32_t shard_first = 0, shard_block = 0;
     int filter_units = -1;                              // lcd_set_option("filter_units")
     int strip_tiles = 0;                                // lcd_set_option("strip_tiles"): tiles per filter workgroup of a pipelined frame (0: planner)
     int sync_all();                                     // stream drained

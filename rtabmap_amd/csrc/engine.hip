@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -250,6 +251,28 @@ int64_t lcd_engine::rows_ub() const {
         if (it->enabled) extra += it->q;
     }
     return n_rows + extra;
+}
+
+int64_t lcd_engine::rows_plan(uint64_t fseq) {
+    if (unreconciled.empty() || !h_vmirror) return n_rows;
+    const unsigned long long v = *(volatile const unsigned long long*)h_vmirror;
+    const uint32_t tag = (uint32_t)(v >> 32);
+    const int64_t cnt = (int64_t)(uint32_t)v;
+    if (tag == 0) return rows_ub();                                  // nothing reported yet
+    if (est_tag != 0 && tag != est_tag) {                             // the reports moved on: rows per frame since the last look
+        const double per = (double)(cnt - est_cnt) / (double)(uint32_t)(tag - est_tag);
+        est_new = std::max(est_new * 0.9, per);
+    }
+    est_tag = tag; est_cnt = cnt;
+    const int64_t ub = rows_ub();
+    int64_t frames = 0; bool found = false;
+    for (auto it = unreconciled.rbegin(); it != unreconciled.rend(); ++it) {
+        if ((uint32_t)(it->seq + 1) == tag) { found = true; break; }
+        if (it->enabled && it->seq + 2 <= fseq) frames += 1;          // an appender the filter's count includes, not reported yet
+    }
+    if (!found) return ub;
+    const int64_t est = cnt + (int64_t)std::ceil((double)frames * (est_new * 1.25 + 8.0));
+    return std::min(std::max(est, cnt), ub);
 }
 
 // the host's row mirror catches up with the device (synchronises)
@@ -1191,7 +1214,8 @@ static int build_knn(lcd_engine* h, lcd_engine::InFlight& f, PipeKnn* kp) {
     const bool incremental = (a.flags & LCD_Q_INCREMENTAL) != 0;
     const bool together = incremental && (a.flags & LCD_Q_NEW_WORDS_COMPARED);
     const int ld = (q + 63) / 64 * 64, bw = ld / 32;
-    const int64_t plan_rows = f.chained ? h->rows_ub() : h->n_rows;
+    const int64_t rows_bound = f.chained ? h->rows_ub() : h->n_rows;   // a true upper bound: the exact redo and the buffers are sized for it
+    const int64_t plan_rows = f.chained ? h->rows_plan(f.vseq) : h->n_rows;
     if (plan_rows > 0x7FFFFFF0ll) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: more than 2^31 rows");
     // The distance tiles get compute units of their own (a tile that shares one with a strip takes twice as long, and so does the
     // strip); the two tail workgroups do not: a filter workgroup holds 66 KB of LDS, so two of the launch's workgroups can share a
@@ -1202,8 +1226,13 @@ static int build_knn(lcd_engine* h, lcd_engine::InFlight& f, PipeKnn* kp) {
         const int n_tiles = (int)((plan_rows + 31) / 32);
         k.plan.tiles_per_block = h->strip_tiles; k.plan.n_blocks = (n_tiles + h->strip_tiles - 1) / h->strip_tiles; k.plan.one_strip = 1;
     }
-    LCD_HIP(h, ring_reserve(h, f.set, &lcd_engine::FrameScratch::d_partial2, knn_bf16_partial_bytes(k.plan)));
-    LCD_HIP(h, ring_reserve(h, f.set, &lcd_engine::FrameScratch::d_partial3, knn_rowpar_partial_bytes((int)plan_rows, q)));
+    {   // the candidate records: sized for this plan AND for the one the upper bound would get (a growing vocabulary crosses the planner's
+        // thresholds: a reallocation drains the stream)
+        size_t bytes = knn_bf16_partial_bytes(k.plan);
+        if (f.chained) bytes = std::max(bytes, knn_bf16_partial_bytes(knn_bf16_plan_pipelined(q, (int)(rows_bound + 8 * (int64_t)q), together ? knn_selfdist_wgs(q) : 0, h->filter_units)));
+        LCD_HIP(h, ring_reserve(h, f.set, &lcd_engine::FrameScratch::d_partial2, bytes));
+    }
+    LCD_HIP(h, ring_reserve(h, f.set, &lcd_engine::FrameScratch::d_partial3, knn_rowpar_partial_bytes((int)(rows_bound + (f.chained ? 8 * (int64_t)q : 0)), q)));
     k.vocab = h->vocab.p; k.vocab_bf = h->vocab_bf.p; k.row_norm = h->row_norm.as<float>(); k.norm_max_bits = h->norm_max.as<uint32_t>();
     k.row_id = h->row_id.as<int32_t>(); k.queries = a.d_descriptors; k.partial = sc.d_partial2.p;
     k.qsplit = sc.d_qsplit.p; k.qnorm = sc.d_qnorm.as<float>();
@@ -1226,7 +1255,7 @@ static int build_knn(lcd_engine* h, lcd_engine::InFlight& f, PipeKnn* kp) {
     r.knn_row = k.out_row; r.row_wslot = h->row_wslot.as<int32_t>(); r.out_wslot = sc.d_out_wslot.as<int32_t>(); r.new_ws = WsRuns();
     r.fail_count = sc.d_fail_count.as<int32_t>();
     RowparArgs& rp = r.rp;
-    rp.enabled = 1; rp.vocab = (const float*)h->vocab.p; rp.row_id = h->row_id.as<int32_t>(); rp.n_rows = (int)plan_rows;
+    rp.enabled = 1; rp.vocab = (const float*)h->vocab.p; rp.row_id = h->row_id.as<int32_t>(); rp.n_rows = (int)rows_bound;
     rp.n_rows_dev = k.n_hi;                                          // the rows that exist when the redo runs: after the previous frame's append
     rp.queries = (const float*)a.d_descriptors; rp.fail_list = sc.d_fail_list.as<int32_t>(); rp.partial = (unsigned long long*)sc.d_partial3.p;
     rp.out_row = k.out_row; rp.out_word = k.out_word; rp.out_dist = k.out_dist;
@@ -1625,8 +1654,9 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
     LCD_HIP(h, dreserve(h, h->d_knn_word, (size_t)q * 2 * 4));
     LCD_HIP(h, dreserve(h, h->d_knn_dist, (size_t)q * 2 * 4));
     // global 2-NN from the gathered per-rank candidates; d_knn_row holds the postings keys of the neighbours this rank owns
+    const bool cyclic = h->shard_block > 0 && first_new_word_id >= h->shard_first && h->shard_first > 0;
     LCD_HIP(h, launch_shard_merge(d_all_cand, world, rank, q, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
-                                  h->d_knn_row.as<int32_t>(), h->stream));
+                                  h->d_knn_row.as<int32_t>(), h->stream, h->shard_block > 0));
     const int have_index = total_live_rows >= 2 ? 1 : 0;
     const bool incremental = (flags & LCD_Q_INCREMENTAL) != 0;
     const bool together = incremental && (flags & LCD_Q_NEW_WORDS_COMPARED);
@@ -1645,7 +1675,10 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
         hipError_t e = t.reserve_new_words(first_new_word_id, q, &new_ws);
         if (e == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_shard_frame_dev: word ids must be below 2^28");
         if (e != hipSuccess) return h->hip_fail(e, "reserve_new_words");
-        if (rank != world - 1) new_ws.n = 0;
+        if (cyclic) {                                      // block-cyclic ownership of the frame's new words (balanced growth)
+            new_ws.own_id0 = first_new_word_id; new_ws.own_first = h->shard_first; new_ws.own_block = h->shard_block;
+            new_ws.own_rank = rank; new_ws.own_world = world;
+        } else if (rank != world - 1) new_ws.n = 0;
     }
     const int rflags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0);
     LCD_HIP(h, launch_resolve(q, rflags, nndr_ratio, have_index, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
@@ -1753,6 +1786,8 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     // compute units the bf16 filter's persistent launch plans for (vocabularies of more 256-word strips than that): -1 built-in, 0 off
     if (!std::strcmp(key, "filter_units") && value >= -1 && value <= 4096) { h->filter_units = (int)value; return LCD_OK; }
     if (!std::strcmp(key, "strip_tiles") && value >= 0 && value <= 8) { h->strip_tiles = (int)value; return LCD_OK; }
+    if (!std::strcmp(key, "shard_growth_first") && value >= 0 && value < (1ll << 28)) { h->shard_first = (int32_t)value; return LCD_OK; }
+    if (!std::strcmp(key, "shard_growth_block") && value >= 0 && value <= (1 << 20)) { h->shard_block = (int32_t)value; return LCD_OK; }
     // 0: lcd_profile_begin brackets only the 2-NN launch of a pipelined frame (an event pair costs the stream ~10 us)
     if (!std::strcmp(key, "profile_likelihood") && (value == 0 || value == 1)) { h->prof_likelihood = value != 0; return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");

@@ -592,7 +592,9 @@ __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, cons
                                                      const int32_t* __restrict__ n_lo = nullptr) {
     // n_lo: the number of rows this search may see, on the device (a pipelined handle appends the previous frames' new words while
     // this launch runs: rows at or beyond n_lo[0] -- up to n_rows, the host's upper bound -- are masked with an infinite |row|^2)
-    const int lo_rows = n_lo ? n_lo[0] : 0x7fffffff;
+    // (n_rows itself may be an ESTIMATE below the device's count -- the launch plan of a growing vocabulary: nothing at or beyond it is
+    // ranked either, the re-rank scans from min(n_rows, n_lo[0]) on)
+    const int lo_rows = min(n_lo ? n_lo[0] : 0x7fffffff, n_rows);
     // NG = 32-query groups per wave: 4 -> four waves, one per SIMD; 2 -> eight waves, two per SIMD (one wave's tile
     // synchronisation, LDS reads and top-3 update hide behind the other's MFMAs).  The workgroup covers BF_QB queries either way.
     static_assert(NG == 4 || NG == 2, "wave tile");
@@ -802,6 +804,7 @@ __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, co
     // queue as the strip's requests below, and its first use would wait for all of them
     int lo_rows = 0x7fffffff;
     if (n_lo) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lo_rows) : "s"(n_lo) : "memory");
+    lo_rows = min(lo_rows, n_rows);                                       // (the plan's n_rows may be an estimate below the device's count)
     const int n_fwg = n_blocks * ((nq + BF_QB - 1) / BF_QB);
     if (bid >= n_fwg) { selfdist_tile(sd, bid - n_fwg, s_dyn); return; }
     const int bx = bid % n_blocks, by = bid / n_blocks;
@@ -1185,12 +1188,14 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                                                      int32_t* __restrict__ out_row, int32_t* __restrict__ out_word,
                                                      float* __restrict__ out_dist, int32_t* __restrict__ fail_list,
                                                      int32_t* __restrict__ fail_count, const CandBits& cb,
-                                                     const int32_t* __restrict__ pend_lo = nullptr, const int32_t* __restrict__ pend_hi = nullptr) {
+                                                     const int32_t* __restrict__ pend_lo = nullptr, const int32_t* __restrict__ pend_hi = nullptr,
+                                                     int pend_cap = 0x7fffffff /* rows the filter's launch plan covered */) {
     static_assert(DIM == 64, "16 lanes x 4 floats per candidate row");
     // rows [pend_lo[0], pend_hi[0]): words the previous frame created, appended on the device after this frame's filter took its
     // snapshot of the vocabulary (VWDictionary::update() of a pipelined handle).  They are scanned exactly here, so the result is
     // the 2-NN over the vocabulary as update() leaves it before this frame.
-    const int p_lo = pend_lo ? pend_lo[0] : 0, p_hi = pend_hi ? pend_hi[0] : 0;
+    // (the plan is made for an ESTIMATE of the row count: what lies between the rows it covered and the device's count is scanned here too)
+    const int p_lo = pend_lo ? min(pend_lo[0], pend_cap) : 0, p_hi = pend_hi ? pend_hi[0] : 0;
     const int hf = HALVES == 2 ? (int)threadIdx.x / MF_BLOCK : 0;
     const int tid = HALVES == 2 ? (int)threadIdx.x % MF_BLOCK : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool valid = qi_first + hf < nq;                             // the odd query out: its half walks the last query again, writes nothing
@@ -1460,7 +1465,7 @@ struct FilterArgs {
 struct RerankArgs {
     const uint64_t* pk; const uint32_t* pl; int n_blocks, nq; const float* vocab; const float* queries; const int32_t* row_id;
     const uint32_t* norm_max_bits; int32_t* out_row; int32_t* out_word; float* out_dist; int32_t* fail_list; int32_t* fail_count; CandBits cb;
-    const int32_t* n_lo; const int32_t* n_hi;
+    const int32_t* n_lo; const int32_t* n_hi; int plan_rows;
 };
 constexpr int PIPE_BLOCK = 256;     // workgroup size of both fused launches (the filter's and the re-rank's)
 
@@ -1520,7 +1525,7 @@ __global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, 
         const int pair = (bid & 7) * (n_rerank_wgs >> 3) + (bid >> 3);
         if (2 * pair >= k.nq) return;
         knn_mfma_rerank_body<64, BF_KEEP, false, true, 2>(2 * pair, k.pk, k.pl, k.n_blocks, k.nq, k.vocab, k.queries, k.row_id, k.norm_max_bits, k.out_row,
-                                                          k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb, k.n_lo, k.n_hi);
+                                                          k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb, k.n_lo, k.n_hi, k.plan_rows);
         B_STAMP(1);
         return;
     }
@@ -1867,7 +1872,7 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
         rk.pk = pk; rk.pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * BF_KEEP * p.qpad);
         rk.n_blocks = p.n_blocks; rk.nq = p.q; rk.vocab = (const float*)k->vocab; rk.queries = (const float*)k->queries; rk.row_id = k->row_id;
         rk.norm_max_bits = k->norm_max_bits; rk.out_row = k->out_row; rk.out_word = k->out_word; rk.out_dist = k->out_dist;
-        rk.fail_list = k->fail_list; rk.fail_count = k->fail_count; rk.cb = k->cb; rk.n_lo = k->n_lo; rk.n_hi = k->n_hi;
+        rk.fail_list = k->fail_list; rk.fail_count = k->fail_count; rk.cb = k->cb; rk.n_lo = k->n_lo; rk.n_hi = k->n_hi; rk.plan_rows = p.n_rows;
         n_rerank = ((p.q + 1) / 2 + 7) & ~7;                          // two queries per workgroup; padded to the XCD count (frame_b_kernel)
     }
     ScoreArgs A{};

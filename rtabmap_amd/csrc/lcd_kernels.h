@@ -52,12 +52,19 @@ inline void cand_bits_layout(CandBits& cb, uint32_t* base, int q, int bw) {
 // concatenated runs (recycled keys come back as a handful of intervals; the rest is one fresh interval).  n == 0: none.
 // n < 0 (decision loop only): the keys are not known yet -- the loop leaves the code -(k + 2) for the frame's k-th new word and the
 // registration, which runs one launch later on a pipelined handle, translates it with the runs it was given.
+// Sharded vocabulary with balanced growth (own_block > 0): the k-th new word of the frame has id own_id0 + k and belongs to rank
+// ((id - own_first) / own_block) % own_world -- every rank reserves the same keys (identical numbering), only the owner references them.
 struct WsRuns {
     int32_t start[16];
     int32_t len[16];
     int32_t n = 0;
+    int32_t own_id0 = 0, own_first = 0, own_block = 0, own_rank = 0, own_world = 1;
 };
 __host__ __device__ inline int32_t ws_runs_at(const WsRuns& r, int k) {
+    if (r.own_block > 0) {
+        const int32_t id = r.own_id0 + k;
+        if (id < r.own_first || ((id - r.own_first) / r.own_block) % r.own_world != r.own_rank) return -1;
+    }
     for (int i = 0; i < r.n; ++i) { if (k < r.len[i]) return r.start[i] + k; k -= r.len[i]; }
     return -1;
 }
@@ -130,8 +137,10 @@ hipError_t launch_findnn_resolve(int q, int flags, float nndr, int have_index, c
 // merge of the all-gathered records [world][q][2] (ties: lower rank, then lower local row); out_wslot is -1 for foreign words.
 hipError_t launch_shard_pack(const int32_t* knn_row, const int32_t* knn_word, const float* knn_dist, const int32_t* row_wslot, int q,
                              void* out_cand, hipStream_t s);
+// by_word: ties go to the lower WORD ID instead of (rank, local row) -- the single-GPU row order when every rank's rows ascend by id and
+// the ranks' id sets interleave (block-cyclic ownership of the words frames create)
 hipError_t launch_shard_merge(const void* all_cand, int world, int rank, int q, int32_t* out_word, float* out_dist, int32_t* out_wslot,
-                              hipStream_t s);
+                              hipStream_t s, bool by_word = false);
 
 // ---- the same filter on the bf16 matrix pipe (three bf16 products per f32 product, fp32 accumulate): needs the hi/lo bf16
 // split of the vocabulary (256 bytes per row) kept by launch_vocab_bf16 next to the rows.

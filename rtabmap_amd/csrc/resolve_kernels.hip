@@ -75,7 +75,7 @@ __global__ void findnn_resolve_kernel(int q, int flags, float nndr, int have_ind
 // shards are consecutive id ranges.  out_wslot[q*2] is the postings key if THIS rank owns the neighbour, else -1.
 struct ShardCand { unsigned long long key; int32_t word; int32_t wslot; };
 __global__ void shard_merge_kernel(const ShardCand* __restrict__ cand, int world, int rank, int q, int32_t* __restrict__ out_word,
-                                   float* __restrict__ out_dist, int32_t* __restrict__ out_wslot) {
+                                   float* __restrict__ out_dist, int32_t* __restrict__ out_wslot, int by_word) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= q) return;
     // composite (distance, rank, local row, slot index) compared lexicographically
@@ -85,7 +85,9 @@ __global__ void shard_merge_kernel(const ShardCand* __restrict__ cand, int world
         for (int j = 0; j < 2; ++j) {
             const ShardCand c = cand[((size_t)r * q + i) * 2 + j];
             if (c.key == KEY_NONE || c.word == 0) continue;
-            const unsigned long long k = (c.key & 0xFFFFFFFF00000000ull) | ((unsigned long long)r << 26) | (c.key & 0x3FFFFFFull);
+            // by_word: (distance, word id) -- rows ascend by id on every rank, so this is the order one GPU holding all rows would see
+            const unsigned long long k = by_word ? ((c.key & 0xFFFFFFFF00000000ull) | (unsigned long long)(uint32_t)c.word)
+                                                 : ((c.key & 0xFFFFFFFF00000000ull) | ((unsigned long long)r << 26) | (c.key & 0x3FFFFFFull));
             const int src = (r * q + i) * 2 + j;
             if (k < bk) { sk = bk; ssrc = bsrc; bk = k; bsrc = src; }
             else if (k < sk) { sk = k; ssrc = src; }
@@ -195,9 +197,9 @@ hipError_t launch_shard_pack(const int32_t* knn_row, const int32_t* knn_word, co
     return hipGetLastError();
 }
 hipError_t launch_shard_merge(const void* all_cand, int world, int rank, int q, int32_t* out_word, float* out_dist, int32_t* out_wslot,
-                              hipStream_t s) {
+                              hipStream_t s, bool by_word) {
     if (q <= 0) return hipSuccess;
-    shard_merge_kernel<<<(q + 255) / 256, 256, 0, s>>>((const ShardCand*)all_cand, world, rank, q, out_word, out_dist, out_wslot);
+    shard_merge_kernel<<<(q + 255) / 256, 256, 0, s>>>((const ShardCand*)all_cand, world, rank, q, out_word, out_dist, out_wslot, by_word ? 1 : 0);
     return hipGetLastError();
 }
 

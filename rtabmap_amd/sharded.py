@@ -214,45 +214,123 @@ def load_shard():
         load()                                                           # liblcd_hip.so first (the driver links against it)
         L = C.CDLL(_b.build_shard())
         vp = C.c_void_p
+        frame_args = [vp, vp, C.c_int, C.c_int, C.c_float, C.c_int32, C.c_int32, C.c_float, C.c_int64, vp, vp, C.c_int64]
         L.lcd_shard_unique_id.argtypes = [vp]
         L.lcd_shard_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+        L.lcd_shard_comm_create_transport.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
         L.lcd_shard_comm_destroy.argtypes = [vp]
         L.lcd_shard_comm_destroy.restype = None
         L.lcd_shard_last_error.argtypes = [vp]
         L.lcd_shard_last_error.restype = C.c_char_p
-        L.lcd_shard_frame.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, C.c_int32, C.c_int32, C.c_float, C.c_int64, vp, vp, C.c_int64]
+        L.lcd_shard_frame.argtypes = frame_args
+        L.lcd_shard_frame_deferred.argtypes = frame_args
+        L.lcd_shard_flush.argtypes = [vp]
+        L.lcd_shard_sig_remove.argtypes = [vp, C.c_int32]
+        L.lcd_shard_set_growth.argtypes = [vp, C.c_int32, C.c_int32]
+        L.lcd_shard_owner_of.argtypes = [vp, C.c_int32]
         _shard_lib = L
     return _shard_lib
 
 
-class NativeShardComm:
-    """One rank of the C++ / RCCL driver around an Engine.  The 128-byte RCCL id travels through torch.distributed (any backend) when
-    world > 1 -- the only thing the process group is used for; the two per-frame exchanges are RCCL calls made by the C++ code."""
+class HostStagedTransport:
+    """lcd_shard_transport over a torch.distributed process group of ANY backend, staged through the host (tests: two ranks sharing one
+    GPU cannot talk RCCL to each other).  The callbacks complete before they return: they wait for `stream`, copy device -> host with the
+    HIP runtime the process already has, exchange over the group, copy back."""
 
-    def __init__(self, eng, rank=0, world=1, group=None):
+    def __init__(self, group=None):
         import ctypes as C
-        self.L, self.eng, self.rank, self.world = load_shard(), eng, rank, world
-        idb = (C.c_ubyte * 128)()
-        if world > 1:
-            box = [None]
-            if rank == 0:
-                assert self.L.lcd_shard_unique_id(idb) == 0, "ncclGetUniqueId failed"
-                box[0] = bytes(idb)
-            dist.broadcast_object_list(box, src=0, group=group)
-            idb = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        self.C, self.group = C, group
+        self.world = dist.get_world_size(group)
+        self.hip = C.CDLL("libamdhip64.so")                            # the runtime torch loaded (same soname: the same library)
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+        REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+        class Transport(C.Structure):
+            _fields_ = [("struct_size", C.c_int32), ("reserved", C.c_int32), ("user", C.c_void_p), ("all_gather", GATHER), ("all_reduce_sum_i64", REDUCE)]
+        self._gather, self._reduce = GATHER(self._all_gather), REDUCE(self._all_reduce)      # (kept alive with the object)
+        self.struct = Transport(C.sizeof(Transport), 0, None, self._gather, self._reduce)
+        self.calls = {"all_gather": 0, "all_reduce": 0}
+
+    def _all_gather(self, user, d_send, d_recv, nbytes, stream):
+        try:
+            self.calls["all_gather"] += 1
+            if self.hip.hipStreamSynchronize(stream) != 0:
+                return 1
+            h = np.empty(nbytes, np.uint8)
+            if self.hip.hipMemcpy(h.ctypes.data, d_send, nbytes, 2) != 0:
+                return 2
+            parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+            dist.all_gather(parts, torch.from_numpy(h), group=self.group)
+            allb = torch.cat(parts).numpy()
+            return 0 if self.hip.hipMemcpy(d_recv, allb.ctypes.data, nbytes * self.world, 1) == 0 else 3
+        except Exception:                                                 # noqa: BLE001 -- no exception crosses the C boundary
+            return 9
+
+    def _all_reduce(self, user, d_buf, count, stream):
+        try:
+            self.calls["all_reduce"] += 1
+            if self.hip.hipStreamSynchronize(stream) != 0:
+                return 1
+            h = np.empty(count, np.int64)
+            if self.hip.hipMemcpy(h.ctypes.data, d_buf, count * 8, 2) != 0:
+                return 2
+            t = torch.from_numpy(h)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return 0 if self.hip.hipMemcpy(d_buf, h.ctypes.data, count * 8, 1) == 0 else 3
+        except Exception:                                                 # noqa: BLE001
+            return 9
+
+
+class NativeShardComm:
+    """One rank of the C++ driver around an Engine.  transport=None: RCCL -- the 128-byte RCCL id travels through torch.distributed (any
+    backend) when world > 1, the only thing the process group is used for; the two per-frame exchanges are RCCL calls made by the C++ code.
+    transport=HostStagedTransport(...): the caller's exchanges (lcd_shard_comm_create_transport)."""
+
+    def __init__(self, eng, rank=0, world=1, group=None, transport=None):
+        import ctypes as C
+        self.L, self.eng, self.rank, self.world, self.transport = load_shard(), eng, rank, world, transport
         h = C.c_void_p()
-        rc = self.L.lcd_shard_comm_create(eng.h, rank, world, idb, C.byref(h))
+        if transport is not None:
+            rc = self.L.lcd_shard_comm_create_transport(eng.h, rank, world, C.byref(transport.struct), C.byref(h))
+        else:
+            idb = (C.c_ubyte * 128)()
+            if world > 1:
+                box = [None]
+                if rank == 0:
+                    assert self.L.lcd_shard_unique_id(idb) == 0, "ncclGetUniqueId failed"
+                    box[0] = bytes(idb)
+                dist.broadcast_object_list(box, src=0, group=group)
+                idb = (C.c_ubyte * 128).from_buffer_copy(box[0])
+            rc = self.L.lcd_shard_comm_create(eng.h, rank, world, idb, C.byref(h))
         if rc != 0:
             raise RuntimeError("lcd_shard_comm_create failed (%d)" % rc)
         self.h = h
 
-    def frame(self, d_desc_ptr, q, sig_id, N, total_live_rows, d_word_ids_ptr, d_like_ptr, like_capacity, incremental=True,
-              new_words_compared=True, nndr=0.8, first_new_word_id=0):
-        flags = (1 if incremental else 0) | (2 if new_words_compared else 0)
-        rc = self.L.lcd_shard_frame(self.h, d_desc_ptr, q, flags, nndr, sig_id, first_new_word_id, float(N), int(total_live_rows), d_word_ids_ptr,
-                                    d_like_ptr, like_capacity)
+    def _ck(self, rc, what):
         if rc != 0:
-            raise RuntimeError("lcd_shard_frame: %s" % self.L.lcd_shard_last_error(self.h).decode())
+            raise RuntimeError("%s: %s" % (what, self.L.lcd_shard_last_error(self.h).decode()))
+
+    def frame(self, d_desc_ptr, q, sig_id, N, total_live_rows, d_word_ids_ptr, d_like_ptr, like_capacity, incremental=True,
+              new_words_compared=True, nndr=0.8, first_new_word_id=0, defer=False):
+        """defer=True: d_like_ptr is written by the NEXT frame call (or flush()): the all-reduce runs under that frame's search"""
+        flags = (1 if incremental else 0) | (2 if new_words_compared else 0)
+        fn = self.L.lcd_shard_frame_deferred if defer else self.L.lcd_shard_frame
+        self._ck(fn(self.h, d_desc_ptr, q, flags, nndr, sig_id, first_new_word_id, float(N), int(total_live_rows), d_word_ids_ptr, d_like_ptr,
+                    like_capacity), "lcd_shard_frame")
+
+    def flush(self):
+        self._ck(self.L.lcd_shard_flush(self.h), "lcd_shard_flush")
+
+    def sig_remove(self, sig_id):
+        self._ck(self.L.lcd_shard_sig_remove(self.h, sig_id), "lcd_shard_sig_remove")
+
+    def set_growth(self, first_incremental_id, block):
+        self._ck(self.L.lcd_shard_set_growth(self.h, first_incremental_id, block), "lcd_shard_set_growth")
+
+    def owner_of(self, word_id):
+        return int(self.L.lcd_shard_owner_of(self.h, word_id))
 
     def close(self):
         if getattr(self, "h", None):

@@ -273,3 +273,137 @@ def test_native_rccl_driver_one_rank_equals_the_single_gpu_frame(oracle):
     comm.close()
     for e in engs:
         e.close()
+
+
+def _native_worker(rank, world, port, out):
+    """Two ranks on ONE GPU through the NATIVE driver (liblcd_shard.so): its exchanges go through the lcd_shard_transport callbacks
+    (host-staged gloo -- two processes on one GPU cannot talk RCCL to each other); everything else is the C++ code a multi-GPU node runs."""
+    _init(rank, world, port)
+    torch.cuda.set_device(0)
+    import rtabmap_amd
+    from rtabmap_amd import synth
+    from rtabmap_amd.sharded import NativeShardComm, HostStagedTransport, shard_bounds
+    n_words, n_sig, q, T = 6000, 700, 160, 9
+    vocab = synth.vocab_surf(n_words)
+    ids = np.arange(1, n_words + 1, dtype=np.int32)
+    words = synth.zipf_words(n_sig, q, n_words, seed=3)
+    sig_ids = np.arange(1, n_sig + 1, dtype=np.int32)
+    offsets = np.arange(0, (n_sig + 1) * q, q, dtype=np.int64)
+    b = shard_bounds(n_words, world)
+    lo, hi = b[rank], b[rank + 1]
+    frames = [synth.frame_from_signature(vocab, words[37 * t + 5], seed=t) for t in range(T)]
+    frames += [np.ascontiguousarray(np.concatenate([frames[t][: q // 2], frames[(t + 1) % T][q // 2:]])) for t in range(T)]   # revisits: created words come back
+
+    def load(eng, sl):
+        eng.vocab_append(vocab[sl], ids[sl])
+        w = words.reshape(-1)
+        mine = np.where((w > sl.start) & (w <= sl.stop), w, -1).astype(np.int32)
+        eng.sig_add_bulk(sig_ids, offsets, mine, np.full(n_sig, q, np.int32))
+
+    def new_words_of(codes, desc, first_new):
+        n_new = int(-codes.min()) if (codes < 0).any() else 0
+        rows = np.stack([desc[int(np.flatnonzero(codes == -(k + 1))[0])] for k in range(n_new)]) if n_new else np.zeros((0, 64), np.float32)
+        return np.arange(first_new, first_new + n_new, dtype=np.int32), rows
+
+    results = {}
+    for mode in ("last_rank", "deferred", "block_cyclic"):
+        eng = rtabmap_amd.Engine("f32", 64, sig_capacity=n_sig + 64)
+        load(eng, slice(lo, hi))
+        tr = HostStagedTransport()
+        comm = NativeShardComm(eng, rank, world, transport=tr)
+        if mode == "block_cyclic":
+            comm.set_growth(n_words + 1, 16)
+        cap = n_sig + 64
+        d_w = torch.zeros(q, dtype=torch.int32, device="cuda")
+        d_l = [torch.zeros(cap, dtype=torch.float32, device="cuda") for _ in range(2)]
+        res, last_id, total_rows, my_rows = [], n_words, n_words, hi - lo
+        owed = None
+        for t, desc in enumerate(frames):
+            d = torch.from_numpy(desc).cuda()
+            comm.frame(d.data_ptr(), q, n_sig + 1 + t, float(n_sig + 1 + t), total_rows, d_w.data_ptr(), d_l[t & 1].data_ptr(), cap,
+                       first_new_word_id=last_id + 1, defer=(mode == "deferred"))
+            eng.synchronize()
+            codes = d_w.cpu().numpy().copy()
+            if mode == "deferred":
+                if owed is not None:                                 # the call above finalised the previous frame's likelihood
+                    res.append((owed[0], d_l[(t - 1) & 1][: owed[1]].cpu().numpy().copy()))
+                owed = (codes, n_sig + 1 + t)
+            else:
+                res.append((codes, d_l[t & 1][: n_sig + 1 + t].cpu().numpy().copy()))
+            if t == 3:
+                comm.sig_remove(3)                                   # queued behind the owed likelihood in deferred mode
+            # VWDictionary::update(): the frame's new words become rows of the rank that owns them
+            new_ids, new_rows = new_words_of(codes, desc, last_id + 1)
+            mine = np.array([comm.owner_of(int(w)) == rank for w in new_ids], bool)
+            if mine.any():
+                eng.vocab_append(new_rows[mine], new_ids[mine])
+                my_rows += int(mine.sum())
+            last_id += len(new_ids)
+            total_rows += len(new_ids)
+        if mode == "deferred":
+            comm.flush()
+            eng.synchronize()
+            res.append((owed[0], d_l[(len(frames) - 1) & 1][: owed[1]].cpu().numpy().copy()))
+        assert tr.calls["all_gather"] == len(frames) and tr.calls["all_reduce"] == len(frames)
+        rows_here, _ = eng.vocab_count()
+        assert rows_here == my_rows
+        counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([my_rows - (hi - lo)], dtype=torch.int64))
+        comm.close()
+        eng.close()
+        results[mode] = (res, [int(c.item()) for c in counts])
+    if rank == 0:
+        eng = rtabmap_amd.Engine("f32", 64, sig_capacity=n_sig + 64)
+        load(eng, slice(0, n_words))
+        cap = n_sig + 64
+        d_w = torch.zeros(q, dtype=torch.int32, device="cuda")
+        d_l = torch.zeros(cap, dtype=torch.float32, device="cuda")
+        ok, msgs, last_id, created = True, [], n_words, 0
+        for t, desc in enumerate(frames):
+            d = torch.from_numpy(desc).cuda()
+            eng.frame_dev(d.data_ptr(), q, n_sig + 1 + t, float(n_sig + 1 + t), d_w.data_ptr(), d_l.data_ptr(), cap, first_new_word_id=last_id + 1)
+            eng.synchronize()
+            codes, l1 = d_w.cpu().numpy().copy(), d_l[: n_sig + 1 + t].cpu().numpy().copy()
+            for mode, (res, _) in results.items():
+                if not np.array_equal(codes, res[t][0]):
+                    ok = False; msgs.append("%s: word ids differ in frame %d" % (mode, t))
+                if res[t][1].shape != l1.shape or not np.array_equal(l1.view(np.uint32), res[t][1].view(np.uint32)):
+                    ok = False; msgs.append("%s: likelihood not bit-identical in frame %d" % (mode, t))
+            if t == 3:
+                eng.sig_remove(3)
+            new_ids, new_rows = new_words_of(codes, desc, last_id + 1)
+            if len(new_ids):
+                eng.vocab_append(new_rows, new_ids)
+            last_id += len(new_ids)
+            created += len(new_ids)
+        eng.close()
+        grown = results["block_cyclic"][1]
+        if created < 200:
+            ok = False; msgs.append("the stream created only %d words" % created)
+        if results["last_rank"][1] != [0, created]:
+            ok = False; msgs.append("last-rank ownership: growth %r" % (results["last_rank"][1],))
+        if sum(grown) != created or abs(grown[0] - grown[1]) > 0.1 * created:
+            ok = False; msgs.append("block-cyclic growth is not balanced: %r of %d" % (grown, created))
+        out.put((ok, msgs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_native_driver_two_ranks_deferred_and_balanced_growth():
+    """liblcd_shard.so with TWO ranks (sharing the test box's one GPU; exchanges through the driver's transport callbacks): the in-order
+    frame, the frame whose all-reduce is left running under the next frame's search (lcd_shard_frame_deferred: retirements queue behind
+    the owed likelihood), and block-cyclic ownership of the words the stream creates (lcd_shard_set_growth: ties by word id) -- each bit
+    for bit the single-GPU engine's word ids and likelihood over a stream whose created words are indexed and matched again; with
+    block-cyclic ownership both ranks grow by the same number of rows (within 10 %), with the default all growth lands on the last rank."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_native_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, msgs = out.get(timeout=900)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ok, msgs
