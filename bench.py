@@ -528,6 +528,8 @@ def with_update_ms(torch, eng, stepper, steps=256, lag=8, rebuild_every=128):
     call of the loop that completes the pipeline).  Returns (ms per step, rows, live rows at the end)."""
     t0 = None
     for i in range(steps + 16):
+        if i == 12:
+            eng.vocab_rebuild()                          # (the first compaction allocates its second set of vocabulary buffers: not timed)
         if i == 16:
             eng.synchronize()
             torch.cuda.synchronize()
@@ -1225,7 +1227,7 @@ def main():
             config["with_update_ms_per_step"] = wu
             config["with_update_note"] = "the headline step + the rest of Memory::preUpdate EVERY frame, nothing completed in between: the signature " \
                                          "registered 8 frames earlier retired too, cleanUnusedWords as one enqueued kernel " \
-                                         "(lcd_vocab_remove_unused_async), lcd_vocab_rebuild every 128th frame (the only draining call; ~20 % of the rows are tombstones by then); 256 steps; " \
+                                         "(lcd_vocab_remove_unused_async), lcd_vocab_rebuild every 128th frame (the only draining call; ~20 %% of the rows are tombstones by then); 256 steps; " \
                                          "vocabulary at the end: %d rows, %d live" % (wrows, wlive)
             engw.close()
             engn = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 8192,

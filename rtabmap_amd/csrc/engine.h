@@ -98,6 +98,8 @@ struct lcd_engine {
     bool rm_pending = false;                            // a clean was enqueued since the last reconciliation
     int frames_since_reconcile = 0;                     // pipelined frames submitted with rm_pending set
     int enqueue_clean();                                // flush the pending retirements, launch the kernel (nothing is synchronised)
+    bool clean_armed = false;                           // a clean waits for the next fused launch pair, whose registration applies the
+                                                        // retirements asked for before it (they ride there: no launches of their own)
     int reconcile();
     int64_t rows_ub() const;
     // The rows the FILTER of chain frame `fseq` will most likely see (the count its launch reads is the one written a launch earlier: the

@@ -194,8 +194,10 @@ int ensure_append_capacity(lcd_engine* h, int64_t rows) {
     }
     const int64_t cap = vocab_cap_rows(h);
     const int64_t first = std::max(h->tail_filled_rows, keep);
-    if (first < cap && knn_mfma_supported(h->dtype, h->kdim)) {
-        LCD_HIP(h, launch_vocab_tail(h->row_norm.as<float>(), h->vocab_bf.p, first, cap - first, h->stream));
+    if (first < cap) {
+        if (knn_mfma_supported(h->dtype, h->kdim)) LCD_HIP(h, launch_vocab_tail(h->row_norm.as<float>(), h->vocab_bf.p, first, cap - first, h->stream));
+        // row id 0 behind the rows: a scan planned for an upper bound of the row count skips what does not exist yet like a tombstone
+        LCD_HIP(h, hipMemsetAsync(h->row_id.as<int32_t>() + first, 0, (size_t)(cap - first) * 4, h->stream));
         h->tail_filled_rows = cap;
     }
     return LCD_OK;
@@ -789,8 +791,11 @@ int lcd_selfdist(lcd_engine* h, const void* queries, int q, float* out_qxq) {
 // device part of addNewWords up to (not including) the decision loop: 2-NN, same-frame distances + candidate bits.
 // Fills the decision loop's arguments.
 static int prepare_resolve(lcd_engine* h, const void* d_desc, int q, int flags, float nndr, int32_t* d_out_word, int32_t* d_out_wslot,
-                           ResolveArgs* r, bool defer_redo = false /* the caller's next launch is the fused frame tail */) {
+                           ResolveArgs* r, bool defer_redo = false /* the caller's next launch is the fused frame tail */,
+                           int64_t rows_now = -1 /* rows to scan when the host's count lags the device's (an upper bound: the rows behind the
+                                                    device's count carry row id 0 and are skipped like tombstones) */) {
     r->rp = RowparArgs{};
+    if (rows_now < 0) rows_now = h->n_rows;
     const int have_index = h->n_live >= 2 ? 1 : 0;                  // VWDictionary.cpp:1015
     const bool incremental = (flags & LCD_Q_INCREMENTAL) != 0;
     const bool together = incremental && (flags & LCD_Q_NEW_WORDS_COMPARED);
@@ -803,7 +808,7 @@ static int prepare_resolve(lcd_engine* h, const void* d_desc, int q, int flags, 
     // With the MFMA filter the same-frame distance matrix does not wait for the 2-NN: extra workgroups of the filter launch
     // compute it, and the re-rank workgroup of a query -- the first to know the query's second neighbour -- derives the query's
     // candidate bits from its (symmetric) row: two launches fewer per frame.
-    const int64_t knn_rows = have_index ? h->n_rows : 0;
+    const int64_t knn_rows = have_index ? rows_now : 0;
     const bool side = together && h->knn_mode != 0 && knn_mfma_supported(h->dtype, h->kdim) && knn_rows >= 256 && q > 0;
     int rc;
     if (side) {
@@ -1179,7 +1184,7 @@ static int finish_frame_ops(lcd_engine* h, lcd_engine::InFlight& f) {
         LCD_HIP(h, e);
     }
     f.links_after.clear();
-    if (f.cleans_after > 0) { f.cleans_after = 0; int rc = h->enqueue_clean(); if (rc) return rc; }
+    if (f.cleans_after > 0) { f.cleans_after = 0; h->clean_armed = true; }   // runs behind the next launch pair (pipeline_launch) or the drain
     for (void* ev : f.events_after) LCD_HIP(h, hipEventRecord((hipEvent_t)ev, h->stream));
     f.events_after.clear();
     return LCD_OK;
@@ -1200,6 +1205,7 @@ int lcd_engine::drain() {
             (void)finish_frame_ops(this, f);
         }
     }
+    if (clean_armed) { clean_armed = false; const int rc = enqueue_clean(); if (rc && !rc_all) rc_all = rc; }
     const int rc3 = reconcile();                                     // rows appended on the device: the host mirror catches up
     return rc_all ? rc_all : rc3;
 }
@@ -1316,6 +1322,12 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
     LCD_HIP(h, launch_frame_b(f_knn ? &k : nullptr, reg_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
                               prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr));
     if (prof2) { h->prof2_n += 1; h->prof2_kernel = "frame_b_kernel (re-rank of frame t-1 + scoring of frame t-3)"; }
+    if (h->clean_armed && f_reg) {
+        // cleanUnusedWords asked for behind an earlier frame: the retirements made in front of it rode with the registration of this
+        // launch A, the reference counts are what Memory::preUpdate would see -- one kernel, between this launch B and the next launch A
+        h->clean_armed = false;
+        int rc = h->enqueue_clean(); if (rc) return rc;               // (flushes what more than four retirements per frame left over)
+    }
     if (f_res) f_res->stage = 2;
     if (f_knn) f_knn->stage = 1;
     if (f_reg) {                                                     // that frame is complete: its decision stage and the calls queued behind it
@@ -1415,16 +1427,34 @@ int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     if ((a->d_posterior || a->d_bayes) && !h->bayes.configured) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: lcd_bayes_configure first");
     if (h->pipeline && q <= 4096 && h->knn_mode == 2 && knn_mfma_supported(h->dtype, h->kdim) && h->n_live >= 2 && h->n_rows >= 256)
         return frame_pipelined(h, a);
-    { int rc = h->drain(); if (rc) return rc; }                    // (also brings the host's row mirror up to date)
-    LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
     const bool app = frame_appends(h, *a);
+    // A stream of appending frames on a plain handle with the exact scan (ORB: config 3) does not wait for the device between frames:
+    // the host's row mirror lags (as on a pipelined handle), the scan is planned for an upper bound of the row count.  Anything else
+    // completes what is owed and brings the mirror up to date first.
+    const bool lazy = app && h->inflight.empty() && h->vcnt_active && h->n_live >= 2 && !(h->knn_mode != 0 && knn_mfma_supported(h->dtype, h->kdim)) &&
+                      h->unreconciled.size() < (size_t)lcd_engine::VLOG / 2 && !(h->rm_pending && h->frames_since_reconcile >= 512);
+    if (!lazy) { int rc = h->drain(); if (rc) return rc; }         // (also brings the host's row mirror up to date)
+    else {
+        if (h->rm_pending) h->frames_since_reconcile += 1;
+        if (h->h_vmirror && h->unreconciled.size() > 8) {           // the bound grows by q per unreported frame: stay within 8 frames of the device
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int spins = 0;; ++spins) {
+                const uint32_t tag = (uint32_t)(*(volatile const unsigned long long*)h->h_vmirror >> 32);
+                if ((uint32_t)h->vseq - tag <= 8u) break;
+                if (spins > 4096) std::this_thread::yield();
+                if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { LCD_HIP(h, hipStreamSynchronize(h->stream)); break; }
+            }
+        }
+    }
+    LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
     if (app) {
         { int rc = activate_dev_rows(h); if (rc) return rc; }
-        { int rc = ensure_append_capacity(h, h->n_rows + 2 * (int64_t)q); if (rc) return rc; }
+        { int rc = ensure_append_capacity(h, h->rows_ub() + 2 * (int64_t)q); if (rc) return rc; }
     }
     // 2-NN + same-frame distances, then ONE single-workgroup launch: decision loop -> pending retirements -> registration / idf
     ResolveArgs r;
-    int rc = prepare_resolve(h, a->d_descriptors, q, a->flags, a->nndr_ratio, a->d_word_ids, h->d_out_wslot.as<int32_t>(), &r, true);
+    int rc = prepare_resolve(h, a->d_descriptors, q, a->flags, a->nndr_ratio, a->d_word_ids, h->d_out_wslot.as<int32_t>(), &r, true,
+                             lazy ? h->rows_ub() : -1);
     if (rc) return rc;
     if (h->d_fail_count.p) { r.fail_count = h->d_fail_count.as<int32_t>(); h->fail_count_clean = true; }   // the tail resets the counters
     const uint64_t vseq = h->vseq;

@@ -192,7 +192,8 @@ __device__ __forceinline__ void retire_body(const RetireArgs& r, const uint32_t*
 // produce |row|^2 (any order will do: the filter needs it to ~dim ulps) and the hi / lo bf16 split the matrix-core filter multiplies.
 template <int NT>
 __device__ __forceinline__ void append_new_rows(const AppendArgs& ap, int q, const uint32_t* mask, const uint32_t* prefix, const WsRuns& new_ws,
-                                                uint32_t* list /* LDS scratch, q words */) {
+                                                uint32_t* list /* LDS scratch, q words */,
+                                                float* stage = nullptr, int stage_rows = 0 /* LDS staging area for the new rows (256 B each) */) {
     const int n_in = ap.cnt_in[0];
     const int mw = (q + 63) / 64 * 2;
     const int n_new = (int)prefix[mw];
@@ -202,46 +203,76 @@ __device__ __forceinline__ void append_new_rows(const AppendArgs& ap, int q, con
     for (int i = tid; i < q; i += NT)
         if ((mask[i >> 5] >> (i & 31)) & 1u) list[new_rank(mask, prefix, i)] = (uint32_t)i;
     __syncthreads();
-    constexpr int G = NT / 16, UN = 4;                                  // 16-lane groups; rows per group and trip (their loads are in flight together)
-    for (int k0 = tid >> 4; k0 < n_take; k0 += G * UN) {
-        uint4 x[UN];
+    auto finish_row = [&](int k, const uint4& x) {                      // lane c of the row's 16-lane group holds floats [4c, 4c + 4)
+        const size_t row = (size_t)n_in + (size_t)k;
+        reinterpret_cast<uint4*>(ap.vocab + row * ap.row_dwords)[c] = x;
+        const float f0 = __uint_as_float(x.x), f1 = __uint_as_float(x.y), f2 = __uint_as_float(x.z), f3 = __uint_as_float(x.w);
+        float s2 = fmaf(f3, f3, fmaf(f2, f2, fmaf(f1, f1, f0 * f0)));
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int k = k0 + u * G;
-            x[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (k < n_take && ap.is_f32_64) x[u] = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(ap.descriptors) + (size_t)list[k] * ap.row_dwords)[c];
+        for (int m = 8; m >= 1; m >>= 1) s2 += __shfl_xor(s2, m, 64);
+        uint2 hi, lo;                                                   // as vocab_bf16_kernel: 64 bf16 "hi" then 64 bf16 "lo" per row
+        bf16_split2_dev(f0, f1, hi.x, lo.x);
+        bf16_split2_dev(f2, f3, hi.y, lo.y);
+        reinterpret_cast<uint2*>(ap.vocab_bf + row * 64)[c] = hi;
+        reinterpret_cast<uint2*>(ap.vocab_bf + row * 64 + 32)[c] = lo;
+        if (c == 0) {
+            ap.row_norm[2 * row] = s2; ap.row_norm[2 * row + 1] = 1.0f;
+            atomicMax(ap.norm_max_bits, __float_as_uint(s2));
         }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int k = k0 + u * G;
-            if (k >= n_take) continue;                                  // uniform over the 16 lanes of the row
-            const size_t row = (size_t)n_in + (size_t)k;
-            uint32_t* dst = ap.vocab + row * ap.row_dwords;
-            if (ap.is_f32_64) {
-                reinterpret_cast<uint4*>(dst)[c] = x[u];
-                const float f0 = __uint_as_float(x[u].x), f1 = __uint_as_float(x[u].y), f2 = __uint_as_float(x[u].z), f3 = __uint_as_float(x[u].w);
-                float s2 = fmaf(f3, f3, fmaf(f2, f2, fmaf(f1, f1, f0 * f0)));
-#pragma unroll
-                for (int m = 8; m >= 1; m >>= 1) s2 += __shfl_xor(s2, m, 64);
-                uint2 hi, lo;                                           // as vocab_bf16_kernel: 64 bf16 "hi" then 64 bf16 "lo" per row
-                bf16_split2_dev(f0, f1, hi.x, lo.x);
-                bf16_split2_dev(f2, f3, hi.y, lo.y);
-                reinterpret_cast<uint2*>(ap.vocab_bf + row * 64)[c] = hi;
-                reinterpret_cast<uint2*>(ap.vocab_bf + row * 64 + 32)[c] = lo;
-                if (c == 0) {
-                    ap.row_norm[2 * row] = s2; ap.row_norm[2 * row + 1] = 1.0f;
-                    atomicMax(ap.norm_max_bits, __float_as_uint(s2));
-                }
-            } else {
-                const uint32_t* src = reinterpret_cast<const uint32_t*>(ap.descriptors) + (size_t)list[k] * ap.row_dwords;
-                for (int d = c; d < ap.row_dwords; d += 16) dst[d] = src[d];
+    };
+    auto finish_ids = [&](int k) {
+        const size_t row = (size_t)n_in + (size_t)k;
+        const int32_t key = new_ws.n > 0 ? ws_runs_at(new_ws, k) : -1;
+        ap.row_id[row] = ap.first_id + k;
+        ap.row_wslot[row] = key;
+        if (key >= 0 && ap.wrow) ap.wrow[key] = (uint32_t)row + 1u;     // the key now belongs to a row: the batched check of
+    };                                                                  // superseded reservations must not hand it out again
+    constexpr int G = NT / 16;                                          // 16-lane groups
+    if (ap.is_f32_64 && stage && stage_rows >= 4) {
+        // Loads and stores share one in-order counter on this architecture: a loop that loads a few rows, writes them out and loads the
+        // next ones waits for the WRITES of every trip before it sees the next loads (measured: 13 us for 150 rows, in the decision
+        // loop's chain).  So all the rows come in first -- LDS-DMA, no registers, one round trip for a whole chunk -- and the writes
+        // follow without anything ever waiting for them.
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int k0 = 0; k0 < n_take; k0 += stage_rows) {
+            const int n_chunk = min(stage_rows, n_take - k0);
+            for (int i = wave; i * 4 < n_chunk; i += NT / 64) {         // one instruction = four rows = 1 KB of LDS
+                const int k = k0 + min(i * 4 + (lane >> 4), n_chunk - 1);
+                const float* src = ap.descriptors + (size_t)list[k] * 64 + (lane & 15) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(stage + (size_t)i * 256), 16, 0, 0);
             }
-            if (c == 0) {
-                const int32_t key = new_ws.n > 0 ? ws_runs_at(new_ws, k) : -1;
-                ap.row_id[row] = ap.first_id + k;
-                ap.row_wslot[row] = key;
-                if (key >= 0 && ap.wrow) ap.wrow[key] = (uint32_t)row + 1u;     // the key now belongs to a row: the batched check of
-            }                                                                   // superseded reservations must not hand it out again
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int k = tid >> 4; k < n_chunk; k += G) {
+                const uint4 x = *reinterpret_cast<const uint4*>(stage + (size_t)k * 64 + c * 4);
+                finish_row(k0 + k, x);
+                if (c == 0) finish_ids(k0 + k);
+            }
+            if (k0 + stage_rows < n_take) __syncthreads();              // the staging area is reused
+        }
+    } else {
+        constexpr int UN = 4;                                           // rows per group and trip (their loads are in flight together)
+        for (int k0 = tid >> 4; k0 < n_take; k0 += G * UN) {
+            uint4 x[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int k = k0 + u * G;
+                x[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (k < n_take && ap.is_f32_64) x[u] = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(ap.descriptors) + (size_t)list[k] * ap.row_dwords)[c];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int k = k0 + u * G;
+                if (k >= n_take) continue;                              // uniform over the 16 lanes of the row
+                if (ap.is_f32_64) finish_row(k, x[u]);
+                else {
+                    uint32_t* dst = ap.vocab + ((size_t)n_in + (size_t)k) * ap.row_dwords;
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(ap.descriptors) + (size_t)list[k] * ap.row_dwords;
+                    for (int d = c; d < ap.row_dwords; d += 16) dst[d] = src[d];
+                }
+                if (c == 0) finish_ids(k);
+            }
         }
     }
     if (tid == 0) {
@@ -334,8 +365,13 @@ __device__ __forceinline__ void frame_resolve_part(uint32_t* ft_dyn_smem, const 
     else fmask = resolve_body<NT>(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
                                   r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
     if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; r.fail_count[3] = 0; }
-    if (r.ap.enabled) append_new_rows<NT>(r.ap, r.q, fmask, ft_dyn_smem + 2 * ((r.q + 63) / 64 * 2), r.new_ws, ft_dyn_smem + 3 * ((r.q + 63) / 64 * 2) + 4);
-    else append_pass_on(r.ap);
+    if (r.ap.enabled) {
+        // the staging area of the new rows lies behind the appender's list, 16-byte aligned; its size comes from the launch (ap.lds_bytes)
+        const int used = (3 * ((r.q + 63) / 64 * 2) + 4 + r.q + 3) & ~3;
+        const int rows = (r.ap.lds_bytes / 4 - used) / 64;
+        append_new_rows<NT>(r.ap, r.q, fmask, ft_dyn_smem + 2 * ((r.q + 63) / 64 * 2), r.new_ws, ft_dyn_smem + 3 * ((r.q + 63) / 64 * 2) + 4,
+                            reinterpret_cast<float*>(ft_dyn_smem + used), rows > 0 ? (rows & ~3) : 0);
+    } else append_pass_on(r.ap);
     FT_STAMP(1);
 }
 template <int NT>

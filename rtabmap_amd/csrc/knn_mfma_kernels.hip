@@ -446,8 +446,8 @@ __device__ __forceinline__ void bf_pair(const uint4 (&ah)[4], const uint4 (&al)[
     for (int st = 0; st < 12; ++st) {
         const int s = st / 3, term = st % 3;                        // (hi, hi), (hi, lo), (lo, hi)
         const uint4& a = term == 2 ? al[s] : ah[s];
-#if LCD_MFMA_ABLATE != 3
-        c0 = bf_mfma(a, term == 1 ? bl0[s] : bh0[s], c0);
+#if LCD_MFMA_ABLATE != 3      // 4 / 5: only the (hi, hi) / the (hi, hi) + (hi, lo) products -- the MFMA count of a one- / two-product filter (timing only)
+        if (LCD_MFMA_ABLATE < 4 || term == 0 || (LCD_MFMA_ABLATE == 5 && term == 1)) c0 = bf_mfma(a, term == 1 ? bl0[s] : bh0[s], c0);
 #endif
         if (PUSH && LCD_MFMA_ABLATE == 1) asm volatile("" :: "v"(p0[st]), "v"(p1[st]));   // keep the ablated chains alive
         if (PUSH && LCD_MFMA_ABLATE != 1) {                         // one MFMA, then the VALU that fits in its 32-cycle shadow
@@ -457,7 +457,7 @@ __device__ __forceinline__ void bf_pair(const uint4 (&ah)[4], const uint4 (&al)[
             __builtin_amdgcn_sched_barrier(0);
         }
 #if LCD_MFMA_ABLATE != 3
-        c1 = bf_mfma(a, term == 1 ? bl1[s] : bh1[s], c1);
+        if (LCD_MFMA_ABLATE < 4 || term == 0 || (LCD_MFMA_ABLATE == 5 && term == 1)) c1 = bf_mfma(a, term == 1 ? bl1[s] : bh1[s], c1);
 #endif
         if (PUSH && LCD_MFMA_ABLATE != 1) {
             __builtin_amdgcn_sched_barrier(0);
@@ -1189,7 +1189,9 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                                                      float* __restrict__ out_dist, int32_t* __restrict__ fail_list,
                                                      int32_t* __restrict__ fail_count, const CandBits& cb,
                                                      const int32_t* __restrict__ pend_lo = nullptr, const int32_t* __restrict__ pend_hi = nullptr,
-                                                     int pend_cap = 0x7fffffff /* rows the filter's launch plan covered */) {
+                                                     int pend_cap = 0x7fffffff /* rows the filter's launch plan covered */,
+                                                     float* stage = nullptr, int stage_rows = 0 /* LDS staging area of the pending rows (256 B each,
+                                                     a multiple of 4), shared by the halves of the workgroup */) {
     static_assert(DIM == 64, "16 lanes x 4 floats per candidate row");
     // rows [pend_lo[0], pend_hi[0]): words the previous frame created, appended on the device after this frame's filter took its
     // snapshot of the vocabulary (VWDictionary::update() of a pipelined handle).  They are scanned exactly here, so the result is
@@ -1198,6 +1200,19 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     const int p_lo = pend_lo ? min(pend_lo[0], pend_cap) : 0, p_hi = pend_hi ? pend_hi[0] : 0;
     const int hf = HALVES == 2 ? (int)threadIdx.x / MF_BLOCK : 0;
     const int tid = HALVES == 2 ? (int)threadIdx.x % MF_BLOCK : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The pending rows are the same for every query: with a staging area they come in by LDS-DMA -- no registers, requested HERE, a
+    // whole chunk in one round trip that runs under the two passes below -- instead of four rows per 16-lane group and trip
+    // (three dependent round trips for the ~150 words a frame creates: +7 us on launch B, measured).
+    auto stage_chunk = [&](int first, int n_chunk) {
+        const int wv = (int)threadIdx.x >> 6, ln = (int)threadIdx.x & 63;
+        for (int i = wv; i * 4 < n_chunk; i += HALVES * MF_WAVES) {      // one instruction = four rows = 1 KB of LDS
+            const int row = first + min(i * 4 + (ln >> 4), n_chunk - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vocab + (size_t)row * DIM + (ln & 15) * 4),
+                                             (__attribute__((address_space(3))) void*)(stage + (size_t)i * 256), 16, 0, 0);
+        }
+    };
+    const bool staged = stage != nullptr && stage_rows >= 4 && p_hi > p_lo;
+    if (staged) stage_chunk(p_lo, min(stage_rows, p_hi - p_lo));
     const bool valid = qi_first + hf < nq;                             // the odd query out: its half walks the last query again, writes nothing
     const int qi = valid ? qi_first + hf : nq - 1;
     __shared__ float s_thr_all[HALVES];
@@ -1320,6 +1335,26 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         uint64_t pb = KEY_NONE, ps = KEY_NONE;
         constexpr int PU = 4;                                          // rows per 16-lane group and trip: their loads are in flight together (more
                                                                        // would cost the whole launch -- the scoring workgroups too -- occupancy)
+        if (staged) {
+            for (int c0 = p_lo; c0 < p_hi; c0 += stage_rows) {
+                const int n_chunk = min(stage_rows, p_hi - c0);
+                if (c0 > p_lo) { __syncthreads(); stage_chunk(c0, n_chunk); }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                for (int r = tid >> 4; r < n_chunk; r += MF_BLOCK / 16) {
+                    const float4 v = *reinterpret_cast<const float4*>(stage + (size_t)r * DIM + (lane & 15) * 4);
+                    const float d0 = __fsub_rn(v.x, q4.x), d1 = __fsub_rn(v.y, q4.y), d2 = __fsub_rn(v.z, q4.z), d3 = __fsub_rn(v.w, q4.w);
+                    float t = __fmul_rn(d0, d0);
+                    t = __fadd_rn(t, __fmul_rn(d1, d1));
+                    t = __fadd_rn(t, __fmul_rn(d2, d2));
+                    t = __fadd_rn(t, __fmul_rn(d3, d3));
+                    float res = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) res = __fadd_rn(res, __shfl(t, (lane & 48) + j, 64));
+                    if ((lane & 15) == 0) top2_push(pb, ps, ((uint64_t)__float_as_uint(res) << 32) | (uint32_t)(c0 + r));
+                }
+            }
+        } else
         for (int base = p_lo; base < p_hi; base += PU * (MF_BLOCK / 16)) {
             float4 v4[PU];
 #pragma unroll
@@ -1466,6 +1501,7 @@ struct RerankArgs {
     const uint64_t* pk; const uint32_t* pl; int n_blocks, nq; const float* vocab; const float* queries; const int32_t* row_id;
     const uint32_t* norm_max_bits; int32_t* out_row; int32_t* out_word; float* out_dist; int32_t* fail_list; int32_t* fail_count; CandBits cb;
     const int32_t* n_lo; const int32_t* n_hi; int plan_rows;
+    int stage_rows;                                                    // rows the launch's dynamic LDS stages (0: none)
 };
 constexpr int PIPE_BLOCK = 256;     // workgroup size of both fused launches (the filter's and the re-rank's)
 
@@ -1516,6 +1552,7 @@ __device__ unsigned long long g_b_timing[2 * 4096];
 #define B_STAMP(i) do { } while (0)
 #endif
 constexpr int PIPE_B_BLOCK = 512;   // workgroup size of launch B: eight waves per sealed bucket, two queries per re-rank workgroup
+constexpr uint32_t PIPE_B_STAGE_ROWS = 160;   // pending rows a re-rank workgroup stages in LDS at a time
 static_assert(PIPE_B_BLOCK == 2 * MF_BLOCK, "the re-rank halves");
 __global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, int n_rerank_wgs, ScoreArgs A) {
     const int bid = (int)blockIdx.x;
@@ -1524,8 +1561,10 @@ __global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, 
         // consecutive query pairs on one XCD: eight queries share a 128-byte line of the block-major candidate records
         const int pair = (bid & 7) * (n_rerank_wgs >> 3) + (bid >> 3);
         if (2 * pair >= k.nq) return;
+        extern __shared__ __attribute__((aligned(16))) float s_dyn_b[];
         knn_mfma_rerank_body<64, BF_KEEP, false, true, 2>(2 * pair, k.pk, k.pl, k.n_blocks, k.nq, k.vocab, k.queries, k.row_id, k.norm_max_bits, k.out_row,
-                                                          k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb, k.n_lo, k.n_hi, k.plan_rows);
+                                                          k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb, k.n_lo, k.n_hi, k.plan_rows,
+                                                          s_dyn_b, k.stage_rows);
         B_STAMP(1);
         return;
     }
@@ -1845,7 +1884,7 @@ hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLa
     const size_t lds = px > 0 ? BF_LDS_BYTES_P : BF_LDS_BYTES_Q;
     if ((resolve && resolve->shmem_resolve > lds) || (reg && reg->shmem > lds)) return hipErrorInvalidValue;
     ResolveArgs r{}; FwArgs a{}; RetireArgs ret{};
-    if (resolve) r = resolve->r;
+    if (resolve) { r = resolve->r; r.ap.lds_bytes = (int)lds; }        // what the decision loop's tables leave of it stages the frame's new rows
     if (reg) { a = reg->a; ret = reg->ret; }
     // ev_begin / ev_end: the launch's own start and end time stamps (hipExtLaunchKernel attaches the two events to the dispatch; a pair
     // of hipEventRecord around it costs the stream ~10 us of barrier packets -- and measures the gap in front of the kernel with it)
@@ -1878,9 +1917,13 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
     ScoreArgs A{};
     if (score) A = *score; else score_wgs = 0;
     if (n_rerank + score_wgs == 0) return hipSuccess;
+    // frames that append their words on the device: 40 KB of dynamic LDS stage 160 pending rows per re-rank workgroup (three workgroups
+    // of launch B share a compute unit: 3 x (40 + 8) KB of its 160 KB)
+    const uint32_t dyn = (k && k->n_hi) ? PIPE_B_STAGE_ROWS * 256u : 0u;
+    rk.stage_rows = dyn ? (int)PIPE_B_STAGE_ROWS : 0;
     if (ev_begin != nullptr && ev_end != nullptr)
-        hipExtLaunchKernelGGL(frame_b_kernel, dim3(n_rerank + score_wgs), dim3(PIPE_B_BLOCK), 0u, s, ev_begin, ev_end, 0u, rk, n_rerank, A);
-    else frame_b_kernel<<<n_rerank + score_wgs, PIPE_B_BLOCK, 0, s>>>(rk, n_rerank, A);
+        hipExtLaunchKernelGGL(frame_b_kernel, dim3(n_rerank + score_wgs), dim3(PIPE_B_BLOCK), dyn, s, ev_begin, ev_end, 0u, rk, n_rerank, A);
+    else frame_b_kernel<<<n_rerank + score_wgs, PIPE_B_BLOCK, dyn, s>>>(rk, n_rerank, A);
     return hipGetLastError();
 }
 

@@ -114,6 +114,8 @@ struct AppendArgs {
     int32_t* log_slot = nullptr;               // receives the number of rows appended (host reconciliation)
     int32_t first_id = 0;
     long long capacity = 0;                    // rows the buffers hold: appends beyond are dropped (cannot happen: the host reserves q per frame)
+    int lds_bytes = 0;                         // dynamic LDS of the workgroup that appends (launch A of a pipelined frame): what the decision loop's
+                                               // own tables leave of it stages the new rows (0: no staging)
     unsigned long long* host_mirror = nullptr; // pinned: (tag << 32 | rows) after this append, read by the host WITHOUT synchronising to
     uint32_t tag = 0;                          // bound the row count it plans the next launches for
 };

@@ -29,12 +29,17 @@ def main():
     cap = n_sig + 4096
     d_like = torch.zeros(cap, dtype=torch.float32, device="cuda")
     lib = capi.load()
-    frames = [torch.from_numpy(synth.frame_from_signature(vocab, words[i * 11], seed=i)).cuda() for i in range(8)]
+    # N_FRAMES distinct frames (8: after the first pass every frame is a revisit that creates no word; 128 with APPEND=1: every frame of
+    # the run creates ~150 words, the growth phase of an incremental dictionary)
+    n_distinct = int(os.environ.get("N_FRAMES", "8"))
+    frames = [torch.from_numpy(synth.frame_from_signature(vocab, words[i * 11], seed=i)).cuda() for i in range(n_distinct)]
     res = []
+    gi = 0
     for rep in range(6):
         n = 10 + rep
         for i in range(n):
-            eng.frame_dev(frames[i % 8].data_ptr(), q, n_sig + 1000 * rep + 1 + i, float(n_sig + 1), d_words.data_ptr(), d_like.data_ptr(), cap,
+            gi += 1
+            eng.frame_dev(frames[(gi if n_distinct > 8 else i) % n_distinct].data_ptr(), q, n_sig + 1000 * rep + 1 + i, float(n_sig + 1), d_words.data_ptr(), d_like.data_ptr(), cap,
                           incremental=True, new_words_compared=True, nndr=0.8, first_new_word_id=n_words + 1 + (100 * rep + i) * q,
                           append_new_words=bool(os.environ.get("APPEND")))
             eng.sig_remove(1 + 20 * rep + i)
