@@ -1016,6 +1016,8 @@ def main():
                          "the other one is measured in the same run as a secondary key")
     ap.add_argument("--config", choices=["headline", "orb_stream", "replay"], default="headline")
     ap.add_argument("--score-block", type=int, default=0, help="experiment: threads per workgroup of the scoring kernel (256/512/1024)")
+    ap.add_argument("--knn-mode", default=None, choices=["bf16", "f16", "mfma32", "valu"],
+                    help="the 2-NN filter of the timed engine (default: bf16x3; f16 = the one-product fp16 filter, LCD_KNN_F16)")
     ap.add_argument("--diag", default="", help="diagnostics only (not the benchmark): comma list of no-new (new words get no references), "
                     "no-retire (the oldest signature is not retired)")
     args = ap.parse_args()
@@ -1106,7 +1108,7 @@ def main():
         src, frames_np = make_frames(rank)                 # replicas: every rank has its own stream of frames
         d_frames = [torch.from_numpy(f).cuda() for f in frames_np]
         eng = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 65536, sig_capacity=n_sig + 8192,
-                                 stream=stream.cuda_stream, pipeline=args.pipeline)
+                                 stream=stream.cuda_stream, pipeline=args.pipeline, knn_mode=args.knn_mode)
         if args.score_block:
             eng.set_option("score_block", args.score_block)
         for kv in filter(None, os.environ.get("LCD_BENCH_OPTS", "").split(",")):      # timing experiments: key=value engine options
@@ -1141,6 +1143,7 @@ def main():
               "step_ms_median": float(np.median(res["per_step_ms"])) if res["per_step_ms"].size else None,
               "step_ms_p95": float(np.percentile(res["per_step_ms"], 95)) if res["per_step_ms"].size else None,
               "world_size_observed": world, "collective_backend": backend, "signatures_bulk_load_s": build_s,
+              "knn_filter": args.knn_mode or "bf16 (three products per fp32 product)",
               "pipeline": "software-pipelined frames, four in flight: 2 launches per frame (A: query pre-split of frame t + filter of t-1 + decision loop "
                           "of t-2 + registration of t-3; B: re-rank of frame t-1 + scoring of t-3), one stream; the step includes VWDictionary::update()'s append branch on the device (append_new_words): the vocabulary "
                           "grows by the frame's new words before the next frame is searched" if (args.pipeline and not shard) else "4 launches per frame, one stream",

@@ -59,7 +59,12 @@ enum lcd_knn_mode {
     LCD_KNN_DEFAULT = 0,       /* = LCD_KNN_BF16X3 where it applies */
     LCD_KNN_EXACT_VALU = 1,    /* exact vector-ALU scan only */
     LCD_KNN_F32_MFMA = 2,      /* fp32 matrix-core filter (v_mfma_f32_32x32x2_f32) + exact re-rank */
-    LCD_KNN_BF16X3 = 3         /* bf16 matrix-core filter, three bf16 products per fp32 product + exact re-rank */
+    LCD_KNN_BF16X3 = 3,        /* bf16 matrix-core filter, three bf16 products per fp32 product + exact re-rank */
+    LCD_KNN_F16 = 4            /* fp16 matrix-core filter, ONE product per fp32 product (operands rounded to IEEE half: a third of the
+                                  matrix work, an error bound of ~2^-10 (|q|^2 + |v|^2) instead of ~2^-14) + exact re-rank.  Made for
+                                  unit-scale descriptors (SURF/SIFT are L2-normalised); queries whose certificate the wider bound
+                                  cannot give -- and descriptors beyond half's range -- go to the exact scan, so the results stay the
+                                  same bits; a vocabulary of near-duplicate words makes that the common case and this mode the slower one */
 };
 
 typedef struct lcd_config {

@@ -27,8 +27,8 @@ SYMBOLS = [
 ]
 
 
-LCD_KNN_DEFAULT, LCD_KNN_EXACT_VALU, LCD_KNN_F32_MFMA, LCD_KNN_BF16X3 = 0, 1, 2, 3
-KNN_MODES = {None: 0, "default": 0, "valu": 1, "exact": 1, "mfma32": 2, "f32": 2, "bf16": 3, "bf16x3": 3}
+LCD_KNN_DEFAULT, LCD_KNN_EXACT_VALU, LCD_KNN_F32_MFMA, LCD_KNN_BF16X3, LCD_KNN_F16 = 0, 1, 2, 3, 4
+KNN_MODES = {None: 0, "default": 0, "valu": 1, "exact": 1, "mfma32": 2, "f32": 2, "bf16": 3, "bf16x3": 3, "f16": 4, "fp16": 4}
 
 
 class LcdConfig(C.Structure):

@@ -45,7 +45,9 @@ struct lcd_engine {
     lcd::DevBuf d_queries, d_partial, d_knn_row, d_knn_word, d_knn_wslot, d_knn_dist, d_selfdist, d_out_word, d_out_wslot,
         d_n_new, d_tmp_i32, d_extra_rows, d_extra_id, d_extra_word, d_extra_dist, d_extra_row, d_like, d_slots, d_bits, row_norm, norm_max, d_partial2, d_partial3, d_fail_list, d_fail_count;
     bool fail_count_clean = false;                      // d_fail_count[0..1] known to be zero (the fused frame tail resets them)
-    int knn_mode = 2;                                   // f32 dim 64: 2 = bf16x3 MFMA filter + exact re-rank (default), 1 = f32 MFMA filter
+    bool bf_family() const { return knn_mode == 2 || knn_mode == 3; }   // the bf16x3 / fp16 filters share kernels, tables and the pipelined frame
+    int f16() const { return knn_mode == 3 ? 1 : 0; }
+    int knn_mode = 2;                                   // f32 dim 64: 2 = bf16x3 MFMA filter + exact re-rank (default), 3 = fp16 one-product filter, 1 = f32 MFMA filter
                                                         // + exact re-rank, 0 = exact VALU scan only (lcd_config.knn_mode)
     // ---- pipelined frames (lcd_config.pipeline): three frames are in flight.  The call for frame t launches
     //        A = filter of frame t  +  decision loop of frame t - 1  +  retirement / registration of frame t - 2

@@ -106,9 +106,10 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
     if (q == 0) return LCD_OK;
     const bool mfma = main_vocab && h->knn_mode != 0 && knn_mfma_supported(h->dtype, h->kdim) && n_rows >= 256;
     const KnnPlan p = knn_plan(q, (int)n_rows, h->row_bytes);
-    if (mfma && h->knn_mode == 2) {
+    if (mfma && h->bf_family()) {
         MfmaPlan mp = knn_bf16_plan(q, (int)n_rows, cb != nullptr ? knn_selfdist_wgs(q) : 0);
         mp.filter_units = h->filter_units;
+        mp.f16 = h->f16();
         LCD_HIP(h, dreserve(h, h->d_partial2, knn_bf16_partial_bytes(mp)));
         LCD_HIP(h, dreserve(h, h->d_fail_list, (size_t)q * 4));
         const bool prof = h->prof_cap > 0 && h->prof_n < h->prof_cap;
@@ -232,7 +233,7 @@ void fill_append(lcd_engine* h, const lcd_frame_args& a, uint64_t vseq, bool ena
     ap.descriptors = (const float*)a.d_descriptors; ap.row_dwords = h->row_bytes / 4; ap.is_f32_64 = knn_mfma_supported(h->dtype, h->kdim) ? 1 : 0;
     ap.vocab = h->vocab.as<uint32_t>(); ap.row_id = h->row_id.as<int32_t>(); ap.row_wslot = h->row_wslot.as<int32_t>();
     ap.row_norm = h->row_norm.as<float>(); ap.norm_max_bits = h->norm_max.as<uint32_t>(); ap.vocab_bf = h->vocab_bf.as<uint32_t>();
-    ap.wrow = h->tfidf.wrow.as<uint32_t>();
+    ap.wrow = h->tfidf.wrow.as<uint32_t>(); ap.f16 = h->f16();
     ap.cnt_in = h->d_vcnt.as<int32_t>() + (vseq & 1); ap.cnt_out = h->d_vcnt.as<int32_t>() + ((vseq + 1) & 1);
     ap.log_slot = h->d_vcnt.as<int32_t>() + 16 + (vseq % lcd_engine::VLOG);
     ap.first_id = a.first_new_word_id; ap.capacity = vocab_cap_rows(h);
@@ -377,7 +378,7 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
     *out = nullptr;
     if (cfg->struct_size != (int32_t)sizeof(lcd_config)) return LCD_ERR_INVALID;
     if (cfg->dim <= 0 || cfg->dim > 4096 || (cfg->dtype != LCD_F32 && cfg->dtype != LCD_U8)) return LCD_ERR_INVALID;
-    if (cfg->knn_mode < LCD_KNN_DEFAULT || cfg->knn_mode > LCD_KNN_BF16X3) return LCD_ERR_INVALID;
+    if (cfg->knn_mode < LCD_KNN_DEFAULT || cfg->knn_mode > LCD_KNN_F16) return LCD_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return LCD_ERR_HIP;
     if (hipSetDevice(cfg->device) != hipSuccess) return LCD_ERR_HIP;
@@ -408,7 +409,7 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
     if (e == hipSuccess) e = h->d_fail_count.reserve(64, 0, h->stream, &h->bytes_device);   // [0] rejected, [1] arrivals, [2] max err / eps
     if (e == hipSuccess) e = h->d_hyp_scratch.reserve(64, 0, h->stream, &h->bytes_device);
     if (e == hipSuccess) e = hipMemsetAsync(h->d_fail_count.p, 0, 64, h->stream);
-    h->knn_mode = cfg->knn_mode == LCD_KNN_EXACT_VALU ? 0 : cfg->knn_mode == LCD_KNN_F32_MFMA ? 1 : 2;
+    h->knn_mode = cfg->knn_mode == LCD_KNN_EXACT_VALU ? 0 : cfg->knn_mode == LCD_KNN_F32_MFMA ? 1 : cfg->knn_mode == LCD_KNN_F16 ? 3 : 2;
     h->kst = h->stream;
     if (cfg->pipeline < 0 || cfg->pipeline > 1) { delete h; return LCD_ERR_INVALID; }
     h->pipeline = cfg->pipeline;
@@ -550,7 +551,7 @@ int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word
                                     h->norm_max.as<uint32_t>(), h->stream));
         if (knn_mfma_supported(h->dtype, h->kdim)) {   // hi/lo bf16 split of the new rows
             LCD_HIP(h, dreserve(h, h->vocab_bf, (size_t)total * 256, (size_t)h->n_rows * 256));
-            LCD_HIP(h, launch_vocab_bf16(h->vocab.p, (int)h->n_rows, n, h->kdim, h->vocab_bf.p, h->stream));
+            LCD_HIP(h, launch_vocab_bf16(h->vocab.p, (int)h->n_rows, n, h->kdim, h->vocab_bf.p, h->stream, h->f16()));
         }
     }
     LCD_HIP(h, hipStreamSynchronize(h->stream));
@@ -707,7 +708,7 @@ int lcd_vocab_rebuild(lcd_engine* h) {
     h->rm_seen = 0;
     if (n && knn_mfma_supported(h->dtype, h->kdim)) {   // the split is recomputed from the compacted rows
         LCD_HIP(h, dreserve(h, h->vocab_bf, (size_t)n * 256));
-        LCD_HIP(h, launch_vocab_bf16(h->vocab.p, 0, n, h->kdim, h->vocab_bf.p, h->stream));
+        LCD_HIP(h, launch_vocab_bf16(h->vocab.p, 0, n, h->kdim, h->vocab_bf.p, h->stream, h->f16()));
     }
     std::vector<int32_t> keys(n);
     for (int i = 0; i < n; ++i) keys[i] = h->h_row_key[perm[i]];
@@ -1228,9 +1229,11 @@ static int build_knn(lcd_engine* h, lcd_engine::InFlight& f, PipeKnn* kp) {
     // compute unit, and one strip less per workgroup is worth more than the two shared units (49 000 words x 500 descriptors:
     // 219 seven-tile strips + 36 tiles + 2 = 257 workgroups, frame 31.6 us; 192 eight-tile strips 32.1; 256 six-tile strips 34.5).
     k.plan = knn_bf16_plan_pipelined(q, (int)plan_rows, together ? knn_selfdist_wgs(q) : 0, h->filter_units);
+    k.plan.f16 = h->f16();
     if (h->strip_tiles > 0 && plan_rows > 0) {                       // timing experiments: a fixed strip length, one workgroup per strip
         const int n_tiles = (int)((plan_rows + 31) / 32);
         k.plan.tiles_per_block = h->strip_tiles; k.plan.n_blocks = (n_tiles + h->strip_tiles - 1) / h->strip_tiles; k.plan.one_strip = 1;
+        k.plan.f16 = h->f16();
     }
     {   // the candidate records: sized for this plan AND for the one the upper bound would get (a growing vocabulary crosses the planner's
         // thresholds: a reallocation drains the stream)
@@ -1401,7 +1404,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
         LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_bits, cand_bits_bytes(q, bw)));
     }
     QSplitArgs qs;
-    qs.queries = (const float*)a->d_descriptors; qs.nq = q; qs.qpad = ld; qs.qsplit = (uint4*)sc.d_qsplit.p; qs.qnorm = sc.d_qnorm.as<float>(); qs.n_wgs = 0;
+    qs.queries = (const float*)a->d_descriptors; qs.nq = q; qs.qpad = ld; qs.qsplit = (uint4*)sc.d_qsplit.p; qs.qnorm = sc.d_qnorm.as<float>(); qs.n_wgs = 0; qs.f16 = h->f16();
     // ---- what the frames in flight owe rides with this frame's launches
     { int rc = pipeline_launch(h, &qs); if (rc) return rc; }
     // ---- this frame's filter, re-rank, decision loop, registration and scoring are owed from here on
@@ -1425,7 +1428,7 @@ int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     if ((a->d_hypothesis || a->d_adjusted || a->d_posterior || a->d_bayes) && !a->d_likelihood)
         return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: the hypothesis needs d_likelihood");
     if ((a->d_posterior || a->d_bayes) && !h->bayes.configured) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: lcd_bayes_configure first");
-    if (h->pipeline && q <= 4096 && h->knn_mode == 2 && knn_mfma_supported(h->dtype, h->kdim) && h->n_live >= 2 && h->n_rows >= 256)
+    if (h->pipeline && q <= 4096 && h->bf_family() && knn_mfma_supported(h->dtype, h->kdim) && h->n_live >= 2 && h->n_rows >= 256)
         return frame_pipelined(h, a);
     const bool app = frame_appends(h, *a);
     // A stream of appending frames on a plain handle with the exact scan (ORB: config 3) does not wait for the device between frames:

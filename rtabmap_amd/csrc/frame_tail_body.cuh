@@ -37,6 +37,14 @@ __device__ __forceinline__ float fixed_to_like(long long acc, uint32_t ni) {
 }
 
 // float pair -> bf16 "hi" (RNE) and bf16 "lo" (the exact remainder, rounded): the split the bf16x3 filter multiplies
+__device__ __forceinline__ void f16_split2_dev(float a, float b, uint32_t& hi, uint32_t& lo) {       // as f16_split2 (knn_mfma_kernels.hip)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const h2 h = __builtin_convertvector((f2){a, b}, h2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    const f2 back = __builtin_convertvector(h, f2);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){__fsub_rn(a, back.x), __fsub_rn(b, back.y)}, h2));
+}
 __device__ __forceinline__ void bf16_split2_dev(float a, float b, uint32_t& hi, uint32_t& lo) {
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -193,8 +201,9 @@ __device__ __forceinline__ void retire_body(const RetireArgs& r, const uint32_t*
 template <int NT>
 __device__ __forceinline__ void append_new_rows(const AppendArgs& ap, int q, const uint32_t* mask, const uint32_t* prefix, const WsRuns& new_ws,
                                                 uint32_t* list /* LDS scratch, q words */,
-                                                float* stage = nullptr, int stage_rows = 0 /* LDS staging area for the new rows (256 B each) */) {
-    const int n_in = ap.cnt_in[0];
+                                                float* stage = nullptr, int stage_rows = 0 /* LDS staging area for the new rows (256 B each) */,
+                                                int n_in_early = -1 /* ap.cnt_in[0], read by the caller ahead of time (a round trip less in the chain) */) {
+    const int n_in = n_in_early >= 0 ? n_in_early : ap.cnt_in[0];
     const int mw = (q + 63) / 64 * 2;
     const int n_new = (int)prefix[mw];
     const int tid = threadIdx.x, c = tid & 15;
@@ -211,8 +220,8 @@ __device__ __forceinline__ void append_new_rows(const AppendArgs& ap, int q, con
 #pragma unroll
         for (int m = 8; m >= 1; m >>= 1) s2 += __shfl_xor(s2, m, 64);
         uint2 hi, lo;                                                   // as vocab_bf16_kernel: 64 bf16 "hi" then 64 bf16 "lo" per row
-        bf16_split2_dev(f0, f1, hi.x, lo.x);
-        bf16_split2_dev(f2, f3, hi.y, lo.y);
+        if (ap.f16) { f16_split2_dev(f0, f1, hi.x, lo.x); f16_split2_dev(f2, f3, hi.y, lo.y); }
+        else { bf16_split2_dev(f0, f1, hi.x, lo.x); bf16_split2_dev(f2, f3, hi.y, lo.y); }
         reinterpret_cast<uint2*>(ap.vocab_bf + row * 64)[c] = hi;
         reinterpret_cast<uint2*>(ap.vocab_bf + row * 64 + 32)[c] = lo;
         if (c == 0) {
@@ -356,6 +365,9 @@ __device__ __forceinline__ void frame_resolve_part(uint32_t* ft_dyn_smem, const 
         }
         __syncthreads();
     }
+    // the row count the appender continues from was written by the previous launch: requested now, a whole decision loop ahead of its use
+    int n_in_early = -1;
+    if (r.ap.enabled && r.ap.cnt_in) n_in_early = gload(r.ap.cnt_in);
     FT_STAMP(0);
     constexpr int KPT = 1024 / NT;
     const uint32_t* fmask;
@@ -370,7 +382,7 @@ __device__ __forceinline__ void frame_resolve_part(uint32_t* ft_dyn_smem, const 
         const int used = (3 * ((r.q + 63) / 64 * 2) + 4 + r.q + 3) & ~3;
         const int rows = (r.ap.lds_bytes / 4 - used) / 64;
         append_new_rows<NT>(r.ap, r.q, fmask, ft_dyn_smem + 2 * ((r.q + 63) / 64 * 2), r.new_ws, ft_dyn_smem + 3 * ((r.q + 63) / 64 * 2) + 4,
-                            reinterpret_cast<float*>(ft_dyn_smem + used), rows > 0 ? (rows & ~3) : 0);
+                            reinterpret_cast<float*>(ft_dyn_smem + used), rows > 0 ? (rows & ~3) : 0, n_in_early);
     } else append_pass_on(r.ap);
     FT_STAMP(1);
 }

@@ -72,14 +72,30 @@ __device__ __forceinline__ void bf16_split2(float a, float b, uint32_t& hi, uint
     const float ra = __fsub_rn(a, __uint_as_float(hi << 16)), rb = __fsub_rn(b, __uint_as_float(hi & 0xFFFF0000u));   // exact
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){ra, rb}, bf16x2_t));
 }
-__global__ void vocab_bf16_kernel(const float* __restrict__ vocab, int first, int n, uint32_t* __restrict__ bf) {
+// The fp16 filter (LCD_KNN_F16, one product per fp32 product: the operand format north_star names for the SURF distance GEMM): the SAME
+// table layout with IEEE half "hi" (RNE, 11 significant bits) and half "lo" (the remainder, unused by the one-product filter) -- the
+// matrix pipe runs v_mfma_f32_32x32x16_f16 at the bf16 rate, a third of the products, an eps of ~2^-10 (|q|^2 + |v|^2) instead of ~2^-14.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void f16_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const f16x2_t h = __builtin_convertvector((f32x2_t){a, b}, f16x2_t);                          // v_cvt_pkrtz would truncate: this rounds to nearest even
+    hi = __builtin_bit_cast(uint32_t, h);
+    const f32x2_t back = __builtin_convertvector(h, f32x2_t);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){__fsub_rn(a, back.x), __fsub_rn(b, back.y)}, f16x2_t));
+}
+template <int M> __device__ __forceinline__ void op_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    if (M == 1) f16_split2(a, b, hi, lo); else bf16_split2(a, b, hi, lo);
+}
+__device__ __forceinline__ void op_split2_rt(int f16, float a, float b, uint32_t& hi, uint32_t& lo) {
+    if (f16) f16_split2(a, b, hi, lo); else bf16_split2(a, b, hi, lo);
+}
+__global__ void vocab_bf16_kernel(const float* __restrict__ vocab, int first, int n, uint32_t* __restrict__ bf, int f16) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 4 floats of a 64-float row
     if (i >= n * 16) return;
     const int r = first + (i >> 4), c = i & 15;
     const float4 x = reinterpret_cast<const float4*>(vocab + (size_t)r * 64)[c];
     uint2 hi, lo;
-    bf16_split2(x.x, x.y, hi.x, lo.x);
-    bf16_split2(x.z, x.w, hi.y, lo.y);
+    op_split2_rt(f16, x.x, x.y, hi.x, lo.x);
+    op_split2_rt(f16, x.z, x.w, hi.y, lo.y);
     reinterpret_cast<uint2*>(bf + (size_t)r * 64)[c] = hi;
     reinterpret_cast<uint2*>(bf + (size_t)r * 64 + 32)[c] = lo;
 }
@@ -427,12 +443,16 @@ __device__ __forceinline__ void dma_tile_part(const float* __restrict__ base, in
                                          (__attribute__((address_space(3))) void*)(lds_slot + i * 256), 16, 0, 0);
     }
 }
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <int M>
 __device__ __forceinline__ f32x16 bf_mfma(const uint4& a, const uint4& b, const f32x16& c) {
+    if (M == 1) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 // One 32-row tile against two 32-query groups: 2 x (1 f32 augmentation step + 12 bf16 steps), the two accumulator chains
 // interleaved; with PUSH the top-3 update of the previous pair's 32 scores is spread between the steps.
-template <bool PUSH>
+// M = 0: bf16, three products per fp32 product (hi.hi + hi.lo + lo.hi); M = 1: fp16, the hi.hi product alone.
+template <bool PUSH, int M>
 __device__ __forceinline__ void bf_pair(const uint4 (&ah)[4], const uint4 (&al)[4], float a_aug, const uint4 (&bh0)[4], const uint4 (&bl0)[4],
                                         float b0_aug, const uint4 (&bh1)[4], const uint4 (&bl1)[4], float b1_aug, f32x16& c0, f32x16& c1,
                                         const f32x16& p0, const f32x16& p1, uint32_t tl, int32_t& k00, int32_t& k01, int32_t& k02,
@@ -447,7 +467,7 @@ __device__ __forceinline__ void bf_pair(const uint4 (&ah)[4], const uint4 (&al)[
         const int s = st / 3, term = st % 3;                        // (hi, hi), (hi, lo), (lo, hi)
         const uint4& a = term == 2 ? al[s] : ah[s];
 #if LCD_MFMA_ABLATE != 3      // 4 / 5: only the (hi, hi) / the (hi, hi) + (hi, lo) products -- the MFMA count of a one- / two-product filter (timing only)
-        if (LCD_MFMA_ABLATE < 4 || term == 0 || (LCD_MFMA_ABLATE == 5 && term == 1)) c0 = bf_mfma(a, term == 1 ? bl0[s] : bh0[s], c0);
+        if ((M == 0 && LCD_MFMA_ABLATE < 4) || term == 0 || (LCD_MFMA_ABLATE == 5 && term == 1)) c0 = bf_mfma<M>(a, term == 1 ? bl0[s] : bh0[s], c0);
 #endif
         if (PUSH && LCD_MFMA_ABLATE == 1) asm volatile("" :: "v"(p0[st]), "v"(p1[st]));   // keep the ablated chains alive
         if (PUSH && LCD_MFMA_ABLATE != 1) {                         // one MFMA, then the VALU that fits in its 32-cycle shadow
@@ -457,7 +477,7 @@ __device__ __forceinline__ void bf_pair(const uint4 (&ah)[4], const uint4 (&al)[
             __builtin_amdgcn_sched_barrier(0);
         }
 #if LCD_MFMA_ABLATE != 3
-        if (LCD_MFMA_ABLATE < 4 || term == 0 || (LCD_MFMA_ABLATE == 5 && term == 1)) c1 = bf_mfma(a, term == 1 ? bl1[s] : bh1[s], c1);
+        if ((M == 0 && LCD_MFMA_ABLATE < 4) || term == 0 || (LCD_MFMA_ABLATE == 5 && term == 1)) c1 = bf_mfma<M>(a, term == 1 ? bl1[s] : bh1[s], c1);
 #endif
         if (PUSH && LCD_MFMA_ABLATE != 1) {
             __builtin_amdgcn_sched_barrier(0);
@@ -584,7 +604,7 @@ __device__ __forceinline__ void selfdist_tile(const SelfdistJob& sd, int k, floa
 // queries of ONE block, so its records leave as full lines; query-major they were 16-byte pieces of 112 000 different lines per frame, and
 // the write-back of those partial lines at the end of the launch was a third of launch A's wall time).  Grid (1-D): n_blocks x ceil(nq / 512) filter
 // workgroups first, then sd.n_tiles distance-matrix workgroups.
-template <int NG>
+template <int NG, int M>
 __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
                                                      int n_rows, const float* __restrict__ queries, int nq, int qpad,
                                                      int tiles_per_block, int n_blocks, uint64_t* __restrict__ partial_keys,
@@ -662,10 +682,10 @@ __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, cons
         b_aug[g] = half == 0 ? 1.0f : qn;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bf16_split2(-2.0f * x[8 * s + 0], -2.0f * x[8 * s + 1], bh[g][s].x, bl[g][s].x);
-            bf16_split2(-2.0f * x[8 * s + 2], -2.0f * x[8 * s + 3], bh[g][s].y, bl[g][s].y);
-            bf16_split2(-2.0f * x[8 * s + 4], -2.0f * x[8 * s + 5], bh[g][s].z, bl[g][s].z);
-            bf16_split2(-2.0f * x[8 * s + 6], -2.0f * x[8 * s + 7], bh[g][s].w, bl[g][s].w);
+            op_split2<M>(-2.0f * x[8 * s + 0], -2.0f * x[8 * s + 1], bh[g][s].x, bl[g][s].x);
+            op_split2<M>(-2.0f * x[8 * s + 2], -2.0f * x[8 * s + 3], bh[g][s].y, bl[g][s].y);
+            op_split2<M>(-2.0f * x[8 * s + 4], -2.0f * x[8 * s + 5], bh[g][s].z, bl[g][s].z);
+            op_split2<M>(-2.0f * x[8 * s + 6], -2.0f * x[8 * s + 7], bh[g][s].w, bl[g][s].w);
         }
     }
 
@@ -711,18 +731,18 @@ __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, cons
             // two accumulator pairs take turns (no copies): groups 0,1 are computed into (x0, x1) while the pending scores of
             // groups 2,3 of the previous tile (p0, p1) are pushed, then groups 2,3 into (p0, p1) while (x0, x1) are pushed
             f32x16 x0, x1;
-            if (t == tile0) bf_pair<false>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, 0u, k0[2], k1[2], k2[2],
+            if (t == tile0) bf_pair<false, M>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, 0u, k0[2], k1[2], k2[2],
                                            k0[3], k1[3], k2[3]);
-            else bf_pair<true>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, tl - 1u, k0[2], k1[2], k2[2], k0[3],
+            else bf_pair<true, M>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, tl - 1u, k0[2], k1[2], k2[2], k0[3],
                                k1[3], k2[3]);
-            bf_pair<true>(ah, al, aug, bh[2], bl[2], b_aug[2], bh[3], bl[3], b_aug[3], p0, p1, x0, x1, tl, k0[0], k1[0], k2[0], k0[1], k1[1], k2[1]);
+            bf_pair<true, M>(ah, al, aug, bh[2], bl[2], b_aug[2], bh[3], bl[3], b_aug[3], p0, p1, x0, x1, tl, k0[0], k1[0], k2[0], k0[1], k1[1], k2[1]);
         } else {
             // one pair per tile: the two accumulator pairs take turns from tile to tile (even tiles -> (p0, p1), odd -> (r0, r1))
-            if (t == tile0) bf_pair<false>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], p0, p1, r0, r1, 0u, k0[0], k1[0], k2[0],
+            if (t == tile0) bf_pair<false, M>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], p0, p1, r0, r1, 0u, k0[0], k1[0], k2[0],
                                            k0[1], k1[1], k2[1]);
-            else if (tl & 1u) bf_pair<true>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], r0, r1, p0, p1, tl - 1u, k0[0], k1[0],
+            else if (tl & 1u) bf_pair<true, M>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], r0, r1, p0, p1, tl - 1u, k0[0], k1[0],
                                             k2[0], k0[1], k1[1], k2[1]);
-            else bf_pair<true>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], p0, p1, r0, r1, tl - 1u, k0[0], k1[0], k2[0], k0[1],
+            else bf_pair<true, M>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], p0, p1, r0, r1, tl - 1u, k0[0], k1[0], k2[0], k0[1],
                                k1[1], k2[1]);
         }
     }
@@ -776,10 +796,10 @@ __device__ __forceinline__ void qsplit_body(const QSplitArgs& qs, int wg) {
         const float4* src = reinterpret_cast<const float4*>(qs.queries + (size_t)min(qi, qs.nq - 1) * 64 + 32 * h + 8 * sx);   // padding repeats the last query
         const float4 a = src[0], b = src[1];
         uint4 hi, lo;
-        bf16_split2(-2.0f * a.x, -2.0f * a.y, hi.x, lo.x);
-        bf16_split2(-2.0f * a.z, -2.0f * a.w, hi.y, lo.y);
-        bf16_split2(-2.0f * b.x, -2.0f * b.y, hi.z, lo.z);
-        bf16_split2(-2.0f * b.z, -2.0f * b.w, hi.w, lo.w);
+        op_split2_rt(qs.f16, -2.0f * a.x, -2.0f * a.y, hi.x, lo.x);
+        op_split2_rt(qs.f16, -2.0f * a.z, -2.0f * a.w, hi.y, lo.y);
+        op_split2_rt(qs.f16, -2.0f * b.x, -2.0f * b.y, hi.z, lo.z);
+        op_split2_rt(qs.f16, -2.0f * b.z, -2.0f * b.w, hi.w, lo.w);
         const size_t base = ((size_t)(qi >> 5) * 4 + sx) * 2;
         qs.qsplit[(base + 0) * 64 + h * 32 + (qi & 31)] = hi;
         qs.qsplit[(base + 1) * 64 + h * 32 + (qi & 31)] = lo;
@@ -792,6 +812,7 @@ __device__ __forceinline__ void qsplit_body(const QSplitArgs& qs, int wg) {
 }
 
 // the filter body over pre-split queries: as knn_bf16_filter_body<4> (one strip per workgroup), without the query staging
+template <int M>
 __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
                                                        int n_rows, const uint4* qsplit, const float* qnorm, int nq, int qpad,
                                                        int tiles_per_block, int n_blocks, uint64_t* __restrict__ partial_keys,
@@ -897,11 +918,11 @@ __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, co
         }
         const uint32_t tl = (uint32_t)ti;
         f32x16 x0, x1;
-        if (t == tile0) bf_pair<false>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, 0u, k0[2], k1[2], k2[2],
+        if (t == tile0) bf_pair<false, M>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, 0u, k0[2], k1[2], k2[2],
                                        k0[3], k1[3], k2[3]);
-        else bf_pair<true>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, tl - 1u, k0[2], k1[2], k2[2], k0[3],
+        else bf_pair<true, M>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, tl - 1u, k0[2], k1[2], k2[2], k0[3],
                            k1[3], k2[3]);
-        bf_pair<true>(ah, al, aug, bh[2], bl[2], b_aug[2], bh[3], bl[3], b_aug[3], p0, p1, x0, x1, tl, k0[0], k1[0], k2[0], k0[1], k1[1], k2[1]);
+        bf_pair<true, M>(ah, al, aug, bh[2], bl[2], b_aug[2], bh[3], bl[3], b_aug[3], p0, p1, x0, x1, tl, k0[0], k1[0], k2[0], k0[1], k1[1], k2[1]);
     }
     if (tile0 < tile1) {
         const uint32_t tlast = (uint32_t)(tile1 - 1 - tile0);
@@ -970,6 +991,7 @@ __device__ __forceinline__ void bf_wait_all_but_request(int wave) {
 }
 // a barrier that waits for this wave's LDS traffic only (__syncthreads() would also wait for the strip in flight)
 __device__ __forceinline__ void bf_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int M>
 __device__ __forceinline__ void knn_bf16_filter_body_p(float* s_dyn, int bid, const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
                                                        int n_rows, const float* __restrict__ queries, int nq, int qpad,
                                                        int tiles_per_block, int n_blocks, int px, uint64_t* __restrict__ partial_keys,
@@ -1029,10 +1051,10 @@ __device__ __forceinline__ void knn_bf16_filter_body_p(float* s_dyn, int bid, co
         b_aug[g] = half == 0 ? 1.0f : qn;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bf16_split2(-2.0f * x[8 * s + 0], -2.0f * x[8 * s + 1], bh[g][s].x, bl[g][s].x);
-            bf16_split2(-2.0f * x[8 * s + 2], -2.0f * x[8 * s + 3], bh[g][s].y, bl[g][s].y);
-            bf16_split2(-2.0f * x[8 * s + 4], -2.0f * x[8 * s + 5], bh[g][s].z, bl[g][s].z);
-            bf16_split2(-2.0f * x[8 * s + 6], -2.0f * x[8 * s + 7], bh[g][s].w, bl[g][s].w);
+            op_split2<M>(-2.0f * x[8 * s + 0], -2.0f * x[8 * s + 1], bh[g][s].x, bl[g][s].x);
+            op_split2<M>(-2.0f * x[8 * s + 2], -2.0f * x[8 * s + 3], bh[g][s].y, bl[g][s].y);
+            op_split2<M>(-2.0f * x[8 * s + 4], -2.0f * x[8 * s + 5], bh[g][s].z, bl[g][s].z);
+            op_split2<M>(-2.0f * x[8 * s + 6], -2.0f * x[8 * s + 7], bh[g][s].w, bl[g][s].w);
         }
     }
     __syncthreads();                                                 // every wave has its queries in registers: the staging area is free
@@ -1085,11 +1107,11 @@ __device__ __forceinline__ void knn_bf16_filter_body_p(float* s_dyn, int bid, co
             }
             const uint32_t tl = (uint32_t)ti;
             f32x16 x0, x1;
-            if (t == tile0) bf_pair<false>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, 0u, k0[2], k1[2], k2[2],
+            if (t == tile0) bf_pair<false, M>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, 0u, k0[2], k1[2], k2[2],
                                            k0[3], k1[3], k2[3]);
-            else bf_pair<true>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, tl - 1u, k0[2], k1[2], k2[2], k0[3],
+            else bf_pair<true, M>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], x0, x1, p0, p1, tl - 1u, k0[2], k1[2], k2[2], k0[3],
                                k1[3], k2[3]);
-            bf_pair<true>(ah, al, aug, bh[2], bl[2], b_aug[2], bh[3], bl[3], b_aug[3], p0, p1, x0, x1, tl, k0[0], k1[0], k2[0], k0[1], k1[1], k2[1]);
+            bf_pair<true, M>(ah, al, aug, bh[2], bl[2], b_aug[2], bh[3], bl[3], b_aug[3], p0, p1, x0, x1, tl, k0[0], k1[0], k2[0], k0[1], k1[1], k2[1]);
         }
         if (tile0 < tile1) {
             const uint32_t tlast = (uint32_t)(tile1 - 1 - tile0);
@@ -1119,12 +1141,13 @@ __device__ __forceinline__ void knn_bf16_filter_body_p(float* s_dyn, int bid, co
         }
     }
 }
+template <int M>
 __global__ __launch_bounds__(256) void knn_bf16_filter_kernel_p(const float* __restrict__ vocab_bf, const float* __restrict__ row_norm, int n_rows,
                                                                 const float* __restrict__ queries, int nq, int qpad, int tiles_per_block, int n_blocks,
                                                                 int px, uint64_t* __restrict__ partial_keys, uint32_t* __restrict__ partial_bound,
                                                                 SelfdistJob sd) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn_p[];
-    knn_bf16_filter_body_p(s_dyn_p, (int)blockIdx.x, vocab_bf, row_norm, n_rows, queries, nq, qpad, tiles_per_block, n_blocks, px, partial_keys,
+    knn_bf16_filter_body_p<M>(s_dyn_p, (int)blockIdx.x, vocab_bf, row_norm, n_rows, queries, nq, qpad, tiles_per_block, n_blocks, px, partial_keys,
                            partial_bound, sd);
 }
 
@@ -1141,6 +1164,15 @@ __device__ __forceinline__ float eps_bf16(int dim, float qn, float vn_max) {
     const float u = 5.9604645e-8f;
     return (3.1f * 1.5258789e-5f + ((3.0f * (float)dim + 4.0f) * 8.0f + 1.5f * (float)dim + 12.0f) * u) * 1.25f * (qn + vn_max);
 }
+// |fp16 one-product filter score - reference distance| <= eps: both operands rounded to half (u16 = 2^-11, relative, inside half's normal
+// range): |q16.v16 - q.v| <= (2 u16 + u16^2) |q||v|, i.e. (2 u16 + u16^2)(|q|^2 + |v|^2) on the score -2 q.v (tests/test_fp16_split_bound.py);
+// components below half's normal range (2^-14) are rounded with an ABSOLUTE error <= 2^-25 each: 2 * dim * 2^-25 (|q| + |v|) more on the
+// score, charged with |x| <= 1 + |x|^2; the accumulation (dim products in fp32 by the matrix pipe) and norm terms as in eps_bf16.
+__device__ __forceinline__ float eps_f16(int dim, float qn, float vn_max) {
+    const float u = 5.9604645e-8f, u16 = 4.8828125e-4f;
+    return ((2.0f * u16 + u16 * u16) + (((float)dim + 4.0f) * 8.0f + 1.5f * (float)dim + 12.0f) * u) * 1.25f * (qn + vn_max) +
+           2.0f * (float)dim * 2.9802322e-8f * (2.0f + qn + vn_max);
+}
 
 // ------------------------------------------------------------------------------------------------ re-rank + certificate
 // |filter score - reference distance| <= eps: both are fp32 evaluations of the same real number d = |v - q|^2 <= 2 (|v|^2 + |q|^2).
@@ -1154,13 +1186,13 @@ __device__ __forceinline__ float eps_for(int dim, float qn, float vn_max) {
     return (3.5f * (float)dim + 16.0f) * 5.9604645e-8f * 1.25f * (qn + vn_max);
 }
 
-template <int NG>
+template <int NG, int M>
 __global__ __launch_bounds__((BF_QB / (NG * 32)) * 64) void knn_bf16_filter_kernel(const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
                                                                       int n_rows, const float* __restrict__ queries, int nq, int qpad,
                                                                       int tiles_per_block, int n_blocks, uint64_t* __restrict__ partial_keys,
                                                                       uint32_t* __restrict__ partial_bound, SelfdistJob sd) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn_f[];
-    knn_bf16_filter_body<NG>(s_dyn_f, (int)blockIdx.x, vocab_bf, row_norm, n_rows, queries, nq, qpad, tiles_per_block, n_blocks, partial_keys,
+    knn_bf16_filter_body<NG, M>(s_dyn_f, (int)blockIdx.x, vocab_bf, row_norm, n_rows, queries, nq, qpad, tiles_per_block, n_blocks, partial_keys,
                              partial_bound, sd);
 }
 
@@ -1191,7 +1223,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                                                      const int32_t* __restrict__ pend_lo = nullptr, const int32_t* __restrict__ pend_hi = nullptr,
                                                      int pend_cap = 0x7fffffff /* rows the filter's launch plan covered */,
                                                      float* stage = nullptr, int stage_rows = 0 /* LDS staging area of the pending rows (256 B each,
-                                                     a multiple of 4), shared by the halves of the workgroup */) {
+                                                     a multiple of 4), shared by the halves of the workgroup */,
+                                                     int f16 = 0 /* the keys come from the one-product fp16 filter (eps_f16) */) {
     static_assert(DIM == 64, "16 lanes x 4 floats per candidate row");
     // rows [pend_lo[0], pend_hi[0]): words the previous frame created, appended on the device after this frame's filter took its
     // snapshot of the vocabulary (VWDictionary::update() of a pipelined handle).  They are scanned exactly here, so the result is
@@ -1203,16 +1236,18 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     // The pending rows are the same for every query: with a staging area they come in by LDS-DMA -- no registers, requested HERE, a
     // whole chunk in one round trip that runs under the two passes below -- instead of four rows per 16-lane group and trip
     // (three dependent round trips for the ~150 words a frame creates: +7 us on launch B, measured).
+    // LDS slot (row r, position s) holds the row's 16-byte chunk s ^ (r & 15): sixteen consecutive lanes that read the same chunk of
+    // sixteen consecutive rows touch sixteen different positions (no bank conflict)
     auto stage_chunk = [&](int first, int n_chunk) {
         const int wv = (int)threadIdx.x >> 6, ln = (int)threadIdx.x & 63;
         for (int i = wv; i * 4 < n_chunk; i += HALVES * MF_WAVES) {      // one instruction = four rows = 1 KB of LDS
-            const int row = first + min(i * 4 + (ln >> 4), n_chunk - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vocab + (size_t)row * DIM + (ln & 15) * 4),
+            const int rl = min(i * 4 + (ln >> 4), n_chunk - 1);          // (the rows of a partial last group repeat the chunk's last row)
+            const int chunk = (ln & 15) ^ ((i * 4 + (ln >> 4)) & 15);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vocab + (size_t)(first + rl) * DIM + chunk * 4),
                                              (__attribute__((address_space(3))) void*)(stage + (size_t)i * 256), 16, 0, 0);
         }
     };
     const bool staged = stage != nullptr && stage_rows >= 4 && p_hi > p_lo;
-    if (staged) stage_chunk(p_lo, min(stage_rows, p_hi - p_lo));
     const bool valid = qi_first + hf < nq;                             // the odd query out: its half walks the last query again, writes nothing
     const int qi = valid ? qi_first + hf : nq - 1;
     __shared__ float s_thr_all[HALVES];
@@ -1277,6 +1312,10 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     }
     if (lane == 0) { s_a0[wave] = a0; s_a1[wave] = a1; s_bound[wave] = bound; }
     if (tid == 0) s_ncand = 0;
+    // the pending rows are requested here -- behind the keys, which have arrived, and in front of pass 2's row reads, whose round trip
+    // they share (a request in front of the keys would make the first use of a key wait for the whole chunk: the counter is in-order)
+    if (staged) stage_chunk(p_lo, min(stage_rows, p_hi - p_lo));
+    if (staged && lane < 16 && wave == 0) reinterpret_cast<float4*>(stage + (size_t)stage_rows * DIM)[hf * 16 + lane] = q4;   // the query, for every lane
     __syncthreads();
     a0 = s_a0[0]; a1 = s_a1[0]; bound = s_bound[0];
 #pragma unroll
@@ -1286,7 +1325,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         a0 = min(a0, o0);
         bound = min(bound, s_bound[w]);
     }
-    const float eps = BF16 ? eps_bf16(DIM, qn, vn_max) : eps_for(DIM, qn, vn_max);
+    const float eps = BF16 ? (f16 ? eps_f16(DIM, qn, vn_max) : eps_bf16(DIM, qn, vn_max)) : eps_for(DIM, qn, vn_max);
     const float tau = __uint_as_float(a1);
     const float thr = tau + (2.0f * eps + tau * 3.0517578e-5f);               // +inf when fewer than two finite keys exist
 
@@ -1341,17 +1380,24 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                 if (c0 > p_lo) { __syncthreads(); stage_chunk(c0, n_chunk); }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                for (int r = tid >> 4; r < n_chunk; r += MF_BLOCK / 16) {
-                    const float4 v = *reinterpret_cast<const float4*>(stage + (size_t)r * DIM + (lane & 15) * 4);
-                    const float d0 = __fsub_rn(v.x, q4.x), d1 = __fsub_rn(v.y, q4.y), d2 = __fsub_rn(v.z, q4.z), d3 = __fsub_rn(v.w, q4.w);
-                    float t = __fmul_rn(d0, d0);
-                    t = __fadd_rn(t, __fmul_rn(d1, d1));
-                    t = __fadd_rn(t, __fmul_rn(d2, d2));
-                    t = __fadd_rn(t, __fmul_rn(d3, d3));
+                // ONE LANE PER ROW: the sixteen 4-float terms are formed and added by the same lane in the reference's order (dist.h:150-177),
+                // the row's chunks from LDS, the query's as a broadcast read -- no cross-lane traffic (sixteen lanes per row gathered the
+                // terms with sixteen ds_bpermute per row: at ~150 pending rows per query that was the whole cost of the scan)
+                const float4* sq = reinterpret_cast<const float4*>(stage + (size_t)stage_rows * DIM) + hf * 16;
+                for (int r = tid; r < n_chunk; r += MF_BLOCK) {
+                    const float4* sv = reinterpret_cast<const float4*>(stage + (size_t)r * DIM);
                     float res = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) res = __fadd_rn(res, __shfl(t, (lane & 48) + j, 64));
-                    if ((lane & 15) == 0) top2_push(pb, ps, ((uint64_t)__float_as_uint(res) << 32) | (uint32_t)(c0 + r));
+#pragma unroll 4
+                    for (int c = 0; c < 16; ++c) {
+                        const float4 v = sv[c ^ (r & 15)], qq = sq[c];
+                        const float d0 = __fsub_rn(v.x, qq.x), d1 = __fsub_rn(v.y, qq.y), d2 = __fsub_rn(v.z, qq.z), d3 = __fsub_rn(v.w, qq.w);
+                        float t = __fmul_rn(d0, d0);
+                        t = __fadd_rn(t, __fmul_rn(d1, d1));
+                        t = __fadd_rn(t, __fmul_rn(d2, d2));
+                        t = __fadd_rn(t, __fmul_rn(d3, d3));
+                        res = __fadd_rn(res, t);
+                    }
+                    top2_push(pb, ps, ((uint64_t)__float_as_uint(res) << 32) | (uint32_t)(c0 + r));
                 }
             }
         } else
@@ -1443,6 +1489,9 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         // the certificate's premise is |filter score - exact distance| <= eps for every row; on the re-ranked candidates that error was
         // just measured: half the budget used up anywhere means the bound is no longer trusted for this query -> exact redo
         if (err_ratio >= 0.5f) ok = false;
+        // fp16 operands hold magnitudes up to 65504: descriptors far outside that (the filter multiplies -2 q) are not this filter's
+        // business -- the exact scan takes the query
+        if (f16 && !(qn < 1.0e8f && vn_max < 1.0e8f)) ok = false;
         if (!ok) fail_list[atomicAdd(fail_count, 1)] = qi;
     }
     if (cb.bits) {                                                    // the query's row of the candidate bit matrix (uniform branch)
@@ -1477,9 +1526,10 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
                                                                    const uint32_t* __restrict__ norm_max_bits,
                                                                    int32_t* __restrict__ out_row, int32_t* __restrict__ out_word,
                                                                    float* __restrict__ out_dist, int32_t* __restrict__ fail_list,
-                                                                   int32_t* __restrict__ fail_count, CandBits cb) {
+                                                                   int32_t* __restrict__ fail_count, CandBits cb, int f16) {
     knn_mfma_rerank_body<DIM, KEEP, LAST_KEY_BOUNDS, BF16>((int)blockIdx.x, partial_keys, partial_lmin, n_blocks, nq, vocab, queries, row_id,
-                                                          norm_max_bits, out_row, out_word, out_dist, fail_list, fail_count, cb);
+                                                          norm_max_bits, out_row, out_word, out_dist, fail_list, fail_count, cb, nullptr, nullptr,
+                                                          0x7fffffff, nullptr, 0, f16);
 }
 
 // ------------------------------------------------------------------------------------------------ software-pipelined frames
@@ -1502,6 +1552,7 @@ struct RerankArgs {
     const uint32_t* norm_max_bits; int32_t* out_row; int32_t* out_word; float* out_dist; int32_t* fail_list; int32_t* fail_count; CandBits cb;
     const int32_t* n_lo; const int32_t* n_hi; int plan_rows;
     int stage_rows;                                                    // rows the launch's dynamic LDS stages (0: none)
+    int f16;                                                           // the filter multiplied fp16 operands (one product): eps_f16
 };
 constexpr int PIPE_BLOCK = 256;     // workgroup size of both fused launches (the filter's and the re-rank's)
 
@@ -1516,7 +1567,7 @@ __device__ unsigned long long g_a_timing[2 * 4096];
 #define A_STAMP(i) do { } while (0)
 #endif
 // grid order: decision loop, registration, filter workgroups (+ distance tiles), query pre-split workgroups, redo helpers
-template <bool PERSISTENT>
+template <bool PERSISTENT, int M>
 __device__ __forceinline__ void frame_a_body(float* s_dyn, const FilterArgs& f, int px, const TailRoles& tr, const ResolveArgs& r, const FwArgs& a,
                                              const RetireArgs& ret, const QSplitArgs& qs) {
     const int bid = (int)blockIdx.x;
@@ -1528,22 +1579,24 @@ __device__ __forceinline__ void frame_a_body(float* s_dyn, const FilterArgs& f, 
     if (bid >= after_filter && bid < after_filter + tr.n_q_wgs) { qsplit_body(qs, bid - after_filter); A_STAMP(1); return; }
     if (bid >= after_filter + tr.n_q_wgs) { frame_resolve_part<PIPE_BLOCK>((uint32_t*)s_dyn, r, bid - after_filter - tr.n_q_wgs + 1, 1 + tr.n_redo); A_STAMP(1); return; }
     if constexpr (PERSISTENT)
-        knn_bf16_filter_body_p(s_dyn, bid - n_front, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, px, f.pk,
+        knn_bf16_filter_body_p<M>(s_dyn, bid - n_front, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, px, f.pk,
                                f.pl, f.sd, f.n_lo);
     else
-        knn_bf16_filter_body_q(s_dyn, bid - n_front, f.vocab_bf, f.row_norm, f.n_rows, f.qsplit, f.qnorm, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, f.pk,
+        knn_bf16_filter_body_q<M>(s_dyn, bid - n_front, f.vocab_bf, f.row_norm, f.n_rows, f.qsplit, f.qnorm, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, f.pk,
                                f.pl, f.sd, f.n_lo);
     A_STAMP(1);
 }
 // two workgroups per compute unit: 66 KB of LDS each, and a register budget of two waves per SIMD
+template <int M>
 __global__ __launch_bounds__(PIPE_BLOCK, 2) void frame_a_kernel(FilterArgs f, TailRoles tr, ResolveArgs r, FwArgs a, RetireArgs ret, QSplitArgs qs) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn_a[];
-    frame_a_body<false>(s_dyn_a, f, 0, tr, r, a, ret, qs);
+    frame_a_body<false, M>(s_dyn_a, f, 0, tr, r, a, ret, qs);
 }
 // the same launch over a vocabulary of more strips than compute units: persistent filter workgroups (knn_bf16_filter_body_p)
+template <int M>
 __global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel_p(FilterArgs f, int px, TailRoles tr, ResolveArgs r, FwArgs a, RetireArgs ret, QSplitArgs qs) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn_ap[];
-    frame_a_body<true>(s_dyn_ap, f, px, tr, r, a, ret, qs);
+    frame_a_body<true, M>(s_dyn_ap, f, px, tr, r, a, ret, qs);
 }
 #ifdef LCD_B_TIMING   // timing experiment only: start / end of every workgroup of launch B (100 MHz)
 __device__ unsigned long long g_b_timing[2 * 4096];
@@ -1564,7 +1617,7 @@ __global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, 
         extern __shared__ __attribute__((aligned(16))) float s_dyn_b[];
         knn_mfma_rerank_body<64, BF_KEEP, false, true, 2>(2 * pair, k.pk, k.pl, k.n_blocks, k.nq, k.vocab, k.queries, k.row_id, k.norm_max_bits, k.out_row,
                                                           k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb, k.n_lo, k.n_hi, k.plan_rows,
-                                                          s_dyn_b, k.stage_rows);
+                                                          s_dyn_b, k.stage_rows, k.f16);
         B_STAMP(1);
         return;
     }
@@ -1686,7 +1739,7 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
     knn_mfma_rerank_kernel<64, MF_KEEP, true, false><<<p.q, MF_BLOCK, 0, s>>>(pk, pl, p.n_blocks, p.q, (const float*)vocab,
                                                                                    (const float*)queries, row_id, norm_max_bits, out_row,
                                                                                    out_word, out_dist, fail_list, fail_count,
-                                                                                   cb ? *cb : CandBits{});
+                                                                                   cb ? *cb : CandBits{}, 0);
     return hipGetLastError();
 }
 
@@ -1726,10 +1779,10 @@ size_t knn_bf16_partial_bytes(const MfmaPlan& p) {
     const size_t nb = (size_t)(p.n_blocks > 0 ? p.n_blocks : 1);
     return nb * BF_KEEP * p.qpad * sizeof(uint64_t) + nb * p.qpad * sizeof(uint32_t);
 }
-hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void* bf, hipStream_t s) {
+hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void* bf, hipStream_t s, int f16) {
     if (n <= 0) return hipSuccess;
     if (dim != 64) return hipErrorInvalidValue;
-    vocab_bf16_kernel<<<(n * 16 + 255) / 256, 256, 0, s>>>((const float*)vocab, first, n, (uint32_t*)bf);
+    vocab_bf16_kernel<<<(n * 16 + 255) / 256, 256, 0, s>>>((const float*)vocab, first, n, (uint32_t*)bf, f16);
     return hipGetLastError();
 }
 // Persistent filter workgroups per block of 512 queries, or 0: the one-strip kernel (every strip gets its own workgroup; up to one
@@ -1789,12 +1842,12 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
         if (e != hipSuccess) return e;
     }
     if (p.n_blocks > 0) {
-        constexpr int ng = 4;                                         // waves per SIMD = 4 / ng (2 measured equal)
-        static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_bf16_filter_kernel<4>),
+        // (one wave per SIMD, NG = 4; the two-waves-per-SIMD variant measured equal and is no longer instantiated)
+        static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_bf16_filter_kernel<4, 0>),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES);
-        static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_bf16_filter_kernel<2>),
+        static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_bf16_filter_kernel<4, 1>),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES);
-        (void)attr4; (void)attr2;
+        (void)attr0; (void)attr1;
         SelfdistJob sd;
         if (with_selfdist && cb) {                                    // the same-frame distance matrix rides along
             sd.queries = (const float*)queries; sd.nq = p.q; sd.out = const_cast<float*>(cb->selfdist); sd.ld = cb->ld; sd.n_tiles = selfdist_tiles(p.q);
@@ -1803,17 +1856,22 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
         const int px = bf16_persistent_px(p);
         if (ev_begin) { e = hipEventRecord(ev_begin, s); if (e != hipSuccess) return e; }
         if (px > 0) {
-            static const hipError_t attrp = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_bf16_filter_kernel_p),
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES_P);
-            (void)attrp;
-            knn_bf16_filter_kernel_p<<<sd.n_tiles + px * ((p.q + BF_QB - 1) / BF_QB), 256, BF_LDS_BYTES_P, s>>>(
-                (const float*)vocab_bf, row_norm, p.n_rows, (const float*)queries, p.q, p.qpad, p.tiles_per_block, p.n_blocks, px, pk, pl, sd);
-        } else if (ng == 4)
-            knn_bf16_filter_kernel<4><<<grid, 256, BF_LDS_BYTES, s>>>((const float*)vocab_bf, row_norm, p.n_rows, (const float*)queries, p.q,
-                                                                       p.qpad, p.tiles_per_block, p.n_blocks, pk, pl, sd);
+            static const hipError_t attrp0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_bf16_filter_kernel_p<0>),
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES_P);
+            static const hipError_t attrp1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_bf16_filter_kernel_p<1>),
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES_P);
+            (void)attrp0; (void)attrp1;
+            const int gp = sd.n_tiles + px * ((p.q + BF_QB - 1) / BF_QB);
+            if (p.f16) knn_bf16_filter_kernel_p<1><<<gp, 256, BF_LDS_BYTES_P, s>>>((const float*)vocab_bf, row_norm, p.n_rows, (const float*)queries, p.q, p.qpad,
+                                                                                   p.tiles_per_block, p.n_blocks, px, pk, pl, sd);
+            else knn_bf16_filter_kernel_p<0><<<gp, 256, BF_LDS_BYTES_P, s>>>((const float*)vocab_bf, row_norm, p.n_rows, (const float*)queries, p.q, p.qpad,
+                                                                             p.tiles_per_block, p.n_blocks, px, pk, pl, sd);
+        } else if (p.f16)
+            knn_bf16_filter_kernel<4, 1><<<grid, 256, BF_LDS_BYTES, s>>>((const float*)vocab_bf, row_norm, p.n_rows, (const float*)queries, p.q,
+                                                                          p.qpad, p.tiles_per_block, p.n_blocks, pk, pl, sd);
         else
-            knn_bf16_filter_kernel<2><<<grid, 512, BF_LDS_BYTES, s>>>((const float*)vocab_bf, row_norm, p.n_rows, (const float*)queries, p.q,
-                                                                       p.qpad, p.tiles_per_block, p.n_blocks, pk, pl, sd);
+            knn_bf16_filter_kernel<4, 0><<<grid, 256, BF_LDS_BYTES, s>>>((const float*)vocab_bf, row_norm, p.n_rows, (const float*)queries, p.q,
+                                                                          p.qpad, p.tiles_per_block, p.n_blocks, pk, pl, sd);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (ev_end) { e = hipEventRecord(ev_end, s); if (e != hipSuccess) return e; }
@@ -1826,7 +1884,7 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
     }
     knn_mfma_rerank_kernel<64, BF_KEEP, false, true><<<p.q, MF_BLOCK, 0, s_rerank>>>(
         pk, pl, p.n_blocks, p.q, (const float*)vocab, (const float*)queries, row_id, norm_max_bits, out_row, out_word, out_dist, fail_list,
-        fail_count, cb ? *cb : CandBits{});
+        fail_count, cb ? *cb : CandBits{}, p.f16);
     return hipGetLastError();
 }
 
@@ -1853,9 +1911,11 @@ size_t knn_qsplit_bytes(int q) { return (size_t)((q + 63) / 64 * 64) * 256; }
 
 hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLaunch* resolve, const TailLaunch* reg, hipStream_t s, hipEvent_t ev_begin,
                           hipEvent_t ev_end) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       (int)BF_LDS_BYTES_Q);
-    (void)attr;
+    static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)BF_LDS_BYTES_Q);
+    static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)BF_LDS_BYTES_Q);
+    (void)attr0; (void)attr1;
     FilterArgs f{};
     MfmaPlan p;
     p.q = 0; p.qpad = 0; p.n_rows = 0; p.tiles_per_block = 1; p.n_blocks = 0;
@@ -1889,15 +1949,26 @@ hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLa
     // ev_begin / ev_end: the launch's own start and end time stamps (hipExtLaunchKernel attaches the two events to the dispatch; a pair
     // of hipEventRecord around it costs the stream ~10 us of barrier packets -- and measures the gap in front of the kernel with it)
     const bool timed = ev_begin != nullptr && ev_end != nullptr;
+    const bool f16 = p.f16 != 0;
     if (px > 0) {
-        static const hipError_t attrp = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel_p),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES_P);
-        (void)attrp;
-        if (timed) hipExtLaunchKernelGGL(frame_a_kernel_p, dim3(grid), dim3(PIPE_BLOCK), (uint32_t)BF_LDS_BYTES_P, s, ev_begin, ev_end, 0u, f, px, tr, r, a, ret, qs);
-        else frame_a_kernel_p<<<grid, PIPE_BLOCK, BF_LDS_BYTES_P, s>>>(f, px, tr, r, a, ret, qs);
+        static const hipError_t attrp0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel_p<0>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES_P);
+        static const hipError_t attrp1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel_p<1>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES_P);
+        (void)attrp0; (void)attrp1;
+        if (f16) {
+            if (timed) hipExtLaunchKernelGGL(frame_a_kernel_p<1>, dim3(grid), dim3(PIPE_BLOCK), (uint32_t)BF_LDS_BYTES_P, s, ev_begin, ev_end, 0u, f, px, tr, r, a, ret, qs);
+            else frame_a_kernel_p<1><<<grid, PIPE_BLOCK, BF_LDS_BYTES_P, s>>>(f, px, tr, r, a, ret, qs);
+        } else {
+            if (timed) hipExtLaunchKernelGGL(frame_a_kernel_p<0>, dim3(grid), dim3(PIPE_BLOCK), (uint32_t)BF_LDS_BYTES_P, s, ev_begin, ev_end, 0u, f, px, tr, r, a, ret, qs);
+            else frame_a_kernel_p<0><<<grid, PIPE_BLOCK, BF_LDS_BYTES_P, s>>>(f, px, tr, r, a, ret, qs);
+        }
+    } else if (f16) {
+        if (timed) hipExtLaunchKernelGGL(frame_a_kernel<1>, dim3(grid), dim3(PIPE_BLOCK), (uint32_t)BF_LDS_BYTES_Q, s, ev_begin, ev_end, 0u, f, tr, r, a, ret, qs);
+        else frame_a_kernel<1><<<grid, PIPE_BLOCK, BF_LDS_BYTES_Q, s>>>(f, tr, r, a, ret, qs);
     } else {
-        if (timed) hipExtLaunchKernelGGL(frame_a_kernel, dim3(grid), dim3(PIPE_BLOCK), (uint32_t)BF_LDS_BYTES_Q, s, ev_begin, ev_end, 0u, f, tr, r, a, ret, qs);
-        else frame_a_kernel<<<grid, PIPE_BLOCK, BF_LDS_BYTES_Q, s>>>(f, tr, r, a, ret, qs);
+        if (timed) hipExtLaunchKernelGGL(frame_a_kernel<0>, dim3(grid), dim3(PIPE_BLOCK), (uint32_t)BF_LDS_BYTES_Q, s, ev_begin, ev_end, 0u, f, tr, r, a, ret, qs);
+        else frame_a_kernel<0><<<grid, PIPE_BLOCK, BF_LDS_BYTES_Q, s>>>(f, tr, r, a, ret, qs);
     }
     return hipGetLastError();
 }
@@ -1911,7 +1982,7 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
         rk.pk = pk; rk.pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * BF_KEEP * p.qpad);
         rk.n_blocks = p.n_blocks; rk.nq = p.q; rk.vocab = (const float*)k->vocab; rk.queries = (const float*)k->queries; rk.row_id = k->row_id;
         rk.norm_max_bits = k->norm_max_bits; rk.out_row = k->out_row; rk.out_word = k->out_word; rk.out_dist = k->out_dist;
-        rk.fail_list = k->fail_list; rk.fail_count = k->fail_count; rk.cb = k->cb; rk.n_lo = k->n_lo; rk.n_hi = k->n_hi; rk.plan_rows = p.n_rows;
+        rk.fail_list = k->fail_list; rk.fail_count = k->fail_count; rk.cb = k->cb; rk.n_lo = k->n_lo; rk.n_hi = k->n_hi; rk.plan_rows = p.n_rows; rk.f16 = p.f16;
         n_rerank = ((p.q + 1) / 2 + 7) & ~7;                          // two queries per workgroup; padded to the XCD count (frame_b_kernel)
     }
     ScoreArgs A{};
@@ -1919,7 +1990,7 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
     if (n_rerank + score_wgs == 0) return hipSuccess;
     // frames that append their words on the device: 40 KB of dynamic LDS stage 160 pending rows per re-rank workgroup (three workgroups
     // of launch B share a compute unit: 3 x (40 + 8) KB of its 160 KB)
-    const uint32_t dyn = (k && k->n_hi) ? PIPE_B_STAGE_ROWS * 256u : 0u;
+    const uint32_t dyn = (k && k->n_hi) ? PIPE_B_STAGE_ROWS * 256u + 512u : 0u;   // + the workgroup's two queries
     rk.stage_rows = dyn ? (int)PIPE_B_STAGE_ROWS : 0;
     if (ev_begin != nullptr && ev_end != nullptr)
         hipExtLaunchKernelGGL(frame_b_kernel, dim3(n_rerank + score_wgs), dim3(PIPE_B_BLOCK), dyn, s, ev_begin, ev_end, 0u, rk, n_rerank, A);

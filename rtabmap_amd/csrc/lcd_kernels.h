@@ -87,6 +87,7 @@ struct MfmaPlan {
     int filter_units = -1;   // compute units the persistent bf16 filter plans for (-1: built-in; 0: one workgroup per strip always)
     int other_wgs = 0;       // long-running workgroups of other kinds in the same launch (each holds a compute unit like a filter workgroup)
     int one_strip = 0;       // 1: one workgroup per strip whatever the number of strips (lcd_set_option "strip_tiles")
+    int f16 = 0;             // 1: the operand tables hold IEEE half and the filter multiplies ONE product per fp32 product (LCD_KNN_F16)
 };
 bool knn_mfma_supported(int dtype, int dim);
 void knn_set_compute_units(int cus);           // the device's compute units: what the filter launch plans fill (256 unless told otherwise)
@@ -147,7 +148,7 @@ hipError_t launch_shard_merge(const void* all_cand, int world, int rank, int q, 
 MfmaPlan knn_bf16_plan(int q, int n_rows, int other_wgs = 0 /* long-running workgroups sharing the launch */);
 int knn_selfdist_wgs(int q);   // distance-matrix workgroups of a q-descriptor frame
 size_t knn_bf16_partial_bytes(const MfmaPlan& p);
-hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void* bf, hipStream_t s);
+hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void* bf, hipStream_t s, int f16 = 0);
 hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, const float* row_norm, const uint32_t* norm_max_bits,
                            const int32_t* row_id, const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word,
                            float* out_dist, int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin = nullptr,

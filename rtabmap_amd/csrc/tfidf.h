@@ -107,6 +107,7 @@ struct AppendArgs {
     const float* descriptors = nullptr;        // [q x dim floats] of the frame (dim == 64) or [q x row_bytes] bytes
     int row_dwords = 0;                        // dwords per stored row
     int is_f32_64 = 0;                         // rows are 64 floats: also the augmentation entries and the bf16 split
+    int f16 = 0;                               // ... the split table holds IEEE half (LCD_KNN_F16) instead of bf16
     uint32_t* vocab = nullptr; int32_t* row_id = nullptr; int32_t* row_wslot = nullptr;
     uint32_t* wrow = nullptr;                  // Tfidf::wrow: the appended rows claim their postings keys
     float* row_norm = nullptr; uint32_t* norm_max_bits = nullptr; uint32_t* vocab_bf = nullptr;
@@ -179,7 +180,7 @@ struct PipeKnn {
     const int32_t* n_hi = nullptr;   // also scans [n_lo[0], n_hi[0]) exactly -- the words the previous frame appended meanwhile (AppendArgs)
 };
 // the new frame's queries -> MFMA operand order in global memory (knn_mfma_kernels.hip, qsplit_body): a few workgroups of launch A
-struct QSplitArgs { const float* queries; int nq, qpad; uint4* qsplit; float* qnorm; int n_wgs; };
+struct QSplitArgs { const float* queries; int nq, qpad; uint4* qsplit; float* qnorm; int n_wgs; int f16 = 0; /* operands as IEEE half */ };
 size_t knn_qsplit_bytes(int q);
 int pipe_block_size();      // workgroup size of launch A (the filter's)
 int pipe_b_block_size();    // workgroup size of launch B (re-rank + scoring)

@@ -13,7 +13,7 @@ from test_gpu_frame_stream import _revisit, RTOL, ATOL
 pytestmark = pytest.mark.gpu
 
 
-def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="surf"):
+def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="surf", knn_mode=None):
     import rtabmap_amd
     rng = np.random.default_rng(seed)
     base = synth.vocab_surf(n_words, seed=seed + 1) if kind == "surf" else synth.vocab_orb(n_words, seed=seed + 1)
@@ -41,7 +41,7 @@ def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="su
         live = np.array(m.signature_ids(), np.int32)
         likes.append(m.compute_likelihood(np.array(exp, np.int32), live)[1])
     assert not m.vwd.get_unused_word_ids()
-    eng = rtabmap_amd.Engine("f32" if kind == "surf" else "u8", base.shape[1], sig_capacity=n_bulk + n_frames + 8, pipeline=pipeline)
+    eng = rtabmap_amd.Engine("f32" if kind == "surf" else "u8", base.shape[1], sig_capacity=n_bulk + n_frames + 8, pipeline=pipeline, knn_mode=knn_mode)
     eng.vocab_append(base, ids)
     eng.sig_add_bulk(np.arange(1, n_bulk + 1, dtype=np.int32), np.arange(0, (n_bulk + 1) * q, q, dtype=np.int64), words.reshape(-1))
     cap = n_bulk + n_frames + 8
@@ -88,6 +88,14 @@ def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="su
 @pytest.mark.parametrize("pipeline", [False, True])
 def test_append_new_words_on_the_device(oracle, pipeline):
     assert _stream(oracle, pipeline, n_words=3000, q=96, n_frames=30, seed=11) > 200
+
+
+@pytest.mark.parametrize("pipeline,n_words,q", [(False, 3000, 96), (True, 3000, 96), (True, 72000, 700)])
+def test_append_new_words_with_the_fp16_filter(oracle, pipeline, n_words, q):
+    """LCD_KNN_F16: the one-product fp16 matrix-core filter (operand tables in IEEE half, rows appended on the device split the same
+    way, the re-rank's wider error bound) gives the same word ids, likelihood and vocabulary as the exact scan -- plain handle,
+    pipelined frames, and the persistent filter over a vocabulary that grows while frames are in flight."""
+    assert _stream(oracle, pipeline, n_words=n_words, q=q, n_frames=8 if n_words > 10000 else 30, seed=13, knn_mode="f16") > 100
 
 
 def test_append_new_words_on_the_device_orb(oracle):

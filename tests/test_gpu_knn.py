@@ -163,13 +163,15 @@ def test_knn2_mfma_filter_matches_exact_scan_and_falls_back_on_clusters(oracle, 
         q[100:160] = v[123] + (np.arange(60, dtype=np.float32)[:, None] * np.float32(1e-5))
     ids = np.arange(1, 20001, dtype=np.int32)
     res = {}
-    for mode in ("bf16", "mfma32", "valu"):
+    for mode in ("bf16", "f16", "mfma32", "valu"):
         eng = rtabmap_amd.Engine("f32", 64, knn_mode=mode)
         eng.vocab_append(v, ids)
         res[mode] = eng.knn2(q)
         st = eng.stats()
         fb = st["knn_last_fallback_queries"]
-        if mode != "valu":
+        if mode == "f16":                # (the one-product fp16 filter's wider error bound sends a few more queries to the exact scan)
+            assert (33 <= fb < 200) if many_clusters else (1 <= fb <= 100), (mode, fb)
+        elif mode != "valu":
             assert (33 <= fb < 120) if many_clusters else (1 <= fb <= 32), (mode, fb)   # the cluster queries, not everything
         else:
             assert fb == 0
@@ -189,9 +191,11 @@ def test_knn2_mfma_filter_matches_exact_scan_and_falls_back_on_clusters(oracle, 
     np.testing.assert_array_equal(res["bf16"][1], res["valu"][1])
     np.testing.assert_array_equal(res["mfma32"][0], res["valu"][0])
     np.testing.assert_array_equal(res["mfma32"][1], res["valu"][1])
+    np.testing.assert_array_equal(res["f16"][0], res["valu"][0])
+    np.testing.assert_array_equal(res["f16"][1], res["valu"][1])
 
 
-@pytest.mark.parametrize("mode", ["bf16", "mfma32"])
+@pytest.mark.parametrize("mode", ["bf16", "mfma32", "f16"])
 def test_knn2_filter_error_bound_on_wide_range_descriptors(oracle, monkeypatch, mode):
     """The filter certificate rests on |filter score - exact distance| <= eps.  Descriptors with a wide dynamic range (large
     and tiny components, mixed signs, non-unit norms, queries far from and equal to rows) must stay inside it, and the answers
@@ -211,7 +215,16 @@ def test_knn2_filter_error_bound_on_wide_range_descriptors(oracle, monkeypatch, 
     eng.vocab_append(v, ids)
     _check(eng, oracle, v, ids, q)
     r = eng.stats()["knn_max_err_ratio"]
-    assert 0.0 < r < 0.5, r
+    if mode == "f16":                    # components beyond half's range: every query must have gone to the exact scan (and come back exact)
+        assert eng.stats()["knn_last_fallback_queries"] == qn
+        v2 = (v / np.float32(2.0 ** 22)).astype(np.float32)          # the same descriptors scaled into range: filter + certificate again
+        eng2 = rtabmap_amd.Engine("f32", 64, knn_mode=mode)
+        eng2.vocab_append(v2, ids)
+        q2 = (q / np.float32(2.0 ** 22)).astype(np.float32)
+        _check(eng2, oracle, v2, ids, q2)
+        eng2.close()
+    else:
+        assert 0.0 < r < 0.5, r
     eng.close()
 
 
@@ -255,7 +268,7 @@ def test_knn2_one_million_words_properties(oracle):
     v[999_999] = v[pick[0]]                                   # a duplicate far away: the lower row must win the tie
     ids = np.arange(1, n + 1, dtype=np.int32)
     res = {}
-    for mode in ("bf16", "valu"):
+    for mode in ("bf16", "f16", "valu"):
         eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n, knn_mode=mode)
         for a in range(0, n, 250_000):
             eng.vocab_append(v[a:a + 250_000], ids[a:a + 250_000])
@@ -264,6 +277,8 @@ def test_knn2_one_million_words_properties(oracle):
     w, d = res["bf16"]
     np.testing.assert_array_equal(w, res["valu"][0])
     np.testing.assert_array_equal(d, res["valu"][1])
+    np.testing.assert_array_equal(res["f16"][0], res["valu"][0])
+    np.testing.assert_array_equal(res["f16"][1], res["valu"][1])
     first_row = {}
     for r in pick[:250]:
         first_row.setdefault(int(r), int(r))

@@ -21,7 +21,7 @@ def main():
         v = rng.standard_normal((n, 64)).astype(np.float32)
         v /= np.linalg.norm(v, axis=1, keepdims=True)
         qs = v[rng.integers(0, n, q)] + rng.standard_normal((q, 64)).astype(np.float32) * np.float32(0.02)
-        eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n)
+        eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n, knn_mode=os.environ.get("KNN_MODE") or None)
         ids = np.arange(1, n + 1, dtype=np.int32)
         for a in range(0, n, 250_000):
             eng.vocab_append(v[a:a + 250_000], ids[a:a + 250_000])
