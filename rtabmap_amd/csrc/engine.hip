@@ -226,10 +226,12 @@ void refresh_vocab_ptrs(lcd_engine* h, ResolveArgs* r) {
 }
 
 // the append (or, for a frame that appends nothing, the hand-over of the row count) that rides with the decision loop of chain frame `vseq`
-void fill_append(lcd_engine* h, const lcd_frame_args& a, uint64_t vseq, bool enabled, ResolveArgs* r) {
+void fill_append(lcd_engine* h, const lcd_frame_args& a, uint64_t vseq, bool enabled, ResolveArgs* r, uint32_t* list_out = nullptr) {
     AppendArgs& ap = r->ap;
     ap = AppendArgs();
     ap.enabled = enabled ? 1 : 0;
+    // pipelined frames of 64-float rows: the decision loop publishes the list, workgroups of launch B write the rows (append_rows_body)
+    if (list_out && knn_mfma_supported(h->dtype, h->kdim)) { ap.defer_rows = 1; ap.list_out = list_out; }
     ap.descriptors = (const float*)a.d_descriptors; ap.row_dwords = h->row_bytes / 4; ap.is_f32_64 = knn_mfma_supported(h->dtype, h->kdim) ? 1 : 0;
     ap.vocab = h->vocab.as<uint32_t>(); ap.row_id = h->row_id.as<int32_t>(); ap.row_wslot = h->row_wslot.as<int32_t>();
     ap.row_norm = h->row_norm.as<float>(); ap.norm_max_bits = h->norm_max.as<uint32_t>(); ap.vocab_bf = h->vocab_bf.as<uint32_t>();
@@ -438,7 +440,7 @@ void lcd_destroy(lcd_engine* h) {
     h->bayes.destroy();
     for (lcd_engine::FrameScratch& sc : h->ring) {
         DevBuf* all[] = {&sc.d_knn_row, &sc.d_knn_word, &sc.d_knn_dist, &sc.d_selfdist, &sc.d_bits, &sc.d_partial2, &sc.d_partial3, &sc.d_fail_list,
-                         &sc.d_fail_count, &sc.d_out_wslot, &sc.d_qsplit, &sc.d_qnorm};
+                         &sc.d_fail_count, &sc.d_out_wslot, &sc.d_qsplit, &sc.d_qnorm, &sc.d_applist};
         for (DevBuf* d : all) d->release(&h->bytes_device);
     }
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -1297,7 +1299,7 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
         tl_res.r = f_res->r;
         tl_res.r.new_ws = f_res->runs;
         refresh_vocab_ptrs(h, &tl_res.r);
-        if (f_res->chained) fill_append(h, f_res->a, f_res->vseq, frame_appends(h, f_res->a), &tl_res.r);
+        if (f_res->chained) fill_append(h, f_res->a, f_res->vseq, frame_appends(h, f_res->a), &tl_res.r, h->ring[f_res->set].d_applist.as<uint32_t>());
         resolve_launch_info(tl_res.r, pipe_block_size(), &tl_res.n_redo, &tl_res.shmem_resolve);
     }
     if (f_reg) {
@@ -1320,10 +1322,12 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
         h->prof_kernel = knn_bf16_persistent(k.plan) ? "frame_a_kernel_p (persistent bf16 filter of frame t-1 + query pre-split of t + decision loop of t-2 + registration of t-3)"
                                                      : "frame_a_kernel (bf16 filter of frame t-1 + query pre-split of t + decision loop of t-2 + registration of t-3)";
     }
-    LCD_HIP(h, t.flush_held_if_due());
     const bool prof2 = f_knn && reg_like && h->prof_likelihood && h->prof_cap > 0 && h->prof2_n < h->prof_cap;
+    AppendRowsArgs app;
+    if (f_res && tl_res.r.ap.enabled && tl_res.r.ap.defer_rows) { app.ap = tl_res.r.ap; app.new_ws = tl_res.r.new_ws; }
     LCD_HIP(h, launch_frame_b(f_knn ? &k : nullptr, reg_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
-                              prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr));
+                              prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr, app.ap.enabled ? &app : nullptr));
+    LCD_HIP(h, t.flush_held_if_due());                               // (behind launch B: the rows it writes claim their postings keys there)
     if (prof2) { h->prof2_n += 1; h->prof2_kernel = "frame_b_kernel (re-rank of frame t-1 + scoring of frame t-3)"; }
     if (h->clean_armed && f_reg) {
         // cleanUnusedWords asked for behind an earlier frame: the retirements made in front of it rode with the registration of this
@@ -1399,6 +1403,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_knn_word, (size_t)q * 2 * 4));
     LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_knn_dist, (size_t)q * 2 * 4));
     LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_out_wslot, (size_t)q * 4));
+    LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_applist, (size_t)std::max(q, 512) * 4));   // (the re-rank reads 512 entries unconditionally)
     if (together) {
         LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_selfdist, (size_t)q * ld * 4));
         LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_bits, cand_bits_bytes(q, bw)));

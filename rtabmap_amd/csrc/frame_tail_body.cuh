@@ -193,11 +193,106 @@ __device__ __forceinline__ void retire_body(const RetireArgs& r, const uint32_t*
     }
 }
 
+#ifdef LCD_TAIL_TIMING   // timing experiment only: 100 MHz stamps between the phases of the frame tail
+__device__ unsigned long long g_tail_timing[8];
+#define FT_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_tail_timing[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FT_STAMP(i) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------- new words -> vocabulary rows
 // VWDictionary::update()'s append branch for the words the decision loop has just created (AppendArgs, tfidf.h).  `mask` / `prefix`:
 // the loop's final new-word mask and its word prefix sums (LDS); descriptor i created the k-th new word iff its bit is set, k = its
 // rank.  Sixteen lanes per descriptor: lane c moves the 16-byte chunk c, c + 16, ... of the row; for 64-float rows the same lanes
 // produce |row|^2 (any order will do: the filter needs it to ~dim ulps) and the hi / lo bf16 split the matrix-core filter multiplies.
+// one appended row, by the 16 lanes that hold it (lane c: floats [4c, 4c + 4) in x): the vocabulary row, |row|^2 (any order will do: the
+// filter needs it to ~dim ulps), the hi / lo operand split the matrix-core filter multiplies; norm_max collects the largest |row|^2
+__device__ __forceinline__ void append_write_row(const AppendArgs& ap, size_t row, int c, const uint4& x, float& norm_max) {
+    reinterpret_cast<uint4*>(ap.vocab + row * ap.row_dwords)[c] = x;
+    const float f0 = __uint_as_float(x.x), f1 = __uint_as_float(x.y), f2 = __uint_as_float(x.z), f3 = __uint_as_float(x.w);
+    float s2 = fmaf(f3, f3, fmaf(f2, f2, fmaf(f1, f1, f0 * f0)));
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) s2 += __shfl_xor(s2, m, 64);
+    uint2 hi, lo;                                                       // as vocab_bf16_kernel: 64 "hi" then 64 "lo" per row
+    if (ap.f16) { f16_split2_dev(f0, f1, hi.x, lo.x); f16_split2_dev(f2, f3, hi.y, lo.y); }
+    else { bf16_split2_dev(f0, f1, hi.x, lo.x); bf16_split2_dev(f2, f3, hi.y, lo.y); }
+    reinterpret_cast<uint2*>(ap.vocab_bf + row * 64)[c] = hi;
+    reinterpret_cast<uint2*>(ap.vocab_bf + row * 64 + 32)[c] = lo;
+    if (c == 0) {
+        ap.row_norm[2 * row] = s2; ap.row_norm[2 * row + 1] = 1.0f;
+        norm_max = fmaxf(norm_max, s2);                                 // (one atomic per workgroup at the end, not one per row on one address)
+    }
+}
+__device__ __forceinline__ void append_write_ids(const AppendArgs& ap, const WsRuns& new_ws, size_t row, int k) {
+    const int32_t key = new_ws.n > 0 ? ws_runs_at(new_ws, k) : -1;
+    ap.row_id[row] = ap.first_id + k;
+    ap.row_wslot[row] = key;
+    if (key >= 0 && ap.wrow) ap.wrow[key] = (uint32_t)row + 1u;         // the key now belongs to a row: the batched check of superseded
+}                                                                       // reservations must not hand it out again
+__device__ __forceinline__ void append_norm_max(const AppendArgs& ap, float norm_max) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) norm_max = fmaxf(norm_max, __shfl_xor(norm_max, m, 64));
+    if ((threadIdx.x & 63) == 0 && norm_max > 0.0f) atomicMax(ap.norm_max_bits, __float_as_uint(norm_max));
+}
+
+// Deferred append, first half (the decision loop's workgroup, launch A): which descriptors became words, and how many rows there are now.
+template <int NT>
+__device__ __forceinline__ void append_publish(const AppendArgs& ap, int q, const uint32_t* mask, const uint32_t* prefix, int n_in_early) {
+    const int n_in = n_in_early >= 0 ? n_in_early : ap.cnt_in[0];
+    const int mw = (q + 63) / 64 * 2;
+    const int n_new = (int)prefix[mw];
+    const int n_take = (long long)n_in + n_new <= ap.capacity ? n_new : 0;
+    if (n_take > 0)
+        for (int i = threadIdx.x; i < q; i += NT)
+            if ((mask[i >> 5] >> (i & 31)) & 1u) ap.list_out[new_rank(mask, prefix, i)] = (uint32_t)i;
+    if (threadIdx.x == 0) {
+        ap.cnt_out[0] = n_in + n_take;
+        if (ap.log_slot) ap.log_slot[0] = n_take;
+        if (ap.host_mirror) __hip_atomic_store(ap.host_mirror, ((unsigned long long)ap.tag << 32) | (unsigned long long)(uint32_t)(n_in + n_take), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// Deferred append, second half (APPEND_ROW_WGS workgroups of launch B of the same pair): workgroup `wg` writes its share of the rows.
+// stage: LDS staging area (256 B per row, stage_rows of them); without one the rows travel through registers.
+template <int NT>
+__device__ __forceinline__ void append_rows_body(const AppendRowsArgs& A, int wg, float* stage, int stage_rows) {
+    const AppendArgs& ap = A.ap;
+    const int n_in = ap.cnt_in[0], n_new = ap.log_slot[0];
+    const int per = (n_new + A.n_wgs - 1) / A.n_wgs;
+    const int k_lo = min(wg * per, n_new), k_hi = min(k_lo + per, n_new);
+    const int tid = threadIdx.x, c = tid & 15, lane = tid & 63, wave = tid >> 6;
+    constexpr int G = NT / 16;
+    float norm_max = 0.0f;
+    if (ap.is_f32_64 && stage && stage_rows >= 4) {
+        for (int k0 = k_lo; k0 < k_hi; k0 += stage_rows) {
+            const int n_chunk = min(stage_rows, k_hi - k0);
+            for (int i = wave; i * 4 < n_chunk; i += NT / 64) {         // one instruction = four rows = 1 KB of LDS
+                const int k = k0 + min(i * 4 + (lane >> 4), n_chunk - 1);
+                const float* src = ap.descriptors + (size_t)gload(ap.list_out + k) * 64 + (lane & 15) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(stage + (size_t)i * 256), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int k = tid >> 4; k < n_chunk; k += G) {
+                const uint4 x = *reinterpret_cast<const uint4*>(stage + (size_t)k * 64 + c * 4);
+                append_write_row(ap, (size_t)n_in + (size_t)(k0 + k), c, x, norm_max);
+                if (c == 0) append_write_ids(ap, A.new_ws, (size_t)n_in + (size_t)(k0 + k), k0 + k);
+            }
+            if (k0 + stage_rows < k_hi) __syncthreads();
+        }
+    } else {
+        for (int k = k_lo + (tid >> 4); k < k_hi; k += G) {
+            const size_t row = (size_t)n_in + (size_t)k;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(ap.descriptors) + (size_t)gload(ap.list_out + k) * ap.row_dwords;
+            if (ap.is_f32_64) append_write_row(ap, row, c, reinterpret_cast<const uint4*>(src)[c], norm_max);
+            else { uint32_t* dst = ap.vocab + row * ap.row_dwords; for (int d = c; d < ap.row_dwords; d += 16) dst[d] = src[d]; }
+            if (c == 0) append_write_ids(ap, A.new_ws, row, k);
+        }
+    }
+    if (ap.is_f32_64) append_norm_max(ap, norm_max);
+}
+
 template <int NT>
 __device__ __forceinline__ void append_new_rows(const AppendArgs& ap, int q, const uint32_t* mask, const uint32_t* prefix, const WsRuns& new_ws,
                                                 uint32_t* list /* LDS scratch, q words */,
@@ -212,30 +307,9 @@ __device__ __forceinline__ void append_new_rows(const AppendArgs& ap, int q, con
     for (int i = tid; i < q; i += NT)
         if ((mask[i >> 5] >> (i & 31)) & 1u) list[new_rank(mask, prefix, i)] = (uint32_t)i;
     __syncthreads();
-    auto finish_row = [&](int k, const uint4& x) {                      // lane c of the row's 16-lane group holds floats [4c, 4c + 4)
-        const size_t row = (size_t)n_in + (size_t)k;
-        reinterpret_cast<uint4*>(ap.vocab + row * ap.row_dwords)[c] = x;
-        const float f0 = __uint_as_float(x.x), f1 = __uint_as_float(x.y), f2 = __uint_as_float(x.z), f3 = __uint_as_float(x.w);
-        float s2 = fmaf(f3, f3, fmaf(f2, f2, fmaf(f1, f1, f0 * f0)));
-#pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) s2 += __shfl_xor(s2, m, 64);
-        uint2 hi, lo;                                                   // as vocab_bf16_kernel: 64 bf16 "hi" then 64 bf16 "lo" per row
-        if (ap.f16) { f16_split2_dev(f0, f1, hi.x, lo.x); f16_split2_dev(f2, f3, hi.y, lo.y); }
-        else { bf16_split2_dev(f0, f1, hi.x, lo.x); bf16_split2_dev(f2, f3, hi.y, lo.y); }
-        reinterpret_cast<uint2*>(ap.vocab_bf + row * 64)[c] = hi;
-        reinterpret_cast<uint2*>(ap.vocab_bf + row * 64 + 32)[c] = lo;
-        if (c == 0) {
-            ap.row_norm[2 * row] = s2; ap.row_norm[2 * row + 1] = 1.0f;
-            atomicMax(ap.norm_max_bits, __float_as_uint(s2));
-        }
-    };
-    auto finish_ids = [&](int k) {
-        const size_t row = (size_t)n_in + (size_t)k;
-        const int32_t key = new_ws.n > 0 ? ws_runs_at(new_ws, k) : -1;
-        ap.row_id[row] = ap.first_id + k;
-        ap.row_wslot[row] = key;
-        if (key >= 0 && ap.wrow) ap.wrow[key] = (uint32_t)row + 1u;     // the key now belongs to a row: the batched check of
-    };                                                                  // superseded reservations must not hand it out again
+    float norm_max = 0.0f;
+    auto finish_row = [&](int k, const uint4& x) { append_write_row(ap, (size_t)n_in + (size_t)k, c, x, norm_max); };
+    auto finish_ids = [&](int k) { append_write_ids(ap, new_ws, (size_t)n_in + (size_t)k, k); };
     constexpr int G = NT / 16;                                          // 16-lane groups
     if (ap.is_f32_64 && stage && stage_rows >= 4) {
         // Loads and stores share one in-order counter on this architecture: a loop that loads a few rows, writes them out and loads the
@@ -251,8 +325,10 @@ __device__ __forceinline__ void append_new_rows(const AppendArgs& ap, int q, con
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(stage + (size_t)i * 256), 16, 0, 0);
             }
+            FT_STAMP(2);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            FT_STAMP(3);
             for (int k = tid >> 4; k < n_chunk; k += G) {
                 const uint4 x = *reinterpret_cast<const uint4*>(stage + (size_t)k * 64 + c * 4);
                 finish_row(k0 + k, x);
@@ -284,6 +360,7 @@ __device__ __forceinline__ void append_new_rows(const AppendArgs& ap, int q, con
             }
         }
     }
+    if (ap.is_f32_64 && n_take > 0) append_norm_max(ap, norm_max);      // the running maximum of |row|^2 (the filters' error bound uses it)
     if (tid == 0) {
         const int n_out = n_in + n_take;
         if (ap.is_f32_64) { ap.row_norm[2 * (size_t)n_out] = __int_as_float(0x7f800000); ap.row_norm[2 * (size_t)n_out + 1] = 1.0f; }   // sentinel
@@ -303,13 +380,6 @@ __device__ __forceinline__ void append_pass_on(const AppendArgs& ap) {
                                                __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-
-#ifdef LCD_TAIL_TIMING   // timing experiment only: 100 MHz stamps between the phases of the frame tail
-__device__ unsigned long long g_tail_timing[8];
-#define FT_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_tail_timing[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define FT_STAMP(i) do { } while (0)
-#endif
 
 // The single-workgroup tail of a frame in ONE launch: addNewWords decision loop (resolve_body.cuh) -> pending retirements
 // -> unique words / registration / idf (frame_words_body).  Saves two dependent kernel boundaries per frame.
@@ -377,7 +447,8 @@ __device__ __forceinline__ void frame_resolve_part(uint32_t* ft_dyn_smem, const 
     else fmask = resolve_body<NT>(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
                                   r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
     if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; r.fail_count[3] = 0; }
-    if (r.ap.enabled) {
+    if (r.ap.enabled && r.ap.defer_rows) append_publish<NT>(r.ap, r.q, fmask, ft_dyn_smem + 2 * ((r.q + 63) / 64 * 2), n_in_early);
+    else if (r.ap.enabled) {
         // the staging area of the new rows lies behind the appender's list, 16-byte aligned; its size comes from the launch (ap.lds_bytes)
         const int used = (3 * ((r.q + 63) / 64 * 2) + 4 + r.q + 3) & ~3;
         const int rows = (r.ap.lds_bytes / 4 - used) / 64;

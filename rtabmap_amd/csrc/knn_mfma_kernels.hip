@@ -1207,6 +1207,12 @@ __global__ __launch_bounds__((BF_QB / (NG * 32)) * 64) void knn_bf16_filter_kern
 // KEEP keys per (row block, query); LAST_KEY_BOUNDS: the block's last kept key also bounds what its merge dropped (f32 filter);
 // BF16: the keys come from the bf16x3 filter (eps_bf16).  fail_count[2] collects max |score - distance| / eps (diagnostics).
 constexpr int RR_MAX_CAND = 128;
+#ifdef LCD_B_TIMING   // timing experiment only: phases of the re-rank workgroups of launch B (100 MHz), without extra barriers
+__device__ unsigned long long g_rr_timing[8 * 512];
+#define RR_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 512) g_rr_timing[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RR_STAMP(i) do { } while (0)
+#endif
 // HALVES = 2: a workgroup of 2 x MF_BLOCK threads re-ranks TWO queries (qi_first, qi_first + 1), one per half -- launch B of a
 // pipelined frame runs with 512-thread workgroups because its scoring half needs eight waves per bucket (a 4-wave scoring workgroup
 // takes twice as long), and a re-rank workgroup that used only half of its threads idled the other.  The halves share nothing but the
@@ -1224,13 +1230,20 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                                                      int pend_cap = 0x7fffffff /* rows the filter's launch plan covered */,
                                                      float* stage = nullptr, int stage_rows = 0 /* LDS staging area of the pending rows (256 B each,
                                                      a multiple of 4), shared by the halves of the workgroup */,
-                                                     int f16 = 0 /* the keys come from the one-product fp16 filter (eps_f16) */) {
+                                                     int f16 = 0 /* the keys come from the one-product fp16 filter (eps_f16) */,
+                                                     const float* __restrict__ pend_desc = nullptr, const uint32_t* __restrict__ pend_list = nullptr,
+                                                     int32_t pend_first_id = 0
+                                                     /* rows at or beyond pend_lo[0] are not vocabulary rows yet (a deferred append writes them in this
+                                                        very launch): row pend_lo[0] + j is descriptor pend_list[j] of pend_desc, word pend_first_id + j */) {
     static_assert(DIM == 64, "16 lanes x 4 floats per candidate row");
     // rows [pend_lo[0], pend_hi[0]): words the previous frame created, appended on the device after this frame's filter took its
     // snapshot of the vocabulary (VWDictionary::update() of a pipelined handle).  They are scanned exactly here, so the result is
     // the 2-NN over the vocabulary as update() leaves it before this frame.
     // (the plan is made for an ESTIMATE of the row count: what lies between the rows it covered and the device's count is scanned here too)
-    const int p_lo = pend_lo ? min(pend_lo[0], pend_cap) : 0, p_hi = pend_hi ? pend_hi[0] : 0;
+    const int n_lo0 = pend_lo ? pend_lo[0] : 0;
+    const int p_lo = pend_lo ? min(n_lo0, pend_cap) : 0, p_hi = pend_hi ? pend_hi[0] : 0;
+    __shared__ uint32_t s_plist[HALVES * MF_BLOCK];                    // the first entries of pend_list (one per thread: read with the keys)
+    const uint32_t plreg = pend_list ? pend_list[threadIdx.x] : 0u;    // (the list buffer holds at least HALVES * MF_BLOCK entries)
     const int hf = HALVES == 2 ? (int)threadIdx.x / MF_BLOCK : 0;
     const int tid = HALVES == 2 ? (int)threadIdx.x % MF_BLOCK : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // The pending rows are the same for every query: with a staging area they come in by LDS-DMA -- no registers, requested HERE, a
@@ -1240,10 +1253,21 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     // sixteen consecutive rows touch sixteen different positions (no bank conflict)
     auto stage_chunk = [&](int first, int n_chunk) {
         const int wv = (int)threadIdx.x >> 6, ln = (int)threadIdx.x & 63;
-        for (int i = wv; i * 4 < n_chunk; i += HALVES * MF_WAVES) {      // one instruction = four rows = 1 KB of LDS
+        // every re-rank workgroup of the launch wants the SAME rows at the same moment: each starts at another row (rotation by workgroup
+        // index), so that at any time the requests spread over all the L2 channels instead of queueing at one
+        const int n_inst = (n_chunk + 3) / 4;
+        const int rot = (int)(((unsigned)blockIdx.x * 13u) % (unsigned)n_inst);
+        for (int i0 = wv; i0 < n_inst; i0 += HALVES * MF_WAVES) {        // one instruction = four rows = 1 KB of LDS
+            const int i = i0 + rot < n_inst ? i0 + rot : i0 + rot - n_inst;
             const int rl = min(i * 4 + (ln >> 4), n_chunk - 1);          // (the rows of a partial last group repeat the chunk's last row)
             const int chunk = (ln & 15) ^ ((i * 4 + (ln >> 4)) & 15);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vocab + (size_t)(first + rl) * DIM + chunk * 4),
+            const int r = first + rl;
+            const float* src = vocab + (size_t)r * DIM;
+            if (pend_list && r >= n_lo0) {                               // a row that is being written in this launch: its descriptor
+                const int j = r - n_lo0;
+                src = pend_desc + (size_t)(j < HALVES * MF_BLOCK ? s_plist[j] : pend_list[j]) * DIM;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + chunk * 4),
                                              (__attribute__((address_space(3))) void*)(stage + (size_t)i * 256), 16, 0, 0);
         }
     };
@@ -1276,6 +1300,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     // Everything that does not depend on other loads is requested up front (the kernel is a chain of round trips): the first two
     // keys and the first bound of every thread, the query slice, the vocabulary norm bound and -- for the candidate bits -- the
     // thread's two entries of the query's row of the same-frame distance matrix.
+    RR_STAMP(0);
     const uint64_t kreg0 = tid < n_keys ? key_at(tid) : KEY_NONE;
     const uint64_t kreg1 = tid + MF_BLOCK < n_keys ? key_at(tid + MF_BLOCK) : KEY_NONE;
     const uint32_t breg0 = tid < n_blocks ? bound_at(tid) : INF;
@@ -1314,9 +1339,11 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     if (tid == 0) s_ncand = 0;
     // the pending rows are requested here -- behind the keys, which have arrived, and in front of pass 2's row reads, whose round trip
     // they share (a request in front of the keys would make the first use of a key wait for the whole chunk: the counter is in-order)
+    if (pend_list) { s_plist[threadIdx.x] = plreg; lds_barrier(); }
     if (staged) stage_chunk(p_lo, min(stage_rows, p_hi - p_lo));
     if (staged && lane < 16 && wave == 0) reinterpret_cast<float4*>(stage + (size_t)stage_rows * DIM)[hf * 16 + lane] = q4;   // the query, for every lane
-    __syncthreads();
+    lds_barrier();                                                     // (LDS traffic only: __syncthreads() would also wait for the rows just requested)
+    RR_STAMP(1);
     a0 = s_a0[0]; a1 = s_a1[0]; bound = s_bound[0];
 #pragma unroll
     for (int w = 1; w < MF_WAVES; ++w) {
@@ -1340,7 +1367,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     take(kreg0);
     take(kreg1);
     for (int c = tid + 2 * MF_BLOCK; c < n_keys; c += MF_BLOCK) take(key_at(c));
-    __syncthreads();
+    lds_barrier();
+    RR_STAMP(2);
     const int n_cand = s_ncand;
     const bool overflow = n_cand > RR_MAX_CAND;
     // ... get their exact distances (reference arithmetic, dist.h:150-177), one candidate per 16-lane group and trip; the word
@@ -1370,6 +1398,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) err_ratio = fmaxf(err_ratio, __shfl_xor(err_ratio, m, 64));
     if (lane == 0) s_err[wave] = err_ratio;
+    RR_STAMP(3);
     {   // the pending rows, sixteen lanes each, in the reference's arithmetic
         uint64_t pb = KEY_NONE, ps = KEY_NONE;
         constexpr int PU = 4;                                          // rows per 16-lane group and trip: their loads are in flight together (more
@@ -1380,6 +1409,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                 if (c0 > p_lo) { __syncthreads(); stage_chunk(c0, n_chunk); }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                RR_STAMP(4);
                 // ONE LANE PER ROW: the sixteen 4-float terms are formed and added by the same lane in the reference's order (dist.h:150-177),
                 // the row's chunks from LDS, the query's as a broadcast read -- no cross-lane traffic (sixteen lanes per row gathered the
                 // terms with sixteen ds_bpermute per row: at ~150 pending rows per query that was the whole cost of the scan)
@@ -1401,7 +1431,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                 }
             }
         } else
-        for (int base = p_lo; base < p_hi; base += PU * (MF_BLOCK / 16)) {
+        for (int base = p_lo; base < (pend_list ? min(p_hi, n_lo0) : p_hi); base += PU * (MF_BLOCK / 16)) {   // (rows of a deferred append need the staged path)
             float4 v4[PU];
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
@@ -1432,7 +1462,9 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
             if (lane == 0) { s_pend[wave][0] = pb; s_pend[wave][1] = ps; }
         }
     }
+    RR_STAMP(5);
     __syncthreads();
+    RR_STAMP(6);
     // the two best (distance, row) keys: ties go to the lower ROW (result_set.h:151-171), so the comparison key carries the row
     uint64_t best = KEY_NONE, second = KEY_NONE;
     int sbest = -1, ssecond = -1;
@@ -1476,7 +1508,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
             if (k[j] == KEY_NONE) { out_row[2 * qi + j] = -1; out_word[2 * qi + j] = 0; out_dist[2 * qi + j] = -1.0f; }
             else {
                 out_row[2 * qi + j] = (int32_t)(uint32_t)k[j];
-                out_word[2 * qi + j] = sl[j] >= 0 ? s_word[sl[j]] : row_id[(uint32_t)k[j]];
+                const int32_t rw = (int32_t)(uint32_t)k[j];
+                out_word[2 * qi + j] = sl[j] >= 0 ? s_word[sl[j]] : ((pend_list && rw >= n_lo0) ? pend_first_id + (rw - n_lo0) : row_id[rw]);
                 out_dist[2 * qi + j] = __uint_as_float((uint32_t)(k[j] >> 32));
             }
         }
@@ -1553,6 +1586,7 @@ struct RerankArgs {
     const int32_t* n_lo; const int32_t* n_hi; int plan_rows;
     int stage_rows;                                                    // rows the launch's dynamic LDS stages (0: none)
     int f16;                                                           // the filter multiplied fp16 operands (one product): eps_f16
+    const float* pend_desc; const uint32_t* pend_list; int32_t pend_first_id;   // the rows a deferred append writes in this launch, as descriptors
 };
 constexpr int PIPE_BLOCK = 256;     // workgroup size of both fused launches (the filter's and the re-rank's)
 
@@ -1607,9 +1641,15 @@ __device__ unsigned long long g_b_timing[2 * 4096];
 constexpr int PIPE_B_BLOCK = 512;   // workgroup size of launch B: eight waves per sealed bucket, two queries per re-rank workgroup
 constexpr uint32_t PIPE_B_STAGE_ROWS = 160;   // pending rows a re-rank workgroup stages in LDS at a time
 static_assert(PIPE_B_BLOCK == 2 * MF_BLOCK, "the re-rank halves");
-__global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, int n_rerank_wgs, ScoreArgs A) {
+__global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, int n_rerank_wgs, ScoreArgs A, int n_score_wgs, AppendRowsArgs app) {
     const int bid = (int)blockIdx.x;
     B_STAMP(0);
+    if (bid >= n_rerank_wgs + n_score_wgs) {                             // the rows the decision loop of launch A published (deferred append)
+        extern __shared__ __attribute__((aligned(16))) float s_dyn_b2[];
+        append_rows_body<PIPE_B_BLOCK>(app, bid - n_rerank_wgs - n_score_wgs, app.ap.lds_bytes >= 1024 ? s_dyn_b2 : nullptr, (app.ap.lds_bytes / 256) & ~3);
+        B_STAMP(1);
+        return;
+    }
     if (bid < n_rerank_wgs) {                                            // (a multiple of 8: see launch_frame_b)
         // consecutive query pairs on one XCD: eight queries share a 128-byte line of the block-major candidate records
         const int pair = (bid & 7) * (n_rerank_wgs >> 3) + (bid >> 3);
@@ -1617,7 +1657,7 @@ __global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, 
         extern __shared__ __attribute__((aligned(16))) float s_dyn_b[];
         knn_mfma_rerank_body<64, BF_KEEP, false, true, 2>(2 * pair, k.pk, k.pl, k.n_blocks, k.nq, k.vocab, k.queries, k.row_id, k.norm_max_bits, k.out_row,
                                                           k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb, k.n_lo, k.n_hi, k.plan_rows,
-                                                          s_dyn_b, k.stage_rows, k.f16);
+                                                          s_dyn_b, k.stage_rows, k.f16, k.pend_desc, k.pend_list, k.pend_first_id);
         B_STAMP(1);
         return;
     }
@@ -1641,6 +1681,10 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_rowpar_kernel(RowparArgs a, int3
 extern "C" int lcd_debug_a_timing(unsigned long long* out, int n_words) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcd::g_a_timing), (size_t)n_words * 8);
+}
+extern "C" int lcd_debug_rr_timing(unsigned long long* out, int n_words) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcd::g_rr_timing), (size_t)n_words * 8);
 }
 extern "C" int lcd_debug_b_timing(unsigned long long* out, int n_words) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
@@ -1973,7 +2017,8 @@ hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLa
     return hipGetLastError();
 }
 
-hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wgs, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end) {
+hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wgs, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
+                          const AppendRowsArgs* app) {
     RerankArgs rk{};
     int n_rerank = 0;
     if (k) {
@@ -1987,14 +2032,19 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
     }
     ScoreArgs A{};
     if (score) A = *score; else score_wgs = 0;
-    if (n_rerank + score_wgs == 0) return hipSuccess;
+    AppendRowsArgs ar{};
+    int n_app = 0;
+    if (app && app->ap.enabled && app->ap.defer_rows) { ar = *app; n_app = ar.n_wgs = APPEND_ROW_WGS; }
+    if (n_rerank + score_wgs + n_app == 0) return hipSuccess;
     // frames that append their words on the device: 40 KB of dynamic LDS stage 160 pending rows per re-rank workgroup (three workgroups
-    // of launch B share a compute unit: 3 x (40 + 8) KB of its 160 KB)
-    const uint32_t dyn = (k && k->n_hi) ? PIPE_B_STAGE_ROWS * 256u + 512u : 0u;   // + the workgroup's two queries
-    rk.stage_rows = dyn ? (int)PIPE_B_STAGE_ROWS : 0;
+    // of launch B share a compute unit: 3 x (40 + 10) KB of its 160 KB); the workgroups that write appended rows stage them there too
+    const uint32_t dyn = ((k && k->n_hi) || n_app) ? PIPE_B_STAGE_ROWS * 256u + 512u : 0u;   // + the workgroup's two queries
+    rk.stage_rows = (dyn && k && k->n_hi) ? (int)PIPE_B_STAGE_ROWS : 0;
+    ar.ap.lds_bytes = (int)(PIPE_B_STAGE_ROWS * 256u);
+    if (k && n_app) { rk.pend_desc = ar.ap.descriptors; rk.pend_list = ar.ap.list_out; rk.pend_first_id = ar.ap.first_id; }   // k's pending rows ARE the rows being written
     if (ev_begin != nullptr && ev_end != nullptr)
-        hipExtLaunchKernelGGL(frame_b_kernel, dim3(n_rerank + score_wgs), dim3(PIPE_B_BLOCK), dyn, s, ev_begin, ev_end, 0u, rk, n_rerank, A);
-    else frame_b_kernel<<<n_rerank + score_wgs, PIPE_B_BLOCK, dyn, s>>>(rk, n_rerank, A);
+        hipExtLaunchKernelGGL(frame_b_kernel, dim3(n_rerank + score_wgs + n_app), dim3(PIPE_B_BLOCK), dyn, s, ev_begin, ev_end, 0u, rk, n_rerank, A, score_wgs, ar);
+    else frame_b_kernel<<<n_rerank + score_wgs + n_app, PIPE_B_BLOCK, dyn, s>>>(rk, n_rerank, A, score_wgs, ar);
     return hipGetLastError();
 }
 

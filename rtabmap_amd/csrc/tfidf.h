@@ -117,9 +117,19 @@ struct AppendArgs {
     long long capacity = 0;                    // rows the buffers hold: appends beyond are dropped (cannot happen: the host reserves q per frame)
     int lds_bytes = 0;                         // dynamic LDS of the workgroup that appends (launch A of a pipelined frame): what the decision loop's
                                                // own tables leave of it stages the new rows (0: no staging)
+    // defer_rows (pipelined frames): the decision loop's workgroup only PUBLISHES which descriptors became words (list_out[k] = index of the
+    // k-th new word's descriptor) and the new row count; the rows themselves -- copy, |row|^2, operand split, ids, keys -- are written by a
+    // few workgroups of launch B of the same pair (append_rows_body), off the single-workgroup chain that bounds launch A.  The re-rank of
+    // the next frame, which runs in that same launch B, reads its pending rows straight from the descriptors through the same list.
+    int defer_rows = 0;
+    uint32_t* list_out = nullptr;
     unsigned long long* host_mirror = nullptr; // pinned: (tag << 32 | rows) after this append, read by the host WITHOUT synchronising to
     uint32_t tag = 0;                          // bound the row count it plans the next launches for
 };
+
+// the row-writing half of a deferred append (launch B): the appender's arguments + the postings keys of the frame's new words
+struct AppendRowsArgs { AppendArgs ap; WsRuns new_ws; int n_wgs = 0; };
+constexpr int APPEND_ROW_WGS = 8;          // workgroups of launch B that write the rows a frame appended
 
 // arguments of the addNewWords decision loop (resolve_body.cuh) when it is fused into the frame-words launch
 struct ResolveArgs {
@@ -190,8 +200,9 @@ void resolve_launch_info(const ResolveArgs& r, int block, int* n_redo, size_t* s
 // k: the frame whose filter runs (NULL: none); qs: the frame whose queries are pre-split for the NEXT launch's filter (NULL: none)
 hipError_t launch_frame_a(const PipeKnn* k, const QSplitArgs* qs, const TailLaunch* resolve, const TailLaunch* reg, hipStream_t s,
                           hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+// app: the rows the decision loop of launch A of this pair published (NULL: none); they are also the pending rows of k's re-rank
 hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wgs, hipStream_t s, hipEvent_t ev_begin = nullptr,
-                          hipEvent_t ev_end = nullptr);
+                          hipEvent_t ev_end = nullptr, const AppendRowsArgs* app = nullptr);
 
 // recycled allocations of bucket-sized device buffers (a bucket is born and dies every 256 frames in steady state:
 // hipMalloc / hipFree there would synchronise the device)

@@ -99,6 +99,14 @@ def main():
                     print("  %-8s start min %5.2f median %5.2f max %5.2f | end median %5.2f p90 %5.2f max %5.2f | duration median %5.2f p90 %5.2f max %5.2f" %
                           (nme, st.min(), np.median(st), st.max(), np.median(en), np.percentile(en, 90), en.max(), np.median(en - st),
                            np.percentile(en - st, 90), (en - st).max()))
+        if hasattr(lib, "lcd_debug_rr_timing") and rep == 5:
+            rr = (ctypes.c_ulonglong * (8 * 512))()
+            assert lib.lcd_debug_rr_timing(rr, 8 * 512) == 0
+            t8 = np.frombuffer(rr, dtype=np.uint64).reshape(-1, 8).astype(np.float64)[:250, :7]
+            t8 = (t8 - t8[:, :1]) / 100.0
+            print("re-rank phases, 250 workgroups, median / p90 us after the workgroup's first stamp: " +
+                  " | ".join("%s %.2f/%.2f" % (nme, np.median(t8[:, i]), np.percentile(t8[:, i], 90)) for i, nme in
+                             [(1, "keys in, pass 1"), (2, "candidates chosen"), (3, "exact rows done"), (4, "pending rows staged"), (5, "pending scanned"), (6, "barrier")]))
         if rep == 5:
             rb = np.array(tb[8:16], dtype=np.float64); ft = np.array(tb[0:8], dtype=np.float64)
             print("decision loop stamps (us after its first): " + " ".join("%.2f" % ((x - rb[0]) / 100.0) for x in rb[:6]) +
