@@ -43,6 +43,9 @@ PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
 
 
 DIAG = set()
+# the matrix-core filter of every SURF engine of this run: the one-product fp16 filter (LCD_KNN_F16, what the north star names for the SURF
+# L2-distance GEMM) unless --knn-mode says otherwise; every mode returns the same bits (exact re-rank + certificate + exact redo)
+KNN_MODE = "f16"
 
 
 def log(*a):
@@ -287,12 +290,13 @@ def rooflines(eng, n_rows_rank, n_sig, shard, knn=None):
     kern_ms, kern_n, kern_name = eng.profile_read() if knn is None else knn
     flops = 2.0 * Q * n_rows_rank * DIM           # ALGORITHMIC work per launch: GEMM-equivalent 2*Q*N*D
     achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-    bf16 = "bf16" in kern_name
+    f16 = "fp16" in kern_name
+    bf16 = "bf16" in kern_name or f16              # (the dense fp16 and bf16 matrix peaks are the same figure)
     peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
     roof_knn = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": pmc_traffic(kern_name), "traffic_unit": "GB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)", "kernel": kern_name,
-                "ms": kern_ms, "samples": kern_n, "mfma_dtype": "bf16 (3 products per fp32 product, fp32 accumulate)" if bf16 else "f32",
-                "executed_tflops": (3.0 if bf16 else 1.0) * achieved, "frac_of_f32_mfma_peak": achieved / PEAK_F32_TFLOPS,
+                "ms": kern_ms, "samples": kern_n, "mfma_dtype": ("fp16 (1 product per fp32 product, fp32 accumulate)" if f16 else "bf16 (3 products per fp32 product, fp32 accumulate)") if bf16 else "f32",
+                "executed_tflops": (3.0 if (bf16 and not f16) else 1.0) * achieved, "frac_of_f32_mfma_peak": achieved / PEAK_F32_TFLOPS,
                 "algorithmic_gbps": (n_rows_rank * DIM * 4 + Q * DIM * 4 + Q * 16) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0}
     roof_score = None
     if sc_ms > 0:
@@ -329,7 +333,7 @@ def parity_block(torch, vocab, words, frames_np, m, n_frames=3):
     (preUpdate: cleanUnusedWords + VWDictionary::update(), then addNewWords) -> computeLikelihood."""
     import rtabmap_amd
     n_sig = words.shape[0]
-    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 64, pipeline=1)
+    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 64, pipeline=1, knn_mode=KNN_MODE)
     load_engine(eng, vocab, words)
     cap = n_sig + 16
     d_desc = [torch.from_numpy(frames_np[t]).cuda() for t in range(n_frames)]
@@ -806,7 +810,7 @@ def run_replay(args):
                      for v in range(V) for p in range(P)])                         # [V * P, q, 64]: view v of place p at v * P + p
     d_pool = torch.from_numpy(pool).cuda()
     stream = torch.cuda.Stream()
-    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=N_WORDS + V * P * q // 2, sig_capacity=n_total + 4096, stream=stream.cuda_stream, pipeline=1)
+    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=N_WORDS + V * P * q // 2, sig_capacity=n_total + 4096, stream=stream.cuda_stream, pipeline=1, knn_mode=KNN_MODE)
     eng.vocab_append(vocab, np.arange(1, N_WORDS + 1, dtype=np.int32))
     cap = n_total + 64
     depth = eng.pipeline_depth() + 1
@@ -1017,12 +1021,15 @@ def main():
     ap.add_argument("--config", choices=["headline", "orb_stream", "replay"], default="headline")
     ap.add_argument("--score-block", type=int, default=0, help="experiment: threads per workgroup of the scoring kernel (256/512/1024)")
     ap.add_argument("--knn-mode", default=None, choices=["bf16", "f16", "mfma32", "valu"],
-                    help="the 2-NN filter of the timed engine (default: bf16x3; f16 = the one-product fp16 filter, LCD_KNN_F16)")
+                    help="the 2-NN filter of every SURF engine of the run (default: f16 = the one-product fp16 matrix-core filter, LCD_KNN_F16; "
+                         "bf16 = the library's default, three bf16 products per fp32 product)")
     ap.add_argument("--diag", default="", help="diagnostics only (not the benchmark): comma list of no-new (new words get no references), "
                     "no-retire (the oldest signature is not retired)")
     args = ap.parse_args()
 
     DIAG.update(x for x in args.diag.split(",") if x)
+    if args.knn_mode:
+        globals()["KNN_MODE"] = args.knn_mode
     if args.words != N_WORDS:
         globals()["N_WORDS"] = args.words
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1108,7 +1115,7 @@ def main():
         src, frames_np = make_frames(rank)                 # replicas: every rank has its own stream of frames
         d_frames = [torch.from_numpy(f).cuda() for f in frames_np]
         eng = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 65536, sig_capacity=n_sig + 8192,
-                                 stream=stream.cuda_stream, pipeline=args.pipeline, knn_mode=args.knn_mode)
+                                 stream=stream.cuda_stream, pipeline=args.pipeline, knn_mode=KNN_MODE)
         if args.score_block:
             eng.set_option("score_block", args.score_block)
         for kv in filter(None, os.environ.get("LCD_BENCH_OPTS", "").split(",")):      # timing experiments: key=value engine options
@@ -1143,7 +1150,8 @@ def main():
               "step_ms_median": float(np.median(res["per_step_ms"])) if res["per_step_ms"].size else None,
               "step_ms_p95": float(np.percentile(res["per_step_ms"], 95)) if res["per_step_ms"].size else None,
               "world_size_observed": world, "collective_backend": backend, "signatures_bulk_load_s": build_s,
-              "knn_filter": args.knn_mode or "bf16 (three products per fp32 product)",
+              "knn_filter": {"f16": "fp16 matrix-core filter, one product per fp32 product (LCD_KNN_F16) + exact fp32 re-rank + certificate",
+                             "bf16": "bf16 matrix-core filter, three products per fp32 product (LCD_KNN_BF16X3) + exact fp32 re-rank + certificate"}.get(KNN_MODE, KNN_MODE),
               "pipeline": "software-pipelined frames, four in flight: 2 launches per frame (A: query pre-split of frame t + filter of t-1 + decision loop "
                           "of t-2 + registration of t-3; B: re-rank of frame t-1 + scoring of t-3), one stream; the step includes VWDictionary::update()'s append branch on the device (append_new_words): the vocabulary "
                           "grows by the frame's new words before the next frame is searched" if (args.pipeline and not shard) else "4 launches per frame, one stream",
@@ -1168,7 +1176,7 @@ def main():
                 src2, fr2 = make_frames(rank)
                 d_fr2 = [torch.from_numpy(f).cuda() for f in fr2]
                 eng2 = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 1024, sig_capacity=n_sig + 8192,
-                                          stream=stream.cuda_stream, pipeline=args.pipeline)
+                                          stream=stream.cuda_stream, pipeline=args.pipeline, knn_mode=KNN_MODE)
                 load_engine(eng2, vocab, words)
                 st2 = Stepper(eng2, torch, d_fr2, n_sig, cap)
                 r2 = timed_loop(torch, dist, world, stream, st2, args.steps, args.warmup, eng=eng2)
@@ -1207,7 +1215,7 @@ def main():
     if world == 1 and rank == 0:
         if not args.no_extras:
             engu = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 8192,
-                                      stream=stream.cuda_stream, pipeline=0 if args.pipeline else 1)
+                                      stream=stream.cuda_stream, pipeline=0 if args.pipeline else 1, knn_mode=KNN_MODE)
             if args.score_block:
                 engu.set_option("score_block", args.score_block)
             load_engine(engu, vocab, words)
@@ -1223,7 +1231,7 @@ def main():
                 out["roofline_score_standalone"] = su
             config["host_path_ms_per_step"] = host_path_ms(torch, engu, frames_np, n_sig)
             engw = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 65536, sig_capacity=n_sig + 8192,
-                                      stream=stream.cuda_stream, pipeline=args.pipeline)
+                                      stream=stream.cuda_stream, pipeline=args.pipeline, knn_mode=KNN_MODE)
             load_engine(engw, vocab, words)
             stw = Stepper(engw, torch, d_frames, n_sig, cap)
             wu, wrows, wlive = with_update_ms(torch, engw, stw)
@@ -1234,7 +1242,7 @@ def main():
                                          "vocabulary at the end: %d rows, %d live" % (wrows, wlive)
             engw.close()
             engn = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 8192,
-                                      stream=stream.cuda_stream, pipeline=args.pipeline)
+                                      stream=stream.cuda_stream, pipeline=args.pipeline, knn_mode=KNN_MODE)
             load_engine(engn, vocab, words)
             stn = Stepper(engn, torch, d_frames, n_sig, cap, append=False)
             rn = timed_loop(torch, dist, 1, stream, stn, args.steps, args.warmup, eng=engn, per_step_events=False)
@@ -1257,7 +1265,7 @@ def main():
             config["host_path_note"] = "lcd_quantize + lcd_sig_add + lcd_likelihood + lcd_sig_remove from host pointers (PCIe + syncs included)"
             engu.close()
             engb = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 8192,
-                                      stream=stream.cuda_stream, pipeline=args.pipeline)
+                                      stream=stream.cuda_stream, pipeline=args.pipeline, knn_mode=KNN_MODE)
             load_engine(engb, vocab, words)
             stb = BayesStepper(engb, torch, d_frames, n_sig, cap)
             rb = timed_loop(torch, dist, 1, stream, stb, max(50, min(args.steps, 200)), 10, eng=engb, per_step_events=False)

@@ -158,6 +158,8 @@ class Engine:
         self.dtype = LCD_F32 if dtype in (LCD_F32, np.float32, "f32") else LCD_U8
         self.np_dtype = np.float32 if self.dtype == LCD_F32 else np.uint8
         self.dim = int(dim)
+        if knn_mode is None:                              # test runs of the whole suite on another filter (this glue only: the library reads no environment)
+            knn_mode = os.environ.get("LCD_PY_KNN_MODE") or None
         mode = KNN_MODES[knn_mode] if (knn_mode is None or isinstance(knn_mode, str)) else int(knn_mode)
         cfg = LcdConfig(C.sizeof(LcdConfig), device, self.dtype, self.dim, vocab_capacity, sig_capacity, 0, mode, stream,
                         1 if pipeline else 0, 0)

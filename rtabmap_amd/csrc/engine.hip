@@ -118,7 +118,8 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
                                    h->kst, prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr,
                                    !h->fail_count_clean, cb, cb != nullptr));
         h->fail_count_clean = false;
-        if (prof) { h->prof_n += 1; h->prof_kernel = knn_bf16_persistent(mp) ? "knn_bf16_filter_kernel_p" : "knn_bf16_filter_kernel"; }
+        if (prof) { h->prof_n += 1; h->prof_kernel = h->f16() ? (knn_bf16_persistent(mp) ? "knn_bf16_filter_kernel_p (fp16 operands)" : "knn_bf16_filter_kernel (fp16 operands)")
+                                                             : (knn_bf16_persistent(mp) ? "knn_bf16_filter_kernel_p" : "knn_bf16_filter_kernel"); }
         LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
         if (defer_redo) fill_redo(h, defer_redo, vocab, row_id, (int)n_rows, d_queries, o_row, o_word, o_dist, cb);
         else LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(),
@@ -1319,8 +1320,12 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
                               prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr));
     if (prof) {
         h->prof_n += 1;
-        h->prof_kernel = knn_bf16_persistent(k.plan) ? "frame_a_kernel_p (persistent bf16 filter of frame t-1 + query pre-split of t + decision loop of t-2 + registration of t-3)"
-                                                     : "frame_a_kernel (bf16 filter of frame t-1 + query pre-split of t + decision loop of t-2 + registration of t-3)";
+        if (h->f16())
+            h->prof_kernel = knn_bf16_persistent(k.plan) ? "frame_a_kernel_p (persistent fp16 filter of frame t-1 + query pre-split of t + decision loop of t-2 + registration of t-3)"
+                                                         : "frame_a_kernel (fp16 filter of frame t-1 + query pre-split of t + decision loop of t-2 + registration of t-3)";
+        else
+            h->prof_kernel = knn_bf16_persistent(k.plan) ? "frame_a_kernel_p (persistent bf16 filter of frame t-1 + query pre-split of t + decision loop of t-2 + registration of t-3)"
+                                                         : "frame_a_kernel (bf16 filter of frame t-1 + query pre-split of t + decision loop of t-2 + registration of t-3)";
     }
     const bool prof2 = f_knn && reg_like && h->prof_likelihood && h->prof_cap > 0 && h->prof2_n < h->prof_cap;
     AppendRowsArgs app;

@@ -142,6 +142,10 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
                                                                                           // atomics drop the line from L2, the read then misses)
             if (a.want_q) d4[r] = a.did[w4[r]];
         }
+        // all four answers are awaited HERE, in front of the first store: behind a store (the branches below hide the count of operations
+        // in flight from the compiler, which then waits for everything) each entry would wait for the stores of the one before it
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(n4[r]), "+v"(d4[r]));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (!o4[r]) continue;
@@ -195,7 +199,7 @@ __device__ __forceinline__ void retire_body(const RetireArgs& r, const uint32_t*
 
 #ifdef LCD_TAIL_TIMING   // timing experiment only: 100 MHz stamps between the phases of the frame tail
 __device__ unsigned long long g_tail_timing[8];
-#define FT_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_tail_timing[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define FT_STAMP(i) do { __builtin_amdgcn_s_barrier(); if (threadIdx.x == 0) g_tail_timing[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define FT_STAMP(i) do { } while (0)
 #endif
@@ -238,14 +242,15 @@ __device__ __forceinline__ void append_norm_max(const AppendArgs& ap, float norm
 // Deferred append, first half (the decision loop's workgroup, launch A): which descriptors became words, and how many rows there are now.
 template <int NT>
 __device__ __forceinline__ void append_publish(const AppendArgs& ap, int q, const uint32_t* mask, const uint32_t* prefix, int n_in_early) {
-    const int n_in = n_in_early >= 0 ? n_in_early : ap.cnt_in[0];
+    const int n_in = n_in_early;                        // ap.cnt_in[0], read by the caller a whole decision loop ahead (a read here would wait for
+                                                        // the loop's stores); < 0: no counter, nothing is appended
     const int mw = (q + 63) / 64 * 2;
     const int n_new = (int)prefix[mw];
-    const int n_take = (long long)n_in + n_new <= ap.capacity ? n_new : 0;
+    const int n_take = (n_in >= 0 && (long long)n_in + n_new <= ap.capacity) ? n_new : 0;
     if (n_take > 0)
         for (int i = threadIdx.x; i < q; i += NT)
             if ((mask[i >> 5] >> (i & 31)) & 1u) ap.list_out[new_rank(mask, prefix, i)] = (uint32_t)i;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && n_in >= 0) {
         ap.cnt_out[0] = n_in + n_take;
         if (ap.log_slot) ap.log_slot[0] = n_take;
         if (ap.host_mirror) __hip_atomic_store(ap.host_mirror, ((unsigned long long)ap.tag << 32) | (unsigned long long)(uint32_t)(n_in + n_take), __ATOMIC_RELAXED,
@@ -399,6 +404,8 @@ __device__ __forceinline__ void frame_tail_body(uint32_t* ft_dyn_smem, const Res
     uint32_t ne0 = 0u;
     const bool have_ne0 = a.do_register && a.ne_counter != nullptr;
     if (threadIdx.x == 0 && have_ne0) ne0 = gload(a.ne_counter);
+    int n_in_early = -1;                                // the appender's row count: the previous launch wrote it (see frame_resolve_part)
+    if (r.ap.enabled && r.ap.cnt_in) n_in_early = gload(r.ap.cnt_in);
     FT_STAMP(0);
     // frames of up to 1024 descriptors: the register-resident decision loop, its result handed to the registration through LDS
     constexpr int KPT = 1024 / NT;                     // descriptors per thread of the register-resident loop: frames of up to 1024
@@ -406,12 +413,14 @@ __device__ __forceinline__ void frame_tail_body(uint32_t* ft_dyn_smem, const Res
     const uint32_t* fmask;
     if (lds_ws) fmask = resolve_body_fast<NT, KPT>(ft_dyn_smem, lds_ws, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld,
                                                    r.cand_bits, r.bw, r.out_word, r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws, r.cand_list,
-                                                   r.cand_cnt);
-    else fmask = resolve_body<NT>(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
-                                  r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
+                                                   r.cand_cnt, &n_in_early);
+    else { asm volatile("" : "+v"(n_in_early), "+v"(ne0));
+           fmask = resolve_body<NT>(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
+                                    r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws); }
     if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; r.fail_count[3] = 0; }
     // (before the registration reuses the LDS; the list scratch lies behind the word slots handed over in LDS)
-    if (r.ap.enabled) append_new_rows<NT>(r.ap, r.q, fmask, ft_dyn_smem + 2 * ((r.q + 63) / 64 * 2), r.new_ws, ft_dyn_smem + 2 * a.H + a.H / 64 + 8 + r.q);
+    if (r.ap.enabled) append_new_rows<NT>(r.ap, r.q, fmask, ft_dyn_smem + 2 * ((r.q + 63) / 64 * 2), r.new_ws, ft_dyn_smem + 2 * a.H + a.H / 64 + 8 + r.q,
+                                          nullptr, 0, n_in_early);
     else append_pass_on(r.ap);
     FT_STAMP(1);
     retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
@@ -443,9 +452,10 @@ __device__ __forceinline__ void frame_resolve_part(uint32_t* ft_dyn_smem, const 
     const uint32_t* fmask;
     if (r.q <= KPT * NT) fmask = resolve_body_fast<NT, KPT>(ft_dyn_smem, nullptr, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist,
                                                             r.ld, r.cand_bits, r.bw, r.out_word, r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws,
-                                                            r.cand_list, r.cand_cnt);
-    else fmask = resolve_body<NT>(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
-                                  r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws);
+                                                            r.cand_list, r.cand_cnt, &n_in_early);
+    else { asm volatile("" : "+v"(n_in_early)); fmask = resolve_body<NT>(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
+                                  r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws); }   // (both paths leave n_in_early awaited: the
+                                                                        // compiler's wait in front of its use would otherwise cover the loop's stores)
     if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; r.fail_count[3] = 0; }
     if (r.ap.enabled && r.ap.defer_rows) append_publish<NT>(r.ap, r.q, fmask, ft_dyn_smem + 2 * ((r.q + 63) / 64 * 2), n_in_early);
     else if (r.ap.enabled) {
@@ -462,11 +472,34 @@ __device__ __forceinline__ void frame_register_part(uint32_t* ft_dyn_smem, const
     uint32_t ne0 = 0u;
     const bool have_ne0 = a.do_register && a.ne_counter != nullptr;
     if (threadIdx.x == 0 && have_ne0) ne0 = gload(a.ne_counter);
+    // The frame's word slots (written by the decision loop one launch earlier) are requested HERE, in front of the retirement's reads:
+    // they arrive with them (one in-order counter), are parked in LDS, and the table phases of frame_words_body then run on LDS alone
+    // while the retirement's atomics are acknowledged -- instead of a barrier that waits for those acknowledgements and a round trip
+    // for the word slots behind it.  (The barrier in front of frame_words_body's second pass still orders the reference counts.)
+    constexpr int KS = 4;
+    const bool pre = a.n <= KS * NT && a.xlate == nullptr && a.src != nullptr;
+    int32_t ws_pre[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        const int i = (int)threadIdx.x + k * NT;
+        ws_pre[k] = (pre && i < a.n) ? gload(a.src + i) : -1;
+    }
     FT_STAMP(4);
     retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
-    __syncthreads();
-    FT_STAMP(5);
-    frame_words_body<NT, true>(ft_dyn_smem, a, nullptr, have_ne0, ne0);
+    if (!pre) {
+        __syncthreads();
+        FT_STAMP(5);
+        frame_words_body<NT, true>(ft_dyn_smem, a, nullptr, have_ne0, ne0);
+    } else {
+        int32_t* lds_ws = (int32_t*)(ft_dyn_smem + 2 * a.H + a.H / 64 + 8);      // behind the tables (as in frame_tail_body)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const int i = (int)threadIdx.x + k * NT;
+            if (i < a.n) lds_ws[i] = ws_pre[k];                           // read back by the same thread
+        }
+        FT_STAMP(5);
+        frame_words_body<NT, true>(ft_dyn_smem, a, lds_ws, have_ne0, ne0);
+    }
     FT_STAMP(6);
 }
 

@@ -1251,19 +1251,37 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     // (three dependent round trips for the ~150 words a frame creates: +7 us on launch B, measured).
     // LDS slot (row r, position s) holds the row's 16-byte chunk s ^ (r & 15): sixteen consecutive lanes that read the same chunk of
     // sixteen consecutive rows touch sixteen different positions (no bank conflict)
+    // (list_in_lds: every list entry the chunk can need lies in s_plist.  The other case -- a frame that created more than
+    // HALVES * MF_BLOCK words -- reads the list from memory inside the issue loop, and a read there makes every trip wait for the
+    // requests of the trip before it (one in-order counter): five serial round trips instead of one, 2.6 us on the ~150 rows a frame
+    // creates.  So the common case gets a loop of its own without any read.)
     auto stage_chunk = [&](int first, int n_chunk) {
         const int wv = (int)threadIdx.x >> 6, ln = (int)threadIdx.x & 63;
         // every re-rank workgroup of the launch wants the SAME rows at the same moment: each starts at another row (rotation by workgroup
         // index), so that at any time the requests spread over all the L2 channels instead of queueing at one
         const int n_inst = (n_chunk + 3) / 4;
         const int rot = (int)(((unsigned)blockIdx.x * 13u) % (unsigned)n_inst);
-        for (int i0 = wv; i0 < n_inst; i0 += HALVES * MF_WAVES) {        // one instruction = four rows = 1 KB of LDS
+        const bool list_in_lds = !pend_list || first + n_chunk - n_lo0 <= HALVES * MF_BLOCK;
+        if (list_in_lds) {
+            for (int i0 = wv; i0 < n_inst; i0 += HALVES * MF_WAVES) {    // one instruction = four rows = 1 KB of LDS
+                const int i = i0 + rot < n_inst ? i0 + rot : i0 + rot - n_inst;
+                const int rl = min(i * 4 + (ln >> 4), n_chunk - 1);      // (the rows of a partial last group repeat the chunk's last row)
+                const int chunk = (ln & 15) ^ ((i * 4 + (ln >> 4)) & 15);
+                const int r = first + rl;
+                const float* src = vocab + (size_t)r * DIM;
+                if (pend_list && r >= n_lo0) src = pend_desc + (size_t)s_plist[r - n_lo0] * DIM;   // a row that is being written in this launch: its descriptor
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + chunk * 4),
+                                                 (__attribute__((address_space(3))) void*)(stage + (size_t)i * 256), 16, 0, 0);
+            }
+            return;
+        }
+        for (int i0 = wv; i0 < n_inst; i0 += HALVES * MF_WAVES) {
             const int i = i0 + rot < n_inst ? i0 + rot : i0 + rot - n_inst;
-            const int rl = min(i * 4 + (ln >> 4), n_chunk - 1);          // (the rows of a partial last group repeat the chunk's last row)
+            const int rl = min(i * 4 + (ln >> 4), n_chunk - 1);
             const int chunk = (ln & 15) ^ ((i * 4 + (ln >> 4)) & 15);
             const int r = first + rl;
             const float* src = vocab + (size_t)r * DIM;
-            if (pend_list && r >= n_lo0) {                               // a row that is being written in this launch: its descriptor
+            if (pend_list && r >= n_lo0) {
                 const int j = r - n_lo0;
                 src = pend_desc + (size_t)(j < HALVES * MF_BLOCK ? s_plist[j] : pend_list[j]) * DIM;
             }
@@ -1303,6 +1321,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     RR_STAMP(0);
     const uint64_t kreg0 = tid < n_keys ? key_at(tid) : KEY_NONE;
     const uint64_t kreg1 = tid + MF_BLOCK < n_keys ? key_at(tid + MF_BLOCK) : KEY_NONE;
+    const uint64_t kreg2 = tid + 2 * MF_BLOCK < n_keys ? key_at(tid + 2 * MF_BLOCK) : KEY_NONE;   // (219 strips x 3 keys: a third of the threads have a third key)
     const uint32_t breg0 = tid < n_blocks ? bound_at(tid) : INF;
     const float4 q4 = reinterpret_cast<const float4*>(queries + (size_t)qi * DIM)[lane & 15];
     const float vn_max = __uint_as_float(norm_max_bits[0]);
@@ -1326,7 +1345,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     };
     see(kreg0, tid);
     see(kreg1, tid + MF_BLOCK);
-    for (int c = tid + 2 * MF_BLOCK; c < n_keys; c += MF_BLOCK) see(key_at(c), c);
+    see(kreg2, tid + 2 * MF_BLOCK);
+    for (int c = tid + 3 * MF_BLOCK; c < n_keys; c += MF_BLOCK) see(key_at(c), c);
     for (int c = tid + MF_BLOCK; c < n_blocks; c += MF_BLOCK) bound = min(bound, bound_at(c));
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -1366,7 +1386,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     };
     take(kreg0);
     take(kreg1);
-    for (int c = tid + 2 * MF_BLOCK; c < n_keys; c += MF_BLOCK) take(key_at(c));
+    take(kreg2);
+    for (int c = tid + 3 * MF_BLOCK; c < n_keys; c += MF_BLOCK) take(key_at(c));
     lds_barrier();
     RR_STAMP(2);
     const int n_cand = s_ncand;
@@ -1463,8 +1484,9 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         }
     }
     RR_STAMP(5);
-    __syncthreads();
+    lds_barrier();                                                     // (what the halves hand over lies in LDS; no store is outstanding here)
     RR_STAMP(6);
+    asm volatile("" : "+v"(dreg0), "+v"(dreg1));                       // (requested at the top, long since here: no wait for them behind the stores below)
     // the two best (distance, row) keys: ties go to the lower ROW (result_set.h:151-171), so the comparison key carries the row
     uint64_t best = KEY_NONE, second = KEY_NONE;
     int sbest = -1, ssecond = -1;
@@ -1480,6 +1502,9 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
             top2_push(best, second, ob);
             top2_push(best, second, os);
         }
+#ifdef LCD_RR_SUBSTAMP
+        RR_STAMP(4);
+#endif
         if (p_hi > p_lo) {                                             // the pending rows' two best join (their rows differ from every kept key's)
 #pragma unroll
             for (int w = 0; w < MF_WAVES; ++w) { top2_push(best, second, s_pend[w][0]); top2_push(best, second, s_pend[w][1]); }
@@ -1496,22 +1521,25 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
             sbest = max(sbest, __shfl_xor(sbest, m, 64));
             ssecond = max(ssecond, __shfl_xor(ssecond, m, 64));
         }
+#ifdef LCD_RR_SUBSTAMP
+        RR_STAMP(5);
+#endif
     }
     if (tid == 0) s_thr = (cb.have_index && second != KEY_NONE) ? __uint_as_float((uint32_t)(second >> 32)) : __int_as_float(0x7f800000);
+    // The tail of the chain: thread 0 writes the query's results.  Everything that READS memory comes first -- the word ids of winners
+    // that have no candidate slot, the certificate's operands -- and the stores last: the wait counter is one in-order counter for loads
+    // and stores, so a load (or the reload of a spilled register) behind a store waits for the store's acknowledgement, a full round
+    // trip each time (three of them in the first version of this block: 3.6 us of an 8 us chain, measured with in-kernel stamps).
     if (tid == 0 && valid) {
         err_ratio = fmaxf(fmaxf(s_err[0], s_err[1]), fmaxf(s_err[2], s_err[3]));
-        if (err_ratio > 0.0f && eps > 0.0f) atomicMax(reinterpret_cast<uint32_t*>(fail_count) + 2, __float_as_uint(err_ratio));
         const uint64_t k[2] = {best, second};
         const int sl[2] = {sbest, ssecond};
+        int32_t wout[2] = {0, 0};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if (k[j] == KEY_NONE) { out_row[2 * qi + j] = -1; out_word[2 * qi + j] = 0; out_dist[2 * qi + j] = -1.0f; }
-            else {
-                out_row[2 * qi + j] = (int32_t)(uint32_t)k[j];
-                const int32_t rw = (int32_t)(uint32_t)k[j];
-                out_word[2 * qi + j] = sl[j] >= 0 ? s_word[sl[j]] : ((pend_list && rw >= n_lo0) ? pend_first_id + (rw - n_lo0) : row_id[rw]);
-                out_dist[2 * qi + j] = __uint_as_float((uint32_t)(k[j] >> 32));
-            }
+            if (k[j] == KEY_NONE) continue;
+            const int32_t rw = (int32_t)(uint32_t)k[j];
+            wout[j] = sl[j] >= 0 ? s_word[sl[j]] : ((pend_list && rw >= n_lo0) ? pend_first_id + (rw - n_lo0) : row_id[rw]);
         }
         // certificate: every row the filter dropped is strictly farther than the exact second neighbour
         bool ok = !overflow;
@@ -1525,13 +1553,27 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         // fp16 operands hold magnitudes up to 65504: descriptors far outside that (the filter multiplies -2 q) are not this filter's
         // business -- the exact scan takes the query
         if (f16 && !(qn < 1.0e8f && vn_max < 1.0e8f)) ok = false;
+        const bool report = err_ratio > 0.0f && eps > 0.0f;
+        int reject = ok ? 0 : 1;
+        asm volatile("" : "+v"(wout[0]), "+v"(wout[1]), "+v"(reject) :: "memory");   // every load of this thread has arrived: stores only from here
+        ok = reject == 0;
+        if (report) atomicMax(reinterpret_cast<uint32_t*>(fail_count) + 2, __float_as_uint(err_ratio));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            out_row[2 * qi + j] = k[j] == KEY_NONE ? -1 : (int32_t)(uint32_t)k[j];
+            out_word[2 * qi + j] = wout[j];
+            out_dist[2 * qi + j] = k[j] == KEY_NONE ? -1.0f : __uint_as_float((uint32_t)(k[j] >> 32));
+        }
         if (!ok) fail_list[atomicAdd(fail_count, 1)] = qi;
     }
+    RR_STAMP(7);
     if (cb.bits) {                                                    // the query's row of the candidate bit matrix (uniform branch)
         __shared__ int s_below_all[HALVES];                           // + the compact list of the set bits below qi (CandBits::list)
         int& s_below = s_below_all[hf];
         if (tid == 0) s_below = 0;
-        __syncthreads();
+        // LDS-only barriers from here on: thread 0 has just stored the query's results, and __syncthreads() would hold the whole
+        // workgroup until those stores are acknowledged -- a memory round trip per barrier, twice, at the end of a latency chain
+        lds_barrier();
         const float thr2 = s_thr;
         for (int base = wave * 64; base < cb.ld; base += MF_BLOCK) {
             const int r = base + lane;
@@ -1545,7 +1587,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
             }
         }
         if (cb.cnt) {
-            __syncthreads();
+            lds_barrier();
             if (tid == 0 && valid) cb.cnt[qi] = s_below;
         }
     }
@@ -1596,7 +1638,7 @@ constexpr int PIPE_BLOCK = 256;     // workgroup size of both fused launches (th
 struct TailRoles { int has_resolve, has_register, n_redo, n_filter_wgs, n_q_wgs; };
 #ifdef LCD_B_TIMING   // timing experiment only: start / end of every workgroup of launch A (100 MHz)
 __device__ unsigned long long g_a_timing[2 * 4096];
-#define A_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4096) g_a_timing[2 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define A_STAMP(i) do { __builtin_amdgcn_s_barrier(); if (threadIdx.x == 0 && blockIdx.x < 4096) g_a_timing[2 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define A_STAMP(i) do { } while (0)
 #endif
@@ -1634,7 +1676,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void frame_a_kernel_p(FilterArgs f, int
 }
 #ifdef LCD_B_TIMING   // timing experiment only: start / end of every workgroup of launch B (100 MHz)
 __device__ unsigned long long g_b_timing[2 * 4096];
-#define B_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4096) g_b_timing[2 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define B_STAMP(i) do { __builtin_amdgcn_s_barrier(); if (threadIdx.x == 0 && blockIdx.x < 4096) g_b_timing[2 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define B_STAMP(i) do { } while (0)
 #endif
@@ -1986,7 +2028,7 @@ hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLa
     const int grid = tr.n_filter_wgs + tr.has_resolve + tr.has_register + tr.n_redo + tr.n_q_wgs;
     if (grid == 0) return hipSuccess;
     const size_t lds = px > 0 ? BF_LDS_BYTES_P : BF_LDS_BYTES_Q;
-    if ((resolve && resolve->shmem_resolve > lds) || (reg && reg->shmem > lds)) return hipErrorInvalidValue;
+    if ((resolve && resolve->shmem_resolve > lds) || (reg && reg->shmem + (size_t)reg->a.n * 4 > lds)) return hipErrorInvalidValue;   // (+ the word slots parked in LDS)
     ResolveArgs r{}; FwArgs a{}; RetireArgs ret{};
     if (resolve) { r = resolve->r; r.ap.lds_bytes = (int)lds; }        // what the decision loop's tables leave of it stages the frame's new rows
     if (reg) { a = reg->a; ret = reg->ret; }

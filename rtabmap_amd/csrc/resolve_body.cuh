@@ -12,7 +12,7 @@ constexpr int LCD_Q_NEW_WORDS_COMPARED = 2;
 
 #ifdef LCD_TAIL_TIMING   // timing experiment only: 100 MHz stamps inside the fast decision loop
 __device__ unsigned long long g_resolve_timing[8];
-#define RB_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_resolve_timing[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define RB_STAMP(i) do { __builtin_amdgcn_s_barrier(); if (threadIdx.x == 0) g_resolve_timing[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 __device__ unsigned long long g_sweep_timing[32];                    // [wave][point]: per-wave stamps inside the first sweep, no barrier added
 #define SW_STAMP(p) do { if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 4 && sweep == 0) g_sweep_timing[(threadIdx.x >> 6) * 8 + (p)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -94,7 +94,8 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
                                                   int32_t* __restrict__ out_word, int32_t* __restrict__ out_n_new,
                                                   const int32_t* __restrict__ knn_row, const int32_t* __restrict__ row_wslot,
                                                   int32_t* __restrict__ out_wslot, const WsRuns& new_ws,
-                                                  const uint2* __restrict__ cand_list = nullptr, const int32_t* __restrict__ cand_cnt = nullptr) {
+                                                  const uint2* __restrict__ cand_list = nullptr, const int32_t* __restrict__ cand_cnt = nullptr,
+                                                  int* keep_in_reg = nullptr) {
     const int mw = (q + 63) / 64 * 2;
     uint32_t* mask_cur = rs_smem;
     uint32_t* mask_next = rs_smem + mw;
@@ -295,14 +296,19 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
             if (w < mw) prefix[w] = run + x - c;
             run += __shfl(x, 63, 64);
         }
-        if (tid == 0) { prefix[mw] = run; out_n_new[0] = (int32_t)run; }
+        if (tid == 0) prefix[mw] = run;                              // (out_n_new is stored with the word ids below: no store in front of a read)
     }
     lds_barrier();
     RB_STAMP(4);
+    // every descriptor's word and postings key first, the stores behind them: the keys of new words are looked up in the launch
+    // arguments (memory reads), and a read that follows a store waits for the store's acknowledgement (one in-order counter) --
+    // store / look-up / store / ... was four round trips at the end of this chain
+    int wv_[KPT]; int32_t wsv_[KPT];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const int i = tid + k * NT;
         const Dsc& S = st[k];
+        wv_[k] = 0; wsv_[k] = -1;
         if (i >= q) continue;
         const bool is_new = (mask_cur[i >> 5] >> (i & 31)) & 1u;
         int w;
@@ -311,13 +317,23 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
             w = S.win;
             if (w < 0) w = -(new_rank(mask_cur, prefix, -w - 1) + 1);   // matched a same-frame new word
         }
-        out_word[i] = w;
         int32_t ws = -1;
         if (w < 0 && new_ws.n > 0) ws = ws_runs_at(new_ws, -w - 1);
         if (w < 0 && new_ws.n < 0) ws = w - 1;                          // split tail: code -(k + 2), translated by the registration workgroup
         if (w > 0) { if (S.w0 == w) ws = S.ws_a; else if (S.w1 == w) ws = S.ws_b; }
-        if (lds_wslot) lds_wslot[i] = ws;
-        else if (out_wslot) out_wslot[i] = ws;
+        wv_[k] = w; wsv_[k] = ws;
+    }
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) asm volatile("" : "+v"(wv_[k]), "+v"(wsv_[k]));
+    if (keep_in_reg) asm volatile("" : "+v"(*keep_in_reg));              // a value the caller reads right after the stores below
+    if (tid == 0) out_n_new[0] = (int32_t)prefix[mw];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int i = tid + k * NT;
+        if (i >= q) continue;
+        out_word[i] = wv_[k];
+        if (lds_wslot) lds_wslot[i] = wsv_[k];
+        else if (out_wslot) out_wslot[i] = wsv_[k];
     }
     RB_STAMP(5);
     return mask_cur;                                   // the final new-word mask (its word prefix sums are at rs_smem + 2 * mw)

@@ -102,8 +102,17 @@ def main():
         if hasattr(lib, "lcd_debug_rr_timing") and rep == 5:
             rr = (ctypes.c_ulonglong * (8 * 512))()
             assert lib.lcd_debug_rr_timing(rr, 8 * 512) == 0
-            t8 = np.frombuffer(rr, dtype=np.uint64).reshape(-1, 8).astype(np.float64)[:250, :7]
-            t8 = (t8 - t8[:, :1]) / 100.0
+            t8raw = np.frombuffer(rr, dtype=np.uint64).reshape(-1, 8).astype(np.float64)[:250]
+            if hasattr(lib, "lcd_debug_b_timing"):
+                bb3 = (ctypes.c_ulonglong * (2 * 4096))()
+                assert lib.lcd_debug_b_timing(bb3, 2 * 4096) == 0
+                b3 = np.frombuffer(bb3, dtype=np.uint64).reshape(-1, 2).astype(np.float64)[:250]
+                if os.environ.get("RR_SUBSTAMP"):
+                    print("re-rank sub-stamps after the barrier: first reduction %.2f, second reduction %.2f, results written %.2f us" %
+                          tuple(np.median(t8raw[:, i] - t8raw[:, 6]) / 100.0 for i in (4, 5, 7)))
+                print("re-rank workgroups: first phase stamp - workgroup start median %.2f us; results written - barrier %.2f; workgroup end - barrier stamp median %.2f us" %
+                      (np.median(t8raw[:, 0] - b3[:, 0]) / 100.0, np.median(t8raw[:, 7] - t8raw[:, 6]) / 100.0, np.median(b3[:, 1] - t8raw[:, 6]) / 100.0))
+            t8 = (t8raw[:, :7] - t8raw[:, :1]) / 100.0
             print("re-rank phases, 250 workgroups, median / p90 us after the workgroup's first stamp: " +
                   " | ".join("%s %.2f/%.2f" % (nme, np.median(t8[:, i]), np.percentile(t8[:, i], 90)) for i, nme in
                              [(1, "keys in, pass 1"), (2, "candidates chosen"), (3, "exact rows done"), (4, "pending rows staged"), (5, "pending scanned"), (6, "barrier")]))
