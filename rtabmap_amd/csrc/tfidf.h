@@ -288,6 +288,7 @@ struct Tfidf {
     // the device tombstoned the row of word `word_id` (key `ws`): if that is the word's permanent key it goes to the batched check
     void forget_word(int32_t word_id, int32_t ws);
     void free_wslot(int32_t w);          // into the interval set
+    void free_wslot_run(int32_t start, int32_t len);   // a run of consecutive keys, one operation
     int32_t take_wslot();                // one recycled wslot, or -1
     void harvest_released(bool wait);
     // reserve n wslots for the new words first_id, first_id + 1, ... of the coming frame (recycled intervals first)

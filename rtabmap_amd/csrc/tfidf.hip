@@ -470,6 +470,26 @@ void Tfidf::free_wslot(int32_t w) {
     ws_free_count += 1;
 }
 
+// the same for a run of consecutive keys [start, start + len): one interval operation for the whole run
+void Tfidf::free_wslot_run(int32_t start, int32_t len) {
+    if (len <= 0) return;
+    auto next = ws_free.lower_bound(start);
+    const bool clash_next = next != ws_free.end() && next->first < start + len;
+    const bool clash_prev = next != ws_free.begin() && std::prev(next)->first + std::prev(next)->second > start;
+    if (len == 1 || clash_next || clash_prev) {                          // (an overlap cannot happen; key by key it is at least ignored safely)
+        for (int32_t k = 0; k < len; ++k) free_wslot(start + k);
+        return;
+    }
+    int32_t s0 = start, l0 = len;
+    if (next != ws_free.begin()) {
+        auto prev = std::prev(next);
+        if (prev->first + prev->second == start) { s0 = prev->first; l0 += prev->second; ws_free.erase(prev); }
+    }
+    if (next != ws_free.end() && next->first == start + len) { l0 += next->second; ws_free.erase(next); }
+    ws_free[s0] = l0;
+    ws_free_count += len;
+}
+
 int32_t Tfidf::take_wslot() {
     if (ws_free.empty()) return -1;
     auto it = std::prev(ws_free.end());
@@ -531,8 +551,17 @@ void Tfidf::harvest_released(bool wait) {
         ReleaseBatch& r = releasing[i];
         const hipError_t q = wait ? hipEventSynchronize(r.blk.ev) : hipEventQuery(r.blk.ev);
         if (q != hipSuccess) { ++i; continue; }
+        // the verdicts of a batch are mostly "free" for long runs of consecutive keys (what a frame reserved and did not use): a run
+        // goes back into the interval set with ONE operation -- key by key a batch of 16 384 keys kept the host busy for ~0.2 ms, a
+        // pause of the enqueueing thread every ~40 frames
+        int32_t run_start = 0, run_len = 0;
         for (size_t k = 0; k < r.ws.size(); ++k) {
-            if (r.ok[k] == 1) { free_wslot(r.ws[k]); continue; }
+            if (r.ok[k] == 1) {
+                if (run_len > 0 && r.ws[k] == run_start + run_len) { run_len += 1; continue; }
+                free_wslot_run(run_start, run_len);
+                run_start = r.ws[k]; run_len = 1;
+                continue;
+            }
             // still referenced, or the key of a vocabulary row.  A wslot reserved for a frame's new word: the word exists (the frame
             // created it) and keeps it.
             const int32_t id = k < r.ids.size() ? r.ids[k] : 0;
@@ -545,6 +574,7 @@ void Tfidf::harvest_released(bool wait) {
                 ghost_ws.push_back(r.ws[k]);
             }
         }
+        free_wslot_run(run_start, run_len);
         pin_free.push_back(r.blk);
         releasing.erase(releasing.begin() + i);
     }
