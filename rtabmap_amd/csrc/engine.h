@@ -117,7 +117,8 @@ struct lcd_engine {
     int filter_units = -1;                              // lcd_set_option("filter_units")
     int strip_tiles = 0;                                // lcd_set_option("strip_tiles"): tiles per filter workgroup of a pipelined frame (0: planner)
     int sync_all();                                     // stream drained
-    int drain();                                        // complete the owed index stage (stand-alone launches)
+    int drain(bool rows = true);                        // complete the owed index stage (stand-alone launches); rows: the host's row mirror
+                                                        // catches up with the rows appended / removed on the device (reconcile(): synchronises, two small reads)
     const char* prof2_kernel = "score_kernel";
     lcd::PinBuf h_in, h_out, h_out2;
     lcd::Bayes bayes;                                   // Bayes filter over the signature slots (bayes.h)

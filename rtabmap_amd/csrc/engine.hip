@@ -466,7 +466,10 @@ const char* lcd_last_error(const lcd_engine* h) { return h ? h->err.c_str() : "n
 int lcd_synchronize(lcd_engine* h) {
     LCD_TRY
     LCD_CHECK_HANDLE(h);
-    LCD_DEV(h);
+    LCD_DEV_NODRAIN(h);
+    // what the frames in flight owe is completed and awaited; the host's row mirror is NOT brought up to date here (nothing a caller can
+    // observe after this call needs it: every call that does completes the reconciliation itself) -- two device reads less per call
+    { int rc = h->drain(false); if (rc) return rc; }
     return h->sync_all();
     LCD_CATCH(h)
 }
@@ -1196,7 +1199,7 @@ static int finish_frame_ops(lcd_engine* h, lcd_engine::InFlight& f) {
 
 static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs);
 
-int lcd_engine::drain() {
+int lcd_engine::drain(bool rows) {
     int rc_all = LCD_OK;
     while (!inflight.empty()) {                                      // three fused launch pairs complete what is owed, oldest first
         const size_t before = inflight.size();
@@ -1210,7 +1213,7 @@ int lcd_engine::drain() {
         }
     }
     if (clean_armed) { clean_armed = false; const int rc = enqueue_clean(); if (rc && !rc_all) rc_all = rc; }
-    const int rc3 = reconcile();                                     // rows appended on the device: the host mirror catches up
+    const int rc3 = rows ? reconcile() : LCD_OK;                     // rows appended on the device: the host mirror catches up
     return rc_all ? rc_all : rc3;
 }
 

@@ -14,11 +14,7 @@ const float kDefaultVirtualPlacePrior = 0.9f;
 
 bool parseBool(const std::string& s) { return s == "true" || s == "True" || s == "TRUE" || s == "1"; }
 // uStr2Float: the decimal mark may be '.' or ',' whatever the locale
-float str2Float(const std::string& s) {
-    std::string v = s;
-    for (size_t i = 0; i < v.size(); ++i) if (v[i] == ',') v[i] = '.';
-    return (float)strtod(v.c_str(), 0);
-}
+float str2Float(const std::string& s) { return uStr2Float(s); }   // classic ("C") locale whatever LC_NUMERIC says (VWDictionaryHip.h)
 void logError(const std::string& m) { fprintf(stderr, "[ERROR] %s\n", m.c_str()); }
 }  // namespace
 

@@ -130,7 +130,7 @@ void VWDictionaryHip::setFixedDictionary(const std::string& dictionaryPath) {
                 if ((int)tok.size() != dim + 1) continue;   // "Cannot parse line" warning in the reference
                 const int id = atoi(tok[0].c_str());
                 std::vector<float> v(dim);
-                for (int k = 0; k < dim; ++k) { std::string x = tok[k + 1]; std::replace(x.begin(), x.end(), ',', '.'); v[k] = (float)strtod(x.c_str(), 0); }
+                for (int k = 0; k < dim; ++k) v[k] = uStr2Float(tok[k + 1]);   // (',' or '.', classic locale: UConversion.cpp:138)
                 VisualWord* vw = new VisualWord(id, Mat(1, dim, MAT_32F, v.data()), 0);
                 vw->setSaved(true);
                 _visualWords.insert(_visualWords.end(), std::pair<int, VisualWord*>(id, vw));

@@ -39,6 +39,8 @@ cd /tmp
 # 2. kernel trace + stats
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $BENCH > $O/kt_bench.json 2> $O/kt.err
 kstats $O/kt $O/${TAG}_bench_kernel_trace.txt
+# the launch timeline of the same run (start, duration, gap to the previous kernel): 80 kernels from the middle of the timed region
+python $ROOT/tools/timeline_dump.py $(find $O/kt -name '*kernel_trace.csv' | head -1) 900 80 > $O/${TAG}_dispatch_timeline.txt 2>&1
 # 3. HBM traffic: one counter per pass
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o pmc -- $BENCH > /dev/null 2> $O/pmc_$c.err
