@@ -829,6 +829,9 @@ def run_replay(args):
 
     def frame_index(t):
         return ((t // P) % V) * P + (t % P)
+    # word ids: frame t may create the ids [first, first + id_stride).  q per frame when that fits below the engine's 2^28 ids; a replay of
+    # 10^6 frames gets the largest stride that does (268) -- checked against the logged codes afterwards: no frame created more
+    id_stride = min(q, ((1 << 28) - N_WORDS - 2 - q) // max(n_total, 1))
     t_start = time.perf_counter()
     marks = {}
     for t in range(n_total):
@@ -838,7 +841,7 @@ def run_replay(args):
         a.d_descriptors = pool_ptr + frame_index(t) * q * DIM * 4
         a.sig_id = t + 1
         a.N = float(t + 1)
-        a.first_new_word_id = N_WORDS + 1 + t * q                # an upper bound per frame: nothing is read back
+        a.first_new_word_id = N_WORDS + 1 + t * id_stride        # an upper bound per frame: nothing is read back
         a.d_word_ids = wp + t * q * 4
         k = sample_slot.get(t)
         if k is not None:
@@ -873,7 +876,9 @@ def run_replay(args):
     # ---- parity on the sampled frames
     t_par = time.perf_counter()
     log = d_words.cpu().numpy()                                                    # [n_total, q] codes: > 0 word id, < 0 the frame's -(k+1)-th new word
-    first_new = N_WORDS + 1 + np.arange(n_total, dtype=np.int64) * q
+    first_new = N_WORDS + 1 + np.arange(n_total, dtype=np.int64) * id_stride
+    if int(-log.min()) > id_stride:
+        raise SystemExit("replay: a frame created %d words, more than the id stride %d of this run" % (int(-log.min()), id_stride))
     ids_log = np.where(log < 0, first_new[:, None] - log - 1, log).astype(np.int32)
     created_by = np.flatnonzero((log < 0).any(axis=1))                             # frames that created words (the first laps)
     o = O.OracleVWDictionary(strategy=O.kNNBruteForce, incremental=True, nndr=NNDR, new_words_compared_together=True)

@@ -1836,6 +1836,8 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     if (!std::strcmp(key, "shard_growth_block") && value >= 0 && value <= (1 << 20)) { h->shard_block = (int32_t)value; return LCD_OK; }
     // 0: lcd_profile_begin brackets only the 2-NN launch of a pipelined frame (an event pair costs the stream ~10 us)
     if (!std::strcmp(key, "profile_likelihood") && (value == 0 || value == 1)) { h->prof_likelihood = value != 0; return LCD_OK; }
+    // (process-wide, for tests) sealed buckets from which the rows of a deferred append are written by a launch of their own; -1: built-in
+    if (!std::strcmp(key, "append_split_buckets") && value >= -1 && value <= (1 << 24)) { knn_set_append_split_buckets((int)value); return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");
     LCD_CATCH(h)
 }

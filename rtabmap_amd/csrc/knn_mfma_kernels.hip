@@ -1682,11 +1682,19 @@ __device__ unsigned long long g_b_timing[2 * 4096];
 #endif
 constexpr int PIPE_B_BLOCK = 512;   // workgroup size of launch B: eight waves per sealed bucket, two queries per re-rank workgroup
 constexpr uint32_t PIPE_B_STAGE_ROWS = 160;   // pending rows a re-rank workgroup stages in LDS at a time
+constexpr int APPEND_SPLIT_BUCKETS = 1024;    // sealed buckets (x 256 signatures) from which a deferred append's row writers get a launch of their own
+static int g_append_split_buckets = APPEND_SPLIT_BUCKETS;   // (lcd_set_option "append_split_buckets": tests run the split at small sizes)
 static_assert(PIPE_B_BLOCK == 2 * MF_BLOCK, "the re-rank halves");
+// WITH_APPEND: the workgroups that write a deferred append's rows ride in this launch.  Their mere presence changes the register
+// allocation of the whole kernel: the scoring branch, which holds everything in registers without them, then parks ~14 values in scratch
+// memory and reloads them inside its latency chain (launch B at 10^6 signatures: 47 -> 62 us; compile-time evidence: the kernel's scratch
+// accesses by source file, tools/store_wait_audit.py's sibling in DESIGN 7a).  A memory of >= APPEND_SPLIT_BUCKETS sealed buckets
+// therefore launches the row writers as a kernel of their own behind launch B (one more launch, ~4 us, against ~15 us of scoring).
+template <bool WITH_APPEND>
 __global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, int n_rerank_wgs, ScoreArgs A, int n_score_wgs, AppendRowsArgs app) {
     const int bid = (int)blockIdx.x;
     B_STAMP(0);
-    if (bid >= n_rerank_wgs + n_score_wgs) {                             // the rows the decision loop of launch A published (deferred append)
+    if (WITH_APPEND && bid >= n_rerank_wgs + n_score_wgs) {              // the rows the decision loop of launch A published (deferred append)
         extern __shared__ __attribute__((aligned(16))) float s_dyn_b2[];
         append_rows_body<PIPE_B_BLOCK>(app, bid - n_rerank_wgs - n_score_wgs, app.ap.lds_bytes >= 1024 ? s_dyn_b2 : nullptr, (app.ap.lds_bytes / 256) & ~3);
         B_STAMP(1);
@@ -1709,6 +1717,11 @@ __global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, 
         if (b < A.n_closed) score_sealed_body<PIPE_B_BLOCK>(A, b);
     } else score_open_body<PIPE_B_BLOCK>(A, g - A.n_closed_pad);
     B_STAMP(1);
+}
+
+__global__ __launch_bounds__(PIPE_B_BLOCK) void append_rows_kernel(AppendRowsArgs app) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn_ar[];
+    append_rows_body<PIPE_B_BLOCK>(app, (int)blockIdx.x, app.ap.lds_bytes >= 1024 ? s_dyn_ar : nullptr, (app.ap.lds_bytes / 256) & ~3);
 }
 
 // ------------------------------------------------------------------------------------------------ row-parallel exact scan
@@ -1834,6 +1847,7 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
 // plans are tested with on a machine without a device)
 static int g_plan_cus = 256;
 void knn_set_compute_units(int cus) { if (cus >= 16 && cus <= 4096) g_plan_cus = cus; }
+void knn_set_append_split_buckets(int n) { g_append_split_buckets = n >= 0 ? n : APPEND_SPLIT_BUCKETS; }
 int knn_selfdist_wgs(int q) { return selfdist_tiles(q); }
 // other_wgs: workgroups of the same launch that run for about as long as a filter workgroup (distance-matrix tiles, the frame tail's
 // two workgroups).  Every workgroup of the launch holds a whole compute unit's LDS: 256 strips + 2 tail workgroups used to leave two
@@ -2084,9 +2098,19 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
     rk.stage_rows = (dyn && k && k->n_hi) ? (int)PIPE_B_STAGE_ROWS : 0;
     ar.ap.lds_bytes = (int)(PIPE_B_STAGE_ROWS * 256u);
     if (k && n_app) { rk.pend_desc = ar.ap.descriptors; rk.pend_list = ar.ap.list_out; rk.pend_first_id = ar.ap.first_id; }   // k's pending rows ARE the rows being written
+    const bool split = n_app > 0 && score && score->n_closed >= g_append_split_buckets;   // (see frame_b_kernel)
+    if (split || n_app == 0) {
+        if (n_rerank + score_wgs > 0) {
+            if (ev_begin != nullptr && ev_end != nullptr)
+                hipExtLaunchKernelGGL(frame_b_kernel<false>, dim3(n_rerank + score_wgs), dim3(PIPE_B_BLOCK), dyn, s, ev_begin, ev_end, 0u, rk, n_rerank, A, score_wgs, ar);
+            else frame_b_kernel<false><<<n_rerank + score_wgs, PIPE_B_BLOCK, dyn, s>>>(rk, n_rerank, A, score_wgs, ar);
+        }
+        if (n_app > 0) append_rows_kernel<<<n_app, PIPE_B_BLOCK, PIPE_B_STAGE_ROWS * 256u, s>>>(ar);
+        return hipGetLastError();
+    }
     if (ev_begin != nullptr && ev_end != nullptr)
-        hipExtLaunchKernelGGL(frame_b_kernel, dim3(n_rerank + score_wgs + n_app), dim3(PIPE_B_BLOCK), dyn, s, ev_begin, ev_end, 0u, rk, n_rerank, A, score_wgs, ar);
-    else frame_b_kernel<<<n_rerank + score_wgs + n_app, PIPE_B_BLOCK, dyn, s>>>(rk, n_rerank, A, score_wgs, ar);
+        hipExtLaunchKernelGGL(frame_b_kernel<true>, dim3(n_rerank + score_wgs + n_app), dim3(PIPE_B_BLOCK), dyn, s, ev_begin, ev_end, 0u, rk, n_rerank, A, score_wgs, ar);
+    else frame_b_kernel<true><<<n_rerank + score_wgs + n_app, PIPE_B_BLOCK, dyn, s>>>(rk, n_rerank, A, score_wgs, ar);
     return hipGetLastError();
 }
 

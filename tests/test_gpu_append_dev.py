@@ -13,7 +13,7 @@ from test_gpu_frame_stream import _revisit, RTOL, ATOL
 pytestmark = pytest.mark.gpu
 
 
-def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="surf", knn_mode=None):
+def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="surf", knn_mode=None, options=None):
     import rtabmap_amd
     rng = np.random.default_rng(seed)
     base = synth.vocab_surf(n_words, seed=seed + 1) if kind == "surf" else synth.vocab_orb(n_words, seed=seed + 1)
@@ -42,6 +42,8 @@ def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="su
         likes.append(m.compute_likelihood(np.array(exp, np.int32), live)[1])
     assert not m.vwd.get_unused_word_ids()
     eng = rtabmap_amd.Engine("f32" if kind == "surf" else "u8", base.shape[1], sig_capacity=n_bulk + n_frames + 8, pipeline=pipeline, knn_mode=knn_mode)
+    for key, value in (options or {}).items():
+        eng.set_option(key, value)
     eng.vocab_append(base, ids)
     eng.sig_add_bulk(np.arange(1, n_bulk + 1, dtype=np.int32), np.arange(0, (n_bulk + 1) * q, q, dtype=np.int64), words.reshape(-1))
     cap = n_bulk + n_frames + 8
@@ -81,8 +83,16 @@ def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="su
     assert kid[:, 0].tolist() == vi[:: max(1, n_created // 16)].tolist() and not kd[:, 0].any()
     st = eng.stats()
     assert st["vocab_rows"] == n_words + n_created
+    for key in (options or {}):
+        eng.set_option(key, -1)                   # (process-wide options go back to their built-in values)
     eng.close()
     return n_created
+
+
+def test_appended_rows_written_by_a_launch_of_their_own(oracle):
+    # memories of 1024 sealed buckets and more leave the row writers of a deferred append to a kernel behind launch B (the scoring branch of
+    # the fused launch keeps its registers that way); the option runs that path at this test's size
+    assert _stream(oracle, True, n_words=3000, q=96, n_frames=30, seed=13, options={"append_split_buckets": 0}) > 200
 
 
 @pytest.mark.parametrize("pipeline", [False, True])
