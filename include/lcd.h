@@ -337,7 +337,9 @@ int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, co
  * (256 / 512 / 1024).  "filter_units": compute units the bf16 filter plans its persistent workgroups for when the vocabulary has
  * more 256-word strips than that (-1 built-in, 0 never persistent).  "profile_likelihood": 0 = lcd_profile_begin brackets only the
  * 2-NN launch of a pipelined frame (every timed launch costs stream time).  "strip_tiles": 32-word tiles per filter workgroup of a
- * pipelined frame (1 .. 8; 0 = the built-in plan).  Unknown keys / values -> LCD_ERR_INVALID.
+ * pipelined frame (1 .. 8; 0 = the built-in plan).  "append_split_buckets" (process-wide): sealed buckets of 256 signatures from which
+ * the rows a frame appends are written by a kernel of their own behind launch B instead of by workgroups inside it (-1 = built-in, 1 024).
+ * Unknown keys / values -> LCD_ERR_INVALID.
  * The two keys that DO change what a call means (sharded handles only, identical on every rank): "shard_growth_first" = F and
  * "shard_growth_block" = B > 0 make lcd_shard_frame_dev give the words frames create (ids >= F) to rank ((id - F) / B) % world instead of
  * the last rank, and merge the gathered candidates with ties going to the lower WORD ID -- the single-GPU row order as long as every rank
