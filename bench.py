@@ -889,6 +889,7 @@ def run_replay(args):
     mem = None                                                                      # the C++ oracle memory, while the replay fits it
     mem_upto = 0
     ids_equal, max_rel, n_cmp, hyp_ok, checked = True, 0.0, 0, True, []
+    hyp_same = hyp_near = 0
     knn_s = lik_s = 0.0
     for t in sample_t:
         # the dictionary as update() leaves it in front of frame t: every word a frame < t created, in id order
@@ -944,8 +945,16 @@ def run_replay(args):
         if n_cons > 0:
             adj = O.adjust_likelihood(np.concatenate([[0.0], Lo[:n_cons]]).astype(np.float32), 0.0)
             best = int(np.argmax(Lo[:n_cons]))
-            hyp_ok &= bool(int(hyp[t, 0]) == best + 1 or Lo[int(hyp[t, 0]) - 1] == Lo[best])
-            hyp_ok &= bool(abs(float(hyp[t, 3:4].view(np.float32)[0]) - float(adj[1 + best])) <= 1e-4 * max(abs(float(adj[1 + best])), 1e-3))
+            # the best candidate: the same signature, or -- a place seen hundreds of times leaves hundreds of signatures with the same words,
+            # whose likelihoods differ by rounding only (the device sums exactly, the reference in float) -- one whose reference
+            # likelihood lies within the parity bound of the reference's maximum
+            dev = int(hyp[t, 0]) - 1
+            same = dev == best
+            near = 0 <= dev < n_cons and float(Lo[dev]) >= float(Lo[best]) * (1.0 - 1e-4)
+            hyp_same += int(same); hyp_near += int(near and not same)
+            hyp_ok &= bool(same or near)
+            ref_adj = float(adj[1 + (dev if near else best)])
+            hyp_ok &= bool(abs(float(hyp[t, 3:4].view(np.float32)[0]) - ref_adj) <= 1e-4 * max(abs(ref_adj), 1e-3))
         checked.append({"frame": int(t), "signatures": int(t + 1), "likelihood_by": how})
     par_s = time.perf_counter() - t_par
     # ---- CPU baseline on a bounded sample: the reference's kd-tree / exact scan over the FINAL dictionary + the restated std::map TF-IDF
@@ -990,7 +999,8 @@ def run_replay(args):
                       "mean_adjusted_likelihood_of_hits": float(adjusted[hit].mean()) if hit.any() else None,
                       "rule": "every frame from the second lap on: the best raw-likelihood candidate outside the newest %d signatures shows the frame's place" % stm},
            "parity": {"frames_checked": checked, "word_ids_equal": bool(ids_equal), "likelihood_max_rel": max_rel, "likelihood_values_compared": n_cmp,
-                      "adjust_likelihood_and_best_candidate_equal": bool(hyp_ok), "bound": "1e-4 relative (abs floor 1e-7)",
+                      "adjust_likelihood_and_best_candidate_equal": bool(hyp_ok), "best_candidate_identical": hyp_same,
+                      "best_candidate_a_rounding_tie": hyp_near, "bound": "1e-4 relative (abs floor 1e-7)",
                       "oracle_seconds": {"addNewWords": knn_s, "computeLikelihood": lik_s},
                       "path": "sampled frames of the replay: word ids vs the C++ oracle's addNewWords over the dictionary replayed from the device's word "
                               "log; likelihood + adjustLikelihood vs Memory::computeLikelihood on the memory replayed from that log (C++ std::map oracle up "
