@@ -1113,6 +1113,29 @@ hipError_t Tfidf::retire(int32_t sig_id) {
 
 }  // namespace lcd
 
+// The interval set of recycled postings keys, as the engine keeps it (host code, no device needed: tests).  keys[0 .. n) with ok[i] != 0 are
+// freed -- by_runs: consecutive keys as ONE interval operation (Tfidf::free_wslot_run, what harvest_released does), else key by key --
+// then `take` keys are taken back; out receives the intervals as (start, length) pairs in ascending order.  Returns the number of pairs
+// (or -1 if out is too small); *count = free keys as the set counts them.
+extern "C" int lcd_debug_key_intervals(const int32_t* keys, const unsigned char* ok, int n, int by_runs, int take, int32_t* out, int cap, long long* count) {
+    lcd::Tfidf t;
+    int32_t run_start = 0, run_len = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!ok[i]) { if (by_runs) { t.free_wslot_run(run_start, run_len); run_len = 0; } continue; }
+        if (!by_runs) { t.free_wslot(keys[i]); continue; }
+        if (run_len > 0 && keys[i] == run_start + run_len) { run_len += 1; continue; }
+        t.free_wslot_run(run_start, run_len);
+        run_start = keys[i]; run_len = 1;
+    }
+    if (by_runs) t.free_wslot_run(run_start, run_len);
+    for (int i = 0; i < take; ++i) (void)t.take_wslot();
+    if ((int)t.ws_free.size() > cap) return -1;
+    int k = 0;
+    for (const auto& kv : t.ws_free) { out[2 * k] = kv.first; out[2 * k + 1] = kv.second; k += 1; }
+    if (count) *count = (long long)t.ws_free_count;
+    return k;
+}
+
 #ifdef LCD_SCORE_TIMING
 extern "C" int lcd_debug_score_timing(unsigned long long* out, int n_words) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
