@@ -88,7 +88,10 @@ int create_common(lcd_engine* engine, int rank, int world, lcd_shard_comm** out,
     if (!c) return LCD_ERR_NOMEM;
     c->eng = engine; c->rank = rank; c->world = world;
     c->stream = (hipStream_t)lcd_stream(engine);
-    if (hipGetDevice(&c->device) != hipSuccess) { delete c; return LCD_ERR_HIP; }
+    // the exchange buffers must live on the ENGINE's device, which need not be the calling thread's current one: ask the engine's stream
+    hipDevice_t dev = 0;
+    if (c->stream && hipStreamGetDevice(c->stream, &dev) == hipSuccess) c->device = (int)dev;
+    else if (hipGetDevice(&c->device) != hipSuccess) { delete c; return LCD_ERR_HIP; }
     *made = c;
     return LCD_OK;
 }
