@@ -92,6 +92,8 @@ int create_common(lcd_engine* engine, int rank, int world, lcd_shard_comm** out,
     hipDevice_t dev = 0;
     if (c->stream && hipStreamGetDevice(c->stream, &dev) == hipSuccess) c->device = (int)dev;
     else if (hipGetDevice(&c->device) != hipSuccess) { delete c; return LCD_ERR_HIP; }
+    // ... and so must the second stream and the events made next (finish_create): they are created on the calling thread's CURRENT device
+    if (hipSetDevice(c->device) != hipSuccess) { delete c; return LCD_ERR_HIP; }
     *made = c;
     return LCD_OK;
 }
@@ -99,6 +101,8 @@ int create_common(lcd_engine* engine, int rank, int world, lcd_shard_comm** out,
 int frame_impl(lcd_shard_comm* c, bool deferred, const void* d_descriptors, int q, int flags, float nndr_ratio, int32_t sig_id, int32_t first_new_word_id,
                float N, int64_t total_live_rows, int32_t* d_word_ids, float* d_likelihood, int64_t likelihood_capacity) {
     if (q <= 0 || !d_descriptors || !d_word_ids) return c->fail(LCD_ERR_INVALID, "lcd_shard_frame: bad argument");
+    // one thread may drive several engines: the copies, events and collectives below are issued for THIS engine's device
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(LCD_ERR_HIP, "hipSetDevice");
     const size_t n_rec = (size_t)q * 2;
     { int rc = grow(c, c->d_cand, c->cand_cap, n_rec); if (rc) return rc; }
     { int rc = grow(c, c->d_all, c->all_cap, n_rec * (size_t)c->world); if (rc) return rc; }
