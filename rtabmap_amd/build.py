@@ -80,7 +80,7 @@ def _build_locked(verbose):
 
 
 HOST_OUT = os.path.join(HERE, "liblcd_host.so")
-HOST_SOURCES = ["VWDictionaryHip.cpp", "MemoryHip.cpp", "BayesFilterHip.cpp", "RtabmapHip.cpp", "c_shim.cpp"]
+HOST_SOURCES = ["VWDictionaryHip.cpp", "MemoryHip.cpp", "BayesFilterHip.cpp", "RtabmapHip.cpp", "DbLoaderHip.cpp", "c_shim.cpp"]
 
 
 def build_host(force=False, verbose=False):
@@ -94,7 +94,7 @@ def build_host(force=False, verbose=False):
             return HOST_OUT
     cxx = shutil.which("g++") or "g++"
     cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_OUT] + [os.path.join(hdir, s) for s in HOST_SOURCES] + \
-          ["-L" + HERE, "-llcd_hip", "-Wl,-rpath,$ORIGIN"]
+          ["-L" + HERE, "-llcd_hip", "-ldl", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -1,6 +1,8 @@
 // MemoryHip.cpp -- see MemoryHip.h.
 #include "MemoryHip.h"
 
+#include "DbLoaderHip.h"
+
 #include <cstdio>
 #include <cstdlib>
 #include <set>
@@ -126,6 +128,47 @@ int MemoryHip::addSignature(const std::vector<int>& wordIds, int id) {
     if (id > _idCount) _idCount = id;
     _workingMem.insert(id);                     // Memory::loadDataFromDb: loaded signatures enter the working memory (:447-480)
     return id;
+}
+
+int MemoryHip::loadDataFromDb(const std::string& path, bool lastStateOnly) {
+    DbLoaderHip db;
+    DbDictionary dict;
+    DbSignatures sigs;
+    _loadError.clear();
+    if (!db.open(path) || !db.loadSignatureWords(sigs, lastStateOnly) || !db.loadDictionary(dict, sigs.sigIds.empty() && _vwd->isIncremental())) {
+        _loadError = db.lastError();
+        return -1;
+    }
+    // which words to keep: an incremental dictionary only what the loaded signatures reference (Memory.cpp:394-424)
+    std::set<int> referenced;
+    if (_vwd->isIncremental() && !sigs.sigIds.empty())
+        for (size_t k = 0; k < sigs.wordIds.size(); ++k) if (sigs.wordIds[k] > 0) referenced.insert(sigs.wordIds[k]);
+    const bool filter = _vwd->isIncremental() && !sigs.sigIds.empty();
+    const size_t rowBytes = (size_t)dict.cols * (dict.type == MAT_32F ? 4 : 1);
+    for (size_t k = 0; k < dict.wordIds.size(); ++k) {
+        if (filter && !referenced.count(dict.wordIds[k])) continue;
+        VisualWord* vw = new VisualWord(dict.wordIds[k], Mat(1, dict.cols, dict.type, dict.rows.data() + k * rowBytes));
+        vw->setSaved(true);
+        _vwd->addWord(vw);
+    }
+    if (_vwd->isIncremental()) _vwd->setLastWordId(dict.lastWordId);
+    _vwd->update();
+    if (_vwd->getVisualWords().size() && !_vwd->isAvailable()) { _loadError = _vwd->lastError(); return -1; }
+    int loaded = 0;
+    for (size_t s = 0; s < sigs.sigIds.size(); ++s) {
+        const std::vector<int> words(sigs.wordIds.begin() + sigs.offsets[s], sigs.wordIds.begin() + sigs.offsets[s + 1]);
+        for (size_t k = 0; k < words.size(); ++k)
+            if (words[k] > 0 && !_vwd->getWord(words[k])) {
+                _loadError = "The dictionary is empty or missing some words from nodes in WM (word " + std::to_string(words[k]) + " of node " +
+                             std::to_string(sigs.sigIds[s]) + ")";
+                fprintf(stderr, "[ERROR] %s\n", _loadError.c_str());
+                return -1;
+            }
+        if (this->addSignature(words, sigs.sigIds[s]) != sigs.sigIds[s]) { _loadError = "node " + std::to_string(sigs.sigIds[s]) + " is in memory already"; return -1; }
+        loaded += 1;
+    }
+    if (!_vwd->flushReferencesBulk([this](int id) { return this->getNi(id); })) { _loadError = _vwd->lastError(); return -1; }
+    return loaded;
 }
 
 int MemoryHip::getNi(int signatureId) const {   // Memory.cpp:4955-4968

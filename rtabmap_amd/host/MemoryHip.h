@@ -12,6 +12,7 @@
 #include <list>
 #include <map>
 #include <set>
+#include <string>
 #include <vector>
 
 #include "VWDictionaryHip.h"
@@ -29,6 +30,13 @@ public:
     int update(const Mat& descriptors, int nQuantized, std::vector<int>& wordIds);
     // a signature given directly by its word ids (database replay, Memory.cpp:447-480)
     int addSignature(const std::vector<int>& wordIds, int id = 0);
+    // Memory::loadDataFromDb (Memory.cpp:392-480) from a RTAB-Map database file: the nodes of the last saved state (or all of them) become
+    // signatures of the working memory, the dictionary is loaded -- an incremental one only with the words those signatures reference
+    // (DBDriver::loadWords), a fixed one whole (DBDriver::load) --, indexed by ONE update(), the references added, and the device
+    // receives them with ONE bulk registration (DbLoaderHip.h).  Returns the number of signatures loaded, -1 on error (lastError()).
+    // A signature that references a word the database does not hold makes the load fail (the reference would rebuild the dictionary
+    // from the nodes' own descriptors, Memory.cpp:481-565: out of scope).
+    int loadDataFromDb(const std::string& path, bool lastStateOnly = true);
     void forget(int signatureId);                   // moveToTrash -> disableWordsRef; the node leaves _signatures
     int getNi(int signatureId) const;
     size_t signaturesSize() const { return _signatures.size(); }
@@ -51,11 +59,13 @@ public:
     // every signature's references are on the device (the Bayes filter works on registered signatures)
     bool flushReferences() { return _vwd->flushReferences([this](int s) { return this->getNi(s); }); }
     const std::string& lastError() const { return _vwd->lastError(); }
+    const std::string& loadError() const { return _loadError; }        // of the last loadDataFromDb that returned -1
 
 private:
     void preUpdate();
     void cleanUnusedWords();
     VWDictionaryHip* _vwd;
+    std::string _loadError;                         // of the last loadDataFromDb
     std::map<int, std::vector<int> > _signatures;   // id -> words in keypoint order (Signature::getWords keys)
     std::map<int, int> _dbNi;                       // DBDriver::getInvertedIndexNi of transferred nodes
     int _idCount;

@@ -468,6 +468,30 @@ bool VWDictionaryHip::flushReferences(const std::function<int(int)>& getNi) {
     return true;
 }
 
+bool VWDictionaryHip::flushReferencesBulk(const std::function<int(int)>& getNi) {
+    if (_dirtySigs.empty()) return true;
+    if (!_engine) { _lastError = "no device engine"; return false; }
+    std::vector<int32_t> sigIds, words, ni;
+    std::vector<int64_t> offsets(1, 0);
+    for (std::set<int>::iterator s = _dirtySigs.begin(); s != _dirtySigs.end(); ++s) {
+        if (_deviceSigs.count(*s)) continue;                              // registered already: its changes go through flushReferences
+        std::map<int, std::vector<int> >::iterator w = _sigWords.find(*s);
+        if (w == _sigWords.end() || w->second.empty()) continue;
+        sigIds.push_back(*s);
+        words.insert(words.end(), w->second.begin(), w->second.end());
+        offsets.push_back((int64_t)words.size());
+        ni.push_back(getNi ? getNi(*s) : (int)w->second.size());
+    }
+    if (!sigIds.empty()) {
+        if (lcd_sig_add_bulk(_engine, (int)sigIds.size(), sigIds.data(), offsets.data(), words.data(), ni.data()) != LCD_OK) {
+            _lastError = lcd_last_error(_engine);
+            return false;
+        }
+        for (size_t k = 0; k < sigIds.size(); ++k) { _deviceSigs.insert(sigIds[k]); _dirtySigs.erase(sigIds[k]); }
+    }
+    return flushReferences(getNi);
+}
+
 // Memory::computeLikelihood, TF-IDF branch (Memory.cpp:2215-2291)
 std::map<int, float> VWDictionaryHip::computeLikelihood(const std::list<int>& wordIds, const std::list<int>& ids, float N,
                                                         const std::function<int(int)>& getNi) {

@@ -120,6 +120,10 @@ public:
 
     // send the references added / removed since the last call to the device's inverted index (computeLikelihood does it itself)
     bool flushReferences(const std::function<int(int)>& getNi);
+    // the same for a memory that has just been loaded (Memory::loadDataFromDb, Memory.cpp:447-480): every signature that is not on the
+    // device yet goes there with ONE lcd_sig_add_bulk instead of one lcd_sig_add each; what is left (signatures whose references
+    // changed after they were registered) is flushed as usual
+    bool flushReferencesBulk(const std::function<int(int)>& getNi);
 
     // The engine is a cache of this object's state (failure row; the reference repairs its dictionary on load,
     // Memory.cpp:481-565, and rebuilds a bad FLANN index, VWDictionary.cpp:835-838): after a device fault -- or whenever the caller

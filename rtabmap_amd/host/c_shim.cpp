@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "BayesFilterHip.h"
+#include "DbLoaderHip.h"
 #include "MemoryHip.h"
 #include "RtabmapHip.h"
 
@@ -131,6 +132,48 @@ double hmem_time_loop(void* h, const void* descs, int n_frames, int rows, int co
     }
     return total / steps;
 }
+
+// ---- the database reader (DbLoaderHip.h): no device call is made by the hdb_* entries
+struct HDb { DbLoaderHip db; DbDictionary dict; DbSignatures sigs; };
+void* hdb_open(const char* path) {
+    HDb* h = new HDb();
+    if (!h->db.open(path ? path : "")) { delete h; return nullptr; }
+    return h;
+}
+void hdb_close(void* h) { delete (HDb*)h; }
+const char* hdb_version(void* h) { return ((HDb*)h)->db.version().c_str(); }
+const char* hdb_last_error(void* h) { return ((HDb*)h)->db.lastError().c_str(); }
+// out4: type (0 = CV_8U, 5 = CV_32F, -1 none), descriptor size, last word id, bytes of the rows; returns the number of words, -1 on error
+int hdb_load_dictionary(void* h, int lastStateOnly, int* out4) {
+    HDb* d = (HDb*)h;
+    if (!d->db.loadDictionary(d->dict, lastStateOnly != 0)) return -1;
+    out4[0] = d->dict.type; out4[1] = d->dict.cols; out4[2] = d->dict.lastWordId; out4[3] = (int)d->dict.rows.size();
+    return (int)d->dict.wordIds.size();
+}
+void hdb_dictionary_copy(void* h, int* wordIds, unsigned char* rows) {
+    HDb* d = (HDb*)h;
+    if (!d->dict.wordIds.empty()) std::memcpy(wordIds, d->dict.wordIds.data(), d->dict.wordIds.size() * sizeof(int));
+    if (!d->dict.rows.empty()) std::memcpy(rows, d->dict.rows.data(), d->dict.rows.size());
+}
+// returns the number of signatures (-1 on error); *nWords = total word entries
+int hdb_load_signatures(void* h, int lastStateOnly, long long* nWords) {
+    HDb* d = (HDb*)h;
+    if (!d->db.loadSignatureWords(d->sigs, lastStateOnly != 0)) return -1;
+    *nWords = (long long)d->sigs.wordIds.size();
+    return (int)d->sigs.sigIds.size();
+}
+void hdb_signatures_copy(void* h, int* sigIds, long long* offsets, int* wordIds, int* ni) {
+    HDb* d = (HDb*)h;
+    const size_t n = d->sigs.sigIds.size();
+    if (n) { std::memcpy(sigIds, d->sigs.sigIds.data(), n * sizeof(int)); std::memcpy(ni, d->sigs.ni.data(), n * sizeof(int)); }
+    for (size_t i = 0; i < d->sigs.offsets.size(); ++i) offsets[i] = (long long)d->sigs.offsets[i];
+    if (!d->sigs.wordIds.empty()) std::memcpy(wordIds, d->sigs.wordIds.data(), d->sigs.wordIds.size() * sizeof(int));
+}
+int hdb_get_ni(void* h, int nodeId) { return ((HDb*)h)->db.getNi(nodeId); }
+int hdb_version_cmp(const char* a, const char* b) { return DbLoaderHip::versionCmp(a, b); }
+// Memory::loadDataFromDb through the mirror (device: the dictionary's update() and ONE bulk registration)
+int hmem_load_data_from_db(void* h, const char* path, int lastStateOnly) { return ((MemoryHip*)h)->loadDataFromDb(path ? path : "", lastStateOnly != 0); }
+const char* hmem_load_error(void* h) { return ((MemoryHip*)h)->loadError().c_str(); }
 
 // type 1: Memory::addLink of a global loop closure; type 0: a neighbour link as the database hands it to a replayed signature
 int hmem_add_link(void* h, int from, int to, int type) {

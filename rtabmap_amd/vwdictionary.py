@@ -88,6 +88,9 @@ def lib():
         L.hmem_num_signatures.argtypes = [vp]
         L.hmem_num_signatures.restype = C.c_long
         L.hmem_compute_likelihood.argtypes = [vp, vp, ci, vp, ci, vp, vp]
+        L.hmem_load_data_from_db.argtypes = [vp, C.c_char_p, ci]
+        L.hmem_load_error.argtypes = [vp]
+        L.hmem_load_error.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -215,6 +218,15 @@ class MemoryHip:
 
     def forget(self, sig_id):
         lib().hmem_forget(self.h, sig_id)
+
+    def load_data_from_db(self, path, last_state_only=True):
+        """Memory::loadDataFromDb from a RTAB-Map database file (MemoryHip::loadDataFromDb, rtabmap_amd/host/DbLoaderHip.h): the
+        dictionary indexed by one update(), every signature's references registered on the device in one bulk call.
+        Returns the number of signatures loaded; raises with the loader's message on failure."""
+        n = lib().hmem_load_data_from_db(self.h, str(path).encode(), int(last_state_only))
+        if n < 0:
+            raise RuntimeError("loadDataFromDb: " + lib().hmem_load_error(self.h).decode())
+        return n
 
     def time_loop(self, frames, steps):
         """update + computeLikelihood against every signature + forget(oldest) per frame, looped and timed in C++ -> ms per frame"""
