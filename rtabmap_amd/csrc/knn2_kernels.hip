@@ -96,8 +96,20 @@ __device__ __forceinline__ float l2_ref_dyn(const float* __restrict__ row, const
 template <int W>
 __device__ __forceinline__ uint32_t hamming_ref(const uint32_t* __restrict__ row, const uint32_t (&q)[W]) {
     uint32_t d = 0;
+#ifdef LCD_HAMMING_CHAIN   // experiment (not in the default build, not yet run on a GPU): the bit counts of a row accumulate in the instruction
+                           // itself (v_bcnt_u32_b32 d, x, d = popcount(x) + d), one chain per row.  Left to the compiler the eight counts of a
+                           // 256-bit row are summed as a tree -- eight v_bcnt_u32_b32 + three v_add3_u32 (tools/isa_loop_histogram.py: 94 VALU
+                           // per trip of four rows, 82 this way; SURVEY.md 8d counts 16 per row: 8 xor + 8 counts); the four rows of a trip
+                           // keep four chains in flight.  An integer sum: the same number in any order.
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const uint32_t x = row[w] ^ q[w];
+        asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(d));
+    }
+#else
 #pragma unroll
     for (int w = 0; w < W; ++w) d += __popc(row[w] ^ q[w]);
+#endif
     return d;
 }
 __device__ __forceinline__ uint32_t hamming_dyn(const uint32_t* __restrict__ row, const uint32_t* __restrict__ q, int w32) {

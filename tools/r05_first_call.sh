@@ -1,9 +1,11 @@
 #!/bin/bash
 # The first GPU call of the next round: what round 4 prepared without a GPU, verified and timed in one pass (~6 min of box time).
 #   (here)   python tools/build_variant.py apprr -DLCD_APPEND_FROM_RERANK
+#   (here)   python tools/build_variant.py hchain -DLCD_HAMMING_CHAIN
 #   (here)   gpurun --timeout 900 -- 'bash tools/r05_first_call.sh'
 # Writes gpurun_out/r05a/: the GPU suite on the product library, the append / frame-stream suites on the variant library, a same-box A/B
-# of the two (200 steps, three alternating runs each, headline and 10^6 signatures).
+# of the two (200 steps, three alternating runs each, headline and 10^6 signatures); the Hamming-scan variant (bit counts accumulated in the
+# instruction: 94 -> 82 VALU per four rows) on the exact-scan suites and against the product scan at 200 000 ORB words.
 set -u
 ROOT=$(pwd)
 O=$ROOT/gpurun_out/r05a
@@ -44,4 +46,17 @@ for f in sorted(glob.glob(sys.argv[1] + "/[hm]_*.json")):
     except Exception as e:
         print(f, "ERR", e)
 P
+fi
+
+# 4. the Hamming scan with the bit counts accumulated in the instruction (knn2_kernels.hip, LCD_HAMMING_CHAIN): bit-exact suites, then the scan's
+#    own time at 200 000 words x 500 descriptors (tools/bench_orb.py prints the kernel's HIP-event time), alternating
+HV=$ROOT/rtabmap_amd/liblcd_hip_hchain.so
+if [ -f $HV ]; then
+    LCD_LIB_PATH=$HV timeout 300 python -m pytest tests/test_gpu_knn.py tests/test_gpu_quantize.py tests/test_gpu_fuzz.py -x -q -p no:cacheprovider > $O/pytest_hchain.log 2>&1
+    tail -2 $O/pytest_hchain.log
+    for i in 1 2; do
+        timeout 120 python tools/bench_orb.py > $O/orb_prod_$i.json 2>/dev/null
+        LCD_LIB_PATH=$HV timeout 120 python tools/bench_orb.py > $O/orb_hchain_$i.json 2>/dev/null
+    done
+    tail -n 1 $O/orb_prod_*.json $O/orb_hchain_*.json
 fi
