@@ -119,6 +119,13 @@ def ref():
         R.ref_dist_hamming.restype = C.c_uint
         for f in ("ref_dist_l2", "ref_dist_l1", "ref_dist_hamming"):
             getattr(R, f).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        if hasattr(R, "ref_umean_list"):                          # (a library built before these entries existed lacks them: rebuild with make ref)
+            R.ref_umean_list.restype = C.c_float
+            R.ref_umean_list.argtypes = [C.c_void_p, C.c_size_t]
+            R.ref_uvariance_list.restype = C.c_float
+            R.ref_uvariance_list.argtypes = [C.c_void_p, C.c_size_t, C.c_float]
+            R.ref_ustr2float.restype = C.c_float
+            R.ref_ustr2float.argtypes = [C.c_char_p]
         _ref = R
     return _ref
 

@@ -6,12 +6,18 @@
 //   * the real reference arithmetic for L2 / L1 / Hamming      (rtflann/algorithms/dist.h:150,211,555)
 //   * the real exact 2-NN with its tie-break                   (linear_index.h:129-144, result_set.h:151-171)
 //   * the reference's default approximate kd-tree (speed only) (kdtree_index.h, FlannIndex.cpp:298)
+//   * the statistics helpers Rtabmap::adjustLikelihood calls   (utilite UMath.h: uMean(list) :419-432, uVariance(list, mean) :512-526)
+//     and its number parser                                    (utilite UConversion.cpp: uStr2Float)
 // so that the hand-written restatement in lcd_oracle.cpp can be pinned against reference code, and so
 // that bench.py can time the reference CPU search on the GPU box's host cores.
 #include <cstdint>
 #include <cstring>
+#include <list>
+#include <string>
 #include <vector>
 #include "rtflann/flann.hpp"
+#include "rtabmap/utilite/UConversion.h"
+#include "rtabmap/utilite/UMath.h"
 
 namespace {
 
@@ -92,5 +98,9 @@ float ref_dist_l1(const float* a, const float* b, size_t n) { return rtflann::L1
 unsigned ref_dist_hamming(const unsigned char* a, const unsigned char* b, size_t n) {
     return rtflann::Hamming<unsigned char>()(a, b, n);
 }
+// the reference's own templates on a std::list<float>, as Rtabmap::adjustLikelihood (Rtabmap.cpp:5717-5720) instantiates them
+float ref_umean_list(const float* v, size_t n) { std::list<float> l(v, v + n); return uMean(l); }
+float ref_uvariance_list(const float* v, size_t n, float mean) { std::list<float> l(v, v + n); return uVariance(l, mean); }
+float ref_ustr2float(const char* s) { return uStr2Float(std::string(s)); }
 
 }  // extern "C"

@@ -49,9 +49,9 @@ inline float uStr2Float(const std::string& s) {
     for (size_t i = 0; i < v.size(); ++i) if (v[i] == ',') v[i] = '.';
     std::istringstream in(v);
     in.imbue(std::locale::classic());
-    double value = 0.0;
+    float value = 0.0f;                     // extracted as a float, like the reference: out of range reads as +-FLT_MAX, not as infinity
     in >> value;
-    return (float)value;
+    return value;
 }
 
 class VisualWord {   // reference VisualWord.h:38-64, VisualWord.cpp:36-70

@@ -133,6 +133,9 @@ double hmem_time_loop(void* h, const void* descs, int n_frames, int rows, int co
     return total / steps;
 }
 
+// uStr2Float as the mirror's parameter parsing uses it (VWDictionaryHip.h; the reference's: utilite UConversion.cpp)
+float hutil_str2float(const char* s) { return uStr2Float(std::string(s ? s : "")); }
+
 // ---- the database reader (DbLoaderHip.h): no device call is made by the hdb_* entries
 struct HDb { DbLoaderHip db; DbDictionary dict; DbSignatures sigs; };
 void* hdb_open(const char* path) {

@@ -1,0 +1,92 @@
+"""Pins the statistics of the restated Rtabmap::adjustLikelihood (oracle/lcd_oracle.cpp; Rtabmap.cpp:5691-5760) against the reference's
+OWN uMean / uVariance templates (utilite UMath.h:419-432, 512-526) compiled in place (oracle/_ref/librtflann_ref.so): the float
+accumulation order of those two helpers decides the bits of every adjusted likelihood.  The statements around them are replayed here in
+numpy float32, one rounding per C operation.  Also: the host mirror's uStr2Float (VWDictionaryHip.h) against the reference's
+(UConversion.cpp), which reads Kp/NndrRatio, Rtabmap/LoopThr and the text dictionary.  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    if not oracle.have_ref():
+        try:
+            oracle.build(ref=True)
+        except Exception:
+            pass
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref/librtflann_ref.so not built and /root/reference absent")
+    r = oracle.ref()
+    if not hasattr(r, "ref_umean_list"):
+        try:
+            oracle.build(ref=True)
+        except Exception:
+            pass
+        pytest.skip("oracle/_ref/librtflann_ref.so predates ref_umean_list: rebuilt for the next run (make -C oracle ref)")
+    return r
+
+
+def _adjust_with_reference_statistics(ref, L, ratio):
+    """Rtabmap::adjustLikelihood statement by statement, mean and variance from the reference's templates."""
+    f = np.float32
+    L = L.astype(np.float32).copy()
+    values = np.ascontiguousarray(L[1:][L[1:] > 0])
+    p = values.ctypes.data_as(C.c_void_p)
+    mean = f(ref.ref_umean_list(p, values.size))
+    var = f(ref.ref_uvariance_list(p, values.size, mean))
+    std = f(np.sqrt(var))
+    eps, mx = f(0.0001), f(0.0)
+    out = L.copy()
+    for i in range(1, L.size):
+        v = L[i]
+        out[i] = f(1.0)
+        if v > f(mean + std):
+            if ratio == 0 and mean:
+                out[i] = f(f(v - f(std - eps)) / mean)
+            elif ratio != 0 and std:
+                out[i] = f(f(v - mean) / std)
+        if v > mx:
+            mx = v
+    if ratio == 0 and std > eps and mx:
+        out[0] = f(f(mean / std) + f(1.0))
+    elif ratio != 0 and mx > mean:
+        out[0] = f(f(std / f(mx - mean)) + f(1.0))
+    else:
+        out[0] = f(2.0)
+    return out
+
+
+@pytest.mark.parametrize("ratio", [0.0, 0.5])
+def test_adjust_likelihood_statistics_are_the_reference_templates(oracle, ref, ratio):
+    rng = np.random.default_rng(17)
+    cases = []
+    for n in (2, 3, 5, 17, 84, 500, 4001):
+        for kind in range(4):
+            L = rng.random(n).astype(np.float32) * np.float32(0.02)
+            if kind == 1:
+                L[rng.random(n) < 0.7] = 0.0                     # most places share no word with the frame
+            if kind == 2:
+                L[1:] = np.float32(0.0125)                       # all equal: variance 0
+            if kind == 3:
+                L[rng.random(n) < 0.3] *= np.float32(-1.0)       # negative idf terms (N < nw)
+                L[rng.integers(1, n)] = np.float32(0.9)          # one outstanding place
+            cases.append(L)
+    cases.append(np.zeros(40, np.float32))                      # nothing positive: mean 0, the virtual place gets 2
+    cases.append(np.array([0.0, 0.3], np.float32))              # one value: uVariance of a single element is 0
+    for L in cases:
+        got = oracle.adjust_likelihood(L, ratio)
+        exp = _adjust_with_reference_statistics(ref, L, ratio)
+        np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32), err_msg="n=%d" % L.size)
+
+
+def test_mirror_number_parser_is_the_reference_one(ref):
+    from rtabmap_amd import vwdictionary as V
+    L = V.lib()
+    L.hutil_str2float.restype = C.c_float
+    L.hutil_str2float.argtypes = [C.c_char_p]
+    for s in ["0.8", "0,8", "1e-3", "1,5e2", "7", "-2,25", "  3.5", "3.5  ", "abc", "", "1.5f", "1.2.3", "0.11", ".5", "5.", "+4", "1e", "0x10",
+              "0.10000000149", "123456789.125", "1e39", "-1e-46"]:
+        a, b = L.hutil_str2float(s.encode()), ref.ref_ustr2float(s.encode())
+        assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32) or (np.isnan(a) and np.isnan(b)), (s, a, b)
