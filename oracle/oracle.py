@@ -126,6 +126,8 @@ def ref():
             R.ref_uvariance_list.argtypes = [C.c_void_p, C.c_size_t, C.c_float]
             R.ref_ustr2float.restype = C.c_float
             R.ref_ustr2float.argtypes = [C.c_char_p]
+        if hasattr(R, "ref_ustrnumcmp"):
+            R.ref_ustrnumcmp.argtypes = [C.c_char_p, C.c_char_p]
         _ref = R
     return _ref
 

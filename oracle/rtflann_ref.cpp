@@ -18,6 +18,7 @@
 #include "rtflann/flann.hpp"
 #include "rtabmap/utilite/UConversion.h"
 #include "rtabmap/utilite/UMath.h"
+#include "rtabmap/utilite/UStl.h"
 
 namespace {
 
@@ -102,5 +103,7 @@ unsigned ref_dist_hamming(const unsigned char* a, const unsigned char* b, size_t
 float ref_umean_list(const float* v, size_t n) { std::list<float> l(v, v + n); return uMean(l); }
 float ref_uvariance_list(const float* v, size_t n, float mean) { std::list<float> l(v, v + n); return uVariance(l, mean); }
 float ref_ustr2float(const char* s) { return uStr2Float(std::string(s)); }
+// the version comparison of the database driver's schema switches (utilite UStl.h:717-790)
+int ref_ustrnumcmp(const char* a, const char* b) { return uStrNumCmp(std::string(a), std::string(b)); }
 
 }  // extern "C"

@@ -53,9 +53,9 @@ bool DbLoaderHip::fail(const std::string& what) {
 
 int DbLoaderHip::versionCmp(const std::string& a, const std::string& b) {
     // uStrNumCmp on dotted versions: component by component as numbers (the reference compares digit runs by length, then as text --
-    // the same order for components without leading zeros)
+    // the same order for components without leading zeros), over the components BOTH strings have: "0.21" equals "0.21.4", as there
     size_t i = 0, j = 0;
-    while (i < a.size() || j < b.size()) {
+    while (i < a.size() && j < b.size()) {
         long x = 0, y = 0;
         while (i < a.size() && a[i] != '.') { if (a[i] >= '0' && a[i] <= '9') x = x * 10 + (a[i] - '0'); ++i; }
         while (j < b.size() && b[j] != '.') { if (b[j] >= '0' && b[j] <= '9') y = y * 10 + (b[j] - '0'); ++j; }

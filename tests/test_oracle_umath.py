@@ -90,3 +90,19 @@ def test_mirror_number_parser_is_the_reference_one(ref):
               "0.10000000149", "123456789.125", "1e39", "-1e-46"]:
         a, b = L.hutil_str2float(s.encode()), ref.ref_ustr2float(s.encode())
         assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32) or (np.isnan(a) and np.isnan(b)), (s, a, b)
+
+
+def test_database_version_order_is_the_reference_one(ref):
+    """DbLoaderHip::versionCmp (the schema switches of the database reader) against the reference's uStrNumCmp (UStl.h:717-790) on
+    every pair of versions the driver compares or a database can carry"""
+    if not hasattr(ref, "ref_ustrnumcmp"):
+        pytest.skip("oracle/_ref/librtflann_ref.so predates ref_ustrnumcmp (make -C oracle ref)")
+    from rtabmap_amd import vwdictionary as V
+    L = V.lib()
+    L.hdb_version_cmp.argtypes = [C.c_char_p, C.c_char_p]
+    versions = ["0.0.0", "0.9.0", "0.10.0", "0.11.2", "0.11.10", "0.11.11", "0.11.12", "0.12.0", "0.12.9", "0.13.0", "0.14.0", "0.17.3", "0.18.0",
+                "0.20.23", "0.21.4", "0.23.0", "1.0.0", "0.21", "0.9"]
+    sign = lambda x: (x > 0) - (x < 0)
+    for a in versions:
+        for b in versions:
+            assert sign(L.hdb_version_cmp(a.encode(), b.encode())) == sign(ref.ref_ustrnumcmp(a.encode(), b.encode())), (a, b)
