@@ -32,6 +32,7 @@ public:
 
     const std::map<int, float>& getPosterior() const { return _posterior; }
     float getVirtualPlacePrior() const { return _virtualPlacePrior; }
+    bool isFullPredictionUpdate() const { return _fullPredictionUpdate; }
     const std::vector<double>& getPredictionLC() const { return _predictionLC; }   // {Vp, Lc, l1, l2, l3, l4...}
     std::string getPredictionLCStr() const;
 

@@ -36,6 +36,7 @@ public:
     float getHighestHypothesisValue() const { return _highestHypothesis.second; }
     int getLastLocationId() const { return _lastLocationId; }
     float getLoopThr() const { return _loopThr; }
+    float getLoopRatio() const { return _loopRatio; }
     const MemoryHip* getMemory() const { return _memory; }
     MemoryHip* getMemory() { return _memory; }
     BayesFilterHip* getBayesFilter() { return _bayesFilter; }

@@ -97,6 +97,7 @@ public:
     void setLastWordId(int id) { _lastWordId = id; }
     const std::map<int, VisualWord*>& getVisualWords() const { return _visualWords; }
     float getNndrRatio() const { return _nndrRatio; }
+    bool isNewWordsComparedTogether() const { return _newWordsComparedTogether; }
     unsigned int getNotIndexedWordsCount() const { return (unsigned int)_notIndexedWords.size(); }
     int getLastIndexedWordId() const;
     int getTotalActiveReferences() const { return _totalActiveReferences; }

@@ -133,6 +133,21 @@ double hmem_time_loop(void* h, const void* descs, int n_frames, int rows, int co
     return total / steps;
 }
 
+// the values the mirror's classes take when no parameter is given (tests/test_parameter_defaults.py compares them with the defaults of
+// the reference's Parameters.h): out[0..7] = Kp/NndrRatio, Kp/IncrementalDictionary, Kp/NewWordsComparedTogether, Mem/STMSize,
+// Rtabmap/LoopThr, Rtabmap/LoopRatio, Bayes/VirtualPlacePriorThr, Bayes/FullPredictionUpdate; then the Bayes/PredictionLC values.
+// Returns the number of PredictionLC values.  No device call is made (the engine is created on first use).
+int hparams_defaults(double* out, int cap) {
+    RtabmapHip r((ParametersMap()));
+    const VWDictionaryHip* d = r.getMemory()->getVWDictionary();
+    out[0] = d->getNndrRatio(); out[1] = d->isIncremental() ? 1 : 0; out[2] = d->isNewWordsComparedTogether() ? 1 : 0;
+    out[3] = r.getMemory()->getMaxStMemSize(); out[4] = r.getLoopThr(); out[5] = r.getLoopRatio();
+    out[6] = r.getBayesFilter()->getVirtualPlacePrior(); out[7] = r.getBayesFilter()->isFullPredictionUpdate() ? 1 : 0;
+    const std::vector<double>& lc = r.getBayesFilter()->getPredictionLC();
+    for (size_t i = 0; i < lc.size() && 8 + (int)i < cap; ++i) out[8 + i] = lc[i];
+    return (int)lc.size();
+}
+
 // uStr2Float as the mirror's parameter parsing uses it (VWDictionaryHip.h; the reference's: utilite UConversion.cpp)
 float hutil_str2float(const char* s) { return uStr2Float(std::string(s ? s : "")); }
 
