@@ -1,8 +1,8 @@
 #!/bin/bash
-# The first GPU call of the next round: what round 4 prepared without a GPU, verified and timed in one pass (~6 min of box time).
+# The first GPU call of the next round: what round 4 prepared without a GPU, verified and timed in one pass (~10-12 min of box time).
 #   (here)   python tools/build_variant.py apprr -DLCD_APPEND_FROM_RERANK
 #   (here)   python tools/build_variant.py hchain -DLCD_HAMMING_CHAIN
-#   (here)   gpurun --timeout 900 -- 'bash tools/r05_first_call.sh'
+#   (here)   gpurun --timeout 1200 -- 'bash tools/r05_first_call.sh'
 # Writes gpurun_out/r05a/: the GPU suite on the product library, the append / frame-stream suites on the variant library, a same-box A/B
 # of the two (200 steps, three alternating runs each, headline and 10^6 signatures); the Hamming-scan variant (bit counts accumulated in the
 # instruction: 94 -> 82 VALU per four rows) on the exact-scan suites and against the product scan at 200 000 ORB words.
