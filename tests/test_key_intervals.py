@@ -31,6 +31,11 @@ def test_runs_and_single_keys_leave_the_same_intervals():
         a, ca = _intervals(lib, keys, ok, by_runs=False)
         b, cb = _intervals(lib, keys, ok, by_runs=True)
         assert a == b and ca == cb == int(ok.sum())
+        free = np.unique(keys[ok == 1])                       # ... and they are the maximal runs of the SET of freed keys
+        cuts = np.flatnonzero(np.diff(free) != 1)
+        first = np.concatenate([[0], cuts + 1])
+        last = np.concatenate([cuts, [free.size - 1]])
+        assert b == [[int(free[i]), int(free[j] - free[i] + 1)] for i, j in zip(first, last)] if free.size else b == []
         # the set is a partition into maximal intervals: sorted, disjoint, not adjacent
         for (s0, l0), (s1, _) in zip(b, b[1:]):
             assert s0 + l0 < s1
