@@ -116,3 +116,40 @@ def test_a_hanging_secondary_measurement_does_not_cost_the_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] == 2 * 20 * 100000 / (4.0e-5 * 20)
     assert "timed out" in d["config"]["secondary_parallelism_error"]
+
+
+FAKE_SHARD = '''
+    import rtabmap_amd.sharded as S
+
+    class FakeShard:
+        def __init__(self, *a, **k): self.eng, self.lo, self.hi = FakeEngine(), 0, 24500
+        def load_vocabulary(self, rows, ids): pass
+        def add_signatures_bulk(self, *a, **k): pass
+        def frame(self, *a, **k): return None, None
+        def retire(self, sig): pass
+        def flush(self): return FakeLike()
+        def close(self): pass
+    S.ShardedLoopClosure = FakeShard
+'''
+
+
+def test_both_parallelisms_at_two_ranks():
+    """N = 2 (stand-ins): replicas as the primary measurement with the sharded frame as the secondary key, and the other way round"""
+    env = {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "LCD_BENCH_BACKEND": "gloo"}
+    r = _run(textwrap.dedent(FAKE_SHARD) + textwrap.dedent('''
+        sys.argv = ["bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-pmc"]
+        B.main()
+    '''), env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "secondary_parallelism_error" not in d["config"], d["config"].get("secondary_parallelism_error")
+    assert d["config"]["shard_ms_per_step"] > 0 and d["config"]["shard_value"] > 0 and "replicas" in d["config"]["parallelism"]
+    r = _run(textwrap.dedent(FAKE_SHARD) + textwrap.dedent('''
+        sys.argv = ["bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-pmc", "--parallelism", "shard"]
+        B.main()
+    '''), env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "secondary_parallelism_error" not in d["config"], d["config"].get("secondary_parallelism_error")
+    assert d["config"]["replicas_value"] > 0 and "sharded" in d["config"]["parallelism"]
+    assert d["value"] == 20 * 100000 / (4.0e-5 * 20)                       # ONE frame stream over both GPUs
