@@ -38,6 +38,8 @@
 #include <list>
 #include <map>
 #include <set>
+#include <locale>
+#include <sstream>
 #include <string>
 #include <vector>
 #ifdef _OPENMP
@@ -511,7 +513,11 @@ struct VWDictionary {
             std::vector<float> v(dim);
             for (int k = 0; k < dim; ++k) {   // uStr2Float: ',' -> '.', C locale (UConversion.cpp:138)
                 std::string x = tok[k + 1]; std::replace(x.begin(), x.end(), ',', '.');
-                v[k] = (float)strtod(x.c_str(), 0);   // reference: istringstream >> float in the C locale
+                std::istringstream in(x);             // as the reference: a float extracted from a stream in the C locale (one rounding;
+                in.imbue(std::locale::classic());     // out of range reads as +-FLT_MAX) -- pinned by tests/test_oracle_umath.py
+                float value = 0.0f;
+                in >> value;
+                v[k] = value;
             }
             VisualWord* vw = new VisualWord(id, (const unsigned char*)v.data(), dim, T_F32);
             visualWords.insert(visualWords.end(), std::make_pair(id, vw));

@@ -128,6 +128,8 @@ def ref():
             R.ref_ustr2float.argtypes = [C.c_char_p]
         if hasattr(R, "ref_ustrnumcmp"):
             R.ref_ustrnumcmp.argtypes = [C.c_char_p, C.c_char_p]
+        if hasattr(R, "ref_dictionary_text_roundtrip"):
+            R.ref_dictionary_text_roundtrip.argtypes = [C.c_char_p, C.c_char_p]
         _ref = R
     return _ref
 

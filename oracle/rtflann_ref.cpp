@@ -11,8 +11,12 @@
 // so that the hand-written restatement in lcd_oracle.cpp can be pinned against reference code, and so
 // that bench.py can time the reference CPU search on the GPU box's host cores.
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <list>
+#include <map>
 #include <string>
 #include <vector>
 #include "rtflann/flann.hpp"
@@ -103,6 +107,50 @@ unsigned ref_dist_hamming(const unsigned char* a, const unsigned char* b, size_t
 float ref_umean_list(const float* v, size_t n) { std::list<float> l(v, v + n); return uMean(l); }
 float ref_uvariance_list(const float* v, size_t n, float mean) { std::list<float> l(v, v + n); return uVariance(l, mean); }
 float ref_ustr2float(const char* s) { return uStr2Float(std::string(s)); }
+// The text dictionary reader of VWDictionary::setFixedDictionary (VWDictionary.cpp:189-243) and the descriptor writer of
+// exportDictionary (:1650-1690), statement by statement on a std::map of float rows instead of VisualWord / cv::Mat, with the reference's
+// OWN tokenisers and number parser (uSplitNumChar, uIsDigit, uSplit, uStr2Float): what the restated loaders must reproduce on awkward
+// files (repeated spaces, decimal commas, short lines, repeated ids).  Returns the number of words written, < 0 on error.
+int ref_dictionary_text_roundtrip(const char* in, const char* out) {
+    std::ifstream file;
+    file.open(in, std::ifstream::in);
+    if (!file.good()) return -1;
+    std::string str;
+    std::list<std::string> strList;
+    std::getline(file, str);
+    strList = uSplitNumChar(str);
+    int dimension = 0;
+    for (std::list<std::string>::iterator iter = strList.begin(); iter != strList.end(); ++iter) {
+        if (uIsDigit(iter->at(0))) { dimension = std::atoi(iter->c_str()); break; }
+    }
+    if (dimension <= 0 || dimension > 1000) return -2;
+    std::map<int, std::vector<float> > words;
+    while (file.good()) {
+        std::getline(file, str);
+        strList = uSplit(str);
+        if ((int)strList.size() == dimension + 1) {
+            std::list<std::string>::iterator iter = strList.begin();
+            int id = std::atoi(iter->c_str());
+            std::vector<float> descriptor(dimension);
+            ++iter;
+            int i = 0;
+            for (; i < dimension && iter != strList.end(); ++i, ++iter) descriptor[i] = uStr2Float(*iter);
+            words.insert(words.end(), std::pair<int, std::vector<float> >(id, descriptor));   // (an id seen before is ignored, as by _visualWords.insert)
+        }
+    }
+    file.close();
+    FILE* fo = fopen(out, "w");
+    if (!fo) return -3;
+    if (words.size() == 0) fprintf(fo, "WordID Descriptors...\n");
+    else fprintf(fo, "WordID Descriptors...%d\n", (int)words.begin()->second.size());
+    for (std::map<int, std::vector<float> >::const_iterator iter = words.begin(); iter != words.end(); ++iter) {
+        fprintf(fo, "%d ", iter->first);
+        for (size_t i = 0; i < iter->second.size(); i++) fprintf(fo, "%f ", iter->second[i]);
+        fprintf(fo, "\n");
+    }
+    fclose(fo);
+    return (int)words.size();
+}
 // the version comparison of the database driver's schema switches (utilite UStl.h:717-790)
 int ref_ustrnumcmp(const char* a, const char* b) { return uStrNumCmp(std::string(a), std::string(b)); }
 

@@ -106,3 +106,45 @@ def test_database_version_order_is_the_reference_one(ref):
     for a in versions:
         for b in versions:
             assert sign(L.hdb_version_cmp(a.encode(), b.encode())) == sign(ref.ref_ustrnumcmp(a.encode(), b.encode())), (a, b)
+
+
+AWKWARD = """WordID Descriptors...4
+7 0.5 1,25 -3e-2 4
+8  1  2 3   4
+9 1 2 3
+7 9 9 9 9
+12 0.1234564 0.1234565 1e-7 123456.789 
+abc 1 2 3 4
+10\t1 2 3 4
+5 1 2 3 4 5
+3 .5 5. +4 -0
+11 1 2 3 4\r
+"""
+
+
+def test_text_dictionary_tokenisation_is_the_reference_one(oracle, ref, tmp_path, capfd):
+    """The restated loaders of the fixed text dictionary (oracle: lcd_oracle.cpp, mirror: VWDictionaryHip::setFixedDictionary) against
+    the reference's reader statements run with its OWN uSplitNumChar / uSplit / uStr2Float (oracle/rtflann_ref.cpp), on a file with
+    repeated spaces, decimal commas, lines of the wrong length, a repeated id, a non-numeric id, a tab and a carriage return: the same
+    words in, the same text out (exportDictionary's %f).  The mirror indexes nothing here (no device): its host maps are what is exported."""
+    if not hasattr(ref, "ref_dictionary_text_roundtrip"):
+        pytest.skip("oracle/_ref/librtflann_ref.so predates ref_dictionary_text_roundtrip (make -C oracle ref)")
+    from rtabmap_amd.vwdictionary import VWDictionaryHip
+    src = tmp_path / "awkward.txt"
+    src.write_text(AWKWARD)
+    want = tmp_path / "reference.txt"
+    n = ref.ref_dictionary_text_roundtrip(str(src).encode(), str(want).encode())
+    assert n == 6                                                           # ids 0 ("abc"), 3, 7, 8, 11, 12
+    text = want.read_text()
+    assert text.splitlines()[0] == "WordID Descriptors...4" and [l.split()[0] for l in text.splitlines()[1:]] == ["0", "3", "7", "8", "11", "12"]
+    assert text.splitlines()[3] == "7 0.500000 1.250000 -0.030000 4.000000 "  # the first line of id 7 stays; the decimal comma is read
+    o = oracle.OracleVWDictionary(strategy=oracle.kNNBruteForce, incremental=False)
+    assert o.load_fixed_text(str(src)) == n + 1 and o.visual_words == n          # (the oracle's return value counts the accepted LINES: id 7 twice)
+    o.export_text(None, str(tmp_path / "oracle.txt"))
+    assert (tmp_path / "oracle.txt").read_text() == text
+    h = VWDictionaryHip(incremental=False, dictionary_path=str(src))         # (logs that no device engine can be created: expected here)
+    assert h.visual_words == n
+    h.export_text(None, str(tmp_path / "mirror.txt"))
+    assert (tmp_path / "mirror.txt").read_text() == text
+    h.close()
+    capfd.readouterr()
