@@ -269,13 +269,27 @@ def measure_pmc(extra_args=()):
         shutil.rmtree(base, ignore_errors=True)
 
 
+N_SIG_RUN = N_SIG       # --signatures of this run (the committed PMC summary is only valid for the headline's 49 000 words x 100 000 signatures)
+
+
+def pmc_source(name, note=""):
+    """Where pmc_traffic(name) comes from: "live" (this run's passes), "committed" (the headline configuration's summary), or None."""
+    key = name.split(" ")[0].split("<")[0]
+    if key in PMC_LIVE:
+        return "live: " + note if note else "live"
+    if N_WORDS != 49000 or N_SIG_RUN != N_SIG:
+        return None
+    return "committed summary of the headline command (%s)%s" % (os.path.relpath(PMC_PROFILE, ROOT), "; " + note if note else "")
+
+
 def pmc_traffic(name):
     """HBM traffic per launch of a kernel in GB: from this run's own rocprofv3 --pmc passes (measure_pmc) when they ran, else from the
-    committed summary of the same command (profiles/r03_pmc.json); null when neither has the kernel."""
+    committed summary of the SAME configuration (the headline's words AND signatures: PMC_PROFILE); null otherwise -- a figure measured
+    on another memory size is not this run's traffic."""
     key = name.split(" ")[0].split("<")[0]
     if key in PMC_LIVE:
         return PMC_LIVE[key]["hbm_bytes_per_launch"] / 1e9
-    if N_WORDS != 49000:
+    if N_WORDS != 49000 or N_SIG_RUN != N_SIG:
         return None                                      # the committed summary is the headline configuration's
     try:
         pmc = json.load(open(PMC_PROFILE))
@@ -294,7 +308,7 @@ def rooflines(eng, n_rows_rank, n_sig, shard, knn=None):
     bf16 = "bf16" in kern_name or f16              # (the dense fp16 and bf16 matrix peaks are the same figure)
     peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
     roof_knn = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": pmc_traffic(kern_name), "traffic_unit": "GB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)", "kernel": kern_name,
+                "traffic": pmc_traffic(kern_name), "traffic_source": pmc_source(kern_name), "traffic_unit": "GB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)", "kernel": kern_name,
                 "ms": kern_ms, "samples": kern_n, "mfma_dtype": ("fp16 (1 product per fp32 product, fp32 accumulate)" if f16 else "bf16 (3 products per fp32 product, fp32 accumulate)") if bf16 else "f32",
                 "executed_tflops": (3.0 if (bf16 and not f16) else 1.0) * achieved, "frac_of_f32_mfma_peak": achieved / PEAK_F32_TFLOPS,
                 "algorithmic_gbps": (n_rows_rank * DIM * 4 + Q * DIM * 4 + Q * 16) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0}
@@ -307,7 +321,7 @@ def rooflines(eng, n_rows_rank, n_sig, shard, knn=None):
         sc_bytes = work["dense_row_bytes"] + 4.0 * work["sparse_postings"] + 8.0 * work["open_log_entries"] + 8.0 * n_sig
         gbps = sc_bytes / (sc_ms * 1e-3) / 1e9
         roof_score = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-                      "traffic": pmc_traffic(sc_name), "traffic_unit": "GB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)", "kernel": sc_name,
+                      "traffic": pmc_traffic(sc_name), "traffic_source": pmc_source(sc_name), "traffic_unit": "GB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)", "kernel": sc_name,
                       "ms": sc_ms, "samples": sc_n, "algorithmic_bytes_per_launch": sc_bytes, "work": work,
                       "frac_if_4B_per_posting": (4.0 * work["postings"] + 8.0 * n_sig) / (sc_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS}
     return roof_knn, roof_score
@@ -1078,6 +1092,7 @@ def main():
     from rtabmap_amd import synth
     stream = torch.cuda.Stream()
     n_sig = args.signatures
+    globals()["N_SIG_RUN"] = n_sig
     shard = world > 1 and (args.parallelism == "shard" or (args.parallelism == "auto" and N_WORDS // world >= 100000))
     vocab, words = make_state(n_sig)
     cap = n_sig + args.steps + args.warmup + 4096
@@ -1316,7 +1331,7 @@ def main():
             for k in ("roofline", "roofline_score", "roofline_knn", "roofline_knn_standalone", "roofline_score_standalone"):
                 if out.get(k):
                     out[k]["traffic"] = pmc_traffic(out[k]["kernel"])
-                    out[k]["traffic_source"] = note if PMC_LIVE else note + " (profiles/r03_pmc.json)"
+                    out[k]["traffic_source"] = pmc_source(out[k]["kernel"], note)
         if not args.no_cpu_baseline:
             m = build_oracle(vocab, words)
             par, t_lin_port, t_lik = parity_block(torch, vocab, words, frames_np, m)

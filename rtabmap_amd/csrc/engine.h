@@ -100,7 +100,8 @@ struct lcd_engine {
     int64_t rm_seen = 0;                                // log entries the host mirror has caught up with
     bool rm_pending = false;                            // a clean was enqueued since the last reconciliation
     int frames_since_reconcile = 0;                     // pipelined frames submitted with rm_pending set
-    int enqueue_clean();                                // flush the pending retirements, launch the kernel (nothing is synchronised)
+    int enqueue_clean(const int32_t* reg_cnt = nullptr);  // flush the pending retirements, launch the kernel (nothing is synchronised); reg_cnt:
+                                                        // device row count as of the newest registered frame (rows behind it are not scanned)
     bool clean_armed = false;                           // a clean waits for the next fused launch pair, whose registration applies the
                                                         // retirements asked for before it (they ride there: no launches of their own)
     int reconcile();

@@ -341,7 +341,7 @@ int lcd_engine::reconcile() {
     return LCD_OK;
 }
 
-int lcd_engine::enqueue_clean() {
+int lcd_engine::enqueue_clean(const int32_t* reg_cnt) {
     const int64_t rows = rows_ub();
     if (rows <= 0) return LCD_OK;
     hipError_t e = tfidf.flush_retire();                 // retirements ride with the next registration otherwise: the counts would be stale
@@ -355,7 +355,7 @@ int lcd_engine::enqueue_clean() {
     }
     e = launch_clean_unused(row_id.as<int32_t>(), row_wslot.as<int32_t>(), tfidf.nw.as<uint32_t>(), tfidf.wrow.as<uint32_t>(),
                             dtype == LCD_F32 ? row_norm.as<float>() : nullptr, (int)rows, vcnt_active ? d_vcnt.as<int32_t>() : nullptr,
-                            d_rmlog.as<int32_t>(), (int)((d_rmlog.cap / 4 - 16) / 2), stream);
+                            vcnt_active ? reg_cnt : nullptr, d_rmlog.as<int32_t>(), (int)((d_rmlog.cap / 4 - 16) / 2), stream);
     if (e != hipSuccess) return hip_fail(e, "clean_unused_kernel");
     rm_pending = true;
     return LCD_OK;
@@ -1340,8 +1340,12 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
     if (h->clean_armed && f_reg) {
         // cleanUnusedWords asked for behind an earlier frame: the retirements made in front of it rode with the registration of this
         // launch A, the reference counts are what Memory::preUpdate would see -- one kernel, between this launch B and the next launch A
+        // f_res's decision loop ran in this launch A and its new words are rows since this launch B, but they get their first reference
+        // with its registration, in the NEXT launch A: the clean stops at the count f_res started from (the counter it read, untouched
+        // until the next decision loop writes it) -- addNewWords references a word as it creates it, cleanUnusedWords never sees one
         h->clean_armed = false;
-        int rc = h->enqueue_clean(); if (rc) return rc;               // (flushes what more than four retirements per frame left over)
+        const int32_t* reg_cnt = f_res && f_res->chained ? h->d_vcnt.as<int32_t>() + (f_res->vseq & 1) : nullptr;
+        int rc = h->enqueue_clean(reg_cnt); if (rc) return rc;        // (flushes what more than four retirements per frame left over)
     }
     if (f_res) f_res->stage = 2;
     if (f_knn) f_knn->stage = 1;
@@ -1700,9 +1704,14 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
     LCD_HIP(h, dreserve(h, h->d_knn_word, (size_t)q * 2 * 4));
     LCD_HIP(h, dreserve(h, h->d_knn_dist, (size_t)q * 2 * 4));
     // global 2-NN from the gathered per-rank candidates; d_knn_row holds the postings keys of the neighbours this rank owns
-    const bool cyclic = h->shard_block > 0 && first_new_word_id >= h->shard_first && h->shard_first > 0;
+    // ONE flag decides both the owner of a new word and the order of equal distances in the merge (block-cyclic owners need ties by word
+    // id; ties by (rank, row) need every new word on the last rank): a block without a first id is no growth policy, and a frame whose
+    // new ids would lie in front of the policy's origin has no owner rule at all -- refused rather than guessed
+    const bool cyclic = h->shard_block > 0 && h->shard_first > 0;
+    if (cyclic && sig_id != 0 && first_new_word_id > 0 && (flags & LCD_Q_INCREMENTAL) && first_new_word_id < h->shard_first)
+        return h->fail(LCD_ERR_INVALID, "lcd_shard_frame_dev: first_new_word_id lies in front of shard_growth_first");
     LCD_HIP(h, launch_shard_merge(d_all_cand, world, rank, q, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
-                                  h->d_knn_row.as<int32_t>(), h->stream, h->shard_block > 0));
+                                  h->d_knn_row.as<int32_t>(), h->stream, cyclic));
     const int have_index = total_live_rows >= 2 ? 1 : 0;
     const bool incremental = (flags & LCD_Q_INCREMENTAL) != 0;
     const bool together = incremental && (flags & LCD_Q_NEW_WORDS_COMPARED);

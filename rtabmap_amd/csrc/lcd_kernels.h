@@ -165,7 +165,7 @@ hipError_t launch_unused_rows(const int32_t* row_id, const int32_t* row_wslot, c
                               int cap, hipStream_t s);
 // cleanUnusedWords on the device (resolve_kernels.hip, clean_unused_kernel): rmlog[0] counts, rmlog[16 ..] lists {row, postings key} of the rows tombstoned (cap pairs)
 hipError_t launch_clean_unused(int32_t* row_id, const int32_t* row_wslot, const uint32_t* nw, uint32_t* wrow, float* aug, int n_rows,
-                               const int32_t* dev_cnt, int32_t* rmlog, int cap, hipStream_t s);
+                               const int32_t* dev_cnt, const int32_t* reg_cnt, int32_t* rmlog, int cap, hipStream_t s);
 // row_id[rows[i]] = 0
 hipError_t launch_tombstone(int32_t* row_id, const int32_t* rows, int n, hipStream_t s);
 

@@ -141,12 +141,16 @@ __global__ void unused_rows_kernel(const int32_t* __restrict__ row_id, const int
 // Memory::cleanUnusedWords (Memory.cpp:6899-6920) entirely on the device, enqueued behind the frames in flight: every live row whose word
 // nobody references is tombstoned here (row_id = 0, |row|^2 = +inf so that no filter ranks it, its postings key released from the row)
 // and logged for the host, which catches up the next time the handle is drained.  dev_cnt: the two alternating row counters of a handle
-// whose frames append their words on the device (the larger one is the newest), NULL: n_rows is exact.
+// whose frames append their words on the device (the larger one is the newest), NULL: n_rows is exact.  reg_cnt: the counter that holds
+// the row count as of the newest REGISTERED frame -- the rows behind it belong to a frame in flight whose decision loop has run but whose
+// registration (the only place its words get their first reference) has not: VWDictionary::addNewWords gives a new word its reference
+// at once (VWDictionary.cpp:1185-1195), so Memory::cleanUnusedWords never sees such a word; those rows are not scanned.
 __global__ void clean_unused_kernel(int32_t* __restrict__ row_id, const int32_t* __restrict__ row_wslot, const uint32_t* __restrict__ nw,
                                     uint32_t* __restrict__ wrow, float* __restrict__ aug, int n_rows, const int32_t* __restrict__ dev_cnt,
-                                    int32_t* __restrict__ rmlog, int cap) {
+                                    const int32_t* __restrict__ reg_cnt, int32_t* __restrict__ rmlog, int cap) {
     int n = n_rows;
     if (dev_cnt) n = min(n_rows, max(dev_cnt[0], dev_cnt[1]));
+    if (reg_cnt) n = min(n, reg_cnt[0]);
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
         if (row_id[r] == 0) continue;
         const int32_t ws = row_wslot[r];
@@ -221,10 +225,10 @@ hipError_t launch_unused_rows(const int32_t* row_id, const int32_t* row_wslot, c
     return hipGetLastError();
 }
 hipError_t launch_clean_unused(int32_t* row_id, const int32_t* row_wslot, const uint32_t* nw, uint32_t* wrow, float* aug, int n_rows,
-                               const int32_t* dev_cnt, int32_t* rmlog, int cap, hipStream_t s) {
+                               const int32_t* dev_cnt, const int32_t* reg_cnt, int32_t* rmlog, int cap, hipStream_t s) {
     if (n_rows <= 0) return hipSuccess;
     const int blocks = (n_rows + 255) / 256 < 1024 ? (n_rows + 255) / 256 : 1024;
-    clean_unused_kernel<<<blocks, 256, 0, s>>>(row_id, row_wslot, nw, wrow, aug, n_rows, dev_cnt, rmlog, cap);
+    clean_unused_kernel<<<blocks, 256, 0, s>>>(row_id, row_wslot, nw, wrow, aug, n_rows, dev_cnt, reg_cnt, rmlog, cap);
     return hipGetLastError();
 }
 hipError_t launch_tombstone(int32_t* row_id, const int32_t* rows, int n, hipStream_t s) {

@@ -157,7 +157,9 @@ bool DbLoaderHip::loadDictionary(DbDictionary& out, bool lastStateOnly) {
         }
         out.wordIds.push_back(id);
         const unsigned char* b = static_cast<const unsigned char*>(blob);
-        out.rows.insert(out.rows.end(), b, b + bytes);
+        // exactly one row: a CV_32F blob may carry up to three stray bytes (bytes / 4 == size) -- the reference copies them into a Mat
+        // of its own per word, here the rows are one array with stride cols * elemSize
+        out.rows.insert(out.rows.end(), b, b + (size_t)size * (type == MAT_32F ? sizeof(float) : 1));
     }
     if (rc != kSqliteDone) return fail("DB error (" + _version + ")");
     out.lastWordId = getLastWordId();

@@ -37,7 +37,10 @@ struct DbSignatures {
     std::vector<int32_t> sigIds;            // ascending node ids
     std::vector<int64_t> offsets;           // sigIds.size() + 1 offsets into wordIds
     std::vector<int32_t> wordIds;           // per node in ascending word id, duplicates = occurrences, ids <= 0 kept (they count in ni)
-    std::vector<int32_t> ni;                // Memory::getNi of every node = its number of features
+    std::vector<int32_t> ni;                // Memory::getNi of every LOADED node = Signature::getWords().size(): every feature row, a NULL
+                                            // word_id included (sqlite3_column_int reads it as 0 and the reference inserts it,
+                                            // DBDriverSqlite3.cpp:3912); DbLoaderHip::getNi(node) is the other reading -- the SQL
+                                            // count(word_id) of a node that is NOT in memory, which skips NULLs (:2788-2794)
 };
 
 class DbLoaderHip {

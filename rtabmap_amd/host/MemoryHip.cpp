@@ -145,13 +145,33 @@ int MemoryHip::loadDataFromDb(const std::string& path, bool lastStateOnly) {
         for (size_t k = 0; k < sigs.wordIds.size(); ++k) if (sigs.wordIds[k] > 0) referenced.insert(sigs.wordIds[k]);
     const bool filter = _vwd->isIncremental() && !sigs.sigIds.empty();
     const size_t rowBytes = (size_t)dict.cols * (dict.type == MAT_32F ? 4 : 1);
+    // every check that can fail comes BEFORE the first change of state: a refused load leaves the memory as it was
+    {
+        std::set<int> have(dict.wordIds.begin(), dict.wordIds.end()), nodes;
+        const std::map<int, VisualWord*>& old = _vwd->getVisualWords();
+        for (size_t s = 0; s < sigs.sigIds.size(); ++s) {
+            if (_signatures.count(sigs.sigIds[s]) || !nodes.insert(sigs.sigIds[s]).second) {
+                _loadError = "node " + std::to_string(sigs.sigIds[s]) + " is in memory already";
+                return -1;
+            }
+            for (int64_t k = sigs.offsets[s]; k < sigs.offsets[s + 1]; ++k) {
+                const int w = sigs.wordIds[(size_t)k];
+                if (w > 0 && !have.count(w) && !old.count(w)) {
+                    _loadError = "The dictionary is empty or missing some words from nodes in WM (word " + std::to_string(w) + " of node " +
+                                 std::to_string(sigs.sigIds[s]) + ")";
+                    fprintf(stderr, "[ERROR] %s\n", _loadError.c_str());
+                    return -1;
+                }
+            }
+        }
+    }
     for (size_t k = 0; k < dict.wordIds.size(); ++k) {
         if (filter && !referenced.count(dict.wordIds[k])) continue;
         VisualWord* vw = new VisualWord(dict.wordIds[k], Mat(1, dict.cols, dict.type, dict.rows.data() + k * rowBytes));
         vw->setSaved(true);
         _vwd->addWord(vw);
     }
-    if (_vwd->isIncremental()) _vwd->setLastWordId(dict.lastWordId);
+    if (!dict.wordIds.empty() || dict.lastWordId > 0) _vwd->setLastWordId(dict.lastWordId);   // DBDriverSqlite3::loadQuery :3617-3619: fixed dictionaries too
     _vwd->update();
     if (_vwd->getVisualWords().size() && !_vwd->isAvailable()) { _loadError = _vwd->lastError(); return -1; }
     int loaded = 0;

@@ -49,7 +49,8 @@ def _lib():
     return L
 
 
-def _make_db(path, kind, version="0.21.4", n_words=300, n_nodes=40, seed=3, old_words=0, old_nodes=0, bad_word=None, reference_last_word=False):
+def _make_db(path, kind, version="0.21.4", n_words=300, n_nodes=40, seed=3, old_words=0, old_nodes=0, bad_word=None, reference_last_word=False,
+             stray_word=None):
     """Returns (word ids, rows, {node: word ids in keypoint order}).  The first `old_words` words / `old_nodes` nodes carry a
     time_enter older than the last Info row: they are not part of the last saved state."""
     rng = np.random.default_rng(seed)
@@ -69,6 +70,8 @@ def _make_db(path, kind, version="0.21.4", n_words=300, n_nodes=40, seed=3, old_
         blob = rows[k].tobytes()
         if bad_word is not None and k == bad_word:
             blob = blob[:-3]
+        if stray_word is not None and k == stray_word:
+            blob = blob + b"\xAB\xCD"                                                                 # bytes / 4 == size still holds: accepted as CV_32F
         stamp = "2020-03-01 00:00:00" if k < old_words else "2020-06-01 12:00:00"
         db.execute("INSERT INTO Word (id, descriptor_size, descriptor, time_enter) VALUES (?,?,?,?)", (int(ids[k]), size, blob, stamp))
     sigs = {}
@@ -128,6 +131,18 @@ def test_reader_hands_back_the_bulk_arrays(tmp_path, kind, version):
         assert got.tolist() == sorted(sigs[node].tolist()), "node %d" % node         # ORDER BY word_id; duplicates and negative ids kept
         assert r["ni"][k] == len(sigs[node]) == r["ni_of"](node)
     assert r["ni_of"](424242) == 0
+    L.hdb_close(h)
+
+
+def test_a_blob_with_stray_bytes_does_not_shift_the_rows_behind_it(tmp_path):
+    """DBDriverSqlite3.cpp:3593 accepts a CV_32F blob of 4 x size + 1..3 bytes (integer division) and builds ONE Mat per word; the reader's
+    rows are one array with stride cols x 4, so it must take exactly one row from such a blob (the advisor's round-4 finding)"""
+    L = _lib()
+    path = str(tmp_path / "stray.db")
+    ids, rows, sigs = _make_db(path, "surf", n_words=40, n_nodes=4, stray_word=11)
+    h, r = _read(L, path, False, False)
+    assert r["word_ids"].tolist() == ids.tolist()
+    assert r["rows"].size == rows.nbytes and r["rows"].tobytes() == rows.tobytes()
     L.hdb_close(h)
 
 

@@ -13,7 +13,7 @@ from test_gpu_frame_stream import _revisit, RTOL, ATOL
 pytestmark = pytest.mark.gpu
 
 
-def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="surf", knn_mode=None, options=None):
+def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="surf", knn_mode=None, options=None, clean_every_frame=False):
     import rtabmap_amd
     rng = np.random.default_rng(seed)
     base = synth.vocab_surf(n_words, seed=seed + 1) if kind == "surf" else synth.vocab_orb(n_words, seed=seed + 1)
@@ -54,6 +54,8 @@ def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="su
     for t in range(n_frames):
         eng.frame_dev(d_desc[t].data_ptr(), q, n_bulk + 1 + t, float(n_bulk + 1 + t), d_w[t].data_ptr(), d_l[t].data_ptr(), cap,
                       first_new_word_id=first_new[t], append_new_words=True)
+        if clean_every_frame:
+            eng.vocab_remove_unused_async()       # Memory::preUpdate of the next frame; no word is ever unused here: it must remove nothing
         if sync_every and t % sync_every == sync_every - 1:
             eng.synchronize()                     # completes the owed stages stand-alone: the appends of the drained frames included
     eng.synchronize()
@@ -93,6 +95,17 @@ def test_appended_rows_written_by_a_launch_of_their_own(oracle):
     # memories of 1024 sealed buckets and more leave the row writers of a deferred append to a kernel behind launch B (the scoring branch of
     # the fused launch keeps its registers that way); the option runs that path at this test's size
     assert _stream(oracle, True, n_words=3000, q=96, n_frames=30, seed=13, options={"append_split_buckets": 0}) > 200
+
+
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_words_of_a_frame_in_flight_survive_the_enqueued_clean(oracle, pipeline):
+    """cleanUnusedWords enqueued behind EVERY frame of a stream in which no word ever loses its last reference (nothing is retired, every
+    base word is referenced): the reference's clean removes nothing (a word addNewWords creates is referenced as it is created,
+    VWDictionary.cpp:1185-1195), so the stream must be the oracle's word for word -- the words a frame creates are matched, as positive
+    ids, by the revisits a few frames later, and every created row is alive at the end.  On a pipelined handle the clean runs between a
+    frame's row writers and its registration: it must not take the not yet referenced rows for unused words (the advisor's round-4
+    finding)."""
+    assert _stream(oracle, pipeline, n_words=3000, q=96, n_frames=40, seed=17, clean_every_frame=True) > 200
 
 
 @pytest.mark.parametrize("pipeline", [False, True])
