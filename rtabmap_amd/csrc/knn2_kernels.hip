@@ -96,21 +96,16 @@ __device__ __forceinline__ float l2_ref_dyn(const float* __restrict__ row, const
 template <int W>
 __device__ __forceinline__ uint32_t hamming_ref(const uint32_t* __restrict__ row, const uint32_t (&q)[W]) {
     uint32_t d = 0;
-#ifdef LCD_HAMMING_CHAIN   // experiment (not in the default build, not yet run on a GPU): the bit counts of a row accumulate in the instruction
-                           // itself (v_bcnt_u32_b32 d, x, d = popcount(x) + d), one chain per row.  Left to the compiler the eight counts of a
-                           // 256-bit row are summed as a tree -- eight v_bcnt_u32_b32 + three v_add3_u32 (tools/isa_loop_histogram.py: 94 VALU
-                           // per trip of four rows, 82 this way; SURVEY.md 8d counts 16 per row: 8 xor + 8 counts; with the pointer form of the loop below
-                           // 143 -> 110 instructions per trip); the four rows of a trip
-                           // keep four chains in flight.  An integer sum: the same number in any order.
+    // The bit counts of a row accumulate in the instruction itself (v_bcnt_u32_b32 d, x, d = popcount(x) + d), one chain per row.  Left
+    // to the compiler the eight counts of a 256-bit row are summed as a tree -- eight v_bcnt_u32_b32 + three v_add3_u32
+    // (tools/isa_loop_histogram.py: 94 VALU per trip of four rows, 82 this way; SURVEY.md 8d counts 16 per row: 8 xor + 8 counts); the
+    // four rows of a trip keep four chains in flight.  An integer sum: the same number in any order.  Measured (round 5, same box,
+    // 200 000 words x 500 descriptors): scan 77.6 -> 67.3 us, -13 % (profiles/r05_first_call.txt).
 #pragma unroll
     for (int w = 0; w < W; ++w) {
         const uint32_t x = row[w] ^ q[w];
         asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(d));
     }
-#else
-#pragma unroll
-    for (int w = 0; w < W; ++w) d += __popc(row[w] ^ q[w]);
-#endif
     return d;
 }
 __device__ __forceinline__ uint32_t hamming_dyn(const uint32_t* __restrict__ row, const uint32_t* __restrict__ q, int w32) {
@@ -217,7 +212,7 @@ __global__ __launch_bounds__(BLOCK) void knn2_hamming_kernel(const uint32_t* __r
     int r = s.begin;
     // 4 rows per trip: the 4 scalar row loads (and the 4 tombstone flags) are issued back to back, so one wave has
     // 128 B of vocabulary in flight while it works; tombstones are masked by a wave-uniform select, not a branch.
-#ifdef LCD_HAMMING_CHAIN   // (same experiment: the row and flag addresses as two pointers that advance, not recomputed from the row index on every trip)
+    // the row and flag addresses are two pointers that advance, not recomputed from the row index on every trip (46 -> 25 scalar instructions)
     const uint32_t* vp = vocab + (size_t)r * W;
     const int32_t* ip = row_id + r;
     for (; r + 4 <= s.end; r += 4, vp += 4 * W, ip += 4) {
@@ -230,18 +225,6 @@ __global__ __launch_bounds__(BLOCK) void knn2_hamming_kernel(const uint32_t* __r
 #pragma unroll
         for (int u = 0; u < 4; ++u) top2_push32(best, second, key[u]);
     }
-#else
-    for (; r + 4 <= s.end; r += 4) {
-        uint32_t key[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t d = hamming_ref<W>(vocab + (size_t)(r + u) * W, q);
-            key[u] = row_id[r + u] != 0 ? ((d << HSHIFT) | (uint32_t)(r + u - row0)) : ~0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) top2_push32(best, second, key[u]);
-    }
-#endif
     for (; r < s.end; ++r) {
         if (row_id[r] == 0) continue;
         const uint32_t d = hamming_ref<W>(vocab + (size_t)r * W, q);

@@ -1235,10 +1235,10 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                                                      int32_t pend_first_id = 0
                                                      /* rows at or beyond pend_lo[0] are not vocabulary rows yet (a deferred append writes them in this
                                                         very launch): row pend_lo[0] + j is descriptor pend_list[j] of pend_desc, word pend_first_id + j */
-#ifdef LCD_APPEND_FROM_RERANK   // experiment (not built by default, not yet run on a GPU -- DESIGN.md section 8 item 2): the re-rank workgroups
-                                // WRITE the rows of the deferred append from the copy they have staged anyway; workgroup wr_index of wr_n
+                                // The re-rank workgroups WRITE the rows of the deferred append from the copy they have staged anyway (round 5: the
+                                // default since it passed the GPU suite; launch B 15.3 -> 13.8 us at the headline, profiles/r05_first_call.txt);
+                                // workgroup wr_index of wr_n
                                                      , const AppendRowsArgs& wr = AppendRowsArgs(), bool wr_on = false, int wr_index = 0, int wr_n = 1
-#endif
                                                      ) {
     static_assert(DIM == 64, "16 lanes x 4 floats per candidate row");
     // rows [pend_lo[0], pend_hi[0]): words the previous frame created, appended on the device after this frame's filter took its
@@ -1295,7 +1295,6 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         }
     };
     const bool staged = stage != nullptr && stage_rows >= 4 && p_hi > p_lo;
-#ifdef LCD_APPEND_FROM_RERANK
     // rows [n_lo0, p_hi) ARE the rows of the deferred append, and every re-rank workgroup has them in its staging area: workgroup wr_index
     // of wr_n writes rows wr_index, wr_index + wr_n, ... (16 lanes per row) -- no workgroups of their own, no third branch in the kernel (whose
     // presence makes the scoring branch spill).  Stores only, at the END of the body: a read behind them would wait for them.
@@ -1318,7 +1317,6 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         }
         append_norm_max(ap, nmax);
     };
-#endif
     const bool valid = qi_first + hf < nq;                             // the odd query out: its half walks the last query again, writes nothing
     const int qi = valid ? qi_first + hf : nq - 1;
     __shared__ float s_thr_all[HALVES];
@@ -1479,10 +1477,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                     }
                     top2_push(pb, ps, ((uint64_t)__float_as_uint(res) << 32) | (uint32_t)(c0 + r));
                 }
-#ifdef LCD_APPEND_FROM_RERANK
                 if (wr_on && c0 + stage_rows < p_hi) write_rows(c0, n_chunk);   // (more than one chunk: the staging area is about to be reused;
                                                                                 // the LAST chunk's rows are written at the very end of the body)
-#endif
             }
         } else
         for (int base = p_lo; base < (pend_list ? min(p_hi, n_lo0) : p_hi); base += PU * (MF_BLOCK / 16)) {   // (rows of a deferred append need the staged path)
@@ -1624,12 +1620,10 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
             if (tid == 0 && valid) cb.cnt[qi] = s_below;
         }
     }
-#ifdef LCD_APPEND_FROM_RERANK
     if (wr_on && staged) {                                             // the last (usually the only) chunk is still in the staging area
         const int c0_last = p_lo + ((p_hi - p_lo - 1) / stage_rows) * stage_rows;
         write_rows(c0_last, min(stage_rows, p_hi - c0_last));
     }
-#endif
 }
 
 template <int DIM, int KEEP, bool LAST_KEY_BOUNDS, bool BF16>
@@ -1747,9 +1741,7 @@ __global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, 
         knn_mfma_rerank_body<64, BF_KEEP, false, true, 2>(2 * pair, k.pk, k.pl, k.n_blocks, k.nq, k.vocab, k.queries, k.row_id, k.norm_max_bits, k.out_row,
                                                           k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb, k.n_lo, k.n_hi, k.plan_rows,
                                                           s_dyn_b, k.stage_rows, k.f16, k.pend_desc, k.pend_list, k.pend_first_id
-#ifdef LCD_APPEND_FROM_RERANK
                                                           , app, !WITH_APPEND && app.ap.enabled && app.ap.defer_rows, pair, (k.nq + 1) / 2
-#endif
                                                           );
         B_STAMP(1);
         return;
@@ -2141,10 +2133,8 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
     rk.stage_rows = (dyn && k && k->n_hi) ? (int)PIPE_B_STAGE_ROWS : 0;
     ar.ap.lds_bytes = (int)(PIPE_B_STAGE_ROWS * 256u);
     if (k && n_app) { rk.pend_desc = ar.ap.descriptors; rk.pend_list = ar.ap.list_out; rk.pend_first_id = ar.ap.first_id; }   // k's pending rows ARE the rows being written
-#ifdef LCD_APPEND_FROM_RERANK
     if (k && n_app > 0 && k->n_hi && k->plan.q > 0 && rk.stage_rows >= 4) n_app = 0;   // the re-rank workgroups write the rows (`ar` stays filled in: they get it);
                                                                                       // without re-rank workgroups or a staging area the writers stay
-#endif
     const bool split = n_app > 0 && score && score->n_closed >= g_append_split_buckets;   // (see frame_b_kernel)
     if (split || n_app == 0) {
         if (n_rerank + score_wgs > 0) {

@@ -3,10 +3,7 @@ the reference's table definitions (tests/test_db_loader.py) is loaded -- diction
 and the memory then behaves like an oracle memory that got the same words and signatures one call at a time: dictionary state,
 likelihood, and the word ids of frames processed afterwards.
 
-Written in round 4 WITHOUT a GPU to run it on: it stays out of `pytest -m gpu` until it has passed once
-(LCD_RUN_UNVERIFIED=1 python -m pytest tests/test_gpu_db_load.py; tools/r05_first_call.sh does that) -- then the skip below goes."""
-import os
-
+Written in round 4 without a GPU; first run (and green) in round 5's first GPU call (profiles/r05_first_call.txt): part of `pytest -m gpu`."""
 import numpy as np
 import pytest
 
@@ -14,8 +11,7 @@ from rtabmap_amd import synth
 from test_db_loader import _make_db
 from test_gpu_frame_stream import RTOL, ATOL
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.environ.get("LCD_RUN_UNVERIFIED"), reason="not yet run on a GPU (round 4 ended without GPU time): LCD_RUN_UNVERIFIED=1 runs it")]
+pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("kind", ["surf", "orb"])

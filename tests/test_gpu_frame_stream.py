@@ -300,12 +300,16 @@ def test_pipelined_frames_across_growing_word_tables():
     assert (out[0][0] < 0).sum() > T * q // 2                         # most descriptors became new words
 
 
-@pytest.mark.parametrize("n_sig,pipeline", [(20000, False), (100000, True)])
-def test_frame_dev_at_headline_sizes(oracle, n_sig, pipeline):
+@pytest.mark.parametrize("n_sig,pipeline,bench_mode", [(20000, False, False), (100000, True, False), (100000, True, True)])
+def test_frame_dev_at_headline_sizes(oracle, n_sig, pipeline, bench_mode):
     """BASELINE.json's configuration: 49k SURF words, 500 descriptors per frame, a Zipf memory of 100 000 signatures x 500 words (and a
-    20 000-signature one on a plain handle).  Three frames through lcd_frame_dev with retirement of the oldest signature: ids identical,
-    likelihood within 1e-4 over every slot, the same best candidate, sampled nw identical."""
+    20 000-signature one on a plain handle).  Frames through lcd_frame_dev with retirement of the oldest signature: ids identical,
+    likelihood within 1e-4 over every slot, the same best candidate, sampled nw identical.  bench_mode = the step bench.py times, so that
+    the driver's own `pytest -m gpu` covers the benchmarked configuration: the fp16 one-product matrix-core filter (LCD_KNN_F16),
+    update()'s append on the device (append_new_words), six frames enqueued back to back (four in flight), nothing completed in between."""
     import rtabmap_amd
+    if bench_mode:
+        return _headline_bench_mode(oracle, n_sig)
     n_words, q = 49000, 500
     vocab = synth.vocab_surf(n_words)
     words = synth.zipf_words(n_sig, q, n_words, seed=100000)
@@ -345,6 +349,62 @@ def test_frame_dev_at_headline_sizes(oracle, n_sig, pipeline):
         eng.sig_remove(t + 1)
     st = eng.stats()
     assert st["dense_words"] > 50 and st["buckets_sealed"] == n_sig // 256
+    eng.close()
+
+
+def _headline_bench_mode(oracle, n_sig, n_frames=6):
+    import rtabmap_amd
+    n_words, q = 49000, 500
+    vocab = synth.vocab_surf(n_words)
+    words = synth.zipf_words(n_sig, q, n_words, seed=100000)
+    ids = np.arange(1, n_words + 1, dtype=np.int32)
+    m = oracle.OracleMemory(strategy=oracle.kNNBruteForce, nndr=0.8, new_words_compared_together=True)
+    for i, r in zip(ids, vocab):
+        m.vwd.add_word(int(i), r)
+    m.vwd.update()
+    assert m.add_signatures_bulk(words) == 1
+    eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 8192, sig_capacity=n_sig + 64, pipeline=True, knn_mode="f16")
+    eng.vocab_append(vocab, ids)
+    eng.sig_add_bulk(np.arange(1, n_sig + 1, dtype=np.int32), np.arange(0, (n_sig + 1) * q, q, dtype=np.int64), words.reshape(-1))
+    cap = n_sig + 16
+    rng = np.random.default_rng(5)
+    src0 = int(rng.integers(100, n_sig))
+    frames, first_new, expected, likes = [], [], [], []
+    for t in range(n_frames):
+        # every other frame looks at the place of the frame before it again: the words that frame created are matched as rows of the vocabulary
+        src = src0 if t % 2 else int(rng.integers(100, n_sig))
+        src0 = src
+        desc = synth.frame_from_signature(vocab, words[src], seed=(950 + t - 1) if t % 2 else (950 + t))
+        if t % 2:
+            desc = (desc + np.float32(1e-3) * np.random.default_rng(t).standard_normal(desc.shape).astype(np.float32)).astype(np.float32)
+        first_new.append(m.vwd.last_word_id + 1)
+        sid, exp = m.update(desc)
+        frames.append(desc)
+        expected.append(exp)
+        live = np.array(m.signature_ids(), np.int32)
+        likes.append(m.compute_likelihood(np.array(exp, np.int32), live))
+        m.forget(t + 1)
+    d_desc = [torch.from_numpy(f).cuda() for f in frames]
+    d_words = torch.zeros((n_frames, q), dtype=torch.int32, device="cuda")
+    d_like = torch.zeros((n_frames, cap), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for t in range(n_frames):
+        eng.frame_dev(d_desc[t].data_ptr(), q, n_sig + 1 + t, float(n_sig + 1), d_words[t].data_ptr(), d_like[t].data_ptr(), cap,
+                      first_new_word_id=first_new[t], append_new_words=True)
+        eng.sig_remove(t + 1)
+    eng.synchronize()
+    got, like = d_words.cpu().numpy(), d_like.cpu().numpy()
+    matched_new = 0
+    for t in range(n_frames):
+        mapped = np.where(got[t] < 0, first_new[t] - got[t] - 1, got[t])
+        assert mapped.tolist() == expected[t], "frame %d" % t
+        if t % 2:
+            matched_new += int(((got[t] > n_words)).sum())
+        oi, Lo = likes[t]
+        Lh = like[t][oi - 1]                                    # signature id s sits in slot s - 1 in this test
+        np.testing.assert_allclose(Lh, Lo, rtol=RTOL, atol=ATOL, err_msg="frame %d" % t)
+        assert int(np.argmax(Lh[:-1])) == int(np.argmax(Lo[:-1]))
+    assert matched_new > 50, "the revisits must match words the frames before them created (rows appended on the device)"
     eng.close()
 
 
