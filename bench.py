@@ -608,11 +608,14 @@ def frame_latency_ms(torch, eng, stepper, stream, base_i, n=48):
             "single_frame_then_synchronize_median": float(np.median(single[2:]))}
 
 
-def cpp_interface_ms(vocab, words, frames_np, n_sig_small=10000, steps=12):
-    """What a caller of the reference's own interface gets: C++ MemoryHip::update (-> VWDictionaryHip::addNewWords) +
-    MemoryHip::computeLikelihood against every signature + forget of the oldest, in a C++ loop inside liblcd_host.so (cv::Mat-like host
-    matrices in, std::list / std::map out, the host mirror's std::map bookkeeping included) -- on a memory of `n_sig_small` signatures
-    (loading 100 000 signatures into the mirror's std::map containers takes minutes, as it does in the reference)."""
+def cpp_interface_ms(vocab, words, frames_np, n_sig, steps=12):
+    """What a caller of the reference's own interface gets, at the headline's memory size: C++ MemoryHip::update (-> VWDictionaryHip::
+    addNewWordsAndScore -> ONE lcd_frame_host call: quantisation, references, update()'s append, likelihood) + Memory::computeLikelihood of
+    the new signature against every signature + forget of the oldest, in a C++ loop inside liblcd_host.so (cv::Mat-like host matrices in,
+    the host mirror's std::map bookkeeping included).  Three ways to take the likelihood: the reference's std::map by value, a
+    caller-owned std::map updated in place, flat vectors; and the call-by-call path of rounds 1-4 on the same memory.
+    (The mirror's containers are filled by Memory::addSignature in C++ -- 50 M std::map insertions at 100 000 signatures -- and the
+    device by one bulk registration.)"""
     from rtabmap_amd import vwdictionary as V
     mem = V.MemoryHip(strategy=V.kNNBruteForceHIP, incremental=True, nndr=NNDR, new_words_compared_together=True)
     vw = mem.vwd
@@ -620,12 +623,17 @@ def cpp_interface_ms(vocab, words, frames_np, n_sig_small=10000, steps=12):
         vw.add_word(w, vocab[w - 1])
     vw.update()
     t0 = time.perf_counter()
-    for s_ in range(n_sig_small):
-        mem.add_signature(words[s_])
+    mem.add_signatures_bulk(words[:n_sig])
     load_s = time.perf_counter() - t0
-    ms = mem.time_loop(np.stack(frames_np[: min(len(frames_np), 16)]), steps)
+    fr = np.stack(frames_np[: min(len(frames_np), 16)])
+    out = {"signatures": n_sig, "load_s": load_s}
+    out["map_by_value"] = mem.time_loop_modes(fr, steps, 0)
+    out["map_in_place"] = mem.time_loop_modes(fr, steps, 1)
+    out["flat"] = mem.time_loop_modes(fr, steps, 2)
+    mem.set_device_frames(False)
+    out["call_by_call_map_by_value"] = mem.time_loop_modes(fr, max(3, steps // 3), 0)
     mem.close()
-    return ms, n_sig_small, load_s
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------- ORB stream
@@ -1302,11 +1310,18 @@ def main():
                           "in front of the device included; single = one frame then lcd_synchronize (its stages run stand-alone)"
             config["frame_latency_ms"] = lat
             try:
-                cms, cn, cload = cpp_interface_ms(vocab, words, frames_np)
-                config["cpp_interface_ms_per_step"] = cms
-                config["cpp_interface_note"] = "C++ loop in liblcd_host.so through the reference's interface: MemoryHip::update (VWDictionaryHip::addNewWords) + " \
-                                               "computeLikelihood against all %d signatures of its memory + forget(oldest), host matrices in, std::map out " \
-                                               "(%d signatures loaded into the mirror's containers in %.1f s)" % (cn, cn, cload)
+                ci = cpp_interface_ms(vocab, words, frames_np, n_sig)
+                config["cpp_interface_ms_per_step"] = ci["map_by_value"]["step"]
+                config["cpp_interface_inplace_map_ms_per_step"] = ci["map_in_place"]["step"]
+                config["cpp_interface_flat_ms_per_step"] = ci["flat"]["step"]
+                config["cpp_interface_call_by_call_ms_per_step"] = ci["call_by_call_map_by_value"]["step"]
+                config["cpp_interface_detail"] = ci
+                config["cpp_interface_note"] = "C++ loop in liblcd_host.so through the reference's interface at %d signatures: MemoryHip::update (ONE lcd_frame_host call: " \
+                                               "quantisation + references + update()'s append + likelihood; host matrices in, the mirror's std::map bookkeeping included) + " \
+                                               "Memory::computeLikelihood(signature, ids) against every signature + forget(oldest).  ms_per_step = the reference's own signature " \
+                                               "(std::map by value: ~10^5 node allocations per frame); inplace_map = a caller-owned std::map updated in place; flat = two vectors; " \
+                                               "call_by_call = rounds 1-4's path (lcd_quantize, lcd_sig_add, lcd_likelihood) on the same memory.  detail = ms of " \
+                                               "{step, update, likelihood, forget}; mirror filled in %.1f s" % (ci["signatures"], ci["load_s"])
             except Exception as e:                                # noqa: BLE001
                 config["cpp_interface_error"] = "%s: %s" % (type(e).__name__, e)
             config["host_path_note"] = "lcd_quantize + lcd_sig_add + lcd_likelihood + lcd_sig_remove from host pointers (PCIe + syncs included)"

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LCD_ABI_VERSION 4
+#define LCD_ABI_VERSION 5
 
 typedef struct lcd_engine lcd_engine;
 
@@ -254,6 +254,34 @@ typedef struct lcd_frame_args {
     struct lcd_bayes_result* d_bayes;  /* out, may be NULL: the highest loop-closure hypothesis (Rtabmap.cpp:2147-2158), 32 bytes */
 } lcd_frame_args;
 int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* args);
+
+/* The same frame for a caller whose descriptors live in HOST memory -- what corelib hands VWDictionary::addNewWords (a cv::Mat,
+ * VWDictionary.cpp:913) and gets back from Memory::computeLikelihood (Memory.cpp:2177): ONE call, one synchronisation.  The descriptors
+ * are copied to the device (engine-owned pinned staging), the frame runs as lcd_frame_dev describes (quantisation -> the signature's
+ * references -> [append_new_words: the words it creates become vocabulary rows, VWDictionary::update()'s append branch] -> TF-IDF
+ * likelihood against every registered signature), and the word ids and the dense likelihood over the signature slots come back.
+ * Slots are handed out in registration order (lcd_sig_add, lcd_sig_add_bulk in array order, frames) and never reused; a retired
+ * signature's slot scores 0.  What the frames in flight of a pipelined handle owe is completed first and this frame is completed
+ * before the call returns (a host caller needs its answer: use a plain handle).  (ABI v5; the reference-side caller is
+ * rtabmap_amd/host/VWDictionaryHip::addNewWordsAndScore.) */
+typedef struct lcd_frame_host_args {
+    int32_t struct_size;               /* sizeof(lcd_frame_host_args) */
+    int32_t q;                         /* descriptors in the frame (1..8192) */
+    const void* descriptors;           /* HOST [q x dim], row-major, as cv::Mat::data of a continuous matrix */
+    int32_t flags;                     /* lcd_quantize_flags */
+    float nndr_ratio;
+    int32_t sig_id;                    /* != 0: register the frame as this signature */
+    int32_t first_new_word_id;         /* as lcd_frame_args */
+    float N;                           /* as lcd_frame_args */
+    int32_t append_new_words;          /* as lcd_frame_args */
+    int32_t* word_ids;                 /* HOST out [q], as lcd_quantize */
+    float* likelihood;                 /* HOST out, may be NULL: [likelihood_capacity], entry = signature slot */
+    int64_t likelihood_capacity;       /* floats available at likelihood (>= slots after this frame, else LCD_ERR_INVALID) */
+    int64_t* n_slots;                  /* HOST out, may be NULL: slots in use after this frame = entries written */
+} lcd_frame_host_args;
+int lcd_frame_host(lcd_engine* h, const lcd_frame_host_args* args);
+/* slots in use (host bookkeeping, nothing is synchronised or completed): what lcd_frame_host's likelihood_capacity must cover is this + 1 */
+int lcd_slot_count(const lcd_engine* h, int64_t* n_slots);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Bayes filter over the signatures of the working memory ("next" row f2 of the scope table).

@@ -22,7 +22,7 @@ SYMBOLS = [
     "lcd_vocab_clear", "lcd_vocab_append", "lcd_vocab_remove", "lcd_vocab_remove_unused", "lcd_vocab_remove_unused_async", "lcd_vocab_rebuild", "lcd_vocab_count", "lcd_vocab_read",
     "lcd_knn2", "lcd_selfdist", "lcd_quantize", "lcd_find_nn",
     "lcd_sig_add", "lcd_sig_remove", "lcd_sig_add_bulk", "lcd_sig_count", "lcd_word_nrefs",
-    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_adjust_likelihood_dev", "lcd_frame_dev", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood", "lcd_profile_score_work", "lcd_set_option", "lcd_record_event",
+    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_adjust_likelihood_dev", "lcd_frame_dev", "lcd_frame_host", "lcd_slot_count", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood", "lcd_profile_score_work", "lcd_set_option", "lcd_record_event",
     "lcd_bayes_configure", "lcd_bayes_reset", "lcd_bayes_set_neighbors", "lcd_bayes_update_dev", "lcd_bayes_update", "lcd_bayes_posterior",
 ]
 
@@ -49,6 +49,12 @@ class LcdFrameArgs(C.Structure):
                 ("likelihood_capacity", C.c_int64), ("d_hypothesis", C.c_void_p), ("d_adjusted", C.c_void_p),
                 ("virtual_place_ratio", C.c_float), ("append_new_words", C.c_int32), ("ready_event", C.c_void_p),
                 ("d_posterior", C.c_void_p), ("d_bayes", C.c_void_p)]
+
+
+class LcdFrameHostArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("q", C.c_int32), ("descriptors", C.c_void_p), ("flags", C.c_int32), ("nndr_ratio", C.c_float),
+                ("sig_id", C.c_int32), ("first_new_word_id", C.c_int32), ("N", C.c_float), ("append_new_words", C.c_int32),
+                ("word_ids", C.c_void_p), ("likelihood", C.c_void_p), ("likelihood_capacity", C.c_int64), ("n_slots", C.c_void_p)]
 
 
 class LcdBayesResult(C.Structure):
@@ -122,6 +128,8 @@ def load():
     L.lcd_adjust_likelihood.argtypes = [vp, vp, C.c_int, f32]
     L.lcd_adjust_likelihood_dev.argtypes = [vp, vp, C.c_int, f32]
     L.lcd_frame_dev.argtypes = [vp, C.POINTER(LcdFrameArgs)]
+    L.lcd_frame_host.argtypes = [vp, C.POINTER(LcdFrameHostArgs)]
+    L.lcd_slot_count.argtypes = [vp, C.POINTER(C.c_int64)]
     L.lcd_knn2_dev.argtypes = [vp, vp, C.c_int, vp, vp]
     L.lcd_shard_knn2_dev.argtypes = [vp, vp, C.c_int, vp]
     L.lcd_shard_frame_dev.argtypes = [vp, vp, C.c_int, C.c_int, f32, i32, i32, f32, C.c_int, C.c_int, vp, i64, vp, vp, i64]
@@ -320,6 +328,23 @@ class Engine:
                          d_word_ids_ptr, d_like_ptr, like_capacity, d_hypothesis_ptr, d_adjusted_ptr, virtual_place_ratio,
                          1 if append_new_words else 0, ready_event, d_posterior_ptr, d_bayes_ptr)
         self._ck(self.L.lcd_frame_dev(self.h, C.byref(a)))
+
+    def frame_host(self, desc, sig_id, N, incremental=True, new_words_compared=True, nndr=0.8, first_new_word_id=0, append_new_words=False,
+                   want_likelihood=True):
+        """lcd_frame_host: host descriptors in, (word ids, dense likelihood over the signature slots) out, one synchronisation."""
+        d = np.ascontiguousarray(desc)
+        q = d.shape[0]
+        flags = (LCD_Q_INCREMENTAL if incremental else 0) | (LCD_Q_NEW_WORDS_COMPARED if new_words_compared else 0)
+        n = C.c_int64(0)
+        self._ck(self.L.lcd_slot_count(self.h, C.byref(n)))
+        words = np.zeros(q, np.int32)
+        like = np.zeros(n.value + 1, np.float32) if want_likelihood else None
+        ns = C.c_int64(0)
+        a = LcdFrameHostArgs(C.sizeof(LcdFrameHostArgs), q, _p(d), flags, nndr, sig_id, first_new_word_id, float(N), 1 if append_new_words else 0,
+                             _p(words), _p(like) if like is not None else None, like.shape[0] if like is not None else 0,
+                             C.cast(C.byref(ns), C.c_void_p))
+        self._ck(self.L.lcd_frame_host(self.h, C.byref(a)))
+        return words, (like[: ns.value] if like is not None else None)
 
     def frame_args(self, **kw):
         """A reusable argument block for frame_dev_args (callers in a tight loop change a few fields per frame)."""

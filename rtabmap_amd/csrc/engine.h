@@ -122,6 +122,8 @@ struct lcd_engine {
                                                         // catches up with the rows appended / removed on the device (reconcile(): synchronises, two small reads)
     const char* prof2_kernel = "score_kernel";
     lcd::PinBuf h_in, h_out, h_out2;
+    lcd::PinBuf h_frame_in, h_frame_out;                // lcd_frame_host: descriptors in, word ids + likelihood out (one synchronisation per call)
+    lcd::DevBuf d_frame_desc, d_frame_words, d_frame_like;
     lcd::Bayes bayes;                                   // Bayes filter over the signature slots (bayes.h)
     lcd::DevBuf d_adj_scratch;                          // adjusted likelihood when the caller wants the posterior but not that vector
     lcd::DevBuf d_hyp_scratch;                          // hypothesis record when the caller only wants the adjusted vector

@@ -1433,11 +1433,65 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     return LCD_OK;
 }
 
+static int frame_dev_body(lcd_engine* h, const lcd_frame_args* a);
+
 int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     LCD_TRY
     LCD_CHECK_HANDLE(h);
     FrameHostTimer timer__(h);
     LCD_DEV_NODRAIN(h);
+    return frame_dev_body(h, a);
+    LCD_CATCH(h)
+}
+
+int lcd_slot_count(const lcd_engine* h, int64_t* n_slots) {
+    if (!h || !n_slots) return LCD_ERR_INVALID;
+    int64_t owed = 0;
+    for (const lcd_engine::InFlight& f : h->inflight) if (f.a.sig_id != 0) owed += 1;
+    *n_slots = h->tfidf.n_slots + owed;
+    return LCD_OK;
+}
+
+int lcd_frame_host(lcd_engine* h, const lcd_frame_host_args* a) {
+    LCD_TRY
+    LCD_CHECK_HANDLE(h);
+    LCD_DEV(h);                                                      // completes what a pipelined handle owes
+    if (!a || a->struct_size != (int32_t)sizeof(lcd_frame_host_args)) return h->fail(LCD_ERR_INVALID, "lcd_frame_host: bad argument block");
+    const int q = a->q;
+    if (q <= 0 || q > 8192 || !a->descriptors || !a->word_ids) return h->fail(LCD_ERR_INVALID, "lcd_frame_host: bad argument");
+    const size_t src_row = (size_t)h->dim * (h->dtype == LCD_F32 ? 4 : 1);
+    if (src_row != (size_t)h->row_bytes) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_frame_host: rows of this size are padded on the device (use lcd_quantize)");
+    const int64_t slots_after = h->tfidf.n_slots + (a->sig_id != 0 ? 1 : 0);
+    if (a->likelihood && a->likelihood_capacity < slots_after) return h->fail(LCD_ERR_INVALID, "lcd_frame_host: likelihood buffer too small");
+    // descriptors: host -> pinned staging -> device, on the engine's stream (the one synchronisation at the end frees the staging)
+    const size_t dbytes = (size_t)q * h->row_bytes;
+    LCD_HIP(h, h->h_frame_in.reserve(dbytes));
+    std::memcpy(h->h_frame_in.p, a->descriptors, dbytes);
+    LCD_HIP(h, dreserve(h, h->d_frame_desc, std::max<size_t>(dbytes, 16)));
+    LCD_HIP(h, dreserve(h, h->d_frame_words, (size_t)q * 4));
+    if (a->likelihood) LCD_HIP(h, dreserve(h, h->d_frame_like, (size_t)std::max<int64_t>(slots_after, 1) * 4));
+    LCD_HIP(h, hipMemcpyAsync(h->d_frame_desc.p, h->h_frame_in.p, dbytes, hipMemcpyHostToDevice, h->stream));
+    lcd_frame_args fa;
+    std::memset(&fa, 0, sizeof(fa));
+    fa.struct_size = (int32_t)sizeof(fa); fa.q = q; fa.d_descriptors = h->d_frame_desc.p; fa.flags = a->flags; fa.nndr_ratio = a->nndr_ratio;
+    fa.sig_id = a->sig_id; fa.first_new_word_id = a->first_new_word_id; fa.N = a->N; fa.append_new_words = a->append_new_words;
+    fa.d_word_ids = h->d_frame_words.as<int32_t>();
+    if (a->likelihood) { fa.d_likelihood = h->d_frame_like.as<float>(); fa.likelihood_capacity = (int64_t)(h->d_frame_like.cap / 4); }
+    { int rc = frame_dev_body(h, &fa); if (rc) return rc; }
+    { int rc = h->drain(false); if (rc) return rc; }                  // a pipelined handle: the frame's stages stand-alone (the row mirror is not needed here)
+    const size_t wbytes = (size_t)q * 4, lbytes = a->likelihood ? (size_t)slots_after * 4 : 0;
+    LCD_HIP(h, h->h_frame_out.reserve(wbytes + lbytes + 16));
+    LCD_HIP(h, hipMemcpyAsync(h->h_frame_out.p, h->d_frame_words.p, wbytes, hipMemcpyDeviceToHost, h->stream));
+    if (lbytes) LCD_HIP(h, hipMemcpyAsync((char*)h->h_frame_out.p + wbytes, h->d_frame_like.p, lbytes, hipMemcpyDeviceToHost, h->stream));
+    LCD_HIP(h, hipStreamSynchronize(h->stream));
+    std::memcpy(a->word_ids, h->h_frame_out.p, wbytes);
+    if (lbytes) std::memcpy(a->likelihood, (const char*)h->h_frame_out.p + wbytes, lbytes);
+    if (a->n_slots) *a->n_slots = slots_after;
+    return LCD_OK;
+    LCD_CATCH(h)
+}
+
+static int frame_dev_body(lcd_engine* h, const lcd_frame_args* a) {
     if (!a || a->struct_size != (int32_t)sizeof(lcd_frame_args)) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: bad argument block");
     const int q = a->q;
     if (q <= 0 || q > 8192 || !a->d_descriptors || !a->d_word_ids) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: bad argument");
@@ -1480,7 +1534,6 @@ int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     const uint64_t vseq = h->vseq;
     if (app) { h->unreconciled.push_back(lcd_engine::DevAppend{vseq, a->first_new_word_id, q, true}); h->vseq += 1; }
     return frame_stage_s(h, *a, r, app, vseq);
-    LCD_CATCH(h)
 }
 
 int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_ids, float* d_dist) {

@@ -790,24 +790,36 @@ __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, cons
 // only the strip (8 tiles + augmentation entries = 66 KB) and TWO workgroups share a compute unit.
 constexpr size_t BF_LDS_BYTES_Q = (size_t)MF_STRIP_TILES * BF_TILE_F * 4 + (size_t)MF_STRIP_TILES * 64 * 4;
 
+__device__ __forceinline__ void qsplit_item(const QSplitArgs& qs, int t, const float4& a, const float4& b) {
+    const int qi = t >> 3, h = (t >> 2) & 1, sx = t & 3;
+    uint4 hi, lo;
+    op_split2_rt(qs.f16, -2.0f * a.x, -2.0f * a.y, hi.x, lo.x);
+    op_split2_rt(qs.f16, -2.0f * a.z, -2.0f * a.w, hi.y, lo.y);
+    op_split2_rt(qs.f16, -2.0f * b.x, -2.0f * b.y, hi.z, lo.z);
+    op_split2_rt(qs.f16, -2.0f * b.z, -2.0f * b.w, hi.w, lo.w);
+    const size_t base = ((size_t)(qi >> 5) * 4 + sx) * 2;
+    qs.qsplit[(base + 0) * 64 + h * 32 + (qi & 31)] = hi;
+    qs.qsplit[(base + 1) * 64 + h * 32 + (qi & 31)] = lo;
+    float part = fmaf(b.w, b.w, fmaf(b.z, b.z, fmaf(b.y, b.y, fmaf(b.x, b.x, fmaf(a.w, a.w, fmaf(a.z, a.z, fmaf(a.y, a.y, a.x * a.x)))))));
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    if ((t & 7) == 0) qs.qnorm[qi] = part;
+}
+// One item = eight floats of one query.  A thread's items are READ first and written afterwards: loads and stores share one in-order
+// counter, so a second trip's loads behind a first trip's stores wait for a store round trip that carries no data (round 4's stamps:
+// the eight two-trip workgroups took 17 us, the longest chain of launch A).  Frames of up to 1 024 descriptors get one item per thread.
 __device__ __forceinline__ void qsplit_body(const QSplitArgs& qs, int wg) {
-    for (int t = wg * (int)blockDim.x + (int)threadIdx.x; t < qs.qpad * 8; t += qs.n_wgs * (int)blockDim.x) {   // (qpad * 8 is a multiple of 64)
-        const int qi = t >> 3, h = (t >> 2) & 1, sx = t & 3;
-        const float4* src = reinterpret_cast<const float4*>(qs.queries + (size_t)min(qi, qs.nq - 1) * 64 + 32 * h + 8 * sx);   // padding repeats the last query
-        const float4 a = src[0], b = src[1];
-        uint4 hi, lo;
-        op_split2_rt(qs.f16, -2.0f * a.x, -2.0f * a.y, hi.x, lo.x);
-        op_split2_rt(qs.f16, -2.0f * a.z, -2.0f * a.w, hi.y, lo.y);
-        op_split2_rt(qs.f16, -2.0f * b.x, -2.0f * b.y, hi.z, lo.z);
-        op_split2_rt(qs.f16, -2.0f * b.z, -2.0f * b.w, hi.w, lo.w);
-        const size_t base = ((size_t)(qi >> 5) * 4 + sx) * 2;
-        qs.qsplit[(base + 0) * 64 + h * 32 + (qi & 31)] = hi;
-        qs.qsplit[(base + 1) * 64 + h * 32 + (qi & 31)] = lo;
-        float part = fmaf(b.w, b.w, fmaf(b.z, b.z, fmaf(b.y, b.y, fmaf(b.x, b.x, fmaf(a.w, a.w, fmaf(a.z, a.z, fmaf(a.y, a.y, a.x * a.x)))))));
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        part += __shfl_xor(part, 4, 64);
-        if ((t & 7) == 0) qs.qnorm[qi] = part;
+    const int n_items = qs.qpad * 8, stride = qs.n_wgs * (int)blockDim.x;   // (qpad * 8 is a multiple of 64: a wave's lanes take part together)
+    for (int t0 = wg * (int)blockDim.x + (int)threadIdx.x; t0 < n_items; t0 += 2 * stride) {
+        const int t1 = t0 + stride;
+        const bool two = t1 < n_items;
+        const int tt = two ? t1 : t0;
+        const float4* s0 = reinterpret_cast<const float4*>(qs.queries + (size_t)min(t0 >> 3, qs.nq - 1) * 64 + 32 * ((t0 >> 2) & 1) + 8 * (t0 & 3));   // padding repeats the last query
+        const float4* s1 = reinterpret_cast<const float4*>(qs.queries + (size_t)min(tt >> 3, qs.nq - 1) * 64 + 32 * ((tt >> 2) & 1) + 8 * (tt & 3));
+        const float4 a0 = s0[0], b0 = s0[1], a1 = s1[0], b1 = s1[1];
+        qsplit_item(qs, t0, a0, b0);
+        if (two) qsplit_item(qs, t1, a1, b1);
     }
 }
 
@@ -2072,7 +2084,7 @@ hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLa
     tr.n_filter_wgs = p.q > 0 ? f.sd.n_tiles + (px > 0 ? px : p.n_blocks) * ((p.q + BF_QB - 1) / BF_QB) : 0;
     tr.has_resolve = resolve ? 1 : 0; tr.has_register = reg ? 1 : 0; tr.n_redo = resolve ? resolve->n_redo : 0;
     QSplitArgs qs{};
-    if (qsp) { qs = *qsp; qs.n_wgs = (qs.qpad * 8 + PIPE_BLOCK * 2 - 1) / (PIPE_BLOCK * 2); if (qs.n_wgs < 1) qs.n_wgs = 1; }
+    if (qsp) { qs = *qsp; qs.n_wgs = std::min((qs.qpad * 8 + PIPE_BLOCK - 1) / PIPE_BLOCK, 32); if (qs.n_wgs < 1) qs.n_wgs = 1; }   // one item per thread up to 1 024 descriptors
     tr.n_q_wgs = qsp ? qs.n_wgs : 0;
     const int grid = tr.n_filter_wgs + tr.has_resolve + tr.has_register + tr.n_redo + tr.n_q_wgs;
     if (grid == 0) return hipSuccess;

@@ -3,6 +3,7 @@
 
 #include "DbLoaderHip.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <set>
@@ -11,7 +12,8 @@ namespace rtabmap_amd {
 
 const int MemoryHip::kIdVirtual = -1;
 
-MemoryHip::MemoryHip(const ParametersMap& parameters, int device) : _vwd(new VWDictionaryHip(parameters, device)), _idCount(0), _maxStMemSize(10) {
+MemoryHip::MemoryHip(const ParametersMap& parameters, int device)
+    : _vwd(new VWDictionaryHip(parameters, device)), _idCount(0), _maxStMemSize(10), _deviceFrames(true), _likeSig(0), _likeSortedValid(false) {
     ParametersMap::const_iterator it = parameters.find("Mem/STMSize");
     if (it != parameters.end()) _maxStMemSize = atoi(it->second.c_str());
     if (_maxStMemSize < 0) _maxStMemSize = 0;
@@ -38,7 +40,14 @@ int MemoryHip::update(const Mat& descriptors, int nQuantized, std::vector<int>& 
     std::list<int> wordIds;
     const int rows = descriptors.rows;
     int nq = nQuantized < 0 || nQuantized > rows ? rows : nQuantized;
-    if (rows) {
+    _likeSig = 0;
+    bool fast = false;
+    if (rows && nq == rows && _deviceFrames && _vwd->isIncremental()) {
+        // quantisation + the signature's references + update()'s append + the likelihood of Rtabmap.cpp:2117, one device call
+        fast = _vwd->addNewWordsAndScore(descriptors, id, (float)(_signatures.size() + 1), [this](int s) { return this->getNi(s); }, wordIds, _likeSlots);
+        if (fast && !_likeSlots.empty()) { _likeSig = id; _likeSortedValid = false; }
+    }
+    if (rows && !fast) {
         if (nq > 0) {
             Mat forQuantization = nq == rows ? descriptors : Mat(nq, descriptors.cols, descriptors.type(), descriptors.data.data());
             wordIds = _vwd->addNewWords(forQuantization, id);
@@ -121,6 +130,7 @@ std::map<int, int> MemoryHip::getNeighborsId(int signatureId, int maxGraphDepth)
 }
 
 int MemoryHip::addSignature(const std::vector<int>& wordIds, int id) {
+    _likeSig = 0;
     if (id == 0) id = ++_idCount;
     if (_signatures.count(id)) return 0;
     for (size_t k = 0; k < wordIds.size(); ++k) if (wordIds[k] > 0) _vwd->addWordRef(wordIds[k], id);
@@ -201,6 +211,7 @@ int MemoryHip::getNi(int signatureId) const {   // Memory.cpp:4955-4968
 void MemoryHip::forget(int signatureId) {
     std::map<int, std::vector<int> >::iterator it = _signatures.find(signatureId);
     if (it == _signatures.end()) return;
+    _likeSig = 0;                               // N and the references change: the frame's likelihood is no longer Memory::computeLikelihood's
     std::set<int> keys(it->second.begin(), it->second.end());   // uUniqueKeys (Memory.cpp:6885)
     for (std::set<int>::iterator k = keys.begin(); k != keys.end(); ++k) _vwd->removeAllWordRef(*k, signatureId);
     _dbNi[signatureId] = (int)it->second.size();
@@ -220,10 +231,76 @@ std::map<int, float> MemoryHip::computeLikelihood(const std::list<int>& wordIds,
     return _vwd->computeLikelihood(wordIds, ids, N, [this](int s) { return this->getNi(s); });
 }
 
+// (signature id, likelihood) of every signature registered on the device, ascending id, from the frame's slot-indexed result
+const std::vector<std::pair<int, float> >& MemoryHip::sortedLikelihood() {
+    if (_likeSortedValid) return _likeSorted;
+    const std::vector<int>& slotSig = _vwd->slotSignatures();
+    _likeSorted.clear();
+    const size_t n = std::min(slotSig.size(), _likeSlots.size());
+    _likeSorted.reserve(n);
+    bool ascending = true;
+    for (size_t s = 0; s < n; ++s) {
+        if (slotSig[s] == 0) continue;
+        if (!_likeSorted.empty() && slotSig[s] < _likeSorted.back().first) ascending = false;
+        _likeSorted.push_back(std::pair<int, float>(slotSig[s], _likeSlots[s]));
+    }
+    if (!ascending) std::sort(_likeSorted.begin(), _likeSorted.end());   // (re-registered signatures sit in later slots)
+    _likeSortedValid = true;
+    return _likeSorted;
+}
+
+static float lookupSorted(const std::vector<std::pair<int, float> >& v, size_t& cursor, int id) {
+    // ids usually arrive ascending (Rtabmap builds the list from a std::map): a cursor that only moves forward; else a binary search
+    if (cursor < v.size() && v[cursor].first <= id) {
+        while (cursor < v.size() && v[cursor].first < id) ++cursor;
+        return cursor < v.size() && v[cursor].first == id ? v[cursor].second : 0.0f;
+    }
+    std::vector<std::pair<int, float> >::const_iterator it = std::lower_bound(v.begin(), v.end(), std::pair<int, float>(id, -1e30f));
+    cursor = (size_t)(it - v.begin());
+    return it != v.end() && it->first == id ? it->second : 0.0f;
+}
+
 std::map<int, float> MemoryHip::computeLikelihood(int signatureId, const std::list<int>& ids) {
     std::map<int, std::vector<int> >::const_iterator it = _signatures.find(signatureId);
     if (it == _signatures.end()) return std::map<int, float>();   // "The signature is null" (Memory.cpp:2222)
+    if (_likeSig != 0 && _likeSig == signatureId) {
+        std::map<int, float> likelihood;
+        if (ids.empty()) { fprintf(stderr, "[WARN] ids list is empty\n"); return likelihood; }   // :2227-2231
+        const std::vector<std::pair<int, float> >& v = sortedLikelihood();
+        size_t cursor = 0;
+        bool sorted = true; int last = 0; bool first = true;
+        for (std::list<int>::const_iterator i = ids.begin(); i != ids.end(); ++i) { if (!first && *i <= last) { sorted = false; break; } last = *i; first = false; }
+        if (sorted) for (std::list<int>::const_iterator i = ids.begin(); i != ids.end(); ++i) likelihood.insert(likelihood.end(), std::pair<int, float>(*i, lookupSorted(v, cursor, *i)));
+        else for (std::list<int>::const_iterator i = ids.begin(); i != ids.end(); ++i) likelihood[*i] = lookupSorted(v, cursor, *i);
+        return likelihood;
+    }
     return computeLikelihood(std::list<int>(it->second.begin(), it->second.end()), ids);
+}
+
+void MemoryHip::computeLikelihood(int signatureId, const std::list<int>& ids, std::map<int, float>& likelihood) {
+    if (_likeSig == 0 || _likeSig != signatureId || !_signatures.count(signatureId) || ids.empty()) { likelihood = this->computeLikelihood(signatureId, ids); return; }
+    const std::vector<std::pair<int, float> >& v = sortedLikelihood();
+    size_t cursor = 0;
+    std::map<int, float>::iterator m = likelihood.begin();
+    int last = 0; bool first = true;
+    for (std::list<int>::const_iterator i = ids.begin(); i != ids.end(); ++i) {
+        if (!first && *i <= last) { likelihood = this->computeLikelihood(signatureId, ids); return; }   // unsorted ids: the plain way
+        last = *i; first = false;
+        while (m != likelihood.end() && m->first < *i) m = likelihood.erase(m);
+        const float val = lookupSorted(v, cursor, *i);
+        if (m != likelihood.end() && m->first == *i) { m->second = val; ++m; }
+        else m = ++likelihood.insert(m, std::pair<int, float>(*i, val));
+    }
+    likelihood.erase(m, likelihood.end());
+}
+
+bool MemoryHip::computeLikelihoodFlat(int signatureId, std::vector<int>& sigIds, std::vector<float>& values) {
+    if (_likeSig == 0 || _likeSig != signatureId) return false;
+    const std::vector<std::pair<int, float> >& v = sortedLikelihood();
+    sigIds.resize(v.size());
+    values.resize(v.size());
+    for (size_t k = 0; k < v.size(); ++k) { sigIds[k] = v[k].first; values[k] = v[k].second; }
+    return true;
 }
 
 }  // namespace rtabmap_amd

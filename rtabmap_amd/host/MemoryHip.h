@@ -43,6 +43,21 @@ public:
     std::vector<int> signatureIds() const;
     std::map<int, float> computeLikelihood(int signatureId, const std::list<int>& ids);
     std::map<int, float> computeLikelihood(const std::list<int>& wordIds, const std::list<int>& ids);
+    // The device-resident frame (round 5).  update() quantises, registers the signature, appends its new words to the device vocabulary
+    // and scores it against every registered signature in ONE device call (VWDictionaryHip::addNewWordsAndScore -> lcd_frame_host); the
+    // computeLikelihood(signatureId, ids) that Rtabmap::process makes next (Rtabmap.cpp:2117) is answered from that result when nothing
+    // changed in between (same N, same references) -- otherwise, and for any other signature, it runs lcd_likelihood as before.
+    // setDeviceFrames(false) gives the call-by-call path of rounds 1-4 back (lcd_quantize, lcd_sig_add, lcd_likelihood: five
+    // synchronisations per frame).  Results are the same (tests run both).
+    void setDeviceFrames(bool on) { _deviceFrames = on; _likeSig = 0; }
+    bool deviceFrames() const { return _deviceFrames; }
+    // the same answer into a caller-owned map: entries whose keys are already there are overwritten in place (Rtabmap asks for nearly the
+    // same ids frame after frame: a std::map of 100 000 fresh nodes costs milliseconds of allocation), others inserted, keys not in
+    // `ids` erased
+    void computeLikelihood(int signatureId, const std::list<int>& ids, std::map<int, float>& likelihood);
+    // ... and as two parallel vectors over EVERY signature registered on the device, ascending id (what a caller that feeds
+    // adjustLikelihood / the Bayes filter from flat arrays wants).  false: no result of update() is at hand for that signature.
+    bool computeLikelihoodFlat(int signatureId, std::vector<int>& sigIds, std::vector<float>& values);
 
     // ---- what BayesFilter::computePosterior asks
     enum LinkType { kNeighbor = 0, kGlobalClosure = 1 };   // Link::Type (Link.h:42-56), the two kinds this subset creates
@@ -58,6 +73,8 @@ public:
     int getMaxStMemSize() const { return _maxStMemSize; }
     // every signature's references are on the device (the Bayes filter works on registered signatures)
     bool flushReferences() { return _vwd->flushReferences([this](int s) { return this->getNi(s); }); }
+    // the same after many addSignature calls (a memory replayed without a database): ONE bulk registration
+    bool flushReferencesBulk() { return _vwd->flushReferencesBulk([this](int s) { return this->getNi(s); }); }
     const std::string& lastError() const { return _vwd->lastError(); }
     const std::string& loadError() const { return _loadError; }        // of the last loadDataFromDb that returned -1
 
@@ -73,6 +90,13 @@ private:
     std::set<int> _stMem, _workingMem;
     int _maxStMemSize;                              // Mem/STMSize (Parameters.h: 10)
     std::map<int, std::map<int, LinkType> > _links; // Signature::getLinks(): id -> (other id -> type)
+    // the likelihood update() brought back with the frame: by device slot, for signature _likeSig (0: none / stale)
+    bool _deviceFrames;
+    int _likeSig;
+    std::vector<float> _likeSlots;
+    std::vector<std::pair<int, float> > _likeSorted;   // (signature id, value) ascending id, built on demand from _likeSlots
+    bool _likeSortedValid;
+    const std::vector<std::pair<int, float> >& sortedLikelihood();
 };
 
 }  // namespace rtabmap_amd

@@ -164,6 +164,9 @@ std::vector<int> VWDictionaryHip::getIndexedWordIds() const {
 bool VWDictionaryHip::rebuildEngine() {
     if (_engine) { lcd_destroy(_engine); _engine = nullptr; }
     _deviceSigs.clear();
+    _slotSig.clear();
+    _sigSlot.clear();
+    _deviceRows.clear();                                             // (their words are in _notIndexedWords: the next update() appends them)
     _dirtySigs.clear();
     for (std::map<int, std::vector<int> >::const_iterator s = _sigWords.begin(); s != _sigWords.end(); ++s) _dirtySigs.insert(s->first);
     if (_visualWords.empty()) return true;                           // nothing to replay: the engine is created by the next update()
@@ -205,20 +208,25 @@ void VWDictionaryHip::update() {
         // stage the not-indexed rows (ascending id, std::set order)
         std::vector<int32_t> newIds;
         std::vector<unsigned char> newRows;
+        std::vector<int32_t> allNew(_notIndexedWords.begin(), _notIndexedWords.end());   // ascending id: the row order of the append branch
         for (std::set<int>::iterator it = _notIndexedWords.begin(); it != _notIndexedWords.end(); ++it) {
+            if (_deviceRows.count(*it)) continue;                        // a row already (addNewWordsAndScore appended it on the device)
             std::map<int, VisualWord*>::iterator w = _visualWords.find(*it);
             if (w == _visualWords.end()) continue;
             const Mat& d = w->second->getDescriptor();
             newRows.insert(newRows.end(), d.data.begin(), d.data.end());
             newIds.push_back(*it);
         }
-        if (_notIndexedWords.size() && _removedIndexedWords.size() == 0 && _visualWords.size()) {
+        // rows the device appended lie behind the indexed ones in creation (= ascending id) order; words that still have to be sent would
+        // land behind THEM, which is the append branch's order only when their ids are higher -- otherwise the rebuild branch sorts
+        const bool mixed = !_deviceRows.empty() && !newIds.empty() && newIds.front() < *_deviceRows.rbegin();
+        if (_notIndexedWords.size() && _removedIndexedWords.size() == 0 && _visualWords.size() && !mixed) {
             // brute-force append branch (:571-609)
-            if (lcd_vocab_append(_engine, newRows.data(), (int)newIds.size(), newIds.data()) != LCD_OK) { _lastError = lcd_last_error(_engine); logError("%s", _lastError.c_str()); return; }
+            if (!newIds.empty() && lcd_vocab_append(_engine, newRows.data(), (int)newIds.size(), newIds.data()) != LCD_OK) { _lastError = lcd_last_error(_engine); logError("%s", _lastError.c_str()); return; }
             int i = (int)_mapIndexId.size() ? _mapIndexId.rbegin()->first + 1 : 0;
-            for (size_t k = 0; k < newIds.size(); ++k, ++i) {
-                _mapIndexId.insert(_mapIndexId.end(), std::pair<int, int>(i, newIds[k]));
-                _mapIdIndex.insert(std::pair<int, int>(newIds[k], i));
+            for (size_t k = 0; k < allNew.size(); ++k, ++i) {
+                _mapIndexId.insert(_mapIndexId.end(), std::pair<int, int>(i, allNew[k]));
+                _mapIdIndex.insert(std::pair<int, int>(allNew[k], i));
             }
         } else {
             // full rebuild in ascending word id (:610-690) -- done on the device: tombstone the removed rows, append the
@@ -245,6 +253,7 @@ void VWDictionaryHip::update() {
     }
     _notIndexedWords.clear();
     _removedIndexedWords.clear();
+    _deviceRows.clear();
 }
 
 void VWDictionaryHip::clear(bool printWarningsIfNotEmpty) {   // :843-873
@@ -261,11 +270,12 @@ void VWDictionaryHip::clear(bool printWarningsIfNotEmpty) {   // :843-873
     _unusedWords.clear();
     if (_engine) {
         lcd_vocab_clear(_engine);
-        for (std::set<int>::iterator s = _deviceSigs.begin(); s != _deviceSigs.end(); ++s) lcd_sig_remove(_engine, *s);
+        for (std::set<int>::iterator s = _deviceSigs.begin(); s != _deviceSigs.end(); ++s) { lcd_sig_remove(_engine, *s); slotRetire(*s); }
     }
     _sigWords.clear();
     _dirtySigs.clear();
     _deviceSigs.clear();
+    _deviceRows.clear();
 }
 
 bool VWDictionaryHip::addWordRef(int wordId, int signatureId) {   // :880-897
@@ -335,7 +345,8 @@ void VWDictionaryHip::removeWords(const std::vector<VisualWord*>& words) {   // 
     for (unsigned int i = 0; i < words.size(); ++i) {
         _visualWords.erase(words[i]->id());
         _unusedWords.erase(words[i]->id());
-        if (_notIndexedWords.erase(words[i]->id()) == 0) _removedIndexedWords.insert(words[i]->id());
+        const bool onDevice = _deviceRows.erase(words[i]->id()) != 0;  // created by a device-resident frame: a vocabulary row although update() has not run
+        if (_notIndexedWords.erase(words[i]->id()) == 0 || onDevice) _removedIndexedWords.insert(words[i]->id());
     }
 }
 void VWDictionaryHip::deleteUnusedWords() {   // :1609-1617
@@ -398,6 +409,78 @@ std::list<int> VWDictionaryHip::addNewWords(const Mat& descriptorsIn, int signat
     return wordIds;
 }
 
+// ---------------------------------------------------------------------------------------------- addNewWords + computeLikelihood, one device call
+bool VWDictionaryHip::addNewWordsAndScore(const Mat& descriptorsIn, int signatureId, float N, const std::function<int(int)>& getNi,
+                                          std::list<int>& wordIds, std::vector<float>& likelihoodBySlot) {
+    wordIds.clear();
+    if (!_incrementalDictionary || descriptorsIn.rows == 0 || descriptorsIn.cols == 0 || signatureId == 0) return false;
+    if (_notIndexedWords.size() || _removedIndexedWords.size()) return false;       // update() first (Memory::preUpdate runs it)
+    if (descriptorsIn.type() != MAT_32F && descriptorsIn.type() != MAT_8U) return false;
+    if (_visualWords.size()) {
+        const Mat& first = _visualWords.begin()->second->getDescriptor();
+        if (first.cols != descriptorsIn.cols || first.type() != descriptorsIn.type()) return false;   // addNewWords reports it (:948-957)
+    }
+    if (descriptorsIn.rowBytes() % 4 != 0) return false;                            // rows the device pads: lcd_quantize takes them
+    if (_deviceSigs.count(signatureId) || _sigWords.count(signatureId)) return false;
+    if (!ensureEngine(descriptorsIn.type(), descriptorsIn.cols)) return false;
+    if (!flushReferences(getNi)) return false;                                      // the device index is what the host maps say
+    const int q = descriptorsIn.rows;
+    std::vector<int32_t> out(q, 0);
+    likelihoodBySlot.assign(_slotSig.size() + 1, 0.0f);
+    int64_t nSlots = 0;
+    lcd_frame_host_args a;
+    std::memset(&a, 0, sizeof(a));
+    a.struct_size = (int32_t)sizeof(a); a.q = q; a.descriptors = descriptorsIn.data.data();
+    a.flags = LCD_Q_INCREMENTAL | (_newWordsComparedTogether ? LCD_Q_NEW_WORDS_COMPARED : 0); a.nndr_ratio = _nndrRatio;
+    a.sig_id = signatureId; a.first_new_word_id = _lastWordId + 1; a.N = N; a.append_new_words = 1;
+    a.word_ids = out.data(); a.likelihood = likelihoodBySlot.data(); a.likelihood_capacity = (int64_t)likelihoodBySlot.size(); a.n_slots = &nSlots;
+    const int rc = lcd_frame_host(_engine, &a);
+    if (rc != LCD_OK) {
+        _lastError = lcd_last_error(_engine);
+        if (rc != LCD_ERR_UNSUPPORTED) logError("%s", _lastError.c_str());
+        return false;                                                               // nothing was registered: the caller takes the slow path
+    }
+    if (nSlots != (int64_t)_slotSig.size() + 1) {                                   // the mirror of the slot table is out of step: do not guess
+        _lastError = "slot table of the device and its host mirror differ";
+        logError("%s", _lastError.c_str());
+        likelihoodBySlot.clear();
+    }
+    // bookkeeping of the per-descriptor loop (:1162-1219), in descriptor order; the references are on the device already
+    std::vector<int> created;
+    std::vector<int>& sw = _sigWords[signatureId];
+    for (int i = 0; i < q; ++i) {
+        const int w = out[i];
+        int id = 0;
+        if (w < 0) {
+            const int k = -w - 1;
+            if (k == (int)created.size()) {
+                VisualWord* vw = new VisualWord(getNextId(), descriptorsIn.row(i), signatureId);   // :1185-1195
+                _visualWords.insert(_visualWords.end(), std::pair<int, VisualWord*>(vw->id(), vw));
+                _notIndexedWords.insert(_notIndexedWords.end(), vw->id());
+                _deviceRows.insert(_deviceRows.end(), vw->id());
+                created.push_back(vw->id());
+                wordIds.push_back(vw->id());
+                sw.push_back(vw->id());
+                continue;
+            }
+            if (k > (int)created.size()) { logError("inconsistent new-word index returned by the device"); break; }
+            id = created[k];                                                        // a word created earlier in this call (:1140-1160, :1207)
+        } else if (w > 0) id = w;
+        else continue;
+        std::map<int, VisualWord*>::iterator it = _visualWords.find(id);            // addWordRef (:880-897) without the dirty mark
+        if (it == _visualWords.end()) { fprintf(stderr, "[WARN] Not found word %d (dict size=%d)\n", id, (int)_visualWords.size()); continue; }
+        it->second->addRef(signatureId);
+        _totalActiveReferences += 1;
+        _unusedWords.erase(id);
+        sw.push_back(id);
+        wordIds.push_back(id);
+    }
+    _totalActiveReferences += (int)_notIndexedWords.size();   // :1227 (sic)
+    _deviceSigs.insert(signatureId);
+    slotAdd(signatureId);
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------- findNN  :1231-1552
 std::vector<int> VWDictionaryHip::findNN(const std::list<VisualWord*>& vws) const {
     if (_visualWords.size() && vws.size()) {
@@ -454,12 +537,14 @@ bool VWDictionaryHip::flushReferences(const std::function<int(int)>& getNi) {
         if (_deviceSigs.count(*s)) {
             if (lcd_sig_remove(_engine, *s) != LCD_OK) { _lastError = lcd_last_error(_engine); return false; }
             _deviceSigs.erase(*s);
+            slotRetire(*s);
         }
         std::map<int, std::vector<int> >::iterator w = _sigWords.find(*s);
         if (w != _sigWords.end() && !w->second.empty()) {
             const int ni = getNi ? getNi(*s) : (int)w->second.size();
             if (lcd_sig_add(_engine, *s, w->second.data(), (int)w->second.size(), ni) != LCD_OK) { _lastError = lcd_last_error(_engine); return false; }
             _deviceSigs.insert(*s);
+            slotAdd(*s);
         } else if (w != _sigWords.end()) {
             _sigWords.erase(w);
         }
@@ -487,7 +572,7 @@ bool VWDictionaryHip::flushReferencesBulk(const std::function<int(int)>& getNi) 
             _lastError = lcd_last_error(_engine);
             return false;
         }
-        for (size_t k = 0; k < sigIds.size(); ++k) { _deviceSigs.insert(sigIds[k]); _dirtySigs.erase(sigIds[k]); }
+        for (size_t k = 0; k < sigIds.size(); ++k) { _deviceSigs.insert(sigIds[k]); _dirtySigs.erase(sigIds[k]); slotAdd(sigIds[k]); }
     }
     return flushReferences(getNi);
 }

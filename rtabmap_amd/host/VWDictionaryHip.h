@@ -119,6 +119,19 @@ public:
     std::map<int, float> computeLikelihood(const std::list<int>& wordIds, const std::list<int>& ids, float N,
                                            const std::function<int(int)>& getNi);
 
+    // ---- Memory::update's quantisation AND Memory::computeLikelihood of the new signature in ONE device call (lcd_frame_host, ABI v5):
+    // addNewWords(descriptors, signatureId) with the bookkeeping of :1162-1219 -- plus, on the device, the signature's references (no
+    // flushReferences for it later), the words it creates appended to the device vocabulary (the append branch of the update() that
+    // Memory::preUpdate runs in front of the NEXT frame, :571-609: that update() then only moves them to the indexed words) and the
+    // TF-IDF likelihood of the new signature against every registered signature, by device slot (slotSignatures()).  One
+    // synchronisation instead of five.  N / getNi as for computeLikelihood (N counts the new signature).
+    // Returns false -- nothing changed -- when the fast path does not apply (fixed dictionary, words waiting for update(), rows the
+    // device pads, no engine): the caller runs addNewWords() + computeLikelihood() instead.
+    bool addNewWordsAndScore(const Mat& descriptors, int signatureId, float N, const std::function<int(int)>& getNi, std::list<int>& wordIds,
+                             std::vector<float>& likelihoodBySlot);
+    // device slot -> signature id (0: the slot's signature was removed); slots are handed out in registration order
+    const std::vector<int>& slotSignatures() const { return _slotSig; }
+
     // send the references added / removed since the last call to the device's inverted index (computeLikelihood does it itself)
     bool flushReferences(const std::function<int(int)>& getNi);
     // the same for a memory that has just been loaded (Memory::loadDataFromDb, Memory.cpp:447-480): every signature that is not on the
@@ -167,6 +180,15 @@ private:
     std::map<int, std::vector<int> > _sigWords;   // signature -> word ids referenced (one entry per addWordRef)
     std::set<int> _dirtySigs;
     std::set<int> _deviceSigs;
+    // mirror of the engine's slot table (lcd.h: slots in registration order, never reused)
+    std::vector<int> _slotSig;
+    std::map<int, int> _sigSlot;
+    void slotAdd(int signatureId) { _sigSlot[signatureId] = (int)_slotSig.size(); _slotSig.push_back(signatureId); }
+    void slotRetire(int signatureId) { std::map<int, int>::iterator i = _sigSlot.find(signatureId); if (i != _sigSlot.end()) { _slotSig[(size_t)i->second] = 0; _sigSlot.erase(i); } }
+    // words a frame created that are ALREADY rows of the device vocabulary (addNewWordsAndScore with append_new_words): still in
+    // _notIndexedWords on the host until update() runs
+    std::set<int> _deviceRows;
+    std::vector<float> _likeScratch;
 };
 
 }  // namespace rtabmap_amd

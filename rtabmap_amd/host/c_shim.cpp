@@ -133,6 +133,67 @@ double hmem_time_loop(void* h, const void* descs, int n_frames, int rows, int co
     return total / steps;
 }
 
+void hmem_set_device_frames(void* h, int on) { ((MemoryHip*)h)->setDeviceFrames(on != 0); }
+// n signatures of q words each (ids first_id, first_id + 1, ...) through addSignature, then ONE bulk registration on the device
+int hmem_add_signatures_bulk(void* h, const int* words, int n, int q, int first_id) {
+    MemoryHip* m = (MemoryHip*)h;
+    for (int s = 0; s < n; ++s)
+        if (m->addSignature(std::vector<int>(words + (size_t)s * q, words + (size_t)(s + 1) * q), first_id + s) != first_id + s) return -1;
+    return m->flushReferencesBulk() ? n : -1;
+}
+// computeLikelihoodFlat of the signature update() has just created: returns the number of entries (-1: no result at hand)
+int hmem_compute_likelihood_flat(void* h, int sigId, int* outIds, float* out, int cap) {
+    std::vector<int> ids; std::vector<float> v;
+    if (!((MemoryHip*)h)->computeLikelihoodFlat(sigId, ids, v)) return -1;
+    for (size_t i = 0; i < ids.size() && (int)i < cap; ++i) { outIds[i] = ids[i]; out[i] = v[i]; }
+    return (int)ids.size();
+}
+// Memory::computeLikelihood(signature id, ids) -- the overload Rtabmap::process calls (Rtabmap.cpp:2117): after update() it is answered
+// from the frame's own device call
+int hmem_compute_likelihood_of(void* h, int sigId, const int* ids, int nids, int* outIds, float* out) {
+    std::map<int, float> L = ((MemoryHip*)h)->computeLikelihood(sigId, std::list<int>(ids, ids + nids));
+    int n = 0;
+    for (std::map<int, float>::iterator i = L.begin(); i != L.end(); ++i, ++n) { outIds[n] = i->first; out[n] = i->second; }
+    return n;
+}
+
+// hmem_time_loop with the three ways a caller can take the likelihood (bench.py's cpp_interface_* keys), the caller's own list of ids
+// kept from frame to frame (one push, one pop) instead of rebuilt: mode 0 = std::map by value (the reference's signature), 1 = into a
+// caller-owned std::map updated in place, 2 = flat vectors.  out4 = mean ms per frame of {whole step, update, computeLikelihood, forget}.
+int hmem_time_loop_modes(void* h, const void* descs, int n_frames, int rows, int cols, int type, int steps, int mode, double* out4) {
+    MemoryHip* m = (MemoryHip*)h;
+    const size_t frame_bytes = (size_t)rows * cols * (type == 0 ? 4 : 1);
+    std::vector<int> ids;
+    const std::vector<int> all0 = m->signatureIds();
+    std::list<int> lst(all0.begin(), all0.end());
+    std::map<int, float> keep;
+    std::vector<int> fi; std::vector<float> fv;
+    double t[4] = {0, 0, 0, 0};
+    for (int i = 0; i < steps + 2; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const Mat d = make_mat((const char*)descs + (size_t)(i % n_frames) * frame_bytes, rows, cols, type);
+        const int id = m->update(d, -1, ids);
+        lst.push_back(id);
+        const auto t1 = std::chrono::steady_clock::now();
+        size_t n_out = 0;
+        if (mode == 0) { const std::map<int, float> L = m->computeLikelihood(id, lst); n_out = L.size(); }
+        else if (mode == 1) { m->computeLikelihood(id, lst, keep); n_out = keep.size(); }
+        else { if (!m->computeLikelihoodFlat(id, fi, fv)) return -1; n_out = fi.size(); }
+        const auto t2 = std::chrono::steady_clock::now();
+        if (!lst.empty()) { m->forget(lst.front()); lst.pop_front(); }
+        const auto t3 = std::chrono::steady_clock::now();
+        if (n_out == 0) return -1;
+        if (i >= 2) {
+            t[0] += std::chrono::duration<double, std::milli>(t3 - t0).count();
+            t[1] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+            t[2] += std::chrono::duration<double, std::milli>(t2 - t1).count();
+            t[3] += std::chrono::duration<double, std::milli>(t3 - t2).count();
+        }
+    }
+    for (int k = 0; k < 4; ++k) out4[k] = t[k] / steps;
+    return 0;
+}
+
 // the values the mirror's classes take when no parameter is given (tests/test_parameter_defaults.py compares them with the defaults of
 // the reference's Parameters.h): out[0..7] = Kp/NndrRatio, Kp/IncrementalDictionary, Kp/NewWordsComparedTogether, Mem/STMSize,
 // Rtabmap/LoopThr, Rtabmap/LoopRatio, Bayes/VirtualPlacePriorThr, Bayes/FullPredictionUpdate; then the Bayes/PredictionLC values.

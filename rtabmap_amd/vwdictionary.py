@@ -58,6 +58,12 @@ def lib():
         L.hmem_create_stm.argtypes = [ci, ci, cf, ci, C.c_char_p, ci, ci]
         L.hmem_time_loop.argtypes = [vp, vp, ci, ci, ci, ci, ci]
         L.hmem_time_loop.restype = C.c_double
+        L.hmem_time_loop_modes.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.hmem_set_device_frames.argtypes = [vp, ci]
+        L.hmem_set_device_frames.restype = None
+        L.hmem_add_signatures_bulk.argtypes = [vp, vp, ci, ci, ci]
+        L.hmem_compute_likelihood_flat.argtypes = [vp, ci, vp, vp, ci]
+        L.hmem_compute_likelihood_of.argtypes = [vp, ci, vp, ci, vp, vp]
         L.hmem_add_link.argtypes = [vp, ci, ci, ci]
         L.hmem_get_neighbors_id.argtypes = [vp, ci, ci, vp, vp, ci]
         L.hmem_ids.argtypes = [vp, ci, vp, ci]
@@ -232,6 +238,42 @@ class MemoryHip:
         """update + computeLikelihood against every signature + forget(oldest) per frame, looped and timed in C++ -> ms per frame"""
         f = np.ascontiguousarray(frames)
         return float(lib().hmem_time_loop(self.h, _p(f), f.shape[0], f.shape[1], f.shape[2], _type_of(f), int(steps)))
+
+    def time_loop_modes(self, frames, steps, mode):
+        """The same loop with the caller's list of ids kept from frame to frame; mode 0: std::map by value (the reference's signature),
+        1: into a caller-owned std::map updated in place, 2: flat vectors.  -> ms per frame {step, update, likelihood, forget}"""
+        f = np.ascontiguousarray(frames)
+        out = np.zeros(4, np.float64)
+        if lib().hmem_time_loop_modes(self.h, _p(f), f.shape[0], f.shape[1], f.shape[2], _type_of(f), int(steps), int(mode), _p(out)) != 0:
+            raise RuntimeError("hmem_time_loop_modes failed: " + self.vwd.last_error())
+        return dict(zip(("step", "update", "likelihood", "forget"), out.tolist()))
+
+    def set_device_frames(self, on):
+        """MemoryHip::setDeviceFrames: update() as ONE device call (lcd_frame_host) that also brings the likelihood back (default), or the
+        call-by-call path (lcd_quantize / lcd_sig_add / lcd_likelihood)."""
+        lib().hmem_set_device_frames(self.h, int(bool(on)))
+
+    def add_signatures_bulk(self, words, first_id=1):
+        """n signatures (rows of `words`) through Memory::addSignature in C++, then ONE bulk registration on the device"""
+        w = np.ascontiguousarray(words, dtype=np.int32)
+        n = lib().hmem_add_signatures_bulk(self.h, _p(w), w.shape[0], w.shape[1], int(first_id))
+        if n != w.shape[0]:
+            raise RuntimeError("add_signatures_bulk failed: " + self.vwd.last_error())
+        return n
+
+    def compute_likelihood_of(self, sig_id, ids):
+        """Memory::computeLikelihood(signature id, ids) -> (ids ascending, values)"""
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        oi, ov = np.zeros(max(a.shape[0], 1), np.int32), np.zeros(max(a.shape[0], 1), np.float32)
+        n = lib().hmem_compute_likelihood_of(self.h, int(sig_id), _p(a), a.shape[0], _p(oi), _p(ov))
+        return oi[:n], ov[:n]
+
+    def compute_likelihood_flat(self, sig_id, cap=1 << 21):
+        oi, ov = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+        n = lib().hmem_compute_likelihood_flat(self.h, int(sig_id), _p(oi), _p(ov), cap)
+        if n < 0:
+            return None
+        return oi[:n], ov[:n]
 
     def get_ni(self, sig_id):
         return lib().hmem_get_ni(self.h, sig_id)

@@ -520,3 +520,50 @@ def test_bulk_load_matches_incremental_registration(oracle):
     assert idf < 0 and (La < 0).any()
     np.testing.assert_allclose(La, exp, rtol=1e-5, atol=1e-9)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("kind,pipeline", [("surf", False), ("orb", False), ("surf", True)])
+def test_frame_host_is_frame_dev_with_the_copies(kind, pipeline):
+    """lcd_frame_host (ABI v5: host descriptors in, word ids + dense likelihood out, one synchronisation -- what the reference-interface
+    mirror calls per frame) against lcd_frame_dev on a twin engine fed through device pointers: the same bits, frame after frame, with
+    update()'s append on the device, a retirement per frame, and lcd_slot_count telling the caller how large its likelihood buffer must be."""
+    import rtabmap_amd
+    n_words, q, n_bulk, n_frames = 3000, 96, 40, 12
+    rng = np.random.default_rng(91)
+    base = synth.vocab_surf(n_words, seed=92) if kind == "surf" else synth.vocab_orb(n_words, seed=92)
+    words = synth.zipf_words(n_bulk, q, n_words, seed=93)
+    ids = np.arange(1, n_words + 1, dtype=np.int32)
+    engs = []
+    for p in (False, pipeline):
+        e = rtabmap_amd.Engine("f32" if kind == "surf" else "u8", base.shape[1], sig_capacity=n_bulk + n_frames + 8, pipeline=p)
+        e.vocab_append(base, ids)
+        e.sig_add_bulk(np.arange(1, n_bulk + 1, dtype=np.int32), np.arange(0, (n_bulk + 1) * q, q, dtype=np.int64), words.reshape(-1))
+        engs.append(e)
+    dev, host = engs
+    cap = n_bulk + n_frames + 8
+    d_w = torch.zeros(q, dtype=torch.int32, device="cuda")
+    d_l = torch.zeros(cap, dtype=torch.float32, device="cuda")
+    history = [base[rng.integers(0, n_words, q)] for _ in range(2)]
+    first_new = n_words + 1
+    created = 0
+    for t in range(n_frames):
+        desc = _revisit(rng, kind, history, base, q, fresh_frac=0.3)
+        history.append(desc)
+        sid = n_bulk + 1 + t
+        d = torch.from_numpy(desc).cuda()
+        dev.frame_dev(d.data_ptr(), q, sid, float(n_bulk + 1), d_w.data_ptr(), d_l.data_ptr(), cap, first_new_word_id=first_new, append_new_words=True)
+        dev.synchronize()
+        exp_w, exp_l = d_w.cpu().numpy(), d_l[:sid].cpu().numpy()
+        got_w, got_l = host.frame_host(desc, sid, float(n_bulk + 1), first_new_word_id=first_new, append_new_words=True)
+        np.testing.assert_array_equal(got_w, exp_w, err_msg="frame %d" % t)
+        assert got_l.shape[0] == sid
+        np.testing.assert_array_equal(got_l, exp_l, err_msg="frame %d" % t)
+        n_new = int(-exp_w.min()) if exp_w.min() < 0 else 0
+        created += n_new
+        first_new += n_new
+        dev.sig_remove(t + 1)
+        host.sig_remove(t + 1)
+    assert created > 100
+    assert dev.vocab_count() == host.vocab_count() == (n_words + created, n_words + created)
+    for e in engs:
+        e.close()

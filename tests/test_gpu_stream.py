@@ -31,11 +31,17 @@ def _same_state(o, h):
 
 @pytest.mark.parametrize("kind", ["orb", "surf"])
 @pytest.mark.parametrize("together", [True, False])
-def test_incremental_stream(oracle, kind, together):
+@pytest.mark.parametrize("device_frames", [True, False])
+def test_incremental_stream(oracle, kind, together, device_frames):
+    """device_frames: MemoryHip::update as ONE device call (lcd_frame_host: quantisation, the signature's references, update()'s append
+    and the likelihood of Rtabmap.cpp:2117 -- the default since round 5) or the call-by-call path of rounds 1-4.  Frames that keep
+    unquantised features take the call-by-call path in both modes, so the two are also interleaved here; forgetting removes words the
+    device appended itself."""
     from rtabmap_amd.vwdictionary import MemoryHip
     frames = _frames(kind, 14, 160)
     o = oracle.OracleMemory(strategy=oracle.kNNBruteForce, nndr=0.8, new_words_compared_together=together)
     h = MemoryHip(nndr=0.8, new_words_compared_together=together)
+    h.set_device_frames(device_frames)
     W = 6                                            # working-memory size: older frames are forgotten (words get removed)
     for t, desc in enumerate(frames):
         nq = None if t % 5 else desc.shape[0] - 7   # some frames keep features that are not quantised (ids -1,-2,..)
@@ -45,11 +51,22 @@ def test_incremental_stream(oracle, kind, together):
         _same_state(o, h)
         ids = np.array(o.signature_ids(), np.int32)
         oi, Lo = o.compute_likelihood(np.array(ido, np.int32), ids)
+        # Memory::computeLikelihood(signature, ids): answered from the frame's own device call when update() took the fast path
+        fi, Lf = h.compute_likelihood_of(sh, ids)
+        assert oi.tolist() == fi.tolist()
+        np.testing.assert_allclose(Lf, Lo, rtol=RTOL, atol=ATOL)
+        flat = h.compute_likelihood_flat(sh)
+        assert (flat is not None) == (device_frames and nq is None)
+        if flat is not None:
+            assert flat[0].tolist() == sorted(flat[0].tolist()) and set(flat[0].tolist()) <= set(oi.tolist()) and sh in flat[0].tolist()
+            lut = dict(zip(oi.tolist(), Lo.tolist()))
+            np.testing.assert_allclose(flat[1], np.array([lut[i] for i in flat[0].tolist()], np.float32), rtol=RTOL, atol=ATOL)
         hi, Lh = h.compute_likelihood(np.array(idh, np.int32), ids)
         assert oi.tolist() == hi.tolist()
         np.testing.assert_allclose(Lh, Lo, rtol=RTOL, atol=ATOL)
         if Lo[:-1].size and Lo[:-1].max() > 0:
             assert int(np.argmax(Lh[:-1])) == int(np.argmax(Lo[:-1]))
+            assert int(np.argmax(Lf[:-1])) == int(np.argmax(Lo[:-1]))
         if so > W:
             o.forget(so - W)
             h.forget(so - W)
