@@ -630,6 +630,7 @@ def cpp_interface_ms(vocab, words, frames_np, n_sig, steps=12):
     out["map_by_value"] = mem.time_loop_modes(fr, steps, 0)
     out["map_in_place"] = mem.time_loop_modes(fr, steps, 1)
     out["flat"] = mem.time_loop_modes(fr, steps, 2)
+    out["update_ms_inside_lcd_frame_host"] = mem.fast_frame_device_ms()      # copies + launches + the one synchronisation; the rest of `update` is std::map bookkeeping
     mem.set_device_frames(False)
     out["call_by_call_map_by_value"] = mem.time_loop_modes(fr, max(3, steps // 3), 0)
     mem.close()
@@ -1034,6 +1035,261 @@ def run_replay(args):
     print(json.dumps(out), flush=True)
 
 
+def run_replay_growing(args):
+    """Config 5's stand-in with what config 5 is about (Memory.cpp:5941-6059, Rtabmap.cpp:2117): a replay whose INCREMENTAL dictionary starts
+    EMPTY and keeps growing, with the whole of Memory::preUpdate live.  Trajectory: every other frame is the first visit of a NEW place
+    (n/2 places over n frames), the frames in between revisit a place seen before (uniform over the places so far).  A place = q - 1
+    descriptors near words of a 49 000-word Zipf world (the robot's environment: these become dictionary words as they are first seen) +
+    one descriptor of its own (a word only this place has); a revisit = the place's descriptors + N(0, 0.03^2) noise, renormalised.  So
+    the dictionary covers the world's used words within the first thousands of frames and then grows by about one word per new place
+    (> 500 000 words at 10^6 frames), > 50 % of the frames create words.  Every frame: cleanUnusedWords (lcd_vocab_remove_unused_async)
+    -> update() (the previous frame's words became rows on the device) -> addNewWords -> references -> computeLikelihood against every
+    live signature -> adjustLikelihood + best candidate; every 8th frame the oldest signature is retired (its words lose a reference;
+    a word without references is removed by the next clean); lcd_vocab_rebuild every 8192 frames (the only draining call) compacts the
+    tombstones.  Descriptors are generated ON the device (torch, seeded) in batches; nothing but the per-frame arguments crosses PCIe.
+    Recall: a revisit counts when the best candidate outside the newest 30 signatures shows its place (over the revisits whose place
+    still has its first signature in memory).  Parity on frames sampled across the run: the pipeline is completed in front of a sampled
+    frame and the device's vocabulary read back -- the frame's word ids must be VWDictionary::addNewWords' (C++ oracle) over exactly
+    that dictionary in row order; likelihood and adjustLikelihood's record against the numpy restatement of Memory::computeLikelihood
+    (pinned to the C++ oracle) on the live signatures replayed from the device's word log."""
+    import torch
+    import rtabmap_amd
+    from rtabmap_amd import synth
+    import oracle as O
+    from oracle import tfidf_np
+    n = args.signatures if args.signatures != N_SIG else 1_000_000
+    q, stm, retire_every, rebuild_every, B, sigma = Q, 30, 8, 8192, 512, 0.03
+    n_places = n // 2 + 1
+    stream = torch.cuda.Stream()
+    vocab = synth.vocab_surf(N_WORDS)
+    t_gen = time.perf_counter()
+    with torch.cuda.stream(stream):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(20260922)
+        d_world = torch.from_numpy(vocab).cuda()
+        ranks = torch.arange(1, N_WORDS + 1, dtype=torch.float64, device="cuda")
+        probs = (1.0 / ranks)
+        probs = (probs / probs.sum()).float()
+        perm = torch.randperm(N_WORDS, generator=g, device="cuda")
+        pool = torch.empty((n_places, q, DIM), dtype=torch.float32, device="cuda")     # view 0 of every place: 128 KB each, resident in HBM
+        CH = 2048
+        for c0 in range(0, n_places, CH):
+            ch = min(CH, n_places - c0)
+            idx = perm[torch.multinomial(probs.expand(ch, -1), q - 1, True, generator=g)]
+            known = d_world[idx] + sigma * torch.randn((ch, q - 1, DIM), generator=g, device="cuda")
+            own = torch.randn((ch, 1, DIM), generator=g, device="cuda")
+            blk = torch.cat([known, own], dim=1)
+            pool[c0:c0 + ch] = blk / blk.norm(dim=2, keepdim=True)
+        del idx, known, own, blk
+    stream.synchronize()
+    gen_s = time.perf_counter() - t_gen
+    # trajectory (host): even frames first visits, odd frames revisits
+    ts = np.arange(n, dtype=np.int64)
+    rng = np.random.default_rng(77)
+    place = np.where(ts % 2 == 0, ts // 2, (rng.random(n) * (ts // 2 + 1)).astype(np.int64))
+    place = np.minimum(place, ts // 2)
+    d_place = torch.from_numpy(place).cuda()
+    revisit = torch.from_numpy((ts % 2 == 1)).cuda()
+    # word ids: frame t may create the ids [first_new[t], first_new[t] + stride[t]): q for the first frames (an empty dictionary: nearly every
+    # descriptor is a new word), 64 once the world's words are in -- checked against the logged codes afterwards
+    early = min(n, 20000)
+    stride = np.where(ts < early, q, 64).astype(np.int64)
+    first_new = 1 + np.concatenate([[0], np.cumsum(stride)[:-1]])
+    if first_new[-1] + q >= (1 << 28):
+        raise SystemExit("replay_growing: word ids would pass 2^28")
+    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=max(1 << 16, min(2 * n, 1_400_000)), sig_capacity=n + 4096, stream=stream.cuda_stream, pipeline=1, knn_mode=KNN_MODE)
+    cap = n + 64
+    depth = eng.pipeline_depth() + 1
+    want = [1001, 5000, 20001, n // 8 + 1, n // 4, n // 2 + 1, (3 * n) // 4, n - 2]
+    sample_t = sorted(set(t for t in want if 64 <= t < n))
+    if n > 300_000:
+        sample_t = sample_t[:3] + sample_t[-3:]                                         # the C++ oracle scans the whole dictionary per sample
+    sample_slot = {t: k for k, t in enumerate(sample_t)}
+    d_words = torch.zeros((n, q), dtype=torch.int32, device="cuda")
+    d_like = torch.zeros((depth, cap), dtype=torch.float32, device="cuda")
+    d_like_s = [torch.zeros(t + 2, dtype=torch.float32, device="cuda") for t in sample_t]
+    d_hyp = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+    bufs = [torch.empty((B, q, DIM), dtype=torch.float32, device="cuda") for _ in range(2)]
+    snap = {}
+    torch.cuda.synchronize()
+    a = eng.frame_args(q=q, flags=3, nndr_ratio=NNDR, exclude_recent=stm, append_new_words=1)
+    wp, lp, hp = d_words.data_ptr(), d_like.data_ptr(), d_hyp.data_ptr()
+    n_prof = 40
+    retired = 0
+    paused = 0.0
+    marks = {}
+    t_start = time.perf_counter()
+    for t in range(n):
+        b = (t // B) & 1
+        if t % B == 0:
+            with torch.cuda.stream(stream):                                             # the batch's descriptors, on the engine's stream
+                sl = slice(t, min(t + B, n))
+                x = pool[d_place[sl]]
+                x = x + (sigma * revisit[sl].float()).view(-1, 1, 1) * torch.randn(x.shape, generator=g, device="cuda")
+                bufs[b][: x.shape[0]] = x / x.norm(dim=2, keepdim=True)
+        if t in sample_slot:
+            t0 = time.perf_counter()
+            eng.synchronize()
+            rows_t, live_t = eng.vocab_count()
+            vr, vi = eng.vocab_read(0, rows_t) if rows_t else (np.zeros((0, DIM), np.float32), np.zeros(0, np.int32))
+            snap[t] = (vr[vi != 0].copy(), vi[vi != 0].copy(), bufs[b][t % B].cpu().numpy(), retired)
+            paused += time.perf_counter() - t0
+        if t == n - n_prof:
+            eng.synchronize()
+            eng.profile_begin(n_prof)
+        a.d_descriptors = bufs[b].data_ptr() + (t % B) * q * DIM * 4
+        a.sig_id = t + 1
+        a.N = float(t + 1 - retired)
+        a.first_new_word_id = int(first_new[t])
+        a.d_word_ids = wp + t * q * 4
+        k = sample_slot.get(t)
+        if k is not None:
+            a.d_likelihood = d_like_s[k].data_ptr()
+            a.likelihood_capacity = t + 2
+        else:
+            a.d_likelihood = lp + (t % depth) * cap * 4
+            a.likelihood_capacity = cap
+        a.d_hypothesis = hp + t * 32
+        eng.frame_dev_args(a)
+        if t % retire_every == retire_every - 1:
+            retired += 1
+            eng.sig_remove(retired)
+        eng.vocab_remove_unused_async()
+        if t % rebuild_every == rebuild_every - 1:
+            eng.vocab_rebuild()
+        if t + 1 in (100_000, 500_000):
+            eng.synchronize()
+            marks[t + 1] = time.perf_counter() - t_start - paused
+    eng.synchronize()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t_start - paused
+    rows, live = eng.vocab_count()
+    roof_knn, roof_score = rooflines(eng, rows, n - retired, False)
+    for r in (roof_knn, roof_score):
+        if r:
+            r["measured_in"] = "HIP events attached to the launches of the last %d frames (dictionary and memory at their final size)" % n_prof
+    # ---- recall
+    hyp = d_hyp.cpu().numpy()
+    best_sig = hyp[:, 0].astype(np.int64)
+    retired_at = ts // retire_every                                                     # signatures 1 .. retired_at[t] are gone when frame t is scored (its own call's retirement comes after)
+    first_sig = 2 * place + 1                                                           # the place's first visit is signature 2 * place + 1
+    counted = (ts % 2 == 1) & (first_sig > retired_at) & (first_sig <= ts - stm)
+    hit = counted & (best_sig > 0) & (place[np.clip(best_sig - 1, 0, n - 1)] == place)
+    recall = float(hit.sum()) / max(int(counted.sum()), 1)
+    # ---- the word log
+    log = d_words.cpu().numpy()
+    n_new_frame = np.where((log < 0).any(axis=1), -log.min(axis=1), 0)
+    if (n_new_frame > stride).any():
+        bad = int(np.flatnonzero(n_new_frame > stride)[0])
+        raise SystemExit("replay_growing: frame %d created %d words, more than its id stride %d" % (bad, int(n_new_frame[bad]), int(stride[bad])))
+    ids_log = np.where(log < 0, first_new[:, None] - log - 1, log).astype(np.int32)
+    created = int(n_new_frame.sum())
+    # ---- parity on the sampled frames
+    t_par = time.perf_counter()
+    ids_equal, max_rel, n_cmp, hyp_ok, checked = True, 0.0, 0, True, []
+    hyp_same = hyp_near = 0
+    knn_s = lik_s = 0.0
+    for t in sample_t:
+        vr, vi, desc, ret_t = snap[t]
+        o = O.OracleVWDictionary(strategy=O.kNNBruteForce, incremental=True, nndr=NNDR, new_words_compared_together=True)
+        for w, r in zip(vi.tolist(), vr):
+            o.add_word(int(w), r)
+        rows_ascending = bool((np.diff(vi) > 0).all())                                 # the oracle's update() indexes in ascending id: the device's row order must be that
+        o.update()
+        last_before = o.last_word_id
+        t1 = time.perf_counter()
+        exp = o.add_new_words(desc, t + 1)
+        knn_s += time.perf_counter() - t1
+        canon_o = [-(w - last_before) if w > last_before else w for w in exp]
+        ok = bool(canon_o == log[t].tolist())
+        ids_equal &= ok
+        o.close()
+        t2 = time.perf_counter()
+        Lo = tfidf_np.compute_likelihood_dense(ids_log[ret_t: t + 1], ids_log[t])
+        lik_s += time.perf_counter() - t2
+        Lh = d_like_s[sample_slot[t]][ret_t: t + 1].cpu().numpy()
+        err = np.abs(Lh - Lo) / np.maximum(np.abs(Lo), 1e-7 / 1e-4)
+        max_rel = max(max_rel, float(err.max()))
+        n_cmp += int(Lo.size)
+        dead = d_like_s[sample_slot[t]][:ret_t].cpu().numpy()
+        hyp_ok &= bool(not dead.any())                                                  # retired signatures score 0
+        n_cons = t + 1 - stm - ret_t
+        if n_cons > 0:
+            adj = O.adjust_likelihood(np.concatenate([[0.0], Lo[:n_cons]]).astype(np.float32), 0.0)
+            best = int(np.argmax(Lo[:n_cons]))
+            dev = int(hyp[t, 0]) - 1 - ret_t
+            same = dev == best
+            near = 0 <= dev < n_cons and float(Lo[dev]) >= float(Lo[best]) * (1.0 - 1e-4)
+            hyp_same += int(same); hyp_near += int(near and not same)
+            hyp_ok &= bool(same or near)
+            ref_adj = float(adj[1 + (dev if near else best)])
+            hyp_ok &= bool(abs(float(hyp[t, 3:4].view(np.float32)[0]) - ref_adj) <= 1e-4 * max(abs(ref_adj), 1e-3))
+        checked.append({"frame": int(t), "live_signatures": int(t + 1 - ret_t), "dictionary_words": int(vi.size), "rows_ascending": rows_ascending,
+                        "word_ids_equal": ok})
+    par_s = time.perf_counter() - t_par
+    # ---- CPU baseline on a bounded sample: the reference's kd-tree over the FINAL dictionary + the restated std::map TF-IDF on a
+    # 20 000-signature window of the log, scaled linearly to the final memory (the reference's loop is linear in the postings)
+    vr, vi = eng.vocab_read(0, rows)
+    vr = vr[vi != 0]
+    sample_desc = bufs[((n - 1) // B) & 1][: 5].cpu().numpy()
+    if O.have_ref():
+        kd = O.RefIndex(vr, algo=O.ALGO_KDTREE, trees=4)
+        t1 = time.perf_counter()
+        for i in range(5):
+            kd.knn(sample_desc[i], k=2, checks=32, cores=1)
+        t_knn_cpu = (time.perf_counter() - t1) / 5
+        knn_what, kind = "rtflann kd-tree (4 trees, 32 checks), 1 core, %d words" % vr.shape[0], "reference"
+    else:
+        t1 = time.perf_counter()
+        O.knn2_linear(vr, sample_desc[0])
+        t_knn_cpu = time.perf_counter() - t1
+        knn_what, kind = "exact linear port, 1 core, %d words" % vr.shape[0], "port"
+    win = min(20000, n - retired)
+    mem = O.OracleMemory(strategy=O.kNNBruteForce, nndr=NNDR)
+    lo = n - win
+    for wid in np.unique(ids_log[lo:]).tolist():
+        if wid > 0:
+            mem.vwd.add_word(int(wid), vocab[0])
+    for f in range(lo, n):
+        mem.add_signature_with_id(f + 1, ids_log[f])
+    t1 = time.perf_counter()
+    for i in range(3):
+        mem.compute_likelihood(ids_log[n - 1 - i], np.arange(lo + 1, n + 1, dtype=np.int32))
+    t_lik_cpu = (time.perf_counter() - t1) / 3 * ((n - retired) / float(win))
+    lik_what = "restated std::map Memory::computeLikelihood on the newest %d signatures, scaled x%.1f to %d" % (win, (n - retired) / float(win), n - retired)
+    mem.close()
+    eng.close()
+    live_total = float(np.sum(ts + 1 - retired_at))
+    out = {"metric": "loop-closure candidates/sec (descriptor-stream replay, growing dictionary, memory grown to %d signatures)" % (n - retired),
+           "unit": "candidates/s", "value": live_total / wall, "n_gpus": 1, "steps": n, "warmup": 0, "ms_per_step": 1e3 * wall / n,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (generated on the device)",
+           "config": {"workload": "config 5 stand-in with a GROWING incremental dictionary (SURVEY.md 8d; Memory.cpp:5941-6059, Rtabmap.cpp:2117): %d frames x %d SURF "
+                                  "descriptors, dictionary from EMPTY, every other frame a new place (one word of its own + words of a 49k-word Zipf world), "
+                                  "the others revisits with noise; per frame cleanUnusedWords (enqueued) -> update() on the device -> addNewWords -> references -> "
+                                  "computeLikelihood against every live signature -> adjustLikelihood + best candidate; the oldest signature retired every %dth "
+                                  "frame, lcd_vocab_rebuild every %d frames; pipelined lcd_frame_dev" % (n, q, retire_every, rebuild_every),
+                      "dictionary_rows_at_the_end": int(rows), "dictionary_words_at_the_end": int(live), "words_created": created,
+                      "frames_that_created_words": int((n_new_frame > 0).sum()), "frames_that_created_words_frac": float((n_new_frame > 0).mean()),
+                      "signatures_live_at_the_end": int(n - retired), "signatures_retired": int(retired),
+                      "frames_per_s": n / wall, "wall_s": wall, "wall_s_at_frames": {str(k): v for k, v in marks.items()},
+                      "ms_per_frame_last_half": 1e3 * (wall - marks.get(500_000, 0.0)) / (n - 500_000) if 500_000 in marks and n > 500_000 else None,
+                      "descriptor_pool_generated_on_device_s": gen_s, "parity_host_seconds": par_s, "paused_for_snapshots_s": paused},
+           "roofline": roof_score if (roof_score is not None and roof_knn is not None and roof_score["ms"] > roof_knn["ms"]) else (roof_knn or roof_score),
+           "roofline_score": roof_score, "roofline_knn": roof_knn,
+           "recall": {"revisits_counted": int(counted.sum()), "loop_closures_found": int(hit.sum()), "recall": recall,
+                      "rule": "revisit frames whose place still has its first signature in memory, older than the newest %d: the best raw-likelihood candidate shows the frame's place" % stm},
+           "parity": {"frames_checked": checked, "word_ids_equal": bool(ids_equal), "likelihood_max_rel": max_rel, "likelihood_values_compared": n_cmp,
+                      "adjust_likelihood_and_best_candidate_equal": bool(hyp_ok), "best_candidate_identical": hyp_same, "best_candidate_a_rounding_tie": hyp_near,
+                      "bound": "1e-4 relative (abs floor 1e-7)", "oracle_seconds": {"addNewWords": knn_s, "computeLikelihood": lik_s},
+                      "path": "sampled frames: the pipeline is completed and the device's dictionary read back in front of the frame; word ids vs the C++ oracle's "
+                              "VWDictionary::addNewWords over that dictionary; likelihood + adjustLikelihood vs the numpy restatement of Memory::computeLikelihood "
+                              "(oracle/tfidf_np.py, pinned to the C++ oracle) on the live signatures replayed from the device's word log"},
+           "cpu_baseline": {"value": (n - retired) / (t_knn_cpu + t_lik_cpu), "unit": "candidates/s (at the final dictionary and memory size)", "cores": 1, "kind": kind,
+                            "sample": "5 frames x %s (%.1f ms/frame) + 3 frames x %s (%.0f ms/frame)" % (knn_what, 1e3 * t_knn_cpu, lik_what, 1e3 * t_lik_cpu)}}
+    out["cpu_baseline"]["gpu_at_the_final_size"] = (n - retired) / (1e-3 * (out["config"]["ms_per_frame_last_half"] or out["ms_per_step"]))
+    print(json.dumps(out), flush=True)
+
+
 # ----------------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -1055,7 +1311,7 @@ def main():
                          "GPU (weak scaling, no data-path collective).  auto: the shard from 100 000 words per GPU up (config 4: 1M words "
                          "over 8 GPUs), replicas below (a 49k-word vocabulary is 12.5 MB: sharding it only adds two exchanges per frame); "
                          "the other one is measured in the same run as a secondary key")
-    ap.add_argument("--config", choices=["headline", "orb_stream", "replay"], default="headline")
+    ap.add_argument("--config", choices=["headline", "orb_stream", "replay", "replay_growing"], default="headline")
     ap.add_argument("--score-block", type=int, default=0, help="experiment: threads per workgroup of the scoring kernel (256/512/1024)")
     ap.add_argument("--knn-mode", default=None, choices=["bf16", "f16", "mfma32", "valu"],
                     help="the 2-NN filter of every SURF engine of the run (default: f16 = the one-product fp16 matrix-core filter, LCD_KNN_F16; "
@@ -1081,6 +1337,8 @@ def main():
         return run_orb_stream(args)
     if args.config == "replay":
         return run_replay(args)
+    if args.config == "replay_growing":
+        return run_replay_growing(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
@@ -1114,20 +1372,23 @@ def main():
         fr = [synth.frame_from_signature(vocab, words[s], seed=1000 * stream_id + i) for i, s in enumerate(src)]
         return src, fr
 
-    def run_shard():
+    def run_shard(force_path=False):
         """ONE frame stream, the vocabulary sharded by word-id range over the ranks: all-gather of the top-2 records + int64 all-reduce
-        of the partial likelihood per frame.  Returns (timed_loop result, rooflines, last likelihood, build seconds, frame sources)."""
+        of the partial likelihood per frame.  Returns (timed_loop result, rooflines, last likelihood, build seconds, frame sources).
+        force_path (one rank): the sharded stages themselves instead of the fused single-GPU frame a world of one would take."""
         from rtabmap_amd.sharded import ShardedLoopClosure
         src, frames_np = make_frames(0)                    # all ranks see the same frames
         d_frames = [torch.from_numpy(f).cuda() for f in frames_np]
-        sh = ShardedLoopClosure("f32", DIM, rank=rank, world=world, device=local, stream=stream, vocab_capacity=N_WORDS + 1024,
-                                sig_capacity=n_sig + 8192)
+        sh = ShardedLoopClosure("f32", DIM, rank=rank, world=world, device=local, stream=stream, vocab_capacity=N_WORDS + 65536,
+                                sig_capacity=n_sig + 8192, knn_mode=KNN_MODE)
+        sh.force_sharded_path = bool(force_path)
         t0 = time.perf_counter()
         sh.load_vocabulary(vocab, np.arange(1, N_WORDS + 1, dtype=np.int32))
         w = words.reshape(-1)
         sh.add_signatures_bulk(np.arange(1, n_sig + 1, dtype=np.int32), np.arange(0, (n_sig + 1) * Q, Q, dtype=np.int64), w,
                                owned_mask=(w > sh.lo) & (w <= sh.hi))
         build_s = time.perf_counter() - t0
+        sh.enable_device_append(N_WORDS + 1, 16)          # the step includes update(): each rank appends the new words it owns, on the device
         state = {"next": n_sig + 1, "old": 1, "like": None, "first_new": N_WORDS + 1}
 
         def step(i):
@@ -1325,6 +1586,15 @@ def main():
             except Exception as e:                                # noqa: BLE001
                 config["cpp_interface_error"] = "%s: %s" % (type(e).__name__, e)
             config["host_path_note"] = "lcd_quantize + lcd_sig_add + lcd_likelihood + lcd_sig_remove from host pointers (PCIe + syncs included)"
+            try:
+                rs = run_shard(force_path=True)[0]
+                config["shard_stages_world1_ms_per_step"] = 1e3 * rs["wall"] / args.steps
+                config["shard_stages_world1_note"] = "ONE rank running the SHARDED stages (what each of N ranks runs, without the wire): local search -> " \
+                                                     "candidate records -> merge + decision loop (replicated) -> update()'s append of the owned new words on the " \
+                                                     "device (shard_append) -> registration -> integer scoring -> conversion, unfused: 8 launches and one " \
+                                                     "synchronisation (row mirror) per frame; to be read against ms_per_step (the fused, pipelined single-GPU frame)"
+            except Exception as e:                                # noqa: BLE001
+                config["shard_stages_world1_error"] = "%s: %s" % (type(e).__name__, e)
             engu.close()
             engb = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 8192,
                                       stream=stream.cuda_stream, pipeline=args.pipeline, knn_mode=KNN_MODE)

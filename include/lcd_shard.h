@@ -52,6 +52,12 @@ const char* lcd_shard_last_error(const lcd_shard_comm* c);
  * row of a word VWDictionary::update() indexes (the initial vocabulary keeps the consecutive ranges it was loaded with: -1). */
 int lcd_shard_set_growth(lcd_shard_comm* c, int32_t first_incremental_id, int32_t block);
 int lcd_shard_owner_of(const lcd_shard_comm* c, int32_t word_id);
+/* VWDictionary::update()'s append branch on the device, sharded (v3): with on = 1 every frame that creates words (LCD_Q_INCREMENTAL,
+ * first_new_word_id > 0) leaves the words THIS rank owns as rows of its shard before the next frame is searched -- no
+ * lcd_shard_owner_of / lcd_vocab_append round trip through the caller, no read-back; the host's row mirror catches up when the next
+ * frame's search is planned (one stream synchronisation).  Same value on every rank.  What lcd_frame_args.append_new_words is to one GPU
+ * (Memory.cpp:1004-1016: update() runs before every addNewWords). */
+int lcd_shard_set_append(lcd_shard_comm* c, int on);
 
 /* One frame through the sharded path (arguments as lcd_frame_args / lcd_shard_frame_dev; total_live_rows = live vocabulary rows over ALL
  * ranks, VWDictionary.cpp:1015).  d_word_ids[q] and d_likelihood[likelihood_capacity >= slots after the frame] are device buffers of this

@@ -87,7 +87,9 @@ struct lcd_engine {
     static constexpr int VLOG = 4096;
     lcd::DevBuf d_vcnt;                                 // int32: [0], [1] row counters, [16 .. 16 + VLOG) rows appended by frame seq % VLOG
     unsigned long long* h_vmirror = nullptr;            // pinned: (seq + 1) << 32 | rows after that frame's append
-    struct DevAppend { uint64_t seq; int32_t first_id; int32_t q; bool enabled; };
+    struct DevAppend { uint64_t seq; int32_t first_id; int32_t q; bool enabled;
+                       // sharded append (lcd_shard_frame_dev): the log holds the frame's TOTAL of new words, this rank owns the ids the rule gives it
+                       int32_t own_world = 0, own_rank = 0, own_first = 0, own_block = 0; };
     std::deque<DevAppend> unreconciled;                 // frames whose appends the host mirror has not caught up with
     uint64_t vseq = 0;                                  // sequence number of the next frame in the chain: it reads counter vseq & 1, writes the other
     bool vcnt_active = false;                           // the counters hold the row count (set when the first appending frame arrives)
@@ -115,6 +117,7 @@ struct lcd_engine {
     // sharded vocabulary, balanced growth (lcd_set_option "shard_growth_first" / "shard_growth_block"): the words frames create (ids >=
     // shard_first) belong to rank ((id - shard_first) / shard_block) % world; 0 = they belong to the last rank
     int32_t shard_first = 0, shard_block = 0;
+    int shard_append = 0;                               // lcd_set_option("shard_append"): lcd_shard_frame_dev appends the new words this rank owns on the device
     int filter_units = -1;                              // lcd_set_option("filter_units")
     int strip_tiles = 0;                                // lcd_set_option("strip_tiles"): tiles per filter workgroup of a pipelined frame (0: planner)
     int sync_all();                                     // stream drained

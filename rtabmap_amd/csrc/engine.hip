@@ -296,15 +296,22 @@ int lcd_engine::reconcile() {
     for (const DevAppend& a : unreconciled) {
         if (!a.enabled) continue;
         const int n = log[(size_t)(a.seq % VLOG)];
+        int taken = 0;
         for (int k = 0; k < n; ++k) {
             const int32_t id = a.first_id + k;
+            if (a.own_world > 0) {                                    // a sharded append: n is the frame's total, this rank wrote the ids it owns
+                const bool mine = a.own_block > 0 ? (id >= a.own_first && ((id - a.own_first) / a.own_block) % a.own_world == a.own_rank)
+                                                  : a.own_rank == a.own_world - 1;
+                if (!mine) continue;
+            }
             if (rows_sorted && !h_row_key.empty() && id <= h_row_key.back()) rows_sorted = false;
-            if (word_row_valid) word_row[id] = (int32_t)(n_rows + k);
+            if (word_row_valid) word_row[id] = (int32_t)(n_rows + taken);
             h_row_key.push_back(id);
             h_row_live.push_back(1);
+            taken += 1;
         }
-        n_rows += n;
-        n_live += n;
+        n_rows += taken;
+        n_live += taken;
     }
     unreconciled.clear();
     if (rm_pending) {
@@ -1487,6 +1494,27 @@ int lcd_frame_host(lcd_engine* h, const lcd_frame_host_args* a) {
     std::memcpy(a->word_ids, h->h_frame_out.p, wbytes);
     if (lbytes) std::memcpy(a->likelihood, (const char*)h->h_frame_out.p + wbytes, lbytes);
     if (a->n_slots) *a->n_slots = slots_after;
+    // The word ids are here and the stream is idle: the rows this frame appended on the device are known without asking the device's log
+    // (the k-th new word carries the code -(k + 1)), so the host's row mirror catches up now -- the next call finds nothing to reconcile
+    // (a synchronisation and two small blocking copies less per frame).  Only when this frame is the one unreconciled appender.
+    if (h->unreconciled.size() == 1 && h->unreconciled.front().enabled && h->unreconciled.front().own_world == 0 && !h->rm_pending &&
+        h->unreconciled.front().first_id == a->first_new_word_id && h->h_vmirror) {
+        int n_new = 0;
+        for (int i = 0; i < q; ++i) n_new = std::max(n_new, -a->word_ids[i]);
+        const unsigned long long v = *(volatile const unsigned long long*)h->h_vmirror;   // what the appender reported: (tag << 32) | rows
+        if ((uint32_t)(v >> 32) == (uint32_t)(h->unreconciled.front().seq + 1) && (int64_t)(uint32_t)v == h->n_rows + n_new) {
+            for (int k = 0; k < n_new; ++k) {
+                const int32_t id = a->first_new_word_id + k;
+                if (h->rows_sorted && !h->h_row_key.empty() && id <= h->h_row_key.back()) h->rows_sorted = false;
+                if (h->word_row_valid) h->word_row[id] = (int32_t)(h->n_rows + k);
+                h->h_row_key.push_back(id);
+                h->h_row_live.push_back(1);
+            }
+            h->n_rows += n_new;
+            h->n_live += n_new;
+            h->unreconciled.clear();
+        }
+    }
     return LCD_OK;
     LCD_CATCH(h)
 }
@@ -1793,6 +1821,25 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
                               together ? h->d_selfdist.as<float>() : nullptr, ld, together ? h->d_bits.as<uint32_t>() : nullptr, bw,
                               d_word_ids, h->d_n_new.as<int32_t>(), h->stream, h->d_knn_row.as<int32_t>(), nullptr,
                               h->d_out_wslot.as<int32_t>(), &new_ws));
+    if (h->shard_append && incremental && first_new_word_id > 0 && h->row_bytes == h->dim * (h->dtype == LCD_F32 ? 4 : 1)) {
+        // VWDictionary::update()'s append branch, this rank's share, on the device: the words the frame created that this rank owns become
+        // rows of its shard before the next frame is searched (lcd_shard_knn2_dev catches the host's row mirror up: one synchronisation,
+        // no lcd_vocab_append, nothing read back by the caller)
+        { int rc = activate_dev_rows(h); if (rc) return rc; }
+        { int rc = ensure_append_capacity(h, h->rows_ub() + (int64_t)q); if (rc) return rc; }
+        lcd_frame_args fa;
+        std::memset(&fa, 0, sizeof(fa));
+        fa.d_descriptors = d_descriptors; fa.first_new_word_id = first_new_word_id; fa.q = q;
+        ResolveArgs ra;
+        const uint64_t vseq = h->vseq;
+        fill_append(h, fa, vseq, true, &ra);
+        WsRuns keys = new_ws;                              // (n == 0 on a rank that owns nothing in last-rank mode: it appends nothing either)
+        LCD_HIP(h, launch_shard_append(ra.ap, keys, d_word_ids, q, rank, world, cyclic ? h->shard_first : 0, cyclic ? h->shard_block : 0, h->stream));
+        lcd_engine::DevAppend da{vseq, first_new_word_id, q, true};
+        da.own_world = world; da.own_rank = rank; da.own_first = cyclic ? h->shard_first : 0; da.own_block = cyclic ? h->shard_block : 0;
+        h->unreconciled.push_back(da);
+        h->vseq += 1;
+    }
     if (sig_id != 0) LCD_HIP(h, t.register_dev(sig_id, h->d_out_wslot.as<int32_t>(), q, q, N));
     else LCD_HIP(h, t.query_dev(h->d_out_wslot.as<int32_t>(), q, N));
     if (d_lfix) {
@@ -1896,6 +1943,7 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     if (!std::strcmp(key, "strip_tiles") && value >= 0 && value <= 8) { h->strip_tiles = (int)value; return LCD_OK; }
     if (!std::strcmp(key, "shard_growth_first") && value >= 0 && value < (1ll << 28)) { h->shard_first = (int32_t)value; return LCD_OK; }
     if (!std::strcmp(key, "shard_growth_block") && value >= 0 && value <= (1 << 20)) { h->shard_block = (int32_t)value; return LCD_OK; }
+    if (!std::strcmp(key, "shard_append") && (value == 0 || value == 1)) { h->shard_append = (int)value; return LCD_OK; }
     // 0: lcd_profile_begin brackets only the 2-NN launch of a pipelined frame (an event pair costs the stream ~10 us)
     if (!std::strcmp(key, "profile_likelihood") && (value == 0 || value == 1)) { h->prof_likelihood = value != 0; return LCD_OK; }
     // (process-wide, for tests) sealed buckets from which the rows of a deferred append are written by a launch of their own; -1: built-in

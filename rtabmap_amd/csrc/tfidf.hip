@@ -337,6 +337,62 @@ inline int next_pow2(int v) { int p = 2; while (p < v) p <<= 1; return p; }
 
 }  // namespace
 
+// VWDictionary::update()'s append branch for ONE RANK of a sharded vocabulary (lcd_shard_frame_dev with "shard_append"): the decision
+// loop ran replicated on the merged candidates, so every rank holds the same codes; this rank turns the new words it OWNS into rows of
+// its shard -- behind the rows it has, in word order -- without the host.  Ownership as WsRuns says (block-cyclic over the ranks, or all
+// to the last rank); the count of owned ids below a given id has a closed form, so a word's row needs no scan.  One workgroup.
+__device__ __forceinline__ int shard_owned_below(int32_t id, int32_t first, int32_t block, int rank, int world) {   // owned ids in [first, id)
+    if (id <= first) return 0;
+    const long long x = (long long)id - first, cyc = (long long)block * world;
+    const long long rem = x % cyc - (long long)rank * block;
+    return (int)((x / cyc) * block + (rem < 0 ? 0 : (rem > block ? block : rem)));
+}
+__global__ __launch_bounds__(1024) void shard_append_kernel(AppendArgs ap, WsRuns new_ws, const int32_t* __restrict__ codes, int q, int rank, int world,
+                                                           int32_t own_first, int32_t own_block) {
+    extern __shared__ int s_first[];                                   // [q]: the descriptor that created the k-th new word
+    __shared__ int s_n_new;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_n_new = 0;
+    for (int k = tid; k < q; k += blockDim.x) s_first[k] = 0x7fffffff;
+    __syncthreads();
+    for (int i = tid; i < q; i += blockDim.x) {
+        const int c = codes[i];
+        if (c < 0) { atomicMin(&s_first[-c - 1], i); atomicMax(&s_n_new, -c); }   // (a later descriptor that matched the new word carries the same code)
+    }
+    __syncthreads();
+    const int n_new = s_n_new, n_in = ap.cnt_in[0];
+    auto below = [&](int k) -> int {                                   // owned words among the frame's first k new words
+        if (own_block > 0) return shard_owned_below(ap.first_id + k, own_first, own_block, rank, world) - shard_owned_below(ap.first_id, own_first, own_block, rank, world);
+        return rank == world - 1 ? k : 0;
+    };
+    const int n_own = below(n_new);
+    const int n_take = (long long)n_in + n_own <= ap.capacity ? n_own : 0;
+    const int c = tid & 15;
+    float norm_max = 0.0f;
+    for (int k = tid >> 4; k < n_new && n_take > 0; k += (int)blockDim.x >> 4) {
+        const int j = below(k);
+        if (below(k + 1) == j) continue;                               // another rank's word (uniform over the row's 16 lanes)
+        const size_t row = (size_t)n_in + (size_t)j;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(ap.descriptors) + (size_t)s_first[k] * ap.row_dwords;
+        if (ap.is_f32_64) append_write_row(ap, row, c, reinterpret_cast<const uint4*>(src)[c], norm_max);
+        else { uint32_t* dst = ap.vocab + row * ap.row_dwords; for (int d = c; d < ap.row_dwords; d += 16) dst[d] = src[d]; }
+        if (c == 0) append_write_ids(ap, new_ws, row, k);
+    }
+    if (ap.is_f32_64) append_norm_max(ap, norm_max);
+    if (tid == 0) {
+        ap.cnt_out[0] = n_in + n_take;
+        if (ap.log_slot) ap.log_slot[0] = n_take > 0 || n_own == 0 ? n_new : -1;   // the host derives the owned ids from the frame's total (-1: dropped, no room)
+        if (ap.host_mirror) __hip_atomic_store(ap.host_mirror, ((unsigned long long)ap.tag << 32) | (unsigned long long)(uint32_t)(n_in + n_take), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+hipError_t launch_shard_append(const AppendArgs& ap, const WsRuns& new_ws, const int32_t* codes, int q, int rank, int world, int32_t own_first,
+                               int32_t own_block, hipStream_t s) {
+    if (q <= 0 || q > 8192) return hipErrorInvalidValue;
+    shard_append_kernel<<<1, 1024, (size_t)q * 4, s>>>(ap, new_ws, codes, q, rank, world, own_first, own_block);
+    return hipGetLastError();
+}
+
 hipError_t launch_gather_f32(const float* dense, const int64_t* slots, int n, float* out, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     gather_f32_kernel<<<(n + 255) / 256, 256, 0, s>>>(dense, (const long long*)slots, n, out);

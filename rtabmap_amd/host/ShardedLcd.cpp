@@ -229,6 +229,14 @@ int lcd_shard_set_growth(lcd_shard_comm* c, int32_t first_incremental_id, int32_
     SHARD_CATCH(c)
 }
 
+int lcd_shard_set_append(lcd_shard_comm* c, int on) {
+    if (!c) return LCD_ERR_INVALID;
+    SHARD_TRY
+    if (lcd_set_option(c->eng, "shard_append", on ? 1 : 0) != LCD_OK) return c->fail(LCD_ERR_STATE, lcd_last_error(c->eng));
+    return LCD_OK;
+    SHARD_CATCH(c)
+}
+
 int lcd_shard_owner_of(const lcd_shard_comm* c, int32_t word_id) {
     if (!c) return -1;
     if (c->grow_block > 0) return word_id >= c->grow_first ? ((word_id - c->grow_first) / c->grow_block) % c->world : -1;

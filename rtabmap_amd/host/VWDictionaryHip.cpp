@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -434,7 +435,10 @@ bool VWDictionaryHip::addNewWordsAndScore(const Mat& descriptorsIn, int signatur
     a.flags = LCD_Q_INCREMENTAL | (_newWordsComparedTogether ? LCD_Q_NEW_WORDS_COMPARED : 0); a.nndr_ratio = _nndrRatio;
     a.sig_id = signatureId; a.first_new_word_id = _lastWordId + 1; a.N = N; a.append_new_words = 1;
     a.word_ids = out.data(); a.likelihood = likelihoodBySlot.data(); a.likelihood_capacity = (int64_t)likelihoodBySlot.size(); a.n_slots = &nSlots;
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     const int rc = lcd_frame_host(_engine, &a);
+    _fastDeviceNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    _fastCalls += 1;
     if (rc != LCD_OK) {
         _lastError = lcd_last_error(_engine);
         if (rc != LCD_ERR_UNSUPPORTED) logError("%s", _lastError.c_str());
@@ -509,6 +513,10 @@ std::vector<int> VWDictionaryHip::findNN(const Mat& queryIn) const {
         std::vector<int32_t> extraIds;
         std::vector<unsigned char> extraRows;
         for (std::set<int>::const_iterator it = _notIndexedWords.begin(); it != _notIndexedWords.end(); ++it) {
+            // a word a device-resident frame created is a row of the device vocabulary already (the indexed search covers it, behind every
+            // indexed row: the same candidates, the same order on ties with indexed words): passed again as an extra it would be its own
+            // second neighbour and fail the ratio test against itself
+            if (_deviceRows.count(*it)) continue;
             const VisualWord* vw = _visualWords.at(*it);
             extraRows.insert(extraRows.end(), vw->getDescriptor().data.begin(), vw->getDescriptor().data.end());
             extraIds.push_back(*it);

@@ -131,6 +131,9 @@ public:
                              std::vector<float>& likelihoodBySlot);
     // device slot -> signature id (0: the slot's signature was removed); slots are handed out in registration order
     const std::vector<int>& slotSignatures() const { return _slotSig; }
+    // host time spent INSIDE lcd_frame_host by addNewWordsAndScore (copies, launches, the one synchronisation) and the number of calls:
+    // what is left of a caller's update() time is the mirror's own std::map bookkeeping
+    void fastFrameStats(long long* deviceCallNs, long long* calls) const { *deviceCallNs = _fastDeviceNs; *calls = _fastCalls; }
 
     // send the references added / removed since the last call to the device's inverted index (computeLikelihood does it itself)
     bool flushReferences(const std::function<int(int)>& getNi);
@@ -188,7 +191,7 @@ private:
     // words a frame created that are ALREADY rows of the device vocabulary (addNewWordsAndScore with append_new_words): still in
     // _notIndexedWords on the host until update() runs
     std::set<int> _deviceRows;
-    std::vector<float> _likeScratch;
+    long long _fastDeviceNs = 0, _fastCalls = 0;
 };
 
 }  // namespace rtabmap_amd

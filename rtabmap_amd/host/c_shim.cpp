@@ -134,6 +134,12 @@ double hmem_time_loop(void* h, const void* descs, int n_frames, int rows, int co
 }
 
 void hmem_set_device_frames(void* h, int on) { ((MemoryHip*)h)->setDeviceFrames(on != 0); }
+// mean milliseconds a device-resident update() spent inside lcd_frame_host so far (-1: none ran)
+double hmem_fast_frame_device_ms(void* h) {
+    long long ns = 0, calls = 0;
+    ((MemoryHip*)h)->getVWDictionary()->fastFrameStats(&ns, &calls);
+    return calls ? 1e-6 * (double)ns / (double)calls : -1.0;
+}
 // n signatures of q words each (ids first_id, first_id + 1, ...) through addSignature, then ONE bulk registration on the device
 int hmem_add_signatures_bulk(void* h, const int* words, int n, int q, int first_id) {
     MemoryHip* m = (MemoryHip*)h;

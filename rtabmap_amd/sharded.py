@@ -32,14 +32,19 @@ def shard_bounds(n_rows, world):
 
 
 class ShardedLoopClosure:
-    def __init__(self, dtype, dim, rank=None, world=None, device=0, group=None, stream=None, vocab_capacity=0, sig_capacity=0):
+    def __init__(self, dtype, dim, rank=None, world=None, device=0, group=None, stream=None, vocab_capacity=0, sig_capacity=0, knn_mode=None):
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.device = torch.device("cuda", device)
         self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        # one rank owns everything: the sharded frame IS the single-GPU frame, software-pipelined like it (frame(defer=True) hands the
+        # likelihood back one call late either way); several ranks: plain handles, the exchanges sit between the stages
         self.eng = Engine(dtype, dim, device=device, vocab_capacity=vocab_capacity, sig_capacity=sig_capacity,
-                          stream=self.stream.cuda_stream)
+                          stream=self.stream.cuda_stream, knn_mode=knn_mode)
+        self._append = False
+        self.force_sharded_path = False  # world 1 only: run the sharded stages (local search -> records -> merge -> registration -> integer
+                                         # scoring -> conversion) instead of the fused single-GPU frame: what one rank of N pays without the wire
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
         self.total_rows = 0
         self.lo = self.hi = 0            # owned word-id range (ids lo+1 .. hi when ids are 1..n in row order)
@@ -68,6 +73,16 @@ class ShardedLoopClosure:
         mine = np.where(owned_mask, w, -1).astype(np.int32)
         ni = np.diff(np.asarray(offsets, dtype=np.int64)).astype(np.int32)
         self.eng.sig_add_bulk(sig_ids, offsets, mine, ni)
+
+    def enable_device_append(self, first_incremental_id, block=16):
+        """VWDictionary::update()'s append on the device for every frame from here on: the words frames create (ids from
+        first_incremental_id on) become rows of the rank that owns them -- block-cyclically over the ranks -- inside the frame call
+        (lcd_set_option "shard_growth_first" / "shard_growth_block" / "shard_append"); world 1: lcd_frame_args.append_new_words."""
+        self._append = True
+        if self.world > 1 or self.force_sharded_path:
+            self.eng.set_option("shard_growth_first", int(first_incremental_id))
+            self.eng.set_option("shard_growth_block", int(block))
+            self.eng.set_option("shard_append", 1)
 
     def retire(self, sig_id):
         if self._pending is not None:    # the owed likelihood is finalised against the signature table as its frame left it
@@ -144,7 +159,7 @@ class ShardedLoopClosure:
         q = d_desc.shape[0]
         par = self._n_frames & 1
         self._n_frames += 1
-        if self.world == 1:
+        if self.world == 1 and not self.force_sharded_path:
             # one rank owns everything: the sharded frame IS the single-GPU frame (fused launches, no exchange)
             prev = self._complete_pending()
             with torch.cuda.stream(self.stream):
@@ -153,7 +168,7 @@ class ShardedLoopClosure:
                 like = self._buf("like%d" % par, (n_slots + 2,), torch.float32)
                 self.eng.frame_dev(d_desc.data_ptr(), q, sig_id, N, words.data_ptr(), like.data_ptr() if want_likelihood else None,
                                    like.shape[0], incremental=incremental, new_words_compared=new_words_compared, nndr=nndr,
-                                   first_new_word_id=first_new_word_id)
+                                   first_new_word_id=first_new_word_id, append_new_words=self._append)
                 _, n_slots = self.eng.slots_dev()
             if defer and want_likelihood:                 # nothing to overlap; the same contract: one frame late
                 self._owed_single = like[:n_slots]
@@ -228,6 +243,7 @@ def load_shard():
         L.lcd_shard_sig_remove.argtypes = [vp, C.c_int32]
         L.lcd_shard_set_growth.argtypes = [vp, C.c_int32, C.c_int32]
         L.lcd_shard_owner_of.argtypes = [vp, C.c_int32]
+        L.lcd_shard_set_append.argtypes = [vp, C.c_int]
         _shard_lib = L
     return _shard_lib
 
@@ -331,6 +347,10 @@ class NativeShardComm:
 
     def owner_of(self, word_id):
         return int(self.L.lcd_shard_owner_of(self.h, word_id))
+
+    def set_append(self, on=True):
+        """lcd_shard_set_append: the words a frame creates become rows of the owning rank's shard on the device (update()'s append)"""
+        self._ck(self.L.lcd_shard_set_append(self.h, 1 if on else 0), "lcd_shard_set_append")
 
     def close(self):
         if getattr(self, "h", None):

@@ -61,6 +61,8 @@ def lib():
         L.hmem_time_loop_modes.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.hmem_set_device_frames.argtypes = [vp, ci]
         L.hmem_set_device_frames.restype = None
+        L.hmem_fast_frame_device_ms.argtypes = [vp]
+        L.hmem_fast_frame_device_ms.restype = C.c_double
         L.hmem_add_signatures_bulk.argtypes = [vp, vp, ci, ci, ci]
         L.hmem_compute_likelihood_flat.argtypes = [vp, ci, vp, vp, ci]
         L.hmem_compute_likelihood_of.argtypes = [vp, ci, vp, ci, vp, vp]
@@ -247,6 +249,10 @@ class MemoryHip:
         if lib().hmem_time_loop_modes(self.h, _p(f), f.shape[0], f.shape[1], f.shape[2], _type_of(f), int(steps), int(mode), _p(out)) != 0:
             raise RuntimeError("hmem_time_loop_modes failed: " + self.vwd.last_error())
         return dict(zip(("step", "update", "likelihood", "forget"), out.tolist()))
+
+    def fast_frame_device_ms(self):
+        """mean ms a device-resident update() spent inside lcd_frame_host (the rest of update() is the mirror's std::map bookkeeping)"""
+        return float(lib().hmem_fast_frame_device_ms(self.h))
 
     def set_device_frames(self, on):
         """MemoryHip::setDeviceFrames: update() as ONE device call (lcd_frame_host) that also brings the likelihood back (default), or the

@@ -28,7 +28,7 @@ def test_shard_driver_builds_and_exports_every_declared_symbol():
     header = open(os.path.join(os.path.dirname(__file__), "..", "include", "lcd_shard.h")).read()
     declared = set(re.findall(r"\b(lcd_shard_[a-z0-9_]+)\s*\(", header)) - {"lcd_shard_knn2_dev", "lcd_shard_frame_dev"}
     assert declared == {"lcd_shard_unique_id", "lcd_shard_comm_create", "lcd_shard_comm_create_transport", "lcd_shard_comm_destroy",
-                        "lcd_shard_last_error", "lcd_shard_set_growth", "lcd_shard_owner_of", "lcd_shard_frame", "lcd_shard_frame_deferred",
+                        "lcd_shard_last_error", "lcd_shard_set_growth", "lcd_shard_owner_of", "lcd_shard_set_append", "lcd_shard_frame", "lcd_shard_frame_deferred",
                         "lcd_shard_flush", "lcd_shard_sig_remove"}
     for s in declared:
         assert hasattr(L, s), s

@@ -124,6 +124,7 @@ FAKE_SHARD = '''
     class FakeShard:
         def __init__(self, *a, **k): self.eng, self.lo, self.hi = FakeEngine(), 0, 24500
         def load_vocabulary(self, rows, ids): pass
+        def enable_device_append(self, *a, **k): pass
         def add_signatures_bulk(self, *a, **k): pass
         def frame(self, *a, **k): return None, None
         def retire(self, sig): pass

@@ -306,13 +306,16 @@ def _native_worker(rank, world, port, out):
         return np.arange(first_new, first_new + n_new, dtype=np.int32), rows
 
     results = {}
-    for mode in ("last_rank", "deferred", "block_cyclic"):
+    for mode in ("last_rank", "deferred", "block_cyclic", "last_rank_dev", "block_cyclic_dev_deferred"):
         eng = rtabmap_amd.Engine("f32", 64, sig_capacity=n_sig + 64)
         load(eng, slice(lo, hi))
         tr = HostStagedTransport()
         comm = NativeShardComm(eng, rank, world, transport=tr)
-        if mode == "block_cyclic":
+        if mode.startswith("block_cyclic"):
             comm.set_growth(n_words + 1, 16)
+        on_device = "_dev" in mode                                   # update()'s append on the device: no lcd_vocab_append in the loop (lcd_shard_set_append)
+        if on_device:
+            comm.set_append(True)
         cap = n_sig + 64
         d_w = torch.zeros(q, dtype=torch.int32, device="cuda")
         d_l = [torch.zeros(cap, dtype=torch.float32, device="cuda") for _ in range(2)]
@@ -321,10 +324,10 @@ def _native_worker(rank, world, port, out):
         for t, desc in enumerate(frames):
             d = torch.from_numpy(desc).cuda()
             comm.frame(d.data_ptr(), q, n_sig + 1 + t, float(n_sig + 1 + t), total_rows, d_w.data_ptr(), d_l[t & 1].data_ptr(), cap,
-                       first_new_word_id=last_id + 1, defer=(mode == "deferred"))
+                       first_new_word_id=last_id + 1, defer=mode.endswith("deferred"))
             eng.synchronize()
             codes = d_w.cpu().numpy().copy()
-            if mode == "deferred":
+            if mode.endswith("deferred"):
                 if owed is not None:                                 # the call above finalised the previous frame's likelihood
                     res.append((owed[0], d_l[(t - 1) & 1][: owed[1]].cpu().numpy().copy()))
                 owed = (codes, n_sig + 1 + t)
@@ -336,17 +339,24 @@ def _native_worker(rank, world, port, out):
             new_ids, new_rows = new_words_of(codes, desc, last_id + 1)
             mine = np.array([comm.owner_of(int(w)) == rank for w in new_ids], bool)
             if mine.any():
-                eng.vocab_append(new_rows[mine], new_ids[mine])
+                if not on_device:
+                    eng.vocab_append(new_rows[mine], new_ids[mine])
                 my_rows += int(mine.sum())
             last_id += len(new_ids)
             total_rows += len(new_ids)
-        if mode == "deferred":
+        if mode.endswith("deferred"):
             comm.flush()
             eng.synchronize()
             res.append((owed[0], d_l[(len(frames) - 1) & 1][: owed[1]].cpu().numpy().copy()))
         assert tr.calls["all_gather"] == len(frames) and tr.calls["all_reduce"] == len(frames)
         rows_here, _ = eng.vocab_count()
         assert rows_here == my_rows
+        if on_device and my_rows > hi - lo:
+            # the rows the device appended are this rank's words, in id order, with the descriptors that created them
+            vr, vi = eng.vocab_read(hi - lo, my_rows - (hi - lo))
+            assert vi.tolist() == sorted(vi.tolist()) and all(comm.owner_of(int(w)) == rank for w in vi.tolist())
+            probe_id, probe_d = eng.knn2(vr[:8])
+            assert probe_id[:, 0].tolist() == vi[:8].tolist() and not probe_d[:, 0].any()
         counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(counts, torch.tensor([my_rows - (hi - lo)], dtype=torch.int64))
         comm.close()
@@ -380,10 +390,13 @@ def _native_worker(rank, world, port, out):
         grown = results["block_cyclic"][1]
         if created < 200:
             ok = False; msgs.append("the stream created only %d words" % created)
-        if results["last_rank"][1] != [0, created]:
-            ok = False; msgs.append("last-rank ownership: growth %r" % (results["last_rank"][1],))
-        if sum(grown) != created or abs(grown[0] - grown[1]) > 0.1 * created:
-            ok = False; msgs.append("block-cyclic growth is not balanced: %r of %d" % (grown, created))
+        for m_ in ("last_rank", "last_rank_dev"):
+            if results[m_][1] != [0, created]:
+                ok = False; msgs.append("%s ownership: growth %r" % (m_, results[m_][1]))
+        for m_ in ("block_cyclic", "block_cyclic_dev_deferred"):
+            grown = results[m_][1]
+            if sum(grown) != created or abs(grown[0] - grown[1]) > 0.1 * created:
+                ok = False; msgs.append("%s growth is not balanced: %r of %d" % (m_, grown, created))
         out.put((ok, msgs))
     dist.barrier()
     dist.destroy_process_group()
@@ -393,7 +406,9 @@ def _native_worker(rank, world, port, out):
 def test_native_driver_two_ranks_deferred_and_balanced_growth():
     """liblcd_shard.so with TWO ranks (sharing the test box's one GPU; exchanges through the driver's transport callbacks): the in-order
     frame, the frame whose all-reduce is left running under the next frame's search (lcd_shard_frame_deferred: retirements queue behind
-    the owed likelihood), and block-cyclic ownership of the words the stream creates (lcd_shard_set_growth: ties by word id) -- each bit
+    the owed likelihood), block-cyclic ownership of the words the stream creates (lcd_shard_set_growth: ties by word id), and -- round 5 --
+    the same with VWDictionary::update()'s append ON THE DEVICE (lcd_shard_set_append: every rank turns the new words it owns into rows of
+    its shard from the replicated decision, no lcd_vocab_append in the loop; last-rank and block-cyclic + deferred) -- each bit
     for bit the single-GPU engine's word ids and likelihood over a stream whose created words are indexed and matched again; with
     block-cyclic ownership both ranks grow by the same number of rows (within 10 %), with the default all growth lands on the last rank."""
     ctx = mp.get_context("spawn")
