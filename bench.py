@@ -826,6 +826,7 @@ def run_replay(args):
     import oracle as O
     from oracle import tfidf_np
     n_total = args.signatures if args.signatures != N_SIG else 1_000_000
+    globals()["N_SIG_RUN"] = n_total
     P, V, q, stm, n_samples = 2048, 2, Q, 30, 20
     vocab = synth.vocab_surf(N_WORDS)
     place_words = synth.zipf_words(P, q, N_WORDS, seed=5)
@@ -1039,8 +1040,10 @@ def run_replay_growing(args):
     """Config 5's stand-in with what config 5 is about (Memory.cpp:5941-6059, Rtabmap.cpp:2117): a replay whose INCREMENTAL dictionary starts
     EMPTY and keeps growing, with the whole of Memory::preUpdate live.  Trajectory: every other frame is the first visit of a NEW place
     (n/2 places over n frames), the frames in between revisit a place seen before (uniform over the places so far).  A place = q - 1
-    descriptors near words of a 49 000-word Zipf world (the robot's environment: these become dictionary words as they are first seen) +
-    one descriptor of its own (a word only this place has); a revisit = the place's descriptors + N(0, 0.03^2) noise, renormalised.  So
+    descriptors near words (N(0, 0.015^2) noise) of a 49 000-word Zipf world (the robot's environment: these become dictionary words as they are first seen) +
+    one descriptor of its own (a word only this place has); a revisit = the place's descriptors + N(0, 0.015^2) noise, renormalised
+    (two sightings of a world word are 2 sigma^2 D apart: at sigma = 0.03 the ratio test starts rejecting them against the world's closest
+    pairs, and a word with two entries is rejected at every later sighting -- the dictionary then doubles every few thousand frames).  So
     the dictionary covers the world's used words within the first thousands of frames and then grows by about one word per new place
     (> 500 000 words at 10^6 frames), > 50 % of the frames create words.  Every frame: cleanUnusedWords (lcd_vocab_remove_unused_async)
     -> update() (the previous frame's words became rows on the device) -> addNewWords -> references -> computeLikelihood against every
@@ -1058,7 +1061,8 @@ def run_replay_growing(args):
     import oracle as O
     from oracle import tfidf_np
     n = args.signatures if args.signatures != N_SIG else 1_000_000
-    q, stm, retire_every, rebuild_every, B, sigma = Q, 30, 8, 8192, 512, 0.03
+    globals()["N_SIG_RUN"] = n
+    q, stm, retire_every, rebuild_every, B, sigma = Q, 30, 8, 8192, 512, 0.015
     n_places = n // 2 + 1
     stream = torch.cuda.Stream()
     vocab = synth.vocab_surf(N_WORDS)
@@ -1091,9 +1095,9 @@ def run_replay_growing(args):
     d_place = torch.from_numpy(place).cuda()
     revisit = torch.from_numpy((ts % 2 == 1)).cuda()
     # word ids: frame t may create the ids [first_new[t], first_new[t] + stride[t]): q for the first frames (an empty dictionary: nearly every
-    # descriptor is a new word), 64 once the world's words are in -- checked against the logged codes afterwards
+    # descriptor is a new word), 192 once the world's words are in -- checked against the logged codes afterwards
     early = min(n, 20000)
-    stride = np.where(ts < early, q, 64).astype(np.int64)
+    stride = np.where(ts < early, q, 192).astype(np.int64)
     first_new = 1 + np.concatenate([[0], np.cumsum(stride)[:-1]])
     if first_new[-1] + q >= (1 << 28):
         raise SystemExit("replay_growing: word ids would pass 2^28")
@@ -1167,6 +1171,9 @@ def run_replay_growing(args):
     roof_knn, roof_score = rooflines(eng, rows, n - retired, False)
     for r in (roof_knn, roof_score):
         if r:
+            r["traffic"] = None                                    # (the committed PMC summary is the headline configuration's)
+            r["traffic_source"] = None
+            r["traffic_note"] = "not measured for this configuration"
             r["measured_in"] = "HIP events attached to the launches of the last %d frames (dictionary and memory at their final size)" % n_prof
     # ---- recall
     hyp = d_hyp.cpu().numpy()

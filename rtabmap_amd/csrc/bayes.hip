@@ -26,6 +26,10 @@ namespace lcd {
 namespace {
 
 constexpr int DC_BLOCK = 256;
+// Measured at 100 000 slots (round 5, same box, with_bayes ms per step; profiles/r05_ab_notes.txt): 256 / 512 / 1024 / 2048 / 4096 workgroups per pass
+// -> 0.107 / 0.083 / 0.076 / 0.091 / 0.130.  Also measured and NOT kept: every list row of three steps requested up front, then every gather
+// (two round trips per workgroup instead of one per step): 114 / 128-capped registers instead of 86 / 100 -> pass 1 15.7 -> 17.7 us, pass 2 20.5 ->
+// 59.5 us -- the passes live on resident waves, not on the length of one workgroup's chain.
 constexpr int DC_MAX_GRID = 1024;
 constexpr uint32_t SLOT_MASK = (1u << BAYES_SLOT_BITS) - 1u;
 constexpr int ROWS = 6;                   // list rows (8 entries each) requested up front by the passes: 48 entries cover a chain neighbourhood (33)

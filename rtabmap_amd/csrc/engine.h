@@ -142,6 +142,10 @@ struct lcd_engine {
 
     // ---- statistics
     int64_t knn_launches = 0, likelihood_launches = 0, rebuilds = 0, frame_calls = 0, frame_host_ns = 0;
+    // where the host time of a pipelined lcd_frame_dev goes (lcd_debug_host_profile): ns accumulated per section
+    //   0 checks + throttle + capacity   1 ring reservations   2 reserve_frame_words + decision-loop arguments   3 registration + scoring arguments
+    //   4 filter plan (build_knn)   5 launch A   6 launch B   7 the rest of pipeline_launch (flush_held, finish_frame_ops)   8 calls
+    int64_t host_prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     int fail(int code, const std::string& msg) { err = msg; return code; }
     int hip_fail(hipError_t e, const char* what) {

@@ -1205,6 +1205,11 @@ static int finish_frame_ops(lcd_engine* h, lcd_engine::InFlight& f) {
 }
 
 static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs);
+struct HostLap {   // section timer of the pipelined frame's host path (host_prof)
+    lcd_engine* h; std::chrono::steady_clock::time_point t;
+    explicit HostLap(lcd_engine* e) : h(e), t(std::chrono::steady_clock::now()) {}
+    void lap(int i) { const auto n = std::chrono::steady_clock::now(); h->host_prof[i] += std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count(); t = n; }
+};
 
 int lcd_engine::drain(bool rows) {
     int rc_all = LCD_OK;
@@ -1300,6 +1305,7 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
     }
     TailLaunch tl_reg, tl_res; ScoreArgs sa; int score_wgs = 0;
     bool reg_like = false;
+    HostLap lap(h);
     if (f_res) {
         // FIRST, before any launch argument is built: the reservation may move the word-indexed tables (they double when the keys run
         // out -- every ~3 000 frames at 150 new words per frame), and the registration / scoring arguments below hold pointers into
@@ -1313,6 +1319,7 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
         if (f_res->chained) fill_append(h, f_res->a, f_res->vseq, frame_appends(h, f_res->a), &tl_res.r, h->ring[f_res->set].d_applist.as<uint32_t>());
         resolve_launch_info(tl_res.r, pipe_block_size(), &tl_res.n_redo, &tl_res.shmem_resolve);
     }
+    lap.lap(2);
     if (f_reg) {
         const lcd_frame_args& pa = f_reg->a;
         if (pa.sig_id != 0) LCD_HIP(h, t.register_dev(pa.sig_id, f_reg->r.out_wslot, pa.q, pa.q, pa.N, nullptr, false, &tl_reg));
@@ -1323,8 +1330,10 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
             h->likelihood_launches += 1;
         }
     }
+    lap.lap(3);
     PipeKnn k;
     if (f_knn) { int rc = build_knn(h, *f_knn, &k); if (rc) return rc; h->knn_launches += 1; }
+    lap.lap(4);
     const bool prof = f_knn && h->prof_cap > 0 && h->prof_n < h->prof_cap;
     LCD_HIP(h, launch_frame_a(f_knn ? &k : nullptr, qs, f_res ? &tl_res : nullptr, f_reg ? &tl_reg : nullptr, h->stream,
                               prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr));
@@ -1337,11 +1346,13 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
             h->prof_kernel = knn_bf16_persistent(k.plan) ? "frame_a_kernel_p (persistent bf16 filter of frame t-1 + query pre-split of t + decision loop of t-2 + registration of t-3)"
                                                          : "frame_a_kernel (bf16 filter of frame t-1 + query pre-split of t + decision loop of t-2 + registration of t-3)";
     }
+    lap.lap(5);
     const bool prof2 = f_knn && reg_like && h->prof_likelihood && h->prof_cap > 0 && h->prof2_n < h->prof_cap;
     AppendRowsArgs app;
     if (f_res && tl_res.r.ap.enabled && tl_res.r.ap.defer_rows) { app.ap = tl_res.r.ap; app.new_ws = tl_res.r.new_ws; }
     LCD_HIP(h, launch_frame_b(f_knn ? &k : nullptr, reg_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
                               prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr, app.ap.enabled ? &app : nullptr));
+    lap.lap(6);
     LCD_HIP(h, t.flush_held_if_due());                               // (behind launch B: the rows it writes claim their postings keys there)
     if (prof2) { h->prof2_n += 1; h->prof2_kernel = "frame_b_kernel (re-rank of frame t-1 + scoring of frame t-3)"; }
     if (h->clean_armed && f_reg) {
@@ -1363,6 +1374,7 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
         int rc = finish_frame_ops(h, done);
         if (rc) return rc;
     }
+    lap.lap(7);
     return LCD_OK;
 }
 
@@ -1372,6 +1384,8 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
 static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     Tfidf& t = h->tfidf;
     const int q = a->q;
+    HostLap lap0(h);
+    h->host_prof[8] += 1;
     // validate against the index as it will be once the owed stages have run
     int64_t owed_slots = 0;
     for (const lcd_engine::InFlight& f : h->inflight) {
@@ -1414,6 +1428,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     const bool incremental = (a->flags & LCD_Q_INCREMENTAL) != 0;
     const bool together = incremental && (a->flags & LCD_Q_NEW_WORDS_COMPARED);
     const int ld = (q + 63) / 64 * 64, bw = ld / 32;
+    lap0.lap(0);
     // ---- the frame's scratch set (what does not depend on the launch plan; the partial keys are sized when the filter is planned)
     LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_qsplit, knn_qsplit_bytes(q)));
     LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_qnorm, (size_t)ld * 4));
@@ -1429,6 +1444,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     }
     QSplitArgs qs;
     qs.queries = (const float*)a->d_descriptors; qs.nq = q; qs.qpad = ld; qs.qsplit = (uint4*)sc.d_qsplit.p; qs.qnorm = sc.d_qnorm.as<float>(); qs.n_wgs = 0; qs.f16 = h->f16();
+    lap0.lap(1);
     // ---- what the frames in flight owe rides with this frame's launches
     { int rc = pipeline_launch(h, &qs); if (rc) return rc; }
     // ---- this frame's filter, re-rank, decision loop, registration and scoring are owed from here on
@@ -1449,6 +1465,13 @@ int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     LCD_DEV_NODRAIN(h);
     return frame_dev_body(h, a);
     LCD_CATCH(h)
+}
+
+// where the host time of the pipelined lcd_frame_dev calls went so far (engine.h: host_prof): out9[0..7] ns per section, out9[8] calls.  Not part of lcd.h.
+int lcd_debug_host_profile(const lcd_engine* h, int64_t* out9) {
+    if (!h || !out9) return LCD_ERR_INVALID;
+    for (int i = 0; i < 9; ++i) out9[i] = h->host_prof[i];
+    return LCD_OK;
 }
 
 int lcd_slot_count(const lcd_engine* h, int64_t* n_slots) {
