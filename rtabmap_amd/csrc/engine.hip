@@ -1971,6 +1971,7 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     if (!std::strcmp(key, "profile_likelihood") && (value == 0 || value == 1)) { h->prof_likelihood = value != 0; return LCD_OK; }
     // (process-wide, for tests) sealed buckets from which the rows of a deferred append are written by a launch of their own; -1: built-in
     if (!std::strcmp(key, "append_split_buckets") && value >= -1 && value <= (1 << 24)) { knn_set_append_split_buckets((int)value); return LCD_OK; }
+    if (!std::strcmp(key, "append_from_rerank") && value >= -1 && value <= 1) { knn_set_append_from_rerank(value != 0 ? 1 : 0); return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");
     LCD_CATCH(h)
 }

@@ -1895,6 +1895,8 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
 static int g_plan_cus = 256;
 void knn_set_compute_units(int cus) { if (cus >= 16 && cus <= 4096) g_plan_cus = cus; }
 void knn_set_append_split_buckets(int n) { g_append_split_buckets = n >= 0 ? n : APPEND_SPLIT_BUCKETS; }
+static int g_append_from_rerank = 1;           // (lcd_set_option "append_from_rerank": 0 = the eight row-writer workgroups of round 4, for A/B runs)
+void knn_set_append_from_rerank(int on) { g_append_from_rerank = on != 0 ? 1 : 0; }
 int knn_selfdist_wgs(int q) { return selfdist_tiles(q); }
 // other_wgs: workgroups of the same launch that run for about as long as a filter workgroup (distance-matrix tiles, the frame tail's
 // two workgroups).  Every workgroup of the launch holds a whole compute unit's LDS: 256 strips + 2 tail workgroups used to leave two
@@ -2145,7 +2147,14 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
     rk.stage_rows = (dyn && k && k->n_hi) ? (int)PIPE_B_STAGE_ROWS : 0;
     ar.ap.lds_bytes = (int)(PIPE_B_STAGE_ROWS * 256u);
     if (k && n_app) { rk.pend_desc = ar.ap.descriptors; rk.pend_list = ar.ap.list_out; rk.pend_first_id = ar.ap.first_id; }   // k's pending rows ARE the rows being written
-    if (k && n_app > 0 && k->n_hi && k->plan.q > 0 && rk.stage_rows >= 4) n_app = 0;   // the re-rank workgroups write the rows (`ar` stays filled in: they get it);
+    // Who writes the rows of the deferred append: the re-rank workgroups (they hold the rows in their staging area) -- no third branch in the
+    // kernel, whose presence makes the scoring branch spill: launch B 15.4 -> 13.8 us once frames create few words.  While frames create
+    // ~150 words each (the driver's 20 steps) the two ways are within box-to-box noise of each other (0.0387 against 0.0380 ms per frame
+    // on one box, 0.0418 against 0.0427 on another), and choosing per launch by the expected number of new rows lost to both (the second
+    // kernel variant is loaded in the middle of the stream): profiles/r05_ab_notes.txt 6.  "append_from_rerank" = 0 keeps round 4's eight
+    // row-writer workgroups for A/B runs.
+    const bool writers = g_append_from_rerank == 0;
+    if (!writers && k && n_app > 0 && k->n_hi && k->plan.q > 0 && rk.stage_rows >= 4) n_app = 0;   // the re-rank workgroups write the rows (`ar` stays filled in: they get it);
                                                                                       // without re-rank workgroups or a staging area the writers stay
     const bool split = n_app > 0 && score && score->n_closed >= g_append_split_buckets;   // (see frame_b_kernel)
     if (split || n_app == 0) {

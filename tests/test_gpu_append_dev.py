@@ -94,7 +94,7 @@ def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="su
 def test_appended_rows_written_by_a_launch_of_their_own(oracle):
     # memories of 1024 sealed buckets and more leave the row writers of a deferred append to a kernel behind launch B (the scoring branch of
     # the fused launch keeps its registers that way); the option runs that path at this test's size
-    assert _stream(oracle, True, n_words=3000, q=96, n_frames=30, seed=13, options={"append_split_buckets": 0}) > 200
+    assert _stream(oracle, True, n_words=3000, q=96, n_frames=30, seed=13, options={"append_split_buckets": 0, "append_from_rerank": 0}) > 200
 
 
 @pytest.mark.parametrize("pipeline", [False, True])
@@ -111,6 +111,14 @@ def test_words_of_a_frame_in_flight_survive_the_enqueued_clean(oracle, pipeline)
 @pytest.mark.parametrize("pipeline", [False, True])
 def test_append_new_words_on_the_device(oracle, pipeline):
     assert _stream(oracle, pipeline, n_words=3000, q=96, n_frames=30, seed=11) > 200
+
+
+@pytest.mark.parametrize("who", [0, 1])
+def test_rows_of_the_deferred_append_written_by_either_kind_of_workgroup(oracle, who):
+    """the rows a frame appended are written by the re-rank workgroups of launch B from their staging area (the default) or by round 4's
+    eight row-writer workgroups (lcd_set_option "append_from_rerank" = 0, kept for A/B runs and for frames without re-rank workgroups):
+    same results"""
+    assert _stream(oracle, True, n_words=3000, q=96, n_frames=30, seed=19, options={"append_from_rerank": who}) > 200
 
 
 @pytest.mark.parametrize("pipeline,n_words,q", [(False, 3000, 96), (True, 3000, 96), (True, 72000, 700)])

@@ -1,9 +1,10 @@
 #!/bin/bash
 # One GPU-box pass that produces everything kept under profiles/ for a round:
-#   tools/profile_round.sh r03 [part]       (run from the repo root on the MI355X box; writes gpurun_out/<tag>/)
+#   tools/profile_round.sh r05 [part]       (run from the repo root on the MI355X box; writes gpurun_out/<tag>/)
 # part 1: the default bench line exactly as the driver runs it, kernel trace + stats, the two HBM counter passes (FETCH_SIZE, WRITE_SIZE;
 #         separate runs, kernel trace only), one SQ counter pass
-# part 2: the secondary configurations (1M signatures, 125k words = config 4's per-GPU share, ORB stream = config 3, replay = config 5 stand-in)
+# part 2: 1M signatures, 125k words = config 4's per-GPU share (with parity + CPU legs), ORB stream = config 3;  part 3: the config 5 stand-ins (replay, replay_growing);
+# part 4: 10^6 words on one GPU (config 4's whole vocabulary) with parity + CPU legs
 set -u
 TAG=${1:-r03}
 PART=${2:-all}
@@ -58,9 +59,10 @@ fi
 
 if [ "$PART" = all ] || [ "$PART" = 2 ]; then
 cd $ROOT
-timeout 600 python bench.py --signatures 1000000 --steps 100 --warmup 10 --no-cpu-baseline --no-extras > $O/${TAG}_bench_1m.json 2> $O/bench_1m.err
-# config 4's per-GPU share: 125 000 words, persistent filter workgroups; HBM traffic of THIS configuration measured by the run itself
-timeout 900 python bench.py --words 125000 --steps 200 --warmup 20 --no-cpu-baseline --no-extras --pmc > $O/${TAG}_bench_125k_words.json 2> $O/bench_125k_words.err
+# 10^6 signatures: launch B becomes the dominant kernel; HBM traffic of THIS memory measured by the run itself
+timeout 900 python bench.py --signatures 1000000 --steps 100 --warmup 10 --no-cpu-baseline --no-extras --pmc > $O/${TAG}_bench_1m.json 2> $O/bench_1m.err
+# config 4's per-GPU share: 125 000 words, persistent filter workgroups -- WITH the parity block and the CPU legs; traffic measured by the run
+timeout 1200 python bench.py --words 125000 --steps 200 --warmup 20 --no-extras > $O/${TAG}_bench_125k_words.json 2> $O/bench_125k_words.err
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt125 -o kt -- python $ROOT/bench.py --words 125000 --steps 100 --warmup 10 --no-cpu-baseline --no-extras > /dev/null 2> $O/kt125.err
 kstats $O/kt125 $O/${TAG}_kernel_trace_125k_words.txt
@@ -73,7 +75,18 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktorb -o 
 kstats $O/ktorb $O/${TAG}_kernel_trace_orb.txt
 rm -rf $O/ktorb
 cd $ROOT
-# config 5 stand-in: replay with revisits, memory grown to 1M signatures through the frame path
+fi
+
+if [ "$PART" = all ] || [ "$PART" = 3 ]; then
+cd $ROOT
+# config 5 stand-ins: the replay with revisits (fixed world, memory grown to 10^6 signatures) and the one whose dictionary grows from empty
 timeout 1500 python bench.py --config replay --signatures 1000000 > $O/${TAG}_bench_replay_1m.json 2> $O/bench_replay.err
+timeout 2400 python bench.py --config replay_growing --signatures 1000000 > $O/${TAG}_bench_replay_growing_1m.json 2> $O/bench_replay_growing.err
+fi
+
+if [ "$PART" = all ] || [ "$PART" = 4 ]; then
+cd $ROOT
+# config 4's whole vocabulary on ONE GPU: 10^6 words, with the parity block and the CPU legs (the oracle's exact scan is ~15 s per frame: few steps)
+timeout 2400 python bench.py --words 1000000 --steps 8 --warmup 2 --no-extras > $O/${TAG}_bench_1m_words.json 2> $O/bench_1m_words.err
 fi
 ls -la $O

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Kernel timeline of a rocprofv3 --kernel-trace CSV: python tools/timeline_dump.py <csv> [first] [count]
+"""Kernel timeline of a rocprofv3 --kernel-trace CSV: python tools/timeline_dump.py <csv> [first | kernel name] [count]
 start offset, duration, gap to the previous kernel (us), grid size, name -- every kernel, in start order."""
 import csv
 import sys
@@ -11,6 +11,10 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Workgroup_Size_X", "?")))
     rows.sort()
+    if len(sys.argv) > 2 and not sys.argv[2].lstrip("-").isdigit():      # a kernel name: start at its first launch (e.g. frame_a_kernel)
+        name = sys.argv[2]
+        hits = [i for i, r in enumerate(rows) if name in r[2]]
+        sys.argv[2] = str(hits[0] if hits else 0)
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     count = int(sys.argv[3]) if len(sys.argv) > 3 else 200
     if first < 0:
