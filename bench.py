@@ -39,7 +39,7 @@ NNDR = 0.8
 PEAK_F32_TFLOPS = 157.3
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBPS = 8000.0
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
 
 
 DIAG = set()
