@@ -239,6 +239,27 @@ __device__ __forceinline__ void push_group(const f32x16& acc, uint32_t tl, int32
     for (int r = 0; r < 16; ++r) top3_push32(k0, k1, k2, strip_key(acc[r], mask, base | (uint32_t)r));
 }
 
+// The bf16 / fp16 filters select GROUPS: the four accumulator registers 4g .. 4g + 3 of a lane are four CONSECUTIVE vocabulary rows
+// (t * 32 + 8 g + 4 half + {0, 1, 2, 3}); the lane keeps the three groups with the smallest minimum -- one key per group (the minimum's bits,
+// the index of the group's FIRST register), 6 VALU per four scores (v_min3_f32, v_min_f32, v_and_or_b32, v_med3_i32 x 2, v_min_i32)
+// instead of 16.  Complete for the re-rank, which evaluates all four rows of a kept group exactly: every row of the true top-3 lies in a
+// group whose minimum is <= that row's score, and a group WITHOUT such a row has a minimum >= the third-best row's score -- so the
+// three groups with the smallest minima contain the three best rows, and the bound on what was dropped (the third kept key) holds as
+// before.  (The filter loop was issue-bound 2:1 on exactly this selection: 354 instructions per 32-row tile against 768 matrix-pipe
+// cycles with one fp16 product per fp32 product)
+__device__ __forceinline__ float min4(float a, float b, float c, float d) { return fminf(fminf(fminf(a, b), c), d); }
+__device__ __forceinline__ void push_group4(const f32x16& acc, uint32_t tl, int32_t& k0, int32_t& k1, int32_t& k2) {
+#if LCD_MFMA_ABLATE == 1
+    asm volatile("" :: "v"(acc[0]), "v"(acc[5]), "v"(acc[10]), "v"(acc[15]));
+    k0 = min(k0, __float_as_int(acc[3])); (void)tl; (void)k1; (void)k2;
+    return;
+#endif
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tl << 4));
+    const uint32_t mask = strip_mask();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) top3_push32(k0, k1, k2, strip_key(min4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]), mask, base | (uint32_t)(4 * g)));
+}
+
 // One software-pipeline step in explicit program order: the 66 MFMAs of a group pair (two interleaved accumulator chains)
 // with the top-3 update of the PREVIOUS pair's 32 scores spread between them -- 4 MFMAs, then the update of one score of
 // each pending accumulator (~14 VALU), sixteen times.  A wave issues in order and the compiler otherwise emits the MFMAs
@@ -472,8 +493,7 @@ __device__ __forceinline__ void bf_pair(const uint4 (&ah)[4], const uint4 (&al)[
         if (PUSH && LCD_MFMA_ABLATE == 1) asm volatile("" :: "v"(p0[st]), "v"(p1[st]));   // keep the ablated chains alive
         if (PUSH && LCD_MFMA_ABLATE != 1) {                         // one MFMA, then the VALU that fits in its 32-cycle shadow
             __builtin_amdgcn_sched_barrier(0);
-            top3_push32(k00, k01, k02, strip_key(p0[st], mask, base | (uint32_t)st));
-            if (st < 4) top3_push32(k00, k01, k02, strip_key(p0[12 + st], mask, base | (uint32_t)(12 + st)));
+            if (st < 4) top3_push32(k00, k01, k02, strip_key(min4(p0[4 * st], p0[4 * st + 1], p0[4 * st + 2], p0[4 * st + 3]), mask, base | (uint32_t)(4 * st)));   // group st of the previous pair
             __builtin_amdgcn_sched_barrier(0);
         }
 #if LCD_MFMA_ABLATE != 3
@@ -481,8 +501,7 @@ __device__ __forceinline__ void bf_pair(const uint4 (&ah)[4], const uint4 (&al)[
 #endif
         if (PUSH && LCD_MFMA_ABLATE != 1) {
             __builtin_amdgcn_sched_barrier(0);
-            top3_push32(k10, k11, k12, strip_key(p1[st], mask, base | (uint32_t)st));
-            if (st < 4) top3_push32(k10, k11, k12, strip_key(p1[12 + st], mask, base | (uint32_t)(12 + st)));
+            if (st < 4) top3_push32(k10, k11, k12, strip_key(min4(p1[4 * st], p1[4 * st + 1], p1[4 * st + 2], p1[4 * st + 3]), mask, base | (uint32_t)(4 * st)));
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -749,11 +768,11 @@ __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, cons
     if (tile0 < tile1) {
         const uint32_t tlast = (uint32_t)(tile1 - 1 - tile0);
         if (NG == 2 && (tlast & 1u)) {
-            push_group(r0, tlast, k0[0], k1[0], k2[0]);
-            push_group(r1, tlast, k0[1], k1[1], k2[1]);
+            push_group4(r0, tlast, k0[0], k1[0], k2[0]);
+            push_group4(r1, tlast, k0[1], k1[1], k2[1]);
         } else {
-            push_group(p0, tlast, k0[NG - 2], k1[NG - 2], k2[NG - 2]);
-            push_group(p1, tlast, k0[NG - 1], k1[NG - 1], k2[NG - 1]);
+            push_group4(p0, tlast, k0[NG - 2], k1[NG - 2], k2[NG - 2]);
+            push_group4(p1, tlast, k0[NG - 1], k1[NG - 1], k2[NG - 1]);
         }
     }
     MF_STAMP(2);
@@ -938,8 +957,8 @@ __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, co
     }
     if (tile0 < tile1) {
         const uint32_t tlast = (uint32_t)(tile1 - 1 - tile0);
-        push_group(p0, tlast, k0[NG - 2], k1[NG - 2], k2[NG - 2]);
-        push_group(p1, tlast, k0[NG - 1], k1[NG - 1], k2[NG - 1]);
+        push_group4(p0, tlast, k0[NG - 2], k1[NG - 2], k2[NG - 2]);
+        push_group4(p1, tlast, k0[NG - 1], k1[NG - 1], k2[NG - 1]);
     }
     MF_STAMP(2);
 #pragma unroll
@@ -1127,8 +1146,8 @@ __device__ __forceinline__ void knn_bf16_filter_body_p(float* s_dyn, int bid, co
         }
         if (tile0 < tile1) {
             const uint32_t tlast = (uint32_t)(tile1 - 1 - tile0);
-            push_group(p0, tlast, k0[NG - 2], k1[NG - 2], k2[NG - 2]);
-            push_group(p1, tlast, k0[NG - 1], k1[NG - 1], k2[NG - 1]);
+            push_group4(p0, tlast, k0[NG - 2], k1[NG - 2], k2[NG - 2]);
+            push_group4(p1, tlast, k0[NG - 1], k1[NG - 1], k2[NG - 1]);
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -1334,6 +1353,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     __shared__ float s_thr_all[HALVES];
     float& s_thr = s_thr_all[hf];
     const int n_keys = n_blocks * KEEP;
+    constexpr int GS = BF16 ? 4 : 1;                                   // rows a key stands for (see the exact phase)
+    constexpr int RR_KEYS = RR_MAX_CAND / GS;                          // keys under the threshold a query may have before it goes to the exact redo
     // key c of the query: block c / KEEP, entry c % KEEP.  The bf16 filter's records are block-major ([block][query][KEEP], see
     // knn_bf16_filter_body), the f32 filter's query-major
     const int qpad_t = (nq + 63) / 64 * 64;
@@ -1420,7 +1441,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         const uint32_t sc = (uint32_t)(k >> 32);
         if (k != KEY_NONE && sc < INF && __uint_as_float(sc) <= thr) {
             const int slot = atomicAdd(&s_ncand, 1);
-            if (slot < RR_MAX_CAND) s_cand[slot] = k;
+            if (slot < RR_KEYS) s_cand[slot] = k;
         }
     };
     take(kreg0);
@@ -1429,17 +1450,27 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     for (int c = tid + 3 * MF_BLOCK; c < n_keys; c += MF_BLOCK) take(key_at(c));
     lds_barrier();
     RR_STAMP(2);
-    const int n_cand = s_ncand;
-    const bool overflow = n_cand > RR_MAX_CAND;
+    const int n_keys_in = s_ncand;
+    const bool overflow = n_keys_in > RR_KEYS;
+    // A key of the bf16 / fp16 filters stands for a GROUP of four consecutive rows (push_group4: the key's score is the group's minimum, its
+    // row the group's first): candidate slot i is row (i & 3) of key i >> 2 -- the four rows of a key are the four 16-lane groups of ONE
+    // wave and trip.  A row of the group that is a tombstone, does not exist (yet), or lies at / behind the rows the pending scan covers is
+    // no candidate: its exact distance reads +inf.  row_limit: the rows the keys may name (the filter's own row limit when rows are
+    // appended on the device -- what lies behind is scanned exactly below --, else the plan's row count).
+    const int n_cand = overflow ? n_keys_in : n_keys_in * GS;           // candidate ROWS
+    const uint32_t row_limit = (uint32_t)(pend_lo ? p_lo : pend_cap);
+    auto cand_row = [&](int i) -> uint32_t { return (uint32_t)s_cand[GS == 4 ? (i >> 2) : i] + (GS == 4 ? (uint32_t)(i & 3) : 0u); };
     // ... get their exact distances (reference arithmetic, dist.h:150-177), one candidate per 16-lane group and trip; the word
     // id of the row is fetched in the same round trip
     float err_ratio = 0.0f;
     if (!overflow) {
         for (int i = tid >> 4; i < n_cand; i += MF_BLOCK / 16) {
-            const uint64_t k = s_cand[i];
-            const uint32_t row = (uint32_t)k;
-            const float4 v4 = reinterpret_cast<const float4*>(vocab + (size_t)row * DIM)[lane & 15];
-            const int32_t wid = (lane & 15) == 0 ? row_id[row] : 0;
+            const uint64_t k = s_cand[GS == 4 ? (i >> 2) : i];
+            const uint32_t row = cand_row(i);
+            const bool in_range = GS == 1 || row < row_limit;
+            const uint32_t rrow = in_range ? row : (uint32_t)k;            // (an address that exists: the group's first row)
+            const float4 v4 = reinterpret_cast<const float4*>(vocab + (size_t)rrow * DIM)[lane & 15];
+            const int32_t wid = (lane & 15) == 0 ? row_id[rrow] : 0;
             const float d0 = __fsub_rn(v4.x, q4.x), d1 = __fsub_rn(v4.y, q4.y), d2 = __fsub_rn(v4.z, q4.z), d3 = __fsub_rn(v4.w, q4.w);
             float t = __fmul_rn(d0, d0);
             t = __fadd_rn(t, __fmul_rn(d1, d1));
@@ -1448,10 +1479,14 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
             float res = 0.0f;
 #pragma unroll
             for (int j = 0; j < 16; ++j) res = __fadd_rn(res, __shfl(t, (lane & 48) + j, 64));
+            const bool live = in_range && (GS == 1 || __shfl(wid, lane & 48, 64) != 0);
+            if (!live) res = __int_as_float(0x7f800000);
+            float gmin = res;                                            // the filter's score of a key is its group's minimum
+            if (GS == 4) { gmin = fminf(gmin, __shfl_xor(gmin, 16, 64)); gmin = fminf(gmin, __shfl_xor(gmin, 32, 64)); }
             if ((lane & 15) == 0) {
-                s_exact[i] = ((uint64_t)__float_as_uint(res) << 32) | (uint32_t)i;   // the slot stands in for the row: see below
+                s_exact[i] = live ? (((uint64_t)__float_as_uint(res) << 32) | (uint32_t)i) : KEY_NONE;   // the slot stands in for the row: see below
                 s_word[i] = wid;
-                err_ratio = fmaxf(err_ratio, fabsf(__uint_as_float((uint32_t)(k >> 32)) - res) / eps);
+                if (gmin < __int_as_float(0x7f800000)) err_ratio = fmaxf(err_ratio, fabsf(__uint_as_float((uint32_t)(k >> 32)) - gmin) / eps);
             }
         }
     }
@@ -1535,7 +1570,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         if (!overflow)
             for (int i = lane; i < n_cand; i += 64) {
                 const uint64_t e = s_exact[i];
-                top2_push(best, second, (e & 0xFFFFFFFF00000000ull) | (uint32_t)s_cand[(uint32_t)e]);
+                if (e == KEY_NONE) continue;                              // (a row of a key's group that is no candidate)
+                top2_push(best, second, (e & 0xFFFFFFFF00000000ull) | cand_row((int)(uint32_t)e));
             }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -1553,7 +1589,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         // which candidate slots won (for their word ids; a pending row that won has no slot: -1)
         if (!overflow)
             for (int i = lane; i < n_cand; i += 64) {
-                const uint64_t key = (s_exact[i] & 0xFFFFFFFF00000000ull) | (uint32_t)s_cand[i];
+                if (s_exact[i] == KEY_NONE) continue;
+                const uint64_t key = (s_exact[i] & 0xFFFFFFFF00000000ull) | cand_row(i);
                 if (key == best) sbest = i;
                 if (key == second) ssecond = i;
             }
@@ -1646,10 +1683,10 @@ __global__ __launch_bounds__(MF_BLOCK) void knn_mfma_rerank_kernel(const uint64_
                                                                    const uint32_t* __restrict__ norm_max_bits,
                                                                    int32_t* __restrict__ out_row, int32_t* __restrict__ out_word,
                                                                    float* __restrict__ out_dist, int32_t* __restrict__ fail_list,
-                                                                   int32_t* __restrict__ fail_count, CandBits cb, int f16) {
+                                                                   int32_t* __restrict__ fail_count, CandBits cb, int f16, int n_rows) {
     knn_mfma_rerank_body<DIM, KEEP, LAST_KEY_BOUNDS, BF16>((int)blockIdx.x, partial_keys, partial_lmin, n_blocks, nq, vocab, queries, row_id,
                                                           norm_max_bits, out_row, out_word, out_dist, fail_list, fail_count, cb, nullptr, nullptr,
-                                                          0x7fffffff, nullptr, 0, f16);
+                                                          n_rows, nullptr, 0, f16);
 }
 
 // ------------------------------------------------------------------------------------------------ software-pipelined frames
@@ -1885,7 +1922,7 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
     knn_mfma_rerank_kernel<64, MF_KEEP, true, false><<<p.q, MF_BLOCK, 0, s>>>(pk, pl, p.n_blocks, p.q, (const float*)vocab,
                                                                                    (const float*)queries, row_id, norm_max_bits, out_row,
                                                                                    out_word, out_dist, fail_list, fail_count,
-                                                                                   cb ? *cb : CandBits{}, 0);
+                                                                                   cb ? *cb : CandBits{}, 0, p.n_rows);
     return hipGetLastError();
 }
 
@@ -2033,7 +2070,7 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
     }
     knn_mfma_rerank_kernel<64, BF_KEEP, false, true><<<p.q, MF_BLOCK, 0, s_rerank>>>(
         pk, pl, p.n_blocks, p.q, (const float*)vocab, (const float*)queries, row_id, norm_max_bits, out_row, out_word, out_dist, fail_list,
-        fail_count, cb ? *cb : CandBits{}, p.f16);
+        fail_count, cb ? *cb : CandBits{}, p.f16, p.n_rows);
     return hipGetLastError();
 }
 

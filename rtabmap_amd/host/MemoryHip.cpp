@@ -213,7 +213,7 @@ void MemoryHip::forget(int signatureId) {
     if (it == _signatures.end()) return;
     _likeSig = 0;                               // N and the references change: the frame's likelihood is no longer Memory::computeLikelihood's
     std::set<int> keys(it->second.begin(), it->second.end());   // uUniqueKeys (Memory.cpp:6885)
-    for (std::set<int>::iterator k = keys.begin(); k != keys.end(); ++k) _vwd->removeAllWordRef(*k, signatureId);
+    _vwd->removeAllWordRefs(keys, signatureId);
     _dbNi[signatureId] = (int)it->second.size();
     _signatures.erase(it);
     _stMem.erase(signatureId);                  // the links stay (they are in the database): getNeighborsId stops at the missing node

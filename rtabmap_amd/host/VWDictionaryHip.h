@@ -92,6 +92,7 @@ public:
 
     bool addWordRef(int wordId, int signatureId);
     void removeAllWordRef(int wordId, int signatureId);
+    void removeAllWordRefs(const std::set<int>& wordIds, int signatureId);   // the same for every unique word of a signature (Memory::disableWordsRef)
     const VisualWord* getWord(int id) const;
     VisualWord* getUnusedWord(int id) const;
     void setLastWordId(int id) { _lastWordId = id; }
@@ -184,6 +185,15 @@ private:
     std::set<int> _dirtySigs;
     std::set<int> _deviceSigs;
     // mirror of the engine's slot table (lcd.h: slots in registration order, never reused)
+    // id -> word, beside _visualWords (the reference's std::map stays the authority and the iteration order; this is the O(1) way to it
+    // for the per-descriptor bookkeeping of a frame)
+    std::vector<VisualWord*> _byId;
+    void indexWord(VisualWord* vw) { if (vw->id() >= 0) { if ((size_t)vw->id() >= _byId.size()) _byId.resize((size_t)vw->id() + 1 + _byId.size() / 2, nullptr); _byId[(size_t)vw->id()] = vw; } }
+    VisualWord* lookupWord(int id) const {
+        if (id >= 0 && (size_t)id < _byId.size()) return _byId[(size_t)id];
+        std::map<int, VisualWord*>::const_iterator it = _visualWords.find(id);
+        return it == _visualWords.end() ? nullptr : it->second;
+    }
     std::vector<int> _slotSig;
     std::map<int, int> _sigSlot;
     void slotAdd(int signatureId) { _sigSlot[signatureId] = (int)_slotSig.size(); _slotSig.push_back(signatureId); }
