@@ -1419,6 +1419,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     if (tid == 0) s_ncand = 0;
     // the pending rows are requested here -- behind the keys, which have arrived, and in front of pass 2's row reads, whose round trip
     // they share (a request in front of the keys would make the first use of a key wait for the whole chunk: the counter is in-order)
+    // (measured in round 5, profiles/r05_ab_notes.txt 8: requested in FRONT of the keys instead, the driver's 20 steps take 0.0392-0.0401 ms
+    // per frame against 0.0384-0.0390)
     if (pend_list) { s_plist[threadIdx.x] = plreg; lds_barrier(); }
     if (staged) stage_chunk(p_lo, min(stage_rows, p_hi - p_lo));
     if (staged && lane < 16 && wave == 0) reinterpret_cast<float4*>(stage + (size_t)stage_rows * DIM)[hf * 16 + lane] = q4;   // the query, for every lane

@@ -290,3 +290,41 @@ def test_knn2_one_million_words_properties(oracle):
     idx, d_ref = oracle.knn2_linear(v, qs[sample], threads=8)
     np.testing.assert_array_equal(w[sample], ids[idx])
     np.testing.assert_array_equal(d[sample], d_ref)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_knn2_keys_that_stand_for_four_rows(oracle, mode):
+    """The bf16 / fp16 filters keep one key per four consecutive rows and the re-rank evaluates the four rows of a kept key exactly
+    (push_group4).  What that must get right, on a SURF vocabulary whose size is no multiple of four: both neighbours of a query inside ONE
+    group (an exact duplicate and a near copy next to it), a tombstone between them, the nearest row the LAST row of the table (the group's
+    other rows do not exist), a group whose best row is a tombstone (its other rows must not be dropped with it), and an exact tie between
+    rows of one group (the lower row wins)."""
+    n = 20003
+    rng = np.random.default_rng(41)
+    v = synth.vocab_surf(n, seed=42)
+    q = synth.queries_surf(v, 240, seed=43, frac_known=0.5)
+
+    def near(row, sigma):
+        x = v[row] + sigma * rng.standard_normal(64).astype(np.float32)
+        return (x / np.linalg.norm(x)).astype(np.float32)
+    removed = np.zeros(n, np.uint8)
+    for k in range(40):                                   # group base 4 * g: rows g4 .. g4 + 3
+        g4 = 4 * int(rng.integers(10, n // 4 - 10))
+        kind = k % 5
+        if kind == 0:                                     # duplicate + near copy inside one group
+            q[k] = near(g4 + 1, 0.0); v[g4 + 2] = near(g4 + 1, 0.01)
+        elif kind == 1:                                   # ... with a tombstone between them
+            q[k] = near(g4, 0.0); v[g4 + 2] = near(g4, 0.01); removed[g4 + 1] = 1
+        elif kind == 2:                                   # the group's best row is a tombstone: the second best of the group must survive
+            q[k] = near(g4 + 3, 0.0); removed[g4 + 3] = 1; v[g4] = near(g4 + 3, 0.02)
+        elif kind == 3:                                   # an exact tie inside the group
+            v[g4 + 2] = v[g4 + 1]; q[k] = near(g4 + 1, 0.005)
+        else:                                             # the table's last row, alone in its group (n % 4 == 3: rows n-3 .. n-1 exist)
+            q[k] = near(n - 1, 0.003)
+    ids = np.arange(1, n + 1, dtype=np.int32)
+    eng = _engine("f32", 64, knn_mode=mode)
+    eng.vocab_append(v, ids)
+    eng.vocab_remove(ids[removed == 1])
+    _check(eng, oracle, v, ids, q, removed=removed)
+    assert eng.stats()["knn_last_fallback_queries"] < 40, "the planted cases must go through the filter + re-rank, not through the exact redo"
+    eng.close()
