@@ -62,6 +62,7 @@ struct lcd_engine {
         lcd::DevBuf d_knn_row, d_knn_word, d_knn_dist, d_selfdist, d_bits, d_partial2, d_partial3, d_fail_list, d_fail_count, d_out_wslot;
         lcd::DevBuf d_qsplit, d_qnorm;                  // the frame's queries pre-split into bf16 matrix-core operands, their norms
         lcd::DevBuf d_applist;                          // deferred append: which descriptors of the frame became words (AppendArgs::list_out)
+        lcd::DevBuf d_cross;                            // the frame's distances to the descriptors of the frame before it (PipeKnn::cross)
         bool fail_count_clean = false;
     };
     static constexpr int PIPE_SETS = 4;                 // a frame's set is in use for four calls (pre-split .. registration)

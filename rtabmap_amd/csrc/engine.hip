@@ -448,7 +448,7 @@ void lcd_destroy(lcd_engine* h) {
     h->bayes.destroy();
     for (lcd_engine::FrameScratch& sc : h->ring) {
         DevBuf* all[] = {&sc.d_knn_row, &sc.d_knn_word, &sc.d_knn_dist, &sc.d_selfdist, &sc.d_bits, &sc.d_partial2, &sc.d_partial3, &sc.d_fail_list,
-                         &sc.d_fail_count, &sc.d_out_wslot, &sc.d_qsplit, &sc.d_qnorm, &sc.d_applist};
+                         &sc.d_fail_count, &sc.d_out_wslot, &sc.d_qsplit, &sc.d_qnorm, &sc.d_applist, &sc.d_cross};
         for (DevBuf* d : all) d->release(&h->bytes_device);
     }
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -1333,6 +1333,16 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
     lap.lap(3);
     PipeKnn k;
     if (f_knn) { int rc = build_knn(h, *f_knn, &k); if (rc) return rc; h->knn_launches += 1; }
+    if (f_knn && f_res && tl_res.r.ap.enabled && tl_res.r.ap.defer_rows && tl_res.r.ap.is_f32_64 && knn_cross_frames()) {
+        // The rows f_res appends (its decision loop rides in this launch A) are descriptors of f_res, and f_knn's re-rank (this launch B)
+        // must scan them exactly: extra distance tiles of launch A compute f_knn x f_res in the reference's arithmetic, the re-rank reads
+        // its pending rows' distances there instead of staging the rows (the buffer was sized when f_knn was submitted: no reallocation here)
+        const int ncols = f_res->a.q, ldx = (ncols + 63) / 64 * 64;
+        lcd::DevBuf& xb = h->ring[f_knn->set].d_cross;
+        if (ncols > 0 && f_knn->a.q > 0 && xb.cap >= (size_t)f_knn->a.q * ldx * 4) {
+            k.cross = xb.as<float>(); k.cross_ld = ldx; k.cross_cols = tl_res.r.ap.descriptors; k.cross_ncols = ncols;
+        }
+    }
     lap.lap(4);
     const bool prof = f_knn && h->prof_cap > 0 && h->prof_n < h->prof_cap;
     LCD_HIP(h, launch_frame_a(f_knn ? &k : nullptr, qs, f_res ? &tl_res : nullptr, f_reg ? &tl_reg : nullptr, h->stream,
@@ -1442,6 +1452,8 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
         LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_selfdist, (size_t)q * ld * 4));
         LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_bits, cand_bits_bytes(q, bw)));
     }
+    if (chained && !h->inflight.empty() && h->dtype == LCD_F32 && h->kdim == 64 && knn_cross_frames())   // (pipeline_launch: this frame x the frame before it)
+        LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_cross, (size_t)q * ((h->inflight.back().a.q + 63) / 64 * 64) * 4));
     QSplitArgs qs;
     qs.queries = (const float*)a->d_descriptors; qs.nq = q; qs.qpad = ld; qs.qsplit = (uint4*)sc.d_qsplit.p; qs.qnorm = sc.d_qnorm.as<float>(); qs.n_wgs = 0; qs.f16 = h->f16();
     lap0.lap(1);
@@ -1971,6 +1983,7 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     if (!std::strcmp(key, "profile_likelihood") && (value == 0 || value == 1)) { h->prof_likelihood = value != 0; return LCD_OK; }
     // (process-wide, for tests) sealed buckets from which the rows of a deferred append are written by a launch of their own; -1: built-in
     if (!std::strcmp(key, "append_split_buckets") && value >= -1 && value <= (1 << 24)) { knn_set_append_split_buckets((int)value); return LCD_OK; }
+    if (!std::strcmp(key, "cross_frame_tiles") && value >= -1 && value <= 1) { knn_set_cross_frames((int)value); return LCD_OK; }
     if (!std::strcmp(key, "append_from_rerank") && value >= -1 && value <= 1) { knn_set_append_from_rerank(value != 0 ? 1 : 0); return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");
     LCD_CATCH(h)

@@ -544,14 +544,32 @@ struct SelfdistJob {
     int nq = 0;
     float* out = nullptr;              // [nq x ld]
     int ld = 0;
-    int n_tiles = 0;                   // workgroups: T (T + 1) / 2, T = ceil(nq / 64); 0 = no job
+    int n_tiles = 0;                   // workgroups: n_self + the cross-frame tiles; 0 = no job
+    int n_self = 0;                    // T (T + 1) / 2, T = ceil(nq / 64): the tiles of the upper triangle of the same-frame matrix (0: not asked for)
+    // cross-frame tiles (round 5): X[r][c] = |q_r - o_c|^2 against the descriptors of the frame BEFORE this one, ceil(nq / 64) x ceil(n_other / 64)
+    // full tiles.  The rows that frame appends to the vocabulary ARE descriptors of it, and this frame's re-rank (launch B of the same pair) has to
+    // scan them exactly -- they are not in the filter's snapshot.  With this matrix that scan is one gathered read per pending row instead of
+    // 38 KB of rows staged through LDS by each of 250 workgroups (+9.6 MB per launch) and ~150 distances per query.
+    const float* other = nullptr; int n_other = 0;
+    float* xout = nullptr; int xld = 0;
 };
 inline int selfdist_tiles(int q) { const int T = (q + 63) / 64; return T * (T + 1) / 2; }
 __device__ __forceinline__ void selfdist_tile(const SelfdistJob& sd, int k, float* __restrict__ lds) {
     const int T = (sd.nq + 63) / 64;
-    int ti = 0, rem = k;
-    while (rem >= T - ti) { rem -= T - ti; ++ti; }
-    const int tj = ti + rem;
+    const bool xj = k >= sd.n_self;                    // uniform: a cross-frame tile
+    const float* __restrict__ colsrc = xj ? sd.other : sd.queries;
+    const int ncol = xj ? sd.n_other : sd.nq;
+    float* __restrict__ out = xj ? sd.xout : sd.out;
+    const int ld = xj ? sd.xld : sd.ld;
+    int ti = 0, tj;
+    if (xj) {
+        const int Tc = (ncol + 63) / 64;
+        ti = (k - sd.n_self) / Tc; tj = (k - sd.n_self) % Tc;
+    } else {
+        int rem = k;
+        while (rem >= T - ti) { rem -= T - ti; ++ti; }
+        tj = ti + rem;
+    }
     const int tid = threadIdx.x;
     const bool act = tid < 256;                        // the tile is the work of 256 threads; a larger workgroup's other threads idle
     float* sA = lds;                   // rows of tile ti   [64][64] swizzled
@@ -562,9 +580,9 @@ __device__ __forceinline__ void selfdist_tile(const SelfdistJob& sd, int k, floa
         for (int u = 0; u < 4; ++u) {
             const int e = tid + u * 256;                   // float4 index within a tile: row e / 16, chunk e % 16
             const int r = e >> 4, c = e & 15;
-            const int ra = min(ti * 64 + r, sd.nq - 1), rb = min(tj * 64 + r, sd.nq - 1);
+            const int ra = min(ti * 64 + r, sd.nq - 1), rb = min(tj * 64 + r, ncol - 1);
             const float4 a = reinterpret_cast<const float4*>(sd.queries + (size_t)ra * 64)[c];
-            const float4 b = reinterpret_cast<const float4*>(sd.queries + (size_t)rb * 64)[c];
+            const float4 b = reinterpret_cast<const float4*>(colsrc + (size_t)rb * 64)[c];
             *reinterpret_cast<float4*>(sA + r * 64 + ((c ^ (r & 15)) << 2)) = a;
             *reinterpret_cast<float4*>(sB + r * 64 + ((c ^ (r & 15)) << 2)) = b;
         }
@@ -601,11 +619,11 @@ __device__ __forceinline__ void selfdist_tile(const SelfdistJob& sd, int k, floa
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const int r = ti * 64 + ty + 16 * m, c = tj * 64 + tx + 16 * n;
-                if (r < sd.nq && c < sd.nq) sd.out[(size_t)r * sd.ld + c] = res[m][n];
+                if (r < sd.nq && c < ncol) out[(size_t)r * ld + c] = res[m][n];
                 sT[(ty + 16 * m) * 65 + tx + 16 * n] = res[m][n];
             }
     }
-    if (ti == tj) return;                              // uniform
+    if (xj || ti == tj) return;                        // uniform
     __syncthreads();
     if (act) {
 #pragma unroll
@@ -1266,6 +1284,10 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                                                      int32_t pend_first_id = 0
                                                      /* rows at or beyond pend_lo[0] are not vocabulary rows yet (a deferred append writes them in this
                                                         very launch): row pend_lo[0] + j is descriptor pend_list[j] of pend_desc, word pend_first_id + j */
+                                                     , const float* __restrict__ cross = nullptr, int cross_ld = 0
+                                                     /* cross[qi * cross_ld + c] = |query qi - descriptor c of pend_desc|^2, from the cross-frame tiles of
+                                                        launch A of this pair (selfdist_tile): the pending rows' distances are read, not computed; NULL: the
+                                                        rows are staged and their distances computed here */
                                 // The re-rank workgroups WRITE the rows of the deferred append from the copy they have staged anyway (round 5: the
                                 // default since it passed the GPU suite; launch B 15.3 -> 13.8 us at the headline, profiles/r05_first_call.txt);
                                 // workgroup wr_index of wr_n
@@ -1325,16 +1347,25 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                                              (__attribute__((address_space(3))) void*)(stage + (size_t)i * 256), 16, 0, 0);
         }
     };
-    const bool staged = stage != nullptr && stage_rows >= 4 && p_hi > p_lo;
+    // With the cross-frame matrix the pending rows need no staging: row n_lo0 + j is descriptor pend_list[j] of the frame before, and the
+    // query's distance to it is cross[qi][pend_list[j]] -- in the reference's arithmetic, computed by launch A.  Each workgroup stages only the
+    // rows it WRITES (row wr_index + m wr_n at place m), and the distances are gathered into the staging area by 4-byte LDS-DMA (no registers):
+    // half hf's value j at xd[hf * XD_MAX + j].  Not when rows of the vocabulary itself are pending (the plan covered fewer rows than exist).
+    constexpr int XD_MAX = 2048, XD_OWN = 32;                           // pending rows / rows of its own a workgroup can take this way (40 KB of LDS)
+    const int n_own = (wr_on && p_hi - n_lo0 > wr_index) ? (p_hi - n_lo0 - wr_index + wr_n - 1) / wr_n : 0;
+    const bool use_cross = cross != nullptr && pend_list != nullptr && stage != nullptr && stage_rows >= XD_OWN + HALVES * XD_MAX / DIM && p_hi > p_lo && p_lo == n_lo0 &&
+                           p_hi - p_lo <= XD_MAX && n_own <= XD_OWN;
+    float* const xd = stage + XD_OWN * DIM;
+    const bool staged = stage != nullptr && stage_rows >= 4 && p_hi > p_lo && !use_cross;
     // rows [n_lo0, p_hi) ARE the rows of the deferred append, and every re-rank workgroup has them in its staging area: workgroup wr_index
     // of wr_n writes rows wr_index, wr_index + wr_n, ... (16 lanes per row) -- no workgroups of their own, no third branch in the kernel (whose
     // presence makes the scoring branch spill).  Stores only, at the END of the body: a read behind them would wait for them.
-    auto write_rows = [&](int c0, int n_chunk) {
+    auto write_rows = [&](int c0, int n_chunk, bool own = false) {      // own: the staging area holds this workgroup's rows only (use_cross)
         const AppendArgs& ap = wr.ap;
         const int n_new = p_hi - n_lo0, c16 = (int)threadIdx.x & 15;
         float nmax = 0.0f;
-        for (int j = wr_index + wr_n * ((int)threadIdx.x >> 4); j < n_new; j += wr_n * (HALVES * MF_BLOCK / 16)) {
-            const int rl = n_lo0 + j - c0;                             // the row's place in the staged chunk (uniform over its 16 lanes)
+        for (int j = wr_index + wr_n * ((int)threadIdx.x >> 4), m = (int)threadIdx.x >> 4; j < n_new; j += wr_n * (HALVES * MF_BLOCK / 16), m += HALVES * MF_BLOCK / 16) {
+            const int rl = own ? m : n_lo0 + j - c0;                   // the row's place in the staged chunk (uniform over its 16 lanes)
             if (rl < 0 || rl >= n_chunk) continue;
             const int32_t key = (c16 == 0 && wr.new_ws.n > 0) ? ws_runs_at(wr.new_ws, j) : -1;      // (looked up in front of the row's stores)
             const uint4 x = *reinterpret_cast<const uint4*>(stage + (size_t)rl * DIM + ((c16 ^ (rl & 15)) * 4));
@@ -1423,6 +1454,24 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     // per frame against 0.0384-0.0390)
     if (pend_list) { s_plist[threadIdx.x] = plreg; lds_barrier(); }
     if (staged) stage_chunk(p_lo, min(stage_rows, p_hi - p_lo));
+    if (use_cross) {
+        const int wv = (int)threadIdx.x >> 6, ln = (int)threadIdx.x & 63;
+        auto plist_at = [&](int j) -> uint32_t { return j < HALVES * MF_BLOCK ? s_plist[j] : pend_list[j]; };
+        for (int i = wv; i * 4 < n_own; i += HALVES * MF_WAVES) {      // the rows this workgroup writes: four per instruction, as stage_chunk lays them out
+            const int rl = min(i * 4 + (ln >> 4), n_own - 1);
+            const int chunk = (ln & 15) ^ ((i * 4 + (ln >> 4)) & 15);
+            const float* src = pend_desc + (size_t)plist_at(wr_index + wr_n * rl) * DIM;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + chunk * 4),
+                                             (__attribute__((address_space(3))) void*)(stage + (size_t)i * 256), 16, 0, 0);
+        }
+        const int n_pend = p_hi - p_lo;
+        const float* crow = cross + (size_t)qi * cross_ld;
+        for (int j0 = 0; j0 < n_pend; j0 += MF_BLOCK) {                // 64 values per instruction, lane l's at the instruction's base + 4 l
+            const float* src = crow + plist_at(min(j0 + tid, n_pend - 1));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xd + hf * XD_MAX + j0 + wave * 64), 4, 0, 0);
+        }
+    }
     if (staged && lane < 16 && wave == 0) reinterpret_cast<float4*>(stage + (size_t)stage_rows * DIM)[hf * 16 + lane] = q4;   // the query, for every lane
     lds_barrier();                                                     // (LDS traffic only: __syncthreads() would also wait for the rows just requested)
     RR_STAMP(1);
@@ -1500,7 +1549,12 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         uint64_t pb = KEY_NONE, ps = KEY_NONE;
         constexpr int PU = 4;                                          // rows per 16-lane group and trip: their loads are in flight together (more
                                                                        // would cost the whole launch -- the scoring workgroups too -- occupancy)
-        if (staged) {
+        if (use_cross) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (each lane reads what its own request brought: no barrier)
+            RR_STAMP(4);
+            for (int j = tid; j < p_hi - p_lo; j += MF_BLOCK)
+                top2_push(pb, ps, ((uint64_t)__float_as_uint(xd[hf * XD_MAX + j]) << 32) | (uint32_t)(p_lo + j));
+        } else if (staged) {
             for (int c0 = p_lo; c0 < p_hi; c0 += stage_rows) {
                 const int n_chunk = min(stage_rows, p_hi - c0);
                 if (c0 > p_lo) { __syncthreads(); stage_chunk(c0, n_chunk); }
@@ -1671,6 +1725,10 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
             if (tid == 0 && valid) cb.cnt[qi] = s_below;
         }
     }
+    if (n_own > 0 && use_cross) {                                      // (every wave has waited for its requests; the rows came with wave 0's, ...)
+        __syncthreads();
+        write_rows(0, n_own, true);
+    }
     if (wr_on && staged) {                                             // the last (usually the only) chunk is still in the staging area
         const int c0_last = p_lo + ((p_hi - p_lo - 1) / stage_rows) * stage_rows;
         write_rows(c0_last, min(stage_rows, p_hi - c0_last));
@@ -1713,6 +1771,7 @@ struct RerankArgs {
     int stage_rows;                                                    // rows the launch's dynamic LDS stages (0: none)
     int f16;                                                           // the filter multiplied fp16 operands (one product): eps_f16
     const float* pend_desc; const uint32_t* pend_list; int32_t pend_first_id;   // the rows a deferred append writes in this launch, as descriptors
+    const float* cross; int cross_ld;                                  // this frame's distances to every descriptor of pend_desc (CrossJob of the previous pair), or NULL
 };
 constexpr int PIPE_BLOCK = 256;     // workgroup size of both fused launches (the filter's and the re-rank's)
 
@@ -1791,7 +1850,7 @@ __global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, 
         extern __shared__ __attribute__((aligned(16))) float s_dyn_b[];
         knn_mfma_rerank_body<64, BF_KEEP, false, true, 2>(2 * pair, k.pk, k.pl, k.n_blocks, k.nq, k.vocab, k.queries, k.row_id, k.norm_max_bits, k.out_row,
                                                           k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb, k.n_lo, k.n_hi, k.plan_rows,
-                                                          s_dyn_b, k.stage_rows, k.f16, k.pend_desc, k.pend_list, k.pend_first_id
+                                                          s_dyn_b, k.stage_rows, k.f16, k.pend_desc, k.pend_list, k.pend_first_id, k.cross, k.cross_ld
                                                           , app, !WITH_APPEND && app.ap.enabled && app.ap.defer_rows, pair, (k.nq + 1) / 2
                                                           );
         B_STAMP(1);
@@ -2038,7 +2097,7 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
         (void)attr0; (void)attr1;
         SelfdistJob sd;
         if (with_selfdist && cb) {                                    // the same-frame distance matrix rides along
-            sd.queries = (const float*)queries; sd.nq = p.q; sd.out = const_cast<float*>(cb->selfdist); sd.ld = cb->ld; sd.n_tiles = selfdist_tiles(p.q);
+            sd.queries = (const float*)queries; sd.nq = p.q; sd.out = const_cast<float*>(cb->selfdist); sd.ld = cb->ld; sd.n_tiles = sd.n_self = selfdist_tiles(p.q);
         }
         const int grid = sd.n_tiles + p.n_blocks * ((p.q + BF_QB - 1) / BF_QB);
         const int px = bf16_persistent_px(p);
@@ -2097,6 +2156,16 @@ int pipe_b_block_size() { return PIPE_B_BLOCK; }
 
 size_t knn_qsplit_bytes(int q) { return (size_t)((q + 63) / 64 * 64) * 256; }
 
+// lcd_set_option "cross_frame_tiles" = 1: launch A also computes the frame's distances to the frame before it, and the re-rank reads its
+// pending rows' distances there instead of staging the rows.  Built, bit-identical (tests/test_gpu_append_dev.py), and NOT the default:
+// measured on one box with the kernel trace of the driver's command (profiles/r05_ab_notes.txt 9), launch B 19.7 -> 17.5 us while every
+// frame creates ~150 words, but the 64 extra tiles share compute units with the filter strips -- launch A 14.2 -> 15.3 us there and
+// 13.3 -> 15.0 us once frames mostly revisit (where launch B gains nothing): 0.0417 -> 0.0412 ms per frame over the driver's 20 steps,
+// 0.0409 -> 0.0412 over 200, and the filter launch is the one the roofline is quoted on.
+static int g_cross_frames = 0;
+void knn_set_cross_frames(int on) { g_cross_frames = on > 0 ? 1 : 0; }
+bool knn_cross_frames() { return g_cross_frames != 0; }
+
 hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLaunch* resolve, const TailLaunch* reg, hipStream_t s, hipEvent_t ev_begin,
                           hipEvent_t ev_end) {
     static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2116,7 +2185,12 @@ hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLa
         f.tiles_per_block = p.tiles_per_block; f.n_blocks = p.n_blocks; f.pk = pk; f.pl = pl; f.n_lo = k.n_lo;
         f.qsplit = (const uint4*)k.qsplit; f.qnorm = k.qnorm;
         if (k.cb.selfdist) {                                          // the same-frame distance matrix rides along
-            f.sd.queries = (const float*)k.queries; f.sd.nq = p.q; f.sd.out = const_cast<float*>(k.cb.selfdist); f.sd.ld = k.cb.ld; f.sd.n_tiles = selfdist_tiles(p.q);
+            f.sd.queries = (const float*)k.queries; f.sd.nq = p.q; f.sd.out = const_cast<float*>(k.cb.selfdist); f.sd.ld = k.cb.ld; f.sd.n_tiles = f.sd.n_self = selfdist_tiles(p.q);
+        }
+        if (g_cross_frames && k.cross && k.cross_cols && k.cross_ncols > 0 && p.q > 0) {   // ... and so do this frame's distances to the frame before it
+            f.sd.queries = (const float*)k.queries; f.sd.nq = p.q;
+            f.sd.other = (const float*)k.cross_cols; f.sd.n_other = k.cross_ncols; f.sd.xout = k.cross; f.sd.xld = k.cross_ld;
+            f.sd.n_tiles += ((p.q + 63) / 64) * ((k.cross_ncols + 63) / 64);
         }
     }
     const int px = p.q > 0 ? bf16_persistent_px(p) : 0;
@@ -2161,6 +2235,7 @@ hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLa
     return hipGetLastError();
 }
 
+
 hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wgs, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
                           const AppendRowsArgs* app) {
     RerankArgs rk{};
@@ -2186,6 +2261,8 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
     rk.stage_rows = (dyn && k && k->n_hi) ? (int)PIPE_B_STAGE_ROWS : 0;
     ar.ap.lds_bytes = (int)(PIPE_B_STAGE_ROWS * 256u);
     if (k && n_app) { rk.pend_desc = ar.ap.descriptors; rk.pend_list = ar.ap.list_out; rk.pend_first_id = ar.ap.first_id; }   // k's pending rows ARE the rows being written
+    // ... and their distances to k's queries were computed by launch A of this pair (selfdist_tile's cross-frame tiles), if it knew both frames
+    if (k && n_app && g_cross_frames && k->cross && k->cross_cols == (const void*)ar.ap.descriptors) { rk.cross = k->cross; rk.cross_ld = k->cross_ld; }
     // Who writes the rows of the deferred append: the re-rank workgroups (they hold the rows in their staging area) -- no third branch in the
     // kernel, whose presence makes the scoring branch spill: launch B 15.4 -> 13.8 us once frames create few words.  While frames create
     // ~150 words each (the driver's 20 steps) the two ways are within box-to-box noise of each other (0.0387 against 0.0380 ms per frame

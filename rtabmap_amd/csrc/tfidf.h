@@ -188,6 +188,9 @@ struct PipeKnn {
     const float* qnorm = nullptr;    // norms: what the one-strip filter of a pipelined launch reads instead of the descriptors
     const int32_t* n_lo = nullptr;   // device row counts (NULL: the host's plan.n_rows is exact): the filter sees rows [0, n_lo[0]), the re-rank
     const int32_t* n_hi = nullptr;   // also scans [n_lo[0], n_hi[0]) exactly -- the words the previous frame appended meanwhile (AppendArgs)
+    float* cross = nullptr;          // [q x cross_ld] distances of this frame's queries to the cross_ncols descriptors at cross_cols (the frame
+    int cross_ld = 0;                // before it): written by extra tiles of launch A, read by the re-rank of launch B for its pending rows (which are
+    const void* cross_cols = nullptr; int cross_ncols = 0;   // descriptors of that frame); NULL: the re-rank stages the pending rows and computes them
 };
 // the new frame's queries -> MFMA operand order in global memory (knn_mfma_kernels.hip, qsplit_body): a few workgroups of launch A
 struct QSplitArgs { const float* queries; int nq, qpad; uint4* qsplit; float* qnorm; int n_wgs; int f16 = 0; /* operands as IEEE half */ };

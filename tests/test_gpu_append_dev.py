@@ -121,6 +121,14 @@ def test_rows_of_the_deferred_append_written_by_either_kind_of_workgroup(oracle,
     assert _stream(oracle, True, n_words=3000, q=96, n_frames=30, seed=19, options={"append_from_rerank": who}) > 200
 
 
+@pytest.mark.parametrize("n_words,q,n_frames,knn_mode", [(3000, 96, 30, None), (3000, 200, 12, "f16"), (72000, 700, 8, "f16")])
+def test_pending_rows_read_from_the_cross_frame_tiles(oracle, n_words, q, n_frames, knn_mode):
+    """lcd_set_option "cross_frame_tiles" = 1: the words the previous frame created are descriptors of that frame, so extra distance tiles of
+    launch A compute this frame x the frame before it in the reference's arithmetic and the re-rank gathers its pending rows' distances from
+    that matrix (each workgroup stages only the rows it writes) -- word ids, likelihood and vocabulary as with the staged rows"""
+    assert _stream(oracle, True, n_words=n_words, q=q, n_frames=n_frames, seed=29, knn_mode=knn_mode, options={"cross_frame_tiles": 1}) > 100
+
+
 @pytest.mark.parametrize("pipeline,n_words,q", [(False, 3000, 96), (True, 3000, 96), (True, 72000, 700)])
 def test_append_new_words_with_the_fp16_filter(oracle, pipeline, n_words, q):
     """LCD_KNN_F16: the one-product fp16 matrix-core filter (operand tables in IEEE half, rows appended on the device split the same
