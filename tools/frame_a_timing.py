@@ -22,7 +22,8 @@ def main():
     eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 65536, sig_capacity=n_sig + 4096, pipeline=True)
     for kv in filter(None, os.environ.get("LCD_BENCH_OPTS", "").split(",")):
         eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-    strip = int(os.environ.get("LCD_BENCH_OPTS", "strip_tiles=0").split("strip_tiles=")[-1].split(",")[0] or 0)
+    opts = dict(kv.split("=") for kv in filter(None, os.environ.get("LCD_BENCH_OPTS", "").split(",")))
+    strip = int(opts.get("strip_tiles", 0))
     eng.vocab_append(vocab, np.arange(1, n_words + 1, dtype=np.int32))
     eng.sig_add_bulk(np.arange(1, n_sig + 1, dtype=np.int32), np.arange(0, (n_sig + 1) * q, q, dtype=np.int64), words.reshape(-1))
     d_words = torch.zeros(q, dtype=torch.int32, device="cuda")
