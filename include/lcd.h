@@ -367,6 +367,9 @@ int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, co
  * 2-NN launch of a pipelined frame (every timed launch costs stream time).  "strip_tiles": 32-word tiles per filter workgroup of a
  * pipelined frame (1 .. 8; 0 = the built-in plan).  "append_split_buckets" (process-wide): sealed buckets of 256 signatures from which
  * the rows a frame appends are written by a kernel of their own behind launch B instead of by workgroups inside it (-1 = built-in, 1 024).
+ * "append_from_rerank" (process-wide): 1 (built-in) = those rows are written by the re-rank workgroups of launch B, 0 = by eight row-writer
+ * workgroups.  "cross_frame_tiles" (process-wide): 1 = launch A also computes a frame's distances to the frame before it and the re-rank reads
+ * the distances of the rows that frame appended from there instead of staging the rows (0 / -1 = built-in: staged).
  * Unknown keys / values -> LCD_ERR_INVALID.
  * The two keys that DO change what a call means (sharded handles only, identical on every rank): "shard_growth_first" = F and
  * "shard_growth_block" = B > 0 make lcd_shard_frame_dev give the words frames create (ids >= F) to rank ((id - F) / B) % world instead of
