@@ -1964,6 +1964,10 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
     if (reset_count) {   // [0] rejected queries, [1] arrival counter of the row-parallel redo (the fused frame tail leaves them zeroed)
         e = hipMemsetAsync(fail_count, 0, 8, s);
         if (e != hipSuccess) return e;
+        // ... and the "redo done" flag: a stand-alone redo (knn_rowpar_kernel) leaves it raised, and the decision workgroup of a fused frame
+        // tail that found it raised would not wait for ITS redo ([2], the running maximum of the error ratio, stays)
+        e = hipMemsetAsync(fail_count + 3, 0, 4, s);
+        if (e != hipSuccess) return e;
     }
     if (p.n_blocks > 0) {
         const int ng = mfma_ng();
@@ -2086,6 +2090,10 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
     hipError_t e = hipSuccess;
     if (reset_count) {
         e = hipMemsetAsync(fail_count, 0, 8, s);
+        if (e != hipSuccess) return e;
+        // ... and the "redo done" flag: a stand-alone redo (knn_rowpar_kernel) leaves it raised, and the decision workgroup of a fused frame
+        // tail that found it raised would not wait for ITS redo ([2], the running maximum of the error ratio, stays)
+        e = hipMemsetAsync(fail_count + 3, 0, 4, s);
         if (e != hipSuccess) return e;
     }
     if (p.n_blocks > 0) {
