@@ -79,8 +79,11 @@ def main():
             groups = [("decision loop", idx == 0), ("registration", idx == 1)]
             if n_f:
                 a0 = 2 + n_f
-                groups += [("filter", (idx >= 2) & (idx < a0)), ("distance tiles", (idx >= a0) & (idx < a0 + 36)),
-                           ("query pre-split", (idx >= a0 + 36) & (idx < a0 + 44)), ("redo helpers", idx >= a0 + 44)]
+                T = (q + 63) // 64
+                n_tl = T * (T + 1) // 2 + (T * T if int(opts.get("cross_frame_tiles", 0)) else 0)   # same-frame tiles (+ cross-frame ones)
+                n_qs = max(1, min((T * 64 * 8 + 255) // 256, 32))                                   # launch_frame_a: one item per thread
+                groups += [("filter", (idx >= 2) & (idx < a0)), ("distance tiles", (idx >= a0) & (idx < a0 + n_tl)),
+                           ("query pre-split", (idx >= a0 + n_tl) & (idx < a0 + n_tl + n_qs)), ("redo helpers", idx >= a0 + n_tl + n_qs)]
             for nme, m in groups:
                 if m.sum():
                     st, en = b[m, 0], b[m, 1]
