@@ -374,7 +374,9 @@ int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, co
  * The two keys that DO change what a call means (sharded handles only, identical on every rank): "shard_growth_first" = F and
  * "shard_growth_block" = B > 0 make lcd_shard_frame_dev give the words frames create (ids >= F) to rank ((id - F) / B) % world instead of
  * the last rank, and merge the gathered candidates with ties going to the lower WORD ID -- the single-GPU row order as long as every rank
- * appends its words in ascending id ("block-cyclic so growth stays balanced"). */
+ * appends its words in ascending id ("block-cyclic so growth stays balanced").  "shard_append" = 1 (what
+ * lcd_shard_set_append of include/lcd_shard.h sets): lcd_shard_frame_dev also turns the new words this rank owns into rows of its shard,
+ * on the device, from the replicated decision -- VWDictionary::update()'s append, per rank. */
 int lcd_set_option(lcd_engine* h, const char* key, int64_t value);
 
 /* the work of ONE scoring launch for the words of the last frame (diagnostic, synchronises): out8[0] bytes of dense count rows

@@ -83,3 +83,17 @@ def test_pipelined_filter_plan_covers_every_size():
     assert lib.lcd_debug_frame_plan(500, 49000, 1, out) == 0 and list(out)[:3] == [7, 219, 0]
     assert lib.lcd_debug_frame_plan(500, 59000, 1, out) == 0 and list(out)[:3] == [5, 369, 0]
     assert lib.lcd_debug_frame_plan(500, 125000, 1, out) == 0 and out[2] > 0
+
+
+def test_every_option_key_the_library_accepts_is_documented_in_the_headers():
+    """lcd_set_option's keys are part of the boundary: each one the engine compares against must be named in include/*.h"""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    keys = set()
+    for path in glob.glob(os.path.join(root, "rtabmap_amd", "csrc", "*.hip")):
+        keys |= set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', open(path).read()))
+    assert len(keys) >= 8
+    headers = "".join(open(p).read() for p in glob.glob(os.path.join(root, "include", "*.h")))
+    missing = sorted(k for k in keys if '"%s"' % k not in headers)
+    assert not missing, "option keys without a word in include/*.h: %s" % missing
