@@ -223,6 +223,13 @@ def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None
     return {"wall": wall, "dev_ms": evs[0].elapsed_time(evs[steps]), "host_enqueue": host_enqueue, "per_step_ms": per_step}
 
 
+# The pass / fail rule for Rtabmap::adjustLikelihood's value on the replays (the advisor's round-5 finding: the check must gate, not inform).
+ADJ_GATE_NOTE = ("adjusted_value_ok = for every sampled frame: |device - formula with exactly rounded (double) statistics| <= 1e-4 relative AND "
+                 "|device - reference value with its float statistics| <= 1e-4 + e_ref, where e_ref = |reference float value - double value| measured on "
+                 "that very sample.  uMean / uVariance (UMath.h:419-432, 512-526) add ~10^5..10^6 floats sequentially: their own rounding error "
+                 "(up to (n - 1) 2^-24 relative, observed 4e-5..2e-4) is not something a device that sums exactly can or should reproduce; "
+                 "it is measured per sample and granted, nothing else is.  At <= 10^5 signatures e_ref stays below 1e-5 and the plain 1e-4 bound decides "
+                 "(tests/test_gpu_bayes.py, the headline parity block).")
 PMC_LIVE = {}          # kernel -> {"fetch_kb", "write_kb", "hbm_bytes_per_launch"}: measured by THIS run (measure_pmc), else the committed profile
 
 
@@ -932,7 +939,8 @@ def run_replay(args):
     mem_upto = 0
     ids_equal, max_rel, n_cmp, hyp_ok, checked = True, 0.0, 0, True, []
     hyp_same = hyp_near = 0
-    adj_rel_ref = adj_rel_exact = 0.0
+    adj_rel_ref = adj_rel_exact = adj_ref_own = 0.0
+    adj_ok = True
     knn_s = lik_s = 0.0
     for t in sample_t:
         # the dictionary as update() leaves it in front of frame t: every word a frame < t created, in id order
@@ -1002,6 +1010,12 @@ def run_replay(args):
             adj_rel_ref = max(adj_rel_ref, abs(got_adj - ref_adj) / max(abs(ref_adj), 1e-3))
             ex_adj = adjusted_exact(Lo[:n_cons], Lo[pick])
             adj_rel_exact = max(adj_rel_exact, abs(got_adj - ex_adj) / max(abs(ex_adj), 1e-3))
+            # the gate (ADJ_GATE_NOTE): within 1e-4 of the reference's formula, and of the reference's float-accumulated value up to what
+            # that accumulation itself lost on THIS sample (|float statistics - double statistics|, measured here, not a constant)
+            ref_own = abs(ref_adj - ex_adj) / max(abs(ex_adj), 1e-3)
+            adj_ref_own = max(adj_ref_own, ref_own)
+            adj_ok &= bool(abs(got_adj - ex_adj) / max(abs(ex_adj), 1e-3) <= 1e-4 and
+                           abs(got_adj - ref_adj) / max(abs(ref_adj), 1e-3) <= 1e-4 + ref_own)
         checked.append({"frame": int(t), "signatures": int(t + 1), "likelihood_by": how})
     par_s = time.perf_counter() - t_par
     # ---- CPU baseline on a bounded sample: the reference's kd-tree / exact scan over the FINAL dictionary + the restated std::map TF-IDF
@@ -1046,11 +1060,11 @@ def run_replay(args):
                       "mean_adjusted_likelihood_of_hits": float(adjusted[hit].mean()) if hit.any() else None,
                       "rule": "every frame from the second lap on: the best raw-likelihood candidate outside the newest %d signatures shows the frame's place" % stm},
            "parity": {"frames_checked": checked, "word_ids_equal": bool(ids_equal), "likelihood_max_rel": max_rel, "likelihood_values_compared": n_cmp,
-                      "best_candidate_equal_or_a_rounding_tie": bool(hyp_ok), "best_candidate_identical": hyp_same,
+                      "adjust_likelihood_and_best_candidate_ok": bool(hyp_ok and adj_ok), "best_candidate_equal_or_a_rounding_tie": bool(hyp_ok), "adjusted_value_ok": bool(adj_ok), "best_candidate_identical": hyp_same,
                       "best_candidate_a_rounding_tie": hyp_near, "bound": "1e-4 relative (abs floor 1e-7)",
                       "adjusted_value_max_rel_vs_reference_float_statistics": adj_rel_ref,
                       "adjusted_value_max_rel_vs_the_same_formula_with_double_statistics": adj_rel_exact,
-                      "adjusted_value_within_1e-4_of_the_reference": bool(adj_rel_ref <= 1e-4),
+                      "adjusted_value_within_1e-4_of_the_reference": bool(adj_rel_ref <= 1e-4), "reference_float_statistics_own_error_max_rel": adj_ref_own, "adjusted_value_gate": ADJ_GATE_NOTE,
                       "adjusted_value_note": "Rtabmap::adjustLikelihood divides by uMean and subtracts sqrt(uVariance), which the reference accumulates in FLOAT over "
                                              "every positive likelihood in signature order (UMath.h:419-432, 512-526; restated that way by the oracle); the device sums "
                                              "in double.  Over ~10^6 values the float sum itself deviates from the exact one by more than the parity bound, so the first "
@@ -1225,7 +1239,8 @@ def run_replay_growing(args):
     t_par = time.perf_counter()
     ids_equal, max_rel, n_cmp, hyp_ok, checked = True, 0.0, 0, True, []
     hyp_same = hyp_near = 0
-    adj_rel_ref = adj_rel_exact = 0.0
+    adj_rel_ref = adj_rel_exact = adj_ref_own = 0.0
+    adj_ok = True
     knn_s = lik_s = 0.0
     for t in sample_t:
         vr, vi, desc, ret_t = snap[t]
@@ -1266,6 +1281,10 @@ def run_replay_growing(args):
             adj_rel_ref = max(adj_rel_ref, abs(got_adj - ref_adj) / max(abs(ref_adj), 1e-3))
             ex_adj = adjusted_exact(Lo[:n_cons], Lo[pick])
             adj_rel_exact = max(adj_rel_exact, abs(got_adj - ex_adj) / max(abs(ex_adj), 1e-3))
+            ref_own = abs(ref_adj - ex_adj) / max(abs(ex_adj), 1e-3)                    # (ADJ_GATE_NOTE)
+            adj_ref_own = max(adj_ref_own, ref_own)
+            adj_ok &= bool(abs(got_adj - ex_adj) / max(abs(ex_adj), 1e-3) <= 1e-4 and
+                           abs(got_adj - ref_adj) / max(abs(ref_adj), 1e-3) <= 1e-4 + ref_own)
         checked.append({"frame": int(t), "live_signatures": int(t + 1 - ret_t), "dictionary_words": int(vi.size), "rows_ascending": rows_ascending,
                         "word_ids_equal": ok})
     par_s = time.perf_counter() - t_par
@@ -1321,10 +1340,10 @@ def run_replay_growing(args):
            "recall": {"revisits_counted": int(counted.sum()), "loop_closures_found": int(hit.sum()), "recall": recall,
                       "rule": "revisit frames whose place still has its first signature in memory, older than the newest %d: the best raw-likelihood candidate shows the frame's place" % stm},
            "parity": {"frames_checked": checked, "word_ids_equal": bool(ids_equal), "likelihood_max_rel": max_rel, "likelihood_values_compared": n_cmp,
-                      "best_candidate_equal_or_a_rounding_tie_and_retired_slots_zero": bool(hyp_ok), "best_candidate_identical": hyp_same, "best_candidate_a_rounding_tie": hyp_near,
+                      "adjust_likelihood_and_best_candidate_ok": bool(hyp_ok and adj_ok), "best_candidate_equal_or_a_rounding_tie_and_retired_slots_zero": bool(hyp_ok), "adjusted_value_ok": bool(adj_ok), "best_candidate_identical": hyp_same, "best_candidate_a_rounding_tie": hyp_near,
                       "adjusted_value_max_rel_vs_reference_float_statistics": adj_rel_ref,
                       "adjusted_value_max_rel_vs_the_same_formula_with_double_statistics": adj_rel_exact,
-                      "adjusted_value_within_1e-4_of_the_reference": bool(adj_rel_ref <= 1e-4),
+                      "adjusted_value_within_1e-4_of_the_reference": bool(adj_rel_ref <= 1e-4), "reference_float_statistics_own_error_max_rel": adj_ref_own, "adjusted_value_gate": ADJ_GATE_NOTE,
                       "adjusted_value_note": "the reference accumulates uMean / uVariance in FLOAT over every positive likelihood (UMath.h:419-432, 512-526; the oracle "
                                              "restates that), the device in double: over ~10^6 values the first figure is dominated by the reference's own accumulation error",
                       "bound": "1e-4 relative (abs floor 1e-7)", "oracle_seconds": {"addNewWords": knn_s, "computeLikelihood": lik_s},

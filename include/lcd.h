@@ -361,14 +361,15 @@ int lcd_profile_read(lcd_engine* h, float* avg_ms, int* n_samples, const char** 
 /* the same for the fused likelihood kernel of lcd_frame_dev (both series are recorded while profiling is enabled) */
 int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, const char** kernel_name);
 
-/* tuning knobs for experiments (results never depend on them).  "score_block": threads per workgroup of the scoring kernel
+/* tuning knobs for experiments (results never depend on them; every one of them is per handle).  "filter_delay": the filter workgroups
+ * of a pipelined frame's launch A wait value x 64 clocks in front of their first request (0 .. 127; timing experiments).  "score_block": threads per workgroup of the scoring kernel
  * (256 / 512 / 1024).  "filter_units": compute units the bf16 filter plans its persistent workgroups for when the vocabulary has
  * more 256-word strips than that (-1 built-in, 0 never persistent).  "profile_likelihood": 0 = lcd_profile_begin brackets only the
  * 2-NN launch of a pipelined frame (every timed launch costs stream time).  "strip_tiles": 32-word tiles per filter workgroup of a
- * pipelined frame (1 .. 8; 0 = the built-in plan).  "append_split_buckets" (process-wide): sealed buckets of 256 signatures from which
+ * pipelined frame (1 .. 8; 0 = the built-in plan).  "append_split_buckets": sealed buckets of 256 signatures from which
  * the rows a frame appends are written by a kernel of their own behind launch B instead of by workgroups inside it (-1 = built-in, 1 024).
- * "append_from_rerank" (process-wide): 1 (built-in) = those rows are written by the re-rank workgroups of launch B, 0 = by eight row-writer
- * workgroups.  "cross_frame_tiles" (process-wide): 1 = launch A also computes a frame's distances to the frame before it and the re-rank reads
+ * "append_from_rerank": 1 (built-in) = those rows are written by the re-rank workgroups of launch B, 0 = by eight row-writer
+ * workgroups.  "cross_frame_tiles": 1 = launch A also computes a frame's distances to the frame before it and the re-rank reads
  * the distances of the rows that frame appended from there instead of staging the rows (0 / -1 = built-in: staged).
  * Unknown keys / values -> LCD_ERR_INVALID.
  * The two keys that DO change what a call means (sharded handles only, identical on every rank): "shard_growth_first" = F and

@@ -108,6 +108,7 @@ struct lcd_engine {
     bool clean_armed = false;                           // a clean waits for the next fused launch pair, whose registration applies the
                                                         // retirements asked for before it (they ride there: no launches of their own)
     int reconcile();
+    void mirror_push_row(int32_t id, int64_t row);     // a row the device appended enters h_row_key / h_row_live / word_row
     int64_t rows_ub() const;
     // The rows the FILTER of chain frame `fseq` will most likely see (the count its launch reads is the one written a launch earlier: the
     // words of the frames up to fseq - 2): what the newest finished appender reported + an estimate per appending frame between that one
@@ -121,6 +122,7 @@ struct lcd_engine {
     int shard_append = 0;                               // lcd_set_option("shard_append"): lcd_shard_frame_dev appends the new words this rank owns on the device
     int filter_units = -1;                              // lcd_set_option("filter_units")
     int strip_tiles = 0;                                // lcd_set_option("strip_tiles"): tiles per filter workgroup of a pipelined frame (0: planner)
+    lcd::PipeOpts popt;                                 // options of the fused launches ("cross_frame_tiles", "append_from_rerank", "append_split_buckets", "filter_delay"); f16 follows knn_mode
     int sync_all();                                     // stream drained
     int drain(bool rows = true);                        // complete the owed index stage (stand-alone launches); rows: the host's row mirror
                                                         // catches up with the rows appended / removed on the device (reconcile(): synchronises, two small reads)

@@ -281,6 +281,14 @@ int64_t lcd_engine::rows_plan(uint64_t fseq) {
     return std::min(std::max(est, cnt), ub);
 }
 
+// one row the device appended enters the host's row mirror (the caller adds to n_rows / n_live)
+void lcd_engine::mirror_push_row(int32_t id, int64_t row) {
+    if (rows_sorted && !h_row_key.empty() && id <= h_row_key.back()) rows_sorted = false;
+    if (word_row_valid) word_row[id] = (int32_t)row;
+    h_row_key.push_back(id);
+    h_row_live.push_back(1);
+}
+
 // the host's row mirror catches up with the device (synchronises)
 int lcd_engine::reconcile() {
     if (unreconciled.empty() && !rm_pending) return LCD_OK;
@@ -304,10 +312,7 @@ int lcd_engine::reconcile() {
                                                   : a.own_rank == a.own_world - 1;
                 if (!mine) continue;
             }
-            if (rows_sorted && !h_row_key.empty() && id <= h_row_key.back()) rows_sorted = false;
-            if (word_row_valid) word_row[id] = (int32_t)(n_rows + taken);
-            h_row_key.push_back(id);
-            h_row_live.push_back(1);
+            mirror_push_row(id, n_rows + taken);
             taken += 1;
         }
         n_rows += taken;
@@ -1333,7 +1338,7 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
     lap.lap(3);
     PipeKnn k;
     if (f_knn) { int rc = build_knn(h, *f_knn, &k); if (rc) return rc; h->knn_launches += 1; }
-    if (f_knn && f_res && tl_res.r.ap.enabled && tl_res.r.ap.defer_rows && tl_res.r.ap.is_f32_64 && knn_cross_frames()) {
+    if (f_knn && f_res && tl_res.r.ap.enabled && tl_res.r.ap.defer_rows && tl_res.r.ap.is_f32_64 && h->popt.cross_frames) {
         // The rows f_res appends (its decision loop rides in this launch A) are descriptors of f_res, and f_knn's re-rank (this launch B)
         // must scan them exactly: extra distance tiles of launch A compute f_knn x f_res in the reference's arithmetic, the re-rank reads
         // its pending rows' distances there instead of staging the rows (the buffer was sized when f_knn was submitted: no reallocation here)
@@ -1345,8 +1350,9 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
     }
     lap.lap(4);
     const bool prof = f_knn && h->prof_cap > 0 && h->prof_n < h->prof_cap;
+    h->popt.f16 = h->f16();
     LCD_HIP(h, launch_frame_a(f_knn ? &k : nullptr, qs, f_res ? &tl_res : nullptr, f_reg ? &tl_reg : nullptr, h->stream,
-                              prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr));
+                              prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr, h->popt));
     if (prof) {
         h->prof_n += 1;
         if (h->f16())
@@ -1361,7 +1367,7 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
     AppendRowsArgs app;
     if (f_res && tl_res.r.ap.enabled && tl_res.r.ap.defer_rows) { app.ap = tl_res.r.ap; app.new_ws = tl_res.r.new_ws; }
     LCD_HIP(h, launch_frame_b(f_knn ? &k : nullptr, reg_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
-                              prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr, app.ap.enabled ? &app : nullptr));
+                              prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr, app.ap.enabled ? &app : nullptr, h->popt));
     lap.lap(6);
     LCD_HIP(h, t.flush_held_if_due());                               // (behind launch B: the rows it writes claim their postings keys there)
     if (prof2) { h->prof2_n += 1; h->prof2_kernel = "frame_b_kernel (re-rank of frame t-1 + scoring of frame t-3)"; }
@@ -1452,7 +1458,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
         LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_selfdist, (size_t)q * ld * 4));
         LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_bits, cand_bits_bytes(q, bw)));
     }
-    if (chained && !h->inflight.empty() && h->dtype == LCD_F32 && h->kdim == 64 && knn_cross_frames())   // (pipeline_launch: this frame x the frame before it)
+    if (chained && !h->inflight.empty() && h->dtype == LCD_F32 && h->kdim == 64 && h->popt.cross_frames)   // (pipeline_launch: this frame x the frame before it)
         LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_cross, (size_t)q * ((h->inflight.back().a.q + 63) / 64 * 64) * 4));
     QSplitArgs qs;
     qs.queries = (const float*)a->d_descriptors; qs.nq = q; qs.qpad = ld; qs.qsplit = (uint4*)sc.d_qsplit.p; qs.qnorm = sc.d_qnorm.as<float>(); qs.n_wgs = 0; qs.f16 = h->f16();
@@ -1513,19 +1519,24 @@ int lcd_frame_host(lcd_engine* h, const lcd_frame_host_args* a) {
     LCD_HIP(h, dreserve(h, h->d_frame_words, (size_t)q * 4));
     if (a->likelihood) LCD_HIP(h, dreserve(h, h->d_frame_like, (size_t)std::max<int64_t>(slots_after, 1) * 4));
     LCD_HIP(h, hipMemcpyAsync(h->d_frame_desc.p, h->h_frame_in.p, dbytes, hipMemcpyHostToDevice, h->stream));
+    // from here on a copy out of / into the pinned staging may be in flight: a failure synchronises before it returns (the next call --
+    // the mirror falls back to the call-by-call path on the same engine straight away -- reuses h_frame_in / h_frame_out)
+    auto bail = [&](int rc) { (void)hipStreamSynchronize(h->stream); return rc; };
+#define LCD_HIP_B(h, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return bail((h)->hip_fail(e__, #call)); } while (0)
     lcd_frame_args fa;
     std::memset(&fa, 0, sizeof(fa));
     fa.struct_size = (int32_t)sizeof(fa); fa.q = q; fa.d_descriptors = h->d_frame_desc.p; fa.flags = a->flags; fa.nndr_ratio = a->nndr_ratio;
     fa.sig_id = a->sig_id; fa.first_new_word_id = a->first_new_word_id; fa.N = a->N; fa.append_new_words = a->append_new_words;
     fa.d_word_ids = h->d_frame_words.as<int32_t>();
     if (a->likelihood) { fa.d_likelihood = h->d_frame_like.as<float>(); fa.likelihood_capacity = (int64_t)(h->d_frame_like.cap / 4); }
-    { int rc = frame_dev_body(h, &fa); if (rc) return rc; }
-    { int rc = h->drain(false); if (rc) return rc; }                  // a pipelined handle: the frame's stages stand-alone (the row mirror is not needed here)
+    { int rc = frame_dev_body(h, &fa); if (rc) return bail(rc); }
+    { int rc = h->drain(false); if (rc) return bail(rc); }            // a pipelined handle: the frame's stages stand-alone (the row mirror is not needed here)
     const size_t wbytes = (size_t)q * 4, lbytes = a->likelihood ? (size_t)slots_after * 4 : 0;
-    LCD_HIP(h, h->h_frame_out.reserve(wbytes + lbytes + 16));
-    LCD_HIP(h, hipMemcpyAsync(h->h_frame_out.p, h->d_frame_words.p, wbytes, hipMemcpyDeviceToHost, h->stream));
-    if (lbytes) LCD_HIP(h, hipMemcpyAsync((char*)h->h_frame_out.p + wbytes, h->d_frame_like.p, lbytes, hipMemcpyDeviceToHost, h->stream));
+    LCD_HIP_B(h, h->h_frame_out.reserve(wbytes + lbytes + 16));
+    LCD_HIP_B(h, hipMemcpyAsync(h->h_frame_out.p, h->d_frame_words.p, wbytes, hipMemcpyDeviceToHost, h->stream));
+    if (lbytes) LCD_HIP_B(h, hipMemcpyAsync((char*)h->h_frame_out.p + wbytes, h->d_frame_like.p, lbytes, hipMemcpyDeviceToHost, h->stream));
     LCD_HIP(h, hipStreamSynchronize(h->stream));
+#undef LCD_HIP_B
     std::memcpy(a->word_ids, h->h_frame_out.p, wbytes);
     if (lbytes) std::memcpy(a->likelihood, (const char*)h->h_frame_out.p + wbytes, lbytes);
     if (a->n_slots) *a->n_slots = slots_after;
@@ -1538,16 +1549,11 @@ int lcd_frame_host(lcd_engine* h, const lcd_frame_host_args* a) {
         for (int i = 0; i < q; ++i) n_new = std::max(n_new, -a->word_ids[i]);
         const unsigned long long v = *(volatile const unsigned long long*)h->h_vmirror;   // what the appender reported: (tag << 32) | rows
         if ((uint32_t)(v >> 32) == (uint32_t)(h->unreconciled.front().seq + 1) && (int64_t)(uint32_t)v == h->n_rows + n_new) {
-            for (int k = 0; k < n_new; ++k) {
-                const int32_t id = a->first_new_word_id + k;
-                if (h->rows_sorted && !h->h_row_key.empty() && id <= h->h_row_key.back()) h->rows_sorted = false;
-                if (h->word_row_valid) h->word_row[id] = (int32_t)(h->n_rows + k);
-                h->h_row_key.push_back(id);
-                h->h_row_live.push_back(1);
-            }
+            for (int k = 0; k < n_new; ++k) h->mirror_push_row(a->first_new_word_id + k, h->n_rows + k);
             h->n_rows += n_new;
             h->n_live += n_new;
             h->unreconciled.clear();
+            h->frames_since_reconcile = 0;                               // (what reconcile() leaves: nothing is owed to the mirror)
         }
     }
     return LCD_OK;
@@ -1824,7 +1830,10 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
     // id; ties by (rank, row) need every new word on the last rank): a block without a first id is no growth policy, and a frame whose
     // new ids would lie in front of the policy's origin has no owner rule at all -- refused rather than guessed
     const bool cyclic = h->shard_block > 0 && h->shard_first > 0;
-    if (cyclic && sig_id != 0 && first_new_word_id > 0 && (flags & LCD_Q_INCREMENTAL) && first_new_word_id < h->shard_first)
+    // the frame's new words become rows of this rank's shard on the device (shard_append): they need postings keys and an owner whether or
+    // not the frame is registered as a signature (a query-only frame: the single-GPU path reserves keys whenever frame_appends() holds)
+    const bool dev_append = h->shard_append && (flags & LCD_Q_INCREMENTAL) && first_new_word_id > 0 && h->row_bytes == h->dim * (h->dtype == LCD_F32 ? 4 : 1);
+    if (cyclic && (sig_id != 0 || dev_append) && first_new_word_id > 0 && (flags & LCD_Q_INCREMENTAL) && first_new_word_id < h->shard_first)
         return h->fail(LCD_ERR_INVALID, "lcd_shard_frame_dev: first_new_word_id lies in front of shard_growth_first");
     LCD_HIP(h, launch_shard_merge(d_all_cand, world, rank, q, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
                                   h->d_knn_row.as<int32_t>(), h->stream, cyclic));
@@ -1842,7 +1851,7 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
     // new words: every rank reserves the same keys (identical call sequence => identical numbering); only the LAST rank, which
     // will hold their rows, references them
     WsRuns new_ws;
-    if (sig_id != 0 && first_new_word_id > 0 && incremental) {
+    if ((sig_id != 0 || dev_append) && first_new_word_id > 0 && incremental) {
         hipError_t e = t.reserve_new_words(first_new_word_id, q, &new_ws);
         if (e == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_shard_frame_dev: word ids must be below 2^28");
         if (e != hipSuccess) return h->hip_fail(e, "reserve_new_words");
@@ -1856,7 +1865,7 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
                               together ? h->d_selfdist.as<float>() : nullptr, ld, together ? h->d_bits.as<uint32_t>() : nullptr, bw,
                               d_word_ids, h->d_n_new.as<int32_t>(), h->stream, h->d_knn_row.as<int32_t>(), nullptr,
                               h->d_out_wslot.as<int32_t>(), &new_ws));
-    if (h->shard_append && incremental && first_new_word_id > 0 && h->row_bytes == h->dim * (h->dtype == LCD_F32 ? 4 : 1)) {
+    if (dev_append) {
         // VWDictionary::update()'s append branch, this rank's share, on the device: the words the frame created that this rank owns become
         // rows of its shard before the next frame is searched (lcd_shard_knn2_dev catches the host's row mirror up: one synchronisation,
         // no lcd_vocab_append, nothing read back by the caller)
@@ -1981,10 +1990,13 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     if (!std::strcmp(key, "shard_append") && (value == 0 || value == 1)) { h->shard_append = (int)value; return LCD_OK; }
     // 0: lcd_profile_begin brackets only the 2-NN launch of a pipelined frame (an event pair costs the stream ~10 us)
     if (!std::strcmp(key, "profile_likelihood") && (value == 0 || value == 1)) { h->prof_likelihood = value != 0; return LCD_OK; }
-    // (process-wide, for tests) sealed buckets from which the rows of a deferred append are written by a launch of their own; -1: built-in
-    if (!std::strcmp(key, "append_split_buckets") && value >= -1 && value <= (1 << 24)) { knn_set_append_split_buckets((int)value); return LCD_OK; }
-    if (!std::strcmp(key, "cross_frame_tiles") && value >= -1 && value <= 1) { knn_set_cross_frames((int)value); return LCD_OK; }
-    if (!std::strcmp(key, "append_from_rerank") && value >= -1 && value <= 1) { knn_set_append_from_rerank(value != 0 ? 1 : 0); return LCD_OK; }
+    // (per handle, like every option) sealed buckets from which the rows of a deferred append are written by a launch of their own; -1: built-in
+    if (!std::strcmp(key, "append_split_buckets") && value >= -1 && value <= (1 << 24)) { h->popt.append_split_buckets = (int)value; return LCD_OK; }
+    if (!std::strcmp(key, "cross_frame_tiles") && value >= -1 && value <= 1) { h->popt.cross_frames = value > 0 ? 1 : 0; return LCD_OK; }
+    if (!std::strcmp(key, "append_from_rerank") && value >= -1 && value <= 1) { h->popt.append_from_rerank = value != 0 ? 1 : 0; return LCD_OK; }
+    // timing experiments: the filter workgroups of launch A wait value x 64 clocks in front of their first request (the single-workgroup
+    // chains of the launch then get their first round trip ahead of the strips' opening burst)
+    if (!std::strcmp(key, "filter_delay") && value >= 0 && value <= 127) { h->popt.filter_delay = (int)value; return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");
     LCD_CATCH(h)
 }

@@ -1763,6 +1763,7 @@ struct FilterArgs {
     const float* vocab_bf; const float* row_norm; int n_rows; const float* queries; int nq, qpad, tiles_per_block, n_blocks;
     uint64_t* pk; uint32_t* pl; SelfdistJob sd; const int32_t* n_lo;
     const uint4* qsplit; const float* qnorm;                           // pre-split queries (non-persistent pipelined launch)
+    int delay;                                                         // PipeOpts::filter_delay (timing experiments)
 };
 struct RerankArgs {
     const uint64_t* pk; const uint32_t* pl; int n_blocks, nq; const float* vocab; const float* queries; const int32_t* row_id;
@@ -1797,6 +1798,7 @@ __device__ __forceinline__ void frame_a_body(float* s_dyn, const FilterArgs& f, 
     const int after_filter = n_front + tr.n_filter_wgs;
     if (bid >= after_filter && bid < after_filter + tr.n_q_wgs) { qsplit_body(qs, bid - after_filter); A_STAMP(1); return; }
     if (bid >= after_filter + tr.n_q_wgs) { frame_resolve_part<PIPE_BLOCK>((uint32_t*)s_dyn, r, bid - after_filter - tr.n_q_wgs + 1, 1 + tr.n_redo); A_STAMP(1); return; }
+    for (int i = 0; i < f.delay; ++i) __builtin_amdgcn_s_sleep(1);      // (0 unless "filter_delay" is set)
     if constexpr (PERSISTENT)
         knn_bf16_filter_body_p<M>(s_dyn, bid - n_front, f.vocab_bf, f.row_norm, f.n_rows, f.queries, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, px, f.pk,
                                f.pl, f.sd, f.n_lo);
@@ -1826,7 +1828,6 @@ __device__ unsigned long long g_b_timing[2 * 4096];
 constexpr int PIPE_B_BLOCK = 512;   // workgroup size of launch B: eight waves per sealed bucket, two queries per re-rank workgroup
 constexpr uint32_t PIPE_B_STAGE_ROWS = 160;   // pending rows a re-rank workgroup stages in LDS at a time
 constexpr int APPEND_SPLIT_BUCKETS = 1024;    // sealed buckets (x 256 signatures) from which a deferred append's row writers get a launch of their own
-static int g_append_split_buckets = APPEND_SPLIT_BUCKETS;   // (lcd_set_option "append_split_buckets": tests run the split at small sizes)
 static_assert(PIPE_B_BLOCK == 2 * MF_BLOCK, "the re-rank halves");
 // WITH_APPEND: the workgroups that write a deferred append's rows ride in this launch.  Their mere presence changes the register
 // allocation of the whole kernel: the scoring branch, which holds everything in registers without them, then parks ~14 values in scratch
@@ -1996,9 +1997,6 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
 // plans are tested with on a machine without a device)
 static int g_plan_cus = 256;
 void knn_set_compute_units(int cus) { if (cus >= 16 && cus <= 4096) g_plan_cus = cus; }
-void knn_set_append_split_buckets(int n) { g_append_split_buckets = n >= 0 ? n : APPEND_SPLIT_BUCKETS; }
-static int g_append_from_rerank = 1;           // (lcd_set_option "append_from_rerank": 0 = the eight row-writer workgroups of round 4, for A/B runs)
-void knn_set_append_from_rerank(int on) { g_append_from_rerank = on != 0 ? 1 : 0; }
 int knn_selfdist_wgs(int q) { return selfdist_tiles(q); }
 // other_wgs: workgroups of the same launch that run for about as long as a filter workgroup (distance-matrix tiles, the frame tail's
 // two workgroups).  Every workgroup of the launch holds a whole compute unit's LDS: 256 strips + 2 tail workgroups used to leave two
@@ -2170,12 +2168,9 @@ size_t knn_qsplit_bytes(int q) { return (size_t)((q + 63) / 64 * 64) * 256; }
 // frame creates ~150 words, but the 64 extra tiles share compute units with the filter strips -- launch A 14.2 -> 15.3 us there and
 // 13.3 -> 15.0 us once frames mostly revisit (where launch B gains nothing): 0.0417 -> 0.0412 ms per frame over the driver's 20 steps,
 // 0.0409 -> 0.0412 over 200, and the filter launch is the one the roofline is quoted on.
-static int g_cross_frames = 0;
-void knn_set_cross_frames(int on) { g_cross_frames = on > 0 ? 1 : 0; }
-bool knn_cross_frames() { return g_cross_frames != 0; }
 
 hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLaunch* resolve, const TailLaunch* reg, hipStream_t s, hipEvent_t ev_begin,
-                          hipEvent_t ev_end) {
+                          hipEvent_t ev_end, const PipeOpts& opt) {
     static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)BF_LDS_BYTES_Q);
     static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2195,12 +2190,13 @@ hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLa
         if (k.cb.selfdist) {                                          // the same-frame distance matrix rides along
             f.sd.queries = (const float*)k.queries; f.sd.nq = p.q; f.sd.out = const_cast<float*>(k.cb.selfdist); f.sd.ld = k.cb.ld; f.sd.n_tiles = f.sd.n_self = selfdist_tiles(p.q);
         }
-        if (g_cross_frames && k.cross && k.cross_cols && k.cross_ncols > 0 && p.q > 0) {   // ... and so do this frame's distances to the frame before it
+        if (opt.cross_frames && k.cross && k.cross_cols && k.cross_ncols > 0 && p.q > 0) {   // ... and so do this frame's distances to the frame before it
             f.sd.queries = (const float*)k.queries; f.sd.nq = p.q;
             f.sd.other = (const float*)k.cross_cols; f.sd.n_other = k.cross_ncols; f.sd.xout = k.cross; f.sd.xld = k.cross_ld;
             f.sd.n_tiles += ((p.q + 63) / 64) * ((k.cross_ncols + 63) / 64);
         }
     }
+    f.delay = opt.filter_delay;
     const int px = p.q > 0 ? bf16_persistent_px(p) : 0;
     if (px == 0 && p.q > 0 && (!f.qsplit || !f.qnorm)) return hipErrorInvalidValue;      // the one-strip launch reads pre-split queries
     TailRoles tr;
@@ -2219,7 +2215,7 @@ hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLa
     // ev_begin / ev_end: the launch's own start and end time stamps (hipExtLaunchKernel attaches the two events to the dispatch; a pair
     // of hipEventRecord around it costs the stream ~10 us of barrier packets -- and measures the gap in front of the kernel with it)
     const bool timed = ev_begin != nullptr && ev_end != nullptr;
-    const bool f16 = p.f16 != 0;
+    const bool f16 = kp ? p.f16 != 0 : opt.f16 != 0;                    // (no filter: the variant the handle's filter launches keep hot)
     if (px > 0) {
         static const hipError_t attrp0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&frame_a_kernel_p<0>),
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES_P);
@@ -2245,7 +2241,7 @@ hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLa
 
 
 hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wgs, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
-                          const AppendRowsArgs* app) {
+                          const AppendRowsArgs* app, const PipeOpts& opt) {
     RerankArgs rk{};
     int n_rerank = 0;
     if (k) {
@@ -2270,17 +2266,17 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
     ar.ap.lds_bytes = (int)(PIPE_B_STAGE_ROWS * 256u);
     if (k && n_app) { rk.pend_desc = ar.ap.descriptors; rk.pend_list = ar.ap.list_out; rk.pend_first_id = ar.ap.first_id; }   // k's pending rows ARE the rows being written
     // ... and their distances to k's queries were computed by launch A of this pair (selfdist_tile's cross-frame tiles), if it knew both frames
-    if (k && n_app && g_cross_frames && k->cross && k->cross_cols == (const void*)ar.ap.descriptors) { rk.cross = k->cross; rk.cross_ld = k->cross_ld; }
+    if (k && n_app && opt.cross_frames && k->cross && k->cross_cols == (const void*)ar.ap.descriptors) { rk.cross = k->cross; rk.cross_ld = k->cross_ld; }
     // Who writes the rows of the deferred append: the re-rank workgroups (they hold the rows in their staging area) -- no third branch in the
     // kernel, whose presence makes the scoring branch spill: launch B 15.4 -> 13.8 us once frames create few words.  While frames create
     // ~150 words each (the driver's 20 steps) the two ways are within box-to-box noise of each other (0.0387 against 0.0380 ms per frame
     // on one box, 0.0418 against 0.0427 on another), and choosing per launch by the expected number of new rows lost to both (the second
     // kernel variant is loaded in the middle of the stream): profiles/r05_ab_notes.txt 6.  "append_from_rerank" = 0 keeps round 4's eight
     // row-writer workgroups for A/B runs.
-    const bool writers = g_append_from_rerank == 0;
+    const bool writers = opt.append_from_rerank == 0;
     if (!writers && k && n_app > 0 && k->n_hi && k->plan.q > 0 && rk.stage_rows >= 4) n_app = 0;   // the re-rank workgroups write the rows (`ar` stays filled in: they get it);
                                                                                       // without re-rank workgroups or a staging area the writers stay
-    const bool split = n_app > 0 && score && score->n_closed >= g_append_split_buckets;   // (see frame_b_kernel)
+    const bool split = n_app > 0 && score && score->n_closed >= (opt.append_split_buckets >= 0 ? opt.append_split_buckets : APPEND_SPLIT_BUCKETS);   // (see frame_b_kernel)
     if (split || n_app == 0) {
         if (n_rerank + score_wgs > 0) {
             if (ev_begin != nullptr && ev_end != nullptr)

@@ -90,10 +90,6 @@ struct MfmaPlan {
     int f16 = 0;             // 1: the operand tables hold IEEE half and the filter multiplies ONE product per fp32 product (LCD_KNN_F16)
 };
 bool knn_mfma_supported(int dtype, int dim);
-void knn_set_append_from_rerank(int on);      // 1 (default): the re-rank workgroups of launch B write the rows of a deferred append; 0: eight row-writer workgroups (A/B runs)
-void knn_set_cross_frames(int on);             // 1: launch A also computes the frame's distances to the frame before it, the re-rank reads its pending rows' distances there (0, the default: it stages the rows)
-bool knn_cross_frames();
-void knn_set_append_split_buckets(int n);    // sealed buckets from which launch B leaves the row writers of a deferred append to a kernel of their own (< 0: built-in)
 void knn_set_compute_units(int cus);           // the device's compute units: what the filter launch plans fill (256 unless told otherwise)
 bool knn_bf16_persistent(const MfmaPlan& p);   // the bf16 filter launch of this plan uses the persistent kernels (..._kernel_p)
 MfmaPlan knn_mfma_plan(int q, int n_rows);

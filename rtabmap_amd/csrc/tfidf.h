@@ -201,11 +201,20 @@ void resolve_launch_info(const ResolveArgs& r, int block, int* n_redo, size_t* s
 // filter of the newest frame + the decision loop of one earlier frame (resolve: r / n_redo / shmem_resolve of that TailLaunch) + the
 // registration of a still earlier one (reg: a / ret / shmem); either may be NULL
 // k: the frame whose filter runs (NULL: none); qs: the frame whose queries are pre-split for the NEXT launch's filter (NULL: none)
+// the handle's options that shape the two fused launches (per handle: lcd_set_option writes them into lcd_engine, nothing is process-wide)
+struct PipeOpts {
+    int f16 = 0;                     // the handle's filter multiplies fp16 operands: also picks the kernel variant of launches WITHOUT a filter
+                                     // (pipeline fill / drain), so that they run the code the steady state keeps hot
+    int cross_frames = 0;            // "cross_frame_tiles"
+    int append_from_rerank = 1;      // "append_from_rerank" (0: the eight row-writer workgroups of round 4, for A/B runs)
+    int append_split_buckets = -1;   // "append_split_buckets" (< 0: built-in)
+    int filter_delay = 0;            // "filter_delay": s_sleep units (64 clocks) a filter workgroup waits in front of its first request
+};
 hipError_t launch_frame_a(const PipeKnn* k, const QSplitArgs* qs, const TailLaunch* resolve, const TailLaunch* reg, hipStream_t s,
-                          hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+                          hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const PipeOpts& opt = PipeOpts());
 // app: the rows the decision loop of launch A of this pair published (NULL: none); they are also the pending rows of k's re-rank
 hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wgs, hipStream_t s, hipEvent_t ev_begin = nullptr,
-                          hipEvent_t ev_end = nullptr, const AppendRowsArgs* app = nullptr);
+                          hipEvent_t ev_end = nullptr, const AppendRowsArgs* app = nullptr, const PipeOpts& opt = PipeOpts());
 
 // recycled allocations of bucket-sized device buffers (a bucket is born and dies every 256 frames in steady state:
 // hipMalloc / hipFree there would synchronise the device)

@@ -19,10 +19,10 @@ def _pick(rng, edges, lo, hi):
     return int(rng.choice(edges)) if rng.random() < 0.6 else int(rng.integers(lo, hi))
 
 
-@pytest.mark.parametrize("mode", ["bf16", "mfma32", "valu"])
+@pytest.mark.parametrize("mode", ["bf16", "f16", "mfma32", "valu"])
 def test_fuzz_knn2_f32(oracle, monkeypatch, mode):
     import rtabmap_amd
-    rng = np.random.default_rng({"bf16": 1, "mfma32": 2, "valu": 3}[mode])
+    rng = np.random.default_rng({"bf16": 1, "mfma32": 2, "valu": 3, "f16": 5}[mode])
     for it in range(ITERS):
         n, q = _pick(rng, EDGE_N, 1, 9000), _pick(rng, EDGE_Q, 1, 700)
         v = synth.vocab_surf(n, seed=1000 + it)
@@ -70,11 +70,11 @@ def test_fuzz_knn2_hamming(oracle):
         eng.close()
 
 
-@pytest.mark.parametrize("mode", ["bf16", "valu"])
+@pytest.mark.parametrize("mode", ["bf16", "f16", "valu"])
 def test_fuzz_quantize_and_frame(oracle, monkeypatch, mode):
     """lcd_quantize and the fused lcd_frame_dev tail against the restated addNewWords on random frames."""
     import rtabmap_amd
-    rng = np.random.default_rng(7 if mode == "bf16" else 8)
+    rng = np.random.default_rng({"bf16": 7, "valu": 8, "f16": 9}[mode])
     for it in range(max(4, ITERS // 2)):
         n, q = _pick(rng, [2, 3, 255, 256, 257, 600, 2500], 2, 3000), _pick(rng, [1, 2, 63, 64, 65, 300, 512, 513], 1, 600)
         v = synth.vocab_surf(n, seed=3000 + it)

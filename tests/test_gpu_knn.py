@@ -26,12 +26,13 @@ def _check(eng, oracle, vocab, ids, queries, removed=None):
 
 # the last two: more strips of 256 words than compute units -> the persistent filter workgroups (knn_bf16_filter_body_p), 2 and 1
 # blocks of 512 queries, a ragged last strip
+@pytest.mark.parametrize("mode", ["bf16", "f16"])       # the library's default filter and the one bench.py runs
 @pytest.mark.parametrize("n,q", [(49000, 500), (49000, 1000), (5000, 77), (257, 64), (3, 5), (70001, 1000), (150003, 300)])
-def test_knn2_surf_bit_exact(oracle, n, q):
+def test_knn2_surf_bit_exact(oracle, n, q, mode):
     v = synth.vocab_surf(n)
     qs = synth.queries_surf(v, q)
     ids = np.arange(1, n + 1, dtype=np.int32)
-    eng = _engine("f32", 64)
+    eng = _engine("f32", 64, knn_mode=mode)
     eng.vocab_append(v, ids)
     _check(eng, oracle, v, ids, qs)
     eng.close()

@@ -140,7 +140,7 @@ def test_quantize_large_frame_more_than_1024_descriptors(oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("mode", ["bf16", "mfma32"])
+@pytest.mark.parametrize("mode", ["bf16", "f16", "mfma32"])
 def test_frame_dev_redoes_uncertifiable_queries_inside_the_tail_launch(oracle, monkeypatch, mode):
     """lcd_frame_dev has no launch of its own for the exact redo of queries the filter certificate rejects: extra workgroups
     of the frame-tail launch do it and the decision workgroup waits for them.  A vocabulary with a run of identical rows makes
