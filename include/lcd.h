@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LCD_ABI_VERSION 5
+#define LCD_ABI_VERSION 6
 
 typedef struct lcd_engine lcd_engine;
 
@@ -362,7 +362,7 @@ int lcd_profile_read(lcd_engine* h, float* avg_ms, int* n_samples, const char** 
 int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, const char** kernel_name);
 
 /* tuning knobs for experiments (results never depend on them; every one of them is per handle).  "filter_delay": the filter workgroups
- * of a pipelined frame's launch A wait value x 64 clocks in front of their first request (0 .. 127; timing experiments).  "score_block": threads per workgroup of the scoring kernel
+ * of a pipelined frame's launch A wait value x 64 clocks in front of their first request (0 .. 127; timing experiments).  "roctx": 1 = roctx ranges (see lcd_trace_push below).  "score_block": threads per workgroup of the scoring kernel
  * (256 / 512 / 1024).  "filter_units": compute units the bf16 filter plans its persistent workgroups for when the vocabulary has
  * more 256-word strips than that (-1 built-in, 0 never persistent).  "profile_likelihood": 0 = lcd_profile_begin brackets only the
  * 2-NN launch of a pipelined frame (every timed launch costs stream time).  "strip_tiles": 32-word tiles per filter workgroup of a
@@ -379,6 +379,16 @@ int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, co
  * lcd_shard_set_append of include/lcd_shard.h sets): lcd_shard_frame_dev also turns the new words this rank owns into rows of its shard,
  * on the device, from the replicated decision -- VWDictionary::update()'s append, per rank. */
 int lcd_set_option(lcd_engine* h, const char* key, int64_t value);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * tracing (tracing row; ABI v6).  lcd_set_option("roctx", 1) loads libroctx64.so at run time (no link dependency;
+ * LCD_ERR_UNSUPPORTED when it is not installed) and from then on the engine brackets what it enqueues with roctx ranges that
+ * `rocprofv3 --marker-trace` shows beside the kernels: "lcd_frame_dev", "lcd:launch_A", "lcd:launch_B", "lcd:drain", "lcd_frame_host",
+ * "lcd_likelihood", "lcd_quantize".  lcd_trace_push / lcd_trace_pop put a caller's own range on the same track (the host mirror brackets its
+ * CPU-side stages with the reference's names: "Memory::update", "VWDictionary::addNewWords", "Memory::computeLikelihood", ...).  Both are
+ * no-ops (LCD_OK) while the option is off.  The reference has ULOGGER_DEBUG timings at these places (Memory.cpp:5931,6062; Rtabmap.cpp:4357). */
+int lcd_trace_push(lcd_engine* h, const char* name);
+int lcd_trace_pop(lcd_engine* h);
 
 /* the work of ONE scoring launch for the words of the last frame (diagnostic, synchronises): out8[0] bytes of dense count rows
  * read, [1] sparse postings read (4 B each), [2] directory lookups, [3] lookups that found the word, [4] entries of the open

@@ -22,7 +22,7 @@ SYMBOLS = [
     "lcd_vocab_clear", "lcd_vocab_append", "lcd_vocab_remove", "lcd_vocab_remove_unused", "lcd_vocab_remove_unused_async", "lcd_vocab_rebuild", "lcd_vocab_count", "lcd_vocab_read",
     "lcd_knn2", "lcd_selfdist", "lcd_quantize", "lcd_find_nn",
     "lcd_sig_add", "lcd_sig_remove", "lcd_sig_add_bulk", "lcd_sig_count", "lcd_word_nrefs",
-    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_adjust_likelihood_dev", "lcd_frame_dev", "lcd_frame_host", "lcd_slot_count", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood", "lcd_profile_score_work", "lcd_set_option", "lcd_record_event",
+    "lcd_likelihood", "lcd_adjust_likelihood", "lcd_adjust_likelihood_dev", "lcd_frame_dev", "lcd_frame_host", "lcd_slot_count", "lcd_knn2_dev", "lcd_shard_knn2_dev", "lcd_shard_frame_dev", "lcd_finalize_dev", "lcd_slots_dev", "lcd_stream", "lcd_get_stats", "lcd_profile_begin", "lcd_profile_read", "lcd_profile_read_likelihood", "lcd_profile_score_work", "lcd_set_option", "lcd_record_event", "lcd_trace_push", "lcd_trace_pop",
     "lcd_bayes_configure", "lcd_bayes_reset", "lcd_bayes_set_neighbors", "lcd_bayes_update_dev", "lcd_bayes_update", "lcd_bayes_posterior",
 ]
 

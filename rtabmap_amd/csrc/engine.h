@@ -150,6 +150,15 @@ struct lcd_engine {
     //   4 filter plan (build_knn)   5 launch A   6 launch B   7 the rest of pipeline_launch (flush_held, finish_frame_ops)   8 calls
     int64_t host_prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
+    // ---- roctx ranges (lcd_set_option "roctx"): resolved from libroctx64.so at run time, NULL while off
+    int (*roctx_push)(const char*) = nullptr;
+    int (*roctx_pop)() = nullptr;
+    struct Range {   // a range for the lifetime of a scope
+        lcd_engine* h;
+        Range(lcd_engine* e, const char* name) : h(e && e->roctx_push ? e : nullptr) { if (h) h->roctx_push(name); }
+        ~Range() { if (h) h->roctx_pop(); }
+    };
+
     int fail(int code, const std::string& msg) { err = msg; return code; }
     int hip_fail(hipError_t e, const char* what) {
         err = std::string(what) + ": " + hipGetErrorString(e);

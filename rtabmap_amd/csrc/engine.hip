@@ -5,6 +5,7 @@
 // of the hot path runs in the gfx950 kernels (knn2_kernels.hip, resolve_kernels.hip, tfidf.hip).  There is no CPU
 // fallback: every entry point either runs on the device or returns an error status.
 #include "engine.h"
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -887,6 +888,7 @@ static int quantize_dev(lcd_engine* h, const void* d_desc, int q, int flags, flo
 int lcd_quantize(lcd_engine* h, const void* descriptors, int q, int flags, float nndr_ratio, int32_t* out_word_ids, int32_t* out_n_new) {
     LCD_TRY
     LCD_CHECK_HANDLE(h);
+    lcd_engine::Range range__(h, "lcd_quantize");
     LCD_DEV(h);
     LCD_JOIN_K(h);
     if (q < 0 || (q > 0 && (!descriptors || !out_word_ids))) return h->fail(LCD_ERR_INVALID, "lcd_quantize: null input");
@@ -1052,6 +1054,7 @@ int lcd_word_nrefs(lcd_engine* h, int32_t word_id, int32_t* out_nw) {
 int lcd_likelihood(lcd_engine* h, const int32_t* query_word_ids, int nq, const int32_t* sig_ids, int n_ids, float N, float* out) {
     LCD_TRY
     LCD_CHECK_HANDLE(h);
+    lcd_engine::Range range__(h, "lcd_likelihood");
     LCD_DEV(h);
     if (nq < 0 || n_ids < 0 || (nq > 0 && !query_word_ids) || (n_ids > 0 && (!sig_ids || !out)))
         return h->fail(LCD_ERR_INVALID, "lcd_likelihood: null input");
@@ -1218,6 +1221,7 @@ struct HostLap {   // section timer of the pipelined frame's host path (host_pro
 
 int lcd_engine::drain(bool rows) {
     int rc_all = LCD_OK;
+    Range range__(inflight.empty() ? nullptr : this, "lcd:drain");
     while (!inflight.empty()) {                                      // three fused launch pairs complete what is owed, oldest first
         const size_t before = inflight.size();
         const int stage_front = inflight.front().stage;
@@ -1351,8 +1355,11 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
     lap.lap(4);
     const bool prof = f_knn && h->prof_cap > 0 && h->prof_n < h->prof_cap;
     h->popt.f16 = h->f16();
-    LCD_HIP(h, launch_frame_a(f_knn ? &k : nullptr, qs, f_res ? &tl_res : nullptr, f_reg ? &tl_reg : nullptr, h->stream,
-                              prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr, h->popt));
+    if (h->roctx_push) h->roctx_push("lcd:launch_A");
+    const hipError_t ea__ = launch_frame_a(f_knn ? &k : nullptr, qs, f_res ? &tl_res : nullptr, f_reg ? &tl_reg : nullptr, h->stream,
+                              prof ? h->prof_ev[2 * h->prof_n] : nullptr, prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr, h->popt);
+    if (h->roctx_pop) h->roctx_pop();
+    LCD_HIP(h, ea__);
     if (prof) {
         h->prof_n += 1;
         if (h->f16())
@@ -1366,8 +1373,11 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
     const bool prof2 = f_knn && reg_like && h->prof_likelihood && h->prof_cap > 0 && h->prof2_n < h->prof_cap;
     AppendRowsArgs app;
     if (f_res && tl_res.r.ap.enabled && tl_res.r.ap.defer_rows) { app.ap = tl_res.r.ap; app.new_ws = tl_res.r.new_ws; }
-    LCD_HIP(h, launch_frame_b(f_knn ? &k : nullptr, reg_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
-                              prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr, app.ap.enabled ? &app : nullptr, h->popt));
+    if (h->roctx_push) h->roctx_push("lcd:launch_B");
+    const hipError_t eb__ = launch_frame_b(f_knn ? &k : nullptr, reg_like ? &sa : nullptr, score_wgs, h->stream, prof2 ? h->prof2_ev[2 * h->prof2_n] : nullptr,
+                                           prof2 ? h->prof2_ev[2 * h->prof2_n + 1] : nullptr, app.ap.enabled ? &app : nullptr, h->popt);
+    if (h->roctx_pop) h->roctx_pop();
+    LCD_HIP(h, eb__);
     lap.lap(6);
     LCD_HIP(h, t.flush_held_if_due());                               // (behind launch B: the rows it writes claim their postings keys there)
     if (prof2) { h->prof2_n += 1; h->prof2_kernel = "frame_b_kernel (re-rank of frame t-1 + scoring of frame t-3)"; }
@@ -1480,6 +1490,7 @@ int lcd_frame_dev(lcd_engine* h, const lcd_frame_args* a) {
     LCD_TRY
     LCD_CHECK_HANDLE(h);
     FrameHostTimer timer__(h);
+    lcd_engine::Range range__(h, "lcd_frame_dev");
     LCD_DEV_NODRAIN(h);
     return frame_dev_body(h, a);
     LCD_CATCH(h)
@@ -1503,6 +1514,7 @@ int lcd_slot_count(const lcd_engine* h, int64_t* n_slots) {
 int lcd_frame_host(lcd_engine* h, const lcd_frame_host_args* a) {
     LCD_TRY
     LCD_CHECK_HANDLE(h);
+    lcd_engine::Range range__(h, "lcd_frame_host");
     LCD_DEV(h);                                                      // completes what a pipelined handle owes
     if (!a || a->struct_size != (int32_t)sizeof(lcd_frame_host_args)) return h->fail(LCD_ERR_INVALID, "lcd_frame_host: bad argument block");
     const int q = a->q;
@@ -1994,11 +2006,34 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     if (!std::strcmp(key, "append_split_buckets") && value >= -1 && value <= (1 << 24)) { h->popt.append_split_buckets = (int)value; return LCD_OK; }
     if (!std::strcmp(key, "cross_frame_tiles") && value >= -1 && value <= 1) { h->popt.cross_frames = value > 0 ? 1 : 0; return LCD_OK; }
     if (!std::strcmp(key, "append_from_rerank") && value >= -1 && value <= 1) { h->popt.append_from_rerank = value != 0 ? 1 : 0; return LCD_OK; }
+    if (!std::strcmp(key, "roctx") && (value == 0 || value == 1)) {
+        if (!value) { h->roctx_push = nullptr; h->roctx_pop = nullptr; return LCD_OK; }
+        static void* lib = nullptr;                                  // (stays loaded: ranges of other handles may be open)
+        if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_set_option(roctx): libroctx64.so not found");
+        h->roctx_push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+        h->roctx_pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (!h->roctx_push || !h->roctx_pop) { h->roctx_push = nullptr; h->roctx_pop = nullptr; return h->fail(LCD_ERR_UNSUPPORTED, "lcd_set_option(roctx): roctxRangePushA / roctxRangePop not exported"); }
+        return LCD_OK;
+    }
     // timing experiments: the filter workgroups of launch A wait value x 64 clocks in front of their first request (the single-workgroup
     // chains of the launch then get their first round trip ahead of the strips' opening burst)
     if (!std::strcmp(key, "filter_delay") && value >= 0 && value <= 127) { h->popt.filter_delay = (int)value; return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");
     LCD_CATCH(h)
+}
+
+int lcd_trace_push(lcd_engine* h, const char* name) {
+    if (!h || !name) return LCD_ERR_INVALID;
+    if (h->roctx_push) h->roctx_push(name);
+    return LCD_OK;
+}
+int lcd_trace_pop(lcd_engine* h) {
+    if (!h) return LCD_ERR_INVALID;
+    if (h->roctx_pop) h->roctx_pop();
+    return LCD_OK;
 }
 
 int lcd_profile_score_work(lcd_engine* h, int64_t* out8) {

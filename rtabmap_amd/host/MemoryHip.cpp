@@ -4,6 +4,7 @@
 #include "DbLoaderHip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <set>
@@ -12,12 +13,34 @@ namespace rtabmap_amd {
 
 const int MemoryHip::kIdVirtual = -1;
 
+namespace {
+// a roctx range on the engine's track (lcd_set_option "roctx"; a no-op otherwise) + the elapsed milliseconds, like the UTimer the
+// reference wraps around the same stages
+struct Stage {
+    lcd_engine* eng; std::chrono::steady_clock::time_point t0;
+    Stage(VWDictionaryHip* vwd, const char* name) : eng(vwd->engine()), t0(std::chrono::steady_clock::now()) { if (eng) lcd_trace_push(eng, name); }
+    ~Stage() { if (eng) lcd_trace_pop(eng); }
+    float ms() const { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+
 MemoryHip::MemoryHip(const ParametersMap& parameters, int device)
     : _vwd(new VWDictionaryHip(parameters, device)), _idCount(0), _maxStMemSize(10), _deviceFrames(true), _likeSig(0), _likeSortedValid(false) {
     ParametersMap::const_iterator it = parameters.find("Mem/STMSize");
     if (it != parameters.end()) _maxStMemSize = atoi(it->second.c_str());
     if (_maxStMemSize < 0) _maxStMemSize = 0;
     _workingMem.insert(kIdVirtual);             // Memory.cpp:592
+    static const char* names[] = {"TimingMem/Pre_update/ms", "TimingMem/Joining_dictionary_update/ms", "TimingMem/Add_new_words/ms",
+                                  "Timing/Likelihood_computation/ms", "Timing/Forgetting/ms", "Keypoint/Dictionary_size/words",
+                                  "Keypoint/Current_frame/words", "Keypoint/Indexed_words/words", "Keypoint/Index_memory_usage/KB"};
+    for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) _stats[names[i]] = 0.0f;   // (Statistics::_defaultData: every key exists from the start)
+}
+
+void MemoryHip::refreshEngineStatistics() {
+    _stats["Keypoint/Dictionary_size/words"] = (float)_vwd->getVisualWords().size();
+    _stats["Keypoint/Indexed_words/words"] = (float)_vwd->getIndexedWordsCount();
+    lcd_stats st;
+    if (_vwd->engine() && lcd_get_stats(_vwd->engine(), &st) == LCD_OK) _stats["Keypoint/Index_memory_usage/KB"] = (float)(st.bytes_device / 1024);
 }
 MemoryHip::~MemoryHip() { delete _vwd; }
 
@@ -35,7 +58,13 @@ void MemoryHip::preUpdate() {   // Memory.cpp:1004-1016; with Kp/Parallelized th
 }
 
 int MemoryHip::update(const Mat& descriptors, int nQuantized, std::vector<int>& outIds) {
-    this->preUpdate();
+    Stage whole(_vwd, "Memory::update");
+    {
+        Stage st(_vwd, "Memory::preUpdate");
+        this->preUpdate();
+        _stats["TimingMem/Pre_update/ms"] = st.ms();
+    }
+    Stage quant(_vwd, "VWDictionary::addNewWords");
     const int id = ++_idCount;
     std::list<int> wordIds;
     const int rows = descriptors.rows;
@@ -64,6 +93,10 @@ int MemoryHip::update(const Mat& descriptors, int nQuantized, std::vector<int>& 
             for (int i = 0; i < rows; ++i) wordIds.push_back(neg--);
         }
     }
+    _stats["TimingMem/Add_new_words/ms"] = quant.ms();          // (on the device-frame path this also holds the frame's likelihood: one call)
+    _stats["Keypoint/Current_frame/words"] = (float)wordIds.size();
+    _stats["Keypoint/Dictionary_size/words"] = (float)_vwd->getVisualWords().size();
+    _stats["Keypoint/Indexed_words/words"] = (float)_vwd->getIndexedWordsCount();
     _signatures[id] = std::vector<int>(wordIds.begin(), wordIds.end());
     outIds.assign(wordIds.begin(), wordIds.end());
     this->addSignatureToStm(id);
@@ -211,6 +244,8 @@ int MemoryHip::getNi(int signatureId) const {   // Memory.cpp:4955-4968
 void MemoryHip::forget(int signatureId) {
     std::map<int, std::vector<int> >::iterator it = _signatures.find(signatureId);
     if (it == _signatures.end()) return;
+    Stage st(_vwd, "Memory::forget");
+    struct Put { std::map<std::string, float>& m; Stage& s; ~Put() { m["Timing/Forgetting/ms"] = s.ms(); } } put{_stats, st};
     _likeSig = 0;                               // N and the references change: the frame's likelihood is no longer Memory::computeLikelihood's
     std::set<int> keys(it->second.begin(), it->second.end());   // uUniqueKeys (Memory.cpp:6885)
     _vwd->removeAllWordRefs(keys, signatureId);
@@ -227,8 +262,11 @@ std::vector<int> MemoryHip::signatureIds() const {
 }
 
 std::map<int, float> MemoryHip::computeLikelihood(const std::list<int>& wordIds, const std::list<int>& ids) {
+    Stage st(_vwd, "Memory::computeLikelihood");
     const float N = (float)_signatures.size();   // Memory.cpp:2248: every signature in memory, not only `ids`
-    return _vwd->computeLikelihood(wordIds, ids, N, [this](int s) { return this->getNi(s); });
+    std::map<int, float> L = _vwd->computeLikelihood(wordIds, ids, N, [this](int s) { return this->getNi(s); });
+    _stats["Timing/Likelihood_computation/ms"] = st.ms();
+    return L;
 }
 
 // (signature id, likelihood) of every signature registered on the device, ascending id, from the frame's slot-indexed result
@@ -264,6 +302,8 @@ std::map<int, float> MemoryHip::computeLikelihood(int signatureId, const std::li
     std::map<int, std::vector<int> >::const_iterator it = _signatures.find(signatureId);
     if (it == _signatures.end()) return std::map<int, float>();   // "The signature is null" (Memory.cpp:2222)
     if (_likeSig != 0 && _likeSig == signatureId) {
+        Stage st(_vwd, "Memory::computeLikelihood");
+        struct Put { std::map<std::string, float>& m; Stage& s; ~Put() { m["Timing/Likelihood_computation/ms"] = s.ms(); } } put{_stats, st};
         std::map<int, float> likelihood;
         if (ids.empty()) { fprintf(stderr, "[WARN] ids list is empty\n"); return likelihood; }   // :2227-2231
         const std::vector<std::pair<int, float> >& v = sortedLikelihood();
@@ -279,6 +319,8 @@ std::map<int, float> MemoryHip::computeLikelihood(int signatureId, const std::li
 
 void MemoryHip::computeLikelihood(int signatureId, const std::list<int>& ids, std::map<int, float>& likelihood) {
     if (_likeSig == 0 || _likeSig != signatureId || !_signatures.count(signatureId) || ids.empty()) { likelihood = this->computeLikelihood(signatureId, ids); return; }
+    Stage st(_vwd, "Memory::computeLikelihood");
+    struct Put { std::map<std::string, float>& m; Stage& s; ~Put() { m["Timing/Likelihood_computation/ms"] = s.ms(); } } put{_stats, st};
     const std::vector<std::pair<int, float> >& v = sortedLikelihood();
     size_t cursor = 0;
     std::map<int, float>::iterator m = likelihood.begin();

@@ -75,6 +75,14 @@ public:
     bool flushReferences() { return _vwd->flushReferences([this](int s) { return this->getNi(s); }); }
     // the same after many addSignature calls (a memory replayed without a database): ONE bulk registration
     bool flushReferencesBulk() { return _vwd->flushReferencesBulk([this](int s) { return this->getNi(s); }); }
+    // The statistics of the last update() / computeLikelihood() / forget() under the reference's names (Statistics.h:178,189,190,200,201,
+    // 209-212; emitted at Memory.cpp:5931,6062 and Rtabmap.cpp:4357,4367): "TimingMem/Pre_update/ms", "TimingMem/Joining_dictionary_update/ms"
+    // (0: update() runs in line, there is no PreUpdateThread to join), "TimingMem/Add_new_words/ms", "Timing/Likelihood_computation/ms",
+    // "Timing/Forgetting/ms", "Keypoint/Dictionary_size/words", "Keypoint/Current_frame/words", "Keypoint/Indexed_words/words",
+    // "Keypoint/Index_memory_usage/KB" (the engine's HBM, lcd_stats.bytes_device -- the reference reports FLANN's memory here).
+    // The three Keypoint/ engine figures are refreshed by refreshEngineStatistics() (lcd_get_stats synchronises the stream: not per frame).
+    const std::map<std::string, float>& getStatistics() const { return _stats; }
+    void refreshEngineStatistics();
     const std::string& lastError() const { return _vwd->lastError(); }
     const std::string& loadError() const { return _loadError; }        // of the last loadDataFromDb that returned -1
 
@@ -97,6 +105,7 @@ private:
     std::vector<std::pair<int, float> > _likeSorted;   // (signature id, value) ascending id, built on demand from _likeSlots
     bool _likeSortedValid;
     const std::vector<std::pair<int, float> >& sortedLikelihood();
+    std::map<std::string, float> _stats;
 };
 
 }  // namespace rtabmap_amd

@@ -102,6 +102,19 @@ int hmem_add_signature(void* h, int id, const int* wordIds, int n) {
     return ((MemoryHip*)h)->addSignature(std::vector<int>(wordIds, wordIds + n), id);
 }
 void hmem_forget(void* h, int sigId) { ((MemoryHip*)h)->forget(sigId); }
+// the statistics under the reference's names (MemoryHip::getStatistics): value of `name`, -1 if there is no such key; name == NULL: the
+// number of keys; refresh != 0: the engine figures are read first (synchronises)
+float hmem_statistic(void* h, const char* name, int refresh) {
+    MemoryHip* m = (MemoryHip*)h;
+    if (refresh) m->refreshEngineStatistics();
+    if (!name) return (float)m->getStatistics().size();
+    std::map<std::string, float>::const_iterator it = m->getStatistics().find(name);
+    return it == m->getStatistics().end() ? -1.0f : it->second;
+}
+int hmem_set_engine_option(void* h, const char* key, long value) {
+    VWDictionaryHip* d = ((MemoryHip*)h)->getVWDictionary();
+    return d->engine() ? lcd_set_option(d->engine(), key, (int64_t)value) : -1;
+}
 int hmem_get_ni(void* h, int sigId) { return ((MemoryHip*)h)->getNi(sigId); }
 long hmem_num_signatures(void* h) { return (long)((MemoryHip*)h)->signaturesSize(); }
 int hmem_compute_likelihood(void* h, const int* words, int nwords, const int* ids, int nids, int* outIds, float* out) {

@@ -92,6 +92,9 @@ def lib():
         L.hmem_update.argtypes = [vp, vp, ci, ci, ci, ci, vp]
         L.hmem_add_signature.argtypes = [vp, ci, vp, ci]
         L.hmem_forget.argtypes = [vp, ci]
+        L.hmem_statistic.argtypes = [vp, C.c_char_p, ci]
+        L.hmem_statistic.restype = C.c_float
+        L.hmem_set_engine_option.argtypes = [vp, C.c_char_p, C.c_long]
         L.hmem_get_ni.argtypes = [vp, ci]
         L.hmem_num_signatures.argtypes = [vp]
         L.hmem_num_signatures.restype = C.c_long
@@ -226,6 +229,20 @@ class MemoryHip:
 
     def forget(self, sig_id):
         lib().hmem_forget(self.h, sig_id)
+
+    STAT_NAMES = ("TimingMem/Pre_update/ms", "TimingMem/Joining_dictionary_update/ms", "TimingMem/Add_new_words/ms",
+                  "Timing/Likelihood_computation/ms", "Timing/Forgetting/ms", "Keypoint/Dictionary_size/words",
+                  "Keypoint/Current_frame/words", "Keypoint/Indexed_words/words", "Keypoint/Index_memory_usage/KB")
+
+    def statistics(self, refresh=False):
+        """MemoryHip::getStatistics(): the reference's statistic names (Statistics.h:178-212) -> value of the last frame."""
+        out = {}
+        for k, name in enumerate(self.STAT_NAMES):
+            out[name] = float(lib().hmem_statistic(self.h, name.encode(), 1 if (refresh and k == 0) else 0))
+        return out
+
+    def set_engine_option(self, key, value):
+        return int(lib().hmem_set_engine_option(self.h, key.encode(), int(value)))
 
     def load_data_from_db(self, path, last_state_only=True):
         """Memory::loadDataFromDb from a RTAB-Map database file (MemoryHip::loadDataFromDb, rtabmap_amd/host/DbLoaderHip.h): the

@@ -407,3 +407,40 @@ def test_engine_rebuilt_from_the_host_mirror(oracle, kind):
             o.forget(so - W)
             h.forget(so - W)
     h.close()
+
+
+def test_statistics_carry_the_reference_names_and_roctx_ranges_do_not_change_results(oracle):
+    """SURVEY.md section 5, tracing row: MemoryHip reports the stages the reference times under the reference's statistic names
+    (Statistics.h:178,189-190,200-201,209-212; emitted at Memory.cpp:5931,6062, Rtabmap.cpp:4357,4367), and with lcd_set_option("roctx", 1)
+    the engine and the mirror bracket their stages with roctx ranges -- word ids and likelihood stay the oracle's with the ranges on."""
+    from rtabmap_amd.vwdictionary import MemoryHip
+    frames = _frames("surf", 8, 120)
+    o = oracle.OracleMemory(strategy=oracle.kNNBruteForce, nndr=0.8, new_words_compared_together=True)
+    h = MemoryHip(nndr=0.8, new_words_compared_together=True)
+    st0 = h.statistics()
+    assert set(st0) == set(MemoryHip.STAT_NAMES) and all(v == 0.0 for v in st0.values())      # every key exists from the start (Statistics::_defaultData)
+    for name in MemoryHip.STAT_NAMES:                                                       # "<Prefix>/<Name>/<unit>" as RTABMAP_STATS builds them
+        assert name.count("/") == 2 and name.split("/")[0] in ("Timing", "TimingMem", "Keypoint")
+    for t, desc in enumerate(frames):
+        if t == 3:
+            rc = h.set_engine_option("roctx", 1)        # the engine exists from the first update() on
+            assert rc in (0, 5), rc                     # LCD_OK, or LCD_ERR_UNSUPPORTED where libroctx64.so is not installed
+        so, ido = o.update(desc)
+        sh, idh = h.update(desc)
+        assert so == sh and idh == ido, "frame %d" % t
+        ids = np.array(o.signature_ids(), np.int32)
+        oi, Lo = o.compute_likelihood(np.array(ido, np.int32), ids)
+        hi, Lh = h.compute_likelihood_of(sh, ids)
+        assert oi.tolist() == hi.tolist()
+        np.testing.assert_allclose(Lh, Lo, rtol=RTOL, atol=ATOL, err_msg="frame %d" % t)
+        if so > 5:
+            o.forget(so - 5)
+            h.forget(so - 5)
+    st = h.statistics(refresh=True)
+    assert st["TimingMem/Add_new_words/ms"] > 0.0 and st["TimingMem/Pre_update/ms"] > 0.0 and st["Timing/Likelihood_computation/ms"] > 0.0
+    assert st["Timing/Forgetting/ms"] > 0.0 and st["TimingMem/Joining_dictionary_update/ms"] == 0.0
+    assert st["Keypoint/Current_frame/words"] == 120.0
+    assert st["Keypoint/Dictionary_size/words"] == float(o.vwd.visual_words)
+    assert st["Keypoint/Indexed_words/words"] == float(h.vwd.indexed_words)
+    assert st["Keypoint/Index_memory_usage/KB"] > 0.0
+    h.close()
