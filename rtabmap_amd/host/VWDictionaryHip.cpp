@@ -475,7 +475,26 @@ bool VWDictionaryHip::addNewWordsAndScore(const Mat& descriptorsIn, int signatur
         if (rc != LCD_ERR_UNSUPPORTED) logError("%s", _lastError.c_str());
         return false;                                                               // nothing was registered: the caller takes the slow path
     }
-    if (nSlots != (int64_t)_slotSig.size() + 1) {                                   // the mirror of the slot table is out of step: do not guess
+    // Validate the device's answer BEFORE the host maps change (an incremental dictionary gives every descriptor a word: code 0 cannot
+    // occur; the frame's k-th new word appears first as code -(k + 1), in order).  A result that fails this is not repaired by guessing:
+    // the signature and the rows the device registered are dropped with the handle, the engine is replayed from the host maps (which are
+    // untouched), and the caller takes the call-by-call path -- whose padding of missing ids (Memory.cpp:6029-6046) then applies.
+    {
+        int next = 0; bool ok = true;
+        for (int i = 0; i < q && ok; ++i) {
+            if (out[i] == 0) ok = false;
+            else if (out[i] < 0) { const int k = -out[i] - 1; if (k == next) next += 1; else if (k > next) ok = false; }
+        }
+        if (!ok) {
+            _lastError = "inconsistent word ids returned by the device (engine replayed from the host mirror)";
+            logError("%s", _lastError.c_str());
+            likelihoodBySlot.clear();
+            this->rebuildEngine();
+            return false;
+        }
+    }
+    const bool slotsOk = nSlots == (int64_t)_slotSig.size() + 1;
+    if (!slotsOk) {                                                                 // the mirror of the slot table is out of step: do not guess
         _lastError = "slot table of the device and its host mirror differ";
         logError("%s", _lastError.c_str());
         likelihoodBySlot.clear();
@@ -499,8 +518,7 @@ bool VWDictionaryHip::addNewWordsAndScore(const Mat& descriptorsIn, int signatur
                 sw.push_back(vw->id());
                 continue;
             }
-            if (k > (int)created.size()) { logError("inconsistent new-word index returned by the device"); break; }
-            id = created[k];                                                        // a word created earlier in this call (:1140-1160, :1207)
+            id = created[k];                                                        // a word created earlier in this call (:1140-1160, :1207; k validated above)
         } else if (w > 0) id = w;
         else continue;
         VisualWord* vwRef = lookupWord(id);                                         // addWordRef (:880-897) without the dirty mark
@@ -514,6 +532,9 @@ bool VWDictionaryHip::addNewWordsAndScore(const Mat& descriptorsIn, int signatur
     _totalActiveReferences += (int)_notIndexedWords.size();   // :1227 (sic)
     _deviceSigs.insert(signatureId);
     slotAdd(signatureId);
+    // a slot table that was out of step stays out of step: the engine (a cache of these maps) is replayed from them -- slots, rows and
+    // references are then the mirror's again; the frame's likelihood is not reported (the caller computes it the plain way)
+    if (!slotsOk) this->rebuildEngine();
     return true;
 }
 
