@@ -63,6 +63,8 @@ struct lcd_engine {
         lcd::DevBuf d_qsplit, d_qnorm;                  // the frame's queries pre-split into bf16 matrix-core operands, their norms
         lcd::DevBuf d_applist;                          // deferred append: which descriptors of the frame became words (AppendArgs::list_out)
         lcd::DevBuf d_cross;                            // the frame's distances to the descriptors of the frame before it (PipeKnn::cross)
+        lcd::DevBuf d_shadow_bf, d_shadow_norm, d_newmask;   // shadow rows: the frame's descriptors as operand-table rows + augmentation entries (written by its
+                                                        // query pre-split), its final new-word mask + prefix sums (written by its decision loop)
         bool fail_count_clean = false;
     };
     static constexpr int PIPE_SETS = 4;                 // a frame's set is in use for four calls (pre-split .. registration)
@@ -73,6 +75,7 @@ struct lcd_engine {
     struct InFlight {
         lcd_frame_args a; lcd::ResolveArgs r; int set = 0;
         uint64_t vseq = 0; bool chained = false;        // the frame takes part in the device row-count chain (vcnt_active at its call)
+        bool has_shadow = false;                        // its query pre-split also wrote its shadow rows (FrameScratch::d_shadow_bf)
         lcd::WsRuns runs; bool reserved = false;        // postings keys of its new words (reserved when its decision loop is prepared)
         int stage = 0;                                  // what is owed next: 0 filter + re-rank, 1 the decision loop, 2 registration + scoring
         std::vector<int32_t> retire_after;              // lcd_sig_remove calls made while this was the newest frame

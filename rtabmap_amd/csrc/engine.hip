@@ -1240,7 +1240,8 @@ int lcd_engine::drain(bool rows) {
 
 // The 2-NN stage of an in-flight frame, planned when its filter is about to be launched (the row count may have grown since the frame was
 // submitted): scratch of the frame's ring set, launch plan, and the arguments its decision loop will need one launch later.
-static int build_knn(lcd_engine* h, lcd_engine::InFlight& f, PipeKnn* kp) {
+// f_sh: the frame whose decision loop rides in the same launch A and whose shadow rows this filter ranks (NULL: none)
+static int build_knn(lcd_engine* h, lcd_engine::InFlight& f, PipeKnn* kp, const lcd_engine::InFlight* f_sh) {
     PipeKnn& k = *kp;
     const lcd_frame_args& a = f.a;
     const int q = a.q;
@@ -1262,10 +1263,17 @@ static int build_knn(lcd_engine* h, lcd_engine::InFlight& f, PipeKnn* kp) {
         k.plan.tiles_per_block = h->strip_tiles; k.plan.n_blocks = (n_tiles + h->strip_tiles - 1) / h->strip_tiles; k.plan.one_strip = 1;
         k.plan.f16 = h->f16();
     }
+    if (f_sh && !knn_bf16_persistent(k.plan) && plan_rows < (int64_t)SHADOW_ROW_BASE) {
+        const lcd_engine::FrameScratch& ss = h->ring[f_sh->set];
+        k.plan.n_shadow = knn_shadow_strips(f_sh->a.q);
+        k.sh_bf = ss.d_shadow_bf.p; k.sh_norm = ss.d_shadow_norm.as<float>(); k.sh_rows = (f_sh->a.q + 63) / 64 * 64;
+        k.sh_mask = ss.d_newmask.as<uint32_t>(); k.sh_q = f_sh->a.q;
+    }
     {   // the candidate records: sized for this plan AND for the one the upper bound would get (a growing vocabulary crosses the planner's
         // thresholds: a reallocation drains the stream)
         size_t bytes = knn_bf16_partial_bytes(k.plan);
-        if (f.chained) bytes = std::max(bytes, knn_bf16_partial_bytes(knn_bf16_plan_pipelined(q, (int)(rows_bound + 8 * (int64_t)q), together ? knn_selfdist_wgs(q) : 0, h->filter_units)));
+        if (h->popt.shadow_rows) { MfmaPlan worst = k.plan; worst.n_shadow = knn_shadow_strips(4096); bytes = std::max(bytes, knn_bf16_partial_bytes(worst)); }   // (no reallocation when a frame gets shadow strips)
+        if (f.chained) bytes = std::max(bytes, (h->popt.shadow_rows ? (size_t)knn_shadow_strips(4096) * (size_t)((q + 63) / 64 * 64) * 20 : 0) + knn_bf16_partial_bytes(knn_bf16_plan_pipelined(q, (int)(rows_bound + 8 * (int64_t)q), together ? knn_selfdist_wgs(q) : 0, h->filter_units)));
         LCD_HIP(h, ring_reserve(h, f.set, &lcd_engine::FrameScratch::d_partial2, bytes));
     }
     LCD_HIP(h, ring_reserve(h, f.set, &lcd_engine::FrameScratch::d_partial3, knn_rowpar_partial_bytes((int)(rows_bound + (f.chained ? 8 * (int64_t)q : 0)), q)));
@@ -1326,6 +1334,9 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
         tl_res.r.new_ws = f_res->runs;
         refresh_vocab_ptrs(h, &tl_res.r);
         if (f_res->chained) fill_append(h, f_res->a, f_res->vseq, frame_appends(h, f_res->a), &tl_res.r, h->ring[f_res->set].d_applist.as<uint32_t>());
+        // the pinned row-count mirror is a store to HOST memory, waited for at the end of the decision loop's chain: with "mirror_from_b" a
+        // workgroup of launch B of this pair (which writes the frame's rows anyway) stores it instead
+        if (h->popt.mirror_from_b && tl_res.r.ap.enabled && tl_res.r.ap.defer_rows) tl_res.r.ap.mirror_later = 1;
         resolve_launch_info(tl_res.r, pipe_block_size(), &tl_res.n_redo, &tl_res.shmem_resolve);
     }
     lap.lap(2);
@@ -1341,7 +1352,12 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
     }
     lap.lap(3);
     PipeKnn k;
-    if (f_knn) { int rc = build_knn(h, *f_knn, &k); if (rc) return rc; h->knn_launches += 1; }
+    // shadow rows: f_res's new words are not rows when f_knn's filter runs (its decision loop rides in the same launch) -- the filter ranks f_res's
+    // descriptors from the operand rows its query pre-split left, the re-rank keeps the ones the mask f_res's decision loop publishes names
+    const bool sh_ok = f_knn && f_res && f_res->has_shadow && f_res->chained && f_knn->chained && tl_res.r.ap.enabled && tl_res.r.ap.defer_rows && tl_res.r.ap.is_f32_64 &&
+                       h->popt.shadow_rows && !h->popt.cross_frames;
+    if (f_knn) { int rc = build_knn(h, *f_knn, &k, sh_ok ? f_res : nullptr); if (rc) return rc; h->knn_launches += 1; }
+    if (f_res && f_res->has_shadow && tl_res.r.ap.enabled && tl_res.r.ap.defer_rows) tl_res.r.ap.mask_out = h->ring[f_res->set].d_newmask.as<uint32_t>();
     if (f_knn && f_res && tl_res.r.ap.enabled && tl_res.r.ap.defer_rows && tl_res.r.ap.is_f32_64 && h->popt.cross_frames) {
         // The rows f_res appends (its decision loop rides in this launch A) are descriptors of f_res, and f_knn's re-rank (this launch B)
         // must scan them exactly: extra distance tiles of launch A compute f_knn x f_res in the reference's arithmetic, the re-rank reads
@@ -1470,14 +1486,22 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     }
     if (chained && !h->inflight.empty() && h->dtype == LCD_F32 && h->kdim == 64 && h->popt.cross_frames)   // (pipeline_launch: this frame x the frame before it)
         LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_cross, (size_t)q * ((h->inflight.back().a.q + 63) / 64 * 64) * 4));
+    // shadow rows: a frame that appends on the device leaves its descriptors as operand-table rows too, for the filter of the frame behind it
+    const bool with_shadow = chained && app && h->popt.shadow_rows && h->dtype == LCD_F32 && h->kdim == 64 && q <= 4096;
+    if (with_shadow) {
+        LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_shadow_bf, (size_t)ld * 256));
+        LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_shadow_norm, (size_t)(ld + 1) * 8));
+        LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_newmask, (size_t)(2 * (ld / 32) + 4) * 4));
+    }
     QSplitArgs qs;
     qs.queries = (const float*)a->d_descriptors; qs.nq = q; qs.qpad = ld; qs.qsplit = (uint4*)sc.d_qsplit.p; qs.qnorm = sc.d_qnorm.as<float>(); qs.n_wgs = 0; qs.f16 = h->f16();
+    if (with_shadow) { qs.shadow_bf = sc.d_shadow_bf.as<uint32_t>(); qs.shadow_norm = sc.d_shadow_norm.as<float>(); qs.norm_max_bits = h->norm_max.as<uint32_t>(); }
     lap0.lap(1);
     // ---- what the frames in flight owe rides with this frame's launches
     { int rc = pipeline_launch(h, &qs); if (rc) return rc; }
     // ---- this frame's filter, re-rank, decision loop, registration and scoring are owed from here on
     lcd_engine::InFlight nf;
-    nf.a = *a; nf.set = set; nf.stage = 0; nf.vseq = vseq; nf.chained = chained;
+    nf.a = *a; nf.set = set; nf.stage = 0; nf.vseq = vseq; nf.chained = chained; nf.has_shadow = with_shadow;
     if (chained) { h->unreconciled.push_back(lcd_engine::DevAppend{vseq, a->first_new_word_id, q, app}); h->vseq += 1; }
     h->inflight.push_back(std::move(nf));
     h->frame_seq += 1;
@@ -2021,6 +2045,9 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     // timing experiments: the filter workgroups of launch A wait value x 64 clocks in front of their first request (the single-workgroup
     // chains of the launch then get their first round trip ahead of the strips' opening burst)
     if (!std::strcmp(key, "filter_delay") && value >= 0 && value <= 127) { h->popt.filter_delay = (int)value; return LCD_OK; }
+    if (!std::strcmp(key, "shadow_rows") && value >= -1 && value <= 1) { h->popt.shadow_rows = value > 0 ? 1 : 0; return LCD_OK; }
+    if (!std::strcmp(key, "mirror_from_b") && value >= -1 && value <= 1) { h->popt.mirror_from_b = value > 0 ? 1 : 0; return LCD_OK; }
+    if (!std::strcmp(key, "row_writer_wgs") && value >= -1 && value <= 256) { h->popt.row_writer_wgs = value > 0 ? (int)value : 0; return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");
     LCD_CATCH(h)
 }

@@ -250,10 +250,12 @@ __device__ __forceinline__ void append_publish(const AppendArgs& ap, int q, cons
     if (n_take > 0)
         for (int i = threadIdx.x; i < q; i += NT)
             if ((mask[i >> 5] >> (i & 31)) & 1u) ap.list_out[new_rank(mask, prefix, i)] = (uint32_t)i;
+    if (ap.mask_out)                                    // (zeros when nothing is appended: no shadow row is a word then)
+        for (int w = threadIdx.x; w < 2 * mw + 1; w += NT) ap.mask_out[w] = n_take > 0 ? (w < mw ? mask[w] : prefix[w - mw]) : 0u;
     if (threadIdx.x == 0 && n_in >= 0) {
         ap.cnt_out[0] = n_in + n_take;
         if (ap.log_slot) ap.log_slot[0] = n_take;
-        if (ap.host_mirror) __hip_atomic_store(ap.host_mirror, ((unsigned long long)ap.tag << 32) | (unsigned long long)(uint32_t)(n_in + n_take), __ATOMIC_RELAXED,
+        if (ap.host_mirror && !ap.mirror_later) __hip_atomic_store(ap.host_mirror, ((unsigned long long)ap.tag << 32) | (unsigned long long)(uint32_t)(n_in + n_take), __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -296,6 +298,9 @@ __device__ __forceinline__ void append_rows_body(const AppendRowsArgs& A, int wg
         }
     }
     if (ap.is_f32_64) append_norm_max(ap, norm_max);
+    // (AppendArgs::mirror_later: the decision loop left the pinned mirror to this launch)
+    if (ap.mirror_later && ap.host_mirror && wg == 0 && threadIdx.x == 0)
+        __hip_atomic_store(ap.host_mirror, ((unsigned long long)ap.tag << 32) | (unsigned long long)(uint32_t)(n_in + n_new), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <int NT>

@@ -842,6 +842,27 @@ __device__ __forceinline__ void qsplit_item(const QSplitArgs& qs, int t, const f
     part += __shfl_xor(part, 2, 64);
     part += __shfl_xor(part, 4, 64);
     if ((t & 7) == 0) qs.qnorm[qi] = part;
+    if (qs.shadow_bf) {                                                  // the descriptor as a ROW of an operand table (vocab_bf16_kernel's layout): floats [32 h + 8 sx, + 8)
+        uint4 rh, rl;
+        op_split2_rt(qs.f16, a.x, a.y, rh.x, rl.x);
+        op_split2_rt(qs.f16, a.z, a.w, rh.y, rl.y);
+        op_split2_rt(qs.f16, b.x, b.y, rh.z, rl.z);
+        op_split2_rt(qs.f16, b.z, b.w, rh.w, rl.w);
+        uint4* row = reinterpret_cast<uint4*>(qs.shadow_bf + (size_t)qi * 64);
+        row[4 * h + sx] = rh;
+        row[8 + 4 * h + sx] = rl;
+        if ((t & 7) == 0) {                                              // padding rows (they repeat the last descriptor) never rank: |row|^2 = +inf
+            qs.shadow_norm[2 * (size_t)qi] = qi < qs.nq ? part : __int_as_float(0x7f800000);
+            qs.shadow_norm[2 * (size_t)qi + 1] = 1.0f;
+            if (t == 0) { qs.shadow_norm[2 * (size_t)qs.qpad] = __int_as_float(0x7f800000); qs.shadow_norm[2 * (size_t)qs.qpad + 1] = 1.0f; }   // the sentinel
+        }
+        // the filter's error bound is made from the largest |row|^2 the filter may have multiplied: these rows are among them from the next launch on
+        // (a running maximum: raising it early only widens the bound); one atomic per wave
+        float nm = qi < qs.nq ? part : 0.0f;
+#pragma unroll
+        for (int m = 32; m >= 8; m >>= 1) nm = fmaxf(nm, __shfl_xor(nm, m, 64));
+        if (qs.norm_max_bits && (threadIdx.x & 63) == 0 && nm > 0.0f) atomicMax(qs.norm_max_bits, __float_as_uint(nm));
+    }
 }
 // One item = eight floats of one query.  A thread's items are READ first and written afterwards: loads and stores share one in-order
 // counter, so a second trip's loads behind a first trip's stores wait for a store round trip that carries no data (round 4's stamps:
@@ -865,7 +886,9 @@ template <int M>
 __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
                                                        int n_rows, const uint4* qsplit, const float* qnorm, int nq, int qpad,
                                                        int tiles_per_block, int n_blocks, uint64_t* __restrict__ partial_keys,
-                                                       uint32_t* __restrict__ partial_bound, const SelfdistJob& sd, const int32_t* __restrict__ n_lo) {
+                                                       uint32_t* __restrict__ partial_bound, const SelfdistJob& sd, const int32_t* __restrict__ n_lo,
+                                                       const float* __restrict__ sh_bf = nullptr, const float* __restrict__ sh_norm = nullptr, int sh_rows = 0,
+                                                       int sh_blocks = 0) {
     constexpr int NG = 4;
     constexpr int NW = MF_WAVES;
     constexpr int QW = NG * 32;
@@ -875,16 +898,23 @@ __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, co
     int lo_rows = 0x7fffffff;
     if (n_lo) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lo_rows) : "s"(n_lo) : "memory");
     lo_rows = min(lo_rows, n_rows);                                       // (the plan's n_rows may be an estimate below the device's count)
-    const int n_fwg = n_blocks * ((nq + BF_QB - 1) / BF_QB);
+    const int n_strips = n_blocks + sh_blocks;                            // vocabulary strips, then the strips over the shadow rows
+    const int n_fwg = n_strips * ((nq + BF_QB - 1) / BF_QB);
     if (bid >= n_fwg) { selfdist_tile(sd, bid - n_fwg, s_dyn); return; }
-    const int bx = bid % n_blocks, by = bid / n_blocks;
+    const int bx = bid % n_strips, by = bid / n_strips;
+    // A shadow strip multiplies the operand rows the frame before wrote of its own descriptors (qsplit_item): every one of them is visible (the
+    // padding carries +inf), eight tiles per strip, and its keys name rows SHADOW_ROW_BASE + descriptor index -- the re-rank keeps the ones whose
+    // descriptor became a word.  Everything below is the same code on other pointers.
+    const bool shadow = bx >= n_blocks;
+    if (shadow) { vocab_bf = sh_bf; row_norm = sh_norm; n_rows = sh_rows; lo_rows = sh_rows; tiles_per_block = MF_STRIP_TILES; }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 31, half = lane >> 5;
     const int q0 = by * BF_QB + wave * QW;
     float* s_aug = s_dyn + (size_t)MF_STRIP_TILES * BF_TILE_F;          // [MF_STRIP_TILES][64]
     MF_STAMP(0);
-    const int tile0 = bx * tiles_per_block;
+    const int tile0 = (shadow ? bx - n_blocks : bx) * tiles_per_block;
+    const int key_tile0 = tile0 + (shadow ? (int)(SHADOW_ROW_BASE / 32u) : 0);
     const int n_tiles = (n_rows + 31) / 32;
     const int tile1 = min(tile0 + tiles_per_block, n_tiles);
     // First what the loop needs to start -- two tiles, the augmentation entries, the query operands -- and, once that has arrived, the
@@ -981,7 +1011,7 @@ __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, co
     MF_STAMP(2);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const uint64_t a0 = widen_key(k0[g], tile0, half), a1 = widen_key(k1[g], tile0, half), a2 = widen_key(k2[g], tile0, half);
+        const uint64_t a0 = widen_key(k0[g], key_tile0, half), a1 = widen_key(k1[g], key_tile0, half), a2 = widen_key(k2[g], key_tile0, half);
         const uint64_t b0 = shfl_xor_u64(a0, 32), b1 = shfl_xor_u64(a1, 32), b2 = shfl_xor_u64(a2, 32);
         const uint64_t m0 = a0 < b0 ? a0 : b0;
         const uint64_t hx = a0 < b0 ? b0 : a0, lx = a1 < b1 ? a1 : b1;
@@ -1292,6 +1322,17 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                                 // default since it passed the GPU suite; launch B 15.3 -> 13.8 us at the headline, profiles/r05_first_call.txt);
                                 // workgroup wr_index of wr_n
                                                      , const AppendRowsArgs& wr = AppendRowsArgs(), bool wr_on = false, int wr_index = 0, int wr_n = 1
+                                // rows_only (round 6, PipeOpts::row_writer_wgs): this workgroup re-ranks nothing -- it is one of wr_n extra workgroups of
+                                // the re-rank ROLE that only write the appended rows (wr_index, wr_index + wr_n, ...), so that no re-rank workgroup has
+                                // the row stores at the end of its chain (the workgroups that wrote a row ended 3-4 us after those that did not) and
+                                // the kernel gets no third branch (whose register demand made the scoring branch spill)
+                                                     , bool rows_only = false
+                                // shadow rows (round 6): strips n_vocab_blocks .. n_blocks - 1 of the records are the filter's scores of the descriptors of the
+                                // frame before (sh_q of them; keys name rows SHADOW_ROW_BASE + j).  Descriptor j is a row of the vocabulary iff bit j of
+                                // sh_mask is set (the final new-word mask of that frame's decision loop, mw words, followed by its mw + 1 word prefix sums):
+                                // row n_lo0 + rank(j), word pend_first_id + rank(j), read from pend_desc -- an exact candidate like any other, in the same
+                                // round trip.  The rows [n_lo0, p_hi) then need no scan of their own (and are written by the rows_only workgroups).
+                                                     , const uint32_t* __restrict__ sh_mask = nullptr, int sh_q = 0, int n_vocab_blocks = 0x7fffffff
                                                      ) {
     static_assert(DIM == 64, "16 lanes x 4 floats per candidate row");
     // rows [pend_lo[0], pend_hi[0]): words the previous frame created, appended on the device after this frame's filter took its
@@ -1300,8 +1341,16 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     // (the plan is made for an ESTIMATE of the row count: what lies between the rows it covered and the device's count is scanned here too)
     const int n_lo0 = pend_lo ? pend_lo[0] : 0;
     const int p_lo = pend_lo ? min(n_lo0, pend_cap) : 0, p_hi = pend_hi ? pend_hi[0] : 0;
+    // with shadow rows the pending scan only has to cover vocabulary rows the filter's plan did not reach ([p_lo, n_lo0): rare)
+    const int p_hi_s = sh_q > 0 ? min(p_hi, n_lo0) : p_hi;
     __shared__ uint32_t s_plist[HALVES * MF_BLOCK];                    // the first entries of pend_list (one per thread: read with the keys)
     const uint32_t plreg = pend_list ? pend_list[threadIdx.x] : 0u;    // (the list buffer holds at least HALVES * MF_BLOCK entries)
+    constexpr int SH_MW_MAX = 128;                                     // mask words of a frame of 4 096 descriptors
+    __shared__ uint32_t s_shmask[2 * SH_MW_MAX + 1];
+    const int sh_mw = sh_q > 0 ? (sh_q + 63) / 64 * 2 : 0;
+    const uint32_t shreg = (sh_q > 0 && (int)threadIdx.x < 2 * sh_mw + 1) ? sh_mask[threadIdx.x] : 0u;
+    auto sh_isword = [&](uint32_t j) -> bool { return (s_shmask[j >> 5] >> (j & 31)) & 1u; };
+    auto sh_rank = [&](uint32_t j) -> int { return (int)(s_shmask[sh_mw + (j >> 5)] + (uint32_t)__popc(s_shmask[j >> 5] & ((1u << (j & 31)) - 1u))); };
     const int hf = HALVES == 2 ? (int)threadIdx.x / MF_BLOCK : 0;
     const int tid = HALVES == 2 ? (int)threadIdx.x % MF_BLOCK : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // The pending rows are the same for every query: with a staging area they come in by LDS-DMA -- no registers, requested HERE, a
@@ -1353,10 +1402,10 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     // half hf's value j at xd[hf * XD_MAX + j].  Not when rows of the vocabulary itself are pending (the plan covered fewer rows than exist).
     constexpr int XD_MAX = 2048, XD_OWN = 32;                           // pending rows / rows of its own a workgroup can take this way (40 KB of LDS)
     const int n_own = (wr_on && p_hi - n_lo0 > wr_index) ? (p_hi - n_lo0 - wr_index + wr_n - 1) / wr_n : 0;
-    const bool use_cross = cross != nullptr && pend_list != nullptr && stage != nullptr && stage_rows >= XD_OWN + HALVES * XD_MAX / DIM && p_hi > p_lo && p_lo == n_lo0 &&
+    const bool use_cross = sh_q == 0 && cross != nullptr && pend_list != nullptr && stage != nullptr && stage_rows >= XD_OWN + HALVES * XD_MAX / DIM && p_hi > p_lo && p_lo == n_lo0 &&
                            p_hi - p_lo <= XD_MAX && n_own <= XD_OWN;
     float* const xd = stage + XD_OWN * DIM;
-    const bool staged = stage != nullptr && stage_rows >= 4 && p_hi > p_lo && !use_cross;
+    const bool staged = stage != nullptr && stage_rows >= 4 && p_hi_s > p_lo && !use_cross;
     // rows [n_lo0, p_hi) ARE the rows of the deferred append, and every re-rank workgroup has them in its staging area: workgroup wr_index
     // of wr_n writes rows wr_index, wr_index + wr_n, ... (16 lanes per row) -- no workgroups of their own, no third branch in the kernel (whose
     // presence makes the scoring branch spill).  Stores only, at the END of the body: a read behind them would wait for them.
@@ -1379,6 +1428,55 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         }
         append_norm_max(ap, nmax);
     };
+    // the pinned row-count mirror of the frame whose rows this launch writes, when its decision loop left it to this launch (AppendArgs::mirror_later):
+    // one thread of the launch, at the END of its workgroup's body (a store to host memory in front of a load would hold that load for its acknowledgement)
+    auto store_mirror = [&]() {
+        if (wr.ap.mirror_later && wr.ap.host_mirror && wr_on && wr_index == 0 && threadIdx.x == 0)
+            __hip_atomic_store(wr.ap.host_mirror, ((unsigned long long)wr.ap.tag << 32) | (unsigned long long)(uint32_t)p_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    if (rows_only) {                                                   // (uniform over the workgroup)
+        const int n_new = p_hi - n_lo0;
+        if (!wr_on || stage == nullptr || stage_rows < 4 || pend_list == nullptr || n_new <= wr_index) { store_mirror(); return; }
+        s_plist[threadIdx.x] = plreg;
+        lds_barrier();
+        const int wv = (int)threadIdx.x >> 6, ln = (int)threadIdx.x & 63;
+        const int n_mine = (n_new - wr_index + wr_n - 1) / wr_n;       // rows wr_index + wr_n m, m < n_mine
+        const int cap = stage_rows & ~3;
+        for (int m0 = 0; m0 < n_mine; m0 += cap) {                     // (one chunk unless a frame creates more than wr_n x 160 words)
+            const int n_chunk = min(cap, n_mine - m0);
+            if (m0 > 0) __syncthreads();
+            for (int i = wv; i * 4 < n_chunk; i += HALVES * MF_WAVES) { // four rows per instruction, laid out as stage_chunk does
+                const int rl = min(i * 4 + (ln >> 4), n_chunk - 1);
+                const int chunk = (ln & 15) ^ ((i * 4 + (ln >> 4)) & 15);
+                const int j = wr_index + wr_n * (m0 + rl);
+                const float* src = pend_desc + (size_t)(j < HALVES * MF_BLOCK ? s_plist[j] : pend_list[j]) * DIM;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + chunk * 4),
+                                                 (__attribute__((address_space(3))) void*)(stage + (size_t)i * 256), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            {   // write_rows(own = true) over this chunk: staged row m is new word wr_index + wr_n (m0 + m)
+                const AppendArgs& ap = wr.ap;
+                const int c16 = (int)threadIdx.x & 15;
+                float nmax = 0.0f;
+                for (int m = (int)threadIdx.x >> 4; m < n_chunk; m += HALVES * MF_BLOCK / 16) {
+                    const int j = wr_index + wr_n * (m0 + m);
+                    const int32_t key = (c16 == 0 && wr.new_ws.n > 0) ? ws_runs_at(wr.new_ws, j) : -1;
+                    const uint4 x = *reinterpret_cast<const uint4*>(stage + (size_t)m * DIM + ((c16 ^ (m & 15)) * 4));
+                    append_write_row(ap, (size_t)n_lo0 + (size_t)j, c16, x, nmax);
+                    if (c16 == 0) {
+                        const size_t row = (size_t)n_lo0 + (size_t)j;
+                        ap.row_id[row] = ap.first_id + j;
+                        ap.row_wslot[row] = key;
+                        if (key >= 0 && ap.wrow) ap.wrow[key] = (uint32_t)row + 1u;
+                    }
+                }
+                append_norm_max(ap, nmax);
+            }
+        }
+        store_mirror();
+        return;
+    }
     const bool valid = qi_first + hf < nq;                             // the odd query out: its half walks the last query again, writes nothing
     const int qi = valid ? qi_first + hf : nq - 1;
     __shared__ float s_thr_all[HALVES];
@@ -1427,7 +1525,11 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
 
     // ---- pass 1: tau and the bound on dropped rows
     uint32_t a0 = INF, a1 = INF, bound = breg0;
+    // (a shadow strip's key may owe its score to a descriptor that did NOT become a word: tau -- whose meaning is "two true rows lie this close" --
+    // is taken over the vocabulary strips alone; shadow keys at or below the threshold derived from it are candidates like any others, and the rows
+    // a shadow strip dropped are covered by its bound)
     auto see = [&](uint64_t k, int c) {
+        if (c / KEEP >= n_vocab_blocks) return;
         const uint32_t sc = min((uint32_t)(k >> 32), INF);                  // KEY_NONE -> +inf
         if (LAST_KEY_BOUNDS && (c % KEEP) == KEEP - 1) bound = min(bound, sc);   // rows the block merge dropped are no better than its last key
         const uint32_t h = max(a0, sc);
@@ -1452,8 +1554,12 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     // they share (a request in front of the keys would make the first use of a key wait for the whole chunk: the counter is in-order)
     // (measured in round 5, profiles/r05_ab_notes.txt 8: requested in FRONT of the keys instead, the driver's 20 steps take 0.0392-0.0401 ms
     // per frame against 0.0384-0.0390)
-    if (pend_list) { s_plist[threadIdx.x] = plreg; lds_barrier(); }
-    if (staged) stage_chunk(p_lo, min(stage_rows, p_hi - p_lo));
+    if (pend_list || sh_q > 0) {
+        s_plist[threadIdx.x] = plreg;
+        if ((int)threadIdx.x < 2 * sh_mw + 1) s_shmask[threadIdx.x] = shreg;
+        lds_barrier();
+    }
+    if (staged) stage_chunk(p_lo, min(stage_rows, p_hi_s - p_lo));
     if (use_cross) {
         const int wv = (int)threadIdx.x >> 6, ln = (int)threadIdx.x & 63;
         auto plist_at = [&](int j) -> uint32_t { return j < HALVES * MF_BLOCK ? s_plist[j] : pend_list[j]; };
@@ -1511,6 +1617,12 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     const int n_cand = overflow ? n_keys_in : n_keys_in * GS;           // candidate ROWS
     const uint32_t row_limit = (uint32_t)(pend_lo ? p_lo : pend_cap);
     auto cand_row = [&](int i) -> uint32_t { return (uint32_t)s_cand[GS == 4 ? (i >> 2) : i] + (GS == 4 ? (uint32_t)(i & 3) : 0u); };
+    // the vocabulary row a LIVE candidate stands for (the distance tie-break is by row): a shadow candidate is the row its descriptor is being
+    // written to in this very launch -- behind every row the filter saw, in word order
+    auto real_row = [&](int i) -> uint32_t {
+        const uint32_t r = cand_row(i);
+        return (sh_q > 0 && r >= SHADOW_ROW_BASE) ? (uint32_t)(n_lo0 + sh_rank(r - SHADOW_ROW_BASE)) : r;
+    };
     // ... get their exact distances (reference arithmetic, dist.h:150-177), one candidate per 16-lane group and trip; the word
     // id of the row is fetched in the same round trip
     float err_ratio = 0.0f;
@@ -1518,10 +1630,14 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         for (int i = tid >> 4; i < n_cand; i += MF_BLOCK / 16) {
             const uint64_t k = s_cand[GS == 4 ? (i >> 2) : i];
             const uint32_t row = cand_row(i);
-            const bool in_range = GS == 1 || row < row_limit;
+            const bool sh = sh_q > 0 && row >= SHADOW_ROW_BASE;           // (uniform over the wave: the four rows of ONE key)
+            const uint32_t sj = row - SHADOW_ROW_BASE;
+            const bool in_range = sh ? sj < (uint32_t)sh_q : (GS == 1 || row < row_limit);
             const uint32_t rrow = in_range ? row : (uint32_t)k;            // (an address that exists: the group's first row)
-            const float4 v4 = reinterpret_cast<const float4*>(vocab + (size_t)rrow * DIM)[lane & 15];
-            const int32_t wid = (lane & 15) == 0 ? row_id[rrow] : 0;
+            const float* src = sh ? pend_desc + (size_t)(in_range ? sj : (uint32_t)k - SHADOW_ROW_BASE) * DIM : vocab + (size_t)rrow * DIM;
+            const float4 v4 = reinterpret_cast<const float4*>(src)[lane & 15];
+            int32_t wid = 0;
+            if ((lane & 15) == 0) wid = sh ? ((in_range && sh_isword(sj)) ? pend_first_id + sh_rank(sj) : 0) : row_id[rrow];
             const float d0 = __fsub_rn(v4.x, q4.x), d1 = __fsub_rn(v4.y, q4.y), d2 = __fsub_rn(v4.z, q4.z), d3 = __fsub_rn(v4.w, q4.w);
             float t = __fmul_rn(d0, d0);
             t = __fadd_rn(t, __fmul_rn(d1, d1));
@@ -1531,8 +1647,10 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
 #pragma unroll
             for (int j = 0; j < 16; ++j) res = __fadd_rn(res, __shfl(t, (lane & 48) + j, 64));
             const bool live = in_range && (GS == 1 || __shfl(wid, lane & 48, 64) != 0);
+            const float res_raw = res;
             if (!live) res = __int_as_float(0x7f800000);
-            float gmin = res;                                            // the filter's score of a key is its group's minimum
+            // the filter's score of a key is its group's minimum -- over every descriptor of a shadow group, word or not (the filter saw them all)
+            float gmin = (sh && in_range) ? res_raw : res;
             if (GS == 4) { gmin = fminf(gmin, __shfl_xor(gmin, 16, 64)); gmin = fminf(gmin, __shfl_xor(gmin, 32, 64)); }
             if ((lane & 15) == 0) {
                 s_exact[i] = live ? (((uint64_t)__float_as_uint(res) << 32) | (uint32_t)i) : KEY_NONE;   // the slot stands in for the row: see below
@@ -1555,8 +1673,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
             for (int j = tid; j < p_hi - p_lo; j += MF_BLOCK)
                 top2_push(pb, ps, ((uint64_t)__float_as_uint(xd[hf * XD_MAX + j]) << 32) | (uint32_t)(p_lo + j));
         } else if (staged) {
-            for (int c0 = p_lo; c0 < p_hi; c0 += stage_rows) {
-                const int n_chunk = min(stage_rows, p_hi - c0);
+            for (int c0 = p_lo; c0 < p_hi_s; c0 += stage_rows) {
+                const int n_chunk = min(stage_rows, p_hi_s - c0);
                 if (c0 > p_lo) { __syncthreads(); stage_chunk(c0, n_chunk); }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -1580,16 +1698,16 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                     }
                     top2_push(pb, ps, ((uint64_t)__float_as_uint(res) << 32) | (uint32_t)(c0 + r));
                 }
-                if (wr_on && c0 + stage_rows < p_hi) write_rows(c0, n_chunk);   // (more than one chunk: the staging area is about to be reused;
+                if (wr_on && sh_q == 0 && c0 + stage_rows < p_hi) write_rows(c0, n_chunk);   // (more than one chunk: the staging area is about to be reused;
                                                                                 // the LAST chunk's rows are written at the very end of the body)
             }
         } else
-        for (int base = p_lo; base < (pend_list ? min(p_hi, n_lo0) : p_hi); base += PU * (MF_BLOCK / 16)) {   // (rows of a deferred append need the staged path)
+        for (int base = p_lo; base < (pend_list ? min(p_hi_s, n_lo0) : p_hi_s); base += PU * (MF_BLOCK / 16)) {   // (rows of a deferred append need the staged path)
             float4 v4[PU];
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
                 const int r0 = base + u * (MF_BLOCK / 16) + (tid >> 4);
-                v4[u] = reinterpret_cast<const float4*>(vocab + (size_t)min(r0, p_hi - 1) * DIM)[lane & 15];
+                v4[u] = reinterpret_cast<const float4*>(vocab + (size_t)min(r0, p_hi_s - 1) * DIM)[lane & 15];
             }
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
@@ -1602,10 +1720,10 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                 float res = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) res = __fadd_rn(res, __shfl(t, (lane & 48) + j, 64));
-                if ((lane & 15) == 0 && r0 < p_hi) top2_push(pb, ps, ((uint64_t)__float_as_uint(res) << 32) | (uint32_t)r0);
+                if ((lane & 15) == 0 && r0 < p_hi_s) top2_push(pb, ps, ((uint64_t)__float_as_uint(res) << 32) | (uint32_t)r0);
             }
         }
-        if (p_hi > p_lo) {                                             // uniform
+        if (p_hi_s > p_lo) {                                           // uniform
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) {
                 const uint64_t ob = shfl_xor_u64(pb, m), os = shfl_xor_u64(ps, m);
@@ -1627,7 +1745,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
             for (int i = lane; i < n_cand; i += 64) {
                 const uint64_t e = s_exact[i];
                 if (e == KEY_NONE) continue;                              // (a row of a key's group that is no candidate)
-                top2_push(best, second, (e & 0xFFFFFFFF00000000ull) | cand_row((int)(uint32_t)e));
+                top2_push(best, second, (e & 0xFFFFFFFF00000000ull) | real_row((int)(uint32_t)e));
             }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -1638,7 +1756,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
 #ifdef LCD_RR_SUBSTAMP
         RR_STAMP(4);
 #endif
-        if (p_hi > p_lo) {                                             // the pending rows' two best join (their rows differ from every kept key's)
+        if (p_hi_s > p_lo) {                                           // the pending rows' two best join (their rows differ from every kept key's)
 #pragma unroll
             for (int w = 0; w < MF_WAVES; ++w) { top2_push(best, second, s_pend[w][0]); top2_push(best, second, s_pend[w][1]); }
         }
@@ -1646,7 +1764,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         if (!overflow)
             for (int i = lane; i < n_cand; i += 64) {
                 if (s_exact[i] == KEY_NONE) continue;
-                const uint64_t key = (s_exact[i] & 0xFFFFFFFF00000000ull) | cand_row(i);
+                const uint64_t key = (s_exact[i] & 0xFFFFFFFF00000000ull) | real_row(i);
                 if (key == best) sbest = i;
                 if (key == second) ssecond = i;
             }
@@ -1729,10 +1847,11 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         __syncthreads();
         write_rows(0, n_own, true);
     }
-    if (wr_on && staged) {                                             // the last (usually the only) chunk is still in the staging area
+    if (wr_on && staged && sh_q == 0) {                                // the last (usually the only) chunk is still in the staging area
         const int c0_last = p_lo + ((p_hi - p_lo - 1) / stage_rows) * stage_rows;
         write_rows(c0_last, min(stage_rows, p_hi - c0_last));
     }
+    store_mirror();
 }
 
 template <int DIM, int KEEP, bool LAST_KEY_BOUNDS, bool BF16>
@@ -1764,6 +1883,7 @@ struct FilterArgs {
     uint64_t* pk; uint32_t* pl; SelfdistJob sd; const int32_t* n_lo;
     const uint4* qsplit; const float* qnorm;                           // pre-split queries (non-persistent pipelined launch)
     int delay;                                                         // PipeOpts::filter_delay (timing experiments)
+    const float* sh_bf; const float* sh_norm; int sh_rows, sh_blocks;  // shadow rows of the frame before (PipeKnn::sh_bf): sh_blocks extra strips
 };
 struct RerankArgs {
     const uint64_t* pk; const uint32_t* pl; int n_blocks, nq; const float* vocab; const float* queries; const int32_t* row_id;
@@ -1773,6 +1893,7 @@ struct RerankArgs {
     int f16;                                                           // the filter multiplied fp16 operands (one product): eps_f16
     const float* pend_desc; const uint32_t* pend_list; int32_t pend_first_id;   // the rows a deferred append writes in this launch, as descriptors
     const float* cross; int cross_ld;                                  // this frame's distances to every descriptor of pend_desc (CrossJob of the previous pair), or NULL
+    const uint32_t* sh_mask; int sh_q; int n_vocab_blocks;             // shadow rows (knn_mfma_rerank_body): sh_q == 0: none
 };
 constexpr int PIPE_BLOCK = 256;     // workgroup size of both fused launches (the filter's and the re-rank's)
 
@@ -1804,7 +1925,7 @@ __device__ __forceinline__ void frame_a_body(float* s_dyn, const FilterArgs& f, 
                                f.pl, f.sd, f.n_lo);
     else
         knn_bf16_filter_body_q<M>(s_dyn, bid - n_front, f.vocab_bf, f.row_norm, f.n_rows, f.qsplit, f.qnorm, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, f.pk,
-                               f.pl, f.sd, f.n_lo);
+                               f.pl, f.sd, f.n_lo, f.sh_bf, f.sh_norm, f.sh_rows, f.sh_blocks);
     A_STAMP(1);
 }
 // two workgroups per compute unit: 66 KB of LDS each, and a register budget of two waves per SIMD
@@ -1834,26 +1955,32 @@ static_assert(PIPE_B_BLOCK == 2 * MF_BLOCK, "the re-rank halves");
 // memory and reloads them inside its latency chain (launch B at 10^6 signatures: 47 -> 62 us; compile-time evidence: the kernel's scratch
 // accesses by source file, tools/store_wait_audit.py's sibling in DESIGN 7a).  A memory of >= APPEND_SPLIT_BUCKETS sealed buckets
 // therefore launches the row writers as a kernel of their own behind launch B (one more launch, ~4 us, against ~15 us of scoring).
+// n_wr > 0: workgroups [n_rerank_wgs, n_rerank_wgs + n_wr) belong to the re-rank role but only write the appended rows (rows_only above);
+// the re-rank workgroups proper then write none
 template <bool WITH_APPEND>
-__global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, int n_rerank_wgs, ScoreArgs A, int n_score_wgs, AppendRowsArgs app) {
-    const int bid = (int)blockIdx.x;
+__global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, int n_rerank_wgs, ScoreArgs A, int n_score_wgs, AppendRowsArgs app, int n_wr) {
+    int bid = (int)blockIdx.x;
     B_STAMP(0);
+    const bool rows_only = !WITH_APPEND && n_wr > 0 && bid >= n_rerank_wgs && bid < n_rerank_wgs + n_wr;
+    const int wr_index = bid - n_rerank_wgs;
+    if (!WITH_APPEND && n_wr > 0 && bid >= n_rerank_wgs + n_wr) bid -= n_wr;            // the scoring workgroups follow
     if (WITH_APPEND && bid >= n_rerank_wgs + n_score_wgs) {              // the rows the decision loop of launch A published (deferred append)
         extern __shared__ __attribute__((aligned(16))) float s_dyn_b2[];
         append_rows_body<PIPE_B_BLOCK>(app, bid - n_rerank_wgs - n_score_wgs, app.ap.lds_bytes >= 1024 ? s_dyn_b2 : nullptr, (app.ap.lds_bytes / 256) & ~3);
         B_STAMP(1);
         return;
     }
-    if (bid < n_rerank_wgs) {                                            // (a multiple of 8: see launch_frame_b)
+    if (bid < n_rerank_wgs || rows_only) {                               // (a multiple of 8: see launch_frame_b)
         // consecutive query pairs on one XCD: eight queries share a 128-byte line of the block-major candidate records
-        const int pair = (bid & 7) * (n_rerank_wgs >> 3) + (bid >> 3);
+        const int pair = rows_only ? 0 : (bid & 7) * (n_rerank_wgs >> 3) + (bid >> 3);
         if (2 * pair >= k.nq) return;
         extern __shared__ __attribute__((aligned(16))) float s_dyn_b[];
+        const bool wr_any = !WITH_APPEND && app.ap.enabled && app.ap.defer_rows;
         knn_mfma_rerank_body<64, BF_KEEP, false, true, 2>(2 * pair, k.pk, k.pl, k.n_blocks, k.nq, k.vocab, k.queries, k.row_id, k.norm_max_bits, k.out_row,
                                                           k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb, k.n_lo, k.n_hi, k.plan_rows,
                                                           s_dyn_b, k.stage_rows, k.f16, k.pend_desc, k.pend_list, k.pend_first_id, k.cross, k.cross_ld
-                                                          , app, !WITH_APPEND && app.ap.enabled && app.ap.defer_rows, pair, (k.nq + 1) / 2
-                                                          );
+                                                          , app, wr_any && (n_wr == 0 || rows_only), rows_only ? wr_index : pair, n_wr > 0 ? n_wr : (k.nq + 1) / 2
+                                                          , rows_only, k.sh_mask, k.sh_q, k.sh_q > 0 ? k.n_vocab_blocks : 0x7fffffff);
         B_STAMP(1);
         return;
     }
@@ -2025,7 +2152,7 @@ MfmaPlan knn_bf16_plan(int q, int n_rows, int other_wgs) {
     return p;
 }
 size_t knn_bf16_partial_bytes(const MfmaPlan& p) {
-    const size_t nb = (size_t)(p.n_blocks > 0 ? p.n_blocks : 1);
+    const size_t nb = (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) + (size_t)p.n_shadow;
     return nb * BF_KEEP * p.qpad * sizeof(uint64_t) + nb * p.qpad * sizeof(uint32_t);
 }
 hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void* bf, hipStream_t s, int f16) {
@@ -2183,7 +2310,8 @@ hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLa
         const PipeKnn& k = *kp;
         p = k.plan;
         uint64_t* pk = (uint64_t*)k.partial;
-        uint32_t* pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * BF_KEEP * p.qpad);
+        uint32_t* pl = (uint32_t*)(pk + ((size_t)(p.n_blocks > 0 ? p.n_blocks : 1) + (size_t)p.n_shadow) * BF_KEEP * p.qpad);
+        if (p.n_shadow > 0 && k.sh_bf && k.sh_norm && k.sh_rows > 0) { f.sh_bf = (const float*)k.sh_bf; f.sh_norm = k.sh_norm; f.sh_rows = k.sh_rows; f.sh_blocks = p.n_shadow; }
         f.vocab_bf = (const float*)k.vocab_bf; f.row_norm = k.row_norm; f.n_rows = p.n_rows; f.queries = (const float*)k.queries; f.nq = p.q; f.qpad = p.qpad;
         f.tiles_per_block = p.tiles_per_block; f.n_blocks = p.n_blocks; f.pk = pk; f.pl = pl; f.n_lo = k.n_lo;
         f.qsplit = (const uint4*)k.qsplit; f.qnorm = k.qnorm;
@@ -2199,8 +2327,9 @@ hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLa
     f.delay = opt.filter_delay;
     const int px = p.q > 0 ? bf16_persistent_px(p) : 0;
     if (px == 0 && p.q > 0 && (!f.qsplit || !f.qnorm)) return hipErrorInvalidValue;      // the one-strip launch reads pre-split queries
+    if ((px > 0 ? 1 : 0) + (f.sh_blocks != p.n_shadow ? 1 : 0) > 0 && p.n_shadow > 0) return hipErrorInvalidValue;   // shadow strips: one-strip launches with the rows at hand only (the engine plans them so)
     TailRoles tr;
-    tr.n_filter_wgs = p.q > 0 ? f.sd.n_tiles + (px > 0 ? px : p.n_blocks) * ((p.q + BF_QB - 1) / BF_QB) : 0;
+    tr.n_filter_wgs = p.q > 0 ? f.sd.n_tiles + (px > 0 ? px : p.n_blocks + f.sh_blocks) * ((p.q + BF_QB - 1) / BF_QB) : 0;
     tr.has_resolve = resolve ? 1 : 0; tr.has_register = reg ? 1 : 0; tr.n_redo = resolve ? resolve->n_redo : 0;
     QSplitArgs qs{};
     if (qsp) { qs = *qsp; qs.n_wgs = std::min((qs.qpad * 8 + PIPE_BLOCK - 1) / PIPE_BLOCK, 32); if (qs.n_wgs < 1) qs.n_wgs = 1; }   // one item per thread up to 1 024 descriptors
@@ -2247,8 +2376,8 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
     if (k) {
         const MfmaPlan& p = k->plan;
         uint64_t* pk = (uint64_t*)k->partial;
-        rk.pk = pk; rk.pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * BF_KEEP * p.qpad);
-        rk.n_blocks = p.n_blocks; rk.nq = p.q; rk.vocab = (const float*)k->vocab; rk.queries = (const float*)k->queries; rk.row_id = k->row_id;
+        rk.pk = pk; rk.pl = (uint32_t*)(pk + ((size_t)(p.n_blocks > 0 ? p.n_blocks : 1) + (size_t)p.n_shadow) * BF_KEEP * p.qpad);
+        rk.n_blocks = p.n_blocks + p.n_shadow; rk.n_vocab_blocks = p.n_blocks; rk.nq = p.q; rk.vocab = (const float*)k->vocab; rk.queries = (const float*)k->queries; rk.row_id = k->row_id;
         rk.norm_max_bits = k->norm_max_bits; rk.out_row = k->out_row; rk.out_word = k->out_word; rk.out_dist = k->out_dist;
         rk.fail_list = k->fail_list; rk.fail_count = k->fail_count; rk.cb = k->cb; rk.n_lo = k->n_lo; rk.n_hi = k->n_hi; rk.plan_rows = p.n_rows; rk.f16 = p.f16;
         n_rerank = ((p.q + 1) / 2 + 7) & ~7;                          // two queries per workgroup; padded to the XCD count (frame_b_kernel)
@@ -2276,19 +2405,28 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
     const bool writers = opt.append_from_rerank == 0;
     if (!writers && k && n_app > 0 && k->n_hi && k->plan.q > 0 && rk.stage_rows >= 4) n_app = 0;   // the re-rank workgroups write the rows (`ar` stays filled in: they get it);
                                                                                       // without re-rank workgroups or a staging area the writers stay
+    // shadow rows: the filter of launch A ranked the descriptors of the frame whose rows are written here; the re-rank needs that frame's new-word mask
+    const bool shadow = k && k->plan.n_shadow > 0 && k->sh_mask && k->sh_q > 0 && app && app->ap.enabled && app->ap.defer_rows && rk.pend_desc && !rk.cross;
+    if (k && k->plan.n_shadow > 0 && !shadow) return hipErrorInvalidValue;          // (records of shadow strips nobody could interpret: the engine plans them together)
+    if (shadow) { rk.sh_mask = k->sh_mask; rk.sh_q = k->sh_q; }
+    // round 6: rows written by n_wr extra workgroups of the re-rank role instead of by the re-rank workgroups themselves ("row_writer_wgs");
+    // with shadow rows the re-rank workgroups stage nothing they could write, so the writers are not optional
+    const int n_wr = (!writers && n_app == 0 && k && app && app->ap.enabled && app->ap.defer_rows && k->n_hi && k->plan.q > 0 && rk.stage_rows >= 4 && !rk.cross &&
+                      (opt.row_writer_wgs > 0 || shadow)) ? (opt.row_writer_wgs > 0 ? opt.row_writer_wgs : 16) : 0;
+    if (shadow && n_wr == 0) return hipErrorInvalidValue;
     const bool split = n_app > 0 && score && score->n_closed >= (opt.append_split_buckets >= 0 ? opt.append_split_buckets : APPEND_SPLIT_BUCKETS);   // (see frame_b_kernel)
     if (split || n_app == 0) {
         if (n_rerank + score_wgs > 0) {
             if (ev_begin != nullptr && ev_end != nullptr)
-                hipExtLaunchKernelGGL(frame_b_kernel<false>, dim3(n_rerank + score_wgs), dim3(PIPE_B_BLOCK), dyn, s, ev_begin, ev_end, 0u, rk, n_rerank, A, score_wgs, ar);
-            else frame_b_kernel<false><<<n_rerank + score_wgs, PIPE_B_BLOCK, dyn, s>>>(rk, n_rerank, A, score_wgs, ar);
+                hipExtLaunchKernelGGL(frame_b_kernel<false>, dim3(n_rerank + n_wr + score_wgs), dim3(PIPE_B_BLOCK), dyn, s, ev_begin, ev_end, 0u, rk, n_rerank, A, score_wgs, ar, n_wr);
+            else frame_b_kernel<false><<<n_rerank + n_wr + score_wgs, PIPE_B_BLOCK, dyn, s>>>(rk, n_rerank, A, score_wgs, ar, n_wr);
         }
         if (n_app > 0) append_rows_kernel<<<n_app, PIPE_B_BLOCK, PIPE_B_STAGE_ROWS * 256u, s>>>(ar);
         return hipGetLastError();
     }
     if (ev_begin != nullptr && ev_end != nullptr)
-        hipExtLaunchKernelGGL(frame_b_kernel<true>, dim3(n_rerank + score_wgs + n_app), dim3(PIPE_B_BLOCK), dyn, s, ev_begin, ev_end, 0u, rk, n_rerank, A, score_wgs, ar);
-    else frame_b_kernel<true><<<n_rerank + score_wgs + n_app, PIPE_B_BLOCK, dyn, s>>>(rk, n_rerank, A, score_wgs, ar);
+        hipExtLaunchKernelGGL(frame_b_kernel<true>, dim3(n_rerank + score_wgs + n_app), dim3(PIPE_B_BLOCK), dyn, s, ev_begin, ev_end, 0u, rk, n_rerank, A, score_wgs, ar, 0);
+    else frame_b_kernel<true><<<n_rerank + score_wgs + n_app, PIPE_B_BLOCK, dyn, s>>>(rk, n_rerank, A, score_wgs, ar, 0);
     return hipGetLastError();
 }
 

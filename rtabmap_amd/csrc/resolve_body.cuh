@@ -131,11 +131,22 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
     // ---- the same-frame candidates: count + compact list left by the re-rank (one read each); descriptors with more than four, and
     //      paths without the lists, walk their bit row in every sweep instead
     int cn[KPT];
+    // ... and the lists themselves, unconditionally, in the SAME round trip as their counts (32 bytes per descriptor; entries beyond the
+    // count are never looked at): requested behind the counts they used to be a second dependent round trip, ~2 us at the head of the
+    // first sweep (round 5's stamps: 0.9 + 1.3 us in front of the first two descriptors of a thread)
+    uint4 cl_lo[KPT], cl_hi[KPT];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const int i = tid + k * NT;
         cn[k] = 0;
-        if (together && i < q) cn[k] = cand_cnt ? cand_cnt[i] : 5;
+        cl_lo[k] = make_uint4(0u, 0u, 0u, 0u); cl_hi[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (together && i < q) {
+            cn[k] = cand_cnt ? cand_cnt[i] : 5;
+            if (cand_cnt) {
+                cl_lo[k] = *reinterpret_cast<const uint4*>(cand_list + (size_t)i * 4);
+                cl_hi[k] = *reinterpret_cast<const uint4*>(cand_list + (size_t)i * 4 + 2);
+            }
+        }
     }
     // ---- round trip 2: postings keys of both neighbours (consumed after the sweeps) together with the candidate lists below
 #pragma unroll
@@ -155,8 +166,8 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) { S.cj[e] = 0; S.cd[e] = 0.0f; }
         if (cn[k] > 0 && cn[k] <= 4) {
-            const uint4 lo = *reinterpret_cast<const uint4*>(cand_list + (size_t)i * 4);
-            const uint4 hi = cn[k] > 2 ? *reinterpret_cast<const uint4*>(cand_list + (size_t)i * 4 + 2) : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 lo = cl_lo[k];
+            const uint4 hi = cn[k] > 2 ? cl_hi[k] : make_uint4(0u, 0u, 0u, 0u);
             S.cj[0] = (int)lo.x; S.cd[0] = __uint_as_float(lo.y); S.cj[1] = (int)lo.z; S.cd[1] = __uint_as_float(lo.w);
             S.cj[2] = (int)hi.x; S.cd[2] = __uint_as_float(hi.y); S.cj[3] = (int)hi.z; S.cd[3] = __uint_as_float(hi.w);
             S.nc = cn[k];

@@ -125,6 +125,10 @@ struct AppendArgs {
     uint32_t* list_out = nullptr;
     unsigned long long* host_mirror = nullptr; // pinned: (tag << 32 | rows) after this append, read by the host WITHOUT synchronising to
     uint32_t tag = 0;                          // bound the row count it plans the next launches for
+    uint32_t* mask_out = nullptr;              // receives the final new-word mask (mw words) and its word prefix sums (mw + 1), mw = ceil(q / 64) * 2: what the
+                                               // re-rank of the next frame needs to tell which shadow rows are words (zeros when nothing is appended)
+    int mirror_later = 0;                      // 1 (PipeOpts::mirror_from_b): the decision loop leaves the mirror alone -- a workgroup of launch B of the same
+                                               // pair stores it (a write to pinned HOST memory at the end of launch A's longest chain, waited for at s_endpgm)
 };
 
 // the row-writing half of a deferred append (launch B): the appender's arguments + the postings keys of the frame's new words
@@ -188,12 +192,22 @@ struct PipeKnn {
     const float* qnorm = nullptr;    // norms: what the one-strip filter of a pipelined launch reads instead of the descriptors
     const int32_t* n_lo = nullptr;   // device row counts (NULL: the host's plan.n_rows is exact): the filter sees rows [0, n_lo[0]), the re-rank
     const int32_t* n_hi = nullptr;   // also scans [n_lo[0], n_hi[0]) exactly -- the words the previous frame appended meanwhile (AppendArgs)
+    // shadow rows (round 6): the descriptors of the frame whose decision loop rides in the same launch A, as operand-table rows written by that
+    // frame's query pre-split; the filter ranks them in sh_blocks extra strips, the re-rank takes the ones that became words (ShadowArgs)
+    const void* sh_bf = nullptr; const float* sh_norm = nullptr; int sh_rows = 0;   // sh_rows: that frame's padded descriptor count
+    const uint32_t* sh_mask = nullptr; int sh_q = 0;   // that frame's final new-word mask + prefix sums (AppendArgs::mask_out) and its descriptor count
     float* cross = nullptr;          // [q x cross_ld] distances of this frame's queries to the cross_ncols descriptors at cross_cols (the frame
     int cross_ld = 0;                // before it): written by extra tiles of launch A, read by the re-rank of launch B for its pending rows (which are
     const void* cross_cols = nullptr; int cross_ncols = 0;   // descriptors of that frame); NULL: the re-rank stages the pending rows and computes them
 };
 // the new frame's queries -> MFMA operand order in global memory (knn_mfma_kernels.hip, qsplit_body): a few workgroups of launch A
-struct QSplitArgs { const float* queries; int nq, qpad; uint4* qsplit; float* qnorm; int n_wgs; int f16 = 0; /* operands as IEEE half */ };
+struct QSplitArgs { const float* queries; int nq, qpad; uint4* qsplit; float* qnorm; int n_wgs; int f16 = 0; /* operands as IEEE half */
+                    // round 6 ("shadow rows"): the same descriptors once more as ROWS of an operand table (256 B each, the layout of vocab_bf) with their
+                    // augmentation entries ({|d|^2, 1}; {+inf, 1} for the padding rows and the sentinel at qpad) -- what the NEXT frame's filter multiplies
+                    // to rank the words this frame is about to create; NULL: not wanted
+                    uint32_t* shadow_bf = nullptr; float* shadow_norm = nullptr;
+                    uint32_t* norm_max_bits = nullptr;   // the vocabulary's running maximum of |row|^2 (the re-rank's error bound is made from it): shadow rows count from now on
+};
 size_t knn_qsplit_bytes(int q);
 int pipe_block_size();      // workgroup size of launch A (the filter's)
 int pipe_b_block_size();    // workgroup size of launch B (re-rank + scoring)
@@ -209,6 +223,10 @@ struct PipeOpts {
     int append_from_rerank = 1;      // "append_from_rerank" (0: the eight row-writer workgroups of round 4, for A/B runs)
     int append_split_buckets = -1;   // "append_split_buckets" (< 0: built-in)
     int filter_delay = 0;            // "filter_delay": s_sleep units (64 clocks) a filter workgroup waits in front of its first request
+    int shadow_rows = 0;             // "shadow_rows": the filter also ranks the descriptors of the frame before (whose new words are not rows yet)
+    int mirror_from_b = 0;           // "mirror_from_b": the pinned row-count mirror of an appending frame is stored by launch B instead of by the decision loop
+    int row_writer_wgs = 0;          // "row_writer_wgs": > 0 = that many extra workgroups of launch B's re-rank role write the appended rows
+                                     // (0: the re-rank workgroups write them at the end of their own chains)
 };
 hipError_t launch_frame_a(const PipeKnn* k, const QSplitArgs* qs, const TailLaunch* resolve, const TailLaunch* reg, hipStream_t s,
                           hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const PipeOpts& opt = PipeOpts());

@@ -121,6 +121,37 @@ def test_rows_of_the_deferred_append_written_by_either_kind_of_workgroup(oracle,
     assert _stream(oracle, True, n_words=3000, q=96, n_frames=30, seed=19, options={"append_from_rerank": who}) > 200
 
 
+@pytest.mark.parametrize("n_words,q,n_frames,knn_mode,n_wr", [(3000, 96, 30, None, 3), (3000, 200, 12, "f16", 16), (72000, 700, 8, "f16", 24), (3000, 96, 30, "f16", 1)])
+def test_rows_written_by_extra_workgroups_of_the_rerank_role(oracle, n_words, q, n_frames, knn_mode, n_wr):
+    """lcd_set_option "row_writer_wgs" = n: the rows a frame appended are written by n extra workgroups of launch B's re-rank role (no re-rank
+    workgroup then has the row stores at the end of its chain, and the kernel gets no third branch) -- word ids, likelihood and vocabulary as
+    when the re-rank workgroups write them; one writer alone takes every row (several chunks of its staging area at 700 descriptors)"""
+    assert _stream(oracle, True, n_words=n_words, q=q, n_frames=n_frames, seed=31, knn_mode=knn_mode, options={"row_writer_wgs": n_wr}) > 100
+
+
+@pytest.mark.parametrize("n_words,q,n_frames,knn_mode,extra", [(3000, 96, 40, None, {}), (3000, 200, 16, "f16", {"row_writer_wgs": 3}), (72000, 700, 8, "f16", {"mirror_from_b": 1}),
+                                                               (3000, 96, 40, "f16", {"clean": 1}), (150003, 300, 6, "f16", {})])
+def test_new_rows_ranked_by_the_filter_as_shadow_rows(oracle, n_words, q, n_frames, knn_mode, extra):
+    """lcd_set_option "shadow_rows" = 1: the words the previous frame created are descriptors of that frame; its query pre-split leaves them as rows
+    of an operand table, the matrix-core filter of this frame ranks them in extra strips, and the re-rank keeps the candidates whose descriptor
+    the previous decision loop's mask names -- no workgroup stages or scans the new rows.  Word ids, likelihood and vocabulary are the oracle's:
+    streams that revisit the place of the frame before them (words matched one frame after they were created), bf16 and fp16 filters, frames of
+    700 descriptors (three shadow strips, several mask words), a clean behind every frame, and a vocabulary whose filter is persistent (where the
+    option changes nothing: the rows are staged as before)."""
+    opts = {"shadow_rows": 1}
+    opts.update({k: v for k, v in extra.items() if k != "clean"})
+    assert _stream(oracle, True, n_words=n_words, q=q, n_frames=n_frames, seed=41, knn_mode=knn_mode, options=opts, clean_every_frame=bool(extra.get("clean"))) > 100
+
+
+@pytest.mark.parametrize("options", [{"mirror_from_b": 1}, {"mirror_from_b": 1, "row_writer_wgs": 8}, {"mirror_from_b": 1, "append_from_rerank": 0},
+                                     {"mirror_from_b": 1, "append_split_buckets": 0, "append_from_rerank": 0}])
+def test_row_count_mirror_stored_by_launch_b(oracle, options):
+    """lcd_set_option "mirror_from_b" = 1: the pinned row-count mirror the host plans its launches from is stored by the launch that writes the
+    frame's rows (whichever kind of workgroup writes them), not at the end of the decision loop's chain -- same results, and the host's
+    throttle (which reads the mirror's tag) keeps up over a stream longer than its eight-frame window"""
+    assert _stream(oracle, True, n_words=3000, q=96, n_frames=40, seed=37, options=options) > 200
+
+
 @pytest.mark.parametrize("n_words,q,n_frames,knn_mode", [(3000, 96, 30, None), (3000, 200, 12, "f16"), (72000, 700, 8, "f16")])
 def test_pending_rows_read_from_the_cross_frame_tiles(oracle, n_words, q, n_frames, knn_mode):
     """lcd_set_option "cross_frame_tiles" = 1: the words the previous frame created are descriptors of that frame, so extra distance tiles of
