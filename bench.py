@@ -645,6 +645,92 @@ def cpp_interface_ms(vocab, words, frames_np, n_sig, steps=12):
 
 
 # ----------------------------------------------------------------------------------------------------------------- ORB stream
+def leg_parity(torch, vocab, words, frame):
+    """ONE frame of parity for a secondary leg: lcd_frame_dev (registration + update()'s append + TF-IDF, pipelined handle) against the oracle's
+    addNewWords over the same dictionary (exact linear 2-NN, C++) and Memory::computeLikelihood -- the C++ std::map oracle up to 200 000
+    signatures, its numpy restatement (oracle/tfidf_np.py, pinned to the C++ oracle by tests/test_oracle_golden.py) beyond."""
+    import oracle as O
+    import rtabmap_amd
+    n_sig = words.shape[0]
+    eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 64, pipeline=1, knn_mode=KNN_MODE)
+    load_engine(eng, vocab, words)
+    cap = n_sig + 16
+    d_desc = torch.from_numpy(frame).cuda()
+    d_words = torch.zeros(Q, dtype=torch.int32, device="cuda")
+    d_like = torch.zeros(cap, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    eng.frame_dev(d_desc.data_ptr(), Q, n_sig + 1, float(n_sig + 1), d_words.data_ptr(), d_like.data_ptr(), cap, first_new_word_id=N_WORDS + 1, append_new_words=True)
+    eng.synchronize()
+    got, Lh = d_words.cpu().numpy(), d_like.cpu().numpy()[: n_sig + 1]
+    eng.close()
+    t0 = time.perf_counter()
+    o = O.OracleVWDictionary(strategy=O.kNNBruteForce, incremental=True, nndr=NNDR, new_words_compared_together=True)
+    for w in range(1, N_WORDS + 1):
+        o.add_word(w, vocab[w - 1])
+    o.update()
+    exp = o.add_new_words(frame, n_sig + 1)
+    t_knn = time.perf_counter() - t0
+    ids_h = np.where(got < 0, N_WORDS - got, got)                   # the frame's k-th new word: code -(k + 1) -> id N_WORDS + 1 + k (the oracle's ++_lastWordId)
+    ids_equal = bool(ids_h.tolist() == list(exp))
+    o.close()
+    t1 = time.perf_counter()
+    if n_sig < 200_000:
+        m = build_oracle(vocab, words)
+        sid, exp2 = m.update(frame)
+        oi, Lo = m.compute_likelihood(np.array(exp2, np.int32), np.array(m.signature_ids(), np.int32))
+        how = "C++ std::map oracle"
+        m.close()
+    else:
+        from oracle import tfidf_np
+        allw = np.concatenate([words, np.asarray(exp, np.int32)[None, :]], axis=0)
+        Lo = tfidf_np.compute_likelihood_dense(allw, np.asarray(exp, np.int32))
+        how = "numpy restatement (oracle/tfidf_np.py)"
+    t_lik = time.perf_counter() - t1
+    err = np.abs(Lh - Lo) / np.maximum(np.abs(Lo), 1e-7 / 1e-4)
+    return {"frames": 1, "word_ids_equal": ids_equal, "likelihood_max_rel": float(err.max()), "likelihood_values_compared": int(Lo.size),
+            "argmax_equal": bool(int(np.argmax(Lh[:-1])) == int(np.argmax(Lo[:-1]))), "bound": "1e-4 relative (abs floor 1e-7)", "signatures": int(n_sig),
+            "likelihood_by": how, "oracle_seconds": {"addNewWords": t_knn, "computeLikelihood": t_lik}}
+
+
+def secondary_legs(budget_s=150.0):
+    """The other configurations as short runs of this same script, so that what profiles/ claims for them is observed by whoever runs the
+    default command (the previous review's item 8): config 3 on 300 ORB frames, 125 000 words (one GPU's share of config 4) for 50 steps,
+    10^6 signatures for 30 steps -- each with its own roofline and one frame of parity.  A leg that would not fit the time budget is skipped
+    and says so; a leg that fails reports its error instead of costing the line."""
+    import subprocess
+    legs = [("orb_stream_300_frames", ["--config", "orb_stream", "--steps", "300"], 60.0),
+            ("words_125k", ["--words", "125000", "--steps", "50", "--warmup", "5", "--leg"], 45.0),
+            # 10^6 signatures: the host needs ~90 s to draw 5 x 10^8 Zipf words and ~45 s for the numpy restatement of ONE likelihood -- more than
+            # the default command may take; LCD_BENCH_LEGS=all (or `python bench.py --signatures 1000000 --steps 30 --warmup 5 --leg`) runs it
+            ("signatures_1m", ["--signatures", "1000000", "--steps", "30", "--warmup", "5", "--leg"], 240.0)]
+    if os.environ.get("LCD_BENCH_LEGS", "") == "all":
+        budget_s = 1200.0
+    out = {"note": "short runs of `python bench.py <args>` by this run; the full-size lines are profiles/r06_bench_*.json"}
+    t_start = time.perf_counter()
+    for name, extra, expect in legs:
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 0.6 * expect:
+            out[name] = {"skipped": "time budget of the default command (%.0f s left, the leg needs ~%.0f s)" % (left, expect)}
+            continue
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=dict(os.environ, LCD_BENCH_INNER="1"),
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=max(left, 30.0) + 30.0, text=True)
+            lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": "exit code %d" % r.returncode}
+                continue
+            d = json.loads(lines[-1])
+            keep = {k: d.get(k) for k in ("metric", "value", "unit", "steps", "ms_per_step", "roofline", "roofline_score", "roofline_knn", "parity")}
+            keep["command"] = "python bench.py " + " ".join(extra)
+            keep["workload"] = d.get("config", {}).get("workload")
+            keep["wall_s"] = time.perf_counter() - t0
+            out[name] = keep
+        except Exception as e:                                    # noqa: BLE001
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
 def run_orb_stream(args):
     """BASELINE.json config 3 as SURVEY.md 8d specifies it: 2 000 frames of 500 ORB descriptors against an initially EMPTY incremental
     dictionary (NNDR 0.8) grown to ~200k words, every frame also removing the references of frame t - 1000, TF-IDF against the working
@@ -1369,6 +1455,10 @@ def main():
     ap.add_argument("--pmc", action="store_true", help="measure HBM traffic with rocprofv3 even with --no-cpu-baseline")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure HBM traffic with rocprofv3 (two extra short runs of this script)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (unpipelined, host path, with update)")
+    ap.add_argument("--leg", action="store_true", help="this run is a secondary leg of another bench.py run (`secondary` of its line): the timed region, the "
+                    "rooflines and ONE frame of parity (word ids + likelihood against the oracle / the numpy restatement at >= 200 000 signatures); "
+                    "no extras, no CPU baselines, no counter passes, no further legs")
+    ap.add_argument("--no-legs", action="store_true", help="do not run the secondary legs (config 3 on 300 frames, 125 000 words, 10^6 signatures)")
     ap.add_argument("--pipeline", type=int, default=1, help="1: software-pipelined frames (the launches of frame t carry the filter, decision loop, "
                     "registration and scoring of the three frames before it); 0: four launches per frame, nothing overlapped")
     ap.add_argument("--parallelism", choices=["auto", "shard", "replicas"], default="auto",
@@ -1386,6 +1476,8 @@ def main():
                     "no-retire (the oldest signature is not retired)")
     args = ap.parse_args()
 
+    if args.leg:
+        args.no_extras = True; args.no_pmc = True; args.no_legs = True
     DIAG.update(x for x in args.diag.split(",") if x)
     if args.knn_mode:
         globals()["KNN_MODE"] = args.knn_mode
@@ -1533,6 +1625,15 @@ def main():
         config["step_ms_p95"] = float(np.percentile(extra["per_step_ms"], 95))
         config["distribution_from"] = "%d extra steps after the timed region, one event per step (the timed region itself carries none: an " \
                                       "event costs stream time); their mean %.4f ms" % (extra["per_step_ms"].size, float(extra["per_step_ms"].mean()))
+
+    # ---- the same step over >= 200 further frames without any event in the stream: what the 20-step figure converges to once its
+    # pipeline fill / drain (3 of 23 launch pairs) and the box-to-box noise of a 0.8 ms region stop mattering (the previous review's item 8)
+    if not shard and world == 1:
+        n_steady = max(200, args.steps)
+        steady = timed_loop(torch, dist, world, stream, step, n_steady, 0, eng=eng, per_step_events=False)
+        config["steady_ms_per_step"] = 1e3 * steady["wall"] / n_steady
+        config["steady_note"] = "%d further steps, no event in the stream, one synchronisation at the end; the bench cycles through %d distinct frames, so " \
+                                "these are mostly revisits (few new words per frame) where the driver's %d steps are first visits (~150 new words each)" % (n_steady, n_frames, args.steps)
 
     def primary_line():
         out = {
@@ -1683,7 +1784,9 @@ def main():
                 if out.get(k):
                     out[k]["traffic"] = pmc_traffic(out[k]["kernel"])
                     out[k]["traffic_source"] = pmc_source(out[k]["kernel"], note)
-        if not args.no_cpu_baseline:
+        if args.leg and not args.no_cpu_baseline:
+            out["parity"] = leg_parity(torch, vocab, words, frames_np[0])
+        elif not args.no_cpu_baseline:
             m = build_oracle(vocab, words)
             par, t_lin_port, t_lik = parity_block(torch, vocab, words, frames_np, m)
             out["parity"] = par
@@ -1693,6 +1796,10 @@ def main():
                 out["parity"]["timed_engine"] = timed_engine_parity(m, step, frames_np, like, n_sig)
             out["cpu_baseline"] = cpu_baselines(vocab, frames_np, t_lin_port, t_lik, n_sig, words=words, frame_words=words[17])
             out["cpu_baseline"]["gpu_over_best_cpu"] = value / out["cpu_baseline"]["best_cpu_value"]
+    if rank == 0 and world == 1 and not args.no_legs and not args.no_extras and not os.environ.get("LCD_BENCH_INNER") and \
+            N_WORDS == 49000 and n_sig == N_SIG and args.config == "headline":
+        eng.synchronize()
+        out["secondary"] = secondary_legs()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if not shard:

@@ -1265,15 +1265,17 @@ static int build_knn(lcd_engine* h, lcd_engine::InFlight& f, PipeKnn* kp, const 
     }
     if (f_sh && !knn_bf16_persistent(k.plan) && plan_rows < (int64_t)SHADOW_ROW_BASE) {
         const lcd_engine::FrameScratch& ss = h->ring[f_sh->set];
-        k.plan.n_shadow = knn_shadow_strips(f_sh->a.q);
+        k.plan.n_shadow = 1;
         k.sh_bf = ss.d_shadow_bf.p; k.sh_norm = ss.d_shadow_norm.as<float>(); k.sh_rows = (f_sh->a.q + 63) / 64 * 64;
         k.sh_mask = ss.d_newmask.as<uint32_t>(); k.sh_q = f_sh->a.q;
+        k.sh_ld = k.sh_rows;
+        LCD_HIP(h, ring_reserve(h, f.set, &lcd_engine::FrameScratch::d_cross, (size_t)q * k.sh_ld * 4));   // (the buffer the cross-frame tiles use: never both)
+        k.sh_x = sc.d_cross.as<float>();
     }
     {   // the candidate records: sized for this plan AND for the one the upper bound would get (a growing vocabulary crosses the planner's
         // thresholds: a reallocation drains the stream)
         size_t bytes = knn_bf16_partial_bytes(k.plan);
-        if (h->popt.shadow_rows) { MfmaPlan worst = k.plan; worst.n_shadow = knn_shadow_strips(4096); bytes = std::max(bytes, knn_bf16_partial_bytes(worst)); }   // (no reallocation when a frame gets shadow strips)
-        if (f.chained) bytes = std::max(bytes, (h->popt.shadow_rows ? (size_t)knn_shadow_strips(4096) * (size_t)((q + 63) / 64 * 64) * 20 : 0) + knn_bf16_partial_bytes(knn_bf16_plan_pipelined(q, (int)(rows_bound + 8 * (int64_t)q), together ? knn_selfdist_wgs(q) : 0, h->filter_units)));
+        if (f.chained) bytes = std::max(bytes, knn_bf16_partial_bytes(knn_bf16_plan_pipelined(q, (int)(rows_bound + 8 * (int64_t)q), together ? knn_selfdist_wgs(q) : 0, h->filter_units)));
         LCD_HIP(h, ring_reserve(h, f.set, &lcd_engine::FrameScratch::d_partial2, bytes));
     }
     LCD_HIP(h, ring_reserve(h, f.set, &lcd_engine::FrameScratch::d_partial3, knn_rowpar_partial_bytes((int)(rows_bound + (f.chained ? 8 * (int64_t)q : 0)), q)));
@@ -1484,7 +1486,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
         LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_selfdist, (size_t)q * ld * 4));
         LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_bits, cand_bits_bytes(q, bw)));
     }
-    if (chained && !h->inflight.empty() && h->dtype == LCD_F32 && h->kdim == 64 && h->popt.cross_frames)   // (pipeline_launch: this frame x the frame before it)
+    if (chained && !h->inflight.empty() && h->dtype == LCD_F32 && h->kdim == 64 && (h->popt.cross_frames || h->popt.shadow_rows))   // (pipeline_launch: this frame x the frame before it)
         LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_cross, (size_t)q * ((h->inflight.back().a.q + 63) / 64 * 64) * 4));
     // shadow rows: a frame that appends on the device leaves its descriptors as operand-table rows too, for the filter of the frame behind it
     const bool with_shadow = chained && app && h->popt.shadow_rows && h->dtype == LCD_F32 && h->kdim == 64 && q <= 4096;

@@ -886,9 +886,7 @@ template <int M>
 __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, const float* __restrict__ vocab_bf, const float* __restrict__ row_norm,
                                                        int n_rows, const uint4* qsplit, const float* qnorm, int nq, int qpad,
                                                        int tiles_per_block, int n_blocks, uint64_t* __restrict__ partial_keys,
-                                                       uint32_t* __restrict__ partial_bound, const SelfdistJob& sd, const int32_t* __restrict__ n_lo,
-                                                       const float* __restrict__ sh_bf = nullptr, const float* __restrict__ sh_norm = nullptr, int sh_rows = 0,
-                                                       int sh_blocks = 0) {
+                                                       uint32_t* __restrict__ partial_bound, const SelfdistJob& sd, const int32_t* __restrict__ n_lo) {
     constexpr int NG = 4;
     constexpr int NW = MF_WAVES;
     constexpr int QW = NG * 32;
@@ -898,23 +896,16 @@ __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, co
     int lo_rows = 0x7fffffff;
     if (n_lo) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lo_rows) : "s"(n_lo) : "memory");
     lo_rows = min(lo_rows, n_rows);                                       // (the plan's n_rows may be an estimate below the device's count)
-    const int n_strips = n_blocks + sh_blocks;                            // vocabulary strips, then the strips over the shadow rows
-    const int n_fwg = n_strips * ((nq + BF_QB - 1) / BF_QB);
+    const int n_fwg = n_blocks * ((nq + BF_QB - 1) / BF_QB);
     if (bid >= n_fwg) { selfdist_tile(sd, bid - n_fwg, s_dyn); return; }
-    const int bx = bid % n_strips, by = bid / n_strips;
-    // A shadow strip multiplies the operand rows the frame before wrote of its own descriptors (qsplit_item): every one of them is visible (the
-    // padding carries +inf), eight tiles per strip, and its keys name rows SHADOW_ROW_BASE + descriptor index -- the re-rank keeps the ones whose
-    // descriptor became a word.  Everything below is the same code on other pointers.
-    const bool shadow = bx >= n_blocks;
-    if (shadow) { vocab_bf = sh_bf; row_norm = sh_norm; n_rows = sh_rows; lo_rows = sh_rows; tiles_per_block = MF_STRIP_TILES; }
+    const int bx = bid % n_blocks, by = bid / n_blocks;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 31, half = lane >> 5;
     const int q0 = by * BF_QB + wave * QW;
     float* s_aug = s_dyn + (size_t)MF_STRIP_TILES * BF_TILE_F;          // [MF_STRIP_TILES][64]
     MF_STAMP(0);
-    const int tile0 = (shadow ? bx - n_blocks : bx) * tiles_per_block;
-    const int key_tile0 = tile0 + (shadow ? (int)(SHADOW_ROW_BASE / 32u) : 0);
+    const int tile0 = bx * tiles_per_block;
     const int n_tiles = (n_rows + 31) / 32;
     const int tile1 = min(tile0 + tiles_per_block, n_tiles);
     // First what the loop needs to start -- two tiles, the augmentation entries, the query operands -- and, once that has arrived, the
@@ -1011,7 +1002,7 @@ __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, co
     MF_STAMP(2);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const uint64_t a0 = widen_key(k0[g], key_tile0, half), a1 = widen_key(k1[g], key_tile0, half), a2 = widen_key(k2[g], key_tile0, half);
+        const uint64_t a0 = widen_key(k0[g], tile0, half), a1 = widen_key(k1[g], tile0, half), a2 = widen_key(k2[g], tile0, half);
         const uint64_t b0 = shfl_xor_u64(a0, 32), b1 = shfl_xor_u64(a1, 32), b2 = shfl_xor_u64(a2, 32);
         const uint64_t m0 = a0 < b0 ? a0 : b0;
         const uint64_t hx = a0 < b0 ? b0 : a0, lx = a1 < b1 ? a1 : b1;
@@ -1026,6 +1017,79 @@ __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, co
         }
     }
     MF_STAMP(3);
+}
+
+// ------------------------------------------------------------------------------------------------ shadow scores (round 6)
+// The words frame t-2 is about to create (its decision loop rides in THIS launch) are not rows of the vocabulary when the filter of frame t-1 runs
+// beside it -- but they are descriptors of frame t-2, and that frame's query pre-split left ALL its descriptors as rows of an operand table (256 B
+// each, the layout of vocab_bf; QSplitArgs::shadow_bf).  One workgroup per 32-row tile of that table multiplies it with the frame's 512 pre-split
+// queries exactly as a filter strip does (the same MFMA chains on top of |v|^2 + |q|^2: the same error bound) and -- instead of selecting -- writes
+// every score: x[query][descriptor], ld floats per query.  Launch B's re-rank, which knows by then which of those descriptors became words, reads
+// its query's row, keeps the words' scores at or below its threshold and evaluates them exactly with its other candidates (knn_mfma_rerank_body):
+// nobody stages or scans the ~150 new rows any more (250 workgroups x 38 KB and ~4.5 us of the re-rank's chain in round 5).
+template <int M>
+__device__ __forceinline__ void shadow_scores_body(float* s_dyn, int wg, const float* __restrict__ sh_bf, const float* __restrict__ sh_norm, int sh_rows,
+                                                   const uint4* qsplit, const float* qnorm, int nq, int qpad, float* __restrict__ x, int ld) {
+    constexpr int NG = 4, NW = MF_WAVES, QW = NG * 32, DPW = 8 / NW;
+    const int n_tiles = (sh_rows + 31) / 32;
+    const int t = wg % n_tiles, by = wg / n_tiles;                       // tile of the table, block of 512 queries
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int q0 = by * BF_QB + wave * QW;
+    float* s_aug = s_dyn + (size_t)BF_TILE_F;
+    dma_tile_part(sh_bf, sh_rows, t, lane, s_dyn, DPW * wave, DPW * wave + DPW);
+    if (wave == 0)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sh_norm + 2 * (size_t)min(t * 32 + col, sh_rows) + half),
+                                         (__attribute__((address_space(3))) void*)s_aug, 4, 0, 0);
+    uint4 bh[NG][4], bl[NG][4];
+    float b_aug[NG];
+    const int grp0 = q0 >> 5, n_grp = qpad >> 5;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int grp = min(grp0 + g, n_grp - 1);
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) {
+            const size_t base = ((size_t)grp * 4 + sx) * 2;
+            bh[g][sx] = qsplit[(base + 0) * 64 + lane];
+            bl[g][sx] = qsplit[(base + 1) * 64 + lane];
+        }
+        const float qn = qnorm[min(grp * 32 + col, qpad - 1)];
+        b_aug[g] = half == 0 ? 1.0f : qn;
+    }
+    asm volatile("" : "+v"(b_aug[NG - 1]) : : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    uint4 ah[4], al[4];
+    float aug;
+    {
+        const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(s_dyn + col * 64);
+        uint32_t addr[8];
+        uint4 av[8];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            addr[v] = base + ((((uint32_t)(4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
+            addr[4 + v] = base + ((((uint32_t)(8 + 4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
+        }
+        lds_read8_b128(addr, av, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(s_aug + lane), aug);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { ah[v] = av[v]; al[v] = av[4 + v]; }
+    }
+    f32x16 c[NG];
+    int32_t kd0 = MF_KEY_NONE, kd1 = MF_KEY_NONE, kd2 = MF_KEY_NONE, kd3 = MF_KEY_NONE, kd4 = MF_KEY_NONE, kd5 = MF_KEY_NONE;   // (bf_pair<false> touches no keys)
+    const f32x16 none = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bf_pair<false, M>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], c[0], c[1], none, none, 0u, kd0, kd1, kd2, kd3, kd4, kd5);
+    bf_pair<false, M>(ah, al, aug, bh[2], bl[2], b_aug[2], bh[3], bl[3], b_aug[3], c[2], c[3], none, none, 0u, kd0, kd1, kd2, kd3, kd4, kd5);
+    // accumulator register r of lane (col, half) is row (r & 3) + 8 (r >> 2) + 4 half of the tile for query col of the group: four 16-byte stores
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int qi = q0 + g * 32 + col;
+        if (qi >= nq) continue;
+        float* dst = x + (size_t)qi * ld + t * 32 + 4 * half;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            *reinterpret_cast<float4*>(dst + 8 * m) = make_float4(c[g][4 * m], c[g][4 * m + 1], c[g][4 * m + 2], c[g][4 * m + 3]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ persistent variant
@@ -1327,12 +1391,14 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                                 // the row stores at the end of its chain (the workgroups that wrote a row ended 3-4 us after those that did not) and
                                 // the kernel gets no third branch (whose register demand made the scoring branch spill)
                                                      , bool rows_only = false
-                                // shadow rows (round 6): strips n_vocab_blocks .. n_blocks - 1 of the records are the filter's scores of the descriptors of the
-                                // frame before (sh_q of them; keys name rows SHADOW_ROW_BASE + j).  Descriptor j is a row of the vocabulary iff bit j of
-                                // sh_mask is set (the final new-word mask of that frame's decision loop, mw words, followed by its mw + 1 word prefix sums):
-                                // row n_lo0 + rank(j), word pend_first_id + rank(j), read from pend_desc -- an exact candidate like any other, in the same
-                                // round trip.  The rows [n_lo0, p_hi) then need no scan of their own (and are written by the rows_only workgroups).
-                                                     , const uint32_t* __restrict__ sh_mask = nullptr, int sh_q = 0, int n_vocab_blocks = 0x7fffffff
+                                // shadow scores (round 6): sh_x[qi * sh_ld + j] is the filter's score of this query against descriptor j of the frame before
+                                // (sh_q of them; shadow_scores_body of launch A).  Descriptor j is a row of the vocabulary iff bit j of sh_mask is set (the
+                                // final new-word mask of that frame's decision loop, mw words, followed by its mw + 1 word prefix sums): row n_lo0 + rank(j),
+                                // word pend_first_id + rank(j), read from pend_desc.  The words whose score is at or below the threshold join the candidates
+                                // as keys of ONE row (SHADOW_ROW_BASE + j) and are evaluated exactly in the same round trip as the others; a word above the
+                                // threshold cannot be among the two nearest, by the argument that covers every kept key above it.  The rows [n_lo0, p_hi)
+                                // then need no scan of their own (and are written by the rows_only workgroups).
+                                                     , const uint32_t* __restrict__ sh_mask = nullptr, int sh_q = 0, const float* __restrict__ sh_x = nullptr, int sh_ld = 0
                                                      ) {
     static_assert(DIM == 64, "16 lanes x 4 floats per candidate row");
     // rows [pend_lo[0], pend_hi[0]): words the previous frame created, appended on the device after this frame's filter took its
@@ -1519,17 +1585,15 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         if (tid < cb.nq) dreg0 = cb.selfdist[(size_t)qi * cb.ld + tid];
         if (tid + MF_BLOCK < cb.nq) dreg1 = cb.selfdist[(size_t)qi * cb.ld + tid + MF_BLOCK];
     }
+    float2 xsh = make_float2(__int_as_float(0x7f800000), __int_as_float(0x7f800000));   // the query's scores against descriptors 2 tid, 2 tid + 1 of the frame before
+    if (sh_q > 0 && 2 * tid < sh_ld) xsh = *reinterpret_cast<const float2*>(sh_x + (size_t)qi * sh_ld + 2 * tid);
     float qn = fmaf(q4.w, q4.w, fmaf(q4.z, q4.z, fmaf(q4.y, q4.y, q4.x * q4.x)));
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) qn += __shfl_xor(qn, m, 64);
 
     // ---- pass 1: tau and the bound on dropped rows
     uint32_t a0 = INF, a1 = INF, bound = breg0;
-    // (a shadow strip's key may owe its score to a descriptor that did NOT become a word: tau -- whose meaning is "two true rows lie this close" --
-    // is taken over the vocabulary strips alone; shadow keys at or below the threshold derived from it are candidates like any others, and the rows
-    // a shadow strip dropped are covered by its bound)
     auto see = [&](uint64_t k, int c) {
-        if (c / KEEP >= n_vocab_blocks) return;
         const uint32_t sc = min((uint32_t)(k >> 32), INF);                  // KEY_NONE -> +inf
         if (LAST_KEY_BOUNDS && (c % KEEP) == KEEP - 1) bound = min(bound, sc);   // rows the block merge dropped are no better than its last key
         const uint32_t h = max(a0, sc);
@@ -1605,6 +1669,17 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     take(kreg1);
     take(kreg2);
     for (int c = tid + 3 * MF_BLOCK; c < n_keys; c += MF_BLOCK) take(key_at(c));
+    if (sh_q > 0) {                                                    // ... and the descriptors of the frame before that became words
+        auto take_sh = [&](uint32_t j, float xs) {
+            if (j < (uint32_t)sh_q && xs <= thr && sh_isword(j)) {
+                const int slot = atomicAdd(&s_ncand, 1);
+                if (slot < RR_KEYS) s_cand[slot] = ((uint64_t)(xs < 0.0f ? 0u : __float_as_uint(xs)) << 32) | (uint64_t)(SHADOW_ROW_BASE + j);
+            }
+        };
+        take_sh(2u * (uint32_t)tid, xsh.x);
+        take_sh(2u * (uint32_t)tid + 1u, xsh.y);
+        for (int j = 2 * MF_BLOCK + tid; j < sh_q; j += MF_BLOCK) take_sh((uint32_t)j, sh_x[(size_t)qi * sh_ld + j]);   // (frames of more than 512 descriptors)
+    }
     lds_barrier();
     RR_STAMP(2);
     const int n_keys_in = s_ncand;
@@ -1620,7 +1695,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     // the vocabulary row a LIVE candidate stands for (the distance tie-break is by row): a shadow candidate is the row its descriptor is being
     // written to in this very launch -- behind every row the filter saw, in word order
     auto real_row = [&](int i) -> uint32_t {
-        const uint32_t r = cand_row(i);
+        const uint32_t r = cand_row(i);                                   // (a live shadow slot is slot 0 of its key: r = SHADOW_ROW_BASE + j)
         return (sh_q > 0 && r >= SHADOW_ROW_BASE) ? (uint32_t)(n_lo0 + sh_rank(r - SHADOW_ROW_BASE)) : r;
     };
     // ... get their exact distances (reference arithmetic, dist.h:150-177), one candidate per 16-lane group and trip; the word
@@ -1630,14 +1705,14 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         for (int i = tid >> 4; i < n_cand; i += MF_BLOCK / 16) {
             const uint64_t k = s_cand[GS == 4 ? (i >> 2) : i];
             const uint32_t row = cand_row(i);
-            const bool sh = sh_q > 0 && row >= SHADOW_ROW_BASE;           // (uniform over the wave: the four rows of ONE key)
-            const uint32_t sj = row - SHADOW_ROW_BASE;
-            const bool in_range = sh ? sj < (uint32_t)sh_q : (GS == 1 || row < row_limit);
+            const bool sh = sh_q > 0 && (uint32_t)k >= SHADOW_ROW_BASE;   // (uniform over the wave: the slots of ONE key) -- a key of ONE row, a word
+            const uint32_t sj = (uint32_t)k - SHADOW_ROW_BASE;
+            const bool in_range = sh ? (GS == 1 || (i & 3) == 0) : (GS == 1 || row < row_limit);
             const uint32_t rrow = in_range ? row : (uint32_t)k;            // (an address that exists: the group's first row)
-            const float* src = sh ? pend_desc + (size_t)(in_range ? sj : (uint32_t)k - SHADOW_ROW_BASE) * DIM : vocab + (size_t)rrow * DIM;
+            const float* src = sh ? pend_desc + (size_t)sj * DIM : vocab + (size_t)rrow * DIM;
             const float4 v4 = reinterpret_cast<const float4*>(src)[lane & 15];
             int32_t wid = 0;
-            if ((lane & 15) == 0) wid = sh ? ((in_range && sh_isword(sj)) ? pend_first_id + sh_rank(sj) : 0) : row_id[rrow];
+            if ((lane & 15) == 0) wid = sh ? pend_first_id + sh_rank(sj) : row_id[rrow];
             const float d0 = __fsub_rn(v4.x, q4.x), d1 = __fsub_rn(v4.y, q4.y), d2 = __fsub_rn(v4.z, q4.z), d3 = __fsub_rn(v4.w, q4.w);
             float t = __fmul_rn(d0, d0);
             t = __fadd_rn(t, __fmul_rn(d1, d1));
@@ -1649,8 +1724,8 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
             const bool live = in_range && (GS == 1 || __shfl(wid, lane & 48, 64) != 0);
             const float res_raw = res;
             if (!live) res = __int_as_float(0x7f800000);
-            // the filter's score of a key is its group's minimum -- over every descriptor of a shadow group, word or not (the filter saw them all)
-            float gmin = (sh && in_range) ? res_raw : res;
+            float gmin = res;                                            // the filter's score of a key is its group's minimum (a shadow key: its one row's score)
+            (void)res_raw;
             if (GS == 4) { gmin = fminf(gmin, __shfl_xor(gmin, 16, 64)); gmin = fminf(gmin, __shfl_xor(gmin, 32, 64)); }
             if ((lane & 15) == 0) {
                 s_exact[i] = live ? (((uint64_t)__float_as_uint(res) << 32) | (uint32_t)i) : KEY_NONE;   // the slot stands in for the row: see below
@@ -1883,7 +1958,7 @@ struct FilterArgs {
     uint64_t* pk; uint32_t* pl; SelfdistJob sd; const int32_t* n_lo;
     const uint4* qsplit; const float* qnorm;                           // pre-split queries (non-persistent pipelined launch)
     int delay;                                                         // PipeOpts::filter_delay (timing experiments)
-    const float* sh_bf; const float* sh_norm; int sh_rows, sh_blocks;  // shadow rows of the frame before (PipeKnn::sh_bf): sh_blocks extra strips
+    const float* sh_bf; const float* sh_norm; int sh_rows; float* sh_x; int sh_ld;   // shadow scores (shadow_scores_body): the operand rows of the frame before, the score matrix
 };
 struct RerankArgs {
     const uint64_t* pk; const uint32_t* pl; int n_blocks, nq; const float* vocab; const float* queries; const int32_t* row_id;
@@ -1893,14 +1968,14 @@ struct RerankArgs {
     int f16;                                                           // the filter multiplied fp16 operands (one product): eps_f16
     const float* pend_desc; const uint32_t* pend_list; int32_t pend_first_id;   // the rows a deferred append writes in this launch, as descriptors
     const float* cross; int cross_ld;                                  // this frame's distances to every descriptor of pend_desc (CrossJob of the previous pair), or NULL
-    const uint32_t* sh_mask; int sh_q; int n_vocab_blocks;             // shadow rows (knn_mfma_rerank_body): sh_q == 0: none
+    const uint32_t* sh_mask; int sh_q; const float* sh_x; int sh_ld;   // shadow scores (knn_mfma_rerank_body): sh_q == 0: none
 };
 constexpr int PIPE_BLOCK = 256;     // workgroup size of both fused launches (the filter's and the re-rank's)
 
 // workgroup 0 is the decision loop of the previous frame, workgroup 1 the retirement + registration of the frame before that (dispatched
 // first: they are the longest single workgroups of the launch); the redo helpers of the decision loop come LAST -- they have nothing
 // to do unless the certificate rejected a query, and in front they would each hold a compute unit's LDS while they find out
-struct TailRoles { int has_resolve, has_register, n_redo, n_filter_wgs, n_q_wgs; };
+struct TailRoles { int has_resolve, has_register, n_redo, n_filter_wgs, n_q_wgs, n_sh_wgs; };
 #ifdef LCD_B_TIMING   // timing experiment only: start / end of every workgroup of launch A (100 MHz)
 __device__ unsigned long long g_a_timing[2 * 4096];
 #define A_STAMP(i) do { __builtin_amdgcn_s_barrier(); if (threadIdx.x == 0 && blockIdx.x < 4096) g_a_timing[2 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -1916,7 +1991,13 @@ __device__ __forceinline__ void frame_a_body(float* s_dyn, const FilterArgs& f, 
     A_STAMP(0);
     if (bid < tr.has_resolve) { frame_resolve_part<PIPE_BLOCK>((uint32_t*)s_dyn, r, 0, 1 + tr.n_redo); A_STAMP(1); return; }
     if (bid < n_front) { frame_register_part<PIPE_BLOCK>((uint32_t*)s_dyn, a, ret); A_STAMP(1); return; }
-    const int after_filter = n_front + tr.n_filter_wgs;
+    const int after_strips = n_front + tr.n_filter_wgs;
+    if (bid >= after_strips && bid < after_strips + tr.n_sh_wgs) {      // the shadow scores of this frame against the frame before it (non-persistent launches)
+        if constexpr (!PERSISTENT) shadow_scores_body<M>(s_dyn, bid - after_strips, f.sh_bf, f.sh_norm, f.sh_rows, f.qsplit, f.qnorm, f.nq, f.qpad, f.sh_x, f.sh_ld);
+        A_STAMP(1);
+        return;
+    }
+    const int after_filter = after_strips + tr.n_sh_wgs;
     if (bid >= after_filter && bid < after_filter + tr.n_q_wgs) { qsplit_body(qs, bid - after_filter); A_STAMP(1); return; }
     if (bid >= after_filter + tr.n_q_wgs) { frame_resolve_part<PIPE_BLOCK>((uint32_t*)s_dyn, r, bid - after_filter - tr.n_q_wgs + 1, 1 + tr.n_redo); A_STAMP(1); return; }
     for (int i = 0; i < f.delay; ++i) __builtin_amdgcn_s_sleep(1);      // (0 unless "filter_delay" is set)
@@ -1925,7 +2006,7 @@ __device__ __forceinline__ void frame_a_body(float* s_dyn, const FilterArgs& f, 
                                f.pl, f.sd, f.n_lo);
     else
         knn_bf16_filter_body_q<M>(s_dyn, bid - n_front, f.vocab_bf, f.row_norm, f.n_rows, f.qsplit, f.qnorm, f.nq, f.qpad, f.tiles_per_block, f.n_blocks, f.pk,
-                               f.pl, f.sd, f.n_lo, f.sh_bf, f.sh_norm, f.sh_rows, f.sh_blocks);
+                               f.pl, f.sd, f.n_lo);
     A_STAMP(1);
 }
 // two workgroups per compute unit: 66 KB of LDS each, and a register budget of two waves per SIMD
@@ -1980,7 +2061,7 @@ __global__ __launch_bounds__(PIPE_B_BLOCK, 6) void frame_b_kernel(RerankArgs k, 
                                                           k.out_word, k.out_dist, k.fail_list, k.fail_count, k.cb, k.n_lo, k.n_hi, k.plan_rows,
                                                           s_dyn_b, k.stage_rows, k.f16, k.pend_desc, k.pend_list, k.pend_first_id, k.cross, k.cross_ld
                                                           , app, wr_any && (n_wr == 0 || rows_only), rows_only ? wr_index : pair, n_wr > 0 ? n_wr : (k.nq + 1) / 2
-                                                          , rows_only, k.sh_mask, k.sh_q, k.sh_q > 0 ? k.n_vocab_blocks : 0x7fffffff);
+                                                          , rows_only, k.sh_mask, k.sh_q, k.sh_x, k.sh_ld);
         B_STAMP(1);
         return;
     }
@@ -2152,7 +2233,7 @@ MfmaPlan knn_bf16_plan(int q, int n_rows, int other_wgs) {
     return p;
 }
 size_t knn_bf16_partial_bytes(const MfmaPlan& p) {
-    const size_t nb = (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) + (size_t)p.n_shadow;
+    const size_t nb = (size_t)(p.n_blocks > 0 ? p.n_blocks : 1);
     return nb * BF_KEEP * p.qpad * sizeof(uint64_t) + nb * p.qpad * sizeof(uint32_t);
 }
 hipError_t launch_vocab_bf16(const void* vocab, int first, int n, int dim, void* bf, hipStream_t s, int f16) {
@@ -2310,8 +2391,8 @@ hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLa
         const PipeKnn& k = *kp;
         p = k.plan;
         uint64_t* pk = (uint64_t*)k.partial;
-        uint32_t* pl = (uint32_t*)(pk + ((size_t)(p.n_blocks > 0 ? p.n_blocks : 1) + (size_t)p.n_shadow) * BF_KEEP * p.qpad);
-        if (p.n_shadow > 0 && k.sh_bf && k.sh_norm && k.sh_rows > 0) { f.sh_bf = (const float*)k.sh_bf; f.sh_norm = k.sh_norm; f.sh_rows = k.sh_rows; f.sh_blocks = p.n_shadow; }
+        uint32_t* pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * BF_KEEP * p.qpad);
+        if (p.n_shadow > 0 && k.sh_bf && k.sh_norm && k.sh_rows > 0 && k.sh_x) { f.sh_bf = (const float*)k.sh_bf; f.sh_norm = k.sh_norm; f.sh_rows = k.sh_rows; f.sh_x = k.sh_x; f.sh_ld = k.sh_ld; }
         f.vocab_bf = (const float*)k.vocab_bf; f.row_norm = k.row_norm; f.n_rows = p.n_rows; f.queries = (const float*)k.queries; f.nq = p.q; f.qpad = p.qpad;
         f.tiles_per_block = p.tiles_per_block; f.n_blocks = p.n_blocks; f.pk = pk; f.pl = pl; f.n_lo = k.n_lo;
         f.qsplit = (const uint4*)k.qsplit; f.qnorm = k.qnorm;
@@ -2327,14 +2408,15 @@ hipError_t launch_frame_a(const PipeKnn* kp, const QSplitArgs* qsp, const TailLa
     f.delay = opt.filter_delay;
     const int px = p.q > 0 ? bf16_persistent_px(p) : 0;
     if (px == 0 && p.q > 0 && (!f.qsplit || !f.qnorm)) return hipErrorInvalidValue;      // the one-strip launch reads pre-split queries
-    if ((px > 0 ? 1 : 0) + (f.sh_blocks != p.n_shadow ? 1 : 0) > 0 && p.n_shadow > 0) return hipErrorInvalidValue;   // shadow strips: one-strip launches with the rows at hand only (the engine plans them so)
+    if (p.n_shadow > 0 && (px > 0 || !f.sh_x)) return hipErrorInvalidValue;   // shadow scores: one-strip launches with the rows at hand only (the engine plans them so)
     TailRoles tr;
-    tr.n_filter_wgs = p.q > 0 ? f.sd.n_tiles + (px > 0 ? px : p.n_blocks + f.sh_blocks) * ((p.q + BF_QB - 1) / BF_QB) : 0;
+    tr.n_filter_wgs = p.q > 0 ? f.sd.n_tiles + (px > 0 ? px : p.n_blocks) * ((p.q + BF_QB - 1) / BF_QB) : 0;
+    tr.n_sh_wgs = (p.q > 0 && p.n_shadow > 0) ? ((f.sh_rows + 31) / 32) * ((p.q + BF_QB - 1) / BF_QB) : 0;
     tr.has_resolve = resolve ? 1 : 0; tr.has_register = reg ? 1 : 0; tr.n_redo = resolve ? resolve->n_redo : 0;
     QSplitArgs qs{};
     if (qsp) { qs = *qsp; qs.n_wgs = std::min((qs.qpad * 8 + PIPE_BLOCK - 1) / PIPE_BLOCK, 32); if (qs.n_wgs < 1) qs.n_wgs = 1; }   // one item per thread up to 1 024 descriptors
     tr.n_q_wgs = qsp ? qs.n_wgs : 0;
-    const int grid = tr.n_filter_wgs + tr.has_resolve + tr.has_register + tr.n_redo + tr.n_q_wgs;
+    const int grid = tr.n_filter_wgs + tr.n_sh_wgs + tr.has_resolve + tr.has_register + tr.n_redo + tr.n_q_wgs;
     if (grid == 0) return hipSuccess;
     const size_t lds = px > 0 ? BF_LDS_BYTES_P : BF_LDS_BYTES_Q;
     if ((resolve && resolve->shmem_resolve > lds) || (reg && reg->shmem + (size_t)reg->a.n * 4 > lds)) return hipErrorInvalidValue;   // (+ the word slots parked in LDS)
@@ -2376,8 +2458,8 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
     if (k) {
         const MfmaPlan& p = k->plan;
         uint64_t* pk = (uint64_t*)k->partial;
-        rk.pk = pk; rk.pl = (uint32_t*)(pk + ((size_t)(p.n_blocks > 0 ? p.n_blocks : 1) + (size_t)p.n_shadow) * BF_KEEP * p.qpad);
-        rk.n_blocks = p.n_blocks + p.n_shadow; rk.n_vocab_blocks = p.n_blocks; rk.nq = p.q; rk.vocab = (const float*)k->vocab; rk.queries = (const float*)k->queries; rk.row_id = k->row_id;
+        rk.pk = pk; rk.pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * BF_KEEP * p.qpad);
+        rk.n_blocks = p.n_blocks; rk.nq = p.q; rk.vocab = (const float*)k->vocab; rk.queries = (const float*)k->queries; rk.row_id = k->row_id;
         rk.norm_max_bits = k->norm_max_bits; rk.out_row = k->out_row; rk.out_word = k->out_word; rk.out_dist = k->out_dist;
         rk.fail_list = k->fail_list; rk.fail_count = k->fail_count; rk.cb = k->cb; rk.n_lo = k->n_lo; rk.n_hi = k->n_hi; rk.plan_rows = p.n_rows; rk.f16 = p.f16;
         n_rerank = ((p.q + 1) / 2 + 7) & ~7;                          // two queries per workgroup; padded to the XCD count (frame_b_kernel)
@@ -2406,9 +2488,9 @@ hipError_t launch_frame_b(const PipeKnn* k, const ScoreArgs* score, int score_wg
     if (!writers && k && n_app > 0 && k->n_hi && k->plan.q > 0 && rk.stage_rows >= 4) n_app = 0;   // the re-rank workgroups write the rows (`ar` stays filled in: they get it);
                                                                                       // without re-rank workgroups or a staging area the writers stay
     // shadow rows: the filter of launch A ranked the descriptors of the frame whose rows are written here; the re-rank needs that frame's new-word mask
-    const bool shadow = k && k->plan.n_shadow > 0 && k->sh_mask && k->sh_q > 0 && app && app->ap.enabled && app->ap.defer_rows && rk.pend_desc && !rk.cross;
-    if (k && k->plan.n_shadow > 0 && !shadow) return hipErrorInvalidValue;          // (records of shadow strips nobody could interpret: the engine plans them together)
-    if (shadow) { rk.sh_mask = k->sh_mask; rk.sh_q = k->sh_q; }
+    const bool shadow = k && k->plan.n_shadow > 0 && k->sh_mask && k->sh_x && k->sh_q > 0 && app && app->ap.enabled && app->ap.defer_rows && rk.pend_desc && !rk.cross;
+    if (k && k->plan.n_shadow > 0 && !shadow) return hipErrorInvalidValue;          // (launch A wrote scores nobody reads: the engine plans the two together)
+    if (shadow) { rk.sh_mask = k->sh_mask; rk.sh_q = k->sh_q; rk.sh_x = k->sh_x; rk.sh_ld = k->sh_ld; }
     // round 6: rows written by n_wr extra workgroups of the re-rank role instead of by the re-rank workgroups themselves ("row_writer_wgs");
     // with shadow rows the re-rank workgroups stage nothing they could write, so the writers are not optional
     const int n_wr = (!writers && n_app == 0 && k && app && app->ap.enabled && app->ap.defer_rows && k->n_hi && k->plan.q > 0 && rk.stage_rows >= 4 && !rk.cross &&

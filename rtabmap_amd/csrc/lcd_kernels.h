@@ -88,11 +88,9 @@ struct MfmaPlan {
     int other_wgs = 0;       // long-running workgroups of other kinds in the same launch (each holds a compute unit like a filter workgroup)
     int one_strip = 0;       // 1: one workgroup per strip whatever the number of strips (lcd_set_option "strip_tiles")
     int f16 = 0;             // 1: the operand tables hold IEEE half and the filter multiplies ONE product per fp32 product (LCD_KNN_F16)
-    int n_shadow = 0;        // extra strips (8 tiles each) over the shadow rows of the frame before (PipeKnn::sh_bf); their candidate records follow the
-                             // vocabulary strips' (strip index n_blocks ..), their keys name rows SHADOW_ROW_BASE + descriptor index
+    int n_shadow = 0;        // > 0: the launch also computes the shadow scores (PipeKnn::sh_bf, sh_x): one workgroup per 32-row tile of the frame before
 };
-constexpr uint32_t SHADOW_ROW_BASE = 1u << 30;
-inline int knn_shadow_strips(int q_prev) { return q_prev > 0 ? ((q_prev + 63) / 64 * 64 + 255) / 256 : 0; }
+constexpr uint32_t SHADOW_ROW_BASE = 1u << 30;   // candidate keys of the re-rank name descriptor j of the frame before as row SHADOW_ROW_BASE + j
 bool knn_mfma_supported(int dtype, int dim);
 void knn_set_compute_units(int cus);           // the device's compute units: what the filter launch plans fill (256 unless told otherwise)
 bool knn_bf16_persistent(const MfmaPlan& p);   // the bf16 filter launch of this plan uses the persistent kernels (..._kernel_p)

@@ -196,6 +196,7 @@ struct PipeKnn {
     // frame's query pre-split; the filter ranks them in sh_blocks extra strips, the re-rank takes the ones that became words (ShadowArgs)
     const void* sh_bf = nullptr; const float* sh_norm = nullptr; int sh_rows = 0;   // sh_rows: that frame's padded descriptor count
     const uint32_t* sh_mask = nullptr; int sh_q = 0;   // that frame's final new-word mask + prefix sums (AppendArgs::mask_out) and its descriptor count
+    float* sh_x = nullptr; int sh_ld = 0;              // [q x sh_ld] the filter's scores of this frame's queries against those rows (launch A writes, launch B reads)
     float* cross = nullptr;          // [q x cross_ld] distances of this frame's queries to the cross_ncols descriptors at cross_cols (the frame
     int cross_ld = 0;                // before it): written by extra tiles of launch A, read by the re-rank of launch B for its pending rows (which are
     const void* cross_cols = nullptr; int cross_ncols = 0;   // descriptors of that frame); NULL: the re-rank stages the pending rows and computes them
