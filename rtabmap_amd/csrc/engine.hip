@@ -1357,7 +1357,7 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
     // shadow rows: f_res's new words are not rows when f_knn's filter runs (its decision loop rides in the same launch) -- the filter ranks f_res's
     // descriptors from the operand rows its query pre-split left, the re-rank keeps the ones the mask f_res's decision loop publishes names
     const bool sh_ok = f_knn && f_res && f_res->has_shadow && f_res->chained && f_knn->chained && tl_res.r.ap.enabled && tl_res.r.ap.defer_rows && tl_res.r.ap.is_f32_64 &&
-                       h->popt.shadow_rows && !h->popt.cross_frames;
+                       h->popt.shadow_rows && !h->popt.cross_frames && h->popt.append_from_rerank;
     if (f_knn) { int rc = build_knn(h, *f_knn, &k, sh_ok ? f_res : nullptr); if (rc) return rc; h->knn_launches += 1; }
     if (f_res && f_res->has_shadow && tl_res.r.ap.enabled && tl_res.r.ap.defer_rows) tl_res.r.ap.mask_out = h->ring[f_res->set].d_newmask.as<uint32_t>();
     if (f_knn && f_res && tl_res.r.ap.enabled && tl_res.r.ap.defer_rows && tl_res.r.ap.is_f32_64 && h->popt.cross_frames) {
@@ -2047,9 +2047,9 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     // timing experiments: the filter workgroups of launch A wait value x 64 clocks in front of their first request (the single-workgroup
     // chains of the launch then get their first round trip ahead of the strips' opening burst)
     if (!std::strcmp(key, "filter_delay") && value >= 0 && value <= 127) { h->popt.filter_delay = (int)value; return LCD_OK; }
-    if (!std::strcmp(key, "shadow_rows") && value >= -1 && value <= 1) { h->popt.shadow_rows = value > 0 ? 1 : 0; return LCD_OK; }
-    if (!std::strcmp(key, "mirror_from_b") && value >= -1 && value <= 1) { h->popt.mirror_from_b = value > 0 ? 1 : 0; return LCD_OK; }
-    if (!std::strcmp(key, "row_writer_wgs") && value >= -1 && value <= 256) { h->popt.row_writer_wgs = value > 0 ? (int)value : 0; return LCD_OK; }
+    if (!std::strcmp(key, "shadow_rows") && value >= -1 && value <= 1) { h->popt.shadow_rows = value != 0 ? 1 : 0; return LCD_OK; }          // (-1: built-in = on)
+    if (!std::strcmp(key, "mirror_from_b") && value >= -1 && value <= 1) { h->popt.mirror_from_b = value != 0 ? 1 : 0; return LCD_OK; }
+    if (!std::strcmp(key, "row_writer_wgs") && value >= -1 && value <= 256) { h->popt.row_writer_wgs = value >= 0 ? (int)value : PipeOpts().row_writer_wgs; return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");
     LCD_CATCH(h)
 }

@@ -224,10 +224,12 @@ struct PipeOpts {
     int append_from_rerank = 1;      // "append_from_rerank" (0: the eight row-writer workgroups of round 4, for A/B runs)
     int append_split_buckets = -1;   // "append_split_buckets" (< 0: built-in)
     int filter_delay = 0;            // "filter_delay": s_sleep units (64 clocks) a filter workgroup waits in front of its first request
-    int shadow_rows = 0;             // "shadow_rows": the filter also ranks the descriptors of the frame before (whose new words are not rows yet)
-    int mirror_from_b = 0;           // "mirror_from_b": the pinned row-count mirror of an appending frame is stored by launch B instead of by the decision loop
-    int row_writer_wgs = 0;          // "row_writer_wgs": > 0 = that many extra workgroups of launch B's re-rank role write the appended rows
-                                     // (0: the re-rank workgroups write them at the end of their own chains)
+    // round 6, measured by kernel trace on the driver's command (profiles/r06_ab_notes.txt): all three on by default
+    int shadow_rows = 1;             // "shadow_rows": launch A also scores the frame against the descriptors of the frame before (whose new words are not rows
+                                     // yet), the re-rank keeps the words' scores under its threshold: no workgroup stages or scans the new rows (launch B 19.6 -> 15.4 us)
+    int mirror_from_b = 1;           // "mirror_from_b": the pinned row-count mirror of an appending frame is stored by launch B instead of by the decision loop (launch A -0.3 us)
+    int row_writer_wgs = 16;         // "row_writer_wgs": > 0 = that many extra workgroups of launch B's re-rank role write the appended rows (launch B -0.9 us
+                                     // without the shadow scores; with them nobody else could); 0: the re-rank workgroups write them at the end of their own chains
 };
 hipError_t launch_frame_a(const PipeKnn* k, const QSplitArgs* qs, const TailLaunch* resolve, const TailLaunch* reg, hipStream_t s,
                           hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, const PipeOpts& opt = PipeOpts());

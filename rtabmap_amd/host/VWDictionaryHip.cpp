@@ -23,27 +23,50 @@ Mat::Mat(int r, int c, int t, const void* src) : rows(r), cols(c), type_(t) {
 
 // ---------------------------------------------------------------------------------------------- VisualWord
 VisualWord::VisualWord(int id, const Mat& descriptor, int signatureId)
-    : _id(id), _descriptor(descriptor), _saved(false), _totalReferences(0) {
+    : _id(id), _descriptor(descriptor), _saved(false), _totalReferences(0), _head(0), _mapValid(true) {
     if (signatureId) addRef(signatureId);
 }
-// (same container and the same result as the reference's find-then-insert; the two ends are looked at first because that is where a
-// stream's calls land -- the newest signature has the largest id, the signature Memory forgets the smallest -- and a find in the map of a
-// popular word walks ~17 levels of a 10^5-node tree: 0.5 ms per frame of the mirror's time at the headline's memory size)
-void VisualWord::addRef(int signatureId) {
-    if (_references.empty() || _references.rbegin()->first < signatureId) _references.insert(_references.end(), std::pair<int, int>(signatureId, 1));
+// the posting of a signature, or end(): the two ends first (the newest signature has the largest id, the one Memory forgets the smallest --
+// where a stream's calls land), a binary search otherwise
+std::vector<std::pair<int, int> >::iterator VisualWord::findRef(int signatureId) {
+    if (_head == _refs.size()) return _refs.end();
+    if (_refs.back().first == signatureId) return _refs.end() - 1;
+    if (_refs[_head].first == signatureId) return _refs.begin() + _head;
+    std::vector<std::pair<int, int> >::iterator it = std::lower_bound(_refs.begin() + _head, _refs.end(), std::pair<int, int>(signatureId, 0));
+    return (it != _refs.end() && it->first == signatureId) ? it : _refs.end();
+}
+void VisualWord::addRef(int signatureId) {   // VisualWord.cpp:51-60: _references[signatureId] += 1 (inserted when missing), ++_totalReferences
+    if (_head == _refs.size() || _refs.back().first < signatureId) _refs.push_back(std::pair<int, int>(signatureId, 1));
     else {
-        std::map<int, int>::iterator iter = _references.rbegin()->first == signatureId ? --_references.end() : _references.find(signatureId);
-        if (iter != _references.end()) iter->second += 1;
-        else _references.insert(std::pair<int, int>(signatureId, 1));
+        std::vector<std::pair<int, int> >::iterator it = findRef(signatureId);
+        if (it != _refs.end()) it->second += 1;
+        else _refs.insert(std::lower_bound(_refs.begin() + _head, _refs.end(), std::pair<int, int>(signatureId, 0)), std::pair<int, int>(signatureId, 1));
     }
     ++_totalReferences;
+    _mapValid = false;
 }
-int VisualWord::removeAllRef(int signatureId) {
+int VisualWord::removeAllRef(int signatureId) {   // VisualWord.cpp:62-70
     int removed = 0;
-    std::map<int, int>::iterator iter = (!_references.empty() && _references.begin()->first == signatureId) ? _references.begin() : _references.find(signatureId);
-    if (iter != _references.end()) { removed = iter->second; _references.erase(iter); }
+    std::vector<std::pair<int, int> >::iterator it = findRef(signatureId);
+    if (it != _refs.end()) {
+        removed = it->second;
+        if ((size_t)(it - _refs.begin()) == _head) {
+            ++_head;
+            if (_head == _refs.size()) { _refs.clear(); _head = 0; }
+            else if (_head > 64 && _head > _refs.size() - _head) { _refs.erase(_refs.begin(), _refs.begin() + _head); _head = 0; }
+        } else _refs.erase(it);
+        _mapValid = false;
+    }
     _totalReferences -= removed;
     return removed;
+}
+const std::map<int, int>& VisualWord::getReferences() const {
+    if (!_mapValid) {
+        _references.clear();
+        for (size_t k = _head; k < _refs.size(); ++k) _references.insert(_references.end(), _refs[k]);
+        _mapValid = true;
+    }
+    return _references;
 }
 
 // ---------------------------------------------------------------------------------------------- VWDictionaryHip
@@ -305,7 +328,7 @@ void VWDictionaryHip::removeAllWordRef(int wordId, int signatureId) {   // :899-
     std::map<int, VisualWord*>::iterator it = _visualWords.find(wordId);
     if (it != _visualWords.end()) {
         _totalActiveReferences -= it->second->removeAllRef(signatureId);
-        if (it->second->getReferences().size() == 0) _unusedWords.insert(std::pair<int, VisualWord*>(wordId, it->second));
+        if (it->second->getReferencesCount() == 0) _unusedWords.insert(std::pair<int, VisualWord*>(wordId, it->second));
         std::map<int, std::vector<int> >::iterator s = _sigWords.find(signatureId);
         if (s != _sigWords.end()) {
             s->second.erase(std::remove(s->second.begin(), s->second.end(), wordId), s->second.end());
@@ -323,7 +346,7 @@ void VWDictionaryHip::removeAllWordRefs(const std::set<int>& wordIds, int signat
         VisualWord* vw = lookupWord(*k);
         if (!vw) continue;
         _totalActiveReferences -= vw->removeAllRef(signatureId);
-        if (vw->getReferences().size() == 0) _unusedWords.insert(std::pair<int, VisualWord*>(*k, vw));
+        if (vw->getReferencesCount() == 0) _unusedWords.insert(std::pair<int, VisualWord*>(*k, vw));
         any = true;
     }
     std::map<int, std::vector<int> >::iterator s = _sigWords.find(signatureId);
@@ -339,7 +362,7 @@ void VWDictionaryHip::addWord(VisualWord* vw) {   // :1554-1573
     _visualWords.insert(_visualWords.end(), std::pair<int, VisualWord*>(vw->id(), vw));
     indexWord(vw);
     _notIndexedWords.insert(_notIndexedWords.end(), vw->id());
-    if (vw->getReferences().size()) {
+    if (vw->getReferencesCount()) {
         int s = 0;
         for (std::map<int, int>::const_iterator i = vw->getReferences().begin(); i != vw->getReferences().end(); ++i) {
             s += i->second;

@@ -54,7 +54,13 @@ inline float uStr2Float(const std::string& s) {
     return value;
 }
 
-class VisualWord {   // reference VisualWord.h:38-64, VisualWord.cpp:36-70
+// reference VisualWord.h:38-64, VisualWord.cpp:36-70.  Same interface, same answers; the container behind it differs (round 6): the postings
+// (signature id, occurrences) live in a vector sorted by signature id -- 8 bytes each instead of a 48-byte red-black node, the newest signature
+// appended at the back, the one Memory forgets taken from the front (an offset moves; the dead prefix is dropped when it outgrows the live part)
+// -- and the std::map<int, int> the reference's getReferences() returns is built from it ON DEMAND and kept until the next change.  The hot
+// path (addRef per descriptor, removeAllRef per forgotten signature, "any reference left?") never builds it: at 100 000 signatures the maps of
+// the popular words held ~10^5 nodes each and their upkeep was ~1 ms per frame of the mirror's time.
+class VisualWord {
 public:
     VisualWord(int id, const Mat& descriptor, int signatureId = 0);
     void addRef(int signatureId);
@@ -62,7 +68,8 @@ public:
     int getTotalReferences() const { return _totalReferences; }
     int id() const { return _id; }
     const Mat& getDescriptor() const { return _descriptor; }
-    const std::map<int, int>& getReferences() const { return _references; }
+    const std::map<int, int>& getReferences() const;                  // materialised on demand (see above)
+    size_t getReferencesCount() const { return _refs.size() - _head; }   // getReferences().size() without the map
     bool isSaved() const { return _saved; }
     void setSaved(bool saved) { _saved = saved; }
 private:
@@ -70,7 +77,11 @@ private:
     Mat _descriptor;
     bool _saved;
     int _totalReferences;
-    std::map<int, int> _references;   // (signature id , occurrence in the signature)
+    std::vector<std::pair<int, int> > _refs;   // (signature id , occurrence in the signature), ascending id, live from _head on
+    size_t _head;
+    mutable std::map<int, int> _references;    // getReferences()'s answer, valid while _mapValid
+    mutable bool _mapValid;
+    std::vector<std::pair<int, int> >::iterator findRef(int signatureId);
 };
 
 class VWDictionaryHip {

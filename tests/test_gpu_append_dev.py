@@ -143,6 +143,15 @@ def test_new_rows_ranked_by_the_filter_as_shadow_rows(oracle, n_words, q, n_fram
     assert _stream(oracle, True, n_words=n_words, q=q, n_frames=n_frames, seed=41, knn_mode=knn_mode, options=opts, clean_every_frame=bool(extra.get("clean"))) > 100
 
 
+@pytest.mark.parametrize("options", [{"shadow_rows": 0}, {"shadow_rows": 0, "row_writer_wgs": 0}, {"shadow_rows": 0, "row_writer_wgs": 0, "mirror_from_b": 0}])
+@pytest.mark.parametrize("knn_mode", [None, "f16"])
+def test_new_rows_staged_and_scanned_by_the_rerank(oracle, options, knn_mode):
+    """the paths the shadow scores replaced stay in the library (vocabularies whose filter is persistent take them, and the options select them
+    for A/B runs): every re-rank workgroup stages the rows the previous frame appended and scans them exactly -- rows written by the writer
+    workgroups of the re-rank role, or (row_writer_wgs = 0) by the re-rank workgroups from their staging area; mirror stored by either launch"""
+    assert _stream(oracle, True, n_words=3000, q=96, n_frames=30, seed=43, knn_mode=knn_mode, options=options) > 200
+
+
 @pytest.mark.parametrize("options", [{"mirror_from_b": 1}, {"mirror_from_b": 1, "row_writer_wgs": 8}, {"mirror_from_b": 1, "append_from_rerank": 0},
                                      {"mirror_from_b": 1, "append_split_buckets": 0, "append_from_rerank": 0}])
 def test_row_count_mirror_stored_by_launch_b(oracle, options):

@@ -82,8 +82,11 @@ def main():
                 T = (q + 63) // 64
                 n_tl = T * (T + 1) // 2 + (T * T if int(opts.get("cross_frame_tiles", 0)) else 0)   # same-frame tiles (+ cross-frame ones)
                 n_qs = max(1, min((T * 64 * 8 + 255) // 256, 32))                                   # launch_frame_a: one item per thread
-                groups += [("filter", (idx >= 2) & (idx < a0)), ("distance tiles", (idx >= a0) & (idx < a0 + n_tl)),
-                           ("query pre-split", (idx >= a0 + n_tl) & (idx < a0 + n_tl + n_qs)), ("redo helpers", idx >= a0 + n_tl + n_qs)]
+                # round 6: the shadow-score workgroups (one per 32-row tile of the frame before, per block of 512 queries) sit between the tiles and the pre-split
+                n_sh = (T * 2) * ((q + 511) // 512) if (os.environ.get("APPEND") and int(opts.get("shadow_rows", 1)) and not int(opts.get("cross_frame_tiles", 0))) else 0
+                a1 = a0 + n_tl + n_sh
+                groups += [("filter", (idx >= 2) & (idx < a0)), ("distance tiles", (idx >= a0) & (idx < a0 + n_tl)), ("shadow scores", (idx >= a0 + n_tl) & (idx < a1)),
+                           ("query pre-split", (idx >= a1) & (idx < a1 + n_qs)), ("redo helpers", idx >= a1 + n_qs)]
             for nme, m in groups:
                 if m.sum():
                     st, en = b[m, 0], b[m, 1]
