@@ -453,12 +453,18 @@ constexpr size_t BF_LDS_BYTES = (size_t)(MF_WAVES * 4 + 2) * BF_TILE_F * 4 + (si
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 // DMA instructions [i0, i1) of the 8 that move one 32-row x 256-byte tile (same swizzle as dma_a_tile)
+// HI (round 6, the fp16 filter): only the row's first 128-byte line -- the "hi" operands, the only ones the one-product filter multiplies -- is
+// requested: the lanes whose chunk lies in the "lo" line sit the instruction out.  Same instruction count (the waits that count instructions
+// stay valid), same LDS layout (the lo positions are simply never written or read), HALF the bytes: the opening burst of launch A -- every
+// strip asks for its whole strip in the first microsecond -- is 6.3 MB instead of 12.5 MB at 49 000 words.
+template <bool HI = false>
 __device__ __forceinline__ void dma_tile_part(const float* __restrict__ base, int n_rows, int t, int lane, float* __restrict__ lds_slot,
                                               int i0, int i1) {
     for (int i = i0; i < i1; ++i) {
         const int p = i * 64 + lane;
         const int r = p >> 4, cpos = p & 15;
         const int c = cpos ^ (r & 15);
+        if (HI && c >= 8) continue;
         const int row = min(t * 32 + r, n_rows - 1);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)row * 64 + c * 4),
                                          (__attribute__((address_space(3))) void*)(lds_slot + i * 256), 16, 0, 0);
@@ -523,6 +529,24 @@ __device__ __forceinline__ void lds_read8_b128(const uint32_t (&addr)[8], uint4 
     out[0] = __builtin_bit_cast(uint4, v0); out[1] = __builtin_bit_cast(uint4, v1); out[2] = __builtin_bit_cast(uint4, v2);
     out[3] = __builtin_bit_cast(uint4, v3); out[4] = __builtin_bit_cast(uint4, v4); out[5] = __builtin_bit_cast(uint4, v5);
     out[6] = __builtin_bit_cast(uint4, v6); out[7] = __builtin_bit_cast(uint4, v7);
+}
+// the same for the "hi" operands alone (the fp16 filter): four 16-byte reads
+__device__ __forceinline__ void lds_read4_b128(const uint32_t (&addr)[8], uint4 (&out)[8], uint32_t addr32, float& out32) {
+    u32x4_t v0, v1, v2, v3;
+    asm volatile(
+        "ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %7\n\tds_read_b128 %3, %8\n\t"
+        "ds_read_b32 %4, %9\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(out32)
+        : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr32)
+        : "memory");
+    out[0] = __builtin_bit_cast(uint4, v0); out[1] = __builtin_bit_cast(uint4, v1); out[2] = __builtin_bit_cast(uint4, v2);
+    out[3] = __builtin_bit_cast(uint4, v3);
+    out[4] = out[5] = out[6] = out[7] = make_uint4(0u, 0u, 0u, 0u);     // ("lo": never multiplied by the one-product filter)
+}
+template <int M>
+__device__ __forceinline__ void lds_read_ops(const uint32_t (&addr)[8], uint4 (&out)[8], uint32_t addr32, float& out32) {
+    if (M == 1) lds_read4_b128(addr, out, addr32, out32); else lds_read8_b128(addr, out, addr32, out32);
 }
 // third smallest of two sorted triples
 __device__ __forceinline__ uint64_t third_of_two_triples(uint64_t a0, uint64_t a1, uint64_t a2, uint64_t b0, uint64_t b1, uint64_t b2) {
@@ -692,8 +716,8 @@ __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, cons
         augs[i] = row_norm[2 * (size_t)min(t * 32 + col, n_rows) + half];
     }
     if (tile0 < tile1) {
-        dma_tile_part(vocab_bf, n_rows, tile0, lane, s_tile, DPW * wave, DPW * wave + DPW);
-        dma_tile_part(vocab_bf, n_rows, min(tile0 + 1, tile1 - 1), lane, s_tile + BF_TILE_F, DPW * wave, DPW * wave + DPW);
+        dma_tile_part<M == 1>(vocab_bf, n_rows, tile0, lane, s_tile, DPW * wave, DPW * wave + DPW);
+        dma_tile_part<M == 1>(vocab_bf, n_rows, min(tile0 + 1, tile1 - 1), lane, s_tile + BF_TILE_F, DPW * wave, DPW * wave + DPW);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wave == 0) {                                                 // the loop takes them from LDS: a VMEM load there would wait behind the whole prefetch
@@ -735,7 +759,7 @@ __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, cons
     // tiles 2.. of the strip, all requested at once
     __syncthreads();
     for (int t = tile0 + 2; t < tile1; ++t)
-        dma_tile_part(vocab_bf, n_rows, t, lane, s_dyn + (size_t)(t - tile0 - 2) * BF_TILE_F, DPW * wave, DPW * wave + DPW);
+        dma_tile_part<M == 1>(vocab_bf, n_rows, t, lane, s_dyn + (size_t)(t - tile0 - 2) * BF_TILE_F, DPW * wave, DPW * wave + DPW);
     MF_STAMP(1);
     for (int t = tile0; t < tile1; ++t) {
         const int ti = t - tile0;
@@ -759,7 +783,7 @@ __device__ __forceinline__ void knn_bf16_filter_body(float* s_dyn, int bid, cons
                 addr[v] = base + ((((uint32_t)(4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
                 addr[4 + v] = base + ((((uint32_t)(8 + 4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
             }
-            lds_read8_b128(addr, av, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(s_aug + ti * 64 + lane), aug);
+            lds_read_ops<M>(addr, av, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(s_aug + ti * 64 + lane), aug);
 #pragma unroll
             for (int v = 0; v < 4; ++v) { ah[v] = av[v]; al[v] = av[4 + v]; }
         }
@@ -914,8 +938,8 @@ __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, co
     // arrives when the whole vocabulary has crossed the fabric.  Requested all at once and awaited tile by tile is not expressible:
     // the compiler waits for EVERY outstanding request at the first use of an operand register while LDS-DMA is in flight.)
     const int tile_last = max(tile1 - 1, tile0);
-    dma_tile_part(vocab_bf, n_rows, tile0, lane, s_dyn, DPW * wave, DPW * wave + DPW);
-    dma_tile_part(vocab_bf, n_rows, min(tile0 + 1, tile_last), lane, s_dyn + BF_TILE_F, DPW * wave, DPW * wave + DPW);
+    dma_tile_part<M == 1>(vocab_bf, n_rows, tile0, lane, s_dyn, DPW * wave, DPW * wave + DPW);
+    dma_tile_part<M == 1>(vocab_bf, n_rows, min(tile0 + 1, tile_last), lane, s_dyn + BF_TILE_F, DPW * wave, DPW * wave + DPW);
     // the augmentation entries of the strip go straight to LDS as well, two tiles per wave (the mask of rows that do not exist yet
     // is patched into them below)
     static_assert(MF_STRIP_TILES == 2 * NW, "two augmentation rows per wave");
@@ -947,7 +971,7 @@ __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, co
     asm volatile("" : "+v"(b_aug[NG - 1]) : : "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int t = tile0 + 2; t < tile1; ++t)
-        dma_tile_part(vocab_bf, n_rows, t, lane, s_dyn + (size_t)(t - tile0) * BF_TILE_F, DPW * wave, DPW * wave + DPW);
+        dma_tile_part<M == 1>(vocab_bf, n_rows, t, lane, s_dyn + (size_t)(t - tile0) * BF_TILE_F, DPW * wave, DPW * wave + DPW);
     if ((tile0 + MF_STRIP_TILES) * 32 > lo_rows) {                       // (rare: the strip reaches rows that are being appended while this launch runs)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -982,7 +1006,7 @@ __device__ __forceinline__ void knn_bf16_filter_body_q(float* s_dyn, int bid, co
                 addr[v] = base + ((((uint32_t)(4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
                 addr[4 + v] = base + ((((uint32_t)(8 + 4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
             }
-            lds_read8_b128(addr, av, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(s_aug + ti * 64 + lane), aug);
+            lds_read_ops<M>(addr, av, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(s_aug + ti * 64 + lane), aug);
 #pragma unroll
             for (int v = 0; v < 4; ++v) { ah[v] = av[v]; al[v] = av[4 + v]; }
         }
@@ -1038,7 +1062,7 @@ __device__ __forceinline__ void shadow_scores_body(float* s_dyn, int wg, const f
     const int col = lane & 31, half = lane >> 5;
     const int q0 = by * BF_QB + wave * QW;
     float* s_aug = s_dyn + (size_t)BF_TILE_F;
-    dma_tile_part(sh_bf, sh_rows, t, lane, s_dyn, DPW * wave, DPW * wave + DPW);
+    dma_tile_part<M == 1>(sh_bf, sh_rows, t, lane, s_dyn, DPW * wave, DPW * wave + DPW);
     if (wave == 0)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sh_norm + 2 * (size_t)min(t * 32 + col, sh_rows) + half),
                                          (__attribute__((address_space(3))) void*)s_aug, 4, 0, 0);
@@ -1071,7 +1095,7 @@ __device__ __forceinline__ void shadow_scores_body(float* s_dyn, int wg, const f
             addr[v] = base + ((((uint32_t)(4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
             addr[4 + v] = base + ((((uint32_t)(8 + 4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
         }
-        lds_read8_b128(addr, av, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(s_aug + lane), aug);
+        lds_read_ops<M>(addr, av, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(s_aug + lane), aug);
 #pragma unroll
         for (int v = 0; v < 4; ++v) { ah[v] = av[v]; al[v] = av[4 + v]; }
     }
@@ -1104,6 +1128,7 @@ constexpr size_t BF_LDS_BYTES_P = (size_t)(MF_WAVES * 4 + 2) * BF_TILE_F * 4 + (
 // front of the strip before it can name how many may stay in flight
 // the augmentation entry of a column that is not a visible row
 __device__ const float g_aug_inf[2] = {__builtin_inff(), 1.0f};
+template <int M>
 __device__ __forceinline__ void bf_request_strip(const float* __restrict__ vocab_bf, const float* __restrict__ row_norm, int n_rows, int bx,
                                                  int tiles_per_block, int n_tiles, int lane, int wave, int col, int half, float* slots, float* aug_dst) {
     constexpr int DPW = 8 / MF_WAVES;
@@ -1112,7 +1137,7 @@ __device__ __forceinline__ void bf_request_strip(const float* __restrict__ vocab
 #pragma unroll
     for (int i = 0; i < MF_STRIP_TILES; ++i) {
         const int t = min(tile0 + i, max(tile1 - 1, tile0));
-        dma_tile_part(vocab_bf, n_rows, t, lane, slots + (size_t)i * BF_TILE_F, DPW * wave, DPW * wave + DPW);
+        dma_tile_part<M == 1>(vocab_bf, n_rows, t, lane, slots + (size_t)i * BF_TILE_F, DPW * wave, DPW * wave + DPW);
     }
     if (wave == 0) {
 #pragma unroll
@@ -1172,8 +1197,8 @@ __device__ __forceinline__ void knn_bf16_filter_body_p(float* s_dyn, int bid, co
             augs[i] = t * 32 + col >= n_rows ? g_aug_inf[half] : row_norm[2 * (size_t)(t * 32 + col) + half];
         }
         if (tile0 < tile1) {
-            dma_tile_part(vocab_bf, n_rows, tile0, lane, s_tile, DPW * wave, DPW * wave + DPW);
-            dma_tile_part(vocab_bf, n_rows, min(tile0 + 1, tile1 - 1), lane, s_tile + BF_TILE_F, DPW * wave, DPW * wave + DPW);
+            dma_tile_part<M == 1>(vocab_bf, n_rows, tile0, lane, s_tile, DPW * wave, DPW * wave + DPW);
+            dma_tile_part<M == 1>(vocab_bf, n_rows, min(tile0 + 1, tile1 - 1), lane, s_tile + BF_TILE_F, DPW * wave, DPW * wave + DPW);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (wave == 0) {
@@ -1205,9 +1230,9 @@ __device__ __forceinline__ void knn_bf16_filter_body_p(float* s_dyn, int bid, co
         const int tile0 = bx0 * tiles_per_block;
         const int tile1 = min(tile0 + tiles_per_block, n_tiles);
         for (int t = tile0 + 2; t < tile1; ++t)
-            dma_tile_part(vocab_bf, n_rows, t, lane, s_dyn + (size_t)(t - tile0 - 2) * BF_TILE_F, DPW * wave, DPW * wave + DPW);
+            dma_tile_part<M == 1>(vocab_bf, n_rows, t, lane, s_dyn + (size_t)(t - tile0 - 2) * BF_TILE_F, DPW * wave, DPW * wave + DPW);
     }
-    if (n_my > 1) bf_request_strip(vocab_bf, row_norm, n_rows, bx0 + px, tiles_per_block, n_tiles, lane, wave, col, half,
+    if (n_my > 1) bf_request_strip<M>(vocab_bf, row_norm, n_rows, bx0 + px, tiles_per_block, n_tiles, lane, wave, col, half,
                                    s_dyn + (size_t)8 * BF_TILE_F, s_aug + MF_STRIP_TILES * 64);
     // ---- the strips
     for (int s = 0; s < n_my; ++s) {
@@ -1244,7 +1269,7 @@ __device__ __forceinline__ void knn_bf16_filter_body_p(float* s_dyn, int bid, co
                     addr[v] = base + ((((uint32_t)(4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
                     addr[4 + v] = base + ((((uint32_t)(8 + 4 * half + v)) ^ (uint32_t)(col & 15)) << 4);
                 }
-                lds_read8_b128(addr, av, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(aug_s + ti * 64 + lane), aug);
+                lds_read_ops<M>(addr, av, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(aug_s + ti * 64 + lane), aug);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) { ah[v] = av[v]; al[v] = av[4 + v]; }
             }
@@ -1279,7 +1304,7 @@ __device__ __forceinline__ void knn_bf16_filter_body_p(float* s_dyn, int bid, co
         }
         if (s + 2 < n_my) {                                          // strip s is read by every wave: its slots take strip s + 2
             bf_lds_barrier();
-            bf_request_strip(vocab_bf, row_norm, n_rows, bx0 + (s + 2) * px, tiles_per_block, n_tiles, lane, wave, col, half,
+            bf_request_strip<M>(vocab_bf, row_norm, n_rows, bx0 + (s + 2) * px, tiles_per_block, n_tiles, lane, wave, col, half,
                              s_dyn + (size_t)((s & 1) ? 8 : 0) * BF_TILE_F, s_aug + (s & 1) * (MF_STRIP_TILES * 64));
         }
     }
@@ -1702,7 +1727,10 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     // id of the row is fetched in the same round trip
     float err_ratio = 0.0f;
     if (!overflow) {
-        for (int i = tid >> 4; i < n_cand; i += MF_BLOCK / 16) {
+        // Two trips in flight (round 6): the rows of trip t + 1 are requested in front of trip t's arithmetic.  A query whose second neighbour is
+        // far (a descriptor that will become a word) has dozens of keys under its threshold -- four, five trips of sixteen rows -- and with one
+        // trip in flight each was a round trip of its own: those queries' workgroups were the tail of launch B (11.2 us median, 15.5 max).
+        auto request = [&](int i, float4& v4, int32_t& wid) {
             const uint64_t k = s_cand[GS == 4 ? (i >> 2) : i];
             const uint32_t row = cand_row(i);
             const bool sh = sh_q > 0 && (uint32_t)k >= SHADOW_ROW_BASE;   // (uniform over the wave: the slots of ONE key) -- a key of ONE row, a word
@@ -1710,9 +1738,15 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
             const bool in_range = sh ? (GS == 1 || (i & 3) == 0) : (GS == 1 || row < row_limit);
             const uint32_t rrow = in_range ? row : (uint32_t)k;            // (an address that exists: the group's first row)
             const float* src = sh ? pend_desc + (size_t)sj * DIM : vocab + (size_t)rrow * DIM;
-            const float4 v4 = reinterpret_cast<const float4*>(src)[lane & 15];
-            int32_t wid = 0;
+            v4 = reinterpret_cast<const float4*>(src)[lane & 15];
+            wid = 0;
             if ((lane & 15) == 0) wid = sh ? pend_first_id + sh_rank(sj) : row_id[rrow];
+        };
+        auto finish = [&](int i, const float4& v4, int32_t wid) {
+            const uint64_t k = s_cand[GS == 4 ? (i >> 2) : i];
+            const uint32_t row = cand_row(i);
+            const bool sh = sh_q > 0 && (uint32_t)k >= SHADOW_ROW_BASE;
+            const bool in_range = sh ? (GS == 1 || (i & 3) == 0) : (GS == 1 || row < row_limit);
             const float d0 = __fsub_rn(v4.x, q4.x), d1 = __fsub_rn(v4.y, q4.y), d2 = __fsub_rn(v4.z, q4.z), d3 = __fsub_rn(v4.w, q4.w);
             float t = __fmul_rn(d0, d0);
             t = __fadd_rn(t, __fmul_rn(d1, d1));
@@ -1722,16 +1756,26 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
 #pragma unroll
             for (int j = 0; j < 16; ++j) res = __fadd_rn(res, __shfl(t, (lane & 48) + j, 64));
             const bool live = in_range && (GS == 1 || __shfl(wid, lane & 48, 64) != 0);
-            const float res_raw = res;
             if (!live) res = __int_as_float(0x7f800000);
             float gmin = res;                                            // the filter's score of a key is its group's minimum (a shadow key: its one row's score)
-            (void)res_raw;
             if (GS == 4) { gmin = fminf(gmin, __shfl_xor(gmin, 16, 64)); gmin = fminf(gmin, __shfl_xor(gmin, 32, 64)); }
             if ((lane & 15) == 0) {
                 s_exact[i] = live ? (((uint64_t)__float_as_uint(res) << 32) | (uint32_t)i) : KEY_NONE;   // the slot stands in for the row: see below
                 s_word[i] = wid;
                 if (gmin < __int_as_float(0x7f800000)) err_ratio = fmaxf(err_ratio, fabsf(__uint_as_float((uint32_t)(k >> 32)) - gmin) / eps);
             }
+        };
+        constexpr int STEP = MF_BLOCK / 16;
+        // (the trip count is uniform over the WAVE -- the four 16-lane groups of a wave hold the four slots of one key, and n_cand is a multiple
+        // of four -- so the shuffles inside finish() always find their lanes)
+        int i = tid >> 4;
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f); int32_t wa = 0;
+        if (i < n_cand) request(i, va, wa);
+        for (; i < n_cand; i += STEP) {
+            float4 vb = make_float4(0.f, 0.f, 0.f, 0.f); int32_t wb = 0;
+            if (i + STEP < n_cand) request(i + STEP, vb, wb);
+            finish(i, va, wa);
+            va = vb; wa = wb;
         }
     }
 #pragma unroll
@@ -1910,7 +1954,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
             if (lane == 0 && valid) *reinterpret_cast<unsigned long long*>(cb.bits + (size_t)qi * cb.bw + (base >> 5)) = m;
             if (cb.cnt && d < thr2 && r < qi) {
                 const int pos = atomicAdd(&s_below, 1);               // any order: the decision loop takes the two smallest (distance, j)
-                if (pos < 4 && valid) cb.list[(size_t)qi * 4 + pos] = make_uint2((uint32_t)r, __float_as_uint(d));
+                if (pos < CAND_LIST && valid) cb.list[(size_t)qi * CAND_LIST + pos] = make_uint2((uint32_t)r, __float_as_uint(d));
             }
         }
         if (cb.cnt) {

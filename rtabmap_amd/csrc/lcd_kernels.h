@@ -37,15 +37,18 @@ struct CandBits {
     int bw = 0;
     int have_index = 0;
     // the same information in the form the decision loop wants: per descriptor i the number of set bits below i and, when there are
-    // at most four, the (j, distance bits) pairs themselves -- one coalesced read instead of a bit-row scan and distance gathers
-    uint2* list = nullptr;             // [nq x 4] {j, distance bits}
-    int32_t* cnt = nullptr;            // [nq] (> 4: the list is incomplete, use the bit row)
+    // at most CAND_LIST, the (j, distance bits) pairs themselves -- one coalesced read instead of a bit-row scan and distance gathers
+    uint2* list = nullptr;             // [nq x CAND_LIST] {j, distance bits}
+    int32_t* cnt = nullptr;            // [nq] (> CAND_LIST: the list is incomplete, use the bit row)
 };
-inline size_t cand_bits_bytes(int q, int bw) { return (size_t)q * (bw + 9) * 4; }   // bit rows | lists | counts in one buffer
+// (round 6 tried sixteen entries: the decision loop then needs 128 more registers per thread and spills; the descriptors with long lists are the
+// copies of a place's popular words, dozens per frame, which no practical list length covers -- they keep their bit row in registers instead)
+constexpr int CAND_LIST = 4;
+inline size_t cand_bits_bytes(int q, int bw) { return (size_t)q * (bw + 2 * CAND_LIST + 1) * 4; }   // bit rows | lists | counts in one buffer
 inline void cand_bits_layout(CandBits& cb, uint32_t* base, int q, int bw) {
     cb.bits = base; cb.bw = bw;
     cb.list = reinterpret_cast<uint2*>(base + (size_t)q * bw);
-    cb.cnt = reinterpret_cast<int32_t*>(base + (size_t)q * bw + (size_t)q * 8);
+    cb.cnt = reinterpret_cast<int32_t*>(base + (size_t)q * bw + (size_t)q * 2 * CAND_LIST);
 }
 
 // Postings keys reserved for the words a frame may create: the k-th new word of the frame gets the k-th key of the

@@ -134,17 +134,28 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
     // ... and the lists themselves, unconditionally, in the SAME round trip as their counts (32 bytes per descriptor; entries beyond the
     // count are never looked at): requested behind the counts they used to be a second dependent round trip, ~2 us at the head of the
     // first sweep (round 5's stamps: 0.9 + 1.3 us in front of the first two descriptors of a thread)
-    uint4 cl_lo[KPT], cl_hi[KPT];
+    // ... and so is the descriptor's bit row (frames of up to 512 descriptors: 64 bytes): the descriptors that need it -- more than four
+    // candidates: the copies of a place's popular words, dozens per frame -- used to request it behind their count, and the first sweep
+    // waited for that second round trip (and, the counter being in-order, for the postings-key gathers in front of it): 0.8 + 1.3 us at the
+    // head of sweep 0 in round 6's stamps
+    uint4 cl_lo[KPT], cl_hi[KPT], rbq[KPT][4];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const int i = tid + k * NT;
         cn[k] = 0;
         cl_lo[k] = make_uint4(0u, 0u, 0u, 0u); cl_hi[k] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rbq[k][u] = make_uint4(0u, 0u, 0u, 0u);
         if (together && i < q) {
             cn[k] = cand_cnt ? cand_cnt[i] : 5;
             if (cand_cnt) {
                 cl_lo[k] = *reinterpret_cast<const uint4*>(cand_list + (size_t)i * 4);
                 cl_hi[k] = *reinterpret_cast<const uint4*>(cand_list + (size_t)i * 4 + 2);
+            }
+            if (bw <= 16) {
+                const uint4* row = reinterpret_cast<const uint4*>(cand_bits + (size_t)i * bw);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (4 * u < bw) rbq[k][u] = row[u];
             }
         }
     }
@@ -177,11 +188,8 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
 #pragma unroll
         for (int u = 0; u < 16; ++u) S.rb[u] = 0u;
         if (S.overflow && bw <= 16) {
-            const uint4* row = reinterpret_cast<const uint4*>(cand_bits + (size_t)i * bw);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (4 * u < bw) { const uint4 v = row[u]; S.rb[4 * u] = v.x; S.rb[4 * u + 1] = v.y; S.rb[4 * u + 2] = v.z; S.rb[4 * u + 3] = v.w; }
-            }
+            for (int u = 0; u < 4; ++u) { const uint4 v = rbq[k][u]; S.rb[4 * u] = v.x; S.rb[4 * u + 1] = v.y; S.rb[4 * u + 2] = v.z; S.rb[4 * u + 3] = v.w; }
             const int wlast = i >> 5;                            // only j < i
 #pragma unroll
             for (int u = 0; u < 16; ++u) { if (u == wlast) S.rb[u] &= (1u << (i & 31)) - 1u; else if (u > wlast) S.rb[u] = 0u; }

@@ -38,7 +38,7 @@ __device__ __forceinline__ void cand_bits_row(const CandBits& cb, int qi, float 
         if (cb.cnt && n_threads == 64) {
             const unsigned long long m2 = __ballot(d < thr && r < qi);
             const int pos = below + (int)__popcll(m2 & ((1ull << (tid & 63)) - 1ull));
-            if (d < thr && r < qi && pos < 4) cb.list[(size_t)qi * 4 + pos] = make_uint2((uint32_t)r, __float_as_uint(d));
+            if (d < thr && r < qi && pos < CAND_LIST) cb.list[(size_t)qi * CAND_LIST + pos] = make_uint2((uint32_t)r, __float_as_uint(d));
             below += (int)__popcll(m2);
         }
     }
