@@ -362,7 +362,7 @@ int lcd_profile_read(lcd_engine* h, float* avg_ms, int* n_samples, const char** 
 int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, const char** kernel_name);
 
 /* tuning knobs for experiments (results never depend on them; every one of them is per handle).  "filter_delay": the filter workgroups
- * of a pipelined frame's launch A wait value x 64 clocks in front of their first request (0 .. 127; timing experiments).  "roctx": 1 = roctx ranges (see lcd_trace_push below).  "shadow_rows": 1 (built-in) = a frame that appends its words on the device also leaves its descriptors as rows
+ * of a pipelined frame's launch A wait value x 64 clocks in front of their first request (0 .. 127; timing experiments).  "roctx": 1 = roctx ranges (see lcd_trace_push below).  "shadow_rows": 1 (built-in: while the stream creates 16 words per frame or more; 2 = always) = a frame that appends its words on the device also leaves its descriptors as rows
  * of an operand table, and the matrix-core filter of the NEXT frame ranks them beside the vocabulary (its re-rank keeps the ones that became words)
  * instead of every re-rank workgroup staging the new rows and scanning them (0).  "mirror_from_b": 1 (built-in) = the pinned row-count mirror of an appending
  * frame is stored by a workgroup of launch B instead of at the end of the decision loop's chain in launch A.  "row_writer_wgs": the rows a

@@ -1489,7 +1489,11 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     if (chained && !h->inflight.empty() && h->dtype == LCD_F32 && h->kdim == 64 && (h->popt.cross_frames || h->popt.shadow_rows))   // (pipeline_launch: this frame x the frame before it)
         LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_cross, (size_t)q * ((h->inflight.back().a.q + 63) / 64 * 64) * 4));
     // shadow rows: a frame that appends on the device leaves its descriptors as operand-table rows too, for the filter of the frame behind it
-    const bool with_shadow = chained && app && h->popt.shadow_rows && h->dtype == LCD_F32 && h->kdim == 64 && q <= 4096;
+    // (built-in: only while the stream creates words -- the scores cost launch A ~1 us (16 more workgroups, the pre-split's extra stores) and buy launch B
+    // ~3.5 us per frame whose predecessor appended ~150 rows, nothing when it appended none; est_new is the decaying maximum of rows per appending frame
+    // that the launch plans already keep.  "shadow_rows" = 2: always)
+    const bool with_shadow = chained && app && h->popt.shadow_rows && h->dtype == LCD_F32 && h->kdim == 64 && q <= 4096 &&
+                             (h->popt.shadow_rows >= 2 || h->est_new >= 16.0);
     if (with_shadow) {
         LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_shadow_bf, (size_t)ld * 256));
         LCD_HIP(h, ring_reserve(h, set, &lcd_engine::FrameScratch::d_shadow_norm, (size_t)(ld + 1) * 8));
@@ -2047,7 +2051,7 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     // timing experiments: the filter workgroups of launch A wait value x 64 clocks in front of their first request (the single-workgroup
     // chains of the launch then get their first round trip ahead of the strips' opening burst)
     if (!std::strcmp(key, "filter_delay") && value >= 0 && value <= 127) { h->popt.filter_delay = (int)value; return LCD_OK; }
-    if (!std::strcmp(key, "shadow_rows") && value >= -1 && value <= 1) { h->popt.shadow_rows = value != 0 ? 1 : 0; return LCD_OK; }          // (-1: built-in = on)
+    if (!std::strcmp(key, "shadow_rows") && value >= -1 && value <= 2) { h->popt.shadow_rows = value < 0 ? 1 : (int)value; return LCD_OK; }   // (-1: built-in = 1)
     if (!std::strcmp(key, "mirror_from_b") && value >= -1 && value <= 1) { h->popt.mirror_from_b = value != 0 ? 1 : 0; return LCD_OK; }
     if (!std::strcmp(key, "row_writer_wgs") && value >= -1 && value <= 256) { h->popt.row_writer_wgs = value >= 0 ? (int)value : PipeOpts().row_writer_wgs; return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");

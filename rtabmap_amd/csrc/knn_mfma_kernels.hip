@@ -1099,20 +1099,32 @@ __device__ __forceinline__ void shadow_scores_body(float* s_dyn, int wg, const f
 #pragma unroll
         for (int v = 0; v < 4; ++v) { ah[v] = av[v]; al[v] = av[4 + v]; }
     }
+    __builtin_amdgcn_s_barrier();                                        // every wave has its operands: the tile's LDS is free (the scores cross it below)
     f32x16 c[NG];
     int32_t kd0 = MF_KEY_NONE, kd1 = MF_KEY_NONE, kd2 = MF_KEY_NONE, kd3 = MF_KEY_NONE, kd4 = MF_KEY_NONE, kd5 = MF_KEY_NONE;   // (bf_pair<false> touches no keys)
     const f32x16 none = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bf_pair<false, M>(ah, al, aug, bh[0], bl[0], b_aug[0], bh[1], bl[1], b_aug[1], c[0], c[1], none, none, 0u, kd0, kd1, kd2, kd3, kd4, kd5);
     bf_pair<false, M>(ah, al, aug, bh[2], bl[2], b_aug[2], bh[3], bl[3], b_aug[3], c[2], c[3], none, none, 0u, kd0, kd1, kd2, kd3, kd4, kd5);
-    // accumulator register r of lane (col, half) is row (r & 3) + 8 (r >> 2) + 4 half of the tile for query col of the group: four 16-byte stores
+    // Accumulator register r of lane (col, half) is row (r & 3) + 8 (r >> 2) + 4 half of the tile for query col of the group: stored straight from
+    // the registers a query's 128 bytes would leave as eight 16-byte pieces of four different instructions (partial lines: the workgroups ended at
+    // 11.4-12 us, 5 us of it waiting for those stores to be acknowledged).  So the scores cross LDS once -- each wave its own 128 queries x 32 rows
+    // = 16 KB, 16-byte chunk k of a query at position k ^ (query & 7): no bank conflicts either way -- and leave as whole 128-byte lines, eight
+    // queries per instruction.  (The barrier in front of the MFMAs has seen every wave finish reading the tile: its LDS is free.)
+    float* xs = s_dyn + (size_t)wave * (QW * 32);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const int qi = q0 + g * 32 + col;
-        if (qi >= nq) continue;
-        float* dst = x + (size_t)qi * ld + t * 32 + 4 * half;
+        const int ql = g * 32 + col;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-            *reinterpret_cast<float4*>(dst + 8 * m) = make_float4(c[g][4 * m], c[g][4 * m + 1], c[g][4 * m + 2], c[g][4 * m + 3]);
+            *reinterpret_cast<float4*>(xs + (size_t)ql * 32 + (((2 * m + half) ^ (ql & 7)) << 2)) = make_float4(c[g][4 * m], c[g][4 * m + 1], c[g][4 * m + 2], c[g][4 * m + 3]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // (the wave reads back what the wave wrote: no barrier)
+#pragma unroll 4
+    for (int it = 0; it < QW / 8; ++it) {
+        const int ql = it * 8 + (lane >> 3), ck = lane & 7;
+        const int qi = q0 + ql;
+        const float4 v = *reinterpret_cast<const float4*>(xs + (size_t)ql * 32 + ((ck ^ (ql & 7)) << 2));
+        if (qi < nq) *reinterpret_cast<float4*>(x + (size_t)qi * ld + t * 32 + 4 * ck) = v;
     }
 }
 

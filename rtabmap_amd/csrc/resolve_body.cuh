@@ -252,6 +252,13 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
                             }
                         }
                     } else if (bw <= 16) {
+                        // (the descriptors with long lists are the copies of a place's popular words: their candidates are each other, none of
+                        // them a new word -- one branch-free test says so and the walk below, 16 words x a data-dependent loop, is skipped: it was
+                        // most of the 0.4-1.1 us a descriptor cost a sweep in round 6's stamps)
+                        uint32_t any = 0u;
+#pragma unroll
+                        for (int w = 0; w < 16; ++w) any |= S.rb[w] & mreg[w];
+                        if (any)
 #pragma unroll
                         for (int w = 0; w < 16; ++w) {
                             uint32_t m = S.rb[w] & mreg[w];

@@ -225,7 +225,7 @@ struct PipeOpts {
     int append_split_buckets = -1;   // "append_split_buckets" (< 0: built-in)
     int filter_delay = 0;            // "filter_delay": s_sleep units (64 clocks) a filter workgroup waits in front of its first request
     // round 6, measured by kernel trace on the driver's command (profiles/r06_ab_notes.txt): all three on by default
-    int shadow_rows = 1;             // "shadow_rows": launch A also scores the frame against the descriptors of the frame before (whose new words are not rows
+    int shadow_rows = 1;             // "shadow_rows" (1: while the stream creates >= 16 words per frame; 2: always; 0: never): launch A also scores the frame against the descriptors of the frame before (whose new words are not rows
                                      // yet), the re-rank keeps the words' scores under its threshold: no workgroup stages or scans the new rows (launch B 19.6 -> 15.4 us)
     int mirror_from_b = 1;           // "mirror_from_b": the pinned row-count mirror of an appending frame is stored by launch B instead of by the decision loop (launch A -0.3 us)
     int row_writer_wgs = 16;         // "row_writer_wgs": > 0 = that many extra workgroups of launch B's re-rank role write the appended rows (launch B -0.9 us

@@ -338,6 +338,32 @@ void MemoryHip::computeLikelihood(int signatureId, const std::list<int>& ids, st
 
 bool MemoryHip::computeLikelihoodFlat(int signatureId, std::vector<int>& sigIds, std::vector<float>& values) {
     if (_likeSig == 0 || _likeSig != signatureId) return false;
+    if (!_likeSortedValid) {
+        // the usual case -- signatures registered in ascending id, so the device's slot order IS ascending id -- in ONE pass over the slots, without
+        // the (id, value) pairs the map overloads look things up in: 100 000 slots are 1.2 MB read and 0.8 MB written
+        Stage st(_vwd, "Memory::computeLikelihood");
+        const std::vector<int>& slotSig = _vwd->slotSignatures();
+        const size_t n = std::min(slotSig.size(), _likeSlots.size());
+        sigIds.resize(n);
+        values.resize(n);
+        size_t m = 0;
+        int last = 0;
+        bool ascending = true;
+        for (size_t k = 0; k < n; ++k) {
+            const int id = slotSig[k];
+            if (id == 0) continue;
+            if (id < last) { ascending = false; break; }
+            last = id;
+            sigIds[m] = id; values[m] = _likeSlots[k];
+            ++m;
+        }
+        if (ascending) {
+            sigIds.resize(m);
+            values.resize(m);
+            _stats["Timing/Likelihood_computation/ms"] = st.ms();
+            return true;
+        }
+    }
     const std::vector<std::pair<int, float> >& v = sortedLikelihood();
     sigIds.resize(v.size());
     values.resize(v.size());

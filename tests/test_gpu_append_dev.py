@@ -138,7 +138,7 @@ def test_new_rows_ranked_by_the_filter_as_shadow_rows(oracle, n_words, q, n_fram
     streams that revisit the place of the frame before them (words matched one frame after they were created), bf16 and fp16 filters, frames of
     700 descriptors (three shadow strips, several mask words), a clean behind every frame, and a vocabulary whose filter is persistent (where the
     option changes nothing: the rows are staged as before)."""
-    opts = {"shadow_rows": 1}
+    opts = {"shadow_rows": 2}                                          # always (the built-in, 1, waits until the stream has shown that it creates words)
     opts.update({k: v for k, v in extra.items() if k != "clean"})
     assert _stream(oracle, True, n_words=n_words, q=q, n_frames=n_frames, seed=41, knn_mode=knn_mode, options=opts, clean_every_frame=bool(extra.get("clean"))) > 100
 
