@@ -570,6 +570,7 @@ def with_update_ms(torch, eng, stepper, steps=256, lag=8, rebuild_every=128):
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
     rows, live = eng.vocab_count()
+    with_update_ms.divergent_refs = int(eng.stats().get("clean_divergent_refs", 0))   # (see run_replay_growing: async_clean_divergence)
     return ms, rows, live
 
 
@@ -848,6 +849,7 @@ def run_orb_stream(args):
             o2.forget(t + 1 - W)
             live_sigs.remove(t + 1 - W)
     rows_end, live_end = eng.vocab_count()
+    div_refs = int(eng.stats().get("clean_divergent_refs", 0))
     # ---- CPU baseline on a bounded sample: the reference's rtflann Hamming scan over the FINAL vocabulary, 1 core, + the restated TF-IDF
     if O.have_ref():
         lin = O.RefIndex(vr, algo=O.ALGO_LINEAR)
@@ -874,7 +876,9 @@ def run_orb_stream(args):
            "config": {"workload": "config 3: %d ORB frames x %d descriptors, incremental dictionary grown from empty to %d words (%d rows), "
                                   "update() appends on the device, cleanUnusedWords enqueued every frame, W=%d retirement, device-pointer path "
                                   "(lcd_frame_dev, plain handle); %d timed frames, then %d frames one by one next to the oracle" % (n_frames, q, live, rows, W, n_timed, n_frames - T0),
-                      "dictionary_words": int(live), "dictionary_words_at_the_end": int(live_end), "frames_per_s": n_timed / wall},
+                      "dictionary_words": int(live), "dictionary_words_at_the_end": int(live_end), "frames_per_s": n_timed / wall,
+                      "async_clean_divergent_refs": {"references": div_refs, "frames": int(n_frames), "per_10000_frames": 1e4 * div_refs / max(int(n_frames), 1),
+                                                     "note": "a plain handle completes every frame before the enqueued clean runs: 0 by construction (the counter is lcd_stats.clean_divergent_refs)"}},
            "roofline": {"bound": "valu-int", "achieved": achieved, "peak": PEAK_INT, "unit": "T lane-ops/s", "frac": achieved / PEAK_INT, "traffic": None,
                         "kernel": scan_name, "ms": scan_ms, "samples": scan_n, "rows_scanned": int(rows),
                         "algorithmic": "%d x %d descriptor pairs x 16 lane-ops (8 x (xor + bit-count-add))" % (q, rows),
@@ -1405,6 +1409,7 @@ def run_replay_growing(args):
     t_lik_cpu = (time.perf_counter() - t1) / 3 * ((n - retired) / float(win))
     lik_what = "restated std::map Memory::computeLikelihood on the newest %d signatures, scaled x%.1f to %d" % (win, (n - retired) / float(win), n - retired)
     mem.close()
+    div_refs = int(eng.stats().get("clean_divergent_refs", 0))
     eng.close()
     live_total = float(np.sum(ts + 1 - retired_at))
     out = {"metric": "loop-closure candidates/sec (descriptor-stream replay, growing dictionary, memory grown to %d signatures)" % (n - retired),
@@ -1418,6 +1423,12 @@ def run_replay_growing(args):
                       "dictionary_rows_at_the_end": int(rows), "dictionary_words_at_the_end": int(live), "words_created": created,
                       "frames_that_created_words": int((n_new_frame > 0).sum()), "frames_that_created_words_frac": float((n_new_frame > 0).mean()),
                       "signatures_live_at_the_end": int(n - retired), "signatures_retired": int(retired),
+                      "async_clean_divergence": {"references_to_words_the_enqueued_clean_had_tombstoned": div_refs, "frames": int(n),
+                                                 "per_10000_frames": 1e4 * div_refs / max(int(n), 1),
+                                                 "meaning": "a frame in flight matched a word whose last OTHER reference was retired before the enqueued cleanUnusedWords ran: "
+                                                            "the device tombstones the word (the frame keeps its reference, the word is never matched again) where the reference's "
+                                                            "clean, which runs behind that frame's addNewWords (Memory.cpp:6899-6920), keeps it -- counted on the device at registration "
+                                                            "(lcd_stats.clean_divergent_refs)"},
                       "frames_per_s": n / wall, "wall_s": wall, "wall_s_at_frames": {str(k): v for k, v in marks.items()},
                       "ms_per_frame_last_half": 1e3 * (wall - marks.get(500_000, 0.0)) / (n - 500_000) if 500_000 in marks and n > 500_000 else None,
                       "descriptor_pool_generated_on_device_s": gen_s, "parity_host_seconds": par_s, "paused_for_snapshots_s": paused},
@@ -1719,6 +1730,7 @@ def main():
             stw = Stepper(engw, torch, d_frames, n_sig, cap)
             wu, wrows, wlive = with_update_ms(torch, engw, stw)
             config["with_update_ms_per_step"] = wu
+            config["with_update_async_clean_divergent_refs"] = {"references": getattr(with_update_ms, "divergent_refs", None), "frames": 272}
             config["with_update_note"] = "the headline step + the rest of Memory::preUpdate EVERY frame, nothing completed in between: the signature " \
                                          "registered 8 frames earlier retired too, cleanUnusedWords as one enqueued kernel " \
                                          "(lcd_vocab_remove_unused_async), lcd_vocab_rebuild every 128th frame (the only draining call; ~20 %% of the rows are tombstones by then); 256 steps; " \

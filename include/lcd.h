@@ -413,6 +413,10 @@ typedef struct lcd_stats {
     int64_t bytes_device;                  /* HBM held by the handle */
     int64_t knn_last_fallback_queries;     /* queries of the LAST 2-NN call that the MFMA certificate sent to the exact scan */
     double knn_max_err_ratio;              /* largest |filter score - exact distance| / eps seen by the re-rank so far (must stay < 1) */
+    int64_t clean_divergent_refs;          /* (ABI v6) references registered to a word that an ENQUEUED cleanUnusedWords (lcd_vocab_remove_unused_async) had tombstoned
+                                            * while the referencing frame was in flight: the one documented departure of the device-resident mode from the
+                                            * reference, whose clean runs behind that frame's addNewWords and keeps the word (Memory.cpp:6899-6920).  0 on streams
+                                            * that drain before they clean */
 } lcd_stats;
 /* synchronises the engine stream (the fallback counter lives on the device) */
 int lcd_get_stats(lcd_engine* h, lcd_stats* out);

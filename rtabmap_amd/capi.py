@@ -67,7 +67,8 @@ class LcdStats(C.Structure):
                 ("knn_launches", C.c_int64), ("likelihood_launches", C.c_int64), ("rebuilds", C.c_int64),
                 ("buckets_sealed", C.c_int64), ("word_slots", C.c_int64), ("dense_words", C.c_int64),
                 ("frame_calls", C.c_int64), ("frame_host_ns", C.c_int64),
-                ("bytes_device", C.c_int64), ("knn_last_fallback_queries", C.c_int64), ("knn_max_err_ratio", C.c_double)]
+                ("bytes_device", C.c_int64), ("knn_last_fallback_queries", C.c_int64), ("knn_max_err_ratio", C.c_double),
+                ("clean_divergent_refs", C.c_int64)]
 
 
 class LcdError(RuntimeError):

@@ -305,6 +305,7 @@ int lcd_engine::reconcile() {
     for (const DevAppend& a : unreconciled) {
         if (!a.enabled) continue;
         const int n = log[(size_t)(a.seq % VLOG)];
+        est_new = std::max(est_new * 0.9, (double)n);                 // (the estimate the launch plans and the shadow-score switch use: rows_plan() only sees it move while frames are in flight)
         int taken = 0;
         for (int k = 0; k < n; ++k) {
             const int32_t id = a.first_id + k;
@@ -2107,6 +2108,13 @@ int lcd_get_stats(lcd_engine* h, lcd_stats* out) {
     out->word_slots = (int64_t)h->tfidf.n_wslots - h->tfidf.ws_free_count;
     out->dense_words = h->tfidf.h_n_dense ? (int64_t)*(volatile uint32_t*)h->tfidf.h_n_dense : 0;
     out->bytes_device = h->bytes_device;
+    out->clean_divergent_refs = 0;
+    if (h->tfidf.q_meta.p) {
+        uint32_t n = 0;
+        int rc = download(h, &n, h->tfidf.q_meta.as<uint32_t>() + 8, 4, h->h_out2);
+        if (rc) return rc;
+        out->clean_divergent_refs = (int64_t)n;
+    }
     return LCD_OK;
     LCD_CATCH(h)
 }

@@ -121,7 +121,7 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
     // second pass, four table entries per thread and trip: the reference count of every word comes back from a returning atomic
     // (one round trip) -- all four are in flight before the first is used
     for (int i0 = 0; i0 < H; i0 += 4 * NT) {
-        uint32_t w4[4], c4[4], u4[4], n4[4]; int32_t d4[4]; bool o4[4];
+        uint32_t w4[4], c4[4], u4[4], n4[4], r4[4]; int32_t d4[4]; bool o4[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = i0 + r * NT + tid;
@@ -136,8 +136,9 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            n4[r] = 0; d4[r] = -1;
+            n4[r] = 0; d4[r] = -1; r4[r] = 0u;
             if (!o4[r]) continue;
+            if (a.do_register && a.wrow) r4[r] = a.wrow[w4[r]];                          // (in the same round trip as the reference counts)
             n4[r] = a.do_register ? atomicAdd(&a.nw[w4[r]], 1u) + 1u : a.nw[w4[r]];   // (a plain read + fire-and-forget add measured slower:
                                                                                           // atomics drop the line from L2, the read then misses)
             if (a.want_q) d4[r] = a.did[w4[r]];
@@ -145,11 +146,14 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
         // all four answers are awaited HERE, in front of the first store: behind a store (the branches below hide the count of operations
         // in flight from the compiler, which then waits for everything) each entry would wait for the stores of the one before it
 #pragma unroll
-        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(n4[r]), "+v"(d4[r]));
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(n4[r]), "+v"(d4[r]), "+v"(r4[r]));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (!o4[r]) continue;
             const uint32_t w = w4[r], u = u4[r], cnt = c4[r], nwv = n4[r];
+            // a reference to a word the enqueued cleanUnusedWords tombstoned while this frame was in flight (the one documented departure
+            // of the device-resident mode -- the reference's clean runs behind this frame's addNewWords and would have kept the word): counted
+            if (r4[r] == 0xFFFFFFFFu && a.q_meta) atomicAdd(&a.q_meta[8], 1u);
             if (a.do_register) {
                 a.coo_w[base + u] = w;
                 a.coo_pc[base + u] = (a.slot_local << TF_CNT_BITS) | cnt;

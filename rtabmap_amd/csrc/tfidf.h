@@ -158,6 +158,8 @@ struct FwArgs {
     int32_t* slot_sig; uint32_t* slot_ni; uint32_t* slot_begin; uint32_t* slot_cnt;
     uint32_t* q_w; int32_t* q_idf; int32_t* q_did; int32_t* qd_did; int32_t* qd_idf; uint32_t* q_meta; uint2* idf_tab;
     WsRuns new_ws;                                // src entries <= -2 are codes -(k + 2) of the frame's k-th new word (WsRuns, n < 0)
+    const uint32_t* wrow;                         // Tfidf::wrow (NULL: not wanted): a registered word whose key reads 0xFFFFFFFF is a word an enqueued
+                                                  // cleanUnusedWords tombstoned while this frame was in flight -- counted in q_meta[8] (lcd_stats.clean_divergent_refs)
 };
 // signatures whose retirement was requested since the last frame (Memory::disableWordsRef -> removeAllWordRef): their
 // words lose one reference each and the slot is marked dead (ni = 0).  Up to 4 ride along with the next frame-words launch.

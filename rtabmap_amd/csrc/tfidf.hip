@@ -97,6 +97,7 @@ __global__ __launch_bounds__(BR_BLOCK) void bulk_register_kernel(const int32_t* 
     a.coo_w = const_cast<uint32_t*>(tab[b].coo_w); a.coo_pc = const_cast<uint32_t*>(tab[b].coo_pc); a.ne_counter = bkt_ne + b;
     a.slot_sig = slot_sig; a.slot_ni = slot_ni; a.slot_begin = slot_begin; a.slot_cnt = slot_cnt;
     a.q_w = nullptr; a.q_idf = nullptr; a.q_did = nullptr; a.qd_did = nullptr; a.qd_idf = nullptr; a.q_meta = nullptr; a.idf_tab = nullptr;
+    a.wrow = nullptr;
     frame_words_body<BR_BLOCK, false>(br_dyn_smem, a);
 }
 
@@ -959,6 +960,7 @@ static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool id
     a.q_w = t.q_w.as<uint32_t>(); a.q_idf = t.q_idf.as<int32_t>(); a.q_did = t.q_did.as<int32_t>(); a.qd_did = t.qd_did.as<int32_t>();
     a.qd_idf = t.qd_idf.as<int32_t>(); a.q_meta = t.q_meta.as<uint32_t>(); a.idf_tab = t.idf_tab.as<uint2>();
     a.new_ws = new_ws ? *new_ws : WsRuns();
+    a.wrow = t.wrow.as<uint32_t>();
     if (defer && !resolve) {                                            // registration alone, launched inside a later filter launch
         defer->a = a; defer->ret = ret; defer->shmem = shmem;
         t.q_n_ub = n;

@@ -85,6 +85,7 @@ def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="su
     assert kid[:, 0].tolist() == vi[:: max(1, n_created // 16)].tolist() and not kd[:, 0].any()
     st = eng.stats()
     assert st["vocab_rows"] == n_words + n_created
+    assert st["clean_divergent_refs"] == 0        # nothing is retired in these streams: no enqueued clean can have tombstoned a word a frame in flight matched
     for key in (options or {}):
         eng.set_option(key, -1)                   # (process-wide options go back to their built-in values)
     eng.close()
