@@ -693,17 +693,17 @@ def leg_parity(torch, vocab, words, frame):
             "likelihood_by": how, "oracle_seconds": {"addNewWords": t_knn, "computeLikelihood": t_lik}}
 
 
-def secondary_legs(budget_s=150.0):
+def secondary_legs(budget_s=130.0):
     """The other configurations as short runs of this same script, so that what profiles/ claims for them is observed by whoever runs the
     default command (the previous review's item 8): config 3 on 300 ORB frames, 125 000 words (one GPU's share of config 4) for 50 steps,
     10^6 signatures for 30 steps -- each with its own roofline and one frame of parity.  A leg that would not fit the time budget is skipped
     and says so; a leg that fails reports its error instead of costing the line."""
     import subprocess
-    legs = [("orb_stream_300_frames", ["--config", "orb_stream", "--steps", "300"], 60.0),
-            ("words_125k", ["--words", "125000", "--steps", "50", "--warmup", "5", "--leg"], 45.0),
-            # 10^6 signatures: the host needs ~90 s to draw 5 x 10^8 Zipf words and ~45 s for the numpy restatement of ONE likelihood -- more than
-            # the default command may take; LCD_BENCH_LEGS=all (or `python bench.py --signatures 1000000 --steps 30 --warmup 5 --leg`) runs it
-            ("signatures_1m", ["--signatures", "1000000", "--steps", "30", "--warmup", "5", "--leg"], 240.0)]
+    # (expected seconds on the MI355X box of round 6: 8 / 27 / 52 -- drawing 5 x 10^8 Zipf words and the numpy restatement of ONE likelihood over them
+    # take most of the last one; a slower host skips it and says so; LCD_BENCH_LEGS=all lifts the budget)
+    legs = [("orb_stream_300_frames", ["--config", "orb_stream", "--steps", "300"], 15.0),
+            ("words_125k", ["--words", "125000", "--steps", "50", "--warmup", "5", "--leg"], 35.0),
+            ("signatures_1m", ["--signatures", "1000000", "--steps", "30", "--warmup", "5", "--leg"], 70.0)]
     if os.environ.get("LCD_BENCH_LEGS", "") == "all":
         budget_s = 1200.0
     out = {"note": "short runs of `python bench.py <args>` by this run; the full-size lines are profiles/r06_bench_*.json"}
