@@ -842,6 +842,22 @@ static int prepare_resolve(lcd_engine* h, const void* d_desc, int q, int flags, 
         rc = run_knn2_raw(h, d_desc, q, h->vocab.p, h->row_id.as<int32_t>(), knn_rows, true, h->d_knn_row.as<int32_t>(),
                           h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), &cb, defer_redo ? &r->rp : nullptr);
         if (rc) return rc;
+    } else if (together && h->dtype == LCD_U8 && q > 0) {
+        // Hamming frames (config 3): the scan, then ONE launch for the merge of its partial keys, the same-frame distance matrix and the candidate
+        // bit rows (round 6: they were two dependent launches of ~5 us each behind the scan)
+        LCD_HIP(h, dreserve(h, h->d_knn_row, (size_t)q * 2 * 4));
+        LCD_HIP(h, dreserve(h, h->d_knn_word, (size_t)q * 2 * 4));
+        LCD_HIP(h, dreserve(h, h->d_knn_dist, (size_t)q * 2 * 4));
+        const KnnPlan p = knn_plan(q, (int)knn_rows, h->row_bytes);
+        LCD_HIP(h, dreserve(h, h->d_partial, knn_partial_bytes(p)));
+        const bool prof = h->prof_cap > 0 && h->prof_n < h->prof_cap;
+        if (prof) LCD_HIP(h, hipEventRecord(h->prof_ev[2 * h->prof_n], h->kst));
+        LCD_HIP(h, launch_knn2_partial(h->dtype, h->kdim, h->vocab.p, h->row_id.as<int32_t>(), d_desc, p, h->d_partial.as<uint64_t>(), h->kst));
+        if (prof) { LCD_HIP(h, hipEventRecord(h->prof_ev[2 * h->prof_n + 1], h->kst)); h->prof_n += 1; h->prof_kernel = "knn2_hamming_kernel"; }
+        LCD_HIP(h, launch_knn2_merge_selfdist_hamming(p, h->d_partial.as<uint64_t>(), h->row_id.as<int32_t>(), h->d_knn_row.as<int32_t>(),
+                                                      h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), d_desc, h->kdim, h->d_selfdist.as<float>(), ld,
+                                                      have_index, h->d_bits.as<uint32_t>(), bw, h->kst));
+        h->knn_launches += 1;
     } else {
         rc = run_knn2(h, d_desc, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), knn_rows, h->d_knn_row, h->d_knn_word,
                       h->d_knn_dist);

@@ -372,6 +372,59 @@ __global__ __launch_bounds__(BLOCK) void selfdist_hamming_dyn_kernel(const uint3
     if (bits && qi < nq && r0 < nq) reinterpret_cast<unsigned char*>(bits)[(size_t)qi * bw * 4 + (r0 >> 3)] = (unsigned char)word;
 }
 
+// ------------------------------------------------------------------------------------------------ merge + same-frame distances, one launch (round 6)
+// The Hamming frame (config 3) ran the merge of the scan's partial keys and the same-frame distance matrix as two dependent launches of ~5 us each
+// -- the second only because the candidate bits need each query's second-neighbour distance.  One wave per query does both: the merge as
+// knn2_merge_kernel, then the query's ROW of the (symmetric) distance matrix -- lane l takes descriptors l, l + 64, ... -- whose distances are computed
+// while the winner's word id is on its way, and the bit row from ballots once the threshold is known.
+__global__ __launch_bounds__(BLOCK) void knn2_merge_selfdist_hamming_kernel(const uint64_t* __restrict__ partial, int n_keys, int qpad, int nq,
+                                                                            const int32_t* __restrict__ row_id, int32_t* __restrict__ out_row,
+                                                                            int32_t* __restrict__ out_word, float* __restrict__ out_dist,
+                                                                            const uint32_t* __restrict__ queries, int w32, float* __restrict__ sd, int ld,
+                                                                            int have_index, uint32_t* __restrict__ bits, int bw) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    // the query's row of the distance matrix first: it needs nothing from the merge, and its reads travel with the partial keys'
+    const uint32_t* q = queries + (size_t)qi * w32;
+    constexpr int MAXK = 8;                                          // frames of up to 512 descriptors keep their row in registers; longer ones loop again
+    uint32_t dreg[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        const int r = 64 * k + lane;
+        dreg[k] = (r < nq) ? hamming_dyn(queries + (size_t)r * w32, q, w32) : 0xFFFFFFFFu;
+    }
+    uint64_t best = KEY_NONE, second = KEY_NONE;
+    for (int c = lane; c < n_keys; c += 64) top2_push(best, second, partial[(size_t)c * qpad + qi]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint64_t ob = shfl_xor_u64(best, m), os = shfl_xor_u64(second, m);
+        top2_push(best, second, ob);
+        top2_push(best, second, os);
+    }
+    // (every lane holds the merged pair) the two word ids, needed for the threshold below
+    int32_t w0 = 0, w1 = 0;
+    if (best != KEY_NONE) w0 = row_id[(uint32_t)best];
+    if (second != KEY_NONE) w1 = row_id[(uint32_t)second];
+    const float d0 = best == KEY_NONE ? -1.0f : (float)(uint32_t)(best >> 32), d1 = second == KEY_NONE ? -1.0f : (float)(uint32_t)(second >> 32);
+    if (lane == 0) {
+        out_row[2 * qi] = best == KEY_NONE ? -1 : (int32_t)(uint32_t)best;       out_word[2 * qi] = w0;     out_dist[2 * qi] = d0;       // VWDictionary.cpp:1078-1083
+        out_row[2 * qi + 1] = second == KEY_NONE ? -1 : (int32_t)(uint32_t)second; out_word[2 * qi + 1] = w1; out_dist[2 * qi + 1] = d1;
+    }
+    // cand_threshold(): the second indexed neighbour's distance when both neighbours are valid, else +inf
+    const bool v0 = d0 >= 0.0f && w0 != 0, v1 = d1 >= 0.0f && w1 != 0;
+    const float thr = (have_index && v0 && v1) ? d1 : __int_as_float(0x7f800000);
+    for (int k = 0; 64 * k < ld; ++k) {
+        const int r = 64 * k + lane;
+        uint32_t du = k < MAXK ? dreg[k < MAXK ? k : 0] : 0xFFFFFFFFu;
+        if (k >= MAXK) du = (r < nq) ? hamming_dyn(queries + (size_t)r * w32, q, w32) : 0xFFFFFFFFu;
+        const float d = (float)du;
+        if (r < nq) sd[(size_t)qi * ld + r] = d;                      // row qi of the symmetric matrix: D[qi][r] == D[r][qi]
+        const unsigned long long bal = __ballot(r < nq && d < thr);
+        if (bits && lane == 0) { bits[(size_t)qi * bw + 2 * k] = (uint32_t)bal; bits[(size_t)qi * bw + 2 * k + 1] = (uint32_t)(bal >> 32); }
+    }
+}
+
 }  // namespace
 
 // ================================================================================================ host side
@@ -423,6 +476,15 @@ hipError_t launch_knn2_merge(int dtype, const KnnPlan& p, const uint64_t* partia
     if (p.q == 0) return hipSuccess;
     knn2_merge_kernel<<<(p.q + WAVES - 1) / WAVES, BLOCK, 0, s>>>(dtype, partial, p.n_blocks * 2, p.qpad, p.q, row_id,
                                                                    out_row, out_word, out_dist);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn2_merge_selfdist_hamming(const KnnPlan& p, const uint64_t* partial, const int32_t* row_id, int32_t* out_row, int32_t* out_word,
+                                              float* out_dist, const void* queries, int dim_bytes, float* selfdist, int ld, int have_index, uint32_t* bits,
+                                              int bw, hipStream_t s) {
+    if (p.q == 0) return hipSuccess;
+    knn2_merge_selfdist_hamming_kernel<<<(p.q + WAVES - 1) / WAVES, BLOCK, 0, s>>>(partial, p.n_blocks * 2, p.qpad, p.q, row_id, out_row, out_word, out_dist,
+                                                                                    (const uint32_t*)queries, dim_bytes / 4, selfdist, ld, have_index, bits, bw);
     return hipGetLastError();
 }
 

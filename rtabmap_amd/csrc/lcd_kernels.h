@@ -27,6 +27,10 @@ hipError_t launch_knn2_partial(int dtype, int dim, const void* vocab, const int3
 // Merge the partial keys: out_row[q*2] (row or -1), out_word[q*2] (row_id[row] or 0), out_dist[q*2] (float, -1 = none)
 hipError_t launch_knn2_merge(int dtype, const KnnPlan& p, const uint64_t* partial, const int32_t* row_id,
                              int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s);
+// Hamming frames: the merge AND the same-frame distance matrix [q x ld] AND the candidate bit rows [q x bw] in one launch (one wave per query)
+hipError_t launch_knn2_merge_selfdist_hamming(const KnnPlan& p, const uint64_t* partial, const int32_t* row_id, int32_t* out_row, int32_t* out_word,
+                                              float* out_dist, const void* queries, int dim_bytes, float* selfdist, int ld, int have_index, uint32_t* bits,
+                                              int bw, hipStream_t s);
 
 // Optional by-product of the MFMA 2-NN: the candidate bit matrix of the addNewWords resolution (see launch_selfdist) from an
 // already computed same-frame distance matrix.  bits == nullptr: not wanted.
