@@ -46,6 +46,29 @@ int lcd_engine::find_row(int32_t word_id) {
 #define LCD_DEV_NODRAIN(h) LCD_HIP(h, hipSetDevice((h)->device))
 #define LCD_DEV(h) do { LCD_DEV_NODRAIN(h); int rc__ = (h)->drain(); if (rc__) return rc__; } while (0)
 
+// The sharded stages between a frame that appended on the device and the next one need no exact row mirror: the search plans for rows_ub() (the
+// rows behind the device's count carry +inf norms, a zero operand split and row id 0: no scan ranks them), the index calls do not look at rows
+// at all.  Round 6: they complete what is owed WITHOUT reconciling (drain(false)) -- the per-frame synchronisation of the sharded path -- as long
+// as the append log has room and the caller is within 8 frames of the device (the bound grows by q per unreported frame).
+static int drain_keep_rows_lazy(lcd_engine* h) {
+    { int rc = h->drain(false); if (rc) return rc; }
+    const bool lazy = h->vcnt_active && h->shard_append && !h->rm_pending && h->unreconciled.size() < (size_t)lcd_engine::VLOG / 2;
+    if (!lazy) return h->reconcile();
+    if (h->h_vmirror && h->unreconciled.size() > 8) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spins = 0;; ++spins) {
+            const uint32_t tag = (uint32_t)(*(volatile const unsigned long long*)h->h_vmirror >> 32);
+            if ((uint32_t)h->vseq - tag <= 8u) break;
+            if (spins > 4096) std::this_thread::yield();
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+                if (hipStreamSynchronize(h->stream) != hipSuccess) return h->fail(LCD_ERR_HIP, "hipStreamSynchronize");
+                break;
+            }
+        }
+    }
+    return LCD_OK;
+}
+
 int lcd_engine::sync_all() {
     hipError_t e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(stream)");
@@ -1854,12 +1877,14 @@ int lcd_bayes_posterior(lcd_engine* h, const int32_t* sig_ids, int n, float* out
 int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shard_cand* d_cand) {
     LCD_TRY
     LCD_CHECK_HANDLE(h);
-    LCD_DEV(h);
+    LCD_DEV_NODRAIN(h);
+    { int rc = drain_keep_rows_lazy(h); if (rc) return rc; }
     LCD_JOIN_K(h);
     if (q <= 0 || !d_descriptors || !d_cand) return h->fail(LCD_ERR_INVALID, "lcd_shard_knn2_dev: bad argument");
     if (((uintptr_t)d_descriptors & 15u) != 0) return h->fail(LCD_ERR_INVALID, "lcd_shard_knn2_dev: d_descriptors must be 16-byte aligned");
-    if (h->n_rows >= (1 << 26)) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_shard_knn2_dev: a shard holds at most 2^26 - 1 rows (merge key: 26-bit row, 6-bit rank)");
-    int rc = run_knn2(h, d_descriptors, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), h->n_rows, h->d_knn_row,
+    const int64_t rows_scan = h->rows_ub();                           // == n_rows unless this rank appended on the device since the mirror last caught up
+    if (rows_scan >= (1 << 26)) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_shard_knn2_dev: a shard holds at most 2^26 - 1 rows (merge key: 26-bit row, 6-bit rank)");
+    int rc = run_knn2(h, d_descriptors, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), rows_scan, h->d_knn_row,
                       h->d_knn_word, h->d_knn_dist);
     if (rc) return rc;
     LCD_HIP(h, launch_shard_pack(h->d_knn_row.as<int32_t>(), h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
@@ -1873,7 +1898,8 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
                         int32_t* d_word_ids, int64_t* d_lfix, int64_t lfix_capacity) {
     LCD_TRY
     LCD_CHECK_HANDLE(h);
-    LCD_DEV(h);
+    LCD_DEV_NODRAIN(h);
+    { int rc = drain_keep_rows_lazy(h); if (rc) return rc; }
     LCD_JOIN_K(h);
     if (q <= 0 || q > 8192 || !d_descriptors || !d_all_cand || !d_word_ids || world < 1 || world > 64 || rank < 0 || rank >= world)
         return h->fail(LCD_ERR_INVALID, "lcd_shard_frame_dev: bad argument");
@@ -1956,7 +1982,8 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
 int lcd_finalize_dev(lcd_engine* h, int64_t* d_lfix, int64_t n, float* d_likelihood) {
     LCD_TRY
     LCD_CHECK_HANDLE(h);
-    LCD_DEV(h);
+    LCD_DEV_NODRAIN(h);
+    { int rc = drain_keep_rows_lazy(h); if (rc) return rc; }
     if (n < 0 || (n > 0 && (!d_lfix || !d_likelihood))) return h->fail(LCD_ERR_INVALID, "lcd_finalize_dev: bad argument");
     if (n > h->tfidf.n_slots) return h->fail(LCD_ERR_INVALID, "lcd_finalize_dev: more entries than signature slots");
     LCD_HIP(h, h->tfidf.finalize((const long long*)d_lfix, (long long)n, d_likelihood));
@@ -1967,7 +1994,7 @@ int lcd_finalize_dev(lcd_engine* h, int64_t* d_lfix, int64_t n, float* d_likelih
 int lcd_slots_dev(lcd_engine* h, const int32_t** d_slot_sig, int64_t* n_slots) {
     LCD_TRY
     LCD_CHECK_HANDLE(h);
-    { int rc = h->drain(); if (rc) return rc; }
+    { int rc = drain_keep_rows_lazy(h); if (rc) return rc; }           // (the slot table does not depend on the row mirror)
     if (d_slot_sig) *d_slot_sig = h->tfidf.slot_sig.as<int32_t>();
     if (n_slots) *n_slots = h->tfidf.n_slots;
     return LCD_OK;
