@@ -177,6 +177,9 @@ class Engine:
         if rc != LCD_OK:
             raise LcdError(rc, "lcd_create failed (no gfx950 device / HIP runtime?)")
         self.h = h
+        # experiments: LCD_PY_OPTS="key=value,..." sets engine options on every handle this glue creates (the library reads no environment)
+        for kv in filter(None, os.environ.get("LCD_PY_OPTS", "").split(",")):
+            self._ck(self.L.lcd_set_option(self.h, kv.split("=")[0].encode(), int(kv.split("=")[1])))
 
     def close(self):
         if getattr(self, "h", None):

@@ -76,6 +76,7 @@ struct lcd_engine {
         lcd_frame_args a; lcd::ResolveArgs r; int set = 0;
         uint64_t vseq = 0; bool chained = false;        // the frame takes part in the device row-count chain (vcnt_active at its call)
         bool has_shadow = false;                        // its query pre-split also wrote its shadow rows (FrameScratch::d_shadow_bf)
+        bool slots_are_rows = false;                    // its decision loop left vocabulary ROWS in r.out_wslot (PipeOpts::slots_from_rows): the registration looks the keys up
         lcd::WsRuns runs; bool reserved = false;        // postings keys of its new words (reserved when its decision loop is prepared)
         int stage = 0;                                  // what is owed next: 0 filter + re-rank, 1 the decision loop, 2 registration + scoring
         std::vector<int32_t> retire_after;              // lcd_sig_remove calls made while this was the newest frame

@@ -1375,6 +1375,9 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
         tl_res.r = f_res->r;
         tl_res.r.new_ws = f_res->runs;
         refresh_vocab_ptrs(h, &tl_res.r);
+        // (rows instead of postings keys in out_wslot: NULL is the decision loop's "knn_row already holds the word slot"; the registration translates)
+        f_res->slots_are_rows = h->popt.slots_from_rows && tl_res.r.row_wslot && tl_res.r.knn_row && tl_res.r.q <= 1024;
+        if (f_res->slots_are_rows) { tl_res.r.row_wslot = nullptr; tl_res.r.slots_are_rows = 1; }
         if (f_res->chained) fill_append(h, f_res->a, f_res->vseq, frame_appends(h, f_res->a), &tl_res.r, h->ring[f_res->set].d_applist.as<uint32_t>());
         // the pinned row-count mirror is a store to HOST memory, waited for at the end of the decision loop's chain: with "mirror_from_b" a
         // workgroup of launch B of this pair (which writes the frame's rows anyway) stores it instead
@@ -1386,6 +1389,7 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
         const lcd_frame_args& pa = f_reg->a;
         if (pa.sig_id != 0) LCD_HIP(h, t.register_dev(pa.sig_id, f_reg->r.out_wslot, pa.q, pa.q, pa.N, nullptr, false, &tl_reg));
         else LCD_HIP(h, t.query_dev(f_reg->r.out_wslot, pa.q, pa.N, nullptr, false, &tl_reg));
+        if (f_reg->slots_are_rows) tl_reg.a.row_wslot = h->row_wslot.as<int32_t>();
         if (pa.d_likelihood) {
             LCD_HIP(h, t.score_args(pa.d_likelihood, nullptr, pipe_b_block_size(), &sa, &score_wgs));
             reg_like = true;
@@ -2097,6 +2101,7 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     if (!std::strcmp(key, "filter_delay") && value >= 0 && value <= 127) { h->popt.filter_delay = (int)value; return LCD_OK; }
     if (!std::strcmp(key, "shadow_rows") && value >= -1 && value <= 2) { h->popt.shadow_rows = value < 0 ? 1 : (int)value; return LCD_OK; }   // (-1: built-in = 1)
     if (!std::strcmp(key, "mirror_from_b") && value >= -1 && value <= 1) { h->popt.mirror_from_b = value != 0 ? 1 : 0; return LCD_OK; }
+    if (!std::strcmp(key, "slots_from_rows") && value >= -1 && value <= 1) { h->popt.slots_from_rows = value >= 0 ? (int)value : PipeOpts().slots_from_rows; return LCD_OK; }
     if (!std::strcmp(key, "row_writer_wgs") && value >= -1 && value <= 256) { h->popt.row_writer_wgs = value >= 0 ? (int)value : PipeOpts().row_writer_wgs; return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");
     LCD_CATCH(h)

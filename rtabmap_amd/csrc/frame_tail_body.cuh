@@ -78,8 +78,9 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
     if (have_ne0) lds_barrier(); else __syncthreads();
     for (int i = tid; i < a.n; i += NT) {
         int32_t ws = src_lds ? src_lds[i] : a.src[i];
+        if (!src_lds && a.row_wslot) ws = ws >= 0 ? a.row_wslot[ws] : (ws <= -2 ? -ws - 2 : -1);   // (rows and marked keys: see frame_register_part; frames of more than 4 NT words)
         if (a.xlate) ws = (ws > 0 && (long long)ws < a.xlate_n) ? a.xlate[ws] : -1;
-        else if (ws <= -2) ws = a.new_ws.n > 0 ? ws_runs_at(a.new_ws, -ws - 2) : -1;   // the k-th new word of the frame (split tail)
+        else if (ws <= -2) ws = a.new_ws.n > 0 ? ws_runs_at_dev(a.new_ws, -ws - 2) : -1;   // the k-th new word of the frame (split tail)
         if (ws < 0) continue;
         const uint32_t w = (uint32_t)ws;
         uint32_t h = (w * 2654435761u) & (uint32_t)(H - 1);
@@ -134,26 +135,34 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
                 c4[r] = tcnt[i] > TF_CNT_MASK ? TF_CNT_MASK : tcnt[i];
             }
         }
+        // (the answers have NO defaults and are read only where they were requested: merged with a default, each request got a register copy --
+        // a wait -- right behind it, and the four round trips this loop means to overlap ran one after the other: round 6's ISA)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+#pragma clang diagnostic ignored "-Wconditional-uninitialized"
+        const bool want_r = a.do_register && a.wrow;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            n4[r] = 0; d4[r] = -1; r4[r] = 0u;
             if (!o4[r]) continue;
-            if (a.do_register && a.wrow) r4[r] = a.wrow[w4[r]];                          // (in the same round trip as the reference counts)
-            n4[r] = a.do_register ? atomicAdd(&a.nw[w4[r]], 1u) + 1u : a.nw[w4[r]];   // (a plain read + fire-and-forget add measured slower:
-                                                                                          // atomics drop the line from L2, the read then misses)
-            if (a.want_q) d4[r] = a.did[w4[r]];
+            if (want_r) r4[r] = gload(a.wrow + w4[r]);                                   // (in the same round trip as the reference counts)
+            if (a.do_register) n4[r] = atomicAdd(&a.nw[w4[r]], 1u);                      // (a plain read + fire-and-forget add measured slower:
+            else n4[r] = gload(a.nw + w4[r]);                                            // atomics drop the line from L2, the read then misses)
+            if (a.want_q) d4[r] = gload(a.did + w4[r]);
         }
         // all four answers are awaited HERE, in front of the first store: behind a store (the branches below hide the count of operations
         // in flight from the compiler, which then waits for everything) each entry would wait for the stores of the one before it
+        // (as register pins, so that the compiler's own bookkeeping knows the answers are in: behind an opaque wait it would wait again, for
+        // everything, in front of every later read -- i.e. for the stores of the entry before)
 #pragma unroll
         for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(n4[r]), "+v"(d4[r]), "+v"(r4[r]));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (!o4[r]) continue;
-            const uint32_t w = w4[r], u = u4[r], cnt = c4[r], nwv = n4[r];
+            const uint32_t w = w4[r], u = u4[r], cnt = c4[r], nwv = a.do_register ? n4[r] + 1u : n4[r];
             // a reference to a word the enqueued cleanUnusedWords tombstoned while this frame was in flight (the one documented departure
             // of the device-resident mode -- the reference's clean runs behind this frame's addNewWords and would have kept the word): counted
-            if (r4[r] == 0xFFFFFFFFu && a.q_meta) atomicAdd(&a.q_meta[8], 1u);
+            if (want_r && r4[r] == 0xFFFFFFFFu && a.q_meta) atomicAdd(&a.q_meta[8], 1u);
             if (a.do_register) {
                 a.coo_w[base + u] = w;
                 a.coo_pc[base + u] = (a.slot_local << TF_CNT_BITS) | cnt;
@@ -175,6 +184,7 @@ __device__ __forceinline__ void frame_words_body(uint32_t* fw_smem, const FwArgs
             }
         }
     }
+#pragma clang diagnostic pop
     lds_barrier();                                      // only s_misc[1] (LDS) is awaited: the stores above need no acknowledgement here
     if (tid == 0) {
         if (a.want_q) { a.q_meta[0] = U; a.q_meta[1] = s_misc[1]; }
@@ -198,6 +208,33 @@ __device__ __forceinline__ void retire_body(const RetireArgs& r, const uint32_t*
         const uint32_t begin = slot_begin[slot], cnt = slot_cnt[slot];
         for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) atomicSub(&nw[r.coo_w[p][begin + k]], 1u);
         if (threadIdx.x == 0) { slot_ni[slot] = 0u; slot_sig[slot] = 0; }
+    }
+}
+// The same with the log stretch of every retired slot (begin, cnt) already in registers (frame_register_part requests them with its other
+// first reads), and the words of a slot requested two per thread before the first reference count is touched.
+struct RetirePre { uint32_t begin[4], cnt[4]; };
+__device__ __forceinline__ void retire_request(const RetireArgs& r, const uint32_t* __restrict__ slot_begin, const uint32_t* __restrict__ slot_cnt, RetirePre& pre) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {                                       // (slot 0 for the entries that are not there: a request without a condition)
+        const long long slot = p < r.n ? r.slot[p] : 0;
+        pre.begin[p] = gload(slot_begin + slot); pre.cnt[p] = gload(slot_cnt + slot);
+    }
+}
+__device__ __forceinline__ void retire_finish(const RetireArgs& r, const RetirePre& pre, uint32_t* __restrict__ nw, uint32_t* __restrict__ slot_ni,
+                                              int32_t* __restrict__ slot_sig, uint32_t k_first0 = 0u /* entries of slot 0 the caller has already released */) {
+    const uint32_t nt = blockDim.x;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (p >= r.n) continue;
+        const uint32_t begin = pre.begin[p], cnt = pre.cnt[p];
+        for (uint32_t k = threadIdx.x + (p == 0 ? k_first0 : 0u); k < cnt; k += 2 * nt) {
+            const uint32_t k1 = min(k + nt, cnt - 1u);                  // (a clamped second request instead of one under a condition)
+            uint32_t w0 = gload(r.coo_w[p] + begin + k), w1 = gload(r.coo_w[p] + begin + k1);
+            asm volatile("" : "+v"(w0), "+v"(w1));                      // (both requested before either is used: the second one is not sunk under its condition)
+            atomicSub(&nw[w0], 1u);
+            if (k + nt < cnt) atomicSub(&nw[w1], 1u);
+        }
+        if (threadIdx.x == 0) { slot_ni[r.slot[p]] = 0u; slot_sig[r.slot[p]] = 0; }
     }
 }
 
@@ -232,7 +269,7 @@ __device__ __forceinline__ void append_write_row(const AppendArgs& ap, size_t ro
     }
 }
 __device__ __forceinline__ void append_write_ids(const AppendArgs& ap, const WsRuns& new_ws, size_t row, int k) {
-    const int32_t key = new_ws.n > 0 ? ws_runs_at(new_ws, k) : -1;
+    const int32_t key = new_ws.n > 0 ? ws_runs_at_dev(new_ws, k) : -1;
     ap.row_id[row] = ap.first_id + k;
     ap.row_wslot[row] = key;
     if (key >= 0 && ap.wrow) ap.wrow[key] = (uint32_t)row + 1u;         // the key now belongs to a row: the batched check of superseded
@@ -446,24 +483,29 @@ __device__ __forceinline__ void frame_tail_body(uint32_t* ft_dyn_smem, const Res
 template <int NT>
 __device__ __forceinline__ void frame_resolve_part(uint32_t* ft_dyn_smem, const ResolveArgs& r, int wb, int n_wb) {
     if (wb > 0) { rowpar_body<64, NT>(r.rp, wb - 1, n_wb - 1, r.fail_count); return; }
-    if (r.rp.enabled && n_wb > 1) {
+    constexpr int KPT = 1024 / NT;
+    const bool fast = r.q <= KPT * NT;
+    const bool helpers = r.rp.enabled && n_wb > 1;
+    // (frames of up to 1 024 descriptors: the decision loop reads the helpers' counter and the appender's row count WITH its first round
+    // trip -- resolve_body_fast -- instead of two round trips in front of it)
+    if (helpers && !fast) {
         if (threadIdx.x == 0 && r.fail_count[0] > 0) {
             while (__hip_atomic_load(&r.fail_count[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
     }
-    // the row count the appender continues from was written by the previous launch: requested now, a whole decision loop ahead of its use
+    // the row count the appender continues from was written by the previous launch: requested a whole decision loop ahead of its use
     int n_in_early = -1;
-    if (r.ap.enabled && r.ap.cnt_in) n_in_early = gload(r.ap.cnt_in);
+    const int32_t* cnt_in = (r.ap.enabled && r.ap.cnt_in) ? r.ap.cnt_in : nullptr;
+    if (!fast && cnt_in) n_in_early = gload(cnt_in);
     FT_STAMP(0);
-    constexpr int KPT = 1024 / NT;
     const uint32_t* fmask;
-    if (r.q <= KPT * NT) fmask = resolve_body_fast<NT, KPT>(ft_dyn_smem, nullptr, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist,
-                                                            r.ld, r.cand_bits, r.bw, r.out_word, r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws,
-                                                            r.cand_list, r.cand_cnt, &n_in_early);
+    if (fast) fmask = resolve_body_fast<NT, KPT>(ft_dyn_smem, nullptr, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist,
+                                                 r.ld, r.cand_bits, r.bw, r.out_word, r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws,
+                                                 r.cand_list, r.cand_cnt, &n_in_early, cnt_in, helpers ? r.fail_count : nullptr, r.slots_are_rows != 0);
     else { asm volatile("" : "+v"(n_in_early)); fmask = resolve_body<NT>(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
-                                  r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws); }   // (both paths leave n_in_early awaited: the
+                                  r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws, r.slots_are_rows != 0); }   // (both paths leave n_in_early awaited: the
                                                                         // compiler's wait in front of its use would otherwise cover the loop's stores)
     if (threadIdx.x == 0 && r.fail_count) { r.fail_count[0] = 0; r.fail_count[1] = 0; r.fail_count[3] = 0; }
     if (r.ap.enabled && r.ap.defer_rows) append_publish<NT>(r.ap, r.q, fmask, ft_dyn_smem + 2 * ((r.q + 63) / 64 * 2), n_in_early);
@@ -478,37 +520,61 @@ __device__ __forceinline__ void frame_resolve_part(uint32_t* ft_dyn_smem, const 
 }
 template <int NT>
 __device__ __forceinline__ void frame_register_part(uint32_t* ft_dyn_smem, const FwArgs& a, const RetireArgs& retire) {
-    uint32_t ne0 = 0u;
-    const bool have_ne0 = a.do_register && a.ne_counter != nullptr;
-    if (threadIdx.x == 0 && have_ne0) ne0 = gload(a.ne_counter);
-    // The frame's word slots (written by the decision loop one launch earlier) are requested HERE, in front of the retirement's reads:
-    // they arrive with them (one in-order counter), are parked in LDS, and the table phases of frame_words_body then run on LDS alone
-    // while the retirement's atomics are acknowledged -- instead of a barrier that waits for those acknowledgements and a round trip
-    // for the word slots behind it.  (The barrier in front of frame_words_body's second pass still orders the reference counts.)
+    // Everything this chain reads first -- the log position of the open bucket, the frame's word slots (written by the decision loop one
+    // launch earlier), the log stretches of the slots to retire -- is requested in ONE round trip and awaited once: every request WITHOUT a
+    // condition, at a clamped address of an array that is always there, the values selected afterwards.  A request under a condition whose
+    // result is merged with a default makes the compiler copy registers right behind the request, i.e. wait for it -- round 6's ISA had
+    // eight round trips in a row here (ne0, four word slots, begin, cnt, the words).
     constexpr int KS = 4;
+    const bool have_ne0 = a.do_register && a.ne_counter != nullptr;
     const bool pre = a.n <= KS * NT && a.xlate == nullptr && a.src != nullptr;
+    const uint32_t* nep = have_ne0 ? a.ne_counter : a.nw;
+    const int32_t* srcp = pre ? a.src : reinterpret_cast<const int32_t*>(a.nw);
+    const int i_max = pre ? max(a.n - 1, 0) : 0;
+    uint32_t ne0 = gload(nep);
     int32_t ws_pre[KS];
 #pragma unroll
-    for (int k = 0; k < KS; ++k) {
-        const int i = (int)threadIdx.x + k * NT;
-        ws_pre[k] = (pre && i < a.n) ? gload(a.src + i) : -1;
-    }
+    for (int k = 0; k < KS; ++k) ws_pre[k] = gload(srcp + min((int)threadIdx.x + k * NT, i_max));
+    RetirePre rp;
+    retire_request(retire, a.slot_begin, a.slot_cnt, rp);
+    asm volatile("" : "+v"(ne0), "+v"(ws_pre[0]), "+v"(ws_pre[1]), "+v"(ws_pre[2]), "+v"(ws_pre[3]));       // (awaited together, and known to be)
+    asm volatile("" : "+v"(rp.begin[0]), "+v"(rp.begin[1]), "+v"(rp.begin[2]), "+v"(rp.begin[3]), "+v"(rp.cnt[0]), "+v"(rp.cnt[1]), "+v"(rp.cnt[2]), "+v"(rp.cnt[3]));
     FT_STAMP(4);
-    retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
-    if (!pre) {
-        __syncthreads();
-        FT_STAMP(5);
-        frame_words_body<NT, true>(ft_dyn_smem, a, nullptr, have_ne0, ne0);
-    } else {
-        int32_t* lds_ws = (int32_t*)(ft_dyn_smem + 2 * a.H + a.H / 64 + 8);      // behind the tables (as in frame_tail_body)
+    // ---- second round trip, again without conditions: (a) the word slots are vocabulary ROWS (FwArgs::row_wslot: the decision loop of a pipelined
+    // frame leaves the row of the word it chose -- the gather of its postings key used to be a round trip of THAT chain, the longest of launch A, and
+    // sat in front of every wait of its sweeps): their keys; (b) the first 2 NT words of the first signature to retire (one signature of <= 2 NT
+    // unique words is the usual case; the rest goes through retire_finish's loop)
+    const int32_t* rwp = a.row_wslot ? a.row_wslot : reinterpret_cast<const int32_t*>(a.nw);
+    const bool ret0 = retire.n >= 1 && rp.cnt[0] > 0u;
+    const uint32_t* cwp = ret0 ? retire.coo_w[0] + rp.begin[0] : a.nw;
+    const uint32_t cnt0 = ret0 ? rp.cnt[0] : 1u;
+    int32_t key[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) key[k] = gload(rwp + (a.row_wslot ? max(ws_pre[k], 0) : 0));
+    uint32_t rw0 = gload(cwp + min((uint32_t)threadIdx.x, cnt0 - 1u)), rw1 = gload(cwp + min((uint32_t)threadIdx.x + NT, cnt0 - 1u));
+    asm volatile("" : "+v"(key[0]), "+v"(key[1]), "+v"(key[2]), "+v"(key[3]), "+v"(rw0), "+v"(rw1));
+    if (a.row_wslot) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) ws_pre[k] = ws_pre[k] >= 0 ? key[k] : (ws_pre[k] <= -2 ? -ws_pre[k] - 2 : -1);   // (<= -2: the key of a word the frame created)
+    }
+    // the word slots are parked in LDS: the table phases of frame_words_body then run on LDS alone while the retirement's atomics are
+    // acknowledged.  (The barrier in front of frame_words_body's second pass still orders the reference counts.)
+    int32_t* lds_ws = pre ? (int32_t*)(ft_dyn_smem + 2 * a.H + a.H / 64 + 8) : nullptr;      // behind the tables (as in frame_tail_body)
+    if (pre) {
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const int i = (int)threadIdx.x + k * NT;
             if (i < a.n) lds_ws[i] = ws_pre[k];                           // read back by the same thread
         }
-        FT_STAMP(5);
-        frame_words_body<NT, true>(ft_dyn_smem, a, lds_ws, have_ne0, ne0);
     }
+    if (ret0) {
+        if (threadIdx.x < rp.cnt[0]) atomicSub(&a.nw[rw0], 1u);
+        if (threadIdx.x + NT < rp.cnt[0]) atomicSub(&a.nw[rw1], 1u);
+    }
+    retire_finish(retire, rp, a.nw, a.slot_ni, a.slot_sig, ret0 ? 2u * NT : 0u);
+    if (!pre) __syncthreads();
+    FT_STAMP(5);
+    frame_words_body<NT, true>(ft_dyn_smem, a, lds_ws, have_ne0, ne0);
     FT_STAMP(6);
 }
 

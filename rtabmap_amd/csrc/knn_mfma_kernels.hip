@@ -1442,8 +1442,12 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     // snapshot of the vocabulary (VWDictionary::update() of a pipelined handle).  They are scanned exactly here, so the result is
     // the 2-NN over the vocabulary as update() leaves it before this frame.
     // (the plan is made for an ESTIMATE of the row count: what lies between the rows it covered and the device's count is scanned here too)
-    const int n_lo0 = pend_lo ? pend_lo[0] : 0;
-    const int p_lo = pend_lo ? min(n_lo0, pend_cap) : 0, p_hi = pend_hi ? pend_hi[0] : 0;
+    // (both counters through the scalar cache, requested together: as two vector loads the compiler made each uniform right behind its request --
+    // two round trips in a row at the head of every re-rank workgroup, round 6's ISA)
+    int n_lo0 = 0, p_hi_ld = 0;
+    if (pend_lo && pend_hi) asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(n_lo0), "=&s"(p_hi_ld) : "s"(pend_lo), "s"(pend_hi) : "memory");
+    else { if (pend_lo) n_lo0 = pend_lo[0]; if (pend_hi) p_hi_ld = pend_hi[0]; }
+    const int p_lo = pend_lo ? min(n_lo0, pend_cap) : 0, p_hi = p_hi_ld;
     // with shadow rows the pending scan only has to cover vocabulary rows the filter's plan did not reach ([p_lo, n_lo0): rare)
     const int p_hi_s = sh_q > 0 ? min(p_hi, n_lo0) : p_hi;
     __shared__ uint32_t s_plist[HALVES * MF_BLOCK];                    // the first entries of pend_list (one per thread: read with the keys)
@@ -1519,7 +1523,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         for (int j = wr_index + wr_n * ((int)threadIdx.x >> 4), m = (int)threadIdx.x >> 4; j < n_new; j += wr_n * (HALVES * MF_BLOCK / 16), m += HALVES * MF_BLOCK / 16) {
             const int rl = own ? m : n_lo0 + j - c0;                   // the row's place in the staged chunk (uniform over its 16 lanes)
             if (rl < 0 || rl >= n_chunk) continue;
-            const int32_t key = (c16 == 0 && wr.new_ws.n > 0) ? ws_runs_at(wr.new_ws, j) : -1;      // (looked up in front of the row's stores)
+            const int32_t key = (c16 == 0 && wr.new_ws.n > 0) ? ws_runs_at_dev(wr.new_ws, j) : -1;      // (looked up in front of the row's stores)
             const uint4 x = *reinterpret_cast<const uint4*>(stage + (size_t)rl * DIM + ((c16 ^ (rl & 15)) * 4));
             append_write_row(ap, (size_t)n_lo0 + (size_t)j, c16, x, nmax);
             if (c16 == 0) {
@@ -1564,7 +1568,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                 float nmax = 0.0f;
                 for (int m = (int)threadIdx.x >> 4; m < n_chunk; m += HALVES * MF_BLOCK / 16) {
                     const int j = wr_index + wr_n * (m0 + m);
-                    const int32_t key = (c16 == 0 && wr.new_ws.n > 0) ? ws_runs_at(wr.new_ws, j) : -1;
+                    const int32_t key = (c16 == 0 && wr.new_ws.n > 0) ? ws_runs_at_dev(wr.new_ws, j) : -1;
                     const uint4 x = *reinterpret_cast<const uint4*>(stage + (size_t)m * DIM + ((c16 ^ (m & 15)) * 4));
                     append_write_row(ap, (size_t)n_lo0 + (size_t)j, c16, x, nmax);
                     if (c16 == 0) {

@@ -76,6 +76,13 @@ __host__ __device__ inline int32_t ws_runs_at(const WsRuns& r, int k) {
     return -1;
 }
 
+#if defined(__HIPCC__)
+// Device call sites (decision loop, registration, row writers).  A variant that walks ALL runs in a uniform loop (start / len through scalar
+// loads, only k per lane: no per-lane read of the argument segment) was measured and lost: launch A 12.7 -> 15.5 us on the driver's command -- the
+// loop's sixteen dependent selects sit in front of every key in the decision loop's last phase (profiles/r06_ab_notes.txt, item 9).
+__device__ __forceinline__ int32_t ws_runs_at_dev(const WsRuns& r, int k) { return ws_runs_at(r, k); }
+#endif
+
 // Arguments of the exact redo of rejected queries (rowpar_body.cuh).  enabled == 0: no redo wanted.
 struct RowparArgs {
     int enabled = 0;

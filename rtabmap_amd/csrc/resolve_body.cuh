@@ -95,7 +95,8 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
                                                   const int32_t* __restrict__ knn_row, const int32_t* __restrict__ row_wslot,
                                                   int32_t* __restrict__ out_wslot, const WsRuns& new_ws,
                                                   const uint2* __restrict__ cand_list = nullptr, const int32_t* __restrict__ cand_cnt = nullptr,
-                                                  int* keep_in_reg = nullptr) {
+                                                  int* keep_in_reg = nullptr, const int32_t* early_ptr = nullptr, int32_t* helpers_fail = nullptr,
+                                                  bool slots_are_rows = false) {
     const int mw = (q + 63) / 64 * 2;
     uint32_t* mask_cur = rs_smem;
     uint32_t* mask_next = rs_smem + mw;
@@ -115,8 +116,77 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
     };
     Dsc st[KPT];
     RB_STAMP(0);
-    // ---- round trip 1: indexed neighbours + their rows (all descriptors of the thread in flight together)
+    // ---- round trip 1: indexed neighbours + their rows, the same-frame candidates (count + compact list left by the re-rank; descriptors
+    //      with more than four, and paths without the lists, walk their bit row in every sweep instead) and the bit row itself (frames of up
+    //      to 512 descriptors: 64 bytes) -- all descriptors of the thread in flight together
     float d0[KPT], d1[KPT]; int r0[KPT], r1[KPT];
+    int cn[KPT];
+    uint4 cl_lo[KPT], cl_hi[KPT], rbq[KPT][4];
+    // `straight`: every array of the round trip is there (a pipelined frame's decision loop always) -> the requests are issued
+    // UNCONDITIONALLY at clamped addresses, in one straight line, and the values are selected afterwards.  With a request under a
+    // condition the compiler merges the loaded registers with their defaults right behind the request -- a register copy that needs the
+    // data: round 6's ISA had `s_waitcnt vmcnt(2)` behind the first list request of EVERY descriptor of the thread, i.e. four round trips
+    // in a row where the source says one (stamps: 5.1 us from the entry to the reject mask; one round trip is ~2.5 us in that launch).
+    // A bit row is read as four 16-byte pieces whatever its length: the bytes behind a short row are the next rows and, behind the last
+    // row, the compact lists of the same buffer (cand_bits_layout) -- checked here -- and words >= bw are cleared below.
+    const bool straight = have_index && (out_wslot || lds_wslot) && together && cand_cnt && cand_list && bw >= 2 && bw <= 16 && q >= 8 &&
+                          reinterpret_cast<const uint32_t*>(cand_list) == cand_bits + (size_t)q * bw;
+    // early_ptr: a word the caller wants in *keep_in_reg (the appender's row count), requested BEHIND the round trip's requests: in front
+    // of them the compiler's wait for it (the straight block reuses registers the other block loads into) was a round trip of its own.
+    // helpers_fail: the exact-redo helpers' counters ([0] = queries the 2-NN certificate rejected, [3] = helpers done).  The count is
+    // read WITH the round trip, not in front of it (it used to be a scalar load + barrier ahead of everything); the rare frame with
+    // rejected queries waits for the helpers and reads everything again.
+    if (!straight && helpers_fail) {
+        if (tid == 0 && helpers_fail[0] > 0) {
+            while (__hip_atomic_load(&helpers_fail[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+    if (!straight && early_ptr && keep_in_reg) *keep_in_reg = *(const __attribute__((address_space(1))) int32_t*)early_ptr;
+    if (straight) {
+        const int32_t* fcp = helpers_fail ? helpers_fail : out_n_new;      // (always a readable word: the loads below have no condition)
+        const int32_t* ep = early_ptr ? early_ptr : out_n_new;
+        int32_t fc = 0, ev = -1;
+        auto round_trip = [&]() __attribute__((always_inline)) {
+            float2 dd[KPT]; int2 ww[KPT], rr[KPT]; int cr[KPT];
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const int ic = min(tid + k * NT, q - 1);
+                dd[k] = *reinterpret_cast<const float2*>(knn_dist + 2 * ic);
+                ww[k] = *reinterpret_cast<const int2*>(knn_word + 2 * ic);
+                rr[k] = *reinterpret_cast<const int2*>(knn_row + 2 * ic);
+                cr[k] = cand_cnt[ic];
+                cl_lo[k] = *reinterpret_cast<const uint4*>(cand_list + (size_t)ic * 4);
+                cl_hi[k] = *reinterpret_cast<const uint4*>(cand_list + (size_t)ic * 4 + 2);
+                const uint32_t* row = cand_bits + (size_t)ic * bw;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rbq[k][u] = *reinterpret_cast<const uint4*>(row + 4 * u);
+            }
+            fc = *(const __attribute__((address_space(1))) int32_t*)fcp;
+            ev = *(const __attribute__((address_space(1))) int32_t*)ep;
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const bool in = tid + k * NT < q;
+                d0[k] = in ? dd[k].x : -1.0f; d1[k] = in ? dd[k].y : -1.0f;
+                st[k].w0 = in ? ww[k].x : 0; st[k].w1 = in ? ww[k].y : 0;
+                r0[k] = in ? rr[k].x : -1; r1[k] = in ? rr[k].y : -1;
+                cn[k] = in ? cr[k] : 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (4 * u >= bw) rbq[k][u] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        };
+        round_trip();
+        if (helpers_fail && fc > 0) {                                     // (the same word for every thread: the branch is uniform)
+            if (tid == 0) {
+                while (__hip_atomic_load(&helpers_fail[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            round_trip();
+        }
+        if (early_ptr && keep_in_reg) *keep_in_reg = ev;
+    } else {
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const int i = tid + k * NT;
@@ -128,17 +198,6 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
             if (out_wslot || lds_wslot) { const int2 rr = *reinterpret_cast<const int2*>(knn_row + 2 * i); r0[k] = rr.x; r1[k] = rr.y; }
         }
     }
-    // ---- the same-frame candidates: count + compact list left by the re-rank (one read each); descriptors with more than four, and
-    //      paths without the lists, walk their bit row in every sweep instead
-    int cn[KPT];
-    // ... and the lists themselves, unconditionally, in the SAME round trip as their counts (32 bytes per descriptor; entries beyond the
-    // count are never looked at): requested behind the counts they used to be a second dependent round trip, ~2 us at the head of the
-    // first sweep (round 5's stamps: 0.9 + 1.3 us in front of the first two descriptors of a thread)
-    // ... and so is the descriptor's bit row (frames of up to 512 descriptors: 64 bytes): the descriptors that need it -- more than four
-    // candidates: the copies of a place's popular words, dozens per frame -- used to request it behind their count, and the first sweep
-    // waited for that second round trip (and, the counter being in-order, for the postings-key gathers in front of it): 0.8 + 1.3 us at the
-    // head of sweep 0 in round 6's stamps
-    uint4 cl_lo[KPT], cl_hi[KPT], rbq[KPT][4];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const int i = tid + k * NT;
@@ -159,15 +218,20 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
             }
         }
     }
-    // ---- round trip 2: postings keys of both neighbours (consumed after the sweeps) together with the candidate lists below
+    }
+    // ---- round trip 2: postings keys of both neighbours (consumed after the sweeps).  row_wslot == NULL: knn_row IS the word slot -- the sharded
+    //      frame's keys, or, on a pipelined handle, the ROW, whose key the registration looks up one launch later (PipeOpts::slots_from_rows): this
+    //      chain, the longest of launch A, then has no second round trip -- and none in flight in front of the sweeps' waits
+    if (row_wslot) {
 #pragma unroll
-    for (int k = 0; k < KPT; ++k) {
-        const int i = tid + k * NT;
-        st[k].ws_a = -1; st[k].ws_b = -1;
-        if (i < q && (out_wslot || lds_wslot)) {
-            if (r0[k] >= 0) st[k].ws_a = row_wslot ? row_wslot[r0[k]] : r0[k];
-            if (r1[k] >= 0) st[k].ws_b = row_wslot ? row_wslot[r1[k]] : r1[k];
+        for (int k = 0; k < KPT; ++k) {
+            const int32_t a = row_wslot[max(r0[k], 0)], b = row_wslot[max(r1[k], 0)];
+            st[k].ws_a = r0[k] >= 0 ? a : -1;
+            st[k].ws_b = r1[k] >= 0 ? b : -1;
         }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) { st[k].ws_a = r0[k]; st[k].ws_b = r1[k]; }     // (-1 where there is no neighbour)
     }
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
@@ -255,6 +319,8 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
                         // (the descriptors with long lists are the copies of a place's popular words: their candidates are each other, none of
                         // them a new word -- one branch-free test says so and the walk below, 16 words x a data-dependent loop, is skipped: it was
                         // most of the 0.4-1.1 us a descriptor cost a sweep in round 6's stamps)
+                        // (finding the first hit of all the thread's descriptors first and requesting their distances together -- one wait per sweep
+                        // instead of one per descriptor with a hit -- was measured and lost: launch A 12.4 -> 12.8 us, profiles/r06_ab_notes.txt item 9)
                         uint32_t any = 0u;
 #pragma unroll
                         for (int w = 0; w < 16; ++w) any |= S.rb[w] & mreg[w];
@@ -344,7 +410,7 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
             if (w < 0) w = -(new_rank(mask_cur, prefix, -w - 1) + 1);   // matched a same-frame new word
         }
         int32_t ws = -1;
-        if (w < 0 && new_ws.n > 0) ws = ws_runs_at(new_ws, -w - 1);
+        if (w < 0 && new_ws.n > 0) { ws = ws_runs_at_dev(new_ws, -w - 1); if (slots_are_rows) ws = ws >= 0 ? -(ws + 2) : -1; }   // (a key among rows: marked)
         if (w < 0 && new_ws.n < 0) ws = w - 1;                          // split tail: code -(k + 2), translated by the registration workgroup
         if (w > 0) { if (S.w0 == w) ws = S.ws_a; else if (S.w1 == w) ws = S.ws_b; }
         wv_[k] = w; wsv_[k] = ws;
@@ -374,7 +440,7 @@ __device__ __forceinline__ const uint32_t* resolve_body(uint32_t* rs_smem, int q
                                                          const uint32_t* __restrict__ cand_bits, int bw,
                                                          int32_t* __restrict__ out_word, int32_t* __restrict__ out_n_new,
                                                          const int32_t* __restrict__ knn_row, const int32_t* __restrict__ row_wslot,
-                                                         int32_t* __restrict__ out_wslot, const WsRuns& new_ws) {
+                                                         int32_t* __restrict__ out_wslot, const WsRuns& new_ws, bool slots_are_rows = false) {
     // rs_smem: mask_a[mw] | mask_b[mw] | prefix[mw + 1]
     const int mw = (q + 63) / 64 * 2;                 // mask words (a whole number of waves)
     uint32_t* mask_cur = rs_smem;
@@ -449,7 +515,7 @@ __device__ __forceinline__ const uint32_t* resolve_body(uint32_t* rs_smem, int q
             // too -- the VisualWord constructor does addRef(signatureId), VWDictionary.cpp:1185 -- under the k-th key the caller reserved
             // for the frame's new words; without a reservation new words get no posting.
             int32_t ws = -1;
-            if (w < 0 && new_ws.n > 0) ws = ws_runs_at(new_ws, -w - 1);
+            if (w < 0 && new_ws.n > 0) { ws = ws_runs_at_dev(new_ws, -w - 1); if (slots_are_rows) ws = ws >= 0 ? -(ws + 2) : -1; }
             if (w < 0 && new_ws.n < 0) ws = w - 1;                      // split tail: code -(k + 2) (see resolve_body_fast)
             if (w > 0) {
                 if (knn_word[2 * i] == w) ws = row_wslot ? row_wslot[knn_row[2 * i]] : knn_row[2 * i];

@@ -52,7 +52,9 @@ __device__ __forceinline__ void cand_bits_row(const CandBits& cb, int qi, float 
 // a counter, cdna_hip_programming.md guideline 16) merges them, writes the result into the query's own slot (and its row of
 // candidate bits) and raises fail_count[3] for whoever waits for the redo.  Leaves at once when the list is empty.
 //   fail_count: [0] rejected queries, [1] arrival counter, [3] done flag.   wb / n_wb: this workgroup's index / the number of
-//   workgroups walking the rows (NT rows each).
+//   workgroups walking the rows; the rows are walked in chunks of NT (chunk c by workgroup c % n_wb): a launch may bring fewer
+//   workgroups than there are chunks -- the fused frame launch does (REDO_WGS_MAX): its helpers queue for compute-unit slots behind the
+//   filter's workgroups, ~400 of them kept the launch open 1.5-2 us after everything else had finished (round 6's stamps).
 template <int DIM, int NT>
 __device__ __forceinline__ void rowpar_body(const RowparArgs& a, int wb, int n_wb, int32_t* __restrict__ fail_count) {
     const int nf = fail_count[0];
@@ -62,8 +64,10 @@ __device__ __forceinline__ void rowpar_body(const RowparArgs& a, int wb, int n_w
     __shared__ uint64_t s_k[NW][2];
     __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = wb * NT + (int)threadIdx.x;
+    const int n_chunks = (a.n_rows + NT - 1) / NT;
     const int n_rows_now = a.n_rows_dev ? min(a.n_rows_dev[0], a.n_rows) : a.n_rows;
+    for (int ch = wb; ch < n_chunks; ch += n_wb) {
+    const int row = ch * NT + (int)threadIdx.x;
     const bool live = row < n_rows_now && a.row_id[min(row, a.n_rows - 1)] != 0;
     float v[DIM];
     {
@@ -99,9 +103,10 @@ __device__ __forceinline__ void rowpar_body(const RowparArgs& a, int wb, int n_w
         __syncthreads();
         if (threadIdx.x == 0) {
             for (int w = 1; w < NW; ++w) { top2_push(best, second, s_k[w][0]); top2_push(best, second, s_k[w][1]); }
-            a.partial[((size_t)f * n_wb + wb) * 2 + 0] = best;
-            a.partial[((size_t)f * n_wb + wb) * 2 + 1] = second;
+            a.partial[((size_t)f * n_chunks + ch) * 2 + 0] = best;
+            a.partial[((size_t)f * n_chunks + ch) * 2 + 1] = second;
         }
+    }
     }
     // publish this workgroup's keys, find out whether it is the last one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -116,7 +121,7 @@ __device__ __forceinline__ void rowpar_body(const RowparArgs& a, int wb, int n_w
     __syncthreads();
     if (!s_last) return;
     // last workgroup: one wave per listed query merges the n_wb * 2 keys
-    const int n_keys = n_wb * 2;
+    const int n_keys = n_chunks * 2;
     for (int f = wave; f < nf; f += NW) {
         uint64_t best = KEY_NONE, second = KEY_NONE;
         for (int c = lane; c < n_keys; c += 64) top2_push(best, second, a.partial[(size_t)f * n_keys + c]);

@@ -141,6 +141,8 @@ struct ResolveArgs {
     const int32_t* knn_word; const float* knn_dist; const float* selfdist; int ld; const uint32_t* cand_bits; int bw;
     int32_t* out_word; int32_t* out_n_new; const int32_t* knn_row; const int32_t* row_wslot; int32_t* out_wslot;
     const uint2* cand_list; const int32_t* cand_cnt;   // CandBits::list / cnt (NULL: only the bit rows exist)
+    int slots_are_rows = 0;    // 1 (with row_wslot == NULL): out_wslot gets the vocabulary ROW of a matched word (>= 0; FwArgs::row_wslot translates it one
+                           // launch later) and -(key + 2) for a word the frame creates (its key comes from new_ws here and is no row)
     WsRuns new_ws;         // postings keys of the frame's new words (n == 0: new words get no postings)
     int32_t* fail_count;   // reset for the next frame's certificate (saves a memset launch); may be NULL
     RowparArgs rp;         // rp.enabled: the exact redo of rejected queries runs as extra workgroups of the tail launch
@@ -158,6 +160,9 @@ struct FwArgs {
     int32_t* slot_sig; uint32_t* slot_ni; uint32_t* slot_begin; uint32_t* slot_cnt;
     uint32_t* q_w; int32_t* q_idf; int32_t* q_did; int32_t* qd_did; int32_t* qd_idf; uint32_t* q_meta; uint2* idf_tab;
     WsRuns new_ws;                                // src entries <= -2 are codes -(k + 2) of the frame's k-th new word (WsRuns, n < 0)
+    const int32_t* row_wslot;                     // NULL: src holds postings keys.  Otherwise its entries >= 0 are vocabulary ROWS (row_wslot[row] is the key) and its
+                                                  // entries <= -2 are keys themselves, -(key + 2): the words the frame created (ResolveArgs::slots_are_rows)
+                                                  // (the decision loop of a pipelined frame: the gather moved from its chain to the registration's, lcd_set_option "slots_from_rows")
     const uint32_t* wrow;                         // Tfidf::wrow (NULL: not wanted): a registered word whose key reads 0xFFFFFFFF is a word an enqueued
                                                   // cleanUnusedWords tombstoned while this frame was in flight -- counted in q_meta[8] (lcd_stats.clean_divergent_refs)
 };
@@ -214,6 +219,8 @@ struct QSplitArgs { const float* queries; int nq, qpad; uint4* qsplit; float* qn
 size_t knn_qsplit_bytes(int q);
 int pipe_block_size();      // workgroup size of launch A (the filter's)
 int pipe_b_block_size();    // workgroup size of launch B (re-rank + scoring)
+// exact-redo helper workgroups of a fused frame launch (they leave at once when nothing was rejected; rowpar_body walks the rows in chunks)
+constexpr int REDO_WGS_MAX = 32;
 void resolve_launch_info(const ResolveArgs& r, int block, int* n_redo, size_t* shmem);
 // filter of the newest frame + the decision loop of one earlier frame (resolve: r / n_redo / shmem_resolve of that TailLaunch) + the
 // registration of a still earlier one (reg: a / ret / shmem); either may be NULL
@@ -230,6 +237,8 @@ struct PipeOpts {
     int shadow_rows = 1;             // "shadow_rows" (1: while the stream creates >= 16 words per frame; 2: always; 0: never): launch A also scores the frame against the descriptors of the frame before (whose new words are not rows
                                      // yet), the re-rank keeps the words' scores under its threshold: no workgroup stages or scans the new rows (launch B 19.6 -> 15.4 us)
     int mirror_from_b = 1;           // "mirror_from_b": the pinned row-count mirror of an appending frame is stored by launch B instead of by the decision loop (launch A -0.3 us)
+    int slots_from_rows = 1;         // "slots_from_rows": the decision loop leaves the ROW of the word a descriptor matched; the registration (one launch later, in the round
+                                     // trip that fetches the retired signature's words anyway) looks the postings key up.  0: the decision loop gathers the keys itself
     int row_writer_wgs = 16;         // "row_writer_wgs": > 0 = that many extra workgroups of launch B's re-rank role write the appended rows (launch B -0.9 us
                                      // without the shadow scores; with them nobody else could); 0: the re-rank workgroups write them at the end of their own chains
 };

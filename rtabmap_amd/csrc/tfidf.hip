@@ -97,7 +97,7 @@ __global__ __launch_bounds__(BR_BLOCK) void bulk_register_kernel(const int32_t* 
     a.coo_w = const_cast<uint32_t*>(tab[b].coo_w); a.coo_pc = const_cast<uint32_t*>(tab[b].coo_pc); a.ne_counter = bkt_ne + b;
     a.slot_sig = slot_sig; a.slot_ni = slot_ni; a.slot_begin = slot_begin; a.slot_cnt = slot_cnt;
     a.q_w = nullptr; a.q_idf = nullptr; a.q_did = nullptr; a.qd_did = nullptr; a.qd_idf = nullptr; a.q_meta = nullptr; a.idf_tab = nullptr;
-    a.wrow = nullptr;
+    a.wrow = nullptr; a.row_wslot = nullptr;
     frame_words_body<BR_BLOCK, false>(br_dyn_smem, a);
 }
 
@@ -961,6 +961,7 @@ static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool id
     a.qd_idf = t.qd_idf.as<int32_t>(); a.q_meta = t.q_meta.as<uint32_t>(); a.idf_tab = t.idf_tab.as<uint2>();
     a.new_ws = new_ws ? *new_ws : WsRuns();
     a.wrow = t.wrow.as<uint32_t>();
+    a.row_wslot = nullptr;
     if (defer && !resolve) {                                            // registration alone, launched inside a later filter launch
         defer->a = a; defer->ret = ret; defer->shmem = shmem;
         t.q_n_ub = n;
@@ -971,7 +972,7 @@ static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool id
         const int mw = (resolve->q + 63) / 64 * 2;
         shmem = std::max(shmem, (size_t)(3 * mw + 2) * 4) + (size_t)n * 8;    // + the word slots handed over in LDS + the appender's list
         const int block = defer ? pipe_block_size() : FW_BLOCK;
-        const int n_redo = (resolve->rp.enabled && resolve->fail_count) ? (resolve->rp.n_rows + block - 1) / block : 0;
+        const int n_redo = (resolve->rp.enabled && resolve->fail_count) ? std::min((resolve->rp.n_rows + block - 1) / block, defer ? REDO_WGS_MAX : (1 << 30)) : 0;
         if (defer) {                                                    // launched later, inside the next frame's filter launch
             defer->r = *resolve; defer->a = a; defer->ret = ret; defer->n_redo = n_redo; defer->shmem = shmem;
             t.q_n_ub = n;
@@ -1018,7 +1019,7 @@ hipError_t Tfidf::query_dev(const int32_t* d_wslots, int n, float N, const Resol
 void resolve_launch_info(const ResolveArgs& r, int block, int* n_redo, size_t* shmem) {
     const int mw = (r.q + 63) / 64 * 2;
     *shmem = (size_t)(3 * mw + 4) * 4 + (size_t)r.q * 4;               // + the appender's list of word-creating descriptors
-    *n_redo = (r.rp.enabled && r.fail_count) ? (r.rp.n_rows + block - 1) / block : 0;
+    *n_redo = (r.rp.enabled && r.fail_count) ? std::min((r.rp.n_rows + block - 1) / block, REDO_WGS_MAX) : 0;
 }
 
 hipError_t Tfidf::register_bulk(int n_sigs, const int32_t* sig_ids, const int64_t* offsets, const int32_t* ni, const int32_t* d_ids,

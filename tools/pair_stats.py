@@ -38,7 +38,7 @@ def main():
     span = us(reg[-1][1] - reg[0][0])
     gaps = [us(reg[i][0] - reg[i - 1][1]) for i in range(1, len(reg))]
     lead = gaps[0] if gaps else 0.0
-    a_full = [us(e - s) for s, e, k, g in reg if k == "A" and g >= 100000]
+    a_full = [us(e - s) for s, e, k, g in reg if k == "A" and g >= 60000]
     b_full = [us(e - s) for s, e, k, g in reg if k == "B" and g >= 300000]
     b_grow = [d for d in b_full if d >= 17.0]
     b_rev = [d for d in b_full if d < 17.0]
