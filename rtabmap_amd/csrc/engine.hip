@@ -1415,7 +1415,8 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
         }
     }
     lap.lap(4);
-    const bool prof = f_knn && h->prof_cap > 0 && h->prof_n < h->prof_cap;
+    bool prof = f_knn && h->prof_cap > 0 && h->prof_n < h->prof_cap;
+    if (prof && h->prof_skip > 0) { h->prof_skip -= 1; prof = false; }     // ("profile_skip": not the first launches behind an idle queue)
     h->popt.f16 = h->f16();
     if (h->roctx_push) h->roctx_push("lcd:launch_A");
     const hipError_t ea__ = launch_frame_a(f_knn ? &k : nullptr, qs, f_res ? &tl_res : nullptr, f_reg ? &tl_reg : nullptr, h->stream,
@@ -2101,6 +2102,7 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     if (!std::strcmp(key, "filter_delay") && value >= 0 && value <= 127) { h->popt.filter_delay = (int)value; return LCD_OK; }
     if (!std::strcmp(key, "shadow_rows") && value >= -1 && value <= 2) { h->popt.shadow_rows = value < 0 ? 1 : (int)value; return LCD_OK; }   // (-1: built-in = 1)
     if (!std::strcmp(key, "mirror_from_b") && value >= -1 && value <= 1) { h->popt.mirror_from_b = value != 0 ? 1 : 0; return LCD_OK; }
+    if (!std::strcmp(key, "profile_skip") && value >= 0 && value <= (1 << 20)) { h->prof_skip = (int)value; return LCD_OK; }
     if (!std::strcmp(key, "slots_from_rows") && value >= -1 && value <= 1) { h->popt.slots_from_rows = value >= 0 ? (int)value : PipeOpts().slots_from_rows; return LCD_OK; }
     if (!std::strcmp(key, "row_writer_wgs") && value >= -1 && value <= 256) { h->popt.row_writer_wgs = value >= 0 ? (int)value : PipeOpts().row_writer_wgs; return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");
