@@ -1593,7 +1593,10 @@ def main():
         log_frames = (args.warmup + args.steps) if (world == 1 and not args.no_cpu_baseline and args.warmup + args.steps <= 4096) else 0
         step = Stepper(eng, torch, d_frames, n_sig, cap, log_frames=log_frames)
         eng.set_option("profile_likelihood", 0)           # the timed region brackets launch A only (the dominant kernel)
-        eng.set_option("profile_skip", args.steps // 2 if args.steps >= 10 else 0)   # ... of the steps in the middle of the region, not of the first launches behind an idle queue
+        try:
+            eng.set_option("profile_skip", args.steps // 2 if args.steps >= 10 else 0)   # ... of the steps in the middle of the region, not of the first launches behind an idle queue
+        except Exception:                                 # (an older variant library of an A/B run: it samples the first launches)
+            pass
         res = timed_loop(torch, dist, world, stream, step, args.steps, args.warmup, profile_eng=eng, eng=eng, per_step_events=False)
         knn_series = eng.profile_read()
         st = eng.stats()                                  # (drains the engine's thread)

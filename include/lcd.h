@@ -366,7 +366,7 @@ int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, co
  * of an operand table, and the matrix-core filter of the NEXT frame ranks them beside the vocabulary (its re-rank keeps the ones that became words)
  * instead of every re-rank workgroup staging the new rows and scanning them (0).  "mirror_from_b": 1 (built-in) = the pinned row-count mirror of an appending
  * frame is stored by a workgroup of launch B instead of at the end of the decision loop's chain in launch A.  "row_writer_wgs": the rows a
- * frame appends are written by that many extra workgroups of launch B's re-rank role (built-in 16; 0 = by the re-rank workgroups themselves; 0 .. 256).  "slots_from_rows": 1 (built-in) = the decision loop of a
+ * frame appends are written by that many extra workgroups of launch B's re-rank role (built-in 16; 0 = by the re-rank workgroups themselves; 0 .. 256).  "slots_from_rows": 1 (built-in: while the stream creates 16 words per frame or more; 2 = always) = the decision loop of a
  * pipelined frame hands the registration the vocabulary ROW of every matched word and the registration looks the postings key up (in the
  * round trip that fetches the retired signature's words); 0 = the decision loop gathers the keys itself.  "score_block": threads per workgroup of the scoring kernel
  * (256 / 512 / 1024).  "filter_units": compute units the bf16 filter plans its persistent workgroups for when the vocabulary has

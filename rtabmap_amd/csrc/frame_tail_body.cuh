@@ -518,6 +518,47 @@ __device__ __forceinline__ void frame_resolve_part(uint32_t* ft_dyn_smem, const 
     } else append_pass_on(r.ap);
     FT_STAMP(1);
 }
+// The registration of a frame whose word slots are postings KEYS already (FwArgs::row_wslot == NULL: revisit phases of a pipelined stream, and every
+// other caller): the word slots go to LDS after ONE round trip and the table phases of frame_words_body run while the retirement's reads
+// and atomics are in flight.  (Round 6 measured both heads in both regimes, r06_ab_notes.txt 10: the two-round-trip head below wins while frames
+// create words -- its second trip carries the keys the decision loop no longer gathers -- and loses 0.4-0.5 us of launch A once they only revisit.)
+template <int NT>
+__device__ __forceinline__ void frame_register_part_keys(uint32_t* ft_dyn_smem, const FwArgs& a, const RetireArgs& retire) {
+    uint32_t ne0 = 0u;
+    const bool have_ne0 = a.do_register && a.ne_counter != nullptr;
+    if (threadIdx.x == 0 && have_ne0) ne0 = gload(a.ne_counter);
+    // The frame's word slots (written by the decision loop one launch earlier) are requested HERE, in front of the retirement's reads:
+    // they arrive with them (one in-order counter), are parked in LDS, and the table phases of frame_words_body then run on LDS alone
+    // while the retirement's atomics are acknowledged -- instead of a barrier that waits for those acknowledgements and a round trip
+    // for the word slots behind it.  (The barrier in front of frame_words_body's second pass still orders the reference counts.)
+    constexpr int KS = 4;
+    const bool pre = a.n <= KS * NT && a.xlate == nullptr && a.src != nullptr;
+    int32_t ws_pre[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        const int i = (int)threadIdx.x + k * NT;
+        ws_pre[k] = (pre && i < a.n) ? gload(a.src + i) : -1;
+    }
+    FT_STAMP(4);
+    retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
+    if (!pre) {
+        __syncthreads();
+        FT_STAMP(5);
+        frame_words_body<NT, true>(ft_dyn_smem, a, nullptr, have_ne0, ne0);
+    } else {
+        int32_t* lds_ws = (int32_t*)(ft_dyn_smem + 2 * a.H + a.H / 64 + 8);      // behind the tables (as in frame_tail_body)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const int i = (int)threadIdx.x + k * NT;
+            if (i < a.n) lds_ws[i] = ws_pre[k];                           // read back by the same thread
+        }
+        FT_STAMP(5);
+        frame_words_body<NT, true>(ft_dyn_smem, a, lds_ws, have_ne0, ne0);
+    }
+    FT_STAMP(6);
+}
+
+
 template <int NT>
 __device__ __forceinline__ void frame_register_part(uint32_t* ft_dyn_smem, const FwArgs& a, const RetireArgs& retire) {
     // Everything this chain reads first -- the log position of the open bucket, the frame's word slots (written by the decision loop one
@@ -525,6 +566,7 @@ __device__ __forceinline__ void frame_register_part(uint32_t* ft_dyn_smem, const
     // condition, at a clamped address of an array that is always there, the values selected afterwards.  A request under a condition whose
     // result is merged with a default makes the compiler copy registers right behind the request, i.e. wait for it -- round 6's ISA had
     // eight round trips in a row here (ne0, four word slots, begin, cnt, the words).
+    if (!a.row_wslot) { frame_register_part_keys<NT>(ft_dyn_smem, a, retire); return; }
     constexpr int KS = 4;
     const bool have_ne0 = a.do_register && a.ne_counter != nullptr;
     const bool pre = a.n <= KS * NT && a.xlate == nullptr && a.src != nullptr;

@@ -40,20 +40,16 @@ __device__ __forceinline__ void score_segments(const uint32_t* __restrict__ sp_e
         uint32_t e[2]; int32_t f[2]; bool ok[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            // (a posting beyond the wave's total reads the LAST one and drops it: a request under a condition, merged with a default, is awaited
-            // right behind its issue -- the two requests of a trip then take two round trips; round 6's ISA)
-            const uint32_t t_raw = t0 + (uint32_t)(u * 64 + ln);
-            const uint32_t t = min(t_raw, Tw - 1u);
+            const uint32_t t = t0 + (uint32_t)(u * 64 + ln);
             int pos = 0;                                            // number of lanes whose inclusive sum is <= t = the owner of posting t
 #pragma unroll
             for (int step = 32; step >= 1; step >>= 1) { const uint32_t v = __shfl(incl, pos + step - 1, 64); if (v <= t) pos += step; }
             if (pos > 63) pos = 63;
             const uint32_t i_o = __shfl(incl, pos, 64), l_o = __shfl(len, pos, 64), s_o = __shfl(start, pos, 64);
             f[u] = __shfl(idf, pos, 64);
-            ok[u] = t_raw < Tw;
-            e[u] = gload(sp_ent + s_o + (t - (i_o - l_o)));
+            ok[u] = t < Tw;
+            e[u] = ok[u] ? gload(sp_ent + s_o + (t - (i_o - l_o))) : 0u;
         }
-        asm volatile("" : "+v"(e[0]), "+v"(e[1]));
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (!ok[u]) continue;
@@ -85,8 +81,7 @@ __device__ __forceinline__ void score_sealed_body(const ScoreArgs& A, int b) {
     constexpr int KW = SCB >= 512 ? 1 : 512 / SCB;                  // frame words per thread in the fused first pass
     constexpr int NI = TF_R / SCB > 0 ? TF_R / SCB : 1;             // signatures whose ni a thread carries
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
-    const uint32_t D_raw = A.bkt_D[b];                                // (read whatever the state says: under the condition it is a round trip BEHIND the bucket record's)
-    const uint32_t D = live ? D_raw : 0u;
+    const uint32_t D = live ? A.bkt_D[b] : 0u;
     const uint32_t BW = live ? B.W : 0u;
     const uint32_t flags = A.bkt_flags[b];
     const int U = (int)A.q_meta[0];
@@ -121,27 +116,15 @@ __device__ __forceinline__ void score_sealed_body(const ScoreArgs& A, int b) {
     for (int u = 0; u < KW; ++u) {
         const bool dense_here = did[u] >= 0 && (uint32_t)did[u] < D;
         look[u] = idf[u] != 0 && w[u] < BW && (!dense_here || (flags & 1u));   // a dense word has sparse postings only for counts > 255
-        // (requested whether or not the word is looked up -- every word of the frame has a record in the word-major directory, and a masked list
-        // entry reads word 0's --: the dense rows below are then requested in the SAME round trip instead of behind this one's wait)
-        const uint4* rec = reinterpret_cast<const uint4*>(A.dir2 + ((size_t)(w[u] >> 5) * A.dir2_stride + (uint32_t)b) * TF_DIR2_DWORDS);
-        r0[u] = gload4(rec); r1[u] = gload4(rec + 1);
+        r0[u] = make_uint4(0u, 0u, 0u, 0u); r1[u] = r0[u];
+        if (look[u]) {
+            const uint4* rec = reinterpret_cast<const uint4*>(A.dir2 + ((size_t)(w[u] >> 5) * A.dir2_stride + (uint32_t)b) * TF_DIR2_DWORDS);
+            r0[u] = gload4(rec); r1[u] = gload4(rec + 1);
+        }
     }
     uint32_t c[DR];
-    {
-        // dense rows: a row that is not there reads row 0 (or, in a bucket without dense rows, the frame's word list) and drops it
-        const uint32_t* dbase = D > 0u ? reinterpret_cast<const uint32_t*>(B.dense) : A.q_w;
 #pragma unroll
-        for (int u = 0; u < DR; ++u) {
-            const bool ok = dj[u] >= 0 && (uint32_t)dj[u] < D;
-            c[u] = gload(dbase + (ok ? (size_t)dj[u] * (TF_R / 4) : (size_t)0) + ln);
-        }
-#pragma unroll
-        for (int u = 0; u < DR; ++u) asm volatile("" : "+v"(c[u]));
-#pragma unroll
-        for (int u = 0; u < DR; ++u) { if (!(dj[u] >= 0 && (uint32_t)dj[u] < D)) c[u] = 0u; }
-    }
-#pragma unroll
-    for (int u = 0; u < KW; ++u) { if (!look[u]) { r0[u] = make_uint4(0u, 0u, 0u, 0u); r1[u] = r0[u]; } }
+    for (int u = 0; u < DR; ++u) c[u] = (dj[u] >= 0 && (uint32_t)dj[u] < D) ? gload((const uint32_t*)(B.dense + (size_t)dj[u] * TF_R + 4 * ln)) : 0u;
     // ---- stage C: start and length of the words' posting segments, from the record alone (a block with a count that does not
     //      fit its 5-bit field goes through the per-bucket directory: a dependent lookup, rare)
     uint32_t start[KW], len[KW];

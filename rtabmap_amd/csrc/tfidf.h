@@ -220,7 +220,10 @@ size_t knn_qsplit_bytes(int q);
 int pipe_block_size();      // workgroup size of launch A (the filter's)
 int pipe_b_block_size();    // workgroup size of launch B (re-rank + scoring)
 // exact-redo helper workgroups of a fused frame launch (they leave at once when nothing was rejected; rowpar_body walks the rows in chunks)
-constexpr int REDO_WGS_MAX = 32;
+#ifndef LCD_REDO_WGS_MAX      // (timing experiments: tools/build_variant.py <name> -DLCD_REDO_WGS_MAX=<n>)
+#define LCD_REDO_WGS_MAX 32
+#endif
+constexpr int REDO_WGS_MAX = LCD_REDO_WGS_MAX;
 void resolve_launch_info(const ResolveArgs& r, int block, int* n_redo, size_t* shmem);
 // filter of the newest frame + the decision loop of one earlier frame (resolve: r / n_redo / shmem_resolve of that TailLaunch) + the
 // registration of a still earlier one (reg: a / ret / shmem); either may be NULL
@@ -237,8 +240,9 @@ struct PipeOpts {
     int shadow_rows = 1;             // "shadow_rows" (1: while the stream creates >= 16 words per frame; 2: always; 0: never): launch A also scores the frame against the descriptors of the frame before (whose new words are not rows
                                      // yet), the re-rank keeps the words' scores under its threshold: no workgroup stages or scans the new rows (launch B 19.6 -> 15.4 us)
     int mirror_from_b = 1;           // "mirror_from_b": the pinned row-count mirror of an appending frame is stored by launch B instead of by the decision loop (launch A -0.3 us)
-    int slots_from_rows = 1;         // "slots_from_rows": the decision loop leaves the ROW of the word a descriptor matched; the registration (one launch later, in the round
-                                     // trip that fetches the retired signature's words anyway) looks the postings key up.  0: the decision loop gathers the keys itself
+    int slots_from_rows = 1;         // "slots_from_rows" (1: while the stream creates >= 16 words per frame; 2: always; 0: never): the decision loop leaves the ROW of the word a
+                                     // descriptor matched; the registration (one launch later, in the round trip that fetches the retired signature's words anyway) looks the
+                                     // postings key up.  0: the decision loop gathers the keys itself
     int row_writer_wgs = 16;         // "row_writer_wgs": > 0 = that many extra workgroups of launch B's re-rank role write the appended rows (launch B -0.9 us
                                      // without the shadow scores; with them nobody else could); 0: the re-rank workgroups write them at the end of their own chains
 };

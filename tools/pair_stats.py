@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """What the driver's timed region is made of, from a rocprofv3 --kernel-trace CSV of `bench.py --steps K --warmup W --no-cpu-baseline --no-extras --no-pmc`:
-    python tools/pair_stats.py <kernel_trace.csv> [label]
+    python tools/pair_stats.py <kernel_trace.csv> [label] [--dump]      (--dump: also every launch of the region: start, duration, gap in front, grid)
 The fused launches (frame_a_kernel*, frame_b_kernel*) are split into runs at gaps > 60 us; the TIMED region is the first run of at least
 2 K + 4 launches (the warm-up's run is shorter, the per-step-event leg behind it has a gap in front of every launch).  Printed (us):
   span      first launch start -> last launch end of the timed region (the wall clock adds the enqueue latency in front of the first launch)
@@ -29,6 +29,9 @@ def main():
         cur.append(r)
     if cur:
         runs.append(cur)
+    dump = "--dump" in sys.argv
+    if dump:
+        sys.argv.remove("--dump")
     label = sys.argv[2] if len(sys.argv) > 2 else ""
     big = [x for x in runs if len(x) >= 40]
     if not big:
@@ -46,6 +49,11 @@ def main():
     print("%-26s span %7.1f  lead %5.1f  other-gaps %5.1f  launches %d | A %s | B %s  growth %s  revisit %s | drain %s" % (
         label, span, lead, sum(gaps[1:]), len(reg), f(a_full), f(b_full), f(b_grow), f(b_rev),
         " ".join("%s%.1f" % (k, us(e - s)) for s, e, k, g in reg[-6:])))
+    if dump:
+        print("# the launches of the timed region: start (us after the first), duration, gap in front, kind, grid (threads)")
+        for i, (s, e, k, g) in enumerate(reg):
+            print("%9.2f  dur %6.2f  gap %6.2f  %s  grid %7d%s" % (us(s - reg[0][0]), us(e - s), gaps[i - 1] if i else 0.0, k, g,
+                                                              "   <- drain" if i >= len(reg) - 6 else ""))
 
 
 if __name__ == "__main__":

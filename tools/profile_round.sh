@@ -40,8 +40,10 @@ cd /tmp
 # 2. kernel trace + stats
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $BENCH > $O/kt_bench.json 2> $O/kt.err
 kstats $O/kt $O/${TAG}_bench_kernel_trace.txt
-# the launch timeline of the same run (start, duration, gap to the previous kernel): 80 kernels from the middle of the timed region
-python $ROOT/tools/timeline_dump.py $(find $O/kt -name '*kernel_trace.csv' | head -1) 900 80 > $O/${TAG}_dispatch_timeline.txt 2>&1
+# the launch timeline of the DRIVER's command (20 steps + the drain): every fused launch of its timed region
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/kt20 -o kt -- python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-pmc > /dev/null 2> $O/kt20.err
+python $ROOT/tools/pair_stats.py $(find $O/kt20 -name '*kernel_trace.csv' | head -1) "driver's command" --dump > $O/${TAG}_dispatch_timeline.txt 2>&1
+rm -rf $O/kt20
 # 3. HBM traffic: one counter per pass
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o pmc -- $BENCH > /dev/null 2> $O/pmc_$c.err
