@@ -1380,6 +1380,7 @@ static int pipeline_launch(lcd_engine* h, const QSplitArgs* qs) {
         // revisit, the decision loop is short and the registration is what ends launch A: 13.8 -> 14.5 us in the revisit phase with the rows always on, r06_ab_notes.txt 10)
         f_res->slots_are_rows = h->popt.slots_from_rows && (h->popt.slots_from_rows >= 2 || h->est_new >= 16.0) && tl_res.r.row_wslot && tl_res.r.knn_row && tl_res.r.q <= 1024;
         if (f_res->slots_are_rows) { tl_res.r.row_wslot = nullptr; tl_res.r.slots_are_rows = 1; }
+        tl_res.r.straight = (h->popt.decision_straight >= 2 || (h->popt.decision_straight == 1 && h->est_new >= 16.0)) ? 1 : 0;
         if (f_res->chained) fill_append(h, f_res->a, f_res->vseq, frame_appends(h, f_res->a), &tl_res.r, h->ring[f_res->set].d_applist.as<uint32_t>());
         // the pinned row-count mirror is a store to HOST memory, waited for at the end of the decision loop's chain: with "mirror_from_b" a
         // workgroup of launch B of this pair (which writes the frame's rows anyway) stores it instead
@@ -2105,6 +2106,7 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     if (!std::strcmp(key, "shadow_rows") && value >= -1 && value <= 2) { h->popt.shadow_rows = value < 0 ? 1 : (int)value; return LCD_OK; }   // (-1: built-in = 1)
     if (!std::strcmp(key, "mirror_from_b") && value >= -1 && value <= 1) { h->popt.mirror_from_b = value != 0 ? 1 : 0; return LCD_OK; }
     if (!std::strcmp(key, "profile_skip") && value >= 0 && value <= (1 << 20)) { h->prof_skip = (int)value; return LCD_OK; }
+    if (!std::strcmp(key, "decision_straight") && value >= -1 && value <= 2) { h->popt.decision_straight = value >= 0 ? (int)value : PipeOpts().decision_straight; return LCD_OK; }
     if (!std::strcmp(key, "slots_from_rows") && value >= -1 && value <= 2) { h->popt.slots_from_rows = value >= 0 ? (int)value : PipeOpts().slots_from_rows; return LCD_OK; }
     if (!std::strcmp(key, "row_writer_wgs") && value >= -1 && value <= 256) { h->popt.row_writer_wgs = value >= 0 ? (int)value : PipeOpts().row_writer_wgs; return LCD_OK; }
     return h->fail(LCD_ERR_INVALID, "lcd_set_option: unknown key or value");

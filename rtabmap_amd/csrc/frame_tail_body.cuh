@@ -503,7 +503,7 @@ __device__ __forceinline__ void frame_resolve_part(uint32_t* ft_dyn_smem, const 
     const uint32_t* fmask;
     if (fast) fmask = resolve_body_fast<NT, KPT>(ft_dyn_smem, nullptr, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist,
                                                  r.ld, r.cand_bits, r.bw, r.out_word, r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws,
-                                                 r.cand_list, r.cand_cnt, &n_in_early, cnt_in, helpers ? r.fail_count : nullptr, r.slots_are_rows != 0);
+                                                 r.cand_list, r.cand_cnt, &n_in_early, cnt_in, helpers ? r.fail_count : nullptr, r.slots_are_rows != 0, r.straight != 0);
     else { asm volatile("" : "+v"(n_in_early)); fmask = resolve_body<NT>(ft_dyn_smem, r.q, r.flags, r.nndr, r.have_index, r.knn_word, r.knn_dist, r.selfdist, r.ld, r.cand_bits, r.bw, r.out_word,
                                   r.out_n_new, r.knn_row, r.row_wslot, r.out_wslot, r.new_ws, r.slots_are_rows != 0); }   // (both paths leave n_in_early awaited: the
                                                                         // compiler's wait in front of its use would otherwise cover the loop's stores)

@@ -96,7 +96,7 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
                                                   int32_t* __restrict__ out_wslot, const WsRuns& new_ws,
                                                   const uint2* __restrict__ cand_list = nullptr, const int32_t* __restrict__ cand_cnt = nullptr,
                                                   int* keep_in_reg = nullptr, const int32_t* early_ptr = nullptr, int32_t* helpers_fail = nullptr,
-                                                  bool slots_are_rows = false) {
+                                                  bool slots_are_rows = false, bool straight_ok = true) {
     const int mw = (q + 63) / 64 * 2;
     uint32_t* mask_cur = rs_smem;
     uint32_t* mask_next = rs_smem + mw;
@@ -129,7 +129,7 @@ __device__ __forceinline__ const uint32_t* resolve_body_fast(uint32_t* rs_smem, 
     // in a row where the source says one (stamps: 5.1 us from the entry to the reject mask; one round trip is ~2.5 us in that launch).
     // A bit row is read as four 16-byte pieces whatever its length: the bytes behind a short row are the next rows and, behind the last
     // row, the compact lists of the same buffer (cand_bits_layout) -- checked here -- and words >= bw are cleared below.
-    const bool straight = have_index && (out_wslot || lds_wslot) && together && cand_cnt && cand_list && bw >= 2 && bw <= 16 && q >= 8 &&
+    const bool straight = straight_ok && have_index && (out_wslot || lds_wslot) && together && cand_cnt && cand_list && bw >= 2 && bw <= 16 && q >= 8 &&
                           reinterpret_cast<const uint32_t*>(cand_list) == cand_bits + (size_t)q * bw;
     // early_ptr: a word the caller wants in *keep_in_reg (the appender's row count), requested BEHIND the round trip's requests: in front
     // of them the compiler's wait for it (the straight block reuses registers the other block loads into) was a round trip of its own.

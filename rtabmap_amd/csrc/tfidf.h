@@ -141,6 +141,7 @@ struct ResolveArgs {
     const int32_t* knn_word; const float* knn_dist; const float* selfdist; int ld; const uint32_t* cand_bits; int bw;
     int32_t* out_word; int32_t* out_n_new; const int32_t* knn_row; const int32_t* row_wslot; int32_t* out_wslot;
     const uint2* cand_list; const int32_t* cand_cnt;   // CandBits::list / cnt (NULL: only the bit rows exist)
+    int straight = 0;          // 1: the decision loop's first round trip as ONE straight line of unconditional requests (resolve_body_fast; PipeOpts::decision_straight)
     int slots_are_rows = 0;    // 1 (with row_wslot == NULL): out_wslot gets the vocabulary ROW of a matched word (>= 0; FwArgs::row_wslot translates it one
                            // launch later) and -(key + 2) for a word the frame creates (its key comes from new_ws here and is no row)
     WsRuns new_ws;         // postings keys of the frame's new words (n == 0: new words get no postings)
@@ -243,6 +244,9 @@ struct PipeOpts {
     int slots_from_rows = 1;         // "slots_from_rows" (1: while the stream creates >= 16 words per frame; 2: always; 0: never): the decision loop leaves the ROW of the word a
                                      // descriptor matched; the registration (one launch later, in the round trip that fetches the retired signature's words anyway) looks the
                                      // postings key up.  0: the decision loop gathers the keys itself
+    int decision_straight = 1;       // "decision_straight" (1: while the stream creates >= 16 words per frame; 2: always; 0: never): the decision loop requests everything its first round trip
+                                     // reads unconditionally, in one straight line, the helpers' counter and the appender's row count with it (launch A 13.6 -> 12.6 us while frames
+                                     // create words; once they only revisit the launch is 0.4-0.5 us LONGER that way, r06_ab_notes.txt 10)
     int row_writer_wgs = 16;         // "row_writer_wgs": > 0 = that many extra workgroups of launch B's re-rank role write the appended rows (launch B -0.9 us
                                      // without the shadow scores; with them nobody else could); 0: the re-rank workgroups write them at the end of their own chains
 };
