@@ -180,7 +180,7 @@ class BayesStepper(Stepper):
         self.one_id[0] = sid + 1
 
 
-def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None, eng=None, per_step_events=True):
+def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None, eng=None, per_step_events=True, prof_n=0):
     """warmup untimed steps, then exactly `steps` steps bracketed by barrier + synchronize; an event per step for the distribution.
     eng: the engine the steps run on -- its events are recorded in call order (lcd_record_event: a threaded handle enqueues the index
     stage of a frame after lcd_frame_dev returned) and it is drained (lcd_synchronize) before the clock stops."""
@@ -199,9 +199,10 @@ def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None
     rec = (lambda e: eng.record_event(e.cuda_event)) if eng is not None else (lambda e: e.record(stream))
     mid = rec if per_step_events else (lambda e: None)          # an event per step costs a few microseconds of stream time each
     if profile_eng is not None:
-        # HIP events around the dominant launch of the first timed steps (a tenth of them, at least 3): an event pair costs the stream
-        # ~10 us, so the timed region brackets ONE launch per sampled frame; the other big kernel is bracketed in an untimed leg
-        profile_eng.profile_begin(int(os.environ.get("LCD_BENCH_PROF_N", max(3, steps // 10))))
+        # HIP events around the dominant launch of some timed steps (prof_n of them; default a tenth, at least 3): a bracketed launch costs the
+        # stream ~12 us of gaps (6-7 in front of it, 5-6 behind it: profiles/r06_dispatch_timeline.txt), so the timed region brackets ONE launch per
+        # sampled frame -- the headline one in twenty frames -- and the other samples / the other big kernel are taken in the steps right behind it
+        profile_eng.profile_begin(int(os.environ.get("LCD_BENCH_PROF_N", prof_n if prof_n else max(3, steps // 10))))
     t0 = time.perf_counter()
     rec(evs[0])
     for i in range(steps):
@@ -305,10 +306,17 @@ def pmc_traffic(name):
         return None
 
 
-def rooflines(eng, n_rows_rank, n_sig, shard, knn=None):
-    """Both big kernels, from the HIP events the engine recorded around their launches (knn: the 2-NN series read earlier)."""
+def rooflines(eng, n_rows_rank, n_sig, shard, knn=None, knn_timed=None):
+    """Both big kernels, from the HIP events the engine recorded around their launches (knn: the 2-NN series read earlier; knn_timed: the
+    samples taken INSIDE the timed region, averaged with the series the engine holds now -- every bracketed launch costs the stream ~12 us
+    of gaps (profiles/r06_dispatch_timeline.txt), so the timed region carries few of them and the steps right behind it the rest)."""
     sc_ms, sc_n, sc_name = eng.profile_read_likelihood()
     kern_ms, kern_n, kern_name = eng.profile_read() if knn is None else knn
+    if knn_timed is not None and knn_timed[1] > 0:
+        t_ms, t_n, t_name = knn_timed
+        kern_ms = (kern_ms * kern_n + t_ms * t_n) / (kern_n + t_n)
+        kern_n += t_n
+        kern_name = kern_name or t_name
     flops = 2.0 * Q * n_rows_rank * DIM           # ALGORITHMIC work per launch (SURVEY.md 8d): GEMM-equivalent 2*Q*N*D
     achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
     f16 = "fp16" in kern_name
@@ -1597,7 +1605,7 @@ def main():
             eng.set_option("profile_skip", args.steps // 2 if args.steps >= 10 else 0)   # ... of the steps in the middle of the region, not of the first launches behind an idle queue
         except Exception:                                 # (an older variant library of an A/B run: it samples the first launches)
             pass
-        res = timed_loop(torch, dist, world, stream, step, args.steps, args.warmup, profile_eng=eng, eng=eng, per_step_events=False)
+        res = timed_loop(torch, dist, world, stream, step, args.steps, args.warmup, profile_eng=eng, eng=eng, per_step_events=False, prof_n=max(1, args.steps // 20))
         knn_series = eng.profile_read()
         st = eng.stats()                                  # (drains the engine's thread)
         like = step.d_like[: n_sig + args.steps + args.warmup].cpu().numpy()
@@ -1605,7 +1613,9 @@ def main():
         eng.profile_begin(10)
         for i in range(24):
             step(args.warmup + args.steps + i)
-        roof_knn, roof_score = rooflines(eng, N_WORDS, n_sig, False, knn=knn_series)
+        roof_knn, roof_score = rooflines(eng, N_WORDS, n_sig, False, knn_timed=knn_series)
+        roof_knn["measured_in"] = ("%d launch(es) of the timed region (steps from its middle on) + %d of the 24 steps right behind it (HIP events attached to the dispatch); "
+                                   "in the timed region alone: %.4f ms" % (knn_series[1], roof_knn["samples"] - knn_series[1], knn_series[0]))
         if roof_score:
             roof_score["measured_in"] = "24 steps after the timed region (HIP events around launch B of 10 of them)"
         frames_total = world * args.steps
