@@ -371,8 +371,7 @@ int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, co
  * round trip that fetches the retired signature's words); 0 = the decision loop gathers the keys itself.  "score_block": threads per workgroup of the scoring kernel
  * (256 / 512 / 1024).  "filter_units": compute units the bf16 filter plans its persistent workgroups for when the vocabulary has
  * more 256-word strips than that (-1 built-in, 0 never persistent).  "decision_straight": 1 (built-in: while the stream creates 16 words per frame or more; 2 = always; 0 = never) = the decision loop of a pipelined frame requests
- * everything its first round trip reads unconditionally, in one straight line (faster while frames create words, slower once they only revisit: DESIGN.md 4d).  "spin_wait_us": how long a synchronising call polls the stream before it parks the thread in hipStreamSynchronize (built-in 400; 0 = never: being woken costs 10-20 us,
- * more than most of what this engine waits for).  "profile_skip": the number of launches of a pipelined handle that lcd_profile_begin lets pass before it brackets one (0; the first launches behind an idle
+ * everything its first round trip reads unconditionally, in one straight line (faster while frames create words, slower once they only revisit: DESIGN.md 4d).  "profile_skip": the number of launches of a pipelined handle that lcd_profile_begin lets pass before it brackets one (0; the first launches behind an idle
  * queue are not the steady state).  "profile_likelihood": 0 = lcd_profile_begin brackets only the
  * 2-NN launch of a pipelined frame (every timed launch costs stream time).  "strip_tiles": 32-word tiles per filter workgroup of a
  * pipelined frame (1 .. 8; 0 = the built-in plan).  "append_split_buckets": sealed buckets of 256 signatures from which

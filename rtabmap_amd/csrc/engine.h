@@ -144,7 +144,6 @@ struct lcd_engine {
     // ---- event bracketing of the dominant kernel (lcd_profile_*)
     std::vector<hipEvent_t> prof_ev, prof2_ev;          // 2-NN scan kernel / fused likelihood kernel
     int prof_n = 0, prof_cap = 0, prof2_n = 0;
-    int spin_wait_us = 400;                             // "spin_wait_us": sync_all polls the stream that long before it parks the thread in hipStreamSynchronize
     int prof_skip = 0;                                  // "profile_skip": pipelined launches lcd_profile_begin lets pass before it samples
     bool prof_likelihood = true;                        // lcd_set_option("profile_likelihood"): also bracket launch B of a pipelined frame
     const char* prof_kernel = "";

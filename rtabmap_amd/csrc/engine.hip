@@ -70,17 +70,6 @@ static int drain_keep_rows_lazy(lcd_engine* h) {
 }
 
 int lcd_engine::sync_all() {
-    // a bounded busy wait first: hipStreamSynchronize parks the thread, and being woken costs more than most of what this engine waits for
-    // (a drain is ~80 us of launches, lcd_frame_host's frame ~100 us); past spin_wait_us the thread is parked as before ("spin_wait_us", 0 = never spin)
-    if (spin_wait_us > 0) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
-            const hipError_t q = hipStreamQuery(stream);
-            if (q == hipSuccess) return LCD_OK;
-            if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery(stream)");
-            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_wait_us) break;
-        }
-    }
     hipError_t e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(stream)");
     return LCD_OK;
@@ -1636,7 +1625,7 @@ int lcd_frame_host(lcd_engine* h, const lcd_frame_host_args* a) {
     LCD_HIP_B(h, h->h_frame_out.reserve(wbytes + lbytes + 16));
     LCD_HIP_B(h, hipMemcpyAsync(h->h_frame_out.p, h->d_frame_words.p, wbytes, hipMemcpyDeviceToHost, h->stream));
     if (lbytes) LCD_HIP_B(h, hipMemcpyAsync((char*)h->h_frame_out.p + wbytes, h->d_frame_like.p, lbytes, hipMemcpyDeviceToHost, h->stream));
-    { int rc = h->sync_all(); if (rc) return rc; }                      // (polls first: the wake-up of a parked thread is a tenth of this call)
+    LCD_HIP(h, hipStreamSynchronize(h->stream));
 #undef LCD_HIP_B
     std::memcpy(a->word_ids, h->h_frame_out.p, wbytes);
     if (lbytes) std::memcpy(a->likelihood, (const char*)h->h_frame_out.p + wbytes, lbytes);
@@ -2116,7 +2105,6 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     if (!std::strcmp(key, "filter_delay") && value >= 0 && value <= 127) { h->popt.filter_delay = (int)value; return LCD_OK; }
     if (!std::strcmp(key, "shadow_rows") && value >= -1 && value <= 2) { h->popt.shadow_rows = value < 0 ? 1 : (int)value; return LCD_OK; }   // (-1: built-in = 1)
     if (!std::strcmp(key, "mirror_from_b") && value >= -1 && value <= 1) { h->popt.mirror_from_b = value != 0 ? 1 : 0; return LCD_OK; }
-    if (!std::strcmp(key, "spin_wait_us") && value >= 0 && value <= 1000000) { h->spin_wait_us = (int)value; return LCD_OK; }
     if (!std::strcmp(key, "profile_skip") && value >= 0 && value <= (1 << 20)) { h->prof_skip = (int)value; return LCD_OK; }
     if (!std::strcmp(key, "decision_straight") && value >= -1 && value <= 2) { h->popt.decision_straight = value >= 0 ? (int)value : PipeOpts().decision_straight; return LCD_OK; }
     if (!std::strcmp(key, "slots_from_rows") && value >= -1 && value <= 2) { h->popt.slots_from_rows = value >= 0 ? (int)value : PipeOpts().slots_from_rows; return LCD_OK; }
