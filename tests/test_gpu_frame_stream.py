@@ -352,7 +352,7 @@ def test_frame_dev_at_headline_sizes(oracle, n_sig, pipeline, bench_mode):
     eng.close()
 
 
-def _headline_bench_mode(oracle, n_sig, n_frames=6):
+def _headline_bench_mode(oracle, n_sig, n_frames=8):
     import rtabmap_amd
     n_words, q = 49000, 500
     vocab = synth.vocab_surf(n_words)
@@ -363,9 +363,6 @@ def _headline_bench_mode(oracle, n_sig, n_frames=6):
         m.vwd.add_word(int(i), r)
     m.vwd.update()
     assert m.add_signatures_bulk(words) == 1
-    eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 8192, sig_capacity=n_sig + 64, pipeline=True, knn_mode="f16")
-    eng.vocab_append(vocab, ids)
-    eng.sig_add_bulk(np.arange(1, n_sig + 1, dtype=np.int32), np.arange(0, (n_sig + 1) * q, q, dtype=np.int64), words.reshape(-1))
     cap = n_sig + 16
     rng = np.random.default_rng(5)
     src0 = int(rng.integers(100, n_sig))
@@ -385,27 +382,36 @@ def _headline_bench_mode(oracle, n_sig, n_frames=6):
         likes.append(m.compute_likelihood(np.array(exp, np.int32), live))
         m.forget(t + 1)
     d_desc = [torch.from_numpy(f).cuda() for f in frames]
-    d_words = torch.zeros((n_frames, q), dtype=torch.int32, device="cuda")
-    d_like = torch.zeros((n_frames, cap), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
-    for t in range(n_frames):
-        eng.frame_dev(d_desc[t].data_ptr(), q, n_sig + 1 + t, float(n_sig + 1), d_words[t].data_ptr(), d_like[t].data_ptr(), cap,
-                      first_new_word_id=first_new[t], append_new_words=True)
-        eng.sig_remove(t + 1)
-    eng.synchronize()
-    got, like = d_words.cpu().numpy(), d_like.cpu().numpy()
-    matched_new = 0
-    for t in range(n_frames):
-        mapped = np.where(got[t] < 0, first_new[t] - got[t] - 1, got[t])
-        assert mapped.tolist() == expected[t], "frame %d" % t
-        if t % 2:
-            matched_new += int(((got[t] > n_words)).sum())
-        oi, Lo = likes[t]
-        Lh = like[t][oi - 1]                                    # signature id s sits in slot s - 1 in this test
-        np.testing.assert_allclose(Lh, Lo, rtol=RTOL, atol=ATOL, err_msg="frame %d" % t)
-        assert int(np.argmax(Lh[:-1])) == int(np.argmax(Lo[:-1]))
-    assert matched_new > 50, "the revisits must match words the frames before them created (rows appended on the device)"
-    eng.close()
+    # the launch shapes the engine selects by the row-growth estimate (shadow scores, rows instead of postings keys out of the decision loop, its straight
+    # first round trip), as the engine picks them / forced on from the first frame / forced off: the same integers and the same likelihood every way
+    for opts in ({}, {"shadow_rows": 2, "slots_from_rows": 2, "decision_straight": 2}, {"shadow_rows": 0, "slots_from_rows": 0, "decision_straight": 0},
+                 {"shadow_rows": 2, "slots_from_rows": 0, "decision_straight": 2}, {"shadow_rows": 0, "slots_from_rows": 2, "decision_straight": 0}):
+        eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 8192, sig_capacity=n_sig + 64, pipeline=True, knn_mode="f16")
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        eng.vocab_append(vocab, ids)
+        eng.sig_add_bulk(np.arange(1, n_sig + 1, dtype=np.int32), np.arange(0, (n_sig + 1) * q, q, dtype=np.int64), words.reshape(-1))
+        d_words = torch.zeros((n_frames, q), dtype=torch.int32, device="cuda")
+        d_like = torch.zeros((n_frames, cap), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        for t in range(n_frames):
+            eng.frame_dev(d_desc[t].data_ptr(), q, n_sig + 1 + t, float(n_sig + 1), d_words[t].data_ptr(), d_like[t].data_ptr(), cap,
+                          first_new_word_id=first_new[t], append_new_words=True)
+            eng.sig_remove(t + 1)
+        eng.synchronize()
+        got, like = d_words.cpu().numpy(), d_like.cpu().numpy()
+        matched_new = 0
+        for t in range(n_frames):
+            mapped = np.where(got[t] < 0, first_new[t] - got[t] - 1, got[t])
+            assert mapped.tolist() == expected[t], "frame %d, options %r" % (t, opts)
+            if t % 2:
+                matched_new += int(((got[t] > n_words)).sum())
+            oi, Lo = likes[t]
+            Lh = like[t][oi - 1]                                    # signature id s sits in slot s - 1 in this test
+            np.testing.assert_allclose(Lh, Lo, rtol=RTOL, atol=ATOL, err_msg="frame %d, options %r" % (t, opts))
+            assert int(np.argmax(Lh[:-1])) == int(np.argmax(Lo[:-1]))
+        assert matched_new > 50, "the revisits must match words the frames before them created (rows appended on the device)"
+        eng.close()
 
 
 def test_hypothesis_from_the_device(oracle):
