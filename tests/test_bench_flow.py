@@ -68,9 +68,9 @@ STANDINS = textwrap.dedent('''
     rtabmap_amd.Engine = FakeEngine
     B.load_engine = lambda eng, vocab, words, owned=None: 0.04
     B.Stepper = FakeStepper
-    B.timed_loop = lambda torch_, dist_, world, stream, step, steps_, warmup_, profile_eng=None, eng=None, per_step_events=True: {
+    B.timed_loop = lambda torch_, dist_, world, stream, step, steps_, warmup_, profile_eng=None, eng=None, per_step_events=True, prof_n=0: {
         "wall": 4.0e-5 * steps_, "dev_ms": 0.039 * steps_, "host_enqueue": 2.0e-5 * steps_, "per_step_ms": np.full(steps_ if per_step_events else 0, 0.033)}
-    B.rooflines = lambda eng, nw, ns, shard, knn=None: ({"ms": 0.0209, "kernel": "frame_a_kernel (stand-in)", "frac": 0.06},
+    B.rooflines = lambda eng, nw, ns, shard, knn=None, knn_timed=None: ({"ms": 0.0209, "kernel": "frame_a_kernel (stand-in)", "frac": 0.06, "samples": 11},
                                                         {"ms": 0.0155, "kernel": "frame_b_kernel (stand-in)", "frac": 0.11})
     B.make_state = lambda n: (np.zeros((49000, 64), np.float32), np.ones((n, 500), np.int32))
     synth.frame_from_signature = lambda vocab, words, seed=0, **k: np.zeros((500, 64), np.float32)
