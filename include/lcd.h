@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LCD_ABI_VERSION 6
+#define LCD_ABI_VERSION 7
 
 typedef struct lcd_engine lcd_engine;
 
@@ -216,6 +216,7 @@ typedef struct lcd_hypothesis {
     int32_t n_positive;
 } lcd_hypothesis;
 
+#define LCD_NEW_WORD_IDS_AUTO (-1)     /* lcd_frame_args.first_new_word_id: the device numbers the frame's new words (see there) */
 typedef struct lcd_frame_args {
     int32_t struct_size;               /* sizeof(lcd_frame_args) */
     int32_t q;                         /* descriptors in the frame (1..8192) */
@@ -228,7 +229,13 @@ typedef struct lcd_frame_args {
                                           and consecutive frames must number their new words consecutively, as ++_lastWordId does
                                           (:1185).  The frame's signature then references its new words as well, so that a later
                                           frame matching one of them -- after lcd_vocab_append -- scores this signature.
-                                          0: new words get no references (fixed dictionary / caller never indexes them). */
+                                          0: new words get no references (fixed dictionary / caller never indexes them).
+                                          LCD_NEW_WORD_IDS_AUTO (needs append_new_words): the DEVICE numbers the words, exactly as ++_lastWordId does, for a
+                                          caller that does not read back how many words a frame created before it submits the next one: the id of a new
+                                          word is its vocabulary row + (next word id - rows) as they stood when the run of appending frames began -- every
+                                          new word is one row and one id.  The run starts from lcd_set_option(h, "next_word_id", _lastWordId + 1), or from one
+                                          past the highest id the handle has seen; the frame's first id is written to d_first_new_word_id.  (Not in the
+                                          sharded entry points.  ABI v7.) */
     float N;                           /* Memory::getSignatures().size() as the caller counts it (Memory.cpp:2248) */
     int32_t exclude_recent;            /* hypothesis only: the newest `exclude_recent` slots (short-term memory + this frame,
                                           Rtabmap.cpp:2050-2117 compares against the working memory only) are not considered */
@@ -247,7 +254,9 @@ typedef struct lcd_frame_args {
                                           frame's filter has already taken its snapshot by then: its re-rank scans the appended rows exactly, so
                                           the result is the 2-NN over the updated vocabulary.  Removals (lcd_vocab_remove / lcd_vocab_rebuild,
                                           cleanUnusedWords) stay host calls that complete the owed stages first. */
-    void* ready_event;                 /* reserved (NULL) */
+    int32_t* d_first_new_word_id;      /* out, may be NULL (device memory; chained frames: append_new_words on a handle whose rows live on the device): the id of
+                                          the frame's first new word -- first_new_word_id itself, or what LCD_NEW_WORD_IDS_AUTO resolved to (the -(k+1) codes of
+                                          d_word_ids are this + k).  (ABI v7: the field was a reserved pointer, NULL.) */
     float* d_posterior;                /* out, may be NULL (needs d_likelihood and lcd_bayes_configure): the Bayes filter's posterior
                                           after this frame, [n_slots + 1], entry 0 = virtual place, 0 for slots that are retired or
                                           not considered (BayesFilter::computePosterior, BayesFilter.cpp:145-235) */
@@ -371,7 +380,8 @@ int lcd_profile_read_likelihood(lcd_engine* h, float* avg_ms, int* n_samples, co
  * round trip that fetches the retired signature's words); 0 = the decision loop gathers the keys itself.  "score_block": threads per workgroup of the scoring kernel
  * (256 / 512 / 1024).  "filter_units": compute units the bf16 filter plans its persistent workgroups for when the vocabulary has
  * more 256-word strips than that (-1 built-in, 0 never persistent).  "decision_straight": 1 (built-in: while the stream creates 16 words per frame or more; 2 = always; 0 = never) = the decision loop of a pipelined frame requests
- * everything its first round trip reads unconditionally, in one straight line (faster while frames create words, slower once they only revisit: DESIGN.md 4d).  "profile_skip": the number of launches of a pipelined handle that lcd_profile_begin lets pass before it brackets one (0; the first launches behind an idle
+ * everything its first round trip reads unconditionally, in one straight line (faster while frames create words, slower once they only revisit: DESIGN.md 4d).  "next_word_id": one past the highest word id handed out so far (VWDictionary::_lastWordId + 1): where LCD_NEW_WORD_IDS_AUTO continues (never lowered: the handle
+ * keeps the maximum of this and the ids of the rows it has seen).  "profile_skip": the number of launches of a pipelined handle that lcd_profile_begin lets pass before it brackets one (0; the first launches behind an idle
  * queue are not the steady state).  "profile_likelihood": 0 = lcd_profile_begin brackets only the
  * 2-NN launch of a pipelined frame (every timed launch costs stream time).  "strip_tiles": 32-word tiles per filter workgroup of a
  * pipelined frame (1 .. 8; 0 = the built-in plan).  "append_split_buckets": sealed buckets of 256 signatures from which

@@ -14,6 +14,7 @@ from . import build as _build
 LCD_OK = 0
 LCD_F32, LCD_U8 = 0, 1
 LCD_Q_INCREMENTAL, LCD_Q_NEW_WORDS_COMPARED = 1, 2
+LCD_NEW_WORD_IDS_AUTO = -1      # lcd_frame_args.first_new_word_id: the device numbers the frame's new words (include/lcd.h)
 STATUS = {0: "LCD_OK", 1: "LCD_ERR_INVALID", 2: "LCD_ERR_HIP", 3: "LCD_ERR_NOMEM", 4: "LCD_ERR_STATE", 5: "LCD_ERR_UNSUPPORTED"}
 
 # every symbol include/lcd.h declares (tests check that the library exports all of them)
@@ -47,7 +48,7 @@ class LcdFrameArgs(C.Structure):
                 ("nndr_ratio", C.c_float), ("sig_id", C.c_int32), ("first_new_word_id", C.c_int32), ("N", C.c_float),
                 ("exclude_recent", C.c_int32), ("d_word_ids", C.c_void_p), ("d_likelihood", C.c_void_p),
                 ("likelihood_capacity", C.c_int64), ("d_hypothesis", C.c_void_p), ("d_adjusted", C.c_void_p),
-                ("virtual_place_ratio", C.c_float), ("append_new_words", C.c_int32), ("ready_event", C.c_void_p),
+                ("virtual_place_ratio", C.c_float), ("append_new_words", C.c_int32), ("d_first_new_word_id", C.c_void_p),
                 ("d_posterior", C.c_void_p), ("d_bayes", C.c_void_p)]
 
 
@@ -326,11 +327,11 @@ class Engine:
     # ---- device-resident frame path
     def frame_dev(self, d_desc_ptr, q, sig_id, N, d_word_ids_ptr, d_like_ptr, like_capacity, incremental=True,
                   new_words_compared=True, nndr=0.8, first_new_word_id=0, d_hypothesis_ptr=None, d_adjusted_ptr=None,
-                  exclude_recent=0, virtual_place_ratio=0.0, ready_event=None, d_posterior_ptr=None, d_bayes_ptr=None, append_new_words=False):
+                  exclude_recent=0, virtual_place_ratio=0.0, d_first_new_word_id_ptr=None, d_posterior_ptr=None, d_bayes_ptr=None, append_new_words=False):
         flags = (LCD_Q_INCREMENTAL if incremental else 0) | (LCD_Q_NEW_WORDS_COMPARED if new_words_compared else 0)
         a = LcdFrameArgs(C.sizeof(LcdFrameArgs), q, d_desc_ptr, flags, nndr, sig_id, first_new_word_id, float(N), exclude_recent,
                          d_word_ids_ptr, d_like_ptr, like_capacity, d_hypothesis_ptr, d_adjusted_ptr, virtual_place_ratio,
-                         1 if append_new_words else 0, ready_event, d_posterior_ptr, d_bayes_ptr)
+                         1 if append_new_words else 0, d_first_new_word_id_ptr, d_posterior_ptr, d_bayes_ptr)
         self._ck(self.L.lcd_frame_dev(self.h, C.byref(a)))
 
     def frame_host(self, desc, sig_id, N, incremental=True, new_words_compared=True, nndr=0.8, first_new_word_id=0, append_new_words=False,

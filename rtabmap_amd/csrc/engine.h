@@ -95,6 +95,10 @@ struct lcd_engine {
     struct DevAppend { uint64_t seq; int32_t first_id; int32_t q; bool enabled;
                        // sharded append (lcd_shard_frame_dev): the log holds the frame's TOTAL of new words, this rank owns the ids the rule gives it
                        int32_t own_world = 0, own_rank = 0, own_first = 0, own_block = 0; };
+    // LCD_NEW_WORD_IDS_AUTO: the words frames create are numbered on the device, id = row + id_delta (AppendArgs::first_id <= 0; DevAppend::first_id = -id_delta).
+    // next_word_id: one past the highest word id this handle has seen (rows appended by any call; "next_word_id" sets it: VWDictionary::_lastWordId + 1);
+    // id_delta is fixed while appends are unreconciled (every new word is one row and one id), auto_window says the unreconciled appenders are numbered that way
+    int32_t next_word_id = 1, id_delta = 1; bool auto_window = false;
     std::deque<DevAppend> unreconciled;                 // frames whose appends the host mirror has not caught up with
     uint64_t vseq = 0;                                  // sequence number of the next frame in the chain: it reads counter vseq & 1, writes the other
     bool vcnt_active = false;                           // the counters hold the row count (set when the first appending frame arrives)

@@ -263,7 +263,8 @@ void fill_append(lcd_engine* h, const lcd_frame_args& a, uint64_t vseq, bool ena
     ap.wrow = h->tfidf.wrow.as<uint32_t>(); ap.f16 = h->f16();
     ap.cnt_in = h->d_vcnt.as<int32_t>() + (vseq & 1); ap.cnt_out = h->d_vcnt.as<int32_t>() + ((vseq + 1) & 1);
     ap.log_slot = h->d_vcnt.as<int32_t>() + 16 + (vseq % lcd_engine::VLOG);
-    ap.first_id = a.first_new_word_id; ap.capacity = vocab_cap_rows(h);
+    ap.first_id = a.first_new_word_id == LCD_NEW_WORD_IDS_AUTO ? -h->id_delta : a.first_new_word_id; ap.capacity = vocab_cap_rows(h);
+    ap.first_out = (int32_t*)a.d_first_new_word_id;
     ap.host_mirror = h->h_vmirror; ap.tag = (uint32_t)(vseq + 1);
 }
 
@@ -310,6 +311,7 @@ void lcd_engine::mirror_push_row(int32_t id, int64_t row) {
     if (rows_sorted && !h_row_key.empty() && id <= h_row_key.back()) rows_sorted = false;
     if (word_row_valid) word_row[id] = (int32_t)row;
     h_row_key.push_back(id);
+    if (id >= next_word_id) next_word_id = id + 1;
     h_row_live.push_back(1);
 }
 
@@ -325,13 +327,15 @@ int lcd_engine::reconcile() {
         if (e == hipSuccess && n > n1) e = hipMemcpy(log.data(), d_vcnt.as<int32_t>() + 16, std::min(n - n1, (size_t)VLOG) * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpy(append log)");
     }
+    std::vector<std::pair<int64_t, int> > auto_rows;
     for (const DevAppend& a : unreconciled) {
         if (!a.enabled) continue;
         const int n = log[(size_t)(a.seq % VLOG)];
         est_new = std::max(est_new * 0.9, (double)n);                 // (the estimate the launch plans and the shadow-score switch use: rows_plan() only sees it move while frames are in flight)
         int taken = 0;
+        const int64_t rows0 = n_rows;
         for (int k = 0; k < n; ++k) {
-            const int32_t id = a.first_id + k;
+            const int32_t id = a.first_id > 0 ? a.first_id + k : (int32_t)(n_rows + taken) - a.first_id;   // (<= 0: the id follows the row)
             if (a.own_world > 0) {                                    // a sharded append: n is the frame's total, this rank wrote the ids it owns
                 const bool mine = a.own_block > 0 ? (id >= a.own_first && ((id - a.own_first) / a.own_block) % a.own_world == a.own_rank)
                                                   : a.own_rank == a.own_world - 1;
@@ -342,8 +346,20 @@ int lcd_engine::reconcile() {
         }
         n_rows += taken;
         n_live += taken;
+        if (a.first_id <= 0 && taken > 0) auto_rows.push_back(std::pair<int64_t, int>(rows0, taken));
+    }
+    if (!auto_rows.empty()) {
+        // words numbered on the device: the host learns their postings keys from the rows themselves, in ONE copy (with ids the caller supplies
+        // the reservation check pairs them; here nobody knew the ids when the keys were reserved)
+        const int64_t r0 = auto_rows.front().first;
+        std::vector<int32_t> keys((size_t)(n_rows - r0));
+        hipError_t e = hipMemcpy(keys.data(), row_wslot.as<int32_t>() + r0, keys.size() * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpy(row keys)");
+        for (const std::pair<int64_t, int>& ar : auto_rows)
+            for (int k = 0; k < ar.second; ++k) tfidf.adopt_key(h_row_key[(size_t)(ar.first + k)], keys[(size_t)(ar.first + k - r0)]);
     }
     unreconciled.clear();
+    auto_window = false;
     if (rm_pending) {
         // rows tombstoned by the device-side cleanUnusedWords since the last reconciliation: the words are gone (removeWords,
         // VWDictionary.cpp:1595-1607), their postings keys go to the batched check that recycles them once nothing references them
@@ -602,6 +618,7 @@ int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word
         if (h->rows_sorted && !h->h_row_key.empty() && word_ids[i] <= h->h_row_key.back()) h->rows_sorted = false;   // out-of-order id
         if (h->word_row_valid) h->word_row[word_ids[i]] = (int32_t)(h->n_rows + i);
         h->h_row_key.push_back(word_ids[i]);
+        if (word_ids[i] >= h->next_word_id) h->next_word_id = word_ids[i] + 1;
         h->h_row_live.push_back(1);
     }
     h->n_rows = total;
@@ -1195,15 +1212,36 @@ static int frame_score_s(lcd_engine* h, const lcd_frame_args& a) {
 
 // (any descriptor type: rows that are not 64 floats are copied without the matrix-core filter's tables -- such handles are never pipelined)
 static bool frame_appends(const lcd_engine* h, const lcd_frame_args& a) {
-    return a.append_new_words != 0 && a.first_new_word_id > 0 && (a.flags & LCD_Q_INCREMENTAL) != 0 &&
+    return a.append_new_words != 0 && (a.first_new_word_id > 0 || a.first_new_word_id == LCD_NEW_WORD_IDS_AUTO) && (a.flags & LCD_Q_INCREMENTAL) != 0 &&
            h->row_bytes == h->dim * (h->dtype == LCD_F32 ? 4 : 1);     // (rows are stored as they arrive: no padding to add on the device)
+}
+
+// Who numbers the words this frame creates.  LCD_NEW_WORD_IDS_AUTO: the device, id = row + id_delta -- exact as long as every unreconciled appender is
+// numbered that way (one new word = one row = one id), so a change of mode completes what is owed first; id_delta is set while the host's row
+// mirror is current.
+static int id_window(lcd_engine* h, const lcd_frame_args& a) {
+    const bool is_auto = a.first_new_word_id == LCD_NEW_WORD_IDS_AUTO;
+    if (a.first_new_word_id < 0 && !is_auto) return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: first_new_word_id");
+    if (is_auto && !frame_appends(h, a))
+        return h->fail(LCD_ERR_INVALID, "lcd_frame_dev: LCD_NEW_WORD_IDS_AUTO needs append_new_words on an incremental dictionary of unpadded rows");
+    if (!frame_appends(h, a)) return LCD_OK;
+    if (!h->unreconciled.empty() && h->auto_window != is_auto) { int rc = h->drain(); if (rc) return rc; }
+    if (h->unreconciled.empty()) {
+        h->auto_window = is_auto;
+        if (is_auto) {
+            const int64_t d = (int64_t)h->next_word_id - h->n_rows;
+            if (d < 1 || d >= (1ll << 28)) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: next_word_id lies below the ids the vocabulary holds (lcd_set_option \"next_word_id\")");
+            h->id_delta = (int32_t)d;
+        }
+    }
+    return LCD_OK;
 }
 
 static int reserve_frame_words(lcd_engine* h, const lcd_frame_args& a, WsRuns* runs, bool may_flush = true) {
     *runs = WsRuns();
     // postings keys for the words this frame may create (VisualWord(id, descriptor, signatureId) references the signature; a word that
     // becomes a vocabulary row on the device needs its key there as well)
-    if ((a.sig_id != 0 || frame_appends(h, a)) && a.first_new_word_id > 0 && (a.flags & LCD_Q_INCREMENTAL)) {
+    if ((a.sig_id != 0 || frame_appends(h, a)) && (a.first_new_word_id > 0 || (a.first_new_word_id == LCD_NEW_WORD_IDS_AUTO && frame_appends(h, a))) && (a.flags & LCD_Q_INCREMENTAL)) {
         hipError_t e = h->tfidf.reserve_new_words(a.first_new_word_id, a.q, runs, may_flush);
         if (e == hipErrorInvalidValue) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_frame_dev: word ids must be below 2^28");
         LCD_HIP(h, e);
@@ -1492,6 +1530,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     // rows tombstoned by enqueued cleans keep their postings keys out of circulation until the host has caught up with the log: a stream
     // that never completes anything does so every 512 frames (three fused launch pairs, ~0.2 us per frame)
     if (h->rm_pending && ++h->frames_since_reconcile >= 512) { int rc = h->drain(); if (rc) return rc; }
+    { int rc = id_window(h, *a); if (rc) return rc; }
     // rows appended on the device: the counters take over the row count, the buffers keep room for the words of the frames in flight
     const bool app = frame_appends(h, *a);
     if (app) { int rc = activate_dev_rows(h); if (rc) return rc; }
@@ -1556,7 +1595,7 @@ static int frame_pipelined(lcd_engine* h, const lcd_frame_args* a) {
     // ---- this frame's filter, re-rank, decision loop, registration and scoring are owed from here on
     lcd_engine::InFlight nf;
     nf.a = *a; nf.set = set; nf.stage = 0; nf.vseq = vseq; nf.chained = chained; nf.has_shadow = with_shadow;
-    if (chained) { h->unreconciled.push_back(lcd_engine::DevAppend{vseq, a->first_new_word_id, q, app}); h->vseq += 1; }
+    if (chained) { h->unreconciled.push_back(lcd_engine::DevAppend{vseq, a->first_new_word_id == LCD_NEW_WORD_IDS_AUTO ? -h->id_delta : a->first_new_word_id, q, app}); h->vseq += 1; }
     h->inflight.push_back(std::move(nf));
     h->frame_seq += 1;
     return LCD_OK;
@@ -1660,6 +1699,7 @@ static int frame_dev_body(lcd_engine* h, const lcd_frame_args* a) {
     if ((a->d_posterior || a->d_bayes) && !h->bayes.configured) return h->fail(LCD_ERR_STATE, "lcd_frame_dev: lcd_bayes_configure first");
     if (h->pipeline && q <= 4096 && h->bf_family() && knn_mfma_supported(h->dtype, h->kdim) && h->n_live >= 2 && h->n_rows >= 256)
         return frame_pipelined(h, a);
+    { int rc = id_window(h, *a); if (rc) return rc; }
     const bool app = frame_appends(h, *a);
     // A stream of appending frames on a plain handle with the exact scan (ORB: config 3) does not wait for the device between frames:
     // the host's row mirror lags (as on a pipelined handle), the scan is planned for an upper bound of the row count.  Anything else
@@ -1691,7 +1731,7 @@ static int frame_dev_body(lcd_engine* h, const lcd_frame_args* a) {
     if (rc) return rc;
     if (h->d_fail_count.p) { r.fail_count = h->d_fail_count.as<int32_t>(); h->fail_count_clean = true; }   // the tail resets the counters
     const uint64_t vseq = h->vseq;
-    if (app) { h->unreconciled.push_back(lcd_engine::DevAppend{vseq, a->first_new_word_id, q, true}); h->vseq += 1; }
+    if (app) { h->unreconciled.push_back(lcd_engine::DevAppend{vseq, a->first_new_word_id == LCD_NEW_WORD_IDS_AUTO ? -h->id_delta : a->first_new_word_id, q, true}); h->vseq += 1; }
     return frame_stage_s(h, *a, r, app, vseq);
 }
 
@@ -2105,6 +2145,7 @@ int lcd_set_option(lcd_engine* h, const char* key, int64_t value) {
     if (!std::strcmp(key, "filter_delay") && value >= 0 && value <= 127) { h->popt.filter_delay = (int)value; return LCD_OK; }
     if (!std::strcmp(key, "shadow_rows") && value >= -1 && value <= 2) { h->popt.shadow_rows = value < 0 ? 1 : (int)value; return LCD_OK; }   // (-1: built-in = 1)
     if (!std::strcmp(key, "mirror_from_b") && value >= -1 && value <= 1) { h->popt.mirror_from_b = value != 0 ? 1 : 0; return LCD_OK; }
+    if (!std::strcmp(key, "next_word_id") && value >= 1 && value < (1ll << 28)) { h->next_word_id = std::max(h->next_word_id, (int32_t)value); return LCD_OK; }   // (the drain above has brought the row mirror up to date)
     if (!std::strcmp(key, "profile_skip") && value >= 0 && value <= (1 << 20)) { h->prof_skip = (int)value; return LCD_OK; }
     if (!std::strcmp(key, "decision_straight") && value >= -1 && value <= 2) { h->popt.decision_straight = value >= 0 ? (int)value : PipeOpts().decision_straight; return LCD_OK; }
     if (!std::strcmp(key, "slots_from_rows") && value >= -1 && value <= 2) { h->popt.slots_from_rows = value >= 0 ? (int)value : PipeOpts().slots_from_rows; return LCD_OK; }

@@ -270,7 +270,7 @@ __device__ __forceinline__ void append_write_row(const AppendArgs& ap, size_t ro
 }
 __device__ __forceinline__ void append_write_ids(const AppendArgs& ap, const WsRuns& new_ws, size_t row, int k) {
     const int32_t key = new_ws.n > 0 ? ws_runs_at_dev(new_ws, k) : -1;
-    ap.row_id[row] = ap.first_id + k;
+    ap.row_id[row] = ap.first_id > 0 ? ap.first_id + k : (int32_t)row - ap.first_id;   // (first_id <= 0: the id follows the row)
     ap.row_wslot[row] = key;
     if (key >= 0 && ap.wrow) ap.wrow[key] = (uint32_t)row + 1u;         // the key now belongs to a row: the batched check of superseded
 }                                                                       // reservations must not hand it out again
@@ -296,6 +296,7 @@ __device__ __forceinline__ void append_publish(const AppendArgs& ap, int q, cons
     if (threadIdx.x == 0 && n_in >= 0) {
         ap.cnt_out[0] = n_in + n_take;
         if (ap.log_slot) ap.log_slot[0] = n_take;
+        if (ap.first_out) ap.first_out[0] = ap.first_id > 0 ? ap.first_id : n_in - ap.first_id;
         if (ap.host_mirror && !ap.mirror_later) __hip_atomic_store(ap.host_mirror, ((unsigned long long)ap.tag << 32) | (unsigned long long)(uint32_t)(n_in + n_take), __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -417,6 +418,7 @@ __device__ __forceinline__ void append_new_rows(const AppendArgs& ap, int q, con
         if (ap.is_f32_64) { ap.row_norm[2 * (size_t)n_out] = __int_as_float(0x7f800000); ap.row_norm[2 * (size_t)n_out + 1] = 1.0f; }   // sentinel
         ap.cnt_out[0] = n_out;
         if (ap.log_slot) ap.log_slot[0] = n_take;
+        if (ap.first_out) ap.first_out[0] = ap.first_id > 0 ? ap.first_id : n_in - ap.first_id;
         if (ap.host_mirror) __hip_atomic_store(ap.host_mirror, ((unsigned long long)ap.tag << 32) | (unsigned long long)(uint32_t)n_out, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -427,6 +429,7 @@ __device__ __forceinline__ void append_pass_on(const AppendArgs& ap) {
         const int n = ap.cnt_in[0];
         ap.cnt_out[0] = n;
         if (ap.log_slot) ap.log_slot[0] = 0;
+        if (ap.first_out) ap.first_out[0] = ap.first_id > 0 ? ap.first_id : n - ap.first_id;
         if (ap.host_mirror) __hip_atomic_store(ap.host_mirror, ((unsigned long long)ap.tag << 32) | (unsigned long long)(uint32_t)n, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_SYSTEM);
     }

@@ -1448,6 +1448,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
     if (pend_lo && pend_hi) asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(n_lo0), "=&s"(p_hi_ld) : "s"(pend_lo), "s"(pend_hi) : "memory");
     else { if (pend_lo) n_lo0 = pend_lo[0]; if (pend_hi) p_hi_ld = pend_hi[0]; }
     const int p_lo = pend_lo ? min(n_lo0, pend_cap) : 0, p_hi = p_hi_ld;
+    const int32_t pend_id0 = pend_first_id > 0 ? pend_first_id : n_lo0 - pend_first_id;   // word id of the first pending row (<= 0: ids that follow the rows, AppendArgs::first_id)
     // with shadow rows the pending scan only has to cover vocabulary rows the filter's plan did not reach ([p_lo, n_lo0): rare)
     const int p_hi_s = sh_q > 0 ? min(p_hi, n_lo0) : p_hi;
     __shared__ uint32_t s_plist[HALVES * MF_BLOCK];                    // the first entries of pend_list (one per thread: read with the keys)
@@ -1528,7 +1529,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
             append_write_row(ap, (size_t)n_lo0 + (size_t)j, c16, x, nmax);
             if (c16 == 0) {
                 const size_t row = (size_t)n_lo0 + (size_t)j;
-                ap.row_id[row] = ap.first_id + j;
+                ap.row_id[row] = ap.first_id > 0 ? ap.first_id + j : (int32_t)row - ap.first_id;    // (first_id <= 0: the id follows the ROW, AppendArgs)
                 ap.row_wslot[row] = key;
                 if (key >= 0 && ap.wrow) ap.wrow[key] = (uint32_t)row + 1u;
             }
@@ -1573,7 +1574,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
                     append_write_row(ap, (size_t)n_lo0 + (size_t)j, c16, x, nmax);
                     if (c16 == 0) {
                         const size_t row = (size_t)n_lo0 + (size_t)j;
-                        ap.row_id[row] = ap.first_id + j;
+                        ap.row_id[row] = ap.first_id > 0 ? ap.first_id + j : (int32_t)row - ap.first_id;    // (first_id <= 0: the id follows the ROW, AppendArgs)
                         ap.row_wslot[row] = key;
                         if (key >= 0 && ap.wrow) ap.wrow[key] = (uint32_t)row + 1u;
                     }
@@ -1756,7 +1757,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
             const float* src = sh ? pend_desc + (size_t)sj * DIM : vocab + (size_t)rrow * DIM;
             v4 = reinterpret_cast<const float4*>(src)[lane & 15];
             wid = 0;
-            if ((lane & 15) == 0) wid = sh ? pend_first_id + sh_rank(sj) : row_id[rrow];
+            if ((lane & 15) == 0) wid = sh ? pend_id0 + sh_rank(sj) : row_id[rrow];
         };
         auto finish = [&](int i, const float4& v4, int32_t wid) {
             const uint64_t k = s_cand[GS == 4 ? (i >> 2) : i];
@@ -1926,7 +1927,7 @@ __device__ __forceinline__ void knn_mfma_rerank_body(int qi_first, const uint64_
         for (int j = 0; j < 2; ++j) {
             if (k[j] == KEY_NONE) continue;
             const int32_t rw = (int32_t)(uint32_t)k[j];
-            wout[j] = sl[j] >= 0 ? s_word[sl[j]] : ((pend_list && rw >= n_lo0) ? pend_first_id + (rw - n_lo0) : row_id[rw]);
+            wout[j] = sl[j] >= 0 ? s_word[sl[j]] : ((pend_list && rw >= n_lo0) ? pend_id0 + (rw - n_lo0) : row_id[rw]);
         }
         // certificate: every row the filter dropped is strictly farther than the exact second neighbour
         bool ok = !overflow;

@@ -113,7 +113,10 @@ struct AppendArgs {
     float* row_norm = nullptr; uint32_t* norm_max_bits = nullptr; uint32_t* vocab_bf = nullptr;
     const int32_t* cnt_in = nullptr; int32_t* cnt_out = nullptr;
     int32_t* log_slot = nullptr;               // receives the number of rows appended (host reconciliation)
-    int32_t first_id = 0;
+    int32_t first_id = 0;                      // > 0: the k-th new word gets the id first_id + k.  <= 0 (LCD_NEW_WORD_IDS_AUTO): the id FOLLOWS THE ROW, id = row - first_id
+                                               // (-first_id = next word id - rows when the chain of appending frames started: every new word is one row and one id, so the
+                                               // device numbers exactly as ++_lastWordId does, VWDictionary.cpp:1188, without the host knowing how many words a frame made)
+    int32_t* first_out = nullptr;              // receives the id of the frame's first new word (may be NULL)
     long long capacity = 0;                    // rows the buffers hold: appends beyond are dropped (cannot happen: the host reserves q per frame)
     int lds_bytes = 0;                         // dynamic LDS of the workgroup that appends (launch A of a pipelined frame): what the decision loop's
                                                // own tables leave of it stages the new rows (0: no staging)
@@ -347,6 +350,7 @@ struct Tfidf {
     // may_flush = false: the batched check of superseded reservations is not launched here (a pipelined handle launches it with
     // flush_held_if_due() once the registration that may still use those keys is enqueued)
     hipError_t reserve_new_words(int32_t first_id, int n, WsRuns* runs, bool may_flush = true);
+    void adopt_key(int32_t word_id, int32_t ws);   // a word numbered on the device: id and key read from its row at reconciliation
     hipError_t flush_held_if_due() { return held_ws.size() >= 16384 ? flush_held() : hipSuccess; }
     // register one signature whose word slots are already on the device (d_wslots[n]; < 0 = no word); if N > 0 the
     // frame's unique words / idf are left in q_* for a following score()

@@ -561,7 +561,7 @@ hipError_t Tfidf::wslot_of(int32_t word_id, bool create, int32_t* out) {
     if (word_id <= 0) return hipSuccess;
     if ((size_t)word_id < id2ws.size() && id2ws[word_id] >= 0) { *out = id2ws[word_id]; return hipSuccess; }
     int32_t w = -1;
-    if (resv.n > 0 && word_id >= resv.first_id && word_id < resv.first_id + resv.n) {
+    if (resv.n > 0 && resv.first_id > 0 && word_id >= resv.first_id && word_id < resv.first_id + resv.n) {
         // a new word of the last device-quantised frame: its wslot was reserved when the frame was enqueued
         w = ws_runs_at(resv.runs, word_id - resv.first_id);
     } else {
@@ -690,6 +690,12 @@ hipError_t Tfidf::rows_drop_keys(const int32_t* d_row_wslot, const int32_t* d_ro
     wrow_clear_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_row_wslot, d_rows, n, wrow.as<uint32_t>());
     return hipGetLastError();
 }
+// a word the device numbered and keyed (LCD_NEW_WORD_IDS_AUTO): its row says which postings key it holds
+void Tfidf::adopt_key(int32_t word_id, int32_t ws) {
+    if (word_id <= 0 || ws < 0) return;
+    if ((size_t)word_id >= id2ws.size()) id2ws.resize((size_t)word_id + 1 + id2ws.size() / 2, -1);
+    if (id2ws[word_id] < 0) { id2ws[word_id] = ws; id2ws_dirty.push_back(word_id); }
+}
 void Tfidf::forget_word(int32_t word_id, int32_t ws) {
     if (word_id <= 0 || ws < 0 || (size_t)word_id >= id2ws.size() || id2ws[word_id] != ws) return;
     id2ws[word_id] = -1;
@@ -723,16 +729,17 @@ hipError_t Tfidf::release_words(const int32_t* word_ids, int n) {
 // for checking: keys it did not use (nw == 0) are recycled, used ones become the permanent keys of those words.
 hipError_t Tfidf::reserve_new_words(int32_t first_id, int n, WsRuns* runs, bool may_flush) {
     runs->n = 0;
-    if (first_id <= 0 || n <= 0) return hipSuccess;
-    if ((int64_t)first_id + n >= (1 << 28)) return hipErrorInvalidValue;
+    // first_id == -1 (LCD_NEW_WORD_IDS_AUTO): the device numbers the words; the host learns id and key of each from its row when it catches up (adopt_key)
+    if ((first_id <= 0 && first_id != -1) || n <= 0) return hipSuccess;
+    if (first_id > 0 && (int64_t)first_id + n >= (1 << 28)) return hipErrorInvalidValue;
     if (resv.n > 0) {
         int32_t k = 0;
         for (int i = 0; i < resv.runs.n; ++i) {
             for (int32_t j = 0; j < resv.runs.len[i]; ++j, ++k) {
-                const int32_t id = resv.first_id + k;
-                if ((size_t)id < id2ws.size() && id2ws[id] >= 0) continue;    // already the word's permanent key
+                const int32_t id = resv.first_id > 0 ? resv.first_id + k : 0;   // (0: numbered on the device -- the check only decides whether the key is in use)
+                if (id > 0 && (size_t)id < id2ws.size() && id2ws[id] >= 0) continue;    // already the word's permanent key
                 held_ws.push_back(resv.runs.start[i] + j);
-                held_ids.push_back(id < first_id ? id : 0);                   // ids the caller is re-using now name other words
+                held_ids.push_back((id > 0 && (first_id <= 0 || id < first_id)) ? id : 0);   // ids the caller is re-using now name other words
             }
         }
         resv.n = 0;

@@ -16,7 +16,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
     for s in declared:
         assert hasattr(L, s), s
-    assert L.lcd_abi_version() == 6
+    assert L.lcd_abi_version() == 7
 
 
 def test_shard_driver_builds_and_exports_every_declared_symbol():

@@ -13,8 +13,9 @@ from test_gpu_frame_stream import _revisit, RTOL, ATOL
 pytestmark = pytest.mark.gpu
 
 
-def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="surf", knn_mode=None, options=None, clean_every_frame=False):
+def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="surf", knn_mode=None, options=None, clean_every_frame=False, auto_ids=False):
     import rtabmap_amd
+    from rtabmap_amd import capi
     rng = np.random.default_rng(seed)
     base = synth.vocab_surf(n_words, seed=seed + 1) if kind == "surf" else synth.vocab_orb(n_words, seed=seed + 1)
     n_bulk = max(40, (n_words + q - 1) // q + 2)
@@ -50,16 +51,21 @@ def _stream(oracle, pipeline, n_words, q, n_frames, seed, sync_every=0, kind="su
     d_desc = [torch.from_numpy(f).cuda() for f in frames]
     d_w = torch.zeros((n_frames, q), dtype=torch.int32, device="cuda")
     d_l = torch.zeros((n_frames, cap), dtype=torch.float32, device="cuda")
+    d_first = torch.zeros(n_frames, dtype=torch.int32, device="cuda")
+    if auto_ids:                                  # the device numbers the words (LCD_NEW_WORD_IDS_AUTO): the caller only says where the dictionary stands
+        eng.set_option("next_word_id", first_new[0])
     torch.cuda.synchronize()
     for t in range(n_frames):
         eng.frame_dev(d_desc[t].data_ptr(), q, n_bulk + 1 + t, float(n_bulk + 1 + t), d_w[t].data_ptr(), d_l[t].data_ptr(), cap,
-                      first_new_word_id=first_new[t], append_new_words=True)
+                      first_new_word_id=capi.LCD_NEW_WORD_IDS_AUTO if auto_ids else first_new[t], append_new_words=True,
+                      d_first_new_word_id_ptr=d_first[t:].data_ptr())
         if clean_every_frame:
             eng.vocab_remove_unused_async()       # Memory::preUpdate of the next frame; no word is ever unused here: it must remove nothing
         if sync_every and t % sync_every == sync_every - 1:
             eng.synchronize()                     # completes the owed stages stand-alone: the appends of the drained frames included
     eng.synchronize()
     got, like = d_w.cpu().numpy(), d_l.cpu().numpy()
+    assert d_first.cpu().numpy().tolist() == first_new, "the id of every frame's first new word as ++_lastWordId gives it (VWDictionary.cpp:1188)"
     n_created = 0
     for t in range(n_frames):
         mapped = np.where(got[t] < 0, first_new[t] - got[t] - 1, got[t])
@@ -181,6 +187,16 @@ def test_append_new_words_with_the_fp16_filter(oracle, pipeline, n_words, q):
 def test_append_new_words_on_the_device_orb(oracle):
     """256-bit binary descriptors (Hamming scan, plain handle): the rows are copied as they are"""
     assert _stream(oracle, False, n_words=1500, q=96, n_frames=20, seed=31, kind="orb") > 100
+
+
+@pytest.mark.parametrize("kind,pipeline,sync_every,n_words,q,n_frames", [("surf", True, 0, 3000, 96, 30), ("surf", False, 0, 3000, 96, 30), ("orb", False, 0, 1500, 96, 20),
+                                                                         ("surf", True, 5, 2600, 120, 24), ("surf", True, 0, 72000, 700, 8)])
+def test_new_words_numbered_on_the_device(oracle, kind, pipeline, sync_every, n_words, q, n_frames):
+    """LCD_NEW_WORD_IDS_AUTO: a caller that never learns how many words the frames in flight created gets the reference's integers all the same --
+    the id of a new word is its vocabulary row + (next word id - rows) at the start of the run of appending frames (every new word is one row and
+    one id); drains in between, the plain handle's lazy chain (ORB) and vocabulary buffers that grow under the frames included."""
+    assert _stream(oracle, pipeline, n_words=n_words, q=q, n_frames=n_frames, seed=41, sync_every=sync_every, kind=kind, auto_ids=True,
+                   knn_mode="f16" if (kind == "surf" and pipeline) else None) > 50
 
 
 def test_append_new_words_pipelined_with_drains_in_between(oracle):

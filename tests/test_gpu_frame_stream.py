@@ -354,6 +354,7 @@ def test_frame_dev_at_headline_sizes(oracle, n_sig, pipeline, bench_mode):
 
 def _headline_bench_mode(oracle, n_sig, n_frames=8):
     import rtabmap_amd
+    from rtabmap_amd import capi
     n_words, q = 49000, 500
     vocab = synth.vocab_surf(n_words)
     words = synth.zipf_words(n_sig, q, n_words, seed=100000)
@@ -384,8 +385,13 @@ def _headline_bench_mode(oracle, n_sig, n_frames=8):
     d_desc = [torch.from_numpy(f).cuda() for f in frames]
     # the launch shapes the engine selects by the row-growth estimate (shadow scores, rows instead of postings keys out of the decision loop, its straight
     # first round trip), as the engine picks them / forced on from the first frame / forced off: the same integers and the same likelihood every way
+    # ... and with the words numbered ON THE DEVICE (LCD_NEW_WORD_IDS_AUTO: the caller does not know how many words the frames in flight created): the
+    # reference's integers -- ++_lastWordId, VWDictionary.cpp:1188 -- without a renumbering
     for opts in ({}, {"shadow_rows": 2, "slots_from_rows": 2, "decision_straight": 2}, {"shadow_rows": 0, "slots_from_rows": 0, "decision_straight": 0},
-                 {"shadow_rows": 2, "slots_from_rows": 0, "decision_straight": 2}, {"shadow_rows": 0, "slots_from_rows": 2, "decision_straight": 0}):
+                 {"shadow_rows": 2, "slots_from_rows": 0, "decision_straight": 2}, {"shadow_rows": 0, "slots_from_rows": 2, "decision_straight": 0},
+                 {"auto_ids": 1}, {"auto_ids": 1, "shadow_rows": 0}):
+        opts = dict(opts)
+        auto = bool(opts.pop("auto_ids", 0))
         eng = rtabmap_amd.Engine("f32", 64, vocab_capacity=n_words + 8192, sig_capacity=n_sig + 64, pipeline=True, knn_mode="f16")
         for k, v in opts.items():
             eng.set_option(k, v)
@@ -393,13 +399,23 @@ def _headline_bench_mode(oracle, n_sig, n_frames=8):
         eng.sig_add_bulk(np.arange(1, n_sig + 1, dtype=np.int32), np.arange(0, (n_sig + 1) * q, q, dtype=np.int64), words.reshape(-1))
         d_words = torch.zeros((n_frames, q), dtype=torch.int32, device="cuda")
         d_like = torch.zeros((n_frames, cap), dtype=torch.float32, device="cuda")
+        d_first = torch.zeros(n_frames, dtype=torch.int32, device="cuda")
+        if auto:
+            eng.set_option("next_word_id", first_new[0])
         torch.cuda.synchronize()
         for t in range(n_frames):
             eng.frame_dev(d_desc[t].data_ptr(), q, n_sig + 1 + t, float(n_sig + 1), d_words[t].data_ptr(), d_like[t].data_ptr(), cap,
-                          first_new_word_id=first_new[t], append_new_words=True)
+                          first_new_word_id=capi.LCD_NEW_WORD_IDS_AUTO if auto else first_new[t], append_new_words=True,
+                          d_first_new_word_id_ptr=d_first[t:].data_ptr())
             eng.sig_remove(t + 1)
         eng.synchronize()
         got, like = d_words.cpu().numpy(), d_like.cpu().numpy()
+        assert d_first.cpu().numpy().tolist() == first_new, "the id of every frame's first new word, options %r auto %r" % (opts, auto)
+        if auto:                                                    # the host learns ids and postings keys of the device's words from the rows
+            for w in [first_new[1], first_new[2] - 1, first_new[-1]]:
+                refs = m.vwd.word_refs(int(w))
+                if refs is not None:
+                    assert eng.word_nrefs(int(w)) == len(refs), "word %d" % w
         matched_new = 0
         for t in range(n_frames):
             mapped = np.where(got[t] < 0, first_new[t] - got[t] - 1, got[t])
