@@ -30,6 +30,8 @@ import time
 
 import numpy as np
 
+LCD_NEW_WORD_IDS_AUTO = -1          # include/lcd.h: lcd_frame_args.first_new_word_id, the device numbers the frame's new words
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -100,7 +102,7 @@ class Stepper:
         # log_frames > 0: every frame's word ids are kept (one row each) so that the oracle can replay what THIS engine registered
         self.d_words_log = torch.zeros((log_frames, Q), dtype=torch.int32, device="cuda") if log_frames else None
         self.log_base = self.d_words_log.data_ptr() if log_frames else 0
-        self.n_calls, self.first_new_log = 0, []
+        self.n_calls = 0
         self.d_like = torch.zeros(cap, dtype=torch.float32, device="cuda") if want_like else None
         self.next_sig, self.oldest, self.first_new = n_sig + 1, 1, N_WORDS + 1
         self.ptrs = [f.data_ptr() for f in d_frames]
@@ -109,24 +111,32 @@ class Stepper:
         self.args = eng.frame_args(q=Q, flags=3, nndr_ratio=NNDR, N=float(n_sig + 1), d_word_ids=self.d_words.data_ptr(),
                                    d_likelihood=self.d_like.data_ptr(), likelihood_capacity=cap,
                                    append_new_words=1 if (append and "no-new" not in DIAG) else 0)
+        # the words a frame creates are numbered ON THE DEVICE, as ++_lastWordId numbers them (VWDictionary.cpp:1188): nothing is read back between
+        # frames, and the ids are the reference's integers (LCD_NEW_WORD_IDS_AUTO, include/lcd.h); the id of every logged frame's first new word
+        # is kept beside its word ids (the -(k+1) codes of d_word_ids are that id + k)
+        self.auto_ids = bool(self.args.append_new_words) and "bound-ids" not in DIAG
+        self.d_first_log = torch.zeros(max(log_frames, 0) + 1, dtype=torch.int32, device="cuda")
+        if self.auto_ids:
+            eng.set_option("next_word_id", N_WORDS + 1)
 
     def __call__(self, i):
         a = self.args
         a.d_descriptors = self.ptrs[i % len(self.ptrs)]
         a.sig_id = self.next_sig
-        a.first_new_word_id = 0 if "no-new" in DIAG else self.first_new
+        a.first_new_word_id = 0 if "no-new" in DIAG else (LCD_NEW_WORD_IDS_AUTO if self.auto_ids else self.first_new)
         if self.log_base and self.n_calls < self.d_words_log.shape[0]:
             a.d_word_ids = self.log_base + self.n_calls * Q * 4
-            self.first_new_log.append(self.first_new)
+            a.d_first_new_word_id = self.d_first_log.data_ptr() + self.n_calls * 4
         elif self.log_base:
             a.d_word_ids = self.d_words.data_ptr()
+            a.d_first_new_word_id = self.d_first_log.data_ptr() + (self.d_first_log.shape[0] - 1) * 4
         self.n_calls += 1
         self.eng.frame_dev_args(a)
         if "no-retire" not in DIAG:
             self.eng.sig_remove(self.oldest)
         self.next_sig += 1
         self.oldest += 1
-        self.first_new += Q          # an upper bound per frame (nothing is read back): ids only have to ascend
+        self.first_new += Q          # (only without the device's numbering: an upper bound per frame, ids only have to ascend)
 
 
 # Bayes/PredictionLC as BayesFilter::setPredictionLC parses the default string (reference Parameters.h:363; uStr2Float -> double)
@@ -211,11 +221,16 @@ def timed_loop(torch, dist, world, stream, step, steps, warmup, profile_eng=None
     host_enqueue = time.perf_counter() - t0
     if eng is not None:
         eng.synchronize()
+    t_eng = time.perf_counter() - t0
     torch.cuda.synchronize()
+    t_dev1 = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    if os.environ.get("LCD_BENCH_SYNC_BREAKDOWN"):
+        log("[bench] timed region: enqueue done %.1f us, lcd_synchronize returned %.1f, torch.cuda.synchronize %.1f, second %.1f; device span (events) %.1f"
+            % (1e6 * host_enqueue, 1e6 * t_eng, 1e6 * t_dev1, 1e6 * wall, 1e3 * evs[0].elapsed_time(evs[steps])))
     per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]) if per_step_events else np.zeros(0)
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -368,25 +383,24 @@ def parity_block(torch, vocab, words, frames_np, m, n_frames=3):
     d_desc = [torch.from_numpy(frames_np[t]).cuda() for t in range(n_frames)]
     d_words = torch.zeros((n_frames, Q), dtype=torch.int32, device="cuda")
     d_like = torch.zeros((n_frames, cap), dtype=torch.float32, device="cuda")
+    d_first = torch.zeros(n_frames, dtype=torch.int32, device="cuda")
+    eng.set_option("next_word_id", N_WORDS + 1)                    # VWDictionary::_lastWordId + 1
     torch.cuda.synchronize()
-    for t in range(n_frames):      # new words are numbered with an upper bound per frame: nothing is read back in between
+    for t in range(n_frames):      # nothing is read back in between: the device numbers the new words as ++_lastWordId does (VWDictionary.cpp:1188)
         eng.frame_dev(d_desc[t].data_ptr(), Q, n_sig + 1 + t, float(n_sig + 1), d_words[t].data_ptr(), d_like[t].data_ptr(), cap,
-                      first_new_word_id=N_WORDS + 1 + t * Q, append_new_words=True)
+                      first_new_word_id=LCD_NEW_WORD_IDS_AUTO, append_new_words=True, d_first_new_word_id_ptr=d_first[t:].data_ptr())
         eng.sig_remove(t + 1)
     eng.synchronize()
-    got_all, like_all = d_words.cpu().numpy(), d_like.cpu().numpy()
+    got_all, like_all, first_all = d_words.cpu().numpy(), d_like.cpu().numpy(), d_first.cpu().numpy()
     ids_equal, argmax_equal, max_rel, n_cmp = True, True, 0.0, 0
     t_knn = t_lik = 0.0
-    eng2orc = {}                                                   # the engine numbers a frame's new words from its own upper bound
     for t in range(n_frames):
         t1 = time.perf_counter()
         sid, exp = m.update(frames_np[t])                      # exact linear 2-NN + addNewWords, 1 thread
         t2 = time.perf_counter()
         got = got_all[t]
-        ids_h = np.where(got < 0, N_WORDS + 1 + t * Q - got - 1, got).tolist()
-        for j in np.flatnonzero(got < 0).tolist():
-            eng2orc.setdefault(ids_h[j], exp[j])
-        ids_equal &= bool([eng2orc.get(w, w) for w in ids_h] == list(exp))
+        ids_h = np.where(got < 0, int(first_all[t]) - got - 1, got).tolist()
+        ids_equal &= bool(ids_h == list(exp))                  # the reference's integers: no renumbering in between
         live = np.array(m.signature_ids(), np.int32)
         t3 = time.perf_counter()
         oi, Lo = m.compute_likelihood(np.array(exp, np.int32), live)
@@ -401,7 +415,8 @@ def parity_block(torch, vocab, words, frames_np, m, n_frames=3):
         m.forget(t + 1)
     rows, live_rows = eng.vocab_count()
     eng.close()
-    return ({"frames": n_frames, "word_ids_equal": ids_equal, "likelihood_max_rel": max_rel, "likelihood_values_compared": n_cmp,
+    return ({"frames": n_frames, "word_ids_equal": ids_equal, "new_word_ids": "numbered on the device as ++_lastWordId does (LCD_NEW_WORD_IDS_AUTO); compared as they are",
+             "likelihood_max_rel": max_rel, "likelihood_values_compared": n_cmp,
              "argmax_equal": argmax_equal, "bound": "1e-4 relative (abs floor 1e-7)", "signatures": n_sig,
              "vocabulary_rows_after": int(rows), "oracle_words_after": len(m.vwd.word_ids()),
              "path": "lcd_frame_dev (registration + retirement + update()'s append on the device + TF-IDF, pipelined handle, frames enqueued "
@@ -416,13 +431,14 @@ def timed_engine_parity(m, step, frames_np, like_last, n_sig):
     the timed engine left for that frame: the inverted index after hundreds of registrations, retirements, reserved and recycled
     postings keys, pipelined launches.  (Word assignment itself is checked by parity_block on a fresh engine: the oracle's exact
     2-NN of hundreds of frames would take minutes.)"""
-    T = len(step.first_new_log)
+    T = min(step.n_calls, step.d_words_log.shape[0])
     got = step.d_words_log[:T].cpu().numpy()
+    first_new_log = step.d_first_log[:T].cpu().numpy().tolist() if step.auto_ids else [N_WORDS + 1 + i * Q for i in range(T)]
     nf = len(frames_np)
     t0 = time.perf_counter()
     for i in range(T):
         codes = got[i]
-        ids = np.where(codes < 0, step.first_new_log[i] - codes - 1, codes).astype(np.int32)
+        ids = np.where(codes < 0, first_new_log[i] - codes - 1, codes).astype(np.int32)
         seen = set()
         for j in np.flatnonzero(codes < 0).tolist():
             if codes[j] not in seen:                                   # the first descriptor with the code created the word
@@ -768,8 +784,9 @@ def run_orb_stream(args):
     cap = n_frames + 64
     d_words = torch.zeros((n_frames, q), dtype=torch.int32, device="cuda")
     d_like = torch.zeros(cap, dtype=torch.float32, device="cuda")
+    d_first = torch.zeros(n_frames, dtype=torch.int32, device="cuda")     # the id of every frame's first new word, as the device numbered it
     torch.cuda.synchronize()
-    base_ptr, words_ptr = d_frames.data_ptr(), d_words.data_ptr()
+    base_ptr, words_ptr, first_ptr = d_frames.data_ptr(), d_words.data_ptr(), d_first.data_ptr()
     a = eng.frame_args(q=q, flags=3, nndr_ratio=NNDR, d_likelihood=d_like.data_ptr(), likelihood_capacity=cap, append_new_words=1)
     n_prof = 40
     T0 = max(n_frames - n_tail, 0)                                 # the frames from T0 on run one by one next to the oracle
@@ -778,7 +795,8 @@ def run_orb_stream(args):
         a.d_descriptors = base_ptr + t * q * 32
         a.d_word_ids = words_ptr + t * q * 4
         a.sig_id = t + 1
-        a.first_new_word_id = 1 + t * q                      # an upper bound per frame: nothing is read back (ids only have to ascend)
+        a.first_new_word_id = LCD_NEW_WORD_IDS_AUTO          # nothing is read back: the device numbers the words as ++_lastWordId does (VWDictionary.cpp:1188)
+        a.d_first_new_word_id = first_ptr + t * 4
         a.N = float(min(t + 1, W + 1))                      # Memory::getSignatures().size() with the new signature in it (Memory.cpp:2248)
         eng.frame_dev_args(a)
         if t + 1 > W:
@@ -805,17 +823,20 @@ def run_orb_stream(args):
     scan_ms, scan_n, scan_name = eng.profile_read()
     rows, live = eng.vocab_count()
     got = d_words.cpu().numpy()
+    first = d_first.cpu().numpy()
 
     def eng_ids(t, codes):
-        return np.where(codes < 0, 1 + t * q - codes - 1, codes)
+        return np.where(codes < 0, int(first[t]) - codes - 1, codes)
     # ---- parity, head of the stream: the first frames against an oracle that starts empty (it assigns consecutive ids: compare the
     # canonical form -- every word replaced by the position of its first occurrence in the stream)
     o = O.OracleMemory(strategy=O.kNNBruteForce, nndr=NNDR, new_words_compared_together=True)
     canon_o, canon_h, first_o, first_h, exp_lists = [], [], {}, {}, []
+    ids_identical = True                                          # ... and, the words being numbered on the device, the very integers
     for t in range(min(n_check, T0)):
         so, ido = o.update(frames[t])
         exp_lists.append(ido)
         ids_h = eng_ids(t, got[t]).tolist()
+        ids_identical &= bool(ids_h == list(ido))
         for k, (wo, wh) in enumerate(zip(ido, ids_h)):
             canon_o.append(first_o.setdefault(wo, len(first_o)))
             canon_h.append(first_h.setdefault(wh, len(first_h)))
@@ -835,15 +856,17 @@ def run_orb_stream(args):
         tail_state_ok &= bool(set(w.tolist()) <= known)           # a live signature's words are rows of the vocabulary
         assert o2.add_signature_with_id(sid, w) == sid
     tail_state_ok &= not o2.vwd.get_unused_word_ids()            # the device-side cleans left no live row without a reference
-    tail_ids_equal, tail_max_rel, tail_n, eng2orc, t_knn_tail = True, 0.0, 0, {}, 0.0
+    tail_ids_equal, tail_max_rel, tail_n, eng2orc, t_knn_tail, tail_identical = True, 0.0, 0, {}, 0.0, True
     for t in range(T0, n_frames):
         one(t)
         eng.synchronize()
         codes = d_words[t].cpu().numpy()
+        first[t] = int(d_first[t].item())
         t1 = time.perf_counter()
         so, ido = o2.update(frames[t])
         t_knn_tail += time.perf_counter() - t1
         ids_h = eng_ids(t, codes).tolist()
+        tail_identical &= bool(ids_h == list(ido))
         for j in np.flatnonzero(codes < 0).tolist():
             eng2orc.setdefault(ids_h[j], ido[j])
         tail_ids_equal &= bool(so == t + 1 and [eng2orc.get(w, w) for w in ids_h] == list(ido))
@@ -895,9 +918,10 @@ def run_orb_stream(args):
                             "sample": "2 frames x exact Hamming 2-NN over the final %d-row vocabulary (%.0f ms/frame) + restated std::map TF-IDF "
                                       "scaled to %d signatures (%.1f ms/frame)" % (rows, 1e3 * t_knn, cand, 1e3 * t_lik)},
            "parity": {"frames_checked": list(range(min(n_check, T0))) [:3] + ["...", min(n_check, T0) - 1] + list(range(T0, n_frames)),
-                      "head": {"frames": [0, min(n_check, T0) - 1], "word_ids_equal": bool(ids_equal)},
+                      "new_word_ids": "numbered on the device as ++_lastWordId does (LCD_NEW_WORD_IDS_AUTO); word_ids_identical_integers compares them as they are",
+                      "head": {"frames": [0, min(n_check, T0) - 1], "word_ids_equal": bool(ids_equal), "word_ids_identical_integers": bool(ids_identical)},
                       "tail": {"frames": [T0, n_frames - 1], "dictionary_words": int(live), "retirements_before": max(T0 - W, 0),
-                               "state_consistent": bool(tail_state_ok), "word_ids_equal": bool(tail_ids_equal),
+                               "state_consistent": bool(tail_state_ok), "word_ids_equal": bool(tail_ids_equal), "word_ids_identical_integers": bool(tail_identical),
                                "likelihood_max_rel": tail_max_rel, "likelihood_values_compared": tail_n,
                                "oracle_ms_per_frame": 1e3 * t_knn_tail / max(n_frames - T0, 1)},
                       "word_ids_equal": bool(ids_equal and tail_ids_equal and tail_state_ok),
@@ -969,16 +993,16 @@ def run_replay(args):
     d_like = torch.zeros((depth, cap), dtype=torch.float32, device="cuda")
     d_like_s = [torch.zeros(t + 2, dtype=torch.float32, device="cuda") for t in sample_t]
     d_hyp = torch.zeros((n_total, 8), dtype=torch.int32, device="cuda")             # adjustLikelihood's record of EVERY frame (32 B)
+    d_first = torch.zeros(n_total, dtype=torch.int32, device="cuda")                # the id of every frame's first new word, as the device numbered it
     torch.cuda.synchronize()
     a = eng.frame_args(q=q, flags=3, nndr_ratio=NNDR, exclude_recent=stm, append_new_words=1)
-    pool_ptr, wp, lp, hp = d_pool.data_ptr(), d_words.data_ptr(), d_like.data_ptr(), d_hyp.data_ptr()
+    pool_ptr, wp, lp, hp, fp = d_pool.data_ptr(), d_words.data_ptr(), d_like.data_ptr(), d_hyp.data_ptr(), d_first.data_ptr()
+    eng.set_option("next_word_id", N_WORDS + 1)                                     # VWDictionary::_lastWordId + 1
     n_prof = 40
 
     def frame_index(t):
         return ((t // P) % V) * P + (t % P)
-    # word ids: frame t may create the ids [first, first + id_stride).  q per frame when that fits below the engine's 2^28 ids; a replay of
-    # 10^6 frames gets the largest stride that does (268) -- checked against the logged codes afterwards: no frame created more
-    id_stride = min(q, ((1 << 28) - N_WORDS - 2 - q) // max(n_total, 1))
+    # word ids: numbered on the device as ++_lastWordId numbers them (LCD_NEW_WORD_IDS_AUTO; VWDictionary.cpp:1188) -- nothing is read back between frames
     t_start = time.perf_counter()
     marks = {}
     for t in range(n_total):
@@ -988,7 +1012,8 @@ def run_replay(args):
         a.d_descriptors = pool_ptr + frame_index(t) * q * DIM * 4
         a.sig_id = t + 1
         a.N = float(t + 1)
-        a.first_new_word_id = N_WORDS + 1 + t * id_stride        # an upper bound per frame: nothing is read back
+        a.first_new_word_id = LCD_NEW_WORD_IDS_AUTO
+        a.d_first_new_word_id = fp + t * 4
         a.d_word_ids = wp + t * q * 4
         k = sample_slot.get(t)
         if k is not None:
@@ -1023,9 +1048,9 @@ def run_replay(args):
     # ---- parity on the sampled frames
     t_par = time.perf_counter()
     log = d_words.cpu().numpy()                                                    # [n_total, q] codes: > 0 word id, < 0 the frame's -(k+1)-th new word
-    first_new = N_WORDS + 1 + np.arange(n_total, dtype=np.int64) * id_stride
-    if int(-log.min()) > id_stride:
-        raise SystemExit("replay: a frame created %d words, more than the id stride %d of this run" % (int(-log.min()), id_stride))
+    first_new = d_first.cpu().numpy().astype(np.int64)
+    n_new_frame = np.where((log < 0).any(axis=1), -log.min(axis=1), 0)
+    ids_consecutive = bool(first_new[0] == N_WORDS + 1 and np.array_equal(first_new[1:], first_new[:-1] + n_new_frame[:-1]))   # ++_lastWordId over the whole replay
     ids_log = np.where(log < 0, first_new[:, None] - log - 1, log).astype(np.int32)
     created_by = np.flatnonzero((log < 0).any(axis=1))                             # frames that created words (the first laps)
     o = O.OracleVWDictionary(strategy=O.kNNBruteForce, incremental=True, nndr=NNDR, new_words_compared_together=True)
@@ -1157,7 +1182,9 @@ def run_replay(args):
            "recall": {"frames_counted": int(valid.sum()), "loop_closures_found": int(hit.sum()), "recall": recall,
                       "mean_adjusted_likelihood_of_hits": float(adjusted[hit].mean()) if hit.any() else None,
                       "rule": "every frame from the second lap on: the best raw-likelihood candidate outside the newest %d signatures shows the frame's place" % stm},
-           "parity": {"frames_checked": checked, "word_ids_equal": bool(ids_equal), "likelihood_max_rel": max_rel, "likelihood_values_compared": n_cmp,
+           "parity": {"frames_checked": checked, "word_ids_equal": bool(ids_equal),
+                      "new_word_ids_consecutive_over_the_whole_replay": ids_consecutive,     # numbered on the device (LCD_NEW_WORD_IDS_AUTO) exactly as ++_lastWordId would: every frame's first id = the one before + the words that frame created
+                      "likelihood_max_rel": max_rel, "likelihood_values_compared": n_cmp,
                       "adjust_likelihood_and_best_candidate_ok": bool(hyp_ok and adj_ok), "best_candidate_equal_or_a_rounding_tie": bool(hyp_ok), "adjusted_value_ok": bool(adj_ok), "best_candidate_identical": hyp_same,
                       "best_candidate_a_rounding_tie": hyp_near, "bound": "1e-4 relative (abs floor 1e-7)",
                       "adjusted_value_max_rel_vs_reference_float_statistics": adj_rel_ref,
@@ -1236,13 +1263,7 @@ def run_replay_growing(args):
     place = np.minimum(place, ts // 2)
     d_place = torch.from_numpy(place).cuda()
     revisit = torch.from_numpy((ts % 2 == 1)).cuda()
-    # word ids: frame t may create the ids [first_new[t], first_new[t] + stride[t]): q for the first frames (an empty dictionary: nearly every
-    # descriptor is a new word), 192 once the world's words are in -- checked against the logged codes afterwards
-    early = min(n, 20000)
-    stride = np.where(ts < early, q, 192).astype(np.int64)
-    first_new = 1 + np.concatenate([[0], np.cumsum(stride)[:-1]])
-    if first_new[-1] + q >= (1 << 28):
-        raise SystemExit("replay_growing: word ids would pass 2^28")
+    # word ids: numbered on the device as ++_lastWordId numbers them (LCD_NEW_WORD_IDS_AUTO; VWDictionary.cpp:1188) -- nothing is read back between frames
     eng = rtabmap_amd.Engine("f32", DIM, vocab_capacity=max(1 << 16, min(2 * n, 1_400_000)), sig_capacity=n + 4096, stream=stream.cuda_stream, pipeline=1, knn_mode=KNN_MODE)
     cap = n + 64
     depth = eng.pipeline_depth() + 1
@@ -1255,11 +1276,12 @@ def run_replay_growing(args):
     d_like = torch.zeros((depth, cap), dtype=torch.float32, device="cuda")
     d_like_s = [torch.zeros(t + 2, dtype=torch.float32, device="cuda") for t in sample_t]
     d_hyp = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+    d_first = torch.zeros(n, dtype=torch.int32, device="cuda")                      # the id of every frame's first new word, as the device numbered it
     bufs = [torch.empty((B, q, DIM), dtype=torch.float32, device="cuda") for _ in range(2)]
     snap = {}
     torch.cuda.synchronize()
     a = eng.frame_args(q=q, flags=3, nndr_ratio=NNDR, exclude_recent=stm, append_new_words=1)
-    wp, lp, hp = d_words.data_ptr(), d_like.data_ptr(), d_hyp.data_ptr()
+    wp, lp, hp, fp = d_words.data_ptr(), d_like.data_ptr(), d_hyp.data_ptr(), d_first.data_ptr()
     n_prof = 40
     retired = 0
     paused = 0.0
@@ -1286,7 +1308,8 @@ def run_replay_growing(args):
         a.d_descriptors = bufs[b].data_ptr() + (t % B) * q * DIM * 4
         a.sig_id = t + 1
         a.N = float(t + 1 - retired)
-        a.first_new_word_id = int(first_new[t])
+        a.first_new_word_id = LCD_NEW_WORD_IDS_AUTO
+        a.d_first_new_word_id = fp + t * 4
         a.d_word_ids = wp + t * q * 4
         k = sample_slot.get(t)
         if k is not None:
@@ -1328,9 +1351,8 @@ def run_replay_growing(args):
     # ---- the word log
     log = d_words.cpu().numpy()
     n_new_frame = np.where((log < 0).any(axis=1), -log.min(axis=1), 0)
-    if (n_new_frame > stride).any():
-        bad = int(np.flatnonzero(n_new_frame > stride)[0])
-        raise SystemExit("replay_growing: frame %d created %d words, more than its id stride %d" % (bad, int(n_new_frame[bad]), int(stride[bad])))
+    first_new = d_first.cpu().numpy().astype(np.int64)
+    ids_consecutive = bool(first_new[0] == 1 and np.array_equal(first_new[1:], first_new[:-1] + n_new_frame[:-1]))   # ++_lastWordId over the whole replay: cleans, rebuilds, retirements included
     ids_log = np.where(log < 0, first_new[:, None] - log - 1, log).astype(np.int32)
     created = int(n_new_frame.sum())
     # ---- parity on the sampled frames
@@ -1444,7 +1466,9 @@ def run_replay_growing(args):
            "roofline_score": roof_score, "roofline_knn": roof_knn,
            "recall": {"revisits_counted": int(counted.sum()), "loop_closures_found": int(hit.sum()), "recall": recall,
                       "rule": "revisit frames whose place still has its first signature in memory, older than the newest %d: the best raw-likelihood candidate shows the frame's place" % stm},
-           "parity": {"frames_checked": checked, "word_ids_equal": bool(ids_equal), "likelihood_max_rel": max_rel, "likelihood_values_compared": n_cmp,
+           "parity": {"frames_checked": checked, "word_ids_equal": bool(ids_equal),
+                      "new_word_ids_consecutive_over_the_whole_replay": ids_consecutive,     # numbered on the device (LCD_NEW_WORD_IDS_AUTO) exactly as ++_lastWordId would: every frame's first id = the one before + the words that frame created
+                      "likelihood_max_rel": max_rel, "likelihood_values_compared": n_cmp,
                       "adjust_likelihood_and_best_candidate_ok": bool(hyp_ok and adj_ok), "best_candidate_equal_or_a_rounding_tie_and_retired_slots_zero": bool(hyp_ok), "adjusted_value_ok": bool(adj_ok), "best_candidate_identical": hyp_same, "best_candidate_a_rounding_tie": hyp_near,
                       "adjusted_value_max_rel_vs_reference_float_statistics": adj_rel_ref,
                       "adjusted_value_max_rel_vs_the_same_formula_with_double_statistics": adj_rel_exact,
@@ -1492,7 +1516,8 @@ def main():
                     help="the 2-NN filter of every SURF engine of the run (default: f16 = the one-product fp16 matrix-core filter, LCD_KNN_F16; "
                          "bf16 = the library's default, three bf16 products per fp32 product)")
     ap.add_argument("--diag", default="", help="diagnostics only (not the benchmark): comma list of no-new (new words get no references), "
-                    "no-retire (the oldest signature is not retired)")
+                    "no-retire (the oldest signature is not retired), bound-ids (the caller numbers new words with an upper bound per frame instead of "
+                    "the device numbering them as ++_lastWordId does)")
     args = ap.parse_args()
 
     if args.leg:
@@ -1816,7 +1841,7 @@ def main():
             m = build_oracle(vocab, words)
             par, t_lin_port, t_lik = parity_block(torch, vocab, words, frames_np, m)
             out["parity"] = par
-            if step.first_new_log:
+            if step.d_words_log is not None and step.n_calls:
                 m.close()
                 m = build_oracle(vocab, words)                       # a fresh memory: the replay starts where the timed engine started
                 out["parity"]["timed_engine"] = timed_engine_parity(m, step, frames_np, like, n_sig)

@@ -62,7 +62,7 @@ STANDINS = textwrap.dedent('''
 
     class FakeStepper:
         def __init__(self, eng, torch_, d_frames, n_sig_, cap, log_frames=0, append=True):
-            self.d_like, self.first_new_log = FakeLike(), None
+            self.d_like, self.d_words_log, self.n_calls = FakeLike(), None, 0
         def __call__(self, i): pass
 
     rtabmap_amd.Engine = FakeEngine
