@@ -717,7 +717,7 @@ def leg_parity(torch, vocab, words, frame):
             "likelihood_by": how, "oracle_seconds": {"addNewWords": t_knn, "computeLikelihood": t_lik}}
 
 
-def secondary_legs(budget_s=130.0):
+def secondary_legs(budget_s=165.0):
     """The other configurations as short runs of this same script, so that what profiles/ claims for them is observed by whoever runs the
     default command (the previous review's item 8): config 3 on 300 ORB frames, 125 000 words (one GPU's share of config 4) for 50 steps,
     10^6 signatures for 30 steps -- each with its own roofline and one frame of parity.  A leg that would not fit the time budget is skipped
@@ -727,7 +727,10 @@ def secondary_legs(budget_s=130.0):
     # take most of the last one; a slower host skips it and says so; LCD_BENCH_LEGS=all lifts the budget)
     legs = [("orb_stream_300_frames", ["--config", "orb_stream", "--steps", "300"], 15.0),
             ("words_125k", ["--words", "125000", "--steps", "50", "--warmup", "5", "--leg"], 35.0),
-            ("signatures_1m", ["--signatures", "1000000", "--steps", "30", "--warmup", "5", "--leg"], 70.0)]
+            ("signatures_1m", ["--signatures", "1000000", "--steps", "30", "--warmup", "5", "--leg"], 70.0),
+            # the config-5 stand-in whose dictionary grows from empty (update -> addNewWords -> computeLikelihood -> adjustLikelihood every frame, a clean every
+            # frame, retirements, rebuilds), 50 000 frames of the 10^6 of profiles/r06_bench_replay_growing_1m.json
+            ("replay_growing_50k_frames", ["--config", "replay_growing", "--signatures", "50000"], 30.0)]
     if os.environ.get("LCD_BENCH_LEGS", "") == "all":
         budget_s = 1200.0
     out = {"note": "short runs of `python bench.py <args>` by this run; the full-size lines are profiles/r06_bench_*.json"}
@@ -747,6 +750,8 @@ def secondary_legs(budget_s=130.0):
                 continue
             d = json.loads(lines[-1])
             keep = {k: d.get(k) for k in ("metric", "value", "unit", "steps", "ms_per_step", "roofline", "roofline_score", "roofline_knn", "parity")}
+            if d.get("recall") is not None:
+                keep["recall"] = d.get("recall")
             keep["command"] = "python bench.py " + " ".join(extra)
             keep["workload"] = d.get("config", {}).get("workload")
             keep["wall_s"] = time.perf_counter() - t0
