@@ -91,6 +91,7 @@ struct lcd_engine {
     // and catches up with the exact rows (h_row_key ...) the next time the handle is drained (reconcile()).
     static constexpr int VLOG = 4096;
     lcd::DevBuf d_vcnt;                                 // int32: [0], [1] row counters, [16 .. 16 + VLOG) rows appended by frame seq % VLOG
+    int64_t vocab_capacity_cfg = 0;                     // lcd_config.vocab_capacity: every per-row buffer is sized for it
     unsigned long long* h_vmirror = nullptr;            // pinned: (seq + 1) << 32 | rows after that frame's append
     struct DevAppend { uint64_t seq; int32_t first_id; int32_t q; bool enabled;
                        // sharded append (lcd_shard_frame_dev): the log holds the frame's TOTAL of new words, this rank owns the ids the rule gives it

@@ -95,6 +95,13 @@ inline hipError_t ring_reserve(lcd_engine* h, int own_set, DevBuf lcd_engine::Fr
     return hipSuccess;
 }
 
+// ... for a buffer whose size follows the vocabulary: `need` bytes now; when that takes a (re)allocation, `want` >= need bytes are asked for, so that the set does
+// not outgrow the buffer again a few frames later (a reallocation with frames in flight waits for the stream, and every set of the ring pays its own)
+inline hipError_t ring_reserve_grow(lcd_engine* h, int own_set, DevBuf lcd_engine::FrameScratch::*member, size_t need, size_t want) {
+    if ((h->ring[own_set].*member).cap >= need) return hipSuccess;
+    return ring_reserve(h, own_set, member, std::max(need, want));
+}
+
 // copy `rows` host rows (h->dim columns) into a device buffer laid out with h->row_bytes per row (u8 rows zero-padded)
 int upload_rows(lcd_engine* h, const void* rows, int n, DevBuf& dst) {
     const size_t bytes = (size_t)n * h->row_bytes;
@@ -455,6 +462,7 @@ int lcd_create(const lcd_config* cfg, lcd_engine** out) {
         h->own_stream = true;
     }
     const int64_t vcap = cfg->vocab_capacity > 0 ? cfg->vocab_capacity : 4096;
+    h->vocab_capacity_cfg = vcap;
     hipError_t e = h->vocab.reserve((size_t)vcap * h->row_bytes, 0, h->stream, &h->bytes_device);
     if (e == hipSuccess) e = h->row_id.reserve((size_t)vcap * 4, 0, h->stream, &h->bytes_device);
     if (e == hipSuccess) e = h->row_wslot.reserve((size_t)vcap * 4, 0, h->stream, &h->bytes_device);
@@ -609,7 +617,9 @@ int lcd_vocab_append(lcd_engine* h, const void* rows, int n, const int32_t* word
         LCD_HIP(h, launch_row_norms(h->vocab.p, h->row_id.as<int32_t>(), (int)h->n_rows, n, h->kdim, h->row_norm.as<float>(),
                                     h->norm_max.as<uint32_t>(), h->stream));
         if (knn_mfma_supported(h->dtype, h->kdim)) {   // hi/lo bf16 split of the new rows
-            LCD_HIP(h, dreserve(h, h->vocab_bf, (size_t)total * 256, (size_t)h->n_rows * 256));
+            // (for the capacity the caller configured, like the other row buffers: a stream of appending frames must not meet a reallocation -- 32 MB copied
+            // behind a synchronisation -- where this table alone was sized for the rows it was given: 125 000 rows fill a 32 MiB allocation to 131 072)
+            LCD_HIP(h, dreserve(h, h->vocab_bf, (size_t)std::max<int64_t>(total, h->vocab_capacity_cfg) * 256, (size_t)h->n_rows * 256));
             LCD_HIP(h, launch_vocab_bf16(h->vocab.p, (int)h->n_rows, n, h->kdim, h->vocab_bf.p, h->stream, h->f16()));
         }
     }
@@ -1352,11 +1362,21 @@ static int build_knn(lcd_engine* h, lcd_engine::InFlight& f, PipeKnn* kp, const 
     }
     {   // the candidate records: sized for this plan AND for the one the upper bound would get (a growing vocabulary crosses the planner's
         // thresholds: a reallocation drains the stream)
-        size_t bytes = knn_bf16_partial_bytes(k.plan);
-        if (f.chained) bytes = std::max(bytes, knn_bf16_partial_bytes(knn_bf16_plan_pipelined(q, (int)(rows_bound + 8 * (int64_t)q), together ? knn_selfdist_wgs(q) : 0, h->filter_units)));
-        LCD_HIP(h, ring_reserve(h, f.set, &lcd_engine::FrameScratch::d_partial2, bytes));
+        // ... and, when that takes an allocation, for a vocabulary half as large again: a set that outgrows its buffers while frames are in flight reallocates
+        // behind a synchronisation of the stream, and so does each of the other sets when its turn comes -- four stalls of ~0.24 ms in a row where
+        // 125 000 rows happen to fill their allocation (profiles/dead_ends_r06.txt 15)
+        size_t bytes = knn_bf16_partial_bytes(k.plan), want = 0;
+        if (f.chained) {
+            bytes = std::max(bytes, knn_bf16_partial_bytes(knn_bf16_plan_pipelined(q, (int)(rows_bound + 8 * (int64_t)q), together ? knn_selfdist_wgs(q) : 0, h->filter_units)));
+            want = knn_bf16_partial_bytes(knn_bf16_plan_pipelined(q, (int)std::min<int64_t>(rows_bound + rows_bound / 2 + 65536, 0x7FFFFF00ll), together ? knn_selfdist_wgs(q) : 0, h->filter_units));
+        }
+        LCD_HIP(h, ring_reserve_grow(h, f.set, &lcd_engine::FrameScratch::d_partial2, bytes, want));
     }
-    LCD_HIP(h, ring_reserve(h, f.set, &lcd_engine::FrameScratch::d_partial3, knn_rowpar_partial_bytes((int)(rows_bound + (f.chained ? 8 * (int64_t)q : 0)), q)));
+    {
+        const int64_t rows3 = rows_bound + (f.chained ? 8 * (int64_t)q : 0);
+        LCD_HIP(h, ring_reserve_grow(h, f.set, &lcd_engine::FrameScratch::d_partial3, knn_rowpar_partial_bytes((int)rows3, q),
+                                     f.chained ? knn_rowpar_partial_bytes((int)std::min<int64_t>(rows3 + rows3 / 2 + 65536, 0x7FFFFF00ll), q) : 0));
+    }
     k.vocab = h->vocab.p; k.vocab_bf = h->vocab_bf.p; k.row_norm = h->row_norm.as<float>(); k.norm_max_bits = h->norm_max.as<uint32_t>();
     k.row_id = h->row_id.as<int32_t>(); k.queries = a.d_descriptors; k.partial = sc.d_partial2.p;
     k.qsplit = sc.d_qsplit.p; k.qnorm = sc.d_qnorm.as<float>();
