@@ -124,7 +124,28 @@ def build_shard(force=False, verbose=False):
     return SHARD_OUT
 
 
+P2P_OUT = os.path.join(HERE, "liblcd_p2p.so")
+
+
+def build_p2p(force=False, verbose=False):
+    """The one-shot peer-to-peer exchanges of include/lcd_p2p.h (rtabmap_amd/csrc/p2p_exchange.hip): kernels + host code, HIP only."""
+    src = os.path.join(CSRC, "p2p_exchange.hip")
+    deps = [src, os.path.join(HERE, "..", "include", "lcd_p2p.h"), os.path.join(HERE, "..", "include", "lcd_shard.h")]
+    if not force and os.path.exists(P2P_OUT) and os.path.getmtime(P2P_OUT) >= max(os.path.getmtime(d) for d in deps):
+        return P2P_OUT
+    tmp = P2P_OUT + ".tmp.%d" % os.getpid()
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-shared", "-o", tmp, src]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("p2p library build failed:\n" + r.stdout)
+    os.replace(tmp, P2P_OUT)
+    return P2P_OUT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_host(force="--force" in sys.argv, verbose=True))
     print(build_shard(force="--force" in sys.argv, verbose=True))
+    print(build_p2p(force="--force" in sys.argv, verbose=True))

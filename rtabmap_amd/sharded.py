@@ -299,10 +299,93 @@ class HostStagedTransport:
             return 9
 
 
+_p2p_lib = None
+
+
+def load_p2p():
+    """liblcd_p2p.so: the one-shot peer-to-peer exchanges of include/lcd_p2p.h (rtabmap_amd/csrc/p2p_exchange.hip)."""
+    global _p2p_lib
+    if _p2p_lib is None:
+        import ctypes as C
+        from . import build as _b
+        L = C.CDLL(_b.build_p2p())
+        vp = C.c_void_p
+        L.lcd_p2p_create.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+        L.lcd_p2p_export.argtypes = [vp, vp]
+        L.lcd_p2p_connect.argtypes = [vp, vp]
+        L.lcd_p2p_destroy.argtypes = [vp]
+        L.lcd_p2p_destroy.restype = None
+        L.lcd_p2p_last_error.argtypes = [vp]
+        L.lcd_p2p_last_error.restype = C.c_char_p
+        L.lcd_p2p_set_wire.argtypes = [vp, C.c_int]
+        L.lcd_p2p_set_timeout_ms.argtypes = [vp, C.c_int64]
+        L.lcd_p2p_status.argtypes = [vp]
+        L.lcd_p2p_status.restype = C.c_uint32
+        L.lcd_p2p_clear_status.argtypes = [vp]
+        L.lcd_p2p_clear_status.restype = None
+        L.lcd_p2p_all_gather.argtypes = [vp, vp, vp, C.c_size_t, vp]
+        L.lcd_p2p_all_reduce_sum_i64.argtypes = [vp, vp, C.c_size_t, vp]
+        L.lcd_p2p_transport.argtypes = [vp, vp]
+        _p2p_lib = L
+    return _p2p_lib
+
+
+class P2PTransport:
+    """lcd_shard_transport over liblcd_p2p.so: kernels that write the peers' hipIpc-mapped arenas directly (the one-shot
+    reduce-scatter + all-gather next to RCCL).  The process group (any backend) carries the 128-byte exports once, at construction;
+    the per-frame exchanges never touch it.  Works between processes that share ONE GPU too (the test box)."""
+    HANDLE_BYTES = 128
+
+    def __init__(self, rank, world, gather_bytes_per_rank_max, reduce_count_max, group=None, wire="i64", timeout_ms=10000):
+        import ctypes as C
+        self.C, self.L, self.rank, self.world = C, load_p2p(), rank, world
+        h = C.c_void_p()
+        rc = self.L.lcd_p2p_create(rank, world, gather_bytes_per_rank_max, reduce_count_max, C.byref(h))
+        if rc != 0:
+            raise RuntimeError("lcd_p2p_create failed (%d)" % rc)
+        self.h = h
+        mine = (C.c_ubyte * self.HANDLE_BYTES)()
+        self._ck(self.L.lcd_p2p_export(h, mine), "lcd_p2p_export")
+        if world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, bytes(mine), group=group)
+            blob = b"".join(parts)
+            self._ck(self.L.lcd_p2p_connect(h, (C.c_ubyte * len(blob)).from_buffer_copy(blob)), "lcd_p2p_connect")
+        self.set_wire(wire)
+        self._ck(self.L.lcd_p2p_set_timeout_ms(h, timeout_ms), "lcd_p2p_set_timeout_ms")
+
+        class Transport(C.Structure):
+            _fields_ = [("struct_size", C.c_int32), ("reserved", C.c_int32), ("user", C.c_void_p), ("all_gather", C.c_void_p), ("all_reduce_sum_i64", C.c_void_p)]
+        self.struct = Transport()
+        self._ck(self.L.lcd_p2p_transport(h, C.byref(self.struct)), "lcd_p2p_transport")
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s: %s" % (what, self.L.lcd_p2p_last_error(self.h).decode()))
+
+    def set_wire(self, wire):
+        self._ck(self.L.lcd_p2p_set_wire(self.h, {"i64": 0, "f32": 1}[wire]), "lcd_p2p_set_wire")
+
+    def all_gather(self, d_send_ptr, d_recv_ptr, bytes_per_rank, stream=None):
+        self._ck(self.L.lcd_p2p_all_gather(self.h, d_send_ptr, d_recv_ptr, bytes_per_rank, stream), "lcd_p2p_all_gather")
+
+    def all_reduce_sum_i64(self, d_buf_ptr, count, stream=None):
+        self._ck(self.L.lcd_p2p_all_reduce_sum_i64(self.h, d_buf_ptr, count, stream), "lcd_p2p_all_reduce_sum_i64")
+
+    def status(self):
+        """LCD_P2P_TIMEOUT_* bits raised by completed kernels (0: every peer arrived in time)"""
+        return int(self.L.lcd_p2p_status(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lcd_p2p_destroy(self.h)
+            self.h = None
+
+
 class NativeShardComm:
     """One rank of the C++ driver around an Engine.  transport=None: RCCL -- the 128-byte RCCL id travels through torch.distributed (any
     backend) when world > 1, the only thing the process group is used for; the two per-frame exchanges are RCCL calls made by the C++ code.
-    transport=HostStagedTransport(...): the caller's exchanges (lcd_shard_comm_create_transport)."""
+    transport=HostStagedTransport(...) / P2PTransport(...): the caller's exchanges (lcd_shard_comm_create_transport)."""
 
     def __init__(self, eng, rank=0, world=1, group=None, transport=None):
         import ctypes as C

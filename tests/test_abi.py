@@ -34,6 +34,28 @@ def test_shard_driver_builds_and_exports_every_declared_symbol():
         assert hasattr(L, s), s
 
 
+def test_p2p_library_builds_and_exports_every_declared_symbol():
+    """liblcd_p2p.so (include/lcd_p2p.h): compiled for gfx950 here, every declared entry exported, the transport it hands out has the
+    layout lcd_shard_comm_create_transport checks, and without a device nothing is created (no host-staged fallback inside)."""
+    import ctypes as C
+    import torch
+    from rtabmap_amd import build as b
+    L = C.CDLL(b.build_p2p())
+    header = open(os.path.join(os.path.dirname(__file__), "..", "include", "lcd_p2p.h")).read()
+    declared = set(re.findall(r"\b(lcd_p2p_[a-z0-9_]+)\s*\(", header))
+    assert declared == {"lcd_p2p_create", "lcd_p2p_export", "lcd_p2p_connect", "lcd_p2p_destroy", "lcd_p2p_last_error", "lcd_p2p_set_wire",
+                        "lcd_p2p_set_timeout_ms", "lcd_p2p_status", "lcd_p2p_clear_status", "lcd_p2p_all_gather", "lcd_p2p_all_reduce_sum_i64",
+                        "lcd_p2p_transport"}
+    for s in declared:
+        assert hasattr(L, s), s
+    L.lcd_p2p_create.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
+    h = C.c_void_p()
+    assert L.lcd_p2p_create(2, 2, 1024, 1024, C.byref(h)) == 1 and not h.value          # rank outside the world: LCD_ERR_INVALID
+    assert L.lcd_p2p_create(0, 17, 1024, 1024, C.byref(h)) == 1 and not h.value
+    if not torch.cuda.is_available():
+        assert L.lcd_p2p_create(0, 1, 1024, 1024, C.byref(h)) != 0 and not h.value      # no device: an error, not a fallback
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -275,14 +275,15 @@ def test_native_rccl_driver_one_rank_equals_the_single_gpu_frame(oracle):
         e.close()
 
 
-def _native_worker(rank, world, port, out):
+def _native_worker(rank, world, port, out, kind="host"):
     """Two ranks on ONE GPU through the NATIVE driver (liblcd_shard.so): its exchanges go through the lcd_shard_transport callbacks
-    (host-staged gloo -- two processes on one GPU cannot talk RCCL to each other); everything else is the C++ code a multi-GPU node runs."""
+    (kind "host": host-staged gloo -- two processes on one GPU cannot talk RCCL to each other; kind "p2p": liblcd_p2p.so, kernels writing
+    the other process's hipIpc-mapped arena, nothing staged, nothing synchronised); everything else is the C++ code a multi-GPU node runs."""
     _init(rank, world, port)
     torch.cuda.set_device(0)
     import rtabmap_amd
     from rtabmap_amd import synth
-    from rtabmap_amd.sharded import NativeShardComm, HostStagedTransport, shard_bounds
+    from rtabmap_amd.sharded import NativeShardComm, HostStagedTransport, P2PTransport, shard_bounds
     n_words, n_sig, q, T = 6000, 700, 160, 9
     vocab = synth.vocab_surf(n_words)
     ids = np.arange(1, n_words + 1, dtype=np.int32)
@@ -306,10 +307,17 @@ def _native_worker(rank, world, port, out):
         return np.arange(first_new, first_new + n_new, dtype=np.int32), rows
 
     results = {}
-    for mode in ("last_rank", "deferred", "block_cyclic", "last_rank_dev", "block_cyclic_dev_deferred"):
+    modes = ("last_rank", "deferred", "block_cyclic", "last_rank_dev", "block_cyclic_dev_deferred") if kind == "host" else \
+            ("last_rank", "deferred", "block_cyclic_dev_deferred", "last_rank_f32wire", "block_cyclic_dev_deferred_f32wire")
+    for mode in modes:
         eng = rtabmap_amd.Engine("f32", 64, sig_capacity=n_sig + 64)
         load(eng, slice(lo, hi))
-        tr = HostStagedTransport()
+        f32wire = mode.endswith("_f32wire")
+        mode = mode.replace("_f32wire", "")
+        if kind == "host":
+            tr = HostStagedTransport()
+        else:
+            tr = P2PTransport(rank, world, q * 2 * 16, n_sig + 64 + 1, wire="f32" if f32wire else "i64", timeout_ms=20000)
         comm = NativeShardComm(eng, rank, world, transport=tr)
         if mode.startswith("block_cyclic"):
             comm.set_growth(n_words + 1, 16)
@@ -348,7 +356,10 @@ def _native_worker(rank, world, port, out):
             comm.flush()
             eng.synchronize()
             res.append((owed[0], d_l[(len(frames) - 1) & 1][: owed[1]].cpu().numpy().copy()))
-        assert tr.calls["all_gather"] == len(frames) and tr.calls["all_reduce"] == len(frames)
+        if kind == "host":
+            assert tr.calls["all_gather"] == len(frames) and tr.calls["all_reduce"] == len(frames)
+        else:
+            assert tr.status() == 0, "a peer-to-peer exchange timed out: status %d" % tr.status()
         rows_here, _ = eng.vocab_count()
         assert rows_here == my_rows
         if on_device and my_rows > hi - lo:
@@ -360,8 +371,11 @@ def _native_worker(rank, world, port, out):
         counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(counts, torch.tensor([my_rows - (hi - lo)], dtype=torch.int64))
         comm.close()
+        if kind != "host":
+            dist.barrier()                                           # no rank unmaps an arena a peer's kernel may still write
+            tr.close()
         eng.close()
-        results[mode] = (res, [int(c.item()) for c in counts])
+        results[mode + ("_f32wire" if f32wire else "")] = (res, [int(c.item()) for c in counts])
     if rank == 0:
         eng = rtabmap_amd.Engine("f32", 64, sig_capacity=n_sig + 64)
         load(eng, slice(0, n_words))
@@ -377,7 +391,12 @@ def _native_worker(rank, world, port, out):
             for mode, (res, _) in results.items():
                 if not np.array_equal(codes, res[t][0]):
                     ok = False; msgs.append("%s: word ids differ in frame %d" % (mode, t))
-                if res[t][1].shape != l1.shape or not np.array_equal(l1.view(np.uint32), res[t][1].view(np.uint32)):
+                if mode.endswith("_f32wire"):
+                    # the 32-bit float wire rounds each rank's partial sum once (2^-24) and their sum once more
+                    if res[t][1].shape != l1.shape or not np.allclose(res[t][1], l1, rtol=3e-7, atol=0.0) or \
+                            not np.array_equal(res[t][1] == 0, l1 == 0):
+                        ok = False; msgs.append("%s: likelihood beyond 3e-7 relative in frame %d" % (mode, t))
+                elif res[t][1].shape != l1.shape or not np.array_equal(l1.view(np.uint32), res[t][1].view(np.uint32)):
                     ok = False; msgs.append("%s: likelihood not bit-identical in frame %d" % (mode, t))
             if t == 3:
                 eng.sig_remove(3)
@@ -387,13 +406,14 @@ def _native_worker(rank, world, port, out):
             last_id += len(new_ids)
             created += len(new_ids)
         eng.close()
-        grown = results["block_cyclic"][1]
         if created < 200:
             ok = False; msgs.append("the stream created only %d words" % created)
-        for m_ in ("last_rank", "last_rank_dev"):
-            if results[m_][1] != [0, created]:
+        for m_ in ("last_rank", "last_rank_dev", "last_rank_f32wire"):
+            if m_ in results and results[m_][1] != [0, created]:
                 ok = False; msgs.append("%s ownership: growth %r" % (m_, results[m_][1]))
-        for m_ in ("block_cyclic", "block_cyclic_dev_deferred"):
+        for m_ in ("block_cyclic", "block_cyclic_dev_deferred", "block_cyclic_dev_deferred_f32wire"):
+            if m_ not in results:
+                continue
             grown = results[m_][1]
             if sum(grown) != created or abs(grown[0] - grown[1]) > 0.1 * created:
                 ok = False; msgs.append("%s growth is not balanced: %r of %d" % (m_, grown, created))
@@ -411,14 +431,34 @@ def test_native_driver_two_ranks_deferred_and_balanced_growth():
     its shard from the replicated decision, no lcd_vocab_append in the loop; last-rank and block-cyclic + deferred) -- each bit
     for bit the single-GPU engine's word ids and likelihood over a stream whose created words are indexed and matched again; with
     block-cyclic ownership both ranks grow by the same number of rows (within 10 %), with the default all growth lands on the last rank."""
+    _run_native("host")
+
+
+def _run_native(kind):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_native_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_native_worker, args=(r, 2, port, out, kind)) for r in range(2)]
     for p in procs:
         p.start()
-    ok, msgs = out.get(timeout=900)
+    try:
+        ok, msgs = out.get(timeout=900)
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
     for p in procs:
-        p.join(timeout=120)
         assert p.exitcode == 0
     assert ok, msgs
+
+
+@pytest.mark.gpu
+def test_native_driver_two_ranks_over_the_peer_to_peer_transport():
+    """The same two ranks with liblcd_p2p.so as the driver's transport (include/lcd_p2p.h): the all-gather of the candidate records and the
+    all-reduce of the partial likelihood are kernels that write the OTHER process's arena through hipIpc -- no host staging, no stream
+    synchronisation, the deferred all-reduce on the driver's second stream beside the next frame's all-gather.  64-bit integer wire: word
+    ids and likelihood bit for bit the single-GPU engine's (in-order, deferred, block-cyclic growth with update() on the device);
+    32-bit float wire (half the bytes): the same word ids, the likelihood within 3e-7 relative, zeros exactly where the engine has zeros.
+    No exchange may have timed out (lcd_p2p_status == 0)."""
+    _run_native("p2p")
