@@ -717,6 +717,26 @@ def leg_parity(torch, vocab, words, frame):
             "likelihood_by": how, "oracle_seconds": {"addNewWords": t_knn, "computeLikelihood": t_lik}}
 
 
+def p2p_exchange_leg():
+    """The sharded frame's two exchanges through liblcd_p2p.so (include/lcd_p2p.h) between TWO processes sharing this GPU -- the only
+    multi-rank configuration a one-GPU box has: the arenas are mapped through hipIpc exactly as between two GPUs, the wire is local HBM
+    instead of xGMI.  Microseconds per exchange, enqueued back to back (tools/p2p_bench.py); ~10 s."""
+    import subprocess
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "p2p_bench.py"), "--iters", "200"], cwd=ROOT, stdout=subprocess.PIPE,
+                           stderr=subprocess.DEVNULL, timeout=90.0, text=True)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "exit code %d" % r.returncode}
+        d = json.loads(lines[-1])
+        d["command"] = "python tools/p2p_bench.py --iters 200"
+        d["wall_s"] = time.perf_counter() - t0
+        return d
+    except Exception as e:                                        # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def secondary_legs(budget_s=165.0):
     """The other configurations as short runs of this same script, so that what profiles/ claims for them is observed by whoever runs the
     default command (the previous review's item 8): config 3 on 300 ORB frames, 125 000 words (one GPU's share of config 4) for 50 steps,
@@ -734,6 +754,7 @@ def secondary_legs(budget_s=165.0):
     if os.environ.get("LCD_BENCH_LEGS", "") == "all":
         budget_s = 1200.0
     out = {"note": "short runs of `python bench.py <args>` by this run; the full-size lines are profiles/r06_bench_*.json"}
+    out["p2p_exchange_two_ranks_one_gpu"] = p2p_exchange_leg()
     t_start = time.perf_counter()
     for name, extra, expect in legs:
         left = budget_s - (time.perf_counter() - t_start)
@@ -1515,6 +1536,9 @@ def main():
                          "GPU (weak scaling, no data-path collective).  auto: the shard from 100 000 words per GPU up (config 4: 1M words "
                          "over 8 GPUs), replicas below (a 49k-word vocabulary is 12.5 MB: sharding it only adds two exchanges per frame); "
                          "the other one is measured in the same run as a secondary key")
+    ap.add_argument("--exchange", choices=["rccl", "p2p", "p2p-f32"], default="rccl",
+                    help="the two per-frame exchanges of the sharded frame (N > 1): RCCL calls on the process group, or liblcd_p2p.so's one-shot "
+                         "peer-to-peer kernels over hipIpc-mapped arenas (include/lcd_p2p.h; p2p-f32: the all-reduce moves 32-bit floats)")
     ap.add_argument("--config", choices=["headline", "orb_stream", "replay", "replay_growing"], default="headline")
     ap.add_argument("--score-block", type=int, default=0, help="experiment: threads per workgroup of the scoring kernel (256/512/1024)")
     ap.add_argument("--knn-mode", default=None, choices=["bf16", "f16", "mfma32", "valu"],
@@ -1589,6 +1613,8 @@ def main():
         sh = ShardedLoopClosure("f32", DIM, rank=rank, world=world, device=local, stream=stream, vocab_capacity=N_WORDS + 65536,
                                 sig_capacity=n_sig + 8192, knn_mode=KNN_MODE)
         sh.force_sharded_path = bool(force_path)
+        if world > 1 and args.exchange != "rccl":
+            sh.enable_p2p(Q, n_sig + 8192, wire="f32" if args.exchange == "p2p-f32" else "i64")
         t0 = time.perf_counter()
         sh.load_vocabulary(vocab, np.arange(1, N_WORDS + 1, dtype=np.int32))
         w = words.reshape(-1)
@@ -1668,7 +1694,8 @@ def main():
                           "of t-2 + registration of t-3; B: re-rank of frame t-1 + scoring of t-3), one stream; the step includes VWDictionary::update()'s append branch on the device (append_new_words): the vocabulary "
                           "grows by the frame's new words before the next frame is searched" if (args.pipeline and not shard) else "4 launches per frame, one stream",
               "parallelism": ("vocabulary sharded by word-id range over %d GPUs (all-gather top-2 + int64 all-reduce per frame, the all-reduce "
-                              "overlapped with the next frame's search)" % world) if shard
+                              "overlapped with the next frame's search; exchanges: %s)" % (world, {"rccl": "RCCL", "p2p": "liblcd_p2p.so, 64-bit integer wire",
+                                                                                                  "p2p-f32": "liblcd_p2p.so, 32-bit float wire"}[args.exchange])) if shard
               else ("%d independent replicas (one frame stream per GPU, no data-path collective)" % world if world > 1 else "1 GPU")}
 
     if not shard:

@@ -54,6 +54,15 @@ class ShardedLoopClosure:
         self._retire_q = []              # retirements asked for while a likelihood is owed
         self._n_frames = 0
         self._owed_single = None
+        self.p2p = None                  # P2PTransport: the exchanges as liblcd_p2p.so's kernels instead of the process group's calls
+
+    def enable_p2p(self, q_max, slots_max, wire="i64", timeout_ms=10000):
+        """The two per-frame exchanges through liblcd_p2p.so (include/lcd_p2p.h): kernels that write the peers' hipIpc-mapped arenas, enqueued
+        on the engine's stream (the deferred all-reduce on the second one) -- no RCCL call, no host staging.  Every rank calls it, with the
+        same capacities (frames of at most q_max descriptors, at most slots_max signature slots), before the first frame; the process
+        group carries the 128-byte exports once.  wire "f32": the all-reduce moves 32-bit floats (half the bytes, rank-ordered sums)."""
+        if self.world > 1:
+            self.p2p = P2PTransport(self.rank, self.world, int(q_max) * 2 * 16, int(slots_max) + 2, group=self.group, wire=wire, timeout_ms=timeout_ms)
 
     # ---- state
     def load_vocabulary(self, rows, word_ids):
@@ -117,6 +126,8 @@ class ShardedLoopClosure:
     def _all_gather(self, out, inp):
         if self.world == 1:
             out.copy_(inp.reshape(out.shape))
+        elif getattr(self, "p2p", None) is not None:
+            self.p2p.all_gather(inp.data_ptr(), out.data_ptr(), inp.numel() * inp.element_size(), torch.cuda.current_stream(self.device).cuda_stream)
         elif self.backend == "nccl":
             dist.all_gather_into_tensor(out, inp, group=self.group)
         else:
@@ -128,7 +139,9 @@ class ShardedLoopClosure:
     def _all_reduce_sum(self, t, stream=None):
         if self.world == 1:
             return
-        if self.backend == "nccl":
+        if getattr(self, "p2p", None) is not None:
+            self.p2p.all_reduce_sum_i64(t.data_ptr(), t.numel(), torch.cuda.current_stream(self.device).cuda_stream)
+        elif self.backend == "nccl":
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         else:
             (stream or self.stream).synchronize()
@@ -212,6 +225,11 @@ class ShardedLoopClosure:
         return words[:q], prev
 
     def close(self):
+        if getattr(self, "p2p", None) is not None:
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)                    # no rank unmaps an arena a peer's kernel may still write
+            self.p2p.close()
+            self.p2p = None
         self.eng.close()
 
 

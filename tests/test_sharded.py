@@ -157,8 +157,12 @@ def _gpu_worker(rank, world, port, out):
     sig_ids = np.arange(1, n_sig + 1, dtype=np.int32)
     offsets = np.arange(0, (n_sig + 1) * q, q, dtype=np.int64)
     runs = {}
-    for defer in (False, True):
+    for defer in (False, True, "p2p", "p2p deferred"):
+        exchange_p2p = isinstance(defer, str)
+        defer = defer in (True, "p2p deferred")
         sh = ShardedLoopClosure("f32", 64, rank=rank, world=world, device=0, stream=torch.cuda.Stream())
+        if exchange_p2p:
+            sh.enable_p2p(q, n_sig + 16, timeout_ms=20000)          # liblcd_p2p.so instead of the host-staged gloo exchanges
         sh.load_vocabulary(vocab, ids)
         sh.add_signatures_bulk(sig_ids, offsets, words.reshape(-1))
         res = []
@@ -187,8 +191,10 @@ def _gpu_worker(rank, world, port, out):
             likes.append(sh.flush().cpu().numpy().copy())
             assert sh.flush() is None
             res = list(zip(ws, likes))
+        if exchange_p2p:
+            assert sh.p2p.status() == 0
         sh.close()
-        runs[defer] = res
+        runs[("p2p deferred" if defer else "p2p") if exchange_p2p else defer] = res
     if rank == 0:
         # single-GPU engine on the same inputs
         eng = rtabmap_amd.Engine("f32", 64)
@@ -207,7 +213,7 @@ def _gpu_worker(rank, world, port, out):
             n = n_sig + 1 + t
             w1, l1 = d_words.cpu().numpy(), d_like[:n].cpu().numpy()
             for defer, res in runs.items():
-                tag = " (deferred all-reduce)" if defer else ""
+                tag = " (%s)" % ("deferred all-reduce" if defer is True else defer) if defer else ""
                 if not np.array_equal(w1, res[t][0]):
                     ok = False; msgs.append("word ids differ in frame %d%s" % (t, tag))
                 if res[t][1].shape != l1.shape or not np.array_equal(l1.view(np.uint32), res[t][1].view(np.uint32)):
