@@ -1638,6 +1638,36 @@ def main():
         sh.close()
         return res, roofs, like, build_s, src
 
+    def run_shard_native_world1():
+        """The same sharded stages driven by the C++ driver of include/lcd_shard.h (liblcd_shard.so: lcd_shard_frame_deferred +
+        lcd_shard_sig_remove per step, update()'s append on the device), ONE rank, no exchange: what a C++ caller's rank pays without the
+        wire and without this script's Python between the stages."""
+        from rtabmap_amd.sharded import NativeShardComm
+        _, frames_np = make_frames(0)
+        d_frames = [torch.from_numpy(f).cuda() for f in frames_np]
+        e = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 65536, sig_capacity=n_sig + 8192, stream=stream.cuda_stream,
+                               knn_mode=KNN_MODE)
+        load_engine(e, vocab, words)
+        comm = NativeShardComm(e, 0, 1)
+        comm.set_growth(N_WORDS + 1, 16)
+        comm.set_append(True)
+        capl = n_sig + 8192
+        d_w = torch.zeros(Q, dtype=torch.int32, device="cuda")
+        d_l = [torch.zeros(capl, dtype=torch.float32, device="cuda") for _ in range(2)]
+        st = {"next": n_sig + 1, "old": 1, "first_new": N_WORDS + 1, "k": 0}
+
+        def step(i):
+            comm.frame(d_frames[i % n_frames].data_ptr(), Q, st["next"], float(n_sig + 1), N_WORDS, d_w.data_ptr(), d_l[st["k"] & 1].data_ptr(), capl,
+                       nndr=NNDR, first_new_word_id=st["first_new"], defer=True)
+            comm.sig_remove(st["old"])
+            st["next"] += 1; st["old"] += 1; st["first_new"] += Q; st["k"] += 1
+        res = timed_loop(torch, dist, 1, stream, step, args.steps, args.warmup)
+        comm.flush()
+        e.synchronize()
+        comm.close()
+        e.close()
+        return res
+
     results = {}
     # ---- primary measurement
     if shard:
@@ -1845,6 +1875,14 @@ def main():
                                                      "synchronisation (row mirror) per frame; to be read against ms_per_step (the fused, pipelined single-GPU frame)"
             except Exception as e:                                # noqa: BLE001
                 config["shard_stages_world1_error"] = "%s: %s" % (type(e).__name__, e)
+            try:
+                rn = run_shard_native_world1()
+                config["shard_stages_world1_native_ms_per_step"] = 1e3 * rn["wall"] / args.steps
+                config["shard_stages_world1_native_note"] = "the same stages through liblcd_shard.so (lcd_shard_frame_deferred + lcd_shard_sig_remove per step): the C++ " \
+                                                            "driver a multi-GPU caller links, one rank, no exchange; shard_stages_world1_ms_per_step drives them from " \
+                                                            "Python (torch stream contexts and events between the stages) and is bound by that host code"
+            except Exception as e:                                # noqa: BLE001
+                config["shard_stages_world1_native_error"] = "%s: %s" % (type(e).__name__, e)
             engu.close()
             engb = rtabmap_amd.Engine("f32", DIM, device=local, vocab_capacity=N_WORDS + 4096, sig_capacity=n_sig + 8192,
                                       stream=stream.cuda_stream, pipeline=args.pipeline, knn_mode=KNN_MODE)

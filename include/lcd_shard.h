@@ -28,8 +28,8 @@ typedef struct lcd_shard_comm lcd_shard_comm;
 int lcd_shard_unique_id(unsigned char out128[128]);
 /* rank `rank` of `world` (1..64) around an existing engine of that rank's GPU; world == 1 needs no id (may be NULL) and no RCCL call */
 int lcd_shard_comm_create(lcd_engine* engine, int rank, int world, const unsigned char id128[128], lcd_shard_comm** out);
-/* The same driver over exchanges the CALLER provides instead of RCCL (a fabric RCCL does not cover; the 2-rank tests of this repo, whose
- * box has one GPU, stage them through the host).  Both callbacks work on DEVICE buffers of this rank and must be ordered like a RCCL call
+/* The same driver over exchanges the CALLER provides instead of RCCL (a fabric RCCL does not cover; include/lcd_p2p.h fills this struct with
+ * its one-shot peer-to-peer kernels: lcd_p2p_transport; the 2-rank tests of this repo, whose box has one GPU, also stage them through the host).  Both callbacks work on DEVICE buffers of this rank and must be ordered like a RCCL call
  * on `stream`: behind the work already enqueued there, in front of what is enqueued after they return (completing before they return
  * is one way to do that).  Return 0 on success. */
 typedef struct lcd_shard_transport {
