@@ -2223,6 +2223,10 @@ hipError_t launch_norm_tombstone(float* norm, const int32_t* rows, int n, hipStr
     return hipGetLastError();
 }
 
+__global__ void fail_count_reset_kernel(int32_t* __restrict__ fail_count) {
+    if (threadIdx.x < 4 && threadIdx.x != 2) fail_count[threadIdx.x] = 0;
+}
+
 hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, const uint32_t* norm_max_bits, const int32_t* row_id,
                            const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist,
                            int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, bool reset_count,
@@ -2232,11 +2236,11 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
     uint32_t* pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * MF_KEEP * p.qpad);
     hipError_t e = hipSuccess;
     if (reset_count) {   // [0] rejected queries, [1] arrival counter of the row-parallel redo (the fused frame tail leaves them zeroed)
-        e = hipMemsetAsync(fail_count, 0, 8, s);
-        if (e != hipSuccess) return e;
-        // ... and the "redo done" flag: a stand-alone redo (knn_rowpar_kernel) leaves it raised, and the decision workgroup of a fused frame
-        // tail that found it raised would not wait for ITS redo ([2], the running maximum of the error ratio, stays)
-        e = hipMemsetAsync(fail_count + 3, 0, 4, s);
+        // ... and [3], the "redo done" flag: a stand-alone redo (knn_rowpar_kernel) leaves it raised, and the decision workgroup of a fused frame
+        // tail that found it raised would not wait for ITS redo ([2], the running maximum of the error ratio, stays).  One launch for the
+        // three words (two hipMemsetAsync calls were two fill kernels in front of every stand-alone search)
+        fail_count_reset_kernel<<<1, 64, 0, s>>>(fail_count);
+        e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     if (p.n_blocks > 0) {
@@ -2356,11 +2360,11 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
     uint32_t* pl = (uint32_t*)(pk + (size_t)(p.n_blocks > 0 ? p.n_blocks : 1) * BF_KEEP * p.qpad);
     hipError_t e = hipSuccess;
     if (reset_count) {
-        e = hipMemsetAsync(fail_count, 0, 8, s);
-        if (e != hipSuccess) return e;
-        // ... and the "redo done" flag: a stand-alone redo (knn_rowpar_kernel) leaves it raised, and the decision workgroup of a fused frame
-        // tail that found it raised would not wait for ITS redo ([2], the running maximum of the error ratio, stays)
-        e = hipMemsetAsync(fail_count + 3, 0, 4, s);
+        // ... and [3], the "redo done" flag: a stand-alone redo (knn_rowpar_kernel) leaves it raised, and the decision workgroup of a fused frame
+        // tail that found it raised would not wait for ITS redo ([2], the running maximum of the error ratio, stays).  One launch for the
+        // three words (two hipMemsetAsync calls were two fill kernels in front of every stand-alone search)
+        fail_count_reset_kernel<<<1, 64, 0, s>>>(fail_count);
+        e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     if (p.n_blocks > 0) {
