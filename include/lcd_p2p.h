@@ -19,6 +19,9 @@
  * Setup: every rank calls lcd_p2p_create with the SAME capacities, exports LCD_P2P_HANDLE_BYTES, the caller carries the world's exports
  * to every rank by whatever it has (MPI, torch.distributed, a file), lcd_p2p_connect maps them.  Ranks of one process (several GPUs
  * driven by one host thread each) connect through the raw pointers in the export instead of hipIpc.
+ * Lifetime: a rank destroys its lcd_p2p only after EVERY rank has completed its exchanges (a barrier of the caller's: a peer's kernel may still be
+ * writing this rank's arena).  After a time-out the result of that exchange is undefined on the rank that gave up (its buffer holds whatever lay in
+ * the arena); the ranks are in step again as soon as every rank has made the call -- epochs are counted per call, not per success.
  * Ordering contract: every rank makes the same calls in the same order; all-gathers are enqueued on ONE stream per rank; all-reduces are
  * ordered among themselves (the driver of lcd_shard.h does both) -- an all-gather may run beside an all-reduce (separate flags and memory).
  * extern "C", plain pointers and sizes, the status codes of lcd.h; nothing throws across the boundary. */
