@@ -89,28 +89,28 @@ def _p2p_worker(rank, world, port, out):
             msgs.append("concurrent all-reduce %d" % k)
     if tr.status() != 0:
         msgs.append("status %d after the exchanges that must all arrive" % tr.status())
-    # (4) rank 1 arrives 1.5 s late to an all-gather rank 0 waits 300 ms for: rank 0's kernel ends with LCD_P2P_TIMEOUT_GATHER (and whatever
-    #     lay in its mailbox), rank 1 finds rank 0's block already there; the next exchange is in step again
+    # (4) the last rank arrives 1.5 s late to an all-gather the others wait 300 ms for: their kernels end with LCD_P2P_TIMEOUT_GATHER (and
+    #     whatever lay in the mailbox), the late rank finds every block already there; the next exchange is in step again
     dist.barrier()
     tr._ck(tr.L.lcd_p2p_set_timeout_ms(tr.h, 300), "lcd_p2p_set_timeout_ms")
     send = torch.from_numpy(_block(rank, 9001, 16000)).cuda()
     recv = torch.zeros(world * 16000, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
-    if rank == 1:
+    if rank == world - 1:
         time.sleep(1.5)
     t0 = time.time()
     tr.all_gather(send.data_ptr(), recv.data_ptr(), 16000, s1.cuda_stream)
     s1.synchronize()
     waited = time.time() - t0
-    if rank == 0:
+    if rank != world - 1:
         if tr.status() != 1:
-            msgs.append("rank 0 waited for a late peer and reports status %d, not LCD_P2P_TIMEOUT_GATHER" % tr.status())
+            msgs.append("rank %d waited for a late peer and reports status %d, not LCD_P2P_TIMEOUT_GATHER" % (rank, tr.status()))
         if not 0.25 < waited < 1.2:
-            msgs.append("rank 0's bounded wait took %.2f s" % waited)
+            msgs.append("rank %d's bounded wait took %.2f s" % (rank, waited))
         tr.L.lcd_p2p_clear_status(tr.h)
     else:
         if tr.status() != 0 or not np.array_equal(recv.cpu().numpy(), np.concatenate([_block(r, 9001, 16000) for r in range(world)])):
-            msgs.append("the late rank did not find its peer's block")
+            msgs.append("the late rank did not find its peers' blocks")
     dist.barrier()
     tr._ck(tr.L.lcd_p2p_set_timeout_ms(tr.h, 20000), "lcd_p2p_set_timeout_ms")
     send = torch.from_numpy(_block(rank, 9002, 16000)).cuda()
@@ -137,15 +137,17 @@ def _p2p_worker(rank, world, port, out):
 
 
 @pytest.mark.gpu
-def test_p2p_exchanges_between_two_processes():
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_exchanges_between_processes(world):
+    """world 2 and 4 (four processes on the one GPU: three peers per rank, slices of a quarter, counts that do not divide by the world)"""
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_p2p_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_p2p_worker, args=(r, world, port, out)) for r in range(world)]
     for p in procs:
         p.start()
     try:
-        got = [out.get(timeout=600) for _ in range(2)]
+        got = [out.get(timeout=600) for _ in range(world)]
     finally:
         for p in procs:
             p.join(timeout=120)

@@ -74,16 +74,17 @@ def worker(rank, world, port, iters, out):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--world", type=int, default=2, help="ranks (processes) sharing the GPU")
     a = ap.parse_args()
     import socket
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, 2, port, a.iters, out)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, a.world, port, a.iters, out)) for r in range(a.world)]
     for p in procs:
         p.start()
     res = out.get(timeout=600)
     for p in procs:
         p.join(timeout=60)
-    res.update({"world": 2, "gpus": 1, "iters": a.iters, "note": "two processes sharing one MI355X; arenas mapped with hipIpc; no xGMI link involved"})
+    res.update({"world": a.world, "gpus": 1, "iters": a.iters, "note": "%d processes sharing one MI355X;" % a.world + " arenas mapped with hipIpc; no xGMI link involved"})
     print(json.dumps(res))
