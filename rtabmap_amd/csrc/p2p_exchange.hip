@@ -221,10 +221,14 @@ struct lcd_p2p {
 };
 
 namespace {
+// elements per rank's slice of an all-reduce: the ranks' shares rounded up to 4 elements, so that every slice starts on a 16-byte boundary of
+// either wire (slice r = [min(r * chunk, count), min((r + 1) * chunk, count)): the last slices may be short or empty)
+inline size_t all_reduce_chunk(size_t count, int world) { return ((count + (size_t)world - 1) / (size_t)world + 3) / 4 * 4; }
+
 template <typename W>
 int all_reduce_launch(lcd_p2p* p, long long* buf, size_t count, hipStream_t s) {
     const uint64_t epoch = ++p->reduce_epoch;
-    const size_t chunk = ((count + p->world - 1) / p->world + 3) / 4 * 4;
+    const size_t chunk = all_reduce_chunk(count, p->world);
     const size_t per_group = 16 / sizeof(W);
     unsigned g_copy = (unsigned)((count / per_group + 256 * kCopyUnroll - 1) / (256 * kCopyUnroll)); if (g_copy > 256) g_copy = 256; if (g_copy < 1) g_copy = 1;
     unsigned g_red = (unsigned)((chunk / per_group + 511) / 512); if (g_red > 256) g_red = 256; if (g_red < 1) g_red = 1;   // two groups per lane
@@ -406,6 +410,9 @@ int tr_gather(void* user, const void* d_send, void* d_recv, size_t bytes_per_ran
 }
 int tr_reduce(void* user, void* d_buf, size_t count, void* stream) { return lcd_p2p_all_reduce_sum_i64((lcd_p2p*)user, d_buf, count, stream); }
 }  // namespace
+
+/* not part of the ABI (tests/test_p2p_host_logic.py): the slice arithmetic of the all-reduce, callable without a device */
+size_t lcd_p2p_debug_chunk(size_t count, int world) { return world >= 1 ? all_reduce_chunk(count, world) : 0; }
 
 int lcd_p2p_transport(lcd_p2p* p, lcd_shard_transport* out) {
     if (!p || !out) return LCD_ERR_INVALID;
