@@ -62,6 +62,11 @@ void lcd_p2p_destroy(lcd_p2p* p);
 const char* lcd_p2p_last_error(const lcd_p2p* p);
 
 int lcd_p2p_set_wire(lcd_p2p* p, int wire);                 /* enum lcd_p2p_wire; same value on every rank, between exchanges */
+/* on = 1: every wave publishes with the compiler's system-scope release fence and the flags are release stores (an L2 write-back per wave:
+ * 2 - 4 x slower, profiles/r06_p2p_exchange.txt) instead of "wait for the stores' acknowledgement, then a relaxed flag", which rests on the
+ * arenas being mapped uncached on BOTH sides.  A bring-up switch for a fabric this library has not run on (it has only run between processes
+ * of one GPU): if results differ there, turn it on first.  Same value on every rank; default 0. */
+int lcd_p2p_set_conservative_fences(lcd_p2p* p, int on);
 int lcd_p2p_set_timeout_ms(lcd_p2p* p, int64_t ms);         /* how long a kernel polls a flag before it gives up (default 10 000) */
 uint32_t lcd_p2p_status(const lcd_p2p* p);                  /* LCD_P2P_TIMEOUT_* bits raised by kernels that have completed */
 void lcd_p2p_clear_status(lcd_p2p* p);

@@ -29,10 +29,12 @@ constexpr size_t kReduceFlagOff = 2 * kStageFlagOff;                // [peer] th
 constexpr size_t kMailboxOff = 4096;
 constexpr uint32_t kMagic = 0x4c503201u;                            // "LP2" + ABI 1
 
-struct Peers { unsigned char* base[LCD_P2P_MAX_WORLD]; };
+struct Peers { unsigned char* base[LCD_P2P_MAX_WORLD]; int conservative; };   // conservative: lcd_p2p_set_conservative_fences
 
-__device__ __forceinline__ void raise_flag(unsigned char* arena, size_t off, int slot, uint64_t epoch) {
-    __hip_atomic_store((uint64_t*)(arena + off + (size_t)slot * kFlagStride), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+__device__ __forceinline__ void raise_flag(unsigned char* arena, size_t off, int slot, uint64_t epoch, int conservative) {
+    uint64_t* f = (uint64_t*)(arena + off + (size_t)slot * kFlagStride);
+    if (conservative) __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    else __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // polls until the flag has reached `epoch`; gives up after `timeout` ticks of the 100 MHz wall clock and says so in *status (host memory)
 __device__ __forceinline__ void await_flag(const unsigned char* arena, size_t off, int slot, uint64_t epoch, long long timeout, uint32_t* status, uint32_t bit) {
@@ -56,8 +58,9 @@ __device__ __forceinline__ void await_flag(const unsigned char* arena, size_t of
 }
 // true in exactly one workgroup of the launch: the one that finishes last.  Every wave waits for the acknowledgement of its own stores
 // before its workgroup counts, so when the last one has counted every store of the launch is in memory: the flag may follow.
-__device__ __forceinline__ bool last_workgroup(uint32_t* counter, unsigned n_groups) {
+__device__ __forceinline__ bool last_workgroup(uint32_t* counter, unsigned n_groups, int conservative) {
     __shared__ int s_last;
+    if (conservative) __threadfence_system();                        // the compiler's release: L2 write-back and all (see the head of the file)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void p2p_all_gather_kernel(Peers P, int rank, 
     }
     uint4* box = (uint4*)(P.base[p] + kMailboxOff + ((epoch & 1u) * (size_t)world + (size_t)rank) * gcap);
     for (size_t i = first; i < vec; i += step) box[i] = send[i];
-    if (last_workgroup(&counters[p], gridDim.x) && threadIdx.x == 0) raise_flag(P.base[p], kGatherFlagOff, rank, epoch);
+    if (last_workgroup(&counters[p], gridDim.x, P.conservative) && threadIdx.x == 0) raise_flag(P.base[p], kGatherFlagOff, rank, epoch, P.conservative);
     if (threadIdx.x == 0) await_flag(P.base[rank], kGatherFlagOff, p, epoch, timeout, status, LCD_P2P_TIMEOUT_GATHER);
     __syncthreads();
     const uint4* mine = (const uint4*)(P.base[rank] + kMailboxOff + ((epoch & 1u) * (size_t)world + (size_t)p) * gcap);
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void p2p_stage_kernel(Peers P, int rank, int w
         for (int k = 0; k < kCopyUnroll; ++k) if (g + k * 256 < groups) a[k].store_wire(s + (g + k * 256) * N);
     }
     if (blockIdx.x == 0 && groups * N + threadIdx.x < count) s[groups * N + threadIdx.x] = (W)buf[groups * N + threadIdx.x];
-    if (last_workgroup(counter, gridDim.x) && (int)threadIdx.x < world) raise_flag(P.base[threadIdx.x], kStageFlagOff, rank, epoch);
+    if (last_workgroup(counter, gridDim.x, P.conservative) && (int)threadIdx.x < world) raise_flag(P.base[threadIdx.x], kStageFlagOff, rank, epoch, P.conservative);
 }
 // phase 2: slice `rank` of every arena summed in rank order and written back into slice `rank` of every arena, flag B to every peer.
 // Only this rank touches slice `rank` of any arena between the two flags, so the exchange needs no third barrier.
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void p2p_reduce_kernel(Peers P, int rank, int 
         for (int p = 1; p < world; ++p) sum += ((const W*)(P.base[p] + stage_off))[i];
         for (int p = 0; p < world; ++p) ((W*)(P.base[p] + stage_off))[i] = sum;
     }
-    if (last_workgroup(counter, gridDim.x) && (int)threadIdx.x < world) raise_flag(P.base[threadIdx.x], kReduceFlagOff, rank, epoch);
+    if (last_workgroup(counter, gridDim.x, P.conservative) && (int)threadIdx.x < world) raise_flag(P.base[threadIdx.x], kReduceFlagOff, rank, epoch, P.conservative);
 }
 // phase 3: every slice of my arena is final once every peer has raised B
 template <typename W>
@@ -347,6 +350,11 @@ int lcd_p2p_set_wire(lcd_p2p* p, int wire) {
     if (!p) return LCD_ERR_INVALID;
     if (wire != LCD_P2P_WIRE_I64 && wire != LCD_P2P_WIRE_F32) return p->fail(LCD_ERR_INVALID, "lcd_p2p_set_wire: unknown wire");
     p->wire = wire;
+    return LCD_OK;
+}
+int lcd_p2p_set_conservative_fences(lcd_p2p* p, int on) {
+    if (!p) return LCD_ERR_INVALID;
+    p->peers.conservative = on ? 1 : 0;
     return LCD_OK;
 }
 int lcd_p2p_set_timeout_ms(lcd_p2p* p, int64_t ms) {

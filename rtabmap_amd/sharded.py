@@ -337,6 +337,7 @@ def load_p2p():
         L.lcd_p2p_last_error.restype = C.c_char_p
         L.lcd_p2p_set_wire.argtypes = [vp, C.c_int]
         L.lcd_p2p_set_timeout_ms.argtypes = [vp, C.c_int64]
+        L.lcd_p2p_set_conservative_fences.argtypes = [vp, C.c_int]
         L.lcd_p2p_status.argtypes = [vp]
         L.lcd_p2p_status.restype = C.c_uint32
         L.lcd_p2p_clear_status.argtypes = [vp]
@@ -383,6 +384,10 @@ class P2PTransport:
 
     def set_wire(self, wire):
         self._ck(self.L.lcd_p2p_set_wire(self.h, {"i64": 0, "f32": 1}[wire]), "lcd_p2p_set_wire")
+
+    def set_conservative_fences(self, on=True):
+        """lcd_p2p_set_conservative_fences: the compiler's release fences instead of acknowledged stores + relaxed flags (bring-up switch)"""
+        self._ck(self.L.lcd_p2p_set_conservative_fences(self.h, 1 if on else 0), "lcd_p2p_set_conservative_fences")
 
     def all_gather(self, d_send_ptr, d_recv_ptr, bytes_per_rank, stream=None):
         self._ck(self.L.lcd_p2p_all_gather(self.h, d_send_ptr, d_recv_ptr, bytes_per_rank, stream), "lcd_p2p_all_gather")

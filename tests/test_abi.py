@@ -44,7 +44,7 @@ def test_p2p_library_builds_and_exports_every_declared_symbol():
     header = open(os.path.join(os.path.dirname(__file__), "..", "include", "lcd_p2p.h")).read()
     declared = set(re.findall(r"\b(lcd_p2p_[a-z0-9_]+)\s*\(", header))
     assert declared == {"lcd_p2p_create", "lcd_p2p_export", "lcd_p2p_connect", "lcd_p2p_destroy", "lcd_p2p_last_error", "lcd_p2p_set_wire",
-                        "lcd_p2p_set_timeout_ms", "lcd_p2p_status", "lcd_p2p_clear_status", "lcd_p2p_all_gather", "lcd_p2p_all_reduce_sum_i64",
+                        "lcd_p2p_set_timeout_ms", "lcd_p2p_set_conservative_fences", "lcd_p2p_status", "lcd_p2p_clear_status", "lcd_p2p_all_gather", "lcd_p2p_all_reduce_sum_i64",
                         "lcd_p2p_transport"}
     for s in declared:
         assert hasattr(L, s), s

@@ -44,8 +44,11 @@ def _p2p_worker(rank, world, port, out):
             want = np.concatenate([_block(r, it, nbytes) for r in range(world)])
             if not np.array_equal(recv.cpu().numpy(), want):
                 msgs.append("all-gather of %d bytes, exchange %d" % (nbytes, it))
-    # (2) all-reduce, integer wire: exact, including negative operands; float wire: within world * 2^-24 relative of the exact sum
-    for wire in ("i64", "f32"):
+    # (2) all-reduce, integer wire: exact, including negative operands; float wire: within world * 2^-24 relative of the exact sum;
+    #     the integer wire once more with the conservative fences (lcd_p2p_set_conservative_fences: same results, slower)
+    for wire in ("i64", "f32", "i64 conservative"):
+        tr.set_conservative_fences(wire.endswith("conservative"))
+        wire = wire.split()[0]
         tr.set_wire(wire)
         for count in (1, 5, 1000, 100001, max_count):
             for rep in range(2):
@@ -71,6 +74,7 @@ def _p2p_worker(rank, world, port, out):
                     if np.abs(got - want).max() > want.max() * world * 2.0 ** -24:
                         msgs.append("float-wire all-reduce of %d beyond its bound, exchange %d" % (count, it))
     tr.set_wire("i64")
+    tr.set_conservative_fences(False)
     # (3) an all-gather (stream 1) beside an all-reduce (stream 2), 40 pairs enqueued back to back without a host synchronisation in between
     n_pairs, nbytes, count = 40, 16000, 100001
     sends = [torch.from_numpy(_block(rank, 5000 + k, nbytes)).cuda() for k in range(n_pairs)]
