@@ -1956,7 +1956,8 @@ int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shar
                       h->d_knn_word, h->d_knn_dist);
     if (rc) return rc;
     LCD_HIP(h, launch_shard_pack(h->d_knn_row.as<int32_t>(), h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
-                                 h->row_wslot.as<int32_t>(), q, d_cand, h->stream));
+                                 h->row_wslot.as<int32_t>(), q, d_cand, h->stream, h->d_fail_count.as<int32_t>()));
+    h->fail_count_clean = true;                                       // (the pack is the search's last launch and leaves its counters zeroed)
     return LCD_OK;
     LCD_CATCH(h)
 }

@@ -153,7 +153,7 @@ hipError_t launch_findnn_resolve(int q, int flags, float nndr, int have_index, c
 // Sharded vocabulary (one rank per word-id range): local candidates -> 16-byte records {u64 key, i32 word, i32 wslot}, and the
 // merge of the all-gathered records [world][q][2] (ties: lower rank, then lower local row); out_wslot is -1 for foreign words.
 hipError_t launch_shard_pack(const int32_t* knn_row, const int32_t* knn_word, const float* knn_dist, const int32_t* row_wslot, int q,
-                             void* out_cand, hipStream_t s);
+                             void* out_cand, hipStream_t s, int32_t* fail_count = nullptr);
 // by_word: ties go to the lower WORD ID instead of (rank, local row) -- the single-GPU row order when every rank's rows ascend by id and
 // the ranks' id sets interleave (block-cyclic ownership of the words frames create)
 hipError_t launch_shard_merge(const void* all_cand, int world, int rank, int q, int32_t* out_word, float* out_dist, int32_t* out_wslot,

@@ -104,8 +104,11 @@ __global__ void shard_merge_kernel(const ShardCand* __restrict__ cand, int world
 }
 // local candidates of one rank in ShardCand form (dist as float already converted for Hamming by the merge kernel)
 __global__ void shard_pack_kernel(const int32_t* __restrict__ knn_row, const int32_t* __restrict__ knn_word, const float* __restrict__ knn_dist,
-                                  const int32_t* __restrict__ row_wslot, int q2, ShardCand* __restrict__ out) {
+                                  const int32_t* __restrict__ row_wslot, int q2, ShardCand* __restrict__ out, int32_t* __restrict__ fail_count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // the search's last consumer: its counters ([0] rejected queries, [1] arrivals of the redo, [3] redo done) are left clean for the next search
+    // (the fused frame tail does the same for the unsharded handle: one reset launch less per frame)
+    if (fail_count && i < 4 && i != 2) fail_count[i] = 0;
     if (i >= q2) return;
     ShardCand c;
     const int row = knn_row[i];
@@ -195,9 +198,9 @@ hipError_t launch_findnn_resolve(int q, int flags, float nndr, int have_index, c
 }
 
 hipError_t launch_shard_pack(const int32_t* knn_row, const int32_t* knn_word, const float* knn_dist, const int32_t* row_wslot, int q,
-                             void* out_cand, hipStream_t s) {
+                             void* out_cand, hipStream_t s, int32_t* fail_count) {
     if (q <= 0) return hipSuccess;
-    shard_pack_kernel<<<(2 * q + 255) / 256, 256, 0, s>>>(knn_row, knn_word, knn_dist, row_wslot, 2 * q, (ShardCand*)out_cand);
+    shard_pack_kernel<<<(2 * q + 255) / 256, 256, 0, s>>>(knn_row, knn_word, knn_dist, row_wslot, 2 * q, (ShardCand*)out_cand, fail_count);
     return hipGetLastError();
 }
 hipError_t launch_shard_merge(const void* all_cand, int world, int rank, int q, int32_t* out_word, float* out_dist, int32_t* out_wslot,
