@@ -133,7 +133,10 @@ static void fill_redo(lcd_engine* h, RowparArgs* a, const void* vocab, const int
 // 2-NN of q device-resident queries against a row matrix -> o_{row,word,dist}[q*2].  `main_vocab` selects the resident
 // vocabulary (which has row norms and may use the MFMA filter); other matrices (findNN's not-indexed words) use the exact scan.
 int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab, const int32_t* row_id, int64_t n_rows, bool main_vocab,
-                 int32_t* o_row, int32_t* o_word, float* o_dist, const CandBits* cb = nullptr, RowparArgs* defer_redo = nullptr) {
+                 int32_t* o_row, int32_t* o_word, float* o_dist, const CandBits* cb = nullptr, RowparArgs* defer_redo = nullptr,
+                 const ShardPackArgs* pack = nullptr /* a sharded search: the candidate records ride in the redo's launch ... */,
+                 bool* packed = nullptr /* ... when the search has one (matrix-core filter): told here */) {
+    if (packed) *packed = false;
     if (q == 0) return LCD_OK;
     const bool mfma = main_vocab && h->knn_mode != 0 && knn_mfma_supported(h->dtype, h->kdim) && n_rows >= 256;
     const KnnPlan p = knn_plan(q, (int)n_rows, h->row_bytes);
@@ -153,8 +156,11 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
                                                              : (knn_bf16_persistent(mp) ? "knn_bf16_filter_kernel_p" : "knn_bf16_filter_kernel"); }
         LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
         if (defer_redo) fill_redo(h, defer_redo, vocab, row_id, (int)n_rows, d_queries, o_row, o_word, o_dist, cb);
-        else LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(),
-                                          h->d_fail_count.as<int32_t>(), h->d_partial3.p, o_row, o_word, o_dist, h->kst, cb));
+        else {
+            LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(),
+                                         h->d_fail_count.as<int32_t>(), h->d_partial3.p, o_row, o_word, o_dist, h->kst, cb, pack));
+            if (pack && packed) *packed = true;
+        }
     } else if (mfma) {
         const MfmaPlan mp = knn_mfma_plan(q, (int)n_rows);
         LCD_HIP(h, dreserve(h, h->d_partial2, knn_mfma_partial_bytes(mp)));
@@ -170,8 +176,11 @@ int run_knn2_raw(lcd_engine* h, const void* d_queries, int q, const void* vocab,
         // the queries the certificate rejected are redone exactly by the row-parallel kernel (usually none: it leaves at once)
         LCD_HIP(h, dreserve(h, h->d_partial3, knn_rowpar_partial_bytes((int)n_rows, q)));
         if (defer_redo) fill_redo(h, defer_redo, vocab, row_id, (int)n_rows, d_queries, o_row, o_word, o_dist, cb);
-        else LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(),
-                                          h->d_fail_count.as<int32_t>(), h->d_partial3.p, o_row, o_word, o_dist, h->kst, cb));
+        else {
+            LCD_HIP(h, launch_knn_rowpar(h->kdim, vocab, row_id, (int)n_rows, d_queries, h->d_fail_list.as<int32_t>(),
+                                         h->d_fail_count.as<int32_t>(), h->d_partial3.p, o_row, o_word, o_dist, h->kst, cb, pack));
+            if (pack && packed) *packed = true;
+        }
     } else {
         LCD_HIP(h, dreserve(h, h->d_partial, knn_partial_bytes(p)));
         const bool prof = main_vocab && h->prof_cap > 0 && h->prof_n < h->prof_cap;
@@ -1952,12 +1961,20 @@ int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shar
     if (((uintptr_t)d_descriptors & 15u) != 0) return h->fail(LCD_ERR_INVALID, "lcd_shard_knn2_dev: d_descriptors must be 16-byte aligned");
     const int64_t rows_scan = h->rows_ub();                           // == n_rows unless this rank appended on the device since the mirror last caught up
     if (rows_scan >= (1 << 26)) return h->fail(LCD_ERR_UNSUPPORTED, "lcd_shard_knn2_dev: a shard holds at most 2^26 - 1 rows (merge key: 26-bit row, 6-bit rank)");
-    int rc = run_knn2(h, d_descriptors, q, h->vocab.p, h->row_id.as<int32_t>(), h->row_wslot.as<int32_t>(), rows_scan, h->d_knn_row,
-                      h->d_knn_word, h->d_knn_dist);
+    LCD_HIP(h, dreserve(h, h->d_knn_row, (size_t)q * 2 * 4));
+    LCD_HIP(h, dreserve(h, h->d_knn_word, (size_t)q * 2 * 4));
+    LCD_HIP(h, dreserve(h, h->d_knn_dist, (size_t)q * 2 * 4));
+    // the candidate records are the work of the search's last launch: the exact redo's when the search has one (the matrix-core filter; one launch
+    // less per frame and rank), a launch of their own behind the exact scan otherwise.  Either way the search's counters are left zeroed.
+    ShardPackArgs pk;
+    pk.knn_row = h->d_knn_row.as<int32_t>(); pk.knn_word = h->d_knn_word.as<int32_t>(); pk.knn_dist = h->d_knn_dist.as<float>();
+    pk.row_wslot = h->row_wslot.as<int32_t>(); pk.q2 = 2 * q; pk.out = reinterpret_cast<ShardCand*>(d_cand);
+    bool packed = false;
+    int rc = run_knn2_raw(h, d_descriptors, q, h->vocab.p, h->row_id.as<int32_t>(), rows_scan, true, h->d_knn_row.as<int32_t>(),
+                          h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), nullptr, nullptr, &pk, &packed);
     if (rc) return rc;
-    LCD_HIP(h, launch_shard_pack(h->d_knn_row.as<int32_t>(), h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
-                                 h->row_wslot.as<int32_t>(), q, d_cand, h->stream, h->d_fail_count.as<int32_t>()));
-    h->fail_count_clean = true;                                       // (the pack is the search's last launch and leaves its counters zeroed)
+    if (!packed) LCD_HIP(h, launch_shard_pack(pk.knn_row, pk.knn_word, pk.knn_dist, pk.row_wslot, q, d_cand, h->stream, h->d_fail_count.as<int32_t>()));
+    h->fail_count_clean = true;
     return LCD_OK;
     LCD_CATCH(h)
 }
@@ -1989,17 +2006,24 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
     const bool dev_append = h->shard_append && (flags & LCD_Q_INCREMENTAL) && first_new_word_id > 0 && h->row_bytes == h->dim * (h->dtype == LCD_F32 ? 4 : 1);
     if (cyclic && (sig_id != 0 || dev_append) && first_new_word_id > 0 && (flags & LCD_Q_INCREMENTAL) && first_new_word_id < h->shard_first)
         return h->fail(LCD_ERR_INVALID, "lcd_shard_frame_dev: first_new_word_id lies in front of shard_growth_first");
-    LCD_HIP(h, launch_shard_merge(d_all_cand, world, rank, q, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
-                                  h->d_knn_row.as<int32_t>(), h->stream, cyclic));
     const int have_index = total_live_rows >= 2 ? 1 : 0;
     const bool incremental = (flags & LCD_Q_INCREMENTAL) != 0;
     const bool together = incremental && (flags & LCD_Q_NEW_WORDS_COMPARED);
     const int ld = (q + 63) / 64 * 64, bw = ld / 32;
+    // the merge rides at the head of the same-frame distance launch when the frame has one that can carry it (one launch less per frame and rank)
+    const bool merge_in_selfdist = together && selfdist_can_merge(h->dtype, h->kdim);
+    if (!merge_in_selfdist)
+        LCD_HIP(h, launch_shard_merge(d_all_cand, world, rank, q, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
+                                      h->d_knn_row.as<int32_t>(), h->stream, cyclic));
     if (together) {
         LCD_HIP(h, dreserve(h, h->d_selfdist, (size_t)q * ld * 4));
         LCD_HIP(h, dreserve(h, h->d_bits, (size_t)q * bw * 4));
+        ShardMergeJob mj;
+        mj.cand = reinterpret_cast<const ShardCand*>(d_all_cand); mj.world = world; mj.rank = rank; mj.by_word = cyclic ? 1 : 0;
+        mj.out_word = h->d_knn_word.as<int32_t>(); mj.out_dist = h->d_knn_dist.as<float>(); mj.out_wslot = h->d_knn_row.as<int32_t>();
         LCD_HIP(h, launch_selfdist(h->dtype, h->kdim, d_descriptors, q, h->d_selfdist.as<float>(), ld, h->stream, have_index,
-                                   h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), h->d_bits.as<uint32_t>(), bw));
+                                   h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), h->d_bits.as<uint32_t>(), bw,
+                                   merge_in_selfdist ? &mj : nullptr));
     }
     LCD_HIP(h, dreserve(h, h->d_out_wslot, (size_t)q * 4));
     // new words: every rank reserves the same keys (identical call sequence => identical numbering); only the LAST rank, which

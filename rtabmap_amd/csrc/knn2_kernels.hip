@@ -22,6 +22,7 @@
 //   Hamming: popcount(a ^ b) (dist.h:555-579).
 // Bound: VALU issue (3 VALU ops per float element, 2+ per dword for Hamming), not HBM: see DESIGN.md.
 #include "lcd_kernels.h"
+#include "shard_body.cuh"
 
 namespace lcd {
 namespace {
@@ -309,7 +310,8 @@ __device__ __forceinline__ float cand_threshold(int have_index, const int32_t* _
 template <int DIM>
 __global__ __launch_bounds__(BLOCK) void selfdist_l2_kernel(const float* __restrict__ queries, int nq, float* __restrict__ out, int ld,
                                                             int have_index, const int32_t* __restrict__ knn_word,
-                                                            const float* __restrict__ knn_dist, uint32_t* __restrict__ bits, int bw) {
+                                                            const float* __restrict__ knn_dist, uint32_t* __restrict__ bits, int bw,
+                                                            ShardMergeJob mj) {
     // The workgroup's SD_ROWS rows are staged through LDS in the round trip that brings every lane its own query (round 6: the rows used to be
     // read from memory one after the other inside the loop, eight dependent round trips per wave: 10.8 us for 500 x 500 distances).  The
     // arithmetic is l2_ref's, operand for operand: the distances are the reference's bits either way.
@@ -334,7 +336,18 @@ __global__ __launch_bounds__(BLOCK) void selfdist_l2_kernel(const float* __restr
         const float4 v = src[g];
         q[4 * g + 0] = v.x; q[4 * g + 1] = v.y; q[4 * g + 2] = v.z; q[4 * g + 3] = v.w;
     }
-    const float thr = bits ? cand_threshold(have_index, knn_word, knn_dist, qsrc) : 0.0f;
+    float thr = 0.0f;
+    if (mj.cand) {
+        // a sharded frame: the query's global 2-NN is merged here from the ranks' records (shard_merge_kernel's work: one launch less per frame
+        // and rank) -- every workgroup needs its queries' thresholds, the first row block's first wave also writes the result for the decision loop
+        const ShardMerged m = shard_merge_one(mj.cand, mj.world, mj.rank, nq, qsrc, mj.by_word);
+        const bool v0 = m.dist[0] >= 0.0f && m.word[0] != 0, v1 = m.dist[1] >= 0.0f && m.word[1] != 0;   // cand_threshold()
+        thr = (have_index && v0 && v1) ? m.dist[1] : __int_as_float(0x7f800000);
+        if (blockIdx.x == 0 && wave == 0 && qi < nq) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { mj.out_word[2 * qi + j] = m.word[j]; mj.out_dist[2 * qi + j] = m.dist[j]; mj.out_wslot[2 * qi + j] = m.wslot[j]; }
+        }
+    } else if (bits) thr = cand_threshold(have_index, knn_word, knn_dist, qsrc);
 #pragma unroll
     for (int u = 0; u < (V + BLOCK - 1) / BLOCK; ++u) {
         const int v = (int)threadIdx.x + u * BLOCK;
@@ -507,14 +520,19 @@ hipError_t launch_knn2_merge_selfdist_hamming(const KnnPlan& p, const uint64_t* 
     return hipGetLastError();
 }
 
+bool selfdist_can_merge(int dtype, int dim) { return dtype == 0 && (dim == 64 || dim == 128); }
+
 hipError_t launch_selfdist(int dtype, int dim, const void* queries, int q, float* out, int ld, hipStream_t s, int have_index,
-                           const int32_t* knn_word, const float* knn_dist, uint32_t* bits, int bw) {
+                           const int32_t* knn_word, const float* knn_dist, uint32_t* bits, int bw, const ShardMergeJob* merge) {
     if (q == 0) return hipSuccess;
+    if (merge && !selfdist_can_merge(dtype, dim)) return hipErrorInvalidValue;
     dim3 grid((q + SD_ROWS - 1) / SD_ROWS, (q + 63) / 64), block(BLOCK);
     if (dtype == 0) {
         const float* qq = (const float*)queries;
-        if (dim == 64) selfdist_l2_kernel<64><<<grid, block, 0, s>>>(qq, q, out, ld, have_index, knn_word, knn_dist, bits, bw);
-        else if (dim == 128) selfdist_l2_kernel<128><<<grid, block, 0, s>>>(qq, q, out, ld, have_index, knn_word, knn_dist, bits, bw);
+        const ShardMergeJob mj = merge ? *merge : ShardMergeJob{};
+        if (dim == 64) selfdist_l2_kernel<64><<<grid, block, 0, s>>>(qq, q, out, ld, have_index, knn_word, knn_dist, bits, bw, mj);
+        else if (dim == 128) selfdist_l2_kernel<128><<<grid, block, 0, s>>>(qq, q, out, ld, have_index, knn_word, knn_dist, bits, bw, mj);
+        else if (merge) return hipErrorInvalidValue;
         else selfdist_l2_dyn_kernel<<<grid, block, 0, s>>>(qq, q, dim, out, ld, have_index, knn_word, knn_dist, bits, bw);
     } else {
         selfdist_hamming_dyn_kernel<<<grid, block, 0, s>>>((const uint32_t*)queries, q, dim / 4, out, ld, have_index, knn_word, knn_dist,

@@ -27,6 +27,7 @@
 #include <hip/hip_ext.h>
 #include "lcd_kernels.h"
 #include "rowpar_body.cuh"
+#include "shard_body.cuh"
 #include "frame_tail_body.cuh"
 #include "score_body.cuh"
 
@@ -2144,6 +2145,22 @@ __global__ __launch_bounds__(PIPE_B_BLOCK) void append_rows_kernel(AppendRowsArg
 __global__ __launch_bounds__(MF_BLOCK) void knn_rowpar_kernel(RowparArgs a, int32_t* __restrict__ fail_count) {
     rowpar_body<64, MF_BLOCK>(a, (int)blockIdx.x, (int)gridDim.x, fail_count);
 }
+// A sharded search's last launch: the exact redo, then the rank's candidate records (shard_pack_kernel's work -- one launch of ~4.7 us less per
+// frame and rank).  Nothing to redo (the usual frame): every workgroup sees that and packs its stride of the records; the counters are zero
+// already.  A redo: the last workgroup to arrive, which merged and knows every result final, packs all records and zeroes the counters
+// ([0] rejected queries, [1] arrivals, [3] done) -- every other workgroup has read [0] and taken its ticket by then.
+__global__ __launch_bounds__(MF_BLOCK) void knn_rowpar_pack_kernel(RowparArgs a, int32_t* __restrict__ fail_count, ShardPackArgs p) {
+    const int st = rowpar_body<64, MF_BLOCK>(a, (int)blockIdx.x, (int)gridDim.x, fail_count);
+    if (st == 0) {
+        for (int i = (int)blockIdx.x * MF_BLOCK + (int)threadIdx.x; i < p.q2; i += (int)gridDim.x * MF_BLOCK) shard_pack_one(p, i);
+    } else if (st == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // (the redone queries' slots were written by this workgroup's other waves)
+        for (int i = (int)threadIdx.x; i < p.q2; i += MF_BLOCK) shard_pack_one(p, i);
+        if (threadIdx.x < 4 && threadIdx.x != 2) fail_count[threadIdx.x] = 0;
+    }
+}
 
 }  // namespace
 }  // namespace lcd
@@ -2418,14 +2435,15 @@ size_t knn_rowpar_partial_bytes(int n_rows, int q) { return (size_t)(q > 0 ? q :
 
 hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, int n_rows, const void* queries, const int32_t* fail_list,
                              int32_t* fail_count, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s,
-                             const CandBits* cb) {
+                             const CandBits* cb, const ShardPackArgs* pack) {
     if (dim != 64 || n_rows <= 0) return hipErrorInvalidValue;
     RowparArgs a;
     a.enabled = 1; a.vocab = (const float*)vocab; a.row_id = row_id; a.n_rows = n_rows; a.queries = (const float*)queries;
     a.fail_list = fail_list; a.partial = (unsigned long long*)partial; a.out_row = out_row; a.out_word = out_word; a.out_dist = out_dist;
     if (cb) a.cb = *cb;
     const int nb = (n_rows + MF_BLOCK - 1) / MF_BLOCK;
-    knn_rowpar_kernel<<<nb, MF_BLOCK, 0, s>>>(a, fail_count);
+    if (pack) knn_rowpar_pack_kernel<<<nb, MF_BLOCK, 0, s>>>(a, fail_count, *pack);
+    else knn_rowpar_kernel<<<nb, MF_BLOCK, 0, s>>>(a, fail_count);
     return hipGetLastError();
 }
 

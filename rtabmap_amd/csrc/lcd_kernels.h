@@ -119,9 +119,22 @@ hipError_t launch_norm_tombstone(float* norm, const int32_t* rows, int n, hipStr
 hipError_t launch_vocab_tail(float* norm, void* bf, long long first, long long n, hipStream_t s);
 // exact redo of the queries in fail_list (fail_count[0] of them; fail_count[1] is scratch) with one lane per vocabulary row
 size_t knn_rowpar_partial_bytes(int n_rows, int q);
+// A sharded search's candidate record (what the ranks all-gather) and the job that packs a rank's 2 * q local candidates into records:
+// it rides at the end of the exact redo's launch (the search's last), which then also leaves the search's counters zeroed.
+struct ShardCand { unsigned long long key; int32_t word; int32_t wslot; };
+struct ShardPackArgs {
+    const int32_t* knn_row = nullptr; const int32_t* knn_word = nullptr; const float* knn_dist = nullptr; const int32_t* row_wslot = nullptr;
+    int q2 = 0; ShardCand* out = nullptr;
+};
 hipError_t launch_knn_rowpar(int dim, const void* vocab, const int32_t* row_id, int n_rows, const void* queries, const int32_t* fail_list,
                              int32_t* fail_count, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist, hipStream_t s,
-                             const CandBits* cb = nullptr);
+                             const CandBits* cb = nullptr, const ShardPackArgs* pack = nullptr);
+// ... and the job that merges the all-gathered records [world][q][2] into the frame's global 2-NN: it rides at the head of the same-frame distance
+// launch (every workgroup merges its 64 queries itself -- the thresholds of their candidate bits; the first row block's workgroups write the result)
+struct ShardMergeJob {
+    const ShardCand* cand = nullptr; int world = 0, rank = 0, by_word = 0;
+    int32_t* out_word = nullptr; float* out_dist = nullptr; int32_t* out_wslot = nullptr;
+};
 hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, const uint32_t* norm_max_bits, const int32_t* row_id,
                            const void* queries, const MfmaPlan& p, void* partial, int32_t* out_row, int32_t* out_word, float* out_dist,
                            int32_t* fail_list, int32_t* fail_count, hipStream_t s, hipEvent_t ev_begin = nullptr,
@@ -131,8 +144,11 @@ hipError_t launch_knn_mfma(int dim, const void* vocab, const float* row_norm, co
 // q x q distances of a block against itself; out[i*ld + j], ld >= q.  When `bits` is given ([q][bw] words, bw >= ceil(q/32))
 // also the candidate bit matrix of the addNewWords resolution: bit j of row i = dist(j, i) < (distance of i's second
 // indexed neighbour, +inf if it has none) -- see knn2_kernels.hip.
+// `merge` (sharded frames, selfdist_can_merge() kernels only): knn_word / knn_dist are not read but WRITTEN, from the all-gathered records.
 hipError_t launch_selfdist(int dtype, int dim, const void* queries, int q, float* out, int ld, hipStream_t s, int have_index = 0,
-                           const int32_t* knn_word = nullptr, const float* knn_dist = nullptr, uint32_t* bits = nullptr, int bw = 0);
+                           const int32_t* knn_word = nullptr, const float* knn_dist = nullptr, uint32_t* bits = nullptr, int bw = 0,
+                           const ShardMergeJob* merge = nullptr);
+bool selfdist_can_merge(int dtype, int dim);
 
 // The addNewWords decision loop (VWDictionary.cpp:1089-1219) for a whole frame, on the device.
 //   knn_word/knn_dist [q*2] indexed candidates (word 0 / dist < 0 = none); have_index = vocabulary had >= 2 live rows

@@ -18,6 +18,7 @@
 // the frame's heavy part is knn2_kernels.hip.
 #include "lcd_kernels.h"
 #include "resolve_body.cuh"
+#include "shard_body.cuh"
 
 namespace lcd {
 namespace {
@@ -73,48 +74,20 @@ __global__ void findnn_resolve_kernel(int q, int flags, float nndr, int have_ind
 // cand[rank][q][2] = {key = distance bits << 32 | local row, word id, postings key on the owning rank} are merged here.
 // Global row order = (rank, local row): the lower rank, then the lower row, wins ties -- the single-GPU order when the
 // shards are consecutive id ranges.  out_wslot[q*2] is the postings key if THIS rank owns the neighbour, else -1.
-struct ShardCand { unsigned long long key; int32_t word; int32_t wslot; };
 __global__ void shard_merge_kernel(const ShardCand* __restrict__ cand, int world, int rank, int q, int32_t* __restrict__ out_word,
                                    float* __restrict__ out_dist, int32_t* __restrict__ out_wslot, int by_word) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= q) return;
-    // composite (distance, rank, local row, slot index) compared lexicographically
-    unsigned long long bk = KEY_NONE, sk = KEY_NONE;
-    int bsrc = -1, ssrc = -1;
-    for (int r = 0; r < world; ++r) {
-        for (int j = 0; j < 2; ++j) {
-            const ShardCand c = cand[((size_t)r * q + i) * 2 + j];
-            if (c.key == KEY_NONE || c.word == 0) continue;
-            // by_word: (distance, word id) -- rows ascend by id on every rank, so this is the order one GPU holding all rows would see
-            const unsigned long long k = by_word ? ((c.key & 0xFFFFFFFF00000000ull) | (unsigned long long)(uint32_t)c.word)
-                                                 : ((c.key & 0xFFFFFFFF00000000ull) | ((unsigned long long)r << 26) | (c.key & 0x3FFFFFFull));
-            const int src = (r * q + i) * 2 + j;
-            if (k < bk) { sk = bk; ssrc = bsrc; bk = k; bsrc = src; }
-            else if (k < sk) { sk = k; ssrc = src; }
-        }
-    }
-    const int srcs[2] = {bsrc, ssrc};
-    for (int j = 0; j < 2; ++j) {
-        if (srcs[j] < 0) { out_word[2 * i + j] = 0; out_dist[2 * i + j] = -1.0f; out_wslot[2 * i + j] = -1; continue; }
-        const ShardCand c = cand[srcs[j]];
-        out_word[2 * i + j] = c.word;
-        out_dist[2 * i + j] = __uint_as_float((uint32_t)(c.key >> 32));
-        out_wslot[2 * i + j] = (srcs[j] / (2 * q)) == rank ? c.wslot : -1;
-    }
+    const ShardMerged m = shard_merge_one(cand, world, rank, q, i, by_word);          // shard_body.cuh
+    for (int j = 0; j < 2; ++j) { out_word[2 * i + j] = m.word[j]; out_dist[2 * i + j] = m.dist[j]; out_wslot[2 * i + j] = m.wslot[j]; }
 }
 // local candidates of one rank in ShardCand form (dist as float already converted for Hamming by the merge kernel)
-__global__ void shard_pack_kernel(const int32_t* __restrict__ knn_row, const int32_t* __restrict__ knn_word, const float* __restrict__ knn_dist,
-                                  const int32_t* __restrict__ row_wslot, int q2, ShardCand* __restrict__ out, int32_t* __restrict__ fail_count) {
+__global__ void shard_pack_kernel(ShardPackArgs p, int32_t* __restrict__ fail_count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // the search's last consumer: its counters ([0] rejected queries, [1] arrivals of the redo, [3] redo done) are left clean for the next search
     // (the fused frame tail does the same for the unsharded handle: one reset launch less per frame)
     if (fail_count && i < 4 && i != 2) fail_count[i] = 0;
-    if (i >= q2) return;
-    ShardCand c;
-    const int row = knn_row[i];
-    if (row < 0) { c.key = KEY_NONE; c.word = 0; c.wslot = -1; }
-    else { c.key = ((unsigned long long)__float_as_uint(knn_dist[i]) << 32) | (uint32_t)row; c.word = knn_word[i]; c.wslot = row_wslot[row]; }
-    out[i] = c;
+    if (i < p.q2) shard_pack_one(p, i);
 }
 
 // ------------------------------------------------------------------------------------------------ vocabulary upkeep
@@ -200,7 +173,9 @@ hipError_t launch_findnn_resolve(int q, int flags, float nndr, int have_index, c
 hipError_t launch_shard_pack(const int32_t* knn_row, const int32_t* knn_word, const float* knn_dist, const int32_t* row_wslot, int q,
                              void* out_cand, hipStream_t s, int32_t* fail_count) {
     if (q <= 0) return hipSuccess;
-    shard_pack_kernel<<<(2 * q + 255) / 256, 256, 0, s>>>(knn_row, knn_word, knn_dist, row_wslot, 2 * q, (ShardCand*)out_cand, fail_count);
+    ShardPackArgs p;
+    p.knn_row = knn_row; p.knn_word = knn_word; p.knn_dist = knn_dist; p.row_wslot = row_wslot; p.q2 = 2 * q; p.out = (ShardCand*)out_cand;
+    shard_pack_kernel<<<(2 * q + 255) / 256, 256, 0, s>>>(p, fail_count);
     return hipGetLastError();
 }
 hipError_t launch_shard_merge(const void* all_cand, int world, int rank, int q, int32_t* out_word, float* out_dist, int32_t* out_wslot,

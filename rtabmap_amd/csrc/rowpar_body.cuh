@@ -55,10 +55,12 @@ __device__ __forceinline__ void cand_bits_row(const CandBits& cb, int qi, float 
 //   workgroups walking the rows; the rows are walked in chunks of NT (chunk c by workgroup c % n_wb): a launch may bring fewer
 //   workgroups than there are chunks -- the fused frame launch does (REDO_WGS_MAX): its helpers queue for compute-unit slots behind the
 //   filter's workgroups, ~400 of them kept the launch open 1.5-2 us after everything else had finished (round 6's stamps).
+// Returns 0: nothing to redo (every workgroup of the launch sees that); 1: this workgroup's share is done; 2: this workgroup was the last,
+// it merged, and the results of the whole search are final.
 template <int DIM, int NT>
-__device__ __forceinline__ void rowpar_body(const RowparArgs& a, int wb, int n_wb, int32_t* __restrict__ fail_count) {
+__device__ __forceinline__ int rowpar_body(const RowparArgs& a, int wb, int n_wb, int32_t* __restrict__ fail_count) {
     const int nf = fail_count[0];
-    if (nf <= 0) return;
+    if (nf <= 0) return 0;
     constexpr int NW = NT / 64;
     __shared__ float s_q[DIM];
     __shared__ uint64_t s_k[NW][2];
@@ -119,7 +121,7 @@ __device__ __forceinline__ void rowpar_body(const RowparArgs& a, int wb, int n_w
         if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    if (!s_last) return;
+    if (!s_last) return 1;
     // last workgroup: one wave per listed query merges the n_wb * 2 keys
     const int n_keys = n_chunks * 2;
     for (int f = wave; f < nf; f += NW) {
@@ -157,6 +159,7 @@ __device__ __forceinline__ void rowpar_body(const RowparArgs& a, int wb, int n_w
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_store(&fail_count[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    return 2;
 }
 
 }  // namespace

@@ -468,3 +468,51 @@ def test_native_driver_two_ranks_over_the_peer_to_peer_transport():
     32-bit float wire (half the bytes): the same word ids, the likelihood within 3e-7 relative, zeros exactly where the engine has zeros.
     No exchange may have timed out (lcd_p2p_status == 0)."""
     _run_native("p2p")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+def test_shard_search_packs_its_records_in_the_redo_launch(mode):
+    """lcd_shard_knn2_dev has no launch of its own for the candidate records: they are written by the exact redo's launch (the search's
+    last) -- by every workgroup when no query was rejected, by the last workgroup to arrive when some were.  Both cases, frame after frame
+    on one handle (the counters the launch leaves behind must be clean for the next search): the records must be lcd_knn2's rows, words and
+    distances, redone queries included, and a vocabulary too small for the matrix-core filter still gets them from the stand-alone pack."""
+    import torch
+    import rtabmap_amd
+    from rtabmap_amd import synth
+    n = 6000
+    v = synth.vocab_surf(n, seed=21)
+    v[3000:3040] = v[77]                                      # 41 identical rows: some queries of a frame become uncertifiable
+    ids = np.arange(1, n + 1, dtype=np.int32)
+    rec = np.dtype([("key", "<u8"), ("word", "<i4"), ("wslot", "<i4")])
+    for rows in (n, 200):                                     # 200 rows: exact scan, no redo launch
+        eng = rtabmap_amd.Engine("f32", 64, sig_capacity=64, knn_mode=mode)
+        eng.vocab_append(v[:rows], ids[:rows])
+        d_cand = torch.zeros(400 * 2 * 16, dtype=torch.uint8, device="cuda")
+        redone = []
+        for t in range(4):
+            forced = t % 2 == 0 and rows == n
+            # frames with and without a redo alternate: unseen descriptors (nothing near the identical rows) in between
+            q = synth.queries_surf(v[:rows], 400, seed=300 + t, frac_known=0.7 if forced else 0.0, sigma=0.03)
+            if forced:
+                q[5] = v[77]
+                q[6] = v[77] + np.float32(1e-4)
+                q[200:230] = v[77] + (np.arange(30, dtype=np.float32)[:, None] * np.float32(2e-5))
+            words, dists = eng.knn2(q)
+            redone.append(eng.stats()["knn_last_fallback_queries"])
+            if forced:
+                assert redone[-1] >= 1                        # the premise of the test
+            d = torch.from_numpy(q).cuda()
+            d_cand.fill_(0xAB)
+            eng.shard_knn2_dev(d.data_ptr(), 400, d_cand.data_ptr())
+            torch.cuda.synchronize()
+            got = d_cand.cpu().numpy().view(rec).reshape(400, 2)
+            assert np.array_equal(got["word"], words), "frame %d, %d rows" % (t, rows)
+            valid = words != 0
+            assert np.array_equal((got["key"] >> np.uint64(32)).astype(np.uint32)[valid], dists.view(np.uint32)[valid])
+            assert np.all(got["key"][~valid] == np.uint64(0xFFFFFFFFFFFFFFFF))
+            rows_of = (got["key"] & np.uint64(0xFFFFFFFF)).astype(np.int64)[valid]
+            assert np.array_equal(ids[rows_of], words[valid])
+        if rows == n:
+            assert min(redone) == 0, redone                   # ... and its other half: some frame went through the launch without a redo
+        eng.close()
