@@ -343,7 +343,10 @@ int lcd_knn2_dev(lcd_engine* h, const void* d_queries, int q, int32_t* d_word_id
  * every signature (same order => same slots).  Per frame: (1) lcd_shard_knn2_dev on each rank, (2) all-gather of the
  * 16-byte candidate records, (3) lcd_shard_frame_dev on each rank (merge + same-frame resolution, replicated; registers the
  * frame with the words THIS rank owns; integer partial likelihood into d_lfix), (4) all-reduce(sum, int64) of d_lfix --
- * order-free, so the result equals the single-GPU one bit for bit -- (5) lcd_finalize_dev. */
+ * order-free, so the result equals the single-GPU one bit for bit -- (5) lcd_finalize_dev.
+ * (1) and (3) of a frame are one pair: the search also leaves the frame's same-frame distance matrix on the handle (it rides in the
+ * filter's launch), and the frame call that follows it with the SAME d_descriptors pointer and q -- their content unchanged in between --
+ * takes it from there; any other frame call computes the matrix itself. */
 typedef struct lcd_shard_cand { uint64_t key; int32_t word; int32_t wslot; } lcd_shard_cand;
 int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shard_cand* d_cand /* [q*2] */);
 int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int flags, float nndr_ratio, int32_t sig_id,

@@ -44,6 +44,10 @@ struct lcd_engine {
     // ---- per-call scratch
     lcd::DevBuf d_queries, d_partial, d_knn_row, d_knn_word, d_knn_wslot, d_knn_dist, d_selfdist, d_out_word, d_out_wslot,
         d_n_new, d_tmp_i32, d_extra_rows, d_extra_id, d_extra_word, d_extra_dist, d_extra_row, d_like, d_slots, d_bits, row_norm, norm_max, d_partial2, d_partial3, d_fail_list, d_fail_count;
+    // a sharded search (lcd_shard_knn2_dev) leaves the frame's same-frame distance matrix here when its filter launch can carry it; the frame call
+    // behind the all-gather (lcd_shard_frame_dev, same descriptors) then only merges and derives the bit rows
+    lcd::DevBuf d_shard_selfdist;
+    const void* shard_sd_desc = nullptr; int shard_sd_q = 0;
     bool fail_count_clean = false;                      // d_fail_count[0..1] known to be zero (the fused frame tail resets them)
     bool bf_family() const { return knn_mode == 2 || knn_mode == 3; }   // the bf16x3 / fp16 filters share kernels, tables and the pipelined frame
     int f16() const { return knn_mode == 3 ? 1 : 0; }

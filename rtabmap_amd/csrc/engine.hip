@@ -520,7 +520,8 @@ void lcd_destroy(lcd_engine* h) {
                      &h->d_partial, &h->d_knn_row, &h->d_knn_word, &h->d_knn_wslot, &h->d_knn_dist, &h->d_selfdist, &h->d_out_word,
                      &h->d_out_wslot, &h->d_n_new, &h->d_tmp_i32, &h->d_extra_rows, &h->d_extra_id, &h->d_extra_word,
                      &h->d_extra_dist, &h->d_extra_row, &h->d_like, &h->d_slots, &h->d_bits, &h->row_norm, &h->norm_max, &h->d_partial2,
-                     &h->d_fail_list, &h->d_fail_count, &h->d_partial3, &h->row_norm_alt, &h->vocab_bf, &h->d_hyp_scratch, &h->d_adj_scratch};
+                     &h->d_fail_list, &h->d_fail_count, &h->d_partial3, &h->row_norm_alt, &h->vocab_bf, &h->d_hyp_scratch, &h->d_adj_scratch,
+                     &h->d_shard_selfdist};
     for (DevBuf* d : all) d->release(&h->bytes_device);
     h->d_vcnt.release(&h->bytes_device);
     h->d_rmlog.release(&h->bytes_device);
@@ -1970,9 +1971,27 @@ int lcd_shard_knn2_dev(lcd_engine* h, const void* d_descriptors, int q, lcd_shar
     pk.knn_row = h->d_knn_row.as<int32_t>(); pk.knn_word = h->d_knn_word.as<int32_t>(); pk.knn_dist = h->d_knn_dist.as<float>();
     pk.row_wslot = h->row_wslot.as<int32_t>(); pk.q2 = 2 * q; pk.out = reinterpret_cast<ShardCand*>(d_cand);
     bool packed = false;
+    // the same-frame distance matrix needs nothing but the descriptors: it rides in the filter's launch (extra workgroups, as in the single-GPU
+    // frame) instead of waiting behind the all-gather.  No bit rows yet (bits == nullptr): their thresholds are the MERGED second neighbours'.
+    CandBits sd;
+    h->shard_sd_desc = nullptr;
+    bool with_sd = h->knn_mode != 0 && h->bf_family() && knn_mfma_supported(h->dtype, h->kdim) && rows_scan >= 256;
+    if (with_sd) {
+        // ... unless the compute units its tiles take turn a one-strip-per-workgroup filter into the persistent one (between ~56 000 and ~65 000
+        // rows at 500 descriptors: the filter then costs 4 us more, what the ride saves behind the all-gather; r06_call55)
+        MfmaPlan p0 = knn_bf16_plan(q, (int)rows_scan, 0), p1 = knn_bf16_plan(q, (int)rows_scan, knn_selfdist_wgs(q));
+        p0.filter_units = p1.filter_units = h->filter_units;
+        with_sd = knn_bf16_persistent(p0) == knn_bf16_persistent(p1);
+    }
+    if (with_sd) {
+        const int ld = (q + 63) / 64 * 64;
+        LCD_HIP(h, dreserve(h, h->d_shard_selfdist, (size_t)q * ld * 4));
+        sd.selfdist = h->d_shard_selfdist.as<float>(); sd.ld = ld; sd.nq = q;
+    }
     int rc = run_knn2_raw(h, d_descriptors, q, h->vocab.p, h->row_id.as<int32_t>(), rows_scan, true, h->d_knn_row.as<int32_t>(),
-                          h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), nullptr, nullptr, &pk, &packed);
+                          h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(), with_sd ? &sd : nullptr, nullptr, &pk, &packed);
     if (rc) return rc;
+    if (with_sd) { h->shard_sd_desc = d_descriptors; h->shard_sd_q = q; }
     if (!packed) LCD_HIP(h, launch_shard_pack(pk.knn_row, pk.knn_word, pk.knn_dist, pk.row_wslot, q, d_cand, h->stream, h->d_fail_count.as<int32_t>()));
     h->fail_count_clean = true;
     return LCD_OK;
@@ -1987,6 +2006,8 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
     LCD_DEV_NODRAIN(h);
     { int rc = drain_keep_rows_lazy(h); if (rc) return rc; }
     LCD_JOIN_K(h);
+    const bool matrix_left = h->shard_sd_desc != nullptr && h->shard_sd_desc == d_descriptors && h->shard_sd_q == q;   // by this frame's search
+    h->shard_sd_desc = nullptr;                                       // (one frame call per search: whatever happens below, it is used up)
     if (q <= 0 || q > 8192 || !d_descriptors || !d_all_cand || !d_word_ids || world < 1 || world > 64 || rank < 0 || rank >= world)
         return h->fail(LCD_ERR_INVALID, "lcd_shard_frame_dev: bad argument");
     Tfidf& t = h->tfidf;
@@ -2011,11 +2032,20 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
     const bool together = incremental && (flags & LCD_Q_NEW_WORDS_COMPARED);
     const int ld = (q + 63) / 64 * 64, bw = ld / 32;
     // the merge rides at the head of the same-frame distance launch when the frame has one that can carry it (one launch less per frame and rank)
-    const bool merge_in_selfdist = together && selfdist_can_merge(h->dtype, h->kdim);
-    if (!merge_in_selfdist)
+    const bool have_matrix = together && matrix_left;
+    const bool merge_in_selfdist = together && !have_matrix && selfdist_can_merge(h->dtype, h->kdim);
+    if (have_matrix) {
+        LCD_HIP(h, dreserve(h, h->d_bits, (size_t)q * bw * 4));
+        ShardMergeJob mj;
+        mj.cand = reinterpret_cast<const ShardCand*>(d_all_cand); mj.world = world; mj.rank = rank; mj.by_word = cyclic ? 1 : 0;
+        mj.out_word = h->d_knn_word.as<int32_t>(); mj.out_dist = h->d_knn_dist.as<float>(); mj.out_wslot = h->d_knn_row.as<int32_t>();
+        CandBits cb;
+        cb.selfdist = h->d_shard_selfdist.as<float>(); cb.ld = ld; cb.nq = q; cb.bits = h->d_bits.as<uint32_t>(); cb.bw = bw; cb.have_index = have_index;
+        LCD_HIP(h, launch_shard_merge_bits(mj, cb, h->stream));
+    } else if (!merge_in_selfdist)
         LCD_HIP(h, launch_shard_merge(d_all_cand, world, rank, q, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
                                       h->d_knn_row.as<int32_t>(), h->stream, cyclic));
-    if (together) {
+    if (together && !have_matrix) {
         LCD_HIP(h, dreserve(h, h->d_selfdist, (size_t)q * ld * 4));
         LCD_HIP(h, dreserve(h, h->d_bits, (size_t)q * bw * 4));
         ShardMergeJob mj;
@@ -2040,7 +2070,8 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
     }
     const int rflags = (incremental ? LCD_Q_INCREMENTAL : 0) | (together ? LCD_Q_NEW_WORDS_COMPARED : 0);
     LCD_HIP(h, launch_resolve(q, rflags, nndr_ratio, have_index, h->d_knn_word.as<int32_t>(), h->d_knn_dist.as<float>(),
-                              together ? h->d_selfdist.as<float>() : nullptr, ld, together ? h->d_bits.as<uint32_t>() : nullptr, bw,
+                              together ? (have_matrix ? h->d_shard_selfdist.as<float>() : h->d_selfdist.as<float>()) : nullptr, ld,
+                              together ? h->d_bits.as<uint32_t>() : nullptr, bw,
                               d_word_ids, h->d_n_new.as<int32_t>(), h->stream, h->d_knn_row.as<int32_t>(), nullptr,
                               h->d_out_wslot.as<int32_t>(), &new_ws));
     if (dev_append) {

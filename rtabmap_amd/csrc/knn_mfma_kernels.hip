@@ -2145,6 +2145,21 @@ __global__ __launch_bounds__(PIPE_B_BLOCK) void append_rows_kernel(AppendRowsArg
 __global__ __launch_bounds__(MF_BLOCK) void knn_rowpar_kernel(RowparArgs a, int32_t* __restrict__ fail_count) {
     rowpar_body<64, MF_BLOCK>(a, (int)blockIdx.x, (int)gridDim.x, fail_count);
 }
+// shard_merge_kernel + the bit rows of selfdist_l2_kernel for a frame whose distance matrix exists already (lcd_kernels.h): wave w of a workgroup
+// owns query 4 * blockIdx.x + w; its lanes read the same records (one request), then the query's row of the (symmetric) matrix
+__global__ __launch_bounds__(256) void shard_merge_bits_kernel(ShardMergeJob mj, CandBits cb) {
+    const int lane = threadIdx.x & 63;
+    const int qi = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (qi >= cb.nq) return;                                         // (wave-uniform)
+    const ShardMerged m = shard_merge_one(mj.cand, mj.world, mj.rank, cb.nq, qi, mj.by_word);
+    const bool v0 = m.dist[0] >= 0.0f && m.word[0] != 0, v1 = m.dist[1] >= 0.0f && m.word[1] != 0;   // cand_threshold(), knn2_kernels.hip
+    const float thr = (cb.have_index && v0 && v1) ? m.dist[1] : __int_as_float(0x7f800000);
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { mj.out_word[2 * qi + j] = m.word[j]; mj.out_dist[2 * qi + j] = m.dist[j]; mj.out_wslot[2 * qi + j] = m.wslot[j]; }
+    }
+    cand_bits_row(cb, qi, thr, lane, 64);
+}
 // A sharded search's last launch: the exact redo, then the rank's candidate records (shard_pack_kernel's work -- one launch of ~4.7 us less per
 // frame and rank).  Nothing to redo (the usual frame): every workgroup sees that and packs its stride of the records; the counters are zero
 // already.  A redo: the last workgroup to arrive, which merged and knows every result final, packs all records and zeroes the counters
@@ -2428,6 +2443,13 @@ hipError_t launch_knn_bf16(int dim, const void* vocab, const void* vocab_bf, con
     knn_mfma_rerank_kernel<64, BF_KEEP, false, true><<<p.q, MF_BLOCK, 0, s_rerank>>>(
         pk, pl, p.n_blocks, p.q, (const float*)vocab, (const float*)queries, row_id, norm_max_bits, out_row, out_word, out_dist, fail_list,
         fail_count, cb ? *cb : CandBits{}, p.f16, p.n_rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_merge_bits(const ShardMergeJob& mj, const CandBits& cb, hipStream_t s) {
+    if (cb.nq <= 0) return hipSuccess;
+    if (!mj.cand || !cb.selfdist || !cb.bits || (cb.bw & 1) || cb.ld % 64 != 0) return hipErrorInvalidValue;
+    shard_merge_bits_kernel<<<(cb.nq + 3) / 4, 256, 0, s>>>(mj, cb);
     return hipGetLastError();
 }
 

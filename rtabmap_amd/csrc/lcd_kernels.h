@@ -149,6 +149,9 @@ hipError_t launch_selfdist(int dtype, int dim, const void* queries, int q, float
                            const int32_t* knn_word = nullptr, const float* knn_dist = nullptr, uint32_t* bits = nullptr, int bw = 0,
                            const ShardMergeJob* merge = nullptr);
 bool selfdist_can_merge(int dtype, int dim);
+// A sharded frame whose search left the same-frame distance matrix behind (it rode in the filter's launch, cb.selfdist): the merge of the
+// all-gathered records and the candidate bit rows, one wave per query -- all that is left of the same-frame distance launch behind the all-gather.
+hipError_t launch_shard_merge_bits(const ShardMergeJob& mj, const CandBits& cb, hipStream_t s);
 
 // The addNewWords decision loop (VWDictionary.cpp:1089-1219) for a whole frame, on the device.
 //   knn_word/knn_dist [q*2] indexed candidates (word 0 / dist < 0 = none); have_index = vocabulary had >= 2 live rows

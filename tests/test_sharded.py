@@ -516,3 +516,44 @@ def test_shard_search_packs_its_records_in_the_redo_launch(mode):
         if rows == n:
             assert min(redone) == 0, redone                   # ... and its other half: some frame went through the launch without a redo
         eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,how", [("f16", "pair"), ("bf16", "pair"), ("f16", "other_pointer"), ("mfma32", "pair"), ("valu", "pair"),
+                                      ("f16", "not_compared")])
+def test_shard_frame_merge_paths_agree_with_the_plain_engine(mode, how):
+    """Where the merge of the gathered records and the same-frame distances run depends on what the search could carry: the matrix rides in the
+    filter's launch and a small merge + bit-row launch follows the all-gather (pair: search and frame call on the same descriptors, matrix-core
+    filters), or the merge rides at the head of the same-frame distance launch (any other frame call; filters that carry no matrix), or it is a
+    launch of its own (frames whose new words are not compared with each other).  One rank, its own records as the gathered ones: the word
+    assignment must be lcd_quantize's on an unsharded handle with the same rows, frame after frame, with uncertifiable queries among them."""
+    import torch
+    import rtabmap_amd
+    from rtabmap_amd import synth
+    n, q = 6000, 400
+    v = synth.vocab_surf(n, seed=21)
+    v[3000:3040] = v[77]
+    ids = np.arange(1, n + 1, dtype=np.int32)
+    plain = rtabmap_amd.Engine("f32", 64, sig_capacity=64, knn_mode=mode)
+    shard = rtabmap_amd.Engine("f32", 64, sig_capacity=64, knn_mode=mode)
+    for e in (plain, shard):
+        e.vocab_append(v, ids)
+    d_cand = torch.zeros(q * 2 * 16, dtype=torch.uint8, device="cuda")
+    d_words = torch.zeros(q, dtype=torch.int32, device="cuda")
+    compared = how != "not_compared"
+    for t in range(3):
+        x = synth.queries_surf(v, q, seed=500 + t, frac_known=0.6, sigma=0.03)
+        x[5] = v[77]
+        x[200:230] = v[77] + (np.arange(30, dtype=np.float32)[:, None] * np.float32(2e-5))
+        x[390] = x[5]
+        x[120:124] = x[60]                                     # same-frame duplicates of unseen descriptors: the bit rows decide
+        exp, _ = plain.quantize(x, incremental=True, new_words_compared=compared, nndr=0.8)
+        d = torch.from_numpy(x).cuda()
+        shard.shard_knn2_dev(d.data_ptr(), q, d_cand.data_ptr())
+        d2 = d.clone() if how == "other_pointer" else d
+        shard.shard_frame_dev(d2.data_ptr(), q, 0, 10.0, 0, 1, d_cand.data_ptr(), n, d_words.data_ptr(), 0, 0,
+                              incremental=True, new_words_compared=compared, nndr=0.8)
+        torch.cuda.synchronize()
+        assert d_words.cpu().numpy().tolist() == exp.tolist(), "frame %d" % t
+    plain.close()
+    shard.close()
