@@ -2074,6 +2074,7 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
                               together ? h->d_bits.as<uint32_t>() : nullptr, bw,
                               d_word_ids, h->d_n_new.as<int32_t>(), h->stream, h->d_knn_row.as<int32_t>(), nullptr,
                               h->d_out_wslot.as<int32_t>(), &new_ws));
+    ShardAppendJob app;
     if (dev_append) {
         // VWDictionary::update()'s append branch, this rank's share, on the device: the words the frame created that this rank owns become
         // rows of its shard before the next frame is searched (lcd_shard_knn2_dev catches the host's row mirror up: one synchronisation,
@@ -2086,15 +2087,19 @@ int lcd_shard_frame_dev(lcd_engine* h, const void* d_descriptors, int q, int fla
         ResolveArgs ra;
         const uint64_t vseq = h->vseq;
         fill_append(h, fa, vseq, true, &ra);
-        WsRuns keys = new_ws;                              // (n == 0 on a rank that owns nothing in last-rank mode: it appends nothing either)
-        LCD_HIP(h, launch_shard_append(ra.ap, keys, d_word_ids, q, rank, world, cyclic ? h->shard_first : 0, cyclic ? h->shard_block : 0, h->stream));
-        lcd_engine::DevAppend da{vseq, first_new_word_id, q, true};
-        da.own_world = world; da.own_rank = rank; da.own_first = cyclic ? h->shard_first : 0; da.own_block = cyclic ? h->shard_block : 0;
+        // ... as a second workgroup of the registration's launch (the two chains need nothing of each other: one launch less per frame and rank)
+        app.ap = ra.ap; app.new_ws = new_ws;               // (n == 0 on a rank that owns nothing in last-rank mode: it appends nothing either)
+        app.codes = d_word_ids; app.q = q; app.rank = rank; app.world = world;
+        app.own_first = cyclic ? h->shard_first : 0; app.own_block = cyclic ? h->shard_block : 0;
+    }
+    if (sig_id != 0) LCD_HIP(h, t.register_dev(sig_id, h->d_out_wslot.as<int32_t>(), q, q, N, nullptr, false, nullptr, nullptr, dev_append ? &app : nullptr));
+    else LCD_HIP(h, t.query_dev(h->d_out_wslot.as<int32_t>(), q, N, nullptr, false, nullptr, nullptr, dev_append ? &app : nullptr));
+    if (dev_append) {                                      // (enqueued: the host's record of it)
+        lcd_engine::DevAppend da{h->vseq, first_new_word_id, q, true};
+        da.own_world = world; da.own_rank = rank; da.own_first = app.own_first; da.own_block = app.own_block;
         h->unreconciled.push_back(da);
         h->vseq += 1;
     }
-    if (sig_id != 0) LCD_HIP(h, t.register_dev(sig_id, h->d_out_wslot.as<int32_t>(), q, q, N));
-    else LCD_HIP(h, t.query_dev(h->d_out_wslot.as<int32_t>(), q, N));
     if (d_lfix) {
         LCD_HIP(h, t.score_fix((long long*)d_lfix));       // every slot written: no zero-fill needed
         h->likelihood_launches += 1;

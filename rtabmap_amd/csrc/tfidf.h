@@ -133,6 +133,11 @@ struct AppendArgs {
     int mirror_later = 0;                      // 1 (PipeOpts::mirror_from_b): the decision loop leaves the mirror alone -- a workgroup of launch B of the same
                                                // pair stores it (a write to pinned HOST memory at the end of launch A's longest chain, waited for at s_endpgm)
 };
+// one rank's share of update()'s append on a sharded vocabulary (shard_append_body, tfidf.hip): codes = the replicated decision loop's output;
+// own_block > 0: block-cyclic owners from own_first on, else the last rank owns every new word
+struct ShardAppendJob {
+    AppendArgs ap; WsRuns new_ws; const int32_t* codes = nullptr; int q = 0, rank = 0, world = 1; int32_t own_first = 0, own_block = 0;
+};
 
 // the row-writing half of a deferred append (launch B): the appender's arguments + the postings keys of the frame's new words
 struct AppendRowsArgs { AppendArgs ap; WsRuns new_ws; int n_wgs = 0; };
@@ -358,12 +363,14 @@ struct Tfidf {
     // pipe_block_size() threads -- for the filter launch of the next frame to carry (knn_mfma_kernels.hip, frame_a_kernel)
     // defer without resolve: the registration alone is left there (its word slots were written by a decision loop launched earlier;
     // new_ws translates that loop's new-word codes, see WsRuns)
+    // shard_app (sharded frames; neither resolve nor defer): a second workgroup of the registration's launch appends this rank's share of the
+    // frame's new words to its shard (ShardAppendJob) -- the two single-workgroup chains side by side instead of one launch behind the other
     hipError_t register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N, const ResolveArgs* resolve = nullptr,
                             bool ids_given = false /* d_wslots holds word ids, translated on the device */, TailLaunch* defer = nullptr,
-                            const WsRuns* new_ws = nullptr);
+                            const WsRuns* new_ws = nullptr, const ShardAppendJob* shard_app = nullptr);
     // prepare q_* from word slots on the device without registering anything
     hipError_t query_dev(const int32_t* d_wslots, int n, float N, const ResolveArgs* resolve = nullptr, bool ids_given = false,
-                         TailLaunch* defer = nullptr, const WsRuns* new_ws = nullptr);
+                         TailLaunch* defer = nullptr, const WsRuns* new_ws = nullptr, const ShardAppendJob* shard_app = nullptr);
     // Memory::loadDataFromDb replay: many signatures in O(1) launches; d_ids = word ids on the device, offsets[n_sigs + 1]
     hipError_t register_bulk(int n_sigs, const int32_t* sig_ids, const int64_t* offsets, const int32_t* ni, const int32_t* d_ids,
                              int64_t total_ids, int max_n);

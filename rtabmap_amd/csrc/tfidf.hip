@@ -348,9 +348,9 @@ __device__ __forceinline__ int shard_owned_below(int32_t id, int32_t first, int3
     const long long rem = x % cyc - (long long)rank * block;
     return (int)((x / cyc) * block + (rem < 0 ? 0 : (rem > block ? block : rem)));
 }
-__global__ __launch_bounds__(1024) void shard_append_kernel(AppendArgs ap, WsRuns new_ws, const int32_t* __restrict__ codes, int q, int rank, int world,
-                                                           int32_t own_first, int32_t own_block) {
-    extern __shared__ int s_first[];                                   // [q]: the descriptor that created the k-th new word
+__device__ __forceinline__ void shard_append_body(int* s_first /* LDS [q]: the descriptor that created the k-th new word */, const AppendArgs& ap,
+                                                  const WsRuns& new_ws, const int32_t* __restrict__ codes, int q, int rank, int world,
+                                                  int32_t own_first, int32_t own_block) {
     __shared__ int s_n_new;
     const int tid = threadIdx.x;
     if (tid == 0) s_n_new = 0;
@@ -386,6 +386,24 @@ __global__ __launch_bounds__(1024) void shard_append_kernel(AppendArgs ap, WsRun
         if (ap.host_mirror) __hip_atomic_store(ap.host_mirror, ((unsigned long long)ap.tag << 32) | (unsigned long long)(uint32_t)(n_in + n_take), __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+__global__ __launch_bounds__(1024) void shard_append_kernel(AppendArgs ap, WsRuns new_ws, const int32_t* __restrict__ codes, int q, int rank, int world,
+                                                           int32_t own_first, int32_t own_block) {
+    extern __shared__ int s_first[];
+    shard_append_body(s_first, ap, new_ws, codes, q, rank, world, own_first, own_block);
+}
+// the registration of a sharded frame and, beside it, this rank's share of the frame's append: two single-workgroup latency chains that need
+// nothing of each other (the registration reads wrow[] only to COUNT references to words an enqueued clean tombstoned, 0xFFFFFFFF: a key the
+// appender is claiming at that moment reads as 0 or as its row, never as that) -- one launch of two workgroups instead of two launches
+__global__ __launch_bounds__(FW_BLOCK) void frame_words_append_kernel(FwArgs a, RetireArgs retire, ShardAppendJob j) {
+    extern __shared__ uint32_t fwa_dyn_smem[];
+    if (blockIdx.x == 1) {
+        shard_append_body(reinterpret_cast<int*>(fwa_dyn_smem), j.ap, j.new_ws, j.codes, j.q, j.rank, j.world, j.own_first, j.own_block);
+        return;
+    }
+    retire_body(retire, a.slot_begin, a.slot_cnt, a.nw, a.slot_ni, a.slot_sig);
+    __syncthreads();
+    frame_words_body<FW_BLOCK, true>(fwa_dyn_smem, a);
 }
 hipError_t launch_shard_append(const AppendArgs& ap, const WsRuns& new_ws, const int32_t* codes, int q, int rank, int world, int32_t own_first,
                                int32_t own_block, hipStream_t s) {
@@ -471,6 +489,7 @@ hipError_t Tfidf::init(hipStream_t s, int64_t* bytes, int64_t sig_capacity, int6
     h_n_dense[0] = 0;
     TF_TRY(set_max_lds(reinterpret_cast<const void*>(&frame_words_kernel)));
     TF_TRY(set_max_lds(reinterpret_cast<const void*>(&frame_tail_kernel)));
+    TF_TRY(set_max_lds(reinterpret_cast<const void*>(&frame_words_append_kernel)));
     TF_TRY(set_max_lds(reinterpret_cast<const void*>(&bulk_register_kernel)));
     return hipSuccess;
 }
@@ -941,7 +960,9 @@ hipError_t Tfidf::flush_retire() {
 }
 
 static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool ids_given, bool reg, int32_t sig_id, int64_t slot, int32_t ni,
-                                  float N, const ResolveArgs* resolve, TailLaunch* defer, const WsRuns* new_ws = nullptr) {
+                                  float N, const ResolveArgs* resolve, TailLaunch* defer, const WsRuns* new_ws = nullptr,
+                                  const ShardAppendJob* shard_app = nullptr) {
+    if (shard_app && (resolve || defer || shard_app->q <= 0 || shard_app->q > 8192)) return hipErrorInvalidValue;
     const int H = next_pow2(std::max(2 * n, 128));
     size_t shmem = ((size_t)H * 2 + H / 64 + 8) * 4;
     if (ids_given) TF_TRY(t.sync_id2ws());
@@ -986,6 +1007,8 @@ static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool id
             return hipSuccess;
         }
         frame_tail_kernel<<<1 + n_redo, FW_BLOCK, shmem, t.stream>>>(*resolve, a, ret);
+    } else if (shard_app) {
+        frame_words_append_kernel<<<2, FW_BLOCK, std::max(shmem, (size_t)shard_app->q * 4), t.stream>>>(a, ret, *shard_app);
     } else {
         frame_words_kernel<<<1, FW_BLOCK, shmem, t.stream>>>(a, ret);
     }
@@ -994,7 +1017,7 @@ static hipError_t run_frame_words(Tfidf& t, const int32_t* d_src, int n, bool id
 }
 
 hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, int32_t ni, float N, const ResolveArgs* resolve, bool ids_given,
-                               TailLaunch* defer, const WsRuns* new_ws) {
+                               TailLaunch* defer, const WsRuns* new_ws, const ShardAppendJob* shard_app) {
     if (n > TF_MAX_WORDS) return hipErrorInvalidValue;
     const int64_t slot = n_slots;
     TF_TRY(ensure_slots(slot + 1));
@@ -1005,7 +1028,7 @@ hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, i
     }
     Bucket& b = buckets[bi];
     TF_TRY(ensure_log(*this, bi, b.ub_entries + n));
-    TF_TRY(run_frame_words(*this, d_wslots, n, ids_given, true, sig_id, slot, ni, N, resolve, defer, new_ws));
+    TF_TRY(run_frame_words(*this, d_wslots, n, ids_given, true, sig_id, slot, ni, N, resolve, defer, new_ws, shard_app));
     b.ub_entries += n;
     b.n_slots += 1;
     b.live += 1;
@@ -1017,9 +1040,9 @@ hipError_t Tfidf::register_dev(int32_t sig_id, const int32_t* d_wslots, int n, i
 }
 
 hipError_t Tfidf::query_dev(const int32_t* d_wslots, int n, float N, const ResolveArgs* resolve, bool ids_given, TailLaunch* defer,
-                            const WsRuns* new_ws) {
+                            const WsRuns* new_ws, const ShardAppendJob* shard_app) {
     if (n > TF_MAX_WORDS) return hipErrorInvalidValue;
-    return run_frame_words(*this, d_wslots, n, ids_given, false, 0, 0, 0, N, resolve, defer, new_ws);
+    return run_frame_words(*this, d_wslots, n, ids_given, false, 0, 0, 0, N, resolve, defer, new_ws, shard_app);
 }
 
 // the decision loop of a frame as a workgroup of `block` threads inside a later filter launch: its redo helpers and its dynamic LDS
