@@ -398,8 +398,9 @@ struct Tfidf {
 
 // gather of the dense likelihood: out[k] = slots[k] >= 0 ? dense[slots[k]] : 0
 hipError_t launch_gather_f32(const float* dense, const int64_t* slots, int n, float* out, hipStream_t s);
-// one rank's share of update()'s append on a sharded vocabulary (tfidf.hip, shard_append_kernel): codes = the replicated decision loop's
-// output; own_block > 0: block-cyclic owners from own_first on, else the last rank owns every new word
+// one rank's share of update()'s append on a sharded vocabulary as a launch of its own (tfidf.hip, shard_append_kernel): codes = the replicated
+// decision loop's output; own_block > 0: block-cyclic owners from own_first on, else the last rank owns every new word.  lcd_shard_frame_dev no
+// longer calls it -- the append rides in the registration's launch (ShardAppendJob) -- it stays as the stand-alone form of the same body
 hipError_t launch_shard_append(const AppendArgs& ap, const WsRuns& new_ws, const int32_t* codes, int q, int rank, int world, int32_t own_first,
                                int32_t own_block, hipStream_t s);
 
