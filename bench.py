@@ -1871,8 +1871,8 @@ def main():
                 config["shard_stages_world1_ms_per_step"] = 1e3 * rs["wall"] / args.steps
                 config["shard_stages_world1_note"] = "ONE rank running the SHARDED stages (what each of N ranks runs, without the wire): local search -> " \
                                                      "candidate records -> merge + decision loop (replicated) -> update()'s append of the owned new words on the " \
-                                                     "device (shard_append) -> registration -> integer scoring -> conversion, unfused: 8 launches and one " \
-                                                     "synchronisation (row mirror) per frame; to be read against ms_per_step (the fused, pipelined single-GPU frame)"
+                                                     "device (shard_append, beside the registration in one launch) -> integer scoring -> conversion: nine launches per frame, no " \
+                                                     "synchronisation; to be read against ms_per_step (the fused, pipelined single-GPU frame)"
             except Exception as e:                                # noqa: BLE001
                 config["shard_stages_world1_error"] = "%s: %s" % (type(e).__name__, e)
             try:
